@@ -1,0 +1,127 @@
+// TEST INFRASTRUCTURE ONLY -- C entry points of the CPU oracle (loaded with ctypes by tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product path).
+//
+// Threading mirrors the reference engine: one `#pragma omp parallel for` over wavelengths with
+// thread-private solver workspaces (cpp/lib/engine/engine.cpp:610-622).
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "disco_oracle.hpp"
+
+namespace {
+struct Handle {
+    skgeo::Geometry1D geo;
+    skgeo::DiscoGeometry dg;
+    int ss_in_do = 1;
+    std::string error;
+};
+}  // namespace
+
+extern "C" {
+
+// ray_params: per ray [cos_sza, relative_azimuth, observer_altitude, tangent_altitude | cos_viewing_zenith]
+void* orc_create(double cos_sza, double saa, double earth_radius, const double* altitudes, int ngrid, int interp_method,
+                 int geotype, int nstr, int num_sza, int nrays, const int* ray_kinds, const double* ray_params,
+                 int ss_in_do) {
+    try {
+        auto h = std::make_unique<Handle>();
+        h->geo = skgeo::Geometry1D(cos_sza, saa, earth_radius, std::vector<double>(altitudes, altitudes + ngrid),
+                                   (skgeo::Interpolation)interp_method, (skgeo::GeometryType)geotype);
+        std::vector<skgeo::RaySpec> specs(nrays);
+        for (int i = 0; i < nrays; ++i) {
+            specs[i].kind = (skgeo::RaySpec::Kind)ray_kinds[i];
+            specs[i].cos_sza = ray_params[4 * i + 0];
+            specs[i].relative_azimuth = ray_params[4 * i + 1];
+            specs[i].observer_altitude = ray_params[4 * i + 2];
+            specs[i].tangent_altitude = ray_params[4 * i + 3];
+            specs[i].cos_viewing_zenith = ray_params[4 * i + 3];
+        }
+        skgeo::build_disco_geometry(h->geo, specs, nstr, num_sza, h->dg);
+        h->ss_in_do = ss_in_do;
+        return h.release();
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "orc_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+
+void orc_destroy(void* h) { delete static_cast<Handle*>(h); }
+
+int orc_num_sza(void* hv) { return static_cast<Handle*>(hv)->dg.nsza; }
+int orc_chapman(void* hv, double* out) {
+    auto* h = static_cast<Handle*>(hv);
+    std::copy(h->dg.chapman.begin(), h->dg.chapman.end(), out);
+    return 0;
+}
+int orc_streams(void* hv, double* mu, double* wt) {
+    auto* h = static_cast<Handle*>(hv);
+    std::copy(h->dg.mu.begin(), h->dg.mu.end(), mu);
+    std::copy(h->dg.wt.begin(), h->dg.wt.end(), wt);
+    return 0;
+}
+
+// Outputs (C order): radiance[nwavel][nlos], d_k[nwavel][nlos][ngrid], d_ssa[nwavel][nlos][ngrid],
+// d_albedo[nwavel][nlos], los_od[nwavel][nlos], n_azimuth[nwavel].  Derivative outputs may be null.
+int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg,
+            const double* solar_irradiance, const double* albedo, int derivatives, int nthreads, double* radiance,
+            double* d_k, double* d_ssa, double* d_albedo, double* los_od, int* n_azimuth) {
+    auto* h = static_cast<Handle*>(hv);
+    if (!h) return -1;
+    const int nlos = h->dg.nlos, ngrid = h->dg.ngrid;
+    oracle::AtmosphereView atm;
+    atm.ngrid = ngrid;
+    atm.nwavel = nwavel;
+    atm.nleg = nleg;
+    atm.extinction = extinction;
+    atm.ssa = ssa;
+    atm.leg = leg;
+    atm.solar_irradiance = solar_irradiance;
+    atm.albedo = albedo;
+    atm.derivatives = derivatives != 0;
+    int status = 0;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        std::unique_ptr<oracle::Solver> solver;
+        oracle::Result res;
+        try {
+            solver = std::make_unique<oracle::Solver>(h->dg, atm.derivatives, h->ss_in_do != 0);
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "orc_run: %s\n", e.what());
+            status = -3;
+        }
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int w = 0; w < nwavel; ++w) {
+            if (status != 0 || !solver) continue;
+            try {
+                solver->solve(atm, w, res);
+                for (int r = 0; r < nlos; ++r) {
+                    radiance[size_t(w) * nlos + r] = res.radiance[r];
+                    if (los_od) los_od[size_t(w) * nlos + r] = res.los_od[r];
+                    if (atm.derivatives) {
+                        const double* d = &res.deriv[size_t(r) * solver->num_native()];
+                        if (d_k) std::copy(d, d + ngrid, &d_k[(size_t(w) * nlos + r) * ngrid]);
+                        if (d_ssa) std::copy(d + ngrid, d + 2 * ngrid, &d_ssa[(size_t(w) * nlos + r) * ngrid]);
+                        if (d_albedo) d_albedo[size_t(w) * nlos + r] = d[2 * ngrid];
+                    }
+                }
+                if (n_azimuth) n_azimuth[w] = res.num_azimuth_used;
+            } catch (const std::exception& e) {
+                std::fprintf(stderr, "orc_run (wavelength %d): %s\n", w, e.what());
+                status = -3;
+            }
+        }
+    }
+    return status;
+}
+
+}  // extern "C"

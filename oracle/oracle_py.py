@@ -1,0 +1,110 @@
+"""ctypes front end of the CPU oracle (TEST INFRASTRUCTURE ONLY, see disco_oracle.hpp)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+TANGENT_ALTITUDE_SOLAR = 0
+GROUND_VIEWING_SOLAR = 1
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def build(force: bool = False) -> Path:
+    so = _HERE / "liboracle.so"
+    srcs = [_HERE / "oracle_capi.cpp", _HERE / "disco_oracle.hpp", _HERE / "linalg.hpp",
+            _HERE.parent / "sasktran2_amd" / "csrc" / "host" / "geometry.hpp"]
+    if force or not so.exists() or any(s.exists() and s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+        subprocess.check_call(["make", "-C", str(_HERE), "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = build()
+        L = ctypes.CDLL(str(so))
+        L.orc_create.restype = ctypes.c_void_p
+        L.orc_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_int, ctypes.c_int,
+                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int]
+        L.orc_destroy.argtypes = [ctypes.c_void_p]
+        L.orc_run.restype = ctypes.c_int
+        L.orc_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int,
+                              ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _ip]
+        L.orc_num_sza.argtypes = [ctypes.c_void_p]
+        L.orc_chapman.argtypes = [ctypes.c_void_p, _dp]
+        L.orc_streams.argtypes = [ctypes.c_void_p, _dp, _dp]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class OracleEngine:
+    """rays: list of (kind, cos_sza, relative_azimuth, observer_altitude, tangent_altitude|cos_viewing_zenith)."""
+
+    def __init__(self, cos_sza, saa, earth_radius, altitudes, interp_method, geotype, nstr, num_sza, rays,
+                 ss_in_do=True):
+        self.alt = np.ascontiguousarray(altitudes, dtype=np.float64)
+        self.nlos = len(rays)
+        self.ngrid = len(self.alt)
+        self.nstr = nstr
+        kinds = np.ascontiguousarray([r[0] for r in rays], dtype=np.int32)
+        params = np.ascontiguousarray([[r[1], r[2], r[3], r[4]] for r in rays], dtype=np.float64)
+        self._h = lib().orc_create(cos_sza, saa, earth_radius, _p(self.alt), self.ngrid, interp_method, geotype, nstr,
+                                   num_sza, self.nlos, kinds.ctypes.data_as(_ip), _p(params), int(ss_in_do))
+        if not self._h:
+            raise RuntimeError("oracle engine construction failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_destroy(self._h)
+            self._h = None
+
+    def chapman(self):
+        nsza = lib().orc_num_sza(self._h)
+        out = np.zeros((nsza, self.ngrid - 1, self.ngrid - 1))
+        lib().orc_chapman(self._h, _p(out))
+        return out
+
+    def streams(self):
+        mu = np.zeros(self.nstr)
+        wt = np.zeros(self.nstr)
+        lib().orc_streams(self._h, _p(mu), _p(wt))
+        return mu, wt
+
+    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, derivatives=False, nthreads=1):
+        """extinction, ssa: [ngrid, nwavel]; leg: [nleg, ngrid, nwavel]; albedo: [nwavel] (Fortran-style axes as in
+        the reference storage: location fastest)."""
+        k = np.asfortranarray(extinction, dtype=np.float64)
+        w = np.asfortranarray(ssa, dtype=np.float64)
+        lg = np.asfortranarray(leg, dtype=np.float64)
+        nwavel = k.shape[1]
+        alb = np.ascontiguousarray(albedo, dtype=np.float64)
+        irr = None if solar_irradiance is None else np.ascontiguousarray(solar_irradiance, dtype=np.float64)
+        rad = np.zeros((nwavel, self.nlos))
+        od = np.zeros((nwavel, self.nlos))
+        nazi = np.zeros(nwavel, dtype=np.int32)
+        dk = dw = da = None
+        if derivatives:
+            dk = np.zeros((nwavel, self.nlos, self.ngrid))
+            dw = np.zeros((nwavel, self.nlos, self.ngrid))
+            da = np.zeros((nwavel, self.nlos))
+        rc = lib().orc_run(self._h, nwavel, lg.shape[0], _p(k), _p(w), _p(lg), _p(irr), _p(alb), int(derivatives),
+                           nthreads, _p(rad), _p(dk), _p(dw), _p(da), _p(od), nazi.ctypes.data_as(_ip))
+        if rc != 0:
+            raise RuntimeError(f"oracle run failed with code {rc}")
+        out = {"radiance": rad, "los_optical_depth": od, "num_azimuth": nazi}
+        if derivatives:
+            out.update({"d_extinction": dk, "d_ssa": dw, "d_albedo": da})
+        return out
