@@ -95,6 +95,7 @@ class Solver {
     std::vector<double> tab_val;    // [m][slot]  (interior slots then ground slots)
     std::vector<double> tab_deriv;  // [m][slot][nnative]
     std::vector<uint8_t> converged; // [m][slot] (interior only)
+    std::vector<uint8_t> filled;    // [m][slot] value/derivative row written for this wavelength
     bool all_converged = false;
 
     inline int nl(int p) const { return nloc[p]; }
@@ -140,6 +141,7 @@ class Solver {
             tab_val.assign(size_t(nstr) * (npoint + nground), 0.0);
             tab_deriv.assign(size_t(nstr) * (npoint + nground) * nnative, 0.0);
             converged.assign(size_t(nstr) * npoint, 0);
+            filled.assign(size_t(nstr) * (npoint + nground), 0);
         }
     }
     int num_native() const { return nnative; }
@@ -954,6 +956,7 @@ inline void Solver::accumulate_ground(int m, int szaidx) {
             for (int k = 0; k < nk; ++k) diffuse_d[ls + k] += factor * sc_v * d_alb(k);
         }
         tab_val[size_t(m) * nslot + slot] = diffuse;
+        filled[size_t(m) * nslot + slot] = 1;
         if (ND) {
             double* nat = &tab_deriv[(size_t(m) * nslot + slot) * nnative];
             std::fill(nat, nat + nnative, 0.0);
@@ -1058,6 +1061,7 @@ inline void Solver::accumulate_sources(int m, int szaidx) {
             }
             val /= ssa[p];
             tab_val[size_t(m) * nslot + slot] = val;
+            filled[size_t(m) * nslot + slot] = 1;
             if (m >= 2) {
                 double prev = tab_val[size_t(m - 1) * nslot + slot], prev2 = tab_val[size_t(m - 2) * nslot + slot];
                 if ((std::abs(val / prev) < 1e-4 || prev < 1e-10) && (std::abs(val / prev2) < 1e-4 || prev2 < 1e-10)) {
@@ -1088,6 +1092,7 @@ inline void Solver::integrate_los(const AtmosphereView& atm, int w, Result& res)
                 double azf = std::cos(m * (kPi - ray.ground_saa));
                 for (auto& e : ray.ground) {
                     int slot = ground_slot[size_t(e.sza) * G.nangle + e.angle];
+                    if (!filled[size_t(m) * nslot + slot]) continue;
                     I += e.w * azf * tab_val[size_t(m) * nslot + slot];
                     if (nnative) {
                         const double* nat = &tab_deriv[(size_t(m) * nslot + slot) * nnative];
@@ -1126,6 +1131,7 @@ inline void Solver::integrate_los(const AtmosphereView& atm, int w, Result& res)
                     double azf = std::cos(m * L.azi);
                     for (auto& e : L.table) {
                         int slot = point_slot[(size_t(e.sza) * nlyr + e.alt) * G.nangle + e.angle];
+                        if (!filled[size_t(m) * nslot + slot]) continue;
                         const double* nat = &tab_deriv[(size_t(m) * nslot + slot) * nnative];
                         double f = omega * sf * e.w * azf;
                         for (int q = 0; q < nnative; ++q) dI[q] += f * nat[q];
@@ -1145,7 +1151,7 @@ inline void Solver::solve(const AtmosphereView& atm, int w, Result& res) {
     res.num_azimuth_used = 0;
     if (G.spherical_pp) {
         std::fill(tab_val.begin(), tab_val.end(), 0.0);
-        std::fill(tab_deriv.begin(), tab_deriv.end(), 0.0);
+        std::fill(filled.begin(), filled.end(), 0);
         std::fill(converged.begin(), converged.end(), 0);
         for (int s = 0; s < G.nsza; ++s) {
             configure_layers(atm, w, s);

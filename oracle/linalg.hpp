@@ -417,10 +417,12 @@ inline bool lu_factor(int n, double* a, int* piv) {
     return true;
 }
 inline void lu_solve(int n, const double* a, const int* piv, double* b) {
-    for (int k = 0; k < n; ++k) {
+    // rows of L were interchanged retroactively during factorization (LAPACK dgetrf convention),
+    // so all interchanges are applied to b before the unit-lower solve
+    for (int k = 0; k < n; ++k)
         if (piv[k] != k) std::swap(b[k], b[piv[k]]);
+    for (int k = 0; k < n; ++k)
         for (int i = k + 1; i < n; ++i) b[i] -= a[i * n + k] * b[k];
-    }
     for (int k = n - 1; k >= 0; --k) {
         double s = b[k];
         for (int j = k + 1; j < n; ++j) s -= a[k * n + j] * b[j];

@@ -1,0 +1,90 @@
+"""Deterministic inputs shared by the oracle tests, the GPU parity tests, smoke() and bench.py.
+
+`regression_1d` rebuilds the inputs of the reference's spherical regression pin
+(/root/reference/tests/engine/test_1d_solver_regression.py:9-107) and carries its expected
+radiances (:120-139) and LOS optical depths (:210-230).
+`limb_c2` is the BASELINE.json configs[1] workload: spherical limb, 16 streams,
+50 layers, 25 tangent heights, Rayleigh + HG(0.7) aerosol mix so that ~10 azimuth orders are needed.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TANGENT_ALTITUDE_SOLAR = 0
+GROUND_VIEWING_SOLAR = 1
+INTERP_SHELL, INTERP_LINEAR, INTERP_LOWER = 0, 1, 2
+GEO_PLANEPARALLEL, GEO_PSEUDOSPHERICAL, GEO_SPHERICAL = 0, 1, 2
+
+
+def regression_1d(num_wavelengths: int = 3):
+    alt = np.linspace(0.0, 60_000.0, 25)
+    csz = 0.42
+    rays = [
+        (GROUND_VIEWING_SOLAR, csz, -0.7, 200_000.0, 0.32),
+        (GROUND_VIEWING_SOLAR, csz, 0.4, 200_000.0, 0.78),
+        (TANGENT_ALTITUDE_SOLAR, csz, -0.35, 200_000.0, 12_345.0),
+        (TANGENT_ALTITUDE_SOLAR, csz, 0.65, 200_000.0, 27_123.0),
+    ]
+    nw = num_wavelengths
+    k = (2.4e-5 * np.exp(-alt / 7_500.0)[:, None] + 1.0e-9) * np.linspace(0.72, 1.35, nw)[None, :]
+    ssa = 0.91 + 0.025 * np.exp(-alt / 18_000.0)[:, None] - 0.01 * np.linspace(0.0, 1.0, nw)[None, :]
+    leg = np.zeros((16, 25, nw))
+    leg[0], leg[1], leg[2] = 1.0, 0.08, 0.5
+    albedo = np.linspace(0.08, 0.31, nw)
+    geometry = dict(cos_sza=csz, saa=0.35, earth_radius=6_372_000.0, altitudes=alt, interp_method=INTERP_LINEAR,
+                    geotype=GEO_SPHERICAL)
+    config = dict(nstr=8, num_sza=2)
+    expected_radiance = np.array([
+        [0.007325034080894165, 0.003911222331552876, 0.015579706096361565, 0.0038272940915240537],
+        [0.015246498141181428, 0.009498372748059328, 0.024575183549304623, 0.007446741685194283],
+        [0.023780265249057513, 0.016356191357612092, 0.031606480325730144, 0.01139900426172521],
+    ])
+    expected_od = np.array([
+        [0.4046672641890289, 0.16756248699288395, 1.8429222725097874, 0.2573659860040063],
+        [0.581709192271729, 0.2408710750522707, 2.64920076673282, 0.3699636048807591],
+        [0.7587511203544293, 0.31417966311165746, 3.455479260955851, 0.4825612237575118],
+    ])
+    return dict(geometry=geometry, config=config, rays=rays, extinction=k, ssa=ssa, leg=leg, albedo=albedo,
+                expected_radiance=expected_radiance, expected_od=expected_od)
+
+
+def limb_c2(num_wavelengths: int = 10_000, nlyr: int = 50, nstr: int = 16, num_sza: int = 1):
+    alt = np.linspace(0.0, 100_000.0, nlyr + 1)
+    csz = 0.6
+    rays = [(TANGENT_ALTITUDE_SOLAR, csz, 0.0, 600_000.0, float(t)) for t in np.arange(10_000.0, 59_000.0, 2_000.0)]
+    nw = num_wavelengths
+    k = (2.4e-5 * np.exp(-alt / 7_500.0)[:, None] + 1.0e-9) * np.linspace(0.72, 1.35, nw)[None, :]
+    ssa = 0.91 + 0.025 * np.exp(-alt / 18_000.0)[:, None] - 0.01 * np.linspace(0.0, 1.0, nw)[None, :]
+    l = np.arange(nstr)
+    ray = np.zeros(nstr)
+    ray[0], ray[2] = 1.0, 0.5
+    hg = (2 * l + 1) * 0.7 ** l
+    c = 0.3 * np.exp(-alt / 10_000.0)
+    leg = ((1 - c)[None, :] * ray[:, None] + c[None, :] * hg[:, None])[:, :, None] * np.ones((1, 1, nw))
+    albedo = np.linspace(0.08, 0.31, nw)
+    geometry = dict(cos_sza=csz, saa=0.0, earth_radius=6_372_000.0, altitudes=alt, interp_method=INTERP_LINEAR,
+                    geotype=GEO_SPHERICAL)
+    config = dict(nstr=nstr, num_sza=num_sza)
+    return dict(geometry=geometry, config=config, rays=rays, extinction=k, ssa=ssa, leg=leg, albedo=albedo)
+
+
+def planeparallel_case(case: dict):
+    """Engine inputs for one entry of tests/golden/do_scalar_planeparallel.json, built the way the reference's
+    harness does (cpp/lib/tests/sktran_disco/test_util.cpp:24-118)."""
+    nstr = case["nstr"]
+    layers = case["layers_od_ssa_g"]
+    nlyr = len(layers)
+    alt = np.arange(nlyr + 1, dtype=float)
+    csz = case["sun"]["csz"]
+    rays = [(GROUND_VIEWING_SOLAR, csz, -case["sun"]["saz"] + az, alt[-1] + 1, cz) for cz, az in case["los_coszen_az"]]
+    k = np.zeros((nlyr + 1, 1))
+    w = np.zeros((nlyr + 1, 1))
+    leg = np.zeros((nstr, nlyr + 1, 1))
+    for l, (od, ss, g) in enumerate(layers):
+        q = nlyr - l - 1
+        k[q, 0], w[q, 0] = od, ss
+        leg[:, q, 0] = [(2 * i + 1) * g ** i for i in range(nstr)]
+    geometry = dict(cos_sza=csz, saa=0.0, earth_radius=6_372_000.0, altitudes=alt, interp_method=INTERP_LOWER,
+                    geotype=GEO_PLANEPARALLEL)
+    return dict(geometry=geometry, config=dict(nstr=nstr, num_sza=1), rays=rays, extinction=k, ssa=w, leg=leg,
+                albedo=np.array([case["albedo"]]), expected=np.array(case["expected"]) / case["sun"]["direct"])

@@ -1,0 +1,95 @@
+"""Pins the CPU oracle against the reference's own known-answer tests (runs without a GPU)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle.oracle_py import OracleEngine
+from tests import scenarios as sc
+
+GOLDEN = json.loads((Path(__file__).parent / "golden" / "do_scalar_planeparallel.json").read_text())
+
+
+def make_oracle(s, ss_in_do=True):
+    g = s["geometry"]
+    return OracleEngine(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"], g["interp_method"], g["geotype"],
+                        s["config"]["nstr"], s["config"]["num_sza"], s["rays"], ss_in_do=ss_in_do)
+
+
+def run_oracle(s, derivatives=False, **over):
+    eng = make_oracle(s)
+    return eng.run(over.get("extinction", s["extinction"]), over.get("ssa", s["ssa"]), s["leg"],
+                   over.get("albedo", s["albedo"]), derivatives=derivatives)
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=[c["name"] for c in GOLDEN["cases"]])
+def test_planeparallel_known_answers(case):
+    # cpp/lib/tests/sktran_disco/legacy/test_scalar.cpp: |radiance - expected| < SKDO_FPC_EPS (1e-8; 1e-6 for SSA=1)
+    s = sc.planeparallel_case(case)
+    out = run_oracle(s)
+    assert np.max(np.abs(out["radiance"][0] - s["expected"])) < case["tolerance"]
+
+
+def test_planeparallel_three_layers_equal_one():
+    # "Scalar Boundary Conditions", test_scalar.cpp:847-880: 3 identical Rayleigh layers == 1 layer of 3x the depth
+    base = dict(GOLDEN["cases"][0])
+
+    def rayleigh(nl, od):
+        s = sc.planeparallel_case({**base, "layers_od_ssa_g": [[od, 1.0, 0.0]] * nl})
+        s["leg"][:] = 0
+        s["leg"][0], s["leg"][2] = 1.0, 0.5
+        return run_oracle(s)["radiance"][0]
+
+    assert np.max(np.abs(rayleigh(1, 0.6) - rayleigh(3, 0.2))) < 1e-8
+
+
+def test_spherical_regression_radiance_and_optical_depth():
+    # tests/engine/test_1d_solver_regression.py:195-240: rtol 5e-7 (atol 2e-13 / 1e-13)
+    s = sc.regression_1d()
+    out = run_oracle(s, derivatives=True)
+    np.testing.assert_allclose(out["radiance"], s["expected_radiance"], rtol=5e-7, atol=2e-13)
+    np.testing.assert_allclose(out["los_optical_depth"], s["expected_od"], rtol=5e-7, atol=1e-13)
+
+
+def _fd_check(s, out, rel=1e-4):
+    """Analytic WFs == central finite differences, the reference's own criterion
+    (src/sasktran2/test_util/wf.py:9-24: agreement relative to the largest WF of the column)."""
+    ngrid = s["extinction"].shape[0]
+    for name, key, idxs in (("extinction", "d_extinction", (0, 3, ngrid // 2, ngrid - 2)),
+                            ("ssa", "d_ssa", (0, 4, ngrid // 2, ngrid - 1))):
+        for q in idxs:
+            base = s[name]
+            if np.any(base[q, :] == 0):
+                continue  # unused top grid point of the plane-parallel 'lower' grids
+            h = 1e-4 * base[q, :]
+            plus, minus = base.copy(), base.copy()
+            plus[q, :] += h
+            minus[q, :] -= h
+            fd = (run_oracle(s, **{name: plus})["radiance"] - run_oracle(s, **{name: minus})["radiance"]) / (2 * h[:, None])
+            an = out[key][:, :, q]
+            scale = np.abs(out[key]).max(axis=2)
+            assert np.max(np.abs(fd - an) / scale) < rel, (name, q)
+    h = 1e-5
+    fd = (run_oracle(s, albedo=s["albedo"] + h)["radiance"] - run_oracle(s, albedo=s["albedo"] - h)["radiance"]) / (2 * h)
+    np.testing.assert_allclose(out["d_albedo"], fd, rtol=1e-5, atol=1e-12)
+
+
+def test_spherical_weighting_functions_match_finite_differences():
+    s = sc.regression_1d(2)
+    _fd_check(s, run_oracle(s, derivatives=True))
+
+
+def test_planeparallel_weighting_functions_match_finite_differences():
+    case = dict(GOLDEN["cases"][0])
+    case["los_coszen_az"] = case["los_coszen_az"][7:21:3]
+    case["expected"] = case["expected"][7:21:3]
+    s = sc.planeparallel_case(case)
+    _fd_check(s, run_oracle(s, derivatives=True))
+
+
+def test_limb_c2_small_runs_and_needs_many_azimuth_orders():
+    s = sc.limb_c2(num_wavelengths=2)
+    out = run_oracle(s, derivatives=True)
+    assert np.all(np.isfinite(out["radiance"])) and np.all(out["radiance"] > 0)
+    assert out["num_azimuth"].min() >= 6
