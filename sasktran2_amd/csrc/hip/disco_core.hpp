@@ -1,0 +1,1203 @@
+// DISCO hot path for MI355X -- per-task device math (scalar NSTOKES=1).
+//
+// Every function here is `SKD_HD` (host + device): the HIP kernels in disco_kernels.hip call them
+// with one GPU thread per task, and tests/emulate_kernels.cpp compiles the very same source with
+// g++ to run the kernel bodies on the CPU-only authoring container (test infrastructure only; the
+// product library is always the HIP build and fails loudly without a GPU).
+//
+// The formulation is NOT the reference's (and not the oracle's):
+//   * homogeneous solution: the streams x streams problem S-S+ x = k^2 x is symmetrized
+//     (B+- = T S+- T^-1, T = diag sqrt(w mu)), reduced with a Cholesky factor of B+ and solved by
+//     cyclic Jacobi -- no Hessenberg/QR, no pivoting, fixed data flow;
+//     reference: RTESolver::solveHomogeneous cpp/lib/sktran_disco/sktran_do_rte.cpp:382-553
+//   * eigen-pair derivatives by bi-orthogonal perturbation theory (left vectors Y = W M S+ X come for
+//     free) instead of N bordered LU solves; reference: linearizeHomogeneous sktran_do_rte.cpp:197-298
+//   * boundary value problem as a block-tridiagonal system with 2N x 2N blocks (one block row per
+//     layer: downwelling continuity at the layer top, upwelling continuity at its bottom) instead
+//     of LAPACK band storage; reference: solveBVP sktran_do_rte.cpp:1620-1790
+//   * weighting functions by an ADJOINT sweep: one transposed block solve per line of sight and a
+//     reverse-mode chain through beam transmission / average secant, instead of the reference's
+//     dense forward sweep with one right-hand side per atmospheric parameter
+//     (sktran_do_rte.cpp:1730-1789, do_source_diffuse_storage.cpp:957-1094).
+// Results are mathematically identical; parity is asserted on radiances and weighting functions.
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SKD_HD __host__ __device__ inline
+#else
+#define SKD_HD inline
+#endif
+
+namespace skd {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kGreensEps = 1e-4;  // sktran_do_types.h:11
+constexpr double kSSADither = 1e-9;  // sktran_do_specs.h:104
+
+// error bits written to the per-wavelength status word
+enum : int { ERR_CHOLESKY = 1, ERR_EIGEN = 2, ERR_SINGULAR_BVP = 4, ERR_NAN = 8 };
+
+// ------------------------------------------------------------------------------------------------
+// Geometry tables (wavelength independent, uploaded once per engine)
+// ------------------------------------------------------------------------------------------------
+struct Geo {
+    int nstr, N, nlyr, ngrid, nlos, nsza, nangle, npoint, nground, nslot, nq_total;
+    const double* mu;       // [N]
+    const double* wt;       // [N]
+    const double* lpmu;     // [m][i<N][l<nstr]
+    const double* lpcsz;    // [s][m][l]
+    const double* lpang;    // [m][a][l]
+    const double* dh;       // [p]
+    const double* lfrac;    // [p]  relative position of the table altitude inside the layer
+    const int* wq_idx;      // [p][2] optical interpolator (index -1 = unused)
+    const double* wq_w;     // [p][2]
+    const double* chapman;  // [s][p][r]
+    const double* csz;      // [s]
+    const int* pt_start;    // [s*nlyr+p .. +1] needed table angles of (sza, layer)
+    const int* pt_angle;
+    const int* pt_slot;
+    const int* gpt_start;   // [s .. +1] needed ground slots
+    const int* gpt_slot;
+    const int* ray_qstart;  // [los .. +1] ray layers (far end -> observer)
+    const int* ray_ground;  // [los]
+    const double* ray_gsaa; // [los]
+    const int* rl_od_start; // [q .. +1]
+    const int* od_idx;
+    const double* od_w;
+    const int* rl_ssa_start;
+    const int* ssa_idx;
+    const double* ssa_w;
+    const double* rl_azi;   // [q]
+    const int* rl_active;   // [q] 0 when the shell is shorter than MINIMUM_SHELL_SIZE_M
+    const int* rl_tab_start;  // [q .. +1] table entries of a ray layer
+    const int* tab_slot;
+    const double* tab_w;
+    const int* lp_start;    // [(los*nsza+s)*nlyr+p .. +1] table entries of a LOS grouped by (sza, layer)
+    const int* lp_q;
+    const int* lp_angle;
+    const int* lp_slot;
+    const double* lp_w;
+    const int* g_start;     // [los .. +1] ground entries
+    const int* g_slot;
+    const int* g_sza;
+    const double* g_w;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Per-run device buffers.  Unless noted every array is [element][thread] with the thread index
+// (wavelength, or wavelength*nlos+los) fastest, so that consecutive lanes touch consecutive doubles.
+// ------------------------------------------------------------------------------------------------
+struct Bufs {
+    int nw;                 // wavelengths in this launch
+    // inputs in the reference's storage layout (location fastest), cpp/include/c_api/atmosphere.h:77-83
+    const double* ext;      // [w][q]
+    const double* ssa;      // [w][q]
+    const double* leg;      // [w][q][l<nleg]
+    const double* albedo;   // [w]
+    const double* irradiance;  // [w] or null
+    int nleg;
+    // layer optics (K0)
+    double* tau;            // [p][w]
+    double* om;             // [p][w]
+    double* kbar;           // [p][w]
+    double* a;              // [p][l][w]
+    double* T;              // [lev<=nlyr][w]    (current sza)
+    double* sec;            // [p][w]
+    // LOS optics (K0)
+    double* od;             // [q][w]
+    double* omloc;          // [q][w]
+    double* srcw;           // [q][w]  omega_loc (1-exp(-od)) * attenuation(q -> observer)
+    double* att_total;      // [los][w]
+    // per azimuth order
+    double* rec;            // [p][REC][w]
+    double* dinv;           // [p][4N^2][w]
+    double* xsol;           // [p][2N][w]
+    double* J;              // [m][slot][w]
+    uint8_t* conv_order;    // [slot][w]  first azimuth order that is skipped for this table point
+    int* notconv;           // [w]
+    int* norders;           // [w] number of azimuth orders that are solved (stop rule)
+    int* status;            // [w] error bits
+    double* z;              // [p][2N][w*nlos+los]
+    double* grad;           // [4*nlyr+2][w*nlos+los]   reduced gradient of the current sza
+    double* dnat;           // [2*ngrid+1][w*nlos+los]  native derivatives
+    double* radiance;       // [w*nlos+los]
+    double* los_od;         // [w*nlos+los]
+    int derivs;
+};
+
+template <int N> struct Rec {
+    static constexpr int K = 0, DK = N, WP = 2 * N, WM = WP + N * N, DWP = WM + N * N, DWM = DWP + N * N,
+                         AP = DWM + N * N, AM = AP + N, DAP = AM + N, DAM = DAP + N, G = DAM + N, DG = G + 4 * N,
+                         SIZE = DG + 16 * N;
+    // G order: 0 Gplus_top, 1 Gminus_top, 2 Gplus_bottom, 3 Gminus_bottom;  DG[theta][which][i], theta: 0 tau 1 omega 2 T 3 sec
+};
+enum { TH_TAU = 0, TH_OM = 1, TH_T = 2, TH_SEC = 3 };
+
+struct RecView {
+    const double* p;
+    size_t stride;
+    SKD_HD double operator()(int e) const { return p[size_t(e) * stride]; }
+};
+
+// =================================================================================================
+// K0: layer optics + beam attenuation + LOS optics        (one task per wavelength)
+//   reference: OpticalLayerArray ctor / configureTransmission, sktran_do_layerarray.cpp:332-477,890-979
+// =================================================================================================
+SKD_HD void k0_layer_optics(const Geo& g, const Bufs& b, int w) {
+    const int nw = b.nw, nlyr = g.nlyr, nstr = g.nstr, ngrid = g.ngrid;
+    const double* ext = b.ext + size_t(w) * ngrid;
+    const double* ssa = b.ssa + size_t(w) * ngrid;
+    const double* leg = b.leg + size_t(w) * ngrid * b.nleg;
+    double ceiling_depth = 0, floor_depth = 0;
+    for (int p = 0; p < nlyr; ++p) {
+        double od = 0, s = 0;
+        for (int l = 0; l < nstr; ++l) b.a[(size_t(p) * nstr + l) * nw + w] = 0;
+        for (int t = 0; t < 2; ++t) {
+            int q = g.wq_idx[2 * p + t];
+            if (q < 0) continue;
+            double wt = g.wq_w[2 * p + t];
+            double kext = ext[q], kscat = ssa[q] * kext;
+            od += kext * wt;
+            s += kscat * wt;
+            for (int l = 0; l < nstr && l < b.nleg; ++l) b.a[(size_t(p) * nstr + l) * nw + w] += wt * kscat * leg[size_t(q) * b.nleg + l];
+        }
+        if (s > 0) {
+            for (int l = 0; l < nstr; ++l) b.a[(size_t(p) * nstr + l) * nw + w] /= s;
+        } else {
+            b.a[(size_t(p) * nstr) * nw + w] = 0;
+        }
+        s /= od;
+        od *= g.dh[p];
+        floor_depth += od;
+        double te = od / g.dh[p];
+        double se = fmax(te * s, te * kSSADither);
+        double m_ssa = se / te;
+        if (1 - m_ssa < kSSADither) m_ssa = 1 - kSSADither;
+        b.kbar[size_t(p) * nw + w] = te;
+        b.om[size_t(p) * nw + w] = m_ssa;
+        b.tau[size_t(p) * nw + w] = floor_depth - ceiling_depth;
+        ceiling_depth = floor_depth;
+    }
+    // LOS shells: optical depth, local ssa, source weights
+    for (int l = 0; l < g.nlos; ++l) {
+        const int q0 = g.ray_qstart[l], q1 = g.ray_qstart[l + 1];
+        double total = 0;
+        for (int q = q0; q < q1; ++q) {
+            double od = 0;
+            for (int t = g.rl_od_start[q]; t < g.rl_od_start[q + 1]; ++t) od += g.od_w[t] * ext[g.od_idx[t]];
+            double om = 0;
+            for (int t = g.rl_ssa_start[q]; t < g.rl_ssa_start[q + 1]; ++t) om += ssa[g.ssa_idx[t]] * g.ssa_w[t];
+            b.od[size_t(q) * nw + w] = od;
+            b.omloc[size_t(q) * nw + w] = om;
+            total += od;
+        }
+        // attenuation from the near edge of shell q to the observer: product over shells closer to the observer
+        double att = 1.0;
+        for (int q = q1 - 1; q >= q0; --q) {
+            double od = b.od[size_t(q) * nw + w];
+            double sf = 1 - exp(-od);
+            b.srcw[size_t(q) * nw + w] = g.rl_active[q] ? b.omloc[size_t(q) * nw + w] * sf * att : 0.0;
+            att *= exp(-od);
+        }
+        b.att_total[size_t(l) * nw + w] = att;
+        b.los_od[size_t(w) * g.nlos + l] = total;
+    }
+}
+
+// beam transmission at layer ceilings (T[lev]) and average secants for solar zenith index s
+SKD_HD void k0_transmission(const Geo& g, const Bufs& b, int s, int w) {
+    const int nw = b.nw, nlyr = g.nlyr;
+    const double F0 = b.irradiance ? b.irradiance[w] : 1.0;
+    double prev = 0;
+    b.T[w] = F0;
+    for (int p = 0; p < nlyr; ++p) {
+        const double* ch = g.chapman + (size_t(s) * nlyr + p) * nlyr;
+        if (ch[0] < 0) {
+            b.T[size_t(p + 1) * nw + w] = 0.0;
+            b.sec[size_t(p) * nw + w] = 1e10;
+            prev = -1.0;
+            continue;
+        }
+        double sig = 0;
+        for (int r = 0; r < nlyr; ++r) sig += ch[r] * b.tau[size_t(r) * nw + w];
+        b.sec[size_t(p) * nw + w] = (sig - prev) / b.tau[size_t(p) * nw + w];
+        b.T[size_t(p + 1) * nw + w] = exp(-sig) * F0;
+        prev = sig;
+    }
+}
+
+// =================================================================================================
+// small dense helpers on private arrays (row-major, leading dimension LD)
+// =================================================================================================
+template <int N> SKD_HD bool cholesky_lower(double* A) {  // in place, lower triangle
+    for (int j = 0; j < N; ++j) {
+        double d = A[j * N + j];
+        for (int k = 0; k < j; ++k) d -= A[j * N + k] * A[j * N + k];
+        if (!(d > 0)) return false;
+        d = sqrt(d);
+        A[j * N + j] = d;
+        for (int i = j + 1; i < N; ++i) {
+            double s = A[i * N + j];
+            for (int k = 0; k < j; ++k) s -= A[i * N + k] * A[j * N + k];
+            A[i * N + j] = s / d;
+        }
+        for (int i = 0; i < j; ++i) A[i * N + j] = 0;
+    }
+    return true;
+}
+
+// cyclic Jacobi for a symmetric N x N matrix (destroyed); eigenvalues -> lam, eigenvectors -> V columns
+template <int N> SKD_HD bool jacobi_eigen(double* A, double* lam, double* V) {
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) V[i * N + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0, dia = 0;
+        for (int i = 0; i < N; ++i) {
+            dia += A[i * N + i] * A[i * N + i];
+            for (int j = i + 1; j < N; ++j) off += A[i * N + j] * A[i * N + j];
+        }
+        if (off <= 1e-34 * dia || off == 0) {
+            for (int i = 0; i < N; ++i) lam[i] = A[i * N + i];
+            return true;
+        }
+        for (int p = 0; p < N - 1; ++p)
+            for (int q = p + 1; q < N; ++q) {
+                double apq = A[p * N + q];
+                if (apq == 0.0) continue;
+                double app = A[p * N + p], aqq = A[q * N + q];
+                double theta = (aqq - app) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                A[p * N + p] = app - t * apq;
+                A[q * N + q] = aqq + t * apq;
+                A[p * N + q] = 0;
+                A[q * N + p] = 0;
+                for (int r = 0; r < N; ++r) {
+                    if (r != p && r != q) {
+                        double arp = A[r * N + p], arq = A[r * N + q];
+                        double np_ = c * arp - s * arq, nq_ = s * arp + c * arq;
+                        A[r * N + p] = np_;
+                        A[p * N + r] = np_;
+                        A[r * N + q] = nq_;
+                        A[q * N + r] = nq_;
+                    }
+                    double vrp = V[r * N + p], vrq = V[r * N + q];
+                    V[r * N + p] = c * vrp - s * vrq;
+                    V[r * N + q] = s * vrp + c * vrq;
+                }
+            }
+    }
+    for (int i = 0; i < N; ++i) lam[i] = A[i * N + i];
+    return false;
+}
+
+// Gauss-Jordan inverse with partial pivoting of an M x M matrix (row-major); returns false if singular
+template <int M> SKD_HD bool invert(double* A, double* Ainv) {
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < M; ++j) Ainv[i * M + j] = (i == j) ? 1.0 : 0.0;
+    for (int c = 0; c < M; ++c) {
+        int piv = c;
+        double best = fabs(A[c * M + c]);
+        for (int r = c + 1; r < M; ++r)
+            if (fabs(A[r * M + c]) > best) { best = fabs(A[r * M + c]); piv = r; }
+        if (!(best > 0)) return false;
+        if (piv != c)
+            for (int j = 0; j < M; ++j) {
+                double t = A[c * M + j]; A[c * M + j] = A[piv * M + j]; A[piv * M + j] = t;
+                t = Ainv[c * M + j]; Ainv[c * M + j] = Ainv[piv * M + j]; Ainv[piv * M + j] = t;
+            }
+        double inv = 1.0 / A[c * M + c];
+        for (int j = 0; j < M; ++j) { A[c * M + j] *= inv; Ainv[c * M + j] *= inv; }
+        for (int r = 0; r < M; ++r) {
+            if (r == c) continue;
+            double f = A[r * M + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < M; ++j) { A[r * M + j] -= f * A[c * M + j]; Ainv[r * M + j] -= f * Ainv[c * M + j]; }
+        }
+    }
+    return true;
+}
+
+// Green's function multipliers C+-(tau, sec, k; T) with their partial derivatives.
+//   reference: solveParticularGreen, sktran_do_rte.cpp:1039-1237 (second-order Taylor forms when |sec -+ k| <= 1e-4)
+struct Mult { double v, d_tau, d_sec, d_k; };  // dC/dT = v / T
+SKD_HD void green_multipliers(double T, double th, double sc, double ev, Mult& Cp, Mult& Cm) {
+    const double exp_te = exp(-th * ev), exp_ts = exp(-th * sc);
+    if (fabs(sc - ev) > kGreensEps) {
+        double den = sc - ev;
+        Cp.v = T * (exp_te - exp_ts) / den;
+        Cp.d_sec = (T * th * exp_ts - Cp.v) / den;
+        Cp.d_k = (Cp.v - T * th * exp_te) / den;
+        Cp.d_tau = -T / den * (ev * exp_te - sc * exp_ts);
+    } else {
+        Cp.v = T * exp_te * th * (1 - th / 2 * (sc - ev));
+        Cp.d_sec = -th / 2.0 * th * T * exp_te;
+        Cp.d_k = -Cp.v * th + th / 2.0 * th * T * exp_te;
+        Cp.d_tau = T * exp_te * (1 - th * (sc - ev)) - ev * Cp.v;
+    }
+    if (fabs(sc + ev) > kGreensEps) {
+        double den = sc + ev;
+        double exp_sum = exp(-th * (sc + ev));
+        Cm.v = T * (1 - exp_ts * exp_te) / den;
+        Cm.d_sec = (T * th * exp_sum - Cm.v) / den;
+        Cm.d_k = Cm.d_sec;
+        Cm.d_tau = T * exp_sum;
+    } else {
+        Cm.v = T * th * (1 - th / 2 * (sc + ev));
+        Cm.d_sec = -th / 2 * th * T;
+        Cm.d_k = -T * th * th / 2;
+        Cm.d_tau = T * (1 - th * (sc + ev));
+    }
+}
+
+// =================================================================================================
+// K1: homogeneous + particular solution of one layer for azimuth order m   (task = wavelength x layer)
+// =================================================================================================
+template <int N> SKD_HD void k1_layer_solution(const Geo& g, const Bufs& b, int s, int m, int p, int w) {
+    constexpr int NSTR = 2 * N;
+    using R = Rec<N>;
+    const int nw = b.nw;
+    double* rec = b.rec + size_t(p) * R::SIZE * nw + w;
+    auto out = [&](int e) -> double& { return rec[size_t(e) * nw]; };
+    const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
+    const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
+    const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
+    const double* lpcsz = g.lpcsz + (size_t(s) * NSTR + m) * NSTR;
+    double a[NSTR];
+    for (int l = 0; l < NSTR; ++l) a[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
+
+    double Ep[N * N], Em[N * N], Bp[N * N], Bm[N * N], X[N * N], U[N * N], V[N * N], Tm[N * N];
+    double lam[N], kk[N], sq[N], tt[N];
+    for (int i = 0; i < N; ++i) {
+        sq[i] = sqrt(g.wt[i] / g.mu[i]);
+        tt[i] = sqrt(g.wt[i] * g.mu[i]);
+    }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double ep = 0, em = 0;
+            for (int l = m; l < NSTR; ++l) {
+                double t = a[l] * lpmu[i * NSTR + l] * lpmu[j * NSTR + l];
+                if ((l - m) & 1) em += t; else ep += t;
+            }
+            Ep[i * N + j] = Ep[j * N + i] = ep;
+            Em[i * N + j] = Em[j * N + i] = em;
+            double dlt = (i == j) ? 1.0 / g.mu[i] : 0.0;
+            Bp[i * N + j] = Bp[j * N + i] = dlt - sq[i] * sq[j] * om * ep;
+            Bm[i * N + j] = Bm[j * N + i] = dlt - sq[i] * sq[j] * om * em;
+        }
+    int err = 0;
+    if (!cholesky_lower<N>(Bp)) err |= ERR_CHOLESKY;  // Bp now holds R (lower), B+ = R R^T
+    // As = R^T B- R
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            double t = 0;
+            for (int r = j; r < N; ++r) t += Bm[i * N + r] * Bp[r * N + j];
+            Tm[i * N + j] = t;
+        }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double t = 0;
+            for (int r = i; r < N; ++r) t += Bp[r * N + i] * Tm[r * N + j];
+            Bm[i * N + j] = Bm[j * N + i] = t;
+        }
+    if (!jacobi_eigen<N>(Bm, lam, V)) err |= ERR_EIGEN;
+    // xhat = R^-T v ; x = T^-1 xhat
+    for (int j = 0; j < N; ++j) {
+        for (int i = N - 1; i >= 0; --i) {
+            double t = V[i * N + j];
+            for (int r = i + 1; r < N; ++r) t -= Bp[r * N + i] * X[r * N + j];
+            X[i * N + j] = t / Bp[i * N + i];
+        }
+    }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) X[i * N + j] /= tt[i];
+    // S+ (into Bp), S- (into Bm):  S+- = M^-1 (I - om E+- W)
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            double dlt = (i == j) ? 1.0 / g.mu[i] : 0.0;
+            Bp[i * N + j] = dlt - om * g.wt[j] * Ep[i * N + j] / g.mu[i];
+            Bm[i * N + j] = dlt - om * g.wt[j] * Em[i * N + j] / g.mu[i];
+        }
+    for (int j = 0; j < N; ++j) {
+        if (!(lam[j] > 0)) { err |= ERR_EIGEN; lam[j] = fabs(lam[j]) + 1e-300; }
+        kk[j] = sqrt(lam[j]);
+    }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            double t = 0;
+            for (int r = 0; r < N; ++r) t += Bp[i * N + r] * X[r * N + j];
+            U[i * N + j] = t;
+        }
+    // ---- omega derivatives (bi-orthogonal perturbation theory); Ep is reused for d(Gamma) X, Em for Z/C, Tm for dX, V for dU
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            double hm = 0;
+            for (int r = 0; r < N; ++r) hm += Bm[i * N + r] * X[r * N + j] / g.mu[r];
+            Ep[i * N + j] = (2 * X[i * N + j] * lam[j] - U[i * N + j] / g.mu[i] - hm) / om;
+        }
+    double dk[N];
+    double lmax = 0;
+    for (int j = 0; j < N; ++j) lmax = fmax(lmax, lam[j]);
+    for (int aidx = 0; aidx < N; ++aidx)
+        for (int bidx = 0; bidx < N; ++bidx) {
+            double z = 0;
+            for (int i = 0; i < N; ++i) z += g.wt[i] * g.mu[i] * U[i * N + aidx] * Ep[i * N + bidx];
+            if (aidx == bidx) {
+                dk[bidx] = z / (2 * kk[bidx]);
+                Em[aidx * N + bidx] = 0;
+            } else {
+                double den = lam[bidx] - lam[aidx];
+                Em[aidx * N + bidx] = (fabs(den) > 1e-13 * lmax) ? z / den : 0.0;
+            }
+        }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            double t = 0;
+            for (int r = 0; r < N; ++r) t += X[i * N + r] * Em[r * N + j];
+            Tm[i * N + j] = t;  // dX
+        }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            double t = (U[i * N + j] - X[i * N + j] / g.mu[i]) / om;
+            for (int r = 0; r < N; ++r) t += Bp[i * N + r] * Tm[r * N + j];
+            V[i * N + j] = t;  // dU
+        }
+    // W+-, dW+- (stored as W(i, solution j) at i + N j), norms
+    double nrm[N], dnrm[N];
+    for (int j = 0; j < N; ++j) {
+        nrm[j] = 0;
+        dnrm[j] = 0;
+        out(R::K + j) = kk[j];
+        out(R::DK + j) = dk[j];
+        for (int i = 0; i < N; ++i) {
+            double uk = U[i * N + j] / kk[j];
+            double duk = V[i * N + j] / kk[j] - U[i * N + j] * dk[j] / lam[j];
+            double wp = 0.5 * (X[i * N + j] + uk), wm = 0.5 * (X[i * N + j] - uk);
+            double dwp = 0.5 * (Tm[i * N + j] + duk), dwm = 0.5 * (Tm[i * N + j] - duk);
+            out(R::WP + i + N * j) = wp;
+            out(R::WM + i + N * j) = wm;
+            out(R::DWP + i + N * j) = dwp;
+            out(R::DWM + i + N * j) = dwm;
+            // reuse X/U/Tm/V to keep W values in private memory: X<-wp, U<-wm, Tm<-dwp, V<-dwm
+            X[i * N + j] = wp;
+            U[i * N + j] = wm;
+            Tm[i * N + j] = dwp;
+            V[i * N + j] = dwm;
+            nrm[j] += g.wt[i] * g.mu[i] * (wp * wp - wm * wm);
+            dnrm[j] += g.wt[i] * g.mu[i] * 2.0 * (wp * dwp - wm * dwm);
+        }
+    }
+    // ---- particular solution (Green's function)
+    double Qp[N], Qm[N];
+    bool allzero = true;
+    const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * kPi);
+    for (int i = 0; i < N; ++i) {
+        double sp = 0, sn = 0;
+        for (int l = m; l < NSTR; ++l) {
+            double t = a[l] * lpmu[i * NSTR + l] * lpcsz[l];
+            sp += t;
+            sn += ((l - m) & 1) ? -t : t;
+        }
+        Qp[i] = sp * fm * g.wt[i] * om;
+        Qm[i] = sn * fm * g.wt[i] * om;
+        if (Qp[i] != 0 || Qm[i] != 0) allzero = false;
+    }
+    double G[4][N], dG[4][4][N];
+    for (int c = 0; c < 4; ++c)
+        for (int i = 0; i < N; ++i) {
+            G[c][i] = 0;
+            for (int t = 0; t < 4; ++t) dG[t][c][i] = 0;
+        }
+    for (int j = 0; j < N; ++j) {
+        double Ap = 0, Am = 0, dAp = 0, dAm = 0;
+        if (!allzero) {
+            for (int i = 0; i < N; ++i) {
+                double wp = X[i * N + j], wm = U[i * N + j], dwp = Tm[i * N + j], dwm = V[i * N + j];
+                Ap += Qp[i] * wp + Qm[i] * wm;
+                Am += Qm[i] * wp + Qp[i] * wm;
+                dAp += Qp[i] * dwp + Qp[i] / om * wp + Qm[i] * dwm + Qm[i] / om * wm;
+                dAm += Qm[i] * dwp + Qm[i] / om * wp + Qp[i] * dwm + Qp[i] / om * wm;
+            }
+            Ap /= nrm[j];
+            Am /= nrm[j];
+            dAp = dAp / nrm[j] - dnrm[j] * Ap / nrm[j];
+            dAm = dAm / nrm[j] - dnrm[j] * Am / nrm[j];
+            Mult Cp, Cm;
+            green_multipliers(T, th, sc, kk[j], Cp, Cm);
+            const double dCp[4] = {Cp.d_tau, Cp.d_k * dk[j], T != 0 ? Cp.v / T : 0.0, Cp.d_sec};
+            const double dCm[4] = {Cm.d_tau, Cm.d_k * dk[j], T != 0 ? Cm.v / T : 0.0, Cm.d_sec};
+            for (int i = 0; i < N; ++i) {
+                double wp = X[i * N + j], wm = U[i * N + j], dwp = Tm[i * N + j], dwm = V[i * N + j];
+                G[0][i] += Am * Cm.v * wm;
+                G[1][i] += Am * Cm.v * wp;
+                G[2][i] += Ap * Cp.v * wp;
+                G[3][i] += Ap * Cp.v * wm;
+                for (int t = 0; t < 4; ++t) {
+                    dG[t][0][i] += Am * dCm[t] * wm;
+                    dG[t][1][i] += Am * dCm[t] * wp;
+                    dG[t][2][i] += Ap * dCp[t] * wp;
+                    dG[t][3][i] += Ap * dCp[t] * wm;
+                }
+                dG[TH_OM][0][i] += dAm * Cm.v * wm + Am * Cm.v * dwm;
+                dG[TH_OM][1][i] += dAm * Cm.v * wp + Am * Cm.v * dwp;
+                dG[TH_OM][2][i] += dAp * Cp.v * wp + Ap * Cp.v * dwp;
+                dG[TH_OM][3][i] += dAp * Cp.v * wm + Ap * Cp.v * dwm;
+            }
+        }
+        out(R::AP + j) = Ap;
+        out(R::AM + j) = Am;
+        out(R::DAP + j) = dAp;
+        out(R::DAM + j) = dAm;
+    }
+    for (int c = 0; c < 4; ++c)
+        for (int i = 0; i < N; ++i) {
+            out(R::G + c * N + i) = G[c][i];
+            for (int t = 0; t < 4; ++t) out(R::DG + (t * 4 + c) * N + i) = dG[t][c][i];
+        }
+    if (err) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(&b.status[w], err);
+#else
+        b.status[w] |= err;
+#endif
+    }
+}
+
+// =================================================================================================
+// K2a: block-tridiagonal boundary value problem, factor + solve      (task = wavelength)
+//   block row p: rows A  -W+_p L_p - W-_p E_p M_p + [W+_{p-1} E_{p-1} L_{p-1} + W-_{p-1} M_{p-1}] = G+top_p - G+bot_{p-1}
+//                rows B   W-_p E_p L_p + W+_p M_p - [W-_{p+1} L_{p+1} + W+_{p+1} E_{p+1} M_{p+1}] = G-top_{p+1} - G-bot_p
+//                (last layer rows B: ground reflection condition)
+//   reference conditions: bvpTOACondition / bvpContinuityCondition / bvpGroundCondition, sktran_do_rte.cpp:1897-2128
+// =================================================================================================
+template <int N> SKD_HD void k2a_bvp(const Geo& g, const Bufs& b, int s, int m, int w) {
+    using R = Rec<N>;
+    constexpr int M2 = 2 * N;
+    const int nw = b.nw, nlyr = g.nlyr;
+    const double rho = (m == 0) ? b.albedo[w] : 0.0;  // Lambertian
+    const double kd = 2.0;                            // (1 + delta_m0) with m == 0
+    double D[M2 * M2], Dinv[M2 * M2], T1[N * M2], r[M2], rprev[M2], E[N], Eprev[N];
+    auto recp = [&](int p) { return RecView{b.rec + size_t(p) * R::SIZE * nw + w, size_t(nw)}; };
+    for (int p = 0; p < nlyr; ++p) {
+        RecView c = recp(p);
+        const double th = b.tau[size_t(p) * nw + w];
+        for (int j = 0; j < N; ++j) E[j] = exp(-fabs(c(R::K + j)) * th);
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                double wp = c(R::WP + i + N * j), wm = c(R::WM + i + N * j);
+                D[i * M2 + j] = -wp;
+                D[i * M2 + N + j] = -wm * E[j];
+                D[(N + i) * M2 + j] = wm * E[j];
+                D[(N + i) * M2 + N + j] = wp;
+            }
+        for (int i = 0; i < N; ++i) {
+            r[i] = c(R::G + 0 * N + i);
+            r[N + i] = -c(R::G + 3 * N + i);
+        }
+        if (p == nlyr - 1) {
+            if (m == 0) {
+                for (int j = 0; j < N; ++j) {
+                    double sp = 0, sm = 0;
+                    for (int t = 0; t < N; ++t) {
+                        sp += g.wt[t] * g.mu[t] * c(R::WP + t + N * j);
+                        sm += g.wt[t] * g.mu[t] * c(R::WM + t + N * j);
+                    }
+                    for (int i = 0; i < N; ++i) {
+                        D[(N + i) * M2 + j] -= kd * rho * sp * E[j];
+                        D[(N + i) * M2 + N + j] -= kd * rho * sm;
+                    }
+                }
+                double sg = 0;
+                for (int t = 0; t < N; ++t) sg += g.wt[t] * g.mu[t] * c(R::G + 2 * N + t);
+                const double direct = g.csz[s] * rho / kPi * b.T[size_t(nlyr) * nw + w];
+                for (int i = 0; i < N; ++i) r[N + i] += direct + kd * rho * sg;
+            }
+        } else {
+            RecView cn = recp(p + 1);
+            for (int i = 0; i < N; ++i) r[N + i] += cn(R::G + 1 * N + i);
+        }
+        if (p > 0) {
+            RecView cp = recp(p - 1);
+            // T1 = Sub_p * Dinv_{p-1},  Sub_p rows A = [W+_{p-1} E_{p-1} | W-_{p-1}]
+            for (int i = 0; i < N; ++i)
+                for (int j = 0; j < M2; ++j) {
+                    double t = 0;
+                    for (int q = 0; q < N; ++q)
+                        t += cp(R::WP + i + N * q) * Eprev[q] * Dinv[q * M2 + j] + cp(R::WM + i + N * q) * Dinv[(N + q) * M2 + j];
+                    T1[i * M2 + j] = t;
+                }
+            // D rows A -= T1[:, N:] * Sup_{p-1} rows B = [-W-_p | -W+_p E_p]
+            for (int i = 0; i < N; ++i) {
+                for (int j = 0; j < N; ++j) {
+                    double t1 = 0, t2 = 0;
+                    for (int q = 0; q < N; ++q) {
+                        t1 += T1[i * M2 + N + q] * c(R::WM + q + N * j);
+                        t2 += T1[i * M2 + N + q] * c(R::WP + q + N * j);
+                    }
+                    D[i * M2 + j] += t1;
+                    D[i * M2 + N + j] += t2 * E[j];
+                }
+                double t = 0;
+                for (int q = 0; q < M2; ++q) t += T1[i * M2 + q] * rprev[q];
+                r[i] -= cp(R::G + 2 * N + i) + t;
+            }
+        }
+        if (!invert<M2>(D, Dinv)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            atomicOr(&b.status[w], ERR_SINGULAR_BVP);
+#else
+            b.status[w] |= ERR_SINGULAR_BVP;
+#endif
+        }
+        for (int i = 0; i < M2; ++i) {
+            rprev[i] = r[i];
+            b.xsol[(size_t(p) * M2 + i) * nw + w] = r[i];
+            for (int j = 0; j < M2; ++j) b.dinv[(size_t(p) * M2 * M2 + i * M2 + j) * nw + w] = Dinv[i * M2 + j];
+        }
+        for (int j = 0; j < N; ++j) Eprev[j] = E[j];
+    }
+    // back substitution:  x_p = Dinv_p (r'_p - Sup_p x_{p+1})
+    double xn[M2];
+    for (int p = nlyr - 1; p >= 0; --p) {
+        for (int i = 0; i < M2; ++i) r[i] = b.xsol[(size_t(p) * M2 + i) * nw + w];
+        if (p < nlyr - 1) {
+            RecView cn = recp(p + 1);
+            const double thn = b.tau[size_t(p + 1) * nw + w];
+            for (int i = 0; i < N; ++i) {
+                double t = 0;
+                for (int j = 0; j < N; ++j)
+                    t += cn(R::WM + i + N * j) * xn[j] + cn(R::WP + i + N * j) * exp(-fabs(cn(R::K + j)) * thn) * xn[N + j];
+                r[N + i] += t;
+            }
+        }
+        for (int i = 0; i < M2; ++i) {
+            double t = 0;
+            for (int j = 0; j < M2; ++j) t += b.dinv[(size_t(p) * M2 * M2 + i * M2 + j) * nw + w] * r[j];
+            D[i] = t;
+        }
+        for (int i = 0; i < M2; ++i) {
+            xn[i] = D[i];
+            b.xsol[(size_t(p) * M2 + i) * nw + w] = D[i];
+        }
+    }
+}
+
+// layer-interior multipliers of the post-processing (sktran_do_postprocessing.h:19-188), value + partials
+struct PPMult {
+    double hp, hm, Dm, Dp;
+    double hp_tau, hp_k, hm_tau, hm_k;
+    double Dm_tau, Dm_k, Dm_sec, Dp_tau, Dp_k, Dp_sec;  // d/dT = value / T
+};
+SKD_HD void pp_multipliers(double T, double th, double sc, double ev, double lf, PPMult& o) {
+    const double x = th * lf;
+    o.hp = exp(-1.0 * ev * th * lf);
+    o.hm = exp(-ev * th * (1 - lf));
+    o.hp_tau = -o.hp * ev * lf;
+    o.hp_k = -o.hp * th * lf;
+    o.hm_tau = -o.hm * ev * (1 - lf);
+    o.hm_k = -o.hm * th * (1 - lf);
+    {
+        const double den = sc - ev, exk = exp(-x * ev), exs = exp(-x * sc), v = exk - exs;
+        o.Dm = v * T / den;
+        o.Dm_sec = T * (-v / den + exs * x) / den;
+        o.Dm_k = T * (-x * exk + v / den) / den;
+        o.Dm_tau = lf * T * (exs * sc - exk * ev) / den;
+    }
+    {
+        const double den = ev + sc, exs = exp(-x * sc);
+        const double ef2 = exp(-th * sc) * exp(-(th - x) * ev), v = exs - ef2;
+        o.Dp = v * T / den;
+        o.Dp_sec = T * (-v / den - x * exs + th * ef2) / den;
+        o.Dp_k = T * (-v / den + ef2 * (th - x)) / den;
+        o.Dp_tau = T * (-exs * lf * sc + ef2 * sc + ef2 * (ev - lf * ev)) / den;
+    }
+}
+
+// =================================================================================================
+// K3: diffuse source table values J_m at the needed (layer, angle) points + convergence bookkeeping
+//   (task = wavelength x layer; the bottom layer's task also fills the ground rows)
+//   reference: DOSourceDiffuseStorage::accumulate_sources / accumulate_ground_sources,
+//              do_source_diffuse_storage.cpp:435-695,697-1098 (values only)
+// =================================================================================================
+template <int N> SKD_HD void k3_table_values(const Geo& g, const Bufs& b, int s, int m, int p, int w) {
+    constexpr int NSTR = 2 * N;
+    using R = Rec<N>;
+    const int nw = b.nw, nlyr = g.nlyr;
+    RecView c{b.rec + size_t(p) * R::SIZE * nw + w, size_t(nw)};
+    const double th = b.tau[size_t(p) * nw + w];
+    const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
+    const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
+    double a[NSTR], coefL[N], coefM[N], coefP[N], coefQ[N];
+    for (int l = 0; l < NSTR; ++l) a[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
+    // per solution j: J = (1/om) sum_j [ Y+_j (h+_j L_j + A+_j D-_j) + Y-_j (h-_j M_j + A-_j D+_j) ]
+    for (int j = 0; j < N; ++j) {
+        PPMult pm;
+        pp_multipliers(T, th, sc, c(R::K + j), g.lfrac[p], pm);
+        double L = b.xsol[(size_t(p) * 2 * N + j) * nw + w], Mv = b.xsol[(size_t(p) * 2 * N + N + j) * nw + w];
+        coefL[j] = pm.hp * L + c(R::AP + j) * pm.Dm;
+        coefM[j] = pm.hm * Mv + c(R::AM + j) * pm.Dp;
+    }
+    // contract with W first:  J = (1/om) sum_r [ lp_r P_r + lm_r Q_r ],  P_r = sum_j (W+_rj cL_j + W-_rj cM_j),  Q_r = sum_j (W-_rj cL_j + W+_rj cM_j)
+    for (int r = 0; r < N; ++r) {
+        double pr = 0, qr = 0;
+        for (int j = 0; j < N; ++j) {
+            double wp = c(R::WP + r + N * j), wm = c(R::WM + r + N * j);
+            pr += wp * coefL[j] + wm * coefM[j];
+            qr += wm * coefL[j] + wp * coefM[j];
+        }
+        coefP[r] = pr * 0.5 * g.wt[r];
+        coefQ[r] = qr * 0.5 * g.wt[r];
+    }
+    // fold the stream sums into Legendre space: J(angle) = sum_l a_l P_l(angle) [ (-1)^(l-m) cP_l + cQ_l ]
+    double cleg[NSTR];
+    for (int l = 0; l < NSTR; ++l) {
+        double sp = 0, sq = 0;
+        if (l >= m)
+            for (int r = 0; r < N; ++r) {
+                sp += lpmu[r * NSTR + l] * coefP[r];
+                sq += lpmu[r * NSTR + l] * coefQ[r];
+            }
+        cleg[l] = a[l] * ((((l - m) & 1) ? -sp : sp) + sq);
+    }
+    int unconverged = 0;
+    const int t0 = g.pt_start[s * nlyr + p], t1 = g.pt_start[s * nlyr + p + 1];
+    for (int t = t0; t < t1; ++t) {
+        const int slot = g.pt_slot[t];
+        if (b.conv_order[size_t(slot) * nw + w] <= m) continue;
+        const double* lpa = g.lpang + (size_t(m) * g.nangle + g.pt_angle[t]) * NSTR;
+        double val = 0;
+        for (int l = m; l < NSTR; ++l) val += cleg[l] * lpa[l];
+        // (the 1/omega of the table and the omega inside the phase sums cancel)
+        b.J[(size_t(m) * g.nslot + slot) * nw + w] = val;
+        if (m >= 2) {
+            double prev = b.J[(size_t(m - 1) * g.nslot + slot) * nw + w], prev2 = b.J[(size_t(m - 2) * g.nslot + slot) * nw + w];
+            if ((fabs(val / prev) < 1e-4 || prev < 1e-10) && (fabs(val / prev2) < 1e-4 || prev2 < 1e-10)) {
+                b.conv_order[size_t(slot) * nw + w] = (uint8_t)(m + 1);
+            } else {
+                unconverged = 1;
+            }
+        }
+    }
+    if (p == nlyr - 1 && m == 0) {
+        // upwelling diffuse reflection of a Lambertian surface
+        double diffuse = 0;
+        for (int i = 0; i < N; ++i) {
+            double sv = c(R::G + 2 * N + i);
+            for (int j = 0; j < N; ++j) {
+                double st = exp(-fabs(c(R::K + j)) * th);
+                sv += b.xsol[(size_t(p) * 2 * N + j) * nw + w] * c(R::WP + i + N * j) * st +
+                      b.xsol[(size_t(p) * 2 * N + N + j) * nw + w] * c(R::WM + i + N * j);
+            }
+            diffuse += 2.0 * g.mu[i] * g.wt[i] * sv * b.albedo[w];
+        }
+        for (int t = g.gpt_start[s]; t < g.gpt_start[s + 1]; ++t) b.J[(size_t(m) * g.nslot + g.gpt_slot[t]) * nw + w] = diffuse;
+    }
+    if (unconverged) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(&b.notconv[w], 1);
+#else
+        b.notconv[w] |= 1;
+#endif
+    }
+}
+
+// =================================================================================================
+// K2b: adjoint sweep of one line of sight for azimuth order m             (task = wavelength x LOS)
+//   radiance_m(los) = sum_p u_p . x_p + particular ;  z = A^-T u ;  reduced gradient wrt
+//   (tau_p, omega_p, T_p, sec_p)_p, albedo, T_floor accumulated into b.grad.
+// =================================================================================================
+template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int m, int los, int w) {
+    constexpr int NSTR = 2 * N, M2 = 2 * N;
+    using R = Rec<N>;
+    const int nw = b.nw, nlyr = g.nlyr;
+    const size_t tid = size_t(w) * g.nlos + los, nt = size_t(nw) * g.nlos;
+    const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
+    const double rho = (m == 0) ? b.albedo[w] : 0.0;
+    auto recp = [&](int p) { return RecView{b.rec + size_t(p) * R::SIZE * nw + w, size_t(nw)}; };
+    // ground weight of this LOS (order 0 only)
+    double gw = 0;
+    if (m == 0 && g.ray_ground[los]) {
+        for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t)
+            if (g.g_sza[t] == s && b.conv_order[size_t(g.g_slot[t]) * nw + w] > m) gw += g.g_w[t];
+        gw *= b.att_total[size_t(los) * nw + w];
+    }
+    // Legendre-space LOS weights of a layer: ql[l] = sum_entries srcw * w_e * cos(m azi) * P_l(angle)
+    auto los_weights = [&](int p, double* ql) -> bool {
+        for (int l = 0; l < NSTR; ++l) ql[l] = 0;
+        bool any = false;
+        const int base = (los * g.nsza + s) * nlyr + p;
+        for (int t = g.lp_start[base]; t < g.lp_start[base + 1]; ++t) {
+            if (b.conv_order[size_t(g.lp_slot[t]) * nw + w] <= m) continue;
+            const int q = g.lp_q[t];
+            double cw = b.srcw[size_t(q) * nw + w] * g.lp_w[t] * cos(m * g.rl_azi[q]);
+            if (cw == 0.0) continue;
+            any = true;
+            const double* lpa = g.lpang + (size_t(m) * g.nangle + g.lp_angle[t]) * NSTR;
+            for (int l = m; l < NSTR; ++l) ql[l] += cw * lpa[l];
+        }
+        return any;
+    };
+    // ---------------- forward sweep  y_p = Dinv_p^T (u_p - Sup_{p-1}^T y_{p-1})
+    double y[M2], yprev[M2], u[M2], ql[NSTR], a[NSTR];
+    for (int i = 0; i < M2; ++i) yprev[i] = 0;
+    for (int p = 0; p < nlyr; ++p) {
+        RecView c = recp(p);
+        const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
+        const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
+        const bool any = los_weights(p, ql);
+        for (int i = 0; i < M2; ++i) u[i] = 0;
+        if (any) {
+            for (int l = 0; l < NSTR; ++l) a[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
+            double clp[N], clm[N];
+            for (int r = 0; r < N; ++r) {
+                double s0 = 0, s1 = 0;
+                for (int l = m; l < NSTR; ++l) {
+                    double t = a[l] * ql[l] * lpmu[r * NSTR + l];
+                    s0 += t;
+                    s1 += ((l - m) & 1) ? -t : t;
+                }
+                clm[r] = 0.5 * g.wt[r] * om * s0;
+                clp[r] = 0.5 * g.wt[r] * om * s1;
+            }
+            for (int j = 0; j < N; ++j) {
+                double yp = 0, ym = 0;
+                for (int r = 0; r < N; ++r) {
+                    double wp = c(R::WP + r + N * j), wm = c(R::WM + r + N * j);
+                    yp += clp[r] * wp + clm[r] * wm;
+                    ym += clp[r] * wm + clm[r] * wp;
+                }
+                PPMult pm;
+                pp_multipliers(T, th, sc, c(R::K + j), g.lfrac[p], pm);
+                u[j] = yp * pm.hp / om;
+                u[N + j] = ym * pm.hm / om;
+            }
+        }
+        if (p == nlyr - 1 && gw != 0.0) {
+            for (int j = 0; j < N; ++j) {
+                double sp = 0, sm = 0;
+                for (int i = 0; i < N; ++i) {
+                    sp += g.mu[i] * g.wt[i] * c(R::WP + i + N * j);
+                    sm += g.mu[i] * g.wt[i] * c(R::WM + i + N * j);
+                }
+                u[j] += gw * 2.0 * rho * sp * exp(-fabs(c(R::K + j)) * th);
+                u[N + j] += gw * 2.0 * rho * sm;
+            }
+        }
+        if (p > 0) {
+            // Sup_{p-1} rows B (cols of layer p) = [-W-_p | -W+_p E_p];  u_p -= Sup^T yB_{p-1}
+            for (int j = 0; j < N; ++j) {
+                double t1 = 0, t2 = 0;
+                for (int i = 0; i < N; ++i) {
+                    t1 += c(R::WM + i + N * j) * yprev[N + i];
+                    t2 += c(R::WP + i + N * j) * yprev[N + i];
+                }
+                u[j] += t1;
+                u[N + j] += t2 * exp(-fabs(c(R::K + j)) * th);
+            }
+        }
+        for (int i = 0; i < M2; ++i) {
+            double t = 0;
+            for (int j = 0; j < M2; ++j) t += b.dinv[(size_t(p) * M2 * M2 + j * M2 + i) * nw + w] * u[j];
+            y[i] = t;
+        }
+        for (int i = 0; i < M2; ++i) {
+            yprev[i] = y[i];
+            b.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
+        }
+    }
+    // ---------------- backward sweep  z_p = y_p - Dinv_p^T Sub_{p+1}^T zA_{p+1}
+    double zn[M2], t2v[M2];
+    for (int p = nlyr - 1; p >= 0; --p) {
+        for (int i = 0; i < M2; ++i) y[i] = b.z[(size_t(p) * M2 + i) * nt + tid];
+        if (p < nlyr - 1) {
+            RecView c = recp(p);
+            const double th = b.tau[size_t(p) * nw + w];
+            // Sub_{p+1} rows A = [W+_p E_p | W-_p]  ->  v = Sub^T zA_{p+1}
+            for (int j = 0; j < N; ++j) {
+                double t1 = 0, t2 = 0;
+                for (int i = 0; i < N; ++i) {
+                    t1 += c(R::WP + i + N * j) * zn[i];
+                    t2 += c(R::WM + i + N * j) * zn[i];
+                }
+                t2v[j] = t1 * exp(-fabs(c(R::K + j)) * th);
+                t2v[N + j] = t2;
+            }
+            for (int i = 0; i < M2; ++i) {
+                double t = 0;
+                for (int j = 0; j < M2; ++j) t += b.dinv[(size_t(p) * M2 * M2 + j * M2 + i) * nw + w] * t2v[j];
+                y[i] -= t;
+            }
+        }
+        for (int i = 0; i < M2; ++i) {
+            zn[i] = y[i];
+            b.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
+        }
+    }
+    // ---------------- gradient contraction, layer by layer
+    const int NG = 4 * nlyr + 2;
+    (void)NG;
+    double zA[N], zB[N], zAn[N], zBp[N];
+    for (int p = 0; p < nlyr; ++p) {
+        RecView c = recp(p);
+        const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
+        const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
+        for (int i = 0; i < N; ++i) {
+            zA[i] = b.z[(size_t(p) * M2 + i) * nt + tid];
+            zB[i] = b.z[(size_t(p) * M2 + N + i) * nt + tid];
+            zAn[i] = (p < nlyr - 1) ? b.z[(size_t(p + 1) * M2 + i) * nt + tid] : 0.0;
+            zBp[i] = (p > 0) ? b.z[(size_t(p - 1) * M2 + N + i) * nt + tid] : 0.0;
+        }
+        double L[N], Mv[N], E[N], kk[N], dk[N];
+        for (int j = 0; j < N; ++j) {
+            L[j] = b.xsol[(size_t(p) * M2 + j) * nw + w];
+            Mv[j] = b.xsol[(size_t(p) * M2 + N + j) * nw + w];
+            kk[j] = c(R::K + j);
+            dk[j] = c(R::DK + j);
+            E[j] = exp(-fabs(kk[j]) * th);
+        }
+        const bool last = (p == nlyr - 1);
+        // ground reflection operator of the last layer folds into the B rows:  rowsB = I-_bot - Rg I+_bot
+        double zBsum = 0;
+        if (last && m == 0)
+            for (int i = 0; i < N; ++i) zBsum += zB[i];
+        // effective adjoint weights on the four edge intensities (at fixed L, M):
+        //   g = zA . dI+top - zB . dI-bot - zAn . dI+bot + zBp . dI-top   (+ ground:  + kd rho (sum zB) (w mu . dI+bot))
+        double wIpt[N], wImb[N], wIpb[N], wImt[N];
+        for (int i = 0; i < N; ++i) {
+            wIpt[i] = zA[i];
+            wImb[i] = -zB[i];
+            wIpb[i] = -zAn[i] + ((last && m == 0) ? 2.0 * rho * zBsum * g.wt[i] * g.mu[i] : 0.0);
+            wImt[i] = zBp[i];
+        }
+        // contributions through G (all four parameters)
+        double gth[4] = {0, 0, 0, 0};
+        for (int t = 0; t < 4; ++t) {
+            double sacc = 0;
+            for (int i = 0; i < N; ++i)
+                sacc += wIpt[i] * c(R::DG + (t * 4 + 0) * N + i) + wImt[i] * c(R::DG + (t * 4 + 1) * N + i) +
+                        wIpb[i] * c(R::DG + (t * 4 + 2) * N + i) + wImb[i] * c(R::DG + (t * 4 + 3) * N + i);
+            gth[t] = sacc;
+        }
+        // contributions through the homogeneous part a1..a4 (tau and omega only)
+        //   I+top: W+ L + W- (E M);  I-bot: W- (E L) + W+ M;  I+bot: W+ (E L) + W- M;  I-top: W- L + W+ (E M)
+        {
+            double g_tau = 0, g_om = 0;
+            for (int j = 0; j < N; ++j) {
+                double s_pt_p = 0, s_pt_m = 0, s_mb_p = 0, s_mb_m = 0, s_pb_p = 0, s_pb_m = 0, s_mt_p = 0, s_mt_m = 0;
+                double d_pt_p = 0, d_pt_m = 0, d_mb_p = 0, d_mb_m = 0, d_pb_p = 0, d_pb_m = 0, d_mt_p = 0, d_mt_m = 0;
+                for (int i = 0; i < N; ++i) {
+                    double wp = c(R::WP + i + N * j), wm = c(R::WM + i + N * j);
+                    double dwp = c(R::DWP + i + N * j), dwm = c(R::DWM + i + N * j);
+                    s_pt_p += wIpt[i] * wp; s_pt_m += wIpt[i] * wm; d_pt_p += wIpt[i] * dwp; d_pt_m += wIpt[i] * dwm;
+                    s_mb_p += wImb[i] * wp; s_mb_m += wImb[i] * wm; d_mb_p += wImb[i] * dwp; d_mb_m += wImb[i] * dwm;
+                    s_pb_p += wIpb[i] * wp; s_pb_m += wIpb[i] * wm; d_pb_p += wIpb[i] * dwp; d_pb_m += wIpb[i] * dwm;
+                    s_mt_p += wImt[i] * wp; s_mt_m += wImt[i] * wm; d_mt_p += wImt[i] * dwp; d_mt_m += wImt[i] * dwm;
+                }
+                const double EL = E[j] * L[j], EM = E[j] * Mv[j];
+                // derivative of E_j: dE/dtau = -k E, dE/dom = -dk tau E
+                const double coefE = s_pt_m * Mv[j] + s_mb_m * L[j] + s_pb_p * L[j] + s_mt_p * Mv[j];  // multiplies dE_j
+                g_tau += coefE * (-kk[j] * E[j]);
+                g_om += coefE * (-dk[j] * th * E[j]);
+                g_om += d_pt_p * L[j] + d_pt_m * EM + d_mb_m * EL + d_mb_p * Mv[j] + d_pb_p * EL + d_pb_m * Mv[j] + d_mt_m * L[j] + d_mt_p * EM;
+            }
+            gth[TH_TAU] += g_tau;
+            gth[TH_OM] += g_om;
+        }
+        // direct dependence of u.x + particular on the layer parameters (table points of this layer)
+        double direct[4] = {0, 0, 0, 0};
+        const bool any = los_weights(p, ql);
+        if (any) {
+            for (int l = 0; l < NSTR; ++l) a[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
+            double clp[N], clm[N];
+            for (int r = 0; r < N; ++r) {
+                double s0 = 0, s1 = 0;
+                for (int l = m; l < NSTR; ++l) {
+                    double t = a[l] * ql[l] * lpmu[r * NSTR + l];
+                    s0 += t;
+                    s1 += ((l - m) & 1) ? -t : t;
+                }
+                clm[r] = 0.5 * g.wt[r] * om * s0;
+                clp[r] = 0.5 * g.wt[r] * om * s1;
+            }
+            double val = 0, d_tau = 0, d_om = 0, d_T = 0, d_sec = 0;
+            for (int j = 0; j < N; ++j) {
+                double yp = 0, ym = 0, dyp = 0, dym = 0;
+                for (int r = 0; r < N; ++r) {
+                    double wp = c(R::WP + r + N * j), wm = c(R::WM + r + N * j);
+                    double dwp = c(R::DWP + r + N * j), dwm = c(R::DWM + r + N * j);
+                    yp += clp[r] * wp + clm[r] * wm;
+                    ym += clp[r] * wm + clm[r] * wp;
+                    dyp += clp[r] * (dwp + wp / om) + clm[r] * (dwm + wm / om);
+                    dym += clp[r] * (dwm + wm / om) + clm[r] * (dwp + wp / om);
+                }
+                PPMult pm;
+                pp_multipliers(T, th, sc, kk[j], g.lfrac[p], pm);
+                const double Ap = c(R::AP + j), Am = c(R::AM + j), dAp = c(R::DAP + j), dAm = c(R::DAM + j);
+                const double tL = pm.hp * L[j] + Ap * pm.Dm, tM = pm.hm * Mv[j] + Am * pm.Dp;
+                val += yp * tL + ym * tM;
+                d_tau += yp * (pm.hp_tau * L[j] + Ap * pm.Dm_tau) + ym * (pm.hm_tau * Mv[j] + Am * pm.Dp_tau);
+                d_sec += yp * Ap * pm.Dm_sec + ym * Am * pm.Dp_sec;
+                d_T += (T != 0) ? (yp * Ap * pm.Dm + ym * Am * pm.Dp) / T : 0.0;
+                d_om += dyp * tL + dym * tM + yp * (pm.hp_k * dk[j] * L[j] + dAp * pm.Dm + Ap * pm.Dm_k * dk[j]) +
+                        ym * (pm.hm_k * dk[j] * Mv[j] + dAm * pm.Dp + Am * pm.Dp_k * dk[j]);
+            }
+            direct[TH_TAU] = d_tau / om;
+            direct[TH_OM] = d_om / om - val / (om * om);
+            direct[TH_T] = d_T / om;
+            direct[TH_SEC] = d_sec / om;
+        }
+        double galb = 0, gTf = 0;
+        if (last && m == 0) {
+            // ground: u gets gw*2*rho*(w mu)^T (W+ E L + W- M + G+bot) -> direct dependence on tau/omega via E, W, G+bot, and on albedo
+            double ipb_val = 0;  // w mu . I+bot
+            double d_tau = 0, d_om = 0;
+            for (int i = 0; i < N; ++i) {
+                double acc = c(R::G + 2 * N + i);
+                for (int j = 0; j < N; ++j) acc += c(R::WP + i + N * j) * E[j] * L[j] + c(R::WM + i + N * j) * Mv[j];
+                ipb_val += g.wt[i] * g.mu[i] * acc;
+            }
+            if (gw != 0.0) {
+                for (int i = 0; i < N; ++i) {
+                    double f = gw * 2.0 * rho * g.wt[i] * g.mu[i];
+                    for (int t = 0; t < 4; ++t) direct[t] += f * c(R::DG + (t * 4 + 2) * N + i);
+                    for (int j = 0; j < N; ++j) {
+                        d_tau += f * c(R::WP + i + N * j) * (-kk[j] * E[j]) * L[j];
+                        d_om += f * (c(R::DWP + i + N * j) * E[j] * L[j] + c(R::WP + i + N * j) * (-dk[j] * th * E[j]) * L[j] + c(R::DWM + i + N * j) * Mv[j]);
+                    }
+                }
+                direct[TH_TAU] += d_tau;
+                direct[TH_OM] += d_om;
+                galb += gw * 2.0 * ipb_val;
+            }
+            // albedo / floor transmission through the ground boundary rows
+            galb += zBsum * (2.0 * ipb_val + g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w]);
+            gTf += zBsum * g.csz[s] / kPi * rho;
+        }
+        b.grad[size_t(0 * nlyr + p) * nt + tid] += gth[TH_TAU] + direct[TH_TAU];
+        b.grad[size_t(1 * nlyr + p) * nt + tid] += gth[TH_OM] + direct[TH_OM];
+        b.grad[size_t(2 * nlyr + p) * nt + tid] += gth[TH_T] + direct[TH_T];
+        b.grad[size_t(3 * nlyr + p) * nt + tid] += gth[TH_SEC] + direct[TH_SEC];
+        if (last) {
+            b.grad[size_t(4 * nlyr) * nt + tid] += galb;
+            b.grad[size_t(4 * nlyr + 1) * nt + tid] += gTf;
+        }
+    }
+}
+
+// =================================================================================================
+// K4a: reverse chain through the beam (T, sec) and the layer optics into native derivatives
+//      (task = wavelength x LOS, once per solar zenith index)
+//   reference wiring: sktran_do_layerarray.cpp:496-649,729-757 and configureTransmission :890-979
+// =================================================================================================
+SKD_HD void k4a_chain(const Geo& g, const Bufs& b, int s, int los, int w) {
+    const int nw = b.nw, nlyr = g.nlyr, ngrid = g.ngrid;
+    const size_t tid = size_t(w) * g.nlos + los, nt = size_t(nw) * g.nlos;
+    auto G = [&](int e) -> double& { return b.grad[size_t(e) * nt + tid]; };
+    const double* ext = b.ext + size_t(w) * ngrid;
+    const double* ssa = b.ssa + size_t(w) * ngrid;
+    for (int r = 0; r < nlyr; ++r) {
+        double gt = G(r);
+        for (int p = 0; p < nlyr; ++p) {
+            const double* ch = g.chapman + (size_t(s) * nlyr + p) * nlyr;
+            if (ch[0] < 0) continue;
+            // sec_p = (sig_p - sig_{p-1}) / tau_p ;  T_{p+1} = F0 exp(-sig_p)
+            double dsig_p = ch[r];
+            double dsig_pm = 0;
+            bool prev_ok = true;
+            if (p > 0) {
+                const double* chm = g.chapman + (size_t(s) * nlyr + p - 1) * nlyr;
+                if (chm[0] < 0) prev_ok = false; else dsig_pm = chm[r];
+            }
+            const double tau_p = b.tau[size_t(p) * nw + w];
+            // when the level above was in darkness the reference differences against the flagged value with zero derivative
+            double dsec = (dsig_p - (prev_ok ? dsig_pm : 0.0)) / tau_p;
+            if (r == p) dsec -= b.sec[size_t(p) * nw + w] / tau_p;
+            gt += G(3 * nlyr + p) * dsec;
+            // T at the ceiling of layer p+1 (level p+1) depends on sig_p
+            double dT = -b.T[size_t(p + 1) * nw + w] * dsig_p;
+            if (p + 1 < nlyr) gt += G(2 * nlyr + p + 1) * dT;
+            else gt += G(4 * nlyr + 1) * dT;
+        }
+        // tau_r -> extinction ; omega_r -> ssa, extinction
+        const double gom = G(nlyr + r);
+        const double kb = b.kbar[size_t(r) * nw + w], omr = b.om[size_t(r) * nw + w];
+        for (int t = 0; t < 2; ++t) {
+            int q = g.wq_idx[2 * r + t];
+            if (q < 0) continue;
+            double wt = g.wq_w[2 * r + t];
+            b.dnat[size_t(q) * nt + tid] += gt * wt * g.dh[r] + gom * wt * (ssa[q] - omr) / kb;
+            b.dnat[size_t(ngrid + q) * nt + tid] += gom * wt * ext[q] / kb;
+        }
+    }
+    b.dnat[size_t(2 * ngrid) * nt + tid] += G(4 * nlyr);
+    for (int e = 0; e < 4 * nlyr + 2; ++e) G(e) = 0;
+}
+
+// =================================================================================================
+// K4b: line-of-sight integration of the diffuse table (value + the LOS-level derivative terms)
+//      (task = wavelength x LOS)
+//   reference: SourceIntegrator::integrate_ray sourceintegrator.cpp:521-580,
+//              DOSourceInterpolatedPostProcessing::integrated_source/end_of_ray_source do_source_interpolated_pp.cpp:95-211
+// =================================================================================================
+SKD_HD void k4b_los(const Geo& g, const Bufs& b, int los, int w) {
+    const int nw = b.nw, ngrid = g.ngrid, nstr = g.nstr;
+    const size_t tid = size_t(w) * g.nlos + los, nt = size_t(nw) * g.nlos;
+    // I = sum_q a_q omega_q (1 - att_q) sv_q + a_total * ground, a_q = attenuation from the near edge of shell q to the observer
+    double behind = 0;  // radiance arriving at the far edge of the current shell
+    if (g.ray_ground[los]) {
+        for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t) {
+            int slot = g.g_slot[t];
+            if (b.conv_order[size_t(slot) * nw + w] > 0) behind += g.g_w[t] * b.J[size_t(slot) * nw + w];  // order 0 only
+        }
+    }
+    const double att_total = b.att_total[size_t(los) * nw + w];
+    double prod_upto = 1.0;  // prod_{q' <= q} att_q'
+    for (int q = g.ray_qstart[los]; q < g.ray_qstart[los + 1]; ++q) {
+        const double att = exp(-b.od[size_t(q) * nw + w]);
+        prod_upto *= att;
+        double sv = 0;
+        if (g.rl_active[q]) {
+            for (int m = 0; m < nstr; ++m) {
+                double azf = cos(m * g.rl_azi[q]);
+                for (int t = g.rl_tab_start[q]; t < g.rl_tab_start[q + 1]; ++t) {
+                    int slot = g.tab_slot[t];
+                    if (b.conv_order[size_t(slot) * nw + w] <= m) continue;
+                    sv += g.tab_w[t] * azf * b.J[(size_t(m) * g.nslot + slot) * nw + w];
+                }
+            }
+        }
+        const double omega = b.omloc[size_t(q) * nw + w];
+        if (b.derivs) {
+            const double a_q = (prod_upto > 0) ? att_total / prod_upto : 0.0;
+            const double dI_dod = a_q * (-behind * att + omega * att * sv);
+            for (int t = g.rl_od_start[q]; t < g.rl_od_start[q + 1]; ++t) b.dnat[size_t(g.od_idx[t]) * nt + tid] += g.od_w[t] * dI_dod;
+            if (g.rl_active[q]) {
+                const double dI_dom = a_q * (1 - att) * sv;
+                for (int t = g.rl_ssa_start[q]; t < g.rl_ssa_start[q + 1]; ++t) b.dnat[size_t(ngrid + g.ssa_idx[t]) * nt + tid] += g.ssa_w[t] * dI_dom;
+            }
+        }
+        behind = behind * att + (g.rl_active[q] ? omega * (1 - att) * sv : 0.0);
+    }
+    b.radiance[tid] = behind;
+}
+
+// stop rule of the azimuth expansion (DOSource::calculate, do_source.cpp:47-57): after order m >= 2 with every needed
+// table point converged no further order is solved for this solar zenith index.   (task = wavelength)
+SKD_HD void k_stop_rule(const Geo& g, const Bufs& b, int s, int m, int w) {
+    const int nw = b.nw;
+    if (m >= b.norders[w]) return;
+    if (m >= 2 && b.notconv[w] == 0) {
+        b.norders[w] = m + 1;
+        for (int p = 0; p < g.nlyr; ++p)
+            for (int t = g.pt_start[s * g.nlyr + p]; t < g.pt_start[s * g.nlyr + p + 1]; ++t) {
+                uint8_t& c = b.conv_order[size_t(g.pt_slot[t]) * nw + w];
+                if (c > m + 1) c = (uint8_t)(m + 1);
+            }
+    }
+    b.notconv[w] = 0;
+}
+
+}  // namespace skd

@@ -1,0 +1,143 @@
+// Flattens skgeo::DiscoGeometry into the contiguous tables the device code (skd::Geo) reads.
+// Host only; the arrays are uploaded once per engine.
+#pragma once
+#include <vector>
+
+#include "../hip/disco_core.hpp"
+#include "geometry.hpp"
+
+namespace skhost {
+
+struct GeoTables {
+    int nstr = 0, N = 0, nlyr = 0, ngrid = 0, nlos = 0, nsza = 0, nangle = 0, npoint = 0, nground = 0, nslot = 0, nq_total = 0;
+    std::vector<double> mu, wt, lpmu, lpcsz, lpang, dh, lfrac, wq_w, chapman, csz;
+    std::vector<int> wq_idx, pt_start, pt_angle, pt_slot, gpt_start, gpt_slot;
+    std::vector<int> ray_qstart, ray_ground, rl_od_start, od_idx, rl_ssa_start, ssa_idx, rl_active, rl_tab_start, tab_slot;
+    std::vector<double> ray_gsaa, od_w, ssa_w, rl_azi, tab_w;
+    std::vector<int> lp_start, lp_q, lp_angle, lp_slot, g_start, g_slot, g_sza;
+    std::vector<double> lp_w, g_w;
+    std::vector<int> slot_is_ground;  // [nslot]
+
+    void build(const skgeo::DiscoGeometry& G) {
+        nstr = G.nstr; N = nstr / 2; nlyr = G.nlyr; ngrid = G.ngrid; nlos = G.nlos; nsza = G.nsza; nangle = G.nangle;
+        mu.assign(G.mu.begin(), G.mu.begin() + N);
+        wt.assign(G.wt.begin(), G.wt.begin() + N);
+        lpmu.resize(size_t(nstr) * N * nstr);
+        for (int m = 0; m < nstr; ++m)
+            for (int i = 0; i < N; ++i)
+                for (int l = 0; l < nstr; ++l) lpmu[(size_t(m) * N + i) * nstr + l] = G.lpmu(m, i, l);
+        lpcsz = G.lp_csz;
+        lpang = G.lp_angle;
+        csz = G.csz;
+        chapman = G.chapman;
+        dh.resize(nlyr); lfrac.resize(nlyr); wq_idx.assign(2 * nlyr, -1); wq_w.assign(2 * nlyr, 0.0);
+        for (int p = 0; p < nlyr; ++p) {
+            dh[p] = G.ceil_h[p] - G.floor_h[p];
+            double altitude = (G.ceil_h[p] + G.floor_h[p]) / 2.0;
+            lfrac[p] = (G.ceil_h[p] - altitude) / (G.ceil_h[p] - G.floor_h[p]);
+            int c = 0;
+            for (int q = 0; q < ngrid; ++q)
+                if (G.W(p, q) > 0) {
+                    if (c >= 2) throw std::runtime_error("optical interpolator row has more than two entries");
+                    wq_idx[2 * p + c] = q;
+                    wq_w[2 * p + c] = G.W(p, q);
+                    ++c;
+                }
+        }
+        // slots
+        std::vector<int> point_slot(G.need_point.size(), -1), ground_slot(G.need_ground.size(), -1);
+        npoint = 0;
+        for (size_t i = 0; i < G.need_point.size(); ++i)
+            if (G.need_point[i]) point_slot[i] = npoint++;
+        nground = 0;
+        for (size_t i = 0; i < G.need_ground.size(); ++i)
+            if (G.need_ground[i]) ground_slot[i] = npoint + nground++;
+        nslot = npoint + nground;
+        slot_is_ground.assign(nslot, 0);
+        for (int i = npoint; i < nslot; ++i) slot_is_ground[i] = 1;
+        pt_start.assign(size_t(nsza) * nlyr + 1, 0);
+        for (int s = 0; s < nsza; ++s)
+            for (int p = 0; p < nlyr; ++p) {
+                const int lidx = nlyr - 1 - p;
+                for (int a = 0; a < nangle; ++a) {
+                    int slot = point_slot[(size_t(s) * nlyr + lidx) * nangle + a];
+                    if (slot >= 0) { pt_angle.push_back(a); pt_slot.push_back(slot); }
+                }
+                pt_start[size_t(s) * nlyr + p + 1] = (int)pt_slot.size();
+            }
+        gpt_start.assign(nsza + 1, 0);
+        for (int s = 0; s < nsza; ++s) {
+            for (int a = 0; a < nangle; ++a) {
+                int slot = ground_slot[size_t(s) * nangle + a];
+                if (slot >= 0) gpt_slot.push_back(slot);
+            }
+            gpt_start[s + 1] = (int)gpt_slot.size();
+        }
+        // rays
+        ray_qstart.assign(nlos + 1, 0); ray_ground.assign(nlos, 0); ray_gsaa.assign(nlos, 0.0);
+        rl_od_start.assign(1, 0); rl_ssa_start.assign(1, 0); rl_tab_start.assign(1, 0);
+        g_start.assign(nlos + 1, 0);
+        struct LpE { int q, angle, slot; double w; };
+        std::vector<std::vector<LpE>> lp(size_t(nlos) * nsza * nlyr);
+        int q = 0;
+        for (int l = 0; l < nlos; ++l) {
+            const auto& ray = G.rays[l];
+            ray_ground[l] = ray.ground_is_hit ? 1 : 0;
+            ray_gsaa[l] = ray.ground_saa;
+            for (const auto& L : ray.layers) {
+                for (size_t t = 0; t < L.od.idx.size(); ++t) { od_idx.push_back(L.od.idx[t]); od_w.push_back(L.od.w[t]); }
+                rl_od_start.push_back((int)od_idx.size());
+                for (size_t t = 0; t < L.ssa_interp.idx.size(); ++t) { ssa_idx.push_back(L.ssa_interp.idx[t]); ssa_w.push_back(L.ssa_interp.w[t]); }
+                rl_ssa_start.push_back((int)ssa_idx.size());
+                rl_azi.push_back(L.azi);
+                rl_active.push_back(L.layer_distance < 1e-4 ? 0 : 1);
+                for (const auto& e : L.table) {
+                    int slot = point_slot[(size_t(e.sza) * nlyr + e.alt) * nangle + e.angle];
+                    tab_slot.push_back(slot);
+                    tab_w.push_back(e.w);
+                    const int p = nlyr - 1 - e.alt;
+                    lp[(size_t(l) * nsza + e.sza) * nlyr + p].push_back({q, e.angle, slot, e.w});
+                }
+                rl_tab_start.push_back((int)tab_slot.size());
+                ++q;
+            }
+            ray_qstart[l + 1] = q;
+            for (const auto& e : ray.ground) {
+                g_slot.push_back(ground_slot[size_t(e.sza) * nangle + e.angle]);
+                g_sza.push_back(e.sza);
+                g_w.push_back(e.w);
+            }
+            g_start[l + 1] = (int)g_slot.size();
+        }
+        nq_total = q;
+        lp_start.assign(lp.size() + 1, 0);
+        for (size_t i = 0; i < lp.size(); ++i) {
+            for (const auto& e : lp[i]) { lp_q.push_back(e.q); lp_angle.push_back(e.angle); lp_slot.push_back(e.slot); lp_w.push_back(e.w); }
+            lp_start[i + 1] = (int)lp_q.size();
+        }
+    }
+
+    // view over host memory (emulation) -- the HIP driver builds the same struct over device copies
+    skd::Geo host_view() const {
+        skd::Geo g{};
+        fill_scalars(g);
+        g.mu = mu.data(); g.wt = wt.data(); g.lpmu = lpmu.data(); g.lpcsz = lpcsz.data(); g.lpang = lpang.data();
+        g.dh = dh.data(); g.lfrac = lfrac.data(); g.wq_idx = wq_idx.data(); g.wq_w = wq_w.data();
+        g.chapman = chapman.data(); g.csz = csz.data(); g.pt_start = pt_start.data(); g.pt_angle = pt_angle.data();
+        g.pt_slot = pt_slot.data(); g.gpt_start = gpt_start.data(); g.gpt_slot = gpt_slot.data();
+        g.ray_qstart = ray_qstart.data(); g.ray_ground = ray_ground.data(); g.ray_gsaa = ray_gsaa.data();
+        g.rl_od_start = rl_od_start.data(); g.od_idx = od_idx.data(); g.od_w = od_w.data();
+        g.rl_ssa_start = rl_ssa_start.data(); g.ssa_idx = ssa_idx.data(); g.ssa_w = ssa_w.data();
+        g.rl_azi = rl_azi.data(); g.rl_active = rl_active.data(); g.rl_tab_start = rl_tab_start.data();
+        g.tab_slot = tab_slot.data(); g.tab_w = tab_w.data(); g.lp_start = lp_start.data(); g.lp_q = lp_q.data();
+        g.lp_angle = lp_angle.data(); g.lp_slot = lp_slot.data(); g.lp_w = lp_w.data(); g.g_start = g_start.data();
+        g.g_slot = g_slot.data(); g.g_sza = g_sza.data(); g.g_w = g_w.data();
+        return g;
+    }
+    void fill_scalars(skd::Geo& g) const {
+        g.nstr = nstr; g.N = N; g.nlyr = nlyr; g.ngrid = ngrid; g.nlos = nlos; g.nsza = nsza; g.nangle = nangle;
+        g.npoint = npoint; g.nground = nground; g.nslot = nslot; g.nq_total = nq_total;
+    }
+};
+
+}  // namespace skhost

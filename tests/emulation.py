@@ -1,0 +1,66 @@
+"""ctypes front end of tests/emulate_kernels.cpp: the HIP kernel bodies executed on the CPU (TEST INFRASTRUCTURE)."""
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_ROOT = _HERE.parent
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = _HERE / "_build" / "libemu.so"
+        srcs = [_HERE / "emulate_kernels.cpp", _ROOT / "sasktran2_amd/csrc/hip/disco_core.hpp",
+                _ROOT / "sasktran2_amd/csrc/host/geo_tables.hpp", _ROOT / "sasktran2_amd/csrc/host/geometry.hpp"]
+        if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+            so.parent.mkdir(exist_ok=True)
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(srcs[0])])
+        L = ctypes.CDLL(str(so))
+        L.emu_create.restype = ctypes.c_void_p
+        L.emu_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_int, ctypes.c_int,
+                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp]
+        L.emu_destroy.argtypes = [ctypes.c_void_p]
+        L.emu_run.restype = ctypes.c_int
+        L.emu_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int, _dp,
+                              _dp, _dp, _dp, _dp, _ip]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def run_emulated(s, derivatives=True):
+    g = s["geometry"]
+    alt = np.ascontiguousarray(g["altitudes"], dtype=np.float64)
+    rays = s["rays"]
+    kinds = np.ascontiguousarray([r[0] for r in rays], dtype=np.int32)
+    params = np.ascontiguousarray([[r[1], r[2], r[3], r[4]] for r in rays], dtype=np.float64)
+    h = lib().emu_create(g["cos_sza"], g["saa"], g["earth_radius"], _p(alt), len(alt), g["interp_method"], g["geotype"],
+                         s["config"]["nstr"], s["config"]["num_sza"], len(rays), kinds.ctypes.data_as(_ip), _p(params))
+    assert h
+    try:
+        k = np.asfortranarray(s["extinction"], dtype=np.float64)
+        w = np.asfortranarray(s["ssa"], dtype=np.float64)
+        lg = np.asfortranarray(s["leg"], dtype=np.float64)
+        nw, nlos, ngrid = k.shape[1], len(rays), len(alt)
+        alb = np.ascontiguousarray(s["albedo"], dtype=np.float64)
+        rad, od = np.zeros((nw, nlos)), np.zeros((nw, nlos))
+        dk, dw, da = np.zeros((nw, nlos, ngrid)), np.zeros((nw, nlos, ngrid)), np.zeros((nw, nlos))
+        status = np.zeros(nw, dtype=np.int32)
+        rc = lib().emu_run(h, nw, lg.shape[0], _p(k), _p(w), _p(lg), None, _p(alb), int(derivatives), _p(rad), _p(dk),
+                           _p(dw), _p(da), _p(od), status.ctypes.data_as(_ip))
+        assert rc == 0
+        return {"radiance": rad, "los_optical_depth": od, "d_extinction": dk, "d_ssa": dw, "d_albedo": da,
+                "status": status}
+    finally:
+        lib().emu_destroy(h)
