@@ -1,0 +1,262 @@
+"""sasktran2_amd -- MI355X-native drop-in for the DISCO hot path of SASKTRAN2.
+
+The Python surface mirrors the reference's `sasktran2` package for this path (same class / property names and
+argument order): Config, Geometry1D, ViewingGeometry (+ TangentAltitudeSolar, GroundViewingSolar), Atmosphere (raw
+interface) and Engine.calculate_radiance().  Reference: src/sasktran2/{engine,atmosphere,config,geometry}.py,
+src/sasktran2/viewinggeo/wrappers.py.  Everything numerical runs in the HIP library behind the C ABI of
+include/sasktran2_amd.h.
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+
+import numpy as np
+
+from ._lib_loader import last_error, lib
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+class InterpolationMethod(enum.IntEnum):  # cpp/include/sasktran2/grids.h:24
+    ShellInterpolation = 0
+    LinearInterpolation = 1
+    LowerInterpolation = 2
+
+
+class GeometryType(enum.IntEnum):  # cpp/include/sasktran2/geometry.h:11-16
+    PlaneParallel = 0
+    PseudoSpherical = 1
+    Spherical = 2
+    Ellipsoidal = 3
+
+
+class MultipleScatterSource(enum.IntEnum):  # cpp/include/sasktran2/config.h:65-71
+    DiscreteOrdinates = 0
+    SuccessiveOrdersLegacy = 1
+    TwoStream = 2
+    NoSource = 3
+    SuccessiveOrders = 4
+
+
+class SingleScatterSource(enum.IntEnum):  # cpp/include/sasktran2/config.h:41-46
+    Exact = 0
+    SolarTable = 1
+    DiscreteOrdinates = 2
+    NoSource = 3
+
+
+class Config:
+    """src/sasktran2/config.py:21-765 (the keys this path reads)."""
+
+    _KEYS = {"num_stokes": "num_stokes", "num_streams": "num_streams", "num_threads": "num_threads",
+             "num_sza": "num_do_sza", "num_singlescatter_moments": "num_singlescatter_moments",
+             "wavelength_batch_size": "wavelength_batch_size", "output_los_optical_depth": "output_los_optical_depth",
+             "multiple_scatter_source": "multiple_scatter_source", "single_scatter_source": "single_scatter_source",
+             "wf_enabled": "wf_enabled"}
+
+    def __init__(self):
+        object.__setattr__(self, "_h", lib().sk_config_create())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sk_config_destroy(self._h)
+
+    def __getattr__(self, name):
+        key = Config._KEYS.get(name)
+        if key is None:
+            raise AttributeError(name)
+        v = ctypes.c_int()
+        getattr(lib(), f"sk_config_get_{key}")(self._h, ctypes.byref(v))
+        return v.value
+
+    def __setattr__(self, name, value):
+        key = Config._KEYS.get(name)
+        if key is None:
+            raise AttributeError(f"Config has no option {name!r} on the MI355X path")
+        if getattr(lib(), f"sk_config_set_{key}")(self._h, int(value)) != 0:
+            raise RuntimeError(last_error())
+
+
+class Geometry1D:
+    """src/sasktran2/geometry.py:13-56."""
+
+    def __init__(self, cos_sza, solar_azimuth, earth_radius_m, altitude_grid_m,
+                 interpolation_method=InterpolationMethod.LinearInterpolation, geometry_type=GeometryType.Spherical):
+        self._alt = np.ascontiguousarray(np.atleast_1d(altitude_grid_m), dtype=np.float64)
+        self._h = lib().sk_geometry1d_create(cos_sza, solar_azimuth, earth_radius_m, _p(self._alt), len(self._alt),
+                                             int(interpolation_method), int(geometry_type))
+        if not self._h:
+            raise ValueError("invalid Geometry1D")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sk_geometry1d_destroy(self._h)
+
+    def altitudes(self):
+        return self._alt.copy()
+
+
+class TangentAltitudeSolar:
+    def __init__(self, tangent_altitude_m, relative_azimuth, observer_altitude_m, cos_sza):
+        self.args = (tangent_altitude_m, relative_azimuth, observer_altitude_m, cos_sza)
+
+
+class GroundViewingSolar:
+    def __init__(self, cos_sza, relative_azimuth, cos_viewing_zenith, observer_altitude_m):
+        self.args = (cos_sza, relative_azimuth, cos_viewing_zenith, observer_altitude_m)
+
+
+class ViewingGeometry:
+    """src/sasktran2/viewinggeo/wrappers.py:13-36."""
+
+    def __init__(self):
+        self._h = lib().sk_viewing_geometry_create()
+        self._rays = []
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sk_viewing_geometry_destroy(self._h)
+
+    def add_ray(self, ray):
+        if isinstance(ray, TangentAltitudeSolar):
+            lib().sk_viewing_geometry_add_tangent_altitude_solar(self._h, *map(float, ray.args))
+        elif isinstance(ray, GroundViewingSolar):
+            c, az, cv, alt = map(float, ray.args)
+            lib().sk_viewing_geometry_add_ground_viewing_solar(self._h, c, az, alt, cv)
+        else:
+            raise TypeError("unsupported ray type on the MI355X path")
+        self._rays.append(ray)
+
+    @property
+    def observer_rays(self):
+        return self._rays
+
+
+class _Storage:
+    def __init__(self, ngrid, nwavel, nleg):
+        self.total_extinction = np.zeros((ngrid, nwavel), order="F")
+        self.ssa = np.zeros((ngrid, nwavel), order="F")
+        self.emission_source = np.zeros((ngrid, nwavel), order="F")
+        self.leg_coeff = np.zeros((nleg, ngrid, nwavel), order="F")
+        self.solar_irradiance = np.ones(nwavel)
+
+
+class _LegCoeff:
+    def __init__(self, storage):
+        self._s = storage
+
+    @property
+    def a1(self):
+        return self._s.leg_coeff
+
+
+class _Surface:
+    def __init__(self, nwavel):
+        self.albedo = np.zeros(nwavel)
+        self.emission = np.zeros(nwavel)
+
+
+class Atmosphere:
+    """Raw-interface atmosphere (src/sasktran2/atmosphere.py:176-260, 784-806): fill `storage.total_extinction`,
+    `storage.ssa` [altitude, wavelength], `leg_coeff.a1` [moment, altitude, wavelength] and `surface.albedo`."""
+
+    def __init__(self, model_geometry, config, wavelengths_nm=None, wavenumber_cminv=None, numwavel=None,
+                 calculate_derivatives=True, **_):
+        if numwavel is None:
+            src = wavelengths_nm if wavelengths_nm is not None else wavenumber_cminv
+            if src is None:
+                raise ValueError("One of wavelengths_nm, wavenumber_cminv, numwavel must be set")
+            numwavel = len(src)
+        self.wavelengths_nm = None if wavelengths_nm is None else np.asarray(wavelengths_nm, dtype=float)
+        self._ngrid = len(model_geometry.altitudes())
+        self._nwavel = int(numwavel)
+        self._calculate_derivatives = bool(calculate_derivatives)
+        self.storage = _Storage(self._ngrid, self._nwavel, config.num_singlescatter_moments)
+        self.leg_coeff = _LegCoeff(self.storage)
+        self.surface = _Surface(self._nwavel)
+        self._altitudes = model_geometry.altitudes()
+
+    @property
+    def calculate_derivatives(self):
+        return self._calculate_derivatives
+
+
+class Engine:
+    """src/sasktran2/engine.py:70-168,474-612 -- `calculate_radiance(atmosphere)` returns the reference's variables
+    (`radiance[wavelength, los, stokes]`, `wf_extinction` / `wf_ssa` `[altitude, wavelength, los, stokes]`,
+    `wf_albedo[wavelength, los, stokes]`, `los_optical_depth[wavelength, los]`) as a dict of ndarrays, wrapped in an
+    xarray.Dataset when xarray is importable."""
+
+    def __init__(self, config, model_geometry, viewing_geo):
+        self._config, self._geometry, self._viewing = config, model_geometry, viewing_geo
+        self._h = lib().sk_engine_create(config._h, model_geometry._h, viewing_geo._h)
+        if not self._h:
+            raise RuntimeError(f"Engine construction failed: {last_error()}")
+        self.nlos = len(viewing_geo.observer_rays)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sk_engine_destroy(self._h)
+
+    def calculate_radiance(self, atmosphere, as_dataset=True):
+        L = lib()
+        st = atmosphere.storage
+        nw, ngrid, nlos = atmosphere._nwavel, atmosphere._ngrid, self.nlos
+        ext, ssa = np.asfortranarray(st.total_extinction), np.asfortranarray(st.ssa)
+        em, leg = np.asfortranarray(st.emission_source), np.asfortranarray(st.leg_coeff)
+        irr, alb = np.ascontiguousarray(st.solar_irradiance), np.ascontiguousarray(atmosphere.surface.albedo, dtype=float)
+        emis = np.ascontiguousarray(atmosphere.surface.emission)
+        derivs = atmosphere.calculate_derivatives
+        h_st = L.sk_atmosphere_storage_create(ngrid, nw, leg.shape[0], 1, _p(ssa), _p(ext), _p(em), _p(leg), _p(irr))
+        h_brdf = L.sk_brdf_create_lambertian(1)
+        h_su = L.sk_surface_create(nw, 1, _p(emis))
+        L.sk_surface_set_brdf(h_su, h_brdf, _p(alb))
+        h_atm = L.sk_atmosphere_create(h_st, h_su, int(derivs), 0)
+        rad = np.zeros((nw, nlos, 1))
+        h_out = L.sk_output_create(_p(rad), nw * nlos, 1, None, 0)
+        out = {"radiance": rad}
+        try:
+            if derivs:
+                # raw-interface mappings, src/sasktran2/atmosphere.py:784-806
+                for name, which in (("wf_extinction", "d_extinction"), ("wf_ssa", "d_ssa")):
+                    m = ctypes.c_void_p()
+                    L.sk_atmosphere_storage_get_derivative_mapping(h_st, name.encode(), ctypes.byref(m))
+                    ptr = _dp()
+                    getattr(L, f"sk_deriv_mapping_get_{which}")(m, ctypes.byref(ptr))
+                    np.ctypeslib.as_array(ptr, shape=(ngrid * nw,))[:] = 1.0
+                    out[name] = np.zeros((ngrid, nw, nlos, 1))
+                    L.sk_output_assign_derivative_memory(h_out, name.encode(), _p(out[name]), nw * nlos, 1, ngrid)
+                m = ctypes.c_void_p()
+                L.sk_surface_get_derivative_mapping(h_su, b"wf_albedo", ctypes.byref(m))
+                ptr = _dp()
+                L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
+                np.ctypeslib.as_array(ptr, shape=(nw,))[:] = 1.0
+                out["wf_albedo"] = np.zeros((nw, nlos, 1))
+                L.sk_output_assign_surface_derivative_memory(h_out, b"wf_albedo", _p(out["wf_albedo"]), nw * nlos, 1)
+            rc = L.sk_engine_calculate_radiance(self._h, h_atm, h_out, 0)
+            if rc != 0:
+                raise RuntimeError(f"sk_engine_calculate_radiance returned {rc}: {last_error()}")
+            od = _dp()
+            L.sk_output_get_los_optical_depth(h_out, ctypes.byref(od))
+            out["los_optical_depth"] = np.ctypeslib.as_array(od, shape=(nlos, nw)).T.copy()
+        finally:
+            L.sk_output_destroy(h_out)
+            L.sk_atmosphere_destroy(h_atm)
+            L.sk_surface_destroy(h_su)
+            L.sk_brdf_destroy(h_brdf)
+            L.sk_atmosphere_storage_destroy(h_st)
+        if as_dataset:
+            try:
+                import xarray as xr
+            except ImportError:
+                return out
+            dims = {"radiance": ("wavelength", "los", "stokes"), "wf_extinction": ("altitude", "wavelength", "los", "stokes"),
+                    "wf_ssa": ("altitude", "wavelength", "los", "stokes"), "wf_albedo": ("wavelength", "los", "stokes"),
+                    "los_optical_depth": ("wavelength", "los")}
+            return xr.Dataset({k: (dims[k], v) for k, v in out.items()}, coords={"altitude": atmosphere._altitudes})
+        return out

@@ -1,0 +1,82 @@
+"""Loads the HIP shared library (sasktran2_amd/_lib/libsasktran2_amd.so) and declares the C ABI of include/sasktran2_amd.h.
+
+There is deliberately no CPU fallback: if the library is missing or no MI355X is visible, engine construction fails."""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "_lib" / "libsasktran2_amd.so"
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+_LIB = None
+
+# every symbol include/sasktran2_amd.h declares: (name, restype, argtypes)
+_I, _D, _S = ctypes.c_int, ctypes.c_double, ctypes.c_char_p
+SIGNATURES = [
+    ("sk_config_create", _vp, []), ("sk_config_destroy", None, [_vp]),
+    *[(f"sk_config_get_{k}", _I, [_vp, _ip]) for k in ("num_stokes", "multiple_scatter_source", "single_scatter_source",
+      "num_streams", "num_threads", "wavelength_batch_size", "num_singlescatter_moments", "num_do_sza", "wf_enabled",
+      "output_los_optical_depth")],
+    *[(f"sk_config_set_{k}", _I, [_vp, _I]) for k in ("num_stokes", "multiple_scatter_source", "single_scatter_source",
+      "num_streams", "num_threads", "wavelength_batch_size", "num_singlescatter_moments", "num_do_sza", "wf_enabled",
+      "output_los_optical_depth")],
+    ("sk_geometry1d_create", _vp, [_D, _D, _D, _dp, _I, _I, _I]), ("sk_geometry1d_destroy", None, [_vp]),
+    ("sk_geometry1d_get_num_altitudes", _I, [_vp]), ("sk_geometry1d_get_altitudes", _I, [_vp, _dp]),
+    ("sk_viewing_geometry_create", _vp, []), ("sk_viewing_geometry_destroy", None, [_vp]),
+    ("sk_viewing_geometry_add_ground_viewing_solar", None, [_vp, _D, _D, _D, _D]),
+    ("sk_viewing_geometry_add_tangent_altitude_solar", _I, [_vp, _D, _D, _D, _D]),
+    ("sk_viewing_geometry_num_rays", _I, [_vp, _ip]),
+    ("sk_atmosphere_storage_create", _vp, [_I, _I, _I, _I, _dp, _dp, _dp, _dp, _dp]),
+    ("sk_atmosphere_storage_destroy", None, [_vp]),
+    ("sk_atmosphere_storage_get_derivative_mapping", _I, [_vp, _S, ctypes.POINTER(_vp)]),
+    ("sk_atmosphere_storage_get_num_derivative_mappings", _I, [_vp, _ip]),
+    ("sk_atmosphere_storage_get_derivative_mapping_name", _I, [_vp, _I, ctypes.POINTER(_S)]),
+    ("sk_deriv_mapping_get_d_ssa", _I, [_vp, ctypes.POINTER(_dp)]),
+    ("sk_deriv_mapping_get_d_extinction", _I, [_vp, ctypes.POINTER(_dp)]),
+    ("sk_deriv_mapping_get_num_location", _I, [_vp, _ip]), ("sk_deriv_mapping_get_num_wavel", _I, [_vp, _ip]),
+    ("sk_deriv_mapping_get_num_output", _I, [_vp, _ip]), ("sk_deriv_mapping_set_zero", _I, [_vp]),
+    ("sk_brdf_create_lambertian", _vp, [_I]), ("sk_brdf_destroy", None, [_vp]),
+    ("sk_surface_create", _vp, [_I, _I, _dp]), ("sk_surface_destroy", None, [_vp]),
+    ("sk_surface_set_brdf", _I, [_vp, _vp, _dp]),
+    ("sk_surface_get_derivative_mapping", _I, [_vp, _S, ctypes.POINTER(_vp)]),
+    ("sk_surface_deriv_mapping_get_d_brdf", _I, [_vp, ctypes.POINTER(_dp)]),
+    ("sk_atmosphere_create", _vp, [_vp, _vp, _I, _I]), ("sk_atmosphere_destroy", None, [_vp]),
+    ("sk_output_create", _vp, [_dp, _I, _I, _dp, _I]), ("sk_output_destroy", None, [_vp]),
+    ("sk_output_assign_derivative_memory", _I, [_vp, _S, _dp, _I, _I, _I]),
+    ("sk_output_assign_surface_derivative_memory", _I, [_vp, _S, _dp, _I, _I]),
+    ("sk_output_get_los_optical_depth", _I, [_vp, ctypes.POINTER(_dp)]),
+    ("sk_engine_create", _vp, [_vp, _vp, _vp]),
+    ("sk_engine_calculate_radiance", _I, [_vp, _vp, _vp, _I]),
+    ("sk_engine_effective_wavelength_batch_size", _I, [_vp, _I]),
+    ("sk_engine_calculate_radiance_block_thread", _I, [_vp, _vp, _I, _I, _I]),
+    ("sk_engine_destroy", None, [_vp]), ("sk_openmp_support_enabled", _I, []),
+    ("sk_amd_engine_solve_device", _I, [_vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I]),
+    ("sk_amd_engine_num_los", _I, [_vp, _ip]),
+    ("sk_amd_engine_scratch_bytes", _I, [_vp, _I, ctypes.POINTER(ctypes.c_ulonglong)]),
+    ("sk_amd_engine_set_profiling", _I, [_vp, _I]), ("sk_amd_engine_reset_profile", _I, [_vp]),
+    ("sk_amd_engine_kernel_time", _I, [_vp, _S, _dp, ctypes.POINTER(ctypes.c_long)]),
+    ("sk_amd_engine_kernel_names", _I, [_vp, ctypes.c_char_p, _I]),
+    ("sk_amd_last_error", _S, []),
+]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)")
+        L = ctypes.CDLL(str(LIB_PATH))
+        for name, res, args in SIGNATURES:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def last_error() -> str:
+    return lib().sk_amd_last_error().decode()

@@ -1,0 +1,389 @@
+// C ABI of sasktran2_amd (see include/sasktran2_amd.h).  Host side only: object model mirroring the reference's
+// c_api handles, H2D/D2H staging around DeviceEngine::solve_device and the user derivative mappings
+// (reference: OutputC::assign_lane, cpp/lib/output/outputc.cpp:38-236).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/sasktran2_amd.h"
+#include "disco_engine.hpp"
+
+namespace {
+thread_local std::string g_last_error;
+void set_error(const std::string& e) {
+    g_last_error = e;
+    std::fprintf(stderr, "sasktran2_amd: %s\n", e.c_str());
+}
+#define HIPC(expr)                                                                               \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e)); \
+    } while (0)
+}  // namespace
+
+struct Config {
+    int num_stokes = 1, ms_source = 3 /* none */, ss_source = 0 /* exact */, num_streams = 16, num_threads = 1,
+        batch = 1, nmoments = 16, num_sza = 1, wf_enabled = 1, los_od = 0;
+};
+struct Geometry1D {
+    double cos_sza, saa, earth_radius;
+    std::vector<double> grid;
+    int interp, geotype;
+};
+struct ViewingGeometry {
+    std::vector<skgeo::RaySpec> rays;
+};
+struct DerivativeMapping {
+    int nloc = 0, nwavel = 0;
+    std::vector<double> d_ssa, d_extinction;
+};
+struct SurfaceDerivativeMapping {
+    int nwavel = 0;
+    std::vector<double> d_brdf;
+};
+struct AtmosphereStorage {
+    int nloc, nwavel, nleg, nstokes;
+    double *ssa, *ext, *emission, *leg, *irradiance;
+    std::map<std::string, std::unique_ptr<DerivativeMapping>> maps;
+    std::vector<std::string> names;
+};
+struct BRDF {
+    int kind = 0;
+};
+struct Surface {
+    int nwavel, nstokes;
+    double* emission;
+    BRDF* brdf = nullptr;
+    double* brdf_args = nullptr;
+    std::map<std::string, std::unique_ptr<SurfaceDerivativeMapping>> maps;
+};
+struct Atmosphere {
+    AtmosphereStorage* storage;
+    Surface* surface;
+    int derivs;
+};
+struct OutputC {
+    double* radiance;
+    int nrad, nstokes;
+    struct D { double* mem; int nrad, nstokes, nderiv; };
+    std::map<std::string, D> derivs, surface_derivs;
+    std::vector<double> los_od;
+};
+struct Engine {
+    Config config;
+    std::unique_ptr<skdev::DeviceEngine> dev;
+    int nlos = 0, ngrid = 0;
+};
+
+extern "C" {
+
+const char* sk_amd_last_error(void) { return g_last_error.c_str(); }
+
+#define CFG_RW(name, field)                                             \
+    int sk_config_get_##name(Config* c, int* v) {                       \
+        if (!c || !v) return -1;                                        \
+        *v = c->field;                                                  \
+        return 0;                                                       \
+    }                                                                   \
+    int sk_config_set_##name(Config* c, int v) {                        \
+        if (!c) return -1;                                              \
+        c->field = v;                                                   \
+        return 0;                                                       \
+    }
+Config* sk_config_create(void) { return new Config(); }
+void sk_config_destroy(Config* c) { delete c; }
+CFG_RW(num_stokes, num_stokes)
+CFG_RW(multiple_scatter_source, ms_source)
+CFG_RW(single_scatter_source, ss_source)
+CFG_RW(num_streams, num_streams)
+CFG_RW(num_threads, num_threads)
+CFG_RW(wavelength_batch_size, batch)
+CFG_RW(num_singlescatter_moments, nmoments)
+CFG_RW(num_do_sza, num_sza)
+CFG_RW(wf_enabled, wf_enabled)
+CFG_RW(output_los_optical_depth, los_od)
+
+Geometry1D* sk_geometry1d_create(double cos_sza, double saa, double earth_radius, double* grid_values, int n, int interp,
+                                 int geotype) {
+    if (!grid_values || n < 2) return nullptr;
+    auto* g = new Geometry1D{cos_sza, saa, earth_radius, std::vector<double>(grid_values, grid_values + n), interp, geotype};
+    return g;
+}
+void sk_geometry1d_destroy(Geometry1D* g) { delete g; }
+int sk_geometry1d_get_num_altitudes(const Geometry1D* g) { return g ? (int)g->grid.size() : -1; }
+int sk_geometry1d_get_altitudes(const Geometry1D* g, double* a) {
+    if (!g || !a) return -1;
+    std::copy(g->grid.begin(), g->grid.end(), a);
+    return 0;
+}
+
+ViewingGeometry* sk_viewing_geometry_create(void) { return new ViewingGeometry(); }
+void sk_viewing_geometry_destroy(ViewingGeometry* v) { delete v; }
+void sk_viewing_geometry_add_ground_viewing_solar(ViewingGeometry* v, double cos_sza, double rel_az, double obs_alt,
+                                                  double cos_viewing) {
+    if (!v) return;
+    skgeo::RaySpec r{};
+    r.kind = skgeo::RaySpec::ground_viewing_solar;
+    r.cos_sza = cos_sza; r.relative_azimuth = rel_az; r.observer_altitude = obs_alt; r.cos_viewing_zenith = cos_viewing;
+    v->rays.push_back(r);
+}
+int sk_viewing_geometry_add_tangent_altitude_solar(ViewingGeometry* v, double tangent_alt, double rel_az, double obs_alt,
+                                                   double cos_sza) {
+    if (!v) return -1;
+    skgeo::RaySpec r{};
+    r.kind = skgeo::RaySpec::tangent_altitude_solar;
+    r.cos_sza = cos_sza; r.relative_azimuth = rel_az; r.observer_altitude = obs_alt; r.tangent_altitude = tangent_alt;
+    v->rays.push_back(r);
+    return 0;
+}
+int sk_viewing_geometry_num_rays(ViewingGeometry* v, int* n) {
+    if (!v || !n) return -1;
+    *n = (int)v->rays.size();
+    return 0;
+}
+
+AtmosphereStorage* sk_atmosphere_storage_create(int nloc, int nwavel, int nleg, int nstokes, double* ssa, double* ext,
+                                                double* emission, double* leg, double* irradiance) {
+    if (!ssa || !ext || !leg || nloc < 2 || nwavel < 1) return nullptr;
+    auto* s = new AtmosphereStorage{nloc, nwavel, nleg, nstokes, ssa, ext, emission, leg, irradiance, {}, {}};
+    return s;
+}
+void sk_atmosphere_storage_destroy(AtmosphereStorage* s) { delete s; }
+int sk_atmosphere_storage_get_derivative_mapping(AtmosphereStorage* s, const char* name, DerivativeMapping** m) {
+    if (!s || !name || !m) return -1;
+    auto it = s->maps.find(name);
+    if (it == s->maps.end()) {
+        auto dm = std::make_unique<DerivativeMapping>();
+        dm->nloc = s->nloc;
+        dm->nwavel = s->nwavel;
+        dm->d_ssa.assign(size_t(s->nloc) * s->nwavel, 0.0);
+        dm->d_extinction.assign(size_t(s->nloc) * s->nwavel, 0.0);
+        it = s->maps.emplace(name, std::move(dm)).first;
+        s->names.push_back(name);
+    }
+    *m = it->second.get();
+    return 0;
+}
+int sk_atmosphere_storage_get_num_derivative_mappings(AtmosphereStorage* s, int* n) {
+    if (!s || !n) return -1;
+    *n = (int)s->names.size();
+    return 0;
+}
+int sk_atmosphere_storage_get_derivative_mapping_name(AtmosphereStorage* s, int i, const char** name) {
+    if (!s || !name || i < 0 || i >= (int)s->names.size()) return -1;
+    *name = s->names[i].c_str();
+    return 0;
+}
+int sk_deriv_mapping_get_d_ssa(DerivativeMapping* m, double** p) { if (!m || !p) return -1; *p = m->d_ssa.data(); return 0; }
+int sk_deriv_mapping_get_d_extinction(DerivativeMapping* m, double** p) { if (!m || !p) return -1; *p = m->d_extinction.data(); return 0; }
+int sk_deriv_mapping_get_num_location(DerivativeMapping* m, int* n) { if (!m || !n) return -1; *n = m->nloc; return 0; }
+int sk_deriv_mapping_get_num_wavel(DerivativeMapping* m, int* n) { if (!m || !n) return -1; *n = m->nwavel; return 0; }
+int sk_deriv_mapping_get_num_output(DerivativeMapping* m, int* n) { if (!m || !n) return -1; *n = m->nloc; return 0; }
+int sk_deriv_mapping_set_zero(DerivativeMapping* m) {
+    if (!m) return -1;
+    std::fill(m->d_ssa.begin(), m->d_ssa.end(), 0.0);
+    std::fill(m->d_extinction.begin(), m->d_extinction.end(), 0.0);
+    return 0;
+}
+BRDF* sk_brdf_create_lambertian(int) { return new BRDF(); }
+void sk_brdf_destroy(BRDF* b) { delete b; }
+Surface* sk_surface_create(int nwavel, int nstokes, double* emission) { return new Surface{nwavel, nstokes, emission}; }
+void sk_surface_destroy(Surface* s) { delete s; }
+int sk_surface_set_brdf(Surface* s, BRDF* b, double* args) {
+    if (!s || !b || !args) return -1;
+    s->brdf = b;
+    s->brdf_args = args;
+    return 0;
+}
+int sk_surface_get_derivative_mapping(Surface* s, const char* name, SurfaceDerivativeMapping** m) {
+    if (!s || !name || !m) return -1;
+    auto it = s->maps.find(name);
+    if (it == s->maps.end()) {
+        auto dm = std::make_unique<SurfaceDerivativeMapping>();
+        dm->nwavel = s->nwavel;
+        dm->d_brdf.assign(s->nwavel, 0.0);
+        it = s->maps.emplace(name, std::move(dm)).first;
+    }
+    *m = it->second.get();
+    return 0;
+}
+int sk_surface_deriv_mapping_get_d_brdf(SurfaceDerivativeMapping* m, double** p) { if (!m || !p) return -1; *p = m->d_brdf.data(); return 0; }
+Atmosphere* sk_atmosphere_create(AtmosphereStorage* st, Surface* su, int derivs, int) {
+    if (!st || !su) return nullptr;
+    return new Atmosphere{st, su, derivs};
+}
+void sk_atmosphere_destroy(Atmosphere* a) { delete a; }
+
+OutputC* sk_output_create(double* radiance, int nrad, int nstokes, double*, int) {
+    if (!radiance) return nullptr;
+    return new OutputC{radiance, nrad, nstokes, {}, {}, {}};
+}
+void sk_output_destroy(OutputC* o) { delete o; }
+int sk_output_assign_derivative_memory(OutputC* o, const char* name, double* mem, int nrad, int nstokes, int nderiv) {
+    if (!o || !name || !mem) return -1;
+    o->derivs[name] = {mem, nrad, nstokes, nderiv};
+    return 0;
+}
+int sk_output_assign_surface_derivative_memory(OutputC* o, const char* name, double* mem, int nrad, int nstokes) {
+    if (!o || !name || !mem) return -1;
+    o->surface_derivs[name] = {mem, nrad, nstokes, 1};
+    return 0;
+}
+int sk_output_get_los_optical_depth(OutputC* o, double** od) {
+    if (!o || !od) return -1;
+    *od = o->los_od.data();
+    return 0;
+}
+
+Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
+    if (!c || !g || !v) return nullptr;
+    try {
+        if (c->num_stokes != 1) throw std::runtime_error("only NSTOKES=1 is implemented");
+        if (c->ms_source != 0) throw std::runtime_error("multiple_scatter_source must be discrete_ordinates (0)");
+        if (c->ss_source != 2 && c->ss_source != 3)
+            throw std::runtime_error("single_scatter_source must be discrete_ordinates (2) or none (3)");
+        skgeo::Geometry1D geo(g->cos_sza, g->saa, g->earth_radius, g->grid, (skgeo::Interpolation)g->interp,
+                              (skgeo::GeometryType)g->geotype);
+        skgeo::DiscoGeometry dg;
+        skgeo::build_disco_geometry(geo, v->rays, c->num_streams, c->num_sza, dg);
+        auto e = std::make_unique<Engine>();
+        e->config = *c;
+        e->dev = std::make_unique<skdev::DeviceEngine>(dg);
+        e->nlos = dg.nlos;
+        e->ngrid = dg.ngrid;
+        return e.release();
+    } catch (const std::exception& ex) {
+        set_error(std::string("sk_engine_create: ") + ex.what());
+        return nullptr;
+    }
+}
+void sk_engine_destroy(Engine* e) { delete e; }
+int sk_openmp_support_enabled(void) { return 0; }
+int sk_engine_effective_wavelength_batch_size(Engine* e, int) { return e ? 1 : -1; }
+int sk_engine_calculate_radiance_block_thread(Engine* e, OutputC* o, int, int, int) {
+    // the whole spectrum is solved on the GPU inside sk_engine_calculate_radiance (also with only_initialize=1),
+    // so the per-block entry point of the Rayon scheduler has nothing left to do.
+    return (e && o) ? 0 : -1;
+}
+
+int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /*only_initialize*/) {
+    if (!e || !atm || !out || !atm->storage || !atm->surface) return -1;
+    try {
+        const AtmosphereStorage& st = *atm->storage;
+        const Surface& su = *atm->surface;
+        if (st.nstokes != 1 || out->nstokes != 1) return -2;
+        if (st.nloc != e->ngrid) throw std::runtime_error("atmosphere grid does not match the engine geometry");
+        if (!su.brdf_args) throw std::runtime_error("surface has no BRDF set");
+        const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
+        if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");
+        const int derivs = atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty());
+        const size_t nloc_w = size_t(ngrid) * nw, nt = size_t(nw) * nlos;
+        double *d_ext, *d_ssa, *d_leg, *d_alb, *d_irr = nullptr, *d_rad, *d_we = nullptr, *d_ws = nullptr, *d_wa = nullptr, *d_od;
+        int* d_status;
+        std::vector<void*> frees;
+        auto dalloc = [&](size_t bytes) { void* p; HIPC(hipMalloc(&p, bytes)); frees.push_back(p); return p; };
+        struct Guard { std::vector<void*>& f; ~Guard() { for (void* p : f) (void)hipFree(p); } } guard{frees};
+        d_ext = (double*)dalloc(nloc_w * 8); d_ssa = (double*)dalloc(nloc_w * 8); d_leg = (double*)dalloc(nloc_w * st.nleg * 8);
+        d_alb = (double*)dalloc(size_t(nw) * 8); d_rad = (double*)dalloc(nt * 8); d_od = (double*)dalloc(nt * 8);
+        d_status = (int*)dalloc(size_t(nw) * 4);
+        HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyHostToDevice));
+        if (st.irradiance) {
+            d_irr = (double*)dalloc(size_t(nw) * 8);
+            HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyHostToDevice));
+        }
+        if (derivs) {
+            d_we = (double*)dalloc(size_t(ngrid) * nt * 8);
+            d_ws = (double*)dalloc(size_t(ngrid) * nt * 8);
+            d_wa = (double*)dalloc(nt * 8);
+        }
+        e->dev->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status,
+                             nullptr, 0);
+        HIPC(hipDeviceSynchronize());
+        HIPC(hipMemcpy(out->radiance, d_rad, nt * 8, hipMemcpyDeviceToHost));
+        std::vector<int> status(nw);
+        HIPC(hipMemcpy(status.data(), d_status, size_t(nw) * 4, hipMemcpyDeviceToHost));
+        for (int w = 0; w < nw; ++w)
+            if (status[w] != 0) throw std::runtime_error("solver failure (status bits " + std::to_string(status[w]) + ") at wavelength " + std::to_string(w));
+        // LOS optical depth, reference layout column-major [wavel, los]
+        {
+            std::vector<double> od(nt);
+            HIPC(hipMemcpy(od.data(), d_od, nt * 8, hipMemcpyDeviceToHost));
+            out->los_od.resize(nt);
+            for (int w = 0; w < nw; ++w)
+                for (int l = 0; l < nlos; ++l) out->los_od[size_t(l) * nw + w] = od[size_t(w) * nlos + l];
+        }
+        if (derivs) {
+            std::vector<double> we(size_t(ngrid) * nt), ws(size_t(ngrid) * nt), wa(nt);
+            HIPC(hipMemcpy(we.data(), d_we, we.size() * 8, hipMemcpyDeviceToHost));
+            HIPC(hipMemcpy(ws.data(), d_ws, ws.size() * 8, hipMemcpyDeviceToHost));
+            HIPC(hipMemcpy(wa.data(), d_wa, wa.size() * 8, hipMemcpyDeviceToHost));
+            for (auto& kv : out->derivs) {
+                auto it = st.maps.find(kv.first);
+                if (it == st.maps.end()) throw std::runtime_error("no derivative mapping named " + kv.first);
+                const DerivativeMapping& m = *it->second;
+                if (kv.second.nderiv != ngrid || kv.second.nrad != nw * nlos) throw std::runtime_error("derivative memory size mismatch for " + kv.first);
+                double* dst = kv.second.mem;  // C order [nderiv][wavel][los]
+                for (int q = 0; q < ngrid; ++q)
+                    for (int w = 0; w < nw; ++w) {
+                        const double fs = m.d_ssa[size_t(w) * ngrid + q], fk = m.d_extinction[size_t(w) * ngrid + q];
+                        const size_t o = (size_t(q) * nw + w) * nlos;
+                        for (int l = 0; l < nlos; ++l) dst[o + l] = fs * ws[o + l] + fk * we[o + l];
+                    }
+            }
+            for (auto& kv : out->surface_derivs) {
+                auto it = su.maps.find(kv.first);
+                if (it == su.maps.end()) throw std::runtime_error("no surface derivative mapping named " + kv.first);
+                const SurfaceDerivativeMapping& m = *it->second;
+                for (int w = 0; w < nw; ++w)
+                    for (int l = 0; l < nlos; ++l) kv.second.mem[size_t(w) * nlos + l] = wa[size_t(w) * nlos + l] * m.d_brdf[w];
+            }
+        }
+        return 0;
+    } catch (const std::exception& ex) {
+        set_error(std::string("sk_engine_calculate_radiance: ") + ex.what());
+        return -3;
+    }
+}
+
+int sk_amd_engine_solve_device(Engine* e, int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
+                               const double* d_albedo, const double* d_irradiance, int derivatives, double* d_radiance,
+                               double* d_wf_ext, double* d_wf_ssa, double* d_wf_albedo, double* d_los_od, int* d_status,
+                               void* stream, int max_chunk) {
+    if (!e) return -1;
+    try {
+        e->dev->solve_device(nwavel, nleg, d_ext, d_ssa, d_leg, d_albedo, d_irradiance, derivatives, d_radiance, d_wf_ext,
+                             d_wf_ssa, d_wf_albedo, d_los_od, d_status, stream, max_chunk);
+        return 0;
+    } catch (const std::exception& ex) {
+        set_error(std::string("sk_amd_engine_solve_device: ") + ex.what());
+        return -3;
+    }
+}
+int sk_amd_engine_num_los(Engine* e, int* n) { if (!e || !n) return -1; *n = e->nlos; return 0; }
+int sk_amd_engine_scratch_bytes(Engine* e, int nwavel, unsigned long long* bytes) {
+    if (!e || !bytes) return -1;
+    *bytes = (unsigned long long)e->dev->bytes_per_wavelength() * (unsigned long long)nwavel;
+    return 0;
+}
+int sk_amd_engine_set_profiling(Engine* e, int on) { if (!e) return -1; e->dev->set_profiling(on != 0); return 0; }
+int sk_amd_engine_reset_profile(Engine* e) { if (!e) return -1; e->dev->reset_profile(); return 0; }
+int sk_amd_engine_kernel_time(Engine* e, const char* name, double* ms, long* launches) {
+    if (!e || !name || !ms || !launches) return -1;
+    return e->dev->kernel_time(name, ms, launches) ? 0 : -1;
+}
+int sk_amd_engine_kernel_names(Engine* e, char* buf, int len) {
+    if (!e || !buf || len < 1) return -1;
+    std::string s = e->dev->kernel_names();
+    std::snprintf(buf, len, "%s", s.c_str());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+// HIP kernels + device driver of the DISCO hot path (gfx950).
+//
+// Launch structure per spectrum chunk (NW wavelengths resident in HBM, every scratch array laid out
+// [element][wavelength] so that the 64 lanes of a wavefront touch 64 consecutive doubles):
+//
+//   k0_layer_optics      grid over wavelengths              layer optics, LOS shell optics
+//   for each solar-zenith index s:
+//     k0_transmission    grid over wavelengths              beam attenuation, average secants
+//     for azimuth order m = 0 .. (stop rule):
+//       k1_layer_solution  grid over wavelength x layer     eigen-solution + Green's particular solution (+ d/d omega)
+//       k2a_bvp            grid over wavelengths            block-tridiagonal factor/solve
+//       k3_table_values    grid over wavelength x layer     diffuse-source table values, convergence flags
+//       k2b_adjoint        grid over wavelength x LOS       adjoint block sweeps + reduced gradient
+//       k_stop_rule        grid over wavelengths            azimuth stop rule, active-wavelength count
+//     k4a_chain          grid over wavelength x LOS         reverse chain beam/optics -> native derivatives
+//   k4b_los              grid over wavelength x LOS         LOS integration of the table
+//   k_output             grid over wavelength x LOS         writes radiance / weighting functions in the caller's layout
+//
+// The task bodies live in disco_core.hpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "disco_engine.hpp"
+
+namespace skdev {
+
+#define HIP_CHECK(expr)                                                                                        \
+    do {                                                                                                       \
+        hipError_t _e = (expr);                                                                                \
+        if (_e != hipSuccess)                                                                                  \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " + __FILE__ + \
+                                     ":" + std::to_string(__LINE__));                                          \
+    } while (0)
+
+using skd::Bufs;
+using skd::Geo;
+
+constexpr int kBlock = 64;
+
+__global__ void __launch_bounds__(kBlock) kern_k0(Geo g, Bufs b) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= b.nw) return;
+    skd::k0_layer_optics(g, b, w);
+}
+__global__ void __launch_bounds__(kBlock) kern_k0t(Geo g, Bufs b, int s) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= b.nw) return;
+    skd::k0_transmission(g, b, s, w);
+    b.norders[w] = g.nstr;
+    b.notconv[w] = 0;
+}
+template <int N> __global__ void __launch_bounds__(kBlock) kern_k1(Geo g, Bufs b, int s, int m) {
+    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (tid >= size_t(b.nw) * g.nlyr) return;
+    int w = int(tid % b.nw), p = int(tid / b.nw);
+    if (m >= b.norders[w]) return;
+    skd::k1_layer_solution<N>(g, b, s, m, p, w);
+}
+template <int N> __global__ void __launch_bounds__(kBlock) kern_k2a(Geo g, Bufs b, int s, int m) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= b.nw || m >= b.norders[w]) return;
+    skd::k2a_bvp<N>(g, b, s, m, w);
+}
+template <int N> __global__ void __launch_bounds__(kBlock) kern_k3(Geo g, Bufs b, int s, int m) {
+    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (tid >= size_t(b.nw) * g.nlyr) return;
+    int w = int(tid % b.nw), p = int(tid / b.nw);
+    if (m >= b.norders[w]) return;
+    skd::k3_table_values<N>(g, b, s, m, p, w);
+}
+template <int N> __global__ void __launch_bounds__(kBlock) kern_k2b(Geo g, Bufs b, int s, int m) {
+    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (tid >= size_t(b.nw) * g.nlos) return;
+    int w = int(tid / g.nlos), l = int(tid % g.nlos);
+    if (m >= b.norders[w]) return;
+    skd::k2b_adjoint<N>(g, b, s, m, l, w);
+}
+__global__ void __launch_bounds__(kBlock) kern_stop(Geo g, Bufs b, int s, int m, int* active) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= b.nw) return;
+    skd::k_stop_rule(g, b, s, m, w);
+    if (b.norders[w] > m + 1) atomicAdd(active, 1);
+}
+__global__ void __launch_bounds__(kBlock) kern_k4a(Geo g, Bufs b, int s) {
+    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (tid >= size_t(b.nw) * g.nlos) return;
+    skd::k4a_chain(g, b, s, int(tid % g.nlos), int(tid / g.nlos));
+}
+__global__ void __launch_bounds__(kBlock) kern_k4b(Geo g, Bufs b) {
+    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (tid >= size_t(b.nw) * g.nlos) return;
+    skd::k4b_los(g, b, int(tid % g.nlos), int(tid / g.nlos));
+}
+__global__ void __launch_bounds__(256) kern_init(Bufs b, const int* slot_is_ground, int nslot, size_t n_grad, size_t n_dnat) {
+    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (size_t i = tid; i < size_t(nslot) * b.nw; i += stride) b.conv_order[i] = slot_is_ground[i / b.nw] ? 1 : 255;
+    for (size_t i = tid; i < n_grad; i += stride) b.grad[i] = 0.0;
+    for (size_t i = tid; i < n_dnat; i += stride) b.dnat[i] = 0.0;
+    for (size_t i = tid; i < size_t(b.nw); i += stride) b.status[i] = 0;
+}
+// radiance[w][los] and native weighting functions in the reference's user layout [altitude][w][los]
+// (rust/sasktran2-rs/src/bindings/output.rs:420-425); w0 = first wavelength of this chunk, nw_total = full spectrum.
+__global__ void __launch_bounds__(kBlock) kern_output(Geo g, Bufs b, int w0, int nw_total, double* radiance, double* wf_ext,
+                                                      double* wf_ssa, double* wf_alb, double* los_od, int* status) {
+    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t nt = size_t(b.nw) * g.nlos;
+    if (tid >= nt) return;
+    const int w = int(tid / g.nlos), l = int(tid % g.nlos);
+    const size_t o = size_t(w0 + w) * g.nlos + l;
+    radiance[o] = b.radiance[tid];
+    if (los_od) los_od[o] = b.los_od[tid];
+    if (status && l == 0) status[w0 + w] = b.status[w];
+    if (!b.derivs) return;
+    const size_t plane = size_t(nw_total) * g.nlos;
+    for (int q = 0; q < g.ngrid; ++q) {
+        if (wf_ext) wf_ext[size_t(q) * plane + o] = b.dnat[size_t(q) * nt + tid];
+        if (wf_ssa) wf_ssa[size_t(q) * plane + o] = b.dnat[size_t(g.ngrid + q) * nt + tid];
+    }
+    if (wf_alb) wf_alb[o] = b.dnat[size_t(2 * g.ngrid) * nt + tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+struct DevMem {
+    std::vector<void*> ptrs;
+    template <class T> T* alloc(size_t n) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+        ptrs.push_back(p);
+        return static_cast<T*>(p);
+    }
+    template <class T> T* upload(const std::vector<T>& v) {
+        T* p = alloc<T>(v.size());
+        if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return p;
+    }
+    void release() {
+        for (void* p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+    ~DevMem() { release(); }
+};
+
+struct DeviceEngine::Impl {
+    skhost::GeoTables tab;
+    Geo g{};
+    DevMem geo_mem, scratch_mem;
+    int* d_slot_is_ground = nullptr;
+    int* d_active = nullptr;
+    Bufs b{};
+    int chunk_capacity = 0;
+    bool profiling = false;
+    std::map<std::string, std::pair<double, long>> times;  // name -> (ms, launches)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+DeviceEngine::DeviceEngine(const skgeo::DiscoGeometry& dg) : impl_(new Impl) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        throw std::runtime_error("sasktran2_amd: no HIP device available (the MI355X path has no CPU fallback)");
+    if (!dg.spherical_pp) throw std::runtime_error("sasktran2_amd: only spherical geometry is implemented on the device path");
+    Impl& I = *impl_;
+    I.tab.build(dg);
+    const auto& t = I.tab;
+    switch (t.N) { case 1: case 2: case 4: case 8: case 16: break; default: throw std::runtime_error("sasktran2_amd: num_streams must be one of 2, 4, 8, 16, 32"); }
+    Geo& g = I.g;
+    t.fill_scalars(g);
+    DevMem& M = I.geo_mem;
+    g.mu = M.upload(t.mu); g.wt = M.upload(t.wt); g.lpmu = M.upload(t.lpmu); g.lpcsz = M.upload(t.lpcsz); g.lpang = M.upload(t.lpang);
+    g.dh = M.upload(t.dh); g.lfrac = M.upload(t.lfrac); g.wq_idx = M.upload(t.wq_idx); g.wq_w = M.upload(t.wq_w);
+    g.chapman = M.upload(t.chapman); g.csz = M.upload(t.csz); g.pt_start = M.upload(t.pt_start); g.pt_angle = M.upload(t.pt_angle);
+    g.pt_slot = M.upload(t.pt_slot); g.gpt_start = M.upload(t.gpt_start); g.gpt_slot = M.upload(t.gpt_slot);
+    g.ray_qstart = M.upload(t.ray_qstart); g.ray_ground = M.upload(t.ray_ground); g.ray_gsaa = M.upload(t.ray_gsaa);
+    g.rl_od_start = M.upload(t.rl_od_start); g.od_idx = M.upload(t.od_idx); g.od_w = M.upload(t.od_w);
+    g.rl_ssa_start = M.upload(t.rl_ssa_start); g.ssa_idx = M.upload(t.ssa_idx); g.ssa_w = M.upload(t.ssa_w);
+    g.rl_azi = M.upload(t.rl_azi); g.rl_active = M.upload(t.rl_active); g.rl_tab_start = M.upload(t.rl_tab_start);
+    g.tab_slot = M.upload(t.tab_slot); g.tab_w = M.upload(t.tab_w); g.lp_start = M.upload(t.lp_start); g.lp_q = M.upload(t.lp_q);
+    g.lp_angle = M.upload(t.lp_angle); g.lp_slot = M.upload(t.lp_slot); g.lp_w = M.upload(t.lp_w); g.g_start = M.upload(t.g_start);
+    g.g_slot = M.upload(t.g_slot); g.g_sza = M.upload(t.g_sza); g.g_w = M.upload(t.g_w);
+    I.d_slot_is_ground = M.upload(t.slot_is_ground);
+    I.d_active = M.alloc<int>(1);
+    HIP_CHECK(hipEventCreate(&I.ev0));
+    HIP_CHECK(hipEventCreate(&I.ev1));
+}
+
+DeviceEngine::~DeviceEngine() {
+    if (impl_) {
+        if (impl_->ev0) (void)hipEventDestroy(impl_->ev0);
+        if (impl_->ev1) (void)hipEventDestroy(impl_->ev1);
+        delete impl_;
+    }
+}
+
+int DeviceEngine::nlos() const { return impl_->tab.nlos; }
+int DeviceEngine::ngrid() const { return impl_->tab.ngrid; }
+int DeviceEngine::nstr() const { return impl_->tab.nstr; }
+size_t DeviceEngine::scratch_bytes() const { return impl_->scratch_bytes; }
+void DeviceEngine::set_profiling(bool on) { impl_->profiling = on; }
+void DeviceEngine::reset_profile() { impl_->times.clear(); }
+bool DeviceEngine::kernel_time(const char* name, double* ms, long* launches) const {
+    auto it = impl_->times.find(name);
+    if (it == impl_->times.end()) return false;
+    *ms = it->second.first;
+    *launches = it->second.second;
+    return true;
+}
+std::string DeviceEngine::kernel_names() const {
+    std::string s;
+    for (auto& kv : impl_->times) s += (s.empty() ? "" : ",") + kv.first;
+    return s;
+}
+
+size_t DeviceEngine::bytes_per_wavelength() const {
+    const auto& t = impl_->tab;
+    const size_t N = t.N, nlyr = t.nlyr, nstr = t.nstr, nlos = t.nlos;
+    size_t d = 0;
+    d += nlyr * (3 + nstr) + (nlyr + 1) + nlyr;              // tau, om, kbar, a, T, sec
+    d += size_t(t.nq_total) * 3 + nlos;                      // od, omloc, srcw, att_total
+    d += nlyr * (4 * N * N + 26 * N) + nlyr * 4 * N * N + nlyr * 2 * N;  // rec, dinv, xsol
+    d += nstr * size_t(t.nslot);                             // J
+    d += nlyr * 2 * N * nlos + (4 * nlyr + 2) * nlos + (2 * t.ngrid + 1) * nlos + 2 * nlos;  // z, grad, dnat, radiance, los_od
+    return d * sizeof(double) + size_t(t.nslot) + 3 * sizeof(int);
+}
+
+void DeviceEngine::ensure_scratch(int nw) {
+    Impl& I = *impl_;
+    if (nw <= I.chunk_capacity) return;
+    I.scratch_mem.release();
+    const auto& t = I.tab;
+    const size_t N = t.N, nlyr = t.nlyr, nstr = t.nstr, nlos = t.nlos, W = nw, nt = W * nlos;
+    DevMem& M = I.scratch_mem;
+    Bufs& b = I.b;
+    b.tau = M.alloc<double>(nlyr * W); b.om = M.alloc<double>(nlyr * W); b.kbar = M.alloc<double>(nlyr * W);
+    b.a = M.alloc<double>(nlyr * nstr * W); b.T = M.alloc<double>((nlyr + 1) * W); b.sec = M.alloc<double>(nlyr * W);
+    b.od = M.alloc<double>(size_t(t.nq_total) * W); b.omloc = M.alloc<double>(size_t(t.nq_total) * W);
+    b.srcw = M.alloc<double>(size_t(t.nq_total) * W); b.att_total = M.alloc<double>(nlos * W);
+    b.rec = M.alloc<double>(nlyr * (4 * N * N + 26 * N) * W); b.dinv = M.alloc<double>(nlyr * 4 * N * N * W);
+    b.xsol = M.alloc<double>(nlyr * 2 * N * W); b.J = M.alloc<double>(nstr * size_t(t.nslot) * W);
+    b.conv_order = M.alloc<uint8_t>(size_t(t.nslot) * W); b.notconv = M.alloc<int>(W); b.norders = M.alloc<int>(W);
+    b.status = M.alloc<int>(W); b.z = M.alloc<double>(nlyr * 2 * N * nt); b.grad = M.alloc<double>((4 * nlyr + 2) * nt);
+    b.dnat = M.alloc<double>((2 * t.ngrid + 1) * nt); b.radiance = M.alloc<double>(nt); b.los_od = M.alloc<double>(nt);
+    I.chunk_capacity = nw;
+    I.scratch_bytes = bytes_per_wavelength() * W;
+}
+
+namespace {
+struct Timer {
+    DeviceEngine::Impl& I;
+    hipStream_t st;
+    const char* name;
+    Timer(DeviceEngine::Impl& i, hipStream_t s, const char* n) : I(i), st(s), name(n) {
+        if (I.profiling) (void)hipEventRecord(I.ev0, st);
+    }
+    ~Timer() {
+        if (!I.profiling) return;
+        (void)hipEventRecord(I.ev1, st);
+        (void)hipEventSynchronize(I.ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, I.ev0, I.ev1);
+        auto& e = I.times[name];
+        e.first += ms;
+        e.second += 1;
+    }
+};
+inline unsigned blocks(size_t n, int bs = kBlock) { return unsigned((n + bs - 1) / bs); }
+}  // namespace
+
+template <int N>
+static void run_chunk(DeviceEngine::Impl& I, hipStream_t st, int derivs) {
+    const Geo& g = I.g;
+    Bufs& b = I.b;
+    const size_t nw = b.nw, nt = nw * g.nlos;
+    {
+        Timer t(I, st, "init");
+        hipLaunchKernelGGL(kern_init, dim3(1024), dim3(256), 0, st, b, I.d_slot_is_ground, g.nslot, size_t(4 * g.nlyr + 2) * nt,
+                           size_t(2 * g.ngrid + 1) * nt);
+    }
+    {
+        Timer t(I, st, "k0_layer_optics");
+        hipLaunchKernelGGL(kern_k0, dim3(blocks(nw)), dim3(kBlock), 0, st, g, b);
+    }
+    for (int s = 0; s < g.nsza; ++s) {
+        {
+            Timer t(I, st, "k0_transmission");
+            hipLaunchKernelGGL(kern_k0t, dim3(blocks(nw)), dim3(kBlock), 0, st, g, b, s);
+        }
+        for (int m = 0; m < g.nstr; ++m) {
+            {
+                Timer t(I, st, "k1_layer_solution");
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1<N>), dim3(blocks(nw * g.nlyr)), dim3(kBlock), 0, st, g, b, s, m);
+            }
+            {
+                Timer t(I, st, "k2a_bvp");
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a<N>), dim3(blocks(nw)), dim3(kBlock), 0, st, g, b, s, m);
+            }
+            {
+                Timer t(I, st, "k3_table_values");
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k3<N>), dim3(blocks(nw * g.nlyr)), dim3(kBlock), 0, st, g, b, s, m);
+            }
+            if (derivs) {
+                Timer t(I, st, "k2b_adjoint");
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b<N>), dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, s, m);
+            }
+            int active = 0;
+            {
+                Timer t(I, st, "k_stop_rule");
+                HIP_CHECK(hipMemsetAsync(I.d_active, 0, sizeof(int), st));
+                hipLaunchKernelGGL(kern_stop, dim3(blocks(nw)), dim3(kBlock), 0, st, g, b, s, m, I.d_active);
+                HIP_CHECK(hipMemcpyAsync(&active, I.d_active, sizeof(int), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+            }
+            if (active == 0) break;
+        }
+        if (derivs) {
+            Timer t(I, st, "k4a_chain");
+            hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, s);
+        }
+    }
+    {
+        Timer t(I, st, "k4b_los");
+        hipLaunchKernelGGL(kern_k4b, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
+                                const double* d_albedo, const double* d_irradiance, int derivs, double* d_radiance,
+                                double* d_wf_ext, double* d_wf_ssa, double* d_wf_alb, double* d_los_od, int* d_status,
+                                void* stream, int max_chunk) {
+    Impl& I = *impl_;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const auto& t = I.tab;
+    int chunk = max_chunk > 0 ? max_chunk : 4096;
+    if (const char* e = std::getenv("SASKTRAN2_AMD_CHUNK")) chunk = std::max(1, atoi(e));
+    chunk = std::min(chunk, nwavel);
+    ensure_scratch(chunk);
+    for (int w0 = 0; w0 < nwavel; w0 += chunk) {
+        const int nw = std::min(chunk, nwavel - w0);
+        Bufs& b = I.b;
+        b.nw = nw;
+        b.ext = d_ext + size_t(w0) * t.ngrid;
+        b.ssa = d_ssa + size_t(w0) * t.ngrid;
+        b.leg = d_leg + size_t(w0) * t.ngrid * nleg;
+        b.albedo = d_albedo + w0;
+        b.irradiance = d_irradiance ? d_irradiance + w0 : nullptr;
+        b.nleg = nleg;
+        b.derivs = derivs;
+        switch (t.N) {
+            case 1: run_chunk<1>(I, st, derivs); break;
+            case 2: run_chunk<2>(I, st, derivs); break;
+            case 4: run_chunk<4>(I, st, derivs); break;
+            case 8: run_chunk<8>(I, st, derivs); break;
+            case 16: run_chunk<16>(I, st, derivs); break;
+        }
+        Timer tm(I, st, "k_output");
+        hipLaunchKernelGGL(kern_output, dim3(blocks(size_t(nw) * t.nlos)), dim3(kBlock), 0, st, I.g, b, w0, nwavel, d_radiance,
+                           d_wf_ext, d_wf_ssa, d_wf_alb, d_los_od, d_status);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace skdev

@@ -1,0 +1,42 @@
+// Host-facing interface of the device driver (see disco_engine.hip).
+#pragma once
+#include <cstddef>
+#include <string>
+
+#include "../host/geo_tables.hpp"
+
+namespace skdev {
+
+class DeviceEngine {
+  public:
+    struct Impl;
+    explicit DeviceEngine(const skgeo::DiscoGeometry& dg);
+    ~DeviceEngine();
+    DeviceEngine(const DeviceEngine&) = delete;
+    DeviceEngine& operator=(const DeviceEngine&) = delete;
+
+    int nlos() const;
+    int ngrid() const;
+    int nstr() const;
+
+    // All pointers are DEVICE pointers.  Inputs use the reference storage layout (location fastest):
+    //   ext, ssa [nwavel][ngrid], leg [nwavel][ngrid][nleg], albedo / irradiance [nwavel] (irradiance may be null).
+    // Outputs: radiance [nwavel][nlos]; wf_ext, wf_ssa [ngrid][nwavel][nlos]; wf_alb, los_od [nwavel][nlos];
+    // status [nwavel] (error bits, see skd::ERR_*).  Derivative outputs may be null.
+    void solve_device(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
+                      const double* d_albedo, const double* d_irradiance, int derivs, double* d_radiance, double* d_wf_ext,
+                      double* d_wf_ssa, double* d_wf_alb, double* d_los_od, int* d_status, void* stream, int max_chunk);
+
+    size_t bytes_per_wavelength() const;
+    size_t scratch_bytes() const;
+    void set_profiling(bool on);
+    void reset_profile();
+    bool kernel_time(const char* name, double* ms, long* launches) const;
+    std::string kernel_names() const;
+
+  private:
+    void ensure_scratch(int nw);
+    Impl* impl_;
+};
+
+}  // namespace skdev

@@ -1,0 +1,47 @@
+"""Runs a tests/scenarios.py scenario through the product (Python mirror -> C ABI -> HIP) and returns arrays in the
+oracle's output convention ([wavelength, los] radiance, [wavelength, los, altitude] derivatives)."""
+from __future__ import annotations
+
+import numpy as np
+
+import sasktran2_amd as sk
+from tests import scenarios as sc
+
+
+def build_engine(s):
+    g = s["geometry"]
+    config = sk.Config()
+    config.num_streams = s["config"]["nstr"]
+    config.num_sza = s["config"]["num_sza"]
+    config.num_singlescatter_moments = s["leg"].shape[0]
+    config.multiple_scatter_source = sk.MultipleScatterSource.DiscreteOrdinates
+    config.single_scatter_source = sk.SingleScatterSource.DiscreteOrdinates
+    geometry = sk.Geometry1D(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"],
+                             sk.InterpolationMethod(g["interp_method"]), sk.GeometryType(g["geotype"]))
+    viewing = sk.ViewingGeometry()
+    for kind, csz, az, obs, x in s["rays"]:
+        if kind == sc.TANGENT_ALTITUDE_SOLAR:
+            viewing.add_ray(sk.TangentAltitudeSolar(x, az, obs, csz))
+        else:
+            viewing.add_ray(sk.GroundViewingSolar(csz, az, x, obs))
+    return sk.Engine(config, geometry, viewing), config, geometry
+
+
+def run_product(s, derivatives=True, engine=None):
+    if engine is None:
+        engine, config, geometry = build_engine(s)
+    else:
+        engine, config, geometry = engine
+    nw = s["extinction"].shape[1]
+    atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=derivatives)
+    atmosphere.storage.total_extinction[:] = s["extinction"]
+    atmosphere.storage.ssa[:] = s["ssa"]
+    atmosphere.leg_coeff.a1[:] = s["leg"]
+    atmosphere.surface.albedo[:] = s["albedo"]
+    res = engine.calculate_radiance(atmosphere, as_dataset=False)
+    out = {"radiance": res["radiance"][:, :, 0], "los_optical_depth": res["los_optical_depth"]}
+    if derivatives:
+        out["d_extinction"] = np.transpose(res["wf_extinction"][:, :, :, 0], (1, 2, 0))
+        out["d_ssa"] = np.transpose(res["wf_ssa"][:, :, :, 0], (1, 2, 0))
+        out["d_albedo"] = res["wf_albedo"][:, :, 0]
+    return out
