@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: wavelengths/sec (radiance + full weighting functions) of the DISCO hot path.
+
+Workload (BASELINE.json configs[1]): spherical limb scatter, 16 streams, 50 layers, 25 tangent heights,
+10 000 wavelengths, wf_extinction + wf_ssa + wf_albedo.  One "step" = one full pass of the hot path over the spectrum
+with the optical inputs already resident in HBM.  For N > 1 the SAME 10 000 wavelengths are sharded across the ranks
+(contiguous ranges, BASELINE configs[2]) and the radiance/WF block is reassembled with one RCCL all-gather per output
+array inside the timed region -> "scaling": "strong".
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+ALGORITHMIC_BYTES_PER_WAVELENGTH = 28_160  # 7 360 B inputs + 20 800 B outputs
+HBM_PEAK_GBS = 8000.0                      # /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VECTOR_PEAK_TFLOPS = 78.6             # MI355X datasheet (vector FP64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--wavelengths", type=int, default=10_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="wavelengths of the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from sasktran2_amd.device import DeviceSolver
+    from sasktran2_amd.distributed import gather_wavelength_axis, shard_bounds
+    from tests import scenarios as sc
+    from tests.gpu_harness import build_engine
+
+    NW = args.wavelengths
+    s = sc.limb_c2(num_wavelengths=NW)
+    engine, config, geometry = build_engine(s)
+    solver = DeviceSolver(engine)
+    lo, hi = shard_bounds(NW, rank, world)
+    nloc = hi - lo
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    ext = to(s["extinction"][:, lo:hi].T)
+    ssa = to(s["ssa"][:, lo:hi].T)
+    leg = to(np.transpose(s["leg"][:, :, lo:hi], (2, 1, 0)))
+    alb = to(s["albedo"][lo:hi])
+    out = solver.allocate_outputs(nloc, derivatives=True, device=dev)
+
+    def step():
+        solver.solve(ext, ssa, leg, alb, out)
+        if world > 1:
+            full = {"radiance": gather_wavelength_axis(out["radiance"], NW, 0),
+                    "wf_extinction": gather_wavelength_axis(out["wf_extinction"], NW, 1),
+                    "wf_ssa": gather_wavelength_axis(out["wf_ssa"], NW, 1),
+                    "wf_albedo": gather_wavelength_axis(out["wf_albedo"], NW, 0)}
+            return full
+        return out
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    status_bad = int((out["status"] != 0).sum().item())
+    finite = bool(torch.isfinite(res["radiance"]).all().item())
+
+    # ---- per-kernel timing with HIP events on the launch stream (outside the timed region; serialises launches)
+    solver.set_profiling(True)
+    solver.solve(ext, ssa, leg, alb, out)
+    torch.cuda.synchronize()
+    ktimes = solver.kernel_times()
+    solver.set_profiling(False)
+    dominant = max(ktimes, key=lambda k: ktimes[k][0])
+    dom_ms, dom_n = ktimes[dominant]
+    chunk = min(nloc, int(os.environ.get("SASKTRAN2_AMD_CHUNK", "4096")))
+    avg_launch_s = dom_ms / dom_n * 1e-3
+    achieved_gbs = ALGORITHMIC_BYTES_PER_WAVELENGTH * chunk / avg_launch_s / 1e9
+
+    line = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = NW * args.steps / elapsed
+        line = {
+            "metric": "wavelengths/sec (radiance + full WF) 50 layer/16 stream",
+            "value": value, "unit": "wavelengths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2 limb-scatter spherical: 16-stream DISCO, 50 layers, 25 tangent heights 10-58 km, "
+                                   f"{NW} wavelengths, Stokes I + wf_extinction/wf_ssa/wf_albedo",
+                       "wavelengths_per_gpu": nloc, "parallelism": f"wavelength-shard x{world} + RCCL all-gather" if world > 1 else "single GPU",
+                       "single_scatter_source": "discrete_ordinates", "num_sza": 1, "chunk": chunk},
+            "valid": finite and status_bad == 0,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_wavelength": ALGORITHMIC_BYTES_PER_WAVELENGTH,
+                         "avg_launch_ms": dom_ms / dom_n, "launches": dom_n,
+                         "note": "path is FP64-latency/ALU bound, not HBM-streaming (SURVEY 8d); see kernels_ms and DESIGN.md"},
+            "kernels_ms": {k: {"total_ms": round(v[0], 3), "launches": v[1]} for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])},
+            "scratch_gib": solver.scratch_bytes(chunk) / 2 ** 30,
+        }
+    # ---- CPU baseline: the oracle (same algorithm as the reference CPU engine, OpenMP over wavelengths) on a bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from tests.test_oracle_golden import make_oracle
+        cores = len(os.sched_getaffinity(0))
+        eng = make_oracle(s)
+        probe = max(cores, 8)
+        idx = np.linspace(0, NW - 1, probe).astype(int)
+        t = time.perf_counter()
+        eng.run(s["extinction"][:, idx], s["ssa"][:, idx], s["leg"][:, :, idx], s["albedo"][idx], derivatives=True, nthreads=cores)
+        rate = probe / (time.perf_counter() - t)
+        n = args.cpu_sample or int(min(max(rate * 15.0, probe), 4096))
+        idx = np.linspace(0, NW - 1, n).astype(int)
+        t = time.perf_counter()
+        ref = eng.run(s["extinction"][:, idx], s["ssa"][:, idx], s["leg"][:, :, idx], s["albedo"][idx], derivatives=True, nthreads=cores)
+        dt = time.perf_counter() - t
+        got = out["radiance"].cpu().numpy()[idx]
+        parity = float(np.max(np.abs(got / ref["radiance"] - 1)))
+        wf = out["wf_extinction"].cpu().numpy()[:, idx, :]
+        refwf = np.transpose(ref["d_extinction"], (2, 0, 1))
+        wf_parity = float(np.max(np.abs(wf - refwf) / np.abs(refwf).max(axis=0, keepdims=True)))
+        line["cpu_baseline"] = {"value": n / dt, "unit": "wavelengths/s", "cores": cores, "kind": "port",
+                                "sample": f"{n} of the {NW} wavelengths (evenly spaced), same workload incl. weighting functions, {dt:.1f} s",
+                                "parity_radiance_max_rel": parity, "parity_wf_extinction_max_rel_to_profile_max": wf_parity}
+        line["speedup_vs_cpu_baseline"] = line["value"] / (n / dt)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

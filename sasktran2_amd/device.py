@@ -1,0 +1,68 @@
+"""Device-resident front end: inputs and outputs are torch CUDA tensors (float64) that stay in HBM.
+
+PyTorch is plumbing here (device memory, streams, torch.distributed); all arithmetic is in the HIP library via
+`sk_amd_engine_solve_device` (include/sasktran2_amd.h)."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ._lib_loader import last_error, lib
+
+
+class DeviceSolver:
+    def __init__(self, engine):
+        """engine: sasktran2_amd.Engine (owns the geometry tables already uploaded to the GPU)."""
+        self.engine = engine
+        n = ctypes.c_int()
+        lib().sk_amd_engine_num_los(engine._h, ctypes.byref(n))
+        self.nlos = n.value
+        self.ngrid = len(engine._geometry.altitudes())
+
+    def allocate_outputs(self, nwavel, derivatives=True, device="cuda"):
+        kw = dict(dtype=torch.float64, device=device)
+        out = {"radiance": torch.empty((nwavel, self.nlos), **kw), "los_optical_depth": torch.empty((nwavel, self.nlos), **kw),
+               "status": torch.empty(nwavel, dtype=torch.int32, device=device)}
+        if derivatives:
+            out["wf_extinction"] = torch.empty((self.ngrid, nwavel, self.nlos), **kw)
+            out["wf_ssa"] = torch.empty((self.ngrid, nwavel, self.nlos), **kw)
+            out["wf_albedo"] = torch.empty((nwavel, self.nlos), **kw)
+        return out
+
+    def solve(self, extinction, ssa, leg, albedo, out, irradiance=None, max_chunk=0):
+        """extinction, ssa: [nwavel, ngrid]; leg: [nwavel, ngrid, nleg]; albedo: [nwavel] -- contiguous float64 CUDA tensors
+        (this is the reference storage layout, location fastest).  `out` from allocate_outputs().  Asynchronous on torch's
+        current stream except for one 4-byte read-back per azimuth order (stop rule)."""
+        for t in (extinction, ssa, leg, albedo):
+            assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        nw = extinction.shape[0]
+        derivs = "wf_extinction" in out
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        rc = lib().sk_amd_engine_solve_device(
+            self.engine._h, nw, leg.shape[2], p(extinction), p(ssa), p(leg), p(albedo), p(irradiance), int(derivs),
+            p(out["radiance"]), p(out.get("wf_extinction")), p(out.get("wf_ssa")), p(out.get("wf_albedo")),
+            p(out["los_optical_depth"]), p(out["status"]), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), int(max_chunk))
+        if rc != 0:
+            raise RuntimeError(f"sk_amd_engine_solve_device returned {rc}: {last_error()}")
+        return out
+
+    # ---- per-kernel HIP-event timing (serialises launches; use outside the timed region)
+    def set_profiling(self, on):
+        lib().sk_amd_engine_set_profiling(self.engine._h, int(on))
+        lib().sk_amd_engine_reset_profile(self.engine._h)
+
+    def kernel_times(self):
+        buf = ctypes.create_string_buffer(4096)
+        lib().sk_amd_engine_kernel_names(self.engine._h, buf, 4096)
+        res = {}
+        for name in filter(None, buf.value.decode().split(",")):
+            ms, n = ctypes.c_double(), ctypes.c_long()
+            lib().sk_amd_engine_kernel_time(self.engine._h, name.encode(), ctypes.byref(ms), ctypes.byref(n))
+            res[name] = (ms.value, n.value)
+        return res
+
+    def scratch_bytes(self, nwavel):
+        b = ctypes.c_ulonglong()
+        lib().sk_amd_engine_scratch_bytes(self.engine._h, nwavel, ctypes.byref(b))
+        return b.value

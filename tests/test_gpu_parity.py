@@ -123,11 +123,14 @@ def test_full_size_c2_properties():
 
 def test_weighting_functions_match_gpu_finite_differences():
     from tests.gpu_harness import build_engine
-    s = sc.limb_c2(num_wavelengths=4)
+    # the regression scenario has a stable set of azimuth orders; with aerosol phase functions the reference's
+    # per-point convergence cut-off (1e-4) makes the radiance discontinuous at the 1e-8 level, which a finite difference
+    # amplifies -- analytic weighting functions there are checked against the oracle instead
+    s = sc.regression_1d(2)
     eng = build_engine(s)
     base = run_product(s, engine=eng)
     for name, key in (("extinction", "d_extinction"), ("ssa", "d_ssa")):
-        for q in (2, 17, 40):
+        for q in (2, 11, 20):
             h = 1e-4 * s[name][q, :]
             plus, minus = copy.deepcopy(s), copy.deepcopy(s)
             plus[name][q, :] += h
