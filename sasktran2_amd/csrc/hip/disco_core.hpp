@@ -71,6 +71,7 @@ struct Geo {
     const int* ssa_idx;
     const double* ssa_w;
     const double* rl_azi;   // [q]
+    const double* rl_cosm;  // [m][q]  cos(m * azi_q)
     const int* rl_active;   // [q] 0 when the shell is shorter than MINIMUM_SHELL_SIZE_M
     const int* rl_tab_start;  // [q .. +1] table entries of a ray layer
     const int* tab_slot;
@@ -112,11 +113,11 @@ struct Bufs {
     double* srcw;           // [q][w]  omega_loc (1-exp(-od)) * attenuation(q -> observer)
     double* att_total;      // [los][w]
     // per azimuth order
-    double* rec;            // [p][REC][w]
-    double* dinv;           // [p][4N^2][w]
-    double* xsol;           // [p][2N][w]
-    double* J;              // [m][slot][w]
-    uint8_t* conv_order;    // [slot][w]  first azimuth order that is skipped for this table point
+    double* rec;            // [w][p][REC]   (record-major, see rec_at)
+    double* dinv;           // [w][p][4N^2]
+    double* xsol;           // [w][p][2N]
+    double* J;              // [w][m][slot]   (see J_at)
+    uint8_t* conv_order;    // [w][slot]  first azimuth order that is skipped for this table point (see conv_at)
     int* notconv;           // [w]
     int* norders;           // [w] number of azimuth orders that are solved (stop rule)
     int* status;            // [w] error bits
@@ -131,16 +132,24 @@ struct Bufs {
 template <int N> struct Rec {
     static constexpr int K = 0, DK = N, WP = 2 * N, WM = WP + N * N, DWP = WM + N * N, DWM = DWP + N * N,
                          AP = DWM + N * N, AM = AP + N, DAP = AM + N, DAM = DAP + N, G = DAM + N, DG = G + 4 * N,
-                         SIZE = DG + 16 * N;
+                         PPM = DG + 16 * N, E = PPM + 14 * N, SIZE = E + N;
+    // PPM[j][14]: post-processing multipliers of solution j (struct PPMult) and E[j] = exp(-k_j tau), written by K3 so
+    // that the per-LOS adjoint lanes of K2b never evaluate an exponential
     // G order: 0 Gplus_top, 1 Gminus_top, 2 Gplus_bottom, 3 Gminus_bottom;  DG[theta][which][i], theta: 0 tau 1 omega 2 T 3 sec
 };
 enum { TH_TAU = 0, TH_OM = 1, TH_T = 2, TH_SEC = 3 };
 
+// Layer records, block inverses and BVP solutions are stored record-major, [wavelength][layer][element], so that a
+// workgroup that owns one wavelength streams whole records with unit stride.
 struct RecView {
     const double* p;
-    size_t stride;
-    SKD_HD double operator()(int e) const { return p[size_t(e) * stride]; }
+    SKD_HD double operator()(int e) const { return p[e]; }
 };
+SKD_HD double& J_at(const Bufs& b, const Geo& g, int m, int slot, int w) { return b.J[(size_t(w) * g.nstr + m) * g.nslot + slot]; }
+SKD_HD uint8_t& conv_at(const Bufs& b, const Geo& g, int slot, int w) { return b.conv_order[size_t(w) * g.nslot + slot]; }
+template <int N> SKD_HD double* rec_at(const Bufs& b, int nlyr, int p, int w) { return b.rec + (size_t(w) * nlyr + p) * Rec<N>::SIZE; }
+template <int N> SKD_HD double* dinv_at(const Bufs& b, int nlyr, int p, int w) { return b.dinv + (size_t(w) * nlyr + p) * (4 * N * N); }
+template <int N> SKD_HD double* xsol_at(const Bufs& b, int nlyr, int p, int w) { return b.xsol + (size_t(w) * nlyr + p) * (2 * N); }
 
 // =================================================================================================
 // K0: layer optics + beam attenuation + LOS optics        (one task per wavelength)
@@ -360,8 +369,8 @@ template <int N> SKD_HD void k1_layer_solution(const Geo& g, const Bufs& b, int 
     constexpr int NSTR = 2 * N;
     using R = Rec<N>;
     const int nw = b.nw;
-    double* rec = b.rec + size_t(p) * R::SIZE * nw + w;
-    auto out = [&](int e) -> double& { return rec[size_t(e) * nw]; };
+    double* rec = rec_at<N>(b, g.nlyr, p, w);
+    auto out = [&](int e) -> double& { return rec[e]; };
     const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
     const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
     const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
@@ -580,7 +589,7 @@ template <int N> SKD_HD void k2a_bvp(const Geo& g, const Bufs& b, int s, int m, 
     const double rho = (m == 0) ? b.albedo[w] : 0.0;  // Lambertian
     const double kd = 2.0;                            // (1 + delta_m0) with m == 0
     double D[M2 * M2], Dinv[M2 * M2], T1[N * M2], r[M2], rprev[M2], E[N], Eprev[N];
-    auto recp = [&](int p) { return RecView{b.rec + size_t(p) * R::SIZE * nw + w, size_t(nw)}; };
+    auto recp = [&](int p) { return RecView{rec_at<N>(b, nlyr, p, w)}; };
     for (int p = 0; p < nlyr; ++p) {
         RecView c = recp(p);
         const double th = b.tau[size_t(p) * nw + w];
@@ -654,15 +663,15 @@ template <int N> SKD_HD void k2a_bvp(const Geo& g, const Bufs& b, int s, int m, 
         }
         for (int i = 0; i < M2; ++i) {
             rprev[i] = r[i];
-            b.xsol[(size_t(p) * M2 + i) * nw + w] = r[i];
-            for (int j = 0; j < M2; ++j) b.dinv[(size_t(p) * M2 * M2 + i * M2 + j) * nw + w] = Dinv[i * M2 + j];
+            xsol_at<N>(b, nlyr, p, w)[i] = r[i];
+            for (int j = 0; j < M2; ++j) dinv_at<N>(b, nlyr, p, w)[i * M2 + j] = Dinv[i * M2 + j];
         }
         for (int j = 0; j < N; ++j) Eprev[j] = E[j];
     }
     // back substitution:  x_p = Dinv_p (r'_p - Sup_p x_{p+1})
     double xn[M2];
     for (int p = nlyr - 1; p >= 0; --p) {
-        for (int i = 0; i < M2; ++i) r[i] = b.xsol[(size_t(p) * M2 + i) * nw + w];
+        for (int i = 0; i < M2; ++i) r[i] = xsol_at<N>(b, nlyr, p, w)[i];
         if (p < nlyr - 1) {
             RecView cn = recp(p + 1);
             const double thn = b.tau[size_t(p + 1) * nw + w];
@@ -675,12 +684,12 @@ template <int N> SKD_HD void k2a_bvp(const Geo& g, const Bufs& b, int s, int m, 
         }
         for (int i = 0; i < M2; ++i) {
             double t = 0;
-            for (int j = 0; j < M2; ++j) t += b.dinv[(size_t(p) * M2 * M2 + i * M2 + j) * nw + w] * r[j];
+            for (int j = 0; j < M2; ++j) t += dinv_at<N>(b, nlyr, p, w)[i * M2 + j] * r[j];
             D[i] = t;
         }
         for (int i = 0; i < M2; ++i) {
             xn[i] = D[i];
-            b.xsol[(size_t(p) * M2 + i) * nw + w] = D[i];
+            xsol_at<N>(b, nlyr, p, w)[i] = D[i];
         }
     }
 }
@@ -716,6 +725,15 @@ SKD_HD void pp_multipliers(double T, double th, double sc, double ev, double lf,
     }
 }
 
+SKD_HD void ppm_store(double* dst, const PPMult& o) {
+    dst[0] = o.hp; dst[1] = o.hm; dst[2] = o.Dm; dst[3] = o.Dp; dst[4] = o.hp_tau; dst[5] = o.hp_k; dst[6] = o.hm_tau;
+    dst[7] = o.hm_k; dst[8] = o.Dm_tau; dst[9] = o.Dm_k; dst[10] = o.Dm_sec; dst[11] = o.Dp_tau; dst[12] = o.Dp_k; dst[13] = o.Dp_sec;
+}
+SKD_HD void ppm_load(const double* src, PPMult& o) {
+    o.hp = src[0]; o.hm = src[1]; o.Dm = src[2]; o.Dp = src[3]; o.hp_tau = src[4]; o.hp_k = src[5]; o.hm_tau = src[6];
+    o.hm_k = src[7]; o.Dm_tau = src[8]; o.Dm_k = src[9]; o.Dm_sec = src[10]; o.Dp_tau = src[11]; o.Dp_k = src[12]; o.Dp_sec = src[13];
+}
+
 // =================================================================================================
 // K3: diffuse source table values J_m at the needed (layer, angle) points + convergence bookkeeping
 //   (task = wavelength x layer; the bottom layer's task also fills the ground rows)
@@ -726,7 +744,7 @@ template <int N> SKD_HD void k3_table_values(const Geo& g, const Bufs& b, int s,
     constexpr int NSTR = 2 * N;
     using R = Rec<N>;
     const int nw = b.nw, nlyr = g.nlyr;
-    RecView c{b.rec + size_t(p) * R::SIZE * nw + w, size_t(nw)};
+    RecView c{rec_at<N>(b, nlyr, p, w)};
     const double th = b.tau[size_t(p) * nw + w];
     const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
     const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
@@ -736,7 +754,9 @@ template <int N> SKD_HD void k3_table_values(const Geo& g, const Bufs& b, int s,
     for (int j = 0; j < N; ++j) {
         PPMult pm;
         pp_multipliers(T, th, sc, c(R::K + j), g.lfrac[p], pm);
-        double L = b.xsol[(size_t(p) * 2 * N + j) * nw + w], Mv = b.xsol[(size_t(p) * 2 * N + N + j) * nw + w];
+        ppm_store(rec_at<N>(b, nlyr, p, w) + R::PPM + 14 * j, pm);
+        rec_at<N>(b, nlyr, p, w)[R::E + j] = exp(-fabs(c(R::K + j)) * th);
+        double L = xsol_at<N>(b, nlyr, p, w)[j], Mv = xsol_at<N>(b, nlyr, p, w)[N + j];
         coefL[j] = pm.hp * L + c(R::AP + j) * pm.Dm;
         coefM[j] = pm.hm * Mv + c(R::AM + j) * pm.Dp;
     }
@@ -766,16 +786,16 @@ template <int N> SKD_HD void k3_table_values(const Geo& g, const Bufs& b, int s,
     const int t0 = g.pt_start[s * nlyr + p], t1 = g.pt_start[s * nlyr + p + 1];
     for (int t = t0; t < t1; ++t) {
         const int slot = g.pt_slot[t];
-        if (b.conv_order[size_t(slot) * nw + w] <= m) continue;
+        if (conv_at(b, g, slot, w) <= m) continue;
         const double* lpa = g.lpang + (size_t(m) * g.nangle + g.pt_angle[t]) * NSTR;
         double val = 0;
         for (int l = m; l < NSTR; ++l) val += cleg[l] * lpa[l];
         // (the 1/omega of the table and the omega inside the phase sums cancel)
-        b.J[(size_t(m) * g.nslot + slot) * nw + w] = val;
+        J_at(b, g, m, slot, w) = val;
         if (m >= 2) {
-            double prev = b.J[(size_t(m - 1) * g.nslot + slot) * nw + w], prev2 = b.J[(size_t(m - 2) * g.nslot + slot) * nw + w];
+            double prev = J_at(b, g, m - 1, slot, w), prev2 = J_at(b, g, m - 2, slot, w);
             if ((fabs(val / prev) < 1e-4 || prev < 1e-10) && (fabs(val / prev2) < 1e-4 || prev2 < 1e-10)) {
-                b.conv_order[size_t(slot) * nw + w] = (uint8_t)(m + 1);
+                conv_at(b, g, slot, w) = (uint8_t)(m + 1);
             } else {
                 unconverged = 1;
             }
@@ -788,12 +808,12 @@ template <int N> SKD_HD void k3_table_values(const Geo& g, const Bufs& b, int s,
             double sv = c(R::G + 2 * N + i);
             for (int j = 0; j < N; ++j) {
                 double st = exp(-fabs(c(R::K + j)) * th);
-                sv += b.xsol[(size_t(p) * 2 * N + j) * nw + w] * c(R::WP + i + N * j) * st +
-                      b.xsol[(size_t(p) * 2 * N + N + j) * nw + w] * c(R::WM + i + N * j);
+                sv += xsol_at<N>(b, nlyr, p, w)[j] * c(R::WP + i + N * j) * st +
+                      xsol_at<N>(b, nlyr, p, w)[N + j] * c(R::WM + i + N * j);
             }
             diffuse += 2.0 * g.mu[i] * g.wt[i] * sv * b.albedo[w];
         }
-        for (int t = g.gpt_start[s]; t < g.gpt_start[s + 1]; ++t) b.J[(size_t(m) * g.nslot + g.gpt_slot[t]) * nw + w] = diffuse;
+        for (int t = g.gpt_start[s]; t < g.gpt_start[s + 1]; ++t) J_at(b, g, m, g.gpt_slot[t], w) = diffuse;
     }
     if (unconverged) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -809,42 +829,51 @@ template <int N> SKD_HD void k3_table_values(const Geo& g, const Bufs& b, int s,
 //   radiance_m(los) = sum_p u_p . x_p + particular ;  z = A^-T u ;  reduced gradient wrt
 //   (tau_p, omega_p, T_p, sec_p)_p, albedo, T_floor accumulated into b.grad.
 // =================================================================================================
-template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int m, int los, int w) {
-    constexpr int NSTR = 2 * N, M2 = 2 * N;
+template <int N> struct K2bTask {
+    static constexpr int NSTR = 2 * N, M2 = 2 * N;
     using R = Rec<N>;
-    const int nw = b.nw, nlyr = g.nlyr;
-    const size_t tid = size_t(w) * g.nlos + los, nt = size_t(nw) * g.nlos;
-    const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
-    const double rho = (m == 0) ? b.albedo[w] : 0.0;
-    auto recp = [&](int p) { return RecView{b.rec + size_t(p) * R::SIZE * nw + w, size_t(nw)}; };
-    // ground weight of this LOS (order 0 only)
+    const Geo& g;
+    const Bufs& b;
+    const int s, m, los, w, nw, nlyr;
+    const size_t tid, nt;
+    const double* lpmu;
+    const double rho;
     double gw = 0;
-    if (m == 0 && g.ray_ground[los]) {
-        for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t)
-            if (g.g_sza[t] == s && b.conv_order[size_t(g.g_slot[t]) * nw + w] > m) gw += g.g_w[t];
-        gw *= b.att_total[size_t(los) * nw + w];
+    double yprev[M2], zn[M2];
+
+    SKD_HD K2bTask(const Geo& g_, const Bufs& b_, int s_, int m_, int los_, int w_)
+        : g(g_), b(b_), s(s_), m(m_), los(los_), w(w_), nw(b_.nw), nlyr(g_.nlyr), tid(size_t(w_) * g_.nlos + los_),
+          nt(size_t(b_.nw) * g_.nlos), lpmu(g_.lpmu + size_t(m_) * N * NSTR), rho((m_ == 0) ? b_.albedo[w_] : 0.0) {
+        // ground weight of this LOS (order 0 only)
+        if (m == 0 && g.ray_ground[los]) {
+            for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t)
+                if (g.g_sza[t] == s && conv_at(b, g, g.g_slot[t], w) > m) gw += g.g_w[t];
+            gw *= b.att_total[size_t(los) * nw + w];
+        }
+        for (int i = 0; i < M2; ++i) { yprev[i] = 0; zn[i] = 0; }
     }
+
     // Legendre-space LOS weights of a layer: ql[l] = sum_entries srcw * w_e * cos(m azi) * P_l(angle)
-    auto los_weights = [&](int p, double* ql) -> bool {
+    SKD_HD bool los_weights(int p, double* ql) const {
         for (int l = 0; l < NSTR; ++l) ql[l] = 0;
         bool any = false;
         const int base = (los * g.nsza + s) * nlyr + p;
         for (int t = g.lp_start[base]; t < g.lp_start[base + 1]; ++t) {
-            if (b.conv_order[size_t(g.lp_slot[t]) * nw + w] <= m) continue;
+            if (conv_at(b, g, g.lp_slot[t], w) <= m) continue;
             const int q = g.lp_q[t];
-            double cw = b.srcw[size_t(q) * nw + w] * g.lp_w[t] * cos(m * g.rl_azi[q]);
+            double cw = b.srcw[size_t(q) * nw + w] * g.lp_w[t] * g.rl_cosm[size_t(m) * g.nq_total + q];
             if (cw == 0.0) continue;
             any = true;
             const double* lpa = g.lpang + (size_t(m) * g.nangle + g.lp_angle[t]) * NSTR;
             for (int l = m; l < NSTR; ++l) ql[l] += cw * lpa[l];
         }
         return any;
-    };
-    // ---------------- forward sweep  y_p = Dinv_p^T (u_p - Sup_{p-1}^T y_{p-1})
-    double y[M2], yprev[M2], u[M2], ql[NSTR], a[NSTR];
-    for (int i = 0; i < M2; ++i) yprev[i] = 0;
-    for (int p = 0; p < nlyr; ++p) {
-        RecView c = recp(p);
+    }
+
+    // forward sweep step  y_p = Dinv_p^T (u_p - Sup_{p-1}^T y_{p-1});  rec/dinv may live in LDS or global memory
+    SKD_HD void forward(int p, const double* rec, const double* dinv) {
+        RecView c{rec};
+        double y[M2], u[M2], ql[NSTR], a[NSTR];
         const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
         const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
         const bool any = los_weights(p, ql);
@@ -870,7 +899,7 @@ template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int
                     ym += clp[r] * wm + clm[r] * wp;
                 }
                 PPMult pm;
-                pp_multipliers(T, th, sc, c(R::K + j), g.lfrac[p], pm);
+                ppm_load(rec + R::PPM + 14 * j, pm);
                 u[j] = yp * pm.hp / om;
                 u[N + j] = ym * pm.hm / om;
             }
@@ -882,7 +911,7 @@ template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int
                     sp += g.mu[i] * g.wt[i] * c(R::WP + i + N * j);
                     sm += g.mu[i] * g.wt[i] * c(R::WM + i + N * j);
                 }
-                u[j] += gw * 2.0 * rho * sp * exp(-fabs(c(R::K + j)) * th);
+                u[j] += gw * 2.0 * rho * sp * c(R::E + j);
                 u[N + j] += gw * 2.0 * rho * sm;
             }
         }
@@ -895,12 +924,12 @@ template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int
                     t2 += c(R::WP + i + N * j) * yprev[N + i];
                 }
                 u[j] += t1;
-                u[N + j] += t2 * exp(-fabs(c(R::K + j)) * th);
+                u[N + j] += t2 * c(R::E + j);
             }
         }
         for (int i = 0; i < M2; ++i) {
             double t = 0;
-            for (int j = 0; j < M2; ++j) t += b.dinv[(size_t(p) * M2 * M2 + j * M2 + i) * nw + w] * u[j];
+            for (int j = 0; j < M2; ++j) t += dinv[j * M2 + i] * u[j];
             y[i] = t;
         }
         for (int i = 0; i < M2; ++i) {
@@ -908,12 +937,13 @@ template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int
             b.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
         }
     }
-    // ---------------- backward sweep  z_p = y_p - Dinv_p^T Sub_{p+1}^T zA_{p+1}
-    double zn[M2], t2v[M2];
-    for (int p = nlyr - 1; p >= 0; --p) {
+
+    // backward sweep step  z_p = y_p - Dinv_p^T Sub_{p+1}^T zA_{p+1}
+    SKD_HD void backward(int p, const double* rec, const double* dinv) {
+        double y[M2], t2v[M2];
         for (int i = 0; i < M2; ++i) y[i] = b.z[(size_t(p) * M2 + i) * nt + tid];
         if (p < nlyr - 1) {
-            RecView c = recp(p);
+            RecView c{rec};
             const double th = b.tau[size_t(p) * nw + w];
             // Sub_{p+1} rows A = [W+_p E_p | W-_p]  ->  v = Sub^T zA_{p+1}
             for (int j = 0; j < N; ++j) {
@@ -922,12 +952,12 @@ template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int
                     t1 += c(R::WP + i + N * j) * zn[i];
                     t2 += c(R::WM + i + N * j) * zn[i];
                 }
-                t2v[j] = t1 * exp(-fabs(c(R::K + j)) * th);
+                t2v[j] = t1 * c(R::E + j);
                 t2v[N + j] = t2;
             }
             for (int i = 0; i < M2; ++i) {
                 double t = 0;
-                for (int j = 0; j < M2; ++j) t += b.dinv[(size_t(p) * M2 * M2 + j * M2 + i) * nw + w] * t2v[j];
+                for (int j = 0; j < M2; ++j) t += dinv[j * M2 + i] * t2v[j];
                 y[i] -= t;
             }
         }
@@ -936,12 +966,12 @@ template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int
             b.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
         }
     }
-    // ---------------- gradient contraction, layer by layer
-    const int NG = 4 * nlyr + 2;
-    (void)NG;
-    double zA[N], zB[N], zAn[N], zBp[N];
-    for (int p = 0; p < nlyr; ++p) {
-        RecView c = recp(p);
+
+    // reduced-gradient contraction of layer p (z of layers p-1, p, p+1 is read back from b.z)
+    SKD_HD void gradient(int p, const double* rec) {
+        RecView c{rec};
+        double ql[NSTR], a[NSTR];
+        double zA[N], zB[N], zAn[N], zBp[N];
         const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
         const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
         for (int i = 0; i < N; ++i) {
@@ -952,11 +982,11 @@ template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int
         }
         double L[N], Mv[N], E[N], kk[N], dk[N];
         for (int j = 0; j < N; ++j) {
-            L[j] = b.xsol[(size_t(p) * M2 + j) * nw + w];
-            Mv[j] = b.xsol[(size_t(p) * M2 + N + j) * nw + w];
+            L[j] = xsol_at<N>(b, nlyr, p, w)[j];
+            Mv[j] = xsol_at<N>(b, nlyr, p, w)[N + j];
             kk[j] = c(R::K + j);
             dk[j] = c(R::DK + j);
-            E[j] = exp(-fabs(kk[j]) * th);
+            E[j] = c(R::E + j);
         }
         const bool last = (p == nlyr - 1);
         // ground reflection operator of the last layer folds into the B rows:  rowsB = I-_bot - Rg I+_bot
@@ -1034,7 +1064,7 @@ template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int
                     dym += clp[r] * (dwm + wm / om) + clm[r] * (dwp + wp / om);
                 }
                 PPMult pm;
-                pp_multipliers(T, th, sc, kk[j], g.lfrac[p], pm);
+                ppm_load(rec + R::PPM + 14 * j, pm);
                 const double Ap = c(R::AP + j), Am = c(R::AM + j), dAp = c(R::DAP + j), dAm = c(R::DAM + j);
                 const double tL = pm.hp * L[j] + Ap * pm.Dm, tM = pm.hm * Mv[j] + Am * pm.Dp;
                 val += yp * tL + ym * tM;
@@ -1085,6 +1115,14 @@ template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int
             b.grad[size_t(4 * nlyr + 1) * nt + tid] += gTf;
         }
     }
+};
+
+template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int m, int los, int w) {
+    K2bTask<N> t(g, b, s, m, los, w);
+    const int nlyr = g.nlyr;
+    for (int p = 0; p < nlyr; ++p) t.forward(p, rec_at<N>(b, nlyr, p, w), dinv_at<N>(b, nlyr, p, w));
+    for (int p = nlyr - 1; p >= 0; --p) t.backward(p, rec_at<N>(b, nlyr, p, w), dinv_at<N>(b, nlyr, p, w));
+    for (int p = 0; p < nlyr; ++p) t.gradient(p, rec_at<N>(b, nlyr, p, w));
 }
 
 // =================================================================================================
@@ -1150,7 +1188,7 @@ SKD_HD void k4b_los(const Geo& g, const Bufs& b, int los, int w) {
     if (g.ray_ground[los]) {
         for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t) {
             int slot = g.g_slot[t];
-            if (b.conv_order[size_t(slot) * nw + w] > 0) behind += g.g_w[t] * b.J[size_t(slot) * nw + w];  // order 0 only
+            if (conv_at(b, g, slot, w) > 0) behind += g.g_w[t] * J_at(b, g, 0, slot, w);  // order 0 only
         }
     }
     const double att_total = b.att_total[size_t(los) * nw + w];
@@ -1161,11 +1199,11 @@ SKD_HD void k4b_los(const Geo& g, const Bufs& b, int los, int w) {
         double sv = 0;
         if (g.rl_active[q]) {
             for (int m = 0; m < nstr; ++m) {
-                double azf = cos(m * g.rl_azi[q]);
+                double azf = g.rl_cosm[size_t(m) * g.nq_total + q];
                 for (int t = g.rl_tab_start[q]; t < g.rl_tab_start[q + 1]; ++t) {
                     int slot = g.tab_slot[t];
-                    if (b.conv_order[size_t(slot) * nw + w] <= m) continue;
-                    sv += g.tab_w[t] * azf * b.J[(size_t(m) * g.nslot + slot) * nw + w];
+                    if (conv_at(b, g, slot, w) <= m) continue;
+                    sv += g.tab_w[t] * azf * J_at(b, g, m, slot, w);
                 }
             }
         }
@@ -1193,7 +1231,7 @@ SKD_HD void k_stop_rule(const Geo& g, const Bufs& b, int s, int m, int w) {
         b.norders[w] = m + 1;
         for (int p = 0; p < g.nlyr; ++p)
             for (int t = g.pt_start[s * g.nlyr + p]; t < g.pt_start[s * g.nlyr + p + 1]; ++t) {
-                uint8_t& c = b.conv_order[size_t(g.pt_slot[t]) * nw + w];
+                uint8_t& c = conv_at(b, g, g.pt_slot[t], w);
                 if (c > m + 1) c = (uint8_t)(m + 1);
             }
     }

@@ -1,16 +1,16 @@
 // HIP kernels + device driver of the DISCO hot path (gfx950).
 //
-// Launch structure per spectrum chunk (NW wavelengths resident in HBM, every scratch array laid out
-// [element][wavelength] so that the 64 lanes of a wavefront touch 64 consecutive doubles):
+// Launch structure per spectrum chunk (NW wavelengths resident in HBM; layer records, block inverses and table values
+// are wavelength-major so that the wavefront owning a wavelength streams them with unit stride):
 //
 //   k0_layer_optics      grid over wavelengths              layer optics, LOS shell optics
 //   for each solar-zenith index s:
 //     k0_transmission    grid over wavelengths              beam attenuation, average secants
 //     for azimuth order m = 0 .. (stop rule):
 //       k1_layer_solution  grid over wavelength x layer     eigen-solution + Green's particular solution (+ d/d omega)
-//       k2a_bvp            grid over wavelengths            block-tridiagonal factor/solve
-//       k3_table_values    grid over wavelength x layer     diffuse-source table values, convergence flags
-//       k2b_adjoint        grid over wavelength x LOS       adjoint block sweeps + reduced gradient
+//       k2a_bvp            one wavefront per wavelength     block-tridiagonal factor/solve, blocks staged in LDS
+//       k3_table_values    one wavefront per wavelength     diffuse-source table values, convergence flags
+//       k2b_adjoint        one lane per LOS, LDS-shared     adjoint block sweeps + reduced gradient
 //       k_stop_rule        grid over wavelengths            azimuth stop rule, active-wavelength count
 //     k4a_chain          grid over wavelength x LOS         reverse chain beam/optics -> native derivatives
 //   k4b_los              grid over wavelength x LOS         LOS integration of the table
@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "disco_engine.hpp"
+#include "disco_wave_kernels.hpp"
 
 namespace skdev {
 
@@ -63,25 +64,6 @@ template <int N> __global__ void __launch_bounds__(kBlock) kern_k1(Geo g, Bufs b
     if (m >= b.norders[w]) return;
     skd::k1_layer_solution<N>(g, b, s, m, p, w);
 }
-template <int N> __global__ void __launch_bounds__(kBlock) kern_k2a(Geo g, Bufs b, int s, int m) {
-    int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= b.nw || m >= b.norders[w]) return;
-    skd::k2a_bvp<N>(g, b, s, m, w);
-}
-template <int N> __global__ void __launch_bounds__(kBlock) kern_k3(Geo g, Bufs b, int s, int m) {
-    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (tid >= size_t(b.nw) * g.nlyr) return;
-    int w = int(tid % b.nw), p = int(tid / b.nw);
-    if (m >= b.norders[w]) return;
-    skd::k3_table_values<N>(g, b, s, m, p, w);
-}
-template <int N> __global__ void __launch_bounds__(kBlock) kern_k2b(Geo g, Bufs b, int s, int m) {
-    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (tid >= size_t(b.nw) * g.nlos) return;
-    int w = int(tid / g.nlos), l = int(tid % g.nlos);
-    if (m >= b.norders[w]) return;
-    skd::k2b_adjoint<N>(g, b, s, m, l, w);
-}
 __global__ void __launch_bounds__(kBlock) kern_stop(Geo g, Bufs b, int s, int m, int* active) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= b.nw) return;
@@ -101,7 +83,7 @@ __global__ void __launch_bounds__(kBlock) kern_k4b(Geo g, Bufs b) {
 __global__ void __launch_bounds__(256) kern_init(Bufs b, const int* slot_is_ground, int nslot, size_t n_grad, size_t n_dnat) {
     size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     size_t stride = size_t(gridDim.x) * blockDim.x;
-    for (size_t i = tid; i < size_t(nslot) * b.nw; i += stride) b.conv_order[i] = slot_is_ground[i / b.nw] ? 1 : 255;
+    for (size_t i = tid; i < size_t(nslot) * b.nw; i += stride) b.conv_order[i] = slot_is_ground[i % nslot] ? 1 : 255;
     for (size_t i = tid; i < n_grad; i += stride) b.grad[i] = 0.0;
     for (size_t i = tid; i < n_dnat; i += stride) b.dnat[i] = 0.0;
     for (size_t i = tid; i < size_t(b.nw); i += stride) b.status[i] = 0;
@@ -181,7 +163,7 @@ DeviceEngine::DeviceEngine(const skgeo::DiscoGeometry& dg) : impl_(new Impl) {
     g.ray_qstart = M.upload(t.ray_qstart); g.ray_ground = M.upload(t.ray_ground); g.ray_gsaa = M.upload(t.ray_gsaa);
     g.rl_od_start = M.upload(t.rl_od_start); g.od_idx = M.upload(t.od_idx); g.od_w = M.upload(t.od_w);
     g.rl_ssa_start = M.upload(t.rl_ssa_start); g.ssa_idx = M.upload(t.ssa_idx); g.ssa_w = M.upload(t.ssa_w);
-    g.rl_azi = M.upload(t.rl_azi); g.rl_active = M.upload(t.rl_active); g.rl_tab_start = M.upload(t.rl_tab_start);
+    g.rl_azi = M.upload(t.rl_azi); g.rl_cosm = M.upload(t.rl_cosm); g.rl_active = M.upload(t.rl_active); g.rl_tab_start = M.upload(t.rl_tab_start);
     g.tab_slot = M.upload(t.tab_slot); g.tab_w = M.upload(t.tab_w); g.lp_start = M.upload(t.lp_start); g.lp_q = M.upload(t.lp_q);
     g.lp_angle = M.upload(t.lp_angle); g.lp_slot = M.upload(t.lp_slot); g.lp_w = M.upload(t.lp_w); g.g_start = M.upload(t.g_start);
     g.g_slot = M.upload(t.g_slot); g.g_sza = M.upload(t.g_sza); g.g_w = M.upload(t.g_w);
@@ -224,7 +206,7 @@ size_t DeviceEngine::bytes_per_wavelength() const {
     size_t d = 0;
     d += nlyr * (3 + nstr) + (nlyr + 1) + nlyr;              // tau, om, kbar, a, T, sec
     d += size_t(t.nq_total) * 3 + nlos;                      // od, omloc, srcw, att_total
-    d += nlyr * (4 * N * N + 26 * N) + nlyr * 4 * N * N + nlyr * 2 * N;  // rec, dinv, xsol
+    d += nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N;  // rec, dinv, xsol
     d += nstr * size_t(t.nslot);                             // J
     d += nlyr * 2 * N * nlos + (4 * nlyr + 2) * nlos + (2 * t.ngrid + 1) * nlos + 2 * nlos;  // z, grad, dnat, radiance, los_od
     return d * sizeof(double) + size_t(t.nslot) + 3 * sizeof(int);
@@ -242,7 +224,7 @@ void DeviceEngine::ensure_scratch(int nw) {
     b.a = M.alloc<double>(nlyr * nstr * W); b.T = M.alloc<double>((nlyr + 1) * W); b.sec = M.alloc<double>(nlyr * W);
     b.od = M.alloc<double>(size_t(t.nq_total) * W); b.omloc = M.alloc<double>(size_t(t.nq_total) * W);
     b.srcw = M.alloc<double>(size_t(t.nq_total) * W); b.att_total = M.alloc<double>(nlos * W);
-    b.rec = M.alloc<double>(nlyr * (4 * N * N + 26 * N) * W); b.dinv = M.alloc<double>(nlyr * 4 * N * N * W);
+    b.rec = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W); b.dinv = M.alloc<double>(nlyr * 4 * N * N * W);
     b.xsol = M.alloc<double>(nlyr * 2 * N * W); b.J = M.alloc<double>(nstr * size_t(t.nslot) * W);
     b.conv_order = M.alloc<uint8_t>(size_t(t.nslot) * W); b.notconv = M.alloc<int>(W); b.norders = M.alloc<int>(W);
     b.status = M.alloc<int>(W); b.z = M.alloc<double>(nlyr * 2 * N * nt); b.grad = M.alloc<double>((4 * nlyr + 2) * nt);
@@ -299,15 +281,19 @@ static void run_chunk(DeviceEngine::Impl& I, hipStream_t st, int derivs) {
             }
             {
                 Timer t(I, st, "k2a_bvp");
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a<N>), dim3(blocks(nw)), dim3(kBlock), 0, st, g, b, s, m);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
             }
             {
                 Timer t(I, st, "k3_table_values");
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k3<N>), dim3(blocks(nw * g.nlyr)), dim3(kBlock), 0, st, g, b, s, m);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k3_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
             }
             if (derivs) {
                 Timer t(I, st, "k2b_adjoint");
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b<N>), dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, s, m);
+                int lpw = 1;
+                while (lpw < g.nlos && lpw < 64) lpw *= 2;
+                const size_t per_w = (skd::Rec<N>::SIZE + 4 * N * N) * sizeof(double);
+                const int wpb = std::max(1, std::min<int>(64 / lpw, int(49152 / per_w)));
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_wave<N>), dim3(unsigned((nw + wpb - 1) / wpb)), dim3(64), wpb * per_w, st, g, b, s, m, lpw, wpb);
             }
             int active = 0;
             {

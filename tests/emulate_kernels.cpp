@@ -88,7 +88,7 @@ int emu_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
     skd::Geo g = t.host_view();
     const int N = t.N, nlyr = t.nlyr, nstr = t.nstr, nw = nwavel, nlos = t.nlos, ngrid = t.ngrid;
     const size_t nt = size_t(nw) * nlos;
-    int recsize = 4 * N * N + 26 * N;
+    int recsize = 4 * N * N + 41 * N;
     std::vector<double> tau(size_t(nlyr) * nw), om(tau.size()), kbar(tau.size()), a(size_t(nlyr) * nstr * nw),
         T(size_t(nlyr + 1) * nw), sec(tau.size()), od(size_t(t.nq_total) * nw), omloc(od.size()), srcw(od.size()),
         att_total(size_t(nlos) * nw), rec(size_t(nlyr) * recsize * nw), dinv(size_t(nlyr) * 4 * N * N * nw),
@@ -96,7 +96,7 @@ int emu_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
         grad(size_t(4 * nlyr + 2) * nt, 0.0), dnat(size_t(2 * ngrid + 1) * nt, 0.0), rad(nt), lod(nt);
     std::vector<uint8_t> conv(size_t(t.nslot) * nw);
     for (int sl = 0; sl < t.nslot; ++sl)
-        for (int w = 0; w < nw; ++w) conv[size_t(sl) * nw + w] = t.slot_is_ground[sl] ? 1 : 255;
+        for (int w = 0; w < nw; ++w) conv[size_t(w) * t.nslot + sl] = t.slot_is_ground[sl] ? 1 : 255;
     std::vector<int> notconv(nw, 0), norders(nw, nstr), stat(nw, 0);
     skd::Bufs b{};
     b.nw = nw; b.ext = extinction; b.ssa = ssa; b.leg = leg; b.albedo = albedo; b.irradiance = solar_irradiance; b.nleg = nleg;
