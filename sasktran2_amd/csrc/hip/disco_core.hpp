@@ -121,6 +121,8 @@ struct Bufs {
     int* notconv;           // [w]
     int* norders;           // [w] number of azimuth orders that are solved (stop rule)
     int* status;            // [w] error bits
+    double* ops;            // [w][p][Ops::SIZE]  LOS-independent adjoint operators (K2c)
+    double* qlbuf;          // [p][nstr][w*nlos+los]  Legendre-space LOS weights
     double* z;              // [p][2N][w*nlos+los]
     double* grad;           // [4*nlyr+2][w*nlos+los]   reduced gradient of the current sza
     double* dnat;           // [2*ngrid+1][w*nlos+los]  native derivatives
@@ -829,300 +831,247 @@ template <int N> SKD_HD void k3_table_values(const Geo& g, const Bufs& b, int s,
 //   radiance_m(los) = sum_p u_p . x_p + particular ;  z = A^-T u ;  reduced gradient wrt
 //   (tau_p, omega_p, T_p, sec_p)_p, albedo, T_floor accumulated into b.grad.
 // =================================================================================================
+// -------------------------------------------------------------------------------------------------
+// K2c: line-of-sight independent adjoint operators of one layer               (task = wavelength x layer)
+//   Everything a LOS lane needs from layer p is folded into small dense operators acting on the Legendre-space LOS
+//   weights ql[l] and on the neighbouring adjoint vectors:
+//     y_p = FP ql_p + SP yB_{p-1} (+ gw UG)          forward sweep  (FP = Dinv^T F, SP = -Dinv^T Sup^T)
+//     z_p = y_p - BP zA_{p+1}                         backward sweep (BP = Dinv^T Sub^T)
+//     grad_theta = sum_edges wI_edge . DI[theta][edge] + HD[theta] . ql_p + (zBsum + gw) GD[theta]
+// -------------------------------------------------------------------------------------------------
+template <int N> struct Ops {
+    static constexpr int NSTR = 2 * N, M2 = 2 * N;
+    static constexpr int FP = 0, SP = FP + M2 * NSTR, BP = SP + M2 * N, UG = BP + M2 * N, DI = UG + M2, HD = DI + 16 * N,
+                         GD = HD + 4 * NSTR, IPB = GD + 4, SIZE = IPB + 1;
+    // DI[(theta*4 + edge)*N + i], edge: 0 I+top, 1 I-top, 2 I+bot, 3 I-bot
+};
+template <int N> SKD_HD double* ops_at(const Bufs& b, int nlyr, int p, int w) { return b.ops + (size_t(w) * nlyr + p) * Ops<N>::SIZE; }
+
+template <int N> SKD_HD void k2c_layer_ops(const Geo& g, const Bufs& b, int s, int m, int p, int w) {
+    constexpr int NSTR = 2 * N, M2 = 2 * N;
+    using R = Rec<N>;
+    using O = Ops<N>;
+    const int nw = b.nw, nlyr = g.nlyr;
+    RecView c{rec_at<N>(b, nlyr, p, w)};
+    const double* dinv = dinv_at<N>(b, nlyr, p, w);
+    const double* xs = xsol_at<N>(b, nlyr, p, w);
+    double* o = ops_at<N>(b, nlyr, p, w);
+    const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w];
+    const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
+    const bool last = (p == nlyr - 1);
+    const double rho = (m == 0) ? b.albedo[w] : 0.0;
+    double F[M2 * NSTR], HDv[4 * NSTR], tmp[M2];
+    for (int i = 0; i < 4 * NSTR; ++i) HDv[i] = 0;
+    PPMult pm[N];
+    for (int j = 0; j < N; ++j) ppm_load(c.p + R::PPM + 14 * j, pm[j]);
+    // F = [UL; UM] and the direct-dependence rows HD
+    for (int l = 0; l < NSTR; ++l) {
+        const double al = (l >= m) ? b.a[(size_t(p) * NSTR + l) * nw + w] : 0.0;
+        const double sg = ((l - m) & 1) ? -1.0 : 1.0;
+        double val_l = 0;  // coefficient of ql[l] in (omega * layer value)
+        for (int j = 0; j < N; ++j) {
+            double yp = 0, ym = 0, dyp = 0, dym = 0;
+            for (int r = 0; r < N; ++r) {
+                const double cm = 0.5 * g.wt[r] * om * al * lpmu[r * NSTR + l];
+                const double wp = c(R::WP + r + N * j), wm = c(R::WM + r + N * j);
+                const double dwp = c(R::DWP + r + N * j) + wp / om, dwm = c(R::DWM + r + N * j) + wm / om;
+                yp += cm * (sg * wp + wm);
+                ym += cm * (sg * wm + wp);
+                dyp += cm * (sg * dwp + dwm);
+                dym += cm * (sg * dwm + dwp);
+            }
+            F[j * NSTR + l] = yp * pm[j].hp / om;
+            F[(N + j) * NSTR + l] = ym * pm[j].hm / om;
+            const double L = xs[j], Mv = xs[N + j], dk = c(R::DK + j);
+            const double Ap = c(R::AP + j), Am = c(R::AM + j), dAp = c(R::DAP + j), dAm = c(R::DAM + j);
+            const double tL = pm[j].hp * L + Ap * pm[j].Dm, tM = pm[j].hm * Mv + Am * pm[j].Dp;
+            val_l += yp * tL + ym * tM;
+            HDv[TH_TAU * NSTR + l] += yp * (pm[j].hp_tau * L + Ap * pm[j].Dm_tau) + ym * (pm[j].hm_tau * Mv + Am * pm[j].Dp_tau);
+            HDv[TH_SEC * NSTR + l] += yp * Ap * pm[j].Dm_sec + ym * Am * pm[j].Dp_sec;
+            HDv[TH_T * NSTR + l] += (T != 0) ? (yp * Ap * pm[j].Dm + ym * Am * pm[j].Dp) / T : 0.0;
+            HDv[TH_OM * NSTR + l] += dyp * tL + dym * tM + yp * (pm[j].hp_k * dk * L + dAp * pm[j].Dm + Ap * pm[j].Dm_k * dk) +
+                                     ym * (pm[j].hm_k * dk * Mv + dAm * pm[j].Dp + Am * pm[j].Dp_k * dk);
+        }
+        for (int t = 0; t < 4; ++t) HDv[t * NSTR + l] /= om;
+        HDv[TH_OM * NSTR + l] -= val_l / (om * om);
+    }
+    for (int t = 0; t < 4 * NSTR; ++t) o[O::HD + t] = HDv[t];
+    // FP = Dinv^T F
+    for (int i = 0; i < M2; ++i)
+        for (int l = 0; l < NSTR; ++l) {
+            double t = 0;
+            for (int j = 0; j < M2; ++j) t += dinv[j * M2 + i] * F[j * NSTR + l];
+            o[O::FP + i * NSTR + l] = t;
+        }
+    // SP = Dinv^T SupT with SupT[j][i] = W-(i,j), SupT[N+j][i] = W+(i,j) E_j ;  BP = Dinv^T SubT with SubT[j][i] = W+(i,j) E_j, SubT[N+j][i] = W-(i,j)
+    for (int i = 0; i < M2; ++i)
+        for (int cidx = 0; cidx < N; ++cidx) {
+            double t1 = 0, t2 = 0;
+            for (int j = 0; j < N; ++j) {
+                const double wp = c(R::WP + cidx + N * j), wm = c(R::WM + cidx + N * j), E = c(R::E + j);
+                t1 += dinv[j * M2 + i] * wm + dinv[(N + j) * M2 + i] * wp * E;
+                t2 += dinv[j * M2 + i] * wp * E + dinv[(N + j) * M2 + i] * wm;
+            }
+            o[O::SP + i * N + cidx] = t1;
+            o[O::BP + i * N + cidx] = t2;
+        }
+    // edge-intensity derivatives at fixed (L, M)
+    double ipb = 0;
+    for (int i = 0; i < N; ++i) {
+        double d_tau[4] = {0, 0, 0, 0}, d_om[4] = {0, 0, 0, 0}, ipb_i = c(R::G + 2 * N + i);
+        for (int j = 0; j < N; ++j) {
+            const double wp = c(R::WP + i + N * j), wm = c(R::WM + i + N * j), dwp = c(R::DWP + i + N * j), dwm = c(R::DWM + i + N * j);
+            const double E = c(R::E + j), L = xs[j], Mv = xs[N + j];
+            const double dE_tau = -c(R::K + j) * E, dE_om = -c(R::DK + j) * th * E;
+            // I+top = W+ L + W- E M ; I-top = W- L + W+ E M ; I+bot = W+ E L + W- M ; I-bot = W- E L + W+ M
+            d_tau[0] += wm * dE_tau * Mv;
+            d_tau[1] += wp * dE_tau * Mv;
+            d_tau[2] += wp * dE_tau * L;
+            d_tau[3] += wm * dE_tau * L;
+            d_om[0] += dwp * L + dwm * E * Mv + wm * dE_om * Mv;
+            d_om[1] += dwm * L + dwp * E * Mv + wp * dE_om * Mv;
+            d_om[2] += dwp * E * L + wp * dE_om * L + dwm * Mv;
+            d_om[3] += dwm * E * L + wm * dE_om * L + dwp * Mv;
+            ipb_i += wp * E * L + wm * Mv;
+        }
+        ipb += g.wt[i] * g.mu[i] * ipb_i;
+        for (int e = 0; e < 4; ++e) {
+            o[O::DI + (TH_TAU * 4 + e) * N + i] = c(R::DG + (TH_TAU * 4 + e) * N + i) + d_tau[e];
+            o[O::DI + (TH_OM * 4 + e) * N + i] = c(R::DG + (TH_OM * 4 + e) * N + i) + d_om[e];
+            o[O::DI + (TH_T * 4 + e) * N + i] = c(R::DG + (TH_T * 4 + e) * N + i);
+            o[O::DI + (TH_SEC * 4 + e) * N + i] = c(R::DG + (TH_SEC * 4 + e) * N + i);
+        }
+    }
+    o[O::IPB] = ipb;
+    for (int t = 0; t < 4; ++t) {
+        double sacc = 0;
+        if (last && m == 0)
+            for (int i = 0; i < N; ++i) sacc += g.wt[i] * g.mu[i] * o[O::DI + (t * 4 + 2) * N + i];
+        o[O::GD + t] = 2.0 * rho * sacc;
+    }
+    // ground part of u (order 0, last layer): UG = Dinv^T [2 rho sp_j E_j ; 2 rho sm_j]
+    for (int i = 0; i < M2; ++i) tmp[i] = 0;
+    if (last && m == 0)
+        for (int j = 0; j < N; ++j) {
+            double sp = 0, sm = 0;
+            for (int i = 0; i < N; ++i) {
+                sp += g.mu[i] * g.wt[i] * c(R::WP + i + N * j);
+                sm += g.mu[i] * g.wt[i] * c(R::WM + i + N * j);
+            }
+            tmp[j] = 2.0 * rho * sp * c(R::E + j);
+            tmp[N + j] = 2.0 * rho * sm;
+        }
+    for (int i = 0; i < M2; ++i) {
+        double t = 0;
+        for (int j = 0; j < M2; ++j) t += dinv[j * M2 + i] * tmp[j];
+        o[O::UG + i] = t;
+    }
+}
+
+// =================================================================================================
+// K2b: adjoint sweep of one line of sight for azimuth order m             (task = wavelength x LOS)
+//   radiance_m(los) = sum_p u_p . x_p + particular ;  z = A^-T u ;  reduced gradient wrt
+//   (tau_p, omega_p, T_p, sec_p)_p, albedo, T_floor accumulated into b.grad.  Uses the K2c operators.
+// =================================================================================================
 template <int N> struct K2bTask {
     static constexpr int NSTR = 2 * N, M2 = 2 * N;
-    using R = Rec<N>;
+    using O = Ops<N>;
     const Geo& g;
     const Bufs& b;
     const int s, m, los, w, nw, nlyr;
     const size_t tid, nt;
-    const double* lpmu;
-    const double rho;
     double gw = 0;
-    double yprev[M2], zn[M2];
+    double carry[N];  // yB_{p-1} in the forward sweep, zA_{p+1} in the backward sweep
 
     SKD_HD K2bTask(const Geo& g_, const Bufs& b_, int s_, int m_, int los_, int w_)
         : g(g_), b(b_), s(s_), m(m_), los(los_), w(w_), nw(b_.nw), nlyr(g_.nlyr), tid(size_t(w_) * g_.nlos + los_),
-          nt(size_t(b_.nw) * g_.nlos), lpmu(g_.lpmu + size_t(m_) * N * NSTR), rho((m_ == 0) ? b_.albedo[w_] : 0.0) {
+          nt(size_t(b_.nw) * g_.nlos) {
         // ground weight of this LOS (order 0 only)
         if (m == 0 && g.ray_ground[los]) {
             for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t)
                 if (g.g_sza[t] == s && conv_at(b, g, g.g_slot[t], w) > m) gw += g.g_w[t];
             gw *= b.att_total[size_t(los) * nw + w];
         }
-        for (int i = 0; i < M2; ++i) { yprev[i] = 0; zn[i] = 0; }
+        for (int i = 0; i < N; ++i) carry[i] = 0;
     }
 
     // Legendre-space LOS weights of a layer: ql[l] = sum_entries srcw * w_e * cos(m azi) * P_l(angle)
-    SKD_HD bool los_weights(int p, double* ql) const {
+    SKD_HD void los_weights(int p, double* ql) const {
         for (int l = 0; l < NSTR; ++l) ql[l] = 0;
-        bool any = false;
         const int base = (los * g.nsza + s) * nlyr + p;
         for (int t = g.lp_start[base]; t < g.lp_start[base + 1]; ++t) {
             if (conv_at(b, g, g.lp_slot[t], w) <= m) continue;
             const int q = g.lp_q[t];
             double cw = b.srcw[size_t(q) * nw + w] * g.lp_w[t] * g.rl_cosm[size_t(m) * g.nq_total + q];
             if (cw == 0.0) continue;
-            any = true;
             const double* lpa = g.lpang + (size_t(m) * g.nangle + g.lp_angle[t]) * NSTR;
             for (int l = m; l < NSTR; ++l) ql[l] += cw * lpa[l];
         }
-        return any;
     }
 
-    // forward sweep step  y_p = Dinv_p^T (u_p - Sup_{p-1}^T y_{p-1});  rec/dinv may live in LDS or global memory
-    SKD_HD void forward(int p, const double* rec, const double* dinv) {
-        RecView c{rec};
-        double y[M2], u[M2], ql[NSTR], a[NSTR];
-        const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
-        const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
-        const bool any = los_weights(p, ql);
-        for (int i = 0; i < M2; ++i) u[i] = 0;
-        if (any) {
-            for (int l = 0; l < NSTR; ++l) a[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
-            double clp[N], clm[N];
-            for (int r = 0; r < N; ++r) {
-                double s0 = 0, s1 = 0;
-                for (int l = m; l < NSTR; ++l) {
-                    double t = a[l] * ql[l] * lpmu[r * NSTR + l];
-                    s0 += t;
-                    s1 += ((l - m) & 1) ? -t : t;
-                }
-                clm[r] = 0.5 * g.wt[r] * om * s0;
-                clp[r] = 0.5 * g.wt[r] * om * s1;
-            }
-            for (int j = 0; j < N; ++j) {
-                double yp = 0, ym = 0;
-                for (int r = 0; r < N; ++r) {
-                    double wp = c(R::WP + r + N * j), wm = c(R::WM + r + N * j);
-                    yp += clp[r] * wp + clm[r] * wm;
-                    ym += clp[r] * wm + clm[r] * wp;
-                }
-                PPMult pm;
-                ppm_load(rec + R::PPM + 14 * j, pm);
-                u[j] = yp * pm.hp / om;
-                u[N + j] = ym * pm.hm / om;
-            }
-        }
-        if (p == nlyr - 1 && gw != 0.0) {
-            for (int j = 0; j < N; ++j) {
-                double sp = 0, sm = 0;
-                for (int i = 0; i < N; ++i) {
-                    sp += g.mu[i] * g.wt[i] * c(R::WP + i + N * j);
-                    sm += g.mu[i] * g.wt[i] * c(R::WM + i + N * j);
-                }
-                u[j] += gw * 2.0 * rho * sp * c(R::E + j);
-                u[N + j] += gw * 2.0 * rho * sm;
-            }
-        }
-        if (p > 0) {
-            // Sup_{p-1} rows B (cols of layer p) = [-W-_p | -W+_p E_p];  u_p -= Sup^T yB_{p-1}
-            for (int j = 0; j < N; ++j) {
-                double t1 = 0, t2 = 0;
-                for (int i = 0; i < N; ++i) {
-                    t1 += c(R::WM + i + N * j) * yprev[N + i];
-                    t2 += c(R::WP + i + N * j) * yprev[N + i];
-                }
-                u[j] += t1;
-                u[N + j] += t2 * c(R::E + j);
-            }
-        }
+    // forward sweep step; `ops` may live in LDS or global memory
+    SKD_HD void forward(int p, const double* ops) {
+        double ql[NSTR], y[M2];
+        los_weights(p, ql);
+        for (int l = 0; l < NSTR; ++l) b.qlbuf[(size_t(p) * NSTR + l) * nt + tid] = ql[l];
         for (int i = 0; i < M2; ++i) {
-            double t = 0;
-            for (int j = 0; j < M2; ++j) t += dinv[j * M2 + i] * u[j];
+            double t = (p == nlyr - 1) ? gw * ops[O::UG + i] : 0.0;
+            for (int l = m; l < NSTR; ++l) t += ops[O::FP + i * NSTR + l] * ql[l];
+            for (int cidx = 0; cidx < N; ++cidx) t += ops[O::SP + i * N + cidx] * carry[cidx];
             y[i] = t;
         }
-        for (int i = 0; i < M2; ++i) {
-            yprev[i] = y[i];
-            b.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
-        }
+        for (int i = 0; i < M2; ++i) b.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
+        for (int i = 0; i < N; ++i) carry[i] = y[N + i];
     }
 
-    // backward sweep step  z_p = y_p - Dinv_p^T Sub_{p+1}^T zA_{p+1}
-    SKD_HD void backward(int p, const double* rec, const double* dinv) {
-        double y[M2], t2v[M2];
-        for (int i = 0; i < M2; ++i) y[i] = b.z[(size_t(p) * M2 + i) * nt + tid];
-        if (p < nlyr - 1) {
-            RecView c{rec};
-            const double th = b.tau[size_t(p) * nw + w];
-            // Sub_{p+1} rows A = [W+_p E_p | W-_p]  ->  v = Sub^T zA_{p+1}
-            for (int j = 0; j < N; ++j) {
-                double t1 = 0, t2 = 0;
-                for (int i = 0; i < N; ++i) {
-                    t1 += c(R::WP + i + N * j) * zn[i];
-                    t2 += c(R::WM + i + N * j) * zn[i];
-                }
-                t2v[j] = t1 * c(R::E + j);
-                t2v[N + j] = t2;
-            }
-            for (int i = 0; i < M2; ++i) {
-                double t = 0;
-                for (int j = 0; j < M2; ++j) t += dinv[j * M2 + i] * t2v[j];
-                y[i] -= t;
-            }
-        }
+    // backward sweep step  z_p = y_p - BP zA_{p+1}   (call with carry reset to zero before the first step)
+    SKD_HD void backward(int p, const double* ops) {
+        double z[M2];
         for (int i = 0; i < M2; ++i) {
-            zn[i] = y[i];
-            b.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
+            double t = b.z[(size_t(p) * M2 + i) * nt + tid];
+            if (p < nlyr - 1)
+                for (int cidx = 0; cidx < N; ++cidx) t -= ops[O::BP + i * N + cidx] * carry[cidx];
+            z[i] = t;
         }
+        for (int i = 0; i < M2; ++i) b.z[(size_t(p) * M2 + i) * nt + tid] = z[i];
+        for (int i = 0; i < N; ++i) carry[i] = z[i];
     }
 
-    // reduced-gradient contraction of layer p (z of layers p-1, p, p+1 is read back from b.z)
-    SKD_HD void gradient(int p, const double* rec) {
-        RecView c{rec};
-        double ql[NSTR], a[NSTR];
-        double zA[N], zB[N], zAn[N], zBp[N];
-        const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
-        const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
-        for (int i = 0; i < N; ++i) {
-            zA[i] = b.z[(size_t(p) * M2 + i) * nt + tid];
-            zB[i] = b.z[(size_t(p) * M2 + N + i) * nt + tid];
-            zAn[i] = (p < nlyr - 1) ? b.z[(size_t(p + 1) * M2 + i) * nt + tid] : 0.0;
-            zBp[i] = (p > 0) ? b.z[(size_t(p - 1) * M2 + N + i) * nt + tid] : 0.0;
-        }
-        double L[N], Mv[N], E[N], kk[N], dk[N];
-        for (int j = 0; j < N; ++j) {
-            L[j] = xsol_at<N>(b, nlyr, p, w)[j];
-            Mv[j] = xsol_at<N>(b, nlyr, p, w)[N + j];
-            kk[j] = c(R::K + j);
-            dk[j] = c(R::DK + j);
-            E[j] = c(R::E + j);
-        }
+    // reduced-gradient contraction of layer p (z of layers p-1, p, p+1 and ql are read back)
+    SKD_HD void gradient(int p, const double* ops) {
         const bool last = (p == nlyr - 1);
-        // ground reflection operator of the last layer folds into the B rows:  rowsB = I-_bot - Rg I+_bot
-        double zBsum = 0;
-        if (last && m == 0)
-            for (int i = 0; i < N; ++i) zBsum += zB[i];
-        // effective adjoint weights on the four edge intensities (at fixed L, M):
-        //   g = zA . dI+top - zB . dI-bot - zAn . dI+bot + zBp . dI-top   (+ ground:  + kd rho (sum zB) (w mu . dI+bot))
-        double wIpt[N], wImb[N], wIpb[N], wImt[N];
-        for (int i = 0; i < N; ++i) {
-            wIpt[i] = zA[i];
-            wImb[i] = -zB[i];
-            wIpb[i] = -zAn[i] + ((last && m == 0) ? 2.0 * rho * zBsum * g.wt[i] * g.mu[i] : 0.0);
-            wImt[i] = zBp[i];
-        }
-        // contributions through G (all four parameters)
         double gth[4] = {0, 0, 0, 0};
-        for (int t = 0; t < 4; ++t) {
-            double sacc = 0;
-            for (int i = 0; i < N; ++i)
-                sacc += wIpt[i] * c(R::DG + (t * 4 + 0) * N + i) + wImt[i] * c(R::DG + (t * 4 + 1) * N + i) +
-                        wIpb[i] * c(R::DG + (t * 4 + 2) * N + i) + wImb[i] * c(R::DG + (t * 4 + 3) * N + i);
-            gth[t] = sacc;
+        double zBsum = 0;
+        for (int i = 0; i < N; ++i) {
+            const double zA = b.z[(size_t(p) * M2 + i) * nt + tid], zB = b.z[(size_t(p) * M2 + N + i) * nt + tid];
+            const double zAn = last ? 0.0 : b.z[(size_t(p + 1) * M2 + i) * nt + tid];
+            const double zBp = (p > 0) ? b.z[(size_t(p - 1) * M2 + N + i) * nt + tid] : 0.0;
+            if (last && m == 0) zBsum += zB;
+            for (int t = 0; t < 4; ++t)
+                gth[t] += zA * ops[O::DI + (t * 4 + 0) * N + i] + zBp * ops[O::DI + (t * 4 + 1) * N + i] -
+                          zAn * ops[O::DI + (t * 4 + 2) * N + i] - zB * ops[O::DI + (t * 4 + 3) * N + i];
         }
-        // contributions through the homogeneous part a1..a4 (tau and omega only)
-        //   I+top: W+ L + W- (E M);  I-bot: W- (E L) + W+ M;  I+bot: W+ (E L) + W- M;  I-top: W- L + W+ (E M)
-        {
-            double g_tau = 0, g_om = 0;
-            for (int j = 0; j < N; ++j) {
-                double s_pt_p = 0, s_pt_m = 0, s_mb_p = 0, s_mb_m = 0, s_pb_p = 0, s_pb_m = 0, s_mt_p = 0, s_mt_m = 0;
-                double d_pt_p = 0, d_pt_m = 0, d_mb_p = 0, d_mb_m = 0, d_pb_p = 0, d_pb_m = 0, d_mt_p = 0, d_mt_m = 0;
-                for (int i = 0; i < N; ++i) {
-                    double wp = c(R::WP + i + N * j), wm = c(R::WM + i + N * j);
-                    double dwp = c(R::DWP + i + N * j), dwm = c(R::DWM + i + N * j);
-                    s_pt_p += wIpt[i] * wp; s_pt_m += wIpt[i] * wm; d_pt_p += wIpt[i] * dwp; d_pt_m += wIpt[i] * dwm;
-                    s_mb_p += wImb[i] * wp; s_mb_m += wImb[i] * wm; d_mb_p += wImb[i] * dwp; d_mb_m += wImb[i] * dwm;
-                    s_pb_p += wIpb[i] * wp; s_pb_m += wIpb[i] * wm; d_pb_p += wIpb[i] * dwp; d_pb_m += wIpb[i] * dwm;
-                    s_mt_p += wImt[i] * wp; s_mt_m += wImt[i] * wm; d_mt_p += wImt[i] * dwp; d_mt_m += wImt[i] * dwm;
-                }
-                const double EL = E[j] * L[j], EM = E[j] * Mv[j];
-                // derivative of E_j: dE/dtau = -k E, dE/dom = -dk tau E
-                const double coefE = s_pt_m * Mv[j] + s_mb_m * L[j] + s_pb_p * L[j] + s_mt_p * Mv[j];  // multiplies dE_j
-                g_tau += coefE * (-kk[j] * E[j]);
-                g_om += coefE * (-dk[j] * th * E[j]);
-                g_om += d_pt_p * L[j] + d_pt_m * EM + d_mb_m * EL + d_mb_p * Mv[j] + d_pb_p * EL + d_pb_m * Mv[j] + d_mt_m * L[j] + d_mt_p * EM;
-            }
-            gth[TH_TAU] += g_tau;
-            gth[TH_OM] += g_om;
+        for (int l = m; l < NSTR; ++l) {
+            const double q = b.qlbuf[(size_t(p) * NSTR + l) * nt + tid];
+            for (int t = 0; t < 4; ++t) gth[t] += ops[O::HD + t * NSTR + l] * q;
         }
-        // direct dependence of u.x + particular on the layer parameters (table points of this layer)
-        double direct[4] = {0, 0, 0, 0};
-        const bool any = los_weights(p, ql);
-        if (any) {
-            for (int l = 0; l < NSTR; ++l) a[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
-            double clp[N], clm[N];
-            for (int r = 0; r < N; ++r) {
-                double s0 = 0, s1 = 0;
-                for (int l = m; l < NSTR; ++l) {
-                    double t = a[l] * ql[l] * lpmu[r * NSTR + l];
-                    s0 += t;
-                    s1 += ((l - m) & 1) ? -t : t;
-                }
-                clm[r] = 0.5 * g.wt[r] * om * s0;
-                clp[r] = 0.5 * g.wt[r] * om * s1;
-            }
-            double val = 0, d_tau = 0, d_om = 0, d_T = 0, d_sec = 0;
-            for (int j = 0; j < N; ++j) {
-                double yp = 0, ym = 0, dyp = 0, dym = 0;
-                for (int r = 0; r < N; ++r) {
-                    double wp = c(R::WP + r + N * j), wm = c(R::WM + r + N * j);
-                    double dwp = c(R::DWP + r + N * j), dwm = c(R::DWM + r + N * j);
-                    yp += clp[r] * wp + clm[r] * wm;
-                    ym += clp[r] * wm + clm[r] * wp;
-                    dyp += clp[r] * (dwp + wp / om) + clm[r] * (dwm + wm / om);
-                    dym += clp[r] * (dwm + wm / om) + clm[r] * (dwp + wp / om);
-                }
-                PPMult pm;
-                ppm_load(rec + R::PPM + 14 * j, pm);
-                const double Ap = c(R::AP + j), Am = c(R::AM + j), dAp = c(R::DAP + j), dAm = c(R::DAM + j);
-                const double tL = pm.hp * L[j] + Ap * pm.Dm, tM = pm.hm * Mv[j] + Am * pm.Dp;
-                val += yp * tL + ym * tM;
-                d_tau += yp * (pm.hp_tau * L[j] + Ap * pm.Dm_tau) + ym * (pm.hm_tau * Mv[j] + Am * pm.Dp_tau);
-                d_sec += yp * Ap * pm.Dm_sec + ym * Am * pm.Dp_sec;
-                d_T += (T != 0) ? (yp * Ap * pm.Dm + ym * Am * pm.Dp) / T : 0.0;
-                d_om += dyp * tL + dym * tM + yp * (pm.hp_k * dk[j] * L[j] + dAp * pm.Dm + Ap * pm.Dm_k * dk[j]) +
-                        ym * (pm.hm_k * dk[j] * Mv[j] + dAm * pm.Dp + Am * pm.Dp_k * dk[j]);
-            }
-            direct[TH_TAU] = d_tau / om;
-            direct[TH_OM] = d_om / om - val / (om * om);
-            direct[TH_T] = d_T / om;
-            direct[TH_SEC] = d_sec / om;
-        }
-        double galb = 0, gTf = 0;
         if (last && m == 0) {
-            // ground: u gets gw*2*rho*(w mu)^T (W+ E L + W- M + G+bot) -> direct dependence on tau/omega via E, W, G+bot, and on albedo
-            double ipb_val = 0;  // w mu . I+bot
-            double d_tau = 0, d_om = 0;
-            for (int i = 0; i < N; ++i) {
-                double acc = c(R::G + 2 * N + i);
-                for (int j = 0; j < N; ++j) acc += c(R::WP + i + N * j) * E[j] * L[j] + c(R::WM + i + N * j) * Mv[j];
-                ipb_val += g.wt[i] * g.mu[i] * acc;
-            }
-            if (gw != 0.0) {
-                for (int i = 0; i < N; ++i) {
-                    double f = gw * 2.0 * rho * g.wt[i] * g.mu[i];
-                    for (int t = 0; t < 4; ++t) direct[t] += f * c(R::DG + (t * 4 + 2) * N + i);
-                    for (int j = 0; j < N; ++j) {
-                        d_tau += f * c(R::WP + i + N * j) * (-kk[j] * E[j]) * L[j];
-                        d_om += f * (c(R::DWP + i + N * j) * E[j] * L[j] + c(R::WP + i + N * j) * (-dk[j] * th * E[j]) * L[j] + c(R::DWM + i + N * j) * Mv[j]);
-                    }
-                }
-                direct[TH_TAU] += d_tau;
-                direct[TH_OM] += d_om;
-                galb += gw * 2.0 * ipb_val;
-            }
-            // albedo / floor transmission through the ground boundary rows
-            galb += zBsum * (2.0 * ipb_val + g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w]);
-            gTf += zBsum * g.csz[s] / kPi * rho;
+            for (int t = 0; t < 4; ++t) gth[t] += (zBsum + gw) * ops[O::GD + t];
+            const double rho = b.albedo[w], ipb = ops[O::IPB];
+            b.grad[size_t(4 * nlyr) * nt + tid] += gw * 2.0 * ipb + zBsum * (2.0 * ipb + g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w]);
+            b.grad[size_t(4 * nlyr + 1) * nt + tid] += zBsum * g.csz[s] / kPi * rho;
         }
-        b.grad[size_t(0 * nlyr + p) * nt + tid] += gth[TH_TAU] + direct[TH_TAU];
-        b.grad[size_t(1 * nlyr + p) * nt + tid] += gth[TH_OM] + direct[TH_OM];
-        b.grad[size_t(2 * nlyr + p) * nt + tid] += gth[TH_T] + direct[TH_T];
-        b.grad[size_t(3 * nlyr + p) * nt + tid] += gth[TH_SEC] + direct[TH_SEC];
-        if (last) {
-            b.grad[size_t(4 * nlyr) * nt + tid] += galb;
-            b.grad[size_t(4 * nlyr + 1) * nt + tid] += gTf;
-        }
+        for (int t = 0; t < 4; ++t) b.grad[size_t(t * nlyr + p) * nt + tid] += gth[t];
     }
 };
 
 template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int m, int los, int w) {
     K2bTask<N> t(g, b, s, m, los, w);
     const int nlyr = g.nlyr;
-    for (int p = 0; p < nlyr; ++p) t.forward(p, rec_at<N>(b, nlyr, p, w), dinv_at<N>(b, nlyr, p, w));
-    for (int p = nlyr - 1; p >= 0; --p) t.backward(p, rec_at<N>(b, nlyr, p, w), dinv_at<N>(b, nlyr, p, w));
-    for (int p = 0; p < nlyr; ++p) t.gradient(p, rec_at<N>(b, nlyr, p, w));
+    for (int p = 0; p < nlyr; ++p) t.forward(p, ops_at<N>(b, nlyr, p, w));
+    for (int i = 0; i < N; ++i) t.carry[i] = 0;
+    for (int p = nlyr - 1; p >= 0; --p) t.backward(p, ops_at<N>(b, nlyr, p, w));
+    for (int p = 0; p < nlyr; ++p) t.gradient(p, ops_at<N>(b, nlyr, p, w));
 }
 
 // =================================================================================================

@@ -10,7 +10,8 @@
 //       k1_layer_solution  grid over wavelength x layer     eigen-solution + Green's particular solution (+ d/d omega)
 //       k2a_bvp            one wavefront per wavelength     block-tridiagonal factor/solve, blocks staged in LDS
 //       k3_table_values    one wavefront per wavelength     diffuse-source table values, convergence flags
-//       k2b_adjoint        one lane per LOS, LDS-shared     adjoint block sweeps + reduced gradient
+//       k2c_adjoint_ops    one wavefront per wavelength     LOS-independent adjoint operators of every layer
+//       k2b_adjoint        one lane per LOS, LDS-shared     adjoint sweeps + reduced gradient (small mat-vecs)
 //       k_stop_rule        grid over wavelengths            azimuth stop rule, active-wavelength count
 //     k4a_chain          grid over wavelength x LOS         reverse chain beam/optics -> native derivatives
 //   k4b_los              grid over wavelength x LOS         LOS integration of the table
@@ -208,6 +209,7 @@ size_t DeviceEngine::bytes_per_wavelength() const {
     d += size_t(t.nq_total) * 3 + nlos;                      // od, omloc, srcw, att_total
     d += nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N;  // rec, dinv, xsol
     d += nstr * size_t(t.nslot);                             // J
+    d += nlyr * (8 * N * N + 26 * N + 5) + nlyr * nstr * nlos;  // ops, qlbuf
     d += nlyr * 2 * N * nlos + (4 * nlyr + 2) * nlos + (2 * t.ngrid + 1) * nlos + 2 * nlos;  // z, grad, dnat, radiance, los_od
     return d * sizeof(double) + size_t(t.nslot) + 3 * sizeof(int);
 }
@@ -227,7 +229,8 @@ void DeviceEngine::ensure_scratch(int nw) {
     b.rec = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W); b.dinv = M.alloc<double>(nlyr * 4 * N * N * W);
     b.xsol = M.alloc<double>(nlyr * 2 * N * W); b.J = M.alloc<double>(nstr * size_t(t.nslot) * W);
     b.conv_order = M.alloc<uint8_t>(size_t(t.nslot) * W); b.notconv = M.alloc<int>(W); b.norders = M.alloc<int>(W);
-    b.status = M.alloc<int>(W); b.z = M.alloc<double>(nlyr * 2 * N * nt); b.grad = M.alloc<double>((4 * nlyr + 2) * nt);
+    b.status = M.alloc<int>(W); b.z = M.alloc<double>(nlyr * 2 * N * nt);
+    b.ops = M.alloc<double>(nlyr * (8 * N * N + 26 * N + 5) * W); b.qlbuf = M.alloc<double>(nlyr * nstr * nt); b.grad = M.alloc<double>((4 * nlyr + 2) * nt);
     b.dnat = M.alloc<double>((2 * t.ngrid + 1) * nt); b.radiance = M.alloc<double>(nt); b.los_od = M.alloc<double>(nt);
     I.chunk_capacity = nw;
     I.scratch_bytes = bytes_per_wavelength() * W;
@@ -288,11 +291,15 @@ static void run_chunk(DeviceEngine::Impl& I, hipStream_t st, int derivs) {
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k3_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
             }
             if (derivs) {
-                Timer t(I, st, "k2b_adjoint");
                 int lpw = 1;
                 while (lpw < g.nlos && lpw < 64) lpw *= 2;
-                const size_t per_w = (skd::Rec<N>::SIZE + 4 * N * N) * sizeof(double);
+                {
+                    Timer t2(I, st, "k2c_adjoint_ops");
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                }
+                const size_t per_w = skd::Ops<N>::SIZE * sizeof(double);
                 const int wpb = std::max(1, std::min<int>(64 / lpw, int(49152 / per_w)));
+                Timer t(I, st, "k2b_adjoint");
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_wave<N>), dim3(unsigned((nw + wpb - 1) / wpb)), dim3(64), wpb * per_w, st, g, b, s, m, lpw, wpb);
             }
             int active = 0;

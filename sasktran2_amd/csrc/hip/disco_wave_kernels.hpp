@@ -276,28 +276,169 @@ template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs 
 }
 
 // -------------------------------------------------------------------------------------------------------------------
+// K2c: LOS-independent adjoint operators of every layer (see skd::k2c_layer_ops for the definitions).
+// grid = wavelengths, block = 64; the layer record, its block inverse and the work matrices live in LDS.
+// -------------------------------------------------------------------------------------------------------------------
+template <int N> __global__ void __launch_bounds__(64) kern_k2c_wave(Geo g, Bufs b, int s, int m) {
+    constexpr int NSTR = 2 * N, M2 = 2 * N, NN = N * N;
+    using R = skd::Rec<N>;
+    using O = skd::Ops<N>;
+    const int w = blockIdx.x;
+    if (m >= b.norders[w]) return;
+    const int lane = threadIdx.x, nw = b.nw, nlyr = g.nlyr;
+    __shared__ double sRec[R::SIZE];
+    __shared__ double sDinv[M2 * M2], sXs[M2], sa[NSTR];
+    __shared__ double sF[M2 * NSTR], sH[5 * N * NSTR], sTmp[M2], sIpb[N], sDIpb[4 * N];
+    const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
+    const double rho = (m == 0) ? b.albedo[w] : 0.0;
+    for (int p = 0; p < nlyr; ++p) {
+        const bool last = (p == nlyr - 1);
+        const double* rec = skd::rec_at<N>(b, nlyr, p, w);
+        const double* dg = skd::dinv_at<N>(b, nlyr, p, w);
+        const double* xs = skd::xsol_at<N>(b, nlyr, p, w);
+        double* o = skd::ops_at<N>(b, nlyr, p, w);
+        for (int i = lane; i < R::SIZE; i += 64) sRec[i] = rec[i];
+        for (int i = lane; i < M2 * M2; i += 64) sDinv[i] = dg[i];
+        if (lane < M2) sXs[lane] = xs[lane];
+        if (lane < NSTR) sa[lane] = (lane >= m) ? b.a[(size_t(p) * NSTR + lane) * nw + w] : 0.0;
+        const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w];
+        __syncthreads();
+        // phase A: F = [UL; UM] and the per-(j,l) pieces of the direct-dependence rows
+        for (int idx = lane; idx < N * NSTR; idx += 64) {
+            const int j = idx / NSTR, l = idx % NSTR;
+            const double sg = ((l - m) & 1) ? -1.0 : 1.0;
+            double yp = 0, ym = 0, dyp = 0, dym = 0;
+            for (int r = 0; r < N; ++r) {
+                const double cm = 0.5 * g.wt[r] * om * sa[l] * lpmu[r * NSTR + l];
+                const double wp = sRec[R::WP + r + N * j], wm = sRec[R::WM + r + N * j];
+                const double dwp = sRec[R::DWP + r + N * j] + wp / om, dwm = sRec[R::DWM + r + N * j] + wm / om;
+                yp += cm * (sg * wp + wm);
+                ym += cm * (sg * wm + wp);
+                dyp += cm * (sg * dwp + dwm);
+                dym += cm * (sg * dwm + dwp);
+            }
+            skd::PPMult pm;
+            skd::ppm_load(&sRec[R::PPM + 14 * j], pm);
+            sF[j * NSTR + l] = yp * pm.hp / om;
+            sF[(N + j) * NSTR + l] = ym * pm.hm / om;
+            const double L = sXs[j], Mv = sXs[N + j], dk = sRec[R::DK + j];
+            const double Ap = sRec[R::AP + j], Am = sRec[R::AM + j], dAp = sRec[R::DAP + j], dAm = sRec[R::DAM + j];
+            const double tL = pm.hp * L + Ap * pm.Dm, tM = pm.hm * Mv + Am * pm.Dp;
+            sH[(4 * N + j) * NSTR + l] = yp * tL + ym * tM;
+            sH[(skd::TH_TAU * N + j) * NSTR + l] = yp * (pm.hp_tau * L + Ap * pm.Dm_tau) + ym * (pm.hm_tau * Mv + Am * pm.Dp_tau);
+            sH[(skd::TH_SEC * N + j) * NSTR + l] = yp * Ap * pm.Dm_sec + ym * Am * pm.Dp_sec;
+            sH[(skd::TH_T * N + j) * NSTR + l] = (T != 0) ? (yp * Ap * pm.Dm + ym * Am * pm.Dp) / T : 0.0;
+            sH[(skd::TH_OM * N + j) * NSTR + l] = dyp * tL + dym * tM + yp * (pm.hp_k * dk * L + dAp * pm.Dm + Ap * pm.Dm_k * dk) +
+                                                  ym * (pm.hm_k * dk * Mv + dAm * pm.Dp + Am * pm.Dp_k * dk);
+        }
+        // edge-intensity derivatives at fixed (L, M): lanes (i, e)
+        for (int idx = lane; idx < 4 * N; idx += 64) {
+            const int i = idx / 4, e = idx % 4;
+            double d_tau = 0, d_om = 0, ipb_i = sRec[R::G + 2 * N + i];
+            for (int j = 0; j < N; ++j) {
+                const double wp = sRec[R::WP + i + N * j], wm = sRec[R::WM + i + N * j];
+                const double dwp = sRec[R::DWP + i + N * j], dwm = sRec[R::DWM + i + N * j];
+                const double E = sRec[R::E + j], L = sXs[j], Mv = sXs[N + j];
+                const double dE_tau = -sRec[R::K + j] * E, dE_om = -sRec[R::DK + j] * th * E;
+                if (e == 0) { d_tau += wm * dE_tau * Mv; d_om += dwp * L + dwm * E * Mv + wm * dE_om * Mv; }
+                if (e == 1) { d_tau += wp * dE_tau * Mv; d_om += dwm * L + dwp * E * Mv + wp * dE_om * Mv; }
+                if (e == 2) { d_tau += wp * dE_tau * L; d_om += dwp * E * L + wp * dE_om * L + dwm * Mv; ipb_i += wp * E * L + wm * Mv; }
+                if (e == 3) { d_tau += wm * dE_tau * L; d_om += dwm * E * L + wm * dE_om * L + dwp * Mv; }
+            }
+            const double v_tau = sRec[R::DG + (skd::TH_TAU * 4 + e) * N + i] + d_tau;
+            const double v_om = sRec[R::DG + (skd::TH_OM * 4 + e) * N + i] + d_om;
+            const double v_T = sRec[R::DG + (skd::TH_T * 4 + e) * N + i], v_sec = sRec[R::DG + (skd::TH_SEC * 4 + e) * N + i];
+            o[O::DI + (skd::TH_TAU * 4 + e) * N + i] = v_tau;
+            o[O::DI + (skd::TH_OM * 4 + e) * N + i] = v_om;
+            o[O::DI + (skd::TH_T * 4 + e) * N + i] = v_T;
+            o[O::DI + (skd::TH_SEC * 4 + e) * N + i] = v_sec;
+            if (e == 2) {
+                sIpb[i] = g.wt[i] * g.mu[i] * ipb_i;
+                sDIpb[skd::TH_TAU * N + i] = g.wt[i] * g.mu[i] * v_tau;
+                sDIpb[skd::TH_OM * N + i] = g.wt[i] * g.mu[i] * v_om;
+                sDIpb[skd::TH_T * N + i] = g.wt[i] * g.mu[i] * v_T;
+                sDIpb[skd::TH_SEC * N + i] = g.wt[i] * g.mu[i] * v_sec;
+            }
+        }
+        // ground part of u
+        if (lane < N) {
+            double sp = 0, sm = 0;
+            if (last && m == 0)
+                for (int i = 0; i < N; ++i) {
+                    sp += g.mu[i] * g.wt[i] * sRec[R::WP + i + N * lane];
+                    sm += g.mu[i] * g.wt[i] * sRec[R::WM + i + N * lane];
+                }
+            sTmp[lane] = 2.0 * rho * sp * sRec[R::E + lane];
+            sTmp[N + lane] = 2.0 * rho * sm;
+        }
+        __syncthreads();
+        // phase B: HD rows, FP = Dinv^T F, SP / BP, UG, GD, IPB
+        for (int idx = lane; idx < 4 * NSTR; idx += 64) {
+            const int t = idx / NSTR, l = idx % NSTR;
+            double acc = 0, val = 0;
+            for (int j = 0; j < N; ++j) {
+                acc += sH[(t * N + j) * NSTR + l];
+                val += sH[(4 * N + j) * NSTR + l];
+            }
+            acc /= om;
+            if (t == skd::TH_OM) acc -= val / (om * om);
+            o[O::HD + idx] = acc;
+        }
+        for (int idx = lane; idx < M2 * NSTR; idx += 64) {
+            const int i = idx / NSTR, l = idx % NSTR;
+            double t = 0;
+            for (int j = 0; j < M2; ++j) t += sDinv[j * M2 + i] * sF[j * NSTR + l];
+            o[O::FP + idx] = t;
+        }
+        for (int idx = lane; idx < M2 * N; idx += 64) {
+            const int i = idx / N, cidx = idx % N;
+            double t1 = 0, t2 = 0;
+            for (int j = 0; j < N; ++j) {
+                const double wp = sRec[R::WP + cidx + N * j], wm = sRec[R::WM + cidx + N * j], E = sRec[R::E + j];
+                t1 += sDinv[j * M2 + i] * wm + sDinv[(N + j) * M2 + i] * wp * E;
+                t2 += sDinv[j * M2 + i] * wp * E + sDinv[(N + j) * M2 + i] * wm;
+            }
+            o[O::SP + idx] = t1;
+            o[O::BP + idx] = t2;
+        }
+        if (lane < M2) {
+            double t = 0;
+            for (int j = 0; j < M2; ++j) t += sDinv[j * M2 + lane] * sTmp[j];
+            o[O::UG + lane] = t;
+        }
+        if (lane < 4) {
+            double sacc = 0;
+            if (last && m == 0)
+                for (int i = 0; i < N; ++i) sacc += sDIpb[lane * N + i];
+            o[O::GD + lane] = 2.0 * rho * sacc;
+        }
+        if (lane == 4) {
+            double ipb = 0;
+            for (int i = 0; i < N; ++i) ipb += sIpb[i];
+            o[O::IPB] = ipb;
+        }
+        __syncthreads();
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
 // K2b: adjoint sweeps + reduced gradient.  block = 64 lanes = wpb wavelengths x lpw lanes (one lane per LOS);
-// the layer record and the block inverse of each of the workgroup's wavelengths are staged in LDS and read by all
-// of its LOS lanes as broadcasts.  dynamic LDS: wpb * (Rec::SIZE + 4N^2) doubles.
+// the K2c operators of each of the workgroup's wavelengths are staged in LDS and read by all of its LOS lanes as
+// broadcasts.  dynamic LDS: wpb * Ops::SIZE doubles.
 // -------------------------------------------------------------------------------------------------------------------
 template <int N> __global__ void __launch_bounds__(64) kern_k2b_wave(Geo g, Bufs b, int s, int m, int lpw, int wpb) {
-    constexpr int M2 = 2 * N, REC = skd::Rec<N>::SIZE, DSZ = M2 * M2;
+    using O = skd::Ops<N>;
     extern __shared__ double smem[];
     const int lane = threadIdx.x, nlyr = g.nlyr;
     const int sub = lane / lpw, l = lane % lpw;
     const int w_lane = blockIdx.x * wpb + sub;
     const bool w_ok = (sub < wpb) && (w_lane < b.nw) && (m < b.norders[w_lane < b.nw ? w_lane : 0]);
-    double* myRec = smem + size_t(sub < wpb ? sub : 0) * (REC + DSZ);
-    double* myDinv = myRec + REC;
-    auto stage = [&](int p, bool with_dinv) {
+    double* myOps = smem + size_t(sub < wpb ? sub : 0) * O::SIZE;
+    auto stage = [&](int p, int first, int count) {
         __syncthreads();
         if (w_ok) {
-            const double* rec = skd::rec_at<N>(b, nlyr, p, w_lane);
-            for (int i = l; i < REC; i += lpw) myRec[i] = rec[i];
-            if (with_dinv) {
-                const double* dg = skd::dinv_at<N>(b, nlyr, p, w_lane);
-                for (int i = l; i < DSZ; i += lpw) myDinv[i] = dg[i];
-            }
+            const double* src = skd::ops_at<N>(b, nlyr, p, w_lane);
+            for (int i = first + l; i < first + count; i += lpw) myOps[i] = src[i];
         }
         __syncthreads();
     };
@@ -306,16 +447,17 @@ template <int N> __global__ void __launch_bounds__(64) kern_k2b_wave(Geo g, Bufs
         const bool active = w_ok && los < g.nlos;
         skd::K2bTask<N> t(g, b, s, m, active ? los : 0, active ? w_lane : 0);
         for (int p = 0; p < nlyr; ++p) {
-            stage(p, true);
-            if (active) t.forward(p, myRec, myDinv);
+            stage(p, O::FP, O::DI - O::FP);
+            if (active) t.forward(p, myOps);
         }
+        for (int i = 0; i < N; ++i) t.carry[i] = 0;
         for (int p = nlyr - 1; p >= 0; --p) {
-            stage(p, true);
-            if (active) t.backward(p, myRec, myDinv);
+            stage(p, O::BP, O::UG - O::BP);
+            if (active) t.backward(p, myOps);
         }
         for (int p = 0; p < nlyr; ++p) {
-            stage(p, false);
-            if (active) t.gradient(p, myRec);
+            stage(p, O::DI, O::SIZE - O::DI);
+            if (active) t.gradient(p, myOps);
         }
     }
 }

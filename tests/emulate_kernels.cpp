@@ -38,10 +38,14 @@ void run_n(const skd::Geo& g, skd::Bufs& b, int derivs) {
             for (int w = 0; w < nw; ++w)
                 for (int p = 0; p < g.nlyr; ++p)
                     if (m < b.norders[w]) skd::k3_table_values<N>(g, b, s, m, p, w);
-            if (derivs)
+            if (derivs) {
+                for (int w = 0; w < nw; ++w)
+                    for (int p = 0; p < g.nlyr; ++p)
+                        if (m < b.norders[w]) skd::k2c_layer_ops<N>(g, b, s, m, p, w);
                 for (int w = 0; w < nw; ++w)
                     for (int l = 0; l < g.nlos; ++l)
                         if (m < b.norders[w]) skd::k2b_adjoint<N>(g, b, s, m, l, w);
+            }
             for (int w = 0; w < nw; ++w) skd::k_stop_rule(g, b, s, m, w);
         }
         if (derivs)
@@ -93,7 +97,7 @@ int emu_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
         T(size_t(nlyr + 1) * nw), sec(tau.size()), od(size_t(t.nq_total) * nw), omloc(od.size()), srcw(od.size()),
         att_total(size_t(nlos) * nw), rec(size_t(nlyr) * recsize * nw), dinv(size_t(nlyr) * 4 * N * N * nw),
         xsol(size_t(nlyr) * 2 * N * nw), J(size_t(nstr) * t.nslot * nw, 0.0), z(size_t(nlyr) * 2 * N * nt),
-        grad(size_t(4 * nlyr + 2) * nt, 0.0), dnat(size_t(2 * ngrid + 1) * nt, 0.0), rad(nt), lod(nt);
+        grad(size_t(4 * nlyr + 2) * nt, 0.0), ops(size_t(nlyr) * (8 * N * N + 26 * N + 5) * nw), qlbuf(size_t(nlyr) * nstr * nt), dnat(size_t(2 * ngrid + 1) * nt, 0.0), rad(nt), lod(nt);
     std::vector<uint8_t> conv(size_t(t.nslot) * nw);
     for (int sl = 0; sl < t.nslot; ++sl)
         for (int w = 0; w < nw; ++w) conv[size_t(w) * t.nslot + sl] = t.slot_is_ground[sl] ? 1 : 255;
@@ -103,7 +107,7 @@ int emu_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
     b.tau = tau.data(); b.om = om.data(); b.kbar = kbar.data(); b.a = a.data(); b.T = T.data(); b.sec = sec.data();
     b.od = od.data(); b.omloc = omloc.data(); b.srcw = srcw.data(); b.att_total = att_total.data(); b.rec = rec.data();
     b.dinv = dinv.data(); b.xsol = xsol.data(); b.J = J.data(); b.conv_order = conv.data(); b.notconv = notconv.data();
-    b.norders = norders.data(); b.status = stat.data(); b.z = z.data(); b.grad = grad.data(); b.dnat = dnat.data();
+    b.norders = norders.data(); b.status = stat.data(); b.ops = ops.data(); b.qlbuf = qlbuf.data(); b.z = z.data(); b.grad = grad.data(); b.dnat = dnat.data();
     b.radiance = rad.data(); b.los_od = lod.data(); b.derivs = derivatives;
     switch (N) {
         case 1: run_n<1>(g, b, derivatives); break;
