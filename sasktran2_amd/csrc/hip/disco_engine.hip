@@ -7,7 +7,8 @@
 //   for each solar-zenith index s:
 //     k0_transmission    grid over wavelengths              beam attenuation, average secants
 //     for azimuth order m = 0 .. (stop rule):
-//       k1_layer_solution  grid over wavelength x layer     eigen-solution + Green's particular solution (+ d/d omega)
+//       k1_layer_solution  one wavefront per wavelength     lane group per layer: Cholesky + Jacobi eigen-solution in LDS,
+//                                                           Green's particular solution (+ d/d omega)
 //       k2a_bvp            one wavefront per wavelength     block-tridiagonal factor/solve, blocks staged in LDS
 //       k3_table_values    one wavefront per wavelength     diffuse-source table values, convergence flags
 //       k2c_adjoint_ops    one wavefront per wavelength     LOS-independent adjoint operators of every layer
@@ -57,13 +58,6 @@ __global__ void __launch_bounds__(kBlock) kern_k0t(Geo g, Bufs b, int s) {
     skd::k0_transmission(g, b, s, w);
     b.norders[w] = g.nstr;
     b.notconv[w] = 0;
-}
-template <int N> __global__ void __launch_bounds__(kBlock) kern_k1(Geo g, Bufs b, int s, int m) {
-    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (tid >= size_t(b.nw) * g.nlyr) return;
-    int w = int(tid % b.nw), p = int(tid / b.nw);
-    if (m >= b.norders[w]) return;
-    skd::k1_layer_solution<N>(g, b, s, m, p, w);
 }
 __global__ void __launch_bounds__(kBlock) kern_stop(Geo g, Bufs b, int s, int m, int* active) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -280,7 +274,7 @@ static void run_chunk(DeviceEngine::Impl& I, hipStream_t st, int derivs) {
         for (int m = 0; m < g.nstr; ++m) {
             {
                 Timer t(I, st, "k1_layer_solution");
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1<N>), dim3(blocks(nw * g.nlyr)), dim3(kBlock), 0, st, g, b, s, m);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
             }
             {
                 Timer t(I, st, "k2a_bvp");

@@ -16,6 +16,318 @@ using skd::Bufs;
 using skd::Geo;
 
 // -------------------------------------------------------------------------------------------------------------------
+// K1: homogeneous + particular solution of every layer.  grid = wavelengths, block = 64 lanes = NG lane groups of LG
+// lanes; each group owns one layer per pass and keeps the layer's streams x streams matrices in LDS
+// (B+, B-, Cholesky factor, Jacobi work matrix, eigenvectors, ...).  Same mathematics as skd::k1_layer_solution.
+// -------------------------------------------------------------------------------------------------------------------
+template <int N> __global__ void __launch_bounds__(64) kern_k1_wave(Geo g, Bufs b, int s, int m) {
+    constexpr int NSTR = 2 * N, NN = N * N, LG = (N >= 16) ? 64 : 16, NG = 64 / LG;
+    using R = skd::Rec<N>;
+    const int w = blockIdx.x;
+    if (m >= b.norders[w]) return;
+    const int lane = threadIdx.x, grp = lane / LG, gl = lane % LG, nw = b.nw, nlyr = g.nlyr;
+    __shared__ double sMat[NG][8][NN];
+    __shared__ double sVec[NG][18][NSTR];
+    __shared__ double sLp[N * NSTR], sLc[NSTR], sMu[N], sWt[N], sSq[N], sTt[N];
+    __shared__ int sErr;
+    for (int i = lane; i < N * NSTR; i += 64) sLp[i] = g.lpmu[size_t(m) * N * NSTR + i];
+    for (int i = lane; i < NSTR; i += 64) sLc[i] = g.lpcsz[(size_t(s) * NSTR + m) * NSTR + i];
+    if (lane < N) {
+        sMu[lane] = g.mu[lane];
+        sWt[lane] = g.wt[lane];
+        sSq[lane] = sqrt(g.wt[lane] / g.mu[lane]);
+        sTt[lane] = sqrt(g.wt[lane] * g.mu[lane]);
+    }
+    if (lane == 0) sErr = 0;
+    double* Bp = sMat[grp][0];
+    double* Bm = sMat[grp][1];
+    double* Rc = sMat[grp][2];
+    double* M3 = sMat[grp][3];
+    double* M4 = sMat[grp][4];
+    double* M5 = sMat[grp][5];
+    double* M6 = sMat[grp][6];
+    double* M7 = sMat[grp][7];
+    double* va = sVec[grp][0];    // Legendre coefficients a_l
+    double* vlam = sVec[grp][1];
+    double* vk = sVec[grp][2];
+    double* vdk = sVec[grp][3];
+    double* vnrm = sVec[grp][4];
+    double* vdnrm = sVec[grp][5];
+    double* vQp = sVec[grp][6];
+    double* vQm = sVec[grp][7];
+    double* vAp = sVec[grp][8];
+    double* vAm = sVec[grp][9];
+    double* vdAp = sVec[grp][10];
+    double* vdAm = sVec[grp][11];
+    double* vC = sVec[grp][12];   // Cp.v, Cm.v interleaved: [2j], [2j+1]
+    double* vdC = sVec[grp][13];  // dCp[4], dCm[4] per j -> 8N doubles (rows 13..16)
+    const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * skd::kPi);
+    __syncthreads();
+
+    for (int pbase = 0; pbase < nlyr; pbase += NG) {
+        const bool valid = (pbase + grp) < nlyr;
+        const int p = valid ? pbase + grp : nlyr - 1;
+        const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
+        const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
+        double* rec = skd::rec_at<N>(b, nlyr, p, w);
+        for (int l = gl; l < NSTR; l += LG) va[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
+        __syncthreads();
+        // B+-, copy of B+ for the Cholesky factor
+        for (int e = gl; e < NN; e += LG) {
+            const int i = e / N, j = e % N;
+            double ep = 0, em = 0;
+            for (int l = m; l < NSTR; ++l) {
+                const double t = va[l] * sLp[i * NSTR + l] * sLp[j * NSTR + l];
+                if ((l - m) & 1) em += t; else ep += t;
+            }
+            const double dlt = (i == j) ? 1.0 / sMu[i] : 0.0;
+            const double bp = dlt - sSq[i] * sSq[j] * om * ep;
+            Bp[e] = bp;
+            Bm[e] = dlt - sSq[i] * sSq[j] * om * em;
+            Rc[e] = (j <= i) ? bp : 0.0;
+        }
+        __syncthreads();
+        // Cholesky B+ = R R^T (lower), one column per step
+        for (int j = 0; j < N; ++j) {
+            double tj = Rc[j * N + j];
+            for (int k = 0; k < j; ++k) tj -= Rc[j * N + k] * Rc[j * N + k];
+            if (!(tj > 0)) { if (gl == 0) sErr = skd::ERR_CHOLESKY; tj = 1.0; }
+            const double d = sqrt(tj);
+            double val = 0;
+            const int i = gl;
+            const bool mine = (i < N && i >= j);
+            if (mine) {
+                double t = Rc[i * N + j];
+                for (int k = 0; k < j; ++k) t -= Rc[i * N + k] * Rc[j * N + k];
+                val = (i == j) ? d : t / d;
+            }
+            __syncthreads();
+            if (mine) Rc[i * N + j] = val;
+            __syncthreads();
+        }
+        // M3 = B- R ;  M4 = R^T M3 (symmetric)
+        for (int e = gl; e < NN; e += LG) {
+            const int i = e / N, j = e % N;
+            double t = 0;
+            for (int r = j; r < N; ++r) t += Bm[i * N + r] * Rc[r * N + j];
+            M3[e] = t;
+        }
+        __syncthreads();
+        for (int e = gl; e < NN; e += LG) {
+            const int i = e / N, j = e % N;
+            if (j <= i) {
+                double t = 0;
+                for (int r = i; r < N; ++r) t += Rc[r * N + i] * M3[r * N + j];
+                M4[i * N + j] = t;
+                M4[j * N + i] = t;
+            }
+            M5[e] = (i == j) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        // cyclic Jacobi on M4, eigenvectors accumulate in M5
+        bool jac_ok = false;
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            double off = 0, dia = 0;
+            for (int e = gl; e < NN; e += LG) {
+                const int i = e / N, j = e % N;
+                const double v = M4[e] * M4[e];
+                if (i == j) dia += v; else if (j > i) off += v;
+            }
+            for (int o = LG / 2; o >= 1; o >>= 1) {
+                off += __shfl_xor(off, o, LG);
+                dia += __shfl_xor(dia, o, LG);
+            }
+            const bool conv = (off <= 1e-34 * dia) || (off == 0);
+            if (__all(conv)) { jac_ok = true; break; }
+            for (int pp = 0; pp < N - 1; ++pp)
+                for (int qq = pp + 1; qq < N; ++qq) {
+                    const double apq = M4[pp * N + qq], app = M4[pp * N + pp], aqq = M4[qq * N + qq];
+                    double c = 1.0, sn = 0.0, t = 0.0;
+                    if (apq != 0.0) {
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(t * t + 1.0);
+                        sn = t * c;
+                    }
+                    double n0 = 0, n1 = 0;
+                    int kind = 0;  // 1: A row r, 2: diagonal p, 3: diagonal q, 4: V row
+                    int r = gl;
+                    if (gl < N) {
+                        if (r == pp) { kind = 2; n0 = app - t * apq; }
+                        else if (r == qq) { kind = 3; n0 = aqq + t * apq; }
+                        else { kind = 1; const double arp = M4[r * N + pp], arq = M4[r * N + qq]; n0 = c * arp - sn * arq; n1 = sn * arp + c * arq; }
+                    }
+                    double v0 = 0, v1 = 0;
+                    // eigenvector rows: lanes N..2N-1 when the group is wide enough, otherwise the same lanes do both
+                    const int vr = (LG >= 2 * N) ? gl - N : gl;
+                    const bool dov = (LG >= 2 * N) ? (gl >= N && gl < 2 * N) : (gl < N);
+                    if (dov) { const double vrp = M5[vr * N + pp], vrq = M5[vr * N + qq]; v0 = c * vrp - sn * vrq; v1 = sn * vrp + c * vrq; }
+                    __syncthreads();
+                    if (kind == 1) { M4[r * N + pp] = n0; M4[pp * N + r] = n0; M4[r * N + qq] = n1; M4[qq * N + r] = n1; }
+                    if (kind == 2) { M4[pp * N + pp] = n0; M4[pp * N + qq] = 0.0; }
+                    if (kind == 3) { M4[qq * N + qq] = n0; M4[qq * N + pp] = 0.0; }
+                    if (dov) { M5[vr * N + pp] = v0; M5[vr * N + qq] = v1; }
+                    __syncthreads();
+                }
+        }
+        if (!jac_ok && gl == 0) sErr = skd::ERR_EIGEN;
+        if (gl < N) {
+            double lam = M4[gl * N + gl];
+            if (!(lam > 0)) { sErr = skd::ERR_EIGEN; lam = fabs(lam) + 1e-300; }
+            vlam[gl] = lam;
+            vk[gl] = sqrt(lam);
+            // xhat = R^-T v (column gl, in place), x = T^-1 xhat
+            const int j = gl;
+            for (int i = N - 1; i >= 0; --i) {
+                double t = M5[i * N + j];
+                for (int r = i + 1; r < N; ++r) t -= Rc[r * N + i] * M5[r * N + j];
+                M5[i * N + j] = t / Rc[i * N + i];
+            }
+            for (int i = 0; i < N; ++i) M5[i * N + j] /= sTt[i];
+        }
+        __syncthreads();
+        // U (M3) = S+ X with S+-_ir = B+-_ir tt_r / tt_i
+        for (int e = gl; e < NN; e += LG) {
+            const int i = e / N, j = e % N;
+            double t = 0;
+            for (int r = 0; r < N; ++r) t += Bp[i * N + r] * sTt[r] * M5[r * N + j];
+            M3[e] = t / sTt[i];
+        }
+        __syncthreads();
+        // d(Gamma) X (M4)
+        for (int e = gl; e < NN; e += LG) {
+            const int i = e / N, j = e % N;
+            double hm = 0;
+            for (int r = 0; r < N; ++r) hm += Bm[i * N + r] * sTt[r] * M5[r * N + j] / sMu[r];
+            hm /= sTt[i];
+            M4[e] = (2 * M5[e] * vlam[j] - M3[e] / sMu[i] - hm) / om;
+        }
+        __syncthreads();
+        // C (M6), dk
+        double lmax = 0;
+        for (int j = 0; j < N; ++j) lmax = fmax(lmax, vlam[j]);
+        for (int e = gl; e < NN; e += LG) {
+            const int aa = e / N, bb = e % N;
+            double z = 0;
+            for (int i = 0; i < N; ++i) z += sWt[i] * sMu[i] * M3[i * N + aa] * M4[i * N + bb];
+            if (aa == bb) {
+                vdk[bb] = z / (2 * vk[bb]);
+                M6[e] = 0;
+            } else {
+                const double den = vlam[bb] - vlam[aa];
+                M6[e] = (fabs(den) > 1e-13 * lmax) ? z / den : 0.0;
+            }
+        }
+        __syncthreads();
+        // dX (M7) = X C
+        for (int e = gl; e < NN; e += LG) {
+            const int i = e / N, j = e % N;
+            double t = 0;
+            for (int r = 0; r < N; ++r) t += M5[i * N + r] * M6[r * N + j];
+            M7[e] = t;
+        }
+        __syncthreads();
+        // dU (M6) = (U - M^-1 X)/om + S+ dX
+        for (int e = gl; e < NN; e += LG) {
+            const int i = e / N, j = e % N;
+            double t = 0;
+            for (int r = 0; r < N; ++r) t += Bp[i * N + r] * sTt[r] * M7[r * N + j];
+            M6[e] = (M3[e] - M5[e] / sMu[i]) / om + t / sTt[i];
+        }
+        __syncthreads();
+        // W+-, dW+- (element-wise, in place: M5 <- W+, M3 <- W-, M7 <- dW+, M6 <- dW-), stored as W(i, solution j) at i + N j
+        for (int e = gl; e < NN; e += LG) {
+            const int i = e / N, j = e % N;
+            const double X = M5[e], U = M3[e], dX = M7[e], dU = M6[e];
+            const double uk = U / vk[j], duk = dU / vk[j] - U * vdk[j] / vlam[j];
+            const double wp = 0.5 * (X + uk), wm = 0.5 * (X - uk), dwp = 0.5 * (dX + duk), dwm = 0.5 * (dX - duk);
+            M5[e] = wp; M3[e] = wm; M7[e] = dwp; M6[e] = dwm;
+            if (valid) {
+                rec[R::WP + i + N * j] = wp;
+                rec[R::WM + i + N * j] = wm;
+                rec[R::DWP + i + N * j] = dwp;
+                rec[R::DWM + i + N * j] = dwm;
+            }
+        }
+        // solar pseudo-source Q+-
+        if (gl < N) {
+            const int i = gl;
+            double sp = 0, sn = 0;
+            for (int l = m; l < NSTR; ++l) {
+                const double t = va[l] * sLp[i * NSTR + l] * sLc[l];
+                sp += t;
+                sn += ((l - m) & 1) ? -t : t;
+            }
+            vQp[i] = sp * fm * sWt[i] * om;
+            vQm[i] = sn * fm * sWt[i] * om;
+        }
+        __syncthreads();
+        if (gl < N) {
+            const int j = gl;
+            bool allzero = true;
+            for (int i = 0; i < N; ++i) if (vQp[i] != 0 || vQm[i] != 0) allzero = false;
+            double nrm = 0, dnrm = 0, Ap = 0, Am = 0, dAp = 0, dAm = 0;
+            for (int i = 0; i < N; ++i) {
+                const double wp = M5[i * N + j], wm = M3[i * N + j], dwp = M7[i * N + j], dwm = M6[i * N + j];
+                nrm += sWt[i] * sMu[i] * (wp * wp - wm * wm);
+                dnrm += sWt[i] * sMu[i] * 2.0 * (wp * dwp - wm * dwm);
+                Ap += vQp[i] * wp + vQm[i] * wm;
+                Am += vQm[i] * wp + vQp[i] * wm;
+                dAp += vQp[i] * dwp + vQp[i] / om * wp + vQm[i] * dwm + vQm[i] / om * wm;
+                dAm += vQm[i] * dwp + vQm[i] / om * wp + vQp[i] * dwm + vQp[i] / om * wm;
+            }
+            skd::Mult Cp{0, 0, 0, 0}, Cm{0, 0, 0, 0};
+            if (allzero) {
+                Ap = Am = dAp = dAm = 0;
+            } else {
+                Ap /= nrm;
+                Am /= nrm;
+                dAp = dAp / nrm - dnrm * Ap / nrm;
+                dAm = dAm / nrm - dnrm * Am / nrm;
+                skd::green_multipliers(T, th, sc, vk[j], Cp, Cm);
+            }
+            vAp[j] = Ap; vAm[j] = Am; vdAp[j] = dAp; vdAm[j] = dAm;
+            vC[2 * j] = Cp.v;
+            vC[2 * j + 1] = Cm.v;
+            const double dk = vdk[j];
+            vdC[8 * j + 0] = Cp.d_tau; vdC[8 * j + 1] = Cp.d_k * dk; vdC[8 * j + 2] = (T != 0) ? Cp.v / T : 0.0; vdC[8 * j + 3] = Cp.d_sec;
+            vdC[8 * j + 4] = Cm.d_tau; vdC[8 * j + 5] = Cm.d_k * dk; vdC[8 * j + 6] = (T != 0) ? Cm.v / T : 0.0; vdC[8 * j + 7] = Cm.d_sec;
+            if (valid) {
+                rec[R::K + j] = vk[j];
+                rec[R::DK + j] = dk;
+                rec[R::AP + j] = Ap; rec[R::AM + j] = Am; rec[R::DAP + j] = dAp; rec[R::DAM + j] = dAm;
+            }
+        }
+        __syncthreads();
+        // G (4 vectors) and dG (4 params x 4 vectors): items (t in 0..4, c, i), t == 4 -> value
+        for (int it = gl; it < 5 * 4 * N; it += LG) {
+            const int t = it / (4 * N), c = (it / N) % 4, i = it % N;
+            double acc = 0;
+            for (int j = 0; j < N; ++j) {
+                const double wp = M5[i * N + j], wm = M3[i * N + j], dwp = M7[i * N + j], dwm = M6[i * N + j];
+                const bool plusC = (c >= 2);  // G+bot, G-bot use A+ C+ ; G+top, G-top use A- C-
+                const double A = plusC ? vAp[j] : vAm[j], dA = plusC ? vdAp[j] : vdAm[j];
+                const double Cv = plusC ? vC[2 * j] : vC[2 * j + 1];
+                const double wsel = (c == 0 || c == 3) ? wm : wp, dwsel = (c == 0 || c == 3) ? dwm : dwp;
+                if (t == 4) {
+                    acc += A * Cv * wsel;
+                } else {
+                    const double dCv = vdC[8 * j + (plusC ? 0 : 4) + t];
+                    acc += A * dCv * wsel;
+                    if (t == skd::TH_OM) acc += dA * Cv * wsel + A * Cv * dwsel;
+                }
+            }
+            if (valid) {
+                if (t == 4) rec[R::G + c * N + i] = acc;
+                else rec[R::DG + (t * 4 + c) * N + i] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && sErr) atomicOr(&b.status[w], sErr);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
 // K2a: block-tridiagonal BVP, factor + solve.  grid = wavelengths, block = 64.
 // LDS: current/previous layer W+-, k, G (ping-pong), augmented [D | I] for the Gauss-Jordan inverse, previous Dinv.
 // -------------------------------------------------------------------------------------------------------------------
