@@ -4,10 +4,12 @@ There is deliberately no CPU fallback: if the library is missing or no MI355X is
 from __future__ import annotations
 
 import ctypes
+import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "_lib" / "libsasktran2_amd.so"
+# SASKTRAN2_AMD_LIB selects another build of the same HIP library (kernel tuning variants); never a different backend
+LIB_PATH = Path(os.environ.get("SASKTRAN2_AMD_LIB") or (_HERE / "_lib" / "libsasktran2_amd.so"))
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
 _vp = ctypes.c_void_p

@@ -253,7 +253,7 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
         skgeo::build_disco_geometry(geo, v->rays, c->num_streams, c->num_sza, dg);
         auto e = std::make_unique<Engine>();
         e->config = *c;
-        e->dev = std::make_unique<skdev::DeviceEngine>(dg);
+        e->dev = std::make_unique<skdev::DeviceEngine>(dg, c->ss_source == 2);
         e->nlos = dg.nlos;
         e->ngrid = dg.ngrid;
         return e.release();

@@ -85,6 +85,14 @@ struct Geo {
     const int* g_slot;
     const int* g_sza;
     const double* g_w;
+    // plane-parallel post-processing (DOSourcePlaneParallelPostProcessing, do_source_planeparallel.cpp:19-218)
+    int pp_mode;            // 1: analytic layer integration per line of sight instead of the spherical diffuse table
+    int include_ss;         // the solar single-scatter term is part of the DO source (single_scatter_source = DO)
+    const double* pp_mu;    // [los] cosine of the viewing zenith angle (upwelling, > 0)
+    const double* pp_azi;   // [los] relative azimuth
+    const int* pp_first;    // [los] topmost layer the line of sight crosses
+    const double* pp_lf;    // [los] fraction of that layer below the observer (1 when the observer is above it)
+    const double* lplos;    // [los][m][l] Legendre functions at the viewing zenith
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -981,13 +989,14 @@ template <int N> struct K2bTask {
     const int s, m, los, w, nw, nlyr;
     const size_t tid, nt;
     double gw = 0;
+    bool table_weights = true;  // false: the caller supplies u_p directly (plane-parallel), no Legendre-space HD term
     double carry[N];  // yB_{p-1} in the forward sweep, zA_{p+1} in the backward sweep
 
     SKD_HD K2bTask(const Geo& g_, const Bufs& b_, int s_, int m_, int los_, int w_)
         : g(g_), b(b_), s(s_), m(m_), los(los_), w(w_), nw(b_.nw), nlyr(g_.nlyr), tid(size_t(w_) * g_.nlos + los_),
           nt(size_t(b_.nw) * g_.nlos) {
         // ground weight of this LOS (order 0 only)
-        if (m == 0 && g.ray_ground[los]) {
+        if (!g.pp_mode && m == 0 && g.ray_ground[los]) {
             for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t)
                 if (g.g_sza[t] == s && conv_at(b, g, g.g_slot[t], w) > m) gw += g.g_w[t];
             gw *= b.att_total[size_t(los) * nw + w];
@@ -1051,10 +1060,11 @@ template <int N> struct K2bTask {
                 gth[t] += zA * ops[O::DI + (t * 4 + 0) * N + i] + zBp * ops[O::DI + (t * 4 + 1) * N + i] -
                           zAn * ops[O::DI + (t * 4 + 2) * N + i] - zB * ops[O::DI + (t * 4 + 3) * N + i];
         }
-        for (int l = m; l < NSTR; ++l) {
-            const double q = b.qlbuf[(size_t(p) * NSTR + l) * nt + tid];
-            for (int t = 0; t < 4; ++t) gth[t] += ops[O::HD + t * NSTR + l] * q;
-        }
+        if (table_weights)
+            for (int l = m; l < NSTR; ++l) {
+                const double q = b.qlbuf[(size_t(p) * NSTR + l) * nt + tid];
+                for (int t = 0; t < 4; ++t) gth[t] += ops[O::HD + t * NSTR + l] * q;
+            }
         if (last && m == 0) {
             for (int t = 0; t < 4; ++t) gth[t] += (zBsum + gw) * ops[O::GD + t];
             const double rho = b.albedo[w], ipb = ops[O::IPB];
@@ -1069,6 +1079,213 @@ template <int N> SKD_HD void k2b_adjoint(const Geo& g, const Bufs& b, int s, int
     K2bTask<N> t(g, b, s, m, los, w);
     const int nlyr = g.nlyr;
     for (int p = 0; p < nlyr; ++p) t.forward(p, ops_at<N>(b, nlyr, p, w));
+    for (int i = 0; i < N; ++i) t.carry[i] = 0;
+    for (int p = nlyr - 1; p >= 0; --p) t.backward(p, ops_at<N>(b, nlyr, p, w));
+    for (int p = 0; p < nlyr; ++p) t.gradient(p, ops_at<N>(b, nlyr, p, w));
+}
+
+// =================================================================================================
+// KPP: plane-parallel post-processing of one line of sight for azimuth order m     (task = wavelength x LOS)
+//   I_m(los) = sum_p A_p S_p(mu) + A_ground * (reflected intensity),  A_p = attenuation from the top of layer p to
+//   the observer, S_p = analytic integral of the layer source function along the LOS.  The radiance is accumulated
+//   over m with cos(m azimuth); the weighting functions use the same adjoint machinery as the spherical mode
+//   (u_p = dI/d(L_p, M_p), z = A^-T u, reduced gradient wrt tau, omega, T, sec of every layer, albedo, T_floor).
+//   reference: OpticalLayer::integrate_source sktran_do_opticallayer.cpp:93-555, multipliers
+//   sktran_do_postprocessing.h:19-188, computeReflectedIntensities sktran_do_layerarray.cpp:5-288,
+//   DOSourcePlaneParallelPostProcessing::calculate do_source_planeparallel.cpp:19-218
+// =================================================================================================
+struct PPLosMult {
+    double hp, hp_th, hp_k, hm, hm_th, hm_k;
+    double Dm, Dm_th, Dm_k, Dm_T, Dm_sec, Dp, Dp_th, Dp_k, Dp_T, Dp_sec;
+};
+// source-function multiplier of the solar beam, E(mu, x): value and partials wrt (th, T, sec); x = (1 - lf) th
+struct PPBeam { double v, d_th, d_T, d_sec; };
+SKD_HD void pp_beam_multiplier(double mu, double lf, double th, double T, double sc, PPBeam& o) {
+    const double x = (1 - lf) * th, den = 1.0 + mu * sc;
+    const double e1 = exp(-x * sc), e2 = exp(-th * sc) * exp(-(th - x) / mu);
+    o.v = T / den * (e1 - e2);
+    o.d_T = (e1 - e2) / den;
+    o.d_sec = T / den * e2 * th - o.v / den * mu - T / den * e1 * x;
+    o.d_th = T / den * (e2 * (sc + lf / mu) - e1 * (1 - lf) * sc);
+}
+SKD_HD void pp_los_multipliers(double mu, double lf, double th, double T, double sc, double ev, const PPBeam& E, PPLosMult& o) {
+    const double x = (1 - lf) * th, r = th - x;
+    {
+        // h+: 1 + mu k > 1 for an upwelling line of sight, the Taylor branch of the reference is unreachable
+        const double den = 1.0 + mu * ev, e1 = exp(-x * ev), e2 = exp(-th * ev) * exp(-r / mu);
+        o.hp = (e1 - e2) / den;
+        o.hp_th = (-e1 * (1 - lf) * ev + e2 * (ev + lf / mu)) / den;
+        o.hp_k = (-e1 * x + e2 * th) / den - o.hp * mu / den;
+    }
+    {
+        const double den = 1.0 - mu * ev;
+        if (fabs(den) > 0.0001) {
+            const double e1 = exp(-ev * r), e2 = exp(-r / mu);
+            o.hm = (e1 - e2) / den;
+            o.hm_th = (-e1 * lf * ev + e2 * lf / mu) / den;
+            o.hm_k = -e1 * r / den + o.hm * mu / den;
+        } else {
+            // intensity singularity mu k -> 1: first-order expansion and its derivative exactly as the reference writes them
+            const double e1 = exp(-ev * r), c = 1 - r * (ev - 1 / mu);
+            o.hm = e1 * r / mu * c;
+            o.hm_th = -ev * o.hm + e1 / mu * c - e1 * r / mu * (ev - 1 / mu);
+            o.hm_k = -th * o.hm;
+        }
+    }
+    const double ex = exp(-th * sc);
+    {
+        const double den = sc + ev;
+        o.Dp = (-T * ex * o.hm + E.v) / den;
+        o.Dp_sec = (T * o.hm * th * ex - o.Dp + E.d_sec) / den;
+        o.Dp_T = (-o.hm * ex + E.d_T) / den;
+        o.Dp_th = (E.d_th - T * ex * o.hm_th + T * sc * o.hm * ex) / den;
+        o.Dp_k = (-o.Dp - T * ex * o.hm_k) / den;
+    }
+    {
+        const double den = sc - ev;
+        o.Dm = (T * o.hp - E.v) / den;
+        o.Dm_sec = (-o.Dm - E.d_sec) / den;
+        o.Dm_T = (o.hp - E.d_T) / den;
+        o.Dm_th = (T * o.hp_th - E.d_th) / den;
+        o.Dm_k = (T * o.hp_k + o.Dm) / den;
+    }
+}
+
+template <int N> SKD_HD void kpp_los(const Geo& g, const Bufs& b, int s, int m, int los, int w) {
+    constexpr int NSTR = 2 * N, M2 = 2 * N;
+    using R = Rec<N>;
+    using O = Ops<N>;
+    const int nw = b.nw, nlyr = g.nlyr;
+    const size_t tid = size_t(w) * g.nlos + los, nt = size_t(nw) * g.nlos;
+    const double mu = g.pp_mu[los];
+    const double* lpl = g.lplos + (size_t(los) * NSTR + m) * NSTR;
+    const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
+    const double* lpc = g.lpcsz + (size_t(s) * NSTR + m) * NSTR;
+    const int first = g.pp_first[los];
+    const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * kPi);
+    K2bTask<N> t(g, b, s, m, los, w);
+    t.table_weights = false;
+    double Aab = cos(m * g.pp_azi[los]);  // attenuation to the observer x azimuth factor
+    double total = 0;
+    for (int p = 0; p < nlyr; ++p) {
+        double u[M2];
+        for (int i = 0; i < M2; ++i) u[i] = 0;
+        double contrib = 0;
+        if (p >= first) {
+            const double lf = (p == first) ? g.pp_lf[los] : 1.0;
+            RecView c{rec_at<N>(b, nlyr, p, w)};
+            const double* xs = xsol_at<N>(b, nlyr, p, w);
+            const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
+            const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
+            double lp[N], lm[N];
+            double q = 0;
+            for (int r = 0; r < N; ++r) { lp[r] = 0; lm[r] = 0; }
+            for (int l = m; l < NSTR; ++l) {
+                const double al = b.a[(size_t(p) * NSTR + l) * nw + w] * lpl[l];
+                const double sg = ((l - m) & 1) ? -1.0 : 1.0;
+                for (int r = 0; r < N; ++r) {
+                    const double tt = al * lpmu[r * NSTR + l];
+                    lm[r] += tt;
+                    lp[r] += sg * tt;
+                }
+                q += sg * al * lpc[l];
+            }
+            for (int r = 0; r < N; ++r) {
+                lp[r] *= 0.5 * om * g.wt[r];
+                lm[r] *= 0.5 * om * g.wt[r];
+            }
+            const double Q = g.include_ss ? q * fm * om : 0.0;
+            PPBeam E;
+            pp_beam_multiplier(mu, lf, th, T, sc, E);
+            double S = Q * E.v;
+            double dS[4];
+            dS[TH_TAU] = Q * E.d_th;
+            dS[TH_OM] = Q / om * E.v;
+            dS[TH_T] = Q * E.d_T;
+            dS[TH_SEC] = Q * E.d_sec;
+            for (int j = 0; j < N; ++j) {
+                double yp = 0, ym = 0, dyp = 0, dym = 0;
+                for (int r = 0; r < N; ++r) {
+                    const double wp = c(R::WP + r + N * j), wm = c(R::WM + r + N * j);
+                    const double dwp = c(R::DWP + r + N * j), dwm = c(R::DWM + r + N * j);
+                    yp += lp[r] * wp + lm[r] * wm;
+                    ym += lp[r] * wm + lm[r] * wp;
+                    dyp += lp[r] * dwp + lm[r] * dwm;
+                    dym += lp[r] * dwm + lm[r] * dwp;
+                }
+                dyp += yp / om;
+                dym += ym / om;
+                PPLosMult pm;
+                pp_los_multipliers(mu, lf, th, T, sc, c(R::K + j), E, pm);
+                const double L = xs[j], Mv = xs[N + j], dk = c(R::DK + j);
+                const double Ap = c(R::AP + j), Am = c(R::AM + j), dAp = c(R::DAP + j), dAm = c(R::DAM + j);
+                S += yp * pm.hp * L + ym * pm.hm * Mv + Ap * yp * pm.Dm + Am * ym * pm.Dp;
+                dS[TH_TAU] += yp * L * pm.hp_th + ym * Mv * pm.hm_th + Ap * yp * pm.Dm_th + Am * ym * pm.Dp_th;
+                dS[TH_T] += Ap * yp * pm.Dm_T + Am * ym * pm.Dp_T;
+                dS[TH_SEC] += Ap * yp * pm.Dm_sec + Am * ym * pm.Dp_sec;
+                dS[TH_OM] += dyp * (pm.hp * L + Ap * pm.Dm) + dym * (pm.hm * Mv + Am * pm.Dp) +
+                             yp * (pm.hp_k * dk * L + dAp * pm.Dm + Ap * pm.Dm_k * dk) +
+                             ym * (pm.hm_k * dk * Mv + dAm * pm.Dp + Am * pm.Dp_k * dk);
+                u[j] = Aab * yp * pm.hp;
+                u[N + j] = Aab * ym * pm.hm;
+            }
+            contrib = Aab * S;
+            if (b.derivs)
+                for (int th_i = 0; th_i < 4; ++th_i) b.grad[size_t(th_i * nlyr + p) * nt + tid] += Aab * dS[th_i];
+            Aab *= exp(-th * lf / mu);
+        }
+        total += contrib;
+        if (b.derivs) {
+            b.qlbuf[(size_t(p) * NSTR) * nt + tid] = contrib;
+            // forward substitution of A^T z = u:  y_p = Dinv^T u_p + SP yB_{p-1} (+ ground part below)
+            const double* dinv = dinv_at<N>(b, nlyr, p, w);
+            const double* ops = ops_at<N>(b, nlyr, p, w);
+            for (int i = 0; i < M2; ++i) {
+                double acc = 0;
+                for (int j = 0; j < M2; ++j) acc += dinv[j * M2 + i] * u[j];
+                for (int cidx = 0; cidx < N; ++cidx) acc += ops[O::SP + i * N + cidx] * t.carry[cidx];
+                b.z[(size_t(p) * M2 + i) * nt + tid] = acc;
+            }
+            if (p < nlyr - 1)
+                for (int i = 0; i < N; ++i) t.carry[i] = b.z[(size_t(p) * M2 + N + i) * nt + tid];
+        }
+    }
+    // Lambertian ground seen through the whole column (order 0 only)
+    double ground = 0;
+    if (m == 0) {
+        RecView c{rec_at<N>(b, nlyr, nlyr - 1, w)};
+        const double* xs = xsol_at<N>(b, nlyr, nlyr - 1, w);
+        const double th = b.tau[size_t(nlyr - 1) * nw + w], rho = b.albedo[w];
+        double ipb = 0;
+        for (int i = 0; i < N; ++i) {
+            double v = c(R::G + 2 * N + i);
+            for (int j = 0; j < N; ++j)
+                v += c(R::WP + i + N * j) * exp(-fabs(c(R::K + j)) * th) * xs[j] + c(R::WM + i + N * j) * xs[N + j];
+            ipb += g.wt[i] * g.mu[i] * v;
+        }
+        const double direct = g.include_ss ? g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w] : 0.0;
+        ground = Aab * rho * (2.0 * ipb + direct);
+        total += ground;
+        if (b.derivs) {
+            t.gw = Aab;
+            const double* ops = ops_at<N>(b, nlyr, nlyr - 1, w);
+            for (int i = 0; i < M2; ++i) b.z[(size_t(nlyr - 1) * M2 + i) * nt + tid] += t.gw * ops[O::UG + i];
+            // direct-beam part of the reflected intensity (the diffuse part is handled by K2bTask::gradient through gw)
+            b.grad[size_t(4 * nlyr) * nt + tid] += Aab * direct;
+            b.grad[size_t(4 * nlyr + 1) * nt + tid] += g.include_ss ? Aab * rho * g.csz[s] / kPi : 0.0;
+        }
+    }
+    b.radiance[tid] += total;
+    if (!b.derivs) return;
+    // attenuation of everything below a layer: dI/dtau_q = -(lf_q / mu) * (radiance entering the layer from below)
+    {
+        double below = ground;
+        for (int p = nlyr - 1; p >= first; --p) {
+            const double lf = (p == first) ? g.pp_lf[los] : 1.0;
+            b.grad[size_t(TH_TAU * nlyr + p) * nt + tid] -= lf / mu * below;
+            below += b.qlbuf[(size_t(p) * NSTR) * nt + tid];
+        }
+    }
     for (int i = 0; i < N; ++i) t.carry[i] = 0;
     for (int p = nlyr - 1; p >= 0; --p) t.backward(p, ops_at<N>(b, nlyr, p, w));
     for (int p = 0; p < nlyr; ++p) t.gradient(p, ops_at<N>(b, nlyr, p, w));

@@ -75,12 +75,19 @@ __global__ void __launch_bounds__(kBlock) kern_k4b(Geo g, Bufs b) {
     if (tid >= size_t(b.nw) * g.nlos) return;
     skd::k4b_los(g, b, int(tid % g.nlos), int(tid / g.nlos));
 }
-__global__ void __launch_bounds__(256) kern_init(Bufs b, const int* slot_is_ground, int nslot, size_t n_grad, size_t n_dnat) {
+// plane-parallel post-processing: one thread per (wavelength, line of sight), see skd::kpp_los
+template <int N> __global__ void __launch_bounds__(kBlock) kern_kpp(Geo g, Bufs b, int s, int m) {
+    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (tid >= size_t(b.nw) * g.nlos) return;
+    skd::kpp_los<N>(g, b, s, m, int(tid % g.nlos), int(tid / g.nlos));
+}
+__global__ void __launch_bounds__(256) kern_init(Bufs b, const int* slot_is_ground, int nslot, size_t n_grad, size_t n_dnat, size_t n_rad) {
     size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     size_t stride = size_t(gridDim.x) * blockDim.x;
     for (size_t i = tid; i < size_t(nslot) * b.nw; i += stride) b.conv_order[i] = slot_is_ground[i % nslot] ? 1 : 255;
     for (size_t i = tid; i < n_grad; i += stride) b.grad[i] = 0.0;
     for (size_t i = tid; i < n_dnat; i += stride) b.dnat[i] = 0.0;
+    for (size_t i = tid; i < n_rad; i += stride) b.radiance[i] = 0.0;
     for (size_t i = tid; i < size_t(b.nw); i += stride) b.status[i] = 0;
 }
 // radiance[w][los] and native weighting functions in the reference's user layout [altitude][w][los]
@@ -139,12 +146,12 @@ struct DeviceEngine::Impl {
     size_t scratch_bytes = 0;
 };
 
-DeviceEngine::DeviceEngine(const skgeo::DiscoGeometry& dg) : impl_(new Impl) {
+DeviceEngine::DeviceEngine(const skgeo::DiscoGeometry& dg, bool ss_in_do) : impl_(new Impl) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         throw std::runtime_error("sasktran2_amd: no HIP device available (the MI355X path has no CPU fallback)");
-    if (!dg.spherical_pp) throw std::runtime_error("sasktran2_amd: only spherical geometry is implemented on the device path");
     Impl& I = *impl_;
+    I.tab.include_ss = ss_in_do ? 1 : 0;
     I.tab.build(dg);
     const auto& t = I.tab;
     switch (t.N) { case 1: case 2: case 4: case 8: case 16: break; default: throw std::runtime_error("sasktran2_amd: num_streams must be one of 2, 4, 8, 16, 32"); }
@@ -162,6 +169,8 @@ DeviceEngine::DeviceEngine(const skgeo::DiscoGeometry& dg) : impl_(new Impl) {
     g.tab_slot = M.upload(t.tab_slot); g.tab_w = M.upload(t.tab_w); g.lp_start = M.upload(t.lp_start); g.lp_q = M.upload(t.lp_q);
     g.lp_angle = M.upload(t.lp_angle); g.lp_slot = M.upload(t.lp_slot); g.lp_w = M.upload(t.lp_w); g.g_start = M.upload(t.g_start);
     g.g_slot = M.upload(t.g_slot); g.g_sza = M.upload(t.g_sza); g.g_w = M.upload(t.g_w);
+    g.pp_mu = M.upload(t.pp_mu); g.pp_azi = M.upload(t.pp_azi); g.pp_first = M.upload(t.pp_first); g.pp_lf = M.upload(t.pp_lf);
+    g.lplos = M.upload(t.lplos);
     I.d_slot_is_ground = M.upload(t.slot_is_ground);
     I.d_active = M.alloc<int>(1);
     HIP_CHECK(hipEventCreate(&I.ev0));
@@ -260,11 +269,45 @@ static void run_chunk(DeviceEngine::Impl& I, hipStream_t st, int derivs) {
     {
         Timer t(I, st, "init");
         hipLaunchKernelGGL(kern_init, dim3(1024), dim3(256), 0, st, b, I.d_slot_is_ground, g.nslot, size_t(4 * g.nlyr + 2) * nt,
-                           size_t(2 * g.ngrid + 1) * nt);
+                           size_t(2 * g.ngrid + 1) * nt, nt);
     }
     {
         Timer t(I, st, "k0_layer_optics");
         hipLaunchKernelGGL(kern_k0, dim3(blocks(nw)), dim3(kBlock), 0, st, g, b);
+    }
+    if (g.pp_mode) {
+        // plane-parallel post-processing: every azimuth order is solved (do_source_planeparallel.cpp), K3 only fills the
+        // record's E / PPM entries that K2c reads (there is no diffuse table), KPP integrates the lines of sight
+        {
+            Timer t(I, st, "k0_transmission");
+            hipLaunchKernelGGL(kern_k0t, dim3(blocks(nw)), dim3(kBlock), 0, st, g, b, 0);
+        }
+        for (int m = 0; m < g.nstr; ++m) {
+            {
+                Timer t(I, st, "k1_layer_solution");
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, 0, m);
+            }
+            {
+                Timer t(I, st, "k2a_bvp");
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, 0, m);
+            }
+            {
+                Timer t(I, st, "k3_table_values");
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k3_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, 0, m);
+            }
+            if (derivs) {
+                Timer t(I, st, "k2c_adjoint_ops");
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, 0, m);
+            }
+            Timer t(I, st, "kpp_los");
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_kpp<N>), dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, 0, m);
+        }
+        if (derivs) {
+            Timer t(I, st, "k4a_chain");
+            hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, 0);
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
     }
     for (int s = 0; s < g.nsza; ++s) {
         {

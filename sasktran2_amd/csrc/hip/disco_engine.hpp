@@ -10,7 +10,8 @@ namespace skdev {
 class DeviceEngine {
   public:
     struct Impl;
-    explicit DeviceEngine(const skgeo::DiscoGeometry& dg);
+    // ss_in_do: the DO source carries the solar single-scatter term (plane-parallel post-processing only)
+    explicit DeviceEngine(const skgeo::DiscoGeometry& dg, bool ss_in_do = true);
     ~DeviceEngine();
     DeviceEngine(const DeviceEngine&) = delete;
     DeviceEngine& operator=(const DeviceEngine&) = delete;

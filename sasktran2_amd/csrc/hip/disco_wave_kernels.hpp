@@ -10,6 +10,20 @@
 
 #include "disco_core.hpp"
 
+// minimum waves per SIMD requested from the register allocator (second __launch_bounds__ argument)
+#ifndef SKD_WPE_K1
+#define SKD_WPE_K1 1
+#endif
+#ifndef SKD_WPE_K2A
+#define SKD_WPE_K2A 1
+#endif
+#ifndef SKD_WPE_K2C
+#define SKD_WPE_K2C 1
+#endif
+#ifndef SKD_WPE_K2B
+#define SKD_WPE_K2B 1
+#endif
+
 namespace skdev {
 
 using skd::Bufs;
@@ -20,7 +34,7 @@ using skd::Geo;
 // lanes; each group owns one layer per pass and keeps the layer's streams x streams matrices in LDS
 // (B+, B-, Cholesky factor, Jacobi work matrix, eigenvectors, ...).  Same mathematics as skd::k1_layer_solution.
 // -------------------------------------------------------------------------------------------------------------------
-template <int N> __global__ void __launch_bounds__(64) kern_k1_wave(Geo g, Bufs b, int s, int m) {
+template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_k1_wave(Geo g, Bufs b, int s, int m) {
     constexpr int NSTR = 2 * N, NN = N * N, LG = (N >= 16) ? 64 : 16, NG = 64 / LG;
     using R = skd::Rec<N>;
     const int w = blockIdx.x;
@@ -331,7 +345,7 @@ template <int N> __global__ void __launch_bounds__(64) kern_k1_wave(Geo g, Bufs 
 // K2a: block-tridiagonal BVP, factor + solve.  grid = wavelengths, block = 64.
 // LDS: current/previous layer W+-, k, G (ping-pong), augmented [D | I] for the Gauss-Jordan inverse, previous Dinv.
 // -------------------------------------------------------------------------------------------------------------------
-template <int N> __global__ void __launch_bounds__(64) kern_k2a_wave(Geo g, Bufs b, int s, int m) {
+template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2A) kern_k2a_wave(Geo g, Bufs b, int s, int m) {
     constexpr int M2 = 2 * N, LDA = 2 * M2 + 1, LDI = M2 + 1, NN = N * N;
     using R = skd::Rec<N>;
     const int w = blockIdx.x;
@@ -591,7 +605,7 @@ template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs 
 // K2c: LOS-independent adjoint operators of every layer (see skd::k2c_layer_ops for the definitions).
 // grid = wavelengths, block = 64; the layer record, its block inverse and the work matrices live in LDS.
 // -------------------------------------------------------------------------------------------------------------------
-template <int N> __global__ void __launch_bounds__(64) kern_k2c_wave(Geo g, Bufs b, int s, int m) {
+template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2C) kern_k2c_wave(Geo g, Bufs b, int s, int m) {
     constexpr int NSTR = 2 * N, M2 = 2 * N, NN = N * N;
     using R = skd::Rec<N>;
     using O = skd::Ops<N>;
@@ -738,7 +752,7 @@ template <int N> __global__ void __launch_bounds__(64) kern_k2c_wave(Geo g, Bufs
 // the K2c operators of each of the workgroup's wavelengths are staged in LDS and read by all of its LOS lanes as
 // broadcasts.  dynamic LDS: wpb * Ops::SIZE doubles.
 // -------------------------------------------------------------------------------------------------------------------
-template <int N> __global__ void __launch_bounds__(64) kern_k2b_wave(Geo g, Bufs b, int s, int m, int lpw, int wpb) {
+template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2B) kern_k2b_wave(Geo g, Bufs b, int s, int m, int lpw, int wpb) {
     using O = skd::Ops<N>;
     extern __shared__ double smem[];
     const int lane = threadIdx.x, nlyr = g.nlyr;

@@ -17,6 +17,11 @@ struct GeoTables {
     std::vector<int> lp_start, lp_q, lp_angle, lp_slot, g_start, g_slot, g_sza;
     std::vector<double> lp_w, g_w;
     std::vector<int> slot_is_ground;  // [nslot]
+    // plane-parallel post-processing
+    int pp_mode = 0;
+    int include_ss = 1;  // set by the engine from single_scatter_source before the tables are uploaded
+    std::vector<double> pp_mu, pp_azi, pp_lf, lplos;
+    std::vector<int> pp_first;
 
     void build(const skgeo::DiscoGeometry& G) {
         nstr = G.nstr; N = nstr / 2; nlyr = G.nlyr; ngrid = G.ngrid; nlos = G.nlos; nsza = G.nsza; nangle = G.nangle;
@@ -44,6 +49,8 @@ struct GeoTables {
                     ++c;
                 }
         }
+        pp_mode = G.spherical_pp ? 0 : 1;
+        if (pp_mode) { build_plane_parallel(G); return; }
         // slots
         std::vector<int> point_slot(G.need_point.size(), -1), ground_slot(G.need_ground.size(), -1);
         npoint = 0;
@@ -120,6 +127,33 @@ struct GeoTables {
         }
     }
 
+    // plane-parallel mode: no diffuse table and no traced rays; every line of sight is (cos zenith, azimuth, observer altitude).
+    // The observer layer / layer fraction follow OpticalLayerArray::opticalDepthAt and the loop of
+    // DOSourcePlaneParallelPostProcessing::calculate (do_source_planeparallel.cpp:19-218).
+    void build_plane_parallel(const skgeo::DiscoGeometry& G) {
+        npoint = nground = nslot = nq_total = 0;
+        pt_start.assign(size_t(nsza) * nlyr + 1, 0);
+        gpt_start.assign(nsza + 1, 0);
+        ray_qstart.assign(nlos + 1, 0); ray_ground.assign(nlos, 0); ray_gsaa.assign(nlos, 0.0);
+        rl_od_start.assign(1, 0); rl_ssa_start.assign(1, 0); rl_tab_start.assign(1, 0);
+        g_start.assign(nlos + 1, 0);
+        lp_start.assign(size_t(nlos) * nsza * nlyr + 1, 0);
+        lplos = G.lp_los;
+        pp_mu.resize(nlos); pp_azi.resize(nlos); pp_lf.assign(nlos, 1.0); pp_first.assign(nlos, 0);
+        for (int l = 0; l < nlos; ++l) {
+            const auto& los = G.pp_los[l];
+            pp_mu[l] = los.coszenith;
+            pp_azi[l] = los.azimuth;
+            const double alt = los.observer_altitude;
+            if (alt < 0 || alt > G.ceil_h[0]) continue;  // observer outside the atmosphere: the whole column is seen
+            int pl = nlyr - 1;
+            for (int p = 0; p < nlyr; ++p)
+                if (alt <= G.ceil_h[p] && alt >= G.floor_h[p]) { pl = p; break; }
+            pp_first[l] = pl;
+            pp_lf[l] = 1.0 - (G.ceil_h[pl] - alt) / (G.ceil_h[pl] - G.floor_h[pl]);
+        }
+    }
+
     // view over host memory (emulation) -- the HIP driver builds the same struct over device copies
     skd::Geo host_view() const {
         skd::Geo g{};
@@ -135,11 +169,14 @@ struct GeoTables {
         g.tab_slot = tab_slot.data(); g.tab_w = tab_w.data(); g.lp_start = lp_start.data(); g.lp_q = lp_q.data();
         g.lp_angle = lp_angle.data(); g.lp_slot = lp_slot.data(); g.lp_w = lp_w.data(); g.g_start = g_start.data();
         g.g_slot = g_slot.data(); g.g_sza = g_sza.data(); g.g_w = g_w.data();
+        g.pp_mu = pp_mu.data(); g.pp_azi = pp_azi.data(); g.pp_first = pp_first.data(); g.pp_lf = pp_lf.data(); g.lplos = lplos.data();
         return g;
     }
     void fill_scalars(skd::Geo& g) const {
         g.nstr = nstr; g.N = N; g.nlyr = nlyr; g.ngrid = ngrid; g.nlos = nlos; g.nsza = nsza; g.nangle = nangle;
         g.npoint = npoint; g.nground = nground; g.nslot = nslot; g.nq_total = nq_total;
+        g.pp_mode = pp_mode;
+        g.include_ss = include_ss;
     }
 };
 

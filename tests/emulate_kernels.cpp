@@ -20,6 +20,30 @@ template <int N>
 void run_n(const skd::Geo& g, skd::Bufs& b, int derivs) {
     const int nw = b.nw;
     for (int w = 0; w < nw; ++w) skd::k0_layer_optics(g, b, w);
+    if (g.pp_mode) {
+        // plane-parallel launch order of the HIP driver: every azimuth order, K3 only for the record's E / PPM entries
+        for (size_t i = 0; i < size_t(nw) * g.nlos; ++i) b.radiance[i] = 0;
+        for (int w = 0; w < nw; ++w) {
+            skd::k0_transmission(g, b, 0, w);
+            b.norders[w] = g.nstr;
+        }
+        for (int m = 0; m < g.nstr; ++m) {
+            for (int w = 0; w < nw; ++w)
+                for (int p = 0; p < g.nlyr; ++p) skd::k1_layer_solution<N>(g, b, 0, m, p, w);
+            for (int w = 0; w < nw; ++w) skd::k2a_bvp<N>(g, b, 0, m, w);
+            for (int w = 0; w < nw; ++w)
+                for (int p = 0; p < g.nlyr; ++p) skd::k3_table_values<N>(g, b, 0, m, p, w);
+            if (derivs)
+                for (int w = 0; w < nw; ++w)
+                    for (int p = 0; p < g.nlyr; ++p) skd::k2c_layer_ops<N>(g, b, 0, m, p, w);
+            for (int w = 0; w < nw; ++w)
+                for (int l = 0; l < g.nlos; ++l) skd::kpp_los<N>(g, b, 0, m, l, w);
+        }
+        if (derivs)
+            for (int w = 0; w < nw; ++w)
+                for (int l = 0; l < g.nlos; ++l) skd::k4a_chain(g, b, 0, l, w);
+        return;
+    }
     for (int s = 0; s < g.nsza; ++s) {
         for (int w = 0; w < nw; ++w) {
             skd::k0_transmission(g, b, s, w);
@@ -59,7 +83,7 @@ void run_n(const skd::Geo& g, skd::Bufs& b, int derivs) {
 
 extern "C" {
 void* emu_create(double cos_sza, double saa, double earth_radius, const double* altitudes, int ngrid, int interp_method,
-                 int geotype, int nstr, int num_sza, int nrays, const int* ray_kinds, const double* ray_params) {
+                 int geotype, int nstr, int num_sza, int nrays, const int* ray_kinds, const double* ray_params, int ss_in_do) {
     try {
         auto h = std::make_unique<Handle>();
         h->geo = skgeo::Geometry1D(cos_sza, saa, earth_radius, std::vector<double>(altitudes, altitudes + ngrid),
@@ -74,7 +98,7 @@ void* emu_create(double cos_sza, double saa, double earth_radius, const double* 
             specs[i].cos_viewing_zenith = ray_params[4 * i + 3];
         }
         skgeo::build_disco_geometry(h->geo, specs, nstr, num_sza, h->dg);
-        if (!h->dg.spherical_pp) throw std::runtime_error("emulation covers the spherical path only");
+        h->tab.include_ss = ss_in_do;
         h->tab.build(h->dg);
         return h.release();
     } catch (const std::exception& e) {

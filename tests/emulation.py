@@ -26,7 +26,7 @@ def lib():
         L = ctypes.CDLL(str(so))
         L.emu_create.restype = ctypes.c_void_p
         L.emu_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_int, ctypes.c_int,
-                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp]
+                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int]
         L.emu_destroy.argtypes = [ctypes.c_void_p]
         L.emu_run.restype = ctypes.c_int
         L.emu_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int, _dp,
@@ -46,7 +46,8 @@ def run_emulated(s, derivatives=True):
     kinds = np.ascontiguousarray([r[0] for r in rays], dtype=np.int32)
     params = np.ascontiguousarray([[r[1], r[2], r[3], r[4]] for r in rays], dtype=np.float64)
     h = lib().emu_create(g["cos_sza"], g["saa"], g["earth_radius"], _p(alt), len(alt), g["interp_method"], g["geotype"],
-                         s["config"]["nstr"], s["config"]["num_sza"], len(rays), kinds.ctypes.data_as(_ip), _p(params))
+                         s["config"]["nstr"], s["config"]["num_sza"], len(rays), kinds.ctypes.data_as(_ip), _p(params),
+                         int(s["config"].get("ss_in_do", True)))
     assert h
     try:
         k = np.asfortranarray(s["extinction"], dtype=np.float64)

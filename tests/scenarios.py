@@ -88,3 +88,24 @@ def planeparallel_case(case: dict):
                     geotype=GEO_PLANEPARALLEL)
     return dict(geometry=geometry, config=dict(nstr=nstr, num_sza=1), rays=rays, extinction=k, ssa=w, leg=leg,
                 albedo=np.array([case["albedo"]]), expected=np.array(case["expected"]) / case["sun"]["direct"])
+
+
+def nadir_c1(num_wavelengths: int = 100, nstr: int = 2, observer_altitude: float = 200_000.0):
+    """BASELINE.json configs[0]: plane-parallel nadir, 2-stream DISCO, 20 layers, 100 wavelengths,
+    total optical depth swept over [0.05, 2], omega = 0.9, Rayleigh-like a = [1, 0, 0.5], albedo 0.3."""
+    alt = np.linspace(0.0, 100_000.0, 21)
+    csz = 0.6
+    rays = [(GROUND_VIEWING_SOLAR, csz, np.deg2rad(30.0), observer_altitude, 0.8),
+            (GROUND_VIEWING_SOLAR, csz, np.deg2rad(60.0), observer_altitude, 0.92)]
+    nw = num_wavelengths
+    shape = np.exp(-alt / 8_000.0)
+    column = np.trapezoid(shape, alt)
+    k = shape[:, None] / column * np.linspace(0.05, 2.0, nw)[None, :]
+    ssa = np.full((alt.size, nw), 0.9)
+    nleg = max(nstr, 3)
+    leg = np.zeros((nleg, alt.size, nw))
+    leg[0], leg[2] = 1.0, 0.5
+    geometry = dict(cos_sza=csz, saa=0.0, earth_radius=6_372_000.0, altitudes=alt, interp_method=INTERP_LINEAR,
+                    geotype=GEO_PLANEPARALLEL)
+    return dict(geometry=geometry, config=dict(nstr=nstr, num_sza=1), rays=rays, extinction=k, ssa=ssa, leg=leg,
+                albedo=np.full(nw, 0.3))

@@ -138,3 +138,31 @@ def test_weighting_functions_match_gpu_finite_differences():
             fd = (run_product(plus, False, engine=eng)["radiance"] - run_product(minus, False, engine=eng)["radiance"]) / (2 * h[:, None])
             scale = np.abs(base[key]).max(axis=2)
             assert np.max(np.abs(fd - base[key][:, :, q]) / scale) < 1e-5, (name, q)
+
+
+# ---- plane-parallel post-processing on the device (BASELINE configs[0])
+import json
+from pathlib import Path
+
+GOLDEN = json.loads((Path(__file__).parent / "golden" / "do_scalar_planeparallel.json").read_text())
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=[c["name"] for c in GOLDEN["cases"]])
+def test_planeparallel_known_answers_on_device(case):
+    # cpp/lib/tests/sktran_disco/legacy/test_scalar.cpp: |radiance - expected| < 1e-8 (1e-6 for SSA = 1), through the C ABI
+    s = sc.planeparallel_case(case)
+    got = run_product(s, derivatives=False)
+    assert np.max(np.abs(got["radiance"][0] - s["expected"])) < case["tolerance"]
+
+
+@pytest.mark.parametrize("idx", [0, 8, 14, 17, 18])
+def test_planeparallel_weighting_functions_on_device(idx):
+    s = sc.planeparallel_case(GOLDEN["cases"][idx])
+    assert_parity(run_product(s), run_oracle(s, derivatives=True))
+
+
+@pytest.mark.parametrize("nstr,observer", [(2, 200_000.0), (4, 200_000.0), (8, 37_300.0)])
+def test_c1_nadir_matches_oracle(nstr, observer):
+    # BASELINE configs[0]: 1D nadir, 2-stream DISCO, 20 layers, 100 wavelengths
+    s = sc.nadir_c1(num_wavelengths=100, nstr=nstr, observer_altitude=observer)
+    assert_parity(run_product(s), run_oracle(s, derivatives=True))

@@ -49,3 +49,49 @@ def test_conservative_scattering_radiance():
     s["ssa"][:] = 1.0
     o, e = run_oracle(s), run_emulated(s)
     np.testing.assert_allclose(e["radiance"], o["radiance"], rtol=2e-6)
+
+
+# ---- plane-parallel post-processing (kpp_los) against the reference's own known answers and the oracle
+import json
+from pathlib import Path
+
+GOLDEN = json.loads((Path(__file__).parent / "golden" / "do_scalar_planeparallel.json").read_text())
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=[c["name"] for c in GOLDEN["cases"]])
+def test_planeparallel_known_answers_emulated(case):
+    # cpp/lib/tests/sktran_disco/legacy/test_scalar.cpp: |radiance - expected| < 1e-8 (1e-6 for SSA=1)
+    s = sc.planeparallel_case(case)
+    e = run_emulated(s, derivatives=False)
+    assert np.all(e["status"] == 0)
+    assert np.max(np.abs(e["radiance"][0] - s["expected"])) < case["tolerance"]
+
+
+@pytest.mark.parametrize("idx", [0, 3, 8, 14, 17])
+def test_planeparallel_weighting_functions_emulated(idx):
+    s = sc.planeparallel_case(GOLDEN["cases"][idx])
+    o, e = run_oracle(s, derivatives=True), run_emulated(s)
+    np.testing.assert_allclose(e["radiance"], o["radiance"], rtol=1e-8)
+    for k in ("d_extinction", "d_ssa"):
+        scale = np.abs(o[k]).max(axis=2, keepdims=True)
+        assert np.max(np.abs(e[k] - o[k]) / scale) < 1e-7, k
+    np.testing.assert_allclose(e["d_albedo"], o["d_albedo"], rtol=1e-7, atol=1e-14)
+
+
+@pytest.mark.parametrize("nstr,observer", [(2, 200_000.0), (4, 200_000.0), (8, 37_300.0), (2, 50_000.0)])
+def test_c1_nadir_emulated(nstr, observer):
+    # BASELINE configs[0]; the observer inside the atmosphere exercises the partial-layer branch
+    s = sc.nadir_c1(num_wavelengths=5, nstr=nstr, observer_altitude=observer)
+    check(s, rtol_i=1e-9, rtol_wf=1e-7)
+
+
+def test_planeparallel_without_single_scatter_emulated():
+    s = sc.nadir_c1(num_wavelengths=3, nstr=4)
+    s["config"]["ss_in_do"] = False
+    from tests.test_oracle_golden import make_oracle
+    o = make_oracle(s, ss_in_do=False).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
+    e = run_emulated(s)
+    np.testing.assert_allclose(e["radiance"], o["radiance"], rtol=1e-9)
+    np.testing.assert_allclose(e["d_albedo"], o["d_albedo"], rtol=1e-7)
+    for k in ("d_extinction", "d_ssa"):
+        assert np.max(np.abs(e[k] - o[k]) / np.abs(o[k]).max(axis=2, keepdims=True)) < 1e-7
