@@ -1006,6 +1006,10 @@ template <int N> struct K2bTask {
 
     // Legendre-space LOS weights of a layer: ql[l] = sum_entries srcw * w_e * cos(m azi) * P_l(angle)
     SKD_HD void los_weights(int p, double* ql) const {
+#ifdef SKD_EXP_NOQL
+        for (int l = 0; l < NSTR; ++l) ql[l] = 1e-3 * (l + p);
+        return;
+#endif
         for (int l = 0; l < NSTR; ++l) ql[l] = 0;
         const int base = (los * g.nsza + s) * nlyr + p;
         for (int t = g.lp_start[base]; t < g.lp_start[base + 1]; ++t) {

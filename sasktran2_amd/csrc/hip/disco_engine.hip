@@ -212,8 +212,9 @@ size_t DeviceEngine::bytes_per_wavelength() const {
     d += size_t(t.nq_total) * 3 + nlos;                      // od, omloc, srcw, att_total
     d += nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N;  // rec, dinv, xsol
     d += nstr * size_t(t.nslot);                             // J
-    d += nlyr * (8 * N * N + 26 * N + 5) + nlyr * nstr * nlos;  // ops, qlbuf
-    d += nlyr * 2 * N * nlos + (4 * nlyr + 2) * nlos + (2 * t.ngrid + 1) * nlos + 2 * nlos;  // z, grad, dnat, radiance, los_od
+    const size_t nlos_pad = (nlos + 15) / 16 * 16;
+    d += nlyr * (8 * N * N + 26 * N + 5) + nlyr * nstr * nlos_pad;  // ops, qlbuf
+    d += nlyr * 2 * N * nlos_pad + (4 * nlyr + 2) * nlos + (2 * t.ngrid + 1) * nlos + 2 * nlos;  // z, grad, dnat, radiance, los_od
     return d * sizeof(double) + size_t(t.nslot) + 3 * sizeof(int);
 }
 
@@ -223,6 +224,7 @@ void DeviceEngine::ensure_scratch(int nw) {
     I.scratch_mem.release();
     const auto& t = I.tab;
     const size_t N = t.N, nlyr = t.nlyr, nstr = t.nstr, nlos = t.nlos, W = nw, nt = W * nlos;
+    const size_t nlos_pad = (nlos + 15) / 16 * 16;  // the 16-stream sweeps keep whole 16-LOS tiles
     DevMem& M = I.scratch_mem;
     Bufs& b = I.b;
     b.tau = M.alloc<double>(nlyr * W); b.om = M.alloc<double>(nlyr * W); b.kbar = M.alloc<double>(nlyr * W);
@@ -232,8 +234,8 @@ void DeviceEngine::ensure_scratch(int nw) {
     b.rec = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W); b.dinv = M.alloc<double>(nlyr * 4 * N * N * W);
     b.xsol = M.alloc<double>(nlyr * 2 * N * W); b.J = M.alloc<double>(nstr * size_t(t.nslot) * W);
     b.conv_order = M.alloc<uint8_t>(size_t(t.nslot) * W); b.notconv = M.alloc<int>(W); b.norders = M.alloc<int>(W);
-    b.status = M.alloc<int>(W); b.z = M.alloc<double>(nlyr * 2 * N * nt);
-    b.ops = M.alloc<double>(nlyr * (8 * N * N + 26 * N + 5) * W); b.qlbuf = M.alloc<double>(nlyr * nstr * nt); b.grad = M.alloc<double>((4 * nlyr + 2) * nt);
+    b.status = M.alloc<int>(W); b.z = M.alloc<double>(nlyr * 2 * N * W * nlos_pad);
+    b.ops = M.alloc<double>(nlyr * (8 * N * N + 26 * N + 5) * W); b.qlbuf = M.alloc<double>(nlyr * nstr * W * nlos_pad); b.grad = M.alloc<double>((4 * nlyr + 2) * nt);
     b.dnat = M.alloc<double>((2 * t.ngrid + 1) * nt); b.radiance = M.alloc<double>(nt); b.los_od = M.alloc<double>(nt);
     I.chunk_capacity = nw;
     I.scratch_bytes = bytes_per_wavelength() * W;
@@ -330,14 +332,27 @@ static void run_chunk(DeviceEngine::Impl& I, hipStream_t st, int derivs) {
             if (derivs) {
                 int lpw = 1;
                 while (lpw < g.nlos && lpw < 64) lpw *= 2;
-                {
-                    Timer t2(I, st, "k2c_adjoint_ops");
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                if constexpr (N == 8) {
+                    // 16 streams: adjoint operators and sweeps as FP64 matrix-core products (v_mfma_f64_16x16x4_f64)
+                    {
+                        Timer t2(I, st, "k2c_adjoint_ops");
+                        hipLaunchKernelGGL(kern_k2c_mfma8, dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                    }
+                    Timer t(I, st, "k2b_adjoint");
+                    if (g.nlos > 16)
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<2>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                    else
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<1>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                } else {
+                    {
+                        Timer t2(I, st, "k2c_adjoint_ops");
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                    }
+                    const size_t per_w = skd::Ops<N>::SIZE * sizeof(double);
+                    const int wpb = std::max(1, std::min<int>(64 / lpw, int(49152 / per_w)));
+                    Timer t(I, st, "k2b_adjoint");
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_wave<N>), dim3(unsigned((nw + wpb - 1) / wpb)), dim3(64), wpb * per_w, st, g, b, s, m, lpw, wpb);
                 }
-                const size_t per_w = skd::Ops<N>::SIZE * sizeof(double);
-                const int wpb = std::max(1, std::min<int>(64 / lpw, int(49152 / per_w)));
-                Timer t(I, st, "k2b_adjoint");
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_wave<N>), dim3(unsigned((nw + wpb - 1) / wpb)), dim3(64), wpb * per_w, st, g, b, s, m, lpw, wpb);
             }
             int active = 0;
             {

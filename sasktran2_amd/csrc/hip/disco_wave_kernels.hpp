@@ -761,6 +761,9 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2B) kern_k2b_wav
     const bool w_ok = (sub < wpb) && (w_lane < b.nw) && (m < b.norders[w_lane < b.nw ? w_lane : 0]);
     double* myOps = smem + size_t(sub < wpb ? sub : 0) * O::SIZE;
     auto stage = [&](int p, int first, int count) {
+#ifdef SKD_EXP_NOSTAGE
+        if (p != 0 && p != nlyr - 1) return;
+#endif
         __syncthreads();
         if (w_ok) {
             const double* src = skd::ops_at<N>(b, nlyr, p, w_lane);
@@ -785,6 +788,296 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2B) kern_k2b_wav
             stage(p, O::DI, O::SIZE - O::DI);
             if (active) t.gradient(p, myOps);
         }
+    }
+}
+
+// ===================================================================================================================
+// 16-stream path (N = 8, 2N = 16): the adjoint operators and sweeps as 16 x 16 FP64 matrix-core products.
+//   v_mfma_f64_16x16x4_f64 operand maps (gfx950): A: lane l holds A[row = l & 15][k = l >> 4]; B: lane l holds
+//   B[k = l >> 4][col = l & 15]; C/D: register r of lane l holds D[row = (l >> 4) + 4 r][col = l & 15].
+//   Consequences used below: (1) the C/D image of X^T is the A-operand image of X, k-step r in register r;
+//   (2) rows 8..15 (0..7) of a C/D tile are registers 2,3 (0,1) and are the B operand of the next product as they are.
+// ===================================================================================================================
+typedef double mf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mf4 mfma16(double a, double bb, mf4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0); }
+
+// K2c for N = 8.  Same operators as skd::k2c_layer_ops; FP, SP and BP are stored as ready-made A-operand images
+// (FP: k-step r at [FP + 64 r + lane], r < 4;  SP / BP: [SP + 64 r + lane], [BP + 64 r + lane], r < 2) for kern_k2b_mfma8.
+//   FP^T = F^T Dinv  and  [SP | BP]^T = [SupT | SubT]^T Dinv  are two chains of four matrix-core products.
+__global__ void __launch_bounds__(64) kern_k2c_mfma8(Geo g, Bufs b, int s, int m) {
+    constexpr int N = 8, NSTR = 16, M2 = 16;
+    using R = skd::Rec<N>;
+    using O = skd::Ops<N>;
+    const int w = blockIdx.x;
+    if (m >= b.norders[w]) return;
+    const int lane = threadIdx.x, nw = b.nw, nlyr = g.nlyr;
+    __shared__ double sRec[R::SIZE];
+    __shared__ double sXs[M2], sa[NSTR];
+    __shared__ double sF[M2 * NSTR], sST[M2 * M2], sH[5 * N * NSTR], sTmp[M2], sIpb[N], sDIpb[4 * N];
+    const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
+    const double rho = (m == 0) ? b.albedo[w] : 0.0;
+    for (int p = 0; p < nlyr; ++p) {
+        const bool last = (p == nlyr - 1);
+        const double* rec = skd::rec_at<N>(b, nlyr, p, w);
+        const double* dg = skd::dinv_at<N>(b, nlyr, p, w);
+        const double* xs = skd::xsol_at<N>(b, nlyr, p, w);
+        double* o = skd::ops_at<N>(b, nlyr, p, w);
+        for (int i = lane; i < R::SIZE; i += 64) sRec[i] = rec[i];
+        if (lane < M2) sXs[lane] = xs[lane];
+        if (lane < NSTR) sa[lane] = (lane >= m) ? b.a[(size_t(p) * NSTR + lane) * nw + w] : 0.0;
+        double dinv_b[4];  // B operand of both chains: Dinv[4 kk + (lane >> 4)][lane & 15] = dg[64 kk + lane]
+        for (int kk = 0; kk < 4; ++kk) dinv_b[kk] = dg[64 * kk + lane];
+        const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w];
+        __syncthreads();
+        // phase A: F = [UL; UM] and the per-(j,l) pieces of the direct-dependence rows
+        for (int idx = lane; idx < N * NSTR; idx += 64) {
+            const int j = idx / NSTR, l = idx % NSTR;
+            const double sg = ((l - m) & 1) ? -1.0 : 1.0;
+            double yp = 0, ym = 0, dyp = 0, dym = 0;
+            for (int r = 0; r < N; ++r) {
+                const double cm = 0.5 * g.wt[r] * om * sa[l] * lpmu[r * NSTR + l];
+                const double wp = sRec[R::WP + r + N * j], wm = sRec[R::WM + r + N * j];
+                const double dwp = sRec[R::DWP + r + N * j] + wp / om, dwm = sRec[R::DWM + r + N * j] + wm / om;
+                yp += cm * (sg * wp + wm);
+                ym += cm * (sg * wm + wp);
+                dyp += cm * (sg * dwp + dwm);
+                dym += cm * (sg * dwm + dwp);
+            }
+            skd::PPMult pm;
+            skd::ppm_load(&sRec[R::PPM + 14 * j], pm);
+            sF[j * NSTR + l] = yp * pm.hp / om;
+            sF[(N + j) * NSTR + l] = ym * pm.hm / om;
+            const double L = sXs[j], Mv = sXs[N + j], dk = sRec[R::DK + j];
+            const double Ap = sRec[R::AP + j], Am = sRec[R::AM + j], dAp = sRec[R::DAP + j], dAm = sRec[R::DAM + j];
+            const double tL = pm.hp * L + Ap * pm.Dm, tM = pm.hm * Mv + Am * pm.Dp;
+            sH[(4 * N + j) * NSTR + l] = yp * tL + ym * tM;
+            sH[(skd::TH_TAU * N + j) * NSTR + l] = yp * (pm.hp_tau * L + Ap * pm.Dm_tau) + ym * (pm.hm_tau * Mv + Am * pm.Dp_tau);
+            sH[(skd::TH_SEC * N + j) * NSTR + l] = yp * Ap * pm.Dm_sec + ym * Am * pm.Dp_sec;
+            sH[(skd::TH_T * N + j) * NSTR + l] = (T != 0) ? (yp * Ap * pm.Dm + ym * Am * pm.Dp) / T : 0.0;
+            sH[(skd::TH_OM * N + j) * NSTR + l] = dyp * tL + dym * tM + yp * (pm.hp_k * dk * L + dAp * pm.Dm + Ap * pm.Dm_k * dk) +
+                                                  ym * (pm.hm_k * dk * Mv + dAm * pm.Dp + Am * pm.Dp_k * dk);
+        }
+        // [SupT | SubT] (16 x 16, row j): SupT[j][c] = W-(c,j), SupT[N+j][c] = W+(c,j) E_j ; SubT[j][c] = W+(c,j) E_j, SubT[N+j][c] = W-(c,j)
+        for (int idx = lane; idx < M2 * M2; idx += 64) {
+            const int jj = idx / M2, cc = idx % M2;
+            const int j = jj % N, c = cc % N;
+            const double wp = sRec[R::WP + c + N * j], wm = sRec[R::WM + c + N * j], E = sRec[R::E + j];
+            const bool upper = (jj < N), sup = (cc < N);
+            sST[idx] = (upper == sup) ? wm : wp * E;
+        }
+        // edge-intensity derivatives at fixed (L, M): lanes (i, e)
+        for (int idx = lane; idx < 4 * N; idx += 64) {
+            const int i = idx / 4, e = idx % 4;
+            double d_tau = 0, d_om = 0, ipb_i = sRec[R::G + 2 * N + i];
+            for (int j = 0; j < N; ++j) {
+                const double wp = sRec[R::WP + i + N * j], wm = sRec[R::WM + i + N * j];
+                const double dwp = sRec[R::DWP + i + N * j], dwm = sRec[R::DWM + i + N * j];
+                const double E = sRec[R::E + j], L = sXs[j], Mv = sXs[N + j];
+                const double dE_tau = -sRec[R::K + j] * E, dE_om = -sRec[R::DK + j] * th * E;
+                if (e == 0) { d_tau += wm * dE_tau * Mv; d_om += dwp * L + dwm * E * Mv + wm * dE_om * Mv; }
+                if (e == 1) { d_tau += wp * dE_tau * Mv; d_om += dwm * L + dwp * E * Mv + wp * dE_om * Mv; }
+                if (e == 2) { d_tau += wp * dE_tau * L; d_om += dwp * E * L + wp * dE_om * L + dwm * Mv; ipb_i += wp * E * L + wm * Mv; }
+                if (e == 3) { d_tau += wm * dE_tau * L; d_om += dwm * E * L + wm * dE_om * L + dwp * Mv; }
+            }
+            const double v_tau = sRec[R::DG + (skd::TH_TAU * 4 + e) * N + i] + d_tau;
+            const double v_om = sRec[R::DG + (skd::TH_OM * 4 + e) * N + i] + d_om;
+            const double v_T = sRec[R::DG + (skd::TH_T * 4 + e) * N + i], v_sec = sRec[R::DG + (skd::TH_SEC * 4 + e) * N + i];
+            o[O::DI + (skd::TH_TAU * 4 + e) * N + i] = v_tau;
+            o[O::DI + (skd::TH_OM * 4 + e) * N + i] = v_om;
+            o[O::DI + (skd::TH_T * 4 + e) * N + i] = v_T;
+            o[O::DI + (skd::TH_SEC * 4 + e) * N + i] = v_sec;
+            if (e == 2) {
+                sIpb[i] = g.wt[i] * g.mu[i] * ipb_i;
+                sDIpb[skd::TH_TAU * N + i] = g.wt[i] * g.mu[i] * v_tau;
+                sDIpb[skd::TH_OM * N + i] = g.wt[i] * g.mu[i] * v_om;
+                sDIpb[skd::TH_T * N + i] = g.wt[i] * g.mu[i] * v_T;
+                sDIpb[skd::TH_SEC * N + i] = g.wt[i] * g.mu[i] * v_sec;
+            }
+        }
+        // ground part of u
+        if (lane < N) {
+            double sp = 0, sm = 0;
+            if (last && m == 0)
+                for (int i = 0; i < N; ++i) {
+                    sp += g.mu[i] * g.wt[i] * sRec[R::WP + i + N * lane];
+                    sm += g.mu[i] * g.wt[i] * sRec[R::WM + i + N * lane];
+                }
+            sTmp[lane] = 2.0 * rho * sp * sRec[R::E + lane];
+            sTmp[N + lane] = 2.0 * rho * sm;
+        }
+        __syncthreads();
+        // phase B: the two matrix-core chains
+        {
+            mf4 x1 = {0, 0, 0, 0}, x2 = {0, 0, 0, 0};
+            for (int kk = 0; kk < 4; ++kk) {
+                x1 = mfma16(sF[64 * kk + lane], dinv_b[kk], x1);    // (F^T Dinv)[l][i] = FP[i][l]
+                x2 = mfma16(sST[64 * kk + lane], dinv_b[kk], x2);   // rows 0..7: SP^T, rows 8..15: BP^T
+            }
+            for (int r = 0; r < 4; ++r) o[O::FP + 64 * r + lane] = x1[r];
+            o[O::SP + lane] = x2[0];
+            o[O::SP + 64 + lane] = x2[1];
+            o[O::BP + lane] = x2[2];
+            o[O::BP + 64 + lane] = x2[3];
+        }
+        // HD rows, UG, GD, IPB
+        for (int idx = lane; idx < 4 * NSTR; idx += 64) {
+            const int t = idx / NSTR, l = idx % NSTR;
+            double acc = 0, val = 0;
+            for (int j = 0; j < N; ++j) {
+                acc += sH[(t * N + j) * NSTR + l];
+                val += sH[(4 * N + j) * NSTR + l];
+            }
+            acc /= om;
+            if (t == skd::TH_OM) acc -= val / (om * om);
+            o[O::HD + idx] = acc;
+        }
+        if (lane < M2) {
+            double t = 0;
+            if (last && m == 0)
+                for (int j = 0; j < M2; ++j) t += dg[j * M2 + lane] * sTmp[j];
+            o[O::UG + lane] = t;
+        }
+        if (lane < 4) {
+            double sacc = 0;
+            if (last && m == 0)
+                for (int i = 0; i < N; ++i) sacc += sDIpb[lane * N + i];
+            o[O::GD + lane] = 2.0 * rho * sacc;
+        }
+        if (lane == 4) {
+            double ipb = 0;
+            for (int i = 0; i < N; ++i) ipb += sIpb[i];
+            o[O::IPB] = ipb;
+        }
+        __syncthreads();
+    }
+}
+
+// K2b for N = 8: one wavefront per wavelength, 16 lines of sight per matrix-core tile (lane & 15 = line of sight).
+//   forward   Y_p = FP QL_p + SP Y_{p-1}[8:16]            (6 products / tile;  + HD QL_p, 4 products, reduced-gradient part)
+//   backward  Z_p = Y_p - BP Z_{p+1}[0:8]                  (2 products / tile)
+//   gradient  G_p = DI_p . [zA_p, zB_{p-1}, -zA_{p+1}, -zB_p] + HD QL_p   (8 products / tile, rows 0..3 = tau, omega, T, sec;
+//             rows 4..7 carry sum_i zB_i for the ground terms)
+//   Y / Z tiles and the HD part are kept in HBM between the sweeps in their C/D register images
+//   (b.z: [w][p][tile][4][64], b.qlbuf: [w][p][tile][64]); nothing goes through LDS.
+template <int TILES> __global__ void __launch_bounds__(64) kern_k2b_mfma8(Geo g, Bufs b, int s, int m) {
+    constexpr int N = 8, NSTR = 16;
+    using O = skd::Ops<N>;
+    const int w = blockIdx.x;
+    if (m >= b.norders[w]) return;
+    const int lane = threadIdx.x, col = lane & 15, q = lane >> 4, nw = b.nw, nlyr = g.nlyr, nlos = g.nlos;
+    const size_t nt = size_t(nw) * nlos;
+    const int ntile = (nlos + 15) / 16;
+    double* zw = b.z + size_t(w) * nlyr * ntile * 256;
+    double* hw = b.qlbuf + size_t(w) * nlyr * ntile * 64;
+    const bool last_is_ground = (m == 0);
+    for (int tile0 = 0; tile0 < ntile; tile0 += TILES) {
+        int los[TILES];
+        bool ok[TILES];
+        double gw[TILES];
+        for (int t = 0; t < TILES; ++t) {
+            los[t] = (tile0 + t) * 16 + col;
+            ok[t] = (tile0 + t) < ntile && los[t] < nlos;
+            gw[t] = 0;
+            if (ok[t] && m == 0 && g.ray_ground[los[t]]) {
+                double acc = 0;
+                for (int e = g.g_start[los[t]]; e < g.g_start[los[t] + 1]; ++e)
+                    if (g.g_sza[e] == s && skd::conv_at(b, g, g.g_slot[e], w) > m) acc += g.g_w[e];
+                gw[t] = acc * b.att_total[size_t(los[t]) * nw + w];
+            }
+        }
+        // ---------------- forward sweep
+        mf4 yprev[TILES];
+        for (int t = 0; t < TILES; ++t) yprev[t] = mf4{0, 0, 0, 0};
+        for (int p = 0; p < nlyr; ++p) {
+            const double* ops = skd::ops_at<N>(b, nlyr, p, w);
+            double fpa[4], spa[2], hda[4];
+            for (int kk = 0; kk < 4; ++kk) fpa[kk] = ops[O::FP + 64 * kk + lane];
+            for (int kk = 0; kk < 2; ++kk) spa[kk] = ops[O::SP + 64 * kk + lane];
+            for (int kk = 0; kk < 4; ++kk) hda[kk] = (col < 4) ? ops[O::HD + col * NSTR + 4 * kk + q] : 0.0;
+            const bool last = (p == nlyr - 1);
+            for (int t = 0; t < TILES; ++t) {
+                if ((tile0 + t) >= ntile) continue;
+                // Legendre-space LOS weights: this lane holds ql[4 kk + q] of its line of sight
+                double ql4[4] = {0, 0, 0, 0};
+                if (ok[t]) {
+                    const int base = (los[t] * g.nsza + s) * nlyr + p;
+                    for (int e = g.lp_start[base]; e < g.lp_start[base + 1]; ++e) {
+                        if (skd::conv_at(b, g, g.lp_slot[e], w) <= m) continue;
+                        const int rq = g.lp_q[e];
+                        const double cw = b.srcw[size_t(rq) * nw + w] * g.lp_w[e] * g.rl_cosm[size_t(m) * g.nq_total + rq];
+                        if (cw == 0.0) continue;
+                        const double* lpa = g.lpang + (size_t(m) * g.nangle + g.lp_angle[e]) * NSTR;
+                        for (int kk = 0; kk < 4; ++kk)
+                            if (4 * kk + q >= m) ql4[kk] += cw * lpa[4 * kk + q];
+                    }
+                }
+                mf4 acc = {0, 0, 0, 0}, hacc = {0, 0, 0, 0};
+                for (int kk = 0; kk < 4; ++kk) acc = mfma16(fpa[kk], ql4[kk], acc);
+                for (int kk = 0; kk < 2; ++kk) acc = mfma16(spa[kk], yprev[t][2 + kk], acc);
+                for (int kk = 0; kk < 4; ++kk) hacc = mfma16(hda[kk], ql4[kk], hacc);
+                if (last && last_is_ground)
+                    for (int r = 0; r < 4; ++r) acc[r] += ops[O::UG + q + 4 * r] * gw[t];
+                double* zt = zw + (size_t(p) * ntile + tile0 + t) * 256;
+                for (int r = 0; r < 4; ++r) zt[64 * r + lane] = acc[r];
+                hw[(size_t(p) * ntile + tile0 + t) * 64 + lane] = hacc[0];
+                yprev[t] = acc;
+            }
+        }
+        // ---------------- backward sweep with the reduced gradient
+        mf4 znext[TILES], gprev[TILES];
+        double e1prev[2] = {0, 0};  // A operand of the zB_{p-1} term of the layer below (DI edge 1), k-steps 0,1
+        for (int t = 0; t < TILES; ++t) { znext[t] = mf4{0, 0, 0, 0}; gprev[t] = mf4{0, 0, 0, 0}; }
+        for (int p = nlyr - 1; p >= 0; --p) {
+            const double* ops = skd::ops_at<N>(b, nlyr, p, w);
+            const bool last = (p == nlyr - 1);
+            double bpa[2], e0[2], e1[2], e2[2], e3[2];
+            for (int kk = 0; kk < 2; ++kk) {
+                bpa[kk] = -ops[O::BP + 64 * kk + lane];
+                const int i = 4 * kk + q;
+                e0[kk] = (col < 4) ? ops[O::DI + (col * 4 + 0) * N + i] : 0.0;
+                e1[kk] = (col < 4) ? ops[O::DI + (col * 4 + 1) * N + i] : 0.0;
+                e2[kk] = (col < 4) ? -ops[O::DI + (col * 4 + 2) * N + i] : 0.0;
+                e3[kk] = (col < 4) ? -ops[O::DI + (col * 4 + 3) * N + i] : ((col < 8 && last && last_is_ground) ? 1.0 : 0.0);
+            }
+            const double gd = (last && last_is_ground && q < 4) ? ops[O::GD + q] : 0.0;
+            const double ipb = ops[O::IPB];
+            for (int t = 0; t < TILES; ++t) {
+                if ((tile0 + t) >= ntile) continue;
+                const double* zt = zw + (size_t(p) * ntile + tile0 + t) * 256;
+                mf4 z;
+                for (int r = 0; r < 4; ++r) z[r] = zt[64 * r + lane];
+                if (!last)
+                    for (int kk = 0; kk < 2; ++kk) z = mfma16(bpa[kk], znext[t][kk], z);
+                // finish the layer below (p + 1) with zB_p and write it out
+                if (!last) {
+                    mf4 gp = gprev[t];
+                    for (int kk = 0; kk < 2; ++kk) gp = mfma16(e1prev[kk], z[2 + kk], gp);
+                    if (ok[t]) b.grad[size_t(q * nlyr + p + 1) * nt + size_t(w) * nlos + los[t]] += gp[0];
+                }
+                // this layer: HD part from the forward sweep, zA_p, zB_p, zA_{p+1}
+                mf4 ga = {hw[(size_t(p) * ntile + tile0 + t) * 64 + lane], 0, 0, 0};
+                for (int kk = 0; kk < 2; ++kk) ga = mfma16(e0[kk], z[kk], ga);
+                for (int kk = 0; kk < 2; ++kk) ga = mfma16(e3[kk], z[2 + kk], ga);
+                if (!last)
+                    for (int kk = 0; kk < 2; ++kk) ga = mfma16(e2[kk], znext[t][kk], ga);
+                if (last && last_is_ground && ok[t]) {
+                    const double zBsum = ga[1];  // rows 4..7 of the tile
+                    ga[0] += (zBsum + gw[t]) * gd;
+                    if (q == 0) {
+                        const size_t tid = size_t(w) * nlos + los[t];
+                        const double rho = b.albedo[w];
+                        const double tf = g.csz[s] / skd::kPi * b.T[size_t(nlyr) * nw + w];
+                        b.grad[size_t(4 * nlyr) * nt + tid] += gw[t] * 2.0 * ipb + zBsum * (2.0 * ipb + tf);
+                        b.grad[size_t(4 * nlyr + 1) * nt + tid] += zBsum * g.csz[s] / skd::kPi * rho;
+                    }
+                }
+                gprev[t] = ga;
+                znext[t] = z;
+            }
+            for (int kk = 0; kk < 2; ++kk) e1prev[kk] = e1[kk];
+        }
+        for (int t = 0; t < TILES; ++t)
+            if (ok[t]) b.grad[size_t(q * nlyr) * nt + size_t(w) * nlos + los[t]] += gprev[t][0];
     }
 }
 
