@@ -81,6 +81,8 @@ struct Geo {
     const int* lp_angle;
     const int* lp_slot;
     const double* lp_w;
+    const double* lp_cosm;  // [m][entry]  cos(m * azimuth of the entry's ray layer)   (16-stream matrix-core sweeps)
+    int n_lp;               // number of (LOS, sza, layer) table entries
     const int* g_start;     // [los .. +1] ground entries
     const int* g_slot;
     const int* g_sza;
@@ -120,6 +122,7 @@ struct Bufs {
     double* omloc;          // [q][w]
     double* srcw;           // [q][w]  omega_loc (1-exp(-od)) * attenuation(q -> observer)
     double* att_total;      // [los][w]
+    double* cwbuf;          // [w][entry]  srcw of the entry's ray layer x its interpolation weight (16-stream sweeps)
     // per azimuth order
     double* rec;            // [w][p][REC]   (record-major, see rec_at)
     double* dinv;           // [w][p][4N^2]

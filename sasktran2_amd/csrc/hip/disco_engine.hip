@@ -75,6 +75,14 @@ __global__ void __launch_bounds__(kBlock) kern_k4b(Geo g, Bufs b) {
     if (tid >= size_t(b.nw) * g.nlos) return;
     skd::k4b_los(g, b, int(tid % g.nlos), int(tid / g.nlos));
 }
+// table-entry source weights of the 16-stream sweeps: cwbuf[w][e] = srcw[ray layer of e][w] * interpolation weight of e
+__global__ void __launch_bounds__(256) kern_cw(Geo g, Bufs b) {
+    const size_t n = size_t(b.nw) * g.n_lp;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const int w = int(i / g.n_lp), e = int(i % g.n_lp);
+        b.cwbuf[i] = b.srcw[size_t(g.lp_q[e]) * b.nw + w] * g.lp_w[e];
+    }
+}
 // plane-parallel post-processing: one thread per (wavelength, line of sight), see skd::kpp_los
 template <int N> __global__ void __launch_bounds__(kBlock) kern_kpp(Geo g, Bufs b, int s, int m) {
     size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -167,7 +175,7 @@ DeviceEngine::DeviceEngine(const skgeo::DiscoGeometry& dg, bool ss_in_do) : impl
     g.rl_ssa_start = M.upload(t.rl_ssa_start); g.ssa_idx = M.upload(t.ssa_idx); g.ssa_w = M.upload(t.ssa_w);
     g.rl_azi = M.upload(t.rl_azi); g.rl_cosm = M.upload(t.rl_cosm); g.rl_active = M.upload(t.rl_active); g.rl_tab_start = M.upload(t.rl_tab_start);
     g.tab_slot = M.upload(t.tab_slot); g.tab_w = M.upload(t.tab_w); g.lp_start = M.upload(t.lp_start); g.lp_q = M.upload(t.lp_q);
-    g.lp_angle = M.upload(t.lp_angle); g.lp_slot = M.upload(t.lp_slot); g.lp_w = M.upload(t.lp_w); g.g_start = M.upload(t.g_start);
+    g.lp_angle = M.upload(t.lp_angle); g.lp_slot = M.upload(t.lp_slot); g.lp_w = M.upload(t.lp_w); g.lp_cosm = M.upload(t.lp_cosm); g.g_start = M.upload(t.g_start);
     g.g_slot = M.upload(t.g_slot); g.g_sza = M.upload(t.g_sza); g.g_w = M.upload(t.g_w);
     g.pp_mu = M.upload(t.pp_mu); g.pp_azi = M.upload(t.pp_azi); g.pp_first = M.upload(t.pp_first); g.pp_lf = M.upload(t.pp_lf);
     g.lplos = M.upload(t.lplos);
@@ -210,6 +218,7 @@ size_t DeviceEngine::bytes_per_wavelength() const {
     size_t d = 0;
     d += nlyr * (3 + nstr) + (nlyr + 1) + nlyr;              // tau, om, kbar, a, T, sec
     d += size_t(t.nq_total) * 3 + nlos;                      // od, omloc, srcw, att_total
+    if (N == 8) d += t.lp_q.size();                          // cwbuf
     d += nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N;  // rec, dinv, xsol
     d += nstr * size_t(t.nslot);                             // J
     const size_t nlos_pad = (nlos + 15) / 16 * 16;
@@ -231,6 +240,7 @@ void DeviceEngine::ensure_scratch(int nw) {
     b.a = M.alloc<double>(nlyr * nstr * W); b.T = M.alloc<double>((nlyr + 1) * W); b.sec = M.alloc<double>(nlyr * W);
     b.od = M.alloc<double>(size_t(t.nq_total) * W); b.omloc = M.alloc<double>(size_t(t.nq_total) * W);
     b.srcw = M.alloc<double>(size_t(t.nq_total) * W); b.att_total = M.alloc<double>(nlos * W);
+    b.cwbuf = M.alloc<double>(t.N == 8 ? t.lp_q.size() * W : 1);
     b.rec = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W); b.dinv = M.alloc<double>(nlyr * 4 * N * N * W);
     b.xsol = M.alloc<double>(nlyr * 2 * N * W); b.J = M.alloc<double>(nstr * size_t(t.nslot) * W);
     b.conv_order = M.alloc<uint8_t>(size_t(t.nslot) * W); b.notconv = M.alloc<int>(W); b.norders = M.alloc<int>(W);
@@ -310,6 +320,10 @@ static void run_chunk(DeviceEngine::Impl& I, hipStream_t st, int derivs) {
         }
         HIP_CHECK(hipGetLastError());
         return;
+    }
+    if (N == 8 && derivs && g.n_lp > 0) {
+        Timer t(I, st, "k0_entry_weights");
+        hipLaunchKernelGGL(kern_cw, dim3(4096), dim3(256), 0, st, g, b);
     }
     for (int s = 0; s < g.nsza; ++s) {
         {

@@ -75,6 +75,9 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_k1_wave(
     double* vdAm = sVec[grp][11];
     double* vC = sVec[grp][12];   // Cp.v, Cm.v interleaved: [2j], [2j+1]
     double* vdC = sVec[grp][13];  // dCp[4], dCm[4] per j -> 8N doubles (rows 13..16)
+    double* vAl = vQp;       // rotation parameters of the Jacobi rounds (the Q / A rows are written later)
+    double* vBe = vQm;
+    double* vPartner = vAp;
     const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * skd::kPi);
     __syncthreads();
 
@@ -138,51 +141,69 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_k1_wave(
             M5[e] = (i == j) ? 1.0 : 0.0;
         }
         __syncthreads();
-        // cyclic Jacobi on M4, eigenvectors accumulate in M5
-        bool jac_ok = false;
-        for (int sweep = 0; sweep < 60; ++sweep) {
-            double off = 0, dia = 0;
-            for (int e = gl; e < NN; e += LG) {
-                const int i = e / N, j = e % N;
-                const double v = M4[e] * M4[e];
-                if (i == j) dia += v; else if (j > i) off += v;
-            }
-            for (int o = LG / 2; o >= 1; o >>= 1) {
-                off += __shfl_xor(off, o, LG);
-                dia += __shfl_xor(dia, o, LG);
-            }
-            const bool conv = (off <= 1e-34 * dia) || (off == 0);
-            if (__all(conv)) { jac_ok = true; break; }
-            for (int pp = 0; pp < N - 1; ++pp)
-                for (int qq = pp + 1; qq < N; ++qq) {
-                    const double apq = M4[pp * N + qq], app = M4[pp * N + pp], aqq = M4[qq * N + qq];
-                    double c = 1.0, sn = 0.0, t = 0.0;
-                    if (apq != 0.0) {
-                        const double theta = (aqq - app) / (2.0 * apq);
-                        t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                        c = 1.0 / sqrt(t * t + 1.0);
-                        sn = t * c;
-                    }
-                    double n0 = 0, n1 = 0;
-                    int kind = 0;  // 1: A row r, 2: diagonal p, 3: diagonal q, 4: V row
-                    int r = gl;
-                    if (gl < N) {
-                        if (r == pp) { kind = 2; n0 = app - t * apq; }
-                        else if (r == qq) { kind = 3; n0 = aqq + t * apq; }
-                        else { kind = 1; const double arp = M4[r * N + pp], arq = M4[r * N + qq]; n0 = c * arp - sn * arq; n1 = sn * arp + c * arq; }
-                    }
-                    double v0 = 0, v1 = 0;
-                    // eigenvector rows: lanes N..2N-1 when the group is wide enough, otherwise the same lanes do both
-                    const int vr = (LG >= 2 * N) ? gl - N : gl;
-                    const bool dov = (LG >= 2 * N) ? (gl >= N && gl < 2 * N) : (gl < N);
-                    if (dov) { const double vrp = M5[vr * N + pp], vrq = M5[vr * N + qq]; v0 = c * vrp - sn * vrq; v1 = sn * vrp + c * vrq; }
-                    __syncthreads();
-                    if (kind == 1) { M4[r * N + pp] = n0; M4[pp * N + r] = n0; M4[r * N + qq] = n1; M4[qq * N + r] = n1; }
-                    if (kind == 2) { M4[pp * N + pp] = n0; M4[pp * N + qq] = 0.0; }
-                    if (kind == 3) { M4[qq * N + qq] = n0; M4[qq * N + pp] = 0.0; }
-                    if (dov) { M5[vr * N + pp] = v0; M5[vr * N + qq] = v1; }
-                    __syncthreads();
+        // Jacobi on M4 with the round-robin ("tournament") ordering: every round applies N/2 disjoint rotations at once,
+        // A <- J^T A J and V <- V J with J the product of the round's rotations.  Index i of a rotated pair (p, q) has
+        // partner i' and coefficients (al, be) = (c, -s) for i = p, (c, +s) for i = q, so that (A J)[r][i] = al A[r][i] + be A[r][i'].
+        // Eigenvectors accumulate in M5; M6 / M7 are the write buffers of a round (ping-pong, one barrier less).
+        bool jac_ok = (N == 1);
+        constexpr int NM1 = (N > 1) ? N - 1 : 1;
+        if (N > 1) {
+            double* Acur = M4;
+            double* Vcur = M5;
+            double* Anew = M6;
+            double* Vnew = M7;
+            for (int sweep = 0; sweep < 60 && !jac_ok; ++sweep) {
+                double off = 0, dia = 0;
+                for (int e = gl; e < NN; e += LG) {
+                    const int i = e / N, j = e % N;
+                    const double v = Acur[e] * Acur[e];
+                    if (i == j) dia += v; else if (j > i) off += v;
                 }
+                for (int o = LG / 2; o >= 1; o >>= 1) {
+                    off += __shfl_xor(off, o, LG);
+                    dia += __shfl_xor(dia, o, LG);
+                }
+                const bool conv = (off <= 1e-34 * dia) || (off == 0);
+                if (__all(conv)) { jac_ok = true; break; }
+                for (int round = 0; round < N - 1; ++round) {
+                    // pairs of this round: (N-1, round) and ((round + k) mod (N-1), (round - k) mod (N-1)), k = 1 .. N/2-1
+                    for (int t = gl; t < N / 2; t += LG) {
+                        int pp, qq;
+                        if (t == 0) { pp = round; qq = N - 1; }
+                        else { pp = (round + t) % NM1; qq = (round + NM1 - t) % NM1; }
+                        if (pp > qq) { const int tmp = pp; pp = qq; qq = tmp; }
+                        const double apq = Acur[pp * N + qq], app = Acur[pp * N + pp], aqq = Acur[qq * N + qq];
+                        double c = 1.0, sn = 0.0;
+                        if (apq != 0.0) {
+                            const double theta = (aqq - app) / (2.0 * apq);
+                            const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                            c = 1.0 / sqrt(tt * tt + 1.0);
+                            sn = tt * c;
+                        }
+                        vAl[pp] = c; vBe[pp] = -sn; vPartner[pp] = qq;
+                        vAl[qq] = c; vBe[qq] = sn; vPartner[qq] = pp;
+                    }
+                    __syncthreads();
+                    for (int e = gl; e < NN; e += LG) {
+                        const int i = e / N, j = e % N;
+                        const int ip = (int)vPartner[i], jp = (int)vPartner[j];
+                        const double ai = vAl[i], bi = vBe[i], aj = vAl[j], bj = vBe[j];
+                        double v;
+                        if (jp == i) v = 0.0;  // the rotated pair's off-diagonal element is annihilated exactly
+                        else v = ai * (aj * Acur[i * N + j] + bj * Acur[i * N + jp]) + bi * (aj * Acur[ip * N + j] + bj * Acur[ip * N + jp]);
+                        Anew[e] = v;
+                        Vnew[e] = aj * Vcur[i * N + j] + bj * Vcur[i * N + jp];
+                    }
+                    __syncthreads();
+                    { double* tmp = Acur; Acur = Anew; Anew = tmp; }
+                    { double* tmp = Vcur; Vcur = Vnew; Vnew = tmp; }
+                }
+            }
+            // leave the result in M4 / M5 (an odd number of rounds ends in the other pair of buffers)
+            if (Acur != M4) {
+                for (int e = gl; e < NN; e += LG) { M4[e] = Acur[e]; M5[e] = Vcur[e]; }
+                __syncthreads();
+            }
         }
         if (!jac_ok && gl == 0) sErr = skd::ERR_EIGEN;
         if (gl < N) {
@@ -969,6 +990,9 @@ template <int TILES> __global__ void __launch_bounds__(64) kern_k2b_mfma8(Geo g,
     const int ntile = (nlos + 15) / 16;
     double* zw = b.z + size_t(w) * nlyr * ntile * 256;
     double* hw = b.qlbuf + size_t(w) * nlyr * ntile * 64;
+    const double* cwp = b.cwbuf + size_t(w) * g.n_lp;
+    const double* cme = g.lp_cosm + size_t(m) * g.n_lp;
+    const double* lpm = g.lpang + size_t(m) * g.nangle * NSTR;
     const bool last_is_ground = (m == 0);
     for (int tile0 = 0; tile0 < ntile; tile0 += TILES) {
         int los[TILES];
@@ -997,19 +1021,32 @@ template <int TILES> __global__ void __launch_bounds__(64) kern_k2b_mfma8(Geo g,
             const bool last = (p == nlyr - 1);
             for (int t = 0; t < TILES; ++t) {
                 if ((tile0 + t) >= ntile) continue;
-                // Legendre-space LOS weights: this lane holds ql[4 kk + q] of its line of sight
+                // Legendre-space LOS weights: this lane holds ql[4 kk + q] of its line of sight.  Four table entries per
+                // step, branch free, so that the dependent loads of a step are in flight together.
                 double ql4[4] = {0, 0, 0, 0};
+#ifdef SKD_EXP_NOQL
+                if (false) {
+#else
                 if (ok[t]) {
+#endif
                     const int base = (los[t] * g.nsza + s) * nlyr + p;
-                    for (int e = g.lp_start[base]; e < g.lp_start[base + 1]; ++e) {
-                        if (skd::conv_at(b, g, g.lp_slot[e], w) <= m) continue;
-                        const int rq = g.lp_q[e];
-                        const double cw = b.srcw[size_t(rq) * nw + w] * g.lp_w[e] * g.rl_cosm[size_t(m) * g.nq_total + rq];
-                        if (cw == 0.0) continue;
-                        const double* lpa = g.lpang + (size_t(m) * g.nangle + g.lp_angle[e]) * NSTR;
-                        for (int kk = 0; kk < 4; ++kk)
-                            if (4 * kk + q >= m) ql4[kk] += cw * lpa[4 * kk + q];
+                    const int e0 = g.lp_start[base], e1 = g.lp_start[base + 1];
+                    for (int e = e0; e < e1; e += 4) {
+                        double c[4];
+                        const double* lpa[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int ee = (e + u < e1) ? e + u : e1 - 1;
+                            const bool live = (e + u < e1) && skd::conv_at(b, g, g.lp_slot[ee], w) > m;
+                            c[u] = live ? cwp[ee] * cme[ee] : 0.0;
+                            lpa[u] = lpm + size_t(g.lp_angle[ee]) * NSTR + q;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            for (int kk = 0; kk < 4; ++kk) ql4[kk] += c[u] * lpa[u][4 * kk];
                     }
+                    for (int kk = 0; kk < 4; ++kk)
+                        if (4 * kk + q < m) ql4[kk] = 0.0;
                 }
                 mf4 acc = {0, 0, 0, 0}, hacc = {0, 0, 0, 0};
                 for (int kk = 0; kk < 4; ++kk) acc = mfma16(fpa[kk], ql4[kk], acc);
