@@ -97,6 +97,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    run_chunk, run_slots, run_scratch = solver.launch_shape()
     status_bad = int((out["status"] != 0).sum().item())
     finite = bool(torch.isfinite(res["radiance"]).all().item())
 
@@ -108,7 +109,7 @@ def main():
     solver.set_profiling(False)
     dominant = max(ktimes, key=lambda k: ktimes[k][0])
     dom_ms, dom_n = ktimes[dominant]
-    chunk = min(nloc, int(os.environ.get("SASKTRAN2_AMD_CHUNK", "4096")))
+    chunk = solver.launch_shape()[0]  # wavelengths per launch of the profiled pass (one block in flight)
     avg_launch_s = dom_ms / dom_n * 1e-3
     achieved_gbs = ALGORITHMIC_BYTES_PER_WAVELENGTH * chunk / avg_launch_s / 1e9
 
@@ -124,7 +125,7 @@ def main():
             "config": {"workload": "C2 limb-scatter spherical: 16-stream DISCO, 50 layers, 25 tangent heights 10-58 km, "
                                    f"{NW} wavelengths, Stokes I + wf_extinction/wf_ssa/wf_albedo",
                        "wavelengths_per_gpu": nloc, "parallelism": f"wavelength-shard x{world} + RCCL all-gather" if world > 1 else "single GPU",
-                       "single_scatter_source": "discrete_ordinates", "num_sza": 1, "chunk": chunk},
+                       "single_scatter_source": "discrete_ordinates", "num_sza": 1, "wavelengths_per_launch": run_chunk, "blocks_in_flight": run_slots},
             "valid": finite and status_bad == 0,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
@@ -132,7 +133,7 @@ def main():
                          "avg_launch_ms": dom_ms / dom_n, "launches": dom_n,
                          "note": "path is FP64-latency/ALU bound, not HBM-streaming (SURVEY 8d); see kernels_ms and DESIGN.md"},
             "kernels_ms": {k: {"total_ms": round(v[0], 3), "launches": v[1]} for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])},
-            "scratch_gib": solver.scratch_bytes(chunk) / 2 ** 30,
+            "scratch_gib": run_scratch / 2 ** 30,
         }
     # ---- CPU baseline: the oracle (same algorithm as the reference CPU engine, OpenMP over wavelengths) on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

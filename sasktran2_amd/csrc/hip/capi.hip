@@ -373,6 +373,13 @@ int sk_amd_engine_scratch_bytes(Engine* e, int nwavel, unsigned long long* bytes
     *bytes = (unsigned long long)e->dev->bytes_per_wavelength() * (unsigned long long)nwavel;
     return 0;
 }
+int sk_amd_engine_launch_shape(Engine* e, int* chunk, int* slots, unsigned long long* scratch_bytes) {
+    if (!e) return -1;
+    if (chunk) *chunk = e->dev->last_chunk();
+    if (slots) *slots = e->dev->last_slots();
+    if (scratch_bytes) *scratch_bytes = (unsigned long long)e->dev->scratch_bytes();
+    return 0;
+}
 int sk_amd_engine_set_profiling(Engine* e, int on) { if (!e) return -1; e->dev->set_profiling(on != 0); return 0; }
 int sk_amd_engine_reset_profile(Engine* e) { if (!e) return -1; e->dev->reset_profile(); return 0; }
 int sk_amd_engine_kernel_time(Engine* e, const char* name, double* ms, long* launches) {

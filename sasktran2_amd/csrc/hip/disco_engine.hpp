@@ -29,14 +29,16 @@ class DeviceEngine {
                       double* d_wf_ssa, double* d_wf_alb, double* d_los_od, int* d_status, void* stream, int max_chunk);
 
     size_t bytes_per_wavelength() const;
-    size_t scratch_bytes() const;
+    size_t scratch_bytes() const;   // scratch currently allocated (all slots)
+    int last_chunk() const;         // wavelengths per launch of the last solve
+    int last_slots() const;         // blocks of wavelengths in flight (streams) of the last solve
     void set_profiling(bool on);
     void reset_profile();
     bool kernel_time(const char* name, double* ms, long* launches) const;
     std::string kernel_names() const;
 
   private:
-    void ensure_scratch(int nw);
+    void ensure_scratch(int nw, int nslots);
     Impl* impl_;
 };
 

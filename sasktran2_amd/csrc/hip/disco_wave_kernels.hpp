@@ -11,6 +11,9 @@
 #include "disco_core.hpp"
 
 // minimum waves per SIMD requested from the register allocator (second __launch_bounds__ argument)
+#ifndef SKD_EXP_MAXSWEEP
+#define SKD_EXP_MAXSWEEP 60
+#endif
 #ifndef SKD_WPE_K1
 #define SKD_WPE_K1 1
 #endif
@@ -152,7 +155,7 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_k1_wave(
             double* Vcur = M5;
             double* Anew = M6;
             double* Vnew = M7;
-            for (int sweep = 0; sweep < 60 && !jac_ok; ++sweep) {
+            for (int sweep = 0; sweep < SKD_EXP_MAXSWEEP && !jac_ok; ++sweep) {
                 double off = 0, dia = 0;
                 for (int e = gl; e < NN; e += LG) {
                     const int i = e / N, j = e % N;

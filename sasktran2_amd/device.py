@@ -62,6 +62,12 @@ class DeviceSolver:
             res[name] = (ms.value, n.value)
         return res
 
+    def launch_shape(self):
+        """(wavelengths per launch, blocks in flight, scratch bytes allocated) of the last solve."""
+        c, n, b = ctypes.c_int(), ctypes.c_int(), ctypes.c_ulonglong()
+        lib().sk_amd_engine_launch_shape(self.engine._h, ctypes.byref(c), ctypes.byref(n), ctypes.byref(b))
+        return c.value, n.value, b.value
+
     def scratch_bytes(self, nwavel):
         b = ctypes.c_ulonglong()
         lib().sk_amd_engine_scratch_bytes(self.engine._h, nwavel, ctypes.byref(b))
