@@ -367,7 +367,10 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
             }
             {
                 Timer t(I, st, "k2a_bvp");
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                if constexpr (N == 8)
+                    hipLaunchKernelGGL(kern_k2a_mfma8, dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
             }
             {
                 Timer t(I, st, "k3_table_values");

@@ -825,6 +825,174 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2B) kern_k2b_wav
 typedef double mf4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ mf4 mfma16(double a, double bb, mf4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0); }
 
+// K2a for N = 8: block-tridiagonal boundary value problem with the 16 x 16 blocks held in matrix-core accumulators.
+//   per layer   T1^T = Dinv'_{p-1}^T Sub_p^T (4 products), D'_p = D_p + T1[:, 8:16] [W- | W+ E]_p (2), r'_p = r_p - T1 r'_{p-1} (4),
+//               Dinv'_p by in-place Gauss-Jordan with partial (row) pivoting: one rank-1 product per pivot step, the pivot
+//               row / column are fixed up in registers, rows are never moved (the final permutation goes through 2 KB of LDS)
+//   backward    x_p = Dinv'_p (r'_p - Sup_p x_{p+1})   (4 + 4 products)
+//   Vectors are kept "replicated": every lane (col, q) holds entries 4 r + q, r = 0..3, so a vector is a B operand as it is.
+//   Same equations as skd::k2a_bvp / kern_k2a_wave (reference: sktran_do_rte.cpp:1620-1790,1897-2294).
+__global__ void __launch_bounds__(64) kern_k2a_mfma8(Geo g, Bufs b, int s, int m) {
+    constexpr int N = 8, M2 = 16;
+    using R = skd::Rec<N>;
+    const int w = blockIdx.x;
+    if (m >= b.norders[w]) return;
+    const int lane = threadIdx.x, col = lane & 15, q = lane >> 4, jc = col & 7, nw = b.nw, nlyr = g.nlyr;
+    __shared__ double sP[M2 * M2];
+    const double rho = (m == 0) ? b.albedo[w] : 0.0;
+    mf4 dprev = {0, 0, 0, 0};
+    double rprev[4] = {0, 0, 0, 0};
+    int sing = 0;
+    for (int p = 0; p < nlyr; ++p) {
+        const bool last = (p == nlyr - 1);
+        const double* rec = skd::rec_at<N>(b, nlyr, p, w);
+        const double th = b.tau[size_t(p) * nw + w];
+        const double Ecol = exp(-fabs(rec[R::K + jc]) * th);
+        // D_p and r_p, rows 4 r + q
+        mf4 acc;
+        double rv[4];
+        double gsp = 0, gsm = 0, gsg = 0;
+        if (last && m == 0) {
+            for (int t = 0; t < N; ++t) {
+                const double wm_ = g.wt[t] * g.mu[t];
+                gsp += wm_ * rec[R::WP + t + N * jc];
+                gsm += wm_ * rec[R::WM + t + N * jc];
+                gsg += wm_ * rec[R::G + 2 * N + t];
+            }
+        }
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * r + q;
+            double v, rr;
+            if (row < N) {
+                v = (col < N) ? -rec[R::WP + row + N * jc] : -rec[R::WM + row + N * jc] * Ecol;
+                rr = rec[R::G + row];
+                if (p > 0) rr -= skd::rec_at<N>(b, nlyr, p - 1, w)[R::G + 2 * N + row];
+            } else {
+                const int ii = row - N;
+                v = (col < N) ? rec[R::WM + ii + N * jc] * Ecol : rec[R::WP + ii + N * jc];
+                rr = -rec[R::G + 3 * N + ii];
+                if (last) {
+                    if (m == 0) {
+                        v -= 2.0 * rho * ((col < N) ? gsp * Ecol : gsm);
+                        rr += g.csz[s] * rho / skd::kPi * b.T[size_t(nlyr) * nw + w] + 2.0 * rho * gsg;
+                    }
+                } else {
+                    rr += skd::rec_at<N>(b, nlyr, p + 1, w)[R::G + N + ii];
+                }
+            }
+            acc[r] = v;
+            rv[r] = rr;
+        }
+        if (p > 0) {
+            const double* recm = skd::rec_at<N>(b, nlyr, p - 1, w);
+            const double thm = b.tau[size_t(p - 1) * nw + w];
+            mf4 t1 = {0, 0, 0, 0};
+            for (int kk = 0; kk < 4; ++kk) {
+                const int j = 4 * kk + q;
+                double bop = 0.0;  // Sub_p[i = col][j]: [W+_{p-1} E_{p-1} | W-_{p-1}]
+                if (col < N) bop = (j < N) ? recm[R::WP + col + N * j] * exp(-fabs(recm[R::K + j]) * thm) : recm[R::WM + col + N * (j - N)];
+                t1 = mfma16(dprev[kk], bop, t1);
+            }
+            for (int kk = 0; kk < 2; ++kk) {
+                const int jq = 4 * kk + q;  // row of [W-_p | W+_p E_p]
+                const double bop = (col < N) ? rec[R::WM + jq + N * jc] : rec[R::WP + jq + N * jc] * Ecol;
+                acc = mfma16(t1[2 + kk], bop, acc);
+            }
+            mf4 tr = {0, 0, 0, 0};
+            for (int kk = 0; kk < 4; ++kk) tr = mfma16(t1[kk], rprev[kk], tr);
+            for (int r = 0; r < 4; ++r) rv[r] -= tr[r];
+        }
+        // in-place Gauss-Jordan inverse, rows stay where they are: physical row pi(k) is the pivot of column k
+        unsigned used = 0;
+        unsigned long long permP = 0, permI = 0;
+        for (int k = 0; k < M2; ++k) {
+            double bv = -1.0, bs = 0.0;
+            int br = 0;
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * r + q;
+                const double a = fabs(acc[r]);
+                if (!((used >> row) & 1u) && a > bv) { bv = a; bs = acc[r]; br = row; }
+            }
+            for (int off = 16; off <= 32; off <<= 1) {
+                const double ov = __shfl_xor(bv, off), os = __shfl_xor(bs, off);
+                const int orow = __shfl_xor(br, off);
+                if (ov > bv || (ov == bv && orow < br)) { bv = ov; bs = os; br = orow; }
+            }
+            const int pivrow = __builtin_amdgcn_readlane(br, k);
+            double pv = __shfl(bs, k);
+            if (!(fabs(pv) > 0)) { sing = 1; pv = 1.0; }
+            const double ip = 1.0 / pv;
+            const int pr = pivrow >> 2, pq = pivrow & 3;
+            const double rowsel = (pr == 0) ? acc[0] : (pr == 1) ? acc[1] : (pr == 2) ? acc[2] : acc[3];
+            const double rowv = __shfl(rowsel, col + 16 * pq);  // D[pivrow][col]
+            const int src = k + 16 * (col & 3);                 // D[i = col][k] lives in lane (k, i & 3), register i >> 2
+            const double c0 = __shfl(acc[0], src), c1 = __shfl(acc[1], src), c2 = __shfl(acc[2], src), c3 = __shfl(acc[3], src);
+            const int ir = col >> 2;
+            const double colv = (ir == 0) ? c0 : (ir == 1) ? c1 : (ir == 2) ? c2 : c3;
+            const double aop = (q == 0 && col != pivrow) ? -colv * ip : 0.0;
+            const double bop = (q == 0 && col != k) ? rowv : 0.0;
+            acc = mfma16(aop, bop, acc);
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * r + q;
+                if (col == k) acc[r] = (row == pivrow) ? ip : -acc[r] * ip;
+                else if (row == pivrow) acc[r] *= ip;
+            }
+            used |= 1u << pivrow;
+            permP |= (unsigned long long)pivrow << (4 * k);
+            permI |= (unsigned long long)k << (4 * pivrow);
+        }
+        // B[rho][j] = Dinv[piinv(rho)][pi(j)]: scatter to the natural layout
+        __syncthreads();
+        for (int r = 0; r < 4; ++r) {
+            const int prow = 4 * r + q;
+            const int i = int((permI >> (4 * prow)) & 15ull), c = int((permP >> (4 * col)) & 15ull);
+            sP[i * M2 + c] = acc[r];
+        }
+        __syncthreads();
+        double* dg = skd::dinv_at<N>(b, nlyr, p, w);
+        for (int r = 0; r < 4; ++r) {
+            dprev[r] = sP[(4 * r + q) * M2 + col];
+            dg[64 * r + lane] = dprev[r];
+        }
+        double* xs = skd::xsol_at<N>(b, nlyr, p, w);
+        for (int r = 0; r < 4; ++r) {
+            rprev[r] = rv[r];
+            if (col == 0) xs[4 * r + q] = rv[r];
+        }
+    }
+    // back substitution  x_p = Dinv'_p (r'_p - Sup_p x_{p+1})
+    double xn[4] = {0, 0, 0, 0};
+    for (int p = nlyr - 1; p >= 0; --p) {
+        const double* dg = skd::dinv_at<N>(b, nlyr, p, w);
+        double* xs = skd::xsol_at<N>(b, nlyr, p, w);
+        double v[4];
+        for (int r = 0; r < 4; ++r) v[r] = (col == 0) ? xs[4 * r + q] : 0.0;
+        for (int r = 0; r < 4; ++r) v[r] = __shfl(v[r], 16 * q);  // replicate over the 16 columns
+        if (p < nlyr - 1) {
+            const double* recn = skd::rec_at<N>(b, nlyr, p + 1, w);
+            const double thn = b.tau[size_t(p + 1) * nw + w];
+            mf4 sx = {0, 0, 0, 0};
+            for (int kk = 0; kk < 4; ++kk) {
+                const int j = 4 * kk + q;
+                double aop = 0.0;  // rows 8..15: [W-_{p+1} | W+_{p+1} E_{p+1}]
+                if (col >= N) {
+                    const int ii = col - N;
+                    aop = (j < N) ? recn[R::WM + ii + N * j] : recn[R::WP + ii + N * (j - N)] * exp(-fabs(recn[R::K + j - N]) * thn);
+                }
+                sx = mfma16(aop, xn[kk], sx);
+            }
+            for (int r = 0; r < 4; ++r) v[r] += sx[r];
+        }
+        mf4 x = {0, 0, 0, 0};
+        for (int kk = 0; kk < 4; ++kk) x = mfma16(dg[col * M2 + 4 * kk + q], v[kk], x);
+        for (int r = 0; r < 4; ++r) {
+            xn[r] = x[r];
+            if (col == 0) xs[4 * r + q] = x[r];
+        }
+    }
+    if (__any(sing) && lane == 0) atomicOr(&b.status[w], skd::ERR_SINGULAR_BVP);
+}
+
 // K2c for N = 8.  Same operators as skd::k2c_layer_ops; FP, SP and BP are stored as ready-made A-operand images
 // (FP: k-step r at [FP + 64 r + lane], r < 4;  SP / BP: [SP + 64 r + lane], [BP + 64 r + lane], r < 2) for kern_k2b_mfma8.
 //   FP^T = F^T Dinv  and  [SP | BP]^T = [SupT | SubT]^T Dinv  are two chains of four matrix-core products.
