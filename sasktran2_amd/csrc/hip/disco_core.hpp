@@ -346,8 +346,8 @@ template <int M> SKD_HD bool invert(double* A, double* Ainv) {
 // Green's function multipliers C+-(tau, sec, k; T) with their partial derivatives.
 //   reference: solveParticularGreen, sktran_do_rte.cpp:1039-1237 (second-order Taylor forms when |sec -+ k| <= 1e-4)
 struct Mult { double v, d_tau, d_sec, d_k; };  // dC/dT = v / T
-SKD_HD void green_multipliers(double T, double th, double sc, double ev, Mult& Cp, Mult& Cm) {
-    const double exp_te = exp(-th * ev), exp_ts = exp(-th * sc);
+// exp_te = exp(-th ev), exp_ts = exp(-th sc) are passed in (the second one is the same for every solution of a layer)
+SKD_HD void green_multipliers_e(double T, double th, double sc, double ev, double exp_te, double exp_ts, Mult& Cp, Mult& Cm) {
     if (fabs(sc - ev) > kGreensEps) {
         double den = sc - ev;
         Cp.v = T * (exp_te - exp_ts) / den;
@@ -362,8 +362,8 @@ SKD_HD void green_multipliers(double T, double th, double sc, double ev, Mult& C
     }
     if (fabs(sc + ev) > kGreensEps) {
         double den = sc + ev;
-        double exp_sum = exp(-th * (sc + ev));
-        Cm.v = T * (1 - exp_ts * exp_te) / den;
+        double exp_sum = exp_te * exp_ts;
+        Cm.v = T * (1 - exp_sum) / den;
         Cm.d_sec = (T * th * exp_sum - Cm.v) / den;
         Cm.d_k = Cm.d_sec;
         Cm.d_tau = T * exp_sum;
@@ -373,6 +373,9 @@ SKD_HD void green_multipliers(double T, double th, double sc, double ev, Mult& C
         Cm.d_k = -T * th * th / 2;
         Cm.d_tau = T * (1 - th * (sc + ev));
     }
+}
+SKD_HD void green_multipliers(double T, double th, double sc, double ev, Mult& Cp, Mult& Cm) {
+    green_multipliers_e(T, th, sc, ev, exp(-th * ev), exp(-th * sc), Cp, Cm);
 }
 
 // =================================================================================================
@@ -493,6 +496,7 @@ template <int N> SKD_HD void k1_layer_solution(const Geo& g, const Bufs& b, int 
         nrm[j] = 0;
         dnrm[j] = 0;
         out(R::K + j) = kk[j];
+        out(R::E + j) = exp(-kk[j] * th);
         out(R::DK + j) = dk[j];
         for (int i = 0; i < N; ++i) {
             double uk = U[i * N + j] / kk[j];

@@ -303,6 +303,19 @@ struct Timer {
 inline unsigned blocks(size_t n, int bs = kBlock) { return unsigned((n + bs - 1) / bs); }
 }  // namespace
 
+// K1 launch: lane-group width per layer and the split of the layers over blockIdx.y
+template <int N>
+static void launch_k1(hipStream_t st, const Geo& g, const Bufs& b, int s, int m) {
+    constexpr int LG = (N >= 16) ? 64 : SKD_K1_LG;
+    int split = 1;
+    if (const char* e = std::getenv("SASKTRAN2_AMD_K1SPLIT")) split = std::max(1, atoi(e));
+    const int ng = 64 / LG;
+    int lpb = (g.nlyr + split - 1) / split;
+    lpb = (lpb + ng - 1) / ng * ng;
+    const int ny = (g.nlyr + lpb - 1) / lpb;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_wave<N, LG>), dim3(unsigned(b.nw), unsigned(ny)), dim3(64), 0, st, g, b, s, m, lpb);
+}
+
 template <int N>
 static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hipStream_t st, int derivs) {
     const Geo& g = I.g;
@@ -327,7 +340,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
         for (int m = 0; m < g.nstr; ++m) {
             {
                 Timer t(I, st, "k1_layer_solution");
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, 0, m);
+                launch_k1<N>(st, g, b, 0, m);
             }
             {
                 Timer t(I, st, "k2a_bvp");
@@ -363,7 +376,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
         for (int m = 0; m < g.nstr; ++m) {
             {
                 Timer t(I, st, "k1_layer_solution");
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                launch_k1<N>(st, g, b, s, m);
             }
             {
                 Timer t(I, st, "k2a_bvp");

@@ -14,8 +14,20 @@
 #ifndef SKD_EXP_MAXSWEEP
 #define SKD_EXP_MAXSWEEP 60
 #endif
+#ifndef SKD_WPE_K2AM
+#define SKD_WPE_K2AM 4
+#endif
+#ifndef SKD_WPE_K2BM
+#define SKD_WPE_K2BM 1
+#endif
+#ifndef SKD_WPE_K2CM
+#define SKD_WPE_K2CM 1
+#endif
+#ifndef SKD_K1_LG
+#define SKD_K1_LG 32
+#endif
 #ifndef SKD_WPE_K1
-#define SKD_WPE_K1 1
+#define SKD_WPE_K1 2
 #endif
 #ifndef SKD_WPE_K2A
 #define SKD_WPE_K2A 1
@@ -37,8 +49,9 @@ using skd::Geo;
 // lanes; each group owns one layer per pass and keeps the layer's streams x streams matrices in LDS
 // (B+, B-, Cholesky factor, Jacobi work matrix, eigenvectors, ...).  Same mathematics as skd::k1_layer_solution.
 // -------------------------------------------------------------------------------------------------------------------
-template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_k1_wave(Geo g, Bufs b, int s, int m) {
-    constexpr int NSTR = 2 * N, NN = N * N, LG = (N >= 16) ? 64 : 16, NG = 64 / LG;
+template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_k1_wave(Geo g, Bufs b, int s, int m, int layers_per_block) {
+    constexpr int NSTR = 2 * N, NN = N * N, NG = 64 / LG;
+    static_assert(LG >= N && (LG == 16 || LG == 32 || LG == 64), "lane group must cover one matrix row");
     using R = skd::Rec<N>;
     const int w = blockIdx.x;
     if (m >= b.norders[w]) return;
@@ -78,15 +91,18 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_k1_wave(
     double* vdAm = sVec[grp][11];
     double* vC = sVec[grp][12];   // Cp.v, Cm.v interleaved: [2j], [2j+1]
     double* vdC = sVec[grp][13];  // dCp[4], dCm[4] per j -> 8N doubles (rows 13..16)
+    double* vE = vnrm;       // exp(-k_j tau), j < N, and exp(-sec tau) at [N]
+    double* vCoef = vC;      // 10 N doubles: rows 12..16 of sVec
     double* vAl = vQp;       // rotation parameters of the Jacobi rounds (the Q / A rows are written later)
     double* vBe = vQm;
     double* vPartner = vAp;
     const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * skd::kPi);
     __syncthreads();
 
-    for (int pbase = 0; pbase < nlyr; pbase += NG) {
-        const bool valid = (pbase + grp) < nlyr;
-        const int p = valid ? pbase + grp : nlyr - 1;
+    const int p_begin = blockIdx.y * layers_per_block, p_end = min(nlyr, p_begin + layers_per_block);
+    for (int pbase = p_begin; pbase < p_end; pbase += NG) {
+        const bool valid = (pbase + grp) < p_end;
+        const int p = valid ? pbase + grp : p_end - 1;
         const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
         const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
         double* rec = skd::rec_at<N>(b, nlyr, p, w);
@@ -299,65 +315,74 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_k1_wave(
             vQp[i] = sp * fm * sWt[i] * om;
             vQm[i] = sn * fm * sWt[i] * om;
         }
+        // exp(-k_j tau) of every solution and exp(-sec tau) of the layer: one instruction stream for N + 1 lanes
+        if (gl <= N) vE[gl] = exp(-th * ((gl < N) ? vk[gl] : sc));
         __syncthreads();
+        // Green's function coefficients of solution j: norm, A+-, multipliers C+-, and the coefficient vectors of the
+        // particular solution  G = W (A C)  with their derivatives:  coef[(type * 5 + k) * N + j], type 0: (A-, C-), 1: (A+, C+);
+        // k = 0: A C,  k = 1 + theta: d(A C)/d theta at fixed W
         if (gl < N) {
             const int j = gl;
+            const double inv_om = 1.0 / om;
             bool allzero = true;
             for (int i = 0; i < N; ++i) if (vQp[i] != 0 || vQm[i] != 0) allzero = false;
             double nrm = 0, dnrm = 0, Ap = 0, Am = 0, dAp = 0, dAm = 0;
             for (int i = 0; i < N; ++i) {
                 const double wp = M5[i * N + j], wm = M3[i * N + j], dwp = M7[i * N + j], dwm = M6[i * N + j];
-                nrm += sWt[i] * sMu[i] * (wp * wp - wm * wm);
-                dnrm += sWt[i] * sMu[i] * 2.0 * (wp * dwp - wm * dwm);
-                Ap += vQp[i] * wp + vQm[i] * wm;
-                Am += vQm[i] * wp + vQp[i] * wm;
-                dAp += vQp[i] * dwp + vQp[i] / om * wp + vQm[i] * dwm + vQm[i] / om * wm;
-                dAm += vQm[i] * dwp + vQm[i] / om * wp + vQp[i] * dwm + vQp[i] / om * wm;
+                const double wmu = sWt[i] * sMu[i], qp = vQp[i], qm = vQm[i];
+                nrm += wmu * (wp * wp - wm * wm);
+                dnrm += wmu * 2.0 * (wp * dwp - wm * dwm);
+                Ap += qp * wp + qm * wm;
+                Am += qm * wp + qp * wm;
+                dAp += qp * (dwp + inv_om * wp) + qm * (dwm + inv_om * wm);
+                dAm += qm * (dwp + inv_om * wp) + qp * (dwm + inv_om * wm);
             }
             skd::Mult Cp{0, 0, 0, 0}, Cm{0, 0, 0, 0};
             if (allzero) {
                 Ap = Am = dAp = dAm = 0;
             } else {
-                Ap /= nrm;
-                Am /= nrm;
-                dAp = dAp / nrm - dnrm * Ap / nrm;
-                dAm = dAm / nrm - dnrm * Am / nrm;
-                skd::green_multipliers(T, th, sc, vk[j], Cp, Cm);
+                const double inv = 1.0 / nrm;
+                Ap *= inv;
+                Am *= inv;
+                dAp = (dAp - dnrm * Ap) * inv;
+                dAm = (dAm - dnrm * Am) * inv;
+                skd::green_multipliers_e(T, th, sc, vk[j], vE[j], vE[N], Cp, Cm);
             }
-            vAp[j] = Ap; vAm[j] = Am; vdAp[j] = dAp; vdAm[j] = dAm;
-            vC[2 * j] = Cp.v;
-            vC[2 * j + 1] = Cm.v;
-            const double dk = vdk[j];
-            vdC[8 * j + 0] = Cp.d_tau; vdC[8 * j + 1] = Cp.d_k * dk; vdC[8 * j + 2] = (T != 0) ? Cp.v / T : 0.0; vdC[8 * j + 3] = Cp.d_sec;
-            vdC[8 * j + 4] = Cm.d_tau; vdC[8 * j + 5] = Cm.d_k * dk; vdC[8 * j + 6] = (T != 0) ? Cm.v / T : 0.0; vdC[8 * j + 7] = Cm.d_sec;
+            const double dk = vdk[j], invT = (T != 0) ? 1.0 / T : 0.0;
+            const double dCm[4] = {Cm.d_tau, Cm.d_k * dk, Cm.v * invT, Cm.d_sec};
+            const double dCp[4] = {Cp.d_tau, Cp.d_k * dk, Cp.v * invT, Cp.d_sec};
+            vCoef[(0 * 5 + 0) * N + j] = Am * Cm.v;
+            vCoef[(1 * 5 + 0) * N + j] = Ap * Cp.v;
+            for (int t = 0; t < 4; ++t) {
+                vCoef[(0 * 5 + 1 + t) * N + j] = Am * dCm[t] + ((t == skd::TH_OM) ? dAm * Cm.v : 0.0);
+                vCoef[(1 * 5 + 1 + t) * N + j] = Ap * dCp[t] + ((t == skd::TH_OM) ? dAp * Cp.v : 0.0);
+            }
             if (valid) {
                 rec[R::K + j] = vk[j];
+                rec[R::E + j] = vE[j];
                 rec[R::DK + j] = dk;
                 rec[R::AP + j] = Ap; rec[R::AM + j] = Am; rec[R::DAP + j] = dAp; rec[R::DAM + j] = dAm;
             }
         }
         __syncthreads();
-        // G (4 vectors) and dG (4 params x 4 vectors): items (t in 0..4, c, i), t == 4 -> value
-        for (int it = gl; it < 5 * 4 * N; it += LG) {
-            const int t = it / (4 * N), c = (it / N) % 4, i = it % N;
-            double acc = 0;
+        // G (4 vectors) and dG (4 params x 4 vectors).  A lane owns row i of W+ or W- (and of its omega-derivative) and one
+        // coefficient type: G[c] = Wsel coef_0, dG[theta][c] = Wsel coef_{1+theta} (+ dWsel coef_0 for theta = omega),
+        // c = 0: (W-, type 0), 1: (W+, type 0), 2: (W+, type 1), 3: (W-, type 1)
+        for (int it = gl; it < 4 * N; it += LG) {
+            const int i = it % N, sel = (it / N) & 1, type = it / (2 * N);
+            const double* Wsel = sel ? M3 : M5;
+            const double* dWsel = sel ? M6 : M7;
+            const int c = (type == 0) ? (sel ? 0 : 1) : (sel ? 3 : 2);
+            const double* cf = vCoef + (type * 5) * N;
+            double acc[5] = {0, 0, 0, 0, 0}, accd = 0;
             for (int j = 0; j < N; ++j) {
-                const double wp = M5[i * N + j], wm = M3[i * N + j], dwp = M7[i * N + j], dwm = M6[i * N + j];
-                const bool plusC = (c >= 2);  // G+bot, G-bot use A+ C+ ; G+top, G-top use A- C-
-                const double A = plusC ? vAp[j] : vAm[j], dA = plusC ? vdAp[j] : vdAm[j];
-                const double Cv = plusC ? vC[2 * j] : vC[2 * j + 1];
-                const double wsel = (c == 0 || c == 3) ? wm : wp, dwsel = (c == 0 || c == 3) ? dwm : dwp;
-                if (t == 4) {
-                    acc += A * Cv * wsel;
-                } else {
-                    const double dCv = vdC[8 * j + (plusC ? 0 : 4) + t];
-                    acc += A * dCv * wsel;
-                    if (t == skd::TH_OM) acc += dA * Cv * wsel + A * Cv * dwsel;
-                }
+                const double wv = Wsel[i * N + j], dwv = dWsel[i * N + j];
+                for (int k = 0; k < 5; ++k) acc[k] += wv * cf[k * N + j];
+                accd += dwv * cf[j];
             }
             if (valid) {
-                if (t == 4) rec[R::G + c * N + i] = acc;
-                else rec[R::DG + (t * 4 + c) * N + i] = acc;
+                rec[R::G + c * N + i] = acc[0];
+                for (int t = 0; t < 4; ++t) rec[R::DG + (t * 4 + c) * N + i] = acc[1 + t] + ((t == skd::TH_OM) ? accd : 0.0);
             }
         }
         __syncthreads();
@@ -832,7 +857,7 @@ __device__ __forceinline__ mf4 mfma16(double a, double bb, mf4 c) { return __bui
 //   backward    x_p = Dinv'_p (r'_p - Sup_p x_{p+1})   (4 + 4 products)
 //   Vectors are kept "replicated": every lane (col, q) holds entries 4 r + q, r = 0..3, so a vector is a B operand as it is.
 //   Same equations as skd::k2a_bvp / kern_k2a_wave (reference: sktran_do_rte.cpp:1620-1790,1897-2294).
-__global__ void __launch_bounds__(64) kern_k2a_mfma8(Geo g, Bufs b, int s, int m) {
+__global__ void __launch_bounds__(64, SKD_WPE_K2AM) kern_k2a_mfma8(Geo g, Bufs b, int s, int m) {
     constexpr int N = 8, M2 = 16;
     using R = skd::Rec<N>;
     const int w = blockIdx.x;
@@ -846,8 +871,7 @@ __global__ void __launch_bounds__(64) kern_k2a_mfma8(Geo g, Bufs b, int s, int m
     for (int p = 0; p < nlyr; ++p) {
         const bool last = (p == nlyr - 1);
         const double* rec = skd::rec_at<N>(b, nlyr, p, w);
-        const double th = b.tau[size_t(p) * nw + w];
-        const double Ecol = exp(-fabs(rec[R::K + jc]) * th);
+        const double Ecol = rec[R::E + jc];  // exp(-k_j tau), written by K1
         // D_p and r_p, rows 4 r + q
         mf4 acc;
         double rv[4];
@@ -885,12 +909,11 @@ __global__ void __launch_bounds__(64) kern_k2a_mfma8(Geo g, Bufs b, int s, int m
         }
         if (p > 0) {
             const double* recm = skd::rec_at<N>(b, nlyr, p - 1, w);
-            const double thm = b.tau[size_t(p - 1) * nw + w];
             mf4 t1 = {0, 0, 0, 0};
             for (int kk = 0; kk < 4; ++kk) {
                 const int j = 4 * kk + q;
                 double bop = 0.0;  // Sub_p[i = col][j]: [W+_{p-1} E_{p-1} | W-_{p-1}]
-                if (col < N) bop = (j < N) ? recm[R::WP + col + N * j] * exp(-fabs(recm[R::K + j]) * thm) : recm[R::WM + col + N * (j - N)];
+                if (col < N) bop = (j < N) ? recm[R::WP + col + N * j] * recm[R::E + j] : recm[R::WM + col + N * (j - N)];
                 t1 = mfma16(dprev[kk], bop, t1);
             }
             for (int kk = 0; kk < 2; ++kk) {
@@ -906,6 +929,11 @@ __global__ void __launch_bounds__(64) kern_k2a_mfma8(Geo g, Bufs b, int s, int m
         unsigned used = 0;
         unsigned long long permP = 0, permI = 0;
         for (int k = 0; k < M2; ++k) {
+            // column k -> lanes 0..15 (independent of the pivot choice, issued first): D[i = col][k] lives in lane (k, i & 3), register i >> 2
+            const int src = k + 16 * (col & 3);
+            const double c0 = __shfl(acc[0], src), c1 = __shfl(acc[1], src), c2 = __shfl(acc[2], src), c3 = __shfl(acc[3], src);
+            const int ir = col >> 2;
+            const double colv = (ir == 0) ? c0 : (ir == 1) ? c1 : (ir == 2) ? c2 : c3;
             double bv = -1.0, bs = 0.0;
             int br = 0;
             for (int r = 0; r < 4; ++r) {
@@ -921,14 +949,13 @@ __global__ void __launch_bounds__(64) kern_k2a_mfma8(Geo g, Bufs b, int s, int m
             const int pivrow = __builtin_amdgcn_readlane(br, k);
             double pv = __shfl(bs, k);
             if (!(fabs(pv) > 0)) { sing = 1; pv = 1.0; }
-            const double ip = 1.0 / pv;
+            // reciprocal of the pivot: hardware estimate + two Newton steps (full double precision, short dependency chain)
+            double ip = __builtin_amdgcn_rcp(pv);
+            ip = fma(fma(-pv, ip, 1.0), ip, ip);
+            ip = fma(fma(-pv, ip, 1.0), ip, ip);
             const int pr = pivrow >> 2, pq = pivrow & 3;
             const double rowsel = (pr == 0) ? acc[0] : (pr == 1) ? acc[1] : (pr == 2) ? acc[2] : acc[3];
             const double rowv = __shfl(rowsel, col + 16 * pq);  // D[pivrow][col]
-            const int src = k + 16 * (col & 3);                 // D[i = col][k] lives in lane (k, i & 3), register i >> 2
-            const double c0 = __shfl(acc[0], src), c1 = __shfl(acc[1], src), c2 = __shfl(acc[2], src), c3 = __shfl(acc[3], src);
-            const int ir = col >> 2;
-            const double colv = (ir == 0) ? c0 : (ir == 1) ? c1 : (ir == 2) ? c2 : c3;
             const double aop = (q == 0 && col != pivrow) ? -colv * ip : 0.0;
             const double bop = (q == 0 && col != k) ? rowv : 0.0;
             acc = mfma16(aop, bop, acc);
@@ -970,14 +997,13 @@ __global__ void __launch_bounds__(64) kern_k2a_mfma8(Geo g, Bufs b, int s, int m
         for (int r = 0; r < 4; ++r) v[r] = __shfl(v[r], 16 * q);  // replicate over the 16 columns
         if (p < nlyr - 1) {
             const double* recn = skd::rec_at<N>(b, nlyr, p + 1, w);
-            const double thn = b.tau[size_t(p + 1) * nw + w];
             mf4 sx = {0, 0, 0, 0};
             for (int kk = 0; kk < 4; ++kk) {
                 const int j = 4 * kk + q;
                 double aop = 0.0;  // rows 8..15: [W-_{p+1} | W+_{p+1} E_{p+1}]
                 if (col >= N) {
                     const int ii = col - N;
-                    aop = (j < N) ? recn[R::WM + ii + N * j] : recn[R::WP + ii + N * (j - N)] * exp(-fabs(recn[R::K + j - N]) * thn);
+                    aop = (j < N) ? recn[R::WM + ii + N * j] : recn[R::WP + ii + N * (j - N)] * recn[R::E + j - N];
                 }
                 sx = mfma16(aop, xn[kk], sx);
             }
@@ -996,7 +1022,7 @@ __global__ void __launch_bounds__(64) kern_k2a_mfma8(Geo g, Bufs b, int s, int m
 // K2c for N = 8.  Same operators as skd::k2c_layer_ops; FP, SP and BP are stored as ready-made A-operand images
 // (FP: k-step r at [FP + 64 r + lane], r < 4;  SP / BP: [SP + 64 r + lane], [BP + 64 r + lane], r < 2) for kern_k2b_mfma8.
 //   FP^T = F^T Dinv  and  [SP | BP]^T = [SupT | SubT]^T Dinv  are two chains of four matrix-core products.
-__global__ void __launch_bounds__(64) kern_k2c_mfma8(Geo g, Bufs b, int s, int m) {
+__global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b, int s, int m) {
     constexpr int N = 8, NSTR = 16, M2 = 16;
     using R = skd::Rec<N>;
     using O = skd::Ops<N>;
@@ -1151,7 +1177,7 @@ __global__ void __launch_bounds__(64) kern_k2c_mfma8(Geo g, Bufs b, int s, int m
 //             rows 4..7 carry sum_i zB_i for the ground terms)
 //   Y / Z tiles and the HD part are kept in HBM between the sweeps in their C/D register images
 //   (b.z: [w][p][tile][4][64], b.qlbuf: [w][p][tile][64]); nothing goes through LDS.
-template <int TILES> __global__ void __launch_bounds__(64) kern_k2b_mfma8(Geo g, Bufs b, int s, int m) {
+template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2b_mfma8(Geo g, Bufs b, int s, int m) {
     constexpr int N = 8, NSTR = 16;
     using O = skd::Ops<N>;
     const int w = blockIdx.x;
