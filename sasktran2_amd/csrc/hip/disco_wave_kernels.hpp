@@ -58,7 +58,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
     const int lane = threadIdx.x, grp = lane / LG, gl = lane % LG, nw = b.nw, nlyr = g.nlyr;
     __shared__ double sMat[NG][8][NN];
     __shared__ double sVec[NG][18][NSTR];
-    __shared__ double sLp[N * NSTR], sLc[NSTR], sMu[N], sWt[N], sSq[N], sTt[N];
+    __shared__ double sLp[N * NSTR], sLc[NSTR], sMu[N], sWt[N], sSq[N], sTt[N], sIm[N], sIt[N];
     __shared__ int sErr;
     for (int i = lane; i < N * NSTR; i += 64) sLp[i] = g.lpmu[size_t(m) * N * NSTR + i];
     for (int i = lane; i < NSTR; i += 64) sLc[i] = g.lpcsz[(size_t(s) * NSTR + m) * NSTR + i];
@@ -67,6 +67,8 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
         sWt[lane] = g.wt[lane];
         sSq[lane] = sqrt(g.wt[lane] / g.mu[lane]);
         sTt[lane] = sqrt(g.wt[lane] * g.mu[lane]);
+        sIm[lane] = 1.0 / g.mu[lane];
+        sIt[lane] = 1.0 / sqrt(g.wt[lane] * g.mu[lane]);
     }
     if (lane == 0) sErr = 0;
     double* Bp = sMat[grp][0];
@@ -91,6 +93,8 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
     double* vdAm = sVec[grp][11];
     double* vC = sVec[grp][12];   // Cp.v, Cm.v interleaved: [2j], [2j+1]
     double* vdC = sVec[grp][13];  // dCp[4], dCm[4] per j -> 8N doubles (rows 13..16)
+    double* vRinv = vdnrm;   // reciprocal diagonal of the Cholesky factor
+    double* vIk = vAm;       // 1 / k_j
     double* vE = vnrm;       // exp(-k_j tau), j < N, and exp(-sec tau) at [N]
     double* vCoef = vC;      // 10 N doubles: rows 12..16 of sVec
     double* vAl = vQp;       // rotation parameters of the Jacobi rounds (the Q / A rows are written later)
@@ -105,6 +109,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
         const int p = valid ? pbase + grp : p_end - 1;
         const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
         const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
+        const double inv_om_l = 1.0 / om;
         double* rec = skd::rec_at<N>(b, nlyr, p, w);
         for (int l = gl; l < NSTR; l += LG) va[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
         __syncthreads();
@@ -116,7 +121,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
                 const double t = va[l] * sLp[i * NSTR + l] * sLp[j * NSTR + l];
                 if ((l - m) & 1) em += t; else ep += t;
             }
-            const double dlt = (i == j) ? 1.0 / sMu[i] : 0.0;
+            const double dlt = (i == j) ? sIm[i] : 0.0;
             const double bp = dlt - sSq[i] * sSq[j] * om * ep;
             Bp[e] = bp;
             Bm[e] = dlt - sSq[i] * sSq[j] * om * em;
@@ -128,16 +133,17 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             double tj = Rc[j * N + j];
             for (int k = 0; k < j; ++k) tj -= Rc[j * N + k] * Rc[j * N + k];
             if (!(tj > 0)) { if (gl == 0) sErr = skd::ERR_CHOLESKY; tj = 1.0; }
-            const double d = sqrt(tj);
+            const double d = sqrt(tj), rd = 1.0 / d;
             double val = 0;
             const int i = gl;
             const bool mine = (i < N && i >= j);
             if (mine) {
                 double t = Rc[i * N + j];
                 for (int k = 0; k < j; ++k) t -= Rc[i * N + k] * Rc[j * N + k];
-                val = (i == j) ? d : t / d;
+                val = (i == j) ? d : t * rd;
             }
             __syncthreads();
+            if (gl == 0) vRinv[j] = rd;
             if (mine) Rc[i * N + j] = val;
             __syncthreads();
         }
@@ -230,14 +236,15 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             if (!(lam > 0)) { sErr = skd::ERR_EIGEN; lam = fabs(lam) + 1e-300; }
             vlam[gl] = lam;
             vk[gl] = sqrt(lam);
+            vIk[gl] = 1.0 / sqrt(lam);
             // xhat = R^-T v (column gl, in place), x = T^-1 xhat
             const int j = gl;
             for (int i = N - 1; i >= 0; --i) {
                 double t = M5[i * N + j];
                 for (int r = i + 1; r < N; ++r) t -= Rc[r * N + i] * M5[r * N + j];
-                M5[i * N + j] = t / Rc[i * N + i];
+                M5[i * N + j] = t * vRinv[i];
             }
-            for (int i = 0; i < N; ++i) M5[i * N + j] /= sTt[i];
+            for (int i = 0; i < N; ++i) M5[i * N + j] *= sIt[i];
         }
         __syncthreads();
         // U (M3) = S+ X with S+-_ir = B+-_ir tt_r / tt_i
@@ -245,16 +252,16 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             const int i = e / N, j = e % N;
             double t = 0;
             for (int r = 0; r < N; ++r) t += Bp[i * N + r] * sTt[r] * M5[r * N + j];
-            M3[e] = t / sTt[i];
+            M3[e] = t * sIt[i];
         }
         __syncthreads();
         // d(Gamma) X (M4)
         for (int e = gl; e < NN; e += LG) {
             const int i = e / N, j = e % N;
             double hm = 0;
-            for (int r = 0; r < N; ++r) hm += Bm[i * N + r] * sTt[r] * M5[r * N + j] / sMu[r];
-            hm /= sTt[i];
-            M4[e] = (2 * M5[e] * vlam[j] - M3[e] / sMu[i] - hm) / om;
+            for (int r = 0; r < N; ++r) hm += Bm[i * N + r] * (sTt[r] * sIm[r]) * M5[r * N + j];
+            hm *= sIt[i];
+            M4[e] = (2 * M5[e] * vlam[j] - M3[e] * sIm[i] - hm) * inv_om_l;
         }
         __syncthreads();
         // C (M6), dk
@@ -265,7 +272,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             double z = 0;
             for (int i = 0; i < N; ++i) z += sWt[i] * sMu[i] * M3[i * N + aa] * M4[i * N + bb];
             if (aa == bb) {
-                vdk[bb] = z / (2 * vk[bb]);
+                vdk[bb] = 0.5 * z * vIk[bb];
                 M6[e] = 0;
             } else {
                 const double den = vlam[bb] - vlam[aa];
@@ -286,14 +293,15 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             const int i = e / N, j = e % N;
             double t = 0;
             for (int r = 0; r < N; ++r) t += Bp[i * N + r] * sTt[r] * M7[r * N + j];
-            M6[e] = (M3[e] - M5[e] / sMu[i]) / om + t / sTt[i];
+            M6[e] = (M3[e] - M5[e] * sIm[i]) * inv_om_l + t * sIt[i];
         }
         __syncthreads();
         // W+-, dW+- (element-wise, in place: M5 <- W+, M3 <- W-, M7 <- dW+, M6 <- dW-), stored as W(i, solution j) at i + N j
         for (int e = gl; e < NN; e += LG) {
             const int i = e / N, j = e % N;
             const double X = M5[e], U = M3[e], dX = M7[e], dU = M6[e];
-            const double uk = U / vk[j], duk = dU / vk[j] - U * vdk[j] / vlam[j];
+            const double ik = vIk[j];
+            const double uk = U * ik, duk = dU * ik - U * vdk[j] * ik * ik;
             const double wp = 0.5 * (X + uk), wm = 0.5 * (X - uk), dwp = 0.5 * (dX + duk), dwm = 0.5 * (dX - duk);
             M5[e] = wp; M3[e] = wm; M7[e] = dwp; M6[e] = dwm;
             if (valid) {
@@ -677,6 +685,7 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2C) kern_k2c_wav
         if (lane < M2) sXs[lane] = xs[lane];
         if (lane < NSTR) sa[lane] = (lane >= m) ? b.a[(size_t(p) * NSTR + lane) * nw + w] : 0.0;
         const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w];
+        const double inv_om = 1.0 / om, inv_T = (T != 0) ? 1.0 / T : 0.0;
         __syncthreads();
         // phase A: F = [UL; UM] and the per-(j,l) pieces of the direct-dependence rows
         for (int idx = lane; idx < N * NSTR; idx += 64) {
@@ -686,7 +695,7 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2C) kern_k2c_wav
             for (int r = 0; r < N; ++r) {
                 const double cm = 0.5 * g.wt[r] * om * sa[l] * lpmu[r * NSTR + l];
                 const double wp = sRec[R::WP + r + N * j], wm = sRec[R::WM + r + N * j];
-                const double dwp = sRec[R::DWP + r + N * j] + wp / om, dwm = sRec[R::DWM + r + N * j] + wm / om;
+                const double dwp = sRec[R::DWP + r + N * j] + wp * inv_om, dwm = sRec[R::DWM + r + N * j] + wm * inv_om;
                 yp += cm * (sg * wp + wm);
                 ym += cm * (sg * wm + wp);
                 dyp += cm * (sg * dwp + dwm);
@@ -694,15 +703,15 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2C) kern_k2c_wav
             }
             skd::PPMult pm;
             skd::ppm_load(&sRec[R::PPM + 14 * j], pm);
-            sF[j * NSTR + l] = yp * pm.hp / om;
-            sF[(N + j) * NSTR + l] = ym * pm.hm / om;
+            sF[j * NSTR + l] = yp * pm.hp * inv_om;
+            sF[(N + j) * NSTR + l] = ym * pm.hm * inv_om;
             const double L = sXs[j], Mv = sXs[N + j], dk = sRec[R::DK + j];
             const double Ap = sRec[R::AP + j], Am = sRec[R::AM + j], dAp = sRec[R::DAP + j], dAm = sRec[R::DAM + j];
             const double tL = pm.hp * L + Ap * pm.Dm, tM = pm.hm * Mv + Am * pm.Dp;
             sH[(4 * N + j) * NSTR + l] = yp * tL + ym * tM;
             sH[(skd::TH_TAU * N + j) * NSTR + l] = yp * (pm.hp_tau * L + Ap * pm.Dm_tau) + ym * (pm.hm_tau * Mv + Am * pm.Dp_tau);
             sH[(skd::TH_SEC * N + j) * NSTR + l] = yp * Ap * pm.Dm_sec + ym * Am * pm.Dp_sec;
-            sH[(skd::TH_T * N + j) * NSTR + l] = (T != 0) ? (yp * Ap * pm.Dm + ym * Am * pm.Dp) / T : 0.0;
+            sH[(skd::TH_T * N + j) * NSTR + l] = (yp * Ap * pm.Dm + ym * Am * pm.Dp) * inv_T;
             sH[(skd::TH_OM * N + j) * NSTR + l] = dyp * tL + dym * tM + yp * (pm.hp_k * dk * L + dAp * pm.Dm + Ap * pm.Dm_k * dk) +
                                                   ym * (pm.hm_k * dk * Mv + dAm * pm.Dp + Am * pm.Dp_k * dk);
         }
@@ -755,8 +764,8 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2C) kern_k2c_wav
                 acc += sH[(t * N + j) * NSTR + l];
                 val += sH[(4 * N + j) * NSTR + l];
             }
-            acc /= om;
-            if (t == skd::TH_OM) acc -= val / (om * om);
+            acc *= inv_om;
+            if (t == skd::TH_OM) acc -= val * inv_om * inv_om;
             o[O::HD + idx] = acc;
         }
         for (int idx = lane; idx < M2 * NSTR; idx += 64) {
@@ -1046,6 +1055,7 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b
         double dinv_b[4];  // B operand of both chains: Dinv[4 kk + (lane >> 4)][lane & 15] = dg[64 kk + lane]
         for (int kk = 0; kk < 4; ++kk) dinv_b[kk] = dg[64 * kk + lane];
         const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w];
+        const double inv_om = 1.0 / om, inv_T = (T != 0) ? 1.0 / T : 0.0;
         __syncthreads();
         // phase A: F = [UL; UM] and the per-(j,l) pieces of the direct-dependence rows
         for (int idx = lane; idx < N * NSTR; idx += 64) {
@@ -1055,7 +1065,7 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b
             for (int r = 0; r < N; ++r) {
                 const double cm = 0.5 * g.wt[r] * om * sa[l] * lpmu[r * NSTR + l];
                 const double wp = sRec[R::WP + r + N * j], wm = sRec[R::WM + r + N * j];
-                const double dwp = sRec[R::DWP + r + N * j] + wp / om, dwm = sRec[R::DWM + r + N * j] + wm / om;
+                const double dwp = sRec[R::DWP + r + N * j] + wp * inv_om, dwm = sRec[R::DWM + r + N * j] + wm * inv_om;
                 yp += cm * (sg * wp + wm);
                 ym += cm * (sg * wm + wp);
                 dyp += cm * (sg * dwp + dwm);
@@ -1063,15 +1073,15 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b
             }
             skd::PPMult pm;
             skd::ppm_load(&sRec[R::PPM + 14 * j], pm);
-            sF[j * NSTR + l] = yp * pm.hp / om;
-            sF[(N + j) * NSTR + l] = ym * pm.hm / om;
+            sF[j * NSTR + l] = yp * pm.hp * inv_om;
+            sF[(N + j) * NSTR + l] = ym * pm.hm * inv_om;
             const double L = sXs[j], Mv = sXs[N + j], dk = sRec[R::DK + j];
             const double Ap = sRec[R::AP + j], Am = sRec[R::AM + j], dAp = sRec[R::DAP + j], dAm = sRec[R::DAM + j];
             const double tL = pm.hp * L + Ap * pm.Dm, tM = pm.hm * Mv + Am * pm.Dp;
             sH[(4 * N + j) * NSTR + l] = yp * tL + ym * tM;
             sH[(skd::TH_TAU * N + j) * NSTR + l] = yp * (pm.hp_tau * L + Ap * pm.Dm_tau) + ym * (pm.hm_tau * Mv + Am * pm.Dp_tau);
             sH[(skd::TH_SEC * N + j) * NSTR + l] = yp * Ap * pm.Dm_sec + ym * Am * pm.Dp_sec;
-            sH[(skd::TH_T * N + j) * NSTR + l] = (T != 0) ? (yp * Ap * pm.Dm + ym * Am * pm.Dp) / T : 0.0;
+            sH[(skd::TH_T * N + j) * NSTR + l] = (yp * Ap * pm.Dm + ym * Am * pm.Dp) * inv_T;
             sH[(skd::TH_OM * N + j) * NSTR + l] = dyp * tL + dym * tM + yp * (pm.hp_k * dk * L + dAp * pm.Dm + Ap * pm.Dm_k * dk) +
                                                   ym * (pm.hm_k * dk * Mv + dAm * pm.Dp + Am * pm.Dp_k * dk);
         }
@@ -1145,8 +1155,8 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b
                 acc += sH[(t * N + j) * NSTR + l];
                 val += sH[(4 * N + j) * NSTR + l];
             }
-            acc /= om;
-            if (t == skd::TH_OM) acc -= val / (om * om);
+            acc *= inv_om;
+            if (t == skd::TH_OM) acc -= val * inv_om * inv_om;
             o[O::HD + idx] = acc;
         }
         if (lane < M2) {
