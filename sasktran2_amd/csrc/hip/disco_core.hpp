@@ -82,6 +82,8 @@ struct Geo {
     const int* lp_slot;
     const double* lp_w;
     const double* lp_cosm;  // [m][entry]  cos(m * azimuth of the entry's ray layer)   (16-stream matrix-core sweeps)
+    const int* lp_meta;     // [entry][2]  (table slot, table angle) packed for one 8-byte load
+    const double* lpang4;   // [m][a][q<4][kk<4] = lpang[m][a][4 kk + q]  (nstr = 16 only)
     int n_lp;               // number of (LOS, sza, layer) table entries
     const int* g_start;     // [los .. +1] ground entries
     const int* g_slot;

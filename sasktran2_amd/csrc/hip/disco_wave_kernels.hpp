@@ -18,7 +18,7 @@
 #define SKD_WPE_K2AM 4
 #endif
 #ifndef SKD_WPE_K2BM
-#define SKD_WPE_K2BM 1
+#define SKD_WPE_K2BM 4
 #endif
 #ifndef SKD_WPE_K2CM
 #define SKD_WPE_K2CM 1
@@ -1199,7 +1199,8 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
     double* hw = b.qlbuf + size_t(w) * nlyr * ntile * 64;
     const double* cwp = b.cwbuf + size_t(w) * g.n_lp;
     const double* cme = g.lp_cosm + size_t(m) * g.n_lp;
-    const double* lpm = g.lpang + size_t(m) * g.nangle * NSTR;
+    const double* lpm4 = g.lpang4 + size_t(m) * g.nangle * NSTR;
+    const int2* lpmeta = reinterpret_cast<const int2*>(g.lp_meta);
     const bool last_is_ground = (m == 0);
     for (int tile0 = 0; tile0 < ntile; tile0 += TILES) {
         int los[TILES];
@@ -1219,12 +1220,18 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
         // ---------------- forward sweep
         mf4 yprev[TILES];
         for (int t = 0; t < TILES; ++t) yprev[t] = mf4{0, 0, 0, 0};
+        // A operands of the layer (FP, SP, HD); the next layer's are requested before this layer's work starts
+        double fpa[4], spa[2], hda[4], nfpa[4], nspa[2], nhda[4];
+        auto load_fwd = [&](int p, double* f, double* sp_, double* h) {
+            const double* ops = skd::ops_at<N>(b, nlyr, p, w);
+            for (int kk = 0; kk < 4; ++kk) f[kk] = ops[O::FP + 64 * kk + lane];
+            for (int kk = 0; kk < 2; ++kk) sp_[kk] = ops[O::SP + 64 * kk + lane];
+            for (int kk = 0; kk < 4; ++kk) h[kk] = (col < 4) ? ops[O::HD + col * NSTR + 4 * kk + q] : 0.0;
+        };
+        load_fwd(0, fpa, spa, hda);
         for (int p = 0; p < nlyr; ++p) {
             const double* ops = skd::ops_at<N>(b, nlyr, p, w);
-            double fpa[4], spa[2], hda[4];
-            for (int kk = 0; kk < 4; ++kk) fpa[kk] = ops[O::FP + 64 * kk + lane];
-            for (int kk = 0; kk < 2; ++kk) spa[kk] = ops[O::SP + 64 * kk + lane];
-            for (int kk = 0; kk < 4; ++kk) hda[kk] = (col < 4) ? ops[O::HD + col * NSTR + 4 * kk + q] : 0.0;
+            if (p + 1 < nlyr) load_fwd(p + 1, nfpa, nspa, nhda);
             const bool last = (p == nlyr - 1);
             for (int t = 0; t < TILES; ++t) {
                 if ((tile0 + t) >= ntile) continue;
@@ -1240,17 +1247,24 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
                     const int e0 = g.lp_start[base], e1 = g.lp_start[base + 1];
                     for (int e = e0; e < e1; e += 4) {
                         double c[4];
-                        const double* lpa[4];
+                        double2 pa[4], pb[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int ee = (e + u < e1) ? e + u : e1 - 1;
-                            const bool live = (e + u < e1) && skd::conv_at(b, g, g.lp_slot[ee], w) > m;
+                            const int2 meta = lpmeta[ee];  // (slot, angle)
+                            const bool live = (e + u < e1) && skd::conv_at(b, g, meta.x, w) > m;
                             c[u] = live ? cwp[ee] * cme[ee] : 0.0;
-                            lpa[u] = lpm + size_t(g.lp_angle[ee]) * NSTR + q;
+                            const double2* lp2 = reinterpret_cast<const double2*>(lpm4 + (size_t(meta.y) * 4 + q) * 4);
+                            pa[u] = lp2[0];
+                            pb[u] = lp2[1];
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            for (int kk = 0; kk < 4; ++kk) ql4[kk] += c[u] * lpa[u][4 * kk];
+                        for (int u = 0; u < 4; ++u) {
+                            ql4[0] += c[u] * pa[u].x;
+                            ql4[1] += c[u] * pa[u].y;
+                            ql4[2] += c[u] * pb[u].x;
+                            ql4[3] += c[u] * pb[u].y;
+                        }
                     }
                     for (int kk = 0; kk < 4; ++kk)
                         if (4 * kk + q < m) ql4[kk] = 0.0;
@@ -1266,6 +1280,8 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
                 hw[(size_t(p) * ntile + tile0 + t) * 64 + lane] = hacc[0];
                 yprev[t] = acc;
             }
+            for (int kk = 0; kk < 4; ++kk) { fpa[kk] = nfpa[kk]; hda[kk] = nhda[kk]; }
+            for (int kk = 0; kk < 2; ++kk) spa[kk] = nspa[kk];
         }
         // ---------------- backward sweep with the reduced gradient
         mf4 znext[TILES], gprev[TILES];

@@ -15,7 +15,8 @@ struct GeoTables {
     std::vector<int> ray_qstart, ray_ground, rl_od_start, od_idx, rl_ssa_start, ssa_idx, rl_active, rl_tab_start, tab_slot;
     std::vector<double> ray_gsaa, od_w, ssa_w, rl_azi, rl_cosm, tab_w;
     std::vector<int> lp_start, lp_q, lp_angle, lp_slot, g_start, g_slot, g_sza;
-    std::vector<double> lp_w, g_w, lp_cosm;
+    std::vector<double> lp_w, g_w, lp_cosm, lpang4;
+    std::vector<int> lp_meta;
     std::vector<int> slot_is_ground;  // [nslot]
     // plane-parallel post-processing
     int pp_mode = 0;
@@ -125,6 +126,16 @@ struct GeoTables {
             for (const auto& e : lp[i]) { lp_q.push_back(e.q); lp_angle.push_back(e.angle); lp_slot.push_back(e.slot); lp_w.push_back(e.w); }
             lp_start[i + 1] = (int)lp_q.size();
         }
+        lp_meta.resize(2 * lp_q.size());
+        for (size_t e = 0; e < lp_q.size(); ++e) { lp_meta[2 * e] = lp_slot[e]; lp_meta[2 * e + 1] = lp_angle[e]; }
+        if (nstr == 16) {
+            lpang4.resize(lpang.size());
+            for (int m = 0; m < nstr; ++m)
+                for (int a = 0; a < nangle; ++a)
+                    for (int qq = 0; qq < 4; ++qq)
+                        for (int kk = 0; kk < 4; ++kk)
+                            lpang4[((size_t(m) * nangle + a) * 4 + qq) * 4 + kk] = lpang[(size_t(m) * nangle + a) * nstr + 4 * kk + qq];
+        }
         lp_cosm.resize(size_t(nstr) * lp_q.size());
         for (int m = 0; m < nstr; ++m)
             for (size_t e = 0; e < lp_q.size(); ++e) lp_cosm[size_t(m) * lp_q.size() + e] = rl_cosm[size_t(m) * nq_total + lp_q[e]];
@@ -170,7 +181,7 @@ struct GeoTables {
         g.rl_ssa_start = rl_ssa_start.data(); g.ssa_idx = ssa_idx.data(); g.ssa_w = ssa_w.data();
         g.rl_azi = rl_azi.data(); g.rl_cosm = rl_cosm.data(); g.rl_active = rl_active.data(); g.rl_tab_start = rl_tab_start.data();
         g.tab_slot = tab_slot.data(); g.tab_w = tab_w.data(); g.lp_start = lp_start.data(); g.lp_q = lp_q.data();
-        g.lp_angle = lp_angle.data(); g.lp_slot = lp_slot.data(); g.lp_w = lp_w.data(); g.lp_cosm = lp_cosm.data(); g.g_start = g_start.data();
+        g.lp_angle = lp_angle.data(); g.lp_slot = lp_slot.data(); g.lp_w = lp_w.data(); g.lp_cosm = lp_cosm.data(); g.lp_meta = lp_meta.data(); g.lpang4 = lpang4.data(); g.g_start = g_start.data();
         g.g_slot = g_slot.data(); g.g_sza = g_sza.data(); g.g_w = g_w.data();
         g.pp_mu = pp_mu.data(); g.pp_azi = pp_azi.data(); g.pp_first = pp_first.data(); g.pp_lf = pp_lf.data(); g.lplos = lplos.data();
         return g;
