@@ -72,6 +72,7 @@ struct Geo {
     const double* ssa_w;
     const double* rl_azi;   // [q]
     const double* rl_cosm;  // [m][q]  cos(m * azi_q)
+    const double* rl_cosm_t;  // [q][m]  the same, order index fastest (LOS integration)
     const int* rl_active;   // [q] 0 when the shell is shorter than MINIMUM_SHELL_SIZE_M
     const int* rl_tab_start;  // [q .. +1] table entries of a ray layer
     const int* tab_slot;
@@ -129,7 +130,7 @@ struct Bufs {
     double* rec;            // [w][p][REC]   (record-major, see rec_at)
     double* dinv;           // [w][p][4N^2]
     double* xsol;           // [w][p][2N]
-    double* J;              // [w][m][slot]   (see J_at)
+    double* J;              // [w][slot][m]   (see J_at; the orders of a table point are contiguous)
     uint8_t* conv_order;    // [w][slot]  first azimuth order that is skipped for this table point (see conv_at)
     int* notconv;           // [w]
     int* norders;           // [w] number of azimuth orders that are solved (stop rule)
@@ -160,7 +161,7 @@ struct RecView {
     const double* p;
     SKD_HD double operator()(int e) const { return p[e]; }
 };
-SKD_HD double& J_at(const Bufs& b, const Geo& g, int m, int slot, int w) { return b.J[(size_t(w) * g.nstr + m) * g.nslot + slot]; }
+SKD_HD double& J_at(const Bufs& b, const Geo& g, int m, int slot, int w) { return b.J[(size_t(w) * g.nslot + slot) * g.nstr + m]; }
 SKD_HD uint8_t& conv_at(const Bufs& b, const Geo& g, int slot, int w) { return b.conv_order[size_t(w) * g.nslot + slot]; }
 template <int N> SKD_HD double* rec_at(const Bufs& b, int nlyr, int p, int w) { return b.rec + (size_t(w) * nlyr + p) * Rec<N>::SIZE; }
 template <int N> SKD_HD double* dinv_at(const Bufs& b, int nlyr, int p, int w) { return b.dinv + (size_t(w) * nlyr + p) * (4 * N * N); }
@@ -1315,38 +1316,44 @@ SKD_HD void k4a_chain(const Geo& g, const Bufs& b, int s, int los, int w) {
     auto G = [&](int e) -> double& { return b.grad[size_t(e) * nt + tid]; };
     const double* ext = b.ext + size_t(w) * ngrid;
     const double* ssa = b.ssa + size_t(w) * ngrid;
-    for (int r = 0; r < nlyr; ++r) {
-        double gt = G(r);
+    // d/d tau_r of everything downstream: eight layers r per pass so that the gradients G(sec_p), G(T_{p+1}) are read once per pass
+    constexpr int RC = 8;
+    for (int r0 = 0; r0 < nlyr; r0 += RC) {
+        double gt[RC];
+        for (int k = 0; k < RC; ++k) gt[k] = (r0 + k < nlyr) ? G(r0 + k) : 0.0;
         for (int p = 0; p < nlyr; ++p) {
             const double* ch = g.chapman + (size_t(s) * nlyr + p) * nlyr;
             if (ch[0] < 0) continue;
             // sec_p = (sig_p - sig_{p-1}) / tau_p ;  T_{p+1} = F0 exp(-sig_p)
-            double dsig_p = ch[r];
-            double dsig_pm = 0;
-            bool prev_ok = true;
-            if (p > 0) {
-                const double* chm = g.chapman + (size_t(s) * nlyr + p - 1) * nlyr;
-                if (chm[0] < 0) prev_ok = false; else dsig_pm = chm[r];
-            }
-            const double tau_p = b.tau[size_t(p) * nw + w];
+            const double* chm = (p > 0) ? g.chapman + (size_t(s) * nlyr + p - 1) * nlyr : nullptr;
             // when the level above was in darkness the reference differences against the flagged value with zero derivative
-            double dsec = (dsig_p - (prev_ok ? dsig_pm : 0.0)) / tau_p;
-            if (r == p) dsec -= b.sec[size_t(p) * nw + w] / tau_p;
-            gt += G(3 * nlyr + p) * dsec;
-            // T at the ceiling of layer p+1 (level p+1) depends on sig_p
-            double dT = -b.T[size_t(p + 1) * nw + w] * dsig_p;
-            if (p + 1 < nlyr) gt += G(2 * nlyr + p + 1) * dT;
-            else gt += G(4 * nlyr + 1) * dT;
+            const bool prev_ok = (p > 0) && !(chm[0] < 0);
+            const double inv_tau = 1.0 / b.tau[size_t(p) * nw + w];
+            const double gsec = G(3 * nlyr + p), sec_p = b.sec[size_t(p) * nw + w];
+            const double gT = (p + 1 < nlyr) ? G(2 * nlyr + p + 1) : G(4 * nlyr + 1);
+            const double Tn = b.T[size_t(p + 1) * nw + w];
+            for (int k = 0; k < RC; ++k) {
+                const int r = r0 + k;
+                if (r >= nlyr) break;
+                const double dsig_p = ch[r];
+                double dsec = (dsig_p - (prev_ok ? chm[r] : 0.0)) * inv_tau;
+                if (r == p) dsec -= sec_p * inv_tau;
+                gt[k] += gsec * dsec - gT * Tn * dsig_p;
+            }
         }
         // tau_r -> extinction ; omega_r -> ssa, extinction
-        const double gom = G(nlyr + r);
-        const double kb = b.kbar[size_t(r) * nw + w], omr = b.om[size_t(r) * nw + w];
-        for (int t = 0; t < 2; ++t) {
-            int q = g.wq_idx[2 * r + t];
-            if (q < 0) continue;
-            double wt = g.wq_w[2 * r + t];
-            b.dnat[size_t(q) * nt + tid] += gt * wt * g.dh[r] + gom * wt * (ssa[q] - omr) / kb;
-            b.dnat[size_t(ngrid + q) * nt + tid] += gom * wt * ext[q] / kb;
+        for (int k = 0; k < RC; ++k) {
+            const int r = r0 + k;
+            if (r >= nlyr) break;
+            const double gom = G(nlyr + r);
+            const double kb = b.kbar[size_t(r) * nw + w], omr = b.om[size_t(r) * nw + w];
+            for (int t = 0; t < 2; ++t) {
+                int q = g.wq_idx[2 * r + t];
+                if (q < 0) continue;
+                double wt = g.wq_w[2 * r + t];
+                b.dnat[size_t(q) * nt + tid] += gt[k] * wt * g.dh[r] + gom * wt * (ssa[q] - omr) / kb;
+                b.dnat[size_t(ngrid + q) * nt + tid] += gom * wt * ext[q] / kb;
+            }
         }
     }
     b.dnat[size_t(2 * ngrid) * nt + tid] += G(4 * nlyr);
@@ -1377,13 +1384,16 @@ SKD_HD void k4b_los(const Geo& g, const Bufs& b, int los, int w) {
         prod_upto *= att;
         double sv = 0;
         if (g.rl_active[q]) {
-            for (int m = 0; m < nstr; ++m) {
-                double azf = g.rl_cosm[size_t(m) * g.nq_total + q];
-                for (int t = g.rl_tab_start[q]; t < g.rl_tab_start[q + 1]; ++t) {
-                    int slot = g.tab_slot[t];
-                    if (conv_at(b, g, slot, w) <= m) continue;
-                    sv += g.tab_w[t] * azf * J_at(b, g, m, slot, w);
-                }
+            // sum over the table entries of the shell and the azimuth orders each entry's point was solved for
+            const double* cs = g.rl_cosm_t + size_t(q) * nstr;
+            for (int t = g.rl_tab_start[q]; t < g.rl_tab_start[q + 1]; ++t) {
+                const int slot = g.tab_slot[t];
+                const int cv = int(conv_at(b, g, slot, w));
+                const int mmax = (cv < nstr) ? cv : nstr;
+                const double* Jp = &J_at(b, g, 0, slot, w);
+                double a = 0;
+                for (int m = 0; m < mmax; ++m) a += cs[m] * Jp[m];
+                sv += g.tab_w[t] * a;
             }
         }
         const double omega = b.omloc[size_t(q) * nw + w];

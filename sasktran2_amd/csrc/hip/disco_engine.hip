@@ -185,7 +185,7 @@ DeviceEngine::DeviceEngine(const skgeo::DiscoGeometry& dg, bool ss_in_do) : impl
     g.ray_qstart = M.upload(t.ray_qstart); g.ray_ground = M.upload(t.ray_ground); g.ray_gsaa = M.upload(t.ray_gsaa);
     g.rl_od_start = M.upload(t.rl_od_start); g.od_idx = M.upload(t.od_idx); g.od_w = M.upload(t.od_w);
     g.rl_ssa_start = M.upload(t.rl_ssa_start); g.ssa_idx = M.upload(t.ssa_idx); g.ssa_w = M.upload(t.ssa_w);
-    g.rl_azi = M.upload(t.rl_azi); g.rl_cosm = M.upload(t.rl_cosm); g.rl_active = M.upload(t.rl_active); g.rl_tab_start = M.upload(t.rl_tab_start);
+    g.rl_azi = M.upload(t.rl_azi); g.rl_cosm = M.upload(t.rl_cosm); g.rl_cosm_t = M.upload(t.rl_cosm_t); g.rl_active = M.upload(t.rl_active); g.rl_tab_start = M.upload(t.rl_tab_start);
     g.tab_slot = M.upload(t.tab_slot); g.tab_w = M.upload(t.tab_w); g.lp_start = M.upload(t.lp_start); g.lp_q = M.upload(t.lp_q);
     g.lp_angle = M.upload(t.lp_angle); g.lp_slot = M.upload(t.lp_slot); g.lp_w = M.upload(t.lp_w); g.lp_cosm = M.upload(t.lp_cosm); g.lp_meta = M.upload(t.lp_meta); g.lpang4 = M.upload(t.lpang4); g.g_start = M.upload(t.g_start);
     g.g_slot = M.upload(t.g_slot); g.g_sza = M.upload(t.g_sza); g.g_w = M.upload(t.g_w);

@@ -13,7 +13,7 @@ struct GeoTables {
     std::vector<double> mu, wt, lpmu, lpcsz, lpang, dh, lfrac, wq_w, chapman, csz;
     std::vector<int> wq_idx, pt_start, pt_angle, pt_slot, gpt_start, gpt_slot;
     std::vector<int> ray_qstart, ray_ground, rl_od_start, od_idx, rl_ssa_start, ssa_idx, rl_active, rl_tab_start, tab_slot;
-    std::vector<double> ray_gsaa, od_w, ssa_w, rl_azi, rl_cosm, tab_w;
+    std::vector<double> ray_gsaa, od_w, ssa_w, rl_azi, rl_cosm, rl_cosm_t, tab_w;
     std::vector<int> lp_start, lp_q, lp_angle, lp_slot, g_start, g_slot, g_sza;
     std::vector<double> lp_w, g_w, lp_cosm, lpang4;
     std::vector<int> lp_meta;
@@ -121,6 +121,9 @@ struct GeoTables {
         rl_cosm.resize(size_t(nstr) * nq_total);
         for (int m = 0; m < nstr; ++m)
             for (int i = 0; i < nq_total; ++i) rl_cosm[size_t(m) * nq_total + i] = std::cos(m * rl_azi[i]);
+        rl_cosm_t.resize(rl_cosm.size());
+        for (int m = 0; m < nstr; ++m)
+            for (int i = 0; i < nq_total; ++i) rl_cosm_t[size_t(i) * nstr + m] = rl_cosm[size_t(m) * nq_total + i];
         lp_start.assign(lp.size() + 1, 0);
         for (size_t i = 0; i < lp.size(); ++i) {
             for (const auto& e : lp[i]) { lp_q.push_back(e.q); lp_angle.push_back(e.angle); lp_slot.push_back(e.slot); lp_w.push_back(e.w); }
@@ -179,7 +182,7 @@ struct GeoTables {
         g.ray_qstart = ray_qstart.data(); g.ray_ground = ray_ground.data(); g.ray_gsaa = ray_gsaa.data();
         g.rl_od_start = rl_od_start.data(); g.od_idx = od_idx.data(); g.od_w = od_w.data();
         g.rl_ssa_start = rl_ssa_start.data(); g.ssa_idx = ssa_idx.data(); g.ssa_w = ssa_w.data();
-        g.rl_azi = rl_azi.data(); g.rl_cosm = rl_cosm.data(); g.rl_active = rl_active.data(); g.rl_tab_start = rl_tab_start.data();
+        g.rl_azi = rl_azi.data(); g.rl_cosm = rl_cosm.data(); g.rl_cosm_t = rl_cosm_t.data(); g.rl_active = rl_active.data(); g.rl_tab_start = rl_tab_start.data();
         g.tab_slot = tab_slot.data(); g.tab_w = tab_w.data(); g.lp_start = lp_start.data(); g.lp_q = lp_q.data();
         g.lp_angle = lp_angle.data(); g.lp_slot = lp_slot.data(); g.lp_w = lp_w.data(); g.lp_cosm = lp_cosm.data(); g.lp_meta = lp_meta.data(); g.lpang4 = lpang4.data(); g.g_start = g_start.data();
         g.g_slot = g_slot.data(); g.g_sza = g_sza.data(); g.g_w = g_w.data();
