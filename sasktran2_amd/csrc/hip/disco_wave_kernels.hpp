@@ -56,7 +56,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
     const int w = blockIdx.x;
     if (m >= b.norders[w]) return;
     const int lane = threadIdx.x, grp = lane / LG, gl = lane % LG, nw = b.nw, nlyr = g.nlyr;
-    __shared__ double sMat[NG][8][NN];
+    __shared__ double sMat[NG][9][NN];
     __shared__ double sVec[NG][18][NSTR];
     __shared__ double sLp[N * NSTR], sLc[NSTR], sMu[N], sWt[N], sSq[N], sTt[N], sIm[N], sIt[N];
     __shared__ int sErr;
@@ -79,6 +79,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
     double* M5 = sMat[grp][5];
     double* M6 = sMat[grp][6];
     double* M7 = sMat[grp][7];
+    double* Vs = sMat[grp][8];   // eigenvectors of the group's previous layer (Jacobi warm start)
     double* va = sVec[grp][0];    // Legendre coefficients a_l
     double* vlam = sVec[grp][1];
     double* vk = sVec[grp][2];
@@ -166,6 +167,28 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             M5[e] = (i == j) ? 1.0 : 0.0;
         }
         __syncthreads();
+        // warm start: the eigenvectors of the layer this lane group solved in its previous pass (NG layers above) nearly
+        // diagonalise this layer's matrix, so start from A0 = Vs^T M4 Vs, V0 = Vs instead of (M4, I)
+        if (N > 1 && pbase > p_begin) {
+            for (int e = gl; e < NN; e += LG) {
+                const int i = e / N, j = e % N;
+                double t = 0;
+                for (int r = 0; r < N; ++r) t += M4[i * N + r] * Vs[r * N + j];
+                M6[e] = t;
+            }
+            __syncthreads();
+            for (int e = gl; e < NN; e += LG) {
+                const int i = e / N, j = e % N;
+                if (j <= i) {
+                    double t = 0;
+                    for (int r = 0; r < N; ++r) t += Vs[r * N + i] * M6[r * N + j];
+                    M4[i * N + j] = t;
+                    M4[j * N + i] = t;
+                }
+                M5[e] = Vs[e];
+            }
+            __syncthreads();
+        }
         // Jacobi on M4 with the round-robin ("tournament") ordering: every round applies N/2 disjoint rotations at once,
         // A <- J^T A J and V <- V J with J the product of the round's rotations.  Index i of a rotated pair (p, q) has
         // partner i' and coefficients (al, be) = (c, -s) for i = p, (c, +s) for i = q, so that (A J)[r][i] = al A[r][i] + be A[r][i'].
@@ -224,11 +247,13 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
                     { double* tmp = Vcur; Vcur = Vnew; Vnew = tmp; }
                 }
             }
-            // leave the result in M4 / M5 (an odd number of rounds ends in the other pair of buffers)
+            // leave the result in M4 / M5 (an odd number of rounds ends in the other pair of buffers); keep V for the warm start
             if (Acur != M4) {
-                for (int e = gl; e < NN; e += LG) { M4[e] = Acur[e]; M5[e] = Vcur[e]; }
-                __syncthreads();
+                for (int e = gl; e < NN; e += LG) { M4[e] = Acur[e]; M5[e] = Vcur[e]; Vs[e] = Vcur[e]; }
+            } else {
+                for (int e = gl; e < NN; e += LG) Vs[e] = M5[e];
             }
+            __syncthreads();
         }
         if (!jac_ok && gl == 0) sErr = skd::ERR_EIGEN;
         if (gl < N) {
@@ -859,6 +884,76 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2B) kern_k2b_wav
 typedef double mf4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ mf4 mfma16(double a, double bb, mf4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0); }
 
+// 64-bit data-parallel-primitive move and the max all-reduce of a 16-lane row built from it (quad_perm / row_ror patterns)
+template <int CTRL> __device__ __forceinline__ double dpp64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_max(double v) {
+    v = fmax(v, dpp64<0xb1>(v));   // quad_perm [1,0,3,2]
+    v = fmax(v, dpp64<0x4e>(v));   // quad_perm [2,3,0,1]
+    v = fmax(v, dpp64<0x124>(v));  // row_ror 4
+    v = fmax(v, dpp64<0x128>(v));  // row_ror 8
+    return v;
+}
+
+// In-place Gauss-Jordan inverse of a 16 x 16 matrix held as one matrix-core accumulator tile (C/D image: register r of lane
+// (col, q) = element (4 r + q, col)).  Partial (row) pivoting without moving rows: physical row pi(k) is the pivot of column k,
+// one rank-1 matrix-core product per step, pivot row / column fixed up in registers.  On return the tile holds
+// B[rho][j] = Ainv[pi^-1(rho)][pi(j)]; gj16_scatter() writes the natural layout through 2 KB of LDS.  Returns 1 if singular.
+__device__ __forceinline__ int gj16_inplace(mf4& acc, int col, int q, unsigned long long& permP, unsigned long long& permI, double* trace = nullptr) {
+    constexpr int M2 = 16;
+    unsigned used = 0;
+    int sing = 0;
+    permP = 0;
+    permI = 0;
+    for (int k = 0; k < M2; ++k) {
+        // column k -> every 16-lane row: D[i = col][k] lives in lane (k, i & 3), register i >> 2
+        const int src = k + 16 * (col & 3);
+        const double c0 = __shfl(acc[0], src), c1 = __shfl(acc[1], src), c2 = __shfl(acc[2], src), c3 = __shfl(acc[3], src);
+        const int ir = col >> 2;
+        const double colv = (ir == 0) ? c0 : (ir == 1) ? c1 : (ir == 2) ? c2 : c3;
+        // partial pivoting: arg max |D[i][k]| over the rows not used yet, as a max-reduction of keys inside the 16-lane row
+        // (data-parallel-primitive moves, no LDS): key = |value| with the low four mantissa bits replaced by 15 - i
+        const unsigned long long kb = (static_cast<unsigned long long>(__double_as_longlong(fabs(colv))) & ~15ull) | (unsigned long long)(15 - col);
+        const double key = ((used >> col) & 1u) ? 0.0 : __longlong_as_double((long long)kb);
+        const double kmax = row16_max(key);
+        const unsigned long long kmb = (unsigned long long)__double_as_longlong(kmax);
+        const int pivrow = __builtin_amdgcn_readfirstlane(15 - int(kmb & 15ull));
+        double pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(colv), pivrow), __builtin_amdgcn_readlane(__double2loint(colv), pivrow));
+        if ((kmb & ~15ull) == 0ull) { sing = 1; pv = 1.0; }
+        // reciprocal of the pivot: hardware estimate + two Newton steps (full double precision, short dependency chain)
+        double ip = __builtin_amdgcn_rcp(pv);
+        ip = fma(fma(-pv, ip, 1.0), ip, ip);
+        ip = fma(fma(-pv, ip, 1.0), ip, ip);
+        const int pr = pivrow >> 2, pq = pivrow & 3;
+        const double rowsel = (pr == 0) ? acc[0] : (pr == 1) ? acc[1] : (pr == 2) ? acc[2] : acc[3];
+        const double rowv = __shfl(rowsel, col + 16 * pq);  // D[pivrow][col]
+        const double aop = (q == 0 && col != pivrow) ? -colv * ip : 0.0;
+        const double bop = (q == 0 && col != k) ? rowv : 0.0;
+        acc = mfma16(aop, bop, acc);
+        // the rank-1 product leaves the pivot row and column untouched: scale them here
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * r + q;
+            if (col == k) acc[r] = (row == pivrow) ? ip : -acc[r] * ip;
+            else if (row == pivrow) acc[r] *= ip;
+        }
+        if (trace && col == 0 && q == 0) { trace[2 * k] = pivrow; trace[2 * k + 1] = pv; }
+        used |= 1u << pivrow;
+        permP |= (unsigned long long)pivrow << (4 * k);
+        permI |= (unsigned long long)k << (4 * pivrow);
+    }
+    return sing;
+}
+__device__ __forceinline__ void gj16_scatter(const mf4& acc, int col, int q, unsigned long long permP, unsigned long long permI, double* sP) {
+    for (int r = 0; r < 4; ++r) {
+        const int prow = 4 * r + q;
+        const int i = int((permI >> (4 * prow)) & 15ull), c = int((permP >> (4 * col)) & 15ull);
+        sP[i * 16 + c] = acc[r];
+    }
+}
+
 // K2a for N = 8: block-tridiagonal boundary value problem with the 16 x 16 blocks held in matrix-core accumulators.
 //   per layer   T1^T = Dinv'_{p-1}^T Sub_p^T (4 products), D'_p = D_p + T1[:, 8:16] [W- | W+ E]_p (2), r'_p = r_p - T1 r'_{p-1} (4),
 //               Dinv'_p by in-place Gauss-Jordan with partial (row) pivoting: one rank-1 product per pivot step, the pivot
@@ -934,56 +1029,11 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2AM) kern_k2a_mfma8(Geo g, Bufs b
             for (int kk = 0; kk < 4; ++kk) tr = mfma16(t1[kk], rprev[kk], tr);
             for (int r = 0; r < 4; ++r) rv[r] -= tr[r];
         }
-        // in-place Gauss-Jordan inverse, rows stay where they are: physical row pi(k) is the pivot of column k
-        unsigned used = 0;
-        unsigned long long permP = 0, permI = 0;
-        for (int k = 0; k < M2; ++k) {
-            // column k -> lanes 0..15 (independent of the pivot choice, issued first): D[i = col][k] lives in lane (k, i & 3), register i >> 2
-            const int src = k + 16 * (col & 3);
-            const double c0 = __shfl(acc[0], src), c1 = __shfl(acc[1], src), c2 = __shfl(acc[2], src), c3 = __shfl(acc[3], src);
-            const int ir = col >> 2;
-            const double colv = (ir == 0) ? c0 : (ir == 1) ? c1 : (ir == 2) ? c2 : c3;
-            double bv = -1.0, bs = 0.0;
-            int br = 0;
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * r + q;
-                const double a = fabs(acc[r]);
-                if (!((used >> row) & 1u) && a > bv) { bv = a; bs = acc[r]; br = row; }
-            }
-            for (int off = 16; off <= 32; off <<= 1) {
-                const double ov = __shfl_xor(bv, off), os = __shfl_xor(bs, off);
-                const int orow = __shfl_xor(br, off);
-                if (ov > bv || (ov == bv && orow < br)) { bv = ov; bs = os; br = orow; }
-            }
-            const int pivrow = __builtin_amdgcn_readlane(br, k);
-            double pv = __shfl(bs, k);
-            if (!(fabs(pv) > 0)) { sing = 1; pv = 1.0; }
-            // reciprocal of the pivot: hardware estimate + two Newton steps (full double precision, short dependency chain)
-            double ip = __builtin_amdgcn_rcp(pv);
-            ip = fma(fma(-pv, ip, 1.0), ip, ip);
-            ip = fma(fma(-pv, ip, 1.0), ip, ip);
-            const int pr = pivrow >> 2, pq = pivrow & 3;
-            const double rowsel = (pr == 0) ? acc[0] : (pr == 1) ? acc[1] : (pr == 2) ? acc[2] : acc[3];
-            const double rowv = __shfl(rowsel, col + 16 * pq);  // D[pivrow][col]
-            const double aop = (q == 0 && col != pivrow) ? -colv * ip : 0.0;
-            const double bop = (q == 0 && col != k) ? rowv : 0.0;
-            acc = mfma16(aop, bop, acc);
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * r + q;
-                if (col == k) acc[r] = (row == pivrow) ? ip : -acc[r] * ip;
-                else if (row == pivrow) acc[r] *= ip;
-            }
-            used |= 1u << pivrow;
-            permP |= (unsigned long long)pivrow << (4 * k);
-            permI |= (unsigned long long)k << (4 * pivrow);
-        }
-        // B[rho][j] = Dinv[piinv(rho)][pi(j)]: scatter to the natural layout
+        // Dinv'_p: in-place Gauss-Jordan with row pivoting, then the permutation to the natural layout through LDS
+        unsigned long long permP, permI;
+        sing |= gj16_inplace(acc, col, q, permP, permI);
         __syncthreads();
-        for (int r = 0; r < 4; ++r) {
-            const int prow = 4 * r + q;
-            const int i = int((permI >> (4 * prow)) & 15ull), c = int((permP >> (4 * col)) & 15ull);
-            sP[i * M2 + c] = acc[r];
-        }
+        gj16_scatter(acc, col, q, permP, permI, sP);
         __syncthreads();
         double* dg = skd::dinv_at<N>(b, nlyr, p, w);
         for (int r = 0; r < 4; ++r) {
