@@ -171,7 +171,7 @@ template <int N> SKD_HD double* xsol_at(const Bufs& b, int nlyr, int p, int w) {
 // K0: layer optics + beam attenuation + LOS optics        (one task per wavelength)
 //   reference: OpticalLayerArray ctor / configureTransmission, sktran_do_layerarray.cpp:332-477,890-979
 // =================================================================================================
-SKD_HD void k0_layer_optics(const Geo& g, const Bufs& b, int w) {
+SKD_HD void k0_layer_optics(const Geo& g, const Bufs& b, int w, bool with_los_shells = true) {
     const int nw = b.nw, nlyr = g.nlyr, nstr = g.nstr, ngrid = g.ngrid;
     const double* ext = b.ext + size_t(w) * ngrid;
     const double* ssa = b.ssa + size_t(w) * ngrid;
@@ -206,7 +206,8 @@ SKD_HD void k0_layer_optics(const Geo& g, const Bufs& b, int w) {
         b.tau[size_t(p) * nw + w] = floor_depth - ceiling_depth;
         ceiling_depth = floor_depth;
     }
-    // LOS shells: optical depth, local ssa, source weights
+    // LOS shells: optical depth, local ssa, source weights  (the HIP driver runs this part as kern_k0_shells / kern_k0_los)
+    if (!with_los_shells) return;
     for (int l = 0; l < g.nlos; ++l) {
         const int q0 = g.ray_qstart[l], q1 = g.ray_qstart[l + 1];
         double total = 0;
@@ -222,10 +223,9 @@ SKD_HD void k0_layer_optics(const Geo& g, const Bufs& b, int w) {
         // attenuation from the near edge of shell q to the observer: product over shells closer to the observer
         double att = 1.0;
         for (int q = q1 - 1; q >= q0; --q) {
-            double od = b.od[size_t(q) * nw + w];
-            double sf = 1 - exp(-od);
-            b.srcw[size_t(q) * nw + w] = g.rl_active[q] ? b.omloc[size_t(q) * nw + w] * sf * att : 0.0;
-            att *= exp(-od);
+            const double e = exp(-b.od[size_t(q) * nw + w]);
+            b.srcw[size_t(q) * nw + w] = g.rl_active[q] ? b.omloc[size_t(q) * nw + w] * (1 - e) * att : 0.0;
+            att *= e;
         }
         b.att_total[size_t(l) * nw + w] = att;
         b.los_od[size_t(w) * g.nlos + l] = total;
@@ -720,29 +720,34 @@ struct PPMult {
     double hp_tau, hp_k, hm_tau, hm_k;
     double Dm_tau, Dm_k, Dm_sec, Dp_tau, Dp_k, Dp_sec;  // d/dT = value / T
 };
-SKD_HD void pp_multipliers(double T, double th, double sc, double ev, double lf, PPMult& o) {
+// hp = exp(-k x), x = th lf;  hm = exp(-k (th - x));  exs = exp(-sec x);  ets = exp(-sec th)  are passed in
+SKD_HD void pp_multipliers_e(double T, double th, double sc, double ev, double lf, double hp, double hm, double exs, double ets, PPMult& o) {
     const double x = th * lf;
-    o.hp = exp(-1.0 * ev * th * lf);
-    o.hm = exp(-ev * th * (1 - lf));
+    o.hp = hp;
+    o.hm = hm;
     o.hp_tau = -o.hp * ev * lf;
     o.hp_k = -o.hp * th * lf;
     o.hm_tau = -o.hm * ev * (1 - lf);
     o.hm_k = -o.hm * th * (1 - lf);
     {
-        const double den = sc - ev, exk = exp(-x * ev), exs = exp(-x * sc), v = exk - exs;
+        const double den = sc - ev, exk = hp, v = exk - exs;
         o.Dm = v * T / den;
         o.Dm_sec = T * (-v / den + exs * x) / den;
         o.Dm_k = T * (-x * exk + v / den) / den;
         o.Dm_tau = lf * T * (exs * sc - exk * ev) / den;
     }
     {
-        const double den = ev + sc, exs = exp(-x * sc);
-        const double ef2 = exp(-th * sc) * exp(-(th - x) * ev), v = exs - ef2;
+        const double den = ev + sc;
+        const double ef2 = ets * hm, v = exs - ef2;
         o.Dp = v * T / den;
         o.Dp_sec = T * (-v / den - x * exs + th * ef2) / den;
         o.Dp_k = T * (-v / den + ef2 * (th - x)) / den;
         o.Dp_tau = T * (-exs * lf * sc + ef2 * sc + ef2 * (ev - lf * ev)) / den;
     }
+}
+SKD_HD void pp_multipliers(double T, double th, double sc, double ev, double lf, PPMult& o) {
+    const double x = th * lf;
+    pp_multipliers_e(T, th, sc, ev, lf, exp(-ev * x), exp(-ev * (th - x)), exp(-x * sc), exp(-th * sc), o);
 }
 
 SKD_HD void ppm_store(double* dst, const PPMult& o) {

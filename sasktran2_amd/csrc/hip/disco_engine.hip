@@ -51,7 +51,40 @@ constexpr int kBlock = 64;
 __global__ void __launch_bounds__(kBlock) kern_k0(Geo g, Bufs b) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= b.nw) return;
-    skd::k0_layer_optics(g, b, w);
+    skd::k0_layer_optics(g, b, w, false);
+}
+// LOS shells of k0_layer_optics, one thread per (shell, wavelength), wavelength fastest: optical depth, local ssa and the
+// shell transmission exp(-od) (parked in srcw until kern_k0_los turns it into the source weight)
+__global__ void __launch_bounds__(256) kern_k0_shells(Geo g, Bufs b) {
+    const size_t n = size_t(g.nq_total) * b.nw;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const int q = int(i / b.nw), w = int(i % b.nw);
+        const double* ext = b.ext + size_t(w) * g.ngrid;
+        const double* ssa = b.ssa + size_t(w) * g.ngrid;
+        double od = 0, om = 0;
+        for (int t = g.rl_od_start[q]; t < g.rl_od_start[q + 1]; ++t) od += g.od_w[t] * ext[g.od_idx[t]];
+        for (int t = g.rl_ssa_start[q]; t < g.rl_ssa_start[q + 1]; ++t) om += ssa[g.ssa_idx[t]] * g.ssa_w[t];
+        b.od[i] = od;
+        b.omloc[i] = om;
+        b.srcw[i] = exp(-od);
+    }
+}
+// attenuation from every shell to the observer, one thread per (LOS, wavelength), wavelength fastest
+__global__ void __launch_bounds__(256) kern_k0_los(Geo g, Bufs b) {
+    const size_t n = size_t(g.nlos) * b.nw;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const int l = int(i / b.nw), w = int(i % b.nw), nw = b.nw;
+        const int q0 = g.ray_qstart[l], q1 = g.ray_qstart[l + 1];
+        double att = 1.0, total = 0;
+        for (int q = q1 - 1; q >= q0; --q) {
+            const double e = b.srcw[size_t(q) * nw + w];
+            total += b.od[size_t(q) * nw + w];
+            b.srcw[size_t(q) * nw + w] = g.rl_active[q] ? b.omloc[size_t(q) * nw + w] * (1 - e) * att : 0.0;
+            att *= e;
+        }
+        b.att_total[size_t(l) * nw + w] = att;
+        b.los_od[size_t(w) * g.nlos + l] = total;
+    }
 }
 __global__ void __launch_bounds__(kBlock) kern_k0t(Geo g, Bufs b, int s) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,6 +362,8 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
     {
         Timer t(I, st, "k0_layer_optics");
         hipLaunchKernelGGL(kern_k0, dim3(blocks(nw)), dim3(kBlock), 0, st, g, b);
+        if (g.nq_total > 0) hipLaunchKernelGGL(kern_k0_shells, dim3(4096), dim3(256), 0, st, g, b);
+        hipLaunchKernelGGL(kern_k0_los, dim3(unsigned((size_t(g.nlos) * nw + 255) / 256)), dim3(256), 0, st, g, b);
     }
     if (g.pp_mode) {
         // plane-parallel post-processing: every azimuth order is solved (do_source_planeparallel.cpp), K3 only fills the

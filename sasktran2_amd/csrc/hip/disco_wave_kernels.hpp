@@ -606,7 +606,7 @@ template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs 
     const int w = blockIdx.x;
     if (m >= b.norders[w]) return;
     const int lane = threadIdx.x, nw = b.nw, nlyr = g.nlyr;
-    __shared__ double sK[N], sW[2 * NN], sAP[N], sAM[N], sXs[2 * N], sa[NSTR], sCL[N], sCM[N], sP[N], sQ[N], sCleg[NSTR], sRed[N];
+    __shared__ double sK[N], sW[2 * NN], sAP[N], sAM[N], sXs[2 * N], sa[NSTR], sCL[N], sCM[N], sP[N], sQ[N], sCleg[NSTR], sRed[N], sEx[N + 2];
     const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
     int unconverged = 0;
     for (int p = 0; p < nlyr; ++p) {
@@ -618,12 +618,16 @@ template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs 
         for (int l = lane; l < NSTR; l += 64) sa[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
         const double th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
         __syncthreads();
+        // exponentials of the layer in one instruction stream: exp(-k_j x) (lanes < N), exp(-sec x), exp(-sec th);  x = th lfrac
+        const double lf = g.lfrac[p];
+        if (lane < N + 2) sEx[lane] = exp(-((lane < N) ? sK[lane] : sc) * ((lane == N + 1) ? th : th * lf));
+        __syncthreads();
         if (lane < N) {
             skd::PPMult pm;
-            skd::pp_multipliers(T, th, sc, sK[lane], g.lfrac[p], pm);
+            const double Ej = rec[R::E + lane];  // exp(-k_j th), written by K1;  exp(-k (th - x)) = E / exp(-k x)
+            skd::pp_multipliers_e(T, th, sc, sK[lane], lf, sEx[lane], Ej / sEx[lane], sEx[N], sEx[N + 1], pm);
             double* recw = skd::rec_at<N>(b, nlyr, p, w);
             skd::ppm_store(recw + R::PPM + 14 * lane, pm);
-            recw[R::E + lane] = exp(-fabs(sK[lane]) * th);
             sCL[lane] = pm.hp * sXs[lane] + sAP[lane] * pm.Dm;
             sCM[lane] = pm.hm * sXs[N + lane] + sAM[lane] * pm.Dp;
         }
