@@ -21,7 +21,7 @@
 #define SKD_WPE_K2BM 4
 #endif
 #ifndef SKD_WPE_K2CM
-#define SKD_WPE_K2CM 1
+#define SKD_WPE_K2CM 4
 #endif
 #ifndef SKD_K1_LG
 #define SKD_K1_LG 32
@@ -1091,12 +1091,15 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b
     using O = skd::Ops<N>;
     const int w = blockIdx.x;
     if (m >= b.norders[w]) return;
-    const int lane = threadIdx.x, nw = b.nw, nlyr = g.nlyr;
+    const int lane = threadIdx.x, col = lane & 15, q = lane >> 4, jc = col & 7, nw = b.nw, nlyr = g.nlyr;
     __shared__ double sRec[R::SIZE];
-    __shared__ double sXs[M2], sa[NSTR];
-    __shared__ double sF[M2 * NSTR], sST[M2 * M2], sH[5 * N * NSTR], sTmp[M2], sIpb[N], sDIpb[4 * N];
-    const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
+    __shared__ double sXs[M2], sTmp[M2], sIpb[N], sDIpb[4 * N];
     const double rho = (m == 0) ? b.albedo[w] : 0.0;
+    // Legendre sums as a 16 x 16 product:  [YP; YM] = [W+^T W-^T; W-^T W+^T] [P sg; P],  P[r][l] = 1/2 w_r omega a_l P_l^m(mu_r);
+    // this lane's B operand rows are r = q and r = q + 4 of column l = col (constant over the layers up to omega a_l)
+    const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
+    const double pc0 = 0.5 * g.wt[q] * lpmu[q * NSTR + col], pc1 = 0.5 * g.wt[q + 4] * lpmu[(q + 4) * NSTR + col];
+    const double sg = ((col - m) & 1) ? -1.0 : 1.0;
     for (int p = 0; p < nlyr; ++p) {
         const bool last = (p == nlyr - 1);
         const double* rec = skd::rec_at<N>(b, nlyr, p, w);
@@ -1105,49 +1108,74 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b
         double* o = skd::ops_at<N>(b, nlyr, p, w);
         for (int i = lane; i < R::SIZE; i += 64) sRec[i] = rec[i];
         if (lane < M2) sXs[lane] = xs[lane];
-        if (lane < NSTR) sa[lane] = (lane >= m) ? b.a[(size_t(p) * NSTR + lane) * nw + w] : 0.0;
-        double dinv_b[4];  // B operand of both chains: Dinv[4 kk + (lane >> 4)][lane & 15] = dg[64 kk + lane]
+        double dinv_b[4];  // B operand of the Dinv chains: Dinv[4 kk + (lane >> 4)][lane & 15] = dg[64 kk + lane]
         for (int kk = 0; kk < 4; ++kk) dinv_b[kk] = dg[64 * kk + lane];
         const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w];
         const double inv_om = 1.0 / om, inv_T = (T != 0) ? 1.0 / T : 0.0;
+        const double al = (col >= m) ? b.a[(size_t(p) * NSTR + col) * nw + w] : 0.0;
         __syncthreads();
-        // phase A: F = [UL; UM] and the per-(j,l) pieces of the direct-dependence rows
-        for (int idx = lane; idx < N * NSTR; idx += 64) {
-            const int j = idx / NSTR, l = idx % NSTR;
-            const double sg = ((l - m) & 1) ? -1.0 : 1.0;
-            double yp = 0, ym = 0, dyp = 0, dym = 0;
-            for (int r = 0; r < N; ++r) {
-                const double cm = 0.5 * g.wt[r] * om * sa[l] * lpmu[r * NSTR + l];
-                const double wp = sRec[R::WP + r + N * j], wm = sRec[R::WM + r + N * j];
-                const double dwp = sRec[R::DWP + r + N * j] + wp * inv_om, dwm = sRec[R::DWM + r + N * j] + wm * inv_om;
-                yp += cm * (sg * wp + wm);
-                ym += cm * (sg * wm + wp);
-                dyp += cm * (sg * dwp + dwm);
-                dym += cm * (sg * dwm + dwp);
+        // ---- Y = [YP; YM] and its omega derivative DY (rows: solution j / 8 + j, columns: Legendre order l)
+        mf4 Y = {0, 0, 0, 0}, DY = {0, 0, 0, 0};
+        {
+            const bool hi = (col >= N);
+            const double wp0 = sRec[R::WP + q + N * jc], wp1 = sRec[R::WP + 4 + q + N * jc];
+            const double wm0 = sRec[R::WM + q + N * jc], wm1 = sRec[R::WM + 4 + q + N * jc];
+            const double dp0 = sRec[R::DWP + q + N * jc] + wp0 * inv_om, dp1 = sRec[R::DWP + 4 + q + N * jc] + wp1 * inv_om;
+            const double dm0 = sRec[R::DWM + q + N * jc] + wm0 * inv_om, dm1 = sRec[R::DWM + 4 + q + N * jc] + wm1 * inv_om;
+            const double c0 = pc0 * om * al, c1 = pc1 * om * al;
+            const double bP[4] = {sg * c0, sg * c1, c0, c1};
+            const double aW[4] = {hi ? wm0 : wp0, hi ? wm1 : wp1, hi ? wp0 : wm0, hi ? wp1 : wm1};
+            const double aD[4] = {hi ? dm0 : dp0, hi ? dm1 : dp1, hi ? dp0 : dm0, hi ? dp1 : dm1};
+            for (int kk = 0; kk < 4; ++kk) {
+                Y = mfma16(aW[kk], bP[kk], Y);
+                DY = mfma16(aD[kk], bP[kk], DY);
             }
+        }
+        // ---- F = [UL; UM] (C/D image, in place of Y) and the direct-dependence rows HD: this lane holds solutions j = q, q + 4
+        double hd[4] = {0, 0, 0, 0}, val = 0;
+        mf4 Fr;
+        for (int jx = 0; jx < 2; ++jx) {
+            const int j = q + 4 * jx;
             skd::PPMult pm;
             skd::ppm_load(&sRec[R::PPM + 14 * j], pm);
-            sF[j * NSTR + l] = yp * pm.hp * inv_om;
-            sF[(N + j) * NSTR + l] = ym * pm.hm * inv_om;
+            const double yp = Y[jx], ym = Y[2 + jx], dyp = DY[jx], dym = DY[2 + jx];
+            Fr[jx] = yp * pm.hp * inv_om;
+            Fr[2 + jx] = ym * pm.hm * inv_om;
             const double L = sXs[j], Mv = sXs[N + j], dk = sRec[R::DK + j];
             const double Ap = sRec[R::AP + j], Am = sRec[R::AM + j], dAp = sRec[R::DAP + j], dAm = sRec[R::DAM + j];
             const double tL = pm.hp * L + Ap * pm.Dm, tM = pm.hm * Mv + Am * pm.Dp;
-            sH[(4 * N + j) * NSTR + l] = yp * tL + ym * tM;
-            sH[(skd::TH_TAU * N + j) * NSTR + l] = yp * (pm.hp_tau * L + Ap * pm.Dm_tau) + ym * (pm.hm_tau * Mv + Am * pm.Dp_tau);
-            sH[(skd::TH_SEC * N + j) * NSTR + l] = yp * Ap * pm.Dm_sec + ym * Am * pm.Dp_sec;
-            sH[(skd::TH_T * N + j) * NSTR + l] = (yp * Ap * pm.Dm + ym * Am * pm.Dp) * inv_T;
-            sH[(skd::TH_OM * N + j) * NSTR + l] = dyp * tL + dym * tM + yp * (pm.hp_k * dk * L + dAp * pm.Dm + Ap * pm.Dm_k * dk) +
-                                                  ym * (pm.hm_k * dk * Mv + dAm * pm.Dp + Am * pm.Dp_k * dk);
+            val += yp * tL + ym * tM;
+            hd[skd::TH_TAU] += yp * (pm.hp_tau * L + Ap * pm.Dm_tau) + ym * (pm.hm_tau * Mv + Am * pm.Dp_tau);
+            hd[skd::TH_SEC] += yp * Ap * pm.Dm_sec + ym * Am * pm.Dp_sec;
+            hd[skd::TH_T] += (yp * Ap * pm.Dm + ym * Am * pm.Dp) * inv_T;
+            hd[skd::TH_OM] += dyp * tL + dym * tM + yp * (pm.hp_k * dk * L + dAp * pm.Dm + Ap * pm.Dm_k * dk) +
+                              ym * (pm.hm_k * dk * Mv + dAm * pm.Dp + Am * pm.Dp_k * dk);
         }
-        // [SupT | SubT] (16 x 16, row j): SupT[j][c] = W-(c,j), SupT[N+j][c] = W+(c,j) E_j ; SubT[j][c] = W+(c,j) E_j, SubT[N+j][c] = W-(c,j)
-        for (int idx = lane; idx < M2 * M2; idx += 64) {
-            const int jj = idx / M2, cc = idx % M2;
-            const int j = jj % N, c = cc % N;
-            const double wp = sRec[R::WP + c + N * j], wm = sRec[R::WM + c + N * j], E = sRec[R::E + j];
-            const bool upper = (jj < N), sup = (cc < N);
-            sST[idx] = (upper == sup) ? wm : wp * E;
+        for (int off = 16; off <= 32; off <<= 1) {
+            for (int t = 0; t < 4; ++t) hd[t] += __shfl_xor(hd[t], off);
+            val += __shfl_xor(val, off);
         }
-        // edge-intensity derivatives at fixed (L, M): lanes (i, e)
+        if (q == 0)
+            for (int t = 0; t < 4; ++t) o[O::HD + t * NSTR + col] = hd[t] * inv_om - ((t == skd::TH_OM) ? val * inv_om * inv_om : 0.0);
+        // ---- FP^T = F^T Dinv (the C/D image of F is the A operand of F^T) and [SP | BP]^T = [SupT | SubT]^T Dinv
+        {
+            const bool sup = (col < N);
+            const double wm0 = sRec[R::WM + jc + N * q], wm1 = sRec[R::WM + jc + N * (q + 4)];
+            const double we0 = sRec[R::WP + jc + N * q] * sRec[R::E + q], we1 = sRec[R::WP + jc + N * (q + 4)] * sRec[R::E + q + 4];
+            // [SupT | SubT][jj][c']: SupT[j][c] = W-(c,j), SupT[N+j][c] = W+(c,j) E_j ; SubT[j][c] = W+(c,j) E_j, SubT[N+j][c] = W-(c,j)
+            const double aS[4] = {sup ? wm0 : we0, sup ? wm1 : we1, sup ? we0 : wm0, sup ? we1 : wm1};
+            mf4 x1 = {0, 0, 0, 0}, x2 = {0, 0, 0, 0};
+            for (int kk = 0; kk < 4; ++kk) {
+                x1 = mfma16(Fr[kk], dinv_b[kk], x1);   // (F^T Dinv)[l][i] = FP[i][l]
+                x2 = mfma16(aS[kk], dinv_b[kk], x2);   // rows 0..7: SP^T, rows 8..15: BP^T
+            }
+            for (int r = 0; r < 4; ++r) o[O::FP + 64 * r + lane] = x1[r];
+            o[O::SP + lane] = x2[0];
+            o[O::SP + 64 + lane] = x2[1];
+            o[O::BP + lane] = x2[2];
+            o[O::BP + 64 + lane] = x2[3];
+        }
+        // ---- edge-intensity derivatives at fixed (L, M): lanes (i, e)
         for (int idx = lane; idx < 4 * N; idx += 64) {
             const int i = idx / 4, e = idx % 4;
             double d_tau = 0, d_om = 0, ipb_i = sRec[R::G + 2 * N + i];
@@ -1188,31 +1216,7 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b
             sTmp[N + lane] = 2.0 * rho * sm;
         }
         __syncthreads();
-        // phase B: the two matrix-core chains
-        {
-            mf4 x1 = {0, 0, 0, 0}, x2 = {0, 0, 0, 0};
-            for (int kk = 0; kk < 4; ++kk) {
-                x1 = mfma16(sF[64 * kk + lane], dinv_b[kk], x1);    // (F^T Dinv)[l][i] = FP[i][l]
-                x2 = mfma16(sST[64 * kk + lane], dinv_b[kk], x2);   // rows 0..7: SP^T, rows 8..15: BP^T
-            }
-            for (int r = 0; r < 4; ++r) o[O::FP + 64 * r + lane] = x1[r];
-            o[O::SP + lane] = x2[0];
-            o[O::SP + 64 + lane] = x2[1];
-            o[O::BP + lane] = x2[2];
-            o[O::BP + 64 + lane] = x2[3];
-        }
-        // HD rows, UG, GD, IPB
-        for (int idx = lane; idx < 4 * NSTR; idx += 64) {
-            const int t = idx / NSTR, l = idx % NSTR;
-            double acc = 0, val = 0;
-            for (int j = 0; j < N; ++j) {
-                acc += sH[(t * N + j) * NSTR + l];
-                val += sH[(4 * N + j) * NSTR + l];
-            }
-            acc *= inv_om;
-            if (t == skd::TH_OM) acc -= val * inv_om * inv_om;
-            o[O::HD + idx] = acc;
-        }
+        // UG, GD, IPB
         if (lane < M2) {
             double t = 0;
             if (last && m == 0)

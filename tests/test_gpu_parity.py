@@ -166,3 +166,30 @@ def test_c1_nadir_matches_oracle(nstr, observer):
     # BASELINE configs[0]: 1D nadir, 2-stream DISCO, 20 layers, 100 wavelengths
     s = sc.nadir_c1(num_wavelengths=100, nstr=nstr, observer_altitude=observer)
     assert_parity(run_product(s), run_oracle(s, derivatives=True))
+
+
+@pytest.mark.parametrize("nlos", [1, 7, 16, 17, 40])
+def test_c2_line_of_sight_tile_counts(nlos):
+    # the 16-stream adjoint works on tiles of 16 lines of sight (one or two per pass): partial, exact, multiple passes
+    s = sc.limb_c2(num_wavelengths=3)
+    tangents = np.linspace(8_000.0, 61_000.0, nlos)
+    s["rays"] = [(sc.TANGENT_ALTITUDE_SOLAR, 0.6, 0.0, 600_000.0, float(t)) for t in tangents]
+    assert_parity(run_product(s), run_oracle(s, derivatives=True))
+
+
+def test_c2_wavelength_blocks_in_flight_are_equivalent(monkeypatch):
+    # several blocks of wavelengths in flight on their own streams == one block after the other, bit for bit
+    s = sc.limb_c2(num_wavelengths=700)
+    monkeypatch.setenv("SASKTRAN2_AMD_STREAMS", "1")
+    monkeypatch.setenv("SASKTRAN2_AMD_CHUNK", "700")
+    one = run_product(s)
+    monkeypatch.setenv("SASKTRAN2_AMD_STREAMS", "3")
+    monkeypatch.setenv("SASKTRAN2_AMD_CHUNK", "128")
+    many = run_product(s)
+    for k in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
+        assert np.array_equal(one[k], many[k]), k
+
+
+def test_c2_two_solar_zenith_points_matches_oracle():
+    s = sc.limb_c2(num_wavelengths=2, num_sza=2)
+    assert_parity(run_product(s), run_oracle(s, derivatives=True))
