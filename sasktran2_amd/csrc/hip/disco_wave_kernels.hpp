@@ -601,50 +601,55 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2A) kern_k2a_wav
 // K3: diffuse-source table values + convergence flags.  grid = wavelengths, block = 64 (lanes = table angles).
 // -------------------------------------------------------------------------------------------------------------------
 template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs b, int s, int m) {
-    constexpr int NSTR = 2 * N, NN = N * N;
+    // NG lane groups of LG lanes, one layer per group and pass (the per-layer phases only have N .. 2N lanes of work)
+    constexpr int NSTR = 2 * N, NN = N * N, LG = (N >= 16) ? 32 : 16, NG = 64 / LG;
     using R = skd::Rec<N>;
     const int w = blockIdx.x;
     if (m >= b.norders[w]) return;
-    const int lane = threadIdx.x, nw = b.nw, nlyr = g.nlyr;
-    __shared__ double sK[N], sW[2 * NN], sAP[N], sAM[N], sXs[2 * N], sa[NSTR], sCL[N], sCM[N], sP[N], sQ[N], sCleg[NSTR], sRed[N], sEx[N + 2];
+    const int lane = threadIdx.x, grp = lane / LG, gl = lane % LG, nw = b.nw, nlyr = g.nlyr;
+    __shared__ double sKg[NG][N], sWg[NG][2 * NN], sAPg[NG][N], sAMg[NG][N], sXsg[NG][2 * N], sag[NG][NSTR], sCLg[NG][N], sCMg[NG][N],
+        sPg[NG][N], sQg[NG][N], sClegg[NG][NSTR], sRedg[NG][N], sExg[NG][N + 2];
+    double* sK = sKg[grp]; double* sW = sWg[grp]; double* sAP = sAPg[grp]; double* sAM = sAMg[grp]; double* sXs = sXsg[grp];
+    double* sa = sag[grp]; double* sCL = sCLg[grp]; double* sCM = sCMg[grp]; double* sP = sPg[grp]; double* sQ = sQg[grp];
+    double* sCleg = sClegg[grp]; double* sRed = sRedg[grp]; double* sEx = sExg[grp];
     const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
     int unconverged = 0;
-    for (int p = 0; p < nlyr; ++p) {
+    for (int pbase = 0; pbase < nlyr; pbase += NG) {
+        const bool valid = (pbase + grp) < nlyr;
+        const int p = valid ? pbase + grp : nlyr - 1;
         const double* rec = skd::rec_at<N>(b, nlyr, p, w);
         const double* xs = skd::xsol_at<N>(b, nlyr, p, w);
-        for (int i = lane; i < N; i += 64) { sK[i] = rec[R::K + i]; sAP[i] = rec[R::AP + i]; sAM[i] = rec[R::AM + i]; }
-        for (int i = lane; i < 2 * NN; i += 64) sW[i] = rec[R::WP + i];
-        for (int i = lane; i < 2 * N; i += 64) sXs[i] = xs[i];
-        for (int l = lane; l < NSTR; l += 64) sa[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
+        for (int i = gl; i < N; i += LG) { sK[i] = rec[R::K + i]; sAP[i] = rec[R::AP + i]; sAM[i] = rec[R::AM + i]; }
+        for (int i = gl; i < 2 * NN; i += LG) sW[i] = rec[R::WP + i];
+        for (int i = gl; i < 2 * N; i += LG) sXs[i] = xs[i];
+        for (int l = gl; l < NSTR; l += LG) sa[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
         const double th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
         __syncthreads();
         // exponentials of the layer in one instruction stream: exp(-k_j x) (lanes < N), exp(-sec x), exp(-sec th);  x = th lfrac
         const double lf = g.lfrac[p];
-        if (lane < N + 2) sEx[lane] = exp(-((lane < N) ? sK[lane] : sc) * ((lane == N + 1) ? th : th * lf));
+        if (gl < N + 2) sEx[gl] = exp(-((gl < N) ? sK[gl] : sc) * ((gl == N + 1) ? th : th * lf));
         __syncthreads();
-        if (lane < N) {
+        if (gl < N) {
             skd::PPMult pm;
-            const double Ej = rec[R::E + lane];  // exp(-k_j th), written by K1;  exp(-k (th - x)) = E / exp(-k x)
-            skd::pp_multipliers_e(T, th, sc, sK[lane], lf, sEx[lane], Ej / sEx[lane], sEx[N], sEx[N + 1], pm);
-            double* recw = skd::rec_at<N>(b, nlyr, p, w);
-            skd::ppm_store(recw + R::PPM + 14 * lane, pm);
-            sCL[lane] = pm.hp * sXs[lane] + sAP[lane] * pm.Dm;
-            sCM[lane] = pm.hm * sXs[N + lane] + sAM[lane] * pm.Dp;
+            const double Ej = rec[R::E + gl];  // exp(-k_j th), written by K1;  exp(-k (th - x)) = E / exp(-k x)
+            skd::pp_multipliers_e(T, th, sc, sK[gl], lf, sEx[gl], Ej / sEx[gl], sEx[N], sEx[N + 1], pm);
+            if (valid) skd::ppm_store(skd::rec_at<N>(b, nlyr, p, w) + R::PPM + 14 * gl, pm);
+            sCL[gl] = pm.hp * sXs[gl] + sAP[gl] * pm.Dm;
+            sCM[gl] = pm.hm * sXs[N + gl] + sAM[gl] * pm.Dp;
         }
         __syncthreads();
-        if (lane < N) {
+        if (gl < N) {
             double pr = 0, qr = 0;
             for (int j = 0; j < N; ++j) {
-                const double wp = sW[lane + N * j], wm = sW[NN + lane + N * j];
+                const double wp = sW[gl + N * j], wm = sW[NN + gl + N * j];
                 pr += wp * sCL[j] + wm * sCM[j];
                 qr += wm * sCL[j] + wp * sCM[j];
             }
-            sP[lane] = pr * 0.5 * g.wt[lane];
-            sQ[lane] = qr * 0.5 * g.wt[lane];
+            sP[gl] = pr * 0.5 * g.wt[gl];
+            sQ[gl] = qr * 0.5 * g.wt[gl];
         }
         __syncthreads();
-        if (lane < NSTR) {
-            const int l = lane;
+        for (int l = gl; l < NSTR; l += LG) {
             double sp = 0, sq = 0;
             if (l >= m)
                 for (int r = 0; r < N; ++r) {
@@ -654,33 +659,37 @@ template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs 
             sCleg[l] = sa[l] * ((((l - m) & 1) ? -sp : sp) + sq);
         }
         __syncthreads();
-        const int t0 = g.pt_start[s * nlyr + p], t1 = g.pt_start[s * nlyr + p + 1];
-        for (int t = t0 + lane; t < t1; t += 64) {
-            const int slot = g.pt_slot[t];
-            if (skd::conv_at(b, g, slot, w) <= m) continue;
-            const double* lpa = g.lpang + (size_t(m) * g.nangle + g.pt_angle[t]) * NSTR;
-            double val = 0;
-            for (int l = m; l < NSTR; ++l) val += sCleg[l] * lpa[l];
-            skd::J_at(b, g, m, slot, w) = val;
-            if (m >= 2) {
-                const double prev = skd::J_at(b, g, m - 1, slot, w), prev2 = skd::J_at(b, g, m - 2, slot, w);
-                if ((fabs(val / prev) < 1e-4 || prev < 1e-10) && (fabs(val / prev2) < 1e-4 || prev2 < 1e-10))
-                    skd::conv_at(b, g, slot, w) = (uint8_t)(m + 1);
-                else
-                    unconverged = 1;
+        if (valid) {
+            const int t0 = g.pt_start[s * nlyr + p], t1 = g.pt_start[s * nlyr + p + 1];
+            for (int t = t0 + gl; t < t1; t += LG) {
+                const int slot = g.pt_slot[t];
+                if (skd::conv_at(b, g, slot, w) <= m) continue;
+                const double* lpa = g.lpang + (size_t(m) * g.nangle + g.pt_angle[t]) * NSTR;
+                double val = 0;
+                for (int l = m; l < NSTR; ++l) val += sCleg[l] * lpa[l];
+                skd::J_at(b, g, m, slot, w) = val;
+                if (m >= 2) {
+                    const double prev = skd::J_at(b, g, m - 1, slot, w), prev2 = skd::J_at(b, g, m - 2, slot, w);
+                    if ((fabs(val / prev) < 1e-4 || prev < 1e-10) && (fabs(val / prev2) < 1e-4 || prev2 < 1e-10))
+                        skd::conv_at(b, g, slot, w) = (uint8_t)(m + 1);
+                    else
+                        unconverged = 1;
+                }
             }
         }
-        if (p == nlyr - 1 && m == 0) {
-            if (lane < N) {
-                double sv = rec[R::G + 2 * N + lane];
-                for (int j = 0; j < N; ++j)
-                    sv += sXs[j] * sW[lane + N * j] * exp(-fabs(sK[j]) * th) + sXs[N + j] * sW[NN + lane + N * j];
-                sRed[lane] = 2.0 * g.mu[lane] * g.wt[lane] * sv * b.albedo[w];
-            }
-            __syncthreads();
+        // upwelling diffuse reflection of the Lambertian surface (bottom layer, order 0): uniform over the group
+        const bool ground = valid && (p == nlyr - 1) && (m == 0);
+        if (ground && gl < N) {
+            double sv = rec[R::G + 2 * N + gl];
+            for (int j = 0; j < N; ++j)
+                sv += sXs[j] * sW[gl + N * j] * rec[R::E + j] + sXs[N + j] * sW[NN + gl + N * j];
+            sRed[gl] = 2.0 * g.mu[gl] * g.wt[gl] * sv * b.albedo[w];
+        }
+        __syncthreads();
+        if (ground) {
             double diffuse = 0;
             for (int i = 0; i < N; ++i) diffuse += sRed[i];
-            for (int t = g.gpt_start[s] + lane; t < g.gpt_start[s + 1]; t += 64) skd::J_at(b, g, m, g.gpt_slot[t], w) = diffuse;
+            for (int t = g.gpt_start[s] + gl; t < g.gpt_start[s + 1]; t += LG) skd::J_at(b, g, m, g.gpt_slot[t], w) = diffuse;
         }
         __syncthreads();
     }
