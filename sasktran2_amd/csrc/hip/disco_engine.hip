@@ -336,17 +336,32 @@ struct Timer {
 inline unsigned blocks(size_t n, int bs = kBlock) { return unsigned((n + bs - 1) / bs); }
 }  // namespace
 
+// With few wavelengths per launch one wavefront per wavelength cannot fill the device: the layer-parallel kernels (K1, K3,
+// K2c) then split the layers over blockIdx.y and the 16-stream adjoint sweeps one 16-LOS tile per block.
+static int small_batch_split(int nw) {
+    if (const char* e = std::getenv("SASKTRAN2_AMD_SPLIT")) return std::max(1, atoi(e));
+    return nw >= 3000 ? 1 : (nw >= 1500 ? 2 : 4);
+}
 // K1 launch: lane-group width per layer and the split of the layers over blockIdx.y
 template <int N>
 static void launch_k1(hipStream_t st, const Geo& g, const Bufs& b, int s, int m) {
     constexpr int LG = (N >= 16) ? 64 : SKD_K1_LG;
-    int split = 1;
-    if (const char* e = std::getenv("SASKTRAN2_AMD_K1SPLIT")) split = std::max(1, atoi(e));
+    const int split = small_batch_split(b.nw);
     const int ng = 64 / LG;
     int lpb = (g.nlyr + split - 1) / split;
     lpb = (lpb + ng - 1) / ng * ng;
     const int ny = (g.nlyr + lpb - 1) / lpb;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_wave<N, LG>), dim3(unsigned(b.nw), unsigned(ny)), dim3(64), 0, st, g, b, s, m, lpb);
+}
+
+template <int N>
+static void launch_k3(hipStream_t st, const Geo& g, const Bufs& b, int s, int m) {
+    constexpr int NG = (N >= 16) ? 2 : 4;  // layers per pass of kern_k3_wave
+    const int split = small_batch_split(b.nw);
+    int lpb = (g.nlyr + split - 1) / split;
+    lpb = (lpb + NG - 1) / NG * NG;
+    const int ny = (g.nlyr + lpb - 1) / lpb;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k3_wave<N>), dim3(unsigned(b.nw), unsigned(ny)), dim3(64), 0, st, g, b, s, m, lpb);
 }
 
 template <int N>
@@ -383,7 +398,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
             }
             {
                 Timer t(I, st, "k3_table_values");
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k3_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, 0, m);
+                launch_k3<N>(st, g, b, 0, m);
             }
             if (derivs) {
                 Timer t(I, st, "k2c_adjoint_ops");
@@ -422,7 +437,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
             }
             {
                 Timer t(I, st, "k3_table_values");
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k3_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                launch_k3<N>(st, g, b, s, m);
             }
             if (derivs) {
                 int lpw = 1;
@@ -431,13 +446,16 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                     // 16 streams: adjoint operators and sweeps as FP64 matrix-core products (v_mfma_f64_16x16x4_f64)
                     {
                         Timer t2(I, st, "k2c_adjoint_ops");
-                        hipLaunchKernelGGL(kern_k2c_mfma8, dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                        const int split = small_batch_split(int(nw));
+                        const int lpb = (g.nlyr + split - 1) / split, ny = (g.nlyr + lpb - 1) / lpb;
+                        hipLaunchKernelGGL(kern_k2c_mfma8, dim3(unsigned(nw), unsigned(ny)), dim3(64), 0, st, g, b, s, m, lpb);
                     }
                     Timer t(I, st, "k2b_adjoint");
-                    if (g.nlos > 16)
+                    const int ntile = (g.nlos + 15) / 16;
+                    if (ntile > 1 && small_batch_split(int(nw)) == 1)
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<2>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
-                    else
-                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<1>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                    else  // one 16-LOS tile per block (up to 4 blocks per wavelength)
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<1>), dim3(unsigned(nw), unsigned(std::min(ntile, 4))), dim3(64), 0, st, g, b, s, m);
                 } else {
                     {
                         Timer t2(I, st, "k2c_adjoint_ops");
@@ -485,7 +503,8 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
     const auto& t = I.tab;
     // Launch shape (measured on MI355X, C2): several blocks of wavelengths in flight on their own streams beat one
     // large block (29.1k wavelengths/s with 6 x 1667 against 26.0k with 1 x 10000 and 22.3k with 4096-blocks in sequence).
-    int nslots = std::max(1, std::min(6, nwavel / 512));
+    // About 1700 wavelengths per block is the sweet spot (5000 wavelengths: 3 x 1667 -> 113 ms, 6 x 834 -> 145 ms).
+    int nslots = std::max(1, std::min(6, (nwavel + 833) / 1667));
     if (const char* e = std::getenv("SASKTRAN2_AMD_STREAMS")) nslots = std::max(1, atoi(e));
     int chunk = std::min(4096, (nwavel + nslots - 1) / nslots);
     if (max_chunk > 0) chunk = std::min(chunk, max_chunk);

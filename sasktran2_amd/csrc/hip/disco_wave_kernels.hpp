@@ -39,6 +39,12 @@
 #define SKD_WPE_K2B 1
 #endif
 
+#ifdef SKD_K1_TIMING
+#define K1T(i) { long long _t = clock64(); tacc[i] += _t - tlast; tlast = _t; }
+#else
+#define K1T(i)
+#endif
+
 namespace skdev {
 
 using skd::Bufs;
@@ -56,7 +62,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
     const int w = blockIdx.x;
     if (m >= b.norders[w]) return;
     const int lane = threadIdx.x, grp = lane / LG, gl = lane % LG, nw = b.nw, nlyr = g.nlyr;
-    __shared__ double sMat[NG][9][NN];
+    __shared__ double sMat[NG][8][NN];
     __shared__ double sVec[NG][18][NSTR];
     __shared__ double sLp[N * NSTR], sLc[NSTR], sMu[N], sWt[N], sSq[N], sTt[N], sIm[N], sIt[N];
     __shared__ int sErr;
@@ -79,7 +85,6 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
     double* M5 = sMat[grp][5];
     double* M6 = sMat[grp][6];
     double* M7 = sMat[grp][7];
-    double* Vs = sMat[grp][8];   // eigenvectors of the group's previous layer (Jacobi warm start)
     double* va = sVec[grp][0];    // Legendre coefficients a_l
     double* vlam = sVec[grp][1];
     double* vk = sVec[grp][2];
@@ -105,6 +110,9 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
     __syncthreads();
 
     const int p_begin = blockIdx.y * layers_per_block, p_end = min(nlyr, p_begin + layers_per_block);
+#ifdef SKD_K1_TIMING
+    long long tacc[11] = {0,0,0,0,0,0,0,0,0,0,0}, tlast = clock64();
+#endif
     for (int pbase = p_begin; pbase < p_end; pbase += NG) {
         const bool valid = (pbase + grp) < p_end;
         const int p = valid ? pbase + grp : p_end - 1;
@@ -129,6 +137,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             Rc[e] = (j <= i) ? bp : 0.0;
         }
         __syncthreads();
+        K1T(0)
         // Cholesky B+ = R R^T (lower), one column per step
         for (int j = 0; j < N; ++j) {
             double tj = Rc[j * N + j];
@@ -148,6 +157,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             if (mine) Rc[i * N + j] = val;
             __syncthreads();
         }
+        K1T(1)
         // M3 = B- R ;  M4 = R^T M3 (symmetric)
         for (int e = gl; e < NN; e += LG) {
             const int i = e / N, j = e % N;
@@ -167,28 +177,8 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             M5[e] = (i == j) ? 1.0 : 0.0;
         }
         __syncthreads();
-        // warm start: the eigenvectors of the layer this lane group solved in its previous pass (NG layers above) nearly
-        // diagonalise this layer's matrix, so start from A0 = Vs^T M4 Vs, V0 = Vs instead of (M4, I)
-        if (N > 1 && pbase > p_begin) {
-            for (int e = gl; e < NN; e += LG) {
-                const int i = e / N, j = e % N;
-                double t = 0;
-                for (int r = 0; r < N; ++r) t += M4[i * N + r] * Vs[r * N + j];
-                M6[e] = t;
-            }
-            __syncthreads();
-            for (int e = gl; e < NN; e += LG) {
-                const int i = e / N, j = e % N;
-                if (j <= i) {
-                    double t = 0;
-                    for (int r = 0; r < N; ++r) t += Vs[r * N + i] * M6[r * N + j];
-                    M4[i * N + j] = t;
-                    M4[j * N + i] = t;
-                }
-                M5[e] = Vs[e];
-            }
-            __syncthreads();
-        }
+        K1T(2)
+        K1T(3)
         // Jacobi on M4 with the round-robin ("tournament") ordering: every round applies N/2 disjoint rotations at once,
         // A <- J^T A J and V <- V J with J the product of the round's rotations.  Index i of a rotated pair (p, q) has
         // partner i' and coefficients (al, be) = (c, -s) for i = p, (c, +s) for i = q, so that (A J)[r][i] = al A[r][i] + be A[r][i'].
@@ -247,14 +237,13 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
                     { double* tmp = Vcur; Vcur = Vnew; Vnew = tmp; }
                 }
             }
-            // leave the result in M4 / M5 (an odd number of rounds ends in the other pair of buffers); keep V for the warm start
+            // leave the result in M4 / M5 (an odd number of rounds ends in the other pair of buffers)
             if (Acur != M4) {
-                for (int e = gl; e < NN; e += LG) { M4[e] = Acur[e]; M5[e] = Vcur[e]; Vs[e] = Vcur[e]; }
-            } else {
-                for (int e = gl; e < NN; e += LG) Vs[e] = M5[e];
+                for (int e = gl; e < NN; e += LG) { M4[e] = Acur[e]; M5[e] = Vcur[e]; }
+                __syncthreads();
             }
-            __syncthreads();
         }
+        K1T(4)
         if (!jac_ok && gl == 0) sErr = skd::ERR_EIGEN;
         if (gl < N) {
             double lam = M4[gl * N + gl];
@@ -272,6 +261,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             for (int i = 0; i < N; ++i) M5[i * N + j] *= sIt[i];
         }
         __syncthreads();
+        K1T(5)
         // U (M3) = S+ X with S+-_ir = B+-_ir tt_r / tt_i
         for (int e = gl; e < NN; e += LG) {
             const int i = e / N, j = e % N;
@@ -321,6 +311,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             M6[e] = (M3[e] - M5[e] * sIm[i]) * inv_om_l + t * sIt[i];
         }
         __syncthreads();
+        K1T(6)
         // W+-, dW+- (element-wise, in place: M5 <- W+, M3 <- W-, M7 <- dW+, M6 <- dW-), stored as W(i, solution j) at i + N j
         for (int e = gl; e < NN; e += LG) {
             const int i = e / N, j = e % N;
@@ -336,6 +327,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
                 rec[R::DWM + i + N * j] = dwm;
             }
         }
+        K1T(7)
         // solar pseudo-source Q+-
         if (gl < N) {
             const int i = gl;
@@ -351,6 +343,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
         // exp(-k_j tau) of every solution and exp(-sec tau) of the layer: one instruction stream for N + 1 lanes
         if (gl <= N) vE[gl] = exp(-th * ((gl < N) ? vk[gl] : sc));
         __syncthreads();
+        K1T(8)
         // Green's function coefficients of solution j: norm, A+-, multipliers C+-, and the coefficient vectors of the
         // particular solution  G = W (A C)  with their derivatives:  coef[(type * 5 + k) * N + j], type 0: (A-, C-), 1: (A+, C+);
         // k = 0: A C,  k = 1 + theta: d(A C)/d theta at fixed W
@@ -398,6 +391,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             }
         }
         __syncthreads();
+        K1T(9)
         // G (4 vectors) and dG (4 params x 4 vectors).  A lane owns row i of W+ or W- (and of its omega-derivative) and one
         // coefficient type: G[c] = Wsel coef_0, dG[theta][c] = Wsel coef_{1+theta} (+ dWsel coef_0 for theta = omega),
         // c = 0: (W-, type 0), 1: (W+, type 0), 2: (W+, type 1), 3: (W-, type 1)
@@ -418,8 +412,12 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
                 for (int t = 0; t < 4; ++t) rec[R::DG + (t * 4 + c) * N + i] = acc[1 + t] + ((t == skd::TH_OM) ? accd : 0.0);
             }
         }
+        K1T(10)
         __syncthreads();
     }
+#ifdef SKD_K1_TIMING
+    if (lane == 0 && w == 0 && blockIdx.y == 0 && m == 1) printf("K1T build %lld chol %lld m3m4 %lld warm %lld jac %lld backsub %lld UdU %lld W %lld Q %lld coef %lld G %lld\n", tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6], tacc[7], tacc[8], tacc[9], tacc[10]);
+#endif
     if (lane == 0 && sErr) atomicOr(&b.status[w], sErr);
 }
 
@@ -600,7 +598,7 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2A) kern_k2a_wav
 // -------------------------------------------------------------------------------------------------------------------
 // K3: diffuse-source table values + convergence flags.  grid = wavelengths, block = 64 (lanes = table angles).
 // -------------------------------------------------------------------------------------------------------------------
-template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs b, int s, int m) {
+template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs b, int s, int m, int layers_per_block) {
     // NG lane groups of LG lanes, one layer per group and pass (the per-layer phases only have N .. 2N lanes of work)
     constexpr int NSTR = 2 * N, NN = N * N, LG = (N >= 16) ? 32 : 16, NG = 64 / LG;
     using R = skd::Rec<N>;
@@ -614,9 +612,10 @@ template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs 
     double* sCleg = sClegg[grp]; double* sRed = sRedg[grp]; double* sEx = sExg[grp];
     const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
     int unconverged = 0;
-    for (int pbase = 0; pbase < nlyr; pbase += NG) {
-        const bool valid = (pbase + grp) < nlyr;
-        const int p = valid ? pbase + grp : nlyr - 1;
+    const int p_begin = blockIdx.y * layers_per_block, p_end = min(nlyr, p_begin + layers_per_block);
+    for (int pbase = p_begin; pbase < p_end; pbase += NG) {
+        const bool valid = (pbase + grp) < p_end;
+        const int p = valid ? pbase + grp : p_end - 1;
         const double* rec = skd::rec_at<N>(b, nlyr, p, w);
         const double* xs = skd::xsol_at<N>(b, nlyr, p, w);
         for (int i = gl; i < N; i += LG) { sK[i] = rec[R::K + i]; sAP[i] = rec[R::AP + i]; sAM[i] = rec[R::AM + i]; }
@@ -1094,7 +1093,7 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2AM) kern_k2a_mfma8(Geo g, Bufs b
 // K2c for N = 8.  Same operators as skd::k2c_layer_ops; FP, SP and BP are stored as ready-made A-operand images
 // (FP: k-step r at [FP + 64 r + lane], r < 4;  SP / BP: [SP + 64 r + lane], [BP + 64 r + lane], r < 2) for kern_k2b_mfma8.
 //   FP^T = F^T Dinv  and  [SP | BP]^T = [SupT | SubT]^T Dinv  are two chains of four matrix-core products.
-__global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b, int s, int m) {
+__global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b, int s, int m, int layers_per_block) {
     constexpr int N = 8, NSTR = 16, M2 = 16;
     using R = skd::Rec<N>;
     using O = skd::Ops<N>;
@@ -1109,7 +1108,8 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b
     const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
     const double pc0 = 0.5 * g.wt[q] * lpmu[q * NSTR + col], pc1 = 0.5 * g.wt[q + 4] * lpmu[(q + 4) * NSTR + col];
     const double sg = ((col - m) & 1) ? -1.0 : 1.0;
-    for (int p = 0; p < nlyr; ++p) {
+    const int p_begin = blockIdx.y * layers_per_block, p_end = min(nlyr, p_begin + layers_per_block);
+    for (int p = p_begin; p < p_end; ++p) {
         const bool last = (p == nlyr - 1);
         const double* rec = skd::rec_at<N>(b, nlyr, p, w);
         const double* dg = skd::dinv_at<N>(b, nlyr, p, w);
@@ -1269,7 +1269,7 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
     const double* lpm4 = g.lpang4 + size_t(m) * g.nangle * NSTR;
     const int2* lpmeta = reinterpret_cast<const int2*>(g.lp_meta);
     const bool last_is_ground = (m == 0);
-    for (int tile0 = 0; tile0 < ntile; tile0 += TILES) {
+    for (int tile0 = blockIdx.y * TILES; tile0 < ntile; tile0 += gridDim.y * TILES) {
         int los[TILES];
         bool ok[TILES];
         double gw[TILES];
