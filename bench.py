@@ -31,6 +31,49 @@ HBM_PEAK_GBS = 8000.0                      # /opt/skills/guides/MI355X_MICROARCH
 FP64_VECTOR_PEAK_TFLOPS = 78.6             # MI355X datasheet (vector FP64)
 
 
+KERNEL_OF = {"kern_k1_wave": "k1_layer_solution", "kern_k2a_mfma8": "k2a_bvp", "kern_k2a_wave": "k2a_bvp",
+             "kern_k2b_mfma8": "k2b_adjoint", "kern_k2b_wave": "k2b_adjoint", "kern_k2c_mfma8": "k2c_adjoint_ops",
+             "kern_k2c_wave": "k2c_adjoint_ops", "kern_k3_wave": "k3_table_values", "kern_k4a": "k4a_chain", "kern_k4b": "k4b_los",
+             "kern_k0": "k0_layer_optics", "kern_k0_shells": "k0_layer_optics", "kern_k0_los": "k0_layer_optics",
+             "kern_k0t": "k0_transmission", "kern_cw": "k0_entry_weights", "kern_stop": "k_stop_rule", "kern_output": "k_output",
+             "kern_init": "init", "kern_kpp": "kpp_los"}
+
+
+def load_pmc_profile():
+    """Per timer name: HBM bytes and FP64 operations per wavelength and launch, plus '_solve' totals per wavelength and solve,
+    from the newest committed rocprofv3 PMC summary (4096 wavelengths per launch, two solves per profiled run)."""
+    import json
+    import re
+    files = sorted((ROOT / "profiles").glob("*/pmc_and_trace_summary.json"))
+    if not files:
+        return {}
+    out, tot_b, tot_f = {}, 0.0, 0.0
+    for r in json.loads(files[-1].read_text()).get("pmc_4096_wavelengths_per_launch", []):
+        m = re.match(r"(kern_\w+?)(<|$)", r["kernel"])
+        name = KERNEL_OF.get(m.group(1)) if m else None
+        if not name:
+            continue
+        b = (r.get("hbm_read_bytes_per_launch_x2_corrected") or 0) + (r.get("hbm_write_bytes_per_launch") or 0)
+        f = (r.get("fp64_valu_flops_per_launch_upper_bound") or 0) + (r.get("fp64_mfma_flops_per_launch") or 0)
+        e = out.setdefault(name, {"hbm_bytes_per_wavelength": 0.0, "flops_per_wavelength": 0.0})
+        e["hbm_bytes_per_wavelength"] += b / 4096
+        e["flops_per_wavelength"] += f / 4096
+        tot_b += b * r["launches"] / 2 / 4096
+        tot_f += f * r["launches"] / 2 / 4096
+    out["_solve"] = {"hbm_bytes_per_wavelength": tot_b, "flops_per_wavelength": tot_f, "source": files[-1].parent.name}
+    return out
+
+
+def whole_step_rates(pmc, wavelengths_per_s):
+    t = pmc.get("_solve")
+    if not t:
+        return None
+    gbs, tf = t["hbm_bytes_per_wavelength"] * wavelengths_per_s / 1e9, t["flops_per_wavelength"] * wavelengths_per_s / 1e12
+    return {"hbm_GBs": gbs, "hbm_frac_of_8TBs": gbs / HBM_PEAK_GBS, "fp64_TFLOPs": tf, "fp64_frac_of_78.6": tf / FP64_VECTOR_PEAK_TFLOPS,
+            "hbm_bytes_per_wavelength": t["hbm_bytes_per_wavelength"], "fp64_ops_per_wavelength": t["flops_per_wavelength"],
+            "pmc_source": "profiles/" + t["source"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,7 +154,27 @@ def main():
     dom_ms, dom_n = ktimes[dominant]
     chunk = solver.launch_shape()[0]  # wavelengths per launch of the profiled pass (one block in flight)
     avg_launch_s = dom_ms / dom_n * 1e-3
-    achieved_gbs = ALGORITHMIC_BYTES_PER_WAVELENGTH * chunk / avg_launch_s / 1e9
+    # HBM bytes and FP64 operations per wavelength and launch of every kernel, measured with rocprofv3 PMC passes
+    # (tools/profile_gpu.sh -> profiles/<round>/pmc_and_trace_summary.json; FETCH_SIZE x2-corrected as the guide prescribes)
+    pmc = load_pmc_profile()
+    kp = pmc.get(dominant, {})
+    flop_bound = dominant in ("k1_layer_solution", "k2a_bvp")  # dependent FP64 chains / matrix-core steps, little HBM traffic
+    if flop_bound and kp.get("flops_per_wavelength"):
+        achieved = kp["flops_per_wavelength"] * chunk / avg_launch_s / 1e12
+        roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                    "flops_per_launch": kp["flops_per_wavelength"] * chunk,
+                    "note": "FP64 operations executed (PMC: SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 x 64 lanes + matrix-core MOPS x 512), "
+                            "vector and matrix FP64 peak are both 78.6 TFLOP/s on MI355X"}
+    else:
+        achieved = ALGORITHMIC_BYTES_PER_WAVELENGTH * chunk / avg_launch_s / 1e9
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS,
+                    "note": "achieved = algorithmic bytes of the whole path (28 160 B / wavelength) per launch of this kernel; "
+                            "the kernel's own HBM traffic is in `traffic`"}
+    roofline["traffic"] = kp["hbm_bytes_per_wavelength"] * chunk if kp.get("hbm_bytes_per_wavelength") else None
+    roofline.update({"algorithmic_bytes_per_wavelength": ALGORITHMIC_BYTES_PER_WAVELENGTH, "wavelengths_per_launch": chunk,
+                     "avg_launch_ms": dom_ms / dom_n, "launches": dom_n})
 
     line = None
     if rank == 0:
@@ -127,11 +190,8 @@ def main():
                        "wavelengths_per_gpu": nloc, "parallelism": f"wavelength-shard x{world} + RCCL all-gather" if world > 1 else "single GPU",
                        "single_scatter_source": "discrete_ordinates", "num_sza": 1, "wavelengths_per_launch": run_chunk, "blocks_in_flight": run_slots},
             "valid": finite and status_bad == 0,
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_wavelength": ALGORITHMIC_BYTES_PER_WAVELENGTH,
-                         "avg_launch_ms": dom_ms / dom_n, "launches": dom_n,
-                         "note": "path is FP64-latency/ALU bound, not HBM-streaming (SURVEY 8d); see kernels_ms and DESIGN.md"},
+            "roofline": roofline,
+            "whole_step": whole_step_rates(pmc, value),
             "kernels_ms": {k: {"total_ms": round(v[0], 3), "launches": v[1]} for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])},
             "scratch_gib": run_scratch / 2 ** 30,
         }
