@@ -940,10 +940,11 @@ __device__ __forceinline__ int gj16_inplace(mf4& acc, int col, int q, unsigned l
         ip = fma(fma(-pv, ip, 1.0), ip, ip);
         ip = fma(fma(-pv, ip, 1.0), ip, ip);
         const int pr = pivrow >> 2, pq = pivrow & 3;
+        // rank-1 update through k-slot pq of the product: the lanes (col, q = pq) already hold the pivot row D[pivrow][col]
+        // in register pr, and the gathered column is replicated over q, so neither operand needs a cross-lane move
         const double rowsel = (pr == 0) ? acc[0] : (pr == 1) ? acc[1] : (pr == 2) ? acc[2] : acc[3];
-        const double rowv = __shfl(rowsel, col + 16 * pq);  // D[pivrow][col]
-        const double aop = (q == 0 && col != pivrow) ? -colv * ip : 0.0;
-        const double bop = (q == 0 && col != k) ? rowv : 0.0;
+        const double aop = (q == pq && col != pivrow) ? -colv * ip : 0.0;
+        const double bop = (q == pq && col != k) ? rowsel : 0.0;
         acc = mfma16(aop, bop, acc);
         // the rank-1 product leaves the pivot row and column untouched: scale them here
         for (int r = 0; r < 4; ++r) {

@@ -15,7 +15,10 @@ __global__ void invert(const double* A, double* Ainv, int* sing, double* dbg) {
     double key = a[col * 16 + 0];
     dbg[blockIdx.x * 64 + lane] = skdev::row16_max(fabs(key));
     unsigned long long pP, pI;
+    long long t0 = clock64();
     int s = skdev::gj16_inplace(acc, col, q, pP, pI, blockIdx.x == 0 ? dbg + 1024 : nullptr);
+    long long t1 = clock64();
+    if (lane == 0 && blockIdx.x == 1) dbg[1100] = double(t1 - t0);
     __syncthreads();
     skdev::gj16_scatter(acc, col, q, pP, pI, sP);
     __syncthreads();
@@ -45,6 +48,7 @@ int main() {
         double cm = 0; for (int i = 0; i < 16; ++i) cm = fmax(cm, fabs(A[b * 256 + i * 16]));
         printf("matrix %d: |A Ainv - I|max = %.3e sing=%d ; row16_max lanes 0,5,17,63 = %.6f %.6f %.6f %.6f expected %.6f\n", b, err, sing[b], dbg[b * 64], dbg[b * 64 + 5], dbg[b * 64 + 17], dbg[b * 64 + 63], cm);
     }
+    printf("gj16_inplace: %.0f clock ticks for 16 pivot steps (one wave alone on its SIMD)\n", dbg[1100]);
     // host reference pivot sequence for matrix 0 (in-place GJ, rows not moved)
     {
         std::vector<double> M(A.begin(), A.begin() + 256);
