@@ -902,6 +902,16 @@ template <int CTRL> __device__ __forceinline__ double dpp64(double v) {
     const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+template <int CTRL> __device__ __forceinline__ unsigned dpp32u(unsigned v) {
+    return unsigned(__builtin_amdgcn_mov_dpp(int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+    v = max(v, dpp32u<0xb1>(v));
+    v = max(v, dpp32u<0x4e>(v));
+    v = max(v, dpp32u<0x124>(v));
+    v = max(v, dpp32u<0x128>(v));
+    return v;
+}
 __device__ __forceinline__ double row16_max(double v) {
     v = fmax(v, dpp64<0xb1>(v));   // quad_perm [1,0,3,2]
     v = fmax(v, dpp64<0x4e>(v));   // quad_perm [2,3,0,1]
@@ -920,43 +930,77 @@ __device__ __forceinline__ int gj16_inplace(mf4& acc, int col, int q, unsigned l
     int sing = 0;
     permP = 0;
     permI = 0;
-    for (int k = 0; k < M2; ++k) {
-        // column k -> every 16-lane row: D[i = col][k] lives in lane (k, i & 3), register i >> 2
-        const int src = k + 16 * (col & 3);
+#ifdef SKD_GJ_TIMING
+    long long tg[6] = {0, 0, 0, 0, 0, 0}, tl = clock64();
+#define GJT(i) { long long _t = clock64(); tg[i] += _t - tl; tl = _t; }
+#else
+#define GJT(i)
+#endif
+    // column c of the tile -> every 16-lane row: D[i = col][c] lives in lane (c, i & 3), register i >> 2
+    auto gather_col = [&](int c) {
+        const int src = c + 16 * (col & 3);
         const double c0 = __shfl(acc[0], src), c1 = __shfl(acc[1], src), c2 = __shfl(acc[2], src), c3 = __shfl(acc[3], src);
         const int ir = col >> 2;
-        const double colv = (ir == 0) ? c0 : (ir == 1) ? c1 : (ir == 2) ? c2 : c3;
-        // partial pivoting: arg max |D[i][k]| over the rows not used yet, as a max-reduction of keys inside the 16-lane row
-        // (data-parallel-primitive moves, no LDS): key = |value| with the low four mantissa bits replaced by 15 - i
-        const unsigned long long kb = (static_cast<unsigned long long>(__double_as_longlong(fabs(colv))) & ~15ull) | (unsigned long long)(15 - col);
-        const double key = ((used >> col) & 1u) ? 0.0 : __longlong_as_double((long long)kb);
-        const double kmax = row16_max(key);
-        const unsigned long long kmb = (unsigned long long)__double_as_longlong(kmax);
-        const int pivrow = __builtin_amdgcn_readfirstlane(15 - int(kmb & 15ull));
+        return (ir == 0) ? c0 : (ir == 1) ? c1 : (ir == 2) ? c2 : c3;
+    };
+    double colv = gather_col(0);
+    for (int k = 0; k < M2; ++k) {
+        // look-ahead: column k + 1 as it is BEFORE this step's update is requested now (its latency hides behind the pivot
+        // search) and updated analytically below, so the next step does not wait for this step's product and a gather
+        const double cnext = gather_col((k + 1) & 15);
+        GJT(0)
+        // partial pivoting: arg max |D[i][k]| over the rows not used yet, as an unsigned max-reduction of 32-bit keys inside
+        // the 16-lane row (v_max_u32 with DPP operands, no LDS): key = high word of |value| (exponent + 20 mantissa bits,
+        // ordered like the magnitude) with its low four bits replaced by 15 - i.  The pivot only has to be close to the
+        // largest candidate; its exact value is read back below.
+        const unsigned hi = unsigned(__double2hiint(colv)) & 0x7fffffffu;
+        const unsigned key = ((used >> col) & 1u) ? 0u : ((hi & ~15u) | unsigned(15 - col));
+        const unsigned kmb = row16_max_u32(key);
+        GJT(1)
+        const int pivrow = __builtin_amdgcn_readfirstlane(15 - int(kmb & 15u));
         double pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(colv), pivrow), __builtin_amdgcn_readlane(__double2loint(colv), pivrow));
-        if ((kmb & ~15ull) == 0ull) { sing = 1; pv = 1.0; }
+        if (!(fabs(pv) > 0.0)) { sing = 1; pv = 1.0; }
+        GJT(2)
         // reciprocal of the pivot: hardware estimate + two Newton steps (full double precision, short dependency chain)
         double ip = __builtin_amdgcn_rcp(pv);
         ip = fma(fma(-pv, ip, 1.0), ip, ip);
         ip = fma(fma(-pv, ip, 1.0), ip, ip);
+        GJT(3)
         const int pr = pivrow >> 2, pq = pivrow & 3;
         // rank-1 update through k-slot pq of the product: the lanes (col, q = pq) already hold the pivot row D[pivrow][col]
         // in register pr, and the gathered column is replicated over q, so neither operand needs a cross-lane move
         const double rowsel = (pr == 0) ? acc[0] : (pr == 1) ? acc[1] : (pr == 2) ? acc[2] : acc[3];
         const double aop = (q == pq && col != pivrow) ? -colv * ip : 0.0;
         const double bop = (q == pq && col != k) ? rowsel : 0.0;
-        acc = mfma16(aop, bop, acc);
-        // the rank-1 product leaves the pivot row and column untouched: scale them here
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * r + q;
-            if (col == k) acc[r] = (row == pivrow) ? ip : -acc[r] * ip;
-            else if (row == pivrow) acc[r] *= ip;
+        // the rank-1 product leaves the pivot row and column untouched; they are scaled by one fused multiply-add per
+        // register whose factors do not depend on the product (computed while the matrix core works)
+        double ff[4], fg[4];
+        {
+            const double cs = (col == k) ? -ip : 1.0;                 // column k: -D[i][k] / p ; other columns unchanged
+            const double fixv = (col == k) ? ip : rowsel * ip;        // pivot row: D[pivrow][j] / p, (pivrow, k) -> 1 / p
+            for (int r = 0; r < 4; ++r) {
+                const bool sel = (r == pr) && (q == pq);              // r == pr is uniform
+                ff[r] = sel ? 0.0 : cs;
+                fg[r] = sel ? fixv : 0.0;
+            }
         }
+        acc = mfma16(aop, bop, acc);
+        GJT(4)
+        for (int r = 0; r < 4; ++r) acc[r] = fma(acc[r], ff[r], fg[r]);
+        {
+            // column k + 1 after this step: D[i][k+1] - D[i][k] / p * D[pivrow][k+1], pivot row scaled by 1 / p
+            const double b1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cnext), pivrow), __builtin_amdgcn_readlane(__double2loint(cnext), pivrow));
+            colv = (col == pivrow) ? cnext * ip : fma(-colv * ip, b1, cnext);
+        }
+        GJT(5)
         if (trace && col == 0 && q == 0) { trace[2 * k] = pivrow; trace[2 * k + 1] = pv; }
         used |= 1u << pivrow;
         permP |= (unsigned long long)pivrow << (4 * k);
         permI |= (unsigned long long)k << (4 * pivrow);
     }
+#ifdef SKD_GJ_TIMING
+    if (trace && col == 0 && q == 0) for (int i = 0; i < 6; ++i) trace[40 + i] = double(tg[i]);
+#endif
     return sing;
 }
 __device__ __forceinline__ void gj16_scatter(const mf4& acc, int col, int q, unsigned long long permP, unsigned long long permI, double* sP) {

@@ -49,6 +49,7 @@ int main() {
         printf("matrix %d: |A Ainv - I|max = %.3e sing=%d ; row16_max lanes 0,5,17,63 = %.6f %.6f %.6f %.6f expected %.6f\n", b, err, sing[b], dbg[b * 64], dbg[b * 64 + 5], dbg[b * 64 + 17], dbg[b * 64 + 63], cm);
     }
     printf("gj16_inplace: %.0f clock ticks for 16 pivot steps (one wave alone on its SIMD)\n", dbg[1100]);
+    printf("stage ticks (16 steps): gather %.0f keymax %.0f readlanes %.0f rcp %.0f ops+mfma %.0f fixups %.0f\n", dbg[1064], dbg[1065], dbg[1066], dbg[1067], dbg[1068], dbg[1069]);
     // host reference pivot sequence for matrix 0 (in-place GJ, rows not moved)
     {
         std::vector<double> M(A.begin(), A.begin() + 256);
