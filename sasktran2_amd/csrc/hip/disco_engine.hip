@@ -501,10 +501,10 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
     Impl& I = *impl_;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const auto& t = I.tab;
-    // Launch shape (measured on MI355X, C2): several blocks of wavelengths in flight on their own streams beat one
-    // large block (29.1k wavelengths/s with 6 x 1667 against 26.0k with 1 x 10000 and 22.3k with 4096-blocks in sequence).
-    // About 1700 wavelengths per block is the sweet spot (5000 wavelengths: 3 x 1667 -> 113 ms, 6 x 834 -> 145 ms).
-    int nslots = std::max(1, std::min(6, (nwavel + 833) / 1667));
+    // Launch shape (measured on MI355X, C2): two or more blocks of wavelengths in flight on their own streams beat one large
+    // block (10 000 wavelengths: 3 x 3334 -> 215 ms, 2 x 5000 -> 217, 6 x 1667 -> 227, 1 x 10 000 -> 235; 5 000: 3 x 1667 -> 113,
+    // 1 x 5000 -> 135; 2 500: 2 x 1250 -> 64, 1 x 2500 -> 71; below ~2 000 a single block is best).
+    int nslots = (nwavel < 2000) ? 1 : std::max(2, std::min(6, (nwavel + 1667) / 3334));
     if (const char* e = std::getenv("SASKTRAN2_AMD_STREAMS")) nslots = std::max(1, atoi(e));
     int chunk = std::min(4096, (nwavel + nslots - 1) / nslots);
     if (max_chunk > 0) chunk = std::min(chunk, max_chunk);

@@ -1300,6 +1300,9 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b
 //   Y / Z tiles and the HD part are kept in HBM between the sweeps in their C/D register images
 //   (b.z: [w][p][tile][4][64], b.qlbuf: [w][p][tile][64]); nothing goes through LDS.
 template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2b_mfma8(Geo g, Bufs b, int s, int m) {
+    // the one- and two-tile instantiations must round identically (results do not depend on the launch shape): no implicit
+    // contraction of a * b + c in this kernel, fused multiply-adds are written out
+#pragma clang fp contract(off)
     constexpr int N = 8, NSTR = 16;
     using O = skd::Ops<N>;
     const int w = blockIdx.x;

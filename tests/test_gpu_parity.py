@@ -188,6 +188,14 @@ def test_c2_wavelength_blocks_in_flight_are_equivalent(monkeypatch):
     many = run_product(s)
     for k in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
         assert np.array_equal(one[k], many[k]), k
+    # ... and so are the layer / LOS-tile splits of the small-batch launches
+    monkeypatch.setenv("SASKTRAN2_AMD_STREAMS", "1")
+    monkeypatch.setenv("SASKTRAN2_AMD_CHUNK", "700")
+    for split in ("1", "2", "8"):
+        monkeypatch.setenv("SASKTRAN2_AMD_SPLIT", split)
+        other = run_product(s)
+        for k in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
+            assert np.array_equal(one[k], other[k]), (split, k)
 
 
 def test_c2_two_solar_zenith_points_matches_oracle():
