@@ -188,6 +188,13 @@ def test_c2_wavelength_blocks_in_flight_are_equivalent(monkeypatch):
     many = run_product(s)
     for k in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
         assert np.array_equal(one[k], many[k]), k
+    # ... with and without the K1 look-ahead stream
+    for la in ("0", "1"):
+        monkeypatch.setenv("SASKTRAN2_AMD_LOOKAHEAD", la)
+        other = run_product(s)
+        for k in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
+            assert np.array_equal(one[k], other[k]), ("lookahead", la, k)
+    monkeypatch.delenv("SASKTRAN2_AMD_LOOKAHEAD")
     # ... and so are the layer / LOS-tile splits of the small-batch launches
     monkeypatch.setenv("SASKTRAN2_AMD_STREAMS", "1")
     monkeypatch.setenv("SASKTRAN2_AMD_CHUNK", "700")
