@@ -190,9 +190,11 @@ struct DeviceEngine::Impl {
         hipEvent_t done = nullptr;
         // look-ahead of the layer solutions: K1 of order m+1 only needs the layer optics, so it runs on its own stream into
         // the second record buffer while K2a..K2b of order m still work on the first
-        hipStream_t k1_stream = nullptr;
+        hipStream_t k1_stream = nullptr, adj_stream = nullptr;
         double* rec2 = nullptr;
-        std::vector<hipEvent_t> ev_k1, ev_rest;  // per azimuth order
+        double* dinv2 = nullptr;
+        double* xsol2 = nullptr;
+        std::vector<hipEvent_t> ev_k1, ev_bvp, ev_rest;  // per azimuth order
         hipEvent_t ev_begin = nullptr;
     };
     std::vector<std::unique_ptr<Slot>> slots;
@@ -241,6 +243,8 @@ DeviceEngine::~DeviceEngine() {
         for (auto& sl : impl_->slots) {
             if (sl->stream) (void)hipStreamDestroy(sl->stream);
             if (sl->k1_stream) (void)hipStreamDestroy(sl->k1_stream);
+            if (sl->adj_stream) (void)hipStreamDestroy(sl->adj_stream);
+            for (auto e : sl->ev_bvp) (void)hipEventDestroy(e);
             if (sl->done) (void)hipEventDestroy(sl->done);
             if (sl->ev_begin) (void)hipEventDestroy(sl->ev_begin);
             for (auto e : sl->ev_k1) (void)hipEventDestroy(e);
@@ -281,7 +285,7 @@ size_t DeviceEngine::bytes_per_wavelength() const {
     d += nlyr * (3 + nstr) + (nlyr + 1) + nlyr;              // tau, om, kbar, a, T, sec
     d += size_t(t.nq_total) * 3 + nlos;                      // od, omloc, srcw, att_total
     if (N == 8) d += t.lp_q.size();                          // cwbuf
-    d += 2 * nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N;  // rec (two buffers), dinv, xsol
+    d += 2 * (nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N);  // rec, dinv, xsol (two buffers each)
     d += nstr * size_t(t.nslot);                             // J
     const size_t nlos_pad = (nlos + 15) / 16 * 16;
     d += nlyr * (8 * N * N + 26 * N + 5) + nlyr * nstr * nlos_pad;  // ops, qlbuf
@@ -298,12 +302,15 @@ void DeviceEngine::ensure_scratch(int nw, int nslots) {
         auto sl = std::make_unique<Impl::Slot>();
         HIP_CHECK(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&sl->k1_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&sl->adj_stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&sl->ev_begin, hipEventDisableTiming));
         sl->ev_k1.resize(I.tab.nstr);
+        sl->ev_bvp.resize(I.tab.nstr);
         sl->ev_rest.resize(I.tab.nstr);
         for (int i = 0; i < I.tab.nstr; ++i) {
             HIP_CHECK(hipEventCreateWithFlags(&sl->ev_k1[i], hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&sl->ev_bvp[i], hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&sl->ev_rest[i], hipEventDisableTiming));
         }
         I.slots.push_back(std::move(sl));
@@ -321,6 +328,8 @@ void DeviceEngine::ensure_scratch(int nw, int nslots) {
         b.cwbuf = M.alloc<double>(t.N == 8 ? t.lp_q.size() * W : 1);
         b.rec = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W); b.dinv = M.alloc<double>(nlyr * 4 * N * N * W);
         sl->rec2 = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W);
+        sl->dinv2 = M.alloc<double>(nlyr * 4 * N * N * W);
+        sl->xsol2 = M.alloc<double>(nlyr * 2 * N * W);
         b.xsol = M.alloc<double>(nlyr * 2 * N * W); b.J = M.alloc<double>(nstr * size_t(t.nslot) * W);
         b.conv_order = M.alloc<uint8_t>(size_t(t.nslot) * W); b.notconv = M.alloc<int>(W); b.norders = M.alloc<int>(W);
         b.status = M.alloc<int>(W); b.z = M.alloc<double>(nlyr * 2 * N * W * nlos_pad);
@@ -437,32 +446,46 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
         Timer t(I, st, "k0_entry_weights");
         hipLaunchKernelGGL(kern_cw, dim3(4096), dim3(256), 0, st, g, b);
     }
-    // K1 look-ahead (not while profiling, which serialises everything on one stream)
-    // Measured: it pays when few blocks are in flight (1 250 wavelengths: 41.8 -> 39.3 ms) and costs a little when three or more
-    // blocks already overlap their kernels (10 000: 218.7 -> 223.5 ms), so it follows the launch shape unless overridden.
+    // Order pipeline (not while profiling, which serialises everything on one stream).  The layer solutions of order m + 1 only
+    // need the layer optics and the BVP of order m + 1 only K1(m + 1), so with the record / block-inverse / solution buffers
+    // doubled the three stages  K1 | K2a K3 stop | K2c K2b  of consecutive orders run on three streams.  Measured: it pays when few
+    // blocks are in flight (a lone block is bound by the single-wave latency of the layer recursions) and costs a little when
+    // three or more blocks already overlap their kernels, so it follows the launch shape unless SASKTRAN2_AMD_LOOKAHEAD says else.
     static const int lookahead_env = [] { const char* e = std::getenv("SASKTRAN2_AMD_LOOKAHEAD"); return e ? atoi(e) : -1; }();
-    const bool lookahead = !I.profiling && slot.k1_stream != nullptr && (lookahead_env >= 0 ? lookahead_env != 0 : I.last_slots <= 2);
+    const bool pipe = !I.profiling && slot.k1_stream != nullptr && (lookahead_env >= 0 ? lookahead_env != 0 : I.last_slots <= 2);
     double* const rec_buf[2] = {b.rec, slot.rec2};
+    double* const dinv_buf[2] = {b.dinv, slot.dinv2};
+    double* const xsol_buf[2] = {b.xsol, slot.xsol2};
+    hipStream_t sA = pipe ? slot.k1_stream : st, sC = pipe ? slot.adj_stream : st;
     for (int s = 0; s < g.nsza; ++s) {
         {
             Timer t(I, st, "k0_transmission");
             hipLaunchKernelGGL(kern_k0t, dim3(blocks(nw)), dim3(kBlock), 0, st, g, b, s);
         }
-        if (lookahead) {
+        if (pipe) {
             HIP_CHECK(hipEventRecord(slot.ev_begin, st));
-            HIP_CHECK(hipStreamWaitEvent(slot.k1_stream, slot.ev_begin, 0));
+            HIP_CHECK(hipStreamWaitEvent(sA, slot.ev_begin, 0));
+            HIP_CHECK(hipStreamWaitEvent(sC, slot.ev_begin, 0));
         }
+        int last_m = -1;
         for (int m = 0; m < g.nstr; ++m) {
-            if (lookahead) {
-                // record buffer m & 1: K1(m) may start once the rest of order m - 2 has finished with it
+            if (pipe) {
                 b.rec = rec_buf[m & 1];
-                if (m >= 2) HIP_CHECK(hipStreamWaitEvent(slot.k1_stream, slot.ev_rest[m - 2], 0));
-                launch_k1<N>(slot.k1_stream, g, b, s, m);
-                HIP_CHECK(hipEventRecord(slot.ev_k1[m], slot.k1_stream));
+                b.dinv = dinv_buf[m & 1];
+                b.xsol = xsol_buf[m & 1];
+                // buffers of parity m & 1 are free once the adjoint stage of order m - 2 is done
+                if (m >= 2) {
+                    HIP_CHECK(hipStreamWaitEvent(sA, slot.ev_rest[m - 2], 0));
+                    HIP_CHECK(hipStreamWaitEvent(st, slot.ev_rest[m - 2], 0));
+                }
+            }
+            {
+                Timer t(I, sA, "k1_layer_solution");
+                launch_k1<N>(sA, g, b, s, m);
+            }
+            if (pipe) {
+                HIP_CHECK(hipEventRecord(slot.ev_k1[m], sA));
                 HIP_CHECK(hipStreamWaitEvent(st, slot.ev_k1[m], 0));
-            } else {
-                Timer t(I, st, "k1_layer_solution");
-                launch_k1<N>(st, g, b, s, m);
             }
             {
                 Timer t(I, st, "k2a_bvp");
@@ -475,37 +498,43 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                 Timer t(I, st, "k3_table_values");
                 launch_k3<N>(st, g, b, s, m);
             }
+            if (pipe) {
+                HIP_CHECK(hipEventRecord(slot.ev_bvp[m], st));
+                HIP_CHECK(hipStreamWaitEvent(sC, slot.ev_bvp[m], 0));
+            }
             if (derivs) {
                 int lpw = 1;
                 while (lpw < g.nlos && lpw < 64) lpw *= 2;
                 if constexpr (N == 8) {
                     // 16 streams: adjoint operators and sweeps as FP64 matrix-core products (v_mfma_f64_16x16x4_f64)
                     {
-                        Timer t2(I, st, "k2c_adjoint_ops");
+                        Timer t2(I, sC, "k2c_adjoint_ops");
                         const int split = small_batch_split(int(nw));
                         const int lpb = (g.nlyr + split - 1) / split, ny = (g.nlyr + lpb - 1) / lpb;
-                        hipLaunchKernelGGL(kern_k2c_mfma8, dim3(unsigned(nw), unsigned(ny)), dim3(64), 0, st, g, b, s, m, lpb);
+                        hipLaunchKernelGGL(kern_k2c_mfma8, dim3(unsigned(nw), unsigned(ny)), dim3(64), 0, sC, g, b, s, m, lpb);
                     }
-                    Timer t(I, st, "k2b_adjoint");
+                    Timer t(I, sC, "k2b_adjoint");
                     const int ntile = (g.nlos + 15) / 16;
                     if (ntile > 1 && small_batch_split(int(nw)) == 1)
-                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<2>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<2>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m);
                     else  // one 16-LOS tile per block (up to 4 blocks per wavelength)
-                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<1>), dim3(unsigned(nw), unsigned(std::min(ntile, 4))), dim3(64), 0, st, g, b, s, m);
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<1>), dim3(unsigned(nw), unsigned(std::min(ntile, 4))), dim3(64), 0, sC, g, b, s, m);
                 } else {
                     {
-                        Timer t2(I, st, "k2c_adjoint_ops");
-                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                        Timer t2(I, sC, "k2c_adjoint_ops");
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_wave<N>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m);
                     }
                     const size_t per_w = skd::Ops<N>::SIZE * sizeof(double);
                     const int wpb = std::max(1, std::min<int>(64 / lpw, int(49152 / per_w)));
-                    Timer t(I, st, "k2b_adjoint");
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_wave<N>), dim3(unsigned((nw + wpb - 1) / wpb)), dim3(64), wpb * per_w, st, g, b, s, m, lpw, wpb);
+                    Timer t(I, sC, "k2b_adjoint");
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_wave<N>), dim3(unsigned((nw + wpb - 1) / wpb)), dim3(64), wpb * per_w, sC, g, b, s, m, lpw, wpb);
                 }
             }
+            if (pipe) HIP_CHECK(hipEventRecord(slot.ev_rest[m], sC));
             // stop rule.  Kernels of orders beyond a wavelength's last one return at once (norders), so the host only
             // reads the count of still-active wavelengths back when profiling (keeps the per-kernel launch counts exact);
-            // otherwise every order is enqueued without a host round trip.
+            // otherwise every order is enqueued without a host round trip.  (The adjoint stage of order m may still be running:
+            // it only tests conv_order > m, which neither this kernel's clamp to m + 1 nor K3 of order m + 1 changes.)
             int active = 1;
             {
                 Timer t(I, st, "k_stop_rule");
@@ -516,10 +545,13 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                     HIP_CHECK(hipStreamSynchronize(st));
                 }
             }
-            if (lookahead) HIP_CHECK(hipEventRecord(slot.ev_rest[m], st));
+            last_m = m;
             if (active == 0) break;
         }
         b.rec = rec_buf[0];
+        b.dinv = dinv_buf[0];
+        b.xsol = xsol_buf[0];
+        if (pipe && last_m >= 0) HIP_CHECK(hipStreamWaitEvent(st, slot.ev_rest[last_m], 0));  // the whole adjoint stage is in order on sC
         if (derivs) {
             Timer t(I, st, "k4a_chain");
             hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, s);
