@@ -571,12 +571,14 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
     Impl& I = *impl_;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const auto& t = I.tab;
-    // Launch shape (measured on MI355X, C2): two or more blocks of wavelengths in flight on their own streams beat one large
-    // block (10 000 wavelengths: 3 x 3334 -> 215 ms, 2 x 5000 -> 217, 6 x 1667 -> 227, 1 x 10 000 -> 235; 5 000: 3 x 1667 -> 113,
-    // 1 x 5000 -> 135; 2 500: 2 x 1250 -> 64, 1 x 2500 -> 71; below ~2 000 a single block is best).
-    int nslots = (nwavel < 2000) ? 1 : std::max(2, std::min(6, (nwavel + 1667) / 3334));
+    // Launch shape (measured on MI355X, C2, with the three-stage order pipeline of run_chunk): one block of up to 10 000
+    // wavelengths per stream set, at most two blocks in flight (10 000 wavelengths: 1 x 10 000 -> 212 ms, 3 x 3334 without the
+    // pipeline -> 216, 2 x 5000 -> 225; 5 000: 1 x 5000 -> 114, 2 x 2500 -> 115; 2 500: 60 vs 62; 20 000: 2 x 10 000 -> 427, 4 x 5000 -> 447).
+    // Scratch is ~1.55 MB per wavelength, i.e. 15.5 GB per block of 10 000.
+    const int chunk_cap = 10000;
+    int nslots = std::max(1, std::min(2, (nwavel + chunk_cap - 1) / chunk_cap));
     if (const char* e = std::getenv("SASKTRAN2_AMD_STREAMS")) nslots = std::max(1, atoi(e));
-    int chunk = std::min(4096, (nwavel + nslots - 1) / nslots);
+    int chunk = std::min(chunk_cap, (nwavel + nslots - 1) / nslots);
     if (max_chunk > 0) chunk = std::min(chunk, max_chunk);
     if (const char* e = std::getenv("SASKTRAN2_AMD_CHUNK")) chunk = std::max(1, atoi(e));
     chunk = std::max(1, std::min(chunk, nwavel));
