@@ -74,11 +74,48 @@ struct OutputC {
     std::map<std::string, D> derivs, surface_derivs;
     std::vector<double> los_od;
 };
+// grow-only device staging buffers of the host entry point (kept between calls: no hipMalloc / hipFree per spectrum)
+struct DeviceCache {
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    std::map<std::string, Buf> bufs;
+    void* get(const char* name, size_t bytes) {
+        Buf& b = bufs[name];
+        if (bytes > b.cap) {
+            if (b.p) (void)hipFree(b.p);
+            b.p = nullptr;
+            b.cap = 0;
+            if (hipMalloc(&b.p, std::max<size_t>(bytes, 8)) != hipSuccess) throw std::runtime_error(std::string("hipMalloc failed for ") + name);
+            b.cap = bytes;
+        }
+        return b.p;
+    }
+    ~DeviceCache() { for (auto& kv : bufs) if (kv.second.p) (void)hipFree(kv.second.p); }
+};
 struct Engine {
     Config config;
     std::unique_ptr<skdev::DeviceEngine> dev;
     int nlos = 0, ngrid = 0;
+    DeviceCache cache;
 };
+
+// user weighting function = d_ssa (x) dI/d(ssa) + d_extinction (x) dI/dk  (OutputC::assign_lane, cpp/lib/output/outputc.cpp:38-236),
+// evaluated on the device in the output layout [nderiv][wavel][los]; the mapping factors are [wavel][location]
+__global__ void __launch_bounds__(256) kern_map_wf(const double* we, const double* ws, const double* f_ssa, const double* f_ext,
+                                                   double* dst, int ngrid, int nw, int nlos) {
+    const size_t n = size_t(ngrid) * nw * nlos;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const size_t qw = i / nlos;
+        const int q = int(qw / nw), w = int(qw % nw);
+        dst[i] = f_ssa[size_t(w) * ngrid + q] * ws[i] + f_ext[size_t(w) * ngrid + q] * we[i];
+    }
+}
+__global__ void __launch_bounds__(256) kern_transpose_od(const double* od, double* out, int nw, int nlos) {
+    const size_t n = size_t(nw) * nlos;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const int l = int(i / nw), w = int(i % nw);   // reference layout: column-major [wavel, los]
+        out[i] = od[size_t(w) * nlos + l];
+    }
+}
 
 extern "C" {
 
@@ -283,67 +320,66 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");
         const int derivs = atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty());
         const size_t nloc_w = size_t(ngrid) * nw, nt = size_t(nw) * nlos;
-        double *d_ext, *d_ssa, *d_leg, *d_alb, *d_irr = nullptr, *d_rad, *d_we = nullptr, *d_ws = nullptr, *d_wa = nullptr, *d_od;
-        int* d_status;
-        std::vector<void*> frees;
-        auto dalloc = [&](size_t bytes) { void* p; HIPC(hipMalloc(&p, bytes)); frees.push_back(p); return p; };
-        struct Guard { std::vector<void*>& f; ~Guard() { for (void* p : f) (void)hipFree(p); } } guard{frees};
-        d_ext = (double*)dalloc(nloc_w * 8); d_ssa = (double*)dalloc(nloc_w * 8); d_leg = (double*)dalloc(nloc_w * st.nleg * 8);
-        d_alb = (double*)dalloc(size_t(nw) * 8); d_rad = (double*)dalloc(nt * 8); d_od = (double*)dalloc(nt * 8);
-        d_status = (int*)dalloc(size_t(nw) * 4);
+        DeviceCache& C = e->cache;
+        double* d_ext = (double*)C.get("ext", nloc_w * 8);
+        double* d_ssa = (double*)C.get("ssa", nloc_w * 8);
+        double* d_leg = (double*)C.get("leg", nloc_w * st.nleg * 8);
+        double* d_alb = (double*)C.get("albedo", size_t(nw) * 8);
+        double* d_rad = (double*)C.get("radiance", nt * 8);
+        double* d_od = (double*)C.get("los_od", nt * 8);
+        double* d_odt = (double*)C.get("los_od_t", nt * 8);
+        int* d_status = (int*)C.get("status", size_t(nw) * 4);
+        double *d_irr = nullptr, *d_we = nullptr, *d_ws = nullptr, *d_wa = nullptr;
         HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyHostToDevice));
         if (st.irradiance) {
-            d_irr = (double*)dalloc(size_t(nw) * 8);
+            d_irr = (double*)C.get("irradiance", size_t(nw) * 8);
             HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyHostToDevice));
         }
         if (derivs) {
-            d_we = (double*)dalloc(size_t(ngrid) * nt * 8);
-            d_ws = (double*)dalloc(size_t(ngrid) * nt * 8);
-            d_wa = (double*)dalloc(nt * 8);
+            d_we = (double*)C.get("wf_ext", size_t(ngrid) * nt * 8);
+            d_ws = (double*)C.get("wf_ssa", size_t(ngrid) * nt * 8);
+            d_wa = (double*)C.get("wf_alb", nt * 8);
         }
         e->dev->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status,
                              nullptr, 0);
+        hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
+        HIPC(hipGetLastError());
         HIPC(hipDeviceSynchronize());
-        HIPC(hipMemcpy(out->radiance, d_rad, nt * 8, hipMemcpyDeviceToHost));
         std::vector<int> status(nw);
         HIPC(hipMemcpy(status.data(), d_status, size_t(nw) * 4, hipMemcpyDeviceToHost));
         for (int w = 0; w < nw; ++w)
             if (status[w] != 0) throw std::runtime_error("solver failure (status bits " + std::to_string(status[w]) + ") at wavelength " + std::to_string(w));
-        // LOS optical depth, reference layout column-major [wavel, los]
-        {
-            std::vector<double> od(nt);
-            HIPC(hipMemcpy(od.data(), d_od, nt * 8, hipMemcpyDeviceToHost));
-            out->los_od.resize(nt);
-            for (int w = 0; w < nw; ++w)
-                for (int l = 0; l < nlos; ++l) out->los_od[size_t(l) * nw + w] = od[size_t(w) * nlos + l];
-        }
+        HIPC(hipMemcpy(out->radiance, d_rad, nt * 8, hipMemcpyDeviceToHost));
+        out->los_od.resize(nt);
+        HIPC(hipMemcpy(out->los_od.data(), d_odt, nt * 8, hipMemcpyDeviceToHost));
         if (derivs) {
-            std::vector<double> we(size_t(ngrid) * nt), ws(size_t(ngrid) * nt), wa(nt);
-            HIPC(hipMemcpy(we.data(), d_we, we.size() * 8, hipMemcpyDeviceToHost));
-            HIPC(hipMemcpy(ws.data(), d_ws, ws.size() * 8, hipMemcpyDeviceToHost));
-            HIPC(hipMemcpy(wa.data(), d_wa, wa.size() * 8, hipMemcpyDeviceToHost));
+            double* d_fs = (double*)C.get("map_d_ssa", nloc_w * 8);
+            double* d_fk = (double*)C.get("map_d_extinction", nloc_w * 8);
+            double* d_dst = (double*)C.get("wf_user", size_t(ngrid) * nt * 8);
             for (auto& kv : out->derivs) {
                 auto it = st.maps.find(kv.first);
                 if (it == st.maps.end()) throw std::runtime_error("no derivative mapping named " + kv.first);
                 const DerivativeMapping& m = *it->second;
                 if (kv.second.nderiv != ngrid || kv.second.nrad != nw * nlos) throw std::runtime_error("derivative memory size mismatch for " + kv.first);
-                double* dst = kv.second.mem;  // C order [nderiv][wavel][los]
-                for (int q = 0; q < ngrid; ++q)
-                    for (int w = 0; w < nw; ++w) {
-                        const double fs = m.d_ssa[size_t(w) * ngrid + q], fk = m.d_extinction[size_t(w) * ngrid + q];
-                        const size_t o = (size_t(q) * nw + w) * nlos;
-                        for (int l = 0; l < nlos; ++l) dst[o + l] = fs * ws[o + l] + fk * we[o + l];
-                    }
+                HIPC(hipMemcpy(d_fs, m.d_ssa.data(), nloc_w * 8, hipMemcpyHostToDevice));
+                HIPC(hipMemcpy(d_fk, m.d_extinction.data(), nloc_w * 8, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(kern_map_wf, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_dst, ngrid, nw, nlos);
+                HIPC(hipGetLastError());
+                HIPC(hipMemcpy(kv.second.mem, d_dst, size_t(ngrid) * nt * 8, hipMemcpyDeviceToHost));  // C order [nderiv][wavel][los]
             }
-            for (auto& kv : out->surface_derivs) {
-                auto it = su.maps.find(kv.first);
-                if (it == su.maps.end()) throw std::runtime_error("no surface derivative mapping named " + kv.first);
-                const SurfaceDerivativeMapping& m = *it->second;
-                for (int w = 0; w < nw; ++w)
-                    for (int l = 0; l < nlos; ++l) kv.second.mem[size_t(w) * nlos + l] = wa[size_t(w) * nlos + l] * m.d_brdf[w];
+            if (!out->surface_derivs.empty()) {
+                std::vector<double> wa(nt);
+                HIPC(hipMemcpy(wa.data(), d_wa, nt * 8, hipMemcpyDeviceToHost));
+                for (auto& kv : out->surface_derivs) {
+                    auto it = su.maps.find(kv.first);
+                    if (it == su.maps.end()) throw std::runtime_error("no surface derivative mapping named " + kv.first);
+                    const SurfaceDerivativeMapping& m = *it->second;
+                    for (int w = 0; w < nw; ++w)
+                        for (int l = 0; l < nlos; ++l) kv.second.mem[size_t(w) * nlos + l] = wa[size_t(w) * nlos + l] * m.d_brdf[w];
+                }
             }
         }
         return 0;
