@@ -213,9 +213,23 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
                         const double apq = Acur[pp * N + qq], app = Acur[pp * N + pp], aqq = Acur[qq * N + qq];
                         double c = 1.0, sn = 0.0;
                         if (apq != 0.0) {
-                            const double theta = (aqq - app) / (2.0 * apq);
-                            const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                            c = 1.0 / sqrt(tt * tt + 1.0);
+                            // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without the
+                            // division by apq:  t = sgn(d) h / (|d| + sqrt(d^2 + h^2)),  d = aqq - app, h = 2 apq;  c = 1 / sqrt(1 + t^2).
+                            // Reciprocal square roots / reciprocals: hardware estimate + two Newton steps (full double precision).
+                            const double d = aqq - app, h = 2.0 * apq, x = d * d + h * h;
+                            double y = __builtin_amdgcn_rsq(x);
+                            y = y * fma(-0.5 * x * y, y, 1.5);
+                            y = y * fma(-0.5 * x * y, y, 1.5);
+                            const double den = fabs(d) + x * y;
+                            double id = __builtin_amdgcn_rcp(den);
+                            id = fma(fma(-den, id, 1.0), id, id);
+                            id = fma(fma(-den, id, 1.0), id, id);
+                            const double tt = ((d >= 0) ? h : -h) * id;
+                            const double x2 = fma(tt, tt, 1.0);
+                            double y2 = __builtin_amdgcn_rsq(x2);
+                            y2 = y2 * fma(-0.5 * x2 * y2, y2, 1.5);
+                            y2 = y2 * fma(-0.5 * x2 * y2, y2, 1.5);
+                            c = y2;
                             sn = tt * c;
                         }
                         vAl[pp] = c; vBe[pp] = -sn; vPartner[pp] = qq;
