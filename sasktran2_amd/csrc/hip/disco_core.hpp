@@ -284,7 +284,7 @@ template <int N> SKD_HD bool jacobi_eigen(double* A, double* lam, double* V) {
             dia += A[i * N + i] * A[i * N + i];
             for (int j = i + 1; j < N; ++j) off += A[i * N + j] * A[i * N + j];
         }
-        if (off <= 1e-34 * dia || off == 0) {
+        if (off <= 1e-30 * dia || off == 0) {  // off-diagonal norm at the rounding level of the rotations
             for (int i = 0; i < N; ++i) lam[i] = A[i * N + i];
             return true;
         }

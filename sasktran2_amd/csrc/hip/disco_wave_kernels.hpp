@@ -11,6 +11,11 @@
 #include "disco_core.hpp"
 
 // minimum waves per SIMD requested from the register allocator (second __launch_bounds__ argument)
+// Jacobi stops when sum(off-diagonal^2) <= tol * sum(diagonal^2): 1e-30 is an off-diagonal norm of 1e-15 of the diagonal,
+// i.e. the rounding level of the rotations themselves (a tighter test only buys sweeps that change nothing)
+#ifndef SKD_JACOBI_TOL
+#define SKD_JACOBI_TOL 1e-30
+#endif
 #ifndef SKD_EXP_MAXSWEEP
 #define SKD_EXP_MAXSWEEP 60
 #endif
@@ -201,7 +206,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
                     off += __shfl_xor(off, o, LG);
                     dia += __shfl_xor(dia, o, LG);
                 }
-                const bool conv = (off <= 1e-34 * dia) || (off == 0);
+                const bool conv = (off <= SKD_JACOBI_TOL * dia) || (off == 0);
                 if (__all(conv)) { jac_ok = true; break; }
                 for (int round = 0; round < N - 1; ++round) {
                     // pairs of this round: (N-1, round) and ((round + k) mod (N-1), (round - k) mod (N-1)), k = 1 .. N/2-1
