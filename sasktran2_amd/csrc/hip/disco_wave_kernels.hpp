@@ -110,7 +110,6 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
     double* vCoef = vC;      // 10 N doubles: rows 12..16 of sVec
     double* vAl = vQp;       // rotation parameters of the Jacobi rounds (the Q / A rows are written later)
     double* vBe = vQm;
-    double* vPartner = vAp;
     const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * skd::kPi);
     __syncthreads();
 
@@ -237,13 +236,15 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
                             c = y2;
                             sn = tt * c;
                         }
-                        vAl[pp] = c; vBe[pp] = -sn; vPartner[pp] = qq;
-                        vAl[qq] = c; vBe[qq] = sn; vPartner[qq] = pp;
+                        vAl[pp] = c; vBe[pp] = -sn;
+                        vAl[qq] = c; vBe[qq] = sn;
                     }
                     __syncthreads();
                     for (int e = gl; e < NN; e += LG) {
                         const int i = e / N, j = e % N;
-                        const int ip = (int)vPartner[i], jp = (int)vPartner[j];
+                        // partner of index x in this round: N-1 <-> round, otherwise (2 round - x) mod (N-1)
+                        auto partner = [&](int x) { return (x == N - 1) ? round : ((x == round) ? N - 1 : (2 * round + 2 * NM1 - x) % NM1); };
+                        const int ip = partner(i), jp = partner(j);
                         const double ai = vAl[i], bi = vBe[i], aj = vAl[j], bj = vBe[j];
                         double v;
                         if (jp == i) v = 0.0;  // the rotated pair's off-diagonal element is annihilated exactly
