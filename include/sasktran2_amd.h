@@ -18,6 +18,8 @@
 #ifndef SASKTRAN2_AMD_H
 #define SASKTRAN2_AMD_H
 
+#include <stdint.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -136,6 +138,193 @@ int sk_amd_engine_reset_profile(Engine* engine);
 int sk_amd_engine_kernel_time(Engine* engine, const char* kernel_name, double* total_ms, long* launches);
 int sk_amd_engine_kernel_names(Engine* engine, char* buffer, int buffer_len);
 const char* sk_amd_last_error(void);
+
+/* =====================================================================================================================
+ * Rest of the reference's C API (the headers under cpp/include/c_api): every symbol its FFI links against is exported, so replacing
+ * libcsasktran2 by this library is a pure link-time choice.  Entry points outside the DISCO hot path keep the
+ * reference's signatures; they store / return their settings where that is all they do, and report "unsupported"
+ * (-2, or a null handle) where they would need an engine this build does not contain (2D geometry, JVP / VJP, flux
+ * observers, geodetic utilities, non-Lambertian BRDFs, delta-M scaling).  Reference line numbers as above.
+ * ===================================================================================================================== */
+typedef struct Geometry2D Geometry2D;
+typedef struct Geodetic Geodetic;
+typedef struct OutputJVP OutputJVP;
+typedef struct OutputVJP OutputVJP;
+
+/* config.h:32-133 -- stored and returned; values other than the defaults are rejected by sk_engine_create when they would
+ * change the DISCO result (refraction, delta scaling, forced azimuth, emission / occultation sources) */
+int sk_config_get_threading_model(Config* config, int* threading_model);                       /* config.h:32 */
+int sk_config_set_threading_model(Config* config, int threading_model);                        /* config.h:33 */
+int sk_config_get_singlescatter_phasemode(Config* config, int* phasemode);                     /* config.h:40 */
+int sk_config_set_singlescatter_phasemode(Config* config, int phasemode);                      /* config.h:41 */
+int sk_config_get_apply_delta_scaling(Config* config, int* apply_delta_scaling);               /* config.h:44 */
+int sk_config_set_apply_delta_scaling(Config* config, int apply_delta_scaling);                /* config.h:45 */
+int sk_config_get_num_do_forced_azimuth(Config* config, int* num_forced_azimuth);              /* config.h:50 */
+int sk_config_set_num_do_forced_azimuth(Config* config, int num_forced_azimuth);               /* config.h:52 */
+int sk_config_get_do_backprop(Config* config, int* do_backprop);                               /* config.h:53 */
+int sk_config_set_do_backprop(Config* config, int do_backprop);                                /* config.h:54 */
+int sk_config_get_num_do_spherical_iterations(Config* config, int* num_iterations);            /* config.h:55 */
+int sk_config_set_num_do_spherical_iterations(Config* config, int num_iterations);             /* config.h:57 */
+int sk_config_get_num_hr_spherical_iterations(Config* config, int* num_iterations);            /* config.h:61 */
+int sk_config_set_num_hr_spherical_iterations(Config* config, int num_iterations);             /* config.h:63 */
+int sk_config_get_num_hr_incoming(Config* config, int* num_incoming);                          /* config.h:65 */
+int sk_config_set_num_hr_incoming(Config* config, int num_incoming);                           /* config.h:66 */
+int sk_config_get_num_hr_outgoing(Config* config, int* num_outgoing);                          /* config.h:67 */
+int sk_config_set_num_hr_outgoing(Config* config, int num_outgoing);                           /* config.h:68 */
+int sk_config_get_num_hr_full_incoming_points(Config* config, int* num_points);                /* config.h:69 */
+int sk_config_set_num_hr_full_incoming_points(Config* config, int num_points);                 /* config.h:70 */
+int sk_config_get_initialize_hr_with_do(Config* config, int* initialize);                      /* config.h:71 */
+int sk_config_set_initialize_hr_with_do(Config* config, int initialize);                       /* config.h:72 */
+int sk_config_get_successive_orders_relative_tolerance(Config* config, double* tolerance);     /* config.h:75 */
+int sk_config_set_successive_orders_relative_tolerance(Config* config, double tolerance);      /* config.h:77 */
+int sk_config_get_successive_orders_absolute_tolerance(Config* config, double* tolerance);     /* config.h:79 */
+int sk_config_set_successive_orders_absolute_tolerance(Config* config, double tolerance);      /* config.h:81 */
+int sk_config_get_successive_orders_anderson_depth(Config* config, int* depth);                /* config.h:83 */
+int sk_config_set_successive_orders_anderson_depth(Config* config, int depth);                 /* config.h:84 */
+int sk_config_get_successive_orders_damping(Config* config, double* damping);                  /* config.h:85 */
+int sk_config_set_successive_orders_damping(Config* config, double damping);                   /* config.h:86 */
+int sk_config_get_num_successive_orders_altitudes(Config* config, int* num_altitudes);         /* config.h:87 */
+int sk_config_get_successive_orders_altitude_grid_m(Config* config, double* altitude_grid_m);  /* config.h:89 */
+int sk_config_set_successive_orders_altitude_grid_m(Config* config, const double* altitude_grid_m, int num_altitudes); /* config.h:91 */
+int sk_config_get_occultation_source(Config* config, int* occultation_source);                 /* config.h:95 */
+int sk_config_set_occultation_source(Config* config, int occultation_source);                  /* config.h:96 */
+int sk_config_get_emission_source(Config* config, int* emission_source);                       /* config.h:97 */
+int sk_config_set_emission_source(Config* config, int emission_source);                        /* config.h:98 */
+int sk_config_get_los_refraction(Config* config, int* refraction);                             /* config.h:101 */
+int sk_config_set_los_refraction(Config* config, int refraction);                              /* config.h:102 */
+int sk_config_get_solar_refraction(Config* config, int* refraction);                           /* config.h:103 */
+int sk_config_set_solar_refraction(Config* config, int refraction);                            /* config.h:104 */
+int sk_config_get_multiple_scatter_refraction(Config* config, int* refraction);                /* config.h:105 */
+int sk_config_set_multiple_scatter_refraction(Config* config, int refraction);                 /* config.h:106 */
+int sk_config_get_wf_precision(Config* config, int* precision);                                /* config.h:111 */
+int sk_config_set_wf_precision(Config* config, int precision);                                 /* config.h:112 */
+int sk_config_get_stokes_basis(Config* config, int* basis);                                    /* config.h:115 */
+int sk_config_set_stokes_basis(Config* config, int basis);                                     /* config.h:116 */
+int sk_config_get_input_validation_mode(Config* config, int* mode);                            /* config.h:119 */
+int sk_config_set_input_validation_mode(Config* config, int mode);                             /* config.h:120 */
+int sk_config_get_log_level(Config* config, int* log_level);                                   /* config.h:127 */
+int sk_config_set_log_level(Config* config, int log_level);                                    /* config.h:128 */
+int sk_config_get_num_flux_types(Config* config, int* num_flux_types);                         /* config.h:131 */
+int sk_config_get_flux_types(Config* config, int* flux_types);                                 /* config.h:132 */
+int sk_config_set_flux_types(Config* config, const int* flux_types, int num_flux_types);       /* config.h:133 */
+
+/* atmosphere.h:111-188 */
+int sk_atmosphere_storage_get_derivative_mapping_by_index(AtmosphereStorage* storage, int index, DerivativeMapping** mapping); /* :111 */
+int sk_atmosphere_storage_finalize_scattering_derivatives(AtmosphereStorage* storage);         /* atmosphere.h:120 */
+int sk_atmosphere_storage_set_zero(AtmosphereStorage* storage);                                /* atmosphere.h:123 */
+int sk_atmosphere_apply_delta_m_scaling(Atmosphere* atmosphere, int order);                    /* atmosphere.h:150: -2 */
+int sk_atmosphere_mark_changed(Atmosphere* atmosphere);                                        /* atmosphere.h:152 */
+int sk_atmosphere_get_revision(Atmosphere* atmosphere, unsigned long long* revision);          /* atmosphere.h:154 */
+int sk_surface_get_num_derivative_mappings(Surface* storage, int* num_mappings);               /* atmosphere.h:183 */
+int sk_surface_get_derivative_mapping_name(Surface* storage, int index, const char** name);    /* atmosphere.h:185 */
+int sk_surface_set_zero(Surface* storage);                                                     /* atmosphere.h:188 */
+
+/* brdf.h:10-14 -- handles can be created; a non-Lambertian BRDF makes sk_engine_calculate_radiance return -2 */
+BRDF* sk_brdf_create_kokhanovsky(int nstokes);                                                 /* brdf.h:10 */
+BRDF* sk_brdf_create_modis(int nstokes);                                                       /* brdf.h:11 */
+int sk_brdf_get_num_deriv(BRDF* config, int* num_deriv);                                       /* brdf.h:13 */
+int sk_brdf_get_num_args(BRDF* config, int* num_args);                                         /* brdf.h:14 */
+
+/* deriv_mapping.h:10-86 -- scattering-group / Legendre / emission derivatives, interpolators, log-radiance space: stored;
+ * a mapping that uses them makes sk_engine_calculate_radiance return -2 */
+int sk_deriv_mapping_destroy(DerivativeMapping* mapping);                                      /* deriv_mapping.h:10 */
+int sk_deriv_mapping_get_scat_factor(DerivativeMapping* mapping, double** scat_factor);        /* deriv_mapping.h:15 */
+int sk_deriv_mapping_get_d_legendre(DerivativeMapping* mapping, double** d_legendre);          /* deriv_mapping.h:17 */
+int sk_deriv_mapping_get_d_emission(DerivativeMapping* mapping, double** d_emission);          /* deriv_mapping.h:19 */
+int sk_deriv_mapping_get_scat_deriv_index(DerivativeMapping* mapping, int* scat_deriv_index);  /* deriv_mapping.h:21 */
+int sk_deriv_mapping_set_scat_deriv_index(DerivativeMapping* mapping, int scat_deriv_index);   /* deriv_mapping.h:23 */
+int sk_deriv_mapping_get_num_legendre(DerivativeMapping* mapping, int* num_legendre);          /* deriv_mapping.h:29 */
+int sk_deriv_mapping_set_interp_dim(DerivativeMapping* mapping, const char* name);             /* deriv_mapping.h:32 */
+int sk_deriv_mapping_set_assign_name(DerivativeMapping* mapping, const char* name);            /* deriv_mapping.h:34 */
+int sk_deriv_mapping_set_log_radiance_space(DerivativeMapping* mapping, int log_radiance_space); /* deriv_mapping.h:36 */
+int sk_deriv_mapping_get_log_radiance_space(DerivativeMapping* mapping, int* log_radiance_space); /* deriv_mapping.h:38 */
+int sk_deriv_mapping_is_scattering_derivative(DerivativeMapping* mapping, int* is_scattering_derivative); /* deriv_mapping.h:40 */
+int sk_deriv_mapping_get_assign_name(DerivativeMapping* mapping, const char** name);           /* deriv_mapping.h:46 */
+int sk_deriv_mapping_get_interp_dim(DerivativeMapping* mapping, const char** name);            /* deriv_mapping.h:48 */
+int sk_deriv_mapping_set_interpolator(DerivativeMapping* mapping, double* interpolator, int dim1, int dim2); /* deriv_mapping.h:50 */
+int sk_deriv_mapping_clear_interpolator(DerivativeMapping* mapping);                           /* deriv_mapping.h:52 */
+int sk_deriv_mapping_get_interpolator(DerivativeMapping* mapping, double** interpolator, int* dim1, int* dim2); /* deriv_mapping.h:53 */
+int sk_surface_deriv_mapping_get_d_emission(SurfaceDerivativeMapping* mapping, double** emission); /* deriv_mapping.h:58 */
+int sk_surface_deriv_mapping_get_num_wavel(SurfaceDerivativeMapping* mapping, int* num_wavel); /* deriv_mapping.h:61 */
+int sk_surface_deriv_mapping_get_num_brdf_args(SurfaceDerivativeMapping* mapping, int* num_brdf_args); /* deriv_mapping.h:64 */
+int sk_surface_deriv_mapping_get_interpolator(SurfaceDerivativeMapping* mapping, double** interpolator, int* dim1, int* dim2); /* :70 */
+int sk_surface_deriv_mapping_set_interpolator(SurfaceDerivativeMapping* mapping, double* interpolator, int dim1, int dim2); /* :74 */
+int sk_surface_deriv_mapping_get_interp_dim(SurfaceDerivativeMapping* mapping, const char** name); /* deriv_mapping.h:78 */
+int sk_surface_deriv_mapping_set_interp_dim(SurfaceDerivativeMapping* mapping, const char* name);  /* deriv_mapping.h:81 */
+int sk_surface_deriv_mapping_set_zero(SurfaceDerivativeMapping* mapping);                      /* deriv_mapping.h:84 */
+int sk_surface_deriv_mapping_destroy(SurfaceDerivativeMapping* mapping);                       /* deriv_mapping.h:86 */
+
+/* engine.h:20-39 -- the weighting functions of this build are the Jacobian mode; JVP / VJP entry points return -2 */
+Engine* sk_engine_create_2d(Config* engine, Geometry2D* geometry, ViewingGeometry* viewing_geometry); /* engine.h:20: NULL */
+int sk_engine_supports_linearization(Engine* engine, int mode, int* supported);                /* engine.h:27 */
+int sk_engine_linearization_backend(Engine* engine, int mode, int* backend);                   /* engine.h:28 */
+int sk_engine_calculate_jvp(Engine* engine, Atmosphere* atmosphere, OutputJVP* output);        /* engine.h:29 */
+int sk_engine_initialize_jvp(Engine* engine, Atmosphere* atmosphere, OutputJVP* output);       /* engine.h:31 */
+int sk_engine_calculate_jvp_wavelength_thread(Engine* engine, OutputJVP* output, int wavelength, int thread_idx); /* engine.h:33 */
+int sk_engine_calculate_vjp(Engine* engine, Atmosphere* atmosphere, OutputVJP* output);        /* engine.h:35 */
+int sk_engine_initialize_vjp(Engine* engine, Atmosphere* atmosphere, OutputVJP* output);       /* engine.h:37 */
+int sk_engine_calculate_vjp_block_thread(Engine* engine, OutputVJP* output, int wavelength_start, int wavelength_count, int thread_idx); /* :39 */
+
+/* geodetic.h:9-55 -- utility class outside the solver: a handle can be created, every query returns -2 */
+Geodetic* sk_geodetic_create(double equatorial_radius, double flattening_factor);             /* geodetic.h:9 */
+void sk_geodetic_destroy(Geodetic* geodetic);                                                  /* geodetic.h:12 */
+int sk_geodetic_get_altitude(const Geodetic* geodetic, double* altitude);                      /* geodetic.h:14 */
+int sk_geodetic_get_latitude(const Geodetic* geodetic, double* latitude);                      /* geodetic.h:15 */
+int sk_geodetic_get_longitude(const Geodetic* geodetic, double* longitude);                    /* geodetic.h:16 */
+int sk_geodetic_get_location(const Geodetic* geodetic, double* x, double* y, double* z);       /* geodetic.h:17 */
+int sk_geodetic_get_local_south(const Geodetic* geodetic, double* x, double* y, double* z);    /* geodetic.h:20 */
+int sk_geodetic_get_local_up(const Geodetic* geodetic, double* x, double* y, double* z);       /* geodetic.h:23 */
+int sk_geodetic_get_local_west(const Geodetic* geodetic, double* x, double* y, double* z);     /* geodetic.h:26 */
+int sk_geodetic_get_altitude_intercepts(const Geodetic* geodetic, double altitude, double observer_x, double observer_y,
+                                        double observer_z, double look_vector_x, double look_vector_y, double look_vector_z,
+                                        double* x1, double* y1, double* z1, double* x2, double* y2, double* z2); /* geodetic.h:29 */
+int sk_geodetic_from_lat_lon_altitude(const Geodetic* geodetic, double latitude, double longitude, double altitude); /* geodetic.h:34 */
+int sk_geodetic_from_tangent_altitude(const Geodetic* geodetic, double altitude, double observer_x, double observer_y,
+                                      double observer_z, double boresight_x, double boresight_y, double boresight_z,
+                                      double* look_vector_x, double* look_vector_y, double* look_vector_z); /* geodetic.h:37 */
+int sk_geodetic_from_tangent_point(const Geodetic* geodetic, double observer_x, double observer_y, double observer_z,
+                                   double look_vector_x, double look_vector_y, double look_vector_z); /* geodetic.h:45 */
+int sk_geodetic_from_xyz(const Geodetic* geodetic, double x, double y, double z);              /* geodetic.h:50 */
+int sk_geodetic_is_valid(const Geodetic* geodetic, int* is_valid);                             /* geodetic.h:53 */
+int sk_geodetic_get_osculating_spheroid(const Geodetic* geodetic, double* radius, double* offset_x, double* offset_y, double* offset_z); /* :55 */
+
+/* geometry.h:21-47 -- no refraction, no 2D geometry in this build */
+int sk_geometry1d_get_refractive_index_ptr(const Geometry1D* geometry, double** refractive_index); /* geometry.h:21 */
+Geometry2D* sk_geometry2d_create(double cos_sza, double saa, double earth_radius, const double* altitude_grid_values, int num_altitudes,
+                                 const double* horizontal_angle_grid_values, int num_horizontal_locations,
+                                 int altitude_interp_method);                                   /* geometry.h:25: NULL */
+void sk_geometry2d_destroy(Geometry2D* geometry);                                              /* geometry.h:30 */
+int sk_geometry2d_get_location_shape(const Geometry2D* geometry, int* num_horizontal_locations, int* num_altitudes); /* geometry.h:32 */
+int sk_geometry2d_get_altitudes(const Geometry2D* geometry, double* altitudes);                /* geometry.h:36 */
+int sk_geometry2d_get_horizontal_angles(const Geometry2D* geometry, double* horizontal_angles); /* geometry.h:38 */
+int sk_geometry2d_get_refractive_index_ptr(const Geometry2D* geometry, const double** refractive_index); /* geometry.h:41 */
+int sk_geometry2d_get_refractive_index_mut_ptr(Geometry2D* geometry, double** refractive_index); /* geometry.h:44 */
+int sk_geometry2d_get_location_index(const Geometry2D* geometry, int altitude_index, int horizontal_index, int* location_index); /* :47 */
+
+/* output.h:24-51 */
+int sk_output_assign_flux_derivative_memory(OutputC* output, const char* name, double* derivative_mapping, int nrad, int nderiv); /* :24 */
+int sk_output_assign_surface_flux_derivative_memory(OutputC* output, const char* name, double* derivative_mapping, int nrad); /* :28 */
+OutputJVP* sk_output_jvp_create(double* radiance, double* jvp, int nrad, int nstokes);         /* output.h:35 */
+void sk_output_jvp_destroy(OutputJVP* output);                                                 /* output.h:37 */
+int sk_output_jvp_assign_derivative_tangent(OutputJVP* output, const char* name, const double* tangent, int nparam); /* output.h:38 */
+int sk_output_jvp_assign_surface_tangent(OutputJVP* output, const char* name, const double* tangent, int nparam); /* output.h:40 */
+OutputVJP* sk_output_vjp_create(double* radiance, const double* cotangent, int nrad, int nstokes); /* output.h:43 */
+void sk_output_vjp_destroy(OutputVJP* output);                                                 /* output.h:45 */
+int sk_output_vjp_assign_derivative_gradient(OutputVJP* output, const char* name, double* gradient, int nparam); /* output.h:46 */
+int sk_output_vjp_assign_surface_gradient(OutputVJP* output, const char* name, double* gradient, int nparam); /* output.h:49 */
+int sk_output_vjp_finalize(OutputVJP* output);                                                 /* output.h:51 */
+
+/* sk_lapack.h:18 -- dense A X = B with partial pivoting, LAPACK dgesv conventions (column major, 1-based ipiv, info) */
+int64_t sk_lapack_dgesv(int64_t n, int64_t nrhs, double* a, int64_t lda, int64_t* ipiv, double* b, int64_t ldb);
+
+/* viewing_geometry.h:23-38 -- ray kinds this build cannot trace return -2 */
+int sk_viewing_geometry_add_tangent_altitude(ViewingGeometry* geometry, double tangent_altitude_m, double observer_altitude_m,
+                                             double horizontal_angle_radians, double viewing_azimuth_radians); /* viewing_geometry.h:23 */
+int sk_viewing_geometry_add_solar_angles_observer_location(ViewingGeometry* geometry, double cos_sza, double relative_azimuth_angle,
+                                                           double cos_viewing_zenith, double observeraltitude); /* viewing_geometry.h:29 */
+int sk_viewing_geometry_add_flux_observer_solar(ViewingGeometry* geometry, double cos_sza, double observeraltitude); /* viewing_geometry.h:33 */
+int sk_viewing_geometry_num_flux_observers(ViewingGeometry* geometry, int* num_observers);     /* viewing_geometry.h:38 */
+
 
 #ifdef __cplusplus
 }

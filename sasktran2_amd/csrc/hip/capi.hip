@@ -3,6 +3,9 @@
 // (reference: OutputC::assign_lane, cpp/lib/output/outputc.cpp:38-236).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -29,6 +32,16 @@ void set_error(const std::string& e) {
 struct Config {
     int num_stokes = 1, ms_source = 3 /* none */, ss_source = 0 /* exact */, num_streams = 16, num_threads = 1,
         batch = 1, nmoments = 16, num_sza = 1, wf_enabled = 1, los_od = 0;
+    // settings of the reference's Config that this path only stores (defaults: cpp/lib/config/config.cpp:5-32)
+    int threading_model = 0, singlescatter_phasemode = 0, apply_delta_scaling = 0, num_do_forced_azimuth = -1, do_backprop = 0,
+        num_do_spherical_iterations = 0, num_hr_spherical_iterations = 50, num_hr_incoming = 110, num_hr_outgoing = 110,
+        num_hr_full_incoming_points = -1, initialize_hr_with_do = 0, successive_orders_anderson_depth = 3,
+        occultation_source = 1 /* none */, emission_source = 1 /* none */, los_refraction = 0, solar_refraction = 0,
+        multiple_scatter_refraction = 0, wf_precision = 0, stokes_basis = 0, input_validation_mode = 0, log_level = 3 /* warn */;
+    double successive_orders_relative_tolerance = 1.0e-6, successive_orders_absolute_tolerance = 1.0e-12,
+           successive_orders_damping = 1.0;
+    std::vector<double> successive_orders_altitude_grid_m;
+    std::vector<int> flux_types{0, 1};  // upwelling, downwelling
 };
 struct Geometry1D {
     double cos_sza, saa, earth_radius;
@@ -39,12 +52,21 @@ struct ViewingGeometry {
     std::vector<skgeo::RaySpec> rays;
 };
 struct DerivativeMapping {
-    int nloc = 0, nwavel = 0;
+    int nloc = 0, nwavel = 0, nleg = 0;
     std::vector<double> d_ssa, d_extinction;
+    // stored only (deriv_mapping.h:15-53); a mapping that uses them is refused by sk_engine_calculate_radiance
+    std::vector<double> scat_factor, d_legendre, d_emission;
+    int scat_deriv_index = -1, log_radiance_space = 0;
+    std::string interp_dim = "altitude", assign_name;
+    double* interpolator = nullptr;
+    int interp_dim1 = 0, interp_dim2 = 0;
 };
 struct SurfaceDerivativeMapping {
-    int nwavel = 0;
-    std::vector<double> d_brdf;
+    int nwavel = 0, num_brdf_args = 1;
+    std::vector<double> d_brdf, d_emission;
+    std::string interp_dim = "dummy";
+    double* interpolator = nullptr;
+    int interp_dim1 = 0, interp_dim2 = 0;
 };
 struct AtmosphereStorage {
     int nloc, nwavel, nleg, nstokes;
@@ -66,12 +88,17 @@ struct Atmosphere {
     AtmosphereStorage* storage;
     Surface* surface;
     int derivs;
+    unsigned long long revision = 0;
 };
+struct Geometry2D { int unused; };
+struct Geodetic { double equatorial_radius, flattening; };
+struct OutputJVP { double* radiance; double* jvp; int nrad, nstokes; std::map<std::string, std::pair<const double*, int>> tangents, surface_tangents; };
+struct OutputVJP { double* radiance; const double* cotangent; int nrad, nstokes; std::map<std::string, std::pair<double*, int>> gradients, surface_gradients; };
 struct OutputC {
     double* radiance;
     int nrad, nstokes;
     struct D { double* mem; int nrad, nstokes, nderiv; };
-    std::map<std::string, D> derivs, surface_derivs;
+    std::map<std::string, D> derivs, surface_derivs, flux_derivs, surface_flux_derivs;
     std::vector<double> los_od;
 };
 // grow-only device staging buffers of the host entry point (kept between calls: no hipMalloc / hipFree per spectrum)
@@ -200,6 +227,11 @@ int sk_atmosphere_storage_get_derivative_mapping(AtmosphereStorage* s, const cha
         dm->nwavel = s->nwavel;
         dm->d_ssa.assign(size_t(s->nloc) * s->nwavel, 0.0);
         dm->d_extinction.assign(size_t(s->nloc) * s->nwavel, 0.0);
+        dm->nleg = s->nleg;
+        dm->scat_factor.assign(size_t(s->nloc) * s->nwavel, 0.0);
+        dm->d_emission.assign(size_t(s->nloc) * s->nwavel, 0.0);
+        dm->d_legendre.assign(size_t(s->nleg) * s->nloc * s->nwavel, 0.0);
+        dm->assign_name = name;
         it = s->maps.emplace(name, std::move(dm)).first;
         s->names.push_back(name);
     }
@@ -244,6 +276,7 @@ int sk_surface_get_derivative_mapping(Surface* s, const char* name, SurfaceDeriv
         auto dm = std::make_unique<SurfaceDerivativeMapping>();
         dm->nwavel = s->nwavel;
         dm->d_brdf.assign(s->nwavel, 0.0);
+        dm->d_emission.assign(s->nwavel, 0.0);
         it = s->maps.emplace(name, std::move(dm)).first;
     }
     *m = it->second.get();
@@ -284,6 +317,11 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
         if (c->ms_source != 0) throw std::runtime_error("multiple_scatter_source must be discrete_ordinates (0)");
         if (c->ss_source != 2 && c->ss_source != 3)
             throw std::runtime_error("single_scatter_source must be discrete_ordinates (2) or none (3)");
+        if (c->apply_delta_scaling || c->los_refraction || c->solar_refraction || c->multiple_scatter_refraction ||
+            c->num_do_forced_azimuth >= 0 || c->num_do_spherical_iterations > 0 || c->emission_source != 1 || c->occultation_source != 1 ||
+            c->do_backprop)
+            throw std::runtime_error("delta scaling, refraction, forced azimuth count, DO spherical iterations, backprop, emission and "
+                                     "occultation sources are not part of this build");
         skgeo::Geometry1D geo(g->cos_sza, g->saa, g->earth_radius, g->grid, (skgeo::Interpolation)g->interp,
                               (skgeo::GeometryType)g->geotype);
         skgeo::DiscoGeometry dg;
@@ -316,6 +354,18 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (st.nstokes != 1 || out->nstokes != 1) return -2;
         if (st.nloc != e->ngrid) throw std::runtime_error("atmosphere grid does not match the engine geometry");
         if (!su.brdf_args) throw std::runtime_error("surface has no BRDF set");
+        if (su.brdf && su.brdf->kind != 0) return -2;  // only the Lambertian surface is part of this path
+        for (auto& kv : out->derivs) {
+            auto it = st.maps.find(kv.first);
+            if (it == st.maps.end()) continue;
+            const DerivativeMapping& dm = *it->second;
+            bool uses_extra = dm.interpolator != nullptr || dm.scat_deriv_index >= 0 || dm.log_radiance_space != 0;
+            for (double v : dm.d_legendre) uses_extra = uses_extra || (v != 0.0);
+            for (double v : dm.scat_factor) uses_extra = uses_extra || (v != 0.0);
+            for (double v : dm.d_emission) uses_extra = uses_extra || (v != 0.0);
+            if (uses_extra) return -2;  // scattering-group / Legendre / emission derivatives, interpolators, log space
+        }
+        if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
         const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
         if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");
         const int derivs = atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty());
@@ -428,5 +478,7 @@ int sk_amd_engine_kernel_names(Engine* e, char* buf, int len) {
     std::snprintf(buf, len, "%s", s.c_str());
     return 0;
 }
+
+#include "capi_rest.inc"
 
 }  // extern "C"
