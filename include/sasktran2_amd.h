@@ -129,6 +129,9 @@ int sk_amd_engine_solve_device(Engine* engine, int nwavel, int nleg, const doubl
                                const double* d_leg, const double* d_albedo, const double* d_irradiance, int derivatives,
                                double* d_radiance, double* d_wf_ext, double* d_wf_ssa, double* d_wf_albedo,
                                double* d_los_od, int* d_status, void* stream, int max_chunk);
+/* delta-M truncation fraction of already scaled optical properties, DEVICE pointer [nwavel][nlocation] or NULL, for the
+ * following sk_amd_engine_solve_device calls (the host entry point does this itself after sk_atmosphere_apply_delta_m_scaling) */
+int sk_amd_engine_set_delta_m_fraction(Engine* engine, const double* d_f);
 int sk_amd_engine_num_los(Engine* engine, int* nlos);
 int sk_amd_engine_scratch_bytes(Engine* engine, int nwavel, unsigned long long* bytes);
 /* shape of the last solve: wavelengths per kernel launch, blocks in flight (streams), scratch bytes allocated */
@@ -144,7 +147,7 @@ const char* sk_amd_last_error(void);
  * libcsasktran2 by this library is a pure link-time choice.  Entry points outside the DISCO hot path keep the
  * reference's signatures; they store / return their settings where that is all they do, and report "unsupported"
  * (-2, or a null handle) where they would need an engine this build does not contain (2D geometry, JVP / VJP, flux
- * observers, geodetic utilities, non-Lambertian BRDFs, delta-M scaling).  Reference line numbers as above.
+ * observers, geodetic utilities, non-Lambertian BRDFs).  Reference line numbers as above.
  * ===================================================================================================================== */
 typedef struct Geometry2D Geometry2D;
 typedef struct Geodetic Geodetic;
@@ -212,7 +215,7 @@ int sk_config_set_flux_types(Config* config, const int* flux_types, int num_flux
 int sk_atmosphere_storage_get_derivative_mapping_by_index(AtmosphereStorage* storage, int index, DerivativeMapping** mapping); /* :111 */
 int sk_atmosphere_storage_finalize_scattering_derivatives(AtmosphereStorage* storage);         /* atmosphere.h:120 */
 int sk_atmosphere_storage_set_zero(AtmosphereStorage* storage);                                /* atmosphere.h:123 */
-int sk_atmosphere_apply_delta_m_scaling(Atmosphere* atmosphere, int order);                    /* atmosphere.h:150: -2 */
+int sk_atmosphere_apply_delta_m_scaling(Atmosphere* atmosphere, int order);                    /* atmosphere.h:150 (NSTOKES = 1, no scattering-group derivatives) */
 int sk_atmosphere_mark_changed(Atmosphere* atmosphere);                                        /* atmosphere.h:152 */
 int sk_atmosphere_get_revision(Atmosphere* atmosphere, unsigned long long* revision);          /* atmosphere.h:154 */
 int sk_surface_get_num_derivative_mappings(Surface* storage, int* num_mappings);               /* atmosphere.h:183 */

@@ -50,6 +50,7 @@ struct AtmosphereView {
     const double* leg = nullptr;         // [nleg, ngrid, nwavel]
     const double* solar_irradiance = nullptr;  // [nwavel] (nullptr -> 1)
     const double* albedo = nullptr;      // [nwavel] Lambertian
+    const double* delta_f = nullptr;     // [ngrid, nwavel] delta-M truncation fraction of the (already scaled) storage, or null
     bool derivatives = false;
     double k(int q, int w) const { return extinction[size_t(w) * ngrid + q]; }
     double om(int q, int w) const { return ssa[size_t(w) * ngrid + q]; }
@@ -164,7 +165,9 @@ class Solver {
                     double kext = atm.k(q, w), kscat = atm.om(q, w) * kext;
                     od += kext * wt;
                     s += kscat * wt;
-                    for (int l = 0; l < nstr; ++l) ap[l] += wt * kscat * atm.beta(l, q, w);
+                    // delta-M: the multiple-scatter expansion drops the truncated forward peak (sktran_do_layerarray.cpp:395-405)
+                    const double f = atm.delta_f ? atm.delta_f[size_t(w) * atm.ngrid + q] : 0.0;
+                    for (int l = 0; l < nstr; ++l) ap[l] += wt * kscat * (atm.beta(l, q, w) - (2 * l + 1) * f / (1 - f));
                 }
             }
             if (s > 0) for (int l = 0; l < nstr; ++l) ap[l] /= s;

@@ -18,6 +18,7 @@ struct Handle {
     skgeo::Geometry1D geo;
     skgeo::DiscoGeometry dg;
     int ss_in_do = 1;
+    const double* delta_f = nullptr;
     std::string error;
 };
 }  // namespace
@@ -67,6 +68,13 @@ int orc_streams(void* hv, double* mu, double* wt) {
 
 // Outputs (C order): radiance[nwavel][nlos], d_k[nwavel][nlos][ngrid], d_ssa[nwavel][nlos][ngrid],
 // d_albedo[nwavel][nlos], los_od[nwavel][nlos], n_azimuth[nwavel].  Derivative outputs may be null.
+// delta-M truncation fraction f[ngrid, nwavel] (location fastest) of an already scaled storage for the next orc_run calls
+int orc_set_delta_f(void* hv, const double* f) {
+    auto* h = static_cast<Handle*>(hv);
+    if (!h) return -1;
+    h->delta_f = f;
+    return 0;
+}
 int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg,
             const double* solar_irradiance, const double* albedo, int derivatives, int nthreads, double* radiance,
             double* d_k, double* d_ssa, double* d_albedo, double* los_od, int* n_azimuth) {
@@ -82,6 +90,7 @@ int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
     atm.leg = leg;
     atm.solar_irradiance = solar_irradiance;
     atm.albedo = albedo;
+    atm.delta_f = h->delta_f;
     atm.derivatives = derivatives != 0;
     int status = 0;
 #ifdef _OPENMP

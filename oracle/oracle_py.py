@@ -39,6 +39,7 @@ def lib():
         L.orc_run.restype = ctypes.c_int
         L.orc_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int,
                               ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _ip]
+        L.orc_set_delta_f.argtypes = [ctypes.c_void_p, _dp]
         L.orc_num_sza.argtypes = [ctypes.c_void_p]
         L.orc_chapman.argtypes = [ctypes.c_void_p, _dp]
         L.orc_streams.argtypes = [ctypes.c_void_p, _dp, _dp]
@@ -83,13 +84,15 @@ class OracleEngine:
         lib().orc_streams(self._h, _p(mu), _p(wt))
         return mu, wt
 
-    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, derivatives=False, nthreads=1):
+    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, derivatives=False, nthreads=1, delta_f=None):
         """extinction, ssa: [ngrid, nwavel]; leg: [nleg, ngrid, nwavel]; albedo: [nwavel] (Fortran-style axes as in
         the reference storage: location fastest)."""
         k = np.asfortranarray(extinction, dtype=np.float64)
         w = np.asfortranarray(ssa, dtype=np.float64)
         lg = np.asfortranarray(leg, dtype=np.float64)
         nwavel = k.shape[1]
+        df = None if delta_f is None else np.asfortranarray(delta_f, dtype=np.float64)
+        lib().orc_set_delta_f(self._h, _p(df))
         alb = np.ascontiguousarray(albedo, dtype=np.float64)
         irr = None if solar_irradiance is None else np.ascontiguousarray(solar_irradiance, dtype=np.float64)
         rad = np.zeros((nwavel, self.nlos))

@@ -57,7 +57,7 @@ class Config:
              "num_sza": "num_do_sza", "num_singlescatter_moments": "num_singlescatter_moments",
              "wavelength_batch_size": "wavelength_batch_size", "output_los_optical_depth": "output_los_optical_depth",
              "multiple_scatter_source": "multiple_scatter_source", "single_scatter_source": "single_scatter_source",
-             "wf_enabled": "wf_enabled"}
+             "wf_enabled": "wf_enabled", "delta_m_scaling": "apply_delta_scaling"}
 
     def __init__(self):
         object.__setattr__(self, "_h", lib().sk_config_create())
@@ -209,6 +209,12 @@ class Engine:
         nw, ngrid, nlos = atmosphere._nwavel, atmosphere._ngrid, self.nlos
         ext, ssa = np.asfortranarray(st.total_extinction), np.asfortranarray(st.ssa)
         em, leg = np.asfortranarray(st.emission_source), np.asfortranarray(st.leg_coeff)
+        # delta-M scaling rewrites the storage in place (src/sasktran2/atmosphere.py:845-854 applies it with order = num_streams
+        # when more moments than streams are stored): work on copies so that the caller's arrays keep the unscaled properties
+        delta_order = None
+        if self._config.delta_m_scaling and leg.shape[0] > self._config.num_streams:
+            delta_order = int(self._config.num_streams)
+            ext, ssa, leg = ext.copy(order="F"), ssa.copy(order="F"), leg.copy(order="F")
         irr, alb = np.ascontiguousarray(st.solar_irradiance), np.ascontiguousarray(atmosphere.surface.albedo, dtype=float)
         emis = np.ascontiguousarray(atmosphere.surface.emission)
         derivs = atmosphere.calculate_derivatives
@@ -238,6 +244,10 @@ class Engine:
                 np.ctypeslib.as_array(ptr, shape=(nw,))[:] = 1.0
                 out["wf_albedo"] = np.zeros((nw, nlos, 1))
                 L.sk_output_assign_surface_derivative_memory(h_out, b"wf_albedo", _p(out["wf_albedo"]), nw * nlos, 1)
+            if delta_order is not None:
+                rc = L.sk_atmosphere_apply_delta_m_scaling(h_atm, delta_order)
+                if rc != 0:
+                    raise RuntimeError(f"sk_atmosphere_apply_delta_m_scaling returned {rc}")
             rc = L.sk_engine_calculate_radiance(self._h, h_atm, h_out, 0)
             if rc != 0:
                 raise RuntimeError(f"sk_engine_calculate_radiance returned {rc}: {last_error()}")

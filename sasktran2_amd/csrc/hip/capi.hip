@@ -73,6 +73,8 @@ struct AtmosphereStorage {
     double *ssa, *ext, *emission, *leg, *irradiance;
     std::map<std::string, std::unique_ptr<DerivativeMapping>> maps;
     std::vector<std::string> names;
+    std::vector<double> delta_f;  // [nloc, nwavel] (location fastest) once sk_atmosphere_apply_delta_m_scaling has run
+    int delta_order = -1;
 };
 struct BRDF {
     int kind = 0;
@@ -317,10 +319,10 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
         if (c->ms_source != 0) throw std::runtime_error("multiple_scatter_source must be discrete_ordinates (0)");
         if (c->ss_source != 2 && c->ss_source != 3)
             throw std::runtime_error("single_scatter_source must be discrete_ordinates (2) or none (3)");
-        if (c->apply_delta_scaling || c->los_refraction || c->solar_refraction || c->multiple_scatter_refraction ||
+        if (c->los_refraction || c->solar_refraction || c->multiple_scatter_refraction ||
             c->num_do_forced_azimuth >= 0 || c->num_do_spherical_iterations > 0 || c->emission_source != 1 || c->occultation_source != 1 ||
             c->do_backprop)
-            throw std::runtime_error("delta scaling, refraction, forced azimuth count, DO spherical iterations, backprop, emission and "
+            throw std::runtime_error("refraction, forced azimuth count, DO spherical iterations, backprop, emission and "
                                      "occultation sources are not part of this build");
         skgeo::Geometry1D geo(g->cos_sza, g->saa, g->earth_radius, g->grid, (skgeo::Interpolation)g->interp,
                               (skgeo::GeometryType)g->geotype);
@@ -393,8 +395,15 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
             d_ws = (double*)C.get("wf_ssa", size_t(ngrid) * nt * 8);
             d_wa = (double*)C.get("wf_alb", nt * 8);
         }
+        double* d_f = nullptr;
+        if (!st.delta_f.empty()) {
+            d_f = (double*)C.get("delta_f", nloc_w * 8);
+            HIPC(hipMemcpy(d_f, st.delta_f.data(), nloc_w * 8, hipMemcpyHostToDevice));
+        }
+        e->dev->set_delta_m_fraction(d_f);
         e->dev->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status,
                              nullptr, 0);
+        e->dev->set_delta_m_fraction(nullptr);
         hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
         HIPC(hipGetLastError());
         HIPC(hipDeviceSynchronize());
@@ -452,6 +461,11 @@ int sk_amd_engine_solve_device(Engine* e, int nwavel, int nleg, const double* d_
         set_error(std::string("sk_amd_engine_solve_device: ") + ex.what());
         return -3;
     }
+}
+int sk_amd_engine_set_delta_m_fraction(Engine* e, const double* d_f) {
+    if (!e) return -1;
+    e->dev->set_delta_m_fraction(d_f);
+    return 0;
 }
 int sk_amd_engine_num_los(Engine* e, int* n) { if (!e || !n) return -1; *n = e->nlos; return 0; }
 int sk_amd_engine_scratch_bytes(Engine* e, int nwavel, unsigned long long* bytes) {

@@ -112,6 +112,7 @@ struct Bufs {
     const double* leg;      // [w][q][l<nleg]
     const double* albedo;   // [w]
     const double* irradiance;  // [w] or null
+    const double* delta_f;  // [w][q] delta-M truncation fraction of the (already scaled) storage, or null
     int nleg;
     // layer optics (K0)
     double* tau;            // [p][w]
@@ -187,7 +188,10 @@ SKD_HD void k0_layer_optics(const Geo& g, const Bufs& b, int w, bool with_los_sh
             double kext = ext[q], kscat = ssa[q] * kext;
             od += kext * wt;
             s += kscat * wt;
-            for (int l = 0; l < nstr && l < b.nleg; ++l) b.a[(size_t(p) * nstr + l) * nw + w] += wt * kscat * leg[size_t(q) * b.nleg + l];
+            // delta-M: the multiple-scatter expansion drops the truncated forward peak (sktran_do_layerarray.cpp:395-405)
+            const double fq = b.delta_f ? b.delta_f[size_t(w) * ngrid + q] : 0.0, fsub = fq / (1 - fq);
+            for (int l = 0; l < nstr; ++l)
+                b.a[(size_t(p) * nstr + l) * nw + w] += wt * kscat * (((l < b.nleg) ? leg[size_t(q) * b.nleg + l] : 0.0) - (2 * l + 1) * fsub);
         }
         if (s > 0) {
             for (int l = 0; l < nstr; ++l) b.a[(size_t(p) * nstr + l) * nw + w] /= s;

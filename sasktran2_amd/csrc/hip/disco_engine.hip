@@ -201,6 +201,7 @@ struct DeviceEngine::Impl {
     hipEvent_t fork = nullptr;
     int chunk_capacity = 0;
     int last_chunk = 0, last_slots = 0;
+    const double* delta_f = nullptr;
     bool profiling = false;
     std::map<std::string, std::pair<double, long>> times;  // name -> (ms, launches)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -261,6 +262,7 @@ int DeviceEngine::nlos() const { return impl_->tab.nlos; }
 int DeviceEngine::ngrid() const { return impl_->tab.ngrid; }
 int DeviceEngine::nstr() const { return impl_->tab.nstr; }
 size_t DeviceEngine::scratch_bytes() const { return impl_->scratch_bytes; }
+void DeviceEngine::set_delta_m_fraction(const double* d_f) { impl_->delta_f = d_f; }
 int DeviceEngine::last_chunk() const { return impl_->last_chunk; }
 int DeviceEngine::last_slots() const { return impl_->last_slots; }
 void DeviceEngine::set_profiling(bool on) { impl_->profiling = on; }
@@ -603,6 +605,7 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
         b.leg = d_leg + size_t(w0) * t.ngrid * nleg;
         b.albedo = d_albedo + w0;
         b.irradiance = d_irradiance ? d_irradiance + w0 : nullptr;
+        b.delta_f = I.delta_f ? I.delta_f + size_t(w0) * t.ngrid : nullptr;
         b.nleg = nleg;
         b.derivs = derivs;
         switch (t.N) {

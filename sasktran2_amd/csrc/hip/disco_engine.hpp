@@ -28,6 +28,9 @@ class DeviceEngine {
                       const double* d_albedo, const double* d_irradiance, int derivs, double* d_radiance, double* d_wf_ext,
                       double* d_wf_ssa, double* d_wf_alb, double* d_los_od, int* d_status, void* stream, int max_chunk);
 
+    // delta-M truncation fraction of the (already scaled) optical properties: DEVICE pointer [nwavel][ngrid] used by the following
+    // solve_device calls, or null (sk_atmosphere_apply_delta_m_scaling, cpp/lib/atmosphere/atmosphere.cpp:73-200)
+    void set_delta_m_fraction(const double* d_f);
     size_t bytes_per_wavelength() const;
     size_t scratch_bytes() const;   // scratch currently allocated (all slots)
     int last_chunk() const;         // wavelengths per launch of the last solve

@@ -108,6 +108,8 @@ void* emu_create(double cos_sza, double saa, double earth_radius, const double* 
 }
 void emu_destroy(void* h) { delete static_cast<Handle*>(h); }
 
+const double* g_delta_f = nullptr;
+void emu_set_delta_f(const double* f) { g_delta_f = f; }
 int emu_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg,
             const double* solar_irradiance, const double* albedo, int derivatives, double* radiance, double* d_k,
             double* d_ssa, double* d_albedo, double* los_od, int* status) {
@@ -127,7 +129,7 @@ int emu_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
         for (int w = 0; w < nw; ++w) conv[size_t(w) * t.nslot + sl] = t.slot_is_ground[sl] ? 1 : 255;
     std::vector<int> notconv(nw, 0), norders(nw, nstr), stat(nw, 0);
     skd::Bufs b{};
-    b.nw = nw; b.ext = extinction; b.ssa = ssa; b.leg = leg; b.albedo = albedo; b.irradiance = solar_irradiance; b.nleg = nleg;
+    b.nw = nw; b.ext = extinction; b.ssa = ssa; b.leg = leg; b.albedo = albedo; b.irradiance = solar_irradiance; b.delta_f = g_delta_f; b.nleg = nleg;
     b.tau = tau.data(); b.om = om.data(); b.kbar = kbar.data(); b.a = a.data(); b.T = T.data(); b.sec = sec.data();
     b.od = od.data(); b.omloc = omloc.data(); b.srcw = srcw.data(); b.att_total = att_total.data(); b.rec = rec.data();
     b.dinv = dinv.data(); b.xsol = xsol.data(); b.J = J.data(); b.conv_order = conv.data(); b.notconv = notconv.data();

@@ -27,6 +27,7 @@ def lib():
         L.emu_create.restype = ctypes.c_void_p
         L.emu_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int]
+        L.emu_set_delta_f.argtypes = [_dp]
         L.emu_destroy.argtypes = [ctypes.c_void_p]
         L.emu_run.restype = ctypes.c_int
         L.emu_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int, _dp,
@@ -58,6 +59,8 @@ def run_emulated(s, derivatives=True):
         rad, od = np.zeros((nw, nlos)), np.zeros((nw, nlos))
         dk, dw, da = np.zeros((nw, nlos, ngrid)), np.zeros((nw, nlos, ngrid)), np.zeros((nw, nlos))
         status = np.zeros(nw, dtype=np.int32)
+        df = None if s.get("delta_f") is None else np.asfortranarray(s["delta_f"], dtype=np.float64)
+        lib().emu_set_delta_f(_p(df))
         rc = lib().emu_run(h, nw, lg.shape[0], _p(k), _p(w), _p(lg), None, _p(alb), int(derivatives), _p(rad), _p(dk),
                            _p(dw), _p(da), _p(od), status.ctypes.data_as(_ip))
         assert rc == 0

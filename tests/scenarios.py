@@ -109,3 +109,20 @@ def nadir_c1(num_wavelengths: int = 100, nstr: int = 2, observer_altitude: float
                     geotype=GEO_PLANEPARALLEL)
     return dict(geometry=geometry, config=dict(nstr=nstr, num_sza=1), rays=rays, extinction=k, ssa=ssa, leg=leg,
                 albedo=np.full(nw, 0.3))
+
+
+def delta_m_scaled(s: dict, order: int | None = None):
+    """Applies the reference's delta-M scaling (cpp/lib/atmosphere/atmosphere.cpp:73-200, NSTOKES = 1) to a scenario the way
+    sk_atmosphere_apply_delta_m_scaling does in place: returns a new scenario with the scaled extinction / ssa / Legendre
+    coefficients and the truncation fraction `delta_f`, plus the factors that map native derivatives wrt the scaled
+    (k*, w*) back to the unscaled inputs: dI/dk = dI/dk* (1 - w f) ; dI/dw = dI/dw* (1 - f (1 - w*)) / (1 - w f) - dI/dk* k f."""
+    order = s["config"]["nstr"] if order is None else order
+    k, w, leg = s["extinction"], s["ssa"], s["leg"]
+    assert leg.shape[0] > order
+    f = leg[order] / (2 * order + 1)
+    ks = k * (1 - w * f)
+    ws = (1 - f) / (1 - w * f) * w
+    out = dict(s)
+    out.update(extinction=ks, ssa=ws, leg=leg / (1 - f)[None, :, :], delta_f=f,
+               unscale=dict(dk_dk=(1 - w * f), dw_dw=(1 - f * (1 - ws)) / (1 - w * f), dk_dw=-k * f))
+    return out
