@@ -111,6 +111,13 @@ class GroundViewingSolar:
         self.args = (cos_sza, relative_azimuth, cos_viewing_zenith, observer_altitude_m)
 
 
+class SolarAnglesObserverLocation:
+    """src/sasktran2/viewinggeo/wrappers.py:255-295: observer at an altitude, look direction from solar angles at the observer."""
+
+    def __init__(self, cos_sza, relative_azimuth, cos_viewing_zenith, observer_altitude_m):
+        self.args = (cos_sza, relative_azimuth, cos_viewing_zenith, observer_altitude_m)
+
+
 class ViewingGeometry:
     """src/sasktran2/viewinggeo/wrappers.py:13-36."""
 
@@ -128,6 +135,8 @@ class ViewingGeometry:
         elif isinstance(ray, GroundViewingSolar):
             c, az, cv, alt = map(float, ray.args)
             lib().sk_viewing_geometry_add_ground_viewing_solar(self._h, c, az, alt, cv)
+        elif isinstance(ray, SolarAnglesObserverLocation):
+            lib().sk_viewing_geometry_add_solar_angles_observer_location(self._h, *map(float, ray.args))
         else:
             raise TypeError("unsupported ray type on the MI355X path")
         self._rays.append(ray)

@@ -206,10 +206,12 @@ struct ViewingRay {
 
 // user-level ray specifications (cpp/include/c_api/viewing_geometry.h:15-24)
 struct RaySpec {
-    enum Kind { tangent_altitude_solar = 0, ground_viewing_solar = 1 } kind;
+    // viewing_up_solar: observer at `observer_altitude`, look direction given by the zenith cosine and the azimuth relative to
+    // the sun at the observer (ViewingUpSolar, cpp/lib/viewinggeometry/groundviewing.cpp:66-87)
+    enum Kind { tangent_altitude_solar = 0, ground_viewing_solar = 1, viewing_up_solar = 2 } kind;
     double cos_sza, relative_azimuth, observer_altitude;
     double tangent_altitude;    // tangent_altitude_solar
-    double cos_viewing_zenith;  // ground_viewing_solar
+    double cos_viewing_zenith;  // ground_viewing_solar, viewing_up_solar
 };
 
 inline ViewingRay construct_ray(const RaySpec& s, const Coordinates& c) {
@@ -221,6 +223,11 @@ inline ViewingRay construct_ray(const RaySpec& s, const Coordinates& c) {
         double a = c.earth_radius + s.observer_altitude, b = c.earth_radius + s.tangent_altitude;
         double dist = std::sqrt(a * a - b * b);
         ray.observer.position = tp - ray.look_away * dist;
+        ray.relative_azimuth = s.relative_azimuth;
+    } else if (s.kind == RaySpec::viewing_up_solar) {
+        Vec3 at = c.solar_coordinate_vector(s.cos_sza, 0.0, s.observer_altitude);
+        ray.look_away = c.look_vector_from_azimuth(at, s.relative_azimuth, s.cos_viewing_zenith);
+        ray.observer.position = at;
         ray.relative_azimuth = s.relative_azimuth;
     } else {
         Vec3 ground = c.solar_coordinate_vector(s.cos_sza, 0.0, 0.0);

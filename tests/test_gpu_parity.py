@@ -310,3 +310,15 @@ def test_delta_m_user_level_weighting_functions_match_finite_differences():
         fd = (_run_product_delta_m(plus)["radiance"] - _run_product_delta_m(minus)["radiance"]) / (2 * h[:, None])
         scale = np.abs(got[key]).max(axis=2)
         assert np.max(np.abs(fd - got[key][:, :, q]) / scale) < 1e-4, name
+
+
+def test_up_looking_observers_match_oracle():
+    # observers inside the atmosphere (ViewingUpSolar: sk_viewing_geometry_add_solar_angles_observer_location), 8 and 16 streams
+    for nstr in (8, 16):
+        s = sc.regression_1d(2)
+        s["config"]["nstr"] = nstr
+        csz = s["geometry"]["cos_sza"]
+        s["rays"] = [(sc.VIEWING_UP_SOLAR, csz, az, alt, cz)
+                     for az, alt, cz in ((0.0, 1_000.0, 1.0), (0.7, 1_000.0, 0.3), (-2.0, 12_500.0, 0.6), (1.2, 31_000.0, 0.05),
+                                         (0.4, 20_000.0, -0.4), (2.5, 59_000.0, 0.9))]
+        assert_parity(run_product(s), run_oracle(s, derivatives=True))

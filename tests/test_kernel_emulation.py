@@ -146,3 +146,22 @@ def test_delta_m_improves_low_stream_accuracy():
     assert np.abs(scaled / truth - 1).max() < 0.25 * np.abs(plain / truth - 1).max()
     e = run_emulated(d, derivatives=False)
     np.testing.assert_allclose(e["radiance"], scaled, rtol=1e-9)
+
+
+# ---- observers inside the atmosphere looking up / sideways / down (ViewingUpSolar, sk_viewing_geometry_add_solar_angles_observer_location)
+def _up_looking(nw=2):
+    s = sc.regression_1d(nw)
+    csz = s["geometry"]["cos_sza"]
+    s["rays"] = [(sc.VIEWING_UP_SOLAR, csz, az, alt, cz)
+                 for az, alt, cz in ((0.0, 1_000.0, 1.0), (0.7, 1_000.0, 0.3), (-2.0, 12_500.0, 0.6), (1.2, 31_000.0, 0.05),
+                                     (0.4, 20_000.0, -0.4), (2.5, 59_000.0, 0.9))]
+    return s
+
+
+def test_up_looking_observers_emulated():
+    s = _up_looking()
+    check(s, rtol_wf=1e-7)
+    o = run_oracle(s)
+    # an observer just below the top of the atmosphere looking up sees almost nothing; one near the ground looking at the zenith does
+    assert np.all(o["radiance"][:, 5] < 1e-3 * o["radiance"][:, 0])
+    assert np.all(o["radiance"][:, 0] > 0)
