@@ -111,6 +111,14 @@ class GroundViewingSolar:
         self.args = (cos_sza, relative_azimuth, cos_viewing_zenith, observer_altitude_m)
 
 
+class TangentAltitude:
+    """src/sasktran2/viewinggeo/wrappers.py:38-172 (1D use: tangent point at `horizontal_angle` from the reference point in the
+    solar plane, `viewing_azimuth` in its local horizontal plane)."""
+
+    def __init__(self, tangent_altitude_m, observer_altitude_m, horizontal_angle=0.0, viewing_azimuth=0.0):
+        self.args = (tangent_altitude_m, observer_altitude_m, horizontal_angle, viewing_azimuth)
+
+
 class SolarAnglesObserverLocation:
     """src/sasktran2/viewinggeo/wrappers.py:255-295: observer at an altitude, look direction from solar angles at the observer."""
 
@@ -135,6 +143,9 @@ class ViewingGeometry:
         elif isinstance(ray, GroundViewingSolar):
             c, az, cv, alt = map(float, ray.args)
             lib().sk_viewing_geometry_add_ground_viewing_solar(self._h, c, az, alt, cv)
+        elif isinstance(ray, TangentAltitude):
+            if lib().sk_viewing_geometry_add_tangent_altitude(self._h, *map(float, ray.args)) != 0:
+                raise ValueError("invalid TangentAltitude ray")
         elif isinstance(ray, SolarAnglesObserverLocation):
             lib().sk_viewing_geometry_add_solar_angles_observer_location(self._h, *map(float, ray.args))
         else:

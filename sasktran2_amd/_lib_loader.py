@@ -31,6 +31,7 @@ SIGNATURES = [
     ("sk_viewing_geometry_add_ground_viewing_solar", None, [_vp, _D, _D, _D, _D]),
     ("sk_viewing_geometry_add_tangent_altitude_solar", _I, [_vp, _D, _D, _D, _D]),
     ("sk_viewing_geometry_add_solar_angles_observer_location", _I, [_vp, _D, _D, _D, _D]),
+    ("sk_viewing_geometry_add_tangent_altitude", _I, [_vp, _D, _D, _D, _D]),
     ("sk_viewing_geometry_num_rays", _I, [_vp, _ip]),
     ("sk_atmosphere_storage_create", _vp, [_I, _I, _I, _I, _dp, _dp, _dp, _dp, _dp]),
     ("sk_atmosphere_storage_destroy", None, [_vp]),

@@ -208,8 +208,11 @@ struct ViewingRay {
 struct RaySpec {
     // viewing_up_solar: observer at `observer_altitude`, look direction given by the zenith cosine and the azimuth relative to
     // the sun at the observer (ViewingUpSolar, cpp/lib/viewinggeometry/groundviewing.cpp:66-87)
-    enum Kind { tangent_altitude_solar = 0, ground_viewing_solar = 1, viewing_up_solar = 2 } kind;
+    // tangent_altitude: limb ray given by the angle of its tangent point from the reference point in the solar plane and the
+    // viewing azimuth in the local horizontal plane there (TangentAltitude, cpp/lib/viewinggeometry/tangentaltitude.cpp:5-71)
+    enum Kind { tangent_altitude_solar = 0, ground_viewing_solar = 1, viewing_up_solar = 2, tangent_altitude_angles = 3 } kind;
     double cos_sza, relative_azimuth, observer_altitude;
+    double horizontal_angle = 0;  // tangent_altitude (relative_azimuth holds the viewing azimuth)
     double tangent_altitude;    // tangent_altitude_solar
     double cos_viewing_zenith;  // ground_viewing_solar, viewing_up_solar
 };
@@ -223,6 +226,17 @@ inline ViewingRay construct_ray(const RaySpec& s, const Coordinates& c) {
         double a = c.earth_radius + s.observer_altitude, b = c.earth_radius + s.tangent_altitude;
         double dist = std::sqrt(a * a - b * b);
         ray.observer.position = tp - ray.look_away * dist;
+        ray.relative_azimuth = s.relative_azimuth;
+    } else if (s.kind == RaySpec::tangent_altitude_angles) {
+        if (c.geotype != spherical) throw std::invalid_argument("TangentAltitude rays need spherical geometry");
+        if (!(s.observer_altitude >= s.tangent_altitude)) throw std::invalid_argument("observer below the tangent altitude");
+        // rotation of the reference frame about y by the horizontal angle (Coordinates::unit_vector_from_angles / local_x_y_from_angles
+        // with zero out-of-plane angle, cpp/lib/geometry/geometry.cpp:102-129)
+        Vec3 uv = rotate(c.zu, c.yu, s.horizontal_angle), lx = rotate(c.xu, c.yu, s.horizontal_angle), ly = c.yu;
+        Vec3 tp = uv * (c.earth_radius + s.tangent_altitude);
+        ray.look_away = lx * std::cos(s.relative_azimuth) + ly * std::sin(s.relative_azimuth);
+        double a = c.earth_radius + s.observer_altitude, b = c.earth_radius + s.tangent_altitude;
+        ray.observer.position = tp - ray.look_away * std::sqrt(a * a - b * b);
         ray.relative_azimuth = s.relative_azimuth;
     } else if (s.kind == RaySpec::viewing_up_solar) {
         Vec3 at = c.solar_coordinate_vector(s.cos_sza, 0.0, s.observer_altitude);

@@ -92,6 +92,7 @@ void* emu_create(double cos_sza, double saa, double earth_radius, const double* 
         for (int i = 0; i < nrays; ++i) {
             specs[i].kind = (skgeo::RaySpec::Kind)ray_kinds[i];
             specs[i].cos_sza = ray_params[4 * i + 0];
+            specs[i].horizontal_angle = ray_params[4 * i + 0];  // kind 3 (tangent_altitude)
             specs[i].relative_azimuth = ray_params[4 * i + 1];
             specs[i].observer_altitude = ray_params[4 * i + 2];
             specs[i].tangent_altitude = ray_params[4 * i + 3];

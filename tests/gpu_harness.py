@@ -22,6 +22,8 @@ def build_engine(s):
     for kind, csz, az, obs, x in s["rays"]:
         if kind == sc.TANGENT_ALTITUDE_SOLAR:
             viewing.add_ray(sk.TangentAltitudeSolar(x, az, obs, csz))
+        elif kind == sc.TANGENT_ALTITUDE:
+            viewing.add_ray(sk.TangentAltitude(x, obs, csz, az))
         elif kind == sc.VIEWING_UP_SOLAR:
             viewing.add_ray(sk.SolarAnglesObserverLocation(csz, az, x, obs))
         else:

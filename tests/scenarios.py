@@ -13,6 +13,7 @@ import numpy as np
 TANGENT_ALTITUDE_SOLAR = 0
 GROUND_VIEWING_SOLAR = 1
 VIEWING_UP_SOLAR = 2   # (kind, cos_sza, relative_azimuth, observer_altitude, cos_viewing_zenith)
+TANGENT_ALTITUDE = 3   # (kind, horizontal_angle, viewing_azimuth, observer_altitude, tangent_altitude)
 INTERP_SHELL, INTERP_LINEAR, INTERP_LOWER = 0, 1, 2
 GEO_PLANEPARALLEL, GEO_PSEUDOSPHERICAL, GEO_SPHERICAL = 0, 1, 2
 

@@ -322,3 +322,9 @@ def test_up_looking_observers_match_oracle():
                      for az, alt, cz in ((0.0, 1_000.0, 1.0), (0.7, 1_000.0, 0.3), (-2.0, 12_500.0, 0.6), (1.2, 31_000.0, 0.05),
                                          (0.4, 20_000.0, -0.4), (2.5, 59_000.0, 0.9))]
         assert_parity(run_product(s), run_oracle(s, derivatives=True))
+
+
+def test_tangent_altitude_rays_match_oracle():
+    s = sc.limb_c2(num_wavelengths=2)
+    s["rays"] = [(sc.TANGENT_ALTITUDE, th, az, 300_000.0, t) for th, az, t in ((0.0, 0.0, 15_000.0), (0.2, 1.0, 30_000.0), (-0.3, -2.0, 45_000.0))]
+    assert_parity(run_product(s), run_oracle(s, derivatives=True))

@@ -165,3 +165,23 @@ def test_up_looking_observers_emulated():
     # an observer just below the top of the atmosphere looking up sees almost nothing; one near the ground looking at the zenith does
     assert np.all(o["radiance"][:, 5] < 1e-3 * o["radiance"][:, 0])
     assert np.all(o["radiance"][:, 0] > 0)
+
+
+def test_tangent_altitude_rays_equal_their_solar_form():
+    """TangentAltitude (tangent point at an angle from the reference point in the solar plane, azimuth in the local horizontal
+    plane: sk_viewing_geometry_add_tangent_altitude) traces the same line of sight as TangentAltitudeSolar with the tangent
+    point's solar zenith angle and the same azimuth, so both must give the same radiance and weighting functions."""
+    s = sc.regression_1d(2)
+    s["geometry"]["saa"] = 0.0
+    csz0 = s["geometry"]["cos_sza"]
+    rays = []
+    for theta, az in ((0.1, 0.0), (-0.2, 0.0), (0.05, np.pi)):
+        sza_tp = np.arccos(csz0) - theta
+        rays += [(sc.TANGENT_ALTITUDE, theta, az, 200_000.0, 20_000.0),
+                 (sc.TANGENT_ALTITUDE_SOLAR, float(np.cos(sza_tp)), az, 200_000.0, 20_000.0)]
+    s["rays"] = rays
+    o = run_oracle(s, derivatives=True)
+    # (the two constructions differ by the rounding of acos / cos, which moves a sza-table weight by ~1e-8)
+    np.testing.assert_allclose(o["radiance"][:, 0::2], o["radiance"][:, 1::2], rtol=1e-7)
+    np.testing.assert_allclose(o["d_extinction"][:, 0::2], o["d_extinction"][:, 1::2], rtol=1e-6, atol=1e-9)
+    check(s, rtol_wf=1e-7)
