@@ -853,8 +853,35 @@ inline void build_disco_geometry(const Geometry1D& g, const std::vector<RaySpec>
         out.csz = {c.cos_sza_at_reference()};
         out.nsza = 1;
         out.chapman.assign(size_t(nlyr) * nlyr, 0);
-        for (int p = 0; p < nlyr; ++p)
-            for (int q = 0; q <= p; ++q) out.chapman[size_t(p) * nlyr + q] = 1 / out.csz[0];
+        if (c.geotype == pseudospherical) {
+            // pseudo-spherical: plane-parallel diffuse field, solar beam attenuated along its true path through spherical shells
+            // (GeometryLayerArray::calculate_chapman_factors_raytracer, sktran_do_geometrylayerarray.cpp:114-183)
+            SphericalShellRayTracer tracer(g);
+            for (int p = 0; p < nlyr; ++p) {
+                ViewingRay sr;
+                sr.look_away = c.sun;
+                sr.observer.position = c.solar_coordinate_vector(out.csz[0], 0.0, out.floor_h[p]);
+                TracedRay tr;
+                tracer.trace(sr, tr);
+                double* row = &out.chapman[size_t(p) * nlyr];
+                if (tr.ground_is_hit) {
+                    for (int q = 0; q < nlyr; ++q) row[q] = -1.0;
+                    continue;
+                }
+                for (auto& L : tr.layers) {
+                    double dist = L.layer_distance * L.curvature_factor;
+                    double avg_alt = (L.entrance.radius() + L.exit.radius()) / 2.0 - c.earth_radius;
+                    int q = 0;
+                    for (; q < nlyr; ++q)
+                        if (avg_alt >= out.floor_h[q] && avg_alt <= out.ceil_h[q]) break;
+                    if (q == nlyr) q = nlyr - 1;
+                    row[q] += dist / (out.ceil_h[q] - out.floor_h[q]);
+                }
+            }
+        } else {
+            for (int p = 0; p < nlyr; ++p)
+                for (int q = 0; q <= p; ++q) out.chapman[size_t(p) * nlyr + q] = 1 / out.csz[0];
+        }
         out.pp_los.resize(specs.size());
         out.lp_los.assign(specs.size() * size_t(nstr) * nstr, 0);
         for (size_t i = 0; i < specs.size(); ++i) {

@@ -328,3 +328,12 @@ def test_tangent_altitude_rays_match_oracle():
     s = sc.limb_c2(num_wavelengths=2)
     s["rays"] = [(sc.TANGENT_ALTITUDE, th, az, 300_000.0, t) for th, az, t in ((0.0, 0.0, 15_000.0), (0.2, 1.0, 30_000.0), (-0.3, -2.0, 45_000.0))]
     assert_parity(run_product(s), run_oracle(s, derivatives=True))
+
+
+@pytest.mark.parametrize("csz,nstr", [(0.9, 2), (0.3, 8), (0.08, 16)])
+def test_pseudo_spherical_matches_oracle(csz, nstr):
+    s = sc.nadir_c1(num_wavelengths=20, nstr=nstr)
+    s["geometry"]["cos_sza"] = csz
+    s["geometry"]["geotype"] = sc.GEO_PSEUDOSPHERICAL
+    s["rays"] = [(r[0], csz) + tuple(r[2:]) for r in s["rays"]]
+    assert_parity(run_product(s), run_oracle(s, derivatives=True))

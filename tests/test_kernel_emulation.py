@@ -185,3 +185,34 @@ def test_tangent_altitude_rays_equal_their_solar_form():
     np.testing.assert_allclose(o["radiance"][:, 0::2], o["radiance"][:, 1::2], rtol=1e-7)
     np.testing.assert_allclose(o["d_extinction"][:, 0::2], o["d_extinction"][:, 1::2], rtol=1e-6, atol=1e-9)
     check(s, rtol_wf=1e-7)
+
+
+# ---- pseudo-spherical geometry: plane-parallel diffuse field, solar beam along its true path through spherical shells
+def _pseudo_spherical(csz, nw=3, nstr=8):
+    s = sc.nadir_c1(num_wavelengths=nw, nstr=nstr)
+    s["geometry"]["cos_sza"] = csz
+    s["geometry"]["geotype"] = sc.GEO_PSEUDOSPHERICAL
+    s["rays"] = [(r[0], csz) + tuple(r[2:]) for r in s["rays"]]
+    return s
+
+
+@pytest.mark.parametrize("csz", [0.9, 0.3, 0.08])
+def test_pseudo_spherical_chapman_factors_and_parity(csz):
+    s = _pseudo_spherical(csz)
+    from tests.test_oracle_golden import make_oracle
+    eng = make_oracle(s)
+    ch = eng.chapman()[0]
+    # straight-line Chapman factors of the reference (sktran_do_geometrylayerarray.cpp:73-113):
+    # (sqrt(r_ceil^2 - r_p^2 sin^2) - sqrt(r_floor^2 - r_p^2 sin^2)) / (r_ceil - r_floor) for the layers q above the floor of layer p
+    alt, R = s["geometry"]["altitudes"], s["geometry"]["earth_radius"]
+    ceil, floor = alt[::-1][:-1], alt[::-1][1:]
+    for p in range(len(ceil)):
+        rp2 = (R + floor[p]) ** 2 * (1 - csz * csz)
+        want = (np.sqrt((R + ceil[: p + 1]) ** 2 - rp2) - np.sqrt((R + floor[: p + 1]) ** 2 - rp2)) / (ceil[: p + 1] - floor[: p + 1])
+        np.testing.assert_allclose(ch[p, : p + 1], want, rtol=1e-11)
+        assert np.all(ch[p, p + 1:] == 0)
+    check(s, rtol_wf=1e-7)
+    # sun high: pseudo-spherical == plane parallel to a few 1e-4; sun lower: brighter than plane parallel (0.2 - 16 %)
+    pp = dict(s, geometry=dict(s["geometry"], geotype=sc.GEO_PLANEPARALLEL))
+    ratio = run_oracle(s)["radiance"] / run_oracle(pp)["radiance"]
+    assert (np.abs(ratio - 1).max() < 5e-4) if csz > 0.8 else (ratio.min() > 1.001)
