@@ -223,7 +223,9 @@ class Engine:
         if getattr(self, "_h", None):
             lib().sk_engine_destroy(self._h)
 
-    def calculate_radiance(self, atmosphere, as_dataset=True):
+    def calculate_radiance(self, atmosphere, as_dataset=True, _mapping_hook=None):
+        """`_mapping_hook(L, storage_handle, output_handle, out_dict)` lets a caller register further derivative mappings through
+        the C ABI before the solve (used by the tests for interpolated / log-space mappings)."""
         L = lib()
         st = atmosphere.storage
         nw, ngrid, nlos = atmosphere._nwavel, atmosphere._ngrid, self.nlos
@@ -264,6 +266,8 @@ class Engine:
                 np.ctypeslib.as_array(ptr, shape=(nw,))[:] = 1.0
                 out["wf_albedo"] = np.zeros((nw, nlos, 1))
                 L.sk_output_assign_surface_derivative_memory(h_out, b"wf_albedo", _p(out["wf_albedo"]), nw * nlos, 1)
+            if _mapping_hook is not None:
+                _mapping_hook(L, h_st, h_out, out)
             if delta_order is not None:
                 rc = L.sk_atmosphere_apply_delta_m_scaling(h_atm, delta_order)
                 if rc != 0:

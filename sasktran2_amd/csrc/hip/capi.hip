@@ -138,6 +138,28 @@ __global__ void __launch_bounds__(256) kern_map_wf(const double* we, const doubl
         dst[i] = f_ssa[size_t(w) * ngrid + q] * ws[i] + f_ext[size_t(w) * ngrid + q] * we[i];
     }
 }
+// the same followed by the mapping's interpolator (column major [ngrid x nout], OutputC::assign_lane: row of native derivatives
+// times the interpolator) and / or the division by the radiance of a log-radiance-space mapping; dst is [nout][wavel][los]
+__global__ void __launch_bounds__(256) kern_map_wf_interp(const double* we, const double* ws, const double* f_ssa, const double* f_ext,
+                                                          const double* interp, const double* radiance, int log_space, double* dst,
+                                                          int ngrid, int nout, int nw, int nlos) {
+    const size_t n = size_t(nout) * nw * nlos;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const size_t jw = i / nlos;
+        const int j = int(jw / nw), w = int(jw % nw), l = int(i % nlos);
+        double acc = 0;
+        if (interp) {
+            for (int q = 0; q < ngrid; ++q) {
+                const size_t o = (size_t(q) * nw + w) * nlos + l;
+                acc += interp[size_t(j) * ngrid + q] * (f_ssa[size_t(w) * ngrid + q] * ws[o] + f_ext[size_t(w) * ngrid + q] * we[o]);
+            }
+        } else {
+            acc = f_ssa[size_t(w) * ngrid + j] * ws[i] + f_ext[size_t(w) * ngrid + j] * we[i];
+        }
+        if (log_space) acc /= radiance[size_t(w) * nlos + l];
+        dst[i] = acc;
+    }
+}
 __global__ void __launch_bounds__(256) kern_transpose_od(const double* od, double* out, int nw, int nlos) {
     const size_t n = size_t(nw) * nlos;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
@@ -361,11 +383,11 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
             auto it = st.maps.find(kv.first);
             if (it == st.maps.end()) continue;
             const DerivativeMapping& dm = *it->second;
-            bool uses_extra = dm.interpolator != nullptr || dm.scat_deriv_index >= 0 || dm.log_radiance_space != 0;
+            bool uses_extra = dm.scat_deriv_index >= 0;
             for (double v : dm.d_legendre) uses_extra = uses_extra || (v != 0.0);
             for (double v : dm.scat_factor) uses_extra = uses_extra || (v != 0.0);
             for (double v : dm.d_emission) uses_extra = uses_extra || (v != 0.0);
-            if (uses_extra) return -2;  // scattering-group / Legendre / emission derivatives, interpolators, log space
+            if (uses_extra) return -2;  // scattering-group / Legendre / emission derivatives
         }
         if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
         const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
@@ -417,17 +439,29 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (derivs) {
             double* d_fs = (double*)C.get("map_d_ssa", nloc_w * 8);
             double* d_fk = (double*)C.get("map_d_extinction", nloc_w * 8);
-            double* d_dst = (double*)C.get("wf_user", size_t(ngrid) * nt * 8);
             for (auto& kv : out->derivs) {
                 auto it = st.maps.find(kv.first);
                 if (it == st.maps.end()) throw std::runtime_error("no derivative mapping named " + kv.first);
                 const DerivativeMapping& m = *it->second;
-                if (kv.second.nderiv != ngrid || kv.second.nrad != nw * nlos) throw std::runtime_error("derivative memory size mismatch for " + kv.first);
+                const int nout = m.interpolator ? m.interp_dim2 : ngrid;
+                if (m.interpolator && m.interp_dim1 != ngrid) throw std::runtime_error("interpolator of " + kv.first + " does not have one row per grid location");
+                if (kv.second.nderiv != nout || kv.second.nrad != nw * nlos) throw std::runtime_error("derivative memory size mismatch for " + kv.first);
                 HIPC(hipMemcpy(d_fs, m.d_ssa.data(), nloc_w * 8, hipMemcpyHostToDevice));
                 HIPC(hipMemcpy(d_fk, m.d_extinction.data(), nloc_w * 8, hipMemcpyHostToDevice));
-                hipLaunchKernelGGL(kern_map_wf, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_dst, ngrid, nw, nlos);
+                double* d_dst = (double*)C.get("wf_user", size_t(nout) * nt * 8);
+                if (!m.interpolator && !m.log_radiance_space) {
+                    hipLaunchKernelGGL(kern_map_wf, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_dst, ngrid, nw, nlos);
+                } else {
+                    double* d_interp = nullptr;
+                    if (m.interpolator) {
+                        d_interp = (double*)C.get("interpolator", size_t(ngrid) * nout * 8);
+                        HIPC(hipMemcpy(d_interp, m.interpolator, size_t(ngrid) * nout * 8, hipMemcpyHostToDevice));
+                    }
+                    hipLaunchKernelGGL(kern_map_wf_interp, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_interp, d_rad,
+                                       m.log_radiance_space, d_dst, ngrid, nout, nw, nlos);
+                }
                 HIPC(hipGetLastError());
-                HIPC(hipMemcpy(kv.second.mem, d_dst, size_t(ngrid) * nt * 8, hipMemcpyDeviceToHost));  // C order [nderiv][wavel][los]
+                HIPC(hipMemcpy(kv.second.mem, d_dst, size_t(nout) * nt * 8, hipMemcpyDeviceToHost));  // C order [nderiv][wavel][los]
             }
             if (!out->surface_derivs.empty()) {
                 std::vector<double> wa(nt);

@@ -337,3 +337,45 @@ def test_pseudo_spherical_matches_oracle(csz, nstr):
     s["geometry"]["geotype"] = sc.GEO_PSEUDOSPHERICAL
     s["rays"] = [(r[0], csz) + tuple(r[2:]) for r in s["rays"]]
     assert_parity(run_product(s), run_oracle(s, derivatives=True))
+
+
+def test_interpolated_and_log_space_derivative_mappings():
+    """A derivative mapping with an interpolator (native row times an [ngrid x nout] matrix, OutputC::assign_lane) and in
+    log-radiance space equals the same operations applied to the plain wf_extinction / wf_ssa on the host."""
+    import ctypes
+    from tests.gpu_harness import build_engine
+    import sasktran2_amd as sk
+    s = sc.regression_1d(3)
+    engine, config, geometry = build_engine(s)
+    nw, ngrid, nlos, nout = 3, len(s["geometry"]["altitudes"]), len(s["rays"]), 5
+    rng = np.random.default_rng(5)
+    interp = np.asfortranarray(rng.uniform(0, 1, (ngrid, nout)))
+    f_ext = rng.uniform(0.5, 2.0, (ngrid, nw))
+    f_ssa = rng.uniform(-1.0, 1.0, (ngrid, nw))
+    dp, vp = ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
+    keep = {}
+
+    def hook(L, h_st, h_out, out):
+        m = vp()
+        L.sk_atmosphere_storage_get_derivative_mapping(h_st, b"wf_custom", ctypes.byref(m))
+        for which, f in (("d_extinction", f_ext), ("d_ssa", f_ssa)):
+            ptr = dp()
+            getattr(L, f"sk_deriv_mapping_get_{which}")(m, ctypes.byref(ptr))
+            np.ctypeslib.as_array(ptr, shape=(ngrid * nw,))[:] = f.T.reshape(-1)   # [wavel][location]
+        L.sk_deriv_mapping_set_interpolator.argtypes = [vp, dp, ctypes.c_int, ctypes.c_int]
+        assert L.sk_deriv_mapping_set_interpolator(m, interp.ctypes.data_as(dp), ngrid, nout) == 0
+        L.sk_deriv_mapping_set_log_radiance_space.argtypes = [vp, ctypes.c_int]
+        assert L.sk_deriv_mapping_set_log_radiance_space(m, 1) == 0
+        out["wf_custom"] = np.zeros((nout, nw, nlos, 1))
+        keep["mem"] = out["wf_custom"]
+        L.sk_output_assign_derivative_memory(h_out, b"wf_custom", out["wf_custom"].ctypes.data_as(dp), nw * nlos, 1, nout)
+
+    atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=True)
+    atmosphere.storage.total_extinction[:] = s["extinction"]
+    atmosphere.storage.ssa[:] = s["ssa"]
+    atmosphere.leg_coeff.a1[:] = s["leg"]
+    atmosphere.surface.albedo[:] = s["albedo"]
+    res = engine.calculate_radiance(atmosphere, as_dataset=False, _mapping_hook=hook)
+    native = f_ext[:, :, None] * res["wf_extinction"][..., 0] + f_ssa[:, :, None] * res["wf_ssa"][..., 0]   # [ngrid, nw, nlos]
+    want = np.einsum("qj,qwl->jwl", interp, native) / res["radiance"][None, :, :, 0]
+    np.testing.assert_allclose(res["wf_custom"][..., 0], want, rtol=1e-12, atol=1e-300)
