@@ -1,19 +1,20 @@
 // TEST INFRASTRUCTURE ONLY -- CPU oracle for the DISCO (discrete ordinates) hot path.
 //
-// A plain C++ restatement of the reference's per-wavelength scalar (NSTOKES=1) DISCO solver
-// with its dense forward-mode linearization, used ONLY by tests/, __graft_entry__.smoke()
+// A plain C++ restatement of the reference's per-wavelength DISCO solver (NSTOKES = 1 and the polarised
+// NSTOKES = 3 form: n = 3 N rows per hemisphere, index r = 3*stream + stokes) with its dense forward-mode linearization, used ONLY by tests/, __graft_entry__.smoke()
 // and bench.py's cpu_baseline leg.  The product (HIP) path never includes this file.
 //
 // Parity status: PINNED.  Checked against the reference's own known-answer tests
 //   cpp/lib/tests/sktran_disco/legacy/test_scalar.cpp:84-880      (plane parallel, 1e-8)
 //   tests/engine/test_1d_solver_regression.py:112-237             (spherical limb+nadir, 5e-7)
+//   cpp/lib/tests/sktran_disco/legacy/test_vector.cpp:81-314      (NSTOKES=3: scalar equivalence, Siewert, Coulson)
 // see tests/test_oracle_golden.py.
 //
 // Reference files each stage follows (relative to /root/reference):
 //   layer optics + derivative wiring   cpp/lib/sktran_disco/sktran_do_layerarray.cpp:332-477,487-657,729-757
 //   SSA dither                         cpp/lib/sktran_disco/sktran_do_opticallayer.cpp:37-40
 //   beam transmission / secants        cpp/lib/sktran_disco/sktran_do_layerarray.cpp:890-979
-//   S+/S- assembly                     cpp/include/sktran_disco/sktran_do_lpproduct.h:165-263
+//   S+/S- assembly                     cpp/include/sktran_disco/sktran_do_lpproduct.h:22-263 (3x3 Greek-matrix products :38-78)
 //   homogeneous solution               cpp/lib/sktran_disco/sktran_do_rte.cpp:382-553
 //   its linearization                  cpp/lib/sktran_disco/sktran_do_rte.cpp:197-298
 //   Green's function particular sol.   cpp/lib/sktran_disco/sktran_do_rte.cpp:555-580,902-1332
@@ -44,36 +45,40 @@ constexpr double kSSADither = 1e-9;   // sktran_do_specs.h:104
 constexpr double kMinShell = 1e-4;    // MINIMUM_SHELL_SIZE_M
 
 struct AtmosphereView {
-    int ngrid = 0, nwavel = 0, nleg = 0;
+    int ngrid = 0, nwavel = 0, nleg = 0;  // nleg = number of Legendre orders
+    int nstokes = 1;                     // 3: four coefficients (a1, a2, a3, b1) per order, order fastest after the coefficient
     const double* extinction = nullptr;  // [ngrid, nwavel] column-major (location fastest)
     const double* ssa = nullptr;         // [ngrid, nwavel]
-    const double* leg = nullptr;         // [nleg, ngrid, nwavel]
+    const double* leg = nullptr;         // [nleg (* 4), ngrid, nwavel]
     const double* solar_irradiance = nullptr;  // [nwavel] (nullptr -> 1)
     const double* albedo = nullptr;      // [nwavel] Lambertian
     const double* delta_f = nullptr;     // [ngrid, nwavel] delta-M truncation fraction of the (already scaled) storage, or null
     bool derivatives = false;
     double k(int q, int w) const { return extinction[size_t(w) * ngrid + q]; }
     double om(int q, int w) const { return ssa[size_t(w) * ngrid + q]; }
-    double beta(int l, int q, int w) const { return l < nleg ? leg[(size_t(w) * ngrid + q) * nleg + l] : 0.0; }
+    double beta(int l, int q, int w, int c = 0) const {
+        if (l >= nleg) return 0.0;
+        return nstokes == 1 ? leg[(size_t(w) * ngrid + q) * nleg + l] : leg[((size_t(w) * ngrid + q) * nleg + l) * 4 + c];
+    }
 };
 
 // native derivative vector of one (wavelength, los): [0,ngrid) d/dk, [ngrid,2ngrid) d/dssa, [2ngrid] d/dalbedo
 struct Result {
-    std::vector<double> radiance;  // [nlos]
-    std::vector<double> deriv;     // [nlos][nnative]
+    std::vector<double> radiance;  // [nlos][nstokes]
+    std::vector<double> deriv;     // [nlos][nstokes][nnative]
     std::vector<double> los_od;    // [nlos]
     int num_azimuth_used = 0;
 };
 
 class Solver {
     const skgeo::DiscoGeometry& G;
-    const int nstr, N, nlyr, ngrid;
+    const int nstr, N, S, n, nlyr, ngrid;  // n = N * S rows per hemisphere, row r = stream (r / S), Stokes component (r % S)
     int ND = 0;       // DO-internal derivative count
     int nnative = 0;  // native derivative count
     bool include_ss;  // single scatter inside DO (plane parallel only)
 
     // ---- per wavelength layer state
-    std::vector<double> tau, ssa, totext, scatext, od_ceil, od_floor, a;  // a[p*nstr+l]
+    std::vector<double> tau, ssa, totext, scatext, od_ceil, od_floor, a;  // a[(p*nstr+l)*4 + {a1,a2,a3,b1}]
     std::vector<double> sec, dsec, trans, dtrans;                         // dsec[p*ND+d], dtrans[(lev)*ND+d]
     // derivative wiring: DO deriv d -> list of (native idx, weight*extinction)
     struct Wire { int native; double w; };
@@ -81,31 +86,80 @@ class Solver {
     std::vector<int> d_layer, d_kind;  // kind: 0 od, 1 ssa, 2 albedo
     std::vector<int> lstart, nloc;
     double albedo = 0, F0 = 1;
+    // ---- generalized spherical functions packed as [..][l][{P,R,T}]
+    std::vector<double> f_mu, f_csz, f_ang, f_los;
     // ---- per azimuth-order solution
     std::vector<double> eigk, deigk, Wp, Wm, dWp, dWm, Ap, Am, dAp, dAm;
     std::vector<double> Gpt, Gpb, Gmt, Gmb, dGpt, dGpb, dGmt, dGmb;
     std::vector<double> Lc, Mc, dLc, dMc;
     std::vector<double> Splus, Sminus, dSplus, dSminus, Gam, dGam;
     oracle_la::RealEigen eigsolver;
+    oracle_la::FullPivLU fullpiv;
     oracle_la::BandMatrix bvp;
     std::vector<double> rhs;  // [M][1+ND]
     // ---- spherical table
     std::vector<int> point_slot;   // [sza][alt][angle] -> slot or -1
     std::vector<int> ground_slot;  // [sza][angle]
     int npoint = 0, nground = 0;
-    std::vector<double> tab_val;    // [m][slot]  (interior slots then ground slots)
-    std::vector<double> tab_deriv;  // [m][slot][nnative]
+    std::vector<double> tab_val;    // [m][slot][S]  (interior slots then ground slots)
+    std::vector<double> tab_deriv;  // [m][slot][S][nnative]
     std::vector<uint8_t> converged; // [m][slot] (interior only)
     std::vector<uint8_t> filled;    // [m][slot] value/derivative row written for this wavelength
     bool all_converged = false;
 
     inline int nl(int p) const { return nloc[p]; }
-    size_t hidx(int p, int i, int j) const { return (size_t(p) * N + j) * N + i; }          // W(i, solution j)
-    size_t dhidx(int p, int k, int i, int j) const { return ((size_t(p) * 3 + k) * N + j) * N + i; }
+    size_t hidx(int p, int i, int j) const { return (size_t(p) * n + j) * n + i; }          // W(row i, solution j)
+    size_t dhidx(int p, int k, int i, int j) const { return ((size_t(p) * 3 + k) * n + j) * n + i; }
+    double rw(int r) const { return G.wt[r / S]; }
+    double rmu(int r) const { return G.mu[r / S]; }
+    // D = diag(1, 1, -1) per Stokes triple (stokes_negation_factor, sktran_do_polarization_types.h:17-25)
+    double neg(int r) const { return (r % S) >= 2 ? -1.0 : 1.0; }
+    const double* fmu(int m, int i) const { return &f_mu[(size_t(m) * nstr + i) * nstr * 3]; }
+    const double* fcsz(int s, int m) const { return &f_csz[(size_t(s) * nstr + m) * nstr * 3]; }
+    const double* fang(int m, int a_) const { return &f_ang[(size_t(m) * G.nangle + a_) * nstr * 3]; }
+    const double* flos(int j, int m) const { return &f_los[(size_t(j) * nstr + m) * nstr * 3]; }
+    const double* coef(int p, int l) const { return &a[(size_t(p) * nstr + l) * 4]; }
+
+    static void pack(const std::vector<double>& P, const std::vector<double>& R, const std::vector<double>& T, std::vector<double>& out) {
+        out.assign(P.size() * 3, 0.0);
+        for (size_t i = 0; i < P.size(); ++i) {
+            out[3 * i] = P[i];
+            if (!R.empty()) { out[3 * i + 1] = R[i]; out[3 * i + 2] = T[i]; }
+        }
+    }
+
+    // One Legendre order of the (S x S, row-major) product  Pi_l(out) B_l Pi_l(in)  (negation: B_l -> (-1)^(l-m) B_l D)
+    //   lp_triple_product, sktran_do_lpproduct.h:22-79
+    void triple(bool negation, int l, int m, const double* c4, const double* lp1, const double* lp2, double* out) const {
+        double up = 1, lo = 1;
+        if (negation) {
+            lo = -1;
+            if ((l - m) % 2 != 0) { up = -up; lo = -lo; }
+        }
+        const double P1 = lp1[0], P2 = lp2[0];
+        if (S == 1) { out[0] += P1 * P2 * c4[0] * up; return; }
+        const double R1 = lp1[1], T1 = lp1[2], R2 = lp2[1], T2 = lp2[2];
+        const double a1 = c4[0], a2 = c4[1], a3 = c4[2], b1 = c4[3];
+        out[0] += P1 * P2 * a1 * up;
+        out[1] += -1.0 * P1 * R2 * b1 * up;
+        out[2] += 1.0 * P1 * T2 * b1 * up;
+        out[3] += -1.0 * R1 * P2 * b1 * up;
+        out[4] += R1 * R2 * a2 * up + T1 * T2 * a3 * lo;
+        out[5] += -R1 * T2 * a2 * up - T1 * R2 * a3 * lo;
+        out[6] += T1 * P2 * b1 * up;
+        out[7] += -T1 * R2 * a2 * up - R1 * T2 * a3 * lo;
+        out[8] += T1 * T2 * a2 * up + R1 * R2 * a3 * lo;
+    }
+    // sum over l >= m for layer p with function tables lp1/lp2 ([l][3])
+    void triple_sum(bool negation, int m, int p, const double* lp1, const double* lp2, double* out) const {
+        for (int i = 0; i < S * S; ++i) out[i] = 0;
+        for (int l = m; l < nstr; ++l) triple(negation, l, m, coef(p, l), lp1 + 3 * l, lp2 + 3 * l, out);
+    }
 
   public:
     Solver(const skgeo::DiscoGeometry& g, bool derivatives, bool ss_in_do)
-        : G(g), nstr(g.nstr), N(g.nstr / 2), nlyr(g.nlyr), ngrid(g.ngrid), include_ss(ss_in_do) {
+        : G(g), nstr(g.nstr), N(g.nstr / 2), S(g.nstokes), n(g.nstr / 2 * g.nstokes), nlyr(g.nlyr), ngrid(g.ngrid), include_ss(ss_in_do) {
+        if (S != 1 && S != 3) throw std::invalid_argument("NSTOKES must be 1 or 3");
         nnative = derivatives ? 2 * ngrid + 1 : 0;
         lstart.assign(nlyr, 0);
         nloc.assign(nlyr, 0);
@@ -117,21 +171,25 @@ class Solver {
                 ND += nloc[p];
             }
         }
+        pack(G.lp_mu, G.lp_mu_R, G.lp_mu_T, f_mu);
+        pack(G.lp_csz, {}, {}, f_csz);  // only P(mu_0) enters (unpolarised sun: first column of the product)
+        pack(G.lp_angle, G.lp_angle_R, G.lp_angle_T, f_ang);
+        pack(G.lp_los, G.lp_los_R, G.lp_los_T, f_los);
         wires.resize(ND);
         tau.resize(nlyr); ssa.resize(nlyr); totext.resize(nlyr); scatext.resize(nlyr);
-        od_ceil.resize(nlyr); od_floor.resize(nlyr); a.resize(size_t(nlyr) * nstr);
+        od_ceil.resize(nlyr); od_floor.resize(nlyr); a.resize(size_t(nlyr) * nstr * 4);
         sec.resize(nlyr); dsec.resize(size_t(nlyr) * ND); trans.resize(nlyr + 1); dtrans.resize(size_t(nlyr + 1) * ND);
-        eigk.resize(size_t(nlyr) * N); deigk.resize(size_t(nlyr) * 3 * N);
-        Wp.resize(size_t(nlyr) * N * N); Wm.resize(Wp.size());
-        dWp.resize(size_t(nlyr) * 3 * N * N); dWm.resize(dWp.size());
-        Ap.resize(size_t(nlyr) * N); Am.resize(Ap.size()); dAp.resize(size_t(nlyr) * 3 * N); dAm.resize(dAp.size());
-        Gpt.resize(size_t(nlyr) * N); Gpb.resize(Gpt.size()); Gmt.resize(Gpt.size()); Gmb.resize(Gpt.size());
-        dGpt.resize(size_t(nlyr) * ND * N); dGpb.resize(dGpt.size()); dGmt.resize(dGpt.size()); dGmb.resize(dGpt.size());
-        Lc.resize(size_t(nlyr) * N); Mc.resize(Lc.size()); dLc.resize(size_t(nlyr) * ND * N); dMc.resize(dLc.size());
-        Splus.resize(size_t(N) * N); Sminus.resize(Splus.size()); dSplus.resize(3 * Splus.size()); dSminus.resize(dSplus.size());
+        eigk.resize(size_t(nlyr) * n); deigk.resize(size_t(nlyr) * 3 * n);
+        Wp.resize(size_t(nlyr) * n * n); Wm.resize(Wp.size());
+        dWp.resize(size_t(nlyr) * 3 * n * n); dWm.resize(dWp.size());
+        Ap.resize(size_t(nlyr) * n); Am.resize(Ap.size()); dAp.resize(size_t(nlyr) * 3 * n); dAm.resize(dAp.size());
+        Gpt.resize(size_t(nlyr) * n); Gpb.resize(Gpt.size()); Gmt.resize(Gpt.size()); Gmb.resize(Gpt.size());
+        dGpt.resize(size_t(nlyr) * ND * n); dGpb.resize(dGpt.size()); dGmt.resize(dGpt.size()); dGmb.resize(dGpt.size());
+        Lc.resize(size_t(nlyr) * n); Mc.resize(Lc.size()); dLc.resize(size_t(nlyr) * ND * n); dMc.resize(dLc.size());
+        Splus.resize(size_t(n) * n); Sminus.resize(Splus.size()); dSplus.resize(3 * Splus.size()); dSminus.resize(dSplus.size());
         Gam.resize(Splus.size()); dGam.resize(dSplus.size());
-        bvp.resize(nstr * nlyr, 3 * N - 1, 3 * N - 1);
-        rhs.resize(size_t(nstr) * nlyr * (1 + ND));
+        bvp.resize(2 * n * nlyr, 3 * n - 1, 3 * n - 1);
+        rhs.resize(size_t(2 * n) * nlyr * (1 + ND));
         if (G.spherical_pp) {
             point_slot.assign(G.need_point.size(), -1);
             for (size_t i = 0; i < G.need_point.size(); ++i)
@@ -139,38 +197,48 @@ class Solver {
             ground_slot.assign(G.need_ground.size(), -1);
             for (size_t i = 0; i < G.need_ground.size(); ++i)
                 if (G.need_ground[i]) ground_slot[i] = npoint + nground++;
-            tab_val.assign(size_t(nstr) * (npoint + nground), 0.0);
-            tab_deriv.assign(size_t(nstr) * (npoint + nground) * nnative, 0.0);
+            tab_val.assign(size_t(nstr) * (npoint + nground) * S, 0.0);
+            tab_deriv.assign(size_t(nstr) * (npoint + nground) * S * nnative, 0.0);
             converged.assign(size_t(nstr) * npoint, 0);
             filled.assign(size_t(nstr) * (npoint + nground), 0);
         }
     }
     int num_native() const { return nnative; }
+    int num_stokes() const { return S; }
 
   private:
-    double* dG(std::vector<double>& g, int p, int d) { return &g[(size_t(p) * ND + d) * N]; }
-    double* dLM(std::vector<double>& g, int p, int d) { return &g[(size_t(p) * ND + d) * N]; }
+    double* dG(std::vector<double>& g, int p, int d) { return &g[(size_t(p) * ND + d) * n]; }
+    double* dLM(std::vector<double>& g, int p, int d) { return &g[(size_t(p) * ND + d) * n]; }
 
     // ------------------------------------------------------------------ layer optics
     void configure_layers(const AtmosphereView& atm, int w, int szaidx) {
+        if (atm.nstokes != S) throw std::invalid_argument("atmosphere and geometry disagree on NSTOKES");
         double ceiling_depth = 0, floor_depth = 0;
         for (int p = 0; p < nlyr; ++p) {
             double dh = G.ceil_h[p] - G.floor_h[p];
             double od = 0, s = 0;
-            double* ap = &a[size_t(p) * nstr];
-            for (int l = 0; l < nstr; ++l) ap[l] = 0;
+            double* ap = &a[size_t(p) * nstr * 4];
+            for (int l = 0; l < nstr * 4; ++l) ap[l] = 0;
             for (int q = 0; q < ngrid; ++q) {
                 double wt = G.W(p, q);
                 if (wt > 0) {
                     double kext = atm.k(q, w), kscat = atm.om(q, w) * kext;
                     od += kext * wt;
                     s += kscat * wt;
-                    // delta-M: the multiple-scatter expansion drops the truncated forward peak (sktran_do_layerarray.cpp:395-405)
+                    // delta-M: the multiple-scatter expansion drops the truncated forward peak (sktran_do_layerarray.cpp:395-405);
+                    // the a's carry the f subtraction, b1 does not and is stored with its sign flipped (:405-418)
                     const double f = atm.delta_f ? atm.delta_f[size_t(w) * atm.ngrid + q] : 0.0;
-                    for (int l = 0; l < nstr; ++l) ap[l] += wt * kscat * (atm.beta(l, q, w) - (2 * l + 1) * f / (1 - f));
+                    for (int l = 0; l < nstr; ++l) {
+                        ap[4 * l] += wt * kscat * (atm.beta(l, q, w, 0) - (2 * l + 1) * f / (1 - f));
+                        if (S == 3) {
+                            ap[4 * l + 1] += wt * kscat * (atm.beta(l, q, w, 1) - f * (2 * l + 1) / (1 - f));
+                            ap[4 * l + 2] += wt * kscat * (atm.beta(l, q, w, 2) - f * (2 * l + 1) / (1 - f));
+                            ap[4 * l + 3] += -wt * kscat * atm.beta(l, q, w, 3);
+                        }
+                    }
                 }
             }
-            if (s > 0) for (int l = 0; l < nstr; ++l) ap[l] /= s;
+            if (s > 0) for (int l = 0; l < nstr * 4; ++l) ap[l] /= s;
             else ap[0] = 0;
             s /= od;
             od *= dh;
@@ -252,122 +320,123 @@ class Solver {
 
     // ------------------------------------------------------------------ homogeneous solution
     void solve_homogeneous(int m, int p) {
-        const double* ap = &a[size_t(p) * nstr];
         const int nk = nl(p);
         const double om = ssa[p];
+        double spb[9], etab[9];
         for (int i = 0; i < N; ++i)
             for (int j = 0; j < N; ++j) {
-                double sp = 0, eta = 0;
-                for (int l = m; l < nstr; ++l) {
-                    double t = G.lpmu(m, i, l) * G.lpmu(m, j, l) * ap[l];
-                    sp += t;
-                    eta += ((l - m) % 2 != 0) ? -t : t;
-                }
-                double fac = -0.5 * G.wt[j] / G.mu[i];
-                sp *= fac;
-                eta *= fac;
-                for (int k = 0; k < nk; ++k) {
-                    // d_legendre = 0 for the od/ssa/albedo derivatives
-                    double dsp = sp * d_ssa(k), deta = eta * d_ssa(k);
-                    dSminus[(size_t(k) * N + i) * N + j] = dsp - deta;
-                    dSplus[(size_t(k) * N + i) * N + j] = dsp + deta;
-                }
-                sp *= om;
-                eta *= om;
-                if (i == j) sp += 1 / G.mu[i];
-                Sminus[size_t(i) * N + j] = sp - eta;
-                Splus[size_t(i) * N + j] = sp + eta;
+                triple_sum(false, m, p, fmu(m, i), fmu(m, j), spb);
+                triple_sum(true, m, p, fmu(m, i), fmu(m, j), etab);
+                const double fac = -0.5 * G.wt[j] / G.mu[i];
+                for (int s1 = 0; s1 < S; ++s1)
+                    for (int s2 = 0; s2 < S; ++s2) {
+                        const int r = i * S + s1, c = j * S + s2;
+                        double sp = spb[s1 * S + s2] * fac, eta = etab[s1 * S + s2] * fac;
+                        for (int k = 0; k < nk; ++k) {
+                            // d_legendre = 0 for the od/ssa/albedo derivatives
+                            double dsp = sp * d_ssa(k), deta = eta * d_ssa(k);
+                            dSminus[(size_t(k) * n + r) * n + c] = dsp - deta;
+                            dSplus[(size_t(k) * n + r) * n + c] = dsp + deta;
+                        }
+                        sp *= om;
+                        eta *= om;
+                        if (r == c) sp += 1 / G.mu[i];
+                        Sminus[size_t(r) * n + c] = sp - eta;
+                        Splus[size_t(r) * n + c] = sp + eta;
+                    }
             }
         // eigmtx = S- S+
-        for (int i = 0; i < N; ++i)
-            for (int j = 0; j < N; ++j) {
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
                 double s = 0;
-                for (int k = 0; k < N; ++k) s += Sminus[size_t(i) * N + k] * Splus[size_t(k) * N + j];
-                Gam[size_t(i) * N + j] = s;
+                for (int k = 0; k < n; ++k) s += Sminus[size_t(i) * n + k] * Splus[size_t(k) * n + j];
+                Gam[size_t(i) * n + j] = s;
             }
         for (int k = 0; k < nk; ++k) {
-            const double* dsm = &dSminus[size_t(k) * N * N];
-            const double* dsp = &dSplus[size_t(k) * N * N];
-            double* dg = &dGam[size_t(k) * N * N];
-            for (int i = 0; i < N; ++i)
-                for (int j = 0; j < N; ++j) {
+            const double* dsm = &dSminus[size_t(k) * n * n];
+            const double* dsp = &dSplus[size_t(k) * n * n];
+            double* dg = &dGam[size_t(k) * n * n];
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
                     double s = 0;
-                    for (int r = 0; r < N; ++r) s += dsm[size_t(i) * N + r] * Splus[size_t(r) * N + j] + Sminus[size_t(i) * N + r] * dsp[size_t(r) * N + j];
-                    dg[size_t(i) * N + j] = s;
+                    for (int r = 0; r < n; ++r) s += dsm[size_t(i) * n + r] * Splus[size_t(r) * n + j] + Sminus[size_t(i) * n + r] * dsp[size_t(r) * n + j];
+                    dg[size_t(i) * n + j] = s;
                 }
         }
-        std::vector<double> wr(N), wi(N), X(size_t(N) * N), MXm(size_t(N) * N);
-        if (!eigsolver.compute(N, Gam.data(), wr.data(), wi.data(), X.data())) {
+        std::vector<double> wr(n), wi(n), X(size_t(n) * n), MXm(size_t(n) * n);
+        if (!eigsolver.compute(n, Gam.data(), wr.data(), wi.data(), X.data())) {
             // fallback used by the reference: diagonal entries / identity vectors
-            for (int i = 0; i < N; ++i) {
-                wr[i] = Gam[size_t(i) * N + i];
-                for (int j = 0; j < N; ++j) X[size_t(i) * N + j] = (i == j);
+            for (int i = 0; i < n; ++i) {
+                wr[i] = Gam[size_t(i) * n + i];
+                for (int j = 0; j < n; ++j) X[size_t(i) * n + j] = (i == j);
             }
         }
-        for (int j = 0; j < N; ++j) {
+        for (int j = 0; j < n; ++j) {
             double nrm = 0;
-            for (int i = 0; i < N; ++i) nrm += X[size_t(i) * N + j] * X[size_t(i) * N + j];
+            for (int i = 0; i < n; ++i) nrm += X[size_t(i) * n + j] * X[size_t(i) * n + j];
             nrm = std::sqrt(nrm);
-            for (int i = 0; i < N; ++i) X[size_t(i) * N + j] /= nrm;
+            for (int i = 0; i < n; ++i) X[size_t(i) * n + j] /= nrm;
         }
-        for (int i = 0; i < N; ++i)
-            for (int j = 0; j < N; ++j) {
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
                 double s = 0;
-                for (int r = 0; r < N; ++r) s += Splus[size_t(i) * N + r] * X[size_t(r) * N + j];
-                MXm[size_t(i) * N + j] = s;
+                for (int r = 0; r < n; ++r) s += Splus[size_t(i) * n + r] * X[size_t(r) * n + j];
+                MXm[size_t(i) * n + j] = s;
             }
-        double* kk = &eigk[size_t(p) * N];
-        for (int j = 0; j < N; ++j) {
-            if (wr[j] <= 0) throw std::runtime_error("An homogeneous solution was found to be imaginary");
+        double* kk = &eigk[size_t(p) * n];
+        for (int j = 0; j < n; ++j) {
+            if (wr[j] <= 0 && S == 1) throw std::runtime_error("An homogeneous solution was found to be imaginary");
             kk[j] = std::sqrt(std::abs(wr[j]));
-            for (int i = 0; i < N; ++i) {
-                Wp[hidx(p, i, j)] = 0.5 * (X[size_t(i) * N + j] + MXm[size_t(i) * N + j] / kk[j]);
-                Wm[hidx(p, i, j)] = 0.5 * (X[size_t(i) * N + j] - MXm[size_t(i) * N + j] / kk[j]);
+            for (int i = 0; i < n; ++i) {
+                Wp[hidx(p, i, j)] = 0.5 * (X[size_t(i) * n + j] + MXm[size_t(i) * n + j] / kk[j]);
+                Wm[hidx(p, i, j)] = 0.5 * (X[size_t(i) * n + j] - MXm[size_t(i) * n + j] / kk[j]);
             }
         }
         if (nk == 0) return;
-        // linearization: bordered (N+1) systems
-        const int n1 = N + 1;
+        // linearization: bordered (n+1) systems; partial pivoting for NSTOKES = 1, complete pivoting for 3 (sktran_do_rte.cpp:249-263)
+        const int n1 = n + 1;
         std::vector<double> lhs(size_t(n1) * n1), sol(n1);
         std::vector<int> piv(n1);
-        for (int j = 0; j < N; ++j) {
+        for (int j = 0; j < n; ++j) {
             bool factored = false;
             for (int k = 0; k < nk; ++k) {
-                const double* dg = &dGam[size_t(k) * N * N];
+                const double* dg = &dGam[size_t(k) * n * n];
                 bool zero = true;
-                for (int i = 0; i < N; ++i) {
+                for (int i = 0; i < n; ++i) {
                     double s = 0;
-                    for (int r = 0; r < N; ++r) s += dg[size_t(i) * N + r] * X[size_t(r) * N + j];
+                    for (int r = 0; r < n; ++r) s += dg[size_t(i) * n + r] * X[size_t(r) * n + j];
                     sol[i] = -s;
                     if (sol[i] != 0.0) zero = false;
                 }
-                sol[N] = 0;
+                sol[n] = 0;
                 // the reference checks the whole RHS block; with od/albedo columns identically zero this is per column here
                 if (zero) {
-                    for (int i = 0; i <= N; ++i) sol[i] = 0;
+                    for (int i = 0; i <= n; ++i) sol[i] = 0;
                 } else {
                     if (!factored) {
-                        for (int r = 0; r < N; ++r) {
-                            for (int cidx = 0; cidx < N; ++cidx) lhs[size_t(r) * n1 + cidx] = Gam[size_t(r) * N + cidx];
+                        for (int r = 0; r < n; ++r) {
+                            for (int cidx = 0; cidx < n; ++cidx) lhs[size_t(r) * n1 + cidx] = Gam[size_t(r) * n + cidx];
                             lhs[size_t(r) * n1 + r] -= wr[j];
-                            lhs[size_t(r) * n1 + N] = -2 * kk[j] * X[size_t(r) * N + j];
+                            lhs[size_t(r) * n1 + n] = -2 * kk[j] * X[size_t(r) * n + j];
                         }
-                        for (int cidx = 0; cidx < N; ++cidx) lhs[size_t(N) * n1 + cidx] = X[size_t(cidx) * N + j];
-                        lhs[size_t(N) * n1 + N] = 0;
-                        oracle_la::lu_factor(n1, lhs.data(), piv.data());
+                        for (int cidx = 0; cidx < n; ++cidx) lhs[size_t(n) * n1 + cidx] = X[size_t(cidx) * n + j];
+                        lhs[size_t(n) * n1 + n] = 0;
+                        if (S == 1) oracle_la::lu_factor(n1, lhs.data(), piv.data());
+                        else fullpiv.compute(n1, lhs.data());
                         factored = true;
                     }
-                    oracle_la::lu_solve(n1, lhs.data(), piv.data(), sol.data());
+                    if (S == 1) oracle_la::lu_solve(n1, lhs.data(), piv.data(), sol.data());
+                    else fullpiv.solve(sol.data());
                 }
-                double dk = sol[N];
-                deigk[(size_t(p) * 3 + k) * N + j] = dk;
-                const double* dsp = &dSplus[size_t(k) * N * N];
-                for (int i = 0; i < N; ++i) {
+                double dk = sol[n];
+                deigk[(size_t(p) * 3 + k) * n + j] = dk;
+                const double* dsp = &dSplus[size_t(k) * n * n];
+                for (int i = 0; i < n; ++i) {
                     double t1 = 0, t2 = 0, t3 = 0;
-                    for (int r = 0; r < N; ++r) {
-                        t1 += Splus[size_t(i) * N + r] * X[size_t(r) * N + j];
-                        t2 += dsp[size_t(i) * N + r] * X[size_t(r) * N + j];
-                        t3 += Splus[size_t(i) * N + r] * sol[r];
+                    for (int r = 0; r < n; ++r) {
+                        t1 += Splus[size_t(i) * n + r] * X[size_t(r) * n + j];
+                        t2 += dsp[size_t(i) * n + r] * X[size_t(r) * n + j];
+                        t3 += Splus[size_t(i) * n + r] * sol[r];
                     }
                     double first = 0.5 * ((-dk / wr[j]) * t1 + (1 / kk[j]) * t2);
                     dWp[dhidx(p, k, i, j)] = first + 0.5 * (sol[i] + t3 / kk[j]);
@@ -380,38 +449,37 @@ class Solver {
     // ------------------------------------------------------------------ Green's function particular solution
     void solve_particular(int m, int p, int szaidx) {
         const int nk = nl(p), ls = lstart[p];
-        const double* ap = &a[size_t(p) * nstr];
         const double om = ssa[p];
-        std::vector<double> Qp(N), Qm(N), dQp(size_t(3) * N), dQm(size_t(3) * N);
+        std::vector<double> Qp(n), Qm(n), dQp(size_t(3) * n), dQm(size_t(3) * n);
         bool allzero = true;
+        double bneg[9], bpos[9];
         for (int i = 0; i < N; ++i) {
-            double sneg = 0, spos = 0;
-            for (int l = m; l < nstr; ++l) {
-                double t = ap[l] * G.lpmu(m, i, l) * G.lpcsz(szaidx, m, l);
-                spos += t;
-                sneg += ((l - m) % 2 != 0) ? -t : t;
+            // first column of the product with the unpolarised sun (single_scat_st, sktran_do_lpproduct.h:339-384)
+            triple_sum(true, m, p, fmu(m, i), fcsz(szaidx, m), bneg);
+            triple_sum(false, m, p, fmu(m, i), fcsz(szaidx, m), bpos);
+            const double factor = (2 - (m == 0 ? 1 : 0)) * (1.0 / (4.0 * kPi)) * G.wt[i];
+            for (int s1 = 0; s1 < S; ++s1) {
+                const int r = i * S + s1;
+                double sneg = bneg[s1 * S] * factor, spos = bpos[s1 * S] * factor;
+                for (int k = 0; k < nk; ++k) {
+                    dQm[size_t(k) * n + r] = sneg * d_ssa(k);
+                    dQp[size_t(k) * n + r] = spos * d_ssa(k);
+                    if (dQm[size_t(k) * n + r] != 0 || dQp[size_t(k) * n + r] != 0) allzero = false;
+                }
+                Qm[r] = sneg * om;
+                Qp[r] = spos * om;
+                if (Qm[r] != 0 || Qp[r] != 0) allzero = false;
             }
-            double factor = (2 - (m == 0 ? 1 : 0)) * (1.0 / (4.0 * kPi)) * G.wt[i];
-            sneg *= factor;
-            spos *= factor;
-            for (int k = 0; k < nk; ++k) {
-                dQm[size_t(k) * N + i] = sneg * d_ssa(k);
-                dQp[size_t(k) * N + i] = spos * d_ssa(k);
-                if (dQm[size_t(k) * N + i] != 0 || dQp[size_t(k) * N + i] != 0) allzero = false;
-            }
-            Qm[i] = sneg * om;
-            Qp[i] = spos * om;
-            if (Qm[i] != 0 || Qp[i] != 0) allzero = false;
         }
-        double* gpt = &Gpt[size_t(p) * N]; double* gpb = &Gpb[size_t(p) * N];
-        double* gmt = &Gmt[size_t(p) * N]; double* gmb = &Gmb[size_t(p) * N];
-        for (int i = 0; i < N; ++i) { gpt[i] = gpb[i] = gmt[i] = gmb[i] = 0; Ap[size_t(p) * N + i] = Am[size_t(p) * N + i] = 0; }
-        for (int k = 0; k < 3; ++k) for (int i = 0; i < N; ++i) dAp[(size_t(p) * 3 + k) * N + i] = dAm[(size_t(p) * 3 + k) * N + i] = 0;
+        double* gpt = &Gpt[size_t(p) * n]; double* gpb = &Gpb[size_t(p) * n];
+        double* gmt = &Gmt[size_t(p) * n]; double* gmb = &Gmb[size_t(p) * n];
+        for (int i = 0; i < n; ++i) { gpt[i] = gpb[i] = gmt[i] = gmb[i] = 0; Ap[size_t(p) * n + i] = Am[size_t(p) * n + i] = 0; }
+        for (int k = 0; k < 3; ++k) for (int i = 0; i < n; ++i) dAp[(size_t(p) * 3 + k) * n + i] = dAm[(size_t(p) * 3 + k) * n + i] = 0;
         if (ND) {
-            std::memset(dG(dGpt, p, 0), 0, sizeof(double) * ND * N);
-            std::memset(dG(dGpb, p, 0), 0, sizeof(double) * ND * N);
-            std::memset(dG(dGmt, p, 0), 0, sizeof(double) * ND * N);
-            std::memset(dG(dGmb, p, 0), 0, sizeof(double) * ND * N);
+            std::memset(dG(dGpt, p, 0), 0, sizeof(double) * ND * n);
+            std::memset(dG(dGpb, p, 0), 0, sizeof(double) * ND * n);
+            std::memset(dG(dGmt, p, 0), 0, sizeof(double) * ND * n);
+            std::memset(dG(dGmb, p, 0), 0, sizeof(double) * ND * n);
         }
         if (allzero) return;
         const double T = trans[p], sc = sec[p], th = tau[p];
@@ -419,19 +487,19 @@ class Solver {
         const double* dsc = &dsec[size_t(p) * ND];
         const double exp_ts = std::exp(-th * sc);
         std::vector<double> dCp(ND), dCm(ND);
-        for (int i = 0; i < N; ++i) {  // solution index
+        for (int i = 0; i < n; ++i) {  // solution index
             double norm = 0, Apv = 0, Amv = 0;
             double dnorm[3] = {0, 0, 0}, dApv[3] = {0, 0, 0}, dAmv[3] = {0, 0, 0};
-            for (int j = 0; j < N; ++j) {
+            for (int j = 0; j < n; ++j) {
                 double hp = Wp[hidx(p, j, i)], hm = Wm[hidx(p, j, i)];
-                norm += G.wt[j] * G.mu[j] * (hp * hp - hm * hm);
+                norm += rw(j) * rmu(j) * (hp * hp - hm * hm);
                 Apv += Qp[j] * hp + Qm[j] * hm;
                 Amv += Qm[j] * hp + Qp[j] * hm;
                 for (int k = 0; k < nk; ++k) {
                     double dhp = dWp[dhidx(p, k, j, i)], dhm = dWm[dhidx(p, k, j, i)];
-                    dnorm[k] += G.wt[j] * G.mu[j] * (2.0 * dhp * hp - 2.0 * dhm * hm);
-                    dApv[k] += Qp[j] * dhp + dQp[size_t(k) * N + j] * hp + Qm[j] * dhm + dQm[size_t(k) * N + j] * hm;
-                    dAmv[k] += Qm[j] * dhp + dQm[size_t(k) * N + j] * hp + Qp[j] * dhm + dQp[size_t(k) * N + j] * hm;
+                    dnorm[k] += rw(j) * rmu(j) * (2.0 * dhp * hp - 2.0 * dhm * hm);
+                    dApv[k] += Qp[j] * dhp + dQp[size_t(k) * n + j] * hp + Qm[j] * dhm + dQm[size_t(k) * n + j] * hm;
+                    dAmv[k] += Qm[j] * dhp + dQm[size_t(k) * n + j] * hp + Qp[j] * dhm + dQp[size_t(k) * n + j] * hm;
                 }
             }
             Apv /= norm;
@@ -439,12 +507,12 @@ class Solver {
             for (int k = 0; k < nk; ++k) {
                 dApv[k] = dApv[k] / norm - dnorm[k] * Apv / norm;
                 dAmv[k] = dAmv[k] / norm - dnorm[k] * Amv / norm;
-                dAp[(size_t(p) * 3 + k) * N + i] = dApv[k];
-                dAm[(size_t(p) * 3 + k) * N + i] = dAmv[k];
+                dAp[(size_t(p) * 3 + k) * n + i] = dApv[k];
+                dAm[(size_t(p) * 3 + k) * n + i] = dAmv[k];
             }
-            Ap[size_t(p) * N + i] = Apv;
-            Am[size_t(p) * N + i] = Amv;
-            const double ev = eigk[size_t(p) * N + i];
+            Ap[size_t(p) * n + i] = Apv;
+            Am[size_t(p) * n + i] = Amv;
+            const double ev = eigk[size_t(p) * n + i];
             const double exp_te = std::exp(-th * ev);
             double Cp, Cm;
             if (std::abs(sc - ev) > kGreensEps) {
@@ -453,7 +521,7 @@ class Solver {
                 for (int d = 0; d < ND; ++d)
                     dCp[d] = (exp_te - exp_ts) / den * dT[d] + dsc[d] * (T * th * exp_ts - Cp) / den;
                 for (int k = 0; k < nk; ++k) {
-                    double dk = deigk[(size_t(p) * 3 + k) * N + i];
+                    double dk = deigk[(size_t(p) * 3 + k) * n + i];
                     dCp[ls + k] += dk / den * (Cp - T * th * exp_te);
                     dCp[ls + k] -= d_od(k) * T / den * (ev * exp_te - sc * exp_ts);
                 }
@@ -462,7 +530,7 @@ class Solver {
                 for (int d = 0; d < ND; ++d)
                     dCp[d] = exp_te * th * (1 - th / 2 * (sc - ev)) * dT[d] + -1.0 * dsc[d] * th / 2.0 * th * T * exp_te;
                 for (int k = 0; k < nk; ++k) {
-                    double dk = deigk[(size_t(p) * 3 + k) * N + i];
+                    double dk = deigk[(size_t(p) * 3 + k) * n + i];
                     dCp[ls + k] += dk * Cp * -1.0 * th;
                     dCp[ls + k] += dk * th / 2.0 * th * T * exp_te;
                     dCp[ls + k] += d_od(k) * T * exp_te * (1 - th * (sc - ev));
@@ -476,7 +544,7 @@ class Solver {
                 for (int d = 0; d < ND; ++d)
                     dCm[d] = (1 - exp_ts * exp_te) / den * dT[d] + dsc[d] / den * (T * th * exp_sum - Cm);
                 for (int k = 0; k < nk; ++k) {
-                    double dk = deigk[(size_t(p) * 3 + k) * N + i];
+                    double dk = deigk[(size_t(p) * 3 + k) * n + i];
                     dCm[ls + k] += dk / den * (T * th * exp_sum - Cm);
                     dCm[ls + k] += d_od(k) * T * exp_sum;
                 }
@@ -485,29 +553,30 @@ class Solver {
                 for (int d = 0; d < ND; ++d)
                     dCm[d] = dT[d] * th * (1 - th / 2 * (sc + ev)) + dsc[d] * -1.0 * th / 2 * th * T;
                 for (int k = 0; k < nk; ++k) {
-                    double dk = deigk[(size_t(p) * 3 + k) * N + i];
+                    double dk = deigk[(size_t(p) * 3 + k) * n + i];
                     dCm[ls + k] += dk * T * th * th / 2 * -1.0;
                     dCm[ls + k] += d_od(k) * T * (1 - th * (sc + ev));
                 }
             }
-            for (int j = 0; j < N; ++j) {
+            for (int j = 0; j < n; ++j) {
+                const double ng = neg(j);  // G- carries D (sktran_do_rte.cpp:1239-1251)
                 double hp = Wp[hidx(p, j, i)], hm = Wm[hidx(p, j, i)];
                 gpt[j] += Amv * Cm * hm;
-                gmt[j] += Amv * Cm * hp;
+                gmt[j] += ng * Amv * Cm * hp;
                 gpb[j] += Apv * Cp * hp;
-                gmb[j] += Apv * Cp * hm;
+                gmb[j] += ng * Apv * Cp * hm;
                 for (int d = 0; d < ND; ++d) {
                     dG(dGpt, p, d)[j] += Amv * hm * dCm[d];
-                    dG(dGmt, p, d)[j] += Amv * hp * dCm[d];
+                    dG(dGmt, p, d)[j] += ng * Amv * hp * dCm[d];
                     dG(dGpb, p, d)[j] += Apv * hp * dCp[d];
-                    dG(dGmb, p, d)[j] += Apv * hm * dCp[d];
+                    dG(dGmb, p, d)[j] += ng * Apv * hm * dCp[d];
                 }
                 for (int k = 0; k < nk; ++k) {
                     double dhp = dWp[dhidx(p, k, j, i)], dhm = dWm[dhidx(p, k, j, i)];
                     dG(dGpt, p, ls + k)[j] += dAmv[k] * Cm * hm + Amv * Cm * dhm;
-                    dG(dGmt, p, ls + k)[j] += dAmv[k] * Cm * hp + Amv * Cm * dhp;
+                    dG(dGmt, p, ls + k)[j] += ng * (dAmv[k] * Cm * hp + Amv * Cm * dhp);
                     dG(dGpb, p, ls + k)[j] += dApv[k] * Cp * hp + Apv * Cp * dhp;
-                    dG(dGmb, p, ls + k)[j] += dApv[k] * Cp * hm + Apv * Cp * dhm;
+                    dG(dGmb, p, ls + k)[j] += ng * (dApv[k] * Cp * hm + Apv * Cp * dhm);
                 }
             }
         }
@@ -515,74 +584,79 @@ class Solver {
 
     // ------------------------------------------------------------------ boundary value problem
     double rho(int m) const { return m == 0 ? albedo : 0.0; }  // Lambertian, max_azimuthal_order == 1
+    // the Lambertian surface reflects the intensity only, into the intensity only (v_plus/v_minus, sktran_do_rte.h:116-150)
+    bool refl_row(int r) const { return (r % S) == 0; }
 
     void solve_bvp(int m) {
-        const int M = nstr * nlyr, n2 = nstr, nr = 1 + ND;
+        const int n2 = 2 * n, M = n2 * nlyr, nr = 1 + ND;
         bvp.set_zero();
         std::fill(rhs.begin(), rhs.end(), 0.0);
-        auto E = [&](int p, int j) { return std::exp(-std::abs(eigk[size_t(p) * N + j]) * tau[p]); };
+        auto E = [&](int p, int j) { return std::exp(-std::abs(eigk[size_t(p) * n + j]) * tau[p]); };
         const bool refl = (m < 1);
         const double kd = (m == 0) ? 2.0 : 1.0;
         // TOA
-        for (int i = 0; i < N; ++i) {
-            for (int j = 0; j < N; ++j) {
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < n; ++j) {
                 bvp.at(i, j) = Wp[hidx(0, i, j)];
-                bvp.at(i, j + N) = Wm[hidx(0, i, j)] * E(0, j);
+                bvp.at(i, j + n) = Wm[hidx(0, i, j)] * E(0, j);
             }
             rhs[size_t(i) * nr] = -Gpt[i];
             for (int d = 0; d < ND; ++d) rhs[size_t(i) * nr + 1 + d] = -dG(dGpt, 0, d)[i];
         }
-        // continuity
+        // continuity (the "minus" rows carry D, sktran_do_rte.cpp:1971-1990)
         for (int p = 1; p < nlyr; ++p) {
-            int r0 = N + (p - 1) * n2, cu = (p - 1) * n2, cl = p * n2;
-            for (int i = 0; i < N; ++i) {
-                for (int j = 0; j < N; ++j) {
+            int r0 = n + (p - 1) * n2, cu = (p - 1) * n2, cl = p * n2;
+            for (int i = 0; i < n; ++i) {
+                const double ng = neg(i);
+                for (int j = 0; j < n; ++j) {
                     double eu = E(p - 1, j), el = E(p, j);
-                    bvp.at(r0 + i + N, cu + j) = Wp[hidx(p - 1, i, j)] * eu;
-                    bvp.at(r0 + i + N, cl + j) = -Wp[hidx(p, i, j)];
-                    bvp.at(r0 + i, cu + j) = Wm[hidx(p - 1, i, j)] * eu;
-                    bvp.at(r0 + i, cl + j) = -Wm[hidx(p, i, j)];
-                    bvp.at(r0 + i + N, cu + N + j) = Wm[hidx(p - 1, i, j)];
-                    bvp.at(r0 + i + N, cl + N + j) = -Wm[hidx(p, i, j)] * el;
-                    bvp.at(r0 + i, cu + N + j) = Wp[hidx(p - 1, i, j)];
-                    bvp.at(r0 + i, cl + N + j) = -Wp[hidx(p, i, j)] * el;
+                    bvp.at(r0 + i + n, cu + j) = Wp[hidx(p - 1, i, j)] * eu;
+                    bvp.at(r0 + i + n, cl + j) = -Wp[hidx(p, i, j)];
+                    bvp.at(r0 + i, cu + j) = ng * Wm[hidx(p - 1, i, j)] * eu;
+                    bvp.at(r0 + i, cl + j) = -ng * Wm[hidx(p, i, j)];
+                    bvp.at(r0 + i + n, cu + n + j) = Wm[hidx(p - 1, i, j)];
+                    bvp.at(r0 + i + n, cl + n + j) = -Wm[hidx(p, i, j)] * el;
+                    bvp.at(r0 + i, cu + n + j) = ng * Wp[hidx(p - 1, i, j)];
+                    bvp.at(r0 + i, cl + n + j) = -ng * Wp[hidx(p, i, j)] * el;
                 }
-                rhs[size_t(r0 + i) * nr] = -Gmb[size_t(p - 1) * N + i] + Gmt[size_t(p) * N + i];
-                rhs[size_t(r0 + i + N) * nr] = -Gpb[size_t(p - 1) * N + i] + Gpt[size_t(p) * N + i];
+                rhs[size_t(r0 + i) * nr] = -Gmb[size_t(p - 1) * n + i] + Gmt[size_t(p) * n + i];
+                rhs[size_t(r0 + i + n) * nr] = -Gpb[size_t(p - 1) * n + i] + Gpt[size_t(p) * n + i];
                 for (int d = 0; d < ND; ++d) {
                     rhs[size_t(r0 + i) * nr + 1 + d] = dG(dGmt, p, d)[i] - dG(dGmb, p - 1, d)[i];
-                    rhs[size_t(r0 + i + N) * nr + 1 + d] = dG(dGpt, p, d)[i] - dG(dGpb, p - 1, d)[i];
+                    rhs[size_t(r0 + i + n) * nr + 1 + d] = dG(dGpt, p, d)[i] - dG(dGpb, p - 1, d)[i];
                 }
             }
         }
         // ground
         {
-            const int p = nlyr - 1, r0 = M - N, c0 = p * n2;
-            for (int i = 0; i < N; ++i) {
-                for (int j = 0; j < N; ++j) {
+            const int p = nlyr - 1, r0 = M - n, c0 = p * n2;
+            for (int i = 0; i < n; ++i) {
+                const double ng = neg(i);
+                const bool rr = refl && refl_row(i);
+                for (int j = 0; j < n; ++j) {
                     double vm = Wm[hidx(p, i, j)], vp = Wp[hidx(p, i, j)];
-                    if (refl)
+                    if (rr)
                         for (int s = 0; s < N; ++s) {
-                            vm -= kd * rho(m) * G.wt[s] * G.mu[s] * Wp[hidx(p, s, j)];
-                            vp -= kd * rho(m) * G.wt[s] * G.mu[s] * Wm[hidx(p, s, j)];
+                            vm -= kd * rho(m) * G.wt[s] * G.mu[s] * Wp[hidx(p, s * S, j)];
+                            vp -= kd * rho(m) * G.wt[s] * G.mu[s] * Wm[hidx(p, s * S, j)];
                         }
-                    bvp.at(r0 + i, c0 + j) = vm * E(p, j);
-                    bvp.at(r0 + i, c0 + N + j) = vp;
+                    bvp.at(r0 + i, c0 + j) = ng * vm * E(p, j);
+                    bvp.at(r0 + i, c0 + n + j) = ng * vp;
                 }
-                double direct = 0, um = Gmb[size_t(p) * N + i];
-                if (refl) {
+                double direct = 0, um = Gmb[size_t(p) * n + i];
+                if (rr) {
                     direct = G.csz[cur_sza] * rho(m) / kPi * trans[nlyr];
-                    for (int s = 0; s < N; ++s) um -= kd * rho(m) * G.wt[s] * G.mu[s] * Gpb[size_t(p) * N + s];
+                    for (int s = 0; s < N; ++s) um -= kd * rho(m) * G.wt[s] * G.mu[s] * Gpb[size_t(p) * n + s * S];
                 }
                 rhs[size_t(r0 + i) * nr] = direct - um;
                 for (int d = 0; d < ND; ++d) {
                     double dalb = (d_layer[d] == p) ? d_alb(d_kind[d]) : 0.0;
                     double ddir = 0, dum = dG(dGmb, p, d)[i];
-                    if (refl) {
+                    if (rr) {
                         ddir = G.csz[cur_sza] * rho(m) / kPi * dtrans[size_t(nlyr) * ND + d] + G.csz[cur_sza] * dalb / kPi * trans[nlyr];
                         for (int s = 0; s < N; ++s) {
-                            dum -= kd * rho(m) * G.wt[s] * G.mu[s] * dG(dGpb, p, d)[s];
-                            dum -= kd * dalb * G.wt[s] * G.mu[s] * Gpb[size_t(p) * N + s];
+                            dum -= kd * rho(m) * G.wt[s] * G.mu[s] * dG(dGpb, p, d)[s * S];
+                            dum -= kd * dalb * G.wt[s] * G.mu[s] * Gpb[size_t(p) * n + s * S];
                         }
                     }
                     rhs[size_t(r0 + i) * nr + 1 + d] = ddir - dum;
@@ -596,76 +670,77 @@ class Solver {
         for (int r = 0; r < M; ++r) x[r] = rhs[size_t(r) * nr];
         bvp.solve(x.data(), 1);
         for (int p = 0; p < nlyr; ++p)
-            for (int j = 0; j < N; ++j) {
-                Lc[size_t(p) * N + j] = x[size_t(p) * n2 + j];
-                Mc[size_t(p) * N + j] = x[size_t(p) * n2 + N + j];
+            for (int j = 0; j < n; ++j) {
+                Lc[size_t(p) * n + j] = x[size_t(p) * n2 + j];
+                Mc[size_t(p) * n + j] = x[size_t(p) * n2 + n + j];
             }
         if (ND == 0) return;
         // rhs_d -= dA_d x   (dA_d only touches the columns of the derivative's layer)
         for (int d = 0; d < ND; ++d) {
             const int p = d_layer[d], k = d_kind[d], c0 = p * n2;
             const double* xl = &x[c0];
-            const double* xm = &x[c0 + N];
+            const double* xm = &x[c0 + n];
             auto dE = [&](int j) {
-                return -(deigk[(size_t(p) * 3 + k) * N + j] * tau[p] + eigk[size_t(p) * N + j] * d_od(k)) * E(p, j);
+                return -(deigk[(size_t(p) * 3 + k) * n + j] * tau[p] + eigk[size_t(p) * n + j] * d_od(k)) * E(p, j);
             };
             // boundary above layer p
             if (p == 0) {
-                for (int i = 0; i < N; ++i) {
+                for (int i = 0; i < n; ++i) {
                     double s = 0;
-                    for (int j = 0; j < N; ++j)
+                    for (int j = 0; j < n; ++j)
                         s += dWp[dhidx(p, k, i, j)] * xl[j] + (dWm[dhidx(p, k, i, j)] * E(p, j) + Wm[hidx(p, i, j)] * dE(j)) * xm[j];
                     rhs[size_t(i) * nr + 1 + d] -= s;
                 }
             } else {
-                int r0 = N + (p - 1) * n2;
-                for (int i = 0; i < N; ++i) {
+                int r0 = n + (p - 1) * n2;
+                for (int i = 0; i < n; ++i) {
                     double s1 = 0, s0 = 0;
-                    for (int j = 0; j < N; ++j) {
+                    for (int j = 0; j < n; ++j) {
                         s1 += -dWp[dhidx(p, k, i, j)] * xl[j] + (-dWm[dhidx(p, k, i, j)] * E(p, j) - Wm[hidx(p, i, j)] * dE(j)) * xm[j];
                         s0 += -dWm[dhidx(p, k, i, j)] * xl[j] - (dWp[dhidx(p, k, i, j)] * E(p, j) + Wp[hidx(p, i, j)] * dE(j)) * xm[j];
                     }
-                    rhs[size_t(r0 + i + N) * nr + 1 + d] -= s1;
-                    rhs[size_t(r0 + i) * nr + 1 + d] -= s0;
+                    rhs[size_t(r0 + i + n) * nr + 1 + d] -= s1;
+                    rhs[size_t(r0 + i) * nr + 1 + d] -= neg(i) * s0;
                 }
             }
             // boundary below layer p
             if (p == nlyr - 1) {
-                int r0 = M - N;
-                for (int i = 0; i < N; ++i) {
+                int r0 = M - n;
+                for (int i = 0; i < n; ++i) {
+                    const bool rr = refl && refl_row(i);
                     double s = 0;
-                    for (int j = 0; j < N; ++j) {
+                    for (int j = 0; j < n; ++j) {
                         double vm = Wm[hidx(p, i, j)], vp_d = dWp[dhidx(p, k, i, j)], vm_d = dWm[dhidx(p, k, i, j)];
-                        if (refl)
+                        if (rr)
                             for (int t = 0; t < N; ++t) {
                                 double f = kd * G.wt[t] * G.mu[t];
-                                vm -= f * rho(m) * Wp[hidx(p, t, j)];
-                                vm_d -= f * rho(m) * dWp[dhidx(p, k, t, j)] + f * d_alb(k) * Wp[hidx(p, t, j)];
-                                vp_d -= f * rho(m) * dWm[dhidx(p, k, t, j)] + f * d_alb(k) * Wm[hidx(p, t, j)];
+                                vm -= f * rho(m) * Wp[hidx(p, t * S, j)];
+                                vm_d -= f * rho(m) * dWp[dhidx(p, k, t * S, j)] + f * d_alb(k) * Wp[hidx(p, t * S, j)];
+                                vp_d -= f * rho(m) * dWm[dhidx(p, k, t * S, j)] + f * d_alb(k) * Wm[hidx(p, t * S, j)];
                             }
                         s += (vm_d * E(p, j) + vm * dE(j)) * xl[j] + vp_d * xm[j];
                     }
-                    rhs[size_t(r0 + i) * nr + 1 + d] -= s;
+                    rhs[size_t(r0 + i) * nr + 1 + d] -= neg(i) * s;
                 }
             } else {
-                int r0 = N + p * n2;
-                for (int i = 0; i < N; ++i) {
+                int r0 = n + p * n2;
+                for (int i = 0; i < n; ++i) {
                     double s1 = 0, s0 = 0;
-                    for (int j = 0; j < N; ++j) {
+                    for (int j = 0; j < n; ++j) {
                         s1 += (dWp[dhidx(p, k, i, j)] * E(p, j) + Wp[hidx(p, i, j)] * dE(j)) * xl[j] + dWm[dhidx(p, k, i, j)] * xm[j];
                         s0 += (dWm[dhidx(p, k, i, j)] * E(p, j) + Wm[hidx(p, i, j)] * dE(j)) * xl[j] + dWp[dhidx(p, k, i, j)] * xm[j];
                     }
-                    rhs[size_t(r0 + i + N) * nr + 1 + d] -= s1;
-                    rhs[size_t(r0 + i) * nr + 1 + d] -= s0;
+                    rhs[size_t(r0 + i + n) * nr + 1 + d] -= s1;
+                    rhs[size_t(r0 + i) * nr + 1 + d] -= neg(i) * s0;
                 }
             }
         }
         bvp.solve(rhs.data(), nr);  // column 0 is re-solved (cheap) and ignored
         for (int p = 0; p < nlyr; ++p)
             for (int d = 0; d < ND; ++d)
-                for (int j = 0; j < N; ++j) {
+                for (int j = 0; j < n; ++j) {
                     dLM(dLc, p, d)[j] = rhs[size_t(p * n2 + j) * nr + 1 + d];
-                    dLM(dMc, p, d)[j] = rhs[size_t(p * n2 + N + j) * nr + 1 + d];
+                    dLM(dMc, p, d)[j] = rhs[size_t(p * n2 + n + j) * nr + 1 + d];
                 }
     }
 
@@ -683,30 +758,59 @@ class Solver {
         solve_bvp(m);
     }
 
-    // legendre sums at an outgoing direction with tabulated lp_out[l]:  (post-processing call-site naming)
-    //   lm[j] ("lpsum_minus") = 0.5 w_j ssa sum_l a_l P_l(out) P_l(mu_j)
-    //   lp[j] ("lpsum_plus")  = same with (-1)^(l-m)
+    // Legendre sums at an outgoing direction with tabulated functions lp_out ([l][3])  (post-processing call-site naming):
+    //   lm[s][r] ("lpsum_minus") = 0.5 w_j ssa [sum_l Pi_l(out) B_l Pi_l(mu_j)](s, s'),  r = j*S + s'
+    //   lp[s][r] ("lpsum_plus")  = the negated product (scat_phase_f, sktran_do_lpproduct.h:265-337)
     void lpsums(int m, int p, const double* lp_out, double* lp, double* lm, double* dlp, double* dlm) {
-        const double* ap = &a[size_t(p) * nstr];
+        double b0[9], b1[9];
         for (int j = 0; j < N; ++j) {
-            double s0 = 0, s1 = 0;
-            for (int l = m; l < nstr; ++l) {
-                double t = ap[l] * lp_out[l] * G.lpmu(m, j, l);
-                s0 += t;
-                s1 += ((l - m) % 2 != 0) ? -t : t;
-            }
-            for (int k = 0; k < nl(p); ++k) {
-                dlm[size_t(k) * N + j] = s0 * d_ssa(k) * 0.5 * G.wt[j];
-                dlp[size_t(k) * N + j] = s1 * d_ssa(k) * 0.5 * G.wt[j];
-            }
-            lm[j] = s0 * 0.5 * ssa[p] * G.wt[j];
-            lp[j] = s1 * 0.5 * ssa[p] * G.wt[j];
+            triple_sum(false, m, p, lp_out, fmu(m, j), b0);
+            triple_sum(true, m, p, lp_out, fmu(m, j), b1);
+            for (int s1 = 0; s1 < S; ++s1)
+                for (int s2 = 0; s2 < S; ++s2) {
+                    const int r = j * S + s2;
+                    const double s0 = b0[s1 * S + s2], s1v = b1[s1 * S + s2];
+                    for (int k = 0; k < nl(p); ++k) {
+                        dlm[(size_t(k) * S + s1) * n + r] = s0 * d_ssa(k) * 0.5 * G.wt[j];
+                        dlp[(size_t(k) * S + s1) * n + r] = s1v * d_ssa(k) * 0.5 * G.wt[j];
+                    }
+                    lm[size_t(s1) * n + r] = s0 * 0.5 * ssa[p] * G.wt[j];
+                    lp[size_t(s1) * n + r] = s1v * 0.5 * ssa[p] * G.wt[j];
+                }
         }
     }
 
-    void map_to_native(const double* do_deriv, double scale, double* native) const {
+    // Y+-[s][i] = sum_r lp[s][r] W+-(r, i) + lm[s][r] W-+(r, i) and their layer derivatives (sktran_do_opticallayer.cpp:196-262)
+    void ymatrices(int p, const double* lp, const double* lm, const double* dlp, const double* dlm, double* Yp, double* Ym, double* dYp, double* dYm) {
+        const int nk = nl(p);
+        for (int s = 0; s < S; ++s)
+            for (int i = 0; i < n; ++i) {
+                double yp = 0, ym = 0;
+                const double* lps = lp + size_t(s) * n;
+                const double* lms = lm + size_t(s) * n;
+                for (int r = 0; r < n; ++r) {
+                    yp += lps[r] * Wp[hidx(p, r, i)] + lms[r] * Wm[hidx(p, r, i)];
+                    ym += lps[r] * Wm[hidx(p, r, i)] + lms[r] * Wp[hidx(p, r, i)];
+                }
+                Yp[size_t(s) * n + i] = yp;
+                Ym[size_t(s) * n + i] = ym;
+                for (int k = 0; k < nk; ++k) {
+                    const double* dlps = dlp + (size_t(k) * S + s) * n;
+                    const double* dlms = dlm + (size_t(k) * S + s) * n;
+                    double a1 = 0, a2 = 0;
+                    for (int r = 0; r < n; ++r) {
+                        a1 += dlps[r] * Wp[hidx(p, r, i)] + lps[r] * dWp[dhidx(p, k, r, i)] + dlms[r] * Wm[hidx(p, r, i)] + lms[r] * dWm[dhidx(p, k, r, i)];
+                        a2 += dlps[r] * Wm[hidx(p, r, i)] + lps[r] * dWm[dhidx(p, k, r, i)] + dlms[r] * Wp[hidx(p, r, i)] + lms[r] * dWp[dhidx(p, k, r, i)];
+                    }
+                    dYp[(size_t(k) * S + s) * n + i] = a1;
+                    dYm[(size_t(k) * S + s) * n + i] = a2;
+                }
+            }
+    }
+
+    void map_to_native(const double* do_deriv, double scale, double* native, int stride = 1) const {
         for (int d = 0; d < ND; ++d) {
-            double v = do_deriv[d] * scale;
+            double v = do_deriv[size_t(d) * stride] * scale;
             if (v == 0.0) continue;
             for (auto& wr : wires[d]) native[wr.native] += wr.w * v;
         }
@@ -727,8 +831,9 @@ class Solver {
 inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<double>& rad, std::vector<double>& drad) {
     (void)szaidx;
     const int p_bot = nlyr - 1;
-    std::vector<double> comp_d(ND), integ_d(ND), strm_d(ND), lp(N), lm(N), dlp(3 * N), dlm(3 * N);
-    std::vector<double> Yp(N), Ym(N), dYp(3 * N), dYm(3 * N), dEf(ND), dDp(ND), dDm(ND);
+    // per-Stokes derivative blocks are stored [ND][S]
+    std::vector<double> comp(S), comp_d(size_t(ND) * S), integ_d(size_t(ND) * S), strm_d(ND), lp(size_t(S) * n), lm(size_t(S) * n), dlp(size_t(3) * S * n), dlm(size_t(3) * S * n);
+    std::vector<double> Yp(size_t(S) * n), Ym(size_t(S) * n), dYp(size_t(3) * S * n), dYm(size_t(3) * S * n), dEf(ND), dDp(ND), dDm(ND);
     for (size_t j = 0; j < G.pp_los.size(); ++j) {
         const auto& los = G.pp_los[j];
         const double mu = los.coszenith;
@@ -745,28 +850,29 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
                 obs_od = od_floor[pl] - tau[pl] * f;
             }
         }
-        // ground reflection (computeReflectedIntensities)
-        double comp = 0;
+        // ground reflection (computeReflectedIntensities): Lambertian, intensity component only
+        std::fill(comp.begin(), comp.end(), 0.0);
         std::fill(comp_d.begin(), comp_d.end(), 0.0);
         if (m < 1) {
             const int p = p_bot, ls = ND ? lstart[p] : 0, nk = nl(p);
             double diffuse = 0;
             std::vector<double> diffuse_d(ND, 0.0);
-            for (int i = 0; i < N; ++i) {
+            for (int is = 0; is < N; ++is) {
+                const int i = is * S;
                 double r = rho(m);
-                double sc_v = Gpb[size_t(p) * N + i];
+                double sc_v = Gpb[size_t(p) * n + i];
                 for (int d = 0; d < ND; ++d) strm_d[d] = dG(dGpb, p, d)[i];
-                double factor = (m == 0 ? 2.0 : 1.0) * G.mu[i] * G.wt[i];
-                for (int jj = 0; jj < N; ++jj) {
-                    double st = std::exp(-std::abs(eigk[size_t(p) * N + jj]) * tau[p]);
+                double factor = (m == 0 ? 2.0 : 1.0) * G.mu[is] * G.wt[is];
+                for (int jj = 0; jj < n; ++jj) {
+                    double st = std::exp(-std::abs(eigk[size_t(p) * n + jj]) * tau[p]);
                     double hp = Wp[hidx(p, i, jj)], hm = Wm[hidx(p, i, jj)];
-                    sc_v += Lc[size_t(p) * N + jj] * hp * st + Mc[size_t(p) * N + jj] * hm;
+                    sc_v += Lc[size_t(p) * n + jj] * hp * st + Mc[size_t(p) * n + jj] * hm;
                     for (int d = 0; d < ND; ++d)
                         strm_d[d] += dLM(dLc, p, d)[jj] * hp * st + dLM(dMc, p, d)[jj] * hm;
                     for (int k = 0; k < nk; ++k) {
-                        double dst = -(deigk[(size_t(p) * 3 + k) * N + jj] * tau[p] + eigk[size_t(p) * N + jj] * d_od(k)) * st;
-                        strm_d[ls + k] += Lc[size_t(p) * N + jj] * dWp[dhidx(p, k, i, jj)] * st + Lc[size_t(p) * N + jj] * hp * dst;
-                        strm_d[ls + k] += Mc[size_t(p) * N + jj] * dWm[dhidx(p, k, i, jj)];
+                        double dst = -(deigk[(size_t(p) * 3 + k) * n + jj] * tau[p] + eigk[size_t(p) * n + jj] * d_od(k)) * st;
+                        strm_d[ls + k] += Lc[size_t(p) * n + jj] * dWp[dhidx(p, k, i, jj)] * st + Lc[size_t(p) * n + jj] * hp * dst;
+                        strm_d[ls + k] += Mc[size_t(p) * n + jj] * dWm[dhidx(p, k, i, jj)];
                     }
                 }
                 diffuse += factor * sc_v * r;
@@ -775,12 +881,12 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
             }
             if (include_ss) {
                 double direct = G.csz[cur_sza] / kPi * trans[nlyr] * rho(m);
-                comp = direct + diffuse;
-                for (int d = 0; d < ND; ++d) comp_d[d] = G.csz[cur_sza] / kPi * dtrans[size_t(nlyr) * ND + d] * rho(m) + diffuse_d[d];
-                for (int k = 0; k < nk; ++k) comp_d[ls + k] += G.csz[cur_sza] / kPi * trans[nlyr] * d_alb(k);
+                comp[0] = direct + diffuse;
+                for (int d = 0; d < ND; ++d) comp_d[size_t(d) * S] = G.csz[cur_sza] / kPi * dtrans[size_t(nlyr) * ND + d] * rho(m) + diffuse_d[d];
+                for (int k = 0; k < nk; ++k) comp_d[size_t(ls + k) * S] += G.csz[cur_sza] / kPi * trans[nlyr] * d_alb(k);
             } else {
-                comp = diffuse;
-                comp_d = diffuse_d;
+                comp[0] = diffuse;
+                for (int d = 0; d < ND; ++d) comp_d[size_t(d) * S] = diffuse_d[d];
             }
         }
         // upward through the layers
@@ -791,9 +897,10 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
             if (exitod < obs_od) layerfraction = (entry - obs_od) / (entry - exitod);
             const int nk = nl(p), ls = ND ? lstart[p] : 0;
             double att = std::exp(-1.0 * tau[p] * layerfraction / mu);
-            comp *= att;
-            for (int d = 0; d < ND; ++d) comp_d[d] *= att;
-            for (int k = 0; k < nk; ++k) comp_d[ls + k] += -layerfraction / mu * comp * d_od(k);
+            for (int s = 0; s < S; ++s) comp[s] *= att;
+            for (size_t d = 0; d < comp_d.size(); ++d) comp_d[d] *= att;
+            for (int k = 0; k < nk; ++k)
+                for (int s = 0; s < S; ++s) comp_d[size_t(ls + k) * S + s] += -layerfraction / mu * comp[s] * d_od(k);
 
             // integrate_source(m, mu, obsod, lp_mu, ...)
             double exit_od = od_ceil[p];
@@ -802,37 +909,19 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
             const double T = trans[p], sc = sec[p], th = tau[p];
             const double* dT = &dtrans[size_t(p) * ND];
             const double* dsc = &dsec[size_t(p) * ND];
-            lpsums(m, p, &G.lp_los[(j * nstr + m) * nstr], lp.data(), lm.data(), dlp.data(), dlm.data());
-            double Q = 0, dQ[3] = {0, 0, 0};
+            lpsums(m, p, flos(int(j), m), lp.data(), lm.data(), dlp.data(), dlm.data());
+            double Q[3] = {0, 0, 0}, dQ[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // dQ[k][s]
             if (include_ss) {
-                double sneg = 0;
-                const double* ap = &a[size_t(p) * nstr];
-                for (int l = m; l < nstr; ++l) {
-                    double t = ap[l] * G.lplos(j, m, l) * G.lpcsz(cur_sza, m, l);
-                    sneg += ((l - m) % 2 != 0) ? -t : t;
-                }
-                sneg *= (2 - (m == 0 ? 1 : 0)) * (1.0 / (4.0 * kPi));
-                for (int k = 0; k < nk; ++k) dQ[k] = sneg * d_ssa(k);
-                Q = sneg * ssa[p];
-            }
-            for (int i = 0; i < N; ++i) {
-                double yp = 0, ym = 0;
-                for (int r = 0; r < N; ++r) {
-                    yp += lp[r] * Wp[hidx(p, r, i)] + lm[r] * Wm[hidx(p, r, i)];
-                    ym += lp[r] * Wm[hidx(p, r, i)] + lm[r] * Wp[hidx(p, r, i)];
-                }
-                Yp[i] = yp;
-                Ym[i] = ym;
-                for (int k = 0; k < nk; ++k) {
-                    double a1 = 0, a2 = 0;
-                    for (int r = 0; r < N; ++r) {
-                        a1 += dlp[size_t(k) * N + r] * Wp[hidx(p, r, i)] + lp[r] * dWp[dhidx(p, k, r, i)] + dlm[size_t(k) * N + r] * Wm[hidx(p, r, i)] + lm[r] * dWm[dhidx(p, k, r, i)];
-                        a2 += dlp[size_t(k) * N + r] * Wm[hidx(p, r, i)] + lp[r] * dWm[dhidx(p, k, r, i)] + dlm[size_t(k) * N + r] * Wp[hidx(p, r, i)] + lm[r] * dWp[dhidx(p, k, r, i)];
-                    }
-                    dYp[size_t(k) * N + i] = a1;
-                    dYm[size_t(k) * N + i] = a2;
+                double b[9];
+                triple_sum(true, m, p, flos(int(j), m), fcsz(cur_sza, m), b);
+                const double factor = (2 - (m == 0 ? 1 : 0)) * (1.0 / (4.0 * kPi));
+                for (int s = 0; s < S; ++s) {
+                    double sneg = b[s * S] * factor;
+                    for (int k = 0; k < nk; ++k) dQ[k][s] = sneg * d_ssa(k);
+                    Q[s] = sneg * ssa[p];
                 }
             }
+            ymatrices(p, lp.data(), lm.data(), dlp.data(), dlm.data(), Yp.data(), Ym.data(), dYp.data(), dYm.data());
             // E(mu, x, thickness, transmission)
             const double lf = 1 - x / th;
             double Ef;
@@ -845,10 +934,10 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
                 for (int k = 0; k < nk; ++k)
                     dEf[ls + k] += T / den * (e2 * d_od(k) * (sc + lf / mu) - e1 * d_od(k) * (1 - lf) * sc);
             }
-            double J = 0, V = 0;
+            double J[3] = {0, 0, 0}, V[3] = {0, 0, 0};
             std::fill(integ_d.begin(), integ_d.end(), 0.0);
-            for (int i = 0; i < N; ++i) {
-                const double ev = eigk[size_t(p) * N + i];
+            for (int i = 0; i < n; ++i) {
+                const double ev = eigk[size_t(p) * n + i];
                 double hp, hm, dhp[3] = {0, 0, 0}, dhm[3] = {0, 0, 0};
                 {
                     double den = 1.0 + mu * ev;
@@ -856,7 +945,7 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
                         double e1 = std::exp(-x * ev), e2 = std::exp(-1.0 * th * ev) * std::exp(-(th - x) / mu);
                         hp = (e1 - e2) / den;
                         for (int k = 0; k < nk; ++k) {
-                            double dk = deigk[(size_t(p) * 3 + k) * N + i];
+                            double dk = deigk[(size_t(p) * 3 + k) * n + i];
                             dhp[k] = (-1.0 * e1 * (dk * x + d_od(k) * (1 - lf) * ev) + e2 * ((ev + lf / mu) * d_od(k) + th * dk)) / den;
                             dhp[k] -= 1.0 / den * hp * mu * dk;
                         }
@@ -864,7 +953,7 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
                         double e1 = std::exp(-x * ev);
                         hp = (th - x) / mu * e1 * (1 - (th - x) * (ev + 1 / mu));
                         for (int k = 0; k < nk; ++k) {
-                            double dk = deigk[(size_t(p) * 3 + k) * N + i];
+                            double dk = deigk[(size_t(p) * 3 + k) * n + i];
                             dhp[k] = -1.0 * x * dk * hp + 1 / mu * e1 * d_od(k) * (1 - (th - x) * (ev + 1 / mu)) + 1 / mu * e1 * (th - x) * -1.0 * (ev + 1 / mu) * d_od(k);
                         }
                     }
@@ -873,7 +962,7 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
                         double e1 = std::exp(-1.0 * ev * (th - x)), e2 = std::exp(-1 / mu * (th - x));
                         hm = (e1 - e2) / den2;
                         for (int k = 0; k < nk; ++k) {
-                            double dk = deigk[(size_t(p) * 3 + k) * N + i];
+                            double dk = deigk[(size_t(p) * 3 + k) * n + i];
                             dhm[k] = (-1.0 * e1 * (dk * (th - x) + d_od(k) * lf * ev) + e2 * d_od(k) * lf / mu) / den2;
                             dhm[k] += 1.0 / den2 * hm * mu * dk;
                         }
@@ -881,19 +970,12 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
                         double e1 = std::exp(-1.0 * ev * (th - x));
                         hm = e1 * (th - x) / mu * (1 - (th - x) * (ev - 1 / mu));
                         for (int k = 0; k < nk; ++k) {
-                            double dk = deigk[(size_t(p) * 3 + k) * N + i];
+                            double dk = deigk[(size_t(p) * 3 + k) * n + i];
                             dhm[k] = -1.0 * (ev * d_od(k) + th * dk) * hm + e1 * d_od(k) / mu * (1 - (th - x) * (ev - 1 / mu)) + e1 * (th - x) / mu * -1.0 * d_od(k) * (ev - 1 / mu);
                         }
                     }
                 }
-                const double Lv = Lc[size_t(p) * N + i], Mv = Mc[size_t(p) * N + i];
-                J += Yp[i] * hp * Lv + Ym[i] * hm * Mv;
-                for (int k = 0; k < nk; ++k) {
-                    integ_d[ls + k] += dYp[size_t(k) * N + i] * hp * Lv + dYm[size_t(k) * N + i] * hm * Mv;
-                    integ_d[ls + k] += Yp[i] * dhp[k] * Lv + Ym[i] * dhm[k] * Mv;
-                }
-                for (int d = 0; d < ND; ++d)
-                    integ_d[d] += Yp[i] * hp * dLM(dLc, p, d)[i] + Ym[i] * hm * dLM(dMc, p, d)[i];
+                const double Lv = Lc[size_t(p) * n + i], Mv = Mc[size_t(p) * n + i];
                 double expfactor = std::exp(-1 * th * sc);
                 double Dp = (-1 * T * expfactor * hm + Ef) / (sc + ev);
                 double Dm = (T * hp - Ef) / (sc - ev);
@@ -902,27 +984,41 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
                     dDm[d] = dsc[d] * (-Dm) / (sc - ev) + dT[d] * hp / (sc - ev) + dEf[d] * -1.0 / (sc - ev);
                 }
                 for (int k = 0; k < nk; ++k) {
-                    double dk = deigk[(size_t(p) * 3 + k) * N + i];
+                    double dk = deigk[(size_t(p) * 3 + k) * n + i];
                     dDp[ls + k] += dk * (-Dp) / (sc + ev) + dhm[k] * (-T * expfactor) / (sc + ev) + d_od(k) * (T * sc * hm * expfactor) / (sc + ev);
                     dDm[ls + k] += dhp[k] * T / (sc - ev) + dk * Dm / (sc - ev);
                 }
-                const double Apv = Ap[size_t(p) * N + i], Amv = Am[size_t(p) * N + i];
-                V += Apv * Yp[i] * Dm + Amv * Ym[i] * Dp;
-                for (int k = 0; k < nk; ++k) {
-                    integ_d[ls + k] += Apv * dYp[size_t(k) * N + i] * Dm + Amv * dYm[size_t(k) * N + i] * Dp;
-                    integ_d[ls + k] += dAp[(size_t(p) * 3 + k) * N + i] * Yp[i] * Dm + dAm[(size_t(p) * 3 + k) * N + i] * Ym[i] * Dp;
+                const double Apv = Ap[size_t(p) * n + i], Amv = Am[size_t(p) * n + i];
+                for (int s = 0; s < S; ++s) {
+                    const double yp = Yp[size_t(s) * n + i], ym = Ym[size_t(s) * n + i];
+                    J[s] += yp * hp * Lv + ym * hm * Mv;
+                    V[s] += Apv * yp * Dm + Amv * ym * Dp;
+                    for (int k = 0; k < nk; ++k) {
+                        const double dyp = dYp[(size_t(k) * S + s) * n + i], dym = dYm[(size_t(k) * S + s) * n + i];
+                        double& t = integ_d[size_t(ls + k) * S + s];
+                        t += dyp * hp * Lv + dym * hm * Mv;
+                        t += yp * dhp[k] * Lv + ym * dhm[k] * Mv;
+                        t += Apv * dyp * Dm + Amv * dym * Dp;
+                        t += dAp[(size_t(p) * 3 + k) * n + i] * yp * Dm + dAm[(size_t(p) * 3 + k) * n + i] * ym * Dp;
+                    }
+                    for (int d = 0; d < ND; ++d)
+                        integ_d[size_t(d) * S + s] += yp * hp * dLM(dLc, p, d)[i] + ym * hm * dLM(dMc, p, d)[i] + Apv * yp * dDm[d] + Amv * ym * dDp[d];
                 }
-                for (int d = 0; d < ND; ++d) integ_d[d] += Apv * Yp[i] * dDm[d] + Amv * Ym[i] * dDp[d];
             }
-            double integral = J + V + Q * Ef;
-            for (int k = 0; k < nk; ++k) integ_d[ls + k] += dQ[k] * Ef;
-            for (int d = 0; d < ND; ++d) integ_d[d] += Q * dEf[d];
-            comp += integral;
-            for (int d = 0; d < ND; ++d) comp_d[d] += integ_d[d];
+            for (int s = 0; s < S; ++s) {
+                double integral = J[s] + V[s] + Q[s] * Ef;
+                for (int k = 0; k < nk; ++k) integ_d[size_t(ls + k) * S + s] += dQ[k][s] * Ef;
+                for (int d = 0; d < ND; ++d) integ_d[size_t(d) * S + s] += Q[s] * dEf[d];
+                comp[s] += integral;
+                for (int d = 0; d < ND; ++d) comp_d[size_t(d) * S + s] += integ_d[size_t(d) * S + s];
+            }
         }
-        double azf = std::cos(m * los.azimuth);
-        rad[j] += comp * azf;
-        if (ND) map_to_native(comp_d.data(), azf, &drad[j * nnative]);
+        // azimuth expansion: cos for I and Q, sin for U (do_source_planeparallel.cpp:154-190)
+        for (int s = 0; s < S; ++s) {
+            double azf = s < 2 ? std::cos(m * los.azimuth) : std::sin(m * los.azimuth);
+            rad[j * S + s] += comp[s] * azf;
+            if (ND) map_to_native(comp_d.data() + s, azf, &drad[(j * S + s) * nnative], S);
+        }
     }
     (void)res;
 }
@@ -938,31 +1034,34 @@ inline void Solver::accumulate_ground(int m, int szaidx) {
         if (slot < 0) continue;
         double diffuse = 0;
         std::fill(diffuse_d.begin(), diffuse_d.end(), 0.0);
-        for (int i = 0; i < N; ++i) {
+        for (int is = 0; is < N; ++is) {
+            const int i = is * S;  // intensity rows only (Lambertian)
             double r = albedo;  // Lambertian compute_expansion special case
-            double sc_v = Gpb[size_t(p) * N + i];
+            double sc_v = Gpb[size_t(p) * n + i];
             for (int d = 0; d < ND; ++d) strm_d[d] = dG(dGpb, p, d)[i];
-            for (int jj = 0; jj < N; ++jj) {
-                double st = std::exp(-std::abs(eigk[size_t(p) * N + jj]) * tau[p]);
+            for (int jj = 0; jj < n; ++jj) {
+                double st = std::exp(-std::abs(eigk[size_t(p) * n + jj]) * tau[p]);
                 double hp = Wp[hidx(p, i, jj)], hm = Wm[hidx(p, i, jj)];
-                sc_v += Lc[size_t(p) * N + jj] * hp * st + Mc[size_t(p) * N + jj] * hm;
+                sc_v += Lc[size_t(p) * n + jj] * hp * st + Mc[size_t(p) * n + jj] * hm;
                 for (int d = 0; d < ND; ++d) strm_d[d] += dLM(dLc, p, d)[jj] * hp * st + dLM(dMc, p, d)[jj] * hm;
                 for (int k = 0; k < nk; ++k) {
-                    double dst = -(deigk[(size_t(p) * 3 + k) * N + jj] * tau[p] + eigk[size_t(p) * N + jj] * d_od(k)) * st;
-                    strm_d[ls + k] += Lc[size_t(p) * N + jj] * hp * dst + Lc[size_t(p) * N + jj] * dWp[dhidx(p, k, i, jj)] * st;
-                    strm_d[ls + k] += Mc[size_t(p) * N + jj] * dWm[dhidx(p, k, i, jj)];
+                    double dst = -(deigk[(size_t(p) * 3 + k) * n + jj] * tau[p] + eigk[size_t(p) * n + jj] * d_od(k)) * st;
+                    strm_d[ls + k] += Lc[size_t(p) * n + jj] * hp * dst + Lc[size_t(p) * n + jj] * dWp[dhidx(p, k, i, jj)] * st;
+                    strm_d[ls + k] += Mc[size_t(p) * n + jj] * dWm[dhidx(p, k, i, jj)];
                 }
             }
-            double factor = (m == 0 ? 2.0 : 1.0) * G.mu[i] * G.wt[i];
+            double factor = (m == 0 ? 2.0 : 1.0) * G.mu[is] * G.wt[is];
             diffuse += factor * sc_v * r;
             for (int d = 0; d < ND; ++d) diffuse_d[d] += factor * strm_d[d] * r;
             for (int k = 0; k < nk; ++k) diffuse_d[ls + k] += factor * sc_v * d_alb(k);
         }
-        tab_val[size_t(m) * nslot + slot] = diffuse;
+        double* tv = &tab_val[(size_t(m) * nslot + slot) * S];
+        for (int s = 0; s < S; ++s) tv[s] = 0;
+        tv[0] = diffuse;
         filled[size_t(m) * nslot + slot] = 1;
         if (ND) {
-            double* nat = &tab_deriv[(size_t(m) * nslot + slot) * nnative];
-            std::fill(nat, nat + nnative, 0.0);
+            double* nat = &tab_deriv[(size_t(m) * nslot + slot) * S * nnative];
+            std::fill(nat, nat + size_t(S) * nnative, 0.0);
             map_to_native(diffuse_d.data(), 1.0, nat);
         }
     }
@@ -972,8 +1071,9 @@ inline void Solver::accumulate_sources(int m, int szaidx) {
     const size_t nslot = npoint + nground;
     if (m >= 2) all_converged = true;
     accumulate_ground(m, szaidx);
-    std::vector<double> lp(N), lm(N), dlp(3 * N), dlm(3 * N), Yp(N), Ym(N), dYp(3 * N), dYm(3 * N), temp(ND);
-    std::vector<double> hpv(N), hmv(N), dhp(3 * N), dhm(3 * N), Dmv(N), Dpv(N), dDm(size_t(N) * ND), dDp(size_t(N) * ND);
+    std::vector<double> lp(size_t(S) * n), lm(size_t(S) * n), dlp(size_t(3) * S * n), dlm(size_t(3) * S * n);
+    std::vector<double> Yp(size_t(S) * n), Ym(size_t(S) * n), dYp(size_t(3) * S * n), dYm(size_t(3) * S * n), temp(ND);
+    std::vector<double> hpv(n), hmv(n), dhp(3 * n), dhm(3 * n), Dmv(n), Dpv(n), dDm(size_t(n) * ND), dDp(size_t(n) * ND);
     for (int lidx = 0; lidx < nlyr; ++lidx) {
         const int p = nlyr - lidx - 1;
         const int nk = nl(p), ls = ND ? lstart[p] : 0;
@@ -983,14 +1083,14 @@ inline void Solver::accumulate_sources(int m, int szaidx) {
         const double* dT = &dtrans[size_t(p) * ND];
         const double* dsc = &dsec[size_t(p) * ND];
         const double x = th * lf;
-        for (int i = 0; i < N; ++i) {
-            const double ev = eigk[size_t(p) * N + i];
+        for (int i = 0; i < n; ++i) {
+            const double ev = eigk[size_t(p) * n + i];
             hpv[i] = std::exp(-1.0 * ev * th * lf);
             hmv[i] = std::exp(-ev * th * (1 - lf));
             for (int k = 0; k < nk; ++k) {
-                double dk = deigk[(size_t(p) * 3 + k) * N + i];
-                dhp[size_t(k) * N + i] = -hpv[i] * (dk * th * lf + d_od(k) * ev * lf);
-                dhm[size_t(k) * N + i] = -hmv[i] * (dk * th * (1 - lf) + d_od(k) * ev * (1 - lf));
+                double dk = deigk[(size_t(p) * 3 + k) * n + i];
+                dhp[size_t(k) * n + i] = -hpv[i] * (dk * th * lf + d_od(k) * ev * lf);
+                dhm[size_t(k) * n + i] = -hmv[i] * (dk * th * (1 - lf) + d_od(k) * ev * (1 - lf));
             }
             // d_minus_sampled
             {
@@ -999,7 +1099,7 @@ inline void Solver::accumulate_sources(int m, int szaidx) {
                 double* dd = &dDm[size_t(i) * ND];
                 for (int d = 0; d < ND; ++d) dd[d] = dT[d] * v + dsc[d] * T * (-v / denom + std::exp(-x * sc) * x);
                 for (int k = 0; k < nk; ++k) {
-                    double dk = deigk[(size_t(p) * 3 + k) * N + i];
+                    double dk = deigk[(size_t(p) * 3 + k) * n + i];
                     dd[ls + k] += dk * T * (-x * std::exp(-x * ev) + v / denom);
                     dd[ls + k] += lf * d_od(k) * T * (std::exp(-x * sc) * sc - std::exp(-x * ev) * ev);
                 }
@@ -1014,7 +1114,7 @@ inline void Solver::accumulate_sources(int m, int szaidx) {
                 double* dd = &dDp[size_t(i) * ND];
                 for (int d = 0; d < ND; ++d) dd[d] = dT[d] * v + dsc[d] * T * (-v / denom + -x * std::exp(-x * sc) + th * ef2);
                 for (int k = 0; k < nk; ++k) {
-                    double dk = deigk[(size_t(p) * 3 + k) * N + i];
+                    double dk = deigk[(size_t(p) * 3 + k) * n + i];
                     dd[ls + k] += dk * T * (-v / denom + ef2 * (th - x));
                     dd[ls + k] += d_od(k) * T * (-std::exp(-x * sc) * lf * sc + ef2 * sc + ef2 * (ev - lf * ev));
                 }
@@ -1025,59 +1125,46 @@ inline void Solver::accumulate_sources(int m, int szaidx) {
         for (int aidx = 0; aidx < G.nangle; ++aidx) {
             int slot = point_slot[(size_t(szaidx) * nlyr + lidx) * G.nangle + aidx];
             if (slot < 0 || converged[size_t(m) * npoint + slot]) continue;
-            std::fill(temp.begin(), temp.end(), 0.0);
-            lpsums(m, p, &G.lp_angle[(size_t(m) * G.nangle + aidx) * nstr], lp.data(), lm.data(), dlp.data(), dlm.data());
-            for (int i = 0; i < N; ++i) {
-                double yp = 0, ym = 0;
-                for (int r = 0; r < N; ++r) {
-                    yp += lp[r] * Wp[hidx(p, r, i)] + lm[r] * Wm[hidx(p, r, i)];
-                    ym += lp[r] * Wm[hidx(p, r, i)] + lm[r] * Wp[hidx(p, r, i)];
-                }
-                Yp[i] = yp;
-                Ym[i] = ym;
-                for (int k = 0; k < nk; ++k) {
-                    double a1 = 0, a2 = 0;
-                    for (int r = 0; r < N; ++r) {
-                        a1 += dlp[size_t(k) * N + r] * Wp[hidx(p, r, i)] + lp[r] * dWp[dhidx(p, k, r, i)] + dlm[size_t(k) * N + r] * Wm[hidx(p, r, i)] + lm[r] * dWm[dhidx(p, k, r, i)];
-                        a2 += dlp[size_t(k) * N + r] * Wm[hidx(p, r, i)] + lp[r] * dWm[dhidx(p, k, r, i)] + dlm[size_t(k) * N + r] * Wp[hidx(p, r, i)] + lm[r] * dWp[dhidx(p, k, r, i)];
+            lpsums(m, p, fang(m, aidx), lp.data(), lm.data(), dlp.data(), dlm.data());
+            ymatrices(p, lp.data(), lm.data(), dlp.data(), dlm.data(), Yp.data(), Ym.data(), dYp.data(), dYm.data());
+            for (int s = 0; s < S; ++s) {
+                std::fill(temp.begin(), temp.end(), 0.0);
+                double val = 0;
+                for (int i = 0; i < n; ++i) {
+                    const double yp = Yp[size_t(s) * n + i], ym = Ym[size_t(s) * n + i];
+                    const double Lv = Lc[size_t(p) * n + i], Mv = Mc[size_t(p) * n + i];
+                    const double Apv = Ap[size_t(p) * n + i], Amv = Am[size_t(p) * n + i];
+                    val += yp * hpv[i] * Lv + ym * hmv[i] * Mv;
+                    val += Apv * yp * Dmv[i] + Amv * ym * Dpv[i];
+                    const double c1 = yp * hpv[i], c2 = ym * hmv[i], c3 = Apv * yp, c4 = Amv * ym;
+                    for (int d = 0; d < ND; ++d)
+                        temp[d] += dLM(dLc, p, d)[i] * c1 + dLM(dMc, p, d)[i] * c2 + dDm[size_t(i) * ND + d] * c3 + dDp[size_t(i) * ND + d] * c4;
+                    for (int k = 0; k < nk; ++k) {
+                        const double dyp = dYp[(size_t(k) * S + s) * n + i], dym = dYm[(size_t(k) * S + s) * n + i];
+                        temp[ls + k] += dyp * hpv[i] * Lv + dym * hmv[i] * Mv;
+                        temp[ls + k] += dhp[size_t(k) * n + i] * yp * Lv + dhm[size_t(k) * n + i] * ym * Mv;
+                        temp[ls + k] += dyp * Dmv[i] * Apv + dym * Dpv[i] * Amv;
+                        temp[ls + k] += dAp[(size_t(p) * 3 + k) * n + i] * yp * Dmv[i] + dAm[(size_t(p) * 3 + k) * n + i] * ym * Dpv[i];
                     }
-                    dYp[size_t(k) * N + i] = a1;
-                    dYm[size_t(k) * N + i] = a2;
                 }
-            }
-            double val = 0;
-            for (int i = 0; i < N; ++i) {
-                const double Lv = Lc[size_t(p) * N + i], Mv = Mc[size_t(p) * N + i];
-                const double Apv = Ap[size_t(p) * N + i], Amv = Am[size_t(p) * N + i];
-                val += Yp[i] * hpv[i] * Lv + Ym[i] * hmv[i] * Mv;
-                val += Apv * Yp[i] * Dmv[i] + Amv * Ym[i] * Dpv[i];
-                const double c1 = Yp[i] * hpv[i], c2 = Ym[i] * hmv[i], c3 = Apv * Yp[i], c4 = Amv * Ym[i];
-                const double* dl = nullptr; (void)dl;
-                for (int d = 0; d < ND; ++d)
-                    temp[d] += dLM(dLc, p, d)[i] * c1 + dLM(dMc, p, d)[i] * c2 + dDm[size_t(i) * ND + d] * c3 + dDp[size_t(i) * ND + d] * c4;
-                for (int k = 0; k < nk; ++k) {
-                    temp[ls + k] += dYp[size_t(k) * N + i] * hpv[i] * Lv + dYm[size_t(k) * N + i] * hmv[i] * Mv;
-                    temp[ls + k] += dhp[size_t(k) * N + i] * Yp[i] * Lv + dhm[size_t(k) * N + i] * Ym[i] * Mv;
-                    temp[ls + k] += dYp[size_t(k) * N + i] * Dmv[i] * Apv + dYm[size_t(k) * N + i] * Dpv[i] * Amv;
-                    temp[ls + k] += dAp[(size_t(p) * 3 + k) * N + i] * Yp[i] * Dmv[i] + dAm[(size_t(p) * 3 + k) * N + i] * Ym[i] * Dpv[i];
+                val /= ssa[p];
+                tab_val[(size_t(m) * nslot + slot) * S + s] = val;
+                filled[size_t(m) * nslot + slot] = 1;
+                // convergence is judged on the intensity only (do_source_diffuse_storage.cpp:1033-1060)
+                if (m >= 2 && s == 0) {
+                    double prev = tab_val[(size_t(m - 1) * nslot + slot) * S], prev2 = tab_val[(size_t(m - 2) * nslot + slot) * S];
+                    if ((std::abs(val / prev) < 1e-4 || prev < 1e-10) && (std::abs(val / prev2) < 1e-4 || prev2 < 1e-10)) {
+                        for (int azi = m + 1; azi < nstr; ++azi) converged[size_t(azi) * npoint + slot] = 1;
+                    } else {
+                        all_converged = false;
+                    }
                 }
-            }
-            val /= ssa[p];
-            tab_val[size_t(m) * nslot + slot] = val;
-            filled[size_t(m) * nslot + slot] = 1;
-            if (m >= 2) {
-                double prev = tab_val[size_t(m - 1) * nslot + slot], prev2 = tab_val[size_t(m - 2) * nslot + slot];
-                if ((std::abs(val / prev) < 1e-4 || prev < 1e-10) && (std::abs(val / prev2) < 1e-4 || prev2 < 1e-10)) {
-                    for (int azi = m + 1; azi < nstr; ++azi) converged[size_t(azi) * npoint + slot] = 1;
-                } else {
-                    all_converged = false;
+                if (ND) {
+                    for (int k = 0; k < nk; ++k) temp[ls + k] -= d_ssa(k) * val;
+                    double* nat = &tab_deriv[((size_t(m) * nslot + slot) * S + s) * nnative];
+                    std::fill(nat, nat + nnative, 0.0);
+                    map_to_native(temp.data(), 1.0 / ssa[p], nat);
                 }
-            }
-            if (ND) {
-                for (int k = 0; k < nk; ++k) temp[ls + k] -= d_ssa(k) * val;
-                double* nat = &tab_deriv[(size_t(m) * nslot + slot) * nnative];
-                std::fill(nat, nat + nnative, 0.0);
-                map_to_native(temp.data(), 1.0 / ssa[p], nat);
             }
         }
     }
@@ -1085,20 +1172,22 @@ inline void Solver::accumulate_sources(int m, int szaidx) {
 
 inline void Solver::integrate_los(const AtmosphereView& atm, int w, Result& res) {
     const size_t nslot = npoint + nground;
+    std::vector<double> I(S), sv(S);
     for (int r = 0; r < G.nlos; ++r) {
         const auto& ray = G.rays[r];
-        double I = 0;
-        double* dI = nnative ? &res.deriv[size_t(r) * nnative] : nullptr;
+        std::fill(I.begin(), I.end(), 0.0);
+        double* dI = nnative ? &res.deriv[size_t(r) * S * nnative] : nullptr;  // [S][nnative]
         double od_total = 0;
         if (ray.ground_is_hit) {
+            // Lambertian ground: intensity only (end_of_ray_source, do_source_interpolated_pp.cpp:176-211)
             for (int m = 0; m < nstr; ++m) {
                 double azf = std::cos(m * (kPi - ray.ground_saa));
                 for (auto& e : ray.ground) {
                     int slot = ground_slot[size_t(e.sza) * G.nangle + e.angle];
                     if (!filled[size_t(m) * nslot + slot]) continue;
-                    I += e.w * azf * tab_val[size_t(m) * nslot + slot];
+                    I[0] += e.w * azf * tab_val[(size_t(m) * nslot + slot) * S];
                     if (nnative) {
-                        const double* nat = &tab_deriv[(size_t(m) * nslot + slot) * nnative];
+                        const double* nat = &tab_deriv[(size_t(m) * nslot + slot) * S * nnative];
                         for (int q = 0; q < nnative; ++q) dI[q] += e.w * azf * nat[q];
                     }
                 }
@@ -1110,46 +1199,52 @@ inline void Solver::integrate_los(const AtmosphereView& atm, int w, Result& res)
             od_total += od;
             double att = std::exp(-od);
             if (nnative) {
-                for (size_t t = 0; t < L.od.idx.size(); ++t) dI[L.od.idx[t]] -= L.od.w[t] * I;
-                for (int q = 0; q < nnative; ++q) dI[q] *= att;
+                for (int s = 0; s < S; ++s)
+                    for (size_t t = 0; t < L.od.idx.size(); ++t) dI[size_t(s) * nnative + L.od.idx[t]] -= L.od.w[t] * I[s];
+                for (size_t q = 0; q < size_t(S) * nnative; ++q) dI[q] *= att;
             }
-            I *= att;
+            for (int s = 0; s < S; ++s) I[s] *= att;
             if (L.layer_distance < kMinShell) continue;
             double omega = 0;
             for (size_t t = 0; t < L.ssa_interp.idx.size(); ++t) omega += atm.om(L.ssa_interp.idx[t], w) * L.ssa_interp.w[t];
             double sf = 1 - att;
-            double sv = 0;
-            for (int m = 0; m < nstr; ++m) {
-                double azf = std::cos(m * L.azi);
-                for (auto& e : L.table) {
-                    int slot = point_slot[(size_t(e.sza) * nlyr + e.alt) * G.nangle + e.angle];
-                    sv += e.w * azf * tab_val[size_t(m) * nslot + slot];
-                }
-            }
-            I += omega * sf * sv;
-            if (nnative) {
-                for (size_t t = 0; t < L.od.idx.size(); ++t) dI[L.od.idx[t]] += L.od.w[t] * (1 - sf) * sv * omega;
-                for (size_t t = 0; t < L.ssa_interp.idx.size(); ++t) dI[ngrid + L.ssa_interp.idx[t]] += L.ssa_interp.w[t] * sf * sv;
-                for (int m = 0; m < nstr; ++m) {
-                    double azf = std::cos(m * L.azi);
+            // azimuth weights: cos for I and Q, sin for U (do_source_diffuse_storage.cpp:158-184)
+            std::fill(sv.begin(), sv.end(), 0.0);
+            for (int m = 0; m < nstr; ++m)
+                for (int s = 0; s < S; ++s) {
+                    double azf = s < 2 ? std::cos(m * L.azi) : std::sin(m * L.azi);
                     for (auto& e : L.table) {
                         int slot = point_slot[(size_t(e.sza) * nlyr + e.alt) * G.nangle + e.angle];
-                        if (!filled[size_t(m) * nslot + slot]) continue;
-                        const double* nat = &tab_deriv[(size_t(m) * nslot + slot) * nnative];
-                        double f = omega * sf * e.w * azf;
-                        for (int q = 0; q < nnative; ++q) dI[q] += f * nat[q];
+                        sv[s] += e.w * azf * tab_val[(size_t(m) * nslot + slot) * S + s];
+                    }
+                }
+            for (int s = 0; s < S; ++s) I[s] += omega * sf * sv[s];
+            if (nnative) {
+                for (int s = 0; s < S; ++s) {
+                    double* dIs = dI + size_t(s) * nnative;
+                    for (size_t t = 0; t < L.od.idx.size(); ++t) dIs[L.od.idx[t]] += L.od.w[t] * (1 - sf) * sv[s] * omega;
+                    for (size_t t = 0; t < L.ssa_interp.idx.size(); ++t) dIs[ngrid + L.ssa_interp.idx[t]] += L.ssa_interp.w[t] * sf * sv[s];
+                    for (int m = 0; m < nstr; ++m) {
+                        double azf = s < 2 ? std::cos(m * L.azi) : std::sin(m * L.azi);
+                        for (auto& e : L.table) {
+                            int slot = point_slot[(size_t(e.sza) * nlyr + e.alt) * G.nangle + e.angle];
+                            if (!filled[size_t(m) * nslot + slot]) continue;
+                            const double* nat = &tab_deriv[((size_t(m) * nslot + slot) * S + s) * nnative];
+                            double f = omega * sf * e.w * azf;
+                            for (int q = 0; q < nnative; ++q) dIs[q] += f * nat[q];
+                        }
                     }
                 }
             }
         }
-        res.radiance[r] = I;
+        for (int s = 0; s < S; ++s) res.radiance[size_t(r) * S + s] = I[s];
         res.los_od[r] = od_total;
     }
 }
 
 inline void Solver::solve(const AtmosphereView& atm, int w, Result& res) {
-    res.radiance.assign(G.nlos, 0.0);
-    res.deriv.assign(size_t(G.nlos) * nnative, 0.0);
+    res.radiance.assign(size_t(G.nlos) * S, 0.0);
+    res.deriv.assign(size_t(G.nlos) * S * nnative, 0.0);
     res.los_od.assign(G.nlos, 0.0);
     res.num_azimuth_used = 0;
     if (G.spherical_pp) {

@@ -9,7 +9,8 @@
 //   * general band LU with partial pivoting + triangular solves: LAPACK dgbsv/dgbtrs
 //     (call sites sktran_do_rte.cpp:1676-1682,1755-1760; unblocked variant
 //     cpp/lib/sktran_disco/sktran_do_banded_lu.cpp:8-121).  Restated as dgbtf2/dgbtrs.
-//   * small dense LU with partial pivoting: Eigen::PartialPivLU (sktran_do_rte.cpp:255-256).
+//   * small dense LU with partial pivoting: Eigen::PartialPivLU (sktran_do_rte.cpp:255-256), and with
+//     complete pivoting: Eigen::FullPivLU (sktran_do_rte.cpp:258-263, NSTOKES = 3).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -429,6 +430,67 @@ inline void lu_solve(int n, const double* a, const int* piv, double* b) {
         b[k] = s / a[k * n + k];
     }
 }
+
+// ----------------------------------------------------------------------------------------
+// Dense LU with complete pivoting and rank detection: Eigen::FullPivLU, which the reference uses for the bordered
+// eigen-derivative systems of the polarised solver (sktran_do_rte.cpp:258-263).  As in Eigen, pivots below
+// eps * n * |largest pivot| count as zero and the corresponding unknowns of a solve are set to zero.
+// ----------------------------------------------------------------------------------------
+struct FullPivLU {
+    int n = 0, rank = 0;
+    std::vector<double> lu;
+    std::vector<int> rowperm, colperm;  // row k of LU is row rowperm[k] of A, column k is column colperm[k] of A
+    void compute(int n_, const double* a) {
+        n = n_;
+        lu.assign(a, a + size_t(n) * n);
+        rowperm.resize(n);
+        colperm.resize(n);
+        for (int i = 0; i < n; ++i) rowperm[i] = colperm[i] = i;
+        double maxpivot = 0;
+        std::vector<double> piv(n, 0.0);
+        for (int k = 0; k < n; ++k) {
+            int pr = k, pc = k;
+            double best = 0;
+            for (int i = k; i < n; ++i)
+                for (int j = k; j < n; ++j)
+                    if (std::abs(lu[size_t(i) * n + j]) > best) { best = std::abs(lu[size_t(i) * n + j]); pr = i; pc = j; }
+            if (best == 0.0) break;
+            maxpivot = std::max(maxpivot, best);
+            if (pr != k) {
+                for (int j = 0; j < n; ++j) std::swap(lu[size_t(k) * n + j], lu[size_t(pr) * n + j]);
+                std::swap(rowperm[k], rowperm[pr]);
+            }
+            if (pc != k) {
+                for (int i = 0; i < n; ++i) std::swap(lu[size_t(i) * n + k], lu[size_t(i) * n + pc]);
+                std::swap(colperm[k], colperm[pc]);
+            }
+            piv[k] = lu[size_t(k) * n + k];
+            const double inv = 1.0 / piv[k];
+            for (int i = k + 1; i < n; ++i) {
+                double l = lu[size_t(i) * n + k] * inv;
+                lu[size_t(i) * n + k] = l;
+                if (l != 0.0)
+                    for (int j = k + 1; j < n; ++j) lu[size_t(i) * n + j] -= l * lu[size_t(k) * n + j];
+            }
+        }
+        const double thresh = 2.220446049250313e-16 * n * maxpivot;
+        rank = 0;
+        for (int k = 0; k < n; ++k)
+            if (std::abs(piv[k]) > thresh) ++rank;
+    }
+    void solve(double* b) const {
+        std::vector<double> c(n);
+        for (int k = 0; k < n; ++k) c[k] = b[rowperm[k]];
+        for (int k = 0; k < n; ++k)
+            for (int i = k + 1; i < n; ++i) c[i] -= lu[size_t(i) * n + k] * c[k];
+        for (int k = rank - 1; k >= 0; --k) {
+            double s = c[k];
+            for (int j = k + 1; j < rank; ++j) s -= lu[size_t(k) * n + j] * c[j];
+            c[k] = s / lu[size_t(k) * n + k];
+        }
+        for (int k = 0; k < n; ++k) b[colperm[k]] = k < rank ? c[k] : 0.0;
+    }
+};
 
 // ----------------------------------------------------------------------------------------
 // General band matrix, LAPACK column-major band storage: A(i,j) -> ab[(kl+ku+i-j) + j*ldab],

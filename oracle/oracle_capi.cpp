@@ -28,7 +28,7 @@ extern "C" {
 // ray_params: per ray [cos_sza, relative_azimuth, observer_altitude, tangent_altitude | cos_viewing_zenith]
 void* orc_create(double cos_sza, double saa, double earth_radius, const double* altitudes, int ngrid, int interp_method,
                  int geotype, int nstr, int num_sza, int nrays, const int* ray_kinds, const double* ray_params,
-                 int ss_in_do) {
+                 int ss_in_do, int nstokes) {
     try {
         auto h = std::make_unique<Handle>();
         h->geo = skgeo::Geometry1D(cos_sza, saa, earth_radius, std::vector<double>(altitudes, altitudes + ngrid),
@@ -43,7 +43,7 @@ void* orc_create(double cos_sza, double saa, double earth_radius, const double* 
             specs[i].tangent_altitude = ray_params[4 * i + 3];
             specs[i].cos_viewing_zenith = ray_params[4 * i + 3];
         }
-        skgeo::build_disco_geometry(h->geo, specs, nstr, num_sza, h->dg);
+        skgeo::build_disco_geometry(h->geo, specs, nstr, num_sza, h->dg, nstokes);
         h->ss_in_do = ss_in_do;
         return h.release();
     } catch (const std::exception& e) {
@@ -67,8 +67,9 @@ int orc_streams(void* hv, double* mu, double* wt) {
     return 0;
 }
 
-// Outputs (C order): radiance[nwavel][nlos], d_k[nwavel][nlos][ngrid], d_ssa[nwavel][nlos][ngrid],
-// d_albedo[nwavel][nlos], los_od[nwavel][nlos], n_azimuth[nwavel].  Derivative outputs may be null.
+// Outputs (C order, S = nstokes): radiance[nwavel][nlos][S], d_k[nwavel][nlos][S][ngrid], d_ssa[nwavel][nlos][S][ngrid],
+// d_albedo[nwavel][nlos][S], los_od[nwavel][nlos], n_azimuth[nwavel].  Derivative outputs may be null.
+// leg: [nleg (*4 for S = 3: a1, a2, a3, b1 per order), ngrid, nwavel] as in the reference storage.
 // delta-M truncation fraction f[ngrid, nwavel] (location fastest) of an already scaled storage for the next orc_run calls
 int orc_set_delta_f(void* hv, const double* f) {
     auto* h = static_cast<Handle*>(hv);
@@ -81,11 +82,12 @@ int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
             double* d_k, double* d_ssa, double* d_albedo, double* los_od, int* n_azimuth) {
     auto* h = static_cast<Handle*>(hv);
     if (!h) return -1;
-    const int nlos = h->dg.nlos, ngrid = h->dg.ngrid;
+    const int nlos = h->dg.nlos, ngrid = h->dg.ngrid, S = h->dg.nstokes;
     oracle::AtmosphereView atm;
     atm.ngrid = ngrid;
     atm.nwavel = nwavel;
     atm.nleg = nleg;
+    atm.nstokes = S;
     atm.extinction = extinction;
     atm.ssa = ssa;
     atm.leg = leg;
@@ -115,13 +117,16 @@ int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
             try {
                 solver->solve(atm, w, res);
                 for (int r = 0; r < nlos; ++r) {
-                    radiance[size_t(w) * nlos + r] = res.radiance[r];
                     if (los_od) los_od[size_t(w) * nlos + r] = res.los_od[r];
-                    if (atm.derivatives) {
-                        const double* d = &res.deriv[size_t(r) * solver->num_native()];
-                        if (d_k) std::copy(d, d + ngrid, &d_k[(size_t(w) * nlos + r) * ngrid]);
-                        if (d_ssa) std::copy(d + ngrid, d + 2 * ngrid, &d_ssa[(size_t(w) * nlos + r) * ngrid]);
-                        if (d_albedo) d_albedo[size_t(w) * nlos + r] = d[2 * ngrid];
+                    for (int sc = 0; sc < S; ++sc) {
+                        const size_t o = (size_t(w) * nlos + r) * S + sc;
+                        radiance[o] = res.radiance[size_t(r) * S + sc];
+                        if (atm.derivatives) {
+                            const double* d = &res.deriv[(size_t(r) * S + sc) * solver->num_native()];
+                            if (d_k) std::copy(d, d + ngrid, &d_k[o * ngrid]);
+                            if (d_ssa) std::copy(d + ngrid, d + 2 * ngrid, &d_ssa[o * ngrid]);
+                            if (d_albedo) d_albedo[o] = d[2 * ngrid];
+                        }
                     }
                 }
                 if (n_azimuth) n_azimuth[w] = res.num_azimuth_used;

@@ -34,7 +34,7 @@ def lib():
         L = ctypes.CDLL(str(so))
         L.orc_create.restype = ctypes.c_void_p
         L.orc_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_int, ctypes.c_int,
-                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int]
+                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int, ctypes.c_int]
         L.orc_destroy.argtypes = [ctypes.c_void_p]
         L.orc_run.restype = ctypes.c_int
         L.orc_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int,
@@ -55,15 +55,16 @@ class OracleEngine:
     """rays: list of (kind, cos_sza, relative_azimuth, observer_altitude, tangent_altitude|cos_viewing_zenith)."""
 
     def __init__(self, cos_sza, saa, earth_radius, altitudes, interp_method, geotype, nstr, num_sza, rays,
-                 ss_in_do=True):
+                 ss_in_do=True, nstokes=1):
         self.alt = np.ascontiguousarray(altitudes, dtype=np.float64)
         self.nlos = len(rays)
         self.ngrid = len(self.alt)
         self.nstr = nstr
+        self.nstokes = nstokes
         kinds = np.ascontiguousarray([r[0] for r in rays], dtype=np.int32)
         params = np.ascontiguousarray([[r[1], r[2], r[3], r[4]] for r in rays], dtype=np.float64)
         self._h = lib().orc_create(cos_sza, saa, earth_radius, _p(self.alt), self.ngrid, interp_method, geotype, nstr,
-                                   num_sza, self.nlos, kinds.ctypes.data_as(_ip), _p(params), int(ss_in_do))
+                                   num_sza, self.nlos, kinds.ctypes.data_as(_ip), _p(params), int(ss_in_do), int(nstokes))
         if not self._h:
             raise RuntimeError("oracle engine construction failed")
 
@@ -85,8 +86,9 @@ class OracleEngine:
         return mu, wt
 
     def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, derivatives=False, nthreads=1, delta_f=None):
-        """extinction, ssa: [ngrid, nwavel]; leg: [nleg, ngrid, nwavel]; albedo: [nwavel] (Fortran-style axes as in
-        the reference storage: location fastest)."""
+        """extinction, ssa: [ngrid, nwavel]; leg: [nleg, ngrid, nwavel] (nstokes = 3: [4 * nleg, ngrid, nwavel] with
+        a1, a2, a3, b1 per order); albedo: [nwavel] (Fortran-style axes as in the reference storage: location fastest).
+        Outputs carry a trailing Stokes axis for nstokes = 3 (radiance [nwavel, nlos, 3], d_* [nwavel, nlos, 3, ngrid])."""
         k = np.asfortranarray(extinction, dtype=np.float64)
         w = np.asfortranarray(ssa, dtype=np.float64)
         lg = np.asfortranarray(leg, dtype=np.float64)
@@ -95,15 +97,17 @@ class OracleEngine:
         lib().orc_set_delta_f(self._h, _p(df))
         alb = np.ascontiguousarray(albedo, dtype=np.float64)
         irr = None if solar_irradiance is None else np.ascontiguousarray(solar_irradiance, dtype=np.float64)
-        rad = np.zeros((nwavel, self.nlos))
+        S = self.nstokes
+        sshape = (nwavel, self.nlos) if S == 1 else (nwavel, self.nlos, S)
+        rad = np.zeros(sshape)
         od = np.zeros((nwavel, self.nlos))
         nazi = np.zeros(nwavel, dtype=np.int32)
         dk = dw = da = None
         if derivatives:
-            dk = np.zeros((nwavel, self.nlos, self.ngrid))
-            dw = np.zeros((nwavel, self.nlos, self.ngrid))
-            da = np.zeros((nwavel, self.nlos))
-        rc = lib().orc_run(self._h, nwavel, lg.shape[0], _p(k), _p(w), _p(lg), _p(irr), _p(alb), int(derivatives),
+            dk = np.zeros(sshape + (self.ngrid,))
+            dw = np.zeros(sshape + (self.ngrid,))
+            da = np.zeros(sshape)
+        rc = lib().orc_run(self._h, nwavel, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), _p(irr), _p(alb), int(derivatives),
                            nthreads, _p(rad), _p(dk), _p(dw), _p(da), _p(od), nazi.ctypes.data_as(_ip))
         if rc != 0:
             raise RuntimeError(f"oracle run failed with code {rc}")

@@ -641,6 +641,47 @@ inline void wigner_d_m0(int m, double x, int lmax, double* out) {
     }
 }
 
+// d^l_{mn}(theta) for n != 0 (Mishchenko's recurrence F.4.1 with start F.4.3), x = cos(theta); l = 0..lmax-1
+//   cpp/include/sasktran2/math/wigner.h:52-160
+inline void wigner_d_mn(int m, int n, double x, int lmax, double* out) {
+    for (int l = 0; l < lmax; ++l) out[l] = 0.0;
+    const int lmin = std::max(std::abs(m), std::abs(n));
+    if (lmin >= lmax) return;
+    int zeta = 1;
+    if (n < m && ((m - n) % 2 != 0)) zeta = -1;
+    const int den1 = std::abs(m - n), den2 = std::abs(m + n);
+    double factorial = 1;
+    for (int i = 2 * lmin; i > 1; --i) {
+        factorial *= double(i);
+        if (i <= den1) factorial /= double(i);
+        if (i <= den2) factorial /= double(i);
+    }
+    double val = zeta * std::pow(2.0, -double(lmin)) * std::sqrt(factorial) * std::pow(1 - x, den1 / 2.0) * std::pow(1 + x, den2 / 2.0);
+    double prev = 0;
+    out[lmin] = val;
+    for (int l = lmin + 1; l < lmax; ++l) {
+        double mult = 1.0 / ((l - 1) * std::sqrt(double(l * l - m * m)) * std::sqrt(double(l * l - n * n)));
+        double cur = (2 * l - 1) * (l * (l - 1) * x - n * m);
+        double pri = l * std::sqrt(double((l - 1) * (l - 1) - m * m)) * std::sqrt(double((l - 1) * (l - 1) - n * n));
+        double t = val;
+        val = mult * (cur * val - pri * prev);
+        prev = t;
+        out[l] = val;
+    }
+}
+
+// polarised companions of d^l_{m0}:  R = -(d^l_{m2} + d^l_{m,-2})/2,  T = -(d^l_{m2} - d^l_{m,-2})/2
+//   cpp/include/sktran_disco/sktran_do_polarization_types.h:92-107
+inline void gsf_RT(int m, double x, int lmax, double* R, double* T) {
+    std::vector<double> dp(lmax), dn(lmax);
+    wigner_d_mn(m, 2, x, lmax, dp.data());
+    wigner_d_mn(m, -2, x, lmax, dn.data());
+    for (int l = 0; l < lmax; ++l) {
+        R[l] = -0.5 * (dp[l] + dn[l]);
+        T[l] = -0.5 * (dp[l] - dn[l]);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Complete precomputed geometry for one DISCO engine
 // ---------------------------------------------------------------------------
@@ -668,9 +709,11 @@ struct PlaneParallelLOS { double coszenith, azimuth, observer_altitude; };
 
 struct DiscoGeometry {
     int nstr = 0, nlyr = 0, ngrid = 0, nsza = 1, nlos = 0;
+    int nstokes = 1;                    // 1 or 3; the *_R / *_T tables are filled for 3 only
     bool spherical_pp = false;          // true: spherical interpolated post-processing, false: plane-parallel
     std::vector<double> mu, wt;         // nstr
     std::vector<double> lp_mu;          // [m][stream i < nstr][l]
+    std::vector<double> lp_mu_R, lp_mu_T, lp_angle_R, lp_angle_T, lp_los_R, lp_los_T;  // same shapes as lp_mu / lp_angle / lp_los
     std::vector<double> altitudes;      // ngrid
     std::vector<double> ceil_h, floor_h;  // nlyr (p=0 at TOA)
     std::vector<double> interp;         // [nlyr][ngrid] optical interpolator
@@ -697,8 +740,9 @@ struct DiscoGeometry {
 };
 
 inline void build_disco_geometry(const Geometry1D& g, const std::vector<RaySpec>& specs, int nstr, int num_sza,
-                                 DiscoGeometry& out) {
+                                 DiscoGeometry& out, int nstokes = 1) {
     out = DiscoGeometry();
+    out.nstokes = nstokes;
     const Coordinates& c = g.coords;
     const int ng = g.ngrid(), nlyr = ng - 1;
     out.nstr = nstr;
@@ -712,6 +756,13 @@ inline void build_disco_geometry(const Geometry1D& g, const std::vector<RaySpec>
     for (int m = 0; m < nstr; ++m)
         for (int i = 0; i < nstr; ++i)
             wigner_d_m0(m, std::cos(std::acos(out.mu[i])), nstr, &out.lp_mu[(size_t(m) * nstr + i) * nstr]);
+    if (nstokes == 3) {
+        out.lp_mu_R.assign(out.lp_mu.size(), 0);
+        out.lp_mu_T.assign(out.lp_mu.size(), 0);
+        for (int m = 0; m < nstr; ++m)
+            for (int i = 0; i < nstr; ++i)
+                gsf_RT(m, std::cos(std::acos(out.mu[i])), nstr, &out.lp_mu_R[(size_t(m) * nstr + i) * nstr], &out.lp_mu_T[(size_t(m) * nstr + i) * nstr]);
+    }
 
     // layers
     out.ceil_h.resize(nlyr);
@@ -786,6 +837,14 @@ inline void build_disco_geometry(const Geometry1D& g, const std::vector<RaySpec>
         for (int m = 0; m < nstr; ++m)
             for (int a = 0; a < out.nangle; ++a)
                 wigner_d_m0(m, std::cos(std::acos(out.cos_angles[a])), nstr, &out.lp_angle[(size_t(m) * out.nangle + a) * nstr]);
+        if (nstokes == 3) {
+            out.lp_angle_R.assign(out.lp_angle.size(), 0);
+            out.lp_angle_T.assign(out.lp_angle.size(), 0);
+            for (int m = 0; m < nstr; ++m)
+                for (int a = 0; a < out.nangle; ++a)
+                    gsf_RT(m, std::cos(std::acos(out.cos_angles[a])), nstr, &out.lp_angle_R[(size_t(m) * out.nangle + a) * nstr],
+                           &out.lp_angle_T[(size_t(m) * out.nangle + a) * nstr]);
+        }
         out.need_point.assign(size_t(out.nsza) * nlyr * out.nangle, 0);
         out.need_ground.assign(size_t(out.nsza) * out.nangle, 0);
 
@@ -884,6 +943,10 @@ inline void build_disco_geometry(const Geometry1D& g, const std::vector<RaySpec>
         }
         out.pp_los.resize(specs.size());
         out.lp_los.assign(specs.size() * size_t(nstr) * nstr, 0);
+        if (nstokes == 3) {
+            out.lp_los_R.assign(out.lp_los.size(), 0);
+            out.lp_los_T.assign(out.lp_los.size(), 0);
+        }
         for (size_t i = 0; i < specs.size(); ++i) {
             PlaneParallelLOS& l = out.pp_los[i];
             l.coszenith = -vrays[i].look_away.z;
@@ -892,6 +955,9 @@ inline void build_disco_geometry(const Geometry1D& g, const std::vector<RaySpec>
             l.observer_altitude = vrays[i].observer.position.z - c.earth_radius;
             for (int m = 0; m < nstr; ++m)
                 wigner_d_m0(m, std::cos(std::acos(l.coszenith)), nstr, &out.lp_los[(i * nstr + m) * nstr]);
+            if (nstokes == 3)
+                for (int m = 0; m < nstr; ++m)
+                    gsf_RT(m, std::cos(std::acos(l.coszenith)), nstr, &out.lp_los_R[(i * nstr + m) * nstr], &out.lp_los_T[(i * nstr + m) * nstr]);
         }
     }
     out.lp_csz.assign(size_t(out.nsza) * nstr * nstr, 0);

@@ -92,6 +92,62 @@ def planeparallel_case(case: dict):
                 albedo=np.array([case["albedo"]]), expected=np.array(case["expected"]) / case["sun"]["direct"])
 
 
+def planeparallel_vector_case(case: dict, siewert: dict | None = None):
+    """Engine inputs for one entry of tests/golden/do_vector_planeparallel.json (NSTOKES = 3), built the way the reference's
+    harness does (cpp/lib/tests/sktran_disco/test_util.cpp:24-118, cpp/lib/sktran_disco/sktran_do_testing.cpp:5-143):
+    leg[4 l + (0, 1, 2, 3)] = (a1, a2, a3, -b1) of order l."""
+    nstr = case["nstr"]
+    layers = case["layers"]
+    nlyr = len(layers)
+    alt = np.arange(nlyr + 1, dtype=float)
+    csz = case["sun"]["csz"]
+    rays = [(GROUND_VIEWING_SOLAR, csz, -case["sun"]["saz"] + az, alt[-1] + 1, cz) for cz, az in case["los_coszen_az"]]
+    k = np.zeros((nlyr + 1, 1))
+    w = np.zeros((nlyr + 1, 1))
+    leg = np.zeros((4 * nstr, nlyr + 1, 1))
+    for l, spec in enumerate(layers):
+        q = nlyr - l - 1
+        k[q, 0], w[q, 0] = spec[0], spec[1]
+        greek = np.zeros((nstr, 4))  # a1, a2, a3, b1
+        if case["layer_kind"] == "HG":
+            greek[:, 0] = [(2 * i + 1) * spec[2] ** i for i in range(nstr)]
+        elif case["layer_kind"] == "Rayleigh":
+            d = spec[2]
+            greek[0, 0] = 1.0
+            greek[2, 0] = (1 - d) / (2 + d)
+            greek[2, 1] = 6 * (1 - d) / (2 + d)
+            greek[2, 3] = np.sqrt(6.0) * (1 - d) / (2 + d)
+        elif case["layer_kind"] == "Siewert":
+            nt = min(nstr, 12)
+            for c, name in enumerate(("a1", "a2", "a3", "b1")):
+                greek[:nt, c] = siewert[name][:nt]
+        else:
+            raise ValueError(case["layer_kind"])
+        greek[:, 3] *= -1.0
+        leg[:, q, 0] = greek.reshape(-1)
+    geometry = dict(cos_sza=csz, saa=0.0, earth_radius=6_372_000.0, altitudes=alt, interp_method=INTERP_LOWER,
+                    geotype=GEO_PLANEPARALLEL)
+    return dict(geometry=geometry, config=dict(nstr=nstr, num_sza=1, nstokes=3), rays=rays, extinction=k, ssa=w, leg=leg,
+                albedo=np.array([case["albedo"]]),
+                expected=np.array(case["expected_stokes"]).reshape(-1, 3) / case["sun"]["direct"])
+
+
+def to_vector(s: dict, rayleigh_fraction=None):
+    """NSTOKES = 3 version of a scalar scenario: leg[4 l + (0, 1, 2, 3)] = (a1, a2, a3, -b1).  With `rayleigh_fraction` None only
+    a1 is set (the polarised solve must then reproduce the scalar one); otherwise the l = 2 Greek coefficients of Rayleigh
+    scattering (a2_2 = 6 a1_2, b1_2 = sqrt(6) a1_2 for depolarisation 0) are added with that weight."""
+    leg = s["leg"]
+    nleg = leg.shape[0]
+    v = np.zeros((4 * nleg,) + leg.shape[1:])
+    v[0::4] = leg
+    if rayleigh_fraction is not None:
+        v[4 * 2 + 1] = 6.0 * 0.5 * rayleigh_fraction
+        v[4 * 2 + 3] = -np.sqrt(6.0) * 0.5 * rayleigh_fraction
+    out = dict(s)
+    out.update(leg=v, config=dict(s["config"], nstokes=3))
+    return out
+
+
 def nadir_c1(num_wavelengths: int = 100, nstr: int = 2, observer_altitude: float = 200_000.0):
     """BASELINE.json configs[0]: plane-parallel nadir, 2-stream DISCO, 20 layers, 100 wavelengths,
     total optical depth swept over [0.05, 2], omega = 0.9, Rayleigh-like a = [1, 0, 0.5], albedo 0.3."""

@@ -9,12 +9,14 @@ from oracle.oracle_py import OracleEngine
 from tests import scenarios as sc
 
 GOLDEN = json.loads((Path(__file__).parent / "golden" / "do_scalar_planeparallel.json").read_text())
+GOLDEN_VEC = json.loads((Path(__file__).parent / "golden" / "do_vector_planeparallel.json").read_text())
 
 
 def make_oracle(s, ss_in_do=True):
     g = s["geometry"]
     return OracleEngine(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"], g["interp_method"], g["geotype"],
-                        s["config"]["nstr"], s["config"]["num_sza"], s["rays"], ss_in_do=ss_in_do)
+                        s["config"]["nstr"], s["config"]["num_sza"], s["rays"], ss_in_do=ss_in_do,
+                        nstokes=s["config"].get("nstokes", 1))
 
 
 def run_oracle(s, derivatives=False, **over):
@@ -93,3 +95,56 @@ def test_limb_c2_small_runs_and_needs_many_azimuth_orders():
     out = run_oracle(s, derivatives=True)
     assert np.all(np.isfinite(out["radiance"])) and np.all(out["radiance"] > 0)
     assert out["num_azimuth"].min() >= 6
+
+
+# ---------------------------------------------------------------------------------------------- NSTOKES = 3
+@pytest.mark.parametrize("case", GOLDEN_VEC["cases"], ids=[c["name"] for c in GOLDEN_VEC["cases"]])
+def test_vector_planeparallel_known_answers(case):
+    # cpp/lib/tests/sktran_disco/legacy/test_vector.cpp:81-277: |stokes * direct - expected| < tolerance for every (I, Q, U)
+    s = sc.planeparallel_vector_case(case, GOLDEN_VEC["siewert_greek_coefficients"])
+    out = run_oracle(s)
+    assert out["radiance"].shape == (1, len(case["los_coszen_az"]), 3)
+    assert np.max(np.abs(out["radiance"][0] - s["expected"])) * case["sun"]["direct"] < case["tolerance"]
+
+
+def test_vector_three_layers_equal_one():
+    # "Polarization Boundary Conditions", test_vector.cpp:279-314: 3 Rayleigh layers of 0.2 == 1 layer of 0.6, 16 streams, albedo 0.8
+    base = dict(GOLDEN_VEC["cases"][0], layer_kind="Rayleigh", albedo=0.8)
+    one = run_oracle(sc.planeparallel_vector_case({**base, "layers": [[0.6, 1.0, 0.0]]}))["radiance"]
+    three = run_oracle(sc.planeparallel_vector_case({**base, "layers": [[0.2, 1.0, 0.0]] * 3}))["radiance"]
+    assert np.abs(one[..., 1:]).max() > 1e-3   # the case is genuinely polarised
+    assert np.max(np.abs(one - three)) < 1e-6
+
+
+def test_vector_spherical_reduces_to_scalar_and_polarises():
+    # with only a1 set the NSTOKES = 3 spherical solve is the scalar one (pinned above) with Q = U = 0
+    s = sc.regression_1d(2)
+    scalar = run_oracle(s, derivatives=True)
+    vec = run_oracle(sc.to_vector(s), derivatives=True)
+    np.testing.assert_allclose(vec["radiance"][..., 0], scalar["radiance"], rtol=1e-10)
+    assert np.abs(vec["radiance"][..., 1:]).max() < 1e-14
+    np.testing.assert_allclose(vec["d_extinction"][..., 0, :], scalar["d_extinction"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(vec["d_ssa"][..., 0, :], scalar["d_ssa"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(vec["los_optical_depth"], scalar["los_optical_depth"], rtol=1e-14)
+    pol = run_oracle(sc.to_vector(s, rayleigh_fraction=0.9))
+    assert np.abs(pol["radiance"][..., 1]).max() > 1e-4 and np.abs(pol["radiance"][..., 2]).max() > 1e-5
+    # neglecting polarisation changes Rayleigh-like intensities by up to ~10 % (the classic scalar-approximation error)
+    assert 0.01 < np.max(np.abs(pol["radiance"][..., 0] / scalar["radiance"] - 1)) < 0.12
+
+
+def test_vector_spherical_weighting_functions_match_finite_differences():
+    s = sc.to_vector(sc.regression_1d(1), rayleigh_fraction=0.9)
+    out = run_oracle(s, derivatives=True)
+    for name, key in (("extinction", "d_extinction"), ("ssa", "d_ssa")):
+        for q in (0, 5, 12, 23):
+            base = s[name]
+            h = 1e-4 * base[q, :]
+            plus, minus = base.copy(), base.copy()
+            plus[q, :] += h
+            minus[q, :] -= h
+            fd = (run_oracle(s, **{name: plus})["radiance"] - run_oracle(s, **{name: minus})["radiance"]) / (2 * h[:, None, None])
+            scale = np.abs(out[key]).max(axis=3)
+            assert np.max(np.abs(fd - out[key][..., q]) / scale) < 1e-4, (name, q)
+    h = 1e-5
+    fd = (run_oracle(s, albedo=s["albedo"] + h)["radiance"] - run_oracle(s, albedo=s["albedo"] - h)["radiance"]) / (2 * h)
+    np.testing.assert_allclose(out["d_albedo"], fd, rtol=1e-5, atol=1e-11)
