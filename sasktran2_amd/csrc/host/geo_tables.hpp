@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "../hip/disco_core.hpp"
+#include "../hip/disco_vec_core.hpp"
 #include "geometry.hpp"
 
 namespace skhost {
@@ -195,6 +196,43 @@ struct GeoTables {
         g.pp_mode = pp_mode;
         g.n_lp = (int)lp_q.size();
         g.include_ss = include_ss;
+    }
+};
+
+// Tables of the polarised (NSTOKES = 3) path that go with a GeoTables: the R / T companions of the Legendre tables (same
+// shapes; zero-filled for NSTOKES = 1) and the sine azimuth factors of the ray layers (U component).
+struct VecTables {
+    int S = 1;
+    std::vector<double> lpmuR, lpmuT, lpangR, lpangT, lplosR, lplosT, rl_sinm_t;
+    void build(const skgeo::DiscoGeometry& G, const GeoTables& t) {
+        S = G.nstokes;
+        const int nstr = t.nstr, N = t.N;
+        lpmuR.assign(t.lpmu.size(), 0.0);
+        lpmuT.assign(t.lpmu.size(), 0.0);
+        lpangR.assign(t.lpang.size(), 0.0);
+        lpangT.assign(t.lpang.size(), 0.0);
+        lplosR.assign(t.lplos.size(), 0.0);
+        lplosT.assign(t.lplos.size(), 0.0);
+        if (S == 3) {
+            for (int m = 0; m < nstr; ++m)
+                for (int i = 0; i < N; ++i)
+                    for (int l = 0; l < nstr; ++l) {
+                        lpmuR[(size_t(m) * N + i) * nstr + l] = G.lp_mu_R[(size_t(m) * nstr + i) * nstr + l];
+                        lpmuT[(size_t(m) * N + i) * nstr + l] = G.lp_mu_T[(size_t(m) * nstr + i) * nstr + l];
+                    }
+            if (!G.lp_angle_R.empty() && lpangR.size() == G.lp_angle_R.size()) { lpangR = G.lp_angle_R; lpangT = G.lp_angle_T; }
+            if (!G.lp_los_R.empty() && lplosR.size() == G.lp_los_R.size()) { lplosR = G.lp_los_R; lplosT = G.lp_los_T; }
+        }
+        rl_sinm_t.assign(t.rl_azi.size() * size_t(nstr), 0.0);
+        for (size_t q = 0; q < t.rl_azi.size(); ++q)
+            for (int m = 0; m < nstr; ++m) rl_sinm_t[q * nstr + m] = std::sin(m * t.rl_azi[q]);
+    }
+    skv::VGeo host_view() const {
+        skv::VGeo v{};
+        v.S = S;
+        v.lpmuR = lpmuR.data(); v.lpmuT = lpmuT.data(); v.lpangR = lpangR.data(); v.lpangT = lpangT.data();
+        v.lplosR = lplosR.data(); v.lplosT = lplosT.data(); v.rl_sinm_t = rl_sinm_t.data();
+        return v;
     }
 };
 

@@ -1,0 +1,123 @@
+// TEST INFRASTRUCTURE: runs the task bodies of the polarised path (sasktran2_amd/csrc/hip/disco_vec_core.hpp, compiled here
+// with g++) on the CPU, one loop iteration per GPU thread, in the launch order of the HIP driver
+// (sasktran2_amd/csrc/hip/disco_vec_engine.inc).  Not part of the product library and never a fallback.
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../sasktran2_amd/csrc/host/geo_tables.hpp"
+
+namespace {
+struct Handle {
+    skgeo::Geometry1D geo;
+    skgeo::DiscoGeometry dg;
+    skhost::GeoTables tab;
+    skhost::VecTables vtab;
+};
+}  // namespace
+
+extern "C" {
+void* emuv_create(double cos_sza, double saa, double earth_radius, const double* altitudes, int ngrid, int interp_method,
+                  int geotype, int nstr, int num_sza, int nrays, const int* ray_kinds, const double* ray_params, int ss_in_do,
+                  int nstokes) {
+    try {
+        auto h = std::make_unique<Handle>();
+        h->geo = skgeo::Geometry1D(cos_sza, saa, earth_radius, std::vector<double>(altitudes, altitudes + ngrid),
+                                   (skgeo::Interpolation)interp_method, (skgeo::GeometryType)geotype);
+        std::vector<skgeo::RaySpec> specs(nrays);
+        for (int i = 0; i < nrays; ++i) {
+            specs[i].kind = (skgeo::RaySpec::Kind)ray_kinds[i];
+            specs[i].cos_sza = ray_params[4 * i + 0];
+            specs[i].horizontal_angle = ray_params[4 * i + 0];
+            specs[i].relative_azimuth = ray_params[4 * i + 1];
+            specs[i].observer_altitude = ray_params[4 * i + 2];
+            specs[i].tangent_altitude = ray_params[4 * i + 3];
+            specs[i].cos_viewing_zenith = ray_params[4 * i + 3];
+        }
+        skgeo::build_disco_geometry(h->geo, specs, nstr, num_sza, h->dg, nstokes);
+        h->tab.include_ss = ss_in_do;
+        h->tab.build(h->dg);
+        h->vtab.build(h->dg, h->tab);
+        return h.release();
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "emuv_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+void emuv_destroy(void* h) { delete static_cast<Handle*>(h); }
+
+// radiance: [nwavel][nlos][nstokes];  leg: [nwavel][ngrid][nleg][4] (reference storage order, nstokes = 3) or [..][nleg]
+int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg,
+             const double* solar_irradiance, const double* albedo, const double* delta_f, double* radiance, double* los_od, int* status) {
+    auto* h = static_cast<Handle*>(hv);
+    const skhost::GeoTables& t = h->tab;
+    skd::Geo g = t.host_view();
+    skv::VGeo vg = h->vtab.host_view();
+    const int S = vg.S, N = t.N, n = S * N, nlyr = t.nlyr, nstr = t.nstr, nw = nwavel, nlos = t.nlos;
+    const size_t nt = size_t(nw) * nlos;
+    std::vector<double> tau(size_t(nlyr) * nw), om(tau.size()), kbar(tau.size()), a(size_t(nlyr) * nstr * nw), T(size_t(nlyr + 1) * nw),
+        sec(tau.size()), od(size_t(t.nq_total) * nw), omloc(od.size()), srcw(od.size()), att_total(size_t(nlos) * nw), lod(nt);
+    std::vector<uint8_t> conv(size_t(t.nslot) * nw);
+    for (int sl = 0; sl < t.nslot; ++sl)
+        for (int w = 0; w < nw; ++w) conv[size_t(w) * t.nslot + sl] = t.slot_is_ground[sl] ? 1 : 255;
+    std::vector<int> notconv(nw, 0), norders(nw, nstr), stat(nw, 0);
+    skd::Bufs b{};
+    b.nw = nw; b.ext = extinction; b.ssa = ssa; b.leg = nullptr; b.nleg = 0; b.albedo = albedo; b.irradiance = solar_irradiance; b.delta_f = delta_f;
+    b.tau = tau.data(); b.om = om.data(); b.kbar = kbar.data(); b.a = a.data(); b.T = T.data(); b.sec = sec.data();
+    b.od = od.data(); b.omloc = omloc.data(); b.srcw = srcw.data(); b.att_total = att_total.data();
+    b.conv_order = conv.data(); b.notconv = notconv.data(); b.norders = norders.data(); b.status = stat.data(); b.los_od = lod.data();
+    const skv::VRec R(n);
+    std::vector<double> a4(size_t(nlyr) * nstr * 4 * nw), rec(size_t(nlyr) * R.size() * nw), dinv(size_t(nlyr) * 4 * n * n * nw),
+        xsol(size_t(nlyr) * 2 * n * nw), J(size_t(nstr) * std::max(t.nslot, 1) * nw * S, 0.0), rad(nt * S, 0.0);
+    std::vector<double> scratch(std::max({skv::kv1_scratch(n), skv::kv2_scratch(n), skv::kv3_scratch(n, nstr), skv::kvpp_scratch(n)}));
+    skv::VBufs v{};
+    v.S = S; v.n = n; v.leg = leg; v.nleg = nleg; v.a4 = a4.data(); v.rec = rec.data(); v.dinv = dinv.data(); v.xsol = xsol.data();
+    v.J = J.data(); v.radiance = rad.data(); v.scratch = scratch.data(); v.scratch_stride = 1;
+    const skv::Scr scr{scratch.data(), 1};
+    for (int w = 0; w < nw; ++w) {
+        skd::k0_layer_optics(g, b, w);  // tau / omega / LOS shells; its scalar a_l is not used (nleg = 0)
+        skv::kv0_coefficients(g, b, v, w);
+    }
+    if (g.pp_mode) {
+        for (int w = 0; w < nw; ++w) skd::k0_transmission(g, b, 0, w);
+        for (int m = 0; m < nstr; ++m) {
+            for (int w = 0; w < nw; ++w)
+                for (int p = 0; p < nlyr; ++p) skv::kv1_layer_solution(g, vg, b, v, 0, m, p, w, scr);
+            for (int w = 0; w < nw; ++w) skv::kv2_bvp(g, b, v, 0, m, w, scr);
+            for (int w = 0; w < nw; ++w)
+                for (int l = 0; l < nlos; ++l) skv::kvpp_los(g, vg, b, v, 0, m, l, w, scr);
+        }
+    } else {
+        for (int s = 0; s < g.nsza; ++s) {
+            for (int w = 0; w < nw; ++w) {
+                skd::k0_transmission(g, b, s, w);
+                norders[w] = nstr;
+                notconv[w] = 0;
+            }
+            for (int m = 0; m < nstr; ++m) {
+                int active = 0;
+                for (int w = 0; w < nw; ++w) active += (m < norders[w]);
+                if (!active) break;
+                for (int w = 0; w < nw; ++w)
+                    for (int p = 0; p < nlyr; ++p)
+                        if (m < norders[w]) skv::kv1_layer_solution(g, vg, b, v, s, m, p, w, scr);
+                for (int w = 0; w < nw; ++w)
+                    if (m < norders[w]) skv::kv2_bvp(g, b, v, s, m, w, scr);
+                for (int w = 0; w < nw; ++w)
+                    for (int p = 0; p < nlyr; ++p)
+                        if (m < norders[w]) skv::kv3_table_values(g, vg, b, v, s, m, p, w, scr);
+                for (int w = 0; w < nw; ++w) skd::k_stop_rule(g, b, s, m, w);
+            }
+        }
+        for (int w = 0; w < nw; ++w)
+            for (int l = 0; l < nlos; ++l) skv::kv4_los(g, vg, b, v, l, w);
+    }
+    for (size_t i = 0; i < nt * S; ++i) radiance[i] = rad[i];
+    for (size_t i = 0; i < nt; ++i)
+        if (los_od) los_od[i] = lod[i];
+    for (int w = 0; w < nw; ++w)
+        if (status) status[w] = stat[w];
+    return 0;
+}
+}

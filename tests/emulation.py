@@ -68,3 +68,58 @@ def run_emulated(s, derivatives=True):
                 "status": status}
     finally:
         lib().emu_destroy(h)
+
+
+# ---------------------------------------------------------------------------------------------- polarised path
+_LIBV = None
+
+
+def libv():
+    global _LIBV
+    if _LIBV is None:
+        so = _HERE / "_build" / "libemuv.so"
+        srcs = [_HERE / "emulate_vector.cpp", _ROOT / "sasktran2_amd/csrc/hip/disco_vec_core.hpp",
+                _ROOT / "sasktran2_amd/csrc/hip/disco_core.hpp", _ROOT / "sasktran2_amd/csrc/host/geo_tables.hpp",
+                _ROOT / "sasktran2_amd/csrc/host/geometry.hpp"]
+        if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+            so.parent.mkdir(exist_ok=True)
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(srcs[0])])
+        L = ctypes.CDLL(str(so))
+        L.emuv_create.restype = ctypes.c_void_p
+        L.emuv_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int, ctypes.c_int]
+        L.emuv_destroy.argtypes = [ctypes.c_void_p]
+        L.emuv_run.restype = ctypes.c_int
+        L.emuv_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]
+        _LIBV = L
+    return _LIBV
+
+
+def run_emulated_vector(s):
+    """Radiances [nwavel, nlos, nstokes] of the polarised task bodies (disco_vec_core.hpp) executed on the CPU."""
+    g = s["geometry"]
+    alt = np.ascontiguousarray(g["altitudes"], dtype=np.float64)
+    rays = s["rays"]
+    kinds = np.ascontiguousarray([r[0] for r in rays], dtype=np.int32)
+    params = np.ascontiguousarray([[r[1], r[2], r[3], r[4]] for r in rays], dtype=np.float64)
+    S = s["config"].get("nstokes", 1)
+    L = libv()
+    h = L.emuv_create(g["cos_sza"], g["saa"], g["earth_radius"], _p(alt), len(alt), g["interp_method"], g["geotype"],
+                      s["config"]["nstr"], s["config"]["num_sza"], len(rays), kinds.ctypes.data_as(_ip), _p(params),
+                      int(s["config"].get("ss_in_do", True)), S)
+    assert h
+    try:
+        k = np.asfortranarray(s["extinction"], dtype=np.float64)
+        w = np.asfortranarray(s["ssa"], dtype=np.float64)
+        lg = np.asfortranarray(s["leg"], dtype=np.float64)
+        nw, nlos = k.shape[1], len(rays)
+        alb = np.ascontiguousarray(s["albedo"], dtype=np.float64)
+        df = None if s.get("delta_f") is None else np.asfortranarray(s["delta_f"], dtype=np.float64)
+        rad, od = np.zeros((nw, nlos, S)), np.zeros((nw, nlos))
+        status = np.zeros(nw, dtype=np.int32)
+        rc = L.emuv_run(h, nw, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), None, _p(alb), _p(df), _p(rad), _p(od),
+                        status.ctypes.data_as(_ip))
+        assert rc == 0
+        return {"radiance": rad if S == 3 else rad[..., 0], "los_optical_depth": od, "status": status}
+    finally:
+        L.emuv_destroy(h)

@@ -1,0 +1,49 @@
+"""The task bodies of the polarised (NSTOKES = 3) device path, executed on the CPU, against the reference's vector known-answer
+tests and the pinned oracle (runs without a GPU; the same bodies run as HIP kernels in tests/test_gpu_parity.py)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests import scenarios as sc
+from tests.emulation import run_emulated_vector
+from tests.test_oracle_golden import run_oracle
+
+GOLDEN_VEC = json.loads((Path(__file__).parent / "golden" / "do_vector_planeparallel.json").read_text())
+
+
+@pytest.mark.parametrize("case", GOLDEN_VEC["cases"], ids=[c["name"] for c in GOLDEN_VEC["cases"]])
+def test_vector_known_answers_emulated(case):
+    # cpp/lib/tests/sktran_disco/legacy/test_vector.cpp:81-277 with the reference's own tolerances
+    s = sc.planeparallel_vector_case(case, GOLDEN_VEC["siewert_greek_coefficients"])
+    out = run_emulated_vector(s)
+    assert not out["status"].any()
+    assert np.max(np.abs(out["radiance"][0] - s["expected"])) * case["sun"]["direct"] < case["tolerance"]
+    # and against the oracle at the north-star tolerance (1e-6 relative on Stokes I)
+    ora = run_oracle(s)["radiance"]
+    # conservative scattering (Coulson's tables, ssa dithered to 1 - 1e-9) makes the smallest eigenvalue ~1e-9 and the two
+    # eigen-solvers agree to ~1e-5 only; the reference loosens its own tolerance a hundredfold for SSA = 1 (test_scalar.cpp)
+    conservative = any(layer[1] >= 1.0 for layer in case["layers"])
+    np.testing.assert_allclose(out["radiance"][..., 0], ora[..., 0], rtol=5e-5 if conservative else 1e-6)
+    assert np.max(np.abs(out["radiance"] - ora)) < (5e-6 if conservative else 1e-9)
+
+
+def test_vector_path_reproduces_scalar_path_for_one_stokes_component():
+    # NSTOKES = 1 through the run-time-n task bodies == the pinned scalar oracle (plane parallel and spherical)
+    case = dict(json.loads((Path(__file__).parent / "golden" / "do_scalar_planeparallel.json").read_text())["cases"][0])
+    s = sc.planeparallel_case(case)
+    np.testing.assert_allclose(run_emulated_vector(s)["radiance"], run_oracle(s)["radiance"], rtol=1e-10)
+    s = sc.regression_1d(3)
+    out = run_emulated_vector(s)
+    np.testing.assert_allclose(out["radiance"], s["expected_radiance"], rtol=5e-7, atol=2e-13)   # the reference's regression values
+
+
+def test_vector_spherical_matches_oracle():
+    s = sc.to_vector(sc.regression_1d(2), rayleigh_fraction=0.9)
+    out = run_emulated_vector(s)
+    ora = run_oracle(s)
+    assert not out["status"].any()
+    np.testing.assert_allclose(out["radiance"][..., 0], ora["radiance"][..., 0], rtol=1e-6)
+    assert np.max(np.abs(out["radiance"] - ora["radiance"])) < 1e-9 * np.abs(ora["radiance"]).max() + 1e-12
+    np.testing.assert_allclose(out["los_optical_depth"], ora["los_optical_depth"], rtol=1e-12)
