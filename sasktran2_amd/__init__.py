@@ -158,21 +158,42 @@ class ViewingGeometry:
 
 
 class _Storage:
-    def __init__(self, ngrid, nwavel, nleg):
+    def __init__(self, ngrid, nwavel, nleg, nstokes=1):
         self.total_extinction = np.zeros((ngrid, nwavel), order="F")
         self.ssa = np.zeros((ngrid, nwavel), order="F")
         self.emission_source = np.zeros((ngrid, nwavel), order="F")
-        self.leg_coeff = np.zeros((nleg, ngrid, nwavel), order="F")
+        # NSTOKES = 3: four Greek coefficients per order, order-major (cpp/include/c_api/atmosphere.h:77-83)
+        self.leg_coeff = np.zeros((nleg * (4 if nstokes == 3 else 1), ngrid, nwavel), order="F")
         self.solar_irradiance = np.ones(nwavel)
 
 
 class _LegCoeff:
-    def __init__(self, storage):
+    """Views of the Greek coefficients (src/sasktran2/atmosphere.py `leg_coeff.a1 / a2 / a3 / b1`)."""
+
+    def __init__(self, storage, nstokes=1):
         self._s = storage
+        self._step = 4 if nstokes == 3 else 1
 
     @property
     def a1(self):
-        return self._s.leg_coeff
+        return self._s.leg_coeff[0::self._step]
+
+    def _polarised(self, k):
+        if self._step == 1:
+            raise AttributeError("only a1 exists for NSTOKES = 1")
+        return self._s.leg_coeff[k::4]
+
+    @property
+    def a2(self):
+        return self._polarised(1)
+
+    @property
+    def a3(self):
+        return self._polarised(2)
+
+    @property
+    def b1(self):
+        return self._polarised(3)
 
 
 class _Surface:
@@ -196,8 +217,9 @@ class Atmosphere:
         self._ngrid = len(model_geometry.altitudes())
         self._nwavel = int(numwavel)
         self._calculate_derivatives = bool(calculate_derivatives)
-        self.storage = _Storage(self._ngrid, self._nwavel, config.num_singlescatter_moments)
-        self.leg_coeff = _LegCoeff(self.storage)
+        self.nstokes = int(config.num_stokes)
+        self.storage = _Storage(self._ngrid, self._nwavel, config.num_singlescatter_moments, self.nstokes)
+        self.leg_coeff = _LegCoeff(self.storage, self.nstokes)
         self.surface = _Surface(self._nwavel)
         self._altitudes = model_geometry.altitudes()
 
@@ -229,24 +251,26 @@ class Engine:
         L = lib()
         st = atmosphere.storage
         nw, ngrid, nlos = atmosphere._nwavel, atmosphere._ngrid, self.nlos
+        S = int(self._config.num_stokes)
+        per = 4 if S == 3 else 1
         ext, ssa = np.asfortranarray(st.total_extinction), np.asfortranarray(st.ssa)
         em, leg = np.asfortranarray(st.emission_source), np.asfortranarray(st.leg_coeff)
         # delta-M scaling rewrites the storage in place (src/sasktran2/atmosphere.py:845-854 applies it with order = num_streams
         # when more moments than streams are stored): work on copies so that the caller's arrays keep the unscaled properties
         delta_order = None
-        if self._config.delta_m_scaling and leg.shape[0] > self._config.num_streams:
+        if self._config.delta_m_scaling and S == 1 and leg.shape[0] > self._config.num_streams:
             delta_order = int(self._config.num_streams)
             ext, ssa, leg = ext.copy(order="F"), ssa.copy(order="F"), leg.copy(order="F")
         irr, alb = np.ascontiguousarray(st.solar_irradiance), np.ascontiguousarray(atmosphere.surface.albedo, dtype=float)
         emis = np.ascontiguousarray(atmosphere.surface.emission)
         derivs = atmosphere.calculate_derivatives
-        h_st = L.sk_atmosphere_storage_create(ngrid, nw, leg.shape[0], 1, _p(ssa), _p(ext), _p(em), _p(leg), _p(irr))
-        h_brdf = L.sk_brdf_create_lambertian(1)
-        h_su = L.sk_surface_create(nw, 1, _p(emis))
+        h_st = L.sk_atmosphere_storage_create(ngrid, nw, leg.shape[0] // per, S, _p(ssa), _p(ext), _p(em), _p(leg), _p(irr))
+        h_brdf = L.sk_brdf_create_lambertian(S)
+        h_su = L.sk_surface_create(nw, S, _p(emis))
         L.sk_surface_set_brdf(h_su, h_brdf, _p(alb))
         h_atm = L.sk_atmosphere_create(h_st, h_su, int(derivs), 0)
-        rad = np.zeros((nw, nlos, 1))
-        h_out = L.sk_output_create(_p(rad), nw * nlos, 1, None, 0)
+        rad = np.zeros((nw, nlos, S))
+        h_out = L.sk_output_create(_p(rad), nw * nlos, S, None, 0)
         out = {"radiance": rad}
         try:
             if derivs:
@@ -257,15 +281,15 @@ class Engine:
                     ptr = _dp()
                     getattr(L, f"sk_deriv_mapping_get_{which}")(m, ctypes.byref(ptr))
                     np.ctypeslib.as_array(ptr, shape=(ngrid * nw,))[:] = 1.0
-                    out[name] = np.zeros((ngrid, nw, nlos, 1))
-                    L.sk_output_assign_derivative_memory(h_out, name.encode(), _p(out[name]), nw * nlos, 1, ngrid)
+                    out[name] = np.zeros((ngrid, nw, nlos, S))
+                    L.sk_output_assign_derivative_memory(h_out, name.encode(), _p(out[name]), nw * nlos, S, ngrid)
                 m = ctypes.c_void_p()
                 L.sk_surface_get_derivative_mapping(h_su, b"wf_albedo", ctypes.byref(m))
                 ptr = _dp()
                 L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
                 np.ctypeslib.as_array(ptr, shape=(nw,))[:] = 1.0
-                out["wf_albedo"] = np.zeros((nw, nlos, 1))
-                L.sk_output_assign_surface_derivative_memory(h_out, b"wf_albedo", _p(out["wf_albedo"]), nw * nlos, 1)
+                out["wf_albedo"] = np.zeros((nw, nlos, S))
+                L.sk_output_assign_surface_derivative_memory(h_out, b"wf_albedo", _p(out["wf_albedo"]), nw * nlos, S)
             if _mapping_hook is not None:
                 _mapping_hook(L, h_st, h_out, out)
             if delta_order is not None:

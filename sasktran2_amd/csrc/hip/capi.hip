@@ -337,7 +337,8 @@ int sk_output_get_los_optical_depth(OutputC* o, double** od) {
 Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
     if (!c || !g || !v) return nullptr;
     try {
-        if (c->num_stokes != 1) throw std::runtime_error("only NSTOKES=1 is implemented");
+        if (c->num_stokes != 1 && c->num_stokes != 3) throw std::runtime_error("NSTOKES must be 1 or 3");
+        if (c->num_stokes == 3 && c->stokes_basis != 0) throw std::runtime_error("only the standard Stokes basis is part of this build");
         if (c->ms_source != 0) throw std::runtime_error("multiple_scatter_source must be discrete_ordinates (0)");
         if (c->ss_source != 2 && c->ss_source != 3)
             throw std::runtime_error("single_scatter_source must be discrete_ordinates (2) or none (3)");
@@ -349,7 +350,7 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
         skgeo::Geometry1D geo(g->cos_sza, g->saa, g->earth_radius, g->grid, (skgeo::Interpolation)g->interp,
                               (skgeo::GeometryType)g->geotype);
         skgeo::DiscoGeometry dg;
-        skgeo::build_disco_geometry(geo, v->rays, c->num_streams, c->num_sza, dg);
+        skgeo::build_disco_geometry(geo, v->rays, c->num_streams, c->num_sza, dg, c->num_stokes);
         auto e = std::make_unique<Engine>();
         e->config = *c;
         e->dev = std::make_unique<skdev::DeviceEngine>(dg, c->ss_source == 2);
@@ -370,15 +371,70 @@ int sk_engine_calculate_radiance_block_thread(Engine* e, OutputC* o, int, int, i
     return (e && o) ? 0 : -1;
 }
 
+// NSTOKES = 3 (and NSTOKES = 1 stream counts outside the matrix-core path): radiances [wavel][los][stokes] and LOS optical depths;
+// weighting functions of this path are not built, a request for them is answered with -2.
+static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
+    const AtmosphereStorage& st = *atm->storage;
+    const Surface& su = *atm->surface;
+    const int S = e->config.num_stokes;
+    if (atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty())) {
+        set_error("sk_engine_calculate_radiance: weighting functions are not available for NSTOKES = 3 / this stream count");
+        return -2;
+    }
+    if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
+    const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
+    if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");
+    const size_t nloc_w = size_t(ngrid) * nw, nt = size_t(nw) * nlos, per = (S == 3) ? 4 : 1;
+    DeviceCache& C = e->cache;
+    double* d_ext = (double*)C.get("ext", nloc_w * 8);
+    double* d_ssa = (double*)C.get("ssa", nloc_w * 8);
+    double* d_leg = (double*)C.get("leg", nloc_w * st.nleg * per * 8);
+    double* d_alb = (double*)C.get("albedo", size_t(nw) * 8);
+    double* d_rad = (double*)C.get("radiance", nt * S * 8);
+    double* d_od = (double*)C.get("los_od", nt * 8);
+    double* d_odt = (double*)C.get("los_od_t", nt * 8);
+    int* d_status = (int*)C.get("status", size_t(nw) * 4);
+    double* d_irr = nullptr;
+    HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * per * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyHostToDevice));
+    if (st.irradiance) {
+        d_irr = (double*)C.get("irradiance", size_t(nw) * 8);
+        HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyHostToDevice));
+    }
+    double* d_f = nullptr;
+    if (!st.delta_f.empty()) {
+        d_f = (double*)C.get("delta_f", nloc_w * 8);
+        HIPC(hipMemcpy(d_f, st.delta_f.data(), nloc_w * 8, hipMemcpyHostToDevice));
+    }
+    e->dev->set_delta_m_fraction(d_f);
+    e->dev->solve_device_vector(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, d_od, d_status, nullptr);
+    e->dev->set_delta_m_fraction(nullptr);
+    hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
+    HIPC(hipGetLastError());
+    HIPC(hipDeviceSynchronize());
+    std::vector<int> status(nw);
+    HIPC(hipMemcpy(status.data(), d_status, size_t(nw) * 4, hipMemcpyDeviceToHost));
+    for (int w = 0; w < nw; ++w)
+        if (status[w] != 0) throw std::runtime_error("solver failure (status bits " + std::to_string(status[w]) + ") at wavelength " + std::to_string(w));
+    HIPC(hipMemcpy(out->radiance, d_rad, nt * S * 8, hipMemcpyDeviceToHost));
+    out->los_od.resize(nt);
+    HIPC(hipMemcpy(out->los_od.data(), d_odt, nt * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /*only_initialize*/) {
     if (!e || !atm || !out || !atm->storage || !atm->surface) return -1;
     try {
         const AtmosphereStorage& st = *atm->storage;
         const Surface& su = *atm->surface;
-        if (st.nstokes != 1 || out->nstokes != 1) return -2;
+        const int S = e->config.num_stokes;
+        if (st.nstokes != S || out->nstokes != S) return -2;
         if (st.nloc != e->ngrid) throw std::runtime_error("atmosphere grid does not match the engine geometry");
         if (!su.brdf_args) throw std::runtime_error("surface has no BRDF set");
         if (su.brdf && su.brdf->kind != 0) return -2;  // only the Lambertian surface is part of this path
+        if (e->dev->vector_mode()) return calculate_radiance_vector(e, atm, out);
         for (auto& kv : out->derivs) {
             auto it = st.maps.find(kv.first);
             if (it == st.maps.end()) continue;

@@ -179,6 +179,7 @@ struct DeviceEngine::Impl {
     Geo g{};
     DevMem geo_mem;
     int* d_slot_is_ground = nullptr;
+    int* d_vec_active = nullptr;  // dummy counter of the stop-rule kernel in the polarised driver
     // One "slot" = scratch buffers + stream for one block of wavelengths in flight.  Blocks of a spectrum are dealt
     // round-robin to the slots; kernels of different slots run concurrently (a single one of these latency-bound
     // kernels cannot fill the SIMDs by itself).
@@ -216,7 +217,9 @@ DeviceEngine::DeviceEngine(const skgeo::DiscoGeometry& dg, bool ss_in_do) : impl
     I.tab.include_ss = ss_in_do ? 1 : 0;
     I.tab.build(dg);
     const auto& t = I.tab;
-    switch (t.N) { case 1: case 2: case 4: case 8: case 16: break; default: throw std::runtime_error("sasktran2_amd: num_streams must be one of 2, 4, 8, 16, 32"); }
+    const bool matrix_path = (t.N == 1 || t.N == 2 || t.N == 4 || t.N == 8 || t.N == 16);
+    vector_mode_ = (dg.nstokes == 3) || !matrix_path;  // radiances through the run-time-n task bodies (disco_vec_core.hpp)
+    if (dg.nstokes != 1 && dg.nstokes != 3) throw std::runtime_error("sasktran2_amd: NSTOKES must be 1 or 3");
     Geo& g = I.g;
     t.fill_scalars(g);
     DevMem& M = I.geo_mem;
@@ -234,9 +237,11 @@ DeviceEngine::DeviceEngine(const skgeo::DiscoGeometry& dg, bool ss_in_do) : impl
     g.pp_mu = M.upload(t.pp_mu); g.pp_azi = M.upload(t.pp_azi); g.pp_first = M.upload(t.pp_first); g.pp_lf = M.upload(t.pp_lf);
     g.lplos = M.upload(t.lplos);
     I.d_slot_is_ground = M.upload(t.slot_is_ground);
+    I.d_vec_active = M.alloc<int>(1);
     HIP_CHECK(hipEventCreateWithFlags(&I.fork, hipEventDisableTiming));
     HIP_CHECK(hipEventCreate(&I.ev0));
     HIP_CHECK(hipEventCreate(&I.ev1));
+    if (vector_mode_) init_vector(dg);
 }
 
 DeviceEngine::~DeviceEngine() {
@@ -254,6 +259,7 @@ DeviceEngine::~DeviceEngine() {
         if (impl_->fork) (void)hipEventDestroy(impl_->fork);
         if (impl_->ev0) (void)hipEventDestroy(impl_->ev0);
         if (impl_->ev1) (void)hipEventDestroy(impl_->ev1);
+        destroy_vector();
         delete impl_;
     }
 }
@@ -571,6 +577,7 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
                                 double* d_wf_ext, double* d_wf_ssa, double* d_wf_alb, double* d_los_od, int* d_status,
                                 void* stream, int max_chunk) {
     Impl& I = *impl_;
+    if (vector_mode_) throw std::runtime_error("sasktran2_amd: this stream count / NSTOKES is served by solve_device_vector (radiances only)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const auto& t = I.tab;
     // Launch shape (measured on MI355X, C2, with the three-stage order pipeline of run_chunk): one block of up to 10 000
@@ -626,5 +633,7 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
         }
     HIP_CHECK(hipGetLastError());
 }
+
+#include "disco_vec_engine.inc"
 
 }  // namespace skdev

@@ -10,6 +10,7 @@ namespace skdev {
 class DeviceEngine {
   public:
     struct Impl;
+    struct VecImpl;
     // ss_in_do: the DO source carries the solar single-scatter term (plane-parallel post-processing only)
     explicit DeviceEngine(const skgeo::DiscoGeometry& dg, bool ss_in_do = true);
     ~DeviceEngine();
@@ -31,6 +32,13 @@ class DeviceEngine {
     // delta-M truncation fraction of the (already scaled) optical properties: DEVICE pointer [nwavel][ngrid] used by the following
     // solve_device calls, or null (sk_atmosphere_apply_delta_m_scaling, cpp/lib/atmosphere/atmosphere.cpp:73-200)
     void set_delta_m_fraction(const double* d_f);
+
+    // Polarised path (NSTOKES = 3; also NSTOKES = 1 with a stream count the matrix-core path does not cover): radiances only.
+    // d_leg: [nwavel][ngrid][nleg][4] (a1, a2, a3, b1) for NSTOKES = 3; d_radiance: [nwavel][nlos][nstokes].
+    bool vector_mode() const { return vector_mode_; }
+    int nstokes() const;
+    void solve_device_vector(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg, const double* d_albedo,
+                             const double* d_irradiance, double* d_radiance, double* d_los_od, int* d_status, void* stream);
     size_t bytes_per_wavelength() const;
     size_t scratch_bytes() const;   // scratch currently allocated (all slots)
     int last_chunk() const;         // wavelengths per launch of the last solve
@@ -42,7 +50,12 @@ class DeviceEngine {
 
   private:
     void ensure_scratch(int nw, int nslots);
+    void init_vector(const skgeo::DiscoGeometry& dg);
+    void ensure_vector_scratch(int nw);
+    void destroy_vector();
     Impl* impl_;
+    VecImpl* vec_ = nullptr;
+    bool vector_mode_ = false;
 };
 
 }  // namespace skdev

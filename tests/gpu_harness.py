@@ -13,7 +13,9 @@ def build_engine(s):
     config = sk.Config()
     config.num_streams = s["config"]["nstr"]
     config.num_sza = s["config"]["num_sza"]
-    config.num_singlescatter_moments = s["leg"].shape[0]
+    nstokes = s["config"].get("nstokes", 1)
+    config.num_stokes = nstokes
+    config.num_singlescatter_moments = s["leg"].shape[0] // (4 if nstokes == 3 else 1)
     config.multiple_scatter_source = sk.MultipleScatterSource.DiscreteOrdinates
     config.single_scatter_source = sk.SingleScatterSource.DiscreteOrdinates
     geometry = sk.Geometry1D(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"],
@@ -40,9 +42,14 @@ def run_product(s, derivatives=True, engine=None):
     atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=derivatives)
     atmosphere.storage.total_extinction[:] = s["extinction"]
     atmosphere.storage.ssa[:] = s["ssa"]
-    atmosphere.leg_coeff.a1[:] = s["leg"]
+    if s["config"].get("nstokes", 1) == 3:
+        atmosphere.storage.leg_coeff[:] = s["leg"]   # (a1, a2, a3, b1) per order, as the reference stores them
+    else:
+        atmosphere.leg_coeff.a1[:] = s["leg"]
     atmosphere.surface.albedo[:] = s["albedo"]
     res = engine.calculate_radiance(atmosphere, as_dataset=False)
+    if s["config"].get("nstokes", 1) == 3:
+        return {"radiance": res["radiance"], "los_optical_depth": res["los_optical_depth"]}
     out = {"radiance": res["radiance"][:, :, 0], "los_optical_depth": res["los_optical_depth"]}
     if derivatives:
         out["d_extinction"] = np.transpose(res["wf_extinction"][:, :, :, 0], (1, 2, 0))

@@ -2,6 +2,8 @@
 reference's own pinned values.  Tolerances are BASELINE.json's: 1e-6 relative on Stokes I, 1e-4 on weighting functions
 (relative to the largest weighting function of the profile, the reference's own WF criterion)."""
 import copy
+import json
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -379,3 +381,54 @@ def test_interpolated_and_log_space_derivative_mappings():
     native = f_ext[:, :, None] * res["wf_extinction"][..., 0] + f_ssa[:, :, None] * res["wf_ssa"][..., 0]   # [ngrid, nw, nlos]
     want = np.einsum("qj,qwl->jwl", interp, native) / res["radiance"][None, :, :, 0]
     np.testing.assert_allclose(res["wf_custom"][..., 0], want, rtol=1e-12, atol=1e-300)
+
+
+# ---------------------------------------------------------------------------------------------- NSTOKES = 3 (radiances)
+_GOLDEN_VEC = json.loads((Path(__file__).parent / "golden" / "do_vector_planeparallel.json").read_text())
+
+
+@pytest.mark.parametrize("case", _GOLDEN_VEC["cases"], ids=[c["name"] for c in _GOLDEN_VEC["cases"]])
+def test_vector_known_answers_on_device(case):
+    """The reference's polarised known-answer tests (test_vector.cpp:81-277: scalar equivalence, Siewert, Coulson) through the C
+    ABI with NSTOKES = 3, at the reference's tolerances and against the pinned oracle."""
+    s = sc.planeparallel_vector_case(case, _GOLDEN_VEC["siewert_greek_coefficients"])
+    out = run_product(s, derivatives=False)
+    assert out["radiance"].shape == (1, len(case["los_coszen_az"]), 3)
+    assert np.max(np.abs(out["radiance"][0] - s["expected"])) * case["sun"]["direct"] < case["tolerance"]
+    ora = run_oracle(s)["radiance"]
+    conservative = any(layer[1] >= 1.0 for layer in case["layers"])   # see tests/test_vector_emulation.py
+    np.testing.assert_allclose(out["radiance"][..., 0], ora[..., 0], rtol=5e-5 if conservative else 1e-6)
+    assert np.max(np.abs(out["radiance"] - ora)) < (5e-6 if conservative else 1e-9)
+
+
+def test_vector_spherical_limb_on_device():
+    s = sc.to_vector(sc.regression_1d(5), rayleigh_fraction=0.9)
+    out = run_product(s, derivatives=False)
+    ora = run_oracle(s)
+    np.testing.assert_allclose(out["radiance"][..., 0], ora["radiance"][..., 0], rtol=1e-6)
+    assert np.max(np.abs(out["radiance"] - ora["radiance"])) < 1e-9 * np.abs(ora["radiance"]).max() + 1e-12
+    np.testing.assert_allclose(out["los_optical_depth"], ora["los_optical_depth"], rtol=1e-12)
+    assert np.abs(out["radiance"][..., 1:]).max() > 1e-4
+
+
+def test_vector_limb_16_streams_on_device():
+    # C4-like (polarised limb) at 16 streams, 50 layers, a few wavelengths
+    s = sc.to_vector(sc.limb_c2(num_wavelengths=3), rayleigh_fraction=0.6)
+    out = run_product(s, derivatives=False)
+    ora = run_oracle(s)
+    np.testing.assert_allclose(out["radiance"][..., 0], ora["radiance"][..., 0], rtol=1e-6)
+    assert np.max(np.abs(out["radiance"] - ora["radiance"])) < 1e-8 * np.abs(ora["radiance"]).max()
+
+
+def test_vector_weighting_functions_are_refused():
+    s = sc.to_vector(sc.regression_1d(1), rayleigh_fraction=0.9)
+    with pytest.raises(RuntimeError, match="-2"):
+        run_product(s, derivatives=True)
+
+
+def test_scalar_40_streams_through_the_runtime_n_path():
+    # stream counts outside {2, 4, 8, 16, 32} are served (radiances only) by the run-time-n task bodies
+    case = dict(json.loads((Path(__file__).parent / "golden" / "do_scalar_planeparallel.json").read_text())["cases"][0], nstr=40)
+    s = sc.planeparallel_case(case)
+    out = run_product(s, derivatives=False)
+    np.testing.assert_allclose(out["radiance"], run_oracle(s)["radiance"], rtol=1e-8)
