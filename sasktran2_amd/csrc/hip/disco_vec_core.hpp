@@ -2,8 +2,9 @@
 //
 // Same formulation as disco_core.hpp (symmetrised eigenproblem + Jacobi, Green's function particular solution,
 // block-tridiagonal boundary value problem, Legendre-space source table) written for a run-time matrix size
-// n = NSTOKES * N (row r = NSTOKES * stream + Stokes component) and one GPU thread per task, with every work matrix in a
-// thread-strided HBM scratch ([element][thread], so the lanes of a wavefront touch consecutive doubles).  It is the
+// n = NSTOKES * N (row r = NSTOKES * stream + Stokes component).  The two heavy stages (layer eigen-solution, boundary value
+// problem) are written for a team of lanes sharing the work matrices of one task (a wavefront / workgroup with the matrices in
+// LDS when they fit, in HBM otherwise); the light stages run one thread per task with a thread-strided HBM scratch.  It is the
 // device-side specification the matrix-core kernels of the scalar path will be generalised against; the C ABI uses it for
 // NSTOKES = 3 radiances (weighting functions of the polarised solver are not built yet).
 //
@@ -153,166 +154,228 @@ SKD_HD void load_coef(const Bufs& b, const VBufs& v, int nstr, int p, int l, int
     for (int c = 0; c < 4; ++c) c4[c] = a[size_t(c) * b.nw];
 }
 
-// =================================================================================================
-// KV1: homogeneous + particular solution of one layer for azimuth order m    (task = wavelength x layer)
-//   scratch: 8 n^2 + 6 n doubles per thread
-// =================================================================================================
-SKD_HD size_t kv1_scratch(int n) { return 8 * size_t(n) * n + 6 * size_t(n); }
+// A team of lanes (a wavefront or a workgroup on the device, one "lane" on the CPU) works on one task: every lane calls the
+// task function with the same arguments, loops written with SKV_PAR are shared out over the lanes and team.sync() separates a
+// phase that writes shared work arrays from the next one that reads them.
+struct Team {
+    int lane, width;
+    SKD_HD void sync() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __syncthreads();
+#endif
+    }
+};
+#define SKV_PAR(i, count) for (int i = team.lane; i < (count); i += team.width)
 
-SKD_HD void kv1_layer_solution(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, Scr scr) {
+// =================================================================================================
+// KV1: homogeneous + particular solution of one layer for azimuth order m    (task = wavelength x layer, one team)
+//   ws: 8 n^2 + 8 n + 64 doubles of team-shared work space (LDS when it fits, HBM otherwise)
+// =================================================================================================
+SKD_HD size_t kv1_scratch(int n) { return 8 * size_t(n) * n + 8 * size_t(n) + 64; }
+
+SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws) {
     const int N = g.N, S = v.S, n = v.n, nstr = g.nstr, nw = b.nw;
     const VRec R(n);
     double* rec = vrec_at(v, g.nlyr, p, w);
     const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
     const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
-    const size_t nn = size_t(n) * n;
-    Scr Ep = scr.sub(0), Em = scr.sub(nn), Bp = scr.sub(2 * nn), Bm = scr.sub(3 * nn), Tm = scr.sub(4 * nn), V = scr.sub(5 * nn),
-        X = scr.sub(6 * nn), U = scr.sub(7 * nn);
-    Scr lam = scr.sub(8 * nn), kk = scr.sub(8 * nn + n), nrm = scr.sub(8 * nn + 2 * n), Qp = scr.sub(8 * nn + 3 * n),
-        Qm = scr.sub(8 * nn + 4 * n), tmp = scr.sub(8 * nn + 5 * n);
+    const int nn = n * n;
+    double *Ep = ws, *Em = ws + nn, *Bp = ws + 2 * nn, *Bm = ws + 3 * nn, *Tm = ws + 4 * nn, *V = ws + 5 * nn, *X = ws + 6 * nn, *U = ws + 7 * nn;
+    double *lam = ws + 8 * nn, *kk = lam + n, *nrm = kk + n, *Qp = nrm + n, *Qm = Qp + n, *acp = Qm + n, *acm = acp + n, *rot = acm + n;  // rot: n + 64
     auto rw = [&](int r) { return g.wt[r / S]; };
     auto rmu = [&](int r) { return g.mu[r / S]; };
-    // ---- E+ = (plain + negated) / 2, E- = (plain - negated) / 2 of the Greek-matrix products, block by block
-    for (int e = 0; e < int(nn); ++e) { Ep[e] = 0; Em[e] = 0; }
-    for (int l = m; l < nstr; ++l) {
-        double c4[4];
-        load_coef(b, v, nstr, p, l, w, c4);
-        const double sg = ((l - m) & 1) ? -1.0 : 1.0;
-        for (int i = 0; i < N; ++i) {
-            const Fun3 fi = fun_mu(g, vg, m, i);
-            for (int j = 0; j < N; ++j) {
-                const Fun3 fj = fun_mu(g, vg, m, j);
-                if (S == 1) {
-                    const double t = c4[0] * fi.P[l] * fj.P[l];
-                    Ep[size_t(i) * n + j] += 0.5 * (t + sg * t);
-                    Em[size_t(i) * n + j] += 0.5 * (t - sg * t);
-                    continue;
-                }
-                // columns of Pi_l(mu_j), pushed through B_l and B_l D, then Pi_l(mu_i)
-                for (int s2 = 0; s2 < 3; ++s2) {
-                    double ex[3] = {0, 0, 0}, col[3], bc[3], bdc[3], y0[3], y1[3];
-                    ex[s2] = 1;
-                    pi_apply(fj.P[l], fj.R[l], fj.T[l], ex, col);
-                    greek_apply(c4, col, bc);
-                    const double dcol[3] = {col[0], col[1], -col[2]};
-                    greek_apply(c4, dcol, bdc);
-                    pi_apply(fi.P[l], fi.R[l], fi.T[l], bc, y0);
-                    pi_apply(fi.P[l], fi.R[l], fi.T[l], bdc, y1);
-                    for (int s1 = 0; s1 < 3; ++s1) {
-                        const size_t e = size_t(i * 3 + s1) * n + (j * 3 + s2);
-                        Ep[e] += 0.5 * (y0[s1] + sg * y1[s1]);
-                        Em[e] += 0.5 * (y0[s1] - sg * y1[s1]);
-                    }
+    // ---- E+ = (plain + negated) / 2, E- = (plain - negated) / 2 of the Greek-matrix products: one (i, j) block per lane
+    SKV_PAR(blk, N * N) {
+        const int i = blk / N, j = blk % N;
+        double ep[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, em[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const Fun3 fi = fun_mu(g, vg, m, i), fj = fun_mu(g, vg, m, j);
+        for (int l = m; l < nstr; ++l) {
+            double c4[4];
+            load_coef(b, v, nstr, p, l, w, c4);
+            const double sg = ((l - m) & 1) ? -1.0 : 1.0;
+            if (S == 1) {
+                const double t = c4[0] * fi.P[l] * fj.P[l];
+                ep[0] += 0.5 * (t + sg * t);
+                em[0] += 0.5 * (t - sg * t);
+                continue;
+            }
+            // columns of Pi_l(mu_j), pushed through B_l and B_l D, then Pi_l(mu_i)
+            for (int s2 = 0; s2 < 3; ++s2) {
+                double ex[3] = {0, 0, 0}, col[3], bc[3], bdc[3], y0[3], y1[3];
+                ex[s2] = 1;
+                pi_apply(fj.P[l], fj.R[l], fj.T[l], ex, col);
+                greek_apply(c4, col, bc);
+                const double dcol[3] = {col[0], col[1], -col[2]};
+                greek_apply(c4, dcol, bdc);
+                pi_apply(fi.P[l], fi.R[l], fi.T[l], bc, y0);
+                pi_apply(fi.P[l], fi.R[l], fi.T[l], bdc, y1);
+                for (int s1 = 0; s1 < 3; ++s1) {
+                    ep[s1 * 3 + s2] += 0.5 * (y0[s1] + sg * y1[s1]);
+                    em[s1 * 3 + s2] += 0.5 * (y0[s1] - sg * y1[s1]);
                 }
             }
         }
+        for (int s1 = 0; s1 < S; ++s1)
+            for (int s2 = 0; s2 < S; ++s2) {
+                const int r = i * S + s1, c = j * S + s2;
+                const double e_p = ep[s1 * 3 + s2], e_m = em[s1 * 3 + s2];
+                Ep[r * n + c] = e_p;
+                Em[r * n + c] = e_m;
+                const double dlt = (r == c) ? 1.0 / rmu(r) : 0.0;
+                const double sq = sqrt(rw(r) / rmu(r)) * sqrt(rw(c) / rmu(c));
+                Bp[r * n + c] = dlt - sq * om * e_p;
+                Bm[r * n + c] = dlt - sq * om * e_m;
+            }
     }
-    for (int r = 0; r < n; ++r)
-        for (int c = 0; c < n; ++c) {
-            const double dlt = (r == c) ? 1.0 / rmu(r) : 0.0;
-            const double sq = sqrt(rw(r) / rmu(r)) * sqrt(rw(c) / rmu(c));
-            Bp[size_t(r) * n + c] = dlt - sq * om * Ep[size_t(r) * n + c];
-            Bm[size_t(r) * n + c] = dlt - sq * om * Em[size_t(r) * n + c];
-        }
+    team.sync();
     int err = 0;
-    // ---- Cholesky B+ = L L^T (lower, in place)
+    // ---- Cholesky B+ = L L^T (lower, in place), one column per step
     for (int j = 0; j < n; ++j) {
-        double d = Bp[size_t(j) * n + j];
-        for (int k = 0; k < j; ++k) d -= Bp[size_t(j) * n + k] * Bp[size_t(j) * n + k];
+        double d = Bp[j * n + j];
+        for (int k = 0; k < j; ++k) d -= Bp[j * n + k] * Bp[j * n + k];
         if (!(d > 0)) { err |= skd::ERR_CHOLESKY; d = 1.0; }
         d = sqrt(d);
-        Bp[size_t(j) * n + j] = d;
-        for (int i = j + 1; i < n; ++i) {
-            double t = Bp[size_t(i) * n + j];
-            for (int k = 0; k < j; ++k) t -= Bp[size_t(i) * n + k] * Bp[size_t(j) * n + k];
-            Bp[size_t(i) * n + j] = t / d;
+        team.sync();
+        SKV_PAR(i, n) {
+            if (i > j) {
+                double t = Bp[i * n + j];
+                for (int k = 0; k < j; ++k) t -= Bp[i * n + k] * Bp[j * n + k];
+                Bp[i * n + j] = t / d;
+            } else if (i == j) {
+                Bp[j * n + j] = d;
+            } else {
+                Bp[i * n + j] = 0;
+            }
         }
-        for (int i = 0; i < j; ++i) Bp[size_t(i) * n + j] = 0;
+        team.sync();
     }
     // ---- As = L^T B- L (into Bm)
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
+    SKV_PAR(e, nn) {
+        const int i = e / n, j = e % n;
+        double t = 0;
+        for (int r = j; r < n; ++r) t += Bm[i * n + r] * Bp[r * n + j];
+        Tm[e] = t;
+    }
+    team.sync();
+    SKV_PAR(e, nn) {
+        const int i = e / n, j = e % n;
+        if (j <= i) {
             double t = 0;
-            for (int r = j; r < n; ++r) t += Bm[size_t(i) * n + r] * Bp[size_t(r) * n + j];
-            Tm[size_t(i) * n + j] = t;
+            for (int r = i; r < n; ++r) t += Bp[r * n + i] * Tm[r * n + j];
+            Bm[i * n + j] = t;
+            Bm[j * n + i] = t;
         }
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j <= i; ++j) {
-            double t = 0;
-            for (int r = i; r < n; ++r) t += Bp[size_t(r) * n + i] * Tm[size_t(r) * n + j];
-            Bm[size_t(i) * n + j] = t;
-            Bm[size_t(j) * n + i] = t;
-        }
-    // ---- cyclic Jacobi on As, eigenvectors -> V
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) V[size_t(i) * n + j] = (i == j) ? 1.0 : 0.0;
-    bool converged = false;
-    for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
-        double off = 0, dia = 0;
-        for (int i = 0; i < n; ++i) {
-            dia += Bm[size_t(i) * n + i] * Bm[size_t(i) * n + i];
-            for (int j = i + 1; j < n; ++j) off += Bm[size_t(i) * n + j] * Bm[size_t(i) * n + j];
-        }
-        if (off <= 1e-30 * dia || off == 0) { converged = true; break; }
-        for (int pp = 0; pp < n - 1; ++pp)
-            for (int q = pp + 1; q < n; ++q) {
-                const double apq = Bm[size_t(pp) * n + q];
-                if (apq == 0.0) continue;
-                const double app = Bm[size_t(pp) * n + pp], aqq = Bm[size_t(q) * n + q];
-                const double theta = (aqq - app) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-                Bm[size_t(pp) * n + pp] = app - t * apq;
-                Bm[size_t(q) * n + q] = aqq + t * apq;
-                Bm[size_t(pp) * n + q] = 0;
-                Bm[size_t(q) * n + pp] = 0;
-                for (int r = 0; r < n; ++r) {
-                    if (r != pp && r != q) {
-                        const double arp = Bm[size_t(r) * n + pp], arq = Bm[size_t(r) * n + q];
-                        const double np_ = c * arp - sn * arq, nq_ = sn * arp + c * arq;
-                        Bm[size_t(r) * n + pp] = np_;
-                        Bm[size_t(pp) * n + r] = np_;
-                        Bm[size_t(r) * n + q] = nq_;
-                        Bm[size_t(q) * n + r] = nq_;
+        V[e] = (i == j) ? 1.0 : 0.0;
+    }
+    team.sync();
+    // ---- Jacobi with the round-robin ("tournament") ordering: n/2 disjoint rotations per step, applied as A <- J^T A J
+    {
+        const int np = (n + 1) & ~1, half = np / 2;
+        double* rc = rot;          // cos of pair k
+        double* rs = rot + half;   // sin of pair k (0 when the pair is skipped)
+        bool converged = false;
+        for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
+            double off = 0, dia = 0;
+            for (int i = 0; i < n; ++i) {
+                dia += Bm[i * n + i] * Bm[i * n + i];
+                for (int j = i + 1; j < n; ++j) off += Bm[i * n + j] * Bm[i * n + j];
+            }
+            if (off <= 1e-30 * dia || off == 0) { converged = true; break; }
+            for (int step = 0; step < np - 1; ++step) {
+                auto pair_of = [&](int k, int& pp, int& q) {
+                    int a_, b_;
+                    if (k == 0) { a_ = np - 1; b_ = step; }
+                    else { a_ = (step + k) % (np - 1); b_ = (step - k + (np - 1)) % (np - 1); }
+                    pp = a_ < b_ ? a_ : b_;
+                    q = a_ < b_ ? b_ : a_;
+                };
+                team.sync();
+                SKV_PAR(k, half) {
+                    int pp, q;
+                    pair_of(k, pp, q);
+                    double c = 1.0, sn = 0.0;
+                    if (q < n) {
+                        const double apq = Bm[pp * n + q];
+                        if (apq != 0.0) {
+                            const double app = Bm[pp * n + pp], aqq = Bm[q * n + q];
+                            const double theta = (aqq - app) / (2.0 * apq);
+                            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                            c = 1.0 / sqrt(t * t + 1.0);
+                            sn = t * c;
+                        }
                     }
-                    const double vrp = V[size_t(r) * n + pp], vrq = V[size_t(r) * n + q];
-                    V[size_t(r) * n + pp] = c * vrp - sn * vrq;
-                    V[size_t(r) * n + q] = sn * vrp + c * vrq;
+                    rc[k] = c;
+                    rs[k] = sn;
+                }
+                team.sync();
+                SKV_PAR(e, half * n) {  // columns: A <- A J, V <- V J
+                    const int k = e / n, r = e % n;
+                    const double c = rc[k], sn = rs[k];
+                    if (sn != 0.0) {
+                        int pp, q;
+                        pair_of(k, pp, q);
+                        const double arp = Bm[r * n + pp], arq = Bm[r * n + q];
+                        Bm[r * n + pp] = c * arp - sn * arq;
+                        Bm[r * n + q] = sn * arp + c * arq;
+                        const double vrp = V[r * n + pp], vrq = V[r * n + q];
+                        V[r * n + pp] = c * vrp - sn * vrq;
+                        V[r * n + q] = sn * vrp + c * vrq;
+                    }
+                }
+                team.sync();
+                SKV_PAR(e, half * n) {  // rows: A <- J^T A
+                    const int k = e / n, cidx = e % n;
+                    const double c = rc[k], sn = rs[k];
+                    if (sn != 0.0) {
+                        int pp, q;
+                        pair_of(k, pp, q);
+                        const double apc = Bm[pp * n + cidx], aqc = Bm[q * n + cidx];
+                        double vp_ = c * apc - sn * aqc, vq_ = sn * apc + c * aqc;
+                        if (cidx == q) vp_ = 0.0;   // the rotated pair is annihilated exactly
+                        if (cidx == pp) vq_ = 0.0;
+                        Bm[pp * n + cidx] = vp_;
+                        Bm[q * n + cidx] = vq_;
+                    }
                 }
             }
+            team.sync();
+        }
+        if (!converged) err |= skd::ERR_EIGEN;
     }
-    if (!converged) err |= skd::ERR_EIGEN;
-    for (int j = 0; j < n; ++j) {
-        double l_ = Bm[size_t(j) * n + j];
-        if (!(l_ > 0)) { err |= skd::ERR_EIGEN; l_ = fabs(l_) + 1e-300; }
-        lam[j] = l_;
+    team.sync();
+    SKV_PAR(j, n) {
+        double l_ = Bm[j * n + j];
+        if (!(l_ > 0)) { l_ = fabs(l_) + 1e-300; lam[j] = -1.0; } else { lam[j] = l_; }
         kk[j] = sqrt(l_);
     }
-    // ---- X = T^-1 L^-T V ;  U = S+ X with S+ = M^-1 (I - om E+ W)
+    team.sync();
     for (int j = 0; j < n; ++j)
+        if (lam[j] < 0) err |= skd::ERR_EIGEN;
+    // ---- X = T^-1 L^-T V (one column per lane) ;  U = S+ X with S+ = M^-1 (I - om E+ W)
+    SKV_PAR(j, n) {
         for (int i = n - 1; i >= 0; --i) {
-            double t = V[size_t(i) * n + j];
-            for (int r = i + 1; r < n; ++r) t -= Bp[size_t(r) * n + i] * X[size_t(r) * n + j];
-            X[size_t(i) * n + j] = t / Bp[size_t(i) * n + i];
+            double t = V[i * n + j];
+            for (int r = i + 1; r < n; ++r) t -= Bp[r * n + i] * X[r * n + j];
+            X[i * n + j] = t / Bp[i * n + i];
         }
-    for (int i = 0; i < n; ++i) {
-        const double tt = sqrt(rw(i) * rmu(i));
-        for (int j = 0; j < n; ++j) X[size_t(i) * n + j] /= tt;
+        for (int i = 0; i < n; ++i) X[i * n + j] /= sqrt(rw(i) * rmu(i));
     }
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            double t = X[size_t(i) * n + j] / rmu(i);
-            for (int r = 0; r < n; ++r) t -= om * rw(r) * Ep[size_t(i) * n + r] / rmu(i) * X[size_t(r) * n + j];
-            U[size_t(i) * n + j] = t;
-        }
-    // ---- W+-, norms
-    for (int j = 0; j < n; ++j) {
+    team.sync();
+    SKV_PAR(e, nn) {
+        const int i = e / n, j = e % n;
+        double t = 0;
+        for (int r = 0; r < n; ++r) t += rw(r) * Ep[i * n + r] * X[r * n + j];
+        U[e] = (X[e] - om * t) / rmu(i);
+    }
+    team.sync();
+    // ---- W+-, norms (one solution per lane)
+    SKV_PAR(j, n) {
         double nr = 0;
         rec[R.K() + j] = kk[j];
         rec[R.E() + j] = exp(-kk[j] * th);
         for (int i = 0; i < n; ++i) {
-            const double uk = U[size_t(i) * n + j] / kk[j];
-            const double wp = 0.5 * (X[size_t(i) * n + j] + uk), wm = 0.5 * (X[size_t(i) * n + j] - uk);
+            const double uk = U[i * n + j] / kk[j];
+            const double wp = 0.5 * (X[i * n + j] + uk), wm = 0.5 * (X[i * n + j] - uk);
             rec[R.WP() + i + n * j] = wp;
             rec[R.WM() + i + n * j] = wm;
             nr += rw(i) * rmu(i) * (wp * wp - wm * wm);
@@ -322,39 +385,34 @@ SKD_HD void kv1_layer_solution(const Geo& g, const VGeo& vg, const Bufs& b, cons
     // ---- solar pseudo-source: first column of the products with the unpolarised sun (single_scat_st, sktran_do_lpproduct.h:339-384)
     const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * kPi);
     const double* lpc = g.lpcsz + (size_t(s) * nstr + m) * nstr;
-    bool allzero = true;
-    for (int r = 0; r < n; ++r) { Qp[r] = 0; Qm[r] = 0; }
-    for (int l = m; l < nstr; ++l) {
-        double c4[4];
-        load_coef(b, v, nstr, p, l, w, c4);
-        const double sg = ((l - m) & 1) ? -1.0 : 1.0;
-        const double x[3] = {lpc[l], 0, 0};
-        double bx[3];
-        greek_apply(c4, x, bx);  // B_l D x = B_l x for a pure-intensity vector
-        for (int i = 0; i < N; ++i) {
-            const Fun3 fi = fun_mu(g, vg, m, i);
-            if (S == 1) {
-                Qp[i] += bx[0] * fi.P[l];
-                Qm[i] += sg * bx[0] * fi.P[l];
-            } else {
-                double y[3];
-                pi_apply(fi.P[l], fi.R[l], fi.T[l], bx, y);
-                for (int s1 = 0; s1 < 3; ++s1) {
-                    Qp[i * 3 + s1] += y[s1];
-                    Qm[i * 3 + s1] += sg * y[s1];
-                }
+    SKV_PAR(i, N) {
+        double qp[3] = {0, 0, 0}, qm[3] = {0, 0, 0};
+        const Fun3 fi = fun_mu(g, vg, m, i);
+        for (int l = m; l < nstr; ++l) {
+            double c4[4];
+            load_coef(b, v, nstr, p, l, w, c4);
+            const double sg = ((l - m) & 1) ? -1.0 : 1.0;
+            const double x[3] = {lpc[l], 0, 0};
+            double bx[3], y[3] = {0, 0, 0};
+            greek_apply(c4, x, bx);  // B_l D x = B_l x for a pure-intensity vector
+            if (S == 1) y[0] = bx[0] * fi.P[l];
+            else pi_apply(fi.P[l], fi.R[l], fi.T[l], bx, y);
+            for (int s1 = 0; s1 < S; ++s1) {
+                qp[s1] += y[s1];
+                qm[s1] += sg * y[s1];
             }
         }
+        for (int s1 = 0; s1 < S; ++s1) {
+            Qp[i * S + s1] = qp[s1] * fm * g.wt[i] * om;
+            Qm[i * S + s1] = qm[s1] * fm * g.wt[i] * om;
+        }
     }
-    for (int r = 0; r < n; ++r) {
-        Qp[r] *= fm * rw(r) * om;
-        Qm[r] *= fm * rw(r) * om;
+    team.sync();
+    bool allzero = true;
+    for (int r = 0; r < n; ++r)
         if (Qp[r] != 0 || Qm[r] != 0) allzero = false;
-    }
-    for (int c = 0; c < 4; ++c)
-        for (int i = 0; i < n; ++i) rec[R.G() + c * n + i] = 0;
-    for (int j = 0; j < n; ++j) {
-        double Ap = 0, Am = 0;
+    SKV_PAR(j, n) {
+        double Ap = 0, Am = 0, cp = 0, cm = 0;
         if (!allzero) {
             for (int i = 0; i < n; ++i) {
                 const double wp = rec[R.WP() + i + n * j], wm = rec[R.WM() + i + n * j];
@@ -365,19 +423,31 @@ SKD_HD void kv1_layer_solution(const Geo& g, const VGeo& vg, const Bufs& b, cons
             Am /= nrm[j];
             skd::Mult Cp, Cm;
             skd::green_multipliers(T, th, sc, kk[j], Cp, Cm);
-            for (int i = 0; i < n; ++i) {
-                const double wp = rec[R.WP() + i + n * j], wm = rec[R.WM() + i + n * j];
-                rec[R.G() + 0 * n + i] += Am * Cm.v * wm;
-                rec[R.G() + 1 * n + i] += Am * Cm.v * wp;
-                rec[R.G() + 2 * n + i] += Ap * Cp.v * wp;
-                rec[R.G() + 3 * n + i] += Ap * Cp.v * wm;
-            }
+            cp = Ap * Cp.v;
+            cm = Am * Cm.v;
         }
         rec[R.AP() + j] = Ap;
         rec[R.AM() + j] = Am;
+        acp[j] = cp;
+        acm[j] = cm;
     }
-    (void)tmp;
-    if (err) {
+    team.sync();
+    SKV_PAR(i, n) {
+        double g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+        for (int j = 0; j < n; ++j) {
+            const double wp = rec[R.WP() + i + n * j], wm = rec[R.WM() + i + n * j];
+            g0 += acm[j] * wm;
+            g1 += acm[j] * wp;
+            g2 += acp[j] * wp;
+            g3 += acp[j] * wm;
+        }
+        rec[R.G() + 0 * n + i] = g0;
+        rec[R.G() + 1 * n + i] = g1;
+        rec[R.G() + 2 * n + i] = g2;
+        rec[R.G() + 3 * n + i] = g3;
+    }
+    team.sync();
+    if (err && team.lane == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
         atomicOr(&b.status[w], err);
 #else
@@ -387,147 +457,159 @@ SKD_HD void kv1_layer_solution(const Geo& g, const VGeo& vg, const Bufs& b, cons
 }
 
 // =================================================================================================
-// KV2: block-tridiagonal boundary value problem, factor + solve                 (task = wavelength)
-//   same block rows as skd::k2a_bvp with 2n x 2n blocks; scratch: 10 n^2 + 8 n doubles per thread
+// KV2: block-tridiagonal boundary value problem, factor + solve                 (task = wavelength, one team)
+//   same block rows as skd::k2a_bvp with 2n x 2n blocks; ws: 10 n^2 + 10 n doubles of team-shared work space
 // =================================================================================================
-SKD_HD size_t kv2_scratch(int n) { return 10 * size_t(n) * n + 8 * size_t(n); }
+SKD_HD size_t kv2_scratch(int n) { return 10 * size_t(n) * n + 10 * size_t(n); }
 
-SKD_HD void kv2_bvp(const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, Scr scr) {
+SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, double* ws) {
     const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nw = b.nw, nlyr = g.nlyr;
     const VRec R(n);
     const double rho = (m == 0) ? b.albedo[w] : 0.0;  // Lambertian
     const double kd = 2.0;
-    const size_t mm = size_t(M2) * M2;
-    Scr D = scr.sub(0), Dinv = scr.sub(mm), T1 = scr.sub(2 * mm), r = scr.sub(2 * mm + size_t(n) * M2), rprev = scr.sub(2 * mm + size_t(n) * M2 + M2),
-        E = scr.sub(2 * mm + size_t(n) * M2 + 2 * M2), Eprev = scr.sub(2 * mm + size_t(n) * M2 + 2 * M2 + n), xn = scr.sub(2 * mm + size_t(n) * M2 + 2 * M2 + 2 * n);
+    const int mm = M2 * M2;
+    double *D = ws, *Dinv = ws + mm, *T1 = ws + 2 * mm, *r = T1 + n * M2, *rprev = r + M2, *xn = rprev + M2, *fcol = xn + M2, *refl = fcol + M2;  // refl: 2n
+    bool singular = false;
     for (int p = 0; p < nlyr; ++p) {
         const double* c = vrec_at(v, nlyr, p, w);
-        for (int j = 0; j < n; ++j) E[j] = c[R.E() + j];
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) {
-                const double wp = c[R.WP() + i + n * j], wm = c[R.WM() + i + n * j];
-                D[size_t(i) * M2 + j] = -wp;
-                D[size_t(i) * M2 + n + j] = -wm * E[j];
-                D[size_t(n + i) * M2 + j] = wm * E[j];
-                D[size_t(n + i) * M2 + n + j] = wp;
-            }
-        for (int i = 0; i < n; ++i) {
-            r[i] = c[R.G() + 0 * n + i];
-            r[n + i] = -c[R.G() + 3 * n + i];
-        }
-        if (p == nlyr - 1) {
-            if (m == 0) {
-                // Lambertian reflection: intensity rows only, fed by the intensity rows of the downwelling field
-                for (int j = 0; j < n; ++j) {
-                    double sp = 0, sm = 0;
-                    for (int t = 0; t < N; ++t) {
-                        sp += g.wt[t] * g.mu[t] * c[R.WP() + t * S + n * j];
-                        sm += g.wt[t] * g.mu[t] * c[R.WM() + t * S + n * j];
-                    }
-                    for (int i = 0; i < N; ++i) {
-                        D[size_t(n + i * S) * M2 + j] -= kd * rho * sp * E[j];
-                        D[size_t(n + i * S) * M2 + n + j] -= kd * rho * sm;
-                    }
-                }
-                double sg = 0;
-                for (int t = 0; t < N; ++t) sg += g.wt[t] * g.mu[t] * c[R.G() + 2 * n + t * S];
-                const double direct = g.csz[s] * rho / kPi * b.T[size_t(nlyr) * nw + w];
-                for (int i = 0; i < N; ++i) r[n + i * S] += direct + kd * rho * sg;
-            }
-        } else {
-            const double* cn = vrec_at(v, nlyr, p + 1, w);
-            for (int i = 0; i < n; ++i) r[n + i] += cn[R.G() + 1 * n + i];
-        }
+        const double* cprev = (p > 0) ? vrec_at(v, nlyr, p - 1, w) : c;
+        team.sync();
         if (p > 0) {
-            const double* cp = vrec_at(v, nlyr, p - 1, w);
-            for (int i = 0; i < n; ++i)
-                for (int j = 0; j < M2; ++j) {
-                    double t = 0;
-                    for (int q = 0; q < n; ++q)
-                        t += cp[R.WP() + i + n * q] * Eprev[q] * Dinv[size_t(q) * M2 + j] + cp[R.WM() + i + n * q] * Dinv[size_t(n + q) * M2 + j];
-                    T1[size_t(i) * M2 + j] = t;
-                }
-            for (int i = 0; i < n; ++i) {
-                for (int j = 0; j < n; ++j) {
-                    double t1 = 0, t2 = 0;
-                    for (int q = 0; q < n; ++q) {
-                        t1 += T1[size_t(i) * M2 + n + q] * c[R.WM() + q + n * j];
-                        t2 += T1[size_t(i) * M2 + n + q] * c[R.WP() + q + n * j];
-                    }
-                    D[size_t(i) * M2 + j] += t1;
-                    D[size_t(i) * M2 + n + j] += t2 * E[j];
-                }
+            // T1 = Sub_p Dinv_{p-1},  Sub_p rows A = [W+_{p-1} E_{p-1} | W-_{p-1}]   (Dinv still holds layer p - 1)
+            SKV_PAR(e, n * M2) {
+                const int i = e / M2, j = e % M2;
                 double t = 0;
-                for (int q = 0; q < M2; ++q) t += T1[size_t(i) * M2 + q] * rprev[q];
-                r[i] -= cp[R.G() + 2 * n + i] + t;
+                for (int q = 0; q < n; ++q)
+                    t += cprev[R.WP() + i + n * q] * cprev[R.E() + q] * Dinv[q * M2 + j] + cprev[R.WM() + i + n * q] * Dinv[(n + q) * M2 + j];
+                T1[e] = t;
             }
         }
+        if (p == nlyr - 1 && m == 0) {
+            // Lambertian reflection sums over the intensity rows of the downwelling field
+            SKV_PAR(j, n) {
+                double sp = 0, sm = 0;
+                for (int t = 0; t < N; ++t) {
+                    sp += g.wt[t] * g.mu[t] * c[R.WP() + t * S + n * j];
+                    sm += g.wt[t] * g.mu[t] * c[R.WM() + t * S + n * j];
+                }
+                refl[j] = kd * rho * sp * c[R.E() + j];
+                refl[n + j] = kd * rho * sm;
+            }
+        }
+        team.sync();
+        SKV_PAR(e, n * n) {
+            const int i = e / n, j = e % n;
+            const double wp = c[R.WP() + i + n * j], wm = c[R.WM() + i + n * j], Ej = c[R.E() + j];
+            double d00 = -wp, d01 = -wm * Ej, d10 = wm * Ej, d11 = wp;
+            if (p == nlyr - 1 && m == 0 && (i % S) == 0) {
+                d10 -= refl[j];
+                d11 -= refl[n + j];
+            }
+            if (p > 0) {
+                double t1 = 0, t2 = 0;
+                for (int q = 0; q < n; ++q) {
+                    t1 += T1[i * M2 + n + q] * c[R.WM() + q + n * j];
+                    t2 += T1[i * M2 + n + q] * c[R.WP() + q + n * j];
+                }
+                d00 += t1;
+                d01 += t2 * Ej;
+            }
+            D[i * M2 + j] = d00;
+            D[i * M2 + n + j] = d01;
+            D[(n + i) * M2 + j] = d10;
+            D[(n + i) * M2 + n + j] = d11;
+        }
+        SKV_PAR(i, n) {
+            double ra = c[R.G() + 0 * n + i], rb = -c[R.G() + 3 * n + i];
+            if (p == nlyr - 1) {
+                if (m == 0 && (i % S) == 0) {
+                    double sg = 0;
+                    for (int t = 0; t < N; ++t) sg += g.wt[t] * g.mu[t] * c[R.G() + 2 * n + t * S];
+                    rb += g.csz[s] * rho / kPi * b.T[size_t(nlyr) * nw + w] + kd * rho * sg;
+                }
+            } else {
+                rb += vrec_at(v, nlyr, p + 1, w)[R.G() + 1 * n + i];
+            }
+            if (p > 0) {
+                double t = 0;
+                for (int q = 0; q < M2; ++q) t += T1[i * M2 + q] * rprev[q];
+                ra -= cprev[R.G() + 2 * n + i] + t;
+            }
+            r[i] = ra;
+            r[n + i] = rb;
+        }
+        team.sync();
         // Gauss-Jordan inverse with partial pivoting
-        bool singular = false;
-        for (int i = 0; i < M2; ++i)
-            for (int j = 0; j < M2; ++j) Dinv[size_t(i) * M2 + j] = (i == j) ? 1.0 : 0.0;
+        SKV_PAR(e, mm) Dinv[e] = (e / M2 == e % M2) ? 1.0 : 0.0;
+        team.sync();
         for (int cc = 0; cc < M2; ++cc) {
             int piv = cc;
-            double best = fabs(D[size_t(cc) * M2 + cc]);
-            for (int rr = cc + 1; rr < M2; ++rr)
-                if (fabs(D[size_t(rr) * M2 + cc]) > best) { best = fabs(D[size_t(rr) * M2 + cc]); piv = rr; }
-            if (!(best > 0)) { singular = true; break; }
-            if (piv != cc)
-                for (int j = 0; j < M2; ++j) {
-                    double t = D[size_t(cc) * M2 + j]; D[size_t(cc) * M2 + j] = D[size_t(piv) * M2 + j]; D[size_t(piv) * M2 + j] = t;
-                    t = Dinv[size_t(cc) * M2 + j]; Dinv[size_t(cc) * M2 + j] = Dinv[size_t(piv) * M2 + j]; Dinv[size_t(piv) * M2 + j] = t;
-                }
-            const double inv = 1.0 / D[size_t(cc) * M2 + cc];
-            for (int j = 0; j < M2; ++j) { D[size_t(cc) * M2 + j] *= inv; Dinv[size_t(cc) * M2 + j] *= inv; }
-            for (int rr = 0; rr < M2; ++rr) {
-                if (rr == cc) continue;
-                const double f = D[size_t(rr) * M2 + cc];
-                if (f == 0.0) continue;
-                for (int j = 0; j < M2; ++j) {
-                    D[size_t(rr) * M2 + j] -= f * D[size_t(cc) * M2 + j];
-                    Dinv[size_t(rr) * M2 + j] -= f * Dinv[size_t(cc) * M2 + j];
-                }
+            double best = fabs(D[cc * M2 + cc]);
+            for (int rr = cc + 1; rr < M2; ++rr) {
+                const double a_ = fabs(D[rr * M2 + cc]);
+                if (a_ > best) { best = a_; piv = rr; }
             }
-        }
-        if (singular) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            atomicOr(&b.status[w], skd::ERR_SINGULAR_BVP);
-#else
-            b.status[w] |= skd::ERR_SINGULAR_BVP;
-#endif
+            if (!(best > 0)) { singular = true; break; }
+            const double inv = 1.0 / D[piv * M2 + cc];
+            team.sync();
+            SKV_PAR(j, 2 * M2) {  // swap rows cc <-> piv and scale the pivot row (D for j < M2, Dinv for j >= M2)
+                double* Mx = (j < M2) ? D : Dinv;
+                const int jj = (j < M2) ? j : j - M2;
+                const double a_ = Mx[cc * M2 + jj], b_ = Mx[piv * M2 + jj];
+                Mx[piv * M2 + jj] = a_;
+                Mx[cc * M2 + jj] = b_ * inv;
+            }
+            team.sync();
+            SKV_PAR(rr, M2) fcol[rr] = (rr == cc) ? 0.0 : D[rr * M2 + cc];
+            team.sync();
+            SKV_PAR(e, 2 * mm) {
+                double* Mx = (e < mm) ? D : Dinv;
+                const int ee = (e < mm) ? e : e - mm;
+                const int rr = ee / M2, j = ee % M2;
+                const double f = fcol[rr];
+                if (f != 0.0) Mx[ee] -= f * Mx[cc * M2 + j];
+            }
+            team.sync();
         }
         double* dst = vdinv_at(v, nlyr, p, w);
         double* xs = vxsol_at(v, nlyr, p, w);
-        for (int i = 0; i < M2; ++i) {
+        SKV_PAR(e, mm) dst[e] = Dinv[e];
+        SKV_PAR(i, M2) {
             rprev[i] = r[i];
             xs[i] = r[i];
-            for (int j = 0; j < M2; ++j) dst[size_t(i) * M2 + j] = Dinv[size_t(i) * M2 + j];
         }
-        for (int j = 0; j < n; ++j) Eprev[j] = E[j];
+    }
+    team.sync();
+    if (singular && team.lane == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(&b.status[w], skd::ERR_SINGULAR_BVP);
+#else
+        b.status[w] |= skd::ERR_SINGULAR_BVP;
+#endif
     }
     // back substitution:  x_p = Dinv_p (r'_p - Sup_p x_{p+1})
     for (int p = nlyr - 1; p >= 0; --p) {
         double* xs = vxsol_at(v, nlyr, p, w);
         const double* dinv = vdinv_at(v, nlyr, p, w);
-        for (int i = 0; i < M2; ++i) r[i] = xs[i];
-        if (p < nlyr - 1) {
-            const double* cn = vrec_at(v, nlyr, p + 1, w);
-            for (int i = 0; i < n; ++i) {
-                double t = 0;
-                for (int j = 0; j < n; ++j) t += cn[R.WM() + i + n * j] * xn[j] + cn[R.WP() + i + n * j] * cn[R.E() + j] * xn[n + j];
-                r[n + i] += t;
+        team.sync();
+        SKV_PAR(i, M2) {
+            double t = xs[i];
+            if (p < nlyr - 1 && i >= n) {
+                const double* cn = vrec_at(v, nlyr, p + 1, w);
+                const int ii = i - n;
+                for (int j = 0; j < n; ++j) t += cn[R.WM() + ii + n * j] * xn[j] + cn[R.WP() + ii + n * j] * cn[R.E() + j] * xn[n + j];
             }
+            r[i] = t;
         }
-        for (int i = 0; i < M2; ++i) {
+        team.sync();
+        SKV_PAR(i, M2) {
             double t = 0;
-            for (int j = 0; j < M2; ++j) t += dinv[size_t(i) * M2 + j] * r[j];
-            D[i] = t;
-        }
-        for (int i = 0; i < M2; ++i) {
-            xn[i] = D[i];
-            xs[i] = D[i];
+            for (int j = 0; j < M2; ++j) t += dinv[i * M2 + j] * r[j];
+            xn[i] = t;
+            xs[i] = t;
         }
     }
+    team.sync();
 }
 
 // Legendre-space source vectors of a layer:  J(out)[s] = sum_l [Pi_l(out) v_l][s],

@@ -75,6 +75,8 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     v.S = S; v.n = n; v.leg = leg; v.nleg = nleg; v.a4 = a4.data(); v.rec = rec.data(); v.dinv = dinv.data(); v.xsol = xsol.data();
     v.J = J.data(); v.radiance = rad.data(); v.scratch = scratch.data(); v.scratch_stride = 1;
     const skv::Scr scr{scratch.data(), 1};
+    const skv::Team team{0, 1};
+    double* ws = scratch.data();
     for (int w = 0; w < nw; ++w) {
         skd::k0_layer_optics(g, b, w);  // tau / omega / LOS shells; its scalar a_l is not used (nleg = 0)
         skv::kv0_coefficients(g, b, v, w);
@@ -83,8 +85,8 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
         for (int w = 0; w < nw; ++w) skd::k0_transmission(g, b, 0, w);
         for (int m = 0; m < nstr; ++m) {
             for (int w = 0; w < nw; ++w)
-                for (int p = 0; p < nlyr; ++p) skv::kv1_layer_solution(g, vg, b, v, 0, m, p, w, scr);
-            for (int w = 0; w < nw; ++w) skv::kv2_bvp(g, b, v, 0, m, w, scr);
+                for (int p = 0; p < nlyr; ++p) skv::kv1_layer_solution(team, g, vg, b, v, 0, m, p, w, ws);
+            for (int w = 0; w < nw; ++w) skv::kv2_bvp(team, g, b, v, 0, m, w, ws);
             for (int w = 0; w < nw; ++w)
                 for (int l = 0; l < nlos; ++l) skv::kvpp_los(g, vg, b, v, 0, m, l, w, scr);
         }
@@ -101,9 +103,9 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                 if (!active) break;
                 for (int w = 0; w < nw; ++w)
                     for (int p = 0; p < nlyr; ++p)
-                        if (m < norders[w]) skv::kv1_layer_solution(g, vg, b, v, s, m, p, w, scr);
+                        if (m < norders[w]) skv::kv1_layer_solution(team, g, vg, b, v, s, m, p, w, ws);
                 for (int w = 0; w < nw; ++w)
-                    if (m < norders[w]) skv::kv2_bvp(g, b, v, s, m, w, scr);
+                    if (m < norders[w]) skv::kv2_bvp(team, g, b, v, s, m, w, ws);
                 for (int w = 0; w < nw; ++w)
                     for (int p = 0; p < nlyr; ++p)
                         if (m < norders[w]) skv::kv3_table_values(g, vg, b, v, s, m, p, w, scr);
