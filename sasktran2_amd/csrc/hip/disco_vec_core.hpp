@@ -167,6 +167,20 @@ struct Team {
 };
 #define SKV_PAR(i, count) for (int i = team.lane; i < (count); i += team.width)
 
+// sum of f(q), q in [lo, hi), with four independent partial sums (the loads of four terms are in flight together)
+template <class F> SKD_HD double sum4(int lo, int hi, F f) {
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    int q = lo;
+    for (; q + 3 < hi; q += 4) {
+        t0 += f(q);
+        t1 += f(q + 1);
+        t2 += f(q + 2);
+        t3 += f(q + 3);
+    }
+    for (; q < hi; ++q) t0 += f(q);
+    return (t0 + t1) + (t2 + t3);
+}
+
 // =================================================================================================
 // KV1: homogeneous + particular solution of one layer for azimuth order m    (task = wavelength x layer, one team)
 //   ws: 8 n^2 + 8 n + 64 doubles of team-shared work space (LDS when it fits, HBM otherwise)
@@ -231,15 +245,13 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
     int err = 0;
     // ---- Cholesky B+ = L L^T (lower, in place), one column per step
     for (int j = 0; j < n; ++j) {
-        double d = Bp[j * n + j];
-        for (int k = 0; k < j; ++k) d -= Bp[j * n + k] * Bp[j * n + k];
+        double d = Bp[j * n + j] - sum4(0, j, [&](int k) { return Bp[j * n + k] * Bp[j * n + k]; });
         if (!(d > 0)) { err |= skd::ERR_CHOLESKY; d = 1.0; }
         d = sqrt(d);
         team.sync();
         SKV_PAR(i, n) {
             if (i > j) {
-                double t = Bp[i * n + j];
-                for (int k = 0; k < j; ++k) t -= Bp[i * n + k] * Bp[j * n + k];
+                const double t = Bp[i * n + j] - sum4(0, j, [&](int k) { return Bp[i * n + k] * Bp[j * n + k]; });
                 Bp[i * n + j] = t / d;
             } else if (i == j) {
                 Bp[j * n + j] = d;
@@ -252,16 +264,13 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
     // ---- As = L^T B- L (into Bm)
     SKV_PAR(e, nn) {
         const int i = e / n, j = e % n;
-        double t = 0;
-        for (int r = j; r < n; ++r) t += Bm[i * n + r] * Bp[r * n + j];
-        Tm[e] = t;
+        Tm[e] = sum4(j, n, [&](int r) { return Bm[i * n + r] * Bp[r * n + j]; });
     }
     team.sync();
     SKV_PAR(e, nn) {
         const int i = e / n, j = e % n;
         if (j <= i) {
-            double t = 0;
-            for (int r = i; r < n; ++r) t += Bp[r * n + i] * Tm[r * n + j];
+            const double t = sum4(i, n, [&](int r) { return Bp[r * n + i] * Tm[r * n + j]; });
             Bm[i * n + j] = t;
             Bm[j * n + i] = t;
         }
@@ -354,8 +363,7 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
     // ---- X = T^-1 L^-T V (one column per lane) ;  U = S+ X with S+ = M^-1 (I - om E+ W)
     SKV_PAR(j, n) {
         for (int i = n - 1; i >= 0; --i) {
-            double t = V[i * n + j];
-            for (int r = i + 1; r < n; ++r) t -= Bp[r * n + i] * X[r * n + j];
+            const double t = V[i * n + j] - sum4(i + 1, n, [&](int r) { return Bp[r * n + i] * X[r * n + j]; });
             X[i * n + j] = t / Bp[i * n + i];
         }
         for (int i = 0; i < n; ++i) X[i * n + j] /= sqrt(rw(i) * rmu(i));
@@ -363,8 +371,7 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
     team.sync();
     SKV_PAR(e, nn) {
         const int i = e / n, j = e % n;
-        double t = 0;
-        for (int r = 0; r < n; ++r) t += rw(r) * Ep[i * n + r] * X[r * n + j];
+        const double t = sum4(0, n, [&](int r) { return rw(r) * Ep[i * n + r] * X[r * n + j]; });
         U[e] = (X[e] - om * t) / rmu(i);
     }
     team.sync();
@@ -458,17 +465,20 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
 
 // =================================================================================================
 // KV2: block-tridiagonal boundary value problem, factor + solve                 (task = wavelength, one team)
-//   same block rows as skd::k2a_bvp with 2n x 2n blocks; ws: 10 n^2 + 10 n doubles of team-shared work space
+//   same block rows as skd::k2a_bvp with 2n x 2n blocks; team-shared work space: ws (8 n^2 + 10 n doubles: the block and its
+//   inverse, vectors) and t1 (2 n^2 doubles), which may live in different memories (LDS / HBM)
 // =================================================================================================
-SKD_HD size_t kv2_scratch(int n) { return 10 * size_t(n) * n + 10 * size_t(n); }
+SKD_HD size_t kv2_scratch_main(int n) { return 8 * size_t(n) * n + 10 * size_t(n); }
+SKD_HD size_t kv2_scratch_t1(int n) { return 2 * size_t(n) * n; }
+SKD_HD size_t kv2_scratch(int n) { return kv2_scratch_main(n) + kv2_scratch_t1(n); }
 
-SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, double* ws) {
+SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, double* ws, double* T1) {
     const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nw = b.nw, nlyr = g.nlyr;
     const VRec R(n);
     const double rho = (m == 0) ? b.albedo[w] : 0.0;  // Lambertian
     const double kd = 2.0;
     const int mm = M2 * M2;
-    double *D = ws, *Dinv = ws + mm, *T1 = ws + 2 * mm, *r = T1 + n * M2, *rprev = r + M2, *xn = rprev + M2, *fcol = xn + M2, *refl = fcol + M2;  // refl: 2n
+    double *D = ws, *Dinv = ws + mm, *r = ws + 2 * mm, *rprev = r + M2, *xn = rprev + M2, *fcol = xn + M2, *refl = fcol + M2;  // refl: 2n
     bool singular = false;
     for (int p = 0; p < nlyr; ++p) {
         const double* c = vrec_at(v, nlyr, p, w);
@@ -478,10 +488,9 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
             // T1 = Sub_p Dinv_{p-1},  Sub_p rows A = [W+_{p-1} E_{p-1} | W-_{p-1}]   (Dinv still holds layer p - 1)
             SKV_PAR(e, n * M2) {
                 const int i = e / M2, j = e % M2;
-                double t = 0;
-                for (int q = 0; q < n; ++q)
-                    t += cprev[R.WP() + i + n * q] * cprev[R.E() + q] * Dinv[q * M2 + j] + cprev[R.WM() + i + n * q] * Dinv[(n + q) * M2 + j];
-                T1[e] = t;
+                T1[e] = sum4(0, n, [&](int q) {
+                    return cprev[R.WP() + i + n * q] * cprev[R.E() + q] * Dinv[q * M2 + j] + cprev[R.WM() + i + n * q] * Dinv[(n + q) * M2 + j];
+                });
             }
         }
         if (p == nlyr - 1 && m == 0) {
@@ -506,13 +515,8 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
                 d11 -= refl[n + j];
             }
             if (p > 0) {
-                double t1 = 0, t2 = 0;
-                for (int q = 0; q < n; ++q) {
-                    t1 += T1[i * M2 + n + q] * c[R.WM() + q + n * j];
-                    t2 += T1[i * M2 + n + q] * c[R.WP() + q + n * j];
-                }
-                d00 += t1;
-                d01 += t2 * Ej;
+                d00 += sum4(0, n, [&](int q) { return T1[i * M2 + n + q] * c[R.WM() + q + n * j]; });
+                d01 += sum4(0, n, [&](int q) { return T1[i * M2 + n + q] * c[R.WP() + q + n * j]; }) * Ej;
             }
             D[i * M2 + j] = d00;
             D[i * M2 + n + j] = d01;
@@ -531,9 +535,7 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
                 rb += vrec_at(v, nlyr, p + 1, w)[R.G() + 1 * n + i];
             }
             if (p > 0) {
-                double t = 0;
-                for (int q = 0; q < M2; ++q) t += T1[i * M2 + q] * rprev[q];
-                ra -= cprev[R.G() + 2 * n + i] + t;
+                ra -= cprev[R.G() + 2 * n + i] + sum4(0, M2, [&](int q) { return T1[i * M2 + q] * rprev[q]; });
             }
             r[i] = ra;
             r[n + i] = rb;
@@ -597,14 +599,13 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
             if (p < nlyr - 1 && i >= n) {
                 const double* cn = vrec_at(v, nlyr, p + 1, w);
                 const int ii = i - n;
-                for (int j = 0; j < n; ++j) t += cn[R.WM() + ii + n * j] * xn[j] + cn[R.WP() + ii + n * j] * cn[R.E() + j] * xn[n + j];
+                t += sum4(0, n, [&](int j) { return cn[R.WM() + ii + n * j] * xn[j] + cn[R.WP() + ii + n * j] * cn[R.E() + j] * xn[n + j]; });
             }
             r[i] = t;
         }
         team.sync();
         SKV_PAR(i, M2) {
-            double t = 0;
-            for (int j = 0; j < M2; ++j) t += dinv[i * M2 + j] * r[j];
+            const double t = sum4(0, M2, [&](int j) { return dinv[i * M2 + j] * r[j]; });
             xn[i] = t;
             xs[i] = t;
         }

@@ -86,7 +86,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
         for (int m = 0; m < nstr; ++m) {
             for (int w = 0; w < nw; ++w)
                 for (int p = 0; p < nlyr; ++p) skv::kv1_layer_solution(team, g, vg, b, v, 0, m, p, w, ws);
-            for (int w = 0; w < nw; ++w) skv::kv2_bvp(team, g, b, v, 0, m, w, ws);
+            for (int w = 0; w < nw; ++w) skv::kv2_bvp(team, g, b, v, 0, m, w, ws, ws + skv::kv2_scratch_main(n));
             for (int w = 0; w < nw; ++w)
                 for (int l = 0; l < nlos; ++l) skv::kvpp_los(g, vg, b, v, 0, m, l, w, scr);
         }
@@ -105,7 +105,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                     for (int p = 0; p < nlyr; ++p)
                         if (m < norders[w]) skv::kv1_layer_solution(team, g, vg, b, v, s, m, p, w, ws);
                 for (int w = 0; w < nw; ++w)
-                    if (m < norders[w]) skv::kv2_bvp(team, g, b, v, s, m, w, ws);
+                    if (m < norders[w]) skv::kv2_bvp(team, g, b, v, s, m, w, ws, ws + skv::kv2_scratch_main(n));
                 for (int w = 0; w < nw; ++w)
                     for (int p = 0; p < nlyr; ++p)
                         if (m < norders[w]) skv::kv3_table_values(g, vg, b, v, s, m, p, w, scr);

@@ -19,4 +19,11 @@ for nstr, nlyr, nw in cases:
     t = time.time()
     out = run_product(s, derivatives=False, engine=eng)
     dt = time.time() - t
+    from sasktran2_amd.device import DeviceSolver
+    ds = DeviceSolver(eng[0])
+    ds.set_profiling(True)
+    run_product(s, derivatives=False, engine=eng)
+    kt = ds.kernel_times()
+    ds.set_profiling(False)
+    print("   kernels (ms):", {k: round(v[0], 1) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}, flush=True)
     print(f"nstr {nstr} nlyr {nlyr} nw {nw}: {dt*1e3:.1f} ms/call, {nw/dt:.1f} wavelengths/s, I range {out['radiance'][...,0].min():.3e}..{out['radiance'][...,0].max():.3e}", flush=True)
