@@ -28,7 +28,7 @@ extern "C" {
 // ray_params: per ray [cos_sza, relative_azimuth, observer_altitude, tangent_altitude | cos_viewing_zenith]
 void* orc_create(double cos_sza, double saa, double earth_radius, const double* altitudes, int ngrid, int interp_method,
                  int geotype, int nstr, int num_sza, int nrays, const int* ray_kinds, const double* ray_params,
-                 int ss_in_do, int nstokes) {
+                 int ss_in_do, int nstokes, int stokes_basis) {
     try {
         auto h = std::make_unique<Handle>();
         h->geo = skgeo::Geometry1D(cos_sza, saa, earth_radius, std::vector<double>(altitudes, altitudes + ngrid),
@@ -43,7 +43,7 @@ void* orc_create(double cos_sza, double saa, double earth_radius, const double* 
             specs[i].tangent_altitude = ray_params[4 * i + 3];
             specs[i].cos_viewing_zenith = ray_params[4 * i + 3];
         }
-        skgeo::build_disco_geometry(h->geo, specs, nstr, num_sza, h->dg, nstokes);
+        skgeo::build_disco_geometry(h->geo, specs, nstr, num_sza, h->dg, nstokes, stokes_basis);
         h->ss_in_do = ss_in_do;
         return h.release();
     } catch (const std::exception& e) {
@@ -120,12 +120,21 @@ int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
                     if (los_od) los_od[size_t(w) * nlos + r] = res.los_od[r];
                     for (int sc = 0; sc < S; ++sc) {
                         const size_t o = (size_t(w) * nlos + r) * S + sc;
-                        radiance[o] = res.radiance[size_t(r) * S + sc];
+                        // rotation of (Q, U) into the configured Stokes basis (OutputC::assign_lane, cpp/lib/output/outputc.cpp:108-228)
+                        const double C = h->dg.stokes_C[r], Sn = h->dg.stokes_S[r];
+                        const int nn = solver->num_native();
+                        auto mix = [&](const double* base, size_t stride, size_t off) {
+                            if (sc == 0 || S == 1) return base[(size_t(r) * S + sc) * stride + off];
+                            const double q = base[(size_t(r) * S + 1) * stride + off], u = base[(size_t(r) * S + 2) * stride + off];
+                            return sc == 1 ? C * q - Sn * u : Sn * q + C * u;
+                        };
+                        radiance[o] = mix(res.radiance.data(), 1, 0);
                         if (atm.derivatives) {
-                            const double* d = &res.deriv[(size_t(r) * S + sc) * solver->num_native()];
-                            if (d_k) std::copy(d, d + ngrid, &d_k[o * ngrid]);
-                            if (d_ssa) std::copy(d + ngrid, d + 2 * ngrid, &d_ssa[o * ngrid]);
-                            if (d_albedo) d_albedo[o] = d[2 * ngrid];
+                            for (int q = 0; q < ngrid; ++q) {
+                                if (d_k) d_k[o * ngrid + q] = mix(res.deriv.data(), nn, q);
+                                if (d_ssa) d_ssa[o * ngrid + q] = mix(res.deriv.data(), nn, ngrid + q);
+                            }
+                            if (d_albedo) d_albedo[o] = mix(res.deriv.data(), nn, 2 * ngrid);
                         }
                     }
                 }

@@ -34,7 +34,7 @@ def lib():
         L = ctypes.CDLL(str(so))
         L.orc_create.restype = ctypes.c_void_p
         L.orc_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_int, ctypes.c_int,
-                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int, ctypes.c_int]
+                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.orc_destroy.argtypes = [ctypes.c_void_p]
         L.orc_run.restype = ctypes.c_int
         L.orc_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int,
@@ -55,7 +55,7 @@ class OracleEngine:
     """rays: list of (kind, cos_sza, relative_azimuth, observer_altitude, tangent_altitude|cos_viewing_zenith)."""
 
     def __init__(self, cos_sza, saa, earth_radius, altitudes, interp_method, geotype, nstr, num_sza, rays,
-                 ss_in_do=True, nstokes=1):
+                 ss_in_do=True, nstokes=1, stokes_basis=0):
         self.alt = np.ascontiguousarray(altitudes, dtype=np.float64)
         self.nlos = len(rays)
         self.ngrid = len(self.alt)
@@ -64,7 +64,7 @@ class OracleEngine:
         kinds = np.ascontiguousarray([r[0] for r in rays], dtype=np.int32)
         params = np.ascontiguousarray([[r[1], r[2], r[3], r[4]] for r in rays], dtype=np.float64)
         self._h = lib().orc_create(cos_sza, saa, earth_radius, _p(self.alt), self.ngrid, interp_method, geotype, nstr,
-                                   num_sza, self.nlos, kinds.ctypes.data_as(_ip), _p(params), int(ss_in_do), int(nstokes))
+                                   num_sza, self.nlos, kinds.ctypes.data_as(_ip), _p(params), int(ss_in_do), int(nstokes), int(stokes_basis))
         if not self._h:
             raise RuntimeError("oracle engine construction failed")
 

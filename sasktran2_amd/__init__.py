@@ -50,6 +50,12 @@ class SingleScatterSource(enum.IntEnum):  # cpp/include/sasktran2/config.h:41-46
     NoSource = 3
 
 
+class StokesBasis(enum.IntEnum):  # cpp/include/sasktran2/config.h:145
+    Standard = 0
+    Solar = 1
+    Observer = 2
+
+
 class Config:
     """src/sasktran2/config.py:21-765 (the keys this path reads)."""
 
@@ -57,7 +63,7 @@ class Config:
              "num_sza": "num_do_sza", "num_singlescatter_moments": "num_singlescatter_moments",
              "wavelength_batch_size": "wavelength_batch_size", "output_los_optical_depth": "output_los_optical_depth",
              "multiple_scatter_source": "multiple_scatter_source", "single_scatter_source": "single_scatter_source",
-             "wf_enabled": "wf_enabled", "delta_m_scaling": "apply_delta_scaling"}
+             "wf_enabled": "wf_enabled", "delta_m_scaling": "apply_delta_scaling", "stokes_basis": "stokes_basis"}
 
     def __init__(self):
         object.__setattr__(self, "_h", lib().sk_config_create())

@@ -338,7 +338,7 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
     if (!c || !g || !v) return nullptr;
     try {
         if (c->num_stokes != 1 && c->num_stokes != 3) throw std::runtime_error("NSTOKES must be 1 or 3");
-        if (c->num_stokes == 3 && c->stokes_basis != 0) throw std::runtime_error("only the standard Stokes basis is part of this build");
+        if (c->stokes_basis < 0 || c->stokes_basis > 2) throw std::runtime_error("stokes_basis must be standard (0), solar (1) or observer (2)");
         if (c->ms_source != 0) throw std::runtime_error("multiple_scatter_source must be discrete_ordinates (0)");
         if (c->ss_source != 2 && c->ss_source != 3)
             throw std::runtime_error("single_scatter_source must be discrete_ordinates (2) or none (3)");
@@ -350,7 +350,7 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
         skgeo::Geometry1D geo(g->cos_sza, g->saa, g->earth_radius, g->grid, (skgeo::Interpolation)g->interp,
                               (skgeo::GeometryType)g->geotype);
         skgeo::DiscoGeometry dg;
-        skgeo::build_disco_geometry(geo, v->rays, c->num_streams, c->num_sza, dg, c->num_stokes);
+        skgeo::build_disco_geometry(geo, v->rays, c->num_streams, c->num_sza, dg, c->num_stokes, c->stokes_basis);
         auto e = std::make_unique<Engine>();
         e->config = *c;
         e->dev = std::make_unique<skdev::DeviceEngine>(dg, c->ss_source == 2);

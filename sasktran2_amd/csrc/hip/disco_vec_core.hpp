@@ -37,6 +37,8 @@ struct VGeo {
     const double* lplosR;   // [los][m][l]
     const double* lplosT;
     const double* rl_sinm_t;  // [q][m]  sin(m * azi_q)
+    const double* stokes_c;   // [los] rotation of (Q, U) into the configured Stokes basis, cpp/lib/output/outputc.cpp:223-228
+    const double* stokes_s;
 };
 
 struct VBufs {
@@ -867,6 +869,15 @@ SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v
     }
     const double cz = cos(m * g.pp_azi[los]), sz = sin(m * g.pp_azi[los]);
     for (int s1 = 0; s1 < S; ++s1) v.radiance[tid * S + s1] += total[s1] * (s1 < 2 ? cz : sz);
+}
+
+// (I, Q, U) of one line of sight in the configured Stokes basis:  Q' = C Q - S U,  U' = S Q + C U
+SKD_HD void stokes_rotate(const VGeo& vg, int los, const double* in, double* out, int S) {
+    out[0] = in[0];
+    if (S == 3) {
+        out[1] = vg.stokes_c[los] * in[1] - vg.stokes_s[los] * in[2];
+        out[2] = vg.stokes_s[los] * in[1] + vg.stokes_c[los] * in[2];
+    }
 }
 
 }  // namespace skv

@@ -203,7 +203,7 @@ struct GeoTables {
 // shapes; zero-filled for NSTOKES = 1) and the sine azimuth factors of the ray layers (U component).
 struct VecTables {
     int S = 1;
-    std::vector<double> lpmuR, lpmuT, lpangR, lpangT, lplosR, lplosT, rl_sinm_t;
+    std::vector<double> lpmuR, lpmuT, lpangR, lpangT, lplosR, lplosT, rl_sinm_t, stokes_c, stokes_s;
     void build(const skgeo::DiscoGeometry& G, const GeoTables& t) {
         S = G.nstokes;
         const int nstr = t.nstr, N = t.N;
@@ -223,6 +223,8 @@ struct VecTables {
             if (!G.lp_angle_R.empty() && lpangR.size() == G.lp_angle_R.size()) { lpangR = G.lp_angle_R; lpangT = G.lp_angle_T; }
             if (!G.lp_los_R.empty() && lplosR.size() == G.lp_los_R.size()) { lplosR = G.lp_los_R; lplosT = G.lp_los_T; }
         }
+        stokes_c = G.stokes_C;
+        stokes_s = G.stokes_S;
         rl_sinm_t.assign(t.rl_azi.size() * size_t(nstr), 0.0);
         for (size_t q = 0; q < t.rl_azi.size(); ++q)
             for (int m = 0; m < nstr; ++m) rl_sinm_t[q * nstr + m] = std::sin(m * t.rl_azi[q]);
@@ -232,6 +234,7 @@ struct VecTables {
         v.S = S;
         v.lpmuR = lpmuR.data(); v.lpmuT = lpmuT.data(); v.lpangR = lpangR.data(); v.lpangT = lpangT.data();
         v.lplosR = lplosR.data(); v.lplosT = lplosT.data(); v.rl_sinm_t = rl_sinm_t.data();
+        v.stokes_c = stokes_c.data(); v.stokes_s = stokes_s.data();
         return v;
     }
 };

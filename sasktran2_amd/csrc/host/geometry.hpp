@@ -178,6 +178,29 @@ struct Coordinates {
         return v * (altitude + earth_radius);
     }
 
+    // Rotation (cos 2a, sin 2a) of (Q, U) from the standard basis to the solar / observer bases
+    //   cpp/lib/geometry/geometry.cpp:232-306 (stokes_standard_to_solar, stokes_standard_to_observer)
+    void stokes_standard_to_solar(const Vec3& look, double& C, double& S) const {
+        C = 1.0; S = 0.0;
+        if (std::fabs(sun.dot(look)) >= 1 || std::fabs(zu.dot(look)) >= 1) return;
+        Vec3 perp_z = (zu - look * zu.dot(look)).normalized();
+        Vec3 perp_sun = (sun - look * sun.dot(look)).normalized();
+        double ca = std::min(1.0, std::max(-1.0, perp_z.dot(perp_sun)));
+        double a = std::acos(ca);
+        C = std::cos(2 * a);
+        S = -std::sin(2 * a);
+    }
+    void stokes_standard_to_observer(const Vec3& look, const Vec3& position, double& C, double& S) const {
+        C = 1.0; S = 0.0;
+        Vec3 pn = position.normalized();
+        if (std::fabs(pn.dot(look)) >= 1 || std::fabs(zu.dot(look)) >= 1) return;
+        Vec3 perp_z = (zu - look * zu.dot(look)).normalized();
+        double ca = std::min(1.0, std::max(-1.0, perp_z.dot(pn)));  // as written in the reference (:291)
+        double a = std::acos(ca);
+        C = std::cos(2 * a);
+        S = std::sin(2 * a);
+    }
+
     Vec3 look_vector_from_azimuth(const Vec3& location, double saa, double cos_viewing) const {
         Vec3 up = (geotype == spherical) ? location.normalized() : zu;
         Vec3 sun_horiz = sun - up * up.dot(sun);
@@ -710,6 +733,7 @@ struct PlaneParallelLOS { double coszenith, azimuth, observer_altitude; };
 struct DiscoGeometry {
     int nstr = 0, nlyr = 0, ngrid = 0, nsza = 1, nlos = 0;
     int nstokes = 1;                    // 1 or 3; the *_R / *_T tables are filled for 3 only
+    std::vector<double> stokes_C, stokes_S;  // [nlos] rotation of (Q, U) into the configured Stokes basis (1, 0 for the standard basis)
     bool spherical_pp = false;          // true: spherical interpolated post-processing, false: plane-parallel
     std::vector<double> mu, wt;         // nstr
     std::vector<double> lp_mu;          // [m][stream i < nstr][l]
@@ -740,7 +764,7 @@ struct DiscoGeometry {
 };
 
 inline void build_disco_geometry(const Geometry1D& g, const std::vector<RaySpec>& specs, int nstr, int num_sza,
-                                 DiscoGeometry& out, int nstokes = 1) {
+                                 DiscoGeometry& out, int nstokes = 1, int stokes_basis = 0) {
     out = DiscoGeometry();
     out.nstokes = nstokes;
     const Coordinates& c = g.coords;
@@ -784,6 +808,13 @@ inline void build_disco_geometry(const Geometry1D& g, const std::vector<RaySpec>
     std::vector<TracedRay> traced(specs.size());
     std::vector<ViewingRay> vrays(specs.size());
     for (size_t i = 0; i < specs.size(); ++i) vrays[i] = construct_ray(specs[i], c);
+    // Stokes basis of the output: 0 standard, 1 solar, 2 observer (Output::initialize, cpp/lib/output/output.cpp:27-55)
+    out.stokes_C.assign(specs.size(), 1.0);
+    out.stokes_S.assign(specs.size(), 0.0);
+    for (size_t i = 0; i < specs.size(); ++i) {
+        if (stokes_basis == 1) c.stokes_standard_to_solar(vrays[i].look_away, out.stokes_C[i], out.stokes_S[i]);
+        if (stokes_basis == 2) c.stokes_standard_to_observer(vrays[i].look_away, vrays[i].observer.position, out.stokes_C[i], out.stokes_S[i]);
+    }
 
     if (c.geotype == spherical) {
         SphericalShellRayTracer tracer(g);

@@ -20,7 +20,7 @@ struct Handle {
 extern "C" {
 void* emuv_create(double cos_sza, double saa, double earth_radius, const double* altitudes, int ngrid, int interp_method,
                   int geotype, int nstr, int num_sza, int nrays, const int* ray_kinds, const double* ray_params, int ss_in_do,
-                  int nstokes) {
+                  int nstokes, int stokes_basis) {
     try {
         auto h = std::make_unique<Handle>();
         h->geo = skgeo::Geometry1D(cos_sza, saa, earth_radius, std::vector<double>(altitudes, altitudes + ngrid),
@@ -35,7 +35,7 @@ void* emuv_create(double cos_sza, double saa, double earth_radius, const double*
             specs[i].tangent_altitude = ray_params[4 * i + 3];
             specs[i].cos_viewing_zenith = ray_params[4 * i + 3];
         }
-        skgeo::build_disco_geometry(h->geo, specs, nstr, num_sza, h->dg, nstokes);
+        skgeo::build_disco_geometry(h->geo, specs, nstr, num_sza, h->dg, nstokes, stokes_basis);
         h->tab.include_ss = ss_in_do;
         h->tab.build(h->dg);
         h->vtab.build(h->dg, h->tab);
@@ -115,7 +115,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
         for (int w = 0; w < nw; ++w)
             for (int l = 0; l < nlos; ++l) skv::kv4_los(g, vg, b, v, l, w);
     }
-    for (size_t i = 0; i < nt * S; ++i) radiance[i] = rad[i];
+    for (size_t i = 0; i < nt; ++i) skv::stokes_rotate(vg, int(i % nlos), &rad[i * S], &radiance[i * S], S);
     for (size_t i = 0; i < nt; ++i)
         if (los_od) los_od[i] = lod[i];
     for (int w = 0; w < nw; ++w)

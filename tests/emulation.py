@@ -87,7 +87,7 @@ def libv():
         L = ctypes.CDLL(str(so))
         L.emuv_create.restype = ctypes.c_void_p
         L.emuv_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_int, ctypes.c_int,
-                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int, ctypes.c_int]
+                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.emuv_destroy.argtypes = [ctypes.c_void_p]
         L.emuv_run.restype = ctypes.c_int
         L.emuv_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]
@@ -106,7 +106,7 @@ def run_emulated_vector(s):
     L = libv()
     h = L.emuv_create(g["cos_sza"], g["saa"], g["earth_radius"], _p(alt), len(alt), g["interp_method"], g["geotype"],
                       s["config"]["nstr"], s["config"]["num_sza"], len(rays), kinds.ctypes.data_as(_ip), _p(params),
-                      int(s["config"].get("ss_in_do", True)), S)
+                      int(s["config"].get("ss_in_do", True)), S, int(s["config"].get("stokes_basis", 0)))
     assert h
     try:
         k = np.asfortranarray(s["extinction"], dtype=np.float64)

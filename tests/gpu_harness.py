@@ -15,6 +15,7 @@ def build_engine(s):
     config.num_sza = s["config"]["num_sza"]
     nstokes = s["config"].get("nstokes", 1)
     config.num_stokes = nstokes
+    config.stokes_basis = s["config"].get("stokes_basis", 0)
     config.num_singlescatter_moments = s["leg"].shape[0] // (4 if nstokes == 3 else 1)
     config.multiple_scatter_source = sk.MultipleScatterSource.DiscreteOrdinates
     config.single_scatter_source = sk.SingleScatterSource.DiscreteOrdinates

@@ -432,3 +432,14 @@ def test_scalar_40_streams_through_the_runtime_n_path():
     s = sc.planeparallel_case(case)
     out = run_product(s, derivatives=False)
     np.testing.assert_allclose(out["radiance"], run_oracle(s)["radiance"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("basis", [1, 2], ids=["solar", "observer"])
+def test_vector_stokes_basis_on_device(basis):
+    base = sc.to_vector(sc.regression_1d(2), rayleigh_fraction=0.9)
+    s = dict(base, config=dict(base["config"], stokes_basis=basis))
+    out = run_product(s, derivatives=False)["radiance"]
+    std = run_product(base, derivatives=False)["radiance"]
+    np.testing.assert_allclose(out[..., 0], std[..., 0], rtol=1e-14)
+    np.testing.assert_allclose(out[..., 1] ** 2 + out[..., 2] ** 2, std[..., 1] ** 2 + std[..., 2] ** 2, rtol=1e-12)
+    np.testing.assert_allclose(out, run_oracle(s)["radiance"], rtol=1e-6, atol=1e-12)

@@ -16,7 +16,7 @@ def make_oracle(s, ss_in_do=True):
     g = s["geometry"]
     return OracleEngine(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"], g["interp_method"], g["geotype"],
                         s["config"]["nstr"], s["config"]["num_sza"], s["rays"], ss_in_do=ss_in_do,
-                        nstokes=s["config"].get("nstokes", 1))
+                        nstokes=s["config"].get("nstokes", 1), stokes_basis=s["config"].get("stokes_basis", 0))
 
 
 def run_oracle(s, derivatives=False, **over):

@@ -47,3 +47,17 @@ def test_vector_spherical_matches_oracle():
     np.testing.assert_allclose(out["radiance"][..., 0], ora["radiance"][..., 0], rtol=1e-6)
     assert np.max(np.abs(out["radiance"] - ora["radiance"])) < 1e-9 * np.abs(ora["radiance"]).max() + 1e-12
     np.testing.assert_allclose(out["los_optical_depth"], ora["los_optical_depth"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("basis", [1, 2], ids=["solar", "observer"])
+def test_stokes_basis_rotation(basis):
+    """cpp/lib/output/output.cpp:27-55, cpp/lib/geometry/geometry.cpp:232-306: (Q, U) rotated by (cos 2a, -/+ sin 2a) with a the angle
+    between the projections of the reference z axis and of the sun (observer position) on the plane normal to the look vector."""
+    base = sc.to_vector(sc.regression_1d(1), rayleigh_fraction=0.9)
+    std = run_emulated_vector(base)["radiance"]
+    s = dict(base, config=dict(base["config"], stokes_basis=basis))
+    rot = run_emulated_vector(s)["radiance"]
+    np.testing.assert_allclose(rot[..., 0], std[..., 0], rtol=1e-14)
+    np.testing.assert_allclose(rot[..., 1] ** 2 + rot[..., 2] ** 2, std[..., 1] ** 2 + std[..., 2] ** 2, rtol=1e-12)
+    assert np.abs(rot[..., 1:] - std[..., 1:]).max() > 1e-6   # the bases differ for these rays
+    np.testing.assert_allclose(rot, run_oracle(s)["radiance"], rtol=1e-6, atol=1e-12)
