@@ -215,7 +215,19 @@ def main():
         wf = out["wf_extinction"].cpu().numpy()[:, idx, :]
         refwf = np.transpose(ref["d_extinction"], (2, 0, 1))
         wf_parity = float(np.max(np.abs(wf - refwf) / np.abs(refwf).max(axis=0, keepdims=True)))
+        # one-thread rate of the same port on a handful of wavelengths, and the host CPU model
+        idx1 = np.linspace(0, NW - 1, 4).astype(int)
+        t = time.perf_counter()
+        eng.run(s["extinction"][:, idx1], s["ssa"][:, idx1], s["leg"][:, :, idx1], s["albedo"][idx1], derivatives=True, nthreads=1)
+        one_thread = len(idx1) / (time.perf_counter() - t)
+        cpu_model = ""
+        try:
+            with open("/proc/cpuinfo") as f:
+                cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+        except OSError:
+            pass
         line["cpu_baseline"] = {"value": n / dt, "unit": "wavelengths/s", "cores": cores, "kind": "port",
+                                "one_thread_value": one_thread, "cpu_model": cpu_model,
                                 "sample": f"{n} of the {NW} wavelengths (evenly spaced), same workload incl. weighting functions, {dt:.1f} s",
                                 "parity_radiance_max_rel": parity, "parity_wf_extinction_max_rel_to_profile_max": wf_parity}
         line["speedup_vs_cpu_baseline"] = line["value"] / (n / dt)

@@ -46,11 +46,17 @@ struct VBufs {
     const double* leg;      // [w][q][nleg][4]  (a1, a2, a3, b1 as stored by the caller, cpp/include/c_api/atmosphere.h:77-83)
     int nleg;
     double* a4;             // [p][l][4][w]  layer Greek coefficients (b1 with the sign flip of sktran_do_layerarray.cpp:418)
-    double* rec;            // [w][p][REC]   REC = 2 n^2 + 8 n : K, E, WP, WM, AP, AM, G[4]
+    double* rec;            // [w][p][REC]   REC = 4 n^2 + 41 n, see VRec
     double* dinv;           // [w][p][4 n^2]
     double* xsol;           // [w][p][2 n]
     double* J;              // [w][slot][m][S]
     double* radiance;       // [w*nlos+los][S]
+    double* ops;            // [w][p][VOps::size]  LOS-independent adjoint operators (weighting functions)
+    double* z;              // [p][2 n][tid3]   tid3 = (w * nlos + los) * S + Stokes component
+    double* qlbuf;          // [p][NL][tid3]    Legendre-space LOS weights
+    double* grad;           // [4 nlyr + 2][tid3] reduced gradient of the current solar zenith index
+    double* dnat;           // [2 ngrid + 1][tid3] native derivatives
+    int derivs;
     double* scratch;        // [element][thread] work matrices of the running kernel
     size_t scratch_stride;  // threads of the running kernel
 };
@@ -58,14 +64,24 @@ struct VBufs {
 struct VRec {
     int n;
     SKD_HD explicit VRec(int n_) : n(n_) {}
+    // same record as skd::Rec with N -> n: eigenvalues, exp(-k tau), d k / d omega, W+-, d W+- / d omega, Green's coefficients and
+    // their omega derivatives, edge values of the particular solution G[4][n] (0 G+top, 1 G-top, 2 G+bottom, 3 G-bottom, no D factor),
+    // DG[theta][4][n] (theta: tau, omega, T, sec), post-processing multipliers PPM[n][14]
     SKD_HD int K() const { return 0; }
     SKD_HD int E() const { return n; }
-    SKD_HD int WP() const { return 2 * n; }
-    SKD_HD int WM() const { return 2 * n + n * n; }
-    SKD_HD int AP() const { return 2 * n + 2 * n * n; }
-    SKD_HD int AM() const { return 3 * n + 2 * n * n; }
-    SKD_HD int G() const { return 4 * n + 2 * n * n; }   // 0 G+top, 1 G-top, 2 G+bottom, 3 G-bottom (no D factor)
-    SKD_HD int size() const { return 8 * n + 2 * n * n; }
+    SKD_HD int DK() const { return 2 * n; }
+    SKD_HD int WP() const { return 3 * n; }
+    SKD_HD int WM() const { return 3 * n + n * n; }
+    SKD_HD int DWP() const { return 3 * n + 2 * n * n; }
+    SKD_HD int DWM() const { return 3 * n + 3 * n * n; }
+    SKD_HD int AP() const { return 3 * n + 4 * n * n; }
+    SKD_HD int AM() const { return AP() + n; }
+    SKD_HD int DAP() const { return AP() + 2 * n; }
+    SKD_HD int DAM() const { return AP() + 3 * n; }
+    SKD_HD int G() const { return AP() + 4 * n; }
+    SKD_HD int DG() const { return G() + 4 * n; }
+    SKD_HD int PPM() const { return DG() + 16 * n; }
+    SKD_HD int size() const { return PPM() + 14 * n; }
 };
 SKD_HD double* vrec_at(const VBufs& v, int nlyr, int p, int w) { return v.rec + (size_t(w) * nlyr + p) * VRec(v.n).size(); }
 SKD_HD double* vdinv_at(const VBufs& v, int nlyr, int p, int w) { return v.dinv + (size_t(w) * nlyr + p) * (4 * size_t(v.n) * v.n); }
@@ -185,11 +201,12 @@ template <class F> SKD_HD double sum4(int lo, int hi, F f) {
 
 // =================================================================================================
 // KV1: homogeneous + particular solution of one layer for azimuth order m    (task = wavelength x layer, one team)
-//   ws: 8 n^2 + 8 n + 64 doubles of team-shared work space (LDS when it fits, HBM otherwise)
+//   ws: 8 n^2 + 20 n + 64 doubles of team-shared work space (LDS when it fits, HBM otherwise)
 // =================================================================================================
-SKD_HD size_t kv1_scratch(int n) { return 8 * size_t(n) * n + 8 * size_t(n) + 64; }
+SKD_HD size_t kv1_scratch(int n) { return 8 * size_t(n) * n + 20 * size_t(n) + 64; }
 
-SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws) {
+SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws,
+                                   bool derivs = false) {
     const int N = g.N, S = v.S, n = v.n, nstr = g.nstr, nw = b.nw;
     const VRec R(n);
     double* rec = vrec_at(v, g.nlyr, p, w);
@@ -197,7 +214,8 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
     const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
     const int nn = n * n;
     double *Ep = ws, *Em = ws + nn, *Bp = ws + 2 * nn, *Bm = ws + 3 * nn, *Tm = ws + 4 * nn, *V = ws + 5 * nn, *X = ws + 6 * nn, *U = ws + 7 * nn;
-    double *lam = ws + 8 * nn, *kk = lam + n, *nrm = kk + n, *Qp = nrm + n, *Qm = Qp + n, *acp = Qm + n, *acm = acp + n, *rot = acm + n;  // rot: n + 64
+    double *lam = ws + 8 * nn, *kk = lam + n, *nrm = kk + n, *Qp = nrm + n, *Qm = Qp + n, *acp = Qm + n, *acm = acp + n, *rot = acm + n, *coef = rot + n + 64;  // rot: n + 64, coef: 12 n
+    (void)acm;
     auto rw = [&](int r) { return g.wt[r / S]; };
     auto rmu = [&](int r) { return g.mu[r / S]; };
     // ---- E+ = (plain + negated) / 2, E- = (plain - negated) / 2 of the Greek-matrix products: one (i, j) block per lane
@@ -377,19 +395,69 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
         U[e] = (X[e] - om * t) / rmu(i);
     }
     team.sync();
-    // ---- W+-, norms (one solution per lane)
+    // ---- omega derivatives by bi-orthogonal perturbation theory (left vectors W M S+ X), as skd::k1_layer_solution:
+    //      d(Gamma) X_j = [2 lam_j X_j - M^-1 U_j - S- M^-1 X_j] / om ;  dk_j = z_jj / (2 k_j) ;  dX = X C, C_ab = z_ab / (lam_b - lam_a)
+    double* dX = V;    // V is free once X is known
+    double* dU = Bm;   // As was consumed by the Jacobi sweeps
+    double* dk = acp;  // reused before the Green's coefficients need it
+    if (derivs) {
+        SKV_PAR(e, nn) {
+            const int i = e / n, j = e % n;
+            const double hm = X[e] / (rmu(i) * rmu(i)) -
+                              om / rmu(i) * sum4(0, n, [&](int r) { return rw(r) * Em[i * n + r] * X[r * n + j] / rmu(r); });
+            Tm[e] = (2 * X[e] * lam[j] - U[e] / rmu(i) - hm) / om;   // d(Gamma) X
+        }
+        team.sync();
+        double lmax = 0;
+        for (int j = 0; j < n; ++j) lmax = fmax(lmax, lam[j]);
+        SKV_PAR(e, nn) {
+            const int a_ = e / n, b_ = e % n;
+            const double z = sum4(0, n, [&](int i) { return rw(i) * rmu(i) * U[i * n + a_] * Tm[i * n + b_]; });
+            if (a_ == b_) {
+                dk[b_] = z / (2 * kk[b_]);
+                Bm[e] = 0;
+            } else {
+                const double den = lam[b_] - lam[a_];
+                Bm[e] = (fabs(den) > 1e-13 * lmax) ? z / den : 0.0;
+            }
+        }
+        team.sync();
+        SKV_PAR(e, nn) {
+            const int i = e / n, j = e % n;
+            dX[e] = sum4(0, n, [&](int r) { return X[i * n + r] * Bm[r * n + j]; });
+        }
+        team.sync();
+        SKV_PAR(e, nn) {
+            const int i = e / n, j = e % n;
+            const double t = sum4(0, n, [&](int r) { return rw(r) * Ep[i * n + r] * dX[r * n + j]; });
+            Tm[e] = (U[e] - X[e] / rmu(i)) / om + (dX[e] - om * t) / rmu(i);   // dU (into Tm; Bm still holds C)
+        }
+        team.sync();
+        dU = Tm;
+    }
+    // ---- W+-, dW+-, norms (one solution per lane)
+    double* dnrm = rot;  // the rotation parameters of the Jacobi sweeps are free now (n + 64 >= n doubles)
     SKV_PAR(j, n) {
-        double nr = 0;
+        double nr = 0, dnr = 0;
         rec[R.K() + j] = kk[j];
         rec[R.E() + j] = exp(-kk[j] * th);
+        rec[R.DK() + j] = derivs ? dk[j] : 0.0;
         for (int i = 0; i < n; ++i) {
             const double uk = U[i * n + j] / kk[j];
             const double wp = 0.5 * (X[i * n + j] + uk), wm = 0.5 * (X[i * n + j] - uk);
             rec[R.WP() + i + n * j] = wp;
             rec[R.WM() + i + n * j] = wm;
             nr += rw(i) * rmu(i) * (wp * wp - wm * wm);
+            if (derivs) {
+                const double duk = dU[i * n + j] / kk[j] - U[i * n + j] * dk[j] / lam[j];
+                const double dwp = 0.5 * (dX[i * n + j] + duk), dwm = 0.5 * (dX[i * n + j] - duk);
+                rec[R.DWP() + i + n * j] = dwp;
+                rec[R.DWM() + i + n * j] = dwm;
+                dnr += rw(i) * rmu(i) * 2.0 * (wp * dwp - wm * dwm);
+            }
         }
         nrm[j] = nr;
+        dnrm[j] = dnr;
     }
     // ---- solar pseudo-source: first column of the products with the unpolarised sun (single_scat_st, sktran_do_lpproduct.h:339-384)
     const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * kPi);
@@ -420,40 +488,80 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
     bool allzero = true;
     for (int r = 0; r < n; ++r)
         if (Qp[r] != 0 || Qm[r] != 0) allzero = false;
+    // Green's coefficients and multipliers per solution: coef[j][12] = Am Cm, Ap Cp, Am dCm[4], Ap dCp[4], dAm Cm, dAp Cp
     SKV_PAR(j, n) {
-        double Ap = 0, Am = 0, cp = 0, cm = 0;
+        double Ap = 0, Am = 0, dAp = 0, dAm = 0;
+        double* cj = coef + 12 * j;
+        for (int t = 0; t < 12; ++t) cj[t] = 0;
         if (!allzero) {
             for (int i = 0; i < n; ++i) {
                 const double wp = rec[R.WP() + i + n * j], wm = rec[R.WM() + i + n * j];
                 Ap += Qp[i] * wp + Qm[i] * wm;
                 Am += Qm[i] * wp + Qp[i] * wm;
+                if (derivs) {
+                    const double dwp = rec[R.DWP() + i + n * j], dwm = rec[R.DWM() + i + n * j];
+                    dAp += Qp[i] * dwp + Qp[i] / om * wp + Qm[i] * dwm + Qm[i] / om * wm;
+                    dAm += Qm[i] * dwp + Qm[i] / om * wp + Qp[i] * dwm + Qp[i] / om * wm;
+                }
             }
             Ap /= nrm[j];
             Am /= nrm[j];
+            dAp = dAp / nrm[j] - dnrm[j] * Ap / nrm[j];
+            dAm = dAm / nrm[j] - dnrm[j] * Am / nrm[j];
             skd::Mult Cp, Cm;
             skd::green_multipliers(T, th, sc, kk[j], Cp, Cm);
-            cp = Ap * Cp.v;
-            cm = Am * Cm.v;
+            cj[0] = Am * Cm.v;
+            cj[1] = Ap * Cp.v;
+            if (derivs) {
+                const double dkj = rec[R.DK() + j];
+                const double dCp[4] = {Cp.d_tau, Cp.d_k * dkj, T != 0 ? Cp.v / T : 0.0, Cp.d_sec};
+                const double dCm[4] = {Cm.d_tau, Cm.d_k * dkj, T != 0 ? Cm.v / T : 0.0, Cm.d_sec};
+                for (int t = 0; t < 4; ++t) {
+                    cj[2 + t] = Am * dCm[t];
+                    cj[6 + t] = Ap * dCp[t];
+                }
+                cj[10] = dAm * Cm.v;
+                cj[11] = dAp * Cp.v;
+            }
         }
         rec[R.AP() + j] = Ap;
         rec[R.AM() + j] = Am;
-        acp[j] = cp;
-        acm[j] = cm;
+        rec[R.DAP() + j] = derivs ? dAp : 0.0;
+        rec[R.DAM() + j] = derivs ? dAm : 0.0;
     }
     team.sync();
     SKV_PAR(i, n) {
         double g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+        double dg[4][4];
+        for (int t = 0; t < 4; ++t)
+            for (int c = 0; c < 4; ++c) dg[t][c] = 0;
         for (int j = 0; j < n; ++j) {
+            const double* cj = coef + 12 * j;
             const double wp = rec[R.WP() + i + n * j], wm = rec[R.WM() + i + n * j];
-            g0 += acm[j] * wm;
-            g1 += acm[j] * wp;
-            g2 += acp[j] * wp;
-            g3 += acp[j] * wm;
+            g0 += cj[0] * wm;
+            g1 += cj[0] * wp;
+            g2 += cj[1] * wp;
+            g3 += cj[1] * wm;
+            if (derivs) {
+                const double dwp = rec[R.DWP() + i + n * j], dwm = rec[R.DWM() + i + n * j];
+                for (int t = 0; t < 4; ++t) {
+                    dg[t][0] += cj[2 + t] * wm;
+                    dg[t][1] += cj[2 + t] * wp;
+                    dg[t][2] += cj[6 + t] * wp;
+                    dg[t][3] += cj[6 + t] * wm;
+                }
+                dg[skd::TH_OM][0] += cj[10] * wm + cj[0] * dwm;
+                dg[skd::TH_OM][1] += cj[10] * wp + cj[0] * dwp;
+                dg[skd::TH_OM][2] += cj[11] * wp + cj[1] * dwp;
+                dg[skd::TH_OM][3] += cj[11] * wm + cj[1] * dwm;
+            }
         }
         rec[R.G() + 0 * n + i] = g0;
         rec[R.G() + 1 * n + i] = g1;
         rec[R.G() + 2 * n + i] = g2;
         rec[R.G() + 3 * n + i] = g3;
+        for (int t = 0; t < 4; ++t)
+            for (int c = 0; c < 4; ++c) rec[R.DG() + (t * 4 + c) * n + i] = dg[t][c];
     }
     team.sync();
     if (err && team.lane == 0) {
@@ -677,6 +785,7 @@ SKD_HD void kv3_table_values(const Geo& g, const VGeo& vg, const Bufs& b, const 
     for (int j = 0; j < n; ++j) {
         skd::PPMult pm;
         skd::pp_multipliers(T, th, sc, c[R.K() + j], g.lfrac[p], pm);
+        if (v.derivs) skd::ppm_store(vrec_at(v, nlyr, p, w) + R.PPM() + 14 * j, pm);
         cL[j] = pm.hp * xs[j] + c[R.AP() + j] * pm.Dm;
         cM[j] = pm.hm * xs[n + j] + c[R.AM() + j] * pm.Dp;
     }
@@ -747,8 +856,12 @@ SKD_HD void kv4_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v,
             if (skd::conv_at(b, g, slot, w) > 0) behind[0] += g.g_w[t] * vJ_at(v, g, 0, slot, w, 0);  // order 0 only
         }
     }
+    const double att_total = b.att_total[size_t(los) * nw + w];
+    const size_t nt3 = size_t(nw) * g.nlos * S;
+    double prod_upto = 1.0;  // prod_{q' <= q} att_q'
     for (int q = g.ray_qstart[los]; q < g.ray_qstart[los + 1]; ++q) {
         const double att = exp(-b.od[size_t(q) * nw + w]);
+        prod_upto *= att;
         double sv[3] = {0, 0, 0};
         if (g.rl_active[q]) {
             const double* cs = g.rl_cosm_t + size_t(q) * nstr;
@@ -764,6 +877,20 @@ SKD_HD void kv4_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v,
             }
         }
         const double omega = b.omloc[size_t(q) * nw + w];
+        if (v.derivs) {
+            // LOS-level derivative terms (shell optical depth, local single-scatter albedo), as skd::k4b_los
+            const double a_q = (prod_upto > 0) ? att_total / prod_upto : 0.0;
+            for (int c = 0; c < S; ++c) {
+                const size_t t3 = tid * S + c;
+                const double dI_dod = a_q * (-behind[c] * att + omega * att * sv[c]);
+                for (int t = g.rl_od_start[q]; t < g.rl_od_start[q + 1]; ++t) v.dnat[size_t(g.od_idx[t]) * nt3 + t3] += g.od_w[t] * dI_dod;
+                if (g.rl_active[q]) {
+                    const double dI_dom = a_q * (1 - att) * sv[c];
+                    for (int t = g.rl_ssa_start[q]; t < g.rl_ssa_start[q + 1]; ++t)
+                        v.dnat[size_t(g.ngrid + g.ssa_idx[t]) * nt3 + t3] += g.ssa_w[t] * dI_dom;
+                }
+            }
+        }
         for (int c = 0; c < S; ++c) behind[c] = behind[c] * att + (g.rl_active[q] ? omega * (1 - att) * sv[c] : 0.0);
     }
     for (int c = 0; c < S; ++c) v.radiance[tid * S + c] = behind[c];
@@ -869,6 +996,272 @@ SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v
     }
     const double cz = cos(m * g.pp_azi[los]), sz = sin(m * g.pp_azi[los]);
     for (int s1 = 0; s1 < S; ++s1) v.radiance[tid * S + s1] += total[s1] * (s1 < 2 ? cz : sz);
+}
+
+// =================================================================================================
+// Weighting functions of the polarised path: the adjoint machinery of skd::k2c_layer_ops / skd::K2bTask with N -> n and the
+// Legendre space widened to NL = C nstr numbers per layer, index (l, c), c < C = 3 (1 for NSTOKES = 1): the source of a table
+// point is  J(out)[s] = sum_l [Pi_l(out) v_l][s]  with  v_l = om B_l [ (-1)^(l-m) D tP_l + tM_l ]  linear in (cL, cM) = the layer's
+// BVP coefficients times multipliers, so one adjoint sweep per (line of sight, Stokes component) yields the reduced gradient wrt
+// (tau, omega, T, sec) of every layer; skd::k4a_chain then maps it to the native derivatives.
+// =================================================================================================
+struct VOps {
+    int n, NL;
+    SKD_HD VOps(int n_, int NL_) : n(n_), NL(NL_) {}
+    SKD_HD int FP() const { return 0; }                        // [2n][NL]
+    SKD_HD int SP() const { return 2 * n * NL; }               // [2n][n]
+    SKD_HD int BP() const { return SP() + 2 * n * n; }         // [2n][n]
+    SKD_HD int UG() const { return BP() + 2 * n * n; }         // [2n]
+    SKD_HD int DI() const { return UG() + 2 * n; }             // [(theta*4 + edge)][n]
+    SKD_HD int HD() const { return DI() + 16 * n; }            // [4][NL]
+    SKD_HD int GD() const { return HD() + 4 * NL; }            // [4]
+    SKD_HD int IPB() const { return GD() + 4; }
+    SKD_HD int size() const { return IPB() + 1; }
+};
+SKD_HD int legendre_space(const Geo& g, int S) { return (S == 3 ? 3 : 1) * g.nstr; }
+SKD_HD double* vops_at(const VBufs& v, const Geo& g, int p, int w) {
+    return v.ops + (size_t(w) * g.nlyr + p) * VOps(v.n, legendre_space(g, v.S)).size();
+}
+
+// KV2C: adjoint operators of one layer                        (task = wavelength x layer, one team)
+//   ws: 2n NL + 4 n doubles of team-shared work space (F, temporaries)
+SKD_HD size_t kv2c_scratch(int n, int NL) { return 2 * size_t(n) * NL + 4 * size_t(n); }
+
+SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws) {
+    const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
+    const VRec R(n);
+    const VOps O(n, NL);
+    const double* c = vrec_at(v, nlyr, p, w);
+    const double* dinv = vdinv_at(v, nlyr, p, w);
+    const double* xs = vxsol_at(v, nlyr, p, w);
+    double* o = vops_at(v, g, p, w);
+    const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w];
+    const bool last = (p == nlyr - 1);
+    const double rho = (m == 0) ? b.albedo[w] : 0.0;
+    double *F = ws, *tmp = ws + M2 * NL, *ipbv = tmp + M2;   // F [2n][NL], tmp [2n], ipbv [n]
+    (void)s;
+    // ---- F = [UL; UM] and the direct-dependence rows HD: one Legendre order per lane
+    SKV_PAR(l, nstr) {
+        double hd[4][3], val[3] = {0, 0, 0};
+        for (int t = 0; t < 4; ++t)
+            for (int cc = 0; cc < 3; ++cc) hd[t][cc] = 0;
+        double c4[4];
+        load_coef(b, v, nstr, p, l, w, c4);
+        const double sg = ((l - m) & 1) ? -1.0 : 1.0;
+        for (int a_ = 0; a_ < n; ++a_) {
+            double yp[3] = {0, 0, 0}, ym[3] = {0, 0, 0}, dyp[3] = {0, 0, 0}, dym[3] = {0, 0, 0};
+            if (l >= m) {
+                double tP[3] = {0, 0, 0}, tM[3] = {0, 0, 0}, dtP[3] = {0, 0, 0}, dtM[3] = {0, 0, 0};
+                for (int j = 0; j < N; ++j) {
+                    const Fun3 fj = fun_mu(g, vg, m, j);
+                    const double hw = 0.5 * g.wt[j];
+                    double wp[3] = {0, 0, 0}, wm[3] = {0, 0, 0}, dwp[3] = {0, 0, 0}, dwm[3] = {0, 0, 0};
+                    for (int s2 = 0; s2 < S; ++s2) {
+                        const int r = j * S + s2;
+                        wp[s2] = c[R.WP() + r + n * a_];
+                        wm[s2] = c[R.WM() + r + n * a_];
+                        dwp[s2] = c[R.DWP() + r + n * a_] + wp[s2] / om;
+                        dwm[s2] = c[R.DWM() + r + n * a_] + wm[s2] / om;
+                    }
+                    double y[3];
+                    if (S == 1) {
+                        tP[0] += hw * fj.P[l] * wp[0]; tM[0] += hw * fj.P[l] * wm[0];
+                        dtP[0] += hw * fj.P[l] * dwp[0]; dtM[0] += hw * fj.P[l] * dwm[0];
+                    } else {
+                        pi_apply(fj.P[l], fj.R[l], fj.T[l], wp, y);  for (int cc = 0; cc < 3; ++cc) tP[cc] += hw * y[cc];
+                        pi_apply(fj.P[l], fj.R[l], fj.T[l], wm, y);  for (int cc = 0; cc < 3; ++cc) tM[cc] += hw * y[cc];
+                        pi_apply(fj.P[l], fj.R[l], fj.T[l], dwp, y); for (int cc = 0; cc < 3; ++cc) dtP[cc] += hw * y[cc];
+                        pi_apply(fj.P[l], fj.R[l], fj.T[l], dwm, y); for (int cc = 0; cc < 3; ++cc) dtM[cc] += hw * y[cc];
+                    }
+                }
+                const double xP[3] = {sg * tP[0] + tM[0], sg * tP[1] + tM[1], -sg * tP[2] + tM[2]};
+                const double xM[3] = {sg * tM[0] + tP[0], sg * tM[1] + tP[1], -sg * tM[2] + tP[2]};
+                const double dxP[3] = {sg * dtP[0] + dtM[0], sg * dtP[1] + dtM[1], -sg * dtP[2] + dtM[2]};
+                const double dxM[3] = {sg * dtM[0] + dtP[0], sg * dtM[1] + dtP[1], -sg * dtM[2] + dtP[2]};
+                greek_apply(c4, xP, yp);
+                greek_apply(c4, xM, ym);
+                greek_apply(c4, dxP, dyp);
+                greek_apply(c4, dxM, dym);
+                for (int cc = 0; cc < 3; ++cc) { yp[cc] *= om; ym[cc] *= om; dyp[cc] *= om; dym[cc] *= om; }
+            }
+            skd::PPMult pm;
+            skd::ppm_load(c + R.PPM() + 14 * a_, pm);
+            const double L = xs[a_], Mv = xs[n + a_], dk = c[R.DK() + a_];
+            const double Ap = c[R.AP() + a_], Am = c[R.AM() + a_], dAp = c[R.DAP() + a_], dAm = c[R.DAM() + a_];
+            const double tL = pm.hp * L + Ap * pm.Dm, tM_ = pm.hm * Mv + Am * pm.Dp;
+            for (int cc = 0; cc < C; ++cc) {
+                F[a_ * NL + l * C + cc] = yp[cc] * pm.hp / om;
+                F[(n + a_) * NL + l * C + cc] = ym[cc] * pm.hm / om;
+                val[cc] += yp[cc] * tL + ym[cc] * tM_;
+                hd[skd::TH_TAU][cc] += yp[cc] * (pm.hp_tau * L + Ap * pm.Dm_tau) + ym[cc] * (pm.hm_tau * Mv + Am * pm.Dp_tau);
+                hd[skd::TH_SEC][cc] += yp[cc] * Ap * pm.Dm_sec + ym[cc] * Am * pm.Dp_sec;
+                hd[skd::TH_T][cc] += (T != 0) ? (yp[cc] * Ap * pm.Dm + ym[cc] * Am * pm.Dp) / T : 0.0;
+                hd[skd::TH_OM][cc] += dyp[cc] * tL + dym[cc] * tM_ + yp[cc] * (pm.hp_k * dk * L + dAp * pm.Dm + Ap * pm.Dm_k * dk) +
+                                      ym[cc] * (pm.hm_k * dk * Mv + dAm * pm.Dp + Am * pm.Dp_k * dk);
+            }
+        }
+        for (int cc = 0; cc < C; ++cc) {
+            for (int t = 0; t < 4; ++t) hd[t][cc] /= om;
+            hd[skd::TH_OM][cc] -= val[cc] / (om * om);
+            for (int t = 0; t < 4; ++t) o[O.HD() + t * NL + l * C + cc] = hd[t][cc];
+        }
+    }
+    team.sync();
+    // ---- FP = Dinv^T F
+    SKV_PAR(e, M2 * NL) {
+        const int i = e / NL, lam_ = e % NL;
+        o[O.FP() + e] = sum4(0, M2, [&](int j) { return dinv[j * M2 + i] * F[j * NL + lam_]; });
+    }
+    // ---- SP = Dinv^T SupT, BP = Dinv^T SubT  (SupT[j][i] = W-(i,j), SupT[n+j][i] = W+(i,j) E_j ; SubT[j][i] = W+(i,j) E_j, SubT[n+j][i] = W-(i,j))
+    SKV_PAR(e, M2 * n) {
+        const int i = e / n, cidx = e % n;
+        double t1 = 0, t2 = 0;
+        for (int j = 0; j < n; ++j) {
+            const double wp = c[R.WP() + cidx + n * j], wm = c[R.WM() + cidx + n * j], E = c[R.E() + j];
+            t1 += dinv[j * M2 + i] * wm + dinv[(n + j) * M2 + i] * wp * E;
+            t2 += dinv[j * M2 + i] * wp * E + dinv[(n + j) * M2 + i] * wm;
+        }
+        o[O.SP() + e] = t1;
+        o[O.BP() + e] = t2;
+    }
+    // ---- edge-intensity derivatives at fixed (L, M), one row per lane
+    SKV_PAR(i, n) {
+        double d_tau[4] = {0, 0, 0, 0}, d_om[4] = {0, 0, 0, 0}, ipb_i = c[R.G() + 2 * n + i];
+        for (int j = 0; j < n; ++j) {
+            const double wp = c[R.WP() + i + n * j], wm = c[R.WM() + i + n * j], dwp = c[R.DWP() + i + n * j], dwm = c[R.DWM() + i + n * j];
+            const double E = c[R.E() + j], L = xs[j], Mv = xs[n + j];
+            const double dE_tau = -c[R.K() + j] * E, dE_om = -c[R.DK() + j] * th * E;
+            d_tau[0] += wm * dE_tau * Mv;
+            d_tau[1] += wp * dE_tau * Mv;
+            d_tau[2] += wp * dE_tau * L;
+            d_tau[3] += wm * dE_tau * L;
+            d_om[0] += dwp * L + dwm * E * Mv + wm * dE_om * Mv;
+            d_om[1] += dwm * L + dwp * E * Mv + wp * dE_om * Mv;
+            d_om[2] += dwp * E * L + wp * dE_om * L + dwm * Mv;
+            d_om[3] += dwm * E * L + wm * dE_om * L + dwp * Mv;
+            ipb_i += wp * E * L + wm * Mv;
+        }
+        ipbv[i] = ((i % S) == 0) ? g.wt[i / S] * g.mu[i / S] * ipb_i : 0.0;
+        for (int e = 0; e < 4; ++e) {
+            o[O.DI() + (skd::TH_TAU * 4 + e) * n + i] = c[R.DG() + (skd::TH_TAU * 4 + e) * n + i] + d_tau[e];
+            o[O.DI() + (skd::TH_OM * 4 + e) * n + i] = c[R.DG() + (skd::TH_OM * 4 + e) * n + i] + d_om[e];
+            o[O.DI() + (skd::TH_T * 4 + e) * n + i] = c[R.DG() + (skd::TH_T * 4 + e) * n + i];
+            o[O.DI() + (skd::TH_SEC * 4 + e) * n + i] = c[R.DG() + (skd::TH_SEC * 4 + e) * n + i];
+        }
+    }
+    // ground part of u (order 0, last layer): tmp = [2 rho sp_j E_j ; 2 rho sm_j] over the intensity rows
+    SKV_PAR(j, n) {
+        double sp = 0, sm = 0;
+        if (last && m == 0)
+            for (int i = 0; i < N; ++i) {
+                sp += g.mu[i] * g.wt[i] * c[R.WP() + i * S + n * j];
+                sm += g.mu[i] * g.wt[i] * c[R.WM() + i * S + n * j];
+            }
+        tmp[j] = 2.0 * rho * sp * c[R.E() + j];
+        tmp[n + j] = 2.0 * rho * sm;
+    }
+    team.sync();
+    SKV_PAR(i, M2) o[O.UG() + i] = sum4(0, M2, [&](int j) { return dinv[j * M2 + i] * tmp[j]; });
+    if (team.lane == 0) {
+        double ipb = 0;
+        for (int i = 0; i < n; ++i) ipb += ipbv[i];
+        o[O.IPB()] = ipb;
+        for (int t = 0; t < 4; ++t) {
+            double sacc = 0;
+            if (last && m == 0)
+                for (int i = 0; i < N; ++i) sacc += g.wt[i] * g.mu[i] * o[O.DI() + (t * 4 + 2) * n + i * S];
+            o[O.GD() + t] = 2.0 * rho * sacc;
+        }
+    }
+    team.sync();
+}
+
+// KV2B: adjoint sweep of one (line of sight, Stokes component) for azimuth order m   (task = wavelength x LOS x Stokes)
+//   scratch: NL + 3 n doubles per thread
+SKD_HD size_t kv2b_scratch(int n, int NL) { return size_t(NL) + 3 * size_t(n); }
+
+SKD_HD void kv2b_adjoint(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int los, int sout, int w, Scr scr) {
+    const int S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
+    const VOps O(n, NL);
+    const size_t tid = (size_t(w) * g.nlos + los) * S + sout, nt = size_t(nw) * g.nlos * S;
+    Scr ql = scr.sub(0), y = scr.sub(NL), carry = scr.sub(NL + M2);
+    double gw = 0;  // the Lambertian ground feeds the intensity only
+    if (sout == 0 && m == 0 && g.ray_ground[los]) {
+        for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t)
+            if (g.g_sza[t] == s && skd::conv_at(b, g, g.g_slot[t], w) > m) gw += g.g_w[t];
+        gw *= b.att_total[size_t(los) * nw + w];
+    }
+    for (int i = 0; i < n; ++i) carry[i] = 0;
+    // ---- forward sweep  y_p = FP ql_p + SP yB_{p-1} (+ gw UG)
+    for (int p = 0; p < nlyr; ++p) {
+        const double* ops = vops_at(v, g, p, w);
+        for (int l = 0; l < NL; ++l) ql[l] = 0;
+        const int base = (los * g.nsza + s) * nlyr + p;
+        for (int t = g.lp_start[base]; t < g.lp_start[base + 1]; ++t) {
+            if (skd::conv_at(b, g, g.lp_slot[t], w) <= m) continue;
+            const int q = g.lp_q[t];
+            const double az = (sout < 2) ? g.rl_cosm[size_t(m) * g.nq_total + q] : vg.rl_sinm_t[size_t(q) * nstr + m];
+            const double cw = b.srcw[size_t(q) * nw + w] * g.lp_w[t] * az;
+            if (cw == 0.0) continue;
+            const Fun3 fa = fun_ang(g, vg, m, g.lp_angle[t]);
+            for (int l = m; l < nstr; ++l) {
+                if (S == 1) { ql[l] += cw * fa.P[l]; continue; }
+                // row `sout` of Pi_l(angle)
+                if (sout == 0) ql[l * 3] += cw * fa.P[l];
+                else if (sout == 1) { ql[l * 3 + 1] += cw * fa.R[l]; ql[l * 3 + 2] -= cw * fa.T[l]; }
+                else { ql[l * 3 + 1] -= cw * fa.T[l]; ql[l * 3 + 2] += cw * fa.R[l]; }
+            }
+        }
+        for (int l = 0; l < NL; ++l) v.qlbuf[(size_t(p) * NL + l) * nt + tid] = ql[l];
+        for (int i = 0; i < M2; ++i) {
+            double t = (p == nlyr - 1) ? gw * ops[O.UG() + i] : 0.0;
+            for (int l = m * C; l < NL; ++l) t += ops[O.FP() + i * NL + l] * ql[l];
+            for (int cidx = 0; cidx < n; ++cidx) t += ops[O.SP() + i * n + cidx] * carry[cidx];
+            y[i] = t;
+        }
+        for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
+        for (int i = 0; i < n; ++i) carry[i] = y[n + i];
+    }
+    // ---- backward sweep  z_p = y_p - BP zA_{p+1}
+    for (int i = 0; i < n; ++i) carry[i] = 0;
+    for (int p = nlyr - 1; p >= 0; --p) {
+        const double* ops = vops_at(v, g, p, w);
+        for (int i = 0; i < M2; ++i) {
+            double t = v.z[(size_t(p) * M2 + i) * nt + tid];
+            if (p < nlyr - 1)
+                for (int cidx = 0; cidx < n; ++cidx) t -= ops[O.BP() + i * n + cidx] * carry[cidx];
+            y[i] = t;
+        }
+        for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
+        for (int i = 0; i < n; ++i) carry[i] = y[i];
+    }
+    // ---- reduced gradient
+    for (int p = 0; p < nlyr; ++p) {
+        const double* ops = vops_at(v, g, p, w);
+        const bool last = (p == nlyr - 1);
+        double gth[4] = {0, 0, 0, 0};
+        double zBsum = 0;
+        for (int i = 0; i < n; ++i) {
+            const double zA = v.z[(size_t(p) * M2 + i) * nt + tid], zB = v.z[(size_t(p) * M2 + n + i) * nt + tid];
+            const double zAn = last ? 0.0 : v.z[(size_t(p + 1) * M2 + i) * nt + tid];
+            const double zBp = (p > 0) ? v.z[(size_t(p - 1) * M2 + n + i) * nt + tid] : 0.0;
+            if (last && m == 0 && (i % S) == 0) zBsum += zB;
+            for (int t = 0; t < 4; ++t)
+                gth[t] += zA * ops[O.DI() + (t * 4 + 0) * n + i] + zBp * ops[O.DI() + (t * 4 + 1) * n + i] -
+                          zAn * ops[O.DI() + (t * 4 + 2) * n + i] - zB * ops[O.DI() + (t * 4 + 3) * n + i];
+        }
+        for (int l = m * C; l < NL; ++l) {
+            const double q = v.qlbuf[(size_t(p) * NL + l) * nt + tid];
+            for (int t = 0; t < 4; ++t) gth[t] += ops[O.HD() + t * NL + l] * q;
+        }
+        if (last && m == 0) {
+            for (int t = 0; t < 4; ++t) gth[t] += (zBsum + gw) * ops[O.GD() + t];
+            const double rho = b.albedo[w], ipb = ops[O.IPB()];
+            v.grad[size_t(4 * nlyr) * nt + tid] += gw * 2.0 * ipb + zBsum * (2.0 * ipb + g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w]);
+            v.grad[size_t(4 * nlyr + 1) * nt + tid] += zBsum * g.csz[s] / kPi * rho;
+        }
+        for (int t = 0; t < 4; ++t) v.grad[size_t(t * nlyr + p) * nt + tid] += gth[t];
+    }
 }
 
 // (I, Q, U) of one line of sight in the configured Stokes basis:  Q' = C Q - S U,  U' = S Q + C U

@@ -49,7 +49,8 @@ void emuv_destroy(void* h) { delete static_cast<Handle*>(h); }
 
 // radiance: [nwavel][nlos][nstokes];  leg: [nwavel][ngrid][nleg][4] (reference storage order, nstokes = 3) or [..][nleg]
 int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg,
-             const double* solar_irradiance, const double* albedo, const double* delta_f, double* radiance, double* los_od, int* status) {
+             const double* solar_irradiance, const double* albedo, const double* delta_f, double* radiance, double* los_od, int* status,
+             int derivatives, double* d_k, double* d_ssa, double* d_albedo) {
     auto* h = static_cast<Handle*>(hv);
     const skhost::GeoTables& t = h->tab;
     skd::Geo g = t.host_view();
@@ -70,10 +71,18 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     const skv::VRec R(n);
     std::vector<double> a4(size_t(nlyr) * nstr * 4 * nw), rec(size_t(nlyr) * R.size() * nw), dinv(size_t(nlyr) * 4 * n * n * nw),
         xsol(size_t(nlyr) * 2 * n * nw), J(size_t(nstr) * std::max(t.nslot, 1) * nw * S, 0.0), rad(nt * S, 0.0);
-    std::vector<double> scratch(std::max({skv::kv1_scratch(n), skv::kv2_scratch(n), skv::kv3_scratch(n, nstr), skv::kvpp_scratch(n)}));
+    const int NL = skv::legendre_space(g, S), ngrid = t.ngrid;
+    const size_t nt3 = nt * S;
+    if (derivatives && g.pp_mode) return -2;  // weighting functions of the polarised path: spherical post-processing only
+    std::vector<double> scratch(std::max({skv::kv1_scratch(n), skv::kv2_scratch(n), skv::kv3_scratch(n, nstr), skv::kvpp_scratch(n),
+                                          skv::kv2c_scratch(n, NL), skv::kv2b_scratch(n, NL)}));
+    std::vector<double> ops(derivatives ? size_t(nlyr) * skv::VOps(n, NL).size() * nw : 1), zb(derivatives ? size_t(nlyr) * 2 * n * nt3 : 1),
+        qlb(derivatives ? size_t(nlyr) * NL * nt3 : 1), grad(derivatives ? size_t(4 * nlyr + 2) * nt3 : 1, 0.0),
+        dnat(derivatives ? size_t(2 * ngrid + 1) * nt3 : 1, 0.0);
     skv::VBufs v{};
     v.S = S; v.n = n; v.leg = leg; v.nleg = nleg; v.a4 = a4.data(); v.rec = rec.data(); v.dinv = dinv.data(); v.xsol = xsol.data();
     v.J = J.data(); v.radiance = rad.data(); v.scratch = scratch.data(); v.scratch_stride = 1;
+    v.ops = ops.data(); v.z = zb.data(); v.qlbuf = qlb.data(); v.grad = grad.data(); v.dnat = dnat.data(); v.derivs = derivatives;
     const skv::Scr scr{scratch.data(), 1};
     const skv::Team team{0, 1};
     double* ws = scratch.data();
@@ -103,13 +112,32 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                 if (!active) break;
                 for (int w = 0; w < nw; ++w)
                     for (int p = 0; p < nlyr; ++p)
-                        if (m < norders[w]) skv::kv1_layer_solution(team, g, vg, b, v, s, m, p, w, ws);
+                        if (m < norders[w]) skv::kv1_layer_solution(team, g, vg, b, v, s, m, p, w, ws, derivatives != 0);
                 for (int w = 0; w < nw; ++w)
                     if (m < norders[w]) skv::kv2_bvp(team, g, b, v, s, m, w, ws, ws + skv::kv2_scratch_main(n));
                 for (int w = 0; w < nw; ++w)
                     for (int p = 0; p < nlyr; ++p)
                         if (m < norders[w]) skv::kv3_table_values(g, vg, b, v, s, m, p, w, scr);
+                if (derivatives) {
+                    for (int w = 0; w < nw; ++w)
+                        for (int p = 0; p < nlyr; ++p)
+                            if (m < norders[w]) skv::kv2c_layer_ops(team, g, vg, b, v, s, m, p, w, ws);
+                    for (int w = 0; w < nw; ++w)
+                        for (int l = 0; l < nlos; ++l)
+                            for (int so = 0; so < S; ++so)
+                                if (m < norders[w]) skv::kv2b_adjoint(g, vg, b, v, s, m, l, so, w, scr);
+                }
                 for (int w = 0; w < nw; ++w) skd::k_stop_rule(g, b, s, m, w);
+            }
+            if (derivatives) {
+                // reverse chain beam / optics -> native derivatives: the scalar task body with (LOS, Stokes) as the line-of-sight index
+                skd::Geo g3 = g;
+                g3.nlos = nlos * S;
+                skd::Bufs b3 = b;
+                b3.grad = grad.data();
+                b3.dnat = dnat.data();
+                for (int w = 0; w < nw; ++w)
+                    for (int l3 = 0; l3 < nlos * S; ++l3) skd::k4a_chain(g3, b3, s, l3, w);
             }
         }
         for (int w = 0; w < nw; ++w)
@@ -118,6 +146,22 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     for (size_t i = 0; i < nt; ++i) skv::stokes_rotate(vg, int(i % nlos), &rad[i * S], &radiance[i * S], S);
     for (size_t i = 0; i < nt; ++i)
         if (los_od) los_od[i] = lod[i];
+    if (derivatives) {
+        // [w][los][S][ngrid], Stokes rotation applied to the derivatives as to the radiance
+        for (size_t i = 0; i < nt; ++i) {
+            const int los = int(i % nlos);
+            for (int q = 0; q <= 2 * ngrid; ++q) {
+                double in[3] = {0, 0, 0}, out[3];
+                for (int c = 0; c < S; ++c) in[c] = dnat[size_t(q) * nt3 + i * S + c];
+                skv::stokes_rotate(vg, los, in, out, S);
+                for (int c = 0; c < S; ++c) {
+                    if (q < ngrid) { if (d_k) d_k[(i * S + c) * ngrid + q] = out[c]; }
+                    else if (q < 2 * ngrid) { if (d_ssa) d_ssa[(i * S + c) * ngrid + (q - ngrid)] = out[c]; }
+                    else if (d_albedo) d_albedo[i * S + c] = out[c];
+                }
+            }
+        }
+    }
     for (int w = 0; w < nw; ++w)
         if (status) status[w] = stat[w];
     return 0;

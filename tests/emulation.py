@@ -90,12 +90,13 @@ def libv():
                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.emuv_destroy.argtypes = [ctypes.c_void_p]
         L.emuv_run.restype = ctypes.c_int
-        L.emuv_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]
+        L.emuv_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip,
+                               ctypes.c_int, _dp, _dp, _dp]
         _LIBV = L
     return _LIBV
 
 
-def run_emulated_vector(s):
+def run_emulated_vector(s, derivatives=False):
     """Radiances [nwavel, nlos, nstokes] of the polarised task bodies (disco_vec_core.hpp) executed on the CPU."""
     g = s["geometry"]
     alt = np.ascontiguousarray(g["altitudes"], dtype=np.float64)
@@ -117,9 +118,17 @@ def run_emulated_vector(s):
         df = None if s.get("delta_f") is None else np.asfortranarray(s["delta_f"], dtype=np.float64)
         rad, od = np.zeros((nw, nlos, S)), np.zeros((nw, nlos))
         status = np.zeros(nw, dtype=np.int32)
+        ngrid = len(alt)
+        dk = dw = da = None
+        if derivatives:
+            dk, dw, da = np.zeros((nw, nlos, S, ngrid)), np.zeros((nw, nlos, S, ngrid)), np.zeros((nw, nlos, S))
         rc = L.emuv_run(h, nw, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), None, _p(alb), _p(df), _p(rad), _p(od),
-                        status.ctypes.data_as(_ip))
-        assert rc == 0
-        return {"radiance": rad if S == 3 else rad[..., 0], "los_optical_depth": od, "status": status}
+                        status.ctypes.data_as(_ip), int(derivatives), _p(dk), _p(dw), _p(da))
+        assert rc == 0, rc
+        out = {"radiance": rad if S == 3 else rad[..., 0], "los_optical_depth": od, "status": status}
+        if derivatives:
+            sq = (lambda a: a) if S == 3 else (lambda a: a[:, :, 0])
+            out.update({"d_extinction": sq(dk), "d_ssa": sq(dw), "d_albedo": sq(da)})
+        return out
     finally:
         L.emuv_destroy(h)
