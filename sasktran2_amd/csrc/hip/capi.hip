@@ -142,7 +142,8 @@ __global__ void __launch_bounds__(256) kern_map_wf(const double* we, const doubl
 // times the interpolator) and / or the division by the radiance of a log-radiance-space mapping; dst is [nout][wavel][los]
 __global__ void __launch_bounds__(256) kern_map_wf_interp(const double* we, const double* ws, const double* f_ssa, const double* f_ext,
                                                           const double* interp, const double* radiance, int log_space, double* dst,
-                                                          int ngrid, int nout, int nw, int nlos) {
+                                                          int ngrid, int nout, int nw, int nlos, int S = 1) {
+    // nlos counts (line of sight, Stokes component) pairs; a log-radiance mapping divides every component by the intensity
     const size_t n = size_t(nout) * nw * nlos;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         const size_t jw = i / nlos;
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(256) kern_map_wf_interp(const double* we, cons
         } else {
             acc = f_ssa[size_t(w) * ngrid + j] * ws[i] + f_ext[size_t(w) * ngrid + j] * we[i];
         }
-        if (log_space) acc /= radiance[size_t(w) * nlos + l];
+        if (log_space) acc /= radiance[size_t(w) * nlos + (l / S) * S];
         dst[i] = acc;
     }
 }
@@ -371,14 +372,63 @@ int sk_engine_calculate_radiance_block_thread(Engine* e, OutputC* o, int, int, i
     return (e && o) ? 0 : -1;
 }
 
-// NSTOKES = 3 (and NSTOKES = 1 stream counts outside the matrix-core path): radiances [wavel][los][stokes] and LOS optical depths;
-// weighting functions of this path are not built, a request for them is answered with -2.
+// native weighting functions (device, [ngrid][wavel][los][S] / [wavel][los][S]) -> the caller's derivative mappings
+static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const Surface& su, OutputC* out, const double* d_we, const double* d_ws,
+                                 const double* d_wa, const double* d_rad, int S) {
+    DeviceCache& C = e->cache;
+    const int nw = st.nwavel, ngrid = e->ngrid, nlos = e->nlos * S;   // (line of sight, Stokes component) pairs
+    const size_t nloc_w = size_t(ngrid) * nw, nt = size_t(nw) * nlos;
+    {
+            double* d_fs = (double*)C.get("map_d_ssa", nloc_w * 8);
+            double* d_fk = (double*)C.get("map_d_extinction", nloc_w * 8);
+            for (auto& kv : out->derivs) {
+                auto it = st.maps.find(kv.first);
+                if (it == st.maps.end()) throw std::runtime_error("no derivative mapping named " + kv.first);
+                const DerivativeMapping& m = *it->second;
+                const int nout = m.interpolator ? m.interp_dim2 : ngrid;
+                if (m.interpolator && m.interp_dim1 != ngrid) throw std::runtime_error("interpolator of " + kv.first + " does not have one row per grid location");
+                if (kv.second.nderiv != nout || kv.second.nrad * kv.second.nstokes != nw * nlos) throw std::runtime_error("derivative memory size mismatch for " + kv.first);
+                HIPC(hipMemcpy(d_fs, m.d_ssa.data(), nloc_w * 8, hipMemcpyHostToDevice));
+                HIPC(hipMemcpy(d_fk, m.d_extinction.data(), nloc_w * 8, hipMemcpyHostToDevice));
+                double* d_dst = (double*)C.get("wf_user", size_t(nout) * nt * 8);
+                if (!m.interpolator && !m.log_radiance_space) {
+                    hipLaunchKernelGGL(kern_map_wf, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_dst, ngrid, nw, nlos);
+                } else {
+                    double* d_interp = nullptr;
+                    if (m.interpolator) {
+                        d_interp = (double*)C.get("interpolator", size_t(ngrid) * nout * 8);
+                        HIPC(hipMemcpy(d_interp, m.interpolator, size_t(ngrid) * nout * 8, hipMemcpyHostToDevice));
+                    }
+                    hipLaunchKernelGGL(kern_map_wf_interp, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_interp, d_rad,
+                                       m.log_radiance_space, d_dst, ngrid, nout, nw, nlos, S);
+                }
+                HIPC(hipGetLastError());
+                HIPC(hipMemcpy(kv.second.mem, d_dst, size_t(nout) * nt * 8, hipMemcpyDeviceToHost));  // C order [nderiv][wavel][los]
+            }
+            if (!out->surface_derivs.empty()) {
+                std::vector<double> wa(nt);
+                HIPC(hipMemcpy(wa.data(), d_wa, nt * 8, hipMemcpyDeviceToHost));
+                for (auto& kv : out->surface_derivs) {
+                    auto it = su.maps.find(kv.first);
+                    if (it == su.maps.end()) throw std::runtime_error("no surface derivative mapping named " + kv.first);
+                    const SurfaceDerivativeMapping& m = *it->second;
+                    for (int w = 0; w < nw; ++w)
+                        for (int l = 0; l < nlos; ++l) kv.second.mem[size_t(w) * nlos + l] = wa[size_t(w) * nlos + l] * m.d_brdf[w];
+                }
+            }
+    }
+}
+
+// NSTOKES = 3 (and NSTOKES = 1 stream counts outside the matrix-core path): radiances [wavel][los][stokes], LOS optical depths and,
+// with the spherical post-processing, weighting functions [nderiv][wavel][los][stokes]; plane-parallel weighting functions of this
+// path are not built, a request for them is answered with -2.
 static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     const AtmosphereStorage& st = *atm->storage;
     const Surface& su = *atm->surface;
     const int S = e->config.num_stokes;
-    if (atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty())) {
-        set_error("sk_engine_calculate_radiance: weighting functions are not available for NSTOKES = 3 / this stream count");
+    const int derivs = atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty());
+    if (derivs && e->dev->plane_parallel()) {
+        set_error("sk_engine_calculate_radiance: weighting functions of the NSTOKES = 3 / run-time-n path need a spherical geometry");
         return -2;
     }
     if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
@@ -394,7 +444,7 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     double* d_od = (double*)C.get("los_od", nt * 8);
     double* d_odt = (double*)C.get("los_od_t", nt * 8);
     int* d_status = (int*)C.get("status", size_t(nw) * 4);
-    double* d_irr = nullptr;
+    double *d_irr = nullptr, *d_we = nullptr, *d_ws = nullptr, *d_wa = nullptr;
     HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * per * 8, hipMemcpyHostToDevice));
@@ -403,13 +453,18 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
         d_irr = (double*)C.get("irradiance", size_t(nw) * 8);
         HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyHostToDevice));
     }
+    if (derivs) {
+        d_we = (double*)C.get("wf_ext", size_t(ngrid) * nt * S * 8);
+        d_ws = (double*)C.get("wf_ssa", size_t(ngrid) * nt * S * 8);
+        d_wa = (double*)C.get("wf_alb", nt * S * 8);
+    }
     double* d_f = nullptr;
     if (!st.delta_f.empty()) {
         d_f = (double*)C.get("delta_f", nloc_w * 8);
         HIPC(hipMemcpy(d_f, st.delta_f.data(), nloc_w * 8, hipMemcpyHostToDevice));
     }
     e->dev->set_delta_m_fraction(d_f);
-    e->dev->solve_device_vector(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, d_od, d_status, nullptr);
+    e->dev->solve_device_vector(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status, nullptr);
     e->dev->set_delta_m_fraction(nullptr);
     hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
     HIPC(hipGetLastError());
@@ -421,6 +476,7 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     HIPC(hipMemcpy(out->radiance, d_rad, nt * S * 8, hipMemcpyDeviceToHost));
     out->los_od.resize(nt);
     HIPC(hipMemcpy(out->los_od.data(), d_odt, nt * 8, hipMemcpyDeviceToHost));
+    if (derivs) map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, S);
     return 0;
 }
 
@@ -493,43 +549,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         out->los_od.resize(nt);
         HIPC(hipMemcpy(out->los_od.data(), d_odt, nt * 8, hipMemcpyDeviceToHost));
         if (derivs) {
-            double* d_fs = (double*)C.get("map_d_ssa", nloc_w * 8);
-            double* d_fk = (double*)C.get("map_d_extinction", nloc_w * 8);
-            for (auto& kv : out->derivs) {
-                auto it = st.maps.find(kv.first);
-                if (it == st.maps.end()) throw std::runtime_error("no derivative mapping named " + kv.first);
-                const DerivativeMapping& m = *it->second;
-                const int nout = m.interpolator ? m.interp_dim2 : ngrid;
-                if (m.interpolator && m.interp_dim1 != ngrid) throw std::runtime_error("interpolator of " + kv.first + " does not have one row per grid location");
-                if (kv.second.nderiv != nout || kv.second.nrad != nw * nlos) throw std::runtime_error("derivative memory size mismatch for " + kv.first);
-                HIPC(hipMemcpy(d_fs, m.d_ssa.data(), nloc_w * 8, hipMemcpyHostToDevice));
-                HIPC(hipMemcpy(d_fk, m.d_extinction.data(), nloc_w * 8, hipMemcpyHostToDevice));
-                double* d_dst = (double*)C.get("wf_user", size_t(nout) * nt * 8);
-                if (!m.interpolator && !m.log_radiance_space) {
-                    hipLaunchKernelGGL(kern_map_wf, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_dst, ngrid, nw, nlos);
-                } else {
-                    double* d_interp = nullptr;
-                    if (m.interpolator) {
-                        d_interp = (double*)C.get("interpolator", size_t(ngrid) * nout * 8);
-                        HIPC(hipMemcpy(d_interp, m.interpolator, size_t(ngrid) * nout * 8, hipMemcpyHostToDevice));
-                    }
-                    hipLaunchKernelGGL(kern_map_wf_interp, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_interp, d_rad,
-                                       m.log_radiance_space, d_dst, ngrid, nout, nw, nlos);
-                }
-                HIPC(hipGetLastError());
-                HIPC(hipMemcpy(kv.second.mem, d_dst, size_t(nout) * nt * 8, hipMemcpyDeviceToHost));  // C order [nderiv][wavel][los]
-            }
-            if (!out->surface_derivs.empty()) {
-                std::vector<double> wa(nt);
-                HIPC(hipMemcpy(wa.data(), d_wa, nt * 8, hipMemcpyDeviceToHost));
-                for (auto& kv : out->surface_derivs) {
-                    auto it = su.maps.find(kv.first);
-                    if (it == su.maps.end()) throw std::runtime_error("no surface derivative mapping named " + kv.first);
-                    const SurfaceDerivativeMapping& m = *it->second;
-                    for (int w = 0; w < nw; ++w)
-                        for (int l = 0; l < nlos; ++l) kv.second.mem[size_t(w) * nlos + l] = wa[size_t(w) * nlos + l] * m.d_brdf[w];
-                }
-            }
+            map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, 1);
         }
         return 0;
     } catch (const std::exception& ex) {

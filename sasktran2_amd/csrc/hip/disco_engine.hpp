@@ -33,12 +33,15 @@ class DeviceEngine {
     // solve_device calls, or null (sk_atmosphere_apply_delta_m_scaling, cpp/lib/atmosphere/atmosphere.cpp:73-200)
     void set_delta_m_fraction(const double* d_f);
 
-    // Polarised path (NSTOKES = 3; also NSTOKES = 1 with a stream count the matrix-core path does not cover): radiances only.
+    // Polarised path (NSTOKES = 3; also NSTOKES = 1 with a stream count the matrix-core path does not cover).
     // d_leg: [nwavel][ngrid][nleg][4] (a1, a2, a3, b1) for NSTOKES = 3; d_radiance: [nwavel][nlos][nstokes].
     bool vector_mode() const { return vector_mode_; }
     int nstokes() const;
+    bool plane_parallel() const;
+    // With derivs (spherical post-processing only): wf_ext / wf_ssa [ngrid][nwavel][nlos][nstokes], wf_alb [nwavel][nlos][nstokes].
     void solve_device_vector(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg, const double* d_albedo,
-                             const double* d_irradiance, double* d_radiance, double* d_los_od, int* d_status, void* stream);
+                             const double* d_irradiance, int derivs, double* d_radiance, double* d_wf_ext, double* d_wf_ssa, double* d_wf_alb,
+                             double* d_los_od, int* d_status, void* stream);
     size_t bytes_per_wavelength() const;
     size_t scratch_bytes() const;   // scratch currently allocated (all slots)
     int last_chunk() const;         // wavelengths per launch of the last solve
@@ -51,7 +54,7 @@ class DeviceEngine {
   private:
     void ensure_scratch(int nw, int nslots);
     void init_vector(const skgeo::DiscoGeometry& dg);
-    void ensure_vector_scratch(int nw);
+    void ensure_vector_scratch(int nw, bool derivs);
     void destroy_vector();
     Impl* impl_;
     VecImpl* vec_ = nullptr;

@@ -50,7 +50,12 @@ def run_product(s, derivatives=True, engine=None):
     atmosphere.surface.albedo[:] = s["albedo"]
     res = engine.calculate_radiance(atmosphere, as_dataset=False)
     if s["config"].get("nstokes", 1) == 3:
-        return {"radiance": res["radiance"], "los_optical_depth": res["los_optical_depth"]}
+        out = {"radiance": res["radiance"], "los_optical_depth": res["los_optical_depth"]}
+        if derivatives:   # [wavel, los, stokes, altitude] as the oracle front end returns them
+            out["d_extinction"] = np.transpose(res["wf_extinction"], (1, 2, 3, 0))
+            out["d_ssa"] = np.transpose(res["wf_ssa"], (1, 2, 3, 0))
+            out["d_albedo"] = res["wf_albedo"]
+        return out
     out = {"radiance": res["radiance"][:, :, 0], "los_optical_depth": res["los_optical_depth"]}
     if derivatives:
         out["d_extinction"] = np.transpose(res["wf_extinction"][:, :, :, 0], (1, 2, 0))
