@@ -1024,8 +1024,8 @@ SKD_HD double* vops_at(const VBufs& v, const Geo& g, int p, int w) {
 }
 
 // KV2C: adjoint operators of one layer                        (task = wavelength x layer, one team)
-//   ws: 2n NL + 4 n doubles of team-shared work space (F, temporaries)
-SKD_HD size_t kv2c_scratch(int n, int NL) { return 2 * size_t(n) * NL + 4 * size_t(n); }
+//   ws: 2n NL + 4 n + 5 NL n doubles of team-shared work space (F, temporaries, partial sums of the HD rows)
+SKD_HD size_t kv2c_scratch(int n, int NL) { return 2 * size_t(n) * NL + 4 * size_t(n) + 5 * size_t(NL) * n; }
 
 SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws) {
     const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
@@ -1038,17 +1038,20 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
     const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w];
     const bool last = (p == nlyr - 1);
     const double rho = (m == 0) ? b.albedo[w] : 0.0;
-    double *F = ws, *tmp = ws + M2 * NL, *ipbv = tmp + M2;   // F [2n][NL], tmp [2n], ipbv [n]
+    double *F = ws, *tmp = ws + M2 * NL, *ipbv = tmp + M2, *part = ipbv + 2 * n;   // F [2n][NL], tmp [2n], ipbv [n], part [K][5][NL]
     (void)s;
-    // ---- F = [UL; UM] and the direct-dependence rows HD: one Legendre order per lane
-    SKV_PAR(l, nstr) {
+    // ---- F = [UL; UM] and the direct-dependence rows HD: a lane takes one Legendre order and one of K slices of the solutions
+    const int K = (team.width / nstr) < 1 ? 1 : ((team.width / nstr) > n ? n : (team.width / nstr)), per_k = (n + K - 1) / K;
+    SKV_PAR(item, nstr * K) {
+        const int l = item % nstr, kslice = item / nstr;
+        const int a_lo = kslice * per_k, a_hi = (a_lo + per_k < n) ? a_lo + per_k : n;
         double hd[4][3], val[3] = {0, 0, 0};
         for (int t = 0; t < 4; ++t)
             for (int cc = 0; cc < 3; ++cc) hd[t][cc] = 0;
         double c4[4];
         load_coef(b, v, nstr, p, l, w, c4);
         const double sg = ((l - m) & 1) ? -1.0 : 1.0;
-        for (int a_ = 0; a_ < n; ++a_) {
+        for (int a_ = a_lo; a_ < a_hi; ++a_) {
             double yp[3] = {0, 0, 0}, ym[3] = {0, 0, 0}, dyp[3] = {0, 0, 0}, dym[3] = {0, 0, 0};
             if (l >= m) {
                 double tP[3] = {0, 0, 0}, tM[3] = {0, 0, 0}, dtP[3] = {0, 0, 0}, dtM[3] = {0, 0, 0};
@@ -1101,10 +1104,20 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
             }
         }
         for (int cc = 0; cc < C; ++cc) {
-            for (int t = 0; t < 4; ++t) hd[t][cc] /= om;
-            hd[skd::TH_OM][cc] -= val[cc] / (om * om);
-            for (int t = 0; t < 4; ++t) o[O.HD() + t * NL + l * C + cc] = hd[t][cc];
+            for (int t = 0; t < 4; ++t) part[(kslice * 5 + t) * NL + l * C + cc] = hd[t][cc];
+            part[(kslice * 5 + 4) * NL + l * C + cc] = val[cc];
         }
+    }
+    team.sync();
+    SKV_PAR(lam_, NL) {
+        double hd[4] = {0, 0, 0, 0}, val = 0;
+        for (int k = 0; k < K; ++k) {
+            for (int t = 0; t < 4; ++t) hd[t] += part[(k * 5 + t) * NL + lam_];
+            val += part[(k * 5 + 4) * NL + lam_];
+        }
+        for (int t = 0; t < 4; ++t) hd[t] /= om;
+        hd[skd::TH_OM] -= val / (om * om);
+        for (int t = 0; t < 4; ++t) o[O.HD() + t * NL + lam_] = hd[t];
     }
     team.sync();
     // ---- FP = Dinv^T F
@@ -1215,8 +1228,8 @@ SKD_HD void kv2b_adjoint(const Geo& g, const VGeo& vg, const Bufs& b, const VBuf
         for (int l = 0; l < NL; ++l) v.qlbuf[(size_t(p) * NL + l) * nt + tid] = ql[l];
         for (int i = 0; i < M2; ++i) {
             double t = (p == nlyr - 1) ? gw * ops[O.UG() + i] : 0.0;
-            for (int l = m * C; l < NL; ++l) t += ops[O.FP() + i * NL + l] * ql[l];
-            for (int cidx = 0; cidx < n; ++cidx) t += ops[O.SP() + i * n + cidx] * carry[cidx];
+            t += sum4(m * C, NL, [&](int l) { return ops[O.FP() + i * NL + l] * ql[l]; });
+            t += sum4(0, n, [&](int cidx) { return ops[O.SP() + i * n + cidx] * carry[cidx]; });
             y[i] = t;
         }
         for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
@@ -1228,8 +1241,7 @@ SKD_HD void kv2b_adjoint(const Geo& g, const VGeo& vg, const Bufs& b, const VBuf
         const double* ops = vops_at(v, g, p, w);
         for (int i = 0; i < M2; ++i) {
             double t = v.z[(size_t(p) * M2 + i) * nt + tid];
-            if (p < nlyr - 1)
-                for (int cidx = 0; cidx < n; ++cidx) t -= ops[O.BP() + i * n + cidx] * carry[cidx];
+            if (p < nlyr - 1) t -= sum4(0, n, [&](int cidx) { return ops[O.BP() + i * n + cidx] * carry[cidx]; });
             y[i] = t;
         }
         for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt + tid] = y[i];

@@ -1,4 +1,5 @@
 """Throughput of the polarised (NSTOKES = 3) path on one GPU: limb geometry of BASELINE configs[3] at a few sizes."""
+import os
 import sys
 import time
 
@@ -15,14 +16,15 @@ if os.environ.get('VEC_CASES'):
 for nstr, nlyr, nw in cases:
     s = sc.to_vector(sc.limb_c2(num_wavelengths=nw, nlyr=nlyr, nstr=nstr), rayleigh_fraction=0.6)
     eng = build_engine(s)
-    run_product(s, derivatives=False, engine=eng)
+    DER = bool(int(os.environ.get('VEC_DERIVS', '0')))
+    run_product(s, derivatives=DER, engine=eng)
     t = time.time()
-    out = run_product(s, derivatives=False, engine=eng)
+    out = run_product(s, derivatives=DER, engine=eng)
     dt = time.time() - t
     from sasktran2_amd.device import DeviceSolver
     ds = DeviceSolver(eng[0])
     ds.set_profiling(True)
-    run_product(s, derivatives=False, engine=eng)
+    run_product(s, derivatives=DER, engine=eng)
     kt = ds.kernel_times()
     ds.set_profiling(False)
     print("   kernels (ms):", {k: round(v[0], 1) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}, flush=True)
