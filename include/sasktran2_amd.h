@@ -6,11 +6,11 @@
  * Each declaration cites the reference header line it replaces (paths relative to /root/reference).
  *
  * Return codes (cpp/c_api/engine.cpp:52-85,116-138): 0 success, -1 null/invalid handle, -2 unsupported mode
- * (NSTOKES other than 1 / 3, weighting functions with NSTOKES = 3, non-DISCO sources, refraction, scattering-group derivatives), -3 runtime failure (message on stderr).
+ * (NSTOKES other than 1 / 3, plane-parallel weighting functions with NSTOKES = 3, non-DISCO sources, refraction, scattering-group derivatives), -3 runtime failure (message on stderr).
  * No exception crosses the ABI.  All numeric arrays are caller-owned; the library only reads/writes them
  * during calls (cpp/include/sasktran2/atmosphere/grid_storage.h:77-102).
  *
- * Scope of this build: NSTOKES = 1 (radiances + weighting functions) and NSTOKES = 3 (radiances; standard Stokes basis),
+ * Scope of this build: NSTOKES = 1 and NSTOKES = 3 (radiances + weighting functions; standard / solar / observer Stokes basis),
  * multiple_scatter_source = discrete_ordinates (0), single_scatter_source in
  * {discrete_ordinates (2), none (3)}, Geometry1D in spherical, pseudo-spherical or plane-parallel form with linear
  * interpolation, Lambertian surface, delta-M scaling, derivative mappings with d_extinction / d_ssa (optionally with an
