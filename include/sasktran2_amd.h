@@ -6,7 +6,7 @@
  * Each declaration cites the reference header line it replaces (paths relative to /root/reference).
  *
  * Return codes (cpp/c_api/engine.cpp:52-85,116-138): 0 success, -1 null/invalid handle, -2 unsupported mode
- * (NSTOKES other than 1 / 3, plane-parallel weighting functions with NSTOKES = 3, non-DISCO sources, refraction, scattering-group derivatives), -3 runtime failure (message on stderr).
+ * (NSTOKES other than 1 / 3, non-DISCO sources, refraction, scattering-group derivatives), -3 runtime failure (message on stderr).
  * No exception crosses the ABI.  All numeric arrays are caller-owned; the library only reads/writes them
  * during calls (cpp/include/sasktran2/atmosphere/grid_storage.h:77-102).
  *

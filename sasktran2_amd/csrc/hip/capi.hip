@@ -419,18 +419,13 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
     }
 }
 
-// NSTOKES = 3 (and NSTOKES = 1 stream counts outside the matrix-core path): radiances [wavel][los][stokes], LOS optical depths and,
-// with the spherical post-processing, weighting functions [nderiv][wavel][los][stokes]; plane-parallel weighting functions of this
-// path are not built, a request for them is answered with -2.
+// NSTOKES = 3 (and NSTOKES = 1 stream counts outside the matrix-core path): radiances [wavel][los][stokes], LOS optical depths and
+// weighting functions [nderiv][wavel][los][stokes].
 static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     const AtmosphereStorage& st = *atm->storage;
     const Surface& su = *atm->surface;
     const int S = e->config.num_stokes;
     const int derivs = atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty());
-    if (derivs && e->dev->plane_parallel()) {
-        set_error("sk_engine_calculate_radiance: weighting functions of the NSTOKES = 3 / run-time-n path need a spherical geometry");
-        return -2;
-    }
     if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
     const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
     if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");

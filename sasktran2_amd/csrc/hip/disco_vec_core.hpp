@@ -897,108 +897,6 @@ SKD_HD void kv4_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v,
 }
 
 // =================================================================================================
-// KVPP: plane-parallel line of sight for azimuth order m, 3 Stokes components      (task = wavelength x LOS)
-//   reference: OpticalLayer::integrate_source sktran_do_opticallayer.cpp:93-555, computeReflectedIntensities
-//   sktran_do_layerarray.cpp:5-288, DOSourcePlaneParallelPostProcessing::calculate do_source_planeparallel.cpp:60-218
-//   scratch: 7 n doubles per thread
-// =================================================================================================
-SKD_HD size_t kvpp_scratch(int n) { return 7 * size_t(n); }
-
-SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int los, int w, Scr scr) {
-    const int N = g.N, S = v.S, n = v.n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr;
-    const VRec R(n);
-    const size_t tid = size_t(w) * g.nlos + los;
-    const double mu = g.pp_mu[los];
-    const Fun3 fl = fun_los(g, vg, m, los);
-    const double* lpc = g.lpcsz + (size_t(s) * nstr + m) * nstr;
-    const int first = g.pp_first[los];
-    const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * kPi);
-    Scr yp = scr.sub(0), ym = scr.sub(3 * size_t(n)), lrow = scr.sub(6 * size_t(n));  // yp/ym: [S][n]
-    double att = 1.0;  // attenuation to the observer
-    double total[3] = {0, 0, 0};
-    for (int p = first; p < nlyr; ++p) {
-        const double lf = (p == first) ? g.pp_lf[los] : 1.0;
-        const double* c = vrec_at(v, nlyr, p, w);
-        const double* xs = vxsol_at(v, nlyr, p, w);
-        const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
-        const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
-        // Y+-[s][a] = sum_r lp[s][r] W+-(r,a) + lm[s][r] W-+(r,a);  lm = (om w_j / 2) [Pi(out) B Pi(mu_j)], lp the negated product
-        for (int e = 0; e < S * n; ++e) { yp[e] = 0; ym[e] = 0; }
-        double Q[3] = {0, 0, 0};
-        for (int l = m; l < nstr; ++l) {
-            double c4[4];
-            load_coef(b, v, nstr, p, l, w, c4);
-            const double sg = ((l - m) & 1) ? -1.0 : 1.0;
-            for (int s1 = 0; s1 < S; ++s1) {
-                // row s1 of Pi_l(out) B_l  (B_l symmetric: the row is B_l applied to row s1 of Pi_l(out))
-                double ex[3] = {0, 0, 0}, prow[3], brow[3];
-                ex[s1] = 1;
-                pi_apply(fl.P[l], fl.R[l], fl.T[l], ex, prow);  // Pi symmetric: row s1 = column s1
-                greek_apply(c4, prow, brow);
-                // lm row over r = (j, s2):  (brow . Pi_l(mu_j)[:, s2]) ;  lp row: ((brow D) . Pi_l(mu_j)[:, s2]) (-1)^(l-m)
-                for (int j = 0; j < N; ++j) {
-                    const Fun3 fj = fun_mu(g, vg, m, j);
-                    const double wj = 0.5 * om * g.wt[j];
-                    if (S == 1) {
-                        const double t = brow[0] * fj.P[l] * wj;
-                        lrow[j] = t;
-                        lrow[n + j] = sg * t;
-                    } else {
-                        double y0[3], y1[3];
-                        const double bd[3] = {brow[0], brow[1], -brow[2]};
-                        pi_apply(fj.P[l], fj.R[l], fj.T[l], brow, y0);
-                        pi_apply(fj.P[l], fj.R[l], fj.T[l], bd, y1);
-                        for (int s2 = 0; s2 < 3; ++s2) {
-                            lrow[j * 3 + s2] = y0[s2] * wj;
-                            lrow[n + j * 3 + s2] = sg * y1[s2] * wj;
-                        }
-                    }
-                }
-                for (int a = 0; a < n; ++a) {
-                    double tp = 0, tm = 0;
-                    for (int r = 0; r < n; ++r) {
-                        const double wp = c[R.WP() + r + n * a], wm = c[R.WM() + r + n * a];
-                        tp += lrow[n + r] * wp + lrow[r] * wm;
-                        tm += lrow[n + r] * wm + lrow[r] * wp;
-                    }
-                    yp[size_t(s1) * n + a] += tp;
-                    ym[size_t(s1) * n + a] += tm;
-                }
-                // solar single-scatter term: first column of the negated product with the sun direction
-                if (g.include_ss) Q[s1] += sg * brow[0] * lpc[l] * fm * om;
-            }
-        }
-        skd::PPBeam Eb;
-        skd::pp_beam_multiplier(mu, lf, th, T, sc, Eb);
-        double Ssrc[3] = {Q[0] * Eb.v, Q[1] * Eb.v, Q[2] * Eb.v};
-        for (int a = 0; a < n; ++a) {
-            skd::PPLosMult pm;
-            skd::pp_los_multipliers(mu, lf, th, T, sc, c[R.K() + a], Eb, pm);
-            const double L = xs[a], Mv = xs[n + a], Ap = c[R.AP() + a], Am = c[R.AM() + a];
-            for (int s1 = 0; s1 < S; ++s1)
-                Ssrc[s1] += yp[size_t(s1) * n + a] * (pm.hp * L + Ap * pm.Dm) + ym[size_t(s1) * n + a] * (pm.hm * Mv + Am * pm.Dp);
-        }
-        for (int s1 = 0; s1 < S; ++s1) total[s1] += att * Ssrc[s1];
-        att *= exp(-th * lf / mu);
-    }
-    if (m == 0) {
-        const double* c = vrec_at(v, nlyr, nlyr - 1, w);
-        const double* xs = vxsol_at(v, nlyr, nlyr - 1, w);
-        const double rho = b.albedo[w];
-        double ipb = 0;
-        for (int i = 0; i < N; ++i) {
-            double val = c[R.G() + 2 * n + i * S];
-            for (int j = 0; j < n; ++j) val += c[R.WP() + i * S + n * j] * c[R.E() + j] * xs[j] + c[R.WM() + i * S + n * j] * xs[n + j];
-            ipb += g.wt[i] * g.mu[i] * val;
-        }
-        const double direct = g.include_ss ? g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w] : 0.0;
-        total[0] += att * rho * (2.0 * ipb + direct);
-    }
-    const double cz = cos(m * g.pp_azi[los]), sz = sin(m * g.pp_azi[los]);
-    for (int s1 = 0; s1 < S; ++s1) v.radiance[tid * S + s1] += total[s1] * (s1 < 2 ? cz : sz);
-}
-
-// =================================================================================================
 // Weighting functions of the polarised path: the adjoint machinery of skd::k2c_layer_ops / skd::K2bTask with N -> n and the
 // Legendre space widened to NL = C nstr numbers per layer, index (l, c), c < C = 3 (1 for NSTOKES = 1): the source of a table
 // point is  J(out)[s] = sum_l [Pi_l(out) v_l][s]  with  v_l = om B_l [ (-1)^(l-m) D tP_l + tM_l ]  linear in (cL, cM) = the layer's
@@ -1041,8 +939,10 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
     double *F = ws, *tmp = ws + M2 * NL, *ipbv = tmp + M2, *part = ipbv + 2 * n;   // F [2n][NL], tmp [2n], ipbv [n], part [K][5][NL]
     (void)s;
     // ---- F = [UL; UM] and the direct-dependence rows HD: a lane takes one Legendre order and one of K slices of the solutions
+    // (plane-parallel post-processing supplies u_p directly: F, FP and HD are not needed)
+    const bool table = !g.pp_mode;
     const int K = (team.width / nstr) < 1 ? 1 : ((team.width / nstr) > n ? n : (team.width / nstr)), per_k = (n + K - 1) / K;
-    SKV_PAR(item, nstr * K) {
+    if (table) SKV_PAR(item, nstr * K) {
         const int l = item % nstr, kslice = item / nstr;
         const int a_lo = kslice * per_k, a_hi = (a_lo + per_k < n) ? a_lo + per_k : n;
         double hd[4][3], val[3] = {0, 0, 0};
@@ -1109,7 +1009,7 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
         }
     }
     team.sync();
-    SKV_PAR(lam_, NL) {
+    if (table) SKV_PAR(lam_, NL) {
         double hd[4] = {0, 0, 0, 0}, val = 0;
         for (int k = 0; k < K; ++k) {
             for (int t = 0; t < 4; ++t) hd[t] += part[(k * 5 + t) * NL + lam_];
@@ -1121,7 +1021,7 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
     }
     team.sync();
     // ---- FP = Dinv^T F
-    SKV_PAR(e, M2 * NL) {
+    if (table) SKV_PAR(e, M2 * NL) {
         const int i = e / NL, lam_ = e % NL;
         o[O.FP() + e] = sum4(0, M2, [&](int j) { return dinv[j * M2 + i] * F[j * NL + lam_]; });
     }
@@ -1189,6 +1089,54 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
     team.sync();
 }
 
+// backward sweep  z_p = y_p - BP zA_{p+1}  and reduced-gradient contraction of one (line of sight, Stokes component); the forward
+// sweep has left y in v.z.  table_weights: the Legendre-space HD term applies (spherical table; false for plane parallel)
+SKD_HD void adjoint_backward_gradient(const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, size_t tid, size_t nt, double gw,
+                                      bool table_weights, Scr y, Scr carry) {
+    const int S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
+    const VOps O(n, NL);
+    // ---- backward sweep  z_p = y_p - BP zA_{p+1}
+    for (int i = 0; i < n; ++i) carry[i] = 0;
+    for (int p = nlyr - 1; p >= 0; --p) {
+        const double* ops = vops_at(v, g, p, w);
+        for (int i = 0; i < M2; ++i) {
+            double t = v.z[(size_t(p) * M2 + i) * nt + tid];
+            if (p < nlyr - 1) t -= sum4(0, n, [&](int cidx) { return ops[O.BP() + i * n + cidx] * carry[cidx]; });
+            y[i] = t;
+        }
+        for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
+        for (int i = 0; i < n; ++i) carry[i] = y[i];
+    }
+    // ---- reduced gradient
+    for (int p = 0; p < nlyr; ++p) {
+        const double* ops = vops_at(v, g, p, w);
+        const bool last = (p == nlyr - 1);
+        double gth[4] = {0, 0, 0, 0};
+        double zBsum = 0;
+        for (int i = 0; i < n; ++i) {
+            const double zA = v.z[(size_t(p) * M2 + i) * nt + tid], zB = v.z[(size_t(p) * M2 + n + i) * nt + tid];
+            const double zAn = last ? 0.0 : v.z[(size_t(p + 1) * M2 + i) * nt + tid];
+            const double zBp = (p > 0) ? v.z[(size_t(p - 1) * M2 + n + i) * nt + tid] : 0.0;
+            if (last && m == 0 && (i % S) == 0) zBsum += zB;
+            for (int t = 0; t < 4; ++t)
+                gth[t] += zA * ops[O.DI() + (t * 4 + 0) * n + i] + zBp * ops[O.DI() + (t * 4 + 1) * n + i] -
+                          zAn * ops[O.DI() + (t * 4 + 2) * n + i] - zB * ops[O.DI() + (t * 4 + 3) * n + i];
+        }
+        if (table_weights)
+            for (int l = m * C; l < NL; ++l) {
+                const double q = v.qlbuf[(size_t(p) * NL + l) * nt + tid];
+                for (int t = 0; t < 4; ++t) gth[t] += ops[O.HD() + t * NL + l] * q;
+            }
+        if (last && m == 0) {
+            for (int t = 0; t < 4; ++t) gth[t] += (zBsum + gw) * ops[O.GD() + t];
+            const double rho = b.albedo[w], ipb = ops[O.IPB()];
+            v.grad[size_t(4 * nlyr) * nt + tid] += gw * 2.0 * ipb + zBsum * (2.0 * ipb + g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w]);
+            v.grad[size_t(4 * nlyr + 1) * nt + tid] += zBsum * g.csz[s] / kPi * rho;
+        }
+        for (int t = 0; t < 4; ++t) v.grad[size_t(t * nlyr + p) * nt + tid] += gth[t];
+    }
+}
+
 // KV2B: adjoint sweep of one (line of sight, Stokes component) for azimuth order m   (task = wavelength x LOS x Stokes)
 //   scratch: NL + 3 n doubles per thread
 SKD_HD size_t kv2b_scratch(int n, int NL) { return size_t(NL) + 3 * size_t(n); }
@@ -1235,44 +1183,185 @@ SKD_HD void kv2b_adjoint(const Geo& g, const VGeo& vg, const Bufs& b, const VBuf
         for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
         for (int i = 0; i < n; ++i) carry[i] = y[n + i];
     }
-    // ---- backward sweep  z_p = y_p - BP zA_{p+1}
-    for (int i = 0; i < n; ++i) carry[i] = 0;
-    for (int p = nlyr - 1; p >= 0; --p) {
-        const double* ops = vops_at(v, g, p, w);
-        for (int i = 0; i < M2; ++i) {
-            double t = v.z[(size_t(p) * M2 + i) * nt + tid];
-            if (p < nlyr - 1) t -= sum4(0, n, [&](int cidx) { return ops[O.BP() + i * n + cidx] * carry[cidx]; });
-            y[i] = t;
-        }
-        for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
-        for (int i = 0; i < n; ++i) carry[i] = y[i];
-    }
-    // ---- reduced gradient
+    adjoint_backward_gradient(g, b, v, s, m, w, tid, nt, gw, true, y, carry);
+}
+
+// =================================================================================================
+// KVPP: plane-parallel line of sight for azimuth order m, 3 Stokes components      (task = wavelength x LOS)
+//   reference: OpticalLayer::integrate_source sktran_do_opticallayer.cpp:93-555, computeReflectedIntensities
+//   sktran_do_layerarray.cpp:5-288, DOSourcePlaneParallelPostProcessing::calculate do_source_planeparallel.cpp:60-218
+//   With v.derivs the same adjoint machinery as the spherical mode runs per Stokes component (u_p = dI/d(L_p, M_p) supplied
+//   directly, as skd::kpp_los): the operators of kv2c_layer_ops must be up to date.   scratch: 21 n doubles per thread
+// =================================================================================================
+SKD_HD size_t kvpp_scratch(int n) { return 21 * size_t(n); }
+
+SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int los, int w, Scr scr) {
+    const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
+    const VRec R(n);
+    const VOps O(n, NL);
+    const size_t tid = size_t(w) * g.nlos + los, nt3 = size_t(nw) * g.nlos * S;
+    const double mu = g.pp_mu[los];
+    const Fun3 fl = fun_los(g, vg, m, los);
+    const double* lpc = g.lpcsz + (size_t(s) * nstr + m) * nstr;
+    const int first = g.pp_first[los];
+    const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * kPi);
+    const bool derivs = v.derivs != 0;
+    Scr yp = scr.sub(0), ym = scr.sub(3 * size_t(n)), dyp = scr.sub(6 * size_t(n)), dym = scr.sub(9 * size_t(n)), lrow = scr.sub(12 * size_t(n)),
+        carry = scr.sub(14 * size_t(n)), u = scr.sub(17 * size_t(n)), yv = scr.sub(19 * size_t(n));  // yp .. dym: [S][n]; carry: [S][n]
+    const double azf[3] = {cos(m * g.pp_azi[los]), cos(m * g.pp_azi[los]), sin(m * g.pp_azi[los])};
+    double att = 1.0;  // attenuation to the observer
+    double total[3] = {0, 0, 0};
+    if (derivs)
+        for (int e = 0; e < S * n; ++e) carry[e] = 0;
     for (int p = 0; p < nlyr; ++p) {
-        const double* ops = vops_at(v, g, p, w);
-        const bool last = (p == nlyr - 1);
-        double gth[4] = {0, 0, 0, 0};
-        double zBsum = 0;
-        for (int i = 0; i < n; ++i) {
-            const double zA = v.z[(size_t(p) * M2 + i) * nt + tid], zB = v.z[(size_t(p) * M2 + n + i) * nt + tid];
-            const double zAn = last ? 0.0 : v.z[(size_t(p + 1) * M2 + i) * nt + tid];
-            const double zBp = (p > 0) ? v.z[(size_t(p - 1) * M2 + n + i) * nt + tid] : 0.0;
-            if (last && m == 0 && (i % S) == 0) zBsum += zB;
-            for (int t = 0; t < 4; ++t)
-                gth[t] += zA * ops[O.DI() + (t * 4 + 0) * n + i] + zBp * ops[O.DI() + (t * 4 + 1) * n + i] -
-                          zAn * ops[O.DI() + (t * 4 + 2) * n + i] - zB * ops[O.DI() + (t * 4 + 3) * n + i];
+        double contrib[3] = {0, 0, 0};
+        const bool in = (p >= first);
+        const double lf = (p == first) ? g.pp_lf[los] : 1.0;
+        const double* c = vrec_at(v, nlyr, p, w);
+        const double* xs = vxsol_at(v, nlyr, p, w);
+        const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
+        const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
+        double Q[3] = {0, 0, 0};
+        skd::PPBeam Eb{0, 0, 0, 0};
+        if (in) {
+            // Y+-[s][a] = sum_r lp[s][r] W+-(r,a) + lm[s][r] W-+(r,a);  lm = (om w_j / 2) [Pi(out) B Pi(mu_j)], lp the negated product
+            for (int e = 0; e < S * n; ++e) { yp[e] = 0; ym[e] = 0; dyp[e] = 0; dym[e] = 0; }
+            for (int l = m; l < nstr; ++l) {
+                double c4[4];
+                load_coef(b, v, nstr, p, l, w, c4);
+                const double sg = ((l - m) & 1) ? -1.0 : 1.0;
+                for (int s1 = 0; s1 < S; ++s1) {
+                    // row s1 of Pi_l(out) B_l  (B_l and Pi_l symmetric)
+                    double ex[3] = {0, 0, 0}, prow[3], brow[3];
+                    ex[s1] = 1;
+                    pi_apply(fl.P[l], fl.R[l], fl.T[l], ex, prow);
+                    greek_apply(c4, prow, brow);
+                    for (int j = 0; j < N; ++j) {
+                        const Fun3 fj = fun_mu(g, vg, m, j);
+                        const double wj = 0.5 * om * g.wt[j];
+                        if (S == 1) {
+                            const double t = brow[0] * fj.P[l] * wj;
+                            lrow[j] = t;
+                            lrow[n + j] = sg * t;
+                        } else {
+                            double y0[3], y1[3];
+                            const double bd[3] = {brow[0], brow[1], -brow[2]};
+                            pi_apply(fj.P[l], fj.R[l], fj.T[l], brow, y0);
+                            pi_apply(fj.P[l], fj.R[l], fj.T[l], bd, y1);
+                            for (int s2 = 0; s2 < 3; ++s2) {
+                                lrow[j * 3 + s2] = y0[s2] * wj;
+                                lrow[n + j * 3 + s2] = sg * y1[s2] * wj;
+                            }
+                        }
+                    }
+                    for (int a = 0; a < n; ++a) {
+                        double tp = 0, tm = 0, dtp = 0, dtm = 0;
+                        for (int r = 0; r < n; ++r) {
+                            const double wp = c[R.WP() + r + n * a], wm = c[R.WM() + r + n * a];
+                            tp += lrow[n + r] * wp + lrow[r] * wm;
+                            tm += lrow[n + r] * wm + lrow[r] * wp;
+                            if (derivs) {
+                                const double dwp = c[R.DWP() + r + n * a], dwm = c[R.DWM() + r + n * a];
+                                dtp += lrow[n + r] * dwp + lrow[r] * dwm;
+                                dtm += lrow[n + r] * dwm + lrow[r] * dwp;
+                            }
+                        }
+                        yp[size_t(s1) * n + a] += tp;
+                        ym[size_t(s1) * n + a] += tm;
+                        dyp[size_t(s1) * n + a] += dtp + tp / om;
+                        dym[size_t(s1) * n + a] += dtm + tm / om;
+                    }
+                    // solar single-scatter term: first column of the negated product with the sun direction
+                    if (g.include_ss) Q[s1] += sg * brow[0] * lpc[l] * fm * om;
+                }
+            }
+            skd::pp_beam_multiplier(mu, lf, th, T, sc, Eb);
         }
-        for (int l = m * C; l < NL; ++l) {
-            const double q = v.qlbuf[(size_t(p) * NL + l) * nt + tid];
-            for (int t = 0; t < 4; ++t) gth[t] += ops[O.HD() + t * NL + l] * q;
+        for (int s1 = 0; s1 < S; ++s1) {
+            const double A = att * azf[s1];
+            double Ssrc = Q[s1] * Eb.v;
+            double dS[4] = {Q[s1] * Eb.d_th, Q[s1] / om * Eb.v, Q[s1] * Eb.d_T, Q[s1] * Eb.d_sec};
+            for (int i = 0; i < M2; ++i) u[i] = 0;
+            if (in)
+                for (int a = 0; a < n; ++a) {
+                    skd::PPLosMult pm;
+                    skd::pp_los_multipliers(mu, lf, th, T, sc, c[R.K() + a], Eb, pm);
+                    const double L = xs[a], Mv = xs[n + a], Ap = c[R.AP() + a], Am = c[R.AM() + a];
+                    const double y_p = yp[size_t(s1) * n + a], y_m = ym[size_t(s1) * n + a];
+                    Ssrc += y_p * (pm.hp * L + Ap * pm.Dm) + y_m * (pm.hm * Mv + Am * pm.Dp);
+                    if (derivs) {
+                        const double dk = c[R.DK() + a], dAp = c[R.DAP() + a], dAm = c[R.DAM() + a];
+                        dS[skd::TH_TAU] += y_p * L * pm.hp_th + y_m * Mv * pm.hm_th + Ap * y_p * pm.Dm_th + Am * y_m * pm.Dp_th;
+                        dS[skd::TH_T] += Ap * y_p * pm.Dm_T + Am * y_m * pm.Dp_T;
+                        dS[skd::TH_SEC] += Ap * y_p * pm.Dm_sec + Am * y_m * pm.Dp_sec;
+                        dS[skd::TH_OM] += dyp[size_t(s1) * n + a] * (pm.hp * L + Ap * pm.Dm) + dym[size_t(s1) * n + a] * (pm.hm * Mv + Am * pm.Dp) +
+                                          y_p * (pm.hp_k * dk * L + dAp * pm.Dm + Ap * pm.Dm_k * dk) +
+                                          y_m * (pm.hm_k * dk * Mv + dAm * pm.Dp + Am * pm.Dp_k * dk);
+                        u[a] = A * y_p * pm.hp;
+                        u[n + a] = A * y_m * pm.hm;
+                    }
+                }
+            contrib[s1] = in ? A * Ssrc : 0.0;
+            total[s1] += contrib[s1];
+            if (derivs) {
+                const size_t t3 = tid * S + s1;
+                if (in)
+                    for (int t = 0; t < 4; ++t) v.grad[size_t(t * nlyr + p) * nt3 + t3] += A * dS[t];
+                v.qlbuf[(size_t(p) * NL) * nt3 + t3] = contrib[s1];
+                // forward substitution of A^T z = u:  y_p = Dinv^T u_p + SP yB_{p-1}
+                const double* dinv = vdinv_at(v, nlyr, p, w);
+                const double* ops = vops_at(v, g, p, w);
+                for (int i = 0; i < M2; ++i) {
+                    double acc = 0;
+                    for (int j = 0; j < M2; ++j) acc += dinv[size_t(j) * M2 + i] * u[j];
+                    for (int cidx = 0; cidx < n; ++cidx) acc += ops[O.SP() + i * n + cidx] * carry[size_t(s1) * n + cidx];
+                    yv[i] = acc;
+                }
+                for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt3 + t3] = yv[i];
+                if (p < nlyr - 1)
+                    for (int i = 0; i < n; ++i) carry[size_t(s1) * n + i] = yv[n + i];
+            }
         }
-        if (last && m == 0) {
-            for (int t = 0; t < 4; ++t) gth[t] += (zBsum + gw) * ops[O.GD() + t];
-            const double rho = b.albedo[w], ipb = ops[O.IPB()];
-            v.grad[size_t(4 * nlyr) * nt + tid] += gw * 2.0 * ipb + zBsum * (2.0 * ipb + g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w]);
-            v.grad[size_t(4 * nlyr + 1) * nt + tid] += zBsum * g.csz[s] / kPi * rho;
+        if (in) att *= exp(-th * lf / mu);
+    }
+    // Lambertian ground seen through the whole column (order 0, intensity only)
+    double ground = 0, gw = 0;
+    if (m == 0) {
+        const double* c = vrec_at(v, nlyr, nlyr - 1, w);
+        const double* xs = vxsol_at(v, nlyr, nlyr - 1, w);
+        const double rho = b.albedo[w];
+        double ipb = 0;
+        for (int i = 0; i < N; ++i) {
+            double val = c[R.G() + 2 * n + i * S];
+            for (int j = 0; j < n; ++j) val += c[R.WP() + i * S + n * j] * c[R.E() + j] * xs[j] + c[R.WM() + i * S + n * j] * xs[n + j];
+            ipb += g.wt[i] * g.mu[i] * val;
         }
-        for (int t = 0; t < 4; ++t) v.grad[size_t(t * nlyr + p) * nt + tid] += gth[t];
+        const double direct = g.include_ss ? g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w] : 0.0;
+        const double A = att * azf[0];
+        ground = A * rho * (2.0 * ipb + direct);
+        total[0] += ground;
+        if (derivs) {
+            gw = A;
+            const size_t t3 = tid * S;
+            const double* ops = vops_at(v, g, nlyr - 1, w);
+            for (int i = 0; i < M2; ++i) v.z[(size_t(nlyr - 1) * M2 + i) * nt3 + t3] += gw * ops[O.UG() + i];
+            // direct-beam part of the reflected intensity (the diffuse part goes through gw in the gradient contraction)
+            v.grad[size_t(4 * nlyr) * nt3 + t3] += A * direct;
+            v.grad[size_t(4 * nlyr + 1) * nt3 + t3] += g.include_ss ? A * rho * g.csz[s] / kPi : 0.0;
+        }
+    }
+    for (int s1 = 0; s1 < S; ++s1) v.radiance[tid * S + s1] += total[s1];
+    if (!derivs) return;
+    for (int s1 = 0; s1 < S; ++s1) {
+        const size_t t3 = tid * S + s1;
+        // attenuation of everything below a layer: dI/dtau_q = -(lf_q / mu) * (radiance entering the layer from below)
+        double below = (s1 == 0) ? ground : 0.0;
+        for (int p = nlyr - 1; p >= first; --p) {
+            const double lf = (p == first) ? g.pp_lf[los] : 1.0;
+            v.grad[size_t(skd::TH_TAU * nlyr + p) * nt3 + t3] -= lf / mu * below;
+            below += v.qlbuf[(size_t(p) * NL) * nt3 + t3];
+        }
+        adjoint_backward_gradient(g, b, v, s, m, w, t3, nt3, (s1 == 0) ? gw : 0.0, false, yv, carry.sub(size_t(s1) * n));
     }
 }
 

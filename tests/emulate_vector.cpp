@@ -73,7 +73,6 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
         xsol(size_t(nlyr) * 2 * n * nw), J(size_t(nstr) * std::max(t.nslot, 1) * nw * S, 0.0), rad(nt * S, 0.0);
     const int NL = skv::legendre_space(g, S), ngrid = t.ngrid;
     const size_t nt3 = nt * S;
-    if (derivatives && g.pp_mode) return -2;  // weighting functions of the polarised path: spherical post-processing only
     std::vector<double> scratch(std::max({skv::kv1_scratch(n), skv::kv2_scratch(n), skv::kv3_scratch(n, nstr), skv::kvpp_scratch(n),
                                           skv::kv2c_scratch(n, NL), skv::kv2b_scratch(n, NL)}));
     std::vector<double> ops(derivatives ? size_t(nlyr) * skv::VOps(n, NL).size() * nw : 1), zb(derivatives ? size_t(nlyr) * 2 * n * nt3 : 1),
@@ -94,10 +93,22 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
         for (int w = 0; w < nw; ++w) skd::k0_transmission(g, b, 0, w);
         for (int m = 0; m < nstr; ++m) {
             for (int w = 0; w < nw; ++w)
-                for (int p = 0; p < nlyr; ++p) skv::kv1_layer_solution(team, g, vg, b, v, 0, m, p, w, ws);
+                for (int p = 0; p < nlyr; ++p) skv::kv1_layer_solution(team, g, vg, b, v, 0, m, p, w, ws, derivatives != 0);
             for (int w = 0; w < nw; ++w) skv::kv2_bvp(team, g, b, v, 0, m, w, ws, ws + skv::kv2_scratch_main(n));
+            if (derivatives)
+                for (int w = 0; w < nw; ++w)
+                    for (int p = 0; p < nlyr; ++p) skv::kv2c_layer_ops(team, g, vg, b, v, 0, m, p, w, ws);
             for (int w = 0; w < nw; ++w)
                 for (int l = 0; l < nlos; ++l) skv::kvpp_los(g, vg, b, v, 0, m, l, w, scr);
+        }
+        if (derivatives) {
+            skd::Geo g3 = g;
+            g3.nlos = nlos * S;
+            skd::Bufs b3 = b;
+            b3.grad = grad.data();
+            b3.dnat = dnat.data();
+            for (int w = 0; w < nw; ++w)
+                for (int l3 = 0; l3 < nlos * S; ++l3) skd::k4a_chain(g3, b3, 0, l3, w);
         }
     } else {
         for (int s = 0; s < g.nsza; ++s) {

@@ -445,11 +445,15 @@ def test_vector_weighting_functions_in_solar_basis_on_device():
     _assert_vector_wf_parity(run_product(s, derivatives=True), run_oracle(s, derivatives=True))
 
 
-def test_vector_planeparallel_weighting_functions_are_refused():
-    case = _GOLDEN_VEC["cases"][1]
+def test_vector_planeparallel_weighting_functions_on_device():
+    case = dict(_GOLDEN_VEC["cases"][1], nstr=8, layers=[[0.3, 0.95], [0.3, 0.9], [0.4, 0.973527]])
     s = sc.planeparallel_vector_case(case, _GOLDEN_VEC["siewert_greek_coefficients"])
-    with pytest.raises(RuntimeError, match="-2"):
-        run_product(s, derivatives=True)
+    s["albedo"][:] = 0.3
+    got = run_product(s, derivatives=True)
+    ref = run_oracle(s, derivatives=True)
+    np.testing.assert_allclose(got["radiance"], ref["radiance"], rtol=1e-6, atol=1e-12)
+    # the top grid point of the 'lower' interpolation carries no layer: zero weighting functions on both sides
+    _assert_vector_wf_parity(got, ref)
 
 
 def test_scalar_12_streams_weighting_functions_through_the_runtime_n_path():

@@ -61,3 +61,25 @@ def test_stokes_basis_rotation(basis):
     np.testing.assert_allclose(rot[..., 1] ** 2 + rot[..., 2] ** 2, std[..., 1] ** 2 + std[..., 2] ** 2, rtol=1e-12)
     assert np.abs(rot[..., 1:] - std[..., 1:]).max() > 1e-6   # the bases differ for these rays
     np.testing.assert_allclose(rot, run_oracle(s)["radiance"], rtol=1e-6, atol=1e-12)
+
+
+def _wf_close(got, ref, tol=1e-9):
+    for k in ("d_extinction", "d_ssa", "d_albedo"):
+        scale = np.abs(ref[k]).max()
+        assert np.max(np.abs(got[k] - ref[k])) <= tol * (scale if scale > 0 else 1.0), k
+
+
+def test_vector_weighting_functions_match_oracle_spherical_and_planeparallel():
+    """Adjoint weighting functions of I, Q and U (one sweep per line of sight and Stokes component) against the oracle's dense
+    forward-mode linearization, which itself matches finite differences (tests/test_oracle_golden.py)."""
+    s = sc.to_vector(sc.regression_1d(2), rayleigh_fraction=0.9)
+    _wf_close(run_emulated_vector(s, derivatives=True), run_oracle(s, derivatives=True))
+    case = dict(GOLDEN_VEC["cases"][1], nstr=8, layers=[[0.3, 0.95], [0.3, 0.9], [0.4, 0.973527]])
+    s = sc.planeparallel_vector_case(case, GOLDEN_VEC["siewert_greek_coefficients"])
+    s["albedo"][:] = 0.3
+    _wf_close(run_emulated_vector(s, derivatives=True), run_oracle(s, derivatives=True))
+
+
+def test_scalar_weighting_functions_through_the_runtime_n_bodies():
+    s = sc.regression_1d(2)
+    _wf_close(run_emulated_vector(s, derivatives=True), run_oracle(s, derivatives=True))
