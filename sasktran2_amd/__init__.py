@@ -264,7 +264,7 @@ class Engine:
         # delta-M scaling rewrites the storage in place (src/sasktran2/atmosphere.py:845-854 applies it with order = num_streams
         # when more moments than streams are stored): work on copies so that the caller's arrays keep the unscaled properties
         delta_order = None
-        if self._config.delta_m_scaling and S == 1 and leg.shape[0] > self._config.num_streams:
+        if self._config.delta_m_scaling and leg.shape[0] // per > self._config.num_streams:
             delta_order = int(self._config.num_streams)
             ext, ssa, leg = ext.copy(order="F"), ssa.copy(order="F"), leg.copy(order="F")
         irr, alb = np.ascontiguousarray(st.solar_irradiance), np.ascontiguousarray(atmosphere.surface.albedo, dtype=float)

@@ -176,8 +176,9 @@ def delta_m_scaled(s: dict, order: int | None = None):
     (k*, w*) back to the unscaled inputs: dI/dk = dI/dk* (1 - w f) ; dI/dw = dI/dw* (1 - f (1 - w*)) / (1 - w f) - dI/dk* k f."""
     order = s["config"]["nstr"] if order is None else order
     k, w, leg = s["extinction"], s["ssa"], s["leg"]
-    assert leg.shape[0] > order
-    f = leg[order] / (2 * order + 1)
+    stack = 4 if s["config"].get("nstokes", 1) == 3 else 1   # NSTOKES = 3: f from a1, all four Greek coefficients scaled
+    assert leg.shape[0] // stack > order
+    f = leg[order * stack] / (2 * order + 1)
     ks = k * (1 - w * f)
     ws = (1 - f) / (1 - w * f) * w
     out = dict(s)

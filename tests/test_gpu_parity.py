@@ -480,3 +480,22 @@ def test_vector_stokes_basis_on_device(basis):
     np.testing.assert_allclose(out[..., 0], std[..., 0], rtol=1e-14)
     np.testing.assert_allclose(out[..., 1] ** 2 + out[..., 2] ** 2, std[..., 1] ** 2 + std[..., 2] ** 2, rtol=1e-12)
     np.testing.assert_allclose(out, run_oracle(s)["radiance"], rtol=1e-6, atol=1e-12)
+
+
+def test_vector_delta_m_scaling_on_device():
+    """delta-M for NSTOKES = 3 (atmosphere.cpp:80-140: f from a1 of the truncation order, all four Greek coefficients scaled; the DO layer
+    optics subtract (2l + 1) f / (1 - f) from a1, a2, a3 only, sktran_do_layerarray.cpp:405-418)."""
+    from tests.test_oracle_golden import make_oracle
+    base = _peaked_limb(nw=2, nstr=8, nmom=24, g=0.8)
+    s = sc.to_vector(base, rayleigh_fraction=0.5)
+    d = sc.delta_m_scaled(s)
+    o = make_oracle(d).run(d["extinction"], d["ssa"], d["leg"], d["albedo"], derivatives=True, delta_f=d["delta_f"])
+    got = _run_product_delta_m(s)
+    np.testing.assert_allclose(got["radiance"][..., 0], o["radiance"][..., 0], rtol=RTOL_I)
+    assert np.max(np.abs(got["radiance"] - o["radiance"])) < 1e-9 * np.abs(o["radiance"]).max()
+    u = d["unscale"]
+    want_k = o["d_extinction"] * u["dk_dk"].T[:, None, None, :]
+    want_w = o["d_ssa"] * u["dw_dw"].T[:, None, None, :] + o["d_extinction"] * u["dk_dw"].T[:, None, None, :]
+    for name, want in (("d_extinction", want_k), ("d_ssa", want_w)):
+        scale = np.abs(want).max(axis=3, keepdims=True)
+        assert np.max(np.abs(got[name] - want) / np.where(scale > 0, scale, 1.0)) < RTOL_WF, name
