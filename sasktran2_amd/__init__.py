@@ -270,7 +270,7 @@ class Engine:
         irr, alb = np.ascontiguousarray(st.solar_irradiance), np.ascontiguousarray(atmosphere.surface.albedo, dtype=float)
         emis = np.ascontiguousarray(atmosphere.surface.emission)
         derivs = atmosphere.calculate_derivatives
-        h_st = L.sk_atmosphere_storage_create(ngrid, nw, leg.shape[0] // per, S, _p(ssa), _p(ext), _p(em), _p(leg), _p(irr))
+        h_st = L.sk_atmosphere_storage_create(ngrid, nw, leg.shape[0], S, _p(ssa), _p(ext), _p(em), _p(leg), _p(irr))
         h_brdf = L.sk_brdf_create_lambertian(S)
         h_su = L.sk_surface_create(nw, S, _p(emis))
         L.sk_surface_set_brdf(h_su, h_brdf, _p(alb))

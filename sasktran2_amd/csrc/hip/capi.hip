@@ -429,11 +429,15 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
     const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
     if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");
+    // st.nleg is the first dimension of leg_coeff as the caller passes it (nphase_moments, cpp/c_api/atmosphere.cpp:18-19): for
+    // NSTOKES = 3 that is 4 numbers (a1, a2, a3, b1) per Legendre order
     const size_t nloc_w = size_t(ngrid) * nw, nt = size_t(nw) * nlos, per = (S == 3) ? 4 : 1;
+    if (st.nleg % int(per) != 0) throw std::runtime_error("leg_coeff must hold four coefficients per Legendre order for NSTOKES = 3");
+    const int norder = st.nleg / int(per);
     DeviceCache& C = e->cache;
     double* d_ext = (double*)C.get("ext", nloc_w * 8);
     double* d_ssa = (double*)C.get("ssa", nloc_w * 8);
-    double* d_leg = (double*)C.get("leg", nloc_w * st.nleg * per * 8);
+    double* d_leg = (double*)C.get("leg", nloc_w * st.nleg * 8);
     double* d_alb = (double*)C.get("albedo", size_t(nw) * 8);
     double* d_rad = (double*)C.get("radiance", nt * S * 8);
     double* d_od = (double*)C.get("los_od", nt * 8);
@@ -442,7 +446,7 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     double *d_irr = nullptr, *d_we = nullptr, *d_ws = nullptr, *d_wa = nullptr;
     HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * per * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyHostToDevice));
     if (st.irradiance) {
         d_irr = (double*)C.get("irradiance", size_t(nw) * 8);
@@ -459,7 +463,7 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
         HIPC(hipMemcpy(d_f, st.delta_f.data(), nloc_w * 8, hipMemcpyHostToDevice));
     }
     e->dev->set_delta_m_fraction(d_f);
-    e->dev->solve_device_vector(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status, nullptr);
+    e->dev->solve_device_vector(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status, nullptr);
     e->dev->set_delta_m_fraction(nullptr);
     hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
     HIPC(hipGetLastError());
