@@ -57,13 +57,17 @@ struct VBufs {
     double* grad;           // [4 nlyr + 2][tid3] reduced gradient of the current solar zenith index
     double* dnat;           // [2 ngrid + 1][tid3] native derivatives
     int derivs;
+    // scattering-group derivatives (directional derivatives wrt the layer Greek coefficients, sktran_do_layerarray.cpp:496-513,759-860)
+    int ngroups;            // G
+    const double* dleg;     // [g][w][q][nleg][4 | 1]  d_legendre of the scattering derivative mappings, caller layout
+    double* da4;            // [g][p][l][4][w]  direction of the layer coefficients for group g
     double* scratch;        // [element][thread] work matrices of the running kernel
     size_t scratch_stride;  // threads of the running kernel
 };
 
 struct VRec {
-    int n;
-    SKD_HD explicit VRec(int n_) : n(n_) {}
+    int n, ngrp;
+    SKD_HD explicit VRec(int n_, int G_ = 0) : n(n_), ngrp(G_) {}
     // same record as skd::Rec with N -> n: eigenvalues, exp(-k tau), d k / d omega, W+-, d W+- / d omega, Green's coefficients and
     // their omega derivatives, edge values of the particular solution G[4][n] (0 G+top, 1 G-top, 2 G+bottom, 3 G-bottom, no D factor),
     // DG[theta][4][n] (theta: tau, omega, T, sec), post-processing multipliers PPM[n][14]
@@ -81,9 +85,17 @@ struct VRec {
     SKD_HD int G() const { return AP() + 4 * n; }
     SKD_HD int DG() const { return G() + 4 * n; }
     SKD_HD int PPM() const { return DG() + 16 * n; }
-    SKD_HD int size() const { return PPM() + 14 * n; }
+    // per scattering group g: d k, d W+-, d A+-, d G[4] along the group's coefficient direction
+    SKD_HD int GRP(int g) const { return PPM() + 14 * n + g * (2 * n * n + 7 * n); }
+    SKD_HD int GDK(int g) const { return GRP(g); }
+    SKD_HD int GDWP(int g) const { return GRP(g) + n; }
+    SKD_HD int GDWM(int g) const { return GRP(g) + n + n * n; }
+    SKD_HD int GDAP(int g) const { return GRP(g) + n + 2 * n * n; }
+    SKD_HD int GDAM(int g) const { return GDAP(g) + n; }
+    SKD_HD int GDG(int g) const { return GDAP(g) + 2 * n; }   // [4 edges][n]
+    SKD_HD int size() const { return GRP(ngrp); }
 };
-SKD_HD double* vrec_at(const VBufs& v, int nlyr, int p, int w) { return v.rec + (size_t(w) * nlyr + p) * VRec(v.n).size(); }
+SKD_HD double* vrec_at(const VBufs& v, int nlyr, int p, int w) { return v.rec + (size_t(w) * nlyr + p) * VRec(v.n, v.ngroups).size(); }
 SKD_HD double* vdinv_at(const VBufs& v, int nlyr, int p, int w) { return v.dinv + (size_t(w) * nlyr + p) * (4 * size_t(v.n) * v.n); }
 SKD_HD double* vxsol_at(const VBufs& v, int nlyr, int p, int w) { return v.xsol + (size_t(w) * nlyr + p) * (2 * v.n); }
 SKD_HD double& vJ_at(const VBufs& v, const Geo& g, int m, int slot, int w, int s) {
@@ -164,11 +176,39 @@ SKD_HD void kv0_coefficients(const Geo& g, const Bufs& b, const VBufs& v, int w)
         } else {
             v.a4[(size_t(p) * nstr * 4) * nw + w] = 0;
         }
+        // scattering-group directions of the layer coefficients: d_legendre of the mapping at the layer's last contributing grid
+        // point plus the distance of that point's coefficients from the layer mean (sktran_do_layerarray.cpp:759-860; the reference
+        // assigns the direction once per layer, from the last entry of its interpolation stencil)
+        if (v.derivs && v.ngroups > 0) {
+            const int qs = (g.wq_idx[2 * p + 1] >= 0) ? g.wq_idx[2 * p + 1] : g.wq_idx[2 * p];
+            const double fq = b.delta_f ? b.delta_f[size_t(w) * ngrid + qs] : 0.0, fsub = fq / (1 - fq);
+            for (int gi = 0; gi < v.ngroups; ++gi) {
+                const double* dl = v.dleg + ((size_t(gi) * nw + w) * ngrid + qs) * v.nleg * per;
+                for (int l = 0; l < nstr; ++l) {
+                    const bool have = l < v.nleg;
+                    const double* c = leg + (size_t(qs) * v.nleg + l) * per;
+                    const double* a = v.a4 + (size_t(p) * nstr + l) * 4 * nw + w;
+                    double* d = v.da4 + ((size_t(gi) * nlyr + p) * nstr + l) * 4 * nw + w;
+                    for (int cc = 0; cc < 4; ++cc) d[size_t(cc) * nw] = 0;
+                    d[0] = (have ? dl[l * per] + c[0] : 0.0) - (2 * l + 1) * fsub - a[0];
+                    if (S == 3) {
+                        d[size_t(1) * nw] = (have ? dl[l * per + 1] + c[1] : 0.0) - (2 * l + 1) * fsub - a[size_t(1) * nw];
+                        d[size_t(2) * nw] = (have ? dl[l * per + 2] + c[2] : 0.0) - (2 * l + 1) * fsub - a[size_t(2) * nw];
+                        d[size_t(3) * nw] = (have ? -dl[l * per + 3] - c[3] : 0.0) - a[size_t(3) * nw];
+                    }
+                }
+            }
+        }
     }
 }
 
 SKD_HD void load_coef(const Bufs& b, const VBufs& v, int nstr, int p, int l, int w, double* c4) {
     const double* a = v.a4 + (size_t(p) * nstr + l) * 4 * b.nw + w;
+    for (int c = 0; c < 4; ++c) c4[c] = a[size_t(c) * b.nw];
+}
+// direction of the layer coefficients for scattering group gi
+SKD_HD void load_dcoef(const Geo& g, const Bufs& b, const VBufs& v, int gi, int p, int l, int w, double* c4) {
+    const double* a = v.da4 + ((size_t(gi) * g.nlyr + p) * g.nstr + l) * 4 * b.nw + w;
     for (int c = 0; c < 4; ++c) c4[c] = a[size_t(c) * b.nw];
 }
 
@@ -563,6 +603,164 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
         for (int t = 0; t < 4; ++t)
             for (int c = 0; c < 4; ++c) rec[R.DG() + (t * 4 + c) * n + i] = dg[t][c];
     }
+    // ---- scattering groups: the same perturbation theory along a general direction dc of the layer coefficients,
+    //      dS+- = -om M^-1 dE+-(dc) W ;  d(Gamma) X = dS- U + S- (dS+ X) ;  dU = dS+ X + S+ dX ;  dQ = Q(dc)
+    //      (the omega derivative above is the direction dc = c / om)
+    if (derivs && v.ngroups > 0) {
+        const VRec RG(n, v.ngroups);
+        double *dEp = Bp, *dEm = Bm, *A1 = Tm, *A2 = V;   // the Cholesky factor, C, dU and dX are no longer needed
+        double *dQp = coef, *dQm = coef + n, *dnrm_g = coef + 2 * n, *fcm = coef + 3 * n, *fcp = coef + 4 * n, *dkg = coef + 5 * n;
+        for (int gi = 0; gi < v.ngroups; ++gi) {
+            team.sync();
+            SKV_PAR(blk, N * N) {
+                const int i = blk / N, j = blk % N;
+                double ep[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, em[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                const Fun3 fi = fun_mu(g, vg, m, i), fj = fun_mu(g, vg, m, j);
+                for (int l = m; l < nstr; ++l) {
+                    double c4[4];
+                    load_dcoef(g, b, v, gi, p, l, w, c4);
+                    const double sg = ((l - m) & 1) ? -1.0 : 1.0;
+                    if (S == 1) {
+                        const double t = c4[0] * fi.P[l] * fj.P[l];
+                        ep[0] += 0.5 * (t + sg * t);
+                        em[0] += 0.5 * (t - sg * t);
+                        continue;
+                    }
+                    for (int s2 = 0; s2 < 3; ++s2) {
+                        double ex[3] = {0, 0, 0}, col[3], bc[3], bdc[3], y0[3], y1[3];
+                        ex[s2] = 1;
+                        pi_apply(fj.P[l], fj.R[l], fj.T[l], ex, col);
+                        greek_apply(c4, col, bc);
+                        const double dcol[3] = {col[0], col[1], -col[2]};
+                        greek_apply(c4, dcol, bdc);
+                        pi_apply(fi.P[l], fi.R[l], fi.T[l], bc, y0);
+                        pi_apply(fi.P[l], fi.R[l], fi.T[l], bdc, y1);
+                        for (int s1 = 0; s1 < 3; ++s1) {
+                            ep[s1 * 3 + s2] += 0.5 * (y0[s1] + sg * y1[s1]);
+                            em[s1 * 3 + s2] += 0.5 * (y0[s1] - sg * y1[s1]);
+                        }
+                    }
+                }
+                for (int s1 = 0; s1 < S; ++s1)
+                    for (int s2 = 0; s2 < S; ++s2) {
+                        dEp[(i * S + s1) * n + j * S + s2] = ep[s1 * 3 + s2];
+                        dEm[(i * S + s1) * n + j * S + s2] = em[s1 * 3 + s2];
+                    }
+            }
+            team.sync();
+            SKV_PAR(e, nn) {   // A1 = dS+ X, A2 = dS- U
+                const int i = e / n, j = e % n;
+                A1[e] = -om / rmu(i) * sum4(0, n, [&](int r) { return rw(r) * dEp[i * n + r] * X[r * n + j]; });
+                A2[e] = -om / rmu(i) * sum4(0, n, [&](int r) { return rw(r) * dEm[i * n + r] * U[r * n + j]; });
+            }
+            team.sync();
+            SKV_PAR(e, nn) {   // d(Gamma) X = A2 + S- A1   (into dEm, which is consumed)
+                const int i = e / n, j = e % n;
+                const double t = sum4(0, n, [&](int r) { return rw(r) * Em[i * n + r] * A1[r * n + j]; });
+                dEm[e] = A2[e] + (A1[e] - om * t) / rmu(i);
+            }
+            team.sync();
+            double lmax = 0;
+            for (int j = 0; j < n; ++j) lmax = fmax(lmax, lam[j]);
+            SKV_PAR(e, nn) {   // C (into A2)
+                const int a_ = e / n, b_ = e % n;
+                const double z = sum4(0, n, [&](int i) { return rw(i) * rmu(i) * U[i * n + a_] * dEm[i * n + b_]; });
+                if (a_ == b_) {
+                    dkg[b_] = z / (2 * kk[b_]);
+                    A2[e] = 0;
+                } else {
+                    const double den = lam[b_] - lam[a_];
+                    A2[e] = (fabs(den) > 1e-13 * lmax) ? z / den : 0.0;
+                }
+            }
+            team.sync();
+            SKV_PAR(e, nn) {   // dX = X C  (into dEm)
+                const int i = e / n, j = e % n;
+                dEm[e] = sum4(0, n, [&](int r) { return X[i * n + r] * A2[r * n + j]; });
+            }
+            team.sync();
+            SKV_PAR(e, nn) {   // dU = A1 + S+ dX  (into A2)
+                const int i = e / n, j = e % n;
+                const double t = sum4(0, n, [&](int r) { return rw(r) * Ep[i * n + r] * dEm[r * n + j]; });
+                A2[e] = A1[e] + (dEm[e] - om * t) / rmu(i);
+            }
+            team.sync();
+            SKV_PAR(j, n) {
+                double dnr = 0;
+                rec[RG.GDK(gi) + j] = dkg[j];
+                for (int i = 0; i < n; ++i) {
+                    const double duk = A2[i * n + j] / kk[j] - U[i * n + j] * dkg[j] / lam[j];
+                    const double dwp = 0.5 * (dEm[i * n + j] + duk), dwm = 0.5 * (dEm[i * n + j] - duk);
+                    rec[RG.GDWP(gi) + i + n * j] = dwp;
+                    rec[RG.GDWM(gi) + i + n * j] = dwm;
+                    dnr += rw(i) * rmu(i) * 2.0 * (rec[R.WP() + i + n * j] * dwp - rec[R.WM() + i + n * j] * dwm);
+                }
+                dnrm_g[j] = dnr;
+            }
+            SKV_PAR(i, N) {   // dQ+- along the direction
+                double qp[3] = {0, 0, 0}, qm[3] = {0, 0, 0};
+                const Fun3 fi = fun_mu(g, vg, m, i);
+                for (int l = m; l < nstr; ++l) {
+                    double c4[4];
+                    load_dcoef(g, b, v, gi, p, l, w, c4);
+                    const double sg = ((l - m) & 1) ? -1.0 : 1.0;
+                    const double x[3] = {lpc[l], 0, 0};
+                    double bx[3], y[3] = {0, 0, 0};
+                    greek_apply(c4, x, bx);
+                    if (S == 1) y[0] = bx[0] * fi.P[l];
+                    else pi_apply(fi.P[l], fi.R[l], fi.T[l], bx, y);
+                    for (int s1 = 0; s1 < S; ++s1) {
+                        qp[s1] += y[s1];
+                        qm[s1] += sg * y[s1];
+                    }
+                }
+                for (int s1 = 0; s1 < S; ++s1) {
+                    dQp[i * S + s1] = qp[s1] * fm * g.wt[i] * om;
+                    dQm[i * S + s1] = qm[s1] * fm * g.wt[i] * om;
+                }
+            }
+            team.sync();
+            SKV_PAR(j, n) {
+                double dAp = 0, dAm = 0, f_cm = 0, f_cp = 0;
+                const double Ap = rec[R.AP() + j], Am = rec[R.AM() + j];
+                for (int i = 0; i < n; ++i) {
+                    const double wp = rec[R.WP() + i + n * j], wm = rec[R.WM() + i + n * j];
+                    const double dwp = rec[RG.GDWP(gi) + i + n * j], dwm = rec[RG.GDWM(gi) + i + n * j];
+                    dAp += Qp[i] * dwp + dQp[i] * wp + Qm[i] * dwm + dQm[i] * wm;
+                    dAm += Qm[i] * dwp + dQm[i] * wp + Qp[i] * dwm + dQp[i] * wm;
+                }
+                dAp = dAp / nrm[j] - dnrm_g[j] * Ap / nrm[j];
+                dAm = dAm / nrm[j] - dnrm_g[j] * Am / nrm[j];
+                skd::Mult Cp, Cm;
+                skd::green_multipliers(T, th, sc, kk[j], Cp, Cm);
+                f_cm = Am * Cm.d_k * dkg[j] + dAm * Cm.v;
+                f_cp = Ap * Cp.d_k * dkg[j] + dAp * Cp.v;
+                rec[RG.GDAP(gi) + j] = dAp;
+                rec[RG.GDAM(gi) + j] = dAm;
+                fcm[j] = f_cm;
+                fcp[j] = f_cp;
+                // the products A C themselves for the dW terms
+                acp[j] = Ap * Cp.v;
+                acm[j] = Am * Cm.v;
+            }
+            team.sync();
+            SKV_PAR(i, n) {
+                double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+                for (int j = 0; j < n; ++j) {
+                    const double wp = rec[R.WP() + i + n * j], wm = rec[R.WM() + i + n * j];
+                    const double dwp = rec[RG.GDWP(gi) + i + n * j], dwm = rec[RG.GDWM(gi) + i + n * j];
+                    d0 += fcm[j] * wm + acm[j] * dwm;
+                    d1 += fcm[j] * wp + acm[j] * dwp;
+                    d2 += fcp[j] * wp + acp[j] * dwp;
+                    d3 += fcp[j] * wm + acp[j] * dwm;
+                }
+                rec[RG.GDG(gi) + 0 * n + i] = d0;
+                rec[RG.GDG(gi) + 1 * n + i] = d1;
+                rec[RG.GDG(gi) + 2 * n + i] = d2;
+                rec[RG.GDG(gi) + 3 * n + i] = d3;
+            }
+        }
+    }
     team.sync();
     if (err && team.lane == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -904,8 +1102,8 @@ SKD_HD void kv4_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v,
 // (tau, omega, T, sec) of every layer; skd::k4a_chain then maps it to the native derivatives.
 // =================================================================================================
 struct VOps {
-    int n, NL;
-    SKD_HD VOps(int n_, int NL_) : n(n_), NL(NL_) {}
+    int n, NL, G;
+    SKD_HD VOps(int n_, int NL_, int G_ = 0) : n(n_), NL(NL_), G(G_) {}
     SKD_HD int FP() const { return 0; }                        // [2n][NL]
     SKD_HD int SP() const { return 2 * n * NL; }               // [2n][n]
     SKD_HD int BP() const { return SP() + 2 * n * n; }         // [2n][n]
@@ -914,21 +1112,24 @@ struct VOps {
     SKD_HD int HD() const { return DI() + 16 * n; }            // [4][NL]
     SKD_HD int GD() const { return HD() + 4 * NL; }            // [4]
     SKD_HD int IPB() const { return GD() + 4; }
-    SKD_HD int size() const { return IPB() + 1; }
+    SKD_HD int GDI(int g) const { return IPB() + 1 + g * (4 * n + NL + 1); }   // [4 edges][n] of group g
+    SKD_HD int GHD(int g) const { return GDI(g) + 4 * n; }                   // [NL]
+    SKD_HD int GGD(int g) const { return GHD(g) + NL; }
+    SKD_HD int size() const { return GDI(G); }
 };
 SKD_HD int legendre_space(const Geo& g, int S) { return (S == 3 ? 3 : 1) * g.nstr; }
 SKD_HD double* vops_at(const VBufs& v, const Geo& g, int p, int w) {
-    return v.ops + (size_t(w) * g.nlyr + p) * VOps(v.n, legendre_space(g, v.S)).size();
+    return v.ops + (size_t(w) * g.nlyr + p) * VOps(v.n, legendre_space(g, v.S), v.ngroups).size();
 }
 
 // KV2C: adjoint operators of one layer                        (task = wavelength x layer, one team)
 //   ws: 2n NL + 4 n + 5 NL n doubles of team-shared work space (F, temporaries, partial sums of the HD rows)
-SKD_HD size_t kv2c_scratch(int n, int NL) { return 2 * size_t(n) * NL + 4 * size_t(n) + 5 * size_t(NL) * n; }
+SKD_HD size_t kv2c_scratch(int n, int NL, int G = 0) { return 2 * size_t(n) * NL + 4 * size_t(n) + (5 + size_t(G)) * size_t(NL) * n; }
 
 SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws) {
     const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
     const VRec R(n);
-    const VOps O(n, NL);
+    const VOps O(n, NL, v.ngroups);
     const double* c = vrec_at(v, nlyr, p, w);
     const double* dinv = vdinv_at(v, nlyr, p, w);
     const double* xs = vxsol_at(v, nlyr, p, w);
@@ -945,14 +1146,19 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
     if (table) SKV_PAR(item, nstr * K) {
         const int l = item % nstr, kslice = item / nstr;
         const int a_lo = kslice * per_k, a_hi = (a_lo + per_k < n) ? a_lo + per_k : n;
+        const int NG = v.ngroups, NP = 5 + NG;
+        const VRec RG(n, NG);
         double hd[4][3], val[3] = {0, 0, 0};
         for (int t = 0; t < 4; ++t)
             for (int cc = 0; cc < 3; ++cc) hd[t][cc] = 0;
+        for (int gi = 0; gi < NG; ++gi)
+            for (int cc = 0; cc < C; ++cc) part[(kslice * NP + 5 + gi) * NL + l * C + cc] = 0;
         double c4[4];
         load_coef(b, v, nstr, p, l, w, c4);
         const double sg = ((l - m) & 1) ? -1.0 : 1.0;
         for (int a_ = a_lo; a_ < a_hi; ++a_) {
             double yp[3] = {0, 0, 0}, ym[3] = {0, 0, 0}, dyp[3] = {0, 0, 0}, dym[3] = {0, 0, 0};
+            double xPk[3] = {0, 0, 0}, xMk[3] = {0, 0, 0};
             if (l >= m) {
                 double tP[3] = {0, 0, 0}, tM[3] = {0, 0, 0}, dtP[3] = {0, 0, 0}, dtM[3] = {0, 0, 0};
                 for (int j = 0; j < N; ++j) {
@@ -981,6 +1187,7 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
                 const double xM[3] = {sg * tM[0] + tP[0], sg * tM[1] + tP[1], -sg * tM[2] + tP[2]};
                 const double dxP[3] = {sg * dtP[0] + dtM[0], sg * dtP[1] + dtM[1], -sg * dtP[2] + dtM[2]};
                 const double dxM[3] = {sg * dtM[0] + dtP[0], sg * dtM[1] + dtP[1], -sg * dtM[2] + dtP[2]};
+                for (int cc = 0; cc < 3; ++cc) { xPk[cc] = xP[cc]; xMk[cc] = xM[cc]; }
                 greek_apply(c4, xP, yp);
                 greek_apply(c4, xM, ym);
                 greek_apply(c4, dxP, dyp);
@@ -992,6 +1199,40 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
             const double L = xs[a_], Mv = xs[n + a_], dk = c[R.DK() + a_];
             const double Ap = c[R.AP() + a_], Am = c[R.AM() + a_], dAp = c[R.DAP() + a_], dAm = c[R.DAM() + a_];
             const double tL = pm.hp * L + Ap * pm.Dm, tM_ = pm.hm * Mv + Am * pm.Dp;
+            if (l >= m)
+                for (int gi = 0; gi < NG; ++gi) {
+                    // direction derivative of (yp, ym): om [ B_l (sg D dtP + dtM) + dB_l (sg D tP + tM) ] with dW of the group
+                    double gtP[3] = {0, 0, 0}, gtM[3] = {0, 0, 0};
+                    for (int j = 0; j < N; ++j) {
+                        const Fun3 fj = fun_mu(g, vg, m, j);
+                        const double hw = 0.5 * g.wt[j];
+                        double dwp[3] = {0, 0, 0}, dwm[3] = {0, 0, 0}, y[3];
+                        for (int s2 = 0; s2 < S; ++s2) {
+                            dwp[s2] = c[RG.GDWP(gi) + j * S + s2 + n * a_];
+                            dwm[s2] = c[RG.GDWM(gi) + j * S + s2 + n * a_];
+                        }
+                        if (S == 1) { gtP[0] += hw * fj.P[l] * dwp[0]; gtM[0] += hw * fj.P[l] * dwm[0]; }
+                        else {
+                            pi_apply(fj.P[l], fj.R[l], fj.T[l], dwp, y); for (int cc = 0; cc < 3; ++cc) gtP[cc] += hw * y[cc];
+                            pi_apply(fj.P[l], fj.R[l], fj.T[l], dwm, y); for (int cc = 0; cc < 3; ++cc) gtM[cc] += hw * y[cc];
+                        }
+                    }
+                    const double gxP[3] = {sg * gtP[0] + gtM[0], sg * gtP[1] + gtM[1], -sg * gtP[2] + gtM[2]};
+                    const double gxM[3] = {sg * gtM[0] + gtP[0], sg * gtM[1] + gtP[1], -sg * gtM[2] + gtP[2]};
+                    double dc4[4], gyp[3], gym[3], eyp[3], eym[3];
+                    load_dcoef(g, b, v, gi, p, l, w, dc4);
+                    greek_apply(c4, gxP, gyp);
+                    greek_apply(c4, gxM, gym);
+                    greek_apply(dc4, xPk, eyp);
+                    greek_apply(dc4, xMk, eym);
+                    const double dkg = c[RG.GDK(gi) + a_], dApg = c[RG.GDAP(gi) + a_], dAmg = c[RG.GDAM(gi) + a_];
+                    for (int cc = 0; cc < C; ++cc) {
+                        const double dy_p = om * (gyp[cc] + eyp[cc]), dy_m = om * (gym[cc] + eym[cc]);
+                        part[(kslice * NP + 5 + gi) * NL + l * C + cc] +=
+                            dy_p * tL + dy_m * tM_ + yp[cc] * (pm.hp_k * dkg * L + dApg * pm.Dm + Ap * pm.Dm_k * dkg) +
+                            ym[cc] * (pm.hm_k * dkg * Mv + dAmg * pm.Dp + Am * pm.Dp_k * dkg);
+                    }
+                }
             for (int cc = 0; cc < C; ++cc) {
                 F[a_ * NL + l * C + cc] = yp[cc] * pm.hp / om;
                 F[(n + a_) * NL + l * C + cc] = ym[cc] * pm.hm / om;
@@ -1004,20 +1245,26 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
             }
         }
         for (int cc = 0; cc < C; ++cc) {
-            for (int t = 0; t < 4; ++t) part[(kslice * 5 + t) * NL + l * C + cc] = hd[t][cc];
-            part[(kslice * 5 + 4) * NL + l * C + cc] = val[cc];
+            for (int t = 0; t < 4; ++t) part[(kslice * NP + t) * NL + l * C + cc] = hd[t][cc];
+            part[(kslice * NP + 4) * NL + l * C + cc] = val[cc];
         }
     }
     team.sync();
     if (table) SKV_PAR(lam_, NL) {
+        const int NP = 5 + v.ngroups;
         double hd[4] = {0, 0, 0, 0}, val = 0;
         for (int k = 0; k < K; ++k) {
-            for (int t = 0; t < 4; ++t) hd[t] += part[(k * 5 + t) * NL + lam_];
-            val += part[(k * 5 + 4) * NL + lam_];
+            for (int t = 0; t < 4; ++t) hd[t] += part[(k * NP + t) * NL + lam_];
+            val += part[(k * NP + 4) * NL + lam_];
         }
         for (int t = 0; t < 4; ++t) hd[t] /= om;
         hd[skd::TH_OM] -= val / (om * om);
         for (int t = 0; t < 4; ++t) o[O.HD() + t * NL + lam_] = hd[t];
+        for (int gi = 0; gi < v.ngroups; ++gi) {
+            double h = 0;
+            for (int k = 0; k < K; ++k) h += part[(k * NP + 5 + gi) * NL + lam_];
+            o[O.GHD(gi) + lam_] = h / om;
+        }
     }
     team.sync();
     // ---- FP = Dinv^T F
@@ -1055,6 +1302,21 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
             ipb_i += wp * E * L + wm * Mv;
         }
         ipbv[i] = ((i % S) == 0) ? g.wt[i / S] * g.mu[i / S] * ipb_i : 0.0;
+        for (int gi = 0; gi < v.ngroups; ++gi) {
+            const VRec RG(n, v.ngroups);
+            double dg[4] = {0, 0, 0, 0};
+            for (int j = 0; j < n; ++j) {
+                const double wp = c[R.WP() + i + n * j], wm = c[R.WM() + i + n * j];
+                const double dwp = c[RG.GDWP(gi) + i + n * j], dwm = c[RG.GDWM(gi) + i + n * j];
+                const double E = c[R.E() + j], L = xs[j], Mv = xs[n + j];
+                const double dE = -c[RG.GDK(gi) + j] * th * E;
+                dg[0] += dwp * L + dwm * E * Mv + wm * dE * Mv;
+                dg[1] += dwm * L + dwp * E * Mv + wp * dE * Mv;
+                dg[2] += dwp * E * L + wp * dE * L + dwm * Mv;
+                dg[3] += dwm * E * L + wm * dE * L + dwp * Mv;
+            }
+            for (int e = 0; e < 4; ++e) o[O.GDI(gi) + e * n + i] = c[RG.GDG(gi) + e * n + i] + dg[e];
+        }
         for (int e = 0; e < 4; ++e) {
             o[O.DI() + (skd::TH_TAU * 4 + e) * n + i] = c[R.DG() + (skd::TH_TAU * 4 + e) * n + i] + d_tau[e];
             o[O.DI() + (skd::TH_OM * 4 + e) * n + i] = c[R.DG() + (skd::TH_OM * 4 + e) * n + i] + d_om[e];
@@ -1085,6 +1347,12 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
                 for (int i = 0; i < N; ++i) sacc += g.wt[i] * g.mu[i] * o[O.DI() + (t * 4 + 2) * n + i * S];
             o[O.GD() + t] = 2.0 * rho * sacc;
         }
+        for (int gi = 0; gi < v.ngroups; ++gi) {
+            double sacc = 0;
+            if (last && m == 0)
+                for (int i = 0; i < N; ++i) sacc += g.wt[i] * g.mu[i] * o[O.GDI(gi) + 2 * n + i * S];
+            o[O.GGD(gi)] = 2.0 * rho * sacc;
+        }
     }
     team.sync();
 }
@@ -1094,7 +1362,7 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
 SKD_HD void adjoint_backward_gradient(const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, size_t tid, size_t nt, double gw,
                                       bool table_weights, Scr y, Scr carry) {
     const int S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
-    const VOps O(n, NL);
+    const VOps O(n, NL, v.ngroups);
     // ---- backward sweep  z_p = y_p - BP zA_{p+1}
     for (int i = 0; i < n; ++i) carry[i] = 0;
     for (int p = nlyr - 1; p >= 0; --p) {
@@ -1134,6 +1402,21 @@ SKD_HD void adjoint_backward_gradient(const Geo& g, const Bufs& b, const VBufs& 
             v.grad[size_t(4 * nlyr + 1) * nt + tid] += zBsum * g.csz[s] / kPi * rho;
         }
         for (int t = 0; t < 4; ++t) v.grad[size_t(t * nlyr + p) * nt + tid] += gth[t];
+        // scattering groups: the same contraction with the group's DI / HD / GD rows
+        for (int gi = 0; gi < v.ngroups; ++gi) {
+            double gg = 0;
+            for (int i = 0; i < n; ++i) {
+                const double zA = v.z[(size_t(p) * M2 + i) * nt + tid], zB = v.z[(size_t(p) * M2 + n + i) * nt + tid];
+                const double zAn = last ? 0.0 : v.z[(size_t(p + 1) * M2 + i) * nt + tid];
+                const double zBp = (p > 0) ? v.z[(size_t(p - 1) * M2 + n + i) * nt + tid] : 0.0;
+                gg += zA * ops[O.GDI(gi) + 0 * n + i] + zBp * ops[O.GDI(gi) + 1 * n + i] - zAn * ops[O.GDI(gi) + 2 * n + i] -
+                      zB * ops[O.GDI(gi) + 3 * n + i];
+            }
+            if (table_weights)
+                for (int l = m * C; l < NL; ++l) gg += ops[O.GHD(gi) + l] * v.qlbuf[(size_t(p) * NL + l) * nt + tid];
+            if (last && m == 0) gg += (zBsum + gw) * ops[O.GGD(gi)];
+            v.grad[size_t(4 * nlyr + 2 + gi * nlyr + p) * nt + tid] += gg;
+        }
     }
 }
 
@@ -1143,7 +1426,7 @@ SKD_HD size_t kv2b_scratch(int n, int NL) { return size_t(NL) + 3 * size_t(n); }
 
 SKD_HD void kv2b_adjoint(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int los, int sout, int w, Scr scr) {
     const int S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
-    const VOps O(n, NL);
+    const VOps O(n, NL, v.ngroups);
     const size_t tid = (size_t(w) * g.nlos + los) * S + sout, nt = size_t(nw) * g.nlos * S;
     Scr ql = scr.sub(0), y = scr.sub(NL), carry = scr.sub(NL + M2);
     double gw = 0;  // the Lambertian ground feeds the intensity only
@@ -1198,7 +1481,7 @@ SKD_HD size_t kvpp_scratch(int n) { return 21 * size_t(n); }
 SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int los, int w, Scr scr) {
     const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
     const VRec R(n);
-    const VOps O(n, NL);
+    const VOps O(n, NL, v.ngroups);
     const size_t tid = size_t(w) * g.nlos + los, nt3 = size_t(nw) * g.nlos * S;
     const double mu = g.pp_mu[los];
     const Fun3 fl = fun_los(g, vg, m, los);
@@ -1363,6 +1646,26 @@ SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v
         }
         adjoint_backward_gradient(g, b, v, s, m, w, t3, nt3, (s1 == 0) ? gw : 0.0, false, yv, carry.sub(size_t(s1) * n));
     }
+}
+
+// Scattering-group gradients of the layers -> native derivatives [2 ngrid + 1 + g ngrid + q]: layer p feeds its stencil points q
+// with weight w_pq omega_q k_q / (layer scattering extinction)  (sktran_do_layerarray.cpp:502-511,768-775).  Clears the rows
+// (one call per solar zenith index).                                      (task = wavelength x LOS x Stokes)
+SKD_HD void kv4g_chain(const Geo& g, const Bufs& b, const VBufs& v, int w, size_t tid, size_t nt) {
+    const int nw = b.nw, nlyr = g.nlyr, ngrid = g.ngrid;
+    const double* ext = b.ext + size_t(w) * ngrid;
+    const double* ssa = b.ssa + size_t(w) * ngrid;
+    for (int gi = 0; gi < v.ngroups; ++gi)
+        for (int p = 0; p < nlyr; ++p) {
+            double& gr = v.grad[size_t(4 * nlyr + 2 + gi * nlyr + p) * nt + tid];
+            const double scat = b.om[size_t(p) * nw + w] * b.kbar[size_t(p) * nw + w];
+            for (int t = 0; t < 2; ++t) {
+                const int q = g.wq_idx[2 * p + t];
+                if (q < 0) continue;
+                v.dnat[size_t(2 * ngrid + 1 + gi * ngrid + q) * nt + tid] += gr * g.wq_w[2 * p + t] * ssa[q] * ext[q] / scat;
+            }
+            gr = 0;
+        }
 }
 
 // (I, Q, U) of one line of sight in the configured Stokes basis:  Q' = C Q - S U,  U' = S Q + C U

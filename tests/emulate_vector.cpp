@@ -50,7 +50,7 @@ void emuv_destroy(void* h) { delete static_cast<Handle*>(h); }
 // radiance: [nwavel][nlos][nstokes];  leg: [nwavel][ngrid][nleg][4] (reference storage order, nstokes = 3) or [..][nleg]
 int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg,
              const double* solar_irradiance, const double* albedo, const double* delta_f, double* radiance, double* los_od, int* status,
-             int derivatives, double* d_k, double* d_ssa, double* d_albedo) {
+             int derivatives, double* d_k, double* d_ssa, double* d_albedo, int ngroups, const double* d_legendre, double* d_scat) {
     auto* h = static_cast<Handle*>(hv);
     const skhost::GeoTables& t = h->tab;
     skd::Geo g = t.host_view();
@@ -69,19 +69,21 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     b.od = od.data(); b.omloc = omloc.data(); b.srcw = srcw.data(); b.att_total = att_total.data();
     b.conv_order = conv.data(); b.notconv = notconv.data(); b.norders = norders.data(); b.status = stat.data(); b.los_od = lod.data();
     const skv::VRec R(n);
-    std::vector<double> a4(size_t(nlyr) * nstr * 4 * nw), rec(size_t(nlyr) * R.size() * nw), dinv(size_t(nlyr) * 4 * n * n * nw),
+    std::vector<double> a4(size_t(nlyr) * nstr * 4 * nw), rec(size_t(nlyr) * skv::VRec(n, derivatives ? ngroups : 0).size() * nw), dinv(size_t(nlyr) * 4 * n * n * nw),
         xsol(size_t(nlyr) * 2 * n * nw), J(size_t(nstr) * std::max(t.nslot, 1) * nw * S, 0.0), rad(nt * S, 0.0);
     const int NL = skv::legendre_space(g, S), ngrid = t.ngrid;
     const size_t nt3 = nt * S;
     std::vector<double> scratch(std::max({skv::kv1_scratch(n), skv::kv2_scratch(n), skv::kv3_scratch(n, nstr), skv::kvpp_scratch(n),
-                                          skv::kv2c_scratch(n, NL), skv::kv2b_scratch(n, NL)}));
-    std::vector<double> ops(derivatives ? size_t(nlyr) * skv::VOps(n, NL).size() * nw : 1), zb(derivatives ? size_t(nlyr) * 2 * n * nt3 : 1),
-        qlb(derivatives ? size_t(nlyr) * NL * nt3 : 1), grad(derivatives ? size_t(4 * nlyr + 2) * nt3 : 1, 0.0),
-        dnat(derivatives ? size_t(2 * ngrid + 1) * nt3 : 1, 0.0);
+                                          skv::kv2c_scratch(n, NL, ngroups), skv::kv2b_scratch(n, NL)}));
+    const int G = derivatives ? ngroups : 0;
+    std::vector<double> ops(derivatives ? size_t(nlyr) * skv::VOps(n, NL, G).size() * nw : 1), zb(derivatives ? size_t(nlyr) * 2 * n * nt3 : 1),
+        qlb(derivatives ? size_t(nlyr) * NL * nt3 : 1), grad(derivatives ? size_t(4 * nlyr + 2 + G * nlyr) * nt3 : 1, 0.0),
+        dnat(derivatives ? size_t(2 * ngrid + 1 + G * ngrid) * nt3 : 1, 0.0), da4(size_t(std::max(G, 1)) * nlyr * nstr * 4 * nw, 0.0);
     skv::VBufs v{};
     v.S = S; v.n = n; v.leg = leg; v.nleg = nleg; v.a4 = a4.data(); v.rec = rec.data(); v.dinv = dinv.data(); v.xsol = xsol.data();
     v.J = J.data(); v.radiance = rad.data(); v.scratch = scratch.data(); v.scratch_stride = 1;
     v.ops = ops.data(); v.z = zb.data(); v.qlbuf = qlb.data(); v.grad = grad.data(); v.dnat = dnat.data(); v.derivs = derivatives;
+    v.ngroups = G; v.dleg = d_legendre; v.da4 = da4.data();
     const skv::Scr scr{scratch.data(), 1};
     const skv::Team team{0, 1};
     double* ws = scratch.data();
@@ -148,7 +150,10 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                 b3.grad = grad.data();
                 b3.dnat = dnat.data();
                 for (int w = 0; w < nw; ++w)
-                    for (int l3 = 0; l3 < nlos * S; ++l3) skd::k4a_chain(g3, b3, s, l3, w);
+                    for (int l3 = 0; l3 < nlos * S; ++l3) {
+                        skd::k4a_chain(g3, b3, s, l3, w);
+                        skv::kv4g_chain(g, b, v, w, size_t(w) * nlos * S + l3, nt3);
+                    }
             }
         }
         for (int w = 0; w < nw; ++w)
@@ -171,6 +176,15 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                     else if (d_albedo) d_albedo[i * S + c] = out[c];
                 }
             }
+            // scattering groups: d_scat [w][los][S][G][ngrid]
+            for (int gi = 0; gi < G; ++gi)
+                for (int q = 0; q < ngrid; ++q) {
+                    double in[3] = {0, 0, 0}, out[3];
+                    for (int c = 0; c < S; ++c) in[c] = dnat[size_t(2 * ngrid + 1 + gi * ngrid + q) * nt3 + i * S + c];
+                    skv::stokes_rotate(vg, los, in, out, S);
+                    for (int c = 0; c < S; ++c)
+                        if (d_scat) d_scat[((i * S + c) * G + gi) * ngrid + q] = out[c];
+                }
         }
     }
     for (int w = 0; w < nw; ++w)

@@ -91,12 +91,13 @@ def libv():
         L.emuv_destroy.argtypes = [ctypes.c_void_p]
         L.emuv_run.restype = ctypes.c_int
         L.emuv_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip,
-                               ctypes.c_int, _dp, _dp, _dp]
+                               ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _dp, _dp]
         _LIBV = L
     return _LIBV
 
 
-def run_emulated_vector(s, derivatives=False):
+def run_emulated_vector(s, derivatives=False, d_legendre=None):
+    """d_legendre: optional [G, nleg (*4), ngrid, nwavel] directions of scattering derivative groups (deriv_mapping.h d_legendre)."""
     """Radiances [nwavel, nlos, nstokes] of the polarised task bodies (disco_vec_core.hpp) executed on the CPU."""
     g = s["geometry"]
     alt = np.ascontiguousarray(g["altitudes"], dtype=np.float64)
@@ -122,13 +123,20 @@ def run_emulated_vector(s, derivatives=False):
         dk = dw = da = None
         if derivatives:
             dk, dw, da = np.zeros((nw, nlos, S, ngrid)), np.zeros((nw, nlos, S, ngrid)), np.zeros((nw, nlos, S))
+        G, dl, dsc = 0, None, None
+        if derivatives and d_legendre is not None:
+            G = len(d_legendre)
+            dl = np.ascontiguousarray(np.stack([np.asfortranarray(x).ravel(order="F") for x in d_legendre]))   # [G][w][q][leg]
+            dsc = np.zeros((nw, nlos, S, G, ngrid))
         rc = L.emuv_run(h, nw, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), None, _p(alb), _p(df), _p(rad), _p(od),
-                        status.ctypes.data_as(_ip), int(derivatives), _p(dk), _p(dw), _p(da))
+                        status.ctypes.data_as(_ip), int(derivatives), _p(dk), _p(dw), _p(da), G, _p(dl), _p(dsc))
         assert rc == 0, rc
         out = {"radiance": rad if S == 3 else rad[..., 0], "los_optical_depth": od, "status": status}
         if derivatives:
             sq = (lambda a: a) if S == 3 else (lambda a: a[:, :, 0])
             out.update({"d_extinction": sq(dk), "d_ssa": sq(dw), "d_albedo": sq(da)})
+            if dsc is not None:
+                out["d_scat"] = dsc if S == 3 else dsc[:, :, 0]
         return out
     finally:
         L.emuv_destroy(h)
