@@ -130,19 +130,24 @@ struct Engine {
 // user weighting function = d_ssa (x) dI/d(ssa) + d_extinction (x) dI/dk  (OutputC::assign_lane, cpp/lib/output/outputc.cpp:38-236),
 // evaluated on the device in the output layout [nderiv][wavel][los]; the mapping factors are [wavel][location]
 __global__ void __launch_bounds__(256) kern_map_wf(const double* we, const double* ws, const double* f_ssa, const double* f_ext,
-                                                   double* dst, int ngrid, int nw, int nlos) {
+                                                   double* dst, int ngrid, int nw, int nlos, const double* wg = nullptr,
+                                                   const double* f_scat = nullptr) {
+    // wg / f_scat: native scattering-group derivatives and the mapping's scat_factor (outputc.cpp:76-90), or null
     const size_t n = size_t(ngrid) * nw * nlos;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         const size_t qw = i / nlos;
         const int q = int(qw / nw), w = int(qw % nw);
-        dst[i] = f_ssa[size_t(w) * ngrid + q] * ws[i] + f_ext[size_t(w) * ngrid + q] * we[i];
+        double acc = f_ssa[size_t(w) * ngrid + q] * ws[i] + f_ext[size_t(w) * ngrid + q] * we[i];
+        if (wg) acc += f_scat[size_t(w) * ngrid + q] * wg[i];
+        dst[i] = acc;
     }
 }
 // the same followed by the mapping's interpolator (column major [ngrid x nout], OutputC::assign_lane: row of native derivatives
 // times the interpolator) and / or the division by the radiance of a log-radiance-space mapping; dst is [nout][wavel][los]
 __global__ void __launch_bounds__(256) kern_map_wf_interp(const double* we, const double* ws, const double* f_ssa, const double* f_ext,
                                                           const double* interp, const double* radiance, int log_space, double* dst,
-                                                          int ngrid, int nout, int nw, int nlos, int S = 1) {
+                                                          int ngrid, int nout, int nw, int nlos, int S = 1, const double* wg = nullptr,
+                                                          const double* f_scat = nullptr) {
     // nlos counts (line of sight, Stokes component) pairs; a log-radiance mapping divides every component by the intensity
     const size_t n = size_t(nout) * nw * nlos;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
@@ -152,10 +157,13 @@ __global__ void __launch_bounds__(256) kern_map_wf_interp(const double* we, cons
         if (interp) {
             for (int q = 0; q < ngrid; ++q) {
                 const size_t o = (size_t(q) * nw + w) * nlos + l;
-                acc += interp[size_t(j) * ngrid + q] * (f_ssa[size_t(w) * ngrid + q] * ws[o] + f_ext[size_t(w) * ngrid + q] * we[o]);
+                double v = f_ssa[size_t(w) * ngrid + q] * ws[o] + f_ext[size_t(w) * ngrid + q] * we[o];
+                if (wg) v += f_scat[size_t(w) * ngrid + q] * wg[o];
+                acc += interp[size_t(j) * ngrid + q] * v;
             }
         } else {
             acc = f_ssa[size_t(w) * ngrid + j] * ws[i] + f_ext[size_t(w) * ngrid + j] * we[i];
+            if (wg) acc += f_scat[size_t(w) * ngrid + j] * wg[i];
         }
         if (log_space) acc /= radiance[size_t(w) * nlos + (l / S) * S];
         dst[i] = acc;
@@ -373,8 +381,17 @@ int sk_engine_calculate_radiance_block_thread(Engine* e, OutputC* o, int, int, i
 }
 
 // native weighting functions (device, [ngrid][wavel][los][S] / [wavel][los][S]) -> the caller's derivative mappings
+static bool is_scattering_mapping(const DerivativeMapping& dm) {
+    if (dm.scat_deriv_index >= 0) return true;
+    for (double v : dm.d_legendre) if (v != 0.0) return true;
+    for (double v : dm.scat_factor) if (v != 0.0) return true;
+    return false;
+}
+
+// d_wg: native scattering-group derivatives [group][ngrid][wavel][los][S] with groups in the order of `group_of` (mapping name -> group)
 static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const Surface& su, OutputC* out, const double* d_we, const double* d_ws,
-                                 const double* d_wa, const double* d_rad, int S) {
+                                 const double* d_wa, const double* d_rad, int S, const double* d_wg = nullptr,
+                                 const std::map<std::string, int>* group_of = nullptr) {
     DeviceCache& C = e->cache;
     const int nw = st.nwavel, ngrid = e->ngrid, nlos = e->nlos * S;   // (line of sight, Stokes component) pairs
     const size_t nloc_w = size_t(ngrid) * nw, nt = size_t(nw) * nlos;
@@ -391,8 +408,15 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
                 HIPC(hipMemcpy(d_fs, m.d_ssa.data(), nloc_w * 8, hipMemcpyHostToDevice));
                 HIPC(hipMemcpy(d_fk, m.d_extinction.data(), nloc_w * 8, hipMemcpyHostToDevice));
                 double* d_dst = (double*)C.get("wf_user", size_t(nout) * nt * 8);
+                const double* d_wgm = nullptr;
+                double* d_fg = nullptr;
+                if (group_of && group_of->count(kv.first)) {
+                    d_wgm = d_wg + size_t(group_of->at(kv.first)) * ngrid * nt;
+                    d_fg = (double*)C.get("map_scat_factor", nloc_w * 8);
+                    HIPC(hipMemcpy(d_fg, m.scat_factor.data(), nloc_w * 8, hipMemcpyHostToDevice));
+                }
                 if (!m.interpolator && !m.log_radiance_space) {
-                    hipLaunchKernelGGL(kern_map_wf, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_dst, ngrid, nw, nlos);
+                    hipLaunchKernelGGL(kern_map_wf, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_dst, ngrid, nw, nlos, d_wgm, d_fg);
                 } else {
                     double* d_interp = nullptr;
                     if (m.interpolator) {
@@ -400,7 +424,7 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
                         HIPC(hipMemcpy(d_interp, m.interpolator, size_t(ngrid) * nout * 8, hipMemcpyHostToDevice));
                     }
                     hipLaunchKernelGGL(kern_map_wf_interp, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_interp, d_rad,
-                                       m.log_radiance_space, d_dst, ngrid, nout, nw, nlos, S);
+                                       m.log_radiance_space, d_dst, ngrid, nout, nw, nlos, S, d_wgm, d_fg);
                 }
                 HIPC(hipGetLastError());
                 HIPC(hipMemcpy(kv.second.mem, d_dst, size_t(nout) * nt * 8, hipMemcpyDeviceToHost));  // C order [nderiv][wavel][los]
@@ -452,10 +476,32 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
         d_irr = (double*)C.get("irradiance", size_t(nw) * 8);
         HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyHostToDevice));
     }
+    // scattering derivative groups: one per requested mapping that carries d_legendre / scat_factor (finalize_scattering_derivatives,
+    // cpp/include/sasktran2/atmosphere/grid_storage.h:190-214)
+    std::map<std::string, int> group_of;
+    double *d_dleg = nullptr, *d_wg = nullptr;
     if (derivs) {
         d_we = (double*)C.get("wf_ext", size_t(ngrid) * nt * S * 8);
         d_ws = (double*)C.get("wf_ssa", size_t(ngrid) * nt * S * 8);
         d_wa = (double*)C.get("wf_alb", nt * S * 8);
+        for (auto& kv : out->derivs) {
+            auto it = st.maps.find(kv.first);
+            if (it != st.maps.end() && is_scattering_mapping(*it->second)) {
+                const int gidx = (int)group_of.size();
+                group_of[kv.first] = gidx;
+            }
+        }
+        if (!group_of.empty()) {
+            if (e->dev->plane_parallel()) {
+                set_error("sk_engine_calculate_radiance: scattering-group derivatives need a spherical geometry");
+                return -2;
+            }
+            const size_t per_g = nloc_w * st.nleg;
+            d_dleg = (double*)C.get("d_legendre", group_of.size() * per_g * 8);
+            for (auto& kv : group_of)
+                HIPC(hipMemcpy(d_dleg + size_t(kv.second) * per_g, st.maps.at(kv.first)->d_legendre.data(), per_g * 8, hipMemcpyHostToDevice));
+            d_wg = (double*)C.get("wf_scat", group_of.size() * size_t(ngrid) * nt * S * 8);
+        }
     }
     double* d_f = nullptr;
     if (!st.delta_f.empty()) {
@@ -463,7 +509,8 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
         HIPC(hipMemcpy(d_f, st.delta_f.data(), nloc_w * 8, hipMemcpyHostToDevice));
     }
     e->dev->set_delta_m_fraction(d_f);
-    e->dev->solve_device_vector(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status, nullptr);
+    e->dev->solve_device_vector(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status, nullptr,
+                                (int)group_of.size(), d_dleg, d_wg);
     e->dev->set_delta_m_fraction(nullptr);
     hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
     HIPC(hipGetLastError());
@@ -475,7 +522,7 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     HIPC(hipMemcpy(out->radiance, d_rad, nt * S * 8, hipMemcpyDeviceToHost));
     out->los_od.resize(nt);
     HIPC(hipMemcpy(out->los_od.data(), d_odt, nt * 8, hipMemcpyDeviceToHost));
-    if (derivs) map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, S);
+    if (derivs) map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, S, d_wg, group_of.empty() ? nullptr : &group_of);
     return 0;
 }
 
@@ -489,17 +536,16 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (st.nloc != e->ngrid) throw std::runtime_error("atmosphere grid does not match the engine geometry");
         if (!su.brdf_args) throw std::runtime_error("surface has no BRDF set");
         if (su.brdf && su.brdf->kind != 0) return -2;  // only the Lambertian surface is part of this path
-        if (e->dev->vector_mode()) return calculate_radiance_vector(e, atm, out);
+        bool scattering_groups = false;
         for (auto& kv : out->derivs) {
             auto it = st.maps.find(kv.first);
             if (it == st.maps.end()) continue;
-            const DerivativeMapping& dm = *it->second;
-            bool uses_extra = dm.scat_deriv_index >= 0;
-            for (double v : dm.d_legendre) uses_extra = uses_extra || (v != 0.0);
-            for (double v : dm.scat_factor) uses_extra = uses_extra || (v != 0.0);
-            for (double v : dm.d_emission) uses_extra = uses_extra || (v != 0.0);
-            if (uses_extra) return -2;  // scattering-group / Legendre / emission derivatives
+            for (double v : it->second->d_emission)
+                if (v != 0.0) return -2;   // emission derivatives are not part of this path
+            scattering_groups = scattering_groups || is_scattering_mapping(*it->second);
         }
+        // scattering-group derivatives are served by the run-time-n kernels for every stream count
+        if (e->dev->vector_mode() || (scattering_groups && atm->derivs && e->config.wf_enabled)) return calculate_radiance_vector(e, atm, out);
         if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
         const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
         if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");

@@ -241,7 +241,7 @@ DeviceEngine::DeviceEngine(const skgeo::DiscoGeometry& dg, bool ss_in_do) : impl
     HIP_CHECK(hipEventCreateWithFlags(&I.fork, hipEventDisableTiming));
     HIP_CHECK(hipEventCreate(&I.ev0));
     HIP_CHECK(hipEventCreate(&I.ev1));
-    if (vector_mode_) init_vector(dg);
+    init_vector(dg);   // the run-time-n path also serves scattering-group derivatives of engines on the matrix-core path
 }
 
 DeviceEngine::~DeviceEngine() {

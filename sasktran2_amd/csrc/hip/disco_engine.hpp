@@ -41,7 +41,8 @@ class DeviceEngine {
     // With derivs (spherical post-processing only): wf_ext / wf_ssa [ngrid][nwavel][nlos][nstokes], wf_alb [nwavel][nlos][nstokes].
     void solve_device_vector(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg, const double* d_albedo,
                              const double* d_irradiance, int derivs, double* d_radiance, double* d_wf_ext, double* d_wf_ssa, double* d_wf_alb,
-                             double* d_los_od, int* d_status, void* stream);
+                             double* d_los_od, int* d_status, void* stream, int ngroups = 0, const double* d_dleg = nullptr,
+                             double* d_wf_scat = nullptr);   // scattering groups: d_dleg [G][nwavel][ngrid][nleg (*4)], wf_scat [G][ngrid][nwavel][nlos][S]
     size_t bytes_per_wavelength() const;
     size_t scratch_bytes() const;   // scratch currently allocated (all slots)
     int last_chunk() const;         // wavelengths per launch of the last solve
@@ -54,7 +55,7 @@ class DeviceEngine {
   private:
     void ensure_scratch(int nw, int nslots);
     void init_vector(const skgeo::DiscoGeometry& dg);
-    void ensure_vector_scratch(int nw, bool derivs);
+    void ensure_vector_scratch(int nw, bool derivs, int ngroups);
     void destroy_vector();
     Impl* impl_;
     VecImpl* vec_ = nullptr;

@@ -499,3 +499,81 @@ def test_vector_delta_m_scaling_on_device():
     for name, want in (("d_extinction", want_k), ("d_ssa", want_w)):
         scale = np.abs(want).max(axis=3, keepdims=True)
         assert np.max(np.abs(got[name] - want) / np.where(scale > 0, scale, 1.0)) < RTOL_WF, name
+
+
+# ---------------------------------------------------------------------------------------------- scattering-group derivatives
+def _mixture(x, nw=1, nstr=8):
+    """Background atmosphere + a scattering constituent with profile x (number-density like): returns the scenario and what a
+    constituent's derivative mapping holds (d_extinction, d_ssa, d_legendre = constituent - mixture coefficients, scat_factor),
+    the reference's convention (src/sasktran2/constituent, cpp/lib/output/outputc.cpp:60-90)."""
+    s = sc.regression_1d(nw)
+    s = dict(s, config=dict(s["config"], nstr=nstr))
+    ka = s["extinction"]
+    wa = np.full_like(ka, 0.93)
+    nl = 16
+    l = np.arange(nl)
+    ba = np.zeros(nl)
+    ba[0], ba[1], ba[2] = 1.0, 0.08, 0.5
+    bc = (2 * l + 1) * 0.6 ** l
+    e, wc = 0.3 * ka, 0.95
+    k = ka + x[:, None] * e
+    sca = ka * wa + x[:, None] * e * wc
+    w = sca / k
+    beta = ((ka * wa)[None] * ba[:, None, None] + (x[:, None] * e * wc)[None] * bc[:, None, None]) / sca[None]
+    mapping = dict(d_extinction=e, d_ssa=e * (wc - w) / k, d_legendre=bc[:, None, None] - beta, scat_factor=e * wc / sca)
+    return dict(s, extinction=k, ssa=w, leg=beta), mapping
+
+
+@pytest.mark.parametrize("nstr", [8, 16], ids=["8 streams", "16 streams (matrix-core engine, routed)"])
+def test_scattering_group_derivatives_match_finite_differences(nstr):
+    """A derivative mapping with d_legendre / scat_factor (a scattering constituent's number-density weighting function) through the C ABI:
+    analytic == central finite differences of the product's own radiances, the reference's criterion for weighting functions."""
+    import ctypes
+    from tests.gpu_harness import build_engine
+    import sasktran2_amd as sk
+    ng, nw = 25, 1
+    x0 = np.ones(ng)
+    s, mp = _mixture(x0, nw, nstr)
+    engine, config, geometry = build_engine(s)
+    dp, vp = ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
+    nlos = len(s["rays"])
+
+    def hook(L, h_st, h_out, out):
+        m = vp()
+        L.sk_atmosphere_storage_get_derivative_mapping(h_st, b"wf_scatterer", ctypes.byref(m))
+        for which, arr in (("d_extinction", mp["d_extinction"]), ("d_ssa", mp["d_ssa"])):
+            ptr = dp()
+            getattr(L, f"sk_deriv_mapping_get_{which}")(m, ctypes.byref(ptr))
+            np.ctypeslib.as_array(ptr, shape=(ng * nw,))[:] = arr.T.reshape(-1)
+        for fn, arr, size in (("sk_deriv_mapping_get_scat_factor", mp["scat_factor"].T.reshape(-1), ng * nw),
+                              ("sk_deriv_mapping_get_d_legendre", np.asfortranarray(mp["d_legendre"]).ravel(order="F"), 16 * ng * nw)):
+            f = getattr(L, fn)
+            f.argtypes = [vp, ctypes.POINTER(dp)]
+            ptr = dp()
+            assert f(m, ctypes.byref(ptr)) == 0
+            np.ctypeslib.as_array(ptr, shape=(size,))[:] = arr
+        out["wf_scatterer"] = np.zeros((ng, nw, nlos, 1))
+        L.sk_output_assign_derivative_memory(h_out, b"wf_scatterer", out["wf_scatterer"].ctypes.data_as(dp), nw * nlos, 1, ng)
+
+    def solve(scn, with_hook):
+        atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=with_hook)
+        atmosphere.storage.total_extinction[:] = scn["extinction"]
+        atmosphere.storage.ssa[:] = scn["ssa"]
+        atmosphere.leg_coeff.a1[:] = scn["leg"]
+        atmosphere.surface.albedo[:] = scn["albedo"]
+        return engine.calculate_radiance(atmosphere, as_dataset=False, _mapping_hook=hook if with_hook else None)
+
+    res = solve(s, True)
+    # the plain mappings of the same solve agree with the oracle (the run-time-n kernels serve the whole request)
+    ora = run_oracle(s, derivatives=True)
+    np.testing.assert_allclose(res["radiance"][..., 0], ora["radiance"], rtol=RTOL_I)
+    scale = np.abs(ora["d_extinction"]).max(axis=2, keepdims=True)
+    assert np.max(np.abs(np.transpose(res["wf_extinction"][..., 0], (1, 2, 0)) - ora["d_extinction"]) / scale) < RTOL_WF
+    for q in (0, 4, 9, 17, 24):
+        h = 1e-5
+        xp, xm = x0.copy(), x0.copy()
+        xp[q] += h
+        xm[q] -= h
+        fd = (solve(_mixture(xp, nw, nstr)[0], False)["radiance"] - solve(_mixture(xm, nw, nstr)[0], False)["radiance"]) / (2 * h)
+        an = res["wf_scatterer"][q]
+        assert np.max(np.abs(fd - an)) < 1e-5 * np.abs(res["wf_scatterer"]).max(), q
