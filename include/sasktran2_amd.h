@@ -6,7 +6,7 @@
  * Each declaration cites the reference header line it replaces (paths relative to /root/reference).
  *
  * Return codes (cpp/c_api/engine.cpp:52-85,116-138): 0 success, -1 null/invalid handle, -2 unsupported mode
- * (NSTOKES other than 1 / 3, non-DISCO sources, refraction, scattering-group derivatives), -3 runtime failure (message on stderr).
+ * (NSTOKES other than 1 / 3, non-DISCO sources, refraction, emission derivatives), -3 runtime failure (message on stderr).
  * No exception crosses the ABI.  All numeric arrays are caller-owned; the library only reads/writes them
  * during calls (cpp/include/sasktran2/atmosphere/grid_storage.h:77-102).
  *
@@ -14,7 +14,7 @@
  * multiple_scatter_source = discrete_ordinates (0), single_scatter_source in
  * {discrete_ordinates (2), none (3)}, Geometry1D in spherical, pseudo-spherical or plane-parallel form with linear
  * interpolation, Lambertian surface, delta-M scaling, derivative mappings with d_extinction / d_ssa (optionally with an
- * interpolator and in log-radiance space; no scattering groups / d_legendre / d_emission) and surface d_brdf.
+ * interpolator and in log-radiance space, and with d_legendre / scat_factor = scattering-group derivatives; no d_emission) and surface d_brdf.
  * Everything is computed on the GPU; there is no CPU fallback.
  */
 #ifndef SASKTRAN2_AMD_H
@@ -230,9 +230,9 @@ BRDF* sk_brdf_create_modis(int nstokes);                                        
 int sk_brdf_get_num_deriv(BRDF* config, int* num_deriv);                                       /* brdf.h:13 */
 int sk_brdf_get_num_args(BRDF* config, int* num_args);                                         /* brdf.h:14 */
 
-/* deriv_mapping.h:10-86 -- interpolators ([ngrid x nout], column-major) and log-radiance space are applied on the device
- * (cpp/lib/output/outputc.cpp:108-132); scattering-group / Legendre / emission derivative settings are stored, and a mapping
- * that uses them makes sk_engine_calculate_radiance return -2 */
+/* deriv_mapping.h:10-86 -- interpolators ([ngrid x nout], column-major), log-radiance space and scattering-group mappings
+ * (d_legendre [nleg, nloc, nwavel], scat_factor) are applied on the device (cpp/lib/output/outputc.cpp:60-132); emission derivative
+ * settings are stored, and a mapping that uses them makes sk_engine_calculate_radiance return -2 */
 int sk_deriv_mapping_destroy(DerivativeMapping* mapping);                                      /* deriv_mapping.h:10 */
 int sk_deriv_mapping_get_scat_factor(DerivativeMapping* mapping, double** scat_factor);        /* deriv_mapping.h:15 */
 int sk_deriv_mapping_get_d_legendre(DerivativeMapping* mapping, double** d_legendre);          /* deriv_mapping.h:17 */
