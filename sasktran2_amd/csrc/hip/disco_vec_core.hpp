@@ -771,12 +771,126 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
     }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Gauss-Jordan inverse with partial pivoting of an M2 x M2 matrix (M2 = 16 T) by a team of 256 lanes that keeps the matrix and the
+// growing inverse in registers: element (r, c) lives in lane (r % 16, c % 16), slot (r / 16, c / 16).  Per pivot two barriers: the
+// candidates of the pivot search, then the pivot row, the displaced row and the pivot column through `buf` (LDS, double-buffered by
+// pivot parity); every lane then updates its 2 T^2 elements with fused multiply-adds.  D is read, Dinv written (row-major, LDS or HBM).
+template <int T> __device__ bool gj_inverse_registers(const double* D, double* Dinv, double* buf) {
+    constexpr int MP = 16 * T;
+    const int lane = threadIdx.x, ly = lane >> 4, lx = lane & 15;
+    double a[T][T], b[T][T];
+#pragma unroll
+    for (int rb = 0; rb < T; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < T; ++cb) {
+            const int r = rb * 16 + ly, c = cb * 16 + lx;
+            a[rb][cb] = D[r * MP + c];
+            b[rb][cb] = (r == c) ? 1.0 : 0.0;
+        }
+    double* cand = buf + 10 * MP;   // [2][32]
+    bool ok = true;
+#pragma unroll
+    for (int kb = 0; kb < T; ++kb)
+        for (int kl = 0; kl < 16 && ok; ++kl) {
+            const int cc = kb * 16 + kl, par = cc & 1;
+            double* rowp = buf + par * 5 * MP;   // [2 MP] row that becomes the pivot row (old row piv): matrix part, inverse part
+            double* rowc = rowp + 2 * MP;        // [2 MP] old row cc
+            double* colf = rowp + 4 * MP;        // [MP]   column cc
+            double* cnd = cand + par * 32;
+            // ---- pivot search over rows >= cc of column cc
+            if (lx == kl) {
+                double best = -1.0;
+                int brow = cc;
+#pragma unroll
+                for (int rb = 0; rb < T; ++rb) {
+                    const int r = rb * 16 + ly;
+                    const double v = fabs(a[rb][kb]);
+                    if (r >= cc && v > best) { best = v; brow = r; }
+                }
+                cnd[ly] = best;
+                cnd[16 + ly] = double(brow);
+            }
+            __syncthreads();
+            double pv = -1.0;
+            int piv = cc;
+            for (int t = 0; t < 16; ++t) {
+                const double v = cnd[t];
+                const int rr = int(cnd[16 + t]);
+                if (v > pv || (v == pv && rr < piv)) { pv = v; piv = rr; }
+            }
+            if (!(pv > 0)) { ok = false; break; }
+            const int prb = piv >> 4, pl = piv & 15;
+            // ---- publish the two rows and the column
+            if (ly == pl) {
+#pragma unroll
+                for (int cb = 0; cb < T; ++cb) {
+                    double va = 0, vb = 0;
+#pragma unroll
+                    for (int rb = 0; rb < T; ++rb)
+                        if (rb == prb) { va = a[rb][cb]; vb = b[rb][cb]; }
+                    rowp[cb * 16 + lx] = va;
+                    rowp[MP + cb * 16 + lx] = vb;
+                }
+            }
+            if (ly == kl) {
+#pragma unroll
+                for (int cb = 0; cb < T; ++cb) {
+                    rowc[cb * 16 + lx] = a[kb][cb];
+                    rowc[MP + cb * 16 + lx] = b[kb][cb];
+                }
+            }
+            if (lx == kl) {
+#pragma unroll
+                for (int rb = 0; rb < T; ++rb) colf[rb * 16 + ly] = a[rb][kb];
+            }
+            __syncthreads();
+            // ---- update: row cc <- (old row piv) / pivot, row piv <- old row cc, every row r != cc loses f_r times the new pivot row
+            const double inv = 1.0 / rowp[cc];
+            double pa[T], pb[T];
+#pragma unroll
+            for (int cb = 0; cb < T; ++cb) {
+                pa[cb] = rowp[cb * 16 + lx] * inv;
+                pb[cb] = rowp[MP + cb * 16 + lx] * inv;
+            }
+#pragma unroll
+            for (int rb = 0; rb < T; ++rb) {
+                const int r = rb * 16 + ly;
+                if (r == cc) {
+#pragma unroll
+                    for (int cb = 0; cb < T; ++cb) { a[rb][cb] = pa[cb]; b[rb][cb] = pb[cb]; }
+                } else if (r == piv) {
+                    const double f = colf[cc];   // the displaced row cc carries its own column-cc entry
+#pragma unroll
+                    for (int cb = 0; cb < T; ++cb) {
+                        a[rb][cb] = rowc[cb * 16 + lx] - f * pa[cb];
+                        b[rb][cb] = rowc[MP + cb * 16 + lx] - f * pb[cb];
+                    }
+                } else {
+                    const double f = colf[r];
+                    if (f != 0.0) {
+#pragma unroll
+                        for (int cb = 0; cb < T; ++cb) { a[rb][cb] -= f * pa[cb]; b[rb][cb] -= f * pb[cb]; }
+                    }
+                }
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < T; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < T; ++cb) Dinv[(rb * 16 + ly) * MP + cb * 16 + lx] = b[rb][cb];
+    __syncthreads();
+    return ok;
+}
+#endif
+
 // =================================================================================================
 // KV2: block-tridiagonal boundary value problem, factor + solve                 (task = wavelength, one team)
 //   same block rows as skd::k2a_bvp with 2n x 2n blocks; team-shared work space: ws (8 n^2 + 10 n doubles: the block and its
 //   inverse, vectors) and t1 (2 n^2 doubles), which may live in different memories (LDS / HBM)
 // =================================================================================================
-SKD_HD size_t kv2_scratch_main(int n) { return 8 * size_t(n) * n + 10 * size_t(n); }
+SKD_HD size_t kv2_scratch_main(int n) { return 8 * size_t(n) * n + 30 * size_t(n) + 64; }
 SKD_HD size_t kv2_scratch_t1(int n) { return 2 * size_t(n) * n; }
 SKD_HD size_t kv2_scratch(int n) { return kv2_scratch_main(n) + kv2_scratch_t1(n); }
 
@@ -787,6 +901,7 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
     const double kd = 2.0;
     const int mm = M2 * M2;
     double *D = ws, *Dinv = ws + mm, *r = ws + 2 * mm, *rprev = r + M2, *xn = rprev + M2, *fcol = xn + M2, *refl = fcol + M2;  // refl: 2n
+    double* gjbuf = refl + 2 * n;  // 10 M2 + 64 doubles, exchange buffers of the register-resident inversion
     bool singular = false;
     for (int p = 0; p < nlyr; ++p) {
         const double* c = vrec_at(v, nlyr, p, w);
@@ -794,8 +909,9 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
         team.sync();
         if (p > 0) {
             // T1 = Sub_p Dinv_{p-1},  Sub_p rows A = [W+_{p-1} E_{p-1} | W-_{p-1}]   (Dinv still holds layer p - 1)
+            // stored transposed, T1[j][i], with the lanes running over i: coalesced reads of W+-_{p-1}, broadcast reads of Dinv
             SKV_PAR(e, n * M2) {
-                const int i = e / M2, j = e % M2;
+                const int i = e % n, j = e / n;
                 T1[e] = sum4(0, n, [&](int q) {
                     return cprev[R.WP() + i + n * q] * cprev[R.E() + q] * Dinv[q * M2 + j] + cprev[R.WM() + i + n * q] * Dinv[(n + q) * M2 + j];
                 });
@@ -815,7 +931,7 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
         }
         team.sync();
         SKV_PAR(e, n * n) {
-            const int i = e / n, j = e % n;
+            const int i = e % n, j = e / n;   // lanes over i: coalesced W+-(i, j), consecutive T1[.][i], broadcast W+-(q, j)
             const double wp = c[R.WP() + i + n * j], wm = c[R.WM() + i + n * j], Ej = c[R.E() + j];
             double d00 = -wp, d01 = -wm * Ej, d10 = wm * Ej, d11 = wp;
             if (p == nlyr - 1 && m == 0 && (i % S) == 0) {
@@ -823,8 +939,8 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
                 d11 -= refl[n + j];
             }
             if (p > 0) {
-                d00 += sum4(0, n, [&](int q) { return T1[i * M2 + n + q] * c[R.WM() + q + n * j]; });
-                d01 += sum4(0, n, [&](int q) { return T1[i * M2 + n + q] * c[R.WP() + q + n * j]; }) * Ej;
+                d00 += sum4(0, n, [&](int q) { return T1[(n + q) * n + i] * c[R.WM() + q + n * j]; });
+                d01 += sum4(0, n, [&](int q) { return T1[(n + q) * n + i] * c[R.WP() + q + n * j]; }) * Ej;
             }
             D[i * M2 + j] = d00;
             D[i * M2 + n + j] = d01;
@@ -843,16 +959,24 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
                 rb += vrec_at(v, nlyr, p + 1, w)[R.G() + 1 * n + i];
             }
             if (p > 0) {
-                ra -= cprev[R.G() + 2 * n + i] + sum4(0, M2, [&](int q) { return T1[i * M2 + q] * rprev[q]; });
+                ra -= cprev[R.G() + 2 * n + i] + sum4(0, M2, [&](int q) { return T1[q * n + i] * rprev[q]; });
             }
             r[i] = ra;
             r[n + i] = rb;
         }
         team.sync();
-        // Gauss-Jordan inverse with partial pivoting
-        SKV_PAR(e, mm) Dinv[e] = (e / M2 == e % M2) ? 1.0 : 0.0;
+        // Gauss-Jordan inverse with partial pivoting: register-resident for 256-lane teams and 48 x 48 / 96 x 96 blocks, else in place
+        bool inverted = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (team.width == 256 && (M2 == 48 || M2 == 96)) {
+            const bool ok = (M2 == 48) ? gj_inverse_registers<3>(D, Dinv, gjbuf) : gj_inverse_registers<6>(D, Dinv, gjbuf);
+            if (!ok) singular = true;
+            inverted = true;
+        }
+#endif
+        if (!inverted) SKV_PAR(e, mm) Dinv[e] = (e / M2 == e % M2) ? 1.0 : 0.0;
         team.sync();
-        for (int cc = 0; cc < M2; ++cc) {
+        for (int cc = 0; cc < M2 && !inverted; ++cc) {
             int piv = cc;
             double best = fabs(D[cc * M2 + cc]);
             for (int rr = cc + 1; rr < M2; ++rr) {
