@@ -492,10 +492,6 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
             }
         }
         if (!group_of.empty()) {
-            if (e->dev->plane_parallel()) {
-                set_error("sk_engine_calculate_radiance: scattering-group derivatives need a spherical geometry");
-                return -2;
-            }
             const size_t per_g = nloc_w * st.nleg;
             d_dleg = (double*)C.get("d_legendre", group_of.size() * per_g * 8);
             for (auto& kv : group_of)

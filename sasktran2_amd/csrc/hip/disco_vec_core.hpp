@@ -1598,9 +1598,9 @@ SKD_HD void kv2b_adjoint(const Geo& g, const VGeo& vg, const Bufs& b, const VBuf
 //   reference: OpticalLayer::integrate_source sktran_do_opticallayer.cpp:93-555, computeReflectedIntensities
 //   sktran_do_layerarray.cpp:5-288, DOSourcePlaneParallelPostProcessing::calculate do_source_planeparallel.cpp:60-218
 //   With v.derivs the same adjoint machinery as the spherical mode runs per Stokes component (u_p = dI/d(L_p, M_p) supplied
-//   directly, as skd::kpp_los): the operators of kv2c_layer_ops must be up to date.   scratch: 21 n doubles per thread
+//   directly, as skd::kpp_los): the operators of kv2c_layer_ops must be up to date.   scratch: (21 + 8 G) n doubles per thread
 // =================================================================================================
-SKD_HD size_t kvpp_scratch(int n) { return 21 * size_t(n); }
+SKD_HD size_t kvpp_scratch(int n, int G = 0) { return (21 + 8 * size_t(G)) * size_t(n); }
 
 SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int los, int w, Scr scr) {
     const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
@@ -1614,7 +1614,10 @@ SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v
     const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * kPi);
     const bool derivs = v.derivs != 0;
     Scr yp = scr.sub(0), ym = scr.sub(3 * size_t(n)), dyp = scr.sub(6 * size_t(n)), dym = scr.sub(9 * size_t(n)), lrow = scr.sub(12 * size_t(n)),
-        carry = scr.sub(14 * size_t(n)), u = scr.sub(17 * size_t(n)), yv = scr.sub(19 * size_t(n));  // yp .. dym: [S][n]; carry: [S][n]
+        carry = scr.sub(14 * size_t(n)), u = scr.sub(17 * size_t(n)), yv = scr.sub(19 * size_t(n)),  // yp .. dym: [S][n]; carry: [S][n]
+        gy = scr.sub(21 * size_t(n));  // per scattering group: d yp, d ym [S][n] each (6 n), d lrow (2 n)
+    const int NG = derivs ? v.ngroups : 0;
+    const VRec RG(n, v.ngroups);
     const double azf[3] = {cos(m * g.pp_azi[los]), cos(m * g.pp_azi[los]), sin(m * g.pp_azi[los])};
     double att = 1.0;  // attenuation to the observer
     double total[3] = {0, 0, 0};
@@ -1633,6 +1636,11 @@ SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v
         if (in) {
             // Y+-[s][a] = sum_r lp[s][r] W+-(r,a) + lm[s][r] W-+(r,a);  lm = (om w_j / 2) [Pi(out) B Pi(mu_j)], lp the negated product
             for (int e = 0; e < S * n; ++e) { yp[e] = 0; ym[e] = 0; dyp[e] = 0; dym[e] = 0; }
+            for (int gi = 0; gi < NG; ++gi)
+                for (int e = 0; e < 6 * n; ++e) gy[size_t(gi) * 8 * n + e] = 0;
+            double Qg[4][3];
+            for (int gi = 0; gi < 4; ++gi)
+                for (int cc = 0; cc < 3; ++cc) Qg[gi][cc] = 0;
             for (int l = m; l < nstr; ++l) {
                 double c4[4];
                 load_coef(b, v, nstr, p, l, w, c4);
@@ -1680,9 +1688,63 @@ SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v
                     }
                     // solar single-scatter term: first column of the negated product with the sun direction
                     if (g.include_ss) Q[s1] += sg * brow[0] * lpc[l] * fm * om;
+                    // scattering groups: d(lrow) W + lrow dW_g  (direction dc of the coefficients)
+                    for (int gi = 0; gi < NG && gi < 4; ++gi) {
+                        Scr gyp = gy.sub(size_t(gi) * 8 * n), gym = gy.sub(size_t(gi) * 8 * n + 3 * size_t(n)), dl = gy.sub(size_t(gi) * 8 * n + 6 * size_t(n));
+                        double dc4[4], dbrow[3];
+                        load_dcoef(g, b, v, gi, p, l, w, dc4);
+                        greek_apply(dc4, prow, dbrow);
+                        for (int j = 0; j < N; ++j) {
+                            const Fun3 fj = fun_mu(g, vg, m, j);
+                            const double wj = 0.5 * om * g.wt[j];
+                            if (S == 1) {
+                                const double t = dbrow[0] * fj.P[l] * wj;
+                                dl[j] = t;
+                                dl[n + j] = sg * t;
+                            } else {
+                                double y0[3], y1[3];
+                                const double bd[3] = {dbrow[0], dbrow[1], -dbrow[2]};
+                                pi_apply(fj.P[l], fj.R[l], fj.T[l], dbrow, y0);
+                                pi_apply(fj.P[l], fj.R[l], fj.T[l], bd, y1);
+                                for (int s2 = 0; s2 < 3; ++s2) {
+                                    dl[j * 3 + s2] = y0[s2] * wj;
+                                    dl[n + j * 3 + s2] = sg * y1[s2] * wj;
+                                }
+                            }
+                        }
+                        for (int a = 0; a < n; ++a) {
+                            double tp = 0, tm = 0;
+                            for (int r = 0; r < n; ++r) {
+                                const double wp = c[R.WP() + r + n * a], wm = c[R.WM() + r + n * a];
+                                const double dwp = c[RG.GDWP(gi) + r + n * a], dwm = c[RG.GDWM(gi) + r + n * a];
+                                tp += dl[n + r] * wp + dl[r] * wm + lrow[n + r] * dwp + lrow[r] * dwm;
+                                tm += dl[n + r] * wm + dl[r] * wp + lrow[n + r] * dwm + lrow[r] * dwp;
+                            }
+                            gyp[size_t(s1) * n + a] += tp;
+                            gym[size_t(s1) * n + a] += tm;
+                        }
+                        if (g.include_ss) Qg[gi][s1] += sg * dbrow[0] * lpc[l] * fm * om;
+                    }
                 }
             }
             skd::pp_beam_multiplier(mu, lf, th, T, sc, Eb);
+            // group rows of the layer source (no explicit 1 / omega here: the source is not divided by omega in this mode)
+            for (int gi = 0; gi < NG && gi < 4; ++gi) {
+                Scr gyp = gy.sub(size_t(gi) * 8 * n), gym = gy.sub(size_t(gi) * 8 * n + 3 * size_t(n));
+                for (int s1 = 0; s1 < S; ++s1) {
+                    double dSg = Qg[gi][s1] * Eb.v;
+                    for (int a = 0; a < n; ++a) {
+                        skd::PPLosMult pm;
+                        skd::pp_los_multipliers(mu, lf, th, T, sc, c[R.K() + a], Eb, pm);
+                        const double L = xs[a], Mv = xs[n + a], Ap = c[R.AP() + a], Am = c[R.AM() + a];
+                        const double dk = c[RG.GDK(gi) + a], dAp = c[RG.GDAP(gi) + a], dAm = c[RG.GDAM(gi) + a];
+                        const double y_p = yp[size_t(s1) * n + a], y_m = ym[size_t(s1) * n + a];
+                        dSg += gyp[size_t(s1) * n + a] * (pm.hp * L + Ap * pm.Dm) + gym[size_t(s1) * n + a] * (pm.hm * Mv + Am * pm.Dp) +
+                               y_p * (pm.hp_k * dk * L + dAp * pm.Dm + Ap * pm.Dm_k * dk) + y_m * (pm.hm_k * dk * Mv + dAm * pm.Dp + Am * pm.Dp_k * dk);
+                    }
+                    v.grad[size_t(4 * nlyr + 2 + gi * nlyr + p) * nt3 + tid * S + s1] += att * azf[s1] * dSg;
+                }
+            }
         }
         for (int s1 = 0; s1 < S; ++s1) {
             const double A = att * azf[s1];

@@ -73,7 +73,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
         xsol(size_t(nlyr) * 2 * n * nw), J(size_t(nstr) * std::max(t.nslot, 1) * nw * S, 0.0), rad(nt * S, 0.0);
     const int NL = skv::legendre_space(g, S), ngrid = t.ngrid;
     const size_t nt3 = nt * S;
-    std::vector<double> scratch(std::max({skv::kv1_scratch(n), skv::kv2_scratch(n), skv::kv3_scratch(n, nstr), skv::kvpp_scratch(n),
+    std::vector<double> scratch(std::max({skv::kv1_scratch(n), skv::kv2_scratch(n), skv::kv3_scratch(n, nstr), skv::kvpp_scratch(n, ngroups),
                                           skv::kv2c_scratch(n, NL, ngroups), skv::kv2b_scratch(n, NL)}));
     const int G = derivatives ? ngroups : 0;
     std::vector<double> ops(derivatives ? size_t(nlyr) * skv::VOps(n, NL, G).size() * nw : 1), zb(derivatives ? size_t(nlyr) * 2 * n * nt3 : 1),
@@ -110,7 +110,10 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
             b3.grad = grad.data();
             b3.dnat = dnat.data();
             for (int w = 0; w < nw; ++w)
-                for (int l3 = 0; l3 < nlos * S; ++l3) skd::k4a_chain(g3, b3, 0, l3, w);
+                for (int l3 = 0; l3 < nlos * S; ++l3) {
+                    skd::k4a_chain(g3, b3, 0, l3, w);
+                    skv::kv4g_chain(g, b, v, w, size_t(w) * nlos * S + l3, nt3);
+                }
         }
     } else {
         for (int s = 0; s < g.nsza; ++s) {

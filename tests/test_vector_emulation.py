@@ -83,3 +83,52 @@ def test_vector_weighting_functions_match_oracle_spherical_and_planeparallel():
 def test_scalar_weighting_functions_through_the_runtime_n_bodies():
     s = sc.regression_1d(2)
     _wf_close(run_emulated_vector(s, derivatives=True), run_oracle(s, derivatives=True))
+
+
+def _mixture_spherical(x, vector):
+    """Background + a scattering constituent with profile x; returns the scenario and the constituent's mapping arrays (see
+    tests/test_gpu_parity.py::_mixture).  vector: the constituent also carries a2 / b1 (polarising) coefficients."""
+    s = sc.regression_1d(1)
+    ka = s["extinction"]
+    wa = np.full_like(ka, 0.93)
+    nl = 16
+    l = np.arange(nl)
+    ba = np.zeros(nl)
+    ba[0], ba[1], ba[2] = 1.0, 0.08, 0.5
+    bc = (2 * l + 1) * 0.6 ** l
+    e, wc = 0.3 * ka, 0.95
+    k = ka + x[:, None] * e
+    sca = ka * wa + x[:, None] * e * wc
+    w = sca / k
+    beta = ((ka * wa)[None] * ba[:, None, None] + (x[:, None] * e * wc)[None] * bc[:, None, None]) / sca[None]
+    out = dict(s, extinction=k, ssa=w, leg=beta)
+    dleg = bc[:, None, None] - beta
+    if vector:
+        out = sc.to_vector(out, rayleigh_fraction=None)
+        frac = x[:, None] * e * wc / sca
+        out["leg"][4 * 2 + 1] = 3.0 * frac
+        out["leg"][4 * 2 + 3] = -np.sqrt(6.0) * 0.5 * frac
+        bc4 = np.zeros(4 * nl)
+        bc4[0::4] = bc
+        bc4[4 * 2 + 1], bc4[4 * 2 + 3] = 3.0, -np.sqrt(6.0) * 0.5
+        dleg = bc4[:, None, None] - out["leg"]
+    return out, dict(d_extinction=e, d_ssa=e * (wc - w) / k, scat_factor=e * wc / sca, d_legendre=dleg)
+
+
+@pytest.mark.parametrize("vector", [False, True], ids=["NSTOKES=1", "NSTOKES=3"])
+def test_scattering_group_derivatives_match_finite_differences_emulated(vector):
+    """Number-density weighting function of a scattering constituent = d_extinction dI/dk + d_ssa dI/dw + scat_factor dI/dscat
+    (cpp/lib/output/outputc.cpp:60-90) against central finite differences of the radiances."""
+    x0 = np.ones(25)
+    s, mp = _mixture_spherical(x0, vector)
+    out = run_emulated_vector(s, derivatives=True, d_legendre=[mp["d_legendre"]])
+    for q in (0, 9, 24):
+        h = 1e-5
+        xp, xm = x0.copy(), x0.copy()
+        xp[q] += h
+        xm[q] -= h
+        fd = (run_emulated_vector(_mixture_spherical(xp, vector)[0])["radiance"] - run_emulated_vector(_mixture_spherical(xm, vector)[0])["radiance"]) / (2 * h)
+        scat = out["d_scat"][:, :, :, 0, q] if vector else out["d_scat"][:, :, 0, q]
+        an = mp["d_extinction"][q, 0] * out["d_extinction"][..., q] + mp["d_ssa"][q, 0] * out["d_ssa"][..., q] + mp["scat_factor"][q, 0] * scat
+        assert np.abs(mp["scat_factor"][q, 0] * scat).max() > 0.05 * np.abs(an).max()   # the scattering part matters
+        assert np.abs(fd - an).max() < 1e-6 * np.abs(an).max(), q
