@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[2]))
 from tests import scenarios as sc
 from tests.gpu_harness import build_engine, run_product
 
