@@ -59,7 +59,8 @@ struct VBufs {
     int derivs;
     // scattering-group derivatives (directional derivatives wrt the layer Greek coefficients, sktran_do_layerarray.cpp:496-513,759-860)
     int ngroups;            // G
-    const double* dleg;     // [g][w][q][nleg][4 | 1]  d_legendre of the scattering derivative mappings, caller layout
+    const double* dleg;     // [g][wavelength of the whole spectrum][q][nleg][4 | 1]  d_legendre of the scattering derivative mappings
+    int dleg_nw, dleg_w0;   // wavelengths of the whole spectrum and offset of this block in it
     double* da4;            // [g][p][l][4][w]  direction of the layer coefficients for group g
     double* scratch;        // [element][thread] work matrices of the running kernel
     size_t scratch_stride;  // threads of the running kernel
@@ -183,7 +184,7 @@ SKD_HD void kv0_coefficients(const Geo& g, const Bufs& b, const VBufs& v, int w)
             const int qs = (g.wq_idx[2 * p + 1] >= 0) ? g.wq_idx[2 * p + 1] : g.wq_idx[2 * p];
             const double fq = b.delta_f ? b.delta_f[size_t(w) * ngrid + qs] : 0.0, fsub = fq / (1 - fq);
             for (int gi = 0; gi < v.ngroups; ++gi) {
-                const double* dl = v.dleg + ((size_t(gi) * nw + w) * ngrid + qs) * v.nleg * per;
+                const double* dl = v.dleg + ((size_t(gi) * v.dleg_nw + v.dleg_w0 + w) * ngrid + qs) * v.nleg * per;
                 for (int l = 0; l < nstr; ++l) {
                     const bool have = l < v.nleg;
                     const double* c = leg + (size_t(qs) * v.nleg + l) * per;

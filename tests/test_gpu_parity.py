@@ -577,3 +577,13 @@ def test_scattering_group_derivatives_match_finite_differences(nstr):
         fd = (solve(_mixture(xp, nw, nstr)[0], False)["radiance"] - solve(_mixture(xm, nw, nstr)[0], False)["radiance"]) / (2 * h)
         an = res["wf_scatterer"][q]
         assert np.max(np.abs(fd - an)) < 1e-5 * np.abs(res["wf_scatterer"]).max(), q
+
+
+def test_vector_results_do_not_depend_on_the_block_size(monkeypatch):
+    # blocks of the spectrum are independent: a chunked solve is bit-identical (radiances, weighting functions, group derivatives' inputs)
+    s = sc.to_vector(sc.regression_1d(5), rayleigh_fraction=0.9)
+    full = run_product(s, derivatives=True)
+    monkeypatch.setenv("SASKTRAN2_AMD_CHUNK", "2")
+    part = run_product(s, derivatives=True)
+    for k in ("radiance", "d_extinction", "d_ssa", "d_albedo", "los_optical_depth"):
+        assert np.array_equal(full[k], part[k]), k
