@@ -158,7 +158,9 @@ def main():
     # (tools/profile_gpu.sh -> profiles/<round>/pmc_and_trace_summary.json; FETCH_SIZE x2-corrected as the guide prescribes)
     pmc = load_pmc_profile()
     kp = pmc.get(dominant, {})
-    flop_bound = dominant in ("k1_layer_solution", "k2a_bvp")  # dependent FP64 chains / matrix-core steps, little HBM traffic
+    # the four kernels that carry the solve (layer eigen-solution, BVP elimination, adjoint operators, adjoint sweeps) are FP64
+    # vector / matrix-core kernels: they are priced against the FP64 peak; `traffic` and `hbm_traffic_frac` show their HBM side
+    flop_bound = dominant in ("k1_layer_solution", "k2a_bvp", "k2c_adjoint_ops", "k2b_adjoint")
     if flop_bound and kp.get("flops_per_wavelength"):
         achieved = kp["flops_per_wavelength"] * chunk / avg_launch_s / 1e12
         roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -173,6 +175,8 @@ def main():
                     "note": "achieved = algorithmic bytes of the whole path (28 160 B / wavelength) per launch of this kernel; "
                             "the kernel's own HBM traffic is in `traffic`"}
     roofline["traffic"] = kp["hbm_bytes_per_wavelength"] * chunk if kp.get("hbm_bytes_per_wavelength") else None
+    if roofline["traffic"]:
+        roofline["hbm_traffic_frac"] = roofline["traffic"] / avg_launch_s / 1e9 / HBM_PEAK_GBS   # measured bytes, not algorithmic ones
     roofline.update({"algorithmic_bytes_per_wavelength": ALGORITHMIC_BYTES_PER_WAVELENGTH, "wavelengths_per_launch": chunk,
                      "avg_launch_ms": dom_ms / dom_n, "launches": dom_n})
 
@@ -192,6 +196,10 @@ def main():
             "valid": finite and status_bad == 0,
             "roofline": roofline,
             "whole_step": whole_step_rates(pmc, value),
+            # SURVEY.md 8d asks for both whole-path figures: algorithmic bytes (28 160 B / wavelength) and counted FP64 operations
+            "whole_path": {"achieved_hbm_algorithmic_GBs": ALGORITHMIC_BYTES_PER_WAVELENGTH * value / 1e9,
+                           "achieved_hbm_algorithmic_frac": ALGORITHMIC_BYTES_PER_WAVELENGTH * value / 1e9 / HBM_PEAK_GBS,
+                           "achieved_fp64_frac": (whole_step_rates(pmc, value) or {}).get("fp64_frac_of_78.6")},
             "kernels_ms": {k: {"total_ms": round(v[0], 3), "launches": v[1]} for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])},
             "scratch_gib": run_scratch / 2 ** 30,
         }

@@ -1319,6 +1319,14 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b
 //             rows 4..7 carry sum_i zB_i for the ground terms)
 //   Y / Z tiles and the HD part are kept in HBM between the sweeps in their C/D register images
 //   (b.z: [w][p][tile][4][64], b.qlbuf: [w][p][tile][64]); nothing goes through LDS.
+// streamed once between the sweeps: optional non-temporal access (experiment switch SKD_EXP_NT)
+#ifdef SKD_EXP_NT
+#define SKD_NT_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define SKD_NT_LD(ptr) __builtin_nontemporal_load((ptr))
+#else
+#define SKD_NT_ST(ptr, val) (*(ptr) = (val))
+#define SKD_NT_LD(ptr) (*(ptr))
+#endif
 template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2b_mfma8(Geo g, Bufs b, int s, int m) {
     // the one- and two-tile instantiations must round identically (results do not depend on the launch shape): no implicit
     // contraction of a * b + c in this kernel, fused multiply-adds are written out
@@ -1411,8 +1419,8 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
                 if (last && last_is_ground)
                     for (int r = 0; r < 4; ++r) acc[r] += ops[O::UG + q + 4 * r] * gw[t];
                 double* zt = zw + (size_t(p) * ntile + tile0 + t) * 256;
-                for (int r = 0; r < 4; ++r) zt[64 * r + lane] = acc[r];
-                hw[(size_t(p) * ntile + tile0 + t) * 64 + lane] = hacc[0];
+                for (int r = 0; r < 4; ++r) SKD_NT_ST(&zt[64 * r + lane], acc[r]);
+                SKD_NT_ST(&hw[(size_t(p) * ntile + tile0 + t) * 64 + lane], hacc[0]);
                 yprev[t] = acc;
             }
             for (int kk = 0; kk < 4; ++kk) { fpa[kk] = nfpa[kk]; hda[kk] = nhda[kk]; }
@@ -1440,7 +1448,7 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
                 if ((tile0 + t) >= ntile) continue;
                 const double* zt = zw + (size_t(p) * ntile + tile0 + t) * 256;
                 mf4 z;
-                for (int r = 0; r < 4; ++r) z[r] = zt[64 * r + lane];
+                for (int r = 0; r < 4; ++r) z[r] = SKD_NT_LD(&zt[64 * r + lane]);
                 if (!last)
                     for (int kk = 0; kk < 2; ++kk) z = mfma16(bpa[kk], znext[t][kk], z);
                 // finish the layer below (p + 1) with zB_p and write it out
@@ -1450,7 +1458,7 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
                     if (ok[t]) b.grad[size_t(q * nlyr + p + 1) * nt + size_t(w) * nlos + los[t]] += gp[0];
                 }
                 // this layer: HD part from the forward sweep, zA_p, zB_p, zA_{p+1}
-                mf4 ga = {hw[(size_t(p) * ntile + tile0 + t) * 64 + lane], 0, 0, 0};
+                mf4 ga = {SKD_NT_LD(&hw[(size_t(p) * ntile + tile0 + t) * 64 + lane]), 0, 0, 0};
                 for (int kk = 0; kk < 2; ++kk) ga = mfma16(e0[kk], z[kk], ga);
                 for (int kk = 0; kk < 2; ++kk) ga = mfma16(e3[kk], z[2 + kk], ga);
                 if (!last)
