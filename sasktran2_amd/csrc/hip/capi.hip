@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -541,7 +542,10 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
             scattering_groups = scattering_groups || is_scattering_mapping(*it->second);
         }
         // scattering-group derivatives are served by the run-time-n kernels for every stream count
-        if (e->dev->vector_mode() || (scattering_groups && atm->derivs && e->config.wf_enabled)) return calculate_radiance_vector(e, atm, out);
+        // SASKTRAN2_AMD_RUNTIME_N=1 sends every request through the run-time-n kernels (cross-check of the two device implementations)
+        const char* force_env = std::getenv("SASKTRAN2_AMD_RUNTIME_N");
+        const bool force = force_env && atoi(force_env) != 0;
+        if (force || e->dev->vector_mode() || (scattering_groups && atm->derivs && e->config.wf_enabled)) return calculate_radiance_vector(e, atm, out);
         if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
         const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
         if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");

@@ -587,3 +587,17 @@ def test_vector_results_do_not_depend_on_the_block_size(monkeypatch):
     part = run_product(s, derivatives=True)
     for k in ("radiance", "d_extinction", "d_ssa", "d_albedo", "los_optical_depth"):
         assert np.array_equal(full[k], part[k]), k
+
+
+def test_matrix_core_and_runtime_n_kernels_agree(monkeypatch):
+    """Two independent device implementations of the same formulation (16-stream matrix-core kernels vs the run-time-n team kernels)
+    on the C2 shape: radiances to 1e-11, weighting functions to 1e-8 of the profile maximum."""
+    s = sc.limb_c2(num_wavelengths=4)
+    fast = run_product(s, derivatives=True)
+    monkeypatch.setenv("SASKTRAN2_AMD_RUNTIME_N", "1")
+    slow = run_product(s, derivatives=True)
+    np.testing.assert_allclose(slow["radiance"], fast["radiance"], rtol=1e-11)
+    for k in ("d_extinction", "d_ssa"):
+        scale = np.abs(fast[k]).max(axis=2, keepdims=True)
+        assert np.max(np.abs(slow[k] - fast[k]) / scale) < 1e-8, k
+    np.testing.assert_allclose(slow["d_albedo"], fast["d_albedo"], rtol=1e-8)
