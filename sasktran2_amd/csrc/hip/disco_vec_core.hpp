@@ -908,6 +908,7 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
         const double* c = vrec_at(v, nlyr, p, w);
         const double* cprev = (p > 0) ? vrec_at(v, nlyr, p - 1, w) : c;
         team.sync();
+#ifndef SKV_EXP_SKIP_T1
         if (p > 0) {
             // T1 = Sub_p Dinv_{p-1},  Sub_p rows A = [W+_{p-1} E_{p-1} | W-_{p-1}]   (Dinv still holds layer p - 1)
             // stored transposed, T1[j][i], with the lanes running over i: coalesced reads of W+-_{p-1}, broadcast reads of Dinv
@@ -918,6 +919,7 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
                 });
             }
         }
+#endif
         if (p == nlyr - 1 && m == 0) {
             // Lambertian reflection sums over the intensity rows of the downwelling field
             SKV_PAR(j, n) {
@@ -939,10 +941,12 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
                 d10 -= refl[j];
                 d11 -= refl[n + j];
             }
+#ifndef SKV_EXP_SKIP_T1
             if (p > 0) {
                 d00 += sum4(0, n, [&](int q) { return T1[(n + q) * n + i] * c[R.WM() + q + n * j]; });
                 d01 += sum4(0, n, [&](int q) { return T1[(n + q) * n + i] * c[R.WP() + q + n * j]; }) * Ej;
             }
+#endif
             D[i * M2 + j] = d00;
             D[i * M2 + n + j] = d01;
             D[(n + i) * M2 + j] = d10;
@@ -969,7 +973,13 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
         // Gauss-Jordan inverse with partial pivoting: register-resident for 256-lane teams and 48 x 48 / 96 x 96 blocks, else in place
         bool inverted = false;
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifdef SKV_EXP_SKIP_GJ
+        if (true) { SKV_PAR(e, mm) Dinv[e] = (e / M2 == e % M2) ? 1.0 : 0.0; inverted = true; } else
+#endif
         if (team.width == 256 && (M2 == 48 || M2 == 96)) {
+#ifdef SKV_EXP_GJ2X
+            (void)((M2 == 48) ? gj_inverse_registers<3>(D, Dinv, gjbuf) : gj_inverse_registers<6>(D, Dinv, gjbuf));
+#endif
             const bool ok = (M2 == 48) ? gj_inverse_registers<3>(D, Dinv, gjbuf) : gj_inverse_registers<6>(D, Dinv, gjbuf);
             if (!ok) singular = true;
             inverted = true;
