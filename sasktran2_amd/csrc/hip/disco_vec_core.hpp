@@ -886,6 +886,109 @@ template <int T> __device__ bool gj_inverse_registers(const double* D, double* D
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// In-place Gauss-Jordan inverse with partial pivoting of an M2 x M2 matrix (M2 = 8 TS) by ONE wavefront that keeps the matrix in
+// registers: element (r, c) lives in lane (r % 8) * 8 + (c % 8), slot (r / 8, c / 8).  Pivot search, row exchange and the broadcast of
+// the pivot row / column are wave shuffles, so a pivot costs no barrier at all (the 256-lane version above pays two workgroup barriers and
+// several dependent LDS round trips per pivot at one wavefront per SIMD).  The row exchanges are undone as column exchanges when the
+// result is written.  D is read, Dinv written (row-major); ibuf: 2 M2 ints of LDS / HBM scratch.  Call with the lanes of one wavefront.
+template <int TS> __device__ bool gj_inverse_wave(const double* D, double* Dinv, int* ibuf) {
+    constexpr int MP = 8 * TS;
+    const int lane = threadIdx.x & 63, ly = lane >> 3, lx = lane & 7;
+    double a[TS][TS];
+#pragma unroll
+    for (int rb = 0; rb < TS; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < TS; ++cb) a[rb][cb] = D[(rb * 8 + ly) * MP + cb * 8 + lx];
+    int* ipiv = ibuf;        // [MP]
+    int* dst = ibuf + MP;    // [MP] final column of each computed column
+    bool ok = true;
+#pragma unroll
+    for (int kb = 0; kb < TS; ++kb)
+        for (int kl = 0; kl < 8 && ok; ++kl) {
+            const int cc = kb * 8 + kl;
+            // ---- pivot search in column cc (lanes lx == kl hold it), rows >= cc
+            double best = -1.0;
+            int brow = cc;
+#pragma unroll
+            for (int rb = 0; rb < TS; ++rb) {
+                const int r = rb * 8 + ly;
+                const double v = fabs(a[rb][kb]);
+                if (lx == kl && r >= cc && (v > best || (v == best && r < brow))) { best = v; brow = r; }
+            }
+#pragma unroll
+            for (int off = 8; off <= 32; off <<= 1) {   // over ly (lane bits 3..5), same lx
+                const double ob = __shfl_xor(best, off);
+                const int orow = __shfl_xor(brow, off);
+                if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
+            }
+            const double pvabs = __shfl(best, (lane & 56) | kl);
+            const int piv = __shfl(brow, (lane & 56) | kl);
+            if (!(pvabs > 0)) { ok = false; break; }
+            if (lane == 0) ipiv[cc] = piv;
+            const int prb = piv >> 3, pl = piv & 7;
+            // ---- exchange rows cc <-> piv; every lane ends up with the new pivot row's entries of its columns in prow[]
+            double prow[TS];
+#pragma unroll
+            for (int cb = 0; cb < TS; ++cb) {
+                double mine_p = 0;
+#pragma unroll
+                for (int rb = 0; rb < TS; ++rb)
+                    if (rb == prb) mine_p = a[rb][cb];
+                const double xc = __shfl(a[kb][cb], (kl << 3) | lx);    // old row cc
+                const double xp = __shfl(mine_p, (pl << 3) | lx);       // old row piv = new pivot row
+                if (piv != cc) {
+                    if (ly == kl) a[kb][cb] = xp;
+                    if (ly == pl) {
+#pragma unroll
+                        for (int rb = 0; rb < TS; ++rb)
+                            if (rb == prb) a[rb][cb] = xc;
+                    }
+                }
+                prow[cb] = xp;
+            }
+            const double pv = __shfl(prow[kb], (lane & 56) | kl);
+            const double inv = 1.0 / pv;
+            // ---- eliminate: row cc <- row / pivot (its column-cc entry 1 / pivot); row r <- row r - f_r (new row cc), column cc -> -f_r / pivot
+#pragma unroll
+            for (int rb = 0; rb < TS; ++rb) {
+                const int r = rb * 8 + ly;
+                const double f = __shfl(a[rb][kb], (lane & 56) | kl);   // a[r][cc] after the exchange
+                if (r == cc) {
+#pragma unroll
+                    for (int cb = 0; cb < TS; ++cb) a[rb][cb] = prow[cb] * inv;
+                    if (lx == kl) a[rb][kb] = inv;
+                } else {
+#pragma unroll
+                    for (int cb = 0; cb < TS; ++cb) a[rb][cb] -= f * (prow[cb] * inv);
+                    if (lx == kl) a[rb][kb] = -f * inv;
+                }
+            }
+        }
+    // ---- undo the row exchanges as column exchanges (k descending) while writing out
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0 && ok) {
+        for (int c = 0; c < MP; ++c) dst[c] = c;   // dst[c] = computed column that ends at final column c (built as src), inverted below
+        for (int k = MP - 1; k >= 0; --k) {
+            const int p = ipiv[k];
+            if (p != k) { const int t = dst[k]; dst[k] = dst[p]; dst[p] = t; }
+        }
+        // invert: ipiv is free now, reuse it as final column of computed column
+        for (int c = 0; c < MP; ++c) ipiv[dst[c]] = c;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (ok) {
+#pragma unroll
+        for (int rb = 0; rb < TS; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < TS; ++cb) Dinv[(rb * 8 + ly) * MP + ipiv[cb * 8 + lx]] = a[rb][cb];
+    }
+    return ok;
+}
+#endif
+
 // =================================================================================================
 // KV2: block-tridiagonal boundary value problem, factor + solve                 (task = wavelength, one team)
 //   same block rows as skd::k2a_bvp with 2n x 2n blocks; team-shared work space: ws (8 n^2 + 10 n doubles: the block and its
@@ -975,6 +1078,21 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifdef SKV_EXP_SKIP_GJ
         if (true) { SKV_PAR(e, mm) Dinv[e] = (e / M2 == e % M2) ? 1.0 : 0.0; inverted = true; } else
+#endif
+#ifndef SKV_GJ_TEAM
+        if (team.width >= 64 && M2 == 48) {
+            // one wavefront inverts the 48 x 48 block in its registers with shuffles (no barrier per pivot), the others wait.  Measured
+            // (16 streams, 50 layers, 1024 wavelengths): BVP stage 425 -> 330 ms; the 96 x 96 instance (144 doubles per lane) spills and is
+            // 6x slower than the 256-lane version below, which therefore keeps the 32-stream blocks
+            __shared__ int gj_ok;
+            if (team.lane < 64) {
+                const bool ok = gj_inverse_wave<6>(D, Dinv, reinterpret_cast<int*>(gjbuf));
+                if (team.lane == 0) gj_ok = ok ? 1 : 0;
+            }
+            team.sync();
+            if (!gj_ok) singular = true;
+            inverted = true;
+        } else
 #endif
         if (team.width == 256 && (M2 == 48 || M2 == 96)) {
 #ifdef SKV_EXP_GJ2X
