@@ -1521,9 +1521,28 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
     }
     team.sync();
     // ---- FP = Dinv^T F
-    if (table) SKV_PAR(e, M2 * NL) {
-        const int i = e / NL, lam_ = e % NL;
-        o[O.FP() + e] = sum4(0, M2, [&](int j) { return dinv[j * M2 + i] * F[j * NL + lam_]; });
+    if (table) {
+        const int NL4 = (NL + 3) / 4;   // four consecutive Legendre-space columns per item: one load of Dinv feeds four products
+        SKV_PAR(e, M2 * NL4) {
+            const int i = e / NL4, l0 = (e % NL4) * 4;
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            if (l0 + 3 < NL) {
+                for (int j = 0; j < M2; ++j) {
+                    const double dv = dinv[j * M2 + i];
+                    const double* fr = F + j * NL + l0;
+                    a0 += dv * fr[0];
+                    a1 += dv * fr[1];
+                    a2 += dv * fr[2];
+                    a3 += dv * fr[3];
+                }
+                o[O.FP() + i * NL + l0] = a0;
+                o[O.FP() + i * NL + l0 + 1] = a1;
+                o[O.FP() + i * NL + l0 + 2] = a2;
+                o[O.FP() + i * NL + l0 + 3] = a3;
+            } else {
+                for (int l = l0; l < NL; ++l) o[O.FP() + i * NL + l] = sum4(0, M2, [&](int j) { return dinv[j * M2 + i] * F[j * NL + l]; });
+            }
+        }
     }
     // ---- SP = Dinv^T SupT, BP = Dinv^T SubT  (SupT[j][i] = W-(i,j), SupT[n+j][i] = W+(i,j) E_j ; SubT[j][i] = W+(i,j) E_j, SubT[n+j][i] = W-(i,j))
     SKV_PAR(e, M2 * n) {
@@ -1610,6 +1629,28 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
     team.sync();
 }
 
+// out[i] (+)= sum_{k in [k0, K)} A[i * ld + k] * x[k], i < M: eight outputs at a time, so that one load of x[k] (thread-strided scratch) feeds
+// eight fused multiply-adds whose A operands are the same for every lane of a wavefront (broadcast loads)
+template <class Out> SKD_HD void matvec8(const double* A, int ld, int M, int k0, int K, const Scr& x, double sign, Out out) {
+    for (int i0 = 0; i0 < M; i0 += 8) {
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int cnt = (M - i0 < 8) ? M - i0 : 8;
+        if (cnt == 8) {
+            for (int k = k0; k < K; ++k) {
+                const double xv = x[k];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += A[(i0 + u) * ld + k] * xv;
+            }
+        } else {
+            for (int k = k0; k < K; ++k) {
+                const double xv = x[k];
+                for (int u = 0; u < cnt; ++u) acc[u] += A[(i0 + u) * ld + k] * xv;
+            }
+        }
+        for (int u = 0; u < cnt; ++u) out(i0 + u, sign * acc[u]);
+    }
+}
+
 // backward sweep  z_p = y_p - BP zA_{p+1}  and reduced-gradient contraction of one (line of sight, Stokes component); the forward
 // sweep has left y in v.z.  table_weights: the Legendre-space HD term applies (spherical table; false for plane parallel)
 SKD_HD void adjoint_backward_gradient(const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, size_t tid, size_t nt, double gw,
@@ -1620,11 +1661,8 @@ SKD_HD void adjoint_backward_gradient(const Geo& g, const Bufs& b, const VBufs& 
     for (int i = 0; i < n; ++i) carry[i] = 0;
     for (int p = nlyr - 1; p >= 0; --p) {
         const double* ops = vops_at(v, g, p, w);
-        for (int i = 0; i < M2; ++i) {
-            double t = v.z[(size_t(p) * M2 + i) * nt + tid];
-            if (p < nlyr - 1) t -= sum4(0, n, [&](int cidx) { return ops[O.BP() + i * n + cidx] * carry[cidx]; });
-            y[i] = t;
-        }
+        for (int i = 0; i < M2; ++i) y[i] = v.z[(size_t(p) * M2 + i) * nt + tid];
+        if (p < nlyr - 1) matvec8(ops + O.BP(), n, M2, 0, n, carry, -1.0, [&](int i, double t) { y[i] += t; });
         for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
         for (int i = 0; i < n; ++i) carry[i] = y[i];
     }
@@ -1710,12 +1748,9 @@ SKD_HD void kv2b_adjoint(const Geo& g, const VGeo& vg, const Bufs& b, const VBuf
             }
         }
         for (int l = 0; l < NL; ++l) v.qlbuf[(size_t(p) * NL + l) * nt + tid] = ql[l];
-        for (int i = 0; i < M2; ++i) {
-            double t = (p == nlyr - 1) ? gw * ops[O.UG() + i] : 0.0;
-            t += sum4(m * C, NL, [&](int l) { return ops[O.FP() + i * NL + l] * ql[l]; });
-            t += sum4(0, n, [&](int cidx) { return ops[O.SP() + i * n + cidx] * carry[cidx]; });
-            y[i] = t;
-        }
+        for (int i = 0; i < M2; ++i) y[i] = (p == nlyr - 1) ? gw * ops[O.UG() + i] : 0.0;
+        matvec8(ops + O.FP(), NL, M2, m * C, NL, ql, 1.0, [&](int i, double t) { y[i] += t; });
+        matvec8(ops + O.SP(), n, M2, 0, n, carry, 1.0, [&](int i, double t) { y[i] += t; });
         for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
         for (int i = 0; i < n; ++i) carry[i] = y[n + i];
     }
