@@ -57,6 +57,7 @@ struct DerivativeMapping {
     std::vector<double> d_ssa, d_extinction;
     // stored only (deriv_mapping.h:15-53); a mapping that uses them is refused by sk_engine_calculate_radiance
     std::vector<double> scat_factor, d_legendre, d_emission;
+    std::vector<double> d_f;   // [nloc * nwavel] derivative of the delta-M truncation fraction along this scattering group (set by the scaling)
     int scat_deriv_index = -1, log_radiance_space = 0;
     std::string interp_dim = "altitude", assign_name;
     double* interpolator = nullptr;
@@ -480,7 +481,7 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     // scattering derivative groups: one per requested mapping that carries d_legendre / scat_factor (finalize_scattering_derivatives,
     // cpp/include/sasktran2/atmosphere/grid_storage.h:190-214)
     std::map<std::string, int> group_of;
-    double *d_dleg = nullptr, *d_wg = nullptr;
+    double *d_dleg = nullptr, *d_wg = nullptr, *d_dfg = nullptr;
     if (derivs) {
         d_we = (double*)C.get("wf_ext", size_t(ngrid) * nt * S * 8);
         d_ws = (double*)C.get("wf_ssa", size_t(ngrid) * nt * S * 8);
@@ -498,6 +499,14 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
             for (auto& kv : group_of)
                 HIPC(hipMemcpy(d_dleg + size_t(kv.second) * per_g, st.maps.at(kv.first)->d_legendre.data(), per_g * 8, hipMemcpyHostToDevice));
             d_wg = (double*)C.get("wf_scat", group_of.size() * size_t(ngrid) * nt * S * 8);
+            if (!st.delta_f.empty()) {
+                d_dfg = (double*)C.get("d_f_groups", group_of.size() * nloc_w * 8);
+                for (auto& kv : group_of) {
+                    const auto& df = st.maps.at(kv.first)->d_f;
+                    if (df.size() != nloc_w) throw std::runtime_error("scattering mapping " + kv.first + " was created after the delta-M scaling");
+                    HIPC(hipMemcpy(d_dfg + size_t(kv.second) * nloc_w, df.data(), nloc_w * 8, hipMemcpyHostToDevice));
+                }
+            }
         }
     }
     double* d_f = nullptr;
@@ -507,7 +516,7 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     }
     e->dev->set_delta_m_fraction(d_f);
     e->dev->solve_device_vector(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status, nullptr,
-                                (int)group_of.size(), d_dleg, d_wg);
+                                (int)group_of.size(), d_dleg, d_wg, d_dfg);
     e->dev->set_delta_m_fraction(nullptr);
     hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
     HIPC(hipGetLastError());

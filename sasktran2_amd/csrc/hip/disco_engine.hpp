@@ -42,7 +42,7 @@ class DeviceEngine {
     void solve_device_vector(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg, const double* d_albedo,
                              const double* d_irradiance, int derivs, double* d_radiance, double* d_wf_ext, double* d_wf_ssa, double* d_wf_alb,
                              double* d_los_od, int* d_status, void* stream, int ngroups = 0, const double* d_dleg = nullptr,
-                             double* d_wf_scat = nullptr);   // scattering groups: d_dleg [G][nwavel][ngrid][nleg (*4)], wf_scat [G][ngrid][nwavel][nlos][S]
+                             double* d_wf_scat = nullptr, const double* d_dfg = nullptr);   // scattering groups: d_dleg [G][nwavel][ngrid][nleg (*4)], wf_scat [G][ngrid][nwavel][nlos][S]
     size_t bytes_per_wavelength() const;
     size_t scratch_bytes() const;   // scratch currently allocated (all slots)
     int last_chunk() const;         // wavelengths per launch of the last solve

@@ -61,6 +61,7 @@ struct VBufs {
     int ngroups;            // G
     const double* dleg;     // [g][wavelength of the whole spectrum][q][nleg][4 | 1]  d_legendre of the scattering derivative mappings
     int dleg_nw, dleg_w0;   // wavelengths of the whole spectrum and offset of this block in it
+    const double* dfg;      // [g][wavelength of the whole spectrum][q] d(delta-M truncation fraction) along the group, or null
     double* da4;            // [g][p][l][4][w]  direction of the layer coefficients for group g
     double* scratch;        // [element][thread] work matrices of the running kernel
     size_t scratch_stride;  // threads of the running kernel
@@ -191,10 +192,12 @@ SKD_HD void kv0_coefficients(const Geo& g, const Bufs& b, const VBufs& v, int w)
                     const double* a = v.a4 + (size_t(p) * nstr + l) * 4 * nw + w;
                     double* d = v.da4 + ((size_t(gi) * nlyr + p) * nstr + l) * 4 * nw + w;
                     for (int cc = 0; cc < 4; ++cc) d[size_t(cc) * nw] = 0;
-                    d[0] = (have ? dl[l * per] + c[0] : 0.0) - (2 * l + 1) * fsub - a[0];
+                    // the group also moves the truncation fraction: -(2l + 1) d_f / (1 - f)^2 on a1, a2, a3 (sktran_do_layerarray.cpp:777-790,826-843)
+                    const double dft = v.dfg ? (2 * l + 1) * v.dfg[(size_t(gi) * v.dleg_nw + v.dleg_w0 + w) * ngrid + qs] / ((1 - fq) * (1 - fq)) : 0.0;
+                    d[0] = (have ? dl[l * per] + c[0] : 0.0) - (2 * l + 1) * fsub - a[0] - dft;
                     if (S == 3) {
-                        d[size_t(1) * nw] = (have ? dl[l * per + 1] + c[1] : 0.0) - (2 * l + 1) * fsub - a[size_t(1) * nw];
-                        d[size_t(2) * nw] = (have ? dl[l * per + 2] + c[2] : 0.0) - (2 * l + 1) * fsub - a[size_t(2) * nw];
+                        d[size_t(1) * nw] = (have ? dl[l * per + 1] + c[1] : 0.0) - (2 * l + 1) * fsub - a[size_t(1) * nw] - dft;
+                        d[size_t(2) * nw] = (have ? dl[l * per + 2] + c[2] : 0.0) - (2 * l + 1) * fsub - a[size_t(2) * nw] - dft;
                         d[size_t(3) * nw] = (have ? -dl[l * per + 3] - c[3] : 0.0) - a[size_t(3) * nw];
                     }
                 }

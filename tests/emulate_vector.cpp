@@ -83,7 +83,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     v.S = S; v.n = n; v.leg = leg; v.nleg = nleg; v.a4 = a4.data(); v.rec = rec.data(); v.dinv = dinv.data(); v.xsol = xsol.data();
     v.J = J.data(); v.radiance = rad.data(); v.scratch = scratch.data(); v.scratch_stride = 1;
     v.ops = ops.data(); v.z = zb.data(); v.qlbuf = qlb.data(); v.grad = grad.data(); v.dnat = dnat.data(); v.derivs = derivatives;
-    v.ngroups = G; v.dleg = d_legendre; v.dleg_nw = nw; v.dleg_w0 = 0; v.da4 = da4.data();
+    v.ngroups = G; v.dleg = d_legendre; v.dleg_nw = nw; v.dleg_w0 = 0; v.dfg = nullptr; v.da4 = da4.data();
     const skv::Scr scr{scratch.data(), 1};
     const skv::Team team{0, 1};
     double* ws = scratch.data();

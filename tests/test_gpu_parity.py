@@ -502,7 +502,7 @@ def test_vector_delta_m_scaling_on_device():
 
 
 # ---------------------------------------------------------------------------------------------- scattering-group derivatives
-def _mixture(x, nw=1, nstr=8):
+def _mixture(x, nw=1, nstr=8, g=0.6):
     """Background atmosphere + a scattering constituent with profile x (number-density like): returns the scenario and what a
     constituent's derivative mapping holds (d_extinction, d_ssa, d_legendre = constituent - mixture coefficients, scat_factor),
     the reference's convention (src/sasktran2/constituent, cpp/lib/output/outputc.cpp:60-90)."""
@@ -514,7 +514,7 @@ def _mixture(x, nw=1, nstr=8):
     l = np.arange(nl)
     ba = np.zeros(nl)
     ba[0], ba[1], ba[2] = 1.0, 0.08, 0.5
-    bc = (2 * l + 1) * 0.6 ** l
+    bc = (2 * l + 1) * g ** l
     e, wc = 0.3 * ka, 0.95
     k = ka + x[:, None] * e
     sca = ka * wa + x[:, None] * e * wc
@@ -524,8 +524,9 @@ def _mixture(x, nw=1, nstr=8):
     return dict(s, extinction=k, ssa=w, leg=beta), mapping
 
 
-@pytest.mark.parametrize("nstr", [8, 16], ids=["8 streams", "16 streams (matrix-core engine, routed)"])
-def test_scattering_group_derivatives_match_finite_differences(nstr):
+@pytest.mark.parametrize("nstr,delta_m", [(8, False), (16, False), (8, True)],
+                         ids=["8 streams", "16 streams (matrix-core engine, routed)", "8 streams, delta-M scaled"])
+def test_scattering_group_derivatives_match_finite_differences(nstr, delta_m):
     """A derivative mapping with d_legendre / scat_factor (a scattering constituent's number-density weighting function) through the C ABI:
     analytic == central finite differences of the product's own radiances, the reference's criterion for weighting functions."""
     import ctypes
@@ -533,8 +534,10 @@ def test_scattering_group_derivatives_match_finite_differences(nstr):
     import sasktran2_amd as sk
     ng, nw = 25, 1
     x0 = np.ones(ng)
-    s, mp = _mixture(x0, nw, nstr)
+    gc = 0.85 if delta_m else 0.6   # a forward-peaked constituent for the scaled case: truncation fraction of a few per cent
+    s, mp = _mixture(x0, nw, nstr, gc)
     engine, config, geometry = build_engine(s)
+    config.delta_m_scaling = delta_m   # 16 moments stored, 8 streams: truncation order 8 (the group also moves the truncation fraction)
     dp, vp = ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
     nlos = len(s["rays"])
 
@@ -564,17 +567,18 @@ def test_scattering_group_derivatives_match_finite_differences(nstr):
         return engine.calculate_radiance(atmosphere, as_dataset=False, _mapping_hook=hook if with_hook else None)
 
     res = solve(s, True)
-    # the plain mappings of the same solve agree with the oracle (the run-time-n kernels serve the whole request)
-    ora = run_oracle(s, derivatives=True)
-    np.testing.assert_allclose(res["radiance"][..., 0], ora["radiance"], rtol=RTOL_I)
-    scale = np.abs(ora["d_extinction"]).max(axis=2, keepdims=True)
-    assert np.max(np.abs(np.transpose(res["wf_extinction"][..., 0], (1, 2, 0)) - ora["d_extinction"]) / scale) < RTOL_WF
+    if not delta_m:
+        # the plain mappings of the same solve agree with the oracle (the run-time-n kernels serve the whole request)
+        ora = run_oracle(s, derivatives=True)
+        np.testing.assert_allclose(res["radiance"][..., 0], ora["radiance"], rtol=RTOL_I)
+        scale = np.abs(ora["d_extinction"]).max(axis=2, keepdims=True)
+        assert np.max(np.abs(np.transpose(res["wf_extinction"][..., 0], (1, 2, 0)) - ora["d_extinction"]) / scale) < RTOL_WF
     for q in (0, 4, 9, 17, 24):
         h = 1e-5
         xp, xm = x0.copy(), x0.copy()
         xp[q] += h
         xm[q] -= h
-        fd = (solve(_mixture(xp, nw, nstr)[0], False)["radiance"] - solve(_mixture(xm, nw, nstr)[0], False)["radiance"]) / (2 * h)
+        fd = (solve(_mixture(xp, nw, nstr, gc)[0], False)["radiance"] - solve(_mixture(xm, nw, nstr, gc)[0], False)["radiance"]) / (2 * h)
         an = res["wf_scatterer"][q]
         assert np.max(np.abs(fd - an)) < 1e-5 * np.abs(res["wf_scatterer"]).max(), q
 
