@@ -605,3 +605,45 @@ def test_matrix_core_and_runtime_n_kernels_agree(monkeypatch):
         scale = np.abs(fast[k]).max(axis=2, keepdims=True)
         assert np.max(np.abs(slow[k] - fast[k]) / scale) < 1e-8, k
     np.testing.assert_allclose(slow["d_albedo"], fast["d_albedo"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_polarised_atmospheres_match_oracle(seed):
+    """Randomised polarised scenes (layers, stream count incl. odd half-counts, optical thickness, albedo, Rayleigh-like Greek coefficients mixed
+    with an unpolarised Henyey-Greenstein part, geometry type) through the C ABI with NSTOKES = 3 against the oracle, weighting functions included."""
+    rng = np.random.default_rng(977 + seed)
+    nlyr = int(rng.integers(2, 25))
+    nstr = int(rng.choice([4, 6, 8, 10, 16]))
+    nw = 2
+    spherical = rng.random() < 0.7
+    alt = np.linspace(0.0, float(rng.uniform(30_000.0, 90_000.0)), nlyr + 1)
+    csz = float(rng.uniform(0.2, 0.9))
+    rays = []
+    for _ in range(int(rng.integers(1, 8))):
+        if spherical and rng.random() < 0.6:
+            rays.append((sc.TANGENT_ALTITUDE_SOLAR, csz, float(rng.uniform(-3, 3)), 600_000.0, float(rng.uniform(0.05, 0.9) * alt[-1])))
+        else:
+            rays.append((sc.GROUND_VIEWING_SOLAR, csz, float(rng.uniform(-3, 3)), 600_000.0, float(rng.uniform(0.2, 1.0))))
+    scale = 10.0 ** rng.uniform(-6.0, -3.5)
+    k = (scale * np.exp(-alt / rng.uniform(5_000.0, 12_000.0))[:, None] + 1e-10) * np.linspace(0.8, 1.3, nw)[None, :]
+    ssa = np.clip(rng.uniform(0.4, 0.98) + 0.03 * rng.standard_normal((alt.size, nw)), 0.05, 0.999)
+    g_hg, l = rng.uniform(0.0, 0.8), np.arange(nstr)
+    c = rng.uniform(0.0, 0.6) * np.exp(-alt / 9_000.0)
+    ray = np.zeros(nstr)
+    ray[0] = 1.0
+    if nstr > 2:
+        ray[2] = 0.5
+    a1 = ((1 - c)[None, :] * ray[:, None] + c[None, :] * ((2 * l + 1) * g_hg ** l)[:, None])[:, :, None] * np.ones((1, 1, nw))
+    base = dict(geometry=dict(cos_sza=csz, saa=float(rng.uniform(-1, 1)), earth_radius=6_372_000.0, altitudes=alt,
+                              interp_method=sc.INTERP_LINEAR, geotype=sc.GEO_SPHERICAL if spherical else sc.GEO_PLANEPARALLEL),
+                config=dict(nstr=nstr, num_sza=int(rng.integers(1, 3)) if spherical else 1), rays=rays, extinction=k, ssa=ssa, leg=a1,
+                albedo=rng.uniform(0.0, 0.9, nw))
+    s = sc.to_vector(base, rayleigh_fraction=None)
+    if nstr > 2:   # Rayleigh part of the polarising coefficients, weighted like the Rayleigh part of a1
+        s["leg"][4 * 2 + 1] = 6.0 * 0.5 * (1 - c)[:, None]
+        s["leg"][4 * 2 + 3] = -np.sqrt(6.0) * 0.5 * (1 - c)[:, None]
+        s["leg"][4 * 1 + 2] = 0.0
+    got, ref = run_product(s, derivatives=True), run_oracle(s, derivatives=True)
+    np.testing.assert_allclose(got["radiance"][..., 0], ref["radiance"][..., 0], rtol=RTOL_I)
+    assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-8 * np.abs(ref["radiance"]).max()
+    _assert_vector_wf_parity(got, ref)
