@@ -342,7 +342,7 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
     }
     team.sync();
     // ---- Jacobi with the round-robin ("tournament") ordering: n/2 disjoint rotations per step, applied as A <- J^T A J
-    {
+    auto jacobi = [&](double* Mx) {
         const int np = (n + 1) & ~1, half = np / 2;
         double* rc = rot;          // cos of pair k
         double* rs = rot + half;   // sin of pair k (0 when the pair is skipped)
@@ -350,8 +350,8 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
         for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
             double off = 0, dia = 0;
             for (int i = 0; i < n; ++i) {
-                dia += Bm[i * n + i] * Bm[i * n + i];
-                for (int j = i + 1; j < n; ++j) off += Bm[i * n + j] * Bm[i * n + j];
+                dia += Mx[i * n + i] * Mx[i * n + i];
+                for (int j = i + 1; j < n; ++j) off += Mx[i * n + j] * Mx[i * n + j];
             }
             if (off <= 1e-30 * dia || off == 0) { converged = true; break; }
             for (int step = 0; step < np - 1; ++step) {
@@ -368,9 +368,9 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
                     pair_of(k, pp, q);
                     double c = 1.0, sn = 0.0;
                     if (q < n) {
-                        const double apq = Bm[pp * n + q];
+                        const double apq = Mx[pp * n + q];
                         if (apq != 0.0) {
-                            const double app = Bm[pp * n + pp], aqq = Bm[q * n + q];
+                            const double app = Mx[pp * n + pp], aqq = Mx[q * n + q];
                             const double theta = (aqq - app) / (2.0 * apq);
                             const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                             c = 1.0 / sqrt(t * t + 1.0);
@@ -387,9 +387,9 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
                     if (sn != 0.0) {
                         int pp, q;
                         pair_of(k, pp, q);
-                        const double arp = Bm[r * n + pp], arq = Bm[r * n + q];
-                        Bm[r * n + pp] = c * arp - sn * arq;
-                        Bm[r * n + q] = sn * arp + c * arq;
+                        const double arp = Mx[r * n + pp], arq = Mx[r * n + q];
+                        Mx[r * n + pp] = c * arp - sn * arq;
+                        Mx[r * n + q] = sn * arp + c * arq;
                         const double vrp = V[r * n + pp], vrq = V[r * n + q];
                         V[r * n + pp] = c * vrp - sn * vrq;
                         V[r * n + q] = sn * vrp + c * vrq;
@@ -402,19 +402,28 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
                     if (sn != 0.0) {
                         int pp, q;
                         pair_of(k, pp, q);
-                        const double apc = Bm[pp * n + cidx], aqc = Bm[q * n + cidx];
+                        const double apc = Mx[pp * n + cidx], aqc = Mx[q * n + cidx];
                         double vp_ = c * apc - sn * aqc, vq_ = sn * apc + c * aqc;
                         if (cidx == q) vp_ = 0.0;   // the rotated pair is annihilated exactly
                         if (cidx == pp) vq_ = 0.0;
-                        Bm[pp * n + cidx] = vp_;
-                        Bm[q * n + cidx] = vq_;
+                        Mx[pp * n + cidx] = vp_;
+                        Mx[q * n + cidx] = vq_;
                     }
                 }
             }
             team.sync();
         }
         if (!converged) err |= skd::ERR_EIGEN;
-    }
+    };
+#ifdef SKV_EXP_JAC2X
+    SKV_PAR(e, nn) Tm[e] = Bm[e];
+    team.sync();
+    jacobi(Tm);
+    team.sync();
+    SKV_PAR(e, nn) V[e] = (e / n == e % n) ? 1.0 : 0.0;
+    team.sync();
+#endif
+    jacobi(Bm);
     team.sync();
     SKV_PAR(j, n) {
         double l_ = Bm[j * n + j];
