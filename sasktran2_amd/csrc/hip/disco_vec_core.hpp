@@ -243,6 +243,43 @@ template <class F> SKD_HD double sum4(int lo, int hi, F f) {
     return (t0 + t1) + (t2 + t3);
 }
 
+// Team matrix product  C(i, j) = sum_{k < K} A(i, k) B(k, j),  i < M, j < N, with operands and result given by functors.  On the device
+// every wavefront of the team takes 16 x 16 output tiles in turn and accumulates them on the FP64 matrix cores
+// (v_mfma_f64_16x16x4_f64: A lane l = A[l & 15][l >> 4], B lane l = B[l >> 4][l & 15], D register r = D[(l >> 4) + 4 r][l & 15]), one
+// operand load of each kind per lane and 1024 multiply-adds per instruction; on the CPU (emulation) it is the plain triple loop.
+// The caller separates it from neighbouring phases with team.sync().
+template <class FA, class FB, class FC> SKD_HD void team_gemm(const Team& team, int M, int N, int K, FA a, FB b, FC store) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef double mf4v __attribute__((ext_vector_type(4)));
+    const int wave = team.lane >> 6, nwaves = (team.width + 63) >> 6, l = team.lane & 63;
+    const int tn = (N + 15) / 16, ntile = ((M + 15) / 16) * tn;
+    const int lr = l & 15, kq = l >> 4;
+    for (int t = wave; t < ntile; t += nwaves) {
+        const int i0 = (t / tn) * 16, j0 = (t % tn) * 16;
+        const int ar = i0 + lr, bc = j0 + lr;
+        mf4v acc = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + kq;
+            const double av = (ar < M && k < K) ? a(ar, k) : 0.0;
+            const double bv = (bc < N && k < K) ? b(k, bc) : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i0 + kq + 4 * r, col = j0 + lr;
+            if (row < M && col < N) store(row, col, acc[r]);
+        }
+    }
+#else
+    SKV_PAR(e, M * N) {
+        const int i = e / N, j = e % N;
+        double t = 0;
+        for (int k = 0; k < K; ++k) t += a(i, k) * b(k, j);
+        store(i, j, t);
+    }
+#endif
+}
+
 // =================================================================================================
 // KV1: homogeneous + particular solution of one layer for azimuth order m    (task = wavelength x layer, one team)
 //   ws: 8 n^2 + 20 n + 64 doubles of team-shared work space (LDS when it fits, HBM otherwise)
@@ -326,20 +363,18 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
         team.sync();
     }
     // ---- As = L^T B- L (into Bm)
-    SKV_PAR(e, nn) {
-        const int i = e / n, j = e % n;
-        Tm[e] = sum4(j, n, [&](int r) { return Bm[i * n + r] * Bp[r * n + j]; });
-    }
+    // (the strict upper triangle of the Cholesky factor is zero, so the full-range products are the triangular ones)
+    team_gemm(team, n, n, n, [&](int i, int r) { return Bm[i * n + r]; }, [&](int r, int j) { return Bp[r * n + j]; },
+              [&](int i, int j, double val) { Tm[i * n + j] = val; });
     team.sync();
-    SKV_PAR(e, nn) {
-        const int i = e / n, j = e % n;
-        if (j <= i) {
-            const double t = sum4(i, n, [&](int r) { return Bp[r * n + i] * Tm[r * n + j]; });
-            Bm[i * n + j] = t;
-            Bm[j * n + i] = t;
-        }
-        V[e] = (i == j) ? 1.0 : 0.0;
-    }
+    team_gemm(team, n, n, n, [&](int i, int r) { return Bp[r * n + i]; }, [&](int r, int j) { return Tm[r * n + j]; },
+              [&](int i, int j, double val) {
+                  if (j <= i) {   // one writer per unordered pair: exactly symmetric storage
+                      Bm[i * n + j] = val;
+                      Bm[j * n + i] = val;
+                  }
+              });
+    SKV_PAR(e, nn) V[e] = (e / n == e % n) ? 1.0 : 0.0;
     team.sync();
     // ---- Jacobi with the round-robin ("tournament") ordering: n/2 disjoint rotations per step, applied as A <- J^T A J
     auto jacobi = [&](double* Mx) {
@@ -442,11 +477,8 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
         for (int i = 0; i < n; ++i) X[i * n + j] /= sqrt(rw(i) * rmu(i));
     }
     team.sync();
-    SKV_PAR(e, nn) {
-        const int i = e / n, j = e % n;
-        const double t = sum4(0, n, [&](int r) { return rw(r) * Ep[i * n + r] * X[r * n + j]; });
-        U[e] = (X[e] - om * t) / rmu(i);
-    }
+    team_gemm(team, n, n, n, [&](int i, int r) { return rw(r) * Ep[i * n + r]; }, [&](int r, int j) { return X[r * n + j]; },
+              [&](int i, int j, double val) { U[i * n + j] = (X[i * n + j] - om * val) / rmu(i); });
     team.sync();
     // ---- omega derivatives by bi-orthogonal perturbation theory (left vectors W M S+ X), as skd::k1_layer_solution:
     //      d(Gamma) X_j = [2 lam_j X_j - M^-1 U_j - S- M^-1 X_j] / om ;  dk_j = z_jj / (2 k_j) ;  dX = X C, C_ab = z_ab / (lam_b - lam_a)
@@ -1027,12 +1059,9 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
         if (p > 0) {
             // T1 = Sub_p Dinv_{p-1},  Sub_p rows A = [W+_{p-1} E_{p-1} | W-_{p-1}]   (Dinv still holds layer p - 1)
             // stored transposed, T1[j][i], with the lanes running over i: coalesced reads of W+-_{p-1}, broadcast reads of Dinv
-            SKV_PAR(e, n * M2) {
-                const int i = e % n, j = e / n;
-                T1[e] = sum4(0, n, [&](int q) {
-                    return cprev[R.WP() + i + n * q] * cprev[R.E() + q] * Dinv[q * M2 + j] + cprev[R.WM() + i + n * q] * Dinv[(n + q) * M2 + j];
-                });
-            }
+            team_gemm(team, n, M2, M2,
+                      [&](int i, int k) { return k < n ? cprev[R.WP() + i + n * k] * cprev[R.E() + k] : cprev[R.WM() + i + n * (k - n)]; },
+                      [&](int k, int j) { return Dinv[k * M2 + j]; }, [&](int i, int j, double val) { T1[j * n + i] = val; });
         }
 #endif
         if (p == nlyr - 1 && m == 0) {
@@ -1056,17 +1085,20 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
                 d10 -= refl[j];
                 d11 -= refl[n + j];
             }
-#ifndef SKV_EXP_SKIP_T1
-            if (p > 0) {
-                d00 += sum4(0, n, [&](int q) { return T1[(n + q) * n + i] * c[R.WM() + q + n * j]; });
-                d01 += sum4(0, n, [&](int q) { return T1[(n + q) * n + i] * c[R.WP() + q + n * j]; }) * Ej;
-            }
-#endif
             D[i * M2 + j] = d00;
             D[i * M2 + n + j] = d01;
             D[(n + i) * M2 + j] = d10;
             D[(n + i) * M2 + n + j] = d11;
         }
+#ifndef SKV_EXP_SKIP_T1
+        if (p > 0) {
+            // rows A += T1[:, n:] [W-_p | W+_p E_p]
+            team.sync();
+            team_gemm(team, n, M2, n, [&](int i, int k) { return T1[(n + k) * n + i]; },
+                      [&](int k, int j) { return j < n ? c[R.WM() + k + n * j] : c[R.WP() + k + n * (j - n)] * c[R.E() + (j - n)]; },
+                      [&](int i, int j, double val) { D[i * M2 + j] += val; });
+        }
+#endif
         SKV_PAR(i, n) {
             double ra = c[R.G() + 0 * n + i], rb = -c[R.G() + 3 * n + i];
             if (p == nlyr - 1) {
@@ -1533,41 +1565,21 @@ SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const
     }
     team.sync();
     // ---- FP = Dinv^T F
-    if (table) {
-        const int NL4 = (NL + 3) / 4;   // four consecutive Legendre-space columns per item: one load of Dinv feeds four products
-        SKV_PAR(e, M2 * NL4) {
-            const int i = e / NL4, l0 = (e % NL4) * 4;
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            if (l0 + 3 < NL) {
-                for (int j = 0; j < M2; ++j) {
-                    const double dv = dinv[j * M2 + i];
-                    const double* fr = F + j * NL + l0;
-                    a0 += dv * fr[0];
-                    a1 += dv * fr[1];
-                    a2 += dv * fr[2];
-                    a3 += dv * fr[3];
-                }
-                o[O.FP() + i * NL + l0] = a0;
-                o[O.FP() + i * NL + l0 + 1] = a1;
-                o[O.FP() + i * NL + l0 + 2] = a2;
-                o[O.FP() + i * NL + l0 + 3] = a3;
-            } else {
-                for (int l = l0; l < NL; ++l) o[O.FP() + i * NL + l] = sum4(0, M2, [&](int j) { return dinv[j * M2 + i] * F[j * NL + l]; });
-            }
-        }
-    }
+    if (table)
+        team_gemm(team, M2, NL, M2, [&](int i, int j) { return dinv[j * M2 + i]; }, [&](int j, int lam_) { return F[j * NL + lam_]; },
+                  [&](int i, int lam_, double val) { o[O.FP() + i * NL + lam_] = val; });
     // ---- SP = Dinv^T SupT, BP = Dinv^T SubT  (SupT[j][i] = W-(i,j), SupT[n+j][i] = W+(i,j) E_j ; SubT[j][i] = W+(i,j) E_j, SubT[n+j][i] = W-(i,j))
-    SKV_PAR(e, M2 * n) {
-        const int i = e / n, cidx = e % n;
-        double t1 = 0, t2 = 0;
-        for (int j = 0; j < n; ++j) {
-            const double wp = c[R.WP() + cidx + n * j], wm = c[R.WM() + cidx + n * j], E = c[R.E() + j];
-            t1 += dinv[j * M2 + i] * wm + dinv[(n + j) * M2 + i] * wp * E;
-            t2 += dinv[j * M2 + i] * wp * E + dinv[(n + j) * M2 + i] * wm;
-        }
-        o[O.SP() + e] = t1;
-        o[O.BP() + e] = t2;
-    }
+    team_gemm(team, M2, M2, M2, [&](int i, int j) { return dinv[j * M2 + i]; },
+              [&](int j, int cc) {   // columns 0 .. n-1: SupT, n .. 2n-1: SubT
+                  const int cidx = cc < n ? cc : cc - n, jj = j < n ? j : j - n;
+                  const double wp = c[R.WP() + cidx + n * jj], wm = c[R.WM() + cidx + n * jj], E = c[R.E() + jj];
+                  const bool minus = (cc < n) == (j < n);   // SupT rows j < n and SubT rows j >= n carry W-
+                  return minus ? wm : wp * E;
+              },
+              [&](int i, int cc, double val) {
+                  if (cc < n) o[O.SP() + i * n + cc] = val;
+                  else o[O.BP() + i * n + (cc - n)] = val;
+              });
     // ---- edge-intensity derivatives at fixed (L, M), one row per lane
     SKV_PAR(i, n) {
         double d_tau[4] = {0, 0, 0, 0}, d_om[4] = {0, 0, 0, 0}, ipb_i = c[R.G() + 2 * n + i];
