@@ -1677,20 +1677,11 @@ template <class Out> SKD_HD void matvec8(const double* A, int ld, int M, int k0,
 
 // backward sweep  z_p = y_p - BP zA_{p+1}  and reduced-gradient contraction of one (line of sight, Stokes component); the forward
 // sweep has left y in v.z.  table_weights: the Legendre-space HD term applies (spherical table; false for plane parallel)
-SKD_HD void adjoint_backward_gradient(const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, size_t tid, size_t nt, double gw,
-                                      bool table_weights, Scr y, Scr carry) {
+// reduced-gradient contraction of one (line of sight, Stokes component) from the adjoint vectors z left in v.z
+SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, size_t tid, size_t nt, double gw,
+                                    bool table_weights) {
     const int S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
     const VOps O(n, NL, v.ngroups);
-    // ---- backward sweep  z_p = y_p - BP zA_{p+1}
-    for (int i = 0; i < n; ++i) carry[i] = 0;
-    for (int p = nlyr - 1; p >= 0; --p) {
-        const double* ops = vops_at(v, g, p, w);
-        for (int i = 0; i < M2; ++i) y[i] = v.z[(size_t(p) * M2 + i) * nt + tid];
-        if (p < nlyr - 1) matvec8(ops + O.BP(), n, M2, 0, n, carry, -1.0, [&](int i, double t) { y[i] += t; });
-        for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
-        for (int i = 0; i < n; ++i) carry[i] = y[i];
-    }
-    // ---- reduced gradient
     for (int p = 0; p < nlyr; ++p) {
         const double* ops = vops_at(v, g, p, w);
         const bool last = (p == nlyr - 1);
@@ -1733,6 +1724,22 @@ SKD_HD void adjoint_backward_gradient(const Geo& g, const Bufs& b, const VBufs& 
             v.grad[size_t(4 * nlyr + 2 + gi * nlyr + p) * nt + tid] += gg;
         }
     }
+}
+
+SKD_HD void adjoint_backward_gradient(const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, size_t tid, size_t nt, double gw,
+                                      bool table_weights, Scr y, Scr carry) {
+    const int S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
+    const VOps O(n, NL, v.ngroups);
+    // ---- backward sweep  z_p = y_p - BP zA_{p+1}
+    for (int i = 0; i < n; ++i) carry[i] = 0;
+    for (int p = nlyr - 1; p >= 0; --p) {
+        const double* ops = vops_at(v, g, p, w);
+        for (int i = 0; i < M2; ++i) y[i] = v.z[(size_t(p) * M2 + i) * nt + tid];
+        if (p < nlyr - 1) matvec8(ops + O.BP(), n, M2, 0, n, carry, -1.0, [&](int i, double t) { y[i] += t; });
+        for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
+        for (int i = 0; i < n; ++i) carry[i] = y[i];
+    }
+    adjoint_gradient_column(g, b, v, s, m, w, tid, nt, gw, table_weights);
 }
 
 // KV2B: adjoint sweep of one (line of sight, Stokes component) for azimuth order m   (task = wavelength x LOS x Stokes)
@@ -1779,6 +1786,93 @@ SKD_HD void kv2b_adjoint(const Geo& g, const VGeo& vg, const Bufs& b, const VBuf
         for (int i = 0; i < n; ++i) carry[i] = y[n + i];
     }
     adjoint_backward_gradient(g, b, v, s, m, w, tid, nt, gw, true, y, carry);
+}
+
+// KV2B (team form): the adjoint sweeps of ALL (line of sight, Stokes component) columns of one wavelength as matrix products
+//   Y_p = FP QL_p + SP Y_{p-1}[n:] (+ gw UG),   Z_p = Y_p - BP Z_{p+1}[:n]      (M2 x NC, NC = nlos * S columns)
+// on the matrix cores (team_gemm), then the reduced-gradient contraction per column.   (task = wavelength, one team)
+//   ws: (NL + 3 n + 1) NC doubles of team-shared work space: QL [NL][NC], Y [2n][NC], carry [n][NC], gw [NC]
+SKD_HD size_t kv2bt_scratch(int n, int NL, int NC) { return (size_t(NL) + 3 * size_t(n) + 1) * size_t(NC); }
+
+SKD_HD void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int w, double* ws) {
+    const int S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr, NC = g.nlos * S;
+    const VOps O(n, NL, v.ngroups);
+    const size_t nt = size_t(nw) * NC, t0 = size_t(w) * NC;
+    double *QL = ws, *Y = QL + size_t(NL) * NC, *Cc = Y + size_t(M2) * NC, *gwv = Cc + size_t(n) * NC;
+    SKV_PAR(col, NC) {
+        const int los = col / S, sout = col % S;
+        double gw = 0;  // the Lambertian ground feeds the intensity only
+        if (sout == 0 && m == 0 && g.ray_ground[los]) {
+            for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t)
+                if (g.g_sza[t] == s && skd::conv_at(b, g, g.g_slot[t], w) > m) gw += g.g_w[t];
+            gw *= b.att_total[size_t(los) * nw + w];
+        }
+        gwv[col] = gw;
+        for (int i = 0; i < n; ++i) Cc[size_t(i) * NC + col] = 0;
+    }
+    // ---- forward sweep
+    for (int p = 0; p < nlyr; ++p) {
+        const double* ops = vops_at(v, g, p, w);
+        const bool last = (p == nlyr - 1);
+        team.sync();
+        SKV_PAR(col, NC) {   // Legendre-space weights of the column's line of sight (row `sout` of Pi_l at the table angles)
+            const int los = col / S, sout = col % S;
+            for (int l = 0; l < NL; ++l) QL[size_t(l) * NC + col] = 0;
+            const int base = (los * g.nsza + s) * nlyr + p;
+            for (int t = g.lp_start[base]; t < g.lp_start[base + 1]; ++t) {
+                if (skd::conv_at(b, g, g.lp_slot[t], w) <= m) continue;
+                const int q = g.lp_q[t];
+                const double az = (sout < 2) ? g.rl_cosm[size_t(m) * g.nq_total + q] : vg.rl_sinm_t[size_t(q) * nstr + m];
+                const double cw = b.srcw[size_t(q) * nw + w] * g.lp_w[t] * az;
+                if (cw == 0.0) continue;
+                const Fun3 fa = fun_ang(g, vg, m, g.lp_angle[t]);
+                for (int l = m; l < nstr; ++l) {
+                    if (S == 1) { QL[size_t(l) * NC + col] += cw * fa.P[l]; continue; }
+                    if (sout == 0) QL[size_t(l * 3) * NC + col] += cw * fa.P[l];
+                    else if (sout == 1) { QL[size_t(l * 3 + 1) * NC + col] += cw * fa.R[l]; QL[size_t(l * 3 + 2) * NC + col] -= cw * fa.T[l]; }
+                    else { QL[size_t(l * 3 + 1) * NC + col] -= cw * fa.T[l]; QL[size_t(l * 3 + 2) * NC + col] += cw * fa.R[l]; }
+                }
+            }
+            for (int l = 0; l < NL; ++l) v.qlbuf[(size_t(p) * NL + l) * nt + t0 + col] = QL[size_t(l) * NC + col];
+        }
+        team.sync();
+        team_gemm(team, M2, NC, NL, [&](int i, int k) { return ops[O.FP() + i * NL + k]; }, [&](int k, int col) { return QL[size_t(k) * NC + col]; },
+                  [&](int i, int col, double val) { Y[size_t(i) * NC + col] = val + (last ? gwv[col] * ops[O.UG() + i] : 0.0); });
+        team.sync();
+        team_gemm(team, M2, NC, n, [&](int i, int k) { return ops[O.SP() + i * n + k]; }, [&](int k, int col) { return Cc[size_t(k) * NC + col]; },
+                  [&](int i, int col, double val) { Y[size_t(i) * NC + col] += val; });
+        team.sync();
+        SKV_PAR(e, M2 * NC) {
+            const int i = e / NC, col = e % NC;
+            const double yv = Y[e];
+            v.z[(size_t(p) * M2 + i) * nt + t0 + col] = yv;
+            if (i >= n) Cc[size_t(i - n) * NC + col] = yv;
+        }
+    }
+    // ---- backward sweep
+    team.sync();
+    SKV_PAR(e, n * NC) Cc[e] = 0;
+    for (int p = nlyr - 1; p >= 0; --p) {
+        const double* ops = vops_at(v, g, p, w);
+        team.sync();
+        SKV_PAR(e, M2 * NC) Y[e] = v.z[(size_t(p) * M2 + e / NC) * nt + t0 + e % NC];
+        team.sync();
+        if (p < nlyr - 1) {
+            team_gemm(team, M2, NC, n, [&](int i, int k) { return ops[O.BP() + i * n + k]; }, [&](int k, int col) { return Cc[size_t(k) * NC + col]; },
+                      [&](int i, int col, double val) { Y[size_t(i) * NC + col] -= val; });
+            team.sync();
+        }
+        SKV_PAR(e, M2 * NC) {
+            const int i = e / NC, col = e % NC;
+            const double zv = Y[e];
+            v.z[(size_t(p) * M2 + i) * nt + t0 + col] = zv;
+            if (i < n) Cc[size_t(i) * NC + col] = zv;
+        }
+    }
+    team.sync();
+    // ---- reduced gradient, one column per lane
+    SKV_PAR(col, NC) adjoint_gradient_column(g, b, v, s, m, w, t0 + col, nt, gwv[col], true);
+    team.sync();
 }
 
 // =================================================================================================

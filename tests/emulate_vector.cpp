@@ -74,7 +74,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     const int NL = skv::legendre_space(g, S), ngrid = t.ngrid;
     const size_t nt3 = nt * S;
     std::vector<double> scratch(std::max({skv::kv1_scratch(n), skv::kv2_scratch(n), skv::kv3_scratch(n, nstr), skv::kvpp_scratch(n, ngroups),
-                                          skv::kv2c_scratch(n, NL, ngroups), skv::kv2b_scratch(n, NL)}));
+                                          skv::kv2c_scratch(n, NL, ngroups), skv::kv2b_scratch(n, NL), skv::kv2bt_scratch(n, NL, nlos * S)}));
     const int G = derivatives ? ngroups : 0;
     std::vector<double> ops(derivatives ? size_t(nlyr) * skv::VOps(n, NL, G).size() * nw : 1), zb(derivatives ? size_t(nlyr) * 2 * n * nt3 : 1),
         qlb(derivatives ? size_t(nlyr) * NL * nt3 : 1), grad(derivatives ? size_t(4 * nlyr + 2 + G * nlyr) * nt3 : 1, 0.0),
@@ -139,9 +139,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                         for (int p = 0; p < nlyr; ++p)
                             if (m < norders[w]) skv::kv2c_layer_ops(team, g, vg, b, v, s, m, p, w, ws);
                     for (int w = 0; w < nw; ++w)
-                        for (int l = 0; l < nlos; ++l)
-                            for (int so = 0; so < S; ++so)
-                                if (m < norders[w]) skv::kv2b_adjoint(g, vg, b, v, s, m, l, so, w, scr);
+                        if (m < norders[w]) skv::kv2b_team(team, g, vg, b, v, s, m, w, ws);
                 }
                 for (int w = 0; w < nw; ++w) skd::k_stop_rule(g, b, s, m, w);
             }
