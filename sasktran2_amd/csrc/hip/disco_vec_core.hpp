@@ -486,37 +486,30 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
     double* dU = Bm;   // As was consumed by the Jacobi sweeps
     double* dk = acp;  // reused before the Green's coefficients need it
     if (derivs) {
-        SKV_PAR(e, nn) {
-            const int i = e / n, j = e % n;
-            const double hm = X[e] / (rmu(i) * rmu(i)) -
-                              om / rmu(i) * sum4(0, n, [&](int r) { return rw(r) * Em[i * n + r] * X[r * n + j] / rmu(r); });
-            Tm[e] = (2 * X[e] * lam[j] - U[e] / rmu(i) - hm) / om;   // d(Gamma) X
-        }
+        team_gemm(team, n, n, n, [&](int i, int r) { return rw(r) * Em[i * n + r] / rmu(r); }, [&](int r, int j) { return X[r * n + j]; },
+                  [&](int i, int j, double val) {
+                      const double hm = X[i * n + j] / (rmu(i) * rmu(i)) - om / rmu(i) * val;
+                      Tm[i * n + j] = (2 * X[i * n + j] * lam[j] - U[i * n + j] / rmu(i) - hm) / om;   // d(Gamma) X
+                  });
         team.sync();
         double lmax = 0;
         for (int j = 0; j < n; ++j) lmax = fmax(lmax, lam[j]);
-        SKV_PAR(e, nn) {
-            const int a_ = e / n, b_ = e % n;
-            const double z = sum4(0, n, [&](int i) { return rw(i) * rmu(i) * U[i * n + a_] * Tm[i * n + b_]; });
-            if (a_ == b_) {
-                dk[b_] = z / (2 * kk[b_]);
-                Bm[e] = 0;
-            } else {
-                const double den = lam[b_] - lam[a_];
-                Bm[e] = (fabs(den) > 1e-13 * lmax) ? z / den : 0.0;
-            }
-        }
+        team_gemm(team, n, n, n, [&](int a_, int i) { return rw(i) * rmu(i) * U[i * n + a_]; }, [&](int i, int b_) { return Tm[i * n + b_]; },
+                  [&](int a_, int b_, double z) {
+                      if (a_ == b_) {
+                          dk[b_] = z / (2 * kk[b_]);
+                          Bm[a_ * n + b_] = 0;
+                      } else {
+                          const double den = lam[b_] - lam[a_];
+                          Bm[a_ * n + b_] = (fabs(den) > 1e-13 * lmax) ? z / den : 0.0;
+                      }
+                  });
         team.sync();
-        SKV_PAR(e, nn) {
-            const int i = e / n, j = e % n;
-            dX[e] = sum4(0, n, [&](int r) { return X[i * n + r] * Bm[r * n + j]; });
-        }
+        team_gemm(team, n, n, n, [&](int i, int r) { return X[i * n + r]; }, [&](int r, int j) { return Bm[r * n + j]; },
+                  [&](int i, int j, double val) { dX[i * n + j] = val; });
         team.sync();
-        SKV_PAR(e, nn) {
-            const int i = e / n, j = e % n;
-            const double t = sum4(0, n, [&](int r) { return rw(r) * Ep[i * n + r] * dX[r * n + j]; });
-            Tm[e] = (U[e] - X[e] / rmu(i)) / om + (dX[e] - om * t) / rmu(i);   // dU (into Tm; Bm still holds C)
-        }
+        team_gemm(team, n, n, n, [&](int i, int r) { return rw(r) * Ep[i * n + r]; }, [&](int r, int j) { return dX[r * n + j]; },
+                  [&](int i, int j, double val) { Tm[i * n + j] = (U[i * n + j] - X[i * n + j] / rmu(i)) / om + (dX[i * n + j] - om * val) / rmu(i); });
         team.sync();
         dU = Tm;
     }
@@ -693,42 +686,37 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
                     }
             }
             team.sync();
-            SKV_PAR(e, nn) {   // A1 = dS+ X, A2 = dS- U
-                const int i = e / n, j = e % n;
-                A1[e] = -om / rmu(i) * sum4(0, n, [&](int r) { return rw(r) * dEp[i * n + r] * X[r * n + j]; });
-                A2[e] = -om / rmu(i) * sum4(0, n, [&](int r) { return rw(r) * dEm[i * n + r] * U[r * n + j]; });
-            }
+            // A1 = dS+ X, A2 = dS- U
+            team_gemm(team, n, n, n, [&](int i, int r) { return rw(r) * dEp[i * n + r]; }, [&](int r, int j) { return X[r * n + j]; },
+                      [&](int i, int j, double val) { A1[i * n + j] = -om / rmu(i) * val; });
+            team_gemm(team, n, n, n, [&](int i, int r) { return rw(r) * dEm[i * n + r]; }, [&](int r, int j) { return U[r * n + j]; },
+                      [&](int i, int j, double val) { A2[i * n + j] = -om / rmu(i) * val; });
             team.sync();
-            SKV_PAR(e, nn) {   // d(Gamma) X = A2 + S- A1   (into dEm, which is consumed)
-                const int i = e / n, j = e % n;
-                const double t = sum4(0, n, [&](int r) { return rw(r) * Em[i * n + r] * A1[r * n + j]; });
-                dEm[e] = A2[e] + (A1[e] - om * t) / rmu(i);
-            }
+            // d(Gamma) X = A2 + S- A1   (into dEm, which is consumed)
+            team_gemm(team, n, n, n, [&](int i, int r) { return rw(r) * Em[i * n + r]; }, [&](int r, int j) { return A1[r * n + j]; },
+                      [&](int i, int j, double val) { dEm[i * n + j] = A2[i * n + j] + (A1[i * n + j] - om * val) / rmu(i); });
             team.sync();
             double lmax = 0;
             for (int j = 0; j < n; ++j) lmax = fmax(lmax, lam[j]);
-            SKV_PAR(e, nn) {   // C (into A2)
-                const int a_ = e / n, b_ = e % n;
-                const double z = sum4(0, n, [&](int i) { return rw(i) * rmu(i) * U[i * n + a_] * dEm[i * n + b_]; });
-                if (a_ == b_) {
-                    dkg[b_] = z / (2 * kk[b_]);
-                    A2[e] = 0;
-                } else {
-                    const double den = lam[b_] - lam[a_];
-                    A2[e] = (fabs(den) > 1e-13 * lmax) ? z / den : 0.0;
-                }
-            }
+            // C (into A2)
+            team_gemm(team, n, n, n, [&](int a_, int i) { return rw(i) * rmu(i) * U[i * n + a_]; }, [&](int i, int b_) { return dEm[i * n + b_]; },
+                      [&](int a_, int b_, double z) {
+                          if (a_ == b_) {
+                              dkg[b_] = z / (2 * kk[b_]);
+                              A2[a_ * n + b_] = 0;
+                          } else {
+                              const double den = lam[b_] - lam[a_];
+                              A2[a_ * n + b_] = (fabs(den) > 1e-13 * lmax) ? z / den : 0.0;
+                          }
+                      });
             team.sync();
-            SKV_PAR(e, nn) {   // dX = X C  (into dEm)
-                const int i = e / n, j = e % n;
-                dEm[e] = sum4(0, n, [&](int r) { return X[i * n + r] * A2[r * n + j]; });
-            }
+            // dX = X C  (into dEm)
+            team_gemm(team, n, n, n, [&](int i, int r) { return X[i * n + r]; }, [&](int r, int j) { return A2[r * n + j]; },
+                      [&](int i, int j, double val) { dEm[i * n + j] = val; });
             team.sync();
-            SKV_PAR(e, nn) {   // dU = A1 + S+ dX  (into A2)
-                const int i = e / n, j = e % n;
-                const double t = sum4(0, n, [&](int r) { return rw(r) * Ep[i * n + r] * dEm[r * n + j]; });
-                A2[e] = A1[e] + (dEm[e] - om * t) / rmu(i);
-            }
+            // dU = A1 + S+ dX  (into A2)
+            team_gemm(team, n, n, n, [&](int i, int r) { return rw(r) * Ep[i * n + r]; }, [&](int r, int j) { return dEm[r * n + j]; },
+                      [&](int i, int j, double val) { A2[i * n + j] = A1[i * n + j] + (dEm[i * n + j] - om * val) / rmu(i); });
             team.sync();
             SKV_PAR(j, n) {
                 double dnr = 0;
