@@ -248,6 +248,14 @@ template <class F> SKD_HD double sum4(int lo, int hi, F f) {
 // (v_mfma_f64_16x16x4_f64: A lane l = A[l & 15][l >> 4], B lane l = B[l >> 4][l & 15], D register r = D[(l >> 4) + 4 r][l & 15]), one
 // operand load of each kind per lane and 1024 multiply-adds per instruction; on the CPU (emulation) it is the plain triple loop.
 // The caller separates it from neighbouring phases with team.sync().
+SKD_HD double recip_sqrt(double x) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return rsqrt(x);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+
 template <class FA, class FB, class FC> SKD_HD void team_gemm(const Team& team, int M, int N, int K, FA a, FB b, FC store) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef double mf4v __attribute__((ext_vector_type(4)));
@@ -376,24 +384,40 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
               });
     SKV_PAR(e, nn) V[e] = (e / n == e % n) ? 1.0 : 0.0;
     team.sync();
-    // ---- Jacobi with the round-robin ("tournament") ordering: n/2 disjoint rotations per step, applied as A <- J^T A J
+    // ---- Jacobi with the round-robin ("tournament") ordering: n/2 disjoint rotations per step, applied as A <- J^T A J.
+    //      Each round is one pass over the 2x2 blocks (pair k rows x pair k' columns): a block is read, rotated from both sides and
+    //      written by one lane, so the update is in place and needs no barrier between the column and the row rotation.
     auto jacobi = [&](double* Mx) {
         const int np = (n + 1) & ~1, half = np / 2;
         double* rc = rot;          // cos of pair k
         double* rs = rot + half;   // sin of pair k (0 when the pair is skipped)
+        const float inv_half = 1.0f / float(half);
         bool converged = false;
         for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
+            // convergence: off-diagonal mass against the diagonal (row sums in parallel, then every lane adds the n row sums)
+            team.sync();
+            SKV_PAR(i, n) rot[i] = sum4(i + 1, n, [&](int j) { return Mx[i * n + j] * Mx[i * n + j]; });
+            team.sync();
             double off = 0, dia = 0;
             for (int i = 0; i < n; ++i) {
                 dia += Mx[i * n + i] * Mx[i * n + i];
-                for (int j = i + 1; j < n; ++j) off += Mx[i * n + j] * Mx[i * n + j];
+                off += rot[i];
             }
+#ifdef SKV_EXP_JAC_SWEEPS
+            if (sweep >= SKV_EXP_JAC_SWEEPS) { converged = true; break; }
+#else
             if (off <= 1e-30 * dia || off == 0) { converged = true; break; }
+#endif
             for (int step = 0; step < np - 1; ++step) {
                 auto pair_of = [&](int k, int& pp, int& q) {
                     int a_, b_;
                     if (k == 0) { a_ = np - 1; b_ = step; }
-                    else { a_ = (step + k) % (np - 1); b_ = (step - k + (np - 1)) % (np - 1); }
+                    else {
+                        a_ = step + k;
+                        if (a_ >= np - 1) a_ -= np - 1;
+                        b_ = step - k;
+                        if (b_ < 0) b_ += np - 1;
+                    }
                     pp = a_ < b_ ? a_ : b_;
                     q = a_ < b_ ? b_ : a_;
                 };
@@ -402,47 +426,104 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
                     int pp, q;
                     pair_of(k, pp, q);
                     double c = 1.0, sn = 0.0;
-                    if (q < n) {
+#ifndef SKV_EXP_JAC_NOROT
+                    if (q < n)
+#else
+                    if (q < 0)
+#endif
+                    {
                         const double apq = Mx[pp * n + q];
                         if (apq != 0.0) {
-                            const double app = Mx[pp * n + pp], aqq = Mx[q * n + q];
-                            const double theta = (aqq - app) / (2.0 * apq);
-                            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                            c = 1.0 / sqrt(t * t + 1.0);
-                            sn = t * c;
+                            // tan(2 phi) = apq / d, |phi| <= pi/4:  cos(2 phi) = |d| / r,  c = sqrt((1 + cos 2phi) / 2),
+                            // s = sin(2 phi) / (2 c) -- two reciprocal square roots, no cancellation
+                            const double d = 0.5 * (Mx[q * n + q] - Mx[pp * n + pp]);
+                            const double inv_r = recip_sqrt(d * d + apq * apq);
+                            const double h = 0.5 + 0.5 * fabs(d) * inv_r;
+                            const double inv_c = recip_sqrt(h);
+                            c = h * inv_c;
+                            sn = (d >= 0 ? 0.5 : -0.5) * apq * inv_r * inv_c;
                         }
                     }
                     rc[k] = c;
                     rs[k] = sn;
                 }
                 team.sync();
-                SKV_PAR(e, half * n) {  // columns: A <- A J, V <- V J
-                    const int k = e / n, r = e % n;
-                    const double c = rc[k], sn = rs[k];
-                    if (sn != 0.0) {
-                        int pp, q;
-                        pair_of(k, pp, q);
-                        const double arp = Mx[r * n + pp], arq = Mx[r * n + q];
-                        Mx[r * n + pp] = c * arp - sn * arq;
-                        Mx[r * n + q] = sn * arp + c * arq;
-                        const double vrp = V[r * n + pp], vrq = V[r * n + q];
-                        V[r * n + pp] = c * vrp - sn * vrq;
-                        V[r * n + q] = sn * vrp + c * vrq;
+                // A <- J^T A J by blocks, four blocks in flight per lane
+#ifdef SKV_EXP_JAC_NOA
+                const int nblk = 0;
+#else
+                const int nblk = half * half;
+#endif
+                for (int b0 = team.lane; b0 < nblk; b0 += 4 * team.width) {
+                    double a00[4], a01[4], a10[4], a11[4], c1[4], s1[4], c2[4], s2[4];
+                    int P1[4], Q1[4], P2[4], Q2[4];
+                    bool same[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int bk = b0 + u * team.width;
+                        P1[u] = -1;
+                        if (bk < nblk) {
+                            const int k = int((float(bk) + 0.5f) * inv_half), k2 = bk - k * half;
+                            pair_of(k, P1[u], Q1[u]);
+                            pair_of(k2, P2[u], Q2[u]);
+                            same[u] = k == k2;
+                            c1[u] = rc[k];
+                            s1[u] = rs[k];
+                            c2[u] = rc[k2];
+                            s2[u] = rs[k2];
+                            const bool v1 = Q1[u] < n, v2 = Q2[u] < n;
+                            a00[u] = Mx[P1[u] * n + P2[u]];
+                            a01[u] = v2 ? Mx[P1[u] * n + Q2[u]] : 0.0;
+                            a10[u] = v1 ? Mx[Q1[u] * n + P2[u]] : 0.0;
+                            a11[u] = (v1 && v2) ? Mx[Q1[u] * n + Q2[u]] : 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (P1[u] < 0) continue;
+                        // columns (pair k'), then rows (pair k)
+                        const double t00 = c2[u] * a00[u] - s2[u] * a01[u], t01 = s2[u] * a00[u] + c2[u] * a01[u];
+                        const double t10 = c2[u] * a10[u] - s2[u] * a11[u], t11 = s2[u] * a10[u] + c2[u] * a11[u];
+                        double r00 = c1[u] * t00 - s1[u] * t10, r10 = s1[u] * t00 + c1[u] * t10;
+                        double r01 = c1[u] * t01 - s1[u] * t11, r11 = s1[u] * t01 + c1[u] * t11;
+                        if (same[u] && s1[u] != 0.0) r01 = r10 = 0.0;   // the rotated pair is annihilated exactly
+                        const bool v1 = Q1[u] < n, v2 = Q2[u] < n;
+                        Mx[P1[u] * n + P2[u]] = r00;
+                        if (v2) Mx[P1[u] * n + Q2[u]] = r01;
+                        if (v1) Mx[Q1[u] * n + P2[u]] = r10;
+                        if (v1 && v2) Mx[Q1[u] * n + Q2[u]] = r11;
                     }
                 }
-                team.sync();
-                SKV_PAR(e, half * n) {  // rows: A <- J^T A
-                    const int k = e / n, cidx = e % n;
-                    const double c = rc[k], sn = rs[k];
-                    if (sn != 0.0) {
-                        int pp, q;
-                        pair_of(k, pp, q);
-                        const double apc = Mx[pp * n + cidx], aqc = Mx[q * n + cidx];
-                        double vp_ = c * apc - sn * aqc, vq_ = sn * apc + c * aqc;
-                        if (cidx == q) vp_ = 0.0;   // the rotated pair is annihilated exactly
-                        if (cidx == pp) vq_ = 0.0;
-                        Mx[pp * n + cidx] = vp_;
-                        Mx[q * n + cidx] = vq_;
+                // V <- V J, four (row, pair) items in flight per lane
+#ifdef SKV_EXP_JAC_NOV
+                const int nvj = 0;
+#else
+                const int nvj = n * half;
+#endif
+                for (int e0 = team.lane; e0 < nvj; e0 += 4 * team.width) {
+                    double vp_[4], vq_[4], c2[4], s2[4];
+                    int R[4], P2[4], Q2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = e0 + u * team.width;
+                        R[u] = -1;
+                        if (e < nvj) {
+                            const int r = int((float(e) + 0.5f) * inv_half), k2 = e - r * half;
+                            pair_of(k2, P2[u], Q2[u]);
+                            if (Q2[u] < n) {
+                                R[u] = r;
+                                c2[u] = rc[k2];
+                                s2[u] = rs[k2];
+                                vp_[u] = V[r * n + P2[u]];
+                                vq_[u] = V[r * n + Q2[u]];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (R[u] < 0) continue;
+                        V[R[u] * n + P2[u]] = c2[u] * vp_[u] - s2[u] * vq_[u];
+                        V[R[u] * n + Q2[u]] = s2[u] * vp_[u] + c2[u] * vq_[u];
                     }
                 }
             }
