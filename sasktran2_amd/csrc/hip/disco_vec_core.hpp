@@ -886,10 +886,21 @@ SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, c
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// Gauss-Jordan inverse with partial pivoting of an M2 x M2 matrix (M2 = 16 T) by a team of 256 lanes that keeps the matrix and the
-// growing inverse in registers: element (r, c) lives in lane (r % 16, c % 16), slot (r / 16, c / 16).  Per pivot two barriers: the
+// |v| with the row index in the low byte of the mantissa: the maximum of such values is the pivot candidate and names its row
+// (a relative perturbation of 2^-44 of the comparison, irrelevant for the choice of a pivot); rows below `first` do not compete
+__device__ __forceinline__ double pivot_candidate(double v, int row, int first) {
+    const long long bits = (__double_as_longlong(fabs(v)) & ~0xFFll) | row;
+    return row >= first ? __longlong_as_double(bits) : -1.0;
+}
+__device__ __forceinline__ int pivot_row(double cand) { return int(__double_as_longlong(cand) & 0xFF); }
+__device__ __forceinline__ bool pivot_usable(double cand) { return __longlong_as_double(__double_as_longlong(cand) & ~0xFFll) > 0.0; }
+
+// Gauss-Jordan inverse with partial pivoting of an M2 x M2 matrix (M2 = 16 T <= 128) by a team of 256 lanes that keeps the matrix and
+// the growing inverse in registers: element (r, c) lives in lane (r % 16, c % 16), slot (r / 16, c / 16).  Per pivot two barriers: the
 // candidates of the pivot search, then the pivot row, the displaced row and the pivot column through `buf` (LDS, double-buffered by
-// pivot parity); every lane then updates its 2 T^2 elements with fused multiply-adds.  D is read, Dinv written (row-major, LDS or HBM).
+// pivot parity); every lane then updates its 2 T^2 elements with fused multiply-adds.  The pivot row is wave-uniform (held in a
+// scalar register), so picking the register slot that holds it is a scalar branch, not a select chain over the slots.
+// D is read, Dinv written (row-major, LDS or HBM).
 template <int T> __device__ bool gj_inverse_registers(const double* D, double* Dinv, double* buf) {
     constexpr int MP = 16 * T;
     const int lane = threadIdx.x, ly = lane >> 4, lx = lane & 15;
@@ -902,7 +913,7 @@ template <int T> __device__ bool gj_inverse_registers(const double* D, double* D
             a[rb][cb] = D[r * MP + c];
             b[rb][cb] = (r == c) ? 1.0 : 0.0;
         }
-    double* cand = buf + 10 * MP;   // [2][32]
+    double* cand = buf + 10 * MP;   // [2][16]
     bool ok = true;
 #pragma unroll
     for (int kb = 0; kb < T; ++kb)
@@ -911,42 +922,31 @@ template <int T> __device__ bool gj_inverse_registers(const double* D, double* D
             double* rowp = buf + par * 5 * MP;   // [2 MP] row that becomes the pivot row (old row piv): matrix part, inverse part
             double* rowc = rowp + 2 * MP;        // [2 MP] old row cc
             double* colf = rowp + 4 * MP;        // [MP]   column cc
-            double* cnd = cand + par * 32;
+            double* cnd = cand + par * 16;
             // ---- pivot search over rows >= cc of column cc
             if (lx == kl) {
                 double best = -1.0;
-                int brow = cc;
 #pragma unroll
-                for (int rb = 0; rb < T; ++rb) {
-                    const int r = rb * 16 + ly;
-                    const double v = fabs(a[rb][kb]);
-                    if (r >= cc && v > best) { best = v; brow = r; }
-                }
+                for (int rb = 0; rb < T; ++rb) best = fmax(best, pivot_candidate(a[rb][kb], rb * 16 + ly, cc));
                 cnd[ly] = best;
-                cnd[16 + ly] = double(brow);
             }
             __syncthreads();
-            double pv = -1.0;
-            int piv = cc;
-            for (int t = 0; t < 16; ++t) {
-                const double v = cnd[t];
-                const int rr = int(cnd[16 + t]);
-                if (v > pv || (v == pv && rr < piv)) { pv = v; piv = rr; }
-            }
-            if (!(pv > 0)) { ok = false; break; }
+            double pvc = cnd[0];
+#pragma unroll
+            for (int t = 1; t < 16; ++t) pvc = fmax(pvc, cnd[t]);
+            if (!pivot_usable(pvc)) { ok = false; break; }
+            const int piv = __builtin_amdgcn_readfirstlane(pivot_row(pvc));
             const int prb = piv >> 4, pl = piv & 15;
             // ---- publish the two rows and the column
-            if (ly == pl) {
 #pragma unroll
-                for (int cb = 0; cb < T; ++cb) {
-                    double va = 0, vb = 0;
+            for (int rb = 0; rb < T; ++rb)
+                if (rb == prb && ly == pl) {
 #pragma unroll
-                    for (int rb = 0; rb < T; ++rb)
-                        if (rb == prb) { va = a[rb][cb]; vb = b[rb][cb]; }
-                    rowp[cb * 16 + lx] = va;
-                    rowp[MP + cb * 16 + lx] = vb;
+                    for (int cb = 0; cb < T; ++cb) {
+                        rowp[cb * 16 + lx] = a[rb][cb];
+                        rowp[MP + cb * 16 + lx] = b[rb][cb];
+                    }
                 }
-            }
             if (ly == kl) {
 #pragma unroll
                 for (int cb = 0; cb < T; ++cb) {
@@ -959,7 +959,7 @@ template <int T> __device__ bool gj_inverse_registers(const double* D, double* D
                 for (int rb = 0; rb < T; ++rb) colf[rb * 16 + ly] = a[rb][kb];
             }
             __syncthreads();
-            // ---- update: row cc <- (old row piv) / pivot, row piv <- old row cc, every row r != cc loses f_r times the new pivot row
+            // ---- update: every row loses f_r times the new pivot row; then row piv <- old row cc (eliminated), row cc <- pivot row
             const double inv = 1.0 / rowp[cc];
             double pa[T], pb[T];
 #pragma unroll
@@ -969,24 +969,23 @@ template <int T> __device__ bool gj_inverse_registers(const double* D, double* D
             }
 #pragma unroll
             for (int rb = 0; rb < T; ++rb) {
-                const int r = rb * 16 + ly;
-                if (r == cc) {
+                const double f = colf[rb * 16 + ly];
 #pragma unroll
-                    for (int cb = 0; cb < T; ++cb) { a[rb][cb] = pa[cb]; b[rb][cb] = pb[cb]; }
-                } else if (r == piv) {
+                for (int cb = 0; cb < T; ++cb) { a[rb][cb] -= f * pa[cb]; b[rb][cb] -= f * pb[cb]; }
+            }
+#pragma unroll
+            for (int rb = 0; rb < T; ++rb)
+                if (rb == prb && ly == pl) {
                     const double f = colf[cc];   // the displaced row cc carries its own column-cc entry
 #pragma unroll
                     for (int cb = 0; cb < T; ++cb) {
                         a[rb][cb] = rowc[cb * 16 + lx] - f * pa[cb];
                         b[rb][cb] = rowc[MP + cb * 16 + lx] - f * pb[cb];
                     }
-                } else {
-                    const double f = colf[r];
-                    if (f != 0.0) {
-#pragma unroll
-                        for (int cb = 0; cb < T; ++cb) { a[rb][cb] -= f * pa[cb]; b[rb][cb] -= f * pb[cb]; }
-                    }
                 }
+            if (ly == kl) {
+#pragma unroll
+                for (int cb = 0; cb < T; ++cb) { a[kb][cb] = pa[cb]; b[kb][cb] = pb[cb]; }
             }
         }
     __syncthreads();
@@ -997,9 +996,7 @@ template <int T> __device__ bool gj_inverse_registers(const double* D, double* D
     __syncthreads();
     return ok;
 }
-#endif
 
-#if defined(__HIP_DEVICE_COMPILE__)
 // In-place Gauss-Jordan inverse with partial pivoting of an M2 x M2 matrix (M2 = 8 TS) by ONE wavefront that keeps the matrix in
 // registers: element (r, c) lives in lane (r % 8) * 8 + (c % 8), slot (r / 8, c / 8).  Pivot search, row exchange and the broadcast of
 // the pivot row / column are wave shuffles, so a pivot costs no barrier at all (the 256-lane version above pays two workgroup barriers and
@@ -1020,62 +1017,58 @@ template <int TS> __device__ bool gj_inverse_wave(const double* D, double* Dinv,
     for (int kb = 0; kb < TS; ++kb)
         for (int kl = 0; kl < 8 && ok; ++kl) {
             const int cc = kb * 8 + kl;
-            // ---- pivot search in column cc (lanes lx == kl hold it), rows >= cc
+            // ---- pivot search in column cc (lanes lx == kl hold it), rows >= cc: maximum over the wavefront of the tagged magnitudes
             double best = -1.0;
-            int brow = cc;
 #pragma unroll
-            for (int rb = 0; rb < TS; ++rb) {
-                const int r = rb * 8 + ly;
-                const double v = fabs(a[rb][kb]);
-                if (lx == kl && r >= cc && (v > best || (v == best && r < brow))) { best = v; brow = r; }
-            }
+            for (int rb = 0; rb < TS; ++rb) best = fmax(best, pivot_candidate(a[rb][kb], rb * 8 + ly, cc));
+            if (lx != kl) best = -1.0;
 #pragma unroll
-            for (int off = 8; off <= 32; off <<= 1) {   // over ly (lane bits 3..5), same lx
-                const double ob = __shfl_xor(best, off);
-                const int orow = __shfl_xor(brow, off);
-                if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
-            }
-            const double pvabs = __shfl(best, (lane & 56) | kl);
-            const int piv = __shfl(brow, (lane & 56) | kl);
-            if (!(pvabs > 0)) { ok = false; break; }
+            for (int off = 1; off <= 32; off <<= 1) best = fmax(best, __shfl_xor(best, off));
+            if (!pivot_usable(best)) { ok = false; break; }
+            const int piv = __builtin_amdgcn_readfirstlane(pivot_row(best));
             if (lane == 0) ipiv[cc] = piv;
             const int prb = piv >> 3, pl = piv & 7;
             // ---- exchange rows cc <-> piv; every lane ends up with the new pivot row's entries of its columns in prow[]
-            double prow[TS];
+            double prow[TS], mine_p[TS] = {};
 #pragma unroll
-            for (int cb = 0; cb < TS; ++cb) {
-                double mine_p = 0;
+            for (int rb = 0; rb < TS; ++rb)
+                if (rb == prb) {
+#pragma unroll
+                    for (int cb = 0; cb < TS; ++cb) mine_p[cb] = a[rb][cb];
+                }
+#pragma unroll
+            for (int cb = 0; cb < TS; ++cb) prow[cb] = __shfl(mine_p[cb], (pl << 3) | lx);   // old row piv = new pivot row
+            if (piv != cc) {
+                double xc[TS];
+#pragma unroll
+                for (int cb = 0; cb < TS; ++cb) xc[cb] = __shfl(a[kb][cb], (kl << 3) | lx);   // old row cc
+                if (ly == kl) {
+#pragma unroll
+                    for (int cb = 0; cb < TS; ++cb) a[kb][cb] = prow[cb];
+                }
 #pragma unroll
                 for (int rb = 0; rb < TS; ++rb)
-                    if (rb == prb) mine_p = a[rb][cb];
-                const double xc = __shfl(a[kb][cb], (kl << 3) | lx);    // old row cc
-                const double xp = __shfl(mine_p, (pl << 3) | lx);       // old row piv = new pivot row
-                if (piv != cc) {
-                    if (ly == kl) a[kb][cb] = xp;
-                    if (ly == pl) {
+                    if (rb == prb && ly == pl) {
 #pragma unroll
-                        for (int rb = 0; rb < TS; ++rb)
-                            if (rb == prb) a[rb][cb] = xc;
+                        for (int cb = 0; cb < TS; ++cb) a[rb][cb] = xc[cb];
                     }
-                }
-                prow[cb] = xp;
             }
             const double pv = __shfl(prow[kb], (lane & 56) | kl);
             const double inv = 1.0 / pv;
-            // ---- eliminate: row cc <- row / pivot (its column-cc entry 1 / pivot); row r <- row r - f_r (new row cc), column cc -> -f_r / pivot
+#pragma unroll
+            for (int cb = 0; cb < TS; ++cb) prow[cb] *= inv;
+            // ---- eliminate: row r <- row r - f_r (new row cc), column cc -> -f_r / pivot; then row cc <- row / pivot, its column-cc entry 1 / pivot
 #pragma unroll
             for (int rb = 0; rb < TS; ++rb) {
-                const int r = rb * 8 + ly;
                 const double f = __shfl(a[rb][kb], (lane & 56) | kl);   // a[r][cc] after the exchange
-                if (r == cc) {
 #pragma unroll
-                    for (int cb = 0; cb < TS; ++cb) a[rb][cb] = prow[cb] * inv;
-                    if (lx == kl) a[rb][kb] = inv;
-                } else {
+                for (int cb = 0; cb < TS; ++cb) a[rb][cb] -= f * prow[cb];
+                if (lx == kl) a[rb][kb] = -f * inv;
+            }
+            if (ly == kl) {
 #pragma unroll
-                    for (int cb = 0; cb < TS; ++cb) a[rb][cb] -= f * (prow[cb] * inv);
-                    if (lx == kl) a[rb][kb] = -f * inv;
-                }
+                for (int cb = 0; cb < TS; ++cb) a[kb][cb] = prow[cb];
+                if (lx == kl) a[kb][kb] = inv;
             }
         }
     // ---- undo the row exchanges as column exchanges (k descending) while writing out
