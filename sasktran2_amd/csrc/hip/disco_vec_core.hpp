@@ -23,6 +23,14 @@
 
 namespace skv {
 
+// team kernel bodies are always inlined into their __global__ wrappers: the address space of the work matrices (LDS / HBM) is then known
+// to the compiler (ds_ instead of flat_ instructions) and no call frame is needed
+#if defined(__HIPCC__)
+#define SKV_TEAM_BODY __host__ __device__ inline __attribute__((always_inline))
+#else
+#define SKV_TEAM_BODY inline
+#endif
+
 using skd::Bufs;
 using skd::Geo;
 using skd::kPi;
@@ -243,11 +251,6 @@ template <class F> SKD_HD double sum4(int lo, int hi, F f) {
     return (t0 + t1) + (t2 + t3);
 }
 
-// Team matrix product  C(i, j) = sum_{k < K} A(i, k) B(k, j),  i < M, j < N, with operands and result given by functors.  On the device
-// every wavefront of the team takes 16 x 16 output tiles in turn and accumulates them on the FP64 matrix cores
-// (v_mfma_f64_16x16x4_f64: A lane l = A[l & 15][l >> 4], B lane l = B[l >> 4][l & 15], D register r = D[(l >> 4) + 4 r][l & 15]), one
-// operand load of each kind per lane and 1024 multiply-adds per instruction; on the CPU (emulation) it is the plain triple loop.
-// The caller separates it from neighbouring phases with team.sync().
 SKD_HD double recip_sqrt(double x) {
 #ifdef __HIP_DEVICE_COMPILE__
     return rsqrt(x);
@@ -256,27 +259,65 @@ SKD_HD double recip_sqrt(double x) {
 #endif
 }
 
-template <class FA, class FB, class FC> SKD_HD void team_gemm(const Team& team, int M, int N, int K, FA a, FB b, FC store) {
+// Team matrix product  C(i, j) = sum_{k < K} A(i, k) B(k, j),  i < M, j < N, with operands and result given by functors.  On the device
+// every wavefront of the team takes strips of up to four 16 x 16 output tiles of one row block in turn and accumulates them on the
+// FP64 matrix cores (v_mfma_f64_16x16x4_f64: A lane l = A[l & 15][l >> 4], B lane l = B[l >> 4][l & 15], D register r =
+// D[(l >> 4) + 4 r][l & 15]): one A operand feeds the strip's independent accumulators (the matrix-core pipeline stays busy between
+// dependent instructions, a quarter of the A traffic), two k-steps of operand loads are in flight at a time.  Every output element is
+// accumulated in k order in one accumulator, so the result does not depend on the strip shape.  On the CPU (emulation) it is the
+// plain triple loop.  The caller separates it from neighbouring phases with team.sync().
+template <class FA, class FB, class FC> SKV_TEAM_BODY void team_gemm(const Team& team, int M, int N, int K, FA a, FB b, FC store) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef double mf4v __attribute__((ext_vector_type(4)));
     const int wave = team.lane >> 6, nwaves = (team.width + 63) >> 6, l = team.lane & 63;
-    const int tn = (N + 15) / 16, ntile = ((M + 15) / 16) * tn;
+    const int tn = (N + 15) / 16, tm = (M + 15) / 16;
+    const int ngrp = (tn + 3) / 4, gs = (tn + ngrp - 1) / ngrp;   // column tiles per strip (<= 4), strips per row block
     const int lr = l & 15, kq = l >> 4;
-    for (int t = wave; t < ntile; t += nwaves) {
-        const int i0 = (t / tn) * 16, j0 = (t % tn) * 16;
-        const int ar = i0 + lr, bc = j0 + lr;
-        mf4v acc = {0, 0, 0, 0};
-        for (int k0 = 0; k0 < K; k0 += 4) {
+    for (int t = wave; t < tm * ngrp; t += nwaves) {
+        const int i0 = (t / ngrp) * 16, jt0 = (t % ngrp) * gs;
+        const int gw = (tn - jt0 < gs) ? tn - jt0 : gs;           // tiles of this strip (wave-uniform)
+        const int ar = i0 + lr, bc = jt0 * 16 + lr;
+        const bool arow = ar < M;
+        mf4v acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = mf4v{0, 0, 0, 0};
+        int k0 = 0;
+        for (; k0 + 8 <= K; k0 += 8) {
+            const int ka = k0 + kq, kb = k0 + 4 + kq;
+            const double av0 = arow ? a(ar, ka) : 0.0, av1 = arow ? a(ar, kb) : 0.0;
+            double bv0[4], bv1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool on = u < gw && bc + 16 * u < N;
+                bv0[u] = on ? b(ka, bc + 16 * u) : 0.0;
+                bv1[u] = on ? b(kb, bc + 16 * u) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < gw) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv0[u], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < gw) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv1[u], acc[u], 0, 0, 0);
+        }
+        for (; k0 < K; k0 += 4) {
             const int k = k0 + kq;
-            const double av = (ar < M && k < K) ? a(ar, k) : 0.0;
-            const double bv = (bc < N && k < K) ? b(k, bc) : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            const double av = (arow && k < K) ? a(ar, k) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < gw) {
+                    const double bv = (bc + 16 * u < N && k < K) ? b(k, bc + 16 * u) : 0.0;
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[u], 0, 0, 0);
+                }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = i0 + kq + 4 * r, col = j0 + lr;
-            if (row < M && col < N) store(row, col, acc[r]);
-        }
+        for (int u = 0; u < 4; ++u)
+            if (u < gw) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + kq + 4 * r, col = (jt0 + u) * 16 + lr;
+                    if (row < M && col < N) store(row, col, acc[u][r]);
+                }
+            }
     }
 #else
     SKV_PAR(e, M * N) {
@@ -294,7 +335,7 @@ template <class FA, class FB, class FC> SKD_HD void team_gemm(const Team& team, 
 // =================================================================================================
 SKD_HD size_t kv1_scratch(int n) { return 8 * size_t(n) * n + 20 * size_t(n) + 64; }
 
-SKD_HD void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws,
+SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws,
                                    bool derivs = false) {
     const int N = g.N, S = v.S, n = v.n, nstr = g.nstr, nw = b.nw;
     const VRec R(n);
@@ -1104,7 +1145,10 @@ SKD_HD size_t kv2_scratch_main(int n) { return 8 * size_t(n) * n + 30 * size_t(n
 SKD_HD size_t kv2_scratch_t1(int n) { return 2 * size_t(n) * n; }
 SKD_HD size_t kv2_scratch(int n) { return kv2_scratch_main(n) + kv2_scratch_t1(n); }
 
-SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, double* ws, double* T1) {
+// GJ selects the block inversion: 0 = in place in the work space (any size, any team), 1 = one wavefront's registers (M2 = 48, team >= 64
+// lanes), 2 = the registers of a 256-lane team (M2 = 96); a separate instantiation each, so the small-block kernels do not carry the
+// register footprint of the 96 x 96 one (occupancy)
+template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, double* ws, double* T1) {
     const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nw = b.nw, nlyr = g.nlyr;
     const VRec R(n);
     const double rho = (m == 0) ? b.albedo[w] : 0.0;  // Lambertian
@@ -1185,11 +1229,8 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
 #ifdef SKV_EXP_SKIP_GJ
         if (true) { SKV_PAR(e, mm) Dinv[e] = (e / M2 == e % M2) ? 1.0 : 0.0; inverted = true; } else
 #endif
-#ifndef SKV_GJ_TEAM
-        if (team.width >= 64 && M2 == 48) {
-            // one wavefront inverts the 48 x 48 block in its registers with shuffles (no barrier per pivot), the others wait.  Measured
-            // (16 streams, 50 layers, 1024 wavelengths): BVP stage 425 -> 330 ms; the 96 x 96 instance (144 doubles per lane) spills and is
-            // 6x slower than the 256-lane version below, which therefore keeps the 32-stream blocks
+        if constexpr (GJ == 1) {
+            // one wavefront inverts the 48 x 48 block in its registers with shuffles (no barrier per pivot), the others wait
             __shared__ int gj_ok;
             if (team.lane < 64) {
                 const bool ok = gj_inverse_wave<6>(D, Dinv, reinterpret_cast<int*>(gjbuf));
@@ -1198,14 +1239,9 @@ SKD_HD void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& 
             team.sync();
             if (!gj_ok) singular = true;
             inverted = true;
-        } else
-#endif
-        if (team.width == 256 && (M2 == 48 || M2 == 96)) {
-#ifdef SKV_EXP_GJ2X
-            (void)((M2 == 48) ? gj_inverse_registers<3>(D, Dinv, gjbuf) : gj_inverse_registers<6>(D, Dinv, gjbuf));
-#endif
-            const bool ok = (M2 == 48) ? gj_inverse_registers<3>(D, Dinv, gjbuf) : gj_inverse_registers<6>(D, Dinv, gjbuf);
-            if (!ok) singular = true;
+        } else if constexpr (GJ == 2) {
+            // 96 x 96: the block and its inverse in the registers of all 256 lanes
+            if (!gj_inverse_registers<6>(D, Dinv, gjbuf)) singular = true;
             inverted = true;
         }
 #endif
@@ -1485,7 +1521,7 @@ SKD_HD double* vops_at(const VBufs& v, const Geo& g, int p, int w) {
 //   ws: 2n NL + 4 n + 5 NL n doubles of team-shared work space (F, temporaries, partial sums of the HD rows)
 SKD_HD size_t kv2c_scratch(int n, int NL, int G = 0) { return 2 * size_t(n) * NL + 4 * size_t(n) + (5 + size_t(G)) * size_t(NL) * n; }
 
-SKD_HD void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws) {
+SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws) {
     const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
     const VRec R(n);
     const VOps O(n, NL, v.ngroups);
@@ -1856,7 +1892,7 @@ SKD_HD void kv2b_adjoint(const Geo& g, const VGeo& vg, const Bufs& b, const VBuf
 //   ws: (NL + 3 n + 1) NC doubles of team-shared work space: QL [NL][NC], Y [2n][NC], carry [n][NC], gw [NC]
 SKD_HD size_t kv2bt_scratch(int n, int NL, int NC) { return (size_t(NL) + 3 * size_t(n) + 1) * size_t(NC); }
 
-SKD_HD void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int w, double* ws) {
+SKV_TEAM_BODY void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int w, double* ws) {
     const int S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr, NC = g.nlos * S;
     const VOps O(n, NL, v.ngroups);
     const size_t nt = size_t(nw) * NC, t0 = size_t(w) * NC;
