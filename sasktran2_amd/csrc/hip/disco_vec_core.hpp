@@ -936,33 +936,32 @@ __device__ __forceinline__ double pivot_candidate(double v, int row, int first) 
 __device__ __forceinline__ int pivot_row(double cand) { return int(__double_as_longlong(cand) & 0xFF); }
 __device__ __forceinline__ bool pivot_usable(double cand) { return __longlong_as_double(__double_as_longlong(cand) & ~0xFFll) > 0.0; }
 
-// Gauss-Jordan inverse with partial pivoting of an M2 x M2 matrix (M2 = 16 T <= 128) by a team of 256 lanes that keeps the matrix and
-// the growing inverse in registers: element (r, c) lives in lane (r % 16, c % 16), slot (r / 16, c / 16).  Per pivot two barriers: the
-// candidates of the pivot search, then the pivot row, the displaced row and the pivot column through `buf` (LDS, double-buffered by
-// pivot parity); every lane then updates its 2 T^2 elements with fused multiply-adds.  The pivot row is wave-uniform (held in a
-// scalar register), so picking the register slot that holds it is a scalar branch, not a select chain over the slots.
-// D is read, Dinv written (row-major, LDS or HBM).
+// In-place Gauss-Jordan inverse with partial pivoting of an M2 x M2 matrix (M2 = 16 T <= 128) by a team of 256 lanes that keeps the
+// matrix in registers: element (r, c) lives in lane (r % 16, c % 16), slot (r / 16, c / 16).  Per pivot two barriers: the candidates of
+// the pivot search, then the pivot row, the displaced row and the pivot column through `buf` (LDS, double-buffered by pivot parity); every
+// lane then updates its T^2 elements with fused multiply-adds; the eliminated column is overwritten by the column of the inverse (zeroed
+// before the update, with 1 / pivot standing in for the pivot row's entry).  The pivot row is wave-uniform (held in a scalar register), so
+// picking the register slot that holds it is a scalar branch, not a select chain over the slots.  The row exchanges are undone as
+// column exchanges when the result is written.  D is read, Dinv written (row-major, LDS or HBM); buf: 10 M2 + 64 doubles of LDS.
 template <int T> __device__ bool gj_inverse_registers(const double* D, double* Dinv, double* buf) {
     constexpr int MP = 16 * T;
     const int lane = threadIdx.x, ly = lane >> 4, lx = lane & 15;
-    double a[T][T], b[T][T];
+    double a[T][T];
 #pragma unroll
     for (int rb = 0; rb < T; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < T; ++cb) {
-            const int r = rb * 16 + ly, c = cb * 16 + lx;
-            a[rb][cb] = D[r * MP + c];
-            b[rb][cb] = (r == c) ? 1.0 : 0.0;
-        }
-    double* cand = buf + 10 * MP;   // [2][16]
+        for (int cb = 0; cb < T; ++cb) a[rb][cb] = D[(rb * 16 + ly) * MP + cb * 16 + lx];
+    double* cand = buf + 6 * MP;                          // [2][16]
+    int* ipiv = reinterpret_cast<int*>(buf + 6 * MP + 32);  // [MP]
+    int* dst = ipiv + MP;                                  // [MP]
     bool ok = true;
 #pragma unroll
     for (int kb = 0; kb < T; ++kb)
         for (int kl = 0; kl < 16 && ok; ++kl) {
             const int cc = kb * 16 + kl, par = cc & 1;
-            double* rowp = buf + par * 5 * MP;   // [2 MP] row that becomes the pivot row (old row piv): matrix part, inverse part
-            double* rowc = rowp + 2 * MP;        // [2 MP] old row cc
-            double* colf = rowp + 4 * MP;        // [MP]   column cc
+            double* rowp = buf + par * 3 * MP;   // [MP] row that becomes the pivot row (old row piv)
+            double* rowc = rowp + MP;            // [MP] old row cc
+            double* colf = rowp + 2 * MP;        // [MP] column cc
             double* cnd = cand + par * 16;
             // ---- pivot search over rows >= cc of column cc
             if (lx == kl) {
@@ -978,41 +977,37 @@ template <int T> __device__ bool gj_inverse_registers(const double* D, double* D
             if (!pivot_usable(pvc)) { ok = false; break; }
             const int piv = __builtin_amdgcn_readfirstlane(pivot_row(pvc));
             const int prb = piv >> 4, pl = piv & 15;
+            if (lane == 0) ipiv[cc] = piv;
             // ---- publish the two rows and the column
 #pragma unroll
             for (int rb = 0; rb < T; ++rb)
                 if (rb == prb && ly == pl) {
 #pragma unroll
-                    for (int cb = 0; cb < T; ++cb) {
-                        rowp[cb * 16 + lx] = a[rb][cb];
-                        rowp[MP + cb * 16 + lx] = b[rb][cb];
-                    }
+                    for (int cb = 0; cb < T; ++cb) rowp[cb * 16 + lx] = a[rb][cb];
                 }
             if (ly == kl) {
 #pragma unroll
-                for (int cb = 0; cb < T; ++cb) {
-                    rowc[cb * 16 + lx] = a[kb][cb];
-                    rowc[MP + cb * 16 + lx] = b[kb][cb];
-                }
+                for (int cb = 0; cb < T; ++cb) rowc[cb * 16 + lx] = a[kb][cb];
             }
             if (lx == kl) {
 #pragma unroll
-                for (int rb = 0; rb < T; ++rb) colf[rb * 16 + ly] = a[rb][kb];
+                for (int rb = 0; rb < T; ++rb) {
+                    colf[rb * 16 + ly] = a[rb][kb];
+                    a[rb][kb] = 0.0;             // the column of the inverse grows here
+                }
             }
             __syncthreads();
             // ---- update: every row loses f_r times the new pivot row; then row piv <- old row cc (eliminated), row cc <- pivot row
             const double inv = 1.0 / rowp[cc];
-            double pa[T], pb[T];
+            double pa[T];
 #pragma unroll
-            for (int cb = 0; cb < T; ++cb) {
-                pa[cb] = rowp[cb * 16 + lx] * inv;
-                pb[cb] = rowp[MP + cb * 16 + lx] * inv;
-            }
+            for (int cb = 0; cb < T; ++cb) pa[cb] = rowp[cb * 16 + lx] * inv;
+            if (lx == kl) pa[kb] = inv;
 #pragma unroll
             for (int rb = 0; rb < T; ++rb) {
                 const double f = colf[rb * 16 + ly];
 #pragma unroll
-                for (int cb = 0; cb < T; ++cb) { a[rb][cb] -= f * pa[cb]; b[rb][cb] -= f * pb[cb]; }
+                for (int cb = 0; cb < T; ++cb) a[rb][cb] -= f * pa[cb];
             }
 #pragma unroll
             for (int rb = 0; rb < T; ++rb)
@@ -1020,20 +1015,32 @@ template <int T> __device__ bool gj_inverse_registers(const double* D, double* D
                     const double f = colf[cc];   // the displaced row cc carries its own column-cc entry
 #pragma unroll
                     for (int cb = 0; cb < T; ++cb) {
-                        a[rb][cb] = rowc[cb * 16 + lx] - f * pa[cb];
-                        b[rb][cb] = rowc[MP + cb * 16 + lx] - f * pb[cb];
+                        const double old = (cb == kb && lx == kl) ? 0.0 : rowc[cb * 16 + lx];
+                        a[rb][cb] = old - f * pa[cb];
                     }
                 }
             if (ly == kl) {
 #pragma unroll
-                for (int cb = 0; cb < T; ++cb) { a[kb][cb] = pa[cb]; b[kb][cb] = pb[cb]; }
+                for (int cb = 0; cb < T; ++cb) a[kb][cb] = pa[cb];
             }
         }
     __syncthreads();
+    // ---- undo the row exchanges as column exchanges (k descending) while writing out
+    if (lane == 0 && ok) {
+        for (int c = 0; c < MP; ++c) dst[c] = c;
+        for (int k = MP - 1; k >= 0; --k) {
+            const int p = ipiv[k];
+            if (p != k) { const int t = dst[k]; dst[k] = dst[p]; dst[p] = t; }
+        }
+        for (int c = 0; c < MP; ++c) ipiv[dst[c]] = c;   // final column of computed column
+    }
+    __syncthreads();
+    if (ok) {
 #pragma unroll
-    for (int rb = 0; rb < T; ++rb)
+        for (int rb = 0; rb < T; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < T; ++cb) Dinv[(rb * 16 + ly) * MP + cb * 16 + lx] = b[rb][cb];
+            for (int cb = 0; cb < T; ++cb) Dinv[(rb * 16 + ly) * MP + ipiv[cb * 16 + lx]] = a[rb][cb];
+    }
     __syncthreads();
     return ok;
 }
