@@ -1,12 +1,12 @@
-// DISCO hot path for MI355X -- polarised (NSTOKES = 3) radiances, per-task device math, first correct form.
+// DISCO hot path for MI355X -- polarised (NSTOKES = 3) radiances and weighting functions, run-time matrix size.
 //
 // Same formulation as disco_core.hpp (symmetrised eigenproblem + Jacobi, Green's function particular solution,
 // block-tridiagonal boundary value problem, Legendre-space source table) written for a run-time matrix size
 // n = NSTOKES * N (row r = NSTOKES * stream + Stokes component).  The two heavy stages (layer eigen-solution, boundary value
 // problem) are written for a team of lanes sharing the work matrices of one task (a wavefront / workgroup with the matrices in
-// LDS when they fit, in HBM otherwise); the light stages run one thread per task with a thread-strided HBM scratch.  It is the
-// device-side specification the matrix-core kernels of the scalar path will be generalised against; the C ABI uses it for
-// NSTOKES = 3 radiances (weighting functions of the polarised solver are not built yet).
+// LDS when they fit, in HBM otherwise) with the matrix products on the FP64 matrix cores (team_gemm); the light stages run one thread
+// per task with a thread-strided HBM scratch.  The C ABI uses it for NSTOKES = 3, for stream counts off the matrix-core path of the
+// scalar kernels and for scattering-group weighting functions.
 //
 // Facts the formulation rests on (checked numerically against the oracle, tests/test_vector_emulation.py):
 //   * with the Greek matrix B_l = [[a1, -b1, 0], [-b1, a2, 0], [0, 0, a3]], Pi_l = [[P, 0, 0], [0, R, -T], [0, -T, R]] and
