@@ -19,6 +19,7 @@
 //   * a Lambertian surface couples intensity rows only (v_plus / v_minus, sktran_do_rte.h:116-150).
 // The same file is compiled with g++ by tests/emulate_vector.cpp (test infrastructure) to run the task bodies on the CPU.
 #pragma once
+#include <type_traits>
 #include "disco_core.hpp"
 
 namespace skv {
@@ -329,6 +330,344 @@ template <class FA, class FB, class FC> SKV_TEAM_BODY void team_gemm(const Team&
 #endif
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Register-resident form of team_jacobi for even n with at most 4 blocks and 8 eigenvector pairs per lane.  The matrix lives in POSITION
+// space: the rotations of every round pair the positions (2k, 2k+1), and between rounds the data move by the fixed round-robin permutation
+// pi (position 0 stays, the even positions shift up, the odd ones down, the ends cross over), so after the n - 1 rounds of a sweep every
+// entry is back at its own index.  A lane owns the same 2x2 blocks (pair k rows x pair k' columns) and eigenvector pairs in every round:
+// it keeps them in registers, rotates them, writes the results to their permuted places in LDS, and after the barrier reads its own
+// places again; all addresses are computed once.  The lanes that own the diagonal blocks compute the rotations from their registers.
+// A round costs two barriers and no index arithmetic.  The pairing sequence differs from the indexed form (same sweeps, other order).
+SKV_TEAM_BODY bool team_jacobi_registers(const Team& team, int n, double* Mx, double* V, double* rot) {
+    constexpr int UA = 4, UV = 8;
+    const int half = n / 2, nblk = half * half, nvj = n * half;
+    const int nua = (nblk + team.width - 1) / team.width, nuv = (nvj + team.width - 1) / team.width;   // slots in use (team-uniform)
+    double* cs = rot;            // (cos, sin) of pair k at [2 k], [2 k + 1]
+    double* red = rot + n;       // [2][16] partial sums of the convergence test, one pair per wavefront
+    auto perm = [&](int i) {     // round-robin move of position i
+        if (i == 0 || n == 2) return i;
+        if (i & 1) return (i == 1) ? 2 : i - 2;
+        return (i == n - 2) ? n - 1 : i + 2;
+    };
+    double a00[UA], a01[UA], a10[UA], a11[UA], vp[UV], vq[UV];
+    int own[UA], dst00[UA], dst01[UA], dst10[UA], dst11[UA], kk1[UA], kk2[UA], vown[UV], vdp[UV], vdq[UV], vk2[UV];
+    bool aon[UA], von[UV];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+        const int bk = team.lane + u * team.width;
+        aon[u] = u < nua && bk < nblk;
+        // the diagonal blocks come first (slot 0 of the first lanes: only they compute rotations), then the off-diagonal ones row by row
+        int k = 0, k2 = 0;
+        if (aon[u]) {
+            if (bk < half) {
+                k = k2 = bk;
+            } else {
+                const int o = bk - half, j = o % (half - 1);
+                k = o / (half - 1);
+                k2 = j + (j >= k ? 1 : 0);
+            }
+        }
+        kk1[u] = k;
+        kk2[u] = k2;
+        own[u] = (2 * k) * n + 2 * k2;
+        const int pr0 = perm(2 * k), pr1 = perm(2 * k + 1), pc0 = perm(2 * k2), pc1 = perm(2 * k2 + 1);
+        dst00[u] = pr0 * n + pc0;
+        dst01[u] = pr0 * n + pc1;
+        dst10[u] = pr1 * n + pc0;
+        dst11[u] = pr1 * n + pc1;
+        a00[u] = a01[u] = a10[u] = a11[u] = 0.0;
+        if (aon[u]) {
+            a00[u] = Mx[own[u]];
+            a01[u] = Mx[own[u] + 1];
+            a10[u] = Mx[own[u] + n];
+            a11[u] = Mx[own[u] + n + 1];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+        const int e = team.lane + u * team.width;
+        von[u] = u < nuv && e < nvj;
+        const int r = von[u] ? e / half : 0, k2 = von[u] ? e % half : 0;
+        vk2[u] = k2;
+        vown[u] = r * n + 2 * k2;
+        vdp[u] = r * n + perm(2 * k2);
+        vdq[u] = r * n + perm(2 * k2 + 1);
+        vp[u] = vq[u] = 0.0;
+        if (von[u]) {
+            vp[u] = V[vown[u]];
+            vq[u] = V[vown[u] + 1];
+        }
+    }
+    bool converged = false;
+    for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
+        // convergence: off-diagonal mass (upper triangle) against the diagonal, from the registers
+        double off = 0, dia = 0;
+#pragma unroll
+        for (int u = 0; u < UA; ++u)
+            if (aon[u]) {
+                if (kk1[u] == kk2[u]) {
+                    dia += a00[u] * a00[u] + a11[u] * a11[u];
+                    off += a01[u] * a01[u];
+                } else if (kk1[u] < kk2[u]) {
+                    off += a00[u] * a00[u] + a01[u] * a01[u] + a10[u] * a10[u] + a11[u] * a11[u];
+                }
+            }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            off += __shfl_xor(off, o);
+            dia += __shfl_xor(dia, o);
+        }
+        team.sync();
+        if ((team.lane & 63) == 0) {
+            red[team.lane >> 6] = off;
+            red[16 + (team.lane >> 6)] = dia;
+        }
+        team.sync();
+        off = 0;
+        dia = 0;
+        for (int wv = 0; wv < (team.width + 63) / 64; ++wv) {
+            off += red[wv];
+            dia += red[16 + wv];
+        }
+#ifdef SKV_EXP_JAC_SWEEPS
+        if (sweep >= SKV_EXP_JAC_SWEEPS) { converged = true; break; }
+#else
+        if (off <= 1e-30 * dia || off == 0) { converged = true; break; }
+#endif
+        for (int step = 0; step < n - 1; ++step) {
+            // ---- rotations from the diagonal blocks (slot 0 of the lanes below half)
+            if (team.lane < half) {
+                double c = 1.0, sn = 0.0;
+                const double apq = a01[0];
+                if (apq != 0.0) {
+                    const double d = 0.5 * (a11[0] - a00[0]);
+                    const double inv_r = recip_sqrt(d * d + apq * apq);
+                    const double h = 0.5 + 0.5 * fabs(d) * inv_r;
+                    const double inv_c = recip_sqrt(h);
+                    c = h * inv_c;
+                    sn = (d >= 0 ? 0.5 : -0.5) * apq * inv_r * inv_c;
+                }
+                cs[2 * team.lane] = c;
+                cs[2 * team.lane + 1] = sn;
+            }
+            team.sync();
+            // ---- rotate the blocks and the eigenvector pairs, results to their next places
+#pragma unroll
+            for (int u = 0; u < UA; ++u)
+                if (u < nua) {
+                    const double c1 = cs[2 * kk1[u]], s1 = cs[2 * kk1[u] + 1], c2 = cs[2 * kk2[u]], s2 = cs[2 * kk2[u] + 1];
+                    const double t00 = c2 * a00[u] - s2 * a01[u], t01 = s2 * a00[u] + c2 * a01[u];
+                    const double t10 = c2 * a10[u] - s2 * a11[u], t11 = s2 * a10[u] + c2 * a11[u];
+                    const bool zero = u == 0 && team.lane < half && s1 != 0.0;   // the rotated pair is annihilated exactly
+                    const double r00 = c1 * t00 - s1 * t10, r11 = s1 * t01 + c1 * t11;
+                    const double r10 = zero ? 0.0 : s1 * t00 + c1 * t10, r01 = zero ? 0.0 : c1 * t01 - s1 * t11;
+                    if (aon[u]) {
+                        Mx[dst00[u]] = r00;
+                        Mx[dst01[u]] = r01;
+                        Mx[dst10[u]] = r10;
+                        Mx[dst11[u]] = r11;
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < UV; ++u)
+                if (u < nuv) {
+                    const double c2 = cs[2 * vk2[u]], s2 = cs[2 * vk2[u] + 1];
+                    const double np_ = c2 * vp[u] - s2 * vq[u], nq_ = s2 * vp[u] + c2 * vq[u];
+                    if (von[u]) {
+                        V[vdp[u]] = np_;
+                        V[vdq[u]] = nq_;
+                    }
+                }
+            team.sync();
+#pragma unroll
+            for (int u = 0; u < UA; ++u)
+                if (u < nua && aon[u]) {
+                    a00[u] = Mx[own[u]];
+                    a01[u] = Mx[own[u] + 1];
+                    a10[u] = Mx[own[u] + n];
+                    a11[u] = Mx[own[u] + n + 1];
+                }
+#pragma unroll
+            for (int u = 0; u < UV; ++u)
+                if (u < nuv && von[u]) {
+                    vp[u] = V[vown[u]];
+                    vq[u] = V[vown[u] + 1];
+                }
+        }
+    }
+    team.sync();
+    return converged;
+}
+#endif
+
+// Symmetric eigenproblem of a team: cyclic Jacobi with the round-robin ("tournament") ordering, n/2 disjoint rotations per round applied
+// as A <- J^T A J, V <- V J (V must hold the identity on entry; the eigenvalues end on the diagonal of Mx).  Each round is one pass over
+// the 2x2 blocks (pair k rows x pair k' columns): a block is read, rotated from both sides and written by one lane, so the update is in
+// place and needs no barrier between the column and the row rotation.  rot: n + 64 doubles of team-shared work space.
+// Returns false when 60 sweeps did not converge.
+SKV_TEAM_BODY bool team_jacobi(const Team& team, int n, double* Mx, double* V, double* rot) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SKV_JACOBI_INDEXED)
+    if ((n & 1) == 0 && (n / 2) * (n / 2) <= 4 * team.width && n * (n / 2) <= 8 * team.width && team.width <= 1024)
+        return team_jacobi_registers(team, n, Mx, V, rot);
+#endif
+    const int np = (n + 1) & ~1, half = np / 2;
+    double* cs = rot;                                  // (cos, sin) of pair k at [2 k], [2 k + 1] (sin = 0 when the pair is skipped)
+    int* pq = reinterpret_cast<int*>(rot + np);        // members of pair k in this round: p | q << 16  (np + half / 2 <= n + 64 doubles)
+    const float inv_half = 1.0f / float(half);
+    bool converged = false;
+    for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
+        // convergence: off-diagonal mass against the diagonal (row sums in parallel, then every lane adds the n row sums)
+        team.sync();
+        SKV_PAR(i, n) rot[i] = sum4(i + 1, n, [&](int j) { return Mx[i * n + j] * Mx[i * n + j]; });
+        team.sync();
+        double off = 0, dia = 0;
+        for (int i = 0; i < n; ++i) {
+            dia += Mx[i * n + i] * Mx[i * n + i];
+            off += rot[i];
+        }
+#ifdef SKV_EXP_JAC_SWEEPS
+        if (sweep >= SKV_EXP_JAC_SWEEPS) { converged = true; break; }
+#else
+        if (off <= 1e-30 * dia || off == 0) { converged = true; break; }
+#endif
+        for (int step = 0; step < np - 1; ++step) {
+            auto pair_of = [&](int k, int& pp, int& q) {
+                // branch-free: k = 0 pairs the fixed index np - 1 with `step`, k > 0 pairs (step + k) with (step - k) modulo np - 1
+                const int up = step + k, dn = step - k;
+                const int a_ = (k == 0) ? np - 1 : (up >= np - 1 ? up - (np - 1) : up);
+                const int b_ = (k == 0) ? step : (dn < 0 ? dn + (np - 1) : dn);
+                pp = a_ < b_ ? a_ : b_;
+                q = a_ < b_ ? b_ : a_;
+            };
+            team.sync();
+            SKV_PAR(k, half) {
+                int pp, q;
+                pair_of(k, pp, q);
+                double c = 1.0, sn = 0.0;
+#ifndef SKV_EXP_JAC_NOROT
+                if (q < n)
+#else
+                if (q < 0)
+#endif
+                {
+                    const double apq = Mx[pp * n + q];
+                    if (apq != 0.0) {
+                        // tan(2 phi) = apq / d, |phi| <= pi/4:  cos(2 phi) = |d| / r,  c = sqrt((1 + cos 2phi) / 2),
+                        // s = sin(2 phi) / (2 c) -- two reciprocal square roots, no cancellation
+                        const double d = 0.5 * (Mx[q * n + q] - Mx[pp * n + pp]);
+                        const double inv_r = recip_sqrt(d * d + apq * apq);
+                        const double h = 0.5 + 0.5 * fabs(d) * inv_r;
+                        const double inv_c = recip_sqrt(h);
+                        c = h * inv_c;
+                        sn = (d >= 0 ? 0.5 : -0.5) * apq * inv_r * inv_c;
+                    }
+                }
+                cs[2 * k] = c;
+                cs[2 * k + 1] = sn;
+                pq[k] = pp | (q << 16);
+            }
+            team.sync();
+            // A <- J^T A J by blocks, four blocks in flight per lane.  Index arithmetic and loads are branch-free (slots beyond the
+            // last block repeat the lane's first block, the phantom index of an odd n is clamped: its rotation is the identity, so the
+            // clamped operands only reach results that are not stored); only the stores are predicated.
+#ifdef SKV_EXP_JAC_NOA
+            const int nblk = 0;
+#else
+            const int nblk = half * half;
+#endif
+            auto block_phase = [&](auto UC) {
+              constexpr int U = decltype(UC)::value;
+              for (int b0 = team.lane; b0 < nblk; b0 += U * team.width) {
+                double r00[U], r01[U], r10[U], r11[U];
+                int i00[U], i01[U], i10[U], i11[U];
+                bool on[U], v1[U], v2[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int bk_ = b0 + u * team.width;
+                    on[u] = bk_ < nblk;
+                    const int bk = on[u] ? bk_ : b0;
+                    const int k = int((float(bk) + 0.5f) * inv_half), k2 = bk - k * half;
+                    const int w1 = pq[k], w2 = pq[k2];
+                    const int P1 = w1 & 0xFFFF, Q1 = w1 >> 16, P2 = w2 & 0xFFFF, Q2 = w2 >> 16;
+                    v1[u] = Q1 < n;
+                    v2[u] = Q2 < n;
+                    const int Q1c = v1[u] ? Q1 : n - 1, Q2c = v2[u] ? Q2 : n - 1;
+                    i00[u] = P1 * n + P2;
+                    i01[u] = P1 * n + Q2c;
+                    i10[u] = Q1c * n + P2;
+                    i11[u] = Q1c * n + Q2c;
+                    const double c1 = cs[2 * k], s1 = cs[2 * k + 1], c2 = cs[2 * k2], s2 = cs[2 * k2 + 1];
+                    const double a00 = Mx[i00[u]], a01 = Mx[i01[u]], a10 = Mx[i10[u]], a11 = Mx[i11[u]];
+                    // columns (pair k'), then rows (pair k)
+                    const double t00 = c2 * a00 - s2 * a01, t01 = s2 * a00 + c2 * a01;
+                    const double t10 = c2 * a10 - s2 * a11, t11 = s2 * a10 + c2 * a11;
+                    const bool zero = (k == k2) && s1 != 0.0;   // the rotated pair is annihilated exactly
+                    r00[u] = c1 * t00 - s1 * t10;
+                    r10[u] = zero ? 0.0 : s1 * t00 + c1 * t10;
+                    r01[u] = zero ? 0.0 : c1 * t01 - s1 * t11;
+                    r11[u] = s1 * t01 + c1 * t11;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (on[u]) {
+                        Mx[i00[u]] = r00[u];
+                        if (v2[u]) Mx[i01[u]] = r01[u];
+                        if (v1[u]) Mx[i10[u]] = r10[u];
+                        if (v1[u] && v2[u]) Mx[i11[u]] = r11[u];
+                    }
+                }
+              }
+            };
+            // blocks in flight per lane: as many as the lane has (1, 2 or 4)
+            if (nblk <= team.width) block_phase(std::integral_constant<int, 1>{});
+            else if (nblk <= 2 * team.width) block_phase(std::integral_constant<int, 2>{});
+            else block_phase(std::integral_constant<int, 4>{});
+            // V <- V J, four (row, pair) items in flight per lane
+#ifdef SKV_EXP_JAC_NOV
+            const int nvj = 0;
+#else
+            const int nvj = n * half;
+#endif
+            auto vector_phase = [&](auto UC) {
+              constexpr int U = decltype(UC)::value;
+              for (int e0 = team.lane; e0 < nvj; e0 += U * team.width) {
+                double np_[U], nq_[U];
+                int ip[U], iq[U];
+                bool on[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e_ = e0 + u * team.width;
+                    const bool in = e_ < nvj;
+                    const int e = in ? e_ : e0;
+                    const int r = int((float(e) + 0.5f) * inv_half), k2 = e - r * half;
+                    const int w2 = pq[k2];
+                    const int P2 = w2 & 0xFFFF, Q2 = w2 >> 16;
+                    on[u] = in && Q2 < n;
+                    ip[u] = r * n + P2;
+                    iq[u] = r * n + (Q2 < n ? Q2 : n - 1);
+                    const double c2 = cs[2 * k2], s2 = cs[2 * k2 + 1];
+                    const double vp_ = V[ip[u]], vq_ = V[iq[u]];
+                    np_[u] = c2 * vp_ - s2 * vq_;
+                    nq_[u] = s2 * vp_ + c2 * vq_;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (on[u]) {
+                        V[ip[u]] = np_[u];
+                        V[iq[u]] = nq_[u];
+                    }
+                }
+              }
+            };
+            if (nvj <= team.width) vector_phase(std::integral_constant<int, 1>{});
+            else if (nvj <= 2 * team.width) vector_phase(std::integral_constant<int, 2>{});
+            else vector_phase(std::integral_constant<int, 4>{});
+        }
+        team.sync();
+    }
+    return converged;
+}
+
 // =================================================================================================
 // KV1: homogeneous + particular solution of one layer for azimuth order m    (task = wavelength x layer, one team)
 //   ws: 8 n^2 + 20 n + 64 doubles of team-shared work space (LDS when it fits, HBM otherwise)
@@ -425,152 +764,9 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
               });
     SKV_PAR(e, nn) V[e] = (e / n == e % n) ? 1.0 : 0.0;
     team.sync();
-    // ---- Jacobi with the round-robin ("tournament") ordering: n/2 disjoint rotations per step, applied as A <- J^T A J.
-    //      Each round is one pass over the 2x2 blocks (pair k rows x pair k' columns): a block is read, rotated from both sides and
-    //      written by one lane, so the update is in place and needs no barrier between the column and the row rotation.
+    // ---- eigen-decomposition of the symmetrised matrix (team_jacobi)
     auto jacobi = [&](double* Mx) {
-        const int np = (n + 1) & ~1, half = np / 2;
-        double* rc = rot;          // cos of pair k
-        double* rs = rot + half;   // sin of pair k (0 when the pair is skipped)
-        const float inv_half = 1.0f / float(half);
-        bool converged = false;
-        for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
-            // convergence: off-diagonal mass against the diagonal (row sums in parallel, then every lane adds the n row sums)
-            team.sync();
-            SKV_PAR(i, n) rot[i] = sum4(i + 1, n, [&](int j) { return Mx[i * n + j] * Mx[i * n + j]; });
-            team.sync();
-            double off = 0, dia = 0;
-            for (int i = 0; i < n; ++i) {
-                dia += Mx[i * n + i] * Mx[i * n + i];
-                off += rot[i];
-            }
-#ifdef SKV_EXP_JAC_SWEEPS
-            if (sweep >= SKV_EXP_JAC_SWEEPS) { converged = true; break; }
-#else
-            if (off <= 1e-30 * dia || off == 0) { converged = true; break; }
-#endif
-            for (int step = 0; step < np - 1; ++step) {
-                auto pair_of = [&](int k, int& pp, int& q) {
-                    int a_, b_;
-                    if (k == 0) { a_ = np - 1; b_ = step; }
-                    else {
-                        a_ = step + k;
-                        if (a_ >= np - 1) a_ -= np - 1;
-                        b_ = step - k;
-                        if (b_ < 0) b_ += np - 1;
-                    }
-                    pp = a_ < b_ ? a_ : b_;
-                    q = a_ < b_ ? b_ : a_;
-                };
-                team.sync();
-                SKV_PAR(k, half) {
-                    int pp, q;
-                    pair_of(k, pp, q);
-                    double c = 1.0, sn = 0.0;
-#ifndef SKV_EXP_JAC_NOROT
-                    if (q < n)
-#else
-                    if (q < 0)
-#endif
-                    {
-                        const double apq = Mx[pp * n + q];
-                        if (apq != 0.0) {
-                            // tan(2 phi) = apq / d, |phi| <= pi/4:  cos(2 phi) = |d| / r,  c = sqrt((1 + cos 2phi) / 2),
-                            // s = sin(2 phi) / (2 c) -- two reciprocal square roots, no cancellation
-                            const double d = 0.5 * (Mx[q * n + q] - Mx[pp * n + pp]);
-                            const double inv_r = recip_sqrt(d * d + apq * apq);
-                            const double h = 0.5 + 0.5 * fabs(d) * inv_r;
-                            const double inv_c = recip_sqrt(h);
-                            c = h * inv_c;
-                            sn = (d >= 0 ? 0.5 : -0.5) * apq * inv_r * inv_c;
-                        }
-                    }
-                    rc[k] = c;
-                    rs[k] = sn;
-                }
-                team.sync();
-                // A <- J^T A J by blocks, four blocks in flight per lane
-#ifdef SKV_EXP_JAC_NOA
-                const int nblk = 0;
-#else
-                const int nblk = half * half;
-#endif
-                for (int b0 = team.lane; b0 < nblk; b0 += 4 * team.width) {
-                    double a00[4], a01[4], a10[4], a11[4], c1[4], s1[4], c2[4], s2[4];
-                    int P1[4], Q1[4], P2[4], Q2[4];
-                    bool same[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int bk = b0 + u * team.width;
-                        P1[u] = -1;
-                        if (bk < nblk) {
-                            const int k = int((float(bk) + 0.5f) * inv_half), k2 = bk - k * half;
-                            pair_of(k, P1[u], Q1[u]);
-                            pair_of(k2, P2[u], Q2[u]);
-                            same[u] = k == k2;
-                            c1[u] = rc[k];
-                            s1[u] = rs[k];
-                            c2[u] = rc[k2];
-                            s2[u] = rs[k2];
-                            const bool v1 = Q1[u] < n, v2 = Q2[u] < n;
-                            a00[u] = Mx[P1[u] * n + P2[u]];
-                            a01[u] = v2 ? Mx[P1[u] * n + Q2[u]] : 0.0;
-                            a10[u] = v1 ? Mx[Q1[u] * n + P2[u]] : 0.0;
-                            a11[u] = (v1 && v2) ? Mx[Q1[u] * n + Q2[u]] : 0.0;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (P1[u] < 0) continue;
-                        // columns (pair k'), then rows (pair k)
-                        const double t00 = c2[u] * a00[u] - s2[u] * a01[u], t01 = s2[u] * a00[u] + c2[u] * a01[u];
-                        const double t10 = c2[u] * a10[u] - s2[u] * a11[u], t11 = s2[u] * a10[u] + c2[u] * a11[u];
-                        double r00 = c1[u] * t00 - s1[u] * t10, r10 = s1[u] * t00 + c1[u] * t10;
-                        double r01 = c1[u] * t01 - s1[u] * t11, r11 = s1[u] * t01 + c1[u] * t11;
-                        if (same[u] && s1[u] != 0.0) r01 = r10 = 0.0;   // the rotated pair is annihilated exactly
-                        const bool v1 = Q1[u] < n, v2 = Q2[u] < n;
-                        Mx[P1[u] * n + P2[u]] = r00;
-                        if (v2) Mx[P1[u] * n + Q2[u]] = r01;
-                        if (v1) Mx[Q1[u] * n + P2[u]] = r10;
-                        if (v1 && v2) Mx[Q1[u] * n + Q2[u]] = r11;
-                    }
-                }
-                // V <- V J, four (row, pair) items in flight per lane
-#ifdef SKV_EXP_JAC_NOV
-                const int nvj = 0;
-#else
-                const int nvj = n * half;
-#endif
-                for (int e0 = team.lane; e0 < nvj; e0 += 4 * team.width) {
-                    double vp_[4], vq_[4], c2[4], s2[4];
-                    int R[4], P2[4], Q2[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e = e0 + u * team.width;
-                        R[u] = -1;
-                        if (e < nvj) {
-                            const int r = int((float(e) + 0.5f) * inv_half), k2 = e - r * half;
-                            pair_of(k2, P2[u], Q2[u]);
-                            if (Q2[u] < n) {
-                                R[u] = r;
-                                c2[u] = rc[k2];
-                                s2[u] = rs[k2];
-                                vp_[u] = V[r * n + P2[u]];
-                                vq_[u] = V[r * n + Q2[u]];
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (R[u] < 0) continue;
-                        V[R[u] * n + P2[u]] = c2[u] * vp_[u] - s2[u] * vq_[u];
-                        V[R[u] * n + Q2[u]] = s2[u] * vp_[u] + c2[u] * vq_[u];
-                    }
-                }
-            }
-            team.sync();
-        }
-        if (!converged) err |= skd::ERR_EIGEN;
+        if (!team_jacobi(team, n, Mx, V, rot)) err |= skd::ERR_EIGEN;
     };
 #ifdef SKV_EXP_JAC2X
     SKV_PAR(e, nn) Tm[e] = Bm[e];

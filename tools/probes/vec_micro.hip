@@ -6,7 +6,7 @@
 #include <vector>
 #include "disco_vec_core.hpp"
 
-template <int MODE, int M2> __global__ void __launch_bounds__(256) kern(double* out, int reps) {
+template <int MODE, int M2> __global__ void __launch_bounds__(512) kern(double* out, int reps) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ double lds[];
     double* D = lds;
@@ -25,6 +25,15 @@ template <int MODE, int M2> __global__ void __launch_bounds__(256) kern(double* 
             else skv::gj_inverse_registers<3>(D, Dinv, buf);
         } else if constexpr (MODE == 1) {
             if (threadIdx.x < 64) skv::gj_inverse_wave<M2 / 8>(D, Dinv, reinterpret_cast<int*>(buf));
+        } else if constexpr (MODE == 3) {
+            // symmetric test matrix (strong diagonal, smooth off-diagonal part) and V = identity
+            for (int e = threadIdx.x; e < M2 * M2; e += blockDim.x) {
+                const int i = e / M2, j = e % M2;
+                D[e] = (i == j ? 1.0 + 0.05 * i : 0.0) + 0.3 / (1.0 + i + j + r);
+                Dinv[e] = (i == j) ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            skv::team_jacobi(team, M2, D, Dinv, buf);
         } else {
             skv::team_gemm(team, M2, M2, M2, [&](int i, int k) { return D[i * M2 + k]; }, [&](int k, int j) { return D[k * M2 + j]; },
                            [&](int i, int j, double v) { Dinv[i * M2 + j] = v; });
@@ -39,7 +48,7 @@ template <int MODE, int M2> __global__ void __launch_bounds__(256) kern(double* 
 template <int MODE, int M2> void run(const char* name, int threads) {
     const int reps = 50, blocks = 256;
     double* out;
-    hipMalloc(&out, sizeof(double) * blocks * 256);
+    hipMalloc(&out, sizeof(double) * blocks * 512);
     const size_t bytes = sizeof(double) * (2 * M2 * M2 + 10 * M2 + 128);
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern<MODE, M2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
     hipEvent_t e0, e1;
@@ -64,6 +73,10 @@ int main() {
     run<0, 48>("gj_inverse_registers<3>", 256);
     run<1, 48>("gj_inverse_wave<6>", 64);
     run<1, 48>("gj_inverse_wave<6> (256 thr)", 256);
+    run<3, 48>("team_jacobi", 256);
+    run<3, 48>("team_jacobi", 512);
+    run<3, 24>("team_jacobi", 128);
+    run<3, 24>("team_jacobi", 64);
     run<2, 96>("team_gemm", 256);
     run<2, 48>("team_gemm", 256);
     run<2, 48>("team_gemm", 64);
