@@ -1723,6 +1723,11 @@ SKD_HD double* vops_at(const VBufs& v, const Geo& g, int p, int w) {
 // KV2C: adjoint operators of one layer                        (task = wavelength x layer, one team)
 //   ws: 2n NL + 4 n + 5 NL n doubles of team-shared work space (F, temporaries, partial sums of the HD rows)
 SKD_HD size_t kv2c_scratch(int n, int NL, int G = 0) { return 2 * size_t(n) * NL + 4 * size_t(n) + (5 + size_t(G)) * size_t(NL) * n; }
+// the same for a team of `width` lanes: it cuts the solutions into K = width / nstr slices (at most n), not into n
+SKD_HD size_t kv2c_scratch_team(int n, int NL, int G, int width, int nstr) {
+    const int K = (width / nstr) < 1 ? 1 : ((width / nstr) > n ? n : (width / nstr));
+    return 2 * size_t(n) * NL + 4 * size_t(n) + (5 + size_t(G)) * size_t(NL) * K;
+}
 
 SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws) {
     const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
