@@ -420,6 +420,18 @@ def test_vector_limb_16_streams_on_device():
     assert np.max(np.abs(out["radiance"] - ora["radiance"])) < 1e-8 * np.abs(ora["radiance"]).max()
 
 
+@pytest.mark.parametrize("nstr", [24, 32])
+def test_vector_limb_many_streams_with_weighting_functions_on_device(nstr):
+    """The large polarised systems (n = 36: 72 x 72 blocks inverted in the work space, 256-lane register Jacobi; n = 48 as in BASELINE
+    configs[3]: 96 x 96 blocks in the registers of a 256-lane team, 512-lane register Jacobi) against the oracle, weighting functions included."""
+    s = sc.to_vector(sc.limb_c2(num_wavelengths=2, nlyr=12, nstr=nstr), rayleigh_fraction=0.6)
+    s["rays"] = s["rays"][::5]
+    got, ref = run_product(s, derivatives=True), run_oracle(s, derivatives=True)
+    np.testing.assert_allclose(got["radiance"][..., 0], ref["radiance"][..., 0], rtol=RTOL_I)
+    assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-8 * np.abs(ref["radiance"]).max()
+    _assert_vector_wf_parity(got, ref)
+
+
 def _assert_vector_wf_parity(got, ref):
     for k in ("d_extinction", "d_ssa"):
         scale = np.abs(ref[k]).max(axis=3, keepdims=True)          # largest weighting function of the profile, per Stokes component
