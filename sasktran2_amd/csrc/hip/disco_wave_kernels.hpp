@@ -113,6 +113,54 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
     const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * skd::kPi);
     __syncthreads();
 
+#ifndef SKD_K1_JACOBI_LDS
+    // Register-resident Jacobi (see the eigen stage below): the matrix lives in position space -- every round rotates the position
+    // pairs (2k, 2k+1), between rounds the data move by the fixed round-robin permutation -- so a lane owns the same 2x2 blocks (pair k
+    // rows x pair k' columns, the diagonal blocks first) and eigenvector pairs in every round; their LDS places are computed once here.
+    constexpr int JH = (N > 1) ? N / 2 : 1, JNB = JH * JH, JNV = N * JH, JUA = (JNB + LG - 1) / LG, JUV = (JNV + LG - 1) / LG;
+    int j_own[JUA], j_d00[JUA], j_d01[JUA], j_d10[JUA], j_d11[JUA], j_k1[JUA], j_k2[JUA], jv_own[JUV], jv_dp[JUV], jv_dq[JUV], jv_k2[JUV];
+    bool j_on[JUA], jv_on[JUV];
+    {
+        auto jperm = [](int i) {   // round-robin move of position i: 0 stays, even positions shift up, odd ones down, the ends cross over
+            if (i == 0 || N == 2) return i;
+            if (i & 1) return (i == 1) ? 2 : i - 2;
+            return (i == N - 2) ? N - 1 : i + 2;
+        };
+#pragma unroll
+        for (int u = 0; u < JUA; ++u) {
+            const int bk = gl + u * LG;
+            j_on[u] = bk < JNB;
+            int k = 0, k2 = 0;
+            if (j_on[u]) {
+                if (bk < JH) {
+                    k = k2 = bk;
+                } else {
+                    const int o = bk - JH, j = o % (JH > 1 ? JH - 1 : 1);
+                    k = o / (JH > 1 ? JH - 1 : 1);
+                    k2 = j + (j >= k ? 1 : 0);
+                }
+            }
+            j_k1[u] = k;
+            j_k2[u] = k2;
+            j_own[u] = (2 * k) * N + 2 * k2;
+            const int pr0 = jperm(2 * k), pr1 = jperm(2 * k + 1), pc0 = jperm(2 * k2), pc1 = jperm(2 * k2 + 1);
+            j_d00[u] = pr0 * N + pc0;
+            j_d01[u] = pr0 * N + pc1;
+            j_d10[u] = pr1 * N + pc0;
+            j_d11[u] = pr1 * N + pc1;
+        }
+#pragma unroll
+        for (int u = 0; u < JUV; ++u) {
+            const int e = gl + u * LG;
+            jv_on[u] = e < JNV;
+            const int r = jv_on[u] ? e / JH : 0, k2 = jv_on[u] ? e % JH : 0;
+            jv_k2[u] = k2;
+            jv_own[u] = r * N + 2 * k2;
+            jv_dp[u] = r * N + jperm(2 * k2);
+            jv_dq[u] = r * N + jperm(2 * k2 + 1);
+        }
+    }
+#endif
     const int p_begin = blockIdx.y * layers_per_block, p_end = min(nlyr, p_begin + layers_per_block);
 #ifdef SKD_K1_TIMING
     long long tacc[11] = {0,0,0,0,0,0,0,0,0,0,0}, tlast = clock64();
@@ -188,6 +236,118 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
         // partner i' and coefficients (al, be) = (c, -s) for i = p, (c, +s) for i = q, so that (A J)[r][i] = al A[r][i] + be A[r][i'].
         // Eigenvectors accumulate in M5; M6 / M7 are the write buffers of a round (ping-pong, one barrier less).
         bool jac_ok = (N == 1);
+#ifndef SKD_K1_JACOBI_LDS
+        if (N > 1) {
+            double a00[JUA], a01[JUA], a10[JUA], a11[JUA], evp[JUV], evq[JUV];
+#pragma unroll
+            for (int u = 0; u < JUA; ++u) {
+                a00[u] = a01[u] = a10[u] = a11[u] = 0.0;
+                if (j_on[u]) {
+                    a00[u] = M4[j_own[u]];
+                    a01[u] = M4[j_own[u] + 1];
+                    a10[u] = M4[j_own[u] + N];
+                    a11[u] = M4[j_own[u] + N + 1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < JUV; ++u) {
+                evp[u] = evq[u] = 0.0;
+                if (jv_on[u]) {
+                    evp[u] = M5[jv_own[u]];
+                    evq[u] = M5[jv_own[u] + 1];
+                }
+            }
+            for (int sweep = 0; sweep < SKD_EXP_MAXSWEEP && !jac_ok; ++sweep) {
+                // convergence: off-diagonal mass (upper triangle) against the diagonal, from the registers
+                double off = 0, dia = 0;
+#pragma unroll
+                for (int u = 0; u < JUA; ++u)
+                    if (j_on[u]) {
+                        if (j_k1[u] == j_k2[u]) {
+                            dia += a00[u] * a00[u] + a11[u] * a11[u];
+                            off += a01[u] * a01[u];
+                        } else if (j_k1[u] < j_k2[u]) {
+                            off += a00[u] * a00[u] + a01[u] * a01[u] + a10[u] * a10[u] + a11[u] * a11[u];
+                        }
+                    }
+                for (int o = LG / 2; o >= 1; o >>= 1) {
+                    off += __shfl_xor(off, o, LG);
+                    dia += __shfl_xor(dia, o, LG);
+                }
+                const bool conv = (off <= SKD_JACOBI_TOL * dia) || (off == 0);
+                if (__all(conv)) { jac_ok = true; break; }
+                for (int round = 0; round < N - 1; ++round) {
+                    // rotations of the position pairs (2k, 2k+1), by the lanes holding the diagonal blocks (slot 0 of the first N/2 lanes)
+                    if (gl < JH) {
+                        const double apq = a01[0], app = a00[0], aqq = a11[0];
+                        double c = 1.0, sn = 0.0;
+                        if (apq != 0.0) {
+                            // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without the
+                            // division by apq:  t = sgn(d) h / (|d| + sqrt(d^2 + h^2)),  d = aqq - app, h = 2 apq;  c = 1 / sqrt(1 + t^2).
+                            // Reciprocal square roots / reciprocals: hardware estimate + two Newton steps (full double precision).
+                            const double d = aqq - app, h = 2.0 * apq, x = d * d + h * h;
+                            double y = __builtin_amdgcn_rsq(x);
+                            y = y * fma(-0.5 * x * y, y, 1.5);
+                            y = y * fma(-0.5 * x * y, y, 1.5);
+                            const double den = fabs(d) + x * y;
+                            double id = __builtin_amdgcn_rcp(den);
+                            id = fma(fma(-den, id, 1.0), id, id);
+                            id = fma(fma(-den, id, 1.0), id, id);
+                            const double tt = ((d >= 0) ? h : -h) * id;
+                            const double x2 = fma(tt, tt, 1.0);
+                            double y2 = __builtin_amdgcn_rsq(x2);
+                            y2 = y2 * fma(-0.5 * x2 * y2, y2, 1.5);
+                            y2 = y2 * fma(-0.5 * x2 * y2, y2, 1.5);
+                            c = y2;
+                            sn = tt * c;
+                        }
+                        vAl[gl] = c;
+                        vBe[gl] = sn;
+                    }
+                    __syncthreads();
+                    // A <- J^T A J, V <- V J on the registers, results to their next places
+#pragma unroll
+                    for (int u = 0; u < JUA; ++u) {
+                        const double c1 = vAl[j_k1[u]], s1 = vBe[j_k1[u]], c2 = vAl[j_k2[u]], s2 = vBe[j_k2[u]];
+                        const double t00 = c2 * a00[u] - s2 * a01[u], t01 = s2 * a00[u] + c2 * a01[u];
+                        const double t10 = c2 * a10[u] - s2 * a11[u], t11 = s2 * a10[u] + c2 * a11[u];
+                        const bool zero = (u == 0) && (gl < JH) && (s1 != 0.0);   // the rotated pair's off-diagonal element is annihilated exactly
+                        const double r00 = c1 * t00 - s1 * t10, r11 = s1 * t01 + c1 * t11;
+                        const double r10 = zero ? 0.0 : s1 * t00 + c1 * t10, r01 = zero ? 0.0 : c1 * t01 - s1 * t11;
+                        if (j_on[u]) {
+                            M4[j_d00[u]] = r00;
+                            M4[j_d01[u]] = r01;
+                            M4[j_d10[u]] = r10;
+                            M4[j_d11[u]] = r11;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < JUV; ++u) {
+                        const double c2 = vAl[jv_k2[u]], s2 = vBe[jv_k2[u]];
+                        if (jv_on[u]) {
+                            M5[jv_dp[u]] = c2 * evp[u] - s2 * evq[u];
+                            M5[jv_dq[u]] = s2 * evp[u] + c2 * evq[u];
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < JUA; ++u)
+                        if (j_on[u]) {
+                            a00[u] = M4[j_own[u]];
+                            a01[u] = M4[j_own[u] + 1];
+                            a10[u] = M4[j_own[u] + N];
+                            a11[u] = M4[j_own[u] + N + 1];
+                        }
+#pragma unroll
+                    for (int u = 0; u < JUV; ++u)
+                        if (jv_on[u]) {
+                            evp[u] = M5[jv_own[u]];
+                            evq[u] = M5[jv_own[u] + 1];
+                        }
+                }
+            }
+        }
+#else
         constexpr int NM1 = (N > 1) ? N - 1 : 1;
         if (N > 1) {
             double* Acur = M4;
@@ -263,6 +423,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
                 __syncthreads();
             }
         }
+#endif
         K1T(4)
         if (!jac_ok && gl == 0) sErr = skd::ERR_EIGEN;
         if (gl < N) {
