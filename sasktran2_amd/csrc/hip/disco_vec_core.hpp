@@ -673,6 +673,11 @@ SKV_TEAM_BODY bool team_jacobi(const Team& team, int n, double* Mx, double* V, d
 //   ws: 8 n^2 + 20 n + 64 doubles of team-shared work space (LDS when it fits, HBM otherwise)
 // =================================================================================================
 SKD_HD size_t kv1_scratch(int n) { return 8 * size_t(n) * n + 20 * size_t(n) + 64; }
+#if defined(SKV_K1_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define KV1T(i) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; }
+#else
+#define KV1T(i)
+#endif
 
 SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws,
                                    bool derivs = false) {
@@ -687,6 +692,9 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
     (void)acm;
     auto rw = [&](int r) { return g.wt[r / S]; };
     auto rmu = [&](int r) { return g.mu[r / S]; };
+#if defined(SKV_K1_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
     // ---- E+ = (plain + negated) / 2, E- = (plain - negated) / 2 of the Greek-matrix products: one (i, j) block per lane
     SKV_PAR(blk, N * N) {
         const int i = blk / N, j = blk % N;
@@ -732,6 +740,7 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
     }
     team.sync();
     int err = 0;
+    KV1T(0)
     // ---- Cholesky B+ = L L^T (lower, in place), one column per step
     for (int j = 0; j < n; ++j) {
         double d = Bp[j * n + j] - sum4(0, j, [&](int k) { return Bp[j * n + k] * Bp[j * n + k]; });
@@ -750,6 +759,7 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
         }
         team.sync();
     }
+    KV1T(1)
     // ---- As = L^T B- L (into Bm)
     // (the strict upper triangle of the Cholesky factor is zero, so the full-range products are the triangular ones)
     team_gemm(team, n, n, n, [&](int i, int r) { return Bm[i * n + r]; }, [&](int r, int j) { return Bp[r * n + j]; },
@@ -764,6 +774,7 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
               });
     SKV_PAR(e, nn) V[e] = (e / n == e % n) ? 1.0 : 0.0;
     team.sync();
+    KV1T(2)
     // ---- eigen-decomposition of the symmetrised matrix (team_jacobi)
     auto jacobi = [&](double* Mx) {
         if (!team_jacobi(team, n, Mx, V, rot)) err |= skd::ERR_EIGEN;
@@ -778,6 +789,7 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
 #endif
     jacobi(Bm);
     team.sync();
+    KV1T(3)
     SKV_PAR(j, n) {
         double l_ = Bm[j * n + j];
         if (!(l_ > 0)) { l_ = fabs(l_) + 1e-300; lam[j] = -1.0; } else { lam[j] = l_; }
@@ -798,6 +810,7 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
     team_gemm(team, n, n, n, [&](int i, int r) { return rw(r) * Ep[i * n + r]; }, [&](int r, int j) { return X[r * n + j]; },
               [&](int i, int j, double val) { U[i * n + j] = (X[i * n + j] - om * val) / rmu(i); });
     team.sync();
+    KV1T(4)
     // ---- omega derivatives by bi-orthogonal perturbation theory (left vectors W M S+ X), as skd::k1_layer_solution:
     //      d(Gamma) X_j = [2 lam_j X_j - M^-1 U_j - S- M^-1 X_j] / om ;  dk_j = z_jj / (2 k_j) ;  dX = X C, C_ab = z_ab / (lam_b - lam_a)
     double* dX = V;    // V is free once X is known
@@ -831,6 +844,7 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
         team.sync();
         dU = Tm;
     }
+    KV1T(5)
     // ---- W+-, dW+-, norms (one solution per lane)
     double* dnrm = rot;  // the rotation parameters of the Jacobi sweeps are free now (n + 64 >= n doubles)
     SKV_PAR(j, n) {
@@ -855,6 +869,7 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
         nrm[j] = nr;
         dnrm[j] = dnr;
     }
+    KV1T(6)
     // ---- solar pseudo-source: first column of the products with the unpolarised sun (single_scat_st, sktran_do_lpproduct.h:339-384)
     const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * kPi);
     const double* lpc = g.lpcsz + (size_t(s) * nstr + m) * nstr;
@@ -959,6 +974,7 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
         for (int t = 0; t < 4; ++t)
             for (int c = 0; c < 4; ++c) rec[R.DG() + (t * 4 + c) * n + i] = dg[t][c];
     }
+    KV1T(7)
     // ---- scattering groups: the same perturbation theory along a general direction dc of the layer coefficients,
     //      dS+- = -om M^-1 dE+-(dc) W ;  d(Gamma) X = dS- U + S- (dS+ X) ;  dU = dS+ X + S+ dX ;  dQ = Q(dc)
     //      (the omega derivative above is the direction dc = c / om)
@@ -1112,6 +1128,12 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
             }
         }
     }
+    KV1T(8)
+#if defined(SKV_K1_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    if (team.lane == 0 && w == 0 && p == g.nlyr / 2 && m == 1)
+        printf("KV1T n %d lanes %d: build %lld chol %lld LtBL %lld jacobi %lld eigvec+U %lld om-derivs %lld W+norms %lld Q/Green/G %lld groups %lld\n", n, team.width,
+               tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6], tacc[7], tacc[8]);
+#endif
     team.sync();
     if (err && team.lane == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
