@@ -232,9 +232,10 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
         K1T(2)
         K1T(3)
         // Jacobi on M4 with the round-robin ("tournament") ordering: every round applies N/2 disjoint rotations at once,
-        // A <- J^T A J and V <- V J with J the product of the round's rotations.  Index i of a rotated pair (p, q) has
-        // partner i' and coefficients (al, be) = (c, -s) for i = p, (c, +s) for i = q, so that (A J)[r][i] = al A[r][i] + be A[r][i'].
-        // Eigenvectors accumulate in M5; M6 / M7 are the write buffers of a round (ping-pong, one barrier less).
+        // A <- J^T A J and V <- V J with J the product of the round's rotations; eigenvectors accumulate in M5.
+        // Default: register-resident blocks in position space (ownership tables above): rotate in registers, write to the permuted
+        // places, read the own places back.  SKD_K1_JACOBI_LDS keeps the earlier form for comparison (index i of a rotated pair (p, q)
+        // has partner i' and coefficients (al, be) = (c, -s) for i = p, (c, +s) for i = q; M6 / M7 are the ping-pong write buffers).
         bool jac_ok = (N == 1);
 #ifndef SKD_K1_JACOBI_LDS
         if (N > 1) {
