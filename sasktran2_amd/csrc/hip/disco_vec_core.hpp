@@ -1752,6 +1752,12 @@ SKD_HD size_t kv2c_scratch_team(int n, int NL, int G, int width, int nstr) {
 }
 
 SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws) {
+#if defined(SKV_K2C_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define KV2CT(i) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; }
+#else
+#define KV2CT(i)
+#endif
     const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
     const VRec R(n);
     const VOps O(n, NL, v.ngroups);
@@ -1892,10 +1898,12 @@ SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg
         }
     }
     team.sync();
+    KV2CT(0)
     // ---- FP = Dinv^T F
     if (table)
         team_gemm(team, M2, NL, M2, [&](int i, int j) { return dinv[j * M2 + i]; }, [&](int j, int lam_) { return F[j * NL + lam_]; },
                   [&](int i, int lam_, double val) { o[O.FP() + i * NL + lam_] = val; });
+    KV2CT(1)
     // ---- SP = Dinv^T SupT, BP = Dinv^T SubT  (SupT[j][i] = W-(i,j), SupT[n+j][i] = W+(i,j) E_j ; SubT[j][i] = W+(i,j) E_j, SubT[n+j][i] = W-(i,j))
     team_gemm(team, M2, M2, M2, [&](int i, int j) { return dinv[j * M2 + i]; },
               [&](int j, int cc) {   // columns 0 .. n-1: SupT, n .. 2n-1: SubT
@@ -1908,6 +1916,7 @@ SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg
                   if (cc < n) o[O.SP() + i * n + cc] = val;
                   else o[O.BP() + i * n + (cc - n)] = val;
               });
+    KV2CT(2)
     // ---- edge-intensity derivatives at fixed (L, M), one row per lane
     SKV_PAR(i, n) {
         double d_tau[4] = {0, 0, 0, 0}, d_om[4] = {0, 0, 0, 0}, ipb_i = c[R.G() + 2 * n + i];
@@ -1948,6 +1957,7 @@ SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg
             o[O.DI() + (skd::TH_SEC * 4 + e) * n + i] = c[R.DG() + (skd::TH_SEC * 4 + e) * n + i];
         }
     }
+    KV2CT(3)
     // ground part of u (order 0, last layer): tmp = [2 rho sp_j E_j ; 2 rho sm_j] over the intensity rows
     SKV_PAR(j, n) {
         double sp = 0, sm = 0;
@@ -1979,6 +1989,13 @@ SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg
         }
     }
     team.sync();
+    KV2CT(4)
+#if defined(SKV_K2C_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    // phase shares measured (32 / 16 streams): Legendre sums + F / HD rows 55 / 46 %, FP 13 / 10 %, SP / BP 18 / 14 %, edge derivatives 9 / 25 %.
+    // (the Legendre sums as one fused team_gemm with the result staged in HBM were measured slower: 198 -> 224 ms, 110 -> 128 ms)
+    if (team.lane == 0 && w == 0 && p == g.nlyr / 2 && m == 1)
+        printf("KV2CT n %d lanes %d: F/HD %lld FP %lld SP/BP %lld edge %lld ground/UG %lld\n", n, team.width, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
+#endif
 }
 
 // out[i] (+)= sum_{k in [k0, K)} A[i * ld + k] * x[k], i < M: eight outputs at a time, so that one load of x[k] (thread-strided scratch) feeds
