@@ -123,6 +123,44 @@ def test_full_size_c2_properties():
     assert d2.max() < 1e-5
 
 
+def test_full_size_c4_properties():
+    """BASELINE configs[3] at full size (NSTOKES = 3, 32 streams, 60 layers, 5 000 wavelengths, weighting functions): size-independent
+    properties + oracle spot checks.  The spectrum is solved in balanced blocks sized from the free HBM; a subset solved alone must agree
+    bit for bit (wavelength independence across block boundaries)."""
+    from tests.gpu_harness import build_engine
+    nw = 5_000
+    s = sc.to_vector(sc.limb_c2(num_wavelengths=nw, nlyr=60, nstr=32), rayleigh_fraction=0.6)
+    eng = build_engine(s)
+    full = run_product(s, derivatives=True, engine=eng)
+    assert np.all(np.isfinite(full["radiance"])) and np.all(full["radiance"][..., 0] > 0)
+    for k in ("d_extinction", "d_ssa", "d_albedo"):
+        assert np.all(np.isfinite(full[k]))
+    assert np.abs(full["radiance"][..., 1:]).max() > 1e-4          # the scene polarises
+    idx = np.array([0, 2_499, 2_500, 4_999])                        # both sides of the block boundary of a two-block solve
+    sub = copy.deepcopy(s)
+    for k in ("extinction", "ssa"):
+        sub[k] = s[k][:, idx]
+    sub["leg"] = s["leg"][:, :, idx]
+    sub["albedo"] = s["albedo"][idx]
+    part = run_product(sub, derivatives=True, engine=eng)
+    for k in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
+        np.testing.assert_array_equal(part[k], full[k][idx])
+    # oracle spot check (dense forward-mode linearization, ~11 s per wavelength and core) on two of them
+    two = copy.deepcopy(sub)
+    for k in ("extinction", "ssa"):
+        two[k] = sub[k][:, [0, 3]]
+    two["leg"] = sub["leg"][:, :, [0, 3]]
+    two["albedo"] = sub["albedo"][[0, 3]]
+    ref = run_oracle(two, derivatives=True)
+    got = {k: part[k][[0, 3]] for k in ("radiance", "d_extinction", "d_ssa", "d_albedo")}   # wavelength is the first axis of every output
+    np.testing.assert_allclose(got["radiance"][..., 0], ref["radiance"][..., 0], rtol=RTOL_I)
+    assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-8 * np.abs(ref["radiance"]).max()
+    _assert_vector_wf_parity(got, ref)
+    # smoothness in wavelength: inputs vary linearly, so second differences of the intensity spectrum are small
+    d2 = np.abs(np.diff(full["radiance"][..., 0], 2, axis=0)) / full["radiance"][1:-1, :, 0]
+    assert d2.max() < 1e-5
+
+
 def test_weighting_functions_match_gpu_finite_differences():
     from tests.gpu_harness import build_engine
     # the regression scenario has a stable set of azimuth orders; with aerosol phase functions the reference's
