@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I sasktran2_amd/csrc/hip tools/probes/vec_micro.hip -o tools/probes/_bin/vec_micro
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "disco_vec_core.hpp"
 
@@ -45,8 +46,9 @@ template <int MODE, int M2> __global__ void __launch_bounds__(512) kern(double* 
 #endif
 }
 
+static int g_blocks = 256;
 template <int MODE, int M2> void run(const char* name, int threads) {
-    const int reps = 50, blocks = 256;
+    const int reps = 50, blocks = g_blocks;
     double* out;
     hipMalloc(&out, sizeof(double) * blocks * 512);
     const size_t bytes = sizeof(double) * (2 * M2 * M2 + 10 * M2 + 128);
@@ -68,7 +70,9 @@ template <int MODE, int M2> void run(const char* name, int threads) {
     hipFree(out);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_blocks = atoi(argv[1]);   // workgroups in flight (256 = one per CU)
+    printf("workgroups: %d\n", g_blocks);
     run<0, 96>("gj_inverse_registers<6>", 256);
     run<0, 48>("gj_inverse_registers<3>", 256);
     run<1, 48>("gj_inverse_wave<6>", 64);
