@@ -741,20 +741,30 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
     team.sync();
     int err = 0;
     KV1T(0)
-    // ---- Cholesky B+ = L L^T (lower, in place), one column per step
-    for (int j = 0; j < n; ++j) {
-        double d = Bp[j * n + j] - sum4(0, j, [&](int k) { return Bp[j * n + k] * Bp[j * n + k]; });
-        if (!(d > 0)) { err |= skd::ERR_CHOLESKY; d = 1.0; }
-        d = sqrt(d);
-        team.sync();
-        SKV_PAR(i, n) {
-            if (i > j) {
-                const double t = Bp[i * n + j] - sum4(0, j, [&](int k) { return Bp[i * n + k] * Bp[j * n + k]; });
-                Bp[i * n + j] = t / d;
-            } else if (i == j) {
-                Bp[j * n + j] = d;
-            } else {
-                Bp[i * n + j] = 0;
+    // ---- Cholesky B+ = L L^T (lower, in place), right-looking: step j scales column j and takes its outer product off the trailing
+    //      lower triangle.  The column is staged in a contiguous vector first: the trailing update then reads rows contiguously and the
+    //      staged column as a broadcast / contiguous vector (a dot-product form walks the rows with stride n: 24- to 32-way LDS bank
+    //      conflicts at n = 24 / 48, measured 11-13 % of the whole eigen stage).
+    {
+        double* colj = rot;   // staged column j, already divided by the pivot's square root (free until the Jacobi sweeps)
+        for (int j = 0; j < n; ++j) {
+            team.sync();      // trailing update of step j - 1 visible
+            double d = Bp[j * n + j];
+            if (!(d > 0)) { err |= skd::ERR_CHOLESKY; d = 1.0; }
+            d = sqrt(d);
+            const double inv_d = 1.0 / d;
+            SKV_PAR(i, n) {
+                const double l_ij = (i > j) ? Bp[i * n + j] * inv_d : (i == j ? d : 0.0);
+                colj[i] = l_ij;
+                if (i != j) Bp[i * n + j] = l_ij;   // final column j of the factor (zero above the diagonal); the pivot itself is still being read
+            }
+            team.sync();
+            if (team.lane == 0) Bp[j * n + j] = d;
+            const int mrem = n - j - 1;
+            const float inv_m = mrem > 0 ? 1.0f / float(mrem) : 0.0f;
+            SKV_PAR(e, mrem * mrem) {
+                const int ii = int((float(e) + 0.5f) * inv_m), i = j + 1 + ii, k = j + 1 + (e - ii * mrem);
+                if (k <= i) Bp[i * n + k] -= colj[i] * colj[k];
             }
         }
         team.sync();
