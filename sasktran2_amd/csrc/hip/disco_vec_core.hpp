@@ -915,14 +915,19 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
         double* cj = coef + 12 * j;
         for (int t = 0; t < 12; ++t) cj[t] = 0;
         if (!allzero) {
+            // W+- and their derivatives from the team-shared X, U, dX, dU (contiguous over the solutions; the stored records would be
+            // walked with stride n in HBM)
+            const double inv_k = 1.0 / kk[j], dk_l = derivs ? dk[j] / lam[j] : 0.0, inv_om = 1.0 / om;
             for (int i = 0; i < n; ++i) {
-                const double wp = rec[R.WP() + i + n * j], wm = rec[R.WM() + i + n * j];
+                const double uk = U[i * n + j] * inv_k;
+                const double wp = 0.5 * (X[i * n + j] + uk), wm = 0.5 * (X[i * n + j] - uk);
                 Ap += Qp[i] * wp + Qm[i] * wm;
                 Am += Qm[i] * wp + Qp[i] * wm;
                 if (derivs) {
-                    const double dwp = rec[R.DWP() + i + n * j], dwm = rec[R.DWM() + i + n * j];
-                    dAp += Qp[i] * dwp + Qp[i] / om * wp + Qm[i] * dwm + Qm[i] / om * wm;
-                    dAm += Qm[i] * dwp + Qm[i] / om * wp + Qp[i] * dwm + Qp[i] / om * wm;
+                    const double duk = dU[i * n + j] * inv_k - U[i * n + j] * dk_l;
+                    const double dwp = 0.5 * (dX[i * n + j] + duk), dwm = 0.5 * (dX[i * n + j] - duk);
+                    dAp += Qp[i] * dwp + Qp[i] * inv_om * wp + Qm[i] * dwm + Qm[i] * inv_om * wm;
+                    dAm += Qm[i] * dwp + Qm[i] * inv_om * wp + Qp[i] * dwm + Qp[i] * inv_om * wm;
                 }
             }
             Ap /= nrm[j];
