@@ -1396,6 +1396,12 @@ template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g,
     const int mm = M2 * M2;
     double *D = ws, *Dinv = ws + mm, *r = ws + 2 * mm, *rprev = r + M2, *xn = rprev + M2, *fcol = xn + M2, *refl = fcol + M2;  // refl: 2n
     double* gjbuf = refl + 2 * n;  // 10 M2 + 64 doubles, exchange buffers of the register-resident inversion
+#if defined(SKV_K2_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define KV2T(i) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; }
+#else
+#define KV2T(i)
+#endif
     bool singular = false;
     for (int p = 0; p < nlyr; ++p) {
         const double* c = vrec_at(v, nlyr, p, w);
@@ -1410,6 +1416,7 @@ template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g,
                       [&](int k, int j) { return Dinv[k * M2 + j]; }, [&](int i, int j, double val) { T1[j * n + i] = val; });
         }
 #endif
+        KV2T(0)
         if (p == nlyr - 1 && m == 0) {
             // Lambertian reflection sums over the intensity rows of the downwelling field
             SKV_PAR(j, n) {
@@ -1463,6 +1470,7 @@ template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g,
             r[n + i] = rb;
         }
         team.sync();
+        KV2T(1)
         // Gauss-Jordan inverse with partial pivoting: register-resident for 256-lane teams and 48 x 48 / 96 x 96 blocks, else in place
         bool inverted = false;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1516,6 +1524,7 @@ template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g,
             }
             team.sync();
         }
+        KV2T(2)
         double* dst = vdinv_at(v, nlyr, p, w);
         double* xs = vxsol_at(v, nlyr, p, w);
         SKV_PAR(e, mm) dst[e] = Dinv[e];
@@ -1524,6 +1533,7 @@ template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g,
             xs[i] = r[i];
         }
     }
+    KV2T(3)
     team.sync();
     if (singular && team.lane == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1554,6 +1564,11 @@ template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g,
         }
     }
     team.sync();
+    KV2T(4)
+#if defined(SKV_K2_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    if (team.lane == 0 && w == 0 && m == 1)
+        printf("KV2T n %d lanes %d: T1 %lld D+update+r %lld inverse %lld store %lld backsub %lld\n", n, team.width, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
+#endif
 }
 
 // Legendre-space source vectors of a layer:  J(out)[s] = sum_l [Pi_l(out) v_l][s],
