@@ -1381,7 +1381,8 @@ template <int TS> __device__ bool gj_inverse_wave(const double* D, double* Dinv,
 //   same block rows as skd::k2a_bvp with 2n x 2n blocks; team-shared work space: ws (8 n^2 + 10 n doubles: the block and its
 //   inverse, vectors) and t1 (2 n^2 doubles), which may live in different memories (LDS / HBM)
 // =================================================================================================
-SKD_HD size_t kv2_scratch_main(int n) { return 8 * size_t(n) * n + 30 * size_t(n) + 64; }
+//   with a register-resident inversion (GJ != 0) the inverse overwrites the block: `inplace` halves the matrix part
+SKD_HD size_t kv2_scratch_main(int n, bool inplace = false) { return (inplace ? 4 : 8) * size_t(n) * n + 30 * size_t(n) + 64; }
 SKD_HD size_t kv2_scratch_t1(int n) { return 2 * size_t(n) * n; }
 SKD_HD size_t kv2_scratch(int n) { return kv2_scratch_main(n) + kv2_scratch_t1(n); }
 
@@ -1394,7 +1395,10 @@ template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g,
     const double rho = (m == 0) ? b.albedo[w] : 0.0;  // Lambertian
     const double kd = 2.0;
     const int mm = M2 * M2;
-    double *D = ws, *Dinv = ws + mm, *r = ws + 2 * mm, *rprev = r + M2, *xn = rprev + M2, *fcol = xn + M2, *refl = fcol + M2;  // refl: 2n
+    // the register-resident inversions read the whole block before they write the inverse, and the block of the next layer is only built after
+    // the product with the previous inverse: block and inverse share their storage then
+    constexpr bool inplace = (GJ != 0);
+    double *D = ws, *Dinv = inplace ? ws : ws + mm, *r = ws + (inplace ? 1 : 2) * mm, *rprev = r + M2, *xn = rprev + M2, *fcol = xn + M2, *refl = fcol + M2;  // refl: 2n
     double* gjbuf = refl + 2 * n;  // 10 M2 + 64 doubles, exchange buffers of the register-resident inversion
 #if defined(SKV_K2_TIMING) && defined(__HIP_DEVICE_COMPILE__)
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
