@@ -66,6 +66,7 @@ struct VBufs {
     double* grad;           // [4 nlyr + 2][tid3] reduced gradient of the current solar zenith index
     double* dnat;           // [2 ngrid + 1][tid3] native derivatives
     int derivs;
+    int k1_compact;         // eigen-stage work space in its compact layout (kv1_scratch(n, true)); set by the launcher
     // scattering-group derivatives (directional derivatives wrt the layer Greek coefficients, sktran_do_layerarray.cpp:496-513,759-860)
     int ngroups;            // G
     const double* dleg;     // [g][wavelength of the whole spectrum][q][nleg][4 | 1]  d_legendre of the scattering derivative mappings
@@ -672,7 +673,9 @@ SKV_TEAM_BODY bool team_jacobi(const Team& team, int n, double* Mx, double* V, d
 // KV1: homogeneous + particular solution of one layer for azimuth order m    (task = wavelength x layer, one team)
 //   ws: 8 n^2 + 20 n + 64 doubles of team-shared work space (LDS when it fits, HBM otherwise)
 // =================================================================================================
-SKD_HD size_t kv1_scratch(int n) { return 8 * size_t(n) * n + 20 * size_t(n) + 64; }
+//   `compact`: without scattering groups the Green's-function coefficients (12 n doubles) live in the storage of the Cholesky factor, which
+//   is dead by then -- at 16 polarised streams that is what lets a fourth team onto the CU (38.9 instead of 41.2 KB)
+SKD_HD size_t kv1_scratch(int n, bool compact = false) { return 8 * size_t(n) * n + (compact ? 8 : 20) * size_t(n) + 64; }
 #if defined(SKV_K1_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 #define KV1T(i) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; }
 #else
@@ -688,7 +691,7 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
     const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
     const int nn = n * n;
     double *Ep = ws, *Em = ws + nn, *Bp = ws + 2 * nn, *Bm = ws + 3 * nn, *Tm = ws + 4 * nn, *V = ws + 5 * nn, *X = ws + 6 * nn, *U = ws + 7 * nn;
-    double *lam = ws + 8 * nn, *kk = lam + n, *nrm = kk + n, *Qp = nrm + n, *Qm = Qp + n, *acp = Qm + n, *acm = acp + n, *rot = acm + n, *coef = rot + n + 64;  // rot: n + 64, coef: 12 n
+    double *lam = ws + 8 * nn, *kk = lam + n, *nrm = kk + n, *Qp = nrm + n, *Qm = Qp + n, *acp = Qm + n, *acm = acp + n, *rot = acm + n, *coef = (v.ngroups > 0 || !v.k1_compact) ? rot + n + 64 : Bp;  // rot: n + 64, coef: 12 n (see kv1_scratch)
     (void)acm;
     auto rw = [&](int r) { return g.wt[r / S]; };
     auto rmu = [&](int r) { return g.mu[r / S]; };
