@@ -633,6 +633,23 @@ def test_scattering_group_derivatives_match_finite_differences(nstr, delta_m):
         assert np.max(np.abs(fd - an)) < 1e-5 * np.abs(res["wf_scatterer"]).max(), q
 
 
+@pytest.mark.parametrize("knob,value", [("SASKTRAN2_AMD_VEC_W48", "1"), ("SASKTRAN2_AMD_VEC_W48", "0"), ("SASKTRAN2_AMD_VEC_LDS", "30"),
+                                        ("SASKTRAN2_AMD_VEC_T2", "256"), ("SASKTRAN2_AMD_VEC_T2B", "256"), ("SASKTRAN2_AMD_VEC_SWEEP_THREADS", "1")])
+def test_vector_occupancy_variants_agree(monkeypatch, knob, value):
+    """The launch variants the polarised driver chooses between by block size (register-limited 48 x 48 BVP kernel with T1 in HBM, work
+    matrices in HBM instead of LDS, other team widths, per-column adjoint sweeps) are the same arithmetic: 16-stream limb scene with weighting functions."""
+    s = sc.to_vector(sc.limb_c2(num_wavelengths=3, nlyr=20, nstr=16), rayleigh_fraction=0.6)
+    s["rays"] = s["rays"][::4]
+    base = run_product(s, derivatives=True)
+    monkeypatch.setenv(knob, value)
+    other = run_product(s, derivatives=True)
+    np.testing.assert_allclose(other["radiance"], base["radiance"], rtol=1e-11, atol=1e-18)
+    for k in ("d_extinction", "d_ssa"):
+        scale = np.abs(base[k]).max(axis=3, keepdims=True)
+        assert np.max(np.abs(other[k] - base[k]) / np.where(scale > 0, scale, 1.0)) < 1e-9, k
+    np.testing.assert_allclose(other["d_albedo"], base["d_albedo"], rtol=1e-9, atol=1e-18)
+
+
 def test_vector_results_do_not_depend_on_the_block_size(monkeypatch):
     # blocks of the spectrum are independent: a chunked solve is bit-identical (radiances, weighting functions, group derivatives' inputs)
     s = sc.to_vector(sc.regression_1d(5), rayleigh_fraction=0.9)
