@@ -2197,25 +2197,46 @@ SKV_TEAM_BODY void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, con
         const double* ops = vops_at(v, g, p, w);
         const bool last = (p == nlyr - 1);
         team.sync();
-        SKV_PAR(col, NC) {   // Legendre-space weights of the column's line of sight (row `sout` of Pi_l at the table angles)
-            const int los = col / S, sout = col % S;
-            for (int l = 0; l < NL; ++l) QL[size_t(l) * NC + col] = 0;
-            const int base = (los * g.nsza + s) * nlyr + p;
-            for (int t = g.lp_start[base]; t < g.lp_start[base + 1]; ++t) {
-                if (skd::conv_at(b, g, g.lp_slot[t], w) <= m) continue;
-                const int q = g.lp_q[t];
-                const double az = (sout < 2) ? g.rl_cosm[size_t(m) * g.nq_total + q] : vg.rl_sinm_t[size_t(q) * nstr + m];
-                const double cw = b.srcw[size_t(q) * nw + w] * g.lp_w[t] * az;
-                if (cw == 0.0) continue;
-                const Fun3 fa = fun_ang(g, vg, m, g.lp_angle[t]);
-                for (int l = m; l < nstr; ++l) {
-                    if (S == 1) { QL[size_t(l) * NC + col] += cw * fa.P[l]; continue; }
-                    if (sout == 0) QL[size_t(l * 3) * NC + col] += cw * fa.P[l];
-                    else if (sout == 1) { QL[size_t(l * 3 + 1) * NC + col] += cw * fa.R[l]; QL[size_t(l * 3 + 2) * NC + col] -= cw * fa.T[l]; }
-                    else { QL[size_t(l * 3 + 1) * NC + col] -= cw * fa.T[l]; QL[size_t(l * 3 + 2) * NC + col] += cw * fa.R[l]; }
+        {   // Legendre-space weights of the column's line of sight (row `sout` of Pi_l at the table angles): a lane takes one column and a
+            // chunk of the Legendre orders, accumulates in registers (eight orders at a time) and writes every entry once
+            const int LC = (team.width / NC) < 1 ? 1 : ((team.width / NC) > nstr ? nstr : (team.width / NC)), per = (nstr + LC - 1) / LC;
+            SKV_PAR(item, NC * LC) {
+                const int col = item % NC, ch = item / NC, los = col / S, sout = col % S;
+                const int l0 = ch * per, l1 = (l0 + per < nstr) ? l0 + per : nstr;
+                const int base = (los * g.nsza + s) * nlyr + p;
+                for (int lb = l0; lb < l1; lb += 4) {
+                    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+                    for (int t = g.lp_start[base]; t < g.lp_start[base + 1]; ++t) {
+                        if (skd::conv_at(b, g, g.lp_slot[t], w) <= m) continue;
+                        const int q = g.lp_q[t];
+                        const double az = (sout < 2) ? g.rl_cosm[size_t(m) * g.nq_total + q] : vg.rl_sinm_t[size_t(q) * nstr + m];
+                        const double cw = b.srcw[size_t(q) * nw + w] * g.lp_w[t] * az;
+                        if (cw == 0.0) continue;
+                        const Fun3 fa = fun_ang(g, vg, m, g.lp_angle[t]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int l = lb + u;
+                            if (l >= l1 || l < m) continue;
+                            if (S == 1 || sout == 0) a0[u] += cw * fa.P[l];
+                            else if (sout == 1) { a1[u] += cw * fa.R[l]; a2[u] -= cw * fa.T[l]; }
+                            else { a1[u] -= cw * fa.T[l]; a2[u] += cw * fa.R[l]; }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int l = lb + u;
+                        if (l >= l1) continue;
+                        QL[size_t(l * C) * NC + col] = a0[u];
+                        v.qlbuf[(size_t(p) * NL + l * C) * nt + t0 + col] = a0[u];
+                        if (C == 3) {
+                            QL[size_t(l * C + 1) * NC + col] = a1[u];
+                            QL[size_t(l * C + 2) * NC + col] = a2[u];
+                            v.qlbuf[(size_t(p) * NL + l * C + 1) * nt + t0 + col] = a1[u];
+                            v.qlbuf[(size_t(p) * NL + l * C + 2) * nt + t0 + col] = a2[u];
+                        }
+                    }
                 }
             }
-            for (int l = 0; l < NL; ++l) v.qlbuf[(size_t(p) * NL + l) * nt + t0 + col] = QL[size_t(l) * NC + col];
         }
         team.sync();
         team_gemm(team, M2, NC, NL, [&](int i, int k) { return ops[O.FP() + i * NL + k]; }, [&](int k, int col) { return QL[size_t(k) * NC + col]; },
