@@ -2273,9 +2273,75 @@ SKV_TEAM_BODY void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, con
         }
     }
     team.sync();
-    // ---- reduced gradient, one column per lane
-    SKV_PAR(col, NC) adjoint_gradient_column(g, b, v, s, m, w, t0 + col, nt, gwv[col], true);
-    team.sync();
+    // ---- reduced gradient: a lane takes one column and a chunk of the contraction indices (solutions, Legendre entries), the partial
+    //      sums meet in the free QL storage; the sweep states are read once.  (More than four scattering groups: one column per lane.)
+    const int NG = v.ngroups, NR = 4 + NG;
+    int CH = team.width / NC;
+    if (CH > 8) CH = 8;
+    while (CH > 1 && CH * (NR + 1) > NL) --CH;
+    if (NG > 4 || CH < 2) {
+        SKV_PAR(col, NC) adjoint_gradient_column(g, b, v, s, m, w, t0 + col, nt, gwv[col], true);
+        team.sync();
+        return;
+    }
+    double* part = QL;   // [CH][NR + 1][NC]
+    const int peri = (n + CH - 1) / CH, perl = (NL + CH - 1) / CH;
+    for (int p = 0; p < nlyr; ++p) {
+        const double* ops = vops_at(v, g, p, w);
+        const bool last = (p == nlyr - 1);
+        SKV_PAR(item, NC * CH) {
+            const int col = item % NC, ch = item / NC;
+            const size_t tid = t0 + col;
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, zs = 0;
+            const int i0 = ch * peri, i1 = (i0 + peri < n) ? i0 + peri : n;
+            for (int i = i0; i < i1; ++i) {
+                const double zA = v.z[(size_t(p) * M2 + i) * nt + tid], zB = v.z[(size_t(p) * M2 + n + i) * nt + tid];
+                const double zAn = last ? 0.0 : v.z[(size_t(p + 1) * M2 + i) * nt + tid];
+                const double zBp = (p > 0) ? v.z[(size_t(p - 1) * M2 + n + i) * nt + tid] : 0.0;
+                if (last && m == 0 && (i % S) == 0) zs += zB;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[t] += zA * ops[O.DI() + (t * 4 + 0) * n + i] + zBp * ops[O.DI() + (t * 4 + 1) * n + i] -
+                              zAn * ops[O.DI() + (t * 4 + 2) * n + i] - zB * ops[O.DI() + (t * 4 + 3) * n + i];
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi)
+                    if (gi < NG)
+                        acc[4 + gi] += zA * ops[O.GDI(gi) + 0 * n + i] + zBp * ops[O.GDI(gi) + 1 * n + i] - zAn * ops[O.GDI(gi) + 2 * n + i] -
+                                       zB * ops[O.GDI(gi) + 3 * n + i];
+            }
+            const int lf = m * C, l0 = (ch * perl > lf) ? ch * perl : lf, l1 = (ch * perl + perl < NL) ? ch * perl + perl : NL;
+            for (int l = l0; l < l1; ++l) {
+                const double q = v.qlbuf[(size_t(p) * NL + l) * nt + tid];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] += ops[O.HD() + t * NL + l] * q;
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi)
+                    if (gi < NG) acc[4 + gi] += ops[O.GHD(gi) + l] * q;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r < NR) part[(size_t(ch) * (NR + 1) + r) * NC + col] = acc[r];
+            part[(size_t(ch) * (NR + 1) + NR) * NC + col] = zs;
+        }
+        team.sync();
+        SKV_PAR(item, NC * NR) {
+            const int col = item % NC, r = item / NC;
+            const size_t tid = t0 + col;
+            double a_ = 0, zs = 0;
+            for (int ch = 0; ch < CH; ++ch) {
+                a_ += part[(size_t(ch) * (NR + 1) + r) * NC + col];
+                zs += part[(size_t(ch) * (NR + 1) + NR) * NC + col];
+            }
+            if (last && m == 0) a_ += (zs + gwv[col]) * ops[(r < 4) ? O.GD() + r : O.GGD(r - 4)];
+            v.grad[(r < 4 ? size_t(r * nlyr + p) : size_t(4 * nlyr + 2 + (r - 4) * nlyr + p)) * nt + tid] += a_;
+            if (r == 0 && last && m == 0) {
+                const double rho = b.albedo[w], ipb = ops[O.IPB()], gw = gwv[col];
+                v.grad[size_t(4 * nlyr) * nt + tid] += gw * 2.0 * ipb + zs * (2.0 * ipb + g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w]);
+                v.grad[size_t(4 * nlyr + 1) * nt + tid] += zs * g.csz[s] / kPi * rho;
+            }
+        }
+        team.sync();
+    }
 }
 
 // =================================================================================================
