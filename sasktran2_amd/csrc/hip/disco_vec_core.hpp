@@ -1954,7 +1954,52 @@ SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg
                   else o[O.BP() + i * n + (cc - n)] = val;
               });
     KV2CT(2)
-    // ---- edge-intensity derivatives at fixed (L, M), one row per lane
+    // ---- edge-intensity derivatives at fixed (L, M).  Without scattering groups a lane takes one row and a chunk of the solutions, the
+    //      partial sums meet in the (now free) storage of the HD partial sums; otherwise one row per lane.
+    int CHE = (v.ngroups == 0) ? team.width / n : 1;
+    if (CHE > 8) CHE = 8;
+    while (CHE > 1 && size_t(CHE) * 9 * n > size_t(K) * (5 + v.ngroups) * NL) --CHE;
+    if (CHE >= 2) {
+        const int perj = (n + CHE - 1) / CHE;
+        SKV_PAR(item, n * CHE) {
+            const int i = item % n, ch = item / n, j0 = ch * perj, j1 = (j0 + perj < n) ? j0 + perj : n;
+            double d_tau[4] = {0, 0, 0, 0}, d_om[4] = {0, 0, 0, 0}, ipb_i = 0;
+            for (int j = j0; j < j1; ++j) {
+                const double wp = c[R.WP() + i + n * j], wm = c[R.WM() + i + n * j], dwp = c[R.DWP() + i + n * j], dwm = c[R.DWM() + i + n * j];
+                const double E = c[R.E() + j], L = xs[j], Mv = xs[n + j];
+                const double dE_tau = -c[R.K() + j] * E, dE_om = -c[R.DK() + j] * th * E;
+                d_tau[0] += wm * dE_tau * Mv;
+                d_tau[1] += wp * dE_tau * Mv;
+                d_tau[2] += wp * dE_tau * L;
+                d_tau[3] += wm * dE_tau * L;
+                d_om[0] += dwp * L + dwm * E * Mv + wm * dE_om * Mv;
+                d_om[1] += dwm * L + dwp * E * Mv + wp * dE_om * Mv;
+                d_om[2] += dwp * E * L + wp * dE_om * L + dwm * Mv;
+                d_om[3] += dwm * E * L + wm * dE_om * L + dwp * Mv;
+                ipb_i += wp * E * L + wm * Mv;
+            }
+            double* pc = part + size_t(ch) * 9 * n;
+            for (int e = 0; e < 4; ++e) {
+                pc[e * n + i] = d_tau[e];
+                pc[(4 + e) * n + i] = d_om[e];
+            }
+            pc[8 * n + i] = ipb_i;
+        }
+        team.sync();
+        SKV_PAR(i, n) {
+            double sums[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int ch = 0; ch < CHE; ++ch)
+                for (int e = 0; e < 9; ++e) sums[e] += part[(size_t(ch) * 9 + e) * n + i];
+            const double ipb_i = c[R.G() + 2 * n + i] + sums[8];
+            ipbv[i] = ((i % S) == 0) ? g.wt[i / S] * g.mu[i / S] * ipb_i : 0.0;
+            for (int e = 0; e < 4; ++e) {
+                o[O.DI() + (skd::TH_TAU * 4 + e) * n + i] = c[R.DG() + (skd::TH_TAU * 4 + e) * n + i] + sums[e];
+                o[O.DI() + (skd::TH_OM * 4 + e) * n + i] = c[R.DG() + (skd::TH_OM * 4 + e) * n + i] + sums[4 + e];
+                o[O.DI() + (skd::TH_T * 4 + e) * n + i] = c[R.DG() + (skd::TH_T * 4 + e) * n + i];
+                o[O.DI() + (skd::TH_SEC * 4 + e) * n + i] = c[R.DG() + (skd::TH_SEC * 4 + e) * n + i];
+            }
+        }
+    } else
     SKV_PAR(i, n) {
         double d_tau[4] = {0, 0, 0, 0}, d_om[4] = {0, 0, 0, 0}, ipb_i = c[R.G() + 2 * n + i];
         for (int j = 0; j < n; ++j) {
