@@ -233,6 +233,33 @@ class Atmosphere:
     def calculate_derivatives(self):
         return self._calculate_derivatives
 
+    def _native_handles(self, L, nstokes):
+        """The storage / surface / atmosphere handles of this object (created once, as `Atmosphere.internal_object()` of the
+        reference) over private Fortran-ordered buffers that every calculation refills."""
+        if getattr(self, "_H", None) is None:
+            st = self.storage
+            H = {"ext": np.zeros_like(st.total_extinction, order="F"), "ssa": np.zeros_like(st.ssa, order="F"),
+                 "em": np.zeros_like(st.emission_source, order="F"), "leg": np.zeros_like(st.leg_coeff, order="F"),
+                 "irr": np.ones(self._nwavel), "alb": np.zeros(self._nwavel), "emis": np.zeros(self._nwavel)}
+            H["storage"] = L.sk_atmosphere_storage_create(self._ngrid, self._nwavel, H["leg"].shape[0], nstokes, _p(H["ssa"]),
+                                                          _p(H["ext"]), _p(H["em"]), _p(H["leg"]), _p(H["irr"]))
+            H["brdf"] = L.sk_brdf_create_lambertian(nstokes)
+            H["surface"] = L.sk_surface_create(self._nwavel, nstokes, _p(H["emis"]))
+            L.sk_surface_set_brdf(H["surface"], H["brdf"], _p(H["alb"]))
+            H["atmosphere"] = L.sk_atmosphere_create(H["storage"], H["surface"], int(self._calculate_derivatives), 0)
+            self._H = H
+        return self._H
+
+    def __del__(self):
+        H = getattr(self, "_H", None)
+        if H is not None:
+            L = lib()
+            L.sk_atmosphere_destroy(H["atmosphere"])
+            L.sk_surface_destroy(H["surface"])
+            L.sk_brdf_destroy(H["brdf"])
+            L.sk_atmosphere_storage_destroy(H["storage"])
+            self._H = None
+
 
 class Engine:
     """src/sasktran2/engine.py:70-168,474-612 -- `calculate_radiance(atmosphere)` returns the reference's variables
@@ -253,28 +280,31 @@ class Engine:
 
     def calculate_radiance(self, atmosphere, as_dataset=True, _mapping_hook=None):
         """`_mapping_hook(L, storage_handle, output_handle, out_dict)` lets a caller register further derivative mappings through
-        the C ABI before the solve (used by the tests for interpolated / log-space mappings)."""
+        the C ABI before the solve (used by the tests for interpolated / log-space mappings).
+
+        Handle flow of the reference (src/sasktran2/atmosphere.py:719-858): ONE storage / surface / atmosphere handle per Atmosphere
+        object, and before every calculation set_zero -> refill -> derivative mappings -> apply_delta_m_scaling on that handle."""
         L = lib()
         st = atmosphere.storage
         nw, ngrid, nlos = atmosphere._nwavel, atmosphere._ngrid, self.nlos
         S = int(self._config.num_stokes)
         per = 4 if S == 3 else 1
-        ext, ssa = np.asfortranarray(st.total_extinction), np.asfortranarray(st.ssa)
-        em, leg = np.asfortranarray(st.emission_source), np.asfortranarray(st.leg_coeff)
+        H = atmosphere._native_handles(L, S)
+        L.sk_atmosphere_storage_set_zero(H["storage"])
         # delta-M scaling rewrites the storage in place (src/sasktran2/atmosphere.py:845-854 applies it with order = num_streams
-        # when more moments than streams are stored): work on copies so that the caller's arrays keep the unscaled properties
+        # when more moments than streams are stored): the handle maps private copies, the caller's arrays keep the unscaled properties
+        H["ext"][...] = st.total_extinction
+        H["ssa"][...] = st.ssa
+        H["em"][...] = st.emission_source
+        H["leg"][...] = st.leg_coeff
+        H["irr"][...] = st.solar_irradiance
+        H["alb"][...] = atmosphere.surface.albedo
+        H["emis"][...] = atmosphere.surface.emission
         delta_order = None
-        if self._config.delta_m_scaling and leg.shape[0] // per > self._config.num_streams:
+        if self._config.delta_m_scaling and H["leg"].shape[0] // per > self._config.num_streams:
             delta_order = int(self._config.num_streams)
-            ext, ssa, leg = ext.copy(order="F"), ssa.copy(order="F"), leg.copy(order="F")
-        irr, alb = np.ascontiguousarray(st.solar_irradiance), np.ascontiguousarray(atmosphere.surface.albedo, dtype=float)
-        emis = np.ascontiguousarray(atmosphere.surface.emission)
         derivs = atmosphere.calculate_derivatives
-        h_st = L.sk_atmosphere_storage_create(ngrid, nw, leg.shape[0], S, _p(ssa), _p(ext), _p(em), _p(leg), _p(irr))
-        h_brdf = L.sk_brdf_create_lambertian(S)
-        h_su = L.sk_surface_create(nw, S, _p(emis))
-        L.sk_surface_set_brdf(h_su, h_brdf, _p(alb))
-        h_atm = L.sk_atmosphere_create(h_st, h_su, int(derivs), 0)
+        h_st, h_su, h_atm = H["storage"], H["surface"], H["atmosphere"]
         rad = np.zeros((nw, nlos, S))
         h_out = L.sk_output_create(_p(rad), nw * nlos, S, None, 0)
         out = {"radiance": rad}
@@ -310,10 +340,6 @@ class Engine:
             out["los_optical_depth"] = np.ctypeslib.as_array(od, shape=(nlos, nw)).T.copy()
         finally:
             L.sk_output_destroy(h_out)
-            L.sk_atmosphere_destroy(h_atm)
-            L.sk_surface_destroy(h_su)
-            L.sk_brdf_destroy(h_brdf)
-            L.sk_atmosphere_storage_destroy(h_st)
         if as_dataset:
             try:
                 import xarray as xr

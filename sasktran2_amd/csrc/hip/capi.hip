@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <limits>
 #include <map>
 #include <memory>
 #include <string>
@@ -290,8 +291,10 @@ int sk_deriv_mapping_get_num_wavel(DerivativeMapping* m, int* n) { if (!m || !n)
 int sk_deriv_mapping_get_num_output(DerivativeMapping* m, int* n) { if (!m || !n) return -1; *n = m->nloc; return 0; }
 int sk_deriv_mapping_set_zero(DerivativeMapping* m) {
     if (!m) return -1;
-    std::fill(m->d_ssa.begin(), m->d_ssa.end(), 0.0);
-    std::fill(m->d_extinction.begin(), m->d_extinction.end(), 0.0);
+    // every native array of the mapping, as DerivativeMapping::set_zero (cpp/lib/derivative_mapping/derivative_mapping.cpp:61-77),
+    // and the truncation-fraction derivative the delta-M scaling left behind
+    for (std::vector<double>* v : {&m->d_ssa, &m->d_extinction, &m->scat_factor, &m->d_legendre, &m->d_emission, &m->d_f})
+        std::fill(v->begin(), v->end(), 0.0);
     return 0;
 }
 BRDF* sk_brdf_create_lambertian(int) { return new BRDF(); }
@@ -532,6 +535,27 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     return 0;
 }
 
+// Sasktran2::validate_input_atmosphere (cpp/lib/engine/engine.cpp:481-540, cpp/include/sasktran2/validation/validation.h:12-64): unless
+// input_validation_mode is `disabled` (2), extinction must be finite and >= 0 and the single scatter albedo finite and inside [0, 1];
+// the first offending (location, wavelength) is reported in the error text the way the reference logs it.
+static void validate_input_atmosphere(const Engine* e, const AtmosphereStorage& st) {
+    if (e->config.input_validation_mode == 2) return;
+    if (!st.ext || !st.ssa || !st.leg) throw std::runtime_error("Invalid input: atmosphere storage has null arrays");
+    auto scan = [&](const double* a, const char* name, double lo, double hi) {
+        const size_t n = size_t(st.nloc) * st.nwavel;
+        for (size_t i = 0; i < n; ++i) {
+            const double v = a[i];
+            if (std::isfinite(v) && v >= lo && v <= hi) continue;
+            const std::string where = " at location: " + std::to_string(i % st.nloc) + " and wavelength: " + std::to_string(i / st.nloc);
+            if (!std::isfinite(v)) throw std::runtime_error(std::string("Invalid input. ") + name + " contains non-finite values" + where);
+            if (v < lo) throw std::runtime_error(std::string("Invalid input. ") + name + " contains values less than " + std::to_string(lo) + where);
+            throw std::runtime_error(std::string("Invalid input. ") + name + " contains values greater than " + std::to_string(hi) + where);
+        }
+    };
+    scan(st.ext, "Atmosphere total extinction", 0.0, std::numeric_limits<double>::infinity());
+    scan(st.ssa, "Atmosphere single scatter albedo", 0.0, 1.0);
+}
+
 int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /*only_initialize*/) {
     if (!e || !atm || !out || !atm->storage || !atm->surface) return -1;
     try {
@@ -542,6 +566,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (st.nloc != e->ngrid) throw std::runtime_error("atmosphere grid does not match the engine geometry");
         if (!su.brdf_args) throw std::runtime_error("surface has no BRDF set");
         if (su.brdf && su.brdf->kind != 0) return -2;  // only the Lambertian surface is part of this path
+        validate_input_atmosphere(e, st);
         bool scattering_groups = false;
         for (auto& kv : out->derivs) {
             auto it = st.maps.find(kv.first);
@@ -618,6 +643,14 @@ int sk_amd_engine_solve_device(Engine* e, int nwavel, int nleg, const double* d_
                                void* stream, int max_chunk) {
     if (!e) return -1;
     try {
+        // the device-resident entry point cannot look at the values (they live in HBM; non-physical optics surface as status bits),
+        // but shapes and pointers are checked before any kernel sees them
+        if (e->dev->vector_mode()) throw std::runtime_error("this engine runs the run-time-n / polarised kernels: use sk_engine_calculate_radiance");
+        if (nwavel <= 0 || nleg <= 0) throw std::runtime_error("nwavel and nleg must be positive");
+        if (!d_ext || !d_ssa || !d_leg || !d_albedo || !d_radiance || !d_los_od || !d_status)
+            throw std::runtime_error("null device pointer (extinction, ssa, leg_coeff, albedo, radiance, los_od and status are required)");
+        if (derivatives && (!d_wf_ext || !d_wf_ssa || !d_wf_albedo)) throw std::runtime_error("derivatives requested without weighting-function buffers");
+        if (max_chunk < 0) throw std::runtime_error("max_chunk must be >= 0");
         e->dev->solve_device(nwavel, nleg, d_ext, d_ssa, d_leg, d_albedo, d_irradiance, derivatives, d_radiance, d_wf_ext,
                              d_wf_ssa, d_wf_albedo, d_los_od, d_status, stream, max_chunk);
         return 0;

@@ -1422,6 +1422,8 @@ SKD_HD void k4b_los(const Geo& g, const Bufs& b, int los, int w) {
 
 // stop rule of the azimuth expansion (DOSource::calculate, do_source.cpp:47-57): after order m >= 2 with every needed
 // table point converged no further order is solved for this solar zenith index.   (task = wavelength)
+// INVARIANT the order pipeline of run_chunk relies on (kernels of other orders read these without an event): norders[w] is only ever
+// lowered, and only to m + 1 > m; conv_order entries are only ever lowered, and only to m + 1 (K3 of order m + 1 writes m + 2).
 SKD_HD void k_stop_rule(const Geo& g, const Bufs& b, int s, int m, int w) {
     const int nw = b.nw;
     if (m >= b.norders[w]) return;

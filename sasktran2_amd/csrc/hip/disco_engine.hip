@@ -459,7 +459,18 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
     // doubled the three stages  K1 | K2a K3 stop | K2c K2b  of consecutive orders run on three streams.  Measured: it pays when few
     // blocks are in flight (a lone block is bound by the single-wave latency of the layer recursions) and costs a little when
     // three or more blocks already overlap their kernels, so it follows the launch shape unless SASKTRAN2_AMD_LOOKAHEAD says else.
-    static const int lookahead_env = [] { const char* e = std::getenv("SASKTRAN2_AMD_LOOKAHEAD"); return e ? atoi(e) : -1; }();
+    //
+    // Cross-stream accesses that carry no event (deliberately: an event after kern_stop(m - 1) would chain K1(m) behind the BVP of the
+    // previous order and undo the look-ahead).  They rest on one invariant, kept by k_stop_rule and K3 (k3_table_values):
+    //     `norders[w]` and `conv_order[w][slot]` only ever move to values GREATER than the order in flight that could read them.
+    //  * K1(m) on the look-ahead stream tests `m >= norders[w]` while kern_stop(m - 2) / kern_stop(m - 1) on `st` may lower norders to
+    //    m - 1 or m.  A stale (larger) value only makes K1(m) fill the record of parity m & 1 for an order nobody reads: that buffer
+    //    is free (ev_rest[m - 2]), and every consumer of order m (K2a, K3, stop on `st`; K2c / K2b behind ev_bvp[m]) is ordered after
+    //    kern_stop(m - 1) and sees the final count.
+    //  * K2c / K2b(m) on the adjoint stream test `conv_order > m` while kern_stop(m) clamps entries > m + 1 down to m + 1 and K3(m + 1)
+    //    writes m + 2: the test's outcome is the same before and after either write (single-byte / 4-byte stores, no tearing).
+    // tests/test_gpu_parity.py::test_c2_wavelength_blocks_in_flight_are_equivalent compares LOOKAHEAD=0 and =1 bit for bit.
+    const int lookahead_env = [] { const char* e = std::getenv("SASKTRAN2_AMD_LOOKAHEAD"); return e ? atoi(e) : -1; }();
     const bool pipe = !I.profiling && slot.k1_stream != nullptr && (lookahead_env >= 0 ? lookahead_env != 0 : I.last_slots <= 2);
     double* const rec_buf[2] = {b.rec, slot.rec2};
     double* const dinv_buf[2] = {b.dinv, slot.dinv2};
@@ -588,6 +599,21 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
     int nslots = std::max(1, std::min(2, (nwavel + chunk_cap - 1) / chunk_cap));
     if (const char* e = std::getenv("SASKTRAN2_AMD_STREAMS")) nslots = std::max(1, atoi(e));
     int chunk = std::min(chunk_cap, (nwavel + nslots - 1) / nslots);
+    {
+        // HBM budget: all blocks in flight may take half of what is free now plus what this engine already holds (as the polarised
+        // driver does); a tall geometry (e.g. 100 layers x 32 streams x 100 lines of sight ~ 10 MB per wavelength) then runs in
+        // smaller balanced blocks instead of failing in hipMalloc
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const size_t per_w = bytes_per_wavelength();
+        size_t budget = size_t(0.5 * double(free_b + I.scratch_bytes));
+        if (const char* e = std::getenv("SASKTRAN2_AMD_HBM_BUDGET_MB")) budget = size_t(std::max(1, atoi(e))) << 20;  // tests
+        const size_t fit = std::max<size_t>(1, budget / (per_w * size_t(nslots)));
+        if (size_t(chunk) > fit) {
+            const size_t per_slot = (size_t(nwavel) + nslots - 1) / nslots, nblocks = (per_slot + fit - 1) / fit;
+            chunk = int((per_slot + nblocks - 1) / nblocks);
+        }
+    }
     if (max_chunk > 0) chunk = std::min(chunk, max_chunk);
     if (const char* e = std::getenv("SASKTRAN2_AMD_CHUNK")) chunk = std::max(1, atoi(e));
     chunk = std::max(1, std::min(chunk, nwavel));

@@ -109,3 +109,77 @@ def test_handles_without_gpu(built):
         from tests.gpu_harness import build_engine
         with pytest.raises(RuntimeError, match="no HIP device"):
             build_engine(sc.regression_1d())
+
+
+def _storage_with_mapping(L, nloc, nw, nleg, ssa, ext, em, leg, irr):
+    import ctypes
+    dp = ctypes.POINTER(ctypes.c_double)
+    p = lambda a: a.ctypes.data_as(dp)
+    h = L.sk_atmosphere_storage_create(nloc, nw, nleg, 1, p(ssa), p(ext), p(em), p(leg), p(irr))
+    m = ctypes.c_void_p()
+    assert L.sk_atmosphere_storage_get_derivative_mapping(h, b"wf_x", ctypes.byref(m)) == 0
+    views = {}
+    for which, n in (("d_ssa", nloc * nw), ("d_extinction", nloc * nw), ("scat_factor", nloc * nw), ("d_legendre", nleg * nloc * nw)):
+        ptr = dp()
+        assert getattr(L, f"sk_deriv_mapping_get_{which}")(m, ctypes.byref(ptr)) == 0
+        import numpy as np
+        views[which] = np.ctypeslib.as_array(ptr, shape=(n,))
+    return h, m, views
+
+
+def test_storage_handle_reuse_resets_delta_m_state(built):
+    """The reference's Python layer runs set_zero -> refill -> apply_delta_m_scaling on ONE storage handle before every calculation
+    (src/sasktran2/atmosphere.py:719-858; set_zero zeroes f and every mapping, grid_storage.h:319-329).  A second pass over the same
+    handle with different optics must leave exactly the state a fresh handle gets."""
+    import ctypes
+    import numpy as np
+    L = built.lib()
+    nloc, nw, nleg, order = 5, 2, 12, 8
+    rng = np.random.default_rng(11)
+    l = np.arange(nleg)
+
+    def optics(g):
+        ext = np.asfortranarray(rng.uniform(1e-6, 1e-4, (nloc, nw)))
+        ssa = np.asfortranarray(rng.uniform(0.5, 0.99, (nloc, nw)))
+        leg = np.asfortranarray(np.broadcast_to(((2 * l + 1) * g ** l)[:, None, None], (nleg, nloc, nw)).copy())
+        return ext, ssa, leg
+
+    def fill_and_scale(h_atm, views, arrays, src):
+        for a, b in zip(arrays, src):
+            a[...] = b
+        views["d_ssa"][:] = 1.0
+        views["d_extinction"][:] = 1.0
+        assert L.sk_atmosphere_apply_delta_m_scaling(h_atm, order) == 0
+
+    em, irr = np.zeros((nloc, nw), order="F"), np.ones(nw)
+    surface_emission = np.zeros(nw)
+    h_su = L.sk_surface_create(nw, 1, surface_emission.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    first, second = optics(0.8), optics(0.6)
+    # handle A: first optics, then set_zero and the second optics
+    ext, ssa, leg = (np.zeros_like(x) for x in first)
+    hA, mA, vA = _storage_with_mapping(L, nloc, nw, nleg, ssa, ext, em, leg, irr)
+    atmA = L.sk_atmosphere_create(hA, h_su, 1, 0)
+    fill_and_scale(atmA, vA, (ext, ssa, leg), first)
+    assert L.sk_atmosphere_storage_set_zero(hA) == 0
+    assert not ext.any() and not ssa.any() and not leg.any()
+    assert not any(v.any() for v in vA.values())
+    fill_and_scale(atmA, vA, (ext, ssa, leg), second)
+    # handle B: second optics on a fresh handle
+    ext2, ssa2, leg2 = (np.zeros_like(x) for x in second)
+    hB, mB, vB = _storage_with_mapping(L, nloc, nw, nleg, ssa2, ext2, em, leg2, irr)
+    atmB = L.sk_atmosphere_create(hB, h_su, 1, 0)
+    fill_and_scale(atmB, vB, (ext2, ssa2, leg2), second)
+    for a, b in ((ext, ext2), (ssa, ssa2), (leg, leg2), (vA["d_ssa"], vB["d_ssa"]), (vA["d_extinction"], vB["d_extinction"])):
+        np.testing.assert_array_equal(a, b)
+    f = second[2][order] / (2 * order + 1)
+    np.testing.assert_allclose(ext, second[0] * (1 - second[1] * f), rtol=1e-15)
+    # sk_deriv_mapping_set_zero clears every native array of the mapping
+    vA["scat_factor"][:] = 2.0
+    vA["d_legendre"][:] = 3.0
+    assert L.sk_deriv_mapping_set_zero(mA) == 0
+    assert not any(v.any() for v in vA.values())
+    for h in (atmA, atmB):
+        L.sk_atmosphere_destroy(h)
+    for h in (hA, hB):
+        L.sk_atmosphere_storage_destroy(h)
+    L.sk_surface_destroy(h_su)

@@ -235,6 +235,22 @@ def test_c2_wavelength_blocks_in_flight_are_equivalent(monkeypatch):
         for k in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
             assert np.array_equal(one[k], other[k]), ("lookahead", la, k)
     monkeypatch.delenv("SASKTRAN2_AMD_LOOKAHEAD")
+    # ... and the balanced smaller blocks the driver falls back to when the HBM budget does not hold the default block
+    monkeypatch.delenv("SASKTRAN2_AMD_CHUNK")
+    monkeypatch.setenv("SASKTRAN2_AMD_STREAMS", "1")
+    monkeypatch.setenv("SASKTRAN2_AMD_HBM_BUDGET_MB", "400")   # ~1.5 MB of scratch per wavelength: 700 wavelengths do not fit
+    from tests.gpu_harness import build_engine
+    import ctypes
+    import sasktran2_amd._lib_loader as ll
+    eng = build_engine(s)
+    small = run_product(s, engine=eng)
+    chunk, slots = ctypes.c_int(), ctypes.c_int()
+    ll.lib().sk_amd_engine_launch_shape(eng[0]._h, ctypes.byref(chunk), ctypes.byref(slots), None)
+    nblocks = -(-700 // chunk.value)
+    assert 1 <= chunk.value < 700 and chunk.value == -(-700 // nblocks)   # fits the budget, no short tail block
+    for k in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
+        assert np.array_equal(one[k], small[k]), ("hbm budget", k)
+    monkeypatch.delenv("SASKTRAN2_AMD_HBM_BUDGET_MB")
     # ... and so are the layer / LOS-tile splits of the small-batch launches
     monkeypatch.setenv("SASKTRAN2_AMD_STREAMS", "1")
     monkeypatch.setenv("SASKTRAN2_AMD_CHUNK", "700")
@@ -325,6 +341,35 @@ def test_delta_m_scaling_matches_oracle_and_user_level_finite_differences():
     for name, want in (("d_extinction", want_k), ("d_ssa", want_w)):
         scale = np.abs(want).max(axis=2, keepdims=True)
         assert np.max(np.abs(got[name] - want) / scale) < RTOL_WF, name
+
+
+def test_delta_m_state_is_reset_when_a_storage_handle_is_reused():
+    """One Atmosphere object = one storage handle (as the reference's Python layer): a second calculation with different optics runs
+    set_zero -> refill -> apply_delta_m_scaling on the same handle and must equal the calculation on a fresh handle bit for bit."""
+    import sasktran2_amd as sk
+    from tests.gpu_harness import build_engine
+    first, second = _peaked_limb(g=0.85), _peaked_limb(g=0.7)
+    second["extinction"] = second["extinction"] * 1.3
+    second["ssa"] = second["ssa"] * 0.97
+    engine, config, geometry = build_engine(first)
+    config.delta_m_scaling = True
+
+    def fill(atmosphere, s):
+        atmosphere.storage.total_extinction[:] = s["extinction"]
+        atmosphere.storage.ssa[:] = s["ssa"]
+        atmosphere.leg_coeff.a1[:] = s["leg"]
+        atmosphere.surface.albedo[:] = s["albedo"]
+
+    reused = sk.Atmosphere(geometry, config, numwavel=2, calculate_derivatives=True)
+    fill(reused, first)
+    engine.calculate_radiance(reused, as_dataset=False)
+    fill(reused, second)
+    again = engine.calculate_radiance(reused, as_dataset=False)
+    fresh = sk.Atmosphere(geometry, config, numwavel=2, calculate_derivatives=True)
+    fill(fresh, second)
+    want = engine.calculate_radiance(fresh, as_dataset=False)
+    for key in ("radiance", "wf_extinction", "wf_ssa", "wf_albedo"):
+        np.testing.assert_array_equal(again[key], want[key])
 
 
 def test_delta_m_user_level_weighting_functions_match_finite_differences():
