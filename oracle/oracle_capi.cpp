@@ -12,6 +12,7 @@
 #endif
 
 #include "disco_oracle.hpp"
+#include "so_oracle.hpp"
 
 namespace {
 struct Handle {
@@ -141,6 +142,110 @@ int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
                 if (n_azimuth) n_azimuth[w] = res.num_azimuth_used;
             } catch (const std::exception& e) {
                 std::fprintf(stderr, "orc_run (wavelength %d): %s\n", w, e.what());
+                status = -3;
+            }
+        }
+    }
+    return status;
+}
+
+// ---- exact single scatter + legacy successive orders (so_oracle.hpp)
+struct SoHandle {
+    skgeo::Geometry1D geo;
+    skso::SoGeometry sg;
+    int num_iterations = 50;
+};
+
+void* orso_create(double cos_sza, double saa, double earth_radius, const double* altitudes, int ngrid, int interp_method, int geotype,
+                  int nrays, const int* ray_kinds, const double* ray_params, int nstokes, int stokes_basis, int num_ss_moments,
+                  int num_ms_moments, int num_incoming, int num_outgoing, int num_sza, int num_iterations, int single_scatter,
+                  int multiple_scatter) {
+    try {
+        auto h = std::make_unique<SoHandle>();
+        h->geo = skgeo::Geometry1D(cos_sza, saa, earth_radius, std::vector<double>(altitudes, altitudes + ngrid),
+                                   (skgeo::Interpolation)interp_method, (skgeo::GeometryType)geotype);
+        std::vector<skgeo::RaySpec> specs(nrays);
+        for (int i = 0; i < nrays; ++i) {
+            specs[i].kind = (skgeo::RaySpec::Kind)ray_kinds[i];
+            specs[i].cos_sza = ray_params[4 * i + 0];
+            specs[i].horizontal_angle = ray_params[4 * i + 0];
+            specs[i].relative_azimuth = ray_params[4 * i + 1];
+            specs[i].observer_altitude = ray_params[4 * i + 2];
+            specs[i].tangent_altitude = ray_params[4 * i + 3];
+            specs[i].cos_viewing_zenith = ray_params[4 * i + 3];
+        }
+        skso::Settings cfg;
+        cfg.nstokes = nstokes;
+        cfg.num_ss_moments = num_ss_moments;
+        cfg.num_ms_moments = num_ms_moments;
+        cfg.num_incoming = num_incoming;
+        cfg.num_outgoing = num_outgoing;
+        cfg.num_sza = num_sza;
+        cfg.single_scatter = single_scatter != 0;
+        cfg.multiple_scatter = multiple_scatter != 0;
+        skso::build_so_geometry(h->geo, specs, cfg, h->sg, stokes_basis);
+        h->num_iterations = num_iterations;
+        return h.release();
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "orso_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+void orso_destroy(void* h) { delete static_cast<SoHandle*>(h); }
+int orso_lebedev(int npoints, double* xyzw) {
+    try {
+        const std::vector<double> s = skleb::sphere(npoints);
+        std::copy(s.begin(), s.end(), xyzw);
+        return 0;
+    } catch (const std::exception&) { return -1; }
+}
+// sizes of the diffuse discretisation: points, incoming rays, outgoing directions, accumulation-matrix entries
+int orso_sizes(void* hv, int* out) {
+    auto* h = static_cast<SoHandle*>(hv);
+    if (!h) return -1;
+    out[0] = h->sg.npoints;
+    out[1] = h->sg.in_start.empty() ? 0 : h->sg.in_start.back();
+    out[2] = h->sg.out_start.empty() ? 0 : h->sg.out_start.back();
+    out[3] = (int)h->sg.accumulation.w.size();
+    return 0;
+}
+// radiance[nwavel][nlos][S], los_od[nwavel][nlos]
+int orso_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg, const double* solar_irradiance,
+             const double* albedo, int nthreads, double* radiance, double* los_od) {
+    auto* h = static_cast<SoHandle*>(hv);
+    if (!h) return -1;
+    const int nlos = h->sg.nlos, S = h->sg.cfg.nstokes;
+    oracle_so::AtmosphereView atm;
+    atm.ngrid = h->sg.ngrid;
+    atm.nwavel = nwavel;
+    atm.nleg = nleg;
+    atm.nstokes = S;
+    atm.extinction = extinction;
+    atm.ssa = ssa;
+    atm.leg = leg;
+    atm.solar_irradiance = solar_irradiance;
+    atm.albedo = albedo;
+    int status = 0;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        oracle_so::Solver solver(h->sg);
+        solver.num_iterations = h->num_iterations;
+        oracle_so::Result res;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int w = 0; w < nwavel; ++w) {
+            if (status != 0) continue;
+            try {
+                solver.solve(atm, w, res);
+                for (int i = 0; i < nlos * S; ++i) radiance[size_t(w) * nlos * S + i] = res.radiance[i];
+                if (los_od)
+                    for (int r = 0; r < nlos; ++r) los_od[size_t(w) * nlos + r] = res.los_od[r];
+            } catch (const std::exception& e) {
+                std::fprintf(stderr, "orso_run (wavelength %d): %s\n", w, e.what());
                 status = -3;
             }
         }

@@ -115,3 +115,51 @@ class OracleEngine:
         if derivatives:
             out.update({"d_extinction": dk, "d_ssa": dw, "d_albedo": da})
         return out
+
+
+class SoOracleEngine:
+    """Exact single scatter + legacy successive orders (oracle/so_oracle.hpp).  rays as for OracleEngine."""
+
+    def __init__(self, cos_sza, saa, earth_radius, altitudes, interp_method, geotype, rays, nstokes=1, stokes_basis=0,
+                 num_ss_moments=16, num_ms_moments=16, num_incoming=110, num_outgoing=110, num_sza=1, num_iterations=50,
+                 single_scatter=True, multiple_scatter=True):
+        L = lib()
+        L.orso_create.restype = ctypes.c_void_p
+        L.orso_create.argtypes = [ctypes.c_double] * 3 + [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp] + [ctypes.c_int] * 10
+        L.orso_destroy.argtypes = [ctypes.c_void_p]
+        L.orso_sizes.argtypes = [ctypes.c_void_p, _ip]
+        L.orso_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int, _dp, _dp]
+        self.alt = np.ascontiguousarray(altitudes, dtype=np.float64)
+        self.nlos, self.ngrid, self.nstokes = len(rays), len(self.alt), nstokes
+        kinds = np.ascontiguousarray([r[0] for r in rays], dtype=np.int32)
+        params = np.ascontiguousarray([[r[1], r[2], r[3], r[4]] for r in rays], dtype=np.float64)
+        self._h = L.orso_create(cos_sza, saa, earth_radius, _p(self.alt), self.ngrid, interp_method, geotype, self.nlos,
+                                kinds.ctypes.data_as(_ip), _p(params), int(nstokes), int(stokes_basis), int(num_ss_moments),
+                                int(num_ms_moments), int(num_incoming), int(num_outgoing), int(num_sza), int(num_iterations),
+                                int(single_scatter), int(multiple_scatter))
+        if not self._h:
+            raise RuntimeError("successive-orders oracle construction failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orso_destroy(self._h)
+            self._h = None
+
+    def sizes(self):
+        out = np.zeros(4, dtype=np.int32)
+        lib().orso_sizes(self._h, out.ctypes.data_as(_ip))
+        return dict(points=int(out[0]), incoming_rays=int(out[1]), outgoing_directions=int(out[2]), accumulation_entries=int(out[3]))
+
+    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, nthreads=1):
+        k = np.asfortranarray(extinction, dtype=np.float64)
+        w = np.asfortranarray(ssa, dtype=np.float64)
+        lg = np.asfortranarray(leg, dtype=np.float64)
+        nwavel, S = k.shape[1], self.nstokes
+        alb = np.ascontiguousarray(albedo, dtype=np.float64)
+        irr = None if solar_irradiance is None else np.ascontiguousarray(solar_irradiance, dtype=np.float64)
+        rad = np.zeros((nwavel, self.nlos, S))
+        od = np.zeros((nwavel, self.nlos))
+        rc = lib().orso_run(self._h, nwavel, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), _p(irr), _p(alb), nthreads, _p(rad), _p(od))
+        if rc != 0:
+            raise RuntimeError(f"successive-orders oracle run failed with code {rc}")
+        return {"radiance": rad, "los_optical_depth": od}

@@ -1,0 +1,240 @@
+// TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's exact single-scatter source and legacy successive-orders
+// ("HR") multiple-scatter source.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it; the product
+// path never does.
+//
+// Follows, per wavelength:
+//   cpp/lib/solar/singlescattersource.cpp:103-160 (solar transmission at the layer boundaries), :574-636 (ground term),
+//       :950-1167 (layer source = (1 - e^-od)/od (start f_start + end f_end) distance), cpp/include/sasktran2/solartransmission.h:733-846
+//       (endpoint source k w T P / 4 pi), cpp/lib/phasefunction/phasehandler.cpp:381-470,666-812 (phase from Legendre, Stokes rotation)
+//   cpp/lib/sourceintegrator/sourceintegrator.cpp:521-580 (backward LOS recursion), :666-760 (first-order incoming radiance and
+//       accumulation-matrix values along the incoming rays)
+//   cpp/lib/hr/diffuse_table.cpp:673-820,885-1064 (scattering matrices, fixed number of iterations, LOS source), cpp/lib/hr/diffuse_point.cpp:199-296
+// Geometry tables: sasktran2_amd/csrc/host/so_geometry.hpp (wavelength independent, shared with the product as the DO geometry is).
+//
+// PARITY PIN: tests/engine/test_1d_solver_regression.py:140-197 (NSTOKES = 3, exact single scatter + SuccessiveOrdersLegacy with
+// 3 iterations and 26 / 26 directions, rtol 5e-7), transcribed in tests/golden/.
+#pragma once
+#include <cmath>
+#include <vector>
+
+#include "../sasktran2_amd/csrc/host/so_geometry.hpp"
+
+namespace oracle_so {
+
+struct AtmosphereView {
+    int ngrid = 0, nwavel = 0, nleg = 0, nstokes = 1;   // nleg = Legendre orders stored (x 4 Greek constants for NSTOKES = 3)
+    const double* extinction = nullptr;                  // [ngrid, nwavel], location fastest
+    const double* ssa = nullptr;
+    const double* leg = nullptr;                         // [nleg (x 4), ngrid, nwavel]
+    const double* solar_irradiance = nullptr;            // [nwavel] or null (1)
+    const double* albedo = nullptr;                      // [nwavel]
+};
+
+struct Result {
+    std::vector<double> radiance;   // [nlos][S]
+    std::vector<double> los_od;     // [nlos]
+};
+
+class Solver {
+    const skso::SoGeometry& g_;
+    const int S_;
+    std::vector<double> T_los_, T_inc_, table_od_, first_, incoming_, outgoing_, acc_, layer_factor_, ground_factor_, M_, phase_;
+
+    static double dot(const skso::Csr& c, int row, const double* x) {
+        double s = 0;
+        for (int e = c.start[row]; e < c.start[row + 1]; ++e) s += c.w[e] * x[c.idx[e]];
+        return s;
+    }
+    // phase functions of every grid point for the scattering angle of ray r: P11 (and P12 for NSTOKES = 3)
+    void ray_phase(const skso::RaySet& rs, int r, const AtmosphereView& a, int w, double* p11, double* p12) const {
+        const int per = (S_ == 3) ? 4 : 1, nm = std::min(g_.cfg.num_ss_moments, a.nleg);
+        for (int q = 0; q < a.ngrid; ++q) {
+            const double* lc = a.leg + (size_t(w) * a.ngrid + q) * a.nleg * per;
+            double s1 = 0, s2 = 0;
+            for (int l = 0; l < nm; ++l) {
+                s1 += lc[l * per] * rs.d00[size_t(r) * g_.cfg.num_ss_moments + l];
+                if (S_ == 3) s2 += lc[l * per + 3] * rs.d02[size_t(r) * g_.cfg.num_ss_moments + l];
+            }
+            p11[q] = s1;
+            if (S_ == 3) p12[q] = s2;
+        }
+    }
+    // k w T P / 4 pi at one layer boundary
+    void endpoint_source(const skso::RaySet& rs, int r, int layer, const double* wts, double T, const double* k, const double* om,
+                         const double* p11, const double* p12, double* out) const {
+        double ke = 0, oe = 0, a = 0, b = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int q = rs.stencil_idx[size_t(layer) * 4 + i];
+            const double wt = wts[size_t(layer) * 4 + i];
+            if (q < 0 || wt == 0.0) continue;
+            ke += k[q] * wt;
+            oe += om[q] * wt;
+            a += p11[q] * wt;
+            if (S_ == 3) b += p12[q] * wt;
+        }
+        const double amp = ke * oe * T / (skgeo::kPi * 4);
+        out[0] = amp * a;
+        if (S_ == 3) {
+            out[1] = amp * (-rs.C2[r] * b);
+            out[2] = amp * (-rs.S2[r] * b);
+        }
+    }
+    void layer_source(const skso::RaySet& rs, int r, int layer, int j, const double* T, double od, const double* k, const double* om,
+                      const double* p11, const double* p12, double* out) const {
+        for (int s = 0; s < S_; ++s) out[s] = 0;
+        if (rs.tiny[layer]) return;
+        const int e0 = rs.endpoint_start[r];
+        double st[3], en[3];
+        endpoint_source(rs, r, layer, rs.w_entrance.data(), T[e0 + j + 1], k, om, p11, p12, st);
+        endpoint_source(rs, r, layer, rs.w_exit.data(), T[e0 + j], k, om, p11, p12, en);
+        const double sf = (std::abs(od) < 1e-12) ? 1.0 : -std::expm1(-od) / od;
+        for (int s = 0; s < S_; ++s) out[s] = sf * (st[s] * rs.quad_start[layer] + en[s] * rs.quad_end[layer]);
+    }
+
+  public:
+    explicit Solver(const skso::SoGeometry& g) : g_(g), S_(g.cfg.nstokes) {}
+
+    void solve(const AtmosphereView& a, int w, Result& res) {
+        const int ngrid = a.ngrid, nlos = g_.nlos, per = (S_ == 3) ? 4 : 1;
+        const double* k = a.extinction + size_t(w) * ngrid;
+        const double* om = a.ssa + size_t(w) * ngrid;
+        const double F = a.solar_irradiance ? a.solar_irradiance[w] : 1.0;
+        const double albedo = a.albedo[w];
+        res.radiance.assign(size_t(nlos) * S_, 0.0);
+        res.los_od.assign(nlos, 0.0);
+        std::vector<double> p11(ngrid), p12(ngrid);
+        const bool ss = g_.cfg.single_scatter, ms = g_.cfg.multiple_scatter && g_.npoints > 0;
+
+        // ---- diffuse field
+        if (ms) {
+            const skso::RaySet& in = g_.incoming;
+            const int nr = in.nrays, nout_total = g_.out_start.back();
+            // solar transmission table -> layer boundaries of the incoming rays
+            table_od_.resize(g_.table.od.rows());
+            for (int t = 0; t < g_.table.od.rows(); ++t) table_od_[t] = dot(g_.table.od, t, k);
+            T_inc_.resize(in.solar.rows());
+            for (int e = 0; e < in.solar.rows(); ++e) T_inc_[e] = std::exp(-dot(in.solar, e, table_od_.data())) * F;
+            first_.assign(size_t(nr) * S_, 0.0);
+            layer_factor_.assign(in.nlayers(), 0.0);
+            ground_factor_.assign(nr, 0.0);
+            for (int r = 0; r < nr; ++r) {
+                const int l0 = in.layer_start[r], n = in.layer_start[r + 1] - l0;
+                if (n == 0) continue;
+                ray_phase(in, r, a, w, p11.data(), p12.data());
+                double cur = 0, src[3];
+                for (int j = n - 1; j >= 0; --j) {
+                    const int L = l0 + j;
+                    const double od = dot(in.od, L, k), att = std::exp(-od), before = std::exp(-cur);
+                    layer_source(in, r, L, j, T_inc_.data(), od, k, om, p11.data(), p12.data(), src);
+                    for (int s = 0; s < S_; ++s) first_[size_t(r) * S_ + s] += src[s] * before;
+                    const double omega = in.mid_w[2 * L] * om[in.mid_idx[2 * L]] + in.mid_w[2 * L + 1] * om[in.mid_idx[2 * L + 1]];
+                    layer_factor_[L] = omega * (1 - att) * before;
+                    cur += od;
+                }
+                if (in.ground_is_hit[r]) {
+                    if (in.ground_mu_in[r] > 0)
+                        first_[size_t(r) * S_] += T_inc_[in.endpoint_start[r]] * (albedo / skgeo::kPi) * in.ground_mu_in[r] * std::exp(-cur);
+                    ground_factor_[r] = std::exp(-cur);
+                }
+            }
+            acc_.resize(g_.accumulation.w.size());
+            for (int r = 0; r < nr; ++r)
+                for (int e = g_.accumulation.start[r]; e < g_.accumulation.start[r + 1]; ++e) {
+                    const int L = g_.accumulation_layer[e];
+                    acc_[e] = g_.accumulation.w[e] * (L >= 0 ? layer_factor_[L] : ground_factor_[r]);
+                }
+            // scattering matrices of the interior points
+            const int rows = g_.nout * S_, cols = g_.nin * S_, nm = std::min(g_.cfg.num_ms_moments, a.nleg);
+            M_.assign(size_t(g_.ninterior) * rows * cols, 0.0);
+            for (int p = 0; p < g_.ninterior; ++p) {
+                double* M = M_.data() + size_t(p) * rows * cols;
+                for (int l = 0; l < nm; ++l)
+                    for (int greek = 0; greek < per; ++greek) {
+                        double c = 0;
+                        for (int i = 0; i < 2; ++i)
+                            c += g_.point_leg_w[2 * p + i] * a.leg[(size_t(w) * ngrid + g_.point_leg_idx[2 * p + i]) * a.nleg * per + l * per + greek];
+                        if (c == 0.0) continue;
+                        const double* B = g_.scat_basis.data() + (size_t(l) * per + greek) * rows * cols;
+                        for (size_t i = 0; i < size_t(rows) * cols; ++i) M[i] += c * B[i];
+                    }
+            }
+            incoming_ = first_;
+            outgoing_.assign(size_t(nout_total) * S_, 0.0);
+            // num_hr_spherical_iterations passes (diffuse_table.cpp:751-819)
+            for (int it = 0; it < num_iterations; ++it) {
+                if (it > 0)
+                    for (int r = 0; r < nr; ++r)
+                        for (int s = 0; s < S_; ++s) {
+                            double v = 0;
+                            for (int e = g_.accumulation.start[r]; e < g_.accumulation.start[r + 1]; ++e) v += acc_[e] * outgoing_[size_t(g_.accumulation.idx[e]) * S_ + s];
+                            incoming_[size_t(r) * S_ + s] = v + first_[size_t(r) * S_ + s];
+                        }
+                for (int p = 0; p < g_.npoints; ++p) {
+                    const double* inc = incoming_.data() + size_t(g_.in_start[p]) * S_;
+                    double* out = outgoing_.data() + size_t(g_.out_start[p]) * S_;
+                    if (p < g_.ninterior) {
+                        const double* M = M_.data() + size_t(p) * rows * cols;
+                        for (int o = 0; o < rows; ++o) {
+                            double v = 0;
+                            for (int i = 0; i < cols; ++i) v += M[size_t(o) * cols + i] * inc[i];
+                            out[o] = v;
+                        }
+                    } else {
+                        const int gi = p - g_.ninterior;
+                        double v = 0;
+                        for (int i = 0; i < g_.ground_nin[gi]; ++i) v += (albedo / skgeo::kPi) * g_.ground_in_factor[gi][i] * inc[size_t(i) * S_];
+                        for (int o = 0; o < g_.ground_nout[gi]; ++o) {
+                            out[size_t(o) * S_] = v;
+                            for (int s = 1; s < S_; ++s) out[size_t(o) * S_ + s] = 0;
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- lines of sight
+        const skso::RaySet& lo = g_.los;
+        if (ss) {
+            T_los_.resize(lo.solar.rows());
+            for (int e = 0; e < lo.solar.rows(); ++e) T_los_[e] = lo.solar_blocked[e] ? 0.0 : std::exp(-dot(lo.solar, e, k)) * F;
+        }
+        for (int r = 0; r < nlos; ++r) {
+            const int l0 = lo.layer_start[r], n = lo.layer_start[r + 1] - l0;
+            double rad[3] = {0, 0, 0}, src[3], total_od = 0;
+            if (n > 0 && ss) ray_phase(lo, r, a, w, p11.data(), p12.data());
+            if (n > 0 && lo.ground_is_hit[r]) {
+                if (ss && lo.ground_mu_in[r] > 0) rad[0] += T_los_[lo.endpoint_start[r]] * (albedo / skgeo::kPi) * lo.ground_mu_in[r];
+                if (ms && num_iterations > 0)
+                    for (int e = g_.los_ground.start[r]; e < g_.los_ground.start[r + 1]; ++e)
+                        for (int s = 0; s < S_; ++s) rad[s] += g_.los_ground.w[e] * outgoing_[size_t(g_.los_ground.idx[e]) * S_ + s];
+            }
+            for (int j = 0; j < n; ++j) {
+                const int L = l0 + j;
+                const double od = dot(lo.od, L, k), att = std::exp(-od);
+                total_od += od;
+                for (int s = 0; s < S_; ++s) rad[s] *= att;
+                if (ss) {
+                    layer_source(lo, r, L, j, T_los_.data(), od, k, om, p11.data(), p12.data(), src);
+                    for (int s = 0; s < S_; ++s) rad[s] += src[s];
+                }
+                if (ms && num_iterations > 0) {
+                    const double omega = lo.mid_w[2 * L] * om[lo.mid_idx[2 * L]] + lo.mid_w[2 * L + 1] * om[lo.mid_idx[2 * L + 1]];
+                    const double f = omega * (1 - att);
+                    for (int e = g_.los_source.start[L]; e < g_.los_source.start[L + 1]; ++e)
+                        for (int s = 0; s < S_; ++s) rad[s] += f * g_.los_source.w[e] * outgoing_[size_t(g_.los_source.idx[e]) * S_ + s];
+                }
+            }
+            res.los_od[r] = total_od;
+            // Stokes basis of the output (OutputC::assign_lane)
+            res.radiance[size_t(r) * S_] = rad[0];
+            if (S_ == 3) {
+                const double C = g_.stokes_C[r], Sn = g_.stokes_S[r];
+                res.radiance[size_t(r) * S_ + 1] = C * rad[1] - Sn * rad[2];
+                res.radiance[size_t(r) * S_ + 2] = Sn * rad[1] + C * rad[2];
+            }
+        }
+    }
+    int num_iterations = 50;   // Config::num_hr_spherical_iterations
+};
+
+}  // namespace oracle_so

@@ -185,3 +185,40 @@ def delta_m_scaled(s: dict, order: int | None = None):
     out.update(extinction=ks, ssa=ws, leg=leg / (1 - f)[None, :, :], delta_f=f,
                unscale=dict(dk_dk=(1 - w * f), dw_dw=(1 - f * (1 - ws)) / (1 - w * f), dk_dw=-k * f))
     return out
+
+
+def regression_so(num_wavelengths: int = 2, nstokes: int = 3):
+    """Inputs of the reference's successive-orders regression pin (tests/engine/test_1d_solver_regression.py:9-109, source
+    "successive_orders": exact single scatter + SuccessiveOrdersLegacy, 3 iterations, 26 / 26 directions) with the expected
+    Stokes vectors of tests/golden/so_regression.json."""
+    import json
+    from pathlib import Path
+    s = regression_1d(num_wavelengths)
+    nw = num_wavelengths
+    if nstokes == 3:
+        leg = np.zeros((16 * 4, 25, nw))
+        leg[0::4] = s["leg"]
+        leg[2 * 4 + 1] = 3.0
+        leg[2 * 4 + 3] = -np.sqrt(6.0) / 2.0
+        s["leg"] = leg
+    s["config"] = dict(nstokes=nstokes, num_streams=8, num_singlescatter_moments=16, num_sza=2, num_iterations=3,
+                       num_incoming=26, num_outgoing=26, single_scatter="exact", multiple_scatter="successive_orders_legacy")
+    gold = json.loads((Path(__file__).parent / "golden" / "so_regression.json").read_text())
+    if nw == 2 and nstokes == 3:
+        s["expected_radiance"] = np.array(gold["expected_radiance_wavel_los_stokes"])
+        s["expected_od"] = regression_1d(3)["expected_od"][gold["optical_depth_rows_of_the_do_case"]]
+        s["rtol"], s["atol"] = gold["rtol"], gold["atol"]
+    else:
+        s.pop("expected_radiance", None)
+        s.pop("expected_od", None)
+    return s
+
+
+def limb_c5(num_wavelengths: int = 20_000, nlyr: int = 50, num_iterations: int = 10, num_directions: int = 110):
+    """BASELINE.json configs[4]: the C2 limb geometry and optical properties, exact single scatter plus
+    10 successive orders of scattering with 110 incoming / 110 outgoing directions per diffuse point."""
+    s = limb_c2(num_wavelengths, nlyr=nlyr, nstr=16)
+    s["config"] = dict(nstokes=1, num_streams=16, num_singlescatter_moments=16, num_sza=1, num_iterations=num_iterations,
+                       num_incoming=num_directions, num_outgoing=num_directions, single_scatter="exact",
+                       multiple_scatter="successive_orders_legacy")
+    return s

@@ -1,0 +1,90 @@
+"""CPU oracle of the exact single-scatter + legacy successive-orders sources (oracle/so_oracle.hpp) against the reference's
+own pinned values and against physical properties.  No GPU needed."""
+import numpy as np
+import pytest
+
+from tests import scenarios as sc
+
+
+def make_so_oracle(s, **override):
+    from oracle.oracle_py import SoOracleEngine
+    g, c = s["geometry"], dict(s["config"], **override)
+    return SoOracleEngine(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"], g["interp_method"], g["geotype"], s["rays"],
+                          nstokes=c["nstokes"], stokes_basis=c.get("stokes_basis", 0), num_ss_moments=c["num_singlescatter_moments"],
+                          num_ms_moments=c["num_streams"], num_incoming=c["num_incoming"], num_outgoing=c["num_outgoing"],
+                          num_sza=c["num_sza"], num_iterations=c["num_iterations"], single_scatter=c["single_scatter"] == "exact",
+                          multiple_scatter=c["multiple_scatter"] == "successive_orders_legacy")
+
+
+def run_so_oracle(s, nthreads=2, **override):
+    return make_so_oracle(s, **override).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], nthreads=nthreads)
+
+
+def test_lebedev_generator_is_a_quadrature():
+    """Weights sum to one and every rule integrates the spherical harmonics it is designed for (checked through x^2, x^4, x^2 y^2:
+    1/3, 1/5, 1/15) -- the orbit parameters of sasktran2_amd/csrc/host/lebedev.hpp are the published Lebedev-Laikov ones."""
+    import ctypes
+    from oracle.oracle_py import lib, _dp
+    L = lib()
+    L.orso_lebedev.argtypes = [ctypes.c_int, _dp]
+    for n in (6, 14, 26, 38, 50, 74, 86, 110, 146, 170, 194, 230, 266, 302, 350, 434, 590, 770, 974):
+        xyzw = np.zeros((n, 4))
+        assert L.orso_lebedev(n, xyzw.ctypes.data_as(_dp)) == 0
+        x, y, z, w = xyzw.T
+        np.testing.assert_allclose(x * x + y * y + z * z, 1.0, atol=2e-15)
+        assert abs(w.sum() - 1) < 2e-14
+        assert abs((w * x * x).sum() - 1 / 3) < 1e-14
+        if n >= 14:
+            assert abs((w * x ** 4).sum() - 1 / 5) < 1e-14
+            assert abs((w * x * x * y * y).sum() - 1 / 15) < 1e-14
+    # the point order is the one the reference's interpolation tie-breaks depend on: first orbit = the six axis points
+    assert np.array_equal(xyzw[:6, :3], [[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]])
+
+
+def test_successive_orders_regression_pin():
+    """tests/engine/test_1d_solver_regression.py:140-240: NSTOKES = 3 Stokes vectors of 4 rays x 2 wavelengths at rtol 5e-7."""
+    s = sc.regression_so()
+    got = run_so_oracle(s)
+    np.testing.assert_allclose(got["radiance"], s["expected_radiance"], rtol=s["rtol"], atol=s["atol"])
+    np.testing.assert_allclose(got["los_optical_depth"], s["expected_od"], rtol=5e-7, atol=1e-13)
+
+
+def test_scalar_intensity_is_close_to_the_polarised_one_and_orders_add_up():
+    s3, s1 = sc.regression_so(), sc.regression_so(nstokes=1)
+    v, sca = run_so_oracle(s3), run_so_oracle(s1)
+    # neglecting polarisation changes Rayleigh-like intensities by a few per cent at most
+    assert np.max(np.abs(sca["radiance"][..., 0] / v["radiance"][..., 0] - 1)) < 0.05
+    # every further order of scattering adds a positive, shrinking amount
+    series = [run_so_oracle(s1, num_iterations=n)["radiance"][..., 0] for n in (0, 1, 2, 3, 6)]
+    steps = [b - a for a, b in zip(series[:-1], series[1:])]
+    assert all(np.all(d > 0) for d in steps)
+    assert np.all(steps[1] < steps[0]) and np.all(steps[2] < steps[1])
+    # no multiple-scatter source at all == zero iterations
+    only_ss = run_so_oracle(s1, multiple_scatter="none")
+    np.testing.assert_allclose(only_ss["radiance"], series[0][..., None], rtol=1e-14)
+
+
+def test_single_scatter_is_linear_in_the_solar_irradiance_and_black_without_scatterers():
+    s = sc.regression_so(nstokes=1)
+    o = make_so_oracle(s)
+    one = o.run(s["extinction"], s["ssa"], s["leg"], s["albedo"])["radiance"]
+    two = o.run(s["extinction"], s["ssa"], s["leg"], s["albedo"], solar_irradiance=np.full(2, 2.5))["radiance"]
+    np.testing.assert_allclose(two, 2.5 * one, rtol=1e-13)
+    dark = o.run(s["extinction"], np.zeros_like(s["ssa"]), s["leg"], np.zeros(2))["radiance"]
+    assert np.all(dark == 0)
+
+
+def test_successive_orders_converges_to_the_discrete_ordinates_field():
+    """Independent check of the whole diffuse machinery: many orders of scattering on 110 directions approach the
+    discrete-ordinates multiple-scatter solution of the same scene (different discretisations: agreement to a few per cent; measured 2-5.4 %)."""
+    from tests.test_oracle_golden import run_oracle
+    s = sc.regression_so(nstokes=1)
+    s["config"].update(num_incoming=110, num_outgoing=110, num_iterations=25)
+    so = run_so_oracle(s)["radiance"][..., 0]
+    d = sc.regression_1d(2)
+    d["config"]["nstr"] = 16
+    do = run_oracle(d, derivatives=False)["radiance"]
+    ss = run_so_oracle(s, multiple_scatter="none")["radiance"][..., 0]
+    # in spherical geometry the reference's DO source (and the oracle's) delivers the multiple-scatter term only
+    ms_so = so - ss
+    assert np.max(np.abs(ms_so / do - 1)) < 0.07
