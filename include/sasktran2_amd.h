@@ -134,6 +134,15 @@ int sk_amd_engine_solve_device(Engine* engine, int nwavel, int nleg, const doubl
 /* delta-M truncation fraction of already scaled optical properties, DEVICE pointer [nwavel][nlocation] or NULL, for the
  * following sk_amd_engine_solve_device calls (the host entry point does this itself after sk_atmosphere_apply_delta_m_scaling) */
 int sk_amd_engine_set_delta_m_fraction(Engine* engine, const double* d_f);
+/* The same for an engine with single_scatter_source = exact and / or multiple_scatter_source = successive_orders_legacy
+ * (replaces, per wavelength, SingleScatterSource<SolarTransmissionExact>::calculate / integrated_source,
+ * cpp/lib/solar/singlescattersource.cpp:103-160,950-1167, and hr::DiffuseTable::calculate, cpp/lib/hr/diffuse_table.cpp:885-962):
+ * d_leg [nwavel][nlocation][nleg (x 4 for NSTOKES = 3)], d_radiance [nwavel][nlos][nstokes], d_los_od [nwavel][nlos] or NULL. */
+int sk_amd_so_engine_solve_device(Engine* engine, int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
+                                  const double* d_albedo, const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream);
+/* sizes[0..5]: incoming rays, their layers, accumulation-matrix entries, outgoing directions, scratch bytes per wavelength,
+ * wavelengths per block of the last solve */
+int sk_amd_so_engine_sizes(Engine* engine, unsigned long long* sizes);
 int sk_amd_engine_num_los(Engine* engine, int* nlos);
 int sk_amd_engine_scratch_bytes(Engine* engine, int nwavel, unsigned long long* bytes);
 /* shape of the last solve: wavelengths per kernel launch, blocks in flight (streams), scratch bytes allocated */

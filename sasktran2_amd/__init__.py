@@ -63,7 +63,10 @@ class Config:
              "num_sza": "num_do_sza", "num_singlescatter_moments": "num_singlescatter_moments",
              "wavelength_batch_size": "wavelength_batch_size", "output_los_optical_depth": "output_los_optical_depth",
              "multiple_scatter_source": "multiple_scatter_source", "single_scatter_source": "single_scatter_source",
-             "wf_enabled": "wf_enabled", "delta_m_scaling": "apply_delta_scaling", "stokes_basis": "stokes_basis"}
+             "wf_enabled": "wf_enabled", "delta_m_scaling": "apply_delta_scaling", "stokes_basis": "stokes_basis",
+             # successive orders (src/sasktran2/config.py:410-418,505-514,607-634 -> the C API's `hr` keys)
+             "num_successive_orders_iterations": "num_hr_spherical_iterations", "num_successive_orders_incoming": "num_hr_incoming",
+             "num_successive_orders_outgoing": "num_hr_outgoing", "init_successive_orders_with_discrete_ordinates": "initialize_hr_with_do"}
 
     def __init__(self):
         object.__setattr__(self, "_h", lib().sk_config_create())

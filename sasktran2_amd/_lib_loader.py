@@ -21,10 +21,12 @@ SIGNATURES = [
     ("sk_config_create", _vp, []), ("sk_config_destroy", None, [_vp]),
     *[(f"sk_config_get_{k}", _I, [_vp, _ip]) for k in ("num_stokes", "multiple_scatter_source", "single_scatter_source",
       "num_streams", "num_threads", "wavelength_batch_size", "num_singlescatter_moments", "num_do_sza", "wf_enabled",
-      "output_los_optical_depth", "apply_delta_scaling", "stokes_basis")],
+      "output_los_optical_depth", "apply_delta_scaling", "stokes_basis", "num_hr_spherical_iterations", "num_hr_incoming",
+      "num_hr_outgoing", "initialize_hr_with_do")],
     *[(f"sk_config_set_{k}", _I, [_vp, _I]) for k in ("num_stokes", "multiple_scatter_source", "single_scatter_source",
       "num_streams", "num_threads", "wavelength_batch_size", "num_singlescatter_moments", "num_do_sza", "wf_enabled",
-      "output_los_optical_depth", "apply_delta_scaling", "stokes_basis")],
+      "output_los_optical_depth", "apply_delta_scaling", "stokes_basis", "num_hr_spherical_iterations", "num_hr_incoming",
+      "num_hr_outgoing", "initialize_hr_with_do")],
     ("sk_geometry1d_create", _vp, [_D, _D, _D, _dp, _I, _I, _I]), ("sk_geometry1d_destroy", None, [_vp]),
     ("sk_geometry1d_get_num_altitudes", _I, [_vp]), ("sk_geometry1d_get_altitudes", _I, [_vp, _dp]),
     ("sk_viewing_geometry_create", _vp, []), ("sk_viewing_geometry_destroy", None, [_vp]),
@@ -62,6 +64,8 @@ SIGNATURES = [
     ("sk_engine_destroy", None, [_vp]), ("sk_openmp_support_enabled", _I, []),
     ("sk_amd_engine_solve_device", _I, [_vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I]),
     ("sk_amd_engine_set_delta_m_fraction", _I, [_vp, _vp]),
+    ("sk_amd_so_engine_solve_device", _I, [_vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("sk_amd_so_engine_sizes", _I, [_vp, ctypes.POINTER(ctypes.c_ulonglong)]),
     ("sk_atmosphere_apply_delta_m_scaling", _I, [_vp, _I]),
     ("sk_amd_engine_num_los", _I, [_vp, _ip]),
     ("sk_amd_engine_scratch_bytes", _I, [_vp, _I, ctypes.POINTER(ctypes.c_ulonglong)]),

@@ -17,6 +17,7 @@
 
 #include "../../../include/sasktran2_amd.h"
 #include "disco_engine.hpp"
+#include "so_engine.hpp"
 
 namespace {
 thread_local std::string g_last_error;
@@ -125,7 +126,8 @@ struct DeviceCache {
 };
 struct Engine {
     Config config;
-    std::unique_ptr<skdev::DeviceEngine> dev;
+    std::unique_ptr<skdev::DeviceEngine> dev;      // discrete-ordinates source (multiple_scatter_source = discrete_ordinates)
+    std::unique_ptr<skdev::SoDeviceEngine> so;     // exact single scatter and / or legacy successive orders
     int nlos = 0, ngrid = 0;
     DeviceCache cache;
 };
@@ -353,9 +355,14 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
     try {
         if (c->num_stokes != 1 && c->num_stokes != 3) throw std::runtime_error("NSTOKES must be 1 or 3");
         if (c->stokes_basis < 0 || c->stokes_basis > 2) throw std::runtime_error("stokes_basis must be standard (0), solar (1) or observer (2)");
-        if (c->ms_source != 0) throw std::runtime_error("multiple_scatter_source must be discrete_ordinates (0)");
-        if (c->ss_source != 2 && c->ss_source != 3)
-            throw std::runtime_error("single_scatter_source must be discrete_ordinates (2) or none (3)");
+        // sources of this build (cpp/include/sasktran2/config.h:41-71): multiple scatter discrete_ordinates (0), successive_orders_legacy (1)
+        // or none (3); single scatter exact (0), discrete_ordinates (2) or none (3)
+        if (c->ms_source != 0 && c->ms_source != 1 && c->ms_source != 3)
+            throw std::runtime_error("multiple_scatter_source must be discrete_ordinates (0), successive_orders_legacy (1) or none (3); "
+                                     "twostream (2) and successive_orders (4) are not part of this build");
+        if (c->ss_source != 0 && c->ss_source != 2 && c->ss_source != 3)
+            throw std::runtime_error("single_scatter_source must be exact (0), discrete_ordinates (2) or none (3); solartable (1) is not part of this build");
+        if (c->ss_source == 2 && c->ms_source != 0) throw std::runtime_error("single_scatter_source = discrete_ordinates needs multiple_scatter_source = discrete_ordinates");
         if (c->los_refraction || c->solar_refraction || c->multiple_scatter_refraction ||
             c->num_do_forced_azimuth >= 0 || c->num_do_spherical_iterations > 0 || c->emission_source != 1 || c->occultation_source != 1 ||
             c->do_backprop)
@@ -363,13 +370,37 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
                                      "occultation sources are not part of this build");
         skgeo::Geometry1D geo(g->cos_sza, g->saa, g->earth_radius, g->grid, (skgeo::Interpolation)g->interp,
                               (skgeo::GeometryType)g->geotype);
-        skgeo::DiscoGeometry dg;
-        skgeo::build_disco_geometry(geo, v->rays, c->num_streams, c->num_sza, dg, c->num_stokes, c->stokes_basis);
         auto e = std::make_unique<Engine>();
         e->config = *c;
-        e->dev = std::make_unique<skdev::DeviceEngine>(dg, c->ss_source == 2);
-        e->nlos = dg.nlos;
-        e->ngrid = dg.ngrid;
+        e->nlos = (int)v->rays.size();
+        e->ngrid = (int)g->grid.size();
+        if (c->ms_source == 0) {
+            skgeo::DiscoGeometry dg;
+            skgeo::build_disco_geometry(geo, v->rays, c->num_streams, c->num_sza, dg, c->num_stokes, c->stokes_basis);
+            e->dev = std::make_unique<skdev::DeviceEngine>(dg, c->ss_source == 2);
+            e->nlos = dg.nlos;
+            e->ngrid = dg.ngrid;
+            if (c->ss_source == 0 && !dg.spherical_pp)
+                throw std::runtime_error("single_scatter_source = exact with discrete ordinates needs spherical geometry (in plane-parallel "
+                                         "geometry the discrete-ordinates source carries the single scatter itself)");
+        }
+        if (c->ss_source == 0 || c->ms_source == 1) {
+            if (c->ms_source == 1 && (c->initialize_hr_with_do || c->num_hr_full_incoming_points > 0))
+                throw std::runtime_error("initialize_hr_with_do and num_hr_full_incoming_points are not part of this build");
+            skso::Settings cfg;
+            cfg.nstokes = c->num_stokes;
+            cfg.num_ss_moments = c->nmoments;
+            cfg.num_ms_moments = c->num_streams;
+            cfg.num_incoming = c->num_hr_incoming;
+            cfg.num_outgoing = c->num_hr_outgoing;
+            cfg.num_sza = c->num_sza;
+            cfg.single_scatter = c->ss_source == 0;
+            cfg.multiple_scatter = c->ms_source == 1;
+            skso::SoGeometry sg;
+            skso::build_so_geometry(geo, v->rays, cfg, sg, c->stokes_basis);
+            e->so = std::make_unique<skdev::SoDeviceEngine>(sg, c->num_hr_spherical_iterations);
+        }
+        if (!e->dev && !e->so) throw std::runtime_error("no source term configured (single_scatter_source and multiple_scatter_source are both none)");
         return e.release();
     } catch (const std::exception& ex) {
         set_error(std::string("sk_engine_create: ") + ex.what());
@@ -535,6 +566,48 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     return 0;
 }
 
+// exact single scatter and / or legacy successive orders (e->so): radiances [wavel][los][stokes] and LOS optical depths.  With
+// `add` the radiance is added to what the discrete-ordinates source already wrote (multiple_scatter_source = discrete_ordinates with
+// single_scatter_source = exact: in spherical geometry the DO source delivers the multiple-scatter term only).
+static int calculate_radiance_so(Engine* e, Atmosphere* atm, OutputC* out, bool add) {
+    const AtmosphereStorage& st = *atm->storage;
+    const Surface& su = *atm->surface;
+    const int S = e->config.num_stokes, per = (S == 3) ? 4 : 1;
+    const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
+    if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");
+    if (st.nleg % per != 0) throw std::runtime_error("leg_coeff must hold four coefficients per Legendre order for NSTOKES = 3");
+    const size_t nloc_w = size_t(ngrid) * nw, nt = size_t(nw) * nlos;
+    DeviceCache& C = e->cache;
+    double* d_ext = (double*)C.get("so_ext", nloc_w * 8);
+    double* d_ssa = (double*)C.get("so_ssa", nloc_w * 8);
+    double* d_leg = (double*)C.get("so_leg", nloc_w * st.nleg * 8);
+    double* d_alb = (double*)C.get("so_albedo", size_t(nw) * 8);
+    double* d_rad = (double*)C.get("so_radiance", nt * S * 8);
+    double* d_od = (double*)C.get("so_los_od", nt * 8);
+    double* d_irr = nullptr;
+    HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyHostToDevice));
+    if (st.irradiance) {
+        d_irr = (double*)C.get("so_irradiance", size_t(nw) * 8);
+        HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyHostToDevice));
+    }
+    e->so->solve_device(nw, st.nleg / per, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, d_od, nullptr, 0);
+    HIPC(hipDeviceSynchronize());
+    std::vector<double> rad(nt * S), od(nt);
+    HIPC(hipMemcpy(rad.data(), d_rad, nt * S * 8, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(od.data(), d_od, nt * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nt * S; ++i) {
+        if (!std::isfinite(rad[i])) throw std::runtime_error("solver failure (non-finite radiance) at wavelength " + std::to_string(i / (size_t(nlos) * S)));
+        out->radiance[i] = add ? out->radiance[i] + rad[i] : rad[i];
+    }
+    out->los_od.resize(nt);
+    for (int w = 0; w < nw; ++w)
+        for (int r = 0; r < nlos; ++r) out->los_od[size_t(r) * nw + w] = od[size_t(w) * nlos + r];
+    return 0;
+}
+
 // Sasktran2::validate_input_atmosphere (cpp/lib/engine/engine.cpp:481-540, cpp/include/sasktran2/validation/validation.h:12-64): unless
 // input_validation_mode is `disabled` (2), extinction must be finite and >= 0 and the single scatter albedo finite and inside [0, 1];
 // the first offending (location, wavelength) is reported in the error text the way the reference logs it.
@@ -567,6 +640,16 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (!su.brdf_args) throw std::runtime_error("surface has no BRDF set");
         if (su.brdf && su.brdf->kind != 0) return -2;  // only the Lambertian surface is part of this path
         validate_input_atmosphere(e, st);
+        if (e->so) {
+            // weighting functions of the exact single-scatter / successive-orders sources are not part of this build: asking for them is an
+            // error rather than a silently incomplete Jacobian
+            if (atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty())) {
+                set_error("sk_engine_calculate_radiance: weighting functions are not available with single_scatter_source = exact or "
+                          "multiple_scatter_source = successive_orders_legacy in this build (create the atmosphere with calculate_derivatives = 0)");
+                return -2;
+            }
+            if (!e->dev) return calculate_radiance_so(e, atm, out, false);
+        }
         bool scattering_groups = false;
         for (auto& kv : out->derivs) {
             auto it = st.maps.find(kv.first);
@@ -579,7 +662,10 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         // SASKTRAN2_AMD_RUNTIME_N=1 sends every request through the run-time-n kernels (cross-check of the two device implementations)
         const char* force_env = std::getenv("SASKTRAN2_AMD_RUNTIME_N");
         const bool force = force_env && atoi(force_env) != 0;
-        if (force || e->dev->vector_mode() || (scattering_groups && atm->derivs && e->config.wf_enabled)) return calculate_radiance_vector(e, atm, out);
+        if (force || e->dev->vector_mode() || (scattering_groups && atm->derivs && e->config.wf_enabled)) {
+            const int rc = calculate_radiance_vector(e, atm, out);
+            return (rc == 0 && e->so) ? calculate_radiance_so(e, atm, out, true) : rc;
+        }
         if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
         const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
         if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");
@@ -630,7 +716,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (derivs) {
             map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, 1);
         }
-        return 0;
+        return e->so ? calculate_radiance_so(e, atm, out, true) : 0;
     } catch (const std::exception& ex) {
         set_error(std::string("sk_engine_calculate_radiance: ") + ex.what());
         return -3;
@@ -645,6 +731,7 @@ int sk_amd_engine_solve_device(Engine* e, int nwavel, int nleg, const double* d_
     try {
         // the device-resident entry point cannot look at the values (they live in HBM; non-physical optics surface as status bits),
         // but shapes and pointers are checked before any kernel sees them
+        if (!e->dev || e->so) throw std::runtime_error("this entry point serves discrete-ordinates engines: use sk_amd_so_engine_solve_device or sk_engine_calculate_radiance");
         if (e->dev->vector_mode()) throw std::runtime_error("this engine runs the run-time-n / polarised kernels: use sk_engine_calculate_radiance");
         if (nwavel <= 0 || nleg <= 0) throw std::runtime_error("nwavel and nleg must be positive");
         if (!d_ext || !d_ssa || !d_leg || !d_albedo || !d_radiance || !d_los_od || !d_status)
@@ -660,33 +747,75 @@ int sk_amd_engine_solve_device(Engine* e, int nwavel, int nleg, const double* d_
     }
 }
 int sk_amd_engine_set_delta_m_fraction(Engine* e, const double* d_f) {
-    if (!e) return -1;
+    if (!e || !e->dev) return -1;
     e->dev->set_delta_m_fraction(d_f);
     return 0;
 }
 int sk_amd_engine_num_los(Engine* e, int* n) { if (!e || !n) return -1; *n = e->nlos; return 0; }
 int sk_amd_engine_scratch_bytes(Engine* e, int nwavel, unsigned long long* bytes) {
     if (!e || !bytes) return -1;
-    *bytes = (unsigned long long)e->dev->bytes_per_wavelength() * (unsigned long long)nwavel;
+    *bytes = (unsigned long long)((e->dev ? e->dev->bytes_per_wavelength() : 0) + (e->so ? e->so->bytes_per_wavelength() : 0)) * (unsigned long long)nwavel;
     return 0;
 }
 int sk_amd_engine_launch_shape(Engine* e, int* chunk, int* slots, unsigned long long* scratch_bytes) {
     if (!e) return -1;
-    if (chunk) *chunk = e->dev->last_chunk();
-    if (slots) *slots = e->dev->last_slots();
-    if (scratch_bytes) *scratch_bytes = (unsigned long long)e->dev->scratch_bytes();
+    if (chunk) *chunk = e->dev ? e->dev->last_chunk() : e->so->last_chunk();
+    if (slots) *slots = e->dev ? e->dev->last_slots() : 1;
+    if (scratch_bytes) *scratch_bytes = (unsigned long long)((e->dev ? e->dev->scratch_bytes() : 0) + (e->so ? e->so->scratch_bytes() : 0));
     return 0;
 }
-int sk_amd_engine_set_profiling(Engine* e, int on) { if (!e) return -1; e->dev->set_profiling(on != 0); return 0; }
-int sk_amd_engine_reset_profile(Engine* e) { if (!e) return -1; e->dev->reset_profile(); return 0; }
+// per-kernel timing (HIP events around every launch, serialised): both device engines of the handle
+int sk_amd_engine_set_profiling(Engine* e, int on) {
+    if (!e) return -1;
+    if (e->dev) e->dev->set_profiling(on != 0);
+    if (e->so) e->so->set_profiling(on != 0);
+    return 0;
+}
+int sk_amd_engine_reset_profile(Engine* e) {
+    if (!e) return -1;
+    if (e->dev) e->dev->reset_profile();
+    if (e->so) e->so->reset_profile();
+    return 0;
+}
 int sk_amd_engine_kernel_time(Engine* e, const char* name, double* ms, long* launches) {
     if (!e || !name || !ms || !launches) return -1;
-    return e->dev->kernel_time(name, ms, launches) ? 0 : -1;
+    if (e->dev && e->dev->kernel_time(name, ms, launches)) return 0;
+    return (e->so && e->so->kernel_time(name, ms, launches)) ? 0 : -1;
 }
 int sk_amd_engine_kernel_names(Engine* e, char* buf, int len) {
     if (!e || !buf || len < 1) return -1;
-    std::string s = e->dev->kernel_names();
+    std::string s = e->dev ? e->dev->kernel_names() : std::string();
+    if (e->so) {
+        const std::string t = e->so->kernel_names();
+        if (!t.empty()) s += (s.empty() ? "" : ",") + t;
+    }
     std::snprintf(buf, len, "%s", s.c_str());
+    return 0;
+}
+
+// device-resident entry point of the exact single-scatter / successive-orders engine (bench.py, callers that keep spectra in HBM)
+int sk_amd_so_engine_solve_device(Engine* e, int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
+                                  const double* d_albedo, const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream) {
+    if (!e) return -1;
+    try {
+        if (!e->so) throw std::runtime_error("the engine has no exact single-scatter / successive-orders source");
+        if (!d_ext || !d_ssa || !d_leg || !d_albedo || !d_radiance) throw std::runtime_error("null device pointer");
+        e->so->solve_device(nwavel, nleg, d_ext, d_ssa, d_leg, d_albedo, d_irradiance, d_radiance, d_los_od, stream, 0);
+        return 0;
+    } catch (const std::exception& ex) {
+        set_error(std::string("sk_amd_so_engine_solve_device: ") + ex.what());
+        return -3;
+    }
+}
+// sizes[0..5]: incoming rays, their layers, accumulation-matrix entries, outgoing directions, scratch bytes per wavelength, wavelengths per block of the last solve
+int sk_amd_so_engine_sizes(Engine* e, unsigned long long* sizes) {
+    if (!e || !sizes || !e->so) return -1;
+    sizes[0] = e->so->num_incoming_rays();
+    sizes[1] = e->so->num_incoming_layers();
+    sizes[2] = e->so->num_accumulation_entries();
+    sizes[3] = e->so->num_outgoing();
+    sizes[4] = e->so->bytes_per_wavelength();
+    sizes[5] = (unsigned long long)e->so->last_chunk();
     return 0;
 }
 

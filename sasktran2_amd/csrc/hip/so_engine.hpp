@@ -1,0 +1,45 @@
+// Host-facing interface of the exact single-scatter + successive-orders device driver (see so_engine.hip).
+#pragma once
+#include <cstddef>
+#include <string>
+
+#include "../host/so_geometry.hpp"
+
+namespace skdev {
+
+class SoDeviceEngine {
+  public:
+    struct Impl;
+    SoDeviceEngine(const skso::SoGeometry& g, int num_iterations);
+    ~SoDeviceEngine();
+    SoDeviceEngine(const SoDeviceEngine&) = delete;
+    SoDeviceEngine& operator=(const SoDeviceEngine&) = delete;
+
+    int nlos() const;
+    int ngrid() const;
+    int nstokes() const;
+
+    // All pointers are DEVICE pointers in the reference storage layout (location fastest):
+    //   ext, ssa [nwavel][ngrid]; leg [nwavel][ngrid][nleg (x 4: a1, a2, a3, b1 for NSTOKES = 3)]; albedo / irradiance [nwavel] (irradiance may be null).
+    // Outputs: radiance [nwavel][nlos][nstokes] (accumulate != 0: added to what is there), los_od [nwavel][nlos] (may be null).
+    void solve_device(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg, const double* d_albedo,
+                      const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream, int accumulate = 0);
+
+    size_t bytes_per_wavelength() const;
+    size_t scratch_bytes() const;
+    int last_chunk() const;
+    void set_profiling(bool on);
+    void reset_profile();
+    bool kernel_time(const char* name, double* ms, long* launches) const;
+    std::string kernel_names() const;
+    // sizes of the diffuse discretisation (for the roofline bookkeeping of bench.py)
+    size_t num_incoming_rays() const;
+    size_t num_incoming_layers() const;
+    size_t num_accumulation_entries() const;
+    size_t num_outgoing() const;
+
+  private:
+    Impl* impl_;
+};
+
+}  // namespace skdev

@@ -62,3 +62,50 @@ def run_product(s, derivatives=True, engine=None):
         out["d_ssa"] = np.transpose(res["wf_ssa"][:, :, :, 0], (1, 2, 0))
         out["d_albedo"] = res["wf_albedo"][:, :, 0]
     return out
+
+
+def build_so_engine(s, **override):
+    """Engine for a tests/scenarios.py successive-orders scenario (config keys of scenarios.regression_so)."""
+    g, c = s["geometry"], dict(s["config"], **override)
+    config = sk.Config()
+    config.num_stokes = c["nstokes"]
+    config.stokes_basis = c.get("stokes_basis", 0)
+    config.num_streams = c["num_streams"]
+    config.num_singlescatter_moments = c["num_singlescatter_moments"]
+    config.num_sza = c["num_sza"]
+    config.single_scatter_source = {"exact": sk.SingleScatterSource.Exact, "none": sk.SingleScatterSource.NoSource}[c["single_scatter"]]
+    config.multiple_scatter_source = {"successive_orders_legacy": sk.MultipleScatterSource.SuccessiveOrdersLegacy,
+                                      "discrete_ordinates": sk.MultipleScatterSource.DiscreteOrdinates,
+                                      "none": sk.MultipleScatterSource.NoSource}[c["multiple_scatter"]]
+    config.num_successive_orders_iterations = c["num_iterations"]
+    config.num_successive_orders_incoming = c["num_incoming"]
+    config.num_successive_orders_outgoing = c["num_outgoing"]
+    config.init_successive_orders_with_discrete_ordinates = False
+    geometry = sk.Geometry1D(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"],
+                             sk.InterpolationMethod(g["interp_method"]), sk.GeometryType(g["geotype"]))
+    viewing = sk.ViewingGeometry()
+    for kind, csz, az, obs, x in s["rays"]:
+        if kind == sc.TANGENT_ALTITUDE_SOLAR:
+            viewing.add_ray(sk.TangentAltitudeSolar(x, az, obs, csz))
+        elif kind == sc.TANGENT_ALTITUDE:
+            viewing.add_ray(sk.TangentAltitude(x, obs, csz, az))
+        elif kind == sc.VIEWING_UP_SOLAR:
+            viewing.add_ray(sk.SolarAnglesObserverLocation(csz, az, x, obs))
+        else:
+            viewing.add_ray(sk.GroundViewingSolar(csz, az, x, obs))
+    return sk.Engine(config, geometry, viewing), config, geometry
+
+
+def run_product_so(s, engine=None, solar_irradiance=None, **override):
+    """Radiances [wavelength, los, stokes] and LOS optical depths of the exact single-scatter / successive-orders path."""
+    engine, config, geometry = engine if engine is not None else build_so_engine(s, **override)
+    nw = s["extinction"].shape[1]
+    atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=False)
+    atmosphere.storage.total_extinction[:] = s["extinction"]
+    atmosphere.storage.ssa[:] = s["ssa"]
+    atmosphere.storage.leg_coeff[:] = s["leg"]
+    if solar_irradiance is not None:
+        atmosphere.storage.solar_irradiance[:] = solar_irradiance
+    atmosphere.surface.albedo[:] = s["albedo"]
+    res = engine.calculate_radiance(atmosphere, as_dataset=False)
+    return {"radiance": res["radiance"], "los_optical_depth": res["los_optical_depth"]}
