@@ -79,7 +79,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--wavelengths", type=int, default=10_000)
+    ap.add_argument("--wavelengths", type=int, default=0, help="0 = the workload's own size (C2: 10 000, C5: 20 000)")
+    ap.add_argument("--workload", choices=("c2", "c5"), default="c2",
+                    help="c2 (default, BASELINE.json's metric): 16-stream DISCO limb + weighting functions; c5: BASELINE configs[4], "
+                         "exact single scatter + 10 successive orders of scattering")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="wavelengths of the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -100,7 +103,13 @@ def main():
     from tests import scenarios as sc
     from tests.gpu_harness import build_engine
 
-    NW = args.wavelengths
+    if args.workload == "c5":
+        from bench_so import run_c5
+        run_c5(args, world, rank, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    NW = args.wavelengths or 10_000
     s = sc.limb_c2(num_wavelengths=NW)
     engine, config, geometry = build_engine(s)
     solver = DeviceSolver(engine)

@@ -72,3 +72,38 @@ class DeviceSolver:
         b = ctypes.c_ulonglong()
         lib().sk_amd_engine_scratch_bytes(self.engine._h, nwavel, ctypes.byref(b))
         return b.value
+
+
+class SoDeviceSolver(DeviceSolver):
+    """Device-resident front end of an engine with single_scatter_source = exact and / or multiple_scatter_source =
+    successive_orders_legacy (`sk_amd_so_engine_solve_device`): radiances [nwavel, nlos, nstokes] and LOS optical depths."""
+
+    def __init__(self, engine):
+        super().__init__(engine)
+        self.nstokes = int(engine._config.num_stokes)
+
+    def allocate_outputs(self, nwavel, derivatives=False, device="cuda"):
+        if derivatives:
+            raise ValueError("weighting functions are not available on the successive-orders path")
+        kw = dict(dtype=torch.float64, device=device)
+        return {"radiance": torch.empty((nwavel, self.nlos, self.nstokes), **kw), "los_optical_depth": torch.empty((nwavel, self.nlos), **kw)}
+
+    def solve(self, extinction, ssa, leg, albedo, out, irradiance=None, max_chunk=0):
+        """extinction, ssa: [nwavel, ngrid]; leg: [nwavel, ngrid, nleg (x 4 for NSTOKES = 3)]; albedo: [nwavel] -- contiguous float64
+        CUDA tensors in the reference storage layout.  Asynchronous on torch's current stream."""
+        for t in (extinction, ssa, leg, albedo):
+            assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        per = 4 if self.nstokes == 3 else 1
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        rc = lib().sk_amd_so_engine_solve_device(
+            self.engine._h, extinction.shape[0], leg.shape[2] // per, p(extinction), p(ssa), p(leg), p(albedo), p(irradiance),
+            p(out["radiance"]), p(out["los_optical_depth"]), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sk_amd_so_engine_solve_device returned {rc}: {last_error()}")
+        return out
+
+    def sizes(self):
+        v = (ctypes.c_ulonglong * 6)()
+        lib().sk_amd_so_engine_sizes(self.engine._h, v)
+        return dict(incoming_rays=v[0], incoming_layers=v[1], accumulation_entries=v[2], outgoing_directions=v[3],
+                    scratch_bytes_per_wavelength=v[4], wavelengths_per_block=v[5])
