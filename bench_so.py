@@ -79,8 +79,10 @@ def run_c5(args, world, rank, dev):
         "so_accumulate": {"bytes": 8 * (nl + 3 * nr + no), "flops": 2 * ne},
         # reads incoming + the points' Legendre coefficients, writes outgoing; 2 x moments x rows x cols per interior point
         "so_scatter": {"bytes": 8 * (nr + no + npts * nmom), "flops": 2 * nmom * ndir * c["num_incoming"] * npts},
-        # writes the layer factors + first order / incoming; the table / optics it reads are L2 resident
-        "so_march_incoming": {"bytes": 8 * (nl + 3 * nr), "flops": None},
+        # per layer: writes optical depth, unattenuated source and omega (1 - e^-od); the table / optics it reads are L2 resident
+        "so_layers": {"bytes": 8 * 3 * nl, "flops": None},
+        # reads those three, writes the layer factors in place + first order / incoming
+        "so_scan": {"bytes": 8 * (4 * nl + 3 * nr), "flops": None},
         "so_march_los": {"bytes": 8 * (nlos * 2), "flops": None},
         "so_tables": {"bytes": 8 * (100 * ngrid + npts * nmom), "flops": None},
         "so_transpose": {"bytes": 16 * ngrid * (2 + nmom), "flops": None},

@@ -1,14 +1,14 @@
 // HIP kernels + device driver of the exact single-scatter source and the successive-orders ("HR", legacy) multiple-scatter
 // source (gfx950).  Reference stages and where they run here:
 //
-//   solar transmission at every layer boundary        cpp/lib/solar/singlescattersource.cpp:103-160           k_so_march (exact rows / table)
+//   solar transmission at every layer boundary        cpp/lib/solar/singlescattersource.cpp:103-160           k_so_layers (table) / k_so_march (exact rows)
 //   single-scatter layer source, ground term           singlescattersource.cpp:574-636,950-1167,
-//                                                      cpp/include/sasktran2/solartransmission.h:733-846      k_so_march
-//   first-order incoming radiance + accumulation       cpp/lib/sourceintegrator/sourceintegrator.cpp:666-760   k_so_march<incoming>
+//                                                      cpp/include/sasktran2/solartransmission.h:733-846      k_so_layers / k_so_march
+//   first-order incoming radiance + accumulation       cpp/lib/sourceintegrator/sourceintegrator.cpp:666-760   k_so_layers (per layer) + k_so_scan (along the ray)
 //   scattering matrices x incoming                     cpp/lib/hr/diffuse_table.cpp:673-716,775-808,
 //                                                      cpp/lib/hr/diffuse_point.cpp:199-296                    k_so_scatter
 //   incoming = accumulation x outgoing + first order   diffuse_table.cpp:755-770                               k_so_accumulate
-//   LOS integration of both sources                    sourceintegrator.cpp:521-580, diffuse_table.cpp:965-1064  k_so_march<los>
+//   LOS integration of both sources                    sourceintegrator.cpp:521-580, diffuse_table.cpp:965-1064  k_so_march
 //
 // MI355X formulation: a LANE IS A WAVELENGTH.  Every per-wavelength array is stored [item][wavelength] (wavelength fastest), so the
 // 64 lanes of a wavefront read 512 contiguous bytes; every geometric quantity (layer stencils, interpolation weights, CSR rows of the
@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -42,6 +43,8 @@ namespace skdev {
 namespace {
 constexpr double kPi = 3.14159265358979323846;
 constexpr int kWave = 64;
+constexpr int kPad = 128;   // wavelengths of a block are padded to two wavefronts (k_so_scatter serves two slabs per wave)
+constexpr int kLayersPerBlock = 2;
 
 struct DevCsr {
     const int* start;
@@ -64,14 +67,37 @@ struct DevRays {
     const unsigned char* solar_blocked;
     const double *C2, *S2, *d00, *d02;      // per ray; d00 / d02 [ray][num_ss_moments]
 };
+// everything k_so_layers needs of one incoming-ray layer in one 256-byte record (four s_load_dwordx16): one scalar round trip instead
+// of a chain of dependent index loads
+struct LayerRec {
+    int q[4];            // grid stencil (union of the two boundaries), padded with 0
+    int mid[2];          // atmosphere stencil of the mid point
+    int tx[4], te[4];    // solar-table stencil of the exit / entrance boundary
+    int ray, tiny;
+    double wod[4], went[4], wexit[4], midw[2], quad_start, quad_end, twx[4], twe[4];
+};
+static_assert(sizeof(LayerRec) == 256, "LayerRec layout");
+// six accumulation-matrix entries that share one factor slot (a ray layer: 2 altitudes x 3 nearest directions; padded with weight 0)
+struct AccGroup {
+    int col[6];
+    int slot, pad;
+    double w[6];
+};
+static_assert(sizeof(AccGroup) == 80, "AccGroup layout");
+
 struct SoGeo {
     int ngrid, nlos, S, num_ss_moments, num_ms_moments;
+    const LayerRec* inc_rec;
+    const AccGroup* acc_group;
+    const int* acc_group_start;             // [incoming rays + 1]
     int npoints, ninterior, nin, nout;
     DevRays los, inc;
     DevCsr table;                           // solar optical depth of the table points over the grid
     int ntable;
     DevCsr acc;                             // accumulation rows per incoming ray
-    const int* acc_layer;
+    const int* acc_layer;                   // factor slot of an entry: its ray layer, or nlayers + ray for the ground term
+    const int* inc_layer_ray;               // [incoming layers] ray of a layer
+    int n_inc_layers, n_out_total;
     DevCsr los_source, los_ground;
     const int *in_start, *out_start, *point_leg_idx;
     const double* point_leg_w;
@@ -79,39 +105,59 @@ struct SoGeo {
     const double* ground_factor;            // concatenated per ground point
     const int* ground_factor_start;         // [nground + 1]
 };
-// per-block scratch, every array [item][nwp] with nwp = wavelengths of the block padded to the wavefront size
+// per-block scratch.  SLAB-MAJOR layout: every array is [slab][item][64] (slab = 64 consecutive wavelengths = one wavefront), so the
+// working set of a slab -- the directions of `outgoing` all rays gather from, the solar table, the optics -- is one contiguous range
+// (2.8 MB of `outgoing` at the C5 size).  [item][wavelength] with a 160 KB row stride put the 5 549 rows of a slab on a fraction of the
+// L2 sets and the gathers missed (PMC: 2.8 x the algorithmic HBM reads in k_so_accumulate).
 struct SoBufs {
     int nw, nwp, nleg, w0, nwavel_total;
     const double *ext, *ssa, *leg, *albedo, *irradiance;   // caller's inputs at the first wavelength of the block
-    double *kT, *omT, *legT, *tab, *cl, *first, *incoming, *outgoing, *factor, *gfactor;
+    double *kT, *omT, *legT, *tab, *cl, *first, *incoming, *outgoing, *factor, *lod, *lsrc;   // factor: [layers + rays] (ground slots last)
     double *radiance, *los_od;                               // caller's outputs (whole spectrum)
     int accumulate;
 };
 
+// pointers of one slab, advanced to this lane: element `item` of array X is X[item * kWave]
+__device__ inline SoBufs slab_view(const SoGeo& g, const SoBufs& b, int slab, int lane) {
+    SoBufs v = b;
+    const size_t o = size_t(slab) * kWave, per = g.S == 3 ? 4 : 1, S = g.S;
+    v.kT += o * g.ngrid + lane;
+    v.omT += o * g.ngrid + lane;
+    v.legT += o * g.ngrid * b.nleg * per + lane;
+    v.tab += o * g.ntable + lane;
+    v.cl += o * g.ninterior * g.num_ms_moments * per + lane;
+    v.first += o * g.inc.nrays * S + lane;
+    v.incoming += o * g.inc.nrays * S + lane;
+    v.outgoing += o * g.n_out_total * S + lane;
+    v.factor += o * (g.n_inc_layers + g.inc.nrays) + lane;
+    v.lod += o * g.n_inc_layers + lane;
+    v.lsrc += o * g.n_inc_layers * S + lane;
+    return v;
+}
+
 // inputs [w][q] -> [q][w]; Legendre / Greek coefficients [w][q][lg] -> [q][lg][w]
 __global__ void __launch_bounds__(256) k_so_transpose(SoGeo g, SoBufs b) {
     const int nlg = b.nleg * (g.S == 3 ? 4 : 1);
-    const size_t per_w = size_t(g.ngrid) * (2 + nlg), n = per_w * b.nwp;
+    const size_t nk = g.ngrid, nl = size_t(g.ngrid) * nlg, per_w = 2 * nk + nl, n = per_w * b.nwp;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
-        const int w = int(i % b.nwp);
-        const size_t item = i / b.nwp;
+        const int lane = int(i % kWave);
+        const size_t t = i / kWave, slab = t / per_w, item = t % per_w;   // item: extinction | ssa | Legendre (q * nlg + lg)
+        const int w = int(slab) * kWave + lane;
         const int ws = w < b.nw ? w : b.nw - 1;   // padding lanes repeat the last wavelength (keeps every lane finite)
-        if (item < size_t(g.ngrid)) b.kT[i] = b.ext[size_t(ws) * g.ngrid + item];
-        else if (item < size_t(2 * g.ngrid)) b.omT[i - size_t(g.ngrid) * b.nwp] = b.ssa[size_t(ws) * g.ngrid + (item - g.ngrid)];
-        else {
-            const size_t t = item - 2 * g.ngrid;   // q * nlg + lg
-            b.legT[t * b.nwp + w] = b.leg[size_t(ws) * g.ngrid * nlg + t];
-        }
+        if (item < nk) b.kT[(slab * nk + item) * kWave + lane] = b.ext[size_t(ws) * g.ngrid + item];
+        else if (item < 2 * nk) b.omT[(slab * nk + (item - nk)) * kWave + lane] = b.ssa[size_t(ws) * g.ngrid + (item - nk)];
+        else b.legT[(slab * nl + (item - 2 * nk)) * kWave + lane] = b.leg[size_t(ws) * nl + (item - 2 * nk)];
     }
 }
 
 // solar optical depth at the table points; Legendre coefficients of the diffuse points
 __global__ void __launch_bounds__(kWave) k_so_tables(SoGeo g, SoBufs b) {
-    const int w = blockIdx.x * kWave + threadIdx.x, item = blockIdx.y, nwp = b.nwp;
+    const int item = blockIdx.y;
+    const SoBufs v = slab_view(g, b, blockIdx.x, threadIdx.x);
     if (item < g.ntable) {
         double od = 0;
-        for (int e = g.table.start[item]; e < g.table.start[item + 1]; ++e) od += g.table.w[e] * b.kT[size_t(g.table.idx[e]) * nwp + w];
-        b.tab[size_t(item) * nwp + w] = od;
+        for (int e = g.table.start[item]; e < g.table.start[item + 1]; ++e) od += g.table.w[e] * v.kT[size_t(g.table.idx[e]) * kWave];
+        v.tab[size_t(item) * kWave] = od;
         return;
     }
     const int per = g.S == 3 ? 4 : 1, nlgB = g.num_ms_moments * per, nlg_in = b.nleg * per;
@@ -119,8 +165,8 @@ __global__ void __launch_bounds__(kWave) k_so_tables(SoGeo g, SoBufs b) {
     double c = 0;
     if (lg < nlg_in)
         for (int i = 0; i < 2; ++i)
-            c += g.point_leg_w[2 * p + i] * b.legT[(size_t(g.point_leg_idx[2 * p + i]) * nlg_in + lg) * nwp + w];
-    b.cl[size_t(t) * nwp + w] = c;
+            c += g.point_leg_w[2 * p + i] * v.legT[(size_t(g.point_leg_idx[2 * p + i]) * nlg_in + lg) * kWave];
+    v.cl[size_t(t) * kWave] = c;
 }
 
 // One ray, 64 wavelengths per wavefront, marched from the observer outward.
@@ -129,7 +175,8 @@ __global__ void __launch_bounds__(kWave) k_so_tables(SoGeo g, SoBufs b) {
 template <int S, bool LOS>
 __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int single_scatter, int multiple_scatter) {
     const DevRays& rs = LOS ? g.los : g.inc;
-    const int w = blockIdx.x * kWave + threadIdx.x, r = blockIdx.y, nwp = b.nwp;
+    const int w = blockIdx.x * kWave + threadIdx.x, r = blockIdx.y;
+    const SoBufs v = slab_view(g, b, blockIdx.x, threadIdx.x);
     const int l0 = rs.layer_start[r], n = rs.layer_start[r + 1] - l0, e0 = rs.endpoint_start[r];
     const int per = S == 3 ? 4 : 1, nlg_in = b.nleg * per, nm = min(g.num_ss_moments, b.nleg);
     const int ws = w < b.nw ? w : b.nw - 1;
@@ -148,10 +195,10 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
         for (int c = 0; c < 4; ++c)
             if (cq[c] == q) { p11 = c11[c]; p12 = c12[c]; return; }
         double s1 = 0, s2 = 0;
-        const double* lq = b.legT + size_t(q) * nlg_in * nwp + w;
+        const double* lq = v.legT + size_t(q) * nlg_in * kWave;
         for (int l = 0; l < nm; ++l) {
-            s1 += lq[size_t(l) * per * nwp] * rs.d00[size_t(r) * g.num_ss_moments + l];
-            if (S == 3) s2 += lq[size_t(l * per + 3) * nwp] * rs.d02[size_t(r) * g.num_ss_moments + l];
+            s1 += lq[size_t(l) * per * kWave] * rs.d00[size_t(r) * g.num_ss_moments + l];
+            if (S == 3) s2 += lq[size_t(l * per + 3) * kWave] * rs.d02[size_t(r) * g.num_ss_moments + l];
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -162,9 +209,9 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
     };
     auto transmission = [&](int e) -> double {
         if (LOS && rs.solar_blocked[e]) return 0.0;
-        const double* x = LOS ? b.kT : b.tab;
+        const double* x = LOS ? v.kT : v.tab;
         double od = 0;
-        for (int t = rs.solar.start[e]; t < rs.solar.start[e + 1]; ++t) od += rs.solar.w[t] * x[size_t(rs.solar.idx[t]) * nwp + w];
+        for (int t = rs.solar.start[e]; t < rs.solar.start[e + 1]; ++t) od += rs.solar.w[t] * x[size_t(rs.solar.idx[t]) * kWave];
         return exp(-od) * F;
     };
     auto endpoint = [&](int L, const double* wts, double T, double* out) {
@@ -175,8 +222,8 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
             if (q < 0 || wt == 0.0) continue;
             double p11, p12;
             phase(q, p11, p12);
-            ke += b.kT[size_t(q) * nwp + w] * wt;
-            oe += b.omT[size_t(q) * nwp + w] * wt;
+            ke += v.kT[size_t(q) * kWave] * wt;
+            oe += v.omT[size_t(q) * kWave] * wt;
             a += p11 * wt;
             bb += p12 * wt;
         }
@@ -194,7 +241,7 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
     for (int j = n - 1; j >= 0; --j) {
         const int L = l0 + j;
         double od = 0;
-        for (int t = rs.od.start[L]; t < rs.od.start[L + 1]; ++t) od += rs.od.w[t] * b.kT[size_t(rs.od.idx[t]) * nwp + w];
+        for (int t = rs.od.start[L]; t < rs.od.start[L + 1]; ++t) od += rs.od.w[t] * v.kT[size_t(rs.od.idx[t]) * kWave];
         const double att = exp(-od);
         if (single_scatter) {
             const double T_exit = transmission(e0 + j);
@@ -209,17 +256,15 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
             T_entrance = T_exit;
         }
         if (multiple_scatter) {
-            const double omega = rs.mid_w[2 * L] * b.omT[size_t(rs.mid_idx[2 * L]) * nwp + w] + rs.mid_w[2 * L + 1] * b.omT[size_t(rs.mid_idx[2 * L + 1]) * nwp + w];
+            const double omega = rs.mid_w[2 * L] * v.omT[size_t(rs.mid_idx[2 * L]) * kWave] + rs.mid_w[2 * L + 1] * v.omT[size_t(rs.mid_idx[2 * L + 1]) * kWave];
             const double f = omega * (1 - att) * before;
             if (LOS) {
                 for (int t = g.los_source.start[L]; t < g.los_source.start[L + 1]; ++t) {
                     const double fw = f * g.los_source.w[t];
-                    const double* o = b.outgoing + size_t(g.los_source.idx[t]) * S * nwp + w;
+                    const double* o = v.outgoing + size_t(g.los_source.idx[t]) * S * kWave;
 #pragma unroll
-                    for (int s = 0; s < S; ++s) val[s] += fw * o[size_t(s) * nwp];
+                    for (int s = 0; s < S; ++s) val[s] += fw * o[size_t(s) * kWave];
                 }
-            } else {
-                b.factor[size_t(L) * nwp + w] = f;
             }
         }
         cur += od;
@@ -232,16 +277,12 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
             if (LOS) {
                 for (int t = g.los_ground.start[r]; t < g.los_ground.start[r + 1]; ++t) {
                     const double fw = before * g.los_ground.w[t];
-                    const double* o = b.outgoing + size_t(g.los_ground.idx[t]) * S * nwp + w;
+                    const double* o = v.outgoing + size_t(g.los_ground.idx[t]) * S * kWave;
 #pragma unroll
-                    for (int s = 0; s < S; ++s) val[s] += fw * o[size_t(s) * nwp];
+                    for (int s = 0; s < S; ++s) val[s] += fw * o[size_t(s) * kWave];
                 }
-            } else {
-                b.gfactor[size_t(r) * nwp + w] = before;
             }
         }
-    } else if (!LOS && multiple_scatter) {
-        b.gfactor[size_t(r) * nwp + w] = 0.0;
     }
     if (LOS) {
         if (w >= b.nw) return;
@@ -249,12 +290,119 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
 #pragma unroll
         for (int s = 0; s < S; ++s) out[s] = b.accumulate ? out[s] + val[s] : val[s];
         if (b.los_od) b.los_od[size_t(b.w0 + w) * g.nlos + r] = total_od;
-    } else {
+    }
+}
+
+// INCOMING RAYS, stage 1: everything of a ray layer that does not depend on the layers in front of it -- optical depth, the
+// unattenuated single-scatter source (table solar transmission at both boundaries) and omega (1 - e^-od).  One layer x 64 wavelengths per
+// wavefront; grid x = layer so that the wavefronts in flight share one wavelength slab of the optics / table in L2.
+// (the tables come as __restrict__ kernel arguments: only then may the compiler keep them on the scalar path next to the stores)
+template <int S>
+__global__ void __launch_bounds__(kWave) k_so_layers(SoGeo g, SoBufs b, const LayerRec* __restrict__ recs, const double* __restrict__ d00tab,
+                                                     const double* __restrict__ d02tab, const double* __restrict__ C2tab,
+                                                     const double* __restrict__ S2tab, double* __restrict__ lod_out,
+                                                     double* __restrict__ factor_out, double* __restrict__ lsrc_out, int layers_per_block) {
+    const int w = blockIdx.y * kWave + threadIdx.x;
+    const SoBufs v = slab_view(g, b, blockIdx.y, threadIdx.x);
+    lod_out += size_t(blockIdx.y) * kWave * g.n_inc_layers + threadIdx.x;
+    factor_out += size_t(blockIdx.y) * kWave * (g.n_inc_layers + g.inc.nrays) + threadIdx.x;
+    lsrc_out += size_t(blockIdx.y) * kWave * g.n_inc_layers * S + threadIdx.x;
+    const int per = S == 3 ? 4 : 1, nlg_in = b.nleg * per, nm = min(g.num_ss_moments, b.nleg);
+    const int ws = w < b.nw ? w : b.nw - 1;
+    const double F = b.irradiance ? b.irradiance[ws] : 1.0;
+    // a wavefront works through kLayersPerBlock layers: one workgroup per layer and slab (45 million of them at the C5 size) is bound
+    // by the dispatcher, not by the arithmetic
+    const int L_end = min(int(blockIdx.x + 1) * layers_per_block, g.n_inc_layers);
+  for (int L = blockIdx.x * layers_per_block; L < L_end; ++L) {
+    const LayerRec& rec = recs[L];
+    const int r = rec.ray;
+    double kq[4], oq[4], od = 0, tod[2] = {0, 0};
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            b.first[(size_t(r) * S + s) * nwp + w] = val[s];
-            b.incoming[(size_t(r) * S + s) * nwp + w] = val[s];
+    for (int i = 0; i < 4; ++i) {
+        kq[i] = v.kT[size_t(rec.q[i]) * kWave];
+        oq[i] = v.omT[size_t(rec.q[i]) * kWave];
+        tod[0] += rec.twx[i] * v.tab[size_t(rec.tx[i]) * kWave];
+        tod[1] += rec.twe[i] * v.tab[size_t(rec.te[i]) * kWave];
+    }
+    const double omega = rec.midw[0] * v.omT[size_t(rec.mid[0]) * kWave] + rec.midw[1] * v.omT[size_t(rec.mid[1]) * kWave];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) od += rec.wod[i] * kq[i];
+    const double em1 = expm1(-od);   // 1 - e^-od = -em1 without cancellation, and the only transcendental this layer needs for its own depth
+    // streaming stores: 3 doubles per layer and wavelength pass through once; kept out of L2 they do not evict the slab's table / optics
+    __builtin_nontemporal_store(od, &lod_out[size_t(L) * kWave]);
+    __builtin_nontemporal_store(omega * (-em1), &factor_out[size_t(L) * kWave]);
+    double src[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) src[s] = 0;
+    if (!rec.tiny) {
+        const double T[2] = {exp(-tod[0]) * F, exp(-tod[1]) * F};   // exit, entrance
+        double ke[2] = {0, 0}, oe[2] = {0, 0}, a[2] = {0, 0}, bb[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double wx = rec.wexit[i], we = rec.went[i];
+            if (wx == 0.0 && we == 0.0) continue;
+            double p11 = 0, p12 = 0;
+            const double* lq = v.legT + size_t(rec.q[i]) * nlg_in * kWave;
+            for (int l = 0; l < nm; ++l) {
+                p11 += lq[size_t(l) * per * kWave] * d00tab[size_t(r) * g.num_ss_moments + l];
+                if (S == 3) p12 += lq[size_t(l * per + 3) * kWave] * d02tab[size_t(r) * g.num_ss_moments + l];
+            }
+            ke[0] += kq[i] * wx; oe[0] += oq[i] * wx; a[0] += p11 * wx; bb[0] += p12 * wx;
+            ke[1] += kq[i] * we; oe[1] += oq[i] * we; a[1] += p11 * we; bb[1] += p12 * we;
         }
+        const double sf = (fabs(od) < 1e-12) ? 1.0 : -em1 / od;
+        const double amp_x = ke[0] * oe[0] * T[0] / (kPi * 4) * rec.quad_end, amp_e = ke[1] * oe[1] * T[1] / (kPi * 4) * rec.quad_start;
+        src[0] = sf * (amp_e * a[1] + amp_x * a[0]);
+        if (S == 3) {
+            const double pol = sf * (amp_e * bb[1] + amp_x * bb[0]);
+            src[1] = -C2tab[r] * pol;
+            src[2] = -S2tab[r] * pol;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) __builtin_nontemporal_store(src[s], &lsrc_out[(size_t(L) * S + s) * kWave]);
+  }
+}
+
+// INCOMING RAYS, stage 2: the scan along a ray from the diffuse point outward -- attenuation in front of every layer, first-order
+// incoming radiance, layer factors of the accumulation matrix (in place over omega (1 - e^-od)), ground term.
+template <int S>
+__global__ void __launch_bounds__(kWave) k_so_scan(SoGeo g, SoBufs b) {
+    const DevRays& rs = g.inc;
+    const int r = blockIdx.x, w = blockIdx.y * kWave + threadIdx.x;
+    const SoBufs v = slab_view(g, b, blockIdx.y, threadIdx.x);
+    const int l0 = rs.layer_start[r], n = rs.layer_start[r + 1] - l0;
+    double val[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) val[s] = 0;
+    double cur = 0, before = 1;
+#pragma unroll 4
+    for (int j = n - 1; j >= 0; --j) {
+        const size_t o = size_t(l0 + j) * kWave;
+        const double od = __builtin_nontemporal_load(&v.lod[o]), f = __builtin_nontemporal_load(&v.factor[o]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) val[s] += __builtin_nontemporal_load(&v.lsrc[(size_t(l0 + j) * S + s) * kWave]) * before;
+        __builtin_nontemporal_store(f * before, &v.factor[o]);
+        cur += od;
+        before = exp(-cur);
+    }
+    double gf = 0;
+    if (n > 0 && rs.ground_is_hit[r]) {
+        gf = before;
+        if (rs.ground_mu_in[r] > 0) {
+            const int ws = w < b.nw ? w : b.nw - 1;
+            const double F = b.irradiance ? b.irradiance[ws] : 1.0;
+            double t_od = 0;
+            const int e = rs.endpoint_start[r];
+            for (int t = rs.solar.start[e]; t < rs.solar.start[e + 1]; ++t) t_od += rs.solar.w[t] * v.tab[size_t(rs.solar.idx[t]) * kWave];
+            val[0] += exp(-t_od) * F * (b.albedo[ws] / kPi) * rs.ground_mu_in[r] * before;
+        }
+    }
+    v.factor[size_t(g.n_inc_layers + r) * kWave] = gf;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        v.first[(size_t(r) * S + s) * kWave] = val[s];
+        v.incoming[(size_t(r) * S + s) * kWave] = val[s];
     }
 }
 
@@ -262,74 +410,121 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
 // Lambertian reflection of the downwelling flux (ground points)
 template <int S>
 __global__ void __launch_bounds__(kWave) k_so_scatter(SoGeo g, SoBufs b) {
-    const int w = blockIdx.x * kWave + threadIdx.x, row = blockIdx.y, p = blockIdx.z, nwp = b.nwp;
+    // two wavelength slabs per wavefront: every scalar-cache operand (one element of the basis) feeds two FMAs
+    const int w = blockIdx.y * (2 * kWave) + threadIdx.x, row = blockIdx.x, p = blockIdx.z;
+    const SoBufs v = slab_view(g, b, 2 * blockIdx.y, threadIdx.x), v2 = slab_view(g, b, 2 * blockIdx.y + 1, threadIdx.x);
     const int nrow = (g.out_start[p + 1] - g.out_start[p]) * S, ncol = (g.in_start[p + 1] - g.in_start[p]) * S;
     if (row >= nrow) return;
-    const double* in = b.incoming + size_t(g.in_start[p]) * S * nwp + w;
-    double* out = b.outgoing + (size_t(g.out_start[p]) * S + row) * nwp + w;
+    const double* __restrict__ in = v.incoming + size_t(g.in_start[p]) * S * kWave;
+    const double* __restrict__ in2 = v2.incoming + size_t(g.in_start[p]) * S * kWave;
+    double* out = v.outgoing + (size_t(g.out_start[p]) * S + row) * kWave;
+    double* out2 = v2.outgoing + (size_t(g.out_start[p]) * S + row) * kWave;
     if (p >= g.ninterior) {
-        double v = 0;
+        double v0 = 0, v1 = 0;
         if (row % S == 0) {
-            const int ws = w < b.nw ? w : b.nw - 1;
+            const int wa = min(w, b.nw - 1), wb2 = min(w + kWave, b.nw - 1);
             const double* f = g.ground_factor + g.ground_factor_start[p - g.ninterior];
-            for (int i = 0; i < ncol / S; ++i) v += f[i] * in[size_t(i) * S * nwp];
-            v *= b.albedo[ws] / kPi;
+            for (int i = 0; i < ncol / S; ++i) {
+                v0 += f[i] * in[size_t(i) * S * kWave];
+                v1 += f[i] * in2[size_t(i) * S * kWave];
+            }
+            v0 *= b.albedo[wa] / kPi;
+            v1 *= b.albedo[wb2] / kPi;
         }
-        *out = v;
+        out[0] = v0;
+        out2[0] = v1;
         return;
     }
     const int per = S == 3 ? 4 : 1, nlgB = g.num_ms_moments * per, nlg = min(g.num_ms_moments, b.nleg) * per;
-    const double* cl = b.cl + size_t(p) * nlgB * nwp + w;
-    const double* B = g.scat_basis + size_t(row) * ncol * nlgB;
-    double sum = 0;
+    const double* __restrict__ cl = v.cl + size_t(p) * nlgB * kWave;
+    const double* __restrict__ cl2 = v2.cl + size_t(p) * nlgB * kWave;
+    const double* __restrict__ B = g.scat_basis + size_t(row) * ncol * nlgB;
+    double sum0 = 0, sum1 = 0;
     for (int c0 = 0; c0 < nlg; c0 += 16) {
-        double acc[16];
+        double acc0[16], acc1[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) acc[t] = 0;
+        for (int t = 0; t < 16; ++t) acc0[t] = acc1[t] = 0;
         const int nt = min(16, nlg - c0);
         if (nt == 16) {
+#pragma unroll 2
             for (int i = 0; i < ncol; ++i) {
-                const double x = in[size_t(i) * nwp];
+                const double x0 = in[size_t(i) * kWave], x1 = in2[size_t(i) * kWave];
                 const double* Bi = B + size_t(i) * nlgB + c0;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) acc[t] += Bi[t] * x;
+                for (int t = 0; t < 16; ++t) { acc0[t] += Bi[t] * x0; acc1[t] += Bi[t] * x1; }
             }
         } else {
             for (int i = 0; i < ncol; ++i) {
-                const double x = in[size_t(i) * nwp];
+                const double x0 = in[size_t(i) * kWave], x1 = in2[size_t(i) * kWave];
                 const double* Bi = B + size_t(i) * nlgB + c0;
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
-                    if (t < nt) acc[t] += Bi[t] * x;
+                    if (t < nt) { acc0[t] += Bi[t] * x0; acc1[t] += Bi[t] * x1; }
             }
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t)
-            if (t < nt) sum += cl[size_t(c0 + t) * nwp] * acc[t];
+            if (t < nt) { sum0 += cl[size_t(c0 + t) * kWave] * acc0[t]; sum1 += cl2[size_t(c0 + t) * kWave] * acc1[t]; }
     }
-    *out = sum;
+    out[0] = sum0;
+    out2[0] = sum1;
 }
 
-// incoming = accumulation matrix x outgoing + first order, one incoming ray x 64 wavelengths per wavefront
+// incoming = accumulation matrix x outgoing + first order, one incoming ray x 64 wavelengths per wavefront.  The matrix entry is
+// (geometric weight, scalar cache) x (factor of its ray layer, one coalesced load); grid x = ray, so that the wavefronts in flight gather
+// from one wavelength slab of `outgoing` (2.8 MB at 5 549 directions) held in L2.
+// Measured (MI355X, C5 size, 11.6 ms per launch): with every gather pointed at ONE line the time does not change, without the factor
+// stream it drops to 9 ms -- the kernel is bound by the vector-memory issue rate (7 wave loads of 512 B per group of 6 entries =
+// 56 cycles of the CU's 64 B/clk L1 path against 116 measured), not by L2 misses or HBM; limiting the wavefronts in flight only hurts.
 template <int S>
 __global__ void __launch_bounds__(kWave) k_so_accumulate(SoGeo g, SoBufs b) {
-    const int w = blockIdx.x * kWave + threadIdx.x, r = blockIdx.y, nwp = b.nwp;
+    const int r = blockIdx.x;
+    const SoBufs v = slab_view(g, b, blockIdx.y, threadIdx.x);
+    const double* __restrict__ factor = v.factor;
+    const double* __restrict__ outgoing = v.outgoing;
     double acc[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) acc[s] = b.first[(size_t(r) * S + s) * nwp + w];
-    const double gf = b.gfactor[size_t(r) * nwp + w];
-    int Lc = -2;
-    double f = 0;
-    for (int e = g.acc.start[r]; e < g.acc.start[r + 1]; ++e) {
-        const int L = g.acc_layer[e];
-        if (L != Lc) { Lc = L; f = L >= 0 ? b.factor[size_t(L) * nwp + w] : gf; }
-        const double fw = f * g.acc.w[e];
-        const double* o = b.outgoing + size_t(g.acc.idx[e]) * S * nwp + w;
+    for (int s = 0; s < S; ++s) acc[s] = __builtin_nontemporal_load(&v.first[(size_t(r) * S + s) * kWave]);
+    // the layer factors are read exactly once per launch (23 GB at the C5 size): streaming loads keep them from evicting the slab of
+    // `outgoing` that every wavefront in flight gathers from (PMC: 2.8 x the algorithmic HBM reads without the hint)
+    const int g0 = g.acc_group_start[r], g1 = g.acc_group_start[r + 1];
+    int gi = g0;
+    for (; gi + 2 <= g1; gi += 2) {   // two groups = 2 factor loads + 12 gathers in flight
+        double f[2], o[2][6][S];
 #pragma unroll
-        for (int s = 0; s < S; ++s) acc[s] += fw * o[size_t(s) * nwp];
+        for (int u = 0; u < 2; ++u) {
+            const AccGroup& G = g.acc_group[gi + u];
+            f[u] = __builtin_nontemporal_load(&factor[size_t(G.slot) * kWave]);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int s = 0; s < S; ++s) o[u][t][s] = outgoing[(size_t(G.col[t]) * S + s) * kWave];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const AccGroup& G = g.acc_group[gi + u];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                double v = 0;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) v += G.w[t] * o[u][t][s];
+                acc[s] += f[u] * v;
+            }
+        }
+    }
+    for (; gi < g1; ++gi) {
+        const AccGroup& G = g.acc_group[gi];
+        const double f = __builtin_nontemporal_load(&factor[size_t(G.slot) * kWave]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            double v = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) v += G.w[t] * outgoing[(size_t(G.col[t]) * S + s) * kWave];
+            acc[s] += f * v;
+        }
     }
 #pragma unroll
-    for (int s = 0; s < S; ++s) b.incoming[(size_t(r) * S + s) * nwp + w] = acc[s];
+    for (int s = 0; s < S; ++s) v.incoming[(size_t(r) * S + s) * kWave] = acc[s];
 }
 
 struct DevMem {
@@ -362,7 +557,7 @@ struct SoDeviceEngine::Impl {
     int num_iterations = 50;
     bool single_scatter = true, multiple_scatter = true;
     int capacity = 0, cap_nleg = 0;
-    size_t n_inc_rays = 0, n_inc_layers = 0, n_acc = 0, n_out = 0, n_table = 0, max_rows = 0;
+    size_t n_inc_rays = 0, n_inc_layers = 0, n_acc = 0, n_out = 0, n_table = 0, max_rows = 0, n_groups = 0;
     size_t scratch_bytes = 0;
     int last_chunk = 0;
     bool profiling = false;
@@ -451,7 +646,80 @@ SoDeviceEngine::SoDeviceEngine(const skso::SoGeometry& sg, int num_iterations) :
         g.table = I.up(sg.table.od);
         g.ntable = sg.table.od.rows();
         g.acc = I.up(sg.accumulation);
-        g.acc_layer = I.tables.upload(sg.accumulation_layer);
+        {
+            std::vector<int> slot(sg.accumulation_layer.size()), layer_ray(sg.incoming.nlayers());
+            const int nl = sg.incoming.nlayers();
+            for (int r = 0; r < sg.incoming.nrays; ++r) {
+                for (int l = sg.incoming.layer_start[r]; l < sg.incoming.layer_start[r + 1]; ++l) layer_ray[l] = r;
+                for (int e = sg.accumulation.start[r]; e < sg.accumulation.start[r + 1]; ++e)
+                    slot[e] = sg.accumulation_layer[e] >= 0 ? sg.accumulation_layer[e] : nl + r;
+            }
+            g.acc_layer = I.tables.upload(slot);
+            g.inc_layer_ray = I.tables.upload(layer_ray);
+            g.n_inc_layers = nl;
+            g.n_out_total = sg.out_start.back();
+            // packed layer records
+            const skso::RaySet& in = sg.incoming;
+            std::vector<LayerRec> rec(nl);
+            for (int r = 0; r < in.nrays; ++r)
+                for (int l = in.layer_start[r]; l < in.layer_start[r + 1]; ++l) {
+                    LayerRec& R = rec[l];
+                    std::memset(&R, 0, sizeof(R));
+                    R.ray = r;
+                    R.tiny = in.tiny[l];
+                    std::vector<double> wod(4, 0.0);
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = in.stencil_idx[4 * l + i];
+                        R.q[i] = std::max(q, 0);
+                        R.went[i] = q < 0 ? 0.0 : in.w_entrance[4 * l + i];
+                        R.wexit[i] = q < 0 ? 0.0 : in.w_exit[4 * l + i];
+                    }
+                    for (int t = in.od.start[l]; t < in.od.start[l + 1]; ++t) {
+                        int slot_i = -1;
+                        for (int i = 0; i < 4; ++i)
+                            if (in.stencil_idx[4 * l + i] == in.od.idx[t]) slot_i = i;
+                        if (slot_i < 0) throw std::runtime_error("sasktran2_amd: optical-depth row outside the layer stencil");
+                        R.wod[slot_i] += in.od.w[t];
+                    }
+                    for (int i = 0; i < 2; ++i) { R.mid[i] = in.mid_idx[2 * l + i]; R.midw[i] = in.mid_w[2 * l + i]; }
+                    R.quad_start = in.quad_start[l];
+                    R.quad_end = in.quad_end[l];
+                    const int e_exit = in.endpoint_start[r] + (l - in.layer_start[r]);
+                    for (int side = 0; side < 2; ++side) {
+                        const int e = e_exit + side, n = in.solar.start[e + 1] - in.solar.start[e];
+                        if (n > 4) throw std::runtime_error("sasktran2_amd: solar-table stencil with more than four points");
+                        for (int i = 0; i < n; ++i) {
+                            (side == 0 ? R.tx : R.te)[i] = in.solar.idx[in.solar.start[e] + i];
+                            (side == 0 ? R.twx : R.twe)[i] = in.solar.w[in.solar.start[e] + i];
+                        }
+                    }
+                }
+            g.inc_rec = I.tables.upload(rec);
+            // accumulation entries in groups of six per factor slot
+            std::vector<AccGroup> groups;
+            std::vector<int> gstart{0};
+            for (int r = 0; r < in.nrays; ++r) {
+                int e = sg.accumulation.start[r];
+                const int e1 = sg.accumulation.start[r + 1];
+                while (e < e1) {
+                    AccGroup G;
+                    std::memset(&G, 0, sizeof(G));
+                    G.slot = slot[e];
+                    int n = 0;
+                    while (e < e1 && n < 6 && slot[e] == G.slot) {
+                        G.col[n] = sg.accumulation.idx[e];
+                        G.w[n] = sg.accumulation.w[e];
+                        ++n;
+                        ++e;
+                    }
+                    groups.push_back(G);
+                }
+                gstart.push_back((int)groups.size());
+            }
+            g.acc_group = I.tables.upload(groups);
+            g.acc_group_start = I.tables.upload(gstart);
+            I.n_groups = groups.size();
+        }
         g.los_source = I.up(sg.los_source);
         g.los_ground = I.up(sg.los_ground);
         g.in_start = I.tables.upload(sg.in_start);
@@ -521,7 +789,7 @@ static size_t so_doubles_per_wavelength(const SoDeviceEngine::Impl& I, int nleg)
     const size_t per = g.S == 3 ? 4 : 1, S = g.S;
     size_t d = size_t(g.ngrid) * (2 + size_t(nleg) * per);
     if (I.multiple_scatter)
-        d += I.n_table + size_t(g.ninterior) * g.num_ms_moments * per + 2 * I.n_inc_rays * S + I.n_out * S + I.n_inc_layers + I.n_inc_rays;
+        d += I.n_table + size_t(g.ninterior) * g.num_ms_moments * per + 2 * I.n_inc_rays * S + I.n_out * S + I.n_inc_layers * (2 + S) + I.n_inc_rays;
     return d;
 }
 size_t SoDeviceEngine::bytes_per_wavelength() const { return so_doubles_per_wavelength(*impl_, std::max(impl_->cap_nleg, impl_->g.num_ss_moments)) * sizeof(double); }
@@ -539,11 +807,11 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = size_t(0.5 * double(free_b + I.scratch_bytes));
     if (const char* e = std::getenv("SASKTRAN2_AMD_HBM_BUDGET_MB")) budget = size_t(std::max(1, atoi(e))) << 20;
-    size_t fit = std::max<size_t>(kWave, budget / per_w / kWave * kWave);
-    if (const char* e = std::getenv("SASKTRAN2_AMD_SO_CHUNK")) fit = std::max<size_t>(kWave, size_t(atoi(e)) / kWave * kWave);
+    size_t fit = std::max<size_t>(kPad, budget / per_w / kPad * kPad);
+    if (const char* e = std::getenv("SASKTRAN2_AMD_SO_CHUNK")) fit = std::max<size_t>(kPad, size_t(atoi(e)) / kPad * kPad);
     const size_t nblocks = (size_t(nwavel) + fit - 1) / fit;
     int chunk = int((size_t(nwavel) + nblocks - 1) / nblocks);
-    chunk = (chunk + kWave - 1) / kWave * kWave;
+    chunk = (chunk + kPad - 1) / kPad * kPad;
     I.last_chunk = chunk;
     if (chunk > I.capacity || nleg > I.cap_nleg) {
         I.scratch.release();
@@ -560,15 +828,16 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             b.first = I.scratch.alloc<double>(I.n_inc_rays * S * W);
             b.incoming = I.scratch.alloc<double>(I.n_inc_rays * S * W);
             b.outgoing = I.scratch.alloc<double>(I.n_out * S * W);
-            b.factor = I.scratch.alloc<double>(I.n_inc_layers * W);
-            b.gfactor = I.scratch.alloc<double>(I.n_inc_rays * W);
+            b.factor = I.scratch.alloc<double>((I.n_inc_layers + I.n_inc_rays) * W);
+            b.lod = I.scratch.alloc<double>(I.n_inc_layers * W);
+            b.lsrc = I.scratch.alloc<double>(I.n_inc_layers * S * W);
         }
         I.scratch_bytes = so_doubles_per_wavelength(I, I.cap_nleg) * sizeof(double) * W;
     }
     for (int w0 = 0; w0 < nwavel; w0 += chunk) {
         SoBufs b = I.b;
         b.nw = std::min(chunk, nwavel - w0);
-        b.nwp = (b.nw + kWave - 1) / kWave * kWave;
+        b.nwp = (b.nw + kPad - 1) / kPad * kPad;
         b.nleg = nleg;
         b.w0 = w0;
         b.nwavel_total = nwavel;
@@ -592,19 +861,27 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
                 hipLaunchKernelGGL(k_so_tables, dim3(wb, unsigned(g.ntable + g.ninterior * g.num_ms_moments * per)), dim3(kWave), 0, st, g, b);
             }
             {
-                SoTimer t(I, st, "so_march_incoming");
-                if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_march<1, false>), dim3(wb, unsigned(g.inc.nrays)), dim3(kWave), 0, st, g, b, 1, 1);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_march<3, false>), dim3(wb, unsigned(g.inc.nrays)), dim3(kWave), 0, st, g, b, 1, 1);
+                SoTimer t(I, st, "so_layers");
+                int lpb = kLayersPerBlock;
+                if (const char* e = std::getenv("SASKTRAN2_AMD_SO_LPB")) lpb = std::max(1, atoi(e));
+                const dim3 grid(unsigned((I.n_inc_layers + lpb - 1) / lpb), wb);
+                if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_layers<1>), grid, dim3(kWave), 0, st, g, b, g.inc_rec, g.inc.d00, g.inc.d02, g.inc.C2, g.inc.S2, b.lod, b.factor, b.lsrc, lpb);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_layers<3>), grid, dim3(kWave), 0, st, g, b, g.inc_rec, g.inc.d00, g.inc.d02, g.inc.C2, g.inc.S2, b.lod, b.factor, b.lsrc, lpb);
+            }
+            {
+                SoTimer t(I, st, "so_scan");
+                if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scan<1>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scan<3>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b);
             }
             for (int it = 0; it < I.num_iterations; ++it) {
                 if (it > 0) {
                     SoTimer t(I, st, "so_accumulate");
-                    if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_accumulate<1>), dim3(wb, unsigned(g.inc.nrays)), dim3(kWave), 0, st, g, b);
-                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_accumulate<3>), dim3(wb, unsigned(g.inc.nrays)), dim3(kWave), 0, st, g, b);
+                    if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_accumulate<1>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b);
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_accumulate<3>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b);
                 }
                 SoTimer t(I, st, "so_scatter");
-                if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<1>), dim3(wb, unsigned(I.max_rows), unsigned(g.npoints)), dim3(kWave), 0, st, g, b);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<3>), dim3(wb, unsigned(I.max_rows), unsigned(g.npoints)), dim3(kWave), 0, st, g, b);
+                if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<1>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.npoints)), dim3(kWave), 0, st, g, b);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<3>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.npoints)), dim3(kWave), 0, st, g, b);
             }
         }
         {

@@ -57,11 +57,11 @@ def test_different_incoming_and_outgoing_spheres_polarised():
 def test_c5_shape_limb_scene_matches_oracle_and_is_block_invariant(monkeypatch):
     """BASELINE configs[4] geometry at a reduced wavelength count: 50 layers, 25 limb rays, 110 / 110 directions, 10 orders, aerosol
     phase functions with all 16 moments; a spectrum that does not fill the last wavefront; blocks of wavelengths give identical bits."""
-    s = sc.limb_c5(num_wavelengths=70)
+    s = sc.limb_c5(num_wavelengths=200)
     ref = run_so_oracle(s, nthreads=8)
     got = run_product_so(s)
     assert_so_parity(got, ref)
-    monkeypatch.setenv("SASKTRAN2_AMD_SO_CHUNK", "64")
+    monkeypatch.setenv("SASKTRAN2_AMD_SO_CHUNK", "128")
     blocks = run_product_so(s)
     assert np.array_equal(blocks["radiance"], got["radiance"])
 
