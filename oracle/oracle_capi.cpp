@@ -210,8 +210,9 @@ int orso_sizes(void* hv, int* out) {
     return 0;
 }
 // radiance[nwavel][nlos][S], los_od[nwavel][nlos]
+// d_k, d_ssa [nwavel][nlos][S][ngrid], d_albedo [nwavel][nlos][S] (or null): native weighting functions of the exact single scatter
 int orso_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg, const double* solar_irradiance,
-             const double* albedo, int nthreads, double* radiance, double* los_od) {
+             const double* albedo, int nthreads, double* radiance, double* los_od, double* d_k, double* d_ssa, double* d_albedo) {
     auto* h = static_cast<SoHandle*>(hv);
     if (!h) return -1;
     const int nlos = h->sg.nlos, S = h->sg.cfg.nstokes;
@@ -225,6 +226,9 @@ int orso_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     atm.leg = leg;
     atm.solar_irradiance = solar_irradiance;
     atm.albedo = albedo;
+    atm.derivatives = d_k != nullptr;
+    if (atm.derivatives && h->sg.cfg.multiple_scatter && h->num_iterations > 0) return -2;   // the diffuse source is not linearised
+    const int ngrid = h->sg.ngrid, nn = 2 * ngrid + 1;
     int status = 0;
 #ifdef _OPENMP
     if (nthreads < 1) nthreads = 1;
@@ -244,6 +248,15 @@ int orso_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                 for (int i = 0; i < nlos * S; ++i) radiance[size_t(w) * nlos * S + i] = res.radiance[i];
                 if (los_od)
                     for (int r = 0; r < nlos; ++r) los_od[size_t(w) * nlos + r] = res.los_od[r];
+                if (atm.derivatives)
+                    for (int i = 0; i < nlos * S; ++i) {
+                        const double* src = res.deriv.data() + size_t(i) * nn;
+                        for (int q = 0; q < ngrid; ++q) {
+                            d_k[(size_t(w) * nlos * S + i) * ngrid + q] = src[q];
+                            d_ssa[(size_t(w) * nlos * S + i) * ngrid + q] = src[ngrid + q];
+                        }
+                        d_albedo[size_t(w) * nlos * S + i] = src[2 * ngrid];
+                    }
             } catch (const std::exception& e) {
                 std::fprintf(stderr, "orso_run (wavelength %d): %s\n", w, e.what());
                 status = -3;

@@ -128,7 +128,7 @@ class SoOracleEngine:
         L.orso_create.argtypes = [ctypes.c_double] * 3 + [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp] + [ctypes.c_int] * 10
         L.orso_destroy.argtypes = [ctypes.c_void_p]
         L.orso_sizes.argtypes = [ctypes.c_void_p, _ip]
-        L.orso_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int, _dp, _dp]
+        L.orso_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp]
         self.alt = np.ascontiguousarray(altitudes, dtype=np.float64)
         self.nlos, self.ngrid, self.nstokes = len(rays), len(self.alt), nstokes
         kinds = np.ascontiguousarray([r[0] for r in rays], dtype=np.int32)
@@ -150,7 +150,9 @@ class SoOracleEngine:
         lib().orso_sizes(self._h, out.ctypes.data_as(_ip))
         return dict(points=int(out[0]), incoming_rays=int(out[1]), outgoing_directions=int(out[2]), accumulation_entries=int(out[3]))
 
-    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, nthreads=1):
+    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, nthreads=1, derivatives=False):
+        """derivatives: native weighting functions of the exact single-scatter source, d_extinction / d_ssa [nwavel, nlos, S, ngrid],
+        d_albedo [nwavel, nlos, S] (only without the diffuse source)."""
         k = np.asfortranarray(extinction, dtype=np.float64)
         w = np.asfortranarray(ssa, dtype=np.float64)
         lg = np.asfortranarray(leg, dtype=np.float64)
@@ -159,7 +161,14 @@ class SoOracleEngine:
         irr = None if solar_irradiance is None else np.ascontiguousarray(solar_irradiance, dtype=np.float64)
         rad = np.zeros((nwavel, self.nlos, S))
         od = np.zeros((nwavel, self.nlos))
-        rc = lib().orso_run(self._h, nwavel, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), _p(irr), _p(alb), nthreads, _p(rad), _p(od))
+        dk = dw = da = None
+        if derivatives:
+            dk, dw, da = np.zeros((nwavel, self.nlos, S, self.ngrid)), np.zeros((nwavel, self.nlos, S, self.ngrid)), np.zeros((nwavel, self.nlos, S))
+        rc = lib().orso_run(self._h, nwavel, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), _p(irr), _p(alb), nthreads, _p(rad), _p(od),
+                            _p(dk), _p(dw), _p(da))
         if rc != 0:
             raise RuntimeError(f"successive-orders oracle run failed with code {rc}")
-        return {"radiance": rad, "los_optical_depth": od}
+        out = {"radiance": rad, "los_optical_depth": od}
+        if derivatives:
+            out.update({"d_extinction": dk, "d_ssa": dw, "d_albedo": da})
+        return out

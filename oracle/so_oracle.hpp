@@ -28,11 +28,13 @@ struct AtmosphereView {
     const double* leg = nullptr;                         // [nleg (x 4), ngrid, nwavel]
     const double* solar_irradiance = nullptr;            // [nwavel] or null (1)
     const double* albedo = nullptr;                      // [nwavel]
+    bool derivatives = false;                            // native weighting functions of the exact single-scatter source (no diffuse source)
 };
 
 struct Result {
     std::vector<double> radiance;   // [nlos][S]
     std::vector<double> los_od;     // [nlos]
+    std::vector<double> deriv;      // [nlos][S][2 ngrid + 1]: d/dk_q, d/d omega_q, d/d albedo (derivatives only)
 };
 
 class Solver {
@@ -89,6 +91,77 @@ class Solver {
         endpoint_source(rs, r, layer, rs.w_exit.data(), T[e0 + j], k, om, p11, p12, en);
         const double sf = (std::abs(od) < 1e-12) ? 1.0 : -std::expm1(-od) / od;
         for (int s = 0; s < S_; ++s) out[s] = sf * (st[s] * rs.quad_start[layer] + en[s] * rs.quad_end[layer]);
+    }
+
+    // Dense forward-mode linearisation of the single-scatter radiance of one line of sight, in the reference's order of operations:
+    // end-of-ray source, then per layer (far end first) dI <- (dI - d(od) I) e^-od + d(source)   (sourceintegrator.cpp:536-579), with the
+    // layer source's derivatives through the source factor, the solar transmission rows and the local extinction / single scatter
+    // albedo (singlescattersource.cpp:988-1030, solartransmission.h:852-901) and the ground term's (singlescattersource.cpp:607-634).
+    void los_derivatives(const AtmosphereView& a, int w, int r, const double* k, const double* om, double F, double albedo,
+                         const double* p11, const double* p12, Result& res) const {
+        const skso::RaySet& lo = g_.los;
+        const int ngrid = a.ngrid, nn = 2 * ngrid + 1, l0 = lo.layer_start[r], n = lo.layer_start[r + 1] - l0, e0 = lo.endpoint_start[r];
+        std::vector<double> I(S_, 0.0), dI(size_t(S_) * nn, 0.0);
+        auto D = [&](int s, int x) -> double& { return dI[size_t(s) * nn + x]; };
+        if (n > 0 && lo.ground_is_hit[r] && lo.ground_mu_in[r] > 0) {
+            const double base = T_los_[e0] * lo.ground_mu_in[r] / skgeo::kPi;
+            I[0] += base * albedo;
+            D(0, 2 * ngrid) += base;
+            for (int t = lo.solar.start[e0]; t < lo.solar.start[e0 + 1]; ++t) D(0, lo.solar.idx[t]) -= lo.solar.w[t] * base * albedo;
+        }
+        for (int j = 0; j < n; ++j) {
+            const int L = l0 + j;
+            const double od = dot(lo.od, L, k), att = std::exp(-od);
+            for (int t = lo.od.start[L]; t < lo.od.start[L + 1]; ++t)
+                for (int s = 0; s < S_; ++s) D(s, lo.od.idx[t]) -= lo.od.w[t] * I[s];
+            for (int s = 0; s < S_; ++s) I[s] *= att;
+            for (double& v : dI) v *= att;
+            if (lo.tiny[L]) continue;
+            const double sf = (std::abs(od) < 1e-12) ? 1.0 : -std::expm1(-od) / od;
+            const double dsf = (std::abs(od) < 1e-12) ? -0.5 : 1 / od - sf * (1 + 1 / od);
+            double quad_sum[3] = {0, 0, 0};
+            for (int side = 0; side < 2; ++side) {   // 0: entrance (start), 1: exit (end)
+                const double* wts = side == 0 ? lo.w_entrance.data() : lo.w_exit.data();
+                const double quad = side == 0 ? lo.quad_start[L] : lo.quad_end[L], T = T_los_[e0 + j + (side == 0 ? 1 : 0)];
+                const int e = e0 + j + (side == 0 ? 1 : 0);
+                double ke = 0, oe = 0, ph[3] = {0, 0, 0};
+                for (int i = 0; i < 4; ++i) {
+                    const int q = lo.stencil_idx[size_t(L) * 4 + i];
+                    const double wt = wts[size_t(L) * 4 + i];
+                    if (q < 0 || wt == 0.0) continue;
+                    ke += k[q] * wt;
+                    oe += om[q] * wt;
+                    ph[0] += p11[q] * wt;
+                    if (S_ == 3) { ph[1] += -lo.C2[r] * p12[q] * wt; ph[2] += -lo.S2[r] * p12[q] * wt; }
+                }
+                const double unscaled = T / (skgeo::kPi * 4);
+                for (int s = 0; s < S_; ++s) {
+                    const double value = ke * oe * unscaled * ph[s];
+                    quad_sum[s] += value * quad;
+                    I[s] += sf * value * quad;
+                    if (!lo.solar_blocked[e])
+                        for (int t = lo.solar.start[e]; t < lo.solar.start[e + 1]; ++t) D(s, lo.solar.idx[t]) -= sf * quad * lo.solar.w[t] * value;
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = lo.stencil_idx[size_t(L) * 4 + i];
+                        const double wt = wts[size_t(L) * 4 + i];
+                        if (q < 0 || wt == 0.0) continue;
+                        D(s, ngrid + q) += sf * quad * wt * ke * unscaled * ph[s];
+                        D(s, q) += sf * quad * wt * oe * unscaled * ph[s];
+                    }
+                }
+            }
+            for (int t = lo.od.start[L]; t < lo.od.start[L + 1]; ++t)
+                for (int s = 0; s < S_; ++s) D(s, lo.od.idx[t]) += lo.od.w[t] * dsf * quad_sum[s];
+        }
+        if (res.deriv.size() != size_t(g_.nlos) * S_ * nn) res.deriv.assign(size_t(g_.nlos) * S_ * nn, 0.0);
+        const double C = (S_ == 3) ? g_.stokes_C[r] : 1.0, Sn = (S_ == 3) ? g_.stokes_S[r] : 0.0;
+        for (int x = 0; x < nn; ++x) {
+            res.deriv[(size_t(r) * S_) * nn + x] = D(0, x);
+            if (S_ == 3) {
+                res.deriv[(size_t(r) * S_ + 1) * nn + x] = C * D(1, x) - Sn * D(2, x);
+                res.deriv[(size_t(r) * S_ + 2) * nn + x] = Sn * D(1, x) + C * D(2, x);
+            }
+        }
     }
 
   public:
@@ -225,6 +298,7 @@ class Solver {
                 }
             }
             res.los_od[r] = total_od;
+            if (a.derivatives) los_derivatives(a, w, r, k, om, F, albedo, p11.data(), p12.data(), res);
             // Stokes basis of the output (OutputC::assign_lane)
             res.radiance[size_t(r) * S_] = rad[0];
             if (S_ == 3) {

@@ -281,15 +281,12 @@ class Engine:
         if getattr(self, "_h", None):
             lib().sk_engine_destroy(self._h)
 
-    def calculate_radiance(self, atmosphere, as_dataset=True, _mapping_hook=None):
-        """`_mapping_hook(L, storage_handle, output_handle, out_dict)` lets a caller register further derivative mappings through
-        the C ABI before the solve (used by the tests for interpolated / log-space mappings).
-
-        Handle flow of the reference (src/sasktran2/atmosphere.py:719-858): ONE storage / surface / atmosphere handle per Atmosphere
+    def _prepare(self, atmosphere, derivs):
+        """Handle flow of the reference (src/sasktran2/atmosphere.py:719-858): ONE storage / surface / atmosphere handle per Atmosphere
         object, and before every calculation set_zero -> refill -> derivative mappings -> apply_delta_m_scaling on that handle."""
         L = lib()
         st = atmosphere.storage
-        nw, ngrid, nlos = atmosphere._nwavel, atmosphere._ngrid, self.nlos
+        nw, ngrid = atmosphere._nwavel, atmosphere._ngrid
         S = int(self._config.num_stokes)
         per = 4 if S == 3 else 1
         H = atmosphere._native_handles(L, S)
@@ -303,38 +300,101 @@ class Engine:
         H["irr"][...] = st.solar_irradiance
         H["alb"][...] = atmosphere.surface.albedo
         H["emis"][...] = atmosphere.surface.emission
-        delta_order = None
-        if self._config.delta_m_scaling and H["leg"].shape[0] // per > self._config.num_streams:
-            delta_order = int(self._config.num_streams)
+        if derivs:
+            # raw-interface mappings, src/sasktran2/atmosphere.py:784-806
+            for name, which in (("wf_extinction", "d_extinction"), ("wf_ssa", "d_ssa")):
+                m = ctypes.c_void_p()
+                L.sk_atmosphere_storage_get_derivative_mapping(H["storage"], name.encode(), ctypes.byref(m))
+                ptr = _dp()
+                getattr(L, f"sk_deriv_mapping_get_{which}")(m, ctypes.byref(ptr))
+                np.ctypeslib.as_array(ptr, shape=(ngrid * nw,))[:] = 1.0
+            m = ctypes.c_void_p()
+            L.sk_surface_get_derivative_mapping(H["surface"], b"wf_albedo", ctypes.byref(m))
+            ptr = _dp()
+            L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
+            np.ctypeslib.as_array(ptr, shape=(nw,))[:] = 1.0
+        return H, (int(self._config.num_streams) if self._config.delta_m_scaling and H["leg"].shape[0] // per > self._config.num_streams else None)
+
+    def _apply_delta_m(self, H, delta_order):
+        if delta_order is not None:
+            rc = lib().sk_atmosphere_apply_delta_m_scaling(H["atmosphere"], delta_order)
+            if rc != 0:
+                raise RuntimeError(f"sk_atmosphere_apply_delta_m_scaling returned {rc}")
+
+    def calculate_jvp(self, atmosphere, tangents, surface_tangents=None):
+        """Jacobian-vector product (src/sasktran2/engine.py:170-312, `sk_engine_calculate_jvp`): `tangents` maps a derivative-mapping
+        name ("wf_extinction", "wf_ssa") to a vector over its outputs, `surface_tangents` ("wf_albedo") to one value per wavelength.
+        Returns (radiance, jvp), both [wavelength, los, stokes]."""
+        L = lib()
+        H, delta_order = self._prepare(atmosphere, True)
+        self._apply_delta_m(H, delta_order)
+        nw, S = atmosphere._nwavel, int(self._config.num_stokes)
+        rad, jvp = np.zeros((nw, self.nlos, S)), np.zeros((nw, self.nlos, S))
+        h = L.sk_output_jvp_create(_p(rad), _p(jvp), nw * self.nlos, S)
+        keep = []
+        try:
+            for name, t in tangents.items():
+                t = np.ascontiguousarray(t, dtype=float)
+                keep.append(t)
+                L.sk_output_jvp_assign_derivative_tangent(h, name.encode(), _p(t), t.size)
+            for name, t in (surface_tangents or {}).items():
+                t = np.ascontiguousarray(t, dtype=float)
+                keep.append(t)
+                L.sk_output_jvp_assign_surface_tangent(h, name.encode(), _p(t), t.size)
+            rc = L.sk_engine_calculate_jvp(self._h, H["atmosphere"], h)
+            if rc != 0:
+                raise RuntimeError(f"sk_engine_calculate_jvp returned {rc}: {last_error()}")
+        finally:
+            L.sk_output_jvp_destroy(h)
+        return rad, jvp
+
+    def calculate_vjp(self, atmosphere, cotangent, names=("wf_extinction", "wf_ssa"), surface_names=("wf_albedo",)):
+        """Vector-Jacobian product (`sk_engine_calculate_vjp`): cotangent [wavelength, los, stokes] -> (radiance, {name: gradient})."""
+        L = lib()
+        H, delta_order = self._prepare(atmosphere, True)
+        self._apply_delta_m(H, delta_order)
+        nw, S, ngrid = atmosphere._nwavel, int(self._config.num_stokes), atmosphere._ngrid
+        rad = np.zeros((nw, self.nlos, S))
+        cot = np.ascontiguousarray(cotangent, dtype=float).reshape(nw, self.nlos, S)
+        h = L.sk_output_vjp_create(_p(rad), _p(cot), nw * self.nlos, S)
+        grads = {}
+        try:
+            for name in names:
+                grads[name] = np.zeros(ngrid)
+                L.sk_output_vjp_assign_derivative_gradient(h, name.encode(), _p(grads[name]), ngrid)
+            for name in surface_names:
+                grads[name] = np.zeros(nw)
+                L.sk_output_vjp_assign_surface_gradient(h, name.encode(), _p(grads[name]), nw)
+            rc = L.sk_engine_calculate_vjp(self._h, H["atmosphere"], h)
+            if rc != 0:
+                raise RuntimeError(f"sk_engine_calculate_vjp returned {rc}: {last_error()}")
+            L.sk_output_vjp_finalize(h)
+        finally:
+            L.sk_output_vjp_destroy(h)
+        return rad, grads
+
+    def calculate_radiance(self, atmosphere, as_dataset=True, _mapping_hook=None):
+        """`_mapping_hook(L, storage_handle, output_handle, out_dict)` lets a caller register further derivative mappings through
+        the C ABI before the solve (used by the tests for interpolated / log-space mappings)."""
+        L = lib()
+        nw, ngrid, nlos = atmosphere._nwavel, atmosphere._ngrid, self.nlos
+        S = int(self._config.num_stokes)
         derivs = atmosphere.calculate_derivatives
+        H, delta_order = self._prepare(atmosphere, derivs)
         h_st, h_su, h_atm = H["storage"], H["surface"], H["atmosphere"]
         rad = np.zeros((nw, nlos, S))
         h_out = L.sk_output_create(_p(rad), nw * nlos, S, None, 0)
         out = {"radiance": rad}
         try:
             if derivs:
-                # raw-interface mappings, src/sasktran2/atmosphere.py:784-806
-                for name, which in (("wf_extinction", "d_extinction"), ("wf_ssa", "d_ssa")):
-                    m = ctypes.c_void_p()
-                    L.sk_atmosphere_storage_get_derivative_mapping(h_st, name.encode(), ctypes.byref(m))
-                    ptr = _dp()
-                    getattr(L, f"sk_deriv_mapping_get_{which}")(m, ctypes.byref(ptr))
-                    np.ctypeslib.as_array(ptr, shape=(ngrid * nw,))[:] = 1.0
+                for name in ("wf_extinction", "wf_ssa"):
                     out[name] = np.zeros((ngrid, nw, nlos, S))
                     L.sk_output_assign_derivative_memory(h_out, name.encode(), _p(out[name]), nw * nlos, S, ngrid)
-                m = ctypes.c_void_p()
-                L.sk_surface_get_derivative_mapping(h_su, b"wf_albedo", ctypes.byref(m))
-                ptr = _dp()
-                L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
-                np.ctypeslib.as_array(ptr, shape=(nw,))[:] = 1.0
                 out["wf_albedo"] = np.zeros((nw, nlos, S))
                 L.sk_output_assign_surface_derivative_memory(h_out, b"wf_albedo", _p(out["wf_albedo"]), nw * nlos, S)
             if _mapping_hook is not None:
                 _mapping_hook(L, h_st, h_out, out)
-            if delta_order is not None:
-                rc = L.sk_atmosphere_apply_delta_m_scaling(h_atm, delta_order)
-                if rc != 0:
-                    raise RuntimeError(f"sk_atmosphere_apply_delta_m_scaling returned {rc}")
+            self._apply_delta_m(H, delta_order)
             rc = L.sk_engine_calculate_radiance(self._h, h_atm, h_out, 0)
             if rc != 0:
                 raise RuntimeError(f"sk_engine_calculate_radiance returned {rc}: {last_error()}")

@@ -57,6 +57,12 @@ SIGNATURES = [
     ("sk_output_assign_derivative_memory", _I, [_vp, _S, _dp, _I, _I, _I]),
     ("sk_output_assign_surface_derivative_memory", _I, [_vp, _S, _dp, _I, _I]),
     ("sk_output_get_los_optical_depth", _I, [_vp, ctypes.POINTER(_dp)]),
+    ("sk_output_jvp_create", _vp, [_dp, _dp, _I, _I]), ("sk_output_jvp_destroy", None, [_vp]),
+    ("sk_output_jvp_assign_derivative_tangent", _I, [_vp, _S, _dp, _I]), ("sk_output_jvp_assign_surface_tangent", _I, [_vp, _S, _dp, _I]),
+    ("sk_output_vjp_create", _vp, [_dp, _dp, _I, _I]), ("sk_output_vjp_destroy", None, [_vp]),
+    ("sk_output_vjp_assign_derivative_gradient", _I, [_vp, _S, _dp, _I]), ("sk_output_vjp_assign_surface_gradient", _I, [_vp, _S, _dp, _I]),
+    ("sk_output_vjp_finalize", _I, [_vp]),
+    ("sk_engine_calculate_jvp", _I, [_vp, _vp, _vp]), ("sk_engine_calculate_vjp", _I, [_vp, _vp, _vp]),
     ("sk_engine_create", _vp, [_vp, _vp, _vp]),
     ("sk_engine_calculate_radiance", _I, [_vp, _vp, _vp, _I]),
     ("sk_engine_effective_wavelength_batch_size", _I, [_vp, _I]),

@@ -552,6 +552,7 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     e->dev->solve_device_vector(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status, nullptr,
                                 (int)group_of.size(), d_dleg, d_wg, d_dfg);
     e->dev->set_delta_m_fraction(nullptr);
+    if (e->so) e->so->solve_device(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa);
     hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
     HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
@@ -566,14 +567,14 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     return 0;
 }
 
-// exact single scatter and / or legacy successive orders (e->so): radiances [wavel][los][stokes] and LOS optical depths.  With
-// `add` the radiance is added to what the discrete-ordinates source already wrote (multiple_scatter_source = discrete_ordinates with
-// single_scatter_source = exact: in spherical geometry the DO source delivers the multiple-scatter term only).
-static int calculate_radiance_so(Engine* e, Atmosphere* atm, OutputC* out, bool add) {
+// exact single scatter and / or legacy successive orders alone (no discrete-ordinates source): radiances [wavel][los][stokes], LOS optical
+// depths and -- exact single scatter without the diffuse source only -- weighting functions through the caller's derivative mappings.
+static int calculate_radiance_so(Engine* e, Atmosphere* atm, OutputC* out) {
     const AtmosphereStorage& st = *atm->storage;
     const Surface& su = *atm->surface;
     const int S = e->config.num_stokes, per = (S == 3) ? 4 : 1;
     const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
+    const int derivs = atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty());
     if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");
     if (st.nleg % per != 0) throw std::runtime_error("leg_coeff must hold four coefficients per Legendre order for NSTOKES = 3");
     const size_t nloc_w = size_t(ngrid) * nw, nt = size_t(nw) * nlos;
@@ -584,7 +585,7 @@ static int calculate_radiance_so(Engine* e, Atmosphere* atm, OutputC* out, bool 
     double* d_alb = (double*)C.get("so_albedo", size_t(nw) * 8);
     double* d_rad = (double*)C.get("so_radiance", nt * S * 8);
     double* d_od = (double*)C.get("so_los_od", nt * 8);
-    double* d_irr = nullptr;
+    double *d_irr = nullptr, *d_we = nullptr, *d_ws = nullptr, *d_wa = nullptr;
     HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyHostToDevice));
@@ -593,18 +594,22 @@ static int calculate_radiance_so(Engine* e, Atmosphere* atm, OutputC* out, bool 
         d_irr = (double*)C.get("so_irradiance", size_t(nw) * 8);
         HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyHostToDevice));
     }
-    e->so->solve_device(nw, st.nleg / per, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, d_od, nullptr, 0);
-    HIPC(hipDeviceSynchronize());
-    std::vector<double> rad(nt * S), od(nt);
-    HIPC(hipMemcpy(rad.data(), d_rad, nt * S * 8, hipMemcpyDeviceToHost));
-    HIPC(hipMemcpy(od.data(), d_od, nt * 8, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < nt * S; ++i) {
-        if (!std::isfinite(rad[i])) throw std::runtime_error("solver failure (non-finite radiance) at wavelength " + std::to_string(i / (size_t(nlos) * S)));
-        out->radiance[i] = add ? out->radiance[i] + rad[i] : rad[i];
+    if (derivs) {
+        d_we = (double*)C.get("wf_ext", size_t(ngrid) * nt * S * 8);
+        d_ws = (double*)C.get("wf_ssa", size_t(ngrid) * nt * S * 8);
+        d_wa = (double*)C.get("wf_alb", nt * S * 8);
     }
+    e->so->solve_device(nw, st.nleg / per, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, d_od, nullptr, 0, d_we, d_ws, d_wa);
+    HIPC(hipDeviceSynchronize());
+    std::vector<double> od(nt);
+    HIPC(hipMemcpy(out->radiance, d_rad, nt * S * 8, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(od.data(), d_od, nt * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nt * S; ++i)
+        if (!std::isfinite(out->radiance[i])) throw std::runtime_error("solver failure (non-finite radiance) at wavelength " + std::to_string(i / (size_t(nlos) * S)));
     out->los_od.resize(nt);
     for (int w = 0; w < nw; ++w)
         for (int r = 0; r < nlos; ++r) out->los_od[size_t(r) * nw + w] = od[size_t(w) * nlos + r];
+    if (derivs) map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, S);
     return 0;
 }
 
@@ -640,16 +645,24 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (!su.brdf_args) throw std::runtime_error("surface has no BRDF set");
         if (su.brdf && su.brdf->kind != 0) return -2;  // only the Lambertian surface is part of this path
         validate_input_atmosphere(e, st);
-        if (e->so) {
-            // weighting functions of the exact single-scatter / successive-orders sources are not part of this build: asking for them is an
-            // error rather than a silently incomplete Jacobian
-            if (atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty())) {
-                set_error("sk_engine_calculate_radiance: weighting functions are not available with single_scatter_source = exact or "
-                          "multiple_scatter_source = successive_orders_legacy in this build (create the atmosphere with calculate_derivatives = 0)");
+        const bool wants_derivs = atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty());
+        if (e->so && wants_derivs) {
+            // the successive-orders source is not linearised here (the reference's own linearisation of it is approximate); scattering-group
+            // derivatives of the exact single scatter (d_legendre) are not built either: an error rather than a silently incomplete Jacobian
+            if (e->so->has_successive_orders()) {
+                set_error("sk_engine_calculate_radiance: weighting functions are not available with multiple_scatter_source = "
+                          "successive_orders_legacy in this build (create the atmosphere with calculate_derivatives = 0)");
                 return -2;
             }
-            if (!e->dev) return calculate_radiance_so(e, atm, out, false);
+            for (auto& kv : out->derivs) {
+                auto it = st.maps.find(kv.first);
+                if (it != st.maps.end() && is_scattering_mapping(*it->second)) {
+                    set_error("sk_engine_calculate_radiance: scattering-group weighting functions are not available with single_scatter_source = exact in this build");
+                    return -2;
+                }
+            }
         }
+        if (e->so && !e->dev) return calculate_radiance_so(e, atm, out);
         bool scattering_groups = false;
         for (auto& kv : out->derivs) {
             auto it = st.maps.find(kv.first);
@@ -663,8 +676,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         const char* force_env = std::getenv("SASKTRAN2_AMD_RUNTIME_N");
         const bool force = force_env && atoi(force_env) != 0;
         if (force || e->dev->vector_mode() || (scattering_groups && atm->derivs && e->config.wf_enabled)) {
-            const int rc = calculate_radiance_vector(e, atm, out);
-            return (rc == 0 && e->so) ? calculate_radiance_so(e, atm, out, true) : rc;
+            return calculate_radiance_vector(e, atm, out);
         }
         if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
         const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
@@ -703,6 +715,9 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         e->dev->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status,
                              nullptr, 0);
         e->dev->set_delta_m_fraction(nullptr);
+        // single_scatter_source = exact on top of the discrete-ordinates multiple scatter: radiance and native weighting functions are
+        // accumulated on the device before the user mappings are applied
+        if (e->so) e->so->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa);
         hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
         HIPC(hipGetLastError());
         HIPC(hipDeviceSynchronize());
@@ -716,7 +731,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (derivs) {
             map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, 1);
         }
-        return e->so ? calculate_radiance_so(e, atm, out, true) : 0;
+        return 0;
     } catch (const std::exception& ex) {
         set_error(std::string("sk_engine_calculate_radiance: ") + ex.what());
         return -3;

@@ -102,6 +102,7 @@ struct SoGeo {
     const int *in_start, *out_start, *point_leg_idx;
     const double* point_leg_w;
     const double* scat_basis;               // [row][col][num_ms_moments * per]
+    const double *stokes_C, *stokes_S;      // [nlos] rotation of (Q, U) to the configured Stokes basis
     const double* ground_factor;            // concatenated per ground point
     const int* ground_factor_start;         // [nground + 1]
 };
@@ -115,6 +116,9 @@ struct SoBufs {
     double *kT, *omT, *legT, *tab, *cl, *first, *incoming, *outgoing, *factor, *lod, *lsrc;   // factor: [layers + rays] (ground slots last)
     double *radiance, *los_od;                               // caller's outputs (whole spectrum)
     int accumulate;
+    // native weighting functions of the exact single scatter: per-thread accumulators [slab][ray][S][2 ngrid + 1][64] and the caller's
+    // outputs wf_ext / wf_ssa [ngrid][nwavel][nlos][S], wf_alb [nwavel][nlos][S]
+    double *dacc, *wf_ext, *wf_ssa, *wf_alb;
 };
 
 // pointers of one slab, advanced to this lane: element `item` of array X is X[item * kWave]
@@ -132,6 +136,7 @@ __device__ inline SoBufs slab_view(const SoGeo& g, const SoBufs& b, int slab, in
     v.factor += o * (g.n_inc_layers + g.inc.nrays) + lane;
     v.lod += o * g.n_inc_layers + lane;
     v.lsrc += o * g.n_inc_layers * S + lane;
+    if (v.dacc) v.dacc += o * g.nlos * S * (2 * g.ngrid + 1) + lane;
     return v;
 }
 
@@ -287,9 +292,142 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
     if (LOS) {
         if (w >= b.nw) return;
         double* out = b.radiance + (size_t(b.w0 + w) * g.nlos + r) * S;
+        if (S == 3) {   // configured Stokes basis (OutputC::assign_lane)
+            const double C = g.stokes_C[r], Sn = g.stokes_S[r], q = val[1], u = val[S - 1];
+            val[1] = C * q - Sn * u;
+            val[S - 1] = Sn * q + C * u;
+        }
 #pragma unroll
         for (int s = 0; s < S; ++s) out[s] = b.accumulate ? out[s] + val[s] : val[s];
         if (b.los_od) b.los_od[size_t(b.w0 + w) * g.nlos + r] = total_od;
+    }
+}
+
+// Native weighting functions of the exact single-scatter radiance of a line of sight (d/dk_q, d/d omega_q, d/d albedo), reverse mode:
+// with B_j the transmission from layer j to the observer, dI = sum_j B_j (dS_j - I_{j-1} e^{-od_j} d od_j) + ground, where dS_j runs through
+// the source factor (od row), the solar transmission rows of both boundaries and the local extinction / single scatter albedo
+// (singlescattersource.cpp:988-1030, solartransmission.h:852-901, sourceintegrator.cpp:536-579).  One line of sight x 64 wavelengths per
+// wavefront; every lane accumulates into its own column of `dacc` (coalesced read-modify-writes, L1 / L2 resident).
+template <int S>
+__global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b) {
+    const DevRays& rs = g.los;
+    const int w = blockIdx.x * kWave + threadIdx.x, r = blockIdx.y;
+    const SoBufs v = slab_view(g, b, blockIdx.x, threadIdx.x);
+    const int l0 = rs.layer_start[r], n = rs.layer_start[r + 1] - l0, e0 = rs.endpoint_start[r];
+    const int per = S == 3 ? 4 : 1, nlg_in = b.nleg * per, nm = min(g.num_ss_moments, b.nleg), ngrid = g.ngrid, nn = 2 * ngrid + 1;
+    const int ws = w < b.nw ? w : b.nw - 1;
+    const double F = b.irradiance ? b.irradiance[ws] : 1.0, albedo = b.albedo[ws];
+    double* acc = v.dacc + size_t(r) * S * nn * kWave;
+    for (int x = 0; x < S * nn; ++x) acc[size_t(x) * kWave] = 0.0;
+    if (n == 0) return;
+    auto add = [&](int s, int x, double val) { acc[(size_t(s) * nn + x) * kWave] += val; };
+    auto layer_od = [&](int L) {
+        double od = 0;
+        for (int t = rs.od.start[L]; t < rs.od.start[L + 1]; ++t) od += rs.od.w[t] * v.kT[size_t(rs.od.idx[t]) * kWave];
+        return od;
+    };
+    auto transmission = [&](int e) -> double {
+        if (rs.solar_blocked[e]) return 0.0;
+        double od = 0;
+        for (int t = rs.solar.start[e]; t < rs.solar.start[e + 1]; ++t) od += rs.solar.w[t] * v.kT[size_t(rs.solar.idx[t]) * kWave];
+        return exp(-od) * F;
+    };
+    double total = 0;
+    for (int j = 0; j < n; ++j) total += layer_od(l0 + j);
+    double I[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) I[s] = 0;
+    double prefix = 0;                       // optical depth of the layers behind the one in hand
+    double T_exit = transmission(e0);        // far end of the ray
+    if (rs.ground_is_hit[r] && rs.ground_mu_in[r] > 0) {
+        const double Bg = exp(-total), base = T_exit * rs.ground_mu_in[r] / kPi;
+        I[0] = base * albedo;
+        add(0, 2 * ngrid, base * Bg);
+        for (int t = rs.solar.start[e0]; t < rs.solar.start[e0 + 1]; ++t) add(0, rs.solar.idx[t], -rs.solar.w[t] * base * albedo * Bg);
+    }
+    for (int j = 0; j < n; ++j) {
+        const int L = l0 + j;
+        const double od = layer_od(L), att = exp(-od);
+        const double B_in = exp(-(total - prefix));   // transmission of what enters this layer from behind, through it, to the observer
+        prefix += od;
+        const double Bj = exp(-(total - prefix));
+        for (int t = rs.od.start[L]; t < rs.od.start[L + 1]; ++t)
+#pragma unroll
+            for (int s = 0; s < S; ++s) add(s, rs.od.idx[t], -rs.od.w[t] * I[s] * B_in);
+#pragma unroll
+        for (int s = 0; s < S; ++s) I[s] *= att;
+        const double T_ent = transmission(e0 + j + 1);
+        if (!rs.tiny[L]) {
+            const double sf = (fabs(od) < 1e-12) ? 1.0 : -expm1(-od) / od;
+            const double dsf = (fabs(od) < 1e-12) ? -0.5 : 1 / od - sf * (1 + 1 / od);
+            double quad_sum[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) quad_sum[s] = 0;
+            for (int side = 0; side < 2; ++side) {   // 0: entrance, 1: exit
+                const double* wts = side == 0 ? rs.w_entrance : rs.w_exit;
+                const double quad = side == 0 ? rs.quad_start[L] : rs.quad_end[L], T = side == 0 ? T_ent : T_exit;
+                const int e = e0 + j + (side == 0 ? 1 : 0);
+                double ke = 0, oe = 0, ph[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) ph[s] = 0;
+                for (int i = 0; i < 4; ++i) {
+                    const int q = rs.stencil_idx[4 * L + i];
+                    const double wt = wts[4 * L + i];
+                    if (q < 0 || wt == 0.0) continue;
+                    double p11 = 0, p12 = 0;
+                    const double* lq = v.legT + size_t(q) * nlg_in * kWave;
+                    for (int l = 0; l < nm; ++l) {
+                        p11 += lq[size_t(l) * per * kWave] * rs.d00[size_t(r) * g.num_ss_moments + l];
+                        if (S == 3) p12 += lq[size_t(l * per + 3) * kWave] * rs.d02[size_t(r) * g.num_ss_moments + l];
+                    }
+                    ke += v.kT[size_t(q) * kWave] * wt;
+                    oe += v.omT[size_t(q) * kWave] * wt;
+                    ph[0] += p11 * wt;
+                    if (S == 3) { ph[1] += -rs.C2[r] * p12 * wt; ph[2] += -rs.S2[r] * p12 * wt; }
+                }
+                const double unscaled = T / (kPi * 4), c = sf * quad * Bj;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const double value = ke * oe * unscaled * ph[s];
+                    quad_sum[s] += value * quad;
+                    I[s] += sf * value * quad;
+                    if (!rs.solar_blocked[e])
+                        for (int t = rs.solar.start[e]; t < rs.solar.start[e + 1]; ++t) add(s, rs.solar.idx[t], -c * rs.solar.w[t] * value);
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = rs.stencil_idx[4 * L + i];
+                        const double wt = wts[4 * L + i];
+                        if (q < 0 || wt == 0.0) continue;
+                        add(s, ngrid + q, c * wt * ke * unscaled * ph[s]);
+                        add(s, q, c * wt * oe * unscaled * ph[s]);
+                    }
+                }
+            }
+            for (int t = rs.od.start[L]; t < rs.od.start[L + 1]; ++t)
+#pragma unroll
+                for (int s = 0; s < S; ++s) add(s, rs.od.idx[t], rs.od.w[t] * dsf * quad_sum[s] * Bj);
+        }
+        T_exit = T_ent;
+    }
+}
+
+// accumulators -> the caller's layout (wf_ext / wf_ssa [ngrid][nwavel][nlos][S], wf_alb [nwavel][nlos][S]) in the configured Stokes basis
+__global__ void __launch_bounds__(256) k_so_deriv_out(SoGeo g, SoBufs b) {
+    const int S = g.S, nn = 2 * g.ngrid + 1, nlos = g.nlos;
+    const size_t n = size_t(nn) * b.nw * nlos * S;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const int s = int(i % S), r = int((i / S) % nlos), w = int((i / S / nlos) % b.nw), x = int(i / S / nlos / b.nw);
+        const double* a = b.dacc + (size_t(w / kWave) * nlos * S * nn) * kWave + (w % kWave);
+        auto at = [&](int sc) { return a[((size_t(r) * S + sc) * nn + x) * kWave]; };
+        double val = at(s);
+        if (S == 3 && s > 0) {
+            const double C = g.stokes_C[r], Sn = g.stokes_S[r], q = at(1), u = at(2);
+            val = (s == 1) ? C * q - Sn * u : Sn * q + C * u;
+        }
+        double* dst;
+        if (x < g.ngrid) dst = b.wf_ext + ((size_t(x) * b.nwavel_total + b.w0 + w) * nlos + r) * S + s;
+        else if (x < 2 * g.ngrid) dst = b.wf_ssa + ((size_t(x - g.ngrid) * b.nwavel_total + b.w0 + w) * nlos + r) * S + s;
+        else dst = b.wf_alb + (size_t(b.w0 + w) * nlos + r) * S + s;
+        *dst = b.accumulate ? *dst + val : val;
     }
 }
 
@@ -557,6 +695,7 @@ struct SoDeviceEngine::Impl {
     int num_iterations = 50;
     bool single_scatter = true, multiple_scatter = true;
     int capacity = 0, cap_nleg = 0;
+    bool cap_derivs = false;
     size_t n_inc_rays = 0, n_inc_layers = 0, n_acc = 0, n_out = 0, n_table = 0, max_rows = 0, n_groups = 0;
     size_t scratch_bytes = 0;
     int last_chunk = 0;
@@ -636,6 +775,8 @@ SoDeviceEngine::SoDeviceEngine(const skso::SoGeometry& sg, int num_iterations) :
     g.num_ss_moments = sg.cfg.num_ss_moments;
     g.num_ms_moments = sg.cfg.num_ms_moments;
     g.los = I.up(sg.los);
+    g.stokes_C = I.tables.upload(sg.stokes_C);
+    g.stokes_S = I.tables.upload(sg.stokes_S);
     g.npoints = g.ninterior = 0;
     if (I.multiple_scatter) {
         g.npoints = sg.npoints;
@@ -763,6 +904,7 @@ SoDeviceEngine::~SoDeviceEngine() {
 int SoDeviceEngine::nlos() const { return impl_->g.nlos; }
 int SoDeviceEngine::ngrid() const { return impl_->g.ngrid; }
 int SoDeviceEngine::nstokes() const { return impl_->g.S; }
+bool SoDeviceEngine::has_successive_orders() const { return impl_->multiple_scatter; }
 size_t SoDeviceEngine::scratch_bytes() const { return impl_->scratch_bytes; }
 int SoDeviceEngine::last_chunk() const { return impl_->last_chunk; }
 void SoDeviceEngine::set_profiling(bool on) { impl_->profiling = on; }
@@ -795,14 +937,20 @@ static size_t so_doubles_per_wavelength(const SoDeviceEngine::Impl& I, int nleg)
 size_t SoDeviceEngine::bytes_per_wavelength() const { return so_doubles_per_wavelength(*impl_, std::max(impl_->cap_nleg, impl_->g.num_ss_moments)) * sizeof(double); }
 
 void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg, const double* d_albedo,
-                                  const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream, int accumulate) {
+                                  const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream, int accumulate,
+                                  double* d_wf_ext, double* d_wf_ssa, double* d_wf_alb) {
     Impl& I = *impl_;
     SoGeo& g = I.g;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (nwavel <= 0 || nleg <= 0) throw std::runtime_error("sasktran2_amd: nwavel and nleg must be positive");
     const int S = g.S, per = S == 3 ? 4 : 1;
+    const bool derivs = d_wf_ext != nullptr;
+    if (derivs && (!d_wf_ssa || !d_wf_alb)) throw std::runtime_error("sasktran2_amd: weighting functions need all three output buffers");
+    if (derivs && !I.single_scatter) throw std::runtime_error("sasktran2_amd: weighting functions requested from an engine without the exact single-scatter source");
+    if (derivs && I.multiple_scatter) throw std::runtime_error("sasktran2_amd: the successive-orders source is not linearised");
     // block of wavelengths in flight: half of the free HBM (plus what this engine already holds), balanced blocks, multiple of the wavefront
-    const size_t per_w = so_doubles_per_wavelength(I, nleg) * sizeof(double);
+    const size_t deriv_doubles = derivs ? size_t(g.nlos) * S * (2 * g.ngrid + 1) : 0;
+    const size_t per_w = (so_doubles_per_wavelength(I, nleg) + deriv_doubles) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = size_t(0.5 * double(free_b + I.scratch_bytes));
@@ -813,8 +961,9 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     int chunk = int((size_t(nwavel) + nblocks - 1) / nblocks);
     chunk = (chunk + kPad - 1) / kPad * kPad;
     I.last_chunk = chunk;
-    if (chunk > I.capacity || nleg > I.cap_nleg) {
+    if (chunk > I.capacity || nleg > I.cap_nleg || (derivs && !I.cap_derivs)) {
         I.scratch.release();
+        I.cap_derivs = I.cap_derivs || derivs;
         I.capacity = std::max(chunk, I.capacity);
         I.cap_nleg = std::max(nleg, I.cap_nleg);
         const size_t W = I.capacity, nlg = size_t(I.cap_nleg) * per;
@@ -832,7 +981,8 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             b.lod = I.scratch.alloc<double>(I.n_inc_layers * W);
             b.lsrc = I.scratch.alloc<double>(I.n_inc_layers * S * W);
         }
-        I.scratch_bytes = so_doubles_per_wavelength(I, I.cap_nleg) * sizeof(double) * W;
+        b.dacc = I.cap_derivs ? I.scratch.alloc<double>(size_t(g.nlos) * S * (2 * g.ngrid + 1) * W) : nullptr;
+        I.scratch_bytes = (so_doubles_per_wavelength(I, I.cap_nleg) + (I.cap_derivs ? size_t(g.nlos) * S * (2 * g.ngrid + 1) : 0)) * sizeof(double) * W;
     }
     for (int w0 = 0; w0 < nwavel; w0 += chunk) {
         SoBufs b = I.b;
@@ -849,6 +999,10 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
         b.radiance = d_radiance;
         b.los_od = d_los_od;
         b.accumulate = accumulate;
+        b.wf_ext = d_wf_ext;
+        b.wf_ssa = d_wf_ssa;
+        b.wf_alb = d_wf_alb;
+        if (!derivs) b.dacc = nullptr;
         const unsigned wb = unsigned(b.nwp / kWave);
         {
             SoTimer t(I, st, "so_transpose");
@@ -888,6 +1042,12 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             SoTimer t(I, st, "so_march_los");
             if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_march<1, true>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b, ss, ms);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_march<3, true>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b, ss, ms);
+        }
+        if (derivs) {
+            SoTimer t(I, st, "so_los_derivatives");
+            if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_los_deriv<1>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_los_deriv<3>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b);
+            hipLaunchKernelGGL(k_so_deriv_out, dim3(2048), dim3(256), 0, st, g, b);
         }
         SO_HIP_CHECK(hipGetLastError());
     }

@@ -96,11 +96,12 @@ def build_so_engine(s, **override):
     return sk.Engine(config, geometry, viewing), config, geometry
 
 
-def run_product_so(s, engine=None, solar_irradiance=None, **override):
-    """Radiances [wavelength, los, stokes] and LOS optical depths of the exact single-scatter / successive-orders path."""
+def run_product_so(s, engine=None, solar_irradiance=None, derivatives=False, **override):
+    """Radiances [wavelength, los, stokes] and LOS optical depths of the exact single-scatter / successive-orders path; with
+    `derivatives` the weighting functions in the oracle's convention ([wavelength, los, stokes, altitude])."""
     engine, config, geometry = engine if engine is not None else build_so_engine(s, **override)
     nw = s["extinction"].shape[1]
-    atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=False)
+    atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=derivatives)
     atmosphere.storage.total_extinction[:] = s["extinction"]
     atmosphere.storage.ssa[:] = s["ssa"]
     atmosphere.storage.leg_coeff[:] = s["leg"]
@@ -108,4 +109,9 @@ def run_product_so(s, engine=None, solar_irradiance=None, **override):
         atmosphere.storage.solar_irradiance[:] = solar_irradiance
     atmosphere.surface.albedo[:] = s["albedo"]
     res = engine.calculate_radiance(atmosphere, as_dataset=False)
-    return {"radiance": res["radiance"], "los_optical_depth": res["los_optical_depth"]}
+    out = {"radiance": res["radiance"], "los_optical_depth": res["los_optical_depth"]}
+    if derivatives:
+        out["d_extinction"] = np.transpose(res["wf_extinction"], (1, 2, 3, 0))
+        out["d_ssa"] = np.transpose(res["wf_ssa"], (1, 2, 3, 0))
+        out["d_albedo"] = res["wf_albedo"]
+    return out

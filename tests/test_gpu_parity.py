@@ -759,3 +759,50 @@ def test_random_polarised_atmospheres_match_oracle(seed):
     np.testing.assert_allclose(got["radiance"][..., 0], ref["radiance"][..., 0], rtol=RTOL_I)
     assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-8 * np.abs(ref["radiance"]).max()
     _assert_vector_wf_parity(got, ref)
+
+
+# ---- JVP / VJP entry points (sk_engine_calculate_jvp / _vjp: contractions of the native Jacobian, the reference's StreamingJacobian backend)
+@pytest.mark.parametrize("nstokes", [1, 3])
+def test_jvp_and_vjp_are_contractions_of_the_jacobian(nstokes):
+    import sasktran2_amd as sk
+    from tests.gpu_harness import build_engine
+    s = sc.regression_1d(2)
+    if nstokes == 3:
+        s = sc.to_vector(s, rayleigh_fraction=0.9)
+    engine, config, geometry = build_engine(s)
+    atmosphere = sk.Atmosphere(geometry, config, numwavel=2, calculate_derivatives=True)
+    atmosphere.storage.total_extinction[:] = s["extinction"]
+    atmosphere.storage.ssa[:] = s["ssa"]
+    if nstokes == 3:
+        atmosphere.storage.leg_coeff[:] = s["leg"]
+    else:
+        atmosphere.leg_coeff.a1[:] = s["leg"]
+    atmosphere.surface.albedo[:] = s["albedo"]
+    full = engine.calculate_radiance(atmosphere, as_dataset=False)
+    rng = np.random.default_rng(5)
+    ngrid = s["extinction"].shape[0]
+    t_k, t_w, t_a = rng.standard_normal(ngrid) * 1e-6, rng.standard_normal(ngrid) * 1e-2, rng.standard_normal(2) * 0.1
+    rad, jvp = engine.calculate_jvp(atmosphere, {"wf_extinction": t_k, "wf_ssa": t_w}, {"wf_albedo": t_a})
+    want = np.einsum("qwls,q->wls", full["wf_extinction"], t_k) + np.einsum("qwls,q->wls", full["wf_ssa"], t_w) + full["wf_albedo"] * t_a[:, None, None]
+    np.testing.assert_array_equal(rad, full["radiance"])
+    np.testing.assert_allclose(jvp, want, rtol=1e-12, atol=1e-300)
+    # a directional finite difference of the forward model sees the same number
+    h = 1e-3
+    plus, minus = copy.deepcopy(s), copy.deepcopy(s)
+    for sign, sc_ in ((1, plus), (-1, minus)):
+        sc_["extinction"] = s["extinction"] + sign * h * t_k[:, None]
+        sc_["ssa"] = s["ssa"] + sign * h * t_w[:, None]
+        sc_["albedo"] = s["albedo"] + sign * h * t_a
+    fd = (run_product(plus, derivatives=False, engine=(engine, config, geometry))["radiance"]
+          - run_product(minus, derivatives=False, engine=(engine, config, geometry))["radiance"]) / (2 * h)
+    assert np.max(np.abs(fd.reshape(jvp.shape)[..., 0] - jvp[..., 0])) < 1e-4 * np.abs(jvp[..., 0]).max()
+    cot = rng.standard_normal(full["radiance"].shape)
+    rad2, grads = engine.calculate_vjp(atmosphere, cot)
+    np.testing.assert_array_equal(rad2, full["radiance"])
+    np.testing.assert_allclose(grads["wf_extinction"], np.einsum("qwls,wls->q", full["wf_extinction"], cot), rtol=1e-12)
+    np.testing.assert_allclose(grads["wf_ssa"], np.einsum("qwls,wls->q", full["wf_ssa"], cot), rtol=1e-12)
+    np.testing.assert_allclose(grads["wf_albedo"], np.einsum("wls,wls->w", full["wf_albedo"], cot), rtol=1e-12)
+    # <cotangent, J t> == <J^T cotangent, t>
+    lhs = float(np.sum(cot * jvp))
+    rhs = float(grads["wf_extinction"] @ t_k + grads["wf_ssa"] @ t_w + grads["wf_albedo"] @ t_a)
+    assert abs(lhs - rhs) < 1e-11 * max(abs(lhs), abs(rhs))

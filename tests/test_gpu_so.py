@@ -67,19 +67,15 @@ def test_c5_shape_limb_scene_matches_oracle_and_is_block_invariant(monkeypatch):
 
 
 def test_solar_irradiance_scales_the_radiance_and_derivatives_are_refused():
-    import sasktran2_amd as sk
     from tests.gpu_harness import build_so_engine
     s = sc.regression_so(nstokes=1)
     eng = build_so_engine(s)
     one = run_product_so(s, engine=eng)["radiance"]
     two = run_product_so(s, engine=eng, solar_irradiance=np.array([2.0, 3.0]))["radiance"]
     np.testing.assert_allclose(two, one * np.array([2.0, 3.0])[:, None, None], rtol=1e-13)
-    atmosphere = sk.Atmosphere(eng[2], eng[1], numwavel=2, calculate_derivatives=True)
-    atmosphere.storage.total_extinction[:] = s["extinction"]
-    atmosphere.storage.ssa[:] = s["ssa"]
-    atmosphere.storage.leg_coeff[:] = s["leg"]
+    # the successive-orders source is not linearised: asking for weighting functions is an error, not a partial Jacobian
     with pytest.raises(RuntimeError, match="weighting functions are not available"):
-        eng[0].calculate_radiance(atmosphere, as_dataset=False)
+        run_product_so(s, engine=eng, derivatives=True)
 
 
 def test_exact_single_scatter_on_top_of_discrete_ordinates():
@@ -92,3 +88,58 @@ def test_exact_single_scatter_on_top_of_discrete_ordinates():
     d = sc.regression_1d(2)
     do = run_oracle(d, derivatives=False)["radiance"]
     np.testing.assert_allclose(got, ss + do, rtol=1e-6)
+
+
+def assert_so_wf_parity(got, ref, tol=1e-4):
+    """Weighting functions relative to the largest one of their profile (the reference's criterion, BASELINE tolerance 1e-4)."""
+    for key in ("d_extinction", "d_ssa"):
+        scale = np.abs(ref[key]).max(axis=3, keepdims=True)
+        # a Stokes component that vanishes in the chosen basis (rounding-level profile) is compared on the scale of the intensity's profile
+        scale = np.maximum(scale, 1e-6 * scale[:, :, :1])
+        assert np.max(np.abs(got[key] - ref[key]) / scale) < tol, key
+    np.testing.assert_allclose(got["d_albedo"], ref["d_albedo"], rtol=tol, atol=1e-12 * np.abs(ref["radiance"]).max())
+
+
+@pytest.mark.parametrize("nstokes,basis", [(1, 0), (3, 0), (3, 1), (3, 2)], ids=["scalar", "standard basis", "solar basis", "observer basis"])
+def test_exact_single_scatter_weighting_functions_match_oracle(nstokes, basis):
+    """single_scatter_source = exact alone: wf_extinction / wf_ssa / wf_albedo (reverse mode on the device) against the oracle's dense
+    forward-mode linearisation, which matches central finite differences to 1e-6 (tests/test_so_oracle.py)."""
+    s = sc.regression_so(nstokes=nstokes, num_wavelengths=3)
+    s["config"]["stokes_basis"] = basis
+    o = dict(multiple_scatter="none")
+    from tests.test_so_oracle import make_so_oracle
+    ref = make_so_oracle(s, **o).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
+    got = run_product_so(s, derivatives=True, **o)
+    assert_so_parity(got, ref)
+    assert_so_wf_parity(got, ref)
+
+
+def test_exact_single_scatter_weighting_functions_on_the_c5_limb_geometry():
+    s = sc.limb_c5(num_wavelengths=130)
+    o = dict(multiple_scatter="none")
+    from tests.test_so_oracle import make_so_oracle
+    ref = make_so_oracle(s, **o).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, nthreads=8)
+    got = run_product_so(s, derivatives=True, **o)
+    assert_so_parity(got, ref)
+    assert_so_wf_parity(got, ref)
+
+
+@pytest.mark.parametrize("nstokes", [1, 3])
+def test_weighting_functions_of_discrete_ordinates_plus_exact_single_scatter(nstokes):
+    """multiple_scatter_source = discrete_ordinates with single_scatter_source = exact: native weighting functions of both sources are
+    added on the device before the user mappings; checked against oracle(DO, dense forward mode) + oracle(exact single scatter)."""
+    from tests.test_oracle_golden import run_oracle
+    from tests.test_so_oracle import make_so_oracle
+    s = sc.regression_so(nstokes=nstokes, num_wavelengths=2)
+    got = run_product_so(s, derivatives=True, multiple_scatter="discrete_ordinates")
+    ss = make_so_oracle(s, multiple_scatter="none").run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
+    d = sc.regression_1d(2)
+    if nstokes == 3:
+        d = dict(d, leg=s["leg"], config=dict(d["config"], nstokes=3))
+    do = run_oracle(d, derivatives=True)
+    shape = ss["radiance"].shape
+    ref = {"radiance": ss["radiance"] + do["radiance"].reshape(shape), "los_optical_depth": ss["los_optical_depth"],
+           "d_extinction": ss["d_extinction"] + do["d_extinction"].reshape(ss["d_extinction"].shape),
+           "d_ssa": ss["d_ssa"] + do["d_ssa"].reshape(ss["d_ssa"].shape), "d_albedo": ss["d_albedo"] + do["d_albedo"].reshape(shape)}
+    assert_so_parity(got, ref)
+    assert_so_wf_parity(got, ref)

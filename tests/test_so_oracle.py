@@ -88,3 +88,30 @@ def test_successive_orders_converges_to_the_discrete_ordinates_field():
     # in spherical geometry the reference's DO source (and the oracle's) delivers the multiple-scatter term only
     ms_so = so - ss
     assert np.max(np.abs(ms_so / do - 1)) < 0.07
+
+
+@pytest.mark.parametrize("nstokes", [1, 3])
+def test_exact_single_scatter_weighting_functions_match_finite_differences(nstokes):
+    """The reference's own criterion for weighting functions (tests/weightingfunctions/test_lowlevel.py:318-486, src/sasktran2/test_util/wf.py:9-24):
+    analytic == central finite differences, relative to the largest value of the profile."""
+    import copy
+    s = sc.regression_so(nstokes=nstokes)
+    o = make_so_oracle(s, multiple_scatter="none")
+    r = o.run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
+    for name, key in (("extinction", "d_extinction"), ("ssa", "d_ssa")):
+        scale = np.abs(r[key]).max(axis=3)
+        scale = np.where(scale > 0, scale, 1.0)
+        for q in (0, 3, 7, 12, 20, 24):
+            h = 1e-5 * s[name][q]
+            plus, minus = copy.deepcopy(s), copy.deepcopy(s)
+            plus[name][q] += h
+            minus[name][q] -= h
+            fd = (o.run(plus["extinction"], plus["ssa"], plus["leg"], plus["albedo"])["radiance"]
+                  - o.run(minus["extinction"], minus["ssa"], minus["leg"], minus["albedo"])["radiance"]) / (2 * h[:, None, None])
+            assert np.max(np.abs(fd - r[key][..., q]) / scale) < 5e-6, (name, q)
+    h = 1e-6
+    fd = (o.run(s["extinction"], s["ssa"], s["leg"], s["albedo"] + h)["radiance"] - o.run(s["extinction"], s["ssa"], s["leg"], s["albedo"] - h)["radiance"]) / (2 * h)
+    np.testing.assert_allclose(r["d_albedo"], fd, atol=1e-9 * np.abs(r["radiance"]).max() / h * 1e-3 + 1e-10)
+    # the diffuse source is not linearised: the oracle refuses as the product does
+    with pytest.raises(RuntimeError):
+        make_so_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
