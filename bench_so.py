@@ -78,7 +78,10 @@ def run_c5(args, world, rank, dev):
         # reads: layer factors, first order, outgoing (once: it is re-read from L2); writes: incoming
         "so_accumulate": {"bytes": 8 * (nl + 3 * nr + no), "flops": 2 * ne},
         # reads incoming + the points' Legendre coefficients, writes outgoing; 2 x moments x rows x cols per interior point
-        "so_scatter": {"bytes": 8 * (nr + no + npts * nmom), "flops": 2 * nmom * ndir * c["num_incoming"] * npts},
+        # interior points through spherical-harmonic space (k_so_sh): 2 x L^2 x (nin + nout) multiply-adds per point instead of the direct
+        # L x nin x nout; reads incoming + the points' Legendre coefficients, writes / reads the L^2 harmonic coefficients, writes outgoing
+        "so_scatter": {"bytes": 8 * (nr + no + npts * nmom + 2 * npts * nmom * nmom),
+                       "flops": 2 * nmom * nmom * (ndir + c["num_incoming"]) * npts, "direct_flops": 2 * nmom * ndir * c["num_incoming"] * npts},
         # per layer: writes optical depth, unattenuated source and omega (1 - e^-od); the table / optics it reads are L2 resident
         "so_layers": {"bytes": 8 * 3 * nl, "flops": None},
         # reads those three, writes the layer factors in place + first order / incoming
@@ -96,8 +99,8 @@ def run_c5(args, world, rank, dev):
         achieved = m["flops"] * chunk / avg_launch_s / 1e12
         roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS, "flops_per_launch": m["flops"] * chunk,
-                    "note": "exact FP64 operation count 2 x moments x rows x cols per interior diffuse point and wavelength; vector and matrix "
-                            "FP64 peaks are both 78.6 TFLOP/s on MI355X"}
+                    "note": "exact FP64 operation count 2 x L^2 x (incoming + outgoing directions) per interior diffuse point and wavelength "
+                            "(scattering through spherical-harmonic space); vector and matrix FP64 peaks are both 78.6 TFLOP/s on MI355X"}
     else:
         achieved = m["bytes"] * chunk / avg_launch_s / 1e9
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -103,6 +103,11 @@ struct SoGeo {
     const double* point_leg_w;
     const double* scat_basis;               // [row][col][num_ms_moments * per]
     const double *stokes_C, *stokes_S;      // [nlos] rotation of (Q, U) to the configured Stokes basis
+    // scalar scattering through spherical-harmonic space (see k_so_sh): nlm = num_ms_moments^2 real harmonics
+    int nlm, nout_pad;
+    const double* sh_in;                    // [nin][nlm]      w_i Y_lm(in_i) 4 pi / (2l + 1)
+    const double* sh_out;                   // [nlm][nout_pad] Y_lm(out_o)
+    const int* sh_l;                        // [nlm] degree l of harmonic lm
     const double* ground_factor;            // concatenated per ground point
     const int* ground_factor_start;         // [nground + 1]
 };
@@ -114,6 +119,7 @@ struct SoBufs {
     int nw, nwp, nleg, w0, nwavel_total;
     const double *ext, *ssa, *leg, *albedo, *irradiance;   // caller's inputs at the first wavelength of the block
     double *kT, *omT, *legT, *tab, *cl, *first, *incoming, *outgoing, *factor, *lod, *lsrc;   // factor: [layers + rays] (ground slots last)
+    double* sh;                              // [interior point][nlm] c_l x harmonic coefficients of the incoming field
     double *radiance, *los_od;                               // caller's outputs (whole spectrum)
     int accumulate;
     // native weighting functions of the exact single scatter: per-thread accumulators [slab][ray][S][2 ngrid + 1][64] and the caller's
@@ -136,6 +142,7 @@ __device__ inline SoBufs slab_view(const SoGeo& g, const SoBufs& b, int slab, in
     v.factor += o * (g.n_inc_layers + g.inc.nrays) + lane;
     v.lod += o * g.n_inc_layers + lane;
     v.lsrc += o * g.n_inc_layers * S + lane;
+    if (v.sh) v.sh += o * g.ninterior * g.nlm + lane;
     if (v.dacc) v.dacc += o * g.nlos * S * (2 * g.ngrid + 1) + lane;
     return v;
 }
@@ -547,9 +554,9 @@ __global__ void __launch_bounds__(kWave) k_so_scan(SoGeo g, SoBufs b) {
 // outgoing source of one (point, outgoing row) for 64 wavelengths: row of [sum_l c_l B_l] x incoming (interior points),
 // Lambertian reflection of the downwelling flux (ground points)
 template <int S>
-__global__ void __launch_bounds__(kWave) k_so_scatter(SoGeo g, SoBufs b) {
+__global__ void __launch_bounds__(kWave) k_so_scatter(SoGeo g, SoBufs b, int p0) {
     // two wavelength slabs per wavefront: every scalar-cache operand (one element of the basis) feeds two FMAs
-    const int w = blockIdx.y * (2 * kWave) + threadIdx.x, row = blockIdx.x, p = blockIdx.z;
+    const int w = blockIdx.y * (2 * kWave) + threadIdx.x, row = blockIdx.x, p = p0 + blockIdx.z;
     const SoBufs v = slab_view(g, b, 2 * blockIdx.y, threadIdx.x), v2 = slab_view(g, b, 2 * blockIdx.y + 1, threadIdx.x);
     const int nrow = (g.out_start[p + 1] - g.out_start[p]) * S, ncol = (g.in_start[p + 1] - g.in_start[p]) * S;
     if (row >= nrow) return;
@@ -606,6 +613,50 @@ __global__ void __launch_bounds__(kWave) k_so_scatter(SoGeo g, SoBufs b) {
     }
     out[0] = sum0;
     out2[0] = sum1;
+}
+
+// Scalar scattering of the interior points through spherical-harmonic space.  sum_l c_l w_i P_l(o . i) in_i is, by the addition theorem,
+//   b_lm = c_l (4 pi / (2l + 1)) sum_i w_i Y_lm(in_i) in_i      (STAGE 1: 110 -> L^2 numbers per point)
+//   out_o = sum_lm Y_lm(out_o) b_lm                               (STAGE 2: L^2 -> 110)
+// i.e. 2 x 110 x L^2 multiply-adds instead of 110 x 110 x L (3.4 x fewer at L = 16), with wavelength-independent transform matrices as
+// scalar operands.  Both stages are OUT[row][w] = scale x sum_c M[c][row] X[c][w]: 16 rows x two wavelength slabs per wavefront.
+// (The transform is verified against the direct basis at engine construction; the oracle keeps the direct product.)
+template <int STAGE>
+__global__ void __launch_bounds__(kWave) k_so_sh(SoGeo g, SoBufs b, const double* __restrict__ M, const int* __restrict__ row_l) {
+    const int chunk = blockIdx.x, p = blockIdx.z;
+    const SoBufs v = slab_view(g, b, 2 * blockIdx.y, threadIdx.x), v2 = slab_view(g, b, 2 * blockIdx.y + 1, threadIdx.x);
+    const int nrows = STAGE == 1 ? g.nlm : g.nout_pad, ncols = STAGE == 1 ? g.nin : g.nlm;
+    const double* __restrict__ x0 = STAGE == 1 ? v.incoming + size_t(g.in_start[p]) * kWave : v.sh + size_t(p) * g.nlm * kWave;
+    const double* __restrict__ x1 = STAGE == 1 ? v2.incoming + size_t(g.in_start[p]) * kWave : v2.sh + size_t(p) * g.nlm * kWave;
+    double acc0[16], acc1[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc0[t] = acc1[t] = 0;
+    const double* __restrict__ Mc = M + size_t(chunk) * 16;
+#pragma unroll 2
+    for (int c = 0; c < ncols; ++c) {
+        const double a0 = x0[size_t(c) * kWave], a1 = x1[size_t(c) * kWave];
+        const double* __restrict__ Mr = Mc + size_t(c) * nrows;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { acc0[t] += Mr[t] * a0; acc1[t] += Mr[t] * a1; }
+    }
+    if (STAGE == 1) {
+        const int nlgB = g.num_ms_moments, nl_in = min(g.num_ms_moments, b.nleg);
+        double* o0 = v.sh + (size_t(p) * g.nlm + chunk * 16) * kWave;
+        double* o1 = v2.sh + (size_t(p) * g.nlm + chunk * 16) * kWave;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int l = row_l[chunk * 16 + t];
+            const double c0 = l < nl_in ? v.cl[(size_t(p) * nlgB + l) * kWave] : 0.0, c1 = l < nl_in ? v2.cl[(size_t(p) * nlgB + l) * kWave] : 0.0;
+            o0[size_t(t) * kWave] = acc0[t] * c0;
+            o1[size_t(t) * kWave] = acc1[t] * c1;
+        }
+    } else {
+        double* o0 = v.outgoing + (size_t(g.out_start[p]) + chunk * 16) * kWave;
+        double* o1 = v2.outgoing + (size_t(g.out_start[p]) + chunk * 16) * kWave;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (chunk * 16 + t < g.nout) { o0[size_t(t) * kWave] = acc0[t]; o1[size_t(t) * kWave] = acc1[t]; }
+    }
 }
 
 // incoming = accumulation matrix x outgoing + first order, one incoming ray x 64 wavelengths per wavefront.  The matrix entry is
@@ -874,6 +925,68 @@ SoDeviceEngine::SoDeviceEngine(const skso::SoGeometry& sg, int num_iterations) :
             for (int r = 0; r < rows; ++r)
                 for (int c = 0; c < cols; ++c) Bt[(size_t(r) * cols + c) * nlgB + lg] = sg.scat_basis[(size_t(lg) * rows + r) * cols + c];
         g.scat_basis = I.tables.upload(Bt);
+        // Scalar scattering through spherical-harmonic space (k_so_sh) when it is cheaper than the direct product: real orthonormal
+        // harmonics Y_lm, l < L, sum_m Y_lm(a) Y_lm(b) = (2l + 1) / (4 pi) P_l(a . b).  Verified against the direct basis below.
+        g.nlm = 0;
+        const int Lm = sg.cfg.num_ms_moments;
+        if (S == 1 && Lm * Lm % 16 == 0 && size_t(Lm) * Lm * (sg.nin + sg.nout) < size_t(sg.nin) * sg.nout * Lm && !std::getenv("SASKTRAN2_AMD_SO_DIRECT")) {
+            const int nlm = Lm * Lm, nout_pad = (sg.nout + 15) / 16 * 16;
+            auto harmonics = [&](const double* d, std::vector<double>& Y) {   // Y[lm], lm = l^2 + (m + l)
+                const double x = d[0], y = d[1], z = std::max(-1.0, std::min(1.0, d[2]));
+                const double phi = std::atan2(y, x), st = std::sqrt(std::max(0.0, 1 - z * z));
+                Y.assign(nlm, 0.0);
+                for (int m = 0; m < Lm; ++m) {
+                    // associated Legendre P_l^m(z), l = m .. Lm - 1 (without the Condon-Shortley phase: it cancels in the products)
+                    double pmm = 1;
+                    for (int k = 1; k <= m; ++k) pmm *= (2 * k - 1) * st;
+                    double pl2 = 0, pl1 = pmm;
+                    for (int l = m; l < Lm; ++l) {
+                        double plm;
+                        if (l == m) plm = pmm;
+                        else if (l == m + 1) plm = z * (2 * m + 1) * pmm;
+                        else plm = ((2 * l - 1) * z * pl1 - (l + m - 1) * pl2) / (l - m);
+                        if (l > m) { pl2 = pl1; pl1 = plm; }
+                        double ratio = 1;   // (l - m)! / (l + m)!
+                        for (int k = l - m + 1; k <= l + m; ++k) ratio /= k;
+                        const double N = std::sqrt((2 * l + 1) / (4 * kPi) * ratio);
+                        if (m == 0) Y[l * l + l] = N * plm;
+                        else {
+                            Y[l * l + l + m] = std::sqrt(2.0) * N * plm * std::cos(m * phi);
+                            Y[l * l + l - m] = std::sqrt(2.0) * N * plm * std::sin(m * phi);
+                        }
+                    }
+                }
+            };
+            std::vector<double> sh_in(size_t(sg.nin) * nlm), sh_out(size_t(nlm) * nout_pad, 0.0), Y;
+            std::vector<int> sh_l(nlm);
+            for (int l = 0; l < Lm; ++l)
+                for (int m = -l; m <= l; ++m) sh_l[l * l + l + m] = l;
+            for (int i = 0; i < sg.nin; ++i) {
+                harmonics(&sg.in_dir[3 * i], Y);
+                for (int lm = 0; lm < nlm; ++lm) sh_in[size_t(i) * nlm + lm] = sg.in_weight[i] * Y[lm] * 4 * kPi / (2 * sh_l[lm] + 1);
+            }
+            for (int o = 0; o < sg.nout; ++o) {
+                harmonics(&sg.out_dir[3 * o], Y);
+                for (int lm = 0; lm < nlm; ++lm) sh_out[size_t(lm) * nout_pad + o] = Y[lm];
+            }
+            double worst = 0;   // the transform must reproduce every element of the direct basis w_i P_l(o . i)
+            for (int l = 0; l < Lm; ++l)
+                for (int o = 0; o < sg.nout; ++o)
+                    for (int i = 0; i < sg.nin; ++i) {
+                        double v = 0;
+                        for (int lm = l * l; lm < (l + 1) * (l + 1); ++lm) v += sh_out[size_t(lm) * nout_pad + o] * sh_in[size_t(i) * nlm + lm];
+                        worst = std::max(worst, std::abs(v - sg.scat_basis[(size_t(l) * rows + o) * cols + i]));
+                    }
+            if (worst < 1e-13) {
+                g.nlm = nlm;
+                g.nout_pad = nout_pad;
+                g.sh_in = I.tables.upload(sh_in);
+                g.sh_out = I.tables.upload(sh_out);
+                g.sh_l = I.tables.upload(sh_l);
+            } else {
+                std::fprintf(stderr, "sasktran2_amd: spherical-harmonic scattering transform off by %.3e, using the direct product\n", worst);
+            }
+        }
         std::vector<double> gf;
         std::vector<int> gfs{0};
         for (const auto& f : sg.ground_in_factor) {
@@ -931,7 +1044,8 @@ static size_t so_doubles_per_wavelength(const SoDeviceEngine::Impl& I, int nleg)
     const size_t per = g.S == 3 ? 4 : 1, S = g.S;
     size_t d = size_t(g.ngrid) * (2 + size_t(nleg) * per);
     if (I.multiple_scatter)
-        d += I.n_table + size_t(g.ninterior) * g.num_ms_moments * per + 2 * I.n_inc_rays * S + I.n_out * S + I.n_inc_layers * (2 + S) + I.n_inc_rays;
+        d += I.n_table + size_t(g.ninterior) * g.num_ms_moments * per + 2 * I.n_inc_rays * S + I.n_out * S + I.n_inc_layers * (2 + S) + I.n_inc_rays +
+             size_t(g.ninterior) * g.nlm;
     return d;
 }
 size_t SoDeviceEngine::bytes_per_wavelength() const { return so_doubles_per_wavelength(*impl_, std::max(impl_->cap_nleg, impl_->g.num_ss_moments)) * sizeof(double); }
@@ -980,6 +1094,7 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             b.factor = I.scratch.alloc<double>((I.n_inc_layers + I.n_inc_rays) * W);
             b.lod = I.scratch.alloc<double>(I.n_inc_layers * W);
             b.lsrc = I.scratch.alloc<double>(I.n_inc_layers * S * W);
+            b.sh = g.nlm > 0 ? I.scratch.alloc<double>(size_t(g.ninterior) * g.nlm * W) : nullptr;
         }
         b.dacc = I.cap_derivs ? I.scratch.alloc<double>(size_t(g.nlos) * S * (2 * g.ngrid + 1) * W) : nullptr;
         I.scratch_bytes = (so_doubles_per_wavelength(I, I.cap_nleg) + (I.cap_derivs ? size_t(g.nlos) * S * (2 * g.ngrid + 1) : 0)) * sizeof(double) * W;
@@ -1034,8 +1149,15 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
                     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_accumulate<3>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b);
                 }
                 SoTimer t(I, st, "so_scatter");
-                if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<1>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.npoints)), dim3(kWave), 0, st, g, b);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<3>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.npoints)), dim3(kWave), 0, st, g, b);
+                if (S == 1 && g.nlm > 0) {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_sh<1>), dim3(unsigned(g.nlm / 16), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, b, g.sh_in, g.sh_l);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_sh<2>), dim3(unsigned(g.nout_pad / 16), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, b, g.sh_out, g.sh_l);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<1>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.npoints - g.ninterior)), dim3(kWave), 0, st, g, b, g.ninterior);
+                } else if (S == 1) {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<1>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.npoints)), dim3(kWave), 0, st, g, b, 0);
+                } else {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<3>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.npoints)), dim3(kWave), 0, st, g, b, 0);
+                }
             }
         }
         {

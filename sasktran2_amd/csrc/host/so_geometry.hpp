@@ -236,6 +236,7 @@ struct SoGeometry {
     // (nout S) x (nin S) row major; ground pairs: 4 pi mu_in w_in per incoming direction
     std::vector<double> scat_basis;             // [num_ms_moments][ngreek][nout S][nin S]
     int nin = 0, nout = 0;
+    std::vector<double> in_dir, out_dir, in_weight;   // interior sphere pair: unit vectors [n][3], incoming quadrature weights
     std::vector<std::vector<double>> ground_in_factor;   // [ground point][nin_g]
     std::vector<int> ground_nin, ground_nout;
 };
@@ -427,6 +428,11 @@ inline void build_so_geometry(const skgeo::Geometry1D& geo, const std::vector<sk
     g.npoints = g.ninterior + li.num_ground();
     g.nin = full_in.size();
     g.nout = full_out.size();
+    for (int i = 0; i < full_in.size(); ++i) {
+        g.in_dir.insert(g.in_dir.end(), {full_in.dir[i].x, full_in.dir[i].y, full_in.dir[i].z});
+        g.in_weight.push_back(full_in.weight[i]);
+    }
+    for (int o = 0; o < full_out.size(); ++o) g.out_dir.insert(g.out_dir.end(), {full_out.dir[o].x, full_out.dir[o].y, full_out.dir[o].z});
     std::vector<Vec3> point_position(g.npoints);
     g.in_start.assign(1, 0);
     g.out_start.assign(1, 0);
