@@ -154,12 +154,13 @@ struct SoHandle {
     skgeo::Geometry1D geo;
     skso::SoGeometry sg;
     int num_iterations = 50;
+    const double *emission = nullptr, *surface_emission = nullptr;
 };
 
 void* orso_create(double cos_sza, double saa, double earth_radius, const double* altitudes, int ngrid, int interp_method, int geotype,
                   int nrays, const int* ray_kinds, const double* ray_params, int nstokes, int stokes_basis, int num_ss_moments,
                   int num_ms_moments, int num_incoming, int num_outgoing, int num_sza, int num_iterations, int single_scatter,
-                  int multiple_scatter) {
+                  int multiple_scatter, int emission, int occultation) {
     try {
         auto h = std::make_unique<SoHandle>();
         h->geo = skgeo::Geometry1D(cos_sza, saa, earth_radius, std::vector<double>(altitudes, altitudes + ngrid),
@@ -183,6 +184,8 @@ void* orso_create(double cos_sza, double saa, double earth_radius, const double*
         cfg.num_sza = num_sza;
         cfg.single_scatter = single_scatter != 0;
         cfg.multiple_scatter = multiple_scatter != 0;
+        cfg.emission = emission;
+        cfg.occultation = occultation != 0;
         skso::build_so_geometry(h->geo, specs, cfg, h->sg, stokes_basis);
         h->num_iterations = num_iterations;
         return h.release();
@@ -192,6 +195,14 @@ void* orso_create(double cos_sza, double saa, double earth_radius, const double*
     }
 }
 void orso_destroy(void* h) { delete static_cast<SoHandle*>(h); }
+// emission_source [ngrid, nwavel] and surface emission [nwavel] for the following orso_run calls
+int orso_set_emission(void* hv, const double* emission, const double* surface_emission) {
+    auto* h = static_cast<SoHandle*>(hv);
+    if (!h) return -1;
+    h->emission = emission;
+    h->surface_emission = surface_emission;
+    return 0;
+}
 int orso_lebedev(int npoints, double* xyzw) {
     try {
         const std::vector<double> s = skleb::sphere(npoints);
@@ -226,7 +237,11 @@ int orso_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     atm.leg = leg;
     atm.solar_irradiance = solar_irradiance;
     atm.albedo = albedo;
+    atm.emission = h->emission;
+    atm.surface_emission = h->surface_emission;
+    if (h->sg.cfg.emission != 0 && !atm.emission) return -2;
     atm.derivatives = d_k != nullptr;
+    if (atm.derivatives && (h->sg.cfg.emission != 0 || h->sg.cfg.occultation)) return -2;
     if (atm.derivatives && h->sg.cfg.multiple_scatter && h->num_iterations > 0) return -2;   // the diffuse source is not linearised
     const int ngrid = h->sg.ngrid, nn = 2 * ngrid + 1;
     int status = 0;

@@ -122,10 +122,11 @@ class SoOracleEngine:
 
     def __init__(self, cos_sza, saa, earth_radius, altitudes, interp_method, geotype, rays, nstokes=1, stokes_basis=0,
                  num_ss_moments=16, num_ms_moments=16, num_incoming=110, num_outgoing=110, num_sza=1, num_iterations=50,
-                 single_scatter=True, multiple_scatter=True):
+                 single_scatter=True, multiple_scatter=True, emission=0, occultation=False):
         L = lib()
         L.orso_create.restype = ctypes.c_void_p
-        L.orso_create.argtypes = [ctypes.c_double] * 3 + [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp] + [ctypes.c_int] * 10
+        L.orso_create.argtypes = [ctypes.c_double] * 3 + [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp] + [ctypes.c_int] * 12
+        L.orso_set_emission.argtypes = [ctypes.c_void_p, _dp, _dp]
         L.orso_destroy.argtypes = [ctypes.c_void_p]
         L.orso_sizes.argtypes = [ctypes.c_void_p, _ip]
         L.orso_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp]
@@ -136,7 +137,7 @@ class SoOracleEngine:
         self._h = L.orso_create(cos_sza, saa, earth_radius, _p(self.alt), self.ngrid, interp_method, geotype, self.nlos,
                                 kinds.ctypes.data_as(_ip), _p(params), int(nstokes), int(stokes_basis), int(num_ss_moments),
                                 int(num_ms_moments), int(num_incoming), int(num_outgoing), int(num_sza), int(num_iterations),
-                                int(single_scatter), int(multiple_scatter))
+                                int(single_scatter), int(multiple_scatter), int(emission), int(occultation))
         if not self._h:
             raise RuntimeError("successive-orders oracle construction failed")
 
@@ -150,7 +151,7 @@ class SoOracleEngine:
         lib().orso_sizes(self._h, out.ctypes.data_as(_ip))
         return dict(points=int(out[0]), incoming_rays=int(out[1]), outgoing_directions=int(out[2]), accumulation_entries=int(out[3]))
 
-    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, nthreads=1, derivatives=False):
+    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, nthreads=1, derivatives=False, emission=None, surface_emission=None):
         """derivatives: native weighting functions of the exact single-scatter source, d_extinction / d_ssa [nwavel, nlos, S, ngrid],
         d_albedo [nwavel, nlos, S] (only without the diffuse source)."""
         k = np.asfortranarray(extinction, dtype=np.float64)
@@ -161,6 +162,9 @@ class SoOracleEngine:
         irr = None if solar_irradiance is None else np.ascontiguousarray(solar_irradiance, dtype=np.float64)
         rad = np.zeros((nwavel, self.nlos, S))
         od = np.zeros((nwavel, self.nlos))
+        em = None if emission is None else np.asfortranarray(emission, dtype=np.float64)
+        sem = None if surface_emission is None else np.ascontiguousarray(surface_emission, dtype=np.float64)
+        lib().orso_set_emission(self._h, _p(em), _p(sem))
         dk = dw = da = None
         if derivatives:
             dk, dw, da = np.zeros((nwavel, self.nlos, S, self.ngrid)), np.zeros((nwavel, self.nlos, S, self.ngrid)), np.zeros((nwavel, self.nlos, S))

@@ -28,6 +28,8 @@ struct AtmosphereView {
     const double* leg = nullptr;                         // [nleg (x 4), ngrid, nwavel]
     const double* solar_irradiance = nullptr;            // [nwavel] or null (1)
     const double* albedo = nullptr;                      // [nwavel]
+    const double* emission = nullptr;                    // [ngrid, nwavel] emission_source of the storage (settings.emission != 0)
+    const double* surface_emission = nullptr;            // [nwavel]
     bool derivatives = false;                            // native weighting functions of the exact single-scatter source (no diffuse source)
 };
 
@@ -275,6 +277,10 @@ class Solver {
             const int l0 = lo.layer_start[r], n = lo.layer_start[r + 1] - l0;
             double rad[3] = {0, 0, 0}, src[3], total_od = 0;
             if (n > 0 && ss) ray_phase(lo, r, a, w, p11.data(), p12.data());
+            // end-of-ray sources without scattering: surface emission (emission_source.cpp:156-173), unit source of an occultation
+            // behind a ray that leaves the atmosphere (occultation.cpp:26-35)
+            if (n > 0 && g_.cfg.emission != 0 && lo.ground_is_hit[r] && a.surface_emission) rad[0] += a.surface_emission[w];
+            if (g_.cfg.occultation && !(n > 0 && lo.ground_is_hit[r])) rad[0] += 1.0;
             if (n > 0 && lo.ground_is_hit[r]) {
                 if (ss && lo.ground_mu_in[r] > 0) rad[0] += T_los_[lo.endpoint_start[r]] * (albedo / skgeo::kPi) * lo.ground_mu_in[r];
                 if (ms && num_iterations > 0)
@@ -289,6 +295,19 @@ class Solver {
                 if (ss) {
                     layer_source(lo, r, L, j, T_los_.data(), od, k, om, p11.data(), p12.data(), src);
                     for (int s = 0; s < S_; ++s) rad[s] += src[s];
+                }
+                if (g_.cfg.emission != 0 && !lo.tiny[L]) {   // emission_source.cpp:37-100
+                    const double* em = a.emission + size_t(w) * ngrid;
+                    double oms = 0, ome = 0, es = 0, ee = 0;
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = lo.stencil_idx[size_t(L) * 4 + i];
+                        if (q < 0) continue;
+                        const double ws = lo.w_entrance[size_t(L) * 4 + i], we = lo.w_exit[size_t(L) * 4 + i];
+                        oms += om[q] * ws; es += em[q] * ws;
+                        ome += om[q] * we; ee += em[q] * we;
+                    }
+                    if (g_.cfg.emission == 1) rad[0] += (1 - att) * ((1 - oms) * es * lo.frac_start[L] + (1 - ome) * ee * lo.frac_end[L]);
+                    else rad[0] += lo.distance[L] * (es * lo.frac_start[L] + ee * lo.frac_end[L]);
                 }
                 if (ms && num_iterations > 0) {
                     const double omega = lo.mid_w[2 * L] * om[lo.mid_idx[2 * L]] + lo.mid_w[2 * L + 1] * om[lo.mid_idx[2 * L + 1]];

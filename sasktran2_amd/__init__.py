@@ -50,6 +50,19 @@ class SingleScatterSource(enum.IntEnum):  # cpp/include/sasktran2/config.h:41-46
     NoSource = 3
 
 
+class EmissionSource(enum.IntEnum):  # cpp/include/sasktran2/config.h:122-128
+    Standard = 0
+    NoSource = 1
+    DiscreteOrdinates = 2
+    VolumeEmissionRate = 3
+    TwoStream = 4
+
+
+class OccultationSource(enum.IntEnum):  # cpp/include/sasktran2/config.h:104
+    Standard = 0
+    NoSource = 1
+
+
 class StokesBasis(enum.IntEnum):  # cpp/include/sasktran2/config.h:145
     Standard = 0
     Solar = 1
@@ -64,6 +77,7 @@ class Config:
              "wavelength_batch_size": "wavelength_batch_size", "output_los_optical_depth": "output_los_optical_depth",
              "multiple_scatter_source": "multiple_scatter_source", "single_scatter_source": "single_scatter_source",
              "wf_enabled": "wf_enabled", "delta_m_scaling": "apply_delta_scaling", "stokes_basis": "stokes_basis",
+             "emission_source": "emission_source", "occultation_source": "occultation_source",
              # successive orders (src/sasktran2/config.py:410-418,505-514,607-634 -> the C API's `hr` keys)
              "num_successive_orders_iterations": "num_hr_spherical_iterations", "num_successive_orders_incoming": "num_hr_incoming",
              "num_successive_orders_outgoing": "num_hr_outgoing", "init_successive_orders_with_discrete_ordinates": "initialize_hr_with_do"}

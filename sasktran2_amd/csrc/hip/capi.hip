@@ -364,10 +364,14 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
             throw std::runtime_error("single_scatter_source must be exact (0), discrete_ordinates (2) or none (3); solartable (1) is not part of this build");
         if (c->ss_source == 2 && c->ms_source != 0) throw std::runtime_error("single_scatter_source = discrete_ordinates needs multiple_scatter_source = discrete_ordinates");
         if (c->los_refraction || c->solar_refraction || c->multiple_scatter_refraction ||
-            c->num_do_forced_azimuth >= 0 || c->num_do_spherical_iterations > 0 || c->emission_source != 1 || c->occultation_source != 1 ||
-            c->do_backprop)
-            throw std::runtime_error("refraction, forced azimuth count, DO spherical iterations, backprop, emission and "
-                                     "occultation sources are not part of this build");
+            c->num_do_forced_azimuth >= 0 || c->num_do_spherical_iterations > 0 || c->do_backprop)
+            throw std::runtime_error("refraction, forced azimuth count, DO spherical iterations and backprop are not part of this build");
+        // EmissionSource { standard = 0, none = 1, discrete_ordinates = 2, volume_emission_rate = 3, twostream = 4 }, OccultationSource { standard = 0, none = 1 }
+        if (c->emission_source != 0 && c->emission_source != 1 && c->emission_source != 3)
+            throw std::runtime_error("emission_source must be standard (0), none (1) or volume_emission_rate (3); discrete_ordinates (2) and twostream (4) are not part of this build");
+        if (c->occultation_source != 0 && c->occultation_source != 1) throw std::runtime_error("occultation_source must be standard (0) or none (1)");
+        const int emission = c->emission_source == 0 ? 1 : (c->emission_source == 3 ? 2 : 0);
+        const bool occultation = c->occultation_source == 0;
         skgeo::Geometry1D geo(g->cos_sza, g->saa, g->earth_radius, g->grid, (skgeo::Interpolation)g->interp,
                               (skgeo::GeometryType)g->geotype);
         auto e = std::make_unique<Engine>();
@@ -384,7 +388,8 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
                 throw std::runtime_error("single_scatter_source = exact with discrete ordinates needs spherical geometry (in plane-parallel "
                                          "geometry the discrete-ordinates source carries the single scatter itself)");
         }
-        if (c->ss_source == 0 || c->ms_source == 1) {
+        if (c->ss_source == 0 || c->ms_source == 1 || emission != 0 || occultation) {
+            if (g->geotype != 2) throw std::runtime_error("the exact single-scatter, successive-orders, emission and occultation sources need spherical geometry");
             if (c->ms_source == 1 && (c->initialize_hr_with_do || c->num_hr_full_incoming_points > 0))
                 throw std::runtime_error("initialize_hr_with_do and num_hr_full_incoming_points are not part of this build");
             skso::Settings cfg;
@@ -396,6 +401,8 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
             cfg.num_sza = c->num_sza;
             cfg.single_scatter = c->ss_source == 0;
             cfg.multiple_scatter = c->ms_source == 1;
+            cfg.emission = emission;
+            cfg.occultation = occultation;
             skso::SoGeometry sg;
             skso::build_so_geometry(geo, v->rays, cfg, sg, c->stokes_basis);
             e->so = std::make_unique<skdev::SoDeviceEngine>(sg, c->num_hr_spherical_iterations);
@@ -481,6 +488,7 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
 
 // NSTOKES = 3 (and NSTOKES = 1 stream counts outside the matrix-core path): radiances [wavel][los][stokes], LOS optical depths and
 // weighting functions [nderiv][wavel][los][stokes].
+static void upload_emission(Engine* e, const AtmosphereStorage& st, const Surface& su);
 static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     const AtmosphereStorage& st = *atm->storage;
     const Surface& su = *atm->surface;
@@ -552,7 +560,10 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     e->dev->solve_device_vector(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status, nullptr,
                                 (int)group_of.size(), d_dleg, d_wg, d_dfg);
     e->dev->set_delta_m_fraction(nullptr);
-    if (e->so) e->so->solve_device(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa);
+    if (e->so) {
+        upload_emission(e, st, su);
+        e->so->solve_device(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa);
+    }
     hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
     HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
@@ -565,6 +576,22 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     HIPC(hipMemcpy(out->los_od.data(), d_odt, nt * 8, hipMemcpyDeviceToHost));
     if (derivs) map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, S, d_wg, group_of.empty() ? nullptr : &group_of);
     return 0;
+}
+
+// emission_source / surface emission of the storage -> device, for an engine with an emission source (emission_source.cpp:37-173)
+static void upload_emission(Engine* e, const AtmosphereStorage& st, const Surface& su) {
+    if (!e->so || (e->config.emission_source != 0 && e->config.emission_source != 3)) return;
+    if (!st.emission) throw std::runtime_error("the engine has an emission source but the atmosphere storage has no emission_source array");
+    DeviceCache& C = e->cache;
+    const size_t nloc_w = size_t(e->ngrid) * st.nwavel;
+    double* d_em = (double*)C.get("so_emission", nloc_w * 8);
+    HIPC(hipMemcpy(d_em, st.emission, nloc_w * 8, hipMemcpyHostToDevice));
+    double* d_sem = nullptr;
+    if (su.emission) {
+        d_sem = (double*)C.get("so_surface_emission", size_t(st.nwavel) * 8);
+        HIPC(hipMemcpy(d_sem, su.emission, size_t(st.nwavel) * 8, hipMemcpyHostToDevice));
+    }
+    e->so->set_emission(d_em, d_sem);
 }
 
 // exact single scatter and / or legacy successive orders alone (no discrete-ordinates source): radiances [wavel][los][stokes], LOS optical
@@ -599,6 +626,7 @@ static int calculate_radiance_so(Engine* e, Atmosphere* atm, OutputC* out) {
         d_ws = (double*)C.get("wf_ssa", size_t(ngrid) * nt * S * 8);
         d_wa = (double*)C.get("wf_alb", nt * S * 8);
     }
+    upload_emission(e, st, su);
     e->so->solve_device(nw, st.nleg / per, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, d_od, nullptr, 0, d_we, d_ws, d_wa);
     HIPC(hipDeviceSynchronize());
     std::vector<double> od(nt);
@@ -649,9 +677,10 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (e->so && wants_derivs) {
             // the successive-orders source is not linearised here (the reference's own linearisation of it is approximate); scattering-group
             // derivatives of the exact single scatter (d_legendre) are not built either: an error rather than a silently incomplete Jacobian
-            if (e->so->has_successive_orders()) {
+            if (e->so->has_unlinearised_sources()) {
                 set_error("sk_engine_calculate_radiance: weighting functions are not available with multiple_scatter_source = "
-                          "successive_orders_legacy in this build (create the atmosphere with calculate_derivatives = 0)");
+                          "successive_orders_legacy, an emission source or an occultation source in this build (create the atmosphere with "
+                          "calculate_derivatives = 0)");
                 return -2;
             }
             for (auto& kv : out->derivs) {
@@ -717,7 +746,10 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         e->dev->set_delta_m_fraction(nullptr);
         // single_scatter_source = exact on top of the discrete-ordinates multiple scatter: radiance and native weighting functions are
         // accumulated on the device before the user mappings are applied
-        if (e->so) e->so->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa);
+        if (e->so) {
+            upload_emission(e, st, su);
+            e->so->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa);
+        }
         hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
         HIPC(hipGetLastError());
         HIPC(hipDeviceSynchronize());

@@ -60,6 +60,7 @@ struct DevRays {
     const int* stencil_idx;                 // [layer][4]
     const double *w_entrance, *w_exit;      // [layer][4]
     const double *quad_start, *quad_end;    // [layer]
+    const double *frac_start, *frac_end, *distance;   // [layer] quadrature fractions and length (emission sources)
     const unsigned char* tiny;
     const int* mid_idx;                     // [layer][2]
     const double* mid_w;
@@ -87,6 +88,7 @@ static_assert(sizeof(AccGroup) == 80, "AccGroup layout");
 
 struct SoGeo {
     int ngrid, nlos, S, num_ss_moments, num_ms_moments;
+    int emission, occultation;              // line-of-sight sources without scattering (skso::Settings)
     const LayerRec* inc_rec;
     const AccGroup* acc_group;
     const int* acc_group_start;             // [incoming rays + 1]
@@ -118,6 +120,8 @@ struct SoGeo {
 struct SoBufs {
     int nw, nwp, nleg, w0, nwavel_total;
     const double *ext, *ssa, *leg, *albedo, *irradiance;   // caller's inputs at the first wavelength of the block
+    const double *emission, *surface_emission;             // emission_source [w][q], surface emission [w] (emission sources only)
+    double* emT;                                            // emission_source, slab major
     double *kT, *omT, *legT, *tab, *cl, *first, *incoming, *outgoing, *factor, *lod, *lsrc;   // factor: [layers + rays] (ground slots last)
     double* sh;                              // [interior point][nlm] c_l x harmonic coefficients of the incoming field
     double *radiance, *los_od;                               // caller's outputs (whole spectrum)
@@ -134,6 +138,7 @@ __device__ inline SoBufs slab_view(const SoGeo& g, const SoBufs& b, int slab, in
     v.kT += o * g.ngrid + lane;
     v.omT += o * g.ngrid + lane;
     v.legT += o * g.ngrid * b.nleg * per + lane;
+    if (v.emT) v.emT += o * g.ngrid + lane;
     v.tab += o * g.ntable + lane;
     v.cl += o * g.ninterior * g.num_ms_moments * per + lane;
     v.first += o * g.inc.nrays * S + lane;
@@ -159,6 +164,7 @@ __global__ void __launch_bounds__(256) k_so_transpose(SoGeo g, SoBufs b) {
         if (item < nk) b.kT[(slab * nk + item) * kWave + lane] = b.ext[size_t(ws) * g.ngrid + item];
         else if (item < 2 * nk) b.omT[(slab * nk + (item - nk)) * kWave + lane] = b.ssa[size_t(ws) * g.ngrid + (item - nk)];
         else b.legT[(slab * nl + (item - 2 * nk)) * kWave + lane] = b.leg[size_t(ws) * nl + (item - 2 * nk)];
+        if (item < nk && b.emT) b.emT[(slab * nk + item) * kWave + lane] = b.emission[size_t(ws) * g.ngrid + item];
     }
 }
 
@@ -249,6 +255,7 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
 
     double T_entrance = 0;   // transmission at the entrance of the layer in hand = exit of the layer nearer to the observer
     double total_od = 0;
+    const bool emit = LOS && g.emission != 0;
     if (n > 0 && single_scatter) T_entrance = transmission(e0 + n);
     for (int j = n - 1; j >= 0; --j) {
         const int L = l0 + j;
@@ -266,6 +273,18 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
                 for (int s = 0; s < S; ++s) val[s] += sf * (st[s] * rs.quad_start[L] + en[s] * rs.quad_end[L]) * before;
             }
             T_entrance = T_exit;
+        }
+        if (emit && !rs.tiny[L]) {   // EmissionSource::integrated_source (emission_source.cpp:37-100)
+            double oms = 0, ome = 0, es = 0, ee = 0;
+            for (int i = 0; i < 4; ++i) {
+                const int q = rs.stencil_idx[4 * L + i];
+                if (q < 0) continue;
+                const double om_q = v.omT[size_t(q) * kWave], em_q = v.emT[size_t(q) * kWave];
+                oms += om_q * rs.w_entrance[4 * L + i]; es += em_q * rs.w_entrance[4 * L + i];
+                ome += om_q * rs.w_exit[4 * L + i]; ee += em_q * rs.w_exit[4 * L + i];
+            }
+            val[0] += before * (g.emission == 1 ? (1 - att) * ((1 - oms) * es * rs.frac_start[L] + (1 - ome) * ee * rs.frac_end[L])
+                                                : rs.distance[L] * (es * rs.frac_start[L] + ee * rs.frac_end[L]));
         }
         if (multiple_scatter) {
             const double omega = rs.mid_w[2 * L] * v.omT[size_t(rs.mid_idx[2 * L]) * kWave] + rs.mid_w[2 * L + 1] * v.omT[size_t(rs.mid_idx[2 * L + 1]) * kWave];
@@ -297,6 +316,10 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
         }
     }
     if (LOS) {
+        // end-of-ray sources without scattering: surface emission behind a ray that ends on the ground, unit source of an occultation
+        // behind one that leaves the atmosphere
+        if (emit && n > 0 && rs.ground_is_hit[r] && b.surface_emission) val[0] += b.surface_emission[ws] * before;
+        if (g.occultation && !(n > 0 && rs.ground_is_hit[r])) val[0] += before;
         if (w >= b.nw) return;
         double* out = b.radiance + (size_t(b.w0 + w) * g.nlos + r) * S;
         if (S == 3) {   // configured Stokes basis (OutputC::assign_lane)
@@ -747,6 +770,7 @@ struct SoDeviceEngine::Impl {
     bool single_scatter = true, multiple_scatter = true;
     int capacity = 0, cap_nleg = 0;
     bool cap_derivs = false;
+    const double *d_emission = nullptr, *d_surface_emission = nullptr;
     size_t n_inc_rays = 0, n_inc_layers = 0, n_acc = 0, n_out = 0, n_table = 0, max_rows = 0, n_groups = 0;
     size_t scratch_bytes = 0;
     int last_chunk = 0;
@@ -775,6 +799,9 @@ struct SoDeviceEngine::Impl {
         d.w_exit = tables.upload(r.w_exit);
         d.quad_start = tables.upload(r.quad_start);
         d.quad_end = tables.upload(r.quad_end);
+        d.frac_start = tables.upload(r.frac_start);
+        d.frac_end = tables.upload(r.frac_end);
+        d.distance = tables.upload(r.distance);
         d.tiny = tables.upload(bytes(r.tiny));
         d.mid_idx = tables.upload(r.mid_idx);
         d.mid_w = tables.upload(r.mid_w);
@@ -825,6 +852,8 @@ SoDeviceEngine::SoDeviceEngine(const skso::SoGeometry& sg, int num_iterations) :
     g.S = sg.cfg.nstokes;
     g.num_ss_moments = sg.cfg.num_ss_moments;
     g.num_ms_moments = sg.cfg.num_ms_moments;
+    g.emission = sg.cfg.emission;
+    g.occultation = sg.cfg.occultation ? 1 : 0;
     g.los = I.up(sg.los);
     g.stokes_C = I.tables.upload(sg.stokes_C);
     g.stokes_S = I.tables.upload(sg.stokes_S);
@@ -1018,6 +1047,11 @@ int SoDeviceEngine::nlos() const { return impl_->g.nlos; }
 int SoDeviceEngine::ngrid() const { return impl_->g.ngrid; }
 int SoDeviceEngine::nstokes() const { return impl_->g.S; }
 bool SoDeviceEngine::has_successive_orders() const { return impl_->multiple_scatter; }
+bool SoDeviceEngine::has_unlinearised_sources() const { return impl_->multiple_scatter || impl_->g.emission != 0 || impl_->g.occultation != 0; }
+void SoDeviceEngine::set_emission(const double* d_emission, const double* d_surface_emission) {
+    impl_->d_emission = d_emission;
+    impl_->d_surface_emission = d_surface_emission;
+}
 size_t SoDeviceEngine::scratch_bytes() const { return impl_->scratch_bytes; }
 int SoDeviceEngine::last_chunk() const { return impl_->last_chunk; }
 void SoDeviceEngine::set_profiling(bool on) { impl_->profiling = on; }
@@ -1042,7 +1076,7 @@ size_t SoDeviceEngine::num_outgoing() const { return impl_->n_out; }
 static size_t so_doubles_per_wavelength(const SoDeviceEngine::Impl& I, int nleg) {
     const SoGeo& g = I.g;
     const size_t per = g.S == 3 ? 4 : 1, S = g.S;
-    size_t d = size_t(g.ngrid) * (2 + size_t(nleg) * per);
+    size_t d = size_t(g.ngrid) * (2 + size_t(nleg) * per) + (g.emission ? g.ngrid : 0);
     if (I.multiple_scatter)
         d += I.n_table + size_t(g.ninterior) * g.num_ms_moments * per + 2 * I.n_inc_rays * S + I.n_out * S + I.n_inc_layers * (2 + S) + I.n_inc_rays +
              size_t(g.ninterior) * g.nlm;
@@ -1062,6 +1096,8 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     if (derivs && (!d_wf_ssa || !d_wf_alb)) throw std::runtime_error("sasktran2_amd: weighting functions need all three output buffers");
     if (derivs && !I.single_scatter) throw std::runtime_error("sasktran2_amd: weighting functions requested from an engine without the exact single-scatter source");
     if (derivs && I.multiple_scatter) throw std::runtime_error("sasktran2_amd: the successive-orders source is not linearised");
+    if (derivs && (g.emission || g.occultation)) throw std::runtime_error("sasktran2_amd: the emission / occultation sources are not linearised");
+    if (g.emission && !I.d_emission) throw std::runtime_error("sasktran2_amd: the engine has an emission source but no emission_source array was set (set_emission)");
     // block of wavelengths in flight: half of the free HBM (plus what this engine already holds), balanced blocks, multiple of the wavefront
     const size_t deriv_doubles = derivs ? size_t(g.nlos) * S * (2 * g.ngrid + 1) : 0;
     const size_t per_w = (so_doubles_per_wavelength(I, nleg) + deriv_doubles) * sizeof(double);
@@ -1085,6 +1121,7 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
         b.kT = I.scratch.alloc<double>(size_t(g.ngrid) * W);
         b.omT = I.scratch.alloc<double>(size_t(g.ngrid) * W);
         b.legT = I.scratch.alloc<double>(size_t(g.ngrid) * nlg * W);
+        b.emT = g.emission ? I.scratch.alloc<double>(size_t(g.ngrid) * W) : nullptr;
         if (I.multiple_scatter) {
             b.tab = I.scratch.alloc<double>(I.n_table * W);
             b.cl = I.scratch.alloc<double>(size_t(g.ninterior) * g.num_ms_moments * per * W);
@@ -1111,6 +1148,9 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
         b.leg = d_leg + size_t(w0) * g.ngrid * nleg * per;
         b.albedo = d_albedo + w0;
         b.irradiance = d_irradiance ? d_irradiance + w0 : nullptr;
+        b.emission = I.d_emission ? I.d_emission + size_t(w0) * g.ngrid : nullptr;
+        b.surface_emission = I.d_surface_emission ? I.d_surface_emission + w0 : nullptr;
+        if (!g.emission) b.emT = nullptr;
         b.radiance = d_radiance;
         b.los_od = d_los_od;
         b.accumulate = accumulate;

@@ -28,6 +28,10 @@ class SoDeviceEngine {
                       const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream, int accumulate = 0,
                       double* d_wf_ext = nullptr, double* d_wf_ssa = nullptr, double* d_wf_alb = nullptr);
     bool has_successive_orders() const;
+    bool has_unlinearised_sources() const;   // successive orders, emission or occultation: no weighting functions
+    // emission_source [nwavel][ngrid] and surface emission [nwavel] (DEVICE pointers, or null) used by the following solve_device calls of an
+    // engine built with an emission source
+    void set_emission(const double* d_emission, const double* d_surface_emission);
 
     size_t bytes_per_wavelength() const;
     size_t scratch_bytes() const;

@@ -189,6 +189,8 @@ struct RaySet {
     std::vector<int> stencil_idx;               // [nlayers][4] grid indices (sorted union of the two endpoints), -1 = unused
     std::vector<double> w_entrance, w_exit;     // [nlayers][4] interpolation weights of the layer's entrance (observer side) / exit
     std::vector<double> quad_start, quad_end;   // od_quad_start_fraction * layer_distance, od_quad_end_fraction * layer_distance
+    std::vector<double> frac_start, frac_end;   // od_quad_start_fraction, od_quad_end_fraction (emission sources)
+    std::vector<double> distance;               // layer_distance
     std::vector<char> tiny;                     // layer_distance < MINIMUM_SHELL_SIZE_M: no single-scatter source
     std::vector<int> mid_idx;                   // [nlayers][2] atmosphere stencil of the layer mid point (single-scatter albedo of the diffuse source)
     std::vector<double> mid_w;
@@ -214,6 +216,9 @@ struct Settings {
     int num_sza = 1;               // Config::num_do_sza
     bool single_scatter = true;    // SingleScatterSource::Exact on the lines of sight
     bool multiple_scatter = true;  // MultipleScatterSource::SuccessiveOrdersLegacy
+    // line-of-sight source terms without scattering (cpp/lib/emission/emission_source.cpp, cpp/lib/solar/occultation.cpp)
+    int emission = 0;              // 0 none, 1 EmissionSource::standard ((1 - ssa) x emission_source, e.g. Planck), 2 volume_emission_rate
+    bool occultation = false;      // OccultationSource::standard: unit source behind rays that leave the atmosphere (radiance = transmission)
 };
 
 struct SoGeometry {
@@ -273,6 +278,9 @@ inline void append_rays(const skgeo::Geometry1D& geo, const std::vector<skgeo::T
             }
             rs.quad_start.push_back(fs * L.layer_distance);
             rs.quad_end.push_back(fe * L.layer_distance);
+            rs.frac_start.push_back(fs);
+            rs.frac_end.push_back(fe);
+            rs.distance.push_back(L.layer_distance);
             rs.tiny.push_back(L.layer_distance < kMinimumShellSize ? 1 : 0);
             skgeo::Location mid;
             mid.position = (L.entrance.position + L.exit.position) / 2.0;

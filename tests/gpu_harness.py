@@ -81,6 +81,9 @@ def build_so_engine(s, **override):
     config.num_successive_orders_incoming = c["num_incoming"]
     config.num_successive_orders_outgoing = c["num_outgoing"]
     config.init_successive_orders_with_discrete_ordinates = False
+    config.emission_source = {"none": sk.EmissionSource.NoSource, "standard": sk.EmissionSource.Standard,
+                              "volume_emission_rate": sk.EmissionSource.VolumeEmissionRate}[c.get("emission", "none")]
+    config.occultation_source = sk.OccultationSource.Standard if c.get("occultation", False) else sk.OccultationSource.NoSource
     geometry = sk.Geometry1D(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"],
                              sk.InterpolationMethod(g["interp_method"]), sk.GeometryType(g["geotype"]))
     viewing = sk.ViewingGeometry()
@@ -96,7 +99,7 @@ def build_so_engine(s, **override):
     return sk.Engine(config, geometry, viewing), config, geometry
 
 
-def run_product_so(s, engine=None, solar_irradiance=None, derivatives=False, **override):
+def run_product_so(s, engine=None, solar_irradiance=None, derivatives=False, emission_source=None, surface_emission=None, **override):
     """Radiances [wavelength, los, stokes] and LOS optical depths of the exact single-scatter / successive-orders path; with
     `derivatives` the weighting functions in the oracle's convention ([wavelength, los, stokes, altitude])."""
     engine, config, geometry = engine if engine is not None else build_so_engine(s, **override)
@@ -107,6 +110,10 @@ def run_product_so(s, engine=None, solar_irradiance=None, derivatives=False, **o
     atmosphere.storage.leg_coeff[:] = s["leg"]
     if solar_irradiance is not None:
         atmosphere.storage.solar_irradiance[:] = solar_irradiance
+    if emission_source is not None:
+        atmosphere.storage.emission_source[:] = emission_source
+    if surface_emission is not None:
+        atmosphere.surface.emission[:] = surface_emission
     atmosphere.surface.albedo[:] = s["albedo"]
     res = engine.calculate_radiance(atmosphere, as_dataset=False)
     out = {"radiance": res["radiance"], "los_optical_depth": res["los_optical_depth"]}

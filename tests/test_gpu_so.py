@@ -143,3 +143,26 @@ def test_weighting_functions_of_discrete_ordinates_plus_exact_single_scatter(nst
            "d_ssa": ss["d_ssa"] + do["d_ssa"].reshape(ss["d_ssa"].shape), "d_albedo": ss["d_albedo"] + do["d_albedo"].reshape(shape)}
     assert_so_parity(got, ref)
     assert_so_wf_parity(got, ref)
+
+
+@pytest.mark.parametrize("nstokes", [1, 3])
+@pytest.mark.parametrize("emission", ["standard", "volume_emission_rate"])
+def test_emission_and_occultation_sources_match_oracle(nstokes, emission):
+    """emission_source = standard / volume_emission_rate and occultation_source = standard next to the exact single scatter and the
+    successive orders (cpp/lib/emission/emission_source.cpp, cpp/lib/solar/occultation.cpp): the line-of-sight terms add up."""
+    from tests.test_so_oracle import make_so_oracle
+    s = sc.regression_so(nstokes=nstokes, num_wavelengths=3)
+    alt = s["geometry"]["altitudes"]
+    em = 3.0e-4 * np.exp(-alt / 12_000.0)[:, None] * np.linspace(0.7, 1.4, 3)[None, :]
+    sem = np.linspace(1.0e-4, 7.0e-4, 3)
+    o = dict(emission=emission, occultation=True)
+    ref = make_so_oracle(s, **o).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], emission=em, surface_emission=sem)
+    got = run_product_so(s, emission_source=em, surface_emission=sem, **o)
+    assert_so_parity(got, ref)
+    # the sources alone (no scattering source at all): thermal emission + transmission
+    alone = dict(o, single_scatter="none", multiple_scatter="none")
+    ref = make_so_oracle(s, **alone).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], emission=em, surface_emission=sem)
+    got = run_product_so(s, emission_source=em, surface_emission=sem, **alone)
+    assert_so_parity(got, ref)
+    with pytest.raises(RuntimeError, match="weighting functions are not available"):
+        run_product_so(s, emission_source=em, surface_emission=sem, derivatives=True, **alone)

@@ -13,7 +13,9 @@ def make_so_oracle(s, **override):
                           nstokes=c["nstokes"], stokes_basis=c.get("stokes_basis", 0), num_ss_moments=c["num_singlescatter_moments"],
                           num_ms_moments=c["num_streams"], num_incoming=c["num_incoming"], num_outgoing=c["num_outgoing"],
                           num_sza=c["num_sza"], num_iterations=c["num_iterations"], single_scatter=c["single_scatter"] == "exact",
-                          multiple_scatter=c["multiple_scatter"] == "successive_orders_legacy")
+                          multiple_scatter=c["multiple_scatter"] == "successive_orders_legacy",
+                          emission={"none": 0, "standard": 1, "volume_emission_rate": 2}[c.get("emission", "none")],
+                          occultation=bool(c.get("occultation", False)))
 
 
 def run_so_oracle(s, nthreads=2, **override):
@@ -115,3 +117,34 @@ def test_exact_single_scatter_weighting_functions_match_finite_differences(nstok
     # the diffuse source is not linearised: the oracle refuses as the product does
     with pytest.raises(RuntimeError):
         make_so_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
+
+
+def test_emission_and_occultation_sources_have_their_closed_forms():
+    """Line-of-sight sources without scattering (cpp/lib/emission/emission_source.cpp, cpp/lib/solar/occultation.cpp): an occultation gives
+    the transmission e^-tau of rays that leave the atmosphere; an isothermal, non-scattering atmosphere emits B (1 - e^-tau) (+ the
+    attenuated surface emission behind rays that end on the ground); a uniform volume emission rate in a transparent atmosphere
+    integrates to rate x path length."""
+    s = sc.regression_so(nstokes=1)
+    nothing = dict(single_scatter="none", multiple_scatter="none")
+    od = make_so_oracle(s, **nothing, occultation=True).run(s["extinction"], s["ssa"], s["leg"], s["albedo"])
+    hits_ground = np.array([True, True, False, False])
+    np.testing.assert_allclose(od["radiance"][:, ~hits_ground, 0], np.exp(-od["los_optical_depth"][:, ~hits_ground]), rtol=1e-13)
+    assert np.all(od["radiance"][:, hits_ground, 0] == 0)
+    B, Bs = 3.0e-4, 7.0e-4
+    em = make_so_oracle(s, **nothing, emission="standard").run(s["extinction"], np.zeros_like(s["ssa"]), s["leg"], s["albedo"],
+                                                              emission=np.full_like(s["ssa"], B), surface_emission=np.full(2, Bs))
+    tau = em["los_optical_depth"]
+    want = B * (1 - np.exp(-tau)) + np.where(hits_ground[None, :], Bs * np.exp(-tau), 0.0)
+    np.testing.assert_allclose(em["radiance"][..., 0], want, rtol=1e-12)
+    # scattering removes (1 - ssa) of the thermal source
+    half = make_so_oracle(s, **nothing, emission="standard").run(s["extinction"], np.full_like(s["ssa"], 0.25), s["leg"], s["albedo"],
+                                                                emission=np.full_like(s["ssa"], B), surface_emission=np.zeros(2))
+    np.testing.assert_allclose(half["radiance"][..., 0], 0.75 * B * (1 - np.exp(-tau)), rtol=1e-12)
+    thin = make_so_oracle(s, **nothing, emission="volume_emission_rate").run(s["extinction"] * 1e-12, s["ssa"], s["leg"], s["albedo"],
+                                                                            emission=np.full_like(s["ssa"], 2.0), surface_emission=np.zeros(2))
+    alt = s["geometry"]["altitudes"]
+    R, top = s["geometry"]["earth_radius"], alt[-1]
+    # nadir rays: path = chord from the ground to the top of the atmosphere at the viewing zenith angle
+    for r, cvz in ((0, 0.32), (1, 0.78)):
+        path = -R * cvz + np.sqrt((R * cvz) ** 2 + 2 * R * top + top * top)
+        np.testing.assert_allclose(thin["radiance"][:, r, 0], 2.0 * path, rtol=1e-9)
