@@ -53,6 +53,9 @@ struct AtmosphereView {
     const double* solar_irradiance = nullptr;  // [nwavel] (nullptr -> 1)
     const double* albedo = nullptr;      // [nwavel] Lambertian
     const double* delta_f = nullptr;     // [ngrid, nwavel] delta-M truncation fraction of the (already scaled) storage, or null
+    // EmissionSource::discrete_ordinates (plane-parallel post-processing only, radiances only): thermal source inside the DO equations
+    const double* emission = nullptr;          // [ngrid, nwavel] emission_source of the storage, or null
+    const double* surface_emission = nullptr;  // [nwavel], or null
     bool derivatives = false;
     double k(int q, int w) const { return extinction[size_t(w) * ngrid + q]; }
     double om(int q, int w) const { return ssa[size_t(w) * ngrid + q]; }
@@ -76,6 +79,10 @@ class Solver {
     int ND = 0;       // DO-internal derivative count
     int nnative = 0;  // native derivative count
     bool include_ss;  // single scatter inside DO (plane parallel only)
+    // thermal source S(x) = b0 exp(-b1 x) per layer (sktran_do_layerarray.cpp:340-475), its Green's-function coefficients, surface emission
+    bool thermal = false;
+    std::vector<double> th_b0, th_b1, Ap_th, Am_th;
+    double surf_emission = 0;
 
     // ---- per wavelength layer state
     std::vector<double> tau, ssa, totext, scatext, od_ceil, od_floor, a;  // a[(p*nstr+l)*4 + {a1,a2,a3,b1}]
@@ -254,6 +261,22 @@ class Solver {
             od_floor[p] = floor_depth;
             tau[p] = floor_depth - ceiling_depth;
             ceiling_depth = floor_depth;
+        }
+        thermal = atm.emission != nullptr;
+        if (thermal) {
+            if (ND) throw std::invalid_argument("the oracle's thermal source is not linearised");
+            if (G.spherical_pp) throw std::invalid_argument("the discrete-ordinates thermal source needs plane-parallel post-processing");
+            th_b0.assign(nlyr, 0.0); th_b1.assign(nlyr, 0.0); Ap_th.assign(size_t(nlyr) * n, 0.0); Am_th.assign(size_t(nlyr) * n, 0.0);
+            surf_emission = atm.surface_emission ? atm.surface_emission[w] : 0.0;
+            for (int p = 0; p < nlyr; ++p) {
+                int min_q = -1, max_q = -1;
+                for (int q = 0; q < ngrid; ++q)
+                    if (G.W(p, q) > 0) { if (min_q < 0) min_q = q; max_q = q; }
+                const double top = max_q >= 0 ? atm.emission[size_t(w) * ngrid + max_q] : 0.0;
+                const double bot = (min_q >= 0 && min_q != max_q) ? atm.emission[size_t(w) * ngrid + min_q] : top;
+                th_b0[p] = top;
+                if (tau[p] > 1e-10 && top > 1e-30 && bot > 1e-30 && std::abs(top - bot) > 1e-15 * std::max(top, bot)) th_b1[p] = std::log(top / bot) / tau[p];
+            }
         }
         albedo = atm.albedo ? atm.albedo[w] : 0.0;
         F0 = atm.solar_irradiance ? atm.solar_irradiance[w] : 1.0;
@@ -481,6 +504,7 @@ class Solver {
             std::memset(dG(dGmt, p, 0), 0, sizeof(double) * ND * n);
             std::memset(dG(dGmb, p, 0), 0, sizeof(double) * ND * n);
         }
+        if (thermal && m == 0) thermal_particular(p);
         if (allzero) return;
         const double T = trans[p], sc = sec[p], th = tau[p];
         const double* dT = &dtrans[size_t(p) * ND];
@@ -582,6 +606,42 @@ class Solver {
         }
     }
 
+    // thermal particular solution (RTESolver::solveParticularGreenThermal, sktran_do_rte.cpp:1335-1618): the solar one with Q+ = Q- = w (1 - ssa)
+    // on the intensity rows, b0 for the beam transmission and b1 for the average secant; added to the G vectors (values only)
+    void thermal_particular(int p) {
+        const double b0 = th_b0[p], b1 = th_b1[p], th = tau[p];
+        const double exp_tb = std::exp(-th * b1);
+        double* gpt = &Gpt[size_t(p) * n]; double* gpb = &Gpb[size_t(p) * n];
+        double* gmt = &Gmt[size_t(p) * n]; double* gmb = &Gmb[size_t(p) * n];
+        for (int i = 0; i < n; ++i) {
+            double norm = 0, Apv = 0, Amv = 0;
+            for (int j = 0; j < n; j += S) {
+                const double Q = G.wt[j / S] * (1.0 - ssa[p]);
+                const double hp = Wp[hidx(p, j, i)], hm = Wm[hidx(p, j, i)];
+                norm += G.wt[j / S] * G.mu[j / S] * (hp * hp - hm * hm);
+                Apv += Q * hp + Q * hm;
+                Amv += Q * hp + Q * hm;
+            }
+            Apv /= norm;
+            Amv /= norm;
+            Ap_th[size_t(p) * n + i] = Apv;
+            Am_th[size_t(p) * n + i] = Amv;
+            const double ev = eigk[size_t(p) * n + i], exp_te = std::exp(-th * ev);
+            double Cp, Cm;
+            if (std::abs(b1 - ev) > kGreensEps) Cp = b0 * (exp_te - exp_tb) / (b1 - ev);
+            else Cp = b0 * exp_te * th * (1 - th / 2 * (b1 - ev));
+            if (std::abs(b1 + ev) > kGreensEps) Cm = b0 * (1 - exp_tb * exp_te) / (b1 + ev);
+            else Cm = b0 * th * (1 - th / 2 * (b1 + ev));
+            for (int j = 0; j < n; j += S) {
+                const double ng = neg(j), hp = Wp[hidx(p, j, i)], hm = Wm[hidx(p, j, i)];
+                gpt[j] += Amv * Cm * hm;
+                gmt[j] += ng * Amv * Cm * hp;
+                gpb[j] += Apv * Cp * hp;
+                gmb[j] += ng * Apv * Cp * hm;
+            }
+        }
+    }
+
     // ------------------------------------------------------------------ boundary value problem
     double rho(int m) const { return m == 0 ? albedo : 0.0; }  // Lambertian, max_azimuthal_order == 1
     // the Lambertian surface reflects the intensity only, into the intensity only (v_plus/v_minus, sktran_do_rte.h:116-150)
@@ -643,9 +703,9 @@ class Solver {
                     bvp.at(r0 + i, c0 + j) = ng * vm * E(p, j);
                     bvp.at(r0 + i, c0 + n + j) = ng * vp;
                 }
-                double direct = 0, um = Gmb[size_t(p) * n + i];
+                double direct = (thermal && m == 0) ? surf_emission : 0.0, um = Gmb[size_t(p) * n + i];   // ground_direct_sun, sktran_do_rte.h:222-245
                 if (rr) {
-                    direct = G.csz[cur_sza] * rho(m) / kPi * trans[nlyr];
+                    direct += G.csz[cur_sza] * rho(m) / kPi * trans[nlyr];
                     for (int s = 0; s < N; ++s) um -= kd * rho(m) * G.wt[s] * G.mu[s] * Gpb[size_t(p) * n + s * S];
                 }
                 rhs[size_t(r0 + i) * nr] = direct - um;
@@ -882,6 +942,7 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
             if (include_ss) {
                 double direct = G.csz[cur_sza] / kPi * trans[nlyr] * rho(m);
                 comp[0] = direct + diffuse;
+                if (thermal && m == 0) comp[0] += surf_emission;   // sktran_do_layerarray.cpp:255-266
                 for (int d = 0; d < ND; ++d) comp_d[size_t(d) * S] = G.csz[cur_sza] / kPi * dtrans[size_t(nlyr) * ND + d] * rho(m) + diffuse_d[d];
                 for (int k = 0; k < nk; ++k) comp_d[size_t(ls + k) * S] += G.csz[cur_sza] / kPi * trans[nlyr] * d_alb(k);
             } else {
@@ -933,6 +994,11 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
                     dEf[d] = dT[d] / den * (e1 - e2) + dsc[d] * ((T / den * e2 * th) - (Ef / den * mu) + (T / den * e1 * (-1.0 * x)));
                 for (int k = 0; k < nk; ++k)
                     dEf[ls + k] += T / den * (e2 * d_od(k) * (sc + lf / mu) - e1 * d_od(k) * (1 - lf) * sc);
+            }
+            double Ef_th = 0;   // E_thermal (sktran_do_opticallayer.cpp:941-975): E with b0 for the transmission and b1 for the secant
+            if (thermal && m == 0) {
+                const double b0 = th_b0[p], b1 = th_b1[p];
+                Ef_th = b0 / (1.0 + mu * b1) * (std::exp(-x * b1) - std::exp(-1.0 * th * b1) * std::exp(-1.0 * (th - x) / mu));
             }
             double J[3] = {0, 0, 0}, V[3] = {0, 0, 0};
             std::fill(integ_d.begin(), integ_d.end(), 0.0);
@@ -989,10 +1055,17 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
                     dDm[ls + k] += dhp[k] * T / (sc - ev) + dk * Dm / (sc - ev);
                 }
                 const double Apv = Ap[size_t(p) * n + i], Amv = Am[size_t(p) * n + i];
+                double Dm_th = 0, Dp_th = 0;
+                if (thermal && m == 0) {   // sktran_do_opticallayer.cpp:421-431
+                    const double b0 = th_b0[p], b1 = th_b1[p];
+                    Dp_th = (-1 * b0 * std::exp(-th * b1) * hm + Ef_th) / (b1 + ev);
+                    Dm_th = (b0 * hp - Ef_th) / (b1 - ev);
+                }
                 for (int s = 0; s < S; ++s) {
                     const double yp = Yp[size_t(s) * n + i], ym = Ym[size_t(s) * n + i];
                     J[s] += yp * hp * Lv + ym * hm * Mv;
                     V[s] += Apv * yp * Dm + Amv * ym * Dp;
+                    if (thermal && m == 0) V[s] += Ap_th[size_t(p) * n + i] * yp * Dm_th + Am_th[size_t(p) * n + i] * ym * Dp_th;
                     for (int k = 0; k < nk; ++k) {
                         const double dyp = dYp[(size_t(k) * S + s) * n + i], dym = dYm[(size_t(k) * S + s) * n + i];
                         double& t = integ_d[size_t(ls + k) * S + s];
@@ -1007,6 +1080,7 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
             }
             for (int s = 0; s < S; ++s) {
                 double integral = J[s] + V[s] + Q[s] * Ef;
+                if (thermal && m == 0 && s == 0) integral += Ef_th * (1 - ssa[p]);   // sktran_do_opticallayer.cpp:513-521
                 for (int k = 0; k < nk; ++k) integ_d[size_t(ls + k) * S + s] += dQ[k][s] * Ef;
                 for (int d = 0; d < ND; ++d) integ_d[size_t(d) * S + s] += Q[s] * dEf[d];
                 comp[s] += integral;

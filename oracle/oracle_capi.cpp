@@ -20,6 +20,7 @@ struct Handle {
     skgeo::DiscoGeometry dg;
     int ss_in_do = 1;
     const double* delta_f = nullptr;
+    const double *emission = nullptr, *surface_emission = nullptr;
     std::string error;
 };
 }  // namespace
@@ -78,6 +79,14 @@ int orc_set_delta_f(void* hv, const double* f) {
     h->delta_f = f;
     return 0;
 }
+// thermal source of the discrete-ordinates equations for the next orc_run calls: emission_source [ngrid, nwavel], surface emission [nwavel]
+int orc_set_emission(void* hv, const double* emission, const double* surface_emission) {
+    auto* h = static_cast<Handle*>(hv);
+    if (!h) return -1;
+    h->emission = emission;
+    h->surface_emission = surface_emission;
+    return 0;
+}
 int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg,
             const double* solar_irradiance, const double* albedo, int derivatives, int nthreads, double* radiance,
             double* d_k, double* d_ssa, double* d_albedo, double* los_od, int* n_azimuth) {
@@ -95,6 +104,8 @@ int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
     atm.solar_irradiance = solar_irradiance;
     atm.albedo = albedo;
     atm.delta_f = h->delta_f;
+    atm.emission = h->emission;
+    atm.surface_emission = h->surface_emission;
     atm.derivatives = derivatives != 0;
     int status = 0;
 #ifdef _OPENMP

@@ -40,6 +40,7 @@ def lib():
         L.orc_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int,
                               ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _ip]
         L.orc_set_delta_f.argtypes = [ctypes.c_void_p, _dp]
+        L.orc_set_emission.argtypes = [ctypes.c_void_p, _dp, _dp]
         L.orc_num_sza.argtypes = [ctypes.c_void_p]
         L.orc_chapman.argtypes = [ctypes.c_void_p, _dp]
         L.orc_streams.argtypes = [ctypes.c_void_p, _dp, _dp]
@@ -85,7 +86,8 @@ class OracleEngine:
         lib().orc_streams(self._h, _p(mu), _p(wt))
         return mu, wt
 
-    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, derivatives=False, nthreads=1, delta_f=None):
+    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, derivatives=False, nthreads=1, delta_f=None, emission=None,
+            surface_emission=None):
         """extinction, ssa: [ngrid, nwavel]; leg: [nleg, ngrid, nwavel] (nstokes = 3: [4 * nleg, ngrid, nwavel] with
         a1, a2, a3, b1 per order); albedo: [nwavel] (Fortran-style axes as in the reference storage: location fastest).
         Outputs carry a trailing Stokes axis for nstokes = 3 (radiance [nwavel, nlos, 3], d_* [nwavel, nlos, 3, ngrid])."""
@@ -95,6 +97,9 @@ class OracleEngine:
         nwavel = k.shape[1]
         df = None if delta_f is None else np.asfortranarray(delta_f, dtype=np.float64)
         lib().orc_set_delta_f(self._h, _p(df))
+        em = None if emission is None else np.asfortranarray(emission, dtype=np.float64)
+        sem = None if surface_emission is None else np.ascontiguousarray(surface_emission, dtype=np.float64)
+        lib().orc_set_emission(self._h, _p(em), _p(sem))   # EmissionSource::discrete_ordinates (plane parallel, radiances only)
         alb = np.ascontiguousarray(albedo, dtype=np.float64)
         irr = None if solar_irradiance is None else np.ascontiguousarray(solar_irradiance, dtype=np.float64)
         S = self.nstokes

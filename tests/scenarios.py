@@ -222,3 +222,19 @@ def limb_c5(num_wavelengths: int = 20_000, nlyr: int = 50, num_iterations: int =
                        num_incoming=num_directions, num_outgoing=num_directions, single_scatter="exact",
                        multiple_scatter="successive_orders_legacy")
     return s
+
+
+def disort_thermal(surface: bool):
+    """The reference's two DISORT thermal-emission pins (tests/engine/thermal_emissions/test_disort.py:7-112, DISORT test case 7a with
+    modifications): one plane-parallel layer of 1 km, Henyey-Greenstein g = 0.75 with 17 moments, ssa 0.95, 16 streams, delta-M scaling,
+    no sun, emission_source = 1.09657540e-05 everywhere; nadir view.  optical depth 100 without / 1 with surface emission."""
+    od = 1.0 if surface else 100.0
+    alt = np.array([0.0, 1000.0])
+    k = np.full((2, 1), od / 1000.0)
+    ssa = np.full((2, 1), 0.95)
+    leg = ((0.75 ** np.arange(17)) * (2 * np.arange(17) + 1))[:, None, None] * np.ones((1, 2, 1))
+    geometry = dict(cos_sza=0.6, saa=0.0, earth_radius=6_372_000.0, altitudes=alt, interp_method=INTERP_LINEAR, geotype=GEO_PLANEPARALLEL)
+    return dict(geometry=geometry, config=dict(nstr=16, num_sza=1), rays=[(GROUND_VIEWING_SOLAR, 0.6, 0.0, 200_000.0, 1.0)],
+                extinction=k, ssa=ssa, leg=leg, albedo=np.zeros(1), solar_irradiance=np.zeros(1),
+                emission=np.full((2, 1), 1.09657540e-05), surface_emission=np.array([1.09657540e-05 if surface else 0.0]),
+                expected=1.02396134e-05 if surface else 7.93075833e-06, rtol=1e-6)

@@ -148,3 +148,14 @@ def test_vector_spherical_weighting_functions_match_finite_differences():
     h = 1e-5
     fd = (run_oracle(s, albedo=s["albedo"] + h)["radiance"] - run_oracle(s, albedo=s["albedo"] - h)["radiance"]) / (2 * h)
     np.testing.assert_allclose(out["d_albedo"], fd, rtol=1e-5, atol=1e-11)
+
+
+@pytest.mark.parametrize("surface", [False, True], ids=["atmosphere only, optical depth 100", "with surface emission, optical depth 1"])
+def test_disort_thermal_emission_pins(surface):
+    """tests/engine/thermal_emissions/test_disort.py:7-112: emission_source = discrete_ordinates (thermal source inside the DO equations,
+    sktran_do_rte.cpp:1335-1618), values generated with DISORT (test case 7a), rtol 1e-6."""
+    s = sc.disort_thermal(surface)
+    d = sc.delta_m_scaled(s)
+    r = make_oracle(d).run(d["extinction"], d["ssa"], d["leg"], d["albedo"], solar_irradiance=s["solar_irradiance"], delta_f=d["delta_f"],
+                           emission=s["emission"], surface_emission=s["surface_emission"])
+    np.testing.assert_allclose(r["radiance"][0, 0], s["expected"], rtol=s["rtol"])
