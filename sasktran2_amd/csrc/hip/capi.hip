@@ -367,8 +367,11 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
             c->num_do_forced_azimuth >= 0 || c->num_do_spherical_iterations > 0 || c->do_backprop)
             throw std::runtime_error("refraction, forced azimuth count, DO spherical iterations and backprop are not part of this build");
         // EmissionSource { standard = 0, none = 1, discrete_ordinates = 2, volume_emission_rate = 3, twostream = 4 }, OccultationSource { standard = 0, none = 1 }
-        if (c->emission_source != 0 && c->emission_source != 1 && c->emission_source != 3)
-            throw std::runtime_error("emission_source must be standard (0), none (1) or volume_emission_rate (3); discrete_ordinates (2) and twostream (4) are not part of this build");
+        if (c->emission_source < 0 || c->emission_source > 3)
+            throw std::runtime_error("emission_source must be standard (0), none (1), discrete_ordinates (2) or volume_emission_rate (3); twostream (4) is not part of this build");
+        if (c->emission_source == 2 && (c->ms_source != 0 || c->num_stokes != 1 || g->geotype == 2))
+            throw std::runtime_error("emission_source = discrete_ordinates needs multiple_scatter_source = discrete_ordinates, NSTOKES = 1 and plane-parallel / "
+                                     "pseudo-spherical geometry (the reference's thermal post-processing exists for the plane-parallel source only)");
         if (c->occultation_source != 0 && c->occultation_source != 1) throw std::runtime_error("occultation_source must be standard (0) or none (1)");
         const int emission = c->emission_source == 0 ? 1 : (c->emission_source == 3 ? 2 : 0);
         const bool occultation = c->occultation_source == 0;
@@ -384,6 +387,8 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
             e->dev = std::make_unique<skdev::DeviceEngine>(dg, c->ss_source == 2);
             e->nlos = dg.nlos;
             e->ngrid = dg.ngrid;
+            if (c->emission_source == 2 && e->dev->vector_mode())
+                throw std::runtime_error("emission_source = discrete_ordinates needs a stream count of the matrix-core path (2, 4, 8, 16 or 32)");
             if (c->ss_source == 0 && !dg.spherical_pp)
                 throw std::runtime_error("single_scatter_source = exact with discrete ordinates needs spherical geometry (in plane-parallel "
                                          "geometry the discrete-ordinates source carries the single scatter itself)");
@@ -741,9 +746,25 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
             HIPC(hipMemcpy(d_f, st.delta_f.data(), nloc_w * 8, hipMemcpyHostToDevice));
         }
         e->dev->set_delta_m_fraction(d_f);
+        if (e->config.emission_source == 2) {   // thermal source inside the DO equations
+            if (derivs) {
+                set_error("sk_engine_calculate_radiance: weighting functions are not available with emission_source = discrete_ordinates in this build");
+                return -2;
+            }
+            if (!st.emission) throw std::runtime_error("emission_source = discrete_ordinates but the atmosphere storage has no emission_source array");
+            double* d_em = (double*)C.get("do_emission", nloc_w * 8);
+            HIPC(hipMemcpy(d_em, st.emission, nloc_w * 8, hipMemcpyHostToDevice));
+            double* d_sem = nullptr;
+            if (su.emission) {
+                d_sem = (double*)C.get("do_surface_emission", size_t(nw) * 8);
+                HIPC(hipMemcpy(d_sem, su.emission, size_t(nw) * 8, hipMemcpyHostToDevice));
+            }
+            e->dev->set_thermal_emission(d_em, d_sem);
+        }
         e->dev->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status,
                              nullptr, 0);
         e->dev->set_delta_m_fraction(nullptr);
+        e->dev->set_thermal_emission(nullptr, nullptr);
         // single_scatter_source = exact on top of the discrete-ordinates multiple scatter: radiance and native weighting functions are
         // accumulated on the device before the user mappings are applied
         if (e->so) {

@@ -113,6 +113,10 @@ struct Bufs {
     const double* albedo;   // [w]
     const double* irradiance;  // [w] or null
     const double* delta_f;  // [w][q] delta-M truncation fraction of the (already scaled) storage, or null
+    // thermal pass (EmissionSource::discrete_ordinates, plane-parallel post-processing): emission_source [w][q], surface emission [w]
+    const double* emission;
+    const double* surf_em;  // surface emission [w] or null, set only while the thermal pass runs
+    int thermal_pass;       // 1 while the thermal pass runs
     int nleg;
     // layer optics (K0)
     double* tau;            // [p][w]
@@ -256,6 +260,35 @@ SKD_HD void k0_transmission(const Geo& g, const Bufs& b, int s, int w) {
         b.T[size_t(p + 1) * nw + w] = exp(-sig) * F0;
         prev = sig;
     }
+}
+
+// Thermal source of the discrete-ordinates equations, S(x) = (1 - omega) b0 exp(-b1 x) per layer with b0 the emission at the layer's
+// ceiling and b1 = ln(B_top / B_bottom) / tau (sktran_do_layerarray.cpp:340-475).  Its Green's-function particular solution
+// (RTESolver::solveParticularGreenThermal, sktran_do_rte.cpp:1335-1618), post-processing multipliers (sktran_do_opticallayer.cpp:421-431,
+// 941-975) and direct term (1 - omega) E_thermal (:513-521) are the SOLAR ones with b0 in place of the beam transmission, b1 in place of
+// the average secant and Q+ = Q- = w_i (1 - omega).  The solar kernels compute Q = w_i omega / (4 pi) sum_l a_l P_l(mu_i) P_l(mu_0), so
+// the thermal pass reuses them unchanged at order 0 with the "sun" Legendre row (1, 0, 0, ...) of the extra solar index (a_0 = 1) and
+//     T[p]   <- b0_p (1 - omega_p) 4 pi / omega_p,      sec[p] <- b1_p
+// written over the beam arrays once the solar orders are done.  (task = wavelength)
+SKD_HD void k0_thermal(const Geo& g, const Bufs& b, int w) {
+    const int nw = b.nw, nlyr = g.nlyr;
+    const double* em = b.emission + size_t(w) * g.ngrid;
+    for (int p = 0; p < nlyr; ++p) {
+        int lo = -1, hi = -1;
+        for (int t = 0; t < 2; ++t) {
+            const int q = g.wq_idx[2 * p + t];
+            if (q < 0) continue;
+            if (lo < 0 || q < lo) lo = q;
+            if (q > hi) hi = q;
+        }
+        const double top = hi >= 0 ? em[hi] : 0.0, bot = (lo >= 0 && lo != hi) ? em[lo] : top;
+        const double th = b.tau[size_t(p) * nw + w], om = b.om[size_t(p) * nw + w];
+        double b1 = 0.0;
+        if (th > 1e-10 && top > 1e-30 && bot > 1e-30 && fabs(top - bot) > 1e-15 * fmax(top, bot)) b1 = log(top / bot) / th;
+        b.T[size_t(p) * nw + w] = top * (1 - om) * (4.0 * kPi) / om;
+        b.sec[size_t(p) * nw + w] = b1;
+    }
+    b.T[size_t(nlyr) * nw + w] = 0.0;
 }
 
 // =================================================================================================
@@ -645,7 +678,7 @@ template <int N> SKD_HD void k2a_bvp(const Geo& g, const Bufs& b, int s, int m, 
                 }
                 double sg = 0;
                 for (int t = 0; t < N; ++t) sg += g.wt[t] * g.mu[t] * c(R::G + 2 * N + t);
-                const double direct = g.csz[s] * rho / kPi * b.T[size_t(nlyr) * nw + w];
+                const double direct = g.csz[s] * rho / kPi * b.T[size_t(nlyr) * nw + w] + (b.surf_em ? b.surf_em[w] : 0.0);   // + surface emission (thermal pass)
                 for (int i = 0; i < N; ++i) r[N + i] += direct + kd * rho * sg;
             }
         } else {
@@ -1217,7 +1250,9 @@ template <int N> SKD_HD void kpp_los(const Geo& g, const Bufs& b, int s, int m, 
                 lp[r] *= 0.5 * om * g.wt[r];
                 lm[r] *= 0.5 * om * g.wt[r];
             }
-            const double Q = g.include_ss ? q * fm * om : 0.0;
+            // thermal pass: Q E is the direct emission term (1 - omega) E_thermal, present whatever the single-scatter source
+            // (sktran_do_opticallayer.cpp:513-521)
+            const double Q = (g.include_ss || b.thermal_pass) ? q * fm * om : 0.0;
             PPBeam E;
             pp_beam_multiplier(mu, lf, th, T, sc, E);
             double S = Q * E.v;
@@ -1287,7 +1322,8 @@ template <int N> SKD_HD void kpp_los(const Geo& g, const Bufs& b, int s, int m, 
             ipb += g.wt[i] * g.mu[i] * v;
         }
         const double direct = g.include_ss ? g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w] : 0.0;
-        ground = Aab * rho * (2.0 * ipb + direct);
+        // thermal pass: the surface emission joins the reflected intensity where the direct bounce does (sktran_do_layerarray.cpp:255-266)
+        ground = Aab * (rho * (2.0 * ipb + direct) + ((g.include_ss && b.surf_em) ? b.surf_em[w] : 0.0));
         total += ground;
         if (b.derivs) {
             t.gw = Aab;

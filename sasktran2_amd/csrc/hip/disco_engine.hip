@@ -93,6 +93,11 @@ __global__ void __launch_bounds__(kBlock) kern_k0t(Geo g, Bufs b, int s) {
     b.norders[w] = g.nstr;
     b.notconv[w] = 0;
 }
+__global__ void __launch_bounds__(kBlock) kern_k0_thermal(Geo g, Bufs b) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= b.nw) return;
+    skd::k0_thermal(g, b, w);
+}
 __global__ void __launch_bounds__(kBlock) kern_stop(Geo g, Bufs b, int s, int m, int* active) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= b.nw) return;
@@ -187,6 +192,7 @@ struct DeviceEngine::Impl {
         DevMem mem;
         Bufs b{};
         int* d_active = nullptr;
+        const double* thermal_surface = nullptr;   // surface emission of the block in flight (thermal pass)
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
         // look-ahead of the layer solutions: K1 of order m+1 only needs the layer optics, so it runs on its own stream into
@@ -203,6 +209,7 @@ struct DeviceEngine::Impl {
     int chunk_capacity = 0;
     int last_chunk = 0, last_slots = 0;
     const double* delta_f = nullptr;
+    const double *thermal_emission = nullptr, *thermal_surface = nullptr;   // EmissionSource::discrete_ordinates inputs (device) or null
     bool profiling = false;
     std::map<std::string, std::pair<double, long>> times;  // name -> (ms, launches)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -269,6 +276,10 @@ int DeviceEngine::ngrid() const { return impl_->tab.ngrid; }
 int DeviceEngine::nstr() const { return impl_->tab.nstr; }
 size_t DeviceEngine::scratch_bytes() const { return impl_->scratch_bytes; }
 void DeviceEngine::set_delta_m_fraction(const double* d_f) { impl_->delta_f = d_f; }
+void DeviceEngine::set_thermal_emission(const double* d_emission, const double* d_surface_emission) {
+    impl_->thermal_emission = d_emission;
+    impl_->thermal_surface = d_surface_emission;
+}
 int DeviceEngine::last_chunk() const { return impl_->last_chunk; }
 int DeviceEngine::last_slots() const { return impl_->last_slots; }
 void DeviceEngine::set_profiling(bool on) { impl_->profiling = on; }
@@ -446,6 +457,18 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
         if (derivs) {
             Timer t(I, st, "k4a_chain");
             hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, 0);
+        }
+        if (b.emission) {
+            // thermal pass (skd::k0_thermal): the order-0 solve once more with the thermal "beam" in T / sec and the isotropic Legendre row
+            // of the extra solar index; radiances accumulate in kpp_los
+            Timer t(I, st, "thermal_pass");
+            Bufs bt = b;
+            bt.thermal_pass = 1;
+            bt.surf_em = slot.thermal_surface;
+            hipLaunchKernelGGL(kern_k0_thermal, dim3(blocks(nw)), dim3(kBlock), 0, st, g, bt);
+            launch_k1<N>(st, g, bt, g.nsza, 0);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, bt, g.nsza, 0);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_kpp<N>), dim3(blocks(nt)), dim3(kBlock), 0, st, g, bt, g.nsza, 0);
         }
         HIP_CHECK(hipGetLastError());
         return;
@@ -639,6 +662,11 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
         b.albedo = d_albedo + w0;
         b.irradiance = d_irradiance ? d_irradiance + w0 : nullptr;
         b.delta_f = I.delta_f ? I.delta_f + size_t(w0) * t.ngrid : nullptr;
+        b.emission = I.thermal_emission ? I.thermal_emission + size_t(w0) * t.ngrid : nullptr;
+        b.surf_em = nullptr;
+        b.thermal_pass = 0;
+        slot.thermal_surface = I.thermal_surface ? I.thermal_surface + w0 : nullptr;
+        if (b.emission && (!I.g.pp_mode || derivs)) throw std::runtime_error("sasktran2_amd: the discrete-ordinates thermal source needs plane-parallel post-processing and no weighting functions");
         b.nleg = nleg;
         b.derivs = derivs;
         switch (t.N) {

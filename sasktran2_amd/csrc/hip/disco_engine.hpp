@@ -32,6 +32,9 @@ class DeviceEngine {
     // delta-M truncation fraction of the (already scaled) optical properties: DEVICE pointer [nwavel][ngrid] used by the following
     // solve_device calls, or null (sk_atmosphere_apply_delta_m_scaling, cpp/lib/atmosphere/atmosphere.cpp:73-200)
     void set_delta_m_fraction(const double* d_f);
+    // EmissionSource::discrete_ordinates (thermal source inside the DO equations; plane-parallel post-processing, NSTOKES = 1, radiances only):
+    // DEVICE pointers emission_source [nwavel][ngrid] and surface emission [nwavel] (or null) for the following solve_device calls
+    void set_thermal_emission(const double* d_emission, const double* d_surface_emission);
 
     // Polarised path (NSTOKES = 3; also NSTOKES = 1 with a stream count the matrix-core path does not cover).
     // d_leg: [nwavel][ngrid][nleg][4] (a1, a2, a3, b1) for NSTOKES = 3; d_radiance: [nwavel][nlos][nstokes].

@@ -663,7 +663,7 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2A) kern_k2a_wav
                 if (m == 0) {
                     double sg = 0;
                     for (int t = 0; t < N; ++t) sg += g.wt[t] * g.mu[t] * sG[cur][2 * N + t];
-                    rB += g.csz[s] * rho / skd::kPi * b.T[size_t(nlyr) * nw + w] + 2.0 * rho * sg;
+                    rB += g.csz[s] * rho / skd::kPi * b.T[size_t(nlyr) * nw + w] + 2.0 * rho * sg + (b.surf_em ? b.surf_em[w] : 0.0);
                 }
             } else {
                 rB += skd::rec_at<N>(b, nlyr, p + 1, w)[R::G + N + i];

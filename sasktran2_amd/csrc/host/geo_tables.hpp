@@ -36,6 +36,11 @@ struct GeoTables {
         lpcsz = G.lp_csz;
         lpang = G.lp_angle;
         csz = G.csz;
+        // one more "solar zenith index" (s = nsza) for the thermal pass of the plane-parallel engine: an isotropic source is the solar
+        // machinery with Legendre functions of the sun (1, 0, 0, ...) at order 0 and no direct beam on the ground (csz = 0)
+        lpcsz.resize(size_t(nsza + 1) * nstr * nstr, 0.0);
+        lpcsz[size_t(nsza) * nstr * nstr] = 1.0;
+        csz.push_back(0.0);
         chapman = G.chapman;
         dh.resize(nlyr); lfrac.resize(nlyr); wq_idx.assign(2 * nlyr, -1); wq_w.assign(2 * nlyr, 0.0);
         for (int p = 0; p < nlyr; ++p) {

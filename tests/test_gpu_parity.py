@@ -806,3 +806,66 @@ def test_jvp_and_vjp_are_contractions_of_the_jacobian(nstokes):
     lhs = float(np.sum(cot * jvp))
     rhs = float(grads["wf_extinction"] @ t_k + grads["wf_ssa"] @ t_w + grads["wf_albedo"] @ t_a)
     assert abs(lhs - rhs) < 1e-11 * max(abs(lhs), abs(rhs))
+
+
+# ---- thermal emission inside the discrete-ordinates equations (emission_source = discrete_ordinates)
+def _run_thermal(s, delta_m=False):
+    import sasktran2_amd as sk
+    from tests.gpu_harness import build_engine
+    g = s["geometry"]
+    config = sk.Config()
+    config.num_streams = s["config"]["nstr"]
+    config.num_singlescatter_moments = s["leg"].shape[0]
+    config.multiple_scatter_source = sk.MultipleScatterSource.DiscreteOrdinates
+    config.single_scatter_source = sk.SingleScatterSource.DiscreteOrdinates
+    config.emission_source = sk.EmissionSource.DiscreteOrdinates
+    config.delta_m_scaling = delta_m
+    geometry = sk.Geometry1D(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"], sk.InterpolationMethod(g["interp_method"]), sk.GeometryType(g["geotype"]))
+    viewing = sk.ViewingGeometry()
+    for kind, csz, az, obs, x in s["rays"]:
+        viewing.add_ray(sk.GroundViewingSolar(csz, az, x, obs))
+    engine = sk.Engine(config, geometry, viewing)
+    nw = s["extinction"].shape[1]
+    atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=False)
+    atmosphere.storage.total_extinction[:] = s["extinction"]
+    atmosphere.storage.ssa[:] = s["ssa"]
+    atmosphere.leg_coeff.a1[:] = s["leg"]
+    atmosphere.storage.solar_irradiance[:] = s["solar_irradiance"]
+    atmosphere.storage.emission_source[:] = s["emission"]
+    atmosphere.surface.emission[:] = s["surface_emission"]
+    atmosphere.surface.albedo[:] = s["albedo"]
+    return engine.calculate_radiance(atmosphere, as_dataset=False)["radiance"][:, :, 0]
+
+
+@pytest.mark.parametrize("surface", [False, True], ids=["atmosphere only, optical depth 100", "with surface emission, optical depth 1"])
+def test_disort_thermal_emission_pins_on_the_device(surface):
+    """tests/engine/thermal_emissions/test_disort.py:7-112 through the C ABI (delta-M scaling applied by the Python layer as there)."""
+    s = sc.disort_thermal(surface)
+    got = _run_thermal(s, delta_m=True)
+    np.testing.assert_allclose(got[0, 0], s["expected"], rtol=s["rtol"])
+
+
+def test_thermal_emission_with_sun_and_reflecting_surface_matches_oracle():
+    """Several layers with emission rising and falling with altitude (b1 of both signs and zero), sunlight and a reflecting, emitting
+    surface, four nadir-type lines of sight incl. one from inside the atmosphere: the thermal pass adds to the solar solution."""
+    from tests.test_oracle_golden import make_oracle
+    alt = np.linspace(0.0, 40_000.0, 11)
+    nw = 3
+    k = (1.5e-4 * np.exp(-alt / 8_000.0)[:, None] + 2e-7) * np.linspace(0.5, 2.0, nw)[None, :]
+    ssa = np.clip(0.6 + 0.3 * np.sin(alt / 9_000.0)[:, None] * np.ones((1, nw)), 0.05, 0.97)
+    l = np.arange(8)
+    leg = ((2 * l + 1) * 0.55 ** l)[:, None, None] * np.ones((1, alt.size, nw))
+    em = (2.0e-5 * (1 + 0.6 * np.sin(alt / 6_000.0)))[:, None] * np.linspace(0.8, 1.3, nw)[None, :]
+    em[3], em[4] = em[2], em[2]   # two layers of constant emission (b1 = 0)
+    s = dict(geometry=dict(cos_sza=0.45, saa=0.0, earth_radius=6_372_000.0, altitudes=alt, interp_method=sc.INTERP_LINEAR, geotype=sc.GEO_PLANEPARALLEL),
+             config=dict(nstr=8, num_sza=1),
+             rays=[(sc.GROUND_VIEWING_SOLAR, 0.45, 0.3, 200_000.0, 0.9), (sc.GROUND_VIEWING_SOLAR, 0.45, 2.0, 200_000.0, 0.35),
+                   (sc.GROUND_VIEWING_SOLAR, 0.45, 1.0, 17_300.0, 0.6), (sc.GROUND_VIEWING_SOLAR, 0.45, 0.0, 200_000.0, 1.0)],
+             extinction=k, ssa=ssa, leg=leg, albedo=np.array([0.0, 0.3, 0.8]), solar_irradiance=np.array([0.0, 1.0e-4, 3.0e-4]),
+             emission=em, surface_emission=np.array([4.0e-5, 0.0, 2.5e-5]))
+    ref = make_oracle(s).run(k, ssa, leg, s["albedo"], solar_irradiance=s["solar_irradiance"], emission=em, surface_emission=s["surface_emission"])["radiance"]
+    got = _run_thermal(s)
+    np.testing.assert_allclose(got, ref, rtol=RTOL_I)
+    # the thermal part alone is what the pass adds to the sunlit solution
+    sun_only = make_oracle(s).run(k, ssa, leg, s["albedo"], solar_irradiance=s["solar_irradiance"])["radiance"]
+    assert np.all(ref > sun_only)
