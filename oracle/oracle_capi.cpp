@@ -13,6 +13,7 @@
 
 #include "disco_oracle.hpp"
 #include "so_oracle.hpp"
+#include "ts_oracle.hpp"
 
 namespace {
 struct Handle {
@@ -285,6 +286,118 @@ int orso_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                     }
             } catch (const std::exception& e) {
                 std::fprintf(stderr, "orso_run (wavelength %d): %s\n", w, e.what());
+                status = -3;
+            }
+        }
+    }
+    return status;
+}
+
+// ---- two-stream source (ts_oracle.hpp)
+struct TsHandle {
+    skgeo::Geometry1D geo;
+    skts::TsGeometry tg;
+};
+
+void* orts_create(double cos_sza, double saa, double earth_radius, const double* altitudes, int ngrid, int interp_method, int geotype,
+                  int nrays, const int* ray_kinds, const double* ray_params, int num_sza, int solar, int thermal) {
+    try {
+        auto h = std::make_unique<TsHandle>();
+        h->geo = skgeo::Geometry1D(cos_sza, saa, earth_radius, std::vector<double>(altitudes, altitudes + ngrid),
+                                   (skgeo::Interpolation)interp_method, (skgeo::GeometryType)geotype);
+        std::vector<skgeo::RaySpec> specs(nrays);
+        for (int i = 0; i < nrays; ++i) {
+            specs[i].kind = (skgeo::RaySpec::Kind)ray_kinds[i];
+            specs[i].cos_sza = ray_params[4 * i + 0];
+            specs[i].horizontal_angle = ray_params[4 * i + 0];
+            specs[i].relative_azimuth = ray_params[4 * i + 1];
+            specs[i].observer_altitude = ray_params[4 * i + 2];
+            specs[i].tangent_altitude = ray_params[4 * i + 3];
+            specs[i].cos_viewing_zenith = ray_params[4 * i + 3];
+        }
+        skts::Settings cfg;
+        cfg.num_sza = num_sza;
+        cfg.solar = solar != 0;
+        cfg.thermal = thermal != 0;
+        skts::build_ts_geometry(h->geo, specs, cfg, h->tg);
+        return h.release();
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "orts_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+void orts_destroy(void* h) { delete static_cast<TsHandle*>(h); }
+// sizes: columns, segments, optical-depth stencil entries
+int orts_sizes(void* hv, int* out) {
+    auto* h = static_cast<TsHandle*>(hv);
+    if (!h) return -1;
+    out[0] = h->tg.ncol;
+    out[1] = h->tg.nseg();
+    out[2] = (int)h->tg.od_level.size();
+    return 0;
+}
+// Inputs in the engine's storage layout (location fastest): extinction, ssa, emission [nwavel][ngrid], leg [nwavel][ngrid][nleg],
+// delta_f [nwavel][ngrid] or null (truncation fraction already applied to the optical properties), albedo / irradiance / surface emission
+// [nwavel] (irradiance and the emission arrays may be null).  Outputs: radiance [nwavel][nlos] (solar + thermal two-stream sources as
+// configured), d_k / d_ssa / d_b1 / d_emission [nwavel][nlos][ngrid], d_albedo / d_surface_emission [nwavel][nlos] (all or none).
+int orts_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg, const double* delta_f,
+             const double* emission, const double* surface_emission, const double* solar_irradiance, const double* albedo, int nthreads,
+             double* radiance, double* d_k, double* d_ssa, double* d_b1, double* d_emission, double* d_albedo, double* d_surface_emission) {
+    auto* h = static_cast<TsHandle*>(hv);
+    if (!h) return -1;
+    const skts::TsGeometry& g = h->tg;
+    const int nlos = g.nlos, ngrid = g.ngrid;
+    if (g.cfg.thermal && !emission) return -2;
+    const bool derivs = d_k != nullptr;
+    int status = 0;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        std::vector<double> b1(ngrid);
+        oracle_ts::Result res;
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int w = 0; w < nwavel; ++w) {
+            if (status != 0) continue;
+            try {
+                const size_t o = size_t(w) * ngrid;
+                for (int q = 0; q < ngrid; ++q) {
+                    const double f = delta_f ? delta_f[o + q] : 0.0;
+                    b1[q] = (nleg > 1 ? leg[(o + q) * nleg + 1] : 0.0) - 3.0 * f / (1.0 - f);
+                }
+                for (int i = 0; i < nlos; ++i) radiance[size_t(w) * nlos + i] = 0.0;
+                if (derivs) {
+                    for (size_t i = 0; i < size_t(nlos) * ngrid; ++i) {
+                        const size_t j = size_t(w) * nlos * ngrid + i;
+                        d_k[j] = d_ssa[j] = d_b1[j] = d_emission[j] = 0.0;
+                    }
+                    for (int i = 0; i < nlos; ++i) d_albedo[size_t(w) * nlos + i] = d_surface_emission[size_t(w) * nlos + i] = 0.0;
+                }
+                for (int pass = 0; pass < 2; ++pass) {
+                    const bool solar = pass == 0;
+                    if (solar ? !g.cfg.solar : !g.cfg.thermal) continue;
+                    oracle_ts::run_wavelength(g, solar, extinction + o, ssa + o, b1.data(), emission ? emission + o : nullptr, albedo[w],
+                                              solar_irradiance ? solar_irradiance[w] : 1.0, surface_emission ? surface_emission[w] : 0.0,
+                                              derivs, res);
+                    for (int i = 0; i < nlos; ++i) radiance[size_t(w) * nlos + i] += res.radiance[i];
+                    if (!derivs) continue;
+                    for (size_t i = 0; i < size_t(nlos) * ngrid; ++i) {
+                        const size_t j = size_t(w) * nlos * ngrid + i;
+                        d_k[j] += res.d_extinction[i];
+                        d_ssa[j] += res.d_ssa[i];
+                        d_b1[j] += res.d_b1[i];
+                        d_emission[j] += res.d_emission[i];
+                    }
+                    for (int i = 0; i < nlos; ++i) {
+                        d_albedo[size_t(w) * nlos + i] += res.d_albedo[i];
+                        d_surface_emission[size_t(w) * nlos + i] += res.d_surface_emission[i];
+                    }
+                }
+            } catch (const std::exception& e) {
+                std::fprintf(stderr, "orts_run (wavelength %d): %s\n", w, e.what());
                 status = -3;
             }
         }

@@ -181,3 +181,61 @@ class SoOracleEngine:
         if derivatives:
             out.update({"d_extinction": dk, "d_ssa": dw, "d_albedo": da})
         return out
+
+
+class TsOracleEngine:
+    """Two-stream source (oracle/ts_oracle.hpp): multiple_scatter_source = twostream (`solar`) and / or emission_source = twostream
+    (`thermal`).  rays as for OracleEngine."""
+
+    def __init__(self, cos_sza, saa, earth_radius, altitudes, interp_method, geotype, rays, num_sza=1, solar=True, thermal=False):
+        L = lib()
+        L.orts_create.restype = ctypes.c_void_p
+        L.orts_create.argtypes = [ctypes.c_double] * 3 + [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp] + [ctypes.c_int] * 3
+        L.orts_destroy.argtypes = [ctypes.c_void_p]
+        L.orts_sizes.argtypes = [ctypes.c_void_p, _ip]
+        L.orts_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [_dp] * 8 + [ctypes.c_int] + [_dp] * 7
+        self.alt = np.ascontiguousarray(altitudes, dtype=np.float64)
+        self.nlos, self.ngrid = len(rays), len(self.alt)
+        kinds = np.ascontiguousarray([r[0] for r in rays], dtype=np.int32)
+        params = np.ascontiguousarray([[r[1], r[2], r[3], r[4]] for r in rays], dtype=np.float64)
+        self._h = L.orts_create(cos_sza, saa, earth_radius, _p(self.alt), self.ngrid, interp_method, geotype, self.nlos,
+                                kinds.ctypes.data_as(_ip), _p(params), int(num_sza), int(solar), int(thermal))
+        if not self._h:
+            raise RuntimeError("two-stream oracle construction failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orts_destroy(self._h)
+            self._h = None
+
+    def sizes(self):
+        out = np.zeros(3, dtype=np.int32)
+        lib().orts_sizes(self._h, out.ctypes.data_as(_ip))
+        return dict(columns=int(out[0]), segments=int(out[1]), od_entries=int(out[2]))
+
+    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, derivatives=False, nthreads=1, delta_f=None, emission=None,
+            surface_emission=None):
+        """extinction, ssa, emission, delta_f: [ngrid, nwavel]; leg: [nleg, ngrid, nwavel]; albedo, surface_emission: [nwavel].
+        Returns radiance [nwavel, nlos] and, with derivatives, d_extinction / d_ssa / d_b1 / d_emission [nwavel, nlos, ngrid] (b1: the
+        first Legendre coefficient after the delta-M correction) and d_albedo / d_surface_emission [nwavel, nlos]."""
+        k = np.asfortranarray(extinction, dtype=np.float64)
+        w = np.asfortranarray(ssa, dtype=np.float64)
+        lg = np.asfortranarray(leg, dtype=np.float64)
+        nwavel = k.shape[1]
+        df = None if delta_f is None else np.asfortranarray(delta_f, dtype=np.float64)
+        em = None if emission is None else np.asfortranarray(emission, dtype=np.float64)
+        sem = None if surface_emission is None else np.ascontiguousarray(surface_emission, dtype=np.float64)
+        alb = np.ascontiguousarray(albedo, dtype=np.float64)
+        irr = None if solar_irradiance is None else np.ascontiguousarray(solar_irradiance, dtype=np.float64)
+        rad = np.zeros((nwavel, self.nlos))
+        d = [None] * 6
+        if derivatives:
+            d = [np.zeros((nwavel, self.nlos, self.ngrid)) for _ in range(4)] + [np.zeros((nwavel, self.nlos)) for _ in range(2)]
+        rc = lib().orts_run(self._h, nwavel, lg.shape[0], _p(k), _p(w), _p(lg), _p(df), _p(em), _p(sem), _p(irr), _p(alb), nthreads,
+                            _p(rad), _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(d[4]), _p(d[5]))
+        if rc != 0:
+            raise RuntimeError(f"two-stream oracle run failed with code {rc}")
+        out = {"radiance": rad}
+        if derivatives:
+            out.update(dict(zip(("d_extinction", "d_ssa", "d_b1", "d_emission", "d_albedo", "d_surface_emission"), d)))
+        return out

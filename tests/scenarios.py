@@ -238,3 +238,48 @@ def disort_thermal(surface: bool):
                 extinction=k, ssa=ssa, leg=leg, albedo=np.zeros(1), solar_irradiance=np.zeros(1),
                 emission=np.full((2, 1), 1.09657540e-05), surface_emission=np.array([1.09657540e-05 if surface else 0.0]),
                 expected=1.02396134e-05 if surface else 7.93075833e-06, rtol=1e-6)
+
+
+def twostream_reference_case(spherical: bool = True, thermal: bool = False, num_wavelengths: int = 9):
+    """The atmosphere of the reference's two-stream tests (tests/engine/test_twostream.py:34-73: `_case`): 13 levels to 60 km, two limb
+    rays and one nadir ray, omega = 0.85, a1 = [1, 0.2], albedo 0.2, irradiance 1.1; with `thermal` the emission profile and the surface
+    emission of the same function."""
+    alt = np.arange(0.0, 60_001.0, 5_000.0)
+    nw = num_wavelengths
+    if spherical:
+        rays = [(TANGENT_ALTITUDE_SOLAR, 0.6, 0.4, 200_000.0, 15_000.0), (TANGENT_ALTITUDE_SOLAR, 0.6, -0.3, 200_000.0, 35_000.0),
+                (GROUND_VIEWING_SOLAR, 0.6, 0.3, 200_000.0, 0.65)]
+    else:
+        rays = [(GROUND_VIEWING_SOLAR, 0.6, 0.3, 200_000.0, 0.7), (GROUND_VIEWING_SOLAR, 0.6, -0.4, 200_000.0, 0.35)]
+    spectral = 0.8 + 0.05 * np.arange(nw)[None, :]
+    k = (2.0e-5 * np.exp(-alt[:, None] / 8_000.0) + 1.0e-8) * spectral
+    ssa = np.full((alt.size, nw), 0.85)
+    leg = np.zeros((2, alt.size, nw))
+    leg[0], leg[1] = 1.0, 0.2
+    out = dict(geometry=dict(cos_sza=0.6, saa=0.2, earth_radius=6_371_000.0, altitudes=alt, interp_method=INTERP_LINEAR,
+                             geotype=GEO_SPHERICAL if spherical else GEO_PLANEPARALLEL),
+               config=dict(nstr=2, num_sza=3 if spherical else 1), rays=rays, extinction=k, ssa=ssa, leg=leg, albedo=np.full(nw, 0.2),
+               solar_irradiance=np.full(nw, 1.1))
+    if thermal:
+        out["emission"] = (2.0 - 0.03 * np.arange(alt.size)[:, None]) * np.ones((1, nw))
+        out["surface_emission"] = np.full(nw, 1.5)
+    return out
+
+
+def twostream_delta_m_case(num_wavelengths: int = 9):
+    """The reference's delta-M pin of the two-stream source against two-stream discrete ordinates
+    (tests/engine/test_twostream.py:100-156): plane parallel, 9 levels to 40 km, Henyey-Greenstein moments to order 3, UNSCALED inputs
+    (apply `delta_m_scaled(s, 2)`)."""
+    alt = np.arange(0.0, 40_001.0, 5_000.0)
+    nw = num_wavelengths
+    rays = [(GROUND_VIEWING_SOLAR, 0.6, 0.3, 200_000.0, 0.7), (GROUND_VIEWING_SOLAR, 0.6, -0.4, 200_000.0, 0.35)]
+    spectral = 0.8 + 0.04 * np.arange(nw)[None, :]
+    k = (2.0e-5 * np.exp(-alt[:, None] / 8_000.0) + 1.0e-8) * spectral
+    ssa = np.full((alt.size, nw), 0.87)
+    g = 0.62 + 0.01 * np.arange(nw)[None, :] / nw
+    leg = np.zeros((4, alt.size, nw))
+    leg[0], leg[1], leg[2], leg[3] = 1.0, 3.0 * g, 5.0 * g**2, 7.0 * g**3
+    return dict(geometry=dict(cos_sza=0.6, saa=0.2, earth_radius=6_371_000.0, altitudes=alt, interp_method=INTERP_LINEAR,
+                              geotype=GEO_PLANEPARALLEL),
+                config=dict(nstr=2, num_sza=1), rays=rays, extinction=k, ssa=ssa, leg=leg, albedo=np.full(nw, 0.2),
+                solar_irradiance=np.full(nw, 1.1))
