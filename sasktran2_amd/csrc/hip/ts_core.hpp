@@ -1,0 +1,856 @@
+// Two-stream source (multiple_scatter_source = twostream, emission_source = twostream): the per-wavelength arithmetic.
+//
+// Every function here is `TS_HD` (host + device): the HIP kernels of ts_engine.hip call them with one thread per wavelength (lane =
+// wavelength, scratch laid out [item][lane] so that every access of a wavefront is one contiguous 512-byte row), and
+// tests/emulate_twostream.cpp runs the same bodies on the CPU.
+//
+// What is computed (reference: cpp/lib/sktran_disco/cpp_twostream_source.cpp, behaviour restated):
+//   solve_thread   layer optics from the level profiles, slant solar transmission / thermal profile, the two-stream homogeneous and
+//                  particular solutions of every layer for azimuth orders 0 and 1, and the LU sweep of the five-diagonal boundary-value
+//                  problem (:1923-2122, :1861-1899)
+//   view_thread    the radiance of one line of sight: plane parallel (:2550-2668) or the spherical path integration over traced segments
+//                  (:1196-1233, :2160-2234), and its weighting functions.
+// Weighting functions are NOT a translation of the reference's hand-written reverse sweep.  The radiance is F(p, c) with A(p) c = r(p)
+// (p: the five numbers per layer -- optical depth, single-scatter albedo, first phase moment, source amplitude and decay rate -- c: the
+// 2n homogeneous amplitudes).  One transposed five-diagonal solve gives lambda = A^-T dF/dc, and the gradient with respect to p is the
+// p-derivative of the Lagrangian F(p, c) + lambda . (r(p) - A(p) c) at fixed (c, lambda), evaluated layer by layer in forward-mode dual
+// numbers with five directions (D5).  The chain from p to the level profiles is written out by hand (:2839-2921 gives the same result).
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <type_traits>
+
+#if defined(__HIPCC__)
+#define TS_HD __host__ __device__ inline
+#else
+#define TS_HD inline
+#endif
+
+namespace skt {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kFourPi = 4.0 * kPi;
+constexpr double kThermalMinOd = 1.0e-10;        // THERMAL_MIN_OPTICAL_DEPTH, cpp_twostream_source.cpp:21
+constexpr double kThermalMinEmission = 1.0e-30;  // THERMAL_MIN_EMISSION, :22
+constexpr double kSsaCap = 1.0 - 1.0e-9;         // clamp of the layer single-scatter albedo, :1944-1946
+
+struct Geo {
+    int nlyr, ngrid, nlos, ncol, spherical, max_seg;
+    double mu;
+    const double *thickness, *csz, *chapman;         // [nlyr], [ncol], [ncol][nlyr][nlyr]
+    const double *view_cos, *view_azimuth;           // plane parallel, [nlos]
+    const int *ray_start, *ground_hit, *ground_col;  // spherical
+    const double* ground_colw;
+    const int* seg_layer;
+    const double *seg_frac, *seg_cos, *seg_azimuth;
+    const int* seg_col;
+    const double* seg_colw;
+    const int *od_start, *od_level;
+    const double* od_weight;
+};
+
+struct Bufs {
+    int nw, W, w0, nw_total, nleg, derivs, accumulate;
+    // inputs in the reference storage layout (location fastest); delta_f, irradiance, emission, surface_emission may be null
+    const double *ext, *ssa, *leg, *delta_f, *albedo, *irradiance, *emission, *surface_emission;
+    // outputs: radiance [nw_total][nlos]; wf_ext / wf_ssa / wf_b1 / wf_em [ngrid][nw_total][nlos]; wf_alb / wf_sem [nw_total][nlos]
+    double *radiance, *wf_ext, *wf_ssa, *wf_b1, *wf_alb, *wf_em, *wf_sem;
+    // scratch, every item a row of W lanes
+    double* lay;    // [3][n]                   od, ssa, b1 of the layers
+    double* colv;   // [ncol][2n + 1]           source amplitude at the n + 1 boundaries (solar: transmission) and decay rate of the n layers
+    double* lu;     // [ncol][naz][6][2n]       c (solution), alpha, beta, gamma, e, 1 / mu of the LU sweep
+    double* lam;    // [nlos][ncol][naz][2n]    dF/dc, then lambda
+    double* g5;     // [nlos][ncol][n][5]       gradient with respect to the layer parameters
+    double* gsum;   // [nlos][3][n]             od / ssa / b1 gradients summed over the columns
+    double* path;   // [nlos][3][max_seg]       spherical: transmission, source and incoming radiance of every segment
+    double* glev;   // [nlos][ngrid]            spherical: level-extinction gradient of the path transmissions
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// dual numbers: value and the derivatives with respect to (od, ssa, b1, amplitude, rate) of one layer
+// ---------------------------------------------------------------------------------------------------------------------------
+struct D5 {
+    double v;
+    double d[5];
+};
+TS_HD D5 mkd(double v) { return {v, {0, 0, 0, 0, 0}}; }
+TS_HD D5 seed(double v, int dir) {
+    D5 r = mkd(v);
+    r.d[dir] = 1.0;
+    return r;
+}
+TS_HD D5 operator+(const D5& a, const D5& b) { D5 r; r.v = a.v + b.v; for (int i = 0; i < 5; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+TS_HD D5 operator-(const D5& a, const D5& b) { D5 r; r.v = a.v - b.v; for (int i = 0; i < 5; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+TS_HD D5 operator*(const D5& a, const D5& b) { D5 r; r.v = a.v * b.v; for (int i = 0; i < 5; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+TS_HD D5 operator/(const D5& a, const D5& b) {
+    D5 r;
+    const double ib = 1.0 / b.v;
+    r.v = a.v * ib;
+    for (int i = 0; i < 5; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+    return r;
+}
+TS_HD D5 operator-(const D5& a) { D5 r; r.v = -a.v; for (int i = 0; i < 5; ++i) r.d[i] = -a.d[i]; return r; }
+TS_HD D5 operator+(const D5& a, double b) { D5 r = a; r.v += b; return r; }
+TS_HD D5 operator+(double a, const D5& b) { D5 r = b; r.v += a; return r; }
+TS_HD D5 operator-(const D5& a, double b) { D5 r = a; r.v -= b; return r; }
+TS_HD D5 operator-(double a, const D5& b) { D5 r; r.v = a - b.v; for (int i = 0; i < 5; ++i) r.d[i] = -b.d[i]; return r; }
+TS_HD D5 operator*(const D5& a, double b) { D5 r; r.v = a.v * b; for (int i = 0; i < 5; ++i) r.d[i] = a.d[i] * b; return r; }
+TS_HD D5 operator*(double a, const D5& b) { return b * a; }
+TS_HD D5 operator/(const D5& a, double b) { return a * (1.0 / b); }
+TS_HD D5 operator/(double a, const D5& b) {
+    D5 r;
+    const double ib = 1.0 / b.v;
+    r.v = a * ib;
+    for (int i = 0; i < 5; ++i) r.d[i] = -r.v * b.d[i] * ib;
+    return r;
+}
+TS_HD D5& operator+=(D5& a, const D5& b) { a = a + b; return a; }
+
+TS_HD double val(double x) { return x; }
+TS_HD double val(const D5& x) { return x.v; }
+TS_HD double dpart(double, int) { return 0.0; }
+TS_HD double dpart(const D5& x, int i) { return x.d[i]; }
+TS_HD double t_exp(double x) { return exp(x); }
+TS_HD D5 t_exp(const D5& x) { D5 r; r.v = exp(x.v); for (int i = 0; i < 5; ++i) r.d[i] = r.v * x.d[i]; return r; }
+TS_HD double t_sqrt(double x) { return sqrt(x); }
+TS_HD D5 t_sqrt(const D5& x) { D5 r; r.v = sqrt(x.v); const double h = 0.5 / r.v; for (int i = 0; i < 5; ++i) r.d[i] = h * x.d[i]; return r; }
+template <class S> TS_HD S cst(double v);
+template <> TS_HD double cst<double>(double v) { return v; }
+template <> TS_HD D5 cst<D5>(double v) { return mkd(v); }
+// a function of three arguments with known partial derivatives
+TS_HD double fn3(double v, double, double, double, double, double, double) { return v; }
+TS_HD D5 fn3(double v, const D5& a, double da, const D5& b, double db, const D5& c, double dc) {
+    D5 r;
+    r.v = v;
+    for (int i = 0; i < 5; ++i) r.d[i] = da * a.d[i] + db * b.d[i] + dc * c.d[i];
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// removable singularities (cpp_twostream_source.cpp:30-128)
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Stable { double value, da, db, dt; };
+
+// integral of x^order exp(-rate x) over [0, thickness]
+TS_HD double exp_moment(int order, double rate, double thickness) {
+    if (thickness == 0.0) return 0.0;
+    const double x = rate * thickness;
+    double unit;
+    if (fabs(x) < 0.5) {
+        double term = 1.0;
+        unit = 0.0;
+        for (int j = 0; j < 40; ++j) {
+            const double c = term / double(order + j + 1);
+            unit += c;
+            if (fabs(c) <= 2.220446049250313e-16 * fmax(fabs(unit), 1.0)) break;
+            term *= -x / double(j + 1);
+        }
+    } else {
+        const double e = exp(-x);
+        unit = -expm1(-x) / x;
+        for (int j = 1; j <= order; ++j) unit = (double(j) * unit - e) / x;
+    }
+    double p = thickness;
+    for (int j = 0; j < order; ++j) p *= thickness;
+    return p * unit;
+}
+// (exp(-a t) - exp(-b t)) / (b - a)
+TS_HD Stable exp_difference(double a, double b, double t) {
+    const double delta = b - a;
+    if (fabs(delta * t) > 1.0e-5) {
+        const double ea = exp(-a * t), eb = exp(-b * t), num = ea - eb, inv = 1.0 / delta, inv2 = inv * inv;
+        return {num * inv, (-t * ea * delta + num) * inv2, (t * eb * delta - num) * inv2, (-a * ea + b * eb) * inv};
+    }
+    const double mid = 0.5 * (a + b), half = 0.5 * delta, u = half * t, u2 = u * u;
+    const double sinhc = 1.0 + u2 * (1.0 / 6.0 + u2 * (1.0 / 120.0 + u2 / 5040.0));
+    const double dsinhc = u * (1.0 / 3.0 + u2 * (1.0 / 30.0 + u2 / 840.0));
+    const double em = exp(-mid * t), value = t * em * sinhc;
+    const double dmid = -t * value, dhalf = t * t * em * dsinhc;
+    return {value, 0.5 * (dmid - dhalf), 0.5 * (dmid + dhalf), em * ((1.0 - mid * t) * sinhc + t * half * dsinhc)};
+}
+// integral over [0, t] of exp_difference(a, b, x)
+TS_HD Stable integrated_exp_difference(double a, double b, double t) {
+    const double delta = b - a;
+    if (fabs(delta * t) > 1.0e-4) {
+        const Stable ga = exp_difference(0.0, a, t), gb = exp_difference(0.0, b, t);
+        const double num = ga.value - gb.value, inv = 1.0 / delta, inv2 = inv * inv;
+        return {num * inv, (ga.db * delta + num) * inv2, (-gb.db * delta - num) * inv2, exp_difference(a, b, t).value};
+    }
+    const double mid = 0.5 * (a + b), half = 0.5 * delta, h2 = half * half;
+    const double m1 = exp_moment(1, mid, t), m2 = exp_moment(2, mid, t), m3 = exp_moment(3, mid, t), m4 = exp_moment(4, mid, t);
+    const double dmid = -m2 - h2 * m4 / 6.0, dhalf = half * m3 / 3.0;
+    return {m1 + h2 * m3 / 6.0, 0.5 * (dmid - dhalf), 0.5 * (dmid + dhalf), exp_difference(a, b, t).value};
+}
+template <class S> TS_HD S stable_exp_difference(const S& a, const S& b, const S& t) {
+    const Stable s = exp_difference(val(a), val(b), val(t));
+    return fn3(s.value, a, s.da, b, s.db, t, s.dt);
+}
+template <class S> TS_HD S stable_integrated_exp_difference(const S& a, const S& b, const S& t) {
+    const Stable s = integrated_exp_difference(val(a), val(b), val(t));
+    return fn3(s.value, a, s.da, b, s.db, t, s.dt);
+}
+// (exp_a - exp_b) / (b - a) given exp_a = exp(-a t), exp_b = exp(-b t), with the limit b -> a (:551-581)
+template <class S> TS_HD S exp_difference_ratio(const S& exp_a, const S& exp_b, const S& a, const S& b, const S& t) {
+    if (fabs((val(b) - val(a)) * val(t)) <= 1.0e-5) return stable_exp_difference(a, b, t);
+    return (exp_a - exp_b) / (b - a);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// one layer, one azimuth order
+// ---------------------------------------------------------------------------------------------------------------------------
+template <class S> struct LayerP { S od, ssa, b1, amp, rate; };   // amp / rate: solar transmission at the layer top and slant secant,
+                                                                  // or thermal emission at the layer top and its decay rate
+TS_HD LayerP<double> make_p(double od, double ssa, double b1, double amp, double rate, double) { return {od, ssa, b1, amp, rate}; }
+TS_HD LayerP<D5> make_p(double od, double ssa, double b1, double amp, double rate, const D5&) {
+    return {seed(od, 0), seed(ssa, 1), seed(b1, 2), seed(amp, 3), seed(rate, 4)};
+}
+
+template <class S> struct LayerSol {
+    S k, xp, xm, omega;   // eigenvalue, the two components of the eigenvector, exp(-k od)
+    S upper, lower;       // particular-solution amplitudes: solar (a+, a-), thermal (a_t, a_t)
+    S expo;               // exp(-rate od)
+};
+
+// homogeneous and particular solution of a layer (forward_explicit_layers, :2048-2096)
+template <class S, bool SOLAR> TS_HD LayerSol<S> layer_solution(int az, const LayerP<S>& p, double mu, double csz, double angular) {
+    LayerSol<S> h;
+    S d, s;
+    if (az == 0) {
+        d = p.ssa * p.b1 * mu - 1.0 / mu;
+        s = (p.ssa - 1.0) / mu;
+    } else {
+        d = cst<S>(-1.0 / mu);
+        s = (p.ssa * p.b1 * (1.0 - mu * mu) - 2.0) / (2.0 * mu);
+    }
+    h.k = t_sqrt(s * d);
+    const S s_over_k = s / h.k;
+    h.xp = 0.5 * (1.0 - s_over_k);
+    h.xm = 0.5 * (1.0 + s_over_k);
+    h.omega = t_exp(-(h.k * p.od));
+    h.expo = t_exp(-(p.rate * p.od));
+    const S norm = mu * (h.xp * h.xp - h.xm * h.xm);
+    if (SOLAR) {
+        S qp, qm;
+        if (az == 0) {
+            qp = p.ssa * (1.0 + p.b1 * (csz * mu)) / kFourPi;
+            qm = p.ssa * (1.0 - p.b1 * (csz * mu)) / kFourPi;
+        } else {
+            qp = p.ssa * p.b1 * (angular / kFourPi);
+            qm = qp;
+        }
+        h.upper = (qp * h.xp + qm * h.xm) / norm;
+        h.lower = (qm * h.xp + qp * h.xm) / norm;
+    } else {
+        h.upper = (1.0 - p.ssa) * (h.xp + h.xm) / norm;
+        h.lower = h.upper;
+    }
+    return h;
+}
+
+// The four particular-solution values at the layer boundaries (:2097-2118): g+ / g- at the top (t) and bottom (b)
+template <class S> struct Boundary { S gpt, gpb, gmt, gmb; };
+template <class S> TS_HD Boundary<S> boundary_particular(const LayerP<S>& p, const LayerSol<S>& h) {
+    const S cp = p.amp * exp_difference_ratio(h.omega, h.expo, h.k, p.rate, p.od);
+    const S cm = p.amp * exp_difference_ratio(cst<S>(1.0), h.omega * h.expo, cst<S>(0.0), p.rate + h.k, p.od);
+    Boundary<S> g;
+    g.gpt = h.lower * cm * h.xm;
+    g.gpb = h.upper * cp * h.xp;
+    g.gmt = h.lower * cm * h.xp;
+    g.gmb = h.upper * cp * h.xm;
+    return g;
+}
+
+// phase-function sums of the two streams toward a propagation cosine (explicit_lpsum, :2145-2158)
+template <class S, bool SOLAR> TS_HD void lpsum(int az, double phase_mu, double phase_sine, const LayerP<S>& p, S& lp, S& lm) {
+    if (az == 0) {
+        lp = 0.5 * p.ssa * (1.0 - p.b1 * phase_mu);
+        lm = 0.5 * p.ssa * (1.0 + p.b1 * phase_mu);
+    } else if (SOLAR) {
+        lp = p.ssa * p.b1 * phase_sine;
+        lm = lp;
+    } else {
+        lp = cst<S>(0.0);
+        lm = lp;
+    }
+}
+
+// layer-integrated source toward a plane-parallel viewing cosine, one azimuth order: c0 U + c1 V + P (explicit_plane_view, :2598-2640).
+// `beam` = exp(-od / vc), `source_integral` the attenuated integral of the driving term (see plane_source_integral)
+template <class S, bool SOLAR>
+TS_HD void plane_source_terms(int az, const LayerP<S>& p, const LayerSol<S>& h, double vc, double mu, bool fast, const S& beam,
+                              const S& source_integral, S& U, S& V, S& P) {
+    const double inv = 1.0 / vc, phase_mu = vc * mu;
+    const double phase_sine = 0.25 * sqrt(fmax(0.0, (1.0 - vc * vc) * (1.0 - mu * mu)));
+    S lp, lm;
+    lpsum<S, SOLAR>(az, phase_mu, phase_sine, p, lp, lm);
+    const S yp = lp * h.xp + lm * h.xm, ym = lp * h.xm + lm * h.xp;
+    S hm, hp, dp_ratio, dm_ratio;
+    if (fast) {
+        hm = (h.omega - beam) / (1.0 - h.k * vc);
+        hp = (1.0 - h.omega * beam) / (1.0 + h.k * vc);
+        dp_ratio = (source_integral - h.expo * hm) / (p.rate + h.k);
+        dm_ratio = (hp - source_integral) / (p.rate - h.k);
+    } else {
+        const S tinv = cst<S>(inv), zero = cst<S>(0.0);
+        hm = inv * stable_exp_difference(h.k, tinv, p.od);
+        hp = inv * stable_exp_difference(zero, h.k + tinv, p.od);
+        dp_ratio = inv * stable_integrated_exp_difference(p.rate + h.k, p.rate + tinv, p.od);
+        dm_ratio = inv * stable_integrated_exp_difference(h.k + tinv, p.rate + tinv, p.od);
+    }
+    U = yp * hp;
+    V = ym * hm;
+    P = h.upper * yp * (p.amp * dm_ratio) + h.lower * ym * (p.amp * dp_ratio);
+}
+template <class S> TS_HD S plane_source_integral(const LayerP<S>& p, const S& expo, const S& beam, double vc, bool fast) {
+    if (fast) return (1.0 - expo * beam) / (1.0 + p.rate * vc);
+    return (1.0 / vc) * stable_exp_difference(cst<S>(0.0), p.rate + cst<S>(1.0 / vc), p.od);
+}
+// no exponent difference of this layer near a removable singularity (plane_source_nonresonant, :1843-1859)
+TS_HD bool plane_nonresonant(double rate, double k, double od, double inv) {
+    const double diff[5] = {rate + inv, inv - k, k + inv, rate + k, rate - k};
+    for (int i = 0; i < 5; ++i)
+        if (fabs(diff[i] * od) <= 1.0e-5) return false;
+    return true;
+}
+
+// source function inside a layer, a fraction of its optical depth below its top, one azimuth order: c0 U + c1 V + P (:2160-2234)
+template <class S, bool SOLAR>
+TS_HD void local_source_terms(int az, const LayerP<S>& p, const LayerSol<S>& h, double frac_top, double cosine, double mu, S& U, S& V, S& P) {
+    const double phase_mu = cosine * mu;
+    const double phase_sine = 0.25 * sqrt(fmax(0.0, (1.0 - cosine * cosine) * (1.0 - mu * mu)));
+    const double frac_bottom = 1.0 - frac_top;
+    S lp, lm;
+    lpsum<S, SOLAR>(az, phase_mu, phase_sine, p, lp, lm);
+    const S yp = lp * h.xp + lm * h.xm, ym = lp * h.xm + lm * h.xp;
+    const S top_e = t_exp(-(h.k * p.od * frac_top)), bottom_e = t_exp(-(h.k * p.od * frac_bottom));
+    const S beam = t_exp(-(p.rate * p.od * frac_top));
+    const S plus = p.amp * exp_difference_ratio(top_e, beam, h.k, p.rate, p.od * frac_top);
+    const S minus = p.amp * frac_bottom *
+                    exp_difference_ratio(beam, h.expo * bottom_e, p.rate * frac_top, p.rate + h.k * frac_bottom, p.od);
+    U = yp * top_e;
+    V = ym * bottom_e;
+    P = h.upper * yp * plus + h.lower * ym * minus;
+}
+// the emission itself seen along the path (thermal only): amp exp(-rate od frac) (1 - ssa)
+template <class S> TS_HD S local_emission(const LayerP<S>& p, double frac_top) {
+    return p.amp * t_exp(-(p.rate * p.od * frac_top)) * (1.0 - p.ssa);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// scratch addressing (every item a row of b.W lanes)
+// ---------------------------------------------------------------------------------------------------------------------------
+TS_HD int naz_of(bool solar) { return solar ? 2 : 1; }
+TS_HD double& lay_at(const Bufs& b, const Geo& g, int which, int l, int w) { return b.lay[(size_t(which) * g.nlyr + l) * b.W + w]; }
+TS_HD double& amp_at(const Bufs& b, const Geo& g, int col, int boundary, int w) { return b.colv[(size_t(col) * (2 * g.nlyr + 1) + boundary) * b.W + w]; }
+TS_HD double& rate_at(const Bufs& b, const Geo& g, int col, int l, int w) { return b.colv[(size_t(col) * (2 * g.nlyr + 1) + g.nlyr + 1 + l) * b.W + w]; }
+enum { LU_C = 0, LU_ALPHA, LU_BETA, LU_GAMMA, LU_E, LU_IMU };
+TS_HD double& lu_at(const Bufs& b, const Geo& g, int naz, int col, int az, int which, int row, int w) {
+    return b.lu[(((size_t(col) * naz + az) * 6 + which) * (2 * g.nlyr) + row) * b.W + w];
+}
+TS_HD double& lam_at(const Bufs& b, const Geo& g, int naz, int view, int col, int az, int row, int w) {
+    return b.lam[(((size_t(view) * g.ncol + col) * naz + az) * (2 * g.nlyr) + row) * b.W + w];
+}
+TS_HD double& g5_at(const Bufs& b, const Geo& g, int view, int col, int l, int dir, int w) {
+    return b.g5[(((size_t(view) * g.ncol + col) * g.nlyr + l) * 5 + dir) * b.W + w];
+}
+TS_HD double& gsum_at(const Bufs& b, const Geo& g, int view, int which, int l, int w) {
+    return b.gsum[((size_t(view) * 3 + which) * g.nlyr + l) * b.W + w];
+}
+TS_HD double& path_at(const Bufs& b, const Geo& g, int view, int which, int seg, int w) {
+    return b.path[((size_t(view) * 3 + which) * g.max_seg + seg) * b.W + w];
+}
+TS_HD double& glev_at(const Bufs& b, const Geo& g, int view, int level, int w) { return b.glev[(size_t(view) * g.ngrid + level) * b.W + w]; }
+
+// level values of wavelength gw, levels counted from the top (load_extinction ... load_emission, :863-917)
+struct LevelIn { double ext, ssa, b1, em; };
+TS_HD LevelIn load_level(const Geo& g, const Bufs& b, size_t gw, int t) {
+    const size_t o = gw * g.ngrid + (g.ngrid - 1 - t);
+    LevelIn v;
+    v.ext = b.ext[o];
+    v.ssa = b.ssa[o];
+    const double f = b.delta_f ? b.delta_f[o] : 0.0;
+    v.b1 = (b.nleg > 1 ? b.leg[o * b.nleg + 1] : 0.0) - 3.0 * f / (1.0 - f);
+    v.em = b.emission ? b.emission[o] : 0.0;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// solve: layer optics, source amplitudes and the LU sweep of the boundary-value problem of every column
+// `lds`: n values per thread (layer optical depths), element i of this thread at lds[i * ls]
+// ---------------------------------------------------------------------------------------------------------------------------
+template <bool SOLAR> TS_HD void solve_thread(const Geo& g, const Bufs& b, int w, double* lds, int ls) {
+    const int n = g.nlyr, naz = naz_of(SOLAR), N = 2 * n;
+    const size_t gw = size_t(b.w0) + w;
+    const double mu = g.mu;
+    const double albedo = b.albedo[gw];
+    const double irradiance = SOLAR ? (b.irradiance ? b.irradiance[gw] : 1.0) : 0.0;
+    const double surface_emission = (!SOLAR && b.surface_emission) ? b.surface_emission[gw] : 0.0;
+
+    // layer optics (prepare_explicit_column, :1926-1955)
+    LevelIn top = load_level(g, b, gw, 0);
+    for (int l = 0; l < n; ++l) {
+        const LevelIn bot = load_level(g, b, gw, l + 1);
+        const double scat_top = top.ext * top.ssa, scat_bot = bot.ext * bot.ssa;
+        const double mean_ext = 0.5 * (top.ext + bot.ext), mean_scat = 0.5 * (scat_top + scat_bot);
+        const double od = mean_ext * g.thickness[l];
+        const double ssa = fmin(mean_ext > 0.0 ? mean_scat / mean_ext : 0.0, kSsaCap);
+        const double b1 = mean_scat > 0.0 ? 0.5 * (scat_top * top.b1 + scat_bot * bot.b1) / mean_scat : 0.0;
+        lds[l * ls] = od;
+        lay_at(b, g, 0, l, w) = od;
+        lay_at(b, g, 1, l, w) = ssa;
+        lay_at(b, g, 2, l, w) = b1;
+        if (!SOLAR) {
+            double slope = 0.0;
+            if (od > kThermalMinOd && top.em > kThermalMinEmission && bot.em > kThermalMinEmission) slope = log1p((top.em - bot.em) / bot.em) / od;
+            amp_at(b, g, 0, l, w) = top.em;
+            rate_at(b, g, 0, l, w) = slope;
+        }
+        top = bot;
+    }
+    const int ncol = SOLAR ? g.ncol : 1;
+    for (int col = 0; col < ncol; ++col) {
+        const double csz = g.csz[col];
+        if (SOLAR) {
+            // slant transmission to every boundary and the mean secant of every layer (:1956-1973)
+            amp_at(b, g, col, 0, w) = irradiance;
+            double att_prev = 0.0;
+            const double* chap = g.chapman + size_t(col) * n * n;
+            for (int bd = 0; bd < n; ++bd) {
+                double slant = 0.0;
+                for (int l = 0; l < n; ++l) {
+                    const double f = chap[size_t(bd) * n + l];
+                    if (f != 0.0) slant += lds[l * ls] * f;
+                }
+                amp_at(b, g, col, bd + 1, w) = exp(-slant) * irradiance;
+                const double od = lds[bd * ls];
+                rate_at(b, g, col, bd, w) = od > 0.0 ? (att_prev + slant) / od : 0.0;
+                att_prev = -slant;
+            }
+        }
+        const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
+        for (int az = 0; az < naz; ++az) {
+            // rows of the five-diagonal system layer by layer, eliminated as they appear (:1976-2028, :1861-1888)
+            const double delta = az == 0 ? 1.0 : 0.0;
+            double a1 = 0, a2 = 0, b1r = 0, b2r = 0, z1 = 0, z2 = 0;   // alpha, beta, z of rows i - 1 and i - 2
+            double pxp = 0, pxm = 0, pom = 0, pgpb = 0, pgmb = 0;      // previous layer
+            int row = 0;
+            auto eliminate = [&](double e, double c, double d, double a, double bb, double rhs) {
+                const double gamma = c - a2 * e;
+                const double imu = 1.0 / (d - b2r * e - a1 * gamma);
+                const double alpha = (a - b1r * gamma) * imu;
+                const double beta = bb * imu;
+                const double z = (rhs - z2 * e - z1 * gamma) * imu;
+                lu_at(b, g, naz, col, az, LU_C, row, w) = z;
+                lu_at(b, g, naz, col, az, LU_ALPHA, row, w) = alpha;
+                lu_at(b, g, naz, col, az, LU_BETA, row, w) = beta;
+                if (b.derivs) {
+                    lu_at(b, g, naz, col, az, LU_GAMMA, row, w) = gamma;
+                    lu_at(b, g, naz, col, az, LU_E, row, w) = e;
+                    lu_at(b, g, naz, col, az, LU_IMU, row, w) = imu;
+                }
+                a2 = a1; a1 = alpha; b2r = b1r; b1r = beta; z2 = z1; z1 = z;
+                ++row;
+            };
+            for (int l = 0; l < n; ++l) {
+                const LayerP<double> p = {lds[l * ls], lay_at(b, g, 1, l, w), lay_at(b, g, 2, l, w), amp_at(b, g, col, l, w), rate_at(b, g, col, l, w)};
+                const LayerSol<double> h = layer_solution<double, SOLAR>(az, p, mu, csz, angular);
+                const Boundary<double> q = boundary_particular(p, h);
+                if (l == 0) {
+                    eliminate(0.0, 0.0, h.xp, h.xm * h.omega, 0.0, -q.gpt);
+                } else {
+                    eliminate(0.0, pxm * pom, pxp, -h.xm, -h.xp * h.omega, q.gmt - pgmb);
+                    eliminate(pxp * pom, pxm, -h.xp, -h.xm * h.omega, 0.0, q.gpt - pgpb);
+                }
+                pxp = h.xp; pxm = h.xm; pom = h.omega; pgpb = q.gpb; pgmb = q.gmb;
+            }
+            const double direct = SOLAR ? delta * csz * albedo / kPi * amp_at(b, g, col, n, w) : surface_emission;
+            eliminate(0.0, (pxm - 2.0 * mu * albedo * delta * pxp) * pom, pxp - 2.0 * mu * albedo * delta * pxm, 0.0, 0.0,
+                      direct - (pgmb - 2.0 * delta * mu * albedo * pgpb));
+            // back substitution (:1889-1898)
+            double x1 = 0, x2 = 0;
+            for (int i = N - 1; i >= 0; --i) {
+                const double x = lu_at(b, g, naz, col, az, LU_C, i, w) - lu_at(b, g, naz, col, az, LU_ALPHA, i, w) * x1 -
+                                 lu_at(b, g, naz, col, az, LU_BETA, i, w) * x2;
+                lu_at(b, g, naz, col, az, LU_C, i, w) = x;
+                x2 = x1;
+                x1 = x;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// view: radiance of one line of sight and, with DERIVS, its weighting functions
+// `lds`: n + 1 values per thread, element i of this thread at lds[i * ls]
+// ---------------------------------------------------------------------------------------------------------------------------
+template <bool SOLAR> TS_HD LayerP<double> load_p(const Geo& g, const Bufs& b, int col, int l, int w) {
+    return {lay_at(b, g, 0, l, w), lay_at(b, g, 1, l, w), lay_at(b, g, 2, l, w), amp_at(b, g, SOLAR ? col : 0, l, w), rate_at(b, g, SOLAR ? col : 0, l, w)};
+}
+template <class S> TS_HD LayerP<S> lift(const LayerP<double>& p) { return make_p(p.od, p.ssa, p.b1, p.amp, p.rate, S()); }
+
+// upwelling radiance leaving the Lambertian surface divided by (2 mu albedo): the downwelling stream at the bottom of the last layer
+// (explicit_surface_source, :2403-2419)
+template <class S> TS_HD S bottom_plus(const LayerSol<S>& h, const Boundary<S>& q, double c0, double c1) {
+    return q.gpb + c0 * (h.xp * h.omega) + c1 * h.xm;
+}
+
+template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bufs& b, int w, int view, double* lds, int ls) {
+    using S = typename std::conditional<DERIVS, D5, double>::type;
+    const int n = g.nlyr, naz = naz_of(SOLAR), N = 2 * n, ncol = SOLAR ? g.ncol : 1;
+    const size_t gw = size_t(b.w0) + w;
+    const double mu = g.mu;
+    const double albedo = b.albedo[gw];
+    const double surface_emission = (!SOLAR && b.surface_emission) ? b.surface_emission[gw] : 0.0;
+    double radiance = 0.0;
+    double g_albedo = 0.0, g_surface_emission = 0.0;
+    // weight of the surface term of every column in the radiance; (ground_lo, ground_up, ground_uw) for the spherical case
+    double surf_weight = 0.0, ground_uw = 0.0;
+    int ground_lo = 0, ground_up = 0;
+    double plane_total_over_vc = 0.0;   // plane parallel: F / view cosine, the optical-depth gradient of the attenuation above a layer
+
+    if (DERIVS) {
+        for (int col = 0; col < ncol; ++col) {
+            for (int az = 0; az < naz; ++az)
+                for (int i = 0; i < N; ++i) lam_at(b, g, naz, view, col, az, i, w) = 0.0;
+            for (int l = 0; l < n; ++l)
+                for (int d = 0; d < 5; ++d) g5_at(b, g, view, col, l, d, w) = 0.0;
+        }
+        for (int l = 0; l < n; ++l)
+            for (int k = 0; k < 3; ++k) gsum_at(b, g, view, k, l, w) = 0.0;
+    }
+
+    if (!g.spherical) {
+        // ---- plane parallel (:2550-2668): layer-integrated sources attenuated to the top of the atmosphere
+        const double vc = g.view_cos[view], inv = 1.0 / vc, csz = g.csz[0];
+        const double azw[2] = {1.0, cos(g.view_azimuth[view])};
+        const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
+        double attenuation = 1.0;
+        for (int l = 0; l < n; ++l) {
+            const LayerP<double> pv = load_p<SOLAR>(g, b, 0, l, w);
+            const LayerP<S> p = lift<S>(pv);
+            const S beam = t_exp(-(p.od * inv));
+            S source = cst<S>(0.0);
+            for (int az = 0; az < naz; ++az) {
+                const LayerSol<S> h = layer_solution<S, SOLAR>(az, p, mu, csz, angular);
+                const bool fast = plane_nonresonant(pv.rate, val(h.k), pv.od, inv);
+                const S source_integral = plane_source_integral(p, h.expo, beam, vc, fast);
+                S U, V, P;
+                plane_source_terms<S, SOLAR>(az, p, h, vc, mu, fast, beam, source_integral, U, V, P);
+                const double c0 = lu_at(b, g, naz, 0, az, LU_C, 2 * l, w), c1 = lu_at(b, g, naz, 0, az, LU_C, 2 * l + 1, w);
+                source += azw[az] * (c0 * U + c1 * V + P);
+                if (!SOLAR && az == 0) source += p.amp * source_integral * (1.0 - p.ssa);
+                if (DERIVS) {
+                    lam_at(b, g, naz, view, 0, az, 2 * l, w) = attenuation * azw[az] * val(U);
+                    lam_at(b, g, naz, view, 0, az, 2 * l + 1, w) = attenuation * azw[az] * val(V);
+                }
+            }
+            radiance += val(source) * attenuation;
+            if (DERIVS) {
+                for (int d = 0; d < 5; ++d) g5_at(b, g, view, 0, l, d, w) = attenuation * dpart(source, d);
+                // every source below this layer is attenuated by exp(-od / vc) of this one: -(F - sources down to this layer) / vc,
+                // the F part is added once the radiance is known
+                g5_at(b, g, view, 0, l, 0, w) += radiance * inv;
+            }
+            attenuation *= val(beam);
+        }
+        surf_weight = attenuation;
+    } else {
+        // ---- spherical (:1196-1233): R <- R t + S (1 - t) over the traced segments, far end first
+        const int s0 = g.ray_start[view], s1 = g.ray_start[view + 1];
+        ground_lo = SOLAR ? g.ground_col[2 * view] : 0;
+        ground_up = SOLAR ? g.ground_col[2 * view + 1] : 0;
+        ground_uw = SOLAR ? g.ground_colw[view] : 0.0;
+        auto surface_of = [&](int col) {
+            const LayerP<double> p = load_p<SOLAR>(g, b, col, n - 1, w);
+            const double csz = g.csz[col];
+            const LayerSol<double> h = layer_solution<double, SOLAR>(0, p, mu, csz, 0.0);
+            const Boundary<double> q = boundary_particular(p, h);
+            const double base = bottom_plus(h, q, lu_at(b, g, naz, col, 0, LU_C, N - 2, w), lu_at(b, g, naz, col, 0, LU_C, N - 1, w));
+            return base * (2.0 * mu) * albedo + (SOLAR ? 0.0 : surface_emission);
+        };
+        if (g.ground_hit[view]) {
+            radiance = surface_of(ground_lo);
+            if (ground_lo != ground_up) radiance = radiance * (1.0 - ground_uw) + surface_of(ground_up) * ground_uw;
+        }
+        auto segment_source = [&](int s, int col) {
+            const int l = g.seg_layer[s];
+            const LayerP<double> p = load_p<SOLAR>(g, b, col, l, w);
+            const double csz = g.csz[col];
+            const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
+            const double azw[2] = {1.0, cos(g.seg_azimuth[s])};
+            double src = 0.0;
+            for (int az = 0; az < naz; ++az) {
+                const LayerSol<double> h = layer_solution<double, SOLAR>(az, p, mu, csz, angular);
+                double U, V, P;
+                local_source_terms<double, SOLAR>(az, p, h, g.seg_frac[s], g.seg_cos[s], mu, U, V, P);
+                src += azw[az] * (lu_at(b, g, naz, col, az, LU_C, 2 * l, w) * U + lu_at(b, g, naz, col, az, LU_C, 2 * l + 1, w) * V + P);
+            }
+            if (!SOLAR) src += local_emission(p, g.seg_frac[s]);
+            return src;
+        };
+        for (int s = s0; s < s1; ++s) {
+            double od = 0.0;
+            for (int j = g.od_start[s]; j < g.od_start[s + 1]; ++j) od += b.ext[gw * g.ngrid + (g.ngrid - 1 - g.od_level[j])] * g.od_weight[j];
+            const double t = exp(-od);
+            const int lo = SOLAR ? g.seg_col[2 * s] : 0, up = SOLAR ? g.seg_col[2 * s + 1] : 0;
+            double src = segment_source(s, lo);
+            if (lo != up) {
+                const double uw = g.seg_colw[s];
+                src = src * (1.0 - uw) + segment_source(s, up) * uw;
+            }
+            if (DERIVS) {
+                path_at(b, g, view, 0, s - s0, w) = t;
+                path_at(b, g, view, 1, s - s0, w) = src;
+                path_at(b, g, view, 2, s - s0, w) = radiance;
+            }
+            radiance = radiance * t + src * (1.0 - t);
+        }
+        if (DERIVS) {
+            // reverse sweep over the segments: weights of the sources, level-extinction gradient of the transmissions, and the
+            // source gradients (dual numbers) gathered per (column, layer)
+            for (int t = 0; t < g.ngrid; ++t) glev_at(b, g, view, t, w) = 0.0;
+            double d_rad = 1.0;
+            for (int s = s1 - 1; s >= s0; --s) {
+                const double t = path_at(b, g, view, 0, s - s0, w), src = path_at(b, g, view, 1, s - s0, w), incoming = path_at(b, g, view, 2, s - s0, w);
+                const double d_od = -d_rad * (incoming - src) * t;
+                for (int j = g.od_start[s]; j < g.od_start[s + 1]; ++j) glev_at(b, g, view, g.od_level[j], w) += d_od * g.od_weight[j];
+                const double d_src = d_rad * (1.0 - t);
+                const int lo = SOLAR ? g.seg_col[2 * s] : 0, up = SOLAR ? g.seg_col[2 * s + 1] : 0;
+                const double uw = (lo != up) ? g.seg_colw[s] : 0.0;
+                const int l = g.seg_layer[s];
+                for (int side = 0; side < (lo != up ? 2 : 1); ++side) {
+                    const int col = side == 0 ? lo : up;
+                    const double wgt = d_src * (side == 0 ? 1.0 - uw : uw);
+                    const LayerP<D5> p = lift<D5>(load_p<SOLAR>(g, b, col, l, w));
+                    const double csz = g.csz[col];
+                    const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
+                    const double azw[2] = {1.0, cos(g.seg_azimuth[s])};
+                    D5 acc = mkd(0.0);
+                    for (int az = 0; az < naz; ++az) {
+                        const LayerSol<D5> h = layer_solution<D5, SOLAR>(az, p, mu, csz, angular);
+                        D5 U, V, P;
+                        local_source_terms<D5, SOLAR>(az, p, h, g.seg_frac[s], g.seg_cos[s], mu, U, V, P);
+                        const double c0 = lu_at(b, g, naz, col, az, LU_C, 2 * l, w), c1 = lu_at(b, g, naz, col, az, LU_C, 2 * l + 1, w);
+                        acc += azw[az] * (c0 * U + c1 * V + P);
+                        lam_at(b, g, naz, view, col, az, 2 * l, w) += wgt * azw[az] * U.v;
+                        lam_at(b, g, naz, view, col, az, 2 * l + 1, w) += wgt * azw[az] * V.v;
+                    }
+                    if (!SOLAR) acc += local_emission(p, g.seg_frac[s]);
+                    for (int d = 0; d < 5; ++d) g5_at(b, g, view, col, l, d, w) += wgt * acc.d[d];
+                }
+                d_rad *= t;
+            }
+            surf_weight = g.ground_hit[view] ? d_rad : 0.0;
+        }
+    }
+
+    if (!g.spherical) {
+        // surface term of the plane-parallel radiance
+        const LayerP<double> p = load_p<SOLAR>(g, b, 0, n - 1, w);
+        const LayerSol<double> h = layer_solution<double, SOLAR>(0, p, mu, g.csz[0], 0.0);
+        const Boundary<double> q = boundary_particular(p, h);
+        const double base = bottom_plus(h, q, lu_at(b, g, naz, 0, 0, LU_C, N - 2, w), lu_at(b, g, naz, 0, 0, LU_C, N - 1, w));
+        radiance += surf_weight * (base * (2.0 * mu) * albedo + surface_emission);
+        plane_total_over_vc = radiance / g.view_cos[view];
+    }
+    {
+        double* dst = b.radiance + gw * g.nlos + view;
+        *dst = b.accumulate ? *dst + radiance : radiance;
+    }
+    if (!DERIVS) return;
+
+    // ---- the boundary-value problem's share of the gradient, column by column
+    for (int col = 0; col < ncol; ++col) {
+        const double csz = g.csz[col];
+        const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
+        double ws = surf_weight;   // weight of this column's surface source in the radiance
+        if (g.spherical && SOLAR) {
+            ws = 0.0;
+            if (col == ground_lo) ws += surf_weight * (ground_lo != ground_up ? 1.0 - ground_uw : 1.0);
+            if (col == ground_up && ground_lo != ground_up) ws += surf_weight * ground_uw;
+        }
+        if (!SOLAR) g_surface_emission += ws;
+        const double wsurf = ws * (2.0 * mu) * albedo;   // multiplies the downwelling stream at the ground
+        for (int i = 0; i <= n; ++i) lds[i * ls] = 0.0;  // gradient with respect to the solar attenuation exponent at every boundary
+        for (int az = 0; az < naz; ++az) {
+            const double delta = az == 0 ? 1.0 : 0.0;
+            // dF/dc of the surface term, then lambda = A^-T dF/dc (pentadiagonal_transpose_solve, :1901-1921)
+            if (az == 0 && wsurf != 0.0) {
+                const LayerP<double> p = load_p<SOLAR>(g, b, col, n - 1, w);
+                const LayerSol<double> h = layer_solution<double, SOLAR>(0, p, mu, csz, 0.0);
+                lam_at(b, g, naz, view, col, 0, N - 2, w) += wsurf * h.xp * h.omega;
+                lam_at(b, g, naz, view, col, 0, N - 1, w) += wsurf * h.xm;
+            }
+            {
+                double r1 = 0, r2 = 0;
+                for (int i = 0; i < N; ++i) {
+                    double r = lam_at(b, g, naz, view, col, az, i, w);
+                    if (i >= 1) r -= lu_at(b, g, naz, col, az, LU_ALPHA, i - 1, w) * r1;
+                    if (i >= 2) r -= lu_at(b, g, naz, col, az, LU_BETA, i - 2, w) * r2;
+                    lam_at(b, g, naz, view, col, az, i, w) = r;
+                    r2 = r1;
+                    r1 = r;
+                }
+                double x1 = 0, x2 = 0;
+                for (int i = N - 1; i >= 0; --i) {
+                    double r = lam_at(b, g, naz, view, col, az, i, w);
+                    if (i + 1 < N) r -= lu_at(b, g, naz, col, az, LU_GAMMA, i + 1, w) * x1;
+                    if (i + 2 < N) r -= lu_at(b, g, naz, col, az, LU_E, i + 2, w) * x2;
+                    r *= lu_at(b, g, naz, col, az, LU_IMU, i, w);
+                    lam_at(b, g, naz, view, col, az, i, w) = r;
+                    x2 = x1;
+                    x1 = r;
+                }
+            }
+            // Lagrangian of every layer: lambda . (r - A c) restricted to the rows that hold this layer, plus the surface term
+            for (int l = n - 1; l >= 0; --l) {
+                const LayerP<double> pv = load_p<SOLAR>(g, b, col, l, w);
+                const LayerP<D5> p = lift<D5>(pv);
+                const LayerSol<D5> h = layer_solution<D5, SOLAR>(az, p, mu, csz, angular);
+                const Boundary<D5> q = boundary_particular(p, h);
+                const double c0 = lu_at(b, g, naz, col, az, LU_C, 2 * l, w), c1 = lu_at(b, g, naz, col, az, LU_C, 2 * l + 1, w);
+                const D5 xpo = h.xp * h.omega, xmo = h.xm * h.omega;
+                const D5 top_plus = q.gpt + c0 * h.xp + c1 * xmo, top_minus = q.gmt + c0 * h.xm + c1 * xpo;
+                const D5 bot_plus = q.gpb + c0 * xpo + c1 * h.xm, bot_minus = q.gmb + c0 * xmo + c1 * h.xp;
+                D5 G;
+                if (l == 0) G = -(lam_at(b, g, naz, view, col, az, 0, w) * top_plus);
+                else G = lam_at(b, g, naz, view, col, az, 2 * l - 1, w) * top_minus + lam_at(b, g, naz, view, col, az, 2 * l, w) * top_plus;
+                if (l == n - 1) {
+                    const double lam_last = lam_at(b, g, naz, view, col, az, N - 1, w);
+                    const double refl = 2.0 * mu * albedo * delta;
+                    G += lam_last * (refl * bot_plus - bot_minus);
+                    if (az == 0) G += wsurf * bot_plus;
+                    // the surface row also holds the albedo, the transmission to the ground and the surface emission
+                    const double amp_ground = SOLAR ? amp_at(b, g, col, n, w) : 0.0;
+                    g_albedo += lam_last * (delta * csz / kPi * amp_ground + 2.0 * mu * delta * bot_plus.v);
+                    if (az == 0) g_albedo += ws * (2.0 * mu) * bot_plus.v;
+                    if (SOLAR) lds[n * ls] += lam_last * delta * csz * albedo / kPi * amp_ground;
+                    else g_surface_emission += lam_last;
+                } else {
+                    G += -(lam_at(b, g, naz, view, col, az, 2 * l + 1, w) * bot_minus) - lam_at(b, g, naz, view, col, az, 2 * l + 2, w) * bot_plus;
+                }
+                for (int d = 0; d < 5; ++d) g5_at(b, g, view, col, l, d, w) += G.d[d];
+            }
+        }
+        // from (amplitude, rate) of this column to the layer optical depths or the level emissions
+        for (int l = n - 1; l >= 0; --l) {
+            const LayerP<double> pv = load_p<SOLAR>(g, b, col, l, w);
+            double g_od = g5_at(b, g, view, col, l, 0, w);
+            if (!g.spherical) g_od -= plane_total_over_vc;
+            const double g_amp = g5_at(b, g, view, col, l, 3, w), g_rate = g5_at(b, g, view, col, l, 4, w);
+            if (SOLAR) {
+                // amplitude = irradiance exp(att_l); rate = (att_l - att_(l+1)) / od  (map_explicit_to_levels, :2843-2865)
+                if (l > 0) lds[l * ls] += g_amp * pv.amp;
+                if (pv.od > 0.0) {
+                    const double wgt = g_rate / pv.od;
+                    lds[l * ls] += wgt;
+                    lds[(l + 1) * ls] -= wgt;
+                    g_od -= g_rate * pv.rate / pv.od;
+                }
+            }
+            // (thermal: amplitude = emission at the top level, rate = log(top / bottom) / od, :2868-2887 -- mapped with the levels below)
+            gsum_at(b, g, view, 0, l, w) += g_od;
+            gsum_at(b, g, view, 1, l, w) += g5_at(b, g, view, col, l, 1, w);
+            gsum_at(b, g, view, 2, l, w) += g5_at(b, g, view, col, l, 2, w);
+        }
+        if (SOLAR) {
+            // attenuation exponents are minus the Chapman-weighted optical depths above the boundary
+            const double* chap = g.chapman + size_t(col) * n * n;
+            for (int l = 0; l < n; ++l) {
+                double acc = 0.0;
+                for (int bd = 1; bd <= n; ++bd) {
+                    const double f = chap[size_t(bd - 1) * n + l];
+                    if (f != 0.0) acc += lds[bd * ls] * f;
+                }
+                gsum_at(b, g, view, 0, l, w) -= acc;
+            }
+        }
+    }
+
+    // ---- from the layers to the level profiles (map_explicit_to_levels, :2889-2919) and out
+    {
+        double carry_ext = 0.0, carry_ssa = 0.0, carry_b1 = 0.0, carry_em = 0.0;
+        LevelIn top = load_level(g, b, gw, 0);
+        for (int t = 0; t <= n; ++t) {
+            double o_ext = carry_ext, o_ssa = carry_ssa, o_b1 = carry_b1, o_em = carry_em;
+            carry_ext = carry_ssa = carry_b1 = carry_em = 0.0;
+            if (t < n) {
+                const int l = t;
+                const LevelIn bot = load_level(g, b, gw, l + 1);
+                const double od = lay_at(b, g, 0, l, w), ssa = lay_at(b, g, 1, l, w), b1 = lay_at(b, g, 2, l, w);
+                double g_od = gsum_at(b, g, view, 0, l, w);
+                const double g_ssa = ssa >= kSsaCap ? 0.0 : gsum_at(b, g, view, 1, l, w), g_b1 = gsum_at(b, g, view, 2, l, w);
+                if (!SOLAR) {
+                    const double g_amp = g5_at(b, g, view, 0, l, 3, w), g_rate = g5_at(b, g, view, 0, l, 4, w);
+                    o_em += g_amp;
+                    if (od > kThermalMinOd && top.em > kThermalMinEmission && bot.em > kThermalMinEmission) {
+                        o_em += g_rate / (top.em * od);
+                        carry_em -= g_rate / (bot.em * od);
+                        g_od -= g_rate * rate_at(b, g, 0, l, w) / od;
+                    }
+                }
+                const double dz = g.thickness[l];
+                const double mean_ext = od / dz, mean_scat = ssa * mean_ext;
+                const double c_od = 0.5 * g_od * dz;
+                const double c_ssa = mean_ext > 0.0 ? 0.5 * g_ssa / mean_ext : 0.0;
+                const double c_b1 = mean_scat > 0.0 ? 0.5 * g_b1 / mean_scat : 0.0;
+                const double db_top = top.b1 - b1, db_bot = bot.b1 - b1;
+                o_ext += c_od + c_ssa * (top.ssa - ssa) + c_b1 * top.ssa * db_top;
+                o_ssa += c_ssa * top.ext + c_b1 * top.ext * db_top;
+                o_b1 += c_b1 * top.ssa * top.ext;
+                carry_ext = c_od + c_ssa * (bot.ssa - ssa) + c_b1 * bot.ssa * db_bot;
+                carry_ssa = c_ssa * bot.ext + c_b1 * bot.ext * db_bot;
+                carry_b1 = c_b1 * bot.ssa * bot.ext;
+                top = bot;
+            }
+            if (g.spherical) o_ext += glev_at(b, g, view, t, w);
+            const size_t o = (size_t(g.ngrid - 1 - t) * b.nw_total + gw) * g.nlos + view;
+            if (b.accumulate) {
+                b.wf_ext[o] += o_ext;
+                b.wf_ssa[o] += o_ssa;
+                b.wf_b1[o] += o_b1;
+                if (!SOLAR && b.wf_em) b.wf_em[o] += o_em;
+            } else {
+                b.wf_ext[o] = o_ext;
+                b.wf_ssa[o] = o_ssa;
+                b.wf_b1[o] = o_b1;
+                if (b.wf_em) b.wf_em[o] = SOLAR ? 0.0 : o_em;
+            }
+        }
+        const size_t o = gw * g.nlos + view;
+        if (b.accumulate) {
+            b.wf_alb[o] += g_albedo;
+            if (b.wf_sem) b.wf_sem[o] += g_surface_emission;
+        } else {
+            b.wf_alb[o] = g_albedo;
+            if (b.wf_sem) b.wf_sem[o] = g_surface_emission;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// scratch sizes in doubles for W lanes (shared by the HIP driver and the CPU emulation of the tests)
+// ---------------------------------------------------------------------------------------------------------------------------
+struct ScratchSizes {
+    size_t lay, colv, lu, lam, g5, gsum, path, glev;
+    size_t total() const { return lay + colv + lu + lam + g5 + gsum + path + glev; }
+};
+inline ScratchSizes scratch_sizes(int nlyr, int ngrid, int nlos, int ncol, int max_seg, bool spherical, bool derivs, size_t W) {
+    ScratchSizes z{};
+    const size_t n = size_t(nlyr);
+    z.lay = 3 * n * W;
+    z.colv = size_t(ncol) * (2 * n + 1) * W;
+    z.lu = size_t(ncol) * 2 * 6 * (2 * n) * W;
+    if (derivs) {
+        z.lam = size_t(nlos) * ncol * 2 * (2 * n) * W;
+        z.g5 = size_t(nlos) * ncol * n * 5 * W;
+        z.gsum = size_t(nlos) * 3 * n * W;
+        if (spherical) {
+            z.path = size_t(nlos) * 3 * size_t(max_seg) * W;
+            z.glev = size_t(nlos) * size_t(ngrid) * W;
+        }
+    }
+    return z;
+}
+
+}  // namespace skt

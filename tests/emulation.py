@@ -140,3 +140,63 @@ def run_emulated_vector(s, derivatives=False, d_legendre=None):
         return out
     finally:
         L.emuv_destroy(h)
+
+
+# ---- two-stream source (tests/emulate_twostream.cpp runs sasktran2_amd/csrc/hip/ts_core.hpp on the CPU)
+_LIB_TS = None
+
+
+def lib_ts():
+    global _LIB_TS
+    if _LIB_TS is None:
+        so = _HERE / "_build" / "libemuts.so"
+        srcs = [_HERE / "emulate_twostream.cpp", _ROOT / "sasktran2_amd/csrc/hip/ts_core.hpp",
+                _ROOT / "sasktran2_amd/csrc/host/ts_geometry.hpp", _ROOT / "sasktran2_amd/csrc/host/geometry.hpp"]
+        if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+            so.parent.mkdir(exist_ok=True)
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(srcs[0])])
+        L = ctypes.CDLL(str(so))
+        L.emts_create.restype = ctypes.c_void_p
+        L.emts_create.argtypes = [ctypes.c_double] * 3 + [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp] + [ctypes.c_int] * 3
+        L.emts_destroy.argtypes = [ctypes.c_void_p]
+        L.emts_run.restype = ctypes.c_int
+        L.emts_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [_dp] * 15
+        _LIB_TS = L
+    return _LIB_TS
+
+
+def run_emulated_twostream(s, derivatives=True, solar=True, thermal=False):
+    """The two-stream kernels on the CPU.  Returns the oracle's output names and layouts: radiance [nw, nlos], d_extinction / d_ssa /
+    d_b1 / d_emission [nw, nlos, ngrid], d_albedo / d_surface_emission [nw, nlos]."""
+    g = s["geometry"]
+    alt = np.ascontiguousarray(g["altitudes"], dtype=np.float64)
+    rays = s["rays"]
+    kinds = np.ascontiguousarray([r[0] for r in rays], dtype=np.int32)
+    params = np.ascontiguousarray([[r[1], r[2], r[3], r[4]] for r in rays], dtype=np.float64)
+    L = lib_ts()
+    h = L.emts_create(g["cos_sza"], g["saa"], g["earth_radius"], _p(alt), len(alt), g["interp_method"], g["geotype"], len(rays),
+                      kinds.ctypes.data_as(_ip), _p(params), int(s["config"]["num_sza"]), int(solar), int(thermal))
+    assert h
+    try:
+        k = np.asfortranarray(s["extinction"], dtype=np.float64)
+        w = np.asfortranarray(s["ssa"], dtype=np.float64)
+        lg = np.asfortranarray(s["leg"], dtype=np.float64)
+        nw, nlos, ngrid = k.shape[1], len(rays), len(alt)
+        alb = np.ascontiguousarray(s["albedo"], dtype=np.float64)
+        opt = lambda key, f: None if s.get(key) is None else f(s[key], dtype=np.float64)
+        df, em = opt("delta_f", np.asfortranarray), opt("emission", np.asfortranarray)
+        sem, irr = opt("surface_emission", np.ascontiguousarray), opt("solar_irradiance", np.ascontiguousarray)
+        rad = np.zeros((nw, nlos))
+        wf = [None] * 6
+        if derivatives:
+            wf = [np.zeros((ngrid, nw, nlos)) for _ in range(4)] + [np.zeros((nw, nlos)) for _ in range(2)]
+        rc = L.emts_run(h, nw, lg.shape[0], _p(k), _p(w), _p(lg), _p(df), _p(em), _p(sem), _p(irr), _p(alb), _p(rad), *[_p(a) for a in wf])
+        assert rc == 0, rc
+        out = {"radiance": rad}
+        if derivatives:
+            for name, a in zip(("d_extinction", "d_ssa", "d_b1", "d_emission"), wf[:4]):
+                out[name] = np.ascontiguousarray(a.transpose(1, 2, 0))
+            out["d_albedo"], out["d_surface_emission"] = wf[4], wf[5]
+        return out
+    finally:
+        L.emts_destroy(h)
