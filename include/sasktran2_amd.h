@@ -140,6 +140,19 @@ int sk_amd_engine_set_delta_m_fraction(Engine* engine, const double* d_f);
  * d_leg [nwavel][nlocation][nleg (x 4 for NSTOKES = 3)], d_radiance [nwavel][nlos][nstokes], d_los_od [nwavel][nlos] or NULL. */
 int sk_amd_so_engine_solve_device(Engine* engine, int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
                                   const double* d_albedo, const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream);
+/* The same for an engine whose source is the two-stream one (multiple_scatter_source = twostream and / or emission_source = twostream;
+ * replaces, per wavelength block, CppTwoStreamSourceAdapter::calculate + start_of_ray_source,
+ * cpp/lib/sktran_disco/cpp_twostream_source.cpp:3532-3630).  Inputs in the reference storage layout: d_ext, d_ssa, d_delta_f, d_emission
+ * [nwavel][nlocation], d_leg [nwavel][nlocation][nleg], d_albedo / d_irradiance / d_surface_emission [nwavel]; d_delta_f (truncation
+ * fraction of already delta-M scaled optics), d_irradiance, d_emission and d_surface_emission may be NULL as the configured sources allow.
+ * Outputs: d_radiance [nwavel][nlos], d_los_od [nwavel][nlos] or NULL, and -- all of d_wf_ext / d_wf_ssa / d_wf_b1 / d_wf_albedo or none --
+ * d_wf_ext, d_wf_ssa, d_wf_b1 (first Legendre coefficient), d_wf_emission [nlocation][nwavel][nlos], d_wf_albedo,
+ * d_wf_surface_emission [nwavel][nlos] (the two emission outputs may be NULL).  max_chunk: wavelengths per kernel launch, 0 = automatic. */
+int sk_amd_ts_engine_solve_device(Engine* engine, int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
+                                  const double* d_delta_f, const double* d_albedo, const double* d_irradiance, const double* d_emission,
+                                  const double* d_surface_emission, double* d_radiance, double* d_los_od, double* d_wf_ext, double* d_wf_ssa,
+                                  double* d_wf_b1, double* d_wf_albedo, double* d_wf_emission, double* d_wf_surface_emission, void* stream,
+                                  int max_chunk);
 /* sizes[0..5]: incoming rays, their layers, accumulation-matrix entries, outgoing directions, scratch bytes per wavelength,
  * wavelengths per block of the last solve */
 int sk_amd_so_engine_sizes(Engine* engine, unsigned long long* sizes);

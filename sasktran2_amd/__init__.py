@@ -77,7 +77,7 @@ class Config:
              "wavelength_batch_size": "wavelength_batch_size", "output_los_optical_depth": "output_los_optical_depth",
              "multiple_scatter_source": "multiple_scatter_source", "single_scatter_source": "single_scatter_source",
              "wf_enabled": "wf_enabled", "delta_m_scaling": "apply_delta_scaling", "stokes_basis": "stokes_basis",
-             "emission_source": "emission_source", "occultation_source": "occultation_source",
+             "emission_source": "emission_source", "occultation_source": "occultation_source", "do_backprop": "do_backprop",
              # successive orders (src/sasktran2/config.py:410-418,505-514,607-634 -> the C API's `hr` keys)
              "num_successive_orders_iterations": "num_hr_spherical_iterations", "num_successive_orders_incoming": "num_hr_incoming",
              "num_successive_orders_outgoing": "num_hr_outgoing", "init_successive_orders_with_discrete_ordinates": "initialize_hr_with_do"}
@@ -407,7 +407,9 @@ class Engine:
                 out["wf_albedo"] = np.zeros((nw, nlos, S))
                 L.sk_output_assign_surface_derivative_memory(h_out, b"wf_albedo", _p(out["wf_albedo"]), nw * nlos, S)
             if _mapping_hook is not None:
+                out["_surface_handle"] = h_su
                 _mapping_hook(L, h_st, h_out, out)
+                out.pop("_surface_handle", None)
             self._apply_delta_m(H, delta_order)
             rc = L.sk_engine_calculate_radiance(self._h, h_atm, h_out, 0)
             if rc != 0:

@@ -72,6 +72,7 @@ SIGNATURES = [
     ("sk_amd_engine_set_delta_m_fraction", _I, [_vp, _vp]),
     ("sk_amd_so_engine_solve_device", _I, [_vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("sk_amd_so_engine_sizes", _I, [_vp, ctypes.POINTER(ctypes.c_ulonglong)]),
+    ("sk_amd_ts_engine_solve_device", _I, [_vp, _I, _I] + [_vp] * 17 + [_I]),
     ("sk_atmosphere_apply_delta_m_scaling", _I, [_vp, _I]),
     ("sk_amd_engine_num_los", _I, [_vp, _ip]),
     ("sk_amd_engine_scratch_bytes", _I, [_vp, _I, ctypes.POINTER(ctypes.c_ulonglong)]),

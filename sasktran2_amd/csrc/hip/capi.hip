@@ -18,6 +18,7 @@
 #include "../../../include/sasktran2_amd.h"
 #include "disco_engine.hpp"
 #include "so_engine.hpp"
+#include "ts_engine.hpp"
 
 namespace {
 thread_local std::string g_last_error;
@@ -128,6 +129,7 @@ struct Engine {
     Config config;
     std::unique_ptr<skdev::DeviceEngine> dev;      // discrete-ordinates source (multiple_scatter_source = discrete_ordinates)
     std::unique_ptr<skdev::SoDeviceEngine> so;     // exact single scatter and / or legacy successive orders
+    std::unique_ptr<skdev::TsDeviceEngine> ts;     // two-stream source (multiple_scatter_source = twostream, emission_source = twostream)
     int nlos = 0, ngrid = 0;
     DeviceCache cache;
 };
@@ -136,7 +138,7 @@ struct Engine {
 // evaluated on the device in the output layout [nderiv][wavel][los]; the mapping factors are [wavel][location]
 __global__ void __launch_bounds__(256) kern_map_wf(const double* we, const double* ws, const double* f_ssa, const double* f_ext,
                                                    double* dst, int ngrid, int nw, int nlos, const double* wg = nullptr,
-                                                   const double* f_scat = nullptr) {
+                                                   const double* f_scat = nullptr, const double* wem = nullptr, const double* f_em = nullptr) {
     // wg / f_scat: native scattering-group derivatives and the mapping's scat_factor (outputc.cpp:76-90), or null
     const size_t n = size_t(ngrid) * nw * nlos;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
@@ -144,6 +146,7 @@ __global__ void __launch_bounds__(256) kern_map_wf(const double* we, const doubl
         const int q = int(qw / nw), w = int(qw % nw);
         double acc = f_ssa[size_t(w) * ngrid + q] * ws[i] + f_ext[size_t(w) * ngrid + q] * we[i];
         if (wg) acc += f_scat[size_t(w) * ngrid + q] * wg[i];
+        if (wem) acc += f_em[size_t(w) * ngrid + q] * wem[i];   // d_emission x dI/d(emission) (two-stream thermal source)
         dst[i] = acc;
     }
 }
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(256) kern_map_wf(const double* we, const doubl
 __global__ void __launch_bounds__(256) kern_map_wf_interp(const double* we, const double* ws, const double* f_ssa, const double* f_ext,
                                                           const double* interp, const double* radiance, int log_space, double* dst,
                                                           int ngrid, int nout, int nw, int nlos, int S = 1, const double* wg = nullptr,
-                                                          const double* f_scat = nullptr) {
+                                                          const double* f_scat = nullptr, const double* wem = nullptr, const double* f_em = nullptr) {
     // nlos counts (line of sight, Stokes component) pairs; a log-radiance mapping divides every component by the intensity
     const size_t n = size_t(nout) * nw * nlos;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
@@ -164,14 +167,30 @@ __global__ void __launch_bounds__(256) kern_map_wf_interp(const double* we, cons
                 const size_t o = (size_t(q) * nw + w) * nlos + l;
                 double v = f_ssa[size_t(w) * ngrid + q] * ws[o] + f_ext[size_t(w) * ngrid + q] * we[o];
                 if (wg) v += f_scat[size_t(w) * ngrid + q] * wg[o];
+                if (wem) v += f_em[size_t(w) * ngrid + q] * wem[o];
                 acc += interp[size_t(j) * ngrid + q] * v;
             }
         } else {
             acc = f_ssa[size_t(w) * ngrid + j] * ws[i] + f_ext[size_t(w) * ngrid + j] * we[i];
             if (wg) acc += f_scat[size_t(w) * ngrid + j] * wg[i];
+            if (wem) acc += f_em[size_t(w) * ngrid + j] * wem[i];
         }
         if (log_space) acc /= radiance[size_t(w) * nlos + (l / S) * S];
         dst[i] = acc;
+    }
+}
+// two-stream source: scattering-group derivative = dI/d(b1) x (d_legendre(1) - 3 d_f / (1 - f)^2)
+// (CppTwoStreamSourceAdapter::start_of_ray_source, cpp/lib/sktran_disco/cpp_twostream_source.cpp:3583-3604); wb1 / dst [ngrid][wavel][los]
+__global__ void __launch_bounds__(256) kern_ts_scat_group(const double* wb1, const double* dleg, const double* f, const double* df, double* dst,
+                                                          int ngrid, int nw, int nlos, int nleg) {
+    const size_t n = size_t(ngrid) * nw * nlos;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const size_t qw = i / nlos;
+        const int q = int(qw / nw), w = int(qw % nw);
+        const size_t o = size_t(w) * ngrid + q;
+        double d = nleg > 1 ? dleg[o * nleg + 1] : 0.0;
+        if (f && df) d -= 3.0 * df[o] / ((1.0 - f[o]) * (1.0 - f[o]));
+        dst[i] = wb1[i] * d;
     }
 }
 __global__ void __launch_bounds__(256) kern_transpose_od(const double* od, double* out, int nw, int nlos) {
@@ -355,20 +374,29 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
     try {
         if (c->num_stokes != 1 && c->num_stokes != 3) throw std::runtime_error("NSTOKES must be 1 or 3");
         if (c->stokes_basis < 0 || c->stokes_basis > 2) throw std::runtime_error("stokes_basis must be standard (0), solar (1) or observer (2)");
-        // sources of this build (cpp/include/sasktran2/config.h:41-71): multiple scatter discrete_ordinates (0), successive_orders_legacy (1)
-        // or none (3); single scatter exact (0), discrete_ordinates (2) or none (3)
-        if (c->ms_source != 0 && c->ms_source != 1 && c->ms_source != 3)
-            throw std::runtime_error("multiple_scatter_source must be discrete_ordinates (0), successive_orders_legacy (1) or none (3); "
-                                     "twostream (2) and successive_orders (4) are not part of this build");
+        // sources of this build (cpp/include/sasktran2/config.h:41-71): multiple scatter discrete_ordinates (0), successive_orders_legacy (1),
+        // twostream (2) or none (3); single scatter exact (0), discrete_ordinates (2) or none (3)
+        if (c->ms_source < 0 || c->ms_source > 3)
+            throw std::runtime_error("multiple_scatter_source must be discrete_ordinates (0), successive_orders_legacy (1), twostream (2) or none (3); "
+                                     "successive_orders (4) is not part of this build");
+        const bool two_stream = c->ms_source == 2 || c->emission_source == 4;
         if (c->ss_source != 0 && c->ss_source != 2 && c->ss_source != 3)
             throw std::runtime_error("single_scatter_source must be exact (0), discrete_ordinates (2) or none (3); solartable (1) is not part of this build");
         if (c->ss_source == 2 && c->ms_source != 0) throw std::runtime_error("single_scatter_source = discrete_ordinates needs multiple_scatter_source = discrete_ordinates");
+        // do_backprop selects the reverse-mode linearisation of the reference's discrete-ordinates source; the two-stream source is
+        // linearised in reverse mode whatever the flag says (the reference's two-stream tests all set it)
         if (c->los_refraction || c->solar_refraction || c->multiple_scatter_refraction ||
-            c->num_do_forced_azimuth >= 0 || c->num_do_spherical_iterations > 0 || c->do_backprop)
+            c->num_do_forced_azimuth >= 0 || c->num_do_spherical_iterations > 0 || (c->do_backprop && !two_stream))
             throw std::runtime_error("refraction, forced azimuth count, DO spherical iterations and backprop are not part of this build");
         // EmissionSource { standard = 0, none = 1, discrete_ordinates = 2, volume_emission_rate = 3, twostream = 4 }, OccultationSource { standard = 0, none = 1 }
-        if (c->emission_source < 0 || c->emission_source > 3)
-            throw std::runtime_error("emission_source must be standard (0), none (1), discrete_ordinates (2) or volume_emission_rate (3); twostream (4) is not part of this build");
+        if (c->emission_source < 0 || c->emission_source > 4)
+            throw std::runtime_error("emission_source must be standard (0), none (1), discrete_ordinates (2), volume_emission_rate (3) or twostream (4)");
+        if (two_stream) {
+            // the reference builds the two-stream sources for NSTOKES = 1 only (cpp/lib/engine/engine.cpp:264-276, 384-397)
+            if (c->num_stokes != 1) throw std::runtime_error("the two-stream source is only implemented for NSTOKES = 1");
+            if (c->ms_source == 0 || c->ms_source == 1)
+                throw std::runtime_error("emission_source = twostream next to a discrete-ordinates or successive-orders multiple-scatter source is not part of this build");
+        }
         if (c->emission_source == 2 && (c->ms_source != 0 || c->num_stokes != 1 || g->geotype == 2))
             throw std::runtime_error("emission_source = discrete_ordinates needs multiple_scatter_source = discrete_ordinates, NSTOKES = 1 and plane-parallel / "
                                      "pseudo-spherical geometry (the reference's thermal post-processing exists for the plane-parallel source only)");
@@ -393,6 +421,15 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
                 throw std::runtime_error("single_scatter_source = exact with discrete ordinates needs spherical geometry (in plane-parallel "
                                          "geometry the discrete-ordinates source carries the single scatter itself)");
         }
+        if (two_stream) {
+            skts::Settings cfg;
+            cfg.num_sza = c->num_sza;
+            cfg.solar = c->ms_source == 2;
+            cfg.thermal = c->emission_source == 4;
+            skts::TsGeometry tg;
+            skts::build_ts_geometry(geo, v->rays, cfg, tg);
+            e->ts = std::make_unique<skdev::TsDeviceEngine>(tg);
+        }
         if (c->ss_source == 0 || c->ms_source == 1 || emission != 0 || occultation) {
             if (g->geotype != 2) throw std::runtime_error("the exact single-scatter, successive-orders, emission and occultation sources need spherical geometry");
             if (c->ms_source == 1 && (c->initialize_hr_with_do || c->num_hr_full_incoming_points > 0))
@@ -412,7 +449,7 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
             skso::build_so_geometry(geo, v->rays, cfg, sg, c->stokes_basis);
             e->so = std::make_unique<skdev::SoDeviceEngine>(sg, c->num_hr_spherical_iterations);
         }
-        if (!e->dev && !e->so) throw std::runtime_error("no source term configured (single_scatter_source and multiple_scatter_source are both none)");
+        if (!e->dev && !e->so && !e->ts) throw std::runtime_error("no source term configured (single_scatter_source and multiple_scatter_source are both none)");
         return e.release();
     } catch (const std::exception& ex) {
         set_error(std::string("sk_engine_create: ") + ex.what());
@@ -437,9 +474,11 @@ static bool is_scattering_mapping(const DerivativeMapping& dm) {
 }
 
 // d_wg: native scattering-group derivatives [group][ngrid][wavel][los][S] with groups in the order of `group_of` (mapping name -> group)
+// d_wem / d_wsem: native derivatives with respect to the emission profile [ngrid][wavel][los] and the surface emission [wavel][los]
+// (two-stream thermal source), applied through the mappings' d_emission
 static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const Surface& su, OutputC* out, const double* d_we, const double* d_ws,
                                  const double* d_wa, const double* d_rad, int S, const double* d_wg = nullptr,
-                                 const std::map<std::string, int>* group_of = nullptr) {
+                                 const std::map<std::string, int>* group_of = nullptr, const double* d_wem = nullptr, const double* d_wsem = nullptr) {
     DeviceCache& C = e->cache;
     const int nw = st.nwavel, ngrid = e->ngrid, nlos = e->nlos * S;   // (line of sight, Stokes component) pairs
     const size_t nloc_w = size_t(ngrid) * nw, nt = size_t(nw) * nlos;
@@ -463,8 +502,15 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
                     d_fg = (double*)C.get("map_scat_factor", nloc_w * 8);
                     HIPC(hipMemcpy(d_fg, m.scat_factor.data(), nloc_w * 8, hipMemcpyHostToDevice));
                 }
+                const double* d_wemm = nullptr;
+                double* d_fem = nullptr;
+                if (d_wem && std::any_of(m.d_emission.begin(), m.d_emission.end(), [](double v) { return v != 0.0; })) {
+                    d_wemm = d_wem;
+                    d_fem = (double*)C.get("map_d_emission", nloc_w * 8);
+                    HIPC(hipMemcpy(d_fem, m.d_emission.data(), nloc_w * 8, hipMemcpyHostToDevice));
+                }
                 if (!m.interpolator && !m.log_radiance_space) {
-                    hipLaunchKernelGGL(kern_map_wf, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_dst, ngrid, nw, nlos, d_wgm, d_fg);
+                    hipLaunchKernelGGL(kern_map_wf, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_dst, ngrid, nw, nlos, d_wgm, d_fg, d_wemm, d_fem);
                 } else {
                     double* d_interp = nullptr;
                     if (m.interpolator) {
@@ -472,20 +518,28 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
                         HIPC(hipMemcpy(d_interp, m.interpolator, size_t(ngrid) * nout * 8, hipMemcpyHostToDevice));
                     }
                     hipLaunchKernelGGL(kern_map_wf_interp, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_interp, d_rad,
-                                       m.log_radiance_space, d_dst, ngrid, nout, nw, nlos, S, d_wgm, d_fg);
+                                       m.log_radiance_space, d_dst, ngrid, nout, nw, nlos, S, d_wgm, d_fg, d_wemm, d_fem);
                 }
                 HIPC(hipGetLastError());
                 HIPC(hipMemcpy(kv.second.mem, d_dst, size_t(nout) * nt * 8, hipMemcpyDeviceToHost));  // C order [nderiv][wavel][los]
             }
             if (!out->surface_derivs.empty()) {
-                std::vector<double> wa(nt);
+                std::vector<double> wa(nt), wsem;
                 HIPC(hipMemcpy(wa.data(), d_wa, nt * 8, hipMemcpyDeviceToHost));
+                if (d_wsem) {
+                    wsem.resize(nt);
+                    HIPC(hipMemcpy(wsem.data(), d_wsem, nt * 8, hipMemcpyDeviceToHost));
+                }
                 for (auto& kv : out->surface_derivs) {
                     auto it = su.maps.find(kv.first);
                     if (it == su.maps.end()) throw std::runtime_error("no surface derivative mapping named " + kv.first);
                     const SurfaceDerivativeMapping& m = *it->second;
                     for (int w = 0; w < nw; ++w)
-                        for (int l = 0; l < nlos; ++l) kv.second.mem[size_t(w) * nlos + l] = wa[size_t(w) * nlos + l] * m.d_brdf[w];
+                        for (int l = 0; l < nlos; ++l) {
+                            double v = wa[size_t(w) * nlos + l] * m.d_brdf[w];
+                            if (d_wsem) v += wsem[size_t(w) * nlos + l] * m.d_emission[w];
+                            kv.second.mem[size_t(w) * nlos + l] = v;
+                        }
                 }
             }
     }
@@ -646,6 +700,115 @@ static int calculate_radiance_so(Engine* e, Atmosphere* atm, OutputC* out) {
     return 0;
 }
 
+// two-stream source (multiple_scatter_source = twostream and / or emission_source = twostream), optionally with the exact single scatter
+// and the line-of-sight sources of the successive-orders engine on top: radiances [wavel][los], LOS optical depths and weighting functions
+// through the caller's derivative mappings (extinction, ssa, scattering groups through the first Legendre coefficient, albedo, emission)
+static int calculate_radiance_ts(Engine* e, Atmosphere* atm, OutputC* out) {
+    const AtmosphereStorage& st = *atm->storage;
+    const Surface& su = *atm->surface;
+    const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
+    const int derivs = atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty());
+    if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
+    if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");
+    const size_t nloc_w = size_t(ngrid) * nw, nt = size_t(nw) * nlos;
+    DeviceCache& C = e->cache;
+    skdev::TsDeviceEngine::Inputs in;
+    skdev::TsDeviceEngine::Outputs o;
+    in.nleg = st.nleg;
+    double* d_ext = (double*)C.get("ext", nloc_w * 8);
+    double* d_ssa = (double*)C.get("ssa", nloc_w * 8);
+    double* d_leg = (double*)C.get("leg", nloc_w * st.nleg * 8);
+    double* d_alb = (double*)C.get("albedo", size_t(nw) * 8);
+    double* d_rad = (double*)C.get("radiance", nt * 8);
+    double* d_od = (double*)C.get("los_od", nt * 8);
+    HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyHostToDevice));
+    in.ext = d_ext; in.ssa = d_ssa; in.leg = d_leg; in.albedo = d_alb;
+    double* d_irr = nullptr;
+    if (st.irradiance) {
+        d_irr = (double*)C.get("irradiance", size_t(nw) * 8);
+        HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyHostToDevice));
+    }
+    in.irradiance = d_irr;
+    double* d_f = nullptr;
+    if (!st.delta_f.empty()) {
+        d_f = (double*)C.get("delta_f", nloc_w * 8);
+        HIPC(hipMemcpy(d_f, st.delta_f.data(), nloc_w * 8, hipMemcpyHostToDevice));
+    }
+    in.delta_f = d_f;
+    if (e->ts->thermal()) {
+        if (!st.emission) throw std::runtime_error("emission_source = twostream but the atmosphere storage has no emission_source array");
+        double* d_em = (double*)C.get("ts_emission", nloc_w * 8);
+        HIPC(hipMemcpy(d_em, st.emission, nloc_w * 8, hipMemcpyHostToDevice));
+        in.emission = d_em;
+        if (su.emission) {
+            double* d_sem = (double*)C.get("ts_surface_emission", size_t(nw) * 8);
+            HIPC(hipMemcpy(d_sem, su.emission, size_t(nw) * 8, hipMemcpyHostToDevice));
+            in.surface_emission = d_sem;
+        }
+    }
+    o.radiance = d_rad;
+    o.los_od = d_od;
+    double *d_we = nullptr, *d_ws = nullptr, *d_wb = nullptr, *d_wa = nullptr, *d_wem = nullptr, *d_wsem = nullptr, *d_wg = nullptr;
+    std::map<std::string, int> group_of;
+    if (derivs) {
+        d_we = (double*)C.get("wf_ext", size_t(ngrid) * nt * 8);
+        d_ws = (double*)C.get("wf_ssa", size_t(ngrid) * nt * 8);
+        d_wb = (double*)C.get("wf_b1", size_t(ngrid) * nt * 8);
+        d_wa = (double*)C.get("wf_alb", nt * 8);
+        o.wf_ext = d_we; o.wf_ssa = d_ws; o.wf_b1 = d_wb; o.wf_albedo = d_wa;
+        if (e->ts->thermal()) {
+            d_wem = (double*)C.get("wf_emission", size_t(ngrid) * nt * 8);
+            d_wsem = (double*)C.get("wf_surface_emission", nt * 8);
+            o.wf_emission = d_wem; o.wf_surface_emission = d_wsem;
+        }
+        for (auto& kv : out->derivs) {
+            auto it = st.maps.find(kv.first);
+            if (it != st.maps.end() && is_scattering_mapping(*it->second)) {
+                const int gidx = (int)group_of.size();
+                group_of[kv.first] = gidx;
+            }
+        }
+    }
+    e->ts->solve_device(nw, in, o, nullptr);
+    if (!group_of.empty()) {
+        // native scattering-group derivatives from dI/d(b1)
+        const size_t per_g = nloc_w * st.nleg;
+        double* d_dleg = (double*)C.get("d_legendre", per_g * 8);
+        double* d_df = (double*)C.get("d_f_groups", nloc_w * 8);
+        d_wg = (double*)C.get("wf_scat", group_of.size() * size_t(ngrid) * nt * 8);
+        for (auto& kv : group_of) {
+            const DerivativeMapping& m = *st.maps.at(kv.first);
+            HIPC(hipMemcpy(d_dleg, m.d_legendre.data(), per_g * 8, hipMemcpyHostToDevice));
+            const bool with_f = d_f && m.d_f.size() == nloc_w;
+            if (d_f && !with_f) throw std::runtime_error("scattering mapping " + kv.first + " was created after the delta-M scaling");
+            if (with_f) HIPC(hipMemcpy(d_df, m.d_f.data(), nloc_w * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(kern_ts_scat_group, dim3(2048), dim3(256), 0, nullptr, d_wb, d_dleg, with_f ? d_f : nullptr, with_f ? d_df : nullptr,
+                               d_wg + size_t(kv.second) * ngrid * nt, ngrid, nw, nlos, st.nleg);
+            HIPC(hipGetLastError());
+            HIPC(hipDeviceSynchronize());   // d_dleg / d_df are reused by the next group
+        }
+    }
+    if (e->so) {
+        // exact single scatter (and the emission / occultation line-of-sight sources) accumulated on top; its optical depths are the same rays'
+        upload_emission(e, st, su);
+        e->so->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa);
+    }
+    HIPC(hipDeviceSynchronize());
+    std::vector<double> od(nt);
+    HIPC(hipMemcpy(out->radiance, d_rad, nt * 8, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(od.data(), d_od, nt * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nt; ++i)
+        if (!std::isfinite(out->radiance[i])) throw std::runtime_error("solver failure (non-finite radiance) at wavelength " + std::to_string(i / size_t(nlos)));
+    out->los_od.resize(nt);
+    for (int w = 0; w < nw; ++w)
+        for (int r = 0; r < nlos; ++r) out->los_od[size_t(r) * nw + w] = od[size_t(w) * nlos + r];
+    if (derivs) map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, 1, d_wg, group_of.empty() ? nullptr : &group_of, d_wem, d_wsem);
+    return 0;
+}
+
 // Sasktran2::validate_input_atmosphere (cpp/lib/engine/engine.cpp:481-540, cpp/include/sasktran2/validation/validation.h:12-64): unless
 // input_validation_mode is `disabled` (2), extinction must be finite and >= 0 and the single scatter albedo finite and inside [0, 1];
 // the first offending (location, wavelength) is reported in the error text the way the reference logs it.
@@ -696,6 +859,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
                 }
             }
         }
+        if (e->ts) return calculate_radiance_ts(e, atm, out);
         if (e->so && !e->dev) return calculate_radiance_so(e, atm, out);
         bool scattering_groups = false;
         for (auto& kv : out->derivs) {
@@ -822,14 +986,16 @@ int sk_amd_engine_set_delta_m_fraction(Engine* e, const double* d_f) {
 int sk_amd_engine_num_los(Engine* e, int* n) { if (!e || !n) return -1; *n = e->nlos; return 0; }
 int sk_amd_engine_scratch_bytes(Engine* e, int nwavel, unsigned long long* bytes) {
     if (!e || !bytes) return -1;
-    *bytes = (unsigned long long)((e->dev ? e->dev->bytes_per_wavelength() : 0) + (e->so ? e->so->bytes_per_wavelength() : 0)) * (unsigned long long)nwavel;
+    *bytes = (unsigned long long)((e->dev ? e->dev->bytes_per_wavelength() : 0) + (e->so ? e->so->bytes_per_wavelength() : 0) +
+                                  (e->ts ? e->ts->bytes_per_wavelength(true) : 0)) * (unsigned long long)nwavel;
     return 0;
 }
 int sk_amd_engine_launch_shape(Engine* e, int* chunk, int* slots, unsigned long long* scratch_bytes) {
     if (!e) return -1;
-    if (chunk) *chunk = e->dev ? e->dev->last_chunk() : e->so->last_chunk();
+    if (chunk) *chunk = e->dev ? e->dev->last_chunk() : (e->ts ? e->ts->last_chunk() : e->so->last_chunk());
     if (slots) *slots = e->dev ? e->dev->last_slots() : 1;
-    if (scratch_bytes) *scratch_bytes = (unsigned long long)((e->dev ? e->dev->scratch_bytes() : 0) + (e->so ? e->so->scratch_bytes() : 0));
+    if (scratch_bytes) *scratch_bytes = (unsigned long long)((e->dev ? e->dev->scratch_bytes() : 0) + (e->so ? e->so->scratch_bytes() : 0) +
+                                                             (e->ts ? e->ts->scratch_bytes() : 0));
     return 0;
 }
 // per-kernel timing (HIP events around every launch, serialised): both device engines of the handle
@@ -837,18 +1003,21 @@ int sk_amd_engine_set_profiling(Engine* e, int on) {
     if (!e) return -1;
     if (e->dev) e->dev->set_profiling(on != 0);
     if (e->so) e->so->set_profiling(on != 0);
+    if (e->ts) e->ts->set_profiling(on != 0);
     return 0;
 }
 int sk_amd_engine_reset_profile(Engine* e) {
     if (!e) return -1;
     if (e->dev) e->dev->reset_profile();
     if (e->so) e->so->reset_profile();
+    if (e->ts) e->ts->reset_profile();
     return 0;
 }
 int sk_amd_engine_kernel_time(Engine* e, const char* name, double* ms, long* launches) {
     if (!e || !name || !ms || !launches) return -1;
     if (e->dev && e->dev->kernel_time(name, ms, launches)) return 0;
-    return (e->so && e->so->kernel_time(name, ms, launches)) ? 0 : -1;
+    if (e->so && e->so->kernel_time(name, ms, launches)) return 0;
+    return (e->ts && e->ts->kernel_time(name, ms, launches)) ? 0 : -1;
 }
 int sk_amd_engine_kernel_names(Engine* e, char* buf, int len) {
     if (!e || !buf || len < 1) return -1;
@@ -857,8 +1026,43 @@ int sk_amd_engine_kernel_names(Engine* e, char* buf, int len) {
         const std::string t = e->so->kernel_names();
         if (!t.empty()) s += (s.empty() ? "" : ",") + t;
     }
+    if (e->ts) {
+        const std::string t = e->ts->kernel_names();
+        if (!t.empty()) s += (s.empty() ? "" : ",") + t;
+    }
     std::snprintf(buf, len, "%s", s.c_str());
     return 0;
+}
+
+// device-resident entry point of the two-stream engine (bench.py, callers that keep spectra in HBM).  Inputs in the reference storage
+// layout: ext, ssa, delta_f, emission [nwavel][ngrid], leg [nwavel][ngrid][nleg], albedo / irradiance / surface_emission [nwavel]
+// (delta_f, irradiance, emission, surface_emission may be null as the configured sources allow).  Outputs: radiance [nwavel][nlos], los_od
+// [nwavel][nlos] or null, and -- all of wf_ext / wf_ssa / wf_b1 / wf_albedo or none -- wf_ext, wf_ssa, wf_b1, wf_emission
+// [ngrid][nwavel][nlos], wf_albedo, wf_surface_emission [nwavel][nlos] (the two emission outputs may be null).
+int sk_amd_ts_engine_solve_device(Engine* e, int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
+                                  const double* d_delta_f, const double* d_albedo, const double* d_irradiance, const double* d_emission,
+                                  const double* d_surface_emission, double* d_radiance, double* d_los_od, double* d_wf_ext, double* d_wf_ssa,
+                                  double* d_wf_b1, double* d_wf_albedo, double* d_wf_emission, double* d_wf_surface_emission, void* stream,
+                                  int max_chunk) {
+    if (!e) return -1;
+    try {
+        if (!e->ts) throw std::runtime_error("the engine has no two-stream source");
+        if (e->so) throw std::runtime_error("this entry point serves engines whose only source is the two-stream one: use sk_engine_calculate_radiance");
+        if (max_chunk < 0) throw std::runtime_error("max_chunk must be >= 0");
+        skdev::TsDeviceEngine::Inputs in;
+        in.nleg = nleg;
+        in.ext = d_ext; in.ssa = d_ssa; in.leg = d_leg; in.delta_f = d_delta_f; in.albedo = d_albedo; in.irradiance = d_irradiance;
+        in.emission = d_emission; in.surface_emission = d_surface_emission;
+        skdev::TsDeviceEngine::Outputs o;
+        o.radiance = d_radiance; o.los_od = d_los_od;
+        o.wf_ext = d_wf_ext; o.wf_ssa = d_wf_ssa; o.wf_b1 = d_wf_b1; o.wf_albedo = d_wf_albedo; o.wf_emission = d_wf_emission;
+        o.wf_surface_emission = d_wf_surface_emission;
+        e->ts->solve_device(nwavel, in, o, stream, max_chunk);
+        return 0;
+    } catch (const std::exception& ex) {
+        set_error(std::string("sk_amd_ts_engine_solve_device: ") + ex.what());
+        return -3;
+    }
 }
 
 // device-resident entry point of the exact single-scatter / successive-orders engine (bench.py, callers that keep spectra in HBM)

@@ -55,6 +55,7 @@ struct Bufs {
     const double *ext, *ssa, *leg, *delta_f, *albedo, *irradiance, *emission, *surface_emission;
     // outputs: radiance [nw_total][nlos]; wf_ext / wf_ssa / wf_b1 / wf_em [ngrid][nw_total][nlos]; wf_alb / wf_sem [nw_total][nlos]
     double *radiance, *wf_ext, *wf_ssa, *wf_b1, *wf_alb, *wf_em, *wf_sem;
+    double* los_od;   // [nw_total][nlos] optical depth along the line of sight, or null
     // scratch, every item a row of W lanes
     double* lay;    // [3][n]                   od, ssa, b1 of the layers
     double* colv;   // [ncol][2n + 1]           source amplitude at the n + 1 boundaries (solar: transmission) and decay rate of the n layers
@@ -506,6 +507,7 @@ template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bu
     // weight of the surface term of every column in the radiance; (ground_lo, ground_up, ground_uw) for the spherical case
     double surf_weight = 0.0, ground_uw = 0.0;
     int ground_lo = 0, ground_up = 0;
+    double path_od = 0.0;
     double plane_total_over_vc = 0.0;   // plane parallel: F / view cosine, the optical-depth gradient of the attenuation above a layer
 
     if (DERIVS) {
@@ -527,6 +529,7 @@ template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bu
         double attenuation = 1.0;
         for (int l = 0; l < n; ++l) {
             const LayerP<double> pv = load_p<SOLAR>(g, b, 0, l, w);
+            path_od += pv.od * inv;
             const LayerP<S> p = lift<S>(pv);
             const S beam = t_exp(-(p.od * inv));
             S source = cst<S>(0.0);
@@ -592,6 +595,7 @@ template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bu
             double od = 0.0;
             for (int j = g.od_start[s]; j < g.od_start[s + 1]; ++j) od += b.ext[gw * g.ngrid + (g.ngrid - 1 - g.od_level[j])] * g.od_weight[j];
             const double t = exp(-od);
+            path_od += od;
             const int lo = SOLAR ? g.seg_col[2 * s] : 0, up = SOLAR ? g.seg_col[2 * s + 1] : 0;
             double src = segment_source(s, lo);
             if (lo != up) {
@@ -656,6 +660,7 @@ template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bu
     {
         double* dst = b.radiance + gw * g.nlos + view;
         *dst = b.accumulate ? *dst + radiance : radiance;
+        if (b.los_od) b.los_od[gw * g.nlos + view] = path_od;
     }
     if (!DERIVS) return;
 

@@ -107,3 +107,38 @@ class SoDeviceSolver(DeviceSolver):
         lib().sk_amd_so_engine_sizes(self.engine._h, v)
         return dict(incoming_rays=v[0], incoming_layers=v[1], accumulation_entries=v[2], outgoing_directions=v[3],
                     scratch_bytes_per_wavelength=v[4], wavelengths_per_block=v[5])
+
+
+class TsDeviceSolver(DeviceSolver):
+    """Device-resident front end of an engine whose source is the two-stream one (multiple_scatter_source = twostream and / or
+    emission_source = twostream; `sk_amd_ts_engine_solve_device`): radiances [nwavel, nlos], LOS optical depths and, with derivatives,
+    wf_extinction / wf_ssa / wf_b1 / wf_emission [ngrid, nwavel, nlos] and wf_albedo / wf_surface_emission [nwavel, nlos]."""
+
+    def __init__(self, engine):
+        super().__init__(engine)
+        self.thermal = int(engine._config.emission_source) == 4
+
+    def allocate_outputs(self, nwavel, derivatives=True, device="cuda"):
+        kw = dict(dtype=torch.float64, device=device)
+        out = {"radiance": torch.empty((nwavel, self.nlos), **kw), "los_optical_depth": torch.empty((nwavel, self.nlos), **kw)}
+        if derivatives:
+            for name in ("wf_extinction", "wf_ssa", "wf_b1") + (("wf_emission",) if self.thermal else ()):
+                out[name] = torch.empty((self.ngrid, nwavel, self.nlos), **kw)
+            for name in ("wf_albedo",) + (("wf_surface_emission",) if self.thermal else ()):
+                out[name] = torch.empty((nwavel, self.nlos), **kw)
+        return out
+
+    def solve(self, extinction, ssa, leg, albedo, out, irradiance=None, max_chunk=0, delta_f=None, emission=None, surface_emission=None):
+        """extinction, ssa, delta_f, emission: [nwavel, ngrid]; leg: [nwavel, ngrid, nleg]; albedo, irradiance, surface_emission: [nwavel]
+        -- contiguous float64 CUDA tensors in the reference storage layout.  Asynchronous on torch's current stream."""
+        for t in (extinction, ssa, leg, albedo, irradiance, delta_f, emission, surface_emission):
+            assert t is None or (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous())
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        rc = lib().sk_amd_ts_engine_solve_device(
+            self.engine._h, extinction.shape[0], leg.shape[2], p(extinction), p(ssa), p(leg), p(delta_f), p(albedo), p(irradiance),
+            p(emission), p(surface_emission), p(out["radiance"]), p(out.get("los_optical_depth")), p(out.get("wf_extinction")),
+            p(out.get("wf_ssa")), p(out.get("wf_b1")), p(out.get("wf_albedo")), p(out.get("wf_emission")),
+            p(out.get("wf_surface_emission")), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), int(max_chunk))
+        if rc != 0:
+            raise RuntimeError(f"sk_amd_ts_engine_solve_device returned {rc}: {last_error()}")
+        return out

@@ -122,3 +122,86 @@ def run_product_so(s, engine=None, solar_irradiance=None, derivatives=False, emi
         out["d_ssa"] = np.transpose(res["wf_ssa"], (1, 2, 3, 0))
         out["d_albedo"] = res["wf_albedo"]
     return out
+
+
+def build_ts_engine(s, solar=True, thermal=False, single_scatter="none", delta_m=False):
+    """Engine with the two-stream source for a tests/scenarios.py scenario (multiple_scatter_source = twostream and / or emission_source =
+    twostream, as the reference's tests/engine/test_twostream.py:8-31 configures it)."""
+    g = s["geometry"]
+    config = sk.Config()
+    config.num_streams = 2
+    config.num_sza = s["config"]["num_sza"]
+    config.do_backprop = True
+    config.num_singlescatter_moments = s["leg"].shape[0]
+    config.delta_m_scaling = delta_m
+    config.single_scatter_source = {"exact": sk.SingleScatterSource.Exact, "none": sk.SingleScatterSource.NoSource}[single_scatter]
+    config.multiple_scatter_source = sk.MultipleScatterSource.TwoStream if solar else sk.MultipleScatterSource.NoSource
+    config.emission_source = sk.EmissionSource.TwoStream if thermal else sk.EmissionSource.NoSource
+    geometry = sk.Geometry1D(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"],
+                             sk.InterpolationMethod(g["interp_method"]), sk.GeometryType(g["geotype"]))
+    viewing = sk.ViewingGeometry()
+    for kind, csz, az, obs, x in s["rays"]:
+        if kind == sc.TANGENT_ALTITUDE_SOLAR:
+            viewing.add_ray(sk.TangentAltitudeSolar(x, az, obs, csz))
+        elif kind == sc.VIEWING_UP_SOLAR:
+            viewing.add_ray(sk.SolarAnglesObserverLocation(csz, az, x, obs))
+        else:
+            viewing.add_ray(sk.GroundViewingSolar(csz, az, x, obs))
+    return sk.Engine(config, geometry, viewing), config, geometry
+
+
+def run_product_ts(s, engine=None, derivatives=True, solar=True, thermal=False, **kw):
+    """The two-stream source through the C ABI, in the two-stream oracle's output convention: radiance [wavelength, los], d_extinction /
+    d_ssa / d_b1 / d_emission [wavelength, los, altitude], d_albedo / d_surface_emission [wavelength, los].  d_b1 and the emission
+    derivatives come out of derivative mappings registered the way the reference's tests do (rust/sasktran2-rs/tests/twostream.rs:38-83):
+    "wf_b1" with d_legendre(1) = 1, scat_factor = 1; "wf_emission" / "wf_surface_emission" with d_emission = 1."""
+    import ctypes
+    engine, config, geometry = engine if engine is not None else build_ts_engine(s, solar=solar, thermal=thermal, **kw)
+    ng, nw = s["extinction"].shape
+    nlos, nleg = len(s["rays"]), s["leg"].shape[0]
+    dp, vp = ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
+    atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=derivatives)
+    atmosphere.storage.total_extinction[:] = s["extinction"]
+    atmosphere.storage.ssa[:] = s["ssa"]
+    atmosphere.leg_coeff.a1[:] = s["leg"]
+    atmosphere.surface.albedo[:] = s["albedo"]
+    if s.get("solar_irradiance") is not None:
+        atmosphere.storage.solar_irradiance[:] = s["solar_irradiance"]
+    if thermal:
+        atmosphere.storage.emission_source[:] = s["emission"]
+        atmosphere.surface.emission[:] = s["surface_emission"]
+
+    def fill(L, getter, mapping, values):
+        f = getattr(L, getter)
+        f.argtypes = [vp, ctypes.POINTER(dp)]
+        ptr = dp()
+        assert f(mapping, ctypes.byref(ptr)) == 0
+        np.ctypeslib.as_array(ptr, shape=(values.size,))[:] = values
+
+    def hook(L, h_st, h_out, out):
+        m = vp()
+        L.sk_atmosphere_storage_get_derivative_mapping(h_st, b"wf_b1", ctypes.byref(m))
+        dleg = np.zeros((nleg, ng, nw))
+        dleg[1] = 1.0
+        fill(L, "sk_deriv_mapping_get_d_legendre", m, np.asfortranarray(dleg).ravel(order="F"))
+        fill(L, "sk_deriv_mapping_get_scat_factor", m, np.ones(ng * nw))
+        out["wf_b1"] = np.zeros((ng, nw, nlos, 1))
+        L.sk_output_assign_derivative_memory(h_out, b"wf_b1", out["wf_b1"].ctypes.data_as(dp), nw * nlos, 1, ng)
+        if thermal:
+            L.sk_atmosphere_storage_get_derivative_mapping(h_st, b"wf_emission", ctypes.byref(m))
+            fill(L, "sk_deriv_mapping_get_d_emission", m, np.ones(ng * nw))
+            out["wf_emission"] = np.zeros((ng, nw, nlos, 1))
+            L.sk_output_assign_derivative_memory(h_out, b"wf_emission", out["wf_emission"].ctypes.data_as(dp), nw * nlos, 1, ng)
+            L.sk_surface_get_derivative_mapping(out["_surface_handle"], b"wf_surface_emission", ctypes.byref(m))
+            fill(L, "sk_surface_deriv_mapping_get_d_emission", m, np.ones(nw))
+            out["wf_surface_emission"] = np.zeros((nw, nlos, 1))
+            L.sk_output_assign_surface_derivative_memory(h_out, b"wf_surface_emission", out["wf_surface_emission"].ctypes.data_as(dp), nw * nlos, 1)
+
+    res = engine.calculate_radiance(atmosphere, as_dataset=False, _mapping_hook=hook if derivatives else None)
+    out = {"radiance": res["radiance"][:, :, 0], "los_optical_depth": res["los_optical_depth"]}
+    if derivatives:
+        for name, key in (("d_extinction", "wf_extinction"), ("d_ssa", "wf_ssa"), ("d_b1", "wf_b1"), ("d_emission", "wf_emission")):
+            out[name] = np.transpose(res[key][..., 0], (1, 2, 0)) if key in res else np.zeros((nw, nlos, ng))
+        out["d_albedo"] = res["wf_albedo"][:, :, 0]
+        out["d_surface_emission"] = res["wf_surface_emission"][:, :, 0] if "wf_surface_emission" in res else np.zeros((nw, nlos))
+    return out

@@ -1,0 +1,185 @@
+"""GPU parity of the two-stream source (multiple_scatter_source = twostream, emission_source = twostream) through the C ABI against the
+two-stream oracle (oracle/ts_oracle.hpp, pinned in tests/test_ts_oracle.py): radiances to 1e-6 and weighting functions to 1e-4 of the
+profile maximum are the bar of BASELINE.json's north star; the assertions below are tighter."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from tests import scenarios as sc
+from tests.test_ts_oracle import resonance_cases, run_ts, ts_oracle
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("d_extinction", "d_ssa", "d_b1", "d_emission", "d_albedo", "d_surface_emission")
+RTOL_I, RTOL_WF = 1e-9, 1e-8
+
+
+def compare(out, ref, rtol_i=RTOL_I, rtol_wf=RTOL_WF, names=NAMES):
+    np.testing.assert_allclose(out["radiance"], ref["radiance"], rtol=rtol_i, atol=1e-300)
+    floor = 1e-10 * np.max(np.abs(ref["radiance"]))
+    for name in names:
+        scale = np.max(np.abs(ref[name]), axis=-1, keepdims=True) if ref[name].ndim == 3 else np.abs(ref[name])
+        err = np.abs(out[name] - ref[name]) / np.maximum(scale, floor)
+        assert np.max(err) < rtol_wf, (name, float(np.max(err)))
+
+
+def varied(s):
+    s["ssa"] = s["ssa"] + 0.002 * np.arange(s["ssa"].shape[0])[:, None]
+    s["leg"][1] += 0.01 * np.arange(s["ssa"].shape[0])[:, None]
+    return s
+
+
+@pytest.mark.parametrize("spherical", [False, True], ids=["plane parallel", "spherical"])
+@pytest.mark.parametrize("sources", ["solar", "thermal", "both"])
+def test_reference_case(spherical, sources):
+    # the atmosphere and lines of sight of tests/engine/test_twostream.py:34-73
+    from tests.gpu_harness import run_product_ts
+    s = varied(sc.twostream_reference_case(spherical=spherical, thermal=sources != "solar"))
+    solar, thermal = sources != "thermal", sources != "solar"
+    ref = run_ts(s, ts_oracle(s, solar=solar, thermal=thermal), derivatives=True)
+    out = run_product_ts(s, solar=solar, thermal=thermal)
+    compare(out, ref)
+    fwd = run_product_ts(s, solar=solar, thermal=thermal, derivatives=False)
+    np.testing.assert_allclose(fwd["radiance"], ref["radiance"], rtol=RTOL_I)
+
+
+def test_delta_m_pin():
+    # tests/engine/test_twostream.py:100-156: delta-M scaled plane-parallel case; the product scales the optics itself
+    # (sk_atmosphere_apply_delta_m_scaling) and maps the weighting functions back to the unscaled inputs
+    from tests.gpu_harness import run_product_ts
+    s = sc.twostream_delta_m_case()
+    d = sc.delta_m_scaled(s, 2)
+    ref = run_ts(d, ts_oracle(d), derivatives=True)
+    out = run_product_ts(s, delta_m=True)
+    np.testing.assert_allclose(out["radiance"], ref["radiance"], rtol=RTOL_I)
+    u = d["unscale"]
+    want_k = ref["d_extinction"] * u["dk_dk"].T[:, None, :]
+    want_w = ref["d_ssa"] * u["dw_dw"].T[:, None, :] + ref["d_extinction"] * u["dk_dw"].T[:, None, :]
+    for got, want in ((out["d_extinction"], want_k), (out["d_ssa"], want_w)):
+        assert np.max(np.abs(got - want) / np.max(np.abs(want), axis=-1, keepdims=True)) < RTOL_WF
+    np.testing.assert_allclose(out["d_albedo"], ref["d_albedo"], rtol=RTOL_WF)
+
+
+def test_delta_m_phase_derivative_matches_finite_differences():
+    # the scattering-group derivative through d_legendre(1) with the delta-M correction -3 d_f / (1 - f)^2 (cpp_twostream_source.cpp:3583-3604):
+    # with two streams the truncation order is 2, so a change of the first moment leaves f alone and the oracle's d_b1 / (1 - f) applies
+    from tests.gpu_harness import run_product_ts
+    s = sc.twostream_delta_m_case(3)
+    d = sc.delta_m_scaled(s, 2)
+    ref = run_ts(d, ts_oracle(d), derivatives=True)
+    out = run_product_ts(s, delta_m=True)
+    want = ref["d_b1"] / (1 - d["delta_f"]).T[:, None, :]
+    assert np.max(np.abs(out["d_b1"] - want) / np.max(np.abs(want), axis=-1, keepdims=True)) < RTOL_WF
+
+
+def test_limb_scan_50_layers():
+    # the limb geometry of BASELINE configs[1] (25 tangent heights, 51 levels) with three solar-zenith columns
+    from tests.gpu_harness import run_product_ts
+    c2 = sc.limb_c2(num_wavelengths=70, nlyr=50, nstr=2)
+    s = dict(c2, leg=c2["leg"][:2].copy(), config=dict(nstr=2, num_sza=3), solar_irradiance=np.linspace(0.9, 1.2, 70))
+    ref = run_ts(s, ts_oracle(s), derivatives=True)
+    out = run_product_ts(s)
+    compare(out, ref, names=NAMES[:3] + ("d_albedo",))
+    np.testing.assert_allclose(out["los_optical_depth"], _los_od(s), rtol=1e-12)
+
+
+def _los_od(s):
+    from oracle.oracle_py import OracleEngine
+    g = s["geometry"]
+    do = OracleEngine(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"], g["interp_method"], g["geotype"], 2, 1, s["rays"], ss_in_do=False)
+    return do.run(s["extinction"], s["ssa"], s["leg"], s["albedo"])["los_optical_depth"]
+
+
+def twostream_benchmark(num_wavelengths):
+    """The reference's two-stream benchmark (cpp/lib/tests/twostream/test_twostream.cpp:6-66): plane parallel, 20 layers of 1 m, extinction
+    0.01, conservative scattering, a1 = [1, 0, 0.5], albedo 0.5, one nadir-like line of sight; here with a spectral ramp on the extinction."""
+    alt = np.arange(21.0)
+    nw = num_wavelengths
+    leg = np.zeros((16, 21, nw))
+    leg[0], leg[2] = 1.0, 0.5
+    return dict(geometry=dict(cos_sza=0.6, saa=0.0, earth_radius=6_371_000.0, altitudes=alt, interp_method=sc.INTERP_LOWER, geotype=sc.GEO_PLANEPARALLEL),
+                config=dict(nstr=2, num_sza=1), rays=[(sc.GROUND_VIEWING_SOLAR, 0.6, np.pi / 3, 200_000.0, 0.6)],
+                extinction=0.01 * np.linspace(0.5, 20.0, nw)[None, :] * np.ones((21, 1)), ssa=np.ones((21, nw)), leg=leg, albedo=np.full(nw, 0.5))
+
+
+def test_reference_benchmark_configuration():
+    from tests.gpu_harness import run_product_ts
+    s = twostream_benchmark(300)
+    ref = run_ts(s, ts_oracle(s), derivatives=True)
+    out = run_product_ts(s)
+    compare(out, ref, names=("d_extinction", "d_b1", "d_albedo"))
+    assert np.max(np.abs(out["d_ssa"])) <= 1e-12 * np.max(np.abs(out["d_extinction"]))   # conservative scattering: capped, no ssa derivative
+
+
+def test_resonances_on_device():
+    from tests.gpu_harness import run_product_ts
+    solar, thermal = resonance_cases()
+    compare(run_product_ts(solar), run_ts(solar, ts_oracle(solar), derivatives=True), rtol_i=1e-8, rtol_wf=1e-6)
+    compare(run_product_ts(thermal, solar=False, thermal=True), run_ts(thermal, ts_oracle(thermal, solar=False, thermal=True), derivatives=True),
+            rtol_i=1e-8, rtol_wf=1e-6)
+
+
+def test_blocks_of_the_spectrum_are_independent(monkeypatch):
+    from tests.gpu_harness import run_product_ts
+    s = varied(sc.twostream_reference_case(spherical=True, thermal=True, num_wavelengths=200))
+    full = run_product_ts(s, solar=True, thermal=True)
+    monkeypatch.setenv("SASKTRAN2_AMD_TS_CHUNK", "64")
+    blocks = run_product_ts(s, solar=True, thermal=True)
+    for k in full:
+        assert np.array_equal(full[k], blocks[k]), k
+
+
+def test_exact_single_scatter_on_top():
+    # single_scatter_source = exact + multiple_scatter_source = twostream: the two sources add (radiances and weighting functions)
+    from tests.gpu_harness import build_so_engine, run_product_so, run_product_ts
+    s = varied(sc.twostream_reference_case(spherical=True))
+    both = run_product_ts(s, single_scatter="exact")
+    ms = run_product_ts(s)
+    so_s = dict(s, config=dict(nstokes=1, num_streams=2, num_singlescatter_moments=2, num_sza=3, single_scatter="exact", multiple_scatter="none",
+                               num_iterations=0, num_incoming=26, num_outgoing=26))
+    ss = run_product_so(so_s, solar_irradiance=s["solar_irradiance"], derivatives=True)
+    np.testing.assert_allclose(both["radiance"], ms["radiance"] + ss["radiance"][..., 0], rtol=1e-12)
+    np.testing.assert_allclose(both["d_extinction"], ms["d_extinction"] + ss["d_extinction"][:, :, 0, :], rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(both["d_albedo"], ms["d_albedo"] + ss["d_albedo"][..., 0], rtol=1e-10, atol=1e-18)
+
+
+def test_device_resident_entry_point():
+    import torch
+    import sasktran2_amd as sk
+    from sasktran2_amd.device import TsDeviceSolver
+    from tests.gpu_harness import build_ts_engine, run_product_ts
+    s = varied(sc.twostream_reference_case(spherical=True, thermal=True, num_wavelengths=130))
+    engine, config, geometry = build_ts_engine(s, solar=True, thermal=True)
+    host = run_product_ts(s, engine=(engine, config, geometry), solar=True, thermal=True)
+    solver = TsDeviceSolver(engine)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")  # noqa: E731
+    out = solver.allocate_outputs(130)
+    solver.solve(t(s["extinction"].T), t(s["ssa"].T), t(np.transpose(s["leg"], (2, 1, 0))), t(s["albedo"]), out, irradiance=t(s["solar_irradiance"]),
+                 emission=t(s["emission"].T), surface_emission=t(s["surface_emission"]))
+    torch.cuda.synchronize()
+    assert np.array_equal(out["radiance"].cpu().numpy(), host["radiance"])
+    assert np.array_equal(np.transpose(out["wf_extinction"].cpu().numpy(), (1, 2, 0)), host["d_extinction"])
+    assert np.array_equal(np.transpose(out["wf_emission"].cpu().numpy(), (1, 2, 0)), host["d_emission"])
+    assert np.array_equal(out["wf_surface_emission"].cpu().numpy(), host["d_surface_emission"])
+    assert np.array_equal(out["los_optical_depth"].cpu().numpy(), host["los_optical_depth"])
+
+
+def test_refusals():
+    import sasktran2_amd as sk
+    from tests.gpu_harness import build_ts_engine
+    s = sc.twostream_reference_case(spherical=True)
+    g = s["geometry"]
+    config = sk.Config()
+    config.num_stokes = 3
+    config.multiple_scatter_source = sk.MultipleScatterSource.TwoStream
+    geometry = sk.Geometry1D(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"])
+    viewing = sk.ViewingGeometry()
+    viewing.add_ray(sk.TangentAltitudeSolar(15_000.0, 0.4, 200_000.0, 0.6))
+    with pytest.raises(Exception, match="NSTOKES = 1"):
+        sk.Engine(config, geometry, viewing)
+    # downward-looking plane-parallel rays only (cpp_twostream_source.cpp:3419-3424)
+    pp = sc.twostream_reference_case(spherical=False)
+    pp["rays"] = [(sc.VIEWING_UP_SOLAR, 0.6, 0.0, 0.0, 0.5)]
+    with pytest.raises(Exception):
+        build_ts_engine(pp)
