@@ -150,7 +150,7 @@ def build_ts_engine(s, solar=True, thermal=False, single_scatter="none", delta_m
     return sk.Engine(config, geometry, viewing), config, geometry
 
 
-def run_product_ts(s, engine=None, derivatives=True, solar=True, thermal=False, **kw):
+def run_product_ts(s, engine=None, derivatives=True, solar=True, thermal=False, b1_mapping=True, **kw):
     """The two-stream source through the C ABI, in the two-stream oracle's output convention: radiance [wavelength, los], d_extinction /
     d_ssa / d_b1 / d_emission [wavelength, los, altitude], d_albedo / d_surface_emission [wavelength, los].  d_b1 and the emission
     derivatives come out of derivative mappings registered the way the reference's tests do (rust/sasktran2-rs/tests/twostream.rs:38-83):
@@ -180,13 +180,14 @@ def run_product_ts(s, engine=None, derivatives=True, solar=True, thermal=False, 
 
     def hook(L, h_st, h_out, out):
         m = vp()
-        L.sk_atmosphere_storage_get_derivative_mapping(h_st, b"wf_b1", ctypes.byref(m))
-        dleg = np.zeros((nleg, ng, nw))
-        dleg[1] = 1.0
-        fill(L, "sk_deriv_mapping_get_d_legendre", m, np.asfortranarray(dleg).ravel(order="F"))
-        fill(L, "sk_deriv_mapping_get_scat_factor", m, np.ones(ng * nw))
-        out["wf_b1"] = np.zeros((ng, nw, nlos, 1))
-        L.sk_output_assign_derivative_memory(h_out, b"wf_b1", out["wf_b1"].ctypes.data_as(dp), nw * nlos, 1, ng)
+        if b1_mapping:
+            L.sk_atmosphere_storage_get_derivative_mapping(h_st, b"wf_b1", ctypes.byref(m))
+            dleg = np.zeros((nleg, ng, nw))
+            dleg[1] = 1.0
+            fill(L, "sk_deriv_mapping_get_d_legendre", m, np.asfortranarray(dleg).ravel(order="F"))
+            fill(L, "sk_deriv_mapping_get_scat_factor", m, np.ones(ng * nw))
+            out["wf_b1"] = np.zeros((ng, nw, nlos, 1))
+            L.sk_output_assign_derivative_memory(h_out, b"wf_b1", out["wf_b1"].ctypes.data_as(dp), nw * nlos, 1, ng)
         if thermal:
             L.sk_atmosphere_storage_get_derivative_mapping(h_st, b"wf_emission", ctypes.byref(m))
             fill(L, "sk_deriv_mapping_get_d_emission", m, np.ones(ng * nw))

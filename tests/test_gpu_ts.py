@@ -76,7 +76,7 @@ def test_delta_m_phase_derivative_matches_finite_differences():
 def test_limb_scan_50_layers():
     # the limb geometry of BASELINE configs[1] (25 tangent heights, 51 levels) with three solar-zenith columns
     from tests.gpu_harness import run_product_ts
-    c2 = sc.limb_c2(num_wavelengths=70, nlyr=50, nstr=2)
+    c2 = sc.limb_c2(num_wavelengths=70, nlyr=50, nstr=16)
     s = dict(c2, leg=c2["leg"][:2].copy(), config=dict(nstr=2, num_sza=3), solar_irradiance=np.linspace(0.9, 1.2, 70))
     ref = run_ts(s, ts_oracle(s), derivatives=True)
     out = run_product_ts(s)
@@ -134,7 +134,7 @@ def test_exact_single_scatter_on_top():
     # single_scatter_source = exact + multiple_scatter_source = twostream: the two sources add (radiances and weighting functions)
     from tests.gpu_harness import build_so_engine, run_product_so, run_product_ts
     s = varied(sc.twostream_reference_case(spherical=True))
-    both = run_product_ts(s, single_scatter="exact")
+    both = run_product_ts(s, single_scatter="exact", b1_mapping=False)   # (no scattering-group mapping next to the exact single scatter)
     ms = run_product_ts(s)
     so_s = dict(s, config=dict(nstokes=1, num_streams=2, num_singlescatter_moments=2, num_sza=3, single_scatter="exact", multiple_scatter="none",
                                num_iterations=0, num_incoming=26, num_outgoing=26))
@@ -145,8 +145,17 @@ def test_exact_single_scatter_on_top():
 
 
 def test_device_resident_entry_point():
+    # torch and the product library each bring a HIP runtime; torch has to initialise first (as in bench.py), so this runs in a fresh process
+    import subprocess
+    import sys
+    from pathlib import Path
+    code = "import torch; torch.cuda.init(); from tests.test_gpu_ts import device_resident_check; device_resident_check()"
+    r = subprocess.run([sys.executable, "-c", code], cwd=Path(__file__).resolve().parents[1], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def device_resident_check():
     import torch
-    import sasktran2_amd as sk
     from sasktran2_amd.device import TsDeviceSolver
     from tests.gpu_harness import build_ts_engine, run_product_ts
     s = varied(sc.twostream_reference_case(spherical=True, thermal=True, num_wavelengths=130))
