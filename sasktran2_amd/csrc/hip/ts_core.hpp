@@ -8,8 +8,9 @@
 //   solve_thread   layer optics from the level profiles, slant solar transmission / thermal profile, the two-stream homogeneous and
 //                  particular solutions of every layer for azimuth orders 0 and 1, and the LU sweep of the five-diagonal boundary-value
 //                  problem (:1923-2122, :1861-1899)
-//   view_thread    the radiance of one line of sight: plane parallel (:2550-2668) or the spherical path integration over traced segments
-//                  (:1196-1233, :2160-2234), and its weighting functions.
+//   view_forward_thread   the radiance of one line of sight: plane parallel (:2550-2668) or the spherical path integration over traced
+//                         segments (:1196-1233, :2160-2234); with weighting functions also dF/dc and the forward half of the transposed solve
+//   view_adjoint_thread   the weighting functions of that line of sight.
 // Weighting functions are NOT a translation of the reference's hand-written reverse sweep.  The radiance is F(p, c) with A(p) c = r(p)
 // (p: the five numbers per layer -- optical depth, single-scatter albedo, first phase moment, source amplitude and decay rate -- c: the
 // 2n homogeneous amplitudes).  One transposed five-diagonal solve gives lambda = A^-T dF/dc, and the gradient with respect to p is the
@@ -22,8 +23,10 @@
 
 #if defined(__HIPCC__)
 #define TS_HD __host__ __device__ inline
+#define TS_HD_COLD __host__ __device__ __attribute__((noinline))   // rarely taken series branches: kept out of the callers' register budget
 #else
 #define TS_HD inline
+#define TS_HD_COLD inline
 #endif
 
 namespace skt {
@@ -62,7 +65,8 @@ struct Bufs {
     double* lu;     // [ncol][naz][6][2n]       c (solution), alpha, beta, gamma, e, 1 / mu of the LU sweep
     double* lam;    // [nlos][ncol][naz][2n]    dF/dc, then lambda
     double* g5;     // [nlos][ncol][n][5]       gradient with respect to the layer parameters
-    double* gsum;   // [nlos][3][n]             od / ssa / b1 gradients summed over the columns
+    double* gsum;   // [nlos][5][n]             od / ssa / b1 gradients summed over the columns; thermal: amplitude / rate gradients
+    double* vstate; // [nlos][2]                weight of the surface term in the radiance, optical depth along the line of sight
     double* path;   // [nlos][3][max_seg]       spherical: transmission, source and incoming radiance of every segment
     double* glev;   // [nlos][ngrid]            spherical: level-extinction gradient of the path transmissions
 };
@@ -156,7 +160,7 @@ TS_HD double exp_moment(int order, double rate, double thickness) {
     return p * unit;
 }
 // (exp(-a t) - exp(-b t)) / (b - a)
-TS_HD Stable exp_difference(double a, double b, double t) {
+TS_HD_COLD Stable exp_difference(double a, double b, double t) {
     const double delta = b - a;
     if (fabs(delta * t) > 1.0e-5) {
         const double ea = exp(-a * t), eb = exp(-b * t), num = ea - eb, inv = 1.0 / delta, inv2 = inv * inv;
@@ -170,7 +174,7 @@ TS_HD Stable exp_difference(double a, double b, double t) {
     return {value, 0.5 * (dmid - dhalf), 0.5 * (dmid + dhalf), em * ((1.0 - mid * t) * sinhc + t * half * dsinhc)};
 }
 // integral over [0, t] of exp_difference(a, b, x)
-TS_HD Stable integrated_exp_difference(double a, double b, double t) {
+TS_HD_COLD Stable integrated_exp_difference(double a, double b, double t) {
     const double delta = b - a;
     if (fabs(delta * t) > 1.0e-4) {
         const Stable ga = exp_difference(0.0, a, t), gb = exp_difference(0.0, b, t);
@@ -355,11 +359,12 @@ TS_HD double& g5_at(const Bufs& b, const Geo& g, int view, int col, int l, int d
     return b.g5[(((size_t(view) * g.ncol + col) * g.nlyr + l) * 5 + dir) * b.W + w];
 }
 TS_HD double& gsum_at(const Bufs& b, const Geo& g, int view, int which, int l, int w) {
-    return b.gsum[((size_t(view) * 3 + which) * g.nlyr + l) * b.W + w];
+    return b.gsum[((size_t(view) * 5 + which) * g.nlyr + l) * b.W + w];
 }
 TS_HD double& path_at(const Bufs& b, const Geo& g, int view, int which, int seg, int w) {
     return b.path[((size_t(view) * 3 + which) * g.max_seg + seg) * b.W + w];
 }
+TS_HD double& vstate_at(const Bufs& b, const Geo& g, int view, int which, int w) { return b.vstate[(size_t(view) * 2 + which) * b.W + w]; }
 TS_HD double& glev_at(const Bufs& b, const Geo& g, int view, int level, int w) { return b.glev[(size_t(view) * g.ngrid + level) * b.W + w]; }
 
 // level values of wavelength gw, levels counted from the top (load_extinction ... load_emission, :863-917)
@@ -452,8 +457,12 @@ template <bool SOLAR> TS_HD void solve_thread(const Geo& g, const Bufs& b, int w
                 a2 = a1; a1 = alpha; b2r = b1r; b1r = beta; z2 = z1; z1 = z;
                 ++row;
             };
+            // (the layer parameters are fetched one layer ahead: the stores of the elimination would otherwise hold the next loads back)
+            auto fetch = [&](int l) { return LayerP<double>{lds[l * ls], lay_at(b, g, 1, l, w), lay_at(b, g, 2, l, w), amp_at(b, g, col, l, w), rate_at(b, g, col, l, w)}; };
+            LayerP<double> next = fetch(0);
             for (int l = 0; l < n; ++l) {
-                const LayerP<double> p = {lds[l * ls], lay_at(b, g, 1, l, w), lay_at(b, g, 2, l, w), amp_at(b, g, col, l, w), rate_at(b, g, col, l, w)};
+                const LayerP<double> p = next;
+                if (l + 1 < n) next = fetch(l + 1);
                 const LayerSol<double> h = layer_solution<double, SOLAR>(az, p, mu, csz, angular);
                 const Boundary<double> q = boundary_particular(p, h);
                 if (l == 0) {
@@ -468,21 +477,31 @@ template <bool SOLAR> TS_HD void solve_thread(const Geo& g, const Bufs& b, int w
             eliminate(0.0, (pxm - 2.0 * mu * albedo * delta * pxp) * pom, pxp - 2.0 * mu * albedo * delta * pxm, 0.0, 0.0,
                       direct - (pgmb - 2.0 * delta * mu * albedo * pgpb));
             // back substitution (:1889-1898)
+            // (four rows per round trip: the loads of a block are issued together, ahead of the stores of the block before)
             double x1 = 0, x2 = 0;
-            for (int i = N - 1; i >= 0; --i) {
-                const double x = lu_at(b, g, naz, col, az, LU_C, i, w) - lu_at(b, g, naz, col, az, LU_ALPHA, i, w) * x1 -
-                                 lu_at(b, g, naz, col, az, LU_BETA, i, w) * x2;
-                lu_at(b, g, naz, col, az, LU_C, i, w) = x;
-                x2 = x1;
-                x1 = x;
+            for (int top = N - 1; top >= 0; top -= 4) {
+                double z[4], al[4], be[4];
+                for (int j = 0; j < 4; ++j) {
+                    const int i = top - j;
+                    z[j] = i >= 0 ? lu_at(b, g, naz, col, az, LU_C, i, w) : 0.0;
+                    al[j] = i >= 0 ? lu_at(b, g, naz, col, az, LU_ALPHA, i, w) : 0.0;
+                    be[j] = i >= 0 ? lu_at(b, g, naz, col, az, LU_BETA, i, w) : 0.0;
+                }
+                for (int j = 0; j < 4; ++j) {
+                    const int i = top - j;
+                    if (i < 0) break;
+                    const double x = z[j] - al[j] * x1 - be[j] * x2;
+                    lu_at(b, g, naz, col, az, LU_C, i, w) = x;
+                    x2 = x1;
+                    x1 = x;
+                }
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// view: radiance of one line of sight and, with DERIVS, its weighting functions
-// `lds`: n + 1 values per thread, element i of this thread at lds[i * ls]
+// view: radiance of one line of sight (view_forward_thread) and its weighting functions (view_adjoint_thread)
 // ---------------------------------------------------------------------------------------------------------------------------
 template <bool SOLAR> TS_HD LayerP<double> load_p(const Geo& g, const Bufs& b, int col, int l, int w) {
     return {lay_at(b, g, 0, l, w), lay_at(b, g, 1, l, w), lay_at(b, g, 2, l, w), amp_at(b, g, SOLAR ? col : 0, l, w), rate_at(b, g, SOLAR ? col : 0, l, w)};
@@ -495,80 +514,98 @@ template <class S> TS_HD S bottom_plus(const LayerSol<S>& h, const Boundary<S>& 
     return q.gpb + c0 * (h.xp * h.omega) + c1 * h.xm;
 }
 
-template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bufs& b, int w, int view, double* lds, int ls) {
-    using S = typename std::conditional<DERIVS, D5, double>::type;
-    const int n = g.nlyr, naz = naz_of(SOLAR), N = 2 * n, ncol = SOLAR ? g.ncol : 1;
+template <bool SOLAR, bool DERIVS, bool SPHERICAL> TS_HD void view_forward_thread(const Geo& g, const Bufs& b, int w, int view) {
+    constexpr int NAZ = SOLAR ? 2 : 1;
+    const int n = g.nlyr, N = 2 * n;
     const size_t gw = size_t(b.w0) + w;
     const double mu = g.mu;
     const double albedo = b.albedo[gw];
     const double surface_emission = (!SOLAR && b.surface_emission) ? b.surface_emission[gw] : 0.0;
-    double radiance = 0.0;
-    double g_albedo = 0.0, g_surface_emission = 0.0;
-    // weight of the surface term of every column in the radiance; (ground_lo, ground_up, ground_uw) for the spherical case
-    double surf_weight = 0.0, ground_uw = 0.0;
-    int ground_lo = 0, ground_up = 0;
-    double path_od = 0.0;
-    double plane_total_over_vc = 0.0;   // plane parallel: F / view cosine, the optical-depth gradient of the attenuation above a layer
+    double radiance = 0.0, path_od = 0.0, surf_weight = 0.0;
 
-    if (DERIVS) {
-        for (int col = 0; col < ncol; ++col) {
-            for (int az = 0; az < naz; ++az)
-                for (int i = 0; i < N; ++i) lam_at(b, g, naz, view, col, az, i, w) = 0.0;
-            for (int l = 0; l < n; ++l)
-                for (int d = 0; d < 5; ++d) g5_at(b, g, view, col, l, d, w) = 0.0;
-        }
-        for (int l = 0; l < n; ++l)
-            for (int k = 0; k < 3; ++k) gsum_at(b, g, view, k, l, w) = 0.0;
-    }
-
-    if (!g.spherical) {
-        // ---- plane parallel (:2550-2668): layer-integrated sources attenuated to the top of the atmosphere
+    if (!SPHERICAL) {
+        // ---- plane parallel (:2550-2668): layer-integrated sources attenuated to the top of the atmosphere.  With DERIVS the rows of
+        // dF/dc appear top-down, which is the order of the forward half of the transposed solve (U^T y = dF/dc): it is done on the fly
         const double vc = g.view_cos[view], inv = 1.0 / vc, csz = g.csz[0];
         const double azw[2] = {1.0, cos(g.view_azimuth[view])};
         const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
         double attenuation = 1.0;
+        double y1[NAZ], y2[NAZ], al1[NAZ], be1[NAZ], be2[NAZ];   // y, alpha, beta of the rows i - 1 and i - 2
+        for (int az = 0; az < NAZ; ++az) y1[az] = y2[az] = al1[az] = be1[az] = be2[az] = 0.0;
+        // everything a layer reads from scratch, fetched one layer ahead of its use
+        struct Fetch {
+            LayerP<double> p;
+            double c0[NAZ], c1[NAZ], al_a[NAZ], be_a[NAZ], al_b[NAZ], be_b[NAZ];
+        };
+        auto fetch = [&](int l) {
+            Fetch f;
+            f.p = load_p<SOLAR>(g, b, 0, l, w);
+            for (int az = 0; az < NAZ; ++az) {
+                f.c0[az] = lu_at(b, g, NAZ, 0, az, LU_C, 2 * l, w);
+                f.c1[az] = lu_at(b, g, NAZ, 0, az, LU_C, 2 * l + 1, w);
+                if (DERIVS) {
+                    f.al_a[az] = lu_at(b, g, NAZ, 0, az, LU_ALPHA, 2 * l, w);
+                    f.be_a[az] = lu_at(b, g, NAZ, 0, az, LU_BETA, 2 * l, w);
+                    f.al_b[az] = lu_at(b, g, NAZ, 0, az, LU_ALPHA, 2 * l + 1, w);
+                    f.be_b[az] = lu_at(b, g, NAZ, 0, az, LU_BETA, 2 * l + 1, w);
+                }
+            }
+            return f;
+        };
+        Fetch next = fetch(0);
         for (int l = 0; l < n; ++l) {
-            const LayerP<double> pv = load_p<SOLAR>(g, b, 0, l, w);
-            path_od += pv.od * inv;
-            const LayerP<S> p = lift<S>(pv);
-            const S beam = t_exp(-(p.od * inv));
-            S source = cst<S>(0.0);
-            for (int az = 0; az < naz; ++az) {
-                const LayerSol<S> h = layer_solution<S, SOLAR>(az, p, mu, csz, angular);
-                const bool fast = plane_nonresonant(pv.rate, val(h.k), pv.od, inv);
-                const S source_integral = plane_source_integral(p, h.expo, beam, vc, fast);
-                S U, V, P;
-                plane_source_terms<S, SOLAR>(az, p, h, vc, mu, fast, beam, source_integral, U, V, P);
-                const double c0 = lu_at(b, g, naz, 0, az, LU_C, 2 * l, w), c1 = lu_at(b, g, naz, 0, az, LU_C, 2 * l + 1, w);
+            const Fetch cur = next;
+            if (l + 1 < n) next = fetch(l + 1);
+            const LayerP<double>& p = cur.p;
+            path_od += p.od * inv;
+            const double beam = exp(-p.od * inv);
+            double source = 0.0;
+            for (int az = 0; az < NAZ; ++az) {
+                const LayerSol<double> h = layer_solution<double, SOLAR>(az, p, mu, csz, angular);
+                const bool fast = plane_nonresonant(p.rate, h.k, p.od, inv);
+                const double source_integral = plane_source_integral(p, h.expo, beam, vc, fast);
+                double U, V, P;
+                plane_source_terms<double, SOLAR>(az, p, h, vc, mu, fast, beam, source_integral, U, V, P);
+                const double c0 = cur.c0[az], c1 = cur.c1[az];
                 source += azw[az] * (c0 * U + c1 * V + P);
                 if (!SOLAR && az == 0) source += p.amp * source_integral * (1.0 - p.ssa);
                 if (DERIVS) {
-                    lam_at(b, g, naz, view, 0, az, 2 * l, w) = attenuation * azw[az] * val(U);
-                    lam_at(b, g, naz, view, 0, az, 2 * l + 1, w) = attenuation * azw[az] * val(V);
+                    double r0 = attenuation * azw[az] * U, r1 = attenuation * azw[az] * V;
+                    if (l == n - 1 && az == 0) {   // the surface term 2 mu albedo (downwelling stream at the ground), attenuated by the whole column
+                        const double wsurf = attenuation * beam * (2.0 * mu) * albedo;
+                        r0 += wsurf * h.xp * h.omega;
+                        r1 += wsurf * h.xm;
+                    }
+                    const double ya = r0 - al1[az] * y1[az] - be2[az] * y2[az];
+                    const double yb = r1 - cur.al_a[az] * ya - be1[az] * y1[az];
+                    lam_at(b, g, NAZ, view, 0, az, 2 * l, w) = ya;
+                    lam_at(b, g, NAZ, view, 0, az, 2 * l + 1, w) = yb;
+                    y2[az] = ya;
+                    y1[az] = yb;
+                    be2[az] = cur.be_a[az];
+                    al1[az] = cur.al_b[az];
+                    be1[az] = cur.be_b[az];
+                }
+                if (l == n - 1 && az == 0) {
+                    const Boundary<double> q = boundary_particular(p, h);
+                    surf_weight = attenuation * beam;
+                    radiance += surf_weight * (bottom_plus(h, q, c0, c1) * (2.0 * mu) * albedo + surface_emission);
                 }
             }
-            radiance += val(source) * attenuation;
-            if (DERIVS) {
-                for (int d = 0; d < 5; ++d) g5_at(b, g, view, 0, l, d, w) = attenuation * dpart(source, d);
-                // every source below this layer is attenuated by exp(-od / vc) of this one: -(F - sources down to this layer) / vc,
-                // the F part is added once the radiance is known
-                g5_at(b, g, view, 0, l, 0, w) += radiance * inv;
-            }
-            attenuation *= val(beam);
+            radiance += source * attenuation;
+            attenuation *= beam;
         }
-        surf_weight = attenuation;
     } else {
         // ---- spherical (:1196-1233): R <- R t + S (1 - t) over the traced segments, far end first
+        const int ncol = SOLAR ? g.ncol : 1;
         const int s0 = g.ray_start[view], s1 = g.ray_start[view + 1];
-        ground_lo = SOLAR ? g.ground_col[2 * view] : 0;
-        ground_up = SOLAR ? g.ground_col[2 * view + 1] : 0;
-        ground_uw = SOLAR ? g.ground_colw[view] : 0.0;
+        const int ground_lo = SOLAR ? g.ground_col[2 * view] : 0, ground_up = SOLAR ? g.ground_col[2 * view + 1] : 0;
+        const double ground_uw = SOLAR ? g.ground_colw[view] : 0.0;
         auto surface_of = [&](int col) {
             const LayerP<double> p = load_p<SOLAR>(g, b, col, n - 1, w);
-            const double csz = g.csz[col];
-            const LayerSol<double> h = layer_solution<double, SOLAR>(0, p, mu, csz, 0.0);
+            const LayerSol<double> h = layer_solution<double, SOLAR>(0, p, mu, g.csz[col], 0.0);
             const Boundary<double> q = boundary_particular(p, h);
-            const double base = bottom_plus(h, q, lu_at(b, g, naz, col, 0, LU_C, N - 2, w), lu_at(b, g, naz, col, 0, LU_C, N - 1, w));
+            const double base = bottom_plus(h, q, lu_at(b, g, NAZ, col, 0, LU_C, N - 2, w), lu_at(b, g, NAZ, col, 0, LU_C, N - 1, w));
             return base * (2.0 * mu) * albedo + (SOLAR ? 0.0 : surface_emission);
         };
         if (g.ground_hit[view]) {
@@ -582,11 +619,11 @@ template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bu
             const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
             const double azw[2] = {1.0, cos(g.seg_azimuth[s])};
             double src = 0.0;
-            for (int az = 0; az < naz; ++az) {
+            for (int az = 0; az < NAZ; ++az) {
                 const LayerSol<double> h = layer_solution<double, SOLAR>(az, p, mu, csz, angular);
                 double U, V, P;
                 local_source_terms<double, SOLAR>(az, p, h, g.seg_frac[s], g.seg_cos[s], mu, U, V, P);
-                src += azw[az] * (lu_at(b, g, naz, col, az, LU_C, 2 * l, w) * U + lu_at(b, g, naz, col, az, LU_C, 2 * l + 1, w) * V + P);
+                src += azw[az] * (lu_at(b, g, NAZ, col, az, LU_C, 2 * l, w) * U + lu_at(b, g, NAZ, col, az, LU_C, 2 * l + 1, w) * V + P);
             }
             if (!SOLAR) src += local_emission(p, g.seg_frac[s]);
             return src;
@@ -610,9 +647,15 @@ template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bu
             radiance = radiance * t + src * (1.0 - t);
         }
         if (DERIVS) {
+            for (int col = 0; col < ncol; ++col) {
+                for (int az = 0; az < NAZ; ++az)
+                    for (int i = 0; i < N; ++i) lam_at(b, g, NAZ, view, col, az, i, w) = 0.0;
+                for (int l = 0; l < n; ++l)
+                    for (int d = 0; d < 5; ++d) g5_at(b, g, view, col, l, d, w) = 0.0;
+            }
+            for (int t = 0; t < g.ngrid; ++t) glev_at(b, g, view, t, w) = 0.0;
             // reverse sweep over the segments: weights of the sources, level-extinction gradient of the transmissions, and the
             // source gradients (dual numbers) gathered per (column, layer)
-            for (int t = 0; t < g.ngrid; ++t) glev_at(b, g, view, t, w) = 0.0;
             double d_rad = 1.0;
             for (int s = s1 - 1; s >= s0; --s) {
                 const double t = path_at(b, g, view, 0, s - s0, w), src = path_at(b, g, view, 1, s - s0, w), incoming = path_at(b, g, view, 2, s - s0, w);
@@ -630,14 +673,14 @@ template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bu
                     const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
                     const double azw[2] = {1.0, cos(g.seg_azimuth[s])};
                     D5 acc = mkd(0.0);
-                    for (int az = 0; az < naz; ++az) {
+                    for (int az = 0; az < NAZ; ++az) {
                         const LayerSol<D5> h = layer_solution<D5, SOLAR>(az, p, mu, csz, angular);
                         D5 U, V, P;
                         local_source_terms<D5, SOLAR>(az, p, h, g.seg_frac[s], g.seg_cos[s], mu, U, V, P);
-                        const double c0 = lu_at(b, g, naz, col, az, LU_C, 2 * l, w), c1 = lu_at(b, g, naz, col, az, LU_C, 2 * l + 1, w);
+                        const double c0 = lu_at(b, g, NAZ, col, az, LU_C, 2 * l, w), c1 = lu_at(b, g, NAZ, col, az, LU_C, 2 * l + 1, w);
                         acc += azw[az] * (c0 * U + c1 * V + P);
-                        lam_at(b, g, naz, view, col, az, 2 * l, w) += wgt * azw[az] * U.v;
-                        lam_at(b, g, naz, view, col, az, 2 * l + 1, w) += wgt * azw[az] * V.v;
+                        lam_at(b, g, NAZ, view, col, az, 2 * l, w) += wgt * azw[az] * U.v;
+                        lam_at(b, g, NAZ, view, col, az, 2 * l + 1, w) += wgt * azw[az] * V.v;
                     }
                     if (!SOLAR) acc += local_emission(p, g.seg_frac[s]);
                     for (int d = 0; d < 5; ++d) g5_at(b, g, view, col, l, d, w) += wgt * acc.d[d];
@@ -645,31 +688,228 @@ template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bu
                 d_rad *= t;
             }
             surf_weight = g.ground_hit[view] ? d_rad : 0.0;
+            // dF/dc of the surface term, then the forward half of the transposed solve, U^T y = dF/dc, in place
+            for (int col = 0; col < ncol; ++col) {
+                double ws = surf_weight;
+                if (SOLAR) {
+                    ws = 0.0;
+                    if (col == ground_lo) ws += surf_weight * (ground_lo != ground_up ? 1.0 - ground_uw : 1.0);
+                    if (col == ground_up && ground_lo != ground_up) ws += surf_weight * ground_uw;
+                }
+                if (ws != 0.0) {
+                    const double wsurf = ws * (2.0 * mu) * albedo;
+                    const LayerP<double> p = load_p<SOLAR>(g, b, col, n - 1, w);
+                    const LayerSol<double> h = layer_solution<double, SOLAR>(0, p, mu, g.csz[col], 0.0);
+                    lam_at(b, g, NAZ, view, col, 0, N - 2, w) += wsurf * h.xp * h.omega;
+                    lam_at(b, g, NAZ, view, col, 0, N - 1, w) += wsurf * h.xm;
+                }
+                for (int az = 0; az < NAZ; ++az) {
+                    double r1 = 0, r2 = 0;
+                    for (int i = 0; i < N; ++i) {
+                        double r = lam_at(b, g, NAZ, view, col, az, i, w);
+                        if (i >= 1) r -= lu_at(b, g, NAZ, col, az, LU_ALPHA, i - 1, w) * r1;
+                        if (i >= 2) r -= lu_at(b, g, NAZ, col, az, LU_BETA, i - 2, w) * r2;
+                        lam_at(b, g, NAZ, view, col, az, i, w) = r;
+                        r2 = r1;
+                        r1 = r;
+                    }
+                }
+            }
         }
-    }
-
-    if (!g.spherical) {
-        // surface term of the plane-parallel radiance
-        const LayerP<double> p = load_p<SOLAR>(g, b, 0, n - 1, w);
-        const LayerSol<double> h = layer_solution<double, SOLAR>(0, p, mu, g.csz[0], 0.0);
-        const Boundary<double> q = boundary_particular(p, h);
-        const double base = bottom_plus(h, q, lu_at(b, g, naz, 0, 0, LU_C, N - 2, w), lu_at(b, g, naz, 0, 0, LU_C, N - 1, w));
-        radiance += surf_weight * (base * (2.0 * mu) * albedo + surface_emission);
-        plane_total_over_vc = radiance / g.view_cos[view];
     }
     {
         double* dst = b.radiance + gw * g.nlos + view;
         *dst = b.accumulate ? *dst + radiance : radiance;
         if (b.los_od) b.los_od[gw * g.nlos + view] = path_od;
     }
-    if (!DERIVS) return;
+    if (DERIVS) {
+        vstate_at(b, g, view, 0, w) = surf_weight;
+        vstate_at(b, g, view, 1, w) = path_od;
+    }
+}
 
-    // ---- the boundary-value problem's share of the gradient, column by column
+// ---------------------------------------------------------------------------------------------------------------------------
+// hand-written reverse sweep of one (layer, azimuth order) of the Lagrangian.  The value differentiated is
+//   Tp top_plus + Tm top_minus + Bp bot_plus + Bm bot_minus + Ws (c0 U + c1 V + P [+ thermal emission term])
+// with top_plus = gpt + c0 xp + c1 xm omega, top_minus = gmt + c0 xm + c1 xp omega, bot_plus = gpb + c0 xp omega + c1 xm,
+// bot_minus = gmb + c0 xm omega + c1 xp (the two streams at the layer boundaries) and (U, V, P) of plane_source_terms; PLANE = false leaves
+// the source out (spherical geometry, where the segment sources are differentiated in the forward kernel).  g += d/d(od, ssa, b1, amp, rate).
+// Every quotient of exponentials enters as a function of (k, rate, od) with its three partial derivatives: the direct form from the
+// exponentials at hand, or -- per quotient, where its own exponent difference is near the removable singularity -- the series of
+// exp_difference / integrated_exp_difference (:64-128).  view_adjoint_thread<.., DUAL = true> differentiates the same value in dual
+// numbers: the cross-check of this function in the tests.
+// ---------------------------------------------------------------------------------------------------------------------------
+// (exp_a - exp_b) / (b - a) with exp_a = exp(-a t), exp_b = exp(-b t) and its partial derivatives with respect to a, b, t
+TS_HD Stable edr_partials(double exp_a, double exp_b, double a, double b, double t) {
+    const double delta = b - a;
+    if (fabs(delta * t) <= 1.0e-5) return exp_difference(a, b, t);
+    const double num = exp_a - exp_b, inv = 1.0 / delta, inv2 = inv * inv;
+    return {num * inv, (-t * exp_a * delta + num) * inv2, (t * exp_b * delta - num) * inv2, (-a * exp_a + b * exp_b) * inv};
+}
+// integral over [0, t] of edr(a, b, x) given ga = edr(0, a, t), gb = edr(0, b, t) (values and d/db) and eab = edr(a, b, t)
+TS_HD Stable iedr_partials(const Stable& ga, const Stable& gb, double eab, double a, double b, double t) {
+    const double delta = b - a;
+    if (fabs(delta * t) <= 1.0e-4) return integrated_exp_difference(a, b, t);
+    const double num = ga.value - gb.value, inv = 1.0 / delta, inv2 = inv * inv;
+    return {num * inv, (ga.db * delta + num) * inv2, (-gb.db * delta - num) * inv2, eab};
+}
+
+template <bool SOLAR, bool PLANE>
+TS_HD void layer_adjoint(int az, const LayerP<double>& p, const LayerSol<double>& h, double mu, double csz, double angular, double c0, double c1,
+                         double Tp, double Tm, double Bp, double Bm, double Ws, double vc, double g[5], double& bot_plus, double& source) {
+    const double xp = h.xp, xm = h.xm, om = h.omega, ex = h.expo, k = h.k, upper = h.upper, lower = h.lower;
+    const double od = p.od, ssa = p.ssa, b1 = p.b1, amp = p.amp, rate = p.rate;
+    const Stable cpr = edr_partials(om, ex, k, rate, od);              // d/dk = da, d/drate = db
+    const Stable cmr = edr_partials(1.0, om * ex, 0.0, rate + k, od);  // d/dk = d/drate = db
+    const double cp = amp * cpr.value, cm = amp * cmr.value;
+    bot_plus = upper * cp * xp + c0 * xp * om + c1 * xm;
+    // ---- the two streams at the boundaries
+    const double zt = Tp * xm + Tm * xp, zb = Bp * xp + Bm * xm;
+    double a_lower = cm * zt, a_upper = cp * zb;
+    const double a_cm = lower * zt, a_cp = upper * zb;
+    const double k_xp = Tp * c0 + Bm * c1, k_xm = Tm * c0 + Bp * c1, k_xpo = Tm * c1 + Bp * c0, k_xmo = Tp * c1 + Bm * c0;
+    double a_xp = lower * cm * Tm + upper * cp * Bp + k_xp + om * k_xpo;
+    double a_xm = lower * cm * Tp + upper * cp * Bm + k_xm + om * k_xmo;
+    const double a_om = k_xpo * xp + k_xmo * xm;
+    // cp = amp cpr, cm = amp cmr
+    const double a_cpr = a_cp * amp, a_cmr = a_cm * amp;
+    double a_amp = a_cp * cpr.value + a_cm * cmr.value;
+    double a_k = a_cpr * cpr.da + a_cmr * cmr.db, a_rate = a_cpr * cpr.db + a_cmr * cmr.db, a_od = a_cpr * cpr.dt + a_cmr * cmr.dt;
+    double a_ssa = 0.0, a_b1 = 0.0;
+    source = 0.0;
+    if (PLANE) {
+        // ---- layer-integrated source toward the viewing cosine (explicit_plane_view, :2598-2640)
+        const double inv = 1.0 / vc, phase_mu = vc * mu, phase_sine = 0.25 * sqrt(fmax(0.0, (1.0 - vc * vc) * (1.0 - mu * mu)));
+        double lp, lm;
+        if (az == 0) {
+            lp = 0.5 * ssa * (1.0 - b1 * phase_mu);
+            lm = 0.5 * ssa * (1.0 + b1 * phase_mu);
+        } else {
+            lp = lm = SOLAR ? ssa * b1 * phase_sine : 0.0;
+        }
+        const double yp = lp * xp + lm * xm, ym = lp * xm + lm * xp;
+        const double beam = exp(-od * inv);
+        const Stable e_hm = edr_partials(om, beam, k, inv, od);             // hm = inv e_hm:  d/dk = da
+        const Stable e_hp = edr_partials(1.0, om * beam, 0.0, k + inv, od); // hp = inv e_hp:  d/dk = db
+        const Stable e_si = edr_partials(1.0, ex * beam, 0.0, rate + inv, od);   // source_integral = inv e_si:  d/drate = db
+        // dp_ratio = inv iedr(rate + k, rate + inv), dm_ratio = inv iedr(k + inv, rate + inv)
+        const Stable e_dp = iedr_partials(cmr, e_si, ex * e_hm.value, rate + k, rate + inv, od);    // d/dk = da, d/drate = da + db
+        const Stable e_dm = iedr_partials(e_hp, e_si, beam * cpr.value, k + inv, rate + inv, od);   // d/dk = da, d/drate = db
+        const double hm = inv * e_hm.value, hp = inv * e_hp.value, si = inv * e_si.value, dpr = inv * e_dp.value, dmr = inv * e_dm.value;
+        source = c0 * yp * hp + c1 * ym * hm + amp * (upper * yp * dmr + lower * ym * dpr);
+        double a_si = 0.0;
+        if (!SOLAR && az == 0) {
+            source += amp * si * (1.0 - ssa);
+            a_amp += Ws * si * (1.0 - ssa);
+            a_si = Ws * amp * (1.0 - ssa);
+            a_ssa -= Ws * amp * si;
+        }
+        const double a_yp = Ws * (c0 * hp + amp * upper * dmr), a_ym = Ws * (c1 * hm + amp * lower * dpr);
+        const double a_hp = Ws * c0 * yp * inv, a_hm = Ws * c1 * ym * inv;                            // adjoints of e_hp, e_hm
+        const double a_dm = Ws * amp * upper * yp * inv, a_dp = Ws * amp * lower * ym * inv;          // adjoints of e_dm, e_dp
+        a_si *= inv;                                                                                   // adjoint of e_si
+        a_upper += Ws * amp * yp * dmr;
+        a_lower += Ws * amp * ym * dpr;
+        a_amp += Ws * (upper * yp * dmr + lower * ym * dpr);
+        a_k += a_hm * e_hm.da + a_hp * e_hp.db + a_dp * e_dp.da + a_dm * e_dm.da;
+        a_rate += a_si * e_si.db + a_dp * (e_dp.da + e_dp.db) + a_dm * e_dm.db;
+        a_od += a_hm * e_hm.dt + a_hp * e_hp.dt + a_si * e_si.dt + a_dp * e_dp.dt + a_dm * e_dm.dt;
+        // yp = lp xp + lm xm, ym = lp xm + lm xp
+        const double a_lp = a_yp * xp + a_ym * xm, a_lm = a_yp * xm + a_ym * xp;
+        a_xp += a_yp * lp + a_ym * lm;
+        a_xm += a_yp * lm + a_ym * lp;
+        if (az == 0) {
+            a_ssa += 0.5 * (a_lp * (1.0 - b1 * phase_mu) + a_lm * (1.0 + b1 * phase_mu));
+            a_b1 += 0.5 * ssa * phase_mu * (a_lm - a_lp);
+        } else if (SOLAR) {
+            a_ssa += (a_lp + a_lm) * b1 * phase_sine;
+            a_b1 += (a_lp + a_lm) * ssa * phase_sine;
+        }
+    }
+    // ---- particular-solution amplitudes
+    const double norm = mu * (xp * xp - xm * xm), i_norm = 1.0 / norm;
+    double a_norm;
+    if (SOLAR) {
+        double qp, qm;
+        if (az == 0) {
+            qp = ssa * (1.0 + b1 * (csz * mu)) / kFourPi;
+            qm = ssa * (1.0 - b1 * (csz * mu)) / kFourPi;
+        } else {
+            qp = qm = ssa * b1 * (angular / kFourPi);
+        }
+        const double a_qp = (a_upper * xp + a_lower * xm) * i_norm, a_qm = (a_upper * xm + a_lower * xp) * i_norm;
+        a_xp += (a_upper * qp + a_lower * qm) * i_norm;
+        a_xm += (a_upper * qm + a_lower * qp) * i_norm;
+        a_norm = -(a_upper * upper + a_lower * lower) * i_norm;
+        if (az == 0) {
+            a_ssa += (a_qp * (1.0 + b1 * (csz * mu)) + a_qm * (1.0 - b1 * (csz * mu))) / kFourPi;
+            a_b1 += ssa * (csz * mu) * (a_qp - a_qm) / kFourPi;
+        } else {
+            a_ssa += (a_qp + a_qm) * b1 * (angular / kFourPi);
+            a_b1 += (a_qp + a_qm) * ssa * (angular / kFourPi);
+        }
+    } else {
+        const double a_at = a_upper + a_lower;
+        a_ssa -= a_at * (xp + xm) * i_norm;
+        a_xp += a_at * (1.0 - ssa) * i_norm;
+        a_xm += a_at * (1.0 - ssa) * i_norm;
+        a_norm = -a_at * upper * i_norm;
+    }
+    a_xp += a_norm * 2.0 * mu * xp;
+    a_xm -= a_norm * 2.0 * mu * xm;
+    // ---- omega = exp(-k od) (the exponentials inside the quotients are accounted for by their own partial derivatives),
+    // xp / xm = (1 -/+ s / k) / 2, k = sqrt(s d)
+    a_k -= a_om * om * od;
+    a_od -= a_om * om * k;
+    double s, d;
+    if (az == 0) {
+        d = ssa * b1 * mu - 1.0 / mu;
+        s = (ssa - 1.0) / mu;
+    } else {
+        d = -1.0 / mu;
+        s = (ssa * b1 * (1.0 - mu * mu) - 2.0) / (2.0 * mu);
+    }
+    const double i_k = 1.0 / k, a_sk = 0.5 * (a_xm - a_xp);
+    a_k -= a_sk * s * i_k * i_k;
+    const double a_s = a_sk * i_k + a_k * 0.5 * d * i_k, a_d = a_k * 0.5 * s * i_k;
+    if (az == 0) {
+        a_ssa += a_d * b1 * mu + a_s / mu;
+        a_b1 += a_d * ssa * mu;
+    } else {
+        a_ssa += a_s * b1 * (1.0 - mu * mu) / (2.0 * mu);
+        a_b1 += a_s * ssa * (1.0 - mu * mu) / (2.0 * mu);
+    }
+    g[0] += a_od;
+    g[1] += a_ssa;
+    g[2] += a_b1;
+    g[3] += a_amp;
+    g[4] += a_rate;
+}
+
+// Weighting functions of one line of sight: the backward half of the transposed solve (L^T lambda = y) fused with the Lagrangian of every
+// layer, bottom-up; then the chain from the layer parameters to the level profiles.
+// DUAL = false (the product): the hand-written reverse sweep of the layers (layer_adjoint); DUAL = true (tests only): the same Lagrangian
+// differentiated in dual numbers.
+// `lds`: n + 1 values per thread, element i of this thread at lds[i * ls]
+template <bool SOLAR, bool SPHERICAL, bool DUAL = false> TS_HD void view_adjoint_thread(const Geo& g, const Bufs& b, int w, int view, double* lds, int ls) {
+    constexpr int NAZ = SOLAR ? 2 : 1;
+    const int n = g.nlyr, N = 2 * n, ncol = SOLAR ? g.ncol : 1;
+    const size_t gw = size_t(b.w0) + w;
+    const double mu = g.mu;
+    const double albedo = b.albedo[gw];
+    const double surface_emission = (!SOLAR && b.surface_emission) ? b.surface_emission[gw] : 0.0;
+    const double surf_weight = vstate_at(b, g, view, 0, w);
+    constexpr bool plane = !SPHERICAL;
+    const double vc = plane ? g.view_cos[view] : 1.0, inv = 1.0 / vc;
+    const int ground_lo = (!plane && SOLAR) ? g.ground_col[2 * view] : 0, ground_up = (!plane && SOLAR) ? g.ground_col[2 * view + 1] : 0;
+    const double ground_uw = (!plane && SOLAR) ? g.ground_colw[view] : 0.0;
+    double g_albedo = 0.0, g_surface_emission = 0.0;
+
     for (int col = 0; col < ncol; ++col) {
         const double csz = g.csz[col];
         const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
         double ws = surf_weight;   // weight of this column's surface source in the radiance
-        if (g.spherical && SOLAR) {
+        if (!plane && SOLAR) {
             ws = 0.0;
             if (col == ground_lo) ws += surf_weight * (ground_lo != ground_up ? 1.0 - ground_uw : 1.0);
             if (col == ground_up && ground_lo != ground_up) ws += surf_weight * ground_uw;
@@ -677,86 +917,141 @@ template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bu
         if (!SOLAR) g_surface_emission += ws;
         const double wsurf = ws * (2.0 * mu) * albedo;   // multiplies the downwelling stream at the ground
         for (int i = 0; i <= n; ++i) lds[i * ls] = 0.0;  // gradient with respect to the solar attenuation exponent at every boundary
-        for (int az = 0; az < naz; ++az) {
+        // one azimuth order after the other (their Lagrangians add up): half the live state of a fused loop
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (int az = 0; az < NAZ; ++az) {
             const double delta = az == 0 ? 1.0 : 0.0;
-            // dF/dc of the surface term, then lambda = A^-T dF/dc (pentadiagonal_transpose_solve, :1901-1921)
-            if (az == 0 && wsurf != 0.0) {
-                const LayerP<double> p = load_p<SOLAR>(g, b, col, n - 1, w);
-                const LayerSol<double> h = layer_solution<double, SOLAR>(0, p, mu, csz, 0.0);
-                lam_at(b, g, naz, view, col, 0, N - 2, w) += wsurf * h.xp * h.omega;
-                lam_at(b, g, naz, view, col, 0, N - 1, w) += wsurf * h.xm;
-            }
-            {
-                double r1 = 0, r2 = 0;
-                for (int i = 0; i < N; ++i) {
-                    double r = lam_at(b, g, naz, view, col, az, i, w);
-                    if (i >= 1) r -= lu_at(b, g, naz, col, az, LU_ALPHA, i - 1, w) * r1;
-                    if (i >= 2) r -= lu_at(b, g, naz, col, az, LU_BETA, i - 2, w) * r2;
-                    lam_at(b, g, naz, view, col, az, i, w) = r;
-                    r2 = r1;
-                    r1 = r;
-                }
-                double x1 = 0, x2 = 0;
-                for (int i = N - 1; i >= 0; --i) {
-                    double r = lam_at(b, g, naz, view, col, az, i, w);
-                    if (i + 1 < N) r -= lu_at(b, g, naz, col, az, LU_GAMMA, i + 1, w) * x1;
-                    if (i + 2 < N) r -= lu_at(b, g, naz, col, az, LU_E, i + 2, w) * x2;
-                    r *= lu_at(b, g, naz, col, az, LU_IMU, i, w);
-                    lam_at(b, g, naz, view, col, az, i, w) = r;
-                    x2 = x1;
-                    x1 = r;
-                }
-            }
-            // Lagrangian of every layer: lambda . (r - A c) restricted to the rows that hold this layer, plus the surface term
+            const double azw = plane ? (az == 0 ? 1.0 : cos(g.view_azimuth[view])) : 0.0;
+            double xa = 0.0, xb = 0.0;   // lambda of rows 2l + 1 and 2l + 2
+            // plane parallel: optical depth from the top to the layer (over the view cosine) and the radiance gathered below the layer
+            double tau_over_vc = plane ? vstate_at(b, g, view, 1, w) : 0.0, below = 0.0;
+            // everything a layer reads from scratch, fetched one layer ahead of its use (the stores of a layer would otherwise hold the
+            // next layer's loads back)
+            struct Fetch {
+                LayerP<double> p;
+                double c0, c1, y_plus, y_minus, gamma_plus, gamma_minus, imu_plus, imu_minus;
+            };
+            auto fetch = [&](int l) {
+                Fetch f;
+                f.p = load_p<SOLAR>(g, b, col, l, w);
+                f.c0 = lu_at(b, g, NAZ, col, az, LU_C, 2 * l, w);
+                f.c1 = lu_at(b, g, NAZ, col, az, LU_C, 2 * l + 1, w);
+                f.y_plus = lam_at(b, g, NAZ, view, col, az, 2 * l, w);
+                f.gamma_plus = lu_at(b, g, NAZ, col, az, LU_GAMMA, 2 * l + 1, w);
+                f.imu_plus = lu_at(b, g, NAZ, col, az, LU_IMU, 2 * l, w);
+                f.y_minus = l > 0 ? lam_at(b, g, NAZ, view, col, az, 2 * l - 1, w) : 0.0;
+                f.gamma_minus = l > 0 ? lu_at(b, g, NAZ, col, az, LU_GAMMA, 2 * l, w) : 0.0;
+                f.imu_minus = l > 0 ? lu_at(b, g, NAZ, col, az, LU_IMU, 2 * l - 1, w) : 0.0;
+                return f;
+            };
+            Fetch next = fetch(n - 1);
+            xa = lam_at(b, g, NAZ, view, col, az, N - 1, w) * lu_at(b, g, NAZ, col, az, LU_IMU, N - 1, w);
             for (int l = n - 1; l >= 0; --l) {
-                const LayerP<double> pv = load_p<SOLAR>(g, b, col, l, w);
-                const LayerP<D5> p = lift<D5>(pv);
-                const LayerSol<D5> h = layer_solution<D5, SOLAR>(az, p, mu, csz, angular);
-                const Boundary<D5> q = boundary_particular(p, h);
-                const double c0 = lu_at(b, g, naz, col, az, LU_C, 2 * l, w), c1 = lu_at(b, g, naz, col, az, LU_C, 2 * l + 1, w);
-                const D5 xpo = h.xp * h.omega, xmo = h.xm * h.omega;
-                const D5 top_plus = q.gpt + c0 * h.xp + c1 * xmo, top_minus = q.gmt + c0 * h.xm + c1 * xpo;
-                const D5 bot_plus = q.gpb + c0 * xpo + c1 * h.xm, bot_minus = q.gmb + c0 * xmo + c1 * h.xp;
-                D5 G;
-                if (l == 0) G = -(lam_at(b, g, naz, view, col, az, 0, w) * top_plus);
-                else G = lam_at(b, g, naz, view, col, az, 2 * l - 1, w) * top_minus + lam_at(b, g, naz, view, col, az, 2 * l, w) * top_plus;
+                const Fetch cur = next;
+                if (l > 0) next = fetch(l - 1);
+                const LayerP<double>& pv = cur.p;
+                double attenuation = 0.0;
+                if (plane) {
+                    tau_over_vc -= pv.od * inv;
+                    attenuation = exp(-fmax(tau_over_vc, 0.0));
+                }
+                double G[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+                const LayerSol<double> hv = layer_solution<double, SOLAR>(az, pv, mu, csz, angular);
+                const double c0 = cur.c0, c1 = cur.c1;
+                // lambda of the rows above this layer: L^T lambda = y backwards (pentadiagonal_transpose_solve, :1911-1920); the
+                // second sub-diagonal of row 2l + 2 is xp omega of this layer (:2008)
+                const double e_below = l < n - 1 ? hv.xp * hv.omega : 0.0;
+                const double lam_top_plus = (cur.y_plus - cur.gamma_plus * xa - e_below * xb) * cur.imu_plus;
+                const double lam_top_minus = l > 0 ? (cur.y_minus - cur.gamma_minus * lam_top_plus) * cur.imu_minus : 0.0;
+                // weights of the four boundary streams of this layer in the Lagrangian (rows 2l - 1, 2l above; 2l + 1, 2l + 2 or the surface row below)
+                const double lam_last = xa;
+                const double Tp = l == 0 ? -lam_top_plus : lam_top_plus, Tm = l == 0 ? 0.0 : lam_top_minus;
+                double Bp, Bm;
                 if (l == n - 1) {
-                    const double lam_last = lam_at(b, g, naz, view, col, az, N - 1, w);
-                    const double refl = 2.0 * mu * albedo * delta;
-                    G += lam_last * (refl * bot_plus - bot_minus);
-                    if (az == 0) G += wsurf * bot_plus;
+                    Bp = lam_last * (2.0 * mu * albedo * delta) + (az == 0 ? wsurf : 0.0);
+                    Bm = -lam_last;
+                } else {
+                    Bp = -xb;
+                    Bm = -xa;
+                }
+                const double Ws = attenuation * azw;
+                double bot_plus_v = 0.0, source_v = 0.0;
+                if (!DUAL) {
+                    layer_adjoint<SOLAR, plane>(az, pv, hv, mu, csz, angular, c0, c1, Tp, Tm, Bp, Bm, Ws, vc, G, bot_plus_v, source_v);
+                } else {
+                    const LayerP<D5> p = lift<D5>(pv);
+                    const LayerSol<D5> h = layer_solution<D5, SOLAR>(az, p, mu, csz, angular);
+                    const Boundary<D5> q = boundary_particular(p, h);
+                    const D5 xpo = h.xp * h.omega, xmo = h.xm * h.omega;
+                    const D5 top_plus = q.gpt + c0 * h.xp + c1 * xmo, top_minus = q.gmt + c0 * h.xm + c1 * xpo;
+                    const D5 bot_plus = q.gpb + c0 * xpo + c1 * h.xm, bot_minus = q.gmb + c0 * xmo + c1 * h.xp;
+                    D5 L = Tp * top_plus + Tm * top_minus + Bp * bot_plus + Bm * bot_minus;
+                    bot_plus_v = bot_plus.v;
+                    if (plane) {
+                        const D5 beam = t_exp(-(p.od * inv));
+                        const bool fast = plane_nonresonant(pv.rate, h.k.v, pv.od, inv);
+                        const D5 source_integral = plane_source_integral(p, h.expo, beam, vc, fast);
+                        D5 U, V, P;
+                        plane_source_terms<D5, SOLAR>(az, p, h, vc, mu, fast, beam, source_integral, U, V, P);
+                        D5 src = c0 * U + c1 * V + P;
+                        if (!SOLAR && az == 0) src += p.amp * source_integral * (1.0 - p.ssa);
+                        L += Ws * src;
+                        source_v = src.v;
+                    }
+                    for (int d = 0; d < 5; ++d) G[d] += L.d[d];
+                }
+                if (l == n - 1) {
                     // the surface row also holds the albedo, the transmission to the ground and the surface emission
                     const double amp_ground = SOLAR ? amp_at(b, g, col, n, w) : 0.0;
-                    g_albedo += lam_last * (delta * csz / kPi * amp_ground + 2.0 * mu * delta * bot_plus.v);
-                    if (az == 0) g_albedo += ws * (2.0 * mu) * bot_plus.v;
+                    g_albedo += lam_last * (delta * csz / kPi * amp_ground + 2.0 * mu * delta * bot_plus_v);
+                    if (az == 0) {
+                        g_albedo += ws * (2.0 * mu) * bot_plus_v;
+                        if (plane) below = ws * (bot_plus_v * (2.0 * mu) * albedo + surface_emission);
+                    }
                     if (SOLAR) lds[n * ls] += lam_last * delta * csz * albedo / kPi * amp_ground;
                     else g_surface_emission += lam_last;
+                }
+                xb = lam_top_plus;
+                xa = lam_top_minus;
+
+                double g_od = G[0], g_ssa = G[1], g_b1 = G[2], g_amp = G[3], g_rate = G[4];
+                if (plane) {
+                    // every source below this layer is attenuated by exp(-od / vc) of this one
+                    g_od -= below * inv;
+                    below += Ws * source_v;
+                } else if (az == 0) {
+                    g_od += g5_at(b, g, view, col, l, 0, w);
+                    g_ssa += g5_at(b, g, view, col, l, 1, w);
+                    g_b1 += g5_at(b, g, view, col, l, 2, w);
+                    g_amp += g5_at(b, g, view, col, l, 3, w);
+                    g_rate += g5_at(b, g, view, col, l, 4, w);
+                }
+                if (SOLAR) {
+                    // amplitude = irradiance exp(att_l); rate = (att_l - att_(l+1)) / od  (map_explicit_to_levels, :2843-2865)
+                    if (l > 0) lds[l * ls] += g_amp * pv.amp;
+                    if (pv.od > 0.0) {
+                        const double wgt = g_rate / pv.od;
+                        lds[l * ls] += wgt;
+                        lds[(l + 1) * ls] -= wgt;
+                        g_od -= g_rate * pv.rate / pv.od;
+                    }
                 } else {
-                    G += -(lam_at(b, g, naz, view, col, az, 2 * l + 1, w) * bot_minus) - lam_at(b, g, naz, view, col, az, 2 * l + 2, w) * bot_plus;
+                    // (thermal: amplitude = emission at the top level, rate = log(top / bottom) / od, :2868-2887 -- mapped with the levels below)
+                    gsum_at(b, g, view, 3, l, w) = g_amp;
+                    gsum_at(b, g, view, 4, l, w) = g_rate;
                 }
-                for (int d = 0; d < 5; ++d) g5_at(b, g, view, col, l, d, w) += G.d[d];
-            }
-        }
-        // from (amplitude, rate) of this column to the layer optical depths or the level emissions
-        for (int l = n - 1; l >= 0; --l) {
-            const LayerP<double> pv = load_p<SOLAR>(g, b, col, l, w);
-            double g_od = g5_at(b, g, view, col, l, 0, w);
-            if (!g.spherical) g_od -= plane_total_over_vc;
-            const double g_amp = g5_at(b, g, view, col, l, 3, w), g_rate = g5_at(b, g, view, col, l, 4, w);
-            if (SOLAR) {
-                // amplitude = irradiance exp(att_l); rate = (att_l - att_(l+1)) / od  (map_explicit_to_levels, :2843-2865)
-                if (l > 0) lds[l * ls] += g_amp * pv.amp;
-                if (pv.od > 0.0) {
-                    const double wgt = g_rate / pv.od;
-                    lds[l * ls] += wgt;
-                    lds[(l + 1) * ls] -= wgt;
-                    g_od -= g_rate * pv.rate / pv.od;
+                if (col == 0 && az == 0) {
+                    gsum_at(b, g, view, 0, l, w) = g_od;
+                    gsum_at(b, g, view, 1, l, w) = g_ssa;
+                    gsum_at(b, g, view, 2, l, w) = g_b1;
+                } else {
+                    gsum_at(b, g, view, 0, l, w) += g_od;
+                    gsum_at(b, g, view, 1, l, w) += g_ssa;
+                    gsum_at(b, g, view, 2, l, w) += g_b1;
                 }
             }
-            // (thermal: amplitude = emission at the top level, rate = log(top / bottom) / od, :2868-2887 -- mapped with the levels below)
-            gsum_at(b, g, view, 0, l, w) += g_od;
-            gsum_at(b, g, view, 1, l, w) += g5_at(b, g, view, col, l, 1, w);
-            gsum_at(b, g, view, 2, l, w) += g5_at(b, g, view, col, l, 2, w);
         }
         if (SOLAR) {
             // attenuation exponents are minus the Chapman-weighted optical depths above the boundary
@@ -773,63 +1068,61 @@ template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bu
     }
 
     // ---- from the layers to the level profiles (map_explicit_to_levels, :2889-2919) and out
-    {
-        double carry_ext = 0.0, carry_ssa = 0.0, carry_b1 = 0.0, carry_em = 0.0;
-        LevelIn top = load_level(g, b, gw, 0);
-        for (int t = 0; t <= n; ++t) {
-            double o_ext = carry_ext, o_ssa = carry_ssa, o_b1 = carry_b1, o_em = carry_em;
-            carry_ext = carry_ssa = carry_b1 = carry_em = 0.0;
-            if (t < n) {
-                const int l = t;
-                const LevelIn bot = load_level(g, b, gw, l + 1);
-                const double od = lay_at(b, g, 0, l, w), ssa = lay_at(b, g, 1, l, w), b1 = lay_at(b, g, 2, l, w);
-                double g_od = gsum_at(b, g, view, 0, l, w);
-                const double g_ssa = ssa >= kSsaCap ? 0.0 : gsum_at(b, g, view, 1, l, w), g_b1 = gsum_at(b, g, view, 2, l, w);
-                if (!SOLAR) {
-                    const double g_amp = g5_at(b, g, view, 0, l, 3, w), g_rate = g5_at(b, g, view, 0, l, 4, w);
-                    o_em += g_amp;
-                    if (od > kThermalMinOd && top.em > kThermalMinEmission && bot.em > kThermalMinEmission) {
-                        o_em += g_rate / (top.em * od);
-                        carry_em -= g_rate / (bot.em * od);
-                        g_od -= g_rate * rate_at(b, g, 0, l, w) / od;
-                    }
+    double carry_ext = 0.0, carry_ssa = 0.0, carry_b1 = 0.0, carry_em = 0.0;
+    LevelIn top = load_level(g, b, gw, 0);
+    for (int t = 0; t <= n; ++t) {
+        double o_ext = carry_ext, o_ssa = carry_ssa, o_b1 = carry_b1, o_em = carry_em;
+        carry_ext = carry_ssa = carry_b1 = carry_em = 0.0;
+        if (t < n) {
+            const int l = t;
+            const LevelIn bot = load_level(g, b, gw, l + 1);
+            const double od = lay_at(b, g, 0, l, w), ssa = lay_at(b, g, 1, l, w), b1 = lay_at(b, g, 2, l, w);
+            double g_od = gsum_at(b, g, view, 0, l, w);
+            const double g_ssa = ssa >= kSsaCap ? 0.0 : gsum_at(b, g, view, 1, l, w), g_b1 = gsum_at(b, g, view, 2, l, w);
+            if (!SOLAR) {
+                const double g_amp = gsum_at(b, g, view, 3, l, w), g_rate = gsum_at(b, g, view, 4, l, w);
+                o_em += g_amp;
+                if (od > kThermalMinOd && top.em > kThermalMinEmission && bot.em > kThermalMinEmission) {
+                    o_em += g_rate / (top.em * od);
+                    carry_em -= g_rate / (bot.em * od);
+                    g_od -= g_rate * rate_at(b, g, 0, l, w) / od;
                 }
-                const double dz = g.thickness[l];
-                const double mean_ext = od / dz, mean_scat = ssa * mean_ext;
-                const double c_od = 0.5 * g_od * dz;
-                const double c_ssa = mean_ext > 0.0 ? 0.5 * g_ssa / mean_ext : 0.0;
-                const double c_b1 = mean_scat > 0.0 ? 0.5 * g_b1 / mean_scat : 0.0;
-                const double db_top = top.b1 - b1, db_bot = bot.b1 - b1;
-                o_ext += c_od + c_ssa * (top.ssa - ssa) + c_b1 * top.ssa * db_top;
-                o_ssa += c_ssa * top.ext + c_b1 * top.ext * db_top;
-                o_b1 += c_b1 * top.ssa * top.ext;
-                carry_ext = c_od + c_ssa * (bot.ssa - ssa) + c_b1 * bot.ssa * db_bot;
-                carry_ssa = c_ssa * bot.ext + c_b1 * bot.ext * db_bot;
-                carry_b1 = c_b1 * bot.ssa * bot.ext;
-                top = bot;
             }
-            if (g.spherical) o_ext += glev_at(b, g, view, t, w);
-            const size_t o = (size_t(g.ngrid - 1 - t) * b.nw_total + gw) * g.nlos + view;
-            if (b.accumulate) {
-                b.wf_ext[o] += o_ext;
-                b.wf_ssa[o] += o_ssa;
-                b.wf_b1[o] += o_b1;
-                if (!SOLAR && b.wf_em) b.wf_em[o] += o_em;
-            } else {
-                b.wf_ext[o] = o_ext;
-                b.wf_ssa[o] = o_ssa;
-                b.wf_b1[o] = o_b1;
-                if (b.wf_em) b.wf_em[o] = SOLAR ? 0.0 : o_em;
-            }
+            const double dz = g.thickness[l];
+            const double mean_ext = od / dz, mean_scat = ssa * mean_ext;
+            const double c_od = 0.5 * g_od * dz;
+            const double c_ssa = mean_ext > 0.0 ? 0.5 * g_ssa / mean_ext : 0.0;
+            const double c_b1 = mean_scat > 0.0 ? 0.5 * g_b1 / mean_scat : 0.0;
+            const double db_top = top.b1 - b1, db_bot = bot.b1 - b1;
+            o_ext += c_od + c_ssa * (top.ssa - ssa) + c_b1 * top.ssa * db_top;
+            o_ssa += c_ssa * top.ext + c_b1 * top.ext * db_top;
+            o_b1 += c_b1 * top.ssa * top.ext;
+            carry_ext = c_od + c_ssa * (bot.ssa - ssa) + c_b1 * bot.ssa * db_bot;
+            carry_ssa = c_ssa * bot.ext + c_b1 * bot.ext * db_bot;
+            carry_b1 = c_b1 * bot.ssa * bot.ext;
+            top = bot;
         }
-        const size_t o = gw * g.nlos + view;
+        if (!plane) o_ext += glev_at(b, g, view, t, w);
+        const size_t o = (size_t(g.ngrid - 1 - t) * b.nw_total + gw) * g.nlos + view;
         if (b.accumulate) {
-            b.wf_alb[o] += g_albedo;
-            if (b.wf_sem) b.wf_sem[o] += g_surface_emission;
+            b.wf_ext[o] += o_ext;
+            b.wf_ssa[o] += o_ssa;
+            b.wf_b1[o] += o_b1;
+            if (!SOLAR && b.wf_em) b.wf_em[o] += o_em;
         } else {
-            b.wf_alb[o] = g_albedo;
-            if (b.wf_sem) b.wf_sem[o] = g_surface_emission;
+            b.wf_ext[o] = o_ext;
+            b.wf_ssa[o] = o_ssa;
+            b.wf_b1[o] = o_b1;
+            if (b.wf_em) b.wf_em[o] = SOLAR ? 0.0 : o_em;
         }
+    }
+    const size_t o = gw * g.nlos + view;
+    if (b.accumulate) {
+        b.wf_alb[o] += g_albedo;
+        if (b.wf_sem) b.wf_sem[o] += g_surface_emission;
+    } else {
+        b.wf_alb[o] = g_albedo;
+        if (b.wf_sem) b.wf_sem[o] = g_surface_emission;
     }
 }
 
@@ -837,8 +1130,8 @@ template <bool SOLAR, bool DERIVS> TS_HD void view_thread(const Geo& g, const Bu
 // scratch sizes in doubles for W lanes (shared by the HIP driver and the CPU emulation of the tests)
 // ---------------------------------------------------------------------------------------------------------------------------
 struct ScratchSizes {
-    size_t lay, colv, lu, lam, g5, gsum, path, glev;
-    size_t total() const { return lay + colv + lu + lam + g5 + gsum + path + glev; }
+    size_t lay, colv, lu, lam, g5, gsum, vstate, path, glev;
+    size_t total() const { return lay + colv + lu + lam + g5 + gsum + vstate + path + glev; }
 };
 inline ScratchSizes scratch_sizes(int nlyr, int ngrid, int nlos, int ncol, int max_seg, bool spherical, bool derivs, size_t W) {
     ScratchSizes z{};
@@ -848,9 +1141,10 @@ inline ScratchSizes scratch_sizes(int nlyr, int ngrid, int nlos, int ncol, int m
     z.lu = size_t(ncol) * 2 * 6 * (2 * n) * W;
     if (derivs) {
         z.lam = size_t(nlos) * ncol * 2 * (2 * n) * W;
-        z.g5 = size_t(nlos) * ncol * n * 5 * W;
-        z.gsum = size_t(nlos) * 3 * n * W;
+        z.gsum = size_t(nlos) * 5 * n * W;
+        z.vstate = size_t(nlos) * 2 * W;
         if (spherical) {
+            z.g5 = size_t(nlos) * ncol * n * 5 * W;
             z.path = size_t(nlos) * 3 * size_t(max_seg) * W;
             z.glev = size_t(nlos) * size_t(ngrid) * W;
         }

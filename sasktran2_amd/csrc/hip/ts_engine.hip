@@ -1,9 +1,9 @@
 // Two-stream source on the device (multiple_scatter_source = twostream, emission_source = twostream).
 //
-// One thread per wavelength (kernel k_ts_solve) or per (wavelength, line of sight) (k_ts_view); the arithmetic is in ts_core.hpp, shared with
+// One thread per wavelength (kernel k_ts_solve) or per (wavelength, line of sight) (k_ts_view, k_ts_adjoint); the arithmetic is in ts_core.hpp, shared with
 // the CPU emulation of the tests.  Every piece of state that outlives a kernel sits in scratch rows of W lanes ([item][lane]: a
 // wavefront's access to one item is one contiguous 512-byte row); the wave-uniform geometry (Chapman factors, segments, stencils) is
-// read through the scalar cache.  Wavelengths are processed in blocks small enough for the scratch to stay near the L2 / Infinity Cache.
+// read through the scalar cache.  A launch takes as many wavelengths as the HBM budget allows.
 //
 // Reference replaced: CppTwoStreamSourceAdapter<ONLY_SOLAR | ONLY_THERMAL> (cpp/lib/sktran_disco/cpp_twostream_source.cpp), which packs 8
 // wavelengths into one SIMD register the same way (LANES = 8, :19); here a wavefront carries 64.
@@ -31,6 +31,9 @@ namespace skdev {
 
 namespace {
 constexpr int kWave = 64;
+#ifndef TS_ADJOINT_WAVES
+#define TS_ADJOINT_WAVES 2
+#endif
 
 template <bool SOLAR> __global__ void __launch_bounds__(kWave) k_ts_solve(const skt::Geo g, const skt::Bufs b) {
     extern __shared__ double lds[];
@@ -38,11 +41,25 @@ template <bool SOLAR> __global__ void __launch_bounds__(kWave) k_ts_solve(const 
     if (w >= b.nw) return;
     skt::solve_thread<SOLAR>(g, b, w, lds + threadIdx.x, kWave);
 }
-template <bool SOLAR, bool DERIVS> __global__ void __launch_bounds__(kWave) k_ts_view(const skt::Geo g, const skt::Bufs b) {
+template <bool SOLAR, bool DERIVS, bool SPHERICAL> __global__ void __launch_bounds__(kWave) k_ts_view(const skt::Geo g, const skt::Bufs b) {
+    const int w = blockIdx.x * kWave + threadIdx.x;
+    if (w >= b.nw) return;
+    skt::view_forward_thread<SOLAR, DERIVS, SPHERICAL>(g, b, w, blockIdx.y);
+}
+// two wavefronts per SIMD: the plane-parallel solar instance needs a few registers more than the 256 that allows, a handful of spills is the better trade
+template <bool SOLAR, bool SPHERICAL> __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(TS_ADJOINT_WAVES))) k_ts_adjoint(const skt::Geo g, const skt::Bufs b) {
     extern __shared__ double lds[];
     const int w = blockIdx.x * kWave + threadIdx.x;
     if (w >= b.nw) return;
-    skt::view_thread<SOLAR, DERIVS>(g, b, w, blockIdx.y, lds + threadIdx.x, kWave);
+    skt::view_adjoint_thread<SOLAR, SPHERICAL>(g, b, w, blockIdx.y, lds + threadIdx.x, kWave);
+}
+template <bool SOLAR, bool DERIVS> void launch_view(bool spherical, dim3 grid, hipStream_t st, const skt::Geo& g, const skt::Bufs& b) {
+    if (spherical) hipLaunchKernelGGL((k_ts_view<SOLAR, DERIVS, true>), grid, dim3(kWave), 0, st, g, b);
+    else hipLaunchKernelGGL((k_ts_view<SOLAR, DERIVS, false>), grid, dim3(kWave), 0, st, g, b);
+}
+template <bool SOLAR> void launch_adjoint(bool spherical, dim3 grid, size_t lds_bytes, hipStream_t st, const skt::Geo& g, const skt::Bufs& b) {
+    if (spherical) hipLaunchKernelGGL((k_ts_adjoint<SOLAR, true>), grid, dim3(kWave), lds_bytes, st, g, b);
+    else hipLaunchKernelGGL((k_ts_adjoint<SOLAR, false>), grid, dim3(kWave), lds_bytes, st, g, b);
 }
 
 struct DevMem {
@@ -195,14 +212,14 @@ void TsDeviceEngine::solve_device(int nwavel, const Inputs& in, const Outputs& o
     const bool derivs = out.wf_ext != nullptr;
     if (derivs && (!out.wf_ssa || !out.wf_b1 || !out.wf_albedo)) throw std::runtime_error("two-stream source: weighting functions need wf_ext, wf_ssa, wf_b1 and wf_albedo together");
 
-    // wavelengths per launch: enough threads to fill the chip, scratch small enough to stay close to the caches, inside the HBM budget
+    // wavelengths per launch: as many as the HBM budget allows
     const size_t per_w = bytes_per_wavelength(derivs);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = size_t(0.5 * double(free_b + I.scratch_bytes));
     if (const char* e = std::getenv("SASKTRAN2_AMD_HBM_BUDGET_MB")) budget = size_t(std::max(1, atoi(e))) << 20;
     size_t fit = std::max<size_t>(kWave, budget / per_w / kWave * kWave);
-    size_t want = 65536;
+    size_t want = size_t(1) << 22;   // no cache to stay inside: the more wavefronts per launch the better the latencies overlap
     if (const char* e = std::getenv("SASKTRAN2_AMD_TS_CHUNK")) want = std::max<size_t>(kWave, size_t(atoi(e)));
     if (max_chunk > 0) want = std::min<size_t>(want, size_t(max_chunk));
     fit = std::min(fit, std::max<size_t>(kWave, want / kWave * kWave));
@@ -221,6 +238,7 @@ void TsDeviceEngine::solve_device(int nwavel, const Inputs& in, const Outputs& o
         I.b.lam = I.scratch.alloc<double>(z.lam);
         I.b.g5 = I.scratch.alloc<double>(z.g5);
         I.b.gsum = I.scratch.alloc<double>(z.gsum);
+        I.b.vstate = I.scratch.alloc<double>(z.vstate);
         I.b.path = I.scratch.alloc<double>(z.path);
         I.b.glev = I.scratch.alloc<double>(z.glev);
         I.scratch_bytes = z.total() * sizeof(double);
@@ -253,13 +271,19 @@ void TsDeviceEngine::solve_device(int nwavel, const Inputs& in, const Outputs& o
             }
             {
                 TsTimer t(I, st, solar ? "ts_view" : "ts_view_thermal");
+                const bool sph = g.spherical != 0;
                 if (solar) {
-                    if (derivs) hipLaunchKernelGGL((k_ts_view<true, true>), grid_v, dim3(kWave), lds_bytes, st, g, b);
-                    else hipLaunchKernelGGL((k_ts_view<true, false>), grid_v, dim3(kWave), lds_bytes, st, g, b);
+                    if (derivs) launch_view<true, true>(sph, grid_v, st, g, b);
+                    else launch_view<true, false>(sph, grid_v, st, g, b);
                 } else {
-                    if (derivs) hipLaunchKernelGGL((k_ts_view<false, true>), grid_v, dim3(kWave), lds_bytes, st, g, b);
-                    else hipLaunchKernelGGL((k_ts_view<false, false>), grid_v, dim3(kWave), lds_bytes, st, g, b);
+                    if (derivs) launch_view<false, true>(sph, grid_v, st, g, b);
+                    else launch_view<false, false>(sph, grid_v, st, g, b);
                 }
+            }
+            if (derivs) {
+                TsTimer t(I, st, solar ? "ts_adjoint" : "ts_adjoint_thermal");
+                if (solar) launch_adjoint<true>(g.spherical != 0, grid_v, lds_bytes, st, g, b);
+                else launch_adjoint<false>(g.spherical != 0, grid_v, lds_bytes, st, g, b);
             }
             TS_HIP_CHECK(hipGetLastError());
             ++pass;

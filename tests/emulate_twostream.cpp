@@ -50,7 +50,8 @@ void emts_destroy(void* h) { delete static_cast<Handle*>(h); }
 // radiance [nwavel][nlos]; wf_ext / wf_ssa / wf_b1 / wf_em [ngrid][nwavel][nlos]; wf_alb / wf_sem [nwavel][nlos] (all or none)
 int emts_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg, const double* delta_f,
              const double* emission, const double* surface_emission, const double* solar_irradiance, const double* albedo,
-             double* radiance, double* wf_ext, double* wf_ssa, double* wf_b1, double* wf_em, double* wf_alb, double* wf_sem) {
+             double* radiance, double* wf_ext, double* wf_ssa, double* wf_b1, double* wf_em, double* wf_alb, double* wf_sem, int dual_adjoint) {
+    // dual_adjoint 0: as the HIP driver (hand-written reverse sweep of the layers); 1: the same Lagrangian differentiated in dual numbers
     auto* h = static_cast<Handle*>(hv);
     if (!h) return -1;
     const skts::TsGeometry& tg = h->tg;
@@ -72,9 +73,9 @@ int emts_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     b.emission = emission; b.surface_emission = surface_emission;
     b.radiance = radiance; b.wf_ext = wf_ext; b.wf_ssa = wf_ssa; b.wf_b1 = wf_b1; b.wf_alb = wf_alb; b.wf_em = wf_em; b.wf_sem = wf_sem;
     const skt::ScratchSizes z = skt::scratch_sizes(g.nlyr, g.ngrid, g.nlos, g.ncol, g.max_seg, g.spherical != 0, derivs, size_t(b.W));
-    std::vector<double> lay(z.lay), colv(z.colv), lu(z.lu), lam(z.lam), g5(z.g5), gsum(z.gsum), path(z.path), glev(z.glev);
+    std::vector<double> lay(z.lay), colv(z.colv), lu(z.lu), lam(z.lam), g5(z.g5), gsum(z.gsum), vstate(z.vstate), path(z.path), glev(z.glev);
     b.lay = lay.data(); b.colv = colv.data(); b.lu = lu.data(); b.lam = lam.data(); b.g5 = g5.data(); b.gsum = gsum.data();
-    b.path = path.data(); b.glev = glev.data();
+    b.path = path.data(); b.glev = glev.data(); b.vstate = vstate.data();
     std::vector<double> lds(size_t(g.nlyr) + 1);
     int pass = 0;
     for (int solar = 1; solar >= 0; --solar) {
@@ -85,16 +86,37 @@ int emts_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
             if (solar) skt::solve_thread<true>(g, b, w, lds.data(), 1);
             else skt::solve_thread<false>(g, b, w, lds.data(), 1);
         }
-        for (int v = 0; v < g.nlos; ++v)
-            for (int w = 0; w < nwavel; ++w) {
-                if (solar) {
-                    if (derivs) skt::view_thread<true, true>(g, b, w, v, lds.data(), 1);
-                    else skt::view_thread<true, false>(g, b, w, v, lds.data(), 1);
-                } else {
-                    if (derivs) skt::view_thread<false, true>(g, b, w, v, lds.data(), 1);
-                    else skt::view_thread<false, false>(g, b, w, v, lds.data(), 1);
-                }
+        auto forward = [&](int w, int v) {
+            const int key = (solar ? 4 : 0) + (derivs ? 2 : 0) + (g.spherical ? 1 : 0);
+            switch (key) {
+                case 0: skt::view_forward_thread<false, false, false>(g, b, w, v); break;
+                case 1: skt::view_forward_thread<false, false, true>(g, b, w, v); break;
+                case 2: skt::view_forward_thread<false, true, false>(g, b, w, v); break;
+                case 3: skt::view_forward_thread<false, true, true>(g, b, w, v); break;
+                case 4: skt::view_forward_thread<true, false, false>(g, b, w, v); break;
+                case 5: skt::view_forward_thread<true, false, true>(g, b, w, v); break;
+                case 6: skt::view_forward_thread<true, true, false>(g, b, w, v); break;
+                default: skt::view_forward_thread<true, true, true>(g, b, w, v); break;
             }
+        };
+        auto adjoint = [&](int w, int v) {
+            const int key = (solar ? 4 : 0) + (g.spherical ? 2 : 0) + (dual_adjoint ? 1 : 0);
+            switch (key) {
+                case 0: skt::view_adjoint_thread<false, false, false>(g, b, w, v, lds.data(), 1); break;
+                case 1: skt::view_adjoint_thread<false, false, true>(g, b, w, v, lds.data(), 1); break;
+                case 2: skt::view_adjoint_thread<false, true, false>(g, b, w, v, lds.data(), 1); break;
+                case 3: skt::view_adjoint_thread<false, true, true>(g, b, w, v, lds.data(), 1); break;
+                case 4: skt::view_adjoint_thread<true, false, false>(g, b, w, v, lds.data(), 1); break;
+                case 5: skt::view_adjoint_thread<true, false, true>(g, b, w, v, lds.data(), 1); break;
+                case 6: skt::view_adjoint_thread<true, true, false>(g, b, w, v, lds.data(), 1); break;
+                default: skt::view_adjoint_thread<true, true, true>(g, b, w, v, lds.data(), 1); break;
+            }
+        };
+        for (int v = 0; v < g.nlos; ++v)
+            for (int w = 0; w < nwavel; ++w) forward(w, v);
+        if (derivs)
+            for (int v = 0; v < g.nlos; ++v)
+                for (int w = 0; w < nwavel; ++w) adjoint(w, v);
         ++pass;
     }
     return 0;

@@ -12,9 +12,9 @@ from tests.test_ts_oracle import resonance_cases, run_ts, ts_oracle
 NAMES = ("d_extinction", "d_ssa", "d_b1", "d_emission", "d_albedo", "d_surface_emission")
 
 
-def compare(s, solar=True, thermal=False, rtol=1e-9):
+def compare(s, solar=True, thermal=False, rtol=1e-9, dual_adjoint=False):
     ref = run_ts(s, ts_oracle(s, solar=solar, thermal=thermal), derivatives=True)
-    out = run_emulated_twostream(s, derivatives=True, solar=solar, thermal=thermal)
+    out = run_emulated_twostream(s, derivatives=True, solar=solar, thermal=thermal, dual_adjoint=dual_adjoint)
     fwd = run_emulated_twostream(s, derivatives=False, solar=solar, thermal=thermal)
     np.testing.assert_allclose(out["radiance"], ref["radiance"], rtol=rtol, atol=1e-300)
     np.testing.assert_allclose(fwd["radiance"], ref["radiance"], rtol=rtol, atol=1e-300)
@@ -32,11 +32,12 @@ def test_plane_parallel_delta_m():
 
 @pytest.mark.parametrize("spherical", [False, True])
 @pytest.mark.parametrize("sources", ["solar", "thermal", "both"])
-def test_reference_case(spherical, sources):
+@pytest.mark.parametrize("dual_adjoint", [False, True], ids=["reverse sweep (the product)", "dual numbers (cross-check)"])
+def test_reference_case(spherical, sources, dual_adjoint):
     s = sc.twostream_reference_case(spherical=spherical, thermal=sources != "solar")
     s["ssa"] = s["ssa"] + 0.002 * np.arange(13)[:, None]
     s["leg"][1] += 0.01 * np.arange(13)[:, None]
-    compare(s, solar=sources != "thermal", thermal=sources != "solar")
+    compare(s, solar=sources != "thermal", thermal=sources != "solar", dual_adjoint=dual_adjoint)
 
 
 def test_single_column_spherical():
@@ -45,10 +46,24 @@ def test_single_column_spherical():
     compare(s)
 
 
-def test_resonances():
+@pytest.mark.parametrize("dual_adjoint", [False, True], ids=["reverse sweep (the product)", "dual numbers (cross-check)"])
+def test_resonances(dual_adjoint):
     solar, thermal = resonance_cases()
-    compare(solar, rtol=1e-7)
-    compare(thermal, solar=False, thermal=True, rtol=1e-7)
+    compare(solar, rtol=1e-7, dual_adjoint=dual_adjoint)
+    compare(thermal, solar=False, thermal=True, rtol=1e-7, dual_adjoint=dual_adjoint)
+
+
+def test_view_resonances():
+    # a viewing cosine equal to 1 / eigenvalue of either azimuth order, in thin and in thick layers (the quotients of the layer-integrated source)
+    s = sc.twostream_reference_case(spherical=False)
+    w, b1, mu = 0.85, 0.2, 0.5
+    k0 = np.sqrt((w * b1 * mu - 1 / mu) * ((w - 1) / mu))
+    k1 = np.sqrt((-1 / mu) * ((w * b1 * (1 - mu * mu) - 2) / (2 * mu)))
+    s["rays"] = [(sc.GROUND_VIEWING_SOLAR, 0.6, 0.3, 200_000.0, 1 / k1), (sc.GROUND_VIEWING_SOLAR, 0.6, -0.4, 200_000.0, min(1 / k0, 0.999))]
+    for scale in (1.0, 30.0):
+        t = dict(s, extinction=s["extinction"] * scale)
+        compare(t, rtol=1e-7)
+        compare(t, rtol=1e-7, dual_adjoint=True)
 
 
 def test_conservative_scattering_and_empty_upper_levels():

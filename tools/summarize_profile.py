@@ -24,7 +24,7 @@ def find(sub, pattern):
 
 
 def short(name):
-    m = re.search(r"(kern_\w+|k_so_\w+)(<[^>]*>)?", name)
+    m = re.search(r"(kern_\w+|k_so_\w+|k_ts_\w+)(<[^>]*>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
 
@@ -88,5 +88,9 @@ for k, d in pmc.items():
         r["valu_active_over_wave_cycles"] = d.get("SQ_ACTIVE_INST_VALU_per_launch", 0) / d["SQ_WAVE_CYCLES_per_launch"]
     rows.append(r)
 rows.sort(key=lambda r: -(r.get("hbm_read_bytes_per_launch_x2_corrected") or 0))
-out["pmc_4096_wavelengths_per_launch"] = rows
+if os.environ.get("PMC_WAVELENGTHS"):   # PMC passes taken at another launch size (tools/profile_ts.sh)
+    out["wavelengths_per_launch"] = int(os.environ["PMC_WAVELENGTHS"])
+    out["pmc"] = rows
+else:
+    out["pmc_4096_wavelengths_per_launch"] = rows
 print(json.dumps(out, indent=1))
