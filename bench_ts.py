@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0
 ROOT = Path(__file__).resolve().parent
-PMC_KERNEL_OF = {"k_ts_solve": "ts_solve", "k_ts_view": "ts_view"}
+PMC_KERNEL_OF = {"k_ts_solve": "ts_solve", "k_ts_view": "ts_view", "k_ts_adjoint": "ts_adjoint", "k_ts_up": "ts_up"}
 
 
 def pmc_bytes_per_wavelength():
@@ -41,12 +41,14 @@ def pmc_bytes_per_wavelength():
     return out
 
 
-def scenario(num_wavelengths, nlyr=20):
+def scenario(num_wavelengths, nlyr=20, nleg=16):
     from tests import scenarios as sc
     alt = np.arange(nlyr + 1.0)
     nw = num_wavelengths
-    leg = np.zeros((16, nlyr + 1, nw))
-    leg[0], leg[2] = 1.0, 0.5
+    leg = np.zeros((nleg, nlyr + 1, nw))
+    leg[0] = 1.0
+    if nleg > 2:
+        leg[2] = 0.5
     # the reference benchmark fills every wavelength with the same numbers; a spectral ramp on the extinction (total optical depth 0.1 ... 4)
     # and a slightly absorbing, slightly anisotropic medium keep every derivative alive
     leg[1] = 0.3
@@ -63,7 +65,7 @@ def run_twostream(args, world, rank, dev):
     from tests.gpu_harness import build_ts_engine
 
     NW = args.wavelengths or 220_000
-    s = scenario(NW)
+    s = scenario(NW, nleg=int(os.environ.get("TS_BENCH_NLEG", "16")))   # (TS_BENCH_NLEG: probe of the cost of the strided moment read)
     ngrid, nlos = s["extinction"].shape[0], len(s["rays"])
     engine, config, geometry = build_ts_engine(s)
     solver = TsDeviceSolver(engine)

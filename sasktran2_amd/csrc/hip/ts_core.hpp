@@ -61,8 +61,9 @@ struct Bufs {
     double* los_od;   // [nw_total][nlos] optical depth along the line of sight, or null
     // scratch, every item a row of W lanes
     double* lay;    // [3][n]                   od, ssa, b1 of the layers
+    double* lev;    // [4][n + 1]               extinction, ssa, b1, emission of the levels (top first): the strided inputs are read once
     double* colv;   // [ncol][2n + 1]           source amplitude at the n + 1 boundaries (solar: transmission) and decay rate of the n layers
-    double* lu;     // [ncol][naz][6][2n]       c (solution), alpha, beta, gamma, e, 1 / mu of the LU sweep
+    double* lu;     // [ncol][naz][5][2n]       c (solution), alpha, beta, gamma, 1 / mu of the LU sweep
     double* lam;    // [nlos][ncol][naz][2n]    dF/dc, then lambda
     double* g5;     // [nlos][ncol][n][5]       gradient with respect to the layer parameters
     double* gsum;   // [nlos][5][n]             od / ssa / b1 gradients summed over the columns; thermal: amplitude / rate gradients
@@ -346,11 +347,12 @@ template <class S> TS_HD S local_emission(const LayerP<S>& p, double frac_top) {
 // ---------------------------------------------------------------------------------------------------------------------------
 TS_HD int naz_of(bool solar) { return solar ? 2 : 1; }
 TS_HD double& lay_at(const Bufs& b, const Geo& g, int which, int l, int w) { return b.lay[(size_t(which) * g.nlyr + l) * b.W + w]; }
+TS_HD double& lev_at(const Bufs& b, const Geo& g, int which, int t, int w) { return b.lev[(size_t(which) * g.ngrid + t) * b.W + w]; }
 TS_HD double& amp_at(const Bufs& b, const Geo& g, int col, int boundary, int w) { return b.colv[(size_t(col) * (2 * g.nlyr + 1) + boundary) * b.W + w]; }
 TS_HD double& rate_at(const Bufs& b, const Geo& g, int col, int l, int w) { return b.colv[(size_t(col) * (2 * g.nlyr + 1) + g.nlyr + 1 + l) * b.W + w]; }
-enum { LU_C = 0, LU_ALPHA, LU_BETA, LU_GAMMA, LU_E, LU_IMU };
+enum { LU_C = 0, LU_ALPHA, LU_BETA, LU_GAMMA, LU_IMU };
 TS_HD double& lu_at(const Bufs& b, const Geo& g, int naz, int col, int az, int which, int row, int w) {
-    return b.lu[(((size_t(col) * naz + az) * 6 + which) * (2 * g.nlyr) + row) * b.W + w];
+    return b.lu[(((size_t(col) * naz + az) * 5 + which) * (2 * g.nlyr) + row) * b.W + w];
 }
 TS_HD double& lam_at(const Bufs& b, const Geo& g, int naz, int view, int col, int az, int row, int w) {
     return b.lam[(((size_t(view) * g.ncol + col) * naz + az) * (2 * g.nlyr) + row) * b.W + w];
@@ -384,7 +386,11 @@ TS_HD LevelIn load_level(const Geo& g, const Bufs& b, size_t gw, int t) {
 // solve: layer optics, source amplitudes and the LU sweep of the boundary-value problem of every column
 // `lds`: n values per thread (layer optical depths), element i of this thread at lds[i * ls]
 // ---------------------------------------------------------------------------------------------------------------------------
-template <bool SOLAR> TS_HD void solve_thread(const Geo& g, const Bufs& b, int w, double* lds, int ls) {
+// FUSED (plane-parallel geometry with ONE line of sight): the back substitution is left to the upward pass (view_adjoint_thread /
+// fused_radiance_thread with FUSED) and, with weighting functions, the rows of dF/dc of that line of sight are formed here, top-down, and
+// taken through the forward half of the transposed solve as the LU sweep produces its rows -- the solution c, alpha and beta are then
+// never read by a later kernel.
+template <bool SOLAR, bool FUSED = false> TS_HD void solve_thread(const Geo& g, const Bufs& b, int w, double* lds, int ls) {
     const int n = g.nlyr, naz = naz_of(SOLAR), N = 2 * n;
     const size_t gw = size_t(b.w0) + w;
     const double mu = g.mu;
@@ -394,8 +400,17 @@ template <bool SOLAR> TS_HD void solve_thread(const Geo& g, const Bufs& b, int w
 
     // layer optics (prepare_explicit_column, :1926-1955)
     LevelIn top = load_level(g, b, gw, 0);
+    auto keep_level = [&](int t, const LevelIn& v) {
+        if (!b.derivs) return;
+        lev_at(b, g, 0, t, w) = v.ext;
+        lev_at(b, g, 1, t, w) = v.ssa;
+        lev_at(b, g, 2, t, w) = v.b1;
+        if (!SOLAR) lev_at(b, g, 3, t, w) = v.em;
+    };
+    keep_level(0, top);
     for (int l = 0; l < n; ++l) {
         const LevelIn bot = load_level(g, b, gw, l + 1);
+        keep_level(l + 1, bot);
         const double scat_top = top.ext * top.ssa, scat_bot = bot.ext * bot.ssa;
         const double mean_ext = 0.5 * (top.ext + bot.ext), mean_scat = 0.5 * (scat_top + scat_bot);
         const double od = mean_ext * g.thickness[l];
@@ -434,9 +449,13 @@ template <bool SOLAR> TS_HD void solve_thread(const Geo& g, const Bufs& b, int w
             }
         }
         const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
+        const bool rows = FUSED && b.derivs;
+        const double vc = FUSED ? g.view_cos[0] : 1.0, vinv = 1.0 / vc;
         for (int az = 0; az < naz; ++az) {
             // rows of the five-diagonal system layer by layer, eliminated as they appear (:1976-2028, :1861-1888)
             const double delta = az == 0 ? 1.0 : 0.0;
+            const double azw = FUSED ? (az == 0 ? 1.0 : cos(g.view_azimuth[0])) : 0.0;
+            double attenuation = 1.0, path_od = 0.0, ym1 = 0.0, ym2 = 0.0, pend = 0.0;   // FUSED: y of rows i - 1, i - 2; dF/dc of row 2l - 1
             double a1 = 0, a2 = 0, b1r = 0, b2r = 0, z1 = 0, z2 = 0;   // alpha, beta, z of rows i - 1 and i - 2
             double pxp = 0, pxm = 0, pom = 0, pgpb = 0, pgmb = 0;      // previous layer
             int row = 0;
@@ -449,9 +468,8 @@ template <bool SOLAR> TS_HD void solve_thread(const Geo& g, const Bufs& b, int w
                 lu_at(b, g, naz, col, az, LU_C, row, w) = z;
                 lu_at(b, g, naz, col, az, LU_ALPHA, row, w) = alpha;
                 lu_at(b, g, naz, col, az, LU_BETA, row, w) = beta;
-                if (b.derivs) {
+                if (b.derivs) {   // (the second sub-diagonal e is xp omega of a layer: the adjoint recomputes it)
                     lu_at(b, g, naz, col, az, LU_GAMMA, row, w) = gamma;
-                    lu_at(b, g, naz, col, az, LU_E, row, w) = e;
                     lu_at(b, g, naz, col, az, LU_IMU, row, w) = imu;
                 }
                 a2 = a1; a1 = alpha; b2r = b1r; b1r = beta; z2 = z1; z1 = z;
@@ -465,6 +483,15 @@ template <bool SOLAR> TS_HD void solve_thread(const Geo& g, const Bufs& b, int w
                 if (l + 1 < n) next = fetch(l + 1);
                 const LayerSol<double> h = layer_solution<double, SOLAR>(az, p, mu, csz, angular);
                 const Boundary<double> q = boundary_particular(p, h);
+                double beta_two_back = 0.0;
+                if (rows && l > 0) {
+                    // U^T y = dF/dc: row 2l - 1 needs alpha of row 2l - 2 and beta of row 2l - 3, the last rows eliminated so far
+                    const double y = pend - a1 * ym1 - b2r * ym2;
+                    lam_at(b, g, naz, 0, 0, az, 2 * l - 1, w) = y;
+                    ym2 = ym1;
+                    ym1 = y;
+                    beta_two_back = b1r;   // beta of row 2l - 2
+                }
                 if (l == 0) {
                     eliminate(0.0, 0.0, h.xp, h.xm * h.omega, 0.0, -q.gpt);
                 } else {
@@ -472,10 +499,40 @@ template <bool SOLAR> TS_HD void solve_thread(const Geo& g, const Bufs& b, int w
                     eliminate(pxp * pom, pxm, -h.xp, -h.xm * h.omega, 0.0, q.gpt - pgpb);
                 }
                 pxp = h.xp; pxm = h.xm; pom = h.omega; pgpb = q.gpb; pgmb = q.gmb;
+                if (FUSED) {
+                    const double beam = exp(-p.od * vinv);
+                    if (rows) {
+                        // dF/dc of the two amplitudes of this layer (explicit_plane_view, :2598-2640) and the surface term under the last layer
+                        const bool fast = plane_nonresonant(p.rate, h.k, p.od, vinv);
+                        const double source_integral = plane_source_integral(p, h.expo, beam, vc, fast);
+                        double U, V, P;
+                        plane_source_terms<double, SOLAR>(az, p, h, vc, mu, fast, beam, source_integral, U, V, P);
+                        double r0 = attenuation * azw * U, r1 = attenuation * azw * V;
+                        if (l == n - 1 && az == 0) {
+                            const double wsurf = attenuation * beam * (2.0 * mu) * albedo;
+                            r0 += wsurf * h.xp * h.omega;
+                            r1 += wsurf * h.xm;
+                        }
+                        // row 2l: alpha of row 2l - 1 (the row before the last one eliminated) and beta of row 2l - 2
+                        const double y = l == 0 ? r0 : r0 - a2 * ym1 - beta_two_back * ym2;
+                        lam_at(b, g, naz, 0, 0, az, 2 * l, w) = y;
+                        ym2 = ym1;
+                        ym1 = y;
+                        pend = r1;
+                    }
+                    path_od += p.od * vinv;
+                    attenuation *= beam;
+                }
+            }
+            if (rows) lam_at(b, g, naz, 0, 0, az, N - 1, w) = pend - a1 * ym1 - b2r * ym2;   // row 2n - 1: alpha of 2n - 2, beta of 2n - 3
+            if (FUSED && az == 0) {
+                vstate_at(b, g, 0, 0, w) = attenuation;   // weight of the surface term in the radiance
+                vstate_at(b, g, 0, 1, w) = path_od;
             }
             const double direct = SOLAR ? delta * csz * albedo / kPi * amp_at(b, g, col, n, w) : surface_emission;
             eliminate(0.0, (pxm - 2.0 * mu * albedo * delta * pxp) * pom, pxp - 2.0 * mu * albedo * delta * pxm, 0.0, 0.0,
                       direct - (pgmb - 2.0 * delta * mu * albedo * pgpb));
+            if (FUSED) continue;   // the upward pass substitutes back as it goes
             // back substitution (:1889-1898)
             // (four rows per round trip: the loads of a block are issued together, ahead of the stores of the block before)
             double x1 = 0, x2 = 0;
@@ -728,6 +785,49 @@ template <bool SOLAR, bool DERIVS, bool SPHERICAL> TS_HD void view_forward_threa
     }
 }
 
+// radiance of the single plane-parallel line of sight after solve_thread<.., FUSED> when no weighting functions are asked for: back
+// substitution and layer sources on the way up
+template <bool SOLAR> TS_HD void fused_radiance_thread(const Geo& g, const Bufs& b, int w) {
+    constexpr int NAZ = SOLAR ? 2 : 1;
+    const int n = g.nlyr;
+    const size_t gw = size_t(b.w0) + w;
+    const double mu = g.mu, csz = g.csz[0], vc = g.view_cos[0], inv = 1.0 / vc;
+    const double albedo = b.albedo[gw];
+    const double surface_emission = (!SOLAR && b.surface_emission) ? b.surface_emission[gw] : 0.0;
+    const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
+    double radiance = 0.0;
+    for (int az = 0; az < NAZ; ++az) {
+        const double azw = az == 0 ? 1.0 : cos(g.view_azimuth[0]);
+        double tau_over_vc = vstate_at(b, g, 0, 1, w), cn0 = 0.0, cn1 = 0.0;
+        for (int l = n - 1; l >= 0; --l) {
+            const LayerP<double> p = load_p<SOLAR>(g, b, 0, l, w);
+            const double c1 = lu_at(b, g, NAZ, 0, az, LU_C, 2 * l + 1, w) - lu_at(b, g, NAZ, 0, az, LU_ALPHA, 2 * l + 1, w) * cn0 -
+                              lu_at(b, g, NAZ, 0, az, LU_BETA, 2 * l + 1, w) * cn1;
+            const double c0 = lu_at(b, g, NAZ, 0, az, LU_C, 2 * l, w) - lu_at(b, g, NAZ, 0, az, LU_ALPHA, 2 * l, w) * c1 -
+                              lu_at(b, g, NAZ, 0, az, LU_BETA, 2 * l, w) * cn0;
+            cn1 = c1;
+            cn0 = c0;
+            tau_over_vc -= p.od * inv;
+            const double attenuation = exp(-fmax(tau_over_vc, 0.0)), beam = exp(-p.od * inv);
+            const LayerSol<double> h = layer_solution<double, SOLAR>(az, p, mu, csz, angular);
+            const bool fast = plane_nonresonant(p.rate, h.k, p.od, inv);
+            const double source_integral = plane_source_integral(p, h.expo, beam, vc, fast);
+            double U, V, P;
+            plane_source_terms<double, SOLAR>(az, p, h, vc, mu, fast, beam, source_integral, U, V, P);
+            double source = azw * (c0 * U + c1 * V + P);
+            if (!SOLAR && az == 0) source += p.amp * source_integral * (1.0 - p.ssa);
+            radiance += attenuation * source;
+            if (l == n - 1 && az == 0) {
+                const Boundary<double> q = boundary_particular(p, h);
+                radiance += vstate_at(b, g, 0, 0, w) * (bottom_plus(h, q, c0, c1) * (2.0 * mu) * albedo + surface_emission);
+            }
+        }
+    }
+    double* dst = b.radiance + gw * g.nlos;
+    *dst = b.accumulate ? *dst + radiance : radiance;
+    if (b.los_od) b.los_od[gw * g.nlos] = vstate_at(b, g, 0, 1, w);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // hand-written reverse sweep of one (layer, azimuth order) of the Lagrangian.  The value differentiated is
 //   Tp top_plus + Tm top_minus + Bp bot_plus + Bm bot_minus + Ws (c0 U + c1 V + P [+ thermal emission term])
@@ -891,7 +991,10 @@ TS_HD void layer_adjoint(int az, const LayerP<double>& p, const LayerSol<double>
 // DUAL = false (the product): the hand-written reverse sweep of the layers (layer_adjoint); DUAL = true (tests only): the same Lagrangian
 // differentiated in dual numbers.
 // `lds`: n + 1 values per thread, element i of this thread at lds[i * ls]
-template <bool SOLAR, bool SPHERICAL, bool DUAL = false> TS_HD void view_adjoint_thread(const Geo& g, const Bufs& b, int w, int view, double* lds, int ls) {
+// FUSED (plane-parallel geometry with one line of sight, after solve_thread<.., FUSED>): the solution c is substituted back on the way up
+// instead of being read, and the radiance -- the same layer sources this sweep evaluates anyway -- is written here.
+template <bool SOLAR, bool SPHERICAL, bool DUAL = false, bool FUSED = false>
+TS_HD void view_adjoint_thread(const Geo& g, const Bufs& b, int w, int view, double* lds, int ls) {
     constexpr int NAZ = SOLAR ? 2 : 1;
     const int n = g.nlyr, N = 2 * n, ncol = SOLAR ? g.ncol : 1;
     const size_t gw = size_t(b.w0) + w;
@@ -903,7 +1006,7 @@ template <bool SOLAR, bool SPHERICAL, bool DUAL = false> TS_HD void view_adjoint
     const double vc = plane ? g.view_cos[view] : 1.0, inv = 1.0 / vc;
     const int ground_lo = (!plane && SOLAR) ? g.ground_col[2 * view] : 0, ground_up = (!plane && SOLAR) ? g.ground_col[2 * view + 1] : 0;
     const double ground_uw = (!plane && SOLAR) ? g.ground_colw[view] : 0.0;
-    double g_albedo = 0.0, g_surface_emission = 0.0;
+    double g_albedo = 0.0, g_surface_emission = 0.0, fused_radiance = 0.0;
 
     for (int col = 0; col < ncol; ++col) {
         const double csz = g.csz[col];
@@ -932,12 +1035,19 @@ template <bool SOLAR, bool SPHERICAL, bool DUAL = false> TS_HD void view_adjoint
             struct Fetch {
                 LayerP<double> p;
                 double c0, c1, y_plus, y_minus, gamma_plus, gamma_minus, imu_plus, imu_minus;
+                double al0, be0, al1, be1;   // FUSED: c0 / c1 hold z of the rows 2l, 2l + 1, these their alpha and beta
             };
             auto fetch = [&](int l) {
                 Fetch f;
                 f.p = load_p<SOLAR>(g, b, col, l, w);
                 f.c0 = lu_at(b, g, NAZ, col, az, LU_C, 2 * l, w);
                 f.c1 = lu_at(b, g, NAZ, col, az, LU_C, 2 * l + 1, w);
+                if (FUSED) {
+                    f.al0 = lu_at(b, g, NAZ, col, az, LU_ALPHA, 2 * l, w);
+                    f.be0 = lu_at(b, g, NAZ, col, az, LU_BETA, 2 * l, w);
+                    f.al1 = lu_at(b, g, NAZ, col, az, LU_ALPHA, 2 * l + 1, w);
+                    f.be1 = lu_at(b, g, NAZ, col, az, LU_BETA, 2 * l + 1, w);
+                }
                 f.y_plus = lam_at(b, g, NAZ, view, col, az, 2 * l, w);
                 f.gamma_plus = lu_at(b, g, NAZ, col, az, LU_GAMMA, 2 * l + 1, w);
                 f.imu_plus = lu_at(b, g, NAZ, col, az, LU_IMU, 2 * l, w);
@@ -948,6 +1058,7 @@ template <bool SOLAR, bool SPHERICAL, bool DUAL = false> TS_HD void view_adjoint
             };
             Fetch next = fetch(n - 1);
             xa = lam_at(b, g, NAZ, view, col, az, N - 1, w) * lu_at(b, g, NAZ, col, az, LU_IMU, N - 1, w);
+            double cn0 = 0.0, cn1 = 0.0;   // FUSED: c of rows 2l + 2, 2l + 3
             for (int l = n - 1; l >= 0; --l) {
                 const Fetch cur = next;
                 if (l > 0) next = fetch(l - 1);
@@ -959,7 +1070,13 @@ template <bool SOLAR, bool SPHERICAL, bool DUAL = false> TS_HD void view_adjoint
                 }
                 double G[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
                 const LayerSol<double> hv = layer_solution<double, SOLAR>(az, pv, mu, csz, angular);
-                const double c0 = cur.c0, c1 = cur.c1;
+                double c0 = cur.c0, c1 = cur.c1;
+                if (FUSED) {   // back substitution (:1889-1898)
+                    c1 = cur.c1 - cur.al1 * cn0 - cur.be1 * cn1;
+                    c0 = cur.c0 - cur.al0 * c1 - cur.be0 * cn0;
+                    cn1 = c1;
+                    cn0 = c0;
+                }
                 // lambda of the rows above this layer: L^T lambda = y backwards (pentadiagonal_transpose_solve, :1911-1920); the
                 // second sub-diagonal of row 2l + 2 is xp omega of this layer (:2008)
                 const double e_below = l < n - 1 ? hv.xp * hv.omega : 0.0;
@@ -1052,6 +1169,7 @@ template <bool SOLAR, bool SPHERICAL, bool DUAL = false> TS_HD void view_adjoint
                     gsum_at(b, g, view, 2, l, w) += g_b1;
                 }
             }
+            if (FUSED) fused_radiance += below;   // surface term and every layer source of this azimuth order, attenuated to the top
         }
         if (SOLAR) {
             // attenuation exponents are minus the Chapman-weighted optical depths above the boundary
@@ -1067,15 +1185,21 @@ template <bool SOLAR, bool SPHERICAL, bool DUAL = false> TS_HD void view_adjoint
         }
     }
 
+    if (FUSED) {
+        double* dst = b.radiance + gw * g.nlos + view;
+        *dst = b.accumulate ? *dst + fused_radiance : fused_radiance;
+        if (b.los_od) b.los_od[gw * g.nlos + view] = vstate_at(b, g, view, 1, w);
+    }
     // ---- from the layers to the level profiles (map_explicit_to_levels, :2889-2919) and out
     double carry_ext = 0.0, carry_ssa = 0.0, carry_b1 = 0.0, carry_em = 0.0;
-    LevelIn top = load_level(g, b, gw, 0);
+    auto level = [&](int t) { return LevelIn{lev_at(b, g, 0, t, w), lev_at(b, g, 1, t, w), lev_at(b, g, 2, t, w), SOLAR ? 0.0 : lev_at(b, g, 3, t, w)}; };
+    LevelIn top = level(0);
     for (int t = 0; t <= n; ++t) {
         double o_ext = carry_ext, o_ssa = carry_ssa, o_b1 = carry_b1, o_em = carry_em;
         carry_ext = carry_ssa = carry_b1 = carry_em = 0.0;
         if (t < n) {
             const int l = t;
-            const LevelIn bot = load_level(g, b, gw, l + 1);
+            const LevelIn bot = level(l + 1);
             const double od = lay_at(b, g, 0, l, w), ssa = lay_at(b, g, 1, l, w), b1 = lay_at(b, g, 2, l, w);
             double g_od = gsum_at(b, g, view, 0, l, w);
             const double g_ssa = ssa >= kSsaCap ? 0.0 : gsum_at(b, g, view, 1, l, w), g_b1 = gsum_at(b, g, view, 2, l, w);
@@ -1130,19 +1254,20 @@ template <bool SOLAR, bool SPHERICAL, bool DUAL = false> TS_HD void view_adjoint
 // scratch sizes in doubles for W lanes (shared by the HIP driver and the CPU emulation of the tests)
 // ---------------------------------------------------------------------------------------------------------------------------
 struct ScratchSizes {
-    size_t lay, colv, lu, lam, g5, gsum, vstate, path, glev;
-    size_t total() const { return lay + colv + lu + lam + g5 + gsum + vstate + path + glev; }
+    size_t lay, lev, colv, lu, lam, g5, gsum, vstate, path, glev;
+    size_t total() const { return lay + lev + colv + lu + lam + g5 + gsum + vstate + path + glev; }
 };
 inline ScratchSizes scratch_sizes(int nlyr, int ngrid, int nlos, int ncol, int max_seg, bool spherical, bool derivs, size_t W) {
     ScratchSizes z{};
     const size_t n = size_t(nlyr);
     z.lay = 3 * n * W;
     z.colv = size_t(ncol) * (2 * n + 1) * W;
-    z.lu = size_t(ncol) * 2 * 6 * (2 * n) * W;
+    z.lu = size_t(ncol) * 2 * 5 * (2 * n) * W;
+    z.vstate = size_t(nlos) * 2 * W;
     if (derivs) {
+        z.lev = 4 * size_t(ngrid) * W;
         z.lam = size_t(nlos) * ncol * 2 * (2 * n) * W;
         z.gsum = size_t(nlos) * 5 * n * W;
-        z.vstate = size_t(nlos) * 2 * W;
         if (spherical) {
             z.g5 = size_t(nlos) * ncol * n * 5 * W;
             z.path = size_t(nlos) * 3 * size_t(max_seg) * W;

@@ -35,11 +35,21 @@ constexpr int kWave = 64;
 #define TS_ADJOINT_WAVES 2
 #endif
 
-template <bool SOLAR> __global__ void __launch_bounds__(kWave) k_ts_solve(const skt::Geo g, const skt::Bufs b) {
+template <bool SOLAR, bool FUSED> __global__ void __launch_bounds__(kWave) k_ts_solve(const skt::Geo g, const skt::Bufs b) {
     extern __shared__ double lds[];
     const int w = blockIdx.x * kWave + threadIdx.x;
     if (w >= b.nw) return;
-    skt::solve_thread<SOLAR>(g, b, w, lds + threadIdx.x, kWave);
+    skt::solve_thread<SOLAR, FUSED>(g, b, w, lds + threadIdx.x, kWave);
+}
+// plane-parallel geometry with one line of sight: the upward pass after k_ts_solve<.., true> (back substitution, layer sources, radiance
+// and -- DERIVS -- the adjoint sweep)
+template <bool SOLAR, bool DERIVS> __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(TS_ADJOINT_WAVES)))
+k_ts_up(const skt::Geo g, const skt::Bufs b) {
+    extern __shared__ double lds[];
+    const int w = blockIdx.x * kWave + threadIdx.x;
+    if (w >= b.nw) return;
+    if (DERIVS) skt::view_adjoint_thread<SOLAR, false, false, true>(g, b, w, 0, lds + threadIdx.x, kWave);
+    else skt::fused_radiance_thread<SOLAR>(g, b, w);
 }
 template <bool SOLAR, bool DERIVS, bool SPHERICAL> __global__ void __launch_bounds__(kWave) k_ts_view(const skt::Geo g, const skt::Bufs b) {
     const int w = blockIdx.x * kWave + threadIdx.x;
@@ -233,6 +243,7 @@ void TsDeviceEngine::solve_device(int nwavel, const Inputs& in, const Outputs& o
         I.capacity = std::max(chunk, I.capacity);
         const skt::ScratchSizes z = skt::scratch_sizes(g.nlyr, g.ngrid, g.nlos, g.ncol, g.max_seg, g.spherical != 0, I.cap_derivs, size_t(I.capacity));
         I.b.lay = I.scratch.alloc<double>(z.lay);
+        I.b.lev = I.scratch.alloc<double>(z.lev);
         I.b.colv = I.scratch.alloc<double>(z.colv);
         I.b.lu = I.scratch.alloc<double>(z.lu);
         I.b.lam = I.scratch.alloc<double>(z.lam);
@@ -264,10 +275,32 @@ void TsDeviceEngine::solve_device(int nwavel, const Inputs& in, const Outputs& o
         for (int solar = 1; solar >= 0; --solar) {
             if (solar ? !I.cfg.solar : !I.cfg.thermal) continue;
             b.accumulate = (out.accumulate || pass > 0) ? 1 : 0;
+            // plane-parallel geometry with one line of sight: two fused passes instead of three kernels (ts_core.hpp, solve_thread FUSED)
+            const bool fused = !g.spherical && g.nlos == 1 && !std::getenv("SASKTRAN2_AMD_TS_UNFUSED");
+            if (fused) {
+                {
+                    TsTimer t(I, st, solar ? "ts_solve" : "ts_solve_thermal");
+                    if (solar) hipLaunchKernelGGL((k_ts_solve<true, true>), grid_w, dim3(kWave), lds_bytes, st, g, b);
+                    else hipLaunchKernelGGL((k_ts_solve<false, true>), grid_w, dim3(kWave), lds_bytes, st, g, b);
+                }
+                {
+                    TsTimer t(I, st, solar ? "ts_up" : "ts_up_thermal");
+                    if (solar) {
+                        if (derivs) hipLaunchKernelGGL((k_ts_up<true, true>), grid_w, dim3(kWave), lds_bytes, st, g, b);
+                        else hipLaunchKernelGGL((k_ts_up<true, false>), grid_w, dim3(kWave), lds_bytes, st, g, b);
+                    } else {
+                        if (derivs) hipLaunchKernelGGL((k_ts_up<false, true>), grid_w, dim3(kWave), lds_bytes, st, g, b);
+                        else hipLaunchKernelGGL((k_ts_up<false, false>), grid_w, dim3(kWave), lds_bytes, st, g, b);
+                    }
+                }
+                TS_HIP_CHECK(hipGetLastError());
+                ++pass;
+                continue;
+            }
             {
                 TsTimer t(I, st, solar ? "ts_solve" : "ts_solve_thermal");
-                if (solar) hipLaunchKernelGGL(k_ts_solve<true>, grid_w, dim3(kWave), lds_bytes, st, g, b);
-                else hipLaunchKernelGGL(k_ts_solve<false>, grid_w, dim3(kWave), lds_bytes, st, g, b);
+                if (solar) hipLaunchKernelGGL((k_ts_solve<true, false>), grid_w, dim3(kWave), lds_bytes, st, g, b);
+                else hipLaunchKernelGGL((k_ts_solve<false, false>), grid_w, dim3(kWave), lds_bytes, st, g, b);
             }
             {
                 TsTimer t(I, st, solar ? "ts_view" : "ts_view_thermal");

@@ -50,7 +50,7 @@ void emts_destroy(void* h) { delete static_cast<Handle*>(h); }
 // radiance [nwavel][nlos]; wf_ext / wf_ssa / wf_b1 / wf_em [ngrid][nwavel][nlos]; wf_alb / wf_sem [nwavel][nlos] (all or none)
 int emts_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg, const double* delta_f,
              const double* emission, const double* surface_emission, const double* solar_irradiance, const double* albedo,
-             double* radiance, double* wf_ext, double* wf_ssa, double* wf_b1, double* wf_em, double* wf_alb, double* wf_sem, int dual_adjoint) {
+             double* radiance, double* wf_ext, double* wf_ssa, double* wf_b1, double* wf_em, double* wf_alb, double* wf_sem, int dual_adjoint, int allow_fused) {
     // dual_adjoint 0: as the HIP driver (hand-written reverse sweep of the layers); 1: the same Lagrangian differentiated in dual numbers
     auto* h = static_cast<Handle*>(hv);
     if (!h) return -1;
@@ -73,8 +73,8 @@ int emts_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     b.emission = emission; b.surface_emission = surface_emission;
     b.radiance = radiance; b.wf_ext = wf_ext; b.wf_ssa = wf_ssa; b.wf_b1 = wf_b1; b.wf_alb = wf_alb; b.wf_em = wf_em; b.wf_sem = wf_sem;
     const skt::ScratchSizes z = skt::scratch_sizes(g.nlyr, g.ngrid, g.nlos, g.ncol, g.max_seg, g.spherical != 0, derivs, size_t(b.W));
-    std::vector<double> lay(z.lay), colv(z.colv), lu(z.lu), lam(z.lam), g5(z.g5), gsum(z.gsum), vstate(z.vstate), path(z.path), glev(z.glev);
-    b.lay = lay.data(); b.colv = colv.data(); b.lu = lu.data(); b.lam = lam.data(); b.g5 = g5.data(); b.gsum = gsum.data();
+    std::vector<double> lay(z.lay), lev(z.lev), colv(z.colv), lu(z.lu), lam(z.lam), g5(z.g5), gsum(z.gsum), vstate(z.vstate), path(z.path), glev(z.glev);
+    b.lay = lay.data(); b.lev = lev.data(); b.colv = colv.data(); b.lu = lu.data(); b.lam = lam.data(); b.g5 = g5.data(); b.gsum = gsum.data();
     b.path = path.data(); b.glev = glev.data(); b.vstate = vstate.data();
     std::vector<double> lds(size_t(g.nlyr) + 1);
     int pass = 0;
@@ -82,6 +82,25 @@ int emts_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
         if (solar ? !tg.cfg.solar : !tg.cfg.thermal) continue;
         if (!solar && !emission) return -2;
         b.accumulate = pass > 0 ? 1 : 0;
+        // plane-parallel geometry with one line of sight: the two fused passes of the HIP driver
+        const bool fused = allow_fused && !g.spherical && g.nlos == 1 && !dual_adjoint;
+        if (fused) {
+            for (int w = 0; w < nwavel; ++w) {
+                if (solar) skt::solve_thread<true, true>(g, b, w, lds.data(), 1);
+                else skt::solve_thread<false, true>(g, b, w, lds.data(), 1);
+            }
+            for (int w = 0; w < nwavel; ++w) {
+                if (derivs) {
+                    if (solar) skt::view_adjoint_thread<true, false, false, true>(g, b, w, 0, lds.data(), 1);
+                    else skt::view_adjoint_thread<false, false, false, true>(g, b, w, 0, lds.data(), 1);
+                } else {
+                    if (solar) skt::fused_radiance_thread<true>(g, b, w);
+                    else skt::fused_radiance_thread<false>(g, b, w);
+                }
+            }
+            ++pass;
+            continue;
+        }
         for (int w = 0; w < nwavel; ++w) {
             if (solar) skt::solve_thread<true>(g, b, w, lds.data(), 1);
             else skt::solve_thread<false>(g, b, w, lds.data(), 1);

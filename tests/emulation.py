@@ -160,12 +160,12 @@ def lib_ts():
         L.emts_create.argtypes = [ctypes.c_double] * 3 + [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp] + [ctypes.c_int] * 3
         L.emts_destroy.argtypes = [ctypes.c_void_p]
         L.emts_run.restype = ctypes.c_int
-        L.emts_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [_dp] * 15 + [ctypes.c_int]
+        L.emts_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [_dp] * 15 + [ctypes.c_int, ctypes.c_int]
         _LIB_TS = L
     return _LIB_TS
 
 
-def run_emulated_twostream(s, derivatives=True, solar=True, thermal=False, dual_adjoint=False):
+def run_emulated_twostream(s, derivatives=True, solar=True, thermal=False, dual_adjoint=False, allow_fused=True):
     """The two-stream kernels on the CPU.  Returns the oracle's output names and layouts: radiance [nw, nlos], d_extinction / d_ssa /
     d_b1 / d_emission [nw, nlos, ngrid], d_albedo / d_surface_emission [nw, nlos]."""
     g = s["geometry"]
@@ -190,7 +190,7 @@ def run_emulated_twostream(s, derivatives=True, solar=True, thermal=False, dual_
         wf = [None] * 6
         if derivatives:
             wf = [np.zeros((ngrid, nw, nlos)) for _ in range(4)] + [np.zeros((nw, nlos)) for _ in range(2)]
-        rc = L.emts_run(h, nw, lg.shape[0], _p(k), _p(w), _p(lg), _p(df), _p(em), _p(sem), _p(irr), _p(alb), _p(rad), *[_p(a) for a in wf], int(dual_adjoint))
+        rc = L.emts_run(h, nw, lg.shape[0], _p(k), _p(w), _p(lg), _p(df), _p(em), _p(sem), _p(irr), _p(alb), _p(rad), *[_p(a) for a in wf], int(dual_adjoint), int(allow_fused))
         assert rc == 0, rc
         out = {"radiance": rad}
         if derivatives:

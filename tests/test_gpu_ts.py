@@ -112,6 +112,22 @@ def test_reference_benchmark_configuration():
     assert np.max(np.abs(out["d_ssa"])) <= 1e-12 * np.max(np.abs(out["d_extinction"]))   # conservative scattering: capped, no ssa derivative
 
 
+@pytest.mark.parametrize("sources", ["solar", "thermal", "both"])
+def test_single_line_of_sight_fused_passes(sources, monkeypatch):
+    # plane-parallel geometry with one line of sight takes two fused passes instead of three kernels: the oracle's numbers either way
+    from tests.gpu_harness import run_product_ts
+    s = varied(sc.twostream_reference_case(spherical=False, thermal=sources != "solar"))
+    s["rays"] = s["rays"][:1]
+    solar, thermal = sources != "thermal", sources != "solar"
+    ref = run_ts(s, ts_oracle(s, solar=solar, thermal=thermal), derivatives=True)
+    fused = run_product_ts(s, solar=solar, thermal=thermal)
+    compare(fused, ref)
+    fwd = run_product_ts(s, solar=solar, thermal=thermal, derivatives=False)
+    np.testing.assert_allclose(fwd["radiance"], ref["radiance"], rtol=RTOL_I)
+    monkeypatch.setenv("SASKTRAN2_AMD_TS_UNFUSED", "1")
+    compare(run_product_ts(s, solar=solar, thermal=thermal), ref)
+
+
 def test_resonances_on_device():
     from tests.gpu_harness import run_product_ts
     solar, thermal = resonance_cases()

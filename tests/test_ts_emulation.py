@@ -74,3 +74,20 @@ def test_conservative_scattering_and_empty_upper_levels():
     s["extinction"] = k
     out = compare(s, rtol=1e-7)
     assert np.max(np.abs(out["d_ssa"])) < 1e-15
+
+
+@pytest.mark.parametrize("sources", ["solar", "thermal", "both"])
+def test_single_line_of_sight_fused_passes(sources):
+    # plane-parallel geometry with one line of sight takes the two fused passes (LU sweep + dF/dc rows down, back substitution + sources +
+    # adjoint up): same numbers as the three-kernel path and as the oracle
+    s = sc.twostream_reference_case(spherical=False, thermal=sources != "solar")
+    s["rays"] = s["rays"][:1]
+    s["ssa"] = s["ssa"] + 0.002 * np.arange(13)[:, None]
+    s["leg"][1] += 0.01 * np.arange(13)[:, None]
+    solar, thermal = sources != "thermal", sources != "solar"
+    fused = compare(s, solar=solar, thermal=thermal)
+    plain = run_emulated_twostream(s, derivatives=True, solar=solar, thermal=thermal, allow_fused=False)
+    for name in fused:
+        np.testing.assert_allclose(fused[name], plain[name], rtol=1e-9, atol=1e-12 * np.max(np.abs(plain[name])), err_msg=name)
+    fwd = run_emulated_twostream(s, derivatives=False, solar=solar, thermal=thermal)
+    np.testing.assert_allclose(fwd["radiance"], plain["radiance"], rtol=1e-12)
