@@ -208,3 +208,33 @@ def test_refusals():
     pp["rays"] = [(sc.VIEWING_UP_SOLAR, 0.6, 0.0, 0.0, 0.5)]
     with pytest.raises(Exception):
         build_ts_engine(pp)
+
+
+def test_jvp_and_vjp_with_the_two_stream_source():
+    # sk_engine_calculate_jvp / _vjp (contractions of the Jacobian) with multiple_scatter_source = twostream
+    import sasktran2_amd as sk
+    from tests.gpu_harness import build_ts_engine
+    s = varied(sc.twostream_reference_case(spherical=True, num_wavelengths=3))
+    engine, config, geometry = build_ts_engine(s)
+    atmosphere = sk.Atmosphere(geometry, config, numwavel=3, calculate_derivatives=True)
+    atmosphere.storage.total_extinction[:] = s["extinction"]
+    atmosphere.storage.ssa[:] = s["ssa"]
+    atmosphere.leg_coeff.a1[:] = s["leg"]
+    atmosphere.surface.albedo[:] = s["albedo"]
+    atmosphere.storage.solar_irradiance[:] = s["solar_irradiance"]
+    full = engine.calculate_radiance(atmosphere, as_dataset=False)
+    rng = np.random.default_rng(11)
+    ngrid = s["extinction"].shape[0]
+    t_k, t_w, t_a = rng.standard_normal(ngrid) * 1e-6, rng.standard_normal(ngrid) * 1e-2, rng.standard_normal(3) * 0.1
+    rad, jvp = engine.calculate_jvp(atmosphere, {"wf_extinction": t_k, "wf_ssa": t_w}, {"wf_albedo": t_a})
+    want = np.einsum("qwls,q->wls", full["wf_extinction"], t_k) + np.einsum("qwls,q->wls", full["wf_ssa"], t_w) + full["wf_albedo"] * t_a[:, None, None]
+    np.testing.assert_array_equal(rad, full["radiance"])
+    np.testing.assert_allclose(jvp, want, rtol=1e-12, atol=1e-300)
+    cot = rng.standard_normal(full["radiance"].shape)
+    rad2, grads = engine.calculate_vjp(atmosphere, cot)
+    np.testing.assert_array_equal(rad2, full["radiance"])
+    np.testing.assert_allclose(grads["wf_extinction"], np.einsum("qwls,wls->q", full["wf_extinction"], cot), rtol=1e-12)
+    np.testing.assert_allclose(grads["wf_albedo"], np.einsum("wls,wls->w", full["wf_albedo"], cot), rtol=1e-12)
+    lhs = float(np.sum(cot * jvp))
+    rhs = float(grads["wf_extinction"] @ t_k + grads["wf_ssa"] @ t_w + grads["wf_albedo"] @ t_a)
+    assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs))
