@@ -238,3 +238,38 @@ def test_jvp_and_vjp_with_the_two_stream_source():
     lhs = float(np.sum(cot * jvp))
     rhs = float(grads["wf_extinction"] @ t_k + grads["wf_ssa"] @ t_w + grads["wf_albedo"] @ t_a)
     assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs))
+
+
+def test_pseudo_spherical_matches_two_stream_discrete_ordinates():
+    # pseudo-spherical geometry: plane-parallel diffuse field, beam attenuated along its true path (ray-traced Chapman factors): the same
+    # equality with two-stream discrete ordinates as in plane-parallel geometry (oracle and device)
+    from oracle.oracle_py import OracleEngine
+    from tests.gpu_harness import run_product_ts
+    s = varied(sc.twostream_reference_case(spherical=False))
+    s["geometry"] = dict(s["geometry"], geotype=sc.GEO_PSEUDOSPHERICAL)
+    g = s["geometry"]
+    do = OracleEngine(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"], g["interp_method"], g["geotype"], 2, 1, s["rays"], ss_in_do=False)
+    ref_do = do.run(s["extinction"], s["ssa"], s["leg"], s["albedo"], solar_irradiance=s["solar_irradiance"], derivatives=True)
+    ref = run_ts(s, ts_oracle(s), derivatives=True)
+    np.testing.assert_allclose(ref["radiance"], ref_do["radiance"], rtol=2e-8)
+    for k in ("d_extinction", "d_ssa"):
+        np.testing.assert_allclose(ref[k], ref_do[k], rtol=2e-8, atol=2e-12, err_msg=k)
+    compare(run_product_ts(s), ref)
+
+
+def test_device_entry_point_refuses_bad_arguments():
+    import ctypes
+    from sasktran2_amd._lib_loader import last_error, lib
+    from tests.gpu_harness import build_ts_engine
+    s = sc.twostream_reference_case(spherical=False, thermal=True)
+    engine, _, _ = build_ts_engine(s, solar=True, thermal=True)
+    n = [None] * 17
+    rc = lib().sk_amd_ts_engine_solve_device(engine._h, 9, 2, *n, None, 0)
+    assert rc == -3 and "null device pointer" in last_error()
+    rc = lib().sk_amd_ts_engine_solve_device(engine._h, 0, 2, *n, None, 0)
+    assert rc == -3 and "nwavel" in last_error()
+    # a discrete-ordinates engine has no two-stream source
+    from tests.gpu_harness import build_engine
+    do_engine, _, _ = build_engine(sc.regression_1d())
+    rc = lib().sk_amd_ts_engine_solve_device(do_engine._h, 9, 2, *n, None, 0)
+    assert rc == -3 and "no two-stream source" in last_error()
