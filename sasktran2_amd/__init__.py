@@ -86,7 +86,7 @@ class Config:
         object.__setattr__(self, "_h", lib().sk_config_create())
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and callable(lib):   # (at interpreter shutdown the module globals may be gone already)
             lib().sk_config_destroy(self._h)
 
     def __getattr__(self, name):
@@ -117,7 +117,7 @@ class Geometry1D:
             raise ValueError("invalid Geometry1D")
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and callable(lib):   # (at interpreter shutdown the module globals may be gone already)
             lib().sk_geometry1d_destroy(self._h)
 
     def altitudes(self):
@@ -157,7 +157,7 @@ class ViewingGeometry:
         self._rays = []
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and callable(lib):   # (at interpreter shutdown the module globals may be gone already)
             lib().sk_viewing_geometry_destroy(self._h)
 
     def add_ray(self, ray):
@@ -269,7 +269,7 @@ class Atmosphere:
 
     def __del__(self):
         H = getattr(self, "_H", None)
-        if H is not None:
+        if H is not None and callable(lib):   # (at interpreter shutdown the module globals may be gone already)
             L = lib()
             L.sk_atmosphere_destroy(H["atmosphere"])
             L.sk_surface_destroy(H["surface"])
@@ -292,7 +292,7 @@ class Engine:
         self.nlos = len(viewing_geo.observer_rays)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and callable(lib):   # (at interpreter shutdown the module globals may be gone already)
             lib().sk_engine_destroy(self._h)
 
     def _prepare(self, atmosphere, derivs):
