@@ -276,3 +276,51 @@ def test_device_entry_point_refuses_bad_arguments():
     do_engine, _, _ = build_engine(sc.regression_1d())
     rc = lib().sk_amd_ts_engine_solve_device(do_engine._h, 9, 2, *n, 0)
     assert rc == -3 and "no two-stream source" in last_error()
+
+
+def test_full_size_twostream_properties():
+    """The benchmark workload at its full size (220 000 wavelengths, bench_ts.scenario) through properties that do not need the oracle at
+    that size: a sub-range of the spectrum solved alone is bit-identical to the same wavelengths inside the full run (blocks are independent
+    whatever the launch shape), radiance and weighting functions are exactly linear in the solar irradiance, every output is finite, and an
+    evenly spaced sample agrees with the oracle."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    code = "import torch; torch.cuda.init(); from tests.test_gpu_ts import full_size_check; full_size_check()"
+    r = subprocess.run([sys.executable, "-c", code], cwd=Path(__file__).resolve().parents[1], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def full_size_check():
+    import torch
+    from bench_ts import scenario
+    from sasktran2_amd.device import TsDeviceSolver
+    from tests.gpu_harness import build_ts_engine
+    NW = 220_000
+    s = scenario(NW)
+    engine, _, _ = build_ts_engine(s)
+    solver = TsDeviceSolver(engine)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    ext, ssa = to(s["extinction"].T), to(s["ssa"].T)
+    leg, alb = to(np.transpose(s["leg"], (2, 1, 0))), to(s["albedo"])
+    irr = torch.ones(NW, dtype=torch.float64, device="cuda")
+    full = solver.solve(ext, ssa, leg, alb, solver.allocate_outputs(NW), irradiance=irr)
+    torch.cuda.synchronize()
+    for v in full.values():
+        assert bool(torch.isfinite(v).all())
+    lo, hi = 70_001, 83_456   # not aligned to a wavefront
+    part = solver.solve(ext[lo:hi].contiguous(), ssa[lo:hi].contiguous(), leg[lo:hi].contiguous(), alb[lo:hi].contiguous(),
+                        solver.allocate_outputs(hi - lo), irradiance=irr[lo:hi].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(part["radiance"], full["radiance"][lo:hi])
+    for k in ("wf_extinction", "wf_ssa", "wf_b1"):
+        assert torch.equal(part[k], full[k][:, lo:hi]), k
+    assert torch.equal(part["wf_albedo"], full["wf_albedo"][lo:hi])
+    double = solver.solve(ext, ssa, leg, alb, solver.allocate_outputs(NW), irradiance=2.0 * irr)
+    torch.cuda.synchronize()
+    assert torch.equal(double["radiance"], 2.0 * full["radiance"]) and torch.equal(double["wf_extinction"], 2.0 * full["wf_extinction"])
+    idx = np.linspace(0, NW - 1, 257).astype(int)
+    ref = ts_oracle(s).run(s["extinction"][:, idx], s["ssa"][:, idx], s["leg"][:, :, idx], s["albedo"][idx], derivatives=True)
+    np.testing.assert_allclose(full["radiance"].cpu().numpy()[idx], ref["radiance"], rtol=1e-9)
+    got = np.transpose(full["wf_extinction"].cpu().numpy()[:, idx], (1, 2, 0))
+    assert np.max(np.abs(got - ref["d_extinction"]) / np.max(np.abs(ref["d_extinction"]), axis=-1, keepdims=True)) < 1e-8
