@@ -40,7 +40,9 @@ constexpr double kSsaCap = 1.0 - 1.0e-9;         // clamp of the layer single-sc
 struct Geo {
     int nlyr, ngrid, nlos, ncol, spherical, max_seg;
     double mu;
-    const double *thickness, *csz, *chapman;         // [nlyr], [ncol], [ncol][nlyr][nlyr]
+    const double *thickness, *csz, *chapman;         // [nlyr], [ncol], [ncol][boundary][layer]
+    const double *chapman_t, *chap_uniform;          // [ncol][layer][boundary]; [ncol] the one factor of a plane-parallel column (layers above the
+                                                     // boundary), 0 for a ray-traced one
     const double *view_cos, *view_azimuth;           // plane parallel, [nlos]
     const int *ray_start, *ground_hit, *ground_col;  // spherical
     const double* ground_colw;
@@ -436,11 +438,23 @@ template <bool SOLAR, bool FUSED = false> TS_HD void solve_thread(const Geo& g, 
             amp_at(b, g, col, 0, w) = irradiance;
             double att_prev = 0.0;
             const double* chap = g.chapman + size_t(col) * n * n;
+            const double uniform = g.chap_uniform[col];
+            double column_od = 0.0;
             for (int bd = 0; bd < n; ++bd) {
                 double slant = 0.0;
-                for (int l = 0; l < n; ++l) {
-                    const double f = chap[size_t(bd) * n + l];
-                    if (f != 0.0) slant += lds[l * ls] * f;
+                if (uniform != 0.0) {
+                    // plane parallel: every layer above the boundary with the same factor (a running sum instead of the table row)
+                    column_od += lds[bd * ls];
+                    slant = column_od * uniform;
+                } else {
+                    // (zero factors contribute nothing: the row is used as it is, four entries per scalar load)
+                    int l = 0;
+                    for (; l + 4 <= n; l += 4) {
+                        const double f0 = chap[size_t(bd) * n + l], f1 = chap[size_t(bd) * n + l + 1], f2 = chap[size_t(bd) * n + l + 2],
+                                     f3 = chap[size_t(bd) * n + l + 3];
+                        slant += lds[l * ls] * f0 + lds[(l + 1) * ls] * f1 + lds[(l + 2) * ls] * f2 + lds[(l + 3) * ls] * f3;
+                    }
+                    for (; l < n; ++l) slant += lds[l * ls] * chap[size_t(bd) * n + l];
                 }
                 amp_at(b, g, col, bd + 1, w) = exp(-slant) * irradiance;
                 const double od = lds[bd * ls];
@@ -1173,12 +1187,23 @@ TS_HD void view_adjoint_thread(const Geo& g, const Bufs& b, int w, int view, dou
         }
         if (SOLAR) {
             // attenuation exponents are minus the Chapman-weighted optical depths above the boundary
-            const double* chap = g.chapman + size_t(col) * n * n;
-            for (int l = 0; l < n; ++l) {
+            const double* chap_t = g.chapman_t + size_t(col) * n * n;   // [layer][boundary below]
+            const double uniform = g.chap_uniform[col];
+            double below_sum = 0.0;
+            for (int l = n - 1; l >= 0; --l) {
                 double acc = 0.0;
-                for (int bd = 1; bd <= n; ++bd) {
-                    const double f = chap[size_t(bd - 1) * n + l];
-                    if (f != 0.0) acc += lds[bd * ls] * f;
+                if (uniform != 0.0) {
+                    // plane parallel: a layer is above every boundary below it, all with the same factor
+                    below_sum += lds[(l + 1) * ls];
+                    acc = below_sum * uniform;
+                } else {
+                    int bd = 0;
+                    for (; bd + 4 <= n; bd += 4) {
+                        const double f0 = chap_t[size_t(l) * n + bd], f1 = chap_t[size_t(l) * n + bd + 1], f2 = chap_t[size_t(l) * n + bd + 2],
+                                     f3 = chap_t[size_t(l) * n + bd + 3];
+                        acc += lds[(bd + 1) * ls] * f0 + lds[(bd + 2) * ls] * f1 + lds[(bd + 3) * ls] * f2 + lds[(bd + 4) * ls] * f3;
+                    }
+                    for (; bd < n; ++bd) acc += lds[(bd + 1) * ls] * chap_t[size_t(l) * n + bd];
                 }
                 gsum_at(b, g, view, 0, l, w) -= acc;
             }

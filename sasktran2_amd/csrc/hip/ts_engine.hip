@@ -157,6 +157,8 @@ TsDeviceEngine::TsDeviceEngine(const skts::TsGeometry& tg) : impl_(new Impl()) {
         g.thickness = I.tables.upload(tg.thickness);
         g.csz = I.tables.upload(tg.csz);
         g.chapman = I.tables.upload(tg.chapman);
+        g.chapman_t = I.tables.upload(tg.chapman_t);
+        g.chap_uniform = I.tables.upload(tg.chap_uniform);
         g.view_cos = I.tables.upload(tg.view_cos);
         g.view_azimuth = I.tables.upload(tg.view_azimuth);
         g.ray_start = I.tables.upload(tg.ray_start);

@@ -36,6 +36,8 @@ struct TsGeometry {
     std::vector<double> thickness;       // [nlyr], layers numbered from the top
     std::vector<double> csz;             // [ncol]
     std::vector<double> chapman;         // [ncol][boundary below layer b: nlyr][layer: nlyr]
+    std::vector<double> chapman_t;       // [ncol][layer][boundary]: the same, transposed (reverse sweeps)
+    std::vector<double> chap_uniform;    // [ncol] plane-parallel column: the one factor of every layer above a boundary; otherwise 0
     // plane parallel
     std::vector<double> view_cos, view_azimuth;   // [nlos]
     // spherical
@@ -92,6 +94,19 @@ inline void build_ts_geometry(const skgeo::Geometry1D& geo, const std::vector<sk
         g.chapman = one.chapman;
     }
 
+    // derived forms of the Chapman table
+    g.chapman_t.assign(g.chapman.size(), 0.0);
+    g.chap_uniform.assign(g.ncol, 0.0);
+    for (int c = 0; c < g.ncol; ++c) {
+        const double f = g.chap(c, 0, 0);
+        bool uniform = f > 0.0;
+        for (int bd = 0; bd < g.nlyr; ++bd)
+            for (int l = 0; l < g.nlyr; ++l) {
+                g.chapman_t[(size_t(c) * g.nlyr + l) * g.nlyr + bd] = g.chap(c, bd, l);
+                uniform = uniform && g.chap(c, bd, l) == (l <= bd ? f : 0.0);
+            }
+        if (uniform) g.chap_uniform[c] = f;
+    }
     if (!sph) {
         g.view_cos.resize(g.nlos);
         g.view_azimuth.resize(g.nlos);

@@ -60,6 +60,7 @@ int emts_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     g.max_seg = 0;
     for (int i = 0; i + 1 < (int)tg.ray_start.size(); ++i) g.max_seg = std::max(g.max_seg, tg.ray_start[i + 1] - tg.ray_start[i]);
     g.thickness = tg.thickness.data(); g.csz = tg.csz.data(); g.chapman = tg.chapman.data();
+    g.chapman_t = tg.chapman_t.data(); g.chap_uniform = tg.chap_uniform.data();
     g.view_cos = tg.view_cos.data(); g.view_azimuth = tg.view_azimuth.data();
     g.ray_start = tg.ray_start.data(); g.ground_hit = tg.ground_hit.data(); g.ground_col = tg.ground_col.data(); g.ground_colw = tg.ground_colw.data();
     g.seg_layer = tg.seg_layer.data(); g.seg_frac = tg.seg_frac.data(); g.seg_cos = tg.seg_cos.data(); g.seg_azimuth = tg.seg_azimuth.data();
