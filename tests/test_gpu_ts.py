@@ -126,6 +126,15 @@ def test_single_line_of_sight_fused_passes(sources, monkeypatch):
     np.testing.assert_allclose(fwd["radiance"], ref["radiance"], rtol=RTOL_I)
     monkeypatch.setenv("SASKTRAN2_AMD_TS_UNFUSED", "1")
     compare(run_product_ts(s, solar=solar, thermal=thermal), ref)
+    monkeypatch.delenv("SASKTRAN2_AMD_TS_UNFUSED")
+    # several launches with a ragged last one: bit-identical to the single launch
+    t = varied(sc.twostream_reference_case(spherical=False, thermal=sources != "solar", num_wavelengths=150))
+    t["rays"] = t["rays"][:1]
+    one = run_product_ts(t, solar=solar, thermal=thermal)
+    monkeypatch.setenv("SASKTRAN2_AMD_TS_CHUNK", "64")
+    blocks = run_product_ts(t, solar=solar, thermal=thermal)
+    for k in one:
+        assert np.array_equal(one[k], blocks[k]), k
 
 
 def test_resonances_on_device():
