@@ -585,7 +585,12 @@ template <class S> TS_HD S bottom_plus(const LayerSol<S>& h, const Boundary<S>& 
     return q.gpb + c0 * (h.xp * h.omega) + c1 * h.xm;
 }
 
-template <bool SOLAR, bool DERIVS, bool SPHERICAL> TS_HD void view_forward_thread(const Geo& g, const Bufs& b, int w, int view) {
+template <bool SOLAR>
+TS_HD void segment_adjoint(int az, const LayerP<double>& p, const LayerSol<double>& h, double mu, double csz, double angular, double frac_top,
+                           double cosine, double c0, double c1, double Ws, double g[5], double& U, double& V);
+
+// DUAL (tests only): the segment sources of the spherical reverse sweep differentiated in dual numbers instead of segment_adjoint
+template <bool SOLAR, bool DERIVS, bool SPHERICAL, bool DUAL = false> TS_HD void view_forward_thread(const Geo& g, const Bufs& b, int w, int view) {
     constexpr int NAZ = SOLAR ? 2 : 1;
     const int n = g.nlyr, N = 2 * n;
     const size_t gw = size_t(b.w0) + w;
@@ -739,22 +744,44 @@ template <bool SOLAR, bool DERIVS, bool SPHERICAL> TS_HD void view_forward_threa
                 for (int side = 0; side < (lo != up ? 2 : 1); ++side) {
                     const int col = side == 0 ? lo : up;
                     const double wgt = d_src * (side == 0 ? 1.0 - uw : uw);
-                    const LayerP<D5> p = lift<D5>(load_p<SOLAR>(g, b, col, l, w));
+                    const LayerP<double> pv = load_p<SOLAR>(g, b, col, l, w);
                     const double csz = g.csz[col];
                     const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
                     const double azw[2] = {1.0, cos(g.seg_azimuth[s])};
-                    D5 acc = mkd(0.0);
-                    for (int az = 0; az < NAZ; ++az) {
-                        const LayerSol<D5> h = layer_solution<D5, SOLAR>(az, p, mu, csz, angular);
-                        D5 U, V, P;
-                        local_source_terms<D5, SOLAR>(az, p, h, g.seg_frac[s], g.seg_cos[s], mu, U, V, P);
-                        const double c0 = lu_at(b, g, NAZ, col, az, LU_C, 2 * l, w), c1 = lu_at(b, g, NAZ, col, az, LU_C, 2 * l + 1, w);
-                        acc += azw[az] * (c0 * U + c1 * V + P);
-                        lam_at(b, g, NAZ, view, col, az, 2 * l, w) += wgt * azw[az] * U.v;
-                        lam_at(b, g, NAZ, view, col, az, 2 * l + 1, w) += wgt * azw[az] * V.v;
+                    double G[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+                    if (!DUAL) {
+                        for (int az = 0; az < NAZ; ++az) {
+                            const LayerSol<double> h = layer_solution<double, SOLAR>(az, pv, mu, csz, angular);
+                            const double c0 = lu_at(b, g, NAZ, col, az, LU_C, 2 * l, w), c1 = lu_at(b, g, NAZ, col, az, LU_C, 2 * l + 1, w);
+                            double U, V;
+                            segment_adjoint<SOLAR>(az, pv, h, mu, csz, angular, g.seg_frac[s], g.seg_cos[s], c0, c1, wgt * azw[az], G, U, V);
+                            lam_at(b, g, NAZ, view, col, az, 2 * l, w) += wgt * azw[az] * U;
+                            lam_at(b, g, NAZ, view, col, az, 2 * l + 1, w) += wgt * azw[az] * V;
+                        }
+                        if (!SOLAR) {
+                            // the emission itself seen along the path: amp exp(-rate od frac) (1 - ssa)
+                            const double ft = g.seg_frac[s], e = exp(-pv.rate * pv.od * ft), v = wgt * e;
+                            G[3] += v * (1.0 - pv.ssa);
+                            G[1] -= v * pv.amp;
+                            G[4] -= v * pv.amp * (1.0 - pv.ssa) * pv.od * ft;
+                            G[0] -= v * pv.amp * (1.0 - pv.ssa) * pv.rate * ft;
+                        }
+                    } else {
+                        const LayerP<D5> p = lift<D5>(pv);
+                        D5 acc = mkd(0.0);
+                        for (int az = 0; az < NAZ; ++az) {
+                            const LayerSol<D5> h = layer_solution<D5, SOLAR>(az, p, mu, csz, angular);
+                            D5 U, V, P;
+                            local_source_terms<D5, SOLAR>(az, p, h, g.seg_frac[s], g.seg_cos[s], mu, U, V, P);
+                            const double c0 = lu_at(b, g, NAZ, col, az, LU_C, 2 * l, w), c1 = lu_at(b, g, NAZ, col, az, LU_C, 2 * l + 1, w);
+                            acc += azw[az] * (c0 * U + c1 * V + P);
+                            lam_at(b, g, NAZ, view, col, az, 2 * l, w) += wgt * azw[az] * U.v;
+                            lam_at(b, g, NAZ, view, col, az, 2 * l + 1, w) += wgt * azw[az] * V.v;
+                        }
+                        if (!SOLAR) acc += local_emission(p, g.seg_frac[s]);
+                        for (int d = 0; d < 5; ++d) G[d] = wgt * acc.d[d];
                     }
-                    if (!SOLAR) acc += local_emission(p, g.seg_frac[s]);
-                    for (int d = 0; d < 5; ++d) g5_at(b, g, view, col, l, d, w) += wgt * acc.d[d];
+                    for (int d = 0; d < 5; ++d) g5_at(b, g, view, col, l, d, w) += G[d];
                 }
                 d_rad *= t;
             }
@@ -853,6 +880,74 @@ template <bool SOLAR> TS_HD void fused_radiance_thread(const Geo& g, const Bufs&
 // exp_difference / integrated_exp_difference (:64-128).  view_adjoint_thread<.., DUAL = true> differentiates the same value in dual
 // numbers: the cross-check of this function in the tests.
 // ---------------------------------------------------------------------------------------------------------------------------
+// the common tail of the reverse sweeps: from the adjoints of the particular-solution amplitudes (upper, lower), the eigenvector components
+// (xp, xm), omega = exp(-k od) and the eigenvalue to the layer parameters
+template <bool SOLAR>
+TS_HD void solution_chain(int az, const LayerP<double>& p, const LayerSol<double>& h, double mu, double csz, double angular, double a_upper,
+                          double a_lower, double a_xp, double a_xm, double a_om, double a_k, double a_od, double a_ssa, double a_b1, double a_amp,
+                          double a_rate, double g[5]) {
+    const double xp = h.xp, xm = h.xm, om = h.omega, k = h.k, upper = h.upper, lower = h.lower;
+    const double od = p.od, ssa = p.ssa, b1 = p.b1;
+    // ---- particular-solution amplitudes
+    const double norm = mu * (xp * xp - xm * xm), i_norm = 1.0 / norm;
+    double a_norm;
+    if (SOLAR) {
+        double qp, qm;
+        if (az == 0) {
+            qp = ssa * (1.0 + b1 * (csz * mu)) / kFourPi;
+            qm = ssa * (1.0 - b1 * (csz * mu)) / kFourPi;
+        } else {
+            qp = qm = ssa * b1 * (angular / kFourPi);
+        }
+        const double a_qp = (a_upper * xp + a_lower * xm) * i_norm, a_qm = (a_upper * xm + a_lower * xp) * i_norm;
+        a_xp += (a_upper * qp + a_lower * qm) * i_norm;
+        a_xm += (a_upper * qm + a_lower * qp) * i_norm;
+        a_norm = -(a_upper * upper + a_lower * lower) * i_norm;
+        if (az == 0) {
+            a_ssa += (a_qp * (1.0 + b1 * (csz * mu)) + a_qm * (1.0 - b1 * (csz * mu))) / kFourPi;
+            a_b1 += ssa * (csz * mu) * (a_qp - a_qm) / kFourPi;
+        } else {
+            a_ssa += (a_qp + a_qm) * b1 * (angular / kFourPi);
+            a_b1 += (a_qp + a_qm) * ssa * (angular / kFourPi);
+        }
+    } else {
+        const double a_at = a_upper + a_lower;
+        a_ssa -= a_at * (xp + xm) * i_norm;
+        a_xp += a_at * (1.0 - ssa) * i_norm;
+        a_xm += a_at * (1.0 - ssa) * i_norm;
+        a_norm = -a_at * upper * i_norm;
+    }
+    a_xp += a_norm * 2.0 * mu * xp;
+    a_xm -= a_norm * 2.0 * mu * xm;
+    // ---- omega = exp(-k od) (the exponentials inside the quotients are accounted for by their own partial derivatives),
+    // xp / xm = (1 -/+ s / k) / 2, k = sqrt(s d)
+    a_k -= a_om * om * od;
+    a_od -= a_om * om * k;
+    double s, d;
+    if (az == 0) {
+        d = ssa * b1 * mu - 1.0 / mu;
+        s = (ssa - 1.0) / mu;
+    } else {
+        d = -1.0 / mu;
+        s = (ssa * b1 * (1.0 - mu * mu) - 2.0) / (2.0 * mu);
+    }
+    const double i_k = 1.0 / k, a_sk = 0.5 * (a_xm - a_xp);
+    a_k -= a_sk * s * i_k * i_k;
+    const double a_s = a_sk * i_k + a_k * 0.5 * d * i_k, a_d = a_k * 0.5 * s * i_k;
+    if (az == 0) {
+        a_ssa += a_d * b1 * mu + a_s / mu;
+        a_b1 += a_d * ssa * mu;
+    } else {
+        a_ssa += a_s * b1 * (1.0 - mu * mu) / (2.0 * mu);
+        a_b1 += a_s * ssa * (1.0 - mu * mu) / (2.0 * mu);
+    }
+    g[0] += a_od;
+    g[1] += a_ssa;
+    g[2] += a_b1;
+    g[3] += a_amp;
+    g[4] += a_rate;
+}
+
 // (exp_a - exp_b) / (b - a) with exp_a = exp(-a t), exp_b = exp(-b t) and its partial derivatives with respect to a, b, t
 TS_HD Stable edr_partials(double exp_a, double exp_b, double a, double b, double t) {
     const double delta = b - a;
@@ -940,64 +1035,51 @@ TS_HD void layer_adjoint(int az, const LayerP<double>& p, const LayerSol<double>
             a_b1 += (a_lp + a_lm) * ssa * phase_sine;
         }
     }
-    // ---- particular-solution amplitudes
-    const double norm = mu * (xp * xp - xm * xm), i_norm = 1.0 / norm;
-    double a_norm;
-    if (SOLAR) {
-        double qp, qm;
-        if (az == 0) {
-            qp = ssa * (1.0 + b1 * (csz * mu)) / kFourPi;
-            qm = ssa * (1.0 - b1 * (csz * mu)) / kFourPi;
-        } else {
-            qp = qm = ssa * b1 * (angular / kFourPi);
-        }
-        const double a_qp = (a_upper * xp + a_lower * xm) * i_norm, a_qm = (a_upper * xm + a_lower * xp) * i_norm;
-        a_xp += (a_upper * qp + a_lower * qm) * i_norm;
-        a_xm += (a_upper * qm + a_lower * qp) * i_norm;
-        a_norm = -(a_upper * upper + a_lower * lower) * i_norm;
-        if (az == 0) {
-            a_ssa += (a_qp * (1.0 + b1 * (csz * mu)) + a_qm * (1.0 - b1 * (csz * mu))) / kFourPi;
-            a_b1 += ssa * (csz * mu) * (a_qp - a_qm) / kFourPi;
-        } else {
-            a_ssa += (a_qp + a_qm) * b1 * (angular / kFourPi);
-            a_b1 += (a_qp + a_qm) * ssa * (angular / kFourPi);
-        }
-    } else {
-        const double a_at = a_upper + a_lower;
-        a_ssa -= a_at * (xp + xm) * i_norm;
-        a_xp += a_at * (1.0 - ssa) * i_norm;
-        a_xm += a_at * (1.0 - ssa) * i_norm;
-        a_norm = -a_at * upper * i_norm;
-    }
-    a_xp += a_norm * 2.0 * mu * xp;
-    a_xm -= a_norm * 2.0 * mu * xm;
-    // ---- omega = exp(-k od) (the exponentials inside the quotients are accounted for by their own partial derivatives),
-    // xp / xm = (1 -/+ s / k) / 2, k = sqrt(s d)
-    a_k -= a_om * om * od;
-    a_od -= a_om * om * k;
-    double s, d;
+    solution_chain<SOLAR>(az, p, h, mu, csz, angular, a_upper, a_lower, a_xp, a_xm, a_om, a_k, a_od, a_ssa, a_b1, a_amp, a_rate, g);
+}
+
+// reverse sweep of the source function of one traced segment (local_source_terms), one azimuth order: g += Ws d(c0 U + c1 V + P) / d(od, ssa,
+// b1, amp, rate); U and V (the dF/dc rows of the segment) are returned
+template <bool SOLAR>
+TS_HD void segment_adjoint(int az, const LayerP<double>& p, const LayerSol<double>& h, double mu, double csz, double angular, double frac_top,
+                           double cosine, double c0, double c1, double Ws, double g[5], double& U, double& V) {
+    const double xp = h.xp, xm = h.xm, k = h.k, upper = h.upper, lower = h.lower, ex = h.expo;
+    const double od = p.od, ssa = p.ssa, b1 = p.b1, amp = p.amp, rate = p.rate;
+    const double frac_bottom = 1.0 - frac_top;
+    const double phase_mu = cosine * mu, phase_sine = 0.25 * sqrt(fmax(0.0, (1.0 - cosine * cosine) * (1.0 - mu * mu)));
+    double lp, lm;
     if (az == 0) {
-        d = ssa * b1 * mu - 1.0 / mu;
-        s = (ssa - 1.0) / mu;
+        lp = 0.5 * ssa * (1.0 - b1 * phase_mu);
+        lm = 0.5 * ssa * (1.0 + b1 * phase_mu);
     } else {
-        d = -1.0 / mu;
-        s = (ssa * b1 * (1.0 - mu * mu) - 2.0) / (2.0 * mu);
+        lp = lm = SOLAR ? ssa * b1 * phase_sine : 0.0;
     }
-    const double i_k = 1.0 / k, a_sk = 0.5 * (a_xm - a_xp);
-    a_k -= a_sk * s * i_k * i_k;
-    const double a_s = a_sk * i_k + a_k * 0.5 * d * i_k, a_d = a_k * 0.5 * s * i_k;
+    const double yp = lp * xp + lm * xm, ym = lp * xm + lm * xp;
+    const double top_e = exp(-k * od * frac_top), bot_e = exp(-k * od * frac_bottom), beam = exp(-rate * od * frac_top);
+    const Stable e_plus = edr_partials(top_e, beam, k, rate, od * frac_top);                                            // d/dk = da, d/drate = db, d/dod = dt frac_top
+    const Stable e_minus = edr_partials(beam, ex * bot_e, rate * frac_top, rate + k * frac_bottom, od);                  // a = rate frac_top, b = rate + k frac_bottom
+    const double plus = amp * e_plus.value, minus = amp * frac_bottom * e_minus.value;
+    U = yp * top_e;
+    V = ym * bot_e;
+    const double a_yp = Ws * (c0 * top_e + upper * plus), a_ym = Ws * (c1 * bot_e + lower * minus);
+    const double a_top = Ws * c0 * yp, a_bot = Ws * c1 * ym;
+    const double a_upper = Ws * yp * plus, a_lower = Ws * ym * minus;
+    const double a_e1 = Ws * upper * yp * amp, a_e2 = Ws * lower * ym * amp * frac_bottom;
+    const double a_amp = Ws * (upper * yp * e_plus.value + lower * ym * frac_bottom * e_minus.value);
+    double a_k = a_e1 * e_plus.da + a_e2 * e_minus.db * frac_bottom - (a_top * top_e * frac_top + a_bot * bot_e * frac_bottom) * od;
+    double a_rate = a_e1 * e_plus.db + a_e2 * (e_minus.da * frac_top + e_minus.db);
+    double a_od = a_e1 * e_plus.dt * frac_top + a_e2 * e_minus.dt - (a_top * top_e * frac_top + a_bot * bot_e * frac_bottom) * k;
+    const double a_lp = a_yp * xp + a_ym * xm, a_lm = a_yp * xm + a_ym * xp;
+    const double a_xp = a_yp * lp + a_ym * lm, a_xm = a_yp * lm + a_ym * lp;
+    double a_ssa = 0.0, a_b1 = 0.0;
     if (az == 0) {
-        a_ssa += a_d * b1 * mu + a_s / mu;
-        a_b1 += a_d * ssa * mu;
-    } else {
-        a_ssa += a_s * b1 * (1.0 - mu * mu) / (2.0 * mu);
-        a_b1 += a_s * ssa * (1.0 - mu * mu) / (2.0 * mu);
+        a_ssa = 0.5 * (a_lp * (1.0 - b1 * phase_mu) + a_lm * (1.0 + b1 * phase_mu));
+        a_b1 = 0.5 * ssa * phase_mu * (a_lm - a_lp);
+    } else if (SOLAR) {
+        a_ssa = (a_lp + a_lm) * b1 * phase_sine;
+        a_b1 = (a_lp + a_lm) * ssa * phase_sine;
     }
-    g[0] += a_od;
-    g[1] += a_ssa;
-    g[2] += a_b1;
-    g[3] += a_amp;
-    g[4] += a_rate;
+    solution_chain<SOLAR>(az, p, h, mu, csz, angular, a_upper, a_lower, a_xp, a_xm, 0.0, a_k, a_od, a_ssa, a_b1, a_amp, a_rate, g);
 }
 
 // Weighting functions of one line of sight: the backward half of the transposed solve (L^T lambda = y) fused with the Lagrangian of every

@@ -112,11 +112,11 @@ int emts_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                 case 0: skt::view_forward_thread<false, false, false>(g, b, w, v); break;
                 case 1: skt::view_forward_thread<false, false, true>(g, b, w, v); break;
                 case 2: skt::view_forward_thread<false, true, false>(g, b, w, v); break;
-                case 3: skt::view_forward_thread<false, true, true>(g, b, w, v); break;
+                case 3: dual_adjoint ? skt::view_forward_thread<false, true, true, true>(g, b, w, v) : skt::view_forward_thread<false, true, true>(g, b, w, v); break;
                 case 4: skt::view_forward_thread<true, false, false>(g, b, w, v); break;
                 case 5: skt::view_forward_thread<true, false, true>(g, b, w, v); break;
                 case 6: skt::view_forward_thread<true, true, false>(g, b, w, v); break;
-                default: skt::view_forward_thread<true, true, true>(g, b, w, v); break;
+                default: dual_adjoint ? skt::view_forward_thread<true, true, true, true>(g, b, w, v) : skt::view_forward_thread<true, true, true>(g, b, w, v); break;
             }
         };
         auto adjoint = [&](int w, int v) {
