@@ -45,6 +45,7 @@ struct Geo {
                                                      // boundary), 0 for a ray-traced one
     const double *view_cos, *view_azimuth;           // plane parallel, [nlos]
     const int *ray_start, *ground_hit, *ground_col;  // spherical
+    const int* view_cols;                            // [nlos][2] first / last column a line of sight refers to
     const double* ground_colw;
     const int* seg_layer;
     const double *seg_frac, *seg_cos, *seg_azimuth;
@@ -722,8 +723,9 @@ template <bool SOLAR, bool DERIVS, bool SPHERICAL, bool DUAL = false> TS_HD void
             }
             radiance = radiance * t + src * (1.0 - t);
         }
+        const int col_first = SOLAR ? g.view_cols[2 * view] : 0, col_last = SOLAR ? g.view_cols[2 * view + 1] : 0;   // columns this line of sight refers to
         if (DERIVS) {
-            for (int col = 0; col < ncol; ++col) {
+            for (int col = col_first; col <= col_last; ++col) {
                 for (int az = 0; az < NAZ; ++az)
                     for (int i = 0; i < N; ++i) lam_at(b, g, NAZ, view, col, az, i, w) = 0.0;
                 for (int l = 0; l < n; ++l)
@@ -787,7 +789,7 @@ template <bool SOLAR, bool DERIVS, bool SPHERICAL, bool DUAL = false> TS_HD void
             }
             surf_weight = g.ground_hit[view] ? d_rad : 0.0;
             // dF/dc of the surface term, then the forward half of the transposed solve, U^T y = dF/dc, in place
-            for (int col = 0; col < ncol; ++col) {
+            for (int col = col_first; col <= col_last; ++col) {
                 double ws = surf_weight;
                 if (SOLAR) {
                     ws = 0.0;
@@ -1103,8 +1105,10 @@ TS_HD void view_adjoint_thread(const Geo& g, const Bufs& b, int w, int view, dou
     const int ground_lo = (!plane && SOLAR) ? g.ground_col[2 * view] : 0, ground_up = (!plane && SOLAR) ? g.ground_col[2 * view + 1] : 0;
     const double ground_uw = (!plane && SOLAR) ? g.ground_colw[view] : 0.0;
     double g_albedo = 0.0, g_surface_emission = 0.0, fused_radiance = 0.0;
+    // columns no source of this line of sight refers to have dF/dc = 0 and contribute nothing
+    const int col_first = (!plane && SOLAR) ? g.view_cols[2 * view] : 0, col_last = (!plane && SOLAR) ? g.view_cols[2 * view + 1] : ncol - 1;
 
-    for (int col = 0; col < ncol; ++col) {
+    for (int col = col_first; col <= col_last; ++col) {
         const double csz = g.csz[col];
         const double angular = sqrt(fmax(0.0, (1.0 - mu * mu) * (1.0 - csz * csz)));
         double ws = surf_weight;   // weight of this column's surface source in the radiance
@@ -1255,7 +1259,7 @@ TS_HD void view_adjoint_thread(const Geo& g, const Bufs& b, int w, int view, dou
                     gsum_at(b, g, view, 3, l, w) = g_amp;
                     gsum_at(b, g, view, 4, l, w) = g_rate;
                 }
-                if (col == 0 && az == 0) {
+                if (col == col_first && az == 0) {
                     gsum_at(b, g, view, 0, l, w) = g_od;
                     gsum_at(b, g, view, 1, l, w) = g_ssa;
                     gsum_at(b, g, view, 2, l, w) = g_b1;

@@ -163,6 +163,7 @@ TsDeviceEngine::TsDeviceEngine(const skts::TsGeometry& tg) : impl_(new Impl()) {
         g.view_azimuth = I.tables.upload(tg.view_azimuth);
         g.ray_start = I.tables.upload(tg.ray_start);
         g.ground_hit = I.tables.upload(tg.ground_hit);
+        g.view_cols = I.tables.upload(tg.view_cols);
         g.ground_col = I.tables.upload(tg.ground_col);
         g.ground_colw = I.tables.upload(tg.ground_colw);
         g.seg_layer = I.tables.upload(tg.seg_layer);

@@ -45,6 +45,7 @@ struct TsGeometry {
     std::vector<int> ground_hit;         // [nlos]
     std::vector<int> ground_col;         // [nlos][2] columns bracketing the cos(SZA) at the ground
     std::vector<double> ground_colw;     // [nlos] weight of the upper column
+    std::vector<int> view_cols;          // [nlos][2] first and last column any source of the line of sight refers to
     std::vector<int> seg_layer;          // layer (from the top) holding the source point
     std::vector<double> seg_frac;        // fraction of the layer between its top and the source point
     std::vector<double> seg_cos;         // cosine of the propagation direction against the local vertical
@@ -167,6 +168,15 @@ inline void build_ts_geometry(const skgeo::Geometry1D& geo, const std::vector<sk
             g.od_start.push_back((int)g.od_level.size());
         }
         g.ray_start.push_back(g.nseg());
+        int clo = g.ground_col[2 * i], chi = g.ground_col[2 * i + 1];
+        if (!tr.ground_is_hit) { clo = g.ncol; chi = -1; }
+        for (int sgm = g.ray_start[i]; sgm < g.ray_start[i + 1]; ++sgm) {
+            clo = std::min(clo, g.seg_col[2 * sgm]);
+            chi = std::max(chi, g.seg_col[2 * sgm + 1]);
+        }
+        if (chi < clo) clo = chi = 0;
+        g.view_cols.push_back(clo);
+        g.view_cols.push_back(chi);
     }
 }
 

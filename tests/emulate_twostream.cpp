@@ -62,6 +62,7 @@ int emts_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     g.thickness = tg.thickness.data(); g.csz = tg.csz.data(); g.chapman = tg.chapman.data();
     g.chapman_t = tg.chapman_t.data(); g.chap_uniform = tg.chap_uniform.data();
     g.view_cos = tg.view_cos.data(); g.view_azimuth = tg.view_azimuth.data();
+    g.view_cols = tg.view_cols.data();
     g.ray_start = tg.ray_start.data(); g.ground_hit = tg.ground_hit.data(); g.ground_col = tg.ground_col.data(); g.ground_colw = tg.ground_colw.data();
     g.seg_layer = tg.seg_layer.data(); g.seg_frac = tg.seg_frac.data(); g.seg_cos = tg.seg_cos.data(); g.seg_azimuth = tg.seg_azimuth.data();
     g.seg_col = tg.seg_col.data(); g.seg_colw = tg.seg_colw.data();
