@@ -183,3 +183,28 @@ def test_storage_handle_reuse_resets_delta_m_state(built):
     for h in (hA, hB):
         L.sk_atmosphere_storage_destroy(h)
     L.sk_surface_destroy(h_su)
+
+
+def test_two_stream_configuration_is_routed(built):
+    # multiple_scatter_source = twostream / emission_source = twostream are accepted by sk_engine_create (configuration errors are reported
+    # before any device is touched; without a GPU the creation then fails for the lack of a HIP device, never for the source)
+    import torch
+    import sasktran2_amd as sk
+    from tests import scenarios as sc
+    from tests.gpu_harness import build_ts_engine
+    config = sk.Config()
+    config.num_stokes = 3
+    config.multiple_scatter_source = sk.MultipleScatterSource.TwoStream
+    geometry = sk.Geometry1D(0.6, 0.0, 6_371_000.0, [0.0, 1000.0, 2000.0])
+    viewing = sk.ViewingGeometry()
+    viewing.add_ray(sk.GroundViewingSolar(0.6, 0.0, 0.8, 200_000.0))
+    with pytest.raises(Exception, match="NSTOKES = 1"):
+        sk.Engine(config, geometry, viewing)
+    config = sk.Config()
+    config.emission_source = sk.EmissionSource.TwoStream
+    config.multiple_scatter_source = sk.MultipleScatterSource.DiscreteOrdinates
+    with pytest.raises(Exception, match="not part of this build"):
+        sk.Engine(config, geometry, viewing)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            build_ts_engine(sc.twostream_reference_case(spherical=True), solar=True, thermal=True)
