@@ -235,7 +235,8 @@ int orso_sizes(void* hv, int* out) {
 // radiance[nwavel][nlos][S], los_od[nwavel][nlos]
 // d_k, d_ssa [nwavel][nlos][S][ngrid], d_albedo [nwavel][nlos][S] (or null): native weighting functions of the exact single scatter
 int orso_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg, const double* solar_irradiance,
-             const double* albedo, int nthreads, double* radiance, double* los_od, double* d_k, double* d_ssa, double* d_albedo) {
+             const double* albedo, int nthreads, double* radiance, double* los_od, double* d_k, double* d_ssa, double* d_albedo,
+             double* d_emission, double* d_surface_emission) {   // the last two [nwavel][nlos][S][ngrid] / [nwavel][nlos][S], or null
     auto* h = static_cast<SoHandle*>(hv);
     if (!h) return -1;
     const int nlos = h->sg.nlos, S = h->sg.cfg.nstokes;
@@ -253,9 +254,8 @@ int orso_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     atm.surface_emission = h->surface_emission;
     if (h->sg.cfg.emission != 0 && !atm.emission) return -2;
     atm.derivatives = d_k != nullptr;
-    if (atm.derivatives && (h->sg.cfg.emission != 0 || h->sg.cfg.occultation)) return -2;
     if (atm.derivatives && h->sg.cfg.multiple_scatter && h->num_iterations > 0) return -2;   // the diffuse source is not linearised
-    const int ngrid = h->sg.ngrid, nn = 2 * ngrid + 1;
+    const int ngrid = h->sg.ngrid, nn = 3 * ngrid + 2;
     int status = 0;
 #ifdef _OPENMP
     if (nthreads < 1) nthreads = 1;
@@ -283,6 +283,9 @@ int orso_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                             d_ssa[(size_t(w) * nlos * S + i) * ngrid + q] = src[ngrid + q];
                         }
                         d_albedo[size_t(w) * nlos * S + i] = src[2 * ngrid];
+                        if (d_emission)
+                            for (int q = 0; q < ngrid; ++q) d_emission[(size_t(w) * nlos * S + i) * ngrid + q] = src[2 * ngrid + 1 + q];
+                        if (d_surface_emission) d_surface_emission[size_t(w) * nlos * S + i] = src[3 * ngrid + 1];
                     }
             } catch (const std::exception& e) {
                 std::fprintf(stderr, "orso_run (wavelength %d): %s\n", w, e.what());

@@ -134,7 +134,7 @@ class SoOracleEngine:
         L.orso_set_emission.argtypes = [ctypes.c_void_p, _dp, _dp]
         L.orso_destroy.argtypes = [ctypes.c_void_p]
         L.orso_sizes.argtypes = [ctypes.c_void_p, _ip]
-        L.orso_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp]
+        L.orso_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         self.alt = np.ascontiguousarray(altitudes, dtype=np.float64)
         self.nlos, self.ngrid, self.nstokes = len(rays), len(self.alt), nstokes
         kinds = np.ascontiguousarray([r[0] for r in rays], dtype=np.int32)
@@ -170,16 +170,17 @@ class SoOracleEngine:
         em = None if emission is None else np.asfortranarray(emission, dtype=np.float64)
         sem = None if surface_emission is None else np.ascontiguousarray(surface_emission, dtype=np.float64)
         lib().orso_set_emission(self._h, _p(em), _p(sem))
-        dk = dw = da = None
+        dk = dw = da = de = ds = None
         if derivatives:
             dk, dw, da = np.zeros((nwavel, self.nlos, S, self.ngrid)), np.zeros((nwavel, self.nlos, S, self.ngrid)), np.zeros((nwavel, self.nlos, S))
+            de, ds = np.zeros((nwavel, self.nlos, S, self.ngrid)), np.zeros((nwavel, self.nlos, S))
         rc = lib().orso_run(self._h, nwavel, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), _p(irr), _p(alb), nthreads, _p(rad), _p(od),
-                            _p(dk), _p(dw), _p(da))
+                            _p(dk), _p(dw), _p(da), _p(de), _p(ds))
         if rc != 0:
             raise RuntimeError(f"successive-orders oracle run failed with code {rc}")
         out = {"radiance": rad, "los_optical_depth": od}
         if derivatives:
-            out.update({"d_extinction": dk, "d_ssa": dw, "d_albedo": da})
+            out.update({"d_extinction": dk, "d_ssa": dw, "d_albedo": da, "d_emission": de, "d_surface_emission": ds})
         return out
 
 

@@ -102,10 +102,19 @@ class Solver {
     void los_derivatives(const AtmosphereView& a, int w, int r, const double* k, const double* om, double F, double albedo,
                          const double* p11, const double* p12, Result& res) const {
         const skso::RaySet& lo = g_.los;
-        const int ngrid = a.ngrid, nn = 2 * ngrid + 1, l0 = lo.layer_start[r], n = lo.layer_start[r + 1] - l0, e0 = lo.endpoint_start[r];
+        // columns of a row of derivatives: extinction [0, ngrid), ssa [ngrid, 2 ngrid), albedo 2 ngrid, emission profile
+        // [2 ngrid + 1, 3 ngrid + 1), surface emission 3 ngrid + 1
+        const int ngrid = a.ngrid, nn = 3 * ngrid + 2, l0 = lo.layer_start[r], n = lo.layer_start[r + 1] - l0, e0 = lo.endpoint_start[r];
+        const bool ss = g_.cfg.single_scatter;
         std::vector<double> I(S_, 0.0), dI(size_t(S_) * nn, 0.0);
         auto D = [&](int s, int x) -> double& { return dI[size_t(s) * nn + x]; };
-        if (n > 0 && lo.ground_is_hit[r] && lo.ground_mu_in[r] > 0) {
+        // end-of-ray sources without scattering (emission_source.cpp:156-173, occultation.cpp:26-35)
+        if (n > 0 && g_.cfg.emission != 0 && lo.ground_is_hit[r] && a.surface_emission) {
+            I[0] += a.surface_emission[w];
+            D(0, 3 * ngrid + 1) += 1.0;
+        }
+        if (g_.cfg.occultation && !(n > 0 && lo.ground_is_hit[r])) I[0] += 1.0;
+        if (ss && n > 0 && lo.ground_is_hit[r] && lo.ground_mu_in[r] > 0) {
             const double base = T_los_[e0] * lo.ground_mu_in[r] / skgeo::kPi;
             I[0] += base * albedo;
             D(0, 2 * ngrid) += base;
@@ -119,6 +128,33 @@ class Solver {
             for (int s = 0; s < S_; ++s) I[s] *= att;
             for (double& v : dI) v *= att;
             if (lo.tiny[L]) continue;
+            if (g_.cfg.emission != 0) {
+                // EmissionSource::integrated_source with its derivatives (emission_source.cpp:37-152)
+                const double* em = a.emission + size_t(w) * ngrid;
+                double oms = 0, ome = 0, es = 0, ee = 0;
+                for (int i = 0; i < 4; ++i) {
+                    const int q = lo.stencil_idx[size_t(L) * 4 + i];
+                    if (q < 0) continue;
+                    const double ws = lo.w_entrance[size_t(L) * 4 + i], we = lo.w_exit[size_t(L) * 4 + i];
+                    oms += om[q] * ws; es += em[q] * ws;
+                    ome += om[q] * we; ee += em[q] * we;
+                }
+                const bool standard = g_.cfg.emission == 1;
+                const double factor = standard ? 1 - att : lo.distance[L];
+                const double cell = standard ? (1 - oms) * es * lo.frac_start[L] + (1 - ome) * ee * lo.frac_end[L]
+                                             : es * lo.frac_start[L] + ee * lo.frac_end[L];
+                I[0] += factor * cell;
+                if (standard)
+                    for (int t = lo.od.start[L]; t < lo.od.start[L + 1]; ++t) D(0, lo.od.idx[t]) += lo.od.w[t] * att * cell;
+                for (int i = 0; i < 4; ++i) {
+                    const int q = lo.stencil_idx[size_t(L) * 4 + i];
+                    if (q < 0) continue;
+                    const double ws = lo.w_entrance[size_t(L) * 4 + i], we = lo.w_exit[size_t(L) * 4 + i];
+                    if (standard) D(0, ngrid + q) -= factor * (ws * es * lo.frac_start[L] + we * ee * lo.frac_end[L]);
+                    D(0, 2 * ngrid + 1 + q) += factor * (ws * (standard ? 1 - oms : 1.0) * lo.frac_start[L] + we * (standard ? 1 - ome : 1.0) * lo.frac_end[L]);
+                }
+            }
+            if (!ss) continue;
             const double sf = (std::abs(od) < 1e-12) ? 1.0 : -std::expm1(-od) / od;
             const double dsf = (std::abs(od) < 1e-12) ? -0.5 : 1 / od - sf * (1 + 1 / od);
             double quad_sum[3] = {0, 0, 0};
@@ -317,7 +353,7 @@ class Solver {
                 }
             }
             res.los_od[r] = total_od;
-            if (a.derivatives) los_derivatives(a, w, r, k, om, F, albedo, p11.data(), p12.data(), res);
+            if (a.derivatives) los_derivatives(a, w, r, k, om, F, albedo, p11.data(), p12.data(), res);   // (row length 3 ngrid + 2)
             // Stokes basis of the output (OutputC::assign_lane)
             res.radiance[size_t(r) * S_] = rad[0];
             if (S_ == 3) {

@@ -686,7 +686,12 @@ static int calculate_radiance_so(Engine* e, Atmosphere* atm, OutputC* out) {
         d_wa = (double*)C.get("wf_alb", nt * S * 8);
     }
     upload_emission(e, st, su);
-    e->so->solve_device(nw, st.nleg / per, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, d_od, nullptr, 0, d_we, d_ws, d_wa);
+    double *d_wem = nullptr, *d_wsem = nullptr;   // emission-profile / surface-emission weighting functions of a line-of-sight emission source
+    if (derivs && e->so->has_emission()) {
+        d_wem = (double*)C.get("wf_emission", size_t(ngrid) * nt * S * 8);
+        d_wsem = (double*)C.get("wf_surface_emission", nt * S * 8);
+    }
+    e->so->solve_device(nw, st.nleg / per, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, d_od, nullptr, 0, d_we, d_ws, d_wa, d_wem, d_wsem);
     HIPC(hipDeviceSynchronize());
     std::vector<double> od(nt);
     HIPC(hipMemcpy(out->radiance, d_rad, nt * S * 8, hipMemcpyDeviceToHost));
@@ -696,7 +701,7 @@ static int calculate_radiance_so(Engine* e, Atmosphere* atm, OutputC* out) {
     out->los_od.resize(nt);
     for (int w = 0; w < nw; ++w)
         for (int r = 0; r < nlos; ++r) out->los_od[size_t(r) * nw + w] = od[size_t(w) * nlos + r];
-    if (derivs) map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, S);
+    if (derivs) map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, S, nullptr, nullptr, d_wem, d_wsem);
     return 0;
 }
 
@@ -759,7 +764,7 @@ static int calculate_radiance_ts(Engine* e, Atmosphere* atm, OutputC* out) {
         d_wb = (double*)C.get("wf_b1", size_t(ngrid) * nt * 8);
         d_wa = (double*)C.get("wf_alb", nt * 8);
         o.wf_ext = d_we; o.wf_ssa = d_ws; o.wf_b1 = d_wb; o.wf_albedo = d_wa;
-        if (e->ts->thermal()) {
+        if (e->ts->thermal() || (e->so && e->so->has_emission())) {
             d_wem = (double*)C.get("wf_emission", size_t(ngrid) * nt * 8);
             d_wsem = (double*)C.get("wf_surface_emission", nt * 8);
             o.wf_emission = d_wem; o.wf_surface_emission = d_wsem;
@@ -794,7 +799,8 @@ static int calculate_radiance_ts(Engine* e, Atmosphere* atm, OutputC* out) {
     if (e->so) {
         // exact single scatter (and the emission / occultation line-of-sight sources) accumulated on top; its optical depths are the same rays'
         upload_emission(e, st, su);
-        e->so->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa);
+        e->so->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa,
+                            e->so->has_emission() ? d_wem : nullptr, e->so->has_emission() ? d_wsem : nullptr);
     }
     HIPC(hipDeviceSynchronize());
     std::vector<double> od(nt);
@@ -847,8 +853,14 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
             // derivatives of the exact single scatter (d_legendre) are not built either: an error rather than a silently incomplete Jacobian
             if (e->so->has_unlinearised_sources()) {
                 set_error("sk_engine_calculate_radiance: weighting functions are not available with multiple_scatter_source = "
-                          "successive_orders_legacy, an emission source or an occultation source in this build (create the atmosphere with "
-                          "calculate_derivatives = 0)");
+                          "successive_orders_legacy in this build (create the atmosphere with calculate_derivatives = 0)");
+                return -2;
+            }
+            // line-of-sight emission next to the discrete-ordinates source: its emission derivatives would have to travel through the DO
+            // paths' mapping calls, which carry none
+            if (e->dev && e->so->has_emission()) {
+                set_error("sk_engine_calculate_radiance: weighting functions of a line-of-sight emission source next to the discrete-ordinates "
+                          "source are not available in this build");
                 return -2;
             }
             for (auto& kv : out->derivs) {

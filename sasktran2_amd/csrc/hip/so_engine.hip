@@ -126,9 +126,10 @@ struct SoBufs {
     double* sh;                              // [interior point][nlm] c_l x harmonic coefficients of the incoming field
     double *radiance, *los_od;                               // caller's outputs (whole spectrum)
     int accumulate;
-    // native weighting functions of the exact single scatter: per-thread accumulators [slab][ray][S][2 ngrid + 1][64] and the caller's
-    // outputs wf_ext / wf_ssa [ngrid][nwavel][nlos][S], wf_alb [nwavel][nlos][S]
-    double *dacc, *wf_ext, *wf_ssa, *wf_alb;
+    // native weighting functions of the sources without a diffuse field (exact single scatter, emission, occultation): per-thread
+    // accumulators [slab][ray][S][3 ngrid + 2][64] -- extinction, ssa, albedo, emission profile, surface emission -- and the caller's outputs
+    // wf_ext / wf_ssa / wf_em [ngrid][nwavel][nlos][S], wf_alb / wf_sem [nwavel][nlos][S] (the two emission outputs may be null)
+    double *dacc, *wf_ext, *wf_ssa, *wf_alb, *wf_em, *wf_sem;
 };
 
 // pointers of one slab, advanced to this lane: element `item` of array X is X[item * kWave]
@@ -148,7 +149,7 @@ __device__ inline SoBufs slab_view(const SoGeo& g, const SoBufs& b, int slab, in
     v.lod += o * g.n_inc_layers + lane;
     v.lsrc += o * g.n_inc_layers * S + lane;
     if (v.sh) v.sh += o * g.ninterior * g.nlm + lane;
-    if (v.dacc) v.dacc += o * g.nlos * S * (2 * g.ngrid + 1) + lane;
+    if (v.dacc) v.dacc += o * g.nlos * S * (3 * g.ngrid + 2) + lane;
     return v;
 }
 
@@ -339,12 +340,12 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
 // (singlescattersource.cpp:988-1030, solartransmission.h:852-901, sourceintegrator.cpp:536-579).  One line of sight x 64 wavelengths per
 // wavefront; every lane accumulates into its own column of `dacc` (coalesced read-modify-writes, L1 / L2 resident).
 template <int S>
-__global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b) {
+__global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b, int single_scatter) {
     const DevRays& rs = g.los;
     const int w = blockIdx.x * kWave + threadIdx.x, r = blockIdx.y;
     const SoBufs v = slab_view(g, b, blockIdx.x, threadIdx.x);
     const int l0 = rs.layer_start[r], n = rs.layer_start[r + 1] - l0, e0 = rs.endpoint_start[r];
-    const int per = S == 3 ? 4 : 1, nlg_in = b.nleg * per, nm = min(g.num_ss_moments, b.nleg), ngrid = g.ngrid, nn = 2 * ngrid + 1;
+    const int per = S == 3 ? 4 : 1, nlg_in = b.nleg * per, nm = min(g.num_ss_moments, b.nleg), ngrid = g.ngrid, nn = 3 * ngrid + 2;
     const int ws = w < b.nw ? w : b.nw - 1;
     const double F = b.irradiance ? b.irradiance[ws] : 1.0, albedo = b.albedo[ws];
     double* acc = v.dacc + size_t(r) * S * nn * kWave;
@@ -357,7 +358,7 @@ __global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b) {
         return od;
     };
     auto transmission = [&](int e) -> double {
-        if (rs.solar_blocked[e]) return 0.0;
+        if (!single_scatter || rs.solar_blocked[e]) return 0.0;
         double od = 0;
         for (int t = rs.solar.start[e]; t < rs.solar.start[e + 1]; ++t) od += rs.solar.w[t] * v.kT[size_t(rs.solar.idx[t]) * kWave];
         return exp(-od) * F;
@@ -369,9 +370,15 @@ __global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b) {
     for (int s = 0; s < S; ++s) I[s] = 0;
     double prefix = 0;                       // optical depth of the layers behind the one in hand
     double T_exit = transmission(e0);        // far end of the ray
-    if (rs.ground_is_hit[r] && rs.ground_mu_in[r] > 0) {
+    // end-of-ray sources without scattering: surface emission (emission_source.cpp:156-173), unit source of an occultation (occultation.cpp:26-35)
+    if (g.emission != 0 && rs.ground_is_hit[r] && b.surface_emission) {
+        I[0] += b.surface_emission[ws];
+        add(0, 3 * ngrid + 1, exp(-total));
+    }
+    if (g.occultation && !rs.ground_is_hit[r]) I[0] += 1.0;
+    if (single_scatter && rs.ground_is_hit[r] && rs.ground_mu_in[r] > 0) {
         const double Bg = exp(-total), base = T_exit * rs.ground_mu_in[r] / kPi;
-        I[0] = base * albedo;
+        I[0] += base * albedo;
         add(0, 2 * ngrid, base * Bg);
         for (int t = rs.solar.start[e0]; t < rs.solar.start[e0 + 1]; ++t) add(0, rs.solar.idx[t], -rs.solar.w[t] * base * albedo * Bg);
     }
@@ -387,7 +394,31 @@ __global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b) {
 #pragma unroll
         for (int s = 0; s < S; ++s) I[s] *= att;
         const double T_ent = transmission(e0 + j + 1);
-        if (!rs.tiny[L]) {
+        if (g.emission != 0 && !rs.tiny[L]) {
+            // EmissionSource::integrated_source with its derivative rows (emission_source.cpp:37-152)
+            double oms = 0, ome = 0, es = 0, ee = 0;
+            for (int i = 0; i < 4; ++i) {
+                const int q = rs.stencil_idx[4 * L + i];
+                if (q < 0) continue;
+                const double om_q = v.omT[size_t(q) * kWave], em_q = v.emT[size_t(q) * kWave];
+                oms += om_q * rs.w_entrance[4 * L + i]; es += em_q * rs.w_entrance[4 * L + i];
+                ome += om_q * rs.w_exit[4 * L + i]; ee += em_q * rs.w_exit[4 * L + i];
+            }
+            const bool standard = g.emission == 1;
+            const double factor = standard ? 1 - att : rs.distance[L];
+            const double cell = standard ? (1 - oms) * es * rs.frac_start[L] + (1 - ome) * ee * rs.frac_end[L] : es * rs.frac_start[L] + ee * rs.frac_end[L];
+            I[0] += factor * cell;
+            if (standard)
+                for (int t = rs.od.start[L]; t < rs.od.start[L + 1]; ++t) add(0, rs.od.idx[t], rs.od.w[t] * att * cell * Bj);
+            for (int i = 0; i < 4; ++i) {
+                const int q = rs.stencil_idx[4 * L + i];
+                if (q < 0) continue;
+                const double wsn = rs.w_entrance[4 * L + i] * rs.frac_start[L], wen = rs.w_exit[4 * L + i] * rs.frac_end[L];
+                if (standard) add(0, ngrid + q, -factor * (wsn * es + wen * ee) * Bj);
+                add(0, 2 * ngrid + 1 + q, factor * (wsn * (standard ? 1 - oms : 1.0) + wen * (standard ? 1 - ome : 1.0)) * Bj);
+            }
+        }
+        if (single_scatter && !rs.tiny[L]) {
             const double sf = (fabs(od) < 1e-12) ? 1.0 : -expm1(-od) / od;
             const double dsf = (fabs(od) < 1e-12) ? -0.5 : 1 / od - sf * (1 + 1 / od);
             double quad_sum[S];
@@ -442,7 +473,7 @@ __global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b) {
 
 // accumulators -> the caller's layout (wf_ext / wf_ssa [ngrid][nwavel][nlos][S], wf_alb [nwavel][nlos][S]) in the configured Stokes basis
 __global__ void __launch_bounds__(256) k_so_deriv_out(SoGeo g, SoBufs b) {
-    const int S = g.S, nn = 2 * g.ngrid + 1, nlos = g.nlos;
+    const int S = g.S, nn = 3 * g.ngrid + 2, nlos = g.nlos;
     const size_t n = size_t(nn) * b.nw * nlos * S;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         const int s = int(i % S), r = int((i / S) % nlos), w = int((i / S / nlos) % b.nw), x = int(i / S / nlos / b.nw);
@@ -456,7 +487,10 @@ __global__ void __launch_bounds__(256) k_so_deriv_out(SoGeo g, SoBufs b) {
         double* dst;
         if (x < g.ngrid) dst = b.wf_ext + ((size_t(x) * b.nwavel_total + b.w0 + w) * nlos + r) * S + s;
         else if (x < 2 * g.ngrid) dst = b.wf_ssa + ((size_t(x - g.ngrid) * b.nwavel_total + b.w0 + w) * nlos + r) * S + s;
-        else dst = b.wf_alb + (size_t(b.w0 + w) * nlos + r) * S + s;
+        else if (x == 2 * g.ngrid) dst = b.wf_alb + (size_t(b.w0 + w) * nlos + r) * S + s;
+        else if (x <= 3 * g.ngrid) dst = b.wf_em ? b.wf_em + ((size_t(x - 2 * g.ngrid - 1) * b.nwavel_total + b.w0 + w) * nlos + r) * S + s : nullptr;
+        else dst = b.wf_sem ? b.wf_sem + (size_t(b.w0 + w) * nlos + r) * S + s : nullptr;
+        if (!dst) continue;
         *dst = b.accumulate ? *dst + val : val;
     }
 }
@@ -1047,7 +1081,8 @@ int SoDeviceEngine::nlos() const { return impl_->g.nlos; }
 int SoDeviceEngine::ngrid() const { return impl_->g.ngrid; }
 int SoDeviceEngine::nstokes() const { return impl_->g.S; }
 bool SoDeviceEngine::has_successive_orders() const { return impl_->multiple_scatter; }
-bool SoDeviceEngine::has_unlinearised_sources() const { return impl_->multiple_scatter || impl_->g.emission != 0 || impl_->g.occultation != 0; }
+bool SoDeviceEngine::has_unlinearised_sources() const { return impl_->multiple_scatter; }
+bool SoDeviceEngine::has_emission() const { return impl_->g.emission != 0; }
 void SoDeviceEngine::set_emission(const double* d_emission, const double* d_surface_emission) {
     impl_->d_emission = d_emission;
     impl_->d_surface_emission = d_surface_emission;
@@ -1086,7 +1121,7 @@ size_t SoDeviceEngine::bytes_per_wavelength() const { return so_doubles_per_wave
 
 void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg, const double* d_albedo,
                                   const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream, int accumulate,
-                                  double* d_wf_ext, double* d_wf_ssa, double* d_wf_alb) {
+                                  double* d_wf_ext, double* d_wf_ssa, double* d_wf_alb, double* d_wf_emission, double* d_wf_surface_emission) {
     Impl& I = *impl_;
     SoGeo& g = I.g;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1094,12 +1129,10 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     const int S = g.S, per = S == 3 ? 4 : 1;
     const bool derivs = d_wf_ext != nullptr;
     if (derivs && (!d_wf_ssa || !d_wf_alb)) throw std::runtime_error("sasktran2_amd: weighting functions need all three output buffers");
-    if (derivs && !I.single_scatter) throw std::runtime_error("sasktran2_amd: weighting functions requested from an engine without the exact single-scatter source");
     if (derivs && I.multiple_scatter) throw std::runtime_error("sasktran2_amd: the successive-orders source is not linearised");
-    if (derivs && (g.emission || g.occultation)) throw std::runtime_error("sasktran2_amd: the emission / occultation sources are not linearised");
     if (g.emission && !I.d_emission) throw std::runtime_error("sasktran2_amd: the engine has an emission source but no emission_source array was set (set_emission)");
     // block of wavelengths in flight: half of the free HBM (plus what this engine already holds), balanced blocks, multiple of the wavefront
-    const size_t deriv_doubles = derivs ? size_t(g.nlos) * S * (2 * g.ngrid + 1) : 0;
+    const size_t deriv_doubles = derivs ? size_t(g.nlos) * S * (3 * g.ngrid + 2) : 0;
     const size_t per_w = (so_doubles_per_wavelength(I, nleg) + deriv_doubles) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
@@ -1133,7 +1166,7 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             b.lsrc = I.scratch.alloc<double>(I.n_inc_layers * S * W);
             b.sh = g.nlm > 0 ? I.scratch.alloc<double>(size_t(g.ninterior) * g.nlm * W) : nullptr;
         }
-        b.dacc = I.cap_derivs ? I.scratch.alloc<double>(size_t(g.nlos) * S * (2 * g.ngrid + 1) * W) : nullptr;
+        b.dacc = I.cap_derivs ? I.scratch.alloc<double>(size_t(g.nlos) * S * (3 * g.ngrid + 2) * W) : nullptr;
         I.scratch_bytes = (so_doubles_per_wavelength(I, I.cap_nleg) + (I.cap_derivs ? size_t(g.nlos) * S * (2 * g.ngrid + 1) : 0)) * sizeof(double) * W;
     }
     for (int w0 = 0; w0 < nwavel; w0 += chunk) {
@@ -1157,6 +1190,8 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
         b.wf_ext = d_wf_ext;
         b.wf_ssa = d_wf_ssa;
         b.wf_alb = d_wf_alb;
+        b.wf_em = d_wf_emission;
+        b.wf_sem = d_wf_surface_emission;
         if (!derivs) b.dacc = nullptr;
         const unsigned wb = unsigned(b.nwp / kWave);
         {
@@ -1207,8 +1242,8 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
         }
         if (derivs) {
             SoTimer t(I, st, "so_los_derivatives");
-            if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_los_deriv<1>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_los_deriv<3>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b);
+            if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_los_deriv<1>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b, ss);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_los_deriv<3>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b, ss);
             hipLaunchKernelGGL(k_so_deriv_out, dim3(2048), dim3(256), 0, st, g, b);
         }
         SO_HIP_CHECK(hipGetLastError());

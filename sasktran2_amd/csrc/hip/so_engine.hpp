@@ -22,13 +22,17 @@ class SoDeviceEngine {
     // All pointers are DEVICE pointers in the reference storage layout (location fastest):
     //   ext, ssa [nwavel][ngrid]; leg [nwavel][ngrid][nleg (x 4: a1, a2, a3, b1 for NSTOKES = 3)]; albedo / irradiance [nwavel] (irradiance may be null).
     // Outputs: radiance [nwavel][nlos][nstokes] (accumulate != 0: added to what is there), los_od [nwavel][nlos] (may be null).
-    // Native weighting functions of the exact single-scatter source (engines without the successive-orders source only):
-    // wf_ext / wf_ssa [ngrid][nwavel][nlos][nstokes], wf_alb [nwavel][nlos][nstokes], all three or none; `accumulate` applies to them too.
+    // Native weighting functions of the sources without a diffuse field -- exact single scatter, line-of-sight emission, occultation -- (engines
+    // without the successive-orders source only): wf_ext / wf_ssa [ngrid][nwavel][nlos][nstokes], wf_alb [nwavel][nlos][nstokes], all three or
+    // none; with an emission source also wf_emission [ngrid][nwavel][nlos][nstokes] and wf_surface_emission [nwavel][nlos][nstokes] (either may
+    // be null); `accumulate` applies to them too.
     void solve_device(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg, const double* d_albedo,
                       const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream, int accumulate = 0,
-                      double* d_wf_ext = nullptr, double* d_wf_ssa = nullptr, double* d_wf_alb = nullptr);
+                      double* d_wf_ext = nullptr, double* d_wf_ssa = nullptr, double* d_wf_alb = nullptr, double* d_wf_emission = nullptr,
+                      double* d_wf_surface_emission = nullptr);
     bool has_successive_orders() const;
-    bool has_unlinearised_sources() const;   // successive orders, emission or occultation: no weighting functions
+    bool has_unlinearised_sources() const;   // successive orders: no weighting functions
+    bool has_emission() const;               // line-of-sight emission source (standard / volume_emission_rate)
     // emission_source [nwavel][ngrid] and surface emission [nwavel] (DEVICE pointers, or null) used by the following solve_device calls of an
     // engine built with an emission source
     void set_emission(const double* d_emission, const double* d_surface_emission);

@@ -101,9 +101,12 @@ def build_so_engine(s, **override):
 
 def run_product_so(s, engine=None, solar_irradiance=None, derivatives=False, emission_source=None, surface_emission=None, **override):
     """Radiances [wavelength, los, stokes] and LOS optical depths of the exact single-scatter / successive-orders path; with
-    `derivatives` the weighting functions in the oracle's convention ([wavelength, los, stokes, altitude])."""
+    `derivatives` the weighting functions in the oracle's convention ([wavelength, los, stokes, altitude]); with an emission source also
+    d_emission / d_surface_emission through "wf_emission" / "wf_surface_emission" mappings with d_emission = 1."""
+    import ctypes
     engine, config, geometry = engine if engine is not None else build_so_engine(s, **override)
-    nw = s["extinction"].shape[1]
+    ng, nw = s["extinction"].shape
+    nlos, S = len(s["rays"]), int(config.num_stokes)
     atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=derivatives)
     atmosphere.storage.total_extinction[:] = s["extinction"]
     atmosphere.storage.ssa[:] = s["ssa"]
@@ -115,12 +118,35 @@ def run_product_so(s, engine=None, solar_irradiance=None, derivatives=False, emi
     if surface_emission is not None:
         atmosphere.surface.emission[:] = surface_emission
     atmosphere.surface.albedo[:] = s["albedo"]
-    res = engine.calculate_radiance(atmosphere, as_dataset=False)
+    dp, vp = ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
+    with_emission = derivatives and int(config.emission_source) in (int(sk.EmissionSource.Standard), int(sk.EmissionSource.VolumeEmissionRate))
+
+    def hook(L, h_st, h_out, out):
+        def fill(getter, mapping, values):
+            f = getattr(L, getter)
+            f.argtypes = [vp, ctypes.POINTER(dp)]
+            ptr = dp()
+            assert f(mapping, ctypes.byref(ptr)) == 0
+            np.ctypeslib.as_array(ptr, shape=(values.size,))[:] = values
+        m = vp()
+        L.sk_atmosphere_storage_get_derivative_mapping(h_st, b"wf_emission", ctypes.byref(m))
+        fill("sk_deriv_mapping_get_d_emission", m, np.ones(ng * nw))
+        out["wf_emission"] = np.zeros((ng, nw, nlos, S))
+        L.sk_output_assign_derivative_memory(h_out, b"wf_emission", out["wf_emission"].ctypes.data_as(dp), nw * nlos, S, ng)
+        L.sk_surface_get_derivative_mapping(out["_surface_handle"], b"wf_surface_emission", ctypes.byref(m))
+        fill("sk_surface_deriv_mapping_get_d_emission", m, np.ones(nw))
+        out["wf_surface_emission"] = np.zeros((nw, nlos, S))
+        L.sk_output_assign_surface_derivative_memory(h_out, b"wf_surface_emission", out["wf_surface_emission"].ctypes.data_as(dp), nw * nlos, S)
+
+    res = engine.calculate_radiance(atmosphere, as_dataset=False, _mapping_hook=hook if with_emission else None)
     out = {"radiance": res["radiance"], "los_optical_depth": res["los_optical_depth"]}
     if derivatives:
         out["d_extinction"] = np.transpose(res["wf_extinction"], (1, 2, 3, 0))
         out["d_ssa"] = np.transpose(res["wf_ssa"], (1, 2, 3, 0))
         out["d_albedo"] = res["wf_albedo"]
+        if with_emission:
+            out["d_emission"] = np.transpose(res["wf_emission"], (1, 2, 3, 0))
+            out["d_surface_emission"] = res["wf_surface_emission"]
     return out
 
 

@@ -164,5 +164,23 @@ def test_emission_and_occultation_sources_match_oracle(nstokes, emission):
     ref = make_so_oracle(s, **alone).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], emission=em, surface_emission=sem)
     got = run_product_so(s, emission_source=em, surface_emission=sem, **alone)
     assert_so_parity(got, ref)
+    # the line-of-sight sources are linearised (emission_source.cpp:100-173): extinction, ssa, emission profile, surface emission
+    ref = make_so_oracle(s, **alone).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], emission=em, surface_emission=sem, derivatives=True)
+    got = run_product_so(s, emission_source=em, surface_emission=sem, derivatives=True, **alone)
+    assert_so_parity(got, ref)
+    for k in ("d_extinction", "d_ssa", "d_emission"):
+        scale = np.maximum(np.abs(ref[k]).max(axis=3, keepdims=True), 1e-300)
+        assert np.max(np.abs(got[k] - ref[k]) / scale) < 1e-10, k
+    np.testing.assert_allclose(got["d_surface_emission"], ref["d_surface_emission"], rtol=1e-12, atol=1e-300)
+    # ... and next to the exact single scatter
+    both = dict(o, multiple_scatter="none")
+    ref = make_so_oracle(s, **both).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], emission=em, surface_emission=sem, derivatives=True)
+    got = run_product_so(s, emission_source=em, surface_emission=sem, derivatives=True, **both)
+    assert_so_parity(got, ref)
+    for k in ("d_extinction", "d_ssa", "d_emission"):
+        scale = np.maximum(np.abs(ref[k]).max(axis=3, keepdims=True), 1e-6 * np.abs(ref["d_extinction"]).max())
+        assert np.max(np.abs(got[k] - ref[k]) / scale) < 1e-9, k
+    np.testing.assert_allclose(got["d_albedo"], ref["d_albedo"], rtol=1e-10, atol=1e-300)
+    # the successive-orders source stays without weighting functions
     with pytest.raises(RuntimeError, match="weighting functions are not available"):
-        run_product_so(s, emission_source=em, surface_emission=sem, derivatives=True, **alone)
+        run_product_so(s, emission_source=em, surface_emission=sem, derivatives=True, **o)

@@ -148,3 +148,44 @@ def test_emission_and_occultation_sources_have_their_closed_forms():
     for r, cvz in ((0, 0.32), (1, 0.78)):
         path = -R * cvz + np.sqrt((R * cvz) ** 2 + 2 * R * top + top * top)
         np.testing.assert_allclose(thin["radiance"][:, r, 0], 2.0 * path, rtol=1e-9)
+
+
+@pytest.mark.parametrize("config", [dict(emission="standard"), dict(emission="volume_emission_rate"), dict(occultation=True),
+                                    dict(emission="standard", single_scatter="exact")],
+                         ids=["standard emission", "volume emission rate", "occultation", "emission + exact single scatter"])
+def test_emission_and_occultation_weighting_functions_match_finite_differences(config):
+    """Weighting functions of the line-of-sight sources without scattering (EmissionSource::integrated_source / end_of_ray_source with their
+    derivative rows, cpp/lib/emission/emission_source.cpp:100-173; the occultation source is differentiated through the path transmission):
+    analytic == central finite differences with respect to extinction, single scatter albedo, the emission profile and the surface emission."""
+    s = sc.regression_so(nstokes=1)
+    base = dict(single_scatter="none", multiple_scatter="none")
+    base.update(config)
+    eng = make_so_oracle(s, **base)
+    nw = s["extinction"].shape[1]
+    alt = s["geometry"]["altitudes"]
+    em = (2.0e-4 + 1.0e-4 * np.exp(-alt / 20_000.0))[:, None] * np.linspace(1.0, 1.3, nw)[None, :]
+    sem = np.linspace(5e-4, 7e-4, nw)
+    args = dict(extinction=s["extinction"], ssa=s["ssa"], emission=em, surface_emission=sem)
+
+    def run(derivatives=False, **over):
+        a = dict(args, **over)
+        return eng.run(a["extinction"], a["ssa"], s["leg"], s["albedo"], derivatives=derivatives, emission=a["emission"],
+                       surface_emission=a["surface_emission"])
+
+    ref = run(True)
+    scale = np.max(np.abs(ref["radiance"]))
+    for name, key in (("d_extinction", "extinction"), ("d_ssa", "ssa"), ("d_emission", "emission")):
+        for q in (0, 3, 11, 24):
+            x = np.array(args[key], copy=True)
+            h = (0.1 if key == "emission" else 1e-5) * x[q, 1] if x[q, 1] != 0 else 1e-9   # (the radiance is linear in the emission: any step)
+            xp, xm = x.copy(), x.copy()
+            xp[q, 1] += h
+            xm[q, 1] -= h
+            fd = (run(**{key: xp})["radiance"][1] - run(**{key: xm})["radiance"][1]) / (2 * h)
+            an = ref[name][1, :, :, q]
+            assert np.max(np.abs(fd - an)) <= 2e-6 * max(np.max(np.abs(an)), scale / abs(x[q, 1]) * 1e-6), (name, q)
+    h = 1e-4
+    fd = (run(surface_emission=sem + h)["radiance"] - run(surface_emission=sem - h)["radiance"]) / (2 * h)
+    np.testing.assert_allclose(ref["d_surface_emission"], fd, rtol=1e-6, atol=1e-9)
+    if "emission" not in config:
+        assert np.all(ref["d_emission"] == 0) and np.all(ref["d_surface_emission"] == 0)
