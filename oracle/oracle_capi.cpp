@@ -194,7 +194,8 @@ void* orso_create(double cos_sza, double saa, double earth_radius, const double*
         cfg.num_incoming = num_incoming;
         cfg.num_outgoing = num_outgoing;
         cfg.num_sza = num_sza;
-        cfg.single_scatter = single_scatter != 0;
+        cfg.single_scatter = single_scatter != 0;   // 1: exact, 2: solar table
+        cfg.solar_table = single_scatter == 2;
         cfg.multiple_scatter = multiple_scatter != 0;
         cfg.emission = emission;
         cfg.occultation = occultation != 0;

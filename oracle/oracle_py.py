@@ -142,7 +142,7 @@ class SoOracleEngine:
         self._h = L.orso_create(cos_sza, saa, earth_radius, _p(self.alt), self.ngrid, interp_method, geotype, self.nlos,
                                 kinds.ctypes.data_as(_ip), _p(params), int(nstokes), int(stokes_basis), int(num_ss_moments),
                                 int(num_ms_moments), int(num_incoming), int(num_outgoing), int(num_sza), int(num_iterations),
-                                int(single_scatter), int(multiple_scatter), int(emission), int(occultation))
+                                int(single_scatter), int(multiple_scatter), int(emission), int(occultation))   # single_scatter: 0 none, 1 exact, 2 solar table
         if not self._h:
             raise RuntimeError("successive-orders oracle construction failed")
 

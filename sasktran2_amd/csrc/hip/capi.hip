@@ -375,13 +375,14 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
         if (c->num_stokes != 1 && c->num_stokes != 3) throw std::runtime_error("NSTOKES must be 1 or 3");
         if (c->stokes_basis < 0 || c->stokes_basis > 2) throw std::runtime_error("stokes_basis must be standard (0), solar (1) or observer (2)");
         // sources of this build (cpp/include/sasktran2/config.h:41-71): multiple scatter discrete_ordinates (0), successive_orders_legacy (1),
-        // twostream (2) or none (3); single scatter exact (0), discrete_ordinates (2) or none (3)
+        // twostream (2) or none (3); single scatter exact (0), solartable (1), discrete_ordinates (2) or none (3)
         if (c->ms_source < 0 || c->ms_source > 3)
             throw std::runtime_error("multiple_scatter_source must be discrete_ordinates (0), successive_orders_legacy (1), twostream (2) or none (3); "
                                      "successive_orders (4) is not part of this build");
         const bool two_stream = c->ms_source == 2 || c->emission_source == 4;
-        if (c->ss_source != 0 && c->ss_source != 2 && c->ss_source != 3)
-            throw std::runtime_error("single_scatter_source must be exact (0), discrete_ordinates (2) or none (3); solartable (1) is not part of this build");
+        if (c->ss_source < 0 || c->ss_source > 3)
+            throw std::runtime_error("single_scatter_source must be exact (0), solartable (1), discrete_ordinates (2) or none (3)");
+        const bool ss_los = c->ss_source == 0 || c->ss_source == 1;   // single scatter integrated along the lines of sight (exact or tabulated solar transmission)
         if (c->ss_source == 2 && c->ms_source != 0) throw std::runtime_error("single_scatter_source = discrete_ordinates needs multiple_scatter_source = discrete_ordinates");
         // do_backprop selects the reverse-mode linearisation of the reference's discrete-ordinates source; the two-stream source is
         // linearised in reverse mode whatever the flag says (the reference's two-stream tests all set it)
@@ -417,7 +418,7 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
             e->ngrid = dg.ngrid;
             if (c->emission_source == 2 && e->dev->vector_mode())
                 throw std::runtime_error("emission_source = discrete_ordinates needs a stream count of the matrix-core path (2, 4, 8, 16 or 32)");
-            if (c->ss_source == 0 && !dg.spherical_pp)
+            if (ss_los && !dg.spherical_pp)
                 throw std::runtime_error("single_scatter_source = exact with discrete ordinates needs spherical geometry (in plane-parallel "
                                          "geometry the discrete-ordinates source carries the single scatter itself)");
         }
@@ -430,7 +431,7 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
             skts::build_ts_geometry(geo, v->rays, cfg, tg);
             e->ts = std::make_unique<skdev::TsDeviceEngine>(tg);
         }
-        if (c->ss_source == 0 || c->ms_source == 1 || emission != 0 || occultation) {
+        if (ss_los || c->ms_source == 1 || emission != 0 || occultation) {
             if (g->geotype != 2) throw std::runtime_error("the exact single-scatter, successive-orders, emission and occultation sources need spherical geometry");
             if (c->ms_source == 1 && (c->initialize_hr_with_do || c->num_hr_full_incoming_points > 0))
                 throw std::runtime_error("initialize_hr_with_do and num_hr_full_incoming_points are not part of this build");
@@ -441,7 +442,8 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
             cfg.num_incoming = c->num_hr_incoming;
             cfg.num_outgoing = c->num_hr_outgoing;
             cfg.num_sza = c->num_sza;
-            cfg.single_scatter = c->ss_source == 0;
+            cfg.single_scatter = ss_los;
+            cfg.solar_table = c->ss_source == 1;
             cfg.multiple_scatter = c->ms_source == 1;
             cfg.emission = emission;
             cfg.occultation = occultation;

@@ -215,6 +215,7 @@ struct Settings {
     int num_incoming = 110, num_outgoing = 110;
     int num_sza = 1;               // Config::num_do_sza
     bool single_scatter = true;    // SingleScatterSource::Exact on the lines of sight
+    bool solar_table = false;      // SingleScatterSource::SolarTable: solar optical depths of the lines of sight interpolated in an (altitude, cos sza) table
     bool multiple_scatter = true;  // MultipleScatterSource::SuccessiveOrdersLegacy
     // line-of-sight source terms without scattering (cpp/lib/emission/emission_source.cpp, cpp/lib/solar/occultation.cpp)
     int emission = 0;              // 0 none, 1 EmissionSource::standard ((1 - ssa) x emission_source, e.g. Planck), 2 volume_emission_rate
@@ -390,6 +391,41 @@ inline std::pair<double, double> min_max_cos_sza(const std::vector<skgeo::Traced
 }
 }  // namespace detail
 
+// Solar transmission of SingleScatterSource<SolarTransmissionTable> at every layer boundary of every ray: the optical depth toward the sun
+// interpolated (bilinear in altitude and cos sza) in a table over the altitude grid x 100 cosines between the smallest and largest cos(SZA) the
+// rays meet (SolarTransmissionTable::initialize_geometry / generate_interpolation_matrix, solartransmissiontable.cpp:113-238).  Optical depth
+// is linear in the extinction profile, so the interpolation is folded into one stencil over the atmosphere grid per boundary -- the consumers
+// see the same rows as for the exact source.  Table points whose solar ray hits the ground keep an empty row (optical depth 0) and nothing
+// is flagged as blocked, as in the reference.
+inline void table_solar(const skgeo::Geometry1D& geo, const skgeo::SphericalShellRayTracer& tracer, const std::vector<skgeo::TracedRay>& rays, RaySet& rs) {
+    using namespace detail;
+    const auto mm = min_max_cos_sza(rays);
+    LocationInterpolator ti;
+    ti.alt = skgeo::Grid(geo.alt.v, skgeo::constant_spacing, skgeo::linear);
+    ti.csz = skgeo::Grid(skgeo::linspaced(100, mm.first, mm.second), skgeo::constant_spacing, skgeo::linear);
+    const int ng = geo.ngrid();
+    std::vector<double> table(size_t(ti.num_interior()) * ng, 0.0), dense(ng);
+    for (int i = 0; i < ti.num_interior(); ++i) {
+        skgeo::Location from;
+        from.position = ti.grid_location(geo.coords, i);
+        if (solar_row(geo, tracer, from, dense)) std::copy(dense.begin(), dense.end(), table.begin() + size_t(i) * ng);
+    }
+    std::vector<std::pair<int, double>> w;
+    auto endpoint = [&](const skgeo::Location& loc) {
+        ti.interior_weights(geo.coords, loc.position, w);
+        std::fill(dense.begin(), dense.end(), 0.0);
+        for (auto& e : w)
+            for (int q = 0; q < ng; ++q) dense[q] += e.second * table[size_t(e.first) * ng + q];
+        push_dense(rs.solar, dense);
+        rs.solar_blocked.push_back(0);
+    };
+    for (const auto& ray : rays)
+        for (int j = 0; j < (int)ray.layers.size(); ++j) {
+            if (j == 0) endpoint(ray.layers[j].exit);
+            endpoint(ray.layers[j].entrance);
+        }
+}
+
 // Builds everything.  `specs` are the lines of sight.
 inline void build_so_geometry(const skgeo::Geometry1D& geo, const std::vector<skgeo::RaySpec>& specs, const Settings& cfg, SoGeometry& g, int stokes_basis = 0) {
     using namespace detail;
@@ -412,7 +448,8 @@ inline void build_so_geometry(const skgeo::Geometry1D& geo, const std::vector<sk
         g.stokes_S.push_back(Sn);
     }
     append_rays(geo, los, cfg.num_ss_moments, S, g.los);
-    exact_solar(geo, tracer, los, g.los);
+    if (cfg.solar_table) table_solar(geo, tracer, los, g.los);
+    else exact_solar(geo, tracer, los, g.los);
     if (!cfg.multiple_scatter) return;
 
     // ---- diffuse points (DiffuseTable::initialize_geometry, construct_diffuse_points)

@@ -73,7 +73,7 @@ def build_so_engine(s, **override):
     config.num_streams = c["num_streams"]
     config.num_singlescatter_moments = c["num_singlescatter_moments"]
     config.num_sza = c["num_sza"]
-    config.single_scatter_source = {"exact": sk.SingleScatterSource.Exact, "none": sk.SingleScatterSource.NoSource}[c["single_scatter"]]
+    config.single_scatter_source = {"exact": sk.SingleScatterSource.Exact, "solartable": sk.SingleScatterSource.SolarTable, "none": sk.SingleScatterSource.NoSource}[c["single_scatter"]]
     config.multiple_scatter_source = {"successive_orders_legacy": sk.MultipleScatterSource.SuccessiveOrdersLegacy,
                                       "discrete_ordinates": sk.MultipleScatterSource.DiscreteOrdinates,
                                       "none": sk.MultipleScatterSource.NoSource}[c["multiple_scatter"]]
@@ -160,7 +160,7 @@ def build_ts_engine(s, solar=True, thermal=False, single_scatter="none", delta_m
     config.do_backprop = True
     config.num_singlescatter_moments = s["leg"].shape[0]
     config.delta_m_scaling = delta_m
-    config.single_scatter_source = {"exact": sk.SingleScatterSource.Exact, "none": sk.SingleScatterSource.NoSource}[single_scatter]
+    config.single_scatter_source = {"exact": sk.SingleScatterSource.Exact, "solartable": sk.SingleScatterSource.SolarTable, "none": sk.SingleScatterSource.NoSource}[single_scatter]
     config.multiple_scatter_source = sk.MultipleScatterSource.TwoStream if solar else sk.MultipleScatterSource.NoSource
     config.emission_source = sk.EmissionSource.TwoStream if thermal else sk.EmissionSource.NoSource
     geometry = sk.Geometry1D(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"],

@@ -184,3 +184,26 @@ def test_emission_and_occultation_sources_match_oracle(nstokes, emission):
     # the successive-orders source stays without weighting functions
     with pytest.raises(RuntimeError, match="weighting functions are not available"):
         run_product_so(s, emission_source=em, surface_emission=sem, derivatives=True, **o)
+
+
+@pytest.mark.parametrize("nstokes", [1, 3])
+def test_solar_table_single_scatter(nstokes):
+    """single_scatter_source = solartable (SingleScatterSource<SolarTransmissionTable>, cpp/lib/solar/solartransmissiontable.cpp:113-238): the
+    solar optical depths of the line-of-sight boundaries come from the (altitude, cos sza) table the successive-orders source uses for its own
+    first order (pinned with it on the reference's regression) instead of a ray trace per boundary: device == oracle, and both within the
+    table's interpolation error of the exact source."""
+    from tests.test_so_oracle import make_so_oracle
+    s = sc.regression_so(nstokes=nstokes, num_wavelengths=3)
+    o = dict(single_scatter="solartable", multiple_scatter="none")
+    ref = make_so_oracle(s, **o).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
+    got = run_product_so(s, derivatives=True, **o)
+    assert_so_parity(got, ref)
+    for k in ("d_extinction", "d_ssa"):
+        scale = np.maximum(np.abs(ref[k]).max(axis=3, keepdims=True), 1e-6 * np.abs(ref[k]).max())
+        assert np.max(np.abs(got[k] - ref[k]) / scale) < 1e-9, k
+    exact = run_product_so(s, single_scatter="exact", multiple_scatter="none")
+    np.testing.assert_allclose(got["radiance"][..., 0], exact["radiance"][..., 0], rtol=2e-4)
+    assert np.max(np.abs(got["radiance"][..., 0] / exact["radiance"][..., 0] - 1)) > 1e-9   # (it IS another source)
+    # with the successive orders on top
+    both = dict(single_scatter="solartable", multiple_scatter="successive_orders_legacy")
+    assert_so_parity(run_product_so(s, **both), make_so_oracle(s, **both).run(s["extinction"], s["ssa"], s["leg"], s["albedo"]))

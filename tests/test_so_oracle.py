@@ -12,7 +12,7 @@ def make_so_oracle(s, **override):
     return SoOracleEngine(g["cos_sza"], g["saa"], g["earth_radius"], g["altitudes"], g["interp_method"], g["geotype"], s["rays"],
                           nstokes=c["nstokes"], stokes_basis=c.get("stokes_basis", 0), num_ss_moments=c["num_singlescatter_moments"],
                           num_ms_moments=c["num_streams"], num_incoming=c["num_incoming"], num_outgoing=c["num_outgoing"],
-                          num_sza=c["num_sza"], num_iterations=c["num_iterations"], single_scatter=c["single_scatter"] == "exact",
+                          num_sza=c["num_sza"], num_iterations=c["num_iterations"], single_scatter={"none": 0, "exact": 1, "solartable": 2}[c["single_scatter"]],
                           multiple_scatter=c["multiple_scatter"] == "successive_orders_legacy",
                           emission={"none": 0, "standard": 1, "volume_emission_rate": 2}[c.get("emission", "none")],
                           occultation=bool(c.get("occultation", False)))
@@ -189,3 +189,23 @@ def test_emission_and_occultation_weighting_functions_match_finite_differences(c
     np.testing.assert_allclose(ref["d_surface_emission"], fd, rtol=1e-6, atol=1e-9)
     if "emission" not in config:
         assert np.all(ref["d_emission"] == 0) and np.all(ref["d_surface_emission"] == 0)
+
+
+def test_solar_table_single_scatter_is_close_to_the_exact_source():
+    # SingleScatterSource<SolarTransmissionTable>: 100 cosines x the altitude grid, bilinear in optical depth (solartransmissiontable.cpp:113-238)
+    s = sc.regression_so(nstokes=1)
+    exact = make_so_oracle(s, multiple_scatter="none").run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
+    table = make_so_oracle(s, multiple_scatter="none", single_scatter="solartable").run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
+    np.testing.assert_allclose(table["radiance"], exact["radiance"], rtol=2e-4)
+    assert np.max(np.abs(table["radiance"] / exact["radiance"] - 1)) > 1e-9
+    assert np.max(np.abs(table["d_extinction"] - exact["d_extinction"])) < 1e-3 * np.max(np.abs(exact["d_extinction"]))
+    # analytic == finite differences for the tabulated source as well
+    k = s["extinction"]
+    eng = make_so_oracle(s, multiple_scatter="none", single_scatter="solartable")
+    for q in (2, 9, 17):
+        h = 1e-5 * k[q, 0]
+        kp, km = k.copy(), k.copy()
+        kp[q, 0] += h
+        km[q, 0] -= h
+        fd = (eng.run(kp, s["ssa"], s["leg"], s["albedo"])["radiance"][0] - eng.run(km, s["ssa"], s["leg"], s["albedo"])["radiance"][0]) / (2 * h)
+        assert np.max(np.abs(fd - table["d_extinction"][0, :, :, q])) < 1e-6 * np.max(np.abs(table["d_extinction"][0]))
