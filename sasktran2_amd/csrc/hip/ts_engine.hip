@@ -51,6 +51,18 @@ k_ts_up(const skt::Geo g, const skt::Bufs b) {
     if (DERIVS) skt::view_adjoint_thread<SOLAR, false, false, true>(g, b, w, 0, lds + threadIdx.x, kWave);
     else skt::fused_radiance_thread<SOLAR>(g, b, w);
 }
+// (wavelength block, line of sight) of a workgroup of the adjoint sweep.  The lines of sight of one wavelength block read the same layer
+// parameters and LU rows: their workgroups get consecutive ids ON THE SAME XCD (workgroup i runs on XCD i mod 8), so that those rows are
+// fetched into one L2 once instead of eight times (6.5 -> 6.2 ms at 25 lines of sight x 10 000 wavelengths).  The forward sweep is better off
+// with the plain (wavelength block fastest) order: neighbours then share a line of sight and with it the scalar-cache lines of its segments.
+__device__ inline bool view_block(int nwb, int nlos, int& wblock, int& view) {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    view = slot % nlos;
+    wblock = (slot / nlos) * 8 + xcd;
+    return wblock < nwb;
+}
+inline unsigned view_grid(int nwb, int nlos) { return unsigned((nwb + 7) / 8 * 8 * nlos); }
+
 template <bool SOLAR, bool DERIVS, bool SPHERICAL> __global__ void __launch_bounds__(kWave) k_ts_view(const skt::Geo g, const skt::Bufs b) {
     const int w = blockIdx.x * kWave + threadIdx.x;
     if (w >= b.nw) return;
@@ -59,9 +71,11 @@ template <bool SOLAR, bool DERIVS, bool SPHERICAL> __global__ void __launch_boun
 // two wavefronts per SIMD: the plane-parallel solar instance needs a few registers more than the 256 that allows, a handful of spills is the better trade
 template <bool SOLAR, bool SPHERICAL> __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(TS_ADJOINT_WAVES))) k_ts_adjoint(const skt::Geo g, const skt::Bufs b) {
     extern __shared__ double lds[];
-    const int w = blockIdx.x * kWave + threadIdx.x;
+    int wblock, view;
+    if (!view_block((b.nw + kWave - 1) / kWave, g.nlos, wblock, view)) return;
+    const int w = wblock * kWave + threadIdx.x;
     if (w >= b.nw) return;
-    skt::view_adjoint_thread<SOLAR, SPHERICAL>(g, b, w, blockIdx.y, lds + threadIdx.x, kWave);
+    skt::view_adjoint_thread<SOLAR, SPHERICAL>(g, b, w, view, lds + threadIdx.x, kWave);
 }
 template <bool SOLAR, bool DERIVS> void launch_view(bool spherical, dim3 grid, hipStream_t st, const skt::Geo& g, const skt::Bufs& b) {
     if (spherical) hipLaunchKernelGGL((k_ts_view<SOLAR, DERIVS, true>), grid, dim3(kWave), 0, st, g, b);
@@ -273,7 +287,7 @@ void TsDeviceEngine::solve_device(int nwavel, const Inputs& in, const Outputs& o
     for (int w0 = 0; w0 < nwavel; w0 += chunk) {
         b.w0 = w0;
         b.nw = std::min(chunk, nwavel - w0);
-        const dim3 grid_w((b.nw + kWave - 1) / kWave), grid_v((b.nw + kWave - 1) / kWave, g.nlos);
+        const dim3 grid_w((b.nw + kWave - 1) / kWave), grid_v((b.nw + kWave - 1) / kWave, g.nlos), grid_a(view_grid((b.nw + kWave - 1) / kWave, g.nlos));
         int pass = 0;
         for (int solar = 1; solar >= 0; --solar) {
             if (solar ? !I.cfg.solar : !I.cfg.thermal) continue;
@@ -318,8 +332,8 @@ void TsDeviceEngine::solve_device(int nwavel, const Inputs& in, const Outputs& o
             }
             if (derivs) {
                 TsTimer t(I, st, solar ? "ts_adjoint" : "ts_adjoint_thermal");
-                if (solar) launch_adjoint<true>(g.spherical != 0, grid_v, lds_bytes, st, g, b);
-                else launch_adjoint<false>(g.spherical != 0, grid_v, lds_bytes, st, g, b);
+                if (solar) launch_adjoint<true>(g.spherical != 0, grid_a, lds_bytes, st, g, b);
+                else launch_adjoint<false>(g.spherical != 0, grid_a, lds_bytes, st, g, b);
             }
             TS_HIP_CHECK(hipGetLastError());
             ++pass;
