@@ -153,6 +153,38 @@ int sk_amd_ts_engine_solve_device(Engine* engine, int nwavel, int nleg, const do
                                   const double* d_surface_emission, double* d_radiance, double* d_los_od, double* d_wf_ext, double* d_wf_ssa,
                                   double* d_wf_b1, double* d_wf_albedo, double* d_wf_emission, double* d_wf_surface_emission, void* stream,
                                   int max_chunk);
+/* ---- optical-property front end on the device ----
+ * Replaces, for the constituents whose contribution is (a sum of) profile x spectrum, what the reference's Rust front end does on the host:
+ * Constituent::add_to_atmosphere / register_derivatives (rust/sasktran2-rs/src/constituent/types/rayleigh.rs:110-258,
+ * vmr_alt_absorber.rs:64-260, number_density_scatterer.rs:218-440, emission.rs:52-116) and AtmosphereStorage::normalize_by_extinctions
+ * (rust/sasktran2-rs/src/bindings/atmosphere_storage.rs:113-153).  The caller hands over what is small -- amount profiles [nlocation],
+ * spectra [nwavel] -- and the storage arrays [nwavel][nlocation] and every derivative mapping are formed in HBM; the storage handle goes
+ * to sk_atmosphere_create / sk_engine_calculate_radiance like one built by sk_atmosphere_storage_create, without an upload.  Host-array
+ * accessors of such a mapping (sk_deriv_mapping_get_d_ssa ...) and sk_atmosphere_storage_set_zero return -2; sk_amd_frontend_download
+ * copies the arrays for inspection.  sk_atmosphere_apply_delta_m_scaling scales storage and mappings in place on the device. */
+typedef struct FrontEnd sk_amd_frontend;
+sk_amd_frontend* sk_amd_frontend_create(int nlocation, int nwavel, int nleg /* first dimension of leg_coeff */, int nstokes);
+void sk_amd_frontend_destroy(sk_amd_frontend* f);
+int sk_amd_frontend_reset(sk_amd_frontend* f);   /* forget terms, mappings, emission */
+/* one rank-one term: amount profile [nlocation] x extinction cross section [nwavel]; scat (scattering cross section [nwavel]) and
+ * leg (phase moments per scattering event [nwavel][nleg]) may be NULL.  Returns the term's index (>= 0) or an error (< 0). */
+int sk_amd_frontend_add_term(sk_amd_frontend* f, const double* profile, const double* ext, const double* scat, const double* leg);
+int sk_amd_frontend_set_profile(sk_amd_frontend* f, int term, const double* profile);
+/* emission[q][w] += Planck radiance B(temperature_k[q], wavelengths_nm[w]) in W / (m^2 sr nm)  (emission.rs:9-16) */
+int sk_amd_frontend_set_planck_emission(sk_amd_frontend* f, const double* temperature_k, const double* wavelengths_nm);
+int sk_amd_frontend_set_solar_irradiance(sk_amd_frontend* f, const double* irradiance /* [nwavel] or NULL */);
+int sk_amd_frontend_assemble(sk_amd_frontend* f);
+/* a derivative mapping from (term index, per-location weight) pairs: e = sum_r weight_r[q] ext_r[w], s = sum_r weight_r[q] scat_r[w] ->
+ * d_extinction = e, d_ssa = e (s / e - ssa) / k, and for scatterer != 0 scat_factor = s / (ssa k), d_legendre = P / s - leg_coeff.
+ * weights: host [nterms][nlocation] or NULL (1); planck_temperature != 0: d_emission = dB/dT; interpolator: host, column major
+ * [nlocation x nout], or NULL; interp_dim / assign_name as deriv_mapping.h:32,40. */
+int sk_amd_frontend_add_mapping(sk_amd_frontend* f, const char* name, int nterms, const int* terms, const double* weights, int scatterer,
+                                int planck_temperature, const double* interpolator, int nout, const char* interp_dim, const char* assign_name);
+AtmosphereStorage* sk_amd_frontend_storage(sk_amd_frontend* f);   /* borrowed: valid until the front end is destroyed, reset or assembled again */
+/* what = "extinction" | "ssa" | "leg_coeff" | "emission" | "delta_f" | "<mapping>:d_extinction" | ":d_ssa" | ":scat_factor" |
+ * ":d_legendre" | ":d_emission" | ":d_f" */
+int sk_amd_frontend_device_pointer(sk_amd_frontend* f, const char* what, const double** pointer, unsigned long long* count);
+int sk_amd_frontend_download(sk_amd_frontend* f, const char* what, double* host_destination);
 /* sizes[0..5]: incoming rays, their layers, accumulation-matrix entries, outgoing directions, scratch bytes per wavelength,
  * wavelengths per block of the last solve */
 int sk_amd_so_engine_sizes(Engine* engine, unsigned long long* sizes);

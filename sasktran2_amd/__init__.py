@@ -225,26 +225,145 @@ class _Surface:
         self.emission = np.zeros(nwavel)
 
 
+class EquationOfState:
+    """Ideal-gas number densities and their derivatives (src/sasktran2/util/state.py:8-114)."""
+    K_BOLTZMANN = 1.380649e-23
+
+    def __init__(self):
+        self.pressure_pa = None
+        self.temperature_k = None
+        self.specific_humidity = None
+
+    @property
+    def air_numberdensity(self):
+        kt = self.K_BOLTZMANN * self.temperature_k
+        return {"N": self.pressure_pa / kt, "dN_dP": 1 / kt, "dN_dT": -self.pressure_pa / (kt * self.temperature_k)}
+
+    @property
+    def dry_air_numberdensity(self):
+        wet = self.air_numberdensity
+        q = 0 if self.specific_humidity is None else self.specific_humidity
+        return {"N": wet["N"] * (1 - q), "dN_dP": wet["dN_dP"] * (1 - q), "dN_dT": wet["dN_dT"] * (1 - q), "dN_dsh": -wet["N"]}
+
+
 class Atmosphere:
-    """Raw-interface atmosphere (src/sasktran2/atmosphere.py:176-260, 784-806): fill `storage.total_extinction`,
-    `storage.ssa` [altitude, wavelength], `leg_coeff.a1` [moment, altitude, wavelength] and `surface.albedo`."""
+    """src/sasktran2/atmosphere.py:176-290, 719-863.  Two ways to fill it, as in the reference:
+
+    * raw interface: fill `storage.total_extinction`, `storage.ssa` [altitude, wavelength], `leg_coeff.a1` [moment, altitude,
+      wavelength] and `surface.albedo`; weighting functions `wf_extinction`, `wf_ssa`, `wf_albedo`;
+    * constituents: `atmosphere["name"] = sk.constituent.X(...)` with `wavelengths_nm`, `pressure_pa`, `temperature_k` set.  The storage
+      and every derivative mapping are then assembled in HBM by the device front end (`sasktran2_amd.frontend`); `storage` reads them
+      back on access, and the weighting functions carry the constituents' names (`wf_<name>_vmr`, `wf_temperature_k`, ...)."""
 
     def __init__(self, model_geometry, config, wavelengths_nm=None, wavenumber_cminv=None, numwavel=None,
-                 calculate_derivatives=True, **_):
+                 calculate_derivatives=True, pressure_derivative=True, temperature_derivative=True, **_):
+        if wavelengths_nm is None and wavenumber_cminv is not None:
+            wavelengths_nm = 1e7 / np.asarray(wavenumber_cminv, dtype=float)
         if numwavel is None:
-            src = wavelengths_nm if wavelengths_nm is not None else wavenumber_cminv
-            if src is None:
+            if wavelengths_nm is None:
                 raise ValueError("One of wavelengths_nm, wavenumber_cminv, numwavel must be set")
-            numwavel = len(src)
+            numwavel = len(wavelengths_nm)
         self.wavelengths_nm = None if wavelengths_nm is None else np.asarray(wavelengths_nm, dtype=float)
         self._ngrid = len(model_geometry.altitudes())
         self._nwavel = int(numwavel)
         self._calculate_derivatives = bool(calculate_derivatives)
+        self._pressure_derivative = bool(pressure_derivative)
+        self._temperature_derivative = bool(temperature_derivative)
         self.nstokes = int(config.num_stokes)
-        self.storage = _Storage(self._ngrid, self._nwavel, config.num_singlescatter_moments, self.nstokes)
-        self.leg_coeff = _LegCoeff(self.storage, self.nstokes)
+        self._num_moments = int(config.num_singlescatter_moments)
+        self._raw_storage = _Storage(self._ngrid, self._nwavel, config.num_singlescatter_moments, self.nstokes)
+        self.leg_coeff = _LegCoeff(self._raw_storage, self.nstokes)
         self.surface = _Surface(self._nwavel)
         self._altitudes = model_geometry.altitudes()
+        self._model_geometry = model_geometry
+        self._config = config
+        self.state_equation = EquationOfState()
+        self._constituents = {}
+        self._frontend = None
+        self._surface_mappings = {}
+
+    # ---- state and constituents (src/sasktran2/atmosphere.py:291-520, 860-864)
+    model_geometry = property(lambda self: self._model_geometry)
+    num_wavel = property(lambda self: self._nwavel)
+    num_locations = property(lambda self: self._ngrid)
+    num_moments = property(lambda self: self._num_moments)
+    num_leg = property(lambda self: self._num_moments * (4 if self.nstokes == 3 else 1))
+    calculate_pressure_derivative = property(lambda self: self._calculate_derivatives and self._pressure_derivative)
+    calculate_temperature_derivative = property(lambda self: self._calculate_derivatives and self._temperature_derivative)
+
+    @property
+    def wavenumbers_cminv(self):
+        return None if self.wavelengths_nm is None else 1e7 / self.wavelengths_nm
+
+    @property
+    def pressure_pa(self):
+        return self.state_equation.pressure_pa
+
+    @pressure_pa.setter
+    def pressure_pa(self, value):
+        self.state_equation.pressure_pa = self._state(value, "pressure_pa")
+
+    @property
+    def temperature_k(self):
+        return self.state_equation.temperature_k
+
+    @temperature_k.setter
+    def temperature_k(self, value):
+        self.state_equation.temperature_k = self._state(value, "temperature_k")
+
+    def _state(self, value, name):
+        value = np.asarray(value, dtype=float)
+        if value.shape != (self._ngrid,):
+            raise ValueError(f"{name} must have one value per grid altitude")
+        return value
+
+    def __setitem__(self, item, value):
+        self._constituents[item] = value
+
+    def __getitem__(self, item):
+        return self._constituents.get(item)
+
+    @property
+    def frontend(self):
+        """the device front end the constituents write their terms and mappings into"""
+        if self._frontend is None:
+            from .frontend import FrontEnd
+            self._frontend = FrontEnd(self._ngrid, self._nwavel, self.num_leg, self.nstokes)
+        return self._frontend
+
+    @property
+    def storage(self):
+        if self._constituents:
+            from .frontend import DeviceStorage
+            if self._frontend is None or not self._frontend.assembled:
+                raise RuntimeError("call Atmosphere.internal_object() (or Engine.calculate_radiance) first: the storage of a constituent "
+                                   "atmosphere is assembled on the device")
+            return DeviceStorage(self._frontend, self._raw_storage.solar_irradiance)
+        return self._raw_storage
+
+    def register_surface_mapping(self, name, interpolator, interp_dim):
+        self._surface_mappings[name] = (np.asarray(interpolator, dtype=float), interp_dim)
+
+    def internal_object(self):
+        """Assemble the atmosphere from its constituents in HBM: add every constituent, normalise, then let every constituent register
+        its derivative mappings (src/sasktran2/atmosphere.py:730-771).  Returns the front end; a raw-interface atmosphere has none."""
+        if not self._constituents:
+            return None
+        fe = self.frontend
+        fe.reset()
+        self._surface_mappings = {}
+        try:
+            for constituent in self._constituents.values():
+                constituent.add_to_atmosphere(self)
+            fe.set_solar_irradiance(self._raw_storage.solar_irradiance)
+            fe.assemble()
+            if self._calculate_derivatives:
+                for name, constituent in self._constituents.items():
+                    constituent.register_derivative(self, name)
+        except Exception:
+            fe.reset()
+            raise
+        return fe
 
     @property
     def calculate_derivatives(self):
@@ -254,7 +373,7 @@ class Atmosphere:
         """The storage / surface / atmosphere handles of this object (created once, as `Atmosphere.internal_object()` of the
         reference) over private Fortran-ordered buffers that every calculation refills."""
         if getattr(self, "_H", None) is None:
-            st = self.storage
+            st = self._raw_storage
             H = {"ext": np.zeros_like(st.total_extinction, order="F"), "ssa": np.zeros_like(st.ssa, order="F"),
                  "em": np.zeros_like(st.emission_source, order="F"), "leg": np.zeros_like(st.leg_coeff, order="F"),
                  "irr": np.ones(self._nwavel), "alb": np.zeros(self._nwavel), "emis": np.zeros(self._nwavel)}
@@ -299,7 +418,7 @@ class Engine:
         """Handle flow of the reference (src/sasktran2/atmosphere.py:719-858): ONE storage / surface / atmosphere handle per Atmosphere
         object, and before every calculation set_zero -> refill -> derivative mappings -> apply_delta_m_scaling on that handle."""
         L = lib()
-        st = atmosphere.storage
+        st = atmosphere._raw_storage
         nw, ngrid = atmosphere._nwavel, atmosphere._ngrid
         S = int(self._config.num_stokes)
         per = 4 if S == 3 else 1
@@ -390,6 +509,10 @@ class Engine:
     def calculate_radiance(self, atmosphere, as_dataset=True, _mapping_hook=None):
         """`_mapping_hook(L, storage_handle, output_handle, out_dict)` lets a caller register further derivative mappings through
         the C ABI before the solve (used by the tests for interpolated / log-space mappings)."""
+        if atmosphere._constituents:
+            if _mapping_hook is not None:
+                raise ValueError("_mapping_hook belongs to the raw interface")
+            return self._calculate_radiance_constituents(atmosphere, as_dataset)
         L = lib()
         nw, ngrid, nlos = atmosphere._nwavel, atmosphere._ngrid, self.nlos
         S = int(self._config.num_stokes)
@@ -429,3 +552,73 @@ class Engine:
                     "los_optical_depth": ("wavelength", "los")}
             return xr.Dataset({k: (dims[k], v) for k, v in out.items()}, coords={"altitude": atmosphere._altitudes})
         return out
+
+    def _calculate_radiance_constituents(self, atmosphere, as_dataset):
+        """Constituent interface: the atmosphere is assembled in HBM (`Atmosphere.internal_object`), the storage handle of the device
+        front end goes to the engine without an upload, and the weighting functions come back under the reference's names: one array
+        per derivative mapping, mappings with the same `assign_name` added up (src/sasktran2/engine.py:340-372)."""
+        L = lib()
+        fe = atmosphere.internal_object()
+        nw, nlos, S = atmosphere._nwavel, self.nlos, int(self._config.num_stokes)
+        derivs = atmosphere.calculate_derivatives
+        alb = np.ascontiguousarray(atmosphere.surface.albedo, dtype=float)
+        emis = np.ascontiguousarray(atmosphere.surface.emission, dtype=float)
+        h_brdf = L.sk_brdf_create_lambertian(S)
+        h_su = L.sk_surface_create(nw, S, _p(emis))
+        L.sk_surface_set_brdf(h_su, h_brdf, _p(alb))
+        h_atm = L.sk_atmosphere_create(fe.storage_handle(), h_su, int(derivs), 0)
+        rad = np.zeros((nw, nlos, S))
+        h_out = L.sk_output_create(_p(rad), nw * nlos, S, None, 0)
+        raw, raw_surface = {}, {}
+        try:
+            if derivs:
+                for name, m in fe.mappings.items():
+                    raw[name] = np.zeros((m.num_output, nw, nlos, S))
+                    L.sk_output_assign_derivative_memory(h_out, name.encode(), _p(raw[name]), nw * nlos, S, m.num_output)
+                for name in atmosphere._surface_mappings:
+                    m = ctypes.c_void_p()
+                    L.sk_surface_get_derivative_mapping(h_su, name.encode(), ctypes.byref(m))
+                    ptr = _dp()
+                    L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
+                    np.ctypeslib.as_array(ptr, shape=(nw,))[:] = 1.0
+                    raw_surface[name] = np.zeros((nw, nlos, S))
+                    L.sk_output_assign_surface_derivative_memory(h_out, name.encode(), _p(raw_surface[name]), nw * nlos, S)
+            # src/sasktran2/atmosphere.py:845-854: scale when more moments are stored than streams are used
+            if self._config.delta_m_scaling and atmosphere.num_moments > self._config.num_streams:
+                rc = L.sk_atmosphere_apply_delta_m_scaling(h_atm, int(self._config.num_streams))
+                if rc != 0:
+                    raise RuntimeError(f"sk_atmosphere_apply_delta_m_scaling returned {rc}: {last_error()}")
+            rc = L.sk_engine_calculate_radiance(self._h, h_atm, h_out, 0)
+            if rc != 0:
+                raise RuntimeError(f"sk_engine_calculate_radiance returned {rc}: {last_error()}")
+            od = _dp()
+            L.sk_output_get_los_optical_depth(h_out, ctypes.byref(od))
+            los_od = np.ctypeslib.as_array(od, shape=(nlos, nw)).T.copy()
+        finally:
+            L.sk_output_destroy(h_out)
+            L.sk_atmosphere_destroy(h_atm)
+            L.sk_surface_destroy(h_su)
+            L.sk_brdf_destroy(h_brdf)
+        out, dims = {"radiance": rad, "los_optical_depth": los_od}, {"radiance": ("wavelength", "los", "stokes"), "los_optical_depth": ("wavelength", "los")}
+        for name, m in fe.mappings.items():
+            key = m.assign_name or name
+            d = (m.interp_dim, "wavelength", "los", "stokes")
+            if key in out:
+                if dims[key] != d or out[key].shape != raw[name].shape:
+                    raise ValueError(f"Radiance derivative mappings assigned to {key!r} have incompatible parameter dimensions")
+                out[key] = out[key] + raw[name]
+            else:
+                out[key], dims[key] = raw[name], d
+        for name, (interp, interp_dim) in atmosphere._surface_mappings.items():
+            out[name] = np.einsum("ij...,il->lij...", raw_surface[name], interp)
+            dims[name] = (interp_dim, "wavelength", "los", "stokes")
+        if as_dataset:
+            try:
+                import xarray as xr
+            except ImportError:
+                return out
+            return xr.Dataset({k: (dims[k], v) for k, v in out.items()})
+        return out
+
+
+from . import constituent, optical  # noqa: E402,F401  (the constituent interface: sk.constituent.Rayleigh, sk.optical.HenyeyGreenstein, ...)

@@ -74,6 +74,14 @@ SIGNATURES = [
     ("sk_amd_so_engine_sizes", _I, [_vp, ctypes.POINTER(ctypes.c_ulonglong)]),
     ("sk_amd_ts_engine_solve_device", _I, [_vp, _I, _I] + [_vp] * 17 + [_I]),
     ("sk_atmosphere_apply_delta_m_scaling", _I, [_vp, _I]),
+    ("sk_amd_frontend_create", _vp, [_I, _I, _I, _I]), ("sk_amd_frontend_destroy", None, [_vp]), ("sk_amd_frontend_reset", _I, [_vp]),
+    ("sk_amd_frontend_add_term", _I, [_vp, _vp, _vp, _vp, _vp]), ("sk_amd_frontend_set_profile", _I, [_vp, _I, _vp]),
+    ("sk_amd_frontend_set_planck_emission", _I, [_vp, _vp, _vp]), ("sk_amd_frontend_set_solar_irradiance", _I, [_vp, _vp]),
+    ("sk_amd_frontend_assemble", _I, [_vp]),
+    ("sk_amd_frontend_add_mapping", _I, [_vp, _S, _I, _vp, _vp, _I, _I, _vp, _I, _S, _S]),
+    ("sk_amd_frontend_storage", _vp, [_vp]),
+    ("sk_amd_frontend_device_pointer", _I, [_vp, _S, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_ulonglong)]),
+    ("sk_amd_frontend_download", _I, [_vp, _S, _vp]),
     ("sk_amd_engine_num_los", _I, [_vp, _ip]),
     ("sk_amd_engine_scratch_bytes", _I, [_vp, _I, ctypes.POINTER(ctypes.c_ulonglong)]),
     ("sk_amd_engine_launch_shape", _I, [_vp, _ip, _ip, ctypes.POINTER(ctypes.c_ulonglong)]),

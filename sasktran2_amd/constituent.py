@@ -1,0 +1,227 @@
+"""Constituents of the reference's atmosphere interface (`atmosphere["o3"] = sk.constituent.VMRAltitudeAbsorber(...)`), for the classes
+whose contribution is a sum of profile x spectrum terms.  Same names, arguments and weighting-function names as the reference; the
+arithmetic on [location x wavelength] arrays runs in `frontend.hip` (see `sasktran2_amd.frontend`), these classes only prepare what is
+small.
+
+Reference behaviour followed (nothing copied):
+  src/sasktran2/constituent/rayleigh.py, rust/sasktran2-rs/src/constituent/types/rayleigh.rs:110-258
+  src/sasktran2/constituent/vmraltitudeabsorber.py, rust/.../vmr_alt_absorber.rs:64-260, 339-399
+  src/sasktran2/constituent/numdenscatterer.py, rust/.../number_density_scatterer.rs:218-440
+  src/sasktran2/constituent/emission.py, rust/.../emission.rs:9-116
+  src/sasktran2/constituent/brdf/lambertiansurface.py, brdf/__init__.py:11-63
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .optical import OpticalProperty, linear_interpolating_matrix, rayleigh_cross_section_bates
+
+
+class Constituent:
+    """src/sasktran2/constituent/base.py"""
+
+    def add_to_atmosphere(self, atmo):
+        raise NotImplementedError
+
+    def register_derivative(self, atmo, name):
+        raise NotImplementedError
+
+
+def _state_derivatives(atmo):
+    """(name, dN/d name) of the state variables weighting functions are asked for (vmr_alt_absorber.rs:183-209)"""
+    air = atmo.state_equation.dry_air_numberdensity
+    out = []
+    if atmo.calculate_pressure_derivative:
+        out.append(("pressure_pa", air["dN_dP"]))
+    if atmo.calculate_temperature_derivative:
+        out.append(("temperature_k", air["dN_dT"]))
+    return out
+
+
+def _require_state(atmo, who):
+    if atmo.wavelengths_nm is None:
+        raise ValueError(f"It is required to give the Atmosphere object wavelengths to use the {who} constituent")
+    if atmo.pressure_pa is None:
+        raise ValueError(f"It is required to set the pressure_pa property in the Atmosphere object to use the {who} constituent")
+    if atmo.temperature_k is None:
+        raise ValueError(f"It is required to set the temperature_k property in the Atmosphere object to use the {who} constituent")
+
+
+class Rayleigh(Constituent):
+    def __init__(self, method="bates", n2_percentage=78.084, o2_percentage=20.946, ar_percentage=0.934, co2_percentage=0.036,
+                 wavelengths_nm=None, xs=None, king_factor=None):
+        method = method.lower()
+        if method not in ("bates", "manual"):
+            raise ValueError("Method must be bates or manual")
+        if method == "manual" and (wavelengths_nm is None or xs is None or king_factor is None):
+            raise ValueError("the manual method needs wavelengths_nm, xs and king_factor")
+        self._method = method
+        self._mix = (n2_percentage, o2_percentage, ar_percentage, co2_percentage)
+        self._table = None if method == "bates" else tuple(np.asarray(v, dtype=float) for v in (wavelengths_nm, xs, king_factor))
+        self._term = None
+
+    def _cross_section(self, wavelengths_nm):
+        if self._method == "bates":
+            return rayleigh_cross_section_bates(wavelengths_nm / 1000.0, *self._mix)
+        wl, xs, king = self._table          # held outside the table (rayleigh.rs:92-105)
+        return np.interp(wavelengths_nm, wl, xs), np.interp(wavelengths_nm, wl, king)
+
+    def add_to_atmosphere(self, atmo):
+        _require_state(atmo, "Rayleigh")
+        sigma, king = self._cross_section(atmo.wavelengths_nm)
+        delta = 6.0 * (king - 1.0) / (3.0 + 7.0 * king)
+        factor = (1.0 - delta) / (2.0 + delta)
+        leg = np.zeros((atmo.num_wavel, atmo.num_leg))
+        if atmo.nstokes == 1:
+            leg[:, 0], leg[:, 2] = 1.0, factor
+        else:   # a1, a2, a3, b1 per order (rayleigh.rs:145-158)
+            leg[:, 0], leg[:, 8], leg[:, 9], leg[:, 11] = 1.0, factor, 6.0 * factor, np.sqrt(6.0) * factor
+        self._term = atmo.frontend.add_term(atmo.state_equation.air_numberdensity["N"], sigma, sigma, leg)
+
+    def register_derivative(self, atmo, name):
+        air = atmo.state_equation.air_numberdensity
+        for key, flag, factor in (("pressure_pa", atmo.calculate_pressure_derivative, air["dN_dP"]),
+                                  ("temperature_k", atmo.calculate_temperature_derivative, air["dN_dT"])):
+            if flag:
+                atmo.frontend.add_mapping(f"wf_{name}_{key}", [self._term], scatterer=True, interpolator=np.diag(factor), interp_dim="altitude",
+                                          assign_name=f"wf_{key}")
+
+
+class VMRAltitudeAbsorber(Constituent):
+    def __init__(self, optical_property: OpticalProperty, altitudes_m, vmr, out_of_bounds_mode="zero"):
+        if optical_property.is_scatterer:
+            raise ValueError("VMRAltitudeAbsorber takes a purely absorbing optical property")
+        self._optical_property = optical_property
+        self._altitudes_m = np.asarray(altitudes_m, dtype=float)
+        self.vmr = np.asarray(vmr, dtype=float)
+        self._mode = out_of_bounds_mode.lower()
+        self._terms = []
+
+    @property
+    def altitudes_m(self):
+        return self._altitudes_m
+
+    def _profile(self, atmo):
+        m = linear_interpolating_matrix(self._altitudes_m, atmo.model_geometry.altitudes(), self._mode)
+        return m, m @ self.vmr
+
+    def add_to_atmosphere(self, atmo):
+        _require_state(atmo, "VMRAltitudeAbsorber")
+        _, vmr = self._profile(atmo)
+        n = atmo.state_equation.dry_air_numberdensity["N"]
+        self._spectral = self._optical_property.spectral_terms(atmo)
+        self._terms = [atmo.frontend.add_term(vmr * n * weight, spec["ext"]) for weight, _, spec in self._spectral]
+
+    def register_derivative(self, atmo, name):
+        m, vmr = self._profile(atmo)
+        n = atmo.state_equation.dry_air_numberdensity["N"]
+        weights = np.array([w for w, _, _ in self._spectral])
+        fe = atmo.frontend
+        fe.add_mapping(f"wf_{name}_vmr", self._terms, weights, interpolator=m * n[:, np.newaxis], interp_dim=f"{name}_altitude")
+        state = _state_derivatives(atmo)
+        for key, factor in state:
+            fe.add_mapping(f"wf_{name}_{key}", self._terms, weights, interpolator=np.diag(vmr * factor), interp_dim="altitude", assign_name=f"wf_{key}")
+        if state:
+            # d(cross section)/d(table parameter) through the interpolation weights (vmr_alt_absorber.rs:233-256)
+            for key in sorted({k for _, slopes, _ in self._spectral for k in slopes}):
+                slopes = np.array([s.get(key, np.zeros(atmo.num_locations)) for _, s, _ in self._spectral])
+                fe.add_mapping(f"wf_{name}_{key}_xs", self._terms, slopes, interpolator=np.diag(vmr * n), interp_dim="altitude", assign_name=f"wf_{key}")
+
+
+class NumberDensityScatterer(Constituent):
+    _wf_name = "number_density"
+
+    def __init__(self, optical_property: OpticalProperty, altitudes_m, number_density, out_of_bounds_mode="zero"):
+        if not optical_property.is_scatterer:
+            raise ValueError("NumberDensityScatterer takes a scattering optical property")
+        self._optical_property = optical_property
+        self._altitudes_m = np.asarray(altitudes_m, dtype=float)
+        self.number_density = np.zeros_like(self._altitudes_m) if number_density is None else np.asarray(number_density, dtype=float)
+        self._mode = out_of_bounds_mode.lower()
+        self._vertical_deriv_factor = np.ones_like(self._altitudes_m)
+        self._terms = []
+
+    @property
+    def altitudes_m(self):
+        return self._altitudes_m
+
+    def add_to_atmosphere(self, atmo):
+        if atmo.wavelengths_nm is None:
+            raise ValueError("the atmosphere needs wavelengths for a scatterer defined by an optical property")
+        m = linear_interpolating_matrix(self._altitudes_m, atmo.model_geometry.altitudes(), self._mode)
+        nd = m @ self.number_density
+        self._spectral = self._optical_property.spectral_terms(atmo)
+        self._terms = [atmo.frontend.add_term(nd * weight, spec["ext"], spec["scat"], spec["leg"]) for weight, _, spec in self._spectral]
+
+    def register_derivative(self, atmo, name):
+        m = linear_interpolating_matrix(self._altitudes_m, atmo.model_geometry.altitudes(), self._mode)
+        weights = np.array([w for w, _, _ in self._spectral])
+        atmo.frontend.add_mapping(f"wf_{name}_{self._wf_name}", self._terms, weights, scatterer=True,
+                                  interpolator=m * self._vertical_deriv_factor[np.newaxis, :], interp_dim=f"{name}_altitude")
+
+
+class ExtinctionScatterer(NumberDensityScatterer):
+    """An extinction profile [1/m] at one wavelength; the number density follows from the optical property's cross section there
+    (src/sasktran2/constituent/numdenscatterer.py:117-197)."""
+    _wf_name = "extinction"
+
+    def __init__(self, optical_property, altitudes_m, extinction_per_m, extinction_wavelength_nm, out_of_bounds_mode="zero"):
+        super().__init__(optical_property, altitudes_m, None, out_of_bounds_mode)
+        self.extinction_per_m = np.asarray(extinction_per_m, dtype=float)
+        self._extinction_wavelength_nm = float(extinction_wavelength_nm)
+
+    def _update_numberdensity(self):
+        xs = self._optical_property.cross_sections(np.array([self._extinction_wavelength_nm]))[0]
+        if not xs > 0.0:
+            raise ValueError("the optical property has no cross section at the extinction wavelength")
+        self._vertical_deriv_factor = np.full(len(self._altitudes_m), 1.0 / xs)
+        self.number_density = self.extinction_per_m / xs
+
+    def add_to_atmosphere(self, atmo):
+        self._update_numberdensity()
+        super().add_to_atmosphere(atmo)
+
+
+class ThermalEmission(Constituent):
+    """Planck emission of the atmosphere at its own temperature (src/sasktran2/constituent/emission.py `ThermalEmission`)."""
+
+    def add_to_atmosphere(self, atmo):
+        if atmo.wavelengths_nm is None or atmo.temperature_k is None:
+            raise ValueError("ThermalEmission needs wavelengths_nm and temperature_k in the Atmosphere object")
+        atmo.frontend.set_planck_emission(atmo.temperature_k, atmo.wavelengths_nm)
+
+    def register_derivative(self, atmo, name):
+        atmo.frontend.add_mapping(f"wf_{name}_temperature_k", planck=True, interp_dim="altitude", assign_name="wf_temperature_k")
+
+
+class LambertianSurface(Constituent):
+    """Albedo constant in wavelength (scalar), on the atmosphere's own wavelength grid, or interpolated from `wavelengths_nm` /
+    `wavenumbers_cminv` (src/sasktran2/constituent/brdf/lambertiansurface.py)."""
+
+    def __init__(self, albedo, wavelengths_nm=None, wavenumbers_cminv=None, out_of_bounds_mode="zero"):
+        self.albedo = np.atleast_1d(np.asarray(albedo, dtype=float))
+        self._mode = out_of_bounds_mode.lower()
+        if wavelengths_nm is not None:
+            self._x, self._var = np.atleast_1d(np.asarray(wavelengths_nm, dtype=float)), "wavelengths_nm"
+        elif wavenumbers_cminv is not None:
+            self._x, self._var = np.atleast_1d(np.asarray(wavenumbers_cminv, dtype=float)), "wavenumbers_cminv"
+        else:
+            self._x, self._var = None, ("constant" if len(self.albedo) == 1 else "native")
+
+    def _interpolating_matrix(self, atmo):
+        if self._var == "constant":
+            return np.ones((atmo.num_wavel, 1))
+        if self._var == "native":
+            if len(self.albedo) != atmo.num_wavel:
+                raise ValueError("The number of albedo values must match the number of wavelengths in the atmosphere")
+            return np.eye(atmo.num_wavel)
+        grid = getattr(atmo, self._var)
+        if grid is None:
+            raise ValueError(f"The atmosphere does not have {self._var} defined, cannot interpolate the user albedo")
+        return linear_interpolating_matrix(self._x, grid, self._mode)
+
+    def add_to_atmosphere(self, atmo):
+        atmo.surface.albedo[:] = self._interpolating_matrix(atmo) @ self.albedo
+
+    def register_derivative(self, atmo, name):
+        atmo.register_surface_mapping(f"wf_{name}_albedo", self._interpolating_matrix(atmo), f"{name}_wavelength")

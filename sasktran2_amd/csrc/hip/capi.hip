@@ -19,6 +19,7 @@
 #include "disco_engine.hpp"
 #include "so_engine.hpp"
 #include "ts_engine.hpp"
+#include "frontend_kernels.hpp"
 
 namespace {
 thread_local std::string g_last_error;
@@ -65,6 +66,22 @@ struct DerivativeMapping {
     std::string interp_dim = "altitude", assign_name;
     double* interpolator = nullptr;
     int interp_dim1 = 0, interp_dim2 = 0;
+    // a mapping formed in HBM by the optical-property front end (frontend.inc): the arrays below replace the host vectors above
+    bool on_device = false, scatterer = false, has_emission = false;
+    const double *dev_d_ssa = nullptr, *dev_d_extinction = nullptr, *dev_scat_factor = nullptr, *dev_d_legendre = nullptr, *dev_d_emission = nullptr,
+                 *dev_d_f = nullptr;
+    std::vector<double> owned_interpolator;
+    const double* src_d_ssa() const { return on_device ? dev_d_ssa : d_ssa.data(); }
+    const double* src_d_extinction() const { return on_device ? dev_d_extinction : d_extinction.data(); }
+    const double* src_scat_factor() const { return on_device ? dev_scat_factor : scat_factor.data(); }
+    const double* src_d_legendre() const { return on_device ? dev_d_legendre : d_legendre.data(); }
+    const double* src_d_emission() const { return on_device ? dev_d_emission : d_emission.data(); }
+    const double* src_d_f() const { return on_device ? dev_d_f : d_f.data(); }
+    bool has_d_f(size_t n) const { return on_device ? dev_d_f != nullptr : d_f.size() == n; }
+    bool uses_emission() const {
+        if (on_device) return has_emission;
+        return std::any_of(d_emission.begin(), d_emission.end(), [](double v) { return v != 0.0; });
+    }
 };
 struct SurfaceDerivativeMapping {
     int nwavel = 0, num_brdf_args = 1;
@@ -80,6 +97,13 @@ struct AtmosphereStorage {
     std::vector<std::string> names;
     std::vector<double> delta_f;  // [nloc, nwavel] (location fastest) once sk_atmosphere_apply_delta_m_scaling has run
     int delta_order = -1;
+    // storage assembled in HBM by the optical-property front end: ssa / ext / emission / leg are DEVICE pointers (irradiance stays a host
+    // array) and the truncation fraction of the delta-M scaling lives in dev_delta_f
+    bool on_device = false;
+    const double* dev_delta_f = nullptr;
+    struct FrontEnd* owner = nullptr;
+    bool has_delta_f() const { return on_device ? dev_delta_f != nullptr : !delta_f.empty(); }
+    const double* src_delta_f() const { return on_device ? dev_delta_f : delta_f.data(); }
 };
 struct BRDF {
     int kind = 0;
@@ -305,13 +329,16 @@ int sk_atmosphere_storage_get_derivative_mapping_name(AtmosphereStorage* s, int 
     *name = s->names[i].c_str();
     return 0;
 }
-int sk_deriv_mapping_get_d_ssa(DerivativeMapping* m, double** p) { if (!m || !p) return -1; *p = m->d_ssa.data(); return 0; }
-int sk_deriv_mapping_get_d_extinction(DerivativeMapping* m, double** p) { if (!m || !p) return -1; *p = m->d_extinction.data(); return 0; }
+// a mapping the front end formed in HBM has no host arrays to hand out (sk_amd_frontend_download copies them for inspection)
+#define SK_HOST_MAPPING(m) do { if ((m)->on_device) { set_error("this derivative mapping lives on the device (sk_amd_frontend_download reads it)"); return -2; } } while (0)
+int sk_deriv_mapping_get_d_ssa(DerivativeMapping* m, double** p) { if (!m || !p) return -1; SK_HOST_MAPPING(m); *p = m->d_ssa.data(); return 0; }
+int sk_deriv_mapping_get_d_extinction(DerivativeMapping* m, double** p) { if (!m || !p) return -1; SK_HOST_MAPPING(m); *p = m->d_extinction.data(); return 0; }
 int sk_deriv_mapping_get_num_location(DerivativeMapping* m, int* n) { if (!m || !n) return -1; *n = m->nloc; return 0; }
 int sk_deriv_mapping_get_num_wavel(DerivativeMapping* m, int* n) { if (!m || !n) return -1; *n = m->nwavel; return 0; }
 int sk_deriv_mapping_get_num_output(DerivativeMapping* m, int* n) { if (!m || !n) return -1; *n = m->nloc; return 0; }
 int sk_deriv_mapping_set_zero(DerivativeMapping* m) {
     if (!m) return -1;
+    SK_HOST_MAPPING(m);
     // every native array of the mapping, as DerivativeMapping::set_zero (cpp/lib/derivative_mapping/derivative_mapping.cpp:61-77),
     // and the truncation-fraction derivative the delta-M scaling left behind
     for (std::vector<double>* v : {&m->d_ssa, &m->d_extinction, &m->scat_factor, &m->d_legendre, &m->d_emission, &m->d_f})
@@ -469,6 +496,7 @@ int sk_engine_calculate_radiance_block_thread(Engine* e, OutputC* o, int, int, i
 
 // native weighting functions (device, [ngrid][wavel][los][S] / [wavel][los][S]) -> the caller's derivative mappings
 static bool is_scattering_mapping(const DerivativeMapping& dm) {
+    if (dm.on_device) return dm.scatterer;
     if (dm.scat_deriv_index >= 0) return true;
     for (double v : dm.d_legendre) if (v != 0.0) return true;
     for (double v : dm.scat_factor) if (v != 0.0) return true;
@@ -494,22 +522,22 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
                 const int nout = m.interpolator ? m.interp_dim2 : ngrid;
                 if (m.interpolator && m.interp_dim1 != ngrid) throw std::runtime_error("interpolator of " + kv.first + " does not have one row per grid location");
                 if (kv.second.nderiv != nout || kv.second.nrad * kv.second.nstokes != nw * nlos) throw std::runtime_error("derivative memory size mismatch for " + kv.first);
-                HIPC(hipMemcpy(d_fs, m.d_ssa.data(), nloc_w * 8, hipMemcpyHostToDevice));
-                HIPC(hipMemcpy(d_fk, m.d_extinction.data(), nloc_w * 8, hipMemcpyHostToDevice));
+                HIPC(hipMemcpy(d_fs, m.src_d_ssa(), nloc_w * 8, hipMemcpyDefault));
+                HIPC(hipMemcpy(d_fk, m.src_d_extinction(), nloc_w * 8, hipMemcpyDefault));
                 double* d_dst = (double*)C.get("wf_user", size_t(nout) * nt * 8);
                 const double* d_wgm = nullptr;
                 double* d_fg = nullptr;
                 if (group_of && group_of->count(kv.first)) {
                     d_wgm = d_wg + size_t(group_of->at(kv.first)) * ngrid * nt;
                     d_fg = (double*)C.get("map_scat_factor", nloc_w * 8);
-                    HIPC(hipMemcpy(d_fg, m.scat_factor.data(), nloc_w * 8, hipMemcpyHostToDevice));
+                    HIPC(hipMemcpy(d_fg, m.src_scat_factor(), nloc_w * 8, hipMemcpyDefault));
                 }
                 const double* d_wemm = nullptr;
                 double* d_fem = nullptr;
-                if (d_wem && std::any_of(m.d_emission.begin(), m.d_emission.end(), [](double v) { return v != 0.0; })) {
+                if (d_wem && m.uses_emission()) {
                     d_wemm = d_wem;
                     d_fem = (double*)C.get("map_d_emission", nloc_w * 8);
-                    HIPC(hipMemcpy(d_fem, m.d_emission.data(), nloc_w * 8, hipMemcpyHostToDevice));
+                    HIPC(hipMemcpy(d_fem, m.src_d_emission(), nloc_w * 8, hipMemcpyDefault));
                 }
                 if (!m.interpolator && !m.log_radiance_space) {
                     hipLaunchKernelGGL(kern_map_wf, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_dst, ngrid, nw, nlos, d_wgm, d_fg, d_wemm, d_fem);
@@ -517,7 +545,7 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
                     double* d_interp = nullptr;
                     if (m.interpolator) {
                         d_interp = (double*)C.get("interpolator", size_t(ngrid) * nout * 8);
-                        HIPC(hipMemcpy(d_interp, m.interpolator, size_t(ngrid) * nout * 8, hipMemcpyHostToDevice));
+                        HIPC(hipMemcpy(d_interp, m.interpolator, size_t(ngrid) * nout * 8, hipMemcpyDefault));
                     }
                     hipLaunchKernelGGL(kern_map_wf_interp, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_interp, d_rad,
                                        m.log_radiance_space, d_dst, ngrid, nout, nw, nlos, S, d_wgm, d_fg, d_wemm, d_fem);
@@ -573,13 +601,13 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     double* d_odt = (double*)C.get("los_od_t", nt * 8);
     int* d_status = (int*)C.get("status", size_t(nw) * 4);
     double *d_irr = nullptr, *d_we = nullptr, *d_ws = nullptr, *d_wa = nullptr;
-    HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyDefault));
+    HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyDefault));
+    HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyDefault));
+    HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyDefault));
     if (st.irradiance) {
         d_irr = (double*)C.get("irradiance", size_t(nw) * 8);
-        HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyDefault));
     }
     // scattering derivative groups: one per requested mapping that carries d_legendre / scat_factor (finalize_scattering_derivatives,
     // cpp/include/sasktran2/atmosphere/grid_storage.h:190-214)
@@ -600,22 +628,22 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
             const size_t per_g = nloc_w * st.nleg;
             d_dleg = (double*)C.get("d_legendre", group_of.size() * per_g * 8);
             for (auto& kv : group_of)
-                HIPC(hipMemcpy(d_dleg + size_t(kv.second) * per_g, st.maps.at(kv.first)->d_legendre.data(), per_g * 8, hipMemcpyHostToDevice));
+                HIPC(hipMemcpy(d_dleg + size_t(kv.second) * per_g, st.maps.at(kv.first)->src_d_legendre(), per_g * 8, hipMemcpyDefault));
             d_wg = (double*)C.get("wf_scat", group_of.size() * size_t(ngrid) * nt * S * 8);
-            if (!st.delta_f.empty()) {
+            if (st.has_delta_f()) {
                 d_dfg = (double*)C.get("d_f_groups", group_of.size() * nloc_w * 8);
                 for (auto& kv : group_of) {
-                    const auto& df = st.maps.at(kv.first)->d_f;
-                    if (df.size() != nloc_w) throw std::runtime_error("scattering mapping " + kv.first + " was created after the delta-M scaling");
-                    HIPC(hipMemcpy(d_dfg + size_t(kv.second) * nloc_w, df.data(), nloc_w * 8, hipMemcpyHostToDevice));
+                    const DerivativeMapping& gm = *st.maps.at(kv.first);
+                    if (!gm.has_d_f(nloc_w)) throw std::runtime_error("scattering mapping " + kv.first + " was created after the delta-M scaling");
+                    HIPC(hipMemcpy(d_dfg + size_t(kv.second) * nloc_w, gm.src_d_f(), nloc_w * 8, hipMemcpyDefault));
                 }
             }
         }
     }
     double* d_f = nullptr;
-    if (!st.delta_f.empty()) {
+    if (st.has_delta_f()) {
         d_f = (double*)C.get("delta_f", nloc_w * 8);
-        HIPC(hipMemcpy(d_f, st.delta_f.data(), nloc_w * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(d_f, st.src_delta_f(), nloc_w * 8, hipMemcpyDefault));
     }
     e->dev->set_delta_m_fraction(d_f);
     e->dev->solve_device_vector(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status, nullptr,
@@ -646,11 +674,11 @@ static void upload_emission(Engine* e, const AtmosphereStorage& st, const Surfac
     DeviceCache& C = e->cache;
     const size_t nloc_w = size_t(e->ngrid) * st.nwavel;
     double* d_em = (double*)C.get("so_emission", nloc_w * 8);
-    HIPC(hipMemcpy(d_em, st.emission, nloc_w * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_em, st.emission, nloc_w * 8, hipMemcpyDefault));
     double* d_sem = nullptr;
     if (su.emission) {
         d_sem = (double*)C.get("so_surface_emission", size_t(st.nwavel) * 8);
-        HIPC(hipMemcpy(d_sem, su.emission, size_t(st.nwavel) * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(d_sem, su.emission, size_t(st.nwavel) * 8, hipMemcpyDefault));
     }
     e->so->set_emission(d_em, d_sem);
 }
@@ -674,13 +702,13 @@ static int calculate_radiance_so(Engine* e, Atmosphere* atm, OutputC* out) {
     double* d_rad = (double*)C.get("so_radiance", nt * S * 8);
     double* d_od = (double*)C.get("so_los_od", nt * 8);
     double *d_irr = nullptr, *d_we = nullptr, *d_ws = nullptr, *d_wa = nullptr;
-    HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyDefault));
+    HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyDefault));
+    HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyDefault));
+    HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyDefault));
     if (st.irradiance) {
         d_irr = (double*)C.get("so_irradiance", size_t(nw) * 8);
-        HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyDefault));
     }
     if (derivs) {
         d_we = (double*)C.get("wf_ext", size_t(ngrid) * nt * S * 8);
@@ -728,31 +756,31 @@ static int calculate_radiance_ts(Engine* e, Atmosphere* atm, OutputC* out) {
     double* d_alb = (double*)C.get("albedo", size_t(nw) * 8);
     double* d_rad = (double*)C.get("radiance", nt * 8);
     double* d_od = (double*)C.get("los_od", nt * 8);
-    HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyDefault));
+    HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyDefault));
+    HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyDefault));
+    HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyDefault));
     in.ext = d_ext; in.ssa = d_ssa; in.leg = d_leg; in.albedo = d_alb;
     double* d_irr = nullptr;
     if (st.irradiance) {
         d_irr = (double*)C.get("irradiance", size_t(nw) * 8);
-        HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyDefault));
     }
     in.irradiance = d_irr;
     double* d_f = nullptr;
-    if (!st.delta_f.empty()) {
+    if (st.has_delta_f()) {
         d_f = (double*)C.get("delta_f", nloc_w * 8);
-        HIPC(hipMemcpy(d_f, st.delta_f.data(), nloc_w * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(d_f, st.src_delta_f(), nloc_w * 8, hipMemcpyDefault));
     }
     in.delta_f = d_f;
     if (e->ts->thermal()) {
         if (!st.emission) throw std::runtime_error("emission_source = twostream but the atmosphere storage has no emission_source array");
         double* d_em = (double*)C.get("ts_emission", nloc_w * 8);
-        HIPC(hipMemcpy(d_em, st.emission, nloc_w * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(d_em, st.emission, nloc_w * 8, hipMemcpyDefault));
         in.emission = d_em;
         if (su.emission) {
             double* d_sem = (double*)C.get("ts_surface_emission", size_t(nw) * 8);
-            HIPC(hipMemcpy(d_sem, su.emission, size_t(nw) * 8, hipMemcpyHostToDevice));
+            HIPC(hipMemcpy(d_sem, su.emission, size_t(nw) * 8, hipMemcpyDefault));
             in.surface_emission = d_sem;
         }
     }
@@ -788,10 +816,10 @@ static int calculate_radiance_ts(Engine* e, Atmosphere* atm, OutputC* out) {
         d_wg = (double*)C.get("wf_scat", group_of.size() * size_t(ngrid) * nt * 8);
         for (auto& kv : group_of) {
             const DerivativeMapping& m = *st.maps.at(kv.first);
-            HIPC(hipMemcpy(d_dleg, m.d_legendre.data(), per_g * 8, hipMemcpyHostToDevice));
-            const bool with_f = d_f && m.d_f.size() == nloc_w;
+            HIPC(hipMemcpy(d_dleg, m.src_d_legendre(), per_g * 8, hipMemcpyDefault));
+            const bool with_f = d_f && m.has_d_f(nloc_w);
             if (d_f && !with_f) throw std::runtime_error("scattering mapping " + kv.first + " was created after the delta-M scaling");
-            if (with_f) HIPC(hipMemcpy(d_df, m.d_f.data(), nloc_w * 8, hipMemcpyHostToDevice));
+            if (with_f) HIPC(hipMemcpy(d_df, m.src_d_f(), nloc_w * 8, hipMemcpyDefault));
             hipLaunchKernelGGL(kern_ts_scat_group, dim3(2048), dim3(256), 0, nullptr, d_wb, d_dleg, with_f ? d_f : nullptr, with_f ? d_df : nullptr,
                                d_wg + size_t(kv.second) * ngrid * nt, ngrid, nw, nlos, st.nleg);
             HIPC(hipGetLastError());
@@ -825,6 +853,23 @@ static void validate_input_atmosphere(const Engine* e, const AtmosphereStorage& 
     if (!st.ext || !st.ssa || !st.leg) throw std::runtime_error("Invalid input: atmosphere storage has null arrays");
     auto scan = [&](const double* a, const char* name, double lo, double hi) {
         const size_t n = size_t(st.nloc) * st.nwavel;
+        if (st.on_device) {
+            // the arrays live in HBM (optical-property front end): the same scan as a kernel, the first offender comes back in one word
+            unsigned long long* d_first = (unsigned long long*)const_cast<Engine*>(e)->cache.get("validate_first", 8);
+            const unsigned long long none = ~0ull;
+            HIPC(hipMemcpy(d_first, &none, 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(skfe::k_fe_validate, dim3(skfe::stream_grid(n)), dim3(256), 0, nullptr, a, n, lo, hi, d_first);
+            HIPC(hipGetLastError());
+            unsigned long long first = none;
+            HIPC(hipMemcpy(&first, d_first, 8, hipMemcpyDeviceToHost));
+            if (first == none) return;
+            const size_t i = size_t(first >> 2);
+            const std::string where = " at location: " + std::to_string(i % st.nloc) + " and wavelength: " + std::to_string(i / st.nloc);
+            const int kind = int(first & 3);
+            if (kind == 1) throw std::runtime_error(std::string("Invalid input. ") + name + " contains non-finite values" + where);
+            if (kind == 2) throw std::runtime_error(std::string("Invalid input. ") + name + " contains values less than " + std::to_string(lo) + where);
+            throw std::runtime_error(std::string("Invalid input. ") + name + " contains values greater than " + std::to_string(hi) + where);
+        }
         for (size_t i = 0; i < n; ++i) {
             const double v = a[i];
             if (std::isfinite(v) && v >= lo && v <= hi) continue;
@@ -879,8 +924,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         for (auto& kv : out->derivs) {
             auto it = st.maps.find(kv.first);
             if (it == st.maps.end()) continue;
-            for (double v : it->second->d_emission)
-                if (v != 0.0) return -2;   // emission derivatives are not part of this path
+            if (it->second->uses_emission()) return -2;   // emission derivatives are not part of this path
             scattering_groups = scattering_groups || is_scattering_mapping(*it->second);
         }
         // scattering-group derivatives are served by the run-time-n kernels for every stream count
@@ -905,13 +949,13 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         double* d_odt = (double*)C.get("los_od_t", nt * 8);
         int* d_status = (int*)C.get("status", size_t(nw) * 4);
         double *d_irr = nullptr, *d_we = nullptr, *d_ws = nullptr, *d_wa = nullptr;
-        HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyHostToDevice));
-        HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyHostToDevice));
-        HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyHostToDevice));
-        HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyDefault));
+        HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyDefault));
+        HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyDefault));
+        HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyDefault));
         if (st.irradiance) {
             d_irr = (double*)C.get("irradiance", size_t(nw) * 8);
-            HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyHostToDevice));
+            HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyDefault));
         }
         if (derivs) {
             d_we = (double*)C.get("wf_ext", size_t(ngrid) * nt * 8);
@@ -919,9 +963,9 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
             d_wa = (double*)C.get("wf_alb", nt * 8);
         }
         double* d_f = nullptr;
-        if (!st.delta_f.empty()) {
+        if (st.has_delta_f()) {
             d_f = (double*)C.get("delta_f", nloc_w * 8);
-            HIPC(hipMemcpy(d_f, st.delta_f.data(), nloc_w * 8, hipMemcpyHostToDevice));
+            HIPC(hipMemcpy(d_f, st.src_delta_f(), nloc_w * 8, hipMemcpyDefault));
         }
         e->dev->set_delta_m_fraction(d_f);
         if (e->config.emission_source == 2) {   // thermal source inside the DO equations
@@ -931,11 +975,11 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
             }
             if (!st.emission) throw std::runtime_error("emission_source = discrete_ordinates but the atmosphere storage has no emission_source array");
             double* d_em = (double*)C.get("do_emission", nloc_w * 8);
-            HIPC(hipMemcpy(d_em, st.emission, nloc_w * 8, hipMemcpyHostToDevice));
+            HIPC(hipMemcpy(d_em, st.emission, nloc_w * 8, hipMemcpyDefault));
             double* d_sem = nullptr;
             if (su.emission) {
                 d_sem = (double*)C.get("do_surface_emission", size_t(nw) * 8);
-                HIPC(hipMemcpy(d_sem, su.emission, size_t(nw) * 8, hipMemcpyHostToDevice));
+                HIPC(hipMemcpy(d_sem, su.emission, size_t(nw) * 8, hipMemcpyDefault));
             }
             e->dev->set_thermal_emission(d_em, d_sem);
         }
@@ -1105,6 +1149,8 @@ int sk_amd_so_engine_sizes(Engine* e, unsigned long long* sizes) {
     return 0;
 }
 
+static int frontend_apply_delta_m(AtmosphereStorage& st, int order, int stack);
 #include "capi_rest.inc"
+#include "frontend.inc"
 
 }  // extern "C"

@@ -1,0 +1,174 @@
+"""Host handle of the device front end (`sk_amd_frontend_*`, include/sasktran2_amd.h): what `Atmosphere.internal_object()` drives when
+constituents are set.  The reference's counterpart is the Rust `PyAtmosphere` storage the constituents write into
+(src/sasktran2/atmosphere.py:262-272, 730-771); here the constituents hand over profiles and spectra, and the [location x wavelength]
+arrays exist only in HBM."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from ._lib_loader import last_error, lib
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+class DeviceMapping:
+    """Read-only view of one derivative mapping held in HBM (`atmosphere.storage.get_derivative_mapping(name)` of the reference)."""
+
+    def __init__(self, fe, name, scatterer, emission, interpolator, interp_dim, assign_name):
+        self._fe, self.name, self.scatterer, self.emission = fe, name, scatterer, emission
+        self.interpolator, self.interp_dim, self.assign_name = interpolator, interp_dim, assign_name
+
+    def _get(self, field, shape):
+        return self._fe.download(f"{self.name}:{field}", shape)
+
+    @property
+    def d_extinction(self):
+        return self._get("d_extinction", (self._fe.nwavel, self._fe.ngrid)).T
+
+    @property
+    def d_ssa(self):
+        return self._get("d_ssa", (self._fe.nwavel, self._fe.ngrid)).T
+
+    @property
+    def scat_factor(self):
+        return self._get("scat_factor", (self._fe.nwavel, self._fe.ngrid)).T if self.scatterer else None
+
+    @property
+    def d_leg_coeff(self):
+        return self._get("d_legendre", (self._fe.nwavel, self._fe.ngrid, self._fe.nleg)).transpose(2, 1, 0) if self.scatterer else None
+
+    @property
+    def d_emission(self):
+        return self._get("d_emission", (self._fe.nwavel, self._fe.ngrid)).T if self.emission else None
+
+    @property
+    def num_output(self):
+        return self._fe.ngrid if self.interpolator is None else self.interpolator.shape[1]
+
+
+class FrontEnd:
+    def __init__(self, ngrid, nwavel, nleg, nstokes):
+        self.ngrid, self.nwavel, self.nleg, self.nstokes = int(ngrid), int(nwavel), int(nleg), int(nstokes)
+        self._h = lib().sk_amd_frontend_create(self.ngrid, self.nwavel, self.nleg, self.nstokes)
+        if not self._h:
+            raise RuntimeError(f"sk_amd_frontend_create failed: {last_error()}")
+        self.mappings = {}
+        self.assembled = False
+
+    def __del__(self):
+        if getattr(self, "_h", None) and callable(lib):
+            lib().sk_amd_frontend_destroy(self._h)
+            self._h = None
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise RuntimeError(f"{what} returned {rc}: {last_error()}")
+        return rc
+
+    def reset(self):
+        self._check(lib().sk_amd_frontend_reset(self._h), "sk_amd_frontend_reset")
+        self.mappings = {}
+        self.assembled = False
+
+    def add_term(self, profile, ext, scat=None, leg=None):
+        profile, ext, scat, leg = _c(profile), _c(ext), _c(scat), _c(leg)
+        if profile.shape != (self.ngrid,) or ext.shape != (self.nwavel,):
+            raise ValueError("a term is profile [location] x spectrum [wavelength]")
+        if scat is not None and scat.shape != (self.nwavel,):
+            raise ValueError("the scattering spectrum has one value per wavelength")
+        if leg is not None and leg.shape != (self.nwavel, self.nleg):
+            raise ValueError("phase moments are [wavelength, first dimension of leg_coeff]")
+        return self._check(lib().sk_amd_frontend_add_term(self._h, _vp(profile), _vp(ext), _vp(scat), _vp(leg)), "sk_amd_frontend_add_term")
+
+    def set_profile(self, term, profile):
+        profile = _c(profile)
+        self._check(lib().sk_amd_frontend_set_profile(self._h, int(term), _vp(profile)), "sk_amd_frontend_set_profile")
+        self.assembled = False
+
+    def set_planck_emission(self, temperature_k, wavelengths_nm):
+        t, w = _c(temperature_k), _c(wavelengths_nm)
+        self._check(lib().sk_amd_frontend_set_planck_emission(self._h, _vp(t), _vp(w)), "sk_amd_frontend_set_planck_emission")
+
+    def set_solar_irradiance(self, irradiance):
+        v = _c(irradiance)
+        self._check(lib().sk_amd_frontend_set_solar_irradiance(self._h, _vp(v)), "sk_amd_frontend_set_solar_irradiance")
+
+    def assemble(self):
+        self._check(lib().sk_amd_frontend_assemble(self._h), "sk_amd_frontend_assemble")
+        self.mappings = {}
+        self.assembled = True
+
+    def add_mapping(self, name, terms=(), weights=None, scatterer=False, planck=False, interpolator=None, interp_dim="altitude", assign_name=""):
+        """interpolator: [location, nout] (rows = model grid), as the reference's mappings hold it"""
+        terms = np.ascontiguousarray(terms, dtype=np.int32)
+        w = None
+        if weights is not None:
+            w = _c(weights)
+            if w.shape != (len(terms), self.ngrid):
+                raise ValueError("weights are [term, location]")
+        interp, nout = None, 0
+        if interpolator is not None:
+            interpolator = np.asarray(interpolator, dtype=np.float64)
+            if interpolator.shape[0] != self.ngrid:
+                raise ValueError("the interpolator has one row per grid location")
+            nout = interpolator.shape[1]
+            interp = np.asfortranarray(interpolator)
+        self._check(lib().sk_amd_frontend_add_mapping(self._h, name.encode(), len(terms), terms.ctypes.data_as(ctypes.c_void_p), _vp(w), int(scatterer),
+                                                      int(planck), _vp(interp), nout, interp_dim.encode(), assign_name.encode()),
+                    "sk_amd_frontend_add_mapping")
+        self.mappings[name] = DeviceMapping(self, name, bool(scatterer), bool(planck), None if interpolator is None else interpolator.copy(),
+                                            interp_dim, assign_name)
+
+    def storage_handle(self):
+        h = lib().sk_amd_frontend_storage(self._h)
+        if not h:
+            raise RuntimeError("the front end has not been assembled")
+        return h
+
+    def download(self, what, shape):
+        out = np.zeros(shape)
+        self._check(lib().sk_amd_frontend_download(self._h, what.encode(), _vp(out)), "sk_amd_frontend_download")
+        return out
+
+    def device_pointer(self, what):
+        p, n = ctypes.c_void_p(), ctypes.c_ulonglong()
+        self._check(lib().sk_amd_frontend_device_pointer(self._h, what.encode(), ctypes.byref(p), ctypes.byref(n)), "sk_amd_frontend_device_pointer")
+        return p.value, n.value
+
+
+class DeviceStorage:
+    """`atmosphere.storage` of an atmosphere assembled on the device: the reference's array names, copied from HBM on access."""
+
+    def __init__(self, fe, solar_irradiance):
+        self._fe = fe
+        self.solar_irradiance = solar_irradiance
+
+    @property
+    def total_extinction(self):
+        return self._fe.download("extinction", (self._fe.nwavel, self._fe.ngrid)).T
+
+    @property
+    def ssa(self):
+        return self._fe.download("ssa", (self._fe.nwavel, self._fe.ngrid)).T
+
+    @property
+    def emission_source(self):
+        return self._fe.download("emission", (self._fe.nwavel, self._fe.ngrid)).T
+
+    @property
+    def leg_coeff(self):
+        return self._fe.download("leg_coeff", (self._fe.nwavel, self._fe.ngrid, self._fe.nleg)).transpose(2, 1, 0)
+
+    def derivative_mapping_names(self):
+        return list(self._fe.mappings)
+
+    def get_derivative_mapping(self, name):
+        return self._fe.mappings[name]

@@ -283,3 +283,70 @@ def twostream_delta_m_case(num_wavelengths: int = 9):
                               geotype=GEO_PLANEPARALLEL),
                 config=dict(nstr=2, num_sza=1), rays=rays, extinction=k, ssa=ssa, leg=leg, albedo=np.full(nw, 0.2),
                 solar_irradiance=np.full(nw, 1.1))
+
+
+# ---------------------------------------------------------------------------------------------------------------- optical-property front end
+def frontend_case(nwavel=40, ngrid=25, seed=3):
+    """State, tables and profiles of a constituent atmosphere: an exponential pressure profile with a lapse-rate /
+    isothermal temperature, a temperature-dependent ozone-like absorber on its own altitude grid, a Henyey-Greenstein aerosol given as
+    number density and one given as extinction at 525 nm."""
+    rng = np.random.default_rng(seed)
+    alt = np.linspace(0.0, 60000.0, ngrid)
+    temperature = np.where(alt < 11000.0, 288.15 - 6.5e-3 * alt, 216.65 + 1.2e-3 * np.maximum(alt - 20000.0, 0.0))
+    pressure = 101325.0 * np.exp(-alt / 7400.0)
+    wavelengths = np.linspace(300.0, 750.0, nwavel)
+    tab_wl = np.linspace(250.0, 800.0, 111)
+    tab_t = np.array([203.0, 223.0, 243.0, 273.0, 293.0])
+    base = 1.1e-23 * np.exp(-((tab_wl - 255.0) / 32.0) ** 2) + 4.5e-25 * np.exp(-((tab_wl - 600.0) / 60.0) ** 2) + 1e-27
+    tab_xs = base[np.newaxis, :] * (1.0 + 2.0e-3 * (tab_t[:, np.newaxis] - 243.0) * (1.0 + 0.3 * np.sin(tab_wl / 40.0))[np.newaxis, :])
+    o3_alt = np.linspace(0.0, 65000.0, 14)
+    o3_vmr = 8e-6 * np.exp(-((o3_alt - 24000.0) / 9000.0) ** 2) + 3e-8
+    hg_wl = np.array([280.0, 350.0, 450.0, 550.0, 700.0, 800.0])
+    hg_xs = 3.0e-14 * (hg_wl / 550.0) ** -1.3
+    hg_ssa = np.array([0.93, 0.95, 0.96, 0.97, 0.975, 0.98])
+    hg_g = np.array([0.74, 0.72, 0.70, 0.68, 0.66, 0.65])
+    aer_alt = np.array([0.0, 5000.0, 12000.0, 20000.0, 30000.0, 45000.0])
+    aer_nd = np.array([4.0e8, 9.0e7, 2.0e7, 8.0e6, 1.5e6, 1.0e5]) * (1.0 + 0.1 * rng.random(6))
+    aer_ext = np.array([2.0e-7, 3.5e-7, 1.2e-7, 4.0e-8, 1.0e-8, 1.0e-9])
+    return dict(altitudes=alt, temperature=temperature, pressure=pressure, wavelengths=wavelengths, tab_wl=tab_wl, tab_t=tab_t, tab_xs=tab_xs,
+                o3_alt=o3_alt, o3_vmr=o3_vmr, hg_wl=hg_wl, hg_xs=hg_xs, hg_scat=hg_xs * hg_ssa, hg_g=hg_g, aer_alt=aer_alt, aer_nd=aer_nd,
+                aer_ext=aer_ext, ext_wavelength=525.0)
+
+
+def frontend_oracle_atmosphere(c, nmoments, nstokes=1, thermal=False, temperature_table=True, extinction_scatterer=True,
+                               pressure_derivative=True, temperature_derivative=True):
+    """The oracle's assembly of `frontend_case` (oracle/frontend_oracle.py)."""
+    from oracle import frontend_oracle as fo
+    a = fo.Atmosphere(c["altitudes"], c["wavelengths"], nmoments, nstokes, c["pressure"], c["temperature"], pressure_derivative, temperature_derivative)
+    a.constituents["rayleigh"] = fo.Rayleigh()
+    wv = 1e7 / c["tab_wl"]
+    order = np.argsort(wv)
+    table = fo.AbsorberTable(wv[order], c["tab_xs"][:, order], c["tab_t"]) if temperature_table else fo.AbsorberTable(wv[order], c["tab_xs"][2, order])
+    a.constituents["o3"] = fo.VMRAltitudeAbsorber(table, c["o3_alt"], c["o3_vmr"], "extend")
+    hg = fo.HenyeyGreensteinTable(c["hg_wl"], c["hg_xs"], c["hg_scat"], c["hg_g"], 64)
+    a.constituents["aerosol"] = fo.NumberDensityScatterer(hg, c["aer_alt"], c["aer_nd"], "zero")
+    if extinction_scatterer:
+        a.constituents["cloud"] = fo.ExtinctionScatterer(hg, c["aer_alt"], c["aer_ext"], c["ext_wavelength"], "zero")
+    if thermal:
+        a.constituents["thermal"] = fo.ThermalEmission()
+    return a
+
+
+def frontend_product_atmosphere(sk, c, geometry, config, thermal=False, temperature_table=True, extinction_scatterer=True,
+                                calculate_derivatives=True, pressure_derivative=True, temperature_derivative=True):
+    """The same atmosphere through the product's constituent interface (sasktran2_amd.constituent / .optical)."""
+    atmo = sk.Atmosphere(geometry, config, wavelengths_nm=c["wavelengths"], calculate_derivatives=calculate_derivatives,
+                         pressure_derivative=pressure_derivative, temperature_derivative=temperature_derivative)
+    atmo.pressure_pa = c["pressure"]
+    atmo.temperature_k = c["temperature"]
+    atmo["rayleigh"] = sk.constituent.Rayleigh()
+    table = (sk.optical.AbsorberDatabaseDim2(wavelength_nm=c["tab_wl"], param=c["tab_t"], xs=c["tab_xs"]) if temperature_table
+             else sk.optical.AbsorberDatabaseDim1(wavelength_nm=c["tab_wl"], xs=c["tab_xs"][2]))
+    atmo["o3"] = sk.constituent.VMRAltitudeAbsorber(table, c["o3_alt"], c["o3_vmr"], "extend")
+    hg = sk.optical.HenyeyGreenstein.from_parameters(c["hg_wl"], c["hg_xs"], c["hg_scat"], c["hg_g"], 64)
+    atmo["aerosol"] = sk.constituent.NumberDensityScatterer(hg, c["aer_alt"], c["aer_nd"], "zero")
+    if extinction_scatterer:
+        atmo["cloud"] = sk.constituent.ExtinctionScatterer(hg, c["aer_alt"], c["aer_ext"], c["ext_wavelength"], "zero")
+    if thermal:
+        atmo["thermal"] = sk.constituent.ThermalEmission()
+    return atmo

@@ -1,0 +1,288 @@
+"""Optical-property front end on the device: parity of frontend.hip -- through the C ABI and the Python constituent
+interface -- with the numpy oracle (oracle/frontend_oracle.py), and the reference's own criterion for this row: weighting functions of
+the constituents' parameters equal finite differences of the radiance (tests/weightingfunctions/test_pressure_temperature.py,
+tests/constituent/test_scatterer_extinction.py:86-160).
+
+Tolerances: storage and mapping arrays 2e-13 relative to the largest element of the array at that wavelength (the device sums all terms in
+one pass, the oracle adds constituent after constituent: a different order of the same sums); radiances 1e-10; weighting functions against
+finite differences 2e-5 (central differences of an FP64 forward model)."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from tests import scenarios as sc
+
+pytestmark = pytest.mark.gpu
+
+
+def _geometry(sk, c, geotype=None):
+    return sk.Geometry1D(0.6, 0.0, 6372000.0, c["altitudes"], sk.InterpolationMethod.LinearInterpolation,
+                         sk.GeometryType.Spherical if geotype is None else geotype)
+
+
+def _config(sk, nstokes=1, streams=4, moments=8, **kw):
+    cfg = sk.Config()
+    cfg.num_stokes = nstokes
+    cfg.num_streams = streams
+    cfg.num_singlescatter_moments = moments
+    cfg.multiple_scatter_source = sk.MultipleScatterSource.DiscreteOrdinates
+    cfg.single_scatter_source = sk.SingleScatterSource.DiscreteOrdinates
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _close(got, want, tol=2e-13):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape
+    scale = np.max(np.abs(want), axis=tuple(range(want.ndim - 1)), keepdims=True) if want.ndim > 1 else np.max(np.abs(want))
+    assert np.all(np.abs(got - want) <= tol * scale + 1e-300), float(np.max(np.abs(got - want) / (scale + 1e-300)))
+
+
+@pytest.mark.parametrize("nstokes", [1, 3])
+def test_storage_and_mappings_match_oracle(nstokes):
+    import sasktran2_amd as sk
+    c = sc.frontend_case(nwavel=33)
+    cfg = _config(sk, nstokes=nstokes, moments=8)
+    atmo = sc.frontend_product_atmosphere(sk, c, _geometry(sk, c), cfg, thermal=True)
+    atmo.internal_object()
+    want = sc.frontend_oracle_atmosphere(c, 8, nstokes, thermal=True).assemble()
+    st = atmo.storage
+    _close(st.total_extinction, want.ext)
+    _close(st.ssa, want.ssa)
+    _close(st.leg_coeff, want.leg)
+    _close(st.emission_source, want.emission)
+    assert set(st.derivative_mapping_names()) == set(want.mappings)
+    for name, w in want.mappings.items():
+        m = st.get_derivative_mapping(name)
+        assert (m.assign_name, m.interp_dim) == (w.assign_name, w.interp_dim), name
+        _close(m.d_extinction, w.d_extinction)
+        # d_ssa is a difference (species ssa - total ssa) scaled by 1/k: compare against the size of its two parts
+        part = np.abs(w.d_extinction) / np.where(want.ext > 0, want.ext, 1.0)
+        assert np.all(np.abs(m.d_ssa - w.d_ssa) <= 1e-12 * np.max(part, axis=0, keepdims=True) + 1e-300), name
+        if w.scat_factor is not None:
+            _close(m.scat_factor, w.scat_factor)
+            assert np.all(np.abs(m.d_leg_coeff - w.d_legendre) <= 2e-13 * (1.0 + np.abs(want.leg))), name
+        else:
+            assert m.scat_factor is None
+        if name == "wf_thermal_temperature_k":
+            _close(m.d_emission, w.d_emission)
+        if w.interpolator is None:
+            assert m.interpolator is None
+        else:
+            np.testing.assert_allclose(m.interpolator, w.interpolator, rtol=1e-14, atol=0)
+
+
+def test_c_abi_terms_profile_update_and_refusals():
+    """the C ABI directly: one term, its derivative mapping, a profile update, and what a device-resident mapping refuses"""
+    import ctypes
+
+    from sasktran2_amd._lib_loader import last_error, lib
+    L = lib()
+    ngrid, nw, nleg = 6, 5, 4
+    rng = np.random.default_rng(1)
+    prof, ext, scat = rng.random(ngrid) + 0.1, rng.random(nw) + 0.5, rng.random(nw) * 0.4
+    leg = rng.random((nw, nleg))
+    leg[:, 0] = 1.0
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+    f = L.sk_amd_frontend_create(ngrid, nw, nleg, 1)
+    assert f
+    try:
+        assert L.sk_amd_frontend_storage(f) is None                     # nothing assembled yet
+        t = L.sk_amd_frontend_add_term(f, vp(prof), vp(ext), vp(scat), vp(leg))
+        assert t == 0 and L.sk_amd_frontend_assemble(f) == 0
+        k = np.zeros((nw, ngrid))
+        assert L.sk_amd_frontend_download(f, b"extinction", vp(k)) == 0
+        np.testing.assert_allclose(k, ext[:, None] * prof[None, :], rtol=1e-15)
+        terms = np.array([0], dtype=np.int32)
+        assert L.sk_amd_frontend_add_mapping(f, b"wf_x", 1, vp(terms), None, 1, 0, None, 0, b"altitude", b"") == 0
+        assert L.sk_amd_frontend_add_mapping(f, b"wf_x", 1, vp(terms), None, 1, 0, None, 0, b"altitude", b"") == -3 and b"exists" in L.sk_amd_last_error()
+        d = np.zeros((nw, ngrid))
+        assert L.sk_amd_frontend_download(f, b"wf_x:d_ssa", vp(d)) == 0
+        np.testing.assert_allclose(d, 0.0, atol=1e-15)                  # a single species: its ssa IS the total ssa
+        dl = np.zeros((nw, ngrid, nleg))
+        assert L.sk_amd_frontend_download(f, b"wf_x:d_legendre", vp(dl)) == 0
+        np.testing.assert_allclose(dl, 0.0, atol=1e-15)
+        # a host accessor of a device mapping is refused, loudly
+        st = L.sk_amd_frontend_storage(f)
+        m = ctypes.c_void_p()
+        assert L.sk_atmosphere_storage_get_derivative_mapping(st, b"wf_x", ctypes.byref(m)) == 0
+        p = ctypes.POINTER(ctypes.c_double)()
+        assert L.sk_deriv_mapping_get_d_ssa(m, ctypes.byref(p)) == -2 and "device" in last_error()
+        assert L.sk_atmosphere_storage_set_zero(st) == -2
+        # amounts change, spectra stay
+        prof2 = prof * 2.0
+        assert L.sk_amd_frontend_set_profile(f, 0, vp(prof2)) == 0 and L.sk_amd_frontend_assemble(f) == 0
+        assert L.sk_amd_frontend_download(f, b"extinction", vp(k)) == 0
+        np.testing.assert_allclose(k, ext[:, None] * prof2[None, :], rtol=1e-15)
+        assert L.sk_amd_frontend_download(f, b"nothing", vp(k)) == -3
+        assert L.sk_amd_frontend_add_term(f, vp(prof), vp(ext), None, vp(leg)) == -3     # moments without a scattering cross section
+    finally:
+        L.sk_amd_frontend_destroy(f)
+
+
+def _engine_case(sk, c, cfg, rays, **atmo_kw):
+    geo = _geometry(sk, c, atmo_kw.pop("geotype", None))
+    vg = sk.ViewingGeometry()
+    for r in rays:
+        vg.add_ray(r)
+    return sk.Engine(cfg, geo, vg), geo
+
+
+def _perturbed(c, key, j, h):
+    cp = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    cp[key][j] += h
+    return cp
+
+
+@pytest.mark.parametrize("key,field,j,step", [
+    ("wf_o3_vmr", "o3_vmr", 5, 2e-8), ("wf_aerosol_number_density", "aer_nd", 2, 2e4), ("wf_cloud_extinction", "aer_ext", 1, 2e-10),
+    ("wf_temperature_k", "temperature", 6, 5e-2), ("wf_pressure_pa", "pressure", 3, 5.0)])
+def test_weighting_functions_match_finite_differences(key, field, j, step):
+    """radiance through the whole chain (constituents -> device assembly -> discrete ordinates), limb and nadir lines of sight"""
+    import sasktran2_amd as sk
+    c = sc.frontend_case(nwavel=6)
+    cfg = _config(sk, streams=8, moments=8)
+    rays = [sk.TangentAltitudeSolar(15000.0, 0.3, 200000.0, 0.6), sk.TangentAltitudeSolar(32000.0, 0.3, 200000.0, 0.6),
+            sk.GroundViewingSolar(0.6, 0.5, 0.8, 200000.0)]
+    engine, geo = _engine_case(sk, c, cfg, rays)
+
+    def radiance(case, derivs):
+        atmo = sc.frontend_product_atmosphere(sk, case, geo, cfg, calculate_derivatives=derivs)
+        atmo["surface"] = sk.constituent.LambertianSurface(0.3)
+        return engine.calculate_radiance(atmo, as_dataset=False)
+    base = radiance(c, True)
+    assert base[key].shape[1:] == (6, 3, 1)
+    fd = (radiance(_perturbed(c, field, j, step), False)["radiance"] - radiance(_perturbed(c, field, j, -step), False)["radiance"]) / (2 * step)
+    got = base[key][j]
+    assert np.max(np.abs(got)) > 0
+    np.testing.assert_allclose(got, fd, rtol=2e-5, atol=2e-6 * np.max(np.abs(fd)))
+    # the surface constituent's weighting function: one parameter (constant albedo) x wavelength x los
+    assert base["wf_surface_albedo"].shape == (1, 6, 3, 1)
+
+
+def test_constituent_path_equals_raw_interface():
+    """the same atmosphere through the raw interface (host arrays from the oracle, uploaded) and through the device front end: radiances
+    agree to rounding, and the absorber weighting function equals interpolator^T (d_extinction x wf_extinction + d_ssa x wf_ssa)"""
+    import sasktran2_amd as sk
+    c = sc.frontend_case(nwavel=9)
+    for delta_m in (False, True):
+        cfg = _config(sk, streams=4, moments=8, delta_m_scaling=delta_m)
+        rays = [sk.TangentAltitudeSolar(20000.0, 0.0, 200000.0, 0.6), sk.GroundViewingSolar(0.6, 1.0, 0.7, 200000.0)]
+        engine, geo = _engine_case(sk, c, cfg, rays)
+        atmo = sc.frontend_product_atmosphere(sk, c, geo, cfg)
+        atmo.surface.albedo[:] = 0.25
+        got = engine.calculate_radiance(atmo, as_dataset=False)
+        want = sc.frontend_oracle_atmosphere(c, 8).assemble()
+        raw = sk.Atmosphere(geo, cfg, numwavel=9)
+        raw.storage.total_extinction[:] = want.ext
+        raw.storage.ssa[:] = want.ssa
+        raw.leg_coeff.a1[:] = want.leg
+        raw.surface.albedo[:] = 0.25
+        ref = engine.calculate_radiance(raw, as_dataset=False)
+        np.testing.assert_allclose(got["radiance"], ref["radiance"], rtol=1e-10)
+        np.testing.assert_allclose(got["los_optical_depth"], ref["los_optical_depth"], rtol=1e-12)
+        if not delta_m:
+            m = want.mappings["wf_o3_vmr"]
+            v = m.d_extinction[:, :, None, None] * ref["wf_extinction"] + m.d_ssa[:, :, None, None] * ref["wf_ssa"]
+            np.testing.assert_allclose(got["wf_o3_vmr"], np.einsum("qj,qwls->jwls", m.interpolator, v), rtol=1e-8, atol=1e-10 * np.max(np.abs(got["wf_o3_vmr"])))   # (the raw run takes the matrix-core kernels, the constituent run -- scattering groups -- the run-time-n ones)
+
+
+def test_delta_m_scaling_on_the_device():
+    """delta-M scaling of storage and mappings in HBM (k_fe_delta_m_*) against the host scaling of sk_atmosphere_apply_delta_m_scaling
+    (same atmosphere through the raw interface, the oracle's mapping arrays written into a host mapping), and the absorber's weighting
+    function against finite differences.  (A scatterer's weighting function under delta-M is NOT compared with finite differences: the
+    discrete-ordinates source takes a layer's scattering direction from one grid point of its stencil, as the reference does --
+    sktran_do_layerarray.cpp:759-860 -- which is exact only while the truncation fraction does not vary over the layer.)"""
+    import ctypes
+
+    import sasktran2_amd as sk
+    c = sc.frontend_case(nwavel=4)
+    ng, nw, moments = 25, 4, 16
+    cfg = _config(sk, streams=4, moments=moments, delta_m_scaling=True)
+    engine, geo = _engine_case(sk, c, cfg, [sk.GroundViewingSolar(0.6, 0.5, 0.8, 200000.0), sk.TangentAltitudeSolar(15000.0, 0.3, 200000.0, 0.6)])
+    kw = dict(extinction_scatterer=False, pressure_derivative=False, temperature_derivative=False)
+
+    def radiance(case, derivs):
+        atmo = sc.frontend_product_atmosphere(sk, case, geo, cfg, calculate_derivatives=derivs, **kw)
+        atmo.surface.albedo[:] = 0.1
+        return engine.calculate_radiance(atmo, as_dataset=False)
+    base = radiance(c, True)
+    want = sc.frontend_oracle_atmosphere(c, moments, **kw).assemble()
+    mp = want.mappings["wf_aerosol_number_density"]
+    dp, vp = ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
+
+    def hook(L, h_st, h_out, out):
+        m = vp()
+        L.sk_atmosphere_storage_get_derivative_mapping(h_st, b"wf_scatterer", ctypes.byref(m))
+        for which, arr in (("d_extinction", mp.d_extinction.T), ("d_ssa", mp.d_ssa.T), ("scat_factor", mp.scat_factor.T),
+                           ("d_legendre", mp.d_legendre.transpose(2, 1, 0))):
+            ptr = dp()
+            assert getattr(L, f"sk_deriv_mapping_get_{which}")(m, ctypes.byref(ptr)) == 0
+            np.ctypeslib.as_array(ptr, shape=(arr.size,))[:] = arr.reshape(-1)
+        out["wf_scatterer"] = np.zeros((ng, nw, 2, 1))
+        L.sk_output_assign_derivative_memory(h_out, b"wf_scatterer", out["wf_scatterer"].ctypes.data_as(dp), nw * 2, 1, ng)
+    raw = sk.Atmosphere(geo, cfg, numwavel=nw)
+    raw.storage.total_extinction[:] = want.ext
+    raw.storage.ssa[:] = want.ssa
+    raw.leg_coeff.a1[:] = want.leg
+    raw.surface.albedo[:] = 0.1
+    host = engine.calculate_radiance(raw, as_dataset=False, _mapping_hook=hook)
+    np.testing.assert_allclose(base["radiance"], host["radiance"], rtol=1e-10)
+    ref = np.einsum("qj,qwls->jwls", mp.interpolator, host["wf_scatterer"])
+    np.testing.assert_allclose(base["wf_aerosol_number_density"], ref, rtol=1e-8, atol=1e-10 * np.max(np.abs(ref)))
+    j, step = 4, 2e-8
+    fd = (radiance(_perturbed(c, "o3_vmr", j, step), False)["radiance"] - radiance(_perturbed(c, "o3_vmr", j, -step), False)["radiance"]) / (2 * step)
+    np.testing.assert_allclose(base["wf_o3_vmr"][j], fd, rtol=2e-5, atol=2e-6 * np.max(np.abs(fd)))
+
+
+def test_two_stream_thermal_source_from_constituents():
+    """emission_source = twostream with the Planck term of ThermalEmission: wf_temperature_k collects the Planck derivative, the number
+    density of every gas and the temperature dependence of the absorber's table"""
+    import sasktran2_amd as sk
+    c = sc.frontend_case(nwavel=5)
+    c["wavelengths"] = np.linspace(9000.0, 11000.0, 5)
+    c["tab_wl"] = np.linspace(8000.0, 12000.0, 111)
+    c["tab_xs"] = c["tab_xs"] * 1e3
+    cfg = sk.Config()
+    cfg.num_streams = 2
+    cfg.num_singlescatter_moments = 4
+    cfg.multiple_scatter_source = sk.MultipleScatterSource.NoSource
+    cfg.single_scatter_source = sk.SingleScatterSource.NoSource
+    cfg.emission_source = sk.EmissionSource.TwoStream
+    engine, geo = _engine_case(sk, c, cfg, [sk.GroundViewingSolar(0.6, 0.0, 0.9, 200000.0)], geotype=sk.GeometryType.PlaneParallel)
+
+    def radiance(case, derivs):
+        atmo = sc.frontend_product_atmosphere(sk, case, geo, cfg, thermal=True, calculate_derivatives=derivs, extinction_scatterer=False)
+        atmo.surface.albedo[:] = 0.02
+        atmo.surface.emission[:] = 0.0
+        return engine.calculate_radiance(atmo, as_dataset=False)
+    base = radiance(c, True)
+    assert np.all(base["radiance"] > 0)
+    for j in (0, 4, 12):
+        step = 2e-2
+        fd = (radiance(_perturbed(c, "temperature", j, step), False)["radiance"] - radiance(_perturbed(c, "temperature", j, -step), False)["radiance"]) / (2 * step)
+        np.testing.assert_allclose(base["wf_temperature_k"][j], fd, rtol=2e-5, atol=2e-6 * np.max(np.abs(fd)))
+
+
+def test_exact_single_scatter_from_constituents_and_input_validation():
+    import sasktran2_amd as sk
+    c = sc.frontend_case(nwavel=7)
+    cfg = sk.Config()
+    cfg.num_singlescatter_moments = 16
+    cfg.multiple_scatter_source = sk.MultipleScatterSource.NoSource
+    cfg.single_scatter_source = sk.SingleScatterSource.Exact
+    engine, geo = _engine_case(sk, c, cfg, [sk.TangentAltitudeSolar(18000.0, 0.2, 200000.0, 0.6)])
+    atmo = sc.frontend_product_atmosphere(sk, c, geo, cfg, calculate_derivatives=False)
+    got = engine.calculate_radiance(atmo, as_dataset=False)
+    want = sc.frontend_oracle_atmosphere(c, 16).assemble(derivatives=False)
+    raw = sk.Atmosphere(geo, cfg, numwavel=7, calculate_derivatives=False)
+    raw.storage.total_extinction[:] = want.ext
+    raw.storage.ssa[:] = want.ssa
+    raw.leg_coeff.a1[:] = want.leg
+    np.testing.assert_allclose(got["radiance"], engine.calculate_radiance(raw, as_dataset=False)["radiance"], rtol=1e-10)
+    # a negative mixing ratio makes a negative extinction: found by the device-side scan, reported like the reference does
+    bad = _perturbed(c, "o3_vmr", 6, -1.0)
+    with pytest.raises(RuntimeError, match="total extinction contains values less than"):
+        engine.calculate_radiance(sc.frontend_product_atmosphere(sk, bad, geo, cfg, calculate_derivatives=False), as_dataset=False)
