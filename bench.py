@@ -80,10 +80,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--wavelengths", type=int, default=0, help="0 = the workload's own size (C2: 10 000, C5: 20 000, twostream: 220 000)")
-    ap.add_argument("--workload", choices=("c2", "c5", "twostream"), default="c2",
+    ap.add_argument("--workload", choices=("c2", "c5", "twostream", "frontend"), default="c2",
                     help="c2 (default, BASELINE.json's metric): 16-stream DISCO limb + weighting functions; c5: BASELINE configs[4], "
                          "exact single scatter + 10 successive orders of scattering; twostream: the reference's two-stream benchmark "
-                         "(20 layers, 220 000 wavelengths, weighting functions)")
+                         "(20 layers, 220 000 wavelengths, weighting functions); frontend: the optical-property front end (constituents -> storage and "
+                         "derivative mappings in HBM) at the C2 size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="wavelengths of the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -104,10 +105,13 @@ def main():
     from tests import scenarios as sc
     from tests.gpu_harness import build_engine
 
-    if args.workload in ("c5", "twostream"):
+    if args.workload in ("c5", "twostream", "frontend"):
         if args.workload == "c5":
             from bench_so import run_c5
             run_c5(args, world, rank, dev)
+        elif args.workload == "frontend":
+            from bench_frontend import run_frontend
+            run_frontend(args, world, rank, dev)
         else:
             from bench_ts import run_twostream
             run_twostream(args, world, rank, dev)

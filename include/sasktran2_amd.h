@@ -185,6 +185,10 @@ AtmosphereStorage* sk_amd_frontend_storage(sk_amd_frontend* f);   /* borrowed: v
  * ":d_legendre" | ":d_emission" | ":d_f" */
 int sk_amd_frontend_device_pointer(sk_amd_frontend* f, const char* what, const double** pointer, unsigned long long* count);
 int sk_amd_frontend_download(sk_amd_frontend* f, const char* what, double* host_destination);
+/* per-kernel HIP-event timing of the front end's launches (serialises them), as sk_amd_engine_set_profiling / _kernel_time / _kernel_names */
+int sk_amd_frontend_set_profiling(sk_amd_frontend* f, int enabled);
+int sk_amd_frontend_kernel_time(sk_amd_frontend* f, const char* kernel_name, double* total_ms, long* launches);
+int sk_amd_frontend_kernel_names(sk_amd_frontend* f, char* buffer, int buffer_len);
 /* sizes[0..5]: incoming rays, their layers, accumulation-matrix entries, outgoing directions, scratch bytes per wavelength,
  * wavelengths per block of the last solve */
 int sk_amd_so_engine_sizes(Engine* engine, unsigned long long* sizes);

@@ -82,6 +82,9 @@ SIGNATURES = [
     ("sk_amd_frontend_storage", _vp, [_vp]),
     ("sk_amd_frontend_device_pointer", _I, [_vp, _S, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_ulonglong)]),
     ("sk_amd_frontend_download", _I, [_vp, _S, _vp]),
+    ("sk_amd_frontend_set_profiling", _I, [_vp, _I]),
+    ("sk_amd_frontend_kernel_time", _I, [_vp, _S, _dp, ctypes.POINTER(ctypes.c_long)]),
+    ("sk_amd_frontend_kernel_names", _I, [_vp, ctypes.c_char_p, _I]),
     ("sk_amd_engine_num_los", _I, [_vp, _ip]),
     ("sk_amd_engine_scratch_bytes", _I, [_vp, _I, ctypes.POINTER(ctypes.c_ulonglong)]),
     ("sk_amd_engine_launch_shape", _I, [_vp, _ip, _ip, ctypes.POINTER(ctypes.c_ulonglong)]),

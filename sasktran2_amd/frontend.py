@@ -138,6 +138,20 @@ class FrontEnd:
         self._check(lib().sk_amd_frontend_download(self._h, what.encode(), _vp(out)), "sk_amd_frontend_download")
         return out
 
+    def set_profiling(self, on):
+        self._check(lib().sk_amd_frontend_set_profiling(self._h, int(bool(on))), "sk_amd_frontend_set_profiling")
+
+    def kernel_times(self):
+        """{kernel: (total ms, launches)} since profiling was switched on"""
+        buf = ctypes.create_string_buffer(1024)
+        lib().sk_amd_frontend_kernel_names(self._h, buf, 1024)
+        out = {}
+        for name in filter(None, buf.value.decode().split(",")):
+            ms, n = ctypes.c_double(), ctypes.c_long()
+            if lib().sk_amd_frontend_kernel_time(self._h, name.encode(), ctypes.byref(ms), ctypes.byref(n)) == 0:
+                out[name] = (ms.value, n.value)
+        return out
+
     def device_pointer(self, what):
         p, n = ctypes.c_void_p(), ctypes.c_ulonglong()
         self._check(lib().sk_amd_frontend_device_pointer(self._h, what.encode(), ctypes.byref(p), ctypes.byref(n)), "sk_amd_frontend_device_pointer")

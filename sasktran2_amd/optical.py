@@ -99,6 +99,19 @@ def _table_spectrum(wvnum_grid, row, wavenumbers):
     return row[i0] * w0 + row[i1] * w1
 
 
+class _SpectrumCache:
+    """The table interpolated to the atmosphere's spectral grid, kept while that grid stays the same (a retrieval changes profiles step
+    after step, not the wavelengths)."""
+
+    def __init__(self):
+        self._key, self._value = None, None
+
+    def get(self, wavenumbers, build):
+        if self._key is None or self._key.shape != wavenumbers.shape or not np.array_equal(self._key, wavenumbers):
+            self._key, self._value = wavenumbers.copy(), build(wavenumbers)
+        return self._value
+
+
 def _sorted_wavenumbers(wavenumber_cminv, wavelength_nm):
     if (wavenumber_cminv is None) == (wavelength_nm is None):
         raise ValueError("give exactly one of wavenumber_cminv and wavelength_nm")
@@ -115,10 +128,11 @@ class AbsorberDatabaseDim1(OpticalProperty):
         self._xs = np.asarray(xs, dtype=float)[order]
         if self._xs.shape != self._wvnum.shape:
             raise ValueError("xs must have one value per spectral grid point")
+        self._cache = _SpectrumCache()
 
     def spectral_terms(self, atmo):
         ones = np.ones(atmo.num_locations)
-        return [(ones, {}, {"ext": _table_spectrum(self._wvnum, self._xs, atmo.wavenumbers_cminv), "scat": None, "leg": None})]
+        return [(ones, {}, {"ext": self._cache.get(atmo.wavenumbers_cminv, lambda wv: _table_spectrum(self._wvnum, self._xs, wv)), "scat": None, "leg": None})]
 
 
 class AbsorberDatabaseDim2(OpticalProperty):
@@ -136,6 +150,7 @@ class AbsorberDatabaseDim2(OpticalProperty):
             raise ValueError("xs must be [parameter, spectral grid]")
         if self._name not in ("temperature_k", "pressure_pa"):
             raise ValueError("the table parameter must be temperature_k or pressure_pa")
+        self._cache = _SpectrumCache()
 
     def spectral_terms(self, atmo):
         values = getattr(atmo, self._name)
@@ -150,12 +165,12 @@ class AbsorberDatabaseDim2(OpticalProperty):
         np.add.at(weight, (i1, loc), w1)
         np.add.at(slope, (i0, loc), dw0)
         np.add.at(slope, (i1, loc), dw1)
+        rows = self._cache.get(atmo.wavenumbers_cminv, lambda wv: np.array([_table_spectrum(self._wvnum, r, wv) for r in self._xs]))
         out = []
         for t in range(len(self._param)):
             if not (weight[t].any() or slope[t].any()):
                 continue
-            out.append((weight[t], {self._name: slope[t]},
-                        {"ext": _table_spectrum(self._wvnum, self._xs[t], atmo.wavenumbers_cminv), "scat": None, "leg": None}))
+            out.append((weight[t], {self._name: slope[t]}, {"ext": rows[t], "scat": None, "leg": None}))
         return out
 
 
@@ -171,6 +186,7 @@ class HenyeyGreenstein(OpticalProperty):
         self._scat = np.asarray(ssa, dtype=float)[order]
         g = np.asarray(g, dtype=float)[order]
         self._moments = np.stack([(2.0 * l + 1.0) * g ** l for l in range(int(max_num_moments))], axis=1)   # [node, l]
+        self._cache = _SpectrumCache()
 
     @classmethod
     def from_parameters(cls, wavelength_nm, xs_total, ssa, g, max_num_moments=128):
@@ -181,10 +197,17 @@ class HenyeyGreenstein(OpticalProperty):
         return _table_spectrum(self._wvnum, self._xs, 1e7 / np.atleast_1d(np.asarray(wavelengths_nm, dtype=float)))
 
     def spectral_terms(self, atmo):
-        wv = atmo.wavenumbers_cminv
         per = 1 if atmo.nstokes == 1 else 4
-        norder = min(self._moments.shape[1], atmo.num_moments)
-        i0, w0, _, i1, w1, _ = interp_weights(self._wvnum, wv, "zero")
-        leg = np.zeros((len(wv), atmo.num_moments * per))
-        leg[:, 0:norder * per:per] = self._moments[i0, :norder] * w0[:, None] + self._moments[i1, :norder] * w1[:, None]
-        return [(np.ones(atmo.num_locations), {}, {"ext": self._xs[i0] * w0 + self._xs[i1] * w1, "scat": self._scat[i0] * w0 + self._scat[i1] * w1, "leg": leg})]
+        nmoments = atmo.num_moments
+
+        def build(wv):
+            norder = min(self._moments.shape[1], nmoments)
+            i0, w0, _, i1, w1, _ = interp_weights(self._wvnum, wv, "zero")
+            leg = np.zeros((len(wv), nmoments * per))
+            leg[:, 0:norder * per:per] = self._moments[i0, :norder] * w0[:, None] + self._moments[i1, :norder] * w1[:, None]
+            return {"ext": self._xs[i0] * w0 + self._xs[i1] * w1, "scat": self._scat[i0] * w0 + self._scat[i1] * w1, "leg": leg, "shape": (nmoments, per)}
+        spec = self._cache.get(atmo.wavenumbers_cminv, build)
+        if spec["shape"] != (nmoments, per):     # the same spectral grid asked for with another moment count / Stokes dimension
+            self._cache = _SpectrumCache()
+            spec = self._cache.get(atmo.wavenumbers_cminv, build)
+        return [(np.ones(atmo.num_locations), {}, spec)]

@@ -24,7 +24,7 @@ def find(sub, pattern):
 
 
 def short(name):
-    m = re.search(r"(kern_\w+|k_so_\w+|k_ts_\w+)(<[^>]*>)?", name)
+    m = re.search(r"(kern_\w+|k_so_\w+|k_ts_\w+|k_fe_\w+)(<[^>]*>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
 
