@@ -1,8 +1,8 @@
 """`bench.py --workload frontend`: the optical-property front end at the size of BASELINE configs[1] -- 51 altitudes,
 10 000 wavelengths, 16 stored Legendre moments.  One step = `Atmosphere.internal_object()`: Rayleigh + a temperature-dependent absorber
 (5 table temperatures) + a Henyey-Greenstein aerosol given as number density + one given as extinction, assembled in HBM together with
-their 8 derivative mappings (wf_o3_vmr, wf_pressure_pa and wf_temperature_k of Rayleigh and of the absorber, the table's own
-temperature derivative, wf_aerosol_number_density, wf_cloud_extinction).  The inputs of this path are profiles and spectra on the host
+their 9 derivative mappings (wf_o3_vmr, wf_pressure_pa and wf_temperature_k of Rayleigh and of the absorber, the table's own
+temperature derivative, wf_aerosol_number_density, wf_cloud_extinction, the Planck term's wf_temperature_k).  The inputs of this path are profiles and spectra on the host
 (a few hundred KB): the step includes preparing and uploading them; what it produces stays in HBM for the engines.
 
 Roofline bookkeeping: every kernel is a stream that writes its output once.  Algorithmic bytes per wavelength = arrays
@@ -119,7 +119,7 @@ def run_frontend(args, world, rank, dev):
         return
     value = NW * args.steps / elapsed
     line = {
-        "metric": "wavelengths/sec, atmosphere assembled from constituents (storage + 8 derivative mappings in HBM)",
+        "metric": "wavelengths/sec, atmosphere assembled from constituents (storage + derivative mappings in HBM)",
         "value": value, "unit": "wavelengths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
