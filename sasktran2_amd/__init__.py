@@ -621,4 +621,4 @@ class Engine:
         return out
 
 
-from . import constituent, optical  # noqa: E402,F401  (the constituent interface: sk.constituent.Rayleigh, sk.optical.HenyeyGreenstein, ...)
+from . import climatology, constituent, optical  # noqa: E402,F401  (the constituent interface: sk.constituent.Rayleigh, sk.optical.HenyeyGreenstein, ...)

@@ -180,3 +180,22 @@ def test_product_host_logic_matches_oracle():
     np.testing.assert_allclose(s["ext"], oxs, rtol=1e-14)
     np.testing.assert_allclose(s["scat"], osc, rtol=1e-14)
     np.testing.assert_allclose(s["leg"], oleg, rtol=1e-14)
+
+
+def test_us76_standard_atmosphere_known_values():
+    """published values of the U.S. Standard Atmosphere 1976 (the numbers the reference's table holds, src/sasktran2/climatology/us76.py)"""
+    from sasktran2_amd.climatology import us76
+    z = np.array([0.0, 5000.0, 10000.0, 20000.0, 30000.0, 50000.0, 70000.0, 80000.0])
+    t, p = us76.temperature_pressure(z)
+    np.testing.assert_allclose(t - 273.15, [15.00, -17.47, -49.90, -56.50, -46.64, -2.5, -53.57, -74.51], atol=6e-3)
+    np.testing.assert_allclose(p, [101325.0, 54048.0, 26500.0, 5529.3, 1197.0, 79.779, 5.2209, 1.0524], rtol=2e-4)
+
+    class _Geo:
+        def altitudes(self):
+            return z
+
+    class _Atmo:
+        model_geometry = _Geo()
+    a = _Atmo()
+    us76.add_us76_standard_atmosphere(a)
+    assert a.temperature_k.shape == (8,) and np.all(np.diff(a.pressure_pa) < 0)
