@@ -196,7 +196,9 @@ int sk_amd_engine_num_los(Engine* engine, int* nlos);
 int sk_amd_engine_scratch_bytes(Engine* engine, int nwavel, unsigned long long* bytes);
 /* shape of the last solve: wavelengths per kernel launch, blocks in flight (streams), scratch bytes allocated */
 int sk_amd_engine_launch_shape(Engine* engine, int* chunk, int* slots, unsigned long long* scratch_bytes);
-int sk_amd_engine_set_profiling(Engine* engine, int enabled);   /* per-kernel HIP-event timing (serialises launches) */
+int sk_amd_engine_set_profiling(Engine* engine, int enabled);   /* 1: per-kernel HIP-event timing, launches serialised; 2 (discrete-ordinates engine):
+                                                                    event pairs on each launch's own stream, nothing serialised -- the kernels'
+                                                                    durations inside the pipelined step; 0: off */
 int sk_amd_engine_reset_profile(Engine* engine);
 int sk_amd_engine_kernel_time(Engine* engine, const char* kernel_name, double* total_ms, long* launches);
 int sk_amd_engine_kernel_names(Engine* engine, char* buffer, int buffer_len);

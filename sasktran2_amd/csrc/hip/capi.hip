@@ -1059,7 +1059,7 @@ int sk_amd_engine_launch_shape(Engine* e, int* chunk, int* slots, unsigned long 
 // per-kernel timing (HIP events around every launch, serialised): both device engines of the handle
 int sk_amd_engine_set_profiling(Engine* e, int on) {
     if (!e) return -1;
-    if (e->dev) e->dev->set_profiling(on != 0);
+    if (e->dev) { if (on == 2) e->dev->set_in_situ_timing(true); else e->dev->set_profiling(on != 0); }
     if (e->so) e->so->set_profiling(on != 0);
     if (e->ts) e->ts->set_profiling(on != 0);
     return 0;

@@ -211,8 +211,34 @@ struct DeviceEngine::Impl {
     const double* delta_f = nullptr;
     const double *thermal_emission = nullptr, *thermal_surface = nullptr;   // EmissionSource::discrete_ordinates inputs (device) or null
     bool profiling = false;
+    // in-situ timing (set_profiling(2)): an event pair around every launch ON ITS OWN STREAM, nothing serialised, read back by
+    // kernel_time() -- the duration of a kernel as it runs inside the pipelined step (what rocprofv3 --kernel-trace sees)
+    bool in_situ = false;
+    struct Pending { const char* name; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
     std::map<std::string, std::pair<double, long>> times;  // name -> (ms, launches)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t pooled_event() {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        HIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
+    void collect() {
+        for (const Pending& q : pending) {
+            (void)hipEventSynchronize(q.b);
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, q.a, q.b) == hipSuccess) {
+                auto& e = times[q.name];
+                e.first += ms;
+                e.second += 1;
+            }
+            event_pool.push_back(q.a);
+            event_pool.push_back(q.b);
+        }
+        pending.clear();
+    }
     size_t scratch_bytes = 0;
 };
 
@@ -263,6 +289,8 @@ DeviceEngine::~DeviceEngine() {
             for (auto e : sl->ev_k1) (void)hipEventDestroy(e);
             for (auto e : sl->ev_rest) (void)hipEventDestroy(e);
         }
+        impl_->collect();
+        for (hipEvent_t e : impl_->event_pool) (void)hipEventDestroy(e);
         if (impl_->fork) (void)hipEventDestroy(impl_->fork);
         if (impl_->ev0) (void)hipEventDestroy(impl_->ev0);
         if (impl_->ev1) (void)hipEventDestroy(impl_->ev1);
@@ -282,9 +310,11 @@ void DeviceEngine::set_thermal_emission(const double* d_emission, const double* 
 }
 int DeviceEngine::last_chunk() const { return impl_->last_chunk; }
 int DeviceEngine::last_slots() const { return impl_->last_slots; }
-void DeviceEngine::set_profiling(bool on) { impl_->profiling = on; }
-void DeviceEngine::reset_profile() { impl_->times.clear(); }
+void DeviceEngine::set_profiling(bool on) { impl_->collect(); impl_->profiling = on; impl_->in_situ = false; }
+void DeviceEngine::set_in_situ_timing(bool on) { impl_->collect(); impl_->in_situ = on; impl_->profiling = false; }
+void DeviceEngine::reset_profile() { impl_->collect(); impl_->times.clear(); }
 bool DeviceEngine::kernel_time(const char* name, double* ms, long* launches) const {
+    impl_->collect();
     auto it = impl_->times.find(name);
     if (it == impl_->times.end()) return false;
     *ms = it->second.first;
@@ -292,6 +322,7 @@ bool DeviceEngine::kernel_time(const char* name, double* ms, long* launches) con
     return true;
 }
 std::string DeviceEngine::kernel_names() const {
+    impl_->collect();
     std::string s;
     for (auto& kv : impl_->times) s += (s.empty() ? "" : ",") + kv.first;
     return s;
@@ -366,10 +397,21 @@ struct Timer {
     DeviceEngine::Impl& I;
     hipStream_t st;
     const char* name;
+    hipEvent_t a = nullptr;
     Timer(DeviceEngine::Impl& i, hipStream_t s, const char* n) : I(i), st(s), name(n) {
         if (I.profiling) (void)hipEventRecord(I.ev0, st);
+        else if (I.in_situ) {
+            a = I.pooled_event();
+            (void)hipEventRecord(a, st);
+        }
     }
     ~Timer() {
+        if (a) {
+            hipEvent_t b = I.pooled_event();
+            (void)hipEventRecord(b, st);
+            I.pending.push_back({name, a, b});
+            return;
+        }
         if (!I.profiling) return;
         (void)hipEventRecord(I.ev1, st);
         (void)hipEventSynchronize(I.ev1);

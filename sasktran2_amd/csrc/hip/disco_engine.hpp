@@ -51,6 +51,8 @@ class DeviceEngine {
     int last_chunk() const;         // wavelengths per launch of the last solve
     int last_slots() const;         // blocks of wavelengths in flight (streams) of the last solve
     void set_profiling(bool on);
+    // event pairs around every launch on its own stream, nothing serialised: kernel durations inside the pipelined step
+    void set_in_situ_timing(bool on);
     void reset_profile();
     bool kernel_time(const char* name, double* ms, long* launches) const;
     std::string kernel_names() const;

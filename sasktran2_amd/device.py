@@ -49,7 +49,12 @@ class DeviceSolver:
 
     # ---- per-kernel HIP-event timing (serialises launches; use outside the timed region)
     def set_profiling(self, on):
+        """True / 1: per-kernel timing with the launches serialised; 2: event pairs on each launch's own stream, nothing serialised
+        (kernel durations inside the pipelined step); False / 0: off"""
         lib().sk_amd_engine_set_profiling(self.engine._h, int(on))
+        lib().sk_amd_engine_reset_profile(self.engine._h)
+
+    def reset_profile(self):
         lib().sk_amd_engine_reset_profile(self.engine._h)
 
     def kernel_times(self):
