@@ -924,7 +924,8 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         for (auto& kv : out->derivs) {
             auto it = st.maps.find(kv.first);
             if (it == st.maps.end()) continue;
-            if (it->second->uses_emission()) return -2;   // emission derivatives are not part of this path
+            // emission derivatives: only the thermal source inside the discrete-ordinates equations carries them on this path
+            if (it->second->uses_emission() && e->config.emission_source != 2) return -2;
             scattering_groups = scattering_groups || is_scattering_mapping(*it->second);
         }
         // scattering-group derivatives are served by the run-time-n kernels for every stream count
@@ -932,6 +933,12 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         const char* force_env = std::getenv("SASKTRAN2_AMD_RUNTIME_N");
         const bool force = force_env && atoi(force_env) != 0;
         if (force || e->dev->vector_mode() || (scattering_groups && atm->derivs && e->config.wf_enabled)) {
+            if (e->config.emission_source == 2) {
+                // the thermal pass lives in the matrix-core path's plane-parallel branch only: refuse rather than drop the source
+                set_error("sk_engine_calculate_radiance: emission_source = discrete_ordinates is not available together with scattering-group "
+                          "weighting functions (d_legendre / scat_factor mappings) or SASKTRAN2_AMD_RUNTIME_N in this build");
+                return -2;
+            }
             return calculate_radiance_vector(e, atm, out);
         }
         if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
@@ -968,10 +975,12 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
             HIPC(hipMemcpy(d_f, st.src_delta_f(), nloc_w * 8, hipMemcpyDefault));
         }
         e->dev->set_delta_m_fraction(d_f);
+        double *d_wem = nullptr, *d_wsem = nullptr;
         if (e->config.emission_source == 2) {   // thermal source inside the DO equations
             if (derivs) {
-                set_error("sk_engine_calculate_radiance: weighting functions are not available with emission_source = discrete_ordinates in this build");
-                return -2;
+                d_wem = (double*)C.get("wf_emission", size_t(ngrid) * nt * 8);
+                d_wsem = (double*)C.get("wf_surface_emission", nt * 8);
+                e->dev->set_thermal_wf_outputs(d_wem, d_wsem);
             }
             if (!st.emission) throw std::runtime_error("emission_source = discrete_ordinates but the atmosphere storage has no emission_source array");
             double* d_em = (double*)C.get("do_emission", nloc_w * 8);
@@ -987,6 +996,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
                              nullptr, 0);
         e->dev->set_delta_m_fraction(nullptr);
         e->dev->set_thermal_emission(nullptr, nullptr);
+        e->dev->set_thermal_wf_outputs(nullptr, nullptr);
         // single_scatter_source = exact on top of the discrete-ordinates multiple scatter: radiance and native weighting functions are
         // accumulated on the device before the user mappings are applied
         if (e->so) {
@@ -1004,7 +1014,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         out->los_od.resize(nt);
         HIPC(hipMemcpy(out->los_od.data(), d_odt, nt * 8, hipMemcpyDeviceToHost));
         if (derivs) {
-            map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, 1);
+            map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, 1, nullptr, nullptr, d_wem, d_wsem);
         }
         return 0;
     } catch (const std::exception& ex) {

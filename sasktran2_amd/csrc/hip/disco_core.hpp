@@ -1125,7 +1125,9 @@ template <int N> struct K2bTask {
             for (int t = 0; t < 4; ++t) gth[t] += (zBsum + gw) * ops[O::GD + t];
             const double rho = b.albedo[w], ipb = ops[O::IPB];
             b.grad[size_t(4 * nlyr) * nt + tid] += gw * 2.0 * ipb + zBsum * (2.0 * ipb + g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w]);
-            b.grad[size_t(4 * nlyr + 1) * nt + tid] += zBsum * g.csz[s] / kPi * rho;
+            // solar: d / d(beam transmission at the ground); thermal pass: d / d(surface emission), which stands beside the direct bounce
+            // in the ground condition without the albedo (k2a ground row)
+            b.grad[size_t(4 * nlyr + 1) * nt + tid] += b.thermal_pass ? zBsum : zBsum * g.csz[s] / kPi * rho;
         }
         for (int t = 0; t < 4; ++t) b.grad[size_t(t * nlyr + p) * nt + tid] += gth[t];
     }
@@ -1331,7 +1333,8 @@ template <int N> SKD_HD void kpp_los(const Geo& g, const Bufs& b, int s, int m, 
             for (int i = 0; i < M2; ++i) b.z[(size_t(nlyr - 1) * M2 + i) * nt + tid] += t.gw * ops[O::UG + i];
             // direct-beam part of the reflected intensity (the diffuse part is handled by K2bTask::gradient through gw)
             b.grad[size_t(4 * nlyr) * nt + tid] += Aab * direct;
-            b.grad[size_t(4 * nlyr + 1) * nt + tid] += g.include_ss ? Aab * rho * g.csz[s] / kPi : 0.0;
+            b.grad[size_t(4 * nlyr + 1) * nt + tid] += b.thermal_pass ? ((g.include_ss && b.surf_em) ? Aab : 0.0)
+                                                                          : (g.include_ss ? Aab * rho * g.csz[s] / kPi : 0.0);
         }
     }
     b.radiance[tid] += total;
@@ -1402,6 +1405,54 @@ SKD_HD void k4a_chain(const Geo& g, const Bufs& b, int s, int los, int w) {
         }
     }
     b.dnat[size_t(2 * ngrid) * nt + tid] += G(4 * nlyr);
+    for (int e = 0; e < 4 * nlyr + 2; ++e) G(e) = 0;
+}
+
+// K4a of the thermal pass (k0_thermal): the layer gradients with respect to (tau, omega, T, sec) -- T = b0 (1 - omega) 4 pi / omega and
+// sec = b1 = ln(B_top / B_bottom) / tau here -- chained into native derivatives.  Nothing depends on the layers above (no beam):
+//   d/d tau_p   = G_tau - G_sec b1 / tau                 d/d omega_p = G_omega - G_T b0 4 pi / omega^2
+//   d/d B_top   = G_T (1 - omega) 4 pi / omega + G_sec / (B_top tau)          d/d B_bottom = -G_sec / (B_bottom tau)
+// (the reference wires the same partials, sktran_do_layerarray.cpp:565-620, 700-727).  Extinction / ssa parts join the solar ones in
+// dnat; the emission profile and surface emission derivatives go straight to the caller's arrays [altitude][w][los], [w][los].
+SKD_HD void k4a_thermal(const Geo& g, const Bufs& b, int los, int w, int w0, int nw_total, double* wf_em, double* wf_sem) {
+    const int nw = b.nw, nlyr = g.nlyr, ngrid = g.ngrid;
+    const size_t tid = size_t(w) * g.nlos + los, nt = size_t(nw) * g.nlos;
+    const size_t o = size_t(w0 + w) * g.nlos + los, plane = size_t(nw_total) * g.nlos;
+    auto G = [&](int e) -> double& { return b.grad[size_t(e) * nt + tid]; };
+    const double* ext = b.ext + size_t(w) * ngrid;
+    const double* ssa = b.ssa + size_t(w) * ngrid;
+    const double* em = b.emission + size_t(w) * ngrid;
+    if (wf_em)
+        for (int q = 0; q < ngrid; ++q) wf_em[size_t(q) * plane + o] = 0.0;
+    for (int r = 0; r < nlyr; ++r) {
+        int lo = -1, hi = -1;
+        for (int t = 0; t < 2; ++t) {
+            const int q = g.wq_idx[2 * r + t];
+            if (q < 0) continue;
+            if (lo < 0 || q < lo) lo = q;
+            if (q > hi) hi = q;
+        }
+        const double th = b.tau[size_t(r) * nw + w], om = b.om[size_t(r) * nw + w], kb = b.kbar[size_t(r) * nw + w];
+        const double top = hi >= 0 ? em[hi] : 0.0, bot = (lo >= 0 && lo != hi) ? em[lo] : top;
+        const double b1 = b.sec[size_t(r) * nw + w];   // as k0_thermal left it
+        const double gT = G(2 * nlyr + r), gsec = G(3 * nlyr + r);
+        const bool slope = th > 1e-10 && top > 1e-30 && bot > 1e-30 && lo != hi && lo >= 0;
+        const double gtau = G(r) - (slope ? gsec * b1 / th : 0.0);
+        const double gom = G(nlyr + r) - gT * top * (4.0 * kPi) / (om * om);
+        if (wf_em && hi >= 0) {
+            wf_em[size_t(hi) * plane + o] += gT * (1 - om) * (4.0 * kPi) / om + (slope ? gsec / (top * th) : 0.0);
+            if (slope) wf_em[size_t(lo) * plane + o] -= gsec / (bot * th);
+        }
+        for (int t = 0; t < 2; ++t) {
+            const int q = g.wq_idx[2 * r + t];
+            if (q < 0) continue;
+            const double wt = g.wq_w[2 * r + t];
+            b.dnat[size_t(q) * nt + tid] += gtau * wt * g.dh[r] + gom * wt * (ssa[q] - om) / kb;
+            b.dnat[size_t(ngrid + q) * nt + tid] += gom * wt * ext[q] / kb;
+        }
+    }
+    b.dnat[size_t(2 * ngrid) * nt + tid] += G(4 * nlyr);
+    if (wf_sem) wf_sem[o] = G(4 * nlyr + 1);
     for (int e = 0; e < 4 * nlyr + 2; ++e) G(e) = 0;
 }
 

@@ -93,6 +93,11 @@ __global__ void __launch_bounds__(kBlock) kern_k0t(Geo g, Bufs b, int s) {
     b.norders[w] = g.nstr;
     b.notconv[w] = 0;
 }
+__global__ void __launch_bounds__(kBlock) kern_k4a_thermal(Geo g, Bufs b, int w0, int nw_total, double* wf_em, double* wf_sem) {
+    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (tid >= size_t(b.nw) * g.nlos) return;
+    skd::k4a_thermal(g, b, int(tid % g.nlos), int(tid / g.nlos), w0, nw_total, wf_em, wf_sem);
+}
 __global__ void __launch_bounds__(kBlock) kern_k0_thermal(Geo g, Bufs b) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= b.nw) return;
@@ -210,6 +215,8 @@ struct DeviceEngine::Impl {
     int last_chunk = 0, last_slots = 0;
     const double* delta_f = nullptr;
     const double *thermal_emission = nullptr, *thermal_surface = nullptr;   // EmissionSource::discrete_ordinates inputs (device) or null
+    double *thermal_wf_emission = nullptr, *thermal_wf_surface = nullptr;   // their weighting functions [ngrid][nwavel][nlos], [nwavel][nlos] or null
+    int thermal_w0 = 0, thermal_nw_total = 0;                               // block in flight of the thermal pass
     bool profiling = false;
     // in-situ timing (set_profiling(2)): an event pair around every launch ON ITS OWN STREAM, nothing serialised, read back by
     // kernel_time() -- the duration of a kernel as it runs inside the pipelined step (what rocprofv3 --kernel-trace sees)
@@ -307,6 +314,10 @@ void DeviceEngine::set_delta_m_fraction(const double* d_f) { impl_->delta_f = d_
 void DeviceEngine::set_thermal_emission(const double* d_emission, const double* d_surface_emission) {
     impl_->thermal_emission = d_emission;
     impl_->thermal_surface = d_surface_emission;
+}
+void DeviceEngine::set_thermal_wf_outputs(double* d_wf_emission, double* d_wf_surface_emission) {
+    impl_->thermal_wf_emission = d_wf_emission;
+    impl_->thermal_wf_surface = d_wf_surface_emission;
 }
 int DeviceEngine::last_chunk() const { return impl_->last_chunk; }
 int DeviceEngine::last_slots() const { return impl_->last_slots; }
@@ -510,7 +521,16 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
             hipLaunchKernelGGL(kern_k0_thermal, dim3(blocks(nw)), dim3(kBlock), 0, st, g, bt);
             launch_k1<N>(st, g, bt, g.nsza, 0);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, bt, g.nsza, 0);
+            if (derivs) {
+                // weighting functions: the adjoint operators of the thermal order-0 solve, the sweeps inside kern_kpp, and the chain from the
+                // layer gradients (tau, omega, T = b0 (1 - omega) 4 pi / omega, sec = b1) to extinction, ssa, emission profile, surface emission
+                launch_k3<N>(st, g, bt, g.nsza, 0);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, bt, g.nsza, 0);
+            }
             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_kpp<N>), dim3(blocks(nt)), dim3(kBlock), 0, st, g, bt, g.nsza, 0);
+            if (derivs)
+                hipLaunchKernelGGL(kern_k4a_thermal, dim3(blocks(nt)), dim3(kBlock), 0, st, g, bt, I.thermal_w0, I.thermal_nw_total, I.thermal_wf_emission,
+                                   I.thermal_wf_surface);
         }
         HIP_CHECK(hipGetLastError());
         return;
@@ -708,7 +728,9 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
         b.surf_em = nullptr;
         b.thermal_pass = 0;
         slot.thermal_surface = I.thermal_surface ? I.thermal_surface + w0 : nullptr;
-        if (b.emission && (!I.g.pp_mode || derivs)) throw std::runtime_error("sasktran2_amd: the discrete-ordinates thermal source needs plane-parallel post-processing and no weighting functions");
+        if (b.emission && !I.g.pp_mode) throw std::runtime_error("sasktran2_amd: the discrete-ordinates thermal source needs plane-parallel post-processing");
+        I.thermal_w0 = w0;
+        I.thermal_nw_total = nwavel;
         b.nleg = nleg;
         b.derivs = derivs;
         switch (t.N) {

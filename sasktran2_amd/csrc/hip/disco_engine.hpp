@@ -35,6 +35,9 @@ class DeviceEngine {
     // EmissionSource::discrete_ordinates (thermal source inside the DO equations; plane-parallel post-processing, NSTOKES = 1, radiances only):
     // DEVICE pointers emission_source [nwavel][ngrid] and surface emission [nwavel] (or null) for the following solve_device calls
     void set_thermal_emission(const double* d_emission, const double* d_surface_emission);
+    // weighting functions of the thermal pass with respect to the emission profile [ngrid][nwavel][nlos] and the surface emission
+    // [nwavel][nlos] (device pointers or null), written by the next solve_device with derivatives
+    void set_thermal_wf_outputs(double* d_wf_emission, double* d_wf_surface_emission);
 
     // Polarised path (NSTOKES = 3; also NSTOKES = 1 with a stream count the matrix-core path does not cover).
     // d_leg: [nwavel][ngrid][nleg][4] (a1, a2, a3, b1) for NSTOKES = 3; d_radiance: [nwavel][nlos][nstokes].
