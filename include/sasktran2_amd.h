@@ -10,11 +10,13 @@
  * No exception crosses the ABI.  All numeric arrays are caller-owned; the library only reads/writes them
  * during calls (cpp/include/sasktran2/atmosphere/grid_storage.h:77-102).
  *
- * Scope of this build: NSTOKES = 1 and NSTOKES = 3 (radiances + weighting functions; standard / solar / observer Stokes basis),
- * multiple_scatter_source = discrete_ordinates (0), single_scatter_source in
- * {discrete_ordinates (2), none (3)}, Geometry1D in spherical, pseudo-spherical or plane-parallel form with linear
- * interpolation, Lambertian surface, delta-M scaling, derivative mappings with d_extinction / d_ssa (optionally with an
- * interpolator and in log-radiance space, and with d_legendre / scat_factor = scattering-group derivatives; no d_emission) and surface d_brdf.
+ * Scope of this build (README.md holds the table of accepted source combinations): NSTOKES = 1 and NSTOKES = 3 (radiances + weighting
+ * functions; standard / solar / observer Stokes basis); multiple_scatter_source discrete_ordinates (0), successive_orders_legacy (1),
+ * twostream (2), none (3); single_scatter_source exact (0), solartable (1), discrete_ordinates (2), none (3); emission_source standard (0),
+ * discrete_ordinates (2), volume_emission_rate (3), twostream (4); occultation_source standard; Geometry1D in spherical,
+ * pseudo-spherical or plane-parallel form with linear interpolation, Lambertian surface, delta-M scaling, derivative mappings with
+ * d_extinction / d_ssa / d_emission (optionally with an interpolator and in log-radiance space, and with d_legendre / scat_factor =
+ * scattering-group derivatives) and surface d_brdf / d_emission; the optical-property front end on the device (sk_amd_frontend_*).
  * Everything is computed on the GPU; there is no CPU fallback.
  */
 #ifndef SASKTRAN2_AMD_H
