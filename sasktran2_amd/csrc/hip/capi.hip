@@ -575,6 +575,26 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
     }
 }
 
+// scattering groups of a request: one per requested mapping that carries d_legendre / scat_factor, in the order of the map
+static std::map<std::string, int> scattering_groups_of(const AtmosphereStorage& st, const OutputC* out) {
+    std::map<std::string, int> group_of;
+    for (auto& kv : out->derivs) {
+        auto it = st.maps.find(kv.first);
+        if (it != st.maps.end() && is_scattering_mapping(*it->second)) {
+            const int gidx = (int)group_of.size();
+            group_of[kv.first] = gidx;
+        }
+    }
+    return group_of;
+}
+// their d_legendre arrays side by side on the device: [group][nwavel][ngrid][nleg] (what the single-scatter source differentiates along)
+static double* upload_group_directions(Engine* e, const AtmosphereStorage& st, const std::map<std::string, int>& group_of, const char* slot) {
+    const size_t per_g = size_t(st.nloc) * st.nwavel * st.nleg;
+    double* d = (double*)e->cache.get(slot, std::max<size_t>(group_of.size(), 1) * per_g * 8);
+    for (auto& kv : group_of) HIPC(hipMemcpy(d + size_t(kv.second) * per_g, st.maps.at(kv.first)->src_d_legendre(), per_g * 8, hipMemcpyDefault));
+    return d;
+}
+
 // NSTOKES = 3 (and NSTOKES = 1 stream counts outside the matrix-core path): radiances [wavel][los][stokes], LOS optical depths and
 // weighting functions [nderiv][wavel][los][stokes].
 static void upload_emission(Engine* e, const AtmosphereStorage& st, const Surface& su);
@@ -651,7 +671,9 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     e->dev->set_delta_m_fraction(nullptr);
     if (e->so) {
         upload_emission(e, st, su);
-        e->so->solve_device(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa);
+        // the exact single scatter differentiates along the same group directions (d_dleg holds them group by group) into the same d_wg
+        e->so->solve_device(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa, nullptr,
+                            nullptr, derivs ? (int)group_of.size() : 0, d_dleg, d_wg);
     }
     hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
     HIPC(hipGetLastError());
@@ -721,7 +743,15 @@ static int calculate_radiance_so(Engine* e, Atmosphere* atm, OutputC* out) {
         d_wem = (double*)C.get("wf_emission", size_t(ngrid) * nt * S * 8);
         d_wsem = (double*)C.get("wf_surface_emission", nt * S * 8);
     }
-    e->so->solve_device(nw, st.nleg / per, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, d_od, nullptr, 0, d_we, d_ws, d_wa, d_wem, d_wsem);
+    std::map<std::string, int> group_of;
+    double *d_dleg = nullptr, *d_wg = nullptr;
+    if (derivs) group_of = scattering_groups_of(st, out);
+    if (!group_of.empty()) {
+        d_dleg = upload_group_directions(e, st, group_of, "so_d_legendre");
+        d_wg = (double*)C.get("wf_scat", group_of.size() * size_t(ngrid) * nt * S * 8);
+    }
+    e->so->solve_device(nw, st.nleg / per, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, d_od, nullptr, 0, d_we, d_ws, d_wa, d_wem, d_wsem,
+                        (int)group_of.size(), d_dleg, d_wg);
     HIPC(hipDeviceSynchronize());
     std::vector<double> od(nt);
     HIPC(hipMemcpy(out->radiance, d_rad, nt * S * 8, hipMemcpyDeviceToHost));
@@ -731,7 +761,7 @@ static int calculate_radiance_so(Engine* e, Atmosphere* atm, OutputC* out) {
     out->los_od.resize(nt);
     for (int w = 0; w < nw; ++w)
         for (int r = 0; r < nlos; ++r) out->los_od[size_t(r) * nw + w] = od[size_t(w) * nlos + r];
-    if (derivs) map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, S, nullptr, nullptr, d_wem, d_wsem);
+    if (derivs) map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, S, d_wg, group_of.empty() ? nullptr : &group_of, d_wem, d_wsem);
     return 0;
 }
 
@@ -829,8 +859,9 @@ static int calculate_radiance_ts(Engine* e, Atmosphere* atm, OutputC* out) {
     if (e->so) {
         // exact single scatter (and the emission / occultation line-of-sight sources) accumulated on top; its optical depths are the same rays'
         upload_emission(e, st, su);
+        double* d_dleg_all = group_of.empty() ? nullptr : upload_group_directions(e, st, group_of, "so_d_legendre");
         e->so->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa,
-                            e->so->has_emission() ? d_wem : nullptr, e->so->has_emission() ? d_wsem : nullptr);
+                            e->so->has_emission() ? d_wem : nullptr, e->so->has_emission() ? d_wsem : nullptr, (int)group_of.size(), d_dleg_all, d_wg);
     }
     HIPC(hipDeviceSynchronize());
     std::vector<double> od(nt);
@@ -896,8 +927,8 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         validate_input_atmosphere(e, st);
         const bool wants_derivs = atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty());
         if (e->so && wants_derivs) {
-            // the successive-orders source is not linearised here (the reference's own linearisation of it is approximate); scattering-group
-            // derivatives of the exact single scatter (d_legendre) are not built either: an error rather than a silently incomplete Jacobian
+            // the successive-orders source is not linearised here (the reference's own linearisation of it is approximate): an error rather
+            // than a silently incomplete Jacobian
             if (e->so->has_unlinearised_sources()) {
                 set_error("sk_engine_calculate_radiance: weighting functions are not available with multiple_scatter_source = "
                           "successive_orders_legacy in this build (create the atmosphere with calculate_derivatives = 0)");
@@ -909,13 +940,6 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
                 set_error("sk_engine_calculate_radiance: weighting functions of a line-of-sight emission source next to the discrete-ordinates "
                           "source are not available in this build");
                 return -2;
-            }
-            for (auto& kv : out->derivs) {
-                auto it = st.maps.find(kv.first);
-                if (it != st.maps.end() && is_scattering_mapping(*it->second)) {
-                    set_error("sk_engine_calculate_radiance: scattering-group weighting functions are not available with single_scatter_source = exact in this build");
-                    return -2;
-                }
             }
         }
         if (e->ts) return calculate_radiance_ts(e, atm, out);

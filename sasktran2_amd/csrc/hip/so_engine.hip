@@ -130,7 +130,16 @@ struct SoBufs {
     // accumulators [slab][ray][S][3 ngrid + 2][64] -- extinction, ssa, albedo, emission profile, surface emission -- and the caller's outputs
     // wf_ext / wf_ssa / wf_em [ngrid][nwavel][nlos][S], wf_alb / wf_sem [nwavel][nlos][S] (the two emission outputs may be null)
     double *dacc, *wf_ext, *wf_ssa, *wf_alb, *wf_em, *wf_sem;
+    // scattering-group derivatives of the single-scatter source (mappings with d_legendre / scat_factor): ngroups directions of the
+    // Legendre / Greek coefficients, dleg [group][nwavel_total][ngrid][nleg * per] (caller's layout), their phase values at the lines of
+    // sight's scattering angles dphT [slab][((group * nlos + ray) * ngrid + q) * ncomp + c][64] (c = 0: P11 part, 1: the P12 part of
+    // NSTOKES = 3), ngroups * ngrid more accumulator slots per (ray, Stokes component) and the caller's output
+    // wf_grp [group][ngrid][nwavel][nlos][S]
+    int ngroups;
+    const double* dleg;
+    double *dphT, *wf_grp;
 };
+__host__ __device__ inline int so_deriv_slots(int ngrid, int ngroups) { return 3 * ngrid + 2 + ngroups * ngrid; }
 
 // pointers of one slab, advanced to this lane: element `item` of array X is X[item * kWave]
 __device__ inline SoBufs slab_view(const SoGeo& g, const SoBufs& b, int slab, int lane) {
@@ -149,7 +158,8 @@ __device__ inline SoBufs slab_view(const SoGeo& g, const SoBufs& b, int slab, in
     v.lod += o * g.n_inc_layers + lane;
     v.lsrc += o * g.n_inc_layers * S + lane;
     if (v.sh) v.sh += o * g.ninterior * g.nlm + lane;
-    if (v.dacc) v.dacc += o * g.nlos * S * (3 * g.ngrid + 2) + lane;
+    if (v.dacc) v.dacc += o * g.nlos * S * so_deriv_slots(g.ngrid, b.ngroups) + lane;
+    if (v.dphT) v.dphT += o * size_t(b.ngroups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1) + lane;
     return v;
 }
 
@@ -345,7 +355,8 @@ __global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b, int s
     const int w = blockIdx.x * kWave + threadIdx.x, r = blockIdx.y;
     const SoBufs v = slab_view(g, b, blockIdx.x, threadIdx.x);
     const int l0 = rs.layer_start[r], n = rs.layer_start[r + 1] - l0, e0 = rs.endpoint_start[r];
-    const int per = S == 3 ? 4 : 1, nlg_in = b.nleg * per, nm = min(g.num_ss_moments, b.nleg), ngrid = g.ngrid, nn = 3 * ngrid + 2;
+    const int per = S == 3 ? 4 : 1, nlg_in = b.nleg * per, nm = min(g.num_ss_moments, b.nleg), ngrid = g.ngrid, nn = so_deriv_slots(ngrid, b.ngroups);
+    const int ncomp = S == 3 ? 2 : 1, grp0 = 3 * ngrid + 2;
     const int ws = w < b.nw ? w : b.nw - 1;
     const double F = b.irradiance ? b.irradiance[ws] : 1.0, albedo = b.albedo[ws];
     double* acc = v.dacc + size_t(r) * S * nn * kWave;
@@ -462,6 +473,20 @@ __global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b, int s
                         add(s, q, c * wt * oe * unscaled * ph[s]);
                     }
                 }
+                // scattering groups: the phase function moves along the group's direction of the coefficients at every stencil point
+                for (int gi = 0; gi < b.ngroups; ++gi)
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = rs.stencil_idx[4 * L + i];
+                        const double wt = wts[4 * L + i];
+                        if (q < 0 || wt == 0.0) continue;
+                        const double* dp = v.dphT + (size_t(gi * g.nlos + r) * ngrid + q) * ncomp * kWave;
+                        const double base = c * wt * ke * oe * unscaled;
+                        add(0, grp0 + gi * ngrid + q, base * dp[0]);
+                        if (S == 3) {
+                            add(1, grp0 + gi * ngrid + q, -rs.C2[r] * base * dp[kWave]);
+                            add(2, grp0 + gi * ngrid + q, -rs.S2[r] * base * dp[kWave]);
+                        }
+                    }
             }
             for (int t = rs.od.start[L]; t < rs.od.start[L + 1]; ++t)
 #pragma unroll
@@ -471,9 +496,31 @@ __global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b, int s
     }
 }
 
+// phase values of the scattering groups' directions at the scattering angle of every line of sight:
+//   dphT[group][ray][q][0] = sum_l dleg_l d00_l(ray),   [1] = sum_l dleg(b1)_l d02_l(ray)  (NSTOKES = 3), slab major.
+// One (group, grid point) x 64 wavelengths per wavefront; every lane reads its own contiguous row of coefficients.
+__global__ void __launch_bounds__(kWave) k_so_group_phase(SoGeo g, SoBufs b) {
+    const DevRays& rs = g.los;
+    const int S = g.S, per = S == 3 ? 4 : 1, ncomp = S == 3 ? 2 : 1, nlg_in = b.nleg * per, nm = min(g.num_ss_moments, b.nleg);
+    const int w = blockIdx.x * kWave + threadIdx.x, gi = blockIdx.y / g.ngrid, q = blockIdx.y % g.ngrid;
+    const SoBufs v = slab_view(g, b, blockIdx.x, threadIdx.x);
+    const int ws = w < b.nw ? w : b.nw - 1;
+    const double* row = b.dleg + ((size_t(gi) * b.nwavel_total + b.w0 + ws) * g.ngrid + q) * nlg_in;
+    for (int r = 0; r < g.nlos; ++r) {
+        double p11 = 0, p12 = 0;
+        for (int l = 0; l < nm; ++l) {
+            p11 += row[l * per] * rs.d00[size_t(r) * g.num_ss_moments + l];
+            if (S == 3) p12 += row[l * per + 3] * rs.d02[size_t(r) * g.num_ss_moments + l];
+        }
+        double* dp = v.dphT + (size_t(gi * g.nlos + r) * g.ngrid + q) * ncomp * kWave;
+        dp[0] = p11;
+        if (S == 3) dp[kWave] = p12;
+    }
+}
+
 // accumulators -> the caller's layout (wf_ext / wf_ssa [ngrid][nwavel][nlos][S], wf_alb [nwavel][nlos][S]) in the configured Stokes basis
 __global__ void __launch_bounds__(256) k_so_deriv_out(SoGeo g, SoBufs b) {
-    const int S = g.S, nn = 3 * g.ngrid + 2, nlos = g.nlos;
+    const int S = g.S, nn = so_deriv_slots(g.ngrid, b.ngroups), nlos = g.nlos;
     const size_t n = size_t(nn) * b.nw * nlos * S;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         const int s = int(i % S), r = int((i / S) % nlos), w = int((i / S / nlos) % b.nw), x = int(i / S / nlos / b.nw);
@@ -489,7 +536,8 @@ __global__ void __launch_bounds__(256) k_so_deriv_out(SoGeo g, SoBufs b) {
         else if (x < 2 * g.ngrid) dst = b.wf_ssa + ((size_t(x - g.ngrid) * b.nwavel_total + b.w0 + w) * nlos + r) * S + s;
         else if (x == 2 * g.ngrid) dst = b.wf_alb + (size_t(b.w0 + w) * nlos + r) * S + s;
         else if (x <= 3 * g.ngrid) dst = b.wf_em ? b.wf_em + ((size_t(x - 2 * g.ngrid - 1) * b.nwavel_total + b.w0 + w) * nlos + r) * S + s : nullptr;
-        else dst = b.wf_sem ? b.wf_sem + (size_t(b.w0 + w) * nlos + r) * S + s : nullptr;
+        else if (x == 3 * g.ngrid + 1) dst = b.wf_sem ? b.wf_sem + (size_t(b.w0 + w) * nlos + r) * S + s : nullptr;
+        else dst = b.wf_grp + ((size_t(x - 3 * g.ngrid - 2) * b.nwavel_total + b.w0 + w) * nlos + r) * S + s;   // x - (3 ngrid + 2) = group * ngrid + q
         if (!dst) continue;
         *dst = b.accumulate ? *dst + val : val;
     }
@@ -804,6 +852,7 @@ struct SoDeviceEngine::Impl {
     bool single_scatter = true, multiple_scatter = true;
     int capacity = 0, cap_nleg = 0;
     bool cap_derivs = false;
+    int cap_groups = 0;   // scattering groups the derivative scratch holds
     const double *d_emission = nullptr, *d_surface_emission = nullptr;
     size_t n_inc_rays = 0, n_inc_layers = 0, n_acc = 0, n_out = 0, n_table = 0, max_rows = 0, n_groups = 0;
     size_t scratch_bytes = 0;
@@ -1121,7 +1170,8 @@ size_t SoDeviceEngine::bytes_per_wavelength() const { return so_doubles_per_wave
 
 void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg, const double* d_albedo,
                                   const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream, int accumulate,
-                                  double* d_wf_ext, double* d_wf_ssa, double* d_wf_alb, double* d_wf_emission, double* d_wf_surface_emission) {
+                                  double* d_wf_ext, double* d_wf_ssa, double* d_wf_alb, double* d_wf_emission, double* d_wf_surface_emission,
+                                  int ngroups, const double* d_dleg, double* d_wf_groups) {
     Impl& I = *impl_;
     SoGeo& g = I.g;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1130,9 +1180,10 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     const bool derivs = d_wf_ext != nullptr;
     if (derivs && (!d_wf_ssa || !d_wf_alb)) throw std::runtime_error("sasktran2_amd: weighting functions need all three output buffers");
     if (derivs && I.multiple_scatter) throw std::runtime_error("sasktran2_amd: the successive-orders source is not linearised");
+    if (ngroups < 0 || (ngroups > 0 && (!derivs || !d_dleg || !d_wf_groups))) throw std::runtime_error("sasktran2_amd: scattering groups need weighting-function buffers, d_legendre and an output");
     if (g.emission && !I.d_emission) throw std::runtime_error("sasktran2_amd: the engine has an emission source but no emission_source array was set (set_emission)");
     // block of wavelengths in flight: half of the free HBM (plus what this engine already holds), balanced blocks, multiple of the wavefront
-    const size_t deriv_doubles = derivs ? size_t(g.nlos) * S * (3 * g.ngrid + 2) : 0;
+    const size_t deriv_doubles = derivs ? size_t(g.nlos) * S * so_deriv_slots(g.ngrid, ngroups) + size_t(ngroups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1) : 0;
     const size_t per_w = (so_doubles_per_wavelength(I, nleg) + deriv_doubles) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
@@ -1144,9 +1195,10 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     int chunk = int((size_t(nwavel) + nblocks - 1) / nblocks);
     chunk = (chunk + kPad - 1) / kPad * kPad;
     I.last_chunk = chunk;
-    if (chunk > I.capacity || nleg > I.cap_nleg || (derivs && !I.cap_derivs)) {
+    if (chunk > I.capacity || nleg > I.cap_nleg || (derivs && !I.cap_derivs) || ngroups > I.cap_groups) {
         I.scratch.release();
         I.cap_derivs = I.cap_derivs || derivs;
+        I.cap_groups = std::max(I.cap_groups, ngroups);
         I.capacity = std::max(chunk, I.capacity);
         I.cap_nleg = std::max(nleg, I.cap_nleg);
         const size_t W = I.capacity, nlg = size_t(I.cap_nleg) * per;
@@ -1166,8 +1218,10 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             b.lsrc = I.scratch.alloc<double>(I.n_inc_layers * S * W);
             b.sh = g.nlm > 0 ? I.scratch.alloc<double>(size_t(g.ninterior) * g.nlm * W) : nullptr;
         }
-        b.dacc = I.cap_derivs ? I.scratch.alloc<double>(size_t(g.nlos) * S * (3 * g.ngrid + 2) * W) : nullptr;
-        I.scratch_bytes = (so_doubles_per_wavelength(I, I.cap_nleg) + (I.cap_derivs ? size_t(g.nlos) * S * (2 * g.ngrid + 1) : 0)) * sizeof(double) * W;
+        b.dacc = I.cap_derivs ? I.scratch.alloc<double>(size_t(g.nlos) * S * so_deriv_slots(g.ngrid, I.cap_groups) * W) : nullptr;
+        b.dphT = I.cap_groups > 0 ? I.scratch.alloc<double>(size_t(I.cap_groups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1) * W) : nullptr;
+        I.scratch_bytes = (so_doubles_per_wavelength(I, I.cap_nleg) + (I.cap_derivs ? size_t(g.nlos) * S * so_deriv_slots(g.ngrid, I.cap_groups) : 0) +
+                           size_t(I.cap_groups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1)) * sizeof(double) * W;
     }
     for (int w0 = 0; w0 < nwavel; w0 += chunk) {
         SoBufs b = I.b;
@@ -1192,6 +1246,10 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
         b.wf_alb = d_wf_alb;
         b.wf_em = d_wf_emission;
         b.wf_sem = d_wf_surface_emission;
+        b.ngroups = ngroups;
+        b.dleg = d_dleg;
+        b.wf_grp = d_wf_groups;
+        if (ngroups == 0) b.dphT = nullptr;
         if (!derivs) b.dacc = nullptr;
         const unsigned wb = unsigned(b.nwp / kWave);
         {
@@ -1242,6 +1300,7 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
         }
         if (derivs) {
             SoTimer t(I, st, "so_los_derivatives");
+            if (ngroups > 0) hipLaunchKernelGGL(k_so_group_phase, dim3(wb, unsigned(ngroups * g.ngrid)), dim3(kWave), 0, st, g, b);
             if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_los_deriv<1>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b, ss);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_los_deriv<3>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b, ss);
             hipLaunchKernelGGL(k_so_deriv_out, dim3(2048), dim3(256), 0, st, g, b);

@@ -29,7 +29,10 @@ class SoDeviceEngine {
     void solve_device(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg, const double* d_albedo,
                       const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream, int accumulate = 0,
                       double* d_wf_ext = nullptr, double* d_wf_ssa = nullptr, double* d_wf_alb = nullptr, double* d_wf_emission = nullptr,
-                      double* d_wf_surface_emission = nullptr);
+                      double* d_wf_surface_emission = nullptr,
+                      // scattering groups of the single-scatter source: ngroups directions d_dleg [group][nwavel][ngrid][nleg (x 4)] of the
+                      // Legendre / Greek coefficients -> d_wf_groups [group][ngrid][nwavel][nlos][nstokes] (accumulated like the others)
+                      int ngroups = 0, const double* d_dleg = nullptr, double* d_wf_groups = nullptr);
     bool has_successive_orders() const;
     bool has_unlinearised_sources() const;   // successive orders: no weighting functions
     bool has_emission() const;               // line-of-sight emission source (standard / volume_emission_rate)

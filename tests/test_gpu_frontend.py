@@ -336,7 +336,7 @@ def test_line_of_sight_emission_and_jvp_vjp_with_device_mappings():
     engine, geo = _engine_case(sk, c, cfg, [sk.TangentAltitudeSolar(12000.0, 0.0, 200000.0, 0.6), sk.GroundViewingSolar(0.6, 0.0, 0.9, 200000.0)])
 
     def radiance(case, derivs):
-        # an absorbing, emitting atmosphere (this engine carries no scattering-group derivatives and says so: no scatterers here)
+        # an absorbing, emitting atmosphere
         atmo = sk.Atmosphere(geo, cfg, wavelengths_nm=case["wavelengths"], calculate_derivatives=derivs)
         atmo.pressure_pa, atmo.temperature_k = case["pressure"], case["temperature"]
         table = sk.optical.AbsorberDatabaseDim2(wavelength_nm=case["tab_wl"], param=case["tab_t"], xs=case["tab_xs"])
@@ -382,3 +382,34 @@ def test_line_of_sight_emission_and_jvp_vjp_with_device_mappings():
         L.sk_atmosphere_destroy(h_atm)
         L.sk_surface_destroy(h_su)
         L.sk_brdf_destroy(h_brdf)
+
+
+@pytest.mark.parametrize("ms,nstokes", [("none", 1), ("none", 3), ("discrete_ordinates", 1), ("twostream", 1)],
+                         ids=["exact single scatter alone", "exact single scatter alone, NSTOKES 3", "+ discrete ordinates", "+ two-stream"])
+def test_scatterer_weighting_functions_with_exact_single_scatter(ms, nstokes):
+    """single_scatter_source = exact -- the reference's limb configuration -- with scatterer constituents: the single-scatter source
+    differentiates along the scattering groups' d_legendre directions (k_so_group_phase / k_so_los_deriv), next to the multiple-scatter
+    engine's own group derivatives; weighting functions of number density, extinction, pressure and vmr against finite differences"""
+    import sasktran2_amd as sk
+    c = sc.frontend_case(nwavel=4)
+    cfg = sk.Config()
+    cfg.num_stokes = nstokes
+    cfg.num_streams = 2 if ms == "twostream" else 4
+    cfg.num_singlescatter_moments = 16
+    cfg.single_scatter_source = sk.SingleScatterSource.Exact
+    cfg.multiple_scatter_source = {"none": sk.MultipleScatterSource.NoSource, "discrete_ordinates": sk.MultipleScatterSource.DiscreteOrdinates,
+                                   "twostream": sk.MultipleScatterSource.TwoStream}[ms]
+    rays = [sk.TangentAltitudeSolar(14000.0, 0.5, 200000.0, 0.6), sk.TangentAltitudeSolar(28000.0, 0.5, 200000.0, 0.6),
+            sk.GroundViewingSolar(0.6, 0.5, 0.8, 200000.0)]
+    engine, geo = _engine_case(sk, c, cfg, rays)
+
+    def radiance(case, derivs):
+        atmo = sc.frontend_product_atmosphere(sk, case, geo, cfg, calculate_derivatives=derivs, temperature_derivative=False)
+        atmo.surface.albedo[:] = 0.2
+        return engine.calculate_radiance(atmo, as_dataset=False)
+    base = radiance(c, True)
+    for key, field, j, step in (("wf_aerosol_number_density", "aer_nd", 2, 2e4), ("wf_cloud_extinction", "aer_ext", 1, 2e-10),
+                                ("wf_pressure_pa", "pressure", 4, 5.0), ("wf_o3_vmr", "o3_vmr", 5, 2e-8)):
+        fd = (radiance(_perturbed(c, field, j, step), False)["radiance"] - radiance(_perturbed(c, field, j, -step), False)["radiance"]) / (2 * step)
+        assert np.max(np.abs(base[key][j])) > 0
+        np.testing.assert_allclose(base[key][j], fd, rtol=3e-5, atol=3e-6 * np.max(np.abs(fd)), err_msg=key)

@@ -159,7 +159,7 @@ def test_exact_single_scatter_on_top():
     # single_scatter_source = exact + multiple_scatter_source = twostream: the two sources add (radiances and weighting functions)
     from tests.gpu_harness import build_so_engine, run_product_so, run_product_ts
     s = varied(sc.twostream_reference_case(spherical=True))
-    both = run_product_ts(s, single_scatter="exact", b1_mapping=False)   # (no scattering-group mapping next to the exact single scatter)
+    both = run_product_ts(s, single_scatter="exact", b1_mapping=False)   # (without the group mapping: the sum below adds the two engines' own extinction / albedo results)
     ms = run_product_ts(s)
     so_s = dict(s, config=dict(nstokes=1, num_streams=2, num_singlescatter_moments=2, num_sza=3, single_scatter="exact", multiple_scatter="none",
                                num_iterations=0, num_incoming=26, num_outgoing=26))
