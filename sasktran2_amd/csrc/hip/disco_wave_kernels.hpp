@@ -840,7 +840,8 @@ template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs 
             sCleg[l] = sa[l] * ((((l - m) & 1) ? -sp : sp) + sq);
         }
         __syncthreads();
-        if (valid) {
+        // (the thermal pass runs with the extra solar index s = nsza, which has no diffuse table: only the record entries above are needed)
+        if (valid && s < g.nsza) {
             const int t0 = g.pt_start[s * nlyr + p], t1 = g.pt_start[s * nlyr + p + 1];
             for (int t = t0 + gl; t < t1; t += LG) {
                 const int slot = g.pt_slot[t];
@@ -867,7 +868,7 @@ template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs 
             sRed[gl] = 2.0 * g.mu[gl] * g.wt[gl] * sv * b.albedo[w];
         }
         __syncthreads();
-        if (ground) {
+        if (ground && s < g.nsza) {
             double diffuse = 0;
             for (int i = 0; i < N; ++i) diffuse += sRed[i];
             for (int t = g.gpt_start[s] + gl; t < g.gpt_start[s + 1]; t += LG) skd::J_at(b, g, m, g.gpt_slot[t], w) = diffuse;
