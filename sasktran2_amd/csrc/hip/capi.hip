@@ -620,7 +620,7 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     double* d_od = (double*)C.get("los_od", nt * 8);
     double* d_odt = (double*)C.get("los_od_t", nt * 8);
     int* d_status = (int*)C.get("status", size_t(nw) * 4);
-    double *d_irr = nullptr, *d_we = nullptr, *d_ws = nullptr, *d_wa = nullptr;
+    double *d_irr = nullptr, *d_we = nullptr, *d_ws = nullptr, *d_wa = nullptr, *d_wem = nullptr, *d_wsem = nullptr;
     HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyDefault));
     HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyDefault));
     HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyDefault));
@@ -672,8 +672,14 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     if (e->so) {
         upload_emission(e, st, su);
         // the exact single scatter differentiates along the same group directions (d_dleg holds them group by group) into the same d_wg
-        e->so->solve_device(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa, nullptr,
-                            nullptr, derivs ? (int)group_of.size() : 0, d_dleg, d_wg);
+        if (derivs && e->so->has_emission()) {
+            d_wem = (double*)C.get("wf_emission", size_t(ngrid) * nt * S * 8);
+            d_wsem = (double*)C.get("wf_surface_emission", nt * S * 8);
+            HIPC(hipMemset(d_wem, 0, size_t(ngrid) * nt * S * 8));
+            HIPC(hipMemset(d_wsem, 0, nt * S * 8));
+        }
+        e->so->solve_device(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa, d_wem,
+                            d_wsem, derivs ? (int)group_of.size() : 0, d_dleg, d_wg);
     }
     hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
     HIPC(hipGetLastError());
@@ -685,7 +691,7 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     HIPC(hipMemcpy(out->radiance, d_rad, nt * S * 8, hipMemcpyDeviceToHost));
     out->los_od.resize(nt);
     HIPC(hipMemcpy(out->los_od.data(), d_odt, nt * 8, hipMemcpyDeviceToHost));
-    if (derivs) map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, S, d_wg, group_of.empty() ? nullptr : &group_of);
+    if (derivs) map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, S, d_wg, group_of.empty() ? nullptr : &group_of, d_wem, d_wsem);
     return 0;
 }
 
@@ -934,13 +940,6 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
                           "successive_orders_legacy in this build (create the atmosphere with calculate_derivatives = 0)");
                 return -2;
             }
-            // line-of-sight emission next to the discrete-ordinates source: its emission derivatives would have to travel through the DO
-            // paths' mapping calls, which carry none
-            if (e->dev && e->so->has_emission()) {
-                set_error("sk_engine_calculate_radiance: weighting functions of a line-of-sight emission source next to the discrete-ordinates "
-                          "source are not available in this build");
-                return -2;
-            }
         }
         if (e->ts) return calculate_radiance_ts(e, atm, out);
         if (e->so && !e->dev) return calculate_radiance_so(e, atm, out);
@@ -949,7 +948,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
             auto it = st.maps.find(kv.first);
             if (it == st.maps.end()) continue;
             // emission derivatives: only the thermal source inside the discrete-ordinates equations carries them on this path
-            if (it->second->uses_emission() && e->config.emission_source != 2) return -2;
+            if (it->second->uses_emission() && e->config.emission_source != 2 && !(e->so && e->so->has_emission())) return -2;
             scattering_groups = scattering_groups || is_scattering_mapping(*it->second);
         }
         // scattering-group derivatives are served by the run-time-n kernels for every stream count
@@ -1025,7 +1024,13 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         // accumulated on the device before the user mappings are applied
         if (e->so) {
             upload_emission(e, st, su);
-            e->so->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa);
+            if (derivs && e->so->has_emission()) {   // line-of-sight emission next to the discrete-ordinates source: its emission derivatives
+                d_wem = (double*)C.get("wf_emission", size_t(ngrid) * nt * 8);
+                d_wsem = (double*)C.get("wf_surface_emission", nt * 8);
+                HIPC(hipMemset(d_wem, 0, size_t(ngrid) * nt * 8));
+                HIPC(hipMemset(d_wsem, 0, nt * 8));
+            }
+            e->so->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa, d_wem, d_wsem);
         }
         hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
         HIPC(hipGetLastError());

@@ -413,3 +413,29 @@ def test_scatterer_weighting_functions_with_exact_single_scatter(ms, nstokes):
         fd = (radiance(_perturbed(c, field, j, step), False)["radiance"] - radiance(_perturbed(c, field, j, -step), False)["radiance"]) / (2 * step)
         assert np.max(np.abs(base[key][j])) > 0
         np.testing.assert_allclose(base[key][j], fd, rtol=3e-5, atol=3e-6 * np.max(np.abs(fd)), err_msg=key)
+
+
+def test_line_of_sight_emission_next_to_discrete_ordinates():
+    """emission_source = standard (Planck term of ThermalEmission integrated along the line of sight) next to the discrete-ordinates solar
+    source with the exact single scatter, scatterers present: wf_temperature_k gathers the Planck derivative, the number densities
+    (scattering groups of Rayleigh) and the absorber's table; against finite differences"""
+    import sasktran2_amd as sk
+    c = sc.frontend_case(nwavel=3)
+    c["wavelengths"] = np.linspace(9500.0, 10500.0, 3)
+    c["tab_wl"] = np.linspace(8000.0, 12000.0, 111)
+    c["tab_xs"] = c["tab_xs"] * 3e3
+    c["hg_wl"] = np.linspace(8000.0, 12000.0, 6)
+    cfg = _config(sk, streams=4, moments=8)
+    cfg.single_scatter_source = sk.SingleScatterSource.Exact
+    cfg.emission_source = sk.EmissionSource.Standard
+    engine, geo = _engine_case(sk, c, cfg, [sk.TangentAltitudeSolar(16000.0, 0.3, 200000.0, 0.6), sk.GroundViewingSolar(0.6, 0.3, 0.8, 200000.0)])
+
+    def radiance(case, derivs):
+        atmo = sc.frontend_product_atmosphere(sk, case, geo, cfg, thermal=True, calculate_derivatives=derivs, extinction_scatterer=False)
+        atmo.surface.albedo[:] = 0.1
+        return engine.calculate_radiance(atmo, as_dataset=False)
+    base = radiance(c, True)
+    for key, field, j, step in (("wf_temperature_k", "temperature", 3, 2e-2), ("wf_temperature_k", "temperature", 12, 2e-2),
+                                ("wf_aerosol_number_density", "aer_nd", 1, 2e4), ("wf_o3_vmr", "o3_vmr", 4, 2e-8)):
+        fd = (radiance(_perturbed(c, field, j, step), False)["radiance"] - radiance(_perturbed(c, field, j, -step), False)["radiance"]) / (2 * step)
+        np.testing.assert_allclose(base[key][j], fd, rtol=3e-5, atol=3e-6 * np.max(np.abs(fd)), err_msg=key)
