@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes
+import os
 import subprocess
 from pathlib import Path
 
@@ -12,17 +13,21 @@ _ROOT = _HERE.parent
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
 _LIB = None
+# SASKTRAN2_AMD_EMU_SANITIZE=1: AddressSanitizer + UBSan builds of the emulation libraries (tools/sanitize_emulation.sh preloads the runtime)
+_SAN = os.environ.get("SASKTRAN2_AMD_EMU_SANITIZE", "") == "1"
+_SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"] if _SAN else []
+_SAN_TAG = "_asan" if _SAN else ""
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        so = _HERE / "_build" / "libemu.so"
+        so = _HERE / "_build" / f"libemu{_SAN_TAG}.so"
         srcs = [_HERE / "emulate_kernels.cpp", _ROOT / "sasktran2_amd/csrc/hip/disco_core.hpp",
                 _ROOT / "sasktran2_amd/csrc/host/geo_tables.hpp", _ROOT / "sasktran2_amd/csrc/host/geometry.hpp"]
         if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
             so.parent.mkdir(exist_ok=True)
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(srcs[0])])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", *_SAN_FLAGS, "-o", str(so), str(srcs[0])])
         L = ctypes.CDLL(str(so))
         L.emu_create.restype = ctypes.c_void_p
         L.emu_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_int, ctypes.c_int,
@@ -77,13 +82,13 @@ _LIBV = None
 def libv():
     global _LIBV
     if _LIBV is None:
-        so = _HERE / "_build" / "libemuv.so"
+        so = _HERE / "_build" / f"libemuv{_SAN_TAG}.so"
         srcs = [_HERE / "emulate_vector.cpp", _ROOT / "sasktran2_amd/csrc/hip/disco_vec_core.hpp",
                 _ROOT / "sasktran2_amd/csrc/hip/disco_core.hpp", _ROOT / "sasktran2_amd/csrc/host/geo_tables.hpp",
                 _ROOT / "sasktran2_amd/csrc/host/geometry.hpp"]
         if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
             so.parent.mkdir(exist_ok=True)
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(srcs[0])])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", *_SAN_FLAGS, "-o", str(so), str(srcs[0])])
         L = ctypes.CDLL(str(so))
         L.emuv_create.restype = ctypes.c_void_p
         L.emuv_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_int, ctypes.c_int,
@@ -149,12 +154,12 @@ _LIB_TS = None
 def lib_ts():
     global _LIB_TS
     if _LIB_TS is None:
-        so = _HERE / "_build" / "libemuts.so"
+        so = _HERE / "_build" / f"libemuts{_SAN_TAG}.so"
         srcs = [_HERE / "emulate_twostream.cpp", _ROOT / "sasktran2_amd/csrc/hip/ts_core.hpp",
                 _ROOT / "sasktran2_amd/csrc/host/ts_geometry.hpp", _ROOT / "sasktran2_amd/csrc/host/geometry.hpp"]
         if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
             so.parent.mkdir(exist_ok=True)
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(srcs[0])])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", *_SAN_FLAGS, "-o", str(so), str(srcs[0])])
         L = ctypes.CDLL(str(so))
         L.emts_create.restype = ctypes.c_void_p
         L.emts_create.argtypes = [ctypes.c_double] * 3 + [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp] + [ctypes.c_int] * 3
