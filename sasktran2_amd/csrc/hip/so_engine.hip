@@ -665,88 +665,121 @@ __global__ void __launch_bounds__(kWave) k_so_scan(SoGeo g, SoBufs b) {
 template <int S>
 __global__ void __launch_bounds__(kWave) k_so_ray(SoGeo g, SoBufs b, const LayerRec* __restrict__ recs, const double* __restrict__ d00tab,
                                                   const double* __restrict__ d02tab, const double* __restrict__ C2tab,
-                                                  const double* __restrict__ S2tab, double* __restrict__ factor_out) {
+                                                  const double* __restrict__ S2tab, double* __restrict__ factor_base) {
+    // two wavelength slabs per wavefront: every scalar-cache operand (a layer record is 256 bytes) feeds both
+    constexpr int NS = 2;
     const DevRays& rs = g.inc;
-    const int r = blockIdx.x, w = blockIdx.y * kWave + threadIdx.x;
-    const SoBufs v = slab_view(g, b, blockIdx.y, threadIdx.x);
-    factor_out += size_t(blockIdx.y) * kWave * (g.n_inc_layers + g.inc.nrays) + threadIdx.x;
+    const int r = blockIdx.x;
+    const SoBufs v[NS] = {slab_view(g, b, NS * blockIdx.y, threadIdx.x), slab_view(g, b, NS * blockIdx.y + 1, threadIdx.x)};
+    double* factor_out[NS];
+    double F[NS], albedo[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int w = (NS * blockIdx.y + k) * kWave + threadIdx.x, ws = w < b.nw ? w : b.nw - 1;
+        factor_out[k] = factor_base + size_t(NS * blockIdx.y + k) * kWave * (g.n_inc_layers + g.inc.nrays) + threadIdx.x;
+        F[k] = b.irradiance ? b.irradiance[ws] : 1.0;
+        albedo[k] = b.albedo[ws];
+    }
     const int l0 = rs.layer_start[r], n = rs.layer_start[r + 1] - l0;
     const int per = S == 3 ? 4 : 1, nlg_in = b.nleg * per, nm = min(g.num_ss_moments, b.nleg);
-    const int ws = w < b.nw ? w : b.nw - 1;
-    const double F = b.irradiance ? b.irradiance[ws] : 1.0;
     const double* d00 = d00tab + size_t(r) * g.num_ss_moments;
     const double* d02 = d02tab + size_t(r) * g.num_ss_moments;
     // boundary source of one endpoint from the record of a layer it belongs to (side 0: the layer's exit, 1: its entrance)
-    auto boundary = [&](const LayerRec& rec, int side, double& Ba, double& Bb) {
+    auto boundary = [&](const LayerRec& rec, int side, double* Ba, double* Bb) {
         const double* wts = side == 0 ? rec.wexit : rec.went;
         const int* tq = side == 0 ? rec.tx : rec.te;
         const double* tw = side == 0 ? rec.twx : rec.twe;
-        double tod = 0, ke = 0, oe = 0, a = 0, bb = 0;
+        double tod[NS], ke[NS], oe[NS], a[NS], bb[NS];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) tod += tw[i] * v.tab[size_t(tq[i]) * kWave];
+        for (int k = 0; k < NS; ++k) tod[k] = ke[k] = oe[k] = a[k] = bb[k] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) tod[k] += tw[i] * v[k].tab[size_t(tq[i]) * kWave];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const double wt = wts[i];
             if (wt == 0.0) continue;
-            double p11 = 0, p12 = 0;
-            const double* lq = v.legT + size_t(rec.q[i]) * nlg_in * kWave;
-            for (int l = 0; l < nm; ++l) {
-                p11 += lq[size_t(l) * per * kWave] * d00[l];
-                if (S == 3) p12 += lq[size_t(l * per + 3) * kWave] * d02[l];
-            }
-            ke += v.kT[size_t(rec.q[i]) * kWave] * wt;
-            oe += v.omT[size_t(rec.q[i]) * kWave] * wt;
-            a += p11 * wt;
-            bb += p12 * wt;
-        }
-        const double amp = ke * oe * (exp(-tod) * F) / (kPi * 4);
-        Ba = amp * a;
-        Bb = amp * bb;
-    };
-    double val[S];
+            double p11[NS], p12[NS];
 #pragma unroll
-    for (int s = 0; s < S; ++s) val[s] = 0;
-    double cur = 0, before = 1, ent_a = 0, ent_b = 0;
+            for (int k = 0; k < NS; ++k) p11[k] = p12[k] = 0;
+            for (int l = 0; l < nm; ++l) {
+                const double c00 = d00[l], c02 = S == 3 ? d02[l] : 0.0;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const double* lq = v[k].legT + size_t(rec.q[i]) * nlg_in * kWave;
+                    p11[k] += lq[size_t(l) * per * kWave] * c00;
+                    if (S == 3) p12[k] += lq[size_t(l * per + 3) * kWave] * c02;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                ke[k] += v[k].kT[size_t(rec.q[i]) * kWave] * wt;
+                oe[k] += v[k].omT[size_t(rec.q[i]) * kWave] * wt;
+                a[k] += p11[k] * wt;
+                bb[k] += p12[k] * wt;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const double amp = ke[k] * oe[k] * (exp(-tod[k]) * F[k]) / (kPi * 4);
+            Ba[k] = amp * a[k];
+            Bb[k] = amp * bb[k];
+        }
+    };
+    double val[NS][S], cur[NS], before[NS], ent_a[NS], ent_b[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        cur[k] = 0; before[k] = 1; ent_a[k] = ent_b[k] = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) val[k][s] = 0;
+    }
     if (n > 0) boundary(recs[l0 + n - 1], 1, ent_a, ent_b);
     for (int j = n - 1; j >= 0; --j) {
         const LayerRec& rec = recs[l0 + j];
-        double od = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) od += rec.wod[i] * v.kT[size_t(rec.q[i]) * kWave];
-        const double omega = rec.midw[0] * v.omT[size_t(rec.mid[0]) * kWave] + rec.midw[1] * v.omT[size_t(rec.mid[1]) * kWave];
-        const double em1 = expm1(-od);
-        double ex_a, ex_b;
+        double ex_a[NS], ex_b[NS];
         boundary(rec, 0, ex_a, ex_b);
-        if (!rec.tiny) {
-            const double sf = (fabs(od) < 1e-12) ? 1.0 : -em1 / od;
-            val[0] += sf * (rec.quad_start * ent_a + rec.quad_end * ex_a) * before;
-            if (S == 3) {
-                const double pol = sf * (rec.quad_start * ent_b + rec.quad_end * ex_b) * before;
-                val[1] += -C2tab[r] * pol;
-                val[2] += -S2tab[r] * pol;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            double od = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) od += rec.wod[i] * v[k].kT[size_t(rec.q[i]) * kWave];
+            const double omega = rec.midw[0] * v[k].omT[size_t(rec.mid[0]) * kWave] + rec.midw[1] * v[k].omT[size_t(rec.mid[1]) * kWave];
+            const double em1 = expm1(-od);
+            if (!rec.tiny) {
+                const double sf = (fabs(od) < 1e-12) ? 1.0 : -em1 / od;
+                val[k][0] += sf * (rec.quad_start * ent_a[k] + rec.quad_end * ex_a[k]) * before[k];
+                if (S == 3) {
+                    const double pol = sf * (rec.quad_start * ent_b[k] + rec.quad_end * ex_b[k]) * before[k];
+                    val[k][1] += -C2tab[r] * pol;
+                    val[k][2] += -S2tab[r] * pol;
+                }
+            }
+            __builtin_nontemporal_store(omega * (-em1) * before[k], &factor_out[k][size_t(l0 + j) * kWave]);
+            cur[k] += od;
+            before[k] = exp(-cur[k]);
+            ent_a[k] = ex_a[k];
+            ent_b[k] = ex_b[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        double gf = 0;
+        if (n > 0 && rs.ground_is_hit[r]) {
+            gf = before[k];
+            if (rs.ground_mu_in[r] > 0) {
+                double t_od = 0;
+                const int e = rs.endpoint_start[r];
+                for (int t = rs.solar.start[e]; t < rs.solar.start[e + 1]; ++t) t_od += rs.solar.w[t] * v[k].tab[size_t(rs.solar.idx[t]) * kWave];
+                val[k][0] += exp(-t_od) * F[k] * (albedo[k] / kPi) * rs.ground_mu_in[r] * before[k];
             }
         }
-        __builtin_nontemporal_store(omega * (-em1) * before, &factor_out[size_t(l0 + j) * kWave]);
-        cur += od;
-        before = exp(-cur);
-        ent_a = ex_a;
-        ent_b = ex_b;
-    }
-    double gf = 0;
-    if (n > 0 && rs.ground_is_hit[r]) {
-        gf = before;
-        if (rs.ground_mu_in[r] > 0) {
-            double t_od = 0;
-            const int e = rs.endpoint_start[r];
-            for (int t = rs.solar.start[e]; t < rs.solar.start[e + 1]; ++t) t_od += rs.solar.w[t] * v.tab[size_t(rs.solar.idx[t]) * kWave];
-            val[0] += exp(-t_od) * F * (b.albedo[ws] / kPi) * rs.ground_mu_in[r] * before;
-        }
-    }
-    factor_out[size_t(g.n_inc_layers + r) * kWave] = gf;
+        factor_out[k][size_t(g.n_inc_layers + r) * kWave] = gf;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        v.first[(size_t(r) * S + s) * kWave] = val[s];
-        v.incoming[(size_t(r) * S + s) * kWave] = val[s];
+        for (int s = 0; s < S; ++s) {
+            v[k].first[(size_t(r) * S + s) * kWave] = val[k][s];
+            v[k].incoming[(size_t(r) * S + s) * kWave] = val[k][s];
+        }
     }
 }
 
@@ -1359,7 +1392,7 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             const char* split_env = std::getenv("SASKTRAN2_AMD_SO_SPLIT_LAYERS");
             if (!(split_env && atoi(split_env) != 0)) {
                 SoTimer t(I, st, "so_ray");
-                const dim3 grid(unsigned(g.inc.nrays), wb);
+                const dim3 grid(unsigned(g.inc.nrays), wb / 2);   // two slabs per wavefront (the block is padded to 128 wavelengths)
                 if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_ray<1>), grid, dim3(kWave), 0, st, g, b, g.inc_rec, g.inc.d00, g.inc.d02, g.inc.C2, g.inc.S2, b.factor);
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_ray<3>), grid, dim3(kWave), 0, st, g, b, g.inc_rec, g.inc.d00, g.inc.d02, g.inc.C2, g.inc.S2, b.factor);
             } else {
