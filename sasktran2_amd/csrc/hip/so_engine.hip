@@ -910,10 +910,14 @@ __global__ void __launch_bounds__(kWave) k_so_accumulate(SoGeo g, SoBufs b) {
     // `outgoing` that every wavefront in flight gathers from (PMC: 2.8 x the algorithmic HBM reads without the hint)
     const int g0 = g.acc_group_start[r], g1 = g.acc_group_start[r + 1];
     int gi = g0;
-    for (; gi + 2 <= g1; gi += 2) {   // two groups = 2 factor loads + 12 gathers in flight
-        double f[2], o[2][6][S];
+#ifndef SKSO_ACC_UNROLL
+#define SKSO_ACC_UNROLL 2
+#endif
+    constexpr int U = SKSO_ACC_UNROLL;
+    for (; gi + U <= g1; gi += U) {   // U groups = U factor loads + 6 U gathers in flight
+        double f[U], o[U][6][S];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const AccGroup& G = g.acc_group[gi + u];
             f[u] = __builtin_nontemporal_load(&factor[size_t(G.slot) * kWave]);
 #pragma unroll
@@ -922,7 +926,7 @@ __global__ void __launch_bounds__(kWave) k_so_accumulate(SoGeo g, SoBufs b) {
                 for (int s = 0; s < S; ++s) o[u][t][s] = outgoing[(size_t(G.col[t]) * S + s) * kWave];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const AccGroup& G = g.acc_group[gi + u];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
