@@ -29,7 +29,7 @@
 #define SKD_WPE_K2CM 4
 #endif
 #ifndef SKD_K1_LG
-#define SKD_K1_LG 32
+#define SKD_K1_LG 16
 #endif
 #ifndef SKD_WPE_K1
 #define SKD_WPE_K1 2
