@@ -845,7 +845,9 @@ template <int N> SKD_HD void k3_table_values(const Geo& g, const Bufs& b, int s,
         cleg[l] = a[l] * ((((l - m) & 1) ? -sp : sp) + sq);
     }
     int unconverged = 0;
-    const int t0 = g.pt_start[s * nlyr + p], t1 = g.pt_start[s * nlyr + p + 1];
+    // (the thermal pass runs with the extra solar index s = nsza, which has no diffuse table)
+    const bool tables = s < g.nsza;
+    const int t0 = tables ? g.pt_start[s * nlyr + p] : 0, t1 = tables ? g.pt_start[s * nlyr + p + 1] : 0;
     for (int t = t0; t < t1; ++t) {
         const int slot = g.pt_slot[t];
         if (conv_at(b, g, slot, w) <= m) continue;
@@ -875,7 +877,8 @@ template <int N> SKD_HD void k3_table_values(const Geo& g, const Bufs& b, int s,
             }
             diffuse += 2.0 * g.mu[i] * g.wt[i] * sv * b.albedo[w];
         }
-        for (int t = g.gpt_start[s]; t < g.gpt_start[s + 1]; ++t) J_at(b, g, m, g.gpt_slot[t], w) = diffuse;
+        if (tables)
+            for (int t = g.gpt_start[s]; t < g.gpt_start[s + 1]; ++t) J_at(b, g, m, g.gpt_slot[t], w) = diffuse;
     }
     if (unconverged) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -10,6 +10,11 @@
 #include "../sasktran2_amd/csrc/host/geo_tables.hpp"
 
 namespace {
+// thermal source inside the discrete-ordinates equations (emu_set_thermal): inputs and the emission weighting-function outputs
+const double* g_emission = nullptr;
+const double* g_surface_emission = nullptr;
+double* g_wf_emission = nullptr;
+double* g_wf_surface_emission = nullptr;
 struct Handle {
     skgeo::Geometry1D geo;
     skgeo::DiscoGeometry dg;
@@ -42,6 +47,29 @@ void run_n(const skd::Geo& g, skd::Bufs& b, int derivs) {
         if (derivs)
             for (int w = 0; w < nw; ++w)
                 for (int l = 0; l < g.nlos; ++l) skd::k4a_chain(g, b, 0, l, w);
+        if (g_emission) {
+            // thermal pass in the launch order of the HIP driver (disco_engine.hip, run_chunk): order 0 once more with the thermal "beam"
+            skd::Bufs bt = b;
+            bt.emission = g_emission;
+            bt.surf_em = g_surface_emission;
+            bt.thermal_pass = 1;
+            const int s = g.nsza;
+            for (int w = 0; w < nw; ++w) skd::k0_thermal(g, bt, w);
+            for (int w = 0; w < nw; ++w)
+                for (int p = 0; p < g.nlyr; ++p) skd::k1_layer_solution<N>(g, bt, s, 0, p, w);
+            for (int w = 0; w < nw; ++w) skd::k2a_bvp<N>(g, bt, s, 0, w);
+            if (derivs) {
+                for (int w = 0; w < nw; ++w)
+                    for (int p = 0; p < g.nlyr; ++p) skd::k3_table_values<N>(g, bt, s, 0, p, w);
+                for (int w = 0; w < nw; ++w)
+                    for (int p = 0; p < g.nlyr; ++p) skd::k2c_layer_ops<N>(g, bt, s, 0, p, w);
+            }
+            for (int w = 0; w < nw; ++w)
+                for (int l = 0; l < g.nlos; ++l) skd::kpp_los<N>(g, bt, s, 0, l, w);
+            if (derivs)
+                for (int w = 0; w < nw; ++w)
+                    for (int l = 0; l < g.nlos; ++l) skd::k4a_thermal(g, bt, l, w, 0, nw, g_wf_emission, g_wf_surface_emission);
+        }
         return;
     }
     for (int s = 0; s < g.nsza; ++s) {
@@ -111,6 +139,13 @@ void emu_destroy(void* h) { delete static_cast<Handle*>(h); }
 
 const double* g_delta_f = nullptr;
 void emu_set_delta_f(const double* f) { g_delta_f = f; }
+// emission [w][q], surface emission [w] (or null), outputs wf_emission [q][w][los], wf_surface_emission [w][los] (or null); all null = off
+void emu_set_thermal(const double* emission, const double* surface_emission, double* wf_emission, double* wf_surface_emission) {
+    g_emission = emission;
+    g_surface_emission = surface_emission;
+    g_wf_emission = wf_emission;
+    g_wf_surface_emission = wf_surface_emission;
+}
 int emu_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg,
             const double* solar_irradiance, const double* albedo, int derivatives, double* radiance, double* d_k,
             double* d_ssa, double* d_albedo, double* los_od, int* status) {

@@ -33,6 +33,7 @@ def lib():
         L.emu_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp, ctypes.c_int]
         L.emu_set_delta_f.argtypes = [_dp]
+        L.emu_set_thermal.argtypes = [_dp, _dp, _dp, _dp]
         L.emu_destroy.argtypes = [ctypes.c_void_p]
         L.emu_run.restype = ctypes.c_int
         L.emu_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_int, _dp,
@@ -66,11 +67,24 @@ def run_emulated(s, derivatives=True):
         status = np.zeros(nw, dtype=np.int32)
         df = None if s.get("delta_f") is None else np.asfortranarray(s["delta_f"], dtype=np.float64)
         lib().emu_set_delta_f(_p(df))
-        rc = lib().emu_run(h, nw, lg.shape[0], _p(k), _p(w), _p(lg), None, _p(alb), int(derivatives), _p(rad), _p(dk),
-                           _p(dw), _p(da), _p(od), status.ctypes.data_as(_ip))
+        # thermal source inside the discrete-ordinates equations (plane-parallel scenes with an "emission" profile)
+        em = sem = wem = wsem = None
+        if s.get("emission") is not None:
+            em = np.asfortranarray(s["emission"], dtype=np.float64)
+            sem = None if s.get("surface_emission") is None else np.ascontiguousarray(s["surface_emission"], dtype=np.float64)
+            wem, wsem = np.zeros((ngrid, nw, nlos)), np.zeros((nw, nlos))
+        irr = None if (em is None or s.get("solar_irradiance") is None) else np.ascontiguousarray(s["solar_irradiance"], dtype=np.float64)
+        lib().emu_set_thermal(_p(em), _p(sem), _p(wem), _p(wsem))
+        try:
+            rc = lib().emu_run(h, nw, lg.shape[0], _p(k), _p(w), _p(lg), _p(irr), _p(alb), int(derivatives), _p(rad), _p(dk),
+                               _p(dw), _p(da), _p(od), status.ctypes.data_as(_ip))
+        finally:
+            lib().emu_set_thermal(None, None, None, None)
         assert rc == 0
-        return {"radiance": rad, "los_optical_depth": od, "d_extinction": dk, "d_ssa": dw, "d_albedo": da,
-                "status": status}
+        out = {"radiance": rad, "los_optical_depth": od, "d_extinction": dk, "d_ssa": dw, "d_albedo": da, "status": status}
+        if wem is not None:
+            out["d_emission"], out["d_surface_emission"] = np.transpose(wem, (1, 2, 0)), wsem
+        return out
     finally:
         lib().emu_destroy(h)
 

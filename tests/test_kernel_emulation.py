@@ -216,3 +216,52 @@ def test_pseudo_spherical_chapman_factors_and_parity(csz):
     pp = dict(s, geometry=dict(s["geometry"], geotype=sc.GEO_PLANEPARALLEL))
     ratio = run_oracle(s)["radiance"] / run_oracle(pp)["radiance"]
     assert (np.abs(ratio - 1).max() < 5e-4) if csz > 0.8 else (ratio.min() > 1.001)
+
+
+# ------------------------------------------------------------------------------------------------ thermal source inside the DO equations
+@pytest.mark.parametrize("surface", [False, True], ids=["optical depth 100", "optical depth 1 with surface emission"])
+def test_thermal_pass_emulated_hits_the_disort_pins(surface):
+    """emission_source = discrete_ordinates: the thermal pass of the HIP driver (k0_thermal + the order-0 solve with the thermal "beam")
+    on the CPU against the reference's DISORT known answers (tests/engine/thermal_emissions/test_disort.py:7-112)"""
+    from tests.emulation import run_emulated
+    s = sc.disort_thermal(surface)
+    d = sc.delta_m_scaled(s)
+    got = run_emulated(dict(d, emission=s["emission"], surface_emission=s["surface_emission"], solar_irradiance=s["solar_irradiance"]), derivatives=False)
+    np.testing.assert_allclose(got["radiance"][0, 0], s["expected"], rtol=s["rtol"])
+
+
+@pytest.mark.parametrize("nstr", [4, 16])
+def test_thermal_weighting_functions_emulated_match_finite_differences(nstr):
+    """weighting functions of the thermal source -- extinction, ssa, albedo, emission profile, surface emission -- from the solar adjoint run
+    on the thermal layer parameters (k4a_thermal) against central differences of the emulated radiances; with the sun on as well"""
+    from tests.emulation import run_emulated
+    ng, nw = 9, 2
+    alt = np.linspace(0.0, 16000.0, ng)
+    geometry = dict(cos_sza=0.6, saa=0.0, earth_radius=6_372_000.0, altitudes=alt, interp_method=sc.INTERP_LINEAR, geotype=sc.GEO_PLANEPARALLEL)
+    base = dict(extinction=(7e-5 * np.exp(-alt / 7000.0))[:, None] * np.array([0.7, 2.0])[None, :],
+                ssa=np.linspace(0.4, 0.8, ng)[:, None] * np.ones((1, nw)),
+                emission=(3.0 * np.exp(-alt / 9000.0) + 0.4)[:, None] * np.array([1.0, 1.4])[None, :],
+                albedo=np.array([0.15, 0.3]), surface_emission=np.array([2.0, 1.2]))
+    leg = ((2 * np.arange(16) + 1) * 0.5 ** np.arange(16))[:, None, None] * np.ones((1, ng, nw))
+    rays = [(sc.GROUND_VIEWING_SOLAR, 0.6, 0.4, 200_000.0, 0.85), (sc.GROUND_VIEWING_SOLAR, 0.6, 1.9, 200_000.0, 0.45)]
+
+    def solve(v, derivs):
+        return run_emulated(dict(geometry=geometry, config=dict(nstr=nstr, num_sza=1), rays=rays, leg=leg, solar_irradiance=np.ones(nw), **v), derivatives=derivs)
+    res = solve(base, True)
+
+    def fd(key, q, h):
+        plus, minus = {k: a.copy() for k, a in base.items()}, {k: a.copy() for k, a in base.items()}
+        if q is None:
+            plus[key] = plus[key] + h
+            minus[key] = minus[key] - h
+        else:
+            plus[key][q] += h
+            minus[key][q] -= h
+        return (solve(plus, False)["radiance"] - solve(minus, False)["radiance"]) / (2 * h)
+    scale = np.max(np.abs(res["radiance"]))
+    for q in (0, 4, 8):
+        np.testing.assert_allclose(res["d_emission"][:, :, q], fd("emission", q, 1e-4), rtol=2e-6, atol=1e-9 * scale)
+        np.testing.assert_allclose(res["d_extinction"][:, :, q], fd("extinction", q, 1e-9), rtol=2e-5, atol=1e-6 * np.max(np.abs(res["d_extinction"])))
+        np.testing.assert_allclose(res["d_ssa"][:, :, q], fd("ssa", q, 1e-6), rtol=2e-5, atol=1e-6 * np.max(np.abs(res["d_ssa"])))
+    np.testing.assert_allclose(res["d_surface_emission"], fd("surface_emission", None, 1e-4), rtol=2e-6, atol=1e-9 * scale)
+    np.testing.assert_allclose(res["d_albedo"], fd("albedo", None, 1e-6), rtol=2e-5, atol=1e-8 * scale)
