@@ -131,6 +131,29 @@ class AbsorberTable:
         return xs, dxs
 
 
+class AbsorberTable2:
+    """Cross sections on a wavenumber grid at (pressure, temperature) nodes: bilinear in the two parameters, held outside (xsec_dbase.rs, Ix3)."""
+
+    def __init__(self, wavenumber_cminv, pressure_pa, temperature_k, xs):
+        self.wvnum, self.pressure, self.temperature = (np.asarray(v, dtype=float) for v in (wavenumber_cminv, pressure_pa, temperature_k))
+        self.xs = np.asarray(xs, dtype=float)
+        assert self.xs.shape == (len(self.pressure), len(self.temperature), len(self.wvnum))
+
+    def cross_section(self, wavenumbers, temperature_k, pressure_pa):
+        """xs, d xs / dP, d xs / dT  [location, wavelength]"""
+        one = AbsorberTable(self.wvnum, self.xs[0, 0])
+        rows = [[one._spectral(self.xs[i, j], wavenumbers) for j in range(len(self.temperature))] for i in range(len(self.pressure))]
+        nloc = len(temperature_k)
+        xs, dp, dt = (np.zeros((nloc, len(wavenumbers))) for _ in range(3))
+        for q in range(nloc):
+            for i, wi, dwi in interp_weights(self.pressure, pressure_pa[q], "extend"):
+                for j, wj, dwj in interp_weights(self.temperature, temperature_k[q], "extend"):
+                    xs[q] += rows[i][j] * wi * wj
+                    dp[q] += rows[i][j] * dwi * wj
+                    dt[q] += rows[i][j] * wi * dwj
+        return xs, dp, dt
+
+
 class HenyeyGreensteinTable:
     """Total cross section, scattering cross section (the reference keeps it in the `ssa` container) and asymmetry parameter on a
     wavelength grid; moments (2l+1) g^l are formed at the nodes and interpolated in wavenumber (scat_dbase.rs:120-157, 161-212)."""
@@ -285,17 +308,25 @@ class VMRAltitudeAbsorber:
     def __init__(self, table, altitudes_m, vmr, out_of_bounds_mode="zero"):
         self.table, self.alts, self.vmr, self.mode = table, np.asarray(altitudes_m, float), np.asarray(vmr, float), out_of_bounds_mode
 
+    def _xs(self, atmo):
+        """cross section and its derivatives with respect to the state variables the table depends on"""
+        if isinstance(self.table, AbsorberTable2):
+            xs, dp, dt = self.table.cross_section(atmo.wavenumbers, atmo.temperature, atmo.pressure)
+            return xs, {"pressure_pa": dp, "temperature_k": dt}
+        xs, dt = self.table.cross_section(atmo.wavenumbers, atmo.temperature)
+        return xs, ({} if dt is None else {"temperature_k": dt})
+
     def add(self, atmo):
         m = interp_matrix(self.alts, atmo.altitudes, self.mode)
         vmr = m @ self.vmr
-        xs, _ = self.table.cross_section(atmo.wavenumbers, atmo.temperature)
+        xs, _ = self._xs(atmo)
         atmo.ext += xs * vmr[:, np.newaxis] * atmo.air()["N"][:, np.newaxis]
 
     def register(self, atmo, name):
         m = interp_matrix(self.alts, atmo.altitudes, self.mode)
         vmr = m @ self.vmr
         air = atmo.air()
-        xs, dxs = self.table.cross_section(atmo.wavenumbers, atmo.temperature)
+        xs, dxs = self._xs(atmo)
         mp = atmo.mapping(f"wf_{name}_vmr")
         _absorber_mapping(mp, xs, atmo)
         mp.interp_dim = f"{name}_altitude"
@@ -311,12 +342,13 @@ class VMRAltitudeAbsorber:
             mp.interp_dim = "altitude"
             mp.assign_name = f"wf_{key}"
             mp.interpolator = np.diag(vmr * factor)
-        if state and dxs is not None:
-            mp = atmo.mapping(f"wf_{name}_temperature_k_xs")
-            _absorber_mapping(mp, dxs, atmo)
-            mp.interp_dim = "altitude"
-            mp.assign_name = "wf_temperature_k"
-            mp.interpolator = np.diag(vmr * air["N"])
+        if state:
+            for key, d in dxs.items():   # vmr_alt_absorber.rs:233-256: one mapping per parameter of the table
+                mp = atmo.mapping(f"wf_{name}_{key}_xs")
+                _absorber_mapping(mp, d, atmo)
+                mp.interp_dim = "altitude"
+                mp.assign_name = f"wf_{key}"
+                mp.interpolator = np.diag(vmr * air["N"])
 
 
 class NumberDensityScatterer:

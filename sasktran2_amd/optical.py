@@ -174,6 +174,48 @@ class AbsorberDatabaseDim2(OpticalProperty):
         return out
 
 
+class AbsorberDatabaseDim3(OpticalProperty):
+    """Cross sections [parameter 0, parameter 1, spectral grid] -- the pressure / temperature tables of line absorbers
+    (`AbsorberDatabaseDim3(wavenumber_cminv, param0, param1, xs, names)`; xsec_dbase.rs, Ix3): bilinear in the two parameters (held outside),
+    one spectral term per table node pair the profile touches, derivative weights for both parameters."""
+
+    def __init__(self, wavenumber_cminv=None, param0=None, param1=None, xs=None, names=("pressure_pa", "temperature_k"), wavelength_nm=None):
+        self._wvnum, order = _sorted_wavenumbers(wavenumber_cminv, wavelength_nm)
+        p0, p1 = np.asarray(param0, dtype=float), np.asarray(param1, dtype=float)
+        o0, o1 = np.argsort(p0), np.argsort(p1)
+        self._p0, self._p1 = p0[o0], p1[o1]
+        self._xs = np.asarray(xs, dtype=float)[o0][:, o1][:, :, order]
+        self._names = tuple(names)
+        if self._xs.shape != (len(p0), len(p1), len(self._wvnum)):
+            raise ValueError("xs must be [parameter 0, parameter 1, spectral grid]")
+        if len(self._names) != 2 or any(n not in ("temperature_k", "pressure_pa") for n in self._names) or self._names[0] == self._names[1]:
+            raise ValueError("the table parameters must be temperature_k and pressure_pa")
+        self._cache = _SpectrumCache()
+
+    def spectral_terms(self, atmo):
+        v0, v1 = getattr(atmo, self._names[0]), getattr(atmo, self._names[1])
+        if v0 is None or v1 is None:
+            raise ValueError("the atmosphere needs pressure_pa and temperature_k for this table")
+        a = interp_weights(self._p0, v0, "extend")
+        b = interp_weights(self._p1, v1, "extend")
+        nloc, n0, n1 = len(v0), len(self._p0), len(self._p1)
+        w = np.zeros((n0, n1, nloc))
+        d0, d1 = np.zeros_like(w), np.zeros_like(w)
+        loc = np.arange(nloc)
+        for ia, wa, da in ((a[0], a[1], a[2]), (a[3], a[4], a[5])):
+            for ib, wb, db in ((b[0], b[1], b[2]), (b[3], b[4], b[5])):
+                np.add.at(w, (ia, ib, loc), wa * wb)
+                np.add.at(d0, (ia, ib, loc), da * wb)
+                np.add.at(d1, (ia, ib, loc), wa * db)
+        rows = self._cache.get(atmo.wavenumbers_cminv, lambda wv: np.array([[_table_spectrum(self._wvnum, r, wv) for r in plane] for plane in self._xs]))
+        out = []
+        for i in range(n0):
+            for j in range(n1):
+                if w[i, j].any() or d0[i, j].any() or d1[i, j].any():
+                    out.append((w[i, j], {self._names[0]: d0[i, j], self._names[1]: d1[i, j]}, {"ext": rows[i, j], "scat": None, "leg": None}))
+        return out
+
+
 class HenyeyGreenstein(OpticalProperty):
     """Scatterer with a Henyey-Greenstein phase function; build with `from_parameters` (src/sasktran2/optical/henyey.py:22-59).
     As in the reference's constituent pipeline `ssa` carries the scattering cross section [m^2]."""

@@ -308,13 +308,18 @@ def frontend_case(nwavel=40, ngrid=25, seed=3):
     aer_alt = np.array([0.0, 5000.0, 12000.0, 20000.0, 30000.0, 45000.0])
     aer_nd = np.array([4.0e8, 9.0e7, 2.0e7, 8.0e6, 1.5e6, 1.0e5]) * (1.0 + 0.1 * rng.random(6))
     aer_ext = np.array([2.0e-7, 3.5e-7, 1.2e-7, 4.0e-8, 1.0e-8, 1.0e-9])
+    # a line-absorber-like table on (pressure, temperature) nodes: pressure broadening lowers the peaks, temperature shifts the strength
+    tab_p = np.array([10.0, 1000.0, 20000.0, 60000.0, 110000.0])
+    pt_xs = (2.0e-25 * (1.0 + 0.5 * np.sin(tab_wl / 7.0)) ** 2)[np.newaxis, np.newaxis, :] * (1.0 / (1.0 + tab_p / 5.0e4))[:, np.newaxis, np.newaxis] \
+        * (1.0 + 3.0e-3 * (tab_t - 243.0))[np.newaxis, :, np.newaxis]
     return dict(altitudes=alt, temperature=temperature, pressure=pressure, wavelengths=wavelengths, tab_wl=tab_wl, tab_t=tab_t, tab_xs=tab_xs,
+                tab_p=tab_p, pt_xs=pt_xs, pt_vmr=1.8e-6 * np.ones(14),
                 o3_alt=o3_alt, o3_vmr=o3_vmr, hg_wl=hg_wl, hg_xs=hg_xs, hg_scat=hg_xs * hg_ssa, hg_g=hg_g, aer_alt=aer_alt, aer_nd=aer_nd,
                 aer_ext=aer_ext, ext_wavelength=525.0)
 
 
 def frontend_oracle_atmosphere(c, nmoments, nstokes=1, thermal=False, temperature_table=True, extinction_scatterer=True,
-                               pressure_derivative=True, temperature_derivative=True):
+                               pressure_derivative=True, temperature_derivative=True, pt_table=False):
     """The oracle's assembly of `frontend_case` (oracle/frontend_oracle.py)."""
     from oracle import frontend_oracle as fo
     a = fo.Atmosphere(c["altitudes"], c["wavelengths"], nmoments, nstokes, c["pressure"], c["temperature"], pressure_derivative, temperature_derivative)
@@ -323,6 +328,8 @@ def frontend_oracle_atmosphere(c, nmoments, nstokes=1, thermal=False, temperatur
     order = np.argsort(wv)
     table = fo.AbsorberTable(wv[order], c["tab_xs"][:, order], c["tab_t"]) if temperature_table else fo.AbsorberTable(wv[order], c["tab_xs"][2, order])
     a.constituents["o3"] = fo.VMRAltitudeAbsorber(table, c["o3_alt"], c["o3_vmr"], "extend")
+    if pt_table:
+        a.constituents["ch4"] = fo.VMRAltitudeAbsorber(fo.AbsorberTable2(wv[order], c["tab_p"], c["tab_t"], c["pt_xs"][:, :, order]), c["o3_alt"], c["pt_vmr"], "extend")
     hg = fo.HenyeyGreensteinTable(c["hg_wl"], c["hg_xs"], c["hg_scat"], c["hg_g"], 64)
     a.constituents["aerosol"] = fo.NumberDensityScatterer(hg, c["aer_alt"], c["aer_nd"], "zero")
     if extinction_scatterer:
@@ -333,7 +340,7 @@ def frontend_oracle_atmosphere(c, nmoments, nstokes=1, thermal=False, temperatur
 
 
 def frontend_product_atmosphere(sk, c, geometry, config, thermal=False, temperature_table=True, extinction_scatterer=True,
-                                calculate_derivatives=True, pressure_derivative=True, temperature_derivative=True):
+                                calculate_derivatives=True, pressure_derivative=True, temperature_derivative=True, pt_table=False):
     """The same atmosphere through the product's constituent interface (sasktran2_amd.constituent / .optical)."""
     atmo = sk.Atmosphere(geometry, config, wavelengths_nm=c["wavelengths"], calculate_derivatives=calculate_derivatives,
                          pressure_derivative=pressure_derivative, temperature_derivative=temperature_derivative)
@@ -343,6 +350,9 @@ def frontend_product_atmosphere(sk, c, geometry, config, thermal=False, temperat
     table = (sk.optical.AbsorberDatabaseDim2(wavelength_nm=c["tab_wl"], param=c["tab_t"], xs=c["tab_xs"]) if temperature_table
              else sk.optical.AbsorberDatabaseDim1(wavelength_nm=c["tab_wl"], xs=c["tab_xs"][2]))
     atmo["o3"] = sk.constituent.VMRAltitudeAbsorber(table, c["o3_alt"], c["o3_vmr"], "extend")
+    if pt_table:
+        atmo["ch4"] = sk.constituent.VMRAltitudeAbsorber(
+            sk.optical.AbsorberDatabaseDim3(wavelength_nm=c["tab_wl"], param0=c["tab_p"], param1=c["tab_t"], xs=c["pt_xs"]), c["o3_alt"], c["pt_vmr"], "extend")
     hg = sk.optical.HenyeyGreenstein.from_parameters(c["hg_wl"], c["hg_xs"], c["hg_scat"], c["hg_g"], 64)
     atmo["aerosol"] = sk.constituent.NumberDensityScatterer(hg, c["aer_alt"], c["aer_nd"], "zero")
     if extinction_scatterer:

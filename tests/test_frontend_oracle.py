@@ -73,14 +73,15 @@ def test_extinction_mapping_matches_storage_difference():
         _check_against_finite_difference({}, "wf_cloud_extinction", perturb, j, 1e-12, 2e-6)
 
 
+@pytest.mark.parametrize("pt_table", [False, True], ids=["temperature table", "+ pressure-temperature table"])
 @pytest.mark.parametrize("key,field,step", [("wf_temperature_k", "temperature", 1e-3), ("wf_pressure_pa", "pressure", 1e-2)])
-def test_state_mappings_match_storage_difference(key, field, step):
+def test_state_mappings_match_storage_difference(key, field, step, pt_table):
     """every constituent that depends on the state adds a mapping with the same assign_name (Rayleigh through N, the absorber through N
     and through its temperature-dependent table); their sum is the total derivative"""
     def perturb(c, j, h):
         c[field][j] += h
     for j in (1, 9, 20):
-        _check_against_finite_difference({}, key, perturb, j, step, 5e-6)
+        _check_against_finite_difference({"pt_table": pt_table}, key, perturb, j, step, 5e-6)
 
 
 def test_thermal_emission_and_its_temperature_mapping():
@@ -175,6 +176,11 @@ def test_product_host_logic_matches_oracle():
     want, dwant = fo.AbsorberTable(wv[order], c["tab_xs"][:, order], c["tab_t"]).cross_section(a.wavenumbers_cminv, c["temperature"])
     np.testing.assert_allclose(xs, want, rtol=1e-14)
     np.testing.assert_allclose(dxs, dwant, rtol=1e-13, atol=1e-45)
+    terms = opt.AbsorberDatabaseDim3(wavelength_nm=c["tab_wl"], param0=c["tab_p"], param1=c["tab_t"], xs=c["pt_xs"]).spectral_terms(a)
+    want, dp, dt = fo.AbsorberTable2(wv[order], c["tab_p"], c["tab_t"], c["pt_xs"][:, :, order]).cross_section(a.wavenumbers_cminv, c["temperature"], c["pressure"])
+    np.testing.assert_allclose(sum(w[:, None] * s["ext"][None, :] for w, _, s in terms), want, rtol=1e-14)
+    np.testing.assert_allclose(sum(d["pressure_pa"][:, None] * s["ext"][None, :] for _, d, s in terms), dp, rtol=1e-13, atol=1e-45)
+    np.testing.assert_allclose(sum(d["temperature_k"][:, None] * s["ext"][None, :] for _, d, s in terms), dt, rtol=1e-13, atol=1e-45)
     (w, _, s), = opt.HenyeyGreenstein.from_parameters(c["hg_wl"], c["hg_xs"], c["hg_scat"], c["hg_g"], 64).spectral_terms(a)
     oxs, osc, oleg = fo.HenyeyGreensteinTable(c["hg_wl"], c["hg_xs"], c["hg_scat"], c["hg_g"], 64).quantities(a.wavenumbers_cminv, 8, 1)
     np.testing.assert_allclose(s["ext"], oxs, rtol=1e-14)
