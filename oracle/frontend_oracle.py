@@ -351,6 +351,39 @@ class VMRAltitudeAbsorber:
                 mp.interpolator = np.diag(vmr * air["N"])
 
 
+class CollisionInducedAbsorber:
+    """collisioninducedabsorber.py:60-126: extinction = xs [m^5] x fraction product x N^2; state derivatives through N and through the table"""
+
+    def __init__(self, table, fraction_product=0.20964 ** 2):
+        self.table, self.fp = table, fraction_product
+
+    def _xs(self, atmo):
+        xs, dt = self.table.cross_section(atmo.wavenumbers, atmo.temperature)
+        return xs, ({} if dt is None else {"temperature_k": dt})
+
+    def add(self, atmo):
+        xs, _ = self._xs(atmo)
+        atmo.ext += xs * (self.fp * atmo.air()["N"] ** 2)[:, np.newaxis]
+
+    def register(self, atmo, name):
+        air = atmo.air()
+        xs, dxs = self._xs(atmo)
+        state = []
+        if atmo.pressure_derivative:
+            state.append(("pressure_pa", air["dN_dP"]))
+        if atmo.temperature_derivative:
+            state.append(("temperature_k", air["dN_dT"]))
+        for key, dn in state:
+            mp = atmo.mapping(f"wf_{name}_{key}")
+            _absorber_mapping(mp, 2 * self.fp * (air["N"] * dn)[:, np.newaxis] * xs, atmo)
+            mp.interp_dim, mp.assign_name = "altitude", f"wf_{key}"
+        if state:
+            for key, d in dxs.items():
+                mp = atmo.mapping(f"wf_{name}_{key}_xs")
+                _absorber_mapping(mp, d * (self.fp * air["N"] ** 2)[:, np.newaxis], atmo)
+                mp.interp_dim, mp.assign_name = "altitude", f"wf_{key}"
+
+
 class NumberDensityScatterer:
     wf_name = "number_density"
 

@@ -7,6 +7,7 @@ Reference behaviour followed (nothing copied):
   src/sasktran2/constituent/rayleigh.py, rust/sasktran2-rs/src/constituent/types/rayleigh.rs:110-258
   src/sasktran2/constituent/vmraltitudeabsorber.py, rust/.../vmr_alt_absorber.rs:64-260, 339-399
   src/sasktran2/constituent/numdenscatterer.py, rust/.../number_density_scatterer.rs:218-440
+  src/sasktran2/constituent/collisioninducedabsorber.py
   src/sasktran2/constituent/emission.py, rust/.../emission.rs:9-116
   src/sasktran2/constituent/brdf/lambertiansurface.py, brdf/__init__.py:11-63
 """
@@ -126,6 +127,41 @@ class VMRAltitudeAbsorber(Constituent):
             for key in sorted({k for _, slopes, _ in self._spectral for k in slopes}):
                 slopes = np.array([s.get(key, np.zeros(atmo.num_locations)) for _, s, _ in self._spectral])
                 fe.add_mapping(f"wf_{name}_{key}_xs", self._terms, slopes, interpolator=np.diag(vmr * n), interp_dim="altitude", assign_name=f"wf_{key}")
+
+
+class CollisionInducedAbsorber(Constituent):
+    """Collision-induced absorption of a pair with constant mole fractions: extinction = cross section [m^5] x (fraction product) x N^2
+    (src/sasktran2/constituent/collisioninducedabsorber.py).  `name`: "O2O2"."""
+
+    def __init__(self, optical_property: OpticalProperty, name: str):
+        if optical_property.is_scatterer:
+            raise ValueError("CollisionInducedAbsorber takes a purely absorbing optical property")
+        if name.lower() != "o2o2":
+            raise ValueError(f"Unknown name '{name}'")
+        self._optical_property = optical_property
+        self._fraction_product = 0.20964 ** 2
+        self._terms = []
+
+    def add_to_atmosphere(self, atmo):
+        _require_state(atmo, "O2O2")
+        n = atmo.state_equation.air_numberdensity["N"]
+        self._spectral = self._optical_property.spectral_terms(atmo)
+        self._terms = [atmo.frontend.add_term(self._fraction_product * n ** 2 * weight, spec["ext"]) for weight, _, spec in self._spectral]
+
+    def register_derivative(self, atmo, name):
+        air = atmo.state_equation.air_numberdensity
+        n = air["N"]
+        weights = np.array([w for w, _, _ in self._spectral])
+        state = [(key, d) for key, flag, d in (("pressure_pa", atmo.calculate_pressure_derivative, air["dN_dP"]),
+                                               ("temperature_k", atmo.calculate_temperature_derivative, air["dN_dT"])) if flag]
+        for key, dn in state:   # through the number density: d(N^2) = 2 N dN
+            atmo.frontend.add_mapping(f"wf_{name}_{key}", self._terms, weights * (2.0 * self._fraction_product * n * dn)[np.newaxis, :],
+                                      interp_dim="altitude", assign_name=f"wf_{key}")
+        if state:
+            for key in sorted({k for _, slopes, _ in self._spectral for k in slopes}):   # through the table's own parameters
+                slopes = np.array([s.get(key, np.zeros(atmo.num_locations)) for _, s, _ in self._spectral])
+                atmo.frontend.add_mapping(f"wf_{name}_{key}_xs", self._terms, slopes * (self._fraction_product * n ** 2)[np.newaxis, :],
+                                          interp_dim="altitude", assign_name=f"wf_{key}")
 
 
 class NumberDensityScatterer(Constituent):

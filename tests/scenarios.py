@@ -319,7 +319,7 @@ def frontend_case(nwavel=40, ngrid=25, seed=3):
 
 
 def frontend_oracle_atmosphere(c, nmoments, nstokes=1, thermal=False, temperature_table=True, extinction_scatterer=True,
-                               pressure_derivative=True, temperature_derivative=True, pt_table=False):
+                               pressure_derivative=True, temperature_derivative=True, pt_table=False, cia=False):
     """The oracle's assembly of `frontend_case` (oracle/frontend_oracle.py)."""
     from oracle import frontend_oracle as fo
     a = fo.Atmosphere(c["altitudes"], c["wavelengths"], nmoments, nstokes, c["pressure"], c["temperature"], pressure_derivative, temperature_derivative)
@@ -328,6 +328,8 @@ def frontend_oracle_atmosphere(c, nmoments, nstokes=1, thermal=False, temperatur
     order = np.argsort(wv)
     table = fo.AbsorberTable(wv[order], c["tab_xs"][:, order], c["tab_t"]) if temperature_table else fo.AbsorberTable(wv[order], c["tab_xs"][2, order])
     a.constituents["o3"] = fo.VMRAltitudeAbsorber(table, c["o3_alt"], c["o3_vmr"], "extend")
+    if cia:   # the same temperature-dependent table stands in for a collision-induced cross section [m^5]
+        a.constituents["o2o2"] = fo.CollisionInducedAbsorber(fo.AbsorberTable(wv[order], c["tab_xs"][:, order] * 3e-33, c["tab_t"]))
     if pt_table:
         a.constituents["ch4"] = fo.VMRAltitudeAbsorber(fo.AbsorberTable2(wv[order], c["tab_p"], c["tab_t"], c["pt_xs"][:, :, order]), c["o3_alt"], c["pt_vmr"], "extend")
     hg = fo.HenyeyGreensteinTable(c["hg_wl"], c["hg_xs"], c["hg_scat"], c["hg_g"], 64)
@@ -340,7 +342,7 @@ def frontend_oracle_atmosphere(c, nmoments, nstokes=1, thermal=False, temperatur
 
 
 def frontend_product_atmosphere(sk, c, geometry, config, thermal=False, temperature_table=True, extinction_scatterer=True,
-                                calculate_derivatives=True, pressure_derivative=True, temperature_derivative=True, pt_table=False):
+                                calculate_derivatives=True, pressure_derivative=True, temperature_derivative=True, pt_table=False, cia=False):
     """The same atmosphere through the product's constituent interface (sasktran2_amd.constituent / .optical)."""
     atmo = sk.Atmosphere(geometry, config, wavelengths_nm=c["wavelengths"], calculate_derivatives=calculate_derivatives,
                          pressure_derivative=pressure_derivative, temperature_derivative=temperature_derivative)
@@ -350,6 +352,9 @@ def frontend_product_atmosphere(sk, c, geometry, config, thermal=False, temperat
     table = (sk.optical.AbsorberDatabaseDim2(wavelength_nm=c["tab_wl"], param=c["tab_t"], xs=c["tab_xs"]) if temperature_table
              else sk.optical.AbsorberDatabaseDim1(wavelength_nm=c["tab_wl"], xs=c["tab_xs"][2]))
     atmo["o3"] = sk.constituent.VMRAltitudeAbsorber(table, c["o3_alt"], c["o3_vmr"], "extend")
+    if cia:
+        atmo["o2o2"] = sk.constituent.CollisionInducedAbsorber(
+            sk.optical.AbsorberDatabaseDim2(wavelength_nm=c["tab_wl"], param=c["tab_t"], xs=c["tab_xs"] * 3e-33), "O2O2")
     if pt_table:
         atmo["ch4"] = sk.constituent.VMRAltitudeAbsorber(
             sk.optical.AbsorberDatabaseDim3(wavelength_nm=c["tab_wl"], param0=c["tab_p"], param1=c["tab_t"], xs=c["pt_xs"]), c["o3_alt"], c["pt_vmr"], "extend")

@@ -81,7 +81,7 @@ def test_state_mappings_match_storage_difference(key, field, step, pt_table):
     def perturb(c, j, h):
         c[field][j] += h
     for j in (1, 9, 20):
-        _check_against_finite_difference({"pt_table": pt_table}, key, perturb, j, step, 5e-6)
+        _check_against_finite_difference({"pt_table": pt_table, "cia": pt_table}, key, perturb, j, step, 5e-6)
 
 
 def test_thermal_emission_and_its_temperature_mapping():

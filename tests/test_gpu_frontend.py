@@ -45,9 +45,9 @@ def test_storage_and_mappings_match_oracle(nstokes):
     import sasktran2_amd as sk
     c = sc.frontend_case(nwavel=33)
     cfg = _config(sk, nstokes=nstokes, moments=8)
-    atmo = sc.frontend_product_atmosphere(sk, c, _geometry(sk, c), cfg, thermal=True, pt_table=True)
+    atmo = sc.frontend_product_atmosphere(sk, c, _geometry(sk, c), cfg, thermal=True, pt_table=True, cia=True)
     atmo.internal_object()
-    want = sc.frontend_oracle_atmosphere(c, 8, nstokes, thermal=True, pt_table=True).assemble()
+    want = sc.frontend_oracle_atmosphere(c, 8, nstokes, thermal=True, pt_table=True, cia=True).assemble()
     st = atmo.storage
     _close(st.total_extinction, want.ext)
     _close(st.ssa, want.ssa)
@@ -149,7 +149,7 @@ def test_weighting_functions_match_finite_differences(key, field, j, step):
     engine, geo = _engine_case(sk, c, cfg, rays)
 
     def radiance(case, derivs):
-        atmo = sc.frontend_product_atmosphere(sk, case, geo, cfg, calculate_derivatives=derivs, pt_table=True)
+        atmo = sc.frontend_product_atmosphere(sk, case, geo, cfg, calculate_derivatives=derivs, pt_table=True, cia=True)
         atmo["surface"] = sk.constituent.LambertianSurface(0.3)
         return engine.calculate_radiance(atmo, as_dataset=False)
     base = radiance(c, True)
