@@ -167,7 +167,9 @@ class CollisionInducedAbsorber(Constituent):
 class NumberDensityScatterer(Constituent):
     _wf_name = "number_density"
 
-    def __init__(self, optical_property: OpticalProperty, altitudes_m, number_density, out_of_bounds_mode="zero"):
+    def __init__(self, optical_property: OpticalProperty, altitudes_m, number_density, out_of_bounds_mode="zero", **kwargs):
+        if kwargs:   # the reference passes these to parameterised scattering databases (particle size axes), which this build does not hold
+            raise ValueError(f"auxiliary optical parameters {sorted(kwargs)} need a parameterised scattering database, which is not part of this build")
         if not optical_property.is_scatterer:
             raise ValueError("NumberDensityScatterer takes a scattering optical property")
         self._optical_property = optical_property
@@ -201,8 +203,8 @@ class ExtinctionScatterer(NumberDensityScatterer):
     (src/sasktran2/constituent/numdenscatterer.py:117-197)."""
     _wf_name = "extinction"
 
-    def __init__(self, optical_property, altitudes_m, extinction_per_m, extinction_wavelength_nm, out_of_bounds_mode="zero"):
-        super().__init__(optical_property, altitudes_m, None, out_of_bounds_mode)
+    def __init__(self, optical_property, altitudes_m, extinction_per_m, extinction_wavelength_nm, out_of_bounds_mode="zero", **kwargs):
+        super().__init__(optical_property, altitudes_m, None, out_of_bounds_mode, **kwargs)
         self.extinction_per_m = np.asarray(extinction_per_m, dtype=float)
         self._extinction_wavelength_nm = float(extinction_wavelength_nm)
 
