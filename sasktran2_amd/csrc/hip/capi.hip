@@ -298,7 +298,10 @@ AtmosphereStorage* sk_atmosphere_storage_create(int nloc, int nwavel, int nleg, 
     auto* s = new AtmosphereStorage{nloc, nwavel, nleg, nstokes, ssa, ext, emission, leg, irradiance, {}, {}};
     return s;
 }
-void sk_atmosphere_storage_destroy(AtmosphereStorage* s) { delete s; }
+void sk_atmosphere_storage_destroy(AtmosphereStorage* s) {
+    if (s && s->owner) return;   // the handle of a device front end (sk_amd_frontend_storage) belongs to it: sk_amd_frontend_destroy frees it
+    delete s;
+}
 int sk_atmosphere_storage_get_derivative_mapping(AtmosphereStorage* s, const char* name, DerivativeMapping** m) {
     if (!s || !name || !m) return -1;
     auto it = s->maps.find(name);
