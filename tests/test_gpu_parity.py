@@ -871,8 +871,8 @@ def test_thermal_emission_with_sun_and_reflecting_surface_matches_oracle():
     assert np.all(ref > sun_only)
 
 
-@pytest.mark.parametrize("nstr", [4, 16], ids=["4 streams", "16 streams"])
-def test_thermal_source_weighting_functions_match_finite_differences(nstr):
+@pytest.mark.parametrize("nstr,delta_m", [(4, False), (16, False), (4, True)], ids=["4 streams", "16 streams", "4 streams, delta-M scaled"])
+def test_thermal_source_weighting_functions_match_finite_differences(nstr, delta_m):
     """emission_source = discrete_ordinates with weighting functions: extinction, ssa, albedo (solar + thermal parts together), the emission
     profile and the surface emission (mappings with d_emission, deriv_mapping.h:15-53) against central differences of the product's own
     radiances -- the reference's criterion (tests/weightingfunctions/test_emissions.py)."""
@@ -886,6 +886,7 @@ def test_thermal_source_weighting_functions_match_finite_differences(nstr):
     config.multiple_scatter_source = sk.MultipleScatterSource.DiscreteOrdinates
     config.single_scatter_source = sk.SingleScatterSource.DiscreteOrdinates
     config.emission_source = sk.EmissionSource.DiscreteOrdinates
+    config.delta_m_scaling = delta_m   # 16 moments stored: truncation at the stream count, the mappings are scaled with the storage
     geometry = sk.Geometry1D(0.6, 0.0, 6372000.0, alt, sk.InterpolationMethod.LinearInterpolation, sk.GeometryType.PlaneParallel)
     viewing = sk.ViewingGeometry()
     viewing.add_ray(sk.GroundViewingSolar(0.6, 0.4, 0.9, 200000.0))
