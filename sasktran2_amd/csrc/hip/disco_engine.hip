@@ -613,7 +613,10 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                     // 16 streams: adjoint operators and sweeps as FP64 matrix-core products (v_mfma_f64_16x16x4_f64)
                     {
                         Timer t2(I, sC, "k2c_adjoint_ops");
-                        const int split = small_batch_split(int(nw));
+                        // the layers of the adjoint operators are independent: three blocks per wavelength also at full size (30 000 wavefronts fill
+                        // the 4 096 resident slots in 7.3 rounds instead of 2.4: 36 -> 32 ms per step alone, 0.4 % of the pipelined step)
+                        int split = std::max(3, small_batch_split(int(nw)));
+                        if (const char* e = std::getenv("SASKTRAN2_AMD_K2C_SPLIT")) split = std::max(1, atoi(e));
                         const int lpb = (g.nlyr + split - 1) / split, ny = (g.nlyr + lpb - 1) / lpb;
                         hipLaunchKernelGGL(kern_k2c_mfma8, dim3(unsigned(nw), unsigned(ny)), dim3(64), 0, sC, g, b, s, m, lpb);
                     }
