@@ -7,7 +7,7 @@ temperature derivative, wf_aerosol_number_density, wf_cloud_extinction, the Plan
 
 Roofline bookkeeping: every kernel is a stream that writes its output once.  Algorithmic bytes per wavelength = arrays
 written (storage: extinction, ssa, emission, nleg Legendre rows; per mapping d_extinction, d_ssa and, for scatterers, scat_factor and
-nleg d_legendre rows) + the totals a mapping has to read (extinction, ssa; leg_coeff for d_legendre), x ngrid x 8 B.  `achieved` prices the
+nleg d_legendre rows) + the totals the mapping stage reads once (extinction, ssa, leg_coeff), x ngrid x 8 B.  `achieved` prices the
 dominant kernel with ITS bytes per launch over its HIP-event time."""
 from __future__ import annotations
 
@@ -44,11 +44,12 @@ def case(nwavel, ngrid=51):
     return c
 
 
-def kernel_bytes(ngrid, nleg, nw):
-    """algorithmic bytes per launch of every front-end kernel at this size"""
+def kernel_bytes(ngrid, nleg, nw, nplain, nscat):
+    """algorithmic bytes per launch of every front-end kernel at this size: arrays written once, totals read once"""
     cell = ngrid * 8 * nw
-    return {"k_fe_assemble": 2 * cell, "k_fe_legendre": nleg * cell, "k_fe_planck": cell, "k_fe_map": (2 + 2) * cell,   # (+ scat_factor: priced below)
-            "k_fe_map_legendre": 2 * nleg * cell}
+    return {"k_fe_assemble": 2 * cell, "k_fe_legendre": nleg * cell, "k_fe_planck": cell,
+            "k_fe_map_all": (2 + 2 * nplain + 3 * nscat) * cell,          # extinction, ssa in; d_extinction, d_ssa (, scat_factor) out per mapping
+            "k_fe_map_legendre_all": (1 + nscat) * nleg * cell}           # leg_coeff in once; d_legendre out per scatterer mapping
 
 
 def run_frontend(args, world, rank, dev):
@@ -95,7 +96,7 @@ def run_frontend(args, world, rank, dev):
     nem = sum(m.emission for m in mappings.values())
     cell = ngrid * 8
     written = cell * (3 + nmoments) + nplain * 2 * cell + nscat * (3 + nmoments) * cell + nem * 3 * cell
-    read = (nplain + nscat) * 2 * cell + nscat * nmoments * cell
+    read = 2 * cell + (nmoments * cell if nscat else 0)   # the totals, once (the mappings are formed by two launches)
     algorithmic = written + read
 
     fe.set_profiling(True)
@@ -105,7 +106,7 @@ def run_frontend(args, world, rank, dev):
     fe.set_profiling(False)
     dominant = max(ktimes, key=lambda k: ktimes[k][0])
     dom_ms, dom_n = ktimes[dominant]
-    per_launch = kernel_bytes(ngrid, nmoments, nloc)[dominant]
+    per_launch = kernel_bytes(ngrid, nmoments, nloc, nplain, nscat)[dominant]
     achieved = per_launch / (dom_ms / dom_n * 1e-3) / 1e9
     kernels_total_ms = sum(v[0] for v in ktimes.values())
     pmc, pmc_nw = pmc_bytes_per_launch()

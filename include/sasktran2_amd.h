@@ -182,6 +182,9 @@ int sk_amd_frontend_assemble(sk_amd_frontend* f);
  * [nlocation x nout], or NULL; interp_dim / assign_name as deriv_mapping.h:32,40. */
 int sk_amd_frontend_add_mapping(sk_amd_frontend* f, const char* name, int nterms, const int* terms, const double* weights, int scatterer,
                                 int planck_temperature, const double* interpolator, int nout, const char* interp_dim, const char* assign_name);
+/* add_mapping only records a mapping; its arrays are formed, together with those of every other pending mapping (two kernel launches for
+ * all of them), by sk_amd_frontend_finalize -- or by the first call that needs them (_storage, _device_pointer, _download, delta-M scaling) */
+int sk_amd_frontend_finalize(sk_amd_frontend* f);
 AtmosphereStorage* sk_amd_frontend_storage(sk_amd_frontend* f);   /* borrowed: valid until the front end is destroyed, reset or assembled again */
 /* what = "extinction" | "ssa" | "leg_coeff" | "emission" | "delta_f" | "<mapping>:d_extinction" | ":d_ssa" | ":scat_factor" |
  * ":d_legendre" | ":d_emission" | ":d_f" */

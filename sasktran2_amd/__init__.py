@@ -360,6 +360,7 @@ class Atmosphere:
             if self._calculate_derivatives:
                 for name, constituent in self._constituents.items():
                     constituent.register_derivative(self, name)
+                fe.finalize()
         except Exception:
             fe.reset()
             raise

@@ -79,6 +79,7 @@ SIGNATURES = [
     ("sk_amd_frontend_set_planck_emission", _I, [_vp, _vp, _vp]), ("sk_amd_frontend_set_solar_irradiance", _I, [_vp, _vp]),
     ("sk_amd_frontend_assemble", _I, [_vp]),
     ("sk_amd_frontend_add_mapping", _I, [_vp, _S, _I, _vp, _vp, _I, _I, _vp, _I, _S, _S]),
+    ("sk_amd_frontend_finalize", _I, [_vp]),
     ("sk_amd_frontend_storage", _vp, [_vp]),
     ("sk_amd_frontend_device_pointer", _I, [_vp, _S, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_ulonglong)]),
     ("sk_amd_frontend_download", _I, [_vp, _S, _vp]),

@@ -120,6 +120,59 @@ __global__ void __launch_bounds__(256) k_fe_map_legendre(const Term* __restrict_
     }
 }
 
+// All pending mappings in one launch each: the totals (extinction, ssa; leg_coeff) are read ONCE per element and every mapping's arrays are
+// written from that read -- with M scatterer mappings the d_legendre stage moves (1 + M) instead of 2 M arrays.
+struct MapDesc {             // device
+    int first, count;        // the mapping's terms in the table of the launch
+    double *d_ext, *d_ssa;   // [nwavel][ngrid]
+    double *scat_factor;     // [nwavel][ngrid] or null (plain mapping)
+    double *d_leg;           // [nwavel][ngrid][nleg] or null
+};
+__global__ void __launch_bounds__(256) k_fe_map_all(const Term* __restrict__ terms, const MapDesc* __restrict__ maps, int nmaps, int ngrid, int nw,
+                                                    const double* __restrict__ ext, const double* __restrict__ ssa) {
+    const size_t n = size_t(ngrid) * nw;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const int w = int(i / ngrid), q = int(i - size_t(w) * ngrid);
+        const double k = ext[i], om = ssa[i];
+        for (int m = 0; m < nmaps; ++m) {
+            const MapDesc d = maps[m];
+            double e = 0.0, s = 0.0;
+            for (int r = d.first; r < d.first + d.count; ++r) {
+                const Term t = terms[r];
+                const double c = t.prof ? t.prof[q] : 1.0;
+                e += t.ext[w] * c;
+                if (t.scat) s += t.scat[w] * c;
+            }
+            const double species_ssa = e != 0.0 ? s / e : 1.0;
+            d.d_ext[i] = e;
+            d.d_ssa[i] = k == 0.0 ? 0.0 : e * (species_ssa - om) / k;
+            if (d.scat_factor) d.scat_factor[i] = om * k != 0.0 ? s / (om * k) : 0.0;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_fe_map_legendre_all(const Term* __restrict__ terms, const MapDesc* __restrict__ maps, int nmaps, int ngrid,
+                                                             int nw, int nleg, const double* __restrict__ leg) {
+    const size_t n = size_t(ngrid) * nw * nleg;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const size_t cell = i / nleg;
+        const int l = int(i - cell * nleg), w = int(cell / ngrid), q = int(cell - size_t(w) * ngrid);
+        const double beta = leg[i];
+        for (int m = 0; m < nmaps; ++m) {
+            const MapDesc d = maps[m];
+            if (!d.d_leg) continue;
+            double s = 0.0, P = 0.0;
+            for (int r = d.first; r < d.first + d.count; ++r) {
+                const Term t = terms[r];
+                if (!t.scat) continue;
+                const double v = t.scat[w] * (t.prof ? t.prof[q] : 1.0);
+                s += v;
+                if (t.leg) P += v * t.leg[size_t(w) * nleg + l];
+            }
+            d.d_leg[i] = (s != 0.0 ? P / s : 0.0) - beta;
+        }
+    }
+}
+
 // validate_input_atmosphere for storage that lives in HBM: first offending element (index, kind 1 non-finite / 2 below / 3 above) or -1
 __global__ void __launch_bounds__(256) k_fe_validate(const double* __restrict__ a, size_t n, double lo, double hi, unsigned long long* first) {
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {

@@ -127,6 +127,10 @@ class FrontEnd:
         self.mappings[name] = DeviceMapping(self, name, bool(scatterer), bool(planck), None if interpolator is None else interpolator.copy(),
                                             interp_dim, assign_name)
 
+    def finalize(self):
+        """form the arrays of every mapping added so far (two launches for all of them)"""
+        self._check(lib().sk_amd_frontend_finalize(self._h), "sk_amd_frontend_finalize")
+
     def storage_handle(self):
         h = lib().sk_amd_frontend_storage(self._h)
         if not h:
