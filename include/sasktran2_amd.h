@@ -171,6 +171,9 @@ int sk_amd_frontend_reset(sk_amd_frontend* f);   /* forget terms, mappings, emis
 /* one rank-one term: amount profile [nlocation] x extinction cross section [nwavel]; scat (scattering cross section [nwavel]) and
  * leg (phase moments per scattering event [nwavel][nleg]) may be NULL.  Returns the term's index (>= 0) or an error (< 0). */
 int sk_amd_frontend_add_term(sk_amd_frontend* f, const double* profile, const double* ext, const double* scat, const double* leg);
+/* the next term again after a reset, keeping the spectra the term at this position held (still in HBM) and taking a new profile; returns
+   the term index, -2 when no term was added at this position before the last reset */
+int sk_amd_frontend_readd_term(sk_amd_frontend* f, const double* profile);
 int sk_amd_frontend_set_profile(sk_amd_frontend* f, int term, const double* profile);
 /* emission[q][w] += Planck radiance B(temperature_k[q], wavelengths_nm[w]) in W / (m^2 sr nm)  (emission.rs:9-16) */
 int sk_amd_frontend_set_planck_emission(sk_amd_frontend* f, const double* temperature_k, const double* wavelengths_nm);

@@ -75,7 +75,7 @@ SIGNATURES = [
     ("sk_amd_ts_engine_solve_device", _I, [_vp, _I, _I] + [_vp] * 17 + [_I]),
     ("sk_atmosphere_apply_delta_m_scaling", _I, [_vp, _I]),
     ("sk_amd_frontend_create", _vp, [_I, _I, _I, _I]), ("sk_amd_frontend_destroy", None, [_vp]), ("sk_amd_frontend_reset", _I, [_vp]),
-    ("sk_amd_frontend_add_term", _I, [_vp, _vp, _vp, _vp, _vp]), ("sk_amd_frontend_set_profile", _I, [_vp, _I, _vp]),
+    ("sk_amd_frontend_add_term", _I, [_vp, _vp, _vp, _vp, _vp]), ("sk_amd_frontend_readd_term", _I, [_vp, _vp]), ("sk_amd_frontend_set_profile", _I, [_vp, _I, _vp]),
     ("sk_amd_frontend_set_planck_emission", _I, [_vp, _vp, _vp]), ("sk_amd_frontend_set_solar_irradiance", _I, [_vp, _vp]),
     ("sk_amd_frontend_assemble", _I, [_vp]),
     ("sk_amd_frontend_add_mapping", _I, [_vp, _S, _I, _vp, _vp, _I, _I, _vp, _I, _S, _S]),

@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .optical import OpticalProperty, linear_interpolating_matrix, rayleigh_cross_section_bates
+from .optical import OpticalProperty, _SpectrumCache, linear_interpolating_matrix, rayleigh_cross_section_bates
 
 
 class Constituent:
@@ -26,6 +26,16 @@ class Constituent:
 
     def register_derivative(self, atmo, name):
         raise NotImplementedError
+
+    def _altitude_matrix(self, atmo):
+        """[grid altitude, own altitude] interpolation matrix; both grids are fixed for the life of their objects, so it is built once per
+        model geometry"""
+        held = getattr(self, "_matrix_for", None)
+        if held is None or held[0] is not atmo.model_geometry:
+            held = (atmo.model_geometry, linear_interpolating_matrix(self._altitudes_m, atmo.model_geometry.altitudes(), self._mode))
+            held[1].setflags(write=False)
+            self._matrix_for = held
+        return held[1]
 
 
 def _state_derivatives(atmo):
@@ -60,6 +70,7 @@ class Rayleigh(Constituent):
         self._mix = (n2_percentage, o2_percentage, ar_percentage, co2_percentage)
         self._table = None if method == "bates" else tuple(np.asarray(v, dtype=float) for v in (wavelengths_nm, xs, king_factor))
         self._term = None
+        self._cache = _SpectrumCache()
 
     def _cross_section(self, wavelengths_nm):
         if self._method == "bates":
@@ -69,14 +80,22 @@ class Rayleigh(Constituent):
 
     def add_to_atmosphere(self, atmo):
         _require_state(atmo, "Rayleigh")
-        sigma, king = self._cross_section(atmo.wavelengths_nm)
-        delta = 6.0 * (king - 1.0) / (3.0 + 7.0 * king)
-        factor = (1.0 - delta) / (2.0 + delta)
-        leg = np.zeros((atmo.num_wavel, atmo.num_leg))
-        if atmo.nstokes == 1:
-            leg[:, 0], leg[:, 2] = 1.0, factor
-        else:   # a1, a2, a3, b1 per order (rayleigh.rs:145-158)
-            leg[:, 0], leg[:, 8], leg[:, 9], leg[:, 11] = 1.0, factor, 6.0 * factor, np.sqrt(6.0) * factor
+        shape = (atmo.num_wavel, atmo.num_leg, atmo.nstokes)
+
+        def build(_):
+            sigma, king = self._cross_section(atmo.wavelengths_nm)
+            delta = 6.0 * (king - 1.0) / (3.0 + 7.0 * king)
+            factor = (1.0 - delta) / (2.0 + delta)
+            leg = np.zeros(shape[:2])
+            if atmo.nstokes == 1:
+                leg[:, 0], leg[:, 2] = 1.0, factor
+            else:   # a1, a2, a3, b1 per order (rayleigh.rs:145-158)
+                leg[:, 0], leg[:, 8], leg[:, 9], leg[:, 11] = 1.0, factor, 6.0 * factor, np.sqrt(6.0) * factor
+            return (np.ascontiguousarray(sigma, dtype=float), leg, shape)
+        sigma, leg, built_for = self._cache.get(atmo.wavenumbers_cminv, build)
+        if built_for != shape:       # the same spectral grid with another moment count / Stokes dimension
+            self._cache = _SpectrumCache()
+            sigma, leg, _ = self._cache.get(atmo.wavenumbers_cminv, build)
         self._term = atmo.frontend.add_term(atmo.state_equation.air_numberdensity["N"], sigma, sigma, leg)
 
     def register_derivative(self, atmo, name):
@@ -103,7 +122,7 @@ class VMRAltitudeAbsorber(Constituent):
         return self._altitudes_m
 
     def _profile(self, atmo):
-        m = linear_interpolating_matrix(self._altitudes_m, atmo.model_geometry.altitudes(), self._mode)
+        m = self._altitude_matrix(atmo)
         return m, m @ self.vmr
 
     def add_to_atmosphere(self, atmo):
@@ -186,13 +205,13 @@ class NumberDensityScatterer(Constituent):
     def add_to_atmosphere(self, atmo):
         if atmo.wavelengths_nm is None:
             raise ValueError("the atmosphere needs wavelengths for a scatterer defined by an optical property")
-        m = linear_interpolating_matrix(self._altitudes_m, atmo.model_geometry.altitudes(), self._mode)
+        m = self._altitude_matrix(atmo)
         nd = m @ self.number_density
         self._spectral = self._optical_property.spectral_terms(atmo)
         self._terms = [atmo.frontend.add_term(nd * weight, spec["ext"], spec["scat"], spec["leg"]) for weight, _, spec in self._spectral]
 
     def register_derivative(self, atmo, name):
-        m = linear_interpolating_matrix(self._altitudes_m, atmo.model_geometry.altitudes(), self._mode)
+        m = self._altitude_matrix(atmo)
         weights = np.array([w for w, _, _ in self._spectral])
         atmo.frontend.add_mapping(f"wf_{name}_{self._wf_name}", self._terms, weights, scatterer=True,
                                   interpolator=m * self._vertical_deriv_factor[np.newaxis, :], interp_dim=f"{name}_altitude")

@@ -19,6 +19,16 @@ def _c(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
 
 
+def _frozen_key(a):
+    """identity of a spectrum that cannot have changed since it was uploaded: (address, shape) of a read-only float64 array (what the
+    optical properties' spectrum caches hand out), None for an absent one, False for anything writeable"""
+    if a is None:
+        return None
+    if not isinstance(a, np.ndarray) or a.flags.writeable or a.dtype != np.float64 or not a.flags.c_contiguous:
+        return False
+    return (a.__array_interface__["data"][0], a.shape)
+
+
 class DeviceMapping:
     """Read-only view of one derivative mapping held in HBM (`atmosphere.storage.get_derivative_mapping(name)` of the reference)."""
 
@@ -62,6 +72,9 @@ class FrontEnd:
             raise RuntimeError(f"sk_amd_frontend_create failed: {last_error()}")
         self.mappings = {}
         self.assembled = False
+        self._nterms = 0
+        self.spectra_reused = 0   # terms of the current assembly whose spectra were already in HBM
+        self._slots = []      # per term position: (key of the spectra in HBM, the arrays themselves -- held so the addresses stay theirs)
 
     def __del__(self):
         if getattr(self, "_h", None) and callable(lib):
@@ -77,6 +90,8 @@ class FrontEnd:
         self._check(lib().sk_amd_frontend_reset(self._h), "sk_amd_frontend_reset")
         self.mappings = {}
         self.assembled = False
+        self._nterms = 0
+        self.spectra_reused = 0
 
     def add_term(self, profile, ext, scat=None, leg=None):
         profile, ext, scat, leg = _c(profile), _c(ext), _c(scat), _c(leg)
@@ -86,7 +101,25 @@ class FrontEnd:
             raise ValueError("the scattering spectrum has one value per wavelength")
         if leg is not None and leg.shape != (self.nwavel, self.nleg):
             raise ValueError("phase moments are [wavelength, first dimension of leg_coeff]")
-        return self._check(lib().sk_amd_frontend_add_term(self._h, _vp(profile), _vp(ext), _vp(scat), _vp(leg)), "sk_amd_frontend_add_term")
+        # spectra that are the same read-only arrays as at this position in the previous assembly are still in HBM: only the profile moves
+        slot, key = self._nterms, (_frozen_key(ext), _frozen_key(scat), _frozen_key(leg))
+        reusable = False not in key
+        if reusable and slot < len(self._slots) and self._slots[slot][0] == key:
+            index = lib().sk_amd_frontend_readd_term(self._h, _vp(profile))
+            self.spectra_reused += index == slot
+        else:
+            index = -2
+        if index == -2:
+            del self._slots[slot:]
+            self._slots.extend([(None, None)] * (slot - len(self._slots)))
+            index = lib().sk_amd_frontend_add_term(self._h, _vp(profile), _vp(ext), _vp(scat), _vp(leg))
+            if index >= 0:
+                self._slots.append((key, (ext, scat, leg)) if reusable else (None, None))
+        if index != slot:
+            self._slots = []
+            self._check(min(index, -1), "sk_amd_frontend_add_term")
+        self._nterms += 1
+        return index
 
     def set_profile(self, term, profile):
         profile = _c(profile)

@@ -101,15 +101,23 @@ def _table_spectrum(wvnum_grid, row, wavenumbers):
 
 class _SpectrumCache:
     """The table interpolated to the atmosphere's spectral grid, kept while that grid stays the same (a retrieval changes profiles step
-    after step, not the wavelengths)."""
+    after step, not the wavelengths).  What it hands out is read-only."""
 
     def __init__(self):
         self._key, self._value = None, None
 
     def get(self, wavenumbers, build):
         if self._key is None or self._key.shape != wavenumbers.shape or not np.array_equal(self._key, wavenumbers):
-            self._key, self._value = wavenumbers.copy(), build(wavenumbers)
+            self._key, self._value = wavenumbers.copy(), _freeze(build(wavenumbers))
         return self._value
+
+
+def _freeze(value):
+    """read-only arrays: the front end keeps a spectrum it was handed in HBM for as long as the same read-only array comes back"""
+    for a in (value.values() if isinstance(value, dict) else value if isinstance(value, tuple) else (value,)):
+        if isinstance(a, np.ndarray):
+            a.setflags(write=False)
+    return value
 
 
 def _sorted_wavenumbers(wavenumber_cminv, wavelength_nm):

@@ -205,3 +205,39 @@ def test_us76_standard_atmosphere_known_values():
     a = _Atmo()
     us76.add_us76_standard_atmosphere(a)
     assert a.temperature_k.shape == (8,) and np.all(np.diff(a.pressure_pa) < 0)
+
+
+def test_cached_spectra_are_read_only_and_keyed_by_identity():
+    """what lets the front end keep a spectrum in HBM from one assembly to the next (sasktran2_amd/frontend.py `_frozen_key`): the
+    optical properties hand out the same read-only arrays while the spectral grid stays the same, new ones when it changes"""
+    import sasktran2_amd.optical as opt
+    from sasktran2_amd.frontend import _frozen_key
+
+    class _Atmo:
+        pass
+    c = sc.frontend_case(nwavel=17)
+    a = _Atmo()
+    a.wavenumbers_cminv, a.temperature_k, a.pressure_pa = 1e7 / c["wavelengths"], c["temperature"], c["pressure"]
+    a.num_locations, a.num_moments, a.nstokes = len(c["altitudes"]), 8, 1
+    table = opt.AbsorberDatabaseDim2(wavelength_nm=c["tab_wl"], param=c["tab_t"], xs=c["tab_xs"])
+    hg = opt.HenyeyGreenstein.from_parameters(c["hg_wl"], c["hg_xs"], c["hg_scat"], c["hg_g"], 64)
+    first = [s for _, _, s in table.spectral_terms(a)] + [hg.spectral_terms(a)[0][2]]
+    a.temperature_k = c["temperature"] + 0.01
+    again = [s for _, _, s in table.spectral_terms(a)] + [hg.spectral_terms(a)[0][2]]
+    assert len(first) == len(again)
+    for s0, s1 in zip(first, again):
+        for field in ("ext", "scat", "leg"):
+            k0, k1 = _frozen_key(s0[field]), _frozen_key(s1[field])
+            assert k0 is not False and k0 == k1
+            if s0[field] is not None:
+                assert not s0[field].flags.writeable
+                with pytest.raises(ValueError):
+                    s0[field][...] = 0.0
+    a.wavenumbers_cminv = a.wavenumbers_cminv * 1.001
+    moved = [s for _, _, s in table.spectral_terms(a)]
+    held = first   # (the front end holds the arrays it uploaded, so a new array cannot take the address of an old one)
+    assert all(_frozen_key(s1["ext"]) != _frozen_key(s0["ext"]) for s0, s1 in zip(held, moved))
+    assert _frozen_key(np.zeros(3)) is False and _frozen_key(None) is None
+    ro = np.zeros((4, 3))
+    ro.setflags(write=False)
+    assert _frozen_key(ro[:, 0]) is False and _frozen_key(ro[1]) == (ro[1].__array_interface__["data"][0], (3,))

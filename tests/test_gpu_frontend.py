@@ -464,3 +464,58 @@ def test_constituent_run_is_independent_of_the_spectrum_it_sits_in():
         scale = np.max(np.abs(ref))
         assert np.max(np.abs(val - ref)) <= 1e-12 * scale, key
     assert all(np.all(np.isfinite(v)) for v in full.values())
+
+
+def test_spectra_stay_in_hbm_between_assemblies():
+    """A retrieval rebuilds its atmosphere step after step with new amounts and the same cross sections: from the second assembly on the
+    terms keep the spectra they uploaded (read-only arrays of the optical properties' caches) and move only their profiles.  The result is
+    that of a front end that never saw the earlier state; a spectrum that changed is uploaded again."""
+    import sasktran2_amd as sk
+    c = sc.frontend_case(nwavel=33)
+    cfg = _config(sk, moments=8)
+    geo = _geometry(sk, c)
+    atmo = sc.frontend_product_atmosphere(sk, c, geo, cfg, thermal=True, pt_table=True, cia=True)
+    fe = atmo.internal_object()
+    nterms = fe._nterms
+    assert nterms > 4 and fe.spectra_reused == 0
+    c2 = dict(c, o3_vmr=c["o3_vmr"] * 1.3, aer_nd=c["aer_nd"] * 0.7, temperature=c["temperature"] + 0.01)
+    atmo["o3"].vmr = c2["o3_vmr"]
+    atmo["aerosol"].number_density = c2["aer_nd"]
+    atmo.temperature_k = c2["temperature"]
+    fe = atmo.internal_object()
+    assert fe._nterms == nterms and fe.spectra_reused == nterms
+    want = sc.frontend_oracle_atmosphere(c2, 8, 1, thermal=True, pt_table=True, cia=True).assemble()
+    st = atmo.storage
+    _close(st.total_extinction, want.ext)
+    _close(st.ssa, want.ssa)
+    _close(st.leg_coeff, want.leg)
+    _close(st.emission_source, want.emission)
+    for name, w in want.mappings.items():
+        m = st.get_derivative_mapping(name)
+        _close(m.d_extinction, w.d_extinction)
+        _close(m.d_ssa, w.d_ssa)
+        if w.d_legendre is not None:
+            _close(m.d_leg_coeff, w.d_legendre)
+    fresh = sc.frontend_product_atmosphere(sk, c2, geo, cfg, thermal=True, pt_table=True, cia=True)
+    fresh.internal_object()
+    assert np.array_equal(fresh.storage.total_extinction, st.total_extinction) and np.array_equal(fresh.storage.leg_coeff, st.leg_coeff)
+    # another spectral grid: everything is uploaded again
+    atmo.wavelengths_nm = c["wavelengths"] * 1.001
+    fe = atmo.internal_object()
+    assert fe.spectra_reused == 0
+    want = sc.frontend_oracle_atmosphere(dict(c2, wavelengths=c["wavelengths"] * 1.001), 8, 1, thermal=True, pt_table=True, cia=True).assemble()
+    _close(atmo.storage.total_extinction, want.ext)
+    _close(atmo.storage.leg_coeff, want.leg)
+    # the C ABI alone: a term added again keeps its spectra, a position that never held one is refused
+    from sasktran2_amd.frontend import FrontEnd
+    raw = FrontEnd(4, 5, 2, 1)
+    prof, ext = np.array([1.0, 2.0, 3.0, 4.0]), np.linspace(1.0, 2.0, 5)
+    raw.add_term(prof, ext)
+    raw.assemble()
+    first = raw.download("extinction", (5, 4))
+    raw.reset()
+    from sasktran2_amd._lib_loader import lib
+    assert lib().sk_amd_frontend_readd_term(raw._h, (2 * prof).ctypes.data) == 0
+    assert lib().sk_amd_frontend_readd_term(raw._h, prof.ctypes.data) == -2
+    raw.assemble()
+    assert np.array_equal(raw.download("extinction", (5, 4)), 2 * first)
