@@ -461,6 +461,23 @@ class ThermalEmission:
         m.assign_name = "wf_temperature_k"
 
 
+class SurfaceThermalEmission:
+    """src/sasktran2/constituent/emission.py:113-190: surface emission [wavelength] += emissivity x B(T_surface); surface mappings
+    wf_<name>_temperature_k (d_emission = emissivity x dB/dT) and wf_<name>_emissivity (d_emission = B), one value per wavelength
+    (interp_dim "dummy" / none: src/sasktran2/engine.py:540-549)."""
+
+    def __init__(self, temperature_k, emissivity):
+        self.temperature_k, self.emissivity = float(temperature_k), np.atleast_1d(np.asarray(emissivity, dtype=float))
+
+    def emission(self, wavelengths_nm):
+        return self.emissivity * planck(self.temperature_k, wavelengths_nm)
+
+    def surface_mappings(self, name, wavelengths_nm):
+        """{mapping name: d_emission [wavelength]}"""
+        return {f"wf_{name}_temperature_k": self.emissivity * d_planck_dT(self.temperature_k, wavelengths_nm),
+                f"wf_{name}_emissivity": planck(self.temperature_k, wavelengths_nm)}
+
+
 # ---------------------------------------------------------------------------------------------------------------- output assembly
 def assemble_weighting_functions(atmo, native):
     """engine.py:340-372 / cpp/lib/output/outputc.cpp:38-236: native = {"ext", "ssa" [nloc, nw, nlos], optional "leg" [nleg, nloc, nw, nlos],

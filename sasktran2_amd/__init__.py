@@ -341,8 +341,12 @@ class Atmosphere:
             return DeviceStorage(self._frontend, self._raw_storage.solar_irradiance)
         return self._raw_storage
 
-    def register_surface_mapping(self, name, interpolator, interp_dim):
-        self._surface_mappings[name] = (np.asarray(interpolator, dtype=float), interp_dim)
+    def register_surface_mapping(self, name, interpolator, interp_dim, d_brdf=1.0, d_emission=None):
+        """a derivative with respect to a surface parameter: d(BRDF argument) and d(surface emission) per wavelength, and the
+        [wavelength, parameter] interpolator its output goes through (None: one value per wavelength, src/sasktran2/engine.py:19-32)"""
+        self._surface_mappings[name] = (None if interpolator is None else np.asarray(interpolator, dtype=float), interp_dim,
+                                        np.broadcast_to(np.asarray(d_brdf, dtype=float), (self._nwavel,)),
+                                        None if d_emission is None else np.broadcast_to(np.asarray(d_emission, dtype=float), (self._nwavel,)))
 
     def internal_object(self):
         """Assemble the atmosphere from its constituents in HBM: add every constituent, normalise, then let every constituent register
@@ -352,6 +356,8 @@ class Atmosphere:
         fe = self.frontend
         fe.reset()
         self._surface_mappings = {}
+        if any(getattr(c, "_adds_surface_emission", False) for c in self._constituents.values()):
+            self.surface.emission[:] = 0.0      # constituents add to it (the reference zeroes the surface before a rebuild)
         try:
             for constituent in self._constituents.values():
                 constituent.add_to_atmosphere(self)
@@ -581,7 +587,10 @@ class Engine:
                     L.sk_surface_get_derivative_mapping(h_su, name.encode(), ctypes.byref(m))
                     ptr = _dp()
                     L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
-                    np.ctypeslib.as_array(ptr, shape=(nw,))[:] = 1.0
+                    np.ctypeslib.as_array(ptr, shape=(nw,))[:] = atmosphere._surface_mappings[name][2]
+                    if atmosphere._surface_mappings[name][3] is not None:
+                        L.sk_surface_deriv_mapping_get_d_emission(m, ctypes.byref(ptr))
+                        np.ctypeslib.as_array(ptr, shape=(nw,))[:] = atmosphere._surface_mappings[name][3]
                     raw_surface[name] = np.zeros((nw, nlos, S))
                     L.sk_output_assign_surface_derivative_memory(h_out, name.encode(), _p(raw_surface[name]), nw * nlos, S)
             # src/sasktran2/atmosphere.py:845-854: scale when more moments are stored than streams are used
@@ -610,9 +619,12 @@ class Engine:
                 out[key] = out[key] + raw[name]
             else:
                 out[key], dims[key] = raw[name], d
-        for name, (interp, interp_dim) in atmosphere._surface_mappings.items():
-            out[name] = np.einsum("ij...,il->lij...", raw_surface[name], interp)
-            dims[name] = (interp_dim, "wavelength", "los", "stokes")
+        for name, (interp, interp_dim, _, _) in atmosphere._surface_mappings.items():
+            if interp is None:      # one value per wavelength (engine.py:19-22, 540-549)
+                out[name], dims[name] = raw_surface[name], ("wavelength", "los", "stokes")
+            else:
+                out[name] = np.einsum("ij...,il->lij...", raw_surface[name], interp)
+                dims[name] = (interp_dim, "wavelength", "los", "stokes")
         if as_dataset:
             try:
                 import xarray as xr

@@ -52,6 +52,7 @@ SIGNATURES = [
     ("sk_surface_set_brdf", _I, [_vp, _vp, _dp]),
     ("sk_surface_get_derivative_mapping", _I, [_vp, _S, ctypes.POINTER(_vp)]),
     ("sk_surface_deriv_mapping_get_d_brdf", _I, [_vp, ctypes.POINTER(_dp)]),
+    ("sk_surface_deriv_mapping_get_d_emission", _I, [_vp, ctypes.POINTER(_dp)]),
     ("sk_atmosphere_create", _vp, [_vp, _vp, _I, _I]), ("sk_atmosphere_destroy", None, [_vp]),
     ("sk_output_create", _vp, [_dp, _I, _I, _dp, _I]), ("sk_output_destroy", None, [_vp]),
     ("sk_output_assign_derivative_memory", _I, [_vp, _S, _dp, _I, _I, _I]),

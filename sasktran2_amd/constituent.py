@@ -251,6 +251,40 @@ class ThermalEmission(Constituent):
         atmo.frontend.add_mapping(f"wf_{name}_temperature_k", planck=True, interp_dim="altitude", assign_name="wf_temperature_k")
 
 
+def _planck(temperature_k, wavelengths_nm):
+    """Planck radiance in W / (m^2 sr nm) and its temperature derivative (emission.rs:9-30)"""
+    h, c, kb = 6.62607015e-34, 299792458.0, 1.380649e-23
+    wl = np.asarray(wavelengths_nm, dtype=float) * 1e-9
+    ex = np.exp(h * c / (wl * kb * temperature_k))
+    return 2.0 * h * c ** 2 / wl ** 5 / (ex - 1.0) * 1e-9, 2.0 * h ** 2 * c ** 3 * ex / (wl ** 6 * kb * temperature_k ** 2 * (ex - 1.0) ** 2) * 1e-9
+
+
+class SurfaceThermalEmission(Constituent):
+    """A surface emitting emissivity x Planck radiance at its own temperature (src/sasktran2/constituent/emission.py:113-190): emissivity
+    constant in wavelength (scalar) or on the atmosphere's wavelength grid.  Weighting functions `wf_<name>_temperature_k` and
+    `wf_<name>_emissivity`, one value per wavelength.  What the surface holds is one number per wavelength: host arithmetic."""
+    _adds_surface_emission = True
+
+    def __init__(self, temperature_k, emissivity):
+        self.temperature_k = float(temperature_k)
+        self.emissivity = np.atleast_1d(np.asarray(emissivity, dtype=float))
+
+    def _emissivity_on_grid(self, atmo):
+        if atmo.wavelengths_nm is None:
+            raise ValueError("SurfaceThermalEmission needs wavelengths_nm in the Atmosphere object")
+        if len(self.emissivity) not in (1, atmo.num_wavel):
+            raise ValueError("the emissivity is a scalar or has one value per wavelength of the atmosphere")
+        return np.broadcast_to(self.emissivity, (atmo.num_wavel,))
+
+    def add_to_atmosphere(self, atmo):
+        atmo.surface.emission[:] += self._emissivity_on_grid(atmo) * _planck(self.temperature_k, atmo.wavelengths_nm)[0]
+
+    def register_derivative(self, atmo, name):
+        b, db = _planck(self.temperature_k, atmo.wavelengths_nm)
+        atmo.register_surface_mapping(f"wf_{name}_temperature_k", None, "dummy", d_brdf=0.0, d_emission=self._emissivity_on_grid(atmo) * db)
+        atmo.register_surface_mapping(f"wf_{name}_emissivity", None, "dummy", d_brdf=0.0, d_emission=b)
+
+
 class LambertianSurface(Constituent):
     """Albedo constant in wavelength (scalar), on the atmosphere's own wavelength grid, or interpolated from `wavelengths_nm` /
     `wavenumbers_cminv` (src/sasktran2/constituent/brdf/lambertiansurface.py)."""

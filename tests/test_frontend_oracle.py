@@ -241,3 +241,17 @@ def test_cached_spectra_are_read_only_and_keyed_by_identity():
     ro = np.zeros((4, 3))
     ro.setflags(write=False)
     assert _frozen_key(ro[:, 0]) is False and _frozen_key(ro[1]) == (ro[1].__array_interface__["data"][0], (3,))
+
+
+def test_surface_thermal_emission_oracle():
+    """emission.py:113-190: emissivity x Planck at the surface temperature; its two surface mappings are the derivatives of that product"""
+    wl = np.linspace(4000.0, 14000.0, 7)
+    eps = np.linspace(0.8, 1.0, 7)
+    s = fo.SurfaceThermalEmission(285.0, eps)
+    maps = s.surface_mappings("ground", wl)
+    h = 1e-3
+    fd = (fo.SurfaceThermalEmission(285.0 + h, eps).emission(wl) - fo.SurfaceThermalEmission(285.0 - h, eps).emission(wl)) / (2 * h)
+    np.testing.assert_allclose(maps["wf_ground_temperature_k"], fd, rtol=1e-8)
+    np.testing.assert_allclose(maps["wf_ground_emissivity"] * eps, s.emission(wl), rtol=1e-15)
+    # a black body at 300 K radiates 9.92 W / (m^2 sr um) at 10 um (Planck's law with the CODATA constants)
+    assert fo.SurfaceThermalEmission(300.0, 1.0).emission(np.array([10000.0]))[0] * 1e3 == pytest.approx(9.924, rel=1e-3)

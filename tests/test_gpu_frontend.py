@@ -519,3 +519,75 @@ def test_spectra_stay_in_hbm_between_assemblies():
     assert lib().sk_amd_frontend_readd_term(raw._h, prof.ctypes.data) == -2
     raw.assemble()
     assert np.array_equal(raw.download("extinction", (5, 4)), 2 * first)
+
+
+@pytest.mark.parametrize("source", ["twostream", "discrete_ordinates", "line_of_sight"])
+def test_surface_thermal_emission_constituent(source):
+    """SurfaceThermalEmission (src/sasktran2/constituent/emission.py:113-190): the surface emits emissivity x Planck(T_surface); what the
+    surface holds equals the oracle, and wf_<name>_temperature_k / wf_<name>_emissivity (one value per wavelength) equal finite differences
+    of the radiance, for each emission source that sees the surface.  Emissivity per wavelength and as a scalar."""
+    import sasktran2_amd as sk
+    from oracle import frontend_oracle as fo
+    c = sc.frontend_case(nwavel=5)
+    c["wavelengths"] = np.linspace(9000.0, 11000.0, 5)
+    c["tab_wl"] = np.linspace(8000.0, 12000.0, 111)
+    c["tab_xs"] = c["tab_xs"] * 1e3
+    c["hg_wl"] = np.linspace(8000.0, 12000.0, 6)
+    cfg = sk.Config()
+    cfg.num_singlescatter_moments = 4
+    cfg.single_scatter_source = sk.SingleScatterSource.NoSource
+    cfg.multiple_scatter_source = sk.MultipleScatterSource.NoSource
+    geotype = sk.GeometryType.PlaneParallel
+    if source == "twostream":
+        cfg.num_streams = 2
+        cfg.emission_source = sk.EmissionSource.TwoStream
+    elif source == "discrete_ordinates":
+        cfg.num_streams = 4
+        cfg.multiple_scatter_source = sk.MultipleScatterSource.DiscreteOrdinates
+        cfg.single_scatter_source = sk.SingleScatterSource.DiscreteOrdinates
+        cfg.emission_source = sk.EmissionSource.DiscreteOrdinates
+    else:
+        cfg.emission_source = sk.EmissionSource.Standard
+        geotype = sk.GeometryType.Spherical
+    engine, geo = _engine_case(sk, c, cfg, [sk.GroundViewingSolar(0.6, 0.0, 0.9, 200000.0), sk.GroundViewingSolar(0.6, 0.5, 0.6, 200000.0)], geotype=geotype)
+    emissivity = np.linspace(0.9, 0.98, 5)
+
+    def radiance(t_surface, eps, derivs=False):
+        # (the thermal pass of the discrete-ordinates engine does not serve scattering-group mappings: Rayleigh without state derivatives)
+        state = source != "discrete_ordinates"
+        atmo = sk.Atmosphere(geo, cfg, wavelengths_nm=c["wavelengths"], calculate_derivatives=derivs, pressure_derivative=state, temperature_derivative=state)
+        atmo.pressure_pa, atmo.temperature_k = c["pressure"], c["temperature"]
+        atmo["rayleigh"] = sk.constituent.Rayleigh()
+        atmo["o3"] = sk.constituent.VMRAltitudeAbsorber(sk.optical.AbsorberDatabaseDim2(wavelength_nm=c["tab_wl"], param=c["tab_t"], xs=c["tab_xs"]),
+                                                        c["o3_alt"], c["o3_vmr"], "extend")
+        atmo["thermal"] = sk.constituent.ThermalEmission()
+        atmo.surface.albedo[:] = 0.03
+        atmo["ground"] = sk.constituent.SurfaceThermalEmission(t_surface, eps)
+        return engine.calculate_radiance(atmo, as_dataset=False), atmo
+    base, atmo = radiance(291.0, emissivity, True)
+    want = fo.SurfaceThermalEmission(291.0, emissivity)
+    np.testing.assert_allclose(atmo.surface.emission, want.emission(c["wavelengths"]), rtol=1e-14)
+    again = engine.calculate_radiance(atmo, as_dataset=False)       # a rebuild starts from a surface that emits nothing
+    assert np.array_equal(again["radiance"], base["radiance"])
+    wf_t, wf_e = base["wf_ground_temperature_k"], base["wf_ground_emissivity"]
+    assert wf_t.shape == base["radiance"].shape == wf_e.shape
+    assert np.all(wf_t > 0) and np.all(wf_e > 0)
+    h = 1e-2
+    fd = (radiance(291.0 + h, emissivity)[0]["radiance"] - radiance(291.0 - h, emissivity)[0]["radiance"]) / (2 * h)
+    np.testing.assert_allclose(wf_t, fd, rtol=2e-6, atol=1e-9 * np.max(np.abs(fd)))   # (opaque wavelengths: rounding of the difference)
+    h = 1e-3
+    for j in (0, 3):
+        de = np.zeros(5)
+        de[j] = h
+        fd = (radiance(291.0, emissivity + de)[0]["radiance"] - radiance(291.0, emissivity - de)[0]["radiance"]) / (2 * h)
+        np.testing.assert_allclose(wf_e[j], fd[j], rtol=1e-7, atol=1e-9 * np.max(np.abs(wf_e)))
+        assert np.all(np.delete(fd, j, axis=0) == 0)
+    # the surface mappings are those of the oracle; a scalar emissivity gives the same numbers as the same value on the grid
+    for name, d_em in want.surface_mappings("ground", c["wavelengths"]).items():
+        np.testing.assert_allclose(atmo._surface_mappings[name][3], d_em, rtol=1e-14)
+    flat, _ = radiance(291.0, 0.95, True)
+    grid, _ = radiance(291.0, np.full(5, 0.95), True)
+    for key in ("radiance", "wf_ground_temperature_k", "wf_ground_emissivity"):
+        assert np.array_equal(flat[key], grid[key])
+    with pytest.raises(ValueError):
+        radiance(291.0, np.ones(3))
