@@ -18,6 +18,8 @@ Reference (behaviour restated, nothing copied):
   rust/sasktran2-rs/src/constituent/types/vmr_alt_absorber.rs:14-260, 339-399   VMRAltitudeAbsorber
   rust/sasktran2-rs/src/constituent/types/number_density_scatterer.rs:218-440   NumberDensityScatterer (density derivative)
   src/sasktran2/constituent/numdenscatterer.py:117-197              ExtinctionScatterer
+  src/sasktran2/constituent/gaussianheight.py:108-232               GaussianHeightExtinction
+  src/sasktran2/constituent/emission.py:113-190                     SurfaceThermalEmission
   rust/sasktran2-rs/src/constituent/types/emission.rs:9-116         ThermalEmission
   rust/sasktran2-rs/src/optical/types/xsec_dbase.rs:66-210          cross-section tables: linear in wavenumber (zero outside), linear in the
                                                                     parameter (held outside)
@@ -435,6 +437,51 @@ class ExtinctionScatterer(NumberDensityScatterer):
     def register(self, atmo, name):
         self._update()
         super().register(atmo, name)
+
+
+class GaussianHeightExtinction(NumberDensityScatterer):
+    """src/sasktran2/constituent/gaussianheight.py:108-232: number density = gaussian(height, FWHM) x vertical optical depth /
+    (trapezoid integral of the gaussian x cross section at the reference wavelength) on the constituent's own altitude grid; one
+    scatterer mapping per parameter (height_m, width_fwhm_m, vertical_optical_depth), each with a one-column interpolator."""
+
+    def __init__(self, table, height_m, width_fwhm_m, vertical_optical_depth, vertical_optical_depth_wavel_nm, altitudes_m, out_of_bounds_mode="zero"):
+        super().__init__(table, altitudes_m, np.zeros(len(altitudes_m)), out_of_bounds_mode)
+        self.height_m, self.width_fwhm_m, self.vertical_optical_depth = float(height_m), float(width_fwhm_m), float(vertical_optical_depth)
+        self.reference_wavelength = float(vertical_optical_depth_wavel_nm)
+
+    def _update(self):
+        a = self.alts
+        self.xs_ref = self.table.quantities(np.array([1e7 / self.reference_wavelength]), 1, 1)[0][0]
+        self.gaussian = np.exp(-4.0 * np.log(2.0) * (a - self.height_m) ** 2 / self.width_fwhm_m ** 2)
+        self.gaussian_od = np.trapezoid(self.gaussian, a)
+        self.number_density = self.gaussian * self.vertical_optical_depth / self.gaussian_od / self.xs_ref
+
+    def add(self, atmo):
+        self._update()
+        super().add(atmo)
+
+    def register(self, atmo, name):
+        self._update()
+        a, g = self.alts, self.gaussian
+        m = interp_matrix(self.alts, atmo.altitudes, self.mode)
+        xs, sc, leg = self.table.quantities(atmo.wavenumbers, atmo.nmoments, atmo.nstokes)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            species_ssa = sc / xs
+        species_ssa[~np.isfinite(species_ssa)] = 1.0
+        dg_dh = g * 8.0 * np.log(2.0) * (a - self.height_m) / self.width_fwhm_m ** 2
+        dg_dw = g * 8.0 * np.log(2.0) * (a - self.height_m) ** 2 / self.width_fwhm_m ** 3
+        outer = self.vertical_optical_depth / self.gaussian_od / self.xs_ref
+        columns = {"height_m": outer * (dg_dh - g * np.trapezoid(dg_dh, a) / self.gaussian_od),
+                   "width_fwhm_m": outer * (dg_dw - g * np.trapezoid(dg_dw, a) / self.gaussian_od),
+                   "vertical_optical_depth": g / self.gaussian_od / self.xs_ref}
+        for key, column in columns.items():
+            mp = atmo.mapping(f"wf_{name}_{key}", scatterer=True)
+            mp.d_extinction += xs[np.newaxis, :]
+            mp.scat_factor += (species_ssa * xs)[np.newaxis, :] / (atmo.ssa * atmo.ext)
+            mp.d_ssa += xs[np.newaxis, :] * (species_ssa[np.newaxis, :] - atmo.ssa) / atmo.ext
+            mp.d_legendre += leg.T[:, np.newaxis, :] - atmo.leg
+            mp.interpolator = m @ column[:, np.newaxis]
+            mp.interp_dim = f"{name}_{key}"
 
 
 def planck(temperature_k, wavelength_nm):

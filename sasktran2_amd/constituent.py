@@ -8,7 +8,8 @@ Reference behaviour followed (nothing copied):
   src/sasktran2/constituent/vmraltitudeabsorber.py, rust/.../vmr_alt_absorber.rs:64-260, 339-399
   src/sasktran2/constituent/numdenscatterer.py, rust/.../number_density_scatterer.rs:218-440
   src/sasktran2/constituent/collisioninducedabsorber.py
-  src/sasktran2/constituent/emission.py, rust/.../emission.rs:9-116
+  src/sasktran2/constituent/gaussianheight.py
+  src/sasktran2/constituent/emission.py (ThermalEmission, SurfaceThermalEmission), rust/.../emission.rs:9-116
   src/sasktran2/constituent/brdf/lambertiansurface.py, brdf/__init__.py:11-63
 """
 from __future__ import annotations
@@ -237,6 +238,46 @@ class ExtinctionScatterer(NumberDensityScatterer):
     def add_to_atmosphere(self, atmo):
         self._update_numberdensity()
         super().add_to_atmosphere(atmo)
+
+
+class GaussianHeightExtinction(NumberDensityScatterer):
+    """A scatterer whose extinction profile is a gaussian in altitude (src/sasktran2/constituent/gaussianheight.py): centre `height_m`,
+    full width at half maximum `width_fwhm_m`, and the vertical optical depth at one wavelength.  Weighting functions
+    `wf_<name>_height_m`, `wf_<name>_width_fwhm_m`, `wf_<name>_vertical_optical_depth` (one parameter each)."""
+
+    def __init__(self, optical_property, height_m, width_fwhm_m, vertical_optical_depth, vertical_optical_depth_wavel_nm, altitudes_m,
+                 out_of_bounds_mode="zero", **kwargs):
+        super().__init__(optical_property, altitudes_m, None, out_of_bounds_mode, **kwargs)
+        self.height_m, self.width_fwhm_m, self.vertical_optical_depth = float(height_m), float(width_fwhm_m), float(vertical_optical_depth)
+        self._vertical_optical_depth_wavel_nm = float(vertical_optical_depth_wavel_nm)
+
+    def _update_numberdensity(self):
+        a = self._altitudes_m
+        self._xs_at_wavel = self._optical_property.cross_sections(np.array([self._vertical_optical_depth_wavel_nm]))[0]
+        if not self._xs_at_wavel > 0.0:
+            raise ValueError("the optical property has no cross section at the wavelength of the vertical optical depth")
+        self._gaussian = np.exp(-4.0 * np.log(2.0) * (a - self.height_m) ** 2 / self.width_fwhm_m ** 2)
+        self._gaussian_od = np.trapezoid(self._gaussian, a)
+        self.number_density = self._gaussian * self.vertical_optical_depth / self._gaussian_od / self._xs_at_wavel
+
+    def add_to_atmosphere(self, atmo):
+        self._update_numberdensity()
+        super().add_to_atmosphere(atmo)
+
+    def register_derivative(self, atmo, name):
+        a, g, ln2 = self._altitudes_m, self._gaussian, np.log(2.0)
+        dg_dh = g * 8.0 * ln2 * (a - self.height_m) / self.width_fwhm_m ** 2
+        dg_dw = g * 8.0 * ln2 * (a - self.height_m) ** 2 / self.width_fwhm_m ** 3
+        outer = self.vertical_optical_depth / self._gaussian_od / self._xs_at_wavel
+        # the integral in the denominator moves with the parameter as well (gaussianheight.py:171-199)
+        columns = {"height_m": outer * (dg_dh - g * np.trapezoid(dg_dh, a) / self._gaussian_od),
+                   "width_fwhm_m": outer * (dg_dw - g * np.trapezoid(dg_dw, a) / self._gaussian_od),
+                   "vertical_optical_depth": g / self._gaussian_od / self._xs_at_wavel}
+        m = self._altitude_matrix(atmo)
+        weights = np.array([w for w, _, _ in self._spectral])
+        for key, column in columns.items():
+            atmo.frontend.add_mapping(f"wf_{name}_{key}", self._terms, weights, scatterer=True, interpolator=m @ column[:, np.newaxis],
+                                      interp_dim=f"{name}_{key}")
 
 
 class ThermalEmission(Constituent):

@@ -255,3 +255,25 @@ def test_surface_thermal_emission_oracle():
     np.testing.assert_allclose(maps["wf_ground_emissivity"] * eps, s.emission(wl), rtol=1e-15)
     # a black body at 300 K radiates 9.92 W / (m^2 sr um) at 10 um (Planck's law with the CODATA constants)
     assert fo.SurfaceThermalEmission(300.0, 1.0).emission(np.array([10000.0]))[0] * 1e3 == pytest.approx(9.924, rel=1e-3)
+
+
+@pytest.mark.parametrize("index,key,step", [(0, "height_m", 1.0), (1, "width_fwhm_m", 1.0), (2, "vertical_optical_depth", 1e-6)])
+def test_gaussian_height_mappings_match_storage_difference(index, key, step):
+    """gaussianheight.py:163-232: the three one-parameter mappings of GaussianHeightExtinction equal finite differences of the assembled
+    storage (the criterion of tests/constituent/test_gaussian_height.py of the reference, on the storage instead of the radiance)"""
+    c = sc.frontend_case(nwavel=12)
+    params = [17000.0, 5000.0, 0.08]
+    base = sc.frontend_oracle_atmosphere(c, 8, gaussian=tuple(params)).assemble()
+    assert np.trapezoid(base.constituents["layer"].number_density, base.constituents["layer"].alts) * base.constituents["layer"].xs_ref == pytest.approx(0.08, rel=1e-13)
+    d_ext, d_ssa, d_leg = _storage_derivative(base, f"wf_layer_{key}")
+    results = []
+    for sign in (+1, -1):
+        p = list(params)
+        p[index] += sign * step
+        a = sc.frontend_oracle_atmosphere(c, 8, gaussian=tuple(p)).assemble(derivatives=False)
+        results.append((a.ext.copy(), a.ssa.copy(), a.leg.copy()))
+    for analytic, plus, minus in ((d_ext[0], results[0][0], results[1][0]), (d_ssa[0], results[0][1], results[1][1]), (d_leg[0], results[0][2], results[1][2])):
+        numeric = (plus - minus) / (2 * step)
+        floor = np.max(np.abs(analytic)) * 2e-6 + 8e-16 * np.max(np.abs(plus)) / step + 1e-300
+        np.testing.assert_allclose(numeric, analytic, rtol=2e-6, atol=floor)
+    assert np.any(d_ext[0] != 0.0) and d_ext.shape[0] == 1

@@ -591,3 +591,44 @@ def test_surface_thermal_emission_constituent(source):
         assert np.array_equal(flat[key], grid[key])
     with pytest.raises(ValueError):
         radiance(291.0, np.ones(3))
+
+
+def test_gaussian_height_extinction_constituent():
+    """GaussianHeightExtinction (src/sasktran2/constituent/gaussianheight.py): storage and the three one-parameter mappings equal the
+    oracle's; wf_<name>_height_m / _width_fwhm_m / _vertical_optical_depth equal finite differences of the radiance (the criterion of
+    the reference's tests/constituent/test_gaussian_height.py), limb and nadir, discrete ordinates + exact single scatter"""
+    import sasktran2_amd as sk
+    c = sc.frontend_case(nwavel=6)
+    cfg = _config(sk, streams=8, moments=8)
+    cfg.single_scatter_source = sk.SingleScatterSource.Exact
+    rays = [sk.TangentAltitudeSolar(15000.0, 0.3, 200000.0, 0.6), sk.TangentAltitudeSolar(24000.0, 0.3, 200000.0, 0.6),
+            sk.GroundViewingSolar(0.6, 0.5, 0.8, 200000.0)]
+    engine, geo = _engine_case(sk, c, cfg, rays)
+    params = (17000.0, 5000.0, 0.08)
+
+    def radiance(p, derivs):
+        atmo = sc.frontend_product_atmosphere(sk, c, geo, cfg, calculate_derivatives=derivs, gaussian=p)
+        atmo.surface.albedo[:] = 0.2
+        return engine.calculate_radiance(atmo, as_dataset=False), atmo
+    base, atmo = radiance(params, True)
+    want = sc.frontend_oracle_atmosphere(c, 8, gaussian=params).assemble()
+    st = atmo.storage
+    _close(st.total_extinction, want.ext)
+    _close(st.ssa, want.ssa)
+    _close(st.leg_coeff, want.leg)
+    for index, (key, step) in enumerate((("height_m", 2.0), ("width_fwhm_m", 2.0), ("vertical_optical_depth", 1e-5))):
+        name = f"wf_layer_{key}"
+        m, w = st.get_derivative_mapping(name), want.mappings[name]
+        assert m.interp_dim == w.interp_dim == f"layer_{key}"
+        _close(m.d_extinction, w.d_extinction)
+        _close(m.d_ssa, w.d_ssa)
+        _close(m.scat_factor, w.scat_factor)
+        _close(m.d_leg_coeff, w.d_legendre)
+        np.testing.assert_allclose(m.interpolator, w.interpolator, rtol=1e-13, atol=1e-300)
+        assert base[name].shape == (1, 6, 3, 1)
+        plus, minus = list(params), list(params)
+        plus[index] += step
+        minus[index] -= step
+        fd = (radiance(tuple(plus), False)[0]["radiance"] - radiance(tuple(minus), False)[0]["radiance"]) / (2 * step)
+        assert np.max(np.abs(fd)) > 0
+        np.testing.assert_allclose(base[name][0], fd, rtol=3e-5, atol=3e-6 * np.max(np.abs(fd)), err_msg=key)
