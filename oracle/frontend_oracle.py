@@ -20,6 +20,7 @@ Reference (behaviour restated, nothing copied):
   src/sasktran2/constituent/numdenscatterer.py:117-197              ExtinctionScatterer
   src/sasktran2/constituent/gaussianheight.py:108-232               GaussianHeightExtinction
   src/sasktran2/constituent/emission.py:113-190                     SurfaceThermalEmission
+  src/sasktran2/constituent/amf.py:24-50                            AirMassFactor
   rust/sasktran2-rs/src/constituent/types/emission.rs:9-116         ThermalEmission
   rust/sasktran2-rs/src/optical/types/xsec_dbase.rs:66-210          cross-section tables: linear in wavenumber (zero outside), linear in the
                                                                     parameter (held outside)
@@ -195,6 +196,7 @@ class Mapping:
         self.interpolator = None       # [nloc, nout]
         self.interp_dim = "altitude"
         self.assign_name = ""
+        self.log_radiance_space = False    # the output is divided by the radiance (cpp/lib/output/outputc.cpp:153-162)
 
 
 class Atmosphere:
@@ -484,6 +486,24 @@ class GaussianHeightExtinction(NumberDensityScatterer):
             mp.interp_dim = f"{name}_{key}"
 
 
+class AirMassFactor:
+    """src/sasktran2/constituent/amf.py:24-50: adds nothing to the atmosphere; its mapping `air_mass_factor` is the derivative of the log
+    radiance with respect to absorber extinction in a layer, per unit of layer thickness, with the sign of an air mass factor"""
+
+    def add(self, atmo):
+        pass
+
+    def register(self, atmo, name):
+        f = -1.0 / np.gradient(atmo.altitudes)
+        f[0] *= 2.0       # half layers at the bottom and the top
+        f[-1] *= 2.0
+        m = atmo.mapping("air_mass_factor")
+        m.d_extinction += f[:, np.newaxis]
+        m.d_ssa += f[:, np.newaxis] * (0.0 - atmo.ssa) / atmo.ext
+        m.log_radiance_space = True
+        m.interp_dim = "altitude"
+
+
 def planck(temperature_k, wavelength_nm):
     """emission.rs:9-16: W / (m^2 sr nm)"""
     wl = wavelength_nm * 1e-9
@@ -528,7 +548,7 @@ class SurfaceThermalEmission:
 # ---------------------------------------------------------------------------------------------------------------- output assembly
 def assemble_weighting_functions(atmo, native):
     """engine.py:340-372 / cpp/lib/output/outputc.cpp:38-236: native = {"ext", "ssa" [nloc, nw, nlos], optional "leg" [nleg, nloc, nw, nlos],
-    "emission" [nloc, nw, nlos]} -> {output name: [nout, nw, nlos]}; mappings with the same assign_name add up."""
+    "emission" [nloc, nw, nlos], "radiance" [nw, nlos] for log-radiance mappings} -> {output name: [nout, nw, nlos]}; mappings with the same assign_name add up."""
     out = {}
     for name, m in atmo.mappings.items():
         v = m.d_extinction[:, :, np.newaxis] * native["ext"] + m.d_ssa[:, :, np.newaxis] * native["ssa"]
@@ -538,6 +558,8 @@ def assemble_weighting_functions(atmo, native):
             v = v + m.d_emission[:, :, np.newaxis] * native["emission"]
         if m.interpolator is not None:
             v = np.einsum("qj,qwr->jwr", m.interpolator, v)
+        if m.log_radiance_space:
+            v = v / native["radiance"][np.newaxis]
         key = m.assign_name or name
         out[key] = out[key] + v if key in out else v
     return out

@@ -44,7 +44,7 @@ SIGNATURES = [
     ("sk_deriv_mapping_get_d_extinction", _I, [_vp, ctypes.POINTER(_dp)]),
     ("sk_deriv_mapping_get_scat_factor", _I, [_vp, ctypes.POINTER(_dp)]),
     ("sk_deriv_mapping_get_d_legendre", _I, [_vp, ctypes.POINTER(_dp)]),
-    ("sk_atmosphere_storage_set_zero", _I, [_vp]),
+    ("sk_atmosphere_storage_set_zero", _I, [_vp]), ("sk_deriv_mapping_set_log_radiance_space", _I, [_vp, _I]),
     ("sk_deriv_mapping_get_num_location", _I, [_vp, _ip]), ("sk_deriv_mapping_get_num_wavel", _I, [_vp, _ip]),
     ("sk_deriv_mapping_get_num_output", _I, [_vp, _ip]), ("sk_deriv_mapping_set_zero", _I, [_vp]),
     ("sk_brdf_create_lambertian", _vp, [_I]), ("sk_brdf_destroy", None, [_vp]),

@@ -9,6 +9,7 @@ Reference behaviour followed (nothing copied):
   src/sasktran2/constituent/numdenscatterer.py, rust/.../number_density_scatterer.rs:218-440
   src/sasktran2/constituent/collisioninducedabsorber.py
   src/sasktran2/constituent/gaussianheight.py
+  src/sasktran2/constituent/amf.py
   src/sasktran2/constituent/emission.py (ThermalEmission, SurfaceThermalEmission), rust/.../emission.rs:9-116
   src/sasktran2/constituent/brdf/lambertiansurface.py, brdf/__init__.py:11-63
 """
@@ -278,6 +279,25 @@ class GaussianHeightExtinction(NumberDensityScatterer):
         for key, column in columns.items():
             atmo.frontend.add_mapping(f"wf_{name}_{key}", self._terms, weights, scatterer=True, interpolator=m @ column[:, np.newaxis],
                                       interp_dim=f"{name}_{key}")
+
+
+class AirMassFactor(Constituent):
+    """Adds nothing to the atmosphere; asks for the weighting function `air_mass_factor` [altitude, wavelength, los, stokes]: the derivative
+    of the log radiance with respect to absorber extinction in a layer per unit of layer thickness, sign of an air mass factor
+    (src/sasktran2/constituent/amf.py).  On the device this is the mapping of an absorber term with a unit spectrum and no amount."""
+    _unit_spectrum = None
+
+    def add_to_atmosphere(self, atmo):
+        if self._unit_spectrum is None or len(self._unit_spectrum) != atmo.num_wavel:
+            self._unit_spectrum = np.ones(atmo.num_wavel)
+            self._unit_spectrum.setflags(write=False)
+        self._term = atmo.frontend.add_term(np.zeros(atmo.num_locations), self._unit_spectrum)
+
+    def register_derivative(self, atmo, name):
+        factors = -1.0 / np.gradient(atmo.model_geometry.altitudes())
+        factors[0] *= 2.0     # half layers at the bottom and the top (amf.py:36-40)
+        factors[-1] *= 2.0
+        atmo.frontend.add_mapping("air_mass_factor", [self._term], factors[np.newaxis, :], interp_dim="altitude", log_radiance_space=True)
 
 
 class ThermalEmission(Constituent):

@@ -32,9 +32,9 @@ def _frozen_key(a):
 class DeviceMapping:
     """Read-only view of one derivative mapping held in HBM (`atmosphere.storage.get_derivative_mapping(name)` of the reference)."""
 
-    def __init__(self, fe, name, scatterer, emission, interpolator, interp_dim, assign_name):
+    def __init__(self, fe, name, scatterer, emission, interpolator, interp_dim, assign_name, log_radiance_space=False):
         self._fe, self.name, self.scatterer, self.emission = fe, name, scatterer, emission
-        self.interpolator, self.interp_dim, self.assign_name = interpolator, interp_dim, assign_name
+        self.interpolator, self.interp_dim, self.assign_name, self.log_radiance_space = interpolator, interp_dim, assign_name, log_radiance_space
 
     def _get(self, field, shape):
         return self._fe.download(f"{self.name}:{field}", shape)
@@ -139,8 +139,10 @@ class FrontEnd:
         self.mappings = {}
         self.assembled = True
 
-    def add_mapping(self, name, terms=(), weights=None, scatterer=False, planck=False, interpolator=None, interp_dim="altitude", assign_name=""):
-        """interpolator: [location, nout] (rows = model grid), as the reference's mappings hold it"""
+    def add_mapping(self, name, terms=(), weights=None, scatterer=False, planck=False, interpolator=None, interp_dim="altitude", assign_name="",
+                    log_radiance_space=False):
+        """interpolator: [location, nout] (rows = model grid), as the reference's mappings hold it; log_radiance_space: the engine divides
+        this weighting function by the radiance (`DerivativeMapping.log_radiance_space` of the reference)"""
         terms = np.ascontiguousarray(terms, dtype=np.int32)
         w = None
         if weights is not None:
@@ -157,8 +159,12 @@ class FrontEnd:
         self._check(lib().sk_amd_frontend_add_mapping(self._h, name.encode(), len(terms), terms.ctypes.data_as(ctypes.c_void_p), _vp(w), int(scatterer),
                                                       int(planck), _vp(interp), nout, interp_dim.encode(), assign_name.encode()),
                     "sk_amd_frontend_add_mapping")
+        if log_radiance_space:
+            m = ctypes.c_void_p()
+            self._check(lib().sk_atmosphere_storage_get_derivative_mapping(self.storage_handle(), name.encode(), ctypes.byref(m)), "sk_atmosphere_storage_get_derivative_mapping")
+            self._check(lib().sk_deriv_mapping_set_log_radiance_space(m, 1), "sk_deriv_mapping_set_log_radiance_space")
         self.mappings[name] = DeviceMapping(self, name, bool(scatterer), bool(planck), None if interpolator is None else interpolator.copy(),
-                                            interp_dim, assign_name)
+                                            interp_dim, assign_name, bool(log_radiance_space))
 
     def finalize(self):
         """form the arrays of every mapping added so far (two launches for all of them)"""

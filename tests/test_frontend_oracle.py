@@ -277,3 +277,24 @@ def test_gaussian_height_mappings_match_storage_difference(index, key, step):
         floor = np.max(np.abs(analytic)) * 2e-6 + 8e-16 * np.max(np.abs(plus)) / step + 1e-300
         np.testing.assert_allclose(numeric, analytic, rtol=2e-6, atol=floor)
     assert np.any(d_ext[0] != 0.0) and d_ext.shape[0] == 1
+
+
+def test_air_mass_factor_mapping_is_an_absorber_perturbation():
+    """amf.py:24-50: the `air_mass_factor` mapping is (-1 / layer thickness) x the storage derivative of adding absorber extinction to a
+    level -- extinction + 1, scattering extinction unchanged -- and is flagged for the log radiance"""
+    from oracle import frontend_oracle as fo
+    c = sc.frontend_case(nwavel=7)
+    a = sc.frontend_oracle_atmosphere(c, 8)
+    a.constituents["amf"] = fo.AirMassFactor()
+    a = a.assemble()
+    m = a.mappings["air_mass_factor"]
+    assert m.log_radiance_space and m.interp_dim == "altitude" and m.interpolator is None and m.scat_factor is None
+    dz = np.gradient(c["altitudes"])
+    dz[0] /= 2.0
+    dz[-1] /= 2.0
+    h = 1e-7 * a.ext
+    ssa_plus = a.ssa * a.ext / (a.ext + h)            # the same scattering extinction in a larger total
+    np.testing.assert_allclose(m.d_extinction * -dz[:, None], 1.0, rtol=1e-14)
+    np.testing.assert_allclose(m.d_ssa * -dz[:, None], (ssa_plus - a.ssa) / h, rtol=1e-6, atol=1e-300)   # (forward difference, step 1e-7 of the extinction)
+    native = {"ext": np.ones((len(dz), 7, 2)), "ssa": np.zeros((len(dz), 7, 2)), "radiance": np.full((7, 2), 4.0)}
+    np.testing.assert_allclose(fo.assemble_weighting_functions(a, native)["air_mass_factor"], np.broadcast_to((-1.0 / dz / 4.0)[:, None, None], (len(dz), 7, 2)), rtol=1e-14)

@@ -632,3 +632,62 @@ def test_gaussian_height_extinction_constituent():
         fd = (radiance(tuple(plus), False)[0]["radiance"] - radiance(tuple(minus), False)[0]["radiance"]) / (2 * step)
         assert np.max(np.abs(fd)) > 0
         np.testing.assert_allclose(base[name][0], fd, rtol=3e-5, atol=3e-6 * np.max(np.abs(fd)), err_msg=key)
+
+
+def test_air_mass_factor_constituent():
+    """AirMassFactor (src/sasktran2/constituent/amf.py; the reference's tests/weightingfunctions/test_amf.py only runs it): the mapping
+    arrays equal the oracle's, the output equals the oracle's assembly of the raw-interface weighting functions divided by the radiance, and
+    it equals -(1 / layer thickness) d ln I / d(absorber extinction of a level) by finite differences of a grey probe absorber."""
+    import sasktran2_amd as sk
+    from oracle import frontend_oracle as fo
+    c = sc.frontend_case(nwavel=5)
+    cfg = _config(sk, streams=4, moments=8)
+    rays = [sk.GroundViewingSolar(0.6, 0.0, 0.8, 200000.0), sk.TangentAltitudeSolar(14000.0, 0.2, 200000.0, 0.6)]
+    engine, geo = _engine_case(sk, c, cfg, rays)
+    ngrid = len(c["altitudes"])
+    sigma = 1e-24
+
+    def radiance(probe, derivs):
+        atmo = sc.frontend_product_atmosphere(sk, c, geo, cfg, calculate_derivatives=derivs, pressure_derivative=False, temperature_derivative=False)
+        atmo.surface.albedo[:] = 0.3
+        atmo["amf"] = sk.constituent.AirMassFactor()
+        if probe is not None:   # grey absorber on the model grid: extinction `probe` [1/m] per level
+            grey = sk.optical.AbsorberDatabaseDim1(wavelength_nm=np.array([200.0, 2000.0]), xs=np.array([sigma, sigma]))
+            air = atmo.state_equation.dry_air_numberdensity["N"]
+            atmo["probe"] = sk.constituent.VMRAltitudeAbsorber(grey, c["altitudes"], probe / (sigma * air), "zero")
+        return engine.calculate_radiance(atmo, as_dataset=False), atmo
+    base, atmo = radiance(None, True)
+    oracle = sc.frontend_oracle_atmosphere(c, 8, pressure_derivative=False, temperature_derivative=False)
+    oracle.constituents["amf"] = fo.AirMassFactor()
+    want = oracle.assemble()
+    m, w = atmo.storage.get_derivative_mapping("air_mass_factor"), want.mappings["air_mass_factor"]
+    assert m.log_radiance_space and m.interp_dim == "altitude"
+    _close(m.d_extinction, w.d_extinction)
+    _close(m.d_ssa, w.d_ssa)
+    _close(atmo.storage.total_extinction, want.ext)      # the constituent itself adds nothing
+    amf = base["air_mass_factor"]
+    assert amf.shape == (ngrid, 5, 2, 1)
+    # raw interface with the oracle's arrays -> native weighting functions -> the oracle's output assembly
+    raw = sk.Atmosphere(geo, cfg, numwavel=5)
+    raw.storage.total_extinction[:], raw.storage.ssa[:] = want.ext, want.ssa
+    raw.leg_coeff.a1[:] = want.leg
+    raw.surface.albedo[:] = 0.3
+    ref = engine.calculate_radiance(raw, as_dataset=False)
+    only = fo.Atmosphere(c["altitudes"], c["wavelengths"], 8)
+    only.mappings = {"air_mass_factor": w}
+    expect = fo.assemble_weighting_functions(only, {"ext": ref["wf_extinction"][..., 0], "ssa": ref["wf_ssa"][..., 0], "radiance": ref["radiance"][..., 0]})
+    # (the two runs take different kernels -- scattering groups send the constituent run to the run-time-n ones -- and the extinction and
+    # albedo terms of this mapping cancel where the air is thin: their rounding difference, 1e-12 of each term, is what is left)
+    np.testing.assert_allclose(amf[..., 0], expect["air_mass_factor"], rtol=5e-6, atol=1e-8 * np.max(np.abs(amf)))
+    # a nadir box air mass factor is positive and of the order of the geometric one, 1 / mu_sun + 1 / mu_view, where the air is thin
+    assert 1.5 < amf[ngrid - 3, -1, 0, 0] < 1.0 / 0.6 + 1.0 / 0.8 + 1.5
+    dz = np.gradient(c["altitudes"])
+    dz[0] /= 2.0
+    dz[-1] /= 2.0
+    for q in (0, 7, 19):
+        h = 0.02 * ((1.0 - want.ssa[q]) * want.ext[q]).min()      # (the minus side must leave an absorbing atmosphere at every wavelength)
+        probe = np.zeros(ngrid)
+        probe[q] = h
+        plus, minus = radiance(probe, False)[0]["radiance"], radiance(-probe, False)[0]["radiance"]
+        fd = -(plus - minus) / (2 * h) / base["radiance"] / dz[q]
+        np.testing.assert_allclose(amf[q], fd, rtol=2e-5, atol=2e-6 * np.max(np.abs(fd)), err_msg=f"level {q}")
