@@ -11,6 +11,7 @@ nleg d_legendre rows) + the totals the mapping stage reads once (extinction, ssa
 dominant kernel with ITS bytes per launch over its HIP-event time."""
 from __future__ import annotations
 
+import gc
 import json
 import os
 import time
@@ -80,6 +81,9 @@ def run_frontend(args, world, rank, dev):
 
     for _ in range(args.warmup):
         step()
+    # a step is under a millisecond; a generation-2 pass of Python's cyclic collector over torch's module objects is 26-42 ms and would
+    # otherwise fall on one of the first timed steps (tools/probes/frontend_steps.py): collect now, as timeit does before a measurement
+    gc.collect()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
