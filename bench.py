@@ -13,6 +13,7 @@ array inside the timed region -> "scaling": "strong".
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -151,6 +152,7 @@ def main():
     solver.set_profiling(2)
     for _ in range(args.warmup):
         step()
+    gc.collect()   # (no generation-2 pass of Python's collector inside the timed region: 26-42 ms with torch loaded, bench_frontend.py)
     sync()
     solver.reset_profile()
     t0 = time.perf_counter()

@@ -8,6 +8,7 @@ wavelength and launch are counted from the engine's own sizes (below); the scatt
 exact operation count 2 x rows x cols x moments per diffuse point."""
 from __future__ import annotations
 
+import gc
 import json
 import os
 import time
@@ -71,6 +72,7 @@ def run_c5(args, world, rank, dev):
 
     for _ in range(args.warmup):
         step()
+    gc.collect()   # (no generation-2 pass of Python's collector inside the timed region: 26-42 ms with torch loaded, bench_frontend.py)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):

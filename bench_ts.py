@@ -9,6 +9,7 @@ moment: 3 x 21 x 8 B, albedo, irradiance) and write the radiance and the weighti
 prices the dominant kernel with those bytes; `traffic` is its measured HBM traffic from the committed rocprofv3 PMC summary."""
 from __future__ import annotations
 
+import gc
 import json
 import os
 import time
@@ -87,6 +88,7 @@ def run_twostream(args, world, rank, dev):
 
     for _ in range(args.warmup):
         step()
+    gc.collect()   # (no generation-2 pass of Python's collector inside the timed region: 26-42 ms with torch loaded, bench_frontend.py)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
