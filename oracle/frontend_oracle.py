@@ -21,6 +21,7 @@ Reference (behaviour restated, nothing copied):
   src/sasktran2/constituent/gaussianheight.py:108-232               GaussianHeightExtinction
   src/sasktran2/constituent/emission.py:113-190                     SurfaceThermalEmission
   src/sasktran2/constituent/amf.py:24-50                            AirMassFactor
+  rust/sasktran2-rs/src/constituent/types/manual.rs:25-111          Manual
   rust/sasktran2-rs/src/constituent/types/emission.rs:9-116         ThermalEmission
   rust/sasktran2-rs/src/optical/types/xsec_dbase.rs:66-210          cross-section tables: linear in wavenumber (zero outside), linear in the
                                                                     parameter (held outside)
@@ -484,6 +485,24 @@ class GaussianHeightExtinction(NumberDensityScatterer):
             mp.d_legendre += leg.T[:, np.newaxis, :] - atmo.leg
             mp.interpolator = m @ column[:, np.newaxis]
             mp.interp_dim = f"{name}_{key}"
+
+
+class Manual:
+    """rust/sasktran2-rs/src/constituent/types/manual.rs:25-111: extinction and single scatter albedo [location, wavelength] (and phase
+    moments [moment, location, wavelength]) given on the model grid, added like any other constituent; no derivatives"""
+
+    def __init__(self, extinction, ssa, legendre_moments=None):
+        self.extinction, self.ssa = np.asarray(extinction, float), np.asarray(ssa, float)
+        self.legendre = None if legendre_moments is None else np.asarray(legendre_moments, float)
+
+    def add(self, atmo):
+        atmo.ext += self.extinction
+        atmo.ssa += self.extinction * self.ssa
+        if self.legendre is not None:
+            atmo.leg += (self.extinction * self.ssa)[np.newaxis] * self.legendre
+
+    def register(self, atmo, name):
+        pass
 
 
 class AirMassFactor:

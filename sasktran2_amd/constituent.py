@@ -10,6 +10,7 @@ Reference behaviour followed (nothing copied):
   src/sasktran2/constituent/collisioninducedabsorber.py
   src/sasktran2/constituent/gaussianheight.py
   src/sasktran2/constituent/amf.py
+  src/sasktran2/constituent/manual.py, rust/.../manual.rs:25-111
   src/sasktran2/constituent/emission.py (ThermalEmission, SurfaceThermalEmission), rust/.../emission.rs:9-116
   src/sasktran2/constituent/brdf/lambertiansurface.py, brdf/__init__.py:11-63
 """
@@ -279,6 +280,63 @@ class GaussianHeightExtinction(NumberDensityScatterer):
         for key, column in columns.items():
             atmo.frontend.add_mapping(f"wf_{name}_{key}", self._terms, weights, scatterer=True, interpolator=m @ column[:, np.newaxis],
                                       interp_dim=f"{name}_{key}")
+
+
+class Manual(Constituent):
+    """Extinction [1/m] and single scatter albedo given directly on the model grid, `[altitude, wavelength]`, optionally with phase moments
+    `[moment, altitude, wavelength]` (first dimension of leg_coeff); mixes with the other constituents; no weighting functions of its own
+    (src/sasktran2/constituent/manual.py, rust/.../manual.rs).  On the device: one term per level, its profile that level alone.  The
+    arrays are copied at construction (and stay in HBM from one assembly to the next)."""
+
+    def __init__(self, extinction, ssa, legendre_moments=None, delta_scale=False):
+        extinction, ssa = np.array(extinction, dtype=float), np.array(ssa, dtype=float)
+        if extinction.shape != ssa.shape:
+            raise ValueError("extinction and ssa must have the same shape")
+        if extinction.ndim == 3:
+            raise NotImplementedError("(horizontal, altitude, wavelength) Manual constituents belong to the 2-D geometry, which is not part of this build")
+        if extinction.ndim != 2:
+            raise ValueError("extinction and ssa must have shape (altitude, wavelength)")
+        leg = None
+        if legendre_moments is not None:
+            leg = np.array(legendre_moments, dtype=float)
+            if leg.ndim != 3 or leg.shape[1:] != extinction.shape:
+                raise ValueError(f"legendre_moments must have shape (moment, *extinction.shape); got {leg.shape} for extinction shape {extinction.shape}")
+        if delta_scale:
+            if leg is None:
+                raise ValueError("legendre_moments must be provided when delta_scale is enabled")
+            # manual.py:87-100 (four Greek coefficients per order): truncation fraction from the last stored a1
+            norder = leg.shape[0] // 4
+            f = leg[::4][-1] / (2.0 * norder + 1)
+            extinction *= 1.0 - ssa * f
+            ssa *= (1.0 - f) / (1.0 - ssa * f)
+            for i in range(norder):
+                for c in range(3):
+                    leg[4 * i + c] = (leg[4 * i + c] - f * (2.0 * i + 1)) / (1.0 - f)
+                leg[4 * i + 3] /= 1.0 - f
+        self._extinction, self._ssa = extinction, ssa
+        self._scat = extinction * ssa
+        self._leg = None if leg is None else np.ascontiguousarray(leg.transpose(1, 2, 0))    # [altitude, wavelength, moment]
+        for a in (self._extinction, self._ssa, self._scat, self._leg):
+            if a is not None:
+                a.setflags(write=False)
+
+    extinction = property(lambda self: self._extinction)
+    ssa = property(lambda self: self._ssa)
+    leg_coeff = property(lambda self: None if self._leg is None else self._leg.transpose(2, 0, 1))
+
+    def add_to_atmosphere(self, atmo):
+        if self._extinction.shape[1] != atmo.num_wavel:
+            raise ValueError(f"Manual constituent wavelength dimension does not match the atmosphere: {self._extinction.shape[1]} != {atmo.num_wavel}")
+        if self._extinction.shape[0] != atmo.num_locations:
+            raise ValueError(f"Altitude-profile Manual constituent does not match the atmosphere: {self._extinction.shape[0]} altitudes != {atmo.num_locations}")
+        if self._leg is not None and self._leg.shape[2] != atmo.num_leg:
+            raise ValueError(f"Manual constituent Legendre moment dimension does not match the atmosphere: {self._leg.shape[2]} != {atmo.num_leg}")
+        level = np.eye(atmo.num_locations)
+        for j in range(atmo.num_locations):
+            atmo.frontend.add_term(level[j], self._extinction[j], self._scat[j], None if self._leg is None else self._leg[j])
+
+    def register_derivative(self, atmo, name):
+        pass
 
 
 class AirMassFactor(Constituent):

@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(256) k_fe_assemble(const Term* __restrict__ te
         for (int r = 0; r < nterms; ++r) {
             const Term t = terms[r];
             const double p = t.prof[q];
+            if (p == 0.0) continue;   // a table node this level does not touch, a level a one-level term does not cover
             k += t.ext[w] * p;
             if (t.scat) s += t.scat[w] * p;
         }
@@ -54,7 +55,9 @@ __global__ void __launch_bounds__(256) k_fe_legendre(const Term* __restrict__ te
         for (int r = 0; r < nterms; ++r) {
             const Term t = terms[r];
             if (!t.scat) continue;
-            const double v = t.scat[w] * t.prof[q];
+            const double p = t.prof[q];
+            if (p == 0.0) continue;
+            const double v = t.scat[w] * p;
             s += v;
             if (t.leg) P += v * t.leg[size_t(w) * nleg + l];
         }

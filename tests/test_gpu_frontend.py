@@ -691,3 +691,72 @@ def test_air_mass_factor_constituent():
         plus, minus = radiance(probe, False)[0]["radiance"], radiance(-probe, False)[0]["radiance"]
         fd = -(plus - minus) / (2 * h) / base["radiance"] / dz[q]
         np.testing.assert_allclose(amf[q], fd, rtol=2e-5, atol=2e-6 * np.max(np.abs(fd)), err_msg=f"level {q}")
+
+
+@pytest.mark.parametrize("nstokes", [1, 3])
+def test_manual_constituent(nstokes):
+    """Manual (src/sasktran2/constituent/manual.py, rust/.../manual.rs:25-111): extinction / single scatter albedo / phase moments given on
+    the model grid add to the other constituents exactly as the oracle adds them; the other constituents' mappings see the totals; the
+    arrays stay in HBM from one assembly to the next; delta_scale follows the reference's formula; shape errors are the reference's."""
+    import sasktran2_amd as sk
+    from oracle import frontend_oracle as fo
+    c = sc.frontend_case(nwavel=9)
+    cfg = _config(sk, nstokes=nstokes, moments=8)
+    geo = _geometry(sk, c)
+    rng = np.random.default_rng(11)
+    ngrid, nleg = len(c["altitudes"]), 8 * (4 if nstokes == 3 else 1)
+    ext = 2e-5 * np.exp(-((c["altitudes"][:, None] - 9000.0) / 2500.0) ** 2) * (1.0 + 0.2 * rng.random((ngrid, 9)))
+    ssa = 0.6 + 0.39 * rng.random((ngrid, 9))
+    leg = rng.random((nleg, ngrid, 9))
+    leg[0] = 1.0
+    atmo = sc.frontend_product_atmosphere(sk, c, geo, cfg)
+    atmo["cloud_layer"] = sk.constituent.Manual(ext, ssa, leg)
+    fe = atmo.internal_object()
+    oracle = sc.frontend_oracle_atmosphere(c, 8, nstokes)
+    oracle.constituents["cloud_layer"] = fo.Manual(ext, ssa, leg)
+    want = oracle.assemble()
+    st = atmo.storage
+    _close(st.total_extinction, want.ext)
+    _close(st.ssa, want.ssa)
+    _close(st.leg_coeff, want.leg)
+    assert set(st.derivative_mapping_names()) == set(want.mappings)      # none of its own
+    for name, w in want.mappings.items():       # (2e-12: next to a layer a thousand times denser than the gas the differences species - total cancel further)
+        m = st.get_derivative_mapping(name)
+        _close(m.d_extinction, w.d_extinction, 2e-12)
+        _close(m.d_ssa, w.d_ssa, 2e-12)
+        if w.d_legendre is not None:
+            _close(m.d_leg_coeff, w.d_legendre, 2e-12)
+            _close(m.scat_factor, w.scat_factor, 2e-12)
+    nterms = fe._nterms
+    fe = atmo.internal_object()
+    assert fe.spectra_reused == nterms and nterms >= ngrid
+    _close(atmo.storage.leg_coeff, want.leg)
+    # without phase moments the layer scatters with no phase function of its own: it adds to extinction and scattering extinction only
+    plain = sc.frontend_product_atmosphere(sk, c, geo, cfg)
+    plain["cloud_layer"] = sk.constituent.Manual(ext, np.zeros_like(ext))
+    plain.internal_object()
+    oracle = sc.frontend_oracle_atmosphere(c, 8, nstokes)
+    oracle.constituents["cloud_layer"] = fo.Manual(ext, np.zeros_like(ext))
+    want0 = oracle.assemble()
+    _close(plain.storage.total_extinction, want0.ext)
+    _close(plain.storage.ssa, want0.ssa)
+    _close(plain.storage.leg_coeff, want0.leg)
+    # delta_scale (manual.py:87-100; four coefficients per order)
+    if nstokes == 3:
+        scaled = sk.constituent.Manual(ext, ssa, leg, delta_scale=True)
+        f = leg[::4][-1] / (2.0 * 8 + 1)
+        np.testing.assert_allclose(scaled.extinction, ext * (1.0 - ssa * f), rtol=1e-15)
+        np.testing.assert_allclose(scaled.ssa, ssa * (1.0 - f) / (1.0 - ssa * f), rtol=1e-15)
+        np.testing.assert_allclose(scaled.leg_coeff[4 * 3 + 1], (leg[4 * 3 + 1] - 7.0 * f) / (1.0 - f), rtol=1e-14)
+        np.testing.assert_allclose(scaled.leg_coeff[4 * 3 + 3], leg[4 * 3 + 3] / (1.0 - f), rtol=1e-14)
+        assert ext[3, 2] != scaled.extinction[3, 2]       # the caller's arrays are left alone
+    with pytest.raises(ValueError, match="same shape"):
+        sk.constituent.Manual(ext, ssa[:, :4])
+    with pytest.raises(ValueError, match="legendre_moments must have shape"):
+        sk.constituent.Manual(ext, ssa, leg[:, :3])
+    with pytest.raises(ValueError, match="delta_scale"):
+        sk.constituent.Manual(ext, ssa, delta_scale=True)
+    bad = sc.frontend_product_atmosphere(sk, c, geo, cfg)
+    bad["cloud_layer"] = sk.constituent.Manual(ext[:, :5], ssa[:, :5])
+    with pytest.raises(ValueError, match="wavelength dimension"):
+        bad.internal_object()
