@@ -147,9 +147,10 @@ __global__ void __launch_bounds__(256) k_fe_map_all(const Term* __restrict__ ter
                 if (t.scat) s += t.scat[w] * c;
             }
             const double species_ssa = e != 0.0 ? s / e : 1.0;
-            d.d_ext[i] = e;
-            d.d_ssa[i] = k == 0.0 ? 0.0 : e * (species_ssa - om) / k;
-            if (d.scat_factor) d.scat_factor[i] = om * k != 0.0 ? s / (om * k) : 0.0;
+            // (written once, read by the engine's mapping kernel much later: streamed past the caches)
+            __builtin_nontemporal_store(e, &d.d_ext[i]);
+            __builtin_nontemporal_store(k == 0.0 ? 0.0 : e * (species_ssa - om) / k, &d.d_ssa[i]);
+            if (d.scat_factor) __builtin_nontemporal_store(om * k != 0.0 ? s / (om * k) : 0.0, &d.scat_factor[i]);
         }
     }
 }
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(256) k_fe_map_legendre_all(const Term* __restr
                 s += v;
                 if (t.leg) P += v * t.leg[size_t(w) * nleg + l];
             }
-            d.d_leg[i] = (s != 0.0 ? P / s : 0.0) - beta;
+            __builtin_nontemporal_store((s != 0.0 ? P / s : 0.0) - beta, &d.d_leg[i]);   // written once, read by another kernel much later
         }
     }
 }
