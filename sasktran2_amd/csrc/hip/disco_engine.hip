@@ -451,6 +451,16 @@ static void launch_k1(hipStream_t st, const Geo& g, const Bufs& b, int s, int m)
     int lpb = (g.nlyr + split - 1) / split;
     lpb = (lpb + ng - 1) / ng * ng;
     const int ny = (g.nlyr + lpb - 1) / lpb;
+    if constexpr (N == 4 || N == 8) {
+        // 8 and 16 streams: the eigenproblems of all (layer, wavelength) pairs one per LANE in registers (kern_kj_lane), the
+        // cooperative kernel continues from the eigen-solution
+        static const bool lane_jacobi = [] { const char* e = std::getenv("SASKTRAN2_AMD_KJ"); return e ? atoi(e) != 0 : true; }();
+        if (lane_jacobi) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_kj_lane<N>), dim3(unsigned((b.nw + 63) / 64), unsigned(g.nlyr)), dim3(64), 0, st, g, b, m);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_wave<N, LG, true>), dim3(unsigned(b.nw), unsigned(ny)), dim3(64), 0, st, g, b, s, m, lpb);
+            return;
+        }
+    }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_wave<N, LG>), dim3(unsigned(b.nw), unsigned(ny)), dim3(64), 0, st, g, b, s, m, lpb);
 }
 
@@ -593,9 +603,14 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
             }
             {
                 Timer t(I, st, "k2a_bvp");
-                if constexpr (N == 8)
-                    hipLaunchKernelGGL(kern_k2a_mfma8, dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
-                else
+                if constexpr (N == 8) {
+                    // column-per-lane BVP, four wavelengths per wavefront (kern_k2a_cols8); SASKTRAN2_AMD_K2A=mfma keeps the matrix-core form
+                    static const bool cols = [] { const char* e = std::getenv("SASKTRAN2_AMD_K2A"); return !(e && std::string(e) == "mfma"); }();
+                    if (cols)
+                        hipLaunchKernelGGL(kern_k2a_cols8, dim3(unsigned((nw + 3) / 4)), dim3(64), 0, st, g, b, s, m);
+                    else
+                        hipLaunchKernelGGL(kern_k2a_mfma8, dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
+                } else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
             }
             {

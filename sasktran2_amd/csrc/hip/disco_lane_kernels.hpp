@@ -1,0 +1,480 @@
+// Lane-per-problem HIP kernels (gfx950): one LANE owns one small dense problem and keeps it entirely in registers, every
+// index a compile-time constant (fully unrolled), so the instruction stream is almost only FP64 fused multiply-adds with no
+// cross-lane traffic, no LDS round trips and no barriers.  64 problems per wavefront instead of 4: the cooperative form of
+// kern_k1_wave spends 57 % of its time in the Jacobi rounds (two barriers and an LDS exchange per round for 16 lanes).
+//
+// HIP only (included by disco_wave_kernels.hpp).  Same mathematics as skd::k1_layer_solution (disco_core.hpp), which stays the
+// CPU-emulated specification; parity is asserted on the GPU against the oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "disco_core.hpp"
+
+#ifndef SKD_WPE_KJ
+#define SKD_WPE_KJ 1
+#endif
+#ifndef SKD_KJ_MAXSWEEP
+#define SKD_KJ_MAXSWEEP 60
+#endif
+#ifndef SKD_KJ_TOL
+#define SKD_KJ_TOL 1e-30
+#endif
+
+namespace skdev {
+
+using skd::Bufs;
+using skd::Geo;
+
+// 1 / sqrt(x) and 1 / x in full double precision: hardware estimate + two Newton steps
+__device__ __forceinline__ double kj_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    return y;
+}
+__device__ __forceinline__ double kj_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// KJ: homogeneous eigenproblem of every layer (reference: sktran_do_rte.cpp:382-553, the eigen-decomposition of S- S+).
+//   grid = (ceil(nw / 64), nlyr), block = 64: lane = wavelength (coalesced reads of the [layer][l][w] layer optics), blockIdx.y = layer.
+//   B+- = delta / mu - sqrt(w_i w_j / mu_i mu_j) omega sum_l a_l P_l^m(mu_i) P_l^m(mu_j)   (l - m even: B+, odd: B-), symmetric
+//   B+ = R R^T (Cholesky), A = R^T B- R, A V = V diag(k^2) by cyclic Jacobi, X = T^-1 R^-T V   (the formulation of kern_k1_wave)
+//   Output into the layer record for kern_k1_wave<.., PRE = true>: k_j^2 at [R::K + j], X(i, j) at [R::DWP + i * N + j]
+//   (both fields are rewritten by K1 itself with their final contents), transposed through LDS so that a record's 72 doubles
+//   leave as contiguous runs.
+// A lane whose problem has converged is frozen (identity rotations), so a problem's result does not depend on the other
+// problems of its wavefront.
+// -------------------------------------------------------------------------------------------------------------------
+template <int N> __global__ void __launch_bounds__(64, SKD_WPE_KJ) kern_kj_lane(Geo g, Bufs b, int m) {
+    constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, HALF = NOUT / 2, STRIDE = HALF + 1;
+    static_assert(NOUT % 2 == 0, "two output halves");
+    using R = skd::Rec<N>;
+    const int lane = threadIdx.x, p = blockIdx.y, nw = b.nw, nlyr = g.nlyr;
+    const int w0 = blockIdx.x * 64, w = w0 + lane;
+    __shared__ double sPP[NPAIR * NSTR];   // sqrt(w_i w_j / mu_i mu_j) P_{m+k}(mu_i) P_{m+k}(mu_j), pair (i >= j), k = l - m (0 past the last order)
+    __shared__ double sIm[N], sIt[N];
+    __shared__ double sOut[64 * STRIDE];
+    __shared__ int sLive[64];
+    const bool live = (w < nw) && (m < b.norders[w]);
+    if (!__any(live)) return;
+    {
+        const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
+        for (int e = lane; e < NPAIR * NSTR; e += 64) {
+            const int pr = e / NSTR, k = e % NSTR, l = m + k;
+            int i = 0;
+            while ((i + 1) * (i + 2) / 2 <= pr) ++i;
+            const int j = pr - i * (i + 1) / 2;
+            sPP[e] = (l < NSTR) ? sqrt(g.wt[i] / g.mu[i]) * sqrt(g.wt[j] / g.mu[j]) * lpmu[i * NSTR + l] * lpmu[j * NSTR + l] : 0.0;
+        }
+        if (lane < N) {
+            sIm[lane] = 1.0 / g.mu[lane];
+            sIt[lane] = 1.0 / sqrt(g.wt[lane] * g.mu[lane]);
+        }
+        sLive[lane] = live ? 1 : 0;
+    }
+    // Legendre coefficients from order m on (a'[k] = a_{m+k}); a lane without a problem solves the identity-like a = 0 case
+    double a[NSTR];
+#pragma unroll
+    for (int k = 0; k < NSTR; ++k) a[k] = (live && m + k < NSTR) ? b.a[(size_t(p) * NSTR + m + k) * nw + w] : 0.0;
+    const double om = live ? b.om[size_t(p) * nw + w] : 0.0;
+    __syncthreads();
+
+    int err = 0;
+    // ---- B+ (lower triangle, becomes the Cholesky factor) and B- (lower triangle)
+    double Rc[N][N], Bm[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const double* pp = &sPP[(i * (i + 1) / 2 + j) * NSTR];
+            double ep = 0, em = 0;
+#pragma unroll
+            for (int k = 0; k < NSTR; k += 2) {
+                ep = fma(a[k], pp[k], ep);
+                em = fma(a[k + 1], pp[k + 1], em);
+            }
+            const double dlt = (i == j) ? sIm[i] : 0.0;
+            Rc[i][j] = fma(-om, ep, dlt);
+            Bm[i][j] = fma(-om, em, dlt);
+        }
+    // ---- Cholesky B+ = R R^T (lower, in place), reciprocal diagonal kept
+    double rinv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double tj = Rc[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) tj = fma(-Rc[j][k], Rc[j][k], tj);
+        if (!(tj > 0)) { err |= skd::ERR_CHOLESKY; tj = 1.0; }
+        const double rd = kj_rsqrt(tj);
+        rinv[j] = rd;
+        Rc[j][j] = tj * rd;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            double t = Rc[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t = fma(-Rc[i][k], Rc[j][k], t);
+            Rc[i][j] = t * rd;
+        }
+    }
+    // ---- A = R^T B- R (upper triangle A[i][j], i <= j), column by column: m3 = B- R[:, j], A[i][j] = sum_{r >= i} R[r][i] m3[r]
+    double A[N][N], V[N][N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double m3[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double t = 0;
+#pragma unroll
+            for (int r = j; r < N; ++r) t = fma((i >= r) ? Bm[i][r] : Bm[r][i], Rc[r][j], t);
+            m3[i] = t;
+        }
+#pragma unroll
+        for (int i = 0; i <= j; ++i) {
+            double t = 0;
+#pragma unroll
+            for (int r = i; r < N; ++r) t = fma(Rc[r][i], m3[r], t);
+            A[i][j] = t;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    // ---- cyclic Jacobi, A <- J^T A J, V <- V J, rotation (p, q): new_p = c x_p - s x_q, new_q = s x_p + c x_q
+    bool done = !live;
+    for (int sweep = 0; sweep < SKD_KJ_MAXSWEEP; ++sweep) {
+        double off = 0, dia = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            dia = fma(A[i][i], A[i][i], dia);
+#pragma unroll
+            for (int j = i + 1; j < N; ++j) off = fma(A[i][j], A[i][j], off);
+        }
+        done = done || (off <= SKD_KJ_TOL * dia) || (off == 0);
+        if (__all(done)) break;
+#pragma unroll
+        for (int pi = 0; pi < N - 1; ++pi)
+#pragma unroll
+            for (int qi = pi + 1; qi < N; ++qi) {
+                const double apq = A[pi][qi], app = A[pi][pi], aqq = A[qi][qi];
+                // t = sgn(d) h / (|d| + sqrt(d^2 + h^2)),  d = aqq - app, h = 2 apq;  c = 1 / sqrt(1 + t^2),  s = t c
+                const double d = aqq - app, h = 2.0 * apq, x = fma(d, d, h * h);
+                const bool rot = !done && (apq != 0.0) && (x > 0.0);
+                const double xs = rot ? x : 1.0;
+                const double den = fabs(d) + xs * kj_rsqrt(xs);
+                double tt = ((d >= 0) ? h : -h) * kj_rcp(den);
+                tt = rot ? tt : 0.0;
+                const double c = kj_rsqrt(fma(tt, tt, 1.0)), sn = tt * c;
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    if (r == pi || r == qi) continue;
+                    double& arp = (r < pi) ? A[r][pi] : A[pi][r];
+                    double& arq = (r < qi) ? A[r][qi] : A[qi][r];
+                    const double vp = arp, vq = arq;
+                    arp = fma(c, vp, -sn * vq);
+                    arq = fma(sn, vp, c * vq);
+                }
+                A[pi][pi] = fma(-tt, apq, app);
+                A[qi][qi] = fma(tt, apq, aqq);
+                A[pi][qi] = rot ? 0.0 : apq;
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    const double vp = V[r][pi], vq = V[r][qi];
+                    V[r][pi] = fma(c, vp, -sn * vq);
+                    V[r][qi] = fma(sn, vp, c * vq);
+                }
+            }
+    }
+    if (!done) err |= skd::ERR_EIGEN;
+    // ---- eigenvalues, X = T^-1 R^-T V (column by column), staged in LDS in two halves and written as contiguous runs
+    double lam[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double l = A[j][j];
+        if (!(l > 0)) { err |= skd::ERR_EIGEN; l = fabs(l) + 1e-300; }
+        lam[j] = l;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+#pragma unroll
+        for (int i = N - 1; i >= 0; --i) {
+            double t = V[i][j];
+#pragma unroll
+            for (int r = i + 1; r < N; ++r) t = fma(-Rc[r][i], V[r][j], t);
+            V[i][j] = t * rinv[i];
+        }
+    }
+    if (live && err) atomicOr(&b.status[w], err);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < HALF; ++e) {
+            const int ee = e + half * HALF;   // 0 .. N - 1: k^2, then X(i, j) at N + i N + j
+            double v;
+            if (ee < N) v = lam[ee];
+            else { const int i = (ee - N) / N, j = (ee - N) % N; v = V[i][j] * sIt[i]; }
+            sOut[lane * STRIDE + e] = v;
+        }
+        __syncthreads();
+        for (int idx = lane; idx < 64 * HALF; idx += 64) {
+            const int rl = idx / HALF, e = idx % HALF, ee = e + half * HALF;
+            if (!sLive[rl]) continue;
+            double* rec = skd::rec_at<N>(b, nlyr, p, w0 + rl);
+            rec[(ee < N) ? (R::K + ee) : (R::DWP + ee - N)] = sOut[rl * STRIDE + e];
+        }
+    }
+}
+
+
+// -------------------------------------------------------------------------------------------------------------------
+// Column-per-lane 16 x 16 linear algebra for the 16-stream boundary value problem: a 16-lane DPP row owns one matrix, lane c
+// holds COLUMN c in registers (compile-time row indices), four matrices (four wavelengths) per wavefront.  A product
+// C = A B needs A[i][j] (register i of lane j, a row_newbcast:j move) and B[j][c] (own register j): no LDS, no shuffles
+// through the LDS crossbar, no run-time register index anywhere.
+// -------------------------------------------------------------------------------------------------------------------
+template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int CNT, class F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, CNT>{}, f);
+}
+// value of lane L of the own 16-lane row (v_mov_b64_dpp row_newbcast:L)
+template <int L> __device__ __forceinline__ double row_bcast(double v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + L, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ double row_dpp64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a row, in every lane (the order of the additions depends on the lane; each lane only uses its own)
+__device__ __forceinline__ double row16_sum(double v) {
+    v += row_dpp64<0xb1>(v);   // quad_perm [1,0,3,2]
+    v += row_dpp64<0x4e>(v);   // quad_perm [2,3,0,1]
+    v += row_dpp64<0x124>(v);  // row_ror 4
+    v += row_dpp64<0x128>(v);  // row_ror 8
+    return v;
+}
+
+// Inverse of a 16 x 16 matrix by Householder QR, column per lane:  H_15 .. H_0 [A | I] = [R | Q^T],  A^-1 = R^-1 Q^T.
+// a[] (column c of A) is destroyed, inv[] receives column c of the inverse.  No pivot search and no data-dependent control
+// flow: unconditionally backward stable, the same instruction stream for every matrix.  Returns 1 if a column norm vanished.
+__device__ __forceinline__ int qr16_inverse_cols(double (&a)[16], double (&inv)[16], int c) {
+    constexpr int M2 = 16;
+    double rinv[M2];   // 1 / R[k][k], the same in every lane of the row
+    int sing = 0;
+#pragma unroll
+    for (int i = 0; i < M2; ++i) inv[i] = (i == c) ? 1.0 : 0.0;
+    static_for<M2>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        // Householder vector of column k (every lane computes it from its own column, lane k's is broadcast):
+        // alpha = -sgn(x_k) |x|, v = x - alpha e_k, beta = 2 / v.v = -1 / (alpha v_k),  1 / alpha = -beta v_k
+        double sg = 0;
+#pragma unroll
+        for (int i = k + 1; i < M2; ++i) sg = fma(a[i], a[i], sg);
+        const double xk = a[k], n2 = fma(xk, xk, sg);
+        const bool zero = !(n2 > 0.0);
+        const double n2s = zero ? 1.0 : n2;
+        const double nrm = n2s * kj_rsqrt(n2s);
+        const double alpha = (xk >= 0) ? -nrm : nrm;
+        const double vk = xk - alpha;
+        const double beta = -kj_rcp(alpha * vk);
+        if (k < M2 - 1) {
+            const double vkb = row_bcast<k>(vk), betab = row_bcast<k>(beta);
+            double vb[M2];
+#pragma unroll
+            for (int i = k + 1; i < M2; ++i) vb[i] = row_bcast<k>(a[i]);
+            rinv[k] = -betab * vkb;
+            sing |= (row_bcast<k>(n2) > 0.0) ? 0 : 1;
+            double da = vkb * a[k], dq = vkb * inv[k];
+#pragma unroll
+            for (int i = k + 1; i < M2; ++i) {
+                da = fma(vb[i], a[i], da);
+                dq = fma(vb[i], inv[i], dq);
+            }
+            const double fa = betab * da, fq = betab * dq;
+            const bool own = (c == k);
+            a[k] = own ? alpha : fma(-fa, vkb, a[k]);
+            inv[k] = fma(-fq, vkb, inv[k]);
+#pragma unroll
+            for (int i = k + 1; i < M2; ++i) {
+                a[i] = own ? 0.0 : fma(-fa, vb[i], a[i]);
+                inv[i] = fma(-fq, vb[i], inv[i]);
+            }
+        } else {
+            // last column: a 1 x 1 reflection is the identity, R[15][15] = x_15
+            const double xb = row_bcast<k>(xk);
+            sing |= (xb == 0.0) ? 1 : 0;
+            rinv[k] = kj_rcp((xb == 0.0) ? 1.0 : xb);
+        }
+    });
+    // back substitution  x = R^-1 y  on the own column of Q^T:  R[i][r] = register i of lane r
+    static_for<M2>([&](auto ic) {
+        constexpr int i = M2 - 1 - decltype(ic)::value;
+        double t = inv[i];
+        static_for<M2 - 1 - i>([&](auto rc) {
+            constexpr int r = i + 1 + decltype(rc)::value;
+            t = fma(-row_bcast<r>(a[i]), inv[r], t);
+        });
+        inv[i] = t * rinv[i];
+    });
+    return sing;
+}
+
+
+#ifndef SKD_WPE_K2AC
+#define SKD_WPE_K2AC 2
+#endif
+// K2a for N = 8 (16 streams), column per lane: the block-tridiagonal boundary value problem of FOUR wavelengths per wavefront
+// (16-lane row = wavelength, lane c = column c of the 16 x 16 blocks).  Same recursion as kern_k2a_mfma8 / skd::k2a_bvp
+// (reference: sktran_do_rte.cpp:1620-1790,1897-2294):
+//   forward   T1 = Sub_p Dinv'_{p-1} (8 x 16),  D'_p = D_p + T1[:, 8:16] S_p,  r'_p = r_p - T1 r'_{p-1},  Dinv'_p = inverse (Householder QR)
+//   backward  x_p = Dinv'_p (r'_p + [0; S_{p+1} x_{p+1}])
+//   with, for column c (j = c & 7, E_j = exp(-k_j tau)):   D[r][c] = -(c < 8 ? W+(r, j) : W-(r, j) E_j), D[8 + i][c] = (c < 8 ? W-(i, j) E_j : W+(i, j)),
+//   Sub_{p+1}[i][c] = (c < 8 ? W+(i, j) E_j : W-(i, j)),  S_p[i][c] = (c < 8 ? W-(i, j) : W+(i, j) E_j)
+// Vectors are distributed (entry c in lane c).  Block inverses leave in the row-major layout kern_k2c_mfma8 reads.
+__global__ void __launch_bounds__(64, SKD_WPE_K2AC) kern_k2a_cols8(Geo g, Bufs b, int s, int m) {
+    constexpr int N = 8, M2 = 16;
+    using R = skd::Rec<N>;
+    const int lane = threadIdx.x, c = lane & 15, grp = lane >> 4, jc = c & 7, nw = b.nw, nlyr = g.nlyr;
+    const bool lo = (c < N);
+    const int w = blockIdx.x * 4 + grp;
+    const bool live = (w < nw) && (m < b.norders[min(w, nw - 1)]);
+    if (!__any(live)) return;
+    const int wl = min(w, nw - 1);   // a row without a wavelength works on a valid record and stores nothing
+    const double rho = (m == 0) ? b.albedo[wl] : 0.0;
+    double wmu[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) wmu[t] = g.wt[t] * g.mu[t];
+    double subc[N], dinv[M2], rprev = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) subc[i] = 0;
+#pragma unroll
+    for (int i = 0; i < M2; ++i) dinv[i] = 0;
+    int sing = 0;
+    // column data of a layer: W+(:, j), W-(:, j), E_j and this lane's entry of G_p (rows < 8: Gplus_top, rows >= 8: Gminus_bottom)
+    double wp[N], wm[N], Ec, gown, gup;   // gup: the neighbour's G entry of the right-hand side (layer above: Gplus_bottom, layer below: Gminus_top)
+    auto load_layer = [&](int p, double (&wp_)[N], double (&wm_)[N], double& E_, double& g_, double& gn_) {
+        const double* rec = skd::rec_at<N>(b, nlyr, p, wl);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            wp_[i] = rec[R::WP + N * jc + i];
+            wm_[i] = rec[R::WM + N * jc + i];
+        }
+        E_ = rec[R::E + jc];
+        g_ = lo ? rec[R::G + c] : -rec[R::G + 3 * N + jc];
+        gn_ = 0;
+        if (lo) { if (p > 0) gn_ = -skd::rec_at<N>(b, nlyr, p - 1, wl)[R::G + 2 * N + c]; }
+        else if (p < nlyr - 1) gn_ = skd::rec_at<N>(b, nlyr, p + 1, wl)[R::G + N + jc];
+    };
+    load_layer(0, wp, wm, Ec, gown, gup);
+    for (int p = 0; p < nlyr; ++p) {
+        const bool last = (p == nlyr - 1);
+        // the next layer's columns are requested now: their latency hides behind the factorisation
+        double nwp[N], nwm[N], nE = 0, ngown = 0, ngup = 0;
+        if (!last) load_layer(p + 1, nwp, nwm, nE, ngown, ngup);
+        double a[M2], sc[N], subn[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double wpe = wp[i] * Ec, wme = wm[i] * Ec;
+            a[i] = -(lo ? wp[i] : wme);
+            a[N + i] = lo ? wme : wp[i];
+            sc[i] = lo ? wm[i] : wpe;
+            subn[i] = lo ? wpe : wm[i];
+        }
+        double rv = gown + gup;
+        if (last && m == 0) {
+            double gsp = 0, gsm = 0, gsg = 0;
+            const double* rec = skd::rec_at<N>(b, nlyr, p, wl);
+#pragma unroll
+            for (int t = 0; t < N; ++t) {
+                gsp = fma(wmu[t], wp[t], gsp);
+                gsm = fma(wmu[t], wm[t], gsm);
+                gsg = fma(wmu[t], rec[R::G + 2 * N + t], gsg);
+            }
+            const double corr = 2.0 * rho * (lo ? gsp * Ec : gsm);
+#pragma unroll
+            for (int i = 0; i < N; ++i) a[N + i] -= corr;
+            if (!lo) rv += g.csz[s] * rho / skd::kPi * b.T[size_t(nlyr) * nw + wl] + 2.0 * rho * gsg;
+        }
+        if (p > 0) {
+            // T1[i][c] = sum_j Sub_p[i][j] Dinv'_{p-1}[j][c]
+            double t1[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) t1[i] = 0;
+            static_for<M2>([&](auto jx) {
+                constexpr int j = decltype(jx)::value;
+#pragma unroll
+                for (int i = 0; i < N; ++i) t1[i] = fma(row_bcast<j>(subc[i]), dinv[j], t1[i]);
+            });
+            // D'[i][c] += sum_q T1[i][8 + q] S_p[q][c]
+            static_for<N>([&](auto qx) {
+                constexpr int q = decltype(qx)::value;
+#pragma unroll
+                for (int i = 0; i < N; ++i) a[i] = fma(row_bcast<N + q>(t1[i]), sc[q], a[i]);
+            });
+            // r'[i] -= sum_c T1[i][c] r'_{p-1}[c]
+            double tr = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double sm = row16_sum(t1[i] * rprev);
+                tr = (c == i) ? sm : tr;
+            }
+            rv -= tr;
+        }
+        sing |= qr16_inverse_cols(a, dinv, c);
+        if (live) {
+            double* dg = skd::dinv_at<N>(b, nlyr, p, w);
+#pragma unroll
+            for (int i = 0; i < M2; ++i) dg[i * M2 + c] = dinv[i];
+            skd::xsol_at<N>(b, nlyr, p, w)[c] = rv;
+        }
+        rprev = rv;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            subc[i] = subn[i];
+            wp[i] = nwp[i];
+            wm[i] = nwm[i];
+        }
+        Ec = nE; gown = ngown; gup = ngup;
+    }
+    // back substitution: row per lane (lane c loads row c of Dinv', 128 contiguous bytes), x distributed
+    double xn = 0;
+    for (int p = nlyr - 1; p >= 0; --p) {
+        const double* dg = skd::dinv_at<N>(b, nlyr, p, wl);
+        double* xs = skd::xsol_at<N>(b, nlyr, p, wl);
+        double drow[M2];
+#pragma unroll
+        for (int j = 0; j < M2; ++j) drow[j] = dg[c * M2 + j];
+        double v = xs[c];
+        if (p < nlyr - 1) {
+            const double* recn = skd::rec_at<N>(b, nlyr, p + 1, wl);
+            const double En = recn[R::E + jc];
+            double sx = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double sci = lo ? recn[R::WM + N * jc + i] : recn[R::WP + N * jc + i] * En;
+                const double sm = row16_sum(sci * xn);
+                sx = (c == N + i) ? sm : sx;
+            }
+            v += sx;
+        }
+        double x = 0;
+        static_for<M2>([&](auto jx) {
+            constexpr int j = decltype(jx)::value;
+            x = fma(drow[j], row_bcast<j>(v), x);
+        });
+        if (live) xs[c] = x;
+        xn = x;
+    }
+    if (live && sing && c == 0) atomicOr(&b.status[w], skd::ERR_SINGULAR_BVP);
+}
+
+}  // namespace skdev

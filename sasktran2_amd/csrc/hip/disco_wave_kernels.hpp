@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "disco_core.hpp"
+#include "disco_lane_kernels.hpp"
 
 // minimum waves per SIMD requested from the register allocator (second __launch_bounds__ argument)
 // Jacobi stops when sum(off-diagonal^2) <= tol * sum(diagonal^2): 1e-30 is an off-diagonal norm of 1e-15 of the diagonal,
@@ -33,6 +34,9 @@
 #endif
 #ifndef SKD_WPE_K1
 #define SKD_WPE_K1 2
+#endif
+#ifndef SKD_WPE_K1P
+#define SKD_WPE_K1P 2
 #endif
 #ifndef SKD_WPE_K2A
 #define SKD_WPE_K2A 1
@@ -60,7 +64,9 @@ using skd::Geo;
 // lanes; each group owns one layer per pass and keeps the layer's streams x streams matrices in LDS
 // (B+, B-, Cholesky factor, Jacobi work matrix, eigenvectors, ...).  Same mathematics as skd::k1_layer_solution.
 // -------------------------------------------------------------------------------------------------------------------
-template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_k1_wave(Geo g, Bufs b, int s, int m, int layers_per_block) {
+// PRE = true: the eigen-solution (k_j^2 and X) of every layer was left in the record by kern_kj_lane (lane-per-problem Jacobi,
+// disco_lane_kernels.hpp); this kernel then skips its own Cholesky / Jacobi / back-substitution stages.
+template <int N, int LG, bool PRE = false> __global__ void __launch_bounds__(64, PRE ? SKD_WPE_K1P : SKD_WPE_K1) kern_k1_wave(Geo g, Bufs b, int s, int m, int layers_per_block) {
     constexpr int NSTR = 2 * N, NN = N * N, NG = 64 / LG;
     static_assert(LG >= N && (LG == 16 || LG == 32 || LG == 64), "lane group must cover one matrix row");
     using R = skd::Rec<N>;
@@ -186,12 +192,16 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             const double bp = dlt - sSq[i] * sSq[j] * om * ep;
             Bp[e] = bp;
             Bm[e] = dlt - sSq[i] * sSq[j] * om * em;
-            Rc[e] = (j <= i) ? bp : 0.0;
+            if (!PRE) Rc[e] = (j <= i) ? bp : 0.0;
+        }
+        if (PRE) {
+            // eigen-solution from kern_kj_lane: X(i, j) at [R::DWP + i N + j] (rewritten with dW+ below), k_j^2 at [R::K + j]
+            for (int e = gl; e < NN; e += LG) M5[e] = rec[R::DWP + e];
         }
         __syncthreads();
         K1T(0)
         // Cholesky B+ = R R^T (lower), one column per step
-        for (int j = 0; j < N; ++j) {
+        for (int j = 0; j < N && !PRE; ++j) {
             double tj = Rc[j * N + j];
             for (int k = 0; k < j; ++k) tj -= Rc[j * N + k] * Rc[j * N + k];
             if (!(tj > 0)) { if (gl == 0) sErr = skd::ERR_CHOLESKY; tj = 1.0; }
@@ -211,14 +221,14 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
         }
         K1T(1)
         // M3 = B- R ;  M4 = R^T M3 (symmetric)
-        for (int e = gl; e < NN; e += LG) {
+        for (int e = gl; e < NN && !PRE; e += LG) {
             const int i = e / N, j = e % N;
             double t = 0;
             for (int r = j; r < N; ++r) t += Bm[i * N + r] * Rc[r * N + j];
             M3[e] = t;
         }
-        __syncthreads();
-        for (int e = gl; e < NN; e += LG) {
+        if (!PRE) __syncthreads();
+        for (int e = gl; e < NN && !PRE; e += LG) {
             const int i = e / N, j = e % N;
             if (j <= i) {
                 double t = 0;
@@ -228,7 +238,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
             }
             M5[e] = (i == j) ? 1.0 : 0.0;
         }
-        __syncthreads();
+        if (!PRE) __syncthreads();
         K1T(2)
         K1T(3)
         // Jacobi on M4 with the round-robin ("tournament") ordering: every round applies N/2 disjoint rotations at once,
@@ -236,9 +246,9 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
         // Default: register-resident blocks in position space (ownership tables above): rotate in registers, write to the permuted
         // places, read the own places back.  SKD_K1_JACOBI_LDS keeps the earlier form for comparison (index i of a rotated pair (p, q)
         // has partner i' and coefficients (al, be) = (c, -s) for i = p, (c, +s) for i = q; M6 / M7 are the ping-pong write buffers).
-        bool jac_ok = (N == 1);
+        bool jac_ok = (N == 1) || PRE;
 #ifndef SKD_K1_JACOBI_LDS
-        if (N > 1) {
+        if (N > 1 && !PRE) {
             double a00[JUA], a01[JUA], a10[JUA], a11[JUA], evp[JUV], evq[JUV];
 #pragma unroll
             for (int u = 0; u < JUA; ++u) {
@@ -350,7 +360,7 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
         }
 #else
         constexpr int NM1 = (N > 1) ? N - 1 : 1;
-        if (N > 1) {
+        if (N > 1 && !PRE) {
             double* Acur = M4;
             double* Vcur = M5;
             double* Anew = M6;
@@ -428,19 +438,19 @@ template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_
         K1T(4)
         if (!jac_ok && gl == 0) sErr = skd::ERR_EIGEN;
         if (gl < N) {
-            double lam = M4[gl * N + gl];
+            double lam = PRE ? rec[R::K + gl] : M4[gl * N + gl];
             if (!(lam > 0)) { sErr = skd::ERR_EIGEN; lam = fabs(lam) + 1e-300; }
             vlam[gl] = lam;
             vk[gl] = sqrt(lam);
             vIk[gl] = 1.0 / sqrt(lam);
             // xhat = R^-T v (column gl, in place), x = T^-1 xhat
             const int j = gl;
-            for (int i = N - 1; i >= 0; --i) {
+            for (int i = N - 1; i >= 0 && !PRE; --i) {
                 double t = M5[i * N + j];
                 for (int r = i + 1; r < N; ++r) t -= Rc[r * N + i] * M5[r * N + j];
                 M5[i * N + j] = t * vRinv[i];
             }
-            for (int i = 0; i < N; ++i) M5[i * N + j] *= sIt[i];
+            for (int i = 0; i < N && !PRE; ++i) M5[i * N + j] *= sIt[i];
         }
         __syncthreads();
         K1T(5)
