@@ -82,9 +82,7 @@ struct Geo {
     const int* lp_angle;
     const int* lp_slot;
     const double* lp_w;
-    const double* lp_cosm;  // [m][entry]  cos(m * azimuth of the entry's ray layer)   (16-stream matrix-core sweeps)
-    const int* lp_meta;     // [entry][2]  (table slot, table angle) packed for one 8-byte load
-    const double* lpang4;   // [m][a][q<4][kk<4] = lpang[m][a][4 kk + q]  (nstr = 16 only)
+    const double* lp_pc;    // [m][entry][q<4][kk<4] = cos(m azimuth of the entry's ray layer) P_{4kk+q}^m(entry's table angle), 0 for l < m  (nstr = 16 only)
     int n_lp;               // number of (LOS, sza, layer) table entries
     const int* g_start;     // [los .. +1] ground entries
     const int* g_slot;
@@ -131,6 +129,7 @@ struct Bufs {
     double* srcw;           // [q][w]  omega_loc (1-exp(-od)) * attenuation(q -> observer)
     double* att_total;      // [los][w]
     double* cwbuf;          // [w][entry]  srcw of the entry's ray layer x its interpolation weight (16-stream sweeps)
+    uint8_t* qlmask;        // [w][entry / 8]  bit j: entry 8 i + j still contributes at the azimuth order of the adjoint stage (kern_qlmask)
     // per azimuth order
     double* rec;            // [w][p][REC]   (record-major, see rec_at)
     double* dinv;           // [w][p][4N^2]

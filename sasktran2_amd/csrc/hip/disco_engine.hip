@@ -127,6 +127,20 @@ __global__ void __launch_bounds__(256) kern_cw(Geo g, Bufs b) {
         b.cwbuf[i] = b.srcw[size_t(g.lp_q[e]) * b.nw + w] * g.lp_w[e];
     }
 }
+// live flags of the table entries at azimuth order m, one byte per 8 entries: the adjoint sweeps test a bit instead of following
+// entry -> table slot -> convergence order (a dependent load per entry, repeated by the four lanes of a line of sight)
+__global__ void __launch_bounds__(256) kern_qlmask(Geo g, Bufs b, int m) {
+    const int nb = g.n_lp / 8;
+    const size_t n = size_t(b.nw) * nb;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const int w = int(i / nb), k = int(i % nb);
+        if (m >= b.norders[w]) continue;
+        unsigned bits = 0;
+        for (int j = 0; j < 8; ++j)
+            if (skd::conv_at(b, g, g.lp_slot[8 * k + j], w) > m) bits |= 1u << j;
+        b.qlmask[i] = uint8_t(bits);
+    }
+}
 // plane-parallel post-processing: one thread per (wavelength, line of sight), see skd::kpp_los
 template <int N> __global__ void __launch_bounds__(kBlock) kern_kpp(Geo g, Bufs b, int s, int m) {
     size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -272,7 +286,7 @@ DeviceEngine::DeviceEngine(const skgeo::DiscoGeometry& dg, bool ss_in_do) : impl
     g.rl_ssa_start = M.upload(t.rl_ssa_start); g.ssa_idx = M.upload(t.ssa_idx); g.ssa_w = M.upload(t.ssa_w);
     g.rl_azi = M.upload(t.rl_azi); g.rl_cosm = M.upload(t.rl_cosm); g.rl_cosm_t = M.upload(t.rl_cosm_t); g.rl_active = M.upload(t.rl_active); g.rl_tab_start = M.upload(t.rl_tab_start);
     g.tab_slot = M.upload(t.tab_slot); g.tab_w = M.upload(t.tab_w); g.lp_start = M.upload(t.lp_start); g.lp_q = M.upload(t.lp_q);
-    g.lp_angle = M.upload(t.lp_angle); g.lp_slot = M.upload(t.lp_slot); g.lp_w = M.upload(t.lp_w); g.lp_cosm = M.upload(t.lp_cosm); g.lp_meta = M.upload(t.lp_meta); g.lpang4 = M.upload(t.lpang4); g.g_start = M.upload(t.g_start);
+    g.lp_angle = M.upload(t.lp_angle); g.lp_slot = M.upload(t.lp_slot); g.lp_w = M.upload(t.lp_w); g.lp_pc = M.upload(t.lp_pc); g.g_start = M.upload(t.g_start);
     g.g_slot = M.upload(t.g_slot); g.g_sza = M.upload(t.g_sza); g.g_w = M.upload(t.g_w);
     g.pp_mu = M.upload(t.pp_mu); g.pp_azi = M.upload(t.pp_azi); g.pp_first = M.upload(t.pp_first); g.pp_lf = M.upload(t.pp_lf);
     g.lplos = M.upload(t.lplos);
@@ -345,7 +359,7 @@ size_t DeviceEngine::bytes_per_wavelength() const {
     size_t d = 0;
     d += nlyr * (3 + nstr) + (nlyr + 1) + nlyr;              // tau, om, kbar, a, T, sec
     d += size_t(t.nq_total) * 3 + nlos;                      // od, omloc, srcw, att_total
-    if (N == 8) d += t.lp_q.size();                          // cwbuf
+    if (N == 8) d += t.lp_q.size() + t.lp_q.size() / 64 + 1; // cwbuf, qlmask
     d += 2 * (nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N);  // rec, dinv, xsol (two buffers each)
     d += nstr * size_t(t.nslot);                             // J
     const size_t nlos_pad = (nlos + 15) / 16 * 16;
@@ -387,6 +401,7 @@ void DeviceEngine::ensure_scratch(int nw, int nslots) {
         b.od = M.alloc<double>(size_t(t.nq_total) * W); b.omloc = M.alloc<double>(size_t(t.nq_total) * W);
         b.srcw = M.alloc<double>(size_t(t.nq_total) * W); b.att_total = M.alloc<double>(nlos * W);
         b.cwbuf = M.alloc<double>(t.N == 8 ? t.lp_q.size() * W : 1);
+        b.qlmask = M.alloc<uint8_t>(t.N == 8 ? t.lp_q.size() / 8 * W + 8 : 8);
         b.rec = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W); b.dinv = M.alloc<double>(nlyr * 4 * N * N * W);
         sl->rec2 = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W);
         sl->dinv2 = M.alloc<double>(nlyr * 4 * N * N * W);
@@ -442,9 +457,22 @@ static int small_batch_split(int nw) {
     if (const char* e = std::getenv("SASKTRAN2_AMD_SPLIT")) return std::max(1, atoi(e));
     return nw >= 3000 ? 1 : (nw >= 1500 ? 2 : 4);
 }
+// Eigen-solutions ahead of K1: 8 and 16 streams solve the eigenproblems of all (layer, wavelength) pairs one per LANE in registers
+// (kern_kj_lane) and the cooperative kernel continues from there.  Returns whether the kernel was launched.
+template <int N>
+static bool launch_kj(hipStream_t st, const Geo& g, const Bufs& b, int m) {
+    if constexpr (N == 4 || N == 8) {
+        static const bool lane_jacobi = [] { const char* e = std::getenv("SASKTRAN2_AMD_KJ"); return e ? atoi(e) != 0 : true; }();
+        if (lane_jacobi) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_kj_lane<N>), dim3(unsigned((b.nw + 63) / 64), unsigned(g.nlyr)), dim3(64), 0, st, g, b, m);
+            return true;
+        }
+    }
+    return false;
+}
 // K1 launch: lane-group width per layer and the split of the layers over blockIdx.y
 template <int N>
-static void launch_k1(hipStream_t st, const Geo& g, const Bufs& b, int s, int m) {
+static void launch_k1(hipStream_t st, const Geo& g, const Bufs& b, int s, int m, bool pre) {
     constexpr int LG = (N >= 16) ? 64 : SKD_K1_LG;
     const int split = small_batch_split(b.nw);
     const int ng = 64 / LG;
@@ -452,12 +480,8 @@ static void launch_k1(hipStream_t st, const Geo& g, const Bufs& b, int s, int m)
     lpb = (lpb + ng - 1) / ng * ng;
     const int ny = (g.nlyr + lpb - 1) / lpb;
     if constexpr (N == 4 || N == 8) {
-        // 8 and 16 streams: the eigenproblems of all (layer, wavelength) pairs one per LANE in registers (kern_kj_lane), the
-        // cooperative kernel continues from the eigen-solution
-        static const bool lane_jacobi = [] { const char* e = std::getenv("SASKTRAN2_AMD_KJ"); return e ? atoi(e) != 0 : true; }();
-        if (lane_jacobi) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_kj_lane<N>), dim3(unsigned((b.nw + 63) / 64), unsigned(g.nlyr)), dim3(64), 0, st, g, b, m);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_wave<N, LG, true>), dim3(unsigned(b.nw), unsigned(ny)), dim3(64), 0, st, g, b, s, m, lpb);
+        if (pre) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1p_wave<N, LG>), dim3(unsigned(b.nw), unsigned(ny)), dim3(64), 0, st, g, b, s, m, lpb);
             return;
         }
     }
@@ -499,8 +523,10 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
         }
         for (int m = 0; m < g.nstr; ++m) {
             {
+                bool pre;
+                { Timer t(I, st, "kj_eigen"); pre = launch_kj<N>(st, g, b, m); }
                 Timer t(I, st, "k1_layer_solution");
-                launch_k1<N>(st, g, b, 0, m);
+                launch_k1<N>(st, g, b, 0, m, pre);
             }
             {
                 Timer t(I, st, "k2a_bvp");
@@ -529,7 +555,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
             bt.thermal_pass = 1;
             bt.surf_em = slot.thermal_surface;
             hipLaunchKernelGGL(kern_k0_thermal, dim3(blocks(nw)), dim3(kBlock), 0, st, g, bt);
-            launch_k1<N>(st, g, bt, g.nsza, 0);
+            launch_k1<N>(st, g, bt, g.nsza, 0, launch_kj<N>(st, g, bt, 0));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, bt, g.nsza, 0);
             if (derivs) {
                 // weighting functions: the adjoint operators of the thermal order-0 solve, the sweeps inside kern_kpp, and the chain from the
@@ -594,8 +620,10 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                 }
             }
             {
+                bool pre;
+                { Timer t(I, sA, "kj_eigen"); pre = launch_kj<N>(sA, g, b, m); }
                 Timer t(I, sA, "k1_layer_solution");
-                launch_k1<N>(sA, g, b, s, m);
+                launch_k1<N>(sA, g, b, s, m, pre);
             }
             if (pipe) {
                 HIP_CHECK(hipEventRecord(slot.ev_k1[m], sA));
@@ -634,6 +662,10 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                         if (const char* e = std::getenv("SASKTRAN2_AMD_K2C_SPLIT")) split = std::max(1, atoi(e));
                         const int lpb = (g.nlyr + split - 1) / split, ny = (g.nlyr + lpb - 1) / lpb;
                         hipLaunchKernelGGL(kern_k2c_mfma8, dim3(unsigned(nw), unsigned(ny)), dim3(64), 0, sC, g, b, s, m, lpb);
+                    }
+                    if (g.n_lp > 0) {
+                        Timer t2(I, sC, "k2q_live_flags");
+                        hipLaunchKernelGGL(kern_qlmask, dim3(2048), dim3(256), 0, sC, g, b, m);
                     }
                     Timer t(I, sC, "k2b_adjoint");
                     const int ntile = (g.nlos + 15) / 16;

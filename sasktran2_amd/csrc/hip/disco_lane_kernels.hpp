@@ -13,6 +13,13 @@
 
 #include "disco_core.hpp"
 
+// scheduling fence between the steps of the unrolled factorisations: without it the scheduler hoists the cross-lane moves of
+// all later steps to the front of the (very long) basic block and spills hundreds of registers
+#ifndef SKD_QR_NOFENCE
+#define SKD_QR_FENCE __builtin_amdgcn_sched_barrier(0);
+#else
+#define SKD_QR_FENCE
+#endif
 #ifndef SKD_WPE_KJ
 #define SKD_WPE_KJ 1
 #endif
@@ -54,7 +61,7 @@ __device__ __forceinline__ double kj_rcp(double x) {
 // problems of its wavefront.
 // -------------------------------------------------------------------------------------------------------------------
 template <int N> __global__ void __launch_bounds__(64, SKD_WPE_KJ) kern_kj_lane(Geo g, Bufs b, int m) {
-    constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, HALF = NOUT / 2, STRIDE = HALF + 1;
+    constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, HALF = NOUT / 2, STRIDE = HALF + 1, NM1 = N - 1, JH = N / 2;
     static_assert(NOUT % 2 == 0, "two output halves");
     using R = skd::Rec<N>;
     const int lane = threadIdx.x, p = blockIdx.y, nw = b.nw, nlyr = g.nlyr;
@@ -151,47 +158,74 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_KJ) kern_kj_lane(
     // ---- cyclic Jacobi, A <- J^T A J, V <- V J, rotation (p, q): new_p = c x_p - s x_q, new_q = s x_p + c x_q
     bool done = !live;
     for (int sweep = 0; sweep < SKD_KJ_MAXSWEEP; ++sweep) {
-        double off = 0, dia = 0;
+        double offp[4] = {0, 0, 0, 0}, dia = 0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             dia = fma(A[i][i], A[i][i], dia);
 #pragma unroll
-            for (int j = i + 1; j < N; ++j) off = fma(A[i][j], A[i][j], off);
+            for (int j = i + 1; j < N; ++j) offp[(i + j) & 3] = fma(A[i][j], A[i][j], offp[(i + j) & 3]);
         }
+        const double off = (offp[0] + offp[1]) + (offp[2] + offp[3]);
         done = done || (off <= SKD_KJ_TOL * dia) || (off == 0);
         if (__all(done)) break;
+        // round-robin ("tournament") ordering: a round rotates N / 2 disjoint pairs, J = product of the round's rotations,
+        // A <- J^T A J, V <- V J.  The N / 2 parameter chains of a round are independent (each is ~25 dependent FP64 operations).
 #pragma unroll
-        for (int pi = 0; pi < N - 1; ++pi)
+        for (int round = 0; round < NM1; ++round) {
+            int pp[JH], qq[JH];
+            double cc[JH], ss[JH], tt[JH];
+            bool rr[JH];
 #pragma unroll
-            for (int qi = pi + 1; qi < N; ++qi) {
-                const double apq = A[pi][qi], app = A[pi][pi], aqq = A[qi][qi];
+            for (int t = 0; t < JH; ++t) {
+                int x, y;
+                if (t == 0) { x = round; y = N - 1; }
+                else { x = (round + t) % NM1; y = (round + NM1 - t) % NM1; }
+                pp[t] = (x < y) ? x : y;
+                qq[t] = (x < y) ? y : x;
+            }
+#pragma unroll
+            for (int t = 0; t < JH; ++t) {
+                const double apq = A[pp[t]][qq[t]], app = A[pp[t]][pp[t]], aqq = A[qq[t]][qq[t]];
                 // t = sgn(d) h / (|d| + sqrt(d^2 + h^2)),  d = aqq - app, h = 2 apq;  c = 1 / sqrt(1 + t^2),  s = t c
                 const double d = aqq - app, h = 2.0 * apq, x = fma(d, d, h * h);
                 const bool rot = !done && (apq != 0.0) && (x > 0.0);
                 const double xs = rot ? x : 1.0;
                 const double den = fabs(d) + xs * kj_rsqrt(xs);
-                double tt = ((d >= 0) ? h : -h) * kj_rcp(den);
-                tt = rot ? tt : 0.0;
-                const double c = kj_rsqrt(fma(tt, tt, 1.0)), sn = tt * c;
-#pragma unroll
-                for (int r = 0; r < N; ++r) {
-                    if (r == pi || r == qi) continue;
-                    double& arp = (r < pi) ? A[r][pi] : A[pi][r];
-                    double& arq = (r < qi) ? A[r][qi] : A[qi][r];
-                    const double vp = arp, vq = arq;
-                    arp = fma(c, vp, -sn * vq);
-                    arq = fma(sn, vp, c * vq);
-                }
-                A[pi][pi] = fma(-tt, apq, app);
-                A[qi][qi] = fma(tt, apq, aqq);
-                A[pi][qi] = rot ? 0.0 : apq;
-#pragma unroll
-                for (int r = 0; r < N; ++r) {
-                    const double vp = V[r][pi], vq = V[r][qi];
-                    V[r][pi] = fma(c, vp, -sn * vq);
-                    V[r][qi] = fma(sn, vp, c * vq);
-                }
+                double tn = ((d >= 0) ? h : -h) * kj_rcp(den);
+                tn = rot ? tn : 0.0;
+                const double c = kj_rsqrt(fma(tn, tn, 1.0));
+                cc[t] = c; ss[t] = tn * c; tt[t] = tn; rr[t] = rot;
+                A[pp[t]][pp[t]] = fma(-tn, apq, app);
+                A[qq[t]][qq[t]] = fma(tn, apq, aqq);
+                A[pp[t]][qq[t]] = rot ? 0.0 : apq;
             }
+            // off-diagonal 2 x 2 blocks (pair t1 rows, pair t2 columns), t1 < t2:  B <- J1^T B J2
+#pragma unroll
+            for (int t1 = 0; t1 < JH; ++t1)
+#pragma unroll
+                for (int t2 = t1 + 1; t2 < JH; ++t2) {
+                    const int p1 = pp[t1], q1 = qq[t1], p2 = pp[t2], q2 = qq[t2];
+                    double& b00 = (p1 < p2) ? A[p1][p2] : A[p2][p1];
+                    double& b01 = (p1 < q2) ? A[p1][q2] : A[q2][p1];
+                    double& b10 = (q1 < p2) ? A[q1][p2] : A[p2][q1];
+                    double& b11 = (q1 < q2) ? A[q1][q2] : A[q2][q1];
+                    const double c1 = cc[t1], s1 = ss[t1], c2 = cc[t2], s2 = ss[t2];
+                    const double u00 = fma(c2, b00, -s2 * b01), u01 = fma(s2, b00, c2 * b01);
+                    const double u10 = fma(c2, b10, -s2 * b11), u11 = fma(s2, b10, c2 * b11);
+                    b00 = fma(c1, u00, -s1 * u10);
+                    b01 = fma(c1, u01, -s1 * u11);
+                    b10 = fma(s1, u00, c1 * u10);
+                    b11 = fma(s1, u01, c1 * u11);
+                }
+#pragma unroll
+            for (int t = 0; t < JH; ++t)
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    const double vp = V[r][pp[t]], vq = V[r][qq[t]];
+                    V[r][pp[t]] = fma(cc[t], vp, -ss[t] * vq);
+                    V[r][qq[t]] = fma(ss[t], vp, cc[t] * vq);
+                }
+        }
     }
     if (!done) err |= skd::ERR_EIGEN;
     // ---- eigenvalues, X = T^-1 R^-T V (column by column), staged in LDS in two halves and written as contiguous runs
@@ -266,7 +300,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 // Inverse of a 16 x 16 matrix by Householder QR, column per lane:  H_15 .. H_0 [A | I] = [R | Q^T],  A^-1 = R^-1 Q^T.
 // a[] (column c of A) is destroyed, inv[] receives column c of the inverse.  No pivot search and no data-dependent control
 // flow: unconditionally backward stable, the same instruction stream for every matrix.  Returns 1 if a column norm vanished.
-__device__ __forceinline__ int qr16_inverse_cols(double (&a)[16], double (&inv)[16], int c) {
+template <class MID> __device__ __forceinline__ int qr16_inverse_cols(double (&a)[16], double (&inv)[16], int c, MID&& mid) {
     constexpr int M2 = 16;
     double rinv[M2];   // 1 / R[k][k], the same in every lane of the row
     int sing = 0;
@@ -274,33 +308,37 @@ __device__ __forceinline__ int qr16_inverse_cols(double (&a)[16], double (&inv)[
     for (int i = 0; i < M2; ++i) inv[i] = (i == c) ? 1.0 : 0.0;
     static_for<M2>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
+        if constexpr (k == 8) mid();
+        SKD_QR_FENCE
         // Householder vector of column k (every lane computes it from its own column, lane k's is broadcast):
         // alpha = -sgn(x_k) |x|, v = x - alpha e_k, beta = 2 / v.v = -1 / (alpha v_k),  1 / alpha = -beta v_k
-        double sg = 0;
+        // (sums of squares and dot products in four partial accumulators: a chain of dependent FP64 operations costs its full latency per link)
+        const double xk = a[k];
+        double sg[4] = {xk * xk, 0, 0, 0};
 #pragma unroll
-        for (int i = k + 1; i < M2; ++i) sg = fma(a[i], a[i], sg);
-        const double xk = a[k], n2 = fma(xk, xk, sg);
+        for (int i = k + 1; i < M2; ++i) sg[(i - k) & 3] = fma(a[i], a[i], sg[(i - k) & 3]);
+        const double n2 = (sg[0] + sg[1]) + (sg[2] + sg[3]);
         const bool zero = !(n2 > 0.0);
         const double n2s = zero ? 1.0 : n2;
         const double nrm = n2s * kj_rsqrt(n2s);
         const double alpha = (xk >= 0) ? -nrm : nrm;
         const double vk = xk - alpha;
         const double beta = -kj_rcp(alpha * vk);
-        if (k < M2 - 1) {
+        if constexpr (k < M2 - 1) {
             const double vkb = row_bcast<k>(vk), betab = row_bcast<k>(beta);
             double vb[M2];
 #pragma unroll
             for (int i = k + 1; i < M2; ++i) vb[i] = row_bcast<k>(a[i]);
+            const bool own = (c == k);
             rinv[k] = -betab * vkb;
             sing |= (row_bcast<k>(n2) > 0.0) ? 0 : 1;
-            double da = vkb * a[k], dq = vkb * inv[k];
+            double da[4] = {vkb * a[k], 0, 0, 0}, dq[4] = {vkb * inv[k], 0, 0, 0};
 #pragma unroll
             for (int i = k + 1; i < M2; ++i) {
-                da = fma(vb[i], a[i], da);
-                dq = fma(vb[i], inv[i], dq);
+                da[(i - k) & 3] = fma(vb[i], a[i], da[(i - k) & 3]);
+                dq[(i - k) & 3] = fma(vb[i], inv[i], dq[(i - k) & 3]);
             }
-            const double fa = betab * da, fq = betab * dq;
-            const bool own = (c == k);
+            const double fa = betab * ((da[0] + da[1]) + (da[2] + da[3])), fq = betab * ((dq[0] + dq[1]) + (dq[2] + dq[3]));
             a[k] = own ? alpha : fma(-fa, vkb, a[k]);
             inv[k] = fma(-fq, vkb, inv[k]);
 #pragma unroll
@@ -315,19 +353,20 @@ __device__ __forceinline__ int qr16_inverse_cols(double (&a)[16], double (&inv)[
             rinv[k] = kj_rcp((xb == 0.0) ? 1.0 : xb);
         }
     });
-    // back substitution  x = R^-1 y  on the own column of Q^T:  R[i][r] = register i of lane r
+    // back substitution  x = R^-1 y  on the own column of Q^T, column oriented:  x_i = y_i / R[i][i],  y_r -= R[r][i] x_i (r < i)
+    // with R[r][i] = register r of lane i
     static_for<M2>([&](auto ic) {
         constexpr int i = M2 - 1 - decltype(ic)::value;
-        double t = inv[i];
-        static_for<M2 - 1 - i>([&](auto rc) {
-            constexpr int r = i + 1 + decltype(rc)::value;
-            t = fma(-row_bcast<r>(a[i]), inv[r], t);
+        SKD_QR_FENCE
+        const double xi = inv[i] * rinv[i];
+        inv[i] = xi;
+        static_for<i>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            inv[r] = fma(-row_bcast<i>(a[r]), xi, inv[r]);
         });
-        inv[i] = t * rinv[i];
     });
     return sing;
 }
-
 
 #ifndef SKD_WPE_K2AC
 #define SKD_WPE_K2AC 2
@@ -377,7 +416,8 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2AC) kern_k2a_cols8(Geo g, Bufs b
     load_layer(0, wp, wm, Ec, gown, gup);
     for (int p = 0; p < nlyr; ++p) {
         const bool last = (p == nlyr - 1);
-        // the next layer's columns are requested now: their latency hides behind the factorisation
+        // the next layer's columns are requested now: their latency hides behind the factorisation (requesting them half way through
+        // it looked better on paper and made the register allocator spill 270 instead of 60 registers)
         double nwp[N], nwm[N], nE = 0, ngown = 0, ngup = 0;
         if (!last) load_layer(p + 1, nwp, nwm, nE, ngown, ngup);
         double a[M2], sc[N], subn[N];
@@ -429,7 +469,7 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2AC) kern_k2a_cols8(Geo g, Bufs b
             }
             rv -= tr;
         }
-        sing |= qr16_inverse_cols(a, dinv, c);
+        sing |= qr16_inverse_cols(a, dinv, c, [] {});
         if (live) {
             double* dg = skd::dinv_at<N>(b, nlyr, p, w);
 #pragma unroll

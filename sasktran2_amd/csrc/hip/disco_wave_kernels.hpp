@@ -66,7 +66,7 @@ using skd::Geo;
 // -------------------------------------------------------------------------------------------------------------------
 // PRE = true: the eigen-solution (k_j^2 and X) of every layer was left in the record by kern_kj_lane (lane-per-problem Jacobi,
 // disco_lane_kernels.hpp); this kernel then skips its own Cholesky / Jacobi / back-substitution stages.
-template <int N, int LG, bool PRE = false> __global__ void __launch_bounds__(64, PRE ? SKD_WPE_K1P : SKD_WPE_K1) kern_k1_wave(Geo g, Bufs b, int s, int m, int layers_per_block) {
+template <int N, int LG, bool PRE> __device__ __forceinline__ void k1_wave_body(const Geo& g, const Bufs& b, int s, int m, int layers_per_block) {
     constexpr int NSTR = 2 * N, NN = N * N, NG = 64 / LG;
     static_assert(LG >= N && (LG == 16 || LG == 32 || LG == 64), "lane group must cover one matrix row");
     using R = skd::Rec<N>;
@@ -611,6 +611,14 @@ template <int N, int LG, bool PRE = false> __global__ void __launch_bounds__(64,
     if (lane == 0 && w == 0 && blockIdx.y == 0 && m == 1) printf("K1T build %lld chol %lld m3m4 %lld warm %lld jac %lld backsub %lld UdU %lld W %lld Q %lld coef %lld G %lld\n", tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6], tacc[7], tacc[8], tacc[9], tacc[10]);
 #endif
     if (lane == 0 && sErr) atomicOr(&b.status[w], sErr);
+}
+// (the occupancy request of a kernel cannot depend on a template parameter: one entry point per register budget)
+template <int N, int LG, bool PRE = false> __global__ void __launch_bounds__(64, SKD_WPE_K1) kern_k1_wave(Geo g, Bufs b, int s, int m, int layers_per_block) {
+    static_assert(!PRE, "the continuation from kern_kj_lane is kern_k1p_wave");
+    k1_wave_body<N, LG, false>(g, b, s, m, layers_per_block);
+}
+template <int N, int LG> __global__ void __launch_bounds__(64, SKD_WPE_K1P) kern_k1p_wave(Geo g, Bufs b, int s, int m, int layers_per_block) {
+    k1_wave_body<N, LG, true>(g, b, s, m, layers_per_block);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -1514,9 +1522,8 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
     double* zw = b.z + size_t(w) * nlyr * ntile * 256;
     double* hw = b.qlbuf + size_t(w) * nlyr * ntile * 64;
     const double* cwp = b.cwbuf + size_t(w) * g.n_lp;
-    const double* cme = g.lp_cosm + size_t(m) * g.n_lp;
-    const double* lpm4 = g.lpang4 + size_t(m) * g.nangle * NSTR;
-    const int2* lpmeta = reinterpret_cast<const int2*>(g.lp_meta);
+    const uint8_t* mrow = b.qlmask + size_t(w) * (g.n_lp / 8);
+    const double* pcm = g.lp_pc + size_t(m) * g.n_lp * NSTR;
     const bool last_is_ground = (m == 0);
     for (int tile0 = blockIdx.y * TILES; tile0 < ntile; tile0 += gridDim.y * TILES) {
         int los[TILES];
@@ -1559,31 +1566,34 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
 #else
                 if (ok[t]) {
 #endif
+                    // groups are padded to multiples of 8 entries (zero weights): per 4 entries two 16-byte loads of weights, eight of the
+                    // cos(m phi) P_l^m table (this lane's 32 bytes per entry) and the live flags of the 8 entries in one byte
                     const int base = (los[t] * g.nsza + s) * nlyr + p;
                     const int e0 = g.lp_start[base], e1 = g.lp_start[base + 1];
-                    for (int e = e0; e < e1; e += 4) {
-                        double c[4];
-                        double2 pa[4], pb[4];
+                    for (int e = e0; e < e1; e += 8) {
+                        const unsigned mk = mrow[e >> 3];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int ee = (e + u < e1) ? e + u : e1 - 1;
-                            const int2 meta = lpmeta[ee];  // (slot, angle)
-                            const bool live = (e + u < e1) && skd::conv_at(b, g, meta.x, w) > m;
-                            c[u] = live ? cwp[ee] * cme[ee] : 0.0;
-                            const double2* lp2 = reinterpret_cast<const double2*>(lpm4 + (size_t(meta.y) * 4 + q) * 4);
-                            pa[u] = lp2[0];
-                            pb[u] = lp2[1];
-                        }
+                        for (int h = 0; h < 2; ++h) {
+                            const double2* cw2 = reinterpret_cast<const double2*>(cwp + e + 4 * h);
+                            const double2* pc2 = reinterpret_cast<const double2*>(pcm + (size_t(e + 4 * h) * 4 + q) * 4);
+                            const double2 cv0 = cw2[0], cv1 = cw2[1];
+                            double2 pa[4], pb[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            ql4[0] += c[u] * pa[u].x;
-                            ql4[1] += c[u] * pa[u].y;
-                            ql4[2] += c[u] * pb[u].x;
-                            ql4[3] += c[u] * pb[u].y;
+                            for (int u = 0; u < 4; ++u) {
+                                pa[u] = pc2[8 * u];
+                                pb[u] = pc2[8 * u + 1];
+                            }
+                            const double c[4] = {((mk >> (4 * h)) & 1u) ? cv0.x : 0.0, ((mk >> (4 * h + 1)) & 1u) ? cv0.y : 0.0,
+                                                 ((mk >> (4 * h + 2)) & 1u) ? cv1.x : 0.0, ((mk >> (4 * h + 3)) & 1u) ? cv1.y : 0.0};
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                ql4[0] += c[u] * pa[u].x;
+                                ql4[1] += c[u] * pa[u].y;
+                                ql4[2] += c[u] * pb[u].x;
+                                ql4[3] += c[u] * pb[u].y;
+                            }
                         }
                     }
-                    for (int kk = 0; kk < 4; ++kk)
-                        if (4 * kk + q < m) ql4[kk] = 0.0;
                 }
                 mf4 acc = {0, 0, 0, 0}, hacc = {0, 0, 0, 0};
                 for (int kk = 0; kk < 4; ++kk) acc = mfma16(fpa[kk], ql4[kk], acc);

@@ -16,8 +16,7 @@ struct GeoTables {
     std::vector<int> ray_qstart, ray_ground, rl_od_start, od_idx, rl_ssa_start, ssa_idx, rl_active, rl_tab_start, tab_slot;
     std::vector<double> ray_gsaa, od_w, ssa_w, rl_azi, rl_cosm, rl_cosm_t, tab_w;
     std::vector<int> lp_start, lp_q, lp_angle, lp_slot, g_start, g_slot, g_sza;
-    std::vector<double> lp_w, g_w, lp_cosm, lpang4;
-    std::vector<int> lp_meta;
+    std::vector<double> lp_w, g_w, lp_pc;
     std::vector<int> slot_is_ground;  // [nslot]
     // plane-parallel post-processing
     int pp_mode = 0;
@@ -130,24 +129,31 @@ struct GeoTables {
         rl_cosm_t.resize(rl_cosm.size());
         for (int m = 0; m < nstr; ++m)
             for (int i = 0; i < nq_total; ++i) rl_cosm_t[size_t(i) * nstr + m] = rl_cosm[size_t(m) * nq_total + i];
+        // 16 streams (matrix-core sweeps): every non-empty (LOS, sza, layer) group is padded to a multiple of 8 entries with zero-weight
+        // copies of its first entry, so that kern_k2b_mfma8 reads a group's weights with 16-byte loads and its live flags as one byte per 8
+        if (nstr == 16)
+            for (auto& grp : lp)
+                while (grp.size() % 8 != 0) { LpE e = grp.front(); e.w = 0.0; grp.push_back(e); }
         lp_start.assign(lp.size() + 1, 0);
         for (size_t i = 0; i < lp.size(); ++i) {
             for (const auto& e : lp[i]) { lp_q.push_back(e.q); lp_angle.push_back(e.angle); lp_slot.push_back(e.slot); lp_w.push_back(e.w); }
             lp_start[i + 1] = (int)lp_q.size();
         }
-        lp_meta.resize(2 * lp_q.size());
-        for (size_t e = 0; e < lp_q.size(); ++e) { lp_meta[2 * e] = lp_slot[e]; lp_meta[2 * e + 1] = lp_angle[e]; }
         if (nstr == 16) {
-            lpang4.resize(lpang.size());
+            // per azimuth order and entry: cos(m azimuth of the entry's ray layer) P_l^m(table angle), l >= m, in the operand order of the
+            // sweeps -- lp_pc[((m n_lp + e) 4 + q) 4 + kk] = value for l = 4 kk + q: one contiguous 32 bytes per lane, nothing indirect
+            const size_t ne = lp_q.size();
+            lp_pc.assign(size_t(nstr) * ne * 16, 0.0);
             for (int m = 0; m < nstr; ++m)
-                for (int a = 0; a < nangle; ++a)
+                for (size_t e = 0; e < ne; ++e) {
+                    const double cm = rl_cosm[size_t(m) * nq_total + lp_q[e]];
                     for (int qq = 0; qq < 4; ++qq)
-                        for (int kk = 0; kk < 4; ++kk)
-                            lpang4[((size_t(m) * nangle + a) * 4 + qq) * 4 + kk] = lpang[(size_t(m) * nangle + a) * nstr + 4 * kk + qq];
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int l = 4 * kk + qq;
+                            lp_pc[((size_t(m) * ne + e) * 4 + qq) * 4 + kk] = (l >= m) ? cm * lpang[(size_t(m) * nangle + lp_angle[e]) * nstr + l] : 0.0;
+                        }
+                }
         }
-        lp_cosm.resize(size_t(nstr) * lp_q.size());
-        for (int m = 0; m < nstr; ++m)
-            for (size_t e = 0; e < lp_q.size(); ++e) lp_cosm[size_t(m) * lp_q.size() + e] = rl_cosm[size_t(m) * nq_total + lp_q[e]];
     }
 
     // plane-parallel mode: no diffuse table and no traced rays; every line of sight is (cos zenith, azimuth, observer altitude).
@@ -190,7 +196,7 @@ struct GeoTables {
         g.rl_ssa_start = rl_ssa_start.data(); g.ssa_idx = ssa_idx.data(); g.ssa_w = ssa_w.data();
         g.rl_azi = rl_azi.data(); g.rl_cosm = rl_cosm.data(); g.rl_cosm_t = rl_cosm_t.data(); g.rl_active = rl_active.data(); g.rl_tab_start = rl_tab_start.data();
         g.tab_slot = tab_slot.data(); g.tab_w = tab_w.data(); g.lp_start = lp_start.data(); g.lp_q = lp_q.data();
-        g.lp_angle = lp_angle.data(); g.lp_slot = lp_slot.data(); g.lp_w = lp_w.data(); g.lp_cosm = lp_cosm.data(); g.lp_meta = lp_meta.data(); g.lpang4 = lpang4.data(); g.g_start = g_start.data();
+        g.lp_angle = lp_angle.data(); g.lp_slot = lp_slot.data(); g.lp_w = lp_w.data(); g.lp_pc = lp_pc.data(); g.g_start = g_start.data();
         g.g_slot = g_slot.data(); g.g_sza = g_sza.data(); g.g_w = g_w.data();
         g.pp_mu = pp_mu.data(); g.pp_azi = pp_azi.data(); g.pp_first = pp_first.data(); g.pp_lf = pp_lf.data(); g.lplos = lplos.data();
         return g;
