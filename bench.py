@@ -32,7 +32,8 @@ HBM_PEAK_GBS = 8000.0                      # /opt/skills/guides/MI355X_MICROARCH
 FP64_VECTOR_PEAK_TFLOPS = 78.6             # MI355X datasheet (vector FP64)
 
 
-KERNEL_OF = {"kern_k1_wave": "k1_layer_solution", "kern_k2a_mfma8": "k2a_bvp", "kern_k2a_wave": "k2a_bvp",
+KERNEL_OF = {"kern_k1_wave": "k1_layer_solution", "kern_k1p_wave": "k1_layer_solution", "kern_kj_lane": "kj_eigen", "kern_k1_lane": "k1_layer_solution",
+             "kern_k2a_cols8": "k2a_bvp", "kern_qlmask": "k2q_live_flags", "kern_k2a_mfma8": "k2a_bvp", "kern_k2a_wave": "k2a_bvp",
              "kern_k2b_mfma8": "k2b_adjoint", "kern_k2b_wave": "k2b_adjoint", "kern_k2c_mfma8": "k2c_adjoint_ops",
              "kern_k2c_wave": "k2c_adjoint_ops", "kern_k3_wave": "k3_table_values", "kern_k4a": "k4a_chain", "kern_k4b": "k4b_los",
              "kern_k0": "k0_layer_optics", "kern_k0_shells": "k0_layer_optics", "kern_k0_los": "k0_layer_optics",
@@ -65,6 +66,41 @@ def load_pmc_profile():
     return out
 
 
+def host_cpus():
+    """(threads this process may really use, logical CPUs it is allowed on, physical cores of the host).  A container's CPU share
+    (cgroup cpu.max) can be far below its affinity mask: a GPU box shows 256 logical CPUs and grants about 16 of them, which is why a
+    256-thread run of the CPU baseline looked as if it did not scale."""
+    logical = len(os.sched_getaffinity(0))
+    usable = logical
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            usable = max(1, min(logical, int(round(int(q) / int(per)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                usable = max(1, min(logical, int(round(q / per))))
+        except (OSError, ValueError):
+            pass
+    physical = set()
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pid = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if pid is not None and cid is not None:
+                    physical.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return usable, logical, (len(physical) or logical)
+
+
 def whole_step_rates(pmc, wavelengths_per_s):
     t = pmc.get("_solve")
     if not t:
@@ -87,6 +123,7 @@ def main():
                          "(20 layers, 220 000 wavelengths, weighting functions); frontend: the optical-property front end (constituents -> storage and "
                          "derivative mappings in HBM) at the C2 size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer call (value_host_path)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="wavelengths of the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -177,44 +214,49 @@ def main():
     torch.cuda.synchronize()
     ktimes = solver.kernel_times()
     solver.set_profiling(False)
-    # the kernel of record is the one that costs the most device time when it has the device to itself (the adjoint sweeps: next to the
-    # other stages of the pipeline K1, K2a and K2b take about the same wall time each); it is priced with its duration IN the timed region
-    dominant = max(ktimes, key=lambda k: ktimes[k][0])
-    dom_ms, dom_n = live[dominant]
-    chunk = run_chunk                 # wavelengths per launch in the timed region
-    avg_launch_s = dom_ms / dom_n * 1e-3
-    iso_ms, iso_n = ktimes.get(dominant, (0.0, 0))
     # HBM bytes and FP64 operations per wavelength and launch of every kernel, measured with rocprofv3 PMC passes
     # (tools/profile_gpu.sh -> profiles/<round>/pmc_and_trace_summary.json; FETCH_SIZE x2-corrected as the guide prescribes)
     pmc = load_pmc_profile()
-    kp = pmc.get(dominant, {})
-    # the four kernels that carry the solve (layer eigen-solution, BVP elimination, adjoint operators, adjoint sweeps) are FP64
-    # vector / matrix-core kernels: they are priced against the FP64 peak; `traffic` and `hbm_traffic_frac` show their HBM side
-    flop_bound = dominant in ("k1_layer_solution", "k2a_bvp", "k2c_adjoint_ops", "k2b_adjoint")
-    if flop_bound and kp.get("flops_per_wavelength"):
-        achieved = kp["flops_per_wavelength"] * chunk / avg_launch_s / 1e12
-        roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
-                    "flops_per_launch": kp["flops_per_wavelength"] * chunk,
-                    "note": "FP64 operations executed (PMC: SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 x 64 lanes + matrix-core MOPS x 512), "
-                            "vector and matrix FP64 peak are both 78.6 TFLOP/s on MI355X"}
-    else:
-        achieved = ALGORITHMIC_BYTES_PER_WAVELENGTH * chunk / avg_launch_s / 1e9
-        roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS,
-                    "note": "achieved = algorithmic bytes of the whole path (28 160 B / wavelength) per launch of this kernel; "
-                            "the kernel's own HBM traffic is in `traffic`"}
-    roofline["traffic"] = kp["hbm_bytes_per_wavelength"] * chunk if kp.get("hbm_bytes_per_wavelength") else None
-    if roofline["traffic"]:
-        roofline["hbm_traffic_frac"] = roofline["traffic"] / avg_launch_s / 1e9 / HBM_PEAK_GBS   # measured bytes, not algorithmic ones
-    roofline.update({"algorithmic_bytes_per_wavelength": ALGORITHMIC_BYTES_PER_WAVELENGTH, "wavelengths_per_launch": chunk,
-                     "avg_launch_ms": dom_ms / dom_n, "launches": dom_n,
-                     "timing": "HIP events around every launch of the kernel on its own stream, over the timed region (the other stages of the "
-                               "order pipeline run next to it)"})
-    if iso_n:
-        # the kernel alone on the device (launch counts differ: the serialised pass stops at the last active azimuth order)
-        roofline["isolated"] = {"avg_launch_ms": iso_ms / iso_n, "launches": iso_n,
-                                "frac": roofline["frac"] * (dom_ms / dom_n) / (iso_ms / iso_n)}
+    chunk = run_chunk                 # wavelengths per launch in the timed region
+
+    def price(kernel):
+        """Roofline of one kernel, priced with its duration IN the timed region (HIP events around every launch on its own stream).
+        The kernels that carry the solve are FP64 vector / matrix-core kernels: FP64 operations executed against the 78.6 TFLOP/s peak,
+        with their measured HBM traffic beside it; the small streaming kernels are priced on bytes."""
+        dom_ms, dom_n = live[kernel]
+        avg_launch_s = dom_ms / dom_n * 1e-3
+        iso_ms, iso_n = ktimes.get(kernel, (0.0, 0))
+        kp = pmc.get(kernel, {})
+        flop_bound = kernel in ("k1_layer_solution", "kj_eigen", "k2a_bvp", "k2c_adjoint_ops", "k2b_adjoint")
+        if flop_bound and kp.get("flops_per_wavelength"):
+            achieved = kp["flops_per_wavelength"] * chunk / avg_launch_s / 1e12
+            r = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "flops_per_launch": kp["flops_per_wavelength"] * chunk,
+                 "note": "FP64 operations executed (PMC: SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 x 64 lanes + matrix-core MOPS x 512), "
+                         "vector and matrix FP64 peak are both 78.6 TFLOP/s on MI355X"}
+        else:
+            achieved = ALGORITHMIC_BYTES_PER_WAVELENGTH * chunk / avg_launch_s / 1e9
+            r = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                 "note": "achieved = algorithmic bytes of the whole path (28 160 B / wavelength) per launch of this kernel; "
+                         "the kernel's own HBM traffic is in `traffic`"}
+        r["traffic"] = kp["hbm_bytes_per_wavelength"] * chunk if kp.get("hbm_bytes_per_wavelength") else None
+        if r["traffic"]:
+            r["hbm_traffic_frac"] = r["traffic"] / avg_launch_s / 1e9 / HBM_PEAK_GBS   # measured bytes, not algorithmic ones
+        r.update({"algorithmic_bytes_per_wavelength": ALGORITHMIC_BYTES_PER_WAVELENGTH, "wavelengths_per_launch": chunk,
+                  "avg_launch_ms": dom_ms / dom_n, "launches": dom_n,
+                  "timing": "HIP events around every launch of the kernel on its own stream, over the timed region (the other stages of the "
+                            "order pipeline run next to it)"})
+        if iso_n:
+            # the kernel alone on the device (launch counts differ: the serialised pass stops at the last active azimuth order)
+            r["isolated"] = {"avg_launch_ms": iso_ms / iso_n, "launches": iso_n, "frac": r["frac"] * (dom_ms / dom_n) / (iso_ms / iso_n)}
+        return r
+
+    # two kernels of record: the one that costs the most device time when it has the device to itself (`roofline`) and the one with the
+    # largest total duration inside the pipelined timed region (`roofline_timed_region`, where the stages stretch each other)
+    dominant = max(ktimes, key=lambda k: ktimes[k][0])
+    dominant_live = max(live, key=lambda k: live[k][0])
+    roofline = price(dominant)
+    roofline_live = price(dominant_live)
 
     line = None
     if rank == 0:
@@ -231,6 +273,7 @@ def main():
                        "single_scatter_source": "discrete_ordinates", "num_sza": 1, "wavelengths_per_launch": run_chunk, "blocks_in_flight": run_slots},
             "valid": finite and status_bad == 0,
             "roofline": roofline,
+            "roofline_timed_region": roofline_live,
             "whole_step": whole_step_rates(pmc, value),
             # SURVEY.md 8d asks for both whole-path figures: algorithmic bytes (28 160 B / wavelength) and counted FP64 operations
             "whole_path": {"achieved_hbm_algorithmic_GBs": ALGORITHMIC_BYTES_PER_WAVELENGTH * value / 1e9,
@@ -240,10 +283,30 @@ def main():
             "kernels_ms_isolated": {k: {"total_ms": round(v[0], 3), "launches": v[1]} for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])},
             "scratch_gib": run_scratch / 2 ** 30,
         }
+    # ---- the drop-in caller's rate: one Engine.calculate_radiance() = sk_engine_calculate_radiance with HOST buffers in and
+    # out -- upload of the optical properties, the solve, the user weighting functions formed on the device, download of radiance + WFs
+    if rank == 0 and world == 1 and not args.no_host_path:
+        import sasktran2_amd as sk
+        atmosphere = sk.Atmosphere(geometry, config, numwavel=NW, calculate_derivatives=True)
+        atmosphere.storage.total_extinction[:] = s["extinction"]
+        atmosphere.storage.ssa[:] = s["ssa"]
+        atmosphere.leg_coeff.a1[:] = s["leg"]
+        atmosphere.surface.albedo[:] = s["albedo"]
+        engine.calculate_radiance(atmosphere, as_dataset=False)
+        gc.collect()
+        reps = 3
+        t = time.perf_counter()
+        for _ in range(reps):
+            host_res = engine.calculate_radiance(atmosphere, as_dataset=False)
+        dt_host = (time.perf_counter() - t) / reps
+        line["value_host_path"] = {"value": NW / dt_host, "unit": "wavelengths/s", "ms_per_call": dt_host * 1e3,
+                                   "what": "Engine.calculate_radiance / sk_engine_calculate_radiance with host buffers: H2D of ext / ssa / "
+                                           "Legendre / albedo, solve, D2H of radiance + wf_extinction + wf_ssa + wf_albedo inside the timer",
+                                   "radiance_equals_device_path": bool(np.array_equal(host_res["radiance"][:, :, 0], out["radiance"].cpu().numpy()))}
     # ---- CPU baseline: the oracle (same algorithm as the reference CPU engine, OpenMP over wavelengths) on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from tests.test_oracle_golden import make_oracle
-        cores = len(os.sched_getaffinity(0))
+        cores, logical_cpus, physical_cores = host_cpus()
         eng = make_oracle(s)
         probe = max(cores, 8)
         idx = np.linspace(0, NW - 1, probe).astype(int)
@@ -261,7 +324,7 @@ def main():
         refwf = np.transpose(ref["d_extinction"], (2, 0, 1))
         wf_parity = float(np.max(np.abs(wf - refwf) / np.abs(refwf).max(axis=0, keepdims=True)))
         # one-thread rate of the same port on a handful of wavelengths, and the host CPU model
-        idx1 = np.linspace(0, NW - 1, 4).astype(int)
+        idx1 = np.linspace(0, NW - 1, 8).astype(int)
         t = time.perf_counter()
         eng.run(s["extinction"][:, idx1], s["ssa"][:, idx1], s["leg"][:, :, idx1], s["albedo"][idx1], derivatives=True, nthreads=1)
         one_thread = len(idx1) / (time.perf_counter() - t)
@@ -273,6 +336,11 @@ def main():
             pass
         line["cpu_baseline"] = {"value": n / dt, "unit": "wavelengths/s", "cores": cores, "kind": "port",
                                 "one_thread_value": one_thread, "cpu_model": cpu_model,
+                                "threads_scaling": (n / dt) / one_thread,
+                                "host_logical_cpus": logical_cpus, "host_physical_cores": physical_cores,
+                                "cores_note": "cores = threads used = the CPU share this process is granted (cgroup cpu.max), not the affinity mask",
+                                "one_thread_x_physical_cores": one_thread * physical_cores,
+                                "value_over_whole_host_estimate": line["value"] / (one_thread * physical_cores),
                                 "sample": f"{n} of the {NW} wavelengths (evenly spaced), same workload incl. weighting functions, {dt:.1f} s",
                                 "parity_radiance_max_rel": parity, "parity_wf_extinction_max_rel_to_profile_max": wf_parity}
         line["speedup_vs_cpu_baseline"] = line["value"] / (n / dt)

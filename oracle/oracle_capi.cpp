@@ -3,6 +3,7 @@
 //
 // Threading mirrors the reference engine: one `#pragma omp parallel for` over wavelengths with
 // thread-private solver workspaces (cpp/lib/engine/engine.cpp:610-622).
+#include <malloc.h>
 #include <cstdio>
 #include <memory>
 #include <string>
@@ -24,6 +25,17 @@ struct Handle {
     const double *emission = nullptr, *surface_emission = nullptr;
     std::string error;
 };
+}  // namespace
+
+namespace {
+// Worker threads allocate and free their per-wavelength work arrays (hundreds of KB each) all the time: keep them inside the thread's malloc
+// arena instead of mmap / munmap per array (the address-space lock would serialise the OpenMP threads of the CPU baseline).
+struct MallocTuning {
+    MallocTuning() {
+        mallopt(M_MMAP_THRESHOLD, 1 << 30);
+        mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    }
+} malloc_tuning;
 }  // namespace
 
 extern "C" {

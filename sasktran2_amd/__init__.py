@@ -8,6 +8,7 @@ include/sasktran2_amd.h.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import enum
 
@@ -461,14 +462,62 @@ class Engine:
             if rc != 0:
                 raise RuntimeError(f"sk_atmosphere_apply_delta_m_scaling returned {rc}")
 
+    @contextlib.contextmanager
+    def _constituent_atmosphere(self, atmosphere):
+        """Atmosphere handle of a constituent atmosphere for one call: the storage assembled in HBM by the front end, a surface with the
+        surface derivative mappings of the constituents, delta-M scaling applied as `calculate_radiance` does.  Yields (front end, surface
+        handle, atmosphere handle) and destroys the per-call handles afterwards."""
+        L = lib()
+        fe = atmosphere.internal_object()
+        nw, S = atmosphere._nwavel, int(self._config.num_stokes)
+        alb = np.ascontiguousarray(atmosphere.surface.albedo, dtype=float)
+        emis = np.ascontiguousarray(atmosphere.surface.emission, dtype=float)
+        h_brdf = L.sk_brdf_create_lambertian(S)
+        h_su = L.sk_surface_create(nw, S, _p(emis))
+        L.sk_surface_set_brdf(h_su, h_brdf, _p(alb))
+        h_atm = L.sk_atmosphere_create(fe.storage_handle(), h_su, int(atmosphere.calculate_derivatives), 0)
+        try:
+            for name, (_, _, d_brdf, d_emission) in atmosphere._surface_mappings.items():
+                m = ctypes.c_void_p()
+                L.sk_surface_get_derivative_mapping(h_su, name.encode(), ctypes.byref(m))
+                ptr = _dp()
+                L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
+                np.ctypeslib.as_array(ptr, shape=(nw,))[:] = d_brdf
+                if d_emission is not None:
+                    L.sk_surface_deriv_mapping_get_d_emission(m, ctypes.byref(ptr))
+                    np.ctypeslib.as_array(ptr, shape=(nw,))[:] = d_emission
+            if self._config.delta_m_scaling and atmosphere.num_moments > self._config.num_streams:
+                rc = L.sk_atmosphere_apply_delta_m_scaling(h_atm, int(self._config.num_streams))
+                if rc != 0:
+                    raise RuntimeError(f"sk_atmosphere_apply_delta_m_scaling returned {rc}: {last_error()}")
+            yield fe, h_su, h_atm
+        finally:
+            L.sk_atmosphere_destroy(h_atm)
+            L.sk_surface_destroy(h_su)
+            L.sk_brdf_destroy(h_brdf)
+            del alb, emis
+
     def calculate_jvp(self, atmosphere, tangents, surface_tangents=None):
         """Jacobian-vector product (src/sasktran2/engine.py:170-312, `sk_engine_calculate_jvp`): `tangents` maps a derivative-mapping
         name ("wf_extinction", "wf_ssa") to a vector over its outputs, `surface_tangents` ("wf_albedo") to one value per wavelength.
         Returns (radiance, jvp), both [wavelength, los, stokes]."""
         L = lib()
-        H, delta_order = self._prepare(atmosphere, True)
-        self._apply_delta_m(H, delta_order)
         nw, S = atmosphere._nwavel, int(self._config.num_stokes)
+        with contextlib.ExitStack() as stack:
+            if atmosphere._constituents:
+                # constituent interface: tangents are keyed by the mapping names of the constituents ("wf_o3_vmr", ...), one value per
+                # output of the mapping; the storage stays in HBM
+                if not atmosphere.calculate_derivatives:
+                    raise ValueError("calculate_jvp needs an Atmosphere with calculate_derivatives=True")
+                _, _, h_atm = stack.enter_context(self._constituent_atmosphere(atmosphere))
+            else:
+                H, delta_order = self._prepare(atmosphere, True)
+                self._apply_delta_m(H, delta_order)
+                h_atm = H["atmosphere"]
+            return self._jvp_on_handle(L, h_atm, nw, S, tangents, surface_tangents)
+
+    def _jvp_on_handle(self, L, h_atm, nw, S, tangents, surface_tangents):
+        H = {"atmosphere": h_atm}
         rad, jvp = np.zeros((nw, self.nlos, S)), np.zeros((nw, self.nlos, S))
         h = L.sk_output_jvp_create(_p(rad), _p(jvp), nw * self.nlos, S)
         keep = []
@@ -491,17 +540,40 @@ class Engine:
     def calculate_vjp(self, atmosphere, cotangent, names=("wf_extinction", "wf_ssa"), surface_names=("wf_albedo",)):
         """Vector-Jacobian product (`sk_engine_calculate_vjp`): cotangent [wavelength, los, stokes] -> (radiance, {name: gradient})."""
         L = lib()
-        H, delta_order = self._prepare(atmosphere, True)
-        self._apply_delta_m(H, delta_order)
         nw, S, ngrid = atmosphere._nwavel, int(self._config.num_stokes), atmosphere._ngrid
+        with contextlib.ExitStack() as stack:
+            if atmosphere._constituents:
+                # constituent interface: one gradient per derivative mapping of the constituents (all of them unless `names` /
+                # `surface_names` were given explicitly), of the mapping's own output size
+                if not atmosphere.calculate_derivatives:
+                    raise ValueError("calculate_vjp needs an Atmosphere with calculate_derivatives=True")
+                fe, _, h_atm = stack.enter_context(self._constituent_atmosphere(atmosphere))
+                if names == ("wf_extinction", "wf_ssa"):
+                    names = tuple(fe.mappings)
+                if surface_names == ("wf_albedo",):
+                    surface_names = tuple(atmosphere._surface_mappings)
+                sizes = {}
+                for name in names:
+                    if name not in fe.mappings:
+                        raise KeyError(f"unknown derivative mapping {name!r}; the constituents registered {sorted(fe.mappings)}")
+                    sizes[name] = fe.mappings[name].num_output
+            else:
+                H, delta_order = self._prepare(atmosphere, True)
+                self._apply_delta_m(H, delta_order)
+                h_atm = H["atmosphere"]
+                sizes = {name: ngrid for name in names}
+            return self._vjp_on_handle(L, h_atm, nw, S, cotangent, names, surface_names, sizes)
+
+    def _vjp_on_handle(self, L, h_atm, nw, S, cotangent, names, surface_names, sizes):
+        H = {"atmosphere": h_atm}
         rad = np.zeros((nw, self.nlos, S))
         cot = np.ascontiguousarray(cotangent, dtype=float).reshape(nw, self.nlos, S)
         h = L.sk_output_vjp_create(_p(rad), _p(cot), nw * self.nlos, S)
         grads = {}
         try:
             for name in names:
-                grads[name] = np.zeros(ngrid)
-                L.sk_output_vjp_assign_derivative_gradient(h, name.encode(), _p(grads[name]), ngrid)
+                grads[name] = np.zeros(sizes[name])
+                L.sk_output_vjp_assign_derivative_gradient(h, name.encode(), _p(grads[name]), sizes[name])
             for name in surface_names:
                 grads[name] = np.zeros(nw)
                 L.sk_output_vjp_assign_surface_gradient(h, name.encode(), _p(grads[name]), nw)

@@ -134,6 +134,8 @@ struct Bufs {
     double* rec;            // [w][p][REC]   (record-major, see rec_at)
     double* dinv;           // [w][p][4N^2]
     double* xsol;           // [w][p][2N]
+    double* eig;            // [p][N + N N][w]  eigen-solutions from kern_kj_lane<N, true> for kern_k1_lane (16 streams, spherical)
+    int k1_lane;            // 1: records written by kern_k1_lane -- Rec::DG holds the coefficient vectors, kern_k2c_mfma8 forms DG itself
     double* J;              // [w][slot][m]   (see J_at; the orders of a table point are contiguous)
     uint8_t* conv_order;    // [w][slot]  first azimuth order that is skipped for this table point (see conv_at)
     int* notconv;           // [w]

@@ -359,7 +359,7 @@ size_t DeviceEngine::bytes_per_wavelength() const {
     size_t d = 0;
     d += nlyr * (3 + nstr) + (nlyr + 1) + nlyr;              // tau, om, kbar, a, T, sec
     d += size_t(t.nq_total) * 3 + nlos;                      // od, omloc, srcw, att_total
-    if (N == 8) d += t.lp_q.size() + t.lp_q.size() / 64 + 1; // cwbuf, qlmask
+    if (N == 8) d += t.lp_q.size() + t.lp_q.size() / 64 + 1 + nlyr * (N + N * N); // cwbuf, qlmask, eig
     d += 2 * (nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N);  // rec, dinv, xsol (two buffers each)
     d += nstr * size_t(t.nslot);                             // J
     const size_t nlos_pad = (nlos + 15) / 16 * 16;
@@ -401,6 +401,7 @@ void DeviceEngine::ensure_scratch(int nw, int nslots) {
         b.od = M.alloc<double>(size_t(t.nq_total) * W); b.omloc = M.alloc<double>(size_t(t.nq_total) * W);
         b.srcw = M.alloc<double>(size_t(t.nq_total) * W); b.att_total = M.alloc<double>(nlos * W);
         b.cwbuf = M.alloc<double>(t.N == 8 ? t.lp_q.size() * W : 1);
+        b.eig = M.alloc<double>(t.N == 8 ? nlyr * (N + N * N) * W : 1);
         b.qlmask = M.alloc<uint8_t>(t.N == 8 ? t.lp_q.size() / 8 * W + 8 : 8);
         b.rec = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W); b.dinv = M.alloc<double>(nlyr * 4 * N * N * W);
         sl->rec2 = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W);
@@ -469,6 +470,21 @@ static bool launch_kj(hipStream_t st, const Geo& g, const Bufs& b, int m) {
         }
     }
     return false;
+}
+// 16 streams, spherical post-processing: the whole layer solution one (layer, wavelength) per lane -- kern_kj_lane<8, true> hands the
+// eigen-solutions over in b.eig, kern_k1_lane writes the records (with the coefficient vectors in place of Rec::DG, see Bufs::k1_lane).
+// Opt-in (SASKTRAN2_AMD_K1=lane): measured on MI355X it computes a launch in a fraction of the cooperative kernel's instruction count but
+// its record stores -- 64-byte runs scattered over each lane's 4.7 KB record, written a solution column at a time -- cost 2.1 x their bytes
+// in HBM write traffic (346 KB instead of 163 KB per wavelength and order) and the kernel ends up write-bound at the cooperative kernel's
+// duration (25 ms per step); it needs a record layout with a column's entries contiguous to pay off.
+static bool k1_lane_enabled() {
+    const char* e = std::getenv("SASKTRAN2_AMD_K1");
+    return e && std::string(e) == "lane";
+}
+static void launch_k1_lane8(hipStream_t st, const Geo& g, const Bufs& b, int s, int m) {
+    const dim3 grid(unsigned((b.nw + 63) / 64), unsigned(g.nlyr));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_kj_lane<8, true>), grid, dim3(64), 0, st, g, b, m);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_lane<8>), grid, dim3(64), 0, st, g, b, s, m);
 }
 // K1 launch: lane-group width per layer and the split of the layers over blockIdx.y
 template <int N>
@@ -619,7 +635,10 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                     HIP_CHECK(hipStreamWaitEvent(st, slot.ev_rest[m - 2], 0));
                 }
             }
-            {
+            if (N == 8 && b.k1_lane) {
+                Timer t(I, sA, "k1_layer_solution");
+                launch_k1_lane8(sA, g, b, s, m);
+            } else {
                 bool pre;
                 { Timer t(I, sA, "kj_eigen"); pre = launch_kj<N>(sA, g, b, m); }
                 Timer t(I, sA, "k1_layer_solution");
@@ -661,7 +680,10 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                         int split = std::max(3, small_batch_split(int(nw)));
                         if (const char* e = std::getenv("SASKTRAN2_AMD_K2C_SPLIT")) split = std::max(1, atoi(e));
                         const int lpb = (g.nlyr + split - 1) / split, ny = (g.nlyr + lpb - 1) / lpb;
-                        hipLaunchKernelGGL(kern_k2c_mfma8, dim3(unsigned(nw), unsigned(ny)), dim3(64), 0, sC, g, b, s, m, lpb);
+                        if (b.k1_lane)
+                            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true>), dim3(unsigned(nw), unsigned(ny)), dim3(64), 0, sC, g, b, s, m, lpb);
+                        else
+                            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<false>), dim3(unsigned(nw), unsigned(ny)), dim3(64), 0, sC, g, b, s, m, lpb);
                     }
                     if (g.n_lp > 0) {
                         Timer t2(I, sC, "k2q_live_flags");
@@ -783,6 +805,7 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
         I.thermal_nw_total = nwavel;
         b.nleg = nleg;
         b.derivs = derivs;
+        b.k1_lane = (t.N == 8 && !I.g.pp_mode && k1_lane_enabled()) ? 1 : 0;
         switch (t.N) {
             case 1: run_chunk<1>(I, slot, cs, derivs); break;
             case 2: run_chunk<2>(I, slot, cs, derivs); break;

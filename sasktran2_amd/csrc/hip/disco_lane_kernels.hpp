@@ -60,7 +60,9 @@ __device__ __forceinline__ double kj_rcp(double x) {
 // A lane whose problem has converged is frozen (identity rotations), so a problem's result does not depend on the other
 // problems of its wavefront.
 // -------------------------------------------------------------------------------------------------------------------
-template <int N> __global__ void __launch_bounds__(64, SKD_WPE_KJ) kern_kj_lane(Geo g, Bufs b, int m) {
+// SOA = true: the eigen-solution goes to b.eig[(layer * (N + N N) + e) * nw + w] (e < N: k_j^2; then Xhat(i, j) = (T X)(i, j), the
+// eigenvectors before the T^-1 scaling) with plain coalesced stores, for kern_k1_lane.
+template <int N, bool SOA = false> __global__ void __launch_bounds__(64, SKD_WPE_KJ) kern_kj_lane(Geo g, Bufs b, int m) {
     constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, HALF = NOUT / 2, STRIDE = HALF + 1, NM1 = N - 1, JH = N / 2;
     static_assert(NOUT % 2 == 0, "two output halves");
     using R = skd::Rec<N>;
@@ -247,6 +249,18 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_KJ) kern_kj_lane(
         }
     }
     if (live && err) atomicOr(&b.status[w], err);
+    if constexpr (SOA) {
+        if (live) {
+            double* out = b.eig + size_t(p) * NOUT * nw + w;
+#pragma unroll
+            for (int j = 0; j < N; ++j) out[size_t(j) * nw] = lam[j];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) out[size_t(N + i * N + j) * nw] = V[i][j];
+        }
+        return;
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
@@ -295,6 +309,308 @@ __device__ __forceinline__ double row16_sum(double v) {
     v += row_dpp64<0x124>(v);  // row_ror 4
     v += row_dpp64<0x128>(v);  // row_ror 8
     return v;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// K1 lane per problem: everything of skd::k1_layer_solution after the eigen-decomposition -- U = S+ X, the eigen-pair derivatives
+// by bi-orthogonal perturbation sums, W+-, dW+-, the Green's function coefficients and the particular solution G -- for one
+// (layer, wavelength) per LANE (reference: sktran_do_rte.cpp:164-298,555-580,902-1332).  Works in the symmetrised variables
+// Xhat = T X, Uhat = T U (T = diag sqrt(w mu)):  Uhat = B+ Xhat,  Mhat_j = (2 k_j^2 xhat_j - xhat_j / mu ... ) see below,
+// z = Uhat^T Mhat,  C_aj = z_aj / (k_j^2 - k_a^2),  dXhat = Xhat C,  dUhat = (Uhat - Xhat / mu) / omega + Uhat C   (B+ dXhat = Uhat C).
+// Solution columns are processed one at a time against the resident Xhat and Uhat (128 registers pairs); B- waits in LDS
+// ([entry][lane], conflict free); a column's 49 record entries leave through a 25-double LDS staging row per lane so that the
+// stores of a record are runs of 8 doubles.  The derivative rows of G (Rec::DG) are NOT formed here: the record's DG area
+// receives the coefficient vectors coef[(type * 5 + k) * N + j] instead and kern_k2c_mfma8 forms DG = [W+; W-] coef as
+// matrix-core products where it needs them (Bufs::k1_lane).
+//   grid = (ceil(nw / 64), nlyr), block = 64, one wavefront per SIMD (the kernel owns the register file).
+// -------------------------------------------------------------------------------------------------------------------
+#ifdef SKD_K1L_NOSTORE
+#define SKD_K1L_OUT(b, nlyr, p, w) if (sOut[0] == 12345.678) skd::rec_at<N>(b, nlyr, p, w)
+#else
+#define SKD_K1L_OUT(b, nlyr, p, w) skd::rec_at<N>(b, nlyr, p, w)
+#endif
+template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bufs b, int s, int m) {
+    constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, CH = 25;
+    using R = skd::Rec<N>;
+    const int lane = threadIdx.x, p = blockIdx.y, nw = b.nw, nlyr = g.nlyr;
+    const int w0 = blockIdx.x * 64, w = w0 + lane;
+    __shared__ double sPP[NPAIR * NSTR];   // sqrt(w_i w_j / mu_i mu_j) P_{m+k}(mu_i) P_{m+k}(mu_j), pair (i >= j), k = l - m
+    __shared__ double sQ[N * NSTR];        // fm w_i P_{m+k}(mu_i) P_{m+k}(mu_0)
+    __shared__ double sIm[N], sIt[N], sWm[N];
+    __shared__ double sBm[NPAIR * 64];
+    __shared__ double sOut[64 * CH];
+    const bool live = (w < nw) && (m < b.norders[min(w, nw - 1)]);
+    if (!__any(live)) return;
+    const int wl = min(w, nw - 1);
+    const unsigned long long livemask = __ballot(live);
+    {
+        const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
+        const double* lpc = g.lpcsz + (size_t(s) * NSTR + m) * NSTR;
+        const double fm = (m == 0 ? 1.0 : 2.0) / (4.0 * skd::kPi);
+        for (int e = lane; e < NPAIR * NSTR; e += 64) {
+            const int pr = e / NSTR, k = e % NSTR, l = m + k;
+            int i = 0;
+            while ((i + 1) * (i + 2) / 2 <= pr) ++i;
+            const int j = pr - i * (i + 1) / 2;
+            sPP[e] = (l < NSTR) ? sqrt(g.wt[i] / g.mu[i]) * sqrt(g.wt[j] / g.mu[j]) * lpmu[i * NSTR + l] * lpmu[j * NSTR + l] : 0.0;
+        }
+        for (int e = lane; e < N * NSTR; e += 64) {
+            const int i = e / NSTR, k = e % NSTR, l = m + k;
+            sQ[e] = (l < NSTR) ? fm * g.wt[i] * lpmu[i * NSTR + l] * lpc[l] : 0.0;
+        }
+        if (lane < N) {
+            sIm[lane] = 1.0 / g.mu[lane];
+            sIt[lane] = 1.0 / sqrt(g.wt[lane] * g.mu[lane]);
+            sWm[lane] = g.wt[lane] * g.mu[lane];
+        }
+    }
+    double a[NSTR];
+#pragma unroll
+    for (int k = 0; k < NSTR; ++k) a[k] = (m + k < NSTR) ? b.a[(size_t(p) * NSTR + m + k) * nw + wl] : 0.0;
+    const double om = b.om[size_t(p) * nw + wl], th = b.tau[size_t(p) * nw + wl];
+    const double T = b.T[size_t(p) * nw + wl], sc = b.sec[size_t(p) * nw + wl];
+    const double inv_om = 1.0 / om;
+    double xh[N][N], lam[N];
+    {
+        const double* in = b.eig + size_t(p) * NOUT * nw + wl;
+#pragma unroll
+        for (int j = 0; j < N; ++j) lam[j] = in[size_t(j) * nw];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) xh[i][j] = in[size_t(N + i * N + j) * nw];
+    }
+    __syncthreads();
+    int err = 0;
+    // ---- B+ (registers, lower triangle) and B- (LDS);  solar pseudo-source Q+- (sktran_do_rte.cpp:555-580);  Uhat = B+ Xhat
+    double uh[N][N], qp[N], qm[N];
+    bool allzero = true;
+    {
+        double bp[N][N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                const double* pp = &sPP[(i * (i + 1) / 2 + j) * NSTR];
+                double ep = 0, em = 0;
+#pragma unroll
+                for (int k = 0; k < NSTR; k += 2) {
+                    ep = fma(a[k], pp[k], ep);
+                    em = fma(a[k + 1], pp[k + 1], em);
+                }
+                const double dlt = (i == j) ? sIm[i] : 0.0;
+                bp[i][j] = fma(-om, ep, dlt);
+                sBm[(i * (i + 1) / 2 + j) * 64 + lane] = fma(-om, em, dlt);
+            }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double sp = 0, sn = 0;
+#pragma unroll
+            for (int k = 0; k < NSTR; k += 2) {
+                sp = fma(a[k], sQ[i * NSTR + k], sp);
+                sn = fma(a[k + 1], sQ[i * NSTR + k + 1], sn);
+            }
+            qp[i] = (sp + sn) * om;
+            qm[i] = (sp - sn) * om;
+            allzero = allzero && (qp[i] == 0.0) && (qm[i] == 0.0);
+        }
+        SKD_QR_FENCE
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double t = 0;
+#pragma unroll
+                for (int r = 0; r < N; ++r) t = fma((i >= r) ? bp[i][r] : bp[r][i], xh[r][j], t);
+                uh[i][j] = t;
+            }
+    }
+    // ---- separation constants
+    double lmax = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double l = lam[j];
+        if (!(l > 0)) { err |= skd::ERR_EIGEN; l = fabs(l) + 1e-300; lam[j] = l; }
+        lmax = fmax(lmax, l);
+    }
+    const double es = exp(-th * sc), invT = (T != 0) ? 1.0 / T : 0.0;
+    double cf0[2][N];   // coefficient of the particular solution itself, type 0: A- C-, type 1: A+ C+
+    // ---- solution columns
+    static_for<N>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        SKD_QR_FENCE
+        const double ikj = kj_rsqrt(lam[j]), kj = lam[j] * ikj, ej = exp(-th * kj);
+        // Mhat_j = (2 k_j^2 xhat_j - uhat_j / mu - B- (xhat_j / mu)) / omega
+        double mh[N];
+        {
+            double y[N], hh[N];
+#pragma unroll
+            for (int r = 0; r < N; ++r) { y[r] = sIm[r] * xh[r][j]; hh[r] = 0; }
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int r = 0; r <= i; ++r) {
+                    const double v = sBm[(i * (i + 1) / 2 + r) * 64 + lane];
+                    hh[i] = fma(v, y[r], hh[i]);
+                    if (r != i) hh[r] = fma(v, y[i], hh[r]);
+                }
+#pragma unroll
+            for (int i = 0; i < N; ++i) mh[i] = (2.0 * xh[i][j] * lam[j] - sIm[i] * uh[i][j] - hh[i]) * inv_om;
+        }
+        // z_a = uhat_a . Mhat_j;  dk_j = z_j / (2 k_j);  C_aj = z_a / (k_j^2 - k_a^2)
+        double cc[N], dk = 0;
+#pragma unroll
+        for (int aa = 0; aa < N; ++aa) {
+            double z = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) z = fma(uh[i][aa], mh[i], z);
+            if (aa == j) { dk = 0.5 * z * ikj; cc[aa] = 0; }
+            else {
+                const double den = lam[j] - lam[aa];
+                const bool okd = fabs(den) > 1e-13 * lmax;
+                cc[aa] = okd ? z * kj_rcp(okd ? den : 1.0) : 0.0;
+            }
+        }
+        // dxhat = Xhat C_j,  duhat = (uhat_j - xhat_j / mu) / omega + Uhat C_j,  W+- = T^-1 (xhat +- uhat / k) / 2 and derivatives;
+        // the W+, W-, dW+ columns go straight to the staging row (the previous chunk has left it), dW- waits for the second chunk;
+        // the sums of the Green's function coefficients of solution j run along (sktran_do_rte.cpp:1039-1237)
+        __syncthreads();
+        double dwm[N];
+        double nrm = 0, dnrm = 0, Ap = 0, Am = 0, dAp = 0, dAm = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double dx = 0, du = (uh[i][j] - sIm[i] * xh[i][j]) * inv_om;
+#pragma unroll
+            for (int aa = 0; aa < N; ++aa) {
+                if (aa == j) continue;
+                dx = fma(xh[i][aa], cc[aa], dx);
+                du = fma(uh[i][aa], cc[aa], du);
+            }
+            const double uk = uh[i][j] * ikj, duk = du * ikj - uh[i][j] * dk * ikj * ikj;
+            const double hs = 0.5 * sIt[i];
+            const double wp = hs * (xh[i][j] + uk), wm = hs * (xh[i][j] - uk), dwp = hs * (dx + duk);
+            dwm[i] = hs * (dx - duk);
+            sOut[lane * CH + i] = wp;
+            sOut[lane * CH + N + i] = wm;
+            sOut[lane * CH + 2 * N + i] = dwp;
+            const double wmu = sWm[i];
+            nrm = fma(wmu, wp * wp - wm * wm, nrm);
+            dnrm = fma(2.0 * wmu, wp * dwp - wm * dwm[i], dnrm);
+            Ap += qp[i] * wp + qm[i] * wm;
+            Am += qm[i] * wp + qp[i] * wm;
+            const double ep_ = fma(inv_om, wp, dwp), em_ = fma(inv_om, wm, dwm[i]);
+            dAp += qp[i] * ep_ + qm[i] * em_;
+            dAm += qm[i] * ep_ + qp[i] * em_;
+        }
+        skd::Mult Cp{0, 0, 0, 0}, Cm{0, 0, 0, 0};
+        if (allzero) {
+            Ap = Am = dAp = dAm = 0;
+        } else {
+            const double inv = 1.0 / nrm;
+            Ap *= inv;
+            Am *= inv;
+            dAp = (dAp - dnrm * Ap) * inv;
+            dAm = (dAm - dnrm * Am) * inv;
+            skd::green_multipliers_e(T, th, sc, kj, ej, es, Cp, Cm);
+        }
+        const double dCm[4] = {Cm.d_tau, Cm.d_k * dk, Cm.v * invT, Cm.d_sec};
+        const double dCp[4] = {Cp.d_tau, Cp.d_k * dk, Cp.v * invT, Cp.d_sec};
+        double coef[10];
+        coef[0] = Am * Cm.v;
+        coef[5] = Ap * Cp.v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            coef[1 + t] = Am * dCm[t] + ((t == skd::TH_OM) ? dAm * Cm.v : 0.0);
+            coef[6 + t] = Ap * dCp[t] + ((t == skd::TH_OM) ? dAp * Cp.v : 0.0);
+        }
+        cf0[0][j] = coef[0];
+        cf0[1][j] = coef[5];
+        // chunk A = W+ W- dW+ columns (24 entries), chunk B = dW- column, coefficients, scalars (25)
+        __syncthreads();
+#pragma unroll 5
+        for (int idx = lane; idx < 64 * CH; idx += 64) {
+            const int rl = idx / CH, e = idx - rl * CH;
+            if (e >= 3 * N || !((livemask >> rl) & 1ull)) continue;
+            const int f = e / N, i = e % N;
+            SKD_K1L_OUT(b, nlyr, p, w0 + rl)[((f == 0) ? R::WP : (f == 1) ? R::WM : R::DWP) + N * j + i] = sOut[idx];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; ++i) sOut[lane * CH + i] = dwm[i];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) sOut[lane * CH + N + t] = coef[t];
+        sOut[lane * CH + N + 10] = kj;
+        sOut[lane * CH + N + 11] = dk;
+        sOut[lane * CH + N + 12] = ej;
+        sOut[lane * CH + N + 13] = Ap;
+        sOut[lane * CH + N + 14] = Am;
+        sOut[lane * CH + N + 15] = dAp;
+        sOut[lane * CH + N + 16] = dAm;
+        __syncthreads();
+#pragma unroll 5
+        for (int idx = lane; idx < 64 * CH; idx += 64) {
+            const int rl = idx / CH, e = idx - rl * CH;
+            if (e >= N + 17 || !((livemask >> rl) & 1ull)) continue;
+            int dest;
+            if (e < N) dest = R::DWM + N * j + e;
+            else if (e < N + 10) dest = R::DG + (e - N) * N + j;
+            else {
+                const int f = e - N - 10;
+                dest = ((f == 0) ? R::K : (f == 1) ? R::DK : (f == 2) ? R::E : (f == 3) ? R::AP : (f == 4) ? R::AM : (f == 5) ? R::DAP : R::DAM) + j;
+            }
+            SKD_K1L_OUT(b, nlyr, p, w0 + rl)[dest] = sOut[idx];
+        }
+    });
+    // ---- particular solution at the layer edges, G[c][i] = sum_j Wsel(i, j) coef0_type(j):  W+- coef = T^-1 (Xhat coef +- Uhat (coef / k)) / 2
+    //      c = 0: (W-, A- C-), 1: (W+, A- C-), 2: (W+, A+ C+), 3: (W-, A+ C+)
+    {
+        double gx[2][N], gu[2][N], cfk[2][N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double ikj = kj_rsqrt(lam[j]);
+            cfk[0][j] = cf0[0][j] * ikj;
+            cfk[1][j] = cf0[1][j] * ikj;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double sx = 0, su = 0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    sx = fma(xh[i][j], cf0[t][j], sx);
+                    su = fma(uh[i][j], cfk[t][j], su);
+                }
+                gx[t][i] = sx;
+                gu[t][i] = su;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double hs = 0.5 * sIt[i];
+            sOut[lane * CH + i] = hs * (gx[0][i] - gu[0][i]);
+            sOut[lane * CH + N + i] = hs * (gx[0][i] + gu[0][i]);
+            sOut[lane * CH + 2 * N + i] = hs * (gx[1][i] + gu[1][i]);
+        }
+        __syncthreads();
+#pragma unroll 5
+        for (int idx = lane; idx < 64 * CH; idx += 64) {
+            const int rl = idx / CH, e = idx - rl * CH;
+            if (e >= 3 * N || !((livemask >> rl) & 1ull)) continue;
+            SKD_K1L_OUT(b, nlyr, p, w0 + rl)[R::G + e] = sOut[idx];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; ++i) sOut[lane * CH + i] = 0.5 * sIt[i] * (gx[1][i] - gu[1][i]);
+        __syncthreads();
+#pragma unroll 5
+        for (int idx = lane; idx < 64 * CH; idx += 64) {
+            const int rl = idx / CH, e = idx - rl * CH;
+            if (e >= N || !((livemask >> rl) & 1ull)) continue;
+            SKD_K1L_OUT(b, nlyr, p, w0 + rl)[R::G + 3 * N + e] = sOut[idx];
+        }
+    }
+    if (live && err) atomicOr(&b.status[w], err);
 }
 
 // Inverse of a 16 x 16 matrix by Householder QR, column per lane:  H_15 .. H_0 [A | I] = [R | Q^T],  A^-1 = R^-1 Q^T.

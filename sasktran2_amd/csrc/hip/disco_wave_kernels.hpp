@@ -171,14 +171,38 @@ template <int N, int LG, bool PRE> __device__ __forceinline__ void k1_wave_body(
 #ifdef SKD_K1_TIMING
     long long tacc[11] = {0,0,0,0,0,0,0,0,0,0,0}, tlast = clock64();
 #endif
+    // inputs of a pass (layer optics; with PRE the eigen-solution left by kern_kj_lane), requested one pass ahead when the register budget
+    // allows it (PRE: the Jacobi state is gone): every pass otherwise starts with two dependent global loads nothing else can hide
+    constexpr int AU = (NSTR + LG - 1) / LG, XU = (NN + LG - 1) / LG;
+    struct PassIn { double om, th, T, sc, a[AU], x[XU], lam; };
+    auto fetch = [&](int pbase_, PassIn& in) {
+        const int pp = (pbase_ + grp < p_end) ? pbase_ + grp : p_end - 1;
+        in.om = b.om[size_t(pp) * nw + w]; in.th = b.tau[size_t(pp) * nw + w];
+        in.T = b.T[size_t(pp) * nw + w]; in.sc = b.sec[size_t(pp) * nw + w];
+#pragma unroll
+        for (int u = 0; u < AU; ++u) in.a[u] = (gl + u * LG < NSTR) ? b.a[(size_t(pp) * NSTR + gl + u * LG) * nw + w] : 0.0;
+        if (PRE) {
+            const double* r = skd::rec_at<N>(b, nlyr, pp, w);
+#pragma unroll
+            for (int u = 0; u < XU; ++u) in.x[u] = (gl + u * LG < NN) ? r[R::DWP + gl + u * LG] : 0.0;
+            in.lam = (gl < N) ? r[R::K + gl] : 0.0;
+        }
+    };
+    PassIn cur;
+    fetch(p_begin, cur);
     for (int pbase = p_begin; pbase < p_end; pbase += NG) {
         const bool valid = (pbase + grp) < p_end;
         const int p = valid ? pbase + grp : p_end - 1;
-        const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
-        const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
+        const double om = cur.om, th = cur.th, T = cur.T, sc = cur.sc;
         const double inv_om_l = 1.0 / om;
         double* rec = skd::rec_at<N>(b, nlyr, p, w);
-        for (int l = gl; l < NSTR; l += LG) va[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
+#pragma unroll
+        for (int u = 0; u < AU; ++u) if (gl + u * LG < NSTR) va[gl + u * LG] = cur.a[u];
+        const double lam_pre = cur.lam;
+        double x_pre[XU];
+#pragma unroll
+        for (int u = 0; u < XU; ++u) x_pre[u] = cur.x[u];
+        if (PRE && pbase + NG < p_end) fetch(pbase + NG, cur);
         __syncthreads();
         // B+-, copy of B+ for the Cholesky factor
         for (int e = gl; e < NN; e += LG) {
@@ -196,7 +220,8 @@ template <int N, int LG, bool PRE> __device__ __forceinline__ void k1_wave_body(
         }
         if (PRE) {
             // eigen-solution from kern_kj_lane: X(i, j) at [R::DWP + i N + j] (rewritten with dW+ below), k_j^2 at [R::K + j]
-            for (int e = gl; e < NN; e += LG) M5[e] = rec[R::DWP + e];
+#pragma unroll
+            for (int u = 0; u < XU; ++u) if (gl + u * LG < NN) M5[gl + u * LG] = x_pre[u];
         }
         __syncthreads();
         K1T(0)
@@ -438,7 +463,7 @@ template <int N, int LG, bool PRE> __device__ __forceinline__ void k1_wave_body(
         K1T(4)
         if (!jac_ok && gl == 0) sErr = skd::ERR_EIGEN;
         if (gl < N) {
-            double lam = PRE ? rec[R::K + gl] : M4[gl * N + gl];
+            double lam = PRE ? lam_pre : M4[gl * N + gl];
             if (!(lam > 0)) { sErr = skd::ERR_EIGEN; lam = fabs(lam) + 1e-300; }
             vlam[gl] = lam;
             vk[gl] = sqrt(lam);
@@ -606,6 +631,7 @@ template <int N, int LG, bool PRE> __device__ __forceinline__ void k1_wave_body(
         }
         K1T(10)
         __syncthreads();
+        if (!PRE && pbase + NG < p_end) fetch(pbase + NG, cur);
     }
 #ifdef SKD_K1_TIMING
     if (lane == 0 && w == 0 && blockIdx.y == 0 && m == 1) printf("K1T build %lld chol %lld m3m4 %lld warm %lld jac %lld backsub %lld UdU %lld W %lld Q %lld coef %lld G %lld\n", tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6], tacc[7], tacc[8], tacc[9], tacc[10]);
@@ -1339,7 +1365,9 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2AM) kern_k2a_mfma8(Geo g, Bufs b
 // K2c for N = 8.  Same operators as skd::k2c_layer_ops; FP, SP and BP are stored as ready-made A-operand images
 // (FP: k-step r at [FP + 64 r + lane], r < 4;  SP / BP: [SP + 64 r + lane], [BP + 64 r + lane], r < 2) for kern_k2b_mfma8.
 //   FP^T = F^T Dinv  and  [SP | BP]^T = [SupT | SubT]^T Dinv  are two chains of four matrix-core products.
-__global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b, int s, int m, int layers_per_block) {
+// K1LANE: the records come from kern_k1_lane (Rec::DG holds the coefficient vectors, DG is formed here); a template parameter, not a
+// run-time branch, so that the usual path does not carry the registers of the extra products
+template <bool K1LANE> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b, int s, int m, int layers_per_block) {
     constexpr int N = 8, NSTR = 16, M2 = 16;
     using R = skd::Rec<N>;
     using O = skd::Ops<N>;
@@ -1369,6 +1397,32 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b
         const double inv_om = 1.0 / om, inv_T = (T != 0) ? 1.0 / T : 0.0;
         const double al = (col >= m) ? b.a[(size_t(p) * NSTR + col) * nw + w] : 0.0;
         __syncthreads();
+        if constexpr (K1LANE) {
+            // records of kern_k1_lane: Rec::DG holds coef[(type * 5 + k) * N + j] (type 0: A- C-, 1: A+ C+; k = 0: the coefficient, 1 + theta:
+            // its derivatives).  DG[theta][c][i] = sum_j Wsel_c(i, j) coef_type(c)[1 + theta][j] + (theta = omega) sum_j dWsel_c(i, j) coef_type(c)[0][j]
+            // as two chained 16 x 16 x 8 products  D = [W+; W-] B + [dW+; dW-] B2  (rows (sel, i), columns (type, k)), B2 = coef[.][0] in the omega column
+            mf4 D = {0, 0, 0, 0};
+            double aw[2], ad[2], bb[2], b2[2];
+            for (int kk = 0; kk < 2; ++kk) {
+                const int j = 4 * kk + q;
+                aw[kk] = (col < N) ? sRec[R::WP + col + N * j] : sRec[R::WM + (col - N) + N * j];
+                ad[kk] = (col < N) ? sRec[R::DWP + col + N * j] : sRec[R::DWM + (col - N) + N * j];
+                bb[kk] = (col < 10) ? sRec[R::DG + col * N + j] : 0.0;
+                b2[kk] = (col == 1 + skd::TH_OM) ? sRec[R::DG + j] : (col == 6 + skd::TH_OM) ? sRec[R::DG + 5 * N + j] : 0.0;
+            }
+            for (int kk = 0; kk < 2; ++kk) D = mfma16(aw[kk], bb[kk], D);
+            for (int kk = 0; kk < 2; ++kk) D = mfma16(ad[kk], b2[kk], D);
+            // lane (col = (type, k), q), register r: row = q + 4 r = (sel, i);  c = 0: (W-, type 0), 1: (W+, 0), 2: (W+, 1), 3: (W-, 1)
+            const int type = (col >= 5) ? 1 : 0, k = col - 5 * type;
+            if (col < 10 && k >= 1) {
+                for (int r = 0; r < 4; ++r) {
+                    const int row = q + 4 * r, sel = row >> 3, i = row & 7;
+                    const int c = (type == 0) ? (sel ? 0 : 1) : (sel ? 3 : 2);
+                    sRec[R::DG + ((k - 1) * 4 + c) * N + i] = D[r];
+                }
+            }
+            __syncthreads();
+        }
         // ---- Y = [YP; YM] and its omega derivative DY (rows: solution j / 8 + j, columns: Legendre order l)
         mf4 Y = {0, 0, 0, 0}, DY = {0, 0, 0, 0};
         {

@@ -3,7 +3,7 @@
 # prints value / ms per step / per-kernel ms (pipelined per step and isolated)
 while [ $# -gt 0 ]; do
   tag=$1; envs=$2; shift 2
-  env $envs python bench.py --no-cpu-baseline --steps ${STEPS:-5} --warmup 2 > gpurun_out/r3_bench_$tag.json 2> gpurun_out/r3_bench_$tag.err
+  env $envs python bench.py --no-cpu-baseline --no-host-path --steps ${STEPS:-5} --warmup 2 > gpurun_out/r3_bench_$tag.json 2> gpurun_out/r3_bench_$tag.err
   python - $tag <<'PY'
 import json, sys
 n = sys.argv[1]
