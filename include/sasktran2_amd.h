@@ -136,6 +136,24 @@ int sk_amd_engine_solve_device(Engine* engine, int nwavel, int nleg, const doubl
 /* delta-M truncation fraction of already scaled optical properties, DEVICE pointer [nwavel][nlocation] or NULL, for the
  * following sk_amd_engine_solve_device calls (the host entry point does this itself after sk_atmosphere_apply_delta_m_scaling) */
 int sk_amd_engine_set_delta_m_fraction(Engine* engine, const double* d_f);
+/* Wavelength-sharded runs, one process per GPU (the reference threads over wavelengths, cpp/lib/engine/engine.cpp:610-622):
+ * a rank solves its contiguous wavelength range into ONE wavelength-major slab -- row w = [radiance | los_od | wf_extinction(q) |
+ * wf_ssa(q) | wf_albedo] x nlos doubles, sk_amd_slab_row_doubles per row -- the ranks exchange slabs with ONE all-gather
+ * (ncclAllGather; rows_per_rank = the largest shard) and sk_amd_unpack_slab writes the reference layouts from the gathered block. */
+int sk_amd_slab_row_doubles(Engine* engine, int derivatives, unsigned long long* doubles_per_row);
+int sk_amd_engine_solve_device_slab(Engine* engine, int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
+                                    const double* d_albedo, const double* d_irradiance, int derivatives, double* d_slab, int* d_status,
+                                    void* stream, int max_chunk);
+int sk_amd_unpack_slab(Engine* engine, const double* d_slab_all, int nwavel, int world, int rows_per_rank, int derivatives,
+                       double* d_radiance, double* d_los_od, double* d_wf_ext, double* d_wf_ssa, double* d_wf_albedo, void* stream);
+/* The same for drop-in callers of the HOST entry point that run one process per GPU: sk_engine_calculate_radiance's arguments plus an
+ * RCCL communicator.  Every rank passes the full atmosphere / output buffers, solves its wavelength range and receives the full result
+ * through one ncclAllGather of the packed slab.  The communicator: rank 0 obtains a 128-byte id (sk_amd_comm_unique_id), the caller
+ * distributes it (MPI_Bcast, a file, a torch store ...), every rank calls sk_amd_comm_create(id, rank, world) after selecting its GPU. */
+int sk_amd_comm_unique_id(char* id128);
+void* sk_amd_comm_create(const char* id128, int rank, int world);
+void sk_amd_comm_destroy(void* comm);
+int sk_amd_engine_calculate_radiance_sharded(Engine* engine, Atmosphere* atmosphere, OutputC* output, void* comm, int rank, int world);
 /* The same for an engine with single_scatter_source = exact and / or multiple_scatter_source = successive_orders_legacy
  * (replaces, per wavelength, SingleScatterSource<SolarTransmissionExact>::calculate / integrated_source,
  * cpp/lib/solar/singlescattersource.cpp:103-160,950-1167, and hr::DiffuseTable::calculate, cpp/lib/hr/diffuse_table.cpp:885-962):

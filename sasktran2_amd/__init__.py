@@ -337,8 +337,7 @@ class Atmosphere:
         if self._constituents:
             from .frontend import DeviceStorage
             if self._frontend is None or not self._frontend.assembled:
-                raise RuntimeError("call Atmosphere.internal_object() (or Engine.calculate_radiance) first: the storage of a constituent "
-                                   "atmosphere is assembled on the device")
+                self.internal_object()   # the reference exposes the storage at any time: assemble on first use
             return DeviceStorage(self._frontend, self._raw_storage.solar_irradiance)
         return self._raw_storage
 
@@ -403,6 +402,30 @@ class Atmosphere:
             L.sk_brdf_destroy(H["brdf"])
             L.sk_atmosphere_storage_destroy(H["storage"])
             self._H = None
+
+
+class Communicator:
+    """RCCL communicator of a wavelength-sharded run (one process per GPU; additive to the reference's surface).  Rank 0 creates the
+    128-byte id with `Communicator.unique_id()`, the application distributes it (MPI, a file, a torch store), every rank constructs
+    `Communicator(id, rank, world)` after selecting its GPU."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        if lib().sk_amd_comm_unique_id(buf) != 0:
+            raise RuntimeError(f"sk_amd_comm_unique_id failed: {last_error()}")
+        return buf.raw
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        self.rank, self.world = rank, world
+        self._h = lib().sk_amd_comm_create(ctypes.create_string_buffer(bytes(unique_id), 128), rank, world)
+        if not self._h:
+            raise RuntimeError(f"sk_amd_comm_create failed: {last_error()}")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and callable(lib):
+            lib().sk_amd_comm_destroy(self._h)
+            self._h = None
 
 
 class Engine:
@@ -585,10 +608,15 @@ class Engine:
             L.sk_output_vjp_destroy(h)
         return rad, grads
 
-    def calculate_radiance(self, atmosphere, as_dataset=True, _mapping_hook=None):
+    def calculate_radiance(self, atmosphere, as_dataset=True, _mapping_hook=None, shard=None):
         """`_mapping_hook(L, storage_handle, output_handle, out_dict)` lets a caller register further derivative mappings through
-        the C ABI before the solve (used by the tests for interpolated / log-space mappings)."""
+        the C ABI before the solve (used by the tests for interpolated / log-space mappings).
+        `shard=(communicator, rank, world)` (additive; `sasktran2_amd.Communicator`): one process per GPU, every rank passes the full
+        atmosphere, solves its wavelength range and receives the full result through one RCCL all-gather
+        (`sk_amd_engine_calculate_radiance_sharded`)."""
         if atmosphere._constituents:
+            if shard is not None:
+                raise ValueError("shard= serves the raw interface (constituent atmospheres live in HBM: use sasktran2_amd.distributed.ShardedSolver)")
             if _mapping_hook is not None:
                 raise ValueError("_mapping_hook belongs to the raw interface")
             return self._calculate_radiance_constituents(atmosphere, as_dataset)
@@ -613,7 +641,11 @@ class Engine:
                 _mapping_hook(L, h_st, h_out, out)
                 out.pop("_surface_handle", None)
             self._apply_delta_m(H, delta_order)
-            rc = L.sk_engine_calculate_radiance(self._h, h_atm, h_out, 0)
+            if shard is not None:
+                comm, rank, world = shard
+                rc = L.sk_amd_engine_calculate_radiance_sharded(self._h, h_atm, h_out, comm._h, int(rank), int(world))
+            else:
+                rc = L.sk_engine_calculate_radiance(self._h, h_atm, h_out, 0)
             if rc != 0:
                 raise RuntimeError(f"sk_engine_calculate_radiance returned {rc}: {last_error()}")
             od = _dp()

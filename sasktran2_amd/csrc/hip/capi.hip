@@ -2,6 +2,7 @@
 // c_api handles, H2D/D2H staging around DeviceEngine::solve_device and the user derivative mappings
 // (reference: OutputC::assign_lane, cpp/lib/output/outputc.cpp:38-236).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -125,12 +126,24 @@ struct Geometry2D { int unused; };
 struct Geodetic { double equatorial_radius, flattening; };
 struct OutputJVP { double* radiance; double* jvp; int nrad, nstokes; std::map<std::string, std::pair<const double*, int>> tangents, surface_tangents; };
 struct OutputVJP { double* radiance; const double* cotangent; int nrad, nstokes; std::map<std::string, std::pair<double*, int>> gradients, surface_gradients; };
+// JVP / VJP requests (sk_engine_calculate_jvp / _vjp): the native derivatives are contracted with the tangents / the cotangent ON THE
+// DEVICE by map_user_derivatives -- no user weighting function [nderiv][wavel][los][stokes] is formed anywhere, nothing of that size
+// crosses PCIe
+struct Contraction {
+    const double* cotangent = nullptr;   // host [wavel][los][stokes], VJP
+    double* jvp = nullptr;               // host [wavel][los][stokes], JVP (overwritten)
+    const std::map<std::string, std::pair<const double*, int>>* tangents = nullptr;
+    const std::map<std::string, std::pair<const double*, int>>* surface_tangents = nullptr;
+    const std::map<std::string, std::pair<double*, int>>* gradients = nullptr;
+    const std::map<std::string, std::pair<double*, int>>* surface_gradients = nullptr;
+};
 struct OutputC {
     double* radiance;
     int nrad, nstokes;
     struct D { double* mem; int nrad, nstokes, nderiv; };
     std::map<std::string, D> derivs, surface_derivs, flux_derivs, surface_flux_derivs;
     std::vector<double> los_od;
+    const Contraction* contract = nullptr;
 };
 // grow-only device staging buffers of the host entry point (kept between calls: no hipMalloc / hipFree per spectrum)
 struct DeviceCache {
@@ -201,6 +214,55 @@ __global__ void __launch_bounds__(256) kern_map_wf_interp(const double* we, cons
         }
         if (log_space) acc /= radiance[size_t(w) * nlos + (l / S) * S];
         dst[i] = acc;
+    }
+}
+// VJP of one mapping at the native level: g[q] = sum over (wavel, los) of cotangent x (d_ssa dI/d(ssa) + d_extinction dI/dk + ...) at grid
+// point q (a log-radiance mapping divides the cotangent by the radiance); one block per q, the mapping's interpolator is applied to g
+// on the host afterwards (gradient = interpolator^T g)
+__global__ void __launch_bounds__(256) kern_vjp_native(const double* we, const double* ws, const double* f_ssa, const double* f_ext, const double* cot,
+                                                       const double* radiance, int log_space, int S, double* g, int ngrid, int nw, int nlos,
+                                                       const double* wg, const double* f_scat, const double* wem, const double* f_em) {
+    __shared__ double red[256];
+    const int q = blockIdx.x;
+    const size_t n = size_t(nw) * nlos;
+    double acc = 0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int w = int(i / nlos), l = int(i % nlos);
+        const size_t o = size_t(q) * n + i, fo = size_t(w) * ngrid + q;
+        double v = f_ssa[fo] * ws[o] + f_ext[fo] * we[o];
+        if (wg) v += f_scat[fo] * wg[o];
+        if (wem) v += f_em[fo] * wem[o];
+        double c = cot[i];
+        if (log_space) c /= radiance[size_t(w) * nlos + (l / S) * S];
+        acc += c * v;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (int(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g[q] = red[0];
+}
+// JVP of one mapping: jvp[wavel][los] += sum_q tn[q] x (d_ssa dI/d(ssa) + d_extinction dI/dk + ...)[q][wavel][los], tn = interpolator x tangent
+__global__ void __launch_bounds__(256) kern_jvp_native(const double* we, const double* ws, const double* f_ssa, const double* f_ext, const double* tn,
+                                                       const double* radiance, int log_space, int S, double* jvp, int ngrid, int nw, int nlos,
+                                                       const double* wg, const double* f_scat, const double* wem, const double* f_em) {
+    const size_t n = size_t(nw) * nlos;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const int w = int(i / nlos), l = int(i % nlos);
+        double acc = 0;
+        for (int q = 0; q < ngrid; ++q) {
+            const double t = tn[q];
+            if (t == 0.0) continue;
+            const size_t o = size_t(q) * n + i, fo = size_t(w) * ngrid + q;
+            double v = f_ssa[fo] * ws[o] + f_ext[fo] * we[o];
+            if (wg) v += f_scat[fo] * wg[o];
+            if (wem) v += f_em[fo] * wem[o];
+            acc += t * v;
+        }
+        if (log_space) acc /= radiance[size_t(w) * nlos + (l / S) * S];
+        jvp[i] += acc;
     }
 }
 // two-stream source: scattering-group derivative = dI/d(b1) x (d_legendre(1) - 3 d_f / (1 - f)^2)
@@ -518,6 +580,16 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
     {
             double* d_fs = (double*)C.get("map_d_ssa", nloc_w * 8);
             double* d_fk = (double*)C.get("map_d_extinction", nloc_w * 8);
+            const Contraction* contract = out->contract;
+            double *d_cot = nullptr, *d_jvp = nullptr;
+            if (contract && contract->gradients) {
+                d_cot = (double*)C.get("vjp_cotangent", nt * 8);
+                HIPC(hipMemcpy(d_cot, contract->cotangent, nt * 8, hipMemcpyHostToDevice));
+            }
+            if (contract && contract->tangents) {
+                d_jvp = (double*)C.get("jvp_product", nt * 8);
+                HIPC(hipMemset(d_jvp, 0, nt * 8));
+            }
             for (auto& kv : out->derivs) {
                 auto it = st.maps.find(kv.first);
                 if (it == st.maps.end()) throw std::runtime_error("no derivative mapping named " + kv.first);
@@ -527,7 +599,7 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
                 if (kv.second.nderiv != nout || kv.second.nrad * kv.second.nstokes != nw * nlos) throw std::runtime_error("derivative memory size mismatch for " + kv.first);
                 HIPC(hipMemcpy(d_fs, m.src_d_ssa(), nloc_w * 8, hipMemcpyDefault));
                 HIPC(hipMemcpy(d_fk, m.src_d_extinction(), nloc_w * 8, hipMemcpyDefault));
-                double* d_dst = (double*)C.get("wf_user", size_t(nout) * nt * 8);
+                double* d_dst = contract ? nullptr : (double*)C.get("wf_user", size_t(nout) * nt * 8);
                 const double* d_wgm = nullptr;
                 double* d_fg = nullptr;
                 if (group_of && group_of->count(kv.first)) {
@@ -541,6 +613,37 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
                     d_wemm = d_wem;
                     d_fem = (double*)C.get("map_d_emission", nloc_w * 8);
                     HIPC(hipMemcpy(d_fem, m.src_d_emission(), nloc_w * 8, hipMemcpyDefault));
+                }
+                if (contract && contract->gradients) {
+                    // VJP: native gradient on the device, the interpolator on the host
+                    double* d_g = (double*)C.get("vjp_native", size_t(ngrid) * 8);
+                    hipLaunchKernelGGL(kern_vjp_native, dim3(ngrid), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_cot, d_rad, m.log_radiance_space, S, d_g,
+                                       ngrid, nw, nlos, d_wgm, d_fg, d_wemm, d_fem);
+                    HIPC(hipGetLastError());
+                    std::vector<double> gn(ngrid);
+                    HIPC(hipMemcpy(gn.data(), d_g, size_t(ngrid) * 8, hipMemcpyDeviceToHost));
+                    double* dst = contract->gradients->at(kv.first).first;
+                    for (int j = 0; j < nout; ++j) {
+                        if (!m.interpolator) { dst[j] = gn[j]; continue; }
+                        double acc = 0;
+                        for (int q = 0; q < ngrid; ++q) acc += m.interpolator[size_t(j) * ngrid + q] * gn[q];
+                        dst[j] = acc;
+                    }
+                    continue;
+                }
+                if (contract && contract->tangents) {
+                    const double* t = contract->tangents->at(kv.first).first;
+                    std::vector<double> tn(ngrid, 0.0);
+                    for (int j = 0; j < nout; ++j) {
+                        if (!m.interpolator) { tn[j] = t[j]; continue; }
+                        for (int q = 0; q < ngrid; ++q) tn[q] += m.interpolator[size_t(j) * ngrid + q] * t[j];
+                    }
+                    double* d_tn = (double*)C.get("jvp_tangent", size_t(ngrid) * 8);
+                    HIPC(hipMemcpy(d_tn, tn.data(), size_t(ngrid) * 8, hipMemcpyHostToDevice));
+                    hipLaunchKernelGGL(kern_jvp_native, dim3(1024), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_tn, d_rad, m.log_radiance_space, S, d_jvp,
+                                       ngrid, nw, nlos, d_wgm, d_fg, d_wemm, d_fem);
+                    HIPC(hipGetLastError());
+                    continue;
                 }
                 if (!m.interpolator && !m.log_radiance_space) {
                     hipLaunchKernelGGL(kern_map_wf, dim3(4096), dim3(256), 0, nullptr, d_we, d_ws, d_fs, d_fk, d_dst, ngrid, nw, nlos, d_wgm, d_fg, d_wemm, d_fem);
@@ -556,6 +659,7 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
                 HIPC(hipGetLastError());
                 HIPC(hipMemcpy(kv.second.mem, d_dst, size_t(nout) * nt * 8, hipMemcpyDeviceToHost));  // C order [nderiv][wavel][los]
             }
+            if (contract && contract->tangents) HIPC(hipMemcpy(contract->jvp, d_jvp, nt * 8, hipMemcpyDeviceToHost));
             if (!out->surface_derivs.empty()) {
                 std::vector<double> wa(nt), wsem;
                 HIPC(hipMemcpy(wa.data(), d_wa, nt * 8, hipMemcpyDeviceToHost));
@@ -567,12 +671,17 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
                     auto it = su.maps.find(kv.first);
                     if (it == su.maps.end()) throw std::runtime_error("no surface derivative mapping named " + kv.first);
                     const SurfaceDerivativeMapping& m = *it->second;
-                    for (int w = 0; w < nw; ++w)
+                    for (int w = 0; w < nw; ++w) {
+                        double gsum = 0;
                         for (int l = 0; l < nlos; ++l) {
                             double v = wa[size_t(w) * nlos + l] * m.d_brdf[w];
                             if (d_wsem) v += wsem[size_t(w) * nlos + l] * m.d_emission[w];
-                            kv.second.mem[size_t(w) * nlos + l] = v;
+                            if (!contract) kv.second.mem[size_t(w) * nlos + l] = v;
+                            else if (contract->surface_tangents) contract->jvp[size_t(w) * nlos + l] += v * contract->surface_tangents->at(kv.first).first[w];
+                            else gsum += v * contract->cotangent[size_t(w) * nlos + l];
                         }
+                        if (contract && contract->surface_gradients) contract->surface_gradients->at(kv.first).first[w] = gsum;
+                    }
                 }
             }
     }
@@ -1078,6 +1187,69 @@ int sk_amd_engine_solve_device(Engine* e, int nwavel, int nleg, const double* d_
         return -3;
     }
 }
+// ---- wavelength-sharded runs (one process per GPU): every rank solves its contiguous wavelength range into ONE wavelength-major slab,
+// the ranks exchange the slabs with ONE all-gather (RCCL over xGMI; the caller's collective or sk_amd_engine_calculate_radiance_sharded),
+// and one kernel unpacks the gathered block into the reference layouts.
+int sk_amd_slab_row_doubles(Engine* e, int derivatives, unsigned long long* n) {
+    if (!e || !n) return -1;
+    *n = (unsigned long long)skdev::DeviceEngine::slab_fields(e->ngrid, derivatives) * (unsigned long long)e->nlos;
+    return 0;
+}
+int sk_amd_engine_solve_device_slab(Engine* e, int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
+                                    const double* d_albedo, const double* d_irradiance, int derivatives, double* d_slab, int* d_status,
+                                    void* stream, int max_chunk) {
+    if (!e) return -1;
+    try {
+        if (!e->dev || e->so || e->dev->vector_mode()) throw std::runtime_error("the slab entry point serves the scalar discrete-ordinates engines");
+        if (nwavel <= 0 || nleg <= 0) throw std::runtime_error("nwavel and nleg must be positive");
+        if (!d_ext || !d_ssa || !d_leg || !d_albedo || !d_slab || !d_status) throw std::runtime_error("null device pointer");
+        if (max_chunk < 0) throw std::runtime_error("max_chunk must be >= 0");
+        e->dev->set_slab_output(d_slab);
+        try {
+            e->dev->solve_device(nwavel, nleg, d_ext, d_ssa, d_leg, d_albedo, d_irradiance, derivatives, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                 d_status, stream, max_chunk);
+        } catch (...) {
+            e->dev->set_slab_output(nullptr);
+            throw;
+        }
+        e->dev->set_slab_output(nullptr);
+        return 0;
+    } catch (const std::exception& ex) {
+        set_error(std::string("sk_amd_engine_solve_device_slab: ") + ex.what());
+        return -3;
+    }
+}
+// gathered slabs [world][rows_per_rank][row] (rank r holds wavelengths shard(r) in its first rows, the rest is padding) -> radiance, los_od
+// [nwavel][nlos], wf_extinction, wf_ssa [ngrid][nwavel][nlos], wf_albedo [nwavel][nlos]; shards as sasktran2_amd.distributed.shard_bounds
+__global__ void __launch_bounds__(256) kern_unpack_slab(const double* slab, int nwavel, int world, int rows_per_rank, int ngrid, int nlos, int derivs,
+                                                        double* radiance, double* los_od, double* wf_ext, double* wf_ssa, double* wf_alb) {
+    const int nf = derivs ? 2 * ngrid + 3 : 2;
+    const size_t n = size_t(nwavel) * nf * nlos;
+    const int base = nwavel / world, extra = nwavel % world;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const int l = int(i % nlos), f = int((i / nlos) % nf), w = int(i / (size_t(nlos) * nf));
+        // rank and local row of wavelength w: the first `extra` ranks hold base + 1 wavelengths
+        int r, loc;
+        if (w < extra * (base + 1)) { r = w / (base + 1); loc = w - r * (base + 1); }
+        else { r = extra + (base > 0 ? (w - extra * (base + 1)) / base : 0); loc = w - extra * (base + 1) - (r - extra) * base; }
+        const double v = slab[((size_t(r) * rows_per_rank + loc) * nf + f) * nlos + l];
+        const size_t o = size_t(w) * nlos + l, plane = size_t(nwavel) * nlos;
+        if (f == 0) radiance[o] = v;
+        else if (f == 1) { if (los_od) los_od[o] = v; }
+        else if (f < 2 + ngrid) wf_ext[size_t(f - 2) * plane + o] = v;
+        else if (f < 2 + 2 * ngrid) wf_ssa[size_t(f - 2 - ngrid) * plane + o] = v;
+        else wf_alb[o] = v;
+    }
+}
+int sk_amd_unpack_slab(Engine* e, const double* d_slab_all, int nwavel, int world, int rows_per_rank, int derivatives, double* d_radiance,
+                       double* d_los_od, double* d_wf_ext, double* d_wf_ssa, double* d_wf_albedo, void* stream) {
+    if (!e || !d_slab_all || !d_radiance) return -1;
+    if (nwavel <= 0 || world <= 0 || rows_per_rank * world < nwavel) return -2;
+    if (derivatives && (!d_wf_ext || !d_wf_ssa || !d_wf_albedo)) return -1;
+    hipLaunchKernelGGL(kern_unpack_slab, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(stream), d_slab_all, nwavel, world, rows_per_rank, e->ngrid,
+                       e->nlos, derivatives, d_radiance, d_los_od, d_wf_ext, d_wf_ssa, d_wf_albedo);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 int sk_amd_engine_set_delta_m_fraction(Engine* e, const double* d_f) {
     if (!e || !e->dev) return -1;
     e->dev->set_delta_m_fraction(d_f);
@@ -1194,5 +1366,6 @@ int sk_amd_so_engine_sizes(Engine* e, unsigned long long* sizes) {
 static int frontend_apply_delta_m(AtmosphereStorage& st, int order, int stack);
 #include "capi_rest.inc"
 #include "frontend.inc"
+#include "capi_sharded.inc"
 
 }  // extern "C"

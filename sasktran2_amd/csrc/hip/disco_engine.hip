@@ -177,6 +177,26 @@ __global__ void __launch_bounds__(kBlock) kern_output(Geo g, Bufs b, int w0, int
     if (wf_alb) wf_alb[o] = b.dnat[size_t(2 * g.ngrid) * nt + tid];
 }
 
+// the same results as one wavelength-major slab row per wavelength (DeviceEngine::set_slab_output): fields radiance, los_od and, with
+// derivatives, wf_extinction[q], wf_ssa[q], wf_albedo, each nlos doubles
+__global__ void __launch_bounds__(kBlock) kern_output_slab(Geo g, Bufs b, int w0, double* slab, int* status) {
+    size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t nt = size_t(b.nw) * g.nlos;
+    if (tid >= nt) return;
+    const int w = int(tid / g.nlos), l = int(tid % g.nlos);
+    const int nf = b.derivs ? 2 * g.ngrid + 3 : 2;
+    double* row = slab + size_t(w0 + w) * nf * g.nlos + l;
+    row[0] = b.radiance[tid];
+    row[g.nlos] = b.los_od[tid];
+    if (status && l == 0) status[w0 + w] = b.status[w];
+    if (!b.derivs) return;
+    for (int q = 0; q < g.ngrid; ++q) {
+        row[size_t(2 + q) * g.nlos] = b.dnat[size_t(q) * nt + tid];
+        row[size_t(2 + g.ngrid + q) * g.nlos] = b.dnat[size_t(g.ngrid + q) * nt + tid];
+    }
+    row[size_t(2 + 2 * g.ngrid) * g.nlos] = b.dnat[size_t(2 * g.ngrid) * nt + tid];
+}
+
 // ------------------------------------------------------------------------------------------------
 struct DevMem {
     std::vector<void*> ptrs;
@@ -228,6 +248,7 @@ struct DeviceEngine::Impl {
     int chunk_capacity = 0;
     int last_chunk = 0, last_slots = 0;
     const double* delta_f = nullptr;
+    double* slab = nullptr;   // set_slab_output
     const double *thermal_emission = nullptr, *thermal_surface = nullptr;   // EmissionSource::discrete_ordinates inputs (device) or null
     double *thermal_wf_emission = nullptr, *thermal_wf_surface = nullptr;   // their weighting functions [ngrid][nwavel][nlos], [nwavel][nlos] or null
     int thermal_w0 = 0, thermal_nw_total = 0;                               // block in flight of the thermal pass
@@ -325,6 +346,7 @@ int DeviceEngine::ngrid() const { return impl_->tab.ngrid; }
 int DeviceEngine::nstr() const { return impl_->tab.nstr; }
 size_t DeviceEngine::scratch_bytes() const { return impl_->scratch_bytes; }
 void DeviceEngine::set_delta_m_fraction(const double* d_f) { impl_->delta_f = d_f; }
+void DeviceEngine::set_slab_output(double* d_slab) { impl_->slab = d_slab; }
 void DeviceEngine::set_thermal_emission(const double* d_emission, const double* d_surface_emission) {
     impl_->thermal_emission = d_emission;
     impl_->thermal_surface = d_surface_emission;
@@ -814,8 +836,11 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
             case 16: run_chunk<16>(I, slot, cs, derivs); break;
         }
         Timer tm(I, cs, "k_output");
-        hipLaunchKernelGGL(kern_output, dim3(blocks(size_t(nw) * t.nlos)), dim3(kBlock), 0, cs, I.g, b, w0, nwavel, d_radiance,
-                           d_wf_ext, d_wf_ssa, d_wf_alb, d_los_od, d_status);
+        if (I.slab)
+            hipLaunchKernelGGL(kern_output_slab, dim3(blocks(size_t(nw) * t.nlos)), dim3(kBlock), 0, cs, I.g, b, w0, I.slab, d_status);
+        else
+            hipLaunchKernelGGL(kern_output, dim3(blocks(size_t(nw) * t.nlos)), dim3(kBlock), 0, cs, I.g, b, w0, nwavel, d_radiance,
+                               d_wf_ext, d_wf_ssa, d_wf_alb, d_los_od, d_status);
     }
     if (fan_out)
         for (int i = 0; i < used; ++i) {

@@ -32,6 +32,11 @@ class DeviceEngine {
     // delta-M truncation fraction of the (already scaled) optical properties: DEVICE pointer [nwavel][ngrid] used by the following
     // solve_device calls, or null (sk_atmosphere_apply_delta_m_scaling, cpp/lib/atmosphere/atmosphere.cpp:73-200)
     void set_delta_m_fraction(const double* d_f);
+    // Wavelength-major output slab for the following solve_device calls (or null): row w of `d_slab` holds, for wavelength w of the call,
+    // [radiance | los_od | wf_extinction(q = 0 .. ngrid-1) | wf_ssa(q) | wf_albedo] x nlos doubles -- what one rank of a wavelength-sharded
+    // run contributes to the single all-gather; the separate output pointers of solve_device are then ignored (status excepted)
+    void set_slab_output(double* d_slab);
+    static int slab_fields(int ngrid, int derivs) { return derivs ? 2 * ngrid + 3 : 2; }
     // EmissionSource::discrete_ordinates (thermal source inside the DO equations; plane-parallel post-processing, NSTOKES = 1, radiances only):
     // DEVICE pointers emission_source [nwavel][ngrid] and surface emission [nwavel] (or null) for the following solve_device calls
     void set_thermal_emission(const double* d_emission, const double* d_surface_emission);

@@ -47,6 +47,36 @@ class DeviceSolver:
             raise RuntimeError(f"sk_amd_engine_solve_device returned {rc}: {last_error()}")
         return out
 
+    # ---- wavelength-sharded runs: one slab per rank, one all-gather, one unpack (sasktran2_amd.distributed.ShardedSolver)
+    def slab_row_doubles(self, derivatives=True):
+        n = ctypes.c_ulonglong()
+        lib().sk_amd_slab_row_doubles(self.engine._h, int(derivatives), ctypes.byref(n))
+        return n.value
+
+    def solve_slab(self, extinction, ssa, leg, albedo, slab, status, derivatives=True, irradiance=None, max_chunk=0):
+        """as solve(), results into the first `nwavel` rows of the wavelength-major `slab` [rows, slab_row_doubles] (float64 CUDA tensor)"""
+        for t in (extinction, ssa, leg, albedo, slab):
+            assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        nw = extinction.shape[0]
+        assert slab.shape[0] >= nw and slab.shape[1] == self.slab_row_doubles(derivatives) and status.shape[0] >= nw
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        rc = lib().sk_amd_engine_solve_device_slab(self.engine._h, nw, leg.shape[2], p(extinction), p(ssa), p(leg), p(albedo), p(irradiance),
+                                                   int(derivatives), p(slab), p(status), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                                   int(max_chunk))
+        if rc != 0:
+            raise RuntimeError(f"sk_amd_engine_solve_device_slab returned {rc}: {last_error()}")
+
+    def unpack_slab(self, slab_all, nwavel, world, rows_per_rank, out):
+        """gathered slabs [world * rows_per_rank, row] -> `out` (allocate_outputs(nwavel, ...)) in the reference layouts"""
+        derivs = "wf_extinction" in out
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        rc = lib().sk_amd_unpack_slab(self.engine._h, p(slab_all), int(nwavel), int(world), int(rows_per_rank), int(derivs), p(out["radiance"]),
+                                      p(out.get("los_optical_depth")), p(out.get("wf_extinction")), p(out.get("wf_ssa")), p(out.get("wf_albedo")),
+                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sk_amd_unpack_slab returned {rc}: {last_error()}")
+        return out
+
     # ---- per-kernel HIP-event timing (serialises launches; use outside the timed region)
     def set_profiling(self, on):
         """True / 1: per-kernel timing with the launches serialised; 2: event pairs on each launch's own stream, nothing serialised

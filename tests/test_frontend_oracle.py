@@ -188,13 +188,31 @@ def test_product_host_logic_matches_oracle():
     np.testing.assert_allclose(s["leg"], oleg, rtol=1e-14)
 
 
-def test_us76_standard_atmosphere_known_values():
-    """published values of the U.S. Standard Atmosphere 1976 (the numbers the reference's table holds, src/sasktran2/climatology/us76.py)"""
+def test_us76_standard_atmosphere_follows_the_reference_table():
+    """`add_us76_standard_atmosphere` of the reference interpolates a 21-node table (src/sasktran2/climatology/us76.py:87-116; the nodes
+    are the fixture tests/golden/us76_nodes.json): linear temperature, log-linear pressure, clamped below -1 km, temperature held and the
+    pressure continued with the last log-slope above 80 km.  Checked at the nodes and at off-node altitudes, where the table and the
+    standard's own equations differ by kelvins."""
+    import json
+    from pathlib import Path
     from sasktran2_amd.climatology import us76
-    z = np.array([0.0, 5000.0, 10000.0, 20000.0, 30000.0, 50000.0, 70000.0, 80000.0])
+    g = json.loads((Path(__file__).parent / "golden" / "us76_nodes.json").read_text())
+    zn, tn, pn = np.array(g["altitude_m"]), np.array(g["temperature_c"]) + 273.15, np.array(g["pressure_1e4_pa"]) * 1e4
+    t, p = us76.temperature_pressure(zn)
+    np.testing.assert_allclose(t, tn, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(p, pn, rtol=1e-14)
+    # off-node: 12 km (between the 10 and 15 km nodes, across the tropopause), 45 km (across the stratopause), 90 km (above the table), -2 km
+    z = np.array([12000.0, 45000.0, 90000.0, -2000.0])
     t, p = us76.temperature_pressure(z)
-    np.testing.assert_allclose(t - 273.15, [15.00, -17.47, -49.90, -56.50, -46.64, -2.5, -53.57, -74.51], atol=6e-3)
-    np.testing.assert_allclose(p, [101325.0, 54048.0, 26500.0, 5529.3, 1197.0, 79.779, 5.2209, 1.0524], rtol=2e-4)
+    f12, f45 = (12000.0 - 10000.0) / 5000.0, (45000.0 - 40000.0) / 10000.0
+    np.testing.assert_allclose(t, [tn[11] + f12 * (tn[12] - tn[11]), tn[16] + f45 * (tn[17] - tn[16]), tn[-1], tn[0]], rtol=1e-14)
+    slope = (np.log(pn[-1]) - np.log(pn[-2])) / 10000.0
+    np.testing.assert_allclose(p, [pn[11] ** (1 - f12) * pn[12] ** f12, pn[16] ** (1 - f45) * pn[17] ** f45,
+                                   pn[-1] * np.exp(slope * 10000.0), pn[0]], rtol=1e-13)
+    # the standard's equations are something else between the nodes: 216.65 K at 12 km against 220.6 K from the table
+    ta, pa = us76.analytic_temperature_pressure(z[:2])
+    assert abs(ta[0] - 216.65) < 1e-9 and abs(t[0] - ta[0]) > 3.0
+    np.testing.assert_allclose(us76.analytic_temperature_pressure(zn[1:-3])[1], pn[1:-3], rtol=6e-4)   # printed precision of the table
 
     class _Geo:
         def altitudes(self):
@@ -204,7 +222,8 @@ def test_us76_standard_atmosphere_known_values():
         model_geometry = _Geo()
     a = _Atmo()
     us76.add_us76_standard_atmosphere(a)
-    assert a.temperature_k.shape == (8,) and np.all(np.diff(a.pressure_pa) < 0)
+    np.testing.assert_array_equal(a.temperature_k, t)
+    np.testing.assert_array_equal(a.pressure_pa, p)
 
 
 def test_cached_spectra_are_read_only_and_keyed_by_identity():

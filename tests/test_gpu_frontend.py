@@ -382,6 +382,21 @@ def test_line_of_sight_emission_and_jvp_vjp_with_device_mappings():
         L.sk_atmosphere_destroy(h_atm)
         L.sk_surface_destroy(h_su)
         L.sk_brdf_destroy(h_brdf)
+    # ... and through the Python surface: Engine.calculate_jvp / calculate_vjp of a CONSTITUENT atmosphere route through the front end
+    # (mapping names of the constituents, the storage stays in HBM) instead of computing on the empty raw storage
+    names = [n for n in base if n.startswith("wf_")]
+    tang = {n: rng.standard_normal(base[n].shape[0]) for n in names if base[n].ndim == 4 and n in fe.mappings}
+    rad_j, jvp_py = engine.calculate_jvp(atmo, tang)
+    np.testing.assert_allclose(rad_j, base["radiance"], rtol=1e-13)
+    want = sum(np.einsum("jwls,j->wls", base[n], t) for n, t in tang.items())
+    np.testing.assert_allclose(jvp_py, want, rtol=1e-9, atol=1e-12 * np.abs(want).max())
+    cot = rng.standard_normal(base["radiance"].shape)
+    rad_v, grads = engine.calculate_vjp(atmo, cot)
+    np.testing.assert_allclose(rad_v, base["radiance"], rtol=1e-13)
+    for n in tang:
+        np.testing.assert_allclose(grads[n], np.einsum("jwls,wls->j", base[n], cot), rtol=1e-9, atol=1e-12 * np.abs(grads[n]).max())
+    with pytest.raises(KeyError):
+        engine.calculate_vjp(atmo, cot, names=("wf_extinction",))
 
 
 @pytest.mark.parametrize("ms,nstokes", [("none", 1), ("none", 3), ("discrete_ordinates", 1), ("twostream", 1)],

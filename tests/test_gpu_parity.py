@@ -785,7 +785,15 @@ def test_jvp_and_vjp_are_contractions_of_the_jacobian(nstokes):
     rad, jvp = engine.calculate_jvp(atmosphere, {"wf_extinction": t_k, "wf_ssa": t_w}, {"wf_albedo": t_a})
     want = np.einsum("qwls,q->wls", full["wf_extinction"], t_k) + np.einsum("qwls,q->wls", full["wf_ssa"], t_w) + full["wf_albedo"] * t_a[:, None, None]
     np.testing.assert_array_equal(rad, full["radiance"])
-    np.testing.assert_allclose(jvp, want, rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(jvp, want, rtol=1e-10, atol=1e-300)   # (contracted on the device: another order of the same sum)
+    # ... and against the ORACLE's dense forward-mode Jacobian contracted on the host (the north-star tolerance of weighting functions)
+    ref = run_oracle(s, derivatives=True)
+    if nstokes == 3:
+        want_o = (np.einsum("wlsq,q->wls", ref["d_extinction"], t_k) + np.einsum("wlsq,q->wls", ref["d_ssa"], t_w)
+                  + ref["d_albedo"] * t_a[:, None, None])
+    else:
+        want_o = (np.einsum("wlq,q->wl", ref["d_extinction"], t_k) + np.einsum("wlq,q->wl", ref["d_ssa"], t_w) + ref["d_albedo"] * t_a[:, None])[..., None]
+    assert np.max(np.abs(jvp - want_o)) < 1e-4 * np.abs(want_o).max()
     # a directional finite difference of the forward model sees the same number
     h = 1e-3
     plus, minus = copy.deepcopy(s), copy.deepcopy(s)
@@ -799,13 +807,22 @@ def test_jvp_and_vjp_are_contractions_of_the_jacobian(nstokes):
     cot = rng.standard_normal(full["radiance"].shape)
     rad2, grads = engine.calculate_vjp(atmosphere, cot)
     np.testing.assert_array_equal(rad2, full["radiance"])
-    np.testing.assert_allclose(grads["wf_extinction"], np.einsum("qwls,wls->q", full["wf_extinction"], cot), rtol=1e-12)
-    np.testing.assert_allclose(grads["wf_ssa"], np.einsum("qwls,wls->q", full["wf_ssa"], cot), rtol=1e-12)
-    np.testing.assert_allclose(grads["wf_albedo"], np.einsum("wls,wls->w", full["wf_albedo"], cot), rtol=1e-12)
+    np.testing.assert_allclose(grads["wf_extinction"], np.einsum("qwls,wls->q", full["wf_extinction"], cot), rtol=1e-9)
+    np.testing.assert_allclose(grads["wf_ssa"], np.einsum("qwls,wls->q", full["wf_ssa"], cot), rtol=1e-9)
+    np.testing.assert_allclose(grads["wf_albedo"], np.einsum("wls,wls->w", full["wf_albedo"], cot), rtol=1e-9)
+    # the oracle's Jacobian transposed on the host
+    if nstokes == 3:
+        g_k, g_w, g_a = (np.einsum("wlsq,wls->q", ref["d_extinction"], cot), np.einsum("wlsq,wls->q", ref["d_ssa"], cot),
+                         np.einsum("wls,wls->w", ref["d_albedo"], cot))
+    else:
+        g_k, g_w, g_a = (np.einsum("wlq,wl->q", ref["d_extinction"], cot[..., 0]), np.einsum("wlq,wl->q", ref["d_ssa"], cot[..., 0]),
+                         np.einsum("wl,wl->w", ref["d_albedo"], cot[..., 0]))
+    for got, want_g in ((grads["wf_extinction"], g_k), (grads["wf_ssa"], g_w), (grads["wf_albedo"], g_a)):
+        assert np.max(np.abs(got - want_g)) < 1e-4 * np.abs(want_g).max()
     # <cotangent, J t> == <J^T cotangent, t>
     lhs = float(np.sum(cot * jvp))
     rhs = float(grads["wf_extinction"] @ t_k + grads["wf_ssa"] @ t_w + grads["wf_albedo"] @ t_a)
-    assert abs(lhs - rhs) < 1e-11 * max(abs(lhs), abs(rhs))
+    assert abs(lhs - rhs) < 1e-9 * max(abs(lhs), abs(rhs))
 
 
 # ---- thermal emission inside the discrete-ordinates equations (emission_source = discrete_ordinates)
