@@ -117,8 +117,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--wavelengths", type=int, default=0, help="0 = the workload's own size (C2: 10 000, C5: 20 000, twostream: 220 000)")
-    ap.add_argument("--workload", choices=("c2", "c5", "twostream", "frontend"), default="c2",
-                    help="c2 (default, BASELINE.json's metric): 16-stream DISCO limb + weighting functions; c5: BASELINE configs[4], "
+    ap.add_argument("--workload", choices=("c2", "c4", "c5", "twostream", "frontend"), default="c2",
+                    help="c2 (default, BASELINE.json's metric): 16-stream DISCO limb + weighting functions; c4: BASELINE configs[3], polarised 32-stream "
+                         "DISCO, 60 layers, 5 000 wavelengths, weighting functions (default 1 warm-up + the given steps of several seconds each); c5: BASELINE configs[4], "
                          "exact single scatter + 10 successive orders of scattering; twostream: the reference's two-stream benchmark "
                          "(20 layers, 220 000 wavelengths, weighting functions); frontend: the optical-property front end (constituents -> storage and "
                          "derivative mappings in HBM) at the C2 size")
@@ -143,8 +144,11 @@ def main():
     from tests import scenarios as sc
     from tests.gpu_harness import build_engine
 
-    if args.workload in ("c5", "twostream", "frontend"):
-        if args.workload == "c5":
+    if args.workload in ("c4", "c5", "twostream", "frontend"):
+        if args.workload == "c4":
+            from bench_c4 import run_c4
+            run_c4(args, world, rank, dev)
+        elif args.workload == "c5":
             from bench_so import run_c5
             run_c5(args, world, rank, dev)
         elif args.workload == "frontend":

@@ -75,6 +75,23 @@ int orc_chapman(void* hv, double* out) {
     std::copy(h->dg.chapman.begin(), h->dg.chapman.end(), out);
     return 0;
 }
+// geometry tables of one line of sight, for the independent geometry check (tests/test_independent_geometry.py): per ray layer (far end ->
+// observer) its length, the azimuth used for cos(m azi) and the diffuse-table stencil (sza index, altitude index, angle index, weight);
+// flattened as  [nlayers, ground_is_hit, ground_saa, nground, (angle, sza, w) x nground, then per layer: distance, azi, n, (sza, alt, angle, w) x n].
+// Returns the number of doubles needed (the caller passes a buffer of `cap` doubles; nothing is written past it).
+int orc_ray_tables(void* hv, int ray, double* out, int cap) {
+    auto* h = static_cast<Handle*>(hv);
+    if (ray < 0 || ray >= int(h->dg.rays.size())) return -1;
+    const skgeo::RayGeom& r = h->dg.rays[ray];
+    std::vector<double> v{double(r.layers.size()), r.ground_is_hit ? 1.0 : 0.0, r.ground_saa, double(r.ground.size())};
+    for (const auto& g : r.ground) { v.push_back(g.angle); v.push_back(g.sza); v.push_back(g.w); }
+    for (const auto& L : r.layers) {
+        v.push_back(L.layer_distance); v.push_back(L.azi); v.push_back(double(L.table.size()));
+        for (const auto& e : L.table) { v.push_back(e.sza); v.push_back(e.alt); v.push_back(e.angle); v.push_back(e.w); }
+    }
+    for (int i = 0; i < int(v.size()) && i < cap; ++i) out[i] = v[i];
+    return int(v.size());
+}
 int orc_streams(void* hv, double* mu, double* wt) {
     auto* h = static_cast<Handle*>(hv);
     std::copy(h->dg.mu.begin(), h->dg.mu.end(), mu);

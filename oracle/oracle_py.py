@@ -80,6 +80,27 @@ class OracleEngine:
         lib().orc_chapman(self._h, _p(out))
         return out
 
+    def ray_tables(self, ray):
+        """diffuse-table stencils of one line of sight as the shared geometry precompute holds them: {"ground_is_hit", "ground_saa",
+        "ground": [(angle, sza, w)], "layers": [{"distance", "azi", "table": [(sza, alt, angle, w)]}] (far end -> observer)}"""
+        L = lib()
+        L.orc_ray_tables.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, ctypes.c_int]
+        n = L.orc_ray_tables(self._h, ray, None, 0)
+        buf = np.zeros(n)
+        L.orc_ray_tables(self._h, ray, _p(buf), n)
+        nl, hit, gsaa, ng = int(buf[0]), bool(buf[1]), buf[2], int(buf[3])
+        pos = 4
+        ground = [(int(buf[pos + 3 * i]), int(buf[pos + 3 * i + 1]), buf[pos + 3 * i + 2]) for i in range(ng)]
+        pos += 3 * ng
+        layers = []
+        for _ in range(nl):
+            dist, azi, k = buf[pos], buf[pos + 1], int(buf[pos + 2])
+            pos += 3
+            table = [(int(buf[pos + 4 * i]), int(buf[pos + 4 * i + 1]), int(buf[pos + 4 * i + 2]), buf[pos + 4 * i + 3]) for i in range(k)]
+            pos += 4 * k
+            layers.append({"distance": dist, "azi": azi, "table": table})
+        return {"ground_is_hit": hit, "ground_saa": gsaa, "ground": ground, "layers": layers}
+
     def streams(self):
         mu = np.zeros(self.nstr)
         wt = np.zeros(self.nstr)

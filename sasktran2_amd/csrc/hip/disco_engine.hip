@@ -130,13 +130,13 @@ __global__ void __launch_bounds__(256) kern_cw(Geo g, Bufs b) {
 // live flags of the table entries at azimuth order m, one byte per 8 entries: the adjoint sweeps test a bit instead of following
 // entry -> table slot -> convergence order (a dependent load per entry, repeated by the four lanes of a line of sight)
 __global__ void __launch_bounds__(256) kern_qlmask(Geo g, Bufs b, int m) {
-    const int nb = g.n_lp / 8;
+    const int nb = (g.n_lp + 7) / 8;
     const size_t n = size_t(b.nw) * nb;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         const int w = int(i / nb), k = int(i % nb);
         if (m >= b.norders[w]) continue;
         unsigned bits = 0;
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8 && 8 * k + j < g.n_lp; ++j)
             if (skd::conv_at(b, g, g.lp_slot[8 * k + j], w) > m) bits |= 1u << j;
         b.qlmask[i] = uint8_t(bits);
     }
@@ -424,7 +424,7 @@ void DeviceEngine::ensure_scratch(int nw, int nslots) {
         b.srcw = M.alloc<double>(size_t(t.nq_total) * W); b.att_total = M.alloc<double>(nlos * W);
         b.cwbuf = M.alloc<double>(t.N == 8 ? t.lp_q.size() * W : 1);
         b.eig = M.alloc<double>(t.N == 8 ? nlyr * (N + N * N) * W : 1);
-        b.qlmask = M.alloc<uint8_t>(t.N == 8 ? t.lp_q.size() / 8 * W + 8 : 8);
+        b.qlmask = M.alloc<uint8_t>(t.N == 8 ? (t.lp_q.size() + 7) / 8 * W + 8 : 8);
         b.rec = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W); b.dinv = M.alloc<double>(nlyr * 4 * N * N * W);
         sl->rec2 = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W);
         sl->dinv2 = M.alloc<double>(nlyr * 4 * N * N * W);

@@ -1576,7 +1576,7 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
     double* zw = b.z + size_t(w) * nlyr * ntile * 256;
     double* hw = b.qlbuf + size_t(w) * nlyr * ntile * 64;
     const double* cwp = b.cwbuf + size_t(w) * g.n_lp;
-    const uint8_t* mrow = b.qlmask + size_t(w) * (g.n_lp / 8);
+    const uint8_t* mrow = b.qlmask + size_t(w) * ((g.n_lp + 7) / 8);
     const double* pcm = g.lp_pc + size_t(m) * g.n_lp * NSTR;
     const bool last_is_ground = (m == 0);
     for (int tile0 = blockIdx.y * TILES; tile0 < ntile; tile0 += gridDim.y * TILES) {
@@ -1620,32 +1620,28 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
 #else
                 if (ok[t]) {
 #endif
-                    // groups are padded to multiples of 8 entries (zero weights): per 4 entries two 16-byte loads of weights, eight of the
-                    // cos(m phi) P_l^m table (this lane's 32 bytes per entry) and the live flags of the 8 entries in one byte
+                    // groups are padded to multiples of 4 entries (zero weights): per 4 entries two 16-byte loads of weights, eight of the
+                    // cos(m phi) P_l^m table (this lane's 32 bytes per entry) and the live flags of the 4 entries in half a byte
                     const int base = (los[t] * g.nsza + s) * nlyr + p;
                     const int e0 = g.lp_start[base], e1 = g.lp_start[base + 1];
-                    for (int e = e0; e < e1; e += 8) {
-                        const unsigned mk = mrow[e >> 3];
+                    for (int e = e0; e < e1; e += 4) {
+                        const unsigned mk = unsigned(mrow[e >> 3]) >> (e & 4);
+                        const double2* cw2 = reinterpret_cast<const double2*>(cwp + e);
+                        const double2* pc2 = reinterpret_cast<const double2*>(pcm + (size_t(e) * 4 + q) * 4);
+                        const double2 cv0 = cw2[0], cv1 = cw2[1];
+                        double2 pa[4], pb[4];
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const double2* cw2 = reinterpret_cast<const double2*>(cwp + e + 4 * h);
-                            const double2* pc2 = reinterpret_cast<const double2*>(pcm + (size_t(e + 4 * h) * 4 + q) * 4);
-                            const double2 cv0 = cw2[0], cv1 = cw2[1];
-                            double2 pa[4], pb[4];
+                        for (int u = 0; u < 4; ++u) {
+                            pa[u] = pc2[8 * u];
+                            pb[u] = pc2[8 * u + 1];
+                        }
+                        const double c[4] = {(mk & 1u) ? cv0.x : 0.0, (mk & 2u) ? cv0.y : 0.0, (mk & 4u) ? cv1.x : 0.0, (mk & 8u) ? cv1.y : 0.0};
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                pa[u] = pc2[8 * u];
-                                pb[u] = pc2[8 * u + 1];
-                            }
-                            const double c[4] = {((mk >> (4 * h)) & 1u) ? cv0.x : 0.0, ((mk >> (4 * h + 1)) & 1u) ? cv0.y : 0.0,
-                                                 ((mk >> (4 * h + 2)) & 1u) ? cv1.x : 0.0, ((mk >> (4 * h + 3)) & 1u) ? cv1.y : 0.0};
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                ql4[0] += c[u] * pa[u].x;
-                                ql4[1] += c[u] * pa[u].y;
-                                ql4[2] += c[u] * pb[u].x;
-                                ql4[3] += c[u] * pb[u].y;
-                            }
+                        for (int u = 0; u < 4; ++u) {
+                            ql4[0] += c[u] * pa[u].x;
+                            ql4[1] += c[u] * pa[u].y;
+                            ql4[2] += c[u] * pb[u].x;
+                            ql4[3] += c[u] * pb[u].y;
                         }
                     }
                 }

@@ -109,7 +109,9 @@ struct GeoTables {
                     tab_slot.push_back(slot);
                     tab_w.push_back(e.w);
                     const int p = nlyr - 1 - e.alt;
-                    lp[(size_t(l) * nsza + e.sza) * nlyr + p].push_back({q, e.angle, slot, e.w});
+                    // (an entry of weight zero adds nothing to any sum over the group: a segment that spans a whole layer sits exactly on a
+                    // table altitude, and half of its 2 x 2 stencil then carries 0 -- at BASELINE configs[1] half of all entries)
+                    if (e.w != 0.0) lp[(size_t(l) * nsza + e.sza) * nlyr + p].push_back({q, e.angle, slot, e.w});
                 }
                 rl_tab_start.push_back((int)tab_slot.size());
                 ++q;
@@ -129,11 +131,11 @@ struct GeoTables {
         rl_cosm_t.resize(rl_cosm.size());
         for (int m = 0; m < nstr; ++m)
             for (int i = 0; i < nq_total; ++i) rl_cosm_t[size_t(i) * nstr + m] = rl_cosm[size_t(m) * nq_total + i];
-        // 16 streams (matrix-core sweeps): every non-empty (LOS, sza, layer) group is padded to a multiple of 8 entries with zero-weight
-        // copies of its first entry, so that kern_k2b_mfma8 reads a group's weights with 16-byte loads and its live flags as one byte per 8
+        // 16 streams (matrix-core sweeps): every non-empty (LOS, sza, layer) group is padded to a multiple of 4 entries with zero-weight
+        // copies of its first entry, so that kern_k2b_mfma8 reads four weights with two 16-byte loads and their live flags as half a byte
         if (nstr == 16)
             for (auto& grp : lp)
-                while (grp.size() % 8 != 0) { LpE e = grp.front(); e.w = 0.0; grp.push_back(e); }
+                while (grp.size() % 4 != 0) { LpE e = grp.front(); e.w = 0.0; grp.push_back(e); }
         lp_start.assign(lp.size() + 1, 0);
         for (size_t i = 0; i < lp.size(); ++i) {
             for (const auto& e : lp[i]) { lp_q.push_back(e.q); lp_angle.push_back(e.angle); lp_slot.push_back(e.slot); lp_w.push_back(e.w); }

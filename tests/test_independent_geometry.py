@@ -233,6 +233,147 @@ def test_chapman_factors_against_closed_form():
             assert chap[p, rr] == 0.0
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Diffuse-source table stencils of the discrete-ordinates post-processing (reference: DOSourceDiffuseStorage::geometry_interpolator,
+# cpp/lib/sktran_disco/source_term/do_source_diffuse_storage.cpp:81-209, used by do_source_interpolated_pp.cpp:95-174): every ray
+# segment reads the table at  altitude = mean radius of its end points,  cos(angle) = - mean of (local up . look-away) at its end points,
+# azimuth = mean of the solar azimuths of the look-away direction at its end points, by linear interpolation in the layer mid-point
+# altitudes and in 100 cosines linspace(-1, 1, 100).  Recomputed here from closed-form shell intersections of the straight ray, with no code
+# of the product, and compared with what the shared geometry precompute holds (oracle accessor ray_tables).
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def ray_crossings(pos, look, alt):
+    """distances along pos + t look (t >= 0) at which the ray is inside the atmosphere, cut at every grid shell and at the tangent point,
+    ending at the ground; consecutive pairs are the ray segments from the observer outward"""
+    r_top, r_gnd = R_EARTH + alt[-1], R_EARTH + alt[0]
+    b, c0 = pos @ look, pos @ pos
+    disc = b * b - (c0 - r_top ** 2)
+    assert disc > 0
+    t_in, t_out = max(-b - np.sqrt(disc), 0.0), -b + np.sqrt(disc)
+    dg = b * b - (c0 - r_gnd ** 2)
+    if dg > 0 and (-b - np.sqrt(dg)) > 0:
+        t_out = -b - np.sqrt(dg)
+    ts = {t_in, t_out}
+    for a in alt[1:-1]:
+        d = b * b - (c0 - (R_EARTH + a) ** 2)
+        if d > 0:
+            for t in (-b - np.sqrt(d), -b + np.sqrt(d)):
+                if t_in < t < t_out:
+                    ts.add(t)
+    if t_in < -b < t_out:
+        ts.add(-b)   # tangent point
+    return np.array(sorted(ts))
+
+
+def linear_stencil(grid, x):
+    """sasktran2::grids::Grid::calculate_interpolation_weights, linear with out-of-bounds 'extend' (the end value)"""
+    if x <= grid[0]:
+        return {0: 1.0}
+    if x >= grid[-1]:
+        return {len(grid) - 1: 1.0}
+    i = int(np.searchsorted(grid, x, side="right")) - 1
+    w = (x - grid[i]) / (grid[i + 1] - grid[i])
+    return {i: 1.0 - w, i + 1: w}
+
+
+def brute_table_stencils(alt, sun, pos, look):
+    mid = 0.5 * (alt[1:] + alt[:-1])
+    cosines = np.linspace(-1.0, 1.0, 100)
+    out = []
+    ts = ray_crossings(pos, look, alt)
+    for t0, t1 in zip(ts[:-1], ts[1:]):
+        pe, px = pos + t0 * look, pos + t1 * look
+        altitude = 0.5 * (np.linalg.norm(pe) + np.linalg.norm(px)) - R_EARTH
+        cos_angle = -0.5 * (unit(pe) @ look + unit(px) @ look)
+        azis = []
+        for p_ in (pe, px):
+            up = unit(p_)
+            los_h, sun_h = unit(look - up * (look @ up)), unit(sun - up * (sun @ up))
+            azis.append(np.arctan2(np.cross(up, sun_h) @ los_h, sun_h @ los_h))
+        st = {}
+        for ia, wa in linear_stencil(mid, altitude).items():
+            for ic, wc in linear_stencil(cosines, cos_angle).items():
+                st[(ia, ic)] = wa * wc
+        out.append({"distance": t1 - t0, "azi": 0.5 * (azis[0] + azis[1]), "table": st})
+    return out[::-1]   # far end -> observer, as the engine orders its ray layers
+
+
+@pytest.mark.parametrize("ray", [
+    ("limb, tangent on a grid level", (sc.TANGENT_ALTITUDE_SOLAR, 0.6, 0.0, 600_000.0, 16_000.0)),
+    ("limb, off-grid tangent, oblique azimuth", (sc.TANGENT_ALTITUDE_SOLAR, 0.35, 1.9, 400_000.0, 23_456.0)),
+    ("nadir", (sc.GROUND_VIEWING_SOLAR, 0.6, 0.7, 300_000.0, 0.77)),
+    ("looking up from 12.3 km", (sc.VIEWING_UP_SOLAR, 0.6, 2.2, 12_300.0, 0.41)),
+    ("looking down from 31.1 km", (sc.VIEWING_UP_SOLAR, 0.5, 0.4, 31_100.0, -0.55)),
+], ids=lambda r: r[0])
+def test_diffuse_table_stencils_against_brute_force(ray):
+    """every segment's (altitude, angle) stencil, weight by weight, its azimuth and its length; a weight of the shared precompute perturbed
+    by 1e-6 fails this test (tolerance 1e-9)"""
+    from tests.test_oracle_golden import make_oracle
+    name, spec = ray
+    kind, csz, az, obs, x = spec
+    cos_sza_ref = 0.6
+    sun = frame(cos_sza_ref)
+    pos, look = {sc.TANGENT_ALTITUDE_SOLAR: tangent_ray, sc.GROUND_VIEWING_SOLAR: nadir_ray, sc.VIEWING_UP_SOLAR: inside_ray}[kind](sun, csz, az, x, obs)
+    s = sc.limb_c2(num_wavelengths=1)
+    s["geometry"]["cos_sza"] = cos_sza_ref
+    s["rays"] = [spec]
+    alt = s["geometry"]["altitudes"]
+    got = make_oracle(s).ray_tables(0)
+    want = brute_table_stencils(alt, sun, pos, look)
+    # the engine keeps zero-length segments (a tangent point on a grid level splits nothing): drop them on its side
+    layers = [L for L in got["layers"] if L["distance"] > 1e-3]
+    assert got["ground_is_hit"] == hits_ground(pos, look)
+    assert len(layers) == len(want), (len(layers), len(want))
+    mirrored = []
+    for L, W in zip(layers, want):
+        assert abs(L["distance"] - W["distance"]) < 1e-6 * max(1.0, W["distance"]), (L["distance"], W["distance"])
+        have = {}
+        for sza, ia, ic, w in L["table"]:
+            assert sza == 0
+            have[(ia, ic)] = have.get((ia, ic), 0.0) + w
+        # (a segment that spans a whole layer sits on a table altitude up to rounding: weights of 1e-12 and less are that rounding)
+        have = {k: v for k, v in have.items() if v > 1e-10}
+        wantw = {k: v for k, v in W["table"].items() if v > 1e-10}
+        assert set(have) == set(wantw), (sorted(have), sorted(wantw))
+        for k in wantw:
+            assert abs(have[k] - wantw[k]) < 1e-9, (k, have[k], wantw[k])
+        assert abs(sum(have.values()) - 1.0) < 1e-9
+        # azimuths enter as cos(m azi) (and sin(m azi) for U): compared on the circle, up to the handedness of this test's own frame
+        # (a mirror image of the scene; the reference's sense of the relative azimuth is pinned by its regression radiances) -- but the
+        # same handedness for every segment of the ray
+        d_same = abs(np.angle(np.exp(1j * (L["azi"] - W["azi"])))), 
+        d_mirr = abs(np.angle(np.exp(1j * (L["azi"] + W["azi"]))))
+        mirrored.append(d_mirr < d_same[0])
+        assert min(d_same[0], d_mirr) < 1e-8, (L["azi"], W["azi"])
+    sig = [m for m, W in zip(mirrored, want) if abs(np.sin(W["azi"])) > 1e-6]
+    assert all(sig) or not any(sig)
+    if got["ground_is_hit"]:
+        # ground point (create_ground_source_interpolator, do_source_diffuse_storage.cpp:211-261): the upwelling table at mu = local up . (-look),
+        # linear in the 100 cosines with a negative lower neighbour moved onto the upper one, azimuth factor cos(m (pi - saa))
+        # (the reference evaluates both at the ENTRANCE of the ray's last layer -- `layers[0].entrance`, do_source_interpolated_pp.cpp:60-72 --
+        # i.e. where the ray enters the lowest shell, not at the ground point itself: mu differs from the ground value in the 4th digit)
+        tg = ray_crossings(pos, look, alt)[-2]
+        pg = pos + tg * look
+        up = unit(pg)
+        mu = up @ (-look)
+        st = linear_stencil(np.linspace(-1.0, 1.0, 100), mu)
+        cosines = np.linspace(-1.0, 1.0, 100)
+        wantg = {}
+        keys = sorted(st)
+        for n, i in enumerate(keys):
+            idx = keys[1] if (n == 0 and len(keys) > 1 and cosines[i] < 0) else i
+            wantg[idx] = wantg.get(idx, 0.0) + st[i]
+        haveg = {}
+        for ic, sza, w in got["ground"]:
+            assert sza == 0
+            haveg[ic] = haveg.get(ic, 0.0) + w
+        assert set(haveg) == set(wantg)
+        for k in wantg:
+            assert abs(haveg[k] - wantg[k]) < 1e-9
+        los_h, sun_h = unit(look - up * (look @ up)), unit(sun - up * (sun @ up))
+        saa = np.arctan2(np.cross(up, sun_h) @ los_h, sun_h @ los_h)
+        assert min(abs(np.angle(np.exp(1j * (got["ground_saa"] - saa)))), abs(np.angle(np.exp(1j * (got["ground_saa"] + saa))))) < 1e-8
+
+
 if __name__ == "__main__":
     for r in [("limb", (sc.TANGENT_ALTITUDE_SOLAR, 0.5, 0.6, 300_000.0, 21_300.0)), ("nadir", (sc.GROUND_VIEWING_SOLAR, 0.5, 1.1, 250_000.0, 0.83))]:
         test_single_scatter_radiance_and_optical_depth_against_brute_force(r)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Profile of bench.py --workload c4 on the GPU box: kernel trace of one full step + separate PMC passes at a reduced block (256 wavelengths).
+# usage (inside gpurun): tools/profile_c4.sh <tag>   -> gpurun_out/prof_<tag>/{trace,fetch,write,f64,mfma,wave}, summary_c4.json
+set -e
+tag=${1:-c4}
+root=$PWD
+out=$root/gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $root/bench.py --workload c4 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $out/trace -o r -- $BENCH --steps 1 --warmup 1 --wavelengths 1024 > $out/trace.log 2>&1
+echo "trace done"
+PMCARGS="--steps 1 --warmup 1 --wavelengths 256"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o r -- $BENCH $PMCARGS > $out/fetch.log 2>&1
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o r -- $BENCH $PMCARGS > $out/write.log 2>&1
+echo "write done"
+rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace -d $out/f64 -o r -- $BENCH $PMCARGS > $out/f64.log 2>&1
+echo "f64 done"
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $out/mfma -o r -- $BENCH $PMCARGS > $out/mfma.log 2>&1
+echo "mfma done"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAVES --kernel-trace -d $out/wave -o r -- $BENCH $PMCARGS > $out/wave.log 2>&1
+echo "wave done"
+cd $root
+PMC_WAVELENGTHS=256 python3 tools/summarize_profile.py $out > $out/summary_c4.json
+tail -c 1200 $out/summary_c4.json
