@@ -196,6 +196,7 @@ struct SoHandle {
     skso::SoGeometry sg;
     int num_iterations = 50;
     const double *emission = nullptr, *surface_emission = nullptr;
+    oracle_so::Solver::FixedPoint fixed_point;
 };
 
 void* orso_create(double cos_sza, double saa, double earth_radius, const double* altitudes, int ngrid, int interp_method, int geotype,
@@ -243,6 +244,17 @@ int orso_set_emission(void* hv, const double* emission, const double* surface_em
     if (!h) return -1;
     h->emission = emission;
     h->surface_emission = surface_emission;
+    return 0;
+}
+// MultipleScatterSource::SuccessiveOrders: fixed point with Anderson mixing instead of a fixed number of legacy passes (so_oracle.hpp)
+int orso_set_fixed_point(void* hv, int enabled, double relative_tolerance, double absolute_tolerance, double damping, int anderson_depth) {
+    auto* h = static_cast<SoHandle*>(hv);
+    if (!h || anderson_depth < 0 || anderson_depth > 3 || !(damping > 0 && damping <= 1)) return -1;
+    h->fixed_point.enabled = enabled != 0;
+    h->fixed_point.relative_tolerance = relative_tolerance;
+    h->fixed_point.absolute_tolerance = absolute_tolerance;
+    h->fixed_point.damping = damping;
+    h->fixed_point.anderson_depth = anderson_depth;
     return 0;
 }
 int orso_lebedev(int npoints, double* xyzw) {
@@ -294,6 +306,7 @@ int orso_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     {
         oracle_so::Solver solver(h->sg);
         solver.num_iterations = h->num_iterations;
+        solver.fixed_point = h->fixed_point;
         oracle_so::Result res;
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)

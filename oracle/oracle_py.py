@@ -148,7 +148,9 @@ class SoOracleEngine:
 
     def __init__(self, cos_sza, saa, earth_radius, altitudes, interp_method, geotype, rays, nstokes=1, stokes_basis=0,
                  num_ss_moments=16, num_ms_moments=16, num_incoming=110, num_outgoing=110, num_sza=1, num_iterations=50,
-                 single_scatter=True, multiple_scatter=True, emission=0, occultation=False):
+                 single_scatter=True, multiple_scatter=True, emission=0, occultation=False, fixed_point=None):
+        """fixed_point: None (legacy passes) or dict(relative_tolerance, absolute_tolerance, damping, anderson_depth) for
+        MultipleScatterSource::SuccessiveOrders (num_iterations is then the iteration limit)"""
         L = lib()
         L.orso_create.restype = ctypes.c_void_p
         L.orso_create.argtypes = [ctypes.c_double] * 3 + [_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _dp] + [ctypes.c_int] * 12
@@ -166,6 +168,11 @@ class SoOracleEngine:
                                 int(single_scatter), int(multiple_scatter), int(emission), int(occultation))   # single_scatter: 0 none, 1 exact, 2 solar table
         if not self._h:
             raise RuntimeError("successive-orders oracle construction failed")
+        if fixed_point is not None:
+            L.orso_set_fixed_point.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+            if L.orso_set_fixed_point(self._h, 1, float(fixed_point.get("relative_tolerance", 1e-6)), float(fixed_point.get("absolute_tolerance", 1e-12)),
+                                      float(fixed_point.get("damping", 1.0)), int(fixed_point.get("anderson_depth", 3))) != 0:
+                raise ValueError("invalid fixed-point settings")
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -271,6 +271,43 @@ class Solver {
             }
             incoming_ = first_;
             outgoing_.assign(size_t(nout_total) * S_, 0.0);
+            // one application of the map  x -> S (first + T x)  of the diffuse field: incoming radiance from the outgoing sources (the
+            // accumulation matrix T), then the scattering / reflection at every diffuse point (S); `from_first`: x = 0, incoming = first
+            auto apply_map = [&](const std::vector<double>& x, std::vector<double>& mapped, bool from_first) {
+                if (!from_first)
+                    for (int r = 0; r < nr; ++r)
+                        for (int s = 0; s < S_; ++s) {
+                            double v = 0;
+                            for (int e = g_.accumulation.start[r]; e < g_.accumulation.start[r + 1]; ++e) v += acc_[e] * x[size_t(g_.accumulation.idx[e]) * S_ + s];
+                            incoming_[size_t(r) * S_ + s] = v + first_[size_t(r) * S_ + s];
+                        }
+                for (int p = 0; p < g_.npoints; ++p) {
+                    const double* inc = incoming_.data() + size_t(g_.in_start[p]) * S_;
+                    double* out = mapped.data() + size_t(g_.out_start[p]) * S_;
+                    if (p < g_.ninterior) {
+                        const double* M = M_.data() + size_t(p) * rows * cols;
+                        for (int o = 0; o < rows; ++o) {
+                            double v = 0;
+                            for (int i = 0; i < cols; ++i) v += M[size_t(o) * cols + i] * inc[i];
+                            out[o] = v;
+                        }
+                    } else {
+                        const int gi = p - g_.ninterior;
+                        double v = 0;
+                        for (int i = 0; i < g_.ground_nin[gi]; ++i) v += (albedo / skgeo::kPi) * g_.ground_in_factor[gi][i] * inc[size_t(i) * S_];
+                        for (int o = 0; o < g_.ground_nout[gi]; ++o) {
+                            out[size_t(o) * S_] = v;
+                            for (int s = 1; s < S_; ++s) out[size_t(o) * S_ + s] = 0;
+                        }
+                    }
+                }
+            };
+            if (fixed_point.enabled) {
+                // MultipleScatterSource::SuccessiveOrders: the fixed point x = S (first + T x) by damped Picard steps with Type-II Anderson
+                // mixing of depth <= 3 and an infinity-norm stop rule (cpp/lib/successive_orders/fixed_point.h:132-258), on the operators of
+                // the legacy discretisation above.  With depth 0, damping 1 and zero tolerances this IS the legacy iteration.
+                fixed_point_iterations_used = solve_fixed_point(apply_map);
+            } else
             // num_hr_spherical_iterations passes (diffuse_table.cpp:751-819)
             for (int it = 0; it < num_iterations; ++it) {
                 if (it > 0)
@@ -364,6 +401,99 @@ class Solver {
         }
     }
     int num_iterations = 50;   // Config::num_hr_spherical_iterations
+    // settings of the reference's FixedPointSolver (fixed_point.h:13-45); maximum_iterations = num_iterations
+    struct FixedPoint { bool enabled = false; double relative_tolerance = 1e-6, absolute_tolerance = 1e-12, damping = 1.0; int anderson_depth = 3; } fixed_point;
+    int fixed_point_iterations_used = 0;
+
+  private:
+    template <typename Map> int solve_fixed_point(Map&& apply_map) {
+        const size_t n = outgoing_.size();
+        const int depth = fixed_point.anderson_depth;
+        std::vector<double>& x = outgoing_;   // the state: total outgoing source of the diffuse points, starts at 0
+        std::vector<double> mapped(n), res(n), prev_x(n), prev_r(n), trial(n);
+        std::vector<std::vector<double>> dX(depth, std::vector<double>(n)), dR(depth, std::vector<double>(n));
+        int hist = 0, start = 0, used = 0;
+        bool have_prev = false;
+        const bool conv_on = fixed_point.relative_tolerance > 0 || fixed_point.absolute_tolerance > 0;
+        for (int it = 0; it < num_iterations; ++it) {
+            apply_map(x, mapped, it == 0);
+            double rn = 0, scale = 0;
+            for (size_t i = 0; i < n; ++i) {
+                res[i] = mapped[i] - x[i];
+                rn = std::max(rn, std::fabs(res[i]));
+                scale = std::max(scale, std::max(std::fabs(x[i]), std::fabs(mapped[i])));
+            }
+            used = it + 1;
+            if (conv_on && rn <= fixed_point.absolute_tolerance + fixed_point.relative_tolerance * scale) { x = mapped; return used; }
+            // history of differences (a ring of `depth` columns)
+            if (have_prev && depth > 0) {
+                int slot;
+                if (hist < depth) { slot = (start + hist) % depth; ++hist; }
+                else { slot = start; start = (start + 1) % depth; }
+                for (size_t i = 0; i < n; ++i) { dX[slot][i] = x[i] - prev_x[i]; dR[slot][i] = res[i] - prev_r[i]; }
+            }
+            prev_x = x;
+            prev_r = res;
+            have_prev = true;
+            bool mixed = false;
+            if (hist > 0) {
+                double G[3][3] = {{0}}, rhs[3] = {0}, c[3] = {0};
+                for (int a = 0; a < hist; ++a) {
+                    const std::vector<double>& ra = dR[(start + a) % depth];
+                    for (size_t i = 0; i < n; ++i) rhs[a] += ra[i] * res[i];
+                    for (int bb = 0; bb <= a; ++bb) {
+                        const std::vector<double>& rb = dR[(start + bb) % depth];
+                        double v = 0;
+                        for (size_t i = 0; i < n; ++i) v += ra[i] * rb[i];
+                        G[a][bb] = G[bb][a] = v;
+                    }
+                }
+                double gmax = 1.0;
+                for (int a = 0; a < hist; ++a) gmax = std::max(gmax, G[a][a]);
+                for (int a = 0; a < hist; ++a) G[a][a] += 1e-14 * gmax;
+                bool ok = solve_small(G, rhs, c, hist);
+                if (ok) {
+                    for (size_t i = 0; i < n; ++i) {
+                        double v = x[i] + fixed_point.damping * res[i];
+                        for (int a = 0; a < hist; ++a) {
+                            const int slot = (start + a) % depth;
+                            v -= c[a] * (dX[slot][i] + fixed_point.damping * dR[slot][i]);
+                        }
+                        trial[i] = v;
+                        ok = ok && std::isfinite(v);
+                    }
+                    if (ok) { x = trial; mixed = true; }
+                }
+            }
+            if (!mixed) {
+                if (fixed_point.damping == 1.0) x = mapped;   // (exactly the legacy pass)
+                else for (size_t i = 0; i < n; ++i) x[i] += fixed_point.damping * res[i];
+            }
+        }
+        return used;
+    }
+    // symmetric positive (semi)definite system of order <= 3 by Gaussian elimination with partial pivoting
+    static bool solve_small(double (&G)[3][3], double (&rhs)[3], double (&c)[3], int n) {
+        double A[3][4];
+        for (int i = 0; i < n; ++i) { for (int j = 0; j < n; ++j) A[i][j] = G[i][j]; A[i][n] = rhs[i]; }
+        for (int k = 0; k < n; ++k) {
+            int piv = k;
+            for (int i = k + 1; i < n; ++i) if (std::fabs(A[i][k]) > std::fabs(A[piv][k])) piv = i;
+            if (!(std::fabs(A[piv][k]) > 0)) return false;
+            if (piv != k) for (int j = 0; j <= n; ++j) std::swap(A[k][j], A[piv][j]);
+            for (int i = k + 1; i < n; ++i) {
+                const double f = A[i][k] / A[k][k];
+                for (int j = k; j <= n; ++j) A[i][j] -= f * A[k][j];
+            }
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double v = A[i][n];
+            for (int j = i + 1; j < n; ++j) v -= A[i][j] * c[j];
+            c[i] = v / A[i][i];
+            if (!std::isfinite(c[i])) return false;
+        }
+        return true;
+    }
 };
 
 }  // namespace oracle_so

@@ -81,7 +81,10 @@ class Config:
              "emission_source": "emission_source", "occultation_source": "occultation_source", "do_backprop": "do_backprop",
              # successive orders (src/sasktran2/config.py:410-418,505-514,607-634 -> the C API's `hr` keys)
              "num_successive_orders_iterations": "num_hr_spherical_iterations", "num_successive_orders_incoming": "num_hr_incoming",
-             "num_successive_orders_outgoing": "num_hr_outgoing", "init_successive_orders_with_discrete_ordinates": "initialize_hr_with_do"}
+             "num_successive_orders_outgoing": "num_hr_outgoing", "init_successive_orders_with_discrete_ordinates": "initialize_hr_with_do",
+             # MultipleScatterSource.SuccessiveOrders: the fixed-point solver's settings (src/sasktran2/config.py:426-503)
+             "successive_orders_anderson_depth": "successive_orders_anderson_depth"}
+    _FLOAT_KEYS = ("successive_orders_relative_tolerance", "successive_orders_absolute_tolerance", "successive_orders_damping")
 
     def __init__(self):
         object.__setattr__(self, "_h", lib().sk_config_create())
@@ -91,6 +94,10 @@ class Config:
             lib().sk_config_destroy(self._h)
 
     def __getattr__(self, name):
+        if name in Config._FLOAT_KEYS:
+            d = ctypes.c_double()
+            getattr(lib(), f"sk_config_get_{name}")(self._h, ctypes.byref(d))
+            return d.value
         key = Config._KEYS.get(name)
         if key is None:
             raise AttributeError(name)
@@ -99,6 +106,10 @@ class Config:
         return v.value
 
     def __setattr__(self, name, value):
+        if name in Config._FLOAT_KEYS:
+            if getattr(lib(), f"sk_config_set_{name}")(self._h, float(value)) != 0:
+                raise RuntimeError(last_error())
+            return
         key = Config._KEYS.get(name)
         if key is None:
             raise AttributeError(f"Config has no option {name!r} on the MI355X path")

@@ -27,6 +27,9 @@ SIGNATURES = [
       "num_streams", "num_threads", "wavelength_batch_size", "num_singlescatter_moments", "num_do_sza", "wf_enabled",
       "output_los_optical_depth", "apply_delta_scaling", "stokes_basis", "num_hr_spherical_iterations", "num_hr_incoming",
       "num_hr_outgoing", "initialize_hr_with_do", "emission_source", "occultation_source", "do_backprop")],
+    *[(f"sk_config_get_{k}", _I, [_vp, _dp]) for k in ("successive_orders_relative_tolerance", "successive_orders_absolute_tolerance", "successive_orders_damping")],
+    *[(f"sk_config_set_{k}", _I, [_vp, _D]) for k in ("successive_orders_relative_tolerance", "successive_orders_absolute_tolerance", "successive_orders_damping")],
+    ("sk_config_get_successive_orders_anderson_depth", _I, [_vp, _ip]), ("sk_config_set_successive_orders_anderson_depth", _I, [_vp, _I]),
     ("sk_geometry1d_create", _vp, [_D, _D, _D, _dp, _I, _I, _I]), ("sk_geometry1d_destroy", None, [_vp]),
     ("sk_geometry1d_get_num_altitudes", _I, [_vp]), ("sk_geometry1d_get_altitudes", _I, [_vp, _dp]),
     ("sk_viewing_geometry_create", _vp, []), ("sk_viewing_geometry_destroy", None, [_vp]),

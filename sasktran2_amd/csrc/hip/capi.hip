@@ -468,9 +468,15 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
         if (c->stokes_basis < 0 || c->stokes_basis > 2) throw std::runtime_error("stokes_basis must be standard (0), solar (1) or observer (2)");
         // sources of this build (cpp/include/sasktran2/config.h:41-71): multiple scatter discrete_ordinates (0), successive_orders_legacy (1),
         // twostream (2) or none (3); single scatter exact (0), solartable (1), discrete_ordinates (2) or none (3)
-        if (c->ms_source < 0 || c->ms_source > 3)
-            throw std::runtime_error("multiple_scatter_source must be discrete_ordinates (0), successive_orders_legacy (1), twostream (2) or none (3); "
-                                     "successive_orders (4) is not part of this build");
+        if (c->ms_source < 0 || c->ms_source > 4)
+            throw std::runtime_error("multiple_scatter_source must be discrete_ordinates (0), successive_orders_legacy (1), twostream (2), none (3) or "
+                                     "successive_orders (4)");
+        // successive_orders (4, cpp/include/sasktran2/config.h:70): the reference's fixed-point / Anderson driver (successive_orders_* keys) on the
+        // diffuse-point discretisation of the legacy source (Lebedev spheres per layer mid point); an explicit successive_orders_altitude_grid_m
+        // (its own node grid) is not part of this build
+        const bool so_new = c->ms_source == 4;
+        if (so_new && !c->successive_orders_altitude_grid_m.empty())
+            throw std::runtime_error("successive_orders_altitude_grid_m is not part of this build (the diffuse points sit at the layer mid points)");
         const bool two_stream = c->ms_source == 2 || c->emission_source == 4;
         if (c->ss_source < 0 || c->ss_source > 3)
             throw std::runtime_error("single_scatter_source must be exact (0), solartable (1), discrete_ordinates (2) or none (3)");
@@ -487,7 +493,7 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
         if (two_stream) {
             // the reference builds the two-stream sources for NSTOKES = 1 only (cpp/lib/engine/engine.cpp:264-276, 384-397)
             if (c->num_stokes != 1) throw std::runtime_error("the two-stream source is only implemented for NSTOKES = 1");
-            if (c->ms_source == 0 || c->ms_source == 1)
+            if (c->ms_source == 0 || c->ms_source == 1 || c->ms_source == 4)
                 throw std::runtime_error("emission_source = twostream next to a discrete-ordinates or successive-orders multiple-scatter source is not part of this build");
         }
         if (c->emission_source == 2 && (c->ms_source != 0 || c->num_stokes != 1 || g->geotype == 2))
@@ -523,9 +529,9 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
             skts::build_ts_geometry(geo, v->rays, cfg, tg);
             e->ts = std::make_unique<skdev::TsDeviceEngine>(tg);
         }
-        if (ss_los || c->ms_source == 1 || emission != 0 || occultation) {
+        if (ss_los || c->ms_source == 1 || so_new || emission != 0 || occultation) {
             if (g->geotype != 2) throw std::runtime_error("the exact single-scatter, successive-orders, emission and occultation sources need spherical geometry");
-            if (c->ms_source == 1 && (c->initialize_hr_with_do || c->num_hr_full_incoming_points > 0))
+            if ((c->ms_source == 1 || so_new) && (c->initialize_hr_with_do || c->num_hr_full_incoming_points > 0))
                 throw std::runtime_error("initialize_hr_with_do and num_hr_full_incoming_points are not part of this build");
             skso::Settings cfg;
             cfg.nstokes = c->num_stokes;
@@ -536,12 +542,15 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
             cfg.num_sza = c->num_sza;
             cfg.single_scatter = ss_los;
             cfg.solar_table = c->ss_source == 1;
-            cfg.multiple_scatter = c->ms_source == 1;
+            cfg.multiple_scatter = c->ms_source == 1 || so_new;
             cfg.emission = emission;
             cfg.occultation = occultation;
             skso::SoGeometry sg;
             skso::build_so_geometry(geo, v->rays, cfg, sg, c->stokes_basis);
             e->so = std::make_unique<skdev::SoDeviceEngine>(sg, c->num_hr_spherical_iterations);
+            if (so_new)
+                e->so->set_fixed_point(true, c->successive_orders_relative_tolerance, c->successive_orders_absolute_tolerance, c->successive_orders_damping,
+                                       c->successive_orders_anderson_depth);
         }
         if (!e->dev && !e->so && !e->ts) throw std::runtime_error("no source term configured (single_scatter_source and multiple_scatter_source are both none)");
         return e.release();

@@ -18,6 +18,8 @@
 // and wavelength), which cuts the per-wavelength HBM stream of an iteration from 8 B per matrix entry to 8 B per ray layer.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -952,6 +954,116 @@ __global__ void __launch_bounds__(kWave) k_so_accumulate(SoGeo g, SoBufs b) {
     for (int s = 0; s < S; ++s) v.incoming[(size_t(r) * S + s) * kWave] = acc[s];
 }
 
+// One step of the fixed-point driver of MultipleScatterSource::SuccessiveOrders (reference: FixedPointSolver::solve / update_history /
+// anderson_update, cpp/lib/successive_orders/fixed_point.h:132-258), one wavelength per LANE: residual and stop rule in the infinity norm,
+// the ring of state / residual differences, the <= 3 x 3 normal equations of the Type-II Anderson step (diagonal regularised by
+// 1e-14 x its scale; an unsolvable or non-finite step falls back to the damped Picard step), the new state.  The state vectors are slab major
+// like every per-wavelength array here ([slab][item][64]), so every pass is a unit-stride stream.  The bookkeeping of the ring (hist, start,
+// slot) is the same for all wavelengths still iterating and comes from the host; a wavelength that met the tolerance keeps its state.
+struct FpStep {
+    int n;                      // state items per wavelength
+    int depth, hist, start;     // ring AFTER this step's history update: `hist` valid columns, oldest at `start`
+    int slot;                   // column written by this step's history update, -1: none (first step or depth 0)
+    int conv_on;
+    double rel, abs, damping;
+};
+__global__ void __launch_bounds__(kWave) k_so_fixed_point(SoBufs b, FpStep P, double* __restrict__ x_, const double* __restrict__ mapped_,
+                                                          double* __restrict__ prev_x_, double* __restrict__ prev_r_, double* __restrict__ dX_,
+                                                          double* __restrict__ dR_, int* __restrict__ done, int* __restrict__ active) {
+    const int lane = threadIdx.x, w = blockIdx.x * kWave + lane;
+    const size_t o = size_t(blockIdx.x) * kWave * P.n + lane, col = size_t(b.nwp) * P.n;   // column stride of the difference rings
+    double* x = x_ + o;
+    const double* mapped = mapped_ + o;
+    double *prev_x = prev_x_ + o, *prev_r = prev_r_ + o, *dX = dX_ + o, *dR = dR_ + o;
+    if (w >= b.nw || done[w]) return;
+    double rn = 0, scale = 0;
+    for (int i = 0; i < P.n; ++i) {
+        const double xi = x[size_t(i) * kWave], mi = mapped[size_t(i) * kWave];
+        rn = fmax(rn, fabs(mi - xi));
+        scale = fmax(scale, fmax(fabs(xi), fabs(mi)));
+    }
+    if (P.conv_on && rn <= P.abs + P.rel * scale) {
+        for (int i = 0; i < P.n; ++i) x[size_t(i) * kWave] = mapped[size_t(i) * kWave];
+        done[w] = 1;
+        return;
+    }
+    if (P.conv_on) atomicAdd(active, 1);
+    // history of differences, then this step's state / residual become the previous ones
+    for (int i = 0; i < P.n; ++i) {
+        const size_t k = size_t(i) * kWave;
+        const double xi = x[k], ri = mapped[k] - xi;
+        if (P.slot >= 0) {
+            dX[col * P.slot + k] = xi - prev_x[k];
+            dR[col * P.slot + k] = ri - prev_r[k];
+        }
+        prev_x[k] = xi;
+        prev_r[k] = ri;
+    }
+    bool mixed = false;
+    double c[3] = {0, 0, 0};
+    if (P.hist > 0) {
+        double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, rhs[3] = {0, 0, 0};
+        const size_t s0 = col * ((P.start + 0) % P.depth), s1 = col * ((P.start + 1) % P.depth), s2 = col * ((P.start + 2) % P.depth);
+        for (int i = 0; i < P.n; ++i) {
+            const size_t k = size_t(i) * kWave;
+            const double ri = prev_r[k];
+            const double r0 = dR[s0 + k], r1 = (P.hist > 1) ? dR[s1 + k] : 0.0, r2 = (P.hist > 2) ? dR[s2 + k] : 0.0;
+            rhs[0] += r0 * ri; rhs[1] += r1 * ri; rhs[2] += r2 * ri;
+            G[0][0] += r0 * r0; G[1][0] += r1 * r0; G[1][1] += r1 * r1; G[2][0] += r2 * r0; G[2][1] += r2 * r1; G[2][2] += r2 * r2;
+        }
+        G[0][1] = G[1][0]; G[0][2] = G[2][0]; G[1][2] = G[2][1];
+        double gmax = 1.0;
+        for (int a = 0; a < P.hist; ++a) gmax = fmax(gmax, G[a][a]);
+        for (int a = 0; a < P.hist; ++a) G[a][a] += 1e-14 * gmax;
+        // symmetric system of order hist <= 3: Gaussian elimination with partial pivoting
+        double A[3][4];
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) A[i][j] = G[i][j]; A[i][3] = rhs[i]; }
+        bool ok = true;
+        const int n = P.hist;
+        for (int k = 0; k < n && ok; ++k) {
+            int piv = k;
+            for (int i = k + 1; i < n; ++i) if (fabs(A[i][k]) > fabs(A[piv][k])) piv = i;
+            if (!(fabs(A[piv][k]) > 0)) { ok = false; break; }
+            if (piv != k) for (int j = 0; j < 4; ++j) { const double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
+            for (int i = k + 1; i < n; ++i) {
+                const double f = A[i][k] / A[k][k];
+                for (int j = k; j < 4; ++j) A[i][j] -= f * A[k][j];
+            }
+        }
+        // (the right-hand side sits in column 3 whatever the order: columns n .. 2 of the eliminated rows are zero)
+        for (int i = n - 1; i >= 0 && ok; --i) {
+            double v = A[i][3];
+            for (int j = i + 1; j < n; ++j) v -= A[i][j] * c[j];
+            c[i] = v / A[i][i];
+            ok = isfinite(c[i]);
+        }
+        if (ok) {
+            for (int i = 0; i < P.n && ok; ++i) {
+                const size_t k = size_t(i) * kWave;
+                double v = prev_x[k] + P.damping * prev_r[k] - c[0] * (dX[s0 + k] + P.damping * dR[s0 + k]);
+                if (P.hist > 1) v -= c[1] * (dX[s1 + k] + P.damping * dR[s1 + k]);
+                if (P.hist > 2) v -= c[2] * (dX[s2 + k] + P.damping * dR[s2 + k]);
+                ok = isfinite(v);
+            }
+            if (ok) {
+                for (int i = 0; i < P.n; ++i) {
+                    const size_t k = size_t(i) * kWave;
+                    double v = prev_x[k] + P.damping * prev_r[k] - c[0] * (dX[s0 + k] + P.damping * dR[s0 + k]);
+                    if (P.hist > 1) v -= c[1] * (dX[s1 + k] + P.damping * dR[s1 + k]);
+                    if (P.hist > 2) v -= c[2] * (dX[s2 + k] + P.damping * dR[s2 + k]);
+                    x[k] = v;
+                }
+                mixed = true;
+            }
+        }
+    }
+    if (!mixed)
+        for (int i = 0; i < P.n; ++i) {
+            const size_t k = size_t(i) * kWave;
+            x[k] = (P.damping == 1.0) ? mapped[k] : x[k] + P.damping * prev_r[k];   // damping 1: exactly the legacy pass
+        }
+}
+
 struct DevMem {
     std::vector<void*> ptrs;
     template <typename T>
@@ -980,6 +1092,12 @@ struct SoDeviceEngine::Impl {
     DevMem tables, scratch;
     SoBufs b{};
     int num_iterations = 50;
+    // fixed-point driver (set_fixed_point): state x, map(x), previous state / residual and the two rings of `depth` difference columns,
+    // each [nwp][n_out x S] slab major; `done` per wavelength, `active` = wavelengths that did not meet the tolerance in the last step
+    struct FixedPoint { bool enabled = false; double rel = 1e-6, abs = 1e-12, damping = 1.0; int depth = 3; } fp;
+    double *fp_x = nullptr, *fp_mapped = nullptr, *fp_prev_x = nullptr, *fp_prev_r = nullptr, *fp_dX = nullptr, *fp_dR = nullptr;
+    int *fp_done = nullptr, *fp_active = nullptr;
+    int fp_last_iterations = 0;
     bool single_scatter = true, multiple_scatter = true;
     int capacity = 0, cap_nleg = 0;
     bool cap_derivs = false;
@@ -1263,6 +1381,21 @@ int SoDeviceEngine::nstokes() const { return impl_->g.S; }
 bool SoDeviceEngine::has_successive_orders() const { return impl_->multiple_scatter; }
 bool SoDeviceEngine::has_unlinearised_sources() const { return impl_->multiple_scatter; }
 bool SoDeviceEngine::has_emission() const { return impl_->g.emission != 0; }
+void SoDeviceEngine::set_fixed_point(bool enabled, double relative_tolerance, double absolute_tolerance, double damping, int anderson_depth) {
+    if (!(relative_tolerance >= 0) || !(absolute_tolerance >= 0) || !std::isfinite(relative_tolerance) || !std::isfinite(absolute_tolerance))
+        throw std::runtime_error("successive-orders tolerances must be finite and non-negative");
+    if (!(damping > 0 && damping <= 1)) throw std::runtime_error("successive-orders damping must lie in (0, 1]");
+    if (anderson_depth < 0 || anderson_depth > 3) throw std::runtime_error("successive-orders Anderson depth must be 0 .. 3 in this build");
+    Impl& I = *impl_;
+    I.fp.enabled = enabled;
+    I.fp.rel = relative_tolerance;
+    I.fp.abs = absolute_tolerance;
+    I.fp.damping = damping;
+    I.fp.depth = anderson_depth;
+    I.scratch.release();   // the next solve sizes its scratch with the state vectors
+    I.capacity = 0;
+}
+int SoDeviceEngine::last_fixed_point_iterations() const { return impl_->fp_last_iterations; }
 void SoDeviceEngine::set_emission(const double* d_emission, const double* d_surface_emission) {
     impl_->d_emission = d_emission;
     impl_->d_surface_emission = d_surface_emission;
@@ -1295,6 +1428,7 @@ static size_t so_doubles_per_wavelength(const SoDeviceEngine::Impl& I, int nleg)
     if (I.multiple_scatter)
         d += I.n_table + size_t(g.ninterior) * g.num_ms_moments * per + 2 * I.n_inc_rays * S + I.n_out * S + I.n_inc_layers * (2 + S) + I.n_inc_rays +
              size_t(g.ninterior) * g.nlm;
+    if (I.multiple_scatter && I.fp.enabled) d += size_t(4 + 2 * I.fp.depth) * I.n_out * S + 1;
     return d;
 }
 size_t SoDeviceEngine::bytes_per_wavelength() const { return so_doubles_per_wavelength(*impl_, std::max(impl_->cap_nleg, impl_->g.num_ss_moments)) * sizeof(double); }
@@ -1348,6 +1482,17 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             b.lod = I.scratch.alloc<double>(I.n_inc_layers * W);
             b.lsrc = I.scratch.alloc<double>(I.n_inc_layers * S * W);
             b.sh = g.nlm > 0 ? I.scratch.alloc<double>(size_t(g.ninterior) * g.nlm * W) : nullptr;
+            if (I.fp.enabled) {
+                const size_t nst = I.n_out * S * W;
+                I.fp_x = I.scratch.alloc<double>(nst);
+                I.fp_mapped = I.scratch.alloc<double>(nst);
+                I.fp_prev_x = I.scratch.alloc<double>(nst);
+                I.fp_prev_r = I.scratch.alloc<double>(nst);
+                I.fp_dX = I.scratch.alloc<double>(nst * std::max(I.fp.depth, 1));
+                I.fp_dR = I.scratch.alloc<double>(nst * std::max(I.fp.depth, 1));
+                I.fp_done = I.scratch.alloc<int>(W);
+                I.fp_active = I.scratch.alloc<int>(1);
+            }
         }
         b.dacc = I.cap_derivs ? I.scratch.alloc<double>(size_t(g.nlos) * S * so_deriv_slots(g.ngrid, I.cap_groups) * W) : nullptr;
         b.dphT = I.cap_groups > 0 ? I.scratch.alloc<double>(size_t(I.cap_groups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1) * W) : nullptr;
@@ -1414,6 +1559,62 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scan<3>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b);
             }
             }
+            // one application of the scattering operator S: b_.incoming -> b_.outgoing
+            auto scatter = [&](const SoBufs& b_) {
+                SoTimer t(I, st, "so_scatter");
+                if (S == 1 && g.nlm > 0) {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_sh<1>), dim3(unsigned(g.nlm / 16), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, b_, g.sh_in, g.sh_l);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_sh<2>), dim3(unsigned(g.nout_pad / 16), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, b_, g.sh_out, g.sh_l);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<1>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.npoints - g.ninterior)), dim3(kWave), 0, st, g, b_, g.ninterior);
+                } else if (S == 1) {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<1>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.npoints)), dim3(kWave), 0, st, g, b_, 0);
+                } else {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<3>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.npoints)), dim3(kWave), 0, st, g, b_, 0);
+                }
+            };
+            if (I.fp.enabled) {
+                // MultipleScatterSource::SuccessiveOrders: fixed point of x -> S (first + T x) with Anderson mixing (k_so_fixed_point).  The state
+                // starts at 0 (the first step is the first scattering order, as the legacy pass); the LOS integration then reads the state.
+                const size_t nst = size_t(g.n_out_total) * S * b.nwp;
+                SO_HIP_CHECK(hipMemsetAsync(I.fp_x, 0, nst * sizeof(double), st));
+                SO_HIP_CHECK(hipMemsetAsync(I.fp_done, 0, size_t(b.nwp) * sizeof(int), st));
+                const bool conv_on = I.fp.rel > 0 || I.fp.abs > 0;
+                int hist = 0, start = 0;
+                bool have_prev = false;
+                I.fp_last_iterations = 0;
+                for (int it = 0; it < I.num_iterations; ++it) {
+                    SoBufs bx = b, bm = b;
+                    bx.outgoing = I.fp_x;
+                    bm.outgoing = I.fp_mapped;
+                    if (it > 0) {
+                        SoTimer t(I, st, "so_accumulate");
+                        if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_accumulate<1>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, bx);
+                        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_accumulate<3>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, bx);
+                    }
+                    scatter(bm);
+                    int slot = -1;
+                    if (have_prev && I.fp.depth > 0) {
+                        if (hist < I.fp.depth) { slot = (start + hist) % I.fp.depth; ++hist; }
+                        else { slot = start; start = (start + 1) % I.fp.depth; }
+                    }
+                    have_prev = true;
+                    {
+                        SoTimer t(I, st, "so_fixed_point");
+                        if (conv_on) SO_HIP_CHECK(hipMemsetAsync(I.fp_active, 0, sizeof(int), st));
+                        const FpStep P{int(g.n_out_total) * S, I.fp.depth, hist, start, slot, conv_on ? 1 : 0, I.fp.rel, I.fp.abs, I.fp.damping};
+                        hipLaunchKernelGGL(k_so_fixed_point, dim3(wb), dim3(kWave), 0, st, b, P, I.fp_x, I.fp_mapped, I.fp_prev_x, I.fp_prev_r, I.fp_dX, I.fp_dR,
+                                           I.fp_done, I.fp_active);
+                    }
+                    I.fp_last_iterations = it + 1;
+                    if (conv_on) {
+                        int active = 1;
+                        SO_HIP_CHECK(hipMemcpyAsync(&active, I.fp_active, sizeof(int), hipMemcpyDeviceToHost, st));
+                        SO_HIP_CHECK(hipStreamSynchronize(st));
+                        if (active == 0) break;
+                    }
+                }
+                b.outgoing = I.fp_x;
+            } else
             for (int it = 0; it < I.num_iterations; ++it) {
                 if (it > 0) {
                     SoTimer t(I, st, "so_accumulate");

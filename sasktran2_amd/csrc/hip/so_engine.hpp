@@ -33,6 +33,12 @@ class SoDeviceEngine {
                       // scattering groups of the single-scatter source: ngroups directions d_dleg [group][nwavel][ngrid][nleg (x 4)] of the
                       // Legendre / Greek coefficients -> d_wf_groups [group][ngrid][nwavel][nlos][nstokes] (accumulated like the others)
                       int ngroups = 0, const double* d_dleg = nullptr, double* d_wf_groups = nullptr);
+    // MultipleScatterSource::SuccessiveOrders (cpp/lib/successive_orders/fixed_point.h): instead of `num_iterations` legacy passes, solve the fixed
+    // point x = S (first + T x) of the diffuse field with damped steps, Type-II Anderson mixing of depth <= 3 and the infinity-norm stop rule
+    // |map(x) - x| <= absolute + relative max(|x|, |map(x)|) per wavelength; `num_iterations` is the iteration limit.  Depth 0, damping 1 and
+    // zero tolerances reproduce the legacy passes bit for bit.  Call before the first solve_device.
+    void set_fixed_point(bool enabled, double relative_tolerance, double absolute_tolerance, double damping, int anderson_depth);
+    int last_fixed_point_iterations() const;   // iterations the last block ran (the limit unless every wavelength met the tolerance earlier)
     bool has_successive_orders() const;
     bool has_unlinearised_sources() const;   // successive orders: no weighting functions
     bool has_emission() const;               // line-of-sight emission source (standard / volume_emission_rate)

@@ -106,8 +106,12 @@ struct GeoTables {
                 rl_active.push_back(L.layer_distance < 1e-4 ? 0 : 1);
                 for (const auto& e : L.table) {
                     int slot = point_slot[(size_t(e.sza) * nlyr + e.alt) * nangle + e.angle];
-                    tab_slot.push_back(slot);
-                    tab_w.push_back(e.w);
+                    // (zero-weight stencil entries stay table points that are solved and tested for convergence, as in the reference, but the
+                    // line-of-sight sums do not read them)
+                    if (e.w != 0.0) {
+                        tab_slot.push_back(slot);
+                        tab_w.push_back(e.w);
+                    }
                     const int p = nlyr - 1 - e.alt;
                     // (an entry of weight zero adds nothing to any sum over the group: a segment that spans a whole layer sits exactly on a
                     // table altitude, and half of its 2 x 2 stencil then carries 0 -- at BASELINE configs[1] half of all entries)

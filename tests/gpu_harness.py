@@ -75,12 +75,18 @@ def build_so_engine(s, **override):
     config.num_sza = c["num_sza"]
     config.single_scatter_source = {"exact": sk.SingleScatterSource.Exact, "solartable": sk.SingleScatterSource.SolarTable, "none": sk.SingleScatterSource.NoSource}[c["single_scatter"]]
     config.multiple_scatter_source = {"successive_orders_legacy": sk.MultipleScatterSource.SuccessiveOrdersLegacy,
+                                      "successive_orders": sk.MultipleScatterSource.SuccessiveOrders,
                                       "discrete_ordinates": sk.MultipleScatterSource.DiscreteOrdinates,
                                       "none": sk.MultipleScatterSource.NoSource}[c["multiple_scatter"]]
     config.num_successive_orders_iterations = c["num_iterations"]
     config.num_successive_orders_incoming = c["num_incoming"]
     config.num_successive_orders_outgoing = c["num_outgoing"]
     config.init_successive_orders_with_discrete_ordinates = False
+    if c["multiple_scatter"] == "successive_orders":
+        config.successive_orders_relative_tolerance = c.get("relative_tolerance", 1e-6)
+        config.successive_orders_absolute_tolerance = c.get("absolute_tolerance", 1e-12)
+        config.successive_orders_damping = c.get("damping", 1.0)
+        config.successive_orders_anderson_depth = c.get("anderson_depth", 3)
     config.emission_source = {"none": sk.EmissionSource.NoSource, "standard": sk.EmissionSource.Standard,
                               "volume_emission_rate": sk.EmissionSource.VolumeEmissionRate}[c.get("emission", "none")]
     config.occultation_source = sk.OccultationSource.Standard if c.get("occultation", False) else sk.OccultationSource.NoSource

@@ -214,6 +214,32 @@ def regression_so(num_wavelengths: int = 2, nstokes: int = 3):
     return s
 
 
+def successive_orders_reference_scene(nstokes: int = 1, iterations: int = 3, source: str = "successive_orders", albedo: float = 0.0, **fixed_point):
+    """The scene of the reference's tests of its new successive-orders source (tests/engine/test_successive_orders_cpp.py:10-121): seven levels
+    0 .. 30 km, two wavelengths, 8 streams / moments, 26 / 26 directions, a nadir and a limb line of sight, exact single scatter.  Its
+    `_config` defaults are zero tolerances, Anderson depth 0 and damping 1 (a fixed number of plain fixed-point steps)."""
+    alt = np.arange(0.0, 30_001.0, 5_000.0)
+    csz = 0.55
+    rays = [(GROUND_VIEWING_SOLAR, csz, 0.35, 100_000.0, 0.72), (TANGENT_ALTITUDE_SOLAR, csz, -0.4, 100_000.0, 11_000.0)]
+    k = (1.4e-5 * np.exp(-alt / 7_600.0)[:, None] + 2.0e-9) * np.array([0.9, 1.1])[None, :]
+    ssa = (0.86 + 0.04 * np.exp(-alt / 14_000.0)[:, None]) - np.array([0.0, 0.015])[None, :]
+    a1 = np.zeros((8, alt.size, 2))
+    a1[0], a1[1], a1[2] = 1.0, 0.08, 0.5
+    if nstokes == 3:
+        leg = np.zeros((8 * 4, alt.size, 2))
+        leg[0::4] = a1
+        leg[2 * 4 + 1] = 3.0
+        leg[2 * 4 + 3] = -np.sqrt(6.0) / 2.0
+    else:
+        leg = a1
+    geometry = dict(cos_sza=csz, saa=0.15, earth_radius=6_372_000.0, altitudes=alt, interp_method=INTERP_LINEAR, geotype=GEO_SPHERICAL)
+    config = dict(nstokes=nstokes, num_streams=8, num_singlescatter_moments=8, num_sza=1, num_iterations=iterations, num_incoming=26, num_outgoing=26,
+                  single_scatter="exact", multiple_scatter=source, relative_tolerance=fixed_point.get("relative_tolerance", 0.0),
+                  absolute_tolerance=fixed_point.get("absolute_tolerance", 0.0), anderson_depth=fixed_point.get("anderson_depth", 0),
+                  damping=fixed_point.get("damping", 1.0))
+    return dict(geometry=geometry, config=config, rays=rays, extinction=k, ssa=ssa, leg=leg, albedo=np.full(2, albedo))
+
+
 def limb_c5(num_wavelengths: int = 20_000, nlyr: int = 50, num_iterations: int = 10, num_directions: int = 110):
     """BASELINE.json configs[4]: the C2 limb geometry and optical properties, exact single scatter plus
     10 successive orders of scattering with 110 incoming / 110 outgoing directions per diffuse point."""

@@ -207,3 +207,72 @@ def test_solar_table_single_scatter(nstokes):
     # with the successive orders on top
     both = dict(single_scatter="solartable", multiple_scatter="successive_orders_legacy")
     assert_so_parity(run_product_so(s, **both), make_so_oracle(s, **both).run(s["extinction"], s["ssa"], s["leg"], s["albedo"]))
+
+
+# ---- MultipleScatterSource.SuccessiveOrders (enum 4): the reference's fixed-point / Anderson driver (cpp/lib/successive_orders/fixed_point.h)
+# on the operators of the legacy discretisation (k_so_fixed_point)
+@pytest.mark.parametrize("nstokes", [1, 3])
+def test_new_source_at_fixed_iterations_agrees_with_the_legacy_source(nstokes):
+    """the reference's pin of its new source (tests/engine/test_successive_orders_cpp.py:158-186: its scene, three iterations, zero
+    tolerances, Anderson depth 0, black surface; rtol 2e-3, atol 2e-7).  On this build's shared discretisation unmixed steps ARE the legacy
+    passes: identical bits."""
+    new = run_product_so(sc.successive_orders_reference_scene(nstokes, 3, "successive_orders"))
+    legacy = run_product_so(sc.successive_orders_reference_scene(nstokes, 3, "successive_orders_legacy"))
+    np.testing.assert_allclose(new["radiance"], legacy["radiance"], rtol=2e-3, atol=2e-7)
+    np.testing.assert_array_equal(new["radiance"], legacy["radiance"])
+    assert np.all(np.isfinite(new["radiance"])) and np.min(new["radiance"][..., 0]) > 1e-6
+    assert_so_parity(new, run_so_oracle(sc.successive_orders_reference_scene(nstokes, 3, "successive_orders")))
+
+
+@pytest.mark.parametrize("case", [dict(anderson_depth=3, num_iterations=6), dict(anderson_depth=2, damping=0.8, num_iterations=7),
+                                  dict(anderson_depth=3, relative_tolerance=1e-7, num_iterations=40),
+                                  dict(anderson_depth=0, relative_tolerance=1e-5, num_iterations=40)],
+                         ids=["anderson 3, six steps", "anderson 2 damped", "anderson 3 to 1e-7", "plain to 1e-5"])
+def test_fixed_point_driver_matches_the_oracle(case):
+    """Anderson mixing, damping and the per-wavelength stop rule on the device against the oracle's restatement of the reference's solver
+    (mixing amplifies rounding differences of the two implementations: 1e-6 relative still holds with margin)"""
+    s = sc.regression_so(nstokes=1, num_wavelengths=5)
+    o = dict(multiple_scatter="successive_orders", relative_tolerance=0.0, absolute_tolerance=0.0)
+    o.update(case)
+    assert_so_parity(run_product_so(s, **o), run_so_oracle(s, **o))
+
+
+def test_zero_tolerances_use_the_iteration_count_and_a_huge_tolerance_stops_after_one_step():
+    """tests/engine/test_successive_orders_cpp.py:225-247"""
+    one = run_product_so(sc.successive_orders_reference_scene(1, 1, albedo=0.12))["radiance"]
+    two = run_product_so(sc.successive_orders_reference_scene(1, 2, albedo=0.12))["radiance"]
+    early = run_product_so(sc.successive_orders_reference_scene(1, 8, albedo=0.12, absolute_tolerance=1e100))["radiance"]
+    np.testing.assert_allclose(early, one, rtol=2e-13, atol=2e-14)
+    assert np.linalg.norm(two - one) > 1e-7 * np.linalg.norm(one)
+
+
+def test_anderson_converges_to_the_limit_of_the_orders_and_settings_are_validated():
+    import sasktran2_amd as sk
+    from tests.gpu_harness import build_so_engine
+    s = sc.regression_so(nstokes=1, num_wavelengths=4)
+    limit = run_product_so(s, num_iterations=60)["radiance"]
+    got = run_product_so(s, num_iterations=60, multiple_scatter="successive_orders", relative_tolerance=1e-10, absolute_tolerance=0.0)["radiance"]
+    assert np.max(np.abs(got / limit - 1)) < 1e-8
+    with pytest.raises(RuntimeError):   # damping outside (0, 1] is refused when the engine is built (fixed_point.h:19-39)
+        build_so_engine(s, multiple_scatter="successive_orders", damping=1.5)
+
+
+def test_full_size_c5_properties_with_the_new_source():
+    """BASELINE configs[4] at full size with multiple_scatter_source = successive_orders (10 fixed-point steps, Anderson depth 3, zero
+    tolerances): finite, positive, smooth in wavelength; a subset of wavelengths solved alone agrees bit for bit (blocks and slabs do not
+    couple wavelengths); oracle spot check"""
+    nw = 20_000
+    s = sc.limb_c5(num_wavelengths=nw)
+    o = dict(multiple_scatter="successive_orders", relative_tolerance=0.0, absolute_tolerance=0.0, anderson_depth=3)
+    from tests.gpu_harness import build_so_engine
+    eng = build_so_engine(s, **o)
+    full = run_product_so(s, engine=eng)["radiance"]
+    assert full.shape == (nw, 25, 1) and np.all(np.isfinite(full)) and np.all(full > 0)
+    d2 = np.abs(np.diff(full[..., 0], 2, axis=0)) / full[1:-1, :, 0]
+    assert d2.max() < 1e-5
+    idx = np.array([0, 63, 64, 9_999, 10_000, 19_999])
+    sub = dict(s, extinction=s["extinction"][:, idx], ssa=s["ssa"][:, idx], leg=s["leg"][:, :, idx], albedo=s["albedo"][idx])
+    part = run_product_so(sub, engine=eng)["radiance"]
+    np.testing.assert_array_equal(part, full[idx])
+    ref = run_so_oracle(sub, nthreads=6, **o)["radiance"]
+    np.testing.assert_allclose(part[..., 0], ref[..., 0], rtol=1e-6)

@@ -13,9 +13,13 @@ def make_so_oracle(s, **override):
                           nstokes=c["nstokes"], stokes_basis=c.get("stokes_basis", 0), num_ss_moments=c["num_singlescatter_moments"],
                           num_ms_moments=c["num_streams"], num_incoming=c["num_incoming"], num_outgoing=c["num_outgoing"],
                           num_sza=c["num_sza"], num_iterations=c["num_iterations"], single_scatter={"none": 0, "exact": 1, "solartable": 2}[c["single_scatter"]],
-                          multiple_scatter=c["multiple_scatter"] == "successive_orders_legacy",
+                          multiple_scatter=c["multiple_scatter"] in ("successive_orders_legacy", "successive_orders"),
                           emission={"none": 0, "standard": 1, "volume_emission_rate": 2}[c.get("emission", "none")],
-                          occultation=bool(c.get("occultation", False)))
+                          occultation=bool(c.get("occultation", False)),
+                          # MultipleScatterSource::SuccessiveOrders: the fixed-point driver (config keys successive_orders_*)
+                          fixed_point=(dict(relative_tolerance=c.get("relative_tolerance", 1e-6), absolute_tolerance=c.get("absolute_tolerance", 1e-12),
+                                            damping=c.get("damping", 1.0), anderson_depth=c.get("anderson_depth", 3))
+                                       if c["multiple_scatter"] == "successive_orders" else None))
 
 
 def run_so_oracle(s, nthreads=2, **override):
@@ -209,3 +213,52 @@ def test_solar_table_single_scatter_is_close_to_the_exact_source():
         km[q, 0] -= h
         fd = (eng.run(kp, s["ssa"], s["leg"], s["albedo"])["radiance"][0] - eng.run(km, s["ssa"], s["leg"], s["albedo"])["radiance"][0]) / (2 * h)
         assert np.max(np.abs(fd - table["d_extinction"][0, :, :, q])) < 1e-6 * np.max(np.abs(table["d_extinction"][0]))
+
+
+# ---- MultipleScatterSource::SuccessiveOrders: the reference's fixed-point / Anderson driver (cpp/lib/successive_orders/fixed_point.h) on
+# the operators of the legacy discretisation
+def test_fixed_point_without_mixing_is_the_legacy_iteration():
+    """depth 0, damping 1, zero tolerances: every step is x <- S (first + T x), i.e. one legacy pass -- bit for bit"""
+    s = sc.regression_so()
+    legacy = run_so_oracle(s, num_iterations=4)
+    fp = run_so_oracle(s, num_iterations=4, multiple_scatter="successive_orders", relative_tolerance=0.0, absolute_tolerance=0.0, anderson_depth=0)
+    np.testing.assert_array_equal(fp["radiance"], legacy["radiance"])
+
+
+def test_anderson_fixed_point_reaches_the_limit_of_the_orders_sooner():
+    """the converged field is the limit of the successive orders; Anderson(3) gets there in fewer applications of the map"""
+    s = sc.regression_so()
+    limit = run_so_oracle(s, num_iterations=60)["radiance"]
+    scale = np.abs(limit[..., 0]).max()
+    tight = run_so_oracle(s, num_iterations=60, multiple_scatter="successive_orders", relative_tolerance=1e-11, absolute_tolerance=0.0)["radiance"]
+    assert np.max(np.abs(tight - limit)) < 1e-9 * scale
+    errs = {}
+    for n in (6, 10):
+        errs["legacy", n] = np.max(np.abs(run_so_oracle(s, num_iterations=n)["radiance"] - limit)) / scale
+        errs["anderson", n] = np.max(np.abs(run_so_oracle(s, num_iterations=n, multiple_scatter="successive_orders", relative_tolerance=0.0,
+                                                          absolute_tolerance=0.0)["radiance"] - limit)) / scale
+    assert errs["anderson", 10] < 0.1 * errs["legacy", 10], errs
+    assert errs["anderson", 10] < errs["anderson", 6], errs
+
+
+def test_fixed_iteration_solution_agrees_with_the_legacy_source():
+    """the reference's own pin of the new source (tests/engine/test_successive_orders_cpp.py:158-186, its scene and its settings: three
+    iterations, zero tolerances, Anderson depth 0, black surface): new and legacy source agree within rtol 2e-3 / atol 2e-7.  Here both run
+    on the same discretisation, so a fixed number of unmixed steps IS the legacy iteration and the two agree to rounding."""
+    for nstokes in (1, 3):
+        new = run_so_oracle(sc.successive_orders_reference_scene(nstokes, 3, "successive_orders"))["radiance"]
+        legacy = run_so_oracle(sc.successive_orders_reference_scene(nstokes, 3, "successive_orders_legacy"))["radiance"]
+        np.testing.assert_allclose(new, legacy, rtol=2e-3, atol=2e-7)
+        np.testing.assert_allclose(new, legacy, rtol=1e-13, atol=1e-18)
+        assert np.all(new[..., 0] > 1e-6)
+        if nstokes == 3:
+            assert np.any(np.abs(new[..., 1]) > 1e-8) and np.any(np.abs(new[..., 2]) > 1e-8)
+
+
+def test_zero_tolerances_use_the_iteration_count_and_a_huge_tolerance_stops_at_once():
+    """tests/engine/test_successive_orders_cpp.py:225-247"""
+    one = run_so_oracle(sc.successive_orders_reference_scene(1, 1, albedo=0.12))["radiance"]
+    two = run_so_oracle(sc.successive_orders_reference_scene(1, 2, albedo=0.12))["radiance"]
+    early = run_so_oracle(sc.successive_orders_reference_scene(1, 8, albedo=0.12, absolute_tolerance=1e100))["radiance"]
+    np.testing.assert_allclose(early, one, rtol=2e-13, atol=2e-14)
+    assert np.linalg.norm(two - one) > 1e-7 * np.linalg.norm(one)
