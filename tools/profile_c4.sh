@@ -23,4 +23,6 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAVES --kernel
 echo "wave done"
 cd $root
 PMC_WAVELENGTHS=256 python3 tools/summarize_profile.py $out > $out/summary_c4.json
+cp $out/trace/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null || true
+rm -rf $out/trace $out/fetch $out/write $out/f64 $out/mfma $out/wave
 tail -c 1200 $out/summary_c4.json

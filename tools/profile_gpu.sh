@@ -25,4 +25,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAVES --kernel
 echo "wave done"
 cd $root
 python3 tools/summarize_profile.py $out > $out/summary.json
+# gpurun merges at most 64 MiB back: keep the summary, the kernel statistics of the trace and the logs, drop the raw databases / traces
+cp $out/trace/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null || true
+rm -rf $out/trace $out/fetch $out/write $out/f64 $out/mfma $out/wave
 tail -c 1500 $out/summary.json
