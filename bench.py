@@ -50,7 +50,10 @@ def load_pmc_profile():
     if not files:
         return {}
     out, tot_b, tot_f = {}, 0.0, 0.0
-    for r in json.loads(files[-1].read_text()).get("pmc_4096_wavelengths_per_launch", []):
+    rows = json.loads(files[-1].read_text()).get("pmc_4096_wavelengths_per_launch", [])
+    # solves in the profiled run = launches of a once-per-solve kernel (timed step, serialised pass, host-path calls)
+    nsolve = max([r["launches"] for r in rows if r["kernel"].startswith("kern_output")] or [2])
+    for r in rows:
         m = re.match(r"(kern_\w+?)(<|$)", r["kernel"])
         name = KERNEL_OF.get(m.group(1)) if m else None
         if not name:
@@ -60,8 +63,8 @@ def load_pmc_profile():
         e = out.setdefault(name, {"hbm_bytes_per_wavelength": 0.0, "flops_per_wavelength": 0.0})
         e["hbm_bytes_per_wavelength"] += b / 4096
         e["flops_per_wavelength"] += f / 4096
-        tot_b += b * r["launches"] / 2 / 4096
-        tot_f += f * r["launches"] / 2 / 4096
+        tot_b += b * r["launches"] / nsolve / 4096
+        tot_f += f * r["launches"] / nsolve / 4096
     out["_solve"] = {"hbm_bytes_per_wavelength": tot_b, "flops_per_wavelength": tot_f, "source": files[-1].parent.name}
     return out
 

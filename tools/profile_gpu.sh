@@ -8,7 +8,7 @@ root=$PWD
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $root/bench.py --no-cpu-baseline"
+BENCH="python3 $root/bench.py --no-cpu-baseline --no-host-path"
 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $out/trace -o r -- $BENCH --steps 2 --warmup 1 > $out/trace.log 2>&1
 echo "trace done"
 PMCARGS="--steps 1 --warmup 0 --wavelengths 4096"
