@@ -264,6 +264,19 @@ int orso_lebedev(int npoints, double* xyzw) {
         return 0;
     } catch (const std::exception&) { return -1; }
 }
+// three-nearest interpolation on a Lebedev sphere (or, with `ground_location` non-null, on its up-looking half at that location) as the shared
+// geometry precompute performs it (skso::UnitSphere::interpolate), for the independent check in tests/test_independent_geometry.py
+int orso_sphere_interpolate(int npoints, const double* direction, const double* ground_location, int* idx, double* w) {
+    try {
+        skso::UnitSphere s = skso::UnitSphere::lebedev(npoints);
+        if (ground_location) s = skso::UnitSphere::ground_of(s, skgeo::Vec3(ground_location[0], ground_location[1], ground_location[2]));
+        std::array<int, 3> i3;
+        std::array<double, 3> w3;
+        s.interpolate(skgeo::Vec3(direction[0], direction[1], direction[2]), i3, w3);
+        for (int k = 0; k < 3; ++k) { idx[k] = i3[k]; w[k] = w3[k]; }
+        return s.size();
+    } catch (const std::exception&) { return -1; }
+}
 // sizes of the diffuse discretisation: points, incoming rays, outgoing directions, accumulation-matrix entries
 int orso_sizes(void* hv, int* out) {
     auto* h = static_cast<SoHandle*>(hv);

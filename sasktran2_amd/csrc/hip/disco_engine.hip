@@ -695,6 +695,15 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                 while (lpw < g.nlos && lpw < 64) lpw *= 2;
                 if constexpr (N == 8) {
                     // 16 streams: adjoint operators and sweeps as FP64 matrix-core products (v_mfma_f64_16x16x4_f64)
+                    const int ntile = (g.nlos + 15) / 16;
+                    // full-size launches with at most two 16-LOS tiles: the forward sweep runs inside the operator kernel (FP, SP, HD stay in
+                    // registers), kern_k2b_mfma8<.., true> keeps the backward sweep; SASKTRAN2_AMD_FUSE=0 keeps the two separate kernels
+                    static const bool fuse_env = [] { const char* e = std::getenv("SASKTRAN2_AMD_FUSE"); return e ? atoi(e) != 0 : true; }();
+                    const bool fused = fuse_env && !b.k1_lane && ntile <= 2 && small_batch_split(int(nw)) == 1 && g.n_lp > 0;
+                    if (g.n_lp > 0) {
+                        Timer t2(I, sC, "k2q_live_flags");
+                        hipLaunchKernelGGL(kern_qlmask, dim3(2048), dim3(256), 0, sC, g, b, m);
+                    }
                     {
                         Timer t2(I, sC, "k2c_adjoint_ops");
                         // the layers of the adjoint operators are independent: three blocks per wavelength also at full size (30 000 wavefronts fill
@@ -702,18 +711,21 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                         int split = std::max(3, small_batch_split(int(nw)));
                         if (const char* e = std::getenv("SASKTRAN2_AMD_K2C_SPLIT")) split = std::max(1, atoi(e));
                         const int lpb = (g.nlyr + split - 1) / split, ny = (g.nlyr + lpb - 1) / lpb;
-                        if (b.k1_lane)
+                        if (fused && ntile == 2)
+                            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<false, 2>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);
+                        else if (fused)
+                            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<false, 1>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);
+                        else if (b.k1_lane)
                             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true>), dim3(unsigned(nw), unsigned(ny)), dim3(64), 0, sC, g, b, s, m, lpb);
                         else
                             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<false>), dim3(unsigned(nw), unsigned(ny)), dim3(64), 0, sC, g, b, s, m, lpb);
                     }
-                    if (g.n_lp > 0) {
-                        Timer t2(I, sC, "k2q_live_flags");
-                        hipLaunchKernelGGL(kern_qlmask, dim3(2048), dim3(256), 0, sC, g, b, m);
-                    }
                     Timer t(I, sC, "k2b_adjoint");
-                    const int ntile = (g.nlos + 15) / 16;
-                    if (ntile > 1 && small_batch_split(int(nw)) == 1)
+                    if (fused && ntile == 2)
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<2, true>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m);
+                    else if (fused)
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<1, true>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m);
+                    else if (ntile > 1 && small_batch_split(int(nw)) == 1)
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<2>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m);
                     else  // one 16-LOS tile per block (up to 4 blocks per wavelength)
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<1>), dim3(unsigned(nw), unsigned(std::min(ntile, 4))), dim3(64), 0, sC, g, b, s, m);

@@ -26,8 +26,10 @@
 #ifndef SKD_WPE_K2BM
 #define SKD_WPE_K2BM 4
 #endif
+// (3 since the forward sweep runs inside kern_k2c_mfma8: at 128 registers the fused kernel spills 33 -- 79 with the next layer's record
+// requested ahead -- and loses: 76 k wavelengths/s at 4 waves per SIMD, 86 k at 3 without the look-ahead, measured on MI355X)
 #ifndef SKD_WPE_K2CM
-#define SKD_WPE_K2CM 4
+#define SKD_WPE_K2CM 3
 #endif
 #ifndef SKD_K1_LG
 #define SKD_K1_LG 16
@@ -1367,8 +1369,20 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2AM) kern_k2a_mfma8(Geo g, Bufs b
 //   FP^T = F^T Dinv  and  [SP | BP]^T = [SupT | SubT]^T Dinv  are two chains of four matrix-core products.
 // K1LANE: the records come from kern_k1_lane (Rec::DG holds the coefficient vectors, DG is formed here); a template parameter, not a
 // run-time branch, so that the usual path does not carry the registers of the extra products
-template <bool K1LANE> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b, int s, int m, int layers_per_block) {
-    constexpr int N = 8, NSTR = 16, M2 = 16;
+// FTILES > 0 (full-size launches, up to 32 lines of sight): the FORWARD sweep of the adjoint (kern_k2b_mfma8's first half) runs inside this
+// kernel, layer by layer, with FP, SP and HD taken from the registers they are formed in -- they never go to HBM (-26 % of the adjoint
+// stage's traffic); only what the backward sweep needs (BP, DI, UG, GD, IPB) is written, and kern_k2b_mfma8<TILES, true> does the backward
+// sweep.  Every statement of the sweep is the one of kern_k2b_mfma8 (same contraction setting), so the two paths agree bit for bit.
+// streamed once between the sweeps: optional non-temporal access (experiment switch SKD_EXP_NT)
+#ifdef SKD_EXP_NT
+#define SKD_NT_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define SKD_NT_LD(ptr) __builtin_nontemporal_load((ptr))
+#else
+#define SKD_NT_ST(ptr, val) (*(ptr) = (val))
+#define SKD_NT_LD(ptr) (*(ptr))
+#endif
+template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b, int s, int m, int layers_per_block) {
+    constexpr int N = 8, NSTR = 16, M2 = 16, FT = (FTILES > 0) ? FTILES : 1;
     using R = skd::Rec<N>;
     using O = skd::Ops<N>;
     const int w = blockIdx.x;
@@ -1376,6 +1390,32 @@ template <bool K1LANE> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_
     const int lane = threadIdx.x, col = lane & 15, q = lane >> 4, jc = col & 7, nw = b.nw, nlyr = g.nlyr;
     __shared__ double sRec[R::SIZE];
     __shared__ double sXs[M2], sTmp[M2], sIpb[N], sDIpb[4 * N];
+    __shared__ double sHD[4 * NSTR], sUG[M2];
+    // ---- state of the fused forward sweep (FTILES > 0), as in kern_k2b_mfma8
+    const int nlos = g.nlos, ntile = (nlos + 15) / 16;
+    double* zw = b.z + size_t(w) * nlyr * ntile * 256;
+    double* hw = b.qlbuf + size_t(w) * nlyr * ntile * 64;
+    const double* cwp = b.cwbuf + size_t(w) * g.n_lp;
+    const uint8_t* mrow = b.qlmask + size_t(w) * ((g.n_lp + 7) / 8);
+    const double* pcm = g.lp_pc + size_t(m) * g.n_lp * NSTR;
+    int los[FT];
+    bool ok[FT];
+    double gw[FT];
+    mf4 yprev[FT];
+    if constexpr (FTILES > 0) {
+        for (int t = 0; t < FT; ++t) {
+            los[t] = t * 16 + col;
+            ok[t] = t < ntile && los[t] < nlos;
+            gw[t] = 0;
+            yprev[t] = mf4{0, 0, 0, 0};
+            if (ok[t] && m == 0 && g.ray_ground[los[t]]) {
+                double acc = 0;
+                for (int e = g.g_start[los[t]]; e < g.g_start[los[t] + 1]; ++e)
+                    if (g.g_sza[e] == s && skd::conv_at(b, g, g.g_slot[e], w) > m) acc += g.g_w[e];
+                gw[t] = acc * b.att_total[size_t(los[t]) * nw + w];
+            }
+        }
+    }
     const double rho = (m == 0) ? b.albedo[w] : 0.0;
     // Legendre sums as a 16 x 16 product:  [YP; YM] = [W+^T W-^T; W-^T W+^T] [P sg; P],  P[r][l] = 1/2 w_r omega a_l P_l^m(mu_r);
     // this lane's B operand rows are r = q and r = q + 4 of column l = col (constant over the layers up to omega a_l)
@@ -1389,7 +1429,16 @@ template <bool K1LANE> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_
         const double* dg = skd::dinv_at<N>(b, nlyr, p, w);
         const double* xs = skd::xsol_at<N>(b, nlyr, p, w);
         double* o = skd::ops_at<N>(b, nlyr, p, w);
-        for (int i = lane; i < R::SIZE; i += 64) sRec[i] = rec[i];
+        {
+            // the record -> LDS through registers, all loads in flight at once (as a rolled loop every element waits for its own load:
+            // measured 52 instead of 41 ms per step for the fused kernel)
+            constexpr int RU = (R::SIZE + 63) / 64;
+            double stage[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) stage[u] = (lane + 64 * u < R::SIZE) ? rec[lane + 64 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < RU; ++u) if (lane + 64 * u < R::SIZE) sRec[lane + 64 * u] = stage[u];
+        }
         if (lane < M2) sXs[lane] = xs[lane];
         double dinv_b[4];  // B operand of the Dinv chains: Dinv[4 kk + (lane >> 4)][lane & 15] = dg[64 kk + lane]
         for (int kk = 0; kk < 4; ++kk) dinv_b[kk] = dg[64 * kk + lane];
@@ -1465,22 +1514,30 @@ template <bool K1LANE> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_
             val += __shfl_xor(val, off);
         }
         if (q == 0)
-            for (int t = 0; t < 4; ++t) o[O::HD + t * NSTR + col] = hd[t] * inv_om - ((t == skd::TH_OM) ? val * inv_om * inv_om : 0.0);
+            for (int t = 0; t < 4; ++t) {
+                const double hv = hd[t] * inv_om - ((t == skd::TH_OM) ? val * inv_om * inv_om : 0.0);
+                if constexpr (FTILES > 0) sHD[t * NSTR + col] = hv;
+                else o[O::HD + t * NSTR + col] = hv;
+            }
         // ---- FP^T = F^T Dinv (the C/D image of F is the A operand of F^T) and [SP | BP]^T = [SupT | SubT]^T Dinv
+        mf4 x1, x2;
         {
             const bool sup = (col < N);
             const double wm0 = sRec[R::WM + jc + N * q], wm1 = sRec[R::WM + jc + N * (q + 4)];
             const double we0 = sRec[R::WP + jc + N * q] * sRec[R::E + q], we1 = sRec[R::WP + jc + N * (q + 4)] * sRec[R::E + q + 4];
             // [SupT | SubT][jj][c']: SupT[j][c] = W-(c,j), SupT[N+j][c] = W+(c,j) E_j ; SubT[j][c] = W+(c,j) E_j, SubT[N+j][c] = W-(c,j)
             const double aS[4] = {sup ? wm0 : we0, sup ? wm1 : we1, sup ? we0 : wm0, sup ? we1 : wm1};
-            mf4 x1 = {0, 0, 0, 0}, x2 = {0, 0, 0, 0};
+            x1 = mf4{0, 0, 0, 0};
+            x2 = mf4{0, 0, 0, 0};
             for (int kk = 0; kk < 4; ++kk) {
                 x1 = mfma16(Fr[kk], dinv_b[kk], x1);   // (F^T Dinv)[l][i] = FP[i][l]
                 x2 = mfma16(aS[kk], dinv_b[kk], x2);   // rows 0..7: SP^T, rows 8..15: BP^T
             }
-            for (int r = 0; r < 4; ++r) o[O::FP + 64 * r + lane] = x1[r];
-            o[O::SP + lane] = x2[0];
-            o[O::SP + 64 + lane] = x2[1];
+            if constexpr (FTILES == 0) {
+                for (int r = 0; r < 4; ++r) o[O::FP + 64 * r + lane] = x1[r];
+                o[O::SP + lane] = x2[0];
+                o[O::SP + 64 + lane] = x2[1];
+            }
             o[O::BP + lane] = x2[2];
             o[O::BP + 64 + lane] = x2[3];
         }
@@ -1531,6 +1588,7 @@ template <bool K1LANE> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_
             if (last && m == 0)
                 for (int j = 0; j < M2; ++j) t += dg[j * M2 + lane] * sTmp[j];
             o[O::UG + lane] = t;
+            if constexpr (FTILES > 0) sUG[lane] = t;
         }
         if (lane < 4) {
             double sacc = 0;
@@ -1544,6 +1602,51 @@ template <bool K1LANE> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_
             o[O::IPB] = ipb;
         }
         __syncthreads();
+        if constexpr (FTILES > 0) {
+            // ---- forward sweep of the adjoint at this layer:  Y_p = FP QL_p + SP Y_{p-1}[8:16]  (+ HD QL_p), statement for statement the
+            // forward half of kern_k2b_mfma8 with its operands taken from x1 (FP), x2[0:2] (SP), sHD and sUG
+#pragma clang fp contract(off)
+            double hda[4];
+            for (int kk = 0; kk < 4; ++kk) hda[kk] = (col < 4) ? sHD[col * NSTR + 4 * kk + q] : 0.0;
+            for (int t = 0; t < FT; ++t) {
+                if (t >= ntile) continue;
+                double ql4[4] = {0, 0, 0, 0};
+                if (ok[t]) {
+                    const int base = (los[t] * g.nsza + s) * nlyr + p;
+                    const int e0 = g.lp_start[base], e1 = g.lp_start[base + 1];
+                    for (int e = e0; e < e1; e += 4) {
+                        const unsigned mk = unsigned(mrow[e >> 3]) >> (e & 4);
+                        const double2* cw2 = reinterpret_cast<const double2*>(cwp + e);
+                        const double2* pc2 = reinterpret_cast<const double2*>(pcm + (size_t(e) * 4 + q) * 4);
+                        const double2 cv0 = cw2[0], cv1 = cw2[1];
+                        double2 pa[4], pb[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            pa[u] = pc2[8 * u];
+                            pb[u] = pc2[8 * u + 1];
+                        }
+                        const double c[4] = {(mk & 1u) ? cv0.x : 0.0, (mk & 2u) ? cv0.y : 0.0, (mk & 4u) ? cv1.x : 0.0, (mk & 8u) ? cv1.y : 0.0};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            ql4[0] += c[u] * pa[u].x;
+                            ql4[1] += c[u] * pa[u].y;
+                            ql4[2] += c[u] * pb[u].x;
+                            ql4[3] += c[u] * pb[u].y;
+                        }
+                    }
+                }
+                mf4 acc = {0, 0, 0, 0}, hacc = {0, 0, 0, 0};
+                for (int kk = 0; kk < 4; ++kk) acc = mfma16(x1[kk], ql4[kk], acc);
+                for (int kk = 0; kk < 2; ++kk) acc = mfma16(x2[kk], yprev[t][2 + kk], acc);
+                for (int kk = 0; kk < 4; ++kk) hacc = mfma16(hda[kk], ql4[kk], hacc);
+                if (last && m == 0)
+                    for (int r = 0; r < 4; ++r) acc[r] += sUG[q + 4 * r] * gw[t];
+                double* zt = zw + (size_t(p) * ntile + t) * 256;
+                for (int r = 0; r < 4; ++r) SKD_NT_ST(&zt[64 * r + lane], acc[r]);
+                SKD_NT_ST(&hw[(size_t(p) * ntile + t) * 64 + lane], hacc[0]);
+                yprev[t] = acc;
+            }
+        }
     }
 }
 
@@ -1554,15 +1657,7 @@ template <bool K1LANE> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_
 //             rows 4..7 carry sum_i zB_i for the ground terms)
 //   Y / Z tiles and the HD part are kept in HBM between the sweeps in their C/D register images
 //   (b.z: [w][p][tile][4][64], b.qlbuf: [w][p][tile][64]); nothing goes through LDS.
-// streamed once between the sweeps: optional non-temporal access (experiment switch SKD_EXP_NT)
-#ifdef SKD_EXP_NT
-#define SKD_NT_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#define SKD_NT_LD(ptr) __builtin_nontemporal_load((ptr))
-#else
-#define SKD_NT_ST(ptr, val) (*(ptr) = (val))
-#define SKD_NT_LD(ptr) (*(ptr))
-#endif
-template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2b_mfma8(Geo g, Bufs b, int s, int m) {
+template <int TILES, bool BWD_ONLY = false> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2b_mfma8(Geo g, Bufs b, int s, int m) {
     // the one- and two-tile instantiations must round identically (results do not depend on the launch shape): no implicit
     // contraction of a * b + c in this kernel, fused multiply-adds are written out
 #pragma clang fp contract(off)
@@ -1594,7 +1689,8 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
                 gw[t] = acc * b.att_total[size_t(los[t]) * nw + w];
             }
         }
-        // ---------------- forward sweep
+        // ---------------- forward sweep (BWD_ONLY: done by kern_k2c_mfma8<.., TILES>, the Y tiles and the HD part are in HBM already)
+        if constexpr (!BWD_ONLY) {
         mf4 yprev[TILES];
         for (int t = 0; t < TILES; ++t) yprev[t] = mf4{0, 0, 0, 0};
         // A operands of the layer (FP, SP, HD); the next layer's are requested before this layer's work starts
@@ -1658,6 +1754,7 @@ template <int TILES> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2
             }
             for (int kk = 0; kk < 4; ++kk) { fpa[kk] = nfpa[kk]; hda[kk] = nhda[kk]; }
             for (int kk = 0; kk < 2; ++kk) spa[kk] = nspa[kk];
+        }
         }
         // ---------------- backward sweep with the reduced gradient
         mf4 znext[TILES], gprev[TILES];

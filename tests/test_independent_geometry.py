@@ -374,6 +374,74 @@ def test_diffuse_table_stencils_against_brute_force(ray):
         assert min(abs(np.angle(np.exp(1j * (got["ground_saa"] - saa)))), abs(np.angle(np.exp(1j * (got["ground_saa"] + saa))))) < 1e-8
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Successive orders: interpolation of a direction on the Lebedev spheres of the diffuse points (reference: LebedevSphere::interpolate,
+# cpp/lib/unitsphere/lebedev.cpp:37-94 -- the three nearest quadrature points by chord length, inverse-distance weights, an exact hit
+# takes everything, ties keep the lower index; UnitSphereGround maps onto the up-looking half and renormalises), recomputed by a stable sort.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _lebedev(npoints):
+    import ctypes
+    from oracle.oracle_py import lib
+    L = lib()
+    xyzw = np.zeros(4 * npoints)
+    assert L.orso_lebedev(npoints, xyzw.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 0
+    return xyzw.reshape(npoints, 4)
+
+
+def _engine_interpolate(npoints, direction, ground_location=None):
+    import ctypes
+    from oracle.oracle_py import lib
+    L = lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.orso_sphere_interpolate.argtypes = [ctypes.c_int, dp, dp, ctypes.POINTER(ctypes.c_int), dp]
+    idx, w = np.zeros(3, dtype=np.int32), np.zeros(3)
+    d = np.ascontiguousarray(direction, dtype=float)
+    g = None if ground_location is None else np.ascontiguousarray(ground_location, dtype=float)
+    n = L.orso_sphere_interpolate(npoints, d.ctypes.data_as(dp), None if g is None else g.ctypes.data_as(dp),
+                                  idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), w.ctypes.data_as(dp))
+    assert n > 0
+    return idx, w, n
+
+
+def brute_sphere_interpolate(points, direction, ground_location=None):
+    sq = np.sum((points[:, :3] - direction[None, :]) ** 2, axis=1)
+    order = np.argsort(sq, kind="stable")[:3]
+    d = sq[order]
+    w = np.zeros(3)
+    if np.any(d < 1e-8):
+        w[int(np.argmax(d < 1e-8))] = 1.0
+    else:
+        w = (1 / np.sqrt(d)) / np.sum(1 / np.sqrt(d))
+    if ground_location is None:
+        return order, w
+    up = points[:, :3] @ ground_location > 0
+    reverse = np.cumsum(up) - 1
+    idx = np.where(up[order], reverse[order], 0)
+    w = np.where(up[order], w, 0.0)
+    return idx, (w / w.sum() if w.sum() > 0 else w)
+
+
+@pytest.mark.parametrize("npoints", [26, 110])
+def test_lebedev_three_nearest_interpolation_against_brute_force(npoints):
+    pts = _lebedev(npoints)
+    assert abs(pts[:, 3].sum() - 1.0) < 1e-13 and np.allclose(np.linalg.norm(pts[:, :3], axis=1), 1.0, atol=1e-14)
+    rng = np.random.default_rng(11)
+    j = next(k for k in range(1, npoints) if pts[0, :3] @ pts[k, :3] > -0.5 and pts[0, :3] @ pts[k, :3] < 0.999)
+    dirs = [unit(v) for v in rng.standard_normal((200, 3))] + [pts[3, :3].copy(), pts[npoints - 1, :3].copy(),
+                                                               unit(pts[0, :3] + pts[j, :3])]   # exact hits and a tie between two points
+    loc = unit(np.array([0.3, -0.2, 0.93]))
+    for d in dirs:
+        for g in (None, loc):
+            idx, w, n = _engine_interpolate(npoints, d, g)
+            bi, bw = brute_sphere_interpolate(pts, d, g)
+            live = bw > 0
+            assert np.array_equal(idx[live], bi[live]), (d, idx, bi)
+            np.testing.assert_allclose(w, bw, rtol=0, atol=1e-13)
+            assert abs(w.sum() - 1.0) < 1e-12 or (g is not None and w.sum() == 0.0)
+            if g is not None:
+                assert n == int(np.sum(pts[:, :3] @ loc > 0))
+
+
 if __name__ == "__main__":
     for r in [("limb", (sc.TANGENT_ALTITUDE_SOLAR, 0.5, 0.6, 300_000.0, 21_300.0)), ("nadir", (sc.GROUND_VIEWING_SOLAR, 0.5, 1.1, 250_000.0, 0.83))]:
         test_single_scatter_radiance_and_optical_depth_against_brute_force(r)
