@@ -324,11 +324,6 @@ __device__ __forceinline__ double row16_sum(double v) {
 // matrix-core products where it needs them (Bufs::k1_lane).
 //   grid = (ceil(nw / 64), nlyr), block = 64, one wavefront per SIMD (the kernel owns the register file).
 // -------------------------------------------------------------------------------------------------------------------
-#ifdef SKD_K1L_NOSTORE
-#define SKD_K1L_OUT(b, nlyr, p, w) if (sOut[0] == 12345.678) skd::rec_at<N>(b, nlyr, p, w)
-#else
-#define SKD_K1L_OUT(b, nlyr, p, w) skd::rec_at<N>(b, nlyr, p, w)
-#endif
 template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bufs b, int s, int m) {
     constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, CH = 25;
     using R = skd::Rec<N>;
@@ -532,7 +527,7 @@ template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bu
             const int rl = idx / CH, e = idx - rl * CH;
             if (e >= 3 * N || !((livemask >> rl) & 1ull)) continue;
             const int f = e / N, i = e % N;
-            SKD_K1L_OUT(b, nlyr, p, w0 + rl)[((f == 0) ? R::WP : (f == 1) ? R::WM : R::DWP) + N * j + i] = sOut[idx];
+            skd::rec_at<N>(b, nlyr, p, w0 + rl)[((f == 0) ? R::WP : (f == 1) ? R::WM : R::DWP) + N * j + i] = sOut[idx];
         }
         __syncthreads();
 #pragma unroll
@@ -558,7 +553,7 @@ template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bu
                 const int f = e - N - 10;
                 dest = ((f == 0) ? R::K : (f == 1) ? R::DK : (f == 2) ? R::E : (f == 3) ? R::AP : (f == 4) ? R::AM : (f == 5) ? R::DAP : R::DAM) + j;
             }
-            SKD_K1L_OUT(b, nlyr, p, w0 + rl)[dest] = sOut[idx];
+            skd::rec_at<N>(b, nlyr, p, w0 + rl)[dest] = sOut[idx];
         }
     });
     // ---- particular solution at the layer edges, G[c][i] = sum_j Wsel(i, j) coef0_type(j):  W+- coef = T^-1 (Xhat coef +- Uhat (coef / k)) / 2
@@ -597,7 +592,7 @@ template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bu
         for (int idx = lane; idx < 64 * CH; idx += 64) {
             const int rl = idx / CH, e = idx - rl * CH;
             if (e >= 3 * N || !((livemask >> rl) & 1ull)) continue;
-            SKD_K1L_OUT(b, nlyr, p, w0 + rl)[R::G + e] = sOut[idx];
+            skd::rec_at<N>(b, nlyr, p, w0 + rl)[R::G + e] = sOut[idx];
         }
         __syncthreads();
 #pragma unroll
@@ -607,7 +602,7 @@ template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bu
         for (int idx = lane; idx < 64 * CH; idx += 64) {
             const int rl = idx / CH, e = idx - rl * CH;
             if (e >= N || !((livemask >> rl) & 1ull)) continue;
-            SKD_K1L_OUT(b, nlyr, p, w0 + rl)[R::G + 3 * N + e] = sOut[idx];
+            skd::rec_at<N>(b, nlyr, p, w0 + rl)[R::G + 3 * N + e] = sOut[idx];
         }
     }
     if (live && err) atomicOr(&b.status[w], err);
