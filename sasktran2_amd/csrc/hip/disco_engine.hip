@@ -237,9 +237,11 @@ struct DeviceEngine::Impl {
         // look-ahead of the layer solutions: K1 of order m+1 only needs the layer optics, so it runs on its own stream into
         // the second record buffer while K2a..K2b of order m still work on the first
         hipStream_t k1_stream = nullptr, adj_stream = nullptr;
-        double* rec2 = nullptr;
-        double* dinv2 = nullptr;
-        double* xsol2 = nullptr;
+        // order pipeline: records, BVP factors and solutions of up to kDepth azimuth orders in flight (buffer 0 is Bufs' own)
+        static constexpr int kDepth = 4;
+        double* recx[kDepth - 1] = {};
+        double* dinvx[kDepth - 1] = {};
+        double* xsolx[kDepth - 1] = {};
         std::vector<hipEvent_t> ev_k1, ev_bvp, ev_rest;  // per azimuth order
         hipEvent_t ev_begin = nullptr;
     };
@@ -382,7 +384,7 @@ size_t DeviceEngine::bytes_per_wavelength() const {
     d += nlyr * (3 + nstr) + (nlyr + 1) + nlyr;              // tau, om, kbar, a, T, sec
     d += size_t(t.nq_total) * 3 + nlos;                      // od, omloc, srcw, att_total
     if (N == 8) d += t.lp_q.size() + t.lp_q.size() / 64 + 1 + nlyr * (N + N * N); // cwbuf, qlmask, eig
-    d += 2 * (nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N);  // rec, dinv, xsol (two buffers each)
+    d += Impl::Slot::kDepth * (nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N);  // rec, dinv, xsol (kDepth buffers each)
     d += nstr * size_t(t.nslot);                             // J
     const size_t nlos_pad = (nlos + 15) / 16 * 16;
     d += nlyr * (8 * N * N + 26 * N + 5) + nlyr * nstr * nlos_pad;  // ops, qlbuf
@@ -426,9 +428,11 @@ void DeviceEngine::ensure_scratch(int nw, int nslots) {
         b.eig = M.alloc<double>(t.N == 8 ? nlyr * (N + N * N) * W : 1);
         b.qlmask = M.alloc<uint8_t>(t.N == 8 ? (t.lp_q.size() + 7) / 8 * W + 8 : 8);
         b.rec = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W); b.dinv = M.alloc<double>(nlyr * 4 * N * N * W);
-        sl->rec2 = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W);
-        sl->dinv2 = M.alloc<double>(nlyr * 4 * N * N * W);
-        sl->xsol2 = M.alloc<double>(nlyr * 2 * N * W);
+        for (int k = 0; k < Impl::Slot::kDepth - 1; ++k) {
+            sl->recx[k] = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W);
+            sl->dinvx[k] = M.alloc<double>(nlyr * 4 * N * N * W);
+            sl->xsolx[k] = M.alloc<double>(nlyr * 2 * N * W);
+        }
         b.xsol = M.alloc<double>(nlyr * 2 * N * W); b.J = M.alloc<double>(nstr * size_t(t.nslot) * W);
         b.conv_order = M.alloc<uint8_t>(size_t(t.nslot) * W); b.notconv = M.alloc<int>(W); b.norders = M.alloc<int>(W);
         b.status = M.alloc<int>(W); b.z = M.alloc<double>(nlyr * 2 * N * W * nlos_pad);
@@ -478,7 +482,9 @@ inline unsigned blocks(size_t n, int bs = kBlock) { return unsigned((n + bs - 1)
 // K2c) then split the layers over blockIdx.y and the 16-stream adjoint sweeps one 16-LOS tile per block.
 static int small_batch_split(int nw) {
     if (const char* e = std::getenv("SASKTRAN2_AMD_SPLIT")) return std::max(1, atoi(e));
-    return nw >= 3000 ? 1 : (nw >= 1500 ? 2 : 4);
+    // (measured with the fused adjoint kernel, MI355X: 2 500 wavelengths 39.4 ms with two blocks per wavelength, 35.3 with one;
+    // 1 250: 22.0 ms with four, 23.0 with two, 23.8 with one)
+    return nw >= 2000 ? 1 : (nw >= 1500 ? 2 : 4);
 }
 // Eigen-solutions ahead of K1: 8 and 16 streams solve the eigenproblems of all (layer, wavelength) pairs one per LANE in registers
 // (kern_kj_lane) and the cooperative kernel continues from there.  Returns whether the kernel was launched.
@@ -622,18 +628,25 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
     // Cross-stream accesses that carry no event (deliberately: an event after kern_stop(m - 1) would chain K1(m) behind the BVP of the
     // previous order and undo the look-ahead).  They rest on one invariant, kept by k_stop_rule and K3 (k3_table_values):
     //     `norders[w]` and `conv_order[w][slot]` only ever move to values GREATER than the order in flight that could read them.
-    //  * K1(m) on the look-ahead stream tests `m >= norders[w]` while kern_stop(m - 2) / kern_stop(m - 1) on `st` may lower norders to
-    //    m - 1 or m.  A stale (larger) value only makes K1(m) fill the record of parity m & 1 for an order nobody reads: that buffer
-    //    is free (ev_rest[m - 2]), and every consumer of order m (K2a, K3, stop on `st`; K2c / K2b behind ev_bvp[m]) is ordered after
+    //  * K1(m) on the look-ahead stream tests `m >= norders[w]` while kern_stop(m - depth) .. kern_stop(m - 1) on `st` may lower norders
+    //    to a value <= m.  A stale (larger) value only makes K1(m) fill record buffer m % depth for an order nobody reads: that buffer
+    //    is free (ev_rest[m - depth]), and every consumer of order m (K3, stop on `st`; K2c / K2b behind ev_bvp[m]) is ordered after
     //    kern_stop(m - 1) and sees the final count.
     //  * K2c / K2b(m) on the adjoint stream test `conv_order > m` while kern_stop(m) clamps entries > m + 1 down to m + 1 and K3(m + 1)
     //    writes m + 2: the test's outcome is the same before and after either write (single-byte / 4-byte stores, no tearing).
     // tests/test_gpu_parity.py::test_c2_wavelength_blocks_in_flight_are_equivalent compares LOOKAHEAD=0 and =1 bit for bit.
     const int lookahead_env = [] { const char* e = std::getenv("SASKTRAN2_AMD_LOOKAHEAD"); return e ? atoi(e) : -1; }();
     const bool pipe = !I.profiling && slot.k1_stream != nullptr && (lookahead_env >= 0 ? lookahead_env != 0 : I.last_slots <= 2);
-    double* const rec_buf[2] = {b.rec, slot.rec2};
-    double* const dinv_buf[2] = {b.dinv, slot.dinv2};
-    double* const xsol_buf[2] = {b.xsol, slot.xsol2};
+    static constexpr int kDepth = DeviceEngine::Impl::Slot::kDepth;
+    double* rec_buf[kDepth] = {b.rec};
+    double* dinv_buf[kDepth] = {b.dinv};
+    double* xsol_buf[kDepth] = {b.xsol};
+    for (int k = 1; k < kDepth; ++k) { rec_buf[k] = slot.recx[k - 1]; dinv_buf[k] = slot.dinvx[k - 1]; xsol_buf[k] = slot.xsolx[k - 1]; }
+    // orders in flight.  A full-size launch fills the chip with two (the kernels of one order already overlap those of the next); a small
+    // one (a rank's share of a sharded run) is a chain of kernels per order that each fill a fraction of it -- K1, BVP, table values,
+    // adjoint operators, sweeps -- and only as many chains run side by side as there are buffers (1 250 wavelengths: 23.3 -> 21.0 ms)
+    static const int depth_env = [] { const char* e = std::getenv("SASKTRAN2_AMD_DEPTH"); return e ? std::min(kDepth, std::max(2, atoi(e))) : 0; }();
+    const int depth = depth_env ? depth_env : (nw < 4000 ? kDepth : 2);
     hipStream_t sA = pipe ? slot.k1_stream : st, sC = pipe ? slot.adj_stream : st;
     for (int s = 0; s < g.nsza; ++s) {
         {
@@ -648,13 +661,13 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
         int last_m = -1;
         for (int m = 0; m < g.nstr; ++m) {
             if (pipe) {
-                b.rec = rec_buf[m & 1];
-                b.dinv = dinv_buf[m & 1];
-                b.xsol = xsol_buf[m & 1];
-                // buffers of parity m & 1 are free once the adjoint stage of order m - 2 is done
-                if (m >= 2) {
-                    HIP_CHECK(hipStreamWaitEvent(sA, slot.ev_rest[m - 2], 0));
-                    HIP_CHECK(hipStreamWaitEvent(st, slot.ev_rest[m - 2], 0));
+                b.rec = rec_buf[m % depth];
+                b.dinv = dinv_buf[m % depth];
+                b.xsol = xsol_buf[m % depth];
+                // buffers m % depth are free once the adjoint stage of order m - depth is done
+                if (m >= depth) {
+                    HIP_CHECK(hipStreamWaitEvent(sA, slot.ev_rest[m - depth], 0));
+                    HIP_CHECK(hipStreamWaitEvent(st, slot.ev_rest[m - depth], 0));
                 }
             }
             if (N == 8 && b.k1_lane) {
@@ -675,7 +688,9 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                 if constexpr (N == 8) {
                     // column-per-lane BVP, four wavelengths per wavefront (kern_k2a_cols8); SASKTRAN2_AMD_K2A=mfma keeps the matrix-core form
                     static const bool cols = [] { const char* e = std::getenv("SASKTRAN2_AMD_K2A"); return !(e && std::string(e) == "mfma"); }();
-                    if (cols)
+                    if (cols && (nw + 3) / 4 <= 1024)   // at most one wavefront per SIMD: the spill-free instantiation
+                        hipLaunchKernelGGL(kern_k2a_cols8_lone, dim3(unsigned((nw + 3) / 4)), dim3(64), 0, st, g, b, s, m);
+                    else if (cols)
                         hipLaunchKernelGGL(kern_k2a_cols8, dim3(unsigned((nw + 3) / 4)), dim3(64), 0, st, g, b, s, m);
                     else
                         hipLaunchKernelGGL(kern_k2a_mfma8, dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
@@ -761,13 +776,20 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
         b.rec = rec_buf[0];
         b.dinv = dinv_buf[0];
         b.xsol = xsol_buf[0];
+        if (s == g.nsza - 1) {
+            // the line-of-sight integration reads the finished diffuse table (J, conv_order: final after this stop rule) and nothing of the
+            // adjoint stage, whose last orders are still running on sC: it goes first, the chain from the layer gradients after it.
+            // (Both add into dnat, in this order in every launch shape.)
+            Timer t(I, st, "k4b_los");
+            hipLaunchKernelGGL(kern_k4b, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b);
+        }
         if (pipe && last_m >= 0) HIP_CHECK(hipStreamWaitEvent(st, slot.ev_rest[last_m], 0));  // the whole adjoint stage is in order on sC
         if (derivs) {
             Timer t(I, st, "k4a_chain");
             hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, s);
         }
     }
-    {
+    if (g.nsza == 0) {
         Timer t(I, st, "k4b_los");
         hipLaunchKernelGGL(kern_k4b, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b);
     }

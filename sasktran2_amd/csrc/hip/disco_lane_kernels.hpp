@@ -690,7 +690,7 @@ template <class MID> __device__ __forceinline__ int qr16_inverse_cols(double (&a
 //   with, for column c (j = c & 7, E_j = exp(-k_j tau)):   D[r][c] = -(c < 8 ? W+(r, j) : W-(r, j) E_j), D[8 + i][c] = (c < 8 ? W-(i, j) E_j : W+(i, j)),
 //   Sub_{p+1}[i][c] = (c < 8 ? W+(i, j) E_j : W-(i, j)),  S_p[i][c] = (c < 8 ? W-(i, j) : W+(i, j) E_j)
 // Vectors are distributed (entry c in lane c).  Block inverses leave in the row-major layout kern_k2c_mfma8 reads.
-__global__ void __launch_bounds__(64, SKD_WPE_K2AC) kern_k2a_cols8(Geo g, Bufs b, int s, int m) {
+__device__ __forceinline__ void k2a_cols8_body(const Geo& g, const Bufs& b, int s, int m) {
     constexpr int N = 8, M2 = 16;
     using R = skd::Rec<N>;
     const int lane = threadIdx.x, c = lane & 15, grp = lane >> 4, jc = c & 7, nw = b.nw, nlyr = g.nlyr;
@@ -827,5 +827,9 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2AC) kern_k2a_cols8(Geo g, Bufs b
     }
     if (live && sing && c == 0) atomicOr(&b.status[w], skd::ERR_SINGULAR_BVP);
 }
+__global__ void __launch_bounds__(64, SKD_WPE_K2AC) kern_k2a_cols8(Geo g, Bufs b, int s, int m) { k2a_cols8_body(g, b, s, m); }
+// the same with the whole register file (one wavefront per SIMD, nothing spilled to scratch) for launches that do not fill the SIMDs anyway:
+// few wavelengths per rank of a sharded run, where the layer recursion of this kernel is the critical path of the order pipeline
+__global__ void __launch_bounds__(64, 1) kern_k2a_cols8_lone(Geo g, Bufs b, int s, int m) { k2a_cols8_body(g, b, s, m); }
 
 }  // namespace skdev
