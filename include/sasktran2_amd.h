@@ -160,6 +160,13 @@ int sk_amd_engine_calculate_radiance_sharded(Engine* engine, Atmosphere* atmosph
  * d_leg [nwavel][nlocation][nleg (x 4 for NSTOKES = 3)], d_radiance [nwavel][nlos][nstokes], d_los_od [nwavel][nlos] or NULL. */
 int sk_amd_so_engine_solve_device(Engine* engine, int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
                                   const double* d_albedo, const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream);
+/* ... with the native weighting functions of every source of the solve -- the exact single scatter in reverse mode along the line of sight,
+ * the successive-orders diffuse field by the discrete adjoint of its passes (the reference's new source serves these through
+ * Sasktran2::calculate_radiance's native VJP, cpp/lib/engine/engine.cpp:625-866; its legacy source has none):
+ * d_wf_ext / d_wf_ssa [nlocation][nwavel][nlos][nstokes], d_wf_albedo [nwavel][nlos][nstokes]. */
+int sk_amd_so_engine_solve_device_wf(Engine* engine, int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
+                                     const double* d_albedo, const double* d_irradiance, double* d_radiance, double* d_los_od,
+                                     double* d_wf_ext, double* d_wf_ssa, double* d_wf_albedo, void* stream);
 /* The same for an engine whose source is the two-stream one (multiple_scatter_source = twostream and / or emission_source = twostream;
  * replaces, per wavelength block, CppTwoStreamSourceAdapter::calculate + start_of_ray_source,
  * cpp/lib/sktran_disco/cpp_twostream_source.cpp:3532-3630).  Inputs in the reference storage layout: d_ext, d_ssa, d_delta_f, d_emission

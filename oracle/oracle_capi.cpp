@@ -309,7 +309,6 @@ int orso_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     atm.surface_emission = h->surface_emission;
     if (h->sg.cfg.emission != 0 && !atm.emission) return -2;
     atm.derivatives = d_k != nullptr;
-    if (atm.derivatives && h->sg.cfg.multiple_scatter && h->num_iterations > 0) return -2;   // the diffuse source is not linearised
     const int ngrid = h->sg.ngrid, nn = 3 * ngrid + 2;
     int status = 0;
 #ifdef _OPENMP

@@ -30,7 +30,8 @@ struct AtmosphereView {
     const double* albedo = nullptr;                      // [nwavel]
     const double* emission = nullptr;                    // [ngrid, nwavel] emission_source of the storage (settings.emission != 0)
     const double* surface_emission = nullptr;            // [nwavel]
-    bool derivatives = false;                            // native weighting functions of the exact single-scatter source (no diffuse source)
+    bool derivatives = false;                            // native weighting functions (extinction, ssa, albedo; emission sources: + emission) of
+                                                         // every source of the solve, the diffuse field through its discrete adjoint (ms_adjoint)
 };
 
 struct Result {
@@ -100,7 +101,7 @@ class Solver {
     // layer source's derivatives through the source factor, the solar transmission rows and the local extinction / single scatter
     // albedo (singlescattersource.cpp:988-1030, solartransmission.h:852-901) and the ground term's (singlescattersource.cpp:607-634).
     void los_derivatives(const AtmosphereView& a, int w, int r, const double* k, const double* om, double F, double albedo,
-                         const double* p11, const double* p12, Result& res) const {
+                         const double* p11, const double* p12, Result& res, bool ms = false, const double* ms_rows = nullptr) const {
         const skso::RaySet& lo = g_.los;
         // columns of a row of derivatives: extinction [0, ngrid), ssa [ngrid, 2 ngrid), albedo 2 ngrid, emission profile
         // [2 ngrid + 1, 3 ngrid + 1), surface emission 3 ngrid + 1
@@ -120,6 +121,11 @@ class Solver {
             D(0, 2 * ngrid) += base;
             for (int t = lo.solar.start[e0]; t < lo.solar.start[e0 + 1]; ++t) D(0, lo.solar.idx[t]) -= lo.solar.w[t] * base * albedo;
         }
+        // diffuse field: its source along the ray is part of I (so that the attenuation derivatives below see it) with the direct
+        // dependence of omega (1 - e^-od) on the layer; the dependence through the outgoing sources themselves is ms_rows (ms_adjoint)
+        if (ms && n > 0 && lo.ground_is_hit[r])
+            for (int e = g_.los_ground.start[r]; e < g_.los_ground.start[r + 1]; ++e)
+                for (int s = 0; s < S_; ++s) I[s] += g_.los_ground.w[e] * outgoing_[size_t(g_.los_ground.idx[e]) * S_ + s];
         for (int j = 0; j < n; ++j) {
             const int L = l0 + j;
             const double od = dot(lo.od, L, k), att = std::exp(-od);
@@ -127,6 +133,16 @@ class Solver {
                 for (int s = 0; s < S_; ++s) D(s, lo.od.idx[t]) -= lo.od.w[t] * I[s];
             for (int s = 0; s < S_; ++s) I[s] *= att;
             for (double& v : dI) v *= att;
+            if (ms) {
+                const double omega = lo.mid_w[2 * L] * om[lo.mid_idx[2 * L]] + lo.mid_w[2 * L + 1] * om[lo.mid_idx[2 * L + 1]];
+                for (int s = 0; s < S_; ++s) {
+                    double X = 0;
+                    for (int e = g_.los_source.start[L]; e < g_.los_source.start[L + 1]; ++e) X += g_.los_source.w[e] * outgoing_[size_t(g_.los_source.idx[e]) * S_ + s];
+                    I[s] += omega * (1 - att) * X;
+                    for (int t = lo.od.start[L]; t < lo.od.start[L + 1]; ++t) D(s, lo.od.idx[t]) += lo.od.w[t] * omega * att * X;
+                    for (int i = 0; i < 2; ++i) D(s, ngrid + lo.mid_idx[2 * L + i]) += lo.mid_w[2 * L + i] * (1 - att) * X;
+                }
+            }
             if (lo.tiny[L]) continue;
             if (g_.cfg.emission != 0) {
                 // EmissionSource::integrated_source with its derivatives (emission_source.cpp:37-152)
@@ -191,6 +207,9 @@ class Solver {
             for (int t = lo.od.start[L]; t < lo.od.start[L + 1]; ++t)
                 for (int s = 0; s < S_; ++s) D(s, lo.od.idx[t]) += lo.od.w[t] * dsf * quad_sum[s];
         }
+        if (ms_rows)
+            for (int s = 0; s < S_; ++s)
+                for (int x = 0; x <= 2 * ngrid; ++x) D(s, x) += ms_rows[size_t(s) * (2 * ngrid + 1) + x];
         if (res.deriv.size() != size_t(g_.nlos) * S_ * nn) res.deriv.assign(size_t(g_.nlos) * S_ * nn, 0.0);
         const double C = (S_ == 3) ? g_.stokes_C[r] : 1.0, Sn = (S_ == 3) ? g_.stokes_S[r] : 0.0;
         for (int x = 0; x < nn; ++x) {
@@ -201,6 +220,184 @@ class Solver {
             }
         }
     }
+
+    // Discrete adjoint of the diffuse field for one line of sight: rows [S][2 ngrid + 1] of d(radiance component s, before the rotation to
+    // the output basis) / d(extinction, ssa, albedo) THROUGH the outgoing sources x (the direct terms are in los_derivatives).
+    //   forward:  x_1 = S(first),  x_k = S(first + A x_{k-1}),  k = 2 .. n;   radiance += sum_j omega_j (1 - e^-od_j) e^-(od nearer) (W x_n)_j + ground
+    //   backward: lambda_n = d radiance / d x_n;  for k = n .. 1:  mu_k = S^T lambda_k,  lambda_{k-1} = A^T mu_k, with
+    //             G(first) += mu_k,  G(A entry e) += mu_k[ray(e)] x_{k-1}[column(e)],  G(albedo) += ground rows of S
+    //   chain:    A entry = weight x layer factor omega (1 - e^-od) e^-(od before) (or the ground factor e^-(od of the ray)); first = the
+    //             single-scatter radiance of the incoming ray: both differentiated per ray layer into extinction (shell optical depths, the
+    //             solar table), ssa and albedo.
+    // (There is no reference for this: the reference's legacy source has no weighting functions; the checker of these rows is a central
+    // finite difference of this solver's own radiances, tests/test_so_oracle.py.)
+    void ms_adjoint(const AtmosphereView& a, int w, int r, const double* k, const double* om, double albedo, std::vector<double>& rows) {
+        const skso::RaySet& lo = g_.los;
+        const skso::RaySet& in = g_.incoming;
+        const int ngrid = a.ngrid, nrw = 2 * ngrid + 1, nr = in.nrays, nout_total = g_.out_start.back();
+        const int rows_m = g_.nout * S_, cols_m = g_.nin * S_;
+        rows.assign(size_t(S_) * nrw, 0.0);
+        const int l0 = lo.layer_start[r], n = lo.layer_start[r + 1] - l0;
+        // legacy passes (and the fixed-point driver when it IS the legacy iteration): the exact transpose of the n passes, x_1 .. x_n kept.
+        // Anderson-mixed / damped / tolerance-stopped driver: the adjoint Neumann series about the final state, lambda <- (S A)^T lambda,
+        // until its infinity norm has dropped by the driver's relative tolerance (at most the driver's iteration limit of terms)
+        const int niter = adj_final_ ? num_iterations : (int)hist_.size();
+        if (n == 0 || niter == 0) return;
+        // transmission from the near edge of LOS layer j to the observer
+        std::vector<double> after(n + 1, 1.0), att(n), omega(n);
+        for (int j = 0; j < n; ++j) att[j] = std::exp(-dot(lo.od, l0 + j, k));
+        for (int j = n - 1; j >= 0; --j) after[j] = after[j + 1] * att[j];   // after[j] = prod_{j' >= j} att; transmission after layer j = after[j + 1]
+        std::vector<double> p11(ngrid), p12(ngrid), lambda(size_t(nout_total) * S_), lnew(size_t(nout_total) * S_), mu(size_t(nr) * S_), incv(size_t(nr) * S_);
+        std::vector<double> Gfirst(size_t(nr) * S_), Glf(in.nlayers()), Ggf(nr), Gk(ngrid), Gom(ngrid), Gtod(g_.table.od.rows()), GT(in.solar.rows());
+        for (int so = 0; so < S_; ++so) {
+            std::fill(lambda.begin(), lambda.end(), 0.0);
+            if (lo.ground_is_hit[r])
+                for (int e = g_.los_ground.start[r]; e < g_.los_ground.start[r + 1]; ++e) lambda[size_t(g_.los_ground.idx[e]) * S_ + so] += g_.los_ground.w[e] * after[0];
+            for (int j = 0; j < n; ++j) {
+                const int L = l0 + j;
+                const double f = (lo.mid_w[2 * L] * om[lo.mid_idx[2 * L]] + lo.mid_w[2 * L + 1] * om[lo.mid_idx[2 * L + 1]]) * (1 - att[j]) * after[j + 1];
+                for (int e = g_.los_source.start[L]; e < g_.los_source.start[L + 1]; ++e) lambda[size_t(g_.los_source.idx[e]) * S_ + so] += f * g_.los_source.w[e];
+            }
+            std::fill(Gfirst.begin(), Gfirst.end(), 0.0); std::fill(Glf.begin(), Glf.end(), 0.0); std::fill(Ggf.begin(), Ggf.end(), 0.0);
+            std::fill(Gk.begin(), Gk.end(), 0.0); std::fill(Gom.begin(), Gom.end(), 0.0); std::fill(Gtod.begin(), Gtod.end(), 0.0); std::fill(GT.begin(), GT.end(), 0.0);
+            double Galb = 0;
+            double lmax = 0;
+            for (int kk = niter; kk >= 1; --kk) {
+                const std::vector<double>* xprev = adj_final_ ? &outgoing_ : ((kk > 1) ? &hist_[kk - 2] : nullptr);   // x_{kk-1}
+                if (adj_final_) {
+                    double ln = 0;
+                    for (double v : lambda) ln = std::max(ln, std::fabs(v));
+                    lmax = std::max(lmax, ln);
+                    if (ln == 0.0 || (fixed_point.relative_tolerance > 0 && ln <= fixed_point.relative_tolerance * lmax)) break;
+                }
+                // incoming field of this pass (ground rows of S need it)
+                for (int rr = 0; rr < nr; ++rr)
+                    for (int s = 0; s < S_; ++s) {
+                        double v = first_[size_t(rr) * S_ + s];
+                        if (xprev)
+                            for (int e = g_.accumulation.start[rr]; e < g_.accumulation.start[rr + 1]; ++e) v += acc_[e] * (*xprev)[size_t(g_.accumulation.idx[e]) * S_ + s];
+                        incv[size_t(rr) * S_ + s] = v;
+                    }
+                std::fill(mu.begin(), mu.end(), 0.0);
+                for (int p = 0; p < g_.npoints; ++p) {
+                    const double* lam = lambda.data() + size_t(g_.out_start[p]) * S_;
+                    double* m = mu.data() + size_t(g_.in_start[p]) * S_;
+                    if (p < g_.ninterior) {
+                        const double* M = M_.data() + size_t(p) * rows_m * cols_m;
+                        for (int o = 0; o < rows_m; ++o) {
+                            if (lam[o] == 0.0) continue;
+                            for (int i = 0; i < cols_m; ++i) m[i] += M[size_t(o) * cols_m + i] * lam[o];
+                        }
+                    } else {
+                        const int gi = p - g_.ninterior;
+                        double ls = 0, is = 0;
+                        for (int o = 0; o < g_.ground_nout[gi]; ++o) ls += lam[size_t(o) * S_];
+                        for (int i = 0; i < g_.ground_nin[gi]; ++i) {
+                            m[size_t(i) * S_] += (albedo / skgeo::kPi) * g_.ground_in_factor[gi][i] * ls;
+                            is += g_.ground_in_factor[gi][i] * incv[(size_t(g_.in_start[p]) + i) * S_];
+                        }
+                        Galb += is * ls / skgeo::kPi;
+                    }
+                }
+                for (size_t i = 0; i < mu.size(); ++i) Gfirst[i] += mu[i];
+                std::fill(lnew.begin(), lnew.end(), 0.0);
+                if (xprev)
+                    for (int rr = 0; rr < nr; ++rr)
+                        for (int e = g_.accumulation.start[rr]; e < g_.accumulation.start[rr + 1]; ++e) {
+                            const int L = g_.accumulation_layer[e], c = g_.accumulation.idx[e];
+                            double sv = 0;
+                            for (int s = 0; s < S_; ++s) {
+                                sv += mu[size_t(rr) * S_ + s] * (*xprev)[size_t(c) * S_ + s];
+                                lnew[size_t(c) * S_ + s] += acc_[e] * mu[size_t(rr) * S_ + s];
+                            }
+                            (L >= 0 ? Glf[L] : Ggf[rr]) += g_.accumulation.w[e] * sv;
+                        }
+                lambda.swap(lnew);
+            }
+            // chain: layer factors, ground factors and first-order incoming radiances -> extinction / ssa / albedo
+            for (int rr = 0; rr < nr; ++rr) {
+                const int il0 = in.layer_start[rr], nn_ = in.layer_start[rr + 1] - il0, e0 = in.endpoint_start[rr];
+                if (nn_ == 0) continue;
+                ray_phase(in, rr, a, w, p11.data(), p12.data());
+                std::vector<double> od(nn_), before(nn_ + 1);
+                for (int j = 0; j < nn_; ++j) od[j] = dot(in.od, il0 + j, k);
+                double cur = 0;
+                for (int j = nn_ - 1; j >= 0; --j) { before[j] = std::exp(-cur); cur += od[j]; }
+                const double all = std::exp(-cur);
+                const double* Gf = Gfirst.data() + size_t(rr) * S_;
+                // what sits behind e^-(od of every layer): the ground terms
+                double Pg = 0;
+                if (in.ground_is_hit[rr]) {
+                    Pg += Ggf[rr] * all;
+                    if (in.ground_mu_in[rr] > 0) {
+                        const double gfirst = T_inc_[e0] * (albedo / skgeo::kPi) * in.ground_mu_in[rr] * all;
+                        Pg += Gf[0] * gfirst;
+                        Galb += Gf[0] * T_inc_[e0] * in.ground_mu_in[rr] * all / skgeo::kPi;
+                        GT[e0] += Gf[0] * (albedo / skgeo::kPi) * in.ground_mu_in[rr] * all;
+                    }
+                }
+                double prefix = Pg;   // sum of P over the layers farther than the current one (+ ground)
+                for (int j = 0; j < nn_; ++j) {
+                    const int L = il0 + j;
+                    const double at = std::exp(-od[j]);
+                    const double omg = in.mid_w[2 * L] * om[in.mid_idx[2 * L]] + in.mid_w[2 * L + 1] * om[in.mid_idx[2 * L + 1]];
+                    double Cod = -prefix + Glf[L] * omg * at * before[j];
+                    for (int i = 0; i < 2; ++i) Gom[in.mid_idx[2 * L + i]] += Glf[L] * in.mid_w[2 * L + i] * (1 - at) * before[j];
+                    double Pj = Glf[L] * omg * (1 - at) * before[j];
+                    if (!in.tiny[L]) {
+                        const double sf = (std::abs(od[j]) < 1e-12) ? 1.0 : -std::expm1(-od[j]) / od[j];
+                        const double dsf = (std::abs(od[j]) < 1e-12) ? -0.5 : 1 / od[j] - sf * (1 + 1 / od[j]);
+                        for (int side = 0; side < 2; ++side) {   // 0: entrance (start), 1: exit (end)
+                            const double* wts = side == 0 ? in.w_entrance.data() : in.w_exit.data();
+                            const double quad = side == 0 ? in.quad_start[L] : in.quad_end[L];
+                            const int e = e0 + j + (side == 0 ? 1 : 0);
+                            double ke = 0, oe = 0, ph[3] = {0, 0, 0};
+                            for (int i = 0; i < 4; ++i) {
+                                const int q = in.stencil_idx[size_t(L) * 4 + i];
+                                const double wt = wts[size_t(L) * 4 + i];
+                                if (q < 0 || wt == 0.0) continue;
+                                ke += k[q] * wt;
+                                oe += om[q] * wt;
+                                ph[0] += p11[q] * wt;
+                                if (S_ == 3) { ph[1] += -in.C2[rr] * p12[q] * wt; ph[2] += -in.S2[rr] * p12[q] * wt; }
+                            }
+                            double gph = 0;   // sum_s G(first_s) phase_s
+                            for (int s = 0; s < S_; ++s) gph += Gf[s] * ph[s];
+                            const double common = gph * quad * before[j] / (skgeo::kPi * 4);   // d first / d (ke oe T sf) of this end
+                            const double val = ke * oe * T_inc_[e];
+                            Pj += common * sf * val;
+                            Cod += common * dsf * val;
+                            GT[e] += common * sf * ke * oe;
+                            for (int i = 0; i < 4; ++i) {
+                                const int q = in.stencil_idx[size_t(L) * 4 + i];
+                                const double wt = wts[size_t(L) * 4 + i];
+                                if (q < 0 || wt == 0.0) continue;
+                                Gk[q] += common * sf * wt * oe * T_inc_[e];
+                                Gom[q] += common * sf * wt * ke * T_inc_[e];
+                            }
+                        }
+                    }
+                    for (int t = in.od.start[L]; t < in.od.start[L + 1]; ++t) Gk[in.od.idx[t]] += in.od.w[t] * Cod;
+                    prefix += Pj;
+                }
+            }
+            // T_inc = F exp(-solar . table_od), table_od = table . extinction
+            for (int e = 0; e < in.solar.rows(); ++e) {
+                if (GT[e] == 0.0) continue;
+                for (int t = in.solar.start[e]; t < in.solar.start[e + 1]; ++t) Gtod[in.solar.idx[t]] -= in.solar.w[t] * T_inc_[e] * GT[e];
+            }
+            for (int t = 0; t < g_.table.od.rows(); ++t) {
+                if (Gtod[t] == 0.0) continue;
+                for (int e = g_.table.od.start[t]; e < g_.table.od.start[t + 1]; ++e) Gk[g_.table.od.idx[e]] += g_.table.od.w[e] * Gtod[t];
+            }
+            double* out = rows.data() + size_t(so) * nrw;
+            for (int q = 0; q < ngrid; ++q) { out[q] = Gk[q]; out[ngrid + q] = Gom[q]; }
+            out[2 * ngrid] = Galb;
+        }
+    }
+    std::vector<std::vector<double>> hist_;   // x_1 .. x_n of the last solve (derivatives only)
+    std::vector<double> ms_rows_;
+    bool adj_final_ = false, record_hist_ = false;
 
   public:
     explicit Solver(const skso::SoGeometry& g) : g_(g), S_(g.cfg.nstokes) {}
@@ -302,11 +499,16 @@ class Solver {
                     }
                 }
             };
+            hist_.clear();
+            adj_final_ = false;
+            const bool fp_is_legacy = fixed_point.anderson_depth == 0 && fixed_point.damping == 1.0 && fixed_point.relative_tolerance == 0 && fixed_point.absolute_tolerance == 0;
+            record_hist_ = a.derivatives && fp_is_legacy;
             if (fixed_point.enabled) {
                 // MultipleScatterSource::SuccessiveOrders: the fixed point x = S (first + T x) by damped Picard steps with Type-II Anderson
                 // mixing of depth <= 3 and an infinity-norm stop rule (cpp/lib/successive_orders/fixed_point.h:132-258), on the operators of
                 // the legacy discretisation above.  With depth 0, damping 1 and zero tolerances this IS the legacy iteration.
                 fixed_point_iterations_used = solve_fixed_point(apply_map);
+                adj_final_ = !fp_is_legacy;   // weighting functions: see ms_adjoint
             } else
             // num_hr_spherical_iterations passes (diffuse_table.cpp:751-819)
             for (int it = 0; it < num_iterations; ++it) {
@@ -337,6 +539,7 @@ class Solver {
                         }
                     }
                 }
+                if (a.derivatives) hist_.push_back(outgoing_);
             }
         }
 
@@ -390,7 +593,11 @@ class Solver {
                 }
             }
             res.los_od[r] = total_od;
-            if (a.derivatives) los_derivatives(a, w, r, k, om, F, albedo, p11.data(), p12.data(), res);   // (row length 3 ngrid + 2)
+            if (a.derivatives) {   // (row length 3 ngrid + 2)
+                const bool msd = ms && num_iterations > 0;
+                if (msd) ms_adjoint(a, w, r, k, om, albedo, ms_rows_);
+                los_derivatives(a, w, r, k, om, F, albedo, p11.data(), p12.data(), res, msd, msd ? ms_rows_.data() : nullptr);
+            }
             // Stokes basis of the output (OutputC::assign_lane)
             res.radiance[size_t(r) * S_] = rad[0];
             if (S_ == 3) {
@@ -469,6 +676,7 @@ class Solver {
                 if (fixed_point.damping == 1.0) x = mapped;   // (exactly the legacy pass)
                 else for (size_t i = 0; i < n; ++i) x[i] += fixed_point.damping * res[i];
             }
+            if (record_hist_) hist_.push_back(x);
         }
         return used;
     }

@@ -80,6 +80,7 @@ SIGNATURES = [
     ("sk_amd_comm_unique_id", _I, [ctypes.c_char_p]), ("sk_amd_comm_create", _vp, [ctypes.c_char_p, _I, _I]), ("sk_amd_comm_destroy", None, [_vp]),
     ("sk_amd_engine_calculate_radiance_sharded", _I, [_vp, _vp, _vp, _vp, _I, _I]),
     ("sk_amd_so_engine_solve_device", _I, [_vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("sk_amd_so_engine_solve_device_wf", _I, [_vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("sk_amd_so_engine_sizes", _I, [_vp, ctypes.POINTER(ctypes.c_ulonglong)]),
     ("sk_amd_ts_engine_solve_device", _I, [_vp, _I, _I] + [_vp] * 17 + [_I]),
     ("sk_atmosphere_apply_delta_m_scaling", _I, [_vp, _I]),

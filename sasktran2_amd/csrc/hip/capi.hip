@@ -1054,11 +1054,10 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         validate_input_atmosphere(e, st);
         const bool wants_derivs = atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty());
         if (e->so && wants_derivs) {
-            // the successive-orders source is not linearised here (the reference's own linearisation of it is approximate): an error rather
-            // than a silently incomplete Jacobian
+            // a source without a linearisation is an error rather than a silently incomplete Jacobian (none today: the successive-orders
+            // diffuse field is differentiated by its discrete adjoint, so_adjoint.inc)
             if (e->so->has_unlinearised_sources()) {
-                set_error("sk_engine_calculate_radiance: weighting functions are not available with multiple_scatter_source = "
-                          "successive_orders_legacy in this build (create the atmosphere with calculate_derivatives = 0)");
+                set_error("sk_engine_calculate_radiance: weighting functions are not available with this combination of sources");
                 return -2;
             }
         }
@@ -1357,6 +1356,22 @@ int sk_amd_so_engine_solve_device(Engine* e, int nwavel, int nleg, const double*
         return 0;
     } catch (const std::exception& ex) {
         set_error(std::string("sk_amd_so_engine_solve_device: ") + ex.what());
+        return -3;
+    }
+}
+// the same with the native weighting functions: d_wf_ext / d_wf_ssa [nlocation][nwavel][nlos][nstokes], d_wf_albedo [nwavel][nlos][nstokes]
+int sk_amd_so_engine_solve_device_wf(Engine* e, int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg,
+                                     const double* d_albedo, const double* d_irradiance, double* d_radiance, double* d_los_od, double* d_wf_ext,
+                                     double* d_wf_ssa, double* d_wf_albedo, void* stream) {
+    if (!e) return -1;
+    try {
+        if (!e->so) throw std::runtime_error("the engine has no exact single-scatter / successive-orders source");
+        if (!d_ext || !d_ssa || !d_leg || !d_albedo || !d_radiance || !d_wf_ext || !d_wf_ssa || !d_wf_albedo) throw std::runtime_error("null device pointer");
+        if (e->so->has_emission()) throw std::runtime_error("emission sources take the host entry point (their derivative outputs are mappings)");
+        e->so->solve_device(nwavel, nleg, d_ext, d_ssa, d_leg, d_albedo, d_irradiance, d_radiance, d_los_od, stream, 0, d_wf_ext, d_wf_ssa, d_wf_albedo);
+        return 0;
+    } catch (const std::exception& ex) {
+        set_error(std::string("sk_amd_so_engine_solve_device_wf: ") + ex.what());
         return -3;
     }
 }

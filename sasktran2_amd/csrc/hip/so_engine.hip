@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
 // (singlescattersource.cpp:988-1030, solartransmission.h:852-901, sourceintegrator.cpp:536-579).  One line of sight x 64 wavelengths per
 // wavefront; every lane accumulates into its own column of `dacc` (coalesced read-modify-writes, L1 / L2 resident).
 template <int S>
-__global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b, int single_scatter) {
+__global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b, int single_scatter, int multiple_scatter) {
     const DevRays& rs = g.los;
     const int w = blockIdx.x * kWave + threadIdx.x, r = blockIdx.y;
     const SoBufs v = slab_view(g, b, blockIdx.x, threadIdx.x);
@@ -395,6 +395,12 @@ __global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b, int s
         add(0, 2 * ngrid, base * Bg);
         for (int t = rs.solar.start[e0]; t < rs.solar.start[e0 + 1]; ++t) add(0, rs.solar.idx[t], -rs.solar.w[t] * base * albedo * Bg);
     }
+    // diffuse field: its source along the ray is part of I (the attenuation derivatives below see it), with the direct dependence of
+    // omega (1 - e^-od) on the layer; the dependence through the outgoing sources themselves is the adjoint of so_adjoint.inc
+    if (multiple_scatter && rs.ground_is_hit[r])
+        for (int e = g.los_ground.start[r]; e < g.los_ground.start[r + 1]; ++e)
+#pragma unroll
+            for (int s = 0; s < S; ++s) I[s] += g.los_ground.w[e] * v.outgoing[(size_t(g.los_ground.idx[e]) * S + s) * kWave];
     for (int j = 0; j < n; ++j) {
         const int L = l0 + j;
         const double od = layer_od(L), att = exp(-od);
@@ -406,6 +412,18 @@ __global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b, int s
             for (int s = 0; s < S; ++s) add(s, rs.od.idx[t], -rs.od.w[t] * I[s] * B_in);
 #pragma unroll
         for (int s = 0; s < S; ++s) I[s] *= att;
+        if (multiple_scatter) {
+            const double omega = rs.mid_w[2 * L] * v.omT[size_t(rs.mid_idx[2 * L]) * kWave] + rs.mid_w[2 * L + 1] * v.omT[size_t(rs.mid_idx[2 * L + 1]) * kWave];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                double X = 0;
+                for (int e = g.los_source.start[L]; e < g.los_source.start[L + 1]; ++e) X += g.los_source.w[e] * v.outgoing[(size_t(g.los_source.idx[e]) * S + s) * kWave];
+                I[s] += omega * (1 - att) * X;
+                for (int t = rs.od.start[L]; t < rs.od.start[L + 1]; ++t) add(s, rs.od.idx[t], rs.od.w[t] * omega * att * X * Bj);
+                add(s, ngrid + rs.mid_idx[2 * L], rs.mid_w[2 * L] * (1 - att) * X * Bj);
+                add(s, ngrid + rs.mid_idx[2 * L + 1], rs.mid_w[2 * L + 1] * (1 - att) * X * Bj);
+            }
+        }
         const double T_ent = transmission(e0 + j + 1);
         if (g.emission != 0 && !rs.tiny[L]) {
             // EmissionSource::integrated_source with its derivative rows (emission_source.cpp:37-152)
@@ -954,6 +972,8 @@ __global__ void __launch_bounds__(kWave) k_so_accumulate(SoGeo g, SoBufs b) {
     for (int s = 0; s < S; ++s) v.incoming[(size_t(r) * S + s) * kWave] = acc[s];
 }
 
+#include "so_adjoint.inc"
+
 // One step of the fixed-point driver of MultipleScatterSource::SuccessiveOrders (reference: FixedPointSolver::solve / update_history /
 // anderson_update, cpp/lib/successive_orders/fixed_point.h:132-258), one wavelength per LANE: residual and stop rule in the infinity norm,
 // the ring of state / residual differences, the <= 3 x 3 normal equations of the Type-II Anderson step (diagonal regularised by
@@ -1098,12 +1118,19 @@ struct SoDeviceEngine::Impl {
     double *fp_x = nullptr, *fp_mapped = nullptr, *fp_prev_x = nullptr, *fp_prev_r = nullptr, *fp_dX = nullptr, *fp_dR = nullptr;
     int *fp_done = nullptr, *fp_active = nullptr;
     int fp_last_iterations = 0;
+    // weighting functions of the diffuse field (so_adjoint.inc): the transposed accumulation matrix, the per-seed scratch and the
+    // outgoing states x_1 .. x_{n-1} of the forward passes
+    const int *accT_start = nullptr, *accT_ray = nullptr, *accT_slot = nullptr;
+    const double* accT_w = nullptr;
+    SoAdj adj{};
+    std::vector<double*> xhist;
+    bool cap_adjoint = false;
     bool single_scatter = true, multiple_scatter = true;
     int capacity = 0, cap_nleg = 0;
     bool cap_derivs = false;
     int cap_groups = 0;   // scattering groups the derivative scratch holds
     const double *d_emission = nullptr, *d_surface_emission = nullptr;
-    size_t n_inc_rays = 0, n_inc_layers = 0, n_acc = 0, n_out = 0, n_table = 0, max_rows = 0, n_groups = 0;
+    size_t n_inc_rays = 0, n_inc_layers = 0, n_acc = 0, n_out = 0, n_table = 0, max_rows = 0, max_cols = 0, n_groups = 0;
     size_t scratch_bytes = 0;
     int last_chunk = 0;
     bool profiling = false;
@@ -1272,6 +1299,26 @@ SoDeviceEngine::SoDeviceEngine(const skso::SoGeometry& sg, int num_iterations) :
             g.acc_group = I.tables.upload(groups);
             g.acc_group_start = I.tables.upload(gstart);
             I.n_groups = groups.size();
+            // the accumulation matrix by COLUMN (outgoing direction): the adjoint's lambda <- A^T mu as a gather
+            {
+                const int ncol = sg.out_start.back();
+                std::vector<int> tstart(ncol + 1, 0), tray(sg.accumulation.idx.size()), tslot(sg.accumulation.idx.size());
+                std::vector<double> tw(sg.accumulation.idx.size());
+                for (int c : sg.accumulation.idx) ++tstart[c + 1];
+                for (int c = 0; c < ncol; ++c) tstart[c + 1] += tstart[c];
+                std::vector<int> fill(tstart.begin(), tstart.end() - 1);
+                for (int r = 0; r < in.nrays; ++r)
+                    for (int e = sg.accumulation.start[r]; e < sg.accumulation.start[r + 1]; ++e) {
+                        const int at = fill[sg.accumulation.idx[e]]++;
+                        tray[at] = r;
+                        tslot[at] = slot[e];
+                        tw[at] = sg.accumulation.w[e];
+                    }
+                I.accT_start = I.tables.upload(tstart);
+                I.accT_ray = I.tables.upload(tray);
+                I.accT_slot = I.tables.upload(tslot);
+                I.accT_w = I.tables.upload(tw);
+            }
         }
         g.los_source = I.up(sg.los_source);
         g.los_ground = I.up(sg.los_ground);
@@ -1362,6 +1409,7 @@ SoDeviceEngine::SoDeviceEngine(const skso::SoGeometry& sg, int num_iterations) :
         I.n_out = sg.out_start.back();
         I.n_table = g.ntable;
         I.max_rows = size_t(sg.nout) * S;
+        I.max_cols = size_t(sg.nin) * S;
     }
     SO_HIP_CHECK(hipEventCreate(&I.ev0));
     SO_HIP_CHECK(hipEventCreate(&I.ev1));
@@ -1379,7 +1427,7 @@ int SoDeviceEngine::nlos() const { return impl_->g.nlos; }
 int SoDeviceEngine::ngrid() const { return impl_->g.ngrid; }
 int SoDeviceEngine::nstokes() const { return impl_->g.S; }
 bool SoDeviceEngine::has_successive_orders() const { return impl_->multiple_scatter; }
-bool SoDeviceEngine::has_unlinearised_sources() const { return impl_->multiple_scatter; }
+bool SoDeviceEngine::has_unlinearised_sources() const { return false; }   // the diffuse field has its discrete adjoint (so_adjoint.inc)
 bool SoDeviceEngine::has_emission() const { return impl_->g.emission != 0; }
 void SoDeviceEngine::set_fixed_point(bool enabled, double relative_tolerance, double absolute_tolerance, double damping, int anderson_depth) {
     if (!(relative_tolerance >= 0) || !(absolute_tolerance >= 0) || !std::isfinite(relative_tolerance) || !std::isfinite(absolute_tolerance))
@@ -1433,6 +1481,47 @@ static size_t so_doubles_per_wavelength(const SoDeviceEngine::Impl& I, int nleg)
 }
 size_t SoDeviceEngine::bytes_per_wavelength() const { return so_doubles_per_wavelength(*impl_, std::max(impl_->cap_nleg, impl_->g.num_ss_moments)) * sizeof(double); }
 
+// The diffuse field's share of the weighting functions of one wavelength block (so_adjoint.inc), seed by seed into the accumulators
+// k_so_los_deriv has filled.
+template <int S>
+static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b, hipStream_t st, unsigned wb, bool adj_final) {
+    SoTimer t(I, st, "so_adjoint");
+    SoAdj A = I.adj;
+    const size_t W = b.nwp, n_state = size_t(g.n_out_total) * S * W, n_rays = size_t(g.inc.nrays) * S * W, n_slots = size_t(g.n_inc_layers + g.inc.nrays) * W;
+    const int n = I.fp.enabled && !adj_final ? I.fp_last_iterations : I.num_iterations;   // passes to transpose / terms of the series
+    const size_t lds_chain = size_t(2) * g.ngrid * kWave * sizeof(double), lds_fold = size_t(g.ngrid) * kWave * sizeof(double);
+    if (lds_chain > 160 * 1024) throw std::runtime_error("sasktran2_amd: successive-orders weighting functions hold 2 x ngrid x 64 doubles in LDS (ngrid <= 160)");
+    if (lds_chain > 64 * 1024) {
+        SO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_so_adj_chain<S>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_chain)));
+        SO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_so_adj_fold), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fold)));
+    }
+    int rays_per_block = 16;
+    if (const char* e = std::getenv("SASKTRAN2_AMD_SO_ADJ_RPB")) rays_per_block = std::max(1, atoi(e));
+    const unsigned nchunks = unsigned((g.inc.nrays + rays_per_block - 1) / rays_per_block);
+    for (int ray = 0; ray < g.nlos; ++ray)
+        for (int comp = 0; comp < S; ++comp) {
+            A.ray = ray;
+            A.comp = comp;
+            A.xprev = nullptr;
+            SO_HIP_CHECK(hipMemsetAsync(A.lam, 0, n_state * sizeof(double), st));
+            SO_HIP_CHECK(hipMemsetAsync(A.gfirst, 0, n_rays * sizeof(double), st));
+            SO_HIP_CHECK(hipMemsetAsync(A.gfac, 0, n_slots * sizeof(double), st));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_seed<S>), dim3(wb), dim3(kWave), 0, st, g, b, A);
+            for (int k = n; k >= 1; --k) {
+                A.xprev = adj_final ? b.outgoing : (k > 1 ? I.xhist[k - 2] : nullptr);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_scatter<S>), dim3(unsigned(I.max_cols), wb, unsigned(g.npoints)), dim3(kWave), 0, st, g, b, A);
+                if (!A.xprev) break;   // the first pass started from x = 0: nothing behind it
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_gfac<S>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b, A);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_accT<S>), dim3(unsigned(g.n_out_total), wb), dim3(kWave), 0, st, g, b, A, I.accT_start, I.accT_ray,
+                                   I.accT_slot, I.accT_w);
+                std::swap(A.lam, A.lam_new);
+            }
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S>), dim3(wb, nchunks), dim3(kWave), lds_chain, st, g, b, A, g.inc_rec, rays_per_block);
+            hipLaunchKernelGGL(k_so_adj_fold, dim3(wb), dim3(kWave), lds_fold, st, g, b, A);
+        }
+    SO_HIP_CHECK(hipGetLastError());
+}
+
 void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const double* d_ssa, const double* d_leg, const double* d_albedo,
                                   const double* d_irradiance, double* d_radiance, double* d_los_od, void* stream, int accumulate,
                                   double* d_wf_ext, double* d_wf_ssa, double* d_wf_alb, double* d_wf_emission, double* d_wf_surface_emission,
@@ -1444,12 +1533,19 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     const int S = g.S, per = S == 3 ? 4 : 1;
     const bool derivs = d_wf_ext != nullptr;
     if (derivs && (!d_wf_ssa || !d_wf_alb)) throw std::runtime_error("sasktran2_amd: weighting functions need all three output buffers");
-    if (derivs && I.multiple_scatter) throw std::runtime_error("sasktran2_amd: the successive-orders source is not linearised");
+    const bool adjoint = derivs && I.multiple_scatter;   // weighting functions through the diffuse field (so_adjoint.inc)
+    if (adjoint && ngroups > 0) throw std::runtime_error("sasktran2_amd: scattering-group weighting functions are not available with the successive-orders source");
+    // the exact transpose of the n passes needs their states; the Anderson-mixed / damped / tolerance-stopped driver is differentiated about
+    // its final state instead (adjoint Neumann series, as many terms as the driver's iteration limit)
+    const bool fp_is_legacy = I.fp.depth == 0 && I.fp.damping == 1.0 && I.fp.rel == 0 && I.fp.abs == 0;
+    const bool adj_final = adjoint && I.fp.enabled && !fp_is_legacy;
+    const size_t n_hist = (adjoint && !adj_final && I.num_iterations > 1) ? size_t(I.num_iterations - 1) : 0;
     if (ngroups < 0 || (ngroups > 0 && (!derivs || !d_dleg || !d_wf_groups))) throw std::runtime_error("sasktran2_amd: scattering groups need weighting-function buffers, d_legendre and an output");
     if (g.emission && !I.d_emission) throw std::runtime_error("sasktran2_amd: the engine has an emission source but no emission_source array was set (set_emission)");
     // block of wavelengths in flight: half of the free HBM (plus what this engine already holds), balanced blocks, multiple of the wavefront
     const size_t deriv_doubles = derivs ? size_t(g.nlos) * S * so_deriv_slots(g.ngrid, ngroups) + size_t(ngroups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1) : 0;
-    const size_t per_w = (so_doubles_per_wavelength(I, nleg) + deriv_doubles) * sizeof(double);
+    const size_t adj_doubles = adjoint ? (2 + n_hist) * I.n_out * S + 2 * I.n_inc_rays * S + (I.n_inc_layers + I.n_inc_rays) + 1 + I.n_table : 0;
+    const size_t per_w = (so_doubles_per_wavelength(I, nleg) + deriv_doubles + adj_doubles) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = size_t(0.5 * double(free_b + I.scratch_bytes));
@@ -1460,9 +1556,11 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     int chunk = int((size_t(nwavel) + nblocks - 1) / nblocks);
     chunk = (chunk + kPad - 1) / kPad * kPad;
     I.last_chunk = chunk;
-    if (chunk > I.capacity || nleg > I.cap_nleg || (derivs && !I.cap_derivs) || ngroups > I.cap_groups) {
+    if (chunk > I.capacity || nleg > I.cap_nleg || (derivs && !I.cap_derivs) || ngroups > I.cap_groups || (adjoint && !I.cap_adjoint) || n_hist > I.xhist.size()) {
         I.scratch.release();
         I.cap_derivs = I.cap_derivs || derivs;
+        I.cap_adjoint = I.cap_adjoint || adjoint;
+        const size_t keep_hist = std::max(n_hist, I.xhist.size());
         I.cap_groups = std::max(I.cap_groups, ngroups);
         I.capacity = std::max(chunk, I.capacity);
         I.cap_nleg = std::max(nleg, I.cap_nleg);
@@ -1493,6 +1591,20 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
                 I.fp_done = I.scratch.alloc<int>(W);
                 I.fp_active = I.scratch.alloc<int>(1);
             }
+        }
+        I.xhist.clear();
+        if (I.cap_adjoint) {
+            SoAdj& A = I.adj;
+            A.lam = I.scratch.alloc<double>(I.n_out * S * W);
+            A.lam_new = I.scratch.alloc<double>(I.n_out * S * W);
+            A.mu = I.scratch.alloc<double>(I.n_inc_rays * S * W);
+            A.gfirst = I.scratch.alloc<double>(I.n_inc_rays * S * W);
+            A.gfac = I.scratch.alloc<double>((I.n_inc_layers + I.n_inc_rays) * W);
+            A.galb = I.scratch.alloc<double>(W);
+            A.gtod = I.scratch.alloc<double>(I.n_table * W);
+            SO_HIP_CHECK(hipMemset(A.galb, 0, W * sizeof(double)));            // (k_so_adj_fold leaves both cleared)
+            SO_HIP_CHECK(hipMemset(A.gtod, 0, I.n_table * W * sizeof(double)));
+            for (size_t k = 0; k < keep_hist; ++k) I.xhist.push_back(I.scratch.alloc<double>(I.n_out * S * W));
         }
         b.dacc = I.cap_derivs ? I.scratch.alloc<double>(size_t(g.nlos) * S * so_deriv_slots(g.ngrid, I.cap_groups) * W) : nullptr;
         b.dphT = I.cap_groups > 0 ? I.scratch.alloc<double>(size_t(I.cap_groups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1) * W) : nullptr;
@@ -1606,6 +1718,7 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
                                            I.fp_done, I.fp_active);
                     }
                     I.fp_last_iterations = it + 1;
+                    if (size_t(it) < n_hist) SO_HIP_CHECK(hipMemcpyAsync(I.xhist[it], I.fp_x, nst * sizeof(double), hipMemcpyDeviceToDevice, st));   // x_{it+1}
                     if (conv_on) {
                         int active = 1;
                         SO_HIP_CHECK(hipMemcpyAsync(&active, I.fp_active, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1631,6 +1744,8 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
                 } else {
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<3>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.npoints)), dim3(kWave), 0, st, g, b, 0);
                 }
+                if (size_t(it) < n_hist)   // x_{it+1}
+                    SO_HIP_CHECK(hipMemcpyAsync(I.xhist[it], b.outgoing, size_t(g.n_out_total) * S * b.nwp * sizeof(double), hipMemcpyDeviceToDevice, st));
             }
         }
         {
@@ -1641,8 +1756,12 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
         if (derivs) {
             SoTimer t(I, st, "so_los_derivatives");
             if (ngroups > 0) hipLaunchKernelGGL(k_so_group_phase, dim3(wb, unsigned(ngroups * g.ngrid)), dim3(kWave), 0, st, g, b);
-            if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_los_deriv<1>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b, ss);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_los_deriv<3>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b, ss);
+            if (S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_los_deriv<1>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b, ss, ms);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_los_deriv<3>), dim3(wb, unsigned(g.nlos)), dim3(kWave), 0, st, g, b, ss, ms);
+            if (adjoint) {
+                if (S == 1) run_adjoint<1>(I, g, b, st, wb, adj_final);
+                else run_adjoint<3>(I, g, b, st, wb, adj_final);
+            }
             hipLaunchKernelGGL(k_so_deriv_out, dim3(2048), dim3(256), 0, st, g, b);
         }
         SO_HIP_CHECK(hipGetLastError());

@@ -118,10 +118,13 @@ class SoDeviceSolver(DeviceSolver):
         self.nstokes = int(engine._config.num_stokes)
 
     def allocate_outputs(self, nwavel, derivatives=False, device="cuda"):
-        if derivatives:
-            raise ValueError("weighting functions are not available on the successive-orders path")
         kw = dict(dtype=torch.float64, device=device)
-        return {"radiance": torch.empty((nwavel, self.nlos, self.nstokes), **kw), "los_optical_depth": torch.empty((nwavel, self.nlos), **kw)}
+        out = {"radiance": torch.empty((nwavel, self.nlos, self.nstokes), **kw), "los_optical_depth": torch.empty((nwavel, self.nlos), **kw)}
+        if derivatives:   # `sk_amd_so_engine_solve_device_wf`
+            out["wf_extinction"] = torch.empty((self.ngrid, nwavel, self.nlos, self.nstokes), **kw)
+            out["wf_ssa"] = torch.empty((self.ngrid, nwavel, self.nlos, self.nstokes), **kw)
+            out["wf_albedo"] = torch.empty((nwavel, self.nlos, self.nstokes), **kw)
+        return out
 
     def solve(self, extinction, ssa, leg, albedo, out, irradiance=None, max_chunk=0):
         """extinction, ssa: [nwavel, ngrid]; leg: [nwavel, ngrid, nleg (x 4 for NSTOKES = 3)]; albedo: [nwavel] -- contiguous float64
@@ -130,9 +133,15 @@ class SoDeviceSolver(DeviceSolver):
             assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
         per = 4 if self.nstokes == 3 else 1
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-        rc = lib().sk_amd_so_engine_solve_device(
-            self.engine._h, extinction.shape[0], leg.shape[2] // per, p(extinction), p(ssa), p(leg), p(albedo), p(irradiance),
-            p(out["radiance"]), p(out["los_optical_depth"]), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if "wf_extinction" in out:
+            rc = lib().sk_amd_so_engine_solve_device_wf(
+                self.engine._h, extinction.shape[0], leg.shape[2] // per, p(extinction), p(ssa), p(leg), p(albedo), p(irradiance),
+                p(out["radiance"]), p(out["los_optical_depth"]), p(out["wf_extinction"]), p(out["wf_ssa"]), p(out["wf_albedo"]), stream)
+        else:
+            rc = lib().sk_amd_so_engine_solve_device(
+                self.engine._h, extinction.shape[0], leg.shape[2] // per, p(extinction), p(ssa), p(leg), p(albedo), p(irradiance),
+                p(out["radiance"]), p(out["los_optical_depth"]), stream)
         if rc != 0:
             raise RuntimeError(f"sk_amd_so_engine_solve_device returned {rc}: {last_error()}")
         return out

@@ -66,16 +66,13 @@ def test_c5_shape_limb_scene_matches_oracle_and_is_block_invariant(monkeypatch):
     assert np.array_equal(blocks["radiance"], got["radiance"])
 
 
-def test_solar_irradiance_scales_the_radiance_and_derivatives_are_refused():
+def test_solar_irradiance_scales_the_radiance():
     from tests.gpu_harness import build_so_engine
     s = sc.regression_so(nstokes=1)
     eng = build_so_engine(s)
     one = run_product_so(s, engine=eng)["radiance"]
     two = run_product_so(s, engine=eng, solar_irradiance=np.array([2.0, 3.0]))["radiance"]
     np.testing.assert_allclose(two, one * np.array([2.0, 3.0])[:, None, None], rtol=1e-13)
-    # the successive-orders source is not linearised: asking for weighting functions is an error, not a partial Jacobian
-    with pytest.raises(RuntimeError, match="weighting functions are not available"):
-        run_product_so(s, engine=eng, derivatives=True)
 
 
 def test_exact_single_scatter_on_top_of_discrete_ordinates():
@@ -181,9 +178,14 @@ def test_emission_and_occultation_sources_match_oracle(nstokes, emission):
         scale = np.maximum(np.abs(ref[k]).max(axis=3, keepdims=True), 1e-6 * np.abs(ref["d_extinction"]).max())
         assert np.max(np.abs(got[k] - ref[k]) / scale) < 1e-9, k
     np.testing.assert_allclose(got["d_albedo"], ref["d_albedo"], rtol=1e-10, atol=1e-300)
-    # the successive-orders source stays without weighting functions
-    with pytest.raises(RuntimeError, match="weighting functions are not available"):
-        run_product_so(s, emission_source=em, surface_emission=sem, derivatives=True, **o)
+    # ... and with the successive-orders diffuse field on top (its discrete adjoint, so_adjoint.inc)
+    ref = make_so_oracle(s, **o).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], emission=em, surface_emission=sem, derivatives=True)
+    got = run_product_so(s, emission_source=em, surface_emission=sem, derivatives=True, **o)
+    assert_so_parity(got, ref)
+    for k in ("d_extinction", "d_ssa", "d_emission"):
+        scale = np.maximum(np.abs(ref[k]).max(axis=3, keepdims=True), 1e-6 * np.abs(ref["d_extinction"]).max())
+        assert np.max(np.abs(got[k] - ref[k]) / scale) < 1e-6, k
+    np.testing.assert_allclose(got["d_albedo"], ref["d_albedo"], rtol=1e-6, atol=1e-300)
 
 
 @pytest.mark.parametrize("nstokes", [1, 3])
@@ -276,3 +278,62 @@ def test_full_size_c5_properties_with_the_new_source():
     np.testing.assert_array_equal(part, full[idx])
     ref = run_so_oracle(sub, nthreads=6, **o)["radiance"]
     np.testing.assert_allclose(part[..., 0], ref[..., 0], rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Weighting functions through the diffuse field: the discrete adjoint of the passes (sasktran2_amd/csrc/hip/so_adjoint.inc).  The reference's
+# legacy source has none; the checkers are the oracle's own adjoint (validated against finite differences on the CPU, test_so_oracle.py)
+# and central finite differences of the DEVICE radiances.
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nstokes,iterations", [(1, 1), (1, 3), (3, 2)])
+def test_successive_orders_weighting_functions_match_the_oracle_adjoint(nstokes, iterations):
+    from tests.test_so_oracle import make_so_oracle
+    s = sc.regression_so(nstokes=nstokes, num_wavelengths=3)
+    s["albedo"] = np.array([0.0, 0.3, 0.8])
+    o = dict(num_iterations=iterations)
+    ref = make_so_oracle(s, **o).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, nthreads=4)
+    got = run_product_so(s, derivatives=True, **o)
+    assert_so_parity(got, ref)
+    assert_so_wf_parity(got, ref, tol=1e-6)
+
+
+def test_successive_orders_weighting_functions_against_finite_differences_of_the_device_radiance():
+    from tests.gpu_harness import build_so_engine
+    s = sc.regression_so(nstokes=1, num_wavelengths=2)
+    s["albedo"] = np.array([0.3, 0.6])
+    eng = build_so_engine(s, num_iterations=4)
+    got = run_product_so(s, engine=eng, derivatives=True)
+    k, w = s["extinction"], s["ssa"]
+    for key, arr, name in (("d_extinction", k, "extinction"), ("d_ssa", w, "ssa")):
+        scale = np.abs(got[key]).max(axis=3)
+        for q in (0, 5, 11, 17):
+            h = 1e-5 * arr[q].max() if name == "extinction" else 1e-5
+            up, dn = arr.copy(), arr.copy()
+            up[q] += h
+            dn[q] -= h
+            rp = run_product_so(dict(s, **{name: up}), engine=eng)["radiance"]
+            rm = run_product_so(dict(s, **{name: dn}), engine=eng)["radiance"]
+            fd = (rp - rm) / (2 * h)
+            assert np.max(np.abs(fd - got[key][..., q]) / scale) < 2e-5, (name, q)
+    h = 1e-5
+    rp = run_product_so(dict(s, albedo=s["albedo"] + h), engine=eng)["radiance"]
+    rm = run_product_so(dict(s, albedo=s["albedo"] - h), engine=eng)["radiance"]
+    np.testing.assert_allclose(got["d_albedo"], (rp - rm) / (2 * h), rtol=1e-6)
+
+
+def test_new_source_weighting_functions_fixed_iterations_and_anderson():
+    """multiple_scatter_source = successive_orders: with depth 0, damping 1 and zero tolerances the driver IS the legacy iteration (exact
+    transpose); the Anderson-mixed, tolerance-stopped driver is differentiated about its final state (adjoint Neumann series)."""
+    from tests.test_so_oracle import make_so_oracle
+    s = sc.regression_so(nstokes=1, num_wavelengths=2)
+    s["albedo"] = np.array([0.2, 0.5])
+    legacy = run_product_so(s, derivatives=True, num_iterations=3)
+    same = run_product_so(s, derivatives=True, num_iterations=3, multiple_scatter="successive_orders", relative_tolerance=0.0, absolute_tolerance=0.0,
+                          damping=1.0, anderson_depth=0)
+    for key in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
+        np.testing.assert_allclose(same[key], legacy[key], rtol=1e-12, atol=1e-300)
+    o = dict(num_iterations=40, multiple_scatter="successive_orders", relative_tolerance=1e-10, absolute_tolerance=0.0, damping=1.0, anderson_depth=3)
+    ref = make_so_oracle(s, **o).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, nthreads=4)
+    got = run_product_so(s, derivatives=True, **o)
+    assert_so_parity(got, ref)
+    assert_so_wf_parity(got, ref, tol=1e-6)

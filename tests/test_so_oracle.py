@@ -118,9 +118,6 @@ def test_exact_single_scatter_weighting_functions_match_finite_differences(nstok
     h = 1e-6
     fd = (o.run(s["extinction"], s["ssa"], s["leg"], s["albedo"] + h)["radiance"] - o.run(s["extinction"], s["ssa"], s["leg"], s["albedo"] - h)["radiance"]) / (2 * h)
     np.testing.assert_allclose(r["d_albedo"], fd, atol=1e-9 * np.abs(r["radiance"]).max() / h * 1e-3 + 1e-10)
-    # the diffuse source is not linearised: the oracle refuses as the product does
-    with pytest.raises(RuntimeError):
-        make_so_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
 
 
 def test_emission_and_occultation_sources_have_their_closed_forms():
@@ -262,3 +259,41 @@ def test_zero_tolerances_use_the_iteration_count_and_a_huge_tolerance_stops_at_o
     early = run_so_oracle(sc.successive_orders_reference_scene(1, 8, albedo=0.12, absolute_tolerance=1e100))["radiance"]
     np.testing.assert_allclose(early, one, rtol=2e-13, atol=2e-14)
     assert np.linalg.norm(two - one) > 1e-7 * np.linalg.norm(one)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Weighting functions through the diffuse field (oracle/so_oracle.hpp, ms_adjoint): the discrete adjoint of the passes against central
+# finite differences of the oracle's own radiances.  (The reference's legacy source has no weighting functions to compare with.)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _fd_check(s, engine, base, tol):
+    k, w = s["extinction"], s["ssa"]
+    run = lambda kk, ww, aa: engine.run(kk, ww, s["leg"], aa, nthreads=4)["radiance"]   # noqa: E731
+    for key, arr, which in (("d_extinction", k, 0), ("d_ssa", w, 1)):
+        scale = np.abs(base[key]).max(axis=-1)
+        for q in range(0, k.shape[0] - 6, 4):   # (the top levels carry too little extinction for a clean difference quotient)
+            h = 1e-6 * arr[q].max() if which == 0 else 1e-6
+            up, dn = arr.copy(), arr.copy()
+            up[q] += h
+            dn[q] -= h
+            fd = (run(up, w, s["albedo"]) - run(dn, w, s["albedo"])) / (2 * h) if which == 0 else (run(k, up, s["albedo"]) - run(k, dn, s["albedo"])) / (2 * h)
+            assert np.max(np.abs(fd - base[key][..., q]) / scale) < tol, (key, q)
+    h = 1e-6
+    fd = (run(k, w, s["albedo"] + h) - run(k, w, s["albedo"] - h)) / (2 * h)
+    np.testing.assert_allclose(base["d_albedo"], fd, rtol=1e-6, atol=1e-9 * np.abs(fd).max())
+
+
+@pytest.mark.parametrize("nstokes", [1, 3])
+def test_diffuse_field_adjoint_against_finite_differences(nstokes):
+    s = sc.regression_so(nstokes=nstokes)
+    s["albedo"] = np.full_like(s["albedo"], 0.3)
+    e = make_so_oracle(s, num_iterations=3)
+    base = e.run(s["extinction"], s["ssa"], s["leg"], s["albedo"], nthreads=4, derivatives=True)
+    _fd_check(s, e, base, 5e-6)
+
+
+def test_diffuse_field_adjoint_of_the_anderson_driver_against_finite_differences():
+    s = sc.regression_so(nstokes=1)
+    s["albedo"] = np.full_like(s["albedo"], 0.3)
+    e = make_so_oracle(s, num_iterations=60, multiple_scatter="successive_orders", relative_tolerance=1e-10, absolute_tolerance=0.0, anderson_depth=3)
+    base = e.run(s["extinction"], s["ssa"], s["leg"], s["albedo"], nthreads=4, derivatives=True)
+    _fd_check(s, e, base, 5e-6)
