@@ -126,6 +126,8 @@ def main():
                          "exact single scatter + 10 successive orders of scattering; twostream: the reference's two-stream benchmark "
                          "(20 layers, 220 000 wavelengths, weighting functions); frontend: the optical-property front end (constituents -> storage and "
                          "derivative mappings in HBM) at the C2 size")
+    ap.add_argument("--weighting-functions", action="store_true",
+                    help="c5 only: also wf_extinction / wf_ssa / wf_albedo of every line of sight (the diffuse field's discrete adjoint)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer call (value_host_path)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="wavelengths of the CPU baseline sample (0 = auto)")

@@ -59,7 +59,8 @@ def run_c5(args, world, rank, dev):
     to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     ext, ssa = to(s["extinction"][:, lo:hi].T), to(s["ssa"][:, lo:hi].T)
     leg, alb = to(np.transpose(s["leg"][:, :, lo:hi], (2, 1, 0))), to(s["albedo"][lo:hi])
-    out = solver.allocate_outputs(nloc, device=dev)
+    wf = bool(getattr(args, "weighting_functions", False))
+    out = solver.allocate_outputs(nloc, derivatives=wf, device=dev)
 
     def step():
         solver.solve(ext, ssa, leg, alb, out)
@@ -147,12 +148,14 @@ def run_c5(args, world, rank, dev):
                 e["fp64_TFLOPs"] = model[k]["flops"] * nloc * launches_per_block / (v[0] * 1e-3) / 1e12
         per_solve[k] = e
     line = {
-        "metric": "wavelengths/sec (radiance, exact single scatter + 10 successive orders) 50 layer / 110 directions",
+        "metric": ("wavelengths/sec (radiance + wf_extinction / wf_ssa / wf_albedo, exact single scatter + 10 successive orders) 50 layer / 110 directions" if wf
+                   else "wavelengths/sec (radiance, exact single scatter + 10 successive orders) 50 layer / 110 directions"),
         "value": value, "unit": "wavelengths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "C5 limb-scatter spherical: exact single scatter + SuccessiveOrdersLegacy, 10 orders, 110 incoming / 110 outgoing "
-                               f"directions, 50 layers, 25 tangent heights 10-58 km, {NW} wavelengths, Stokes I",
+                               f"directions, 50 layers, 25 tangent heights 10-58 km, {NW} wavelengths, Stokes I"
+                               + (", weighting functions of all lines of sight (discrete adjoint of the 10 passes)" if wf else ""),
                    "wavelengths_per_gpu": nloc, "parallelism": f"wavelength-shard x{world} + RCCL all-gather" if world > 1 else "single GPU",
                    "wavelengths_per_launch": chunk, **{k: int(v) for k, v in sizes.items()}},
         "valid": finite, "roofline": roofline, "kernels_ms": per_solve,
@@ -165,12 +168,12 @@ def run_c5(args, world, rank, dev):
         probe = max(cores, 8)
         idx = np.linspace(0, NW - 1, probe).astype(int)
         t = time.perf_counter()
-        eng.run(s["extinction"][:, idx], s["ssa"][:, idx], s["leg"][:, :, idx], s["albedo"][idx], nthreads=cores)
+        eng.run(s["extinction"][:, idx], s["ssa"][:, idx], s["leg"][:, :, idx], s["albedo"][idx], nthreads=cores, derivatives=wf)
         rate = probe / (time.perf_counter() - t)
         n = args.cpu_sample or int(min(max(rate * 15.0, probe), 8192))
         idx = np.linspace(0, NW - 1, n).astype(int)
         t = time.perf_counter()
-        ref = eng.run(s["extinction"][:, idx], s["ssa"][:, idx], s["leg"][:, :, idx], s["albedo"][idx], nthreads=cores)
+        ref = eng.run(s["extinction"][:, idx], s["ssa"][:, idx], s["leg"][:, :, idx], s["albedo"][idx], nthreads=cores, derivatives=wf)
         dt = time.perf_counter() - t
         got = out["radiance"].cpu().numpy()[idx]
         cpu_model = ""
@@ -182,5 +185,9 @@ def run_c5(args, world, rank, dev):
         line["cpu_baseline"] = {"value": n / dt, "unit": "wavelengths/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
                                 "sample": f"{n} of the {NW} wavelengths (evenly spaced), same workload, {dt:.1f} s",
                                 "parity_radiance_max_rel": float(np.max(np.abs(got / ref["radiance"] - 1)))}
+        if wf:   # [ngrid, nwavel, nlos, S] -> the oracle's [nwavel, nlos, S, ngrid], relative to the largest value of each profile
+            for key, name in (("wf_extinction", "d_extinction"), ("wf_ssa", "d_ssa")):
+                g_ = out[key].cpu().numpy()[:, idx].transpose(1, 2, 3, 0)
+                line["cpu_baseline"][f"parity_{key}_max_rel_to_profile_max"] = float(np.max(np.abs(g_ - ref[name]) / np.abs(ref[name]).max(axis=3, keepdims=True)))
         line["speedup_vs_cpu_baseline"] = value / (n / dt)
     print(json.dumps(line), flush=True)

@@ -1122,7 +1122,15 @@ struct SoDeviceEngine::Impl {
     // outgoing states x_1 .. x_{n-1} of the forward passes
     const int *accT_start = nullptr, *accT_ray = nullptr, *accT_slot = nullptr;
     const double* accT_w = nullptr;
+    const int *tabT_start = nullptr, *tabT_row = nullptr;   // the solar table by grid point
+    const double* tabT_w = nullptr;
+    const double *shT_out = nullptr, *shT_in = nullptr;     // transposed spherical-harmonic transforms [nout][nlm], [nlm][nin_pad]
+    int nin_pad = 0;
     SoAdj adj{};
+    double *adj_mu = nullptr, *adj_y = nullptr, *adj_gis = nullptr;   // mu slices [passes + 1], Y per pass, ground flux per pass
+    size_t adj_passes = 0, adj_terms = 0;
+    const int* ray_ground = nullptr;       // [incoming rays] ground point of the ray's diffuse point, or -1
+    const double* ray_gfactor = nullptr;   // [incoming rays] its factor in the point's downwelling flux
     std::vector<double*> xhist;
     bool cap_adjoint = false;
     bool single_scatter = true, multiple_scatter = true;
@@ -1318,6 +1326,30 @@ SoDeviceEngine::SoDeviceEngine(const skso::SoGeometry& sg, int num_iterations) :
                 I.accT_ray = I.tables.upload(tray);
                 I.accT_slot = I.tables.upload(tslot);
                 I.accT_w = I.tables.upload(tw);
+                const skso::Csr& T = sg.table.od;
+                std::vector<int> qstart(sg.ngrid + 1, 0), qrow(T.idx.size());
+                std::vector<double> qw(T.idx.size());
+                for (int c : T.idx) ++qstart[c + 1];
+                for (int c = 0; c < sg.ngrid; ++c) qstart[c + 1] += qstart[c];
+                std::vector<int> qfill(qstart.begin(), qstart.end() - 1);
+                for (int t = 0; t < T.rows(); ++t)
+                    for (int e = T.start[t]; e < T.start[t + 1]; ++e) {
+                        const int at = qfill[T.idx[e]]++;
+                        qrow[at] = t;
+                        qw[at] = T.w[e];
+                    }
+                I.tabT_start = I.tables.upload(qstart);
+                I.tabT_row = I.tables.upload(qrow);
+                I.tabT_w = I.tables.upload(qw);
+                std::vector<int> rg(in.nrays, -1);
+                std::vector<double> rf(in.nrays, 0.0);
+                for (int p = sg.ninterior; p < sg.npoints; ++p)
+                    for (int i = 0; i < sg.ground_nin[p - sg.ninterior]; ++i) {
+                        rg[sg.in_start[p] + i] = p - sg.ninterior;
+                        rf[sg.in_start[p] + i] = sg.ground_in_factor[p - sg.ninterior][i];
+                    }
+                I.ray_ground = I.tables.upload(rg);
+                I.ray_gfactor = I.tables.upload(rf);
             }
         }
         g.los_source = I.up(sg.los_source);
@@ -1391,6 +1423,16 @@ SoDeviceEngine::SoDeviceEngine(const skso::SoGeometry& sg, int num_iterations) :
                 g.sh_in = I.tables.upload(sh_in);
                 g.sh_out = I.tables.upload(sh_out);
                 g.sh_l = I.tables.upload(sh_l);
+                // transposed transforms of the adjoint (k_so_adj_sh)
+                const int nin_pad = (sg.nin + 15) / 16 * 16;
+                std::vector<double> shT_out(size_t(sg.nout) * nlm), shT_in(size_t(nlm) * nin_pad, 0.0);
+                for (int o = 0; o < sg.nout; ++o)
+                    for (int lm = 0; lm < nlm; ++lm) shT_out[size_t(o) * nlm + lm] = sh_out[size_t(lm) * nout_pad + o];
+                for (int i = 0; i < sg.nin; ++i)
+                    for (int lm = 0; lm < nlm; ++lm) shT_in[size_t(lm) * nin_pad + i] = sh_in[size_t(i) * nlm + lm];
+                I.shT_out = I.tables.upload(shT_out);
+                I.shT_in = I.tables.upload(shT_in);
+                I.nin_pad = nin_pad;
             } else {
                 std::fprintf(stderr, "sasktran2_amd: spherical-harmonic scattering transform off by %.3e, using the direct product\n", worst);
             }
@@ -1487,37 +1529,65 @@ template <int S>
 static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b, hipStream_t st, unsigned wb, bool adj_final) {
     SoTimer t(I, st, "so_adjoint");
     SoAdj A = I.adj;
-    const size_t W = b.nwp, n_state = size_t(g.n_out_total) * S * W, n_rays = size_t(g.inc.nrays) * S * W, n_slots = size_t(g.n_inc_layers + g.inc.nrays) * W;
+    const size_t W = b.nwp, Wc = A.wcap, n_state = size_t(g.n_out_total) * S * W, n_rays = size_t(g.inc.nrays) * S * W, n_tab = size_t(g.ntable) * W;
+    const size_t mu_stride = size_t(g.inc.nrays) * S * Wc, y_stride = size_t(g.n_inc_layers + g.inc.nrays) * S * Wc, nground = size_t(g.npoints - g.ninterior);
+    const size_t gis_stride = std::max<size_t>(nground, 1) * Wc;
     const int n = I.fp.enabled && !adj_final ? I.fp_last_iterations : I.num_iterations;   // passes to transpose / terms of the series
-    const size_t lds_chain = size_t(2) * g.ngrid * kWave * sizeof(double), lds_fold = size_t(g.ngrid) * kWave * sizeof(double);
+    const int npass = adj_final ? 1 : std::max(n - 1, 0);
+    if (n > kMaxPasses) throw std::runtime_error("sasktran2_amd: successive-orders weighting functions support at most 64 passes");
+    const size_t lds_chain = size_t(2) * g.ngrid * kWave * sizeof(double);
     if (lds_chain > 160 * 1024) throw std::runtime_error("sasktran2_amd: successive-orders weighting functions hold 2 x ngrid x 64 doubles in LDS (ngrid <= 160)");
-    if (lds_chain > 64 * 1024) {
+    if (lds_chain > 64 * 1024)
         SO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_so_adj_chain<S>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_chain)));
-        SO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_so_adj_fold), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_fold)));
-    }
-    int rays_per_block = 16;
-    if (const char* e = std::getenv("SASKTRAN2_AMD_SO_ADJ_RPB")) rays_per_block = std::max(1, atoi(e));
+    int rays_per_wave = 8;
+    if (const char* e = std::getenv("SASKTRAN2_AMD_SO_ADJ_RPW")) rays_per_wave = std::max(1, atoi(e));
+    const int rays_per_block = rays_per_wave * kChainWaves;
     const unsigned nchunks = unsigned((g.inc.nrays + rays_per_block - 1) / rays_per_block);
+    const bool sh = S == 1 && g.nlm > 0;   // scalar interior points through spherical-harmonic space, as the forward passes
+    const int dbg = [] { const char* e = std::getenv("SASKTRAN2_AMD_SO_ADJ_DEBUG"); return e ? atoi(e) : 0; }();
+    // previous state of pass k (k = 1 .. n), slice of its mu, its Y table and its ground-flux row
+    auto xprev_of = [&](int k) -> const double* { return adj_final ? b.outgoing : (k > 1 ? I.xhist[k - 2] : nullptr); };
+    auto mu_of = [&](int k) { return I.adj_mu + size_t(adj_final ? 1 : (k >= 2 ? k - 2 : npass)) * mu_stride; };
+    auto gis_of = [&](int k) { return I.adj_gis + size_t(adj_final ? 0 : k - 1) * gis_stride; };
+    // seed-independent tables, once per solve: Y_k = W x_{k-1} per factor slot, the ground points' incoming flux of every pass
+    SO_HIP_CHECK(hipMemsetAsync(I.adj_y, 0, std::max<size_t>(npass, 1) * y_stride * sizeof(double), st));
+    SO_HIP_CHECK(hipMemsetAsync(I.adj_gis, 0, size_t(adj_final ? 1 : n) * gis_stride * sizeof(double), st));
+    for (int k = adj_final ? 1 : n; k >= 1; --k) {
+        A.xprev = xprev_of(k);
+        A.y = A.xprev ? I.adj_y + size_t(adj_final ? 0 : k - 2) * y_stride : nullptr;
+        A.gis = gis_of(k);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_y<S>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b, A, I.ray_ground, I.ray_gfactor);
+    }
+    A.y = nullptr;
+    A.npass = npass;
+    A.y_hist = I.adj_y;
+    A.mu_hist = adj_final ? A.gfirst : I.adj_mu;   // about the final state every term meets the same Y: the summed mu is all the chain needs
     for (int ray = 0; ray < g.nlos; ++ray)
         for (int comp = 0; comp < S; ++comp) {
             A.ray = ray;
             A.comp = comp;
-            A.xprev = nullptr;
             SO_HIP_CHECK(hipMemsetAsync(A.lam, 0, n_state * sizeof(double), st));
             SO_HIP_CHECK(hipMemsetAsync(A.gfirst, 0, n_rays * sizeof(double), st));
-            SO_HIP_CHECK(hipMemsetAsync(A.gfac, 0, n_slots * sizeof(double), st));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_seed<S>), dim3(wb), dim3(kWave), 0, st, g, b, A);
             for (int k = n; k >= 1; --k) {
-                A.xprev = adj_final ? b.outgoing : (k > 1 ? I.xhist[k - 2] : nullptr);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_scatter<S>), dim3(unsigned(I.max_cols), wb, unsigned(g.npoints)), dim3(kWave), 0, st, g, b, A);
+                A.xprev = xprev_of(k);
+                A.mu = mu_of(k);
+                A.gis = gis_of(k);
+                if (sh) {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_sh<1>), dim3(unsigned(g.nlm / 16), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, b, A, I.shT_out, g.sh_l, I.nin_pad);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_sh<2>), dim3(unsigned(I.nin_pad / 16), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, b, A, I.shT_in, g.sh_l, I.nin_pad);
+                    if (g.npoints > g.ninterior)
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_scatter<S>), dim3(unsigned(I.max_cols), wb, unsigned(g.npoints - g.ninterior)), dim3(kWave), 0, st, g, b, A, g.ninterior);
+                } else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_scatter<S>), dim3(unsigned(I.max_cols), wb, unsigned(g.npoints)), dim3(kWave), 0, st, g, b, A, 0);
                 if (!A.xprev) break;   // the first pass started from x = 0: nothing behind it
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_gfac<S>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b, A);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_accT<S>), dim3(unsigned(g.n_out_total), wb), dim3(kWave), 0, st, g, b, A, I.accT_start, I.accT_ray,
                                    I.accT_slot, I.accT_w);
                 std::swap(A.lam, A.lam_new);
             }
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S>), dim3(wb, nchunks), dim3(kWave), lds_chain, st, g, b, A, g.inc_rec, rays_per_block);
-            hipLaunchKernelGGL(k_so_adj_fold, dim3(wb), dim3(kWave), lds_fold, st, g, b, A);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S>), dim3(wb, nchunks), dim3(kWave * kChainWaves), lds_chain, st, g, b, A, g.inc_rec, rays_per_wave, dbg);
+            hipLaunchKernelGGL(k_so_adj_fold, dim3(unsigned(g.ngrid), wb), dim3(kWave), 0, st, g, b, A, I.tabT_start, I.tabT_row, I.tabT_w);
+            SO_HIP_CHECK(hipMemsetAsync(A.gtod, 0, n_tab * sizeof(double), st));
         }
     SO_HIP_CHECK(hipGetLastError());
 }
@@ -1544,7 +1614,10 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     if (g.emission && !I.d_emission) throw std::runtime_error("sasktran2_amd: the engine has an emission source but no emission_source array was set (set_emission)");
     // block of wavelengths in flight: half of the free HBM (plus what this engine already holds), balanced blocks, multiple of the wavefront
     const size_t deriv_doubles = derivs ? size_t(g.nlos) * S * so_deriv_slots(g.ngrid, ngroups) + size_t(ngroups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1) : 0;
-    const size_t adj_doubles = adjoint ? (2 + n_hist) * I.n_out * S + 2 * I.n_inc_rays * S + (I.n_inc_layers + I.n_inc_rays) + 1 + I.n_table : 0;
+    const size_t n_pass = adjoint ? (adj_final ? 1 : n_hist) : 0;   // passes with a predecessor: one Y table (and one mu slice) each
+    const size_t n_terms = adjoint ? size_t(std::max(I.num_iterations, 1)) : 0;
+    const size_t adj_doubles = adjoint ? (2 + n_hist) * I.n_out * S + (n_pass + 2) * I.n_inc_rays * S + n_pass * (I.n_inc_layers + I.n_inc_rays) * S + 1 + I.n_table +
+                                             n_terms * (g.npoints - g.ninterior) : 0;
     const size_t per_w = (so_doubles_per_wavelength(I, nleg) + deriv_doubles + adj_doubles) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
@@ -1556,11 +1629,13 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     int chunk = int((size_t(nwavel) + nblocks - 1) / nblocks);
     chunk = (chunk + kPad - 1) / kPad * kPad;
     I.last_chunk = chunk;
-    if (chunk > I.capacity || nleg > I.cap_nleg || (derivs && !I.cap_derivs) || ngroups > I.cap_groups || (adjoint && !I.cap_adjoint) || n_hist > I.xhist.size()) {
+    if (chunk > I.capacity || nleg > I.cap_nleg || (derivs && !I.cap_derivs) || ngroups > I.cap_groups || (adjoint && !I.cap_adjoint) || n_hist > I.xhist.size() || n_pass > I.adj_passes || n_terms > I.adj_terms) {
         I.scratch.release();
         I.cap_derivs = I.cap_derivs || derivs;
         I.cap_adjoint = I.cap_adjoint || adjoint;
         const size_t keep_hist = std::max(n_hist, I.xhist.size());
+        I.adj_passes = std::max(n_pass, I.adj_passes);
+        I.adj_terms = std::max(n_terms, I.adj_terms);
         I.cap_groups = std::max(I.cap_groups, ngroups);
         I.capacity = std::max(chunk, I.capacity);
         I.cap_nleg = std::max(nleg, I.cap_nleg);
@@ -1597,9 +1672,11 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             SoAdj& A = I.adj;
             A.lam = I.scratch.alloc<double>(I.n_out * S * W);
             A.lam_new = I.scratch.alloc<double>(I.n_out * S * W);
-            A.mu = I.scratch.alloc<double>(I.n_inc_rays * S * W);
+            I.adj_mu = I.scratch.alloc<double>((I.adj_passes + 1) * I.n_inc_rays * S * W);
+            I.adj_y = I.scratch.alloc<double>(std::max<size_t>(I.adj_passes, 1) * (I.n_inc_layers + I.n_inc_rays) * S * W);
+            I.adj_gis = I.scratch.alloc<double>(std::max<size_t>(I.adj_terms, 1) * std::max(g.npoints - g.ninterior, 1) * W);
+            A.wcap = W;
             A.gfirst = I.scratch.alloc<double>(I.n_inc_rays * S * W);
-            A.gfac = I.scratch.alloc<double>((I.n_inc_layers + I.n_inc_rays) * W);
             A.galb = I.scratch.alloc<double>(W);
             A.gtod = I.scratch.alloc<double>(I.n_table * W);
             SO_HIP_CHECK(hipMemset(A.galb, 0, W * sizeof(double)));            // (k_so_adj_fold leaves both cleared)
