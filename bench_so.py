@@ -163,7 +163,8 @@ def run_c5(args, world, rank, dev):
     }
     if world == 1 and not args.no_cpu_baseline:
         from tests.test_so_oracle import make_so_oracle
-        cores = len(os.sched_getaffinity(0))
+        from bench import host_cpus
+        cores = host_cpus()[0]   # the share the container grants (cgroup cpu.max), not the affinity mask
         eng = make_so_oracle(s)
         probe = max(cores, 8)
         idx = np.linspace(0, NW - 1, probe).astype(int)
