@@ -75,7 +75,9 @@ template <int N, int LG, bool PRE> __device__ __forceinline__ void k1_wave_body(
     const int w = blockIdx.x;
     if (m >= b.norders[w]) return;
     const int lane = threadIdx.x, grp = lane / LG, gl = lane % LG, nw = b.nw, nlyr = g.nlyr;
-    __shared__ double sMat[NG][8][NN];
+    // (PRE: no Cholesky factor -- seven work matrices, 25 instead of 27 KB of LDS per wavefront: a sixth wavefront per CU)
+    constexpr int NMAT = PRE ? 7 : 8;
+    __shared__ double sMat[NG][NMAT][NN];
     __shared__ double sVec[NG][18][NSTR];
     __shared__ double sLp[N * NSTR], sLc[NSTR], sMu[N], sWt[N], sSq[N], sTt[N], sIm[N], sIt[N];
     __shared__ int sErr;
@@ -92,12 +94,12 @@ template <int N, int LG, bool PRE> __device__ __forceinline__ void k1_wave_body(
     if (lane == 0) sErr = 0;
     double* Bp = sMat[grp][0];
     double* Bm = sMat[grp][1];
-    double* Rc = sMat[grp][2];
-    double* M3 = sMat[grp][3];
-    double* M4 = sMat[grp][4];
-    double* M5 = sMat[grp][5];
-    double* M6 = sMat[grp][6];
-    double* M7 = sMat[grp][7];
+    double* M3 = sMat[grp][2];
+    double* M4 = sMat[grp][3];
+    double* M5 = sMat[grp][4];
+    double* M6 = sMat[grp][5];
+    double* M7 = sMat[grp][6];
+    double* Rc = sMat[grp][NMAT - 1];   // Cholesky factor (PRE: never touched, aliases M7)
     double* va = sVec[grp][0];    // Legendre coefficients a_l
     double* vlam = sVec[grp][1];
     double* vk = sVec[grp][2];
