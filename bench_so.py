@@ -64,7 +64,14 @@ def run_c5(args, world, rank, dev):
 
     def step():
         solver.solve(ext, ssa, leg, alb, out)
-        return gather_wavelength_axis(out["radiance"], NW, 0) if world > 1 else out["radiance"]
+        if world == 1:
+            return out["radiance"]
+        if not wf:
+            return gather_wavelength_axis(out["radiance"], NW, 0)
+        # one wavelength-major slab per rank -- [radiance | wf_extinction | wf_ssa | wf_albedo] per wavelength -- and ONE all-gather
+        slab = torch.cat([out["radiance"].reshape(nloc, -1), out["wf_extinction"].movedim(0, 1).reshape(nloc, -1),
+                          out["wf_ssa"].movedim(0, 1).reshape(nloc, -1), out["wf_albedo"].reshape(nloc, -1)], dim=1)
+        return gather_wavelength_axis(slab, NW, 0)
 
     def sync():
         if world > 1:
