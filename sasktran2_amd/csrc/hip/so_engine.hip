@@ -1537,8 +1537,12 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
     if (n > kMaxPasses) throw std::runtime_error("sasktran2_amd: successive-orders weighting functions support at most 64 passes");
     const size_t lds_chain = size_t(2) * g.ngrid * kWave * sizeof(double);
     if (lds_chain > 160 * 1024) throw std::runtime_error("sasktran2_amd: successive-orders weighting functions hold 2 x ngrid x 64 doubles in LDS (ngrid <= 160)");
-    if (lds_chain > 64 * 1024)
-        SO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_so_adj_chain<S>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_chain)));
+    auto chain_attr = [&](auto kernel) {
+        if (lds_chain > 64 * 1024) SO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_chain)));
+    };
+    chain_attr(&k_so_adj_chain<S, 0>);
+    chain_attr(&k_so_adj_chain<S, 1>);
+    chain_attr(&k_so_adj_chain<S, 9>);
     int rays_per_wave = 8;
     if (const char* e = std::getenv("SASKTRAN2_AMD_SO_ADJ_RPW")) rays_per_wave = std::max(1, atoi(e));
     const int rays_per_block = rays_per_wave * kChainWaves;
@@ -1558,6 +1562,13 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
         A.gis = gis_of(k);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_y<S>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b, A, I.ray_ground, I.ray_gfactor);
     }
+    // the chain with mu_k of a ray in registers for the usual pass counts (one about the final state, nine for ten orders of scattering)
+    auto launch_chain = [&](const SoAdj& A_) {
+        const dim3 grid(wb, nchunks), block(kWave * kChainWaves);
+        if (npass == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 1>), grid, block, lds_chain, st, g, b, A_, g.inc_rec, rays_per_wave, dbg);
+        else if (npass == 9 && S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 9>), grid, block, lds_chain, st, g, b, A_, g.inc_rec, rays_per_wave, dbg);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 0>), grid, block, lds_chain, st, g, b, A_, g.inc_rec, rays_per_wave, dbg);
+    };
     A.y = nullptr;
     A.npass = npass;
     A.y_hist = I.adj_y;
@@ -1585,7 +1596,7 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
                                    I.accT_slot, I.accT_w);
                 std::swap(A.lam, A.lam_new);
             }
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S>), dim3(wb, nchunks), dim3(kWave * kChainWaves), lds_chain, st, g, b, A, g.inc_rec, rays_per_wave, dbg);
+            launch_chain(A);
             hipLaunchKernelGGL(k_so_adj_fold, dim3(unsigned(g.ngrid), wb), dim3(kWave), 0, st, g, b, A, I.tabT_start, I.tabT_row, I.tabT_w);
             SO_HIP_CHECK(hipMemsetAsync(A.gtod, 0, n_tab * sizeof(double), st));
         }
