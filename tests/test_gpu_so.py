@@ -337,3 +337,14 @@ def test_new_source_weighting_functions_fixed_iterations_and_anderson():
     got = run_product_so(s, derivatives=True, **o)
     assert_so_parity(got, ref)
     assert_so_wf_parity(got, ref, tol=1e-6)
+
+
+def test_successive_orders_weighting_functions_on_the_c5_limb_geometry():
+    """BASELINE configs[4]'s discretisation (110 / 110 directions, 50 layers, 25 limb lines of sight, ten passes) at 130 wavelengths: the device
+    rows against the oracle's adjoint, relative to the largest value of each profile."""
+    from tests.test_so_oracle import make_so_oracle
+    s = sc.limb_c5(num_wavelengths=130)
+    ref = make_so_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, nthreads=16)
+    got = run_product_so(s, derivatives=True)
+    assert_so_parity(got, ref)
+    assert_so_wf_parity(got, ref, tol=1e-8)
