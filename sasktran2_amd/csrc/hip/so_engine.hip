@@ -1120,7 +1120,7 @@ struct SoDeviceEngine::Impl {
     int fp_last_iterations = 0;
     // weighting functions of the diffuse field (so_adjoint.inc): the transposed accumulation matrix, the per-seed scratch and the
     // outgoing states x_1 .. x_{n-1} of the forward passes
-    const int *accT_start = nullptr, *accT_ray = nullptr, *accT_slot = nullptr;
+    const int *accT_start = nullptr, *accT_ray = nullptr, *accT_slot = nullptr, *slot_ray = nullptr;
     const double* accT_w = nullptr;
     const int *tabT_start = nullptr, *tabT_row = nullptr;   // the solar table by grid point
     const double* tabT_w = nullptr;
@@ -1326,6 +1326,10 @@ SoDeviceEngine::SoDeviceEngine(const skso::SoGeometry& sg, int num_iterations) :
                 I.accT_ray = I.tables.upload(tray);
                 I.accT_slot = I.tables.upload(tslot);
                 I.accT_w = I.tables.upload(tw);
+                std::vector<int> sr(nl + in.nrays);   // ray of a factor slot (layer slots, then the rays' ground slots)
+                for (int l = 0; l < nl; ++l) sr[l] = layer_ray[l];
+                for (int r = 0; r < in.nrays; ++r) sr[nl + r] = r;
+                I.slot_ray = I.tables.upload(sr);
                 const skso::Csr& T = sg.table.od;
                 std::vector<int> qstart(sg.ngrid + 1, 0), qrow(T.idx.size());
                 std::vector<double> qw(T.idx.size());
@@ -1592,8 +1596,8 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
                 } else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_scatter<S>), dim3(unsigned(I.max_cols), wb, unsigned(g.npoints)), dim3(kWave), 0, st, g, b, A, 0);
                 if (!A.xprev) break;   // the first pass started from x = 0: nothing behind it
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_accT<S>), dim3(unsigned(g.n_out_total), wb), dim3(kWave), 0, st, g, b, A, I.accT_start, I.accT_ray,
-                                   I.accT_slot, I.accT_w);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_nu<S>), dim3(2048, wb), dim3(256), 0, st, g, b, A, I.slot_ray);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_accT<S>), dim3(unsigned(g.n_out_total), wb), dim3(kWave), 0, st, g, b, A, I.accT_start, I.accT_slot, I.accT_w);
                 std::swap(A.lam, A.lam_new);
             }
             launch_chain(A);
@@ -1627,7 +1631,7 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     const size_t deriv_doubles = derivs ? size_t(g.nlos) * S * so_deriv_slots(g.ngrid, ngroups) + size_t(ngroups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1) : 0;
     const size_t n_pass = adjoint ? (adj_final ? 1 : n_hist) : 0;   // passes with a predecessor: one Y table (and one mu slice) each
     const size_t n_terms = adjoint ? size_t(std::max(I.num_iterations, 1)) : 0;
-    const size_t adj_doubles = adjoint ? (2 + n_hist) * I.n_out * S + (n_pass + 2) * I.n_inc_rays * S + n_pass * (I.n_inc_layers + I.n_inc_rays) * S + 1 + I.n_table +
+    const size_t adj_doubles = adjoint ? (2 + n_hist) * I.n_out * S + (n_pass + 2) * I.n_inc_rays * S + (n_pass + 1) * (I.n_inc_layers + I.n_inc_rays) * S + 1 + I.n_table +
                                              n_terms * (g.npoints - g.ninterior) : 0;
     const size_t per_w = (so_doubles_per_wavelength(I, nleg) + deriv_doubles + adj_doubles) * sizeof(double);
     size_t free_b = 0, total_b = 0;
@@ -1688,6 +1692,7 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             I.adj_gis = I.scratch.alloc<double>(std::max<size_t>(I.adj_terms, 1) * std::max(g.npoints - g.ninterior, 1) * W);
             A.wcap = W;
             A.gfirst = I.scratch.alloc<double>(I.n_inc_rays * S * W);
+            A.nu = I.scratch.alloc<double>((I.n_inc_layers + I.n_inc_rays) * S * W);
             A.galb = I.scratch.alloc<double>(W);
             A.gtod = I.scratch.alloc<double>(I.n_table * W);
             SO_HIP_CHECK(hipMemset(A.galb, 0, W * sizeof(double)));            // (k_so_adj_fold leaves both cleared)
