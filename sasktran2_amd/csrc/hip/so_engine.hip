@@ -1552,7 +1552,6 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
     const int rays_per_block = rays_per_wave * kChainWaves;
     const unsigned nchunks = unsigned((g.inc.nrays + rays_per_block - 1) / rays_per_block);
     const bool sh = S == 1 && g.nlm > 0;   // scalar interior points through spherical-harmonic space, as the forward passes
-    const int dbg = [] { const char* e = std::getenv("SASKTRAN2_AMD_SO_ADJ_DEBUG"); return e ? atoi(e) : 0; }();
     // previous state of pass k (k = 1 .. n), slice of its mu, its Y table and its ground-flux row
     auto xprev_of = [&](int k) -> const double* { return adj_final ? b.outgoing : (k > 1 ? I.xhist[k - 2] : nullptr); };
     auto mu_of = [&](int k) { return I.adj_mu + size_t(adj_final ? 1 : (k >= 2 ? k - 2 : npass)) * mu_stride; };
@@ -1569,9 +1568,9 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
     // the chain with mu_k of a ray in registers for the usual pass counts (one about the final state, nine for ten orders of scattering)
     auto launch_chain = [&](const SoAdj& A_) {
         const dim3 grid(wb, nchunks), block(kWave * kChainWaves);
-        if (npass == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 1>), grid, block, lds_chain, st, g, b, A_, g.inc_rec, rays_per_wave, dbg);
-        else if (npass == 9 && S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 9>), grid, block, lds_chain, st, g, b, A_, g.inc_rec, rays_per_wave, dbg);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 0>), grid, block, lds_chain, st, g, b, A_, g.inc_rec, rays_per_wave, dbg);
+        if (npass == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 1>), grid, block, lds_chain, st, g, b, A_, g.inc_rec, rays_per_wave);
+        else if (npass == 9 && S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 9>), grid, block, lds_chain, st, g, b, A_, g.inc_rec, rays_per_wave);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 0>), grid, block, lds_chain, st, g, b, A_, g.inc_rec, rays_per_wave);
     };
     A.y = nullptr;
     A.npass = npass;
