@@ -109,10 +109,10 @@ __global__ void __launch_bounds__(kBlock) kern_stop(Geo g, Bufs b, int s, int m,
     skd::k_stop_rule(g, b, s, m, w);
     if (b.norders[w] > m + 1) atomicAdd(active, 1);
 }
-__global__ void __launch_bounds__(kBlock) kern_k4a(Geo g, Bufs b, int s) {
+__global__ void __launch_bounds__(kBlock) kern_k4a(Geo g, Bufs b, int s, int clear) {
     size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (tid >= size_t(b.nw) * g.nlos) return;
-    skd::k4a_chain(g, b, s, int(tid % g.nlos), int(tid / g.nlos));
+    skd::k4a_chain(g, b, s, int(tid % g.nlos), int(tid / g.nlos), clear != 0);
 }
 __global__ void __launch_bounds__(kBlock) kern_k4b(Geo g, Bufs b) {
     size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -158,23 +158,25 @@ __global__ void __launch_bounds__(256) kern_init(Bufs b, const int* slot_is_grou
 }
 // radiance[w][los] and native weighting functions in the reference's user layout [altitude][w][los]
 // (rust/sasktran2-rs/src/bindings/output.rs:420-425); w0 = first wavelength of this chunk, nw_total = full spectrum.
+// grid.y = altitude planes (one (altitude, wavelength, line of sight) element of each weighting function per thread);
+// plane 0 also moves the radiance, optical depth, albedo row and status
 __global__ void __launch_bounds__(kBlock) kern_output(Geo g, Bufs b, int w0, int nw_total, double* radiance, double* wf_ext,
                                                       double* wf_ssa, double* wf_alb, double* los_od, int* status) {
     size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t nt = size_t(b.nw) * g.nlos;
     if (tid >= nt) return;
-    const int w = int(tid / g.nlos), l = int(tid % g.nlos);
+    const int w = int(tid / g.nlos), l = int(tid % g.nlos), q = blockIdx.y;
     const size_t o = size_t(w0 + w) * g.nlos + l;
-    radiance[o] = b.radiance[tid];
-    if (los_od) los_od[o] = b.los_od[tid];
-    if (status && l == 0) status[w0 + w] = b.status[w];
+    if (q == 0) {
+        radiance[o] = b.radiance[tid];
+        if (los_od) los_od[o] = b.los_od[tid];
+        if (status && l == 0) status[w0 + w] = b.status[w];
+        if (b.derivs && wf_alb) wf_alb[o] = b.dnat[size_t(2 * g.ngrid) * nt + tid];
+    }
     if (!b.derivs) return;
     const size_t plane = size_t(nw_total) * g.nlos;
-    for (int q = 0; q < g.ngrid; ++q) {
-        if (wf_ext) wf_ext[size_t(q) * plane + o] = b.dnat[size_t(q) * nt + tid];
-        if (wf_ssa) wf_ssa[size_t(q) * plane + o] = b.dnat[size_t(g.ngrid + q) * nt + tid];
-    }
-    if (wf_alb) wf_alb[o] = b.dnat[size_t(2 * g.ngrid) * nt + tid];
+    if (wf_ext) __builtin_nontemporal_store(b.dnat[size_t(q) * nt + tid], &wf_ext[size_t(q) * plane + o]);
+    if (wf_ssa) __builtin_nontemporal_store(b.dnat[size_t(g.ngrid + q) * nt + tid], &wf_ssa[size_t(q) * plane + o]);
 }
 
 // the same results as one wavelength-major slab row per wavelength (DeviceEngine::set_slab_output): fields radiance, los_od and, with
@@ -183,18 +185,18 @@ __global__ void __launch_bounds__(kBlock) kern_output_slab(Geo g, Bufs b, int w0
     size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t nt = size_t(b.nw) * g.nlos;
     if (tid >= nt) return;
-    const int w = int(tid / g.nlos), l = int(tid % g.nlos);
+    const int w = int(tid / g.nlos), l = int(tid % g.nlos), q = blockIdx.y;   // grid.y = altitude planes, as kern_output
     const int nf = b.derivs ? 2 * g.ngrid + 3 : 2;
     double* row = slab + size_t(w0 + w) * nf * g.nlos + l;
-    row[0] = b.radiance[tid];
-    row[g.nlos] = b.los_od[tid];
-    if (status && l == 0) status[w0 + w] = b.status[w];
-    if (!b.derivs) return;
-    for (int q = 0; q < g.ngrid; ++q) {
-        row[size_t(2 + q) * g.nlos] = b.dnat[size_t(q) * nt + tid];
-        row[size_t(2 + g.ngrid + q) * g.nlos] = b.dnat[size_t(g.ngrid + q) * nt + tid];
+    if (q == 0) {
+        row[0] = b.radiance[tid];
+        row[g.nlos] = b.los_od[tid];
+        if (status && l == 0) status[w0 + w] = b.status[w];
+        if (b.derivs) row[size_t(2 + 2 * g.ngrid) * g.nlos] = b.dnat[size_t(2 * g.ngrid) * nt + tid];
     }
-    row[size_t(2 + 2 * g.ngrid) * g.nlos] = b.dnat[size_t(2 * g.ngrid) * nt + tid];
+    if (!b.derivs) return;
+    row[size_t(2 + q) * g.nlos] = b.dnat[size_t(q) * nt + tid];
+    row[size_t(2 + g.ngrid + q) * g.nlos] = b.dnat[size_t(g.ngrid + q) * nt + tid];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -589,7 +591,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
         }
         if (derivs) {
             Timer t(I, st, "k4a_chain");
-            hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, 0);
+            hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, 0, 1);
         }
         if (b.emission) {
             // thermal pass (skd::k0_thermal): the order-0 solve once more with the thermal "beam" in T / sec and the isotropic Legendre row
@@ -786,7 +788,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
         if (pipe && last_m >= 0) HIP_CHECK(hipStreamWaitEvent(st, slot.ev_rest[last_m], 0));  // the whole adjoint stage is in order on sC
         if (derivs) {
             Timer t(I, st, "k4a_chain");
-            hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, s);
+            hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, s, s + 1 < g.nsza ? 1 : 0);
         }
     }
     if (g.nsza == 0) {
@@ -871,9 +873,9 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
         }
         Timer tm(I, cs, "k_output");
         if (I.slab)
-            hipLaunchKernelGGL(kern_output_slab, dim3(blocks(size_t(nw) * t.nlos)), dim3(kBlock), 0, cs, I.g, b, w0, I.slab, d_status);
+            hipLaunchKernelGGL(kern_output_slab, dim3(blocks(size_t(nw) * t.nlos), unsigned(b.derivs ? t.ngrid : 1)), dim3(kBlock), 0, cs, I.g, b, w0, I.slab, d_status);
         else
-            hipLaunchKernelGGL(kern_output, dim3(blocks(size_t(nw) * t.nlos)), dim3(kBlock), 0, cs, I.g, b, w0, nwavel, d_radiance,
+            hipLaunchKernelGGL(kern_output, dim3(blocks(size_t(nw) * t.nlos), unsigned(b.derivs ? t.ngrid : 1)), dim3(kBlock), 0, cs, I.g, b, w0, nwavel, d_radiance,
                                d_wf_ext, d_wf_ssa, d_wf_alb, d_los_od, d_status);
     }
     if (fan_out)
