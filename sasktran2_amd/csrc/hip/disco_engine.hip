@@ -53,6 +53,84 @@ __global__ void __launch_bounds__(kBlock) kern_k0(Geo g, Bufs b) {
     if (w >= b.nw) return;
     skd::k0_layer_optics(g, b, w, false);
 }
+// The layer optics of skd::k0_layer_optics for NSTR streams, 64 wavelengths per wavefront: the Legendre coefficients of a grid level
+// ([wavelength][level][order] in the caller's storage: 128-byte runs 6.5 KB apart) come through an LDS tile -- 16 lanes per wavelength fetch
+// its run, four wavelengths per load instruction -- instead of one 8-byte gather per lane, order and level; a level shared by two layers is
+// fetched once; the mixed coefficients of a layer are formed in registers and stored once (the generic form zeroes, accumulates and
+// normalises them in HBM).  Same statements per wavelength, same results.
+template <int NSTR> __global__ void __launch_bounds__(kBlock) kern_k0_tile(Geo g, Bufs b) {
+    __shared__ double tile[2][kBlock][NSTR + 1];
+    __shared__ int tile_q[2];
+    const int lane = threadIdx.x, w0 = blockIdx.x * kBlock, w = w0 + lane, nw = b.nw, nlyr = g.nlyr, ngrid = g.ngrid;
+    const int ws = min(w, nw - 1);
+    const double* ext = b.ext + size_t(ws) * ngrid;
+    const double* ssa = b.ssa + size_t(ws) * ngrid;
+    if (lane < 2) tile_q[lane] = -1;
+    __syncthreads();
+    auto fetch = [&](int q, int buf) {   // Legendre coefficients of level q of the block's wavelengths -> tile[buf]
+        for (int i = 0; i < NSTR; ++i) {
+            const int idx = i * kBlock + lane, wl = idx / NSTR, l = idx % NSTR;
+            const int wg = min(w0 + wl, nw - 1);
+            tile[buf][wl][l] = (l < b.nleg) ? b.leg[(size_t(wg) * ngrid + q) * b.nleg + l] : 0.0;
+        }
+    };
+    double ceiling_depth = 0, floor_depth = 0;
+    for (int p = 0; p < nlyr; ++p) {
+        // the (at most two) levels of this layer: reuse the tile of a level the previous layer brought in
+        int buf_of[2] = {-1, -1};
+        for (int t = 0; t < 2; ++t) {
+            const int q = g.wq_idx[2 * p + t];
+            if (q < 0) continue;
+            int bsel = (tile_q[0] == q) ? 0 : (tile_q[1] == q) ? 1 : -1;
+            if (bsel < 0) {
+                // a free buffer: not the one the other level of this layer sits in
+                bsel = (buf_of[0] == 0 || (t == 0 && tile_q[0] == g.wq_idx[2 * p + 1])) ? 1 : 0;
+                __syncthreads();
+                fetch(q, bsel);
+                if (lane == 0) tile_q[bsel] = q;
+                __syncthreads();
+            }
+            buf_of[t] = bsel;
+        }
+        double od = 0, s = 0, acc[NSTR];
+#pragma unroll
+        for (int l = 0; l < NSTR; ++l) acc[l] = 0;
+        for (int t = 0; t < 2; ++t) {
+            const int q = g.wq_idx[2 * p + t];
+            if (q < 0) continue;
+            const double wt = g.wq_w[2 * p + t];
+            const double kext = ext[q], kscat = ssa[q] * kext;
+            od += kext * wt;
+            s += kscat * wt;
+            const double fq = b.delta_f ? b.delta_f[size_t(ws) * ngrid + q] : 0.0, fsub = fq / (1 - fq);
+            const double* row = tile[buf_of[t]][lane];
+#pragma unroll
+            for (int l = 0; l < NSTR; ++l) acc[l] += wt * kscat * (row[l] - (2 * l + 1) * fsub);
+        }
+        if (w < nw) {
+            if (s > 0) {
+#pragma unroll
+                for (int l = 0; l < NSTR; ++l) b.a[(size_t(p) * NSTR + l) * nw + w] = acc[l] / s;
+            } else {
+#pragma unroll
+                for (int l = 0; l < NSTR; ++l) b.a[(size_t(p) * NSTR + l) * nw + w] = 0.0;
+            }
+        }
+        s /= od;
+        od *= g.dh[p];
+        floor_depth += od;
+        const double te = od / g.dh[p];
+        const double se = fmax(te * s, te * skd::kSSADither);
+        double m_ssa = se / te;
+        if (1 - m_ssa < skd::kSSADither) m_ssa = 1 - skd::kSSADither;
+        if (w < nw) {
+            b.kbar[size_t(p) * nw + w] = te;
+            b.om[size_t(p) * nw + w] = m_ssa;
+            b.tau[size_t(p) * nw + w] = floor_depth - ceiling_depth;
+        }
+        ceiling_depth = floor_depth;
+    }
+}
 // LOS shells of k0_layer_optics, one thread per (shell, wavelength), wavelength fastest: optical depth, local ssa and the
 // shell transmission exp(-od) (parked in srcw until kern_k0_los turns it into the source weight)
 __global__ void __launch_bounds__(256) kern_k0_shells(Geo g, Bufs b) {
@@ -556,7 +634,9 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
     }
     {
         Timer t(I, st, "k0_layer_optics");
-        hipLaunchKernelGGL(kern_k0, dim3(blocks(nw)), dim3(kBlock), 0, st, g, b);
+        static const bool k0_generic = std::getenv("SASKTRAN2_AMD_K0_GENERIC") != nullptr;
+        if (g.nstr == 16 && !k0_generic) hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k0_tile<16>), dim3(blocks(nw)), dim3(kBlock), 0, st, g, b);
+        else hipLaunchKernelGGL(kern_k0, dim3(blocks(nw)), dim3(kBlock), 0, st, g, b);
         if (g.nq_total > 0) hipLaunchKernelGGL(kern_k0_shells, dim3(4096), dim3(256), 0, st, g, b);
         hipLaunchKernelGGL(kern_k0_los, dim3(unsigned((size_t(g.nlos) * nw + 255) / 256)), dim3(256), 0, st, g, b);
     }
