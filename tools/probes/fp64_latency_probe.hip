@@ -47,6 +47,30 @@ __global__ void k_dpp(double* out, long long* cyc, double a, double b) {
     out[threadIdx.x] = x + y + z + w;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+// the same broadcast as two 32-bit DPP moves (low / high word)
+template <int L> __device__ __forceinline__ double bc32(double v) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = int(bits), hi = int(bits >> 32);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + L, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + L, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi2 << 32) | (unsigned)lo2));
+}
+__global__ void k_dpp32(double* out, long long* cyc, double a, double b) {
+    double x = out[threadIdx.x], y = x + 1, z = x + 2, w = x + 3;
+    long long t0 = clock64();
+    for (int i = 0; i < ITER; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            x = fma(bc32<3>(y), a, x);
+            y = fma(bc32<5>(z), a, y);
+            z = fma(bc32<7>(w), a, z);
+            w = fma(bc32<9>(x), a, w);
+        }
+    }
+    long long t1 = clock64();
+    out[threadIdx.x] = x + y + z + w;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
 __global__ void k_dppdep(double* out, long long* cyc, double a, double b) {
     double x = out[threadIdx.x];
     long long t0 = clock64();
@@ -93,6 +117,7 @@ int main() {
         run("4 independent chains", k_ind<4>, w, 16);
         run("8 independent chains", k_ind<8>, w, 16);
         run("fma with row_newbcast src x4", k_dpp, w, 16);
+        run("fma with 2 x b32 row_newbcast x4", k_dpp32, w, 16);
         run("dependent mov_dpp + add", k_dppdep, w, 16);
         run("dependent rsq + add", k_rsq, w, 16);
     }
