@@ -348,3 +348,46 @@ def test_successive_orders_weighting_functions_on_the_c5_limb_geometry():
     got = run_product_so(s, derivatives=True)
     assert_so_parity(got, ref)
     assert_so_wf_parity(got, ref, tol=1e-8)
+
+
+@pytest.mark.parametrize("source,single", [("successive_orders", "exact"), ("successive_orders_legacy", "solartable"), ("successive_orders_legacy", "none")])
+def test_weighting_functions_on_the_reference_scene_of_the_new_source(source, single):
+    """The reference's own scene for its new source (a nadir ray that ends on the ground and a limb ray, seven levels, albedo 0.35): device rows
+    against the oracle's adjoint -- the ground point's outgoing source behind the nadir ray, the table form of the lines of sight's solar
+    transmission and the diffuse field alone."""
+    from tests.test_so_oracle import make_so_oracle
+    s = sc.successive_orders_reference_scene(nstokes=1, iterations=4, source=source, albedo=0.35)
+    s["config"]["single_scatter"] = single
+    ref = make_so_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, nthreads=4)
+    got = run_product_so(s, derivatives=True)
+    assert_so_parity(got, ref)
+    assert_so_wf_parity(got, ref, tol=1e-8)
+
+
+def test_weighting_functions_with_three_solar_zenith_profiles_and_upward_rays():
+    from tests.test_so_oracle import make_so_oracle
+    s = sc.regression_so(nstokes=1, num_wavelengths=2)
+    s["albedo"] = np.array([0.15, 0.4])
+    s["rays"] = list(s["rays"]) + [(sc.VIEWING_UP_SOLAR, 0.6, 0.3, 9_000.0, 0.55)]
+    o = dict(num_sza=3, num_iterations=3)
+    ref = make_so_oracle(s, **o).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, nthreads=4)
+    got = run_product_so(s, derivatives=True, **o)
+    assert_so_parity(got, ref)
+    assert_so_wf_parity(got, ref, tol=1e-8)
+
+
+def test_weighting_functions_scale_with_the_solar_irradiance_at_two_thousand_wavelengths():
+    """Size-independent property on a block of the C5 spectrum: every row is linear in the solar irradiance, and the albedo row of a
+    black surface vanishes only where no line of sight or diffuse ray reaches the ground (limb rays above it still see it through the
+    diffuse field)."""
+    from tests.gpu_harness import build_so_engine
+    s = sc.limb_c5(num_wavelengths=2048, num_iterations=3)
+    eng = build_so_engine(s)
+    one = run_product_so(s, engine=eng, derivatives=True)
+    irr = np.linspace(0.5, 2.0, 2048)
+    two = run_product_so(s, engine=eng, derivatives=True, solar_irradiance=irr)
+    for key in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
+        scale = irr.reshape((-1,) + (1,) * (one[key].ndim - 1))
+        # (rows change sign along the profile: entries next to a zero crossing are sums with cancellation -- the tolerance is on the profile's scale)
+        np.testing.assert_allclose(two[key], one[key] * scale, rtol=1e-11, atol=1e-11 * np.abs(one[key]).max())
+    assert np.all(np.isfinite(one["d_extinction"])) and np.all(one["d_albedo"] > 0)
