@@ -149,6 +149,9 @@ struct Bufs {
     double* radiance;       // [w*nlos+los]
     double* los_od;         // [w*nlos+los]
     int derivs;
+    // 16 streams: a_l (16), omega and tau of a layer in ONE run per (wavelength, layer), [w][p][18] -- what the per-wavelength kernels of an
+    // azimuth order read of the layer optics (from the [p][l][w] arrays every value is its own 64-byte sector); written by kern_k0_tile
+    double* at;
 };
 
 template <int N> struct Rec {

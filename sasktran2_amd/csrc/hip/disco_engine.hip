@@ -107,13 +107,13 @@ template <int NSTR> __global__ void __launch_bounds__(kBlock) kern_k0_tile(Geo g
 #pragma unroll
             for (int l = 0; l < NSTR; ++l) acc[l] += wt * kscat * (row[l] - (2 * l + 1) * fsub);
         }
+        double* at = b.at + (size_t(ws) * nlyr + p) * (NSTR + 2);   // the same values in one run per (wavelength, layer)
         if (w < nw) {
-            if (s > 0) {
 #pragma unroll
-                for (int l = 0; l < NSTR; ++l) b.a[(size_t(p) * NSTR + l) * nw + w] = acc[l] / s;
-            } else {
-#pragma unroll
-                for (int l = 0; l < NSTR; ++l) b.a[(size_t(p) * NSTR + l) * nw + w] = 0.0;
+            for (int l = 0; l < NSTR; ++l) {
+                const double v = (s > 0) ? acc[l] / s : 0.0;
+                b.a[(size_t(p) * NSTR + l) * nw + w] = v;
+                at[l] = v;
             }
         }
         s /= od;
@@ -127,6 +127,8 @@ template <int NSTR> __global__ void __launch_bounds__(kBlock) kern_k0_tile(Geo g
             b.kbar[size_t(p) * nw + w] = te;
             b.om[size_t(p) * nw + w] = m_ssa;
             b.tau[size_t(p) * nw + w] = floor_depth - ceiling_depth;
+            at[NSTR] = m_ssa;
+            at[NSTR + 1] = floor_depth - ceiling_depth;
         }
         ceiling_depth = floor_depth;
     }
@@ -463,7 +465,7 @@ size_t DeviceEngine::bytes_per_wavelength() const {
     size_t d = 0;
     d += nlyr * (3 + nstr) + (nlyr + 1) + nlyr;              // tau, om, kbar, a, T, sec
     d += size_t(t.nq_total) * 3 + nlos;                      // od, omloc, srcw, att_total
-    if (N == 8) d += t.lp_q.size() + t.lp_q.size() / 64 + 1 + nlyr * (N + N * N); // cwbuf, qlmask, eig
+    if (N == 8) d += t.lp_q.size() + t.lp_q.size() / 64 + 1 + nlyr * (N + N * N) + nlyr * 18; // cwbuf, qlmask, eig, at
     d += Impl::Slot::kDepth * (nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N);  // rec, dinv, xsol (kDepth buffers each)
     d += nstr * size_t(t.nslot);                             // J
     const size_t nlos_pad = (nlos + 15) / 16 * 16;
@@ -502,6 +504,7 @@ void DeviceEngine::ensure_scratch(int nw, int nslots) {
         Bufs& b = sl->b;
         b.tau = M.alloc<double>(nlyr * W); b.om = M.alloc<double>(nlyr * W); b.kbar = M.alloc<double>(nlyr * W);
         b.a = M.alloc<double>(nlyr * nstr * W); b.T = M.alloc<double>((nlyr + 1) * W); b.sec = M.alloc<double>(nlyr * W);
+        b.at = M.alloc<double>(nstr == 16 ? nlyr * 18 * W : 1);
         b.od = M.alloc<double>(size_t(t.nq_total) * W); b.omloc = M.alloc<double>(size_t(t.nq_total) * W);
         b.srcw = M.alloc<double>(size_t(t.nq_total) * W); b.att_total = M.alloc<double>(nlos * W);
         b.cwbuf = M.alloc<double>(t.N == 8 ? t.lp_q.size() * W : 1);
@@ -634,8 +637,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
     }
     {
         Timer t(I, st, "k0_layer_optics");
-        static const bool k0_generic = std::getenv("SASKTRAN2_AMD_K0_GENERIC") != nullptr;
-        if (g.nstr == 16 && !k0_generic) hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k0_tile<16>), dim3(blocks(nw)), dim3(kBlock), 0, st, g, b);
+        if (g.nstr == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k0_tile<16>), dim3(blocks(nw)), dim3(kBlock), 0, st, g, b);
         else hipLaunchKernelGGL(kern_k0, dim3(blocks(nw)), dim3(kBlock), 0, st, g, b);
         if (g.nq_total > 0) hipLaunchKernelGGL(kern_k0_shells, dim3(4096), dim3(256), 0, st, g, b);
         hipLaunchKernelGGL(kern_k0_los, dim3(unsigned((size_t(g.nlos) * nw + 255) / 256)), dim3(256), 0, st, g, b);

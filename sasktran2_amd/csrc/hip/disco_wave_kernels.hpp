@@ -181,10 +181,17 @@ template <int N, int LG, bool PRE> __device__ __forceinline__ void k1_wave_body(
     struct PassIn { double om, th, T, sc, a[AU], x[XU], lam; };
     auto fetch = [&](int pbase_, PassIn& in) {
         const int pp = (pbase_ + grp < p_end) ? pbase_ + grp : p_end - 1;
-        in.om = b.om[size_t(pp) * nw + w]; in.th = b.tau[size_t(pp) * nw + w];
-        in.T = b.T[size_t(pp) * nw + w]; in.sc = b.sec[size_t(pp) * nw + w];
+        if constexpr (N == 8) {
+            const double* o = b.at + (size_t(w) * nlyr + pp) * 18;
+            in.om = o[16]; in.th = o[17];
 #pragma unroll
-        for (int u = 0; u < AU; ++u) in.a[u] = (gl + u * LG < NSTR) ? b.a[(size_t(pp) * NSTR + gl + u * LG) * nw + w] : 0.0;
+            for (int u = 0; u < AU; ++u) in.a[u] = (gl + u * LG < NSTR) ? o[gl + u * LG] : 0.0;
+        } else {
+            in.om = b.om[size_t(pp) * nw + w]; in.th = b.tau[size_t(pp) * nw + w];
+#pragma unroll
+            for (int u = 0; u < AU; ++u) in.a[u] = (gl + u * LG < NSTR) ? b.a[(size_t(pp) * NSTR + gl + u * LG) * nw + w] : 0.0;
+        }
+        in.T = b.T[size_t(pp) * nw + w]; in.sc = b.sec[size_t(pp) * nw + w];
         if (PRE) {
             const double* r = skd::rec_at<N>(b, nlyr, pp, w);
 #pragma unroll
@@ -851,8 +858,16 @@ template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs 
         for (int i = gl; i < N; i += LG) { sK[i] = rec[R::K + i]; sAP[i] = rec[R::AP + i]; sAM[i] = rec[R::AM + i]; }
         for (int i = gl; i < 2 * NN; i += LG) sW[i] = rec[R::WP + i];
         for (int i = gl; i < 2 * N; i += LG) sXs[i] = xs[i];
-        for (int l = gl; l < NSTR; l += LG) sa[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
-        const double th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
+        double th;
+        if constexpr (N == 8) {
+            const double* o = b.at + (size_t(w) * nlyr + p) * 18;
+            for (int l = gl; l < NSTR; l += LG) sa[l] = o[l];
+            th = o[17];
+        } else {
+            for (int l = gl; l < NSTR; l += LG) sa[l] = b.a[(size_t(p) * NSTR + l) * nw + w];
+            th = b.tau[size_t(p) * nw + w];
+        }
+        const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
         __syncthreads();
         // exponentials of the layer in one instruction stream: exp(-k_j x) (lanes < N), exp(-sec x), exp(-sec th);  x = th lfrac
         const double lf = g.lfrac[p];
@@ -1444,9 +1459,10 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
         if (lane < M2) sXs[lane] = xs[lane];
         double dinv_b[4];  // B operand of the Dinv chains: Dinv[4 kk + (lane >> 4)][lane & 15] = dg[64 kk + lane]
         for (int kk = 0; kk < 4; ++kk) dinv_b[kk] = dg[64 * kk + lane];
-        const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w];
+        const double* lo = b.at + (size_t(w) * nlyr + p) * 18;
+        const double om = lo[16], th = lo[17], T = b.T[size_t(p) * nw + w];
         const double inv_om = 1.0 / om, inv_T = (T != 0) ? 1.0 / T : 0.0;
-        const double al = (col >= m) ? b.a[(size_t(p) * NSTR + col) * nw + w] : 0.0;
+        const double al = (col >= m) ? lo[col] : 0.0;
         __syncthreads();
         if constexpr (K1LANE) {
             // records of kern_k1_lane: Rec::DG holds coef[(type * 5 + k) * N + j] (type 0: A- C-, 1: A+ C+; k = 0: the coefficient, 1 + theta:
