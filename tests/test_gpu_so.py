@@ -391,3 +391,34 @@ def test_weighting_functions_scale_with_the_solar_irradiance_at_two_thousand_wav
         # (rows change sign along the profile: entries next to a zero crossing are sums with cancellation -- the tolerance is on the profile's scale)
         np.testing.assert_allclose(two[key], one[key] * scale, rtol=1e-11, atol=1e-11 * np.abs(one[key]).max())
     assert np.all(np.isfinite(one["d_extinction"])) and np.all(one["d_albedo"] > 0)
+
+
+def test_jvp_and_vjp_with_the_successive_orders_source():
+    """sk_engine_calculate_jvp / _vjp (contractions of the native derivatives on the device) with the diffuse field of the successive orders
+    in the Jacobian: equal to the contracted weighting functions, and <cotangent, J t> = <J^T cotangent, t>."""
+    import sasktran2_amd as sk
+    from tests.gpu_harness import build_so_engine
+    s = sc.successive_orders_reference_scene(nstokes=1, iterations=3, source="successive_orders", albedo=0.3)
+    engine, config, geometry = build_so_engine(s)
+    nw = s["extinction"].shape[1]
+    atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=True)
+    atmosphere.storage.total_extinction[:] = s["extinction"]
+    atmosphere.storage.ssa[:] = s["ssa"]
+    atmosphere.storage.leg_coeff[:] = s["leg"]
+    atmosphere.surface.albedo[:] = s["albedo"]
+    full = engine.calculate_radiance(atmosphere, as_dataset=False)
+    rng = np.random.default_rng(5)
+    ngrid = s["extinction"].shape[0]
+    t_k, t_w, t_a = rng.standard_normal(ngrid) * 1e-6, rng.standard_normal(ngrid) * 1e-2, rng.standard_normal(nw) * 0.1
+    rad, jvp = engine.calculate_jvp(atmosphere, {"wf_extinction": t_k, "wf_ssa": t_w}, {"wf_albedo": t_a})
+    want = np.einsum("qwls,q->wls", full["wf_extinction"], t_k) + np.einsum("qwls,q->wls", full["wf_ssa"], t_w) + full["wf_albedo"] * t_a[:, None, None]
+    np.testing.assert_array_equal(rad, full["radiance"])
+    np.testing.assert_allclose(jvp, want, rtol=1e-11, atol=1e-300)
+    cot = rng.standard_normal(full["radiance"].shape)
+    rad2, grads = engine.calculate_vjp(atmosphere, cot)
+    np.testing.assert_array_equal(rad2, full["radiance"])
+    np.testing.assert_allclose(grads["wf_extinction"], np.einsum("qwls,wls->q", full["wf_extinction"], cot), rtol=1e-11)
+    np.testing.assert_allclose(grads["wf_albedo"], np.einsum("wls,wls->w", full["wf_albedo"], cot), rtol=1e-11)
+    lhs = float(np.sum(cot * jvp))
+    rhs = float(grads["wf_extinction"] @ t_k + grads["wf_ssa"] @ t_w + grads["wf_albedo"] @ t_a)
+    assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs))
