@@ -1128,6 +1128,10 @@ struct SoDeviceEngine::Impl {
     int nin_pad = 0;
     SoAdj adj{};
     double *adj_mu = nullptr, *adj_y = nullptr, *adj_gis = nullptr;   // mu slices [passes + 1], Y per pass, ground flux per pass
+    // scattering groups through the diffuse field: directions slab major, their phase values on the incoming rays, the coefficient table of
+    // S_{g,i}, its outputs per pass, the seed's per-point sums
+    double *adj_dT = nullptr, *adj_dph = nullptr, *adj_gcl = nullptr, *adj_xg = nullptr, *adj_gpt = nullptr;
+    int adj_groups = 0;
     size_t adj_passes = 0, adj_terms = 0;
     const int* ray_ground = nullptr;       // [incoming rays] ground point of the ray's diffuse point, or -1
     const double* ray_gfactor = nullptr;   // [incoming rays] its factor in the point's downwelling flux
@@ -1542,7 +1546,8 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
     const size_t lds_chain = size_t(2) * g.ngrid * kWave * sizeof(double);
     if (lds_chain > 160 * 1024) throw std::runtime_error("sasktran2_amd: successive-orders weighting functions hold 2 x ngrid x 64 doubles in LDS (ngrid <= 160)");
     auto chain_attr = [&](auto kernel) {
-        if (lds_chain > 64 * 1024) SO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_chain)));
+        if (size_t(2 + b.ngroups) * g.ngrid * kWave * sizeof(double) > 64 * 1024) SO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             int(size_t(2 + b.ngroups) * g.ngrid * kWave * sizeof(double))));
     };
     chain_attr(&k_so_adj_chain<S, 0>);
     chain_attr(&k_so_adj_chain<S, 1>);
@@ -1565,12 +1570,49 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
         A.gis = gis_of(k);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_y<S>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b, A, I.ray_ground, I.ray_gfactor);
     }
+    // scattering groups (scalar engine): directions slab major, their phase values on the incoming rays, and per pass the outputs of the
+    // scattering operator with the groups' coefficients at either level of every interior point (so_adjoint.inc, "scattering groups")
+    const int ngroups = b.ngroups;
+    const size_t xg_pass = size_t(ngroups) * 2 * g.n_out_total * Wc, xg_one = size_t(g.n_out_total) * Wc;
+    auto xg_of = [&](int k) { return I.adj_xg + size_t(adj_final ? 0 : k - 1) * xg_pass; };
+    if (ngroups > 0) {
+        hipLaunchKernelGGL(k_so_adj_dleg_T, dim3(2048), dim3(256), 0, st, g, b, I.adj_dT);
+        hipLaunchKernelGGL(k_so_adj_dph_inc, dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b, I.adj_dT, I.adj_dph);
+        for (int k = adj_final ? 1 : n; k >= 1; --k) {
+            // incoming field of the pass: first + A x_{k-1}
+            const double* xp = xprev_of(k);
+            if (xp) {
+                SoBufs bx = b;
+                bx.outgoing = const_cast<double*>(xp);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_accumulate<S>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, bx);
+            } else
+                SO_HIP_CHECK(hipMemcpyAsync(b.incoming, b.first, n_rays * sizeof(double), hipMemcpyDeviceToDevice, st));
+            for (int gi = 0; gi < ngroups; ++gi)
+                for (int side = 0; side < 2; ++side) {
+                    hipLaunchKernelGGL(k_so_adj_gcl, dim3(unsigned(g.ninterior * g.num_ms_moments), wb), dim3(kWave), 0, st, g, b, I.adj_dT, I.adj_gcl, gi, side);
+                    SoBufs bg = b;
+                    bg.cl = I.adj_gcl;
+                    bg.outgoing = xg_of(k) + size_t(gi * 2 + side) * xg_one;
+                    if (sh) {
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_sh<1>), dim3(unsigned(g.nlm / 16), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, bg, g.sh_in, g.sh_l);
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_sh<2>), dim3(unsigned(g.nout_pad / 16), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, bg, g.sh_out, g.sh_l);
+                    } else
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<1>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, bg, 0);
+                }
+        }
+    }
+    A.ngroups = ngroups;
+    A.dph_inc = ngroups > 0 ? I.adj_dph : nullptr;
+    A.gpt = ngroups > 0 ? I.adj_gpt : nullptr;
+    A.xg = nullptr;
+    const size_t lds_chain_g = size_t(2 + ngroups) * g.ngrid * kWave * sizeof(double);
+    if (lds_chain_g > 160 * 1024) throw std::runtime_error("sasktran2_amd: too many scattering groups for the LDS accumulators of the successive-orders weighting functions");
     // the chain with mu_k of a ray in registers for the usual pass counts (one about the final state, nine for ten orders of scattering)
     auto launch_chain = [&](const SoAdj& A_) {
         const dim3 grid(wb, nchunks), block(kWave * kChainWaves);
-        if (npass == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 1>), grid, block, lds_chain, st, g, b, A_, g.inc_rec, rays_per_wave);
-        else if (npass == 9 && S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 9>), grid, block, lds_chain, st, g, b, A_, g.inc_rec, rays_per_wave);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 0>), grid, block, lds_chain, st, g, b, A_, g.inc_rec, rays_per_wave);
+        if (npass == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 1>), grid, block, lds_chain_g, st, g, b, A_, g.inc_rec, rays_per_wave);
+        else if (npass == 9 && S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 9>), grid, block, lds_chain_g, st, g, b, A_, g.inc_rec, rays_per_wave);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 0>), grid, block, lds_chain_g, st, g, b, A_, g.inc_rec, rays_per_wave);
     };
     A.y = nullptr;
     A.npass = npass;
@@ -1587,6 +1629,10 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
                 A.xprev = xprev_of(k);
                 A.mu = mu_of(k);
                 A.gis = gis_of(k);
+                if (ngroups > 0) {   // lambda_k . S_{g,i}(incoming_k) per interior point
+                    A.xg = xg_of(k);
+                    hipLaunchKernelGGL(k_so_adj_gdot, dim3(unsigned(g.ninterior), wb, unsigned(ngroups * 2)), dim3(kWave), 0, st, g, b, A);
+                }
                 if (sh) {
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_sh<1>), dim3(unsigned(g.nlm / 16), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, b, A, I.shT_out, g.sh_l, I.nin_pad);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_sh<2>), dim3(unsigned(I.nin_pad / 16), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, b, A, I.shT_in, g.sh_l, I.nin_pad);
@@ -1601,6 +1647,7 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
             }
             launch_chain(A);
             hipLaunchKernelGGL(k_so_adj_fold, dim3(unsigned(g.ngrid), wb), dim3(kWave), 0, st, g, b, A, I.tabT_start, I.tabT_row, I.tabT_w);
+            if (ngroups > 0) hipLaunchKernelGGL(k_so_adj_gmap, dim3(wb), dim3(kWave), 0, st, g, b, A);
             SO_HIP_CHECK(hipMemsetAsync(A.gtod, 0, n_tab * sizeof(double), st));
         }
     SO_HIP_CHECK(hipGetLastError());
@@ -1618,7 +1665,7 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     const bool derivs = d_wf_ext != nullptr;
     if (derivs && (!d_wf_ssa || !d_wf_alb)) throw std::runtime_error("sasktran2_amd: weighting functions need all three output buffers");
     const bool adjoint = derivs && I.multiple_scatter;   // weighting functions through the diffuse field (so_adjoint.inc)
-    if (adjoint && ngroups > 0) throw std::runtime_error("sasktran2_amd: scattering-group weighting functions are not available with the successive-orders source");
+    if (adjoint && ngroups > 0 && S != 1) throw std::runtime_error("sasktran2_amd: scattering-group weighting functions with the successive-orders source are available for NSTOKES = 1");
     // the exact transpose of the n passes needs their states; the Anderson-mixed / damped / tolerance-stopped driver is differentiated about
     // its final state instead (adjoint Neumann series, as many terms as the driver's iteration limit)
     const bool fp_is_legacy = I.fp.depth == 0 && I.fp.damping == 1.0 && I.fp.rel == 0 && I.fp.abs == 0;
@@ -1630,8 +1677,10 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     const size_t deriv_doubles = derivs ? size_t(g.nlos) * S * so_deriv_slots(g.ngrid, ngroups) + size_t(ngroups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1) : 0;
     const size_t n_pass = adjoint ? (adj_final ? 1 : n_hist) : 0;   // passes with a predecessor: one Y table (and one mu slice) each
     const size_t n_terms = adjoint ? size_t(std::max(I.num_iterations, 1)) : 0;
-    const size_t adj_doubles = adjoint ? (2 + n_hist) * I.n_out * S + (n_pass + 2) * I.n_inc_rays * S + (n_pass + 1) * (I.n_inc_layers + I.n_inc_rays) * S + 1 + I.n_table +
-                                             n_terms * (g.npoints - g.ninterior) : 0;
+    const size_t adj_group_doubles = (adjoint && ngroups > 0) ? size_t(ngroups) * (size_t(g.ngrid) * nleg + I.n_inc_rays * g.ngrid + size_t(g.ninterior) * 2) +
+                                                                   size_t(g.ninterior) * g.num_ms_moments + n_terms * size_t(ngroups) * 2 * I.n_out : 0;
+    const size_t adj_doubles = adj_group_doubles + (adjoint ? (2 + n_hist) * I.n_out * S + (n_pass + 2) * I.n_inc_rays * S + (n_pass + 1) * (I.n_inc_layers + I.n_inc_rays) * S + 1 + I.n_table +
+                                             n_terms * (g.npoints - g.ninterior) : 0);
     const size_t per_w = (so_doubles_per_wavelength(I, nleg) + deriv_doubles + adj_doubles) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
@@ -1643,13 +1692,14 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     int chunk = int((size_t(nwavel) + nblocks - 1) / nblocks);
     chunk = (chunk + kPad - 1) / kPad * kPad;
     I.last_chunk = chunk;
-    if (chunk > I.capacity || nleg > I.cap_nleg || (derivs && !I.cap_derivs) || ngroups > I.cap_groups || (adjoint && !I.cap_adjoint) || n_hist > I.xhist.size() || n_pass > I.adj_passes || n_terms > I.adj_terms) {
+    if (chunk > I.capacity || nleg > I.cap_nleg || (derivs && !I.cap_derivs) || ngroups > I.cap_groups || (adjoint && !I.cap_adjoint) || n_hist > I.xhist.size() || n_pass > I.adj_passes || n_terms > I.adj_terms || (adjoint && ngroups > I.adj_groups)) {
         I.scratch.release();
         I.cap_derivs = I.cap_derivs || derivs;
         I.cap_adjoint = I.cap_adjoint || adjoint;
         const size_t keep_hist = std::max(n_hist, I.xhist.size());
         I.adj_passes = std::max(n_pass, I.adj_passes);
         I.adj_terms = std::max(n_terms, I.adj_terms);
+        if (adjoint) I.adj_groups = std::max(ngroups, I.adj_groups);
         I.cap_groups = std::max(I.cap_groups, ngroups);
         I.capacity = std::max(chunk, I.capacity);
         I.cap_nleg = std::max(nleg, I.cap_nleg);
@@ -1697,6 +1747,15 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             SO_HIP_CHECK(hipMemset(A.galb, 0, W * sizeof(double)));            // (k_so_adj_fold leaves both cleared)
             SO_HIP_CHECK(hipMemset(A.gtod, 0, I.n_table * W * sizeof(double)));
             for (size_t k = 0; k < keep_hist; ++k) I.xhist.push_back(I.scratch.alloc<double>(I.n_out * S * W));
+            if (I.adj_groups > 0) {
+                const size_t G = I.adj_groups;
+                I.adj_dT = I.scratch.alloc<double>(G * g.ngrid * nlg * W);
+                I.adj_dph = I.scratch.alloc<double>(G * I.n_inc_rays * g.ngrid * W);
+                I.adj_gcl = I.scratch.alloc<double>(size_t(g.ninterior) * g.num_ms_moments * W);
+                I.adj_xg = I.scratch.alloc<double>(std::max<size_t>(I.adj_terms, 1) * G * 2 * I.n_out * W);
+                I.adj_gpt = I.scratch.alloc<double>(G * g.ninterior * 2 * W);
+                SO_HIP_CHECK(hipMemset(I.adj_gpt, 0, G * g.ninterior * 2 * W * sizeof(double)));   // (k_so_adj_gmap leaves it cleared)
+            }
         }
         b.dacc = I.cap_derivs ? I.scratch.alloc<double>(size_t(g.nlos) * S * so_deriv_slots(g.ngrid, I.cap_groups) * W) : nullptr;
         b.dphT = I.cap_groups > 0 ? I.scratch.alloc<double>(size_t(I.cap_groups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1) * W) : nullptr;

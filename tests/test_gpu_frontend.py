@@ -399,8 +399,9 @@ def test_line_of_sight_emission_and_jvp_vjp_with_device_mappings():
         engine.calculate_vjp(atmo, cot, names=("wf_extinction",))
 
 
-@pytest.mark.parametrize("ms,nstokes", [("none", 1), ("none", 3), ("discrete_ordinates", 1), ("twostream", 1)],
-                         ids=["exact single scatter alone", "exact single scatter alone, NSTOKES 3", "+ discrete ordinates", "+ two-stream"])
+@pytest.mark.parametrize("ms,nstokes", [("none", 1), ("none", 3), ("discrete_ordinates", 1), ("twostream", 1), ("successive_orders_legacy", 1), ("successive_orders", 1)],
+                         ids=["exact single scatter alone", "exact single scatter alone, NSTOKES 3", "+ discrete ordinates", "+ two-stream",
+                              "+ successive orders (legacy)", "+ successive orders (Anderson driver)"])
 def test_scatterer_weighting_functions_with_exact_single_scatter(ms, nstokes):
     """single_scatter_source = exact -- the reference's limb configuration -- with scatterer constituents: the single-scatter source
     differentiates along the scattering groups' d_legendre directions (k_so_group_phase / k_so_los_deriv), next to the multiple-scatter
@@ -413,7 +414,18 @@ def test_scatterer_weighting_functions_with_exact_single_scatter(ms, nstokes):
     cfg.num_singlescatter_moments = 16
     cfg.single_scatter_source = sk.SingleScatterSource.Exact
     cfg.multiple_scatter_source = {"none": sk.MultipleScatterSource.NoSource, "discrete_ordinates": sk.MultipleScatterSource.DiscreteOrdinates,
-                                   "twostream": sk.MultipleScatterSource.TwoStream}[ms]
+                                   "twostream": sk.MultipleScatterSource.TwoStream, "successive_orders_legacy": sk.MultipleScatterSource.SuccessiveOrdersLegacy,
+                                   "successive_orders": sk.MultipleScatterSource.SuccessiveOrders}[ms]
+    if ms.startswith("successive_orders"):
+        # the diffuse field's share of the scattering-group rows: first-order phase values on the incoming rays and the points' scattering
+        # matrices (so_adjoint.inc); the Anderson driver converged tightly so that its adjoint about the final state is the derivative
+        cfg.num_streams = 8
+        cfg.num_successive_orders_incoming = cfg.num_successive_orders_outgoing = 26
+        cfg.init_successive_orders_with_discrete_ordinates = False
+        cfg.num_successive_orders_iterations = 3 if ms.endswith("legacy") else 60
+        if ms == "successive_orders":
+            cfg.successive_orders_relative_tolerance = 1e-11
+            cfg.successive_orders_absolute_tolerance = 0.0
     rays = [sk.TangentAltitudeSolar(14000.0, 0.5, 200000.0, 0.6), sk.TangentAltitudeSolar(28000.0, 0.5, 200000.0, 0.6),
             sk.GroundViewingSolar(0.6, 0.5, 0.8, 200000.0)]
     engine, geo = _engine_case(sk, c, cfg, rays)
