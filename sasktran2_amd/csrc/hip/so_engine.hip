@@ -1573,7 +1573,7 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
     // scattering groups (scalar engine): directions slab major, their phase values on the incoming rays, and per pass the outputs of the
     // scattering operator with the groups' coefficients at either level of every interior point (so_adjoint.inc, "scattering groups")
     const int ngroups = b.ngroups;
-    const size_t xg_pass = size_t(ngroups) * 2 * g.n_out_total * Wc, xg_one = size_t(g.n_out_total) * Wc;
+    const size_t xg_pass = size_t(ngroups) * 2 * g.n_out_total * S * Wc, xg_one = size_t(g.n_out_total) * S * Wc;
     auto xg_of = [&](int k) { return I.adj_xg + size_t(adj_final ? 0 : k - 1) * xg_pass; };
     if (ngroups > 0) {
         hipLaunchKernelGGL(k_so_adj_dleg_T, dim3(2048), dim3(256), 0, st, g, b, I.adj_dT);
@@ -1589,7 +1589,7 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
                 SO_HIP_CHECK(hipMemcpyAsync(b.incoming, b.first, n_rays * sizeof(double), hipMemcpyDeviceToDevice, st));
             for (int gi = 0; gi < ngroups; ++gi)
                 for (int side = 0; side < 2; ++side) {
-                    hipLaunchKernelGGL(k_so_adj_gcl, dim3(unsigned(g.ninterior * g.num_ms_moments), wb), dim3(kWave), 0, st, g, b, I.adj_dT, I.adj_gcl, gi, side);
+                    hipLaunchKernelGGL(k_so_adj_gcl, dim3(unsigned(g.ninterior * g.num_ms_moments * (S == 3 ? 4 : 1)), wb), dim3(kWave), 0, st, g, b, I.adj_dT, I.adj_gcl, gi, side);
                     SoBufs bg = b;
                     bg.cl = I.adj_gcl;
                     bg.outgoing = xg_of(k) + size_t(gi * 2 + side) * xg_one;
@@ -1597,7 +1597,7 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_sh<1>), dim3(unsigned(g.nlm / 16), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, bg, g.sh_in, g.sh_l);
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_sh<2>), dim3(unsigned(g.nout_pad / 16), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, bg, g.sh_out, g.sh_l);
                     } else
-                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<1>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, bg, 0);
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_scatter<S>), dim3(unsigned(I.max_rows), wb / 2, unsigned(g.ninterior)), dim3(kWave), 0, st, g, bg, 0);
                 }
         }
     }
@@ -1665,7 +1665,6 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     const bool derivs = d_wf_ext != nullptr;
     if (derivs && (!d_wf_ssa || !d_wf_alb)) throw std::runtime_error("sasktran2_amd: weighting functions need all three output buffers");
     const bool adjoint = derivs && I.multiple_scatter;   // weighting functions through the diffuse field (so_adjoint.inc)
-    if (adjoint && ngroups > 0 && S != 1) throw std::runtime_error("sasktran2_amd: scattering-group weighting functions with the successive-orders source are available for NSTOKES = 1");
     // the exact transpose of the n passes needs their states; the Anderson-mixed / damped / tolerance-stopped driver is differentiated about
     // its final state instead (adjoint Neumann series, as many terms as the driver's iteration limit)
     const bool fp_is_legacy = I.fp.depth == 0 && I.fp.damping == 1.0 && I.fp.rel == 0 && I.fp.abs == 0;
@@ -1677,8 +1676,8 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     const size_t deriv_doubles = derivs ? size_t(g.nlos) * S * so_deriv_slots(g.ngrid, ngroups) + size_t(ngroups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1) : 0;
     const size_t n_pass = adjoint ? (adj_final ? 1 : n_hist) : 0;   // passes with a predecessor: one Y table (and one mu slice) each
     const size_t n_terms = adjoint ? size_t(std::max(I.num_iterations, 1)) : 0;
-    const size_t adj_group_doubles = (adjoint && ngroups > 0) ? size_t(ngroups) * (size_t(g.ngrid) * nleg + I.n_inc_rays * g.ngrid + size_t(g.ninterior) * 2) +
-                                                                   size_t(g.ninterior) * g.num_ms_moments + n_terms * size_t(ngroups) * 2 * I.n_out : 0;
+    const size_t adj_group_doubles = (adjoint && ngroups > 0) ? size_t(ngroups) * (size_t(g.ngrid) * nleg * per + I.n_inc_rays * g.ngrid * (S == 3 ? 2 : 1) + size_t(g.ninterior) * 2) +
+                                                                   size_t(g.ninterior) * g.num_ms_moments * per + n_terms * size_t(ngroups) * 2 * I.n_out * S : 0;
     const size_t adj_doubles = adj_group_doubles + (adjoint ? (2 + n_hist) * I.n_out * S + (n_pass + 2) * I.n_inc_rays * S + (n_pass + 1) * (I.n_inc_layers + I.n_inc_rays) * S + 1 + I.n_table +
                                              n_terms * (g.npoints - g.ninterior) : 0);
     const size_t per_w = (so_doubles_per_wavelength(I, nleg) + deriv_doubles + adj_doubles) * sizeof(double);
@@ -1750,9 +1749,9 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             if (I.adj_groups > 0) {
                 const size_t G = I.adj_groups;
                 I.adj_dT = I.scratch.alloc<double>(G * g.ngrid * nlg * W);
-                I.adj_dph = I.scratch.alloc<double>(G * I.n_inc_rays * g.ngrid * W);
-                I.adj_gcl = I.scratch.alloc<double>(size_t(g.ninterior) * g.num_ms_moments * W);
-                I.adj_xg = I.scratch.alloc<double>(std::max<size_t>(I.adj_terms, 1) * G * 2 * I.n_out * W);
+                I.adj_dph = I.scratch.alloc<double>(G * I.n_inc_rays * g.ngrid * (S == 3 ? 2 : 1) * W);
+                I.adj_gcl = I.scratch.alloc<double>(size_t(g.ninterior) * g.num_ms_moments * per * W);
+                I.adj_xg = I.scratch.alloc<double>(std::max<size_t>(I.adj_terms, 1) * G * 2 * I.n_out * S * W);
                 I.adj_gpt = I.scratch.alloc<double>(G * g.ninterior * 2 * W);
                 SO_HIP_CHECK(hipMemset(I.adj_gpt, 0, G * g.ninterior * 2 * W * sizeof(double)));   // (k_so_adj_gmap leaves it cleared)
             }

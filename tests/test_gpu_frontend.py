@@ -399,9 +399,10 @@ def test_line_of_sight_emission_and_jvp_vjp_with_device_mappings():
         engine.calculate_vjp(atmo, cot, names=("wf_extinction",))
 
 
-@pytest.mark.parametrize("ms,nstokes", [("none", 1), ("none", 3), ("discrete_ordinates", 1), ("twostream", 1), ("successive_orders_legacy", 1), ("successive_orders", 1)],
+@pytest.mark.parametrize("ms,nstokes", [("none", 1), ("none", 3), ("discrete_ordinates", 1), ("twostream", 1), ("successive_orders_legacy", 1), ("successive_orders", 1),
+                                        ("successive_orders_legacy", 3)],
                          ids=["exact single scatter alone", "exact single scatter alone, NSTOKES 3", "+ discrete ordinates", "+ two-stream",
-                              "+ successive orders (legacy)", "+ successive orders (Anderson driver)"])
+                              "+ successive orders (legacy)", "+ successive orders (Anderson driver)", "+ successive orders (legacy), NSTOKES 3"])
 def test_scatterer_weighting_functions_with_exact_single_scatter(ms, nstokes):
     """single_scatter_source = exact -- the reference's limb configuration -- with scatterer constituents: the single-scatter source
     differentiates along the scattering groups' d_legendre directions (k_so_group_phase / k_so_los_deriv), next to the multiple-scatter
