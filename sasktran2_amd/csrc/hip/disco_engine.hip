@@ -216,6 +216,64 @@ __global__ void __launch_bounds__(kBlock) kern_k4a(Geo g, Bufs b, int s, int cle
     if (tid >= size_t(b.nw) * g.nlos) return;
     skd::k4a_chain(g, b, s, int(tid % g.nlos), int(tid / g.nlos), clear != 0);
 }
+// skd::k4a_chain for the LAST solar zenith index of a solve in two steps.  kern_k4a_gt, grid.y = chunks of eight layers r: the derivative
+// of everything downstream with respect to tau_r (the walk over all layers p per chunk -- the per-(wavelength, line of sight) form takes the
+// chunks one after the other) written over the tau rows of the gradient; kern_k4a_apply: tau_r / omega_r -> extinction / ssa of the grid
+// levels in the order of the per-thread form (same sums in the same order: results do not depend on the launch shape).  Nothing is cleared
+// (the next solve's initialisation does that).
+__global__ void __launch_bounds__(kBlock) kern_k4a_gt(Geo g, Bufs b, int s) {
+    const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x, nt = size_t(b.nw) * g.nlos;
+    if (tid >= nt) return;
+    const int w = int(tid / g.nlos), nw = b.nw, nlyr = g.nlyr;
+    auto G = [&](int e) -> double& { return b.grad[size_t(e) * nt + tid]; };
+    constexpr int RC = 8;
+    const int r0 = blockIdx.y * RC;
+    double gt[RC];
+#pragma unroll
+    for (int k = 0; k < RC; ++k) gt[k] = (r0 + k < nlyr) ? G(r0 + k) : 0.0;
+    for (int p = 0; p < nlyr; ++p) {
+        const double* ch = g.chapman + (size_t(s) * nlyr + p) * nlyr;
+        if (ch[0] < 0) continue;
+        const double* chm = (p > 0) ? g.chapman + (size_t(s) * nlyr + p - 1) * nlyr : nullptr;
+        const bool prev_ok = (p > 0) && !(chm[0] < 0);
+        const double inv_tau = 1.0 / b.tau[size_t(p) * nw + w];
+        const double gsec = G(3 * nlyr + p), sec_p = b.sec[size_t(p) * nw + w];
+        const double gT = (p + 1 < nlyr) ? G(2 * nlyr + p + 1) : G(4 * nlyr + 1);
+        const double Tn = b.T[size_t(p + 1) * nw + w];
+#pragma unroll
+        for (int k = 0; k < RC; ++k) {
+            const int r = r0 + k;
+            if (r >= nlyr) break;
+            const double dsig_p = ch[r];
+            double dsec = (dsig_p - (prev_ok ? chm[r] : 0.0)) * inv_tau;
+            if (r == p) dsec -= sec_p * inv_tau;
+            gt[k] += gsec * dsec - gT * Tn * dsig_p;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+        if (r0 + k < nlyr) G(r0 + k) = gt[k];
+}
+__global__ void __launch_bounds__(kBlock) kern_k4a_apply(Geo g, Bufs b) {
+    const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x, nt = size_t(b.nw) * g.nlos;
+    if (tid >= nt) return;
+    const int w = int(tid / g.nlos), nw = b.nw, nlyr = g.nlyr, ngrid = g.ngrid;
+    auto G = [&](int e) { return b.grad[size_t(e) * nt + tid]; };
+    const double* ext = b.ext + size_t(w) * ngrid;
+    const double* ssa = b.ssa + size_t(w) * ngrid;
+    for (int r = 0; r < nlyr; ++r) {
+        const double gtr = G(r), gom = G(nlyr + r);
+        const double kb = b.kbar[size_t(r) * nw + w], omr = b.om[size_t(r) * nw + w];
+        for (int t = 0; t < 2; ++t) {
+            const int q = g.wq_idx[2 * r + t];
+            if (q < 0) continue;
+            const double wt = g.wq_w[2 * r + t];
+            b.dnat[size_t(q) * nt + tid] += gtr * wt * g.dh[r] + gom * wt * (ssa[q] - omr) / kb;
+            b.dnat[size_t(ngrid + q) * nt + tid] += gom * wt * ext[q] / kb;
+        }
+    }
+    b.dnat[size_t(2 * ngrid) * nt + tid] += G(4 * nlyr);
+}
 __global__ void __launch_bounds__(kBlock) kern_k4b(Geo g, Bufs b) {
     size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (tid >= size_t(b.nw) * g.nlos) return;
@@ -892,7 +950,11 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
         if (pipe && last_m >= 0) HIP_CHECK(hipStreamWaitEvent(st, slot.ev_rest[last_m], 0));  // the whole adjoint stage is in order on sC
         if (derivs) {
             Timer t(I, st, "k4a_chain");
-            hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, s, s + 1 < g.nsza ? 1 : 0);
+            if (s + 1 < g.nsza) hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, s, 1);
+            else {
+                hipLaunchKernelGGL(kern_k4a_gt, dim3(blocks(nt), unsigned((g.nlyr + 7) / 8)), dim3(kBlock), 0, st, g, b, s);
+                hipLaunchKernelGGL(kern_k4a_apply, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b);
+            }
         }
     }
     if (g.nsza == 0) {
