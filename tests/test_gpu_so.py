@@ -422,3 +422,35 @@ def test_jvp_and_vjp_with_the_successive_orders_source():
     lhs = float(np.sum(cot * jvp))
     rhs = float(grads["wf_extinction"] @ t_k + grads["wf_ssa"] @ t_w + grads["wf_albedo"] @ t_a)
     assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs))
+
+
+@pytest.mark.parametrize("nstokes", [1, 3])
+def test_device_resident_entry_point_with_weighting_functions_equals_the_host_entry_point(nstokes, monkeypatch):
+    """sk_amd_so_engine_solve_device_wf (inputs and outputs in HBM, device.SoDeviceSolver) against sk_engine_calculate_radiance with host
+    buffers: the same kernels -- the radiances agree bit for bit, also when the spectrum is solved in blocks of 128 wavelengths."""
+    import torch
+    from sasktran2_amd.device import SoDeviceSolver
+    from tests.gpu_harness import build_so_engine
+    nw = 200
+    s = sc.regression_so(nstokes=nstokes, num_wavelengths=nw)
+    s["albedo"] = np.linspace(0.0, 0.6, nw)
+    eng = build_so_engine(s)
+    host = run_product_so(s, engine=eng, derivatives=True)
+    dev = torch.device("cuda", 0)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    ext, ssa = to(s["extinction"].T), to(s["ssa"].T)
+    leg, alb = to(np.transpose(s["leg"], (2, 1, 0))), to(s["albedo"])
+    solver = SoDeviceSolver(eng[0])
+    for chunk in (None, "128"):
+        if chunk:
+            monkeypatch.setenv("SASKTRAN2_AMD_SO_CHUNK", chunk)
+        out = solver.allocate_outputs(nw, derivatives=True, device=dev)
+        solver.solve(ext, ssa, leg, alb, out)
+        torch.cuda.synchronize()
+        assert np.array_equal(out["radiance"].cpu().numpy(), host["radiance"])
+        # (the adjoint's accumulators are filled with floating-point atomics -- LDS and HBM -- whose order is not fixed: its rows agree to
+        # rounding, not bit for bit, from one run to the next)
+        for key, got in (("d_extinction", out["wf_extinction"].cpu().numpy().transpose(1, 2, 3, 0)), ("d_ssa", out["wf_ssa"].cpu().numpy().transpose(1, 2, 3, 0)),
+                         ("d_albedo", out["wf_albedo"].cpu().numpy())):
+            scale = np.abs(host[key]).max(axis=-1, keepdims=True) if host[key].ndim == 4 else np.abs(host[key])
+            assert np.max(np.abs(got - host[key]) / scale) < 1e-12, key
