@@ -404,6 +404,7 @@ struct DeviceEngine::Impl {
         double* recx[kDepth - 1] = {};
         double* dinvx[kDepth - 1] = {};
         double* xsolx[kDepth - 1] = {};
+        uint8_t* qlmaskx[kDepth - 1] = {};   // live-flag rows: formed on the BVP stream right after the table values, read by the adjoint stream
         std::vector<hipEvent_t> ev_k1, ev_bvp, ev_rest;  // per azimuth order
         hipEvent_t ev_begin = nullptr;
     };
@@ -545,7 +546,7 @@ size_t DeviceEngine::bytes_per_wavelength() const {
     size_t d = 0;
     d += nlyr * (3 + nstr) + (nlyr + 1) + nlyr;              // tau, om, kbar, a, T, sec
     d += size_t(t.nq_total) * 3 + nlos;                      // od, omloc, srcw, att_total
-    if (N == 8) d += t.lp_q.size() + t.lp_q.size() / 64 + 1 + nlyr * (N + N * N) + nlyr * 18; // cwbuf, qlmask, eig, at
+    if (N == 8) d += t.lp_q.size() + Impl::Slot::kDepth * (t.lp_q.size() / 64 + 1) + nlyr * (N + N * N) + nlyr * 18; // cwbuf, qlmask rows, eig, at
     d += Impl::Slot::kDepth * (nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N);  // rec, dinv, xsol (kDepth buffers each)
     d += nstr * size_t(t.nslot);                             // J
     const size_t nlos_pad = (nlos + 15) / 16 * 16;
@@ -595,6 +596,7 @@ void DeviceEngine::ensure_scratch(int nw, int nslots) {
             sl->recx[k] = M.alloc<double>(nlyr * (4 * N * N + 41 * N) * W);
             sl->dinvx[k] = M.alloc<double>(nlyr * 4 * N * N * W);
             sl->xsolx[k] = M.alloc<double>(nlyr * 2 * N * W);
+            sl->qlmaskx[k] = M.alloc<uint8_t>(t.N == 8 ? (t.lp_q.size() + 7) / 8 * W + 8 : 8);
         }
         b.xsol = M.alloc<double>(nlyr * 2 * N * W); b.J = M.alloc<double>(nstr * size_t(t.nslot) * W);
         b.conv_order = M.alloc<uint8_t>(size_t(t.nslot) * W); b.notconv = M.alloc<int>(W); b.norders = M.alloc<int>(W);
@@ -805,7 +807,8 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
     double* rec_buf[kDepth] = {b.rec};
     double* dinv_buf[kDepth] = {b.dinv};
     double* xsol_buf[kDepth] = {b.xsol};
-    for (int k = 1; k < kDepth; ++k) { rec_buf[k] = slot.recx[k - 1]; dinv_buf[k] = slot.dinvx[k - 1]; xsol_buf[k] = slot.xsolx[k - 1]; }
+    uint8_t* qlmask_buf[kDepth] = {b.qlmask};
+    for (int k = 1; k < kDepth; ++k) { rec_buf[k] = slot.recx[k - 1]; dinv_buf[k] = slot.dinvx[k - 1]; xsol_buf[k] = slot.xsolx[k - 1]; qlmask_buf[k] = slot.qlmaskx[k - 1]; }
     // orders in flight.  A full-size launch fills the chip with two (the kernels of one order already overlap those of the next); a small
     // one (a rank's share of a sharded run) is a chain of kernels per order that each fill a fraction of it -- K1, BVP, table values,
     // adjoint operators, sweeps -- and only as many chains run side by side as there are buffers (1 250 wavelengths: 23.3 -> 21.0 ms)
@@ -828,6 +831,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                 b.rec = rec_buf[m % depth];
                 b.dinv = dinv_buf[m % depth];
                 b.xsol = xsol_buf[m % depth];
+                b.qlmask = qlmask_buf[m % depth];
                 // buffers m % depth are free once the adjoint stage of order m - depth is done
                 if (m >= depth) {
                     HIP_CHECK(hipStreamWaitEvent(sA, slot.ev_rest[m - depth], 0));
@@ -865,6 +869,15 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                 Timer t(I, st, "k3_table_values");
                 launch_k3<N>(st, g, b, s, m);
             }
+            // live flags of the table entries at this order (they only read what the table values just wrote -- the stop rule's clamp does not
+            // change the test `first skipped order > m` -- into the row of this order's buffer set).  Full-size launches: here, off the adjoint
+            // stream, whose chain of operator kernel and sweeps is the longer one (113 -> 111 ms); small launches: the BVP stream is the
+            // critical one (1 250 wavelengths: 19.4 against 19.8 ms), the flags stay at the head of the adjoint stage
+            const bool flags_here = depth == 2;
+            if (N == 8 && derivs && g.n_lp > 0 && flags_here) {
+                Timer t2(I, st, "k2q_live_flags");
+                hipLaunchKernelGGL(kern_qlmask, dim3(2048), dim3(256), 0, st, g, b, m);
+            }
             if (pipe) {
                 HIP_CHECK(hipEventRecord(slot.ev_bvp[m], st));
                 HIP_CHECK(hipStreamWaitEvent(sC, slot.ev_bvp[m], 0));
@@ -879,7 +892,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                     // registers), kern_k2b_mfma8<.., true> keeps the backward sweep; SASKTRAN2_AMD_FUSE=0 keeps the two separate kernels
                     static const bool fuse_env = [] { const char* e = std::getenv("SASKTRAN2_AMD_FUSE"); return e ? atoi(e) != 0 : true; }();
                     const bool fused = fuse_env && !b.k1_lane && ntile <= 2 && small_batch_split(int(nw)) == 1 && g.n_lp > 0;
-                    if (g.n_lp > 0) {
+                    if (g.n_lp > 0 && !flags_here) {
                         Timer t2(I, sC, "k2q_live_flags");
                         hipLaunchKernelGGL(kern_qlmask, dim3(2048), dim3(256), 0, sC, g, b, m);
                     }
@@ -940,6 +953,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
         b.rec = rec_buf[0];
         b.dinv = dinv_buf[0];
         b.xsol = xsol_buf[0];
+        b.qlmask = qlmask_buf[0];
         if (s == g.nsza - 1) {
             // the line-of-sight integration reads the finished diffuse table (J, conv_order: final after this stop rule) and nothing of the
             // adjoint stage, whose last orders are still running on sC: it goes first, the chain from the layer gradients after it.
