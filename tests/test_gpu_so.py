@@ -454,3 +454,14 @@ def test_device_resident_entry_point_with_weighting_functions_equals_the_host_en
                          ("d_albedo", out["wf_albedo"].cpu().numpy())):
             scale = np.abs(host[key]).max(axis=-1, keepdims=True) if host[key].ndim == 4 else np.abs(host[key])
             assert np.max(np.abs(got - host[key]) / scale) < 1e-12, key
+
+
+def test_weighting_functions_on_a_grid_whose_accumulators_exceed_64_kb_of_lds():
+    """81 grid levels: the chain kernel's extinction / ssa accumulators of a 64-wavelength slab take 83 KB of LDS (the opt-in above the
+    default 64 KB per workgroup); device rows against the oracle's adjoint."""
+    from tests.test_so_oracle import make_so_oracle
+    s = sc.limb_c5(num_wavelengths=70, nlyr=80, num_iterations=2, num_directions=26)
+    ref = make_so_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, nthreads=16)
+    got = run_product_so(s, derivatives=True)
+    assert_so_parity(got, ref)
+    assert_so_wf_parity(got, ref, tol=1e-8)
