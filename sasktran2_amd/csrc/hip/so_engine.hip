@@ -1133,6 +1133,12 @@ struct SoDeviceEngine::Impl {
     double *adj_dT = nullptr, *adj_dph = nullptr, *adj_gcl = nullptr, *adj_xg = nullptr, *adj_gpt = nullptr;
     int adj_groups = 0;
     size_t adj_passes = 0, adj_terms = 0;
+    // fixed-order sums of the chain's contributions (so_adjoint.inc): per incoming layer (first compact slot, used-slot mask | mid slots),
+    // compact slots by grid level, rays that see the lit ground, the incoming rays' solar stencils by table row
+    const int2* chain_meta = nullptr;
+    const int *rowq_start = nullptr, *rowq_c = nullptr, *alb_rays = nullptr, *solT_start = nullptr, *solT_end = nullptr;
+    const double* solT_w = nullptr;
+    int n_used = 0, n_alb = 0, n_endpoints = 0;
     const int* ray_ground = nullptr;       // [incoming rays] ground point of the ray's diffuse point, or -1
     const double* ray_gfactor = nullptr;   // [incoming rays] its factor in the point's downwelling flux
     std::vector<double*> xhist;
@@ -1286,6 +1292,69 @@ SoDeviceEngine::SoDeviceEngine(const skso::SoGeometry& sg, int num_iterations) :
                         }
                     }
                 }
+            // the adjoint's chain (so_adjoint.inc) writes one value per USED stencil slot of a layer and the row kernels sum them per grid
+            // level in the order of these lists: used = a valid stencil slot, or a free slot lent to a level of the layer's mid-point stencil
+            {
+                std::vector<int2> meta(nl);
+                std::vector<std::vector<int>> by_q(sg.ngrid);
+                int c = 0;
+                for (int l = 0; l < nl; ++l) {
+                    LayerRec& R = rec[l];
+                    int mask = 0, mslot[2] = {0, 0};
+                    for (int i = 0; i < 4; ++i)
+                        if (in.stencil_idx[4 * l + i] >= 0) mask |= 1 << i;
+                    for (int j = 0; j < 2; ++j) {
+                        int at = -1;
+                        for (int i = 0; i < 4 && at < 0; ++i)
+                            if (((mask >> i) & 1) && R.q[i] == R.mid[j]) at = i;
+                        for (int i = 0; i < 4 && at < 0; ++i)
+                            if (!((mask >> i) & 1)) {   // (its weights are zero: the other kernels read the level and drop it)
+                                at = i;
+                                R.q[i] = R.mid[j];
+                                mask |= 1 << i;
+                            }
+                        if (at < 0) throw std::runtime_error("sasktran2_amd: mid-point level outside a full layer stencil");
+                        mslot[j] = at;
+                    }
+                    meta[l].x = c;
+                    meta[l].y = mask | (mslot[0] << 4) | (mslot[1] << 6);
+                    for (int i = 0; i < 4; ++i)
+                        if ((mask >> i) & 1) by_q[R.q[i]].push_back(c++);
+                }
+                I.n_used = c;
+                std::vector<int> qs{0}, qc;
+                for (const auto& v : by_q) {
+                    qc.insert(qc.end(), v.begin(), v.end());
+                    qs.push_back((int)qc.size());
+                }
+                I.chain_meta = I.tables.upload(meta);
+                I.rowq_start = I.tables.upload(qs);
+                I.rowq_c = I.tables.upload(qc);
+                std::vector<int> alb;
+                I.n_endpoints = in.endpoint_start.back();
+                std::vector<std::vector<std::pair<int, double>>> by_t(sg.table.od.rows());
+                for (int r = 0; r < in.nrays; ++r) {
+                    const int n = in.layer_start[r + 1] - in.layer_start[r], e0 = in.endpoint_start[r];
+                    if (n == 0) continue;
+                    if (in.ground_is_hit[r] && in.ground_mu_in[r] > 0) alb.push_back(r);
+                    for (int e = e0; e <= e0 + n; ++e)
+                        for (int t = in.solar.start[e]; t < in.solar.start[e + 1]; ++t)
+                            if (in.solar.w[t] != 0.0) by_t[in.solar.idx[t]].push_back({e, in.solar.w[t]});
+                }
+                I.n_alb = (int)alb.size();
+                if (alb.empty()) alb.push_back(0);
+                I.alb_rays = I.tables.upload(alb);
+                std::vector<int> ts{0}, te;
+                std::vector<double> tw;
+                for (const auto& v : by_t) {
+                    for (const auto& ew : v) { te.push_back(ew.first); tw.push_back(ew.second); }
+                    ts.push_back((int)te.size());
+                }
+                if (te.empty()) { te.push_back(0); tw.push_back(0.0); }
+                I.solT_start = I.tables.upload(ts);
+                I.solT_end = I.tables.upload(te);
+                I.solT_w = I.tables.upload(tw);
+            }
             g.inc_rec = I.tables.upload(rec);
             // accumulation entries in groups of six per factor slot
             std::vector<AccGroup> groups;
@@ -1537,21 +1606,12 @@ template <int S>
 static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b, hipStream_t st, unsigned wb, bool adj_final) {
     SoTimer t(I, st, "so_adjoint");
     SoAdj A = I.adj;
-    const size_t W = b.nwp, Wc = A.wcap, n_state = size_t(g.n_out_total) * S * W, n_rays = size_t(g.inc.nrays) * S * W, n_tab = size_t(g.ntable) * W;
+    const size_t W = b.nwp, Wc = A.wcap, n_state = size_t(g.n_out_total) * S * W, n_rays = size_t(g.inc.nrays) * S * W;
     const size_t mu_stride = size_t(g.inc.nrays) * S * Wc, y_stride = size_t(g.n_inc_layers + g.inc.nrays) * S * Wc, nground = size_t(g.npoints - g.ninterior);
     const size_t gis_stride = std::max<size_t>(nground, 1) * Wc;
     const int n = I.fp.enabled && !adj_final ? I.fp_last_iterations : I.num_iterations;   // passes to transpose / terms of the series
     const int npass = adj_final ? 1 : std::max(n - 1, 0);
     if (n > kMaxPasses) throw std::runtime_error("sasktran2_amd: successive-orders weighting functions support at most 64 passes");
-    const size_t lds_chain = size_t(2) * g.ngrid * kWave * sizeof(double);
-    if (lds_chain > 160 * 1024) throw std::runtime_error("sasktran2_amd: successive-orders weighting functions hold 2 x ngrid x 64 doubles in LDS (ngrid <= 160)");
-    auto chain_attr = [&](auto kernel) {
-        if (size_t(2 + b.ngroups) * g.ngrid * kWave * sizeof(double) > 64 * 1024) SO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             int(size_t(2 + b.ngroups) * g.ngrid * kWave * sizeof(double))));
-    };
-    chain_attr(&k_so_adj_chain<S, 0>);
-    chain_attr(&k_so_adj_chain<S, 1>);
-    chain_attr(&k_so_adj_chain<S, 9>);
     int rays_per_wave = 8;
     if (const char* e = std::getenv("SASKTRAN2_AMD_SO_ADJ_RPW")) rays_per_wave = std::max(1, atoi(e));
     const int rays_per_block = rays_per_wave * kChainWaves;
@@ -1563,12 +1623,12 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
     auto gis_of = [&](int k) { return I.adj_gis + size_t(adj_final ? 0 : k - 1) * gis_stride; };
     // seed-independent tables, once per solve: Y_k = W x_{k-1} per factor slot, the ground points' incoming flux of every pass
     SO_HIP_CHECK(hipMemsetAsync(I.adj_y, 0, std::max<size_t>(npass, 1) * y_stride * sizeof(double), st));
-    SO_HIP_CHECK(hipMemsetAsync(I.adj_gis, 0, size_t(adj_final ? 1 : n) * gis_stride * sizeof(double), st));
     for (int k = adj_final ? 1 : n; k >= 1; --k) {
         A.xprev = xprev_of(k);
         A.y = A.xprev ? I.adj_y + size_t(adj_final ? 0 : k - 2) * y_stride : nullptr;
         A.gis = gis_of(k);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_y<S>), dim3(unsigned(g.inc.nrays), wb), dim3(kWave), 0, st, g, b, A, I.ray_ground, I.ray_gfactor);
+        if (nground > 0) hipLaunchKernelGGL(k_so_adj_gis, dim3(unsigned(nground), wb), dim3(kWave), 0, st, g, A, I.ray_ground);
     }
     // scattering groups (scalar engine): directions slab major, their phase values on the incoming rays, and per pass the outputs of the
     // scattering operator with the groups' coefficients at either level of every interior point (so_adjoint.inc, "scattering groups")
@@ -1605,14 +1665,17 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
     A.dph_inc = ngroups > 0 ? I.adj_dph : nullptr;
     A.gpt = ngroups > 0 ? I.adj_gpt : nullptr;
     A.xg = nullptr;
-    const size_t lds_chain_g = size_t(2 + ngroups) * g.ngrid * kWave * sizeof(double);
-    if (lds_chain_g > 160 * 1024) throw std::runtime_error("sasktran2_amd: too many scattering groups for the LDS accumulators of the successive-orders weighting functions");
+    A.n_used = I.n_used;
+    A.cont_alb = 2 * I.n_used;
+    A.cont_end = A.cont_alb + g.inc.nrays;
+    A.cont_grp = A.cont_end + I.n_endpoints;
+    A.ncont = size_t(A.cont_grp) + size_t(I.adj_groups) * I.n_used;   // (the stride the scratch was sized with)
     // the chain with mu_k of a ray in registers for the usual pass counts (one about the final state, nine for ten orders of scattering)
     auto launch_chain = [&](const SoAdj& A_) {
         const dim3 grid(wb, nchunks), block(kWave * kChainWaves);
-        if (npass == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 1>), grid, block, lds_chain_g, st, g, b, A_, g.inc_rec, rays_per_wave);
-        else if (npass == 9 && S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 9>), grid, block, lds_chain_g, st, g, b, A_, g.inc_rec, rays_per_wave);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 0>), grid, block, lds_chain_g, st, g, b, A_, g.inc_rec, rays_per_wave);
+        if (npass == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 1>), grid, block, 0, st, g, b, A_, g.inc_rec, I.chain_meta, rays_per_wave);
+        else if (npass == 9 && S == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 9>), grid, block, 0, st, g, b, A_, g.inc_rec, I.chain_meta, rays_per_wave);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_so_adj_chain<S, 0>), grid, block, 0, st, g, b, A_, g.inc_rec, I.chain_meta, rays_per_wave);
     };
     A.y = nullptr;
     A.npass = npass;
@@ -1646,9 +1709,11 @@ static void run_adjoint(SoDeviceEngine::Impl& I, const SoGeo& g, const SoBufs& b
                 std::swap(A.lam, A.lam_new);
             }
             launch_chain(A);
+            // the chain's contributions summed in the fixed order of the host's lists (no atomics: bit-reproducible for every launch shape)
+            hipLaunchKernelGGL(k_so_adj_gtod, dim3(unsigned(g.ntable), wb), dim3(kWave), 0, st, g, A, I.solT_start, I.solT_end, I.solT_w);
             hipLaunchKernelGGL(k_so_adj_fold, dim3(unsigned(g.ngrid), wb), dim3(kWave), 0, st, g, b, A, I.tabT_start, I.tabT_row, I.tabT_w);
+            hipLaunchKernelGGL(k_so_adj_rows, dim3(unsigned((2 + ngroups) * g.ngrid + 1), wb), dim3(4 * kWave), 0, st, g, b, A, I.rowq_start, I.rowq_c, I.alb_rays, I.n_alb);
             if (ngroups > 0) hipLaunchKernelGGL(k_so_adj_gmap, dim3(wb), dim3(kWave), 0, st, g, b, A);
-            SO_HIP_CHECK(hipMemsetAsync(A.gtod, 0, n_tab * sizeof(double), st));
         }
     SO_HIP_CHECK(hipGetLastError());
 }
@@ -1678,8 +1743,8 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
     const size_t n_terms = adjoint ? size_t(std::max(I.num_iterations, 1)) : 0;
     const size_t adj_group_doubles = (adjoint && ngroups > 0) ? size_t(ngroups) * (size_t(g.ngrid) * nleg * per + I.n_inc_rays * g.ngrid * (S == 3 ? 2 : 1) + size_t(g.ninterior) * 2) +
                                                                    size_t(g.ninterior) * g.num_ms_moments * per + n_terms * size_t(ngroups) * 2 * I.n_out * S : 0;
-    const size_t adj_doubles = adj_group_doubles + (adjoint ? (2 + n_hist) * I.n_out * S + (n_pass + 2) * I.n_inc_rays * S + (n_pass + 1) * (I.n_inc_layers + I.n_inc_rays) * S + 1 + I.n_table +
-                                             n_terms * (g.npoints - g.ninterior) : 0);
+    const size_t adj_doubles = adj_group_doubles + (adjoint ? (2 + n_hist) * I.n_out * S + (n_pass + 2) * I.n_inc_rays * S + (n_pass + 1) * (I.n_inc_layers + I.n_inc_rays) * S + I.n_table +
+                                             (n_terms + 1) * std::max(g.npoints - g.ninterior, 1) + 2 * size_t(I.n_used) + I.n_inc_rays + I.n_endpoints + size_t(ngroups) * I.n_used : 0);
     const size_t per_w = (so_doubles_per_wavelength(I, nleg) + deriv_doubles + adj_doubles) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
@@ -1741,10 +1806,11 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
             A.wcap = W;
             A.gfirst = I.scratch.alloc<double>(I.n_inc_rays * S * W);
             A.nu = I.scratch.alloc<double>((I.n_inc_layers + I.n_inc_rays) * S * W);
-            A.galb = I.scratch.alloc<double>(W);
+            const size_t n_gpt = std::max(g.npoints - g.ninterior, 1);
+            A.galb = I.scratch.alloc<double>(n_gpt * W);
             A.gtod = I.scratch.alloc<double>(I.n_table * W);
-            SO_HIP_CHECK(hipMemset(A.galb, 0, W * sizeof(double)));            // (k_so_adj_fold leaves both cleared)
-            SO_HIP_CHECK(hipMemset(A.gtod, 0, I.n_table * W * sizeof(double)));
+            SO_HIP_CHECK(hipMemset(A.galb, 0, n_gpt * W * sizeof(double)));            // (k_so_adj_fold leaves it cleared)
+            A.cont = I.scratch.alloc<double>((2 * size_t(I.n_used) + I.n_inc_rays + I.n_endpoints + size_t(I.adj_groups) * I.n_used) * W);
             for (size_t k = 0; k < keep_hist; ++k) I.xhist.push_back(I.scratch.alloc<double>(I.n_out * S * W));
             if (I.adj_groups > 0) {
                 const size_t G = I.adj_groups;
