@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer call (value_host_path)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="wavelengths of the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
+    # the cpu_baseline leg of every workload times the oracle built with -O3 -march=native on THIS host (oracle/Makefile, target native)
+    os.environ.setdefault("SASKTRAN2_ORACLE_NATIVE", "1")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -239,6 +241,7 @@ def main():
             achieved = kp["flops_per_wavelength"] * chunk / avg_launch_s / 1e12
             r = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "flops_per_launch": kp["flops_per_wavelength"] * chunk,
+                 "pmc_source": "profiles/" + pmc.get("_solve", {}).get("source", "?") + " (counters of the committed rocprofv3 passes; the durations are live)",
                  "note": "FP64 operations executed (PMC: SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 x 64 lanes + matrix-core MOPS x 512), "
                          "vector and matrix FP64 peak are both 78.6 TFLOP/s on MI355X"}
         else:
@@ -272,6 +275,10 @@ def main():
         line = {
             "metric": "wavelengths/sec (radiance + full WF) 50 layer/16 stream",
             "value": value, "unit": "wavelengths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # two rates, both in the line: `value` has the inputs resident in HBM when the timed region starts (the bench contract of this
+            # build's task statement: a PCIe-inclusive rate is never `value`); `value_host_path` below is SURVEY.md 8(d)'s definition --
+            # one calculate_radiance() with host buffers in and out, transfers inside the timer
+            "value_definition": "device-resident inputs and outputs (HBM); the host-buffer rate of SURVEY 8(d) is value_host_path",
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2 limb-scatter spherical: 16-stream DISCO, 50 layers, 25 tangent heights 10-58 km, "
@@ -343,6 +350,10 @@ def main():
             pass
         line["cpu_baseline"] = {"value": n / dt, "unit": "wavelengths/s", "cores": cores, "kind": "port",
                                 "one_thread_value": one_thread, "cpu_model": cpu_model,
+                                "build": ("g++ -O3 -march=native -ffp-contract=off -fopenmp, compiled on this host (oracle/Makefile: native)" if Path(ROOT / "oracle" / "liboracle_native.so").exists()
+                                          else "g++ -O2 -fopenmp (portable build: no compiler on this host)"),
+                                "what": "the CPU oracle: plain loops where the reference calls Eigen / LAPACK, OpenMP over wavelengths like "
+                                        "cpp/lib/engine/engine.cpp:610; a reported baseline, not the target",
                                 "threads_scaling": (n / dt) / one_thread,
                                 "host_logical_cpus": logical_cpus, "host_physical_cores": physical_cores,
                                 "cores_note": "cores = threads used = the CPU share this process is granted (cgroup cpu.max), not the affinity mask",

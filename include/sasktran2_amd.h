@@ -154,6 +154,13 @@ int sk_amd_comm_unique_id(char* id128);
 void* sk_amd_comm_create(const char* id128, int rank, int world);
 void sk_amd_comm_destroy(void* comm);
 int sk_amd_engine_calculate_radiance_sharded(Engine* engine, Atmosphere* atmosphere, OutputC* output, void* comm, int rank, int world);
+/* Errors: more ranks than wavelengths, flux derivative outputs and device-resident storage are refused alike on every rank (-3) before
+ * anything is exchanged.  A failure of ONE rank's local solve does not leave the others waiting: the rank still takes part in the
+ * all-gather with a zeroed slab and a status word, and every rank returns that rank's code with an error that names it.
+ * RCCL (librccl.so) is loaded on the first sk_amd_comm_* call; the library itself does not depend on it.
+ * ..._emulated: the same partition, local solves and slab arithmetic with the `world` ranks played in turn by the calling process and no
+ * collective -- what one GPU can check of the entry point above (fail_rank >= 0 marks that rank as failed; -1: none). */
+int sk_amd_engine_calculate_radiance_sharded_emulated(Engine* engine, Atmosphere* atmosphere, OutputC* output, int world, int fail_rank);
 /* The same for an engine with single_scatter_source = exact and / or multiple_scatter_source = successive_orders_legacy
  * (replaces, per wavelength, SingleScatterSource<SolarTransmissionExact>::calculate / integrated_source,
  * cpp/lib/solar/singlescattersource.cpp:103-160,950-1167, and hr::DiffuseTable::calculate, cpp/lib/hr/diffuse_table.cpp:885-962):
@@ -236,6 +243,12 @@ int sk_amd_engine_reset_profile(Engine* engine);
 int sk_amd_engine_kernel_time(Engine* engine, const char* kernel_name, double* total_ms, long* launches);
 int sk_amd_engine_kernel_names(Engine* engine, char* buffer, int buffer_len);
 const char* sk_amd_last_error(void);
+/* Page-locked host memory for the arrays a caller hands to sk_atmosphere_storage_create / sk_output_assign_derivative_memory (additive; the
+ * reference maps caller memory, cpp/include/sasktran2/atmosphere/grid_storage.h:77-102, and so does this library): the DMA engines read
+ * and write such arrays without a staging copy -- the host entry point moves 74 MB in and 208 MB out per 10 000 wavelengths of the 16-stream
+ * limb case.  sk_amd_host_alloc returns NULL when the memory cannot be pinned (the caller then uses ordinary memory: every entry point takes both). */
+void* sk_amd_host_alloc(unsigned long long bytes);
+void sk_amd_host_free(void* ptr);
 
 /* =====================================================================================================================
  * Rest of the reference's C API (the headers under cpp/include/c_api): every symbol its FFI links against is exported, so replacing

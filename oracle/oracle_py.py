@@ -19,6 +19,14 @@ _ip = ctypes.POINTER(ctypes.c_int)
 
 
 def build(force: bool = False) -> Path:
+    # SASKTRAN2_ORACLE_NATIVE=1 (bench.py's cpu_baseline leg): the oracle compiled with -O3 -march=native ON the machine that times it
+    native = os.environ.get("SASKTRAN2_ORACLE_NATIVE", "") not in ("", "0")
+    if native:
+        try:
+            subprocess.check_call(["make", "-C", str(_HERE), "-s", "native"])
+            return _HERE / "liboracle_native.so"
+        except (subprocess.CalledProcessError, OSError):
+            pass   # (no compiler on this host: the portable build below)
     so = _HERE / "liboracle.so"
     srcs = [_HERE / "oracle_capi.cpp", _HERE / "disco_oracle.hpp", _HERE / "linalg.hpp",
             _HERE.parent / "sasktran2_amd" / "csrc" / "host" / "geometry.hpp"]

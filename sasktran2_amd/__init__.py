@@ -15,6 +15,7 @@ import enum
 import numpy as np
 
 from ._lib_loader import last_error, lib
+from .hostmem import pool as _host
 
 _dp = ctypes.POINTER(ctypes.c_double)
 
@@ -194,11 +195,12 @@ class ViewingGeometry:
 
 class _Storage:
     def __init__(self, ngrid, nwavel, nleg, nstokes=1):
-        self.total_extinction = np.zeros((ngrid, nwavel), order="F")
-        self.ssa = np.zeros((ngrid, nwavel), order="F")
-        self.emission_source = np.zeros((ngrid, nwavel), order="F")
+        # (large arrays in page-locked memory, hostmem.py: the engine's uploads then run at the DMA engines' rate)
+        self.total_extinction = _host.zeros((ngrid, nwavel), order="F")
+        self.ssa = _host.zeros((ngrid, nwavel), order="F")
+        self.emission_source = _host.zeros((ngrid, nwavel), order="F")
         # NSTOKES = 3: four Greek coefficients per order, order-major (cpp/include/c_api/atmosphere.h:77-83)
-        self.leg_coeff = np.zeros((nleg * (4 if nstokes == 3 else 1), ngrid, nwavel), order="F")
+        self.leg_coeff = _host.zeros((nleg * (4 if nstokes == 3 else 1), ngrid, nwavel), order="F")
         self.solar_irradiance = np.ones(nwavel)
 
 
@@ -387,32 +389,53 @@ class Atmosphere:
     def calculate_derivatives(self):
         return self._calculate_derivatives
 
-    def _native_handles(self, L, nstokes):
+    def _native_handles(self, L, nstokes, direct=False):
         """The storage / surface / atmosphere handles of this object (created once, as `Atmosphere.internal_object()` of the
-        reference) over private Fortran-ordered buffers that every calculation refills."""
-        if getattr(self, "_H", None) is None:
-            st = self._raw_storage
-            H = {"ext": np.zeros_like(st.total_extinction, order="F"), "ssa": np.zeros_like(st.ssa, order="F"),
-                 "em": np.zeros_like(st.emission_source, order="F"), "leg": np.zeros_like(st.leg_coeff, order="F"),
-                 "irr": np.ones(self._nwavel), "alb": np.zeros(self._nwavel), "emis": np.zeros(self._nwavel)}
+        reference).  `direct`: the handle maps the caller-visible storage arrays themselves, as the reference's handle does
+        (cpp/include/sasktran2/atmosphere/grid_storage.h:77-102) -- no host copy per call; otherwise private Fortran-ordered buffers that
+        every calculation refills (delta-M scaling rewrites the storage in place and the caller's arrays keep the unscaled properties)."""
+        handles = self.__dict__.setdefault("_handles", {})
+        st = self._raw_storage
+        H = handles.get(direct)
+        if H is not None and direct and not (H["ext"] is st.total_extinction and H["ssa"] is st.ssa and H["em"] is st.emission_source and
+                                             H["leg"] is st.leg_coeff and H["irr"] is st.solar_irradiance):
+            self._destroy_handles(handles.pop(direct))   # the caller rebound a storage array: map the new one
+            H = None
+        if H is None:
+            if direct:
+                for name in ("total_extinction", "ssa", "emission_source", "leg_coeff", "solar_irradiance"):
+                    a = getattr(st, name)
+                    if a.dtype != np.float64 or not a.flags.f_contiguous:
+                        setattr(st, name, np.asfortranarray(a, dtype=np.float64))
+                H = {"ext": st.total_extinction, "ssa": st.ssa, "em": st.emission_source, "leg": st.leg_coeff, "irr": st.solar_irradiance,
+                     "alb": np.zeros(self._nwavel), "emis": np.zeros(self._nwavel), "mappings_set": False}
+            else:
+                H = {"ext": _host.zeros(st.total_extinction.shape, order="F"), "ssa": _host.zeros(st.ssa.shape, order="F"),
+                     "em": _host.zeros(st.emission_source.shape, order="F"), "leg": _host.zeros(st.leg_coeff.shape, order="F"),
+                     "irr": np.ones(self._nwavel), "alb": np.zeros(self._nwavel), "emis": np.zeros(self._nwavel)}
             H["storage"] = L.sk_atmosphere_storage_create(self._ngrid, self._nwavel, H["leg"].shape[0], nstokes, _p(H["ssa"]),
                                                           _p(H["ext"]), _p(H["em"]), _p(H["leg"]), _p(H["irr"]))
             H["brdf"] = L.sk_brdf_create_lambertian(nstokes)
             H["surface"] = L.sk_surface_create(self._nwavel, nstokes, _p(H["emis"]))
             L.sk_surface_set_brdf(H["surface"], H["brdf"], _p(H["alb"]))
             H["atmosphere"] = L.sk_atmosphere_create(H["storage"], H["surface"], int(self._calculate_derivatives), 0)
-            self._H = H
-        return self._H
+            handles[direct] = H
+        return H
+
+    @staticmethod
+    def _destroy_handles(H):
+        L = lib()
+        L.sk_atmosphere_destroy(H["atmosphere"])
+        L.sk_surface_destroy(H["surface"])
+        L.sk_brdf_destroy(H["brdf"])
+        L.sk_atmosphere_storage_destroy(H["storage"])
 
     def __del__(self):
-        H = getattr(self, "_H", None)
-        if H is not None and callable(lib):   # (at interpreter shutdown the module globals may be gone already)
-            L = lib()
-            L.sk_atmosphere_destroy(H["atmosphere"])
-            L.sk_surface_destroy(H["surface"])
-            L.sk_brdf_destroy(H["brdf"])
-            L.sk_atmosphere_storage_destroy(H["storage"])
-            self._H = None
+        handles = self.__dict__.get("_handles")
+        if handles and callable(lib):   # (at interpreter shutdown the module globals may be gone already)
+            for H in handles.values():
+                self._destroy_handles(H)
+            handles.clear()
 
 
 class Communicator:
@@ -464,19 +487,23 @@ class Engine:
         nw, ngrid = atmosphere._nwavel, atmosphere._ngrid
         S = int(self._config.num_stokes)
         per = 4 if S == 3 else 1
-        H = atmosphere._native_handles(L, S)
-        L.sk_atmosphere_storage_set_zero(H["storage"])
+        delta_order = int(self._config.num_streams) if self._config.delta_m_scaling and st.leg_coeff.shape[0] // per > self._config.num_streams else None
         # delta-M scaling rewrites the storage in place (src/sasktran2/atmosphere.py:845-854 applies it with order = num_streams
-        # when more moments than streams are stored): the handle maps private copies, the caller's arrays keep the unscaled properties
-        H["ext"][...] = st.total_extinction
-        H["ssa"][...] = st.ssa
-        H["em"][...] = st.emission_source
-        H["leg"][...] = st.leg_coeff
-        H["irr"][...] = st.solar_irradiance
+        # when more moments than streams are stored): the handle then maps private copies, the caller's arrays keep the unscaled
+        # properties.  Without it the handle maps the caller-visible arrays themselves and nothing is copied on the host.
+        direct = delta_order is None
+        H = atmosphere._native_handles(L, S, direct)
+        if not direct:
+            L.sk_atmosphere_storage_set_zero(H["storage"])
+            H["ext"][...] = st.total_extinction
+            H["ssa"][...] = st.ssa
+            H["em"][...] = st.emission_source
+            H["leg"][...] = st.leg_coeff
+            H["irr"][...] = st.solar_irradiance
         H["alb"][...] = atmosphere.surface.albedo
         H["emis"][...] = atmosphere.surface.emission
-        if derivs:
-            # raw-interface mappings, src/sasktran2/atmosphere.py:784-806
+        if derivs and not (direct and H["mappings_set"]):
+            # raw-interface mappings, src/sasktran2/atmosphere.py:784-806 (identity; nothing rescales them without delta-M: set once)
             for name, which in (("wf_extinction", "d_extinction"), ("wf_ssa", "d_ssa")):
                 m = ctypes.c_void_p()
                 L.sk_atmosphere_storage_get_derivative_mapping(H["storage"], name.encode(), ctypes.byref(m))
@@ -488,7 +515,9 @@ class Engine:
             ptr = _dp()
             L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
             np.ctypeslib.as_array(ptr, shape=(nw,))[:] = 1.0
-        return H, (int(self._config.num_streams) if self._config.delta_m_scaling and H["leg"].shape[0] // per > self._config.num_streams else None)
+            if direct:
+                H["mappings_set"] = True
+        return H, delta_order
 
     def _apply_delta_m(self, H, delta_order):
         if delta_order is not None:
@@ -624,7 +653,8 @@ class Engine:
         the C ABI before the solve (used by the tests for interpolated / log-space mappings).
         `shard=(communicator, rank, world)` (additive; `sasktran2_amd.Communicator`): one process per GPU, every rank passes the full
         atmosphere, solves its wavelength range and receives the full result through one RCCL all-gather
-        (`sk_amd_engine_calculate_radiance_sharded`)."""
+        (`sk_amd_engine_calculate_radiance_sharded`); `shard=("emulate", world, fail_rank)` plays the ranks of that partition in turn in
+        this process (no collective: what one GPU can check of the sharded entry point; `fail_rank = -1`: no simulated failure)."""
         if atmosphere._constituents:
             if shard is not None:
                 raise ValueError("shard= serves the raw interface (constituent atmospheres live in HBM: use sasktran2_amd.distributed.ShardedSolver)")
@@ -643,7 +673,7 @@ class Engine:
         try:
             if derivs:
                 for name in ("wf_extinction", "wf_ssa"):
-                    out[name] = np.zeros((ngrid, nw, nlos, S))
+                    out[name] = _host.empty((ngrid, nw, nlos, S))   # (written in full by the call; page-locked: see hostmem.py)
                     L.sk_output_assign_derivative_memory(h_out, name.encode(), _p(out[name]), nw * nlos, S, ngrid)
                 out["wf_albedo"] = np.zeros((nw, nlos, S))
                 L.sk_output_assign_surface_derivative_memory(h_out, b"wf_albedo", _p(out["wf_albedo"]), nw * nlos, S)
@@ -652,7 +682,11 @@ class Engine:
                 _mapping_hook(L, h_st, h_out, out)
                 out.pop("_surface_handle", None)
             self._apply_delta_m(H, delta_order)
-            if shard is not None:
+            if shard is not None and shard[0] == "emulate":
+                # the partition of `world` ranks played in turn by this process, no collective (sk_amd_engine_calculate_radiance_sharded_emulated)
+                _, world, fail_rank = shard
+                rc = L.sk_amd_engine_calculate_radiance_sharded_emulated(self._h, h_atm, h_out, int(world), int(fail_rank))
+            elif shard is not None:
                 comm, rank, world = shard
                 rc = L.sk_amd_engine_calculate_radiance_sharded(self._h, h_atm, h_out, comm._h, int(rank), int(world))
             else:
@@ -695,7 +729,7 @@ class Engine:
         try:
             if derivs:
                 for name, m in fe.mappings.items():
-                    raw[name] = np.zeros((m.num_output, nw, nlos, S))
+                    raw[name] = _host.empty((m.num_output, nw, nlos, S))
                     L.sk_output_assign_derivative_memory(h_out, name.encode(), _p(raw[name]), nw * nlos, S, m.num_output)
                 for name in atmosphere._surface_mappings:
                     m = ctypes.c_void_p()

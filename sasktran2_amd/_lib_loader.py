@@ -79,6 +79,7 @@ SIGNATURES = [
     ("sk_amd_unpack_slab", _I, [_vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("sk_amd_comm_unique_id", _I, [ctypes.c_char_p]), ("sk_amd_comm_create", _vp, [ctypes.c_char_p, _I, _I]), ("sk_amd_comm_destroy", None, [_vp]),
     ("sk_amd_engine_calculate_radiance_sharded", _I, [_vp, _vp, _vp, _vp, _I, _I]),
+    ("sk_amd_engine_calculate_radiance_sharded_emulated", _I, [_vp, _vp, _vp, _I, _I]),
     ("sk_amd_so_engine_solve_device", _I, [_vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("sk_amd_so_engine_solve_device_wf", _I, [_vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("sk_amd_so_engine_sizes", _I, [_vp, ctypes.POINTER(ctypes.c_ulonglong)]),
@@ -99,6 +100,8 @@ SIGNATURES = [
     ("sk_amd_engine_num_los", _I, [_vp, _ip]),
     ("sk_amd_engine_scratch_bytes", _I, [_vp, _I, ctypes.POINTER(ctypes.c_ulonglong)]),
     ("sk_amd_engine_launch_shape", _I, [_vp, _ip, _ip, ctypes.POINTER(ctypes.c_ulonglong)]),
+    ("sk_amd_host_alloc", _vp, [ctypes.c_ulonglong]),
+    ("sk_amd_host_free", None, [_vp]),
     ("sk_amd_engine_set_profiling", _I, [_vp, _I]), ("sk_amd_engine_reset_profile", _I, [_vp]),
     ("sk_amd_engine_kernel_time", _I, [_vp, _S, _dp, ctypes.POINTER(ctypes.c_long)]),
     ("sk_amd_engine_kernel_names", _I, [_vp, ctypes.c_char_p, _I]),

@@ -2,9 +2,11 @@
 // c_api handles, H2D/D2H staging around DeviceEngine::solve_device and the user derivative mappings
 // (reference: OutputC::assign_lane, cpp/lib/output/outputc.cpp:38-236).
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types only: the four RCCL calls of the sharded entry point are resolved with dlopen (capi_sharded.inc)
+#include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -23,6 +25,20 @@
 #include "frontend_kernels.hpp"
 
 namespace {
+// SASKTRAN2_AMD_HOST_TIMING=1: wall time of the phases of the host entry point (upload, solve, download ...) on stderr
+struct HostPhases {
+    const bool on = [] { const char* e = std::getenv("SASKTRAN2_AMD_HOST_TIMING"); return e && atoi(e) != 0; }();
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::string log;
+    void mark(const char* name) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto t1 = std::chrono::steady_clock::now();
+        log += std::string(name) + " " + std::to_string(std::chrono::duration<double, std::milli>(t1 - t0).count()) + " ms; ";
+        t0 = t1;
+    }
+    ~HostPhases() { if (on) std::fprintf(stderr, "sasktran2_amd host phases: %s\n", log.c_str()); }
+};
 thread_local std::string g_last_error;
 void set_error(const std::string& e) {
     g_last_error = e;
@@ -1051,7 +1067,9 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (st.nloc != e->ngrid) throw std::runtime_error("atmosphere grid does not match the engine geometry");
         if (!su.brdf_args) throw std::runtime_error("surface has no BRDF set");
         if (su.brdf && su.brdf->kind != 0) return -2;  // only the Lambertian surface is part of this path
+        HostPhases ph;
         validate_input_atmosphere(e, st);
+        ph.mark("validate");
         const bool wants_derivs = atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty());
         if (e->so && wants_derivs) {
             // a source without a linearisation is an error rather than a silently incomplete Jacobian (none today: the successive-orders
@@ -1118,6 +1136,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
             HIPC(hipMemcpy(d_f, st.src_delta_f(), nloc_w * 8, hipMemcpyDefault));
         }
         e->dev->set_delta_m_fraction(d_f);
+        ph.mark("upload");
         double *d_wem = nullptr, *d_wsem = nullptr;
         if (e->config.emission_source == 2) {   // thermal source inside the DO equations
             if (derivs) {
@@ -1155,6 +1174,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
         HIPC(hipGetLastError());
         HIPC(hipDeviceSynchronize());
+        ph.mark("solve");
         std::vector<int> status(nw);
         HIPC(hipMemcpy(status.data(), d_status, size_t(nw) * 4, hipMemcpyDeviceToHost));
         for (int w = 0; w < nw; ++w)
@@ -1162,9 +1182,11 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         HIPC(hipMemcpy(out->radiance, d_rad, nt * 8, hipMemcpyDeviceToHost));
         out->los_od.resize(nt);
         HIPC(hipMemcpy(out->los_od.data(), d_odt, nt * 8, hipMemcpyDeviceToHost));
+        ph.mark("radiance out");
         if (derivs) {
             map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, 1, nullptr, nullptr, d_wem, d_wsem);
         }
+        ph.mark("weighting functions out");
         return 0;
     } catch (const std::exception& ex) {
         set_error(std::string("sk_engine_calculate_radiance: ") + ex.what());
@@ -1269,6 +1291,17 @@ int sk_amd_engine_scratch_bytes(Engine* e, int nwavel, unsigned long long* bytes
     *bytes = (unsigned long long)((e->dev ? e->dev->bytes_per_wavelength() : 0) + (e->so ? e->so->bytes_per_wavelength() : 0) +
                                   (e->ts ? e->ts->bytes_per_wavelength(true) : 0)) * (unsigned long long)nwavel;
     return 0;
+}
+void* sk_amd_host_alloc(unsigned long long bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, size_t(bytes), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void sk_amd_host_free(void* ptr) {
+    if (ptr) (void)hipHostFree(ptr);
 }
 int sk_amd_engine_launch_shape(Engine* e, int* chunk, int* slots, unsigned long long* scratch_bytes) {
     if (!e) return -1;

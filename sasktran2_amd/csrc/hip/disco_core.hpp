@@ -161,6 +161,53 @@ template <int N> struct Rec {
     // PPM[j][14]: post-processing multipliers of solution j (struct PPMult) and E[j] = exp(-k_j tau), written by K3 so
     // that the per-LOS adjoint lanes of K2b never evaluate an exponential
     // G order: 0 Gplus_top, 1 Gminus_top, 2 Gplus_bottom, 3 Gminus_bottom;  DG[theta][which][i], theta: 0 tau 1 omega 2 T 3 sec
+    // element accessors (the kernels that serve both record layouts go through these)
+    static constexpr bool COLUMN_BLOCKS = false;
+    SKD_HD static constexpr int wp(int i, int j) { return WP + i + N * j; }
+    SKD_HD static constexpr int wm(int i, int j) { return WM + i + N * j; }
+    SKD_HD static constexpr int dwp(int i, int j) { return DWP + i + N * j; }
+    SKD_HD static constexpr int dwm(int i, int j) { return DWM + i + N * j; }
+    SKD_HD static constexpr int k(int j) { return K + j; }
+    SKD_HD static constexpr int dk(int j) { return DK + j; }
+    SKD_HD static constexpr int e(int j) { return E + j; }
+    SKD_HD static constexpr int ap(int j) { return AP + j; }
+    SKD_HD static constexpr int am(int j) { return AM + j; }
+    SKD_HD static constexpr int dap(int j) { return DAP + j; }
+    SKD_HD static constexpr int dam(int j) { return DAM + j; }
+    SKD_HD static constexpr int g(int x) { return G + x; }            // x = which * N + i
+    SKD_HD static constexpr int coef(int tk, int j) { return DG + tk * N + j; }   // kern_k1_lane's coefficient vectors, tk = type * 5 + k
+    SKD_HD static constexpr int ppm(int j) { return PPM + 14 * j; }
+};
+// Record of the lane-per-problem K1 (kern_k1_lane, 16 streams): everything K1 knows about SOLUTION j sits in one block of CB doubles
+// -- W+(:, j), W-(:, j), dW+(:, j), dW-(:, j), the ten coefficients of the particular solution, k, dk, A+-, dA+- -- because a
+// lane produces its record one solution column at a time and writes a column's 48 doubles as three full 128-byte lines (the standard
+// layout scatters a column over the record in 64-byte runs: 2.1 x the bytes in HBM write traffic, PMC).  G, exp(-k_j tau) and the post-processing
+// multipliers K3 adds follow the blocks; the derivative rows DG are formed where they are needed (kern_k2c_mfma8) and have no place here.
+// PAD: unused doubles behind every block (the LDS image of kern_k2c_mfma8 uses 1: a block stride of 49 doubles spreads the eight solutions'
+// entries over the banks, 48 puts them on two)
+template <int N, int PAD = 0> struct RecC {
+    static constexpr int CB = 4 * N + 16 + PAD, WPo = 0, WMo = N, DWPo = 2 * N, DWMo = 3 * N, COEFo = 4 * N, Ko = COEFo + 10, DKo = Ko + 1,
+                         APo = Ko + 2, AMo = Ko + 3, DAPo = Ko + 4, DAMo = Ko + 5, G = N * CB, E = G + 4 * N,
+                         TAIL0 = N * (4 * N + 16) + 5 * N,                       // end of E in the unpadded record
+                         PPM = E + N + ((TAIL0 + 15) / 16 * 16 - TAIL0),         // 128-byte aligned there; the padded image only shifts by N PAD
+                         SIZE = PPM + (14 * N + 15) / 16 * 16;
+    // (exp(-k_j tau) of the eight solutions in ONE run behind G: the boundary-value kernel reads W+-(:, j) -- line 0 of block j --, E and G only)
+    static_assert(Ko + 6 + PAD == CB, "column block");
+    static constexpr bool COLUMN_BLOCKS = true;
+    SKD_HD static constexpr int wp(int i, int j) { return j * CB + WPo + i; }
+    SKD_HD static constexpr int wm(int i, int j) { return j * CB + WMo + i; }
+    SKD_HD static constexpr int dwp(int i, int j) { return j * CB + DWPo + i; }
+    SKD_HD static constexpr int dwm(int i, int j) { return j * CB + DWMo + i; }
+    SKD_HD static constexpr int k(int j) { return j * CB + Ko; }
+    SKD_HD static constexpr int dk(int j) { return j * CB + DKo; }
+    SKD_HD static constexpr int e(int j) { return E + j; }
+    SKD_HD static constexpr int ap(int j) { return j * CB + APo; }
+    SKD_HD static constexpr int am(int j) { return j * CB + AMo; }
+    SKD_HD static constexpr int dap(int j) { return j * CB + DAPo; }
+    SKD_HD static constexpr int dam(int j) { return j * CB + DAMo; }
+    SKD_HD static constexpr int g(int x) { return G + x; }
+    SKD_HD static constexpr int coef(int tk, int j) { return j * CB + COEFo + tk; }
+    SKD_HD static constexpr int ppm(int j) { return PPM + 14 * j; }
 };
 enum { TH_TAU = 0, TH_OM = 1, TH_T = 2, TH_SEC = 3 };
 
@@ -173,6 +220,7 @@ struct RecView {
 SKD_HD double& J_at(const Bufs& b, const Geo& g, int m, int slot, int w) { return b.J[(size_t(w) * g.nslot + slot) * g.nstr + m]; }
 SKD_HD uint8_t& conv_at(const Bufs& b, const Geo& g, int slot, int w) { return b.conv_order[size_t(w) * g.nslot + slot]; }
 template <int N> SKD_HD double* rec_at(const Bufs& b, int nlyr, int p, int w) { return b.rec + (size_t(w) * nlyr + p) * Rec<N>::SIZE; }
+template <class R> SKD_HD double* rec_at_r(const Bufs& b, int nlyr, int p, int w) { return b.rec + (size_t(w) * nlyr + p) * R::SIZE; }
 template <int N> SKD_HD double* dinv_at(const Bufs& b, int nlyr, int p, int w) { return b.dinv + (size_t(w) * nlyr + p) * (4 * N * N); }
 template <int N> SKD_HD double* xsol_at(const Bufs& b, int nlyr, int p, int w) { return b.xsol + (size_t(w) * nlyr + p) * (2 * N); }
 

@@ -665,14 +665,14 @@ static bool launch_kj(hipStream_t st, const Geo& g, const Bufs& b, int m) {
     return false;
 }
 // 16 streams, spherical post-processing: the whole layer solution one (layer, wavelength) per lane -- kern_kj_lane<8, true> hands the
-// eigen-solutions over in b.eig, kern_k1_lane writes the records (with the coefficient vectors in place of Rec::DG, see Bufs::k1_lane).
-// Opt-in (SASKTRAN2_AMD_K1=lane): measured on MI355X it computes a launch in a fraction of the cooperative kernel's instruction count but
-// its record stores -- 64-byte runs scattered over each lane's 4.7 KB record, written a solution column at a time -- cost 2.1 x their bytes
-// in HBM write traffic (346 KB instead of 163 KB per wavelength and order) and the kernel ends up write-bound at the cooperative kernel's
-// duration (25 ms per step); it needs a record layout with a column's entries contiguous to pay off.
+// eigen-solutions over in b.eig, kern_k1_lane writes the records in the column-block layout skd::RecC (with the coefficient vectors of the
+// particular solution in place of its derivative rows, see Bufs::k1_lane); the BVP, table-value and adjoint-operator kernels are
+// instantiated for that layout.  Default since round 4 (round 3 wrote the standard layout in 64-byte runs scattered over each lane's
+// record: 2.1 x the bytes in HBM write traffic, and lost to the cooperative kernel).  SASKTRAN2_AMD_K1=wave keeps kern_kj_lane +
+// kern_k1p_wave with standard records (the parity suite compares the two).
 static bool k1_lane_enabled() {
     const char* e = std::getenv("SASKTRAN2_AMD_K1");
-    return e && std::string(e) == "lane";
+    return !(e && std::string(e) == "wave");
 }
 static void launch_k1_lane8(hipStream_t st, const Geo& g, const Bufs& b, int s, int m) {
     const dim3 grid(unsigned((b.nw + 63) / 64), unsigned(g.nlyr));
@@ -704,6 +704,12 @@ static void launch_k3(hipStream_t st, const Geo& g, const Bufs& b, int s, int m)
     int lpb = (g.nlyr + split - 1) / split;
     lpb = (lpb + NG - 1) / NG * NG;
     const int ny = (g.nlyr + lpb - 1) / lpb;
+    if constexpr (N == 8) {
+        if (b.k1_lane) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k3_wave<8, skd::RecC<8>>), dim3(unsigned(b.nw), unsigned(ny)), dim3(64), 0, st, g, b, s, m, lpb);
+            return;
+        }
+    }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k3_wave<N>), dim3(unsigned(b.nw), unsigned(ny)), dim3(64), 0, st, g, b, s, m, lpb);
 }
 
@@ -856,10 +862,15 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                 if constexpr (N == 8) {
                     // column-per-lane BVP, four wavelengths per wavefront (kern_k2a_cols8); SASKTRAN2_AMD_K2A=mfma keeps the matrix-core form
                     static const bool cols = [] { const char* e = std::getenv("SASKTRAN2_AMD_K2A"); return !(e && std::string(e) == "mfma"); }();
-                    if (cols && (nw + 3) / 4 <= 1024)   // at most one wavefront per SIMD: the spill-free instantiation
-                        hipLaunchKernelGGL(kern_k2a_cols8_lone, dim3(unsigned((nw + 3) / 4)), dim3(64), 0, st, g, b, s, m);
+                    const bool lone = (nw + 3) / 4 <= 1024;   // at most one wavefront per SIMD: the spill-free instantiation
+                    if (b.k1_lane && lone)
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_cols8_lone<skd::RecC<8>>), dim3(unsigned((nw + 3) / 4)), dim3(64), 0, st, g, b, s, m);
+                    else if (b.k1_lane)
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_cols8<skd::RecC<8>>), dim3(unsigned((nw + 3) / 4)), dim3(64), 0, st, g, b, s, m);
+                    else if (cols && lone)
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_cols8_lone<skd::Rec<8>>), dim3(unsigned((nw + 3) / 4)), dim3(64), 0, st, g, b, s, m);
                     else if (cols)
-                        hipLaunchKernelGGL(kern_k2a_cols8, dim3(unsigned((nw + 3) / 4)), dim3(64), 0, st, g, b, s, m);
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_cols8<skd::Rec<8>>), dim3(unsigned((nw + 3) / 4)), dim3(64), 0, st, g, b, s, m);
                     else
                         hipLaunchKernelGGL(kern_k2a_mfma8, dim3(unsigned(nw)), dim3(64), 0, st, g, b, s, m);
                 } else
@@ -891,7 +902,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                     // full-size launches with at most two 16-LOS tiles: the forward sweep runs inside the operator kernel (FP, SP, HD stay in
                     // registers), kern_k2b_mfma8<.., true> keeps the backward sweep; SASKTRAN2_AMD_FUSE=0 keeps the two separate kernels
                     static const bool fuse_env = [] { const char* e = std::getenv("SASKTRAN2_AMD_FUSE"); return e ? atoi(e) != 0 : true; }();
-                    const bool fused = fuse_env && !b.k1_lane && ntile <= 2 && small_batch_split(int(nw)) == 1 && g.n_lp > 0;
+                    const bool fused = fuse_env && ntile <= 2 && small_batch_split(int(nw)) == 1 && g.n_lp > 0;
                     if (g.n_lp > 0 && !flags_here) {
                         Timer t2(I, sC, "k2q_live_flags");
                         hipLaunchKernelGGL(kern_qlmask, dim3(2048), dim3(256), 0, sC, g, b, m);
@@ -903,7 +914,11 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                         int split = std::max(3, small_batch_split(int(nw)));
                         if (const char* e = std::getenv("SASKTRAN2_AMD_K2C_SPLIT")) split = std::max(1, atoi(e));
                         const int lpb = (g.nlyr + split - 1) / split, ny = (g.nlyr + lpb - 1) / lpb;
-                        if (fused && ntile == 2)
+                        if (fused && ntile == 2 && b.k1_lane)
+                            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true, 2>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);
+                        else if (fused && b.k1_lane)
+                            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true, 1>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);
+                        else if (fused && ntile == 2)
                             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<false, 2>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);
                         else if (fused)
                             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<false, 1>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);

@@ -318,15 +318,17 @@ __device__ __forceinline__ double row16_sum(double v) {
 // Xhat = T X, Uhat = T U (T = diag sqrt(w mu)):  Uhat = B+ Xhat,  Mhat_j = (2 k_j^2 xhat_j - xhat_j / mu ... ) see below,
 // z = Uhat^T Mhat,  C_aj = z_aj / (k_j^2 - k_a^2),  dXhat = Xhat C,  dUhat = (Uhat - Xhat / mu) / omega + Uhat C   (B+ dXhat = Uhat C).
 // Solution columns are processed one at a time against the resident Xhat and Uhat (128 registers pairs); B- waits in LDS
-// ([entry][lane], conflict free); a column's 49 record entries leave through a 25-double LDS staging row per lane so that the
-// stores of a record are runs of 8 doubles.  The derivative rows of G (Rec::DG) are NOT formed here: the record's DG area
-// receives the coefficient vectors coef[(type * 5 + k) * N + j] instead and kern_k2c_mfma8 forms DG = [W+; W-] coef as
-// matrix-core products where it needs them (Bufs::k1_lane).
+// ([entry][lane], conflict free).  Records are written in the COLUMN-BLOCK layout skd::RecC: the 48 doubles of solution column j are one
+// contiguous run of three 128-byte lines, staged through a 25-double LDS row per lane in two halves and stored as 16-byte pieces
+// (12 per lane and half), so every line leaves whole.  The derivative rows of G (Rec::DG) are NOT formed here: the record holds the
+// coefficient vectors coef[type * 5 + k] of every solution instead and kern_k2c_mfma8 forms DG = [W+; W-] coef as matrix-core
+// products where it needs them (Bufs::k1_lane).
 //   grid = (ceil(nw / 64), nlyr), block = 64, one wavefront per SIMD (the kernel owns the register file).
 // -------------------------------------------------------------------------------------------------------------------
 template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bufs b, int s, int m) {
-    constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, CH = 25;
-    using R = skd::Rec<N>;
+    constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, CH = 3 * N + 1, HB = 3 * N / 2;   // CH: odd staging stride; HB: 16-byte pieces per half block
+    using R = skd::RecC<N>;
+    static_assert(R::CB == 6 * N && N % 2 == 0, "two halves of 3 N doubles per column block");
     const int lane = threadIdx.x, p = blockIdx.y, nw = b.nw, nlyr = g.nlyr;
     const int w0 = blockIdx.x * 64, w = w0 + lane;
     __shared__ double sPP[NPAIR * NSTR];   // sqrt(w_i w_j / mu_i mu_j) P_{m+k}(mu_i) P_{m+k}(mu_j), pair (i >= j), k = l - m
@@ -338,6 +340,16 @@ template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bu
     if (!__any(live)) return;
     const int wl = min(w, nw - 1);
     const unsigned long long livemask = __ballot(live);
+    // 3 N staged doubles of every lane -> element `off` .. of the lanes' records, 16 bytes per store and lane
+    auto store_half = [&](int off, int count2) {
+#pragma unroll 1
+        for (int it = 0; it < HB; ++it) {
+            const int idx = lane + 64 * it, rl = idx / HB, e2 = idx - rl * HB;
+            if (e2 >= count2 || !((livemask >> rl) & 1ull)) continue;
+            const double2 v = make_double2(sOut[rl * CH + 2 * e2], sOut[rl * CH + 2 * e2 + 1]);
+            *reinterpret_cast<double2*>(skd::rec_at_r<R>(b, nlyr, p, w0 + rl) + off + 2 * e2) = v;
+        }
+    };
     {
         const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
         const double* lpc = g.lpcsz + (size_t(s) * NSTR + m) * NSTR;
@@ -520,15 +532,9 @@ template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bu
         }
         cf0[0][j] = coef[0];
         cf0[1][j] = coef[5];
-        // chunk A = W+ W- dW+ columns (24 entries), chunk B = dW- column, coefficients, scalars (25)
+        // first half of the column block: W+ W- dW+ columns; second half: dW- column, the ten coefficients, k, dk, A+, A-, dA+, dA-
         __syncthreads();
-#pragma unroll 5
-        for (int idx = lane; idx < 64 * CH; idx += 64) {
-            const int rl = idx / CH, e = idx - rl * CH;
-            if (e >= 3 * N || !((livemask >> rl) & 1ull)) continue;
-            const int f = e / N, i = e % N;
-            skd::rec_at<N>(b, nlyr, p, w0 + rl)[((f == 0) ? R::WP : (f == 1) ? R::WM : R::DWP) + N * j + i] = sOut[idx];
-        }
+        store_half(j * R::CB, HB);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < N; ++i) sOut[lane * CH + i] = dwm[i];
@@ -536,25 +542,12 @@ template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bu
         for (int t = 0; t < 10; ++t) sOut[lane * CH + N + t] = coef[t];
         sOut[lane * CH + N + 10] = kj;
         sOut[lane * CH + N + 11] = dk;
-        sOut[lane * CH + N + 12] = ej;
-        sOut[lane * CH + N + 13] = Ap;
-        sOut[lane * CH + N + 14] = Am;
-        sOut[lane * CH + N + 15] = dAp;
-        sOut[lane * CH + N + 16] = dAm;
+        sOut[lane * CH + N + 12] = Ap;
+        sOut[lane * CH + N + 13] = Am;
+        sOut[lane * CH + N + 14] = dAp;
+        sOut[lane * CH + N + 15] = dAm;
         __syncthreads();
-#pragma unroll 5
-        for (int idx = lane; idx < 64 * CH; idx += 64) {
-            const int rl = idx / CH, e = idx - rl * CH;
-            if (e >= N + 17 || !((livemask >> rl) & 1ull)) continue;
-            int dest;
-            if (e < N) dest = R::DWM + N * j + e;
-            else if (e < N + 10) dest = R::DG + (e - N) * N + j;
-            else {
-                const int f = e - N - 10;
-                dest = ((f == 0) ? R::K : (f == 1) ? R::DK : (f == 2) ? R::E : (f == 3) ? R::AP : (f == 4) ? R::AM : (f == 5) ? R::DAP : R::DAM) + j;
-            }
-            skd::rec_at<N>(b, nlyr, p, w0 + rl)[dest] = sOut[idx];
-        }
+        store_half(j * R::CB + 3 * N, HB);
     });
     // ---- particular solution at the layer edges, G[c][i] = sum_j Wsel(i, j) coef0_type(j):  W+- coef = T^-1 (Xhat coef +- Uhat (coef / k)) / 2
     //      c = 0: (W-, A- C-), 1: (W+, A- C-), 2: (W+, A+ C+), 3: (W-, A+ C+)
@@ -588,22 +581,16 @@ template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bu
             sOut[lane * CH + 2 * N + i] = hs * (gx[1][i] + gu[1][i]);
         }
         __syncthreads();
-#pragma unroll 5
-        for (int idx = lane; idx < 64 * CH; idx += 64) {
-            const int rl = idx / CH, e = idx - rl * CH;
-            if (e >= 3 * N || !((livemask >> rl) & 1ull)) continue;
-            skd::rec_at<N>(b, nlyr, p, w0 + rl)[R::G + e] = sOut[idx];
-        }
+        store_half(R::G, HB);
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < N; ++i) sOut[lane * CH + i] = 0.5 * sIt[i] * (gx[1][i] - gu[1][i]);
-        __syncthreads();
-#pragma unroll 5
-        for (int idx = lane; idx < 64 * CH; idx += 64) {
-            const int rl = idx / CH, e = idx - rl * CH;
-            if (e >= N || !((livemask >> rl) & 1ull)) continue;
-            skd::rec_at<N>(b, nlyr, p, w0 + rl)[R::G + 3 * N + e] = sOut[idx];
+        for (int i = 0; i < N; ++i) {
+            sOut[lane * CH + i] = 0.5 * sIt[i] * (gx[1][i] - gu[1][i]);
+            sOut[lane * CH + N + i] = exp(-th * (lam[i] * kj_rsqrt(lam[i])));   // exp(-k_j tau): the expression of the solution columns, formed again (no registers across them)
         }
+        __syncthreads();
+        static_assert(R::E == R::G + 4 * N, "exp(-k tau) follows G");
+        store_half(R::G + 3 * N, N);
     }
     if (live && err) atomicOr(&b.status[w], err);
 }
@@ -690,9 +677,8 @@ template <class MID> __device__ __forceinline__ int qr16_inverse_cols(double (&a
 //   with, for column c (j = c & 7, E_j = exp(-k_j tau)):   D[r][c] = -(c < 8 ? W+(r, j) : W-(r, j) E_j), D[8 + i][c] = (c < 8 ? W-(i, j) E_j : W+(i, j)),
 //   Sub_{p+1}[i][c] = (c < 8 ? W+(i, j) E_j : W-(i, j)),  S_p[i][c] = (c < 8 ? W-(i, j) : W+(i, j) E_j)
 // Vectors are distributed (entry c in lane c).  Block inverses leave in the row-major layout kern_k2c_mfma8 reads.
-__device__ __forceinline__ void k2a_cols8_body(const Geo& g, const Bufs& b, int s, int m) {
+template <class R> __device__ __forceinline__ void k2a_cols8_body(const Geo& g, const Bufs& b, int s, int m) {
     constexpr int N = 8, M2 = 16;
-    using R = skd::Rec<N>;
     const int lane = threadIdx.x, c = lane & 15, grp = lane >> 4, jc = c & 7, nw = b.nw, nlyr = g.nlyr;
     const bool lo = (c < N);
     const int w = blockIdx.x * 4 + grp;
@@ -712,17 +698,17 @@ __device__ __forceinline__ void k2a_cols8_body(const Geo& g, const Bufs& b, int 
     // column data of a layer: W+(:, j), W-(:, j), E_j and this lane's entry of G_p (rows < 8: Gplus_top, rows >= 8: Gminus_bottom)
     double wp[N], wm[N], Ec, gown, gup;   // gup: the neighbour's G entry of the right-hand side (layer above: Gplus_bottom, layer below: Gminus_top)
     auto load_layer = [&](int p, double (&wp_)[N], double (&wm_)[N], double& E_, double& g_, double& gn_) {
-        const double* rec = skd::rec_at<N>(b, nlyr, p, wl);
+        const double* rec = skd::rec_at_r<R>(b, nlyr, p, wl);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            wp_[i] = rec[R::WP + N * jc + i];
-            wm_[i] = rec[R::WM + N * jc + i];
+            wp_[i] = rec[R::wp(i, jc)];
+            wm_[i] = rec[R::wm(i, jc)];
         }
-        E_ = rec[R::E + jc];
-        g_ = lo ? rec[R::G + c] : -rec[R::G + 3 * N + jc];
+        E_ = rec[R::e(jc)];
+        g_ = lo ? rec[R::g(c)] : -rec[R::g(3 * N + jc)];
         gn_ = 0;
-        if (lo) { if (p > 0) gn_ = -skd::rec_at<N>(b, nlyr, p - 1, wl)[R::G + 2 * N + c]; }
-        else if (p < nlyr - 1) gn_ = skd::rec_at<N>(b, nlyr, p + 1, wl)[R::G + N + jc];
+        if (lo) { if (p > 0) gn_ = -skd::rec_at_r<R>(b, nlyr, p - 1, wl)[R::g(2 * N + c)]; }
+        else if (p < nlyr - 1) gn_ = skd::rec_at_r<R>(b, nlyr, p + 1, wl)[R::g(N + jc)];
     };
     load_layer(0, wp, wm, Ec, gown, gup);
     for (int p = 0; p < nlyr; ++p) {
@@ -743,12 +729,12 @@ __device__ __forceinline__ void k2a_cols8_body(const Geo& g, const Bufs& b, int 
         double rv = gown + gup;
         if (last && m == 0) {
             double gsp = 0, gsm = 0, gsg = 0;
-            const double* rec = skd::rec_at<N>(b, nlyr, p, wl);
+            const double* rec = skd::rec_at_r<R>(b, nlyr, p, wl);
 #pragma unroll
             for (int t = 0; t < N; ++t) {
                 gsp = fma(wmu[t], wp[t], gsp);
                 gsm = fma(wmu[t], wm[t], gsm);
-                gsg = fma(wmu[t], rec[R::G + 2 * N + t], gsg);
+                gsg = fma(wmu[t], rec[R::g(2 * N + t)], gsg);
             }
             const double corr = 2.0 * rho * (lo ? gsp * Ec : gsm);
 #pragma unroll
@@ -806,12 +792,12 @@ __device__ __forceinline__ void k2a_cols8_body(const Geo& g, const Bufs& b, int 
         for (int j = 0; j < M2; ++j) drow[j] = dg[c * M2 + j];
         double v = xs[c];
         if (p < nlyr - 1) {
-            const double* recn = skd::rec_at<N>(b, nlyr, p + 1, wl);
-            const double En = recn[R::E + jc];
+            const double* recn = skd::rec_at_r<R>(b, nlyr, p + 1, wl);
+            const double En = recn[R::e(jc)];
             double sx = 0;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                const double sci = lo ? recn[R::WM + N * jc + i] : recn[R::WP + N * jc + i] * En;
+                const double sci = lo ? recn[R::wm(i, jc)] : recn[R::wp(i, jc)] * En;
                 const double sm = row16_sum(sci * xn);
                 sx = (c == N + i) ? sm : sx;
             }
@@ -827,9 +813,9 @@ __device__ __forceinline__ void k2a_cols8_body(const Geo& g, const Bufs& b, int 
     }
     if (live && sing && c == 0) atomicOr(&b.status[w], skd::ERR_SINGULAR_BVP);
 }
-__global__ void __launch_bounds__(64, SKD_WPE_K2AC) kern_k2a_cols8(Geo g, Bufs b, int s, int m) { k2a_cols8_body(g, b, s, m); }
+template <class R> __global__ void __launch_bounds__(64, SKD_WPE_K2AC) kern_k2a_cols8(Geo g, Bufs b, int s, int m) { k2a_cols8_body<R>(g, b, s, m); }
 // the same with the whole register file (one wavefront per SIMD, nothing spilled to scratch) for launches that do not fill the SIMDs anyway:
 // few wavelengths per rank of a sharded run, where the layer recursion of this kernel is the critical path of the order pipeline
-__global__ void __launch_bounds__(64, 1) kern_k2a_cols8_lone(Geo g, Bufs b, int s, int m) { k2a_cols8_body(g, b, s, m); }
+template <class R> __global__ void __launch_bounds__(64, 1) kern_k2a_cols8_lone(Geo g, Bufs b, int s, int m) { k2a_cols8_body<R>(g, b, s, m); }
 
 }  // namespace skdev

@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "disco_core.hpp"
 #include "disco_lane_kernels.hpp"
 
@@ -835,10 +837,9 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2A) kern_k2a_wav
 // -------------------------------------------------------------------------------------------------------------------
 // K3: diffuse-source table values + convergence flags.  grid = wavelengths, block = 64 (lanes = table angles).
 // -------------------------------------------------------------------------------------------------------------------
-template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs b, int s, int m, int layers_per_block) {
+template <int N, class R = skd::Rec<N>> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs b, int s, int m, int layers_per_block) {
     // NG lane groups of LG lanes, one layer per group and pass (the per-layer phases only have N .. 2N lanes of work)
     constexpr int NSTR = 2 * N, NN = N * N, LG = (N >= 16) ? 32 : 16, NG = 64 / LG;
-    using R = skd::Rec<N>;
     const int w = blockIdx.x;
     if (m >= b.norders[w]) return;
     const int lane = threadIdx.x, grp = lane / LG, gl = lane % LG, nw = b.nw, nlyr = g.nlyr;
@@ -853,10 +854,10 @@ template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs 
     for (int pbase = p_begin; pbase < p_end; pbase += NG) {
         const bool valid = (pbase + grp) < p_end;
         const int p = valid ? pbase + grp : p_end - 1;
-        const double* rec = skd::rec_at<N>(b, nlyr, p, w);
+        const double* rec = skd::rec_at_r<R>(b, nlyr, p, w);
         const double* xs = skd::xsol_at<N>(b, nlyr, p, w);
-        for (int i = gl; i < N; i += LG) { sK[i] = rec[R::K + i]; sAP[i] = rec[R::AP + i]; sAM[i] = rec[R::AM + i]; }
-        for (int i = gl; i < 2 * NN; i += LG) sW[i] = rec[R::WP + i];
+        for (int i = gl; i < N; i += LG) { sK[i] = rec[R::k(i)]; sAP[i] = rec[R::ap(i)]; sAM[i] = rec[R::am(i)]; }
+        for (int i = gl; i < 2 * NN; i += LG) sW[i] = rec[(i < NN) ? R::wp(i % N, i / N) : R::wm(i % N, (i - NN) / N)];   // sW: W+(i, j) at i + N j, then W-
         for (int i = gl; i < 2 * N; i += LG) sXs[i] = xs[i];
         double th;
         if constexpr (N == 8) {
@@ -875,9 +876,9 @@ template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs 
         __syncthreads();
         if (gl < N) {
             skd::PPMult pm;
-            const double Ej = rec[R::E + gl];  // exp(-k_j th), written by K1;  exp(-k (th - x)) = E / exp(-k x)
+            const double Ej = rec[R::e(gl)];  // exp(-k_j th), written by K1;  exp(-k (th - x)) = E / exp(-k x)
             skd::pp_multipliers_e(T, th, sc, sK[gl], lf, sEx[gl], Ej / sEx[gl], sEx[N], sEx[N + 1], pm);
-            if (valid) skd::ppm_store(skd::rec_at<N>(b, nlyr, p, w) + R::PPM + 14 * gl, pm);
+            if (valid) skd::ppm_store(skd::rec_at_r<R>(b, nlyr, p, w) + R::ppm(gl), pm);
             sCL[gl] = pm.hp * sXs[gl] + sAP[gl] * pm.Dm;
             sCM[gl] = pm.hm * sXs[N + gl] + sAM[gl] * pm.Dp;
         }
@@ -925,9 +926,9 @@ template <int N> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs 
         // upwelling diffuse reflection of the Lambertian surface (bottom layer, order 0): uniform over the group
         const bool ground = valid && (p == nlyr - 1) && (m == 0);
         if (ground && gl < N) {
-            double sv = rec[R::G + 2 * N + gl];
+            double sv = rec[R::g(2 * N + gl)];
             for (int j = 0; j < N; ++j)
-                sv += sXs[j] * sW[gl + N * j] * rec[R::E + j] + sXs[N + j] * sW[NN + gl + N * j];
+                sv += sXs[j] * sW[gl + N * j] * rec[R::e(j)] + sXs[N + j] * sW[NN + gl + N * j];
             sRed[gl] = 2.0 * g.mu[gl] * g.wt[gl] * sv * b.albedo[w];
         }
         __syncthreads();
@@ -1400,12 +1401,14 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2AM) kern_k2a_mfma8(Geo g, Bufs b
 #endif
 template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b, int s, int m, int layers_per_block) {
     constexpr int N = 8, NSTR = 16, M2 = 16, FT = (FTILES > 0) ? FTILES : 1;
-    using R = skd::Rec<N>;
+    using R = std::conditional_t<K1LANE, skd::RecC<N>, skd::Rec<N>>;       // kern_k1_lane writes column-block records
+    using RL = std::conditional_t<K1LANE, skd::RecC<N, 1>, skd::Rec<N>>;   // the record's image in LDS (column blocks padded by one double)
     using O = skd::Ops<N>;
     const int w = blockIdx.x;
     if (m >= b.norders[w]) return;
     const int lane = threadIdx.x, col = lane & 15, q = lane >> 4, jc = col & 7, nw = b.nw, nlyr = g.nlyr;
-    __shared__ double sRec[R::SIZE];
+    __shared__ double sRec[RL::SIZE];
+    __shared__ double sDG[K1LANE ? 16 * N : 1];   // K1LANE: the derivative rows of G, formed below
     __shared__ double sXs[M2], sTmp[M2], sIpb[N], sDIpb[4 * N];
     __shared__ double sHD[4 * NSTR], sUG[M2];
     // ---- state of the fused forward sweep (FTILES > 0), as in kern_k2b_mfma8
@@ -1433,6 +1436,10 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
             }
         }
     }
+    auto dgv = [&](int x) -> double {   // derivative rows of G: in the record (cooperative K1) or formed below (kern_k1_lane's records)
+        if constexpr (K1LANE) return sDG[x];
+        else return sRec[R::DG + x];
+    };
     const double rho = (m == 0) ? b.albedo[w] : 0.0;
     // Legendre sums as a 16 x 16 product:  [YP; YM] = [W+^T W-^T; W-^T W+^T] [P sg; P],  P[r][l] = 1/2 w_r omega a_l P_l^m(mu_r);
     // this lane's B operand rows are r = q and r = q + 4 of column l = col (constant over the layers up to omega a_l)
@@ -1442,7 +1449,7 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
     const int p_begin = blockIdx.y * layers_per_block, p_end = min(nlyr, p_begin + layers_per_block);
     for (int p = p_begin; p < p_end; ++p) {
         const bool last = (p == nlyr - 1);
-        const double* rec = skd::rec_at<N>(b, nlyr, p, w);
+        const double* rec = skd::rec_at_r<R>(b, nlyr, p, w);
         const double* dg = skd::dinv_at<N>(b, nlyr, p, w);
         const double* xs = skd::xsol_at<N>(b, nlyr, p, w);
         double* o = skd::ops_at<N>(b, nlyr, p, w);
@@ -1454,7 +1461,12 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
 #pragma unroll
             for (int u = 0; u < RU; ++u) stage[u] = (lane + 64 * u < R::SIZE) ? rec[lane + 64 * u] : 0.0;
 #pragma unroll
-            for (int u = 0; u < RU; ++u) if (lane + 64 * u < R::SIZE) sRec[lane + 64 * u] = stage[u];
+            for (int u = 0; u < RU; ++u) {
+                const int e = lane + 64 * u;
+                int at = e;
+                if constexpr (K1LANE) at = e + min(e / R::CB, N);   // one double of padding behind every column block
+                if (e < R::SIZE) sRec[at] = stage[u];
+            }
         }
         if (lane < M2) sXs[lane] = xs[lane];
         double dinv_b[4];  // B operand of the Dinv chains: Dinv[4 kk + (lane >> 4)][lane & 15] = dg[64 kk + lane]
@@ -1472,10 +1484,10 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
             double aw[2], ad[2], bb[2], b2[2];
             for (int kk = 0; kk < 2; ++kk) {
                 const int j = 4 * kk + q;
-                aw[kk] = (col < N) ? sRec[R::WP + col + N * j] : sRec[R::WM + (col - N) + N * j];
-                ad[kk] = (col < N) ? sRec[R::DWP + col + N * j] : sRec[R::DWM + (col - N) + N * j];
-                bb[kk] = (col < 10) ? sRec[R::DG + col * N + j] : 0.0;
-                b2[kk] = (col == 1 + skd::TH_OM) ? sRec[R::DG + j] : (col == 6 + skd::TH_OM) ? sRec[R::DG + 5 * N + j] : 0.0;
+                aw[kk] = (col < N) ? sRec[RL::wp(col, j)] : sRec[RL::wm(col - N, j)];
+                ad[kk] = (col < N) ? sRec[RL::dwp(col, j)] : sRec[RL::dwm(col - N, j)];
+                bb[kk] = (col < 10) ? sRec[RL::coef(col, j)] : 0.0;
+                b2[kk] = (col == 1 + skd::TH_OM) ? sRec[RL::coef(0, j)] : (col == 6 + skd::TH_OM) ? sRec[RL::coef(5, j)] : 0.0;
             }
             for (int kk = 0; kk < 2; ++kk) D = mfma16(aw[kk], bb[kk], D);
             for (int kk = 0; kk < 2; ++kk) D = mfma16(ad[kk], b2[kk], D);
@@ -1485,7 +1497,7 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
                 for (int r = 0; r < 4; ++r) {
                     const int row = q + 4 * r, sel = row >> 3, i = row & 7;
                     const int c = (type == 0) ? (sel ? 0 : 1) : (sel ? 3 : 2);
-                    sRec[R::DG + ((k - 1) * 4 + c) * N + i] = D[r];
+                    sDG[((k - 1) * 4 + c) * N + i] = D[r];
                 }
             }
             __syncthreads();
@@ -1494,10 +1506,10 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
         mf4 Y = {0, 0, 0, 0}, DY = {0, 0, 0, 0};
         {
             const bool hi = (col >= N);
-            const double wp0 = sRec[R::WP + q + N * jc], wp1 = sRec[R::WP + 4 + q + N * jc];
-            const double wm0 = sRec[R::WM + q + N * jc], wm1 = sRec[R::WM + 4 + q + N * jc];
-            const double dp0 = sRec[R::DWP + q + N * jc] + wp0 * inv_om, dp1 = sRec[R::DWP + 4 + q + N * jc] + wp1 * inv_om;
-            const double dm0 = sRec[R::DWM + q + N * jc] + wm0 * inv_om, dm1 = sRec[R::DWM + 4 + q + N * jc] + wm1 * inv_om;
+            const double wp0 = sRec[RL::wp(q, jc)], wp1 = sRec[RL::wp(4 + q, jc)];
+            const double wm0 = sRec[RL::wm(q, jc)], wm1 = sRec[RL::wm(4 + q, jc)];
+            const double dp0 = sRec[RL::dwp(q, jc)] + wp0 * inv_om, dp1 = sRec[RL::dwp(4 + q, jc)] + wp1 * inv_om;
+            const double dm0 = sRec[RL::dwm(q, jc)] + wm0 * inv_om, dm1 = sRec[RL::dwm(4 + q, jc)] + wm1 * inv_om;
             const double c0 = pc0 * om * al, c1 = pc1 * om * al;
             const double bP[4] = {sg * c0, sg * c1, c0, c1};
             const double aW[4] = {hi ? wm0 : wp0, hi ? wm1 : wp1, hi ? wp0 : wm0, hi ? wp1 : wm1};
@@ -1513,12 +1525,12 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
         for (int jx = 0; jx < 2; ++jx) {
             const int j = q + 4 * jx;
             skd::PPMult pm;
-            skd::ppm_load(&sRec[R::PPM + 14 * j], pm);
+            skd::ppm_load(&sRec[RL::ppm(j)], pm);
             const double yp = Y[jx], ym = Y[2 + jx], dyp = DY[jx], dym = DY[2 + jx];
             Fr[jx] = yp * pm.hp * inv_om;
             Fr[2 + jx] = ym * pm.hm * inv_om;
-            const double L = sXs[j], Mv = sXs[N + j], dk = sRec[R::DK + j];
-            const double Ap = sRec[R::AP + j], Am = sRec[R::AM + j], dAp = sRec[R::DAP + j], dAm = sRec[R::DAM + j];
+            const double L = sXs[j], Mv = sXs[N + j], dk = sRec[RL::dk(j)];
+            const double Ap = sRec[RL::ap(j)], Am = sRec[RL::am(j)], dAp = sRec[RL::dap(j)], dAm = sRec[RL::dam(j)];
             const double tL = pm.hp * L + Ap * pm.Dm, tM = pm.hm * Mv + Am * pm.Dp;
             val += yp * tL + ym * tM;
             hd[skd::TH_TAU] += yp * (pm.hp_tau * L + Ap * pm.Dm_tau) + ym * (pm.hm_tau * Mv + Am * pm.Dp_tau);
@@ -1541,8 +1553,8 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
         mf4 x1, x2;
         {
             const bool sup = (col < N);
-            const double wm0 = sRec[R::WM + jc + N * q], wm1 = sRec[R::WM + jc + N * (q + 4)];
-            const double we0 = sRec[R::WP + jc + N * q] * sRec[R::E + q], we1 = sRec[R::WP + jc + N * (q + 4)] * sRec[R::E + q + 4];
+            const double wm0 = sRec[RL::wm(jc, q)], wm1 = sRec[RL::wm(jc, q + 4)];
+            const double we0 = sRec[RL::wp(jc, q)] * sRec[RL::e(q)], we1 = sRec[RL::wp(jc, q + 4)] * sRec[RL::e(q + 4)];
             // [SupT | SubT][jj][c']: SupT[j][c] = W-(c,j), SupT[N+j][c] = W+(c,j) E_j ; SubT[j][c] = W+(c,j) E_j, SubT[N+j][c] = W-(c,j)
             const double aS[4] = {sup ? wm0 : we0, sup ? wm1 : we1, sup ? we0 : wm0, sup ? we1 : wm1};
             x1 = mf4{0, 0, 0, 0};
@@ -1562,20 +1574,20 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
         // ---- edge-intensity derivatives at fixed (L, M): lanes (i, e)
         for (int idx = lane; idx < 4 * N; idx += 64) {
             const int i = idx / 4, e = idx % 4;
-            double d_tau = 0, d_om = 0, ipb_i = sRec[R::G + 2 * N + i];
+            double d_tau = 0, d_om = 0, ipb_i = sRec[RL::g(2 * N + i)];
             for (int j = 0; j < N; ++j) {
-                const double wp = sRec[R::WP + i + N * j], wm = sRec[R::WM + i + N * j];
-                const double dwp = sRec[R::DWP + i + N * j], dwm = sRec[R::DWM + i + N * j];
-                const double E = sRec[R::E + j], L = sXs[j], Mv = sXs[N + j];
-                const double dE_tau = -sRec[R::K + j] * E, dE_om = -sRec[R::DK + j] * th * E;
+                const double wp = sRec[RL::wp(i, j)], wm = sRec[RL::wm(i, j)];
+                const double dwp = sRec[RL::dwp(i, j)], dwm = sRec[RL::dwm(i, j)];
+                const double E = sRec[RL::e(j)], L = sXs[j], Mv = sXs[N + j];
+                const double dE_tau = -sRec[RL::k(j)] * E, dE_om = -sRec[RL::dk(j)] * th * E;
                 if (e == 0) { d_tau += wm * dE_tau * Mv; d_om += dwp * L + dwm * E * Mv + wm * dE_om * Mv; }
                 if (e == 1) { d_tau += wp * dE_tau * Mv; d_om += dwm * L + dwp * E * Mv + wp * dE_om * Mv; }
                 if (e == 2) { d_tau += wp * dE_tau * L; d_om += dwp * E * L + wp * dE_om * L + dwm * Mv; ipb_i += wp * E * L + wm * Mv; }
                 if (e == 3) { d_tau += wm * dE_tau * L; d_om += dwm * E * L + wm * dE_om * L + dwp * Mv; }
             }
-            const double v_tau = sRec[R::DG + (skd::TH_TAU * 4 + e) * N + i] + d_tau;
-            const double v_om = sRec[R::DG + (skd::TH_OM * 4 + e) * N + i] + d_om;
-            const double v_T = sRec[R::DG + (skd::TH_T * 4 + e) * N + i], v_sec = sRec[R::DG + (skd::TH_SEC * 4 + e) * N + i];
+            const double v_tau = dgv((skd::TH_TAU * 4 + e) * N + i) + d_tau;
+            const double v_om = dgv((skd::TH_OM * 4 + e) * N + i) + d_om;
+            const double v_T = dgv((skd::TH_T * 4 + e) * N + i), v_sec = dgv((skd::TH_SEC * 4 + e) * N + i);
             o[O::DI + (skd::TH_TAU * 4 + e) * N + i] = v_tau;
             o[O::DI + (skd::TH_OM * 4 + e) * N + i] = v_om;
             o[O::DI + (skd::TH_T * 4 + e) * N + i] = v_T;
@@ -1593,10 +1605,10 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
             double sp = 0, sm = 0;
             if (last && m == 0)
                 for (int i = 0; i < N; ++i) {
-                    sp += g.mu[i] * g.wt[i] * sRec[R::WP + i + N * lane];
-                    sm += g.mu[i] * g.wt[i] * sRec[R::WM + i + N * lane];
+                    sp += g.mu[i] * g.wt[i] * sRec[RL::wp(i, lane)];
+                    sm += g.mu[i] * g.wt[i] * sRec[RL::wm(i, lane)];
                 }
-            sTmp[lane] = 2.0 * rho * sp * sRec[R::E + lane];
+            sTmp[lane] = 2.0 * rho * sp * sRec[RL::e(lane)];
             sTmp[N + lane] = 2.0 * rho * sm;
         }
         __syncthreads();

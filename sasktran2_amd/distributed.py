@@ -67,6 +67,8 @@ class ShardedSolver:
         self.solver, self.nwavel, self.derivatives = solver, nwavel, derivatives
         self.world = _world()
         self.rank = dist.get_rank() if self.world > 1 else 0
+        if self.world > nwavel:   # (the same on every rank: all of them refuse; a rank without wavelengths has nothing to solve)
+            raise ValueError(f"more ranks than wavelengths ({self.world} > {nwavel})")
         self.lo, self.hi = shard_bounds(nwavel, self.rank, self.world)
         self.rows = rows_per_rank(nwavel, self.world)
         self.local = torch.zeros((self.rows, solver.slab_row_doubles(derivatives)), dtype=torch.float64, device=device)

@@ -86,3 +86,56 @@ def test_sharded_host_entry_point_with_a_one_rank_communicator():
     sharded = engine.calculate_radiance(atmosphere, as_dataset=False, shard=(comm, 0, 1))
     for k in ("radiance", "los_optical_depth", "wf_extinction", "wf_ssa", "wf_albedo"):
         np.testing.assert_array_equal(sharded[k], plain[k], err_msg=k)
+
+
+def test_sharded_host_entry_point_partition_arithmetic_on_one_gpu():
+    """The sharded host entry point's slicing (offsets > 0 of extinction, ssa, Legendre coefficients, albedo, delta-M fractions, every
+    derivative mapping), packing and unpacking with the three ranks of an UNEVEN partition of seven wavelengths played in turn by this
+    process (sk_amd_engine_calculate_radiance_sharded_emulated: the entry point's own functions, the all-gather replaced by memcpy): bit
+    for bit the plain call -- also with delta-M scaling, where the truncation fractions are sliced too."""
+    import sasktran2_amd as sk
+    from tests.gpu_harness import build_engine
+    nw = 7
+    for delta_m in (False, True):
+        s = sc.limb_c2(num_wavelengths=nw)
+        if delta_m:
+            s = dict(s, leg=np.concatenate([s["leg"], 0.3 * s["leg"][-4:]], axis=0))   # 20 stored moments for 16 streams
+        engine, config, geometry = build_engine(s)
+        config.delta_m_scaling = delta_m
+        atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=True)
+        atmosphere.storage.total_extinction[:] = s["extinction"]
+        atmosphere.storage.ssa[:] = s["ssa"]
+        atmosphere.leg_coeff.a1[:] = s["leg"]
+        atmosphere.surface.albedo[:] = s["albedo"]
+        plain = engine.calculate_radiance(atmosphere, as_dataset=False)
+        for world in (3, 7):
+            sharded = engine.calculate_radiance(atmosphere, as_dataset=False, shard=("emulate", world, -1))
+            for k in ("radiance", "los_optical_depth", "wf_extinction", "wf_ssa", "wf_albedo"):
+                np.testing.assert_array_equal(sharded[k], plain[k], err_msg=f"{k} world={world} delta_m={delta_m}")
+
+
+def test_sharded_host_entry_point_reports_a_failing_rank_on_every_rank():
+    """A rank whose local solve fails still contributes its (zeroed) slab with a status word; after the exchange EVERY rank returns that
+    rank's code and names it -- nobody is left waiting in the collective.  Emulated ranks: (1) a simulated failure of rank 1, (2) a real
+    one: a non-physical single-scatter albedo in the last rank's shard only.  More ranks than wavelengths and flux derivative outputs are
+    refused before anything is solved."""
+    import sasktran2_amd as sk
+    from tests.gpu_harness import build_engine
+    nw = 5
+    s = sc.limb_c2(num_wavelengths=nw)
+    engine, config, geometry = build_engine(s)
+    atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=True)
+    atmosphere.storage.total_extinction[:] = s["extinction"]
+    atmosphere.storage.ssa[:] = s["ssa"]
+    atmosphere.leg_coeff.a1[:] = s["leg"]
+    atmosphere.surface.albedo[:] = s["albedo"]
+    with pytest.raises(RuntimeError, match="rank 1 failed"):
+        engine.calculate_radiance(atmosphere, as_dataset=False, shard=("emulate", 3, 1))
+    atmosphere.storage.ssa[3, nw - 1] = 1.5
+    with pytest.raises(RuntimeError, match="rank 2 failed"):
+        engine.calculate_radiance(atmosphere, as_dataset=False, shard=("emulate", 3, -1))
+    atmosphere.storage.ssa[3, nw - 1] = s["ssa"][3, nw - 1]
+    with pytest.raises(RuntimeError, match="more ranks than wavelengths"):
+        engine.calculate_radiance(atmosphere, as_dataset=False, shard=("emulate", nw + 1, -1))
+    ok = engine.calculate_radiance(atmosphere, as_dataset=False, shard=("emulate", 2, -1))
+    assert np.all(np.isfinite(ok["radiance"]))

@@ -261,6 +261,27 @@ def test_c2_wavelength_blocks_in_flight_are_equivalent(monkeypatch):
             assert np.array_equal(one[k], other[k]), (split, k)
 
 
+def test_c2_lane_per_problem_layer_solutions_equal_the_cooperative_kernel(monkeypatch):
+    """16 streams: the layer solutions one (layer, wavelength) per lane with column-block records (kern_k1_lane, the default) against the
+    cooperative kernel with standard records (SASKTRAN2_AMD_K1=wave): the same equations in another order of operations -- radiances to
+    1e-12, weighting functions to 1e-9 of the profile maximum --, full-size launch shape (fused adjoint kernel) and the small-batch split."""
+    for nw, split in ((2100, None), (300, "4")):
+        s = sc.limb_c2(num_wavelengths=nw)
+        if split:
+            monkeypatch.setenv("SASKTRAN2_AMD_SPLIT", split)
+        monkeypatch.delenv("SASKTRAN2_AMD_K1", raising=False)
+        lane = run_product(s)
+        monkeypatch.setenv("SASKTRAN2_AMD_K1", "wave")
+        wave = run_product(s)
+        monkeypatch.delenv("SASKTRAN2_AMD_K1")
+        monkeypatch.delenv("SASKTRAN2_AMD_SPLIT", raising=False)
+        np.testing.assert_allclose(lane["radiance"], wave["radiance"], rtol=1e-12)
+        for k in ("d_extinction", "d_ssa"):
+            scale = np.abs(wave[k]).max(axis=2, keepdims=True)
+            assert np.max(np.abs(lane[k] - wave[k]) / scale) < 1e-9, (k, nw)
+        np.testing.assert_allclose(lane["d_albedo"], wave["d_albedo"], rtol=1e-9)
+
+
 def test_c2_two_solar_zenith_points_matches_oracle():
     s = sc.limb_c2(num_wavelengths=2, num_sza=2)
     assert_parity(run_product(s), run_oracle(s, derivatives=True))
