@@ -76,8 +76,16 @@ struct ViewingGeometry {
 struct DerivativeMapping {
     int nloc = 0, nwavel = 0, nleg = 0;
     std::vector<double> d_ssa, d_extinction;
-    // stored only (deriv_mapping.h:15-53); a mapping that uses them is refused by sk_engine_calculate_radiance
+    // scattering-group / emission arrays (deriv_mapping.h:15-53): allocated when the caller first asks for one of them (ensure_optional) --
+    // the 16 Legendre rows of a 10 000-wavelength mapping are 65 MB that a plain extinction / ssa mapping never touches, and every call
+    // scans them for a scattering group.  Empty = all zero.
     std::vector<double> scat_factor, d_legendre, d_emission;
+    void ensure_optional() {
+        const size_t n = size_t(nloc) * nwavel;
+        if (scat_factor.size() != n) scat_factor.assign(n, 0.0);
+        if (d_emission.size() != n) d_emission.assign(n, 0.0);
+        if (d_legendre.size() != n * nleg) d_legendre.assign(n * nleg, 0.0);
+    }
     std::vector<double> d_f;   // [nloc * nwavel] derivative of the delta-M truncation fraction along this scattering group (set by the scaling)
     int scat_deriv_index = -1, log_radiance_space = 0;
     std::string interp_dim = "altitude", assign_name;
@@ -295,6 +303,26 @@ __global__ void __launch_bounds__(256) kern_ts_scat_group(const double* wb1, con
         dst[i] = wb1[i] * d;
     }
 }
+// Host -> device copy of the caller's input arrays.  Page-locked host memory (sk_amd_host_alloc, hipHostMalloc, hipHostRegister) is visible
+// to the device: a streaming kernel reads it over the host link and writes HBM -- no copy-engine round trip (measured under PyTorch's HIP
+// runtime: the FIRST hipMemcpy of a call waited 14-24 ms for the copy engine to wake up, whatever its size; tools/probes/host_path_phases.py).
+// Ordinary (pageable) memory goes through hipMemcpy as before.
+__global__ void __launch_bounds__(256) kern_copy_in(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+    const size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = __builtin_nontemporal_load(&src[i]);
+}
+static void upload_doubles(double* dst, const double* src, size_t n) {
+    if (n == 0) return;
+    hipPointerAttribute_t at{};
+    if (n >= 4096 && hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+        hipLaunchKernelGGL(kern_copy_in, dim3(unsigned(std::min<size_t>(2048, (n + 255) / 256))), dim3(256), 0, nullptr,
+                           static_cast<const double*>(at.devicePointer), dst, n);
+        HIPC(hipGetLastError());
+        return;   // (stream order: the kernels of the solve follow on the same stream)
+    }
+    (void)hipGetLastError();   // (an unregistered pointer makes hipPointerGetAttributes fail: that is the pageable case)
+    HIPC(hipMemcpy(dst, src, n * 8, hipMemcpyDefault));
+}
 __global__ void __launch_bounds__(256) kern_transpose_od(const double* od, double* out, int nw, int nlos) {
     const size_t n = size_t(nw) * nlos;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
@@ -390,9 +418,6 @@ int sk_atmosphere_storage_get_derivative_mapping(AtmosphereStorage* s, const cha
         dm->d_ssa.assign(size_t(s->nloc) * s->nwavel, 0.0);
         dm->d_extinction.assign(size_t(s->nloc) * s->nwavel, 0.0);
         dm->nleg = s->nleg;
-        dm->scat_factor.assign(size_t(s->nloc) * s->nwavel, 0.0);
-        dm->d_emission.assign(size_t(s->nloc) * s->nwavel, 0.0);
-        dm->d_legendre.assign(size_t(s->nleg) * s->nloc * s->nwavel, 0.0);
         dm->assign_name = name;
         it = s->maps.emplace(name, std::move(dm)).first;
         s->names.push_back(name);
@@ -1117,14 +1142,18 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         double* d_odt = (double*)C.get("los_od_t", nt * 8);
         int* d_status = (int*)C.get("status", size_t(nw) * 4);
         double *d_irr = nullptr, *d_we = nullptr, *d_ws = nullptr, *d_wa = nullptr;
-        HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyDefault));
-        HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyDefault));
-        HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyDefault));
+        ph.mark("buffers");
+        upload_doubles(d_ext, st.ext, nloc_w);
+        upload_doubles(d_ssa, st.ssa, nloc_w);
+        ph.mark("ext ssa up");
+        upload_doubles(d_leg, st.leg, nloc_w * st.nleg);
+        ph.mark("leg up");
         HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyDefault));
         if (st.irradiance) {
             d_irr = (double*)C.get("irradiance", size_t(nw) * 8);
             HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyDefault));
         }
+        ph.mark("albedo irradiance up");
         if (derivs) {
             d_we = (double*)C.get("wf_ext", size_t(ngrid) * nt * 8);
             d_ws = (double*)C.get("wf_ssa", size_t(ngrid) * nt * 8);
@@ -1294,7 +1323,9 @@ int sk_amd_engine_scratch_bytes(Engine* e, int nwavel, unsigned long long* bytes
 }
 void* sk_amd_host_alloc(unsigned long long bytes) {
     void* p = nullptr;
-    if (bytes == 0 || hipHostMalloc(&p, size_t(bytes), hipHostMallocDefault) != hipSuccess) {
+    unsigned flags = hipHostMallocDefault;
+    if (const char* e = std::getenv("SASKTRAN2_AMD_HOST_FLAGS")) flags = unsigned(strtoul(e, nullptr, 0));   // (experiments: coherent / non-coherent / write-combined)
+    if (bytes == 0 || hipHostMalloc(&p, size_t(bytes), flags) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }

@@ -28,14 +28,17 @@
 #ifndef SKD_WPE_K2BM
 #define SKD_WPE_K2BM 4
 #endif
-// (3 since the forward sweep runs inside kern_k2c_mfma8: at 128 registers the fused kernel spills 33 -- 79 with the next layer's record
-// requested ahead -- and loses: 76 k wavelengths/s at 4 waves per SIMD, 86 k at 3 without the look-ahead, measured on MI355X)
+// (round 3: 3 -- at 128 registers the fused kernel spilled 33 and lost: 76 k wavelengths/s at 4 waves per SIMD, 86 k at 3.  Round 4: 2.  The
+// kernel is bound by instruction issue (about 1 500 instructions per layer of which 280 are FP64 / matrix-core work: per-phase counts
+// from the assembly between the clock64 stamps of SKD_K2C_TIMING), not by memory latency -- the next layer's inputs arrive by LDS-DMA --,
+// so a third wavefront buys nothing and costs the registers: 41.3 ms per step alone at 3 with 12 spilled, 37.2 ms at 2 with none)
 #ifndef SKD_WPE_K2CM
-#define SKD_WPE_K2CM 3
+#define SKD_WPE_K2CM 2
 #endif
 #ifndef SKD_K1_LG
 #define SKD_K1_LG 16
 #endif
+
 #ifndef SKD_WPE_K1
 #define SKD_WPE_K1 2
 #endif
@@ -62,6 +65,11 @@ namespace skdev {
 
 using skd::Bufs;
 using skd::Geo;
+
+// Ordering of LDS writes and reads between the lanes of a ONE-WAVEFRONT block (every kernel that calls it is launched with 64 threads):
+// the LDS serves a wavefront's requests in order, so it is enough to wait for them (and to keep the compiler from moving memory
+// operations across).  __syncthreads() would add a workgroup fence that drains the global loads, stores and LDS-DMA requests in flight.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // -------------------------------------------------------------------------------------------------------------------
 // K1: homogeneous + particular solution of every layer.  grid = wavelengths, block = 64 lanes = NG lane groups of LG
@@ -869,11 +877,11 @@ template <int N, class R = skd::Rec<N>> __global__ void __launch_bounds__(64) ke
             th = b.tau[size_t(p) * nw + w];
         }
         const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
-        __syncthreads();
+        wave_lds_sync();
         // exponentials of the layer in one instruction stream: exp(-k_j x) (lanes < N), exp(-sec x), exp(-sec th);  x = th lfrac
         const double lf = g.lfrac[p];
         if (gl < N + 2) sEx[gl] = exp(-((gl < N) ? sK[gl] : sc) * ((gl == N + 1) ? th : th * lf));
-        __syncthreads();
+        wave_lds_sync();
         if (gl < N) {
             skd::PPMult pm;
             const double Ej = rec[R::e(gl)];  // exp(-k_j th), written by K1;  exp(-k (th - x)) = E / exp(-k x)
@@ -882,7 +890,7 @@ template <int N, class R = skd::Rec<N>> __global__ void __launch_bounds__(64) ke
             sCL[gl] = pm.hp * sXs[gl] + sAP[gl] * pm.Dm;
             sCM[gl] = pm.hm * sXs[N + gl] + sAM[gl] * pm.Dp;
         }
-        __syncthreads();
+        wave_lds_sync();
         if (gl < N) {
             double pr = 0, qr = 0;
             for (int j = 0; j < N; ++j) {
@@ -893,7 +901,7 @@ template <int N, class R = skd::Rec<N>> __global__ void __launch_bounds__(64) ke
             sP[gl] = pr * 0.5 * g.wt[gl];
             sQ[gl] = qr * 0.5 * g.wt[gl];
         }
-        __syncthreads();
+        wave_lds_sync();
         for (int l = gl; l < NSTR; l += LG) {
             double sp = 0, sq = 0;
             if (l >= m)
@@ -903,7 +911,7 @@ template <int N, class R = skd::Rec<N>> __global__ void __launch_bounds__(64) ke
                 }
             sCleg[l] = sa[l] * ((((l - m) & 1) ? -sp : sp) + sq);
         }
-        __syncthreads();
+        wave_lds_sync();
         // (the thermal pass runs with the extra solar index s = nsza, which has no diffuse table: only the record entries above are needed)
         if (valid && s < g.nsza) {
             const int t0 = g.pt_start[s * nlyr + p], t1 = g.pt_start[s * nlyr + p + 1];
@@ -931,13 +939,13 @@ template <int N, class R = skd::Rec<N>> __global__ void __launch_bounds__(64) ke
                 sv += sXs[j] * sW[gl + N * j] * rec[R::e(j)] + sXs[N + j] * sW[NN + gl + N * j];
             sRed[gl] = 2.0 * g.mu[gl] * g.wt[gl] * sv * b.albedo[w];
         }
-        __syncthreads();
+        wave_lds_sync();
         if (ground && s < g.nsza) {
             double diffuse = 0;
             for (int i = 0; i < N; ++i) diffuse += sRed[i];
             for (int t = g.gpt_start[s] + gl; t < g.gpt_start[s + 1]; t += LG) skd::J_at(b, g, m, g.gpt_slot[t], w) = diffuse;
         }
-        __syncthreads();
+        wave_lds_sync();
     }
     if (__any(unconverged) && lane == 0) b.notconv[w] = 1;
 }
@@ -1385,8 +1393,8 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2AM) kern_k2a_mfma8(Geo g, Bufs b
 // K2c for N = 8.  Same operators as skd::k2c_layer_ops; FP, SP and BP are stored as ready-made A-operand images
 // (FP: k-step r at [FP + 64 r + lane], r < 4;  SP / BP: [SP + 64 r + lane], [BP + 64 r + lane], r < 2) for kern_k2b_mfma8.
 //   FP^T = F^T Dinv  and  [SP | BP]^T = [SupT | SubT]^T Dinv  are two chains of four matrix-core products.
-// K1LANE: the records come from kern_k1_lane (Rec::DG holds the coefficient vectors, DG is formed here); a template parameter, not a
-// run-time branch, so that the usual path does not carry the registers of the extra products
+// K1LANE: the records come from kern_k1_lane (column blocks with the coefficient vectors of the particular solution; the derivative rows
+// of G are formed here, along the loop that needs them); a template parameter, not a run-time branch
 // FTILES > 0 (full-size launches, up to 32 lines of sight): the FORWARD sweep of the adjoint (kern_k2b_mfma8's first half) runs inside this
 // kernel, layer by layer, with FP, SP and HD taken from the registers they are formed in -- they never go to HBM (-26 % of the adjoint
 // stage's traffic); only what the backward sweep needs (BP, DI, UG, GD, IPB) is written, and kern_k2b_mfma8<TILES, true> does the backward
@@ -1402,14 +1410,18 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2AM) kern_k2a_mfma8(Geo g, Bufs b
 template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b, int s, int m, int layers_per_block) {
     constexpr int N = 8, NSTR = 16, M2 = 16, FT = (FTILES > 0) ? FTILES : 1;
     using R = std::conditional_t<K1LANE, skd::RecC<N>, skd::Rec<N>>;       // kern_k1_lane writes column-block records
-    using RL = std::conditional_t<K1LANE, skd::RecC<N, 1>, skd::Rec<N>>;   // the record's image in LDS (column blocks padded by one double)
+    // the record's image in LDS: column blocks 52 doubles apart (104 dwords = 40 mod 64: the eight solutions' entries fall on eight different
+    // bank windows; 48 puts them on two)
+    using RL = std::conditional_t<K1LANE, skd::RecC<N, 4>, skd::Rec<N>>;
+    constexpr int NB = K1LANE ? 2 : 1;   // K1LANE: two record buffers, the next layer's record arrives by LDS-DMA while this one is worked on
     using O = skd::Ops<N>;
     const int w = blockIdx.x;
     if (m >= b.norders[w]) return;
     const int lane = threadIdx.x, col = lane & 15, q = lane >> 4, jc = col & 7, nw = b.nw, nlyr = g.nlyr;
-    __shared__ double sRec[RL::SIZE];
-    __shared__ double sDG[K1LANE ? 16 * N : 1];   // K1LANE: the derivative rows of G, formed below
-    __shared__ double sXs[M2], sTmp[M2], sIpb[N], sDIpb[4 * N];
+    __shared__ double sRecAll[NB * RL::SIZE];
+    // per buffer: the BVP solution (16) and, K1LANE, a_l (16), omega, tau, T of the layer behind it
+    __shared__ double sSmall[NB * 36], sTmp[M2], sIpb[N], sDIpb[4 * N];
+    __shared__ double sDinv[K1LANE ? M2 * M2 : 1];   // K1LANE: block inverse
     __shared__ double sHD[4 * NSTR], sUG[M2];
     // ---- state of the fused forward sweep (FTILES > 0), as in kern_k2b_mfma8
     const int nlos = g.nlos, ntile = (nlos + 15) / 16;
@@ -1436,10 +1448,6 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
             }
         }
     }
-    auto dgv = [&](int x) -> double {   // derivative rows of G: in the record (cooperative K1) or formed below (kern_k1_lane's records)
-        if constexpr (K1LANE) return sDG[x];
-        else return sRec[R::DG + x];
-    };
     const double rho = (m == 0) ? b.albedo[w] : 0.0;
     // Legendre sums as a 16 x 16 product:  [YP; YM] = [W+^T W-^T; W-^T W+^T] [P sg; P],  P[r][l] = 1/2 w_r omega a_l P_l^m(mu_r);
     // this lane's B operand rows are r = q and r = q + 4 of column l = col (constant over the layers up to omega a_l)
@@ -1447,61 +1455,101 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
     const double pc0 = 0.5 * g.wt[q] * lpmu[q * NSTR + col], pc1 = 0.5 * g.wt[q + 4] * lpmu[(q + 4) * NSTR + col];
     const double sg = ((col - m) & 1) ? -1.0 : 1.0;
     const int p_begin = blockIdx.y * layers_per_block, p_end = min(nlyr, p_begin + layers_per_block);
+    // a one-wavefront block needs no barrier between its LDS phases: the LDS serves a wavefront's requests in order, so waiting for them is
+    // enough -- and, unlike __syncthreads(), it leaves the global loads and LDS-DMA requests in flight (the workgroup fence drains them)
+#define K2C_SYNC() do { if constexpr (K1LANE) wave_lds_sync(); else __syncthreads(); } while (0)
+#ifdef SKD_K2C_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define K2CT(i) { long long _t = clock64(); tacc[i] += _t - tlast; tlast = _t; }
+#else
+#define K2CT(i)
+#endif
+    // K1LANE: LDS-DMA requests for layer pn into buffer `buf`.  One request writes 1 KB of LDS, lane L at byte 16 L of it, from a per-lane
+    // source address: the record's image (eight column blocks 416 bytes apart, then the tail) is 4.5 KB = five requests whose lanes
+    // read the record at offsets worked out once (a lane that lands in the padding between two blocks re-reads its block's first bytes);
+    // the block inverse (2 KB, ONE buffer: its B-operand registers are read before the request goes out) two; the BVP solution and a_l /
+    // omega / tau one; T one.  (One request per column block and per small array was 15 requests and 428 instructions a layer.)
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    int roff[5];
+    if constexpr (K1LANE) {
+        constexpr int BLK = RL::CB * 8, DAT = R::CB * 8, NBLK = N * BLK;   // bytes: padded block, its data, all blocks
+        static_assert(RL::SIZE * 8 > 4 * 1024 && RL::SIZE * 8 <= 5 * 1024 && RL::G == N * RL::CB, "five requests for the record's image");
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int at = 16 * (64 * u + lane);   // byte of the image
+            const int j = at / BLK, o = at - j * BLK;
+            roff[u] = (at < NBLK) ? j * DAT + ((o < DAT) ? o : 0) : R::G * 8 + (at - NBLK);
+        }
+    }
+    [[maybe_unused]] auto request_layer = [&](int pn, int buf) {
+        if constexpr (K1LANE) {
+            const char* src = reinterpret_cast<const char*>(skd::rec_at_r<R>(b, nlyr, pn, w));
+            double* dst = sRecAll + buf * RL::SIZE;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) __builtin_amdgcn_global_load_lds((gptr)(src + roff[u]), (lptr)(dst + 128 * u), 16, 0, 0);
+            if (lane < (RL::SIZE * 8 - 4096) / 16) __builtin_amdgcn_global_load_lds((gptr)(src + roff[4]), (lptr)(dst + 512), 16, 0, 0);
+            const char* dsrc = reinterpret_cast<const char*>(skd::dinv_at<N>(b, nlyr, pn, w));
+            __builtin_amdgcn_global_load_lds((gptr)(dsrc + lane * 16), (lptr)(sDinv), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(dsrc + 1024 + lane * 16), (lptr)(sDinv + 128), 16, 0, 0);
+            // solution (128 bytes, lanes 0 .. 7) and a_l / omega / tau (144 bytes, lanes 8 .. 16) side by side; T (8 bytes, two 4-byte lanes) behind
+            const char* xsrc = reinterpret_cast<const char*>(skd::xsol_at<N>(b, nlyr, pn, w));
+            const char* asrc = reinterpret_cast<const char*>(b.at + (size_t(w) * nlyr + pn) * 18);
+            if (lane < 17) __builtin_amdgcn_global_load_lds((gptr)((lane < 8) ? xsrc + lane * 16 : asrc + (lane - 8) * 16), (lptr)(sSmall + buf * 36), 16, 0, 0);
+            if (lane < 2)
+                __builtin_amdgcn_global_load_lds((gptr)(reinterpret_cast<const char*>(b.T + size_t(pn) * nw + w) + lane * 4), (lptr)(sSmall + buf * 36 + 34), 4, 0, 0);
+        }
+    };
+    if constexpr (K1LANE) request_layer(p_begin, 0);
     for (int p = p_begin; p < p_end; ++p) {
         const bool last = (p == nlyr - 1);
         const double* rec = skd::rec_at_r<R>(b, nlyr, p, w);
         const double* dg = skd::dinv_at<N>(b, nlyr, p, w);
         const double* xs = skd::xsol_at<N>(b, nlyr, p, w);
         double* o = skd::ops_at<N>(b, nlyr, p, w);
-        {
-            // the record -> LDS through registers, all loads in flight at once (as a rolled loop every element waits for its own load:
-            // measured 52 instead of 41 ms per step for the fused kernel)
-            constexpr int RU = (R::SIZE + 63) / 64;
-            double stage[RU];
-#pragma unroll
-            for (int u = 0; u < RU; ++u) stage[u] = (lane + 64 * u < R::SIZE) ? rec[lane + 64 * u] : 0.0;
-#pragma unroll
-            for (int u = 0; u < RU; ++u) {
-                const int e = lane + 64 * u;
-                int at = e;
-                if constexpr (K1LANE) at = e + min(e / R::CB, N);   // one double of padding behind every column block
-                if (e < R::SIZE) sRec[at] = stage[u];
-            }
-        }
-        if (lane < M2) sXs[lane] = xs[lane];
+        double* sRec = sRecAll;
+        double* sXs = sSmall;
         double dinv_b[4];  // B operand of the Dinv chains: Dinv[4 kk + (lane >> 4)][lane & 15] = dg[64 kk + lane]
-        for (int kk = 0; kk < 4; ++kk) dinv_b[kk] = dg[64 * kk + lane];
-        const double* lo = b.at + (size_t(w) * nlyr + p) * 18;
-        const double om = lo[16], th = lo[17], T = b.T[size_t(p) * nw + w];
-        const double inv_om = 1.0 / om, inv_T = (T != 0) ? 1.0 / T : 0.0;
-        const double al = (col >= m) ? lo[col] : 0.0;
-        __syncthreads();
+        double om, th, T, al;
         if constexpr (K1LANE) {
-            // records of kern_k1_lane: Rec::DG holds coef[(type * 5 + k) * N + j] (type 0: A- C-, 1: A+ C+; k = 0: the coefficient, 1 + theta:
-            // its derivatives).  DG[theta][c][i] = sum_j Wsel_c(i, j) coef_type(c)[1 + theta][j] + (theta = omega) sum_j dWsel_c(i, j) coef_type(c)[0][j]
-            // as two chained 16 x 16 x 8 products  D = [W+; W-] B + [dW+; dW-] B2  (rows (sel, i), columns (type, k)), B2 = coef[.][0] in the omega column
-            mf4 D = {0, 0, 0, 0};
-            double aw[2], ad[2], bb[2], b2[2];
-            for (int kk = 0; kk < 2; ++kk) {
-                const int j = 4 * kk + q;
-                aw[kk] = (col < N) ? sRec[RL::wp(col, j)] : sRec[RL::wm(col - N, j)];
-                ad[kk] = (col < N) ? sRec[RL::dwp(col, j)] : sRec[RL::dwm(col - N, j)];
-                bb[kk] = (col < 10) ? sRec[RL::coef(col, j)] : 0.0;
-                b2[kk] = (col == 1 + skd::TH_OM) ? sRec[RL::coef(0, j)] : (col == 6 + skd::TH_OM) ? sRec[RL::coef(5, j)] : 0.0;
+            // everything of this layer was requested one layer ago (LDS-DMA: global_load_lds, no registers in between); the next layer's
+            // requests go out now and land while this layer is worked on.  A wavefront is alone with its chain of dependent layers, three of
+            // them per SIMD: without the look-ahead every layer starts with a round trip to HBM (24 % of the kernel's cycles, clock64 phases).
+            const int cur = (p - p_begin) & 1;
+            sRec = sRecAll + cur * RL::SIZE;
+            sXs = sSmall + cur * 36;
+            // everything older than the previous layer's last 5 FTILES stores (the sweep states and HD parts, issued after every load of that
+            // layer: vector-memory operations complete in issue order) must be back -- this layer's LDS-DMA data among it; the stores stay in flight
+            if (FTILES > 0 && p > p_begin) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * FTILES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int kk = 0; kk < 4; ++kk) dinv_b[kk] = sDinv[64 * kk + lane];
+            const double* sLo = sSmall + cur * 36 + M2;
+            om = sLo[16]; th = sLo[17]; T = sLo[18];
+            al = (col >= m) ? sLo[col] : 0.0;
+            if (p + 1 < p_end) {   // (the last layer's ground term reads the block inverse once more, below: nothing overwrites it)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                request_layer(p + 1, cur ^ 1);
             }
-            for (int kk = 0; kk < 2; ++kk) D = mfma16(aw[kk], bb[kk], D);
-            for (int kk = 0; kk < 2; ++kk) D = mfma16(ad[kk], b2[kk], D);
-            // lane (col = (type, k), q), register r: row = q + 4 r = (sel, i);  c = 0: (W-, type 0), 1: (W+, 0), 2: (W+, 1), 3: (W-, 1)
-            const int type = (col >= 5) ? 1 : 0, k = col - 5 * type;
-            if (col < 10 && k >= 1) {
-                for (int r = 0; r < 4; ++r) {
-                    const int row = q + 4 * r, sel = row >> 3, i = row & 7;
-                    const int c = (type == 0) ? (sel ? 0 : 1) : (sel ? 3 : 2);
-                    sDG[((k - 1) * 4 + c) * N + i] = D[r];
-                }
+        } else {
+            {
+                // the record -> LDS through registers, all loads in flight at once (as a rolled loop every element waits for its own load:
+                // measured 52 instead of 41 ms per step for the fused kernel)
+                constexpr int RU = (R::SIZE + 63) / 64;
+                double stage[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) stage[u] = (lane + 64 * u < R::SIZE) ? rec[lane + 64 * u] : 0.0;
+#pragma unroll
+                for (int u = 0; u < RU; ++u) if (lane + 64 * u < R::SIZE) sRec[lane + 64 * u] = stage[u];
             }
+            if (lane < M2) sXs[lane] = xs[lane];
+            for (int kk = 0; kk < 4; ++kk) dinv_b[kk] = dg[64 * kk + lane];
+            const double* lo = b.at + (size_t(w) * nlyr + p) * 18;
+            om = lo[16]; th = lo[17]; T = b.T[size_t(p) * nw + w];
+            al = (col >= m) ? lo[col] : 0.0;
             __syncthreads();
         }
+        const double inv_om = 1.0 / om, inv_T = (T != 0) ? 1.0 / T : 0.0;
+        K2CT(0)
         // ---- Y = [YP; YM] and its omega derivative DY (rows: solution j / 8 + j, columns: Legendre order l)
         mf4 Y = {0, 0, 0, 0}, DY = {0, 0, 0, 0};
         {
@@ -1549,6 +1597,7 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
                 if constexpr (FTILES > 0) sHD[t * NSTR + col] = hv;
                 else o[O::HD + t * NSTR + col] = hv;
             }
+        K2CT(1)
         // ---- FP^T = F^T Dinv (the C/D image of F is the A operand of F^T) and [SP | BP]^T = [SupT | SubT]^T Dinv
         mf4 x1, x2;
         {
@@ -1571,35 +1620,62 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
             o[O::BP + lane] = x2[2];
             o[O::BP + 64 + lane] = x2[3];
         }
-        // ---- edge-intensity derivatives at fixed (L, M): lanes (i, e)
-        for (int idx = lane; idx < 4 * N; idx += 64) {
-            const int i = idx / 4, e = idx % 4;
-            double d_tau = 0, d_om = 0, ipb_i = sRec[RL::g(2 * N + i)];
-            for (int j = 0; j < N; ++j) {
-                const double wp = sRec[RL::wp(i, j)], wm = sRec[RL::wm(i, j)];
-                const double dwp = sRec[RL::dwp(i, j)], dwm = sRec[RL::dwm(i, j)];
+        K2CT(2)
+        // ---- edge-intensity derivatives at fixed (L, M).  All 64 lanes: (stream i, edge e, half h of the solutions), one branch-free form
+        // for the four edges -- with X the edge's "own" W (e = 0, 3: W-, else W+), Y the other one, p = (e < 2 ? M : L), o = the other amplitude:
+        //   d/dtau += X dE/dtau p,   d/domega += dX E p + X dE/domega p + dY o,   I+bottom (e = 2) = G+bottom + X E p + Y o
+        // (the four branches of the per-edge form ran one after the other on a half-empty wavefront: 28 % of this kernel's cycles)
+        {
+            const int i = lane & 7, e = (lane >> 3) & 3, h = lane >> 5;
+            const bool own_minus = (e == 0 || e == 3), pm = (e < 2);
+            // K1LANE (records of kern_k1_lane): the derivative rows of G are not in the record; edge e of stream i is
+            //   DG[theta][e][i] = sum_j X(i, j) coef_type(e)[1 + theta][j] + (theta = omega) sum_j dX(i, j) coef_type(e)[0][j],  type = A- C- (e < 2), A+ C+
+            const int tk0 = (e >= 2) ? 5 : 0;
+            double d_tau = 0, d_om = 0, ipb_i = 0, dg[4] = {0, 0, 0, 0};
+#pragma unroll 2
+            for (int jj = 0; jj < N / 2; ++jj) {
+                const int j = h * (N / 2) + jj;
+                const double X = sRec[own_minus ? RL::wm(i, j) : RL::wp(i, j)], Y = sRec[own_minus ? RL::wp(i, j) : RL::wm(i, j)];
+                const double dX = sRec[own_minus ? RL::dwm(i, j) : RL::dwp(i, j)], dY = sRec[own_minus ? RL::dwp(i, j) : RL::dwm(i, j)];
                 const double E = sRec[RL::e(j)], L = sXs[j], Mv = sXs[N + j];
-                const double dE_tau = -sRec[RL::k(j)] * E, dE_om = -sRec[RL::dk(j)] * th * E;
-                if (e == 0) { d_tau += wm * dE_tau * Mv; d_om += dwp * L + dwm * E * Mv + wm * dE_om * Mv; }
-                if (e == 1) { d_tau += wp * dE_tau * Mv; d_om += dwm * L + dwp * E * Mv + wp * dE_om * Mv; }
-                if (e == 2) { d_tau += wp * dE_tau * L; d_om += dwp * E * L + wp * dE_om * L + dwm * Mv; ipb_i += wp * E * L + wm * Mv; }
-                if (e == 3) { d_tau += wm * dE_tau * L; d_om += dwm * E * L + wm * dE_om * L + dwp * Mv; }
+                const double pa = pm ? Mv : L, oa = pm ? L : Mv;
+                const double t_tau = -sRec[RL::k(j)] * E * pa, t_e = E * pa, t_om = -sRec[RL::dk(j)] * th * E * pa;
+                d_tau += X * t_tau;
+                d_om += dX * t_e + X * t_om + dY * oa;
+                ipb_i += X * t_e + Y * oa;
+                if constexpr (K1LANE) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dg[t] += X * sRec[RL::coef(tk0 + 1 + t, j)];
+                    dg[skd::TH_OM] += dX * sRec[RL::coef(tk0, j)];
+                }
             }
-            const double v_tau = dgv((skd::TH_TAU * 4 + e) * N + i) + d_tau;
-            const double v_om = dgv((skd::TH_OM * 4 + e) * N + i) + d_om;
-            const double v_T = dgv((skd::TH_T * 4 + e) * N + i), v_sec = dgv((skd::TH_SEC * 4 + e) * N + i);
-            o[O::DI + (skd::TH_TAU * 4 + e) * N + i] = v_tau;
-            o[O::DI + (skd::TH_OM * 4 + e) * N + i] = v_om;
-            o[O::DI + (skd::TH_T * 4 + e) * N + i] = v_T;
-            o[O::DI + (skd::TH_SEC * 4 + e) * N + i] = v_sec;
-            if (e == 2) {
-                sIpb[i] = g.wt[i] * g.mu[i] * ipb_i;
-                sDIpb[skd::TH_TAU * N + i] = g.wt[i] * g.mu[i] * v_tau;
-                sDIpb[skd::TH_OM * N + i] = g.wt[i] * g.mu[i] * v_om;
-                sDIpb[skd::TH_T * N + i] = g.wt[i] * g.mu[i] * v_T;
-                sDIpb[skd::TH_SEC * N + i] = g.wt[i] * g.mu[i] * v_sec;
+            d_tau += __shfl_xor(d_tau, 32);
+            d_om += __shfl_xor(d_om, 32);
+            ipb_i += __shfl_xor(ipb_i, 32);
+            if constexpr (K1LANE) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dg[t] += __shfl_xor(dg[t], 32);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dg[t] = sRec[R::DG + (t * 4 + e) * N + i];
+            }
+            const double v_tau = dg[skd::TH_TAU] + d_tau, v_om = dg[skd::TH_OM] + d_om, v_T = dg[skd::TH_T], v_sec = dg[skd::TH_SEC];
+            if (h == 0) {
+                o[O::DI + (skd::TH_TAU * 4 + e) * N + i] = v_tau;
+                o[O::DI + (skd::TH_OM * 4 + e) * N + i] = v_om;
+                o[O::DI + (skd::TH_T * 4 + e) * N + i] = v_T;
+                o[O::DI + (skd::TH_SEC * 4 + e) * N + i] = v_sec;
+                if (e == 2) {
+                    const double wmu = g.wt[i] * g.mu[i];
+                    sIpb[i] = wmu * (sRec[RL::g(2 * N + i)] + ipb_i);
+                    sDIpb[skd::TH_TAU * N + i] = wmu * v_tau;
+                    sDIpb[skd::TH_OM * N + i] = wmu * v_om;
+                    sDIpb[skd::TH_T * N + i] = wmu * v_T;
+                    sDIpb[skd::TH_SEC * N + i] = wmu * v_sec;
+                }
             }
         }
+        K2CT(3)
         // ground part of u
         if (lane < N) {
             double sp = 0, sm = 0;
@@ -1611,12 +1687,12 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
             sTmp[lane] = 2.0 * rho * sp * sRec[RL::e(lane)];
             sTmp[N + lane] = 2.0 * rho * sm;
         }
-        __syncthreads();
+        K2C_SYNC();
         // UG, GD, IPB
         if (lane < M2) {
             double t = 0;
             if (last && m == 0)
-                for (int j = 0; j < M2; ++j) t += dg[j * M2 + lane] * sTmp[j];
+                for (int j = 0; j < M2; ++j) t += (K1LANE ? sDinv[j * M2 + lane] : dg[j * M2 + lane]) * sTmp[j];
             o[O::UG + lane] = t;
             if constexpr (FTILES > 0) sUG[lane] = t;
         }
@@ -1631,7 +1707,8 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
             for (int i = 0; i < N; ++i) ipb += sIpb[i];
             o[O::IPB] = ipb;
         }
-        __syncthreads();
+        K2C_SYNC();
+        K2CT(4)
         if constexpr (FTILES > 0) {
             // ---- forward sweep of the adjoint at this layer:  Y_p = FP QL_p + SP Y_{p-1}[8:16]  (+ HD QL_p), statement for statement the
             // forward half of kern_k2b_mfma8 with its operands taken from x1 (FP), x2[0:2] (SP), sHD and sUG
@@ -1677,7 +1754,11 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
                 yprev[t] = acc;
             }
         }
+        K2CT(5)
     }
+#ifdef SKD_K2C_TIMING
+    if (lane == 0 && w == 100 && m == 1) printf("K2CT stage %lld  Y/F/HD %lld  FP/SP/BP %lld  edges %lld  ground/UG %lld  forward sweep %lld\n", tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5]);
+#endif
 }
 
 // K2b for N = 8: one wavefront per wavelength, 16 lines of sight per matrix-core tile (lane & 15 = line of sight).

@@ -8,6 +8,7 @@ its views are gone.  Without a GPU, or when pinning fails, ordinary NumPy memory
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 import weakref
 
@@ -23,7 +24,7 @@ class _PinnedPool:
         self._free = {}
         self._free_bytes = 0
         self._lock = threading.Lock()
-        self._failed = False
+        self._failed = os.environ.get("SASKTRAN2_AMD_HOST_ALLOC", "pinned") == "pageable"   # (ordinary NumPy memory throughout)
 
     def _release(self, nbytes, ptr):
         from ._lib_loader import lib

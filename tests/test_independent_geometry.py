@@ -255,7 +255,9 @@ def ray_crossings(pos, look, alt):
     ts = {t_in, t_out}
     for a in alt[1:-1]:
         d = b * b - (c0 - (R_EARTH + a) ** 2)
-        if d > 0:
+        # (d = half chord^2 in m^2; the terms are 4e13 m^2, so a ray TANGENT to this shell -- the bench geometry's tangent heights sit on grid
+        # levels -- gives |d| of rounding size, 1e-2 m^2: a contact, not two crossings a decimetre apart)
+        if d > 1.0:
             for t in (-b - np.sqrt(d), -b + np.sqrt(d)):
                 if t_in < t < t_out:
                     ts.add(t)
@@ -307,10 +309,24 @@ def brute_table_stencils(alt, sun, pos, look):
 def test_diffuse_table_stencils_against_brute_force(ray):
     """every segment's (altitude, angle) stencil, weight by weight, its azimuth and its length; a weight of the shared precompute perturbed
     by 1e-6 fails this test (tolerance 1e-9)"""
+    check_table_stencils(ray[1], 0.6)
+
+
+@pytest.mark.parametrize("tangent_km", range(10, 60, 2))
+def test_diffuse_table_stencils_of_the_c2_bench_geometry(tangent_km):
+    """The 25 lines of sight of BASELINE configs[1] (tangent heights 10 .. 58 km on the grid levels of the 51-level atmosphere, observer at
+    600 km, cos(SZA) 0.6, relative azimuth 0 -- tests/scenarios.py limb_c2, what bench.py times): every segment's table stencil, length and
+    azimuth against the closed-form shell intersections of this file.  The oracle shares the geometry precompute with the product, so
+    this is the pin of the bench geometry that does not go through that shared header."""
+    s = sc.limb_c2(num_wavelengths=1)
+    spec = s["rays"][(tangent_km - 10) // 2]
+    assert spec[0] == sc.TANGENT_ALTITUDE_SOLAR and abs(spec[4] - 1000.0 * tangent_km) < 1e-6 and spec[3] == 600_000.0
+    check_table_stencils(spec, s["geometry"]["cos_sza"])
+
+
+def check_table_stencils(spec, cos_sza_ref):
     from tests.test_oracle_golden import make_oracle
-    name, spec = ray
     kind, csz, az, obs, x = spec
-    cos_sza_ref = 0.6
     sun = frame(cos_sza_ref)
     pos, look = {sc.TANGENT_ALTITUDE_SOLAR: tangent_ray, sc.GROUND_VIEWING_SOLAR: nadir_ray, sc.VIEWING_UP_SOLAR: inside_ray}[kind](sun, csz, az, x, obs)
     s = sc.limb_c2(num_wavelengths=1)
@@ -319,8 +335,13 @@ def test_diffuse_table_stencils_against_brute_force(ray):
     alt = s["geometry"]["altitudes"]
     got = make_oracle(s).ray_tables(0)
     want = brute_table_stencils(alt, sun, pos, look)
-    # the engine keeps zero-length segments (a tangent point on a grid level splits nothing): drop them on its side
-    layers = [L for L in got["layers"] if L["distance"] > 1e-3]
+    # the engine keeps zero-length segments (a tangent point on a grid level splits nothing): drop them on its side.  A tangent radius that
+    # ROUNDS a hair below its grid level makes the reference's tracer (std::upper_bound on rt - R, raytracing/spherical_shell.cpp:228-262,
+    # restated in host/geometry.hpp) put two segments of a few centimetres into the layer below -- 2 of the 25 bench rays; they are dropped
+    # too, and the two segments next to them then end 4e-8 in cos(angle) off the tangent point: weights to 5e-6 for such a ray
+    grazing = any(1e-3 < L["distance"] < 1.0 for L in got["layers"])
+    wtol = 5e-6 if grazing else 1e-9
+    layers = [L for L in got["layers"] if L["distance"] >= 1.0] if grazing else [L for L in got["layers"] if L["distance"] > 1e-3]
     assert got["ground_is_hit"] == hits_ground(pos, look)
     assert len(layers) == len(want), (len(layers), len(want))
     mirrored = []
@@ -331,12 +352,12 @@ def test_diffuse_table_stencils_against_brute_force(ray):
             assert sza == 0
             have[(ia, ic)] = have.get((ia, ic), 0.0) + w
         # (a segment that spans a whole layer sits on a table altitude up to rounding: weights of 1e-12 and less are that rounding)
-        have = {k: v for k, v in have.items() if v > 1e-10}
-        wantw = {k: v for k, v in W["table"].items() if v > 1e-10}
+        have = {k: v for k, v in have.items() if v > max(1e-10, wtol)}
+        wantw = {k: v for k, v in W["table"].items() if v > max(1e-10, wtol)}
         assert set(have) == set(wantw), (sorted(have), sorted(wantw))
         for k in wantw:
-            assert abs(have[k] - wantw[k]) < 1e-9, (k, have[k], wantw[k])
-        assert abs(sum(have.values()) - 1.0) < 1e-9
+            assert abs(have[k] - wantw[k]) < wtol, (k, have[k], wantw[k])
+        assert abs(sum(have.values()) - 1.0) < max(1e-9, 4 * wtol)
         # azimuths enter as cos(m azi) (and sin(m azi) for U): compared on the circle, up to the handedness of this test's own frame
         # (a mirror image of the scene; the reference's sense of the relative azimuth is pinned by its regression radiances) -- but the
         # same handedness for every segment of the ray

@@ -10,6 +10,6 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-variable -Wno-unused-b
 /opt/rocm/bin/hipcc $F "$@" -c hip/capi.hip -o $out/$name/capi.o &
 wait
 # the other engines are not touched by the SKD_ switches: their objects come from the regular build (make in sasktran2_amd/csrc)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $out/$name/disco_engine.o $out/$name/capi.o ../_lib/so_engine.o ../_lib/ts_engine.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $out/$name/disco_engine.o $out/$name/capi.o ../_lib/so_engine.o ../_lib/ts_engine.o -ldl -Wl,-rpath,/opt/rocm/lib
 rm -rf $out/$name
 echo built $out/$name.so
