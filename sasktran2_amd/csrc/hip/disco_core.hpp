@@ -152,7 +152,18 @@ struct Bufs {
     // 16 streams: a_l (16), omega and tau of a layer in ONE run per (wavelength, layer), [w][p][18] -- what the per-wavelength kernels of an
     // azimuth order read of the layer optics (from the [p][l][w] arrays every value is its own 64-byte sector); written by kern_k0_tile
     double* at;
+    // Azimuth orders batched into one launch (small launches, 16 streams): gridDim.z = orders, order m0 + blockIdx.z works on its own set of
+    // per-order buffers, ord_* elements behind the set of order m0 (0 when a launch serves one order: order_view then changes nothing)
+    size_t ord_rec, ord_dinv, ord_xsol, ord_eig, ord_ops, ord_z, ord_qlbuf, ord_qlmask, ord_grad;
 };
+#if defined(__HIPCC__)
+// the buffers of azimuth order m0 + mo (mo = blockIdx.z of a batched launch)
+__device__ inline Bufs order_view(Bufs b, unsigned mo) {
+    b.rec += mo * b.ord_rec; b.dinv += mo * b.ord_dinv; b.xsol += mo * b.ord_xsol; b.eig += mo * b.ord_eig; b.ops += mo * b.ord_ops;
+    b.z += mo * b.ord_z; b.qlbuf += mo * b.ord_qlbuf; b.qlmask += mo * b.ord_qlmask; b.grad += mo * b.ord_grad;
+    return b;
+}
+#endif
 
 template <int N> struct Rec {
     static constexpr int K = 0, DK = N, WP = 2 * N, WM = WP + N * N, DWP = WM + N * N, DWM = DWP + N * N,

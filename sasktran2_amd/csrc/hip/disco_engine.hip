@@ -301,6 +301,14 @@ __global__ void __launch_bounds__(256) kern_qlmask(Geo g, Bufs b, int m) {
         b.qlmask[i] = uint8_t(bits);
     }
 }
+// batched azimuth orders: the reduced gradient is the sum of the orders' rows IN ORDER (what the order-by-order path adds up in b.grad)
+__global__ void __launch_bounds__(256) kern_grad_orders(const double* __restrict__ gord, double* __restrict__ grad, size_t n, size_t stride, int norders) {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        double acc = gord[i];
+        for (int m = 1; m < norders; ++m) acc += gord[size_t(m) * stride + i];
+        grad[i] = acc;
+    }
+}
 // plane-parallel post-processing: one thread per (wavelength, line of sight), see skd::kpp_los
 template <int N> __global__ void __launch_bounds__(kBlock) kern_kpp(Geo g, Bufs b, int s, int m) {
     size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -407,6 +415,11 @@ struct DeviceEngine::Impl {
         uint8_t* qlmaskx[kDepth - 1] = {};   // live-flag rows: formed on the BVP stream right after the table values, read by the adjoint stream
         std::vector<hipEvent_t> ev_k1, ev_bvp, ev_rest;  // per azimuth order
         hipEvent_t ev_begin = nullptr;
+        // batched azimuth orders (small launches): one set of per-order buffers for every order, allocated when first needed
+        DevMem batch_mem;
+        int batch_cap = 0;
+        double *bt_rec = nullptr, *bt_dinv = nullptr, *bt_xsol = nullptr, *bt_eig = nullptr, *bt_ops = nullptr, *bt_z = nullptr, *bt_hw = nullptr, *bt_grad = nullptr;
+        uint8_t* bt_qlmask = nullptr;
     };
     std::vector<std::unique_ptr<Slot>> slots;
     hipEvent_t fork = nullptr;
@@ -713,6 +726,131 @@ static void launch_k3(hipStream_t st, const Geo& g, const Bufs& b, int s, int m)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k3_wave<N>), dim3(unsigned(b.nw), unsigned(ny)), dim3(64), 0, st, g, b, s, m, lpb);
 }
 
+// Small launches, 16 streams, spherical: ALL azimuth orders of the block in ONE launch per kernel (gridDim.z = order).  The orders are
+// independent of each other up to the diffuse-table values -- whose stop rule (do_source_diffuse_storage.cpp:1033-1060) compares order m with
+// m - 1 and m - 2 --, so the layer solutions and boundary-value problems of every order run side by side, the table values and the stop rule
+// order after order (short kernels), the adjoint operators and sweeps again side by side in groups of four orders behind them, every order
+// adding into gradient rows of its own that kern_grad_orders sums in order.  A rank's share of a sharded spectrum (1 250 wavelengths of 10 000 on
+// eight GPUs) otherwise is a chain of 16 x 5 kernels that each fill a fraction of the chip: the boundary-value recursion alone 0.9 ms per
+// order.  Same kernels, same statements, same order of the sums: bit-identical to the order-by-order path (tests/test_gpu_parity.py).
+// Returns false (nothing launched) when the per-order buffers do not fit the free HBM.
+static bool run_orders_batched(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hipStream_t st, int derivs, int s) {
+    using RC = skd::RecC<8>;
+    constexpr int N = 8, NORD = 16, GROUP = 4;
+    const Geo& g = I.g;
+    Bufs& b = slot.b;
+    const size_t nw = b.nw, nt = nw * g.nlos, nlyr = g.nlyr;
+    const int ntile = (g.nlos + 15) / 16;
+    const size_t nqm = (size_t(g.n_lp) + 7) / 8;
+    if (int(nw) > slot.batch_cap) {
+        const size_t W = nw;
+        const size_t per_order = (nlyr * (4 * N * N + 41 * N) + nlyr * 4 * N * N + nlyr * 2 * N + nlyr * (N + N * N) + nlyr * skd::Ops<N>::SIZE +
+                                  nlyr * ntile * 256 + nlyr * ntile * 64 + (4 * nlyr + 2) * g.nlos) * sizeof(double) + nqm + 8;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        slot.batch_mem.release();
+        slot.batch_cap = 0;
+        if (per_order * NORD * W > size_t(0.6 * double(free_b))) return false;
+        DevMem& M = slot.batch_mem;
+        slot.bt_rec = M.alloc<double>(NORD * nlyr * (4 * N * N + 41 * N) * W);
+        slot.bt_dinv = M.alloc<double>(NORD * nlyr * 4 * N * N * W);
+        slot.bt_xsol = M.alloc<double>(NORD * nlyr * 2 * N * W);
+        slot.bt_eig = M.alloc<double>(NORD * nlyr * (N + N * N) * W);
+        slot.bt_ops = M.alloc<double>(NORD * nlyr * skd::Ops<N>::SIZE * W);
+        slot.bt_z = M.alloc<double>(NORD * nlyr * ntile * 256 * W);
+        slot.bt_hw = M.alloc<double>(NORD * nlyr * ntile * 64 * W);
+        slot.bt_grad = M.alloc<double>(NORD * (4 * nlyr + 2) * g.nlos * W);
+        slot.bt_qlmask = M.alloc<uint8_t>(NORD * (nqm * W + 8));
+        slot.batch_cap = int(W);
+    }
+    const size_t W = size_t(slot.batch_cap);
+    Bufs bb = b;
+    bb.rec = slot.bt_rec; bb.dinv = slot.bt_dinv; bb.xsol = slot.bt_xsol; bb.eig = slot.bt_eig; bb.ops = slot.bt_ops;
+    bb.z = slot.bt_z; bb.qlbuf = slot.bt_hw; bb.qlmask = slot.bt_qlmask; bb.grad = slot.bt_grad;
+    bb.ord_rec = nlyr * (4 * N * N + 41 * N) * W; bb.ord_dinv = nlyr * 4 * N * N * W; bb.ord_xsol = nlyr * 2 * N * W;
+    bb.ord_eig = nlyr * (N + N * N) * W; bb.ord_ops = nlyr * skd::Ops<N>::SIZE * W; bb.ord_z = nlyr * ntile * 256 * W;
+    bb.ord_qlbuf = nlyr * ntile * 64 * W; bb.ord_qlmask = nqm * W + 8; bb.ord_grad = (4 * nlyr + 2) * g.nlos * W;
+    // the sets from order m on (a batched launch that starts at order m: blockIdx.z counts from there), and one order's set alone for the
+    // kernels that run order by order
+    auto from_order = [&](int m) {
+        Bufs o = bb;
+        o.rec += m * bb.ord_rec; o.dinv += m * bb.ord_dinv; o.xsol += m * bb.ord_xsol; o.eig += m * bb.ord_eig; o.ops += m * bb.ord_ops;
+        o.z += m * bb.ord_z; o.qlbuf += m * bb.ord_qlbuf; o.qlmask += m * bb.ord_qlmask; o.grad += m * bb.ord_grad;
+        return o;
+    };
+    auto order_bufs = [&](int m) {
+        Bufs o = from_order(m);
+        o.ord_rec = o.ord_dinv = o.ord_xsol = o.ord_eig = o.ord_ops = o.ord_z = o.ord_qlbuf = o.ord_qlmask = o.ord_grad = 0;
+        return o;
+    };
+    const bool adj = derivs && g.n_lp > 0;
+    hipStream_t sC = (!I.profiling && slot.adj_stream) ? slot.adj_stream : st;
+    if (adj) HIP_CHECK(hipMemsetAsync(slot.bt_grad, 0, size_t(NORD) * bb.ord_grad * sizeof(double), st));
+    const dim3 lane_grid(unsigned((nw + 63) / 64), unsigned(nlyr), NORD);
+    {
+        Timer t(I, st, "k1_layer_solution");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_kj_lane<8, true>), lane_grid, dim3(64), 0, st, g, bb, 0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_lane<8>), lane_grid, dim3(64), 0, st, g, bb, s, 0);
+    }
+    {
+        Timer t(I, st, "k2a_bvp");
+        const dim3 grid(unsigned((nw + 3) / 4), 1, NORD);
+        if (size_t(grid.x) * NORD <= 1024) hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_cols8_lone<RC>), grid, dim3(64), 0, st, g, bb, s, 0);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_cols8<RC>), grid, dim3(64), 0, st, g, bb, s, 0);
+    }
+    const bool fused = ntile <= 2 && adj;
+    for (int m = 0; m < NORD; ++m) {
+        const Bufs bm = order_bufs(m);
+        {
+            Timer t(I, st, "k3_table_values");
+            launch_k3<8>(st, g, bm, s, m);
+        }
+        if (adj) {
+            Timer t(I, st, "k2q_live_flags");
+            hipLaunchKernelGGL(kern_qlmask, dim3(2048), dim3(256), 0, st, g, bm, m);
+        }
+        {
+            Timer t(I, st, "k_stop_rule");
+            hipLaunchKernelGGL(kern_stop, dim3(blocks(nw)), dim3(kBlock), 0, st, g, bm, s, m, slot.d_active);
+        }
+        if (adj && (m % GROUP == GROUP - 1 || m == NORD - 1)) {
+            // adjoint stage of the orders m0 .. m behind their table values (it only tests conv_order > order, which no later order changes)
+            const int m0 = m / GROUP * GROUP, cnt = m - m0 + 1;
+            const Bufs bg = from_order(m0);
+            if (sC != st) {
+                HIP_CHECK(hipEventRecord(slot.ev_bvp[m], st));
+                HIP_CHECK(hipStreamWaitEvent(sC, slot.ev_bvp[m], 0));
+            }
+            {
+                Timer t(I, sC, "k2c_adjoint_ops");
+                if (fused && ntile == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true, 2>), dim3(unsigned(nw), 1, unsigned(cnt)), dim3(64), 0, sC, g, bg, s, m0, g.nlyr);
+                else if (fused) hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true, 1>), dim3(unsigned(nw), 1, unsigned(cnt)), dim3(64), 0, sC, g, bg, s, m0, g.nlyr);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true>), dim3(unsigned(nw), 1, unsigned(cnt)), dim3(64), 0, sC, g, bg, s, m0, g.nlyr);
+            }
+            Timer t(I, sC, "k2b_adjoint");
+            if (fused && ntile == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<2, true>), dim3(unsigned(nw), 1, unsigned(cnt)), dim3(64), 0, sC, g, bg, s, m0);
+            else if (fused) hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<1, true>), dim3(unsigned(nw), 1, unsigned(cnt)), dim3(64), 0, sC, g, bg, s, m0);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<1>), dim3(unsigned(nw), unsigned(std::min(ntile, 4)), unsigned(cnt)), dim3(64), 0, sC, g, bg, s, m0);
+        }
+    }
+    if (s == g.nsza - 1) {
+        Timer t(I, st, "k4b_los");
+        hipLaunchKernelGGL(kern_k4b, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b);
+    }
+    if (adj) {
+        if (sC != st) {
+            HIP_CHECK(hipEventRecord(slot.ev_rest[NORD - 1], sC));
+            HIP_CHECK(hipStreamWaitEvent(st, slot.ev_rest[NORD - 1], 0));
+        }
+        Timer t(I, st, "k4a_chain");
+        const size_t n_grad = size_t(4 * nlyr + 2) * nt;
+        // (a gradient row is [element][w x nlos + los] with the launch's nt as its row length: the per-order sets are laid out alike)
+        hipLaunchKernelGGL(kern_grad_orders, dim3(2048), dim3(256), 0, st, slot.bt_grad, b.grad, n_grad, bb.ord_grad, NORD);
+    }
+    HIP_CHECK(hipGetLastError());
+    return true;
+}
+
 template <int N>
 static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hipStream_t st, int derivs) {
     const Geo& g = I.g;
@@ -826,6 +964,22 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
             Timer t(I, st, "k0_transmission");
             hipLaunchKernelGGL(kern_k0t, dim3(blocks(nw), unsigned(g.nlyr)), dim3(kBlock), 0, st, g, b, s);
         }
+        if constexpr (N == 8) {
+            // small launches: every azimuth order in one launch per kernel (run_orders_batched); SASKTRAN2_AMD_BATCH_ORDERS = largest block
+            // served that way (0: never)
+            static const int batch_max = [] { const char* e = std::getenv("SASKTRAN2_AMD_BATCH_ORDERS"); return e ? atoi(e) : 2600; }();
+            if (b.k1_lane && int(nw) <= batch_max && g.nstr == 16 && run_orders_batched(I, slot, st, derivs, s)) {
+                if (derivs) {
+                    Timer t(I, st, "k4a_chain");
+                    if (s + 1 < g.nsza) hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, s, 1);
+                    else {
+                        hipLaunchKernelGGL(kern_k4a_gt, dim3(blocks(nt), unsigned((g.nlyr + 7) / 8)), dim3(kBlock), 0, st, g, b, s);
+                        hipLaunchKernelGGL(kern_k4a_apply, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b);
+                    }
+                }
+                continue;
+            }
+        }
         if (pipe) {
             HIP_CHECK(hipEventRecord(slot.ev_begin, st));
             HIP_CHECK(hipStreamWaitEvent(sA, slot.ev_begin, 0));
@@ -862,7 +1016,8 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                 if constexpr (N == 8) {
                     // column-per-lane BVP, four wavelengths per wavefront (kern_k2a_cols8); SASKTRAN2_AMD_K2A=mfma keeps the matrix-core form
                     static const bool cols = [] { const char* e = std::getenv("SASKTRAN2_AMD_K2A"); return !(e && std::string(e) == "mfma"); }();
-                    const bool lone = (nw + 3) / 4 <= 1024;   // at most one wavefront per SIMD: the spill-free instantiation
+                    static const int lone_env = [] { const char* e = std::getenv("SASKTRAN2_AMD_K2A_LONE"); return e ? atoi(e) : -1; }();
+                    const bool lone = lone_env >= 0 ? lone_env != 0 : (nw + 3) / 4 <= 1024;   // at most one wavefront per SIMD: the spill-free instantiation
                     if (b.k1_lane && lone)
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_cols8_lone<skd::RecC<8>>), dim3(unsigned((nw + 3) / 4)), dim3(64), 0, st, g, b, s, m);
                     else if (b.k1_lane)

@@ -63,6 +63,8 @@ __device__ __forceinline__ double kj_rcp(double x) {
 // SOA = true: the eigen-solution goes to b.eig[(layer * (N + N N) + e) * nw + w] (e < N: k_j^2; then Xhat(i, j) = (T X)(i, j), the
 // eigenvectors before the T^-1 scaling) with plain coalesced stores, for kern_k1_lane.
 template <int N, bool SOA = false> __global__ void __launch_bounds__(64, SKD_WPE_KJ) kern_kj_lane(Geo g, Bufs b, int m) {
+    m += blockIdx.z;   // (batched azimuth orders: skd::order_view)
+    b = skd::order_view(b, blockIdx.z);
     constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, HALF = NOUT / 2, STRIDE = HALF + 1, NM1 = N - 1, JH = N / 2;
     static_assert(NOUT % 2 == 0, "two output halves");
     using R = skd::Rec<N>;
@@ -326,6 +328,8 @@ __device__ __forceinline__ double row16_sum(double v) {
 //   grid = (ceil(nw / 64), nlyr), block = 64, one wavefront per SIMD (the kernel owns the register file).
 // -------------------------------------------------------------------------------------------------------------------
 template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bufs b, int s, int m) {
+    m += blockIdx.z;   // (batched azimuth orders: skd::order_view)
+    b = skd::order_view(b, blockIdx.z);
     constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, CH = 3 * N + 1, HB = 3 * N / 2;   // CH: odd staging stride; HB: 16-byte pieces per half block
     using R = skd::RecC<N>;
     static_assert(R::CB == 6 * N && N % 2 == 0, "two halves of 3 N doubles per column block");
@@ -813,9 +817,9 @@ template <class R> __device__ __forceinline__ void k2a_cols8_body(const Geo& g, 
     }
     if (live && sing && c == 0) atomicOr(&b.status[w], skd::ERR_SINGULAR_BVP);
 }
-template <class R> __global__ void __launch_bounds__(64, SKD_WPE_K2AC) kern_k2a_cols8(Geo g, Bufs b, int s, int m) { k2a_cols8_body<R>(g, b, s, m); }
+template <class R> __global__ void __launch_bounds__(64, SKD_WPE_K2AC) kern_k2a_cols8(Geo g, Bufs b, int s, int m) { k2a_cols8_body<R>(g, skd::order_view(b, blockIdx.z), s, m + blockIdx.z); }
 // the same with the whole register file (one wavefront per SIMD, nothing spilled to scratch) for launches that do not fill the SIMDs anyway:
 // few wavelengths per rank of a sharded run, where the layer recursion of this kernel is the critical path of the order pipeline
-template <class R> __global__ void __launch_bounds__(64, 1) kern_k2a_cols8_lone(Geo g, Bufs b, int s, int m) { k2a_cols8_body<R>(g, b, s, m); }
+template <class R> __global__ void __launch_bounds__(64, 1) kern_k2a_cols8_lone(Geo g, Bufs b, int s, int m) { k2a_cols8_body<R>(g, skd::order_view(b, blockIdx.z), s, m + blockIdx.z); }
 
 }  // namespace skdev

@@ -38,6 +38,9 @@
 #ifndef SKD_K1_LG
 #define SKD_K1_LG 16
 #endif
+#ifndef SKD_WPE_K3
+#define SKD_WPE_K3 3
+#endif
 
 #ifndef SKD_WPE_K1
 #define SKD_WPE_K1 2
@@ -845,7 +848,7 @@ template <int N> __global__ void __launch_bounds__(64, SKD_WPE_K2A) kern_k2a_wav
 // -------------------------------------------------------------------------------------------------------------------
 // K3: diffuse-source table values + convergence flags.  grid = wavelengths, block = 64 (lanes = table angles).
 // -------------------------------------------------------------------------------------------------------------------
-template <int N, class R = skd::Rec<N>> __global__ void __launch_bounds__(64) kern_k3_wave(Geo g, Bufs b, int s, int m, int layers_per_block) {
+template <int N, class R = skd::Rec<N>> __global__ void __launch_bounds__(64, SKD_WPE_K3) kern_k3_wave(Geo g, Bufs b, int s, int m, int layers_per_block) {
     // NG lane groups of LG lanes, one layer per group and pass (the per-layer phases only have N .. 2N lanes of work)
     constexpr int NSTR = 2 * N, NN = N * N, LG = (N >= 16) ? 32 : 16, NG = 64 / LG;
     const int w = blockIdx.x;
@@ -1409,6 +1412,8 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2AM) kern_k2a_mfma8(Geo g, Bufs b
 #endif
 template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b, int s, int m, int layers_per_block) {
     constexpr int N = 8, NSTR = 16, M2 = 16, FT = (FTILES > 0) ? FTILES : 1;
+    m += blockIdx.z;   // (batched azimuth orders: skd::order_view)
+    b = skd::order_view(b, blockIdx.z);
     using R = std::conditional_t<K1LANE, skd::RecC<N>, skd::Rec<N>>;       // kern_k1_lane writes column-block records
     // the record's image in LDS: column blocks 52 doubles apart (104 dwords = 40 mod 64: the eight solutions' entries fall on eight different
     // bank windows; 48 puts them on two)
@@ -1774,6 +1779,8 @@ template <int TILES, bool BWD_ONLY = false> __global__ void __launch_bounds__(64
 #pragma clang fp contract(off)
     constexpr int N = 8, NSTR = 16;
     using O = skd::Ops<N>;
+    m += blockIdx.z;   // (batched azimuth orders: skd::order_view; every order then adds into its own gradient rows, kern_grad_orders sums them)
+    b = skd::order_view(b, blockIdx.z);
     const int w = blockIdx.x;
     if (m >= b.norders[w]) return;
     const int lane = threadIdx.x, col = lane & 15, q = lane >> 4, nw = b.nw, nlyr = g.nlyr, nlos = g.nlos;

@@ -261,6 +261,22 @@ def test_c2_wavelength_blocks_in_flight_are_equivalent(monkeypatch):
             assert np.array_equal(one[k], other[k]), (split, k)
 
 
+def test_c2_azimuth_orders_batched_into_one_launch_equal_the_order_pipeline(monkeypatch):
+    """Small launches solve every azimuth order in one launch per kernel (gridDim.z = order, run_orders_batched); bit for bit the
+    order-by-order pipeline, with one and with two 16-LOS tiles, one and two solar zenith points."""
+    for nw, kw in ((300, {}), (130, dict(num_sza=2))):
+        s = sc.limb_c2(num_wavelengths=nw, **kw)
+        for rays in (s["rays"], s["rays"][:9]):
+            s["rays"] = rays
+            monkeypatch.delenv("SASKTRAN2_AMD_BATCH_ORDERS", raising=False)
+            batched = run_product(s)
+            monkeypatch.setenv("SASKTRAN2_AMD_BATCH_ORDERS", "0")
+            pipeline = run_product(s)
+            monkeypatch.delenv("SASKTRAN2_AMD_BATCH_ORDERS")
+            for k in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
+                assert np.array_equal(batched[k], pipeline[k]), (k, nw, len(rays))
+
+
 def test_c2_lane_per_problem_layer_solutions_equal_the_cooperative_kernel(monkeypatch):
     """16 streams: the layer solutions one (layer, wavelength) per lane with column-block records (kern_k1_lane, the default) against the
     cooperative kernel with standard records (SASKTRAN2_AMD_K1=wave): the same equations in another order of operations -- radiances to
