@@ -38,7 +38,7 @@ KERNEL_OF = {"kern_k1_wave": "k1_layer_solution", "kern_k1p_wave": "k1_layer_sol
              "kern_k2c_wave": "k2c_adjoint_ops", "kern_k3_wave": "k3_table_values", "kern_k4a": "k4a_chain", "kern_k4b": "k4b_los",
              "kern_k0": "k0_layer_optics", "kern_k0_tile": "k0_layer_optics", "kern_k0_shells": "k0_layer_optics", "kern_k0_los": "k0_layer_optics",
              "kern_k0t": "k0_transmission", "kern_cw": "k0_entry_weights", "kern_stop": "k_stop_rule", "kern_output": "k_output",
-             "kern_init": "init", "kern_kpp": "kpp_los"}
+             "kern_init": "init", "kern_kpp": "kpp_los", "kern_grad_orders": "k4a_chain", "kern_k4a_gt": "k4a_chain", "kern_k4a_apply": "k4a_chain"}
 
 
 def load_pmc_profile():
