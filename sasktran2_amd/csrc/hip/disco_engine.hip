@@ -687,10 +687,19 @@ static bool k1_lane_enabled() {
     const char* e = std::getenv("SASKTRAN2_AMD_K1");
     return !(e && std::string(e) == "wave");
 }
-static void launch_k1_lane8(hipStream_t st, const Geo& g, const Bufs& b, int s, int m) {
-    const dim3 grid(unsigned((b.nw + 63) / 64), unsigned(g.nlyr));
+// (SASKTRAN2_AMD_K1_FUSED=0: the eigen stage as a kernel of its own, kern_kj_lane<8, true>, handing over through b.eig)
+static bool k1_fused() {
+    static const bool on = [] { const char* e = std::getenv("SASKTRAN2_AMD_K1_FUSED"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
+static void launch_k1_lane8(hipStream_t st, const Geo& g, const Bufs& b, int s, int m, unsigned norders = 1) {
+    const dim3 grid(unsigned((b.nw + 63) / 64), unsigned(g.nlyr), norders);
+    if (k1_fused()) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_lane<8, true>), grid, dim3(64), 0, st, g, b, s, m);
+        return;
+    }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_kj_lane<8, true>), grid, dim3(64), 0, st, g, b, m);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_lane<8>), grid, dim3(64), 0, st, g, b, s, m);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_lane<8, false>), grid, dim3(64), 0, st, g, b, s, m);
 }
 // K1 launch: lane-group width per layer and the split of the layers over blockIdx.y
 template <int N>
@@ -786,11 +795,9 @@ static bool run_orders_batched(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& 
     const bool adj = derivs && g.n_lp > 0;
     hipStream_t sC = (!I.profiling && slot.adj_stream) ? slot.adj_stream : st;
     if (adj) HIP_CHECK(hipMemsetAsync(slot.bt_grad, 0, size_t(NORD) * bb.ord_grad * sizeof(double), st));
-    const dim3 lane_grid(unsigned((nw + 63) / 64), unsigned(nlyr), NORD);
     {
         Timer t(I, st, "k1_layer_solution");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_kj_lane<8, true>), lane_grid, dim3(64), 0, st, g, bb, 0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1_lane<8>), lane_grid, dim3(64), 0, st, g, bb, s, 0);
+        launch_k1_lane8(st, g, bb, s, 0, NORD);
     }
     {
         Timer t(I, st, "k2a_bvp");

@@ -49,58 +49,17 @@ __device__ __forceinline__ double kj_rcp(double x) {
     return y;
 }
 
-// -------------------------------------------------------------------------------------------------------------------
-// KJ: homogeneous eigenproblem of every layer (reference: sktran_do_rte.cpp:382-553, the eigen-decomposition of S- S+).
-//   grid = (ceil(nw / 64), nlyr), block = 64: lane = wavelength (coalesced reads of the [layer][l][w] layer optics), blockIdx.y = layer.
-//   B+- = delta / mu - sqrt(w_i w_j / mu_i mu_j) omega sum_l a_l P_l^m(mu_i) P_l^m(mu_j)   (l - m even: B+, odd: B-), symmetric
-//   B+ = R R^T (Cholesky), A = R^T B- R, A V = V diag(k^2) by cyclic Jacobi, X = T^-1 R^-T V   (the formulation of kern_k1_wave)
-//   Output into the layer record for kern_k1_wave<.., PRE = true>: k_j^2 at [R::K + j], X(i, j) at [R::DWP + i * N + j]
-//   (both fields are rewritten by K1 itself with their final contents), transposed through LDS so that a record's 72 doubles
-//   leave as contiguous runs.
-// A lane whose problem has converged is frozen (identity rotations), so a problem's result does not depend on the other
-// problems of its wavefront.
-// -------------------------------------------------------------------------------------------------------------------
-// SOA = true: the eigen-solution goes to b.eig[(layer * (N + N N) + e) * nw + w] (e < N: k_j^2; then Xhat(i, j) = (T X)(i, j), the
-// eigenvectors before the T^-1 scaling) with plain coalesced stores, for kern_k1_lane.
-template <int N, bool SOA = false> __global__ void __launch_bounds__(64, SKD_WPE_KJ) kern_kj_lane(Geo g, Bufs b, int m) {
-    m += blockIdx.z;   // (batched azimuth orders: skd::order_view)
-    b = skd::order_view(b, blockIdx.z);
-    constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, HALF = NOUT / 2, STRIDE = HALF + 1, NM1 = N - 1, JH = N / 2;
-    static_assert(NOUT % 2 == 0, "two output halves");
-    using R = skd::Rec<N>;
-    const int lane = threadIdx.x, p = blockIdx.y, nw = b.nw, nlyr = g.nlyr;
-    const int w0 = blockIdx.x * 64, w = w0 + lane;
-    __shared__ double sPP[NPAIR * NSTR];   // sqrt(w_i w_j / mu_i mu_j) P_{m+k}(mu_i) P_{m+k}(mu_j), pair (i >= j), k = l - m (0 past the last order)
-    __shared__ double sIm[N], sIt[N];
-    __shared__ double sOut[64 * STRIDE];
-    __shared__ int sLive[64];
-    const bool live = (w < nw) && (m < b.norders[w]);
-    if (!__any(live)) return;
-    {
-        const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
-        for (int e = lane; e < NPAIR * NSTR; e += 64) {
-            const int pr = e / NSTR, k = e % NSTR, l = m + k;
-            int i = 0;
-            while ((i + 1) * (i + 2) / 2 <= pr) ++i;
-            const int j = pr - i * (i + 1) / 2;
-            sPP[e] = (l < NSTR) ? sqrt(g.wt[i] / g.mu[i]) * sqrt(g.wt[j] / g.mu[j]) * lpmu[i * NSTR + l] * lpmu[j * NSTR + l] : 0.0;
-        }
-        if (lane < N) {
-            sIm[lane] = 1.0 / g.mu[lane];
-            sIt[lane] = 1.0 / sqrt(g.wt[lane] * g.mu[lane]);
-        }
-        sLive[lane] = live ? 1 : 0;
-    }
-    // Legendre coefficients from order m on (a'[k] = a_{m+k}); a lane without a problem solves the identity-like a = 0 case
-    double a[NSTR];
-#pragma unroll
-    for (int k = 0; k < NSTR; ++k) a[k] = (live && m + k < NSTR) ? b.a[(size_t(p) * NSTR + m + k) * nw + w] : 0.0;
-    const double om = live ? b.om[size_t(p) * nw + w] : 0.0;
-    __syncthreads();
-
+// Eigen stage of one (layer, wavelength) problem in this lane's registers: B+- from the Legendre coefficients a'[k] = a_{m+k} (sPP, sIm: the
+// block's LDS tables), Cholesky B+ = R R^T, A = R^T B- R, cyclic Jacobi.  Out: Rc (the factor R, lower), rinv (1 / R_ii), V (the eigenvectors of
+// A, NOT yet back-substituted: R^T Xhat), lam (k_j^2, made positive); store_bm(pair, value) receives the entries of B- (lower triangle).
+// Returns the error bits.  Shared by kern_kj_lane (eigen-solutions for the cooperative K1) and kern_k1_lane (whole layer solution per lane).
+template <int N, class BMSTORE>
+__device__ __forceinline__ int kj_eigen_stage(const double (&a)[2 * N], double om, bool live, const double* sPP, const double* sIm, double (&Rc)[N][N],
+                                              double (&rinv)[N], double (&V)[N][N], double (&lam)[N], BMSTORE&& store_bm) {
+    constexpr int NSTR = 2 * N, NM1 = N - 1, JH = N / 2;
     int err = 0;
     // ---- B+ (lower triangle, becomes the Cholesky factor) and B- (lower triangle)
-    double Rc[N][N], Bm[N][N];
+    double Bm[N][N];
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -115,9 +74,9 @@ template <int N, bool SOA = false> __global__ void __launch_bounds__(64, SKD_WPE
             const double dlt = (i == j) ? sIm[i] : 0.0;
             Rc[i][j] = fma(-om, ep, dlt);
             Bm[i][j] = fma(-om, em, dlt);
+            store_bm(i * (i + 1) / 2 + j, Bm[i][j]);
         }
     // ---- Cholesky B+ = R R^T (lower, in place), reciprocal diagonal kept
-    double rinv[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         double tj = Rc[j][j];
@@ -136,7 +95,7 @@ template <int N, bool SOA = false> __global__ void __launch_bounds__(64, SKD_WPE
         }
     }
     // ---- A = R^T B- R (upper triangle A[i][j], i <= j), column by column: m3 = B- R[:, j], A[i][j] = sum_{r >= i} R[r][i] m3[r]
-    double A[N][N], V[N][N];
+    double A[N][N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         double m3[N];
@@ -232,14 +191,67 @@ template <int N, bool SOA = false> __global__ void __launch_bounds__(64, SKD_WPE
         }
     }
     if (!done) err |= skd::ERR_EIGEN;
-    // ---- eigenvalues, X = T^-1 R^-T V (column by column), staged in LDS in two halves and written as contiguous runs
-    double lam[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         double l = A[j][j];
         if (!(l > 0)) { err |= skd::ERR_EIGEN; l = fabs(l) + 1e-300; }
         lam[j] = l;
     }
+    return err;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// KJ: homogeneous eigenproblem of every layer (reference: sktran_do_rte.cpp:382-553, the eigen-decomposition of S- S+).
+//   grid = (ceil(nw / 64), nlyr), block = 64: lane = wavelength (coalesced reads of the [layer][l][w] layer optics), blockIdx.y = layer.
+//   B+- = delta / mu - sqrt(w_i w_j / mu_i mu_j) omega sum_l a_l P_l^m(mu_i) P_l^m(mu_j)   (l - m even: B+, odd: B-), symmetric
+//   B+ = R R^T (Cholesky), A = R^T B- R, A V = V diag(k^2) by cyclic Jacobi, X = T^-1 R^-T V   (the formulation of kern_k1_wave)
+//   Output into the layer record for kern_k1_wave<.., PRE = true>: k_j^2 at [R::K + j], X(i, j) at [R::DWP + i * N + j]
+//   (both fields are rewritten by K1 itself with their final contents), transposed through LDS so that a record's 72 doubles
+//   leave as contiguous runs.
+// A lane whose problem has converged is frozen (identity rotations), so a problem's result does not depend on the other
+// problems of its wavefront.
+// -------------------------------------------------------------------------------------------------------------------
+// SOA = true: the eigen-solution goes to b.eig[(layer * (N + N N) + e) * nw + w] (e < N: k_j^2; then Xhat(i, j) = (T X)(i, j), the
+// eigenvectors before the T^-1 scaling) with plain coalesced stores, for kern_k1_lane.
+template <int N, bool SOA = false> __global__ void __launch_bounds__(64, SKD_WPE_KJ) kern_kj_lane(Geo g, Bufs b, int m) {
+    m += blockIdx.z;   // (batched azimuth orders: skd::order_view)
+    b = skd::order_view(b, blockIdx.z);
+    constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, HALF = NOUT / 2, STRIDE = HALF + 1, NM1 = N - 1, JH = N / 2;
+    static_assert(NOUT % 2 == 0, "two output halves");
+    using R = skd::Rec<N>;
+    const int lane = threadIdx.x, p = blockIdx.y, nw = b.nw, nlyr = g.nlyr;
+    const int w0 = blockIdx.x * 64, w = w0 + lane;
+    __shared__ double sPP[NPAIR * NSTR];   // sqrt(w_i w_j / mu_i mu_j) P_{m+k}(mu_i) P_{m+k}(mu_j), pair (i >= j), k = l - m (0 past the last order)
+    __shared__ double sIm[N], sIt[N];
+    __shared__ double sOut[64 * STRIDE];
+    __shared__ int sLive[64];
+    const bool live = (w < nw) && (m < b.norders[w]);
+    if (!__any(live)) return;
+    {
+        const double* lpmu = g.lpmu + size_t(m) * N * NSTR;
+        for (int e = lane; e < NPAIR * NSTR; e += 64) {
+            const int pr = e / NSTR, k = e % NSTR, l = m + k;
+            int i = 0;
+            while ((i + 1) * (i + 2) / 2 <= pr) ++i;
+            const int j = pr - i * (i + 1) / 2;
+            sPP[e] = (l < NSTR) ? sqrt(g.wt[i] / g.mu[i]) * sqrt(g.wt[j] / g.mu[j]) * lpmu[i * NSTR + l] * lpmu[j * NSTR + l] : 0.0;
+        }
+        if (lane < N) {
+            sIm[lane] = 1.0 / g.mu[lane];
+            sIt[lane] = 1.0 / sqrt(g.wt[lane] * g.mu[lane]);
+        }
+        sLive[lane] = live ? 1 : 0;
+    }
+    // Legendre coefficients from order m on (a'[k] = a_{m+k}); a lane without a problem solves the identity-like a = 0 case
+    double a[NSTR];
+#pragma unroll
+    for (int k = 0; k < NSTR; ++k) a[k] = (live && m + k < NSTR) ? b.a[(size_t(p) * NSTR + m + k) * nw + w] : 0.0;
+    const double om = live ? b.om[size_t(p) * nw + w] : 0.0;
+    __syncthreads();
+
+    double Rc[N][N], rinv[N], V[N][N], lam[N];
+    int err = kj_eigen_stage<N>(a, om, live, sPP, sIm, Rc, rinv, V, lam, [](int, double) {});
+    // ---- X = T^-1 R^-T V (column by column), staged in LDS in two halves and written as contiguous runs
 #pragma unroll
     for (int j = 0; j < N; ++j) {
 #pragma unroll
@@ -327,7 +339,9 @@ __device__ __forceinline__ double row16_sum(double v) {
 // products where it needs them (Bufs::k1_lane).
 //   grid = (ceil(nw / 64), nlyr), block = 64, one wavefront per SIMD (the kernel owns the register file).
 // -------------------------------------------------------------------------------------------------------------------
-template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bufs b, int s, int m) {
+// FUSED: the eigen stage runs here too (kj_eigen_stage) -- no eigen-solution through HBM, B- straight into its LDS table, and
+// Uhat = B+ Xhat = R (R^T Xhat) = R V from the Cholesky factor and the Jacobi eigenvectors at hand (288 instead of 512 multiply-adds, no B+)
+template <int N, bool FUSED = true> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bufs b, int s, int m) {
     m += blockIdx.z;   // (batched azimuth orders: skd::order_view)
     b = skd::order_view(b, blockIdx.z);
     constexpr int NSTR = 2 * N, NPAIR = N * (N + 1) / 2, NOUT = N + N * N, CH = 3 * N + 1, HB = 3 * N / 2;   // CH: odd staging stride; HB: 16-byte pieces per half block
@@ -381,8 +395,10 @@ template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bu
     const double om = b.om[size_t(p) * nw + wl], th = b.tau[size_t(p) * nw + wl];
     const double T = b.T[size_t(p) * nw + wl], sc = b.sec[size_t(p) * nw + wl];
     const double inv_om = 1.0 / om;
-    double xh[N][N], lam[N];
-    {
+    double xh[N][N], lam[N], uh[N][N], qp[N], qm[N];
+    bool allzero = true;
+    int err = 0;
+    if constexpr (!FUSED) {
         const double* in = b.eig + size_t(p) * NOUT * nw + wl;
 #pragma unroll
         for (int j = 0; j < N; ++j) lam[j] = in[size_t(j) * nw];
@@ -392,11 +408,34 @@ template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bu
             for (int j = 0; j < N; ++j) xh[i][j] = in[size_t(N + i * N + j) * nw];
     }
     __syncthreads();
-    int err = 0;
-    // ---- B+ (registers, lower triangle) and B- (LDS);  solar pseudo-source Q+- (sktran_do_rte.cpp:555-580);  Uhat = B+ Xhat
-    double uh[N][N], qp[N], qm[N];
-    bool allzero = true;
-    {
+    if constexpr (FUSED) {
+        // ---- eigen stage (B- goes to LDS as it is formed), then Uhat = R V and Xhat = R^-T V
+        double Rc[N][N], rinv[N];
+        SKD_QR_FENCE
+        err = kj_eigen_stage<N>(a, om, live, sPP, sIm, Rc, rinv, xh, lam, [&](int pair, double v) { sBm[pair * 64 + lane] = v; });
+        SKD_QR_FENCE
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double t = 0;
+#pragma unroll
+                for (int r = 0; r <= i; ++r) t = fma(Rc[i][r], xh[r][j], t);
+                uh[i][j] = t;
+            }
+        SKD_QR_FENCE
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+#pragma unroll
+            for (int i = N - 1; i >= 0; --i) {
+                double t = xh[i][j];
+#pragma unroll
+                for (int r = i + 1; r < N; ++r) t = fma(-Rc[r][i], xh[r][j], t);
+                xh[i][j] = t * rinv[i];
+            }
+        }
+    } else {
+        // ---- B+ (registers, lower triangle) and B- (LDS);  Uhat = B+ Xhat
         double bp[N][N];
 #pragma unroll
         for (int i = 0; i < N; ++i)
@@ -413,18 +452,6 @@ template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bu
                 bp[i][j] = fma(-om, ep, dlt);
                 sBm[(i * (i + 1) / 2 + j) * 64 + lane] = fma(-om, em, dlt);
             }
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            double sp = 0, sn = 0;
-#pragma unroll
-            for (int k = 0; k < NSTR; k += 2) {
-                sp = fma(a[k], sQ[i * NSTR + k], sp);
-                sn = fma(a[k + 1], sQ[i * NSTR + k + 1], sn);
-            }
-            qp[i] = (sp + sn) * om;
-            qm[i] = (sp - sn) * om;
-            allzero = allzero && (qp[i] == 0.0) && (qm[i] == 0.0);
-        }
         SKD_QR_FENCE
 #pragma unroll
         for (int i = 0; i < N; ++i)
@@ -435,6 +462,25 @@ template <int N> __global__ void __launch_bounds__(64, 1) kern_k1_lane(Geo g, Bu
                 for (int r = 0; r < N; ++r) t = fma((i >= r) ? bp[i][r] : bp[r][i], xh[r][j], t);
                 uh[i][j] = t;
             }
+    }
+    // ---- solar pseudo-source Q+- (sktran_do_rte.cpp:555-580); FUSED: the Legendre coefficients are read again here -- sixteen coalesced loads
+    // instead of sixteen register pairs held through the Jacobi sweeps
+    if constexpr (FUSED) {
+        SKD_QR_FENCE
+#pragma unroll
+        for (int k = 0; k < NSTR; ++k) a[k] = (m + k < NSTR) ? b.a[(size_t(p) * NSTR + m + k) * nw + wl] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double sp = 0, sn = 0;
+#pragma unroll
+        for (int k = 0; k < NSTR; k += 2) {
+            sp = fma(a[k], sQ[i * NSTR + k], sp);
+            sn = fma(a[k + 1], sQ[i * NSTR + k + 1], sn);
+        }
+        qp[i] = (sp + sn) * om;
+        qm[i] = (sp - sn) * om;
+        allzero = allzero && (qp[i] == 0.0) && (qm[i] == 0.0);
     }
     // ---- separation constants
     double lmax = 0;
