@@ -648,9 +648,15 @@ template <int N, bool FUSED = true> __global__ void __launch_bounds__(64, 1) ker
 // Inverse of a 16 x 16 matrix by Householder QR, column per lane:  H_15 .. H_0 [A | I] = [R | Q^T],  A^-1 = R^-1 Q^T.
 // a[] (column c of A) is destroyed, inv[] receives column c of the inverse.  No pivot search and no data-dependent control
 // flow: unconditionally backward stable, the same instruction stream for every matrix.  Returns 1 if a column norm vanished.
-template <class MID> __device__ __forceinline__ int qr16_inverse_cols(double (&a)[16], double (&inv)[16], int c, MID&& mid) {
+// sR (optional, LDS, 16 x SKD_K2A_RS doubles of this lane's 16-lane row): the back substitution reads R[r][i] from there -- every lane
+// writes its column of R once, the reads are broadcasts inside the row, two entries per 16-byte read -- instead of one cross-lane move per
+// entry (120 of the 557 v_mov_b64_dpp of a layer; the moves, not the multiply-adds, bound this kernel's issue).
+#ifndef SKD_K2A_RS
+#define SKD_K2A_RS 18
+#endif
+template <bool LDS = false, class MID> __device__ __forceinline__ int qr16_inverse_cols(double (&a)[16], double (&inv)[16], int c, MID&& mid, double* sR = nullptr) {
     constexpr int M2 = 16;
-    double rinv[M2];   // 1 / R[k][k], the same in every lane of the row
+    double rinv[LDS ? 1 : M2];   // 1 / R[k][k], the same in every lane of the row (LDS: kept in the padding behind column k of sR)
     int sing = 0;
 #pragma unroll
     for (int i = 0; i < M2; ++i) inv[i] = (i == c) ? 1.0 : 0.0;
@@ -678,7 +684,7 @@ template <class MID> __device__ __forceinline__ int qr16_inverse_cols(double (&a
 #pragma unroll
             for (int i = k + 1; i < M2; ++i) vb[i] = row_bcast<k>(a[i]);
             const bool own = (c == k);
-            rinv[k] = -betab * vkb;
+            if constexpr (LDS) sR[k * SKD_K2A_RS + 16] = -betab * vkb; else rinv[k] = -betab * vkb;
             sing |= (row_bcast<k>(n2) > 0.0) ? 0 : 1;
             double da[4] = {vkb * a[k], 0, 0, 0}, dq[4] = {vkb * inv[k], 0, 0, 0};
 #pragma unroll
@@ -698,11 +704,30 @@ template <class MID> __device__ __forceinline__ int qr16_inverse_cols(double (&a
             // last column: a 1 x 1 reflection is the identity, R[15][15] = x_15
             const double xb = row_bcast<k>(xk);
             sing |= (xb == 0.0) ? 1 : 0;
-            rinv[k] = kj_rcp((xb == 0.0) ? 1.0 : xb);
+            if constexpr (LDS) sR[k * SKD_K2A_RS + 16] = kj_rcp((xb == 0.0) ? 1.0 : xb); else rinv[k] = kj_rcp((xb == 0.0) ? 1.0 : xb);
         }
     });
     // back substitution  x = R^-1 y  on the own column of Q^T, column oriented:  x_i = y_i / R[i][i],  y_r -= R[r][i] x_i (r < i)
     // with R[r][i] = register r of lane i
+    if constexpr (LDS) {
+        // column c of R (rows r < c; the rest is not read) -> sR[c][r]
+#pragma unroll
+        for (int r = 0; r < M2 - 1; r += 2) *reinterpret_cast<double2*>(&sR[c * SKD_K2A_RS + r]) = make_double2(a[r], a[r + 1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<M2>([&](auto ic) {
+            constexpr int i = M2 - 1 - decltype(ic)::value;
+            SKD_QR_FENCE
+            const double xi = inv[i] * sR[i * SKD_K2A_RS + 16];
+            inv[i] = xi;
+            static_for<(i + 1) / 2>([&](auto rc) {
+                constexpr int r = 2 * decltype(rc)::value;
+                const double2 rr = *reinterpret_cast<const double2*>(&sR[i * SKD_K2A_RS + r]);
+                inv[r] = fma(-rr.x, xi, inv[r]);
+                if constexpr (r + 1 < i) inv[r + 1] = fma(-rr.y, xi, inv[r + 1]);
+            });
+        });
+        return sing;
+    } else {
     static_for<M2>([&](auto ic) {
         constexpr int i = M2 - 1 - decltype(ic)::value;
         SKD_QR_FENCE
@@ -714,6 +739,7 @@ template <class MID> __device__ __forceinline__ int qr16_inverse_cols(double (&a
         });
     });
     return sing;
+    }
 }
 
 #ifndef SKD_WPE_K2AC
@@ -736,9 +762,14 @@ template <class R> __device__ __forceinline__ void k2a_cols8_body(const Geo& g, 
     if (!__any(live)) return;
     const int wl = min(w, nw - 1);   // a row without a wavelength works on a valid record and stores nothing
     const double rho = (m == 0) ? b.albedo[wl] : 0.0;
-    double wmu[N];
-#pragma unroll
-    for (int t = 0; t < N; ++t) wmu[t] = g.wt[t] * g.mu[t];
+    // cross-lane operands of the layer products through LDS (broadcast reads inside a 16-lane row) instead of row_newbcast moves:
+    // Sub (8 x 16), T1 (8 x 16) and the R factor of the block (16 x 16) per wavelength row; row strides padded against bank conflicts
+    // between the four rows of a wavefront
+    constexpr int SS = 8 * 16 + 2, RS = 16 * SKD_K2A_RS + 2;
+    __shared__ __attribute__((aligned(16))) double sSubAll[4 * SS], sT1All[4 * SS], sRAll[4 * RS];
+    double* sSub = sSubAll + grp * SS;
+    double* sT1 = sT1All + grp * SS;
+    double* sRm = sRAll + grp * RS;
     double subc[N], dinv[M2], rprev = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) subc[i] = 0;
@@ -782,9 +813,10 @@ template <class R> __device__ __forceinline__ void k2a_cols8_body(const Geo& g, 
             const double* rec = skd::rec_at_r<R>(b, nlyr, p, wl);
 #pragma unroll
             for (int t = 0; t < N; ++t) {
-                gsp = fma(wmu[t], wp[t], gsp);
-                gsm = fma(wmu[t], wm[t], gsm);
-                gsg = fma(wmu[t], rec[R::g(2 * N + t)], gsg);
+                const double wmu = g.wt[t] * g.mu[t];
+                gsp = fma(wmu, wp[t], gsp);
+                gsm = fma(wmu, wm[t], gsm);
+                gsg = fma(wmu, rec[R::g(2 * N + t)], gsg);
             }
             const double corr = 2.0 * rho * (lo ? gsp * Ec : gsm);
 #pragma unroll
@@ -796,17 +828,33 @@ template <class R> __device__ __forceinline__ void k2a_cols8_body(const Geo& g, 
             double t1[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) t1[i] = 0;
-            static_for<M2>([&](auto jx) {
-                constexpr int j = decltype(jx)::value;
 #pragma unroll
-                for (int i = 0; i < N; ++i) t1[i] = fma(row_bcast<j>(subc[i]), dinv[j], t1[i]);
-            });
+            for (int i = 0; i < N; ++i) sSub[i * 16 + c] = subc[i];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < M2; j += 2) {
+                SKD_QR_FENCE   // (keeps the scheduler from requesting all 64 operand pairs at once: registers)
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double2 sv = *reinterpret_cast<const double2*>(&sSub[i * 16 + j]);
+                    t1[i] = fma(sv.x, dinv[j], t1[i]);
+                    t1[i] = fma(sv.y, dinv[j + 1], t1[i]);
+                }
+            }
             // D'[i][c] += sum_q T1[i][8 + q] S_p[q][c]
-            static_for<N>([&](auto qx) {
-                constexpr int q = decltype(qx)::value;
 #pragma unroll
-                for (int i = 0; i < N; ++i) a[i] = fma(row_bcast<N + q>(t1[i]), sc[q], a[i]);
-            });
+            for (int i = 0; i < N; ++i) sT1[i * 16 + c] = t1[i];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < N; q += 2) {
+                SKD_QR_FENCE
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double2 tv = *reinterpret_cast<const double2*>(&sT1[i * 16 + N + q]);
+                    a[i] = fma(tv.x, sc[q], a[i]);
+                    a[i] = fma(tv.y, sc[q + 1], a[i]);
+                }
+            }
             // r'[i] -= sum_c T1[i][c] r'_{p-1}[c]
             double tr = 0;
 #pragma unroll
@@ -816,7 +864,7 @@ template <class R> __device__ __forceinline__ void k2a_cols8_body(const Geo& g, 
             }
             rv -= tr;
         }
-        sing |= qr16_inverse_cols(a, dinv, c, [] {});
+        sing |= qr16_inverse_cols<true>(a, dinv, c, [] {}, sRm);
         if (live) {
             double* dg = skd::dinv_at<N>(b, nlyr, p, w);
 #pragma unroll
