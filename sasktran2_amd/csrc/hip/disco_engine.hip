@@ -720,9 +720,9 @@ static void launch_k1(hipStream_t st, const Geo& g, const Bufs& b, int s, int m,
 }
 
 template <int N>
-static void launch_k3(hipStream_t st, const Geo& g, const Bufs& b, int s, int m) {
+static void launch_k3(hipStream_t st, const Geo& g, const Bufs& b, int s, int m, int split_override = 0) {
     constexpr int NG = (N >= 16) ? 2 : 4;  // layers per pass of kern_k3_wave
-    const int split = small_batch_split(b.nw);
+    const int split = split_override > 0 ? split_override : small_batch_split(b.nw);
     int lpb = (g.nlyr + split - 1) / split;
     lpb = (lpb + NG - 1) / NG * NG;
     const int ny = (g.nlyr + lpb - 1) / lpb;
@@ -810,7 +810,9 @@ static bool run_orders_batched(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& 
         const Bufs bm = order_bufs(m);
         {
             Timer t(I, st, "k3_table_values");
-            launch_k3<8>(st, g, bm, s, m);
+            // (one pass of four layers per block: the table values are the one stage that runs order after order here, so the length of a
+            // block's chain of passes is what the step waits for -- 16 x)
+            launch_k3<8>(st, g, bm, s, m, (g.nlyr + 3) / 4);
         }
         if (adj) {
             Timer t(I, st, "k2q_live_flags");
