@@ -254,8 +254,10 @@ void sk_amd_host_free(void* ptr);
  * Rest of the reference's C API (the headers under cpp/include/c_api): every symbol its FFI links against is exported, so replacing
  * libcsasktran2 by this library is a pure link-time choice.  Entry points outside the DISCO hot path keep the
  * reference's signatures; they store / return their settings where that is all they do, and report "unsupported"
- * (-2, or a null handle) where they would need an engine this build does not contain (2D geometry, JVP / VJP, flux
- * observers, geodetic utilities, non-Lambertian BRDFs).  Reference line numbers as above.
+ * (-2, or a null handle) where they would need an engine this build does not contain (2D geometry, flux weighting
+ * functions, geodetic utilities, non-Lambertian BRDFs).  Flux observers are served by the plane-parallel discrete-ordinates source
+ * (do_source_planeparallel.cpp:221-566): sk_output_create's flux block is [flux type][wavelength][observer] in the order of
+ * sk_config_set_flux_types (0 upwelling, 1 downwelling, 2 actinic).  Reference line numbers as above.
  * ===================================================================================================================== */
 typedef struct Geometry2D Geometry2D;
 typedef struct Geodetic Geodetic;

@@ -71,6 +71,7 @@ struct Result {
     std::vector<double> deriv;     // [nlos][nstokes][nnative]
     std::vector<double> los_od;    // [nlos]
     int num_azimuth_used = 0;
+    std::vector<double> flux;      // [flux observer][3]: upwelling, downwelling, actinic (plane-parallel post-processing only)
 };
 
 class Solver {
@@ -883,11 +884,65 @@ class Solver {
     void accumulate_sources(int m, int szaidx);
     void integrate_los(const AtmosphereView& atm, int w, Result& res);
 
+    void compute_flux(Result& res);
+
   public:
     void solve(const AtmosphereView& atm, int w, Result& res);
+    // plane-parallel post-processing: > 0 solves exactly this many azimuth orders (Config::num_do_forced_azimuth, do_source_planeparallel.cpp:55-60)
+    int forced_azimuth = 0;
+    // flux observers (altitudes in m above the surface), plane-parallel post-processing only
+    std::vector<double> flux_altitudes;
 };
 
 // ======================================================================================
+// Fluxes through horizontal surfaces at the flux observers from the order-0 solution
+// (DOSourcePlaneParallelPostProcessing::compute_flux, cpp/lib/sktran_disco/source_term/do_source_planeparallel.cpp:221-566; the sampled
+// multipliers h+- and D+- of cpp/include/sktran_disco/sktran_do_postprocessing.h:19-330, values only).
+inline void Solver::compute_flux(Result& res) {
+    if (S != 1) throw std::invalid_argument("flux observers: NSTOKES = 1 only");
+    res.flux.assign(flux_altitudes.size() * 3, 0.0);
+    for (size_t o = 0; o < flux_altitudes.size(); ++o) {
+        const double alt = flux_altitudes[o];
+        // OpticalLayerArray::layerAtAltitude: the first layer from the top whose floor is not above the observer
+        int p = nlyr - 1;
+        for (int r = 0; r < nlyr; ++r)
+            if (G.floor_h[r] <= alt) { p = r; break; }
+        const double lf = (G.ceil_h[p] - alt) / (G.ceil_h[p] - G.floor_h[p]);
+        const double th = tau[p], x = lf * th, T = trans[p], sc = sec[p];
+        double up = 0, dn = 0, up_a = 0, dn_a = 0;
+        for (int j = 0; j < n; ++j) {
+            const double ev = eigk[size_t(p) * n + j];
+            const double Hp = std::exp(-ev * th * lf), Hm = std::exp(-ev * th * (1 - lf));
+            const double Dm = T * (std::exp(-x * ev) - std::exp(-x * sc)) / (sc - ev);
+            const double Dp = T * (std::exp(-x * sc) - std::exp(-th * sc) * std::exp(-(th - x) * ev)) / (ev + sc);
+            double plus = Lc[size_t(p) * n + j] * Hp + Ap[size_t(p) * n + j] * Dm;
+            double minus = Mc[size_t(p) * n + j] * Hm + Am[size_t(p) * n + j] * Dp;
+            if (thermal) {
+                const double b0 = th_b0[p], b1 = th_b1[p];
+                const double Dm_t = b0 * (std::exp(-x * ev) - std::exp(-x * b1)) / (b1 - ev);
+                const double Dp_t = b0 * (std::exp(-x * b1) - std::exp(-th * b1) * std::exp(-(th - x) * ev)) / (ev + b1);
+                plus += Ap_th[size_t(p) * n + j] * Dm_t;
+                minus += Am_th[size_t(p) * n + j] * Dp_t;
+            }
+            for (int l = 0; l < N; ++l) {
+                const double q = G.wt[l] * 2.0 * kPi, hp = Wp[hidx(p, l, j)], hm = Wm[hidx(p, l, j)];
+                const double d = minus * hm + plus * hp, u = minus * hp + plus * hm;
+                dn += q * G.mu[l] * d;
+                up += q * G.mu[l] * u;
+                dn_a += q * d;
+                up_a += q * u;
+            }
+        }
+        if (include_ss) {   // the direct beam at the layer's ceiling, as the reference adds it
+            dn += T * G.csz[cur_sza];
+            dn_a += T;
+        }
+        res.flux[o * 3 + 0] = up;
+        res.flux[o * 3 + 1] = dn;
+        res.flux[o * 3 + 2] = up_a + dn_a;
+    }
+}
+
 inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<double>& rad, std::vector<double>& drad) {
     (void)szaidx;
     const int p_bot = nlyr - 1;
@@ -1338,8 +1393,10 @@ inline void Solver::solve(const AtmosphereView& atm, int w, Result& res) {
         integrate_los(atm, w, res);
     } else {
         configure_layers(atm, w, 0);
-        for (int m = 0; m < nstr; ++m) {
+        const int num_azi = forced_azimuth > 0 ? forced_azimuth : nstr;
+        for (int m = 0; m < num_azi; ++m) {
             solve_order(m, 0);
+            if (m == 0 && !flux_altitudes.empty()) compute_flux(res);
             pp_postprocess(m, 0, res, res.radiance, res.deriv);
             res.num_azimuth_used = m + 1;
         }

@@ -4,6 +4,7 @@
 // Threading mirrors the reference engine: one `#pragma omp parallel for` over wavelengths with
 // thread-private solver workspaces (cpp/lib/engine/engine.cpp:610-622).
 #include <malloc.h>
+#include <algorithm>
 #include <cstdio>
 #include <memory>
 #include <string>
@@ -23,6 +24,9 @@ struct Handle {
     int ss_in_do = 1;
     const double* delta_f = nullptr;
     const double *emission = nullptr, *surface_emission = nullptr;
+    int forced_azimuth = 0;              // plane-parallel post-processing: > 0 solves exactly this many azimuth orders
+    std::vector<double> flux_altitudes;  // flux observers (m)
+    double* flux_out = nullptr;          // [nwavel][observer][3] (upwelling, downwelling, actinic) of the next orc_run calls
     std::string error;
 };
 }  // namespace
@@ -117,6 +121,22 @@ int orc_set_emission(void* hv, const double* emission, const double* surface_emi
     h->surface_emission = surface_emission;
     return 0;
 }
+// plane-parallel post-processing: number of azimuth orders to solve (<= 0: all of them), flux observers and where the next orc_run calls
+// write their fluxes [nwavel][observer][3] (upwelling, downwelling, actinic)
+int orc_set_forced_azimuth(void* hv, int n) {
+    auto* h = static_cast<Handle*>(hv);
+    if (!h) return -1;
+    h->forced_azimuth = n;
+    return 0;
+}
+int orc_set_flux_observers(void* hv, const double* altitudes, int n, double* flux_out) {
+    auto* h = static_cast<Handle*>(hv);
+    if (!h || n < 0 || (n > 0 && (!altitudes || !flux_out))) return -1;
+    if (n > 0 && h->dg.spherical_pp) return -2;
+    h->flux_altitudes.assign(altitudes, altitudes + n);
+    h->flux_out = n > 0 ? flux_out : nullptr;
+    return 0;
+}
 int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg,
             const double* solar_irradiance, const double* albedo, int derivatives, int nthreads, double* radiance,
             double* d_k, double* d_ssa, double* d_albedo, double* los_od, int* n_azimuth) {
@@ -147,6 +167,8 @@ int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
         oracle::Result res;
         try {
             solver = std::make_unique<oracle::Solver>(h->dg, atm.derivatives, h->ss_in_do != 0);
+            solver->forced_azimuth = h->forced_azimuth;
+            solver->flux_altitudes = h->flux_altitudes;
         } catch (const std::exception& e) {
             std::fprintf(stderr, "orc_run: %s\n", e.what());
             status = -3;
@@ -181,6 +203,7 @@ int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
                     }
                 }
                 if (n_azimuth) n_azimuth[w] = res.num_azimuth_used;
+                if (h->flux_out) std::copy(res.flux.begin(), res.flux.end(), h->flux_out + size_t(w) * res.flux.size());
             } catch (const std::exception& e) {
                 std::fprintf(stderr, "orc_run (wavelength %d): %s\n", w, e.what());
                 status = -3;

@@ -49,6 +49,8 @@ def lib():
                               ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _ip]
         L.orc_set_delta_f.argtypes = [ctypes.c_void_p, _dp]
         L.orc_set_emission.argtypes = [ctypes.c_void_p, _dp, _dp]
+        L.orc_set_forced_azimuth.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_set_flux_observers.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp]
         L.orc_num_sza.argtypes = [ctypes.c_void_p]
         L.orc_chapman.argtypes = [ctypes.c_void_p, _dp]
         L.orc_streams.argtypes = [ctypes.c_void_p, _dp, _dp]
@@ -116,10 +118,12 @@ class OracleEngine:
         return mu, wt
 
     def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, derivatives=False, nthreads=1, delta_f=None, emission=None,
-            surface_emission=None):
+            surface_emission=None, forced_azimuth=0, flux_altitudes=None):
         """extinction, ssa: [ngrid, nwavel]; leg: [nleg, ngrid, nwavel] (nstokes = 3: [4 * nleg, ngrid, nwavel] with
         a1, a2, a3, b1 per order); albedo: [nwavel] (Fortran-style axes as in the reference storage: location fastest).
-        Outputs carry a trailing Stokes axis for nstokes = 3 (radiance [nwavel, nlos, 3], d_* [nwavel, nlos, 3, ngrid])."""
+        Outputs carry a trailing Stokes axis for nstokes = 3 (radiance [nwavel, nlos, 3], d_* [nwavel, nlos, 3, ngrid]).
+        Plane-parallel post-processing only: `forced_azimuth` > 0 solves exactly that many azimuth orders (Config.num_forced_azimuth);
+        `flux_altitudes` adds "upwelling_flux", "downwelling_flux", "actinic_flux" [nwavel, observer] at those altitudes."""
         k = np.asfortranarray(extinction, dtype=np.float64)
         w = np.asfortranarray(ssa, dtype=np.float64)
         lg = np.asfortranarray(leg, dtype=np.float64)
@@ -141,11 +145,21 @@ class OracleEngine:
             dk = np.zeros(sshape + (self.ngrid,))
             dw = np.zeros(sshape + (self.ngrid,))
             da = np.zeros(sshape)
+        lib().orc_set_forced_azimuth(self._h, int(forced_azimuth))
+        fa = flux = None
+        if flux_altitudes is not None and len(flux_altitudes) > 0:
+            fa = np.ascontiguousarray(flux_altitudes, dtype=np.float64)
+            flux = np.zeros((nwavel, len(fa), 3))
+        if lib().orc_set_flux_observers(self._h, _p(fa), 0 if fa is None else len(fa), _p(flux)) != 0:
+            raise RuntimeError("oracle: flux observers need plane-parallel post-processing")
         rc = lib().orc_run(self._h, nwavel, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), _p(irr), _p(alb), int(derivatives),
                            nthreads, _p(rad), _p(dk), _p(dw), _p(da), _p(od), nazi.ctypes.data_as(_ip))
         if rc != 0:
             raise RuntimeError(f"oracle run failed with code {rc}")
+        lib().orc_set_flux_observers(self._h, None, 0, None)
         out = {"radiance": rad, "los_optical_depth": od, "num_azimuth": nazi}
+        if flux is not None:
+            out.update({"upwelling_flux": flux[:, :, 0], "downwelling_flux": flux[:, :, 1], "actinic_flux": flux[:, :, 2]})
         if derivatives:
             out.update({"d_extinction": dk, "d_ssa": dw, "d_albedo": da})
         return out

@@ -65,6 +65,13 @@ class OccultationSource(enum.IntEnum):  # cpp/include/sasktran2/config.h:104
     NoSource = 1
 
 
+class FluxType(enum.IntEnum):  # cpp/include/sasktran2/config.h (FluxType)
+    Upwelling = 0
+    Downwelling = 1
+    Actinic = 2
+    Divergence = 3
+
+
 class StokesBasis(enum.IntEnum):  # cpp/include/sasktran2/config.h:145
     Standard = 0
     Solar = 1
@@ -80,6 +87,7 @@ class Config:
              "multiple_scatter_source": "multiple_scatter_source", "single_scatter_source": "single_scatter_source",
              "wf_enabled": "wf_enabled", "delta_m_scaling": "apply_delta_scaling", "stokes_basis": "stokes_basis",
              "emission_source": "emission_source", "occultation_source": "occultation_source", "do_backprop": "do_backprop",
+             "num_forced_azimuth": "num_do_forced_azimuth",   # src/sasktran2/config.py:541-554
              # successive orders (src/sasktran2/config.py:410-418,505-514,607-634 -> the C API's `hr` keys)
              "num_successive_orders_iterations": "num_hr_spherical_iterations", "num_successive_orders_incoming": "num_hr_incoming",
              "num_successive_orders_outgoing": "num_hr_outgoing", "init_successive_orders_with_discrete_ordinates": "initialize_hr_with_do",
@@ -95,6 +103,12 @@ class Config:
             lib().sk_config_destroy(self._h)
 
     def __getattr__(self, name):
+        if name == "flux_types":   # src/sasktran2/config.py:745-765
+            n = ctypes.c_int()
+            lib().sk_config_get_num_flux_types(self._h, ctypes.byref(n))
+            t = (ctypes.c_int * max(n.value, 1))()
+            lib().sk_config_get_flux_types(self._h, t)
+            return [FluxType(t[i]) for i in range(n.value)]
         if name in Config._FLOAT_KEYS:
             d = ctypes.c_double()
             getattr(lib(), f"sk_config_get_{name}")(self._h, ctypes.byref(d))
@@ -107,6 +121,11 @@ class Config:
         return v.value
 
     def __setattr__(self, name, value):
+        if name == "flux_types":
+            t = (ctypes.c_int * max(len(value), 1))(*[int(v) for v in value])
+            if lib().sk_config_set_flux_types(self._h, t, len(value)) != 0:
+                raise RuntimeError(last_error())
+            return
         if name in Config._FLOAT_KEYS:
             if getattr(lib(), f"sk_config_set_{name}")(self._h, float(value)) != 0:
                 raise RuntimeError(last_error())
@@ -162,12 +181,31 @@ class SolarAnglesObserverLocation:
         self.args = (cos_sza, relative_azimuth, cos_viewing_zenith, observer_altitude_m)
 
 
+class FluxObserverSolar:
+    """src/sasktran2/viewinggeo/wrappers.py:297-320: a horizontal surface at an altitude that the fluxes are reported on."""
+
+    def __init__(self, cos_sza, observer_altitude_m):
+        self.args = (cos_sza, observer_altitude_m)
+
+
 class ViewingGeometry:
     """src/sasktran2/viewinggeo/wrappers.py:13-36."""
 
     def __init__(self):
         self._h = lib().sk_viewing_geometry_create()
         self._rays = []
+        self._flux_observers = []
+
+    def add_flux_observer(self, observer):
+        if not isinstance(observer, FluxObserverSolar):
+            raise TypeError("unsupported flux observer type on the MI355X path")
+        if lib().sk_viewing_geometry_add_flux_observer_solar(self._h, *map(float, observer.args)) != 0:
+            raise ValueError("invalid flux observer")
+        self._flux_observers.append(observer)
+
+    @property
+    def flux_observers(self):
+        return self._flux_observers
 
     def __del__(self):
         if getattr(self, "_h", None) and callable(lib):   # (at interpreter shutdown the module globals may be gone already)
@@ -668,7 +706,8 @@ class Engine:
         H, delta_order = self._prepare(atmosphere, derivs)
         h_st, h_su, h_atm = H["storage"], H["surface"], H["atmosphere"]
         rad = np.zeros((nw, nlos, S))
-        h_out = L.sk_output_create(_p(rad), nw * nlos, S, None, 0)
+        flux, flux_names = self._flux_output(nw)
+        h_out = L.sk_output_create(_p(rad), nw * nlos, S, _p(flux) if flux is not None else None, 0 if flux is None else flux.size)
         out = {"radiance": rad}
         try:
             if derivs:
@@ -696,6 +735,8 @@ class Engine:
             od = _dp()
             L.sk_output_get_los_optical_depth(h_out, ctypes.byref(od))
             out["los_optical_depth"] = np.ctypeslib.as_array(od, shape=(nlos, nw)).T.copy()
+            for i, name in enumerate(flux_names):   # src/sasktran2/engine.py:493-509
+                out[f"{name}_flux"] = flux[i]
         finally:
             L.sk_output_destroy(h_out)
         if as_dataset:
@@ -706,8 +747,19 @@ class Engine:
             dims = {"radiance": ("wavelength", "los", "stokes"), "wf_extinction": ("altitude", "wavelength", "los", "stokes"),
                     "wf_ssa": ("altitude", "wavelength", "los", "stokes"), "wf_albedo": ("wavelength", "los", "stokes"),
                     "los_optical_depth": ("wavelength", "los")}
+            dims.update({f"{name}_flux": ("wavelength", "flux_location") for name in flux_names})
             return xr.Dataset({k: (dims[k], v) for k, v in out.items()}, coords={"altitude": atmosphere._altitudes})
         return out
+
+    def _flux_output(self, nw):
+        """The flux array [flux type][wavelength][flux observer] of one call and the names of its types (src/sasktran2/engine.py:493-509),
+        or (None, []) without flux observers."""
+        nobs = len(self._viewing.flux_observers)
+        if nobs == 0:
+            return None, []
+        names = {0: "upwelling", 1: "downwelling", 2: "actinic", 3: "divergence"}
+        types = [names[int(t)] for t in self._config.flux_types]
+        return np.zeros((len(types), nw, nobs)), types
 
     def _calculate_radiance_constituents(self, atmosphere, as_dataset):
         """Constituent interface: the atmosphere is assembled in HBM (`Atmosphere.internal_object`), the storage handle of the device
@@ -724,7 +776,8 @@ class Engine:
         L.sk_surface_set_brdf(h_su, h_brdf, _p(alb))
         h_atm = L.sk_atmosphere_create(fe.storage_handle(), h_su, int(derivs), 0)
         rad = np.zeros((nw, nlos, S))
-        h_out = L.sk_output_create(_p(rad), nw * nlos, S, None, 0)
+        flux, flux_names = self._flux_output(nw)
+        h_out = L.sk_output_create(_p(rad), nw * nlos, S, _p(flux) if flux is not None else None, 0 if flux is None else flux.size)
         raw, raw_surface = {}, {}
         try:
             if derivs:
@@ -759,6 +812,8 @@ class Engine:
             L.sk_surface_destroy(h_su)
             L.sk_brdf_destroy(h_brdf)
         out, dims = {"radiance": rad, "los_optical_depth": los_od}, {"radiance": ("wavelength", "los", "stokes"), "los_optical_depth": ("wavelength", "los")}
+        for i, name in enumerate(flux_names):
+            out[f"{name}_flux"], dims[f"{name}_flux"] = flux[i], ("wavelength", "flux_location")
         for name, m in fe.mappings.items():
             key = m.assign_name or name
             d = (m.interp_dim, "wavelength", "los", "stokes")

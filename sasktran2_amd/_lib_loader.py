@@ -22,11 +22,11 @@ SIGNATURES = [
     *[(f"sk_config_get_{k}", _I, [_vp, _ip]) for k in ("num_stokes", "multiple_scatter_source", "single_scatter_source",
       "num_streams", "num_threads", "wavelength_batch_size", "num_singlescatter_moments", "num_do_sza", "wf_enabled",
       "output_los_optical_depth", "apply_delta_scaling", "stokes_basis", "num_hr_spherical_iterations", "num_hr_incoming",
-      "num_hr_outgoing", "initialize_hr_with_do", "emission_source", "occultation_source", "do_backprop")],
+      "num_hr_outgoing", "initialize_hr_with_do", "emission_source", "occultation_source", "do_backprop", "num_do_forced_azimuth")],
     *[(f"sk_config_set_{k}", _I, [_vp, _I]) for k in ("num_stokes", "multiple_scatter_source", "single_scatter_source",
       "num_streams", "num_threads", "wavelength_batch_size", "num_singlescatter_moments", "num_do_sza", "wf_enabled",
       "output_los_optical_depth", "apply_delta_scaling", "stokes_basis", "num_hr_spherical_iterations", "num_hr_incoming",
-      "num_hr_outgoing", "initialize_hr_with_do", "emission_source", "occultation_source", "do_backprop")],
+      "num_hr_outgoing", "initialize_hr_with_do", "emission_source", "occultation_source", "do_backprop", "num_do_forced_azimuth")],
     *[(f"sk_config_get_{k}", _I, [_vp, _dp]) for k in ("successive_orders_relative_tolerance", "successive_orders_absolute_tolerance", "successive_orders_damping")],
     *[(f"sk_config_set_{k}", _I, [_vp, _D]) for k in ("successive_orders_relative_tolerance", "successive_orders_absolute_tolerance", "successive_orders_damping")],
     ("sk_config_get_successive_orders_anderson_depth", _I, [_vp, _ip]), ("sk_config_set_successive_orders_anderson_depth", _I, [_vp, _I]),
@@ -38,6 +38,8 @@ SIGNATURES = [
     ("sk_viewing_geometry_add_solar_angles_observer_location", _I, [_vp, _D, _D, _D, _D]),
     ("sk_viewing_geometry_add_tangent_altitude", _I, [_vp, _D, _D, _D, _D]),
     ("sk_viewing_geometry_num_rays", _I, [_vp, _ip]),
+    ("sk_viewing_geometry_add_flux_observer_solar", _I, [_vp, _D, _D]), ("sk_viewing_geometry_num_flux_observers", _I, [_vp, _ip]),
+    ("sk_config_get_num_flux_types", _I, [_vp, _ip]), ("sk_config_get_flux_types", _I, [_vp, _ip]), ("sk_config_set_flux_types", _I, [_vp, _ip, _I]),
     ("sk_atmosphere_storage_create", _vp, [_I, _I, _I, _I, _dp, _dp, _dp, _dp, _dp]),
     ("sk_atmosphere_storage_destroy", None, [_vp]),
     ("sk_atmosphere_storage_get_derivative_mapping", _I, [_vp, _S, ctypes.POINTER(_vp)]),

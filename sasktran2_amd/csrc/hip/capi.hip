@@ -72,6 +72,7 @@ struct Geometry1D {
 };
 struct ViewingGeometry {
     std::vector<skgeo::RaySpec> rays;
+    std::vector<std::pair<double, double>> flux_observers;   // FluxObserverSolar (viewing_geometry.h:33): (cos_sza, altitude in m)
 };
 struct DerivativeMapping {
     int nloc = 0, nwavel = 0, nleg = 0;
@@ -168,6 +169,8 @@ struct OutputC {
     std::map<std::string, D> derivs, surface_derivs, flux_derivs, surface_flux_derivs;
     std::vector<double> los_od;
     const Contraction* contract = nullptr;
+    double* flux = nullptr;   // [flux type][wavelength][flux observer] (output.h:11), nflux doubles
+    int nflux = 0;
 };
 // grow-only device staging buffers of the host entry point (kept between calls: no hipMalloc / hipFree per spectrum)
 struct DeviceCache {
@@ -191,7 +194,7 @@ struct Engine {
     std::unique_ptr<skdev::DeviceEngine> dev;      // discrete-ordinates source (multiple_scatter_source = discrete_ordinates)
     std::unique_ptr<skdev::SoDeviceEngine> so;     // exact single scatter and / or legacy successive orders
     std::unique_ptr<skdev::TsDeviceEngine> ts;     // two-stream source (multiple_scatter_source = twostream, emission_source = twostream)
-    int nlos = 0, ngrid = 0;
+    int nlos = 0, ngrid = 0, nflux_obs = 0;
     DeviceCache cache;
 };
 
@@ -481,9 +484,12 @@ Atmosphere* sk_atmosphere_create(AtmosphereStorage* st, Surface* su, int derivs,
 }
 void sk_atmosphere_destroy(Atmosphere* a) { delete a; }
 
-OutputC* sk_output_create(double* radiance, int nrad, int nstokes, double*, int) {
+OutputC* sk_output_create(double* radiance, int nrad, int nstokes, double* flux, int nflux) {
     if (!radiance) return nullptr;
-    return new OutputC{radiance, nrad, nstokes, {}, {}, {}};
+    OutputC* o = new OutputC{radiance, nrad, nstokes, {}, {}, {}};
+    o->flux = nflux > 0 ? flux : nullptr;
+    o->nflux = flux ? std::max(nflux, 0) : 0;
+    return o;
 }
 void sk_output_destroy(OutputC* o) { delete o; }
 int sk_output_assign_derivative_memory(OutputC* o, const char* name, double* mem, int nrad, int nstokes, int nderiv) {
@@ -525,9 +531,11 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
         if (c->ss_source == 2 && c->ms_source != 0) throw std::runtime_error("single_scatter_source = discrete_ordinates needs multiple_scatter_source = discrete_ordinates");
         // do_backprop selects the reverse-mode linearisation of the reference's discrete-ordinates source; the two-stream source is
         // linearised in reverse mode whatever the flag says (the reference's two-stream tests all set it)
+        // num_do_forced_azimuth: the plane-parallel post-processing of the discrete-ordinates source honours it (do_source_planeparallel.cpp:55-60)
+        const bool forced_azimuth_ok = c->num_do_forced_azimuth <= 0 || (c->ms_source == 0 && g->geotype != 2);
         if (c->los_refraction || c->solar_refraction || c->multiple_scatter_refraction ||
-            c->num_do_forced_azimuth >= 0 || c->num_do_spherical_iterations > 0 || (c->do_backprop && !two_stream))
-            throw std::runtime_error("refraction, forced azimuth count, DO spherical iterations and backprop are not part of this build");
+            !forced_azimuth_ok || c->num_do_spherical_iterations > 0 || (c->do_backprop && !two_stream))
+            throw std::runtime_error("refraction, a forced azimuth count outside plane-parallel discrete ordinates, DO spherical iterations and backprop are not part of this build");
         // EmissionSource { standard = 0, none = 1, discrete_ordinates = 2, volume_emission_rate = 3, twostream = 4 }, OccultationSource { standard = 0, none = 1 }
         if (c->emission_source < 0 || c->emission_source > 4)
             throw std::runtime_error("emission_source must be standard (0), none (1), discrete_ordinates (2), volume_emission_rate (3) or twostream (4)");
@@ -560,6 +568,31 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
             if (ss_los && !dg.spherical_pp)
                 throw std::runtime_error("single_scatter_source = exact with discrete ordinates needs spherical geometry (in plane-parallel "
                                          "geometry the discrete-ordinates source carries the single scatter itself)");
+            if (c->num_do_forced_azimuth > 0) {
+                if (e->dev->vector_mode()) throw std::runtime_error("num_do_forced_azimuth needs a stream count of the matrix-core path (2, 4, 8, 16 or 32) and NSTOKES = 1");
+                e->dev->set_forced_azimuth(c->num_do_forced_azimuth);
+            }
+            if (!v->flux_observers.empty()) {
+                // DOSourcePlaneParallelPostProcessing::compute_flux (do_source_planeparallel.cpp:221-566): the layer that holds the observer
+                // (OpticalLayerArray::layerAtAltitude: the first layer from the top whose floor is not above it) and the fraction of the
+                // layer above it
+                if (dg.spherical_pp) throw std::runtime_error("flux observers need plane-parallel or pseudo-spherical geometry (the reference computes fluxes in its plane-parallel post-processing only)");
+                if (e->dev->vector_mode()) throw std::runtime_error("flux observers need a stream count of the matrix-core path (2, 4, 8, 16 or 32) and NSTOKES = 1");
+                std::vector<int> layer;
+                std::vector<double> frac;
+                for (const auto& fo : v->flux_observers) {
+                    const double alt = fo.second;
+                    int p = dg.nlyr - 1;
+                    for (int r = 0; r < dg.nlyr; ++r)
+                        if (dg.floor_h[r] <= alt) { p = r; break; }
+                    layer.push_back(p);
+                    frac.push_back((dg.ceil_h[p] - alt) / (dg.ceil_h[p] - dg.floor_h[p]));
+                }
+                e->dev->set_flux_observers(layer, frac);
+                e->nflux_obs = (int)layer.size();
+            }
+        } else if (!v->flux_observers.empty()) {
+            throw std::runtime_error("flux observers need multiple_scatter_source = discrete_ordinates");
         }
         if (two_stream) {
             skts::Settings cfg;
@@ -1125,11 +1158,27 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
                           "weighting functions (d_legendre / scat_factor mappings) or SASKTRAN2_AMD_RUNTIME_N in this build");
                 return -2;
             }
+            if (e->nflux_obs > 0) {
+                set_error("sk_engine_calculate_radiance: flux observers are not available together with scattering-group weighting functions or "
+                          "SASKTRAN2_AMD_RUNTIME_N in this build");
+                return -2;
+            }
             return calculate_radiance_vector(e, atm, out);
         }
         if (!out->flux_derivs.empty() || !out->surface_flux_derivs.empty()) return -2;
         const int nw = st.nwavel, nlos = e->nlos, ngrid = e->ngrid;
         if (out->nrad != nw * nlos) throw std::runtime_error("output radiance size mismatch");
+        // fluxes at the flux observers: [flux type][wavelength][observer] in the order of Config::flux_types (0 upwelling, 1 downwelling, 2 actinic)
+        double* d_flux = nullptr;
+        const size_t nflux = size_t(e->nflux_obs) * e->config.flux_types.size() * nw;
+        if (e->nflux_obs > 0) {
+            for (int ft : e->config.flux_types)
+                if (ft < 0 || ft > 2) throw std::runtime_error("flux type " + std::to_string(ft) + " is not part of this build (upwelling 0, downwelling 1, actinic 2)");
+            if (!out->flux || size_t(out->nflux) != nflux)
+                throw std::runtime_error("output flux size mismatch: " + std::to_string(out->nflux) + " doubles given, flux types x wavelengths x observers = " + std::to_string(nflux));
+            if (nflux > 0) d_flux = (double*)e->cache.get("flux", nflux * 8);
+            e->dev->set_flux_output(d_flux, e->config.flux_types);
+        }
         const int derivs = atm->derivs && e->config.wf_enabled && (!out->derivs.empty() || !out->surface_derivs.empty());
         const size_t nloc_w = size_t(ngrid) * nw, nt = size_t(nw) * nlos;
         DeviceCache& C = e->cache;
@@ -1188,6 +1237,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         e->dev->set_delta_m_fraction(nullptr);
         e->dev->set_thermal_emission(nullptr, nullptr);
         e->dev->set_thermal_wf_outputs(nullptr, nullptr);
+        e->dev->set_flux_output(nullptr, {});
         // single_scatter_source = exact on top of the discrete-ordinates multiple scatter: radiance and native weighting functions are
         // accumulated on the device before the user mappings are applied
         if (e->so) {
@@ -1211,6 +1261,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         HIPC(hipMemcpy(out->radiance, d_rad, nt * 8, hipMemcpyDeviceToHost));
         out->los_od.resize(nt);
         HIPC(hipMemcpy(out->los_od.data(), d_odt, nt * 8, hipMemcpyDeviceToHost));
+        if (d_flux) HIPC(hipMemcpy(out->flux, d_flux, nflux * 8, hipMemcpyDeviceToHost));
         ph.mark("radiance out");
         if (derivs) {
             map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, 1, nullptr, nullptr, d_wem, d_wsem);

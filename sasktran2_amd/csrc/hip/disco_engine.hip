@@ -301,6 +301,55 @@ __global__ void __launch_bounds__(256) kern_qlmask(Geo g, Bufs b, int m) {
         b.qlmask[i] = uint8_t(bits);
     }
 }
+// Fluxes at the flux observers from the order-0 solution (DOSourcePlaneParallelPostProcessing::compute_flux, do_source_planeparallel.cpp:221-566):
+// inside layer p at optical depth x = fraction x tau the discrete-ordinates intensities at the stream angles are
+//   down_l = sum_j [ W+(l, j) cL_j + W-(l, j) cM_j ],   up_l = sum_j [ W-(l, j) cL_j + W+(l, j) cM_j ],
+//   cL_j = h+_j(x) L_j + A+_j D-_j(x),   cM_j = h-_j(x) M_j + A-_j D+_j(x)      (multipliers: sktran_do_postprocessing.h:19-188)
+// and  downwelling = 2 pi sum_l w_l mu_l down_l  (+ the direct beam  T_ceiling cos(sza)  when the DO source carries the single scatter, as the
+// reference adds it: the transmission at the layer's CEILING), upwelling the same with up_l, actinic both without the mu_l (+ T_ceiling).
+// One thread per (wavelength, observer); accumulate: the thermal pass adds its solution's share (no direct beam).
+template <int N> __global__ void __launch_bounds__(kBlock) kern_flux(Geo g, Bufs b, int s, int nobs, const int* __restrict__ fx_layer,
+                                                                     const double* __restrict__ fx_frac, int ntypes, const int* __restrict__ types,
+                                                                     double* __restrict__ flux, int w0, int nw_total, int accumulate, int direct) {
+    using R = skd::Rec<N>;
+    const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (tid >= size_t(b.nw) * nobs) return;
+    const int w = int(tid / nobs), o = int(tid % nobs), nw = b.nw, nlyr = g.nlyr;
+    const int p = fx_layer[o];
+    const double lf = fx_frac[o];
+    const double* rec = skd::rec_at<N>(b, nlyr, p, w);
+    const double* xs = skd::xsol_at<N>(b, nlyr, p, w);
+    const double th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
+    double cL[N], cM[N];
+    for (int j = 0; j < N; ++j) {
+        skd::PPMult pm;
+        skd::pp_multipliers(T, th, sc, rec[R::K + j], lf, pm);
+        cL[j] = pm.hp * xs[j] + rec[R::AP + j] * pm.Dm;
+        cM[j] = pm.hm * xs[N + j] + rec[R::AM + j] * pm.Dp;
+    }
+    double dn = 0, up = 0, dn_a = 0, up_a = 0;
+    for (int l = 0; l < N; ++l) {
+        double d = 0, u = 0;
+        for (int j = 0; j < N; ++j) {
+            const double wp = rec[R::WP + l + N * j], wm = rec[R::WM + l + N * j];
+            d += wp * cL[j] + wm * cM[j];
+            u += wm * cL[j] + wp * cM[j];
+        }
+        const double q = 2.0 * skd::kPi * g.wt[l];
+        dn += q * g.mu[l] * d;
+        up += q * g.mu[l] * u;
+        dn_a += q * d;
+        up_a += q * u;
+    }
+    for (int t = 0; t < ntypes; ++t) {
+        double v = 0;
+        if (types[t] == 0) v = up;
+        else if (types[t] == 1) v = dn + (direct ? T * g.csz[s] : 0.0);
+        else if (types[t] == 2) v = dn_a + up_a + (direct ? T : 0.0);
+        double* dst = &flux[(size_t(t) * nw_total + w0 + w) * nobs + o];
+        *dst = accumulate ? *dst + v : v;
+    }
+}
 // batched azimuth orders: the reduced gradient is the sum of the orders' rows IN ORDER (what the order-by-order path adds up in b.grad)
 __global__ void __launch_bounds__(256) kern_grad_orders(const double* __restrict__ gord, double* __restrict__ grad, size_t n, size_t stride, int norders) {
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
@@ -430,6 +479,11 @@ struct DeviceEngine::Impl {
     const double *thermal_emission = nullptr, *thermal_surface = nullptr;   // EmissionSource::discrete_ordinates inputs (device) or null
     double *thermal_wf_emission = nullptr, *thermal_wf_surface = nullptr;   // their weighting functions [ngrid][nwavel][nlos], [nwavel][nlos] or null
     int thermal_w0 = 0, thermal_nw_total = 0;                               // block in flight of the thermal pass
+    // flux observers: layer / fraction per observer (device), requested flux types and the output of the solve in hand
+    int nfx = 0, nflux_types = 0;
+    int forced_azimuth = 0;   // > 0: the plane-parallel post-processing solves exactly this many azimuth orders (Config::num_do_forced_azimuth)
+    int *d_fx_layer = nullptr, *d_flux_types = nullptr;
+    double *d_fx_frac = nullptr, *d_flux = nullptr;
     bool profiling = false;
     // in-situ timing (set_profiling(2)): an event pair around every launch ON ITS OWN STREAM, nothing serialised, read back by
     // kernel_time() -- the duration of a kernel as it runs inside the pipelined step (what rocprofv3 --kernel-trace sees)
@@ -532,6 +586,24 @@ void DeviceEngine::set_thermal_emission(const double* d_emission, const double* 
 void DeviceEngine::set_thermal_wf_outputs(double* d_wf_emission, double* d_wf_surface_emission) {
     impl_->thermal_wf_emission = d_wf_emission;
     impl_->thermal_wf_surface = d_wf_surface_emission;
+}
+void DeviceEngine::set_flux_observers(const std::vector<int>& layer, const std::vector<double>& fraction) {
+    Impl& I = *impl_;
+    I.nfx = int(layer.size());
+    I.d_fx_layer = I.geo_mem.upload(layer);
+    I.d_fx_frac = I.geo_mem.upload(fraction);
+    I.d_flux_types = I.geo_mem.alloc<int>(8);
+}
+void DeviceEngine::set_flux_output(double* d_flux, const std::vector<int>& types) {
+    Impl& I = *impl_;
+    I.d_flux = d_flux;
+    I.nflux_types = int(std::min<size_t>(types.size(), 8));
+    if (d_flux && I.nflux_types > 0) HIP_CHECK(hipMemcpy(I.d_flux_types, types.data(), size_t(I.nflux_types) * sizeof(int), hipMemcpyHostToDevice));
+}
+int DeviceEngine::num_flux_observers() const { return impl_->nfx; }
+void DeviceEngine::set_forced_azimuth(int n) {
+    if (n > 0 && !impl_->g.pp_mode) throw std::runtime_error("sasktran2_amd: num_do_forced_azimuth is honoured by the plane-parallel post-processing only");
+    impl_->forced_azimuth = n;
 }
 int DeviceEngine::last_chunk() const { return impl_->last_chunk; }
 int DeviceEngine::last_slots() const { return impl_->last_slots; }
@@ -884,7 +956,9 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
             Timer t(I, st, "k0_transmission");
             hipLaunchKernelGGL(kern_k0t, dim3(blocks(nw), unsigned(g.nlyr)), dim3(kBlock), 0, st, g, b, 0);
         }
-        for (int m = 0; m < g.nstr; ++m) {
+        // do_source_planeparallel.cpp:55-60: num_do_forced_azimuth replaces the stream count as the number of azimuth orders
+        const int num_azi = I.forced_azimuth > 0 ? std::min(I.forced_azimuth, g.nstr) : g.nstr;
+        for (int m = 0; m < num_azi; ++m) {
             {
                 bool pre;
                 { Timer t(I, st, "kj_eigen"); pre = launch_kj<N>(st, g, b, m); }
@@ -894,6 +968,11 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
             {
                 Timer t(I, st, "k2a_bvp");
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, b, 0, m);
+            }
+            if (m == 0 && I.nfx > 0 && I.d_flux && I.nflux_types > 0) {
+                Timer t(I, st, "k_flux");
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_flux<N>), dim3(blocks(nw * size_t(I.nfx))), dim3(kBlock), 0, st, g, b, 0, I.nfx, I.d_fx_layer, I.d_fx_frac,
+                                   I.nflux_types, I.d_flux_types, I.d_flux, I.thermal_w0, I.thermal_nw_total, 0, g.include_ss);
             }
             {
                 Timer t(I, st, "k3_table_values");
@@ -920,6 +999,9 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
             hipLaunchKernelGGL(kern_k0_thermal, dim3(blocks(nw)), dim3(kBlock), 0, st, g, bt);
             launch_k1<N>(st, g, bt, g.nsza, 0, launch_kj<N>(st, g, bt, 0));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2a_wave<N>), dim3(unsigned(nw)), dim3(64), 0, st, g, bt, g.nsza, 0);
+            if (I.nfx > 0 && I.d_flux && I.nflux_types > 0)   // the thermal solution's share of the fluxes
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_flux<N>), dim3(blocks(nw * size_t(I.nfx))), dim3(kBlock), 0, st, g, bt, g.nsza, I.nfx, I.d_fx_layer, I.d_fx_frac,
+                                   I.nflux_types, I.d_flux_types, I.d_flux, I.thermal_w0, I.thermal_nw_total, 1, 0);
             if (derivs) {
                 // weighting functions: the adjoint operators of the thermal order-0 solve, the sweeps inside kern_kpp, and the chain from the
                 // layer gradients (tau, omega, T = b0 (1 - omega) 4 pi / omega, sec = b1) to extinction, ssa, emission profile, surface emission

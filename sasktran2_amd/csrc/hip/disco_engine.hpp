@@ -2,6 +2,7 @@
 #pragma once
 #include <cstddef>
 #include <string>
+#include <vector>
 
 #include "../host/geo_tables.hpp"
 
@@ -43,6 +44,14 @@ class DeviceEngine {
     // weighting functions of the thermal pass with respect to the emission profile [ngrid][nwavel][nlos] and the surface emission
     // [nwavel][nlos] (device pointers or null), written by the next solve_device with derivatives
     void set_thermal_wf_outputs(double* d_wf_emission, double* d_wf_surface_emission);
+    // Flux observers (plane-parallel post-processing, reference: DOSourcePlaneParallelPostProcessing::compute_flux,
+    // source_term/do_source_planeparallel.cpp:221-566): per observer the layer (from the top) that holds it and its position inside it
+    // (0 = ceiling, 1 = floor); per solve the output [flux type][wavelength][observer] (device) and the requested types
+    // (0 upwelling, 1 downwelling, 2 actinic).  Radiance-type fluxes only (no flux weighting functions).
+    void set_flux_observers(const std::vector<int>& layer, const std::vector<double>& fraction);
+    void set_flux_output(double* d_flux, const std::vector<int>& types);
+    int num_flux_observers() const;
+    void set_forced_azimuth(int n);   // plane-parallel post-processing: solve exactly n azimuth orders (n <= streams)
 
     // Polarised path (NSTOKES = 3; also NSTOKES = 1 with a stream count the matrix-core path does not cover).
     // d_leg: [nwavel][ngrid][nleg][4] (a1, a2, a3, b1) for NSTOKES = 3; d_radiance: [nwavel][nlos][nstokes].

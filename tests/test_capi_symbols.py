@@ -68,7 +68,10 @@ def test_stored_settings_and_unsupported_entry_points(built):
     L.sk_viewing_geometry_create.restype = vp
     vg = L.sk_viewing_geometry_create()
     L.sk_viewing_geometry_add_flux_observer_solar.argtypes = [vp, ctypes.c_double, ctypes.c_double]
-    assert L.sk_viewing_geometry_add_flux_observer_solar(vg, 0.5, 1000.0) == -2
+    # flux observers are stored (the plane-parallel discrete-ordinates engine serves them: tests/test_flux.py)
+    assert L.sk_viewing_geometry_add_flux_observer_solar(vg, 0.5, 1000.0) == 0
+    L.sk_viewing_geometry_num_flux_observers.argtypes = [vp, ip]
+    assert L.sk_viewing_geometry_num_flux_observers(vg, ctypes.byref(n)) == 0 and n.value == 1
     L.sk_viewing_geometry_destroy.argtypes = [vp]
     L.sk_viewing_geometry_destroy(vg)
     L.sk_config_destroy.argtypes = [vp]
