@@ -1151,7 +1151,19 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         // SASKTRAN2_AMD_RUNTIME_N=1 sends every request through the run-time-n kernels (cross-check of the two device implementations)
         const char* force_env = std::getenv("SASKTRAN2_AMD_RUNTIME_N");
         const bool force = force_env && atoi(force_env) != 0;
-        if (force || e->dev->vector_mode() || (scattering_groups && atm->derivs && e->config.wf_enabled)) {
+        // 16 streams in spherical geometry with at most 32 lines of sight: up to two scattering groups ride the matrix-core kernels (one more
+        // row per group through kern_k2c_mfma8 / kern_k2b_mfma8, DeviceEngine::set_scattering_groups); SASKTRAN2_AMD_GROUPS=vector keeps the
+        // run-time-n kernels for them (the parity suite compares the two)
+        int ngroups_requested = 0;
+        if (atm->derivs && e->config.wf_enabled)
+            for (auto& kv : out->derivs) {
+                auto it = st.maps.find(kv.first);
+                if (it != st.maps.end() && is_scattering_mapping(*it->second)) ++ngroups_requested;
+            }
+        const char* groups_env = std::getenv("SASKTRAN2_AMD_GROUPS");
+        const bool groups_here = scattering_groups && ngroups_requested > 0 && !force && !e->dev->vector_mode() && e->config.emission_source != 2 &&
+                                 !(groups_env && std::string(groups_env) == "vector") && e->dev->groups_on_matrix_path(ngroups_requested);
+        if (force || e->dev->vector_mode() || (scattering_groups && atm->derivs && e->config.wf_enabled && !groups_here)) {
             if (e->config.emission_source == 2) {
                 // the thermal pass lives in the matrix-core path's plane-parallel branch only: refuse rather than drop the source
                 set_error("sk_engine_calculate_radiance: emission_source = discrete_ordinates is not available together with scattering-group "
@@ -1214,6 +1226,32 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
             HIPC(hipMemcpy(d_f, st.src_delta_f(), nloc_w * 8, hipMemcpyDefault));
         }
         e->dev->set_delta_m_fraction(d_f);
+        // scattering derivative groups on the matrix-core path (as calculate_radiance_vector prepares them for the run-time-n kernels)
+        std::map<std::string, int> group_of;
+        double *d_dleg = nullptr, *d_wg = nullptr, *d_dfg = nullptr;
+        if (derivs && groups_here) {
+            for (auto& kv : out->derivs) {
+                auto it = st.maps.find(kv.first);
+                if (it != st.maps.end() && is_scattering_mapping(*it->second)) {
+                    const int gidx = (int)group_of.size();
+                    group_of[kv.first] = gidx;
+                }
+            }
+            const size_t per_g = nloc_w * st.nleg;
+            d_dleg = (double*)C.get("d_legendre", group_of.size() * per_g * 8);
+            for (auto& kv : group_of)
+                HIPC(hipMemcpy(d_dleg + size_t(kv.second) * per_g, st.maps.at(kv.first)->src_d_legendre(), per_g * 8, hipMemcpyDefault));
+            d_wg = (double*)C.get("wf_scat", group_of.size() * size_t(ngrid) * nt * 8);
+            if (st.has_delta_f()) {
+                d_dfg = (double*)C.get("d_f_groups", group_of.size() * nloc_w * 8);
+                for (auto& kv : group_of) {
+                    const DerivativeMapping& gm = *st.maps.at(kv.first);
+                    if (!gm.has_d_f(nloc_w)) throw std::runtime_error("scattering mapping " + kv.first + " was created after the delta-M scaling");
+                    HIPC(hipMemcpy(d_dfg + size_t(kv.second) * nloc_w, gm.src_d_f(), nloc_w * 8, hipMemcpyDefault));
+                }
+            }
+        }
+        e->dev->set_scattering_groups((int)group_of.size(), d_dleg, d_wg, d_dfg);
         ph.mark("upload");
         double *d_wem = nullptr, *d_wsem = nullptr;
         if (e->config.emission_source == 2) {   // thermal source inside the DO equations
@@ -1238,6 +1276,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         e->dev->set_thermal_emission(nullptr, nullptr);
         e->dev->set_thermal_wf_outputs(nullptr, nullptr);
         e->dev->set_flux_output(nullptr, {});
+        e->dev->set_scattering_groups(0, nullptr, nullptr, nullptr);
         // single_scatter_source = exact on top of the discrete-ordinates multiple scatter: radiance and native weighting functions are
         // accumulated on the device before the user mappings are applied
         if (e->so) {
@@ -1248,7 +1287,9 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
                 HIPC(hipMemset(d_wem, 0, size_t(ngrid) * nt * 8));
                 HIPC(hipMemset(d_wsem, 0, nt * 8));
             }
-            e->so->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa, d_wem, d_wsem);
+            // (the exact single scatter differentiates along the same group directions into the same d_wg)
+            e->so->solve_device(nw, st.nleg, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa, d_wem, d_wsem,
+                                derivs ? (int)group_of.size() : 0, d_dleg, d_wg);
         }
         hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
         HIPC(hipGetLastError());
@@ -1264,7 +1305,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (d_flux) HIPC(hipMemcpy(out->flux, d_flux, nflux * 8, hipMemcpyDeviceToHost));
         ph.mark("radiance out");
         if (derivs) {
-            map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, 1, nullptr, nullptr, d_wem, d_wsem);
+            map_user_derivatives(e, st, su, out, d_we, d_ws, d_wa, d_rad, 1, d_wg, group_of.empty() ? nullptr : &group_of, d_wem, d_wsem);
         }
         ph.mark("weighting functions out");
         return 0;

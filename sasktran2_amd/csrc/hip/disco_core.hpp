@@ -155,6 +155,18 @@ struct Bufs {
     // Azimuth orders batched into one launch (small launches, 16 streams): gridDim.z = orders, order m0 + blockIdx.z works on its own set of
     // per-order buffers, ord_* elements behind the set of order m0 (0 when a launch serves one order: order_view then changes nothing)
     size_t ord_rec, ord_dinv, ord_xsol, ord_eig, ord_ops, ord_z, ord_qlbuf, ord_qlmask, ord_grad;
+    // Scattering-group weighting functions on the 16-stream matrix-core kernels (d_legendre / scat_factor mappings,
+    // sktran_do_layerarray.cpp:496-513,759-860): per group the direction of the layer's Legendre coefficients (kern_k0g), the derivative of
+    // the layer solution along it (kern_k1g_cols8 -> RecG), one more DI / HD / GD row per group in kern_k2c_mfma8 (opsg, hg) and one more
+    // gradient row per group and layer in kern_k2b_mfma8 (grad rows 4 nlyr + 2 + group nlyr + p), chained to the grid by kern_k4g
+    int ngroups;
+    const double* dleg;     // [group][wavelength of the spectrum][q][l < nleg] d_legendre of the group's mapping
+    const double* dfg;      // [group][wavelength of the spectrum][q] d_f of the group's mapping (delta-M scaled storage) or null
+    int dleg_nw, dleg_w0;   // wavelengths of the spectrum, offset of this block in it
+    double* ga;             // [group][p][l][w] direction of a_l
+    double* recg;           // [w][p][group][RecG::SIZE]
+    double* opsg;           // [w][p][group][OpsG::SIZE]
+    double* hg;             // [w][p][tile][64] group rows of the HD part (C/D image rows 8 .. 11 of the forward sweep's second product)
 };
 #if defined(__HIPCC__)
 // the buffers of azimuth order m0 + mo (mo = blockIdx.z of a batched launch)
@@ -164,6 +176,23 @@ __device__ inline Bufs order_view(Bufs b, unsigned mo) {
     return b;
 }
 #endif
+
+// derivative of a layer's solution along a scattering group's direction (16 streams, lane-path records): per solution j a block of CB doubles
+//   dW+(:, j), dW-(:, j), dk_j, dA+_j, dA-_j, d(A- C-)_j, d(A+ C+)_j  (2 N + 5 of CB = 3 N + 2: 52 dwords apart for N = 8, so that the eight
+//   solutions' entries fall on different LDS bank windows in kern_k2c_mfma8's image, which is this layout unchanged), then the direction itself
+template <int N> struct RecG {
+    static constexpr int CB = 3 * N + 2, DWP = 0, DWM = N, DK = 2 * N, DAP = DK + 1, DAM = DK + 2, CGM = DK + 3, CGP = DK + 4;
+    static constexpr int DA = N * CB, SIZE = DA + 2 * N;
+    SKD_HD static constexpr int dwp(int i, int j) { return j * CB + DWP + i; }
+    SKD_HD static constexpr int dwm(int i, int j) { return j * CB + DWM + i; }
+    SKD_HD static constexpr int at(int what, int j) { return j * CB + what; }
+};
+// group rows of the adjoint operators: DI[edge][i] and GD
+template <int N> struct OpsG {
+    static constexpr int DI = 0, GD = 4 * N, SIZE = 4 * N + 8;
+};
+template <int N> SKD_HD double* recg_at(const Bufs& b, int nlyr, int p, int w, int gi) { return b.recg + ((size_t(w) * nlyr + p) * b.ngroups + gi) * RecG<N>::SIZE; }
+template <int N> SKD_HD double* opsg_at(const Bufs& b, int nlyr, int p, int w, int gi) { return b.opsg + ((size_t(w) * nlyr + p) * b.ngroups + gi) * OpsG<N>::SIZE; }
 
 template <int N> struct Rec {
     static constexpr int K = 0, DK = N, WP = 2 * N, WM = WP + N * N, DWP = WM + N * N, DWM = DWP + N * N,

@@ -32,6 +32,7 @@
 
 #include "disco_engine.hpp"
 #include "disco_wave_kernels.hpp"
+#include "disco_group_kernels.hpp"
 
 namespace skdev {
 
@@ -469,8 +470,18 @@ struct DeviceEngine::Impl {
         int batch_cap = 0;
         double *bt_rec = nullptr, *bt_dinv = nullptr, *bt_xsol = nullptr, *bt_eig = nullptr, *bt_ops = nullptr, *bt_z = nullptr, *bt_hw = nullptr, *bt_grad = nullptr;
         uint8_t* bt_qlmask = nullptr;
+        // scattering groups on the matrix-core path (ensure_group_scratch): direction, derivative blocks (one per pipeline buffer), group
+        // operator rows, HD rows of the forward sweep, gradient / native-derivative rows extended by the groups' rows
+        DevMem group_mem;
+        double *ga = nullptr, *recg[kDepth] = {}, *opsg = nullptr, *hg = nullptr, *grad_g = nullptr, *dnat_g = nullptr;
+        double *grad0 = nullptr, *dnat0 = nullptr;   // the plain rows (ensure_scratch)
     };
     std::vector<std::unique_ptr<Slot>> slots;
+    // scattering groups of the solve in hand (set_scattering_groups): count, d_legendre [group][wavelength][q][l], d_f [group][wavelength][q] or
+    // null, output [group][q][wavelength][los]
+    int ngroups = 0, group_cap_w = 0, group_cap_g = 0;
+    const double *g_dleg = nullptr, *g_dfg = nullptr;
+    double* g_wf_scat = nullptr;
     hipEvent_t fork = nullptr;
     int chunk_capacity = 0;
     int last_chunk = 0, last_slots = 0;
@@ -689,10 +700,51 @@ void DeviceEngine::ensure_scratch(int nw, int nslots) {
         b.ops = M.alloc<double>(nlyr * (8 * N * N + 26 * N + 5) * W); b.qlbuf = M.alloc<double>(nlyr * nstr * W * nlos_pad);
         b.grad = M.alloc<double>((4 * nlyr + 2) * nt);
         b.dnat = M.alloc<double>((2 * t.ngrid + 1) * nt); b.radiance = M.alloc<double>(nt); b.los_od = M.alloc<double>(nt);
+        sl->grad0 = b.grad;
+        sl->dnat0 = b.dnat;
         sl->d_active = M.alloc<int>(1);
+        sl->group_mem.release();
     }
+    I.group_cap_w = I.group_cap_g = 0;
     I.chunk_capacity = nw;
     I.scratch_bytes = bytes_per_wavelength() * W * I.slots.size();
+}
+
+static bool k1_lane_enabled();
+// scratch of the scattering groups on the matrix-core path, allocated when a solve first asks for them (3.6 KB per wavelength, layer and group
+// for the derivative blocks of the four pipeline buffers and the operator rows, 0.5 KB per tile for the HD rows)
+void DeviceEngine::ensure_group_scratch(int ngroups) {
+    Impl& I = *impl_;
+    const int nw = I.chunk_capacity;
+    if (ngroups <= I.group_cap_g && nw <= I.group_cap_w) return;
+    const auto& t = I.tab;
+    const size_t N = t.N, nlyr = t.nlyr, nstr = t.nstr, nlos = t.nlos, W = nw, nt = W * nlos, G = ngroups, ntile = (nlos + 15) / 16;
+    for (auto& sl : I.slots) {
+        DevMem& M = sl->group_mem;
+        M.release();
+        sl->ga = M.alloc<double>(G * nlyr * nstr * W);
+        for (int k = 0; k < Impl::Slot::kDepth; ++k) sl->recg[k] = M.alloc<double>(W * nlyr * G * skd::RecG<8>::SIZE);
+        sl->opsg = M.alloc<double>(W * nlyr * G * skd::OpsG<8>::SIZE);
+        sl->hg = M.alloc<double>(W * nlyr * ntile * 64);
+        sl->grad_g = M.alloc<double>((4 * nlyr + 2 + G * nlyr) * nt);
+        sl->dnat_g = M.alloc<double>((2 * t.ngrid + 1 + G * t.ngrid) * nt);
+        (void)N;
+    }
+    I.group_cap_g = ngroups;
+    I.group_cap_w = nw;
+}
+void DeviceEngine::set_scattering_groups(int ngroups, const double* d_dleg, double* d_wf_scat, const double* d_dfg) {
+    Impl& I = *impl_;
+    if (ngroups > 0 && !groups_on_matrix_path(ngroups)) throw std::runtime_error("sasktran2_amd: scattering groups are not served by the matrix-core kernels of this engine");
+    I.ngroups = ngroups;
+    I.g_dleg = d_dleg;
+    I.g_wf_scat = d_wf_scat;
+    I.g_dfg = d_dfg;
+}
+// 16 streams, spherical post-processing, lane-path records, at most two 16-LOS tiles (the fused forward sweep) and two groups
+bool DeviceEngine::groups_on_matrix_path(int ngroups) const {
+    const auto& t = impl_->tab;
+    return !vector_mode_ && t.N == 8 && !impl_->g.pp_mode && k1_lane_enabled() && t.nlos <= 32 && !t.lp_q.empty() && ngroups <= 2;
 }
 
 namespace {
@@ -939,8 +991,8 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
     const size_t nw = b.nw, nt = nw * g.nlos;
     {
         Timer t(I, st, "init");
-        hipLaunchKernelGGL(kern_init, dim3(1024), dim3(256), 0, st, b, I.d_slot_is_ground, g.nslot, size_t(4 * g.nlyr + 2) * nt,
-                           size_t(2 * g.ngrid + 1) * nt, nt);
+        hipLaunchKernelGGL(kern_init, dim3(1024), dim3(256), 0, st, b, I.d_slot_is_ground, g.nslot, size_t(4 * g.nlyr + 2 + b.ngroups * g.nlyr) * nt,
+                           size_t(2 * g.ngrid + 1 + b.ngroups * g.ngrid) * nt, nt);
     }
     {
         Timer t(I, st, "k0_layer_optics");
@@ -948,6 +1000,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
         else hipLaunchKernelGGL(kern_k0, dim3(blocks(nw)), dim3(kBlock), 0, st, g, b);
         if (g.nq_total > 0) hipLaunchKernelGGL(kern_k0_shells, dim3(4096), dim3(256), 0, st, g, b);
         hipLaunchKernelGGL(kern_k0_los, dim3(unsigned((size_t(g.nlos) * nw + 255) / 256)), dim3(256), 0, st, g, b);
+        if (b.ngroups > 0) hipLaunchKernelGGL(kern_k0g, dim3(blocks(nw, 256), unsigned(g.nlyr)), dim3(256), 0, st, g, b);
     }
     if (g.pp_mode) {
         // plane-parallel post-processing: every azimuth order is solved (do_source_planeparallel.cpp), K3 only fills the
@@ -1059,7 +1112,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
             // small launches: every azimuth order in one launch per kernel (run_orders_batched); SASKTRAN2_AMD_BATCH_ORDERS = largest block
             // served that way (0: never)
             static const int batch_max = [] { const char* e = std::getenv("SASKTRAN2_AMD_BATCH_ORDERS"); return e ? atoi(e) : 2600; }();
-            if (b.k1_lane && int(nw) <= batch_max && g.nstr == 16 && run_orders_batched(I, slot, st, derivs, s)) {
+            if (b.k1_lane && b.ngroups == 0 && int(nw) <= batch_max && g.nstr == 16 && run_orders_batched(I, slot, st, derivs, s)) {
                 if (derivs) {
                     Timer t(I, st, "k4a_chain");
                     if (s + 1 < g.nsza) hipLaunchKernelGGL(kern_k4a, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b, s, 1);
@@ -1083,6 +1136,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                 b.dinv = dinv_buf[m % depth];
                 b.xsol = xsol_buf[m % depth];
                 b.qlmask = qlmask_buf[m % depth];
+                if (b.ngroups > 0) b.recg = slot.recg[m % depth];
                 // buffers m % depth are free once the adjoint stage of order m - depth is done
                 if (m >= depth) {
                     HIP_CHECK(hipStreamWaitEvent(sA, slot.ev_rest[m - depth], 0));
@@ -1090,8 +1144,14 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                 }
             }
             if (N == 8 && b.k1_lane) {
-                Timer t(I, sA, "k1_layer_solution");
-                launch_k1_lane8(sA, g, b, s, m);
+                {
+                    Timer t(I, sA, "k1_layer_solution");
+                    launch_k1_lane8(sA, g, b, s, m);
+                }
+                if (b.ngroups > 0 && derivs) {   // the layer solutions' derivatives along the scattering groups' directions
+                    Timer t(I, sA, "k1g_group_derivatives");
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1g_cols8<8>), dim3(unsigned((nw + 7) / 8), unsigned(g.nlyr), unsigned(b.ngroups)), dim3(64), 0, sA, g, b, s, m);
+                }
             } else {
                 bool pre;
                 { Timer t(I, sA, "kj_eigen"); pre = launch_kj<N>(sA, g, b, m); }
@@ -1148,7 +1208,9 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                     // full-size launches with at most two 16-LOS tiles: the forward sweep runs inside the operator kernel (FP, SP, HD stay in
                     // registers), kern_k2b_mfma8<.., true> keeps the backward sweep; SASKTRAN2_AMD_FUSE=0 keeps the two separate kernels
                     static const bool fuse_env = [] { const char* e = std::getenv("SASKTRAN2_AMD_FUSE"); return e ? atoi(e) != 0 : true; }();
-                    const bool fused = fuse_env && ntile <= 2 && small_batch_split(int(nw)) == 1 && g.n_lp > 0;
+                    // (scattering groups: their rows exist in the fused kernels only)
+                    const bool fused = (fuse_env || b.ngroups > 0) && ntile <= 2 && (small_batch_split(int(nw)) == 1 || b.ngroups > 0) && g.n_lp > 0;
+                    if (b.ngroups > 0 && !(fused && b.k1_lane)) throw std::runtime_error("sasktran2_amd: scattering groups need the fused adjoint kernels (at most 32 lines of sight)");
                     if (g.n_lp > 0 && !flags_here) {
                         Timer t2(I, sC, "k2q_live_flags");
                         hipLaunchKernelGGL(kern_qlmask, dim3(2048), dim3(256), 0, sC, g, b, m);
@@ -1160,7 +1222,11 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                         int split = std::max(3, small_batch_split(int(nw)));
                         if (const char* e = std::getenv("SASKTRAN2_AMD_K2C_SPLIT")) split = std::max(1, atoi(e));
                         const int lpb = (g.nlyr + split - 1) / split, ny = (g.nlyr + lpb - 1) / lpb;
-                        if (fused && ntile == 2 && b.k1_lane)
+                        if (b.ngroups > 0 && ntile == 2)
+                            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true, 2, 2>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);
+                        else if (b.ngroups > 0)
+                            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true, 1, 2>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);
+                        else if (fused && ntile == 2 && b.k1_lane)
                             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true, 2>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);
                         else if (fused && b.k1_lane)
                             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true, 1>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);
@@ -1174,7 +1240,11 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<false>), dim3(unsigned(nw), unsigned(ny)), dim3(64), 0, sC, g, b, s, m, lpb);
                     }
                     Timer t(I, sC, "k2b_adjoint");
-                    if (fused && ntile == 2)
+                    if (b.ngroups > 0 && ntile == 2)
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<2, true, true>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m);
+                    else if (b.ngroups > 0)
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<1, true, true>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m);
+                    else if (fused && ntile == 2)
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<2, true>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m);
                     else if (fused)
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2b_mfma8<1, true>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m);
@@ -1230,6 +1300,7 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                 hipLaunchKernelGGL(kern_k4a_gt, dim3(blocks(nt), unsigned((g.nlyr + 7) / 8)), dim3(kBlock), 0, st, g, b, s);
                 hipLaunchKernelGGL(kern_k4a_apply, dim3(blocks(nt)), dim3(kBlock), 0, st, g, b);
             }
+            if (b.ngroups > 0) hipLaunchKernelGGL(kern_k4g, dim3(blocks(nt, 256)), dim3(256), 0, st, g, b);   // (clears the groups' rows for the next sza)
         }
     }
     if (g.nsza == 0) {
@@ -1278,6 +1349,8 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
     I.last_chunk = chunk;
     I.last_slots = nslots;
     ensure_scratch(chunk, nslots);
+    const int ng = derivs ? I.ngroups : 0;
+    if (ng > 0) ensure_group_scratch(ng);
     const bool fan_out = !I.profiling && nslots > 1;
     if (fan_out) HIP_CHECK(hipEventRecord(I.fork, st));
     int used = 0;
@@ -1305,6 +1378,13 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
         b.nleg = nleg;
         b.derivs = derivs;
         b.k1_lane = (t.N == 8 && !I.g.pp_mode && k1_lane_enabled()) ? 1 : 0;
+        b.ngroups = ng;
+        b.grad = ng > 0 ? slot.grad_g : slot.grad0;
+        b.dnat = ng > 0 ? slot.dnat_g : slot.dnat0;
+        if (ng > 0) {
+            b.dleg = I.g_dleg; b.dfg = I.g_dfg; b.dleg_nw = nwavel; b.dleg_w0 = w0;
+            b.ga = slot.ga; b.recg = slot.recg[0]; b.opsg = slot.opsg; b.hg = slot.hg;
+        }
         switch (t.N) {
             case 1: run_chunk<1>(I, slot, cs, derivs); break;
             case 2: run_chunk<2>(I, slot, cs, derivs); break;
@@ -1318,6 +1398,8 @@ void DeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, const
         else
             hipLaunchKernelGGL(kern_output, dim3(blocks(size_t(nw) * t.nlos), unsigned(b.derivs ? t.ngrid : 1)), dim3(kBlock), 0, cs, I.g, b, w0, nwavel, d_radiance,
                                d_wf_ext, d_wf_ssa, d_wf_alb, d_los_od, d_status);
+        if (ng > 0 && I.g_wf_scat)
+            hipLaunchKernelGGL(kern_output_groups, dim3(blocks(size_t(nw) * t.nlos, 256), unsigned(ng * t.ngrid)), dim3(256), 0, cs, I.g, b, w0, nwavel, I.g_wf_scat);
     }
     if (fan_out)
         for (int i = 0; i < used; ++i) {

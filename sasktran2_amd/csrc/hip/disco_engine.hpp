@@ -51,6 +51,12 @@ class DeviceEngine {
     void set_flux_observers(const std::vector<int>& layer, const std::vector<double>& fraction);
     void set_flux_output(double* d_flux, const std::vector<int>& types);
     int num_flux_observers() const;
+    // Scattering-group weighting functions on the 16-stream matrix-core kernels (d_legendre / scat_factor mappings): the groups of the NEXT
+    // solve_device calls -- d_dleg [group][nwavel][ngrid][nleg], d_dfg [group][nwavel][ngrid] (delta-M scaled storage) or null, output
+    // d_wf_scat [group][ngrid][nwavel][nlos].  groups_on_matrix_path says whether this engine's geometry and the group count are served here
+    // (otherwise solve_device_vector's run-time-n kernels are).
+    void set_scattering_groups(int ngroups, const double* d_dleg, double* d_wf_scat, const double* d_dfg);
+    bool groups_on_matrix_path(int ngroups) const;
     void set_forced_azimuth(int n);   // plane-parallel post-processing: solve exactly n azimuth orders (n <= streams)
 
     // Polarised path (NSTOKES = 3; also NSTOKES = 1 with a stream count the matrix-core path does not cover).
@@ -76,6 +82,7 @@ class DeviceEngine {
 
   private:
     void ensure_scratch(int nw, int nslots);
+    void ensure_group_scratch(int ngroups);
     void init_vector(const skgeo::DiscoGeometry& dg);
     void ensure_vector_scratch(int nw, bool derivs, int ngroups);
     void destroy_vector();

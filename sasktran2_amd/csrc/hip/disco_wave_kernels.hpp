@@ -1412,8 +1412,15 @@ __global__ void __launch_bounds__(64, SKD_WPE_K2AM) kern_k2a_mfma8(Geo g, Bufs b
 #define SKD_NT_ST(ptr, val) (*(ptr) = (val))
 #define SKD_NT_LD(ptr) (*(ptr))
 #endif
-template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b, int s, int m, int layers_per_block) {
+// NGM > 0 (K1LANE, FTILES > 0 only): up to NGM scattering groups (b.ngroups): per group one more HD row (rows 8 .. of the forward sweep's second
+// product), DI rows and GD (skd::OpsG) from the group's derivative block (skd::RecG, kern_k1g_cols8), which arrives by LDS-DMA like the record
+template <bool K1LANE, int FTILES = 0, int NGM = 0> __global__ void __launch_bounds__(64, SKD_WPE_K2CM) kern_k2c_mfma8(Geo g, Bufs b, int s, int m, int layers_per_block) {
     constexpr int N = 8, NSTR = 16, M2 = 16, FT = (FTILES > 0) ? FTILES : 1;
+    static_assert(NGM == 0 || (K1LANE && FTILES > 0), "scattering groups: lane-path records and the fused forward sweep");
+    using RG = skd::RecG<N>;
+    using OG = skd::OpsG<N>;
+    constexpr int NGS = (NGM > 0) ? NGM : 1;
+    const int ng = (NGM > 0) ? min(b.ngroups, NGM) : 0;
     m += blockIdx.z;   // (batched azimuth orders: skd::order_view)
     b = skd::order_view(b, blockIdx.z);
     using R = std::conditional_t<K1LANE, skd::RecC<N>, skd::Rec<N>>;       // kern_k1_lane writes column-block records
@@ -1430,6 +1437,8 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
     __shared__ double sSmall[NB * 36], sTmp[M2], sIpb[N], sDIpb[4 * N];
     __shared__ double sDinv[K1LANE ? M2 * M2 : 1];   // K1LANE: block inverse
     __shared__ double sHD[4 * NSTR], sUG[M2];
+    __shared__ __attribute__((aligned(16))) double sGrp[(NGM > 0) ? NB * NGS * RG::SIZE : 1];   // the groups' derivative blocks, two buffers like the record
+    __shared__ double sHDG[NGS * NSTR], sDIpbG[NGS * N];
     // ---- state of the fused forward sweep (FTILES > 0), as in kern_k2b_mfma8
     const int nlos = g.nlos, ntile = (nlos + 15) / 16;
     double* zw = b.z + size_t(w) * nlyr * ntile * 256;
@@ -1505,6 +1514,15 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
             if (lane < 17) __builtin_amdgcn_global_load_lds((gptr)((lane < 8) ? xsrc + lane * 16 : asrc + (lane - 8) * 16), (lptr)(sSmall + buf * 36), 16, 0, 0);
             if (lane < 2)
                 __builtin_amdgcn_global_load_lds((gptr)(reinterpret_cast<const char*>(b.T + size_t(pn) * nw + w) + lane * 4), (lptr)(sSmall + buf * 36 + 34), 4, 0, 0);
+            if constexpr (NGM > 0) {
+                static_assert(RG::SIZE * 8 > 1024 && RG::SIZE * 8 <= 2048 && (RG::SIZE * 8) % 16 == 0, "two requests per group block");
+                for (int gi = 0; gi < ng; ++gi) {
+                    const char* gsrc = reinterpret_cast<const char*>(skd::recg_at<N>(b, nlyr, pn, w, gi));
+                    double* gdst = sGrp + (buf * NGS + gi) * RG::SIZE;
+                    __builtin_amdgcn_global_load_lds((gptr)(gsrc + lane * 16), (lptr)(gdst), 16, 0, 0);
+                    if (lane < (RG::SIZE * 8 - 1024) / 16) __builtin_amdgcn_global_load_lds((gptr)(gsrc + 1024 + lane * 16), (lptr)(gdst + 128), 16, 0, 0);
+                }
+            }
         }
     };
     if constexpr (K1LANE) request_layer(p_begin, 0);
@@ -1559,6 +1577,7 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
         K2CT(0)
         // ---- Y = [YP; YM] and its omega derivative DY (rows: solution j / 8 + j, columns: Legendre order l)
         mf4 Y = {0, 0, 0, 0}, DY = {0, 0, 0, 0};
+        [[maybe_unused]] mf4 DYG[NGS];
         {
             const bool hi = (col >= N);
             const double wp0 = sRec[RL::wp(q, jc)], wp1 = sRec[RL::wp(4 + q, jc)];
@@ -1573,9 +1592,26 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
                 Y = mfma16(aW[kk], bP[kk], Y);
                 DY = mfma16(aD[kk], bP[kk], DY);
             }
+            // group direction: d[YP; YM] = [dW] P(a) + [W] P(da)
+            if constexpr (NGM > 0)
+                for (int gi = 0; gi < ng; ++gi) {
+                    const double* sG = sGrp + ((((p - p_begin) & 1) * NGS) + gi) * RG::SIZE;
+                    const double alg = (col >= m) ? sG[RG::DA + col] : 0.0;
+                    const double g0 = pc0 * om * alg, g1 = pc1 * om * alg;
+                    const double bG[4] = {sg * g0, sg * g1, g0, g1};
+                    const double gp0 = sG[RG::dwp(q, jc)], gp1 = sG[RG::dwp(4 + q, jc)], gm0 = sG[RG::dwm(q, jc)], gm1 = sG[RG::dwm(4 + q, jc)];
+                    const double aG[4] = {hi ? gm0 : gp0, hi ? gm1 : gp1, hi ? gp0 : gm0, hi ? gp1 : gm1};
+                    mf4 t = {0, 0, 0, 0};
+                    for (int kk = 0; kk < 4; ++kk) {
+                        t = mfma16(aG[kk], bP[kk], t);
+                        t = mfma16(aW[kk], bG[kk], t);
+                    }
+                    DYG[gi] = t;
+                }
         }
         // ---- F = [UL; UM] (C/D image, in place of Y) and the direct-dependence rows HD: this lane holds solutions j = q, q + 4
-        double hd[4] = {0, 0, 0, 0}, val = 0;
+        double hd[4] = {0, 0, 0, 0}, val = 0, hdg[NGS];
+        for (int gi = 0; gi < NGS; ++gi) hdg[gi] = 0;
         mf4 Fr;
         for (int jx = 0; jx < 2; ++jx) {
             const int j = q + 4 * jx;
@@ -1593,11 +1629,23 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
             hd[skd::TH_T] += (yp * Ap * pm.Dm + ym * Am * pm.Dp) * inv_T;
             hd[skd::TH_OM] += dyp * tL + dym * tM + yp * (pm.hp_k * dk * L + dAp * pm.Dm + Ap * pm.Dm_k * dk) +
                               ym * (pm.hm_k * dk * Mv + dAm * pm.Dp + Am * pm.Dp_k * dk);
+            if constexpr (NGM > 0)
+                for (int gi = 0; gi < ng; ++gi) {
+                    const double* sG = sGrp + ((((p - p_begin) & 1) * NGS) + gi) * RG::SIZE;
+                    const double dkg = sG[RG::at(RG::DK, j)], dApg = sG[RG::at(RG::DAP, j)], dAmg = sG[RG::at(RG::DAM, j)];
+                    hdg[gi] += DYG[gi][jx] * tL + DYG[gi][2 + jx] * tM + yp * (pm.hp_k * dkg * L + dApg * pm.Dm + Ap * pm.Dm_k * dkg) +
+                               ym * (pm.hm_k * dkg * Mv + dAmg * pm.Dp + Am * pm.Dp_k * dkg);
+                }
         }
         for (int off = 16; off <= 32; off <<= 1) {
             for (int t = 0; t < 4; ++t) hd[t] += __shfl_xor(hd[t], off);
             val += __shfl_xor(val, off);
+            if constexpr (NGM > 0)
+                for (int gi = 0; gi < ng; ++gi) hdg[gi] += __shfl_xor(hdg[gi], off);
         }
+        if constexpr (NGM > 0)
+            if (q == 0)
+                for (int gi = 0; gi < ng; ++gi) sHDG[gi * NSTR + col] = hdg[gi] * inv_om;
         if (q == 0)
             for (int t = 0; t < 4; ++t) {
                 const double hv = hd[t] * inv_om - ((t == skd::TH_OM) ? val * inv_om * inv_om : 0.0);
@@ -1681,6 +1729,27 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
                     sDIpb[skd::TH_SEC * N + i] = wmu * v_sec;
                 }
             }
+            // group rows: the omega row's form with the group's dW, dk and coefficient derivatives
+            if constexpr (NGM > 0)
+                for (int gi = 0; gi < ng; ++gi) {
+                    const double* sG = sGrp + ((((p - p_begin) & 1) * NGS) + gi) * RG::SIZE;
+                    double acc = 0;
+#pragma unroll 2
+                    for (int jj = 0; jj < N / 2; ++jj) {
+                        const int j = h * (N / 2) + jj;
+                        const double X = sRec[own_minus ? RL::wm(i, j) : RL::wp(i, j)];
+                        const double dX = sG[own_minus ? RG::dwm(i, j) : RG::dwp(i, j)], dY = sG[own_minus ? RG::dwp(i, j) : RG::dwm(i, j)];
+                        const double E = sRec[RL::e(j)], L = sXs[j], Mv = sXs[N + j];
+                        const double pa = pm ? Mv : L, oa = pm ? L : Mv;
+                        acc += dX * (E * pa) + X * (-sG[RG::at(RG::DK, j)] * th * E * pa) + dY * oa;
+                        acc += X * sG[RG::at((e >= 2) ? RG::CGP : RG::CGM, j)] + dX * sRec[RL::coef(tk0, j)];
+                    }
+                    acc += __shfl_xor(acc, 32);
+                    if (h == 0) {
+                        skd::opsg_at<N>(b, nlyr, p, w, gi)[OG::DI + e * N + i] = acc;
+                        if (e == 2) sDIpbG[gi * N + i] = g.wt[i] * g.mu[i] * acc;
+                    }
+                }
         }
         K2CT(3)
         // ground part of u
@@ -1714,6 +1783,13 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
             for (int i = 0; i < N; ++i) ipb += sIpb[i];
             o[O::IPB] = ipb;
         }
+        if constexpr (NGM > 0)
+            if (lane >= 8 && lane < 8 + ng) {
+                double sacc = 0;
+                if (last && m == 0)
+                    for (int i = 0; i < N; ++i) sacc += sDIpbG[(lane - 8) * N + i];
+                skd::opsg_at<N>(b, nlyr, p, w, lane - 8)[OG::GD] = 2.0 * rho * sacc;
+            }
         K2C_SYNC();
         K2CT(4)
         if constexpr (FTILES > 0) {
@@ -1722,6 +1798,9 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
 #pragma clang fp contract(off)
             double hda[4];
             for (int kk = 0; kk < 4; ++kk) hda[kk] = (col < 4) ? sHD[col * NSTR + 4 * kk + q] : 0.0;
+            if constexpr (NGM > 0)
+                if (col >= 8 && col < 8 + ng)
+                    for (int kk = 0; kk < 4; ++kk) hda[kk] = sHDG[(col - 8) * NSTR + 4 * kk + q];
             for (int t = 0; t < FT; ++t) {
                 if (t >= ntile) continue;
                 double ql4[4] = {0, 0, 0, 0};
@@ -1758,6 +1837,8 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
                 double* zt = zw + (size_t(p) * ntile + t) * 256;
                 for (int r = 0; r < 4; ++r) SKD_NT_ST(&zt[64 * r + lane], acc[r]);
                 SKD_NT_ST(&hw[(size_t(p) * ntile + t) * 64 + lane], hacc[0]);
+                if constexpr (NGM > 0)
+                    if (ng > 0) SKD_NT_ST(&b.hg[((size_t(w) * nlyr + p) * ntile + t) * 64 + lane], hacc[2]);
                 yprev[t] = acc;
             }
         }
@@ -1775,10 +1856,14 @@ template <bool K1LANE, int FTILES = 0> __global__ void __launch_bounds__(64, SKD
 //             rows 4..7 carry sum_i zB_i for the ground terms)
 //   Y / Z tiles and the HD part are kept in HBM between the sweeps in their C/D register images
 //   (b.z: [w][p][tile][4][64], b.qlbuf: [w][p][tile][64]); nothing goes through LDS.
-template <int TILES, bool BWD_ONLY = false> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2b_mfma8(Geo g, Bufs b, int s, int m) {
+// GROUPS (BWD_ONLY): rows 8 .. 8 + b.ngroups - 1 of the gradient tile are the scattering groups' rows (skd::OpsG, the forward sweep's b.hg)
+template <int TILES, bool BWD_ONLY = false, bool GROUPS = false> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2b_mfma8(Geo g, Bufs b, int s, int m) {
     // the one- and two-tile instantiations must round identically (results do not depend on the launch shape): no implicit
     // contraction of a * b + c in this kernel, fused multiply-adds are written out
 #pragma clang fp contract(off)
+    static_assert(!GROUPS || BWD_ONLY, "group rows: the forward sweep runs in kern_k2c_mfma8");
+    using OG = skd::OpsG<8>;
+    const int ng = GROUPS ? min(b.ngroups, 4) : 0;
     constexpr int N = 8, NSTR = 16;
     using O = skd::Ops<N>;
     m += blockIdx.z;   // (batched azimuth orders: skd::order_view; every order then adds into its own gradient rows, kern_grad_orders sums them)
@@ -1891,8 +1976,19 @@ template <int TILES, bool BWD_ONLY = false> __global__ void __launch_bounds__(64
                 e1[kk] = (col < 4) ? ops[O::DI + (col * 4 + 1) * N + i] : 0.0;
                 e2[kk] = (col < 4) ? -ops[O::DI + (col * 4 + 2) * N + i] : 0.0;
                 e3[kk] = (col < 4) ? -ops[O::DI + (col * 4 + 3) * N + i] : ((col < 8 && last && last_is_ground) ? 1.0 : 0.0);
+                if constexpr (GROUPS)
+                    if (col >= 8 && col < 8 + ng) {
+                        const double* og = skd::opsg_at<N>(b, nlyr, p, w, col - 8);
+                        e0[kk] = og[OG::DI + 0 * N + i];
+                        e1[kk] = og[OG::DI + 1 * N + i];
+                        e2[kk] = -og[OG::DI + 2 * N + i];
+                        e3[kk] = -og[OG::DI + 3 * N + i];
+                    }
             }
             const double gd = (last && last_is_ground && q < 4) ? ops[O::GD + q] : 0.0;
+            double gdg = 0;
+            if constexpr (GROUPS)
+                if (last && last_is_ground && q < ng) gdg = skd::opsg_at<N>(b, nlyr, p, w, q)[OG::GD];
             const double ipb = ops[O::IPB];
             for (int t = 0; t < TILES; ++t) {
                 if ((tile0 + t) >= ntile) continue;
@@ -1906,9 +2002,13 @@ template <int TILES, bool BWD_ONLY = false> __global__ void __launch_bounds__(64
                     mf4 gp = gprev[t];
                     for (int kk = 0; kk < 2; ++kk) gp = mfma16(e1prev[kk], z[2 + kk], gp);
                     if (ok[t]) b.grad[size_t(q * nlyr + p + 1) * nt + size_t(w) * nlos + los[t]] += gp[0];
+                    if constexpr (GROUPS)
+                        if (ok[t] && q < ng) b.grad[size_t(4 * nlyr + 2 + q * nlyr + p + 1) * nt + size_t(w) * nlos + los[t]] += gp[2];
                 }
                 // this layer: HD part from the forward sweep, zA_p, zB_p, zA_{p+1}
                 mf4 ga = {SKD_NT_LD(&hw[(size_t(p) * ntile + tile0 + t) * 64 + lane]), 0, 0, 0};
+                if constexpr (GROUPS)
+                    if (ng > 0) ga[2] = SKD_NT_LD(&b.hg[((size_t(w) * nlyr + p) * ntile + tile0 + t) * 64 + lane]);
                 for (int kk = 0; kk < 2; ++kk) ga = mfma16(e0[kk], z[kk], ga);
                 for (int kk = 0; kk < 2; ++kk) ga = mfma16(e3[kk], z[2 + kk], ga);
                 if (!last)
@@ -1916,6 +2016,7 @@ template <int TILES, bool BWD_ONLY = false> __global__ void __launch_bounds__(64
                 if (last && last_is_ground && ok[t]) {
                     const double zBsum = ga[1];  // rows 4..7 of the tile
                     ga[0] += (zBsum + gw[t]) * gd;
+                    if constexpr (GROUPS) ga[2] += (zBsum + gw[t]) * gdg;
                     if (q == 0) {
                         const size_t tid = size_t(w) * nlos + los[t];
                         const double rho = b.albedo[w];
@@ -1929,8 +2030,11 @@ template <int TILES, bool BWD_ONLY = false> __global__ void __launch_bounds__(64
             }
             for (int kk = 0; kk < 2; ++kk) e1prev[kk] = e1[kk];
         }
-        for (int t = 0; t < TILES; ++t)
+        for (int t = 0; t < TILES; ++t) {
             if (ok[t]) b.grad[size_t(q * nlyr) * nt + size_t(w) * nlos + los[t]] += gprev[t][0];
+            if constexpr (GROUPS)
+                if (ok[t] && q < ng) b.grad[size_t(4 * nlyr + 2 + q * nlyr) * nt + size_t(w) * nlos + los[t]] += gprev[t][2];
+        }
     }
 }
 

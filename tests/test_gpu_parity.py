@@ -715,6 +715,82 @@ def test_scattering_group_derivatives_match_finite_differences(nstr, delta_m):
         assert np.max(np.abs(fd - an)) < 1e-5 * np.abs(res["wf_scatterer"]).max(), q
 
 
+def _group_solve(nw=3, nstr=16, ngroups=2, delta_m=False, nlos_stride=1, kernels=None):
+    """A limb scene with `ngroups` scattering constituents (derivative mappings with d_legendre / scat_factor): every output of one solve."""
+    import ctypes
+    from tests.gpu_harness import build_engine
+    import sasktran2_amd as sk
+    ng = 25
+    gcs = (0.85 if delta_m else 0.6, 0.3)
+    s, mp0 = _mixture(np.ones(ng), nw, nstr, gcs[0])
+    if nlos_stride > 1:
+        s = dict(s, rays=s["rays"][::nlos_stride])
+    # the second group: another phase function on the same mixture (its own direction d_legendre = constituent - mixture coefficients)
+    l = np.arange(16)
+    mps = [mp0, dict(mp0, d_legendre=((2 * l + 1) * gcs[1] ** l)[:, None, None] - s["leg"], scat_factor=0.5 * mp0["scat_factor"],
+                     d_extinction=0.5 * mp0["d_extinction"], d_ssa=0.25 * mp0["d_ssa"])][:ngroups]
+    engine, config, geometry = build_engine(s)
+    config.delta_m_scaling = delta_m
+    dp, vp = ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
+    nlos = len(s["rays"])
+
+    def hook(L, h_st, h_out, out):
+        for gi, mp in enumerate(mps):
+            name = f"wf_scatterer_{gi}".encode()
+            m = vp()
+            L.sk_atmosphere_storage_get_derivative_mapping(h_st, name, ctypes.byref(m))
+            for which, arr in (("d_extinction", mp["d_extinction"]), ("d_ssa", mp["d_ssa"])):
+                ptr = dp()
+                getattr(L, f"sk_deriv_mapping_get_{which}")(m, ctypes.byref(ptr))
+                np.ctypeslib.as_array(ptr, shape=(ng * nw,))[:] = arr.T.reshape(-1)
+            for fn, arr, size in (("sk_deriv_mapping_get_scat_factor", mp["scat_factor"].T.reshape(-1), ng * nw),
+                                  ("sk_deriv_mapping_get_d_legendre", np.asfortranarray(mp["d_legendre"]).ravel(order="F"), 16 * ng * nw)):
+                f = getattr(L, fn)
+                f.argtypes = [vp, ctypes.POINTER(dp)]
+                ptr = dp()
+                assert f(m, ctypes.byref(ptr)) == 0
+                np.ctypeslib.as_array(ptr, shape=(size,))[:] = arr
+            out[name.decode()] = np.zeros((ng, nw, nlos, 1))
+            L.sk_output_assign_derivative_memory(h_out, name, out[name.decode()].ctypes.data_as(dp), nw * nlos, 1, ng)
+
+    atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=True)
+    atmosphere.storage.total_extinction[:] = s["extinction"]
+    atmosphere.storage.ssa[:] = s["ssa"]
+    atmosphere.leg_coeff.a1[:] = s["leg"]
+    atmosphere.surface.albedo[:] = s["albedo"]
+    if kernels is not None:   # which kernels served the request (per-kernel event timing names them)
+        from sasktran2_amd._lib_loader import lib
+        lib().sk_amd_engine_set_profiling(engine._h, 1)
+    out = engine.calculate_radiance(atmosphere, as_dataset=False, _mapping_hook=hook)
+    if kernels is not None:
+        buf = ctypes.create_string_buffer(4096)
+        lib().sk_amd_engine_kernel_names(engine._h, buf, 4096)
+        kernels.extend(buf.value.decode().split(","))
+    return {k: np.array(v) for k, v in out.items() if isinstance(v, np.ndarray)}
+
+
+@pytest.mark.parametrize("delta_m", [False, True], ids=["", "delta-M scaled"])
+@pytest.mark.parametrize("ngroups", [1, 2])
+def test_scattering_groups_on_the_matrix_core_kernels_equal_the_runtime_n_kernels(monkeypatch, ngroups, delta_m):
+    """16 streams, spherical geometry: the groups' rows ride kern_k2c_mfma8 / kern_k2b_mfma8 (kern_k1g_cols8 forms the layer solutions'
+    derivatives along the groups' directions); SASKTRAN2_AMD_GROUPS=vector sends the same request through the run-time-n kernels."""
+    nw = 5
+    monkeypatch.setenv("SASKTRAN2_AMD_GROUPS", "vector")
+    ref = _group_solve(nw, 16, ngroups, delta_m)
+    monkeypatch.setenv("SASKTRAN2_AMD_GROUPS", "matrix")
+    got = _group_solve(nw, 16, ngroups, delta_m)
+    names = []
+    _group_solve(nw, 16, ngroups, delta_m, kernels=names)
+    assert "k1g_group_derivatives" in names and "k2c_adjoint_ops" in names, names
+    monkeypatch.setenv("SASKTRAN2_AMD_CHUNK", "2")     # blocks of the spectrum (the groups' inputs are indexed by the block's offset)
+    blocks = _group_solve(nw, 16, ngroups, delta_m)
+    assert set(got) == set(ref) and f"wf_scatterer_{ngroups - 1}" in got
+    for k in ref:
+        scale = np.abs(ref[k]).max()
+        assert np.max(np.abs(got[k] - ref[k])) <= 1e-10 * scale, k
+        assert np.array_equal(blocks[k], got[k]), k
+
+
 @pytest.mark.parametrize("knob,value", [("SASKTRAN2_AMD_VEC_W48", "1"), ("SASKTRAN2_AMD_VEC_W48", "0"), ("SASKTRAN2_AMD_VEC_LDS", "30"),
                                         ("SASKTRAN2_AMD_VEC_T2", "256"), ("SASKTRAN2_AMD_VEC_T2B", "256"), ("SASKTRAN2_AMD_VEC_SWEEP_THREADS", "1")])
 def test_vector_occupancy_variants_agree(monkeypatch, knob, value):
