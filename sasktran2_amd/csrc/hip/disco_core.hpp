@@ -177,15 +177,16 @@ __device__ inline Bufs order_view(Bufs b, unsigned mo) {
 }
 #endif
 
-// derivative of a layer's solution along a scattering group's direction (16 streams, lane-path records): per solution j a block of CB doubles
-//   dW+(:, j), dW-(:, j), dk_j, dA+_j, dA-_j, d(A- C-)_j, d(A+ C+)_j  (2 N + 5 of CB = 3 N + 2: 52 dwords apart for N = 8, so that the eight
-//   solutions' entries fall on different LDS bank windows in kern_k2c_mfma8's image, which is this layout unchanged), then the direction itself
+// derivative of a layer's solution along a scattering group's direction (16 streams, lane-path records): dW+[i][j], dW-[i][j] stream-major
+// with rows 9 doubles apart, then dk_j, dA+_j, dA-_j, d(A- C-)_j, d(A+ C+)_j as runs of eight, then the direction itself (16).  The eight lanes
+// of a problem in kern_k1g_cols8 (lane = solution j) write 64-byte runs; in kern_k2c_mfma8's LDS image (this layout unchanged) the lanes of an
+// edge (stream i) are 18 dwords apart and the lanes of a Legendre sum (i, j) consecutive: no bank conflicts either way
 template <int N> struct RecG {
-    static constexpr int CB = 3 * N + 2, DWP = 0, DWM = N, DK = 2 * N, DAP = DK + 1, DAM = DK + 2, CGM = DK + 3, CGP = DK + 4;
-    static constexpr int DA = N * CB, SIZE = DA + 2 * N;
-    SKD_HD static constexpr int dwp(int i, int j) { return j * CB + DWP + i; }
-    SKD_HD static constexpr int dwm(int i, int j) { return j * CB + DWM + i; }
-    SKD_HD static constexpr int at(int what, int j) { return j * CB + what; }
+    static constexpr int RS = N + 1, DWP = 0, DWM = N * RS, DK = 2 * N * RS, DAP = DK + N, DAM = DAP + N, CGM = DAM + N, CGP = CGM + N;
+    static constexpr int DA = CGP + N, SIZE = DA + 2 * N;
+    SKD_HD static constexpr int dwp(int i, int j) { return DWP + i * RS + j; }
+    SKD_HD static constexpr int dwm(int i, int j) { return DWM + i * RS + j; }
+    SKD_HD static constexpr int at(int what, int j) { return what + j; }
 };
 // group rows of the adjoint operators: DI[edge][i] and GD
 template <int N> struct OpsG {

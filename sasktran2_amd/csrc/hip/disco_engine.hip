@@ -482,6 +482,7 @@ struct DeviceEngine::Impl {
     int ngroups = 0, group_cap_w = 0, group_cap_g = 0;
     const double *g_dleg = nullptr, *g_dfg = nullptr;
     double* g_wf_scat = nullptr;
+    double *d_k1g_pp = nullptr, *d_k1g_q = nullptr;   // kern_k1g_tables, once per engine
     hipEvent_t fork = nullptr;
     int chunk_capacity = 0;
     int last_chunk = 0, last_slots = 0;
@@ -732,6 +733,13 @@ void DeviceEngine::ensure_group_scratch(int ngroups) {
     }
     I.group_cap_g = ngroups;
     I.group_cap_w = nw;
+    if (!I.d_k1g_pp) {
+        const size_t NP = N * (N + 1) / 2;
+        I.d_k1g_pp = I.geo_mem.alloc<double>(nstr * NP * nstr);
+        I.d_k1g_q = I.geo_mem.alloc<double>(size_t(std::max(I.g.nsza, 1)) * nstr * N * nstr);
+        hipLaunchKernelGGL(kern_k1g_tables, dim3(64), dim3(256), 0, nullptr, I.g, I.d_k1g_pp, I.d_k1g_q);
+        HIP_CHECK(hipDeviceSynchronize());
+    }
 }
 void DeviceEngine::set_scattering_groups(int ngroups, const double* d_dleg, double* d_wf_scat, const double* d_dfg) {
     Impl& I = *impl_;
@@ -1150,7 +1158,9 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                 }
                 if (b.ngroups > 0 && derivs) {   // the layer solutions' derivatives along the scattering groups' directions
                     Timer t(I, sA, "k1g_group_derivatives");
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1g_cols8<8>), dim3(unsigned((nw + 7) / 8), unsigned(g.nlyr), unsigned(b.ngroups)), dim3(64), 0, sA, g, b, s, m);
+                    constexpr int SETS = 4;   // 32 wavelengths per block behind one load of the order's tables
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k1g_cols8<8, SETS>), dim3(unsigned((nw + 8 * SETS - 1) / (8 * SETS)), unsigned(g.nlyr), unsigned(b.ngroups)), dim3(64), 0,
+                                       sA, g, b, s, m, I.d_k1g_pp, I.d_k1g_q);
                 }
             } else {
                 bool pre;
@@ -1222,7 +1232,12 @@ static void run_chunk(DeviceEngine::Impl& I, DeviceEngine::Impl::Slot& slot, hip
                         int split = std::max(3, small_batch_split(int(nw)));
                         if (const char* e = std::getenv("SASKTRAN2_AMD_K2C_SPLIT")) split = std::max(1, atoi(e));
                         const int lpb = (g.nlyr + split - 1) / split, ny = (g.nlyr + lpb - 1) / lpb;
-                        if (b.ngroups > 0 && ntile == 2)
+                        // (one instantiation per group count: the groups' derivative blocks take 3.6 KB of LDS each)
+                        if (b.ngroups == 1 && ntile == 2)
+                            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true, 2, 1>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);
+                        else if (b.ngroups == 1)
+                            hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true, 1, 1>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);
+                        else if (b.ngroups > 0 && ntile == 2)
                             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true, 2, 2>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);
                         else if (b.ngroups > 0)
                             hipLaunchKernelGGL(HIP_KERNEL_NAME(kern_k2c_mfma8<true, 1, 2>), dim3(unsigned(nw)), dim3(64), 0, sC, g, b, s, m, g.nlyr);

@@ -1686,7 +1686,9 @@ template <bool K1LANE, int FTILES = 0, int NGM = 0> __global__ void __launch_bou
             // K1LANE (records of kern_k1_lane): the derivative rows of G are not in the record; edge e of stream i is
             //   DG[theta][e][i] = sum_j X(i, j) coef_type(e)[1 + theta][j] + (theta = omega) sum_j dX(i, j) coef_type(e)[0][j],  type = A- C- (e < 2), A+ C+
             const int tk0 = (e >= 2) ? 5 : 0;
-            double d_tau = 0, d_om = 0, ipb_i = 0, dg[4] = {0, 0, 0, 0};
+            double d_tau = 0, d_om = 0, ipb_i = 0, dg[4] = {0, 0, 0, 0}, dgg[NGS];
+            for (int gi = 0; gi < NGS; ++gi) dgg[gi] = 0;
+            [[maybe_unused]] const double* sG0 = sGrp + (((p - p_begin) & 1) * NGS) * RG::SIZE;
 #pragma unroll 2
             for (int jj = 0; jj < N / 2; ++jj) {
                 const int j = h * (N / 2) + jj;
@@ -1699,9 +1701,19 @@ template <bool K1LANE, int FTILES = 0, int NGM = 0> __global__ void __launch_bou
                 d_om += dX * t_e + X * t_om + dY * oa;
                 ipb_i += X * t_e + Y * oa;
                 if constexpr (K1LANE) {
+                    const double c0 = sRec[RL::coef(tk0, j)];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) dg[t] += X * sRec[RL::coef(tk0 + 1 + t, j)];
-                    dg[skd::TH_OM] += dX * sRec[RL::coef(tk0, j)];
+                    dg[skd::TH_OM] += dX * c0;
+                    // group rows: the omega row's form with the group's dW, dk and coefficient derivatives
+                    if constexpr (NGM > 0)
+#pragma unroll
+                        for (int gi = 0; gi < NGM; ++gi) {
+                            if (gi >= ng) break;
+                            const double* sG = sG0 + gi * RG::SIZE;
+                            const double gX = sG[own_minus ? RG::dwm(i, j) : RG::dwp(i, j)], gY = sG[own_minus ? RG::dwp(i, j) : RG::dwm(i, j)];
+                            dgg[gi] += gX * t_e + X * (-sG[RG::at(RG::DK, j)] * th * t_e) + gY * oa + X * sG[RG::at((e >= 2) ? RG::CGP : RG::CGM, j)] + gX * c0;
+                        }
                 }
             }
             d_tau += __shfl_xor(d_tau, 32);
@@ -1729,21 +1741,9 @@ template <bool K1LANE, int FTILES = 0, int NGM = 0> __global__ void __launch_bou
                     sDIpb[skd::TH_SEC * N + i] = wmu * v_sec;
                 }
             }
-            // group rows: the omega row's form with the group's dW, dk and coefficient derivatives
             if constexpr (NGM > 0)
                 for (int gi = 0; gi < ng; ++gi) {
-                    const double* sG = sGrp + ((((p - p_begin) & 1) * NGS) + gi) * RG::SIZE;
-                    double acc = 0;
-#pragma unroll 2
-                    for (int jj = 0; jj < N / 2; ++jj) {
-                        const int j = h * (N / 2) + jj;
-                        const double X = sRec[own_minus ? RL::wm(i, j) : RL::wp(i, j)];
-                        const double dX = sG[own_minus ? RG::dwm(i, j) : RG::dwp(i, j)], dY = sG[own_minus ? RG::dwp(i, j) : RG::dwm(i, j)];
-                        const double E = sRec[RL::e(j)], L = sXs[j], Mv = sXs[N + j];
-                        const double pa = pm ? Mv : L, oa = pm ? L : Mv;
-                        acc += dX * (E * pa) + X * (-sG[RG::at(RG::DK, j)] * th * E * pa) + dY * oa;
-                        acc += X * sG[RG::at((e >= 2) ? RG::CGP : RG::CGM, j)] + dX * sRec[RL::coef(tk0, j)];
-                    }
+                    double acc = dgg[gi];
                     acc += __shfl_xor(acc, 32);
                     if (h == 0) {
                         skd::opsg_at<N>(b, nlyr, p, w, gi)[OG::DI + e * N + i] = acc;
@@ -1838,7 +1838,7 @@ template <bool K1LANE, int FTILES = 0, int NGM = 0> __global__ void __launch_bou
                 for (int r = 0; r < 4; ++r) SKD_NT_ST(&zt[64 * r + lane], acc[r]);
                 SKD_NT_ST(&hw[(size_t(p) * ntile + t) * 64 + lane], hacc[0]);
                 if constexpr (NGM > 0)
-                    if (ng > 0) SKD_NT_ST(&b.hg[((size_t(w) * nlyr + p) * ntile + t) * 64 + lane], hacc[2]);
+                    if (q < ng) SKD_NT_ST(&b.hg[((size_t(w) * nlyr + p) * ntile + t) * 64 + lane], hacc[2]);   // (rows 8 .. 8 + ng - 1 only: 128 bytes per group)
                 yprev[t] = acc;
             }
         }
@@ -1856,8 +1856,11 @@ template <bool K1LANE, int FTILES = 0, int NGM = 0> __global__ void __launch_bou
 //             rows 4..7 carry sum_i zB_i for the ground terms)
 //   Y / Z tiles and the HD part are kept in HBM between the sweeps in their C/D register images
 //   (b.z: [w][p][tile][4][64], b.qlbuf: [w][p][tile][64]); nothing goes through LDS.
+#ifndef SKD_WPE_K2BG
+#define SKD_WPE_K2BG 4   // (146 registers with the groups' rows, 20 spilled at four wavefronts per SIMD -- and still faster than three: 21.8 / 24.7 ms)
+#endif
 // GROUPS (BWD_ONLY): rows 8 .. 8 + b.ngroups - 1 of the gradient tile are the scattering groups' rows (skd::OpsG, the forward sweep's b.hg)
-template <int TILES, bool BWD_ONLY = false, bool GROUPS = false> __global__ void __launch_bounds__(64, SKD_WPE_K2BM) kern_k2b_mfma8(Geo g, Bufs b, int s, int m) {
+template <int TILES, bool BWD_ONLY = false, bool GROUPS = false> __global__ void __launch_bounds__(64, GROUPS ? SKD_WPE_K2BG : SKD_WPE_K2BM) kern_k2b_mfma8(Geo g, Bufs b, int s, int m) {
     // the one- and two-tile instantiations must round identically (results do not depend on the launch shape): no implicit
     // contraction of a * b + c in this kernel, fused multiply-adds are written out
 #pragma clang fp contract(off)
@@ -1976,14 +1979,15 @@ template <int TILES, bool BWD_ONLY = false, bool GROUPS = false> __global__ void
                 e1[kk] = (col < 4) ? ops[O::DI + (col * 4 + 1) * N + i] : 0.0;
                 e2[kk] = (col < 4) ? -ops[O::DI + (col * 4 + 2) * N + i] : 0.0;
                 e3[kk] = (col < 4) ? -ops[O::DI + (col * 4 + 3) * N + i] : ((col < 8 && last && last_is_ground) ? 1.0 : 0.0);
-                if constexpr (GROUPS)
-                    if (col >= 8 && col < 8 + ng) {
-                        const double* og = skd::opsg_at<N>(b, nlyr, p, w, col - 8);
-                        e0[kk] = og[OG::DI + 0 * N + i];
-                        e1[kk] = og[OG::DI + 1 * N + i];
-                        e2[kk] = -og[OG::DI + 2 * N + i];
-                        e3[kk] = -og[OG::DI + 3 * N + i];
-                    }
+                if constexpr (GROUPS) {   // (every lane loads, from a valid group's rows; lanes of the groups' rows keep the values)
+                    const bool isg = col >= 8 && col < 8 + ng;
+                    const double* og = skd::opsg_at<N>(b, nlyr, p, w, isg ? col - 8 : 0) + OG::DI + i;
+                    const double g0 = og[0], g1 = og[N], g2 = og[2 * N], g3 = og[3 * N];
+                    e0[kk] = isg ? g0 : e0[kk];
+                    e1[kk] = isg ? g1 : e1[kk];
+                    e2[kk] = isg ? -g2 : e2[kk];
+                    e3[kk] = isg ? -g3 : e3[kk];
+                }
             }
             const double gd = (last && last_is_ground && q < 4) ? ops[O::GD + q] : 0.0;
             double gdg = 0;
@@ -2002,13 +2006,15 @@ template <int TILES, bool BWD_ONLY = false, bool GROUPS = false> __global__ void
                     mf4 gp = gprev[t];
                     for (int kk = 0; kk < 2; ++kk) gp = mfma16(e1prev[kk], z[2 + kk], gp);
                     if (ok[t]) b.grad[size_t(q * nlyr + p + 1) * nt + size_t(w) * nlos + los[t]] += gp[0];
+#ifndef SKD_EXP_NOGRMW
                     if constexpr (GROUPS)
                         if (ok[t] && q < ng) b.grad[size_t(4 * nlyr + 2 + q * nlyr + p + 1) * nt + size_t(w) * nlos + los[t]] += gp[2];
+#endif
                 }
                 // this layer: HD part from the forward sweep, zA_p, zB_p, zA_{p+1}
                 mf4 ga = {SKD_NT_LD(&hw[(size_t(p) * ntile + tile0 + t) * 64 + lane]), 0, 0, 0};
                 if constexpr (GROUPS)
-                    if (ng > 0) ga[2] = SKD_NT_LD(&b.hg[((size_t(w) * nlyr + p) * ntile + tile0 + t) * 64 + lane]);
+                    if (q < ng) ga[2] = SKD_NT_LD(&b.hg[((size_t(w) * nlyr + p) * ntile + tile0 + t) * 64 + lane]);
                 for (int kk = 0; kk < 2; ++kk) ga = mfma16(e0[kk], z[kk], ga);
                 for (int kk = 0; kk < 2; ++kk) ga = mfma16(e3[kk], z[2 + kk], ga);
                 if (!last)
