@@ -715,14 +715,21 @@ def test_scattering_group_derivatives_match_finite_differences(nstr, delta_m):
         assert np.max(np.abs(fd - an)) < 1e-5 * np.abs(res["wf_scatterer"]).max(), q
 
 
-def _group_solve(nw=3, nstr=16, ngroups=2, delta_m=False, nlos_stride=1, kernels=None):
+def _group_solve(nw=3, nstr=16, ngroups=2, delta_m=False, nlos_stride=1, kernels=None, scene="regression"):
     """A limb scene with `ngroups` scattering constituents (derivative mappings with d_legendre / scat_factor): every output of one solve."""
     import ctypes
     from tests.gpu_harness import build_engine
     import sasktran2_amd as sk
-    ng = 25
     gcs = (0.85 if delta_m else 0.6, 0.3)
-    s, mp0 = _mixture(np.ones(ng), nw, nstr, gcs[0])
+    if scene == "c2":   # the bench geometry: 51 levels, 25 tangent rays (two 16-LOS tiles), one solar zenith angle
+        s = sc.limb_c2(num_wavelengths=nw, nstr=nstr)
+        ng = s["extinction"].shape[0]
+        e = 0.3 * s["extinction"]
+        mp0 = dict(d_extinction=e, d_ssa=e * (0.95 - s["ssa"]) / s["extinction"], scat_factor=e * 0.95 / (s["extinction"] * s["ssa"]),
+                   d_legendre=((2 * np.arange(16) + 1) * gcs[0] ** np.arange(16))[:, None, None] - s["leg"])
+    else:
+        ng = 25
+        s, mp0 = _mixture(np.ones(ng), nw, nstr, gcs[0])
     if nlos_stride > 1:
         s = dict(s, rays=s["rays"][::nlos_stride])
     # the second group: another phase function on the same mixture (its own direction d_legendre = constituent - mixture coefficients)
@@ -789,6 +796,20 @@ def test_scattering_groups_on_the_matrix_core_kernels_equal_the_runtime_n_kernel
         scale = np.abs(ref[k]).max()
         assert np.max(np.abs(got[k] - ref[k])) <= 1e-10 * scale, k
         assert np.array_equal(blocks[k], got[k]), k
+
+
+@pytest.mark.parametrize("ngroups", [1, 2])
+def test_scattering_groups_at_the_bench_geometry_two_los_tiles(monkeypatch, ngroups):
+    """The C2 geometry (50 layers, 25 tangent rays = two 16-LOS tiles of the adjoint sweeps): the two-tile instantiations of the group rows."""
+    monkeypatch.setenv("SASKTRAN2_AMD_GROUPS", "vector")
+    ref = _group_solve(3, 16, ngroups, scene="c2")
+    monkeypatch.setenv("SASKTRAN2_AMD_GROUPS", "matrix")
+    names = []
+    got = _group_solve(3, 16, ngroups, scene="c2", kernels=names)
+    assert "k1g_group_derivatives" in names
+    for k in ref:
+        assert np.max(np.abs(got[k] - ref[k])) <= 1e-10 * np.abs(ref[k]).max(), k
+    assert np.abs(ref[f"wf_scatterer_{ngroups - 1}"]).max() > 0
 
 
 @pytest.mark.parametrize("knob,value", [("SASKTRAN2_AMD_VEC_W48", "1"), ("SASKTRAN2_AMD_VEC_W48", "0"), ("SASKTRAN2_AMD_VEC_LDS", "30"),
