@@ -563,8 +563,7 @@ Engine* sk_engine_create(Config* c, Geometry1D* g, ViewingGeometry* v) {
             e->dev = std::make_unique<skdev::DeviceEngine>(dg, c->ss_source == 2);
             e->nlos = dg.nlos;
             e->ngrid = dg.ngrid;
-            if (c->emission_source == 2 && e->dev->vector_mode())
-                throw std::runtime_error("emission_source = discrete_ordinates needs a stream count of the matrix-core path (2, 4, 8, 16 or 32)");
+            // (any even stream count: the run-time-n kernels carry the thermal pass too; NSTOKES = 1 is checked above)
             if (ss_los && !dg.spherical_pp)
                 throw std::runtime_error("single_scatter_source = exact with discrete ordinates needs spherical geometry (in plane-parallel "
                                          "geometry the discrete-ordinates source carries the single scatter itself)");
@@ -861,9 +860,27 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
         HIPC(hipMemcpy(d_f, st.src_delta_f(), nloc_w * 8, hipMemcpyDefault));
     }
     e->dev->set_delta_m_fraction(d_f);
+    if (e->config.emission_source == 2) {   // thermal source inside the DO equations (NSTOKES = 1, plane-parallel post-processing)
+        if (derivs) {
+            d_wem = (double*)C.get("wf_emission", size_t(ngrid) * nt * 8);
+            d_wsem = (double*)C.get("wf_surface_emission", nt * 8);
+            e->dev->set_thermal_wf_outputs(d_wem, d_wsem);
+        }
+        if (!st.emission) throw std::runtime_error("emission_source = discrete_ordinates but the atmosphere storage has no emission_source array");
+        double* d_em = (double*)C.get("do_emission", nloc_w * 8);
+        HIPC(hipMemcpy(d_em, st.emission, nloc_w * 8, hipMemcpyDefault));
+        double* d_sem = nullptr;
+        if (su.emission) {
+            d_sem = (double*)C.get("do_surface_emission", size_t(nw) * 8);
+            HIPC(hipMemcpy(d_sem, su.emission, size_t(nw) * 8, hipMemcpyDefault));
+        }
+        e->dev->set_thermal_emission(d_em, d_sem);
+    }
     e->dev->solve_device_vector(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, derivs, d_rad, d_we, d_ws, d_wa, d_od, d_status, nullptr,
                                 (int)group_of.size(), d_dleg, d_wg, d_dfg);
     e->dev->set_delta_m_fraction(nullptr);
+    e->dev->set_thermal_emission(nullptr, nullptr);
+    e->dev->set_thermal_wf_outputs(nullptr, nullptr);
     if (e->so) {
         upload_emission(e, st, su);
         // the exact single scatter differentiates along the same group directions (d_dleg holds them group by group) into the same d_wg
@@ -1164,12 +1181,6 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         const bool groups_here = scattering_groups && ngroups_requested > 0 && !force && !e->dev->vector_mode() && e->config.emission_source != 2 &&
                                  !(groups_env && std::string(groups_env) == "vector") && e->dev->groups_on_matrix_path(ngroups_requested);
         if (force || e->dev->vector_mode() || (scattering_groups && atm->derivs && e->config.wf_enabled && !groups_here)) {
-            if (e->config.emission_source == 2) {
-                // the thermal pass lives in the matrix-core path's plane-parallel branch only: refuse rather than drop the source
-                set_error("sk_engine_calculate_radiance: emission_source = discrete_ordinates is not available together with scattering-group "
-                          "weighting functions (d_legendre / scat_factor mappings) or SASKTRAN2_AMD_RUNTIME_N in this build");
-                return -2;
-            }
             if (e->nflux_obs > 0) {
                 set_error("sk_engine_calculate_radiance: flux observers are not available together with scattering-group weighting functions or "
                           "SASKTRAN2_AMD_RUNTIME_N in this build");

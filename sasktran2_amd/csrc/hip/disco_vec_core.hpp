@@ -269,7 +269,7 @@ SKD_HD double recip_sqrt(double x) {
 // accumulated in k order in one accumulator, so the result does not depend on the strip shape.  On the CPU (emulation) it is the
 // plain triple loop.  The caller separates it from neighbouring phases with team.sync().
 template <class FA, class FB, class FC> SKV_TEAM_BODY void team_gemm(const Team& team, int M, int N, int K, FA a, FB b, FC store) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SKV_GEMM_PLAIN)
     typedef double mf4v __attribute__((ext_vector_type(4)));
     const int wave = team.lane >> 6, nwaves = (team.width + 63) >> 6, l = team.lane & 63;
     const int tn = (N + 15) / 16, tm = (M + 15) / 16;
@@ -674,7 +674,8 @@ SKV_TEAM_BODY bool team_jacobi(const Team& team, int n, double* Mx, double* V, d
 //   ws: 8 n^2 + 20 n + 64 doubles of team-shared work space (LDS when it fits, HBM otherwise)
 // =================================================================================================
 //   `compact`: without scattering groups the Green's-function coefficients (12 n doubles) live in the storage of the Cholesky factor, which
-//   is dead by then -- at 16 polarised streams that is what lets a fourth team onto the CU (38.9 instead of 41.2 KB)
+//   is dead by then -- at 16 polarised streams that is what lets a fourth team onto the CU (38.9 instead of 41.2 KB).  Only for n >= 12
+//   (12 n <= n n): the launcher sets VBufs::k1_compact accordingly
 SKD_HD size_t kv1_scratch(int n, bool compact = false) { return 8 * size_t(n) * n + (compact ? 8 : 20) * size_t(n) + 64; }
 #if defined(SKV_K1_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 #define KV1T(i) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; }
@@ -1465,7 +1466,8 @@ template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g,
                 if (m == 0 && (i % S) == 0) {
                     double sg = 0;
                     for (int t = 0; t < N; ++t) sg += g.wt[t] * g.mu[t] * c[R.G() + 2 * n + t * S];
-                    rb += g.csz[s] * rho / kPi * b.T[size_t(nlyr) * nw + w] + kd * rho * sg;
+                    // (+ surface emission in the thermal pass, as skd::k2a_bvp)
+                    rb += g.csz[s] * rho / kPi * b.T[size_t(nlyr) * nw + w] + (b.surf_em ? b.surf_em[w] : 0.0) + kd * rho * sg;
                 }
             } else {
                 rb += vrec_at(v, nlyr, p + 1, w)[R.G() + 1 * n + i];
@@ -2132,7 +2134,8 @@ SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v,
             for (int t = 0; t < 4; ++t) gth[t] += (zBsum + gw) * ops[O.GD() + t];
             const double rho = b.albedo[w], ipb = ops[O.IPB()];
             v.grad[size_t(4 * nlyr) * nt + tid] += gw * 2.0 * ipb + zBsum * (2.0 * ipb + g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w]);
-            v.grad[size_t(4 * nlyr + 1) * nt + tid] += zBsum * g.csz[s] / kPi * rho;
+            // solar: d / d(beam transmission at the ground); thermal pass: d / d(surface emission) (as skd::K2bTask::gradient)
+            v.grad[size_t(4 * nlyr + 1) * nt + tid] += b.thermal_pass ? zBsum : zBsum * g.csz[s] / kPi * rho;
         }
         for (int t = 0; t < 4; ++t) v.grad[size_t(t * nlyr + p) * nt + tid] += gth[t];
         // scattering groups: the same contraction with the group's DI / HD / GD rows
@@ -2382,7 +2385,7 @@ SKV_TEAM_BODY void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, con
             if (r == 0 && last && m == 0) {
                 const double rho = b.albedo[w], ipb = ops[O.IPB()], gw = gwv[col];
                 v.grad[size_t(4 * nlyr) * nt + tid] += gw * 2.0 * ipb + zs * (2.0 * ipb + g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w]);
-                v.grad[size_t(4 * nlyr + 1) * nt + tid] += zs * g.csz[s] / kPi * rho;
+                v.grad[size_t(4 * nlyr + 1) * nt + tid] += b.thermal_pass ? zs : zs * g.csz[s] / kPi * rho;
             }
         }
         team.sync();
@@ -2483,7 +2486,7 @@ SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v
                         dym[size_t(s1) * n + a] += dtm + tm / om;
                     }
                     // solar single-scatter term: first column of the negated product with the sun direction
-                    if (g.include_ss) Q[s1] += sg * brow[0] * lpc[l] * fm * om;
+                    if (g.include_ss || b.thermal_pass) Q[s1] += sg * brow[0] * lpc[l] * fm * om;   // (thermal pass: the direct emission term, as skd::kpp_los)
                     // scattering groups: d(lrow) W + lrow dW_g  (direction dc of the coefficients)
                     for (int gi = 0; gi < NG && gi < 4; ++gi) {
                         Scr gyp = gy.sub(size_t(gi) * 8 * n), gym = gy.sub(size_t(gi) * 8 * n + 3 * size_t(n)), dl = gy.sub(size_t(gi) * 8 * n + 6 * size_t(n));
@@ -2519,7 +2522,7 @@ SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v
                             gyp[size_t(s1) * n + a] += tp;
                             gym[size_t(s1) * n + a] += tm;
                         }
-                        if (g.include_ss) Qg[gi][s1] += sg * dbrow[0] * lpc[l] * fm * om;
+                        if (g.include_ss || b.thermal_pass) Qg[gi][s1] += sg * dbrow[0] * lpc[l] * fm * om;
                     }
                 }
             }
@@ -2603,7 +2606,8 @@ SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v
         }
         const double direct = g.include_ss ? g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w] : 0.0;
         const double A = att * azf[0];
-        ground = A * rho * (2.0 * ipb + direct);
+        // thermal pass: the surface emission joins the reflected intensity where the direct bounce does (sktran_do_layerarray.cpp:255-266)
+        ground = A * (rho * (2.0 * ipb + direct) + ((g.include_ss && b.surf_em) ? b.surf_em[w] : 0.0));
         total[0] += ground;
         if (derivs) {
             gw = A;
@@ -2612,7 +2616,7 @@ SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v
             for (int i = 0; i < M2; ++i) v.z[(size_t(nlyr - 1) * M2 + i) * nt3 + t3] += gw * ops[O.UG() + i];
             // direct-beam part of the reflected intensity (the diffuse part goes through gw in the gradient contraction)
             v.grad[size_t(4 * nlyr) * nt3 + t3] += A * direct;
-            v.grad[size_t(4 * nlyr + 1) * nt3 + t3] += g.include_ss ? A * rho * g.csz[s] / kPi : 0.0;
+            v.grad[size_t(4 * nlyr + 1) * nt3 + t3] += b.thermal_pass ? ((g.include_ss && b.surf_em) ? A : 0.0) : (g.include_ss ? A * rho * g.csz[s] / kPi : 0.0);
         }
     }
     for (int s1 = 0; s1 < S; ++s1) v.radiance[tid * S + s1] += total[s1];

@@ -839,6 +839,33 @@ def test_vector_results_do_not_depend_on_the_block_size(monkeypatch):
         assert np.array_equal(full[k], part[k]), k
 
 
+@pytest.mark.parametrize("runtime_n", [False, True], ids=["matrix-core kernels", "run-time-n kernels"])
+@pytest.mark.parametrize("geotype", [sc.GEO_PLANEPARALLEL, sc.GEO_SPHERICAL], ids=["plane parallel", "spherical"])
+@pytest.mark.parametrize("nstr", [4, 6, 8, 10, 16])
+def test_few_streams_on_both_device_implementations(nstr, geotype, runtime_n, monkeypatch):
+    """Small systems (n = streams / 2 = 2 .. 8) with weighting functions on the run-time-n kernels (their own stream counts 6 and 10, and
+    the matrix-core counts routed there) and on the matrix-core kernels against the oracle, 16 Legendre moments in the storage.  Round 4 found
+    the eigen stage's compact work-space layout of the run-time-n kernels overrunning its n x n slot for n < 12 (wrong weighting functions
+    at 6 and 10 streams, wrong radiances at n = 2): the layout is now only used from n = 12 on."""
+    if runtime_n:
+        monkeypatch.setenv("SASKTRAN2_AMD_RUNTIME_N", "1")
+    elif nstr in (6, 10):
+        pytest.skip("served by the run-time-n kernels anyway")
+    ng, nw = 11, 3
+    alt = np.linspace(0.0, 20000.0, ng)
+    k = (6e-5 * np.exp(-alt / 7000.0))[:, None] * np.array([0.6, 1.0, 2.5])[None, :]
+    ssa = np.linspace(0.35, 0.8, ng)[:, None] * np.ones((1, nw))
+    leg = ((2 * np.arange(16) + 1) * 0.55 ** np.arange(16))[:, None, None] * np.ones((1, ng, nw))
+    s = dict(geometry=dict(cos_sza=0.6, saa=0.0, earth_radius=6_372_000.0, altitudes=alt, interp_method=sc.INTERP_LINEAR, geotype=geotype),
+             config=dict(nstr=nstr, num_sza=1), rays=[(sc.GROUND_VIEWING_SOLAR, 0.6, 0.4, 200_000.0, 0.9), (sc.GROUND_VIEWING_SOLAR, 0.6, 1.7, 200_000.0, 0.5)],
+             extinction=k, ssa=ssa, leg=leg, albedo=np.array([0.1, 0.25, 0.4]))
+    got, ref = run_product(s), run_oracle(s, derivatives=True)
+    np.testing.assert_allclose(got["radiance"], ref["radiance"], rtol=1e-10)
+    for key in ("d_extinction", "d_ssa"):
+        assert np.max(np.abs(got[key] - ref[key]) / np.abs(ref[key]).max(axis=2, keepdims=True)) < 1e-8, key
+    np.testing.assert_allclose(got["d_albedo"], ref["d_albedo"], rtol=1e-8)
+
+
 def test_matrix_core_and_runtime_n_kernels_agree(monkeypatch):
     """Two independent device implementations of the same formulation (16-stream matrix-core kernels vs the run-time-n team kernels)
     on the C2 shape: radiances to 1e-11, weighting functions to 1e-8 of the profile maximum."""
@@ -1022,13 +1049,17 @@ def test_thermal_emission_with_sun_and_reflecting_surface_matches_oracle():
     assert np.all(ref > sun_only)
 
 
-@pytest.mark.parametrize("nstr,delta_m", [(4, False), (16, False), (4, True)], ids=["4 streams", "16 streams", "4 streams, delta-M scaled"])
-def test_thermal_source_weighting_functions_match_finite_differences(nstr, delta_m):
+@pytest.mark.parametrize("nstr,delta_m,runtime_n", [(4, False, False), (16, False, False), (4, True, False), (8, False, True), (10, False, True), (8, True, True)],
+                         ids=["4 streams", "16 streams", "4 streams, delta-M scaled", "8 streams on the run-time-n kernels", "10 streams (run-time-n kernels)",
+                              "8 streams, delta-M scaled, run-time-n kernels"])
+def test_thermal_source_weighting_functions_match_finite_differences(nstr, delta_m, runtime_n, monkeypatch):
     """emission_source = discrete_ordinates with weighting functions: extinction, ssa, albedo (solar + thermal parts together), the emission
     profile and the surface emission (mappings with d_emission, deriv_mapping.h:15-53) against central differences of the product's own
     radiances -- the reference's criterion (tests/weightingfunctions/test_emissions.py)."""
     import ctypes
     import sasktran2_amd as sk
+    if runtime_n:   # the thermal pass of the run-time-n kernels (any even stream count; SASKTRAN2_AMD_RUNTIME_N routes the matrix-core counts there too)
+        monkeypatch.setenv("SASKTRAN2_AMD_RUNTIME_N", "1")
     ng, nw = 11, 3
     alt = np.linspace(0.0, 20000.0, ng)
     config = sk.Config()
@@ -1079,6 +1110,12 @@ def test_thermal_source_weighting_functions_match_finite_differences(nstr, delta
 
     res = solve(base, True)
     rad = res["radiance"]
+    if runtime_n and nstr in (2, 4, 8, 16, 32):   # the same request on the matrix-core kernels: every output agrees
+        monkeypatch.delenv("SASKTRAN2_AMD_RUNTIME_N")
+        ref = solve(base, True)
+        monkeypatch.setenv("SASKTRAN2_AMD_RUNTIME_N", "1")
+        for key in ("radiance", "wf_extinction", "wf_ssa", "wf_albedo", "wf_emission", "wf_surface_emission"):
+            assert np.max(np.abs(res[key] - ref[key])) <= 1e-9 * np.max(np.abs(ref[key])), key
 
     def fd(key, q, h):
         plus, minus = {k: a.copy() for k, a in base.items()}, {k: a.copy() for k, a in base.items()}
@@ -1099,3 +1136,97 @@ def test_thermal_source_weighting_functions_match_finite_differences(nstr, delta
     np.testing.assert_allclose(res["wf_surface_emission"], fd("sem", None, 1e-4), rtol=2e-6, atol=1e-9 * scale)
     np.testing.assert_allclose(res["wf_albedo"], fd("alb", None, 1e-6), rtol=2e-5, atol=1e-8 * scale)
     assert np.max(np.abs(res["wf_emission"])) > 0 and np.max(np.abs(res["wf_surface_emission"])) > 0
+
+
+def _thermal_mixture(x, nw=2):
+    """A sunlit, emitting plane-parallel atmosphere with a scattering constituent of profile x: storage arrays and the constituent's mapping."""
+    ng = 11
+    alt = np.linspace(0.0, 20000.0, ng)
+    ka = (6e-5 * np.exp(-alt / 7000.0))[:, None] * np.linspace(0.6, 2.5, nw)[None, :]
+    wa = np.linspace(0.35, 0.8, ng)[:, None] * np.ones((1, nw))
+    l = np.arange(16)
+    ba, bc = (2 * l + 1) * 0.2 ** l, (2 * l + 1) * 0.7 ** l
+    e, wc = 0.4 * ka, 0.9
+    k = ka + x[:, None] * e
+    sca = ka * wa + x[:, None] * e * wc
+    w = sca / k
+    beta = ((ka * wa)[None] * ba[:, None, None] + (x[:, None] * e * wc)[None] * bc[:, None, None]) / sca[None]
+    em = (3.0 * np.exp(-alt / 9000.0) + 0.4)[:, None] * np.linspace(1.0, 1.3, nw)[None, :]
+    mapping = dict(d_extinction=e, d_ssa=e * (wc - w) / k, d_legendre=bc[:, None, None] - beta, scat_factor=e * wc / sca)
+    return dict(alt=alt, ext=k, ssa=w, leg=beta, em=em, alb=np.linspace(0.1, 0.4, nw), sem=np.linspace(2.0, 2.6, nw)), mapping
+
+
+@pytest.mark.parametrize("nstr", [8, 10])
+def test_thermal_source_with_a_scattering_group_matches_finite_differences(nstr):
+    """emission_source = discrete_ordinates together with a scattering constituent's number-density weighting function (d_legendre /
+    scat_factor mapping): refused until round 4, now served by the thermal pass of the run-time-n kernels.  Analytic == central finite
+    differences of the product's own radiances (sun + emission)."""
+    import ctypes
+    import sasktran2_amd as sk
+    ng, nw = 11, 2
+    x0 = np.ones(ng)
+    v0, mp = _thermal_mixture(x0, nw)
+    config = sk.Config()
+    config.num_streams = nstr
+    config.num_singlescatter_moments = 16
+    config.multiple_scatter_source = sk.MultipleScatterSource.DiscreteOrdinates
+    config.single_scatter_source = sk.SingleScatterSource.DiscreteOrdinates
+    config.emission_source = sk.EmissionSource.DiscreteOrdinates
+    geometry = sk.Geometry1D(0.6, 0.0, 6372000.0, v0["alt"], sk.InterpolationMethod.LinearInterpolation, sk.GeometryType.PlaneParallel)
+    viewing = sk.ViewingGeometry()
+    viewing.add_ray(sk.GroundViewingSolar(0.6, 0.4, 0.9, 200000.0))
+    viewing.add_ray(sk.GroundViewingSolar(0.6, 1.7, 0.5, 200000.0))
+    engine = sk.Engine(config, geometry, viewing)
+    dp, vp = ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
+
+    def hook(L, h_st, h_out, out):
+        m = vp()
+        L.sk_atmosphere_storage_get_derivative_mapping(h_st, b"wf_scatterer", ctypes.byref(m))
+        for which, arr in (("d_extinction", mp["d_extinction"]), ("d_ssa", mp["d_ssa"])):
+            ptr = dp()
+            getattr(L, f"sk_deriv_mapping_get_{which}")(m, ctypes.byref(ptr))
+            np.ctypeslib.as_array(ptr, shape=(ng * nw,))[:] = arr.T.reshape(-1)
+        for fn, arr, size in (("sk_deriv_mapping_get_scat_factor", mp["scat_factor"].T.reshape(-1), ng * nw),
+                              ("sk_deriv_mapping_get_d_legendre", np.asfortranarray(mp["d_legendre"]).ravel(order="F"), 16 * ng * nw)):
+            f = getattr(L, fn)
+            f.argtypes = [vp, ctypes.POINTER(dp)]
+            ptr = dp()
+            assert f(m, ctypes.byref(ptr)) == 0
+            np.ctypeslib.as_array(ptr, shape=(size,))[:] = arr
+        out["wf_scatterer"] = np.zeros((ng, nw, 2, 1))
+        L.sk_output_assign_derivative_memory(h_out, b"wf_scatterer", out["wf_scatterer"].ctypes.data_as(dp), nw * 2, 1, ng)
+
+    def solve(v, with_hook):
+        atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=with_hook)
+        atmosphere.storage.total_extinction[:] = v["ext"]
+        atmosphere.storage.ssa[:] = v["ssa"]
+        atmosphere.leg_coeff.a1[:] = v["leg"]
+        atmosphere.storage.solar_irradiance[:] = 1.0
+        atmosphere.storage.emission_source[:] = v["em"]
+        atmosphere.surface.emission[:] = v["sem"]
+        atmosphere.surface.albedo[:] = v["alb"]
+        return engine.calculate_radiance(atmosphere, as_dataset=False, _mapping_hook=hook if with_hook else None)
+
+    res = solve(v0, True)
+    assert np.abs(res["wf_scatterer"]).max() > 0
+    for q in (0, 3, 6, 10):
+        h = 1e-5
+        xp, xm = x0.copy(), x0.copy()
+        xp[q] += h
+        xm[q] -= h
+        fd = (solve(_thermal_mixture(xp, nw)[0], False)["radiance"] - solve(_thermal_mixture(xm, nw)[0], False)["radiance"]) / (2 * h)
+        assert np.max(np.abs(fd - res["wf_scatterer"][q])) < 1e-5 * np.abs(res["wf_scatterer"]).max(), q
+    # without the emission the weighting function is a different one: the thermal pass carries its share
+    v_cold = dict(v0, em=0.0 * v0["em"], sem=0.0 * v0["sem"])
+    cold = solve(v_cold, True)
+    assert np.max(np.abs(cold["wf_scatterer"] - res["wf_scatterer"])) > 1e-3 * np.abs(res["wf_scatterer"]).max()
+
+
+def test_thermal_source_run_time_n_kernels_equal_the_matrix_core_path(monkeypatch):
+    """The thermal pass of the two device implementations: radiances of the sunlit, emitting scene with a reflecting, emitting surface."""
+    from tests.test_flux import flux_scene
+    s = flux_scene(8, thermal=True, nw=5)
+    base = _run_thermal(s)
+    monkeypatch.setenv("SASKTRAN2_AMD_RUNTIME_N", "1")
+    other = _run_thermal(s)
+    np.testing.assert_allclose(other, base, rtol=1e-11)
