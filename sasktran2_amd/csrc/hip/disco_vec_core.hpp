@@ -677,6 +677,8 @@ SKV_TEAM_BODY bool team_jacobi(const Team& team, int n, double* Mx, double* V, d
 //   is dead by then -- at 16 polarised streams that is what lets a fourth team onto the CU (38.9 instead of 41.2 KB).  Only for n >= 12
 //   (12 n <= n n): the launcher sets VBufs::k1_compact accordingly
 SKD_HD size_t kv1_scratch(int n, bool compact = false) { return 8 * size_t(n) * n + (compact ? 8 : 20) * size_t(n) + 64; }
+// whether the eigen stage runs in the compact layout (the device launcher and the CPU emulation of the tests both ask here)
+SKD_HD bool kv1_compact_layout(int n, int ngroups) { return ngroups == 0 && n >= 12; }
 #if defined(SKV_K1_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 #define KV1T(i) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; }
 #else

@@ -84,6 +84,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     v.J = J.data(); v.radiance = rad.data(); v.scratch = scratch.data(); v.scratch_stride = 1;
     v.ops = ops.data(); v.z = zb.data(); v.qlbuf = qlb.data(); v.grad = grad.data(); v.dnat = dnat.data(); v.derivs = derivatives;
     v.ngroups = G; v.dleg = d_legendre; v.dleg_nw = nw; v.dleg_w0 = 0; v.dfg = nullptr; v.da4 = da4.data();
+    v.k1_compact = skv::kv1_compact_layout(n, G);   // the work-space layout the device launcher chooses (its aliasing is the same on the CPU)
     const skv::Scr scr{scratch.data(), 1};
     const skv::Team team{0, 1};
     double* ws = scratch.data();
