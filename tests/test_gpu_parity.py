@@ -656,8 +656,8 @@ def _mixture(x, nw=1, nstr=8, g=0.6):
     return dict(s, extinction=k, ssa=w, leg=beta), mapping
 
 
-@pytest.mark.parametrize("nstr,delta_m", [(8, False), (16, False), (8, True)],
-                         ids=["8 streams", "16 streams (matrix-core engine, routed)", "8 streams, delta-M scaled"])
+@pytest.mark.parametrize("nstr,delta_m", [(8, False), (16, False), (8, True), (4, False), (6, False), (10, False)],
+                         ids=["8 streams", "16 streams (matrix-core kernels)", "8 streams, delta-M scaled", "4 streams", "6 streams", "10 streams"])
 def test_scattering_group_derivatives_match_finite_differences(nstr, delta_m):
     """A derivative mapping with d_legendre / scat_factor (a scattering constituent's number-density weighting function) through the C ABI:
     analytic == central finite differences of the product's own radiances, the reference's criterion for weighting functions."""
