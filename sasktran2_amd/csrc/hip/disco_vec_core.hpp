@@ -685,16 +685,26 @@ SKD_HD bool kv1_compact_layout(int n, int ngroups) { return ngroups == 0 && n >=
 #define KV1T(i)
 #endif
 
+//   `park` (no scattering groups): E+ and E- go to HBM / L2 instead of the team's work space and the six other matrices share FOUR slots
+//   by lifetime -- M0: B+ -> its Cholesky factor -> d(Gamma) X -> dX;  M1: B- -> the symmetrised matrix of the Jacobi sweeps -> U;
+//   M2: the product's temporary -> X;  M3: eigenvectors -> C -> dU.  4 n^2 + 19 n + 64 doubles: 79.6 KB at 32 polarised streams (n = 48),
+//   i.e. TWO teams per CU where the 8-matrix layout (148 KB) admits one.  Same operations in the same order: bit-identical results.
+SKD_HD size_t kv1_scratch_parked(int n) { return 4 * size_t(n) * n + 19 * size_t(n) + 64; }
 SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws,
-                                   bool derivs = false) {
+                                   bool derivs = false, double* park = nullptr) {
     const int N = g.N, S = v.S, n = v.n, nstr = g.nstr, nw = b.nw;
     const VRec R(n);
     double* rec = vrec_at(v, g.nlyr, p, w);
     const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w];
     const double T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
     const int nn = n * n;
-    double *Ep = ws, *Em = ws + nn, *Bp = ws + 2 * nn, *Bm = ws + 3 * nn, *Tm = ws + 4 * nn, *V = ws + 5 * nn, *X = ws + 6 * nn, *U = ws + 7 * nn;
-    double *lam = ws + 8 * nn, *kk = lam + n, *nrm = kk + n, *Qp = nrm + n, *Qm = Qp + n, *acp = Qm + n, *acm = acp + n, *rot = acm + n, *coef = (v.ngroups > 0 || !v.k1_compact) ? rot + n + 64 : Bp;  // rot: n + 64, coef: 12 n (see kv1_scratch)
+    const bool parked = park != nullptr;
+    double *Ep = parked ? park : ws, *Em = parked ? park + nn : ws + nn;
+    double *Bp = parked ? ws : ws + 2 * nn, *Bm = parked ? ws + nn : ws + 3 * nn, *Tm = parked ? ws + 2 * nn : ws + 4 * nn, *V = parked ? ws + 3 * nn : ws + 5 * nn;
+    double *X = parked ? Tm : ws + 6 * nn, *U = parked ? Bm : ws + 7 * nn;
+    double *lam = ws + (parked ? 4 : 8) * nn, *kk = lam + n, *nrm = kk + n, *Qp = nrm + n, *Qm = Qp + n, *acp = Qm + n, *acm = acp + n;
+    double *rot = parked ? acm : acm + n;   // acm is only used by the scattering groups, which keep the 8-matrix layout
+    double *coef = (parked || v.ngroups > 0 || !v.k1_compact) ? rot + n + 64 : Bp;  // rot: n + 64, coef: 12 n (see kv1_scratch)
     (void)acm;
     auto rw = [&](int r) { return g.wt[r / S]; };
     auto rmu = [&](int r) { return g.mu[r / S]; };
@@ -829,36 +839,39 @@ SKV_TEAM_BODY void kv1_layer_solution(const Team& team, const Geo& g, const VGeo
     KV1T(4)
     // ---- omega derivatives by bi-orthogonal perturbation theory (left vectors W M S+ X), as skd::k1_layer_solution:
     //      d(Gamma) X_j = [2 lam_j X_j - M^-1 U_j - S- M^-1 X_j] / om ;  dk_j = z_jj / (2 k_j) ;  dX = X C, C_ab = z_ab / (lam_b - lam_a)
-    double* dX = V;    // V is free once X is known
+    double* dX = parked ? Bp : V;    // V is free once X is known (parked: the slot of d(Gamma) X, consumed by the product that forms C)
     double* dU = Bm;   // As was consumed by the Jacobi sweeps
     double* dk = acp;  // reused before the Green's coefficients need it
+    double* DGX = parked ? Bp : Tm;   // d(Gamma) X (parked: the Cholesky factor is dead once X is known)
+    double* Cab = parked ? V : Bm;    // C
+    double* dUo = parked ? V : Tm;    // dU (parked: C is dead once dX is formed)
     if (derivs) {
         team_gemm(team, n, n, n, [&](int i, int r) { return rw(r) * Em[i * n + r] / rmu(r); }, [&](int r, int j) { return X[r * n + j]; },
                   [&](int i, int j, double val) {
                       const double hm = X[i * n + j] / (rmu(i) * rmu(i)) - om / rmu(i) * val;
-                      Tm[i * n + j] = (2 * X[i * n + j] * lam[j] - U[i * n + j] / rmu(i) - hm) / om;   // d(Gamma) X
+                      DGX[i * n + j] = (2 * X[i * n + j] * lam[j] - U[i * n + j] / rmu(i) - hm) / om;   // d(Gamma) X
                   });
         team.sync();
         double lmax = 0;
         for (int j = 0; j < n; ++j) lmax = fmax(lmax, lam[j]);
-        team_gemm(team, n, n, n, [&](int a_, int i) { return rw(i) * rmu(i) * U[i * n + a_]; }, [&](int i, int b_) { return Tm[i * n + b_]; },
+        team_gemm(team, n, n, n, [&](int a_, int i) { return rw(i) * rmu(i) * U[i * n + a_]; }, [&](int i, int b_) { return DGX[i * n + b_]; },
                   [&](int a_, int b_, double z) {
                       if (a_ == b_) {
                           dk[b_] = z / (2 * kk[b_]);
-                          Bm[a_ * n + b_] = 0;
+                          Cab[a_ * n + b_] = 0;
                       } else {
                           const double den = lam[b_] - lam[a_];
-                          Bm[a_ * n + b_] = (fabs(den) > 1e-13 * lmax) ? z / den : 0.0;
+                          Cab[a_ * n + b_] = (fabs(den) > 1e-13 * lmax) ? z / den : 0.0;
                       }
                   });
         team.sync();
-        team_gemm(team, n, n, n, [&](int i, int r) { return X[i * n + r]; }, [&](int r, int j) { return Bm[r * n + j]; },
+        team_gemm(team, n, n, n, [&](int i, int r) { return X[i * n + r]; }, [&](int r, int j) { return Cab[r * n + j]; },
                   [&](int i, int j, double val) { dX[i * n + j] = val; });
         team.sync();
         team_gemm(team, n, n, n, [&](int i, int r) { return rw(r) * Ep[i * n + r]; }, [&](int r, int j) { return dX[r * n + j]; },
-                  [&](int i, int j, double val) { Tm[i * n + j] = (U[i * n + j] - X[i * n + j] / rmu(i)) / om + (dX[i * n + j] - om * val) / rmu(i); });
+                  [&](int i, int j, double val) { dUo[i * n + j] = (U[i * n + j] - X[i * n + j] / rmu(i)) / om + (dX[i * n + j] - om * val) / rmu(i); });
         team.sync();
-        dU = Tm;
+        dU = dUo;
     }
     KV1T(5)
     // ---- W+-, dW+-, norms (one solution per lane)
@@ -1181,7 +1194,8 @@ __device__ __forceinline__ bool pivot_usable(double cand) { return __longlong_as
 // lane then updates its T^2 elements with fused multiply-adds; the eliminated column is overwritten by the column of the inverse (zeroed
 // before the update, with 1 / pivot standing in for the pivot row's entry).  The pivot row is wave-uniform (held in a scalar register), so
 // picking the register slot that holds it is a scalar branch, not a select chain over the slots.  The row exchanges are undone as
-// column exchanges when the result is written.  D is read, Dinv written (row-major, LDS or HBM); buf: 10 M2 + 64 doubles of LDS.
+// column exchanges when the result is written.  D is read, Dinv written (row-major, LDS or HBM); buf: 7 M2 + 32 doubles of LDS, which may lie
+// INSIDE D / Dinv (the block lives in registers between the first and the last barrier of this function).
 template <int T> __device__ bool gj_inverse_registers(const double* D, double* Dinv, double* buf) {
     constexpr int MP = 16 * T;
     const int lane = threadIdx.x, ly = lane >> 4, lx = lane & 15;
@@ -1190,6 +1204,7 @@ template <int T> __device__ bool gj_inverse_registers(const double* D, double* D
     for (int rb = 0; rb < T; ++rb)
 #pragma unroll
         for (int cb = 0; cb < T; ++cb) a[rb][cb] = D[(rb * 16 + ly) * MP + cb * 16 + lx];
+    __syncthreads();   // buf may lie inside D (the block is in registers from here on): every lane has read its elements
     double* cand = buf + 6 * MP;                          // [2][16]
     int* ipiv = reinterpret_cast<int*>(buf + 6 * MP + 32);  // [MP]
     int* dst = ipiv + MP;                                  // [MP]
@@ -1274,11 +1289,15 @@ template <int T> __device__ bool gj_inverse_registers(const double* D, double* D
         for (int c = 0; c < MP; ++c) ipiv[dst[c]] = c;   // final column of computed column
     }
     __syncthreads();
+    int colof[T];      // (buf may lie inside Dinv: the final columns are read before the first element is written)
+#pragma unroll
+    for (int cb = 0; cb < T; ++cb) colof[cb] = ok ? ipiv[cb * 16 + lx] : 0;
+    __syncthreads();
     if (ok) {
 #pragma unroll
         for (int rb = 0; rb < T; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < T; ++cb) Dinv[(rb * 16 + ly) * MP + ipiv[cb * 16 + lx]] = a[rb][cb];
+            for (int cb = 0; cb < T; ++cb) Dinv[(rb * 16 + ly) * MP + colof[cb]] = a[rb][cb];
     }
     __syncthreads();
     return ok;
@@ -1388,7 +1407,10 @@ template <int TS> __device__ bool gj_inverse_wave(const double* D, double* Dinv,
 //   inverse, vectors) and t1 (2 n^2 doubles), which may live in different memories (LDS / HBM)
 // =================================================================================================
 //   with a register-resident inversion (GJ != 0) the inverse overwrites the block: `inplace` halves the matrix part
-SKD_HD size_t kv2_scratch_main(int n, bool inplace = false) { return (inplace ? 4 : 8) * size_t(n) * n + 30 * size_t(n) + 64; }
+//   `gjalias` (GJ == 2): the exchange buffers of the 256-lane inversion lie inside the block's own storage, which is dead while the block is in
+//   registers -- 4 n^2 + 10 n + 64 doubles = 76.3 KB at n = 48: with T1 in HBM / L2 TWO teams share a CU (the inversion is a chain of 96 pivots
+//   with two barriers each at one wavefront per SIMD; a second team fills the gaps)
+SKD_HD size_t kv2_scratch_main(int n, bool inplace = false, bool gjalias = false) { return (inplace ? 4 : 8) * size_t(n) * n + (gjalias ? 10 : 30) * size_t(n) + 64; }
 SKD_HD size_t kv2_scratch_t1(int n) { return 2 * size_t(n) * n; }
 SKD_HD size_t kv2_scratch(int n) { return kv2_scratch_main(n) + kv2_scratch_t1(n); }
 
@@ -1405,7 +1427,7 @@ template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g,
     // the product with the previous inverse: block and inverse share their storage then
     constexpr bool inplace = (GJ != 0);
     double *D = ws, *Dinv = inplace ? ws : ws + mm, *r = ws + (inplace ? 1 : 2) * mm, *rprev = r + M2, *xn = rprev + M2, *fcol = xn + M2, *refl = fcol + M2;  // refl: 2n
-    double* gjbuf = refl + 2 * n;  // 10 M2 + 64 doubles, exchange buffers of the register-resident inversion
+    double* gjbuf = (GJ == 2) ? ws : refl + 2 * n;  // exchange buffers of the register-resident inversions (GJ == 2: inside the block's storage, see kv2_scratch_main)
 #if defined(SKV_K2_TIMING) && defined(__HIP_DEVICE_COMPILE__)
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
 #define KV2T(i) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; }

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <cstdlib>
 #include <vector>
 
 #include "../sasktran2_amd/csrc/host/geo_tables.hpp"
@@ -88,6 +89,10 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     const skv::Scr scr{scratch.data(), 1};
     const skv::Team team{0, 1};
     double* ws = scratch.data();
+    // SKV_EMU_PARK=1: the eigen stage in its parked layout (E+- outside the work space, four matrix slots; the launcher's choice at 32 polarised streams)
+    const char* park_env = std::getenv("SKV_EMU_PARK");
+    std::vector<double> parkbuf((park_env && atoi(park_env) && G == 0) ? 2 * size_t(n) * n : 0);
+    double* park = parkbuf.empty() ? nullptr : parkbuf.data();
     for (int w = 0; w < nw; ++w) {
         skd::k0_layer_optics(g, b, w);  // tau / omega / LOS shells; its scalar a_l is not used (nleg = 0)
         skv::kv0_coefficients(g, b, v, w);
@@ -96,7 +101,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
         for (int w = 0; w < nw; ++w) skd::k0_transmission(g, b, 0, w);
         for (int m = 0; m < nstr; ++m) {
             for (int w = 0; w < nw; ++w)
-                for (int p = 0; p < nlyr; ++p) skv::kv1_layer_solution(team, g, vg, b, v, 0, m, p, w, ws, derivatives != 0);
+                for (int p = 0; p < nlyr; ++p) skv::kv1_layer_solution(team, g, vg, b, v, 0, m, p, w, ws, derivatives != 0, park);
             for (int w = 0; w < nw; ++w) skv::kv2_bvp(team, g, b, v, 0, m, w, ws, ws + skv::kv2_scratch_main(n));
             if (derivatives)
                 for (int w = 0; w < nw; ++w)
@@ -129,7 +134,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                 if (!active) break;
                 for (int w = 0; w < nw; ++w)
                     for (int p = 0; p < nlyr; ++p)
-                        if (m < norders[w]) skv::kv1_layer_solution(team, g, vg, b, v, s, m, p, w, ws, derivatives != 0);
+                        if (m < norders[w]) skv::kv1_layer_solution(team, g, vg, b, v, s, m, p, w, ws, derivatives != 0, park);
                 for (int w = 0; w < nw; ++w)
                     if (m < norders[w]) skv::kv2_bvp(team, g, b, v, s, m, w, ws, ws + skv::kv2_scratch_main(n));
                 for (int w = 0; w < nw; ++w)

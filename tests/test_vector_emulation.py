@@ -132,3 +132,17 @@ def test_scattering_group_derivatives_match_finite_differences_emulated(vector):
         an = mp["d_extinction"][q, 0] * out["d_extinction"][..., q] + mp["d_ssa"][q, 0] * out["d_ssa"][..., q] + mp["scat_factor"][q, 0] * scat
         assert np.abs(mp["scat_factor"][q, 0] * scat).max() > 0.05 * np.abs(an).max()   # the scattering part matters
         assert np.abs(fd - an).max() < 1e-6 * np.abs(an).max(), q
+
+
+@pytest.mark.parametrize("vector", [False, True], ids=["NSTOKES=1", "NSTOKES=3"])
+def test_parked_eigen_stage_layout_is_bit_identical(vector, monkeypatch):
+    """kv1_layer_solution with E+- outside the team's work space and four matrix slots shared by lifetime (the layout that puts two teams
+    on a CU at 32 polarised streams) performs the same operations in the same order: radiances and weighting functions equal bit for bit."""
+    s = sc.regression_1d(2)
+    if vector:
+        s = sc.to_vector(s, rayleigh_fraction=0.9)
+    plain = run_emulated_vector(s, derivatives=True)
+    monkeypatch.setenv("SKV_EMU_PARK", "1")
+    parked = run_emulated_vector(s, derivatives=True)
+    for k in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
+        assert np.array_equal(plain[k], parked[k]), k
