@@ -24,7 +24,8 @@ ROOT = Path(__file__).resolve().parent
 HBM_PEAK_GBS = 8000.0
 FP64_PEAK_TFLOPS = 78.6
 ALGORITHMIC_BYTES_PER_WAVELENGTH = 137_856   # inputs 63 456 B + outputs 74 400 B
-PMC_KERNEL_OF = {"kern_v1": "kv1_layer_solution", "kern_v2": "kv2_bvp", "kern_v2_w48": "kv2_bvp", "kern_v2c": "kv2c_adjoint_ops",
+PMC_KERNEL_OF = {"kern_v1": "kv1_layer_solution", "kern_v1p": "kv1_layer_solution", "kern_v2": "kv2_bvp", "kern_v2_w48": "kv2_bvp", "kern_v2_g96": "kv2_bvp",
+                 "kern_v2c": "kv2c_adjoint_ops",
                  "kern_v2b": "kv2b_adjoint", "kern_v2bt": "kv2b_adjoint", "kern_v3": "kv3_table_values", "kern_v4": "kv4_los",
                  "kern_vk4a": "k4a_chain", "kern_v0": "k0_layer_optics"}
 
@@ -38,7 +39,7 @@ def load_pmc():
     per = float(doc.get("wavelengths_per_launch", 4096))
     out = {}
     for r in doc.get("pmc", doc.get("pmc_4096_wavelengths_per_launch", [])):
-        m = re.match(r"(kern_v\w+?)(<|$)", r["kernel"])
+        m = re.match(r"(kern_v\w+?)(<|\(|$)", r["kernel"])
         name = PMC_KERNEL_OF.get(m.group(1)) if m else None
         if not name:
             continue
