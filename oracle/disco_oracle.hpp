@@ -52,6 +52,10 @@ struct AtmosphereView {
     const double* leg = nullptr;         // [nleg (* 4), ngrid, nwavel]
     const double* solar_irradiance = nullptr;  // [nwavel] (nullptr -> 1)
     const double* albedo = nullptr;      // [nwavel] Lambertian
+    // non-Lambertian surfaces (cpp/include/sasktran2/atmosphere/surface.h:151-352): 0 Lambertian (albedo above), 1 SnowKokhanovsky, 2 MODIS;
+    // brdf_args [nargs, nwavel] column-major (argument fastest, surface.h:366-372); plane-parallel / pseudo-spherical post-processing only
+    int brdf_kind = 0, brdf_nargs = 1;
+    const double* brdf_args = nullptr;
     const double* delta_f = nullptr;     // [ngrid, nwavel] delta-M truncation fraction of the (already scaled) storage, or null
     // EmissionSource::discrete_ordinates (plane-parallel post-processing only, radiances only): thermal source inside the DO equations
     const double* emission = nullptr;          // [ngrid, nwavel] emission_source of the storage, or null
@@ -74,6 +78,58 @@ struct Result {
     std::vector<double> flux;      // [flux observer][3]: upwelling, downwelling, actinic (plane-parallel post-processing only)
 };
 
+// ---- BRDFs of the reference (cpp/include/sasktran2/atmosphere/surface.h): value and derivative wrt argument k of the (0, 0) element;
+//      mu_in / mu_out cosines of the incoming / outgoing zenith angle, phi = azimuth difference, 0 = forward scattering
+struct BrdfKernels { double k_vol, k_geo; };
+inline BrdfKernels modis_kernels(double mu_in, double mu_out, double phi) {   // surface.h:236-281
+    const double csza = mu_in, cvza = mu_out, ssza = std::sqrt(1 - csza * csza), svza = std::sqrt(1 - cvza * cvza);
+    const double tsza = ssza / csza, tvza = svza / cvza, craa = -std::cos(phi), sraa = std::sin(phi);
+    const double csa = std::max(-1.0, std::min(1.0, csza * cvza + ssza * svza * craa)), sa = std::acos(csa), ssa_ = std::sin(sa);
+    BrdfKernels K;
+    K.k_vol = ((0.5 * kPi - sa) * csa + ssa_) / (csza + cvza) - 0.25 * kPi;                       // Ross-thick
+    const double d2 = tsza * tsza + tvza * tvza - 2 * tsza * tvza * craa;
+    const double ct = std::max(-1.0, std::min(1.0, 2 * std::sqrt(d2 + tsza * tsza * tvza * tvza * sraa * sraa) * csza * cvza / (csza + cvza)));
+    const double t = std::acos(ct), st = std::sin(t);
+    const double o = (t - st * ct) * (csza + cvza) / (kPi * csza * cvza);
+    K.k_geo = o - (csza + cvza - 0.5 * (1 + csa)) / (csza * cvza);                                  // Li-sparse-R
+    return K;
+}
+inline void kokhanovsky_parts(double mu_in, double mu_out, double phi, double& r0, double& kk) {   // surface.h:151-204
+    const double mus = mu_in, muv = mu_out, ss = std::sqrt(1 - mus * mus), sv = std::sqrt(1 - muv * muv);
+    const double cost = std::max(-1.0, std::min(1.0, -mus * muv + ss * sv * std::cos(phi)));
+    const double theta = std::acos(cost) * 180.0 / kPi;
+    const double pth = 11.1 * std::exp(-0.087 * theta) + 1.1 * std::exp(-0.014 * theta);
+    r0 = (1.247 + 1.186 * (mus + muv) + 5.157 * mus * muv + pth) / (4.0 * (mus + muv));
+    kk = (3.0 / 7.0) * (1.0 + 2.0 * mus) * (3.0 / 7.0) * (1.0 + 2.0 * muv);
+}
+inline double brdf_value(int kind, double mu_in, double mu_out, double phi, const double* args) {
+    if (kind == 1) {
+        double r0, kk;
+        kokhanovsky_parts(mu_in, mu_out, phi, r0, kk);
+        const double alpha = std::sqrt(4 * kPi * args[0]);
+        return r0 * std::exp(-alpha * kk / r0) / kPi;
+    }
+    if (kind == 2) {
+        const BrdfKernels K = modis_kernels(mu_in, mu_out, phi);
+        return (args[0] + args[1] * K.k_vol + args[2] * K.k_geo) / kPi;
+    }
+    return args[0] / kPi;
+}
+inline double brdf_deriv(int kind, int k, double mu_in, double mu_out, double phi, const double* args) {
+    if (kind == 1) {   // surface.h:206-229 with d_args = 1
+        double r0, kk;
+        kokhanovsky_parts(mu_in, mu_out, phi, r0, kk);
+        const double alpha = std::sqrt(4 * kPi * args[0]), factor = -kk / r0;
+        return r0 * std::exp(alpha * factor) * (2 / alpha * factor);
+    }
+    if (kind == 2) {
+        if (k == 0) return 1.0 / kPi;
+        const BrdfKernels K = modis_kernels(mu_in, mu_out, phi);
+        return (k == 1 ? K.k_vol : K.k_geo) / kPi;
+    }
+    return 1.0 / kPi;
+}
+
 class Solver {
     const skgeo::DiscoGeometry& G;
     const int nstr, N, S, n, nlyr, ngrid;  // n = N * S rows per hemisphere, row r = stream (r / S), Stokes component (r % S)
@@ -94,6 +150,83 @@ class Solver {
     std::vector<int> d_layer, d_kind;  // kind: 0 od, 1 ssa, 2 albedo
     std::vector<int> lstart, nloc;
     double albedo = 0, F0 = 1;
+    // ---- surface: azimuth expansion of the BRDF at the stream / sun / line-of-sight directions (SurfaceStorage::compute_expansion,
+    //      cpp/include/sktran_disco/sktran_do_surface.h:49-94: two 512-point Gauss-Legendre panels over the azimuth) and of its derivative wrt
+    //      the selected argument.  Lambertian: albedo for m = 0 (the special case at :53-57)
+    int brdf_kind = 0, brdf_nargs = 1, surf_max_order = 1;
+    std::vector<double> brdf_arg;                       // arguments of this wavelength
+    int brdf_darg = 0;
+    std::vector<double> qx, qw;                         // positive nodes / weights of the 512-point rule
+    std::vector<double> smp, dsmp;                      // [pair][4 * 256] samples of the BRDF (its derivative) over the azimuth
+    std::vector<double> rss, rsun, rlos, rlossun, drss, drsun, drlos, drlossun;   // order m: [N out][N in], [N], [nlos][N], [nlos]
+    int npair() const { return N * N + N + int(G.pp_los.size()) * (N + 1); }
+    void pair_angles(int pr, double& mu_out, double& mu_in) const {
+        const int nl_ = int(G.pp_los.size());
+        if (pr < N * N) { mu_out = G.mu[pr / N]; mu_in = G.mu[pr % N]; return; }
+        pr -= N * N;
+        if (pr < N) { mu_out = G.mu[pr]; mu_in = G.csz[cur_sza]; return; }
+        pr -= N;
+        if (pr < nl_ * N) { mu_out = G.pp_los[pr / N].coszenith; mu_in = G.mu[pr % N]; return; }
+        pr -= nl_ * N;
+        mu_out = G.pp_los[pr].coszenith; mu_in = G.csz[cur_sza];
+    }
+    void sample_surface() {
+        if (brdf_kind == 0) return;
+        if (qx.empty()) {
+            std::vector<double> x, w;
+            skgeo::gauss_legendre(512, x, w);
+            for (size_t i = 0; i < x.size(); ++i)
+                if (x[i] > 0) { qx.push_back(x[i]); qw.push_back(w[i]); }
+        }
+        const int np = npair(), nq = int(qx.size());
+        smp.assign(size_t(np) * 4 * nq, 0.0);
+        dsmp.assign(smp.size(), 0.0);
+        for (int pr = 0; pr < np; ++pr) {
+            double mo, mi;
+            pair_angles(pr, mo, mi);
+            for (int i = 0; i < nq; ++i) {
+                const double a[4] = {0.5 * qx[i] + 0.5, -0.5 * qx[i] + 0.5, 0.5 * qx[i] - 0.5, -0.5 * qx[i] - 0.5};
+                for (int t = 0; t < 4; ++t) {
+                    smp[(size_t(pr) * nq + i) * 4 + t] = brdf_value(brdf_kind, mi, mo, kPi * a[t], brdf_arg.data());
+                    dsmp[(size_t(pr) * nq + i) * 4 + t] = brdf_deriv(brdf_kind, brdf_darg, mi, mo, kPi * a[t], brdf_arg.data());
+                }
+            }
+        }
+    }
+    void expand_surface(int m) {
+        const int nl_ = int(G.pp_los.size());
+        rss.assign(size_t(N) * N, 0.0); rsun.assign(N, 0.0); rlos.assign(size_t(nl_) * N, 0.0); rlossun.assign(nl_, 0.0);
+        drss.assign(rss.size(), 0.0); drsun.assign(N, 0.0); drlos.assign(rlos.size(), 0.0); drlossun.assign(nl_, 0.0);
+        if (m >= surf_max_order) return;
+        auto put = [&](int pr, double v, double dv) {
+            if (pr < N * N) { rss[pr] = v; drss[pr] = dv; return; }
+            pr -= N * N;
+            if (pr < N) { rsun[pr] = v; drsun[pr] = dv; return; }
+            pr -= N;
+            if (pr < nl_ * N) { rlos[pr] = v; drlos[pr] = dv; return; }
+            pr -= nl_ * N;
+            rlossun[pr] = v; drlossun[pr] = dv;
+        };
+        const int np = npair();
+        if (brdf_kind == 0) {
+            for (int pr = 0; pr < np; ++pr) put(pr, albedo, 1.0);
+            return;
+        }
+        const int nq = int(qx.size());
+        for (int pr = 0; pr < np; ++pr) {
+            double r = 0, dr = 0;
+            for (int i = 0; i < nq; ++i) {
+                const double a[4] = {0.5 * qx[i] + 0.5, -0.5 * qx[i] + 0.5, 0.5 * qx[i] - 0.5, -0.5 * qx[i] - 0.5};
+                for (int t = 0; t < 4; ++t) {
+                    const double cw = 0.5 * qw[i] * std::cos(m * kPi * a[t]);
+                    r += cw * smp[(size_t(pr) * nq + i) * 4 + t];
+                    dr += cw * dsmp[(size_t(pr) * nq + i) * 4 + t];
+                }
+            }
+            const double f = 0.5 * kPi * (m == 0 ? 1.0 : 2.0);
+            put(pr, r * f, dr * f);
+        }
+    }
     // ---- generalized spherical functions packed as [..][l][{P,R,T}]
     std::vector<double> f_mu, f_csz, f_ang, f_los;
     // ---- per azimuth-order solution
@@ -280,6 +413,14 @@ class Solver {
             }
         }
         albedo = atm.albedo ? atm.albedo[w] : 0.0;
+        brdf_kind = atm.brdf_kind;
+        brdf_nargs = atm.brdf_nargs;
+        brdf_darg = surface_deriv_arg;
+        surf_max_order = (brdf_kind == 0) ? 1 : nstr;   // BRDF::max_azimuthal_order: 1 for Lambertian, unbounded otherwise (surface.h:88-90,142)
+        if (brdf_kind != 0) {
+            if (!atm.brdf_args) throw std::invalid_argument("oracle: brdf_args missing");
+            brdf_arg.assign(atm.brdf_args + size_t(w) * brdf_nargs, atm.brdf_args + size_t(w + 1) * brdf_nargs);
+        }
         F0 = atm.solar_irradiance ? atm.solar_irradiance[w] : 1.0;
         // derivative wiring
         for (int d = 0; d < ND; ++d) {
@@ -644,8 +785,8 @@ class Solver {
     }
 
     // ------------------------------------------------------------------ boundary value problem
-    double rho(int m) const { return m == 0 ? albedo : 0.0; }  // Lambertian, max_azimuthal_order == 1
-    // the Lambertian surface reflects the intensity only, into the intensity only (v_plus/v_minus, sktran_do_rte.h:116-150)
+    // the surface reflects the intensity only, into the intensity only (v_plus/v_minus, sktran_do_rte.h:116-150: "TODO: Polarized surface");
+    // rss / rsun / rlos / rlossun hold the order's expansion (expand_surface), zero from the BRDF's max_azimuthal_order on
     bool refl_row(int r) const { return (r % S) == 0; }
 
     void solve_bvp(int m) {
@@ -653,7 +794,7 @@ class Solver {
         bvp.set_zero();
         std::fill(rhs.begin(), rhs.end(), 0.0);
         auto E = [&](int p, int j) { return std::exp(-std::abs(eigk[size_t(p) * n + j]) * tau[p]); };
-        const bool refl = (m < 1);
+        const bool refl = (m < surf_max_order);
         const double kd = (m == 0) ? 2.0 : 1.0;
         // TOA
         for (int i = 0; i < n; ++i) {
@@ -698,26 +839,26 @@ class Solver {
                     double vm = Wm[hidx(p, i, j)], vp = Wp[hidx(p, i, j)];
                     if (rr)
                         for (int s = 0; s < N; ++s) {
-                            vm -= kd * rho(m) * G.wt[s] * G.mu[s] * Wp[hidx(p, s * S, j)];
-                            vp -= kd * rho(m) * G.wt[s] * G.mu[s] * Wm[hidx(p, s * S, j)];
+                            vm -= kd * rss[size_t(i / S) * N + s] * G.wt[s] * G.mu[s] * Wp[hidx(p, s * S, j)];
+                            vp -= kd * rss[size_t(i / S) * N + s] * G.wt[s] * G.mu[s] * Wm[hidx(p, s * S, j)];
                         }
                     bvp.at(r0 + i, c0 + j) = ng * vm * E(p, j);
                     bvp.at(r0 + i, c0 + n + j) = ng * vp;
                 }
                 double direct = (thermal && m == 0) ? surf_emission : 0.0, um = Gmb[size_t(p) * n + i];   // ground_direct_sun, sktran_do_rte.h:222-245
                 if (rr) {
-                    direct += G.csz[cur_sza] * rho(m) / kPi * trans[nlyr];
-                    for (int s = 0; s < N; ++s) um -= kd * rho(m) * G.wt[s] * G.mu[s] * Gpb[size_t(p) * n + s * S];
+                    direct += G.csz[cur_sza] * rsun[i / S] / kPi * trans[nlyr];
+                    for (int s = 0; s < N; ++s) um -= kd * rss[size_t(i / S) * N + s] * G.wt[s] * G.mu[s] * Gpb[size_t(p) * n + s * S];
                 }
                 rhs[size_t(r0 + i) * nr] = direct - um;
                 for (int d = 0; d < ND; ++d) {
                     double dalb = (d_layer[d] == p) ? d_alb(d_kind[d]) : 0.0;
                     double ddir = 0, dum = dG(dGmb, p, d)[i];
                     if (rr) {
-                        ddir = G.csz[cur_sza] * rho(m) / kPi * dtrans[size_t(nlyr) * ND + d] + G.csz[cur_sza] * dalb / kPi * trans[nlyr];
+                        ddir = G.csz[cur_sza] * rsun[i / S] / kPi * dtrans[size_t(nlyr) * ND + d] + G.csz[cur_sza] * dalb * drsun[i / S] / kPi * trans[nlyr];
                         for (int s = 0; s < N; ++s) {
-                            dum -= kd * rho(m) * G.wt[s] * G.mu[s] * dG(dGpb, p, d)[s * S];
-                            dum -= kd * dalb * G.wt[s] * G.mu[s] * Gpb[size_t(p) * n + s * S];
+                            dum -= kd * rss[size_t(i / S) * N + s] * G.wt[s] * G.mu[s] * dG(dGpb, p, d)[s * S];
+                            dum -= kd * dalb * drss[size_t(i / S) * N + s] * G.wt[s] * G.mu[s] * Gpb[size_t(p) * n + s * S];
                         }
                     }
                     rhs[size_t(r0 + i) * nr + 1 + d] = ddir - dum;
@@ -775,9 +916,10 @@ class Solver {
                         if (rr)
                             for (int t = 0; t < N; ++t) {
                                 double f = kd * G.wt[t] * G.mu[t];
-                                vm -= f * rho(m) * Wp[hidx(p, t * S, j)];
-                                vm_d -= f * rho(m) * dWp[dhidx(p, k, t * S, j)] + f * d_alb(k) * Wp[hidx(p, t * S, j)];
-                                vp_d -= f * rho(m) * dWm[dhidx(p, k, t * S, j)] + f * d_alb(k) * Wm[hidx(p, t * S, j)];
+                                const double r_it = rss[size_t(i / S) * N + t], dr_it = d_alb(k) * drss[size_t(i / S) * N + t];
+                                vm -= f * r_it * Wp[hidx(p, t * S, j)];
+                                vm_d -= f * r_it * dWp[dhidx(p, k, t * S, j)] + f * dr_it * Wp[hidx(p, t * S, j)];
+                                vp_d -= f * r_it * dWm[dhidx(p, k, t * S, j)] + f * dr_it * Wm[hidx(p, t * S, j)];
                             }
                         s += (vm_d * E(p, j) + vm * dE(j)) * xl[j] + vp_d * xm[j];
                     }
@@ -892,6 +1034,8 @@ class Solver {
     int forced_azimuth = 0;
     // flux observers (altitudes in m above the surface), plane-parallel post-processing only
     std::vector<double> flux_altitudes;
+    // the BRDF argument the native surface derivative [2 ngrid] is taken for (the caller runs one pass per argument)
+    int surface_deriv_arg = 0;
 };
 
 // ======================================================================================
@@ -968,13 +1112,13 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
         // ground reflection (computeReflectedIntensities): Lambertian, intensity component only
         std::fill(comp.begin(), comp.end(), 0.0);
         std::fill(comp_d.begin(), comp_d.end(), 0.0);
-        if (m < 1) {
+        if (m < surf_max_order) {
             const int p = p_bot, ls = ND ? lstart[p] : 0, nk = nl(p);
             double diffuse = 0;
             std::vector<double> diffuse_d(ND, 0.0);
             for (int is = 0; is < N; ++is) {
                 const int i = is * S;
-                double r = rho(m);
+                const double r = rlos[j * N + is], dr = drlos[j * N + is];   // los_stream expansion of this line of sight
                 double sc_v = Gpb[size_t(p) * n + i];
                 for (int d = 0; d < ND; ++d) strm_d[d] = dG(dGpb, p, d)[i];
                 double factor = (m == 0 ? 2.0 : 1.0) * G.mu[is] * G.wt[is];
@@ -992,14 +1136,14 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
                 }
                 diffuse += factor * sc_v * r;
                 for (int d = 0; d < ND; ++d) diffuse_d[d] += factor * strm_d[d] * r;
-                for (int k = 0; k < nk; ++k) diffuse_d[ls + k] += factor * sc_v * d_alb(k);
+                for (int k = 0; k < nk; ++k) diffuse_d[ls + k] += factor * sc_v * d_alb(k) * dr;
             }
             if (include_ss) {
-                double direct = G.csz[cur_sza] / kPi * trans[nlyr] * rho(m);
+                double direct = G.csz[cur_sza] / kPi * trans[nlyr] * rlossun[j];
                 comp[0] = direct + diffuse;
                 if (thermal && m == 0) comp[0] += surf_emission;   // sktran_do_layerarray.cpp:255-266
-                for (int d = 0; d < ND; ++d) comp_d[size_t(d) * S] = G.csz[cur_sza] / kPi * dtrans[size_t(nlyr) * ND + d] * rho(m) + diffuse_d[d];
-                for (int k = 0; k < nk; ++k) comp_d[size_t(ls + k) * S] += G.csz[cur_sza] / kPi * trans[nlyr] * d_alb(k);
+                for (int d = 0; d < ND; ++d) comp_d[size_t(d) * S] = G.csz[cur_sza] / kPi * dtrans[size_t(nlyr) * ND + d] * rlossun[j] + diffuse_d[d];
+                for (int k = 0; k < nk; ++k) comp_d[size_t(ls + k) * S] += G.csz[cur_sza] / kPi * trans[nlyr] * d_alb(k) * drlossun[j];
             } else {
                 comp[0] = diffuse;
                 for (int d = 0; d < ND; ++d) comp_d[size_t(d) * S] = diffuse_d[d];
@@ -1154,6 +1298,7 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
 
 // ======================================================================================
 inline void Solver::accumulate_ground(int m, int szaidx) {
+    if (brdf_kind != 0) throw std::invalid_argument("oracle: non-Lambertian surfaces are restated for plane-parallel / pseudo-spherical post-processing only");
     if (m >= 1) return;
     const int p = nlyr - 1, ls = ND ? lstart[p] : 0, nk = nl(p);
     const size_t nslot = npoint + nground;
@@ -1384,6 +1529,7 @@ inline void Solver::solve(const AtmosphereView& atm, int w, Result& res) {
             configure_layers(atm, w, s);
             all_converged = false;
             for (int m = 0; m < nstr; ++m) {
+                expand_surface(m);
                 solve_order(m, s);
                 accumulate_sources(m, s);
                 res.num_azimuth_used = std::max(res.num_azimuth_used, m + 1);
@@ -1393,8 +1539,10 @@ inline void Solver::solve(const AtmosphereView& atm, int w, Result& res) {
         integrate_los(atm, w, res);
     } else {
         configure_layers(atm, w, 0);
+        sample_surface();
         const int num_azi = forced_azimuth > 0 ? forced_azimuth : nstr;
         for (int m = 0; m < num_azi; ++m) {
+            expand_surface(m);
             solve_order(m, 0);
             if (m == 0 && !flux_altitudes.empty()) compute_flux(res);
             pp_postprocess(m, 0, res, res.radiance, res.deriv);

@@ -27,6 +27,9 @@ struct Handle {
     int forced_azimuth = 0;              // plane-parallel post-processing: > 0 solves exactly this many azimuth orders
     std::vector<double> flux_altitudes;  // flux observers (m)
     double* flux_out = nullptr;          // [nwavel][observer][3] (upwelling, downwelling, actinic) of the next orc_run calls
+    int brdf_kind = 0, brdf_nargs = 1;   // non-Lambertian surface of the next orc_run calls (orc_set_brdf)
+    const double* brdf_args = nullptr;   // [nwavel][nargs]
+    double* d_brdf_out = nullptr;        // [nwavel][nlos][S][nargs]
     std::string error;
 };
 }  // namespace
@@ -137,6 +140,17 @@ int orc_set_flux_observers(void* hv, const double* altitudes, int n, double* flu
     h->flux_out = n > 0 ? flux_out : nullptr;
     return 0;
 }
+// surface of the next orc_run calls: kind 0 Lambertian (the albedo argument of orc_run), 1 SnowKokhanovsky (1 argument), 2 MODIS (3 arguments);
+// args [nwavel][nargs]; d_brdf_out [nwavel][nlos][S][nargs] receives the derivatives wrt the arguments (or null)
+int orc_set_brdf(void* hv, int kind, int nargs, const double* args, double* d_brdf_out) {
+    auto* h = static_cast<Handle*>(hv);
+    if (!h || kind < 0 || kind > 2 || (kind != 0 && (!args || nargs != (kind == 2 ? 3 : 1)))) return -1;
+    h->brdf_kind = kind;
+    h->brdf_nargs = kind == 0 ? 1 : nargs;
+    h->brdf_args = kind == 0 ? nullptr : args;
+    h->d_brdf_out = kind == 0 ? nullptr : d_brdf_out;
+    return 0;
+}
 int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg,
             const double* solar_irradiance, const double* albedo, int derivatives, int nthreads, double* radiance,
             double* d_k, double* d_ssa, double* d_albedo, double* los_od, int* n_azimuth) {
@@ -153,6 +167,9 @@ int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
     atm.leg = leg;
     atm.solar_irradiance = solar_irradiance;
     atm.albedo = albedo;
+    atm.brdf_kind = h->brdf_kind;
+    atm.brdf_nargs = h->brdf_nargs;
+    atm.brdf_args = h->brdf_args;
     atm.delta_f = h->delta_f;
     atm.emission = h->emission;
     atm.surface_emission = h->surface_emission;
@@ -204,6 +221,25 @@ int orc_run(void* hv, int nwavel, int nleg, const double* extinction, const doub
                 }
                 if (n_azimuth) n_azimuth[w] = res.num_azimuth_used;
                 if (h->flux_out) std::copy(res.flux.begin(), res.flux.end(), h->flux_out + size_t(w) * res.flux.size());
+                // derivatives wrt the BRDF arguments: one pass per argument (the native surface entry [2 ngrid] belongs to the selected one)
+                if (atm.derivatives && h->brdf_kind != 0 && h->d_brdf_out) {
+                    const int nn = solver->num_native(), na = h->brdf_nargs;
+                    for (int a = 0; a < na; ++a) {
+                        if (a > 0) { solver->surface_deriv_arg = a; solver->solve(atm, w, res); }
+                        for (int r = 0; r < nlos; ++r)
+                            for (int sc = 0; sc < S; ++sc) {
+                                const double C = h->dg.stokes_C[r], Sn = h->dg.stokes_S[r];
+                                const double* base = res.deriv.data();
+                                double v = base[(size_t(r) * S + sc) * nn + 2 * ngrid];
+                                if (S == 3 && sc > 0) {
+                                    const double q = base[(size_t(r) * S + 1) * nn + 2 * ngrid], u = base[(size_t(r) * S + 2) * nn + 2 * ngrid];
+                                    v = sc == 1 ? C * q - Sn * u : Sn * q + C * u;
+                                }
+                                h->d_brdf_out[((size_t(w) * nlos + r) * S + sc) * na + a] = v;
+                            }
+                    }
+                    solver->surface_deriv_arg = 0;
+                }
             } catch (const std::exception& e) {
                 std::fprintf(stderr, "orc_run (wavelength %d): %s\n", w, e.what());
                 status = -3;

@@ -118,8 +118,10 @@ class OracleEngine:
         return mu, wt
 
     def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, derivatives=False, nthreads=1, delta_f=None, emission=None,
-            surface_emission=None, forced_azimuth=0, flux_altitudes=None):
-        """extinction, ssa: [ngrid, nwavel]; leg: [nleg, ngrid, nwavel] (nstokes = 3: [4 * nleg, ngrid, nwavel] with
+            surface_emission=None, forced_azimuth=0, flux_altitudes=None, brdf=None):
+        """brdf: None (Lambertian `albedo`) or (kind, args [nwavel, nargs]) with kind "kokhanovsky" (1 argument) / "modis" (isotropic,
+        volumetric, geometric); plane-parallel / pseudo-spherical post-processing only; adds "d_brdf" [nwavel, nlos, (3,) nargs].
+        extinction, ssa: [ngrid, nwavel]; leg: [nleg, ngrid, nwavel] (nstokes = 3: [4 * nleg, ngrid, nwavel] with
         a1, a2, a3, b1 per order); albedo: [nwavel] (Fortran-style axes as in the reference storage: location fastest).
         Outputs carry a trailing Stokes axis for nstokes = 3 (radiance [nwavel, nlos, 3], d_* [nwavel, nlos, 3, ngrid]).
         Plane-parallel post-processing only: `forced_azimuth` > 0 solves exactly that many azimuth orders (Config.num_forced_azimuth);
@@ -146,6 +148,15 @@ class OracleEngine:
             dw = np.zeros(sshape + (self.ngrid,))
             da = np.zeros(sshape)
         lib().orc_set_forced_azimuth(self._h, int(forced_azimuth))
+        bargs = dbr = None
+        if brdf is not None:
+            kind = {"kokhanovsky": 1, "modis": 2}[brdf[0]]
+            bargs = np.ascontiguousarray(brdf[1], dtype=np.float64).reshape(nwavel, -1)
+            dbr = np.zeros(sshape + (bargs.shape[1],)) if derivatives else None
+            L = lib()
+            L.orc_set_brdf.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp]
+            if L.orc_set_brdf(self._h, kind, bargs.shape[1], _p(bargs), _p(dbr)) != 0:
+                raise RuntimeError("oracle: bad BRDF arguments")
         fa = flux = None
         if flux_altitudes is not None and len(flux_altitudes) > 0:
             fa = np.ascontiguousarray(flux_altitudes, dtype=np.float64)
@@ -154,10 +165,14 @@ class OracleEngine:
             raise RuntimeError("oracle: flux observers need plane-parallel post-processing")
         rc = lib().orc_run(self._h, nwavel, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), _p(irr), _p(alb), int(derivatives),
                            nthreads, _p(rad), _p(dk), _p(dw), _p(da), _p(od), nazi.ctypes.data_as(_ip))
+        if brdf is not None:
+            lib().orc_set_brdf(self._h, 0, 1, None, None)
         if rc != 0:
             raise RuntimeError(f"oracle run failed with code {rc}")
         lib().orc_set_flux_observers(self._h, None, 0, None)
         out = {"radiance": rad, "los_optical_depth": od, "num_azimuth": nazi}
+        if dbr is not None:
+            out["d_brdf"] = dbr
         if flux is not None:
             out.update({"upwelling_flux": flux[:, :, 0], "downwelling_flux": flux[:, :, 1], "actinic_flux": flux[:, :, 2]})
         if derivatives:

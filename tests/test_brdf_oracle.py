@@ -1,0 +1,83 @@
+"""Non-Lambertian surfaces (SnowKokhanovsky, MODIS) in the oracle's restatement of the discrete-ordinates ground condition
+(cpp/include/sktran_disco/sktran_do_surface.h:49-201, sktran_do_rte.h:116-345, cpp/include/sasktran2/atmosphere/surface.h:151-352).
+The reference stores no numbers for these surfaces; its own criteria are the ones used here: the analytic weighting functions of the BRDF
+arguments equal central differences (tests/constituent/test_modis.py:103-160, test_kokhanovsky.py) and a MODIS surface with only its
+isotropic kernel IS the Lambertian surface (surface.h:236-281 with args (a, 0, 0))."""
+import numpy as np
+import pytest
+
+from tests import scenarios as sc
+from tests.test_oracle_golden import make_oracle
+
+
+def _scene(nstokes, nstr=8, nw=3):
+    s = sc.nadir_c1(num_wavelengths=nw, nstr=nstr)
+    if nstokes == 3:
+        s = sc.to_vector(s, rayleigh_fraction=0.8)
+    return s
+
+
+def _run(eng, s, brdf, derivatives=False, **over):
+    return eng.run(over.get("extinction", s["extinction"]), over.get("ssa", s["ssa"]), s["leg"], s["albedo"], derivatives=derivatives, brdf=brdf)
+
+
+@pytest.mark.parametrize("nstokes", [1, 3])
+def test_modis_with_its_isotropic_kernel_alone_is_the_lambertian_surface(nstokes):
+    s = _scene(nstokes)
+    eng = make_oracle(s)
+    lam = eng.run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
+    args = np.zeros((len(s["albedo"]), 3))
+    args[:, 0] = s["albedo"]
+    mod = _run(eng, s, ("modis", args), derivatives=True)
+    scale = np.abs(lam["radiance"]).max()
+    assert np.max(np.abs(lam["radiance"] - mod["radiance"])) < 1e-13 * scale
+    assert np.max(np.abs(lam["d_albedo"] - mod["d_brdf"][..., 0])) < 1e-12 * np.abs(lam["d_albedo"]).max()
+    for k in ("d_extinction", "d_ssa"):
+        assert np.max(np.abs(lam[k] - mod[k])) < 1e-12 * np.abs(lam[k]).max()
+
+
+@pytest.mark.parametrize("nstokes", [1, 3])
+@pytest.mark.parametrize("kind,args0,steps", [("modis", [0.2, 0.05, 0.05], [1e-4, 1e-4, 1e-4]), ("kokhanovsky", [0.04], [1e-5])])
+def test_brdf_argument_weighting_functions_match_central_differences(nstokes, kind, args0, steps):
+    s = _scene(nstokes)
+    nw = len(s["albedo"])
+    eng = make_oracle(s)
+    args = np.tile(np.asarray(args0, dtype=float), (nw, 1)) * np.linspace(1.0, 1.3, nw)[:, None]
+    base = _run(eng, s, (kind, args), derivatives=True)
+    assert np.all(np.isfinite(base["radiance"]))
+    for a, h in enumerate(steps):
+        ap, am = args.copy(), args.copy()
+        ap[:, a] += h
+        am[:, a] -= h
+        fd = (_run(eng, s, (kind, ap))["radiance"] - _run(eng, s, (kind, am))["radiance"]) / (2 * h)
+        assert np.max(np.abs(fd - base["d_brdf"][..., a])) < 1e-6 * np.abs(fd).max(), (kind, a)   # the reference's own decimal = 6
+    # the atmospheric weighting functions next to a non-Lambertian surface
+    q = 4
+    k = s["extinction"]
+    hk = 1e-5 * k[q]
+    kp, km = k.copy(), k.copy()
+    kp[q] += hk
+    km[q] -= hk
+    fd = (_run(eng, s, (kind, args), extinction=kp)["radiance"] - _run(eng, s, (kind, args), extinction=km)["radiance"])
+    fd = fd / (2 * hk).reshape((nw,) + (1,) * (fd.ndim - 1))
+    assert np.max(np.abs(fd - base["d_extinction"][..., q])) < 1e-6 * np.abs(base["d_extinction"]).max()
+
+
+def test_brdf_surface_changes_every_azimuth_order():
+    """A Lambertian surface only enters the order-0 boundary condition; a BRDF (max_azimuthal_order unbounded, surface.h:88-90) couples
+    the sun's azimuth into the reflected field: the radiance depends on the relative azimuth of a nadir-looking ray differently."""
+    s = _scene(1)
+    eng = make_oracle(s)
+    nw = len(s["albedo"])
+    a_iso = np.tile([0.3, 0.0, 0.0], (nw, 1))
+    a_vol = np.tile([0.3, 0.3, 0.0], (nw, 1))
+    r_iso, r_vol = _run(eng, s, ("modis", a_iso))["radiance"], _run(eng, s, ("modis", a_vol))["radiance"]
+    # the two lines of sight differ in azimuth and zenith: the volumetric kernel changes their ratio
+    assert np.max(np.abs(r_vol[:, 0] / r_vol[:, 1] - r_iso[:, 0] / r_iso[:, 1])) > 1e-3
+
+
+def test_brdf_in_spherical_post_processing_is_refused():
+    s = sc.regression_1d(1)
+    eng = make_oracle(s)
+    with pytest.raises(RuntimeError):
+        _run(eng, s, ("modis", np.tile([0.2, 0.0, 0.0], (1, 1))))
