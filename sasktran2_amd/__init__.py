@@ -272,9 +272,27 @@ class _LegCoeff:
 
 
 class _Surface:
+    """Surface of an atmosphere: a Lambertian `albedo[wavelength]` by default.  `set_brdf("kokhanovsky" | "modis")` selects one of the reference's
+    other BRDFs (cpp/include/sasktran2/atmosphere/surface.h:151-352) and allocates `brdf_args[argument, wavelength]` as the reference's
+    `Surface.brdf_args` (SnowKokhanovsky: (chi + M) L / wavelength; MODIS: isotropic, volumetric, geometric); their weighting functions come
+    back as `wf_brdf[argument, wavelength, los, stokes]`.  Served by the discrete-ordinates source in plane-parallel / pseudo-spherical geometry."""
+    _NARGS = {"lambertian": 1, "kokhanovsky": 1, "modis": 3}
+
     def __init__(self, nwavel):
         self.albedo = np.zeros(nwavel)
         self.emission = np.zeros(nwavel)
+        self.brdf = "lambertian"
+        self.brdf_args = None
+
+    def set_brdf(self, kind):
+        if kind not in self._NARGS:
+            raise ValueError(f"unknown BRDF {kind!r}: lambertian, kokhanovsky, modis")
+        self.brdf = kind
+        self.brdf_args = None if kind == "lambertian" else np.zeros((self._NARGS[kind], self.albedo.size))
+
+    @property
+    def num_brdf_args(self):
+        return self._NARGS[self.brdf]
 
 
 class EquationOfState:
@@ -435,6 +453,9 @@ class Atmosphere:
         handles = self.__dict__.setdefault("_handles", {})
         st = self._raw_storage
         H = handles.get(direct)
+        if H is not None and H.get("brdf_kind", "lambertian") != self.surface.brdf:
+            self._destroy_handles(handles.pop(direct))   # another BRDF was selected: the surface handle is built for one
+            H = None
         if H is not None and direct and not (H["ext"] is st.total_extinction and H["ssa"] is st.ssa and H["em"] is st.emission_source and
                                              H["leg"] is st.leg_coeff and H["irr"] is st.solar_irradiance):
             self._destroy_handles(handles.pop(direct))   # the caller rebound a storage array: map the new one
@@ -453,10 +474,13 @@ class Atmosphere:
                      "irr": np.ones(self._nwavel), "alb": np.zeros(self._nwavel), "emis": np.zeros(self._nwavel)}
             H["storage"] = L.sk_atmosphere_storage_create(self._ngrid, self._nwavel, H["leg"].shape[0], nstokes, _p(H["ssa"]),
                                                           _p(H["ext"]), _p(H["em"]), _p(H["leg"]), _p(H["irr"]))
-            H["brdf"] = L.sk_brdf_create_lambertian(nstokes)
+            H["brdf_kind"] = self.surface.brdf
+            H["alb"] = np.zeros((self._nwavel, self.surface.num_brdf_args))   # (num_args x num_wavel) column-major, surface.h:366-372
+            H["brdf"] = getattr(L, f"sk_brdf_create_{self.surface.brdf}")(nstokes)
             H["surface"] = L.sk_surface_create(self._nwavel, nstokes, _p(H["emis"]))
             L.sk_surface_set_brdf(H["surface"], H["brdf"], _p(H["alb"]))
             H["atmosphere"] = L.sk_atmosphere_create(H["storage"], H["surface"], int(self._calculate_derivatives), 0)
+            H["mappings_set"] = False
             handles[direct] = H
         return H
 
@@ -538,7 +562,10 @@ class Engine:
             H["em"][...] = st.emission_source
             H["leg"][...] = st.leg_coeff
             H["irr"][...] = st.solar_irradiance
-        H["alb"][...] = atmosphere.surface.albedo
+        if atmosphere.surface.brdf == "lambertian":
+            H["alb"][:, 0] = atmosphere.surface.albedo
+        else:
+            H["alb"][...] = np.asarray(atmosphere.surface.brdf_args, dtype=float).T
         H["emis"][...] = atmosphere.surface.emission
         if derivs and not (direct and H["mappings_set"]):
             # raw-interface mappings, src/sasktran2/atmosphere.py:784-806 (identity; nothing rescales them without delta-M: set once)
@@ -548,11 +575,16 @@ class Engine:
                 ptr = _dp()
                 getattr(L, f"sk_deriv_mapping_get_{which}")(m, ctypes.byref(ptr))
                 np.ctypeslib.as_array(ptr, shape=(ngrid * nw,))[:] = 1.0
-            m = ctypes.c_void_p()
-            L.sk_surface_get_derivative_mapping(H["surface"], b"wf_albedo", ctypes.byref(m))
-            ptr = _dp()
-            L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
-            np.ctypeslib.as_array(ptr, shape=(nw,))[:] = 1.0
+            nargs = atmosphere.surface.num_brdf_args
+            for a in range(nargs):   # one mapping per BRDF argument: d_brdf (num_wavel x num_args, column-major) is its unit column
+                m = ctypes.c_void_p()
+                name = b"wf_albedo" if atmosphere.surface.brdf == "lambertian" else f"wf_brdf_{a}".encode()
+                L.sk_surface_get_derivative_mapping(H["surface"], name, ctypes.byref(m))
+                ptr = _dp()
+                L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
+                d = np.ctypeslib.as_array(ptr, shape=(nargs, nw))
+                d[:] = 0.0
+                d[a] = 1.0
             if direct:
                 H["mappings_set"] = True
         return H, delta_order
@@ -714,8 +746,13 @@ class Engine:
                 for name in ("wf_extinction", "wf_ssa"):
                     out[name] = _host.empty((ngrid, nw, nlos, S))   # (written in full by the call; page-locked: see hostmem.py)
                     L.sk_output_assign_derivative_memory(h_out, name.encode(), _p(out[name]), nw * nlos, S, ngrid)
-                out["wf_albedo"] = np.zeros((nw, nlos, S))
-                L.sk_output_assign_surface_derivative_memory(h_out, b"wf_albedo", _p(out["wf_albedo"]), nw * nlos, S)
+                if atmosphere.surface.brdf == "lambertian":
+                    out["wf_albedo"] = np.zeros((nw, nlos, S))
+                    L.sk_output_assign_surface_derivative_memory(h_out, b"wf_albedo", _p(out["wf_albedo"]), nw * nlos, S)
+                else:
+                    out["wf_brdf"] = np.zeros((atmosphere.surface.num_brdf_args, nw, nlos, S))
+                    for a in range(atmosphere.surface.num_brdf_args):
+                        L.sk_output_assign_surface_derivative_memory(h_out, f"wf_brdf_{a}".encode(), _p(out["wf_brdf"][a]), nw * nlos, S)
             if _mapping_hook is not None:
                 out["_surface_handle"] = h_su
                 _mapping_hook(L, h_st, h_out, out)

@@ -470,7 +470,9 @@ int sk_surface_get_derivative_mapping(Surface* s, const char* name, SurfaceDeriv
     if (it == s->maps.end()) {
         auto dm = std::make_unique<SurfaceDerivativeMapping>();
         dm->nwavel = s->nwavel;
-        dm->d_brdf.assign(s->nwavel, 0.0);
+        // (num_wavel x num_brdf_args, column-major: cpp/include/sasktran2/derivative_mapping.h, surface.h:556-561 -- sized by the BRDF set NOW)
+        dm->num_brdf_args = (s->brdf && s->brdf->kind == 2) ? 3 : 1;
+        dm->d_brdf.assign(size_t(s->nwavel) * dm->num_brdf_args, 0.0);
         dm->d_emission.assign(s->nwavel, 0.0);
         it = s->maps.emplace(name, std::move(dm)).first;
     }
@@ -743,8 +745,11 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
             }
             if (contract && contract->tangents) HIPC(hipMemcpy(contract->jvp, d_jvp, nt * 8, hipMemcpyDeviceToHost));
             if (!out->surface_derivs.empty()) {
-                std::vector<double> wa(nt), wsem;
-                HIPC(hipMemcpy(wa.data(), d_wa, nt * 8, hipMemcpyDeviceToHost));
+                // weighting functions of the BRDF arguments: [argument][wavel][los (, stokes)]; user derivative = sum_a d_brdf(wavel, a) dI / d arg_a
+                // (OutputC::assign_lane, cpp/lib/output/outputc.cpp:165-185)
+                const int nargs = (su.brdf && su.brdf->kind == 2) ? 3 : 1;
+                std::vector<double> wa(nt * nargs), wsem;
+                HIPC(hipMemcpy(wa.data(), d_wa, nt * nargs * 8, hipMemcpyDeviceToHost));
                 if (d_wsem) {
                     wsem.resize(nt);
                     HIPC(hipMemcpy(wsem.data(), d_wsem, nt * 8, hipMemcpyDeviceToHost));
@@ -753,10 +758,12 @@ static void map_user_derivatives(Engine* e, const AtmosphereStorage& st, const S
                     auto it = su.maps.find(kv.first);
                     if (it == su.maps.end()) throw std::runtime_error("no surface derivative mapping named " + kv.first);
                     const SurfaceDerivativeMapping& m = *it->second;
+                    if (m.d_brdf.size() != size_t(nw) * nargs) throw std::runtime_error("surface derivative mapping " + kv.first + " was created for another BRDF (argument count)");
                     for (int w = 0; w < nw; ++w) {
                         double gsum = 0;
                         for (int l = 0; l < nlos; ++l) {
-                            double v = wa[size_t(w) * nlos + l] * m.d_brdf[w];
+                            double v = 0;
+                            for (int a = 0; a < nargs; ++a) v += wa[size_t(a) * nt + size_t(w) * nlos + l] * m.d_brdf[size_t(a) * nw + w];
                             if (d_wsem) v += wsem[size_t(w) * nlos + l] * m.d_emission[w];
                             if (!contract) kv.second.mem[size_t(w) * nlos + l] = v;
                             else if (contract->surface_tangents) contract->jvp[size_t(w) * nlos + l] += v * contract->surface_tangents->at(kv.first).first[w];
@@ -818,7 +825,18 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     HIPC(hipMemcpy(d_ext, st.ext, nloc_w * 8, hipMemcpyDefault));
     HIPC(hipMemcpy(d_ssa, st.ssa, nloc_w * 8, hipMemcpyDefault));
     HIPC(hipMemcpy(d_leg, st.leg, nloc_w * st.nleg * 8, hipMemcpyDefault));
-    HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyDefault));
+    // surface: the Lambertian albedo, or the arguments of a non-Lambertian BRDF [nwavel][nargs] (brdf_args is (nargs x nwavel) column-major,
+    // cpp/include/sasktran2/atmosphere/surface.h:366-372)
+    const int brdf_kind = su.brdf ? su.brdf->kind : 0, brdf_nargs = brdf_kind == 2 ? 3 : 1;
+    if (brdf_kind == 0) {
+        HIPC(hipMemcpy(d_alb, su.brdf_args, size_t(nw) * 8, hipMemcpyDefault));
+    } else {
+        HIPC(hipMemset(d_alb, 0, size_t(nw) * 8));
+        double* d_bargs = (double*)C.get("brdf_args", size_t(nw) * brdf_nargs * 8);
+        HIPC(hipMemcpy(d_bargs, su.brdf_args, size_t(nw) * brdf_nargs * 8, hipMemcpyDefault));
+        e->dev->set_surface_brdf(brdf_kind, brdf_nargs, d_bargs);
+    }
+    struct BrdfReset { skdev::DeviceEngine* d; ~BrdfReset() { d->set_surface_brdf(0, 1, nullptr); } } brdf_reset{e->dev.get()};
     if (st.irradiance) {
         d_irr = (double*)C.get("irradiance", size_t(nw) * 8);
         HIPC(hipMemcpy(d_irr, st.irradiance, size_t(nw) * 8, hipMemcpyDefault));
@@ -830,7 +848,7 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     if (derivs) {
         d_we = (double*)C.get("wf_ext", size_t(ngrid) * nt * S * 8);
         d_ws = (double*)C.get("wf_ssa", size_t(ngrid) * nt * S * 8);
-        d_wa = (double*)C.get("wf_alb", nt * S * 8);
+        d_wa = (double*)C.get("wf_alb", nt * S * brdf_nargs * 8);
         for (auto& kv : out->derivs) {
             auto it = st.maps.find(kv.first);
             if (it != st.maps.end() && is_scattering_mapping(*it->second)) {
@@ -1141,7 +1159,15 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         if (st.nstokes != S || out->nstokes != S) return -2;
         if (st.nloc != e->ngrid) throw std::runtime_error("atmosphere grid does not match the engine geometry");
         if (!su.brdf_args) throw std::runtime_error("surface has no BRDF set");
-        if (su.brdf && su.brdf->kind != 0) return -2;  // only the Lambertian surface is part of this path
+        // non-Lambertian surfaces (SnowKokhanovsky, MODIS): the discrete-ordinates source in plane-parallel / pseudo-spherical geometry, on the
+        // run-time-n kernels; other sources and the spherical post-processing (whose ground points would need a source per outgoing angle,
+        // do_source_diffuse_storage.cpp:435-695) answer -2
+        const bool brdf_surface = su.brdf && su.brdf->kind != 0;
+        if (brdf_surface && (e->ts || e->so || !e->dev || !e->dev->plane_parallel() || e->config.emission_source == 2 || e->nflux_obs > 0)) {
+            set_error("sk_engine_calculate_radiance: a non-Lambertian BRDF is served for multiple_scatter_source = discrete_ordinates with the single "
+                      "scatter inside it, in plane-parallel or pseudo-spherical geometry, without thermal source and flux observers");
+            return -2;
+        }
         HostPhases ph;
         validate_input_atmosphere(e, st);
         ph.mark("validate");
@@ -1156,6 +1182,7 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         }
         if (e->ts) return calculate_radiance_ts(e, atm, out);
         if (e->so && !e->dev) return calculate_radiance_so(e, atm, out);
+        if (brdf_surface) return calculate_radiance_vector(e, atm, out);
         bool scattering_groups = false;
         for (auto& kv : out->derivs) {
             auto it = st.maps.find(kv.first);

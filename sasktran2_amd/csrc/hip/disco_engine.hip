@@ -493,6 +493,8 @@ struct DeviceEngine::Impl {
     int thermal_w0 = 0, thermal_nw_total = 0;                               // block in flight of the thermal pass
     // flux observers: layer / fraction per observer (device), requested flux types and the output of the solve in hand
     int nfx = 0, nflux_types = 0;
+    int brdf_kind = 0, brdf_nargs = 1;        // non-Lambertian surface of the next polarised / run-time-n solves (set_surface_brdf)
+    const double* brdf_args = nullptr;         // [nwavel][nargs] (device)
     int forced_azimuth = 0;   // > 0: the plane-parallel post-processing solves exactly this many azimuth orders (Config::num_do_forced_azimuth)
     int *d_fx_layer = nullptr, *d_flux_types = nullptr;
     double *d_fx_frac = nullptr, *d_flux = nullptr;
@@ -613,6 +615,12 @@ void DeviceEngine::set_flux_output(double* d_flux, const std::vector<int>& types
     if (d_flux && I.nflux_types > 0) HIP_CHECK(hipMemcpy(I.d_flux_types, types.data(), size_t(I.nflux_types) * sizeof(int), hipMemcpyHostToDevice));
 }
 int DeviceEngine::num_flux_observers() const { return impl_->nfx; }
+void DeviceEngine::set_surface_brdf(int kind, int nargs, const double* d_args) {
+    if (kind < 0 || kind > 2 || (kind != 0 && (!d_args || nargs != (kind == 2 ? 3 : 1)))) throw std::runtime_error("sasktran2_amd: bad BRDF kind / argument count");
+    impl_->brdf_kind = kind;
+    impl_->brdf_nargs = kind == 0 ? 1 : nargs;
+    impl_->brdf_args = kind == 0 ? nullptr : d_args;
+}
 void DeviceEngine::set_forced_azimuth(int n) {
     if (n > 0 && !impl_->g.pp_mode) throw std::runtime_error("sasktran2_amd: num_do_forced_azimuth is honoured by the plane-parallel post-processing only");
     impl_->forced_azimuth = n;

@@ -57,6 +57,10 @@ class DeviceEngine {
     // (otherwise solve_device_vector's run-time-n kernels are).
     void set_scattering_groups(int ngroups, const double* d_dleg, double* d_wf_scat, const double* d_dfg);
     bool groups_on_matrix_path(int ngroups) const;
+    // non-Lambertian surface of the next solve_device_vector calls (plane-parallel / pseudo-spherical post-processing, run-time-n kernels):
+    // kind 0 Lambertian (the albedo argument), 1 SnowKokhanovsky, 2 MODIS; d_args [nwavel][nargs] on the device.  The weighting functions of
+    // the arguments go to the albedo output, [nargs][nwavel][los][stokes]
+    void set_surface_brdf(int kind, int nargs, const double* d_args);
     void set_forced_azimuth(int n);   // plane-parallel post-processing: solve exactly n azimuth orders (n <= streams)
 
     // Polarised path (NSTOKES = 3; also NSTOKES = 1 with a stream count the matrix-core path does not cover).

@@ -75,7 +75,101 @@ struct VBufs {
     double* da4;            // [g][p][l][4][w]  direction of the layer coefficients for group g
     double* scratch;        // [element][thread] work matrices of the running kernel
     size_t scratch_stride;  // threads of the running kernel
+    // non-Lambertian surface (plane-parallel / pseudo-spherical post-processing): azimuth expansion of the BRDF per wavelength and order
+    int brdf_kind;          // 0 Lambertian (Bufs::albedo), 1 SnowKokhanovsky, 2 MODIS (cpp/include/sasktran2/atmosphere/surface.h:151-352)
+    int brdf_nargs;
+    const double* surf;     // [w][m][1 + nargs][VSurf::NP]  reflection factors and their derivatives wrt the BRDF arguments (VSurf)
+    double* surf_ops;       // [w][N][2 n + 1]  adjoint operators of the ground: Dinv^T e_t per incoming stream t, then I-_t at the ground
 };
+
+// Reflection factors of one (wavelength, azimuth order): the ground condition of stream i and the reflected intensity of a line of sight are
+//   I+_i = sum_t RS(i, t) I-_t + BS(i) T_ground,     I_los = sum_t RL(los, t) I-_t + BL(los) T_ground
+// with RS(i, t) = (1 + delta_m0) rho_m(mu_i, mu_t) w_t mu_t, BS(i) = cos(sza) rho_m(mu_i, mu_0) / pi and rho_m the azimuth expansion of
+// the BRDF (SurfaceStorage::compute_expansion, cpp/include/sktran_disco/sktran_do_surface.h:49-94; v_plus / v_minus / ground_direct_sun,
+// sktran_do_rte.h:116-345).  Block 0 holds the values, block 1 + a their derivatives wrt BRDF argument a.
+struct VSurf {
+    int N, nlos, nargs;
+    SKD_HD VSurf(int N_, int nlos_, int nargs_) : N(N_), nlos(nlos_), nargs(nargs_) {}
+    SKD_HD int NP() const { return N * N + N + nlos * N + nlos; }
+    SKD_HD int RS(int i, int t) const { return i * N + t; }
+    SKD_HD int BS(int i) const { return N * N + i; }
+    SKD_HD int RL(int los, int t) const { return N * N + N + los * N + t; }
+    SKD_HD int BL(int los) const { return N * N + N + nlos * N + los; }
+    SKD_HD size_t per_order() const { return size_t(1 + nargs) * NP(); }
+};
+SKD_HD const double* vsurf_at(const VBufs& v, const Geo& g, int m, int w) {
+    return v.surf + (size_t(w) * g.nstr + m) * VSurf(g.N, g.nlos, v.brdf_nargs).per_order();
+}
+// gradient / native-derivative rows of BRDF argument a: the Lambertian albedo's rows for a = 0, rows behind the scattering groups' otherwise
+SKD_HD size_t surf_grad_row(const Geo& g, const VBufs& v, int a) { return a == 0 ? size_t(4 * g.nlyr) : size_t(4 * g.nlyr + 2 + v.ngroups * g.nlyr + (a - 1)); }
+SKD_HD size_t surf_dnat_row(const Geo& g, const VBufs& v, int a) { return a == 0 ? size_t(2 * g.ngrid) : size_t(2 * g.ngrid + 1 + v.ngroups * g.ngrid + (a - 1)); }
+
+// ---- the reference's BRDFs (surface.h): geometry-only parts, so that the per-wavelength work is a weighted sum.
+// MODIS (surface.h:236-281): brdf = (iso + vol k_vol + geo k_geo) / pi, linear in its arguments
+SKD_HD void modis_kernels(double mu_in, double mu_out, double phi, double& k_vol, double& k_geo) {
+    const double csza = mu_in, cvza = mu_out, ssza = sqrt(1 - csza * csza), svza = sqrt(1 - cvza * cvza);
+    const double tsza = ssza / csza, tvza = svza / cvza, craa = -cos(phi), sraa = sin(phi);
+    const double csa = fmax(-1.0, fmin(1.0, csza * cvza + ssza * svza * craa)), sa = acos(csa);
+    k_vol = ((0.5 * kPi - sa) * csa + sin(sa)) / (csza + cvza) - 0.25 * kPi;
+    const double d2 = tsza * tsza + tvza * tvza - 2 * tsza * tvza * craa;
+    const double ct = fmax(-1.0, fmin(1.0, 2 * sqrt(d2 + tsza * tsza * tvza * tvza * sraa * sraa) * csza * cvza / (csza + cvza)));
+    const double t = acos(ct);
+    k_geo = (t - sin(t) * ct) * (csza + cvza) / (kPi * csza * cvza) - (csza + cvza - 0.5 * (1 + csa)) / (csza * cvza);
+}
+// SnowKokhanovsky (surface.h:151-229): brdf = r0 exp(-alpha K0(mu_s) K0(mu_v) / r0) / pi, alpha = sqrt(4 pi arg); r0 and the K0 product are geometry
+SKD_HD void kokhanovsky_parts(double mu_in, double mu_out, double phi, double& r0, double& kk) {
+    const double ss = sqrt(1 - mu_in * mu_in), sv = sqrt(1 - mu_out * mu_out);
+    const double cost = fmax(-1.0, fmin(1.0, -mu_in * mu_out + ss * sv * cos(phi)));
+    const double theta = acos(cost) * 180.0 / kPi;
+    r0 = (1.247 + 1.186 * (mu_in + mu_out) + 5.157 * mu_in * mu_out + 11.1 * exp(-0.087 * theta) + 1.1 * exp(-0.014 * theta)) / (4.0 * (mu_in + mu_out));
+    kk = (3.0 / 7.0) * (1.0 + 2.0 * mu_in) * (3.0 / 7.0) * (1.0 + 2.0 * mu_out);
+}
+// Geometry tables of the surface, built once per engine on the host (skhost::SurfaceTables): the NP (outgoing, incoming) direction pairs of
+// VSurf, the NQ = 1024 azimuth samples a_q of the two 512-point Gauss-Legendre panels with weights cw[m][q] = (w_q / 2) cos(m pi a_q) pi (2 -
+// delta_m0) / 2, per pair the factor that turns rho_m into RS / BS / RL / BL, and per BRDF kind its geometry-only samples.
+struct SurfGeo {
+    int NP, NQ, nstr;
+    const double* cw;        // [m][q]
+    const double* factor0;   // [pair] order 0
+    const double* factor;    // [pair] orders > 0
+    const double* modis_ke;  // [2][m][pair] expansions of k_vol, k_geo (already without the 1 / pi)
+    const double* kok_r0;    // [pair][q]
+    const double* kok_kk;    // [pair]
+};
+// Reflection factors of one (pair, wavelength) for every azimuth order: out[(m * (1 + nargs) + block) * NP + pair]
+SKD_HD void surface_expand_pair(const SurfGeo& sg, int kind, int nargs, const double* args, int pair, double* out) {
+    const int NP = sg.NP, nstr = sg.nstr;
+    const size_t po = size_t(1 + nargs) * NP;
+    if (kind == 2) {
+        for (int m = 0; m < nstr; ++m) {
+            const double f = (m == 0) ? sg.factor0[pair] : sg.factor[pair];
+            const double kv = sg.modis_ke[(size_t(0) * nstr + m) * NP + pair], kg = sg.modis_ke[(size_t(1) * nstr + m) * NP + pair];
+            const double iso = (m == 0) ? 1.0 : 0.0;   // a constant BRDF c / pi expands to c at order 0 (the Lambertian special case)
+            out[m * po + pair] = f * (args[0] * iso + args[1] * kv + args[2] * kg);
+            out[m * po + size_t(1) * NP + pair] = f * iso;
+            out[m * po + size_t(2) * NP + pair] = f * kv;
+            out[m * po + size_t(3) * NP + pair] = f * kg;
+        }
+        return;
+    }
+    // SnowKokhanovsky: f_q = r0_q exp(-alpha kk / r0_q) / pi,  d f_q / d arg = -2 kk exp(..) / alpha  (surface.h:206-229)
+    const double alpha = sqrt(4 * kPi * args[0]), kk = sg.kok_kk[pair];
+    for (int m = 0; m < nstr; ++m) { out[m * po + pair] = 0; out[m * po + NP + pair] = 0; }
+    for (int q = 0; q < sg.NQ; ++q) {
+        const double r0 = sg.kok_r0[size_t(pair) * sg.NQ + q], e = exp(-alpha * kk / r0);
+        const double f = r0 * e / kPi, df = -2.0 * kk * e / alpha;
+        for (int m = 0; m < nstr; ++m) {
+            const double c = sg.cw[size_t(m) * sg.NQ + q];
+            out[m * po + pair] += c * f;
+            out[m * po + NP + pair] += c * df;
+        }
+    }
+    for (int m = 0; m < nstr; ++m) {
+        const double f = (m == 0) ? sg.factor0[pair] : sg.factor[pair];
+        out[m * po + pair] *= f;
+        out[m * po + NP + pair] *= f;
+    }
+}
 
 struct VRec {
     int n, ngrp;
@@ -1420,7 +1514,10 @@ SKD_HD size_t kv2_scratch(int n) { return kv2_scratch_main(n) + kv2_scratch_t1(n
 template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, double* ws, double* T1) {
     const int N = g.N, S = v.S, n = v.n, M2 = 2 * n, nw = b.nw, nlyr = g.nlyr;
     const VRec R(n);
-    const double rho = (m == 0) ? b.albedo[w] : 0.0;  // Lambertian
+    const bool brdf = v.brdf_kind != 0;                          // non-Lambertian surface: every order carries a ground reflection (VSurf)
+    const double rho = (m == 0 && !brdf) ? b.albedo[w] : 0.0;   // Lambertian
+    const double* sf = brdf ? vsurf_at(v, g, m, w) : nullptr;
+    const VSurf SF(N, g.nlos, v.brdf_nargs);
     const double kd = 2.0;
     const int mm = M2 * M2;
     // the register-resident inversions read the whole block before they write the inverse, and the block of the next layer is only built after
@@ -1466,9 +1563,18 @@ template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g,
             const int i = e % n, j = e / n;   // lanes over i: coalesced W+-(i, j), consecutive T1[.][i], broadcast W+-(q, j)
             const double wp = c[R.WP() + i + n * j], wm = c[R.WM() + i + n * j], Ej = c[R.E() + j];
             double d00 = -wp, d01 = -wm * Ej, d10 = wm * Ej, d11 = wp;
-            if (p == nlyr - 1 && m == 0 && (i % S) == 0) {
+            if (p == nlyr - 1 && m == 0 && (i % S) == 0 && !brdf) {
                 d10 -= refl[j];
                 d11 -= refl[n + j];
+            }
+            if (p == nlyr - 1 && brdf && (i % S) == 0) {
+                double sp = 0, sm = 0;
+                for (int t = 0; t < N; ++t) {
+                    sp += sf[SF.RS(i / S, t)] * c[R.WP() + t * S + n * j];
+                    sm += sf[SF.RS(i / S, t)] * c[R.WM() + t * S + n * j];
+                }
+                d10 -= sp * Ej;
+                d11 -= sm;
             }
             D[i * M2 + j] = d00;
             D[i * M2 + n + j] = d01;
@@ -1487,11 +1593,16 @@ template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g,
         SKV_PAR(i, n) {
             double ra = c[R.G() + 0 * n + i], rb = -c[R.G() + 3 * n + i];
             if (p == nlyr - 1) {
-                if (m == 0 && (i % S) == 0) {
+                if (m == 0 && (i % S) == 0 && !brdf) {
                     double sg = 0;
                     for (int t = 0; t < N; ++t) sg += g.wt[t] * g.mu[t] * c[R.G() + 2 * n + t * S];
                     // (+ surface emission in the thermal pass, as skd::k2a_bvp)
                     rb += g.csz[s] * rho / kPi * b.T[size_t(nlyr) * nw + w] + (b.surf_em ? b.surf_em[w] : 0.0) + kd * rho * sg;
+                }
+                if (brdf && (i % S) == 0) {
+                    double sg = 0;
+                    for (int t = 0; t < N; ++t) sg += sf[SF.RS(i / S, t)] * c[R.G() + 2 * n + t * S];
+                    rb += sf[SF.BS(i / S)] * b.T[size_t(nlyr) * nw + w] + sg;
                 }
             } else {
                 rb += vrec_at(v, nlyr, p + 1, w)[R.G() + 1 * n + i];
@@ -1830,7 +1941,8 @@ SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg
     double* o = vops_at(v, g, p, w);
     const double om = b.om[size_t(p) * nw + w], th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w];
     const bool last = (p == nlyr - 1);
-    const double rho = (m == 0) ? b.albedo[w] : 0.0;
+    const bool brdf = v.brdf_kind != 0;
+    const double rho = (m == 0 && !brdf) ? b.albedo[w] : 0.0;
     double *F = ws, *tmp = ws + M2 * NL, *ipbv = tmp + M2, *part = ipbv + 2 * n;   // F [2n][NL], tmp [2n], ipbv [n], part [K][5][NL]
     (void)s;
     // ---- F = [UL; UM] and the direct-dependence rows HD: a lane takes one Legendre order and one of K slices of the solutions
@@ -2079,6 +2191,23 @@ SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg
     }
     team.sync();
     SKV_PAR(i, M2) o[O.UG() + i] = sum4(0, M2, [&](int j) { return dinv[j * M2 + i] * tmp[j]; });
+    if (brdf && last) {
+        // non-Lambertian ground: per incoming stream t the adjoint seed Dinv^T e_t, e_t = d I-_t(ground) / d(L, M) = [W+(t, j) E_j ; W-(t, j)], and
+        // I-_t at the ground itself (what the derivatives wrt the BRDF arguments multiply)
+        double* so = v.surf_ops + size_t(w) * N * (M2 + 1);
+        SKV_PAR(item, N * M2) {
+            const int t = item / M2, i = item % M2;
+            so[t * (M2 + 1) + i] = sum4(0, M2, [&](int j) {
+                const double e = j < n ? c[R.WP() + t * S + n * j] * c[R.E() + j] : c[R.WM() + t * S + n * (j - n)];
+                return dinv[j * M2 + i] * e;
+            });
+        }
+        SKV_PAR(t, N) {
+            double val = c[R.G() + 2 * n + t * S];
+            for (int j = 0; j < n; ++j) val += c[R.WP() + t * S + n * j] * c[R.E() + j] * xs[j] + c[R.WM() + t * S + n * j] * xs[n + j];
+            so[t * (M2 + 1) + M2] = val;
+        }
+    }
     if (team.lane == 0) {
         double ipb = 0;
         for (int i = 0; i < n; ++i) ipb += ipbv[i];
@@ -2154,12 +2283,39 @@ SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v,
                 const double q = v.qlbuf[(size_t(p) * NL + l) * nt + tid];
                 for (int t = 0; t < 4; ++t) gth[t] += ops[O.HD() + t * NL + l] * q;
             }
-        if (last && m == 0) {
+        if (last && m == 0 && v.brdf_kind == 0) {
             for (int t = 0; t < 4; ++t) gth[t] += (zBsum + gw) * ops[O.GD() + t];
             const double rho = b.albedo[w], ipb = ops[O.IPB()];
             v.grad[size_t(4 * nlyr) * nt + tid] += gw * 2.0 * ipb + zBsum * (2.0 * ipb + g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w]);
             // solar: d / d(beam transmission at the ground); thermal pass: d / d(surface emission) (as skd::K2bTask::gradient)
             v.grad[size_t(4 * nlyr + 1) * nt + tid] += b.thermal_pass ? zBsum : zBsum * g.csz[s] / kPi * rho;
+        }
+        if (last && v.brdf_kind != 0) {
+            // non-Lambertian ground (every order): the adjoint weight of incoming stream t is c_t = sum_i zB_i RS(i, t) + gw RL(los, t)
+            const int N = g.N, los = int((tid / S) % g.nlos), na = v.brdf_nargs;
+            const VSurf SF(N, g.nlos, na);
+            const double* sf = vsurf_at(v, g, m, w);
+            const double* so = v.surf_ops + size_t(w) * N * (M2 + 1);
+            const double Tg = b.T[size_t(nlyr) * nw + w];
+            double ga[3] = {0, 0, 0}, gT = 0;
+            for (int t = 0; t < N; ++t) {
+                double ct = gw * sf[SF.RL(los, t)], da[3] = {0, 0, 0};
+                for (int a = 0; a < na; ++a) da[a] = gw * sf[size_t(1 + a) * SF.NP() + SF.RL(los, t)];
+                for (int i = 0; i < N; ++i) {
+                    const double zbi = v.z[(size_t(p) * M2 + n + i * S) * nt + tid];
+                    ct += zbi * sf[SF.RS(i, t)];
+                    for (int a = 0; a < na; ++a) da[a] += zbi * sf[size_t(1 + a) * SF.NP() + SF.RS(i, t)];
+                }
+                for (int th4 = 0; th4 < 4; ++th4) gth[th4] += ct * ops[O.DI() + (th4 * 4 + 2) * n + t * S];
+                for (int a = 0; a < na; ++a) ga[a] += da[a] * so[t * (M2 + 1) + M2];
+            }
+            for (int i = 0; i < N; ++i) {
+                const double zbi = v.z[(size_t(p) * M2 + n + i * S) * nt + tid];
+                gT += zbi * sf[SF.BS(i)];
+                for (int a = 0; a < na; ++a) ga[a] += zbi * sf[size_t(1 + a) * SF.NP() + SF.BS(i)] * Tg;
+            }
+            for (int a = 0; a < na; ++a) v.grad[surf_grad_row(g, v, a) * nt + tid] += ga[a];
+            v.grad[size_t(4 * nlyr + 1) * nt + tid] += gT;
         }
         for (int t = 0; t < 4; ++t) v.grad[size_t(t * nlyr + p) * nt + tid] += gth[t];
         // scattering groups: the same contraction with the group's DI / HD / GD rows
@@ -2618,7 +2774,38 @@ SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v
     }
     // Lambertian ground seen through the whole column (order 0, intensity only)
     double ground = 0, gw = 0;
-    if (m == 0) {
+    if (v.brdf_kind != 0) {
+        // non-Lambertian ground: I_los = sum_t RL(los, t) I-_t + BL(los) T_ground in every order (computeReflectedIntensities with the
+        // los_stream / los_solar expansions, sktran_do_layerarray.cpp:5-288)
+        const double* c = vrec_at(v, nlyr, nlyr - 1, w);
+        const double* xs = vxsol_at(v, nlyr, nlyr - 1, w);
+        const VSurf SF(N, g.nlos, v.brdf_nargs);
+        const double* sf = vsurf_at(v, g, m, w);
+        const double Tg = b.T[size_t(nlyr) * nw + w];
+        double refl = 0;
+        for (int t = 0; t < N; ++t) {
+            double val = c[R.G() + 2 * n + t * S];
+            for (int j = 0; j < n; ++j) val += c[R.WP() + t * S + n * j] * c[R.E() + j] * xs[j] + c[R.WM() + t * S + n * j] * xs[n + j];
+            refl += sf[SF.RL(los, t)] * val;
+        }
+        const double A = att * azf[0];
+        ground = A * (refl + (g.include_ss ? sf[SF.BL(los)] * Tg : 0.0));
+        total[0] += ground;
+        if (derivs) {
+            gw = A;
+            const size_t t3 = tid * S;
+            const double* so = v.surf_ops + size_t(w) * N * (M2 + 1);
+            for (int i = 0; i < M2; ++i) {
+                double acc = 0;
+                for (int t = 0; t < N; ++t) acc += sf[SF.RL(los, t)] * so[t * (M2 + 1) + i];
+                v.z[(size_t(nlyr - 1) * M2 + i) * nt3 + t3] += gw * acc;
+            }
+            if (g.include_ss) {   // direct-beam part (the diffuse part goes through gw in the gradient contraction)
+                for (int a = 0; a < v.brdf_nargs; ++a) v.grad[surf_grad_row(g, v, a) * nt3 + t3] += A * sf[size_t(1 + a) * SF.NP() + SF.BL(los)] * Tg;
+                v.grad[size_t(4 * nlyr + 1) * nt3 + t3] += A * sf[SF.BL(los)];
+            }
+        }
+    } else if (m == 0) {
         const double* c = vrec_at(v, nlyr, nlyr - 1, w);
         const double* xs = vxsol_at(v, nlyr, nlyr - 1, w);
         const double rho = b.albedo[w];
@@ -2676,6 +2863,16 @@ SKD_HD void kv4g_chain(const Geo& g, const Bufs& b, const VBufs& v, int w, size_
             }
             gr = 0;
         }
+}
+
+// Gradient rows of the BRDF arguments beyond the first -> native derivative rows (argument 0 rides the albedo row through skd::k4a_chain).
+// Clears the rows (one call per solar zenith index).                      (task = wavelength x LOS x Stokes)
+SKD_HD void kv4s_chain(const Geo& g, const VBufs& v, size_t tid, size_t nt) {
+    for (int a = 1; a < v.brdf_nargs; ++a) {
+        double& gr = v.grad[surf_grad_row(g, v, a) * nt + tid];
+        v.dnat[surf_dnat_row(g, v, a) * nt + tid] += gr;
+        gr = 0;
+    }
 }
 
 // (I, Q, U) of one line of sight in the configured Stokes basis:  Q' = C Q - S U,  U' = S Q + C U

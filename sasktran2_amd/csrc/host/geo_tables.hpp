@@ -218,6 +218,62 @@ struct GeoTables {
 
 // Tables of the polarised (NSTOKES = 3) path that go with a GeoTables: the R / T companions of the Legendre tables (same
 // shapes; zero-filled for NSTOKES = 1) and the sine azimuth factors of the ray layers (U component).
+// Geometry tables of a non-Lambertian surface for plane-parallel / pseudo-spherical post-processing (skv::SurfGeo): built once per engine.
+// Pairs in the order of skv::VSurf: (stream i, stream t), (stream i, sun), (line of sight, stream t), (line of sight, sun).
+struct SurfaceTables {
+    int NP = 0, NQ = 0, nstr = 0;
+    std::vector<double> cw, factor0, factor, modis_ke, kok_r0, kok_kk;
+    template <class KernelsFn, class PartsFn> void build(const GeoTables& t, KernelsFn modis_kernels, PartsFn kokhanovsky_parts) {
+        const double pi = 3.14159265358979323846;
+        const int N = t.N, nlos = t.nlos;
+        nstr = t.nstr;
+        NP = N * N + N + nlos * N + nlos;
+        // the two 512-point Gauss-Legendre panels over the azimuth of SurfaceStorage::compute_expansion (sktran_do_surface.h:62-93)
+        std::vector<double> x, w, aq, wq;
+        skgeo::gauss_legendre(512, x, w);
+        for (size_t i = 0; i < x.size(); ++i)
+            if (x[i] > 0)
+                for (double a : {0.5 * x[i] + 0.5, -0.5 * x[i] + 0.5, 0.5 * x[i] - 0.5, -0.5 * x[i] - 0.5}) { aq.push_back(a); wq.push_back(0.5 * w[i]); }
+        NQ = int(aq.size());
+        cw.resize(size_t(nstr) * NQ);
+        for (int m = 0; m < nstr; ++m)
+            for (int q = 0; q < NQ; ++q) cw[size_t(m) * NQ + q] = wq[q] * std::cos(m * pi * aq[q]) * 0.5 * pi * (m == 0 ? 1.0 : 2.0);
+        std::vector<double> mo(NP), mi(NP);
+        factor0.resize(NP); factor.resize(NP);
+        const double csz0 = t.csz[0];
+        auto set = [&](int pr, double mu_out, double mu_in, int in_stream) {
+            mo[pr] = mu_out; mi[pr] = mu_in;
+            const double f = in_stream >= 0 ? t.wt[in_stream] * t.mu[in_stream] : csz0 / pi;   // (1 + delta_m0) w mu for a stream, cos(sza) / pi for the sun
+            factor0[pr] = in_stream >= 0 ? 2.0 * f : f;
+            factor[pr] = f;
+        };
+        for (int i = 0; i < N; ++i) {
+            for (int tt = 0; tt < N; ++tt) set(i * N + tt, t.mu[i], t.mu[tt], tt);
+            set(N * N + i, t.mu[i], csz0, -1);
+        }
+        for (int l = 0; l < nlos; ++l) {
+            for (int tt = 0; tt < N; ++tt) set(N * N + N + l * N + tt, t.pp_mu[l], t.mu[tt], tt);
+            set(N * N + N + nlos * N + l, t.pp_mu[l], csz0, -1);
+        }
+        modis_ke.assign(size_t(2) * nstr * NP, 0.0);
+        kok_r0.resize(size_t(NP) * NQ); kok_kk.resize(NP);
+        for (int pr = 0; pr < NP; ++pr) {
+            for (int q = 0; q < NQ; ++q) {
+                double kv, kg, r0, kk;
+                modis_kernels(mi[pr], mo[pr], pi * aq[q], kv, kg);
+                kokhanovsky_parts(mi[pr], mo[pr], pi * aq[q], r0, kk);
+                kok_r0[size_t(pr) * NQ + q] = r0;
+                kok_kk[pr] = kk;
+                for (int m = 0; m < nstr; ++m) {
+                    const double c = cw[size_t(m) * NQ + q] / pi;   // the kernels enter the BRDF divided by pi
+                    modis_ke[(size_t(0) * nstr + m) * NP + pr] += c * kv;
+                    modis_ke[(size_t(1) * nstr + m) * NP + pr] += c * kg;
+                }
+            }
+        }
+    }
+};
+
 struct VecTables {
     int S = 1;
     std::vector<double> lpmuR, lpmuT, lpangR, lpangT, lplosR, lplosT, rl_sinm_t, stokes_c, stokes_s;

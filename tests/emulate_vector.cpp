@@ -15,6 +15,10 @@ struct Handle {
     skgeo::DiscoGeometry dg;
     skhost::GeoTables tab;
     skhost::VecTables vtab;
+    // non-Lambertian surface of the next emuv_run calls (emuv_set_brdf)
+    int brdf_kind = 0, brdf_nargs = 1;
+    const double* brdf_args = nullptr;   // [nwavel][nargs]
+    double* d_brdf_out = nullptr;        // [nwavel][nlos][S][nargs]
 };
 }  // namespace
 
@@ -47,6 +51,15 @@ void* emuv_create(double cos_sza, double saa, double earth_radius, const double*
     }
 }
 void emuv_destroy(void* h) { delete static_cast<Handle*>(h); }
+int emuv_set_brdf(void* hv, int kind, int nargs, const double* args, double* d_brdf_out) {
+    auto* h = static_cast<Handle*>(hv);
+    if (!h || kind < 0 || kind > 2) return -1;
+    h->brdf_kind = kind;
+    h->brdf_nargs = kind == 0 ? 1 : nargs;
+    h->brdf_args = kind == 0 ? nullptr : args;
+    h->d_brdf_out = kind == 0 ? nullptr : d_brdf_out;
+    return 0;
+}
 
 // radiance: [nwavel][nlos][nstokes];  leg: [nwavel][ngrid][nleg][4] (reference storage order, nstokes = 3) or [..][nleg]
 int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const double* ssa, const double* leg,
@@ -78,13 +91,32 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                                           skv::kv2c_scratch(n, NL, ngroups), skv::kv2b_scratch(n, NL), skv::kv2bt_scratch(n, NL, nlos * S)}));
     const int G = derivatives ? ngroups : 0;
     std::vector<double> ops(derivatives ? size_t(nlyr) * skv::VOps(n, NL, G).size() * nw : 1), zb(derivatives ? size_t(nlyr) * 2 * n * nt3 : 1),
-        qlb(derivatives ? size_t(nlyr) * NL * nt3 : 1), grad(derivatives ? size_t(4 * nlyr + 2 + G * nlyr) * nt3 : 1, 0.0),
-        dnat(derivatives ? size_t(2 * ngrid + 1 + G * ngrid) * nt3 : 1, 0.0), da4(size_t(std::max(G, 1)) * nlyr * nstr * 4 * nw, 0.0);
+        qlb(derivatives ? size_t(nlyr) * NL * nt3 : 1), grad(derivatives ? size_t(4 * nlyr + 2 + G * nlyr + 2) * nt3 : 1, 0.0),
+        dnat(derivatives ? size_t(2 * ngrid + 1 + G * ngrid + 2) * nt3 : 1, 0.0), da4(size_t(std::max(G, 1)) * nlyr * nstr * 4 * nw, 0.0);
     skv::VBufs v{};
     v.S = S; v.n = n; v.leg = leg; v.nleg = nleg; v.a4 = a4.data(); v.rec = rec.data(); v.dinv = dinv.data(); v.xsol = xsol.data();
     v.J = J.data(); v.radiance = rad.data(); v.scratch = scratch.data(); v.scratch_stride = 1;
     v.ops = ops.data(); v.z = zb.data(); v.qlbuf = qlb.data(); v.grad = grad.data(); v.dnat = dnat.data(); v.derivs = derivatives;
     v.ngroups = G; v.dleg = d_legendre; v.dleg_nw = nw; v.dleg_w0 = 0; v.dfg = nullptr; v.da4 = da4.data();
+    // non-Lambertian surface: the geometry tables and the reflection factors of every (pair, wavelength), as kern_surface_expand forms them
+    skhost::SurfaceTables stab;
+    std::vector<double> surf, surf_ops;
+    v.brdf_kind = h->brdf_kind;
+    v.brdf_nargs = h->brdf_nargs;
+    if (h->brdf_kind != 0) {
+        if (!g.pp_mode) return -2;
+        stab.build(t, [](double mi, double mo, double phi, double& kv, double& kg) { skv::modis_kernels(mi, mo, phi, kv, kg); },
+                   [](double mi, double mo, double phi, double& r0, double& kk) { skv::kokhanovsky_parts(mi, mo, phi, r0, kk); });
+        skv::SurfGeo sg{stab.NP, stab.NQ, stab.nstr, stab.cw.data(), stab.factor0.data(), stab.factor.data(), stab.modis_ke.data(), stab.kok_r0.data(), stab.kok_kk.data()};
+        surf.assign(size_t(nw) * nstr * (1 + h->brdf_nargs) * stab.NP, 0.0);
+        surf_ops.assign(size_t(nw) * N * (2 * n + 1), 0.0);
+        for (int w = 0; w < nw; ++w)
+            for (int pr = 0; pr < stab.NP; ++pr)
+                skv::surface_expand_pair(sg, h->brdf_kind, h->brdf_nargs, h->brdf_args + size_t(w) * h->brdf_nargs, pr,
+                                         surf.data() + size_t(w) * nstr * (1 + h->brdf_nargs) * stab.NP);
+        v.surf = surf.data();
+        v.surf_ops = surf_ops.data();
+    }
     v.k1_compact = skv::kv1_compact_layout(n, G);   // the work-space layout the device launcher chooses (its aliasing is the same on the CPU)
     const skv::Scr scr{scratch.data(), 1};
     const skv::Team team{0, 1};
@@ -119,6 +151,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                 for (int l3 = 0; l3 < nlos * S; ++l3) {
                     skd::k4a_chain(g3, b3, 0, l3, w);
                     skv::kv4g_chain(g, b, v, w, size_t(w) * nlos * S + l3, nt3);
+                    if (v.brdf_kind != 0) skv::kv4s_chain(g, v, size_t(w) * nlos * S + l3, nt3);
                 }
         }
     } else {
@@ -182,6 +215,13 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                     else if (q < 2 * ngrid) { if (d_ssa) d_ssa[(i * S + c) * ngrid + (q - ngrid)] = out[c]; }
                     else if (d_albedo) d_albedo[i * S + c] = out[c];
                 }
+            }
+            // BRDF arguments: d_brdf [w][los][S][nargs]
+            for (int a = 0; a < v.brdf_nargs && h->d_brdf_out; ++a) {
+                double in[3] = {0, 0, 0}, out[3];
+                for (int c = 0; c < S; ++c) in[c] = dnat[skv::surf_dnat_row(g, v, a) * nt3 + i * S + c];
+                skv::stokes_rotate(vg, los, in, out, S);
+                for (int c = 0; c < S; ++c) h->d_brdf_out[(i * S + c) * v.brdf_nargs + a] = out[c];
             }
             // scattering groups: d_scat [w][los][S][G][ngrid]
             for (int gi = 0; gi < G; ++gi)

@@ -115,7 +115,7 @@ def libv():
     return _LIBV
 
 
-def run_emulated_vector(s, derivatives=False, d_legendre=None):
+def run_emulated_vector(s, derivatives=False, d_legendre=None, brdf=None):
     """d_legendre: optional [G, nleg (*4), ngrid, nwavel] directions of scattering derivative groups (deriv_mapping.h d_legendre)."""
     """Radiances [nwavel, nlos, nstokes] of the polarised task bodies (disco_vec_core.hpp) executed on the CPU."""
     g = s["geometry"]
@@ -147,6 +147,13 @@ def run_emulated_vector(s, derivatives=False, d_legendre=None):
             G = len(d_legendre)
             dl = np.ascontiguousarray(np.stack([np.asfortranarray(x).ravel(order="F") for x in d_legendre]))   # [G][w][q][leg]
             dsc = np.zeros((nw, nlos, S, G, ngrid))
+        dbr = None
+        if brdf is not None:   # (kind, args [nwavel, nargs]): non-Lambertian surface, plane-parallel / pseudo-spherical post-processing
+            kind = {"kokhanovsky": 1, "modis": 2}[brdf[0]]
+            bargs = np.ascontiguousarray(brdf[1], dtype=np.float64).reshape(nw, -1)
+            dbr = np.zeros((nw, nlos, S, bargs.shape[1])) if derivatives else None
+            L.emuv_set_brdf.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp]
+            assert L.emuv_set_brdf(h, kind, bargs.shape[1], _p(bargs), _p(dbr)) == 0
         rc = L.emuv_run(h, nw, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), None, _p(alb), _p(df), _p(rad), _p(od),
                         status.ctypes.data_as(_ip), int(derivatives), _p(dk), _p(dw), _p(da), G, _p(dl), _p(dsc))
         assert rc == 0, rc
@@ -154,6 +161,8 @@ def run_emulated_vector(s, derivatives=False, d_legendre=None):
         if derivatives:
             sq = (lambda a: a) if S == 3 else (lambda a: a[:, :, 0])
             out.update({"d_extinction": sq(dk), "d_ssa": sq(dw), "d_albedo": sq(da)})
+            if dbr is not None:
+                out["d_brdf"] = dbr if S == 3 else dbr[:, :, 0]
             if dsc is not None:
                 out["d_scat"] = dsc if S == 3 else dsc[:, :, 0]
         return out

@@ -48,19 +48,29 @@ def run_product(s, derivatives=True, engine=None):
     else:
         atmosphere.leg_coeff.a1[:] = s["leg"]
     atmosphere.surface.albedo[:] = s["albedo"]
+    brdf = s.get("brdf")   # (kind, args [nwavel, nargs]): a non-Lambertian surface; its weighting functions come back as d_brdf [wavel, los, (stokes,) argument]
+    if brdf is not None:
+        atmosphere.surface.set_brdf(brdf[0])
+        atmosphere.surface.brdf_args[:] = np.asarray(brdf[1], dtype=float).T
     res = engine.calculate_radiance(atmosphere, as_dataset=False)
     if s["config"].get("nstokes", 1) == 3:
         out = {"radiance": res["radiance"], "los_optical_depth": res["los_optical_depth"]}
         if derivatives:   # [wavel, los, stokes, altitude] as the oracle front end returns them
             out["d_extinction"] = np.transpose(res["wf_extinction"], (1, 2, 3, 0))
             out["d_ssa"] = np.transpose(res["wf_ssa"], (1, 2, 3, 0))
-            out["d_albedo"] = res["wf_albedo"]
+            if brdf is None:
+                out["d_albedo"] = res["wf_albedo"]
+            else:
+                out["d_brdf"] = np.transpose(res["wf_brdf"], (1, 2, 3, 0))
         return out
     out = {"radiance": res["radiance"][:, :, 0], "los_optical_depth": res["los_optical_depth"]}
     if derivatives:
         out["d_extinction"] = np.transpose(res["wf_extinction"][:, :, :, 0], (1, 2, 0))
         out["d_ssa"] = np.transpose(res["wf_ssa"][:, :, :, 0], (1, 2, 0))
-        out["d_albedo"] = res["wf_albedo"][:, :, 0]
+        if brdf is None:
+            out["d_albedo"] = res["wf_albedo"][:, :, 0]
+        else:
+            out["d_brdf"] = np.transpose(res["wf_brdf"][:, :, :, 0], (1, 2, 0))
     return out
 
 

@@ -1,0 +1,103 @@
+"""Non-Lambertian surfaces (SnowKokhanovsky, MODIS) on the device: the discrete-ordinates ground condition with the azimuth expansion of
+the BRDF (kern_surface_expand, kv2_bvp, kv2c_layer_ops, kvpp_los of the run-time-n kernels) through the C ABI against the oracle
+(oracle/disco_oracle.hpp, pinned by its Lambertian limit and by central differences, tests/test_brdf_oracle.py), and the reference's own
+criterion for these surfaces: analytic weighting functions of the BRDF arguments = central differences (tests/constituent/test_modis.py)."""
+import numpy as np
+import pytest
+
+import sasktran2_amd as sk
+from tests import scenarios as sc
+from tests.gpu_harness import build_engine, run_product
+from tests.test_oracle_golden import make_oracle
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("modis", [0.2, 0.05, 0.05]), ("kokhanovsky", [0.04])]
+
+
+def _scene(nstokes, nstr, nw=5, pseudo_spherical=False):
+    s = sc.nadir_c1(num_wavelengths=nw, nstr=nstr)
+    if pseudo_spherical:
+        s["geometry"]["geotype"] = sc.GEO_PSEUDOSPHERICAL
+    if nstokes == 3:
+        s = sc.to_vector(s, rayleigh_fraction=0.8)
+    return s
+
+
+def _args(args0, nw):
+    return np.tile(np.asarray(args0, dtype=float), (nw, 1)) * np.linspace(1.0, 1.3, nw)[:, None]
+
+
+@pytest.mark.parametrize("nstokes,nstr", [(1, 4), (1, 8), (1, 16), (3, 8)])
+@pytest.mark.parametrize("kind,args0", CASES, ids=[c[0] for c in CASES])
+def test_brdf_radiances_and_weighting_functions_match_the_oracle(nstokes, nstr, kind, args0):
+    s = _scene(nstokes, nstr)
+    nw = len(s["albedo"])
+    s["brdf"] = (kind, _args(args0, nw))
+    got = run_product(s, derivatives=True)
+    ref = make_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, brdf=s["brdf"])
+    scale = np.abs(ref["radiance"]).max()
+    assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-10 * scale       # north star: 1e-6 on Stokes I
+    for k in ("d_extinction", "d_ssa", "d_brdf"):
+        assert np.max(np.abs(got[k] - ref[k])) < 1e-8 * np.abs(ref[k]).max(), k   # north star: 1e-4 on weighting functions
+
+
+def test_brdf_in_pseudo_spherical_geometry_matches_the_oracle():
+    s = _scene(1, 8, pseudo_spherical=True)
+    nw = len(s["albedo"])
+    s["brdf"] = ("modis", _args([0.2, 0.05, 0.05], nw))
+    got = run_product(s, derivatives=True)
+    ref = make_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, brdf=s["brdf"])
+    assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-10 * np.abs(ref["radiance"]).max()
+    for k in ("d_extinction", "d_ssa", "d_brdf"):
+        assert np.max(np.abs(got[k] - ref[k])) < 1e-8 * np.abs(ref[k]).max(), k
+
+
+def test_modis_with_its_isotropic_kernel_alone_equals_the_lambertian_surface_on_the_device():
+    s = _scene(1, 8)
+    nw = len(s["albedo"])
+    lam = run_product(s, derivatives=True)
+    args = np.zeros((nw, 3))
+    args[:, 0] = s["albedo"]
+    s["brdf"] = ("modis", args)
+    mod = run_product(s, derivatives=True)
+    assert np.max(np.abs(lam["radiance"] - mod["radiance"])) < 1e-12 * np.abs(lam["radiance"]).max()
+    assert np.max(np.abs(lam["d_albedo"] - mod["d_brdf"][..., 0])) < 1e-10 * np.abs(lam["d_albedo"]).max()
+    assert np.max(np.abs(lam["d_extinction"] - mod["d_extinction"])) < 1e-10 * np.abs(lam["d_extinction"]).max()
+
+
+@pytest.mark.parametrize("kind,args0,steps", [("modis", [0.1, 0.1, 0.1], [1e-3] * 3), ("kokhanovsky", [0.04], [1e-4])], ids=["modis", "kokhanovsky"])
+def test_brdf_argument_weighting_functions_match_central_differences_of_the_device_radiances(kind, args0, steps):
+    """tests/constituent/test_modis.py:103-160 / test_kokhanovsky.py: numeric_wf with a 0.001 step, decimal = 6."""
+    s = _scene(1, 4)
+    nw = len(s["albedo"])
+    args = _args(args0, nw)
+    eng = build_engine(s)
+    s["brdf"] = (kind, args)
+    base = run_product(s, derivatives=True, engine=eng)
+    for a, h in enumerate(steps):
+        ap, am = args.copy(), args.copy()
+        ap[:, a] += h
+        am[:, a] -= h
+        rp = run_product({**s, "brdf": (kind, ap)}, derivatives=False, engine=eng)["radiance"]
+        rm = run_product({**s, "brdf": (kind, am)}, derivatives=False, engine=eng)["radiance"]
+        fd = (rp - rm) / (2 * h)
+        assert np.max(np.abs(fd - base["d_brdf"][..., a])) < 1e-6 * np.abs(fd).max(), (kind, a)
+
+
+def test_brdf_results_do_not_depend_on_the_wavelength_block(monkeypatch):
+    s = _scene(1, 8, nw=7)
+    s["brdf"] = ("kokhanovsky", _args([0.04], 7))
+    whole = run_product(s, derivatives=True)
+    monkeypatch.setenv("SASKTRAN2_AMD_CHUNK", "3")
+    blocks = run_product(s, derivatives=True)
+    for k in ("radiance", "d_extinction", "d_brdf"):
+        assert np.array_equal(whole[k], blocks[k]), k
+
+
+def test_brdf_outside_the_served_configurations_is_refused_with_a_message():
+    s = sc.regression_1d(1)   # spherical post-processing
+    s["brdf"] = ("modis", _args([0.2, 0.05, 0.05], 1))
+    with pytest.raises(RuntimeError, match="non-Lambertian|-2"):
+        run_product(s, derivatives=False)
+    assert "non-Lambertian" in sk.last_error()

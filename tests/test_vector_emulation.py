@@ -146,3 +146,20 @@ def test_parked_eigen_stage_layout_is_bit_identical(vector, monkeypatch):
     parked = run_emulated_vector(s, derivatives=True)
     for k in ("radiance", "d_extinction", "d_ssa", "d_albedo"):
         assert np.array_equal(plain[k], parked[k]), k
+
+
+@pytest.mark.parametrize("vector", [False, True], ids=["NSTOKES=1", "NSTOKES=3"])
+@pytest.mark.parametrize("kind,args0", [("modis", [0.2, 0.05, 0.05]), ("kokhanovsky", [0.04])], ids=["modis", "kokhanovsky"])
+def test_brdf_surface_bodies_match_the_oracle(vector, kind, args0):
+    """Non-Lambertian ground in the run-time-n task bodies (reflection factors of surface_expand_pair, ground rows of kv2_bvp, ground operators
+    of kv2c_layer_ops, reflected intensity and adjoint seeds of kvpp_los, the BRDF-argument rows of the gradient) against the oracle."""
+    s = sc.nadir_c1(num_wavelengths=3, nstr=8)
+    if vector:
+        s = sc.to_vector(s, rayleigh_fraction=0.8)
+    args = np.tile(np.asarray(args0, dtype=float), (3, 1)) * np.linspace(1.0, 1.3, 3)[:, None]
+    from tests.test_oracle_golden import make_oracle
+    ref = make_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, brdf=(kind, args))
+    got = run_emulated_vector(s, derivatives=True, brdf=(kind, args))
+    assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-12 * np.abs(ref["radiance"]).max()
+    for k in ("d_extinction", "d_ssa", "d_brdf"):
+        assert np.max(np.abs(got[k] - ref[k])) < 1e-10 * np.abs(ref[k]).max(), k
