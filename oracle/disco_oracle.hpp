@@ -1298,7 +1298,13 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
 
 // ======================================================================================
 inline void Solver::accumulate_ground(int m, int szaidx) {
-    if (brdf_kind != 0) throw std::invalid_argument("oracle: non-Lambertian surfaces are restated for plane-parallel / pseudo-spherical post-processing only");
+    if (brdf_kind != 0) {
+        // a ground source per outgoing angle and order (do_source_diffuse_storage.cpp:435-695) is not restated: limb lines of sight only
+        for (int aidx = 0; aidx < G.nangle; ++aidx)
+            if (ground_slot[size_t(szaidx) * G.nangle + aidx] >= 0)
+                throw std::invalid_argument("oracle: non-Lambertian surfaces in spherical geometry are restated for lines of sight that do not end on the ground");
+        return;
+    }
     if (m >= 1) return;
     const int p = nlyr - 1, ls = ND ? lstart[p] : 0, nk = nl(p);
     const size_t nslot = npoint + nground;
@@ -1527,6 +1533,7 @@ inline void Solver::solve(const AtmosphereView& atm, int w, Result& res) {
         std::fill(converged.begin(), converged.end(), 0);
         for (int s = 0; s < G.nsza; ++s) {
             configure_layers(atm, w, s);
+            sample_surface();
             all_converged = false;
             for (int m = 0; m < nstr; ++m) {
                 expand_surface(m);

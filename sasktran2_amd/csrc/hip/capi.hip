@@ -1163,9 +1163,11 @@ int sk_engine_calculate_radiance(Engine* e, Atmosphere* atm, OutputC* out, int /
         // run-time-n kernels; other sources and the spherical post-processing (whose ground points would need a source per outgoing angle,
         // do_source_diffuse_storage.cpp:435-695) answer -2
         const bool brdf_surface = su.brdf && su.brdf->kind != 0;
-        if (brdf_surface && (e->ts || e->so || !e->dev || !e->dev->plane_parallel() || e->config.emission_source == 2 || e->nflux_obs > 0)) {
-            set_error("sk_engine_calculate_radiance: a non-Lambertian BRDF is served for multiple_scatter_source = discrete_ordinates with the single "
-                      "scatter inside it, in plane-parallel or pseudo-spherical geometry, without thermal source and flux observers");
+        const bool so_touches_ground = e->so && (e->so->has_successive_orders() || e->so->has_emission());
+        if (brdf_surface && (e->ts || !e->dev || so_touches_ground || (e->so && e->dev->plane_parallel()) || e->config.emission_source == 2 || e->nflux_obs > 0)) {
+            set_error("sk_engine_calculate_radiance: a non-Lambertian BRDF is served for multiple_scatter_source = discrete_ordinates -- in plane-parallel or "
+                      "pseudo-spherical geometry with the single scatter inside it, in spherical geometry for lines of sight that do not end on the ground -- "
+                      "without thermal source, successive orders and flux observers");
             return -2;
         }
         HostPhases ph;

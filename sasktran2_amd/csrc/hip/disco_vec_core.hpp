@@ -78,6 +78,7 @@ struct VBufs {
     // non-Lambertian surface (plane-parallel / pseudo-spherical post-processing): azimuth expansion of the BRDF per wavelength and order
     int brdf_kind;          // 0 Lambertian (Bufs::albedo), 1 SnowKokhanovsky, 2 MODIS (cpp/include/sasktran2/atmosphere/surface.h:151-352)
     int brdf_nargs;
+    int surf_nlos;          // lines of sight in the table: nlos with plane-parallel post-processing, 0 in spherical geometry (no ray may see the ground there)
     const double* surf;     // [w][m][1 + nargs][VSurf::NP]  reflection factors and their derivatives wrt the BRDF arguments (VSurf)
     double* surf_ops;       // [w][N][2 n + 1]  adjoint operators of the ground: Dinv^T e_t per incoming stream t, then I-_t at the ground
 };
@@ -98,7 +99,7 @@ struct VSurf {
     SKD_HD size_t per_order() const { return size_t(1 + nargs) * NP(); }
 };
 SKD_HD const double* vsurf_at(const VBufs& v, const Geo& g, int m, int w) {
-    return v.surf + (size_t(w) * g.nstr + m) * VSurf(g.N, g.nlos, v.brdf_nargs).per_order();
+    return v.surf + (size_t(w) * g.nstr + m) * VSurf(g.N, v.surf_nlos, v.brdf_nargs).per_order();
 }
 // gradient / native-derivative rows of BRDF argument a: the Lambertian albedo's rows for a = 0, rows behind the scattering groups' otherwise
 SKD_HD size_t surf_grad_row(const Geo& g, const VBufs& v, int a) { return a == 0 ? size_t(4 * g.nlyr) : size_t(4 * g.nlyr + 2 + v.ngroups * g.nlyr + (a - 1)); }
@@ -1517,7 +1518,7 @@ template <int GJ = 0> SKV_TEAM_BODY void kv2_bvp(const Team& team, const Geo& g,
     const bool brdf = v.brdf_kind != 0;                          // non-Lambertian surface: every order carries a ground reflection (VSurf)
     const double rho = (m == 0 && !brdf) ? b.albedo[w] : 0.0;   // Lambertian
     const double* sf = brdf ? vsurf_at(v, g, m, w) : nullptr;
-    const VSurf SF(N, g.nlos, v.brdf_nargs);
+    const VSurf SF(N, v.surf_nlos, v.brdf_nargs);
     const double kd = 2.0;
     const int mm = M2 * M2;
     // the register-resident inversions read the whole block before they write the inverse, and the block of the next layer is only built after
@@ -2293,14 +2294,15 @@ SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v,
         if (last && v.brdf_kind != 0) {
             // non-Lambertian ground (every order): the adjoint weight of incoming stream t is c_t = sum_i zB_i RS(i, t) + gw RL(los, t)
             const int N = g.N, los = int((tid / S) % g.nlos), na = v.brdf_nargs;
-            const VSurf SF(N, g.nlos, na);
+            const VSurf SF(N, v.surf_nlos, na);
             const double* sf = vsurf_at(v, g, m, w);
             const double* so = v.surf_ops + size_t(w) * N * (M2 + 1);
             const double Tg = b.T[size_t(nlyr) * nw + w];
             double ga[3] = {0, 0, 0}, gT = 0;
             for (int t = 0; t < N; ++t) {
-                double ct = gw * sf[SF.RL(los, t)], da[3] = {0, 0, 0};
-                for (int a = 0; a < na; ++a) da[a] = gw * sf[size_t(1 + a) * SF.NP() + SF.RL(los, t)];
+                const bool seen = v.surf_nlos > 0;   // (spherical geometry: no line of sight ends on the ground, gw = 0)
+                double ct = seen ? gw * sf[SF.RL(los, t)] : 0.0, da[3] = {0, 0, 0};
+                for (int a = 0; a < na && seen; ++a) da[a] = gw * sf[size_t(1 + a) * SF.NP() + SF.RL(los, t)];
                 for (int i = 0; i < N; ++i) {
                     const double zbi = v.z[(size_t(p) * M2 + n + i * S) * nt + tid];
                     ct += zbi * sf[SF.RS(i, t)];
@@ -2507,7 +2509,7 @@ SKV_TEAM_BODY void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, con
     int CH = team.width / NC;
     if (CH > 8) CH = 8;
     while (CH > 1 && CH * (NR + 1) > NL) --CH;
-    if (NG > 4 || CH < 2) {
+    if (NG > 4 || CH < 2 || v.brdf_kind != 0) {   // (a non-Lambertian ground weighs the ground rows stream by stream: the per-column form carries it)
         SKV_PAR(col, NC) adjoint_gradient_column(g, b, v, s, m, w, t0 + col, nt, gwv[col], true);
         team.sync();
         return;
@@ -2779,7 +2781,7 @@ SKD_HD void kvpp_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v
         // los_stream / los_solar expansions, sktran_do_layerarray.cpp:5-288)
         const double* c = vrec_at(v, nlyr, nlyr - 1, w);
         const double* xs = vxsol_at(v, nlyr, nlyr - 1, w);
-        const VSurf SF(N, g.nlos, v.brdf_nargs);
+        const VSurf SF(N, v.surf_nlos, v.brdf_nargs);
         const double* sf = vsurf_at(v, g, m, w);
         const double Tg = b.T[size_t(nlyr) * nw + w];
         double refl = 0;

@@ -225,7 +225,7 @@ struct SurfaceTables {
     std::vector<double> cw, factor0, factor, modis_ke, kok_r0, kok_kk;
     template <class KernelsFn, class PartsFn> void build(const GeoTables& t, KernelsFn modis_kernels, PartsFn kokhanovsky_parts) {
         const double pi = 3.14159265358979323846;
-        const int N = t.N, nlos = t.nlos;
+        const int N = t.N, nlos = t.pp_mu.empty() ? 0 : t.nlos;   // (spherical geometry: no line-of-sight pairs, no ray may end on the ground)
         nstr = t.nstr;
         NP = N * N + N + nlos * N + nlos;
         // the two 512-point Gauss-Legendre panels over the azimuth of SurfaceStorage::compute_expansion (sktran_do_surface.h:62-93)

@@ -103,8 +103,13 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     std::vector<double> surf, surf_ops;
     v.brdf_kind = h->brdf_kind;
     v.brdf_nargs = h->brdf_nargs;
+    v.surf_nlos = g.pp_mode ? nlos : 0;
     if (h->brdf_kind != 0) {
-        if (!g.pp_mode) return -2;
+        if (!g.pp_mode) {   // spherical geometry: limb lines of sight, one solar zenith index (as the device driver)
+            if (g.nsza != 1) return -2;
+            for (int l = 0; l < nlos; ++l)
+                if (t.ray_ground[l]) return -2;
+        }
         stab.build(t, [](double mi, double mo, double phi, double& kv, double& kg) { skv::modis_kernels(mi, mo, phi, kv, kg); },
                    [](double mi, double mo, double phi, double& r0, double& kk) { skv::kokhanovsky_parts(mi, mo, phi, r0, kk); });
         skv::SurfGeo sg{stab.NP, stab.NQ, stab.nstr, stab.cw.data(), stab.factor0.data(), stab.factor.data(), stab.modis_ke.data(), stab.kok_r0.data(), stab.kok_kk.data()};
@@ -193,6 +198,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                     for (int l3 = 0; l3 < nlos * S; ++l3) {
                         skd::k4a_chain(g3, b3, s, l3, w);
                         skv::kv4g_chain(g, b, v, w, size_t(w) * nlos * S + l3, nt3);
+                        if (v.brdf_kind != 0) skv::kv4s_chain(g, v, size_t(w) * nlos * S + l3, nt3);
                     }
             }
         }

@@ -76,7 +76,28 @@ def test_brdf_surface_changes_every_azimuth_order():
     assert np.max(np.abs(r_vol[:, 0] / r_vol[:, 1] - r_iso[:, 0] / r_iso[:, 1])) > 1e-3
 
 
-def test_brdf_in_spherical_post_processing_is_refused():
+def test_spherical_limb_geometry_lambertian_limit_and_central_differences():
+    """Spherical post-processing with lines of sight that do not end on the ground: the surface enters through the boundary-value problem."""
+    s = sc.limb_c2(num_wavelengths=2, nlyr=20, nstr=8)
+    s["rays"] = s["rays"][::6]
+    eng = make_oracle(s)
+    lam = eng.run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
+    a0 = np.zeros((2, 3))
+    a0[:, 0] = s["albedo"]
+    mod = _run(eng, s, ("modis", a0), derivatives=True)
+    assert np.max(np.abs(lam["radiance"] - mod["radiance"])) < 1e-13 * np.abs(lam["radiance"]).max()
+    assert np.max(np.abs(lam["d_albedo"] - mod["d_brdf"][..., 0])) < 1e-12 * np.abs(lam["d_albedo"]).max()
+    args = np.tile([0.2, 0.05, 0.05], (2, 1))
+    base = _run(eng, s, ("modis", args), derivatives=True)
+    for a in range(3):
+        ap, am = args.copy(), args.copy()
+        ap[:, a] += 1e-4
+        am[:, a] -= 1e-4
+        fd = (_run(eng, s, ("modis", ap))["radiance"] - _run(eng, s, ("modis", am))["radiance"]) / 2e-4
+        assert np.max(np.abs(fd - base["d_brdf"][..., a])) < 1e-6 * np.abs(fd).max(), a
+
+
+def test_brdf_under_lines_of_sight_that_end_on_the_ground_in_spherical_geometry_is_refused():
     s = sc.regression_1d(1)
     eng = make_oracle(s)
     with pytest.raises(RuntimeError):

@@ -53,6 +53,27 @@ def test_brdf_in_pseudo_spherical_geometry_matches_the_oracle():
         assert np.max(np.abs(got[k] - ref[k])) < 1e-8 * np.abs(ref[k]).max(), k
 
 
+@pytest.mark.parametrize("nstokes,nstr", [(1, 8), (1, 16), (3, 8)])
+@pytest.mark.parametrize("kind,args0", CASES, ids=[c[0] for c in CASES])
+def test_brdf_under_limb_lines_of_sight_in_spherical_geometry_matches_the_oracle(nstokes, nstr, kind, args0):
+    """The bench geometry (BASELINE configs[1]: spherical shell, tangent rays from 600 km) over a non-Lambertian ground: the surface enters
+    through the ground rows of the boundary-value problem of every azimuth order (and moves the limb radiance by tens of per cent)."""
+    s = sc.limb_c2(num_wavelengths=3, nlyr=20, nstr=nstr)
+    s["rays"] = s["rays"][::5]
+    if nstokes == 3:
+        s = sc.to_vector(s, rayleigh_fraction=0.8)
+    nw = 3
+    s["brdf"] = (kind, _args(args0, nw))
+    got = run_product(s, derivatives=True)
+    orc = make_oracle(s)
+    ref = orc.run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, brdf=s["brdf"])
+    lam = orc.run(s["extinction"], s["ssa"], s["leg"], s["albedo"])
+    assert np.max(np.abs(ref["radiance"] - lam["radiance"])) > 0.05 * np.abs(lam["radiance"]).max()
+    assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-10 * np.abs(ref["radiance"]).max()
+    for k in ("d_extinction", "d_ssa", "d_brdf"):
+        assert np.max(np.abs(got[k] - ref[k])) < 1e-8 * np.abs(ref[k]).max(), k
+
+
 def test_modis_with_its_isotropic_kernel_alone_equals_the_lambertian_surface_on_the_device():
     s = _scene(1, 8)
     nw = len(s["albedo"])
@@ -96,7 +117,7 @@ def test_brdf_results_do_not_depend_on_the_wavelength_block(monkeypatch):
 
 
 def test_brdf_outside_the_served_configurations_is_refused_with_a_message():
-    s = sc.regression_1d(1)   # spherical post-processing
+    s = sc.regression_1d(1)   # spherical post-processing with lines of sight that end on the ground
     s["brdf"] = ("modis", _args([0.2, 0.05, 0.05], 1))
     with pytest.raises(RuntimeError, match="non-Lambertian|-2"):
         run_product(s, derivatives=False)

@@ -163,3 +163,15 @@ def test_brdf_surface_bodies_match_the_oracle(vector, kind, args0):
     assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-12 * np.abs(ref["radiance"]).max()
     for k in ("d_extinction", "d_ssa", "d_brdf"):
         assert np.max(np.abs(got[k] - ref[k])) < 1e-10 * np.abs(ref[k]).max(), k
+
+
+def test_brdf_surface_bodies_in_spherical_limb_geometry_match_the_oracle():
+    s = sc.to_vector(sc.limb_c2(num_wavelengths=2, nlyr=20, nstr=8), rayleigh_fraction=0.8)
+    s["rays"] = s["rays"][::6]
+    args = np.tile([0.2, 0.05, 0.05], (2, 1)) * np.linspace(1.0, 1.3, 2)[:, None]
+    from tests.test_oracle_golden import make_oracle
+    ref = make_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, brdf=("modis", args))
+    got = run_emulated_vector(s, derivatives=True, brdf=("modis", args))
+    assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-12 * np.abs(ref["radiance"]).max()
+    for k in ("d_extinction", "d_ssa", "d_brdf"):
+        assert np.max(np.abs(got[k] - ref[k])) < 1e-10 * np.abs(ref[k]).max(), k
