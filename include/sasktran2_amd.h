@@ -255,7 +255,7 @@ void sk_amd_host_free(void* ptr);
  * libcsasktran2 by this library is a pure link-time choice.  Entry points outside the DISCO hot path keep the
  * reference's signatures; they store / return their settings where that is all they do, and report "unsupported"
  * (-2, or a null handle) where they would need an engine this build does not contain (2D geometry, flux weighting
- * functions, geodetic utilities, non-Lambertian BRDFs).  Flux observers are served by the plane-parallel discrete-ordinates source
+ * functions, geodetic utilities).  Flux observers are served by the plane-parallel discrete-ordinates source
  * (do_source_planeparallel.cpp:221-566): sk_output_create's flux block is [flux type][wavelength][observer] in the order of
  * sk_config_set_flux_types (0 upwelling, 1 downwelling, 2 actinic).  Reference line numbers as above.
  * ===================================================================================================================== */
@@ -332,7 +332,10 @@ int sk_surface_get_num_derivative_mappings(Surface* storage, int* num_mappings);
 int sk_surface_get_derivative_mapping_name(Surface* storage, int index, const char** name);    /* atmosphere.h:185 */
 int sk_surface_set_zero(Surface* storage);                                                     /* atmosphere.h:188 */
 
-/* brdf.h:10-14 -- handles can be created; a non-Lambertian BRDF makes sk_engine_calculate_radiance return -2 */
+/* brdf.h:10-14 -- SnowKokhanovsky (1 argument) and MODIS (isotropic, volumetric, geometric) surfaces: served by the discrete-ordinates source in
+ * plane-parallel / pseudo-spherical geometry and, for lines of sight that do not end on the ground, in spherical geometry; brdf_args of
+ * sk_surface_set_brdf is (num_args x num_wavel) column-major, a surface derivative mapping's d_brdf (num_wavel x num_args) column-major
+ * (create the mapping after sk_surface_set_brdf).  Other sources / geometries answer -2 with a message in sk_amd_last_error */
 BRDF* sk_brdf_create_kokhanovsky(int nstokes);                                                 /* brdf.h:10 */
 BRDF* sk_brdf_create_modis(int nstokes);                                                       /* brdf.h:11 */
 int sk_brdf_get_num_deriv(BRDF* config, int* num_deriv);                                       /* brdf.h:13 */
