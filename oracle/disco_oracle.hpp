@@ -113,6 +113,9 @@ inline double brdf_value(int kind, double mu_in, double mu_out, double phi, cons
         const BrdfKernels K = modis_kernels(mu_in, mu_out, phi);
         return (args[0] + args[1] * K.k_vol + args[2] * K.k_geo) / kPi;
     }
+    // kind 3 (oracle only): the functional BRDF of the reference's "BRDF surface" known answer, cpp/lib/tests/sktran_disco/legacy/test_scalar.cpp:806-845
+    // (abs(cos(caz_diff)) * abs(1 - abs(abs(out) - abs(in))) in the legacy convention rho = pi * brdf), scaled by args[0]
+    if (kind == 3) return args[0] * std::abs(std::cos(phi)) * std::abs(1 - std::abs(std::abs(mu_out) - std::abs(mu_in))) / kPi;
     return args[0] / kPi;
 }
 inline double brdf_deriv(int kind, int k, double mu_in, double mu_out, double phi, const double* args) {

@@ -144,7 +144,7 @@ int orc_set_flux_observers(void* hv, const double* altitudes, int n, double* flu
 // args [nwavel][nargs]; d_brdf_out [nwavel][nlos][S][nargs] receives the derivatives wrt the arguments (or null)
 int orc_set_brdf(void* hv, int kind, int nargs, const double* args, double* d_brdf_out) {
     auto* h = static_cast<Handle*>(hv);
-    if (!h || kind < 0 || kind > 2 || (kind != 0 && (!args || nargs != (kind == 2 ? 3 : 1)))) return -1;
+    if (!h || kind < 0 || kind > 3 || (kind != 0 && (!args || nargs != (kind == 2 ? 3 : 1)))) return -1;
     h->brdf_kind = kind;
     h->brdf_nargs = kind == 0 ? 1 : nargs;
     h->brdf_args = kind == 0 ? nullptr : args;

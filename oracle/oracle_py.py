@@ -150,7 +150,7 @@ class OracleEngine:
         lib().orc_set_forced_azimuth(self._h, int(forced_azimuth))
         bargs = dbr = None
         if brdf is not None:
-            kind = {"kokhanovsky": 1, "modis": 2}[brdf[0]]
+            kind = {"kokhanovsky": 1, "modis": 2, "legacy_test_function": 3}[brdf[0]]
             bargs = np.ascontiguousarray(brdf[1], dtype=np.float64).reshape(nwavel, -1)
             dbr = np.zeros(sshape + (bargs.shape[1],)) if derivatives else None
             L = lib()
