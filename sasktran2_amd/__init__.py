@@ -413,8 +413,11 @@ class Atmosphere:
     def register_surface_mapping(self, name, interpolator, interp_dim, d_brdf=1.0, d_emission=None):
         """a derivative with respect to a surface parameter: d(BRDF argument) and d(surface emission) per wavelength, and the
         [wavelength, parameter] interpolator its output goes through (None: one value per wavelength, src/sasktran2/engine.py:19-32)"""
+        d_brdf = np.asarray(d_brdf, dtype=float)
+        # one column per BRDF argument as the reference's mapping (num_wavel x num_args); a vector / scalar is the single argument of a Lambertian or Kokhanovsky surface
+        d_brdf = d_brdf.T if d_brdf.ndim == 2 else np.broadcast_to(d_brdf, (self._nwavel,))[None, :]
         self._surface_mappings[name] = (None if interpolator is None else np.asarray(interpolator, dtype=float), interp_dim,
-                                        np.broadcast_to(np.asarray(d_brdf, dtype=float), (self._nwavel,)),
+                                        np.ascontiguousarray(d_brdf),
                                         None if d_emission is None else np.broadcast_to(np.asarray(d_emission, dtype=float), (self._nwavel,)))
 
     def internal_object(self):
@@ -595,6 +598,35 @@ class Engine:
             if rc != 0:
                 raise RuntimeError(f"sk_atmosphere_apply_delta_m_scaling returned {rc}")
 
+    @staticmethod
+    def _surface_handles(L, atmosphere, S):
+        """BRDF and surface handles of a constituent atmosphere for one call (keeps the argument / emission arrays alive in the tuple)."""
+        nw = atmosphere._nwavel
+        if atmosphere.surface.brdf == "lambertian":
+            alb = np.ascontiguousarray(atmosphere.surface.albedo, dtype=float)
+        else:
+            alb = np.ascontiguousarray(np.asarray(atmosphere.surface.brdf_args, dtype=float).T)   # (num_args x num_wavel) column-major
+        emis = np.ascontiguousarray(atmosphere.surface.emission, dtype=float)
+        h_brdf = getattr(L, f"sk_brdf_create_{atmosphere.surface.brdf}")(S)
+        h_su = L.sk_surface_create(nw, S, _p(emis))
+        L.sk_surface_set_brdf(h_su, h_brdf, _p(alb))
+        return h_brdf, h_su, (alb, emis)
+
+    @staticmethod
+    def _fill_surface_mapping(L, h_su, atmosphere, name):
+        nw, nargs = atmosphere._nwavel, atmosphere.surface.num_brdf_args
+        _, _, d_brdf, d_emission = atmosphere._surface_mappings[name]
+        if d_brdf.shape != (nargs, nw):
+            raise ValueError(f"surface mapping {name!r} holds {d_brdf.shape[0]} BRDF argument(s), the surface has {nargs}")
+        m = ctypes.c_void_p()
+        L.sk_surface_get_derivative_mapping(h_su, name.encode(), ctypes.byref(m))
+        ptr = _dp()
+        L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
+        np.ctypeslib.as_array(ptr, shape=(nargs, nw))[:] = d_brdf
+        if d_emission is not None:
+            L.sk_surface_deriv_mapping_get_d_emission(m, ctypes.byref(ptr))
+            np.ctypeslib.as_array(ptr, shape=(nw,))[:] = d_emission
+
     @contextlib.contextmanager
     def _constituent_atmosphere(self, atmosphere):
         """Atmosphere handle of a constituent atmosphere for one call: the storage assembled in HBM by the front end, a surface with the
@@ -603,22 +635,11 @@ class Engine:
         L = lib()
         fe = atmosphere.internal_object()
         nw, S = atmosphere._nwavel, int(self._config.num_stokes)
-        alb = np.ascontiguousarray(atmosphere.surface.albedo, dtype=float)
-        emis = np.ascontiguousarray(atmosphere.surface.emission, dtype=float)
-        h_brdf = L.sk_brdf_create_lambertian(S)
-        h_su = L.sk_surface_create(nw, S, _p(emis))
-        L.sk_surface_set_brdf(h_su, h_brdf, _p(alb))
+        h_brdf, h_su, _keep = self._surface_handles(L, atmosphere, S)
         h_atm = L.sk_atmosphere_create(fe.storage_handle(), h_su, int(atmosphere.calculate_derivatives), 0)
         try:
-            for name, (_, _, d_brdf, d_emission) in atmosphere._surface_mappings.items():
-                m = ctypes.c_void_p()
-                L.sk_surface_get_derivative_mapping(h_su, name.encode(), ctypes.byref(m))
-                ptr = _dp()
-                L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
-                np.ctypeslib.as_array(ptr, shape=(nw,))[:] = d_brdf
-                if d_emission is not None:
-                    L.sk_surface_deriv_mapping_get_d_emission(m, ctypes.byref(ptr))
-                    np.ctypeslib.as_array(ptr, shape=(nw,))[:] = d_emission
+            for name in atmosphere._surface_mappings:
+                self._fill_surface_mapping(L, h_su, atmosphere, name)
             if self._config.delta_m_scaling and atmosphere.num_moments > self._config.num_streams:
                 rc = L.sk_atmosphere_apply_delta_m_scaling(h_atm, int(self._config.num_streams))
                 if rc != 0:
@@ -806,11 +827,7 @@ class Engine:
         fe = atmosphere.internal_object()
         nw, nlos, S = atmosphere._nwavel, self.nlos, int(self._config.num_stokes)
         derivs = atmosphere.calculate_derivatives
-        alb = np.ascontiguousarray(atmosphere.surface.albedo, dtype=float)
-        emis = np.ascontiguousarray(atmosphere.surface.emission, dtype=float)
-        h_brdf = L.sk_brdf_create_lambertian(S)
-        h_su = L.sk_surface_create(nw, S, _p(emis))
-        L.sk_surface_set_brdf(h_su, h_brdf, _p(alb))
+        h_brdf, h_su, _keep = self._surface_handles(L, atmosphere, S)
         h_atm = L.sk_atmosphere_create(fe.storage_handle(), h_su, int(derivs), 0)
         rad = np.zeros((nw, nlos, S))
         flux, flux_names = self._flux_output(nw)
@@ -822,14 +839,7 @@ class Engine:
                     raw[name] = _host.empty((m.num_output, nw, nlos, S))
                     L.sk_output_assign_derivative_memory(h_out, name.encode(), _p(raw[name]), nw * nlos, S, m.num_output)
                 for name in atmosphere._surface_mappings:
-                    m = ctypes.c_void_p()
-                    L.sk_surface_get_derivative_mapping(h_su, name.encode(), ctypes.byref(m))
-                    ptr = _dp()
-                    L.sk_surface_deriv_mapping_get_d_brdf(m, ctypes.byref(ptr))
-                    np.ctypeslib.as_array(ptr, shape=(nw,))[:] = atmosphere._surface_mappings[name][2]
-                    if atmosphere._surface_mappings[name][3] is not None:
-                        L.sk_surface_deriv_mapping_get_d_emission(m, ctypes.byref(ptr))
-                        np.ctypeslib.as_array(ptr, shape=(nw,))[:] = atmosphere._surface_mappings[name][3]
+                    self._fill_surface_mapping(L, h_su, atmosphere, name)
                     raw_surface[name] = np.zeros((nw, nlos, S))
                     L.sk_output_assign_surface_derivative_memory(h_out, name.encode(), _p(raw_surface[name]), nw * nlos, S)
             # src/sasktran2/atmosphere.py:845-854: scale when more moments are stored than streams are used

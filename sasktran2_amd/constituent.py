@@ -431,7 +431,89 @@ class LambertianSurface(Constituent):
         return linear_interpolating_matrix(self._x, grid, self._mode)
 
     def add_to_atmosphere(self, atmo):
+        if atmo.surface.brdf != "lambertian":
+            atmo.surface.set_brdf("lambertian")
         atmo.surface.albedo[:] = self._interpolating_matrix(atmo) @ self.albedo
 
     def register_derivative(self, atmo, name):
         atmo.register_surface_mapping(f"wf_{name}_albedo", self._interpolating_matrix(atmo), f"{name}_wavelength")
+
+
+class _WavelengthParameters:
+    """Parameters given as scalars, on the atmosphere's wavelength grid, or interpolated from `wavelengths_nm`
+    (WavelengthInterpolatorMixin, src/sasktran2/constituent/brdf/__init__.py)."""
+
+    def _setup_wavelengths(self, wavelengths_nm, out_of_bounds_mode, param_length):
+        self._mode = out_of_bounds_mode.lower()
+        self._x = None if wavelengths_nm is None else np.atleast_1d(np.asarray(wavelengths_nm, dtype=float))
+        self._param_length = param_length
+
+    def _interpolating_matrix(self, atmo):
+        if self._x is None:
+            if self._param_length == 1:
+                return np.ones((atmo.num_wavel, 1))
+            if self._param_length != atmo.num_wavel:
+                raise ValueError("The number of surface parameter values must match the number of wavelengths in the atmosphere")
+            return np.eye(atmo.num_wavel)
+        if atmo.wavelengths_nm is None:
+            raise ValueError("The atmosphere does not have wavelengths_nm defined, cannot interpolate the surface parameters")
+        return linear_interpolating_matrix(self._x, atmo.wavelengths_nm, self._mode)
+
+
+class MODIS(Constituent, _WavelengthParameters):
+    """Kernel-driven BRDF of the MODIS products: isotropic + volumetric (Ross-thick) + geometric (Li-sparse-R) weights
+    (src/sasktran2/constituent/brdf/modis.py; cpp/include/sasktran2/atmosphere/surface.h:236-352).  Weighting functions
+    `wf_{name}_isotropic`, `wf_{name}_volumetric`, `wf_{name}_geometric`."""
+
+    def __init__(self, isotropic, volumetric=0.0, geometric=0.0, wavelengths_nm=None, out_of_bounds_mode="zero"):
+        self.isotropic = np.atleast_1d(np.asarray(isotropic, dtype=float))
+        self.volumetric = np.atleast_1d(np.asarray(volumetric, dtype=float))
+        self.geometric = np.atleast_1d(np.asarray(geometric, dtype=float))
+        self._setup_wavelengths(wavelengths_nm, out_of_bounds_mode, len(self.isotropic))
+
+    def add_to_atmosphere(self, atmo):
+        atmo.surface.set_brdf("modis")
+        m = self._interpolating_matrix(atmo)
+        for a, p in enumerate((self.isotropic, self.volumetric, self.geometric)):
+            atmo.surface.brdf_args[a, :] = m @ (p if len(p) == m.shape[1] else np.broadcast_to(p, (m.shape[1],)))
+
+    def register_derivative(self, atmo, name):
+        m = self._interpolating_matrix(atmo)
+        for a, part in enumerate(("isotropic", "volumetric", "geometric")):
+            d = np.zeros((atmo.num_wavel, 3))
+            d[:, a] = 1.0
+            atmo.register_surface_mapping(f"wf_{name}_{part}", m, f"{name}_wavelength", d_brdf=d)
+
+
+class SnowKokhanovsky(Constituent, _WavelengthParameters):
+    """Snow BRDF of Kokhanovsky with grain parameters L and M (src/sasktran2/constituent/brdf/kokhanovsky.py; surface.h:151-229): the BRDF
+    argument is (chi + M) L / wavelength_nm with chi the imaginary part of the refractive index of ice.  The reference reads chi from its ice
+    data base, which this build does not carry: `refractive_index_fn(wavelengths_nm)` has to return the complex refractive index (imaginary
+    part negative, as the reference's `RefractiveIndex.refractive_index`).  Weighting functions `wf_{name}_L`, `wf_{name}_M`."""
+
+    def __init__(self, L=3_600_000.0, M=5.5e-8, refractive_index_fn=None, wavelengths_nm=None, out_of_bounds_mode="zero"):
+        if refractive_index_fn is None:
+            raise ValueError("SnowKokhanovsky: pass refractive_index_fn (the reference's ice refractive-index table is not part of this build)")
+        self.L = np.atleast_1d(np.asarray(L, dtype=float))
+        self.M = np.atleast_1d(np.asarray(M, dtype=float))
+        self._n = refractive_index_fn.refractive_index if hasattr(refractive_index_fn, "refractive_index") else refractive_index_fn
+        self._setup_wavelengths(wavelengths_nm, out_of_bounds_mode, len(self.L))
+
+    def _factors(self, atmo):
+        if atmo.wavelengths_nm is None:
+            raise ValueError("Atmosphere must have wavelengths defined before using SnowKokhanovsky")
+        m = self._interpolating_matrix(atmo)
+        chi = -np.imag(np.asarray(self._n(atmo.wavelengths_nm)))
+        expand = lambda p: m @ (p if len(p) == m.shape[1] else np.broadcast_to(p, (m.shape[1],)))  # noqa: E731
+        return m, chi, expand(self.L), expand(self.M)
+
+    def add_to_atmosphere(self, atmo):
+        atmo.surface.set_brdf("kokhanovsky")
+        _, chi, L_, M_ = self._factors(atmo)
+        atmo.surface.brdf_args[0, :] = (chi + M_) * L_ / atmo.wavelengths_nm
+
+    def register_derivative(self, atmo, name):
+        m, chi, L_, M_ = self._factors(atmo)
+        atmo.register_surface_mapping(f"wf_{name}_L", m, f"{name}_wavelength", d_brdf=(chi + M_) / atmo.wavelengths_nm)
+        atmo.register_surface_mapping(f"wf_{name}_M", m, f"{name}_wavelength", d_brdf=L_ / atmo.wavelengths_nm)
+

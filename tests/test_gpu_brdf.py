@@ -122,3 +122,61 @@ def test_brdf_outside_the_served_configurations_is_refused_with_a_message():
     with pytest.raises(RuntimeError, match="non-Lambertian|-2"):
         run_product(s, derivatives=False)
     assert "non-Lambertian" in sk.last_error()
+
+
+# ---- the constituent interface, as tests/constituent/test_modis.py / test_kokhanovsky.py of the reference drive it (their pseudo-spherical
+#      discrete-ordinates scenario: 4 streams, one ground-viewing ray; their criterion: analytic = numeric weighting function, decimal = 6)
+def _constituent_scene(sk, surface, derivs=True):
+    from tests.test_gpu_frontend import _config
+    c = sc.frontend_case(nwavel=5)
+    cfg = _config(sk, streams=4, moments=4, delta_m_scaling=False)
+    geo = sk.Geometry1D(0.6, 0.0, 6372000.0, c["altitudes"], sk.InterpolationMethod.LinearInterpolation, sk.GeometryType.PseudoSpherical)
+    vg = sk.ViewingGeometry()
+    vg.add_ray(sk.GroundViewingSolar(0.6, 0.3, 0.5, 200000.0))
+    engine = sk.Engine(cfg, geo, vg)
+    atmo = sc.frontend_product_atmosphere(sk, c, geo, cfg, calculate_derivatives=derivs)
+    atmo["surface"] = surface
+    return engine, atmo
+
+
+def test_modis_constituent_weighting_functions_match_numeric_ones():
+    surface = sk.constituent.MODIS(isotropic=0.1, volumetric=0.1, geometric=0.1)
+    engine, atmo = _constituent_scene(sk, surface)
+    base = engine.calculate_radiance(atmo, as_dataset=False)
+    assert np.all(np.isfinite(base["radiance"]))
+    for part in ("isotropic", "volumetric", "geometric"):
+        wf = base[f"wf_surface_{part}"]
+        assert wf.shape == (1, 5, 1, 1)   # one (wavelength-independent) parameter x wavelength x los x stokes
+        h = 0.001
+        vals = {}
+        for sign in (+1, -1):
+            setattr(surface, part, getattr(surface, part) + sign * h)
+            vals[sign] = engine.calculate_radiance(atmo, as_dataset=False)["radiance"]
+            setattr(surface, part, getattr(surface, part) - sign * h)
+        fd = (vals[+1] - vals[-1]) / (2 * h)
+        assert np.max(np.abs(wf[0] - fd)) < 1e-6 * np.abs(fd).max(), part
+
+
+def test_kokhanovsky_constituent_weighting_functions_match_numeric_ones():
+    ice = lambda wl: 1.31 - 1j * 2e-9 * (np.asarray(wl) / 500.0) ** 2    # a smooth stand-in for the ice data base the reference reads  # noqa: E731
+    surface = sk.constituent.SnowKokhanovsky(L=3.6e6, M=5.5e-8, refractive_index_fn=ice)
+    engine, atmo = _constituent_scene(sk, surface)
+    base = engine.calculate_radiance(atmo, as_dataset=False)
+    assert np.all(base["radiance"] > 0)
+    for part, h in (("L", 3.6e3), ("M", 5.5e-11)):
+        wf = base[f"wf_surface_{part}"]
+        vals = {}
+        for sign in (+1, -1):
+            setattr(surface, part, getattr(surface, part) + sign * h)
+            vals[sign] = engine.calculate_radiance(atmo, as_dataset=False)["radiance"]
+            setattr(surface, part, getattr(surface, part) - sign * h)
+        fd = (vals[+1] - vals[-1]) / (2 * h)
+        assert np.max(np.abs(wf[0] - fd)) < 1e-6 * np.abs(fd).max(), part
+
+
+def test_a_lambertian_constituent_after_a_brdf_constituent_restores_the_lambertian_surface():
+    engine, atmo = _constituent_scene(sk, sk.constituent.MODIS(isotropic=0.3), derivs=False)
+    modis = engine.calculate_radiance(atmo, as_dataset=False)["radiance"]
+    atmo["surface"] = sk.constituent.LambertianSurface(0.3)
+    lam = engine.calculate_radiance(atmo, as_dataset=False)["radiance"]
+    assert np.max(np.abs(modis - lam)) < 1e-12 * np.abs(lam).max()   # MODIS with the isotropic kernel alone IS the Lambertian surface
