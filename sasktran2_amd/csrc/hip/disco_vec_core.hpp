@@ -101,6 +101,7 @@ struct VSurf {
 SKD_HD const double* vsurf_at(const VBufs& v, const Geo& g, int m, int w) {
     return v.surf + (size_t(w) * g.nstr + m) * VSurf(g.N, v.surf_nlos, v.brdf_nargs).per_order();
 }
+constexpr int kMaxGroupsWithBrdf = 8;   // scattering groups served together with a non-Lambertian surface
 // gradient / native-derivative rows of BRDF argument a: the Lambertian albedo's rows for a = 0, rows behind the scattering groups' otherwise
 SKD_HD size_t surf_grad_row(const Geo& g, const VBufs& v, int a) { return a == 0 ? size_t(4 * g.nlyr) : size_t(4 * g.nlyr + 2 + v.ngroups * g.nlyr + (a - 1)); }
 SKD_HD size_t surf_dnat_row(const Geo& g, const VBufs& v, int a) { return a == 0 ? size_t(2 * g.ngrid) : size_t(2 * g.ngrid + 1 + v.ngroups * g.ngrid + (a - 1)); }
@@ -2321,6 +2322,18 @@ SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v,
         }
         for (int t = 0; t < 4; ++t) v.grad[size_t(t * nlyr + p) * nt + tid] += gth[t];
         // scattering groups: the same contraction with the group's DI / HD / GD rows
+        double ggb[kMaxGroupsWithBrdf];   // non-Lambertian ground: sum_t c_t (d I-_t / d group at fixed L, M), the counterpart of (zBsum + gw) GGD
+        for (int gi = 0; gi < kMaxGroupsWithBrdf; ++gi) ggb[gi] = 0;
+        if (last && v.brdf_kind != 0 && v.ngroups > 0) {
+            const int N = g.N, los = int((tid / S) % g.nlos);
+            const VSurf SF(N, v.surf_nlos, v.brdf_nargs);
+            const double* sf = vsurf_at(v, g, m, w);
+            for (int t = 0; t < N; ++t) {
+                double ct = (v.surf_nlos > 0) ? gw * sf[SF.RL(los, t)] : 0.0;
+                for (int i = 0; i < N; ++i) ct += v.z[(size_t(p) * M2 + n + i * S) * nt + tid] * sf[SF.RS(i, t)];
+                for (int gi = 0; gi < v.ngroups && gi < kMaxGroupsWithBrdf; ++gi) ggb[gi] += ct * ops[O.GDI(gi) + 2 * n + t * S];
+            }
+        }
         for (int gi = 0; gi < v.ngroups; ++gi) {
             double gg = 0;
             for (int i = 0; i < n; ++i) {
@@ -2332,7 +2345,8 @@ SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v,
             }
             if (table_weights)
                 for (int l = m * C; l < NL; ++l) gg += ops[O.GHD(gi) + l] * v.qlbuf[(size_t(p) * NL + l) * nt + tid];
-            if (last && m == 0) gg += (zBsum + gw) * ops[O.GGD(gi)];
+            if (last && m == 0 && v.brdf_kind == 0) gg += (zBsum + gw) * ops[O.GGD(gi)];
+            if (last && v.brdf_kind != 0 && gi < kMaxGroupsWithBrdf) gg += ggb[gi];
             v.grad[size_t(4 * nlyr + 2 + gi * nlyr + p) * nt + tid] += gg;
         }
     }

@@ -175,3 +175,39 @@ def test_brdf_surface_bodies_in_spherical_limb_geometry_match_the_oracle():
     assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-12 * np.abs(ref["radiance"]).max()
     for k in ("d_extinction", "d_ssa", "d_brdf"):
         assert np.max(np.abs(got[k] - ref[k])) < 1e-10 * np.abs(ref[k]).max(), k
+
+
+def _mixture_nadir(x):
+    """As _mixture_spherical on the plane-parallel nadir scene (21 levels, 8 streams): a scattering constituent with profile x over the background."""
+    s = sc.nadir_c1(num_wavelengths=1, nstr=8)
+    ka, nl = s["extinction"], 8
+    wa = np.full_like(ka, 0.9)
+    l = np.arange(nl)
+    ba = np.zeros(nl)
+    ba[0], ba[2] = 1.0, 0.5
+    bc = (2 * l + 1) * 0.6 ** l
+    e, wc = 0.3 * ka, 0.95
+    k = ka + x[:, None] * e
+    sca = ka * wa + x[:, None] * e * wc
+    beta = ((ka * wa)[None] * ba[:, None, None] + (x[:, None] * e * wc)[None] * bc[:, None, None]) / sca[None]
+    out = dict(s, extinction=k, ssa=sca / k, leg=beta)
+    return out, dict(d_extinction=e, d_ssa=e * (wc - sca / k) / k, scat_factor=e * wc / sca, d_legendre=bc[:, None, None] - beta)
+
+
+def test_scattering_group_derivatives_over_a_brdf_surface_match_finite_differences_emulated():
+    """The scattering constituent's weighting function when the ground is not Lambertian: the ground rows of the group's gradient weigh the
+    incoming streams one by one (c_t = sum_i zB_i RS(i, t) + gw RL(los, t)) instead of through the rank-one Lambertian sums."""
+    brdf = ("modis", np.array([[0.25, 0.08, 0.03]]))
+    x0 = np.ones(21)
+    s, mp = _mixture_nadir(x0)
+    out = run_emulated_vector(s, derivatives=True, d_legendre=[mp["d_legendre"]], brdf=brdf)
+    for q in (0, 4, 10):   # (levels where the weighting function is large enough for central differences: 1e-3 of it at 100 km is their noise)
+        h = 1e-5
+        xp, xm = x0.copy(), x0.copy()
+        xp[q] += h
+        xm[q] -= h
+        fd = (run_emulated_vector(_mixture_nadir(xp)[0], brdf=brdf)["radiance"] - run_emulated_vector(_mixture_nadir(xm)[0], brdf=brdf)["radiance"]) / (2 * h)
+        scat = out["d_scat"][:, :, 0, q]
+        an = mp["d_extinction"][q, 0] * out["d_extinction"][..., q] + mp["d_ssa"][q, 0] * out["d_ssa"][..., q] + mp["scat_factor"][q, 0] * scat
+        assert np.abs(mp["scat_factor"][q, 0] * scat).max() > 0.05 * np.abs(an).max()
+        assert np.abs(fd - an).max() < 1e-6 * np.abs(an).max(), q
