@@ -649,7 +649,7 @@ class Engine:
             L.sk_atmosphere_destroy(h_atm)
             L.sk_surface_destroy(h_su)
             L.sk_brdf_destroy(h_brdf)
-            del alb, emis
+            del _keep
 
     def calculate_jvp(self, atmosphere, tangents, surface_tangents=None):
         """Jacobian-vector product (src/sasktran2/engine.py:170-312, `sk_engine_calculate_jvp`): `tangents` maps a derivative-mapping
