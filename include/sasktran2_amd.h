@@ -338,6 +338,8 @@ int sk_surface_set_zero(Surface* storage);                                      
  * (create the mapping after sk_surface_set_brdf).  Other sources / geometries answer -2 with a message in sk_amd_last_error */
 BRDF* sk_brdf_create_kokhanovsky(int nstokes);                                                 /* brdf.h:10 */
 BRDF* sk_brdf_create_modis(int nstokes);                                                       /* brdf.h:11 */
+/* additive: the functional BRDF of the reference's "BRDF surface" known answer (legacy/test_scalar.cpp:806-845), one scale argument; for the parity suite */
+BRDF* sk_amd_brdf_create_legacy_test_function(int nstokes);
 int sk_brdf_get_num_deriv(BRDF* config, int* num_deriv);                                       /* brdf.h:13 */
 int sk_brdf_get_num_args(BRDF* config, int* num_args);                                         /* brdf.h:14 */
 

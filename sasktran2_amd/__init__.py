@@ -276,7 +276,8 @@ class _Surface:
     other BRDFs (cpp/include/sasktran2/atmosphere/surface.h:151-352) and allocates `brdf_args[argument, wavelength]` as the reference's
     `Surface.brdf_args` (SnowKokhanovsky: (chi + M) L / wavelength; MODIS: isotropic, volumetric, geometric); their weighting functions come
     back as `wf_brdf[argument, wavelength, los, stokes]`.  Served by the discrete-ordinates source in plane-parallel / pseudo-spherical geometry."""
-    _NARGS = {"lambertian": 1, "kokhanovsky": 1, "modis": 3}
+    _NARGS = {"lambertian": 1, "kokhanovsky": 1, "modis": 3, "legacy_test_function": 1}   # (the last: the reference's functional-BRDF known answer, parity suite only)
+    _CREATE = {"legacy_test_function": "sk_amd_brdf_create_legacy_test_function"}
 
     def __init__(self, nwavel):
         self.albedo = np.zeros(nwavel)
@@ -479,7 +480,7 @@ class Atmosphere:
                                                           _p(H["ext"]), _p(H["em"]), _p(H["leg"]), _p(H["irr"]))
             H["brdf_kind"] = self.surface.brdf
             H["alb"] = np.zeros((self._nwavel, self.surface.num_brdf_args))   # (num_args x num_wavel) column-major, surface.h:366-372
-            H["brdf"] = getattr(L, f"sk_brdf_create_{self.surface.brdf}")(nstokes)
+            H["brdf"] = getattr(L, _Surface._CREATE.get(self.surface.brdf, f"sk_brdf_create_{self.surface.brdf}"))(nstokes)
             H["surface"] = L.sk_surface_create(self._nwavel, nstokes, _p(H["emis"]))
             L.sk_surface_set_brdf(H["surface"], H["brdf"], _p(H["alb"]))
             H["atmosphere"] = L.sk_atmosphere_create(H["storage"], H["surface"], int(self._calculate_derivatives), 0)
@@ -607,7 +608,7 @@ class Engine:
         else:
             alb = np.ascontiguousarray(np.asarray(atmosphere.surface.brdf_args, dtype=float).T)   # (num_args x num_wavel) column-major
         emis = np.ascontiguousarray(atmosphere.surface.emission, dtype=float)
-        h_brdf = getattr(L, f"sk_brdf_create_{atmosphere.surface.brdf}")(S)
+        h_brdf = getattr(L, _Surface._CREATE.get(atmosphere.surface.brdf, f"sk_brdf_create_{atmosphere.surface.brdf}"))(S)
         h_su = L.sk_surface_create(nw, S, _p(emis))
         L.sk_surface_set_brdf(h_su, h_brdf, _p(alb))
         return h_brdf, h_su, (alb, emis)

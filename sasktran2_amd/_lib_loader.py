@@ -53,7 +53,7 @@ SIGNATURES = [
     ("sk_deriv_mapping_get_num_location", _I, [_vp, _ip]), ("sk_deriv_mapping_get_num_wavel", _I, [_vp, _ip]),
     ("sk_deriv_mapping_get_num_output", _I, [_vp, _ip]), ("sk_deriv_mapping_set_zero", _I, [_vp]),
     ("sk_brdf_create_lambertian", _vp, [_I]), ("sk_brdf_destroy", None, [_vp]),
-    ("sk_brdf_create_kokhanovsky", _vp, [_I]), ("sk_brdf_create_modis", _vp, [_I]),
+    ("sk_brdf_create_kokhanovsky", _vp, [_I]), ("sk_brdf_create_modis", _vp, [_I]), ("sk_amd_brdf_create_legacy_test_function", _vp, [_I]),
     ("sk_surface_create", _vp, [_I, _I, _dp]), ("sk_surface_destroy", None, [_vp]),
     ("sk_surface_set_brdf", _I, [_vp, _vp, _dp]),
     ("sk_surface_get_derivative_mapping", _I, [_vp, _S, ctypes.POINTER(_vp)]),

@@ -616,7 +616,7 @@ void DeviceEngine::set_flux_output(double* d_flux, const std::vector<int>& types
 }
 int DeviceEngine::num_flux_observers() const { return impl_->nfx; }
 void DeviceEngine::set_surface_brdf(int kind, int nargs, const double* d_args) {
-    if (kind < 0 || kind > 2 || (kind != 0 && (!d_args || nargs != (kind == 2 ? 3 : 1)))) throw std::runtime_error("sasktran2_amd: bad BRDF kind / argument count");
+    if (kind < 0 || kind > 3 || (kind != 0 && (!d_args || nargs != (kind == 2 ? 3 : 1)))) throw std::runtime_error("sasktran2_amd: bad BRDF kind / argument count");
     impl_->brdf_kind = kind;
     impl_->brdf_nargs = kind == 0 ? 1 : nargs;
     impl_->brdf_args = kind == 0 ? nullptr : d_args;

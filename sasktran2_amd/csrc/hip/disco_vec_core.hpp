@@ -134,7 +134,7 @@ struct SurfGeo {
     const double* cw;        // [m][q]
     const double* factor0;   // [pair] order 0
     const double* factor;    // [pair] orders > 0
-    const double* modis_ke;  // [2][m][pair] expansions of k_vol, k_geo (already without the 1 / pi)
+    const double* modis_ke;  // [3][m][pair] expansions of k_vol, k_geo (already without the 1 / pi) and of the test function of kind 3
     const double* kok_r0;    // [pair][q]
     const double* kok_kk;    // [pair]
 };
@@ -142,6 +142,16 @@ struct SurfGeo {
 SKD_HD void surface_expand_pair(const SurfGeo& sg, int kind, int nargs, const double* args, int pair, double* out) {
     const int NP = sg.NP, nstr = sg.nstr;
     const size_t po = size_t(1 + nargs) * NP;
+    if (kind == 3) {
+        // the functional BRDF of the reference's "BRDF surface" known answer (legacy/test_scalar.cpp:806-845), scaled by its one argument: only
+        // reachable through sk_amd_brdf_create_legacy_test_function, for the parity test of that case
+        for (int m = 0; m < nstr; ++m) {
+            const double f = (m == 0) ? sg.factor0[pair] : sg.factor[pair], ke = sg.modis_ke[(size_t(2) * nstr + m) * NP + pair];
+            out[m * po + pair] = f * args[0] * ke;
+            out[m * po + size_t(1) * NP + pair] = f * ke;
+        }
+        return;
+    }
     if (kind == 2) {
         for (int m = 0; m < nstr; ++m) {
             const double f = (m == 0) ? sg.factor0[pair] : sg.factor[pair];

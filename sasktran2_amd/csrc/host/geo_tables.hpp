@@ -255,7 +255,7 @@ struct SurfaceTables {
             for (int tt = 0; tt < N; ++tt) set(N * N + N + l * N + tt, t.pp_mu[l], t.mu[tt], tt);
             set(N * N + N + nlos * N + l, t.pp_mu[l], csz0, -1);
         }
-        modis_ke.assign(size_t(2) * nstr * NP, 0.0);
+        modis_ke.assign(size_t(3) * nstr * NP, 0.0);
         kok_r0.resize(size_t(NP) * NQ); kok_kk.resize(NP);
         for (int pr = 0; pr < NP; ++pr) {
             for (int q = 0; q < NQ; ++q) {
@@ -268,6 +268,8 @@ struct SurfaceTables {
                     const double c = cw[size_t(m) * NQ + q] / pi;   // the kernels enter the BRDF divided by pi
                     modis_ke[(size_t(0) * nstr + m) * NP + pr] += c * kv;
                     modis_ke[(size_t(1) * nstr + m) * NP + pr] += c * kg;
+                    // kind 3: abs(cos(caz_diff)) * abs(1 - abs(abs(out) - abs(in))) in the legacy convention rho = pi * brdf (test_scalar.cpp:826-831)
+                    modis_ke[(size_t(2) * nstr + m) * NP + pr] += c * std::abs(std::cos(pi * aq[q])) * std::abs(1 - std::abs(std::abs(mo[pr]) - std::abs(mi[pr])));
                 }
             }
         }

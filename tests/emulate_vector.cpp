@@ -53,7 +53,7 @@ void* emuv_create(double cos_sza, double saa, double earth_radius, const double*
 void emuv_destroy(void* h) { delete static_cast<Handle*>(h); }
 int emuv_set_brdf(void* hv, int kind, int nargs, const double* args, double* d_brdf_out) {
     auto* h = static_cast<Handle*>(hv);
-    if (!h || kind < 0 || kind > 2) return -1;
+    if (!h || kind < 0 || kind > 3) return -1;
     h->brdf_kind = kind;
     h->brdf_nargs = kind == 0 ? 1 : nargs;
     h->brdf_args = kind == 0 ? nullptr : args;

@@ -149,7 +149,7 @@ def run_emulated_vector(s, derivatives=False, d_legendre=None, brdf=None):
             dsc = np.zeros((nw, nlos, S, G, ngrid))
         dbr = None
         if brdf is not None:   # (kind, args [nwavel, nargs]): non-Lambertian surface, plane-parallel / pseudo-spherical post-processing
-            kind = {"kokhanovsky": 1, "modis": 2}[brdf[0]]
+            kind = {"kokhanovsky": 1, "modis": 2, "legacy_test_function": 3}[brdf[0]]
             bargs = np.ascontiguousarray(brdf[1], dtype=np.float64).reshape(nw, -1)
             dbr = np.zeros((nw, nlos, S, bargs.shape[1])) if derivatives else None
             L.emuv_set_brdf.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp]

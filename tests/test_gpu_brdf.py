@@ -180,3 +180,24 @@ def test_a_lambertian_constituent_after_a_brdf_constituent_restores_the_lamberti
     atmo["surface"] = sk.constituent.LambertianSurface(0.3)
     lam = engine.calculate_radiance(atmo, as_dataset=False)["radiance"]
     assert np.max(np.abs(modis - lam)) < 1e-12 * np.abs(lam).max()   # MODIS with the isotropic kernel alone IS the Lambertian surface
+
+
+def test_the_references_functional_brdf_known_answer_on_the_device():
+    """cpp/lib/tests/sktran_disco/legacy/test_scalar.cpp:806-845 ("BRDF surface": 32 streams, 35 lines of sight, a functional BRDF; disabled in the
+    reference, its numbers are those of the legacy model): the device equals the oracle and both reproduce the 35 radiances to the truncation
+    error of the azimuth expansion at the BRDF's kink (tests/test_brdf_oracle.py, tests/golden/do_scalar_brdf_legacy.json)."""
+    import json
+    from pathlib import Path
+    root = Path(__file__).parent / "golden"
+    gold = json.loads((root / "do_scalar_brdf_legacy.json").read_text())
+    cases = json.loads((root / "do_scalar_planeparallel.json").read_text())["cases"]
+    s = sc.planeparallel_case(next(c for c in cases if c["name"] == gold["base_case"]))
+    s["brdf"] = (gold["brdf"], np.array([[1.0]]))
+    got = run_product(s, derivatives=True)
+    ref = make_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, brdf=s["brdf"])
+    assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-10 * np.abs(ref["radiance"]).max()
+    for k in ("d_extinction", "d_ssa", "d_brdf"):
+        assert np.max(np.abs(got[k] - ref[k])) < 1e-8 * np.abs(ref[k]).max(), k
+    diff = np.abs(got["radiance"][0] - np.asarray(gold["expected"]))
+    assert diff.max() < 3e-4 and np.median(diff) < 3e-5
+

@@ -211,3 +211,15 @@ def test_scattering_group_derivatives_over_a_brdf_surface_match_finite_differenc
         fd = (run_emulated_vector(_mixture_nadir(xp)[0], brdf=brdf)["radiance"] - run_emulated_vector(_mixture_nadir(xm)[0], brdf=brdf)["radiance"]) / (2 * h)
         assert np.abs(mp["scat_factor"][q, 0] * out["d_scat"][:, :, 0, q]).max() > 0.05 * np.abs(an[..., q]).max()
         assert np.abs(fd - an[..., q]).max() < 1e-6 * scale, q
+
+
+def test_the_references_functional_brdf_known_answer_emulated():
+    import json
+    from pathlib import Path
+    root = Path(__file__).parent / "golden"
+    gold = json.loads((root / "do_scalar_brdf_legacy.json").read_text())
+    cases = json.loads((root / "do_scalar_planeparallel.json").read_text())["cases"]
+    s = sc.planeparallel_case(next(c for c in cases if c["name"] == gold["base_case"]))
+    got = run_emulated_vector(s, brdf=(gold["brdf"], np.array([[1.0]])))["radiance"][0]
+    diff = np.abs(got - np.asarray(gold["expected"]))
+    assert diff.max() < 3e-4 and np.median(diff) < 3e-5
