@@ -130,6 +130,7 @@ inline double brdf_deriv(int kind, int k, double mu_in, double mu_out, double ph
         const BrdfKernels K = modis_kernels(mu_in, mu_out, phi);
         return (k == 1 ? K.k_vol : K.k_geo) / kPi;
     }
+    if (kind == 3) return std::abs(std::cos(phi)) * std::abs(1 - std::abs(std::abs(mu_out) - std::abs(mu_in))) / kPi;   // d / d(scale)
     return 1.0 / kPi;
 }
 
