@@ -163,7 +163,11 @@ class Solver {
     std::vector<double> qx, qw;                         // positive nodes / weights of the 512-point rule
     std::vector<double> smp, dsmp;                      // [pair][4 * 256] samples of the BRDF (its derivative) over the azimuth
     std::vector<double> rss, rsun, rlos, rlossun, drss, drsun, drlos, drlossun;   // order m: [N out][N in], [N], [nlos][N], [nlos]
-    int npair() const { return N * N + N + int(G.pp_los.size()) * (N + 1); }
+    // spherical post-processing: the ground source is evaluated at the cos-angle grid points a line of sight interpolates between
+    // (accumulate_ground_sources, do_source_diffuse_storage.cpp:435-695): expansion at (grid angle, stream) for the needed angles of this sza
+    std::vector<int> gnd_aidx;
+    std::vector<double> rgnd, drgnd;                    // [needed angle][N]
+    int npair() const { return N * N + N + int(G.pp_los.size()) * (N + 1) + int(gnd_aidx.size()) * N; }
     void pair_angles(int pr, double& mu_out, double& mu_in) const {
         const int nl_ = int(G.pp_los.size());
         if (pr < N * N) { mu_out = G.mu[pr / N]; mu_in = G.mu[pr % N]; return; }
@@ -172,9 +176,15 @@ class Solver {
         pr -= N;
         if (pr < nl_ * N) { mu_out = G.pp_los[pr / N].coszenith; mu_in = G.mu[pr % N]; return; }
         pr -= nl_ * N;
-        mu_out = G.pp_los[pr].coszenith; mu_in = G.csz[cur_sza];
+        if (pr < nl_) { mu_out = G.pp_los[pr].coszenith; mu_in = G.csz[cur_sza]; return; }
+        pr -= nl_;
+        mu_out = G.cos_angles[gnd_aidx[pr / N]]; mu_in = G.mu[pr % N];
     }
     void sample_surface() {
+        gnd_aidx.clear();
+        if (G.spherical_pp)
+            for (int aidx = 0; aidx < G.nangle; ++aidx)
+                if (ground_slot[size_t(cur_sza) * G.nangle + aidx] >= 0) gnd_aidx.push_back(aidx);
         if (brdf_kind == 0) return;
         if (qx.empty()) {
             std::vector<double> x, w;
@@ -201,6 +211,7 @@ class Solver {
         const int nl_ = int(G.pp_los.size());
         rss.assign(size_t(N) * N, 0.0); rsun.assign(N, 0.0); rlos.assign(size_t(nl_) * N, 0.0); rlossun.assign(nl_, 0.0);
         drss.assign(rss.size(), 0.0); drsun.assign(N, 0.0); drlos.assign(rlos.size(), 0.0); drlossun.assign(nl_, 0.0);
+        rgnd.assign(gnd_aidx.size() * N, 0.0); drgnd.assign(rgnd.size(), 0.0);
         if (m >= surf_max_order) return;
         auto put = [&](int pr, double v, double dv) {
             if (pr < N * N) { rss[pr] = v; drss[pr] = dv; return; }
@@ -209,7 +220,9 @@ class Solver {
             pr -= N;
             if (pr < nl_ * N) { rlos[pr] = v; drlos[pr] = dv; return; }
             pr -= nl_ * N;
-            rlossun[pr] = v; drlossun[pr] = dv;
+            if (pr < nl_) { rlossun[pr] = v; drlossun[pr] = dv; return; }
+            pr -= nl_;
+            rgnd[pr] = v; drgnd[pr] = dv;
         };
         const int np = npair();
         if (brdf_kind == 0) {
@@ -1302,14 +1315,7 @@ inline void Solver::pp_postprocess(int m, int szaidx, Result& res, std::vector<d
 
 // ======================================================================================
 inline void Solver::accumulate_ground(int m, int szaidx) {
-    if (brdf_kind != 0) {
-        // a ground source per outgoing angle and order (do_source_diffuse_storage.cpp:435-695) is not restated: limb lines of sight only
-        for (int aidx = 0; aidx < G.nangle; ++aidx)
-            if (ground_slot[size_t(szaidx) * G.nangle + aidx] >= 0)
-                throw std::invalid_argument("oracle: non-Lambertian surfaces in spherical geometry are restated for lines of sight that do not end on the ground");
-        return;
-    }
-    if (m >= 1) return;
+    if (m >= surf_max_order) return;   // (m >= max_azimuthal_order: 1 for the Lambertian surface, do_source_diffuse_storage.cpp:445-447)
     const int p = nlyr - 1, ls = ND ? lstart[p] : 0, nk = nl(p);
     const size_t nslot = npoint + nground;
     std::vector<double> strm_d(ND), diffuse_d(ND);
@@ -1319,8 +1325,10 @@ inline void Solver::accumulate_ground(int m, int szaidx) {
         double diffuse = 0;
         std::fill(diffuse_d.begin(), diffuse_d.end(), 0.0);
         for (int is = 0; is < N; ++is) {
-            const int i = is * S;  // intensity rows only (Lambertian)
-            double r = albedo;  // Lambertian compute_expansion special case
+            const int i = is * S;  // intensity rows only ("TODO ... might be fine for scalar surface reflection", :478-486)
+            // compute_expansion(m, mu_in = stream, mu_out = grid angle) (:474-477); the Lambertian special case is the albedo
+            const size_t gk = size_t(std::find(gnd_aidx.begin(), gnd_aidx.end(), aidx) - gnd_aidx.begin());
+            const double r = rgnd[gk * N + is], dr = drgnd[gk * N + is];
             double sc_v = Gpb[size_t(p) * n + i];
             for (int d = 0; d < ND; ++d) strm_d[d] = dG(dGpb, p, d)[i];
             for (int jj = 0; jj < n; ++jj) {
@@ -1337,7 +1345,7 @@ inline void Solver::accumulate_ground(int m, int szaidx) {
             double factor = (m == 0 ? 2.0 : 1.0) * G.mu[is] * G.wt[is];
             diffuse += factor * sc_v * r;
             for (int d = 0; d < ND; ++d) diffuse_d[d] += factor * strm_d[d] * r;
-            for (int k = 0; k < nk; ++k) diffuse_d[ls + k] += factor * sc_v * d_alb(k);
+            for (int k = 0; k < nk; ++k) diffuse_d[ls + k] += factor * sc_v * d_alb(k) * dr;
         }
         double* tv = &tab_val[(size_t(m) * nslot + slot) * S];
         for (int s = 0; s < S; ++s) tv[s] = 0;
@@ -1537,6 +1545,7 @@ inline void Solver::solve(const AtmosphereView& atm, int w, Result& res) {
         std::fill(converged.begin(), converged.end(), 0);
         for (int s = 0; s < G.nsza; ++s) {
             configure_layers(atm, w, s);
+            cur_sza = s;   // (the surface samples are taken for this solar zenith index: the sun's direction enters the stream-sun pairs)
             sample_surface();
             all_converged = false;
             for (int m = 0; m < nstr; ++m) {
@@ -1550,6 +1559,7 @@ inline void Solver::solve(const AtmosphereView& atm, int w, Result& res) {
         integrate_los(atm, w, res);
     } else {
         configure_layers(atm, w, 0);
+        cur_sza = 0;
         sample_surface();
         const int num_azi = forced_azimuth > 0 ? forced_azimuth : nstr;
         for (int m = 0; m < num_azi; ++m) {

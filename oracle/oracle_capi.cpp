@@ -256,6 +256,7 @@ struct SoHandle {
     int num_iterations = 50;
     const double *emission = nullptr, *surface_emission = nullptr;
     oracle_so::Solver::FixedPoint fixed_point;
+    const double* los_albedo = nullptr;   // [nwavel][nlos] pi x brdf at the lines of sight's ground geometry (orso_set_brdf), or null
 };
 
 void* orso_create(double cos_sza, double saa, double earth_radius, const double* altitudes, int ngrid, int interp_method, int geotype,
@@ -316,6 +317,29 @@ int orso_set_fixed_point(void* hv, int enabled, double relative_tolerance, doubl
     h->fixed_point.anderson_depth = anderson_depth;
     return 0;
 }
+// Non-Lambertian surface under the exact single scatter of the next orso_run calls (kind as orc_set_brdf; 0 switches it off): fills
+// los_albedo [nwavel][nlos] = pi x brdf(mu_in, mu_out, phi) at every line of sight's ground geometry (it must stay alive) and, if given,
+// d_los_albedo [nwavel][nlos][nargs] = pi x d brdf / d argument -- the single scatter is linear in that value, so the weighting function of
+// argument a is (d I / d albedo of the run) x d_los_albedo[.., a]   (cpp/lib/solar/singlescattersource.cpp:264-279,574-636)
+int orso_set_brdf(void* hv, int kind, int nargs, const double* args, int nwavel, double* los_albedo, double* d_los_albedo) {
+    auto* h = static_cast<SoHandle*>(hv);
+    if (!h || kind < 0 || kind > 3) return -1;
+    h->los_albedo = nullptr;
+    if (kind == 0) return 0;
+    if (!args || !los_albedo || nargs != (kind == 2 ? 3 : 1)) return -1;
+    const skso::RaySet& lo = h->sg.los;
+    for (int w = 0; w < nwavel; ++w)
+        for (int r = 0; r < lo.nrays; ++r) {
+            const bool lit = lo.ground_is_hit[r] && lo.ground_mu_in[r] > 0;
+            const double* a = args + size_t(w) * nargs;
+            los_albedo[size_t(w) * lo.nrays + r] = lit ? skgeo::kPi * oracle::brdf_value(kind, lo.ground_mu_in[r], lo.ground_mu_out[r], lo.ground_phi[r], a) : 0.0;
+            for (int k = 0; k < nargs && d_los_albedo; ++k)
+                d_los_albedo[(size_t(w) * lo.nrays + r) * nargs + k] =
+                    lit ? skgeo::kPi * oracle::brdf_deriv(kind, k, lo.ground_mu_in[r], lo.ground_mu_out[r], lo.ground_phi[r], a) : 0.0;
+        }
+    h->los_albedo = los_albedo;
+    return 0;
+}
 int orso_lebedev(int npoints, double* xyzw) {
     try {
         const std::vector<double> s = skleb::sphere(npoints);
@@ -364,6 +388,7 @@ int orso_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     atm.leg = leg;
     atm.solar_irradiance = solar_irradiance;
     atm.albedo = albedo;
+    atm.los_albedo = h->los_albedo;
     atm.emission = h->emission;
     atm.surface_emission = h->surface_emission;
     if (h->sg.cfg.emission != 0 && !atm.emission) return -2;

@@ -221,9 +221,10 @@ class SoOracleEngine:
         lib().orso_sizes(self._h, out.ctypes.data_as(_ip))
         return dict(points=int(out[0]), incoming_rays=int(out[1]), outgoing_directions=int(out[2]), accumulation_entries=int(out[3]))
 
-    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, nthreads=1, derivatives=False, emission=None, surface_emission=None):
+    def run(self, extinction, ssa, leg, albedo, solar_irradiance=None, nthreads=1, derivatives=False, emission=None, surface_emission=None, brdf=None):
         """derivatives: native weighting functions of the exact single-scatter source, d_extinction / d_ssa [nwavel, nlos, S, ngrid],
-        d_albedo [nwavel, nlos, S] (only without the diffuse source)."""
+        d_albedo [nwavel, nlos, S] (only without the diffuse source).  brdf = (kind, args [nwavel, nargs]): a non-Lambertian surface under the
+        lines of sight's direct bounce (single scatter only); adds d_brdf [nwavel, nlos, S, nargs]."""
         k = np.asfortranarray(extinction, dtype=np.float64)
         w = np.asfortranarray(ssa, dtype=np.float64)
         lg = np.asfortranarray(leg, dtype=np.float64)
@@ -239,13 +240,25 @@ class SoOracleEngine:
         if derivatives:
             dk, dw, da = np.zeros((nwavel, self.nlos, S, self.ngrid)), np.zeros((nwavel, self.nlos, S, self.ngrid)), np.zeros((nwavel, self.nlos, S))
             de, ds = np.zeros((nwavel, self.nlos, S, self.ngrid)), np.zeros((nwavel, self.nlos, S))
-        rc = lib().orso_run(self._h, nwavel, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), _p(irr), _p(alb), nthreads, _p(rad), _p(od),
-                            _p(dk), _p(dw), _p(da), _p(de), _p(ds))
+        los_alb = d_los_alb = None
+        L = lib()
+        L.orso_set_brdf.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp]
+        if brdf is not None:
+            kind = {"kokhanovsky": 1, "modis": 2, "legacy_test_function": 3}[brdf[0]]
+            bargs = np.ascontiguousarray(brdf[1], dtype=np.float64).reshape(nwavel, -1)
+            los_alb, d_los_alb = np.zeros((nwavel, self.nlos)), np.zeros((nwavel, self.nlos, bargs.shape[1]))
+            if L.orso_set_brdf(self._h, kind, bargs.shape[1], _p(bargs), nwavel, _p(los_alb), _p(d_los_alb)) != 0:
+                raise RuntimeError("successive-orders oracle: bad BRDF arguments")
+        rc = L.orso_run(self._h, nwavel, lg.shape[0] // (4 if S == 3 else 1), _p(k), _p(w), _p(lg), _p(irr), _p(alb), nthreads, _p(rad), _p(od),
+                        _p(dk), _p(dw), _p(da), _p(de), _p(ds))
+        L.orso_set_brdf(self._h, 0, 1, None, 0, None, None)
         if rc != 0:
             raise RuntimeError(f"successive-orders oracle run failed with code {rc}")
         out = {"radiance": rad, "los_optical_depth": od}
         if derivatives:
             out.update({"d_extinction": dk, "d_ssa": dw, "d_albedo": da, "d_emission": de, "d_surface_emission": ds})
+            if brdf is not None:   # the single scatter is linear in pi x brdf: d I / d argument = (d I / d albedo) x pi d brdf / d argument
+                out["d_brdf"] = da[..., None] * d_los_alb[:, :, None, :]
         return out
 
 

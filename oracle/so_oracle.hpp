@@ -28,6 +28,9 @@ struct AtmosphereView {
     const double* leg = nullptr;                         // [nleg (x 4), ngrid, nwavel]
     const double* solar_irradiance = nullptr;            // [nwavel] or null (1)
     const double* albedo = nullptr;                      // [nwavel]
+    // non-Lambertian surface under the exact single scatter: pi x brdf at the ground geometry of every line of sight [nwavel][nlos]
+    // (end_of_ray_source, cpp/lib/solar/singlescattersource.cpp:574-636), or null.  Only the lines of sight's direct bounce uses it.
+    const double* los_albedo = nullptr;
     const double* emission = nullptr;                    // [ngrid, nwavel] emission_source of the storage (settings.emission != 0)
     const double* surface_emission = nullptr;            // [nwavel]
     bool derivatives = false;                            // native weighting functions (extinction, ssa, albedo; emission sources: + emission) of
@@ -117,9 +120,10 @@ class Solver {
         if (g_.cfg.occultation && !(n > 0 && lo.ground_is_hit[r])) I[0] += 1.0;
         if (ss && n > 0 && lo.ground_is_hit[r] && lo.ground_mu_in[r] > 0) {
             const double base = T_los_[e0] * lo.ground_mu_in[r] / skgeo::kPi;
-            I[0] += base * albedo;
+            const double alb_r = a.los_albedo ? a.los_albedo[size_t(w) * lo.nrays + r] : albedo;   // pi x brdf of this ray's ground geometry
+            I[0] += base * alb_r;
             D(0, 2 * ngrid) += base;
-            for (int t = lo.solar.start[e0]; t < lo.solar.start[e0 + 1]; ++t) D(0, lo.solar.idx[t]) -= lo.solar.w[t] * base * albedo;
+            for (int t = lo.solar.start[e0]; t < lo.solar.start[e0 + 1]; ++t) D(0, lo.solar.idx[t]) -= lo.solar.w[t] * base * alb_r;
         }
         // diffuse field: its source along the ray is part of I (so that the attenuation derivatives below see it) with the direct
         // dependence of omega (1 - e^-od) on the layer; the dependence through the outgoing sources themselves is ms_rows (ms_adjoint)
@@ -558,7 +562,8 @@ class Solver {
             if (n > 0 && g_.cfg.emission != 0 && lo.ground_is_hit[r] && a.surface_emission) rad[0] += a.surface_emission[w];
             if (g_.cfg.occultation && !(n > 0 && lo.ground_is_hit[r])) rad[0] += 1.0;
             if (n > 0 && lo.ground_is_hit[r]) {
-                if (ss && lo.ground_mu_in[r] > 0) rad[0] += T_los_[lo.endpoint_start[r]] * (albedo / skgeo::kPi) * lo.ground_mu_in[r];
+                if (ss && lo.ground_mu_in[r] > 0)
+                    rad[0] += T_los_[lo.endpoint_start[r]] * ((a.los_albedo ? a.los_albedo[size_t(w) * lo.nrays + r] : albedo) / skgeo::kPi) * lo.ground_mu_in[r];
                 if (ms && num_iterations > 0)
                     for (int e = g_.los_ground.start[r]; e < g_.los_ground.start[r + 1]; ++e)
                         for (int s = 0; s < S_; ++s) rad[s] += g_.los_ground.w[e] * outgoing_[size_t(g_.los_ground.idx[e]) * S_ + s];

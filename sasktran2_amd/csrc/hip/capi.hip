@@ -799,6 +799,13 @@ static double* upload_group_directions(Engine* e, const AtmosphereStorage& st, c
 // NSTOKES = 3 (and NSTOKES = 1 stream counts outside the matrix-core path): radiances [wavel][los][stokes], LOS optical depths and
 // weighting functions [nderiv][wavel][los][stokes].
 static void upload_emission(Engine* e, const AtmosphereStorage& st, const Surface& su);
+// wf of BRDF argument a [a][wavel][los][S] += (single scatter's d I / d(pi x brdf of the ray) [wavel][los][S]) x d(pi x brdf) / d(argument) [a][los][wavel]
+__global__ void kern_brdf_ss_wf(const double* wa_ss, const double* dalb, double* wa, int nw, int nlos, int S, int nargs) {
+    const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x, nt = size_t(nw) * nlos * S;
+    if (tid >= nt) return;
+    const int w = int(tid / (size_t(nlos) * S)), l = int((tid / S) % nlos);
+    for (int a = 0; a < nargs; ++a) wa[size_t(a) * nt + tid] += wa_ss[tid] * dalb[(size_t(a) * nlos + l) * nw + w];
+}
 static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
     const AtmosphereStorage& st = *atm->storage;
     const Surface& su = *atm->surface;
@@ -908,8 +915,24 @@ static int calculate_radiance_vector(Engine* e, Atmosphere* atm, OutputC* out) {
             HIPC(hipMemset(d_wem, 0, size_t(ngrid) * nt * S * 8));
             HIPC(hipMemset(d_wsem, 0, nt * S * 8));
         }
-        e->so->solve_device(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa, d_wem,
+        // non-Lambertian surface: the direct bounce of a line of sight that ends on the ground sees pi x brdf at its own ground geometry; the
+        // single scatter is linear in that value, so its albedo weighting function times d(value) / d(argument) joins the argument's plane
+        double* d_wa_ss = d_wa;
+        if (brdf_kind != 0) {
+            e->so->set_surface_brdf(brdf_kind, brdf_nargs, (const double*)C.get("brdf_args", size_t(nw) * brdf_nargs * 8));
+            if (derivs) {
+                d_wa_ss = (double*)C.get("wf_alb_ss", nt * S * 8);
+                HIPC(hipMemset(d_wa_ss, 0, nt * S * 8));
+            }
+        }
+        struct SoBrdfReset { skdev::SoDeviceEngine* d; ~SoBrdfReset() { d->set_surface_brdf(0, 1, nullptr); } } so_brdf_reset{e->so.get()};
+        e->so->solve_device(nw, norder, d_ext, d_ssa, d_leg, d_alb, d_irr, d_rad, nullptr, nullptr, 1, derivs ? d_we : nullptr, d_ws, d_wa_ss, d_wem,
                             d_wsem, derivs ? (int)group_of.size() : 0, d_dleg, d_wg);
+        if (brdf_kind != 0 && derivs) {
+            hipLaunchKernelGGL(kern_brdf_ss_wf, dim3(unsigned((nt * S + 255) / 256)), dim3(256), 0, nullptr, d_wa_ss, e->so->los_albedo_derivative(), d_wa, nw, nlos, S,
+                               brdf_nargs);
+            HIPC(hipGetLastError());
+        }
     }
     hipLaunchKernelGGL(kern_transpose_od, dim3(1024), dim3(256), 0, nullptr, d_od, d_odt, nw, nlos);
     HIPC(hipGetLastError());

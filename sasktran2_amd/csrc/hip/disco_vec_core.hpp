@@ -78,7 +78,9 @@ struct VBufs {
     // non-Lambertian surface (plane-parallel / pseudo-spherical post-processing): azimuth expansion of the BRDF per wavelength and order
     int brdf_kind;          // 0 Lambertian (Bufs::albedo), 1 SnowKokhanovsky, 2 MODIS (cpp/include/sasktran2/atmosphere/surface.h:151-352)
     int brdf_nargs;
-    int surf_nlos;          // lines of sight in the table: nlos with plane-parallel post-processing, 0 in spherical geometry (no ray may see the ground there)
+    int surf_nlos;          // "line of sight" rows of the table: nlos with plane-parallel post-processing; in spherical geometry the GROUND POINTS of the
+                            // current solar zenith index (one per needed cos-angle grid point: RL(k, t) = factor from stream t into grid angle k)
+    int surf_slot0;         // spherical geometry: table slot of ground point 0 of the current solar zenith index (the ground slots follow one another)
     const double* surf;     // [w][m][1 + nargs][VSurf::NP]  reflection factors and their derivatives wrt the BRDF arguments (VSurf)
     double* surf_ops;       // [w][N][2 n + 1]  adjoint operators of the ground: Dinv^T e_t per incoming stream t, then I-_t at the ground
 };
@@ -105,6 +107,31 @@ constexpr int kMaxGroupsWithBrdf = 8;   // scattering groups served together wit
 // gradient / native-derivative rows of BRDF argument a: the Lambertian albedo's rows for a = 0, rows behind the scattering groups' otherwise
 SKD_HD size_t surf_grad_row(const Geo& g, const VBufs& v, int a) { return a == 0 ? size_t(4 * g.nlyr) : size_t(4 * g.nlyr + 2 + v.ngroups * g.nlyr + (a - 1)); }
 SKD_HD size_t surf_dnat_row(const Geo& g, const VBufs& v, int a) { return a == 0 ? size_t(2 * g.ngrid) : size_t(2 * g.ngrid + 1 + v.ngroups * g.ngrid + (a - 1)); }
+
+constexpr int kMaxSurfStreams = 32;
+// Weights c_t with which a line of sight sees the downwelling stream intensities at the ground through the surface: block 0 of `sf` for the
+// factors themselves, block 1 + a for their derivatives wrt BRDF argument a.  Plane-parallel post-processing: gw RL(los, t).  Spherical:
+// the ray's ground interpolation over the cos-angle grid points with the order's azimuth factor cos(m (pi - saa)) (create_ground_source_
+// interpolator, do_source_diffuse_storage.cpp:213-265), gw = transmission from the ground to the observer.
+SKD_HD void ground_los_weights(const Geo& g, const Bufs& b, const VBufs& v, const double* sf, int block, int s, int m, int los, int w, double gw, double* c) {
+    const int N = g.N;
+    const VSurf SF(N, v.surf_nlos, v.brdf_nargs);
+    const double* f = sf + size_t(block) * SF.NP();
+    for (int t = 0; t < N; ++t) c[t] = 0;
+    if (gw == 0.0) return;
+    if (g.pp_mode) {
+        for (int t = 0; t < N; ++t) c[t] = gw * f[SF.RL(los, t)];
+        return;
+    }
+    if (!g.ray_ground[los]) return;
+    const double az = cos(m * (kPi - g.ray_gsaa[los]));
+    for (int e = g.g_start[los]; e < g.g_start[los + 1]; ++e) {
+        if (g.g_sza[e] != s || skd::conv_at(b, g, g.g_slot[e], w) <= m) continue;
+        const int k = g.g_slot[e] - v.surf_slot0;
+        const double we = gw * g.g_w[e] * az;
+        for (int t = 0; t < N; ++t) c[t] += we * f[SF.RL(k, t)];
+    }
+}
 
 // ---- the reference's BRDFs (surface.h): geometry-only parts, so that the per-wavelength work is a weighted sum.
 // MODIS (surface.h:236-281): brdf = (iso + vol k_vol + geo k_geo) / pi, linear in its arguments
@@ -1822,7 +1849,24 @@ SKD_HD void kv3_table_values(const Geo& g, const VGeo& vg, const Bufs& b, const 
             }
         }
     }
-    if (p == nlyr - 1 && m == 0) {
+    if (p == nlyr - 1 && v.brdf_kind != 0) {
+        // non-Lambertian surface: the upwelling reflected intensity at every needed cos-angle grid point k, in every order
+        // (accumulate_ground_sources, do_source_diffuse_storage.cpp:435-695): J_m(k) = sum_t RL(k, t) I-_t
+        const VSurf SF(N, v.surf_nlos, v.brdf_nargs);
+        const double* sf = vsurf_at(v, g, m, w);
+        for (int t = g.gpt_start[s]; t < g.gpt_start[s + 1]; ++t) {
+            const int k = g.gpt_slot[t] - v.surf_slot0;
+            double diffuse = 0;
+            for (int i = 0; i < N; ++i) {
+                double sv = c[R.G() + 2 * n + i * S];
+                for (int j = 0; j < n; ++j)
+                    sv += xs[j] * c[R.WP() + i * S + n * j] * c[R.E() + j] + xs[n + j] * c[R.WM() + i * S + n * j];
+                diffuse += sf[SF.RL(k, i)] * sv;
+            }
+            vJ_at(v, g, m, g.gpt_slot[t], w, 0) = diffuse;
+            for (int cidx = 1; cidx < S; ++cidx) vJ_at(v, g, m, g.gpt_slot[t], w, cidx) = 0;
+        }
+    } else if (p == nlyr - 1 && m == 0) {
         // upwelling diffuse reflection of a Lambertian surface (intensity only)
         double diffuse = 0;
         for (int i = 0; i < N; ++i) {
@@ -1857,6 +1901,10 @@ SKD_HD void kv4_los(const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v,
     if (g.ray_ground[los]) {
         for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t) {
             const int slot = g.g_slot[t];
+            if (v.brdf_kind != 0) {   // every order with its azimuth factor (the ground source of a BRDF depends on the outgoing direction)
+                const int cv = int(skd::conv_at(b, g, slot, w)), mmax = (cv < nstr) ? cv : nstr;
+                for (int m = 0; m < mmax; ++m) behind[0] += g.g_w[t] * cos(m * (kPi - g.ray_gsaa[los])) * vJ_at(v, g, m, slot, w, 0);
+            } else
             if (skd::conv_at(b, g, slot, w) > 0) behind[0] += g.g_w[t] * vJ_at(v, g, 0, slot, w, 0);  // order 0 only
         }
     }
@@ -2310,10 +2358,12 @@ SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v,
             const double* so = v.surf_ops + size_t(w) * N * (M2 + 1);
             const double Tg = b.T[size_t(nlyr) * nw + w];
             double ga[3] = {0, 0, 0}, gT = 0;
+            double cg[kMaxSurfStreams], dcg[3][kMaxSurfStreams];
+            ground_los_weights(g, b, v, sf, 0, s, m, los, w, gw, cg);
+            for (int a = 0; a < na; ++a) ground_los_weights(g, b, v, sf, 1 + a, s, m, los, w, gw, dcg[a]);
             for (int t = 0; t < N; ++t) {
-                const bool seen = v.surf_nlos > 0;   // (spherical geometry: no line of sight ends on the ground, gw = 0)
-                double ct = seen ? gw * sf[SF.RL(los, t)] : 0.0, da[3] = {0, 0, 0};
-                for (int a = 0; a < na && seen; ++a) da[a] = gw * sf[size_t(1 + a) * SF.NP() + SF.RL(los, t)];
+                double ct = cg[t], da[3] = {0, 0, 0};
+                for (int a = 0; a < na; ++a) da[a] = dcg[a][t];
                 for (int i = 0; i < N; ++i) {
                     const double zbi = v.z[(size_t(p) * M2 + n + i * S) * nt + tid];
                     ct += zbi * sf[SF.RS(i, t)];
@@ -2338,8 +2388,10 @@ SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v,
             const int N = g.N, los = int((tid / S) % g.nlos);
             const VSurf SF(N, v.surf_nlos, v.brdf_nargs);
             const double* sf = vsurf_at(v, g, m, w);
+            double cg[kMaxSurfStreams];
+            ground_los_weights(g, b, v, sf, 0, s, m, los, w, gw, cg);
             for (int t = 0; t < N; ++t) {
-                double ct = (v.surf_nlos > 0) ? gw * sf[SF.RL(los, t)] : 0.0;
+                double ct = cg[t];
                 for (int i = 0; i < N; ++i) ct += v.z[(size_t(p) * M2 + n + i * S) * nt + tid] * sf[SF.RS(i, t)];
                 for (int gi = 0; gi < v.ngroups && gi < kMaxGroupsWithBrdf; ++gi) ggb[gi] += ct * ops[O.GDI(gi) + 2 * n + t * S];
             }
@@ -2387,11 +2439,17 @@ SKD_HD void kv2b_adjoint(const Geo& g, const VGeo& vg, const Bufs& b, const VBuf
     const VOps O(n, NL, v.ngroups);
     const size_t tid = (size_t(w) * g.nlos + los) * S + sout, nt = size_t(nw) * g.nlos * S;
     Scr ql = scr.sub(0), y = scr.sub(NL), carry = scr.sub(NL + M2);
-    double gw = 0;  // the Lambertian ground feeds the intensity only
-    if (sout == 0 && m == 0 && g.ray_ground[los]) {
+    double gw = 0;  // the ground feeds the intensity only
+    const bool brdf = v.brdf_kind != 0;
+    double cg[kMaxSurfStreams];
+    if (sout == 0 && m == 0 && g.ray_ground[los] && !brdf) {
         for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t)
             if (g.g_sza[t] == s && skd::conv_at(b, g, g.g_slot[t], w) > m) gw += g.g_w[t];
         gw *= b.att_total[size_t(los) * nw + w];
+    }
+    if (brdf) {   // non-Lambertian ground: every order; the ray's ground weights over the incoming streams (ground_los_weights)
+        if (sout == 0 && g.ray_ground[los]) gw = b.att_total[size_t(los) * nw + w];
+        ground_los_weights(g, b, v, vsurf_at(v, g, m, w), 0, s, m, los, w, gw, cg);
     }
     for (int i = 0; i < n; ++i) carry[i] = 0;
     // ---- forward sweep  y_p = FP ql_p + SP yB_{p-1} (+ gw UG)
@@ -2416,6 +2474,14 @@ SKD_HD void kv2b_adjoint(const Geo& g, const VGeo& vg, const Bufs& b, const VBuf
         }
         for (int l = 0; l < NL; ++l) v.qlbuf[(size_t(p) * NL + l) * nt + tid] = ql[l];
         for (int i = 0; i < M2; ++i) y[i] = (p == nlyr - 1) ? gw * ops[O.UG() + i] : 0.0;
+        if (brdf && p == nlyr - 1 && gw != 0.0) {
+            const double* so = v.surf_ops + size_t(w) * g.N * (M2 + 1);
+            for (int i = 0; i < M2; ++i) {
+                double acc = 0;
+                for (int t = 0; t < g.N; ++t) acc += cg[t] * so[t * (M2 + 1) + i];
+                y[i] = acc;
+            }
+        }
         matvec8(ops + O.FP(), NL, M2, m * C, NL, ql, 1.0, [&](int i, double t) { y[i] += t; });
         matvec8(ops + O.SP(), n, M2, 0, n, carry, 1.0, [&](int i, double t) { y[i] += t; });
         for (int i = 0; i < M2; ++i) v.z[(size_t(p) * M2 + i) * nt + tid] = y[i];
@@ -2437,12 +2503,13 @@ SKV_TEAM_BODY void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, con
     double *QL = ws, *Y = QL + size_t(NL) * NC, *Cc = Y + size_t(M2) * NC, *gwv = Cc + size_t(n) * NC;
     SKV_PAR(col, NC) {
         const int los = col / S, sout = col % S;
-        double gw = 0;  // the Lambertian ground feeds the intensity only
-        if (sout == 0 && m == 0 && g.ray_ground[los]) {
+        double gw = 0;  // the ground feeds the intensity only
+        if (sout == 0 && m == 0 && g.ray_ground[los] && v.brdf_kind == 0) {
             for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t)
                 if (g.g_sza[t] == s && skd::conv_at(b, g, g.g_slot[t], w) > m) gw += g.g_w[t];
             gw *= b.att_total[size_t(los) * nw + w];
         }
+        if (v.brdf_kind != 0 && sout == 0 && g.ray_ground[los]) gw = b.att_total[size_t(los) * nw + w];   // (every order; weighed stream by stream below)
         gwv[col] = gw;
         for (int i = 0; i < n; ++i) Cc[size_t(i) * NC + col] = 0;
     }
@@ -2494,7 +2561,17 @@ SKV_TEAM_BODY void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, con
         }
         team.sync();
         team_gemm(team, M2, NC, NL, [&](int i, int k) { return ops[O.FP() + i * NL + k]; }, [&](int k, int col) { return QL[size_t(k) * NC + col]; },
-                  [&](int i, int col, double val) { Y[size_t(i) * NC + col] = val + (last ? gwv[col] * ops[O.UG() + i] : 0.0); });
+                  [&](int i, int col, double val) {
+                      double seed = last ? gwv[col] * ops[O.UG() + i] : 0.0;
+                      if (last && v.brdf_kind != 0 && gwv[col] != 0.0) {   // non-Lambertian ground: sum_t c_t Dinv^T e_t (few columns: the rays that end on the ground)
+                          double cg[kMaxSurfStreams];
+                          ground_los_weights(g, b, v, vsurf_at(v, g, m, w), 0, s, m, col / S, w, gwv[col], cg);
+                          const double* so = v.surf_ops + size_t(w) * g.N * (M2 + 1);
+                          seed = 0;
+                          for (int t = 0; t < g.N; ++t) seed += cg[t] * so[t * (M2 + 1) + i];
+                      }
+                      Y[size_t(i) * NC + col] = val + seed;
+                  });
         team.sync();
         team_gemm(team, M2, NC, n, [&](int i, int k) { return ops[O.SP() + i * n + k]; }, [&](int k, int col) { return Cc[size_t(k) * NC + col]; },
                   [&](int i, int col, double val) { Y[size_t(i) * NC + col] += val; });

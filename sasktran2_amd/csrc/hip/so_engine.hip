@@ -58,6 +58,7 @@ struct DevRays {
     const int *layer_start, *endpoint_start;
     const unsigned char* ground_is_hit;
     const double* ground_mu_in;
+    const double *ground_mu_out, *ground_phi;   // outgoing zenith cosine / azimuth difference at the ground (ground_scattering_geometry, singlescattersource.cpp:264-279)
     DevCsr od;
     const int* stencil_idx;                 // [layer][4]
     const double *w_entrance, *w_exit;      // [layer][4]
@@ -122,6 +123,9 @@ struct SoGeo {
 struct SoBufs {
     int nw, nwp, nleg, w0, nwavel_total;
     const double *ext, *ssa, *leg, *albedo, *irradiance;   // caller's inputs at the first wavelength of the block
+    // non-Lambertian surface: pi x brdf at the ground geometry of every line of sight, [los][nwavel_total] (whole spectrum), or null.  Only the
+    // direct bounce of the lines of sight uses it (end_of_ray_source, cpp/lib/solar/singlescattersource.cpp:574-636)
+    const double* los_albedo;
     const double *emission, *surface_emission;             // emission_source [w][q], surface emission [w] (emission sources only)
     double* emT;                                            // emission_source, slab major
     double *kT, *omT, *legT, *tab, *cl, *first, *incoming, *outgoing, *factor, *lod, *lsrc;   // factor: [layers + rays] (ground slots last)
@@ -211,7 +215,8 @@ __global__ void __launch_bounds__(kWave) k_so_march(SoGeo g, SoBufs b, int singl
     const int l0 = rs.layer_start[r], n = rs.layer_start[r + 1] - l0, e0 = rs.endpoint_start[r];
     const int per = S == 3 ? 4 : 1, nlg_in = b.nleg * per, nm = min(g.num_ss_moments, b.nleg);
     const int ws = w < b.nw ? w : b.nw - 1;
-    const double F = b.irradiance ? b.irradiance[ws] : 1.0, albedo = b.albedo[ws];
+    const double F = b.irradiance ? b.irradiance[ws] : 1.0;
+    const double albedo = (LOS && b.los_albedo) ? b.los_albedo[size_t(r) * b.nwavel_total + b.w0 + ws] : b.albedo[ws];
     double val[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) val[s] = 0;
@@ -360,7 +365,8 @@ __global__ void __launch_bounds__(kWave) k_so_los_deriv(SoGeo g, SoBufs b, int s
     const int per = S == 3 ? 4 : 1, nlg_in = b.nleg * per, nm = min(g.num_ss_moments, b.nleg), ngrid = g.ngrid, nn = so_deriv_slots(ngrid, b.ngroups);
     const int ncomp = S == 3 ? 2 : 1, grp0 = 3 * ngrid + 2;
     const int ws = w < b.nw ? w : b.nw - 1;
-    const double F = b.irradiance ? b.irradiance[ws] : 1.0, albedo = b.albedo[ws];
+    const double F = b.irradiance ? b.irradiance[ws] : 1.0;
+    const double albedo = b.los_albedo ? b.los_albedo[size_t(r) * b.nwavel_total + b.w0 + ws] : b.albedo[ws];   // (slot 2 ngrid: d / d of this value)
     double* acc = v.dacc + size_t(r) * S * nn * kWave;
     for (int x = 0; x < S * nn; ++x) acc[size_t(x) * kWave] = 0.0;
     if (n == 0) return;
@@ -1107,7 +1113,48 @@ struct DevMem {
 };
 }  // namespace
 
+// pi x brdf and its derivatives wrt the BRDF arguments at the ground geometry of the lines of sight (the reference's surfaces,
+// cpp/include/sasktran2/atmosphere/surface.h:151-352; kind 3: the functional BRDF of legacy/test_scalar.cpp:806-845): one thread per (line of sight, wavelength)
+__global__ void __launch_bounds__(256) k_so_los_albedo(DevRays rs, int kind, int nargs, const double* args, int nw, double* alb, double* dalb) {
+    const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (tid >= size_t(rs.nrays) * nw) return;
+    const int r = int(tid / nw), w = int(tid % nw);
+    double val = 0, d[3] = {0, 0, 0};
+    if (rs.ground_is_hit[r] && rs.ground_mu_in[r] > 0) {
+        const double mi = rs.ground_mu_in[r], mo = rs.ground_mu_out[r], phi = rs.ground_phi[r];
+        const double* a = args + size_t(w) * nargs;
+        if (kind == 2) {   // MODIS: (iso + vol k_vol + geo k_geo) / pi  (surface.h:236-281)
+            const double ssza = sqrt(1 - mi * mi), svza = sqrt(1 - mo * mo), tsza = ssza / mi, tvza = svza / mo, craa = -cos(phi), sraa = sin(phi);
+            const double csa = fmax(-1.0, fmin(1.0, mi * mo + ssza * svza * craa)), sa = acos(csa);
+            const double k_vol = ((0.5 * kPi - sa) * csa + sin(sa)) / (mi + mo) - 0.25 * kPi;
+            const double d2 = tsza * tsza + tvza * tvza - 2 * tsza * tvza * craa;
+            const double ct = fmax(-1.0, fmin(1.0, 2 * sqrt(d2 + tsza * tsza * tvza * tvza * sraa * sraa) * mi * mo / (mi + mo))), t = acos(ct);
+            const double k_geo = (t - sin(t) * ct) * (mi + mo) / (kPi * mi * mo) - (mi + mo - 0.5 * (1 + csa)) / (mi * mo);
+            val = a[0] + a[1] * k_vol + a[2] * k_geo;
+            d[0] = 1.0; d[1] = k_vol; d[2] = k_geo;
+        } else if (kind == 1) {   // SnowKokhanovsky: r0 exp(-alpha K0 K0 / r0) / pi, alpha = sqrt(4 pi arg)  (surface.h:151-229)
+            const double ss = sqrt(1 - mi * mi), sv = sqrt(1 - mo * mo), cost = fmax(-1.0, fmin(1.0, -mi * mo + ss * sv * cos(phi)));
+            const double theta = acos(cost) * 180.0 / kPi;
+            const double r0 = (1.247 + 1.186 * (mi + mo) + 5.157 * mi * mo + 11.1 * exp(-0.087 * theta) + 1.1 * exp(-0.014 * theta)) / (4.0 * (mi + mo));
+            const double kk = (3.0 / 7.0) * (1.0 + 2.0 * mi) * (3.0 / 7.0) * (1.0 + 2.0 * mo), alpha = sqrt(4 * kPi * a[0]), e = exp(-alpha * kk / r0);
+            val = r0 * e;
+            d[0] = -2.0 * kPi * kk * e / alpha;
+        } else {                  // kind 3
+            const double f = fabs(cos(phi)) * fabs(1 - fabs(fabs(mo) - fabs(mi)));
+            val = a[0] * f;
+            d[0] = f;
+        }
+    }
+    alb[tid] = val;
+    for (int k = 0; k < nargs; ++k) dalb[size_t(k) * rs.nrays * nw + tid] = d[k];
+}
+
 struct SoDeviceEngine::Impl {
+    int brdf_kind = 0, brdf_nargs = 1;              // non-Lambertian surface of the next solves (set_surface_brdf)
+    const double* brdf_args = nullptr;              // [nwavel][nargs] (device)
+    DevMem brdf_mem;
+    double *los_alb = nullptr, *los_dalb = nullptr; // [los][nwavel], [argument][los][nwavel]
+    size_t brdf_cap = 0;
     SoGeo g{};
     DevMem tables, scratch;
     SoBufs b{};
@@ -1170,6 +1217,8 @@ struct SoDeviceEngine::Impl {
         d.endpoint_start = tables.upload(r.endpoint_start);
         d.ground_is_hit = tables.upload(bytes(r.ground_is_hit));
         d.ground_mu_in = tables.upload(r.ground_mu_in);
+        d.ground_mu_out = tables.upload(r.ground_mu_out);
+        d.ground_phi = tables.upload(r.ground_phi);
         d.od = up(r.od);
         d.stencil_idx = tables.upload(r.stencil_idx);
         d.w_entrance = tables.upload(r.w_entrance);
@@ -1548,6 +1597,14 @@ int SoDeviceEngine::nstokes() const { return impl_->g.S; }
 bool SoDeviceEngine::has_successive_orders() const { return impl_->multiple_scatter; }
 bool SoDeviceEngine::has_unlinearised_sources() const { return false; }   // the diffuse field has its discrete adjoint (so_adjoint.inc)
 bool SoDeviceEngine::has_emission() const { return impl_->g.emission != 0; }
+void SoDeviceEngine::set_surface_brdf(int kind, int nargs, const double* d_args) {
+    if (kind < 0 || kind > 3 || (kind != 0 && (!d_args || nargs != (kind == 2 ? 3 : 1)))) throw std::runtime_error("sasktran2_amd: bad BRDF kind / argument count");
+    if (kind != 0 && has_successive_orders()) throw std::runtime_error("sasktran2_amd: non-Lambertian surfaces are not built for the successive-orders source");
+    impl_->brdf_kind = kind;
+    impl_->brdf_nargs = kind == 0 ? 1 : nargs;
+    impl_->brdf_args = kind == 0 ? nullptr : d_args;
+}
+const double* SoDeviceEngine::los_albedo_derivative() const { return impl_->los_dalb; }
 void SoDeviceEngine::set_fixed_point(bool enabled, double relative_tolerance, double absolute_tolerance, double damping, int anderson_depth) {
     if (!(relative_tolerance >= 0) || !(absolute_tolerance >= 0) || !std::isfinite(relative_tolerance) || !std::isfinite(absolute_tolerance))
         throw std::runtime_error("successive-orders tolerances must be finite and non-negative");
@@ -1827,8 +1884,23 @@ void SoDeviceEngine::solve_device(int nwavel, int nleg, const double* d_ext, con
         I.scratch_bytes = (so_doubles_per_wavelength(I, I.cap_nleg) + (I.cap_derivs ? size_t(g.nlos) * S * so_deriv_slots(g.ngrid, I.cap_groups) : 0) +
                            size_t(I.cap_groups) * g.nlos * g.ngrid * (S == 3 ? 2 : 1)) * sizeof(double) * W;
     }
+    const double* los_albedo = nullptr;
+    if (I.brdf_kind != 0) {
+        const size_t need = size_t(g.nlos) * nwavel * (1 + I.brdf_nargs);
+        if (need > I.brdf_cap) {
+            SO_HIP_CHECK(hipStreamSynchronize(st));
+            I.brdf_mem.release();
+            I.los_alb = I.brdf_mem.alloc<double>(size_t(g.nlos) * nwavel);
+            I.los_dalb = I.brdf_mem.alloc<double>(size_t(g.nlos) * nwavel * I.brdf_nargs);
+            I.brdf_cap = need;
+        }
+        hipLaunchKernelGGL(k_so_los_albedo, dim3(unsigned((size_t(g.nlos) * nwavel + 255) / 256)), dim3(256), 0, st, g.los, I.brdf_kind, I.brdf_nargs, I.brdf_args, nwavel,
+                           I.los_alb, I.los_dalb);
+        los_albedo = I.los_alb;
+    }
     for (int w0 = 0; w0 < nwavel; w0 += chunk) {
         SoBufs b = I.b;
+        b.los_albedo = los_albedo;
         b.nw = std::min(chunk, nwavel - w0);
         b.nwp = (b.nw + kPad - 1) / kPad * kPad;
         b.nleg = nleg;

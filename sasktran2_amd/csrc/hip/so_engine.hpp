@@ -42,6 +42,11 @@ class SoDeviceEngine {
     bool has_successive_orders() const;
     bool has_unlinearised_sources() const;   // successive orders: no weighting functions
     bool has_emission() const;               // line-of-sight emission source (standard / volume_emission_rate)
+    // non-Lambertian surface under the exact single scatter of the next solves (kind 0 Lambertian, 1 SnowKokhanovsky, 2 MODIS; d_args [nwavel][nargs]
+    // on the device): the direct bounce of a line of sight that ends on the ground uses pi x brdf at its ground geometry.  The albedo weighting
+    // function output is then d / d(that value); los_albedo_derivative() [argument][los][nwavel] holds d(value) / d(argument) of the last solve
+    void set_surface_brdf(int kind, int nargs, const double* d_args);
+    const double* los_albedo_derivative() const;
     // emission_source [nwavel][ngrid] and surface emission [nwavel] (DEVICE pointers, or null) used by the following solve_device calls of an
     // engine built with an emission source
     void set_emission(const double* d_emission, const double* d_surface_emission);

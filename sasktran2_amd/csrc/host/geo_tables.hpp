@@ -18,6 +18,7 @@ struct GeoTables {
     std::vector<int> lp_start, lp_q, lp_angle, lp_slot, g_start, g_slot, g_sza;
     std::vector<double> lp_w, g_w, lp_pc;
     std::vector<int> slot_is_ground;  // [nslot]
+    std::vector<double> gpt_mu;       // cos-angle grid value of every ground point of gpt_slot (outgoing zenith cosine of its ground source)
     // plane-parallel post-processing
     int pp_mode = 0;
     int include_ss = 1;  // set by the engine from single_scatter_source before the tables are uploaded
@@ -82,7 +83,7 @@ struct GeoTables {
         for (int s = 0; s < nsza; ++s) {
             for (int a = 0; a < nangle; ++a) {
                 int slot = ground_slot[size_t(s) * nangle + a];
-                if (slot >= 0) gpt_slot.push_back(slot);
+                if (slot >= 0) { gpt_slot.push_back(slot); gpt_mu.push_back(G.cos_angles[a]); }
             }
             gpt_start[s + 1] = (int)gpt_slot.size();
         }
@@ -223,9 +224,12 @@ struct GeoTables {
 struct SurfaceTables {
     int NP = 0, NQ = 0, nstr = 0;
     std::vector<double> cw, factor0, factor, modis_ke, kok_r0, kok_kk;
-    template <class KernelsFn, class PartsFn> void build(const GeoTables& t, KernelsFn modis_kernels, PartsFn kokhanovsky_parts) {
+    // sza: solar zenith index the sun pairs (and, in spherical geometry, the ground points) belong to
+    template <class KernelsFn, class PartsFn> void build(const GeoTables& t, KernelsFn modis_kernels, PartsFn kokhanovsky_parts, int sza = 0) {
         const double pi = 3.14159265358979323846;
-        const int N = t.N, nlos = t.pp_mu.empty() ? 0 : t.nlos;   // (spherical geometry: no line-of-sight pairs, no ray may end on the ground)
+        const bool pp = !t.pp_mu.empty();
+        // "line of sight" rows: the lines of sight with plane-parallel post-processing, the ground points of this sza in spherical geometry
+        const int N = t.N, g0 = pp ? 0 : t.gpt_start[sza], nlos = pp ? t.nlos : t.gpt_start[sza + 1] - g0;
         nstr = t.nstr;
         NP = N * N + N + nlos * N + nlos;
         // the two 512-point Gauss-Legendre panels over the azimuth of SurfaceStorage::compute_expansion (sktran_do_surface.h:62-93)
@@ -240,7 +244,7 @@ struct SurfaceTables {
             for (int q = 0; q < NQ; ++q) cw[size_t(m) * NQ + q] = wq[q] * std::cos(m * pi * aq[q]) * 0.5 * pi * (m == 0 ? 1.0 : 2.0);
         std::vector<double> mo(NP), mi(NP);
         factor0.resize(NP); factor.resize(NP);
-        const double csz0 = t.csz[0];
+        const double csz0 = t.csz[sza];
         auto set = [&](int pr, double mu_out, double mu_in, int in_stream) {
             mo[pr] = mu_out; mi[pr] = mu_in;
             const double f = in_stream >= 0 ? t.wt[in_stream] * t.mu[in_stream] : csz0 / pi;   // (1 + delta_m0) w mu for a stream, cos(sza) / pi for the sun
@@ -252,8 +256,9 @@ struct SurfaceTables {
             set(N * N + i, t.mu[i], csz0, -1);
         }
         for (int l = 0; l < nlos; ++l) {
-            for (int tt = 0; tt < N; ++tt) set(N * N + N + l * N + tt, t.pp_mu[l], t.mu[tt], tt);
-            set(N * N + N + nlos * N + l, t.pp_mu[l], csz0, -1);
+            const double mu_l = pp ? t.pp_mu[l] : t.gpt_mu[g0 + l];
+            for (int tt = 0; tt < N; ++tt) set(N * N + N + l * N + tt, mu_l, t.mu[tt], tt);
+            set(N * N + N + nlos * N + l, mu_l, csz0, -1);   // (spherical geometry: unused -- the direct bounce belongs to the single-scatter source)
         }
         modis_ke.assign(size_t(3) * nstr * NP, 0.0);
         kok_r0.resize(size_t(NP) * NQ); kok_kk.resize(NP);

@@ -184,6 +184,9 @@ struct RaySet {
     std::vector<int> endpoint_start;            // [nrays + 1] into the endpoint arrays (layers + 1 per ray, 0 for an empty ray)
     std::vector<char> ground_is_hit;            // [nrays]
     std::vector<double> ground_mu_in;           // [nrays] cosine of the solar zenith angle at the ground intersection (<= 0: no direct beam)
+    // outgoing zenith cosine and azimuth difference there (SingleScatterSource::ground_scattering_geometry, cpp/lib/solar/singlescattersource.cpp:264-279):
+    // what a non-Lambertian BRDF is evaluated at for the direct bounce
+    std::vector<double> ground_mu_out, ground_phi;
     // per layer
     Csr od;                                     // shell optical depth = od . extinction
     std::vector<int> stencil_idx;               // [nlayers][4] grid indices (sorted union of the two endpoints), -1 = unused
@@ -255,12 +258,14 @@ inline void append_rays(const skgeo::Geometry1D& geo, const std::vector<skgeo::T
     for (const auto& ray : rays) {
         const int n = (int)ray.layers.size();
         rs.ground_is_hit.push_back(ray.ground_is_hit ? 1 : 0);
-        double mu_in = 0;
+        double mu_in = 0, mu_out = 0, saa = 0;
         if (ray.ground_is_hit && n > 0) {
-            double saa;
             skgeo::calculate_csz_saz(geo.coords.sun, ray.layers[0].exit, ray.layers[0].average_look_away, mu_in, saa, geo.coords.geotype);
+            mu_out = -ray.layers[0].exit.cos_zenith_angle(ray.layers[0].average_look_away);
         }
         rs.ground_mu_in.push_back(mu_in);
+        rs.ground_mu_out.push_back(mu_out);
+        rs.ground_phi.push_back(saa);
         for (const auto& L : ray.layers) {
             for (int i = 0; i < L.nw; ++i)
                 if (L.w_od[i] != 0.0) rs.od.push(L.widx[i], L.w_od[i]);

@@ -75,7 +75,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
         sec(tau.size()), od(size_t(t.nq_total) * nw), omloc(od.size()), srcw(od.size()), att_total(size_t(nlos) * nw), lod(nt);
     std::vector<uint8_t> conv(size_t(t.nslot) * nw);
     for (int sl = 0; sl < t.nslot; ++sl)
-        for (int w = 0; w < nw; ++w) conv[size_t(w) * t.nslot + sl] = t.slot_is_ground[sl] ? 1 : 255;
+        for (int w = 0; w < nw; ++w) conv[size_t(w) * t.nslot + sl] = (t.slot_is_ground[sl] && h->brdf_kind == 0) ? 1 : 255;
     std::vector<int> notconv(nw, 0), norders(nw, nstr), stat(nw, 0);
     skd::Bufs b{};
     b.nw = nw; b.ext = extinction; b.ssa = ssa; b.leg = nullptr; b.nleg = 0; b.albedo = albedo; b.irradiance = solar_irradiance; b.delta_f = delta_f;
@@ -98,20 +98,19 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     v.J = J.data(); v.radiance = rad.data(); v.scratch = scratch.data(); v.scratch_stride = 1;
     v.ops = ops.data(); v.z = zb.data(); v.qlbuf = qlb.data(); v.grad = grad.data(); v.dnat = dnat.data(); v.derivs = derivatives;
     v.ngroups = G; v.dleg = d_legendre; v.dleg_nw = nw; v.dleg_w0 = 0; v.dfg = nullptr; v.da4 = da4.data();
-    // non-Lambertian surface: the geometry tables and the reflection factors of every (pair, wavelength), as kern_surface_expand forms them
+    // non-Lambertian surface: the geometry tables and the reflection factors of every (pair, wavelength) for one solar zenith index, as the
+    // device driver forms them (kern_surface_expand once per solar zenith index)
     skhost::SurfaceTables stab;
     std::vector<double> surf, surf_ops;
     v.brdf_kind = h->brdf_kind;
     v.brdf_nargs = h->brdf_nargs;
     v.surf_nlos = g.pp_mode ? nlos : 0;
-    if (h->brdf_kind != 0) {
-        if (!g.pp_mode) {   // spherical geometry: limb lines of sight, one solar zenith index (as the device driver)
-            if (g.nsza != 1) return -2;
-            for (int l = 0; l < nlos; ++l)
-                if (t.ray_ground[l]) return -2;
-        }
+    v.surf_slot0 = 0;
+    auto surface_for = [&](int sz) {
+        if (h->brdf_kind == 0) return;
+        stab = skhost::SurfaceTables();
         stab.build(t, [](double mi, double mo, double phi, double& kv, double& kg) { skv::modis_kernels(mi, mo, phi, kv, kg); },
-                   [](double mi, double mo, double phi, double& r0, double& kk) { skv::kokhanovsky_parts(mi, mo, phi, r0, kk); });
+                   [](double mi, double mo, double phi, double& r0, double& kk) { skv::kokhanovsky_parts(mi, mo, phi, r0, kk); }, sz);
         skv::SurfGeo sg{stab.NP, stab.NQ, stab.nstr, stab.cw.data(), stab.factor0.data(), stab.factor.data(), stab.modis_ke.data(), stab.kok_r0.data(), stab.kok_kk.data()};
         surf.assign(size_t(nw) * nstr * (1 + h->brdf_nargs) * stab.NP, 0.0);
         surf_ops.assign(size_t(nw) * N * (2 * n + 1), 0.0);
@@ -121,7 +120,9 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                                          surf.data() + size_t(w) * nstr * (1 + h->brdf_nargs) * stab.NP);
         v.surf = surf.data();
         v.surf_ops = surf_ops.data();
-    }
+        v.surf_nlos = g.pp_mode ? nlos : t.gpt_start[sz + 1] - t.gpt_start[sz];
+        v.surf_slot0 = (g.pp_mode || v.surf_nlos == 0) ? 0 : t.gpt_slot[t.gpt_start[sz]];
+    };
     v.k1_compact = skv::kv1_compact_layout(n, G);   // the work-space layout the device launcher chooses (its aliasing is the same on the CPU)
     const skv::Scr scr{scratch.data(), 1};
     const skv::Team team{0, 1};
@@ -135,6 +136,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
         skv::kv0_coefficients(g, b, v, w);
     }
     if (g.pp_mode) {
+        surface_for(0);
         for (int w = 0; w < nw; ++w) skd::k0_transmission(g, b, 0, w);
         for (int m = 0; m < nstr; ++m) {
             for (int w = 0; w < nw; ++w)
@@ -161,6 +163,7 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
         }
     } else {
         for (int s = 0; s < g.nsza; ++s) {
+            surface_for(s);
             for (int w = 0; w < nw; ++w) {
                 skd::k0_transmission(g, b, s, w);
                 norders[w] = nstr;

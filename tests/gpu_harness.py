@@ -134,6 +134,10 @@ def run_product_so(s, engine=None, solar_irradiance=None, derivatives=False, emi
     if surface_emission is not None:
         atmosphere.surface.emission[:] = surface_emission
     atmosphere.surface.albedo[:] = s["albedo"]
+    brdf = s.get("brdf")   # (kind, args [nwavel, nargs]): non-Lambertian surface; d_brdf [wavelength, los, argument] (intensity component)
+    if brdf is not None:
+        atmosphere.surface.set_brdf(brdf[0])
+        atmosphere.surface.brdf_args[:] = np.asarray(brdf[1], dtype=float).T
     dp, vp = ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
     with_emission = derivatives and int(config.emission_source) in (int(sk.EmissionSource.Standard), int(sk.EmissionSource.VolumeEmissionRate))
 
@@ -159,7 +163,10 @@ def run_product_so(s, engine=None, solar_irradiance=None, derivatives=False, emi
     if derivatives:
         out["d_extinction"] = np.transpose(res["wf_extinction"], (1, 2, 3, 0))
         out["d_ssa"] = np.transpose(res["wf_ssa"], (1, 2, 3, 0))
-        out["d_albedo"] = res["wf_albedo"]
+        if brdf is None:
+            out["d_albedo"] = res["wf_albedo"]
+        else:
+            out["d_brdf"] = np.transpose(res["wf_brdf"][:, :, :, 0], (1, 2, 0))
         if with_emission:
             out["d_emission"] = np.transpose(res["wf_emission"], (1, 2, 3, 0))
             out["d_surface_emission"] = res["wf_surface_emission"]

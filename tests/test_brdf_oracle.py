@@ -97,11 +97,51 @@ def test_spherical_limb_geometry_lambertian_limit_and_central_differences():
         assert np.max(np.abs(fd - base["d_brdf"][..., a])) < 1e-6 * np.abs(fd).max(), a
 
 
-def test_brdf_under_lines_of_sight_that_end_on_the_ground_in_spherical_geometry_is_refused():
-    s = sc.regression_1d(1)
+@pytest.mark.parametrize("num_sza", [1, 2])
+def test_spherical_geometry_with_lines_of_sight_that_end_on_the_ground(num_sza):
+    """The ground source per outgoing cos-angle grid point and order (accumulate_ground_sources, do_source_diffuse_storage.cpp:435-695): nadir and
+    limb rays of the reference's regression scene, one and two solar zenith profiles -- Lambertian limit, central differences for every argument."""
+    s = sc.regression_1d(2)
+    s["config"]["num_sza"] = num_sza
     eng = make_oracle(s)
-    with pytest.raises(RuntimeError):
-        _run(eng, s, ("modis", np.tile([0.2, 0.0, 0.0], (1, 1))))
+    lam = eng.run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True)
+    a0 = np.zeros((2, 3))
+    a0[:, 0] = s["albedo"]
+    mod = _run(eng, s, ("modis", a0), derivatives=True)
+    assert np.max(np.abs(lam["radiance"] - mod["radiance"])) < 1e-13 * np.abs(lam["radiance"]).max()
+    assert np.max(np.abs(lam["d_albedo"] - mod["d_brdf"][..., 0])) < 1e-12 * np.abs(lam["d_albedo"]).max()
+    for kind, args0, h in (("modis", [0.2, 0.05, 0.05], 1e-4), ("kokhanovsky", [0.04], 1e-5)):
+        args = np.tile(np.asarray(args0, dtype=float), (2, 1))
+        base = _run(eng, s, (kind, args), derivatives=True)
+        for a in range(len(args0)):
+            ap, am = args.copy(), args.copy()
+            ap[:, a] += h
+            am[:, a] -= h
+            fd = (_run(eng, s, (kind, ap))["radiance"] - _run(eng, s, (kind, am))["radiance"]) / (2 * h)
+            assert np.max(np.abs(fd - base["d_brdf"][..., a])) < 1e-6 * np.abs(fd).max(), (kind, a)
+
+
+def test_exact_single_scatter_over_a_brdf_surface():
+    """The direct bounce of a line of sight that ends on the ground (end_of_ray_source, cpp/lib/solar/singlescattersource.cpp:574-636) with pi x brdf at
+    its ground geometry: Lambertian limit and central differences on the single-scatter oracle (oracle/so_oracle.hpp)."""
+    from tests.test_so_oracle import make_so_oracle
+    s = sc.regression_so(2, nstokes=1)
+    eng = make_so_oracle(s, multiple_scatter="none")
+    run = lambda b, d=False: eng.run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=d, brdf=b)   # noqa: E731
+    lam = run(None, True)
+    a0 = np.zeros((2, 3))
+    a0[:, 0] = s["albedo"]
+    mod = run(("modis", a0), True)
+    assert np.array_equal(lam["radiance"], mod["radiance"]) and np.array_equal(lam["d_albedo"], mod["d_brdf"][..., 0])
+    args = np.tile([0.2, 0.05, 0.05], (2, 1))
+    base = run(("modis", args), True)
+    assert np.max(np.abs(base["radiance"] - lam["radiance"])) > 1e-3 * np.abs(lam["radiance"]).max()
+    for a in range(3):
+        ap, am = args.copy(), args.copy()
+        ap[:, a] += 1e-4
+        am[:, a] -= 1e-4
+        fd = (run(("modis", ap))["radiance"] - run(("modis", am))["radiance"]) / 2e-4
+        assert np.max(np.abs(fd - base["d_brdf"][..., a])) < 1e-9 * np.abs(fd).max(), a   # (linear in the arguments)
 
 
 def test_the_references_disabled_brdf_known_answer_is_reproduced_to_its_truncation_error():

@@ -116,11 +116,53 @@ def test_brdf_results_do_not_depend_on_the_wavelength_block(monkeypatch):
         assert np.array_equal(whole[k], blocks[k]), k
 
 
+@pytest.mark.parametrize("nstokes,num_sza,nstr", [(1, 1, 8), (1, 2, 8), (3, 2, 8), (1, 1, 16)])
+@pytest.mark.parametrize("kind,args0", CASES, ids=[c[0] for c in CASES])
+def test_brdf_under_lines_of_sight_that_end_on_the_ground_in_spherical_geometry(nstokes, num_sza, nstr, kind, args0):
+    """The reference's regression scene (two ground-viewing and two limb rays, spherical shell) over a non-Lambertian ground, diffuse field of
+    the discrete-ordinates source alone (single_scatter_source = none): ground source per cos-angle grid point and order."""
+    s = sc.regression_1d(3)
+    s["config"].update(num_sza=num_sza, nstr=nstr)
+    if nstokes == 3:
+        s = sc.to_vector(s, rayleigh_fraction=0.9)
+    s["brdf"] = (kind, _args(args0, 3))
+    got = run_product(s, derivatives=True)
+    ref = make_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, brdf=s["brdf"])
+    assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-10 * np.abs(ref["radiance"]).max()
+    for k in ("d_extinction", "d_ssa", "d_brdf"):
+        assert np.max(np.abs(got[k] - ref[k])) < 1e-8 * np.abs(ref[k]).max(), k
+
+
+@pytest.mark.parametrize("kind,args0", CASES, ids=[c[0] for c in CASES])
+def test_discrete_ordinates_plus_exact_single_scatter_over_a_brdf_surface(kind, args0):
+    """The reference's third BRDF scene (tests/constituent/test_modis.py:62-86: spherical, discrete ordinates + the default exact single scatter, a
+    ground-viewing ray): radiance = DO diffuse part (oracle/disco_oracle.hpp) + single scatter with the direct bounce at pi x brdf
+    (oracle/so_oracle.hpp); weighting functions of the BRDF arguments = the sum of the two sources'."""
+    from tests.gpu_harness import build_so_engine, run_product_so
+    from tests.test_so_oracle import make_so_oracle
+    s = sc.regression_so(3, nstokes=1)
+    s["config"].update(multiple_scatter="discrete_ordinates", num_streams=8)
+    args = _args(args0, 3)
+    eng = build_so_engine(s)
+    s["brdf"] = (kind, args)
+    got = run_product_so(s, engine=eng, derivatives=True)
+    ss = make_so_oracle(s, multiple_scatter="none").run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, brdf=s["brdf"])
+    sd = dict(s, config=dict(nstr=8, num_sza=s["config"]["num_sza"], nstokes=1, ss_in_do=False))
+    do = make_oracle(sd, ss_in_do=False).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, brdf=s["brdf"])
+    ref_rad = ss["radiance"][..., 0] + do["radiance"]
+    assert np.max(np.abs(got["radiance"][..., 0] - ref_rad)) < 1e-9 * np.abs(ref_rad).max()
+    ref_wf = ss["d_brdf"][:, :, 0, :] + do["d_brdf"]
+    assert np.max(np.abs(got["d_brdf"] - ref_wf)) < 1e-8 * np.abs(ref_wf).max()
+    assert np.abs(ss["d_brdf"]).max() > 0.05 * np.abs(ref_wf).max() and np.abs(do["d_brdf"]).max() > 0.05 * np.abs(ref_wf).max()   # both sources matter
+
+
 def test_brdf_outside_the_served_configurations_is_refused_with_a_message():
-    s = sc.regression_1d(1)   # spherical post-processing with lines of sight that end on the ground
+    s = sc.regression_so(1, nstokes=1)   # the successive-orders source
+    eng_ok = True
+    from tests.gpu_harness import build_so_engine, run_product_so
     s["brdf"] = ("modis", _args([0.2, 0.05, 0.05], 1))
     with pytest.raises(RuntimeError, match="non-Lambertian|-2"):
-        run_product(s, derivatives=False)
+        run_product_so(s, engine=build_so_engine(s))
     assert "non-Lambertian" in sk.last_error()
 
 

@@ -223,3 +223,19 @@ def test_the_references_functional_brdf_known_answer_emulated():
     got = run_emulated_vector(s, brdf=(gold["brdf"], np.array([[1.0]])))["radiance"][0]
     diff = np.abs(got - np.asarray(gold["expected"]))
     assert diff.max() < 3e-4 and np.median(diff) < 3e-5
+
+
+@pytest.mark.parametrize("num_sza", [1, 2])
+def test_brdf_ground_source_bodies_in_spherical_geometry_match_the_oracle(num_sza):
+    """Lines of sight that END on a non-Lambertian ground in spherical geometry: ground points per cos-angle grid point and order (kv3), their
+    azimuth sum along the ray (kv4), the stream-by-stream ground seeds of the adjoint sweeps (kv2b), per solar zenith index."""
+    s = sc.to_vector(sc.regression_1d(2), rayleigh_fraction=0.9)
+    s["config"]["num_sza"] = num_sza
+    args = np.tile([0.2, 0.05, 0.05], (2, 1)) * np.linspace(1.0, 1.3, 2)[:, None]
+    from tests.test_oracle_golden import make_oracle
+    ref = make_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, brdf=("modis", args))
+    got = run_emulated_vector(s, derivatives=True, brdf=("modis", args))
+    assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-12 * np.abs(ref["radiance"]).max()
+    for k in ("d_extinction", "d_ssa", "d_brdf"):
+        assert np.max(np.abs(got[k] - ref[k])) < 1e-9 * np.abs(ref[k]).max(), k
+
