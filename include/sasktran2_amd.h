@@ -333,7 +333,7 @@ int sk_surface_get_derivative_mapping_name(Surface* storage, int index, const ch
 int sk_surface_set_zero(Surface* storage);                                                     /* atmosphere.h:188 */
 
 /* brdf.h:10-14 -- SnowKokhanovsky (1 argument) and MODIS (isotropic, volumetric, geometric) surfaces: served by the discrete-ordinates source in
- * plane-parallel / pseudo-spherical geometry and, for lines of sight that do not end on the ground, in spherical geometry; brdf_args of
+ * every geometry type, alone or next to the exact / solar-table single-scatter source; brdf_args of
  * sk_surface_set_brdf is (num_args x num_wavel) column-major, a surface derivative mapping's d_brdf (num_wavel x num_args) column-major
  * (create the mapping after sk_surface_set_brdf).  Other sources / geometries answer -2 with a message in sk_amd_last_error */
 BRDF* sk_brdf_create_kokhanovsky(int nstokes);                                                 /* brdf.h:10 */
