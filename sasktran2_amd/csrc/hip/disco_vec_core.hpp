@@ -2320,7 +2320,8 @@ template <class Out> SKD_HD void matvec8(const double* A, int ld, int M, int k0,
 // backward sweep  z_p = y_p - BP zA_{p+1}  and reduced-gradient contraction of one (line of sight, Stokes component); the forward
 // sweep has left y in v.z.  table_weights: the Legendre-space HD term applies (spherical table; false for plane parallel)
 // reduced-gradient contraction of one (line of sight, Stokes component) from the adjoint vectors z left in v.z
-SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, size_t tid, size_t nt, double gw,
+// (BRDF = false: an instantiation without the non-Lambertian ground, for the tuned team kernel of Lambertian solves -- its register count is its occupancy)
+template <bool BRDF = true> SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v, int s, int m, int w, size_t tid, size_t nt, double gw,
                                     bool table_weights) {
     const int S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr;
     const VOps O(n, NL, v.ngroups);
@@ -2343,14 +2344,14 @@ SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v,
                 const double q = v.qlbuf[(size_t(p) * NL + l) * nt + tid];
                 for (int t = 0; t < 4; ++t) gth[t] += ops[O.HD() + t * NL + l] * q;
             }
-        if (last && m == 0 && v.brdf_kind == 0) {
+        if (last && m == 0 && (!BRDF || v.brdf_kind == 0)) {
             for (int t = 0; t < 4; ++t) gth[t] += (zBsum + gw) * ops[O.GD() + t];
             const double rho = b.albedo[w], ipb = ops[O.IPB()];
             v.grad[size_t(4 * nlyr) * nt + tid] += gw * 2.0 * ipb + zBsum * (2.0 * ipb + g.csz[s] / kPi * b.T[size_t(nlyr) * nw + w]);
             // solar: d / d(beam transmission at the ground); thermal pass: d / d(surface emission) (as skd::K2bTask::gradient)
             v.grad[size_t(4 * nlyr + 1) * nt + tid] += b.thermal_pass ? zBsum : zBsum * g.csz[s] / kPi * rho;
         }
-        if (last && v.brdf_kind != 0) {
+        if constexpr (BRDF) if (last && v.brdf_kind != 0) {
             // non-Lambertian ground (every order): the adjoint weight of incoming stream t is c_t = sum_i zB_i RS(i, t) + gw RL(los, t)
             const int N = g.N, los = int((tid / S) % g.nlos), na = v.brdf_nargs;
             const VSurf SF(N, v.surf_nlos, na);
@@ -2382,9 +2383,9 @@ SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v,
         }
         for (int t = 0; t < 4; ++t) v.grad[size_t(t * nlyr + p) * nt + tid] += gth[t];
         // scattering groups: the same contraction with the group's DI / HD / GD rows
-        double ggb[kMaxGroupsWithBrdf];   // non-Lambertian ground: sum_t c_t (d I-_t / d group at fixed L, M), the counterpart of (zBsum + gw) GGD
-        for (int gi = 0; gi < kMaxGroupsWithBrdf; ++gi) ggb[gi] = 0;
-        if (last && v.brdf_kind != 0 && v.ngroups > 0) {
+        double ggb[BRDF ? kMaxGroupsWithBrdf : 1];   // non-Lambertian ground: sum_t c_t (d I-_t / d group at fixed L, M), the counterpart of (zBsum + gw) GGD
+        for (int gi = 0; gi < (BRDF ? kMaxGroupsWithBrdf : 1); ++gi) ggb[gi] = 0;
+        if constexpr (BRDF) if (last && v.brdf_kind != 0 && v.ngroups > 0) {
             const int N = g.N, los = int((tid / S) % g.nlos);
             const VSurf SF(N, v.surf_nlos, v.brdf_nargs);
             const double* sf = vsurf_at(v, g, m, w);
@@ -2407,8 +2408,8 @@ SKD_HD void adjoint_gradient_column(const Geo& g, const Bufs& b, const VBufs& v,
             }
             if (table_weights)
                 for (int l = m * C; l < NL; ++l) gg += ops[O.GHD(gi) + l] * v.qlbuf[(size_t(p) * NL + l) * nt + tid];
-            if (last && m == 0 && v.brdf_kind == 0) gg += (zBsum + gw) * ops[O.GGD(gi)];
-            if (last && v.brdf_kind != 0 && gi < kMaxGroupsWithBrdf) gg += ggb[gi];
+            if (last && m == 0 && (!BRDF || v.brdf_kind == 0)) gg += (zBsum + gw) * ops[O.GGD(gi)];
+            if constexpr (BRDF) if (last && v.brdf_kind != 0 && gi < kMaxGroupsWithBrdf) gg += ggb[gi];
             v.grad[size_t(4 * nlyr + 2 + gi * nlyr + p) * nt + tid] += gg;
         }
     }
@@ -2496,7 +2497,7 @@ SKD_HD void kv2b_adjoint(const Geo& g, const VGeo& vg, const Bufs& b, const VBuf
 //   ws: (NL + 3 n + 1) NC doubles of team-shared work space: QL [NL][NC], Y [2n][NC], carry [n][NC], gw [NC]
 SKD_HD size_t kv2bt_scratch(int n, int NL, int NC) { return (size_t(NL) + 3 * size_t(n) + 1) * size_t(NC); }
 
-SKV_TEAM_BODY void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int w, double* ws) {
+template <bool BRDF = true> SKV_TEAM_BODY void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int w, double* ws) {
     const int S = v.S, n = v.n, M2 = 2 * n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr, C = (S == 3) ? 3 : 1, NL = C * nstr, NC = g.nlos * S;
     const VOps O(n, NL, v.ngroups);
     const size_t nt = size_t(nw) * NC, t0 = size_t(w) * NC;
@@ -2504,12 +2505,12 @@ SKV_TEAM_BODY void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, con
     SKV_PAR(col, NC) {
         const int los = col / S, sout = col % S;
         double gw = 0;  // the ground feeds the intensity only
-        if (sout == 0 && m == 0 && g.ray_ground[los] && v.brdf_kind == 0) {
+        if (sout == 0 && m == 0 && g.ray_ground[los] && (!BRDF || v.brdf_kind == 0)) {
             for (int t = g.g_start[los]; t < g.g_start[los + 1]; ++t)
                 if (g.g_sza[t] == s && skd::conv_at(b, g, g.g_slot[t], w) > m) gw += g.g_w[t];
             gw *= b.att_total[size_t(los) * nw + w];
         }
-        if (v.brdf_kind != 0 && sout == 0 && g.ray_ground[los]) gw = b.att_total[size_t(los) * nw + w];   // (every order; weighed stream by stream below)
+        if constexpr (BRDF) if (v.brdf_kind != 0 && sout == 0 && g.ray_ground[los]) gw = b.att_total[size_t(los) * nw + w];   // (every order; weighed stream by stream below)
         gwv[col] = gw;
         for (int i = 0; i < n; ++i) Cc[size_t(i) * NC + col] = 0;
     }
@@ -2563,7 +2564,7 @@ SKV_TEAM_BODY void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, con
         team_gemm(team, M2, NC, NL, [&](int i, int k) { return ops[O.FP() + i * NL + k]; }, [&](int k, int col) { return QL[size_t(k) * NC + col]; },
                   [&](int i, int col, double val) {
                       double seed = last ? gwv[col] * ops[O.UG() + i] : 0.0;
-                      if (last && v.brdf_kind != 0 && gwv[col] != 0.0) {   // non-Lambertian ground: sum_t c_t Dinv^T e_t (few columns: the rays that end on the ground)
+                      if constexpr (BRDF) if (last && v.brdf_kind != 0 && gwv[col] != 0.0) {   // non-Lambertian ground: sum_t c_t Dinv^T e_t (few columns: the rays that end on the ground)
                           double cg[kMaxSurfStreams];
                           ground_los_weights(g, b, v, vsurf_at(v, g, m, w), 0, s, m, col / S, w, gwv[col], cg);
                           const double* so = v.surf_ops + size_t(w) * g.N * (M2 + 1);
@@ -2610,8 +2611,8 @@ SKV_TEAM_BODY void kv2b_team(const Team& team, const Geo& g, const VGeo& vg, con
     int CH = team.width / NC;
     if (CH > 8) CH = 8;
     while (CH > 1 && CH * (NR + 1) > NL) --CH;
-    if (NG > 4 || CH < 2 || v.brdf_kind != 0) {   // (a non-Lambertian ground weighs the ground rows stream by stream: the per-column form carries it)
-        SKV_PAR(col, NC) adjoint_gradient_column(g, b, v, s, m, w, t0 + col, nt, gwv[col], true);
+    if (NG > 4 || CH < 2 || (BRDF && v.brdf_kind != 0)) {   // (a non-Lambertian ground weighs the ground rows stream by stream: the per-column form carries it)
+        SKV_PAR(col, NC) adjoint_gradient_column<BRDF>(g, b, v, s, m, w, t0 + col, nt, gwv[col], true);
         team.sync();
         return;
     }
