@@ -243,3 +243,36 @@ def test_the_references_functional_brdf_known_answer_on_the_device():
     diff = np.abs(got["radiance"][0] - np.asarray(gold["expected"]))
     assert diff.max() < 3e-4 and np.median(diff) < 3e-5
 
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_brdf_scenes_match_the_oracle(seed):
+    """Random surface arguments, stream counts, geometry types, Stokes dimensions and solar zenith profiles (nadir + limb rays in spherical
+    geometry, nadir rays otherwise) against the oracle."""
+    rng = np.random.default_rng(4100 + seed)
+    nstokes = int(rng.choice([1, 3]))
+    nstr = int(rng.choice([4, 6, 8, 10, 16] if nstokes == 1 else [4, 6, 8]))
+    geotype = int(rng.choice([sc.GEO_PLANEPARALLEL, sc.GEO_PSEUDOSPHERICAL, sc.GEO_SPHERICAL]))
+    nw = 3
+    if geotype == sc.GEO_SPHERICAL:
+        s = sc.regression_1d(nw)
+        s["config"].update(num_sza=int(rng.choice([1, 2, 3])), nstr=nstr)
+        s["leg"] = s["leg"][:max(nstr, 3)] if s["leg"].shape[0] > max(nstr, 3) else s["leg"]
+    else:
+        s = sc.nadir_c1(num_wavelengths=nw, nstr=nstr)
+        s["geometry"]["geotype"] = geotype
+    s["ssa"] = np.clip(s["ssa"] * rng.uniform(0.6, 1.05), 0.05, 0.999)
+    s["extinction"] = s["extinction"] * rng.uniform(0.5, 2.0)
+    if nstokes == 3:
+        s = sc.to_vector(s, rayleigh_fraction=float(rng.uniform(0.3, 1.0)))
+    if rng.random() < 0.5:
+        kind, args = "modis", np.column_stack([rng.uniform(0.05, 0.5, nw), rng.uniform(0.0, 0.1, nw), rng.uniform(0.0, 0.05, nw)])
+    else:
+        kind, args = "kokhanovsky", rng.uniform(0.005, 0.2, (nw, 1))
+    s["brdf"] = (kind, args)
+    got = run_product(s, derivatives=True)
+    ref = make_oracle(s).run(s["extinction"], s["ssa"], s["leg"], s["albedo"], derivatives=True, brdf=s["brdf"])
+    assert np.all(np.isfinite(got["radiance"]))
+    assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-9 * np.abs(ref["radiance"]).max(), (kind, nstr, geotype, nstokes)
+    for k in ("d_extinction", "d_ssa", "d_brdf"):
+        assert np.max(np.abs(got[k] - ref[k])) < 1e-7 * np.abs(ref[k]).max(), (k, kind, nstr, geotype, nstokes)
