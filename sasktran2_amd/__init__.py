@@ -717,6 +717,8 @@ class Engine:
                 self._apply_delta_m(H, delta_order)
                 h_atm = H["atmosphere"]
                 sizes = {name: ngrid for name in names}
+                if surface_names == ("wf_albedo",) and atmosphere.surface.brdf != "lambertian":   # raw interface: one mapping per BRDF argument
+                    surface_names = tuple(f"wf_brdf_{a}" for a in range(atmosphere.surface.num_brdf_args))
             return self._vjp_on_handle(L, h_atm, nw, S, cotangent, names, surface_names, sizes)
 
     def _vjp_on_handle(self, L, h_atm, nw, S, cotangent, names, surface_names, sizes):

@@ -276,3 +276,34 @@ def test_random_brdf_scenes_match_the_oracle(seed):
     assert np.max(np.abs(got["radiance"] - ref["radiance"])) < 1e-9 * np.abs(ref["radiance"]).max(), (kind, nstr, geotype, nstokes)
     for k in ("d_extinction", "d_ssa", "d_brdf"):
         assert np.max(np.abs(got[k] - ref[k])) < 1e-7 * np.abs(ref[k]).max(), (k, kind, nstr, geotype, nstokes)
+
+
+def test_vjp_and_jvp_over_a_brdf_surface_equal_the_contracted_jacobian():
+    """sk_engine_calculate_vjp / _jvp (contractions of the Jacobian on this path) with the BRDF arguments among the parameters."""
+    s = _scene(1, 8)
+    nw, nlos = len(s["albedo"]), len(s["rays"])
+    args = _args([0.2, 0.05, 0.05], nw)
+    eng = build_engine(s)
+    engine, config, geometry = eng
+    s["brdf"] = ("modis", args)
+    full = run_product(s, derivatives=True, engine=eng)
+    atmosphere = sk.Atmosphere(geometry, config, numwavel=nw, calculate_derivatives=True)
+    atmosphere.storage.total_extinction[:] = s["extinction"]
+    atmosphere.storage.ssa[:] = s["ssa"]
+    atmosphere.leg_coeff.a1[:] = s["leg"]
+    atmosphere.surface.set_brdf("modis")
+    atmosphere.surface.brdf_args[:] = args.T
+    rng = np.random.default_rng(5)
+    cot = rng.normal(size=(nw, nlos, 1))
+    rad, grads = engine.calculate_vjp(atmosphere, cot)
+    assert np.max(np.abs(rad[:, :, 0] - full["radiance"])) < 1e-13 * np.abs(full["radiance"]).max()
+    for a in range(3):
+        want = np.einsum("wl,wl->w", cot[:, :, 0], full["d_brdf"][:, :, a])
+        assert np.max(np.abs(grads[f"wf_brdf_{a}"] - want)) < 1e-10 * np.abs(want).max(), a
+    want = np.einsum("wl,wlq->q", cot[:, :, 0], full["d_extinction"])
+    assert np.max(np.abs(grads["wf_extinction"] - want)) < 1e-10 * np.abs(want).max()
+    t_surf = {f"wf_brdf_{a}": rng.normal(size=nw) for a in range(3)}
+    t_ext = rng.normal(size=len(s["geometry"]["altitudes"])) * 1e-6
+    rad2, jvp = engine.calculate_jvp(atmosphere, {"wf_extinction": t_ext}, surface_tangents=t_surf)
+    want = np.einsum("wlq,q->wl", full["d_extinction"], t_ext) + sum(full["d_brdf"][:, :, a] * t_surf[f"wf_brdf_{a}"][:, None] for a in range(3))
+    assert np.max(np.abs(jvp[:, :, 0] - want)) < 1e-10 * np.abs(want).max()
