@@ -761,7 +761,7 @@ class Engine:
         derivs = atmosphere.calculate_derivatives
         H, delta_order = self._prepare(atmosphere, derivs)
         h_st, h_su, h_atm = H["storage"], H["surface"], H["atmosphere"]
-        rad = np.zeros((nw, nlos, S))
+        rad = _host.zeros((nw, nlos, S))
         flux, flux_names = self._flux_output(nw)
         h_out = L.sk_output_create(_p(rad), nw * nlos, S, _p(flux) if flux is not None else None, 0 if flux is None else flux.size)
         out = {"radiance": rad}
@@ -771,7 +771,7 @@ class Engine:
                     out[name] = _host.empty((ngrid, nw, nlos, S))   # (written in full by the call; page-locked: see hostmem.py)
                     L.sk_output_assign_derivative_memory(h_out, name.encode(), _p(out[name]), nw * nlos, S, ngrid)
                 if atmosphere.surface.brdf == "lambertian":
-                    out["wf_albedo"] = np.zeros((nw, nlos, S))
+                    out["wf_albedo"] = _host.zeros((nw, nlos, S))
                     L.sk_output_assign_surface_derivative_memory(h_out, b"wf_albedo", _p(out["wf_albedo"]), nw * nlos, S)
                 else:
                     out["wf_brdf"] = np.zeros((atmosphere.surface.num_brdf_args, nw, nlos, S))
@@ -832,7 +832,7 @@ class Engine:
         derivs = atmosphere.calculate_derivatives
         h_brdf, h_su, _keep = self._surface_handles(L, atmosphere, S)
         h_atm = L.sk_atmosphere_create(fe.storage_handle(), h_su, int(derivs), 0)
-        rad = np.zeros((nw, nlos, S))
+        rad = _host.zeros((nw, nlos, S))
         flux, flux_names = self._flux_output(nw)
         h_out = L.sk_output_create(_p(rad), nw * nlos, S, _p(flux) if flux is not None else None, 0 if flux is None else flux.size)
         raw, raw_surface = {}, {}
@@ -843,7 +843,7 @@ class Engine:
                     L.sk_output_assign_derivative_memory(h_out, name.encode(), _p(raw[name]), nw * nlos, S, m.num_output)
                 for name in atmosphere._surface_mappings:
                     self._fill_surface_mapping(L, h_su, atmosphere, name)
-                    raw_surface[name] = np.zeros((nw, nlos, S))
+                    raw_surface[name] = _host.zeros((nw, nlos, S))
                     L.sk_output_assign_surface_derivative_memory(h_out, name.encode(), _p(raw_surface[name]), nw * nlos, S)
             # src/sasktran2/atmosphere.py:845-854: scale when more moments are stored than streams are used
             if self._config.delta_m_scaling and atmosphere.num_moments > self._config.num_streams:

@@ -4,7 +4,10 @@ this mirror, only that arrays of a megabyte and more come from `sk_amd_host_allo
 staging copy, which is the difference between ~8 and ~50 GB/s for the 74 MB in / 208 MB out of one 10 000-wavelength call.
 
 Blocks are pooled by size (pinning costs tens of milliseconds per 100 MB): an array's block returns to the pool when the array and all of
-its views are gone.  Without a GPU, or when pinning fails, ordinary NumPy memory is used -- this is memory placement, not a compute path."""
+its views are gone.  EVERY array a call's DMA writes into comes from here, the 2 MB radiance / wf_albedo arrays too: a pageable array that was
+the target of a device-to-host copy and is then dropped by the caller is munmap'ed, the driver invalidates its GPU mapping, and the next
+device synchronisation stalls 20-29 ms (measured round 4, `tools/probes/host_path_patterns.py`: 138.5 -> 110.3 ms per 10 000-wavelength call
+for a caller that drops the previous result before the next call).  Without a GPU, or when pinning fails, ordinary NumPy memory is used -- this is memory placement, not a compute path."""
 from __future__ import annotations
 
 import ctypes
@@ -14,7 +17,7 @@ import weakref
 
 import numpy as np
 
-_SMALL = 1 << 20          # below this an ordinary array
+_SMALL = 128 << 10        # below this an ordinary array (glibc serves it from the heap: no munmap when it is dropped, see below)
 _GRANULE = 2 << 20        # pooled block sizes are multiples of this
 _KEEP = 2 << 30           # free bytes the pool keeps before it returns blocks to the driver
 
