@@ -323,7 +323,10 @@ def main():
         atmosphere.storage.ssa[:] = s["ssa"]
         atmosphere.leg_coeff.a1[:] = s["leg"]
         atmosphere.surface.albedo[:] = s["albedo"]
-        engine.calculate_radiance(atmosphere, as_dataset=False)
+        # warm-up to the steady state of a caller that keeps the previous result while the next call runs: two sets of page-locked output
+        # blocks exist in the mirror's pool before the timer starts (pinning a fresh 208 MB set costs ~10 ms once, hostmem.py)
+        warm = [engine.calculate_radiance(atmosphere, as_dataset=False) for _ in range(2)]
+        del warm
         gc.collect()
         reps = 3
         t = time.perf_counter()
