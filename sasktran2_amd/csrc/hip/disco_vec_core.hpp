@@ -1889,6 +1889,126 @@ SKD_HD void kv3_table_values(const Geo& g, const VGeo& vg, const Bufs& b, const 
     }
 }
 
+// The same task by a TEAM (one wavefront per (layer, wavelength) on the device): the lanes run over the solutions, the rows of W+-, the
+// Legendre orders and the layer's table points in turn, so that the record is read in unit-stride runs across the lanes -- the per-thread form
+// above walks its own 90 KB record (n = 48) with every lane on another cache line and moved 4 x the record's bytes.  Every output element is
+// summed in the order of the per-thread form: bit-identical results.   ws: kv3_scratch(n, nstr) doubles of team-shared work space
+SKV_TEAM_BODY void kv3_table_values_team(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws) {
+    const int N = g.N, S = v.S, n = v.n, nstr = g.nstr, nw = b.nw, nlyr = g.nlyr;
+    const VRec R(n);
+    const double* c = vrec_at(v, nlyr, p, w);
+    const double* xs = vxsol_at(v, nlyr, p, w);
+    const double th = b.tau[size_t(p) * nw + w], T = b.T[size_t(p) * nw + w], sc = b.sec[size_t(p) * nw + w];
+    double *cL = ws, *cM = ws + n, *pq = ws + 2 * n, *vl = ws + 4 * n;
+    SKV_PAR(j, n) {
+        skd::PPMult pm;
+        skd::pp_multipliers(T, th, sc, c[R.K() + j], g.lfrac[p], pm);
+        if (v.derivs) skd::ppm_store(vrec_at(v, nlyr, p, w) + R.PPM() + 14 * j, pm);
+        cL[j] = pm.hp * xs[j] + c[R.AP() + j] * pm.Dm;
+        cM[j] = pm.hm * xs[n + j] + c[R.AM() + j] * pm.Dp;
+    }
+    team.sync();
+    SKV_PAR(r, n) {   // (legendre_source, first half: lanes over the rows r, W+-(r, a) contiguous in r)
+        double pr = 0, qr = 0;
+        for (int a = 0; a < n; ++a) {
+            const double wp = c[R.WP() + r + n * a], wm = c[R.WM() + r + n * a];
+            pr += wp * cL[a] + wm * cM[a];
+            qr += wm * cL[a] + wp * cM[a];
+        }
+        pq[r] = pr * 0.5 * g.wt[r / S];
+        pq[n + r] = qr * 0.5 * g.wt[r / S];
+    }
+    team.sync();
+    SKV_PAR(l, nstr) {   // (second half: lanes over the Legendre orders)
+        double cp[3] = {0, 0, 0}, cq[3] = {0, 0, 0};
+        if (l >= m) {
+            for (int j = 0; j < N; ++j) {
+                const Fun3 fj = fun_mu(g, vg, m, j);
+                if (S == 1) {
+                    cp[0] += fj.P[l] * pq[j];
+                    cq[0] += fj.P[l] * pq[n + j];
+                } else {
+                    const double xp[3] = {pq[3 * j], pq[3 * j + 1], pq[3 * j + 2]}, xq[3] = {pq[n + 3 * j], pq[n + 3 * j + 1], pq[n + 3 * j + 2]};
+                    double y[3];
+                    pi_apply(fj.P[l], fj.R[l], fj.T[l], xp, y);
+                    for (int cc = 0; cc < 3; ++cc) cp[cc] += y[cc];
+                    pi_apply(fj.P[l], fj.R[l], fj.T[l], xq, y);
+                    for (int cc = 0; cc < 3; ++cc) cq[cc] += y[cc];
+                }
+            }
+        }
+        const double sg = ((l - m) & 1) ? -1.0 : 1.0;
+        const double x[3] = {sg * cp[0] + cq[0], sg * cp[1] + cq[1], -sg * cp[2] + cq[2]};
+        double c4[4], y[3];
+        load_coef(b, v, nstr, p, l, w, c4);
+        greek_apply(c4, x, y);
+        for (int cc = 0; cc < 3; ++cc) vl[size_t(l) * 3 + cc] = y[cc];
+    }
+    team.sync();
+    int unconverged = 0;
+    const int t0 = g.pt_start[s * nlyr + p], t1 = g.pt_start[s * nlyr + p + 1];
+    SKV_PAR(tt, t1 - t0) {
+        const int t = t0 + tt, slot = g.pt_slot[t];
+        if (skd::conv_at(b, g, slot, w) <= m) continue;
+        const Fun3 fa = fun_ang(g, vg, m, g.pt_angle[t]);
+        double val[3] = {0, 0, 0};
+        for (int l = m; l < nstr; ++l) {
+            if (S == 1) {
+                val[0] += fa.P[l] * vl[size_t(l) * 3];
+            } else {
+                const double x[3] = {vl[size_t(l) * 3], vl[size_t(l) * 3 + 1], vl[size_t(l) * 3 + 2]};
+                double y[3];
+                pi_apply(fa.P[l], fa.R[l], fa.T[l], x, y);
+                for (int cidx = 0; cidx < 3; ++cidx) val[cidx] += y[cidx];
+            }
+        }
+        for (int cidx = 0; cidx < S; ++cidx) vJ_at(v, g, m, slot, w, cidx) = val[cidx];
+        if (m >= 2) {
+            const double prev = vJ_at(v, g, m - 1, slot, w, 0), prev2 = vJ_at(v, g, m - 2, slot, w, 0);
+            if ((fabs(val[0] / prev) < 1e-4 || prev < 1e-10) && (fabs(val[0] / prev2) < 1e-4 || prev2 < 1e-10)) {
+                skd::conv_at(b, g, slot, w) = (uint8_t)(m + 1);
+            } else {
+                unconverged = 1;
+            }
+        }
+    }
+    if (p == nlyr - 1 && v.brdf_kind != 0) {
+        const VSurf SF(N, v.surf_nlos, v.brdf_nargs);
+        const double* sf = vsurf_at(v, g, m, w);
+        SKV_PAR(tt, g.gpt_start[s + 1] - g.gpt_start[s]) {
+            const int t = g.gpt_start[s] + tt, k = g.gpt_slot[t] - v.surf_slot0;
+            double diffuse = 0;
+            for (int i = 0; i < N; ++i) {
+                double sv = c[R.G() + 2 * n + i * S];
+                for (int j = 0; j < n; ++j)
+                    sv += xs[j] * c[R.WP() + i * S + n * j] * c[R.E() + j] + xs[n + j] * c[R.WM() + i * S + n * j];
+                diffuse += sf[SF.RL(k, i)] * sv;
+            }
+            vJ_at(v, g, m, g.gpt_slot[t], w, 0) = diffuse;
+            for (int cidx = 1; cidx < S; ++cidx) vJ_at(v, g, m, g.gpt_slot[t], w, cidx) = 0;
+        }
+    } else if (p == nlyr - 1 && m == 0 && team.lane == 0) {
+        double diffuse = 0;
+        for (int i = 0; i < N; ++i) {
+            double sv = c[R.G() + 2 * n + i * S];
+            for (int j = 0; j < n; ++j)
+                sv += xs[j] * c[R.WP() + i * S + n * j] * c[R.E() + j] + xs[n + j] * c[R.WM() + i * S + n * j];
+            diffuse += 2.0 * g.mu[i] * g.wt[i] * sv * b.albedo[w];
+        }
+        for (int t = g.gpt_start[s]; t < g.gpt_start[s + 1]; ++t) {
+            vJ_at(v, g, m, g.gpt_slot[t], w, 0) = diffuse;
+            for (int cidx = 1; cidx < S; ++cidx) vJ_at(v, g, m, g.gpt_slot[t], w, cidx) = 0;
+        }
+    }
+    if (unconverged) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(&b.notconv[w], 1);
+#else
+        b.notconv[w] |= 1;
+#endif
+    }
+}
+
 // =================================================================================================
 // KV4: line-of-sight integration of the diffuse table, 3 Stokes components        (task = wavelength x LOS)
 //   azimuth factors cos(m azi) for I and Q, sin(m azi) for U (do_source_diffuse_storage.cpp:158-184); scalar attenuation

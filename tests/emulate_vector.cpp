@@ -131,6 +131,8 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
     const char* park_env = std::getenv("SKV_EMU_PARK");
     std::vector<double> parkbuf((park_env && atoi(park_env) && G == 0) ? 2 * size_t(n) * n : 0);
     double* park = parkbuf.empty() ? nullptr : parkbuf.data();
+    const char* k3_env = std::getenv("SKV_EMU_K3_TEAM");
+    const bool k3_team = k3_env && atoi(k3_env) != 0;
     for (int w = 0; w < nw; ++w) {
         skd::k0_layer_optics(g, b, w);  // tau / omega / LOS shells; its scalar a_l is not used (nleg = 0)
         skv::kv0_coefficients(g, b, v, w);
@@ -180,7 +182,10 @@ int emuv_run(void* hv, int nwavel, int nleg, const double* extinction, const dou
                     if (m < norders[w]) skv::kv2_bvp(team, g, b, v, s, m, w, ws, ws + skv::kv2_scratch_main(n));
                 for (int w = 0; w < nw; ++w)
                     for (int p = 0; p < nlyr; ++p)
-                        if (m < norders[w]) skv::kv3_table_values(g, vg, b, v, s, m, p, w, scr);
+                        if (m < norders[w]) {
+                            if (k3_team) skv::kv3_table_values_team(team, g, vg, b, v, s, m, p, w, ws);   // SKV_EMU_K3_TEAM=1: the device's wavefront form
+                            else skv::kv3_table_values(g, vg, b, v, s, m, p, w, scr);
+                        }
                 if (derivatives) {
                     for (int w = 0; w < nw; ++w)
                         for (int p = 0; p < nlyr; ++p)

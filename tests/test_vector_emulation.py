@@ -239,3 +239,19 @@ def test_brdf_ground_source_bodies_in_spherical_geometry_match_the_oracle(num_sz
     for k in ("d_extinction", "d_ssa", "d_brdf"):
         assert np.max(np.abs(got[k] - ref[k])) < 1e-9 * np.abs(ref[k]).max(), k
 
+
+
+@pytest.mark.parametrize("vector", [False, True], ids=["NSTOKES=1", "NSTOKES=3"])
+def test_team_form_of_the_table_values_is_bit_identical(vector, monkeypatch):
+    """kv3_table_values_team (one wavefront per (layer, wavelength) on the device, unit-stride record reads) sums every output element in the
+    order of the per-thread form: radiances, convergence bookkeeping and weighting functions equal bit for bit -- also over a BRDF ground."""
+    s = sc.regression_1d(2)
+    if vector:
+        s = sc.to_vector(s, rayleigh_fraction=0.9)
+    brdf = ("modis", np.tile([0.2, 0.05, 0.05], (2, 1)))
+    plain = [run_emulated_vector(s, derivatives=True), run_emulated_vector(s, derivatives=True, brdf=brdf)]
+    monkeypatch.setenv("SKV_EMU_K3_TEAM", "1")
+    team = [run_emulated_vector(s, derivatives=True), run_emulated_vector(s, derivatives=True, brdf=brdf)]
+    for a, b_ in zip(plain, team):
+        for k in ("radiance", "d_extinction", "d_ssa"):
+            assert np.array_equal(a[k], b_[k]), k
