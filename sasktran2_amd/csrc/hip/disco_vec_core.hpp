@@ -2105,7 +2105,10 @@ SKD_HD size_t kv2c_scratch_team(int n, int NL, int G, int width, int nstr) {
     return 2 * size_t(n) * NL + 4 * size_t(n) + (5 + size_t(G)) * size_t(NL) * K;
 }
 
-SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws) {
+//   wst (optional, LDS, 4 n^2 doubles): W+, W-, dW+ + W+ / om, dW- + W- / om of the layer staged once with unit-stride loads -- the Legendre sums
+//   below then read their (stream, solution) entries as LDS broadcasts instead of global ones (and without the two divisions per entry and lane)
+SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg, const Bufs& b, const VBufs& v, int s, int m, int p, int w, double* ws,
+                                  double* wst = nullptr) {
 #if defined(SKV_K2C_TIMING) && defined(__HIP_DEVICE_COMPILE__)
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
 #define KV2CT(i) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; }
@@ -2129,6 +2132,19 @@ SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg
     // (plane-parallel post-processing supplies u_p directly: F, FP and HD are not needed)
     const bool table = !g.pp_mode;
     const int K = (team.width / nstr) < 1 ? 1 : ((team.width / nstr) > n ? n : (team.width / nstr)), per_k = (n + K - 1) / K;
+    const bool staged = wst != nullptr && table;
+    if (staged) {
+        const int nn2 = n * n;
+        const double inv_om = 1.0 / om;
+        SKV_PAR(e, nn2) {
+            const double wp = c[R.WP() + e], wm = c[R.WM() + e];
+            wst[e] = wp;
+            wst[nn2 + e] = wm;
+            wst[2 * nn2 + e] = c[R.DWP() + e] + wp * inv_om;
+            wst[3 * nn2 + e] = c[R.DWM() + e] + wm * inv_om;
+        }
+        team.sync();
+    }
     if (table) SKV_PAR(item, nstr * K) {
         const int l = item % nstr, kslice = item / nstr;
         const int a_lo = kslice * per_k, a_hi = (a_lo + per_k < n) ? a_lo + per_k : n;
@@ -2153,6 +2169,14 @@ SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg
                     double wp[3] = {0, 0, 0}, wm[3] = {0, 0, 0}, dwp[3] = {0, 0, 0}, dwm[3] = {0, 0, 0};
                     for (int s2 = 0; s2 < S; ++s2) {
                         const int r = j * S + s2;
+                        if (staged) {
+                            const int e = r + n * a_, nn2 = n * n;
+                            wp[s2] = wst[e];
+                            wm[s2] = wst[nn2 + e];
+                            dwp[s2] = wst[2 * nn2 + e];
+                            dwm[s2] = wst[3 * nn2 + e];
+                            continue;
+                        }
                         wp[s2] = c[R.WP() + r + n * a_];
                         wm[s2] = c[R.WM() + r + n * a_];
                         dwp[s2] = c[R.DWP() + r + n * a_] + wp[s2] / om;
@@ -2263,8 +2287,9 @@ SKV_TEAM_BODY void kv2c_layer_ops(const Team& team, const Geo& g, const VGeo& vg
     team_gemm(team, M2, M2, M2, [&](int i, int j) { return dinv[j * M2 + i]; },
               [&](int j, int cc) {   // columns 0 .. n-1: SupT, n .. 2n-1: SubT
                   const int cidx = cc < n ? cc : cc - n, jj = j < n ? j : j - n;
-                  const double wp = c[R.WP() + cidx + n * jj], wm = c[R.WM() + cidx + n * jj], E = c[R.E() + jj];
                   const bool minus = (cc < n) == (j < n);   // SupT rows j < n and SubT rows j >= n carry W-
+                  if (staged) return minus ? wst[n * n + cidx + n * jj] : wst[cidx + n * jj] * c[R.E() + jj];
+                  const double wp = c[R.WP() + cidx + n * jj], wm = c[R.WM() + cidx + n * jj], E = c[R.E() + jj];
                   return minus ? wm : wp * E;
               },
               [&](int i, int cc, double val) {
